@@ -1,0 +1,509 @@
+/*
+ * dgg_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C, fp32) of the reference's Differentiable Graph Generator hot path:
+ *   DGG_LearnableK_debug.forward            /root/reference/dgm.py:1178-1292
+ *     edge_prob_net  mode "u-v-dist"        dgm.py:1607-1627
+ *     Gumbel perturbation                   dgm.py:1211-1231, gumbel_sample 14-29
+ *     k_estimate_net mode "x" / "input_deg" dgm.py:1562-1586 / 1509-1526, LearnableKEncoder 2029-2063
+ *     select_top_k   "k_times_edge_prob" / "k_only"   dgm.py:1402-1435
+ *   normalize_adj                           model.py:1205-1219
+ *   GCNConv / GraphConvolution aggregation  model.py:580-599, 32-44
+ * in the sparse "top-K per row" formulation that SURVEY.md section 0/8(a) shows to be bit-identical to the
+ * dense N x N reference formulation (the tanh ramp is exactly 0.0f beyond rank k+8.5).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+ * product (dgg_amd/) never does.  Parity is PINNED: tests/test_oracle_golden.py checks every function
+ * here against fixtures produced by importing the reference itself (tests/golden/make_golden.py).
+ *
+ * Canonical arithmetic.  Every floating-point step is written as an explicit sequence of IEEE-754
+ * binary32 operations (add, mul, fmaf, div, sqrt) in a fixed order, with our own exp/log/tanh
+ * polynomials, so that the HIP kernels -- which restate the same sequences independently -- agree
+ * with this file bit-for-bit on scores and therefore on top-k indices.  Against the reference
+ * (torch CPU: vectorised reductions, Sleef transcendentals) values agree to a few ulp; near-ties
+ * can therefore swap ranks, which the golden tests canonicalise.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORA_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------ */
+/* canonical transcendental functions                                                          */
+/* ------------------------------------------------------------------------------------------ */
+static inline float f_from_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t bits_from_f(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* exp: argument clamped to [-87, 88]; n = rint(x*log2e); two-step Cody-Waite; degree-5 Horner (Cephes
+ * expf coefficients) evaluated with fmaf; scaling by an exactly representable power of two. */
+ORA_API float ora_exp(float x) {
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) x = -87.0f;
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float q = 1.9875691500e-4f;
+    q = fmaf(q, r, 1.3981999507e-3f);
+    q = fmaf(q, r, 8.3334519073e-3f);
+    q = fmaf(q, r, 4.1665795894e-2f);
+    q = fmaf(q, r, 1.6666665459e-1f);
+    q = fmaf(q, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = fmaf(q, r2, r);
+    y = y + 1.0f;
+    int32_t e = (int32_t)n;
+    return y * f_from_bits((uint32_t)(e + 127) << 23);
+}
+
+/* log for positive normal x (Cephes logf scheme, fixed fmaf sequence). */
+ORA_API float ora_log(float x) {
+    uint32_t ux = bits_from_f(x);
+    int32_t e = (int32_t)(ux >> 23) - 126;                 /* x = m * 2^e, m in [0.5, 1) */
+    float m = f_from_bits((ux & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) { e -= 1; m = m + m; }
+    m = m - 1.0f;
+    float z = m * m;
+    float q = 7.0376836292e-2f;
+    q = fmaf(q, m, -1.1514610310e-1f);
+    q = fmaf(q, m, 1.1676998740e-1f);
+    q = fmaf(q, m, -1.2420140846e-1f);
+    q = fmaf(q, m, 1.4249322787e-1f);
+    q = fmaf(q, m, -1.6668057665e-1f);
+    q = fmaf(q, m, 2.0000714765e-1f);
+    q = fmaf(q, m, -2.4999993993e-1f);
+    q = fmaf(q, m, 3.3333331174e-1f);
+    float y = (q * m) * z;
+    float fe = (float)e;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(z, -0.5f, y);
+    float r = m + y;
+    r = fmaf(fe, 0.693359375f, r);
+    return r;
+}
+
+/* tanh: |z| < 0.625 -> odd polynomial (Cephes tanhf); else 1 - 2/(exp(2|z|)+1); saturates to +-1 for |z| > 9.1 */
+ORA_API float ora_tanh(float x) {
+    float ax = fabsf(x);
+    float r;
+    if (ax < 0.625f) {
+        float z = x * x;
+        float q = -5.70498872745e-3f;
+        q = fmaf(q, z, 2.06390887954e-2f);
+        q = fmaf(q, z, -5.37397155531e-2f);
+        q = fmaf(q, z, 1.33314422036e-1f);
+        q = fmaf(q, z, -3.33332819422e-1f);
+        q = q * z;
+        return fmaf(q, x, x);
+    }
+    if (ax > 9.1f) r = 1.0f;
+    else {
+        float e = ora_exp(ax + ax);
+        r = 1.0f - 2.0f / (e + 1.0f);
+    }
+    return x < 0.0f ? -r : r;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* counter-based noise: U_ij from a 2-multiply keyed hash, G = -0.3 * log(-log(U))             */
+/* (the reference samples torch.distributions.Gumbel(0, 0.3), dgm.py:1149-1151, 1226; its      */
+/*  stream cannot exist at N=100k, so the at-scale generator is defined here; parity at small  */
+/*  N uses explicit noise tensors instead)                                                     */
+/* ------------------------------------------------------------------------------------------ */
+static inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
+}
+ORA_API void ora_rowkey(uint32_t s0, uint32_t s1, uint32_t i, uint32_t *k1, uint32_t *k2) {
+    *k1 = mix32(i ^ s0);
+    *k2 = mix32(*k1 ^ s1 ^ 0x9E3779B9U);
+}
+/* 24-bit uniform integer for ordered pair (i,j); symmetric: keyed on (min,max). */
+ORA_API uint32_t ora_pair_u24(uint32_t s0, uint32_t s1, uint32_t i, uint32_t j, int symmetric) {
+    uint32_t a = i, b = j;
+    if (symmetric && j < i) { a = j; b = i; }
+    uint32_t k1, k2;
+    ora_rowkey(s0, s1, a, &k1, &k2);
+    uint32_t x = b ^ k1;
+    x *= 0x7feb352dU; x ^= x >> 15; x += k2; x *= 0x846ca68bU;
+    return x >> 8;
+}
+ORA_API float ora_gumbel_u24(uint32_t u24) {
+    if (u24 == 0) u24 = 1;                        /* U in [2^-24, 1-2^-24] */
+    float U = (float)u24 * 5.9604644775390625e-8f; /* exact */
+    float a = -ora_log(U);
+    float b = ora_log(a);
+    return -0.3f * b;
+}
+ORA_API float ora_noise(uint32_t s0, uint32_t s1, uint32_t i, uint32_t j, int symmetric) {
+    if (symmetric && i == j) return 0.0f;          /* dgm.py:1218-1222: diagonal of the symmetric G stays 0 */
+    return ora_gumbel_u24(ora_pair_u24(s0, s1, i, j, symmetric));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* dense layers: acc = 0; acc = fmaf(x_c, w_c, acc) for c ascending; + bias; activation        */
+/* (nn.Linear + LeakyReLU dgm.py:1097-1100, 1123-1130; GCNConv mm model.py:594-598)            */
+/* act: 0 none, 1 leaky_relu(0.01), 2 relu.  w_layout 0: W[out][in] (nn.Linear), 1: W[in][out] */
+/* ------------------------------------------------------------------------------------------ */
+static inline float act_fwd(float v, int act) {
+    if (act == 1) return v > 0.0f ? v : 0.01f * v;
+    if (act == 2) return v > 0.0f ? v : 0.0f;
+    return v;
+}
+ORA_API void ora_linear(const float *x, int64_t N, int d, const float *W, const float *b, int out,
+                        int w_layout, int act, float *y) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; i++) {
+        const float *xi = x + i * d;
+        for (int o = 0; o < out; o++) {
+            float acc = 0.0f;
+            if (w_layout == 0) { const float *w = W + (int64_t)o * d; for (int c = 0; c < d; c++) acc = fmaf(xi[c], w[c], acc); }
+            else { for (int c = 0; c < d; c++) acc = fmaf(xi[c], W[(int64_t)c * out + o], acc); }
+            if (b) acc = acc + b[o];
+            y[i * out + o] = act_fwd(acc, act);
+        }
+    }
+}
+/* backward of y = act(x W^T + b): given dy and y (post-activation), returns dx (optional), dW, db (accumulated
+ * in double, written as float). */
+ORA_API void ora_linear_bwd(const float *x, int64_t N, int d, const float *W, int out, int w_layout, int act,
+                            const float *y, const float *dy, float *dx, float *dW, float *db) {
+    double *aW = (double *)calloc((size_t)out * d, sizeof(double));
+    double *ab = (double *)calloc((size_t)out, sizeof(double));
+    float *dp = (float *)malloc(sizeof(float) * out);
+    for (int64_t i = 0; i < N; i++) {
+        for (int o = 0; o < out; o++) {
+            float g = dy[i * out + o], v = y[i * out + o];
+            if (act == 1) g = v > 0.0f ? g : 0.01f * g;
+            else if (act == 2) g = v > 0.0f ? g : 0.0f;
+            dp[o] = g; ab[o] += g;
+        }
+        const float *xi = x + i * d;
+        for (int o = 0; o < out; o++) { double g = dp[o]; if (g != 0.0) for (int c = 0; c < d; c++) aW[(int64_t)o * d + c] += g * xi[c]; }
+        if (dx) for (int c = 0; c < d; c++) {
+            double s = 0.0;
+            for (int o = 0; o < out; o++) s += (double)dp[o] * (w_layout == 0 ? W[(int64_t)o * d + c] : W[(int64_t)c * out + o]);
+            dx[i * d + c] = (float)s;
+        }
+    }
+    for (int o = 0; o < out; o++) for (int c = 0; c < d; c++) {
+        float v = (float)aW[(int64_t)o * d + c];
+        if (w_layout == 0) dW[(int64_t)o * d + c] = v; else dW[(int64_t)c * out + o] = v;
+    }
+    if (db) for (int o = 0; o < out; o++) db[o] = (float)ab[o];
+    free(aW); free(ab); free(dp);
+}
+
+/* mean and unbiased std of the prior degree (dgm.py:1568-1570), accumulated in double, rounded once */
+ORA_API void ora_degree_stats(const float *deg, int64_t N, float *mu, float *sd) {
+    double s = 0.0;
+    for (int64_t i = 0; i < N; i++) s += deg[i];
+    double m = s / (double)N, v = 0.0;
+    for (int64_t i = 0; i < N; i++) { double t = deg[i] - m; v += t * t; }
+    *mu = (float)m;
+    *sd = (float)sqrt(v / (double)(N - 1));
+}
+
+/* k_estimate_net mode "x" (dgm.py:1562-1586) after the node encoder: xk = leaky(node_encode_for_k(x)).
+ * W1 [h2][h+1], b1[h2] = k_embed.0; Wmu [h4][h2], bmu = k_net.k_mu; Wp [h4], bp = k_net.k_project.
+ * Saves z (post-leaky, [N,h2]), m ([N,h4]) and u = kp*sd+mu ([N]) when the pointers are non-NULL. */
+ORA_API void ora_knet_x(const float *xk, int64_t N, int h, const float *deg, float mu, float sd,
+                        const float *W1, const float *b1, int h2, const float *Wmu, const float *bmu, int h4,
+                        const float *Wp, const float *bp, float *k, float *z_save, float *m_save, float *u_save) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; i++) {
+        float z[256], m[128];
+        float nd = (deg[i] - mu) / (sd + 1e-5f);
+        for (int o = 0; o < h2; o++) {
+            const float *w = W1 + (int64_t)o * (h + 1);
+            float acc = 0.0f;
+            for (int c = 0; c < h; c++) acc = fmaf(xk[i * h + c], w[c], acc);
+            acc = fmaf(nd, w[h], acc);
+            acc = acc + b1[o];
+            z[o] = acc > 0.0f ? acc : 0.01f * acc;
+        }
+        for (int o = 0; o < h4; o++) {
+            float acc = 0.0f;
+            for (int c = 0; c < h2; c++) acc = fmaf(z[c], Wmu[o * h2 + c], acc);
+            m[o] = acc + bmu[o];
+        }
+        float acc = 0.0f;
+        for (int c = 0; c < h4; c++) acc = fmaf(m[c], Wp[c], acc);
+        float kp = acc + bp[0];
+        float u = kp * sd; u = u + mu;
+        k[i] = (u > 0.0f ? u : 0.0f) + 1.0f;
+        if (z_save) memcpy(z_save + i * h2, z, sizeof(float) * h2);
+        if (m_save) memcpy(m_save + i * h4, m, sizeof(float) * h4);
+        if (u_save) u_save[i] = u;
+    }
+}
+/* backward of ora_knet_x: dk -> dxk [N,h], dW1,db1,dWmu,dbmu,dWp,dbp */
+ORA_API void ora_knet_x_bwd(const float *xk, int64_t N, int h, const float *deg, float mu, float sd,
+                            const float *W1, int h2, const float *Wmu, int h4, const float *Wp,
+                            const float *z, const float *m, const float *u, const float *dk,
+                            float *dxk, float *dW1, float *db1, float *dWmu, float *dbmu, float *dWp, float *dbp) {
+    double *aW1 = calloc((size_t)h2 * (h + 1), 8), *ab1 = calloc(h2, 8), *aWmu = calloc((size_t)h4 * h2, 8),
+           *abmu = calloc(h4, 8), *aWp = calloc(h4, 8), abp = 0.0;
+    for (int64_t i = 0; i < N; i++) {
+        float nd = (deg[i] - mu) / (sd + 1e-5f);
+        double dkp = u[i] > 0.0f ? (double)dk[i] * sd : 0.0;
+        abp += dkp;
+        double dm[128], dz[256];
+        for (int c = 0; c < h4; c++) { aWp[c] += dkp * m[i * h4 + c]; dm[c] = dkp * Wp[c]; abmu[c] += dm[c]; }
+        for (int c = 0; c < h2; c++) dz[c] = 0.0;
+        for (int o = 0; o < h4; o++) for (int c = 0; c < h2; c++) { aWmu[o * h2 + c] += dm[o] * z[i * h2 + c]; dz[c] += dm[o] * Wmu[o * h2 + c]; }
+        for (int c = 0; c < h; c++) dxk[i * h + c] = 0.0f;
+        for (int o = 0; o < h2; o++) {
+            double g = z[i * h2 + o] > 0.0f ? dz[o] : 0.01 * dz[o];
+            ab1[o] += g;
+            for (int c = 0; c < h; c++) { aW1[(int64_t)o * (h + 1) + c] += g * xk[i * h + c]; dxk[i * h + c] += (float)(g * W1[(int64_t)o * (h + 1) + c]); }
+            aW1[(int64_t)o * (h + 1) + h] += g * nd;
+        }
+    }
+    for (int64_t t = 0; t < (int64_t)h2 * (h + 1); t++) dW1[t] = (float)aW1[t];
+    for (int t = 0; t < h2; t++) db1[t] = (float)ab1[t];
+    for (int t = 0; t < h4 * h2; t++) dWmu[t] = (float)aWmu[t];
+    for (int t = 0; t < h4; t++) { dbmu[t] = (float)abmu[t]; dWp[t] = (float)aWp[t]; }
+    dbp[0] = (float)abp;
+    free(aW1); free(ab1); free(aWmu); free(abmu); free(aWp);
+}
+
+/* k_estimate_net mode "input_deg" (dgm.py:1509-1526): constants deg_mean/deg_std from args;
+ * Wd[3],bd[3] = input_degree_project (Linear(1,3)); Wmu [h4][3], bmu; Wp[h4], bp. */
+ORA_API void ora_knet_input_deg(const float *deg, int64_t N, float dmean, float dstd, const float *Wd, const float *bd,
+                                const float *Wmu, const float *bmu, int h4, const float *Wp, const float *bp, float *k) {
+    for (int64_t i = 0; i < N; i++) {
+        float nd = (deg[i] - dmean) / (dstd + 1e-5f);
+        float in3[3], m[128];
+        for (int o = 0; o < 3; o++) { float acc = fmaf(nd, Wd[o], 0.0f); in3[o] = acc + bd[o]; }
+        for (int o = 0; o < h4; o++) { float acc = 0.0f; for (int c = 0; c < 3; c++) acc = fmaf(in3[c], Wmu[o * 3 + c], acc); m[o] = acc + bmu[o]; }
+        float acc = 0.0f;
+        for (int c = 0; c < h4; c++) acc = fmaf(m[c], Wp[c], acc);
+        float kp = acc + bp[0];
+        float u = kp * dstd; u = u + dmean;
+        k[i] = (u > 0.0f ? u : 0.0f) + 1.0f;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* pair score (dgm.py:1613-1623 + 1211-1229)                                                   */
+/* ------------------------------------------------------------------------------------------ */
+static inline float pair_dist(const float *a, const float *b, int h) {
+    float d2 = 0.0f;
+    for (int c = 0; c < h; c++) { float df = a[c] - b[c]; d2 = fmaf(df, df, d2); }
+    return sqrtf(d2);
+}
+ORA_API float ora_pair_score(const float *xi, const float *xj, int h, float t, int perturb, float G) {
+    float p = ora_exp(t * pair_dist(xi, xj, h));
+    if (!perturb) return p;
+    float lp = ora_log(p + 1e-8f);
+    return ora_exp(lp + G);
+}
+
+/* selection order: score descending, column ascending; a strict total order */
+typedef struct { float v; int32_t j; } cand_t;
+static inline int better(float v, int32_t j, float v2, int32_t j2) { return v > v2 || (v == v2 && j < j2); }
+static void topk_insert(cand_t *list, int *cnt, int K, float v, int32_t j) {
+    int n = *cnt;
+    if (n == K && !better(v, j, list[K - 1].v, list[K - 1].j)) return;
+    int pos = n < K ? n : K - 1;
+    while (pos > 0 && better(v, j, list[pos - 1].v, list[pos - 1].j)) { list[pos] = list[pos - 1]; pos--; }
+    list[pos].v = v; list[pos].j = j;
+    if (n < K) *cnt = n + 1;
+}
+
+/* noise_mode: 0 none (perturb_edge_prob False), 1 explicit G (row-major [N][N], row i at G + i*N),
+ *             2 counter-based (s0,s1), 3 counter-based symmetric */
+ORA_API void ora_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t,
+                               int noise_mode, const float *G, uint32_t s0, uint32_t s1,
+                               int K, int32_t *idx, float *val) {
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t i = row0; i < row1; i++) {
+        cand_t list[512];
+        int cnt = 0;
+        for (int64_t j = 0; j < N; j++) {
+            float g = 0.0f;
+            if (noise_mode == 1) g = G[i * N + j];
+            else if (noise_mode >= 2) g = ora_noise(s0, s1, (uint32_t)i, (uint32_t)j, noise_mode == 3);
+            float v = ora_pair_score(xp + i * h, xp + j * h, h, t, noise_mode != 0, g);
+            topk_insert(list, &cnt, K, v, (int32_t)j);
+        }
+        for (int r = 0; r < K; r++) {
+            idx[(i - row0) * K + r] = r < cnt ? list[r].j : -1;
+            val[(i - row0) * K + r] = r < cnt ? list[r].v : 0.0f;
+        }
+    }
+}
+
+/* candidates restricted to a CSR graph (the live class's in_adj semantics, dgm.py:1613-1627).
+ * G (noise_mode 1) is dense [N][N]. */
+ORA_API void ora_edgelist_topk(const float *xp, int64_t N, int h, const int64_t *rowptr, const int32_t *col, float t,
+                               int noise_mode, const float *G, uint32_t s0, uint32_t s1,
+                               int K, int32_t *idx, float *val) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < N; i++) {
+        cand_t list[512];
+        int cnt = 0;
+        for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
+            int32_t j = col[e];
+            float g = 0.0f;
+            if (noise_mode == 1) g = G[i * N + j];
+            else if (noise_mode >= 2) g = ora_noise(s0, s1, (uint32_t)i, (uint32_t)j, noise_mode == 3);
+            float v = ora_pair_score(xp + i * h, xp + (int64_t)j * h, h, t, noise_mode != 0, g);
+            topk_insert(list, &cnt, K, v, j);
+        }
+        for (int r = 0; r < K; r++) {
+            idx[i * K + r] = r < cnt ? list[r].j : -1;
+            val[i * K + r] = r < cnt ? list[r].v : 0.0f;
+        }
+    }
+}
+
+/* selection only: dense score rows [R][N] -> top-K (bit-exact target of the HIP selection kernel) */
+ORA_API void ora_select_scores(const float *scores, int64_t R, int64_t N, int K, int32_t *idx, float *val) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < R; i++) {
+        cand_t list[512];
+        int cnt = 0;
+        for (int64_t j = 0; j < N; j++) topk_insert(list, &cnt, K, scores[i * N + j], (int32_t)j);
+        for (int r = 0; r < K; r++) { idx[i * K + r] = r < cnt ? list[r].j : -1; val[i * K + r] = r < cnt ? list[r].v : 0.0f; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* smooth first-k ramp (dgm.py:1410-1417 / 1427-1434), row sums, normalisation (model.py:1215-1218) */
+/* mode 0: k_times_edge_prob  w = s * f ; mode 1: k_only  w = f  (only where idx >= 0)          */
+/* ------------------------------------------------------------------------------------------ */
+static inline float ramp(float r, float k) {
+    float th = ora_tanh(r - k);
+    float a = 1.0f + th;
+    a = 0.5f * a;
+    return 1.0f - a;
+}
+/* row sum in the xor-butterfly order of a 64-lane wavefront reduction (slots >= K are zero) */
+static float butterfly_sum(const float *w, int K) {
+    float s[64], t[64];
+    for (int l = 0; l < 64; l++) s[l] = 0.0f;
+    /* K <= 64: slot l holds w[l]; K == 128: slot l holds w[l] + w[l+64] */
+    for (int l = 0; l < K; l++) s[l & 63] = (l < 64) ? w[l] : s[l & 63] + w[l];
+    for (int off = 32; off >= 1; off >>= 1) {
+        for (int l = 0; l < 64; l++) t[l] = s[l] + s[l ^ off];
+        memcpy(s, t, sizeof(s));
+    }
+    return s[0];
+}
+ORA_API void ora_softk(const int32_t *idx, const float *val, const float *k, int64_t N, int K, int mode,
+                       float *w, float *rs) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; i++) {
+        for (int r = 0; r < K; r++) {
+            float f = ramp((float)r, k[i]);
+            float v = (mode == 0) ? val[i * K + r] * f : f;
+            w[i * K + r] = idx[i * K + r] >= 0 ? v : 0.0f;
+        }
+        rs[i] = butterfly_sum(w + i * K, K);
+    }
+}
+/* A_hat = (a_i * w) * a_j with a = 1/sqrt(rs)  (row sums on BOTH sides, model.py:1215-1218) */
+ORA_API void ora_normalize(const int32_t *idx, const float *w, const float *rs, int64_t N, int K, float *ahat) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; i++) {
+        float ai = 1.0f / sqrtf(rs[i]);
+        for (int r = 0; r < K; r++) {
+            int32_t j = idx[i * K + r];
+            if (j < 0) { ahat[i * K + r] = 0.0f; continue; }
+            float aj = 1.0f / sqrtf(rs[j]);
+            ahat[i * K + r] = (ai * w[i * K + r]) * aj;
+        }
+    }
+}
+/* Y_i = sum_r ahat_ir * X[idx_ir], r ascending, fmaf chain (torch.mm(adj, x), model.py:594 / spmm 34) */
+ORA_API void ora_spmm(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, float *Y) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; i++) {
+        for (int c = 0; c < F; c++) Y[i * F + c] = 0.0f;
+        for (int r = 0; r < K; r++) {
+            int32_t j = idx[i * K + r];
+            if (j < 0) continue;
+            float a = ahat[i * K + r];
+            for (int c = 0; c < F; c++) Y[i * F + c] = fmaf(a, X[(int64_t)j * F + c], Y[i * F + c]);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* backward (autograd of the above; accumulations in double, single-threaded and simple)       */
+/* ------------------------------------------------------------------------------------------ */
+/* dA_ir = <dY_i, X_j>; dX_j += ahat_ir * dY_i */
+ORA_API void ora_spmm_bwd(const int32_t *idx, const float *ahat, const float *X, const float *dY, int64_t N, int K,
+                          int F, float *dA, float *dX) {
+    double *ax = dX ? calloc((size_t)N * F, 8) : NULL;
+    for (int64_t i = 0; i < N; i++) for (int r = 0; r < K; r++) {
+        int32_t j = idx[i * K + r];
+        if (j < 0) { dA[i * K + r] = 0.0f; continue; }
+        double s = 0.0;
+        for (int c = 0; c < F; c++) s += (double)dY[i * F + c] * X[(int64_t)j * F + c];
+        dA[i * K + r] = (float)s;
+        if (ax) { double a = ahat[i * K + r]; for (int c = 0; c < F; c++) ax[(int64_t)j * F + c] += a * dY[i * F + c]; }
+    }
+    if (ax) { for (int64_t t = 0; t < N * F; t++) dX[t] = (float)ax[t]; free(ax); }
+}
+/* normalisation + ramp backward: dA (wrt ahat) -> dval (wrt sorted scores), dk */
+ORA_API void ora_softk_norm_bwd(const int32_t *idx, const float *val, const float *k, const float *w, const float *rs,
+                                const float *dA, int64_t N, int K, int mode, float *dval, float *dk) {
+    double *da = calloc((size_t)N, 8);
+    double *a = malloc(sizeof(double) * N);
+    for (int64_t i = 0; i < N; i++) a[i] = 1.0 / sqrt((double)rs[i]);
+    for (int64_t i = 0; i < N; i++) for (int r = 0; r < K; r++) {
+        int32_t j = idx[i * K + r];
+        if (j < 0) continue;
+        double g = dA[i * K + r], ww = w[i * K + r];
+        da[i] += g * ww * a[j];
+        da[j] += g * ww * a[i];
+    }
+    for (int64_t i = 0; i < N; i++) {
+        double drs = -0.5 * da[i] * a[i] / (double)rs[i];
+        double sk = 0.0;
+        for (int r = 0; r < K; r++) {
+            int32_t j = idx[i * K + r];
+            if (j < 0) { dval[i * K + r] = 0.0f; continue; }
+            double dw = (double)dA[i * K + r] * a[i] * a[j] + drs;
+            double th = ora_tanh((float)r - k[i]);
+            double f = 1.0 - 0.5 * (1.0 + th);
+            double dfdk = 0.5 * (1.0 - th * th);
+            if (mode == 0) { dval[i * K + r] = (float)(dw * f); sk += dw * val[i * K + r] * dfdk; }
+            else { dval[i * K + r] = 0.0f; sk += dw * dfdk; }
+        }
+        dk[i] = (float)sk;
+    }
+    free(da); free(a);
+}
+/* score backward to the projected features: dxp [N,h] (dgm.py:1613-1623, 1213-1229 under autograd).
+ * G explicit dense or counter-based as in ora_allpairs_topk (needed to recompute p from the stored score). */
+ORA_API void ora_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval,
+                          int K, float t, int perturb, float *dxp) {
+    double *acc = calloc((size_t)N * h, 8);
+    for (int64_t i = 0; i < N; i++) for (int r = 0; r < K; r++) {
+        int32_t j = idx[i * K + r];
+        if (j < 0) continue;
+        double g = dval[i * K + r];
+        if (g == 0.0) continue;
+        const float *a = xp + i * h, *b = xp + (int64_t)j * h;
+        float dist = pair_dist(a, b, h);
+        if (dist == 0.0f) continue;                         /* vector_norm backward at 0 is 0 */
+        float p = ora_exp(t * dist);
+        double dp;
+        if (perturb) dp = g * (double)val[i * K + r] / ((double)p + 1e-8);   /* d exp(log(p+1e-8)+G) / dp */
+        else dp = g;
+        double dd = dp * (double)t * (double)p / (double)dist;
+        for (int c = 0; c < h; c++) {
+            double df = (double)a[c] - (double)b[c];
+            acc[i * h + c] += dd * df;
+            acc[(int64_t)j * h + c] -= dd * df;
+        }
+    }
+    for (int64_t tix = 0; tix < N * h; tix++) dxp[tix] = (float)acc[tix];
+    free(acc);
+}

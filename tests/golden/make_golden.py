@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by IMPORTING the reference (runs only in the build container).
+
+The reference (/root/reference, read-only) is imported unmodified behind harness-side shims
+(SURVEY.md Appendix A): torch_geometric / tensorboard stubs, `.cuda()` no-op, `np.float` alias.
+Every fixture holds inputs, the reference module's state_dict, the captured Gumbel noise (or the
+seed of tests/golden_noise.py that regenerates it), the reference outputs and the reference
+gradients for a fixed cotangent.  Fixtures are data only; no reference source is stored.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+"""
+import json
+import os
+import sys
+import warnings
+
+warnings.filterwarnings("ignore")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+from unittest.mock import MagicMock  # noqa: E402
+
+for n in ["torch_geometric", "torch_geometric.datasets", "torch_geometric.nn", "torch_geometric.utils",
+          "torch_geometric.loader", "torch_geometric.data", "torch_geometric.transforms",
+          "torch.utils.tensorboard", "tensorboardX"]:
+    sys.modules[n] = MagicMock()
+import numpy as np  # noqa: E402
+import scipy.sparse  # noqa: E402,F401
+
+np.float = float
+import torch  # noqa: E402
+
+torch.Tensor.cuda = lambda self, *a, **k: self
+import dgm  # noqa: E402
+import model as refmodel  # noqa: E402
+from argparse import Namespace  # noqa: E402
+
+from golden_noise import crc, grid_gumbel, grid_normal  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def base_args(**kw):
+    a = dict(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288,
+             dgg_mode_edge_net="u-v-dist", dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob",
+             debug_step=3, perturb_edge_prob=True, symmetric_noise=False, stochastic_k=False,
+             dgg_adj_input="input_adj", n_dgg_layers=1)
+    a.update(kw)
+    return Namespace(**a)
+
+
+def random_graph(N, avg_deg, gen):
+    """symmetric random graph + self loops, coalesced COO (row-major order)."""
+    p = avg_deg / N
+    A = (torch.rand(N, N, generator=gen) < p / 2).float()
+    A = ((A + A.T) > 0).float()
+    A.fill_diagonal_(0)
+    A = A + torch.eye(N)
+    return A.to_sparse().coalesce()
+
+
+def run_dgg(name, N, d, h, args, in_adj, x, noise, cot, k_scale, store_dense, seed_info=None):
+    """noise: None | dense [N,N] float32 (asym) | dense symmetric [N,N] (sym: upper triangle used)."""
+    torch.manual_seed(1234)
+    m = dgm.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=args)
+    with torch.no_grad():
+        m.k_net.k_project.weight.mul_(k_scale)
+    m.eval()
+    cap = {}
+    if noise is not None:
+        Gt = torch.from_numpy(noise)
+        if args.symmetric_noise:
+            iu, ju = torch.triu_indices(N, N, 1)
+            m.gumbel.sample = lambda shape: Gt[iu, ju]          # dgm.py:1220 draws len(i) values
+        else:
+            m.gumbel.sample = lambda shape: Gt.reshape(shape)   # dgm.py:1226 draws [1,N,N]
+    _sel = m.select_top_k
+
+    def sel(Nn, k, pert, **kw):
+        cap["pert"] = pert.detach().squeeze(0).clone()
+        cap["k"] = k.detach().flatten().clone()
+        return _sel(Nn, k, pert, **kw)
+
+    m.select_top_k = sel
+    x = x.clone().requires_grad_(True)
+    out = m(x, in_adj).to_dense()
+    loss = (out * cot).sum()
+    loss.backward()
+    sd = {k_: v.detach().numpy() for k_, v in m.state_dict().items()}
+    grads = {k_: (p.grad.detach().numpy() if p.grad is not None else np.zeros_like(p.detach().numpy()))
+             for k_, p in m.named_parameters()}
+    deg = in_adj.to_dense().sum(-1)
+    fx = {
+        "x": x.detach().numpy(),
+        "deg": deg.numpy(),
+        "k": cap["k"].numpy(),
+        "g.x": x.grad.numpy(),
+    }
+    ii = in_adj.indices().numpy().astype(np.int32)
+    if in_adj._nnz() < N * N:
+        fx["rows"], fx["cols"] = ii[0], ii[1]
+        fx["adj_vals"] = in_adj.values().numpy()
+    for k_, v in sd.items():
+        fx["p." + k_] = v
+    for k_, v in grads.items():
+        fx["g." + k_] = v
+    outd = out.detach()
+    if store_dense:
+        fx["out"] = outd.numpy()
+        fx["pert"] = cap["pert"].numpy()
+        fx["cot"] = cot.numpy()
+        if noise is not None:
+            fx["G"] = noise
+    else:
+        K = 64
+        v, ix = torch.sort(outd, dim=-1, descending=True, stable=True)
+        assert (v[:, K:] == 0).all()
+        fx["out_idx"] = ix[:, :K].numpy().astype(np.int32)
+        fx["out_val"] = v[:, :K].numpy()
+        pv = torch.gather(cap["pert"], 1, ix[:, :K])
+        fx["pert_val"] = pv.numpy()
+    meta = dict(name=name, N=N, d=d, h=h, torch=torch.__version__, args=vars(args), k_scale=k_scale,
+                reference="dgm.py:1178-1292 DGG_LearnableK_debug.forward", seed_info=seed_info or {})
+    fx["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+    nnz = (outd != 0).sum(-1).float()
+    print(f"{name}: k[{cap['k'].min():.2f},{cap['k'].max():.2f}] nnz/row mean {nnz.mean():.1f} max {nnz.max():.0f}")
+
+
+def edgelist_cases():
+    N, d, h = 96, 24, 16
+    gen = torch.Generator().manual_seed(7)
+    in_adj = random_graph(N, 24, gen)
+    x = torch.randn(N, d, generator=gen)
+    cot = torch.from_numpy(grid_normal(11, (N, N)))
+    Gasym = grid_gumbel(21, (N, N))
+    Gsym = grid_gumbel(22, (N, N))
+    Gsym = np.triu(Gsym, 1) + np.triu(Gsym, 1).T
+    for ksel in ["k_times_edge_prob", "k_only"]:
+        for nz in ["none", "asym", "sym"]:
+            a = base_args(dgg_mode_k_select=ksel, perturb_edge_prob=(nz != "none"),
+                          symmetric_noise=(nz == "sym"))
+            noise = None if nz == "none" else (Gasym if nz == "asym" else Gsym)
+            run_dgg(f"edgelist_{ksel}_{nz}", N, d, h, a, in_adj, x, noise, cot, 1.0, True)
+    a = base_args(dgg_mode_k_net="input_deg", perturb_edge_prob=False, deg_mean=20.0, deg_std=4.0)
+    run_dgg("edgelist_inputdeg_none", N, d, h, a, in_adj, x, None, cot, 1.0, True)
+
+
+def allpairs_cases():
+    N, d, h = 256, 32, 16
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(N, d, generator=gen)
+    c = 8 + 10 * torch.rand(N, 1, generator=gen)
+    in_adj = (c / N * torch.ones(N, N)).to_sparse().coalesce()
+    cot = torch.from_numpy(grid_normal(12, (N, N)))
+    Gasym = grid_gumbel(31, (N, N))
+    Gsym = grid_gumbel(32, (N, N))
+    Gsym = np.triu(Gsym, 1) + np.triu(Gsym, 1).T
+    for nz in ["none", "asym", "sym"]:
+        a = base_args(perturb_edge_prob=(nz != "none"), symmetric_noise=(nz == "sym"))
+        noise = None if nz == "none" else (Gasym if nz == "asym" else Gsym)
+        run_dgg(f"allpairs_n256_{nz}", N, d, h, a, in_adj, x, noise, cot, 30.0, True)
+    # larger, bench-like latent; noise / cotangent regenerated from seeds at test time
+    N, d, h = 1024, 64, 64
+    x = torch.from_numpy(grid_normal(41, (N, d)))
+    c = torch.from_numpy(24 + 16 * np.random.Generator(np.random.PCG64(42)).random((N, 1))).float()
+    in_adj = (c / N * torch.ones(N, N)).to_sparse().coalesce()
+    G = grid_gumbel(43, (N, N))
+    cotn = grid_normal(44, (N, N))
+    a = base_args()
+    run_dgg("allpairs_n1024_asym", N, d, h, a, in_adj, x, G, torch.from_numpy(cotn), 3.0, False,
+            seed_info=dict(x_seed=41, G_seed=43, cot_seed=44, G_crc=crc(G), cot_crc=crc(cotn)))
+
+
+def conv_cases():
+    """normalize_adj (model.py:1205-1219) + GCNConv (580-599) + GraphConvolution/DenseGraphConvolution (14-77)."""
+    N, F, H = 64, 20, 12
+    gen = torch.Generator().manual_seed(9)
+    A = torch.rand(N, N, generator=gen) * (torch.rand(N, N, generator=gen) < 0.2).float()
+    A = A + torch.eye(N)
+    A.requires_grad_(True)
+    x = torch.randn(N, F, generator=gen, requires_grad=True)
+    holder = refmodel.GCN_DGG.__new__(refmodel.GCN_DGG)
+    norm = refmodel.GCN_DGG.normalize_adj(holder, A)
+    conv = refmodel.GCNConv(F, H)
+    with torch.no_grad():
+        conv.W.copy_(torch.rand(F, H, generator=gen))
+    out = conv(x, norm)
+    cot = torch.from_numpy(grid_normal(13, (N, H)))
+    (out * cot).sum().backward()
+    fx = dict(A=A.detach().numpy(), x=x.detach().numpy(), W=conv.W.detach().numpy(), norm=norm.detach().numpy(),
+              out=out.detach().numpy(), cot=cot.numpy(), gA=A.grad.numpy(), gx=x.grad.numpy(),
+              gW=conv.W.grad.numpy())
+    np.savez_compressed(os.path.join(HERE, "conv_gcn.npz"), **fx)
+    print("conv_gcn ok")
+    # GCNII layers
+    for variant in [False, True]:
+        for residual in [False, True]:
+            A2 = norm.detach().clone().requires_grad_(True)
+            inp = torch.randn(N, H, generator=gen, requires_grad=True)
+            h0 = torch.randn(N, H, generator=gen, requires_grad=True)
+            for cls, tag in [(refmodel.GraphConvolution, "sp"), (refmodel.DenseGraphConvolution, "dn")]:
+                for t in (A2, inp, h0):
+                    t.grad = None
+                layer = cls(H, H, residual=residual, variant=variant)
+                with torch.no_grad():
+                    layer.weight.copy_((torch.rand(layer.weight.shape, generator=gen) - 0.5) * 0.5)
+                o = layer(inp, A2, h0, 0.5, 0.1, 3)
+                cot2 = torch.from_numpy(grid_normal(14, (N, H)))
+                (o * cot2).sum().backward()
+                fx = dict(A=A2.detach().numpy(), inp=inp.detach().numpy(), h0=h0.detach().numpy(),
+                          W=layer.weight.detach().numpy(), out=o.detach().numpy(), cot=cot2.numpy(),
+                          gA=A2.grad.numpy(), ginp=inp.grad.numpy(), gh0=h0.grad.numpy(),
+                          gW=layer.weight.grad.numpy(), lamda=0.5, alpha=0.1, l=3)
+                np.savez_compressed(os.path.join(HERE, f"conv_gcnii_{tag}_v{int(variant)}_r{int(residual)}.npz"), **fx)
+    print("conv_gcnii ok")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["edgelist", "allpairs", "conv"]
+    if "edgelist" in which:
+        edgelist_cases()
+    if "allpairs" in which:
+        allpairs_cases()
+    if "conv" in which:
+        conv_cases()
