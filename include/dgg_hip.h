@@ -1,0 +1,128 @@
+/*
+ * dgg_hip.h -- C ABI of libdgg_hip.so, the MI355X (gfx950) implementation of the Differentiable Graph
+ * Generator hot path of avishkarsaha/learning-adaptive-neighborhoods-for-gnns.
+ *
+ * The reference has no FFI: its hot path is a chain of ATen calls on dense [N,N] tensors inside
+ * DGG_LearnableK_debug.forward (reference dgm.py:1178-1292) and the graph-conv layers of model.py.  Each entry
+ * point below names the reference lines it replaces.  All pointers are DEVICE pointers (hipMalloc / torch
+ * caching allocator), fp32 / int32 / int64, row-major and contiguous; `stream` is a hipStream_t passed as
+ * void* (NULL = default stream).  Every function returns 0 on success or a DGG_ERR_* code, with a message
+ * available from dgg_last_error() (thread-local).  No function allocates, synchronises or keeps state; work
+ * buffers are caller-provided, so calls may be captured in a hipGraph.
+ *
+ * Sparse adjacency layout (ELL): idx int32 [rows, K], K <= 64, entry r of a row = its rank-r candidate in
+ * descending score order (ties: lower column first); idx = -1 marks an empty slot.  Row-sharded multi-GPU
+ * use passes the local row range [row0, row1) together with GLOBAL-length per-node arrays.
+ *
+ * Reference-side binding: see INTEGRATION.md (ctypes stub a maintainer would add next to dgm.py).
+ */
+#ifndef DGG_HIP_H
+#define DGG_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGG_OK 0
+#define DGG_ERR_ARG 1          /* invalid argument        (reference: bare assert, dgm.py:1187-1188)            */
+#define DGG_ERR_UNSUPPORTED 2  /* unsupported shape/mode  (reference: Exception("mode not found"), dgm.py:1727) */
+#define DGG_ERR_HIP 3          /* HIP runtime / launch failure                                                  */
+
+/* noise_mode: how the Gumbel perturbation of dgm.py:1211-1229 is supplied */
+#define DGG_NOISE_NONE 0      /* args.perturb_edge_prob == False                                      */
+#define DGG_NOISE_EXPLICIT 1  /* caller passes G (dense, ld = ldG): what gumbel_sample(log_p, G) takes */
+#define DGG_NOISE_HASH 2      /* counter-based Gumbel(0,0.3) keyed on (seed, i, j)                    */
+#define DGG_NOISE_HASH_SYM 3  /* keyed on (seed, min(i,j), max(i,j)), zero diagonal (dgm.py:1216-1223) */
+
+/* activations of dgg_linear_*: */
+#define DGG_ACT_NONE 0
+#define DGG_ACT_LEAKY 1 /* nn.LeakyReLU(0.01), dgm.py:1099 */
+#define DGG_ACT_RELU 2  /* torch.relu, model.py:598 */
+
+/* select_top_k modes (dgm.py:1402-1435) */
+#define DGG_MODE_K_TIMES_EDGE_PROB 0
+#define DGG_MODE_K_ONLY 1
+
+const char *dgg_last_error(void);
+int dgg_abi_version(void);
+
+/* ---- dense layers (fp32 MFMA) ------------------------------------------------------------------------------
+ * y[N,out] = act(x[N,d] W^T + b).  w_layout 0: W[out][d] (nn.Linear: node_encode_for_edges / node_encode_for_k,
+ * dgm.py:1097-1100, 1123-1126, applied at 1609 / 1566); w_layout 1: W[d][out] (GCNConv.W, model.py:583, 594-598;
+ * GraphConvolution.weight, model.py:25, 41).  b may be NULL. */
+int dgg_linear_fwd(const float *x, int64_t N, int d, const float *W, const float *b, int out, int w_layout, int act,
+                   float *y, void *stream);
+/* autograd of the above.  dp_ws: N*out floats of workspace.  dx (nullable) is overwritten; dW (layout of W) and
+ * db (nullable) are accumulated into. */
+int dgg_linear_bwd(const float *x, int64_t N, int d, const float *W, int out, int w_layout, int act, const float *y,
+                   const float *dy, float *dx, float *dW, float *db, float *dp_ws, void *stream);
+/* C[M1,M2] += A[N,M1]^T B[N,M2] (c_layout 1: C stored [M2][M1]); colsum (nullable,[M1]) += column sums of A.
+ * Weight gradients of the per-node layers (autograd of dgm.py:1576-1577). */
+int dgg_gemm_tn_acc(const float *A, const float *B, int64_t N, int M1, int M2, float *C, int c_layout, float *colsum,
+                    void *stream);
+
+/* ---- learned degree k (k_estimate_net, dgm.py:1472-1586; LearnableKEncoder.forward, dgm.py:2051-2063) ------ */
+/* mu_sd[0] = mean(deg), mu_sd[1] = unbiased std(deg)   (dgm.py:1568-1570; deg replaces in_adj.to_dense().sum(-1)) */
+int dgg_degree_stats(const float *deg, int64_t N, float *mu_sd, void *stream);
+/* mode "x" (dgm.py:1562-1586): xk = leaky(node_encode_for_k(x)) [N,h]; W1/b1 = k_embed.0 [h2][h+1]; Wmu/bmu =
+ * k_net.k_mu [h4][h2]; Wp/bp = k_net.k_project [h4]/[1].  Saves (nullable) z [N,h2], u [N] (pre-relu), feat
+ * [N,h+1] = [xk | normalised degree] for the backward. */
+int dgg_knet_x_fwd(const float *xk, int64_t N, int h, const float *deg, const float *mu_sd, const float *W1,
+                   const float *b1, int h2, const float *Wmu, const float *bmu, int h4, const float *Wp, const float *bp,
+                   float *k, float *z_save, float *u_save, float *feat_save, void *stream);
+/* per-node part of the backward: dk -> dkp [N], dm [N,h4], dpre1 [N,h2], dxk [N,h], m [N,h4] (recomputed) */
+int dgg_knet_x_bwd_nodes(int64_t N, int h, const float *mu_sd, const float *W1, int h2, const float *Wmu, int h4,
+                         const float *Wp, const float *bmu, const float *z, const float *u, const float *dk, float *dkp,
+                         float *dm, float *dpre1, float *dxk, float *m_out, void *stream);
+/* mode "input_deg" (dgm.py:1509-1526): Wd/bd = input_degree_project [3]/[3]; Wmu [h4][3] */
+int dgg_knet_input_deg_fwd(const float *deg, int64_t N, float dmean, float dstd, const float *Wd, const float *bd,
+                           const float *Wmu, const float *bmu, int h4, const float *Wp, const float *bp, float *k,
+                           void *stream);
+
+/* ---- pair scoring + per-row top-K ---------------------------------------------------------------------------
+ * edge_prob_net "u-v-dist" (dgm.py:1607-1627) + perturbation (dgm.py:1211-1229) + torch.sort (dgm.py:1404), kept
+ * to the K best per row.  xp [N,h] = leaky(node_encode_for_edges(x)); t = -0.05 (dgm.py:1618).
+ * All-pairs candidates (complete in_adj): rows [row0,row1) of the N x N score matrix; outputs [row1-row0, K].
+ * algo: 0 auto, 1 exhaustive, 2 pruned (identical results).  workspace: dgg_allpairs_workspace_bytes(). */
+int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode,
+                      const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, int algo,
+                      void *workspace, size_t ws_bytes, void *stream);
+/* candidates = stored entries of in_adj as CSR (the live class's semantics, dgm.py:1613-1614) */
+int dgg_edgelist_topk(const float *xp, int64_t N, int h, const int64_t *rowptr, const int32_t *col, float t,
+                      int noise_mode, const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx,
+                      float *val, void *stream);
+/* selection only, from a dense score matrix [R,N] (test entry: torch.sort(pert_edge_p)[:, :K], dgm.py:1404) */
+int dgg_select_scores(const float *scores, int64_t R, int64_t N, int K, int32_t *idx, float *val, void *stream);
+
+/* ---- smooth first-k ramp, normalisation, aggregation ---------------------------------------------------------
+ * w_ir = val_ir * (1 - 0.5(1 + tanh(r - k_i)))  (mode 0, dgm.py:1410-1420)  or the ramp alone (mode 1, 1427-1434);
+ * rs_i = sum_r w_ir. */
+int dgg_softk_fwd(const int32_t *idx, const float *val, const float *k, int64_t N, int K, int mode, float *w, float *rs,
+                  void *stream);
+/* ahat_ir = rs_i^-1/2 w_ir rs_j^-1/2   (normalize_adj, model.py:1205-1219; rs has GLOBAL length, rows are
+ * nodes row0..row0+N-1) */
+int dgg_ell_normalize_fwd(const int32_t *idx, const float *w, const float *rs, int64_t N, int K, int64_t row0,
+                          float *ahat, void *stream);
+/* Y[N,F] = A X   (torch.mm(adj, x) model.py:594, 67; torch.spmm model.py:34); X has GLOBAL rows */
+int dgg_ell_spmm_fwd(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, float *Y,
+                     void *stream);
+/* dA_ir = <dY_i, X_j> (overwritten); dX_j += ahat_ir dY_i (nullable; accumulated with fp32 atomics) */
+int dgg_ell_spmm_bwd(const int32_t *idx, const float *ahat, const float *X, const float *dY, int64_t N, int K, int F,
+                     float *dA, float *dX, void *stream);
+/* normalisation backward, phase 1: da (GLOBAL length, zeroed by caller) += d loss / d rs^-1/2 */
+int dgg_norm_bwd_da(const int32_t *idx, const float *w, const float *rs, const float *dA, int64_t N, int K, int64_t row0,
+                    float *da, void *stream);
+/* phase 2 + ramp backward: dval [N,K], dk [N].  normalized = 0: dA is the cotangent of w itself.
+ * mode 2: no ramp (dval = dw, dk untouched, val/k may be NULL): plain normalize_adj backward */
+int dgg_softk_bwd(const int32_t *idx, const float *val, const float *k, const float *rs, const float *dA, const float *da,
+                  int64_t N, int K, int64_t row0, int mode, int normalized, float *dval, float *dk, void *stream);
+/* score backward to the projected features: dxp [Nglobal,h] += ... (zeroed by caller; fp32 atomics) */
+int dgg_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval, int K,
+                 int64_t row0, float t, int perturb, float *dxp, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGG_HIP_H */

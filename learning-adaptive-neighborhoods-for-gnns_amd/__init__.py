@@ -1,0 +1,13 @@
+"""MI355X-native Differentiable Graph Generator hot path (package directory:
+`learning-adaptive-neighborhoods-for-gnns_amd/`, importable as `dgg_amd` through the shim at the repo root).
+
+Public surface mirrors the reference's modules:
+    dgg_amd.dgm.DGG_LearnableK_debug, dgg_amd.dgm.LearnableKEncoder          (reference dgm.py)
+    dgg_amd.model.{GCNConv, GraphConvolution, DenseGraphConvolution, GCN_DGG, GCNII_DGG, GCNIIppi_DGG}  (model.py)
+plus the containers `AllPairs` / `EllAdjacency` and the raw kernel wrappers in `dgg_amd.ops`.
+"""
+from . import _lib, ops  # noqa: F401
+from .adjacency import AllPairs, EllAdjacency, csr_candidates, ell_from_dense  # noqa: F401
+from .dgm import DGG_LearnableK_debug, LearnableKEncoder  # noqa: F401
+from .model import (DenseGraphConvolution, GCN_DGG, GCNConv, GCNII_DGG, GCNIIppi_DGG,  # noqa: F401
+                    GraphConvolution)

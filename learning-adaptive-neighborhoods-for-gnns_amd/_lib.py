@@ -1,0 +1,60 @@
+"""ctypes binding of libdgg_hip.so (include/dgg_hip.h).  Fails loudly when the HIP library is missing:
+there is no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libdgg_hip.so")
+
+_vp, _i64, _i32, _u32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_float, C.c_size_t
+
+# name -> argtypes, exactly the prototypes of include/dgg_hip.h
+PROTOTYPES = {
+    "dgg_linear_fwd": [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    "dgg_linear_bwd": [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "dgg_gemm_tn_acc": [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp],
+    "dgg_degree_stats": [_vp, _i64, _vp, _vp],
+    "dgg_knet_x_fwd": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "dgg_knet_x_bwd_nodes": [_i64, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "dgg_knet_input_deg_fwd": [_vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
+    "dgg_allpairs_topk": [_vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _vp, _i32, _vp, _sz, _vp],
+    "dgg_edgelist_topk": [_vp, _i64, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _vp, _vp],
+    "dgg_select_scores": [_vp, _i64, _i64, _i32, _vp, _vp, _vp],
+    "dgg_softk_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
+    "dgg_ell_normalize_fwd": [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp],
+    "dgg_ell_spmm_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
+    "dgg_ell_spmm_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
+    "dgg_norm_bwd_da": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp],
+    "dgg_softk_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _vp],
+    "dgg_edge_bwd": [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _vp],
+}
+
+_lib = None
+
+
+class DggHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libdgg_hip.so (built by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise DggHipError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+        L = C.CDLL(SO_PATH)
+        L.dgg_last_error.restype = C.c_char_p
+        L.dgg_abi_version.restype = C.c_int
+        for name, argtypes in PROTOTYPES.items():
+            fn = getattr(L, name)      # AttributeError if the library does not export a declared symbol
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise DggHipError(f"{what} failed (code {code}): {lib().dgg_last_error().decode()}")

@@ -1,0 +1,93 @@
+"""Sparse adjacency containers exchanged between the DGG and the graph-conv layers.
+
+The reference passes torch sparse COO [N,N] tensors and densifies them at every hand-over
+(model.py:1249-1251, 1264, 1274; dgm.py:1298).  Here the learned graph stays in a fixed-width ELL layout
+(idx int32 [N,K], values fp32 [N,K]) end to end; `.to_dense()` / `.to_sparse()` exist so that reference-style
+callers (`unnorm_adj.to_dense()`, model.py:1274) keep working on small graphs.
+"""
+import torch
+
+from . import ops
+
+
+class AllPairs:
+    """Candidate set = every ordered pair (the reference equivalent is a complete in_adj whose row sums are the
+    prior degrees): carries the prior-degree vector read by the k-net (dgm.py:1568)."""
+
+    def __init__(self, prior_degree):
+        self.prior_degree = prior_degree
+        n = prior_degree.shape[0]
+        self.shape = (n, n)
+        self.device = prior_degree.device
+
+
+class EllAdjacency:
+    """Row-major fixed-width sparse matrix: entry (i, idx[i,r]) = values[i,r]; idx == -1 marks padding."""
+
+    def __init__(self, idx, values, n_cols, rs=None, k=None, score=None, normalized=False):
+        self.idx, self._values, self.n_cols = idx, values, n_cols
+        self.rs, self.k, self.score, self.normalized = rs, k, score, normalized
+        self.shape = (idx.shape[0], n_cols)
+        self.device = idx.device
+
+    # --- reference-style accessors ---------------------------------------------------------------------------
+    def values(self):
+        return self._values
+
+    def ell(self):
+        return self.idx, self._values
+
+    def coalesce(self):
+        return self
+
+    def to_dense(self):
+        """Differentiable densification (small graphs / tests only)."""
+        valid = self.idx >= 0
+        cols = self.idx.clamp(min=0).long()
+        out = torch.zeros(self.shape, device=self.device, dtype=self._values.dtype)
+        return out.scatter_add(1, cols, torch.where(valid, self._values, torch.zeros_like(self._values)))
+
+    def to_sparse(self):
+        valid = self.idx >= 0
+        rows = torch.arange(self.shape[0], device=self.device).unsqueeze(1).expand_as(self.idx)[valid]
+        return torch.sparse_coo_tensor(torch.stack([rows, self.idx[valid].long()]), self._values[valid], self.shape)
+
+    # --- fast path -------------------------------------------------------------------------------------------
+    def row_sums(self):
+        if self.rs is None:
+            self.rs = self._values.detach().sum(1)
+        return self.rs
+
+    def normalize(self):
+        """D^-1/2 A D^-1/2 with ROW sums on both sides (normalize_adj, model.py:1205-1219)."""
+        rs = self.row_sums()
+        ahat = ops.EllNormalizeFn.apply(self._values, self.idx, rs)
+        return EllAdjacency(self.idx, ahat, self.n_cols, rs=None, k=self.k, score=self.score, normalized=True)
+
+    def matmul(self, X):
+        """A @ X (torch.mm(adj, x), model.py:594)."""
+        return ops.EllSpmmFn.apply(self._values, self.idx, X)
+
+    __matmul__ = matmul
+
+
+def ell_from_dense(A, K=ops.DEFAULT_K):
+    """Dense [N,N] -> ELL keeping the K largest entries per row (exact when every row has <= K non-zeros)."""
+    assert (A != 0).sum(1).max() <= K, "row has more non-zeros than the ELL width"
+    idx, val = ops.select_scores(A.abs().contiguous(), K)
+    vals = torch.gather(A, 1, idx.clamp(min=0).long())
+    valid = (idx >= 0) & (vals != 0)
+    idx = torch.where(valid, idx, torch.full_like(idx, -1))
+    return EllAdjacency(idx, torch.where(valid, vals, torch.zeros_like(vals)), A.shape[1])
+
+
+def csr_candidates(in_adj):
+    """torch sparse COO [N,N] (coalesced, self loops included by the caller as in model.py:1249-1264) ->
+    (rowptr int64 [N+1], col int32 [E], deg fp32 [N] = row sums of the stored values)."""
+    in_adj = in_adj.coalesce()
+    N = in_adj.shape[0]
+    ind = in_adj.indices()
+    rowptr = torch._convert_indices_from_coo_to_csr(ind[0], N, out_int32=False)
+    col = ind[1].to(torch.int32).contiguous()
+    deg = torch.zeros(N, device=in_adj.device, dtype=torch.float32).index_add_(0, ind[0], in_adj.values().float())
+    return rowptr, col, deg

@@ -1,0 +1,20 @@
+// dgg_api_internal.h -- error plumbing shared by the translation units of libdgg_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DGG_OK 0
+#define DGG_ERR_ARG 1          // invalid argument (reference style: bare assert, dgm.py:1187-1188)
+#define DGG_ERR_UNSUPPORTED 2  // shape/mode outside what the kernels implement (reference: Exception("mode not found"), dgm.py:1727)
+#define DGG_ERR_HIP 3          // a HIP runtime call or kernel launch failed
+
+int dgg_set_error(int code, const char *msg);
+int dgg_check_launch(const char *what);
+int dgg_check_hip(hipError_t e, const char *what);
+
+int dgg_allpairs_topk_exhaustive_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t,
+                                      int noise_mode, const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K,
+                                      int32_t *idx, float *val, hipStream_t st);
+int dgg_allpairs_topk_fast_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t,
+                                int noise_mode, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val,
+                                void *workspace, size_t ws_bytes, hipStream_t st);

@@ -1,0 +1,198 @@
+// dgg_common.h -- device-side building blocks shared by the gfx950 kernels.
+//
+// Canonical arithmetic: every score-path value is produced by an explicit, fixed sequence of IEEE-754
+// binary32 operations (__fadd_rn/__fmul_rn/__fmaf_rn/__fdiv_rn/__fsqrt_rn) so that results do not
+// depend on compiler contraction or on hardware transcendental approximations, and top-k indices are
+// reproducible bit-for-bit.  The sequences restate the reference's math:
+//   exp(t*||u-v||), log(p+1e-8)+G, exp(.)          reference dgm.py:1618-1623, 1213-1229
+//   1 - 0.5*(1 + tanh(r - k))                      reference dgm.py:1410-1414
+// (the reference evaluates them with torch CPU kernels; agreement with it is to a few ulp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DGG_WAVE 64
+
+namespace dgg {
+
+__device__ __forceinline__ float f_from_bits(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t bits_from_f(float f) { return __float_as_uint(f); }
+
+// exp: clamp to [-87, 88]; n = rint(x*log2e); Cody-Waite; degree-5 Horner; exact power-of-two scaling
+__device__ __forceinline__ float c_exp(float x) {
+    x = fminf(x, 88.0f);
+    x = fmaxf(x, -87.0f);
+    float n = __builtin_rintf(__fmul_rn(x, 1.44269504088896341f));
+    float r = __fmaf_rn(n, -0.693359375f, x);
+    r = __fmaf_rn(n, 2.12194440e-4f, r);
+    float q = 1.9875691500e-4f;
+    q = __fmaf_rn(q, r, 1.3981999507e-3f);
+    q = __fmaf_rn(q, r, 8.3334519073e-3f);
+    q = __fmaf_rn(q, r, 4.1665795894e-2f);
+    q = __fmaf_rn(q, r, 1.6666665459e-1f);
+    q = __fmaf_rn(q, r, 5.0000001201e-1f);
+    float r2 = __fmul_rn(r, r);
+    float y = __fmaf_rn(q, r2, r);
+    y = __fadd_rn(y, 1.0f);
+    int e = (int)n;
+    return __fmul_rn(y, f_from_bits((uint32_t)(e + 127) << 23));
+}
+
+// log of a positive normal float
+__device__ __forceinline__ float c_log(float x) {
+    uint32_t ux = bits_from_f(x);
+    int e = (int)(ux >> 23) - 126;
+    float m = f_from_bits((ux & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) { e -= 1; m = __fadd_rn(m, m); }
+    m = __fadd_rn(m, -1.0f);
+    float z = __fmul_rn(m, m);
+    float q = 7.0376836292e-2f;
+    q = __fmaf_rn(q, m, -1.1514610310e-1f);
+    q = __fmaf_rn(q, m, 1.1676998740e-1f);
+    q = __fmaf_rn(q, m, -1.2420140846e-1f);
+    q = __fmaf_rn(q, m, 1.4249322787e-1f);
+    q = __fmaf_rn(q, m, -1.6668057665e-1f);
+    q = __fmaf_rn(q, m, 2.0000714765e-1f);
+    q = __fmaf_rn(q, m, -2.4999993993e-1f);
+    q = __fmaf_rn(q, m, 3.3333331174e-1f);
+    float y = __fmul_rn(__fmul_rn(q, m), z);
+    float fe = (float)e;
+    y = __fmaf_rn(fe, -2.12194440e-4f, y);
+    y = __fmaf_rn(z, -0.5f, y);
+    float r = __fadd_rn(m, y);
+    r = __fmaf_rn(fe, 0.693359375f, r);
+    return r;
+}
+
+__device__ __forceinline__ float c_tanh(float x) {
+    float ax = fabsf(x);
+    if (ax < 0.625f) {
+        float z = __fmul_rn(x, x);
+        float q = -5.70498872745e-3f;
+        q = __fmaf_rn(q, z, 2.06390887954e-2f);
+        q = __fmaf_rn(q, z, -5.37397155531e-2f);
+        q = __fmaf_rn(q, z, 1.33314422036e-1f);
+        q = __fmaf_rn(q, z, -3.33332819422e-1f);
+        q = __fmul_rn(q, z);
+        return __fmaf_rn(q, x, x);
+    }
+    float r;
+    if (ax > 9.1f) r = 1.0f;
+    else {
+        float e = c_exp(__fadd_rn(ax, ax));
+        r = __fadd_rn(1.0f, -__fdiv_rn(2.0f, __fadd_rn(e, 1.0f)));
+    }
+    return x < 0.0f ? -r : r;
+}
+
+// smooth first-k ramp 1 - 0.5*(1 + tanh(r - k))   (reference dgm.py:1412-1414, w = 1)
+__device__ __forceinline__ float c_ramp(float r, float k) {
+    float th = c_tanh(__fadd_rn(r, -k));
+    float a = __fadd_rn(1.0f, th);
+    a = __fmul_rn(0.5f, a);
+    return __fadd_rn(1.0f, -a);
+}
+
+// ---- counter-based noise ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
+}
+__device__ __forceinline__ void rowkey(uint32_t s0, uint32_t s1, uint32_t i, uint32_t &k1, uint32_t &k2) {
+    k1 = mix32(i ^ s0);
+    k2 = mix32(k1 ^ s1 ^ 0x9E3779B9U);
+}
+__device__ __forceinline__ uint32_t pair_u24_keyed(uint32_t k1, uint32_t k2, uint32_t b) {
+    uint32_t x = b ^ k1;
+    x *= 0x7feb352dU; x ^= x >> 15; x += k2; x *= 0x846ca68bU;
+    return x >> 8;
+}
+__device__ __forceinline__ uint32_t pair_u24(uint32_t s0, uint32_t s1, uint32_t i, uint32_t j, bool symmetric) {
+    uint32_t a = i, b = j;
+    if (symmetric && j < i) { a = j; b = i; }
+    uint32_t k1, k2;
+    rowkey(s0, s1, a, k1, k2);
+    return pair_u24_keyed(k1, k2, b);
+}
+__device__ __forceinline__ float gumbel_u24(uint32_t u24) {
+    if (u24 == 0) u24 = 1;
+    float U = __fmul_rn((float)u24, 5.9604644775390625e-8f);
+    float a = -c_log(U);
+    float b = c_log(a);
+    return __fmul_rn(-0.3f, b);
+}
+__device__ __forceinline__ float pair_noise(uint32_t s0, uint32_t s1, uint32_t i, uint32_t j, bool symmetric) {
+    if (symmetric && i == j) return 0.0f;
+    return gumbel_u24(pair_u24(s0, s1, i, j, symmetric));
+}
+
+// score of a pair given the distance (reference dgm.py:1623, 1213-1229)
+__device__ __forceinline__ float score_from_dist(float dist, float t, bool perturb, float G) {
+    float p = c_exp(__fmul_rn(t, dist));
+    if (!perturb) return p;
+    float lp = c_log(__fadd_rn(p, 1e-8f));
+    return c_exp(__fadd_rn(lp, G));
+}
+
+// selection key: (score desc, column asc) packed so that a larger 64-bit key is better.
+// scores are non-negative finite floats, whose bit patterns are monotone.
+__device__ __forceinline__ uint64_t make_key(float v, int32_t col) {
+    return ((uint64_t)bits_from_f(v) << 32) | (uint32_t)(0x7fffffff - col);
+}
+__device__ __forceinline__ float key_val(uint64_t k) { return f_from_bits((uint32_t)(k >> 32)); }
+__device__ __forceinline__ int32_t key_col(uint64_t k) { return 0x7fffffff - (int32_t)(uint32_t)(k & 0xffffffffu); }
+// empty slot: key 0 (value +0.0, column 0x7fffffff) -- ranks below every real candidate except an exact
+// zero score at a larger column, which cannot exist.
+#define DGG_EMPTY_KEY 0ull
+
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// 64-lane bitonic sort, descending by key (lane 0 ends with the largest key)
+__device__ __forceinline__ uint64_t wave_sort_desc(uint64_t key, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            uint64_t other = shfl_xor_u64(key, j);
+            bool up = ((lane & k) == 0);          // this block sorts descending when up
+            bool lower = ((lane & j) == 0);
+            bool take_max = (up == lower);
+            uint64_t mx = key > other ? key : other;
+            uint64_t mn = key > other ? other : key;
+            key = take_max ? mx : mn;
+        }
+    }
+    return key;
+}
+// merge two descending-sorted 64-lane lists, keep the best 64 (descending)
+__device__ __forceinline__ uint64_t wave_merge_top64(uint64_t a, uint64_t b_sorted_desc, int lane) {
+    uint64_t brev = shfl_u64(b_sorted_desc, 63 - lane);   // ascending
+    uint64_t key = a > brev ? a : brev;                     // bitonic sequence holding the 64 largest
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        uint64_t other = shfl_xor_u64(key, j);
+        bool lower = ((lane & j) == 0);
+        uint64_t mx = key > other ? key : other;
+        uint64_t mn = key > other ? other : key;
+        key = lower ? mx : mn;
+    }
+    return key;
+}
+
+__device__ __forceinline__ float wave_sum_butterfly(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+}  // namespace dgg

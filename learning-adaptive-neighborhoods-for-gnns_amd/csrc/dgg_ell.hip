@@ -1,0 +1,301 @@
+// dgg_ell.hip -- everything after selection, on the fixed-width ELL adjacency (idx int32 [N,K], K <= 64).
+//
+// Replaces the dense [N,N] tails of the reference:
+//   smooth first-k ramp * score, unsort         reference dgm.py:1410-1420 (k_times_edge_prob), 1427-1434 (k_only)
+//   normalize_adj  D^-1/2 A D^-1/2 (row sums)   reference model.py:1205-1219
+//   torch.mm(adj, x) / torch.spmm(adj, input)   reference model.py:594, 67, 34
+// and the autograd of all of it (SDDMM, transposed SpMM, ramp/normalisation chain, score -> features).
+// One wavefront owns one row: ELL entry r lives in lane r, feature vectors are spread over lanes, row
+// reductions are 64-lane butterflies.
+#include "dgg_common.h"
+#include "dgg_api_internal.h"
+
+using namespace dgg;
+
+namespace {
+
+constexpr int WPB = 4;   // wavefronts (rows) per workgroup
+
+__device__ __forceinline__ float inv_sqrt_c(float rs) { return __fdiv_rn(1.0f, __fsqrt_rn(rs)); }
+
+// w = score * ramp (mode 0) or ramp (mode 1); rs = row sum (butterfly order)
+__global__ __launch_bounds__(WPB * 64) void softk_fwd_kernel(const int32_t *__restrict__ idx, const float *__restrict__ val,
+                                                            const float *__restrict__ k, int64_t N, int K, int mode,
+                                                            float *__restrict__ w, float *__restrict__ rs) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    float wv = 0.0f;
+    if (lane < K) {
+        float f = c_ramp((float)lane, k[i]);
+        float v = mode == 0 ? __fmul_rn(val[i * K + lane], f) : f;
+        wv = idx[i * K + lane] >= 0 ? v : 0.0f;
+        w[i * K + lane] = wv;
+    }
+    float s = wave_sum_butterfly(wv);
+    if (lane == 0) rs[i] = s;
+}
+
+// ahat_ir = (a_i * w_ir) * a_j,  a = 1/sqrt(rs);  rs is indexed by GLOBAL node id, local row i is node row0+i
+__global__ void normalize_fwd_kernel(const int32_t *__restrict__ idx, const float *__restrict__ w,
+                                     const float *__restrict__ rs, int64_t N, int K, int64_t row0,
+                                     float *__restrict__ ahat) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * K) return;
+    int64_t i = e / K;
+    int32_t j = idx[e];
+    float out = 0.0f;
+    if (j >= 0) {
+        float ai = inv_sqrt_c(rs[row0 + i]);
+        float aj = inv_sqrt_c(rs[j]);
+        out = __fmul_rn(__fmul_rn(ai, w[e]), aj);
+    }
+    ahat[e] = out;
+}
+
+// Y_i[c] = sum_r ahat_ir * X[idx_ir][c], r ascending (fmaf chain).  grid.y walks feature blocks of 64*VEC.
+template <int VEC>
+__global__ __launch_bounds__(WPB * 64) void spmm_fwd_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
+                                                           const float *__restrict__ X, int64_t N, int K, int F,
+                                                           float *__restrict__ Y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int c0 = (blockIdx.y * 64 + lane) * VEC;
+    int32_t jl = lane < K ? idx[i * K + lane] : -1;
+    float al = lane < K ? ahat[i * K + lane] : 0.0f;
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) acc[v] = 0.0f;
+    for (int r = 0; r < K; r++) {
+        int32_t j = __shfl(jl, r, 64);
+        float a = __shfl(al, r, 64);
+        if (j < 0 || a == 0.0f) continue;            // wave-uniform; fmaf(0, x, acc) == acc
+        if (c0 < F) {
+            const float *xr = X + (int64_t)j * F + c0;
+            if (VEC == 4) {
+                float4 xv = *reinterpret_cast<const float4 *>(xr);
+                acc[0] = __fmaf_rn(a, xv.x, acc[0]); acc[1 % VEC] = __fmaf_rn(a, xv.y, acc[1 % VEC]);
+                acc[2 % VEC] = __fmaf_rn(a, xv.z, acc[2 % VEC]); acc[3 % VEC] = __fmaf_rn(a, xv.w, acc[3 % VEC]);
+            } else if (VEC == 2) {
+                float2 xv = *reinterpret_cast<const float2 *>(xr);
+                acc[0] = __fmaf_rn(a, xv.x, acc[0]); acc[1 % VEC] = __fmaf_rn(a, xv.y, acc[1 % VEC]);
+            } else {
+                acc[0] = __fmaf_rn(a, xr[0], acc[0]);
+            }
+        }
+    }
+    if (c0 < F) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) Y[i * F + c0 + v] = acc[v];
+    }
+}
+
+// dA_ir = <dY_i, X_j>;  dX_j += ahat_ir * dY_i (fp32 atomics, optional).  One wavefront per row, features on lanes.
+__global__ __launch_bounds__(WPB * 64) void spmm_bwd_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
+                                                           const float *__restrict__ X, const float *__restrict__ dY,
+                                                           int64_t N, int K, int F, float *__restrict__ dA,
+                                                           float *__restrict__ dX) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    int32_t jl = lane < K ? idx[i * K + lane] : -1;
+    float al = lane < K ? ahat[i * K + lane] : 0.0f;
+    float mine = 0.0f;
+    for (int r = 0; r < K; r++) {
+        int32_t j = __shfl(jl, r, 64);
+        float a = __shfl(al, r, 64);
+        if (j < 0) continue;
+        float part = 0.0f;
+        for (int c = lane; c < F; c += 64) {
+            float g = dY[i * F + c];
+            part = fmaf(g, X[(int64_t)j * F + c], part);
+            if (dX && a != 0.0f) atomicAdd(dX + (int64_t)j * F + c, a * g);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (lane == r) mine = part;
+    }
+    if (lane < K) dA[i * K + lane] = mine;
+}
+
+// normalisation backward, phase 1: da[i] += sum_r dA_ir w_ir a_j ;  da[j] += dA_ir w_ir a_i   (da zeroed by caller)
+__global__ __launch_bounds__(WPB * 64) void norm_bwd_da_kernel(const int32_t *__restrict__ idx, const float *__restrict__ w,
+                                                              const float *__restrict__ rs, const float *__restrict__ dA,
+                                                              int64_t N, int K, int64_t row0, float *__restrict__ da) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    float rowpart = 0.0f;
+    if (lane < K) {
+        int32_t j = idx[i * K + lane];
+        if (j >= 0) {
+            float g = dA[i * K + lane] * w[i * K + lane];
+            if (g != 0.0f) {
+                float ai = inv_sqrt_c(rs[row0 + i]), aj = inv_sqrt_c(rs[j]);
+                rowpart = g * aj;
+                atomicAdd(da + j, g * ai);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) rowpart += __shfl_xor(rowpart, off, 64);
+    if (lane == 0 && rowpart != 0.0f) atomicAdd(da + row0 + i, rowpart);
+}
+
+// phase 2: dw = dA a_i a_j + drs_i (normalized) or dw = dA (not normalized);  dval = dw * f ; dk = sum dw * s * f'
+__global__ __launch_bounds__(WPB * 64) void softk_bwd_kernel(const int32_t *__restrict__ idx, const float *__restrict__ val,
+                                                            const float *__restrict__ k, const float *__restrict__ rs,
+                                                            const float *__restrict__ dA, const float *__restrict__ da,
+                                                            int64_t N, int K, int64_t row0, int mode, int normalized,
+                                                            float *__restrict__ dval, float *__restrict__ dk) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    float skp = 0.0f;
+    if (lane < K) {
+        int32_t j = idx[i * K + lane];
+        float dv = 0.0f;
+        if (j >= 0) {
+            float dw = dA[i * K + lane];
+            if (normalized) {
+                float rsi = rs[row0 + i];
+                float ai = inv_sqrt_c(rsi), aj = inv_sqrt_c(rs[j]);
+                float drs = -0.5f * da[row0 + i] * ai / rsi;
+                dw = dw * ai * aj + drs;
+            }
+            if (mode == 2) dv = dw;                   // no ramp: plain normalisation backward (dval = dw, dk = 0)
+            else {
+                float th = c_tanh((float)lane - k[i]);
+                float f = 1.0f - 0.5f * (1.0f + th);
+                float dfdk = 0.5f * (1.0f - th * th);
+                if (mode == 0) { dv = dw * f; skp = dw * val[i * K + lane] * dfdk; }
+                else skp = dw * dfdk;
+            }
+        }
+        dval[i * K + lane] = dv;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) skp += __shfl_xor(skp, off, 64);
+    if (lane == 0 && dk) dk[i] = skp;
+}
+
+// score backward: dval (wrt the stored score) -> dxp (fp32 atomics; dxp zeroed by caller).  Features on lanes.
+__global__ __launch_bounds__(WPB * 64) void edge_bwd_kernel(const float *__restrict__ xp, int64_t N, int h,
+                                                           const int32_t *__restrict__ idx, const float *__restrict__ val,
+                                                           const float *__restrict__ dval, int K, int64_t row0, float t,
+                                                           int perturb, float *__restrict__ dxp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int64_t gi = row0 + i;
+    int32_t jl = lane < K ? idx[i * K + lane] : -1;
+    float gl = lane < K ? dval[i * K + lane] : 0.0f;
+    float vl = lane < K ? val[i * K + lane] : 0.0f;
+    const int c0 = lane, c1 = lane + 64;            // h <= 128
+    float xi0 = c0 < h ? xp[gi * h + c0] : 0.0f;
+    float xi1 = c1 < h ? xp[gi * h + c1] : 0.0f;
+    float acc0 = 0.0f, acc1 = 0.0f;
+    for (int r = 0; r < K; r++) {
+        int32_t j = __shfl(jl, r, 64);
+        float g = __shfl(gl, r, 64);
+        if (j < 0 || g == 0.0f) continue;
+        float v = __shfl(vl, r, 64);
+        float d0 = c0 < h ? xi0 - xp[(int64_t)j * h + c0] : 0.0f;
+        float d1 = c1 < h ? xi1 - xp[(int64_t)j * h + c1] : 0.0f;
+        float d2 = d0 * d0 + d1 * d1;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) d2 += __shfl_xor(d2, off, 64);
+        if (d2 == 0.0f) continue;                    // vector_norm backward at 0 is 0 (self loop)
+        float dist = sqrtf(d2);
+        float p = c_exp(t * dist);
+        float dp = perturb ? g * v / (p + 1e-8f) : g;
+        float dd = dp * t * p / dist;
+        float e0 = dd * d0, e1 = dd * d1;
+        acc0 += e0; acc1 += e1;
+        if (c0 < h) atomicAdd(dxp + (int64_t)j * h + c0, -e0);
+        if (c1 < h) atomicAdd(dxp + (int64_t)j * h + c1, -e1);
+    }
+    if (c0 < h) atomicAdd(dxp + gi * h + c0, acc0);
+    if (c1 < h) atomicAdd(dxp + gi * h + c1, acc1);
+}
+
+inline unsigned rows_grid(int64_t N) { return (unsigned)((N + WPB - 1) / WPB); }
+
+}  // namespace
+
+extern "C" {
+
+int dgg_softk_fwd(const int32_t *idx, const float *val, const float *k, int64_t N, int K, int mode, float *w, float *rs,
+                  void *stream) {
+    if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(softk_fwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, idx, val, k, N, K,
+                       mode, w, rs);
+    return dgg_check_launch("softk_fwd");
+}
+
+int dgg_ell_normalize_fwd(const int32_t *idx, const float *w, const float *rs, int64_t N, int K, int64_t row0,
+                          float *ahat, void *stream) {
+    if (N == 0) return 0;
+    int64_t n = N * K;
+    hipLaunchKernelGGL(normalize_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, w,
+                       rs, N, K, row0, ahat);
+    return dgg_check_launch("ell_normalize_fwd");
+}
+
+int dgg_ell_spmm_fwd(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, float *Y,
+                     void *stream) {
+    if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    if (N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    bool al16 = ((uintptr_t)X % 16 == 0), al8 = ((uintptr_t)X % 8 == 0);
+    if (F % 4 == 0 && F >= 256 && al16) {
+        dim3 grid(rows_grid(N), (unsigned)((F + 255) / 256));
+        hipLaunchKernelGGL(spmm_fwd_kernel<4>, grid, dim3(WPB * 64), 0, st, idx, ahat, X, N, K, F, Y);
+    } else if (F % 2 == 0 && F >= 128 && al8) {
+        dim3 grid(rows_grid(N), (unsigned)((F + 127) / 128));
+        hipLaunchKernelGGL(spmm_fwd_kernel<2>, grid, dim3(WPB * 64), 0, st, idx, ahat, X, N, K, F, Y);
+    } else {
+        dim3 grid(rows_grid(N), (unsigned)((F + 63) / 64));
+        hipLaunchKernelGGL(spmm_fwd_kernel<1>, grid, dim3(WPB * 64), 0, st, idx, ahat, X, N, K, F, Y);
+    }
+    return dgg_check_launch("ell_spmm_fwd");
+}
+
+// dA [N,K] overwritten; dX (nullable, [Nglobal,F]) accumulated into with atomics
+int dgg_ell_spmm_bwd(const int32_t *idx, const float *ahat, const float *X, const float *dY, int64_t N, int K, int F,
+                     float *dA, float *dX, void *stream) {
+    if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(spmm_bwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, idx, ahat, X, dY, N, K,
+                       F, dA, dX);
+    return dgg_check_launch("ell_spmm_bwd");
+}
+
+int dgg_norm_bwd_da(const int32_t *idx, const float *w, const float *rs, const float *dA, int64_t N, int K, int64_t row0,
+                    float *da, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(norm_bwd_da_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, idx, w, rs, dA, N, K,
+                       row0, da);
+    return dgg_check_launch("norm_bwd_da");
+}
+
+int dgg_softk_bwd(const int32_t *idx, const float *val, const float *k, const float *rs, const float *dA, const float *da,
+                  int64_t N, int K, int64_t row0, int mode, int normalized, float *dval, float *dk, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(softk_bwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, idx, val, k, rs, dA, da,
+                       N, K, row0, mode, normalized, dval, dk);
+    return dgg_check_launch("softk_bwd");
+}
+
+int dgg_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval, int K,
+                 int64_t row0, float t, int perturb, float *dxp, void *stream) {
+    if (h > 128) return dgg_set_error(DGG_ERR_UNSUPPORTED, "edge_bwd supports latent_dim <= 128");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(edge_bwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, xp, N, h, idx, val, dval,
+                       K, row0, t, perturb, dxp);
+    return dgg_check_launch("edge_bwd");
+}
+
+}  // extern "C"

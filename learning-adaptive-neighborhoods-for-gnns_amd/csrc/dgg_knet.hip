@@ -1,0 +1,201 @@
+// dgg_knet.hip -- the learned-degree estimator (per-node MLP that outputs k_i).
+//
+// Replaces k_estimate_net of the live class (reference dgm.py:1472-1586) and LearnableKEncoder.forward
+// (dgm.py:2051-2063, deterministic branch):
+//   mode "x":          nd = (deg - mean) / (std + 1e-5);  z = leaky(k_embed([xk, nd]));  m = k_mu(z);
+//                      kp = k_project(m);  k = relu(kp * std + mean) + 1
+//   mode "input_deg":  nd from the constants deg_mean/deg_std;  in3 = input_degree_project(nd);
+//                      m = k_mu(in3);  kp = k_project(m);  k = relu(kp * deg_std + deg_mean) + 1
+// The reference obtains deg by densifying in_adj (dgm.py:1568); here deg is a length-N vector (CSR row sums, or
+// the prior degree in all-pairs mode).  One wavefront per node: lane o computes output unit o with an
+// fmaf chain over the input units in ascending order (the order of the CPU oracle).
+#include "dgg_common.h"
+#include "dgg_api_internal.h"
+
+using namespace dgg;
+
+namespace dggk {
+
+// mu_sd[0] = mean(deg), mu_sd[1] = unbiased std(deg); double accumulation, single workgroup
+__global__ __launch_bounds__(1024) void degree_stats_kernel(const float *__restrict__ deg, int64_t N,
+                                                            float *__restrict__ mu_sd) {
+    __shared__ double red[1024];
+    __shared__ double mean_s;
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int64_t i = tid; i < N; i += 1024) s += (double)deg[i];
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) mean_s = red[0] / (double)N;
+    __syncthreads();
+    const double m = mean_s;
+    double v = 0.0;
+    for (int64_t i = tid; i < N; i += 1024) { double d = (double)deg[i] - m; v += d * d; }
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) { mu_sd[0] = (float)m; mu_sd[1] = (float)sqrt(red[0] / (double)(N - 1)); }
+}
+
+constexpr int WPB = 4;
+
+// LDS layout: W1 [h2][h+1] | b1 [h2] | Wmu [h4][h2] | bmu [h4] | Wp [h4] | bp
+__global__ __launch_bounds__(WPB * 64) void knet_x_fwd_kernel(
+    const float *__restrict__ xk, int64_t N, int h, const float *__restrict__ deg, const float *__restrict__ mu_sd,
+    const float *__restrict__ W1, const float *__restrict__ b1, int h2, const float *__restrict__ Wmu,
+    const float *__restrict__ bmu, int h4, const float *__restrict__ Wp, const float *__restrict__ bp,
+    float *__restrict__ k, float *__restrict__ z_save, float *__restrict__ u_save, float *__restrict__ feat_save) {
+    extern __shared__ float sm[];
+    float *sW1 = sm, *sWmu = sW1 + h2 * (h + 1);
+    for (int e = threadIdx.x; e < h2 * (h + 1); e += blockDim.x) sW1[e] = W1[e];
+    for (int e = threadIdx.x; e < h4 * h2; e += blockDim.x) sWmu[e] = Wmu[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const float mu = mu_sd[0], sd = mu_sd[1];
+    for (int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); i < N; i += (int64_t)gridDim.x * WPB) {
+        float nd = __fdiv_rn(__fadd_rn(deg[i], -mu), __fadd_rn(sd, 1e-5f));
+        float x0 = lane < h ? xk[i * h + lane] : 0.0f;
+        float x1 = lane + 64 < h ? xk[i * h + lane + 64] : 0.0f;
+        if (feat_save) {
+            if (lane < h) feat_save[i * (h + 1) + lane] = x0;
+            if (lane + 64 < h) feat_save[i * (h + 1) + lane + 64] = x1;
+            if (lane == 0) feat_save[i * (h + 1) + h] = nd;
+        }
+        // z_o, o = lane < h2
+        float acc = 0.0f;
+        const float *wrow = sW1 + (lane < h2 ? lane : 0) * (h + 1);
+        for (int c = 0; c < h; c++) {
+            float xv = c < 64 ? __shfl(x0, c, 64) : __shfl(x1, c - 64, 64);
+            acc = __fmaf_rn(xv, wrow[c], acc);
+        }
+        acc = __fmaf_rn(nd, wrow[h], acc);
+        acc = __fadd_rn(acc, lane < h2 ? b1[lane] : 0.0f);
+        float z = acc > 0.0f ? acc : __fmul_rn(0.01f, acc);
+        if (z_save && lane < h2) z_save[i * h2 + lane] = z;
+        // m_o, o = lane < h4
+        float am = 0.0f;
+        const float *mrow = sWmu + (lane < h4 ? lane : 0) * h2;
+        for (int c = 0; c < h2; c++) am = __fmaf_rn(__shfl(z, c, 64), mrow[c], am);
+        float m = __fadd_rn(am, lane < h4 ? bmu[lane] : 0.0f);
+        // kp
+        float ak = 0.0f;
+        for (int c = 0; c < h4; c++) ak = __fmaf_rn(__shfl(m, c, 64), Wp[c], ak);
+        float kp = __fadd_rn(ak, bp[0]);
+        float u = __fadd_rn(__fmul_rn(kp, sd), mu);
+        if (lane == 0) {
+            k[i] = __fadd_rn(u > 0.0f ? u : 0.0f, 1.0f);
+            if (u_save) u_save[i] = u;
+        }
+    }
+}
+
+// per-node backward: dk -> dkp [N], dm [N,h4], dpre1 [N,h2], dxk [N,h]; m is recomputed from z
+__global__ __launch_bounds__(WPB * 64) void knet_x_bwd_kernel(
+    int64_t N, int h, const float *__restrict__ mu_sd, const float *__restrict__ W1, int h2,
+    const float *__restrict__ Wmu, int h4, const float *__restrict__ Wp, const float *__restrict__ z,
+    const float *__restrict__ u, const float *__restrict__ dk, float *__restrict__ dkp_out, float *__restrict__ dm_out,
+    float *__restrict__ dpre1_out, float *__restrict__ dxk, float *__restrict__ m_out, const float *__restrict__ bmu) {
+    extern __shared__ float sm[];
+    float *sW1 = sm, *sWmu = sW1 + h2 * (h + 1);
+    for (int e = threadIdx.x; e < h2 * (h + 1); e += blockDim.x) sW1[e] = W1[e];
+    for (int e = threadIdx.x; e < h4 * h2; e += blockDim.x) sWmu[e] = Wmu[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const float sd = mu_sd[1];
+    for (int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); i < N; i += (int64_t)gridDim.x * WPB) {
+        float dkp = u[i] > 0.0f ? dk[i] * sd : 0.0f;
+        float zl = lane < h2 ? z[i * h2 + lane] : 0.0f;
+        // recompute m (needed by the k_project weight gradient)
+        float am = 0.0f;
+        const float *mrow = sWmu + (lane < h4 ? lane : 0) * h2;
+        for (int c = 0; c < h2; c++) am = __fmaf_rn(__shfl(zl, c, 64), mrow[c], am);
+        if (lane < h4) m_out[i * h4 + lane] = __fadd_rn(am, bmu[lane]);
+        float dm = lane < h4 ? dkp * Wp[lane] : 0.0f;
+        if (lane < h4) dm_out[i * h4 + lane] = dm;
+        // dz_c = sum_o dm_o Wmu[o][c], c = lane < h2
+        float dz = 0.0f;
+        for (int o = 0; o < h4; o++) dz = fmaf(__shfl(dm, o, 64), sWmu[o * h2 + (lane < h2 ? lane : 0)], dz);
+        float dp1 = lane < h2 ? (zl > 0.0f ? dz : 0.01f * dz) : 0.0f;
+        if (lane < h2) dpre1_out[i * h2 + lane] = dp1;
+        // dxk_c = sum_o dp1_o W1[o][c]
+        float a0 = 0.0f, a1 = 0.0f;
+        for (int o = 0; o < h2; o++) {
+            float g = __shfl(dp1, o, 64);
+            if (lane < h) a0 = fmaf(g, sW1[o * (h + 1) + lane], a0);
+            if (lane + 64 < h) a1 = fmaf(g, sW1[o * (h + 1) + lane + 64], a1);
+        }
+        if (lane < h) dxk[i * h + lane] = a0;
+        if (lane + 64 < h) dxk[i * h + lane + 64] = a1;
+        if (lane == 0) dkp_out[i] = dkp;
+    }
+}
+
+__global__ void knet_input_deg_kernel(const float *__restrict__ deg, int64_t N, float dmean, float dstd,
+                                      const float *__restrict__ Wd, const float *__restrict__ bd,
+                                      const float *__restrict__ Wmu, const float *__restrict__ bmu, int h4,
+                                      const float *__restrict__ Wp, const float *__restrict__ bp, float *__restrict__ k) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float nd = __fdiv_rn(__fadd_rn(deg[i], -dmean), __fadd_rn(dstd, 1e-5f));
+    float in3[3];
+    for (int o = 0; o < 3; o++) in3[o] = __fadd_rn(__fmaf_rn(nd, Wd[o], 0.0f), bd[o]);
+    float ak = 0.0f;
+    for (int o = 0; o < h4; o++) {
+        float acc = 0.0f;
+        for (int c = 0; c < 3; c++) acc = __fmaf_rn(in3[c], Wmu[o * 3 + c], acc);
+        float m = __fadd_rn(acc, bmu[o]);
+        ak = __fmaf_rn(m, Wp[o], ak);
+    }
+    float kp = __fadd_rn(ak, bp[0]);
+    float u = __fadd_rn(__fmul_rn(kp, dstd), dmean);
+    k[i] = __fadd_rn(u > 0.0f ? u : 0.0f, 1.0f);
+}
+
+}  // namespace dggk
+using namespace dggk;
+
+extern "C" {
+
+int dgg_degree_stats(const float *deg, int64_t N, float *mu_sd, void *stream) {
+    if (N < 2) return dgg_set_error(DGG_ERR_ARG, "degree_stats needs N >= 2");
+    hipLaunchKernelGGL(degree_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, deg, N, mu_sd);
+    return dgg_check_launch("degree_stats");
+}
+
+// feat_save (nullable): [N, h+1] = [xk | nd], saved for the k_embed weight gradient
+int dgg_knet_x_fwd(const float *xk, int64_t N, int h, const float *deg, const float *mu_sd, const float *W1,
+                   const float *b1, int h2, const float *Wmu, const float *bmu, int h4, const float *Wp, const float *bp,
+                   float *k, float *z_save, float *u_save, float *feat_save, void *stream) {
+    if (h > 128 || h2 > 64 || h4 > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "k-net supports latent_dim <= 128");
+    if (N == 0) return 0;
+    size_t lds = sizeof(float) * ((size_t)h2 * (h + 1) + (size_t)h4 * h2);
+    unsigned blocks = (unsigned)((N + WPB - 1) / WPB < 2048 ? (N + WPB - 1) / WPB : 2048);
+    hipLaunchKernelGGL(knet_x_fwd_kernel, dim3(blocks), dim3(WPB * 64), lds, (hipStream_t)stream, xk, N, h, deg, mu_sd, W1,
+                       b1, h2, Wmu, bmu, h4, Wp, bp, k, z_save, u_save, feat_save);
+    return dgg_check_launch("knet_x_fwd");
+}
+
+int dgg_knet_x_bwd_nodes(int64_t N, int h, const float *mu_sd, const float *W1, int h2, const float *Wmu, int h4,
+                         const float *Wp, const float *bmu, const float *z, const float *u, const float *dk, float *dkp,
+                         float *dm, float *dpre1, float *dxk, float *m_out, void *stream) {
+    if (h > 128 || h2 > 64 || h4 > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "k-net supports latent_dim <= 128");
+    if (N == 0) return 0;
+    size_t lds = sizeof(float) * ((size_t)h2 * (h + 1) + (size_t)h4 * h2);
+    unsigned blocks = (unsigned)((N + WPB - 1) / WPB < 2048 ? (N + WPB - 1) / WPB : 2048);
+    hipLaunchKernelGGL(knet_x_bwd_kernel, dim3(blocks), dim3(WPB * 64), lds, (hipStream_t)stream, N, h, mu_sd, W1, h2, Wmu,
+                       h4, Wp, z, u, dk, dkp, dm, dpre1, dxk, m_out, bmu);
+    return dgg_check_launch("knet_x_bwd_nodes");
+}
+
+int dgg_knet_input_deg_fwd(const float *deg, int64_t N, float dmean, float dstd, const float *Wd, const float *bd,
+                           const float *Wmu, const float *bmu, int h4, const float *Wp, const float *bp, float *k,
+                           void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(knet_input_deg_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, deg, N,
+                       dmean, dstd, Wd, bd, Wmu, bmu, h4, Wp, bp, k);
+    return dgg_check_launch("knet_input_deg_fwd");
+}
+
+}  // extern "C"

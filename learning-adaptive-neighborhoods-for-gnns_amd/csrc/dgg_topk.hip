@@ -1,0 +1,213 @@
+// dgg_topk.hip -- pair scoring + per-row top-K selection (exhaustive variants).
+//
+// Replaces, for the live class DGG_LearnableK_debug (reference dgm.py:1178-1292):
+//   edge_prob_net "u-v-dist"            dgm.py:1607-1627   exp(-0.05 * ||xp_u - xp_v||)
+//   Gumbel perturbation                 dgm.py:1211-1229   exp(log(p + 1e-8) + G)
+//   torch.sort(descending) + first-K'   dgm.py:1404        -> ELL (idx, score), K' <= 64 per row
+// The dense [N,N] tensors of the reference never exist: a workgroup owns a block of rows, streams
+// column tiles of the projected features through LDS, and every wavefront keeps the running top-64 of its
+// rows in registers (one list entry per lane), merged with a 64-lane bitonic network.
+//
+// Kernels here evaluate EVERY candidate pair with the canonical arithmetic of dgg_common.h
+// (the pruned fast path lives in dgg_topk_fast.hip and must return identical bits).
+#include "dgg_common.h"
+#include "dgg_api_internal.h"
+
+using namespace dgg;
+
+namespace {
+
+constexpr int RW = 16;            // rows per wavefront
+constexpr int WAVES = 4;          // wavefronts per workgroup
+constexpr int RB = RW * WAVES;    // rows per workgroup
+constexpr int TN = 64;            // columns per tile (one per lane)
+
+// ---- all-pairs, exhaustive --------------------------------------------------------------------------
+// LDS: colT[H][TN] (transposed column tile, conflict-free lane-strided reads) + rows[RB][H]
+template <int H>
+__global__ __launch_bounds__(WAVES * 64) void allpairs_topk_exhaustive(
+    const float *__restrict__ xp, int64_t N, int64_t row0, int64_t row1, float t, int noise_mode,
+    const float *__restrict__ G, int64_t ldG, uint32_t s0, uint32_t s1, int K,
+    int32_t *__restrict__ idx, float *__restrict__ val) {
+    __shared__ float colT[H * TN];
+    __shared__ float rowsL[RB * H];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t rbase = row0 + (int64_t)blockIdx.x * RB;
+
+    for (int e = tid; e < RB * H; e += WAVES * 64) {
+        int r = e / H, c = e % H;
+        int64_t gi = rbase + r;
+        rowsL[e] = gi < row1 ? xp[gi * H + c] : 0.0f;
+    }
+    uint64_t list[RW];
+    uint64_t thr[RW];
+#pragma unroll
+    for (int r = 0; r < RW; r++) { list[r] = DGG_EMPTY_KEY; thr[r] = DGG_EMPTY_KEY; }
+    const bool perturb = noise_mode != 0;
+    const bool sym = noise_mode == 3;
+
+    for (int64_t j0 = 0; j0 < N; j0 += TN) {
+        __syncthreads();
+        // stage the column tile transposed: coalesced read of TN rows of H floats
+        for (int e = tid; e < TN * H; e += WAVES * 64) {
+            int jj = e / H, c = e % H;
+            int64_t gj = j0 + jj;
+            colT[c * TN + jj] = gj < N ? xp[gj * H + c] : 0.0f;
+        }
+        __syncthreads();
+        float xj[H];
+#pragma unroll
+        for (int c = 0; c < H; c++) xj[c] = colT[c * TN + lane];
+        const int64_t j = j0 + lane;
+        const bool jvalid = j < N;
+#pragma unroll
+        for (int r = 0; r < RW; r++) {
+            const int lr = wave * RW + r;
+            const int64_t i = rbase + lr;
+            if (i >= row1) continue;                      // wave-uniform
+            const float *xi = rowsL + lr * H;
+            float d2 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < H; c++) {
+                float df = __fadd_rn(xi[c], -xj[c]);
+                d2 = __fmaf_rn(df, df, d2);
+            }
+            float dist = __fsqrt_rn(d2);
+            float g = 0.0f;
+            if (noise_mode == 1) g = jvalid ? G[i * ldG + j] : 0.0f;
+            else if (noise_mode >= 2) g = pair_noise(s0, s1, (uint32_t)i, (uint32_t)j, sym);
+            float v = score_from_dist(dist, t, perturb, g);
+            uint64_t key = jvalid ? make_key(v, (int32_t)j) : DGG_EMPTY_KEY;
+            bool pass = key > thr[r];
+            if (__ballot(pass) != 0ull) {                 // wave-uniform
+                uint64_t cand = pass ? key : DGG_EMPTY_KEY;
+                cand = wave_sort_desc(cand, lane);
+                list[r] = wave_merge_top64(list[r], cand, lane);
+                thr[r] = shfl_u64(list[r], 63);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+        const int64_t i = rbase + wave * RW + r;
+        if (i >= row1) continue;
+        if (lane < K) {
+            int32_t c = key_col(list[r]);
+            bool empty = list[r] == DGG_EMPTY_KEY;
+            idx[(i - row0) * K + lane] = empty ? -1 : c;
+            val[(i - row0) * K + lane] = empty ? 0.0f : key_val(list[r]);
+        }
+    }
+}
+
+// ---- candidates from a CSR graph (edge-list mode): one wavefront per row -----------------------------
+__global__ __launch_bounds__(256) void edgelist_topk_kernel(
+    const float *__restrict__ xp, int64_t N, int h, const int64_t *__restrict__ rowptr,
+    const int32_t *__restrict__ col, float t, int noise_mode, const float *__restrict__ G, int64_t ldG,
+    uint32_t s0, uint32_t s1, int K, int32_t *__restrict__ idx, float *__restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const bool perturb = noise_mode != 0, sym = noise_mode == 3;
+    const float *xi = xp + i * h;
+    uint64_t list = DGG_EMPTY_KEY;
+    const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
+    for (int64_t eb = e0; eb < e1; eb += 64) {
+        int64_t e = eb + lane;
+        uint64_t key = DGG_EMPTY_KEY;
+        if (e < e1) {
+            int32_t j = col[e];
+            const float *xj = xp + (int64_t)j * h;
+            float d2 = 0.0f;
+            for (int c = 0; c < h; c++) {
+                float df = __fadd_rn(xi[c], -xj[c]);
+                d2 = __fmaf_rn(df, df, d2);
+            }
+            float dist = __fsqrt_rn(d2);
+            float g = 0.0f;
+            if (noise_mode == 1) g = G[i * ldG + j];
+            else if (noise_mode >= 2) g = pair_noise(s0, s1, (uint32_t)i, (uint32_t)j, sym);
+            key = make_key(score_from_dist(dist, t, perturb, g), j);
+        }
+        key = wave_sort_desc(key, lane);
+        list = wave_merge_top64(list, key, lane);
+    }
+    if (lane < K) {
+        bool empty = list == DGG_EMPTY_KEY;
+        idx[i * K + lane] = empty ? -1 : key_col(list);
+        val[i * K + lane] = empty ? 0.0f : key_val(list);
+    }
+}
+
+// ---- selection only: dense score rows -> top-K (test entry; bit-exact target) ------------------------
+__global__ __launch_bounds__(256) void select_scores_kernel(const float *__restrict__ scores, int64_t R, int64_t N,
+                                                            int K, int32_t *__restrict__ idx, float *__restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= R) return;
+    uint64_t list = DGG_EMPTY_KEY, thr = DGG_EMPTY_KEY;
+    for (int64_t j0 = 0; j0 < N; j0 += 64) {
+        int64_t j = j0 + lane;
+        uint64_t key = j < N ? make_key(scores[i * N + j], (int32_t)j) : DGG_EMPTY_KEY;
+        bool pass = key > thr;
+        if (__ballot(pass) != 0ull) {
+            uint64_t cand = wave_sort_desc(pass ? key : DGG_EMPTY_KEY, lane);
+            list = wave_merge_top64(list, cand, lane);
+            thr = shfl_u64(list, 63);
+        }
+    }
+    if (lane < K) {
+        bool empty = list == DGG_EMPTY_KEY;
+        idx[i * K + lane] = empty ? -1 : key_col(list);
+        val[i * K + lane] = empty ? 0.0f : key_val(list);
+    }
+}
+
+template <int H>
+int launch_exhaustive(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, int noise_mode, const float *G,
+                      int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, hipStream_t st) {
+    int64_t rows = row1 - row0;
+    if (rows <= 0) return 0;
+    dim3 grid((unsigned)((rows + RB - 1) / RB));
+    hipLaunchKernelGGL(allpairs_topk_exhaustive<H>, grid, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, noise_mode, G,
+                       ldG, s0, s1, K, idx, val);
+    return dgg_check_launch("allpairs_topk_exhaustive");
+}
+
+}  // namespace
+
+int dgg_allpairs_topk_exhaustive_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t,
+                                      int noise_mode, const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K,
+                                      int32_t *idx, float *val, hipStream_t st) {
+    switch (h) {
+        case 8: return launch_exhaustive<8>(xp, N, row0, row1, t, noise_mode, G, ldG, s0, s1, K, idx, val, st);
+        case 16: return launch_exhaustive<16>(xp, N, row0, row1, t, noise_mode, G, ldG, s0, s1, K, idx, val, st);
+        case 32: return launch_exhaustive<32>(xp, N, row0, row1, t, noise_mode, G, ldG, s0, s1, K, idx, val, st);
+        case 64: return launch_exhaustive<64>(xp, N, row0, row1, t, noise_mode, G, ldG, s0, s1, K, idx, val, st);
+        case 128: return launch_exhaustive<128>(xp, N, row0, row1, t, noise_mode, G, ldG, s0, s1, K, idx, val, st);
+        default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "all-pairs scoring supports latent_dim in {8,16,32,64,128}");
+    }
+}
+
+extern "C" {
+
+int dgg_edgelist_topk(const float *xp, int64_t N, int h, const int64_t *rowptr, const int32_t *col, float t,
+                      int noise_mode, const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx,
+                      float *val, void *stream) {
+    if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    if (noise_mode == 1 && !G) return dgg_set_error(DGG_ERR_ARG, "explicit noise requested but G is NULL");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(edgelist_topk_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, xp, N, h,
+                       rowptr, col, t, noise_mode, G, ldG, s0, s1, K, idx, val);
+    return dgg_check_launch("edgelist_topk");
+}
+
+int dgg_select_scores(const float *scores, int64_t R, int64_t N, int K, int32_t *idx, float *val, void *stream) {
+    if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(select_scores_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, scores, R,
+                       N, K, idx, val);
+    return dgg_check_launch("select_scores");
+}
+
+}  // extern "C"

@@ -1,0 +1,161 @@
+"""Differentiable Graph Generator modules with the reference's names, signatures and state_dict keys.
+
+`DGG_LearnableK_debug(in_dim, latent_dim, args).forward(x, in_adj, noise, writer, epoch)` mirrors reference
+dgm.py:1083, 1178 -- the live class behind GCN_DGG / SAGE_DGG / GCNII_DGG / GCNIIppi_DGG (model.py:133, 666, 910,
+1198) -- but runs on the HIP kernels of libdgg_hip.so and returns an `EllAdjacency` (which still offers
+`.to_dense()` / `.to_sparse()`) instead of a sparse COO built from dense [N,N] tensors.
+
+Parameters are created in the reference's order with the reference's layer types, so `state_dict()` has the
+same 34 keys/shapes (reference checkpoints load with strict=True) and the same default initialisation under
+the same torch seed.  Parameters that the reference registers but never uses on this path (t, k_W, edge_encode,
+edge_conv_*, ...) are kept for that reason only.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .adjacency import AllPairs, EllAdjacency, csr_candidates
+
+_EDGE_MODES_NEXT = ("u-v-A_uv", "u-v-deg", "u-v-deg-dist", "edge_conv", "A_uv")
+
+
+class LearnableKEncoder(nn.Module):
+    """k_mu / k_logvar / k_project head (reference dgm.py:2029-2063); deterministic branch on the GPU path."""
+
+    def __init__(self, in_dim, latent_dim, learn_k_bias=False, args=None):
+        super().__init__()
+        self.learn_k_bias = learn_k_bias
+        self.k_mu = nn.Linear(in_dim, latent_dim)
+        self.k_logvar = nn.Linear(in_dim, latent_dim)
+        self.k_project = nn.Linear(latent_dim, 1)
+        self.args = args
+
+
+class _DGGSoftAdjFn(torch.autograd.Function):
+    """x, prior degree, parameters -> soft (unnormalised) ELL adjacency values.  One autograd node for the whole
+    generator: projection, k-net, scoring + top-K, ramp (reference dgm.py:1197-1292)."""
+
+    @staticmethod
+    def forward(ctx, x, deg, We, be, Wk, bk, W1, b1, Wmu, bmu, Wp, bp, cfg):
+        xp = ops.linear_fwd(x, We, be, ops.ACT_LEAKY)
+        xk = ops.linear_fwd(x, Wk, bk, ops.ACT_LEAKY)
+        mu_sd = ops.degree_stats(deg)
+        k, z, u, feat = ops.knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp.reshape(-1), bp)
+        if cfg["cand"] is None:
+            idx, val = ops.allpairs_topk(xp, cfg["K"], cfg["t"], cfg["noise_mode"], cfg["G"], cfg["seed"], algo=cfg["algo"])
+        else:
+            rowptr, col = cfg["cand"]
+            idx, val = ops.edgelist_topk(xp, rowptr, col, cfg["K"], cfg["t"], cfg["noise_mode"], cfg["G"], cfg["seed"])
+        w, rs = ops.softk_fwd(idx, val, k, cfg["mode"])
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, We, Wk, W1, Wmu, bmu, Wp, xp, xk, mu_sd, k, z, u, feat, idx, val)
+        ctx.mark_non_differentiable(idx, val, k, rs)
+        return w, idx, val, k, rs
+
+    @staticmethod
+    def backward(ctx, dw, *_):
+        x, We, Wk, W1, Wmu, bmu, Wp, xp, xk, mu_sd, k, z, u, feat, idx, val = ctx.saved_tensors
+        cfg = ctx.cfg
+        need_dx = ctx.needs_input_grad[0]
+        dval, dk = ops.softk_bwd(idx, val, k, dw.contiguous(), mode=cfg["mode"], normalized=False)
+        dxp = ops.edge_bwd(xp, idx, val, dval, t=cfg["t"], perturb=cfg["noise_mode"] != ops.NOISE_NONE)
+        dx1, dWe, dbe = ops.linear_bwd(x, We, xp, dxp, ops.ACT_LEAKY, need_dx=need_dx)
+        dxk, dW1, db1, dWmu, dbmu, dWp, dbp = ops.knet_x_bwd(xk.shape[1], mu_sd, W1, Wmu, bmu, Wp.reshape(-1), z, u, feat, dk)
+        dx2, dWk, dbk = ops.linear_bwd(x, Wk, xk, dxk, ops.ACT_LEAKY, need_dx=need_dx)
+        dx = dx1 + dx2 if need_dx else None
+        return dx, None, dWe, dbe, dWk, dbk, dW1, db1, dWmu, dbmu, dWp.reshape(Wp.shape), dbp, None
+
+
+class DGG_LearnableK_debug(nn.Module):
+    """Drop-in for reference dgm.py:1077-1727 (modes u-v-dist / x / {k_times_edge_prob, k_only}, soft output)."""
+
+    def __init__(self, in_dim=32, latent_dim=64, args=None):
+        super().__init__()
+        h = latent_dim
+        self.in_dim, self.latent_dim = in_dim, h
+        self.extra_edge_dim, self.extra_k_dim = args.extra_edge_dim, args.extra_k_dim
+        self.hard = args.dgg_hard
+        self.deg_mean, self.deg_std = args.deg_mean, args.deg_std
+        # --- same registration order / layer types as the reference (dgm.py:1097-1143) -> same keys, same init
+        self.node_encode_for_edges = nn.Sequential(nn.Linear(in_dim, h), nn.LeakyReLU())
+        self.edge_encode = nn.Sequential(nn.Linear(2 * h + self.extra_edge_dim, h), nn.LeakyReLU(), nn.Linear(h, 1))
+        self.t = nn.Parameter(torch.tensor(-0.1))
+        self.edge_conv_phi = nn.Linear(h, h // 2)
+        self.edge_conv_theta = nn.Linear(h, h // 2)
+        self.edge_conv_encode = nn.Linear(h // 2, 1)
+        self.edge_prob_net_mode = args.dgg_mode_edge_net
+        self.input_degree_decode = nn.Linear(3, 1, bias=True)
+        self.combine_input_degree = nn.Sequential(nn.Linear(h + 3, h), nn.LeakyReLU())
+        self.adj_project = nn.Linear(1, 1)
+        self.k_net_mode = args.dgg_mode_k_net
+        self.signal_project = nn.Linear(256, 1, bias=True)
+        self.input_degree_project = nn.Linear(1, 3, bias=True)
+        self.node_encode_for_k = nn.Sequential(nn.Linear(in_dim, h), nn.LeakyReLU())
+        self.k_embed = nn.Sequential(nn.Linear(h + self.extra_k_dim, h // 2), nn.LeakyReLU())
+        self.k_W = nn.Parameter(torch.rand(h, h, requires_grad=True))
+        k_in = 3 if self.k_net_mode in ("input_deg", "learn_normalized_degree") else h // 2
+        self.k_net = LearnableKEncoder(in_dim=k_in, latent_dim=h // 4, args=args)
+        self.k_select_mode = args.dgg_mode_k_select
+        self.args = args
+        # --- GPU-path controls (not in the reference) ---------------------------------------------------------
+        self.ell_width = getattr(args, "dgg_ell_width", ops.DEFAULT_K)
+        self.topk_algo = getattr(args, "dgg_topk_algo", 0)
+        self._explicit_noise = None          # test hook: the G that gumbel_sample(log_p, G) would receive
+        self._seed = None
+
+    # test / reproducibility hooks ---------------------------------------------------------------------------
+    def set_noise(self, G):
+        """Use an explicit noise matrix [N,N] (what dgm.py:1226 samples) instead of the counter-based generator."""
+        self._explicit_noise = G
+
+    def set_seed(self, s0, s1=0):
+        self._seed = (int(s0) & 0xFFFFFFFF, int(s1) & 0xFFFFFFFF)
+
+    def _noise_cfg(self):
+        if not self.args.perturb_edge_prob:
+            return ops.NOISE_NONE, None, (0, 0)
+        if self._explicit_noise is not None:
+            return ops.NOISE_EXPLICIT, self._explicit_noise, (0, 0)
+        seed = self._seed
+        if seed is None:   # fresh noise per forward, reproducible under torch.manual_seed (CPU generator: no sync)
+            s = torch.randint(0, 2 ** 31 - 1, (2,))
+            seed = (int(s[0]), int(s[1]))
+        return (ops.NOISE_HASH_SYM if self.args.symmetric_noise else ops.NOISE_HASH), None, seed
+
+    def forward(self, x, in_adj, noise=True, writer=None, epoch=None):
+        """x [N,dim] fp32 on the GPU; in_adj: sparse COO [N,N] (coalesced, self loops added by the caller) whose
+        stored entries are the candidate edges, or `AllPairs(prior_degree)`.  `noise` is accepted and ignored
+        exactly like the reference (perturbation is gated by args.perturb_edge_prob only, dgm.py:1211)."""
+        assert x.ndim == 2 and len(in_adj.shape) == 2
+        if self.edge_prob_net_mode != "u-v-dist":
+            if self.edge_prob_net_mode in _EDGE_MODES_NEXT:
+                raise NotImplementedError(f"edge mode {self.edge_prob_net_mode!r} is a 'next' row (SURVEY.md 8f); "
+                                          "the HIP path implements 'u-v-dist'")
+            raise Exception("mode not found")
+        if self.k_net_mode != "x":
+            raise NotImplementedError(f"k-net mode {self.k_net_mode!r}: the HIP autograd path implements 'x'")
+        if self.k_select_mode not in ("k_times_edge_prob", "k_only"):
+            raise NotImplementedError(f"k-select mode {self.k_select_mode!r} is dead code in the reference")
+        if self.hard:
+            raise NotImplementedError("dgg_hard=True: the reference's hard path is index-confused (SURVEY.md section 7)")
+        if self.args.debug_step in (0, 1):
+            raise NotImplementedError("debug_step 0/1 return dense [N,N] intermediates in the reference")
+        if isinstance(in_adj, AllPairs):
+            cand, deg = None, in_adj.prior_degree
+        else:
+            if isinstance(in_adj, EllAdjacency):     # dgg_adj_input != "input_adj": previous learned graph
+                in_adj = in_adj.to_sparse().detach()
+            rowptr, col, deg = csr_candidates(in_adj)
+            cand = (rowptr, col)
+        noise_mode, G, seed = self._noise_cfg()
+        cfg = dict(cand=cand, K=self.ell_width, t=ops.T_DIST, noise_mode=noise_mode, G=G, seed=seed, algo=self.topk_algo,
+                   mode=ops.MODE_K_TIMES_EDGE_PROB if self.k_select_mode == "k_times_edge_prob" else ops.MODE_K_ONLY)
+        w, idx, val, k, rs = _DGGSoftAdjFn.apply(
+            x, deg, self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias,
+            self.node_encode_for_k[0].weight, self.node_encode_for_k[0].bias, self.k_embed[0].weight, self.k_embed[0].bias,
+            self.k_net.k_mu.weight, self.k_net.k_mu.bias, self.k_net.k_project.weight, self.k_net.k_project.bias, cfg)
+        if writer is not None:   # the two scalars the reference logs from inside the DGG (dgm.py:1259-1261)
+            f = w.detach() if cfg["mode"] == ops.MODE_K_ONLY else (w.detach() / val.clamp(min=1e-30))
+            writer.add_scalar("values/first_k_std", f.sum(-1).std(), epoch)
+            writer.add_scalar("values/first_k_mean", f.sum(-1).mean(), epoch)
+        return EllAdjacency(idx, w, x.shape[0], rs=rs, k=k, score=val)

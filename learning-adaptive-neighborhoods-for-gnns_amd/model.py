@@ -1,0 +1,202 @@
+"""Graph-conv layers and *_DGG model wrappers with the reference's names, signatures and state_dict keys
+(reference model.py), running on the ELL adjacency and the HIP kernels.
+
+Layers accept either an `EllAdjacency` (fast path) or a dense [N,N] tensor whose rows have at most 64 non-zeros
+(converted once).  Dropout / log_softmax / sigmoid and the two `fcs` nn.Linear layers of the GCNII wrappers are
+plain torch, as in the reference: they are outside the hot path (SURVEY.md section 8b, row "Model wrappers").
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.parameter import Parameter
+
+from . import ops
+from .adjacency import EllAdjacency, ell_from_dense
+from .dgm import DGG_LearnableK_debug
+
+
+def _as_ell(adj):
+    if isinstance(adj, EllAdjacency):
+        return adj
+    if adj.is_sparse:
+        adj = adj.to_dense()
+    return ell_from_dense(adj)
+
+
+class GCNConv(nn.Module):
+    """relu((A x) W), W ~ U[0,1)  (reference model.py:580-599)."""
+
+    def __init__(self, in_channels, out_channels, A=None, cached=False):
+        super().__init__()
+        self.W = nn.Parameter(torch.rand(in_channels, out_channels, requires_grad=True))
+
+    def forward(self, x, adj):
+        Ax = _as_ell(adj).matmul(x)
+        return ops.LinearFn.apply(Ax, self.W, None, ops.ACT_RELU, 1)
+
+
+class GraphConvolution(nn.Module):
+    """GCNII layer (reference model.py:14-44): theta = log(lamda/l + 1); hi = A input;
+    support = (1-alpha) hi + alpha h0 (variant: cat[hi, h0]); out = theta support W + (1-theta) r (+ input)."""
+
+    def __init__(self, in_features, out_features, residual=False, variant=False):
+        super().__init__()
+        self.variant = variant
+        self.in_features = 2 * in_features if variant else in_features
+        self.out_features = out_features
+        self.residual = residual
+        self.weight = Parameter(torch.FloatTensor(self.in_features, self.out_features))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.out_features)
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, input, adj, h0, lamda, alpha, l):
+        theta = math.log(lamda / l + 1)
+        hi = _as_ell(adj).matmul(input)
+        if self.variant:
+            support = torch.cat([hi, h0], 1)
+            r = (1 - alpha) * hi + alpha * h0
+        else:
+            support = (1 - alpha) * hi + alpha * h0
+            r = support
+        output = theta * ops.LinearFn.apply(support, self.weight, None, ops.ACT_NONE, 1) + (1 - theta) * r
+        if self.residual:
+            output = output + input
+        return output
+
+
+class DenseGraphConvolution(GraphConvolution):
+    """Same arithmetic as GraphConvolution (reference model.py:47-77 differs only in torch.mm vs torch.spmm)."""
+
+
+def _normalize_adj(A_hat):
+    """D^-1/2 A D^-1/2 with row sums on both sides (reference model.py:1205-1219 and its nine copies)."""
+    if isinstance(A_hat, EllAdjacency):
+        return A_hat.normalize()
+    return _as_ell(A_hat).normalize()
+
+
+def _with_self_loops(in_adj):
+    """in_adj + I as coalesced sparse COO (reference model.py:1249-1251, 1264) without the dense round trip."""
+    if not isinstance(in_adj, torch.Tensor):
+        return in_adj          # AllPairs etc.
+    N = in_adj.shape[0]
+    if not in_adj.is_sparse:
+        in_adj = in_adj.to_sparse()
+    eye_i = torch.arange(N, device=in_adj.device)
+    eye = torch.sparse_coo_tensor(torch.stack([eye_i, eye_i]), torch.ones(N, device=in_adj.device), (N, N))
+    return (in_adj + eye).coalesce()
+
+
+class GCN_DGG(nn.Module):
+    """Two GCNConv layers, one DGG in front of the first (reference model.py:1183-1311).  Returns
+    (log_probs, unnorm_adj, None)."""
+
+    def __init__(self, nfeat=32, nlayers=None, nhidden=32, nclass=10, args=None, **kwargs):
+        super().__init__()
+        self.convs = nn.ModuleList()
+        self.conv1 = GCNConv(nfeat, nhidden)
+        self.conv2 = GCNConv(nhidden, nclass)
+        self.convs.append(self.conv1)
+        self.convs.append(self.conv2)
+        self.dgg_adj_input = args.dgg_adj_input
+        self.dggs = nn.ModuleList([DGG_LearnableK_debug(in_dim=nfeat, latent_dim=nhidden, args=args)])
+        self.params1 = list(self.conv1.parameters())
+        self.params2 = list(self.conv2.parameters())
+        self.params2.extend(list(self.dggs.parameters()))
+
+    normalize_adj = staticmethod(_normalize_adj)
+
+    def forward(self, x, in_adj, noise=True, epoch=None, writer=None):
+        in_adj = _with_self_loops(in_adj)
+        unnorm_adj = in_adj
+        norm_adj = None
+        for i, conv in enumerate(self.convs):
+            if i < len(self.dggs):
+                src = in_adj if self.dgg_adj_input == "input_adj" else unnorm_adj
+                unnorm_adj = self.dgg_net(x, i, src, writer, epoch)
+                norm_adj = _normalize_adj(unnorm_adj)
+            x = conv(x, norm_adj)
+            if i < len(self.convs) - 1:
+                x = F.dropout(x, training=self.training)
+            if writer is not None:
+                writer.add_histogram("gcn_conv{}_dist".format(i + 1), x, epoch)
+        return F.log_softmax(x, dim=-1), unnorm_adj, None
+
+    def dgg_net(self, x, i, unnorm_adj, writer, epoch):
+        return self.dggs[i](x=x, in_adj=unnorm_adj, noise=False, writer=writer, epoch=epoch)
+
+
+class GCNII_DGG(nn.Module):
+    """GCNII stack with DGG-generated adjacency for the first n_dgg_layers layers (reference model.py:649-740).
+    The DGG sees the raw (dropped-out) input features, not the hidden state (model.py:720)."""
+
+    _conv_cls = DenseGraphConvolution
+    _residual = False
+
+    def __init__(self, nfeat, nlayers, nhidden, nclass, dropout, lamda, alpha, variant, args):
+        super().__init__()
+        self.convs = nn.ModuleList()
+        for _ in range(nlayers):
+            if self._residual:
+                self.convs.append(self._conv_cls(nhidden, nhidden, variant=variant, residual=True))
+            else:
+                self.convs.append(self._conv_cls(nhidden, nhidden, variant=variant))
+        self.fcs = nn.ModuleList()
+        self.fcs.append(nn.Linear(nfeat, nhidden))
+        self.fcs.append(nn.Linear(nhidden, nclass))
+        self.dgg_adj_input = args.dgg_adj_input
+        self.dggs = nn.ModuleList()
+        for _ in range(args.n_dgg_layers):
+            self.dggs.append(DGG_LearnableK_debug(in_dim=nfeat, latent_dim=nhidden, args=args))
+        self.params1 = list(self.convs.parameters())
+        self.params1.extend(list(self.dggs.parameters()))
+        self.params2 = list(self.fcs.parameters())
+        self.act_fn = nn.ReLU()
+        self.dropout = dropout
+        self.alpha = alpha
+        self.lamda = lamda
+
+    normalize_adj = staticmethod(_normalize_adj)
+
+    def _body(self, x, in_adj, epoch, writer):
+        _layers = []
+        x = F.dropout(x, self.dropout, training=self.training)
+        layer_inner = self.act_fn(self.fcs[0](x))
+        _layers.append(layer_inner)
+        in_adj = _with_self_loops(in_adj)
+        unnorm_adj = in_adj
+        norm_adj = None
+        for i, con in enumerate(self.convs):
+            if i < len(self.dggs):
+                src = in_adj if self.dgg_adj_input == "input_adj" else unnorm_adj
+                unnorm_adj = self.dgg_net(x, i, src, writer, epoch)
+                norm_adj = _normalize_adj(unnorm_adj)
+            elif norm_adj is None:
+                norm_adj = _normalize_adj(unnorm_adj)
+            layer_inner = F.dropout(layer_inner, self.dropout, training=self.training)
+            layer_inner = self.act_fn(con(layer_inner, norm_adj, _layers[0], self.lamda, self.alpha, i + 1))
+        layer_inner = F.dropout(layer_inner, self.dropout, training=self.training)
+        return self.fcs[-1](layer_inner), unnorm_adj
+
+    def forward(self, x, in_adj, epoch=None, writer=None):
+        out, _ = self._body(x, in_adj, epoch, writer)
+        return F.log_softmax(out, dim=1)
+
+    def dgg_net(self, x, i, unnorm_adj, writer, epoch):
+        return self.dggs[i](x=x, in_adj=unnorm_adj, noise=self.training, writer=writer, epoch=epoch)
+
+
+class GCNIIppi_DGG(GCNII_DGG):
+    """PPI variant (reference model.py:887-965): GraphConvolution(residual=True) layers, sigmoid output."""
+
+    _conv_cls = GraphConvolution
+    _residual = True
+
+    def forward(self, x, in_adj, writer=None, epoch=None):
+        out, _ = self._body(x, in_adj, epoch, writer)
+        return torch.sigmoid(out)

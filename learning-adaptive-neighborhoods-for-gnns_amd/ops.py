@@ -1,0 +1,277 @@
+"""Tensor-level wrappers of the C-ABI kernels and the custom autograd ops built on them.
+
+torch is used for device memory, streams and autograd bookkeeping only: every FLOP of the hot path runs in
+libdgg_hip.so.  Naming follows the reference (dgm.py / model.py) and include/dgg_hip.h.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+NOISE_NONE, NOISE_EXPLICIT, NOISE_HASH, NOISE_HASH_SYM = 0, 1, 2, 3
+ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+MODE_K_TIMES_EDGE_PROB, MODE_K_ONLY = 0, 1
+DEFAULT_K = 64
+T_DIST = -0.05  # reference dgm.py:1618
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype=torch.float32):
+    assert t.is_cuda, "dgg ops run on the GPU only (no CPU fallback)"
+    assert t.dtype == dtype, f"expected {dtype}, got {t.dtype}"
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# raw kernels
+# ------------------------------------------------------------------------------------------------------------
+def linear_fwd(x, W, b=None, act=ACT_NONE, w_layout=0):
+    x, W = _chk(x), _chk(W)
+    N, d = x.shape
+    out = W.shape[0] if w_layout == 0 else W.shape[1]
+    assert (W.shape[1] if w_layout == 0 else W.shape[0]) == d
+    y = torch.empty((N, out), device=x.device, dtype=torch.float32)
+    bb = _chk(b) if b is not None else None
+    _lib.check(_lib.lib().dgg_linear_fwd(_ptr(x), N, d, _ptr(W), _ptr(bb), out, w_layout, act, _ptr(y), _stream()), "linear_fwd")
+    return y
+
+
+def linear_bwd(x, W, y, dy, act=ACT_NONE, w_layout=0, need_dx=True, need_db=True):
+    x, W, dy = _chk(x), _chk(W), _chk(dy)
+    N, d = x.shape
+    out = W.shape[0] if w_layout == 0 else W.shape[1]
+    dx = torch.empty_like(x) if need_dx else None
+    dW = torch.zeros_like(W)
+    db = torch.zeros((out,), device=x.device, dtype=torch.float32) if need_db else None
+    ws = torch.empty((N, out), device=x.device, dtype=torch.float32) if act != ACT_NONE else None
+    yy = _chk(y) if act != ACT_NONE else None
+    _lib.check(_lib.lib().dgg_linear_bwd(_ptr(x), N, d, _ptr(W), out, w_layout, act, _ptr(yy), _ptr(dy), _ptr(dx), _ptr(dW),
+                                         _ptr(db), _ptr(ws), _stream()), "linear_bwd")
+    return dx, dW, db
+
+
+def gemm_tn(A, B, colsum=False):
+    """A[N,M1]^T B[N,M2] -> [M1,M2] (+ column sums of A)."""
+    A, B = _chk(A), _chk(B)
+    N, M1 = A.shape
+    M2 = B.shape[1]
+    Cm = torch.zeros((M1, M2), device=A.device, dtype=torch.float32)
+    cs = torch.zeros((M1,), device=A.device, dtype=torch.float32) if colsum else None
+    _lib.check(_lib.lib().dgg_gemm_tn_acc(_ptr(A), _ptr(B), N, M1, M2, _ptr(Cm), 0, _ptr(cs), _stream()), "gemm_tn_acc")
+    return (Cm, cs) if colsum else Cm
+
+
+def degree_stats(deg):
+    deg = _chk(deg)
+    out = torch.empty((2,), device=deg.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_degree_stats(_ptr(deg), deg.shape[0], _ptr(out), _stream()), "degree_stats")
+    return out
+
+
+def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed=(0, 0), rows=None, algo=0):
+    xp = _chk(xp)
+    N, h = xp.shape
+    r0, r1 = (0, N) if rows is None else rows
+    idx = torch.empty((r1 - r0, K), device=xp.device, dtype=torch.int32)
+    val = torch.empty((r1 - r0, K), device=xp.device, dtype=torch.float32)
+    ldG = 0
+    if G is not None:
+        G = _chk(G)
+        assert G.shape[-1] == N and G.shape[0] == N, "explicit noise must be [N, N]"
+        ldG = N
+    _lib.check(_lib.lib().dgg_allpairs_topk(_ptr(xp), N, h, r0, r1, t, noise_mode, _ptr(G), ldG, seed[0], seed[1], K,
+                                            _ptr(idx), _ptr(val), algo, None, 0, _stream()), "allpairs_topk")
+    return idx, val
+
+
+def edgelist_topk(xp, rowptr, col, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed=(0, 0)):
+    xp = _chk(xp)
+    N, h = xp.shape
+    rowptr, col = _chk(rowptr, torch.int64), _chk(col, torch.int32)
+    idx = torch.empty((N, K), device=xp.device, dtype=torch.int32)
+    val = torch.empty((N, K), device=xp.device, dtype=torch.float32)
+    ldG = 0
+    if G is not None:
+        G = _chk(G)
+        ldG = N
+    _lib.check(_lib.lib().dgg_edgelist_topk(_ptr(xp), N, h, _ptr(rowptr), _ptr(col), t, noise_mode, _ptr(G), ldG, seed[0],
+                                            seed[1], K, _ptr(idx), _ptr(val), _stream()), "edgelist_topk")
+    return idx, val
+
+
+def select_scores(scores, K=DEFAULT_K):
+    scores = _chk(scores)
+    R, N = scores.shape
+    idx = torch.empty((R, K), device=scores.device, dtype=torch.int32)
+    val = torch.empty((R, K), device=scores.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_select_scores(_ptr(scores), R, N, K, _ptr(idx), _ptr(val), _stream()), "select_scores")
+    return idx, val
+
+
+def softk_fwd(idx, val, k, mode=MODE_K_TIMES_EDGE_PROB):
+    N, K = idx.shape
+    w = torch.empty((N, K), device=idx.device, dtype=torch.float32)
+    rs = torch.empty((N,), device=idx.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_softk_fwd(_ptr(idx), _ptr(_chk(val)), _ptr(_chk(k)), N, K, mode, _ptr(w), _ptr(rs), _stream()), "softk_fwd")
+    return w, rs
+
+
+def normalize_fwd(idx, w, rs, row0=0):
+    N, K = idx.shape
+    ahat = torch.empty((N, K), device=idx.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_ell_normalize_fwd(_ptr(idx), _ptr(_chk(w)), _ptr(_chk(rs)), N, K, row0, _ptr(ahat), _stream()), "ell_normalize_fwd")
+    return ahat
+
+
+def spmm_fwd(idx, ahat, X):
+    N, K = idx.shape
+    X = _chk(X)
+    F = X.shape[1]
+    Y = torch.empty((N, F), device=idx.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_ell_spmm_fwd(_ptr(idx), _ptr(_chk(ahat)), _ptr(X), N, K, F, _ptr(Y), _stream()), "ell_spmm_fwd")
+    return Y
+
+
+def spmm_bwd(idx, ahat, X, dY, need_dx=True):
+    N, K = idx.shape
+    X, dY = _chk(X), _chk(dY)
+    F = X.shape[1]
+    dA = torch.empty((N, K), device=idx.device, dtype=torch.float32)
+    dX = torch.zeros_like(X) if need_dx else None
+    _lib.check(_lib.lib().dgg_ell_spmm_bwd(_ptr(idx), _ptr(_chk(ahat)), _ptr(X), _ptr(dY), N, K, F, _ptr(dA), _ptr(dX), _stream()), "ell_spmm_bwd")
+    return dA, dX
+
+
+def norm_bwd_da(idx, w, rs, dA, row0=0):
+    N, K = idx.shape
+    da = torch.zeros_like(rs)
+    _lib.check(_lib.lib().dgg_norm_bwd_da(_ptr(idx), _ptr(_chk(w)), _ptr(_chk(rs)), _ptr(_chk(dA)), N, K, row0, _ptr(da), _stream()), "norm_bwd_da")
+    return da
+
+
+def softk_bwd(idx, val, k, dA, rs=None, da=None, row0=0, mode=MODE_K_TIMES_EDGE_PROB, normalized=False):
+    N, K = idx.shape
+    dval = torch.empty((N, K), device=idx.device, dtype=torch.float32)
+    dk = torch.empty((N,), device=idx.device, dtype=torch.float32) if mode != 2 else None
+    val = _chk(val) if val is not None else None
+    k = _chk(k) if k is not None else None
+    _lib.check(_lib.lib().dgg_softk_bwd(_ptr(idx), _ptr(val), _ptr(k), _ptr(rs), _ptr(_chk(dA)), _ptr(da), N, K, row0, mode,
+                                        int(normalized), _ptr(dval), _ptr(dk), _stream()), "softk_bwd")
+    return dval, dk
+
+
+def edge_bwd(xp, idx, val, dval, row0=0, t=T_DIST, perturb=False):
+    xp = _chk(xp)
+    Ng, h = xp.shape
+    N, K = idx.shape
+    dxp = torch.zeros_like(xp)
+    _lib.check(_lib.lib().dgg_edge_bwd(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(dval)), K, row0, t, int(perturb), _ptr(dxp),
+                                       _stream()), "edge_bwd")
+    return dxp
+
+
+def knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, save=True):
+    xk = _chk(xk)
+    N, h = xk.shape
+    h2, h4 = W1.shape[0], Wmu.shape[0]
+    dev = xk.device
+    k = torch.empty((N,), device=dev, dtype=torch.float32)
+    z = torch.empty((N, h2), device=dev, dtype=torch.float32) if save else None
+    u = torch.empty((N,), device=dev, dtype=torch.float32) if save else None
+    feat = torch.empty((N, h + 1), device=dev, dtype=torch.float32) if save else None
+    _lib.check(_lib.lib().dgg_knet_x_fwd(_ptr(xk), N, h, _ptr(_chk(deg)), _ptr(mu_sd), _ptr(_chk(W1)), _ptr(_chk(b1)), h2, _ptr(_chk(Wmu)),
+                                         _ptr(_chk(bmu)), h4, _ptr(_chk(Wp)), _ptr(_chk(bp)), _ptr(k), _ptr(z), _ptr(u), _ptr(feat), _stream()),
+               "knet_x_fwd")
+    return k, z, u, feat
+
+
+def knet_x_bwd(h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk):
+    """-> dxk [N,h], dW1, db1, dWmu, dbmu, dWp ([1,h4]), dbp ([1])"""
+    N = z.shape[0]
+    h2, h4 = W1.shape[0], Wmu.shape[0]
+    dev = z.device
+    dkp = torch.empty((N, 1), device=dev, dtype=torch.float32)
+    dm = torch.empty((N, h4), device=dev, dtype=torch.float32)
+    dpre1 = torch.empty((N, h2), device=dev, dtype=torch.float32)
+    dxk = torch.empty((N, h), device=dev, dtype=torch.float32)
+    m = torch.empty((N, h4), device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_knet_x_bwd_nodes(N, h, _ptr(mu_sd), _ptr(_chk(W1)), h2, _ptr(_chk(Wmu)), h4, _ptr(_chk(Wp)), _ptr(_chk(bmu)),
+                                               _ptr(z), _ptr(u), _ptr(_chk(dk)), _ptr(dkp), _ptr(dm), _ptr(dpre1), _ptr(dxk), _ptr(m),
+                                               _stream()), "knet_x_bwd_nodes")
+    dW1, db1 = gemm_tn(dpre1, feat, colsum=True)
+    dWmu, dbmu = gemm_tn(dm, z, colsum=True)
+    dWp, dbp = gemm_tn(dkp, m, colsum=True)
+    return dxk, dW1, db1, dWmu, dbmu, dWp, dbp
+
+
+def knet_input_deg_fwd(deg, dmean, dstd, Wd, bd, Wmu, bmu, Wp, bp):
+    deg = _chk(deg)
+    N = deg.shape[0]
+    k = torch.empty((N,), device=deg.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_knet_input_deg_fwd(_ptr(deg), N, float(dmean), float(dstd), _ptr(_chk(Wd)), _ptr(_chk(bd)), _ptr(_chk(Wmu)),
+                                                 _ptr(_chk(bmu)), Wmu.shape[0], _ptr(_chk(Wp)), _ptr(_chk(bp)), _ptr(k), _stream()),
+               "knet_input_deg_fwd")
+    return k
+
+
+# ------------------------------------------------------------------------------------------------------------
+# autograd ops
+# ------------------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """act(x W^T + b) on the fp32 matrix cores (nn.Linear+LeakyReLU dgm.py:1097-1100; GCNConv mm+relu model.py:596-598)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, w_layout):
+        y = linear_fwd(x, W, b, act, w_layout)
+        ctx.save_for_backward(x, W, y)
+        ctx.act, ctx.w_layout, ctx.has_b = act, w_layout, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        dx, dW, db = linear_bwd(x, W, y, dy, ctx.act, ctx.w_layout, need_dx=ctx.needs_input_grad[0], need_db=ctx.has_b)
+        return dx, dW, db, None, None
+
+
+class EllNormalizeFn(torch.autograd.Function):
+    """D^-1/2 A D^-1/2 with row sums on both sides (normalize_adj, model.py:1205-1219) on ELL values."""
+
+    @staticmethod
+    def forward(ctx, w, idx, rs):
+        ahat = normalize_fwd(idx, w, rs)
+        ctx.save_for_backward(w, idx, rs)
+        return ahat
+
+    @staticmethod
+    def backward(ctx, dA):
+        w, idx, rs = ctx.saved_tensors
+        dA = dA.contiguous()
+        da = norm_bwd_da(idx, w, rs, dA)
+        # mode 2 = no ramp: dw = dA a_i a_j - 0.5 da_i a_i / rs_i
+        dw, _ = softk_bwd(idx, None, None, dA, rs=rs, da=da, mode=2, normalized=True)
+        return dw, None, None
+
+
+class EllSpmmFn(torch.autograd.Function):
+    """Y = A X on the ELL adjacency (torch.mm(adj, x) model.py:594, 67 / torch.spmm model.py:34)."""
+
+    @staticmethod
+    def forward(ctx, ahat, idx, X):
+        Y = spmm_fwd(idx, ahat, X)
+        ctx.save_for_backward(ahat, idx, X)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        ahat, idx, X = ctx.saved_tensors
+        dA, dX = spmm_bwd(idx, ahat, X, dY.contiguous(), need_dx=ctx.needs_input_grad[2])
+        return dA, None, dX
