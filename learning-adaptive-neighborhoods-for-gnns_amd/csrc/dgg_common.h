@@ -18,6 +18,11 @@ namespace dgg {
 __device__ __forceinline__ float f_from_bits(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t bits_from_f(float f) { return __float_as_uint(f); }
 
+// IEEE correctly rounded sqrt / div.  NOTE: HIP's __fsqrt_rn maps to the NATIVE (approximate) sqrt unless
+// OCML_BASIC_ROUNDED_OPERATIONS is defined; sqrtf and '/' are correctly rounded under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt.
+__device__ __forceinline__ float c_sqrt(float x) { return sqrtf(x); }
+
 // exp: clamp to [-87, 88]; n = rint(x*log2e); Cody-Waite; degree-5 Horner; exact power-of-two scaling
 __device__ __forceinline__ float c_exp(float x) {
     x = fminf(x, 88.0f);

@@ -16,7 +16,7 @@ namespace {
 
 constexpr int WPB = 4;   // wavefronts (rows) per workgroup
 
-__device__ __forceinline__ float inv_sqrt_c(float rs) { return __fdiv_rn(1.0f, __fsqrt_rn(rs)); }
+__device__ __forceinline__ float inv_sqrt_c(float rs) { return __fdiv_rn(1.0f, c_sqrt(rs)); }
 
 // w = score * ramp (mode 0) or ramp (mode 1); rs = row sum (butterfly order)
 __global__ __launch_bounds__(WPB * 64) void softk_fwd_kernel(const int32_t *__restrict__ idx, const float *__restrict__ val,

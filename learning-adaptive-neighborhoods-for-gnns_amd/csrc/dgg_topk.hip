@@ -72,7 +72,7 @@ __global__ __launch_bounds__(WAVES * 64) void allpairs_topk_exhaustive(
                 float df = __fadd_rn(xi[c], -xj[c]);
                 d2 = __fmaf_rn(df, df, d2);
             }
-            float dist = __fsqrt_rn(d2);
+            float dist = c_sqrt(d2);
             float g = 0.0f;
             if (noise_mode == 1) g = jvalid ? G[i * ldG + j] : 0.0f;
             else if (noise_mode >= 2) g = pair_noise(s0, s1, (uint32_t)i, (uint32_t)j, sym);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void edgelist_topk_kernel(
                 float df = __fadd_rn(xi[c], -xj[c]);
                 d2 = __fmaf_rn(df, df, d2);
             }
-            float dist = __fsqrt_rn(d2);
+            float dist = c_sqrt(d2);
             float g = 0.0f;
             if (noise_mode == 1) g = G[i * ldG + j];
             else if (noise_mode >= 2) g = pair_noise(s0, s1, (uint32_t)i, (uint32_t)j, sym);
