@@ -1,0 +1,110 @@
+"""Node-range sharding of the DGG hot path across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The reference has no distributed code; the all-pairs similarity shards by rows: every
+output row i needs x_i, all candidate x_j, k_i and the row sums rs_j of its selected neighbours, and nothing else
+(sort / ramp act on dim=-1, reference dgm.py:1404-1420).  Rank r owns rows [r*ceil(N/G), ...) of X, of the ELL
+adjacency and of the conv output.  Collectives per step:
+
+  forward   all-gather X [N,d] (once; serves the projection, the scoring and the SpMM gather)
+            all-gather rs [N]   (row sums for the symmetric-ish normalisation, model.py:1215-1218)
+  backward  all-reduce da [N]   (d loss / d rs^-1/2: neighbour-side terms land on non-owner ranks)
+            all-reduce of the replicated weight gradients (one flat bucket, ~35k floats)
+            [reduce-scatter dX [N,d] only when the input features need a gradient]
+
+The projected features xp = leaky(X We^T + be) are recomputed on every rank from the gathered X (2*N*d*h flop,
+negligible next to N^2/G pair scores); its weight gradient is formed from each rank's PARTIAL dxp against the full
+X and summed by the weight all-reduce, so the [N,h] gradient itself never crosses the fabric.
+
+`kern` is the kernel namespace (dgg_amd.ops on the GPU; tests substitute a CPU stand-in built on the oracle so
+that the partition / collective logic is exercised with gloo, world_size 2, without a GPU).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(N, world, rank):
+    per = (N + world - 1) // world
+    r0 = min(rank * per, N)
+    return r0, min(r0 + per, N), per
+
+
+def _all_gather_rows(t_local, N, per, group):
+    """[n_loc, ...] -> [N, ...]; shards are padded to `per` rows for the fixed-size collective."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return t_local
+    pad = per - t_local.shape[0]
+    src = t_local if pad == 0 else torch.cat([t_local, t_local.new_zeros((pad,) + tuple(t_local.shape[1:]))])
+    out = src.new_empty((world * per,) + tuple(t_local.shape[1:]))
+    dist.all_gather_into_tensor(out, src.contiguous(), group=group)
+    return out[:N]
+
+
+class ShardedDGGConv:
+    """One DGG (all-pairs, u-v-dist / x / k_times_edge_prob) + normalise + GCNConv layer, forward and backward,
+    on a row shard.  Parameters are a dict with the reference's names (dgm.py:1097-1143, model.py:583)."""
+
+    PARAM_KEYS = ("We", "be", "Wk", "bk", "W1", "b1", "Wmu", "bmu", "Wp", "bp", "Wc")
+
+    def __init__(self, kern, N, group=None, K=64, t=-0.05, noise_mode=2, seed=(1234, 0), mode=0, algo=0, x_grad=False):
+        self.kern, self.N, self.group = kern, N, group
+        self.K, self.t, self.noise_mode, self.seed, self.mode, self.algo, self.x_grad = K, t, noise_mode, seed, mode, algo, x_grad
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.r0, self.r1, self.per = shard_bounds(N, self.world, self.rank)
+
+    def forward(self, x_local, deg_full, P):
+        kern = self.kern
+        s = {}
+        s["X"] = X = _all_gather_rows(x_local, self.N, self.per, self.group) if self.world > 1 else x_local
+        s["xp"] = xp = kern.linear_fwd(X, P["We"], P["be"], 1, 0)
+        s["xk"] = xk = kern.linear_fwd(x_local, P["Wk"], P["bk"], 1, 0)
+        s["mu_sd"] = mu_sd = kern.degree_stats(deg_full)
+        deg_local = deg_full[self.r0:self.r1].contiguous()
+        s["k"], s["z"], s["u"], s["feat"] = kern.knet_x_fwd(xk, deg_local, mu_sd, P["W1"], P["b1"], P["Wmu"], P["bmu"],
+                                                          P["Wp"].reshape(-1), P["bp"])
+        s["idx"], s["val"] = kern.allpairs_topk(xp, self.K, self.t, self.noise_mode, None, self.seed,
+                                                rows=(self.r0, self.r1), algo=self.algo)
+        s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
+        s["rs"] = rs = _all_gather_rows(rs_local, self.N, self.per, self.group) if self.world > 1 else rs_local
+        s["ahat"] = kern.normalize_fwd(s["idx"], s["w"], rs, self.r0)
+        s["Y"] = kern.spmm_fwd(s["idx"], s["ahat"], X)
+        s["Z"] = kern.linear_fwd(s["Y"], P["Wc"], None, 2, 1)
+        self.saved = s
+        return s["Z"]
+
+    def backward(self, dZ, x_local, P):
+        """-> dict of parameter gradients (summed over ranks) and, if x_grad, 'x' = d loss / d x_local."""
+        kern, s = self.kern, self.saved
+        g = {}
+        dY, g["Wc"], _ = kern.linear_bwd(s["Y"], P["Wc"], s["Z"], dZ, 2, 1, True, False)
+        dA, dX = kern.spmm_bwd(s["idx"], s["ahat"], s["X"], dY, self.x_grad)
+        da = kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0)
+        if self.world > 1:
+            dist.all_reduce(da, group=self.group)
+        dval, dk = kern.softk_bwd(s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.mode, True)
+        dxp = kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0)
+        dX1, g["We"], g["be"] = kern.linear_bwd(s["X"], P["We"], s["xp"], dxp, 1, 0, self.x_grad, True)
+        dxk, g["W1"], g["b1"], g["Wmu"], g["bmu"], dWp, g["bp"] = kern.knet_x_bwd(
+            s["xk"].shape[1], s["mu_sd"], P["W1"], P["Wmu"], P["bmu"], P["Wp"].reshape(-1), s["z"], s["u"], s["feat"], dk)
+        g["Wp"] = dWp.reshape(P["Wp"].shape)
+        dx2, g["Wk"], g["bk"] = kern.linear_bwd(x_local, P["Wk"], s["xk"], dxk, 1, 0, self.x_grad, True)
+        if self.world > 1:
+            flat = torch.cat([g[k].reshape(-1) for k in self.PARAM_KEYS])
+            dist.all_reduce(flat, group=self.group)
+            o = 0
+            for k in self.PARAM_KEYS:
+                n = g[k].numel()
+                g[k] = flat[o:o + n].view_as(g[k])
+                o += n
+        if self.x_grad:
+            dXf = dX + dX1                               # [N,d] partial: neighbour-side terms of every rank
+            if self.world > 1:
+                pad = self.world * self.per - self.N
+                if pad:
+                    dXf = torch.cat([dXf, dXf.new_zeros((pad, dXf.shape[1]))])
+                out = dXf.new_empty((self.per, dXf.shape[1]))
+                dist.reduce_scatter_tensor(out, dXf.contiguous(), group=self.group)
+                dXf = out[: self.r1 - self.r0]
+            g["x"] = dXf + dx2
+        return g

@@ -482,10 +482,17 @@ ORA_API void ora_softk_norm_bwd(const int32_t *idx, const float *val, const floa
 }
 /* score backward to the projected features: dxp [N,h] (dgm.py:1613-1623, 1213-1229 under autograd).
  * G explicit dense or counter-based as in ora_allpairs_topk (needed to recompute p from the stored score). */
+ORA_API void ora_edge_bwd_rows(const float *xp, int64_t N, int64_t R, int h, const int32_t *idx, const float *val,
+                               const float *dval, int K, float t, int perturb, float *dxp);
 ORA_API void ora_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval,
                           int K, float t, int perturb, float *dxp) {
+    ora_edge_bwd_rows(xp, N, N, h, idx, val, dval, K, t, perturb, dxp);
+}
+/* same, for the first R rows of an N-node problem (idx/val/dval are [R,K]; columns index all N nodes) */
+ORA_API void ora_edge_bwd_rows(const float *xp, int64_t N, int64_t R, int h, const int32_t *idx, const float *val,
+                               const float *dval, int K, float t, int perturb, float *dxp) {
     double *acc = calloc((size_t)N * h, 8);
-    for (int64_t i = 0; i < N; i++) for (int r = 0; r < K; r++) {
+    for (int64_t i = 0; i < R; i++) for (int r = 0; r < K; r++) {
         int32_t j = idx[i * K + r];
         if (j < 0) continue;
         double g = dval[i * K + r];
