@@ -89,6 +89,9 @@ int dgg_knet_input_deg_fwd(const float *deg, int64_t N, float dmean, float dstd,
 int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode,
                       const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, int algo,
                       void *workspace, size_t ws_bytes, void *stream);
+/* bytes of device workspace the pruned path needs for (N, h): a bf16 copy of xp plus discounted squared norms;
+ * 0 when the pruned path does not apply (explicit noise, K != 64, latent_dim not in {16,32,64,128}) */
+size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K);
 /* candidates = stored entries of in_adj as CSR (the live class's semantics, dgm.py:1613-1614) */
 int dgg_edgelist_topk(const float *xp, int64_t N, int h, const int64_t *rowptr, const int32_t *col, float t,
                       int noise_mode, const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx,

@@ -29,8 +29,18 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
     if (row0 < 0 || row1 > N || row0 > row1) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk: bad row range");
     if (noise_mode < 0 || noise_mode > 3) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk: bad noise_mode");
     if (noise_mode == 1 && !G) return dgg_set_error(DGG_ERR_ARG, "explicit noise requested but G is NULL");
+    const bool can_fast = dgg_allpairs_fast_supported(h, noise_mode, K) && workspace &&
+                          ws_bytes >= dgg_allpairs_fast_ws_bytes(N, h);
+    if (algo == 2 || (algo == 0 && can_fast && N >= 1024))
+        return dgg_allpairs_topk_fast_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes,
+                                           (hipStream_t)stream);
     return dgg_allpairs_topk_exhaustive_impl(xp, N, h, row0, row1, t, noise_mode, G, ldG, s0, s1, K, idx, val,
                                              (hipStream_t)stream);
+}
+
+// bytes of workspace the pruned path needs (bf16 copy of xp + discounted norms); 0 when it cannot be used
+size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K) {
+    return dgg_allpairs_fast_supported(h, noise_mode, K) ? dgg_allpairs_fast_ws_bytes(N, h) : 0;
 }
 
 }  // extern "C"

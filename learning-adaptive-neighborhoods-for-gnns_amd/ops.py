@@ -87,8 +87,13 @@ def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed
         G = _chk(G)
         assert G.shape[-1] == N and G.shape[0] == N, "explicit noise must be [N, N]"
         ldG = N
+    ws, ws_bytes = None, 0
+    if algo != 1:
+        ws_bytes = int(_lib.lib().dgg_allpairs_workspace_bytes(N, h, noise_mode, K))
+        if ws_bytes:
+            ws = torch.empty((ws_bytes,), device=xp.device, dtype=torch.uint8)
     _lib.check(_lib.lib().dgg_allpairs_topk(_ptr(xp), N, h, r0, r1, t, noise_mode, _ptr(G), ldG, seed[0], seed[1], K,
-                                            _ptr(idx), _ptr(val), algo, None, 0, _stream()), "allpairs_topk")
+                                            _ptr(idx), _ptr(val), algo, _ptr(ws), ws_bytes, _stream()), "allpairs_topk")
     return idx, val
 
 

@@ -73,8 +73,8 @@ def test_allpairs_topk_bit_exact(dev, N, h, noise, algo):
     xp[xp < 0] *= 0.01
     mode = {"none": O.NOISE_NONE, "hash": O.NOISE_HASH, "sym": O.NOISE_HASH_SYM, "explicit": O.NOISE_EXPLICIT}[noise]
     G = grid_gumbel(5, (N, N)) if noise == "explicit" else None
-    if algo == 2 and noise == "explicit":
-        pytest.skip("the pruned path generates its noise in-kernel")
+    if algo == 2 and (noise == "explicit" or h == 8):
+        pytest.skip("the pruned path generates its noise in-kernel and needs latent_dim in {16,32,64,128}")
     idx, val = ops.allpairs_topk(T(xp, dev), K, noise_mode=mode, G=None if G is None else T(G, dev), seed=(77, 5), algo=algo)
     ridx, rval = O.allpairs_topk(xp, K=K, noise_mode=mode, G=G, seed=(77, 5))
     assert np.array_equal(Nn(idx), ridx), "top-k indices differ from the oracle"
