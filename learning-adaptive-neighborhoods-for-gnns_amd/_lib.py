@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libdgg_hip.so")
+SO_PATH = os.environ.get("DGG_HIP_SO", os.path.join(_HERE, "libdgg_hip.so"))   # override: diagnostic builds only
 
 _vp, _i64, _i32, _u32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_float, C.c_size_t
 

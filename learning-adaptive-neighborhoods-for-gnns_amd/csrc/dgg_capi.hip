@@ -21,7 +21,8 @@ extern "C" {
 const char *dgg_last_error(void) { return g_err; }
 int dgg_abi_version(void) { return 1; }
 
-// algo: 0 auto, 1 exhaustive (every pair scored with the canonical arithmetic), 2 pruned fast path
+// algo: 0 auto, 1 exhaustive (every pair scored with the canonical arithmetic), 2 MFMA-bounded pruning,
+//       3 noise-prefilter pruning (perturbed scores only).  All return identical bits.
 int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode,
                       const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, int algo,
                       void *workspace, size_t ws_bytes, void *stream) {
@@ -29,18 +30,22 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
     if (row0 < 0 || row1 > N || row0 > row1) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk: bad row range");
     if (noise_mode < 0 || noise_mode > 3) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk: bad noise_mode");
     if (noise_mode == 1 && !G) return dgg_set_error(DGG_ERR_ARG, "explicit noise requested but G is NULL");
+    hipStream_t st = (hipStream_t)stream;
     const bool can_fast = dgg_allpairs_fast_supported(h, noise_mode, K) && workspace &&
                           ws_bytes >= dgg_allpairs_fast_ws_bytes(N, h);
+    const bool can_np = dgg_allpairs_np_supported(h, noise_mode, K) && workspace && ws_bytes >= dgg_allpairs_np_ws_bytes(N);
+    if (algo == 3 || (algo == 0 && can_np && N >= 1024))
+        return dgg_allpairs_topk_np_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
     if (algo == 2 || (algo == 0 && can_fast && N >= 1024))
-        return dgg_allpairs_topk_fast_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes,
-                                           (hipStream_t)stream);
-    return dgg_allpairs_topk_exhaustive_impl(xp, N, h, row0, row1, t, noise_mode, G, ldG, s0, s1, K, idx, val,
-                                             (hipStream_t)stream);
+        return dgg_allpairs_topk_fast_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
+    return dgg_allpairs_topk_exhaustive_impl(xp, N, h, row0, row1, t, noise_mode, G, ldG, s0, s1, K, idx, val, st);
 }
 
 // bytes of workspace the pruned path needs (bf16 copy of xp + discounted norms); 0 when it cannot be used
 size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K) {
-    return dgg_allpairs_fast_supported(h, noise_mode, K) ? dgg_allpairs_fast_ws_bytes(N, h) : 0;
+    size_t a = dgg_allpairs_fast_supported(h, noise_mode, K) ? dgg_allpairs_fast_ws_bytes(N, h) : 0;
+    size_t b = dgg_allpairs_np_supported(h, noise_mode, K) ? dgg_allpairs_np_ws_bytes(N) : 0;
+    return a > b ? a : b;
 }
 
 }  // extern "C"

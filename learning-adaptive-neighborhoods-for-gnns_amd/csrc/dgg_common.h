@@ -162,36 +162,66 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-// 64-lane bitonic sort, descending by key (lane 0 ends with the largest key)
-__device__ __forceinline__ uint64_t wave_sort_desc(uint64_t key, int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            uint64_t other = shfl_xor_u64(key, j);
-            bool up = ((lane & k) == 0);          // this block sorts descending when up
-            bool lower = ((lane & j) == 0);
-            bool take_max = (up == lower);
-            uint64_t mx = key > other ? key : other;
-            uint64_t mn = key > other ? other : key;
-            key = take_max ? mx : mn;
-        }
+// lane ^ D exchange without the LDS crossbar: DPP quad_perm / row shifts / row_ror for D < 16,
+// v_permlane16_swap / v_permlane32_swap (gfx950) for D = 16 / 32.  ~1-3 VALU ops instead of a ds_bpermute round trip.
+template <int D>
+__device__ __forceinline__ uint32_t xor_shfl(uint32_t v, int lane) {
+    if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (D == 4) {
+        int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);                      // row_shl:4 -> banks 0,2
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);                  // row_shr:4 -> banks 1,3
+    } else if constexpr (D == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true); // row_ror:8
+    else if constexpr (D == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    } else {
+        auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (lane & 32) ? r[0] : r[1];
     }
+}
+template <int D>
+__device__ __forceinline__ uint64_t xor_shfl_u64(uint64_t v, int lane) {
+    uint32_t lo = xor_shfl<D>((uint32_t)v, lane), hi = xor_shfl<D>((uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// one compare-exchange stage of the bitonic network: block size KB, distance D; DESC = final order descending
+template <int KB, int D, bool DESC>
+__device__ __forceinline__ uint64_t bitonic_stage(uint64_t key, int lane) {
+    uint64_t other = xor_shfl_u64<D>(key, lane);
+    bool up = ((lane & KB) == 0) || KB == 64;       // this block is sorted in the final direction
+    bool lower = ((lane & D) == 0);
+    bool take_max = DESC ? (up == lower) : (up != lower);
+    bool gt = key > other;
+    return (gt == take_max) ? key : other;
+}
+template <int KB, int D, bool DESC>
+__device__ __forceinline__ uint64_t bitonic_block(uint64_t key, int lane) {
+    key = bitonic_stage<KB, D, DESC>(key, lane);
+    if constexpr (D > 1) key = bitonic_block<KB, D / 2, DESC>(key, lane);
     return key;
 }
-// merge two descending-sorted 64-lane lists, keep the best 64 (descending)
-__device__ __forceinline__ uint64_t wave_merge_top64(uint64_t a, uint64_t b_sorted_desc, int lane) {
-    uint64_t brev = shfl_u64(b_sorted_desc, 63 - lane);   // ascending
-    uint64_t key = a > brev ? a : brev;                     // bitonic sequence holding the 64 largest
-#pragma unroll
-    for (int j = 32; j > 0; j >>= 1) {
-        uint64_t other = shfl_xor_u64(key, j);
-        bool lower = ((lane & j) == 0);
-        uint64_t mx = key > other ? key : other;
-        uint64_t mn = key > other ? other : key;
-        key = lower ? mx : mn;
-    }
+// 64-lane bitonic sort by key; DESC: lane 0 ends with the largest key, else lane 0 the smallest
+template <bool DESC>
+__device__ __forceinline__ uint64_t wave_sort(uint64_t key, int lane) {
+    key = bitonic_block<2, 1, DESC>(key, lane);
+    key = bitonic_block<4, 2, DESC>(key, lane);
+    key = bitonic_block<8, 4, DESC>(key, lane);
+    key = bitonic_block<16, 8, DESC>(key, lane);
+    key = bitonic_block<32, 16, DESC>(key, lane);
+    key = bitonic_block<64, 32, DESC>(key, lane);
     return key;
+}
+__device__ __forceinline__ uint64_t wave_sort_desc(uint64_t key, int lane) { return wave_sort<true>(key, lane); }
+// merge a descending-sorted list with an ASCENDING-sorted candidate vector, keep the best 64 (descending)
+__device__ __forceinline__ uint64_t wave_merge_top64_asc(uint64_t a_desc, uint64_t b_asc, int lane) {
+    uint64_t key = a_desc > b_asc ? a_desc : b_asc;          // bitonic sequence holding the 64 largest
+    return bitonic_block<64, 32, true>(key, lane);
+}
+// convenience: both inputs descending (one crossbar reversal)
+__device__ __forceinline__ uint64_t wave_merge_top64(uint64_t a, uint64_t b_sorted_desc, int lane) {
+    return wave_merge_top64_asc(a, shfl_u64(b_sorted_desc, 63 - lane), lane);
 }
 
 __device__ __forceinline__ float wave_sum_butterfly(float v) {

@@ -10,20 +10,23 @@
 // whose bound reaches the threshold are scored exactly -- with the canonical fp32 arithmetic of dgg_common.h --
 // and merged.  A pair rejected by the bound provably cannot enter the top-64, so the result is bit-identical.
 //
-//   stage A  (every pair, ~8 VALU ops)   perturbed: the 24-bit uniform of the pair's noise against the row's
+//   stage A  (every pair, ~6 VALU ops)   perturbed: the raw 32-bit hash of the pair's noise against the row's
 //                                        integer threshold (score <= G_ij + log(1+1e-8), distance >= 0);
 //                                        unperturbed: bf16-MFMA distance lower bound against the row's radius.
-//   stage B  (pairs passing A)           upper bound  G_ij + log(exp(t*dL_ij) + 1e-8),  dL_ij a rigorous lower
-//                                        bound of the distance from a bf16 MFMA Gram tile:
+//   stage B  (pairs passing A, batched)  survivors are pushed (ballot-compacted, no atomics) into a wave-private
+//                                        LDS ring; every 64 of them are bounded together, one per lane:
+//                                        G_ij + log(exp(t*dL_ij) + 1e-8) with dL_ij a rigorous lower bound of the
+//                                        distance from the bf16 MFMA Gram tile:
 //                                        d2 >= (n_i + n_j)(1 - eps) - 2 <bf16(x_i), bf16(x_j)>,  eps = 2^-8 (1 + slack)
-//   stage C  (pairs passing B)           appended to the row's pending buffer in LDS; when 64 are pending the
-//                                        wavefront scores them exactly, bitonic-sorts and merges them into the
-//                                        row's list, and tightens the thresholds (about log2(N/64) times per row).
+//   stage C  (pairs passing B)           appended to the row's pending list; when 64 are pending the wavefront
+//                                        scores them exactly, bitonic-sorts (DPP network) and merges them into
+//                                        the row's list and tightens the thresholds (~log2(N/64) times per row).
 //
-// Layout: a workgroup (4 wavefronts) owns 128 rows, one wavefront 32 rows.  MFMA orientation D[a][b]: a = column
-// of the tile, b = row, so that a LANE holds ONE ROW (b = lane & 31) and 16 columns: thresholds, row keys and norms
-// are per-lane registers.  Column tiles (bf16, padded rows: conflict-free ds_read_b128) are staged through LDS,
-// double-buffered, one barrier per 64 columns.
+// Decomposition: one wavefront = one workgroup = RBLK blocks of 32 rows; NO workgroup barriers, so a wavefront that
+// stops to flush delays nobody.  MFMA orientation D[a][b]: a = column of the tile, b = row, so a LANE holds ONE ROW
+// (b = lane & 31) and 16 columns: thresholds, row keys and norms are per-lane registers.  Column tiles (32 columns,
+// bf16) are read coalesced from L2 into registers one tile ahead, written to a wave-private padded LDS image
+// (conflict-free ds_read_b128) and read back as MFMA fragments.
 #include "dgg_common.h"
 #include "dgg_api_internal.h"
 
@@ -32,14 +35,26 @@ using namespace dgg;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef DGG_STAMPS   // diagnostic build only: per-section cycle shares (never quote its run time)
+__device__ unsigned long long dgg_stamp_acc[8];
+#define STAMP(slot)                                                          \
+    do {                                                                     \
+        unsigned long long now_ = __builtin_readcyclecounter();              \
+        stamp_loc[slot] += now_ - stamp_t;                                   \
+        stamp_t = now_;                                                      \
+    } while (0)
+#define COUNT(slot, v) stamp_loc[slot] += (v)
+#else
+#define STAMP(slot)
+#define COUNT(slot, v)
+#endif
+
 namespace {
 
-constexpr int WAVES = 4;
-constexpr int RB = 32 * WAVES;     // rows per workgroup
 constexpr int CT = 32;             // columns per MFMA tile
-constexpr int SC = 64;             // columns staged per barrier
-constexpr int CAP = 96;            // pending-candidate slots per row
-constexpr int FLUSH_AT = 64;       // flush a row once this many are pending (a tile adds at most 32)
+constexpr int CAP = 128;           // pending-candidate slots per row (a batch adds at most 64)
+constexpr int FLUSH_AT = 64;       // flush a row once this many are pending
+constexpr int QN = 128;            // stage-B ring entries
 constexpr float EPS_BF16 = 0.0040f;   // 2^-8 (1 + 2^-9) bf16 rounding of both operands + fp32 accumulation slack
 
 // ---- prologue: bf16 copy of the projected features and discounted squared norms ------------------------------
@@ -59,23 +74,23 @@ __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ xp,
     if (lane == 0) nb[j] = s * (1.0f - EPS_BF16);
 }
 
-__device__ __forceinline__ int col_of_reg(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
-
-// exact canonical score of pair (i, j); xi is wave-uniform
+// exact canonical score of pair (i, j); i is wave-uniform (its features come through the scalar cache)
 template <int H>
 __device__ __forceinline__ float exact_score(const float *__restrict__ xp, int64_t i, int32_t j, float t, int noise_mode,
                                              uint32_t s0, uint32_t s1) {
     const float *xi = xp + i * H;
     const float4 *xj = reinterpret_cast<const float4 *>(xp + (int64_t)j * H);
+    float4 b[H / 4];
+#pragma unroll
+    for (int c4 = 0; c4 < H / 4; c4++) b[c4] = xj[c4];          // every gather in flight before the chain starts
     float d2 = 0.0f;
-#pragma unroll 4
+#pragma unroll
     for (int c4 = 0; c4 < H / 4; c4++) {
-        float4 b = xj[c4];
         float df;
-        df = __fadd_rn(xi[4 * c4 + 0], -b.x); d2 = __fmaf_rn(df, df, d2);
-        df = __fadd_rn(xi[4 * c4 + 1], -b.y); d2 = __fmaf_rn(df, df, d2);
-        df = __fadd_rn(xi[4 * c4 + 2], -b.z); d2 = __fmaf_rn(df, df, d2);
-        df = __fadd_rn(xi[4 * c4 + 3], -b.w); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[4 * c4 + 0], -b[c4].x); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[4 * c4 + 1], -b[c4].y); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[4 * c4 + 2], -b[c4].z); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[4 * c4 + 3], -b[c4].w); d2 = __fmaf_rn(df, df, d2);
     }
     float dist = c_sqrt(d2);
     float g = 0.0f;
@@ -108,234 +123,297 @@ __device__ __forceinline__ RowThr thresholds_from_score(float pp63, float t, boo
     return r;
 }
 
-// score exactly and merge the pending candidates of local row lr (whole wavefront cooperates)
-template <int H>
-__device__ __forceinline__ void flush_row(const float *__restrict__ xp, int64_t i, int64_t out_row, int lr, int lane,
-                                          int *pend, int *cnt, uint32_t *thrA, float *thrB, float t, int noise_mode,
-                                          uint32_t s0, uint32_t s1, int32_t *__restrict__ idx, float *__restrict__ val) {
-    const int n = __builtin_amdgcn_readfirstlane(cnt[lr]);
-    int32_t li = idx[out_row * 64 + lane];
-    float lv = val[out_row * 64 + lane];
-    uint64_t list = li >= 0 ? make_key(lv, li) : DGG_EMPTY_KEY;
-    for (int base = 0; base < n; base += 64) {
-        int e = base + lane;
-        int32_t j = e < n ? pend[lr * CAP + e] : -1;
-        uint64_t key = DGG_EMPTY_KEY;
-        if (j >= 0) key = make_key(exact_score<H>(xp, i, j, t, noise_mode, s0, s1), j);
-        key = wave_sort_desc(key, lane);
-        list = wave_merge_top64(list, key, lane);
-    }
-    bool empty = list == DGG_EMPTY_KEY;
-    idx[out_row * 64 + lane] = empty ? -1 : key_col(list);
-    val[out_row * 64 + lane] = empty ? 0.0f : key_val(list);
-    uint64_t k63 = shfl_u64(list, 63);
-    if (lane == 0) {
-        cnt[lr] = 0;
-        if (k63 != DGG_EMPTY_KEY) {
-            RowThr th = thresholds_from_score(key_val(k63), t, noise_mode != 0);
-            thrA[lr] = th.a;
-            thrB[lr] = th.b;
-        }
-    }
+// upper bound of the perturbed log-score of a pair from the bf16 Gram value and the raw hash
+__device__ __forceinline__ float score_upper_bound(float dot, float ni, float nj, uint32_t x, float t, bool zero_noise) {
+    float L2 = __fmaf_rn(-2.0f, dot, ni + nj);
+    float dL = __fsqrt_rn(fmaxf(L2, 0.0f));
+    float lpub = __logf(__expf(t * dL) + 1e-8f);
+    // -log(U), U = u24 2^-24: series near 1, where the hardware log is inexact
+    uint32_t u24 = x >> 8;
+    u24 = u24 == 0 ? 1u : u24;
+    float epsu = (float)(16777216u - u24) * 5.9604644775390625e-8f;
+    float ser = epsu * (1.0f + epsu * (0.5f + epsu * (0.33333334f + 0.25f * epsu)));
+    float nl = epsu < 0.015625f ? ser : -__logf((float)u24 * 5.9604644775390625e-8f);
+    float G = zero_noise ? 0.0f : -0.3f * __logf(nl);
+    return lpub + G + (3e-5f + 2e-5f * fabsf(lpub));
 }
 
-template <int H, int NOISE>   // NOISE: 0 none, 2 hash, 3 symmetric hash
-__global__ __launch_bounds__(WAVES * 64, 2) void allpairs_topk_fast(
-    const float *__restrict__ xp, const __bf16 *__restrict__ xb, const float *__restrict__ nb, int64_t N, int64_t row0,
-    int64_t row1, float t, uint32_t s0, uint32_t s1, int32_t *__restrict__ idx, float *__restrict__ val) {
-    constexpr int KS = H / 16;                 // MFMA k-steps
-    constexpr int STRIDE = H * 2 + 16;         // bytes per staged column (padded)
-    constexpr int CHUNKS = SC * H * 2 / 16;    // 16-byte pieces per stage
-    constexpr int CPT = (CHUNKS + WAVES * 64 - 1) / (WAVES * 64);
-    __shared__ __attribute__((aligned(16))) unsigned char colA[2][SC * STRIDE];
-    __shared__ float nbt[2][SC];
-    __shared__ int pend[RB * CAP];
-    __shared__ int cnt[RB];
-    __shared__ uint32_t thrA[RB];
-    __shared__ float thrB[RB];
+template <int H, int NOISE, int RBLK>   // NOISE: 0 none, 2 hash, 3 symmetric hash
+__global__ __launch_bounds__(64) void allpairs_topk_fast(
+    const float *__restrict__ xp, const __bf16 *__restrict__ xb, const float *__restrict__ nb, int *__restrict__ pend_g,
+    int64_t N, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1, int32_t *__restrict__ idx,
+    float *__restrict__ val) {
+    constexpr int KS = H / 16;                 // MFMA k-steps == 16-byte chunks per lane per tile
+    constexpr int STRIDE = H * 2 + 16;         // bytes per staged column (padded: conflict-free ds_read_b128)
+    constexpr int RW = 32 * RBLK;              // rows per wavefront
+    __shared__ __attribute__((aligned(16))) unsigned char colA[CT * STRIDE];
+    __shared__ __attribute__((aligned(16))) float nbt[CT];
+    __shared__ int cnt[RW];
+    __shared__ float row_nb[RW];               // discounted norms / log-thresholds of the wave's rows, readable by any lane
+    __shared__ float row_tb[RW];
+    __shared__ uint32_t qj[QN], qx[QN], ql[QN];
+    __shared__ float qa[QN];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x;
     const int r = lane & 31, hh = lane >> 5;
-    const int lr = wave * 32 + r;                               // local row of this lane
-    const int64_t rbase = row0 + (int64_t)blockIdx.x * RB;
-    const int64_t i = rbase + lr;
-    const bool rvalid = i < row1;
-    const int64_t iv = rvalid ? i : row1 - 1;                   // clamp loads of invalid rows
+    const int64_t rbase = row0 + (int64_t)blockIdx.x * RW;
+    int *pend = pend_g + (int64_t)blockIdx.x * RW * CAP;
 
-    // per-row state
-    if (tid < RB) {
-        cnt[tid] = 0;
-        thrA[tid] = NOISE == 0 ? __float_as_uint(3.0e38f) : 0u;   // accept everything until 64 candidates are known
-        thrB[tid] = -3.0e38f;
+    bf16x8 bfr[RBLK][KS];
+    float nbi[RBLK];
+    uint32_t k1[RBLK], k2[RBLK], ta[RBLK];
+    bool rvalid[RBLK];
+    int64_t iv[RBLK];
+#pragma unroll
+    for (int b = 0; b < RBLK; b++) {
+        const int64_t i = rbase + b * 32 + r;
+        rvalid[b] = i < row1;
+        iv[b] = rvalid[b] ? i : row1 - 1;
+#pragma unroll
+        for (int s = 0; s < KS; s++) bfr[b][s] = *reinterpret_cast<const bf16x8 *>(xb + iv[b] * H + 16 * s + 8 * hh);
+        nbi[b] = nb[iv[b]];
+        k1[b] = k2[b] = 0;
+        if (NOISE == 2) rowkey(s0, s1, (uint32_t)iv[b], k1[b], k2[b]);
+        ta[b] = NOISE == 0 ? __float_as_uint(3.0e38f) : 0u;      // accept everything until 64 candidates are known
+        if (!rvalid[b]) ta[b] = NOISE == 0 ? __float_as_uint(-1.0f) : 0xffffffffu;
+        if (hh == 0) { row_nb[b * 32 + r] = nbi[b]; row_tb[b * 32 + r] = rvalid[b] ? -3.0e38f : 3.0e38f; }
     }
-    for (int e = tid; e < RB * 64; e += WAVES * 64) {
+    for (int e = lane; e < RW; e += 64) cnt[e] = 0;
+    for (int e = lane; e < RW * 64; e += 64) {
         int64_t gi = rbase + (e >> 6);
         if (gi < row1) { idx[(gi - row0) * 64 + (e & 63)] = -1; val[(gi - row0) * 64 + (e & 63)] = 0.0f; }
     }
-    // B operand (rows): lane holds xb[row][16s + 8hh .. +8) for every k-step
-    bf16x8 bfr[KS];
-#pragma unroll
-    for (int s = 0; s < KS; s++) bfr[s] = *reinterpret_cast<const bf16x8 *>(xb + iv * H + 16 * s + 8 * hh);
-    const float nbi = nb[iv];
-    uint32_t k1 = 0, k2 = 0;
-    if (NOISE == 2) rowkey(s0, s1, (uint32_t)iv, k1, k2);
+    int qhead = 0, qtail = 0;                  // wave-uniform ring indices (monotone; slot = index & (QN-1))
 
-    // staging registers
-    uint4 stg[CPT];
+    uint4 stg[KS];
     float stg_nb = 0.0f;
-    auto stage_load = [&](int64_t c0) {
+    auto tile_load = [&](int64_t c0) {
 #pragma unroll
-        for (int q = 0; q < CPT; q++) {
-            int ch = tid + q * WAVES * 64;
-            int jj = ch / (H / 8), part = ch % (H / 8);
-            int64_t gj = c0 + jj;
+        for (int q = 0; q < KS; q++) {
+            int ch = q * 64 + lane;
+            int64_t gj = c0 + ch / (H / 8);
             stg[q] = make_uint4(0, 0, 0, 0);
-            if (ch < CHUNKS && gj < N) stg[q] = *reinterpret_cast<const uint4 *>(xb + gj * H + part * 8);
+            if (gj < N) stg[q] = *reinterpret_cast<const uint4 *>(xb + c0 * H + (int64_t)ch * 8);
         }
-        if (tid < SC) stg_nb = (c0 + tid < N) ? nb[c0 + tid] : 3.0e38f;
+        if (NOISE == 0 && lane < CT) stg_nb = (c0 + lane < N) ? nb[c0 + lane] : 3.0e38f;
     };
-    auto stage_store = [&](int buf) {
+    auto tile_store = [&]() {
 #pragma unroll
-        for (int q = 0; q < CPT; q++) {
-            int ch = tid + q * WAVES * 64;
+        for (int q = 0; q < KS; q++) {
+            int ch = q * 64 + lane;
             int jj = ch / (H / 8), part = ch % (H / 8);
-            if (ch < CHUNKS) *reinterpret_cast<uint4 *>(&colA[buf][jj * STRIDE + part * 16]) = stg[q];
+            *reinterpret_cast<uint4 *>(&colA[jj * STRIDE + part * 16]) = stg[q];
         }
-        if (tid < SC) nbt[buf][tid] = stg_nb;
+        if (NOISE == 0 && lane < CT) nbt[lane] = stg_nb;
     };
 
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
+#ifdef DGG_STAMPS
+    unsigned long long stamp_loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = __builtin_readcyclecounter();
+#endif
 
-    const int nstages = (int)((N + SC - 1) / SC);
-    for (int st = 0; st < nstages; st++) {
-        const int buf = st & 1;
-        const int64_t c0 = (int64_t)st * SC;
-        if (st + 1 < nstages) stage_load(c0 + SC);
+    // exact scoring + merge of the pending candidates of local row flr (whole wavefront cooperates)
+    auto do_flush = [&](int flr) {
+        const int64_t fi = rbase + flr;                       // wave-uniform
+        const int64_t out_row = fi - row0;
+        const int n = __builtin_amdgcn_readfirstlane(cnt[flr]);
+        int32_t li = idx[out_row * 64 + lane];
+        float lv = val[out_row * 64 + lane];
+        uint64_t list = li >= 0 ? make_key(lv, li) : DGG_EMPTY_KEY;
+        for (int base = 0; base < n; base += 64) {
+            int e = base + lane;
+            int32_t j = e < n ? pend[flr * CAP + e] : -1;
+            uint64_t key = DGG_EMPTY_KEY;
+            if (j >= 0) key = make_key(exact_score<H>(xp, fi, j, t, NOISE, s0, s1), j);
+            key = wave_sort<false>(key, lane);                // ascending: merges without a reversal
+            list = wave_merge_top64_asc(list, key, lane);
+        }
+        bool empty = list == DGG_EMPTY_KEY;
+        idx[out_row * 64 + lane] = empty ? -1 : key_col(list);
+        val[out_row * 64 + lane] = empty ? 0.0f : key_val(list);
+        uint64_t k63 = shfl_u64(list, 63);
+        if (lane == 0) cnt[flr] = 0;
+        if (k63 != DGG_EMPTY_KEY) {                           // uniform
+            RowThr th = thresholds_from_score(key_val(k63), t, NOISE != 0);
 #pragma unroll
-        for (int tile = 0; tile < SC / CT; tile++) {
-            const int64_t cb = c0 + tile * CT;
-            if (cb >= N) break;                                  // uniform
+            for (int b = 0; b < RBLK; b++)
+                if (flr == b * 32 + r) ta[b] = th.a;
+            if (lane == 0) row_tb[flr] = th.b;
+        }
+        COUNT(5, 1);
+    };
+    auto flush_ready = [&](int threshold) {
+#pragma unroll
+        for (int b = 0; b < RBLK; b++) {
+            int mycnt = cnt[b * 32 + r];
+            uint64_t need = __ballot(mycnt >= threshold && rvalid[b]) & 0xffffffffull;
+            while (need) {
+                int rr = __builtin_ctzll(need);
+                need &= need - 1;
+                do_flush(b * 32 + rr);
+            }
+        }
+    };
+    // stage B on up to 64 queued survivors, one per lane
+    auto drain = [&]() {
+        const int n = qtail - qhead;                          // uniform, 1..64 used
+        const int e = (qhead + lane) & (QN - 1);
+        const bool live = lane < n;
+        uint32_t j = qj[e], x = qx[e], lr = ql[e];
+        float dot = qa[e];
+        qhead += n < 64 ? n : 64;
+        if (live) {
+            float nj = nb[j];
+            float yub = score_upper_bound(dot, row_nb[lr], nj, x, t, NOISE == 3 && (int64_t)j == rbase + lr);
+            if (yub >= row_tb[lr]) {
+                int slot = atomicAdd(&cnt[lr], 1);
+                pend[lr * CAP + slot] = (int)j;
+            }
+        }
+        COUNT(4, 1);
+        flush_ready(FLUSH_AT);
+    };
+
+    tile_load(0);
+    const int ntiles = (int)((N + CT - 1) / CT);
+    for (int tl = 0; tl < ntiles; tl++) {
+        const int64_t cb = (int64_t)tl * CT;
+        __syncthreads();                      // single-wave workgroup: orders the LDS image (previous reads done)
+        tile_store();
+        __syncthreads();
+        if (tl + 1 < ntiles) tile_load(cb + CT);
+        bf16x8 af[KS];
+#pragma unroll
+        for (int s = 0; s < KS; s++) af[s] = *reinterpret_cast<const bf16x8 *>(&colA[r * STRIDE + (16 * s + 8 * hh) * 2]);
+        const uint32_t jbase = (uint32_t)cb | (uint32_t)(4 * hh);
+        const bool tail_tile = cb + CT > N;   // uniform: some columns of this tile do not exist
+#pragma unroll
+        for (int b = 0; b < RBLK; b++) {
             f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 16; q++) acc[q] = 0.0f;
 #pragma unroll
-            for (int s = 0; s < KS; s++) {
-                bf16x8 af = *reinterpret_cast<const bf16x8 *>(&colA[buf][(tile * CT + r) * STRIDE + (16 * s + 8 * hh) * 2]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[s], acc, 0, 0, 0);
-            }
-            const uint32_t ta = rvalid ? thrA[lr] : (NOISE == 0 ? 0u : 0xffffffffu);
-            const float tb = thrB[lr];
-            const int jb = (int)cb + 4 * hh;
+            for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bfr[b][s], acc, 0, 0, 0);
+            const int lr = b * 32 + r;
+            STAMP(0);
             if (NOISE == 0) {
-                // stage A == stage B: distance lower bound against the row's radius
-                const float rad2 = __uint_as_float(ta);
+                const float rad2 = __uint_as_float(ta[b]);
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int a = (q & 3) + 8 * (q >> 2);
-                    float nj = nbt[buf][tile * CT + a + 4 * hh];
-                    float L2 = __fmaf_rn(-2.0f, acc[q], nbi + nj);
-                    bool pass = rvalid && (L2 <= rad2);
-                    if (pass) {
-                        int slot = atomicAdd(&cnt[lr], 1);
-                        pend[lr * CAP + slot] = jb + a;
-                    }
-                }
-            } else {
-                uint32_t xs[16];
-                uint32_t mask = 0;
+                for (int g4 = 0; g4 < 4; g4++) {
+                    float4 nj4 = *reinterpret_cast<const float4 *>(&nbt[8 * g4 + 4 * hh]);
+                    float njs[4] = {nj4.x, nj4.y, nj4.z, nj4.w};
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int a = (q & 3) + 8 * (q >> 2);
-                    const uint32_t j = (uint32_t)(jb + a);
-                    uint32_t x;
-                    if (NOISE == 2) {
-                        x = j ^ k1;
-                        x *= 0x7feb352dU; x ^= x >> 15; x += k2; x *= 0x846ca68bU;
-                    } else {
-                        x = pair_u24(s0, s1, (uint32_t)iv, j, true) << 8;
-                        if (j == (uint32_t)iv) x = 0xffffffffu;             // zero-noise diagonal: decide in stage B
-                    }
-                    xs[q] = x;
-                    mask |= (x >= ta ? 1u : 0u) << q;
-                }
-                if (__ballot(mask != 0) != 0ull) {
-#pragma unroll
-                    for (int q = 0; q < 16; q++) {
-                        const bool pa = (mask >> q) & 1u;
-                        if (__ballot(pa) == 0ull) continue;                  // wave-uniform
-                        const int a = (q & 3) + 8 * (q >> 2);
-                        const int j = jb + a;
-                        float nj = nbt[buf][tile * CT + a + 4 * hh];
-                        float L2 = __fmaf_rn(-2.0f, acc[q], nbi + nj);
-                        float dL = __fsqrt_rn(fmaxf(L2, 0.0f));
-                        float lpub = __logf(__expf(t * dL) + 1e-8f);
-                        // noise upper estimate: -log(U), U = u24 2^-24; series near 1 (hardware log is inexact there)
-                        uint32_t u24 = xs[q] >> 8;
-                        u24 = u24 == 0 ? 1u : u24;
-                        float epsu = (float)(16777216u - u24) * 5.9604644775390625e-8f;
-                        float ser = epsu * (1.0f + epsu * (0.5f + epsu * (0.33333334f + 0.25f * epsu)));
-                        float nl = epsu < 0.015625f ? ser : -__logf((float)u24 * 5.9604644775390625e-8f);
-                        float G = -0.3f * __logf(nl);
-                        if (NOISE == 3 && j == (int)iv) G = 0.0f;
-                        float yub = lpub + G + (3e-5f + 2e-5f * fabsf(lpub));
-                        bool pass = pa && rvalid && (yub >= tb) && (j < N);
-                        if (pass) {
+                    for (int u = 0; u < 4; u++) {
+                        const int q = 4 * g4 + u;
+                        float L2 = __fmaf_rn(-2.0f, acc[q], nbi[b] + njs[u]);
+                        if (L2 <= rad2) {
                             int slot = atomicAdd(&cnt[lr], 1);
-                            pend[lr * CAP + slot] = j;
+                            pend[lr * CAP + slot] = (int)(jbase + (uint32_t)(8 * g4 + u));
                         }
                     }
                 }
-            }
-            // flush rows of this wavefront whose buffer could overflow on the next tile
-            int mycnt = cnt[lr];
-            uint64_t need = __ballot(mycnt >= FLUSH_AT) & 0xffffffffull;
-            while (need) {
-                int rr = __builtin_ctzll(need);
-                need &= need - 1;
-                int flr = wave * 32 + rr;
-                int64_t fi = rbase + flr;
-                flush_row<H>(xp, fi, fi - row0, flr, lane, pend, cnt, thrA, thrB, t, NOISE, s0, s1, idx, val);
+                STAMP(1);
+                flush_ready(FLUSH_AT);
+                STAMP(3);
+            } else {
+                const uint32_t base = jbase ^ k1[b];
+                unsigned long long pm[16];
+                unsigned long long anym = 0ull;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const uint32_t a = (uint32_t)((q & 3) + 8 * (q >> 2));
+                    uint32_t x;
+                    if (NOISE == 2) {
+                        x = base ^ a;
+                        x *= 0x7feb352dU; x ^= x >> 15; x += k2[b]; x *= 0x846ca68bU;
+                    } else {
+                        const uint32_t j = jbase + a;
+                        x = pair_u24(s0, s1, (uint32_t)iv[b], j, true) << 8;
+                        if (j == (uint32_t)iv[b]) x = 0xffffffffu;          // zero-noise diagonal: decided in stage B
+                    }
+                    bool pa = x >= ta[b];
+                    if (tail_tile) pa = pa && ((int64_t)(jbase + a) < N);
+                    pm[q] = __ballot(pa);
+                    anym |= pm[q];
+                }
+                STAMP(1);
+                if (anym != 0ull) {
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const unsigned long long m = pm[q];
+                        if (m == 0ull) continue;                             // wave-uniform
+                        const uint32_t a = (uint32_t)((q & 3) + 8 * (q >> 2));
+                        const uint32_t j = jbase + a;
+                        if ((m >> lane) & 1ull) {
+                            uint32_t x;
+                            if (NOISE == 2) {
+                                x = base ^ a;
+                                x *= 0x7feb352dU; x ^= x >> 15; x += k2[b]; x *= 0x846ca68bU;
+                            } else {
+                                x = pair_u24(s0, s1, (uint32_t)iv[b], j, true) << 8;
+                            }
+                            const int pos = (qtail + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & (QN - 1);
+                            qj[pos] = j; qx[pos] = x; ql[pos] = (uint32_t)lr; qa[pos] = acc[q];
+                        }
+                        qtail += __builtin_popcountll(m);
+                        if (qtail - qhead >= 64) { STAMP(2); drain(); STAMP(3); }
+                    }
+                }
+                STAMP(2);
             }
         }
-        if (st + 1 < nstages) stage_store(buf ^ 1);
-        __syncthreads();
     }
-    // final flush of everything still pending
-    {
-        int mycnt = cnt[lr];
-        uint64_t need = __ballot(mycnt > 0 && rvalid) & 0xffffffffull;
-        while (need) {
-            int rr = __builtin_ctzll(need);
-            need &= need - 1;
-            int flr = wave * 32 + rr;
-            int64_t fi = rbase + flr;
-            flush_row<H>(xp, fi, fi - row0, flr, lane, pend, cnt, thrA, thrB, t, NOISE, s0, s1, idx, val);
-        }
+    // drain the ring, then flush everything still pending
+    if (NOISE != 0) {
+        while (qtail != qhead) drain();
     }
+    flush_ready(1);
+#ifdef DGG_STAMPS
+    STAMP(3);
+    if (lane == 0)
+        for (int q = 0; q < 8; q++) atomicAdd(&dgg_stamp_acc[q], stamp_loc[q]);
+#endif
 }
+
+constexpr int RBLK_DEFAULT = 2;
 
 template <int H>
 int launch_fast(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, int noise_mode, uint32_t s0, uint32_t s1,
                 int32_t *idx, float *val, void *ws, hipStream_t st) {
+    constexpr int RBLK = RBLK_DEFAULT;
     __bf16 *xb = reinterpret_cast<__bf16 *>(ws);
-    float *nb = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + (((size_t)N * H * 2 + 255) / 256) * 256);
+    size_t off = (((size_t)N * H * 2 + 255) / 256) * 256;
+    float *nb = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + off);
+    off += (((size_t)N * 4 + 255) / 256) * 256;
+    int *pend = reinterpret_cast<int *>(reinterpret_cast<char *>(ws) + off);
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, xp, N, H, xb, nb);
-    dim3 grid((unsigned)((row1 - row0 + RB - 1) / RB));
+    dim3 grid((unsigned)((row1 - row0 + 32 * RBLK - 1) / (32 * RBLK)));
     if (noise_mode == 0)
-        hipLaunchKernelGGL((allpairs_topk_fast<H, 0>), grid, dim3(WAVES * 64), 0, st, xp, xb, nb, N, row0, row1, t, s0, s1, idx, val);
+        hipLaunchKernelGGL((allpairs_topk_fast<H, 0, RBLK>), grid, dim3(64), 0, st, xp, xb, nb, pend, N, row0, row1, t, s0, s1, idx, val);
     else if (noise_mode == 2)
-        hipLaunchKernelGGL((allpairs_topk_fast<H, 2>), grid, dim3(WAVES * 64), 0, st, xp, xb, nb, N, row0, row1, t, s0, s1, idx, val);
+        hipLaunchKernelGGL((allpairs_topk_fast<H, 2, RBLK>), grid, dim3(64), 0, st, xp, xb, nb, pend, N, row0, row1, t, s0, s1, idx, val);
     else
-        hipLaunchKernelGGL((allpairs_topk_fast<H, 3>), grid, dim3(WAVES * 64), 0, st, xp, xb, nb, N, row0, row1, t, s0, s1, idx, val);
+        hipLaunchKernelGGL((allpairs_topk_fast<H, 3, RBLK>), grid, dim3(64), 0, st, xp, xb, nb, pend, N, row0, row1, t, s0, s1, idx, val);
     return dgg_check_launch("allpairs_topk_fast");
 }
 
 }  // namespace
 
+#ifdef DGG_STAMPS
+extern "C" int dgg_debug_read_stamps(unsigned long long *out8, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(dgg_stamp_acc), 64);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(dgg_stamp_acc), z, 64);
+    }
+    return e == hipSuccess ? 0 : 3;
+}
+#endif
+
 size_t dgg_allpairs_fast_ws_bytes(int64_t N, int h) {
-    return (((size_t)N * h * 2 + 255) / 256) * 256 + (size_t)N * 4;
+    size_t rows = ((size_t)N + 63) / 64 * 64;
+    return (((size_t)N * h * 2 + 255) / 256) * 256 + (((size_t)N * 4 + 255) / 256) * 256 + rows * CAP * 4;
 }
 
 bool dgg_allpairs_fast_supported(int h, int noise_mode, int K) {
