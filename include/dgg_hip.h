@@ -111,9 +111,11 @@ int dgg_ell_normalize_fwd(const int32_t *idx, const float *w, const float *rs, i
 /* Y[N,F] = A X   (torch.mm(adj, x) model.py:594, 67; torch.spmm model.py:34); X has GLOBAL rows */
 int dgg_ell_spmm_fwd(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, float *Y,
                      void *stream);
-/* dA_ir = <dY_i, X_j> (overwritten); dX_j += ahat_ir dY_i (nullable; accumulated with fp32 atomics) */
+/* dA_ir = <dY_i, X_j> (overwritten); dX_j += ahat_ir dY_i (nullable; accumulated with fp32 atomics).
+ * skip_zero != 0: entries whose value is exactly 0 get dA = 0 without the dot product (valid when the adjacency
+ * comes from dgg_softk_fwd: a zero weight is a saturated ramp, whose gradient is zero as well) */
 int dgg_ell_spmm_bwd(const int32_t *idx, const float *ahat, const float *X, const float *dY, int64_t N, int K, int F,
-                     float *dA, float *dX, void *stream);
+                     int skip_zero, float *dA, float *dX, void *stream);
 /* normalisation backward, phase 1: da (GLOBAL length, zeroed by caller) += d loss / d rs^-1/2 */
 int dgg_norm_bwd_da(const int32_t *idx, const float *w, const float *rs, const float *dA, int64_t N, int K, int64_t row0,
                     float *da, void *stream);

@@ -24,7 +24,7 @@ PROTOTYPES = {
     "dgg_softk_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
     "dgg_ell_normalize_fwd": [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp],
     "dgg_ell_spmm_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp],
-    "dgg_ell_spmm_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
+    "dgg_ell_spmm_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
     "dgg_norm_bwd_da": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp],
     "dgg_softk_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _vp],
     "dgg_edge_bwd": [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _vp],

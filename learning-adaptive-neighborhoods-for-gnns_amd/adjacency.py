@@ -66,7 +66,8 @@ class EllAdjacency:
 
     def matmul(self, X):
         """A @ X (torch.mm(adj, x), model.py:594)."""
-        return ops.EllSpmmFn.apply(self._values, self.idx, X)
+        # weights produced by the DGG ramp: an exact zero is a saturated ramp whose gradient vanishes too
+        return ops.EllSpmmFn.apply(self._values, self.idx, X, self.k is not None)
 
     __matmul__ = matmul
 

@@ -224,6 +224,17 @@ __device__ __forceinline__ uint64_t wave_merge_top64(uint64_t a, uint64_t b_sort
     return wave_merge_top64_asc(a, shfl_u64(b_sorted_desc, 63 - lane), lane);
 }
 
+// order-insensitive 64-lane sum on the DPP / permlane network (no LDS crossbar); every lane gets the total
+__device__ __forceinline__ float wave_sum_dpp(float v, int lane) {
+    v += __uint_as_float(xor_shfl<32>(__float_as_uint(v), lane));
+    v += __uint_as_float(xor_shfl<16>(__float_as_uint(v), lane));
+    v += __uint_as_float(xor_shfl<8>(__float_as_uint(v), lane));
+    v += __uint_as_float(xor_shfl<4>(__float_as_uint(v), lane));
+    v += __uint_as_float(xor_shfl<2>(__float_as_uint(v), lane));
+    v += __uint_as_float(xor_shfl<1>(__float_as_uint(v), lane));
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum_butterfly(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off, 64));

@@ -94,26 +94,48 @@ __global__ __launch_bounds__(WPB * 64) void spmm_fwd_kernel(const int32_t *__res
 // dA_ir = <dY_i, X_j>;  dX_j += ahat_ir * dY_i (fp32 atomics, optional).  One wavefront per row, features on lanes.
 __global__ __launch_bounds__(WPB * 64) void spmm_bwd_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
                                                            const float *__restrict__ X, const float *__restrict__ dY,
-                                                           int64_t N, int K, int F, float *__restrict__ dA,
-                                                           float *__restrict__ dX) {
+                                                           int64_t N, int K, int F, int skip_zero,
+                                                           float *__restrict__ dA, float *__restrict__ dX) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     if (i >= N) return;
     int32_t jl = lane < K ? idx[i * K + lane] : -1;
     float al = lane < K ? ahat[i * K + lane] : 0.0f;
     float mine = 0.0f;
+    // the row's cotangent stays in registers (F <= 256) instead of being re-read for every neighbour
+    const bool small = F <= 256;
+    float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
+    if (small) {
+        if (lane < F) g0 = dY[i * F + lane];
+        if (lane + 64 < F) g1 = dY[i * F + lane + 64];
+        if (lane + 128 < F) g2 = dY[i * F + lane + 128];
+        if (lane + 192 < F) g3 = dY[i * F + lane + 192];
+    }
     for (int r = 0; r < K; r++) {
         int32_t j = __shfl(jl, r, 64);
         float a = __shfl(al, r, 64);
-        if (j < 0) continue;
+        if (j < 0 || (skip_zero && a == 0.0f)) continue;       // wave-uniform
         float part = 0.0f;
-        for (int c = lane; c < F; c += 64) {
-            float g = dY[i * F + c];
-            part = fmaf(g, X[(int64_t)j * F + c], part);
-            if (dX && a != 0.0f) atomicAdd(dX + (int64_t)j * F + c, a * g);
+        const float *xr = X + (int64_t)j * F;
+        if (small) {
+            if (lane < F) part = fmaf(g0, xr[lane], part);
+            if (lane + 64 < F) part = fmaf(g1, xr[lane + 64], part);
+            if (lane + 128 < F) part = fmaf(g2, xr[lane + 128], part);
+            if (lane + 192 < F) part = fmaf(g3, xr[lane + 192], part);
+            if (dX && a != 0.0f) {
+                if (lane < F) atomicAdd(dX + (int64_t)j * F + lane, a * g0);
+                if (lane + 64 < F) atomicAdd(dX + (int64_t)j * F + lane + 64, a * g1);
+                if (lane + 128 < F) atomicAdd(dX + (int64_t)j * F + lane + 128, a * g2);
+                if (lane + 192 < F) atomicAdd(dX + (int64_t)j * F + lane + 192, a * g3);
+            }
+        } else {
+            for (int c = lane; c < F; c += 64) {
+                float g = dY[i * F + c];
+                part = fmaf(g, xr[c], part);
+                if (dX && a != 0.0f) atomicAdd(dX + (int64_t)j * F + c, a * g);
+            }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+        part = wave_sum_dpp(part, lane);
         if (lane == r) mine = part;
     }
     if (lane < K) dA[i * K + lane] = mine;
@@ -265,11 +287,11 @@ int dgg_ell_spmm_fwd(const int32_t *idx, const float *ahat, const float *X, int6
 
 // dA [N,K] overwritten; dX (nullable, [Nglobal,F]) accumulated into with atomics
 int dgg_ell_spmm_bwd(const int32_t *idx, const float *ahat, const float *X, const float *dY, int64_t N, int K, int F,
-                     float *dA, float *dX, void *stream) {
+                     int skip_zero, float *dA, float *dX, void *stream) {
     if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
     if (N == 0) return 0;
     hipLaunchKernelGGL(spmm_bwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, idx, ahat, X, dY, N, K,
-                       F, dA, dX);
+                       F, skip_zero, dA, dX);
     return dgg_check_launch("ell_spmm_bwd");
 }
 

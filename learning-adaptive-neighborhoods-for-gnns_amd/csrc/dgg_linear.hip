@@ -107,7 +107,7 @@ __global__ void act_bwd_kernel(const float *__restrict__ y, const float *__restr
 // C[M1,M2] += A[N,M1]^T * B[N,M2]   (weight gradient: reduction over the node dimension; fp32 atomics)
 // grid: x = row chunks of RCH rows, y = M1 blocks of 128, z = M2 blocks of 128.
 // c_layout 0: C[M1][M2] row-major; 1: C stored transposed C[M2][M1].  colsum (optional, M1 floats) += column sums of A.
-constexpr int RCH = 1024;
+constexpr int RCH = 256;   // rows per workgroup: N/256 workgroups keep all 256 CUs busy at N = 100k
 __global__ __launch_bounds__(256) void gemm_tn_reduce_mfma(const float *__restrict__ A, const float *__restrict__ B,
                                                            int64_t N, int M1, int M2, float *__restrict__ Cout,
                                                            int c_layout, float *__restrict__ colsum) {

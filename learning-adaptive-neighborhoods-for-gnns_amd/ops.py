@@ -145,13 +145,13 @@ def spmm_fwd(idx, ahat, X):
     return Y
 
 
-def spmm_bwd(idx, ahat, X, dY, need_dx=True):
+def spmm_bwd(idx, ahat, X, dY, need_dx=True, skip_zero=False):
     N, K = idx.shape
     X, dY = _chk(X), _chk(dY)
     F = X.shape[1]
     dA = torch.empty((N, K), device=idx.device, dtype=torch.float32)
     dX = torch.zeros_like(X) if need_dx else None
-    _lib.check(_lib.lib().dgg_ell_spmm_bwd(_ptr(idx), _ptr(_chk(ahat)), _ptr(X), _ptr(dY), N, K, F, _ptr(dA), _ptr(dX), _stream()), "ell_spmm_bwd")
+    _lib.check(_lib.lib().dgg_ell_spmm_bwd(_ptr(idx), _ptr(_chk(ahat)), _ptr(X), _ptr(dY), N, K, F, int(skip_zero), _ptr(dA), _ptr(dX), _stream()), "ell_spmm_bwd")
     return dA, dX
 
 
@@ -270,13 +270,14 @@ class EllSpmmFn(torch.autograd.Function):
     """Y = A X on the ELL adjacency (torch.mm(adj, x) model.py:594, 67 / torch.spmm model.py:34)."""
 
     @staticmethod
-    def forward(ctx, ahat, idx, X):
+    def forward(ctx, ahat, idx, X, skip_zero=False):
         Y = spmm_fwd(idx, ahat, X)
         ctx.save_for_backward(ahat, idx, X)
+        ctx.skip_zero = skip_zero
         return Y
 
     @staticmethod
     def backward(ctx, dY):
         ahat, idx, X = ctx.saved_tensors
-        dA, dX = spmm_bwd(idx, ahat, X, dY.contiguous(), need_dx=ctx.needs_input_grad[2])
-        return dA, None, dX
+        dA, dX = spmm_bwd(idx, ahat, X, dY.contiguous(), need_dx=ctx.needs_input_grad[2], skip_zero=ctx.skip_zero)
+        return dA, None, dX, None

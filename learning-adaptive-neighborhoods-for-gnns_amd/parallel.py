@@ -78,7 +78,7 @@ class ShardedDGGConv:
         kern, s = self.kern, self.saved
         g = {}
         dY, g["Wc"], _ = kern.linear_bwd(s["Y"], P["Wc"], s["Z"], dZ, 2, 1, True, False)
-        dA, dX = kern.spmm_bwd(s["idx"], s["ahat"], s["X"], dY, self.x_grad)
+        dA, dX = kern.spmm_bwd(s["idx"], s["ahat"], s["X"], dY, self.x_grad, True)
         da = kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0)
         if self.world > 1:
             dist.all_reduce(da, group=self.group)
