@@ -1,0 +1,228 @@
+"""Row-sharded DGG step (dgg_amd.parallel.ShardedDGGConv) exercised WITHOUT a GPU: 2 processes, gloo backend.
+
+The HIP kernels cannot run here, so the kernel namespace is substituted by a CPU stand-in (numpy + the oracle for
+the all-pairs stage).  What is tested is the partition / collective logic: the 2-rank result (forward rows of each
+rank, summed parameter gradients, reduce-scattered dX) must equal the single-process result on the same inputs.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class CpuKern:
+    """numpy restatement of the dgg_amd.ops signatures used by ShardedDGGConv (test stand-in only)."""
+
+    @staticmethod
+    def _t(a):
+        return torch.from_numpy(np.ascontiguousarray(a))
+
+    def linear_fwd(self, x, W, b, act, w_layout):
+        y = x.numpy() @ (W.numpy().T if w_layout == 0 else W.numpy())
+        if b is not None:
+            y = y + b.numpy()
+        if act == 1:
+            y = np.where(y > 0, y, 0.01 * y)
+        elif act == 2:
+            y = np.maximum(y, 0)
+        return self._t(y.astype(np.float32))
+
+    def linear_bwd(self, x, W, y, dy, act, w_layout, need_dx, need_db):
+        g = dy.numpy().astype(np.float64)
+        if act == 1:
+            g = np.where(y.numpy() > 0, g, 0.01 * g)
+        elif act == 2:
+            g = np.where(y.numpy() > 0, g, 0.0)
+        Wn = W.numpy().astype(np.float64)
+        dW = g.T @ x.numpy() if w_layout == 0 else x.numpy().T.astype(np.float64) @ g
+        dx = (g @ Wn if w_layout == 0 else g @ Wn.T) if need_dx else None
+        return (self._t(dx.astype(np.float32)) if need_dx else None, self._t(dW.astype(np.float32)),
+                self._t(g.sum(0).astype(np.float32)) if need_db else None)
+
+    def degree_stats(self, deg):
+        d = deg.numpy().astype(np.float64)
+        return self._t(np.array([d.mean(), d.std(ddof=1)], np.float32))
+
+    def knet_x_fwd(self, xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp):
+        mu, sd = mu_sd.numpy()
+        nd = (deg.numpy() - mu) / (sd + 1e-5)
+        feat = np.concatenate([xk.numpy(), nd[:, None]], 1).astype(np.float32)
+        pre = feat @ W1.numpy().T + b1.numpy()
+        z = np.where(pre > 0, pre, 0.01 * pre)
+        m = z @ Wmu.numpy().T + bmu.numpy()
+        u = (m @ Wp.numpy() + bp.numpy()[0]) * sd + mu
+        k = np.maximum(u, 0) + 1
+        return self._t(k.astype(np.float32)), self._t(z.astype(np.float32)), self._t(u.astype(np.float32)), self._t(feat)
+
+    def knet_x_bwd(self, h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk):
+        sd = float(mu_sd.numpy()[1])
+        dkp = np.where(u.numpy() > 0, dk.numpy() * sd, 0.0).astype(np.float64)
+        m = z.numpy() @ Wmu.numpy().T + bmu.numpy()
+        dm = dkp[:, None] * Wp.numpy()[None, :]
+        dz = dm @ Wmu.numpy()
+        dp1 = np.where(z.numpy() > 0, dz, 0.01 * dz)
+        dxk = dp1 @ W1.numpy()[:, :h]
+        f32 = lambda a: self._t(np.asarray(a, np.float32))  # noqa: E731
+        return (f32(dxk), f32(dp1.T @ feat.numpy()), f32(dp1.sum(0)), f32(dm.T @ z.numpy()), f32(dm.sum(0)),
+                f32((dkp[:, None] * m).sum(0)[None, :]), f32([dkp.sum()]))
+
+    def allpairs_topk(self, xp, K, t, noise_mode, G, seed, rows=None, algo=0):
+        sys.path.insert(0, ROOT)
+        from oracle import oracle as O
+        idx, val = O.allpairs_topk(xp.numpy(), K=K, t=t, noise_mode=noise_mode, seed=seed, rows=rows)
+        return self._t(idx), self._t(val)
+
+    @staticmethod
+    def _ramp(K, k):
+        r = np.arange(K, dtype=np.float64)[None, :]
+        th = np.tanh(r - k[:, None].astype(np.float64))
+        return 1 - 0.5 * (1 + th), 0.5 * (1 - th * th)
+
+    def softk_fwd(self, idx, val, k, mode):
+        f, _ = self._ramp(idx.shape[1], k.numpy())
+        w = np.where(idx.numpy() >= 0, val.numpy() * f if mode == 0 else f, 0.0).astype(np.float32)
+        return self._t(w), self._t(w.sum(1).astype(np.float32))
+
+    def normalize_fwd(self, idx, w, rs, row0=0):
+        a = 1.0 / np.sqrt(rs.numpy().astype(np.float64))
+        n = idx.shape[0]
+        j = np.maximum(idx.numpy(), 0)
+        out = np.where(idx.numpy() >= 0, a[row0:row0 + n, None] * w.numpy() * a[j], 0.0)
+        return self._t(out.astype(np.float32))
+
+    def spmm_fwd(self, idx, ahat, X):
+        j = np.maximum(idx.numpy(), 0)
+        return self._t(np.einsum("nk,nkf->nf", ahat.numpy().astype(np.float64), X.numpy()[j]).astype(np.float32))
+
+    def spmm_bwd(self, idx, ahat, X, dY, need_dx=True, skip_zero=False):
+        j = np.maximum(idx.numpy(), 0)
+        dA = np.einsum("nf,nkf->nk", dY.numpy().astype(np.float64), X.numpy()[j]) * (idx.numpy() >= 0)
+        dX = None
+        if need_dx:
+            dX = np.zeros(X.shape, np.float64)
+            np.add.at(dX, j.reshape(-1), (ahat.numpy()[:, :, None] * dY.numpy()[:, None, :]).reshape(-1, X.shape[1]))
+            dX = self._t(dX.astype(np.float32))
+        return self._t(dA.astype(np.float32)), dX
+
+    def norm_bwd_da(self, idx, w, rs, dA, row0=0):
+        a = 1.0 / np.sqrt(rs.numpy().astype(np.float64))
+        n = idx.shape[0]
+        j = np.maximum(idx.numpy(), 0)
+        g = dA.numpy().astype(np.float64) * w.numpy() * (idx.numpy() >= 0)
+        da = np.zeros(rs.shape[0], np.float64)
+        da[row0:row0 + n] += (g * a[j]).sum(1)
+        np.add.at(da, j.reshape(-1), (g * a[row0:row0 + n, None]).reshape(-1))
+        return self._t(da.astype(np.float32))
+
+    def softk_bwd(self, idx, val, k, dA, rs=None, da=None, row0=0, mode=0, normalized=False):
+        n, K = idx.shape
+        dw = dA.numpy().astype(np.float64)
+        j = np.maximum(idx.numpy(), 0)
+        if normalized:
+            a = 1.0 / np.sqrt(rs.numpy().astype(np.float64))
+            ai = a[row0:row0 + n]
+            drs = -0.5 * da.numpy()[row0:row0 + n] * ai / rs.numpy()[row0:row0 + n]
+            dw = dw * ai[:, None] * a[j] + drs[:, None]
+        f, dfdk = self._ramp(K, k.numpy())
+        valid = idx.numpy() >= 0
+        dval = np.where(valid, dw * f, 0.0) if mode == 0 else np.zeros_like(dw)
+        dk = (np.where(valid, dw * (val.numpy() if mode == 0 else 1.0) * dfdk, 0.0)).sum(1)
+        return self._t(dval.astype(np.float32)), self._t(dk.astype(np.float32))
+
+    def edge_bwd(self, xp, idx, val, dval, row0=0, t=-0.05, perturb=False):
+        X = xp.numpy().astype(np.float64)
+        n, K = idx.shape
+        out = np.zeros_like(X)
+        j = np.maximum(idx.numpy(), 0)
+        diff = X[row0:row0 + n, None, :] - X[j]
+        dist = np.sqrt((diff ** 2).sum(-1))
+        p = np.exp(t * dist)
+        g = dval.numpy().astype(np.float64) * (idx.numpy() >= 0)
+        dp = g * val.numpy() / (p + 1e-8) if perturb else g
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dd = np.where(dist > 0, dp * t * p / dist, 0.0)
+        e = dd[:, :, None] * diff
+        out[row0:row0 + n] += e.sum(1)
+        np.add.at(out, j.reshape(-1), -e.reshape(-1, X.shape[1]))
+        return self._t(out.astype(np.float32))
+
+
+def make_inputs(N=150, d=12, h=16):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(N, d, generator=g)
+    deg = 6 + 6 * torch.rand(N, generator=g)
+    h2, h4 = h // 2, h // 4
+    P = dict(We=torch.randn(h, d, generator=g) * 0.3, be=torch.randn(h, generator=g) * 0.1,
+             Wk=torch.randn(h, d, generator=g) * 0.3, bk=torch.randn(h, generator=g) * 0.1,
+             W1=torch.randn(h2, h + 1, generator=g) * 0.3, b1=torch.randn(h2, generator=g) * 0.1,
+             Wmu=torch.randn(h4, h2, generator=g) * 0.3, bmu=torch.randn(h4, generator=g) * 0.1,
+             Wp=torch.randn(1, h4, generator=g) * 0.3, bp=torch.tensor([0.05]), Wc=torch.rand(d, 5, generator=g))
+    cot = torch.randn(N, 5, generator=g)
+    return x, deg, P, cot
+
+
+def run_step(x_local, deg, P, cot_local, N, group):
+    sys.path.insert(0, ROOT)
+    from dgg_amd.parallel import ShardedDGGConv
+    layer = ShardedDGGConv(CpuKern(), N, group=group, K=64, noise_mode=2, seed=(5, 6), x_grad=True)
+    Z = layer.forward(x_local, deg, P)
+    g = layer.backward(cot_local, x_local, P)
+    return Z, g
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from dgg_amd.parallel import shard_bounds
+    x, deg, P, cot = make_inputs()
+    N = x.shape[0]
+    r0, r1, _ = shard_bounds(N, world, rank)
+    Z, g = run_step(x[r0:r1].contiguous(), deg, P, cot[r0:r1].contiguous(), N, None)
+    ret[rank] = (r0, r1, Z.numpy(), {k: v.numpy() for k, v in g.items()})
+    dist.destroy_process_group()
+
+
+def test_sharded_step_matches_single_process():
+    x, deg, P, cot = make_inputs()
+    N = x.shape[0]
+    Z1, g1 = run_step(x, deg, P, cot, N, None)          # world 1 (no process group)
+    port = 29500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret[0][1] == ret[1][0] and ret[0][0] == 0 and ret[1][1] == N      # uneven split (75 + 75; per = 75)
+    Z2 = np.concatenate([ret[0][2], ret[1][2]])
+    np.testing.assert_allclose(Z2, Z1.numpy(), rtol=1e-5, atol=1e-6)
+    for k in g1:
+        if k == "x":
+            got = np.concatenate([ret[0][3]["x"], ret[1][3]["x"]])
+        else:
+            got = ret[0][3][k]
+            np.testing.assert_allclose(ret[1][3][k], got, rtol=0, atol=0)   # all-reduced: identical on both ranks
+        ref = g1[k].numpy()
+        np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()))
+
+
+def test_shard_bounds_cover_every_row_once():
+    sys.path.insert(0, ROOT)
+    from dgg_amd.parallel import shard_bounds
+    for N in (1, 7, 64, 100_000, 100_001):
+        for world in (1, 2, 3, 8):
+            seen = 0
+            for r in range(world):
+                r0, r1, per = shard_bounds(N, world, r)
+                assert r0 == min(seen, N) and r1 >= r0 and r1 - r0 <= per
+                seen = r1
+            assert seen == N
