@@ -34,6 +34,10 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
     const bool can_fast = dgg_allpairs_fast_supported(h, noise_mode, K) && workspace &&
                           ws_bytes >= dgg_allpairs_fast_ws_bytes(N, h);
     const bool can_np = dgg_allpairs_np_supported(h, noise_mode, K) && workspace && ws_bytes >= dgg_allpairs_np_ws_bytes(N);
+    const bool can_gv = dgg_allpairs_gv_supported(h, noise_mode, K) && workspace &&
+                        ws_bytes >= dgg_allpairs_gv_ws_bytes(row1 - row0);
+    if (algo == 4 || (algo == 0 && can_gv && N >= 1024))
+        return dgg_allpairs_topk_gv_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
     if (algo == 3 || (algo == 0 && can_np && N >= 1024))
         return dgg_allpairs_topk_np_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
     if (algo == 2 || (algo == 0 && can_fast && N >= 1024))
@@ -45,7 +49,9 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
 size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K) {
     size_t a = dgg_allpairs_fast_supported(h, noise_mode, K) ? dgg_allpairs_fast_ws_bytes(N, h) : 0;
     size_t b = dgg_allpairs_np_supported(h, noise_mode, K) ? dgg_allpairs_np_ws_bytes(N) : 0;
-    return a > b ? a : b;
+    size_t c = dgg_allpairs_gv_supported(h, noise_mode, K) ? dgg_allpairs_gv_ws_bytes(N) : 0;
+    a = a > b ? a : b;
+    return a > c ? a : c;
 }
 
 }  // extern "C"

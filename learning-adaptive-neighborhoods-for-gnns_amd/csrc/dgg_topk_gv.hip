@@ -1,0 +1,294 @@
+// dgg_topk_gv.hip -- "guess and verify": the fastest exact all-pairs top-64 for PERTURBED scores.
+//
+// Same contract and same bits as allpairs_topk_exhaustive (dgg_topk.hip) / allpairs_topk_np (dgg_topk_np.hip):
+//   p'_ij = exp(log(exp(-0.05 ||xp_i - xp_j||) + 1e-8) + G_ij),  64 largest per row     reference dgm.py:1618-1623,
+//                                                                                         1213-1229, 1404
+// The adaptive noise prefilter (dgg_topk_np.hip) learns each row's threshold while it sweeps, which costs ~1200
+// exactly-scored candidates and ~20 merge stops per row.  Here the threshold is GUESSED up front and the result
+// VERIFIED afterwards, so the sweep is a pure integer loop and only ~230 candidates per row are scored:
+//
+//   K0 pilot     262k random pairs -> M = mean p^(1/0.3): for a threshold v, the expected number of pairs of a row
+//                with log-score >= v is  N * M * exp(-v/0.3)  (Gumbel tail); solve for a count of 128 -> gmin0.
+//   K1 sweep     lane = row, column wave-uniform: keep pairs whose noise alone could reach gmin0 (one unsigned
+//                compare of the raw hash), append their column to the row's candidate list.  No features touched.
+//   K2 finalize  one wavefront per row: exact canonical score of the candidates (64 per pass), DPP bitonic sort/merge
+//                -> top-64.  VERIFY: every rejected pair has log-score < gmin0 + 1e-8, so the list is exact iff its
+//                64th log-score >= gmin0 + margin.  Rows that fail (too few / too many candidates, or an unusually
+//                distant node) are appended to a fail list ...
+//   K3 fallback  ... and redone by the adaptive kernel (row-list form), which needs no guess.
+// All four launches are asynchronous on one stream; nothing is read back by the host.
+#include "dgg_common.h"
+#include "dgg_api_internal.h"
+
+using namespace dgg;
+
+namespace {
+
+constexpr int CAPF = 384;          // candidate slots per row in the fixed-threshold sweep (expected ~230)
+constexpr float TARGET = 128.0f;   // expected number of pairs per row above the guessed threshold (need 64)
+constexpr int PILOT_PAIRS = 262144;
+
+struct GvCtl {                     // device-side control block (workspace head)
+    float msum;                    // sum over pilot pairs of p^(1/0.3)
+    int nfail;                     // rows that failed verification
+    float gmin0;                   // guessed log-score threshold (written by K1's first wave for K2)
+    int pad;
+};
+
+template <int H>
+__device__ __forceinline__ float exact_score_gv(const float *__restrict__ xp, int64_t i, int32_t j, float t, bool sym,
+                                                uint32_t s0, uint32_t s1) {
+    const float *xi = xp + i * H;                               // wave-uniform: scalar loads
+    const float4 *xj = reinterpret_cast<const float4 *>(xp + (int64_t)j * H);
+    float d2 = 0.0f;
+#pragma unroll
+    for (int c8 = 0; c8 < H / 8; c8++) {
+        float4 b0 = xj[2 * c8], b1 = xj[2 * c8 + 1];
+        float df;
+        df = __fadd_rn(xi[8 * c8 + 0], -b0.x); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 1], -b0.y); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 2], -b0.z); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 3], -b0.w); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 4], -b1.x); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 5], -b1.y); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 6], -b1.z); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 7], -b1.w); d2 = __fmaf_rn(df, df, d2);
+    }
+    float dist = c_sqrt(d2);
+    float g = pair_noise(s0, s1, (uint32_t)i, (uint32_t)j, sym);
+    return score_from_dist(dist, t, true, g);
+}
+
+// pairs whose raw hash is below the result have noise G < gmin (with margin): they cannot reach log-score gmin + 1e-8
+__device__ __forceinline__ uint32_t hash_threshold_from_gmin(float gmin) {
+    float e1 = __expf((gmin - 1e-3f) * (-1.0f / 0.3f));        // P(G >= gmin - 1e-3) = 1 - exp(-e1) <= e1
+    float c = fminf(e1 * 16777216.0f, 16777216.0f);
+    int um = 16777216 - (int)c - 2;
+    um = um < 0 ? 0 : um;
+    return (uint32_t)um << 8;
+}
+
+// K0: moment of the score distribution from random pairs
+template <int H>
+__global__ __launch_bounds__(256) void gv_pilot(const float *__restrict__ xp, int64_t N, float t, uint32_t s0, uint32_t s1,
+                                                GvCtl *ctl) {
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    uint32_t a = mix32(gid * 2u + 1u + s0), b = mix32(gid * 2u + 2u + s1 * 0x9E3779B9u);
+    int64_t i = (int64_t)(((uint64_t)a * (uint64_t)N) >> 32), j = (int64_t)(((uint64_t)b * (uint64_t)N) >> 32);
+    float d2 = 0.0f;
+    for (int c = 0; c < H; c++) { float df = xp[i * H + c] - xp[j * H + c]; d2 = fmaf(df, df, d2); }
+    float lp = __logf(__expf(t * sqrtf(d2)) + 1e-8f);
+    float m = (i == j) ? 0.0f : __expf(lp * (1.0f / 0.3f));
+    const int lane = threadIdx.x & 63;
+    m = wave_sum_dpp(m, lane);
+    if (lane == 0) atomicAdd(&ctl->msum, m);
+}
+
+// K1: fixed-threshold sweep.  lane = row; pend/cnt are indexed by LOCAL row (i - row0)
+template <bool SYM>
+__global__ __launch_bounds__(64) void gv_sweep(int64_t N, int64_t row0, int64_t row1, uint32_t s0, uint32_t s1,
+                                               GvCtl *ctl, int *__restrict__ pend_g, int *__restrict__ cnt_g) {
+    const int lane = threadIdx.x;
+    const int64_t i = row0 + (int64_t)blockIdx.x * 64 + lane;
+    const bool rvalid = i < row1;
+    const uint32_t iu = (uint32_t)(rvalid ? i : row1 - 1);
+    const int64_t lrow = (int64_t)blockIdx.x * 64 + lane;
+    int *pend = pend_g + lrow * CAPF;
+    // guessed threshold: expected TARGET pairs per row with log-score above it
+    const float M = fmaxf(ctl->msum * (1.0f / PILOT_PAIRS), 1e-30f);
+    const float gmin0 = 0.3f * __logf(fmaxf((float)N * M / TARGET, 1e-30f));
+    if (blockIdx.x == 0 && lane == 0) ctl->gmin0 = gmin0;
+    const uint32_t ta = rvalid ? hash_threshold_from_gmin(gmin0) : 0xffffffffu;
+    uint32_t k1, k2;
+    rowkey(s0, s1, iu, k1, k2);
+    int cnt = 0;
+    auto col_step = [&](uint32_t j) {                            // j: wave-uniform column
+        uint32_t x;
+        if (!SYM) {
+            x = j ^ k1;
+            x *= 0x7feb352dU; x ^= x >> 15; x += k2; x *= 0x846ca68bU;
+        } else {
+            uint32_t kj1, kj2;
+            rowkey(s0, s1, j, kj1, kj2);                         // scalar ALU
+            uint32_t xa = pair_u24_keyed(k1, k2, j) << 8;
+            uint32_t xb = pair_u24_keyed(kj1, kj2, iu) << 8;
+            x = j > iu ? xa : xb;
+            if (j == iu) x = 0xffffffffu;                        // zero-noise diagonal: always a candidate
+        }
+        if (x >= ta) {
+            if (cnt < CAPF) pend[cnt] = (int)j;
+            cnt++;
+        }
+    };
+    const int64_t N8 = N / 8 * 8;
+    for (int64_t j0 = 0; j0 < N8; j0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) col_step((uint32_t)(j0 + u));
+    }
+    for (int64_t j = N8; j < N; j++) col_step((uint32_t)j);
+    if (rvalid) cnt_g[lrow] = cnt;
+}
+
+// K2: exact scoring of the candidates, top-64, verification.  One wavefront per row.
+template <int H, bool SYM>
+__global__ __launch_bounds__(256) void gv_finalize(const float *__restrict__ xp, int64_t N, int64_t row0, int64_t row1,
+                                                   float t, uint32_t s0, uint32_t s1, GvCtl *ctl,
+                                                   const int *__restrict__ pend_g, const int *__restrict__ cnt_g,
+                                                   int *__restrict__ faillist, int32_t *__restrict__ idx,
+                                                   float *__restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t i = row0 + lrow;
+    if (i >= row1) return;
+    const int n = cnt_g[lrow];
+    const int *pl = pend_g + lrow * CAPF;
+    uint64_t list = DGG_EMPTY_KEY;
+    bool ok = n >= 64 && n <= CAPF;
+    if (ok) {
+        for (int base = 0; base < n; base += 64) {
+            int e = base + lane;
+            int32_t j = e < n ? pl[e] : -1;
+            uint64_t key = DGG_EMPTY_KEY;
+            if (j >= 0) key = make_key(exact_score_gv<H>(xp, i, j, t, SYM, s0, s1), j);
+            key = wave_sort<false>(key, lane);
+            list = wave_merge_top64_asc(list, key, lane);
+        }
+        uint64_t k63 = shfl_u64(list, 63);
+        // rejected pairs have log-score < gmin0 + 1e-8: the list is exact iff its 64th entry clears that with margin
+        ok = k63 != DGG_EMPTY_KEY && __logf(key_val(k63)) >= ctl->gmin0 + 1e-3f;
+    }
+    if (ok) {
+        idx[lrow * 64 + lane] = key_col(list);
+        val[lrow * 64 + lane] = key_val(list);
+    } else if (lane == 0) {
+        int slot = atomicAdd(&ctl->nfail, 1);
+        faillist[slot] = (int)lrow;
+    }
+}
+
+// K3: adaptive noise prefilter on the rows of the fail list (lane = listed row); same algorithm as dgg_topk_np.hip
+constexpr int STEP = 8, FLUSH_AT = 56;
+__device__ __forceinline__ uint32_t noise_threshold_gv(float pp63) { return hash_threshold_from_gmin(__logf(pp63)); }
+
+template <int H, bool SYM>
+__global__ __launch_bounds__(64) void gv_fallback(const float *__restrict__ xp, int64_t N, int64_t row0, float t,
+                                                  uint32_t s0, uint32_t s1, const GvCtl *ctl, int *__restrict__ pend_g,
+                                                  const int *__restrict__ faillist, int32_t *__restrict__ idx,
+                                                  float *__restrict__ val) {
+    const int lane = threadIdx.x;
+    const int nfail = ctl->nfail;
+    const int base = blockIdx.x * 64;
+    if (base >= nfail) return;                                   // the usual case: nothing to redo
+    const bool rvalid = base + lane < nfail;
+    const int lrow = faillist[rvalid ? base + lane : base];
+    const uint32_t iu = (uint32_t)(row0 + lrow);
+    int *pend = pend_g + (int64_t)lrow * CAPF;
+    uint32_t k1, k2;
+    rowkey(s0, s1, iu, k1, k2);
+    uint32_t ta = rvalid ? 0u : 0xffffffffu;
+    int cnt = 0;
+    if (rvalid) { /* empty list */ }
+    for (int e = 0; e < 64; e++) {
+        int lr = __shfl(lrow, e, 64);
+        bool v = e + base < nfail;
+        if (v) { idx[(int64_t)lr * 64 + lane] = -1; val[(int64_t)lr * 64 + lane] = 0.0f; }
+    }
+    auto do_flush = [&](int fl) {
+        const int frow = __shfl(lrow, fl, 64);
+        const int64_t fi = row0 + frow;
+        const int n = __shfl(cnt, fl, 64);
+        const int *pl = pend_g + (int64_t)frow * CAPF;
+        int32_t li = idx[(int64_t)frow * 64 + lane];
+        float lv = val[(int64_t)frow * 64 + lane];
+        uint64_t list = li >= 0 ? make_key(lv, li) : DGG_EMPTY_KEY;
+        int32_t j = lane < n ? pl[lane] : -1;
+        uint64_t key = DGG_EMPTY_KEY;
+        if (j >= 0) key = make_key(exact_score_gv<H>(xp, fi, j, t, SYM, s0, s1), j);
+        key = wave_sort<false>(key, lane);
+        list = wave_merge_top64_asc(list, key, lane);
+        bool empty = list == DGG_EMPTY_KEY;
+        idx[(int64_t)frow * 64 + lane] = empty ? -1 : key_col(list);
+        val[(int64_t)frow * 64 + lane] = empty ? 0.0f : key_val(list);
+        uint64_t k63 = shfl_u64(list, 63);
+        if (lane == fl) {
+            cnt = 0;
+            if (k63 != DGG_EMPTY_KEY) ta = noise_threshold_gv(key_val(k63));
+        }
+    };
+    auto col_step = [&](uint32_t j) {
+        uint32_t x;
+        if (!SYM) {
+            x = j ^ k1;
+            x *= 0x7feb352dU; x ^= x >> 15; x += k2; x *= 0x846ca68bU;
+        } else {
+            uint32_t kj1, kj2;
+            rowkey(s0, s1, j, kj1, kj2);
+            uint32_t xa = pair_u24_keyed(k1, k2, j) << 8;
+            uint32_t xb = pair_u24_keyed(kj1, kj2, iu) << 8;
+            x = j > iu ? xa : xb;
+            if (j == iu) x = 0xffffffffu;
+        }
+        if (x >= ta) { pend[cnt] = (int)j; cnt++; }
+    };
+    const int64_t Nfull = N / STEP * STEP;
+    for (int64_t j0 = 0; j0 < Nfull; j0 += STEP) {
+#pragma unroll
+        for (int u = 0; u < STEP; u++) col_step((uint32_t)(j0 + u));
+        uint64_t need = __ballot(cnt >= FLUSH_AT);
+        while (need) { int fl = __builtin_ctzll(need); need &= need - 1; do_flush(fl); }
+    }
+    for (int64_t j = Nfull; j < N; j++) col_step((uint32_t)j);
+    uint64_t need = __ballot(cnt > 0 && rvalid);
+    while (need) { int fl = __builtin_ctzll(need); need &= need - 1; do_flush(fl); }
+}
+
+template <int H>
+int launch_gv(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, int noise_mode, uint32_t s0, uint32_t s1,
+              int32_t *idx, float *val, void *ws, hipStream_t st) {
+    const int64_t R = row1 - row0, R64 = (R + 63) / 64 * 64;
+    char *w = reinterpret_cast<char *>(ws);
+    GvCtl *ctl = reinterpret_cast<GvCtl *>(w);
+    int *cnt = reinterpret_cast<int *>(w + 256);
+    int *faillist = cnt + R64;
+    int *pend = faillist + R64;
+    if (dgg_check_hip(hipMemsetAsync(ctl, 0, sizeof(GvCtl), st), "gv memset") != 0) return DGG_ERR_HIP;
+    const bool sym = noise_mode == 3;
+    hipLaunchKernelGGL(gv_pilot<H>, dim3(PILOT_PAIRS / 256), dim3(256), 0, st, xp, N, t, s0, s1, ctl);
+    dim3 gsweep((unsigned)(R64 / 64));
+    if (sym) hipLaunchKernelGGL(gv_sweep<true>, gsweep, dim3(64), 0, st, N, row0, row1, s0, s1, ctl, pend, cnt);
+    else hipLaunchKernelGGL(gv_sweep<false>, gsweep, dim3(64), 0, st, N, row0, row1, s0, s1, ctl, pend, cnt);
+    dim3 gfin((unsigned)((R + 3) / 4));
+    if (sym) hipLaunchKernelGGL((gv_finalize<H, true>), gfin, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, ctl, pend, cnt, faillist, idx, val);
+    else hipLaunchKernelGGL((gv_finalize<H, false>), gfin, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, ctl, pend, cnt, faillist, idx, val);
+    if (sym) hipLaunchKernelGGL((gv_fallback<H, true>), gsweep, dim3(64), 0, st, xp, N, row0, t, s0, s1, ctl, pend, faillist, idx, val);
+    else hipLaunchKernelGGL((gv_fallback<H, false>), gsweep, dim3(64), 0, st, xp, N, row0, t, s0, s1, ctl, pend, faillist, idx, val);
+    return dgg_check_launch("allpairs_topk_gv");
+}
+
+}  // namespace
+
+size_t dgg_allpairs_gv_ws_bytes(int64_t rows) {
+    size_t R64 = ((size_t)rows + 63) / 64 * 64;
+    return 256 + R64 * 4 * 2 + R64 * (size_t)CAPF * 4;
+}
+
+bool dgg_allpairs_gv_supported(int h, int noise_mode, int K) {
+    return K == 64 && (h == 8 || h == 16 || h == 32 || h == 64 || h == 128) && (noise_mode == 2 || noise_mode == 3);
+}
+
+int dgg_allpairs_topk_gv_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode,
+                              uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, void *workspace, size_t ws_bytes,
+                              hipStream_t st) {
+    if (!dgg_allpairs_gv_supported(h, noise_mode, K))
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "guess-and-verify path needs K=64, in-kernel noise, latent_dim in {8,...,128}");
+    if (!workspace || ws_bytes < dgg_allpairs_gv_ws_bytes(row1 - row0))
+        return dgg_set_error(DGG_ERR_ARG, "guess-and-verify path: workspace too small (dgg_allpairs_workspace_bytes)");
+    if (row1 <= row0) return 0;
+    switch (h) {
+        case 8: return launch_gv<8>(xp, N, row0, row1, t, noise_mode, s0, s1, idx, val, workspace, st);
+        case 16: return launch_gv<16>(xp, N, row0, row1, t, noise_mode, s0, s1, idx, val, workspace, st);
+        case 32: return launch_gv<32>(xp, N, row0, row1, t, noise_mode, s0, s1, idx, val, workspace, st);
+        case 64: return launch_gv<64>(xp, N, row0, row1, t, noise_mode, s0, s1, idx, val, workspace, st);
+        default: return launch_gv<128>(xp, N, row0, row1, t, noise_mode, s0, s1, idx, val, workspace, st);
+    }
+}

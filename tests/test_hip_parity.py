@@ -65,7 +65,7 @@ def test_linear_bwd(dev, N, d, out, layout, act):
 
 @pytest.mark.parametrize("N,h,noise", [(300, 16, "none"), (1000, 64, "hash"), (777, 32, "sym"), (513, 64, "explicit"),
                                        (130, 128, "hash"), (64, 8, "none"), (1, 16, "hash"), (65, 64, "hash")])
-@pytest.mark.parametrize("algo", [1, 2, 3])
+@pytest.mark.parametrize("algo", [1, 2, 3, 4])
 def test_allpairs_topk_bit_exact(dev, N, h, noise, algo):
     from dgg_amd import ops
     rng = np.random.default_rng(3)
@@ -75,8 +75,8 @@ def test_allpairs_topk_bit_exact(dev, N, h, noise, algo):
     G = grid_gumbel(5, (N, N)) if noise == "explicit" else None
     if algo == 2 and (noise == "explicit" or h == 8):
         pytest.skip("the MFMA-pruned path generates its noise in-kernel and needs latent_dim in {16,32,64,128}")
-    if algo == 3 and noise in ("explicit", "none"):
-        pytest.skip("the noise-prefilter path applies to in-kernel noise only")
+    if algo in (3, 4) and noise in ("explicit", "none"):
+        pytest.skip("the noise-prefilter paths apply to in-kernel noise only")
     idx, val = ops.allpairs_topk(T(xp, dev), K, noise_mode=mode, G=None if G is None else T(G, dev), seed=(77, 5), algo=algo)
     ridx, rval = O.allpairs_topk(xp, K=K, noise_mode=mode, G=G, seed=(77, 5))
     assert np.array_equal(Nn(idx), ridx), "top-k indices differ from the oracle"
