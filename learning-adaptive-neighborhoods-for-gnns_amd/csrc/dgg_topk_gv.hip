@@ -24,8 +24,12 @@ using namespace dgg;
 
 namespace {
 
-constexpr int CAPF = 384;          // candidate slots per row in the fixed-threshold sweep (expected ~230)
-constexpr float TARGET = 128.0f;   // expected number of pairs per row above the guessed threshold (need 64)
+constexpr int NSEG = 4;            // column segments swept by separate wavefronts (fixed threshold: no coupling)
+constexpr int CAPS = 160;          // candidate slots per (row, segment)
+constexpr int CAPF = NSEG * CAPS;  // candidate slots per row in the fixed-threshold sweep
+constexpr float TARGET_MAX = 128.0f;   // expected number of pairs per row above the guessed threshold (need 64) ...
+constexpr float TARGET_MIN = 80.0f;    // ... lowered when distances matter (small M) so the candidate lists still fit
+constexpr float ADMIT_MAX = 0.8f * CAPF;
 constexpr int PILOT_PAIRS = 262144;
 
 struct GvCtl {                     // device-side control block (workspace head)
@@ -93,11 +97,16 @@ __global__ __launch_bounds__(64) void gv_sweep(int64_t N, int64_t row0, int64_t 
     const bool rvalid = i < row1;
     const uint32_t iu = (uint32_t)(rvalid ? i : row1 - 1);
     const int64_t lrow = (int64_t)blockIdx.x * 64 + lane;
-    int *pend = pend_g + lrow * CAPF;
+    const int seg = blockIdx.y;                                  // this wavefront sweeps columns [c_lo, c_hi)
+    const int64_t per = ((N + NSEG - 1) / NSEG + 15) / 16 * 16;
+    const int64_t c_lo = seg * per < N ? seg * per : N, c_hi = c_lo + per < N ? c_lo + per : N;
+    int *pend = pend_g + lrow * CAPF + seg * CAPS;
     // guessed threshold: expected TARGET pairs per row with log-score above it
     const float M = fmaxf(ctl->msum * (1.0f / PILOT_PAIRS), 1e-30f);
-    const float gmin0 = 0.3f * __logf(fmaxf((float)N * M / TARGET, 1e-30f));
-    if (blockIdx.x == 0 && lane == 0) ctl->gmin0 = gmin0;
+    // the noise test admits TARGET / M pairs per row: keep that below the list capacity when M is small
+    const float target = fminf(TARGET_MAX, fmaxf(TARGET_MIN, ADMIT_MAX * M));
+    const float gmin0 = 0.3f * __logf(fmaxf((float)N * M / target, 1e-30f));
+    if (blockIdx.x == 0 && seg == 0 && lane == 0) ctl->gmin0 = gmin0;
     const uint32_t ta = rvalid ? hash_threshold_from_gmin(gmin0) : 0xffffffffu;
     uint32_t k1, k2;
     rowkey(s0, s1, iu, k1, k2);
@@ -116,17 +125,36 @@ __global__ __launch_bounds__(64) void gv_sweep(int64_t N, int64_t row0, int64_t 
             if (j == iu) x = 0xffffffffu;                        // zero-noise diagonal: always a candidate
         }
         if (x >= ta) {
-            if (cnt < CAPF) pend[cnt] = (int)j;
+            if (cnt < CAPS) pend[cnt] = (int)j;
             cnt++;
         }
     };
-    const int64_t N8 = N / 8 * 8;
-    for (int64_t j0 = 0; j0 < N8; j0 += 8) {
+    constexpr int UB = 16;                                       // columns hashed together: independent chains (ILP)
+    const int64_t NB = c_lo + (c_hi - c_lo) / UB * UB;
+    if (!SYM) {
+        for (int64_t j0 = c_lo; j0 < NB; j0 += UB) {
+            uint32_t x[UB];
 #pragma unroll
-        for (int u = 0; u < 8; u++) col_step((uint32_t)(j0 + u));
+            for (int u = 0; u < UB; u++) {
+                uint32_t v = (uint32_t)(j0 + u) ^ k1;
+                v *= 0x7feb352dU; v ^= v >> 15; v += k2; v *= 0x846ca68bU;
+                x[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; u++) asm volatile("" : "+v"(x[u]));   // keep the 16 chains interleaved (no sinking)
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                if (x[u] >= ta) {
+                    if (cnt < CAPS) pend[cnt] = (int)(j0 + u);
+                    cnt++;
+                }
+            }
+        }
+        for (int64_t j = NB; j < c_hi; j++) col_step((uint32_t)j);
+    } else {
+        for (int64_t j = c_lo; j < c_hi; j++) col_step((uint32_t)j);
     }
-    for (int64_t j = N8; j < N; j++) col_step((uint32_t)j);
-    if (rvalid) cnt_g[lrow] = cnt;
+    if (rvalid) cnt_g[lrow * NSEG + seg] = cnt;
 }
 
 // K2: exact scoring of the candidates, top-64, verification.  One wavefront per row.
@@ -140,14 +168,33 @@ __global__ __launch_bounds__(256) void gv_finalize(const float *__restrict__ xp,
     const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t i = row0 + lrow;
     if (i >= row1) return;
-    const int n = cnt_g[lrow];
+    // the row's candidates sit in NSEG segment lists; view them as one concatenated list of n entries
+    int ns[NSEG], off[NSEG + 1];
+    off[0] = 0;
+    bool ok = true;
+#pragma unroll
+    for (int s = 0; s < NSEG; s++) {
+        ns[s] = cnt_g[lrow * NSEG + s];
+        ok = ok && ns[s] <= CAPS;
+        off[s + 1] = off[s] + (ns[s] <= CAPS ? ns[s] : CAPS);
+    }
+    const int n = off[NSEG];
     const int *pl = pend_g + lrow * CAPF;
     uint64_t list = DGG_EMPTY_KEY;
-    bool ok = n >= 64 && n <= CAPF;
+    ok = ok && n >= 64;
     if (ok) {
         for (int base = 0; base < n; base += 64) {
             int e = base + lane;
-            int32_t j = e < n ? pl[e] : -1;
+            int32_t j = -1;
+            if (e < n) {
+                int s = 0;
+#pragma unroll
+                for (int q = 1; q < NSEG; q++) s += (e >= off[q]) ? 1 : 0;
+                int o = off[0];
+#pragma unroll
+                for (int q = 1; q < NSEG; q++) o = (s == q) ? off[q] : o;
+                j = pl[s * CAPS + (e - o)];
+            }
             uint64_t key = DGG_EMPTY_KEY;
             if (j >= 0) key = make_key(exact_score_gv<H>(xp, i, j, t, SYM, s0, s1), j);
             key = wave_sort<false>(key, lane);
@@ -228,7 +275,7 @@ __global__ __launch_bounds__(64) void gv_fallback(const float *__restrict__ xp, 
             x = j > iu ? xa : xb;
             if (j == iu) x = 0xffffffffu;
         }
-        if (x >= ta) { pend[cnt] = (int)j; cnt++; }
+        if (x >= ta && rvalid) { pend[cnt] = (int)j; cnt++; }   // rvalid: padding lanes alias a listed row's buffer
     };
     const int64_t Nfull = N / STEP * STEP;
     for (int64_t j0 = 0; j0 < Nfull; j0 += STEP) {
@@ -249,14 +296,15 @@ int launch_gv(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, i
     char *w = reinterpret_cast<char *>(ws);
     GvCtl *ctl = reinterpret_cast<GvCtl *>(w);
     int *cnt = reinterpret_cast<int *>(w + 256);
-    int *faillist = cnt + R64;
+    int *faillist = cnt + R64 * NSEG;
     int *pend = faillist + R64;
     if (dgg_check_hip(hipMemsetAsync(ctl, 0, sizeof(GvCtl), st), "gv memset") != 0) return DGG_ERR_HIP;
     const bool sym = noise_mode == 3;
     hipLaunchKernelGGL(gv_pilot<H>, dim3(PILOT_PAIRS / 256), dim3(256), 0, st, xp, N, t, s0, s1, ctl);
     dim3 gsweep((unsigned)(R64 / 64));
-    if (sym) hipLaunchKernelGGL(gv_sweep<true>, gsweep, dim3(64), 0, st, N, row0, row1, s0, s1, ctl, pend, cnt);
-    else hipLaunchKernelGGL(gv_sweep<false>, gsweep, dim3(64), 0, st, N, row0, row1, s0, s1, ctl, pend, cnt);
+    dim3 gsweep2((unsigned)(R64 / 64), NSEG);
+    if (sym) hipLaunchKernelGGL(gv_sweep<true>, gsweep2, dim3(64), 0, st, N, row0, row1, s0, s1, ctl, pend, cnt);
+    else hipLaunchKernelGGL(gv_sweep<false>, gsweep2, dim3(64), 0, st, N, row0, row1, s0, s1, ctl, pend, cnt);
     dim3 gfin((unsigned)((R + 3) / 4));
     if (sym) hipLaunchKernelGGL((gv_finalize<H, true>), gfin, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, ctl, pend, cnt, faillist, idx, val);
     else hipLaunchKernelGGL((gv_finalize<H, false>), gfin, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, ctl, pend, cnt, faillist, idx, val);
@@ -269,7 +317,7 @@ int launch_gv(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, i
 
 size_t dgg_allpairs_gv_ws_bytes(int64_t rows) {
     size_t R64 = ((size_t)rows + 63) / 64 * 64;
-    return 256 + R64 * 4 * 2 + R64 * (size_t)CAPF * 4;
+    return 256 + R64 * 4 * (NSEG + 1) + R64 * (size_t)CAPF * 4;
 }
 
 bool dgg_allpairs_gv_supported(int h, int noise_mode, int K) {

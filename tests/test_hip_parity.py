@@ -323,7 +323,9 @@ def test_full_size_properties(dev):
     W = (torch.randn(h, d, generator=g) * 0.1).to(dev)
     b = (torch.randn(h, generator=g) * 0.1).to(dev)
     xp = ops.linear_fwd(x, W, b, ops.ACT_LEAKY)
-    idx, val = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_HASH, seed=(1234, 0))
+    idx, val, ws = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_HASH, seed=(1234, 0), return_ws=True)
+    nfail = int(ws[4:8].view(torch.int32).item())          # guess-and-verify control block: rows redone by the fallback
+    assert nfail <= N // 200, f"threshold guess failed verification on {nfail} rows (results stay exact, speed suffers)"
     assert (val[:, :-1] >= val[:, 1:]).all()
     assert (idx >= 0).all() and (idx < N).all()
     srt = idx.sort(dim=1).values
