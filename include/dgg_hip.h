@@ -54,14 +54,17 @@ int dgg_abi_version(void);
  * GraphConvolution.weight, model.py:25, 41).  b may be NULL. */
 int dgg_linear_fwd(const float *x, int64_t N, int d, const float *W, const float *b, int out, int w_layout, int act,
                    float *y, void *stream);
-/* autograd of the above.  dp_ws: N*out floats of workspace.  dx (nullable) is overwritten; dW (layout of W) and
- * db (nullable) are accumulated into. */
+/* autograd of the above.  ws: dgg_linear_bwd_ws_floats(N, d, out) floats of workspace.  dx (nullable) is
+ * overwritten; dW (layout of W) and db (nullable) are accumulated into. */
+size_t dgg_linear_bwd_ws_floats(int64_t N, int d, int out);
 int dgg_linear_bwd(const float *x, int64_t N, int d, const float *W, int out, int w_layout, int act, const float *y,
-                   const float *dy, float *dx, float *dW, float *db, float *dp_ws, void *stream);
+                   const float *dy, float *dx, float *dW, float *db, float *ws, void *stream);
 /* C[M1,M2] += A[N,M1]^T B[N,M2] (c_layout 1: C stored [M2][M1]); colsum (nullable,[M1]) += column sums of A.
- * Weight gradients of the per-node layers (autograd of dgm.py:1576-1577). */
+ * Weight gradients of the per-node layers (autograd of dgm.py:1576-1577).  ws: dgg_gemm_tn_ws_floats(N, M1, M2)
+ * floats (per-chunk partial blocks, summed by a second kernel: no same-address atomics storm). */
+size_t dgg_gemm_tn_ws_floats(int64_t N, int M1, int M2);
 int dgg_gemm_tn_acc(const float *A, const float *B, int64_t N, int M1, int M2, float *C, int c_layout, float *colsum,
-                    void *stream);
+                    float *ws, void *stream);
 
 /* ---- learned degree k (k_estimate_net, dgm.py:1472-1586; LearnableKEncoder.forward, dgm.py:2051-2063) ------ */
 /* mu_sd[0] = mean(deg), mu_sd[1] = unbiased std(deg)   (dgm.py:1568-1570; deg replaces in_adj.to_dense().sum(-1)) */

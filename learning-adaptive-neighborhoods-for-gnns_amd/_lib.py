@@ -12,7 +12,9 @@ _vp, _i64, _i32, _u32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C
 PROTOTYPES = {
     "dgg_linear_fwd": [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "dgg_linear_bwd": [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "dgg_gemm_tn_acc": [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp],
+    "dgg_gemm_tn_acc": [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
+    "dgg_gemm_tn_ws_floats": [_i64, _i32, _i32],
+    "dgg_linear_bwd_ws_floats": [_i64, _i32, _i32],
     "dgg_degree_stats": [_vp, _i64, _vp, _vp],
     "dgg_knet_x_fwd": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_knet_x_bwd_nodes": [_i64, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -52,7 +54,8 @@ def lib():
             fn = getattr(L, name)      # AttributeError if the library does not export a declared symbol
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        L.dgg_allpairs_workspace_bytes.restype = C.c_size_t
+        for name in ("dgg_allpairs_workspace_bytes", "dgg_gemm_tn_ws_floats", "dgg_linear_bwd_ws_floats"):
+            getattr(L, name).restype = C.c_size_t
         _lib = L
     return _lib
 

@@ -17,7 +17,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, LDP = BK + 1;
+constexpr int BM = 128, BK = 32, LDP = BK + 1;
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == 1) return v > 0.0f ? v : __fmul_rn(0.01f, v);
@@ -25,18 +25,21 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     return v;
 }
 
-// y[N,out] = act(x[N,d] * W^T + b);  w_layout 0: W[out][d], 1: W[d][out]
+// y[N,out] = act(x[N,d] * W^T + b);  w_layout 0: W[out][d], 1: W[d][out].  NACC 32-column accumulators per wave
+// (tile width BN = 32*NACC is matched to `out`, so narrow layers do not pay for 128 columns of MFMAs)
+template <int NACC>
 __global__ __launch_bounds__(256) void linear_fwd_mfma(const float *__restrict__ x, int64_t N, int d,
                                                        const float *__restrict__ W, const float *__restrict__ b,
                                                        int out, int w_layout, int act, float *__restrict__ y) {
+    constexpr int BN = 32 * NACC;
     __shared__ float xs[BM * LDP];
     __shared__ float ws[BN * LDP];   // [j][k] (+pad)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    f32x16 acc[4];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int a = 0; a < NACC; a++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[a][r] = 0.0f;
     const int li = lane & 31, hh = lane >> 5;
@@ -67,14 +70,14 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma(const float *__restrict__
         for (int s = 0; s < BK / 2; s++) {
             float av = xa[2 * s];
 #pragma unroll
-            for (int a = 0; a < 4; a++) {
+            for (int a = 0; a < NACC; a++) {
                 float bv = ws[(a * 32 + li) * LDP + 2 * s + hh];
                 acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
             }
         }
     }
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
+    for (int a = 0; a < NACC; a++) {
         int gj = n0 + a * 32 + li;
         if (gj >= out) continue;
         float bj = b ? b[gj] : 0.0f;
@@ -104,69 +107,114 @@ __global__ void act_bwd_kernel(const float *__restrict__ y, const float *__restr
     }
 }
 
-// C[M1,M2] += A[N,M1]^T * B[N,M2]   (weight gradient: reduction over the node dimension; fp32 atomics)
-// grid: x = row chunks of RCH rows, y = M1 blocks of 128, z = M2 blocks of 128.
-// c_layout 0: C[M1][M2] row-major; 1: C stored transposed C[M2][M1].  colsum (optional, M1 floats) += column sums of A.
-constexpr int RCH = 256;   // rows per workgroup: N/256 workgroups keep all 256 CUs busy at N = 100k
-__global__ __launch_bounds__(256) void gemm_tn_reduce_mfma(const float *__restrict__ A, const float *__restrict__ B,
-                                                           int64_t N, int M1, int M2, float *__restrict__ Cout,
-                                                           int c_layout, float *__restrict__ colsum) {
-    __shared__ float as[BK * (BM + 1)];   // [n][o]
-    __shared__ float bs[BK * (BN + 1)];   // [n][c]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t r0 = (int64_t)blockIdx.x * RCH;
-    const int64_t r1 = r0 + RCH < N ? r0 + RCH : N;
-    const int o0 = blockIdx.y * BM, c0 = blockIdx.z * BN;
-    const int li = lane & 31, hh = lane >> 5;
-    f32x16 acc[4];
+// Weight-gradient GEMM: C[M1,M2] += A[N,M1]^T B[N,M2] with tiny M1, M2 (<= a few hundred) and huge N.
+// Stage 1: one wavefront owns a 32 x (32*NBLK) block of C over a chunk of GT_ROWS node rows.  The fp32 MFMA operands are
+// one float per lane (A[n][o0+lane%32], B[n][c0+..+lane%32], n = k-step*2 + lane/32), i.e. 128-byte coalesced row
+// segments, so they are loaded straight from global memory: no LDS, no barriers.  Partial blocks go to a slab
+// [chunk][M1p][M2p] with plain stores -- NOT atomics: every chunk would hit the same few KB of C, and same-address fp32
+// atomics run ~14x below the streaming atomic rate (MI355X_MICROARCH.md, "Global float atomics").
+// Stage 2: gemm_tn_reduce sums the slab over chunks (8-way split, 8 atomics per output) into C / colsum.
+constexpr int GT_ROWS = 256;
+template <int NBLK>
+__global__ __launch_bounds__(64) void gemm_tn_partial(const float *__restrict__ A, const float *__restrict__ B, int64_t N,
+                                                      int M1, int M2, int M1p, int M2p, float *__restrict__ slab,
+                                                      float *__restrict__ cs_slab) {
+    const int lane = threadIdx.x, li = lane & 31, hh = lane >> 5;
+    const int64_t r0 = (int64_t)blockIdx.x * GT_ROWS;
+    const int64_t r1 = r0 + GT_ROWS < N ? r0 + GT_ROWS : N;
+    const int o0 = blockIdx.y * 32, c0 = blockIdx.z * (NBLK * 32);
+    const bool ov = o0 + li < M1;
+    bool cv[NBLK];
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int a = 0; a < NBLK; a++) cv[a] = c0 + a * 32 + li < M2;
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int a = 0; a < NBLK; a++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[a][r] = 0.0f;
-    float csum = 0.0f;   // thread tid < 128 accumulates column o0+tid of A
-    for (int64_t nb = r0; nb < r1; nb += BK) {
-        __syncthreads();
-        for (int e = tid; e < BK * BM; e += 256) {
-            int n = e / BM, o = e % BM;
-            int64_t gn = nb + n;
-            int go = o0 + o;
-            as[n * (BM + 1) + o] = (gn < r1 && go < M1) ? A[gn * M1 + go] : 0.0f;
-        }
-        for (int e = tid; e < BK * BN; e += 256) {
-            int n = e / BN, c = e % BN;
-            int64_t gn = nb + n;
-            int gc = c0 + c;
-            bs[n * (BN + 1) + c] = (gn < r1 && gc < M2) ? B[gn * M2 + gc] : 0.0f;
-        }
-        __syncthreads();
-        if (colsum && blockIdx.z == 0 && tid < BM) {
-#pragma unroll 8
-            for (int n = 0; n < BK; n++) csum += as[n * (BM + 1) + tid];
-        }
+    float csum = 0.0f;
+    const float *ap = A + o0 + li;
+    const float *bp = B + c0 + li;
+#pragma unroll 4
+    for (int64_t nb = r0; nb < r1; nb += 2) {                    // k-step = 2 node rows (one per lane half)
+        const int64_t n = nb + hh;
+        const bool nv = n < r1;
+        float av = (nv && ov) ? ap[n * M1] : 0.0f;
+        csum += av;
 #pragma unroll
-        for (int s = 0; s < BK / 2; s++) {
-            float av = as[(2 * s + hh) * (BM + 1) + wave * 32 + li];
-#pragma unroll
-            for (int a = 0; a < 4; a++) {
-                float bv = bs[(2 * s + hh) * (BN + 1) + a * 32 + li];
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
-            }
+        for (int a = 0; a < NBLK; a++) {
+            float bv = (nv && cv[a]) ? bp[n * M2 + a * 32] : 0.0f;
+            acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
         }
     }
+    float *sl = slab + (int64_t)blockIdx.x * M1p * M2p;
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
-        int gc = c0 + a * 32 + li;
-        if (gc >= M2) continue;
+    for (int a = 0; a < NBLK; a++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            int go = o0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (go < M1) {
-                float *dst = c_layout == 0 ? Cout + (int64_t)go * M2 + gc : Cout + (int64_t)gc * M1 + go;
-                atomicAdd(dst, acc[a][r]);
-            }
+            int go = o0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            sl[(int64_t)go * M2p + c0 + a * 32 + li] = acc[a][r];
         }
     }
-    if (colsum && blockIdx.z == 0 && tid < BM && o0 + tid < M1) atomicAdd(colsum + o0 + tid, csum);
+    if (cs_slab && blockIdx.z == 0) {
+        csum += __uint_as_float(dgg::xor_shfl<32>(__float_as_uint(csum), lane));
+        if (hh == 0) cs_slab[(int64_t)blockIdx.x * M1p + o0 + li] = csum;
+    }
+}
+
+constexpr int GT_SPLIT = 8;
+__global__ __launch_bounds__(256) void gemm_tn_reduce(const float *__restrict__ slab, const float *__restrict__ cs_slab,
+                                                      int nchunks, int M1, int M2, int M1p, int M2p,
+                                                      float *__restrict__ Cout, int c_layout, float *__restrict__ colsum) {
+    const int e = blockIdx.x * 256 + threadIdx.x;                // element of the padded [M1p][M2p] block
+    const int per = (nchunks + GT_SPLIT - 1) / GT_SPLIT;
+    const int k0 = blockIdx.y * per, k1 = k0 + per < nchunks ? k0 + per : nchunks;
+    if (e < M1p * M2p) {
+        const int o = e / M2p, c = e % M2p;
+        if (o < M1 && c < M2) {
+            float s = 0.0f;
+            for (int k = k0; k < k1; k++) s += slab[(int64_t)k * M1p * M2p + e];
+            float *dst = c_layout == 0 ? Cout + (int64_t)o * M2 + c : Cout + (int64_t)c * M1 + o;
+            atomicAdd(dst, s);
+        }
+    }
+    if (colsum && cs_slab && e < M1) {
+        float s = 0.0f;
+        for (int k = k0; k < k1; k++) s += cs_slab[(int64_t)k * M1p + e];
+        atomicAdd(colsum + e, s);
+    }
+}
+
+int launch_linear_fwd(const float *x, int64_t N, int d, const float *W, const float *b, int out, int w_layout, int act,
+                      float *y, hipStream_t st) {
+    const unsigned gx = (unsigned)((N + BM - 1) / BM);
+    if (out <= 32)
+        hipLaunchKernelGGL(linear_fwd_mfma<1>, dim3(gx, (unsigned)((out + 31) / 32)), dim3(256), 0, st, x, N, d, W, b, out, w_layout, act, y);
+    else if (out <= 64)
+        hipLaunchKernelGGL(linear_fwd_mfma<2>, dim3(gx, (unsigned)((out + 63) / 64)), dim3(256), 0, st, x, N, d, W, b, out, w_layout, act, y);
+    else
+        hipLaunchKernelGGL(linear_fwd_mfma<4>, dim3(gx, (unsigned)((out + 127) / 128)), dim3(256), 0, st, x, N, d, W, b, out, w_layout, act, y);
+    return dgg_check_launch("linear_fwd");
+}
+
+size_t gemm_tn_ws_floats(int64_t N, int M1, int M2) {
+    const size_t nch = (size_t)((N + GT_ROWS - 1) / GT_ROWS), M1p = (size_t)(M1 + 31) / 32 * 32, M2p = (size_t)(M2 + 31) / 32 * 32;
+    return nch * M1p * M2p + nch * M1p;
+}
+
+int launch_gemm_tn(const float *A, const float *B, int64_t N, int M1, int M2, float *C, int c_layout, float *colsum,
+                   float *ws, hipStream_t st) {
+    if (!ws) return dgg_set_error(DGG_ERR_ARG, "gemm_tn: workspace is NULL (dgg_gemm_tn_ws_floats)");
+    const int nch = (int)((N + GT_ROWS - 1) / GT_ROWS), M1p = (M1 + 31) / 32 * 32, M2p = (M2 + 31) / 32 * 32;
+    float *slab = ws, *cs_slab = ws + (size_t)nch * M1p * M2p;
+    const unsigned gy = (unsigned)(M1p / 32);
+    if (M2p % 64 == 0)
+        hipLaunchKernelGGL(gemm_tn_partial<2>, dim3(nch, gy, (unsigned)(M2p / 64)), dim3(64), 0, st, A, B, N, M1, M2, M1p, M2p, slab, colsum ? cs_slab : nullptr);
+    else
+        hipLaunchKernelGGL(gemm_tn_partial<1>, dim3(nch, gy, (unsigned)(M2p / 32)), dim3(64), 0, st, A, B, N, M1, M2, M1p, M2p, slab, colsum ? cs_slab : nullptr);
+    hipLaunchKernelGGL(gemm_tn_reduce, dim3((unsigned)((M1p * M2p + 255) / 256), GT_SPLIT), dim3(256), 0, st, slab,
+                       colsum ? cs_slab : nullptr, nch, M1, M2, M1p, M2p, C, c_layout, colsum);
+    return dgg_check_launch("gemm_tn");
 }
 
 }  // namespace
@@ -177,45 +225,43 @@ int dgg_linear_fwd(const float *x, int64_t N, int d, const float *W, const float
                    float *y, void *stream) {
     if (N < 0 || d < 1 || out < 1) return dgg_set_error(DGG_ERR_ARG, "linear_fwd: bad shape");
     if (N == 0) return 0;
-    dim3 grid((unsigned)((N + BM - 1) / BM), (unsigned)((out + BN - 1) / BN));
-    hipLaunchKernelGGL(linear_fwd_mfma, grid, dim3(256), 0, (hipStream_t)stream, x, N, d, W, b, out, w_layout, act, y);
-    return dgg_check_launch("linear_fwd");
+    return launch_linear_fwd(x, N, d, W, b, out, w_layout, act, y, (hipStream_t)stream);
 }
 
-// backward of y = act(x W^T + b).  dp_ws: workspace of N*out floats.  dx (nullable) is OVERWRITTEN;
+// floats of workspace dgg_linear_bwd needs: N*out for the activation backward + the weight-gradient slab
+size_t dgg_linear_bwd_ws_floats(int64_t N, int d, int out) { return (size_t)N * out + gemm_tn_ws_floats(N, out, d); }
+size_t dgg_gemm_tn_ws_floats(int64_t N, int M1, int M2) { return gemm_tn_ws_floats(N, M1, M2); }
+
+// backward of y = act(x W^T + b).  ws: dgg_linear_bwd_ws_floats(N, d, out) floats.  dx (nullable) is OVERWRITTEN;
 // dW (layout of W) and db (nullable) are ACCUMULATED into (caller zeroes them), so that several uses of one
 // weight add up.
 int dgg_linear_bwd(const float *x, int64_t N, int d, const float *W, int out, int w_layout, int act, const float *y,
-                   const float *dy, float *dx, float *dW, float *db, float *dp_ws, void *stream) {
+                   const float *dy, float *dx, float *dW, float *db, float *ws, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (N == 0) return 0;
+    if (!ws) return dgg_set_error(DGG_ERR_ARG, "linear_bwd: workspace is NULL (dgg_linear_bwd_ws_floats)");
     const float *dp = dy;
     if (act != 0) {
         int64_t n = N * out;
         unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-        hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, st, y, dy, n, act, dp_ws);
-        dp = dp_ws;
+        hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, st, y, dy, n, act, ws);
+        dp = ws;
     }
     if (dx) {
         // dx[N,d] = dp[N,out] * W  ==  linear_fwd with the weight read in the transposed layout
-        dim3 grid((unsigned)((N + BM - 1) / BM), (unsigned)((d + BN - 1) / BN));
-        hipLaunchKernelGGL(linear_fwd_mfma, grid, dim3(256), 0, st, dp, N, out, W, (const float *)nullptr, d,
-                           w_layout == 0 ? 1 : 0, 0, dx);
+        int rc = launch_linear_fwd(dp, N, out, W, nullptr, d, w_layout == 0 ? 1 : 0, 0, dx, st);
+        if (rc != 0) return rc;
     }
-    if (dW) {
-        dim3 grid((unsigned)((N + RCH - 1) / RCH), (unsigned)((out + BM - 1) / BM), (unsigned)((d + BN - 1) / BN));
-        hipLaunchKernelGGL(gemm_tn_reduce_mfma, grid, dim3(256), 0, st, dp, x, N, out, d, dW, w_layout == 0 ? 0 : 1, db);
-    }
+    if (dW) return launch_gemm_tn(dp, x, N, out, d, dW, w_layout == 0 ? 0 : 1, db, ws + (size_t)N * out, st);
     return dgg_check_launch("linear_bwd");
 }
 
-// C[M1,M2] += A[N,M1]^T B[N,M2]  (c_layout 1: C stored [M2][M1]); colsum (nullable, [M1]) += column sums of A
+// C[M1,M2] += A[N,M1]^T B[N,M2]  (c_layout 1: C stored [M2][M1]); colsum (nullable, [M1]) += column sums of A;
+// ws: dgg_gemm_tn_ws_floats(N, M1, M2) floats
 int dgg_gemm_tn_acc(const float *A, const float *B, int64_t N, int M1, int M2, float *C, int c_layout, float *colsum,
-                    void *stream) {
+                    float *ws, void *stream) {
     if (N == 0) return 0;
-    dim3 grid((unsigned)((N + RCH - 1) / RCH), (unsigned)((M1 + BM - 1) / BM), (unsigned)((M2 + BN - 1) / BN));
-    hipLaunchKernelGGL(gemm_tn_reduce_mfma, grid, dim3(256), 0, (hipStream_t)stream, A, B, N, M1, M2, C, c_layout, colsum);
-    return dgg_check_launch("gemm_tn_acc");
+    return launch_gemm_tn(A, B, N, M1, M2, C, c_layout, colsum, ws, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -51,7 +51,7 @@ def linear_bwd(x, W, y, dy, act=ACT_NONE, w_layout=0, need_dx=True, need_db=True
     dx = torch.empty_like(x) if need_dx else None
     dW = torch.zeros_like(W)
     db = torch.zeros((out,), device=x.device, dtype=torch.float32) if need_db else None
-    ws = torch.empty((N, out), device=x.device, dtype=torch.float32) if act != ACT_NONE else None
+    ws = torch.empty((int(_lib.lib().dgg_linear_bwd_ws_floats(N, d, out)),), device=x.device, dtype=torch.float32)
     yy = _chk(y) if act != ACT_NONE else None
     _lib.check(_lib.lib().dgg_linear_bwd(_ptr(x), N, d, _ptr(W), out, w_layout, act, _ptr(yy), _ptr(dy), _ptr(dx), _ptr(dW),
                                          _ptr(db), _ptr(ws), _stream()), "linear_bwd")
@@ -65,7 +65,8 @@ def gemm_tn(A, B, colsum=False):
     M2 = B.shape[1]
     Cm = torch.zeros((M1, M2), device=A.device, dtype=torch.float32)
     cs = torch.zeros((M1,), device=A.device, dtype=torch.float32) if colsum else None
-    _lib.check(_lib.lib().dgg_gemm_tn_acc(_ptr(A), _ptr(B), N, M1, M2, _ptr(Cm), 0, _ptr(cs), _stream()), "gemm_tn_acc")
+    ws = torch.empty((int(_lib.lib().dgg_gemm_tn_ws_floats(N, M1, M2)),), device=A.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_gemm_tn_acc(_ptr(A), _ptr(B), N, M1, M2, _ptr(Cm), 0, _ptr(cs), _ptr(ws), _stream()), "gemm_tn_acc")
     return (Cm, cs) if colsum else Cm
 
 
