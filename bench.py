@@ -49,7 +49,7 @@ def make_params(d, h, dev, seed=0):
     return {k: v.detach().to(dev).contiguous() for k, v in P.items()}
 
 
-def cpu_baseline(N, d, h, P, rows, threads):
+def cpu_baseline(N, d, h, P, rows, threads, noise_mode=4):
     """The CPU oracle (oracle/dgg_oracle.c, a port of the reference's arithmetic) timed on a bounded row sample of
     the same N-node problem: `rows` output rows against all N candidate columns, forward + backward."""
     from oracle import oracle as O
@@ -67,7 +67,7 @@ def cpu_baseline(N, d, h, P, rows, threads):
     xk = O.linear(xs, Pn["Wk"], Pn["bk"], O.ACT_LEAKY)
     mu, sd = O.degree_stats(deg)
     k, z, m, u = O.knet_x(xk, deg[:R], mu, sd, Pn["W1"], Pn["b1"], Pn["Wmu"], Pn["bmu"], Pn["Wp"].reshape(-1), Pn["bp"], save=True)
-    idx, val = O.allpairs_topk(xp, K=64, noise_mode=O.NOISE_HASH, seed=(1234, 0), rows=(0, R))
+    idx, val = O.allpairs_topk(xp, K=64, noise_mode=noise_mode, seed=(1234, 0), rows=(0, R))
     w, rs_s = O.softk(idx, val, k)
     rs = np.full((N,), rs_s.mean(), np.float32)               # row sums of unsampled columns: timing-neutral filler
     rs[:R] = rs_s
@@ -112,7 +112,11 @@ def main():
     ap.add_argument("--nodes", type=int, default=100_000)
     ap.add_argument("--feat", type=int, default=128)
     ap.add_argument("--latent", type=int, default=64)
-    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 exhaustive, 2 pruned")
+    ap.add_argument("--algo", type=int, default=0, help="all-pairs kernel for --noise hash: 0 auto, 1 exhaustive, 2 MFMA-bounded, "
+                                                         "3 adaptive noise prefilter, 4 guess-and-verify")
+    ap.add_argument("--noise", choices=["ranked", "hash"], default="ranked",
+                    help="counter-based Gumbel generator: ranked (per-row order statistics, O(N*150) search) or hash "
+                         "(per-pair hash, N^2 sweep); both iid Gumbel(0,0.3)")
     ap.add_argument("--x-grad", action="store_true", help="also compute d loss / d x (reduce-scatter across ranks)")
     ap.add_argument("--no-hipgraph", dest="hipgraph", action="store_false", help="time eager launches instead of a captured hipGraph")
     ap.add_argument("--cpu-rows", type=int, default=2048, help="row sample of the cpu_baseline leg (0 = skip)")
@@ -138,7 +142,8 @@ def main():
     x_local = torch.randn(r1 - r0, d, generator=g).to(dev)
     gd = torch.Generator(device="cpu").manual_seed(7)
     deg = (24 + 16 * torch.rand(N, generator=gd)).to(dev)
-    layer = ShardedDGGConv(ops, N, group=None, K=64, noise_mode=ops.NOISE_HASH, seed=(1234, 0), algo=a.algo, x_grad=a.x_grad)
+    noise_mode = ops.NOISE_RANKED if a.noise == "ranked" else ops.NOISE_HASH
+    layer = ShardedDGGConv(ops, N, group=None, K=64, noise_mode=noise_mode, seed=(1234, 0), algo=a.algo, x_grad=a.x_grad)
 
     def step():
         Z = layer.forward(x_local, deg, P)
@@ -190,10 +195,10 @@ def main():
     xp = layer.saved["xp"]
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     reps = 5
-    ops.allpairs_topk(xp, 64, noise_mode=ops.NOISE_HASH, seed=(1234, 0), rows=(r0, r1), algo=a.algo)
+    ops.allpairs_topk(xp, 64, noise_mode=noise_mode, seed=(1234, 0), rows=(r0, r1), algo=a.algo)
     ev[0].record()
     for _ in range(reps):
-        ops.allpairs_topk(xp, 64, noise_mode=ops.NOISE_HASH, seed=(1234, 0), rows=(r0, r1), algo=a.algo)
+        ops.allpairs_topk(xp, 64, noise_mode=noise_mode, seed=(1234, 0), rows=(r0, r1), algo=a.algo)
     ev[1].record()
     torch.cuda.synchronize()
     t_pair = ev[0].elapsed_time(ev[1]) / reps * 1e-3
@@ -208,7 +213,7 @@ def main():
             "config": {"workload": f"synthetic all-pairs DGG N={N} d={d} h={h} k~{kmean:.1f} K=64, u-v-dist/x/"
                                    f"k_times_edge_prob, Gumbel(0,0.3) perturbation, + normalize + GCNConv({d},64), fwd+bwd",
                        "nodes": N, "feat": d, "latent": h, "ell_width": 64, "pairs_per_s": N * float(N) / T,
-                       "x_grad": a.x_grad, "topk_algo": a.algo, "hipgraph": graph is not None, "parallelism": f"row-shard x{world}"},
+                       "x_grad": a.x_grad, "topk_algo": a.algo, "noise": a.noise, "hipgraph": graph is not None, "parallelism": f"row-shard x{world}"},
             "roofline": {"bound": "mfma", "kernel": "allpairs_topk", "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
                          "kernel_ms": t_pair * 1e3, "flop_per_pair": FLOP_PER_PAIR,
@@ -216,7 +221,7 @@ def main():
         }
         if a.cpu_rows > 0 and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(N, d, h, P, min(a.cpu_rows, N), os.cpu_count() or 1)
+                out["cpu_baseline"] = cpu_baseline(N, d, h, P, min(a.cpu_rows, N), os.cpu_count() or 1, noise_mode)
             except Exception as e:  # the baseline leg must never take the measurement down
                 out["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}

@@ -35,6 +35,8 @@ extern "C" {
 #define DGG_NOISE_EXPLICIT 1  /* caller passes G (dense, ld = ldG): what gumbel_sample(log_p, G) takes */
 #define DGG_NOISE_HASH 2      /* counter-based Gumbel(0,0.3) keyed on (seed, i, j)                    */
 #define DGG_NOISE_HASH_SYM 3  /* keyed on (seed, min(i,j), max(i,j)), zero diagonal (dgm.py:1216-1223) */
+#define DGG_NOISE_RANKED 4    /* counter-based, same iid Gumbel(0,0.3) law, generated per row in decreasing order
+                               * (Renyi spacings + keyed column permutation): all-pairs top-K in O(N*~150) */
 
 /* activations of dgg_linear_*: */
 #define DGG_ACT_NONE 0

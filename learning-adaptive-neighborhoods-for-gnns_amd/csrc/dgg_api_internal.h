@@ -32,3 +32,6 @@ int dgg_allpairs_topk_gv_impl(const float *xp, int64_t N, int h, int64_t row0, i
                               hipStream_t st);
 size_t dgg_allpairs_gv_ws_bytes(int64_t rows);
 bool dgg_allpairs_gv_supported(int h, int noise_mode, int K);
+
+int dgg_allpairs_topk_ranked_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0,
+                                  uint32_t s1, int K, int32_t *idx, float *val, hipStream_t st);

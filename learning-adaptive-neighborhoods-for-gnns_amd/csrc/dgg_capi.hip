@@ -28,9 +28,11 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
                       void *workspace, size_t ws_bytes, void *stream) {
     if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
     if (row0 < 0 || row1 > N || row0 > row1) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk: bad row range");
-    if (noise_mode < 0 || noise_mode > 3) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk: bad noise_mode");
+    if (noise_mode < 0 || noise_mode > 4) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk: bad noise_mode");
     if (noise_mode == 1 && !G) return dgg_set_error(DGG_ERR_ARG, "explicit noise requested but G is NULL");
     hipStream_t st = (hipStream_t)stream;
+    if (noise_mode == 4)   // ranked generator: the row-wise early-stopping search is the only (and exact) evaluator
+        return dgg_allpairs_topk_ranked_impl(xp, N, h, row0, row1, t, s0, s1, K, idx, val, st);
     const bool can_fast = dgg_allpairs_fast_supported(h, noise_mode, K) && workspace &&
                           ws_bytes >= dgg_allpairs_fast_ws_bytes(N, h);
     const bool can_np = dgg_allpairs_np_supported(h, noise_mode, K) && workspace && ws_bytes >= dgg_allpairs_np_ws_bytes(N);

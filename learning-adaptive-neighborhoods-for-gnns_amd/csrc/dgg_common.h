@@ -130,6 +130,34 @@ __device__ __forceinline__ float pair_noise(uint32_t s0, uint32_t s1, uint32_t i
     return gumbel_u24(pair_u24(s0, s1, i, j, symmetric));
 }
 
+// ---- "ranked" counter-based noise (noise_mode 4): same iid Gumbel(0,0.3) law, generated per row in decreasing
+// order.  -log U_(s) = sum_{t<=s} E_t/(N-t+1) (Renyi), prefix sums in exact 2^-40 fixed point (order-independent);
+// rank s sits at column sigma_i(r'), the s-th element < N of a keyed bijection of [0, 2^b) walked in order.
+__device__ __forceinline__ int ranked_bits(int64_t N) { int b = 6; while (((int64_t)1 << b) < N) b++; return b; }
+__device__ __forceinline__ uint32_t ranked_sigma(uint32_t r, uint32_t k1, uint32_t k2, uint32_t k3, int b) {
+    const uint32_t mask = (b >= 32) ? 0xffffffffu : ((1u << b) - 1u);
+    const int hb = (b + 1) / 2;
+    uint32_t x = (r ^ k1) & mask;
+    x = (x * 0x9E3779B1u) & mask; x ^= x >> hb;
+    x = (x + k2) & mask; x = (x * 0x85EBCA77u) & mask; x ^= x >> hb;
+    x = (x * 0xC2B2AE3Du + k3) & mask; x ^= x >> hb;
+    return x;
+}
+__device__ __forceinline__ uint64_t ranked_term(uint32_t k1, uint32_t k3, uint32_t s, int64_t N) {   // s: 1-based rank
+    uint32_t v = mix32(mix32(s + k3) ^ k1) >> 8;
+    if (v == 0) v = 1;
+    float V = __fmul_rn((float)v, 5.9604644775390625e-8f);
+    float E = -c_log(V);
+    float term = __fdiv_rn(E, (float)(N - (int64_t)s + 1));
+    return (uint64_t)__fmul_rn(term, 1099511627776.0f);         // floor(term * 2^40), exact
+}
+__device__ __forceinline__ float ranked_gumbel(uint64_t S) {
+    uint32_t q = (uint32_t)(S >> 16);
+    if (q == 0) q = 1;
+    float L = __fmul_rn((float)q, 5.9604644775390625e-8f);
+    return __fmul_rn(-0.3f, c_log(L));
+}
+
 // score of a pair given the distance (reference dgm.py:1623, 1213-1229)
 __device__ __forceinline__ float score_from_dist(float dist, float t, bool perturb, float G) {
     float p = c_exp(__fmul_rn(t, dist));

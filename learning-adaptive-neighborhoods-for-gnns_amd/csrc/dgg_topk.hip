@@ -196,6 +196,8 @@ int dgg_edgelist_topk(const float *xp, int64_t N, int h, const int64_t *rowptr, 
                       float *val, void *stream) {
     if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
     if (noise_mode == 1 && !G) return dgg_set_error(DGG_ERR_ARG, "explicit noise requested but G is NULL");
+    if (noise_mode < 0 || noise_mode > 3)
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "edgelist_topk: noise_mode must be none / explicit / hash / symmetric hash");
     if (N == 0) return 0;
     hipLaunchKernelGGL(edgelist_topk_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, xp, N, h,
                        rowptr, col, t, noise_mode, G, ldG, s0, s1, K, idx, val);

@@ -120,7 +120,9 @@ class DGG_LearnableK_debug(nn.Module):
         if seed is None:   # fresh noise per forward, reproducible under torch.manual_seed (CPU generator: no sync)
             s = torch.randint(0, 2 ** 31 - 1, (2,))
             seed = (int(s[0]), int(s[1]))
-        return (ops.NOISE_HASH_SYM if self.args.symmetric_noise else ops.NOISE_HASH), None, seed
+        # asymmetric noise: the ranked generator (rows produced in decreasing order -> early-stopping top-k search);
+        # symmetric noise (dgm.py:1216-1223) must be keyed on the unordered pair -> per-pair hash
+        return (ops.NOISE_HASH_SYM if self.args.symmetric_noise else ops.NOISE_RANKED), None, seed
 
     def forward(self, x, in_adj, noise=True, writer=None, epoch=None):
         """x [N,dim] fp32 on the GPU; in_adj: sparse COO [N,N] (coalesced, self loops added by the caller) whose

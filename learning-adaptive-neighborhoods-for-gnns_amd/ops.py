@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 
-NOISE_NONE, NOISE_EXPLICIT, NOISE_HASH, NOISE_HASH_SYM = 0, 1, 2, 3
+NOISE_NONE, NOISE_EXPLICIT, NOISE_HASH, NOISE_HASH_SYM, NOISE_RANKED = 0, 1, 2, 3, 4
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 MODE_K_TIMES_EDGE_PROB, MODE_K_ONLY = 0, 1
 DEFAULT_K = 64

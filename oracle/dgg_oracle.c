@@ -143,6 +143,58 @@ ORA_API float ora_noise(uint32_t s0, uint32_t s1, uint32_t i, uint32_t j, int sy
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* "ranked" counter-based noise (noise_mode 4): the same iid Gumbel(0,0.3) law, generated per  */
+/* row in DECREASING order so that a top-k search can stop early.                              */
+/*   - the order statistics U_(1) >= U_(2) >= ... of N iid uniforms satisfy (Renyi)            */
+/*         -log U_(s) = sum_{t<=s} E_t / (N - t + 1),   E_t iid Exp(1)                          */
+/*     the prefix sums are kept in exact 64-bit fixed point (2^-40), so their value does not   */
+/*     depend on the summation order (sequential here, wavefront scan on the GPU);             */
+/*   - rank s is assigned to column sigma_i(r'), the s-th element < N of a keyed bijection of  */
+/*     [0, 2^b) walked in order r' = 0, 1, 2, ... (b = ceil(log2 N)): a pseudo-random          */
+/*     permutation per row, independent of the values, hence the row is iid again.             */
+/* ------------------------------------------------------------------------------------------ */
+static inline int ranked_bits(int64_t N) { int b = 6; while (((int64_t)1 << b) < N) b++; return b; }
+static inline uint32_t ranked_sigma(uint32_t r, uint32_t k1, uint32_t k2, uint32_t k3, int b) {
+    const uint32_t mask = (b >= 32) ? 0xffffffffu : ((1u << b) - 1u);
+    const int hb = (b + 1) / 2;
+    uint32_t x = (r ^ k1) & mask;
+    x = (x * 0x9E3779B1u) & mask; x ^= x >> hb;
+    x = (x + k2) & mask; x = (x * 0x85EBCA77u) & mask; x ^= x >> hb;
+    x = (x * 0xC2B2AE3Du + k3) & mask; x ^= x >> hb;
+    return x;
+}
+static inline uint64_t ranked_term(uint32_t k1, uint32_t k3, uint32_t s, int64_t N) {   /* s = 1-based rank */
+    uint32_t v = mix32(mix32(s + k3) ^ k1) >> 8;
+    if (v == 0) v = 1;
+    float V = (float)v * 5.9604644775390625e-8f;
+    float E = -ora_log(V);
+    float term = E / (float)(N - (int64_t)s + 1);
+    return (uint64_t)(term * 1099511627776.0f);                 /* floor(term * 2^40), exact */
+}
+static inline float ranked_gumbel(uint64_t S) {                 /* S = fixed-point prefix sum */
+    uint32_t q = (uint32_t)(S >> 16);
+    if (q == 0) q = 1;
+    float L = (float)q * 5.9604644775390625e-8f;                /* -log U_(s), resolution 2^-24 */
+    return -0.3f * ora_log(L);
+}
+/* noise of row i for every column: G[j], j < N */
+ORA_API void ora_ranked_row(uint32_t s0, uint32_t s1, uint32_t i, int64_t N, float *G) {
+    uint32_t k1, k2;
+    ora_rowkey(s0, s1, i, &k1, &k2);
+    const uint32_t k3 = mix32(k2 ^ 0x68E31DA4u);
+    const int b = ranked_bits(N);
+    uint64_t S = 0;
+    uint32_t s = 0;
+    for (uint64_t r = 0; r < ((uint64_t)1 << b); r++) {
+        uint32_t c = ranked_sigma((uint32_t)r, k1, k2, k3, b);
+        if ((int64_t)c >= N) continue;
+        s++;
+        S += ranked_term(k1, k3, s, N);
+        G[c] = ranked_gumbel(S);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* dense layers: acc = 0; acc = fmaf(x_c, w_c, acc) for c ascending; + bias; activation        */
 /* (nn.Linear + LeakyReLU dgm.py:1097-1100, 1123-1130; GCNConv mm model.py:594-598)            */
 /* act: 0 none, 1 leaky_relu(0.01), 2 relu.  w_layout 0: W[out][in] (nn.Linear), 1: W[in][out] */
@@ -314,7 +366,7 @@ static void topk_insert(cand_t *list, int *cnt, int K, float v, int32_t j) {
     if (n < K) *cnt = n + 1;
 }
 
-/* noise_mode: 0 none (perturb_edge_prob False), 1 explicit G (row-major [N][N], row i at G + i*N),
+/* noise_mode: 0 none (perturb_edge_prob False), 1 explicit G (row-major [N][N], row i at G + i*N), 4 ranked counter-based,
  *             2 counter-based (s0,s1), 3 counter-based symmetric */
 ORA_API void ora_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t,
                                int noise_mode, const float *G, uint32_t s0, uint32_t s1,
@@ -323,13 +375,17 @@ ORA_API void ora_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, 
     for (int64_t i = row0; i < row1; i++) {
         cand_t list[512];
         int cnt = 0;
+        float *grow = NULL;
+        if (noise_mode == 4) { grow = (float *)malloc(sizeof(float) * (size_t)N); ora_ranked_row(s0, s1, (uint32_t)i, N, grow); }
         for (int64_t j = 0; j < N; j++) {
             float g = 0.0f;
             if (noise_mode == 1) g = G[i * N + j];
+            else if (noise_mode == 4) g = grow[j];
             else if (noise_mode >= 2) g = ora_noise(s0, s1, (uint32_t)i, (uint32_t)j, noise_mode == 3);
             float v = ora_pair_score(xp + i * h, xp + j * h, h, t, noise_mode != 0, g);
             topk_insert(list, &cnt, K, v, (int32_t)j);
         }
+        free(grow);
         for (int r = 0; r < K; r++) {
             idx[(i - row0) * K + r] = r < cnt ? list[r].j : -1;
             val[(i - row0) * K + r] = r < cnt ? list[r].v : 0.0f;

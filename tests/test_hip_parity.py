@@ -83,6 +83,24 @@ def test_allpairs_topk_bit_exact(dev, N, h, noise, algo):
     assert np.array_equal(Nn(val), rval), "scores differ from the oracle"
 
 
+@pytest.mark.parametrize("N,h", [(1, 16), (63, 8), (64, 16), (300, 32), (1000, 64), (4097, 64), (777, 128)])
+def test_allpairs_topk_ranked_noise_bit_exact(dev, N, h):
+    """ranked noise generator (noise_mode 4): the early-stopping row search on the GPU against the oracle, which
+    generates each row's full noise vector and scores every column"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(11)
+    xp = rng.standard_normal((N, h)).astype(np.float32)
+    xp[xp < 0] *= 0.01
+    idx, val = ops.allpairs_topk(T(xp, dev), K, noise_mode=ops.NOISE_RANKED, seed=(31, 7))
+    ridx, rval = O.allpairs_topk(xp, K=K, noise_mode=O.NOISE_RANKED, seed=(31, 7))
+    assert np.array_equal(Nn(idx), ridx), "top-k indices differ from the oracle"
+    assert np.array_equal(Nn(val), rval), "scores differ from the oracle"
+    # row sharding: the ranked generator is keyed on the global row id
+    if N > 100:
+        sub_i, sub_v = ops.allpairs_topk(T(xp, dev), K, noise_mode=ops.NOISE_RANKED, seed=(31, 7), rows=(N // 3, N // 3 + 50))
+        assert np.array_equal(Nn(sub_i), ridx[N // 3:N // 3 + 50]) and np.array_equal(Nn(sub_v), rval[N // 3:N // 3 + 50])
+
+
 def test_allpairs_row_range_and_ties(dev):
     """row sharding (rows [r0,r1) of the full problem) and exact score ties (duplicate nodes -> lower column first)"""
     from dgg_amd import ops
