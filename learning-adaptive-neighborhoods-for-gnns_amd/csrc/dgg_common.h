@@ -177,6 +177,12 @@ __device__ __forceinline__ int32_t key_col(uint64_t k) { return 0x7fffffff - (in
 // zero score at a larger column, which cannot exist.
 #define DGG_EMPTY_KEY 0ull
 
+// broadcast from a WAVE-UNIFORM lane index: v_readlane (scalar path) instead of a ds_bpermute round trip
+__device__ __forceinline__ float bcast(float v, int uniform_lane) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), uniform_lane));
+}
+__device__ __forceinline__ int32_t bcast(int32_t v, int uniform_lane) { return __builtin_amdgcn_readlane(v, uniform_lane); }
+
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     lo = __shfl(lo, src, 64);

@@ -68,8 +68,8 @@ __global__ __launch_bounds__(WPB * 64) void spmm_fwd_kernel(const int32_t *__res
 #pragma unroll
     for (int v = 0; v < VEC; v++) acc[v] = 0.0f;
     for (int r = 0; r < K; r++) {
-        int32_t j = __shfl(jl, r, 64);
-        float a = __shfl(al, r, 64);
+        int32_t j = bcast(jl, r);
+        float a = bcast(al, r);
         if (j < 0 || a == 0.0f) continue;            // wave-uniform; fmaf(0, x, acc) == acc
         if (c0 < F) {
             const float *xr = X + (int64_t)j * F + c0;
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(WPB * 64) void spmm_bwd_kernel(const int32_t *__res
         if (lane + 192 < F) g3 = dY[i * F + lane + 192];
     }
     for (int r = 0; r < K; r++) {
-        int32_t j = __shfl(jl, r, 64);
-        float a = __shfl(al, r, 64);
+        int32_t j = bcast(jl, r);
+        float a = bcast(al, r);
         if (j < 0 || (skip_zero && a == 0.0f)) continue;       // wave-uniform
         float part = 0.0f;
         const float *xr = X + (int64_t)j * F;
@@ -219,10 +219,10 @@ __global__ __launch_bounds__(WPB * 64) void edge_bwd_kernel(const float *__restr
     float xi1 = c1 < h ? xp[gi * h + c1] : 0.0f;
     float acc0 = 0.0f, acc1 = 0.0f;
     for (int r = 0; r < K; r++) {
-        int32_t j = __shfl(jl, r, 64);
-        float g = __shfl(gl, r, 64);
+        int32_t j = bcast(jl, r);
+        float g = bcast(gl, r);
         if (j < 0 || g == 0.0f) continue;
-        float v = __shfl(vl, r, 64);
+        float v = bcast(vl, r);
         float d0 = c0 < h ? xi0 - xp[(int64_t)j * h + c0] : 0.0f;
         float d1 = c1 < h ? xi1 - xp[(int64_t)j * h + c1] : 0.0f;
         float d2 = d0 * d0 + d1 * d1;

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(WPB * 64) void knet_x_fwd_kernel(
         float acc = 0.0f;
         const float *wrow = sW1 + (lane < h2 ? lane : 0) * (h + 1);
         for (int c = 0; c < h; c++) {
-            float xv = c < 64 ? __shfl(x0, c, 64) : __shfl(x1, c - 64, 64);
+            float xv = c < 64 ? bcast(x0, c) : bcast(x1, c - 64);
             acc = __fmaf_rn(xv, wrow[c], acc);
         }
         acc = __fmaf_rn(nd, wrow[h], acc);
@@ -77,11 +77,11 @@ __global__ __launch_bounds__(WPB * 64) void knet_x_fwd_kernel(
         // m_o, o = lane < h4
         float am = 0.0f;
         const float *mrow = sWmu + (lane < h4 ? lane : 0) * h2;
-        for (int c = 0; c < h2; c++) am = __fmaf_rn(__shfl(z, c, 64), mrow[c], am);
+        for (int c = 0; c < h2; c++) am = __fmaf_rn(bcast(z, c), mrow[c], am);
         float m = __fadd_rn(am, lane < h4 ? bmu[lane] : 0.0f);
         // kp
         float ak = 0.0f;
-        for (int c = 0; c < h4; c++) ak = __fmaf_rn(__shfl(m, c, 64), Wp[c], ak);
+        for (int c = 0; c < h4; c++) ak = __fmaf_rn(bcast(m, c), Wp[c], ak);
         float kp = __fadd_rn(ak, bp[0]);
         float u = __fadd_rn(__fmul_rn(kp, sd), mu);
         if (lane == 0) {
@@ -110,19 +110,19 @@ __global__ __launch_bounds__(WPB * 64) void knet_x_bwd_kernel(
         // recompute m (needed by the k_project weight gradient)
         float am = 0.0f;
         const float *mrow = sWmu + (lane < h4 ? lane : 0) * h2;
-        for (int c = 0; c < h2; c++) am = __fmaf_rn(__shfl(zl, c, 64), mrow[c], am);
+        for (int c = 0; c < h2; c++) am = __fmaf_rn(bcast(zl, c), mrow[c], am);
         if (lane < h4) m_out[i * h4 + lane] = __fadd_rn(am, bmu[lane]);
         float dm = lane < h4 ? dkp * Wp[lane] : 0.0f;
         if (lane < h4) dm_out[i * h4 + lane] = dm;
         // dz_c = sum_o dm_o Wmu[o][c], c = lane < h2
         float dz = 0.0f;
-        for (int o = 0; o < h4; o++) dz = fmaf(__shfl(dm, o, 64), sWmu[o * h2 + (lane < h2 ? lane : 0)], dz);
+        for (int o = 0; o < h4; o++) dz = fmaf(bcast(dm, o), sWmu[o * h2 + (lane < h2 ? lane : 0)], dz);
         float dp1 = lane < h2 ? (zl > 0.0f ? dz : 0.01f * dz) : 0.0f;
         if (lane < h2) dpre1_out[i * h2 + lane] = dp1;
         // dxk_c = sum_o dp1_o W1[o][c]
         float a0 = 0.0f, a1 = 0.0f;
         for (int o = 0; o < h2; o++) {
-            float g = __shfl(dp1, o, 64);
+            float g = bcast(dp1, o);
             if (lane < h) a0 = fmaf(g, sW1[o * (h + 1) + lane], a0);
             if (lane + 64 < h) a1 = fmaf(g, sW1[o * (h + 1) + lane + 64], a1);
         }

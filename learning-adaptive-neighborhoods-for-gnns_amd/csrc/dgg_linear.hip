@@ -135,16 +135,23 @@ __global__ __launch_bounds__(64) void gemm_tn_partial(const float *__restrict__ 
     float csum = 0.0f;
     const float *ap = A + o0 + li;
     const float *bp = B + c0 + li;
-#pragma unroll 4
-    for (int64_t nb = r0; nb < r1; nb += 2) {                    // k-step = 2 node rows (one per lane half)
-        const int64_t n = nb + hh;
-        const bool nv = n < r1;
-        float av = (nv && ov) ? ap[n * M1] : 0.0f;
-        csum += av;
+    // k-step = 2 node rows (one per lane half); PF k-steps are loaded together so that their latencies overlap
+    constexpr int PF = 8;
+    for (int64_t nb = r0; nb < r1; nb += 2 * PF) {
+        float av[PF], bv[PF][NBLK];
 #pragma unroll
-        for (int a = 0; a < NBLK; a++) {
-            float bv = (nv && cv[a]) ? bp[n * M2 + a * 32] : 0.0f;
-            acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
+        for (int u = 0; u < PF; u++) {
+            const int64_t n = nb + 2 * u + hh;
+            const bool nv = n < r1;
+            av[u] = (nv && ov) ? ap[n * M1] : 0.0f;
+#pragma unroll
+            for (int a = 0; a < NBLK; a++) bv[u][a] = (nv && cv[a]) ? bp[n * M2 + a * 32] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            csum += av[u];
+#pragma unroll
+            for (int a = 0; a < NBLK; a++) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][a], acc[a], 0, 0, 0);
         }
     }
     float *sl = slab + (int64_t)blockIdx.x * M1p * M2p;
