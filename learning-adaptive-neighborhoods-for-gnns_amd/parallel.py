@@ -83,6 +83,7 @@ class ShardedDGGConv:
         if self.world > 1:
             dist.all_reduce(da, group=self.group)
         dval, dk = kern.softk_bwd(s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.mode, True)
+        s["dval"] = dval                                 # kept for diagnostics (bench.py times edge_bwd alone)
         dxp = kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0)
         dX1, g["We"], g["be"] = kern.linear_bwd(s["X"], P["We"], s["xp"], dxp, 1, 0, self.x_grad, True)
         dxk, g["W1"], g["b1"], g["Wmu"], g["bmu"], dWp, g["bp"] = kern.knet_x_bwd(
