@@ -224,3 +224,65 @@ if __name__ == "__main__":
         allpairs_cases()
     if "conv" in which:
         conv_cases()
+
+
+def model_cases():
+    """End-to-end eval-mode forwards/backwards of the reference's *_DGG wrappers (model.py:1183-1311, 649-740,
+    887-965) on a small synthetic graph with explicit (captured) noise."""
+    N, d, h, C = 128, 20, 16, 5
+    gen = torch.Generator().manual_seed(10)
+    A = random_graph(N, 10, gen)                       # includes self loops; the wrappers add them again (model.py:1249)
+    A = (A.to_dense() - torch.eye(N)).to_sparse().coalesce()
+    x = torch.rand(N, d, generator=gen)
+    # Pick a noise seed whose reference scores have no near-tie (relative gap < 4e-6) among the ranks that carry ramp
+    # weight: a near-tie is ordered by last-bit rounding, which legitimately differs between the reference's torch
+    # kernels and the canonical arithmetic (SURVEY section 7), and at model level a swapped pair moves outputs by ~1e-3.
+    def min_gap(seed):
+        Gs = torch.from_numpy(grid_gumbel(seed, (N, N)))
+        a = base_args()
+        torch.manual_seed(4321)
+        m = refmodel.GCN_DGG(nfeat=d, nlayers=2, nhidden=h, nclass=C, args=a)
+        m.eval()
+        cap = {}
+        dg = m.dggs[0]
+        dg.gumbel.sample = lambda shape: Gs.reshape(shape)
+        _sel = dg.select_top_k
+        dg.select_top_k = lambda Nn, k, pert, **kw: (cap.update(p=pert.detach().squeeze(0)), _sel(Nn, k, pert, **kw))[1]
+        m(x, A)
+        s = torch.sort(cap["p"], dim=-1, descending=True).values[:, :26]
+        return float(((s[:, :-1] - s[:, 1:]) / s[:, :-1]).min())
+    seed = next(sd for sd in range(51, 200) if min_gap(sd) > 4e-6)
+    G = grid_gumbel(seed, (N, N))
+    cot = torch.from_numpy(grid_normal(52, (N, C)))
+    for name, ctor in [
+        ("model_gcn_dgg", lambda a: refmodel.GCN_DGG(nfeat=d, nlayers=2, nhidden=h, nclass=C, args=a)),
+        ("model_gcnii_dgg", lambda a: refmodel.GCNII_DGG(nfeat=d, nlayers=3, nhidden=h, nclass=C, dropout=0.5, lamda=0.5,
+                                                         alpha=0.1, variant=False, args=a)),
+        ("model_gcniippi_dgg", lambda a: refmodel.GCNIIppi_DGG(nfeat=d, nlayers=3, nhidden=h, nclass=C, dropout=0.5,
+                                                               lamda=0.5, alpha=0.1, variant=True, args=a)),
+    ]:
+        a = base_args()
+        torch.manual_seed(4321)
+        m = ctor(a)
+        m.eval()
+        Gt = torch.from_numpy(G)
+        for dg in m.dggs:
+            dg.gumbel.sample = lambda shape, Gt=Gt: Gt.reshape(shape)
+        out = m(x, A)
+        logp = out[0] if isinstance(out, tuple) else out
+        (logp * cot).sum().backward()
+        extra = {"unnorm": out[1].detach().to_dense().numpy()} if isinstance(out, tuple) else {}
+        fx = {**extra, "x": x.numpy(), "rows": A.indices()[0].numpy().astype(np.int32), "cols": A.indices()[1].numpy().astype(np.int32),
+              "adj_vals": A.values().numpy(), "G": G, "cot": cot.numpy(), "out": logp.detach().numpy()}
+        for k_, v in m.state_dict().items():
+            fx["p." + k_] = v.detach().numpy()
+        for k_, p in m.named_parameters():
+            fx["g." + k_] = p.grad.numpy() if p.grad is not None else np.zeros_like(p.detach().numpy())
+        meta = dict(name=name, N=N, d=d, h=h, C=C, torch=torch.__version__, args=vars(a))
+        fx["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+        print(name, "ok", tuple(logp.shape))
+
+
+if __name__ == "__main__" and "models" in (sys.argv[1:] or ["models"]):
+    model_cases()
