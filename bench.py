@@ -8,7 +8,8 @@ One step = one pass of the hot path over the whole graph: node projection (MFMA)
 all-pairs Gumbel-perturbed scores + per-row top-64 -> smooth first-k ramp -> D^-1/2 A D^-1/2 -> A X W (+relu),
 then the full backward with a ones cotangent (all DGG parameters + conv weight; the input features are data, as in
 the reference's training loop, unless --x-grad).  Inputs are resident in HBM before the timed region.
-Multi-GPU (torchrun, one rank per GPU, RCCL): rows are sharded by node range, STRONG scaling at fixed N.
+Multi-GPU (torchrun, one rank per GPU, RCCL): rows are sharded by node range; WEAK scaling by default (--nodes rows
+per GPU, graph of --nodes * GPUs nodes), --strong for a fixed graph.
 
 Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (dominant kernel) and `cpu_baseline`.
 """
@@ -129,6 +130,9 @@ def main():
                     help="counter-based Gumbel generator: ranked (per-row order statistics, O(N*150) search) or hash "
                          "(per-pair hash, N^2 sweep); both iid Gumbel(0,0.3)")
     ap.add_argument("--x-grad", action="store_true", help="also compute d loss / d x (reduce-scatter across ranks)")
+    ap.add_argument("--strong", action="store_true",
+                    help="multi-GPU: keep the graph at --nodes nodes in total (default: --nodes nodes PER GPU, weak scaling; "
+                         "with the O(N*K) pair search a rank's work depends on its rows, not on the total column count)")
     ap.add_argument("--no-hipgraph", dest="hipgraph", action="store_false", help="time eager launches instead of a captured hipGraph")
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="row sample of the cpu_baseline leg: 0 = auto (64 rows per host core, ~10-20 s), <0 = skip")
@@ -147,7 +151,8 @@ def main():
     from dgg_amd import ops
     from dgg_amd.parallel import ShardedDGGConv, shard_bounds
 
-    N, d, h = a.nodes, a.feat, a.latent
+    # weak scaling (default): every GPU owns --nodes rows of an (--nodes * world)-node graph; --strong keeps N fixed
+    N, d, h = (a.nodes if a.strong else a.nodes * world), a.feat, a.latent
     P = make_params(d, h, dev)
     r0, r1, _ = shard_bounds(N, world, rank)
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
@@ -240,7 +245,7 @@ def main():
         out = {
             "metric": "DGG adj-build+SpMM fwd/bwd selected-edges/s", "value": N * kmean / T, "unit": "edges/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": T * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if a.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic all-pairs DGG N={N} d={d} h={h} k~{kmean:.1f} K=64, u-v-dist/x/"
                                    f"k_times_edge_prob, Gumbel(0,0.3) perturbation, + normalize + GCNConv({d},64), fwd+bwd",
                        "nodes": N, "feat": d, "latent": h, "ell_width": 64, "pairs_per_s": N * float(N) / T,
