@@ -141,6 +141,53 @@ __global__ __launch_bounds__(WPB * 64) void spmm_bwd_kernel(const int32_t *__res
     if (lane < K) dA[i * K + lane] = mine;
 }
 
+// SDDMM only (no dX), F = 128*NV4: TWO neighbours per wave-instruction.  Each 32-lane half owns one neighbour and each
+// lane 4*NV4 features (16-byte loads: a 128-feature row is one 512-byte coalesced segment per half), so the per-edge
+// reduction is a 5-step DPP butterfly inside the half and the instruction count per edge halves.
+template <int NV4>
+__global__ __launch_bounds__(WPB * 64) void sddmm_pair_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
+                                                             const float *__restrict__ X, const float *__restrict__ dY,
+                                                             int64_t N, int K, int skip_zero, float *__restrict__ dA) {
+    constexpr int F = 128 * NV4;
+    const int lane = threadIdx.x & 63, sub = lane & 31, hh = lane >> 5;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    int32_t jl = lane < K ? idx[i * K + lane] : -1;
+    float al = lane < K ? ahat[i * K + lane] : 0.0f;
+    float4 g[NV4];
+#pragma unroll
+    for (int q = 0; q < NV4; q++) g[q] = *reinterpret_cast<const float4 *>(dY + i * F + q * 128 + sub * 4);
+    float mine = 0.0f;
+    for (int r = 0; r < K; r += 2) {
+        const int32_t j0 = bcast(jl, r), j1 = bcast(jl, r + 1 < 64 ? r + 1 : 63);
+        const float a0 = bcast(al, r), a1 = bcast(al, r + 1 < 64 ? r + 1 : 63);
+        const bool v0 = j0 >= 0 && !(skip_zero && a0 == 0.0f);
+        const bool v1 = r + 1 < K && j1 >= 0 && !(skip_zero && a1 == 0.0f);
+        if (!v0 && !v1) continue;                                // wave-uniform
+        const int32_t j = hh ? j1 : j0;
+        const bool v = hh ? v1 : v0;
+        float part = 0.0f;
+        if (v) {
+            const float *xr = X + (int64_t)j * F + sub * 4;
+#pragma unroll
+            for (int q = 0; q < NV4; q++) {
+                float4 xv = *reinterpret_cast<const float4 *>(xr + q * 128);
+                part = fmaf(g[q].x, xv.x, part); part = fmaf(g[q].y, xv.y, part);
+                part = fmaf(g[q].z, xv.z, part); part = fmaf(g[q].w, xv.w, part);
+            }
+        }
+        part += __uint_as_float(xor_shfl<16>(__float_as_uint(part), lane));
+        part += __uint_as_float(xor_shfl<8>(__float_as_uint(part), lane));
+        part += __uint_as_float(xor_shfl<4>(__float_as_uint(part), lane));
+        part += __uint_as_float(xor_shfl<2>(__float_as_uint(part), lane));
+        part += __uint_as_float(xor_shfl<1>(__float_as_uint(part), lane));
+        const float t0 = bcast(part, 0), t1 = bcast(part, 32);
+        if (lane == r) mine = t0;
+        if (lane == r + 1) mine = t1;
+    }
+    if (lane < K) dA[i * K + lane] = mine;
+}
+
 // normalisation backward, phase 1: da[i] += sum_r dA_ir w_ir a_j ;  da[j] += dA_ir w_ir a_i   (da zeroed by caller)
 __global__ __launch_bounds__(WPB * 64) void norm_bwd_da_kernel(const int32_t *__restrict__ idx, const float *__restrict__ w,
                                                               const float *__restrict__ rs, const float *__restrict__ dA,
@@ -290,8 +337,14 @@ int dgg_ell_spmm_bwd(const int32_t *idx, const float *ahat, const float *X, cons
                      int skip_zero, float *dA, float *dX, void *stream) {
     if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
     if (N == 0) return 0;
-    hipLaunchKernelGGL(spmm_bwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, idx, ahat, X, dY, N, K,
-                       F, skip_zero, dA, dX);
+    hipStream_t st = (hipStream_t)stream;
+    const bool al16 = (reinterpret_cast<uintptr_t>(X) % 16 == 0) && (reinterpret_cast<uintptr_t>(dY) % 16 == 0);
+    if (!dX && al16 && F == 128)
+        hipLaunchKernelGGL(sddmm_pair_kernel<1>, dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, N, K, skip_zero, dA);
+    else if (!dX && al16 && F == 256)
+        hipLaunchKernelGGL(sddmm_pair_kernel<2>, dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, N, K, skip_zero, dA);
+    else
+        hipLaunchKernelGGL(spmm_bwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, N, K, F, skip_zero, dA, dX);
     return dgg_check_launch("ell_spmm_bwd");
 }
 

@@ -43,13 +43,26 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma(const float *__restrict__
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[a][r] = 0.0f;
     const int li = lane & 31, hh = lane >> 5;
+    const bool vec4 = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);   // wave-uniform
     for (int k0 = 0; k0 < d; k0 += BK) {
         __syncthreads();
-        for (int e = tid; e < BM * BK; e += 256) {
-            int r = e / BK, c = e % BK;
-            int64_t gi = m0 + r;
-            int gk = k0 + c;
-            xs[r * LDP + c] = (gi < N && gk < d) ? x[gi * d + gk] : 0.0f;
+        if (vec4) {   // 16-byte loads: 8 lanes cover one 128-byte row segment
+#pragma unroll
+            for (int q = 0; q < BM * BK / 4 / 256; q++) {
+                const int e = tid + q * 256, r = e >> 3, c4 = (e & 7) * 4;
+                const int64_t gi = m0 + r;
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (gi < N && k0 + c4 < d) v = *reinterpret_cast<const float4 *>(x + gi * d + k0 + c4);
+                float *dst = xs + r * LDP + c4;
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            }
+        } else {
+            for (int e = tid; e < BM * BK; e += 256) {
+                int r = e / BK, c = e % BK;
+                int64_t gi = m0 + r;
+                int gk = k0 + c;
+                xs[r * LDP + c] = (gi < N && gk < d) ? x[gi * d + gk] : 0.0f;
+            }
         }
         if (w_layout == 0) {
             for (int e = tid; e < BN * BK; e += 256) {
@@ -113,7 +126,7 @@ __global__ void act_bwd_kernel(const float *__restrict__ y, const float *__restr
 // segments, so they are loaded straight from global memory: no LDS, no barriers.  Partial blocks go to a slab
 // [chunk][M1p][M2p] with plain stores -- NOT atomics: every chunk would hit the same few KB of C, and same-address fp32
 // atomics run ~14x below the streaming atomic rate (MI355X_MICROARCH.md, "Global float atomics").
-// Stage 2: gemm_tn_reduce sums the slab over chunks (8-way split, 8 atomics per output) into C / colsum.
+// Stage 2: gemm_tn_reduce sums the slab over chunks (32-way split, 32 atomics per output) into C / colsum.
 constexpr int GT_ROWS = 256;
 template <int NBLK>
 __global__ __launch_bounds__(64) void gemm_tn_partial(const float *__restrict__ A, const float *__restrict__ B, int64_t N,
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(64) void gemm_tn_partial(const float *__restrict__ 
     }
 }
 
-constexpr int GT_SPLIT = 8;
+constexpr int GT_SPLIT = 32;
 __global__ __launch_bounds__(256) void gemm_tn_reduce(const float *__restrict__ slab, const float *__restrict__ cs_slab,
                                                       int nchunks, int M1, int M2, int M1p, int M2p,
                                                       float *__restrict__ Cout, int c_layout, float *__restrict__ colsum) {

@@ -207,6 +207,15 @@ def test_ell_backward_kernels(dev):
     rdA, rdX = O.spmm_bwd(idx, ahat, X, dY)
     np.testing.assert_allclose(Nn(dA), rdA, rtol=1e-4, atol=1e-4 * np.abs(rdA).max())
     np.testing.assert_allclose(Nn(dX), rdX, rtol=1e-4, atol=1e-4 * np.abs(rdX).max())
+    for F2 in (128, 256):                                  # the two-neighbours-per-instruction SDDMM kernel
+        X2 = rng.standard_normal((N, F2)).astype(np.float32)
+        dY2 = rng.standard_normal((N, F2)).astype(np.float32)
+        ref2, _ = O.spmm_bwd(idx, ahat, X2, dY2, need_dx=False)
+        for skip in (False, True):
+            got2, none = ops.spmm_bwd(T(idx, dev), T(ahat, dev), T(X2, dev), T(dY2, dev), need_dx=False, skip_zero=skip)
+            want = np.where(ahat == 0, 0.0, ref2) if skip else ref2
+            assert none is None
+            np.testing.assert_allclose(Nn(got2), want, rtol=1e-4, atol=1e-4 * np.abs(ref2).max())
     da = ops.norm_bwd_da(T(idx, dev), T(w, dev), T(rs, dev), T(rdA, dev))
     dval, dk = ops.softk_bwd(T(idx, dev), T(val, dev), T(k, dev), T(rdA, dev), rs=T(rs, dev), da=da, normalized=True)
     rdval, rdk = O.softk_norm_bwd(idx, val, k, w, rs, rdA)
