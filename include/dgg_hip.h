@@ -132,6 +132,20 @@ int dgg_softk_bwd(const int32_t *idx, const float *val, const float *k, const fl
 int dgg_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval, int K,
                  int64_t row0, float t, int perturb, float *dxp, void *stream);
 
+/* ---- column-side backward terms without global float atomics (dgg_scatter.hip) -----------------------------------
+ * The ACTIVE entries (idx >= 0, w != 0) of an ELL block are partitioned once per forward by destination bucket; the two
+ * backward terms that land on the neighbour j = idx[i][r] (score backward, normalisation backward) are then accumulated
+ * per bucket in LDS.  Same results as dgg_edge_bwd / dgg_norm_bwd_da up to summation order. */
+size_t dgg_part_ws_bytes(int64_t rows, int K, int64_t ncols);   /* 0: partitioned path not applicable */
+int dgg_part_build(const int32_t *idx, const float *w, int64_t rows, int K, int64_t ncols, void *ws, void *stream);
+/* coef_ws: rows*K (+ ncols for dgg_edge_bwd_part) floats; dxp [ncols,h] / da [ncols] zeroed by the caller;
+ * latent_dim in {16,32,64} */
+int dgg_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *dval, int K,
+                      int64_t row0, float t, int perturb, const void *part_ws, int64_t ncols, float *coef_ws, float *dxp,
+                      void *stream);
+int dgg_norm_bwd_da_part(const int32_t *idx, const float *w, const float *rs, const float *dA, int64_t rows, int K, int64_t row0,
+                         const void *part_ws, int64_t ncols, float *coef_ws, float *da, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,10 @@ PROTOTYPES = {
     "dgg_ell_spmm_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
     "dgg_norm_bwd_da": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp],
     "dgg_softk_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _vp],
+    "dgg_part_ws_bytes": [_i64, _i32, _i64],
+    "dgg_part_build": [_vp, _vp, _i64, _i32, _i64, _vp, _vp],
+    "dgg_edge_bwd_part": [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _i64, _vp, _vp, _vp],
+    "dgg_norm_bwd_da_part": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp],
     "dgg_edge_bwd": [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _vp],
 }
 
@@ -54,7 +58,7 @@ def lib():
             fn = getattr(L, name)      # AttributeError if the library does not export a declared symbol
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        for name in ("dgg_allpairs_workspace_bytes", "dgg_gemm_tn_ws_floats", "dgg_linear_bwd_ws_floats"):
+        for name in ("dgg_allpairs_workspace_bytes", "dgg_gemm_tn_ws_floats", "dgg_linear_bwd_ws_floats", "dgg_part_ws_bytes"):
             getattr(L, name).restype = C.c_size_t
         _lib = L
     return _lib

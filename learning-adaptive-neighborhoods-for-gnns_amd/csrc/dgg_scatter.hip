@@ -1,0 +1,399 @@
+// dgg_scatter.hip -- column-side ("transposed") accumulations of the backward pass WITHOUT global float atomics.
+//
+// Two backward terms land on the NEIGHBOUR of an ELL entry (i, r) -> j = idx[i][r] rather than on its owner row:
+//   score backward      dxp_j -= dd_ir (xp_i - xp_j)          autograd of ||xp_u - xp_v||, reference dgm.py:1613-1623
+//   normalisation       da_j  += dA_ir w_ir a_i               autograd of D^-1/2 A D^-1/2, reference model.py:1215-1218
+// Scattering them with global fp32 atomics runs at the atomic rate (~1.3 TB/s for 256-B rows, 17x less for scalars;
+// MI355X_MICROARCH.md "Global float atomics"): 0.9 + 0.2 ms at N = 100k.  Instead the active entries are PARTITIONED
+// once per forward into destination order (a CSC view of the ELL block): two counting passes with LDS histograms over
+// buckets of 128 consecutive nodes (one global integer atomic per workgroup and bucket), then one workgroup per bucket
+// orders its records by node.  The column-side kernels walk the sorted records in fixed chunks (balanced whatever the
+// in-degree skew), reduce each run of equal destinations in registers and flush once per run: ~18x fewer float atomics
+// than the entry-wise scatter (N + nnz/64 runs instead of nnz), 16-byte gathers of the source rows.
+#include "dgg_common.h"
+#include "dgg_api_internal.h"
+
+using namespace dgg;
+
+namespace {
+
+constexpr int BS = 128;            // destination nodes per bucket
+constexpr int PR = 256;            // rows per partition workgroup (4 wavefronts x 64 rows)
+
+struct PartHdr {                   // workspace: [bstart NB+1][cursor NB][tmp rows*K int2][slot rows*K int][recs rows*K int2]
+    int *bstart, *cursor;
+    int2 *tmp;                     // bucket-ordered records (src = row*64 + r, dst = j)
+    int *slot;                     // slot[row*K + r] = position of the entry in recs, -1 if inactive: lets the row-side
+    int2 *recs;                    // kernels write their per-entry coefficient in RECORD order (coalesced reads later)
+};                                 // recs: the records ordered by destination node
+__host__ __device__ inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+inline PartHdr part_layout(void *ws, int64_t nb, int64_t nrec) {
+    char *w = reinterpret_cast<char *>(ws);
+    PartHdr p;
+    p.bstart = reinterpret_cast<int *>(w);
+    p.cursor = reinterpret_cast<int *>(w + align256((size_t)(nb + 1) * 4));
+    p.tmp = reinterpret_cast<int2 *>(w + align256((size_t)(nb + 1) * 4) + align256((size_t)nb * 4));
+    p.slot = reinterpret_cast<int *>(reinterpret_cast<char *>(p.tmp) + align256((size_t)nrec * sizeof(int2)));
+    p.recs = reinterpret_cast<int2 *>(reinterpret_cast<char *>(p.slot) + align256((size_t)nrec * sizeof(int)));
+    return p;
+}
+
+// pass 1 (FILL = false): per-bucket totals.  pass 2 (FILL = true): bucket-sorted records (src = row*64 + r, dst = j)
+template <bool FILL>
+__global__ __launch_bounds__(256) void part_pass(const int32_t *__restrict__ idx, const float *__restrict__ w, int64_t rows,
+                                                 int K, int nb, int *__restrict__ gcount, int2 *__restrict__ recs,
+                                                 int *__restrict__ slotmap) {
+    extern __shared__ int lds[];                                 // hist[nb] (+ base[nb] when filling)
+    int *hist = lds, *base = lds + nb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int b = tid; b < nb; b += 256) hist[b] = 0;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * PR + wave * 64;
+    for (int q = 0; q < 64; q++) {
+        const int64_t i = r0 + q;
+        if (i >= rows) break;
+        if (lane < K) {
+            const int32_t j = idx[i * K + lane];
+            if (j >= 0 && w[i * K + lane] != 0.0f) atomicAdd(&hist[j / BS], 1);
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < nb; b += 256) {
+        const int c = hist[b];
+        if (FILL) { base[b] = c ? atomicAdd(&gcount[b], c) : 0; hist[b] = 0; }
+        else if (c) atomicAdd(&gcount[b], c);
+    }
+    if (!FILL) return;
+    __syncthreads();
+    for (int q = 0; q < 64; q++) {
+        const int64_t i = r0 + q;
+        if (i >= rows) break;
+        if (lane < K) {
+            const int32_t j = idx[i * K + lane];
+            int slot = -1;
+            if (j >= 0 && w[i * K + lane] != 0.0f) {
+                const int b = j / BS;
+                slot = base[b] + atomicAdd(&hist[b], 1);
+                recs[slot] = make_int2((int)(i * 64 + lane), j);
+            }
+            if (slot < 0) slotmap[i * K + lane] = -1;            // active entries: written by part_sort
+        }
+    }
+}
+
+// pass 3: order the records of one bucket by destination node (counting sort on LDS counters); records the final
+// position of every entry in slotmap
+__global__ __launch_bounds__(256) void part_sort(const int *__restrict__ bstart, const int2 *__restrict__ tmp, int K,
+                                                 int2 *__restrict__ recs, int *__restrict__ slotmap) {
+    __shared__ int cnt[BS], base[BS];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int e0 = bstart[b], e1 = bstart[b + 1];
+    if (tid < BS) cnt[tid] = 0;
+    __syncthreads();
+    for (int e = e0 + tid; e < e1; e += 256) atomicAdd(&cnt[tmp[e].y - b * BS], 1);
+    __syncthreads();
+    if (tid < 64) {                                              // exclusive scan of 128 counters by one wavefront
+        const int c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
+        int incl = c0 + c1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (tid >= off) incl += v;
+        }
+        base[2 * tid] = incl - c0 - c1;
+        base[2 * tid + 1] = incl - c1;
+    }
+    __syncthreads();
+    if (tid < BS) cnt[tid] = 0;
+    __syncthreads();
+    for (int e = e0 + tid; e < e1; e += 256) {
+        const int2 rec = tmp[e];
+        const int jl = rec.y - b * BS;
+        const int pos = e0 + base[jl] + atomicAdd(&cnt[jl], 1);
+        recs[pos] = rec;
+        slotmap[(int64_t)(rec.x >> 6) * K + (rec.x & 63)] = pos;
+    }
+}
+
+// exclusive scan of the bucket totals (single workgroup): bstart[0..nb], cursor[b] = bstart[b]
+__global__ __launch_bounds__(1024) void part_scan(int *__restrict__ bstart, int *__restrict__ cursor, int nb) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int lo = tid * per, hi = lo + per < nb ? lo + per : nb;
+    int s = 0;
+    for (int b = lo; b < hi; b++) s += cursor[b];                // cursor holds the totals of pass 1
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;                                     // exclusive prefix of this thread's segment
+    for (int b = lo; b < hi; b++) {
+        const int c = cursor[b];
+        bstart[b] = run;
+        cursor[b] = run;
+        run += c;
+    }
+    if (tid == 1023) bstart[nb] = part[1023];
+}
+
+// ---- score backward, row side: coefficient dd_ir for every entry, dxp_i (own row: plain store) -----------------------
+// H/4 lanes per neighbour (16-byte loads), 256/H neighbours per wave-instruction
+template <int H>
+__global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ xp, int64_t rows, const int32_t *__restrict__ idx,
+                                                     const float *__restrict__ val, const float *__restrict__ dval, int K,
+                                                     int64_t row0, float t, int perturb, const int *__restrict__ slotmap,
+                                                     float *__restrict__ coef, float *__restrict__ dxp) {
+    constexpr int LPR = H / 4;                                   // lanes per neighbour
+    constexpr int NPI = 64 / LPR;                                // neighbours per wave-instruction
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    const int64_t gi = row0 + i;
+    const int32_t jl = lane < K ? idx[i * K + lane] : -1;
+    const float gl = lane < K ? dval[i * K + lane] : 0.0f;
+    const float vl = lane < K ? val[i * K + lane] : 0.0f;
+    const float4 xi = *reinterpret_cast<const float4 *>(xp + gi * H + 4 * c4);
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float mycoef = 0.0f;
+    for (int r0 = 0; r0 < K; r0 += NPI) {
+        const int r = r0 + slot;
+        const int rr = r < 64 ? r : 63;
+        const int32_t j = __shfl(jl, rr, 64);
+        const float g = __shfl(gl, rr, 64), v = __shfl(vl, rr, 64);
+        const bool act = r < K && j >= 0 && g != 0.0f;
+        if (__ballot(act) == 0ull) continue;                     // wave-uniform
+        float4 d = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (act) {
+            const float4 xj = *reinterpret_cast<const float4 *>(xp + (int64_t)j * H + 4 * c4);
+            d = make_float4(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z, xi.w - xj.w);
+        }
+        float d2 = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+        if (LPR > 16) d2 += __uint_as_float(xor_shfl<16>(__float_as_uint(d2), lane));
+        if (LPR > 8) d2 += __uint_as_float(xor_shfl<8>(__float_as_uint(d2), lane));
+        if (LPR > 4) d2 += __uint_as_float(xor_shfl<4>(__float_as_uint(d2), lane));
+        if (LPR > 2) d2 += __uint_as_float(xor_shfl<2>(__float_as_uint(d2), lane));
+        d2 += __uint_as_float(xor_shfl<1>(__float_as_uint(d2), lane));
+        float dd = 0.0f;
+        if (act && d2 != 0.0f) {                                 // vector_norm backward at 0 is 0 (self loop)
+            const float dist = sqrtf(d2);
+            const float p = c_exp(t * dist);
+            const float dp = perturb ? g * v / (p + 1e-8f) : g;
+            dd = dp * t * p / dist;
+        }
+        acc.x += dd * d.x; acc.y += dd * d.y; acc.z += dd * d.z; acc.w += dd * d.w;
+        // hand the coefficient to the lane that owns entry r (lane r): gather from the first lane of each slot
+#pragma unroll
+        for (int s = 0; s < NPI; s++) {
+            const float cs = bcast(dd, s * LPR);
+            if (lane == r0 + s) mycoef = cs;
+        }
+    }
+    // sum the NPI neighbour slots (lanes with equal c4)
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
+        acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+    }
+    if (slot == 0) *reinterpret_cast<float4 *>(dxp + gi * H + 4 * c4) = acc;
+    if (lane < K) {
+        const int sl = slotmap[i * K + lane];
+        if (sl >= 0) coef[sl] = mycoef;                          // record order
+    }
+}
+
+// ---- score backward, column side: chunks of CH destination-ordered records per group of H/4 lanes --------------------
+// acc_j = -sum_e dd_e xp_{i_e} over the run of records with destination j, flushed with H float atomics per run;
+// s_j = sum_e dd_e goes to ssum (one scalar atomic per run) and is applied by edge_cols_finish: dxp_j += s_j xp_j.
+constexpr int CH = 64;
+template <int H>
+__global__ __launch_bounds__(256) void edge_bwd_cols(const float *__restrict__ xp, const int *__restrict__ bstart, int nb,
+                                                     const int2 *__restrict__ recs, const float *__restrict__ coef,
+                                                     int64_t row0, float *__restrict__ ssum, float *__restrict__ dxp) {
+    constexpr int LPR = H / 4;
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, gbase = lane - c4;
+    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int nnz = bstart[nb];
+    const int64_t cbeg = gid * CH;
+    if (cbeg >= nnz) return;
+    const int cend = cbeg + CH < nnz ? (int)cbeg + CH : nnz;
+    int cur = -1;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float sacc = 0.0f;
+    auto flush = [&]() {
+        if (cur >= 0) {
+            float *o = dxp + (int64_t)cur * H + 4 * c4;
+            atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
+            if (c4 == 0 && sacc != 0.0f) atomicAdd(ssum + cur, sacc);
+        }
+    };
+    for (int eb = (int)cbeg; eb < cend; eb += LPR) {             // LPR records per batch, one per lane of the group
+        const int e = eb + c4;
+        const int2 myrec = e < cend ? recs[e] : make_int2(0, -1);
+        const float mycf = e < cend ? coef[e] : 0.0f;
+#pragma unroll
+        for (int u0 = 0; u0 < LPR; u0 += 4) {
+            int src[4], dst[4];
+            float cf[4];
+            float4 xi[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                src[u] = __shfl(myrec.x, gbase + u0 + u, 64);
+                dst[u] = __shfl(myrec.y, gbase + u0 + u, 64);
+                cf[u] = __shfl(mycf, gbase + u0 + u, 64);
+                xi[u] = cf[u] != 0.0f ? *reinterpret_cast<const float4 *>(xp + (row0 + (src[u] >> 6)) * H + 4 * c4)
+                                      : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (dst[u] < 0) continue;
+                if (dst[u] != cur) {
+                    flush();
+                    cur = dst[u];
+                    acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    sacc = 0.0f;
+                }
+                acc.x -= cf[u] * xi[u].x; acc.y -= cf[u] * xi[u].y; acc.z -= cf[u] * xi[u].z; acc.w -= cf[u] * xi[u].w;
+                sacc += cf[u];
+            }
+        }
+    }
+    flush();
+}
+template <int H>
+__global__ __launch_bounds__(256) void edge_cols_finish(const float *__restrict__ xp, const float *__restrict__ ssum,
+                                                        int64_t ncols, float *__restrict__ dxp) {
+    constexpr int LPR = H / 4;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t j = g / LPR;
+    const int c4 = (int)(g % LPR);
+    if (j >= ncols) return;
+    const float sj = ssum[j];
+    if (sj == 0.0f) return;
+    const float4 x = *reinterpret_cast<const float4 *>(xp + j * H + 4 * c4);
+    float4 *o = reinterpret_cast<float4 *>(dxp + j * H + 4 * c4);
+    float4 v = *o;
+    v.x += sj * x.x; v.y += sj * x.y; v.z += sj * x.z; v.w += sj * x.w;
+    *o = v;
+}
+
+// ---- normalisation backward: row side (da_i, per-entry coefficient), column side (bucket sums) -----------------------
+__global__ __launch_bounds__(256) void norm_da_rows(const int32_t *__restrict__ idx, const float *__restrict__ w,
+                                                    const float *__restrict__ rs, const float *__restrict__ dA, int64_t rows,
+                                                    int K, int64_t row0, const int *__restrict__ slotmap,
+                                                    float *__restrict__ coef, float *__restrict__ da) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    float rowpart = 0.0f, cf = 0.0f;
+    if (lane < K) {
+        const int32_t j = idx[i * K + lane];
+        if (j >= 0) {
+            const float g = dA[i * K + lane] * w[i * K + lane];
+            if (g != 0.0f) {
+                const float ai = 1.0f / sqrtf(rs[row0 + i]), aj = 1.0f / sqrtf(rs[j]);
+                rowpart = g * aj;
+                cf = g * ai;
+            }
+        }
+        const int sl = slotmap[i * K + lane];
+        if (sl >= 0) coef[sl] = cf;                              // record order
+    }
+    rowpart = wave_sum_dpp(rowpart, lane);
+    if (lane == 0) da[row0 + i] = rowpart;
+}
+__global__ __launch_bounds__(256) void norm_da_cols(int64_t ncols, const int *__restrict__ bstart, const int2 *__restrict__ recs,
+                                                    const float *__restrict__ coef, float *__restrict__ da) {
+    __shared__ float ssum[BS];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (tid < BS) ssum[tid] = 0.0f;
+    __syncthreads();
+    const int e1 = bstart[b + 1];
+    for (int e = bstart[b] + tid; e < e1; e += 256) {
+        const float cf = coef[e];
+        if (cf != 0.0f) atomicAdd(&ssum[recs[e].y - b * BS], cf);
+    }
+    __syncthreads();
+    if (tid < BS) {
+        const int64_t j = (int64_t)b * BS + tid;
+        if (j < ncols && ssum[tid] != 0.0f) da[j] += ssum[tid];
+    }
+}
+
+inline int64_t nbuckets(int64_t ncols) { return (ncols + BS - 1) / BS; }
+
+}  // namespace
+
+extern "C" {
+
+// bytes of workspace for the partition of an ELL block of `rows` x K entries over `ncols` destination nodes;
+// 0 when the partitioned path does not apply (too many buckets for an LDS histogram)
+size_t dgg_part_ws_bytes(int64_t rows, int K, int64_t ncols) {
+    const int64_t nb = nbuckets(ncols);
+    if (nb > 16384 || K > 64) return 0;
+    return align256((size_t)(nb + 1) * 4) + align256((size_t)nb * 4) + align256((size_t)rows * K * sizeof(int2)) +
+           align256((size_t)rows * K * sizeof(int)) + (size_t)rows * K * sizeof(int2);
+}
+
+// Partition the ACTIVE entries (idx >= 0, w != 0) of idx [rows,K] by destination bucket.
+int dgg_part_build(const int32_t *idx, const float *w, int64_t rows, int K, int64_t ncols, void *ws, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nb = nbuckets(ncols);
+    if (dgg_part_ws_bytes(rows, K, ncols) == 0 || !ws) return dgg_set_error(DGG_ERR_UNSUPPORTED, "part_build: unsupported size or NULL workspace");
+    if (rows == 0) return 0;
+    PartHdr p = part_layout(ws, nb, rows * K);
+    if (dgg_check_hip(hipMemsetAsync(p.cursor, 0, (size_t)nb * 4, st), "part memset") != 0) return DGG_ERR_HIP;
+    const unsigned grid = (unsigned)((rows + PR - 1) / PR);
+    hipLaunchKernelGGL(part_pass<false>, dim3(grid), dim3(256), (size_t)nb * 4, st, idx, w, rows, K, (int)nb, p.cursor, p.tmp, p.slot);
+    hipLaunchKernelGGL(part_scan, dim3(1), dim3(1024), 0, st, p.bstart, p.cursor, (int)nb);
+    hipLaunchKernelGGL(part_pass<true>, dim3(grid), dim3(256), (size_t)nb * 8, st, idx, w, rows, K, (int)nb, p.cursor, p.tmp, p.slot);
+    hipLaunchKernelGGL(part_sort, dim3((unsigned)nb), dim3(256), 0, st, p.bstart, p.tmp, K, p.recs, p.slot);
+    return dgg_check_launch("part_build");
+}
+
+// score backward through the partition: same result as dgg_edge_bwd (up to summation order), no global float atomics.
+// coef_ws: rows*K + ncols floats.  dxp [ncols,h] zeroed by the caller.
+int dgg_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *dval, int K,
+                      int64_t row0, float t, int perturb, const void *part_ws, int64_t ncols, float *coef_ws, float *dxp,
+                      void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) return 0;
+    const int64_t nb = nbuckets(ncols);
+    PartHdr p = part_layout(const_cast<void *>(part_ws), nb, rows * K);
+    const unsigned gr = (unsigned)((rows + 3) / 4);
+    float *ssum = coef_ws + rows * K;
+    if (dgg_check_hip(hipMemsetAsync(ssum, 0, (size_t)ncols * 4, st), "edge_bwd_part memset") != 0) return DGG_ERR_HIP;
+    // upper bound of the chunk count (the live count bstart[nb] is read on the device: no host sync)
+    const int64_t ngroups = (rows * K + CH - 1) / CH;
+#define DGG_EDGE_PART(HH)                                                                                                  \
+    hipLaunchKernelGGL(edge_bwd_rows<HH>, dim3(gr), dim3(256), 0, st, xp, rows, idx, val, dval, K, row0, t, perturb, p.slot, coef_ws, dxp); \
+    hipLaunchKernelGGL(edge_bwd_cols<HH>, dim3((unsigned)((ngroups * (HH / 4) + 255) / 256)), dim3(256), 0, st, xp, p.bstart,   \
+                       (int)nb, p.recs, coef_ws, row0, ssum, dxp);                                                         \
+    hipLaunchKernelGGL(edge_cols_finish<HH>, dim3((unsigned)((ncols * (HH / 4) + 255) / 256)), dim3(256), 0, st, xp, ssum, ncols, dxp)
+    switch (h) {
+        case 16: DGG_EDGE_PART(16); break;
+        case 32: DGG_EDGE_PART(32); break;
+        case 64: DGG_EDGE_PART(64); break;
+        default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "edge_bwd_part supports latent_dim in {16,32,64}");
+    }
+#undef DGG_EDGE_PART
+    return dgg_check_launch("edge_bwd_part");
+}
+
+// normalisation backward phase 1 through the partition; da [ncols] zeroed by the caller
+int dgg_norm_bwd_da_part(const int32_t *idx, const float *w, const float *rs, const float *dA, int64_t rows, int K, int64_t row0,
+                         const void *part_ws, int64_t ncols, float *coef_ws, float *da, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) return 0;
+    const int64_t nb = nbuckets(ncols);
+    PartHdr p = part_layout(const_cast<void *>(part_ws), nb, rows * K);
+    hipLaunchKernelGGL(norm_da_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, idx, w, rs, dA, rows, K, row0, p.slot, coef_ws, da);
+    hipLaunchKernelGGL(norm_da_cols, dim3((unsigned)nb), dim3(256), 0, st, ncols, p.bstart, p.recs, coef_ws, da);
+    return dgg_check_launch("norm_bwd_da_part");
+}
+
+}  // extern "C"

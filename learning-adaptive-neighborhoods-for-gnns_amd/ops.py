@@ -159,9 +159,26 @@ def spmm_bwd(idx, ahat, X, dY, need_dx=True, skip_zero=False):
     return dA, dX
 
 
-def norm_bwd_da(idx, w, rs, dA, row0=0):
+def part_build(idx, w, ncols):
+    """Bucket-partition of the active ELL entries by destination node (dgg_scatter.hip), built once per forward and
+    reused by the column-side terms of the backward.  Returns None when the partitioned path does not apply."""
+    N, K = idx.shape
+    nbytes = int(_lib.lib().dgg_part_ws_bytes(N, K, ncols))
+    if nbytes == 0:
+        return None
+    ws = torch.empty((nbytes,), device=idx.device, dtype=torch.uint8)
+    _lib.check(_lib.lib().dgg_part_build(_ptr(idx), _ptr(_chk(w)), N, K, ncols, _ptr(ws), _stream()), "part_build")
+    return ws
+
+
+def norm_bwd_da(idx, w, rs, dA, row0=0, part=None):
     N, K = idx.shape
     da = torch.zeros_like(rs)
+    if part is not None:
+        coef = torch.empty((N, K), device=idx.device, dtype=torch.float32)
+        _lib.check(_lib.lib().dgg_norm_bwd_da_part(_ptr(idx), _ptr(_chk(w)), _ptr(_chk(rs)), _ptr(_chk(dA)), N, K, row0, _ptr(part),
+                                                   rs.shape[0], _ptr(coef), _ptr(da), _stream()), "norm_bwd_da_part")
+        return da
     _lib.check(_lib.lib().dgg_norm_bwd_da(_ptr(idx), _ptr(_chk(w)), _ptr(_chk(rs)), _ptr(_chk(dA)), N, K, row0, _ptr(da), _stream()), "norm_bwd_da")
     return da
 
@@ -177,11 +194,16 @@ def softk_bwd(idx, val, k, dA, rs=None, da=None, row0=0, mode=MODE_K_TIMES_EDGE_
     return dval, dk
 
 
-def edge_bwd(xp, idx, val, dval, row0=0, t=T_DIST, perturb=False):
+def edge_bwd(xp, idx, val, dval, row0=0, t=T_DIST, perturb=False, part=None):
     xp = _chk(xp)
     Ng, h = xp.shape
     N, K = idx.shape
     dxp = torch.zeros_like(xp)
+    if part is not None and h in (16, 32, 64):
+        coef = torch.empty(N * K + Ng, device=xp.device, dtype=torch.float32)   # per-record coefficients + column sums
+        _lib.check(_lib.lib().dgg_edge_bwd_part(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(dval)), K, row0, t, int(perturb),
+                                                _ptr(part), Ng, _ptr(coef), _ptr(dxp), _stream()), "edge_bwd_part")
+        return dxp
     _lib.check(_lib.lib().dgg_edge_bwd(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(dval)), K, row0, t, int(perturb), _ptr(dxp),
                                        _stream()), "edge_bwd")
     return dxp

@@ -66,6 +66,8 @@ class ShardedDGGConv:
         s["idx"], s["val"] = kern.allpairs_topk(xp, self.K, self.t, self.noise_mode, None, self.seed,
                                                 rows=(self.r0, self.r1), algo=self.algo)
         s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
+        # destination-bucket partition of the active entries: the backward's column-side terms run on it (no atomics)
+        s["part"] = kern.part_build(s["idx"], s["w"], self.N) if hasattr(kern, "part_build") else None
         s["rs"] = rs = _all_gather_rows(rs_local, self.N, self.per, self.group) if self.world > 1 else rs_local
         s["ahat"] = kern.normalize_fwd(s["idx"], s["w"], rs, self.r0)
         s["Y"] = kern.spmm_fwd(s["idx"], s["ahat"], X)
@@ -79,12 +81,15 @@ class ShardedDGGConv:
         g = {}
         dY, g["Wc"], _ = kern.linear_bwd(s["Y"], P["Wc"], s["Z"], dZ, 2, 1, True, False)
         dA, dX = kern.spmm_bwd(s["idx"], s["ahat"], s["X"], dY, self.x_grad, True)
-        da = kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0)
+        part = s.get("part")
+        da = kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0, part) if part is not None else \
+            kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0)
         if self.world > 1:
             dist.all_reduce(da, group=self.group)
         dval, dk = kern.softk_bwd(s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.mode, True)
         s["dval"] = dval                                 # kept for diagnostics (bench.py times edge_bwd alone)
-        dxp = kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0)
+        dxp = kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0, part) \
+            if part is not None else kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0)
         dX1, g["We"], g["be"] = kern.linear_bwd(s["X"], P["We"], s["xp"], dxp, 1, 0, self.x_grad, True)
         dxk, g["W1"], g["b1"], g["Wmu"], g["bmu"], dWp, g["bp"] = kern.knet_x_bwd(
             s["xk"].shape[1], s["mu_sd"], P["W1"], P["Wmu"], P["bmu"], P["Wp"].reshape(-1), s["z"], s["u"], s["feat"], dk)

@@ -221,10 +221,28 @@ def test_ell_backward_kernels(dev):
     rdval, rdk = O.softk_norm_bwd(idx, val, k, w, rs, rdA)
     np.testing.assert_allclose(Nn(dval), rdval, rtol=2e-4, atol=2e-4 * np.abs(rdval).max())
     np.testing.assert_allclose(Nn(dk), rdk, rtol=2e-4, atol=2e-4 * np.abs(rdk).max())
+    part = ops.part_build(T(idx, dev), T(w, dev), N)          # destination-bucket partition (no global float atomics)
+    assert part is not None
+    da_p = ops.norm_bwd_da(T(idx, dev), T(w, dev), T(rs, dev), T(rdA, dev), part=part)
+    np.testing.assert_allclose(Nn(da_p), Nn(da), rtol=2e-4, atol=2e-4 * np.abs(Nn(da)).max())
     for perturb in (False, True):
-        dxp = ops.edge_bwd(T(xp, dev), T(idx, dev), T(val, dev), T(rdval, dev), perturb=perturb)
         rdxp = O.edge_bwd(xp, idx, val, rdval, perturb=perturb)
-        np.testing.assert_allclose(Nn(dxp), rdxp, rtol=2e-4, atol=2e-4 * np.abs(rdxp).max())
+        for pt in (None, part):
+            dxp = ops.edge_bwd(T(xp, dev), T(idx, dev), T(val, dev), T(rdval, dev), perturb=perturb, part=pt)
+            np.testing.assert_allclose(Nn(dxp), rdxp, rtol=2e-4, atol=2e-4 * np.abs(rdxp).max())
+    # partition path at other latent sizes and with a row offset (sharded use: local rows, global columns)
+    for h2 in (16, 32):
+        xp2 = rng.standard_normal((N, h2)).astype(np.float32)
+        i2, v2 = O.allpairs_topk(xp2, K=K, noise_mode=O.NOISE_HASH, seed=(4, 4))
+        w2, _ = O.softk(i2, v2, k)
+        dv2 = (rng.standard_normal((N, K)) * (w2 != 0)).astype(np.float32)
+        ref = O.edge_bwd(xp2, i2, v2, dv2, perturb=True)
+        r0 = 100
+        p_lo = ops.part_build(T(i2[:r0], dev), T(w2[:r0], dev), N)
+        p_hi = ops.part_build(T(i2[r0:], dev), T(w2[r0:], dev), N)
+        got = ops.edge_bwd(T(xp2, dev), T(i2[:r0], dev), T(v2[:r0], dev), T(dv2[:r0], dev), row0=0, perturb=True, part=p_lo) + \
+            ops.edge_bwd(T(xp2, dev), T(i2[r0:], dev), T(v2[r0:], dev), T(dv2[r0:], dev), row0=r0, perturb=True, part=p_hi)
+        np.testing.assert_allclose(Nn(got), ref, rtol=2e-4, atol=2e-4 * np.abs(ref).max())
 
 
 # ---------------------------------------------------------------------------------------------------------------
