@@ -7,8 +7,10 @@
 //   mode "input_deg":  nd from the constants deg_mean/deg_std;  in3 = input_degree_project(nd);
 //                      m = k_mu(in3);  kp = k_project(m);  k = relu(kp * deg_std + deg_mean) + 1
 // The reference obtains deg by densifying in_adj (dgm.py:1568); here deg is a length-N vector (CSR row sums, or
-// the prior degree in all-pairs mode).  One wavefront per node: lane o computes output unit o with an
-// fmaf chain over the input units in ascending order (the order of the CPU oracle).
+// the prior degree in all-pairs mode).  Every output unit is an fmaf chain over the input units in ascending order (the
+// order of the CPU oracle).  latent_dim in {16,32,64,128} with the reference's h/2, h/4 widths: one THREAD per node, the
+// node's activations in registers, the (wave-uniform) weights through scalar loads -- full-rate v_fma, no cross-lane
+// traffic.  Other shapes: one wavefront per node, lane o computes output unit o.
 #include "dgg_common.h"
 #include "dgg_api_internal.h"
 
@@ -132,6 +134,115 @@ __global__ __launch_bounds__(WPB * 64) void knet_x_bwd_kernel(
     }
 }
 
+// ---- thread-per-node variants (H = latent_dim, H2 = H/2, H4 = H/4) ---------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(64) void knet_x_fwd_tpn(
+    const float *__restrict__ xk, int64_t N, const float *__restrict__ deg, const float *__restrict__ mu_sd,
+    const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ Wmu,
+    const float *__restrict__ bmu, const float *__restrict__ Wp, const float *__restrict__ bp,
+    float *__restrict__ k, float *__restrict__ z_save, float *__restrict__ u_save, float *__restrict__ feat_save) {
+    constexpr int H2 = H / 2, H4 = H / 4;
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= N) return;
+    const float mu = mu_sd[0], sd = mu_sd[1];
+    const float nd = __fdiv_rn(__fadd_rn(deg[i], -mu), __fadd_rn(sd, 1e-5f));
+    float x[H];
+#pragma unroll
+    for (int c = 0; c < H; c += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(xk + i * H + c);
+        x[c] = v.x; x[c + 1] = v.y; x[c + 2] = v.z; x[c + 3] = v.w;
+    }
+    if (feat_save) {
+        float *f = feat_save + i * (H + 1);
+#pragma unroll
+        for (int c = 0; c < H; c++) f[c] = x[c];
+        f[H] = nd;
+    }
+    float z[H2];
+#pragma unroll
+    for (int o = 0; o < H2; o++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < H; c++) acc = __fmaf_rn(x[c], W1[o * (H + 1) + c], acc);
+        acc = __fmaf_rn(nd, W1[o * (H + 1) + H], acc);
+        acc = __fadd_rn(acc, b1[o]);
+        z[o] = acc > 0.0f ? acc : __fmul_rn(0.01f, acc);
+    }
+    if (z_save) {
+#pragma unroll
+        for (int o = 0; o < H2; o += 4)
+            *reinterpret_cast<float4 *>(z_save + i * H2 + o) = make_float4(z[o], z[o + 1], z[o + 2], z[o + 3]);
+    }
+    float ak = 0.0f;
+#pragma unroll
+    for (int o = 0; o < H4; o++) {
+        float am = 0.0f;
+#pragma unroll
+        for (int c = 0; c < H2; c++) am = __fmaf_rn(z[c], Wmu[o * H2 + c], am);
+        const float m = __fadd_rn(am, bmu[o]);
+        ak = __fmaf_rn(m, Wp[o], ak);
+    }
+    const float kp = __fadd_rn(ak, bp[0]);
+    const float u = __fadd_rn(__fmul_rn(kp, sd), mu);
+    k[i] = __fadd_rn(u > 0.0f ? u : 0.0f, 1.0f);
+    if (u_save) u_save[i] = u;
+}
+
+template <int H>
+__global__ __launch_bounds__(64) void knet_x_bwd_tpn(
+    int64_t N, const float *__restrict__ mu_sd, const float *__restrict__ W1, const float *__restrict__ Wmu,
+    const float *__restrict__ Wp, const float *__restrict__ z, const float *__restrict__ u, const float *__restrict__ dk,
+    float *__restrict__ dkp_out, float *__restrict__ dm_out, float *__restrict__ dpre1_out, float *__restrict__ dxk,
+    float *__restrict__ m_out, const float *__restrict__ bmu) {
+    constexpr int H2 = H / 2, H4 = H / 4;
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= N) return;
+    const float sd = mu_sd[1];
+    const float dkp = u[i] > 0.0f ? dk[i] * sd : 0.0f;
+    dkp_out[i] = dkp;
+    float zl[H2];
+#pragma unroll
+    for (int c = 0; c < H2; c += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(z + i * H2 + c);
+        zl[c] = v.x; zl[c + 1] = v.y; zl[c + 2] = v.z; zl[c + 3] = v.w;
+    }
+    float mm[H4], dm[H4];
+#pragma unroll
+    for (int o = 0; o < H4; o++) {                               // m recomputed (k_project weight gradient)
+        float am = 0.0f;
+#pragma unroll
+        for (int c = 0; c < H2; c++) am = __fmaf_rn(zl[c], Wmu[o * H2 + c], am);
+        mm[o] = __fadd_rn(am, bmu[o]);
+        dm[o] = dkp * Wp[o];
+    }
+#pragma unroll
+    for (int o = 0; o < H4; o += 4) {
+        *reinterpret_cast<float4 *>(m_out + i * H4 + o) = make_float4(mm[o], mm[o + 1], mm[o + 2], mm[o + 3]);
+        *reinterpret_cast<float4 *>(dm_out + i * H4 + o) = make_float4(dm[o], dm[o + 1], dm[o + 2], dm[o + 3]);
+    }
+    float dp1[H2];
+#pragma unroll
+    for (int c = 0; c < H2; c++) {
+        float dz = 0.0f;
+#pragma unroll
+        for (int o = 0; o < H4; o++) dz = fmaf(dm[o], Wmu[o * H2 + c], dz);
+        dp1[c] = zl[c] > 0.0f ? dz : 0.01f * dz;
+    }
+#pragma unroll
+    for (int c = 0; c < H2; c += 4)
+        *reinterpret_cast<float4 *>(dpre1_out + i * H2 + c) = make_float4(dp1[c], dp1[c + 1], dp1[c + 2], dp1[c + 3]);
+#pragma unroll
+    for (int c = 0; c < H; c += 4) {
+        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int o = 0; o < H2; o++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) a[q] = fmaf(dp1[o], W1[o * (H + 1) + c + q], a[q]);
+        }
+        *reinterpret_cast<float4 *>(dxk + i * H + c) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+}
+
 __global__ void knet_input_deg_kernel(const float *__restrict__ deg, int64_t N, float dmean, float dstd,
                                       const float *__restrict__ Wd, const float *__restrict__ bd,
                                       const float *__restrict__ Wmu, const float *__restrict__ bmu, int h4,
@@ -170,6 +281,20 @@ int dgg_knet_x_fwd(const float *xk, int64_t N, int h, const float *deg, const fl
                    float *k, float *z_save, float *u_save, float *feat_save, void *stream) {
     if (h > 128 || h2 > 64 || h4 > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "k-net supports latent_dim <= 128");
     if (N == 0) return 0;
+    if (h2 * 2 == h && h4 * 4 == h && (h == 16 || h == 32 || h == 64 || h == 128)) {
+        const unsigned nblk = (unsigned)((N + 63) / 64);
+#define DGG_KNET_FWD(HH)                                                                                                   \
+    hipLaunchKernelGGL(knet_x_fwd_tpn<HH>, dim3(nblk), dim3(64), 0, (hipStream_t)stream, xk, N, deg, mu_sd, W1, b1, Wmu, bmu, Wp, \
+                       bp, k, z_save, u_save, feat_save)
+        switch (h) {
+            case 16: DGG_KNET_FWD(16); break;
+            case 32: DGG_KNET_FWD(32); break;
+            case 64: DGG_KNET_FWD(64); break;
+            default: DGG_KNET_FWD(128); break;
+        }
+#undef DGG_KNET_FWD
+        return dgg_check_launch("knet_x_fwd");
+    }
     size_t lds = sizeof(float) * ((size_t)h2 * (h + 1) + (size_t)h4 * h2);
     unsigned blocks = (unsigned)((N + WPB - 1) / WPB < 2048 ? (N + WPB - 1) / WPB : 2048);
     hipLaunchKernelGGL(knet_x_fwd_kernel, dim3(blocks), dim3(WPB * 64), lds, (hipStream_t)stream, xk, N, h, deg, mu_sd, W1,
@@ -182,6 +307,20 @@ int dgg_knet_x_bwd_nodes(int64_t N, int h, const float *mu_sd, const float *W1, 
                          float *dm, float *dpre1, float *dxk, float *m_out, void *stream) {
     if (h > 128 || h2 > 64 || h4 > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "k-net supports latent_dim <= 128");
     if (N == 0) return 0;
+    if (h2 * 2 == h && h4 * 4 == h && (h == 16 || h == 32 || h == 64 || h == 128)) {
+        const unsigned nblk = (unsigned)((N + 63) / 64);
+#define DGG_KNET_BWD(HH)                                                                                                   \
+    hipLaunchKernelGGL(knet_x_bwd_tpn<HH>, dim3(nblk), dim3(64), 0, (hipStream_t)stream, N, mu_sd, W1, Wmu, Wp, z, u, dk, dkp, dm, \
+                       dpre1, dxk, m_out, bmu)
+        switch (h) {
+            case 16: DGG_KNET_BWD(16); break;
+            case 32: DGG_KNET_BWD(32); break;
+            case 64: DGG_KNET_BWD(64); break;
+            default: DGG_KNET_BWD(128); break;
+        }
+#undef DGG_KNET_BWD
+        return dgg_check_launch("knet_x_bwd_nodes");
+    }
     size_t lds = sizeof(float) * ((size_t)h2 * (h + 1) + (size_t)h4 * h2);
     unsigned blocks = (unsigned)((N + WPB - 1) / WPB < 2048 ? (N + WPB - 1) / WPB : 2048);
     hipLaunchKernelGGL(knet_x_bwd_kernel, dim3(blocks), dim3(WPB * 64), lds, (hipStream_t)stream, N, h, mu_sd, W1, h2, Wmu,

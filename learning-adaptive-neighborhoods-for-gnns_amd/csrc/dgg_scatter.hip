@@ -49,13 +49,21 @@ __global__ __launch_bounds__(256) void part_pass(const int32_t *__restrict__ idx
     for (int b = tid; b < nb; b += 256) hist[b] = 0;
     __syncthreads();
     const int64_t r0 = (int64_t)blockIdx.x * PR + wave * 64;
-    for (int q = 0; q < 64; q++) {
-        const int64_t i = r0 + q;
-        if (i >= rows) break;
-        if (lane < K) {
-            const int32_t j = idx[i * K + lane];
-            if (j >= 0 && w[i * K + lane] != 0.0f) atomicAdd(&hist[j / BS], 1);
+    constexpr int UQ = 8;                                        // rows in flight per wavefront (loads before LDS atomics)
+    for (int q0 = 0; q0 < 64; q0 += UQ) {
+        int32_t jj[UQ];
+#pragma unroll
+        for (int u = 0; u < UQ; u++) {
+            const int64_t i = r0 + q0 + u;
+            jj[u] = -1;
+            if (i < rows && lane < K) {
+                const int32_t j = idx[i * K + lane];
+                jj[u] = w[i * K + lane] != 0.0f ? j : -1;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < UQ; u++)
+            if (jj[u] >= 0) atomicAdd(&hist[jj[u] / BS], 1);
     }
     __syncthreads();
     for (int b = tid; b < nb; b += 256) {
@@ -65,32 +73,41 @@ __global__ __launch_bounds__(256) void part_pass(const int32_t *__restrict__ idx
     }
     if (!FILL) return;
     __syncthreads();
-    for (int q = 0; q < 64; q++) {
-        const int64_t i = r0 + q;
-        if (i >= rows) break;
-        if (lane < K) {
-            const int32_t j = idx[i * K + lane];
-            int slot = -1;
-            if (j >= 0 && w[i * K + lane] != 0.0f) {
-                const int b = j / BS;
-                slot = base[b] + atomicAdd(&hist[b], 1);
-                recs[slot] = make_int2((int)(i * 64 + lane), j);
+    for (int q0 = 0; q0 < 64; q0 += UQ) {
+        int32_t jj[UQ];
+#pragma unroll
+        for (int u = 0; u < UQ; u++) {
+            const int64_t i = r0 + q0 + u;
+            jj[u] = -2;                                          // -2: no entry, -1: inactive entry
+            if (i < rows && lane < K) {
+                const int32_t j = idx[i * K + lane];
+                jj[u] = (j >= 0 && w[i * K + lane] != 0.0f) ? j : -1;
             }
-            if (slot < 0) slotmap[i * K + lane] = -1;            // active entries: written by part_sort
+        }
+#pragma unroll
+        for (int u = 0; u < UQ; u++) {
+            const int64_t i = r0 + q0 + u;
+            if (jj[u] >= 0) {
+                const int b = jj[u] / BS;
+                const int slot = base[b] + atomicAdd(&hist[b], 1);
+                recs[slot] = make_int2((int)(i * 64 + lane), jj[u]);
+            } else if (jj[u] == -1) {
+                slotmap[i * K + lane] = -1;                      // active entries: written by part_sort
+            }
         }
     }
 }
 
 // pass 3: order the records of one bucket by destination node (counting sort on LDS counters); records the final
 // position of every entry in slotmap
-__global__ __launch_bounds__(256) void part_sort(const int *__restrict__ bstart, const int2 *__restrict__ tmp, int K,
+__global__ __launch_bounds__(1024) void part_sort(const int *__restrict__ bstart, const int2 *__restrict__ tmp, int K,
                                                  int2 *__restrict__ recs, int *__restrict__ slotmap) {
     __shared__ int cnt[BS], base[BS];
     const int tid = threadIdx.x, b = blockIdx.x;
     const int e0 = bstart[b], e1 = bstart[b + 1];
     if (tid < BS) cnt[tid] = 0;
     __syncthreads();
-    for (int e = e0 + tid; e < e1; e += 256) atomicAdd(&cnt[tmp[e].y - b * BS], 1);
+    for (int e = e0 + tid; e < e1; e += 1024) atomicAdd(&cnt[tmp[e].y - b * BS], 1);
     __syncthreads();
     if (tid < 64) {                                              // exclusive scan of 128 counters by one wavefront
         const int c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
@@ -106,7 +123,7 @@ __global__ __launch_bounds__(256) void part_sort(const int *__restrict__ bstart,
     __syncthreads();
     if (tid < BS) cnt[tid] = 0;
     __syncthreads();
-    for (int e = e0 + tid; e < e1; e += 256) {
+    for (int e = e0 + tid; e < e1; e += 1024) {
         const int2 rec = tmp[e];
         const int jl = rec.y - b * BS;
         const int pos = e0 + base[jl] + atomicAdd(&cnt[jl], 1);
@@ -351,7 +368,7 @@ int dgg_part_build(const int32_t *idx, const float *w, int64_t rows, int K, int6
     hipLaunchKernelGGL(part_pass<false>, dim3(grid), dim3(256), (size_t)nb * 4, st, idx, w, rows, K, (int)nb, p.cursor, p.tmp, p.slot);
     hipLaunchKernelGGL(part_scan, dim3(1), dim3(1024), 0, st, p.bstart, p.cursor, (int)nb);
     hipLaunchKernelGGL(part_pass<true>, dim3(grid), dim3(256), (size_t)nb * 8, st, idx, w, rows, K, (int)nb, p.cursor, p.tmp, p.slot);
-    hipLaunchKernelGGL(part_sort, dim3((unsigned)nb), dim3(256), 0, st, p.bstart, p.tmp, K, p.recs, p.slot);
+    hipLaunchKernelGGL(part_sort, dim3((unsigned)nb), dim3(1024), 0, st, p.bstart, p.tmp, K, p.recs, p.slot);
     return dgg_check_launch("part_build");
 }
 

@@ -5,15 +5,18 @@ output row i needs x_i, all candidate x_j, k_i and the row sums rs_j of its sele
 (sort / ramp act on dim=-1, reference dgm.py:1404-1420).  Rank r owns rows [r*ceil(N/G), ...) of X, of the ELL
 adjacency and of the conv output.  Collectives per step:
 
-  forward   all-gather X [N,d] (once; serves the projection, the scoring and the SpMM gather)
-            all-gather rs [N]   (row sums for the symmetric-ish normalisation, model.py:1215-1218)
+  forward   all-gather xp [N,h]  (projected features of the OWN rows; the scoring needs every candidate's xp_j)
+            all-gather X  [N,d]  (needed only by the SpMM gather: issued asynchronously behind xp, it crosses the
+                                  fabric while the top-k, soft-k and partition kernels run)
+            all-gather rs [N]    (row sums for the symmetric-ish normalisation, model.py:1215-1218)
   backward  all-reduce da [N]   (d loss / d rs^-1/2: neighbour-side terms land on non-owner ranks)
             all-reduce of the replicated weight gradients (one flat bucket, ~35k floats)
             [reduce-scatter dX [N,d] only when the input features need a gradient]
 
-The projected features xp = leaky(X We^T + be) are recomputed on every rank from the gathered X (2*N*d*h flop,
-negligible next to N^2/G pair scores); its weight gradient is formed from each rank's PARTIAL dxp against the full
-X and summed by the weight all-reduce, so the [N,h] gradient itself never crosses the fabric.
+Every rank projects only its own rows (xp = leaky(X We^T + be)) and gathers the rest: with the ranked noise a row
+costs O(150) pair scores, so re-projecting all N rows on every rank would no longer be negligible.  The weight
+gradient of the projection is formed from each rank's PARTIAL dxp against the full X / xp and summed by the weight
+all-reduce, so the [N,h] gradient itself never crosses the fabric.
 
 `kern` is the kernel namespace (dgg_amd.ops on the GPU; tests substitute a CPU stand-in built on the oracle so
 that the partition / collective logic is exercised with gloo, world_size 2, without a GPU).
@@ -28,16 +31,29 @@ def shard_bounds(N, world, rank):
     return r0, min(r0 + per, N), per
 
 
+class _Gather:
+    """A (possibly still running) all-gather of row shards: .get() waits and returns the [N, ...] tensor.  On RCCL the
+    wait is a stream dependency (no host block); shards are padded to `per` rows for the fixed-size collective."""
+
+    def __init__(self, t_local, N, per, group, async_op):
+        pad = per - t_local.shape[0]
+        self.src = t_local.contiguous() if pad == 0 else torch.cat([t_local, t_local.new_zeros((pad,) + tuple(t_local.shape[1:]))])
+        self.out = self.src.new_empty((dist.get_world_size(group) * per,) + tuple(t_local.shape[1:]))
+        self.N = N
+        self.work = dist.all_gather_into_tensor(self.out, self.src, group=group, async_op=async_op)
+
+    def get(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.out[:self.N]
+
+
 def _all_gather_rows(t_local, N, per, group):
-    """[n_loc, ...] -> [N, ...]; shards are padded to `per` rows for the fixed-size collective."""
-    world = dist.get_world_size(group)
-    if world == 1:
+    """[n_loc, ...] -> [N, ...]"""
+    if dist.get_world_size(group) == 1:
         return t_local
-    pad = per - t_local.shape[0]
-    src = t_local if pad == 0 else torch.cat([t_local, t_local.new_zeros((pad,) + tuple(t_local.shape[1:]))])
-    out = src.new_empty((world * per,) + tuple(t_local.shape[1:]))
-    dist.all_gather_into_tensor(out, src.contiguous(), group=group)
-    return out[:N]
+    return _Gather(t_local, N, per, group, False).get()
 
 
 class ShardedDGGConv:
@@ -56,13 +72,16 @@ class ShardedDGGConv:
     def forward(self, x_local, deg_full, P):
         kern = self.kern
         s = {}
-        s["X"] = X = _all_gather_rows(x_local, self.N, self.per, self.group) if self.world > 1 else x_local
-        s["xp"] = xp = kern.linear_fwd(X, P["We"], P["be"], 1, 0)
+        xp = kern.linear_fwd(x_local, P["We"], P["be"], 1, 0)
+        if self.world > 1:                               # xp first (the top-k waits for it), X streams in behind it
+            g_xp = _Gather(xp, self.N, self.per, self.group, True)
+            g_X = _Gather(x_local, self.N, self.per, self.group, True)
         s["xk"] = xk = kern.linear_fwd(x_local, P["Wk"], P["bk"], 1, 0)
         s["mu_sd"] = mu_sd = kern.degree_stats(deg_full)
         deg_local = deg_full[self.r0:self.r1].contiguous()
         s["k"], s["z"], s["u"], s["feat"] = kern.knet_x_fwd(xk, deg_local, mu_sd, P["W1"], P["b1"], P["Wmu"], P["bmu"],
                                                           P["Wp"].reshape(-1), P["bp"])
+        s["xp"] = xp = g_xp.get() if self.world > 1 else xp
         s["idx"], s["val"] = kern.allpairs_topk(xp, self.K, self.t, self.noise_mode, None, self.seed,
                                                 rows=(self.r0, self.r1), algo=self.algo)
         s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
@@ -70,6 +89,7 @@ class ShardedDGGConv:
         s["part"] = kern.part_build(s["idx"], s["w"], self.N) if hasattr(kern, "part_build") else None
         s["rs"] = rs = _all_gather_rows(rs_local, self.N, self.per, self.group) if self.world > 1 else rs_local
         s["ahat"] = kern.normalize_fwd(s["idx"], s["w"], rs, self.r0)
+        s["X"] = X = g_X.get() if self.world > 1 else x_local
         s["Y"] = kern.spmm_fwd(s["idx"], s["ahat"], X)
         s["Z"] = kern.linear_fwd(s["Y"], P["Wc"], None, 2, 1)
         self.saved = s
