@@ -221,16 +221,21 @@ def main():
 
     sv = layer.saved
     rows_loc = r1 - r0
-    t_pair = timed(lambda: ops.allpairs_topk(sv["xp"], 64, noise_mode=noise_mode, seed=(1234, 0), rows=(r0, r1), algo=a.algo))
-    t_edge = timed(lambda: ops.edge_bwd(sv["xp"], sv["idx"], sv["val"], sv["dval"], r0, ops.T_DIST, True))
+    t_pair = timed(lambda: ops.allpairs_topk(sv["xp"], 64, noise_mode=noise_mode, seed=(1234, 0), rows=(r0, r1), algo=a.algo,
+                                             k_limit=sv["k"]))
+    t_edge = timed(lambda: ops.edge_bwd(sv["xp"], sv["idx"], sv["val"], sv["dval"], r0, ops.T_DIST, True, sv["part"]))
     t_sddmm = timed(lambda: ops.spmm_bwd(sv["idx"], sv["ahat"], sv["X"], sv["Y"], False, True))
     t_spmm = timed(lambda: ops.spmm_fwd(sv["idx"], sv["ahat"], sv["X"]))
     active = float((sv["dval"] != 0).sum().item())                # edges with a non-saturated ramp (~ k + 8.5 per row)
     traffic = load_traffic()
+    kept = float((sv["idx"] >= 0).sum().item())                   # ranks kept by k_limit (~ k + 9.5 per row)
     kern = {
-        # score backward: per active edge reads xp_j (4h B) and atomically adds 4h B to dxp_j; per row reads
-        # idx/score/dval (3*256 B) + xp_i and adds dxp_i
-        "edge_bwd": dict(ms=t_edge * 1e3, bytes=active * 8 * h + rows_loc * (3 * 256 + 8 * h)),
+        # pair scoring + top-k: every KEPT entry needs its candidate's xp_j gathered once (4h B; candidates visited
+        # and rejected by the search are overhead, not algorithmic bytes); per row xp_i in, idx/score (2*256 B) out
+        "allpairs_topk": dict(ms=t_pair * 1e3, bytes=kept * 4 * h + rows_loc * (4 * h + 2 * 256)),
+        # score backward (row pass + destination-ordered column pass): per active edge xp_j and xp_i gathered once each
+        # (2*4h B) + record/coefficient (16 B); per row idx/score/dval (3*256 B), xp_i in, dxp_i out and updated
+        "edge_bwd": dict(ms=t_edge * 1e3, bytes=active * (8 * h + 16) + rows_loc * (3 * 256 + 12 * h)),
         # SDDMM dA_ir = <dY_i, X_j>: per active edge one gathered row of X (4d B); per row dY_i, idx, ahat, dA
         "spmm_bwd": dict(ms=t_sddmm * 1e3, bytes=active * 4 * d + rows_loc * (4 * d + 3 * 256)),
         # SpMM Y_i = sum_r A_ir X_j: per active edge one gathered row of X; per row idx, ahat and the output row
@@ -254,7 +259,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": kern[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": traffic.get(dom),
                          "kernel_ms": kern[dom]["ms"], "algorithmic_bytes": kern[dom]["bytes"],
-                         "note": "algorithmic bytes per launch / event-timed duration; fp32 atomics count once"},
+                         "note": "algorithmic bytes per launch / event-timed duration; gathered rows count once per use"},
             "kernels": {n_: {"ms": v["ms"], "GBps": v["GBps"], "frac_hbm": v["GBps"] / HBM_PEAK_GBPS} for n_, v in kern.items()},
             # the north-star pair stage: SURVEY 8(d) algorithmic flops (232/pair over all N^2 pairs) per second; the
             # ranked / pruned kernels score only the pairs that can still enter a row's top-64, so this exceeds the

@@ -90,10 +90,14 @@ int dgg_knet_input_deg_fwd(const float *deg, int64_t N, float dmean, float dstd,
  * edge_prob_net "u-v-dist" (dgm.py:1607-1627) + perturbation (dgm.py:1211-1229) + torch.sort (dgm.py:1404), kept
  * to the K best per row.  xp [N,h] = leaky(node_encode_for_edges(x)); t = -0.05 (dgm.py:1618).
  * All-pairs candidates (complete in_adj): rows [row0,row1) of the N x N score matrix; outputs [row1-row0, K].
- * algo: 0 auto, 1 exhaustive, 2 pruned (identical results).  workspace: dgg_allpairs_workspace_bytes(). */
+ * algo: 0 auto, 1 exhaustive, 2 pruned (identical results).  workspace: dgg_allpairs_workspace_bytes().
+ * k_limit (nullable, [row1-row0]): the learned k of each row.  The soft top-k ramp (dgm.py:1412-1420) is exactly 0.0f
+ * for ranks r >= ceil(k + 8.5), so with k_limit the ranks from ceil(k + 8.5) + 1 on are returned as idx = -1, val = 0
+ * (weights, outputs and gradients are unchanged) and the ranked-noise search stops as soon as the kept ranks are
+ * settled. */
 int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode,
-                      const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, int algo,
-                      void *workspace, size_t ws_bytes, void *stream);
+                      const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val,
+                      const float *k_limit, int algo, void *workspace, size_t ws_bytes, void *stream);
 /* bytes of device workspace the pruned path needs for (N, h): a bf16 copy of xp plus discounted squared norms;
  * 0 when the pruned path does not apply (explicit noise, K != 64, latent_dim not in {16,32,64,128}) */
 size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K);

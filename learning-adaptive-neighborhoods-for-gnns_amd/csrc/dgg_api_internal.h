@@ -34,4 +34,5 @@ size_t dgg_allpairs_gv_ws_bytes(int64_t rows);
 bool dgg_allpairs_gv_supported(int h, int noise_mode, int K);
 
 int dgg_allpairs_topk_ranked_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0,
-                                  uint32_t s1, int K, int32_t *idx, float *val, hipStream_t st);
+                                  uint32_t s1, int K, const float *klim, int32_t *idx, float *val, hipStream_t st);
+int dgg_klimit_truncate_impl(const float *klim, int64_t rows, int K, int32_t *idx, float *val, hipStream_t st);

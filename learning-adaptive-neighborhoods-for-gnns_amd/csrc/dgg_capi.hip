@@ -19,32 +19,36 @@ int dgg_check_launch(const char *what) { return dgg_check_hip(hipGetLastError(),
 extern "C" {
 
 const char *dgg_last_error(void) { return g_err; }
-int dgg_abi_version(void) { return 1; }
+int dgg_abi_version(void) { return 2; }
 
 // algo: 0 auto, 1 exhaustive (every pair scored with the canonical arithmetic), 2 MFMA-bounded pruning,
 //       3 noise-prefilter pruning (perturbed scores only).  All return identical bits.
 int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode,
-                      const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, int algo,
-                      void *workspace, size_t ws_bytes, void *stream) {
+                      const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val,
+                      const float *k_limit, int algo, void *workspace, size_t ws_bytes, void *stream) {
     if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
     if (row0 < 0 || row1 > N || row0 > row1) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk: bad row range");
     if (noise_mode < 0 || noise_mode > 4) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk: bad noise_mode");
     if (noise_mode == 1 && !G) return dgg_set_error(DGG_ERR_ARG, "explicit noise requested but G is NULL");
     hipStream_t st = (hipStream_t)stream;
     if (noise_mode == 4)   // ranked generator: the row-wise early-stopping search is the only (and exact) evaluator
-        return dgg_allpairs_topk_ranked_impl(xp, N, h, row0, row1, t, s0, s1, K, idx, val, st);
+        return dgg_allpairs_topk_ranked_impl(xp, N, h, row0, row1, t, s0, s1, K, k_limit, idx, val, st);
     const bool can_fast = dgg_allpairs_fast_supported(h, noise_mode, K) && workspace &&
                           ws_bytes >= dgg_allpairs_fast_ws_bytes(N, h);
     const bool can_np = dgg_allpairs_np_supported(h, noise_mode, K) && workspace && ws_bytes >= dgg_allpairs_np_ws_bytes(N);
     const bool can_gv = dgg_allpairs_gv_supported(h, noise_mode, K) && workspace &&
                         ws_bytes >= dgg_allpairs_gv_ws_bytes(row1 - row0);
+    int rc;
     if (algo == 4 || (algo == 0 && can_gv && N >= 1024))
-        return dgg_allpairs_topk_gv_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
-    if (algo == 3 || (algo == 0 && can_np && N >= 1024))
-        return dgg_allpairs_topk_np_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
-    if (algo == 2 || (algo == 0 && can_fast && N >= 1024))
-        return dgg_allpairs_topk_fast_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
-    return dgg_allpairs_topk_exhaustive_impl(xp, N, h, row0, row1, t, noise_mode, G, ldG, s0, s1, K, idx, val, st);
+        rc = dgg_allpairs_topk_gv_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
+    else if (algo == 3 || (algo == 0 && can_np && N >= 1024))
+        rc = dgg_allpairs_topk_np_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
+    else if (algo == 2 || (algo == 0 && can_fast && N >= 1024))
+        rc = dgg_allpairs_topk_fast_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
+    else
+        rc = dgg_allpairs_topk_exhaustive_impl(xp, N, h, row0, row1, t, noise_mode, G, ldG, s0, s1, K, idx, val, st);
+    if (rc == 0 && k_limit) rc = dgg_klimit_truncate_impl(k_limit, row1 - row0, K, idx, val, st);
+    return rc;
 }
 
 // bytes of workspace the pruned path needs (bf16 copy of xp + discounted norms); 0 when it cannot be used

@@ -133,6 +133,13 @@ __device__ __forceinline__ float pair_noise(uint32_t s0, uint32_t s1, uint32_t i
 // ---- "ranked" counter-based noise (noise_mode 4): same iid Gumbel(0,0.3) law, generated per row in decreasing
 // order.  -log U_(s) = sum_{t<=s} E_t/(N-t+1) (Renyi), prefix sums in exact 2^-40 fixed point (order-independent);
 // rank s sits at column sigma_i(r'), the s-th element < N of a keyed bijection of [0, 2^b) walked in order.
+// Number of leading ranks of a row that can carry a non-zero soft top-k weight: the ramp 1 - 0.5 (1 + tanh(r - k))
+// (dgm.py:1412-1420) is exactly 0.0f in fp32 for r - k >= 8.5, so ranks r >= ceil(k + 8.5) never matter (+1 margin).
+__host__ __device__ inline int klimit_len(float k, int K) {
+    const float L = ceilf(k + 8.5f) + 1.0f;
+    if (!(L < (float)K)) return K;                               // also NaN
+    return L < 1.0f ? 1 : (int)L;
+}
 __device__ __forceinline__ int ranked_bits(int64_t N) { int b = 6; while (((int64_t)1 << b) < N) b++; return b; }
 __device__ __forceinline__ uint32_t ranked_sigma(uint32_t r, uint32_t k1, uint32_t k2, uint32_t k3, int b) {
     const uint32_t mask = (b >= 32) ? 0xffffffffu : ((1u << b) - 1u);

@@ -31,11 +31,14 @@ __device__ __forceinline__ uint64_t wave_inclusive_scan_u64(uint64_t v, int lane
 template <int H>
 __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restrict__ xp, int64_t N, int64_t row0,
                                                             int64_t row1, float t, uint32_t s0, uint32_t s1,
-                                                            int32_t *__restrict__ idx, float *__restrict__ val) {
+                                                            const float *__restrict__ klim, int32_t *__restrict__ idx,
+                                                            float *__restrict__ val) {
     const int lane = threadIdx.x & 63;
     const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t i = row0 + lrow;
     if (i >= row1) return;
+    // ranks beyond L cannot receive weight (klimit_len): the search only has to settle the first L of the list
+    const int L = klim ? __builtin_amdgcn_readfirstlane(klimit_len(klim[lrow], 64)) : 64;
     uint32_t k1, k2;
     rowkey(s0, s1, (uint32_t)i, k1, k2);
     const uint32_t k3 = mix32(k2 ^ 0x68E31DA4u);
@@ -80,39 +83,54 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
         scount += (uint32_t)nvalid;
         if (scount >= (uint32_t)N) break;                        // every column visited
         // stop test: the lowest noise of this block bounds every rank still to come
-        const uint64_t k63 = shfl_u64(list, 63);
+        const uint64_t k63 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(list >> 32), L - 1) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)list, L - 1);
         if (k63 != DGG_EMPTY_KEY && nvalid > 0) {
             const int last = 63 - __builtin_clzll(m);            // last valid lane = highest rank in the block
             const float gmin = __shfl(G, last, 64);
             if (gmin + 1e-8f + 1e-3f < __logf(key_val(k63))) break;
         }
     }
-    const bool empty = list == DGG_EMPTY_KEY;
+    const bool empty = list == DGG_EMPTY_KEY || lane >= L;
     idx[lrow * 64 + lane] = empty ? -1 : key_col(list);
     val[lrow * 64 + lane] = empty ? 0.0f : key_val(list);
 }
 
 template <int H>
-int launch_ranked(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1, int32_t *idx,
-                  float *val, hipStream_t st) {
+int launch_ranked(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
+                  const float *klim, int32_t *idx, float *val, hipStream_t st) {
     dim3 grid((unsigned)((row1 - row0 + 3) / 4));
-    hipLaunchKernelGGL(allpairs_topk_ranked<H>, grid, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, idx, val);
+    hipLaunchKernelGGL(allpairs_topk_ranked<H>, grid, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, klim, idx, val);
     return dgg_check_launch("allpairs_topk_ranked");
+}
+
+// same cut for the evaluators that always settle all K ranks
+__global__ void klimit_truncate(const float *__restrict__ klim, int64_t rows, int K, int32_t *__restrict__ idx,
+                                float *__restrict__ val) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * K) return;
+    if ((int)(e % K) >= klimit_len(klim[e / K], K)) { idx[e] = -1; val[e] = 0.0f; }
 }
 
 }  // namespace
 
+int dgg_klimit_truncate_impl(const float *klim, int64_t rows, int K, int32_t *idx, float *val, hipStream_t st) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(klimit_truncate, dim3((unsigned)((rows * K + 255) / 256)), dim3(256), 0, st, klim, rows, K, idx, val);
+    return dgg_check_launch("klimit_truncate");
+}
+
 int dgg_allpairs_topk_ranked_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0,
-                                  uint32_t s1, int K, int32_t *idx, float *val, hipStream_t st) {
+                                  uint32_t s1, int K, const float *klim, int32_t *idx, float *val, hipStream_t st) {
     if (K != 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path needs K = 64");
     if (N >= ((int64_t)1 << 31)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path needs N < 2^31");
     if (row1 <= row0) return 0;
     switch (h) {
-        case 8: return launch_ranked<8>(xp, N, row0, row1, t, s0, s1, idx, val, st);
-        case 16: return launch_ranked<16>(xp, N, row0, row1, t, s0, s1, idx, val, st);
-        case 32: return launch_ranked<32>(xp, N, row0, row1, t, s0, s1, idx, val, st);
-        case 64: return launch_ranked<64>(xp, N, row0, row1, t, s0, s1, idx, val, st);
-        case 128: return launch_ranked<128>(xp, N, row0, row1, t, s0, s1, idx, val, st);
+        case 8: return launch_ranked<8>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st);
+        case 16: return launch_ranked<16>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st);
+        case 32: return launch_ranked<32>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st);
+        case 64: return launch_ranked<64>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st);
+        case 128: return launch_ranked<128>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st);
         default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path supports latent_dim in {8,16,32,64,128}");
     }
 }

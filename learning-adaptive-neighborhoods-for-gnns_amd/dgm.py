@@ -42,7 +42,8 @@ class _DGGSoftAdjFn(torch.autograd.Function):
         mu_sd = ops.degree_stats(deg)
         k, z, u, feat = ops.knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp.reshape(-1), bp)
         if cfg["cand"] is None:
-            idx, val = ops.allpairs_topk(xp, cfg["K"], cfg["t"], cfg["noise_mode"], cfg["G"], cfg["seed"], algo=cfg["algo"])
+            idx, val = ops.allpairs_topk(xp, cfg["K"], cfg["t"], cfg["noise_mode"], cfg["G"], cfg["seed"], algo=cfg["algo"],
+                                         k_limit=k)
         else:
             rowptr, col = cfg["cand"]
             idx, val = ops.edgelist_topk(xp, rowptr, col, cfg["K"], cfg["t"], cfg["noise_mode"], cfg["G"], cfg["seed"])

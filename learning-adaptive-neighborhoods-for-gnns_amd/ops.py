@@ -78,7 +78,8 @@ def degree_stats(deg):
 
 
 def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed=(0, 0), rows=None, algo=0,
-                  return_ws=False):
+                  return_ws=False, k_limit=None):
+    """k_limit: learned k of the rows (optional): ranks that the soft top-k ramp zeroes exactly come back as idx = -1."""
     xp = _chk(xp)
     N, h = xp.shape
     r0, r1 = (0, N) if rows is None else rows
@@ -95,7 +96,8 @@ def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed
         if ws_bytes:
             ws = torch.empty((ws_bytes,), device=xp.device, dtype=torch.uint8)
     _lib.check(_lib.lib().dgg_allpairs_topk(_ptr(xp), N, h, r0, r1, t, noise_mode, _ptr(G), ldG, seed[0], seed[1], K,
-                                            _ptr(idx), _ptr(val), algo, _ptr(ws), ws_bytes, _stream()), "allpairs_topk")
+                                            _ptr(idx), _ptr(val), _ptr(None if k_limit is None else _chk(k_limit)), algo, _ptr(ws),
+                                            ws_bytes, _stream()), "allpairs_topk")
     if return_ws:      # diagnostics: the guess-and-verify control block is ws[:16] = (msum f32, nfail i32, gmin0 f32)
         return idx, val, ws
     return idx, val

@@ -83,7 +83,7 @@ class ShardedDGGConv:
                                                           P["Wp"].reshape(-1), P["bp"])
         s["xp"] = xp = g_xp.get() if self.world > 1 else xp
         s["idx"], s["val"] = kern.allpairs_topk(xp, self.K, self.t, self.noise_mode, None, self.seed,
-                                                rows=(self.r0, self.r1), algo=self.algo)
+                                                rows=(self.r0, self.r1), algo=self.algo, k_limit=s["k"])
         s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
         # destination-bucket partition of the active entries: the backward's column-side terms run on it (no atomics)
         s["part"] = kern.part_build(s["idx"], s["w"], self.N) if hasattr(kern, "part_build") else None

@@ -101,6 +101,30 @@ def test_allpairs_topk_ranked_noise_bit_exact(dev, N, h):
         assert np.array_equal(Nn(sub_i), ridx[N // 3:N // 3 + 50]) and np.array_equal(Nn(sub_v), rval[N // 3:N // 3 + 50])
 
 
+@pytest.mark.parametrize("noise,algo", [("ranked", 0), ("hash", 1), ("hash", 4), ("none", 1)])
+def test_allpairs_topk_k_limit(dev, noise, algo):
+    """k_limit: the kept ranks equal the unrestricted result; the cut ranks are exactly those the oracle's soft
+    top-k gives zero weight; weights after the ramp are unchanged"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(12)
+    N, h = 3000, 64
+    xp = rng.standard_normal((N, h)).astype(np.float32)
+    xp[xp < 0] *= 0.01
+    k = rng.uniform(1.0, 70.0, N).astype(np.float32)
+    k[:4] = [1.0, 54.4, 55.6, 200.0]
+    mode = {"ranked": O.NOISE_RANKED, "hash": O.NOISE_HASH, "none": O.NOISE_NONE}[noise]
+    idx, val = ops.allpairs_topk(T(xp, dev), K, noise_mode=mode, seed=(5, 9), algo=algo, k_limit=T(k, dev))
+    ridx, rval = O.allpairs_topk(xp, K=K, noise_mode=mode, seed=(5, 9))
+    rw, _ = O.softk(ridx, rval, k, 0)
+    idx, val = Nn(idx), Nn(val)
+    kept = idx >= 0
+    assert np.array_equal(idx[kept], ridx[kept]) and np.array_equal(val[kept], rval[kept])
+    assert (rw[~kept] == 0.0).all(), "a rank with non-zero weight was cut"
+    assert np.array_equal(kept, np.arange(K)[None, :] < np.minimum(np.ceil(k + np.float32(8.5)) + 1, K)[:, None])
+    w, rs = ops.softk_fwd(T(idx, dev), T(val, dev), T(k, dev), 0)
+    np.testing.assert_array_equal(Nn(w), rw)
+
+
 def test_allpairs_row_range_and_ties(dev):
     """row sharding (rows [r0,r1) of the full problem) and exact score ties (duplicate nodes -> lower column first)"""
     from dgg_amd import ops
@@ -282,7 +306,10 @@ def test_module_matches_reference_golden(dev, name):
     adj = m(x, in_adj)
     # forward against the oracle: bit-exact indices/scores
     r = oracle_forward(fx)
-    assert np.array_equal(Nn(adj.idx), r["idx"]) and np.array_equal(Nn(adj.score), r["val"])
+    gi, gs = Nn(adj.idx), Nn(adj.score)
+    kept = gi >= 0                               # all-pairs mode cuts the ranks the ramp zeroes exactly (k_limit)
+    assert np.array_equal(gi[kept], r["idx"][kept]) and np.array_equal(gs[kept], r["val"][kept])
+    assert (r["w"][~kept] == 0.0).all(), "a rank with non-zero weight was cut"
     np.testing.assert_allclose(Nn(adj.k), fx["k"], rtol=1e-5, atol=1e-5)
     w = Nn(adj.values())
     k_only_sparse = fx["meta"]["args"]["dgg_mode_k_select"] == "k_only" and "rows" in fx

@@ -72,10 +72,14 @@ class CpuKern:
         return (f32(dxk), f32(dp1.T @ feat.numpy()), f32(dp1.sum(0)), f32(dm.T @ z.numpy()), f32(dm.sum(0)),
                 f32((dkp[:, None] * m).sum(0)[None, :]), f32([dkp.sum()]))
 
-    def allpairs_topk(self, xp, K, t, noise_mode, G, seed, rows=None, algo=0):
+    def allpairs_topk(self, xp, K, t, noise_mode, G, seed, rows=None, algo=0, k_limit=None):
         sys.path.insert(0, ROOT)
         from oracle import oracle as O
         idx, val = O.allpairs_topk(xp.numpy(), K=K, t=t, noise_mode=noise_mode, seed=seed, rows=rows)
+        if k_limit is not None:                          # ranks the ramp zeroes exactly (include/dgg_hip.h, k_limit)
+            L = np.minimum(np.ceil(k_limit.numpy() + np.float32(8.5)) + 1, K)
+            cut = np.arange(K)[None, :] >= L[:, None]
+            idx[cut], val[cut] = -1, 0.0
         return self._t(idx), self._t(val)
 
     @staticmethod
