@@ -241,7 +241,10 @@ def main():
         # SpMM Y_i = sum_r A_ir X_j: per active edge one gathered row of X; per row idx, ahat and the output row
         "spmm_fwd": dict(ms=t_spmm * 1e3, bytes=active * 4 * d + rows_loc * (4 * d + 2 * 256)),
     }
-    dom = max(kern, key=lambda n: kern[n]["ms"])
+    kern["edge_bwd"]["composite"] = "edge_bwd_rows + edge_bwd_cols + edge_cols_finish (one C-ABI call, three launches)"
+    # the roofline object describes ONE launch (so that its duration can be checked against the rocprofv3 kernel
+    # stats under profiles/): the longest single kernel of the step
+    dom = max((n for n in kern if "composite" not in kern[n]), key=lambda n: kern[n]["ms"])
     for n_, v in kern.items():
         v["GBps"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
     pairs = float(rows_loc) * N
@@ -260,7 +263,8 @@ def main():
                          "frac": kern[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": traffic.get(dom),
                          "kernel_ms": kern[dom]["ms"], "algorithmic_bytes": kern[dom]["bytes"],
                          "note": "algorithmic bytes per launch / event-timed duration; gathered rows count once per use"},
-            "kernels": {n_: {"ms": v["ms"], "GBps": v["GBps"], "frac_hbm": v["GBps"] / HBM_PEAK_GBPS} for n_, v in kern.items()},
+            "kernels": {n_: {"ms": v["ms"], "GBps": v["GBps"], "frac_hbm": v["GBps"] / HBM_PEAK_GBPS,
+                             **({"composite": v["composite"]} if "composite" in v else {})} for n_, v in kern.items()},
             # the north-star pair stage: SURVEY 8(d) algorithmic flops (232/pair over all N^2 pairs) per second; the
             # ranked / pruned kernels score only the pairs that can still enter a row's top-64, so this exceeds the
             # fp32 peak by construction (the exhaustive kernel, which executes every pair, reaches frac 0.07)

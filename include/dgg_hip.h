@@ -70,7 +70,8 @@ int dgg_gemm_tn_acc(const float *A, const float *B, int64_t N, int M1, int M2, f
 
 /* ---- learned degree k (k_estimate_net, dgm.py:1472-1586; LearnableKEncoder.forward, dgm.py:2051-2063) ------ */
 /* mu_sd[0] = mean(deg), mu_sd[1] = unbiased std(deg)   (dgm.py:1568-1570; deg replaces in_adj.to_dense().sum(-1)) */
-int dgg_degree_stats(const float *deg, int64_t N, float *mu_sd, void *stream);
+int dgg_degree_stats(const float *deg, int64_t N, float *mu_sd, void *ws, void *stream);
+size_t dgg_degree_stats_ws_bytes(void); /* device workspace of dgg_degree_stats (partial sums) */
 /* mode "x" (dgm.py:1562-1586): xk = leaky(node_encode_for_k(x)) [N,h]; W1/b1 = k_embed.0 [h2][h+1]; Wmu/bmu =
  * k_net.k_mu [h4][h2]; Wp/bp = k_net.k_project [h4]/[1].  Saves (nullable) z [N,h2], u [N] (pre-relu), feat
  * [N,h+1] = [xk | normalised degree] for the backward. */

@@ -15,7 +15,8 @@ PROTOTYPES = {
     "dgg_gemm_tn_acc": [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
     "dgg_gemm_tn_ws_floats": [_i64, _i32, _i32],
     "dgg_linear_bwd_ws_floats": [_i64, _i32, _i32],
-    "dgg_degree_stats": [_vp, _i64, _vp, _vp],
+    "dgg_degree_stats": [_vp, _i64, _vp, _vp, _vp],
+    "dgg_degree_stats_ws_bytes": [],
     "dgg_knet_x_fwd": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_knet_x_bwd_nodes": [_i64, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_knet_input_deg_fwd": [_vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
@@ -58,7 +59,8 @@ def lib():
             fn = getattr(L, name)      # AttributeError if the library does not export a declared symbol
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        for name in ("dgg_allpairs_workspace_bytes", "dgg_gemm_tn_ws_floats", "dgg_linear_bwd_ws_floats", "dgg_part_ws_bytes"):
+        for name in ("dgg_allpairs_workspace_bytes", "dgg_gemm_tn_ws_floats", "dgg_linear_bwd_ws_floats", "dgg_part_ws_bytes",
+                     "dgg_degree_stats_ws_bytes"):
             getattr(L, name).restype = C.c_size_t
         _lib = L
     return _lib

@@ -18,27 +18,46 @@ using namespace dgg;
 
 namespace dggk {
 
-// mu_sd[0] = mean(deg), mu_sd[1] = unbiased std(deg); double accumulation, single workgroup
-__global__ __launch_bounds__(1024) void degree_stats_kernel(const float *__restrict__ deg, int64_t N,
-                                                            float *__restrict__ mu_sd) {
-    __shared__ double red[1024];
-    __shared__ double mean_s;
+// mu_sd[0] = mean(deg), mu_sd[1] = unbiased std(deg); double accumulation.  Two passes (mean, then squared deviations)
+// over DS_BLOCKS workgroups each, partial sums combined in a fixed order (deterministic), then a one-thread finish.
+constexpr int DS_BLOCKS = 256;
+__device__ __forceinline__ double ds_block_sum(double v, double *red) {
     const int tid = threadIdx.x;
-    double s = 0.0;
-    for (int64_t i = tid; i < N; i += 1024) s += (double)deg[i];
-    red[tid] = s;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    if (tid == 0) mean_s = red[0] / (double)N;
-    __syncthreads();
-    const double m = mean_s;
-    double v = 0.0;
-    for (int64_t i = tid; i < N; i += 1024) { double d = (double)deg[i] - m; v += d * d; }
-    __syncthreads();
     red[tid] = v;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    if (tid == 0) { mu_sd[0] = (float)m; mu_sd[1] = (float)sqrt(red[0] / (double)(N - 1)); }
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double ds_total(const double *part, double *red) {   // same order in every workgroup
+    return ds_block_sum(part[threadIdx.x], red);
+}
+template <int PASS>
+__global__ __launch_bounds__(256) void degree_stats_pass(const float *__restrict__ deg, int64_t N, double *__restrict__ part,
+                                                         float *__restrict__ mu_sd) {
+    __shared__ double red[256];
+    double m = 0.0;
+    if (PASS >= 1) m = ds_total(part, red) / (double)N;
+    if (PASS == 2) {
+        const double v = ds_total(part + DS_BLOCKS, red);
+        if (threadIdx.x == 0) { mu_sd[0] = (float)m; mu_sd[1] = (float)sqrt(v / (double)(N - 1)); }
+        return;
+    }
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < N; i += stride) {
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (i + 3 < N && ((reinterpret_cast<uintptr_t>(deg) & 15) == 0)) {
+            const float4 q = *reinterpret_cast<const float4 *>(deg + i);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            for (int u = 0; u < 4; u++) { const double d = (double)v[u] - m; s += PASS == 0 ? d : d * d; }
+        } else {
+            for (int u = 0; u < 4 && i + u < N; u++) { const double d = (double)deg[i + u] - m; s += PASS == 0 ? d : d * d; }
+        }
+    }
+    s = ds_block_sum(s, red);
+    if (threadIdx.x == 0) part[PASS * DS_BLOCKS + blockIdx.x] = s;
 }
 
 constexpr int WPB = 4;
@@ -269,9 +288,16 @@ using namespace dggk;
 
 extern "C" {
 
-int dgg_degree_stats(const float *deg, int64_t N, float *mu_sd, void *stream) {
+size_t dgg_degree_stats_ws_bytes(void) { return 2 * DS_BLOCKS * sizeof(double); }
+
+int dgg_degree_stats(const float *deg, int64_t N, float *mu_sd, void *ws, void *stream) {
     if (N < 2) return dgg_set_error(DGG_ERR_ARG, "degree_stats needs N >= 2");
-    hipLaunchKernelGGL(degree_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, deg, N, mu_sd);
+    if (!ws) return dgg_set_error(DGG_ERR_ARG, "degree_stats needs dgg_degree_stats_ws_bytes() bytes of workspace");
+    double *part = reinterpret_cast<double *>(ws);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(degree_stats_pass<0>, dim3(DS_BLOCKS), dim3(256), 0, st, deg, N, part, mu_sd);
+    hipLaunchKernelGGL(degree_stats_pass<1>, dim3(DS_BLOCKS), dim3(256), 0, st, deg, N, part, mu_sd);
+    hipLaunchKernelGGL(degree_stats_pass<2>, dim3(1), dim3(256), 0, st, deg, N, part, mu_sd);
     return dgg_check_launch("degree_stats");
 }
 

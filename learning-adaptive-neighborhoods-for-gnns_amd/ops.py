@@ -49,8 +49,9 @@ def linear_bwd(x, W, y, dy, act=ACT_NONE, w_layout=0, need_dx=True, need_db=True
     N, d = x.shape
     out = W.shape[0] if w_layout == 0 else W.shape[1]
     dx = torch.empty_like(x) if need_dx else None
-    dW = torch.zeros_like(W)
-    db = torch.zeros((out,), device=x.device, dtype=torch.float32) if need_db else None
+    zz = torch.zeros((W.numel() + (out if need_db else 0),), device=x.device, dtype=torch.float32)   # one fill for both
+    dW = zz[:W.numel()].view(W.shape)
+    db = zz[W.numel():] if need_db else None
     ws = torch.empty((int(_lib.lib().dgg_linear_bwd_ws_floats(N, d, out)),), device=x.device, dtype=torch.float32)
     yy = _chk(y) if act != ACT_NONE else None
     _lib.check(_lib.lib().dgg_linear_bwd(_ptr(x), N, d, _ptr(W), out, w_layout, act, _ptr(yy), _ptr(dy), _ptr(dx), _ptr(dW),
@@ -63,8 +64,9 @@ def gemm_tn(A, B, colsum=False):
     A, B = _chk(A), _chk(B)
     N, M1 = A.shape
     M2 = B.shape[1]
-    Cm = torch.zeros((M1, M2), device=A.device, dtype=torch.float32)
-    cs = torch.zeros((M1,), device=A.device, dtype=torch.float32) if colsum else None
+    zz = torch.zeros((M1 * M2 + (M1 if colsum else 0),), device=A.device, dtype=torch.float32)       # one fill for both
+    Cm = zz[:M1 * M2].view(M1, M2)
+    cs = zz[M1 * M2:] if colsum else None
     ws = torch.empty((int(_lib.lib().dgg_gemm_tn_ws_floats(N, M1, M2)),), device=A.device, dtype=torch.float32)
     _lib.check(_lib.lib().dgg_gemm_tn_acc(_ptr(A), _ptr(B), N, M1, M2, _ptr(Cm), 0, _ptr(cs), _ptr(ws), _stream()), "gemm_tn_acc")
     return (Cm, cs) if colsum else Cm
@@ -73,7 +75,8 @@ def gemm_tn(A, B, colsum=False):
 def degree_stats(deg):
     deg = _chk(deg)
     out = torch.empty((2,), device=deg.device, dtype=torch.float32)
-    _lib.check(_lib.lib().dgg_degree_stats(_ptr(deg), deg.shape[0], _ptr(out), _stream()), "degree_stats")
+    ws = torch.empty((int(_lib.lib().dgg_degree_stats_ws_bytes()),), device=deg.device, dtype=torch.uint8)
+    _lib.check(_lib.lib().dgg_degree_stats(_ptr(deg), deg.shape[0], _ptr(out), _ptr(ws), _stream()), "degree_stats")
     return out
 
 

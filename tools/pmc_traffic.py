@@ -13,22 +13,30 @@ import json
 import sys
 from collections import defaultdict
 
-NAMES = {"edge_bwd": "edge_bwd_kernel", "spmm_bwd": "spmm_bwd_kernel", "spmm_fwd": "spmm_fwd_kernel",
-         "allpairs_topk_ranked": "allpairs_topk_ranked", "gemm_tn_partial": "gemm_tn_partial", "linear_fwd": "linear_fwd_mfma",
-         "knet_x_fwd": "knet_x_fwd_kernel", "knet_x_bwd": "knet_x_bwd_kernel", "norm_bwd_da": "norm_bwd_da_kernel"}
+# bench.py kernel key -> rocprof kernel-name substrings (several = one C-ABI call made of several launches: summed)
+NAMES = {"allpairs_topk": ["allpairs_topk_ranked"], "spmm_fwd": ["spmm_fwd_kernel"], "spmm_bwd": ["sddmm_pair_kernel"],
+         "edge_bwd": ["edge_bwd_rows", "edge_bwd_cols", "edge_cols_finish"], "edge_bwd_rows": ["edge_bwd_rows"],
+         "edge_bwd_cols": ["edge_bwd_cols"], "norm_bwd_da": ["norm_da_rows", "norm_da_cols"],
+         "part_build": ["part_pass", "part_sort", "part_scan"], "gemm_tn_partial": ["gemm_tn_partial"],
+         "linear_fwd": ["linear_fwd_mfma"], "knet_x_fwd": ["knet_x_fwd_tpn"], "knet_x_bwd": ["knet_x_bwd_tpn"],
+         "softk_bwd": ["softk_bwd_kernel"]}
 
 
 def per_kernel(d, counter):
-    acc, cnt = defaultdict(float), defaultdict(int)
+    acc, cnt = defaultdict(float), defaultdict(int)                  # per kernel-name substring
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
                 continue
-            for key, pat in NAMES.items():
-                if pat in r["Kernel_Name"]:
-                    acc[key] += float(r["Counter_Value"])
-                    cnt[key] += 1
-    return {k: acc[k] / cnt[k] for k in acc}
+            for pats in NAMES.values():
+                for pat in pats:
+                    if pat in r["Kernel_Name"]:
+                        acc[pat] += float(r["Counter_Value"])
+                        cnt[pat] += 1
+    # average per launch of each kernel; launches of one call summed (part_pass runs twice per call: count both)
+    mult = {"part_pass": 2.0}
+    return {k: sum(acc[p_] / cnt[p_] * mult.get(p_, 1.0) for p_ in pats if cnt[p_]) for k, pats in NAMES.items()
+            if any(cnt[p_] for p_ in pats)}
 
 
 if __name__ == "__main__":
