@@ -570,3 +570,118 @@ ORA_API void ora_edge_bwd_rows(const float *xp, int64_t N, int64_t R, int h, con
     for (int64_t tix = 0; tix < N * h; tix++) dxp[tix] = (float)acc[tix];
     free(acc);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* edge-MLP scorers on a candidate edge list (dgm.py:1628-1719)               */
+/*   u-v-A_uv 1628-1644, u-v-deg 1645-1670, u-v-deg-dist 1671-1702, edge_conv 1703-1719        */
+/* The reference evaluates  sigmoid(W2 act(W1 [x_u, x_v, extras] + b1) + b2)  per edge.  The    */
+/* first layer is split by linearity into per-NODE products AB = xp [Wa | Wb]^T ([N, 2*hw],     */
+/* computed by ora_linear) plus the per-edge extras; canonical order per hidden unit o:         */
+/*   z = A[u][o] + B[v][o]; z = fma(deg_u, wdu[o], z); z = fma(deg_v, wdv[o], z);               */
+/*   z = fma(ex_e, wex[o], z); z += b1[o]; hid = act(z); s = fma(hid, w2[o], s)  (o ascending)  */
+/*   p = 1 / (1 + exp(-(s + b2)))                                                               */
+/* ex_mode: 0 none, 1 per-edge array ex_in (a_uv), 2 exp(t_ex * ||xp_u - xp_v||) (u-v-deg-dist) */
+/* act: 1 LeakyReLU (edge_encode), 0 identity (edge_conv: theta(v-u) + phi(u) is linear)        */
+/* ------------------------------------------------------------------------------------------ */
+static inline float mlp_edge_p(const float *AB, int hw, int64_t u, int64_t v, const float *deg, float ex, int has_ex,
+                               const float *wdu, const float *wdv, const float *wex, const float *b1, const float *w2,
+                               float b2, int act) {
+    const float *A = AB + u * 2 * hw, *B = AB + v * 2 * hw + hw;
+    float s = 0.0f;
+    for (int o = 0; o < hw; o++) {
+        float z = A[o] + B[o];
+        if (deg) { z = fmaf(deg[u], wdu[o], z); z = fmaf(deg[v], wdv[o], z); }
+        if (has_ex) z = fmaf(ex, wex[o], z);
+        z = z + b1[o];
+        float hid = (act == 1) ? (z > 0.0f ? z : 0.01f * z) : z;
+        s = fmaf(hid, w2[o], s);
+    }
+    s = s + b2;
+    return 1.0f / (1.0f + ora_exp(-s));
+}
+ORA_API void ora_edge_mlp_fwd(const float *AB, const float *xp, int64_t N, int h, int hw, const int32_t *erow,
+                              const int32_t *col, int64_t E, const float *deg, const float *ex_in, int ex_mode, float t_ex,
+                              const float *wdu, const float *wdv, const float *wex, const float *b1, const float *w2,
+                              float b2, int act, float *p_edge, float *ex_out) {
+    (void)N;
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < E; e++) {
+        int64_t u = erow[e], v = col[e];
+        float ex = 0.0f;
+        if (ex_mode == 1) ex = ex_in[e];
+        else if (ex_mode == 2) ex = ora_exp(t_ex * pair_dist(xp + u * h, xp + v * h, h));
+        if (ex_out) ex_out[e] = ex;
+        p_edge[e] = mlp_edge_p(AB, hw, u, v, deg, ex, ex_mode != 0, wdu, wdv, wex, b1, w2, b2, act);
+    }
+}
+/* perturbation + per-row top-K on given edge probabilities; columns of a row ascending (coalesced COO), ties by
+ * column; eid = index of the selected candidate in col[] (-1 for empty slots) */
+ORA_API void ora_edgelist_topk_p(const float *p_edge, int64_t N, const int64_t *rowptr, const int32_t *col, int noise_mode,
+                                 const float *G, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, int32_t *eid) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < N; i++) {
+        cand_t list[512];
+        int cnt = 0;
+        for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
+            int32_t j = col[e];
+            float g = 0.0f, v = p_edge[e];
+            if (noise_mode == 1) g = G[i * N + j];
+            else if (noise_mode >= 2) g = ora_noise(s0, s1, (uint32_t)i, (uint32_t)j, noise_mode == 3);
+            if (noise_mode != 0) v = ora_exp(ora_log(v + 1e-8f) + g);
+            topk_insert(list, &cnt, K, v, (int32_t)(e - rowptr[i]));           /* payload: position in the row */
+        }
+        for (int r = 0; r < K; r++) {
+            idx[i * K + r] = r < cnt ? col[rowptr[i] + list[r].j] : -1;
+            val[i * K + r] = r < cnt ? list[r].v : 0.0f;
+            eid[i * K + r] = r < cnt ? (int32_t)(rowptr[i] + list[r].j) : -1;
+        }
+    }
+}
+/* backward of the scorer for the selected entries: dval (wrt the stored score) -> dAB [N, 2*hw], parameter gradients
+ * dpar = [dwdu hw | dwdv hw | dwex hw | db1 hw | dw2 hw | db2 1], dex [N,K] (wrt the per-edge extra).  Double
+ * accumulation, single-threaded and simple. */
+ORA_API void ora_edge_mlp_bwd(const float *AB, int64_t N, int hw, const int32_t *idx, const int32_t *eid, const float *val,
+                              const float *dval, int K, const float *deg, const float *ex, const float *wdu,
+                              const float *wdv, const float *wex, const float *b1, const float *w2, float b2, int act,
+                              int perturb, float *dAB, float *dpar, float *dex) {
+    double *acc = calloc((size_t)N * 2 * hw, 8), *par = calloc((size_t)5 * hw + 1, 8);
+    double *z = malloc(sizeof(double) * hw), *hid = malloc(sizeof(double) * hw);
+    for (int64_t i = 0; i < N; i++) for (int r = 0; r < K; r++) {
+        int32_t j = idx[i * K + r];
+        if (dex) dex[i * K + r] = 0.0f;
+        if (j < 0) continue;
+        double g = dval[i * K + r];
+        double exv = ex ? (double)ex[eid[i * K + r]] : 0.0;
+        const float *A = AB + i * 2 * hw, *B = AB + (int64_t)j * 2 * hw + hw;
+        double s = 0.0;
+        for (int o = 0; o < hw; o++) {
+            double zz = (double)A[o] + (double)B[o];
+            if (deg) zz += (double)deg[i] * wdu[o] + (double)deg[j] * wdv[o];
+            if (ex) zz += exv * wex[o];
+            zz += b1[o];
+            z[o] = zz;
+            hid[o] = (act == 1) ? (zz > 0.0 ? zz : 0.01 * zz) : zz;
+            s += hid[o] * w2[o];
+        }
+        s += b2;
+        double p = 1.0 / (1.0 + exp(-s));
+        double dp = perturb ? g * (double)val[i * K + r] / (p + 1e-8) : g;
+        double ds = dp * p * (1.0 - p);
+        double de = 0.0;
+        for (int o = 0; o < hw; o++) {
+            double dh = ds * w2[o];
+            double dz = (act == 1) ? (z[o] > 0.0 ? dh : 0.01 * dh) : dh;
+            acc[i * 2 * hw + o] += dz;
+            acc[(int64_t)j * 2 * hw + hw + o] += dz;
+            if (deg) { par[o] += dz * deg[i]; par[hw + o] += dz * deg[j]; }
+            if (ex) { par[2 * hw + o] += dz * exv; de += dz * wex[o]; }
+            par[3 * hw + o] += dz;
+            par[4 * hw + o] += ds * hid[o];
+        }
+        par[5 * hw] += ds;
+        if (dex) dex[i * K + r] = (float)de;
+    }
+    for (int64_t e = 0; e < N * 2 * hw; e++) dAB[e] = (float)acc[e];
+    for (int e = 0; e < 5 * hw + 1; e++) dpar[e] = (float)par[e];
+    free(acc); free(par); free(z); free(hid);
+}

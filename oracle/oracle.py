@@ -257,3 +257,45 @@ def edge_bwd(xp, idx, val, dval, t=-0.05, perturb=False):
     lib().ora_edge_bwd(_p(xp), C.c_int64(N), C.c_int(h), _p(idx), _p(val), _p(dval), C.c_int(K), C.c_float(t),
                        C.c_int(int(perturb)), _p(dxp))
     return dxp
+
+
+# ---- edge-MLP scorers on a candidate edge list (dgm.py:1628-1719) ---------------------------
+def edge_mlp_fwd(AB, xp, erow, col, deg, ex_in, ex_mode, t_ex, wdu, wdv, wex, b1, w2, b2, act=1):
+    """-> p_edge [E], ex [E] (the per-edge extra that was used)"""
+    AB, xp = f32(AB), f32(xp)
+    N, h = xp.shape
+    hw = AB.shape[1] // 2
+    erow, col = i32(erow), i32(col)
+    E = col.shape[0]
+    o = lambda a: None if a is None else f32(a)  # noqa: E731
+    deg, ex_in, wdu, wdv, wex, b1, w2 = o(deg), o(ex_in), o(wdu), o(wdv), o(wex), f32(b1), f32(w2)
+    p, ex = np.empty(E, np.float32), np.empty(E, np.float32)
+    lib().ora_edge_mlp_fwd(_p(AB), _p(xp), C.c_int64(N), C.c_int(h), C.c_int(hw), _p(erow), _p(col), C.c_int64(E), _p(deg),
+                           _p(ex_in), C.c_int(ex_mode), C.c_float(t_ex), _p(wdu), _p(wdv), _p(wex), _p(b1), _p(w2),
+                           C.c_float(float(b2)), C.c_int(act), _p(p), _p(ex))
+    return p, ex
+
+
+def edgelist_topk_p(p_edge, N, rowptr, col, K=64, noise_mode=NOISE_NONE, G=None, seed=(0, 0)):
+    p_edge = f32(p_edge)
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    col = i32(col)
+    idx, val, eid = np.empty((N, K), np.int32), np.empty((N, K), np.float32), np.empty((N, K), np.int32)
+    Gc = f32(G) if G is not None else None
+    lib().ora_edgelist_topk_p(_p(p_edge), C.c_int64(N), _p(rowptr), _p(col), C.c_int(noise_mode), _p(Gc), C.c_uint32(seed[0]),
+                              C.c_uint32(seed[1]), C.c_int(K), _p(idx), _p(val), _p(eid))
+    return idx, val, eid
+
+
+def edge_mlp_bwd(AB, idx, eid, val, dval, deg, ex, wdu, wdv, wex, b1, w2, b2, act=1, perturb=False):
+    """-> dAB [N,2hw], dpar = [dwdu|dwdv|dwex|db1|dw2|db2], dex [N,K]"""
+    AB, idx, eid, val, dval = f32(AB), i32(idx), i32(eid), f32(val), f32(dval)
+    N, K = idx.shape
+    hw = AB.shape[1] // 2
+    o = lambda a: None if a is None else f32(a)  # noqa: E731
+    deg, ex, wdu, wdv, wex = o(deg), o(ex), o(wdu), o(wdv), o(wex)
+    dAB, dpar, dex = np.empty_like(AB), np.empty(5 * hw + 1, np.float32), np.empty((N, K), np.float32)
+    lib().ora_edge_mlp_bwd(_p(AB), C.c_int64(N), C.c_int(hw), _p(idx), _p(eid), _p(val), _p(dval), C.c_int(K), _p(deg), _p(ex),
+                           _p(wdu), _p(wdv), _p(wex), _p(f32(b1)), _p(f32(w2)), C.c_float(float(b2)), C.c_int(act),
+                           C.c_int(int(perturb)), _p(dAB), _p(dpar), _p(dex))
+    return dAB, dpar, dex

@@ -146,6 +146,24 @@ def edgelist_cases():
     run_dgg("edgelist_inputdeg_none", N, d, h, a, in_adj, x, None, cot, 1.0, True)
 
 
+def edgemlp_cases():
+    """edge-MLP scorers of the live class (dgm.py:1628-1725) on a weighted candidate graph"""
+    N, d, h = 96, 24, 16
+    gen = torch.Generator().manual_seed(17)
+    A = random_graph(N, 24, gen).to_dense()
+    Wt = 0.5 + torch.rand(N, N, generator=gen)
+    Wt = (Wt + Wt.T) / 2
+    in_adj = (A * Wt).to_sparse().coalesce()            # non-unit edge values: a_uv and the degrees are informative
+    x = torch.randn(N, d, generator=gen)
+    cot = torch.from_numpy(grid_normal(61, (N, N)))
+    G = grid_gumbel(62, (N, N))
+    for mode, extra, nz in [("u-v-deg", 2, "none"), ("u-v-deg", 2, "asym"), ("u-v-A_uv", 1, "none"),
+                            ("u-v-deg-dist", 3, "asym"), ("edge_conv", 0, "none"), ("A_uv", 0, "none")]:
+        a = base_args(dgg_mode_edge_net=mode, extra_edge_dim=extra, perturb_edge_prob=(nz != "none"))
+        run_dgg(f"edgemlp_{mode.replace('-', '').replace('_', '')}_{nz}", N, d, h, a, in_adj, x,
+                None if nz == "none" else G, cot, 1.0, True)
+
+
 def allpairs_cases():
     N, d, h = 256, 32, 16
     gen = torch.Generator().manual_seed(8)
@@ -224,6 +242,8 @@ if __name__ == "__main__":
         allpairs_cases()
     if "conv" in which:
         conv_cases()
+    if "edgemlp" in which:
+        edgemlp_cases()
 
 
 def model_cases():
