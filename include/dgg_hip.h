@@ -106,6 +106,31 @@ size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K);
 int dgg_edgelist_topk(const float *xp, int64_t N, int h, const int64_t *rowptr, const int32_t *col, float t,
                       int noise_mode, const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx,
                       float *val, void *stream);
+
+/* ---- edge-MLP scorers on a candidate edge list (dgm.py:1628-1725: u-v-A_uv, u-v-deg, u-v-deg-dist, edge_conv, A_uv) --
+ * The reference evaluates sigmoid(W2 act(W1 [x_u, x_v, extras] + b1) + b2) per edge (edge_encode, dgm.py:1101-1105;
+ * edge_conv_* 1107-1109; adj_project 1117).  By linearity the first layer is split into per-node products
+ * AB = xp [Wa | Wb]^T ([N, 2*hw], computed with dgg_linear_fwd) and per-edge terms:
+ *   z_o = A[u][o] + B[v][o] (+ deg_u wdu_o + deg_v wdv_o) (+ ex_e wex_o) + b1_o;  p_e = sigmoid(sum_o act(z_o) w2_o + b2)
+ * erow/col [E]: the coalesced COO candidate list (row-major); deg (nullable): row sums of in_adj (dgm.py:1653);
+ * ex_mode 0 none, 1 ex_in[e] (a_uv, dgm.py:1636), 2 exp(t_ex ||xp_u - xp_v||) (dgm.py:1684-1686, needs xp);
+ * act 1 LeakyReLU, 0 identity; b2 is a device pointer (the parameter).  ex_out (nullable, [E]): the extra used. */
+int dgg_edge_mlp_fwd(const float *AB, const float *xp, int64_t N, int h, int hw, const int32_t *erow, const int32_t *col,
+                     int64_t E, const float *deg, const float *ex_in, int ex_mode, float t_ex, const float *wdu,
+                     const float *wdv, const float *wex, const float *b1, const float *w2, const float *b2, int act,
+                     float *p_edge, float *ex_out, void *stream);
+/* perturbation (dgm.py:1211-1229) + torch.sort (dgm.py:1404) kept to the K best per row, on given edge probabilities
+ * p_edge [E] (CSR order, columns of a row ascending).  eid [N,K]: index of each selected candidate in col[] (-1 empty) */
+int dgg_edgelist_topk_p(const float *p_edge, int64_t N, const int64_t *rowptr, const int32_t *col, int noise_mode,
+                        const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, int32_t *eid,
+                        void *stream);
+/* autograd of dgg_edge_mlp_fwd for the selected entries: dval (wrt the stored score) -> dAB [N,2*hw] and
+ * dpar [5*hw+1] = [dwdu | dwdv | dwex | db1 | dw2 | db2] (both ACCUMULATED into: caller zeroes), dex [N,K] (nullable,
+ * overwritten; gradient wrt the per-edge extra).  ex [E] as written by the forward (nullable when ex_mode was 0). */
+int dgg_edge_mlp_bwd(const float *AB, int64_t N, int hw, const int32_t *idx, const int32_t *eid, const float *val,
+                     const float *dval, int K, const float *deg, const float *ex, const float *wdu, const float *wdv,
+                     const float *wex, const float *b1, const float *w2, const float *b2, int act, int perturb, float *dAB,
+                     float *dpar, float *dex, void *stream);
 /* selection only, from a dense score matrix [R,N] (test entry: torch.sort(pert_edge_p)[:, :K], dgm.py:1404) */
 int dgg_select_scores(const float *scores, int64_t R, int64_t N, int K, int32_t *idx, float *val, void *stream);
 

@@ -90,5 +90,8 @@ def csr_candidates(in_adj):
     ind = in_adj.indices()
     rowptr = torch._convert_indices_from_coo_to_csr(ind[0], N, out_int32=False)
     col = ind[1].to(torch.int32).contiguous()
-    deg = torch.zeros(N, device=in_adj.device, dtype=torch.float32).index_add_(0, ind[0], in_adj.values().float())
+    # row sums, deterministic (index_add_ uses float atomics: the last bit would change from call to call, and the raw
+    # degrees are an input of the u-v-deg scorers): differences of a float64 running sum at the row boundaries
+    cs = torch.cat([in_adj.values().new_zeros(1, dtype=torch.float64), in_adj.values().double().cumsum(0)])
+    deg = (cs[rowptr[1:]] - cs[rowptr[:-1]]).float()
     return rowptr, col, deg

@@ -1,0 +1,264 @@
+// dgg_edgemlp.hip -- the edge-MLP scorers of the live class on a candidate edge list:
+//   u-v-A_uv dgm.py:1628-1644, u-v-deg 1645-1670, u-v-deg-dist 1671-1702, edge_conv 1703-1719, A_uv 1720-1725.
+// The reference gathers [x_u, x_v, extras] per edge and runs sigmoid(W2 act(W1 . + b1) + b2) as two GEMMs over E rows.
+// By linearity the first layer splits into per-NODE products AB = xp [Wa | Wb]^T ([N, 2*hw], one MFMA GEMM,
+// dgg_linear_fwd) and per-edge terms, so an edge costs 2*hw gathered floats instead of a (2h+extra) x hw product:
+//   z_o = A[u][o] + B[v][o] (+ deg_u wdu_o + deg_v wdv_o) (+ ex_e wex_o) + b1_o;  p = sigmoid(sum_o act(z_o) w2_o + b2)
+// in exactly the operation order of oracle/dgg_oracle.c (mlp_edge_p).  The scorer writes one probability per candidate
+// edge; perturbation + top-K (edgelist_topk_p) and the soft top-k are shared with the u-v-dist path.
+#include "dgg_common.h"
+#include "dgg_api_internal.h"
+
+using namespace dgg;
+
+namespace {
+
+__device__ __forceinline__ float act_apply(float z, int act) { return act == 1 ? (z > 0.0f ? z : __fmul_rn(0.01f, z)) : z; }
+
+// ---- forward: one thread per candidate edge --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(
+    const float *__restrict__ AB, const float *__restrict__ xp, int h, int hw, const int32_t *__restrict__ erow,
+    const int32_t *__restrict__ col, int64_t E, const float *__restrict__ deg, const float *__restrict__ ex_in, int ex_mode,
+    float t_ex, const float *__restrict__ wdu, const float *__restrict__ wdv, const float *__restrict__ wex,
+    const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2, int act,
+    float *__restrict__ p_edge, float *__restrict__ ex_out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int64_t u = erow[e], v = col[e];
+    float ex = 0.0f;
+    if (ex_mode == 1) {
+        ex = ex_in[e];
+    } else if (ex_mode == 2) {                                    // exp(t ||xp_u - xp_v||), canonical chain (dgm.py:1684-1686)
+        const float *a = xp + u * h, *b = xp + v * h;
+        float d2 = 0.0f;
+        for (int c = 0; c < h; c++) {
+            const float df = __fadd_rn(a[c], -b[c]);
+            d2 = __fmaf_rn(df, df, d2);
+        }
+        ex = c_exp(__fmul_rn(t_ex, c_sqrt(d2)));
+    }
+    if (ex_out) ex_out[e] = ex;
+    const float *A = AB + u * 2 * hw, *B = AB + v * 2 * hw + hw;
+    const float du = deg ? deg[u] : 0.0f, dv = deg ? deg[v] : 0.0f;
+    float s = 0.0f;
+    for (int o = 0; o < hw; o++) {
+        float z = __fadd_rn(A[o], B[o]);
+        if (deg) { z = __fmaf_rn(du, wdu[o], z); z = __fmaf_rn(dv, wdv[o], z); }
+        if (ex_mode != 0) z = __fmaf_rn(ex, wex[o], z);
+        z = __fadd_rn(z, b1[o]);
+        s = __fmaf_rn(act_apply(z, act), w2[o], s);
+    }
+    s = __fadd_rn(s, b2[0]);
+    p_edge[e] = __fdiv_rn(1.0f, __fadd_rn(1.0f, c_exp(-s)));
+}
+
+// ---- perturbation + per-row top-K on given edge probabilities: one wavefront per row ----------------------------------
+// key payload = position of the candidate in its row (columns of a row ascend -> same tie order as the column key)
+__global__ __launch_bounds__(256) void edgelist_topk_p_kernel(
+    const float *__restrict__ p_edge, int64_t N, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    int noise_mode, const float *__restrict__ G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *__restrict__ idx,
+    float *__restrict__ val, int32_t *__restrict__ eid) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const bool sym = noise_mode == 3;
+    uint64_t list = DGG_EMPTY_KEY;
+    const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
+    for (int64_t eb = e0; eb < e1; eb += 64) {
+        const int64_t e = eb + lane;
+        uint64_t key = DGG_EMPTY_KEY;
+        if (e < e1) {
+            float v = p_edge[e];
+            if (noise_mode != 0) {
+                const int32_t j = col[e];
+                const float g = noise_mode == 1 ? G[i * ldG + j] : pair_noise(s0, s1, (uint32_t)i, (uint32_t)j, sym);
+                v = c_exp(__fadd_rn(c_log(__fadd_rn(v, 1e-8f)), g));
+            }
+            key = make_key(v, (int32_t)(e - e0));
+        }
+        key = wave_sort_desc(key, lane);
+        list = wave_merge_top64(list, key, lane);
+    }
+    if (lane < K) {
+        const bool empty = list == DGG_EMPTY_KEY;
+        const int64_t e = e0 + key_col(list);
+        idx[i * K + lane] = empty ? -1 : col[e];
+        val[i * K + lane] = empty ? 0.0f : key_val(list);
+        eid[i * K + lane] = empty ? -1 : (int32_t)e;
+    }
+}
+
+// ---- backward: one wavefront per row, LPE = hw/VEC lanes per selected entry -------------------------------------------
+// dA_i: registers -> plain store; dB_j: float atomics (256-B rows at hw = 64); parameter gradients: registers across the
+// rows of a persistent workgroup -> LDS -> one atomic per workgroup and element.
+template <int VEC>
+__global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
+    const float *__restrict__ AB, int64_t N, int hw, const int32_t *__restrict__ idx, const int32_t *__restrict__ eid,
+    const float *__restrict__ val, const float *__restrict__ dval, int K, const float *__restrict__ deg,
+    const float *__restrict__ ex, const float *__restrict__ wdu, const float *__restrict__ wdv,
+    const float *__restrict__ wex, const float *__restrict__ b1, const float *__restrict__ w2,
+    const float *__restrict__ b2, int act, int perturb, float *__restrict__ dAB, float *__restrict__ dpar,
+    float *__restrict__ dex) {
+    extern __shared__ float red[];                               // [4 waves][5*hw + 1]
+    const int LPE = hw / VEC, EPI = 64 / LPE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane % LPE, slot = lane / LPE;
+    const int o0 = c * VEC;
+    float wdu_r[VEC], wdv_r[VEC], wex_r[VEC], b1_r[VEC], w2_r[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; q++) {
+        wdu_r[q] = deg ? wdu[o0 + q] : 0.0f; wdv_r[q] = deg ? wdv[o0 + q] : 0.0f; wex_r[q] = ex ? wex[o0 + q] : 0.0f;
+        b1_r[q] = b1[o0 + q]; w2_r[q] = w2[o0 + q];
+    }
+    const float b2v = b2[0];
+    float g_wdu[VEC] = {}, g_wdv[VEC] = {}, g_wex[VEC] = {}, g_b1[VEC] = {}, g_w2[VEC] = {}, g_b2 = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < N; i += (int64_t)gridDim.x * 4) {
+        float Ai[VEC], dA[VEC] = {};
+#pragma unroll
+        for (int q = 0; q < VEC; q++) Ai[q] = AB[i * 2 * hw + o0 + q];
+        const float du = deg ? deg[i] : 0.0f;
+        for (int r0 = 0; r0 < K; r0 += EPI) {
+            const int r = r0 + slot;
+            const int32_t j = r < K ? idx[i * K + r] : -1;
+            const float g = r < K ? dval[i * K + r] : 0.0f;
+            const bool actv = j >= 0 && g != 0.0f;
+            if (__ballot(actv) == 0ull) {
+                if (dex && c == 0 && r < K) dex[i * K + r] = 0.0f;
+                continue;
+            }
+            float z[VEC], hid[VEC], part = 0.0f;
+            float dv = 0.0f, exv = 0.0f;
+            if (actv) {
+                dv = deg ? deg[j] : 0.0f;
+                exv = ex ? ex[eid[i * K + r]] : 0.0f;
+#pragma unroll
+                for (int q = 0; q < VEC; q++) {
+                    float zz = Ai[q] + AB[(int64_t)j * 2 * hw + hw + o0 + q];
+                    zz = fmaf(du, wdu_r[q], zz); zz = fmaf(dv, wdv_r[q], zz); zz = fmaf(exv, wex_r[q], zz);
+                    zz += b1_r[q];
+                    z[q] = zz;
+                    hid[q] = act_apply(zz, act);
+                    part = fmaf(hid[q], w2_r[q], part);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < VEC; q++) { z[q] = 0.0f; hid[q] = 0.0f; }
+            }
+            for (int off = 1; off < LPE; off <<= 1) part += __shfl_xor(part, off, 64);
+            float ds = 0.0f;
+            if (actv) {
+                const float p = 1.0f / (1.0f + c_exp(-(part + b2v)));
+                const float dp = perturb ? g * val[i * K + r] / (p + 1e-8f) : g;
+                ds = dp * p * (1.0f - p);
+            }
+            float de = 0.0f;
+#pragma unroll
+            for (int q = 0; q < VEC; q++) {
+                const float dh = ds * w2_r[q];
+                const float dz = act == 1 ? (z[q] > 0.0f ? dh : 0.01f * dh) : dh;
+                dA[q] += dz;
+                g_wdu[q] = fmaf(dz, du, g_wdu[q]); g_wdv[q] = fmaf(dz, dv, g_wdv[q]); g_wex[q] = fmaf(dz, exv, g_wex[q]);
+                g_b1[q] += dz;
+                g_w2[q] = fmaf(ds, hid[q], g_w2[q]);
+                de = fmaf(dz, wex_r[q], de);
+                if (actv && dz != 0.0f) atomicAdd(dAB + (int64_t)j * 2 * hw + hw + o0 + q, dz);
+            }
+            if (c == 0) g_b2 += ds;
+            if (dex) {
+                for (int off = 1; off < LPE; off <<= 1) de += __shfl_xor(de, off, 64);
+                if (c == 0 && r < K) dex[i * K + r] = de;
+            }
+        }
+        for (int off = LPE; off < 64; off <<= 1) {
+#pragma unroll
+            for (int q = 0; q < VEC; q++) dA[q] += __shfl_xor(dA[q], off, 64);
+        }
+        if (slot == 0) {
+#pragma unroll
+            for (int q = 0; q < VEC; q++) dAB[i * 2 * hw + o0 + q] = dA[q];
+        }
+    }
+    // parameter gradients: slots -> lanes of slot 0 -> LDS across waves -> global
+    for (int off = LPE; off < 64; off <<= 1) {
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+            g_wdu[q] += __shfl_xor(g_wdu[q], off, 64); g_wdv[q] += __shfl_xor(g_wdv[q], off, 64);
+            g_wex[q] += __shfl_xor(g_wex[q], off, 64); g_b1[q] += __shfl_xor(g_b1[q], off, 64);
+            g_w2[q] += __shfl_xor(g_w2[q], off, 64);
+        }
+        g_b2 += __shfl_xor(g_b2, off, 64);
+    }
+    const int NP = 5 * hw + 1;
+    if (slot == 0) {
+        float *mine = red + wave * NP;
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+            mine[o0 + q] = g_wdu[q]; mine[hw + o0 + q] = g_wdv[q]; mine[2 * hw + o0 + q] = g_wex[q];
+            mine[3 * hw + o0 + q] = g_b1[q]; mine[4 * hw + o0 + q] = g_w2[q];
+        }
+        if (c == 0) mine[5 * hw] = g_b2;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NP; e += 256) {
+        const float t = (red[e] + red[NP + e]) + (red[2 * NP + e] + red[3 * NP + e]);
+        if (t != 0.0f) atomicAdd(dpar + e, t);
+    }
+}
+
+bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int dgg_edge_mlp_fwd(const float *AB, const float *xp, int64_t N, int h, int hw, const int32_t *erow, const int32_t *col,
+                     int64_t E, const float *deg, const float *ex_in, int ex_mode, float t_ex, const float *wdu,
+                     const float *wdv, const float *wex, const float *b1, const float *w2, const float *b2, int act,
+                     float *p_edge, float *ex_out, void *stream) {
+    (void)N;
+    if (ex_mode < 0 || ex_mode > 2) return dgg_set_error(DGG_ERR_ARG, "edge_mlp_fwd: ex_mode must be 0 (none), 1 (array) or 2 (exp(t dist))");
+    if ((ex_mode == 1 && !ex_in) || (ex_mode == 2 && !xp) || (ex_mode != 0 && !wex) || (deg && (!wdu || !wdv)))
+        return dgg_set_error(DGG_ERR_ARG, "edge_mlp_fwd: missing extras / weights for the requested mode");
+    if (E == 0) return 0;
+    hipLaunchKernelGGL(edge_mlp_fwd_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, AB, xp, h, hw,
+                       erow, col, E, deg, ex_in, ex_mode, t_ex, wdu, wdv, wex, b1, w2, b2, act, p_edge, ex_out);
+    return dgg_check_launch("edge_mlp_fwd");
+}
+
+int dgg_edgelist_topk_p(const float *p_edge, int64_t N, const int64_t *rowptr, const int32_t *col, int noise_mode,
+                        const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, int32_t *eid,
+                        void *stream) {
+    if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    if (noise_mode == 1 && !G) return dgg_set_error(DGG_ERR_ARG, "explicit noise requested but G is NULL");
+    if (noise_mode < 0 || noise_mode > 3)
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "edgelist_topk_p: noise_mode must be none / explicit / hash / symmetric hash");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(edgelist_topk_p_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p_edge, N,
+                       rowptr, col, noise_mode, G, ldG, s0, s1, K, idx, val, eid);
+    return dgg_check_launch("edgelist_topk_p");
+}
+
+// dAB [N, 2*hw] and dpar [5*hw + 1] = [dwdu | dwdv | dwex | db1 | dw2 | db2] are ACCUMULATED into (caller zeroes them);
+// dex (nullable) [N,K] is overwritten.
+int dgg_edge_mlp_bwd(const float *AB, int64_t N, int hw, const int32_t *idx, const int32_t *eid, const float *val,
+                     const float *dval, int K, const float *deg, const float *ex, const float *wdu, const float *wdv,
+                     const float *wex, const float *b1, const float *w2, const float *b2, int act, int perturb, float *dAB,
+                     float *dpar, float *dex, void *stream) {
+    if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    const int vec = hw % 4 == 0 ? 4 : 1;
+    const int lpe = hw / vec;
+    if (!pow2(lpe) || lpe > 64)
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "edge_mlp_bwd: hidden width must be 1, 2 or 4 x a power of two (<= 256)");
+    if ((ex && (!wex || !eid)) || (deg && (!wdu || !wdv))) return dgg_set_error(DGG_ERR_ARG, "edge_mlp_bwd: missing extras / weights");
+    if (N == 0) return 0;
+    const unsigned grid = (unsigned)((N + 3) / 4 < 2048 ? (N + 3) / 4 : 2048);
+    const size_t lds = (size_t)4 * (5 * hw + 1) * sizeof(float);
+    if (vec == 4)
+        hipLaunchKernelGGL(edge_mlp_bwd_kernel<4>, dim3(grid), dim3(256), lds, (hipStream_t)stream, AB, N, hw, idx, eid, val, dval, K,
+                           deg, ex, wdu, wdv, wex, b1, w2, b2, act, perturb, dAB, dpar, dex);
+    else
+        hipLaunchKernelGGL(edge_mlp_bwd_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, AB, N, hw, idx, eid, val, dval, K,
+                           deg, ex, wdu, wdv, wex, b1, w2, b2, act, perturb, dAB, dpar, dex);
+    return dgg_check_launch("edge_mlp_bwd");
+}
+
+}  // extern "C"

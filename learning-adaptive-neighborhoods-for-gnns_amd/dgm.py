@@ -7,8 +7,11 @@ dgm.py:1083, 1178 -- the live class behind GCN_DGG / SAGE_DGG / GCNII_DGG / GCNI
 
 Parameters are created in the reference's order with the reference's layer types, so `state_dict()` has the
 same 34 keys/shapes (reference checkpoints load with strict=True) and the same default initialisation under
-the same torch seed.  Parameters that the reference registers but never uses on this path (t, k_W, edge_encode,
-edge_conv_*, ...) are kept for that reason only.
+the same torch seed.  Parameters that the reference registers but never uses (t, k_W, ...) are kept for that reason only.
+
+Edge scorers: `u-v-dist` (all-pairs or edge-list candidates) and the edge-MLP family on edge-list candidates
+(`u-v-deg` -- the reference's default, train_small_graphs.py:184-191 -- `u-v-A_uv`, `u-v-deg-dist`, `edge_conv`, `A_uv`;
+reference dgm.py:1628-1725).
 """
 import torch
 import torch.nn as nn
@@ -16,7 +19,7 @@ import torch.nn as nn
 from . import ops
 from .adjacency import AllPairs, EllAdjacency, csr_candidates
 
-_EDGE_MODES_NEXT = ("u-v-A_uv", "u-v-deg", "u-v-deg-dist", "edge_conv", "A_uv")
+_EDGE_MLP_MODES = ("u-v-A_uv", "u-v-deg", "u-v-deg-dist", "edge_conv", "A_uv")
 
 
 class LearnableKEncoder(nn.Module):
@@ -65,6 +68,55 @@ class _DGGSoftAdjFn(torch.autograd.Function):
         dx2, dWk, dbk = ops.linear_bwd(x, Wk, xk, dxk, ops.ACT_LEAKY, need_dx=need_dx)
         dx = dx1 + dx2 if need_dx else None
         return dx, None, dWe, dbe, dWk, dbk, dW1, db1, dWmu, dbmu, dWp.reshape(Wp.shape), dbp, None
+
+
+class _DGGEdgeMlpAdjFn(torch.autograd.Function):
+    """Same generator with an edge-MLP scorer on edge-list candidates (reference dgm.py:1628-1725).  The first MLP layer
+    is split into per-node products AB = xp [Wa | Wb]^T (MFMA GEMM) and per-edge terms (include/dgg_hip.h,
+    dgg_edge_mlp_fwd); the mode-specific slicing of the reference's parameters into (Wcat, wdu, wdv, wex, b1, w2, b2)
+    happens in differentiable torch ops on the (tiny) parameter tensors, outside this node."""
+
+    @staticmethod
+    def forward(ctx, x, deg, ex_in, We, be, Wk, bk, W1, b1, Wmu, bmu, Wp, bp, Wcat, wdu, wdv, wex, eb1, w2, b2, cfg):
+        xp = ops.linear_fwd(x, We, be, ops.ACT_LEAKY)
+        xk = ops.linear_fwd(x, Wk, bk, ops.ACT_LEAKY)
+        mu_sd = ops.degree_stats(deg)
+        k, z, u, feat = ops.knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp.reshape(-1), bp)
+        rowptr, col, erow = cfg["cand"]
+        AB = ops.linear_fwd(xp, Wcat, None, ops.ACT_NONE)
+        sdeg = deg if wdu is not None else None
+        p_edge, ex = ops.edge_mlp_fwd(AB, xp, erow, col, sdeg, ex_in, cfg["ex_mode"], cfg["t_ex"], wdu, wdv, wex, eb1, w2, b2,
+                                      cfg["act"])
+        idx, val, eid = ops.edgelist_topk_p(p_edge, x.shape[0], rowptr, col, cfg["K"], cfg["noise_mode"], cfg["G"], cfg["seed"])
+        w, rs = ops.softk_fwd(idx, val, k, cfg["mode"])
+        ctx.cfg = cfg
+        # optional tensors (None allowed): kept outside save_for_backward, detached
+        ctx.opt = tuple(None if t_ is None else t_.detach() for t_ in (sdeg, ex, wdu, wdv, wex))
+        ctx.save_for_backward(x, We, Wk, W1, Wmu, bmu, Wp, xp, xk, mu_sd, k, z, u, feat, idx, val, eid, AB, Wcat, eb1, w2, b2)
+        ctx.mark_non_differentiable(idx, val, k, rs)
+        return w, idx, val, k, rs
+
+    @staticmethod
+    def backward(ctx, dw, *_):
+        x, We, Wk, W1, Wmu, bmu, Wp, xp, xk, mu_sd, k, z, u, feat, idx, val, eid, AB, Wcat, eb1, w2, b2 = ctx.saved_tensors
+        sdeg, ex, wdu, wdv, wex = ctx.opt
+        cfg = ctx.cfg
+        need_dx = ctx.needs_input_grad[0]
+        hw = Wcat.shape[0] // 2
+        dval, dk = ops.softk_bwd(idx, val, k, dw.contiguous(), mode=cfg["mode"], normalized=False)
+        dAB, dpar, dex = ops.edge_mlp_bwd(AB, idx, eid, val, dval, sdeg, ex, wdu, wdv, wex, eb1, w2, b2, cfg["act"],
+                                          cfg["noise_mode"] != ops.NOISE_NONE, need_dex=cfg["ex_mode"] == 2)
+        dxp, dWcat, _ = ops.linear_bwd(xp, Wcat, AB, dAB, ops.ACT_NONE, need_dx=True, need_db=False)
+        if cfg["ex_mode"] == 2:                          # exp(t ||xp_u - xp_v||) also depends on the projection
+            dxp = dxp + ops.edge_bwd(xp, idx, val, dex, t=cfg["t_ex"], perturb=False)
+        dx1, dWe, dbe = ops.linear_bwd(x, We, xp, dxp, ops.ACT_LEAKY, need_dx=need_dx)
+        dxk, dW1, db1, dWmu, dbmu, dWp, dbp = ops.knet_x_bwd(xk.shape[1], mu_sd, W1, Wmu, bmu, Wp.reshape(-1), z, u, feat, dk)
+        dx2, dWk, dbk = ops.linear_bwd(x, Wk, xk, dxk, ops.ACT_LEAKY, need_dx=need_dx)
+        dx = dx1 + dx2 if need_dx else None
+        g = lambda t_, a, b: None if t_ is None else dpar[a:b]  # noqa: E731
+        return (dx, None, None, dWe, dbe, dWk, dbk, dW1, db1, dWmu, dbmu, dWp.reshape(Wp.shape), dbp,
+                dWcat if ctx.needs_input_grad[13] else None, g(wdu, 0, hw), g(wdv, hw, 2 * hw), g(wex, 2 * hw, 3 * hw),
+                dpar[3 * hw:4 * hw], dpar[4 * hw:5 * hw], dpar[5 * hw:5 * hw + 1], None)
 
 
 class DGG_LearnableK_debug(nn.Module):
@@ -125,15 +177,47 @@ class DGG_LearnableK_debug(nn.Module):
         # symmetric noise (dgm.py:1216-1223) must be keyed on the unordered pair -> per-pair hash
         return (ops.NOISE_HASH_SYM if self.args.symmetric_noise else ops.NOISE_RANKED), None, seed
 
+    def _edge_mlp_terms(self, avals):
+        """The reference's scorer parameters in the per-node / per-edge form of dgg_edge_mlp_fwd (differentiable slicing).
+
+            u-v-deg       edge_encode.0 [h, 2h+2] on [u, v, deg_u, deg_v]       (dgm.py:1645-1670; raw degrees)
+            u-v-A_uv      edge_encode.0 [h, 2h+1] on [u, v, a_uv]               (dgm.py:1628-1644)
+            u-v-deg-dist  edge_encode.0 [h, 2h+3] on [u, v, deg_u, deg_v, exp(-||u-v||)]   (dgm.py:1671-1702)
+            edge_conv     theta(v-u) + phi(u) = (phi-theta) u + theta v, bias b_theta + b_phi, no activation (1703-1719)
+            A_uv          adj_project(a_uv): hidden width 1, A = B = 0          (dgm.py:1720-1725)"""
+        h, mode = self.latent_dim, self.edge_prob_net_mode
+        d = dict(wdu=None, wdv=None, wex=None, ex_mode=0, t_ex=0.0, act=ops.ACT_LEAKY)
+        ex_in = None
+        if mode in ("u-v-deg", "u-v-A_uv", "u-v-deg-dist"):
+            W0 = self.edge_encode[0].weight
+            need = {"u-v-deg": 2, "u-v-A_uv": 1, "u-v-deg-dist": 3}[mode]
+            assert W0.shape[1] == 2 * h + need, f"edge mode {mode!r} needs extra_edge_dim={need} (edge_encode.0 is {tuple(W0.shape)})"
+            d.update(Wcat=torch.cat([W0[:, :h], W0[:, h:2 * h]], 0), b1=self.edge_encode[0].bias,
+                     w2=self.edge_encode[2].weight.reshape(-1), b2=self.edge_encode[2].bias)
+            if mode != "u-v-A_uv":
+                d.update(wdu=W0[:, 2 * h], wdv=W0[:, 2 * h + 1])
+            if mode == "u-v-A_uv":
+                d.update(wex=W0[:, 2 * h], ex_mode=1)
+                ex_in = avals
+            if mode == "u-v-deg-dist":
+                d.update(wex=W0[:, 2 * h + 2], ex_mode=2, t_ex=-1.0)
+        elif mode == "edge_conv":
+            Th, Ph = self.edge_conv_theta, self.edge_conv_phi
+            d.update(Wcat=torch.cat([Ph.weight - Th.weight, Th.weight], 0), b1=Th.bias + Ph.bias,
+                     w2=self.edge_conv_encode.weight.reshape(-1), b2=self.edge_conv_encode.bias, act=ops.ACT_NONE)
+        else:
+            w = self.adj_project.weight
+            d.update(Wcat=torch.zeros((2, h), device=w.device, dtype=w.dtype), b1=self.adj_project.bias, w2=torch.ones_like(w).reshape(-1),
+                     b2=torch.zeros_like(self.adj_project.bias), wex=w.reshape(-1), ex_mode=1, act=ops.ACT_NONE)
+            ex_in = avals
+        return d, ex_in
+
     def forward(self, x, in_adj, noise=True, writer=None, epoch=None):
         """x [N,dim] fp32 on the GPU; in_adj: sparse COO [N,N] (coalesced, self loops added by the caller) whose
         stored entries are the candidate edges, or `AllPairs(prior_degree)`.  `noise` is accepted and ignored
         exactly like the reference (perturbation is gated by args.perturb_edge_prob only, dgm.py:1211)."""
         assert x.ndim == 2 and len(in_adj.shape) == 2
-        if self.edge_prob_net_mode != "u-v-dist":
-            if self.edge_prob_net_mode in _EDGE_MODES_NEXT:
-                raise NotImplementedError(f"edge mode {self.edge_prob_net_mode!r} is a 'next' row (SURVEY.md 8f); "
-                                          "the HIP path implements 'u-v-dist'")
+        if self.edge_prob_net_mode != "u-v-dist" and self.edge_prob_net_mode not in _EDGE_MLP_MODES:
             raise Exception("mode not found")
         if self.k_net_mode != "x":
             raise NotImplementedError(f"k-net mode {self.k_net_mode!r}: the HIP autograd path implements 'x'")
@@ -143,20 +227,35 @@ class DGG_LearnableK_debug(nn.Module):
             raise NotImplementedError("dgg_hard=True: the reference's hard path is index-confused (SURVEY.md section 7)")
         if self.args.debug_step in (0, 1):
             raise NotImplementedError("debug_step 0/1 return dense [N,N] intermediates in the reference")
+        avals = erow = None
         if isinstance(in_adj, AllPairs):
+            if self.edge_prob_net_mode != "u-v-dist":
+                raise NotImplementedError("all-pairs candidates are defined for 'u-v-dist' only (the other scorers read "
+                                          "per-edge features of in_adj, dgm.py:1628-1725)")
             cand, deg = None, in_adj.prior_degree
         else:
             if isinstance(in_adj, EllAdjacency):     # dgg_adj_input != "input_adj": previous learned graph
                 in_adj = in_adj.to_sparse().detach()
             rowptr, col, deg = csr_candidates(in_adj)
             cand = (rowptr, col)
+            if self.edge_prob_net_mode != "u-v-dist":
+                in_adj = in_adj.coalesce()
+                erow, avals = in_adj.indices()[0].to(torch.int32), in_adj.values().to(torch.float32)
         noise_mode, G, seed = self._noise_cfg()
+        if noise_mode == ops.NOISE_RANKED and cand is not None:
+            noise_mode = ops.NOISE_HASH              # edge-list candidates: every candidate is scored, per-pair hash noise
         cfg = dict(cand=cand, K=self.ell_width, t=ops.T_DIST, noise_mode=noise_mode, G=G, seed=seed, algo=self.topk_algo,
                    mode=ops.MODE_K_TIMES_EDGE_PROB if self.k_select_mode == "k_times_edge_prob" else ops.MODE_K_ONLY)
-        w, idx, val, k, rs = _DGGSoftAdjFn.apply(
-            x, deg, self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias,
-            self.node_encode_for_k[0].weight, self.node_encode_for_k[0].bias, self.k_embed[0].weight, self.k_embed[0].bias,
-            self.k_net.k_mu.weight, self.k_net.k_mu.bias, self.k_net.k_project.weight, self.k_net.k_project.bias, cfg)
+        common = (self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias,
+                  self.node_encode_for_k[0].weight, self.node_encode_for_k[0].bias, self.k_embed[0].weight, self.k_embed[0].bias,
+                  self.k_net.k_mu.weight, self.k_net.k_mu.bias, self.k_net.k_project.weight, self.k_net.k_project.bias)
+        if self.edge_prob_net_mode == "u-v-dist":
+            w, idx, val, k, rs = _DGGSoftAdjFn.apply(x, deg, *common, cfg)
+        else:
+            mlp, ex_in = self._edge_mlp_terms(avals)
+            cfg.update(cand=(rowptr, col, erow), ex_mode=mlp["ex_mode"], t_ex=mlp["t_ex"], act=mlp["act"])
+            w, idx, val, k, rs = _DGGEdgeMlpAdjFn.apply(x, deg, ex_in, *common, mlp["Wcat"], mlp["wdu"], mlp["wdv"], mlp["wex"],
+                                                        mlp["b1"], mlp["w2"], mlp["b2"], cfg)
         if writer is not None:   # the two scalars the reference logs from inside the DGG (dgm.py:1259-1261)
             f = w.detach() if cfg["mode"] == ops.MODE_K_ONLY else (w.detach() / val.clamp(min=1e-30))
             writer.add_scalar("values/first_k_std", f.sum(-1).std(), epoch)

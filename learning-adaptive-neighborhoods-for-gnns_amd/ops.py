@@ -3,6 +3,7 @@
 torch is used for device memory, streams and autograd bookkeeping only: every FLOP of the hot path runs in
 libdgg_hip.so.  Naming follows the reference (dgm.py / model.py) and include/dgg_hip.h.
 """
+import collections
 import ctypes as C
 
 import torch
@@ -24,10 +25,19 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_KEEP = collections.deque(maxlen=64)
+
+
 def _chk(t, dtype=torch.float32):
     assert t.is_cuda, "dgg ops run on the GPU only (no CPU fallback)"
     assert t.dtype == dtype, f"expected {dtype}, got {t.dtype}"
-    return t if t.is_contiguous() else t.contiguous()
+    if t.is_contiguous():
+        return t
+    # A contiguous copy made here is usually consumed as `_ptr(_chk(x))`: it must outlive the enqueue of the kernel that
+    # reads it (once enqueued, the stream-ordered allocator makes reuse safe), so the last few copies are kept alive.
+    c = t.contiguous()
+    _KEEP.append(c)
+    return c
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -119,6 +129,54 @@ def edgelist_topk(xp, rowptr, col, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE,
     _lib.check(_lib.lib().dgg_edgelist_topk(_ptr(xp), N, h, _ptr(rowptr), _ptr(col), t, noise_mode, _ptr(G), ldG, seed[0],
                                             seed[1], K, _ptr(idx), _ptr(val), _stream()), "edgelist_topk")
     return idx, val
+
+
+def edge_mlp_fwd(AB, xp, erow, col, deg, ex_in, ex_mode, t_ex, wdu, wdv, wex, b1, w2, b2, act=ACT_LEAKY):
+    """edge-MLP scorer on the candidate edges (dgm.py:1628-1725) -> p_edge [E], ex [E] (the per-edge extra used)"""
+    AB, xp = _chk(AB), _chk(xp)
+    N, h = xp.shape
+    hw = AB.shape[1] // 2
+    erow, col = _chk(erow, torch.int32), _chk(col, torch.int32)
+    E = col.shape[0]
+    p_edge = torch.empty((E,), device=xp.device, dtype=torch.float32)
+    ex_out = torch.empty((E,), device=xp.device, dtype=torch.float32) if ex_mode else None
+    o = lambda t_: None if t_ is None else _chk(t_)  # noqa: E731
+    _lib.check(_lib.lib().dgg_edge_mlp_fwd(_ptr(AB), _ptr(xp), N, h, hw, _ptr(erow), _ptr(col), E, _ptr(o(deg)), _ptr(o(ex_in)), ex_mode,
+                                           float(t_ex), _ptr(o(wdu)), _ptr(o(wdv)), _ptr(o(wex)), _ptr(_chk(b1)), _ptr(_chk(w2)),
+                                           _ptr(_chk(b2)), act, _ptr(p_edge), _ptr(ex_out), _stream()), "edge_mlp_fwd")
+    return p_edge, ex_out
+
+
+def edgelist_topk_p(p_edge, N, rowptr, col, K=DEFAULT_K, noise_mode=NOISE_NONE, G=None, seed=(0, 0)):
+    """perturbation + per-row top-K on given edge probabilities -> idx, val, eid [N,K]"""
+    p_edge = _chk(p_edge)
+    rowptr, col = _chk(rowptr, torch.int64), _chk(col, torch.int32)
+    idx = torch.empty((N, K), device=p_edge.device, dtype=torch.int32)
+    val = torch.empty((N, K), device=p_edge.device, dtype=torch.float32)
+    eid = torch.empty((N, K), device=p_edge.device, dtype=torch.int32)
+    ldG = 0
+    if G is not None:
+        G = _chk(G)
+        ldG = G.shape[-1]
+    _lib.check(_lib.lib().dgg_edgelist_topk_p(_ptr(p_edge), N, _ptr(rowptr), _ptr(col), noise_mode, _ptr(G), ldG, seed[0], seed[1], K,
+                                              _ptr(idx), _ptr(val), _ptr(eid), _stream()), "edgelist_topk_p")
+    return idx, val, eid
+
+
+def edge_mlp_bwd(AB, idx, eid, val, dval, deg, ex, wdu, wdv, wex, b1, w2, b2, act=ACT_LEAKY, perturb=False, need_dex=False):
+    """-> dAB [N,2hw], dpar [5hw+1] = [dwdu|dwdv|dwex|db1|dw2|db2], dex [N,K] or None"""
+    AB = _chk(AB)
+    N, K = idx.shape
+    hw = AB.shape[1] // 2
+    zz = torch.zeros((N * 2 * hw + 5 * hw + 1,), device=AB.device, dtype=torch.float32)
+    dAB, dpar = zz[:N * 2 * hw].view(N, 2 * hw), zz[N * 2 * hw:]
+    dex = torch.empty((N, K), device=AB.device, dtype=torch.float32) if need_dex else None
+    o = lambda t_: None if t_ is None else _chk(t_)  # noqa: E731
+    _lib.check(_lib.lib().dgg_edge_mlp_bwd(_ptr(AB), N, hw, _ptr(idx), _ptr(eid), _ptr(_chk(val)), _ptr(_chk(dval)), K, _ptr(o(deg)),
+                                           _ptr(o(ex)), _ptr(o(wdu)), _ptr(o(wdv)), _ptr(o(wex)), _ptr(_chk(b1)), _ptr(_chk(w2)),
+                                           _ptr(_chk(b2)), act, int(perturb), _ptr(dAB), _ptr(dpar), _ptr(dex), _stream()),
+               "edge_mlp_bwd")
+    return dAB, dpar, dex
 
 
 def select_scores(scores, K=DEFAULT_K):

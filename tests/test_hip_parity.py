@@ -304,7 +304,11 @@ def test_module_matches_reference_golden(dev, name):
     else:
         in_adj = dgg_amd.AllPairs(T(fx["deg"], dev))
     adj = m(x, in_adj)
-    # forward against the oracle: bit-exact indices/scores
+    # forward against the oracle: bit-exact indices/scores.  The oracle is fed the degrees the module derives from in_adj
+    # (row sums of the stored values; for non-unit edge values the summation order moves the last bit, and the raw
+    # degrees are an input of the u-v-deg scorers)
+    if "rows" in fx:
+        fx = dict(fx, deg=Nn(dgg_amd.csr_candidates(in_adj)[2]))
     r = oracle_forward(fx)
     gi, gs = Nn(adj.idx), Nn(adj.score)
     kept = gi >= 0                               # all-pairs mode cuts the ranks the ramp zeroes exactly (k_limit)
@@ -332,9 +336,12 @@ def test_module_matches_reference_golden(dev, name):
     (adj.values() * T(cot_ell, dev)).sum().backward()
     grads = {n_: p.grad for n_, p in m.named_parameters() if p.grad is not None}
     grads["x"] = x.grad
-    for key in ["x", "node_encode_for_edges.0.weight", "node_encode_for_edges.0.bias", "node_encode_for_k.0.weight",
-                "node_encode_for_k.0.bias", "k_embed.0.weight", "k_embed.0.bias", "k_net.k_mu.weight", "k_net.k_mu.bias",
-                "k_net.k_project.weight", "k_net.k_project.bias"]:
+    keys = ["x", "node_encode_for_k.0.weight", "node_encode_for_k.0.bias", "k_embed.0.weight", "k_embed.0.bias",
+            "k_net.k_mu.weight", "k_net.k_mu.bias", "k_net.k_project.weight", "k_net.k_project.bias"]
+    # plus every parameter the reference gives a gradient on this configuration (the scorer's parameters by edge mode)
+    keys += [n_ for n_, _ in m.named_parameters() if n_ not in keys and np.abs(fx["g." + n_]).max() > 0]
+    assert fx["meta"]["args"]["dgg_mode_edge_net"] == "A_uv" or "node_encode_for_edges.0.weight" in keys
+    for key in keys:
         ref = fx["g." + key]
         scale = max(np.abs(ref).max(), 1e-6)
         err = np.abs(Nn(grads[key]).reshape(ref.shape) - ref).max() / scale
@@ -474,3 +481,48 @@ def test_sharded_layer_step_matches_cpu_restatement(dev, N, d, h, noise):
         r_ = gr[k_].numpy()
         err = np.abs(Nn(g[k_]).reshape(r_.shape) - r_).max() / max(np.abs(r_).max(), 1e-30)
         assert err <= 3e-4, f"grad {k_}: {err:.3e}"
+
+
+@pytest.mark.parametrize("hw,use_deg,ex_mode,act,noise", [(64, True, 0, 1, "hash"), (16, False, 1, 1, "none"), (32, True, 2, 1, "sym"),
+                                                        (8, False, 0, 0, "none"), (1, False, 1, 0, "hash"), (128, True, 2, 1, "none")])
+def test_edge_mlp_kernels(dev, hw, use_deg, ex_mode, act, noise):
+    """edge-MLP scorer + top-K on given probabilities + its backward against the oracle (bit-exact forward)"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(21)
+    N, h = 900, 32
+    rows, cols = np.nonzero(rng.random((N, N)) < 0.06)
+    rows, cols = rows.astype(np.int32), cols.astype(np.int32)
+    rowptr, col = csr_from_coo(rows, cols, N)
+    E = col.shape[0]
+    xp = rng.standard_normal((N, h)).astype(np.float32)
+    AB = (rng.standard_normal((N, 2 * hw)) * 0.5).astype(np.float32)
+    deg = (3 + 20 * rng.random(N)).astype(np.float32) if use_deg else None
+    aval = (0.5 + rng.random(E)).astype(np.float32) if ex_mode == 1 else None
+    v = lambda s_: (rng.standard_normal(hw) * s_).astype(np.float32)  # noqa: E731
+    wdu, wdv = (v(0.05), v(0.05)) if use_deg else (None, None)
+    wex = v(0.5) if ex_mode else None
+    b1, w2, b2 = v(0.1), v(0.4), np.array([0.1], np.float32)
+    t_ex = -1.0
+    o = lambda a: None if a is None else T(a, dev)  # noqa: E731
+    p_e, ex = ops.edge_mlp_fwd(T(AB, dev), T(xp, dev), T(rows, dev), T(col, dev), o(deg), o(aval), ex_mode, t_ex, o(wdu), o(wdv),
+                               o(wex), T(b1, dev), T(w2, dev), T(b2, dev), act)
+    rp, rex = O.edge_mlp_fwd(AB, xp, rows, col, deg, aval, ex_mode, t_ex, wdu, wdv, wex, b1, w2, b2[0], act)
+    assert np.array_equal(Nn(p_e), rp), "edge probabilities differ from the oracle"
+    if ex_mode:
+        assert np.array_equal(Nn(ex), rex)
+    mode = {"none": O.NOISE_NONE, "hash": O.NOISE_HASH, "sym": O.NOISE_HASH_SYM}[noise]
+    idx, val, eid = ops.edgelist_topk_p(p_e, N, T(rowptr, dev), T(col, dev), K, mode, seed=(9, 4))
+    ridx, rval, reid = O.edgelist_topk_p(rp, N, rowptr, col, K, mode, seed=(9, 4))
+    assert np.array_equal(Nn(idx), ridx) and np.array_equal(Nn(val), rval) and np.array_equal(Nn(eid), reid)
+    dval = (rng.standard_normal((N, K)) * (ridx >= 0)).astype(np.float32)
+    dAB, dpar, dex = ops.edge_mlp_bwd(T(AB, dev), idx, eid, val, T(dval, dev), o(deg), ex, o(wdu), o(wdv), o(wex), T(b1, dev),
+                                      T(w2, dev), T(b2, dev), act, noise != "none", need_dex=True)
+    rdAB, rdpar, rdex = O.edge_mlp_bwd(AB, ridx, reid, rval, dval, deg, rex if ex_mode else None, wdu, wdv, wex, b1, w2, b2[0], act,
+                                       noise != "none")
+    for got, ref in [(dAB, rdAB), (dex, rdex)]:
+        np.testing.assert_allclose(Nn(got), ref, rtol=2e-4, atol=2e-4 * max(np.abs(ref).max(), 1e-30))
+    # parameter gradients: compare block-wise (each block against its own maximum)
+    for b_ in range(5):
+        ref = rdpar[b_ * hw:(b_ + 1) * hw]
+        np.testing.assert_allclose(Nn(dpar)[b_ * hw:(b_ + 1) * hw], ref, rtol=5e-4, atol=5e-4 * max(np.abs(ref).max(), 1e-30))
+    np.testing.assert_allclose(Nn(dpar)[5 * hw], rdpar[5 * hw], rtol=5e-4, atol=1e-5)
