@@ -275,13 +275,17 @@ def model_cases():
     G = grid_gumbel(seed, (N, N))
     cot = torch.from_numpy(grid_normal(52, (N, C)))
     for name, ctor in [
+        # the small-graph script's configuration that runs as shipped: --dgg_mode_edge_net u-v-deg --extra_edge_dim 2,
+        # perturb_edge_prob False (train_small_graphs.py:92-96, 157-163, 184-191; SURVEY 8b')
+        ("model_gcn_dgg_uvdeg", lambda a: refmodel.GCN_DGG(nfeat=d, nlayers=2, nhidden=h, nclass=C, args=a)),
         ("model_gcn_dgg", lambda a: refmodel.GCN_DGG(nfeat=d, nlayers=2, nhidden=h, nclass=C, args=a)),
         ("model_gcnii_dgg", lambda a: refmodel.GCNII_DGG(nfeat=d, nlayers=3, nhidden=h, nclass=C, dropout=0.5, lamda=0.5,
                                                          alpha=0.1, variant=False, args=a)),
         ("model_gcniippi_dgg", lambda a: refmodel.GCNIIppi_DGG(nfeat=d, nlayers=3, nhidden=h, nclass=C, dropout=0.5,
                                                                lamda=0.5, alpha=0.1, variant=True, args=a)),
     ]:
-        a = base_args()
+        a = base_args(dgg_mode_edge_net="u-v-deg", extra_edge_dim=2, perturb_edge_prob=False) if name.endswith("uvdeg") \
+            else base_args()
         torch.manual_seed(4321)
         m = ctor(a)
         m.eval()

@@ -418,7 +418,7 @@ def test_full_size_properties(dev):
     assert torch.equal(sub_i, idx[70_000:70_512]) and torch.equal(sub_v, val[70_000:70_512])
 
 
-@pytest.mark.parametrize("name", ["model_gcn_dgg", "model_gcnii_dgg", "model_gcniippi_dgg"])
+@pytest.mark.parametrize("name", ["model_gcn_dgg", "model_gcn_dgg_uvdeg", "model_gcnii_dgg", "model_gcniippi_dgg"])
 def test_model_wrappers_match_reference_golden(dev, name):
     """dgg_amd.GCN_DGG / GCNII_DGG / GCNIIppi_DGG (eval mode, explicit noise) against the reference's own wrappers
     (model.py:1183-1311, 649-740, 887-965): reference state_dict loads strict, outputs within 1e-5 relative,
@@ -429,7 +429,7 @@ def test_model_wrappers_match_reference_golden(dev, name):
     meta = fx["meta"]
     N, d, h, C = meta["N"], meta["d"], meta["h"], meta["C"]
     args = Namespace(**meta["args"])
-    if name == "model_gcn_dgg":
+    if name.startswith("model_gcn_dgg"):
         m = dgg_amd.GCN_DGG(nfeat=d, nlayers=2, nhidden=h, nclass=C, args=args)
     elif name == "model_gcnii_dgg":
         m = dgg_amd.GCNII_DGG(nfeat=d, nlayers=3, nhidden=h, nclass=C, dropout=0.5, lamda=0.5, alpha=0.1, variant=False, args=args)
