@@ -116,8 +116,124 @@ def _edge_bwd_rows(O, xp, idx, val, dval, R):
     return buf
 
 
+def pubmed_graph(N, n_und, seed=0):
+    """Synthetic symmetric graph with a power-law-ish degree profile + self loops (Pubmed shape)."""
+    rng = np.random.default_rng(seed)
+    wgt = (1.0 / np.arange(1, N + 1) ** 0.5)
+    wgt /= wgt.sum()
+    u = rng.choice(N, size=2 * n_und, p=wgt)
+    v = rng.integers(0, N, size=2 * n_und)
+    keep = u != v
+    e = np.unique(np.stack([np.minimum(u, v)[keep], np.maximum(u, v)[keep]], 1), axis=0)[:n_und]
+    rows = np.concatenate([e[:, 0], e[:, 1], np.arange(N)])
+    cols = np.concatenate([e[:, 1], e[:, 0], np.arange(N)])
+    return rows, cols
+
+
+def bench_edgelist(a, dev):
+    """BASELINE.json configs[1] (Pubmed shape: N=19 717, d=500, edge-list candidates, k~16): the drop-in MODULES
+    (DGG_LearnableK_debug -> normalize -> GCNConv) under autograd, forward + backward, one GPU; the oracle pipeline on
+    all host cores beside it.  Not the headline metric (that is the default workload): run with --workload pubmed."""
+    import dgg_amd
+    from argparse import Namespace
+    N, d, h = 19_717, 500, a.latent
+    rows, cols = pubmed_graph(N, 44_324)
+    E = rows.shape[0]
+    extra = {"u-v-dist": 0, "u-v-deg": 2, "u-v-A_uv": 1, "u-v-deg-dist": 3, "edge_conv": 0, "A_uv": 0}[a.edge_mode]
+    args = Namespace(extra_edge_dim=extra, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288,
+                     dgg_mode_edge_net=a.edge_mode, dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob",
+                     debug_step=3, perturb_edge_prob=True, symmetric_noise=False, stochastic_k=False,
+                     dgg_adj_input="input_adj", n_dgg_layers=1)
+    torch.manual_seed(0)
+    dgg = dgg_amd.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=args)
+    conv = dgg_amd.GCNConv(d, 64)
+    with torch.no_grad():
+        dgg.k_net.k_project.weight.mul_(0.1)
+    dgg, conv = dgg.to(dev), conv.to(dev)
+    dgg.set_seed(1234, 0)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(N, d, generator=g).to(dev)
+    vals = torch.full((E,), 16.0 * N / E)                         # row sums (the prior degree fed to the k-net) average 16
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), vals, (N, N)).coalesce().to(dev)
+    params = [p_ for p_ in list(dgg.parameters()) + list(conv.parameters())]
+
+    def step():
+        for p_ in params:
+            p_.grad = None
+        adj = dgg(x, A)
+        out = conv(x, adj.normalize())
+        out.sum().backward()
+        return adj
+
+    for _ in range(a.warmup):
+        adj = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        adj = step()
+    torch.cuda.synchronize()
+    T = (time.perf_counter() - t0) / a.steps
+    kmean = float(adj.k.mean().item())
+    nsel = float((adj.values() != 0).sum().item())
+    out = {"metric": "DGG adj-build+SpMM fwd/bwd selected-edges/s", "value": nsel / T, "unit": "edges/s", "n_gpus": 1,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": T * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"Pubmed-shape edge-list DGG N={N} d={d} h={h} E={E} (incl. self loops) k~{kmean:.1f}, "
+                                  f"{a.edge_mode}/x/k_times_edge_prob, Gumbel(0,0.3) hash noise, module API under autograd "
+                                  "(DGG_LearnableK_debug + normalize + GCNConv), fwd+bwd",
+                      "nodes": N, "feat": d, "latent": h, "candidate_edges": E, "selected_edges": nsel,
+                      "candidate_edges_per_s": E / T, "edge_mode": a.edge_mode},
+           "roofline": None}
+    if a.cpu_rows >= 0 and a.edge_mode == "u-v-dist":
+        out["cpu_baseline"] = cpu_baseline_edgelist(N, d, h, rows, cols, x.cpu().numpy(), vals.numpy(), dgg, conv,
+                                                    os.cpu_count() or 1)
+    print(json.dumps(out))
+
+
+def cpu_baseline_edgelist(N, d, h, rows, cols, x, vals, dgg, conv, threads):
+    """The oracle's edge-list pipeline (forward + backward) on the whole Pubmed-shape problem, all host cores."""
+    from oracle import oracle as O
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    sd = {k_: v.detach().cpu().numpy() for k_, v in dgg.state_dict().items()}
+    Wc = conv.W.detach().cpu().numpy()
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    rowptr = np.zeros(N + 1, np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    deg = np.zeros(N, np.float32)
+    np.add.at(deg, rows, vals)
+    t0 = time.perf_counter()
+    xp = O.linear(x, sd["node_encode_for_edges.0.weight"], sd["node_encode_for_edges.0.bias"], O.ACT_LEAKY)
+    xk = O.linear(x, sd["node_encode_for_k.0.weight"], sd["node_encode_for_k.0.bias"], O.ACT_LEAKY)
+    mu, sdv = O.degree_stats(deg)
+    Wp = sd["k_net.k_project.weight"].reshape(-1)
+    k, z, m, u = O.knet_x(xk, deg, mu, sdv, sd["k_embed.0.weight"], sd["k_embed.0.bias"], sd["k_net.k_mu.weight"],
+                          sd["k_net.k_mu.bias"], Wp, sd["k_net.k_project.bias"], save=True)
+    idx, val = O.edgelist_topk(xp, rowptr, cols.astype(np.int32), K=64, noise_mode=O.NOISE_HASH, seed=(1234, 0))
+    w, rs = O.softk(idx, val, k)
+    ahat = O.normalize(idx, w, rs)
+    Y = O.spmm(idx, ahat, x)
+    Z = O.linear(Y, Wc, None, O.ACT_RELU, w_layout=1)
+    dY, _, _ = O.linear_bwd(Y, Wc, Z, np.ones_like(Z), act=O.ACT_RELU, w_layout=1)
+    dA, _ = O.spmm_bwd(idx, ahat, x, dY, need_dx=False)
+    dval, dk = O.softk_norm_bwd(idx, val, k, w, rs, dA)
+    dxp = O.edge_bwd(xp, idx, val, dval, perturb=True)
+    O.linear_bwd(x, sd["node_encode_for_edges.0.weight"], xp, dxp, act=O.ACT_LEAKY, need_dx=False)
+    O.knet_x_bwd(xk, deg, mu, sdv, sd["k_embed.0.weight"], sd["k_net.k_mu.weight"], Wp, z, m, u, dk)
+    O.linear_bwd(x, sd["node_encode_for_k.0.weight"], xk, np.zeros_like(xk), act=O.ACT_LEAKY, need_dx=False)
+    dt = time.perf_counter() - t0
+    nsel = float((w != 0).sum())
+    return dict(value=nsel / dt, unit="edges/s", cores=threads, kind="port",
+                sample=f"oracle edge-list pipeline fwd+bwd on the whole problem ({dt:.2f}s)")
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["synthetic", "pubmed"], default="synthetic",
+                    help="synthetic = the BASELINE.json metric config (default); pubmed = configs[1], edge-list candidates")
+    ap.add_argument("--edge-mode", default="u-v-dist", choices=["u-v-dist", "u-v-deg", "u-v-A_uv", "u-v-deg-dist", "edge_conv", "A_uv"],
+                    help="--workload pubmed: edge scorer (dgm.py:1607-1725)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -150,6 +266,9 @@ def main():
     import dgg_amd
     from dgg_amd import ops
     from dgg_amd.parallel import ShardedDGGConv, shard_bounds
+    if a.workload == "pubmed":
+        assert world == 1, "--workload pubmed is a single-GPU measurement"
+        return bench_edgelist(a, dev)
 
     # weak scaling (default): every GPU owns --nodes rows of an (--nodes * world)-node graph; --strong keeps N fixed
     N, d, h = (a.nodes if a.strong else a.nodes * world), a.feat, a.latent
