@@ -44,40 +44,61 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma(const float *__restrict__
         for (int r = 0; r < 16; r++) acc[a][r] = 0.0f;
     const int li = lane & 31, hh = lane >> 5;
     const bool vec4 = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);   // wave-uniform
-    for (int k0 = 0; k0 < d; k0 += BK) {
-        __syncthreads();
+    // Register prefetch: the global loads of K-block i+1 are issued before the MFMAs of block i and written to LDS after
+    // them, so that HBM latency overlaps the matrix-core work of the same workgroup.
+    constexpr int XQ = BM * BK / 4 / 256;                        // float4 per thread and K-block (x tile)
+    constexpr int WQ = BN * BK / 256;                            // floats per thread and K-block (W tile)
+    float4 xr[XQ];
+    float wr[WQ];
+    auto load_block = [&](int k0) {
         if (vec4) {   // 16-byte loads: 8 lanes cover one 128-byte row segment
 #pragma unroll
-            for (int q = 0; q < BM * BK / 4 / 256; q++) {
+            for (int q = 0; q < XQ; q++) {
                 const int e = tid + q * 256, r = e >> 3, c4 = (e & 7) * 4;
                 const int64_t gi = m0 + r;
-                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (gi < N && k0 + c4 < d) v = *reinterpret_cast<const float4 *>(x + gi * d + k0 + c4);
-                float *dst = xs + r * LDP + c4;
-                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                xr[q] = (gi < N && k0 + c4 < d) ? *reinterpret_cast<const float4 *>(x + gi * d + k0 + c4)
+                                                : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
         } else {
-            for (int e = tid; e < BM * BK; e += 256) {
-                int r = e / BK, c = e % BK;
-                int64_t gi = m0 + r;
-                int gk = k0 + c;
-                xs[r * LDP + c] = (gi < N && gk < d) ? x[gi * d + gk] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < XQ; q++) {
+                const int e = tid + q * 256, r = e >> 3, c4 = (e & 7) * 4;
+                const int64_t gi = m0 + r;
+                float t[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) t[u] = (gi < N && k0 + c4 + u < d) ? x[gi * d + k0 + c4 + u] : 0.0f;
+                xr[q] = make_float4(t[0], t[1], t[2], t[3]);
             }
         }
-        if (w_layout == 0) {
-            for (int e = tid; e < BN * BK; e += 256) {
-                int j = e / BK, c = e % BK;
-                int gj = n0 + j, gk = k0 + c;
-                ws[j * LDP + c] = (gj < out && gk < d) ? W[(int64_t)gj * d + gk] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < WQ; q++) {
+            const int e = tid + q * 256;
+            if (w_layout == 0) {
+                const int j = e / BK, c = e % BK, gj = n0 + j, gk = k0 + c;
+                wr[q] = (gj < out && gk < d) ? W[(int64_t)gj * d + gk] : 0.0f;
+            } else {
+                const int c = e / BN, j = e % BN, gj = n0 + j, gk = k0 + c;
+                wr[q] = (gj < out && gk < d) ? W[(int64_t)gk * out + gj] : 0.0f;
             }
-        } else {
-            for (int e = tid; e < BN * BK; e += 256) {
-                int c = e / BN, j = e % BN;
-                int gj = n0 + j, gk = k0 + c;
-                ws[j * LDP + c] = (gj < out && gk < d) ? W[(int64_t)gk * out + gj] : 0.0f;
-            }
+        }
+    };
+    load_block(0);
+    for (int k0 = 0; k0 < d; k0 += BK) {
+        __syncthreads();                                         // previous block's LDS reads are done
+#pragma unroll
+        for (int q = 0; q < XQ; q++) {
+            const int e = tid + q * 256, r = e >> 3, c4 = (e & 7) * 4;
+            float *dst = xs + r * LDP + c4;
+            dst[0] = xr[q].x; dst[1] = xr[q].y; dst[2] = xr[q].z; dst[3] = xr[q].w;
+        }
+#pragma unroll
+        for (int q = 0; q < WQ; q++) {
+            const int e = tid + q * 256;
+            if (w_layout == 0) ws[(e / BK) * LDP + e % BK] = wr[q];
+            else ws[(e % BN) * LDP + e / BN] = wr[q];
         }
         __syncthreads();
+        if (k0 + BK < d) load_block(k0 + BK);                    // in flight during the MFMAs below
         const float *xa = xs + (wave * 32 + li) * LDP + hh;
 #pragma unroll
         for (int s = 0; s < BK / 2; s++) {
@@ -121,64 +142,124 @@ __global__ void act_bwd_kernel(const float *__restrict__ y, const float *__restr
 }
 
 // Weight-gradient GEMM: C[M1,M2] += A[N,M1]^T B[N,M2] with tiny M1, M2 (<= a few hundred) and huge N.
-// Stage 1: one wavefront owns a 32 x (32*NBLK) block of C over a chunk of GT_ROWS node rows.  The fp32 MFMA operands are
-// one float per lane (A[n][o0+lane%32], B[n][c0+..+lane%32], n = k-step*2 + lane/32), i.e. 128-byte coalesced row
-// segments, so they are loaded straight from global memory: no LDS, no barriers.  Partial blocks go to a slab
-// [chunk][M1p][M2p] with plain stores -- NOT atomics: every chunk would hit the same few KB of C, and same-address fp32
-// atomics run ~14x below the streaming atomic rate (MI355X_MICROARCH.md, "Global float atomics").
-// Stage 2: gemm_tn_reduce sums the slab over chunks (32-way split, 32 atomics per output) into C / colsum.
-constexpr int GT_ROWS = 256;
-template <int NBLK>
-__global__ __launch_bounds__(64) void gemm_tn_partial(const float *__restrict__ A, const float *__restrict__ B, int64_t N,
-                                                      int M1, int M2, int M1p, int M2p, float *__restrict__ slab,
-                                                      float *__restrict__ cs_slab) {
-    const int lane = threadIdx.x, li = lane & 31, hh = lane >> 5;
-    const int64_t r0 = (int64_t)blockIdx.x * GT_ROWS;
-    const int64_t r1 = r0 + GT_ROWS < N ? r0 + GT_ROWS : N;
-    const int o0 = blockIdx.y * 32, c0 = blockIdx.z * (NBLK * 32);
-    const bool ov = o0 + li < M1;
-    bool cv[NBLK];
+// Stage 1 (gemm_tn_persist): a PERSISTENT grid of GT_GRID workgroups streams the node rows; every wavefront keeps a
+// (32*MB) x (32*NB) block of C in registers for the whole kernel (up to 64 x 128 = the full weight of the hot path, so A
+// and B are read exactly once).  The fp32 MFMA operands are one float per lane (A[n][o0+..+lane%32],
+// B[n][c0+..+lane%32], n = k-step*2 + lane/32), i.e. 128-byte coalesced row segments, loaded straight from global
+// memory -- no LDS, no barriers in the loop -- with register double buffering: the PF k-steps of batch i+1 are in
+// flight during the MFMAs of batch i.  The four wavefronts of a workgroup are summed through LDS at the end and the
+// workgroup writes ONE partial block to slab[workgroup] with plain stores -- NOT atomics: every workgroup would hit the
+// same few KB of C, and same-address fp32 atomics run ~14x below the streaming atomic rate (MI355X_MICROARCH.md,
+// "Global float atomics").
+// Stage 2: gemm_tn_reduce sums the slab over workgroups (32-way split, 32 atomics per output) into C / colsum.
+constexpr int GT_GRID = 256, GT_PF = 8;
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void gemm_tn_persist(const float *__restrict__ A, const float *__restrict__ B, int64_t N,
+                                                       int M1, int M2, int M1p, int M2p, float *__restrict__ slab,
+                                                       float *__restrict__ cs_slab) {
+    extern __shared__ float red[];                               // [MB*NB*16*64] + [MB*32]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, hh = lane >> 5;
+    const int o0 = blockIdx.y * 32 * MB, c0 = blockIdx.z * 32 * NB;
+    // Loads are UNCONDITIONAL (clamped addresses) so that the compiler can keep two batches in flight (a predicated load
+    // forces s_waitcnt vmcnt(0)): columns beyond M1 / M2 land in padded slab rows / columns that the reduce ignores;
+    // node rows beyond N are clamped to N-1 and their A operand is multiplied by 0.
+    int64_t acol[MB], bcol[NB];
 #pragma unroll
-    for (int a = 0; a < NBLK; a++) cv[a] = c0 + a * 32 + li < M2;
-    f32x16 acc[NBLK];
+    for (int m = 0; m < MB; m++) acol[m] = o0 + m * 32 + li < M1 ? o0 + m * 32 + li : M1 - 1;
 #pragma unroll
-    for (int a = 0; a < NBLK; a++)
+    for (int a = 0; a < NB; a++) bcol[a] = c0 + a * 32 + li < M2 ? c0 + a * 32 + li : M2 - 1;
+    f32x16 acc[MB][NB];
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[a][r] = 0.0f;
-    float csum = 0.0f;
-    const float *ap = A + o0 + li;
-    const float *bp = B + c0 + li;
-    // k-step = 2 node rows (one per lane half); PF k-steps are loaded together so that their latencies overlap
-    constexpr int PF = 8;
-    for (int64_t nb = r0; nb < r1; nb += 2 * PF) {
-        float av[PF], bv[PF][NBLK];
+    for (int m = 0; m < MB; m++)
+#pragma unroll
+        for (int a = 0; a < NB; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][a][r] = 0.0f;
+    float csum[MB];
+#pragma unroll
+    for (int m = 0; m < MB; m++) csum[m] = 0.0f;
+    constexpr int PF = GT_PF;
+    const int64_t step = (int64_t)gridDim.x * 4 * 2 * PF;         // node rows per sweep of the whole grid
+    float av[2][PF][MB], bv[2][PF][NB], rmask[2][PF];
+    auto load = [&](int buf, int64_t base) {
 #pragma unroll
         for (int u = 0; u < PF; u++) {
-            const int64_t n = nb + 2 * u + hh;
-            const bool nv = n < r1;
-            av[u] = (nv && ov) ? ap[n * M1] : 0.0f;
+            const int64_t n = base + 2 * u + hh;
+            const int64_t nc = n < N ? n : N - 1;
+            rmask[buf][u] = n < N ? 1.0f : 0.0f;
 #pragma unroll
-            for (int a = 0; a < NBLK; a++) bv[u][a] = (nv && cv[a]) ? bp[n * M2 + a * 32] : 0.0f;
+            for (int m = 0; m < MB; m++) av[buf][u][m] = A[nc * M1 + acol[m]];
+#pragma unroll
+            for (int a = 0; a < NB; a++) bv[buf][u][a] = B[nc * M2 + bcol[a]];
         }
+    };
+    auto mma = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < PF; u++) {
-            csum += av[u];
 #pragma unroll
-            for (int a = 0; a < NBLK; a++) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][a], acc[a], 0, 0, 0);
+            for (int m = 0; m < MB; m++) {
+                av[buf][u][m] *= rmask[buf][u];
+                csum[m] += av[buf][u][m];
+#pragma unroll
+                for (int a = 0; a < NB; a++)
+                    acc[m][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][m], bv[buf][u][a], acc[m][a], 0, 0, 0);
+            }
         }
+    };
+    int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 2 * PF;
+    if (base < N) load(0, base);
+    while (base < N) {                                           // two batches per trip: buffers alternate statically
+        if (base + step < N) load(1, base + step);
+        mma(0);
+        base += step;
+        if (base >= N) break;
+        if (base + step < N) load(0, base + step);
+        mma(1);
+        base += step;
     }
+    // sum the four wavefronts through LDS (wave 0 accumulates), then one plain store per element
+    float *cred = red + MB * NB * 16 * 64;
+    for (int w = 1; w < 4; w++) {
+        if (wave == w) {
+#pragma unroll
+            for (int m = 0; m < MB; m++) {
+#pragma unroll
+                for (int a = 0; a < NB; a++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) red[((m * NB + a) * 16 + r) * 64 + lane] = acc[m][a][r];
+                cred[m * 64 + lane] = csum[m];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int m = 0; m < MB; m++) {
+#pragma unroll
+                for (int a = 0; a < NB; a++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[m][a][r] += red[((m * NB + a) * 16 + r) * 64 + lane];
+                csum[m] += cred[m * 64 + lane];
+            }
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
     float *sl = slab + (int64_t)blockIdx.x * M1p * M2p;
 #pragma unroll
-    for (int a = 0; a < NBLK; a++) {
+    for (int m = 0; m < MB; m++) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            int go = o0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            sl[(int64_t)go * M2p + c0 + a * 32 + li] = acc[a][r];
+        for (int a = 0; a < NB; a++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int go = o0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int gc = c0 + a * 32 + li;
+                if (go < M1p && gc < M2p) sl[(int64_t)go * M2p + gc] = acc[m][a][r];
+            }
         }
-    }
-    if (cs_slab && blockIdx.z == 0) {
-        csum += __uint_as_float(dgg::xor_shfl<32>(__float_as_uint(csum), lane));
-        if (hh == 0) cs_slab[(int64_t)blockIdx.x * M1p + o0 + li] = csum;
+        if (cs_slab && blockIdx.z == 0) {
+            float t = csum[m] + __uint_as_float(dgg::xor_shfl<32>(__float_as_uint(csum[m]), lane));
+            if (hh == 0 && o0 + m * 32 + li < M1p) cs_slab[(int64_t)blockIdx.x * M1p + o0 + m * 32 + li] = t;
+        }
     }
 }
 
@@ -217,23 +298,38 @@ int launch_linear_fwd(const float *x, int64_t N, int d, const float *W, const fl
     return dgg_check_launch("linear_fwd");
 }
 
+inline int gemm_tn_grid(int64_t N) {
+    const int64_t need = (N + 4 * 2 * GT_PF - 1) / (4 * 2 * GT_PF);
+    return (int)(need < GT_GRID ? (need < 1 ? 1 : need) : GT_GRID);
+}
 size_t gemm_tn_ws_floats(int64_t N, int M1, int M2) {
-    const size_t nch = (size_t)((N + GT_ROWS - 1) / GT_ROWS), M1p = (size_t)(M1 + 31) / 32 * 32, M2p = (size_t)(M2 + 31) / 32 * 32;
-    return nch * M1p * M2p + nch * M1p;
+    const size_t g = (size_t)gemm_tn_grid(N), M1p = (size_t)(M1 + 31) / 32 * 32, M2p = (size_t)(M2 + 31) / 32 * 32;
+    return g * M1p * M2p + g * M1p;
+}
+
+template <int MB, int NB>
+void launch_gemm_tn_persist(const float *A, const float *B, int64_t N, int M1, int M2, int M1p, int M2p, float *slab,
+                            float *cs_slab, int g, hipStream_t st) {
+    const unsigned gy = (unsigned)((M1p / 32 + MB - 1) / MB), gz = (unsigned)((M2p / 32 + NB - 1) / NB);
+    const size_t lds = (size_t)(MB * NB * 16 * 64 + MB * 64) * sizeof(float);
+    hipLaunchKernelGGL((gemm_tn_persist<MB, NB>), dim3(g, gy, gz), dim3(256), lds, st, A, B, N, M1, M2, M1p, M2p, slab, cs_slab);
 }
 
 int launch_gemm_tn(const float *A, const float *B, int64_t N, int M1, int M2, float *C, int c_layout, float *colsum,
                    float *ws, hipStream_t st) {
     if (!ws) return dgg_set_error(DGG_ERR_ARG, "gemm_tn: workspace is NULL (dgg_gemm_tn_ws_floats)");
-    const int nch = (int)((N + GT_ROWS - 1) / GT_ROWS), M1p = (M1 + 31) / 32 * 32, M2p = (M2 + 31) / 32 * 32;
-    float *slab = ws, *cs_slab = ws + (size_t)nch * M1p * M2p;
-    const unsigned gy = (unsigned)(M1p / 32);
-    if (M2p % 64 == 0)
-        hipLaunchKernelGGL(gemm_tn_partial<2>, dim3(nch, gy, (unsigned)(M2p / 64)), dim3(64), 0, st, A, B, N, M1, M2, M1p, M2p, slab, colsum ? cs_slab : nullptr);
-    else
-        hipLaunchKernelGGL(gemm_tn_partial<1>, dim3(nch, gy, (unsigned)(M2p / 32)), dim3(64), 0, st, A, B, N, M1, M2, M1p, M2p, slab, colsum ? cs_slab : nullptr);
-    hipLaunchKernelGGL(gemm_tn_reduce, dim3((unsigned)((M1p * M2p + 255) / 256), GT_SPLIT), dim3(256), 0, st, slab,
-                       colsum ? cs_slab : nullptr, nch, M1, M2, M1p, M2p, C, c_layout, colsum);
+    const int g = gemm_tn_grid(N), M1p = (M1 + 31) / 32 * 32, M2p = (M2 + 31) / 32 * 32;
+    float *slab = ws, *cs_slab = ws + (size_t)g * M1p * M2p;
+    float *csl = colsum ? cs_slab : nullptr;
+    const int mb = M1p / 32 >= 2 ? 2 : 1, nb = M2p / 32 >= 3 ? 4 : M2p / 32;
+    if (mb == 2 && nb == 4) launch_gemm_tn_persist<2, 4>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
+    else if (mb == 2 && nb == 2) launch_gemm_tn_persist<2, 2>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
+    else if (mb == 2) launch_gemm_tn_persist<2, 1>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
+    else if (nb == 4) launch_gemm_tn_persist<1, 4>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
+    else if (nb == 2) launch_gemm_tn_persist<1, 2>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
+    else launch_gemm_tn_persist<1, 1>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
+    hipLaunchKernelGGL(gemm_tn_reduce, dim3((unsigned)((M1p * M2p + 255) / 256), GT_SPLIT), dim3(256), 0, st, slab, csl, g, M1,
+                       M2, M1p, M2p, C, c_layout, colsum);
     return dgg_check_launch("gemm_tn");
 }
 
