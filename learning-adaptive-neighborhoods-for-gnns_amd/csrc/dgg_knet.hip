@@ -262,13 +262,17 @@ __global__ __launch_bounds__(64) void knet_x_bwd_tpn(
     }
 }
 
-__global__ void knet_input_deg_kernel(const float *__restrict__ deg, int64_t N, float dmean, float dstd,
-                                      const float *__restrict__ Wd, const float *__restrict__ bd,
-                                      const float *__restrict__ Wmu, const float *__restrict__ bmu, int h4,
-                                      const float *__restrict__ Wp, const float *__restrict__ bp, float *__restrict__ k) {
+// degree-only modes (dgm.py:1492-1526): nd = (deg - mu) / (sd + eps); mu/sd are constants ("input_deg", eps 1e-5) or the
+// batch statistics read from device memory ("learn_normalized_degree", eps 0)
+__global__ void knet_deg_fwd_kernel(const float *__restrict__ deg, int64_t N, const float *__restrict__ mu_sd, float dmean,
+                                    float dstd, float eps, const float *__restrict__ Wd, const float *__restrict__ bd,
+                                    const float *__restrict__ Wmu, const float *__restrict__ bmu, int h4,
+                                    const float *__restrict__ Wp, const float *__restrict__ bp, float *__restrict__ k,
+                                    float *__restrict__ u_save) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    float nd = __fdiv_rn(__fadd_rn(deg[i], -dmean), __fadd_rn(dstd, 1e-5f));
+    if (mu_sd) { dmean = mu_sd[0]; dstd = mu_sd[1]; }
+    float nd = __fdiv_rn(__fadd_rn(deg[i], -dmean), __fadd_rn(dstd, eps));
     float in3[3];
     for (int o = 0; o < 3; o++) in3[o] = __fadd_rn(__fmaf_rn(nd, Wd[o], 0.0f), bd[o]);
     float ak = 0.0f;
@@ -281,6 +285,30 @@ __global__ void knet_input_deg_kernel(const float *__restrict__ deg, int64_t N, 
     float kp = __fadd_rn(ak, bp[0]);
     float u = __fadd_rn(__fmul_rn(kp, dstd), dmean);
     k[i] = __fadd_rn(u > 0.0f ? u : 0.0f, 1.0f);
+    if (u_save) u_save[i] = u;
+}
+
+// backward: the net is affine in nd_i, so all parameter gradients follow from S0 = sum dkp, S1 = sum dkp * nd
+// (dkp = dk * sd * [u > 0]); block partials in double, one float atomic per block and sum
+__global__ __launch_bounds__(256) void knet_deg_bwd_sums_kernel(const float *__restrict__ deg, int64_t N,
+                                                                const float *__restrict__ mu_sd, float dmean, float dstd,
+                                                                float eps, const float *__restrict__ u,
+                                                                const float *__restrict__ dk, float *__restrict__ S) {
+    __shared__ double r0[256], r1[256];
+    if (mu_sd) { dmean = mu_sd[0]; dstd = mu_sd[1]; }
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+        const double dkp = u[i] > 0.0f ? (double)dk[i] * dstd : 0.0;
+        s0 += dkp;
+        s1 += dkp * (((double)deg[i] - dmean) / ((double)dstd + eps));
+    }
+    r0[threadIdx.x] = s0; r1[threadIdx.x] = s1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { atomicAdd(S, (float)r0[0]); atomicAdd(S + 1, (float)r1[0]); }
 }
 
 }  // namespace dggk
@@ -354,13 +382,29 @@ int dgg_knet_x_bwd_nodes(int64_t N, int h, const float *mu_sd, const float *W1, 
     return dgg_check_launch("knet_x_bwd_nodes");
 }
 
+int dgg_knet_deg_fwd(const float *deg, int64_t N, const float *mu_sd, float dmean, float dstd, float eps, const float *Wd,
+                     const float *bd, const float *Wmu, const float *bmu, int h4, const float *Wp, const float *bp, float *k,
+                     float *u_save, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(knet_deg_fwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, deg, N, mu_sd,
+                       dmean, dstd, eps, Wd, bd, Wmu, bmu, h4, Wp, bp, k, u_save);
+    return dgg_check_launch("knet_deg_fwd");
+}
+
 int dgg_knet_input_deg_fwd(const float *deg, int64_t N, float dmean, float dstd, const float *Wd, const float *bd,
                            const float *Wmu, const float *bmu, int h4, const float *Wp, const float *bp, float *k,
                            void *stream) {
+    return dgg_knet_deg_fwd(deg, N, nullptr, dmean, dstd, 1e-5f, Wd, bd, Wmu, bmu, h4, Wp, bp, k, nullptr, stream);
+}
+
+// S [2] is ACCUMULATED into (caller zeroes it)
+int dgg_knet_deg_bwd_sums(const float *deg, int64_t N, const float *mu_sd, float dmean, float dstd, float eps, const float *u,
+                          const float *dk, float *S, void *stream) {
     if (N == 0) return 0;
-    hipLaunchKernelGGL(knet_input_deg_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, deg, N,
-                       dmean, dstd, Wd, bd, Wmu, bmu, h4, Wp, bp, k);
-    return dgg_check_launch("knet_input_deg_fwd");
+    const unsigned grid = (unsigned)((N + 255) / 256 < 256 ? (N + 255) / 256 : 256);
+    hipLaunchKernelGGL(knet_deg_bwd_sums_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, deg, N, mu_sd, dmean, dstd, eps,
+                       u, dk, S);
+    return dgg_check_launch("knet_deg_bwd_sums");
 }
 
 }  // extern "C"

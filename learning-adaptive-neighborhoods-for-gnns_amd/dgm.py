@@ -34,16 +34,61 @@ class LearnableKEncoder(nn.Module):
         self.args = args
 
 
-class _DGGSoftAdjFn(torch.autograd.Function):
-    """x, prior degree, parameters -> soft (unnormalised) ELL adjacency values.  One autograd node for the whole
-    generator: projection, k-net, scoring + top-K, ramp (reference dgm.py:1197-1292)."""
+class _KnetXFn(torch.autograd.Function):
+    """k_estimate_net mode "x" (reference dgm.py:1562-1586): x, prior degree -> learned k [N]."""
 
     @staticmethod
-    def forward(ctx, x, deg, We, be, Wk, bk, W1, b1, Wmu, bmu, Wp, bp, cfg):
-        xp = ops.linear_fwd(x, We, be, ops.ACT_LEAKY)
+    def forward(ctx, x, deg, Wk, bk, W1, b1, Wmu, bmu, Wp, bp):
         xk = ops.linear_fwd(x, Wk, bk, ops.ACT_LEAKY)
         mu_sd = ops.degree_stats(deg)
         k, z, u, feat = ops.knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp.reshape(-1), bp)
+        ctx.save_for_backward(x, Wk, W1, Wmu, bmu, Wp, xk, mu_sd, z, u, feat)
+        return k
+
+    @staticmethod
+    def backward(ctx, dk):
+        x, Wk, W1, Wmu, bmu, Wp, xk, mu_sd, z, u, feat = ctx.saved_tensors
+        need_dx = ctx.needs_input_grad[0]
+        dxk, dW1, db1, dWmu, dbmu, dWp, dbp = ops.knet_x_bwd(xk.shape[1], mu_sd, W1, Wmu, bmu, Wp.reshape(-1), z, u, feat,
+                                                            dk.contiguous())
+        dx, dWk, dbk = ops.linear_bwd(x, Wk, xk, dxk, ops.ACT_LEAKY, need_dx=need_dx)
+        return dx, None, dWk, dbk, dW1, db1, dWmu, dbmu, dWp.reshape(Wp.shape), dbp
+
+
+class _KnetDegFn(torch.autograd.Function):
+    """Degree-only k-net modes (reference dgm.py:1492-1526): "input_deg" (constants args.deg_mean / deg_std, eps 1e-5)
+    and "learn_normalized_degree" (batch statistics, no eps).  The net is affine in the scalar nd_i, so the backward is
+    two reductions (S0 = sum dkp, S1 = sum dkp nd; HIP) followed by parameter-sized algebra."""
+
+    @staticmethod
+    def forward(ctx, deg, Wd, bd, Wmu, bmu, Wp, bp, consts):
+        mu_sd = ops.degree_stats(deg) if consts is None else None
+        dmean, dstd, eps = (0.0, 0.0, 0.0) if consts is None else (consts[0], consts[1], 1e-5)
+        k, u = ops.knet_deg_fwd(deg, mu_sd, dmean, dstd, eps, Wd.reshape(-1), bd, Wmu, bmu, Wp.reshape(-1), bp)
+        ctx.consts = (dmean, dstd, eps)
+        ctx.mu_sd = mu_sd
+        ctx.save_for_backward(deg, Wd, bd, Wmu, bmu, Wp, u)
+        return k
+
+    @staticmethod
+    def backward(ctx, dk):
+        deg, Wd, bd, Wmu, bmu, Wp, u = ctx.saved_tensors
+        dmean, dstd, eps = ctx.consts
+        S = ops.knet_deg_bwd_sums(deg, ctx.mu_sd, dmean, dstd, eps, u, dk.contiguous())
+        S0, S1 = S[0], S[1]
+        wd, wp = Wd.reshape(-1), Wp.reshape(-1)
+        alpha, beta, gamma = Wmu @ wd, Wmu @ bd + bmu, Wmu.t() @ wp       # m = alpha nd + beta; d in3 = gamma dkp
+        return (None, (gamma * S1).reshape(Wd.shape), gamma * S0, torch.outer(wp, wd * S1 + bd * S0), wp * S0,
+                (alpha * S1 + beta * S0).reshape(Wp.shape), S0.reshape(1), None)
+
+
+class _DGGSoftAdjFn(torch.autograd.Function):
+    """x, learned k, projection parameters -> soft (unnormalised) ELL adjacency values: projection, u-v-dist scoring +
+    perturbation + top-K, ramp (reference dgm.py:1197-1292)."""
+
+    @staticmethod
+    def forward(ctx, x, k, We, be, cfg):
+        xp = ops.linear_fwd(x, We, be, ops.ACT_LEAKY)
         if cfg["cand"] is None:
             idx, val = ops.allpairs_topk(xp, cfg["K"], cfg["t"], cfg["noise_mode"], cfg["G"], cfg["seed"], algo=cfg["algo"],
                                          k_limit=k)
@@ -52,22 +97,18 @@ class _DGGSoftAdjFn(torch.autograd.Function):
             idx, val = ops.edgelist_topk(xp, rowptr, col, cfg["K"], cfg["t"], cfg["noise_mode"], cfg["G"], cfg["seed"])
         w, rs = ops.softk_fwd(idx, val, k, cfg["mode"])
         ctx.cfg = cfg
-        ctx.save_for_backward(x, We, Wk, W1, Wmu, bmu, Wp, xp, xk, mu_sd, k, z, u, feat, idx, val)
-        ctx.mark_non_differentiable(idx, val, k, rs)
-        return w, idx, val, k, rs
+        ctx.save_for_backward(x, We, xp, k, idx, val)
+        ctx.mark_non_differentiable(idx, val, rs)
+        return w, idx, val, rs
 
     @staticmethod
     def backward(ctx, dw, *_):
-        x, We, Wk, W1, Wmu, bmu, Wp, xp, xk, mu_sd, k, z, u, feat, idx, val = ctx.saved_tensors
+        x, We, xp, k, idx, val = ctx.saved_tensors
         cfg = ctx.cfg
-        need_dx = ctx.needs_input_grad[0]
         dval, dk = ops.softk_bwd(idx, val, k, dw.contiguous(), mode=cfg["mode"], normalized=False)
         dxp = ops.edge_bwd(xp, idx, val, dval, t=cfg["t"], perturb=cfg["noise_mode"] != ops.NOISE_NONE)
-        dx1, dWe, dbe = ops.linear_bwd(x, We, xp, dxp, ops.ACT_LEAKY, need_dx=need_dx)
-        dxk, dW1, db1, dWmu, dbmu, dWp, dbp = ops.knet_x_bwd(xk.shape[1], mu_sd, W1, Wmu, bmu, Wp.reshape(-1), z, u, feat, dk)
-        dx2, dWk, dbk = ops.linear_bwd(x, Wk, xk, dxk, ops.ACT_LEAKY, need_dx=need_dx)
-        dx = dx1 + dx2 if need_dx else None
-        return dx, None, dWe, dbe, dWk, dbk, dW1, db1, dWmu, dbmu, dWp.reshape(Wp.shape), dbp, None
+        dx, dWe, dbe = ops.linear_bwd(x, We, xp, dxp, ops.ACT_LEAKY, need_dx=ctx.needs_input_grad[0])
+        return dx, dk, dWe, dbe, None
 
 
 class _DGGEdgeMlpAdjFn(torch.autograd.Function):
@@ -77,11 +118,8 @@ class _DGGEdgeMlpAdjFn(torch.autograd.Function):
     happens in differentiable torch ops on the (tiny) parameter tensors, outside this node."""
 
     @staticmethod
-    def forward(ctx, x, deg, ex_in, We, be, Wk, bk, W1, b1, Wmu, bmu, Wp, bp, Wcat, wdu, wdv, wex, eb1, w2, b2, cfg):
+    def forward(ctx, x, k, deg, ex_in, We, be, Wcat, wdu, wdv, wex, eb1, w2, b2, cfg):
         xp = ops.linear_fwd(x, We, be, ops.ACT_LEAKY)
-        xk = ops.linear_fwd(x, Wk, bk, ops.ACT_LEAKY)
-        mu_sd = ops.degree_stats(deg)
-        k, z, u, feat = ops.knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp.reshape(-1), bp)
         rowptr, col, erow = cfg["cand"]
         AB = ops.linear_fwd(xp, Wcat, None, ops.ACT_NONE)
         sdeg = deg if wdu is not None else None
@@ -92,16 +130,15 @@ class _DGGEdgeMlpAdjFn(torch.autograd.Function):
         ctx.cfg = cfg
         # optional tensors (None allowed): kept outside save_for_backward, detached
         ctx.opt = tuple(None if t_ is None else t_.detach() for t_ in (sdeg, ex, wdu, wdv, wex))
-        ctx.save_for_backward(x, We, Wk, W1, Wmu, bmu, Wp, xp, xk, mu_sd, k, z, u, feat, idx, val, eid, AB, Wcat, eb1, w2, b2)
-        ctx.mark_non_differentiable(idx, val, k, rs)
-        return w, idx, val, k, rs
+        ctx.save_for_backward(x, We, xp, k, idx, val, eid, AB, Wcat, eb1, w2, b2)
+        ctx.mark_non_differentiable(idx, val, rs)
+        return w, idx, val, rs
 
     @staticmethod
     def backward(ctx, dw, *_):
-        x, We, Wk, W1, Wmu, bmu, Wp, xp, xk, mu_sd, k, z, u, feat, idx, val, eid, AB, Wcat, eb1, w2, b2 = ctx.saved_tensors
+        x, We, xp, k, idx, val, eid, AB, Wcat, eb1, w2, b2 = ctx.saved_tensors
         sdeg, ex, wdu, wdv, wex = ctx.opt
         cfg = ctx.cfg
-        need_dx = ctx.needs_input_grad[0]
         hw = Wcat.shape[0] // 2
         dval, dk = ops.softk_bwd(idx, val, k, dw.contiguous(), mode=cfg["mode"], normalized=False)
         dAB, dpar, dex = ops.edge_mlp_bwd(AB, idx, eid, val, dval, sdeg, ex, wdu, wdv, wex, eb1, w2, b2, cfg["act"],
@@ -109,14 +146,10 @@ class _DGGEdgeMlpAdjFn(torch.autograd.Function):
         dxp, dWcat, _ = ops.linear_bwd(xp, Wcat, AB, dAB, ops.ACT_NONE, need_dx=True, need_db=False)
         if cfg["ex_mode"] == 2:                          # exp(t ||xp_u - xp_v||) also depends on the projection
             dxp = dxp + ops.edge_bwd(xp, idx, val, dex, t=cfg["t_ex"], perturb=False)
-        dx1, dWe, dbe = ops.linear_bwd(x, We, xp, dxp, ops.ACT_LEAKY, need_dx=need_dx)
-        dxk, dW1, db1, dWmu, dbmu, dWp, dbp = ops.knet_x_bwd(xk.shape[1], mu_sd, W1, Wmu, bmu, Wp.reshape(-1), z, u, feat, dk)
-        dx2, dWk, dbk = ops.linear_bwd(x, Wk, xk, dxk, ops.ACT_LEAKY, need_dx=need_dx)
-        dx = dx1 + dx2 if need_dx else None
+        dx, dWe, dbe = ops.linear_bwd(x, We, xp, dxp, ops.ACT_LEAKY, need_dx=ctx.needs_input_grad[0])
         g = lambda t_, a, b: None if t_ is None else dpar[a:b]  # noqa: E731
-        return (dx, None, None, dWe, dbe, dWk, dbk, dW1, db1, dWmu, dbmu, dWp.reshape(Wp.shape), dbp,
-                dWcat if ctx.needs_input_grad[13] else None, g(wdu, 0, hw), g(wdv, hw, 2 * hw), g(wex, 2 * hw, 3 * hw),
-                dpar[3 * hw:4 * hw], dpar[4 * hw:5 * hw], dpar[5 * hw:5 * hw + 1], None)
+        return (dx, dk, None, None, dWe, dbe, dWcat if ctx.needs_input_grad[6] else None, g(wdu, 0, hw), g(wdv, hw, 2 * hw),
+                g(wex, 2 * hw, 3 * hw), dpar[3 * hw:4 * hw], dpar[4 * hw:5 * hw], dpar[5 * hw:5 * hw + 1], None)
 
 
 class DGG_LearnableK_debug(nn.Module):
@@ -219,8 +252,11 @@ class DGG_LearnableK_debug(nn.Module):
         assert x.ndim == 2 and len(in_adj.shape) == 2
         if self.edge_prob_net_mode != "u-v-dist" and self.edge_prob_net_mode not in _EDGE_MLP_MODES:
             raise Exception("mode not found")
-        if self.k_net_mode != "x":
-            raise NotImplementedError(f"k-net mode {self.k_net_mode!r}: the HIP autograd path implements 'x'")
+        if self.k_net_mode not in ("x", "input_deg", "learn_normalized_degree"):
+            # "pass" returns k = None, which the reference's own select_top_k cannot consume (dgm.py:1485, 1412);
+            # "gcn-x-deg" aggregates over the dense in_adj (dgm.py:1528-1560)
+            raise NotImplementedError(f"k-net mode {self.k_net_mode!r}: the HIP path implements 'x', 'input_deg' and "
+                                      "'learn_normalized_degree'")
         if self.k_select_mode not in ("k_times_edge_prob", "k_only"):
             raise NotImplementedError(f"k-select mode {self.k_select_mode!r} is dead code in the reference")
         if self.hard:
@@ -246,16 +282,23 @@ class DGG_LearnableK_debug(nn.Module):
             noise_mode = ops.NOISE_HASH              # edge-list candidates: every candidate is scored, per-pair hash noise
         cfg = dict(cand=cand, K=self.ell_width, t=ops.T_DIST, noise_mode=noise_mode, G=G, seed=seed, algo=self.topk_algo,
                    mode=ops.MODE_K_TIMES_EDGE_PROB if self.k_select_mode == "k_times_edge_prob" else ops.MODE_K_ONLY)
-        common = (self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias,
-                  self.node_encode_for_k[0].weight, self.node_encode_for_k[0].bias, self.k_embed[0].weight, self.k_embed[0].bias,
-                  self.k_net.k_mu.weight, self.k_net.k_mu.bias, self.k_net.k_project.weight, self.k_net.k_project.bias)
+        We, be = self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias
+        kn = self.k_net
+        if self.k_net_mode == "x":
+            k = _KnetXFn.apply(x, deg, self.node_encode_for_k[0].weight, self.node_encode_for_k[0].bias, self.k_embed[0].weight,
+                               self.k_embed[0].bias, kn.k_mu.weight, kn.k_mu.bias, kn.k_project.weight, kn.k_project.bias)
+        else:
+            consts = (float(self.deg_mean), float(self.deg_std)) if self.k_net_mode == "input_deg" else None
+            k = _KnetDegFn.apply(deg, self.input_degree_project.weight, self.input_degree_project.bias, kn.k_mu.weight,
+                                 kn.k_mu.bias, kn.k_project.weight, kn.k_project.bias, consts)
         if self.edge_prob_net_mode == "u-v-dist":
-            w, idx, val, k, rs = _DGGSoftAdjFn.apply(x, deg, *common, cfg)
+            w, idx, val, rs = _DGGSoftAdjFn.apply(x, k, We, be, cfg)
         else:
             mlp, ex_in = self._edge_mlp_terms(avals)
             cfg.update(cand=(rowptr, col, erow), ex_mode=mlp["ex_mode"], t_ex=mlp["t_ex"], act=mlp["act"])
-            w, idx, val, k, rs = _DGGEdgeMlpAdjFn.apply(x, deg, ex_in, *common, mlp["Wcat"], mlp["wdu"], mlp["wdv"], mlp["wex"],
-                                                        mlp["b1"], mlp["w2"], mlp["b2"], cfg)
+            w, idx, val, rs = _DGGEdgeMlpAdjFn.apply(x, k, deg, ex_in, We, be, mlp["Wcat"], mlp["wdu"], mlp["wdv"], mlp["wex"],
+                                                     mlp["b1"], mlp["w2"], mlp["b2"], cfg)
+        k = k.detach()
         if writer is not None:   # the two scalars the reference logs from inside the DGG (dgm.py:1259-1261)
             f = w.detach() if cfg["mode"] == ops.MODE_K_ONLY else (w.detach() / val.clamp(min=1e-30))
             writer.add_scalar("values/first_k_std", f.sum(-1).std(), epoch)

@@ -316,6 +316,26 @@ def knet_input_deg_fwd(deg, dmean, dstd, Wd, bd, Wmu, bmu, Wp, bp):
     return k
 
 
+def knet_deg_fwd(deg, mu_sd, dmean, dstd, eps, Wd, bd, Wmu, bmu, Wp, bp):
+    """degree-only k-net (dgm.py:1492-1526) -> k [N], u [N] (pre-relu).  mu_sd: device [2] or None (constants)."""
+    deg = _chk(deg)
+    N = deg.shape[0]
+    k = torch.empty((N,), device=deg.device, dtype=torch.float32)
+    u = torch.empty((N,), device=deg.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_knet_deg_fwd(_ptr(deg), N, _ptr(mu_sd), float(dmean), float(dstd), float(eps), _ptr(_chk(Wd)),
+                                           _ptr(_chk(bd)), _ptr(_chk(Wmu)), _ptr(_chk(bmu)), Wmu.shape[0], _ptr(_chk(Wp)),
+                                           _ptr(_chk(bp)), _ptr(k), _ptr(u), _stream()), "knet_deg_fwd")
+    return k, u
+
+
+def knet_deg_bwd_sums(deg, mu_sd, dmean, dstd, eps, u, dk):
+    """-> S [2] = (sum dkp, sum dkp * nd)"""
+    S = torch.zeros((2,), device=deg.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_knet_deg_bwd_sums(_ptr(_chk(deg)), deg.shape[0], _ptr(mu_sd), float(dmean), float(dstd), float(eps),
+                                                _ptr(_chk(u)), _ptr(_chk(dk)), _ptr(S), _stream()), "knet_deg_bwd_sums")
+    return S
+
+
 # ------------------------------------------------------------------------------------------------------------
 # autograd ops
 # ------------------------------------------------------------------------------------------------------------

@@ -685,3 +685,37 @@ ORA_API void ora_edge_mlp_bwd(const float *AB, int64_t N, int hw, const int32_t 
     for (int e = 0; e < 5 * hw + 1; e++) dpar[e] = (float)par[e];
     free(acc); free(par); free(z); free(hid);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* degree-only k-net modes (dgm.py:1492-1526): "input_deg" (constants deg_mean/deg_std, eps    */
+/* 1e-5) and "learn_normalized_degree" (batch mean/std of deg, no eps).  Forward with saved    */
+/* pre-relu u; backward: the whole net is affine in the scalar nd_i, so every parameter        */
+/* gradient is a combination of S0 = sum_i dkp_i and S1 = sum_i dkp_i nd_i (dkp = dk*sd*[u>0]). */
+/* ------------------------------------------------------------------------------------------ */
+ORA_API void ora_knet_deg(const float *deg, int64_t N, float mu, float sd, float eps, const float *Wd, const float *bd,
+                          const float *Wmu, const float *bmu, int h4, const float *Wp, const float *bp, float *k,
+                          float *u_save) {
+    for (int64_t i = 0; i < N; i++) {
+        float nd = (deg[i] - mu) / (sd + eps);
+        float in3[3], m[128];
+        for (int o = 0; o < 3; o++) { float acc = fmaf(nd, Wd[o], 0.0f); in3[o] = acc + bd[o]; }
+        for (int o = 0; o < h4; o++) { float acc = 0.0f; for (int c = 0; c < 3; c++) acc = fmaf(in3[c], Wmu[o * 3 + c], acc); m[o] = acc + bmu[o]; }
+        float acc = 0.0f;
+        for (int c = 0; c < h4; c++) acc = fmaf(m[c], Wp[c], acc);
+        float kp = acc + bp[0];
+        float u = kp * sd; u = u + mu;
+        k[i] = (u > 0.0f ? u : 0.0f) + 1.0f;
+        if (u_save) u_save[i] = u;
+    }
+}
+/* -> S[0] = sum dkp, S[1] = sum dkp * nd (double accumulation) */
+ORA_API void ora_knet_deg_bwd_sums(const float *deg, int64_t N, float mu, float sd, float eps, const float *u,
+                                   const float *dk, float *S) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t i = 0; i < N; i++) {
+        double dkp = u[i] > 0.0f ? (double)dk[i] * sd : 0.0;
+        double nd = ((double)deg[i] - mu) / ((double)sd + eps);
+        s0 += dkp; s1 += dkp * nd;
+    }
+    S[0] = (float)s0; S[1] = (float)s1;
+}

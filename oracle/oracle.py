@@ -299,3 +299,29 @@ def edge_mlp_bwd(AB, idx, eid, val, dval, deg, ex, wdu, wdv, wex, b1, w2, b2, ac
                            _p(wdu), _p(wdv), _p(wex), _p(f32(b1)), _p(f32(w2)), C.c_float(float(b2)), C.c_int(act),
                            C.c_int(int(perturb)), _p(dAB), _p(dpar), _p(dex))
     return dAB, dpar, dex
+
+
+# ---- degree-only k-net modes (dgm.py:1492-1526) ---------------------------------------------------------------
+def knet_deg(deg, mu, sd, eps, Wd, bd, Wmu, bmu, Wp, bp):
+    """-> k [N], u [N] (pre-relu)"""
+    deg, Wd, bd, Wmu, bmu, Wp, bp = map(f32, (deg, Wd, bd, Wmu, bmu, Wp, bp))
+    N = deg.shape[0]
+    k, u = np.empty((N,), np.float32), np.empty((N,), np.float32)
+    lib().ora_knet_deg(_p(deg), C.c_int64(N), C.c_float(mu), C.c_float(sd), C.c_float(eps), _p(Wd), _p(bd), _p(Wmu), _p(bmu),
+                       C.c_int(Wmu.shape[0]), _p(Wp), _p(bp), _p(k), _p(u))
+    return k, u
+
+
+def knet_deg_bwd(deg, mu, sd, eps, Wd, bd, Wmu, bmu, Wp, u, dk):
+    """-> gradients of (Wd [3], bd [3], Wmu [h4,3], bmu [h4], Wp [h4], bp [1]) from the two sums S0, S1"""
+    deg, u, dk = f32(deg), f32(u), f32(dk)
+    S = np.empty(2, np.float32)
+    lib().ora_knet_deg_bwd_sums(_p(deg), C.c_int64(deg.shape[0]), C.c_float(mu), C.c_float(sd), C.c_float(eps), _p(u), _p(dk), _p(S))
+    return knet_deg_param_grads(S[0], S[1], *(np.asarray(a, np.float64) for a in (Wd, bd, Wmu, bmu, Wp)))
+
+
+def knet_deg_param_grads(S0, S1, Wd, bd, Wmu, bmu, Wp):
+    alpha, beta, gamma = Wmu @ Wd, Wmu @ bd + bmu, Wmu.T @ Wp        # m = alpha nd + beta; d in3 = gamma dkp
+    f = lambda a: np.asarray(a, np.float32)  # noqa: E731
+    return (f(gamma * S1), f(gamma * S0), f(np.outer(Wp, Wd * S1 + bd * S0)), f(Wp * S0), f(alpha * S1 + beta * S0),
+            f([S0]))
