@@ -137,10 +137,35 @@ int dgg_edgelist_topk_p(const float *p_edge, int64_t N, const int64_t *rowptr, c
 /* autograd of dgg_edge_mlp_fwd for the selected entries: dval (wrt the stored score) -> dAB [N,2*hw] and
  * dpar [5*hw+1] = [dwdu | dwdv | dwex | db1 | dw2 | db2] (both ACCUMULATED into: caller zeroes), dex [N,K] (nullable,
  * overwritten; gradient wrt the per-edge extra).  ex [E] as written by the forward (nullable when ex_mode was 0). */
-int dgg_edge_mlp_bwd(const float *AB, int64_t N, int hw, const int32_t *idx, const int32_t *eid, const float *val,
-                     const float *dval, int K, const float *deg, const float *ex, const float *wdu, const float *wdv,
-                     const float *wex, const float *b1, const float *w2, const float *b2, int act, int perturb, float *dAB,
-                     float *dpar, float *dex, void *stream);
+int dgg_edge_mlp_bwd(const float *AB, int64_t N, int hw, const int64_t *rowptr, const int32_t *idx, const int32_t *eid,
+                     const float *val, const float *dval, int K, const float *deg, const float *ex, const float *wdu,
+                     const float *wdv, const float *wex, const float *b1, const float *w2, const float *b2, int act,
+                     int perturb, float *dAB, float *dpar, float *dex, void *stream);
+
+/* ---- CSR-valued adjacency (variable row length) + the `DGG` class "for ICLR" (dgm.py:1730-1815) ---------------------
+ * `DGG.forward` keeps every candidate edge (weight rank * (ramp + 1), dgm.py:1804-1807), so its output has the sparsity
+ * of in_adj (rows up to 168 wide on Cora) and is carried as values [E] on the CSR pattern (rowptr int64 [N+1], col
+ * int32 [E], columns of a row ascending).  dgg_edge_mlp_bwd takes the same pattern through its rowptr argument. */
+/* dgm.py:1791-1812: S_i = sum_j rank_ij; k_i = degree_decoder(S_i) = leaky(S_i w + b) (w, b device pointers);
+ * pos_e = rank position of edge e in its row under torch.sort(descending) (ties: lower column first);
+ * out_e = rank_e * ((1 - 0.5 (1 + tanh(pos_e - k_i))) + 1) */
+int dgg_csr_rank_ramp_fwd(const float *p, const int64_t *rowptr, const int32_t *col, int64_t N, const float *w, const float *b,
+                          float *out, float *S, float *k, int32_t *pos, void *stream);
+/* g = d loss / d out -> dp [E] (direct + through S -> k), dkz [N] = d loss / d (S_i w + b) (dw = <dkz, S>, db = sum dkz) */
+int dgg_csr_rank_ramp_bwd(const float *p, const int64_t *rowptr, int64_t N, const float *w, const float *b, const float *S,
+                          const float *k, const int32_t *pos, const float *g, float *dp, float *dkz, void *stream);
+/* normalize_adj of the *_DGG_00 wrappers (model.py:1340-1352): rs = row sums, ahat_e = rs_i^-1/2 w_e rs_j^-1/2 */
+int dgg_csr_row_sum(const float *vals, const int64_t *rowptr, int64_t N, float *rs, void *stream);
+int dgg_csr_normalize_fwd(const int64_t *rowptr, const int32_t *col, const float *w, const float *rs, int64_t N, float *ahat,
+                          void *stream);
+/* autograd of the two: dA (wrt ahat) -> dw; da_ws [N] zeroed by the caller */
+int dgg_csr_norm_bwd(const int64_t *rowptr, const int32_t *col, const float *w, const float *rs, const float *dA, int64_t N,
+                     float *da_ws, float *dw, void *stream);
+/* torch.mm(adj, x) (model.py:594) on the CSR pattern and its autograd (dA [E]; dX nullable, accumulated into) */
+int dgg_csr_spmm_fwd(const int64_t *rowptr, const int32_t *col, const float *a, const float *X, int64_t N, int F, float *Y,
+                     void *stream);
+int dgg_csr_spmm_bwd(const int64_t *rowptr, const int32_t *col, const float *a, const float *X, const float *dY, int64_t N, int F,
+                     float *dA, float *dX, void *stream);
 /* selection only, from a dense score matrix [R,N] (test entry: torch.sort(pert_edge_p)[:, :K], dgm.py:1404) */
 int dgg_select_scores(const float *scores, int64_t R, int64_t N, int K, int32_t *idx, float *val, void *stream);
 

@@ -2,12 +2,12 @@
 `learning-adaptive-neighborhoods-for-gnns_amd/`, importable as `dgg_amd` through the shim at the repo root).
 
 Public surface mirrors the reference's modules:
-    dgg_amd.dgm.DGG_LearnableK_debug, dgg_amd.dgm.LearnableKEncoder          (reference dgm.py)
-    dgg_amd.model.{GCNConv, GraphConvolution, DenseGraphConvolution, GCN_DGG, GCNII_DGG, GCNIIppi_DGG}  (model.py)
-plus the containers `AllPairs` / `EllAdjacency` and the raw kernel wrappers in `dgg_amd.ops`.
+    dgg_amd.dgm.{DGG_LearnableK_debug, DGG, LearnableKEncoder}               (reference dgm.py)
+    dgg_amd.model.{GCNConv, GraphConvolution, DenseGraphConvolution, GCN_DGG, GCN_DGG_00, GCNII_DGG, GCNIIppi_DGG}  (model.py)
+plus the containers `AllPairs` / `EllAdjacency` / `CsrAdjacency` and the raw kernel wrappers in `dgg_amd.ops`.
 """
 from . import _lib, ops  # noqa: F401
-from .adjacency import AllPairs, EllAdjacency, csr_candidates, ell_from_dense  # noqa: F401
-from .dgm import DGG_LearnableK_debug, LearnableKEncoder  # noqa: F401
-from .model import (DenseGraphConvolution, GCN_DGG, GCNConv, GCNII_DGG, GCNIIppi_DGG,  # noqa: F401
+from .adjacency import AllPairs, CsrAdjacency, EllAdjacency, csr_candidates, csr_pattern, ell_from_dense  # noqa: F401
+from .dgm import DGG, DGG_LearnableK_debug, LearnableKEncoder  # noqa: F401
+from .model import (DenseGraphConvolution, GCN_DGG, GCN_DGG_00, GCNConv, GCNII_DGG, GCNIIppi_DGG,  # noqa: F401
                     GraphConvolution)

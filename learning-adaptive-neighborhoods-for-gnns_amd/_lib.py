@@ -27,7 +27,14 @@ PROTOTYPES = {
     "dgg_edgelist_topk": [_vp, _i64, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _vp, _vp],
     "dgg_edge_mlp_fwd": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "dgg_edgelist_topk_p": [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
-    "dgg_edge_mlp_bwd": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
+    "dgg_edge_mlp_bwd": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
+    "dgg_csr_rank_ramp_fwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "dgg_csr_rank_ramp_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "dgg_csr_row_sum": [_vp, _vp, _i64, _vp, _vp],
+    "dgg_csr_normalize_fwd": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "dgg_csr_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "dgg_csr_spmm_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
+    "dgg_csr_spmm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "dgg_select_scores": [_vp, _i64, _i64, _i32, _vp, _vp, _vp],
     "dgg_softk_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
     "dgg_ell_normalize_fwd": [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp],

@@ -72,6 +72,49 @@ class EllAdjacency:
     __matmul__ = matmul
 
 
+class CsrAdjacency:
+    """Sparse matrix with the pattern of a coalesced COO in_adj (rowptr int64 [N+1], col int32 [E], erow int32 [E]) and
+    its own values [E]: what the `DGG` class returns (every candidate edge kept, dgm.py:1804-1815), rows of any width."""
+
+    def __init__(self, rowptr, col, erow, values, n, k=None):
+        self.rowptr, self.col, self.erow, self._values, self.k = rowptr, col, erow, values, k
+        self.shape = (n, n)
+        self.device = values.device
+
+    def values(self):
+        return self._values
+
+    def coalesce(self):
+        return self
+
+    def indices(self):
+        return torch.stack([self.erow.long(), self.col.long()])
+
+    def to_sparse(self):
+        return torch.sparse_coo_tensor(self.indices(), self._values, self.shape)
+
+    def to_dense(self):
+        out = torch.zeros(self.shape, device=self.device, dtype=self._values.dtype)
+        return out.index_put((self.erow.long(), self.col.long()), self._values, accumulate=True)
+
+    def normalize(self):
+        return CsrAdjacency(self.rowptr, self.col, self.erow, ops.CsrNormalizeFn.apply(self._values, self.rowptr, self.col),
+                            self.shape[0], k=self.k)
+
+    def matmul(self, X):
+        return ops.CsrSpmmFn.apply(self._values, self.rowptr, self.col, X)
+
+    __matmul__ = matmul
+
+
+def csr_pattern(in_adj):
+    """coalesced sparse COO -> (rowptr int64, col int32, erow int32)"""
+    in_adj = in_adj.coalesce()
+    ind = in_adj.indices()
+    rowptr = torch._convert_indices_from_coo_to_csr(ind[0], in_adj.shape[0], out_int32=False)
+    return rowptr, ind[1].to(torch.int32).contiguous(), ind[0].to(torch.int32).contiguous()
+
+
 def ell_from_dense(A, K=ops.DEFAULT_K):
     """Dense [N,N] -> ELL keeping the K largest entries per row (exact when every row has <= K non-zeros)."""
     assert (A != 0).sum(1).max() <= K, "row has more non-zeros than the ELL width"

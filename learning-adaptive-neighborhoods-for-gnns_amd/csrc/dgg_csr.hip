@@ -1,0 +1,249 @@
+// dgg_csr.hip -- adjacency with the sparsity of in_adj (CSR, variable row length) and the tail of the `DGG` class.
+//
+// The `DGG` module "for ICLR" (reference dgm.py:1730-1815, used by GCN_DGG_00 / SAGE_DGG_00 / GAT_DGG_00,
+// model.py:1314-1433) keeps EVERY candidate edge with weight rank * (ramp + 1), so its output is as wide as the widest
+// row of in_adj (168 on Cora) and does not fit the 64-wide ELL of the DGG_LearnableK_debug path.  This file holds
+//   rank_ramp fwd/bwd   S_i = sum_j rank_ij, k_i = leaky(S_i w + b), position in the row sorted by (rank desc, column asc),
+//                       out = rank * ((1 - 0.5 (1 + tanh(pos - k))) + 1)                       dgm.py:1791-1812
+//   row_sum / normalize D^-1/2 A D^-1/2 with row sums on both sides                            model.py:1340-1352
+//   spmm fwd/bwd        torch.mm(adj, x) and its autograd                                      model.py:594
+// One wavefront per row, entries walked in chunks of 64 (lane = entry) or sequentially (lane = feature).
+#include "dgg_common.h"
+#include "dgg_api_internal.h"
+
+using namespace dgg;
+
+namespace {
+
+constexpr int WPB = 4;
+
+// canonical row reduction: entry e of the row goes to slot e mod 64 (sequential adds), then the xor butterfly
+__device__ __forceinline__ float row_sum_strided(const float *__restrict__ v, int64_t e0, int64_t e1, int lane) {
+    float s = 0.0f;
+    for (int64_t e = e0 + lane; e < e1; e += 64) s = __fadd_rn(s, v[e]);
+    return wave_sum_butterfly(s);
+}
+
+__global__ __launch_bounds__(WPB * 64) void csr_row_sum_kernel(const float *__restrict__ vals, const int64_t *__restrict__ rowptr,
+                                                              int64_t N, float *__restrict__ rs) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const float s = row_sum_strided(vals, rowptr[i], rowptr[i + 1], lane);
+    if (lane == 0) rs[i] = s;
+}
+
+__global__ __launch_bounds__(WPB * 64) void csr_normalize_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                                const float *__restrict__ w, const float *__restrict__ rs,
+                                                                int64_t N, float *__restrict__ ahat) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const float ai = __fdiv_rn(1.0f, c_sqrt(rs[i]));
+    for (int64_t e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64)
+        ahat[e] = __fmul_rn(__fmul_rn(ai, w[e]), __fdiv_rn(1.0f, c_sqrt(rs[col[e]])));
+}
+
+// Y_i[c] = sum_e a_e X[col_e][c], e ascending (fmaf chain); lanes = features, grid.y walks blocks of 64 features
+__global__ __launch_bounds__(WPB * 64) void csr_spmm_fwd_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                               const float *__restrict__ a, const float *__restrict__ X, int64_t N,
+                                                               int F, float *__restrict__ Y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int c = blockIdx.y * 64 + lane;
+    float acc = 0.0f;
+    const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
+    for (int64_t eb = e0; eb < e1; eb += 64) {                   // entries of a chunk are loaded one per lane, then broadcast
+        const int64_t e = eb + lane;
+        const int32_t jl = e < e1 ? col[e] : 0;
+        const float al = e < e1 ? a[e] : 0.0f;
+        const int n = e1 - eb < 64 ? (int)(e1 - eb) : 64;
+        for (int r = 0; r < n; r++) {
+            const int32_t j = bcast(jl, r);
+            const float av = bcast(al, r);
+            if (c < F) acc = __fmaf_rn(av, X[(int64_t)j * F + c], acc);
+        }
+    }
+    if (c < F) Y[i * F + c] = acc;
+}
+
+// dA_e = <dY_i, X_j>;  dX_j += a_e dY_i (float atomics, optional)
+__global__ __launch_bounds__(WPB * 64) void csr_spmm_bwd_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                               const float *__restrict__ a, const float *__restrict__ X,
+                                                               const float *__restrict__ dY, int64_t N, int F,
+                                                               float *__restrict__ dA, float *__restrict__ dX) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
+        const int64_t j = col[e];
+        const float av = a[e];
+        float part = 0.0f;
+        for (int c = lane; c < F; c += 64) {
+            const float g = dY[i * F + c];
+            part = fmaf(g, X[j * F + c], part);
+            if (dX && av != 0.0f) atomicAdd(dX + j * F + c, av * g);
+        }
+        part = wave_sum_dpp(part, lane);
+        if (lane == 0) dA[e] = part;
+    }
+}
+
+// normalisation backward, phase 1: da_i += sum_e g_e a_j (row, plain add by one lane), da_j += g_e a_i (atomics); g = dA w
+__global__ __launch_bounds__(WPB * 64) void csr_norm_bwd_da_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                                  const float *__restrict__ w, const float *__restrict__ rs,
+                                                                  const float *__restrict__ dA, int64_t N, float *__restrict__ da) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const float ai = 1.0f / sqrtf(rs[i]);
+    float rowpart = 0.0f;
+    for (int64_t e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64) {
+        const float g = dA[e] * w[e];
+        if (g != 0.0f) {
+            const int32_t j = col[e];
+            rowpart += g * (1.0f / sqrtf(rs[j]));
+            atomicAdd(da + j, g * ai);
+        }
+    }
+    rowpart = wave_sum_dpp(rowpart, lane);
+    if (lane == 0 && rowpart != 0.0f) atomicAdd(da + i, rowpart);
+}
+// phase 2: dw_e = dA_e a_i a_j + drs_i, drs_i = -0.5 da_i a_i / rs_i
+__global__ __launch_bounds__(WPB * 64) void csr_norm_bwd_dw_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                                  const float *__restrict__ rs, const float *__restrict__ dA,
+                                                                  const float *__restrict__ da, int64_t N, float *__restrict__ dw) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const float ai = 1.0f / sqrtf(rs[i]);
+    const float drs = -0.5f * da[i] * ai / rs[i];
+    for (int64_t e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64) dw[e] = dA[e] * ai * (1.0f / sqrtf(rs[col[e]])) + drs;
+}
+
+// ---- `DGG.forward` tail (dgm.py:1791-1812) ----------------------------------------------------------------------------
+// position of an entry = number of entries of its row that sort before it under (rank desc, column asc): every lane
+// counts for its own entries while the row streams through in chunks of 64 broadcast from registers
+__global__ __launch_bounds__(WPB * 64) void csr_rank_ramp_fwd_kernel(const float *__restrict__ p, const int64_t *__restrict__ rowptr,
+                                                                    const int32_t *__restrict__ col, int64_t N,
+                                                                    const float *__restrict__ wb, const float *__restrict__ bb,
+                                                                    float *__restrict__ out, float *__restrict__ S,
+                                                                    float *__restrict__ k, int32_t *__restrict__ pos) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
+    const float s = row_sum_strided(p, e0, e1, lane);
+    const float z = __fadd_rn(__fmul_rn(s, wb[0]), bb[0]);        // degree_decoder: Linear(1,1) + LeakyReLU
+    const float ki = z > 0.0f ? z : __fmul_rn(0.01f, z);
+    if (lane == 0) { S[i] = s; k[i] = ki; }
+    for (int64_t mb = e0; mb < e1; mb += 64) {                   // my entry of this chunk
+        const int64_t me = mb + lane;
+        const bool have = me < e1;
+        const uint64_t mykey = have ? make_key(p[me], col[me]) : 0ull;
+        int cnt = 0;
+        for (int64_t qb = e0; qb < e1; qb += 64) {
+            const int64_t q = qb + lane;
+            const uint64_t qk = q < e1 ? make_key(p[q], col[q]) : 0ull;
+            const int n = e1 - qb < 64 ? (int)(e1 - qb) : 64;
+            for (int r = 0; r < n; r++) cnt += shfl_u64(qk, r) > mykey ? 1 : 0;
+        }
+        if (have) {
+            pos[me] = cnt;
+            const float f = __fadd_rn(c_ramp((float)cnt, ki), 1.0f);
+            out[me] = __fmul_rn(p[me], f);
+        }
+    }
+}
+
+// g = d out -> dp (direct + through S -> k), dkz_i = d loss / d (S_i w + b)
+__global__ __launch_bounds__(WPB * 64) void csr_rank_ramp_bwd_kernel(const float *__restrict__ p, const int64_t *__restrict__ rowptr,
+                                                                    int64_t N, const float *__restrict__ wb,
+                                                                    const float *__restrict__ bb, const float *__restrict__ S,
+                                                                    const float *__restrict__ k, const int32_t *__restrict__ pos,
+                                                                    const float *__restrict__ g, float *__restrict__ dp,
+                                                                    float *__restrict__ dkz) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
+    const float ki = k[i], w = wb[0];
+    float dk = 0.0f;
+    for (int64_t e = e0 + lane; e < e1; e += 64) {
+        const float th = c_tanh((float)pos[e] - ki);
+        dk += g[e] * p[e] * 0.5f * (1.0f - th * th);
+    }
+    dk = wave_sum_butterfly(dk);
+    const float z = S[i] * w + bb[0];
+    const float dz = z > 0.0f ? dk : 0.01f * dk;
+    if (lane == 0) dkz[i] = dz;
+    for (int64_t e = e0 + lane; e < e1; e += 64) {
+        const float th = c_tanh((float)pos[e] - ki);
+        const float f = 1.0f - 0.5f * (1.0f + th) + 1.0f;
+        dp[e] = g[e] * f + dz * w;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dgg_csr_row_sum(const float *vals, const int64_t *rowptr, int64_t N, float *rs, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(csr_row_sum_kernel, dim3((unsigned)((N + WPB - 1) / WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, vals, rowptr, N, rs);
+    return dgg_check_launch("csr_row_sum");
+}
+
+int dgg_csr_normalize_fwd(const int64_t *rowptr, const int32_t *col, const float *w, const float *rs, int64_t N, float *ahat,
+                          void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(csr_normalize_kernel, dim3((unsigned)((N + WPB - 1) / WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, rowptr, col, w,
+                       rs, N, ahat);
+    return dgg_check_launch("csr_normalize_fwd");
+}
+
+int dgg_csr_spmm_fwd(const int64_t *rowptr, const int32_t *col, const float *a, const float *X, int64_t N, int F, float *Y,
+                     void *stream) {
+    if (N == 0 || F == 0) return 0;
+    hipLaunchKernelGGL(csr_spmm_fwd_kernel, dim3((unsigned)((N + WPB - 1) / WPB), (unsigned)((F + 63) / 64)), dim3(WPB * 64), 0,
+                       (hipStream_t)stream, rowptr, col, a, X, N, F, Y);
+    return dgg_check_launch("csr_spmm_fwd");
+}
+
+// dA [E] overwritten; dX (nullable, [N,F]) accumulated into (caller zeroes)
+int dgg_csr_spmm_bwd(const int64_t *rowptr, const int32_t *col, const float *a, const float *X, const float *dY, int64_t N, int F,
+                     float *dA, float *dX, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(csr_spmm_bwd_kernel, dim3((unsigned)((N + WPB - 1) / WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, rowptr, col, a, X,
+                       dY, N, F, dA, dX);
+    return dgg_check_launch("csr_spmm_bwd");
+}
+
+// da_ws [N] zeroed by the caller; dw [E] overwritten
+int dgg_csr_norm_bwd(const int64_t *rowptr, const int32_t *col, const float *w, const float *rs, const float *dA, int64_t N,
+                     float *da_ws, float *dw, void *stream) {
+    if (N == 0) return 0;
+    const dim3 grid((unsigned)((N + WPB - 1) / WPB));
+    hipLaunchKernelGGL(csr_norm_bwd_da_kernel, grid, dim3(WPB * 64), 0, (hipStream_t)stream, rowptr, col, w, rs, dA, N, da_ws);
+    hipLaunchKernelGGL(csr_norm_bwd_dw_kernel, grid, dim3(WPB * 64), 0, (hipStream_t)stream, rowptr, col, rs, dA, da_ws, N, dw);
+    return dgg_check_launch("csr_norm_bwd");
+}
+
+int dgg_csr_rank_ramp_fwd(const float *p, const int64_t *rowptr, const int32_t *col, int64_t N, const float *w, const float *b,
+                          float *out, float *S, float *k, int32_t *pos, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(csr_rank_ramp_fwd_kernel, dim3((unsigned)((N + WPB - 1) / WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, p, rowptr,
+                       col, N, w, b, out, S, k, pos);
+    return dgg_check_launch("csr_rank_ramp_fwd");
+}
+
+int dgg_csr_rank_ramp_bwd(const float *p, const int64_t *rowptr, int64_t N, const float *w, const float *b, const float *S,
+                          const float *k, const int32_t *pos, const float *g, float *dp, float *dkz, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(csr_rank_ramp_bwd_kernel, dim3((unsigned)((N + WPB - 1) / WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, p, rowptr,
+                       N, w, b, S, k, pos, g, dp, dkz);
+    return dgg_check_launch("csr_rank_ramp_bwd");
+}
+
+}  // extern "C"

@@ -93,8 +93,9 @@ __global__ __launch_bounds__(256) void edgelist_topk_p_kernel(
 // rows of a persistent workgroup -> LDS -> one atomic per workgroup and element.
 template <int VEC>
 __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
-    const float *__restrict__ AB, int64_t N, int hw, const int32_t *__restrict__ idx, const int32_t *__restrict__ eid,
-    const float *__restrict__ val, const float *__restrict__ dval, int K, const float *__restrict__ deg,
+    const float *__restrict__ AB, int64_t N, int hw, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ idx,
+    const int32_t *__restrict__ eid, const float *__restrict__ val, const float *__restrict__ dval, int K,
+    const float *__restrict__ deg,
     const float *__restrict__ ex, const float *__restrict__ wdu, const float *__restrict__ wdv,
     const float *__restrict__ wex, const float *__restrict__ b1, const float *__restrict__ w2,
     const float *__restrict__ b2, int act, int perturb, float *__restrict__ dAB, float *__restrict__ dpar,
@@ -116,20 +117,24 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
 #pragma unroll
         for (int q = 0; q < VEC; q++) Ai[q] = AB[i * 2 * hw + o0 + q];
         const float du = deg ? deg[i] : 0.0f;
-        for (int r0 = 0; r0 < K; r0 += EPI) {
+        // entries of the row: ELL [i*K, i*K+K) or, with rowptr, the CSR range of a variable-width adjacency
+        const int64_t base = rowptr ? rowptr[i] : i * K;
+        const int cnt = rowptr ? (int)(rowptr[i + 1] - base) : K;
+        for (int r0 = 0; r0 < cnt; r0 += EPI) {
             const int r = r0 + slot;
-            const int32_t j = r < K ? idx[i * K + r] : -1;
-            const float g = r < K ? dval[i * K + r] : 0.0f;
+            const int64_t en = base + r;
+            const int32_t j = r < cnt ? idx[en] : -1;
+            const float g = r < cnt ? dval[en] : 0.0f;
             const bool actv = j >= 0 && g != 0.0f;
             if (__ballot(actv) == 0ull) {
-                if (dex && c == 0 && r < K) dex[i * K + r] = 0.0f;
+                if (dex && c == 0 && r < cnt) dex[en] = 0.0f;
                 continue;
             }
             float z[VEC], hid[VEC], part = 0.0f;
             float dv = 0.0f, exv = 0.0f;
             if (actv) {
                 dv = deg ? deg[j] : 0.0f;
-                exv = ex ? ex[eid[i * K + r]] : 0.0f;
+                exv = ex ? ex[eid ? eid[en] : en] : 0.0f;
 #pragma unroll
                 for (int q = 0; q < VEC; q++) {
                     float zz = Ai[q] + AB[(int64_t)j * 2 * hw + hw + o0 + q];
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
             float ds = 0.0f;
             if (actv) {
                 const float p = 1.0f / (1.0f + c_exp(-(part + b2v)));
-                const float dp = perturb ? g * val[i * K + r] / (p + 1e-8f) : g;
+                const float dp = perturb ? g * val[en] / (p + 1e-8f) : g;
                 ds = dp * p * (1.0f - p);
             }
             float de = 0.0f;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
             if (c == 0) g_b2 += ds;
             if (dex) {
                 for (int off = 1; off < LPE; off <<= 1) de += __shfl_xor(de, off, 64);
-                if (c == 0 && r < K) dex[i * K + r] = de;
+                if (c == 0 && r < cnt) dex[en] = de;
             }
         }
         for (int off = LPE; off < 64; off <<= 1) {
@@ -238,25 +243,27 @@ int dgg_edgelist_topk_p(const float *p_edge, int64_t N, const int64_t *rowptr, c
 }
 
 // dAB [N, 2*hw] and dpar [5*hw + 1] = [dwdu | dwdv | dwex | db1 | dw2 | db2] are ACCUMULATED into (caller zeroes them);
-// dex (nullable) [N,K] is overwritten.
-int dgg_edge_mlp_bwd(const float *AB, int64_t N, int hw, const int32_t *idx, const int32_t *eid, const float *val,
-                     const float *dval, int K, const float *deg, const float *ex, const float *wdu, const float *wdv,
-                     const float *wex, const float *b1, const float *w2, const float *b2, int act, int perturb, float *dAB,
-                     float *dpar, float *dex, void *stream) {
-    if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+// dex (nullable) [N,K] is overwritten.  rowptr == NULL: ELL adjacency (idx/eid/val/dval/dex are [N,K]); rowptr != NULL:
+// CSR-valued adjacency (idx = col [E], val/dval/dex [E], eid NULL = identity, K ignored).
+int dgg_edge_mlp_bwd(const float *AB, int64_t N, int hw, const int64_t *rowptr, const int32_t *idx, const int32_t *eid,
+                     const float *val, const float *dval, int K, const float *deg, const float *ex, const float *wdu,
+                     const float *wdv, const float *wex, const float *b1, const float *w2, const float *b2, int act,
+                     int perturb, float *dAB, float *dpar, float *dex, void *stream) {
+    if (!rowptr && (K < 1 || K > 64)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
     const int vec = hw % 4 == 0 ? 4 : 1;
     const int lpe = hw / vec;
     if (!pow2(lpe) || lpe > 64)
         return dgg_set_error(DGG_ERR_UNSUPPORTED, "edge_mlp_bwd: hidden width must be 1, 2 or 4 x a power of two (<= 256)");
-    if ((ex && (!wex || !eid)) || (deg && (!wdu || !wdv))) return dgg_set_error(DGG_ERR_ARG, "edge_mlp_bwd: missing extras / weights");
+    if ((ex && (!wex || (!eid && !rowptr))) || (deg && (!wdu || !wdv)))
+        return dgg_set_error(DGG_ERR_ARG, "edge_mlp_bwd: missing extras / weights");
     if (N == 0) return 0;
     const unsigned grid = (unsigned)((N + 3) / 4 < 2048 ? (N + 3) / 4 : 2048);
     const size_t lds = (size_t)4 * (5 * hw + 1) * sizeof(float);
     if (vec == 4)
-        hipLaunchKernelGGL(edge_mlp_bwd_kernel<4>, dim3(grid), dim3(256), lds, (hipStream_t)stream, AB, N, hw, idx, eid, val, dval, K,
+        hipLaunchKernelGGL(edge_mlp_bwd_kernel<4>, dim3(grid), dim3(256), lds, (hipStream_t)stream, AB, N, hw, rowptr, idx, eid, val, dval, K,
                            deg, ex, wdu, wdv, wex, b1, w2, b2, act, perturb, dAB, dpar, dex);
     else
-        hipLaunchKernelGGL(edge_mlp_bwd_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, AB, N, hw, idx, eid, val, dval, K,
+        hipLaunchKernelGGL(edge_mlp_bwd_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, AB, N, hw, rowptr, idx, eid, val, dval, K,
                            deg, ex, wdu, wdv, wex, b1, w2, b2, act, perturb, dAB, dpar, dex);
     return dgg_check_launch("edge_mlp_bwd");
 }

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .adjacency import AllPairs, EllAdjacency, csr_candidates
+from .adjacency import AllPairs, CsrAdjacency, EllAdjacency, csr_candidates, csr_pattern
 
 _EDGE_MLP_MODES = ("u-v-A_uv", "u-v-deg", "u-v-deg-dist", "edge_conv", "A_uv")
 
@@ -304,3 +304,59 @@ class DGG_LearnableK_debug(nn.Module):
             writer.add_scalar("values/first_k_std", f.sum(-1).std(), epoch)
             writer.add_scalar("values/first_k_mean", f.sum(-1).mean(), epoch)
         return EllAdjacency(idx, w, x.shape[0], rs=rs, k=k, score=val)
+
+
+class _DGGClassFn(torch.autograd.Function):
+    """Edge ranks + degree + ramp of the `DGG` class (reference dgm.py:1781-1812) on the CSR pattern of `adj`.
+    W_e (x_u - x_v) = Q_u - Q_v with Q = xe W_e^T, so the scorer is dgg_edge_mlp_fwd with AB = xe [W_e | -W_e]^T,
+    w2 = 1, b2 = 0 (edge_feat.sum(-1), dgm.py:1786)."""
+
+    @staticmethod
+    def forward(ctx, xe, We, be, wdd, bdd, pattern):
+        rowptr, col, erow = pattern
+        h = We.shape[0]
+        Wcat = torch.cat([We, -We], 0)
+        AB = ops.linear_fwd(xe, Wcat, None, ops.ACT_NONE)
+        ones, zero = torch.ones(h, device=xe.device), torch.zeros(1, device=xe.device)
+        p, _ = ops.edge_mlp_fwd(AB, xe, erow, col, None, None, 0, 0.0, None, None, None, be, ones, zero, ops.ACT_LEAKY)
+        out, S, k, pos = ops.csr_rank_ramp_fwd(p, rowptr, col, wdd.reshape(-1), bdd)
+        ctx.save_for_backward(xe, We, be, wdd, bdd, rowptr, col, Wcat, AB, ones, zero, p, S, k, pos)
+        ctx.mark_non_differentiable(k)
+        return out, k
+
+    @staticmethod
+    def backward(ctx, g, _dk):
+        xe, We, be, wdd, bdd, rowptr, col, Wcat, AB, ones, zero, p, S, k, pos = ctx.saved_tensors
+        h = We.shape[0]
+        dp, dkz = ops.csr_rank_ramp_bwd(p, rowptr, wdd.reshape(-1), bdd, S, k, pos, g.contiguous())
+        dAB, dpar, _ = ops.edge_mlp_bwd(AB, col, None, p, dp, None, None, None, None, None, be, ones, zero, ops.ACT_LEAKY, False,
+                                        rowptr=rowptr)
+        dxe, dWcat, _ = ops.linear_bwd(xe, Wcat, AB, dAB, ops.ACT_NONE, need_dx=True, need_db=False)
+        return (dxe, dWcat[:h] - dWcat[h:], dpar[3 * h:4 * h], torch.dot(dkz, S).reshape(wdd.shape), dkz.sum().reshape(bdd.shape),
+                None)
+
+
+class DGG(nn.Module):
+    """Drop-in for the reference's `DGG` "for ICLR" (dgm.py:1730-1815), the generator behind the *_DGG_00 wrappers
+    (model.py:1314-1433): x' = leaky(x W); rank_uv = sigmoid(sum_h leaky(W_e (x'_u - x'_v) + b_e)) on the stored entries of
+    `adj`; k = leaky(Linear(1,1)(sum_v rank_uv)); every edge kept with weight rank * (ramp(position - k) + 1).
+    Returns (CsrAdjacency with the pattern of `adj`, x')."""
+
+    def __init__(self, in_dim=32, latent_dim=64, args=None):
+        super().__init__()
+        self.args = args
+        self.node_encoder = nn.Sequential(nn.Linear(in_dim, latent_dim), nn.LeakyReLU())
+        self.edge_encoder = nn.Sequential(nn.Linear(latent_dim + self.args.extra_edge_dim, latent_dim), nn.LeakyReLU())
+        self.degree_decoder = nn.Sequential(nn.Linear(1, 1, bias=True), nn.LeakyReLU())
+
+    def forward(self, x, adj, noise=True, writer=None, epoch=None):
+        assert x.ndim == 2 and len(adj.shape) == 2
+        assert self.edge_encoder[0].weight.shape[1] == self.node_encoder[0].weight.shape[0], \
+            "DGG feeds x'_u - x'_v (latent_dim features) to edge_encoder: extra_edge_dim must be 0 (dgm.py:1784-1785)"
+        if isinstance(adj, (CsrAdjacency, EllAdjacency)):
+            adj = adj.to_sparse().detach()
+        pattern = csr_pattern(adj)
+        xe = ops.LinearFn.apply(x, self.node_encoder[0].weight, self.node_encoder[0].bias, ops.ACT_LEAKY, 0)
+        out, k = _DGGClassFn.apply(xe, self.edge_encoder[0].weight, self.edge_encoder[0].bias, self.degree_decoder[0].weight,
+                                   self.degree_decoder[0].bias, pattern)
+        return CsrAdjacency(pattern[0], pattern[1], pattern[2], out, x.shape[0], k=k), xe

@@ -13,12 +13,12 @@ import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
 from . import ops
-from .adjacency import EllAdjacency, ell_from_dense
-from .dgm import DGG_LearnableK_debug
+from .adjacency import CsrAdjacency, EllAdjacency, ell_from_dense
+from .dgm import DGG, DGG_LearnableK_debug
 
 
 def _as_ell(adj):
-    if isinstance(adj, EllAdjacency):
+    if isinstance(adj, (EllAdjacency, CsrAdjacency)):
         return adj
     if adj.is_sparse:
         adj = adj.to_dense()
@@ -75,7 +75,7 @@ class DenseGraphConvolution(GraphConvolution):
 
 def _normalize_adj(A_hat):
     """D^-1/2 A D^-1/2 with row sums on both sides (reference model.py:1205-1219 and its nine copies)."""
-    if isinstance(A_hat, EllAdjacency):
+    if isinstance(A_hat, (EllAdjacency, CsrAdjacency)):
         return A_hat.normalize()
     return _as_ell(A_hat).normalize()
 
@@ -129,6 +129,46 @@ class GCN_DGG(nn.Module):
 
     def dgg_net(self, x, i, unnorm_adj, writer, epoch):
         return self.dggs[i](x=x, in_adj=unnorm_adj, noise=False, writer=writer, epoch=epoch)
+
+
+class GCN_DGG_00(nn.Module):
+    """Two GCNConv layers on the encoded features of a `DGG` generator (reference model.py:1314-1433).  Returns
+    (log_probs, unnorm_adj, x_dgg)."""
+
+    def __init__(self, nfeat=32, nlayers=None, nhidden=32, nclass=10, args=None, **kwargs):
+        super().__init__()
+        self.convs = nn.ModuleList()
+        self.conv1 = GCNConv(nhidden, nhidden)
+        self.conv2 = GCNConv(nhidden, nclass)
+        self.convs.append(self.conv1)
+        self.convs.append(self.conv2)
+        self.dgg_adj_input = args.dgg_adj_input
+        self.dggs = nn.ModuleList([DGG(in_dim=nfeat, latent_dim=nhidden, args=args)])
+        self.params1 = list(self.conv1.parameters())
+        self.params2 = list(self.conv2.parameters())
+        self.params2.extend(list(self.dggs.parameters()))
+
+    normalize_adj = staticmethod(_normalize_adj)
+
+    def forward(self, x, in_adj, noise=True, epoch=None, writer=None, **kwargs):
+        in_adj = _with_self_loops(in_adj)
+        unnorm_adj = in_adj
+        norm_adj = x_dgg = None
+        for i, conv in enumerate(self.convs):
+            if i < len(self.dggs):
+                src = in_adj if self.dgg_adj_input == "input_adj" else unnorm_adj
+                unnorm_adj, x_dgg = self.dgg_net(x, i, src, writer, epoch)
+                norm_adj = _normalize_adj(unnorm_adj)
+                x = x_dgg
+            x = conv(x + x_dgg, norm_adj)
+            if i < len(self.convs) - 1:
+                x = F.dropout(x, training=self.training)
+            if writer is not None:
+                writer.add_histogram("gcn_conv{}_dist".format(i + 1), x, epoch)
+        return F.log_softmax(x, dim=-1), unnorm_adj, x_dgg
+
+    def dgg_net(self, x, i, unnorm_adj, writer, epoch):
+        return self.dggs[i](x=x, adj=unnorm_adj, noise=False, writer=writer, epoch=epoch)
 
 
 class GCNII_DGG(nn.Module):

@@ -163,20 +163,85 @@ def edgelist_topk_p(p_edge, N, rowptr, col, K=DEFAULT_K, noise_mode=NOISE_NONE, 
     return idx, val, eid
 
 
-def edge_mlp_bwd(AB, idx, eid, val, dval, deg, ex, wdu, wdv, wex, b1, w2, b2, act=ACT_LEAKY, perturb=False, need_dex=False):
-    """-> dAB [N,2hw], dpar [5hw+1] = [dwdu|dwdv|dwex|db1|dw2|db2], dex [N,K] or None"""
+def edge_mlp_bwd(AB, idx, eid, val, dval, deg, ex, wdu, wdv, wex, b1, w2, b2, act=ACT_LEAKY, perturb=False, need_dex=False,
+                 rowptr=None):
+    """-> dAB [N,2hw], dpar [5hw+1] = [dwdu|dwdv|dwex|db1|dw2|db2], dex (shape of dval) or None.
+    ELL adjacency: idx/eid/val/dval [N,K]; CSR-valued adjacency: rowptr given, idx = col [E], val/dval [E], eid None."""
     AB = _chk(AB)
-    N, K = idx.shape
+    N = AB.shape[0]
+    K = idx.shape[1] if rowptr is None else 0
     hw = AB.shape[1] // 2
     zz = torch.zeros((N * 2 * hw + 5 * hw + 1,), device=AB.device, dtype=torch.float32)
     dAB, dpar = zz[:N * 2 * hw].view(N, 2 * hw), zz[N * 2 * hw:]
-    dex = torch.empty((N, K), device=AB.device, dtype=torch.float32) if need_dex else None
+    dex = torch.empty(tuple(dval.shape), device=AB.device, dtype=torch.float32) if need_dex else None
     o = lambda t_: None if t_ is None else _chk(t_)  # noqa: E731
-    _lib.check(_lib.lib().dgg_edge_mlp_bwd(_ptr(AB), N, hw, _ptr(idx), _ptr(eid), _ptr(_chk(val)), _ptr(_chk(dval)), K, _ptr(o(deg)),
+    _lib.check(_lib.lib().dgg_edge_mlp_bwd(_ptr(AB), N, hw, _ptr(rowptr), _ptr(idx), _ptr(eid), _ptr(_chk(val)), _ptr(_chk(dval)), K, _ptr(o(deg)),
                                            _ptr(o(ex)), _ptr(o(wdu)), _ptr(o(wdv)), _ptr(o(wex)), _ptr(_chk(b1)), _ptr(_chk(w2)),
                                            _ptr(_chk(b2)), act, int(perturb), _ptr(dAB), _ptr(dpar), _ptr(dex), _stream()),
                "edge_mlp_bwd")
     return dAB, dpar, dex
+
+
+# ---- CSR-valued adjacency (variable row length): the `DGG` class and the *_DGG_00 wrappers ----------------------------
+def csr_rank_ramp_fwd(p, rowptr, col, w, b):
+    """dgm.py:1791-1812 -> out [E], S [N], k [N], pos [E] (int32)"""
+    p = _chk(p)
+    N = rowptr.shape[0] - 1
+    out = torch.empty_like(p)
+    S = torch.empty((N,), device=p.device, dtype=torch.float32)
+    k = torch.empty((N,), device=p.device, dtype=torch.float32)
+    pos = torch.empty(p.shape, device=p.device, dtype=torch.int32)
+    _lib.check(_lib.lib().dgg_csr_rank_ramp_fwd(_ptr(p), _ptr(rowptr), _ptr(col), N, _ptr(_chk(w)), _ptr(_chk(b)), _ptr(out), _ptr(S),
+                                                _ptr(k), _ptr(pos), _stream()), "csr_rank_ramp_fwd")
+    return out, S, k, pos
+
+
+def csr_rank_ramp_bwd(p, rowptr, w, b, S, k, pos, g):
+    dp = torch.empty_like(p)
+    dkz = torch.empty_like(S)
+    _lib.check(_lib.lib().dgg_csr_rank_ramp_bwd(_ptr(_chk(p)), _ptr(rowptr), S.shape[0], _ptr(_chk(w)), _ptr(_chk(b)), _ptr(S), _ptr(k),
+                                                _ptr(pos), _ptr(_chk(g)), _ptr(dp), _ptr(dkz), _stream()), "csr_rank_ramp_bwd")
+    return dp, dkz
+
+
+def csr_row_sum(vals, rowptr):
+    N = rowptr.shape[0] - 1
+    rs = torch.empty((N,), device=vals.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_csr_row_sum(_ptr(_chk(vals)), _ptr(rowptr), N, _ptr(rs), _stream()), "csr_row_sum")
+    return rs
+
+
+def csr_normalize_fwd(rowptr, col, w, rs):
+    ahat = torch.empty_like(w)
+    _lib.check(_lib.lib().dgg_csr_normalize_fwd(_ptr(rowptr), _ptr(col), _ptr(_chk(w)), _ptr(_chk(rs)), rs.shape[0], _ptr(ahat),
+                                                _stream()), "csr_normalize_fwd")
+    return ahat
+
+
+def csr_norm_bwd(rowptr, col, w, rs, dA):
+    da = torch.zeros_like(rs)
+    dw = torch.empty_like(w)
+    _lib.check(_lib.lib().dgg_csr_norm_bwd(_ptr(rowptr), _ptr(col), _ptr(_chk(w)), _ptr(_chk(rs)), _ptr(_chk(dA)), rs.shape[0], _ptr(da),
+                                           _ptr(dw), _stream()), "csr_norm_bwd")
+    return dw
+
+
+def csr_spmm_fwd(rowptr, col, a, X):
+    X = _chk(X)
+    N, F = rowptr.shape[0] - 1, X.shape[1]
+    Y = torch.empty((N, F), device=X.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_csr_spmm_fwd(_ptr(rowptr), _ptr(col), _ptr(_chk(a)), _ptr(X), N, F, _ptr(Y), _stream()), "csr_spmm_fwd")
+    return Y
+
+
+def csr_spmm_bwd(rowptr, col, a, X, dY, need_dx=True):
+    X, dY = _chk(X), _chk(dY)
+    N, F = rowptr.shape[0] - 1, X.shape[1]
+    dA = torch.empty_like(a)
+    dX = torch.zeros_like(X) if need_dx else None
+    _lib.check(_lib.lib().dgg_csr_spmm_bwd(_ptr(rowptr), _ptr(col), _ptr(_chk(a)), _ptr(X), _ptr(dY), N, F, _ptr(dA), _ptr(dX),
+                                           _stream()), "csr_spmm_bwd")
+    return dA, dX
 
 
 def select_scores(scores, K=DEFAULT_K):
@@ -390,3 +455,36 @@ class EllSpmmFn(torch.autograd.Function):
         ahat, idx, X = ctx.saved_tensors
         dA, dX = spmm_bwd(idx, ahat, X, dY.contiguous(), need_dx=ctx.needs_input_grad[2], skip_zero=ctx.skip_zero)
         return dA, None, dX, None
+
+
+class CsrNormalizeFn(torch.autograd.Function):
+    """D^-1/2 A D^-1/2 with row sums on both sides (normalize_adj, model.py:1340-1352) on CSR values; the row sums are
+    part of the graph, as in the reference."""
+
+    @staticmethod
+    def forward(ctx, w, rowptr, col):
+        rs = csr_row_sum(w, rowptr)
+        ahat = csr_normalize_fwd(rowptr, col, w, rs)
+        ctx.save_for_backward(w, rowptr, col, rs)
+        return ahat
+
+    @staticmethod
+    def backward(ctx, dA):
+        w, rowptr, col, rs = ctx.saved_tensors
+        return csr_norm_bwd(rowptr, col, w, rs, dA.contiguous()), None, None
+
+
+class CsrSpmmFn(torch.autograd.Function):
+    """Y = A X on a CSR-valued adjacency (torch.mm(adj, x), model.py:594)."""
+
+    @staticmethod
+    def forward(ctx, a, rowptr, col, X):
+        Y = csr_spmm_fwd(rowptr, col, a, X)
+        ctx.save_for_backward(a, rowptr, col, X)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        a, rowptr, col, X = ctx.saved_tensors
+        dA, dX = csr_spmm_bwd(rowptr, col, a, X, dY.contiguous(), need_dx=ctx.needs_input_grad[3])
+        return dA, None, None, dX

@@ -719,3 +719,138 @@ ORA_API void ora_knet_deg_bwd_sums(const float *deg, int64_t N, float mu, float 
     }
     S[0] = (float)s0; S[1] = (float)s1;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* CSR adjacency (variable row length): the `DGG` class "for ICLR" keeps EVERY candidate edge  */
+/* (weight rank * (ramp + 1), dgm.py:1758-1815), so its output has the sparsity of in_adj and  */
+/* rows are not bounded by the ELL width.  Row reductions: lane-strided partial sums (entry e   */
+/* of the row goes to slot e mod 64, sequentially) followed by the xor-butterfly of a wavefront */
+/* ------------------------------------------------------------------------------------------ */
+static float strided_butterfly_sum(const float *v, int64_t n) {
+    float s[64], t[64];
+    for (int l = 0; l < 64; l++) s[l] = 0.0f;
+    for (int64_t e = 0; e < n; e++) s[e & 63] = s[e & 63] + v[e];
+    for (int off = 32; off >= 1; off >>= 1) {
+        for (int l = 0; l < 64; l++) t[l] = s[l] + s[l ^ off];
+        memcpy(s, t, sizeof(s));
+    }
+    return s[0];
+}
+ORA_API void ora_csr_row_sum(const float *vals, const int64_t *rowptr, int64_t N, float *rs) {
+    for (int64_t i = 0; i < N; i++) rs[i] = strided_butterfly_sum(vals + rowptr[i], rowptr[i + 1] - rowptr[i]);
+}
+/* A_hat = (a_i * w) * a_j, a = 1/sqrt(rs)   (model.py:1340-1352 normalize_adj of GCN_DGG_00, same as 1205-1219) */
+ORA_API void ora_csr_normalize(const int64_t *rowptr, const int32_t *col, const float *w, const float *rs, int64_t N,
+                               float *ahat) {
+    for (int64_t i = 0; i < N; i++) {
+        float ai = 1.0f / sqrtf(rs[i]);
+        for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) ahat[e] = (ai * w[e]) * (1.0f / sqrtf(rs[col[e]]));
+    }
+}
+ORA_API void ora_csr_spmm(const int64_t *rowptr, const int32_t *col, const float *a, const float *X, int64_t N, int F,
+                          float *Y) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < N; i++) {
+        for (int c = 0; c < F; c++) Y[i * F + c] = 0.0f;
+        for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++)
+            for (int c = 0; c < F; c++) Y[i * F + c] = fmaf(a[e], X[(int64_t)col[e] * F + c], Y[i * F + c]);
+    }
+}
+ORA_API void ora_csr_spmm_bwd(const int64_t *rowptr, const int32_t *col, const float *a, const float *X, const float *dY,
+                              int64_t N, int F, float *dA, float *dX) {
+    double *acc = calloc((size_t)N * F, 8);
+    for (int64_t i = 0; i < N; i++) for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
+        int64_t j = col[e];
+        double s = 0.0;
+        for (int c = 0; c < F; c++) { s += (double)dY[i * F + c] * X[j * F + c]; acc[j * F + c] += (double)a[e] * dY[i * F + c]; }
+        dA[e] = (float)s;
+    }
+    if (dX) for (int64_t q = 0; q < N * F; q++) dX[q] = (float)acc[q];
+    free(acc);
+}
+/* backward of ora_csr_row_sum + ora_csr_normalize: dA (wrt ahat) -> dw */
+ORA_API void ora_csr_norm_bwd(const int64_t *rowptr, const int32_t *col, const float *w, const float *rs, const float *dA,
+                              int64_t N, float *dw) {
+    double *da = calloc((size_t)N, 8), *a = malloc(sizeof(double) * N);
+    for (int64_t i = 0; i < N; i++) a[i] = 1.0 / sqrt((double)rs[i]);
+    for (int64_t i = 0; i < N; i++) for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
+        double g = (double)dA[e] * w[e];
+        da[i] += g * a[col[e]];
+        da[col[e]] += g * a[i];
+    }
+    for (int64_t i = 0; i < N; i++) {
+        double drs = -0.5 * da[i] * a[i] / (double)rs[i];
+        for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) dw[e] = (float)((double)dA[e] * a[i] * a[col[e]] + drs);
+    }
+    free(da); free(a);
+}
+/* `DGG.forward` after the edge ranks (dgm.py:1791-1812): S_i = sum_j rank_ij; k_i = leaky(S_i * w + b) (degree_decoder,
+ * Linear(1,1) + LeakyReLU); position of every edge in its row sorted by (rank desc, column asc);
+ * out_e = rank_e * ((1 - 0.5 (1 + tanh(pos - k))) + 1).  Saves S, k, pos. */
+ORA_API void ora_csr_rank_ramp(const float *p, const int64_t *rowptr, const int32_t *col, int64_t N, float w, float b,
+                               float *out, float *S, float *k, int32_t *pos) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < N; i++) {
+        int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
+        S[i] = strided_butterfly_sum(p + e0, e1 - e0);
+        float z = S[i] * w; z = z + b;
+        k[i] = z > 0.0f ? z : 0.01f * z;
+        for (int64_t e = e0; e < e1; e++) {
+            int c = 0;
+            for (int64_t q = e0; q < e1; q++) c += better(p[q], col[q], p[e], col[e]);
+            pos[e] = c;
+            float f = ramp((float)c, k[i]);
+            f = f + 1.0f;
+            out[e] = p[e] * f;
+        }
+    }
+}
+/* backward: g = d out -> dp (incl. the path through S -> k), dkz_i = d loss / d (S_i w + b) (for dw, db) */
+ORA_API void ora_csr_rank_ramp_bwd(const float *p, const int64_t *rowptr, int64_t N, float w, float b, const float *S,
+                                   const float *k, const int32_t *pos, const float *g, float *dp, float *dkz) {
+    for (int64_t i = 0; i < N; i++) {
+        double dk = 0.0;
+        for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
+            double th = ora_tanh((float)pos[e] - k[i]);
+            dk += (double)g[e] * p[e] * 0.5 * (1.0 - th * th);
+        }
+        double z = (double)S[i] * w + b;
+        double dz = z > 0.0 ? dk : 0.01 * dk;
+        dkz[i] = (float)dz;
+        for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
+            double th = ora_tanh((float)pos[e] - k[i]);
+            double f = 1.0 - 0.5 * (1.0 + th) + 1.0;
+            dp[e] = (float)((double)g[e] * f + dz * w);
+        }
+    }
+}
+/* ora_edge_mlp_bwd on a CSR-valued adjacency: entry e of row i is (i, col[e]) with cotangent dval[e] */
+ORA_API void ora_edge_mlp_bwd_csr(const float *AB, int64_t N, int hw, const int64_t *rowptr, const int32_t *col,
+                                  const float *dval, const float *b1, const float *w2, float b2, int act, float *dAB,
+                                  float *dpar) {
+    double *acc = calloc((size_t)N * 2 * hw, 8), *par = calloc((size_t)5 * hw + 1, 8);
+    double *z = malloc(sizeof(double) * hw), *hid = malloc(sizeof(double) * hw);
+    for (int64_t i = 0; i < N; i++) for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
+        int64_t j = col[e];
+        const float *A = AB + i * 2 * hw, *B = AB + j * 2 * hw + hw;
+        double s = 0.0;
+        for (int o = 0; o < hw; o++) {
+            double zz = (double)A[o] + (double)B[o] + b1[o];
+            z[o] = zz; hid[o] = (act == 1) ? (zz > 0.0 ? zz : 0.01 * zz) : zz;
+            s += hid[o] * w2[o];
+        }
+        s += b2;
+        double pp = 1.0 / (1.0 + exp(-s));
+        double ds = (double)dval[e] * pp * (1.0 - pp);
+        for (int o = 0; o < hw; o++) {
+            double dh = ds * w2[o];
+            double dz = (act == 1) ? (z[o] > 0.0 ? dh : 0.01 * dh) : dh;
+            acc[i * 2 * hw + o] += dz; acc[j * 2 * hw + hw + o] += dz;
+            par[3 * hw + o] += dz; par[4 * hw + o] += ds * hid[o];
+        }
+        par[5 * hw] += ds;
+    }
+    for (int64_t q = 0; q < N * 2 * hw; q++) dAB[q] = (float)acc[q];
+    for (int q = 0; q < 5 * hw + 1; q++) dpar[q] = (float)par[q];
+    free(acc); free(par); free(z); free(hid);
+}

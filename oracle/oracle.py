@@ -325,3 +325,73 @@ def knet_deg_param_grads(S0, S1, Wd, bd, Wmu, bmu, Wp):
     f = lambda a: np.asarray(a, np.float32)  # noqa: E731
     return (f(gamma * S1), f(gamma * S0), f(np.outer(Wp, Wd * S1 + bd * S0)), f(Wp * S0), f(alpha * S1 + beta * S0),
             f([S0]))
+
+
+# ---- CSR adjacency + the `DGG` class "for ICLR" (dgm.py:1730-1815; GCN_DGG_00 model.py:1314-1433) ---------------
+def _rp(rowptr):
+    return np.ascontiguousarray(rowptr, dtype=np.int64)
+
+
+def csr_row_sum(vals, rowptr):
+    vals, rowptr = f32(vals), _rp(rowptr)
+    rs = np.empty(rowptr.shape[0] - 1, np.float32)
+    lib().ora_csr_row_sum(_p(vals), _p(rowptr), C.c_int64(rs.shape[0]), _p(rs))
+    return rs
+
+
+def csr_normalize(rowptr, col, w, rs):
+    rowptr, col, w, rs = _rp(rowptr), i32(col), f32(w), f32(rs)
+    ahat = np.empty_like(w)
+    lib().ora_csr_normalize(_p(rowptr), _p(col), _p(w), _p(rs), C.c_int64(rs.shape[0]), _p(ahat))
+    return ahat
+
+
+def csr_spmm(rowptr, col, a, X):
+    rowptr, col, a, X = _rp(rowptr), i32(col), f32(a), f32(X)
+    N, F = X.shape
+    Y = np.empty((rowptr.shape[0] - 1, F), np.float32)
+    lib().ora_csr_spmm(_p(rowptr), _p(col), _p(a), _p(X), C.c_int64(Y.shape[0]), C.c_int(F), _p(Y))
+    return Y
+
+
+def csr_spmm_bwd(rowptr, col, a, X, dY, need_dx=True):
+    rowptr, col, a, X, dY = _rp(rowptr), i32(col), f32(a), f32(X), f32(dY)
+    dA = np.empty_like(a)
+    dX = np.empty_like(X) if need_dx else None
+    lib().ora_csr_spmm_bwd(_p(rowptr), _p(col), _p(a), _p(X), _p(dY), C.c_int64(X.shape[0]), C.c_int(X.shape[1]), _p(dA), _p(dX))
+    return dA, dX
+
+
+def csr_norm_bwd(rowptr, col, w, rs, dA):
+    rowptr, col, w, rs, dA = _rp(rowptr), i32(col), f32(w), f32(rs), f32(dA)
+    dw = np.empty_like(w)
+    lib().ora_csr_norm_bwd(_p(rowptr), _p(col), _p(w), _p(rs), _p(dA), C.c_int64(rs.shape[0]), _p(dw))
+    return dw
+
+
+def csr_rank_ramp(p, rowptr, col, w, b):
+    """-> out [E], S [N], k [N], pos [E]"""
+    p, rowptr, col = f32(p), _rp(rowptr), i32(col)
+    N = rowptr.shape[0] - 1
+    out, S, k, pos = np.empty_like(p), np.empty(N, np.float32), np.empty(N, np.float32), np.empty(p.shape[0], np.int32)
+    lib().ora_csr_rank_ramp(_p(p), _p(rowptr), _p(col), C.c_int64(N), C.c_float(float(w)), C.c_float(float(b)), _p(out), _p(S),
+                            _p(k), _p(pos))
+    return out, S, k, pos
+
+
+def csr_rank_ramp_bwd(p, rowptr, w, b, S, k, pos, g):
+    """-> dp [E], dkz [N]"""
+    p, rowptr, S, k, pos, g = f32(p), _rp(rowptr), f32(S), f32(k), i32(pos), f32(g)
+    dp, dkz = np.empty_like(p), np.empty_like(S)
+    lib().ora_csr_rank_ramp_bwd(_p(p), _p(rowptr), C.c_int64(S.shape[0]), C.c_float(float(w)), C.c_float(float(b)), _p(S), _p(k),
+                                _p(pos), _p(g), _p(dp), _p(dkz))
+    return dp, dkz
+
+
+def edge_mlp_bwd_csr(AB, rowptr, col, dval, b1, w2, b2, act=1):
+    AB, rowptr, col, dval = f32(AB), _rp(rowptr), i32(col), f32(dval)
+    hw = AB.shape[1] // 2
+    dAB, dpar = np.empty_like(AB), np.empty(5 * hw + 1, np.float32)
+    lib().ora_edge_mlp_bwd_csr(_p(AB), C.c_int64(AB.shape[0]), C.c_int(hw), _p(rowptr), _p(col), _p(dval), _p(f32(b1)), _p(f32(w2)),
+                               C.c_float(float(b2)), C.c_int(act), _p(dAB), _p(dpar))
+    return dAB, dpar

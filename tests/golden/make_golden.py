@@ -166,6 +166,58 @@ def edgemlp_cases():
                 None if nz == "none" else G, cot, 1.0, True)
 
 
+def dggclass_cases():
+    """`DGG` "for ICLR" (dgm.py:1730-1815) and its wrapper GCN_DGG_00 (model.py:1314-1433); hub rows exceed 64 entries"""
+    N, d, h, C = 160, 20, 16, 5
+    gen = torch.Generator().manual_seed(27)
+    A = random_graph(N, 12, gen).to_dense()
+    A[:3, :] = (torch.rand(3, N, generator=gen) < 0.6).float()      # three hubs with ~100 neighbours (> ELL width)
+    A = ((A + A.T) > 0).float()
+    A.fill_diagonal_(1.0)
+    in_adj = A.to_sparse().coalesce()
+    x = torch.randn(N, d, generator=gen)
+    a = base_args()
+    torch.manual_seed(99)
+    m = dgm.DGG(in_dim=d, latent_dim=h, args=a)
+    m.eval()
+    xr = x.clone().requires_grad_(True)
+    out, xe = m(xr, in_adj)
+    outd = out.to_dense()
+    cot = torch.from_numpy(grid_normal(71, (N, N)))
+    cote = torch.from_numpy(grid_normal(72, (N, h)))
+    ((outd * cot).sum() + (xe * cote).sum()).backward()
+    ii = in_adj.indices().numpy().astype(np.int32)
+    fx = {"x": x.numpy(), "rows": ii[0], "cols": ii[1], "adj_vals": in_adj.values().numpy(), "out": outd.detach().numpy(),
+          "xe": xe.detach().numpy(), "cot": cot.numpy(), "cote": cote.numpy(), "g.x": xr.grad.numpy()}
+    for k_, v in m.state_dict().items():
+        fx["p." + k_] = v.detach().numpy()
+    for k_, p_ in m.named_parameters():
+        fx["g." + k_] = p_.grad.numpy()
+    meta = dict(name="dggclass", N=N, d=d, h=h, torch=torch.__version__, args=vars(a), reference="dgm.py:1758-1815 DGG.forward")
+    fx["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "dggclass.npz"), **fx)
+    print("dggclass ok: max row nnz", int((outd != 0).sum(-1).max()))
+    # wrapper: in_adj WITHOUT self loops (the wrapper adds them, model.py:1380-1383)
+    A2 = (A - torch.eye(N)).to_sparse().coalesce()
+    torch.manual_seed(4321)
+    mm = refmodel.GCN_DGG_00(nfeat=d, nlayers=2, nhidden=h, nclass=C, args=a)
+    mm.eval()
+    logp, unnorm, x_dgg = mm(x, A2)
+    cot2 = torch.from_numpy(grid_normal(73, (N, C)))
+    (logp * cot2).sum().backward()
+    fx = {"x": x.numpy(), "rows": A2.indices()[0].numpy().astype(np.int32), "cols": A2.indices()[1].numpy().astype(np.int32),
+          "adj_vals": A2.values().numpy(), "cot": cot2.numpy(), "out": logp.detach().numpy(),
+          "unnorm": unnorm.detach().to_dense().numpy(), "x_dgg": x_dgg.detach().numpy()}
+    for k_, v in mm.state_dict().items():
+        fx["p." + k_] = v.detach().numpy()
+    for k_, p_ in mm.named_parameters():
+        fx["g." + k_] = p_.grad.numpy() if p_.grad is not None else np.zeros_like(p_.detach().numpy())
+    meta = dict(name="model_gcn_dgg_00", N=N, d=d, h=h, C=C, torch=torch.__version__, args=vars(a))
+    fx["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "model_gcn_dgg_00.npz"), **fx)
+    print("model_gcn_dgg_00 ok", tuple(logp.shape))
+
+
 def allpairs_cases():
     N, d, h = 256, 32, 16
     gen = torch.Generator().manual_seed(8)
@@ -246,6 +298,8 @@ if __name__ == "__main__":
         conv_cases()
     if "edgemlp" in which:
         edgemlp_cases()
+    if "dggclass" in which:
+        dggclass_cases()
 
 
 def model_cases():

@@ -525,3 +525,112 @@ def test_edge_mlp_kernels(dev, hw, use_deg, ex_mode, act, noise):
         ref = rdpar[b_ * hw:(b_ + 1) * hw]
         np.testing.assert_allclose(Nn(dpar)[b_ * hw:(b_ + 1) * hw], ref, rtol=5e-4, atol=5e-4 * max(np.abs(ref).max(), 1e-30))
     np.testing.assert_allclose(Nn(dpar)[5 * hw], rdpar[5 * hw], rtol=5e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CSR-valued adjacency, the `DGG` class "for ICLR" and GCN_DGG_00 (dgm.py:1730-1815, model.py:1314-1433)
+# ---------------------------------------------------------------------------------------------------------------
+def test_csr_kernels(dev):
+    from dgg_amd import ops
+    rng = np.random.default_rng(31)
+    N, F = 700, 96
+    dens = rng.random((N, N)) < 0.03
+    dens[:4] = rng.random((4, N)) < 0.5                       # rows far wider than 64 entries
+    rows, cols = np.nonzero(dens)
+    rows, cols = rows.astype(np.int32), cols.astype(np.int32)
+    rowptr, col = csr_from_coo(rows, cols, N)
+    E = col.shape[0]
+    p = (0.05 + 0.9 * rng.random(E)).astype(np.float32)
+    p[rowptr[1]:rowptr[1] + 40] = p[rowptr[1]]                # exact ties: lower column first
+    w, b = np.array([0.07], np.float32), np.array([-0.3], np.float32)
+    rp, cl = T(rowptr, dev), T(col, dev)
+    out, S, k, pos = ops.csr_rank_ramp_fwd(T(p, dev), rp, cl, T(w, dev), T(b, dev))
+    rout, rS, rk, rpos = O.csr_rank_ramp(p, rowptr, col, w[0], b[0])
+    assert np.array_equal(Nn(pos), rpos) and np.array_equal(Nn(S), rS) and np.array_equal(Nn(k), rk) and np.array_equal(Nn(out), rout)
+    g = rng.standard_normal(E).astype(np.float32)
+    dp, dkz = ops.csr_rank_ramp_bwd(T(p, dev), rp, T(w, dev), T(b, dev), S, k, pos, T(g, dev))
+    rdp, rdkz = O.csr_rank_ramp_bwd(p, rowptr, w[0], b[0], rS, rk, rpos, g)
+    np.testing.assert_allclose(Nn(dp), rdp, rtol=2e-4, atol=2e-4 * np.abs(rdp).max())
+    np.testing.assert_allclose(Nn(dkz), rdkz, rtol=2e-4, atol=2e-4 * np.abs(rdkz).max())
+    # normalisation + SpMM
+    rs = ops.csr_row_sum(out, rp)
+    assert np.array_equal(Nn(rs), O.csr_row_sum(rout, rowptr))
+    ahat = ops.csr_normalize_fwd(rp, cl, out, rs)
+    rah = O.csr_normalize(rowptr, col, rout, Nn(rs))
+    assert np.array_equal(Nn(ahat), rah)
+    X = rng.standard_normal((N, F)).astype(np.float32)
+    Y = ops.csr_spmm_fwd(rp, cl, ahat, T(X, dev))
+    assert np.array_equal(Nn(Y), O.csr_spmm(rowptr, col, rah, X))
+    dY = rng.standard_normal((N, F)).astype(np.float32)
+    dA, dX = ops.csr_spmm_bwd(rp, cl, ahat, T(X, dev), T(dY, dev))
+    rdA, rdX = O.csr_spmm_bwd(rowptr, col, rah, X, dY)
+    np.testing.assert_allclose(Nn(dA), rdA, rtol=1e-4, atol=1e-4 * np.abs(rdA).max())
+    np.testing.assert_allclose(Nn(dX), rdX, rtol=1e-4, atol=1e-4 * np.abs(rdX).max())
+    dw = ops.csr_norm_bwd(rp, cl, out, rs, T(rdA, dev))
+    rdw = O.csr_norm_bwd(rowptr, col, rout, Nn(rs), rdA)
+    np.testing.assert_allclose(Nn(dw), rdw, rtol=2e-4, atol=2e-4 * np.abs(rdw).max())
+    # scorer backward on the CSR pattern
+    hw = 16
+    AB = (rng.standard_normal((N, 2 * hw)) * 0.5).astype(np.float32)
+    b1, ones, zero = (rng.standard_normal(hw) * 0.1).astype(np.float32), np.ones(hw, np.float32), np.zeros(1, np.float32)
+    dAB, dpar, _ = ops.edge_mlp_bwd(T(AB, dev), cl, None, T(p, dev), T(g, dev), None, None, None, None, None, T(b1, dev), T(ones, dev),
+                                    T(zero, dev), 1, False, rowptr=rp)
+    rdAB, rdpar = O.edge_mlp_bwd_csr(AB, rowptr, col, g, b1, ones, 0.0, 1)
+    np.testing.assert_allclose(Nn(dAB), rdAB, rtol=2e-4, atol=2e-4 * np.abs(rdAB).max())
+    np.testing.assert_allclose(Nn(dpar)[3 * hw:], rdpar[3 * hw:], rtol=5e-4, atol=5e-4 * np.abs(rdpar).max())
+
+
+def test_dgg_class_matches_reference_golden(dev):
+    """dgg_amd.DGG (dgm.py:1730-1815): reference state_dict loads strict; output == oracle bit-for-bit and within 1e-5 of
+    the reference; gradients of x and every parameter within 2e-4"""
+    import dgg_amd
+    from argparse import Namespace
+    from test_oracle_golden import oracle_dggclass_forward
+    fx = load_fixture("dggclass")
+    meta = fx["meta"]
+    N = meta["N"]
+    m = dgg_amd.DGG(in_dim=meta["d"], latent_dim=meta["h"], args=Namespace(**meta["args"]))
+    m.load_state_dict({k_[2:]: torch.from_numpy(v) for k_, v in fx.items() if k_.startswith("p.")}, strict=True)
+    m = m.to(dev)
+    ind = torch.from_numpy(np.stack([fx["rows"], fx["cols"]]).astype(np.int64))
+    A = torch.sparse_coo_tensor(ind, torch.from_numpy(fx["adj_vals"]), (N, N)).coalesce().to(dev)
+    x = T(fx["x"], dev).requires_grad_(True)
+    adj, xe = m(x, A)
+    r = oracle_dggclass_forward(fx["x"], fx["rows"], fx["cols"], N, lambda s_: fx["p." + s_])
+    assert np.array_equal(Nn(adj.values()), r["out"]) and np.array_equal(Nn(xe), r["xe"])
+    np.testing.assert_allclose(Nn(adj.to_dense()), fx["out"], rtol=0, atol=1e-5)
+    assert int(np.diff(Nn(adj.rowptr)).max()) > 64
+    ((adj.to_dense() * T(fx["cot"], dev)).sum() + (xe * T(fx["cote"], dev)).sum()).backward()
+    grads = {n_: p_.grad for n_, p_ in m.named_parameters()}
+    grads["x"] = x.grad
+    for key, got in grads.items():
+        ref = fx["g." + key]
+        err = np.abs(Nn(got).reshape(ref.shape) - ref).max() / max(np.abs(ref).max(), 1e-6)
+        assert err <= 2e-4, f"grad {key}: {err:.3e}"
+
+
+def test_gcn_dgg_00_matches_reference_golden(dev):
+    import dgg_amd
+    from argparse import Namespace
+    fx = load_fixture("model_gcn_dgg_00")
+    meta = fx["meta"]
+    N, d, h, C = meta["N"], meta["d"], meta["h"], meta["C"]
+    m = dgg_amd.GCN_DGG_00(nfeat=d, nlayers=2, nhidden=h, nclass=C, args=Namespace(**meta["args"]))
+    m.load_state_dict({k_[2:]: torch.from_numpy(v) for k_, v in fx.items() if k_.startswith("p.")}, strict=True)
+    m = m.to(dev).eval()
+    ind = torch.from_numpy(np.stack([fx["rows"], fx["cols"]]).astype(np.int64))
+    A = torch.sparse_coo_tensor(ind, torch.from_numpy(fx["adj_vals"]), (N, N)).coalesce().to(dev)
+    logp, unnorm, x_dgg = m(T(fx["x"], dev), A)
+    np.testing.assert_allclose(Nn(x_dgg), fx["x_dgg"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(Nn(unnorm.to_dense()), fx["unnorm"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(Nn(logp), fx["out"], rtol=1e-5, atol=2e-5)
+    (logp * T(fx["cot"], dev)).sum().backward()
+    checked = 0
+    for k_, p_ in m.named_parameters():
+        ref = fx["g." + k_]
+        if np.abs(ref).max() == 0:
+            continue
+        err = np.abs(Nn(p_.grad).reshape(ref.shape) - ref).max() / np.abs(ref).max()
+        assert err <= 2e-4, f"grad {k_}: {err:.3e}"
+        checked += 1
+    assert checked >= 8
