@@ -34,25 +34,23 @@ class LearnableKEncoder(nn.Module):
         self.args = args
 
 
-class _KnetXFn(torch.autograd.Function):
-    """k_estimate_net mode "x" (reference dgm.py:1562-1586): x, prior degree -> learned k [N]."""
+class _KnetFeatFn(torch.autograd.Function):
+    """k_estimate_net after the node encoder (reference dgm.py:1566-1586, shared by modes "x" and "gcn-x-deg"):
+    per-node features xk [N,h], prior degree -> learned k [N]."""
 
     @staticmethod
-    def forward(ctx, x, deg, Wk, bk, W1, b1, Wmu, bmu, Wp, bp):
-        xk = ops.linear_fwd(x, Wk, bk, ops.ACT_LEAKY)
+    def forward(ctx, xk, deg, W1, b1, Wmu, bmu, Wp, bp):
         mu_sd = ops.degree_stats(deg)
         k, z, u, feat = ops.knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp.reshape(-1), bp)
-        ctx.save_for_backward(x, Wk, W1, Wmu, bmu, Wp, xk, mu_sd, z, u, feat)
+        ctx.h = xk.shape[1]
+        ctx.save_for_backward(W1, Wmu, bmu, Wp, mu_sd, z, u, feat)
         return k
 
     @staticmethod
     def backward(ctx, dk):
-        x, Wk, W1, Wmu, bmu, Wp, xk, mu_sd, z, u, feat = ctx.saved_tensors
-        need_dx = ctx.needs_input_grad[0]
-        dxk, dW1, db1, dWmu, dbmu, dWp, dbp = ops.knet_x_bwd(xk.shape[1], mu_sd, W1, Wmu, bmu, Wp.reshape(-1), z, u, feat,
-                                                            dk.contiguous())
-        dx, dWk, dbk = ops.linear_bwd(x, Wk, xk, dxk, ops.ACT_LEAKY, need_dx=need_dx)
-        return dx, None, dWk, dbk, dW1, db1, dWmu, dbmu, dWp.reshape(Wp.shape), dbp
+        W1, Wmu, bmu, Wp, mu_sd, z, u, feat = ctx.saved_tensors
+        dxk, dW1, db1, dWmu, dbmu, dWp, dbp = ops.knet_x_bwd(ctx.h, mu_sd, W1, Wmu, bmu, Wp.reshape(-1), z, u, feat, dk.contiguous())
+        return dxk, None, dW1, db1, dWmu, dbmu, dWp.reshape(Wp.shape), dbp
 
 
 class _KnetDegFn(torch.autograd.Function):
@@ -252,11 +250,10 @@ class DGG_LearnableK_debug(nn.Module):
         assert x.ndim == 2 and len(in_adj.shape) == 2
         if self.edge_prob_net_mode != "u-v-dist" and self.edge_prob_net_mode not in _EDGE_MLP_MODES:
             raise Exception("mode not found")
-        if self.k_net_mode not in ("x", "input_deg", "learn_normalized_degree"):
-            # "pass" returns k = None, which the reference's own select_top_k cannot consume (dgm.py:1485, 1412);
-            # "gcn-x-deg" aggregates over the dense in_adj (dgm.py:1528-1560)
-            raise NotImplementedError(f"k-net mode {self.k_net_mode!r}: the HIP path implements 'x', 'input_deg' and "
-                                      "'learn_normalized_degree'")
+        if self.k_net_mode not in ("x", "gcn-x-deg", "input_deg", "learn_normalized_degree"):
+            # "pass" returns k = None, which the reference's own select_top_k cannot consume (dgm.py:1485, 1412)
+            raise NotImplementedError(f"k-net mode {self.k_net_mode!r}: the HIP path implements 'x', 'gcn-x-deg', 'input_deg' "
+                                      "and 'learn_normalized_degree'")
         if self.k_select_mode not in ("k_times_edge_prob", "k_only"):
             raise NotImplementedError(f"k-select mode {self.k_select_mode!r} is dead code in the reference")
         if self.hard:
@@ -284,9 +281,16 @@ class DGG_LearnableK_debug(nn.Module):
                    mode=ops.MODE_K_TIMES_EDGE_PROB if self.k_select_mode == "k_times_edge_prob" else ops.MODE_K_ONLY)
         We, be = self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias
         kn = self.k_net
-        if self.k_net_mode == "x":
-            k = _KnetXFn.apply(x, deg, self.node_encode_for_k[0].weight, self.node_encode_for_k[0].bias, self.k_embed[0].weight,
-                               self.k_embed[0].bias, kn.k_mu.weight, kn.k_mu.bias, kn.k_project.weight, kn.k_project.bias)
+        if self.k_net_mode in ("x", "gcn-x-deg"):
+            xk = ops.LinearFn.apply(x, self.node_encode_for_k[0].weight, self.node_encode_for_k[0].bias, ops.ACT_LEAKY, 0)
+            if self.k_net_mode == "gcn-x-deg":       # relu(normalize_adj(in_adj) @ xk @ k_W)   (dgm.py:1528-1540)
+                if cand is None:
+                    raise NotImplementedError("k-net mode 'gcn-x-deg' aggregates over the stored entries of in_adj")
+                pat = csr_pattern(in_adj)
+                nadj = CsrAdjacency(pat[0], pat[1], pat[2], in_adj.coalesce().values().float(), x.shape[0]).normalize()
+                xk = ops.LinearFn.apply(nadj.matmul(xk), self.k_W, None, ops.ACT_RELU, 1)
+            k = _KnetFeatFn.apply(xk, deg, self.k_embed[0].weight, self.k_embed[0].bias, kn.k_mu.weight, kn.k_mu.bias,
+                                  kn.k_project.weight, kn.k_project.bias)
         else:
             consts = (float(self.deg_mean), float(self.deg_std)) if self.k_net_mode == "input_deg" else None
             k = _KnetDegFn.apply(deg, self.input_degree_project.weight, self.input_degree_project.bias, kn.k_mu.weight,

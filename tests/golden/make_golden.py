@@ -146,6 +146,8 @@ def edgelist_cases():
     run_dgg("edgelist_inputdeg_none", N, d, h, a, in_adj, x, None, cot, 1.0, True)
     a = base_args(dgg_mode_k_net="learn_normalized_degree", perturb_edge_prob=True)
     run_dgg("edgelist_lnd_asym", N, d, h, a, in_adj, x, Gasym, cot, 1.0, True)
+    a = base_args(dgg_mode_k_net="gcn-x-deg", perturb_edge_prob=False)
+    run_dgg("edgelist_gcnxdeg_none", N, d, h, a, in_adj, x, None, cot, 1.0, True)
 
 
 def edgemlp_cases():
