@@ -343,7 +343,8 @@ def main():
     t_pair = timed(lambda: ops.allpairs_topk(sv["xp"], 64, noise_mode=noise_mode, seed=(1234, 0), rows=(r0, r1), algo=a.algo,
                                              k_limit=sv["k"]))
     t_edge = timed(lambda: ops.edge_bwd(sv["xp"], sv["idx"], sv["val"], sv["dval"], r0, ops.T_DIST, True, sv["part"]))
-    t_sddmm = timed(lambda: ops.spmm_bwd(sv["idx"], sv["ahat"], sv["X"], sv["Y"], False, True))
+    t_sddmm = timed(lambda: ops.sddmm_norm(sv["idx"], sv["ahat"], sv["w"], sv["rs"], sv["X"], sv["Y"], r0, sv["part"], True)
+                    or ops.spmm_bwd(sv["idx"], sv["ahat"], sv["X"], sv["Y"], False, True))
     t_spmm = timed(lambda: ops.spmm_fwd(sv["idx"], sv["ahat"], sv["X"]))
     active = float((sv["dval"] != 0).sum().item())                # edges with a non-saturated ramp (~ k + 8.5 per row)
     traffic = load_traffic()
@@ -355,8 +356,9 @@ def main():
         # score backward (row pass + destination-ordered column pass): per active edge xp_j and xp_i gathered once each
         # (2*4h B) + record/coefficient (16 B); per row idx/score/dval (3*256 B), xp_i in, dxp_i out and updated
         "edge_bwd": dict(ms=t_edge * 1e3, bytes=active * (8 * h + 16) + rows_loc * (3 * 256 + 12 * h)),
-        # SDDMM dA_ir = <dY_i, X_j>: per active edge one gathered row of X (4d B); per row dY_i, idx, ahat, dA
-        "spmm_bwd": dict(ms=t_sddmm * 1e3, bytes=active * 4 * d + rows_loc * (4 * d + 3 * 256)),
+        # SDDMM dA_ir = <dY_i, X_j> (+ fused row side of the normalisation backward): per active edge one gathered row
+        # of X (4d B) + its coefficient (4 B); per row dY_i, idx, ahat, w, slot map in, dA out
+        "spmm_bwd": dict(ms=t_sddmm * 1e3, bytes=active * (4 * d + 4) + rows_loc * (4 * d + 6 * 256)),
         # SpMM Y_i = sum_r A_ir X_j: per active edge one gathered row of X; per row idx, ahat and the output row
         "spmm_fwd": dict(ms=t_spmm * 1e3, bytes=active * 4 * d + rows_loc * (4 * d + 2 * 256)),
     }

@@ -144,10 +144,17 @@ __global__ __launch_bounds__(WPB * 64) void spmm_bwd_kernel(const int32_t *__res
 // SDDMM only (no dX), F = 128*NV4: TWO neighbours per wave-instruction.  Each 32-lane half owns one neighbour and each
 // lane 4*NV4 features (16-byte loads: a 128-feature row is one 512-byte coalesced segment per half), so the per-edge
 // reduction is a 5-step DPP butterfly inside the half and the instruction count per edge halves.
-template <int NV4>
+// NORM: also the row-side half of the normalisation backward, which needs nothing but dA, ahat and w of the row:
+//   da_i = sum_r dA_ir w_ir a_j = (sum_r dA_ir ahat_ir) / a_i   (plain store),
+//   coef_ir = dA_ir w_ir a_i  written in the destination-ordered record order of the partition (dgg_scatter.hip),
+// which removes a separate pass over idx / w / dA and its 4-byte gathers of rs[j].
+template <int NV4, bool NORM>
 __global__ __launch_bounds__(WPB * 64) void sddmm_pair_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
                                                              const float *__restrict__ X, const float *__restrict__ dY,
-                                                             int64_t N, int K, int skip_zero, float *__restrict__ dA) {
+                                                             int64_t N, int K, int skip_zero, float *__restrict__ dA,
+                                                             const float *__restrict__ w, const float *__restrict__ rs,
+                                                             int64_t row0, const int *__restrict__ slotmap,
+                                                             float *__restrict__ coef, float *__restrict__ da) {
     constexpr int F = 128 * NV4;
     const int lane = threadIdx.x & 63, sub = lane & 31, hh = lane >> 5;
     const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -186,6 +193,17 @@ __global__ __launch_bounds__(WPB * 64) void sddmm_pair_kernel(const int32_t *__r
         if (lane == r + 1) mine = t1;
     }
     if (lane < K) dA[i * K + lane] = mine;
+    if (NORM) {
+        const float ri = rs[row0 + i];
+        const float ai = 1.0f / sqrtf(ri);
+        float rowpart = mine * al;                               // lanes >= K hold 0
+        rowpart = wave_sum_dpp(rowpart, lane);
+        if (lane == 0) da[row0 + i] = rowpart * sqrtf(ri);
+        if (lane < K) {
+            const int sl = slotmap[i * K + lane];
+            if (sl >= 0) coef[sl] = mine * w[i * K + lane] * ai;
+        }
+    }
 }
 
 // normalisation backward, phase 1: da[i] += sum_r dA_ir w_ir a_j ;  da[j] += dA_ir w_ir a_i   (da zeroed by caller)
@@ -340,12 +358,36 @@ int dgg_ell_spmm_bwd(const int32_t *idx, const float *ahat, const float *X, cons
     hipStream_t st = (hipStream_t)stream;
     const bool al16 = (reinterpret_cast<uintptr_t>(X) % 16 == 0) && (reinterpret_cast<uintptr_t>(dY) % 16 == 0);
     if (!dX && al16 && F == 128)
-        hipLaunchKernelGGL(sddmm_pair_kernel<1>, dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, N, K, skip_zero, dA);
+        hipLaunchKernelGGL((sddmm_pair_kernel<1, false>), dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, N, K, skip_zero, dA,
+                           nullptr, nullptr, 0, nullptr, nullptr, nullptr);
     else if (!dX && al16 && F == 256)
-        hipLaunchKernelGGL(sddmm_pair_kernel<2>, dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, N, K, skip_zero, dA);
+        hipLaunchKernelGGL((sddmm_pair_kernel<2, false>), dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, N, K, skip_zero, dA,
+                           nullptr, nullptr, 0, nullptr, nullptr, nullptr);
     else
         hipLaunchKernelGGL(spmm_bwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, N, K, F, skip_zero, dA, dX);
     return dgg_check_launch("ell_spmm_bwd");
+}
+
+// SDDMM (dA = <dY_i, X_j>, no dX) fused with the normalisation backward's phase 1 through the partition of the forward:
+// dA [rows,K] and da [ncols] (zeroed by the caller) out; coef_ws: rows*K floats.  DGG_ERR_UNSUPPORTED when the fused
+// kernel does not cover the shape (F not in {128, 256} or unaligned rows): use dgg_ell_spmm_bwd + dgg_norm_bwd_da_part.
+int dgg_ell_sddmm_norm_part(const int32_t *idx, const float *ahat, const float *w, const float *rs, const float *X,
+                            const float *dY, int64_t rows, int K, int F, int64_t row0, int skip_zero, const void *part_ws,
+                            int64_t ncols, float *coef_ws, float *dA, float *da, void *stream) {
+    if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    const bool al16 = (reinterpret_cast<uintptr_t>(X) % 16 == 0) && (reinterpret_cast<uintptr_t>(dY) % 16 == 0);
+    const int *slotmap = dgg_part_slotmap(part_ws, rows, K, ncols);
+    if (!al16 || (F != 128 && F != 256) || !slotmap)
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "sddmm_norm_part: feature width must be 128 or 256 (16-byte aligned rows)");
+    if (rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (F == 128)
+        hipLaunchKernelGGL((sddmm_pair_kernel<1, true>), dim3(rows_grid(rows)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, rows, K,
+                           skip_zero, dA, w, rs, row0, slotmap, coef_ws, da);
+    else
+        hipLaunchKernelGGL((sddmm_pair_kernel<2, true>), dim3(rows_grid(rows)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, rows, K,
+                           skip_zero, dA, w, rs, row0, slotmap, coef_ws, da);
+    return dgg_norm_da_cols_impl(part_ws, rows, K, ncols, coef_ws, da, st);
 }
 
 int dgg_norm_bwd_da(const int32_t *idx, const float *w, const float *rs, const float *dA, int64_t N, int K, int64_t row0,

@@ -345,6 +345,19 @@ inline int64_t nbuckets(int64_t ncols) { return (ncols + BS - 1) / BS; }
 
 }  // namespace
 
+const int *dgg_part_slotmap(const void *part_ws, int64_t rows, int K, int64_t ncols) {
+    if (!part_ws || dgg_part_ws_bytes(rows, K, ncols) == 0) return nullptr;
+    return part_layout(const_cast<void *>(part_ws), nbuckets(ncols), rows * K).slot;
+}
+
+int dgg_norm_da_cols_impl(const void *part_ws, int64_t rows, int K, int64_t ncols, const float *coef_ws, float *da,
+                          hipStream_t st) {
+    const int64_t nb = nbuckets(ncols);
+    PartHdr p = part_layout(const_cast<void *>(part_ws), nb, rows * K);
+    hipLaunchKernelGGL(norm_da_cols, dim3((unsigned)nb), dim3(256), 0, st, ncols, p.bstart, p.recs, coef_ws, da);
+    return dgg_check_launch("norm_da_cols");
+}
+
 extern "C" {
 
 // bytes of workspace for the partition of an ELL block of `rows` x K entries over `ncols` destination nodes;

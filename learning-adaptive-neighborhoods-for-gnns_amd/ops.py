@@ -287,6 +287,23 @@ def spmm_bwd(idx, ahat, X, dY, need_dx=True, skip_zero=False):
     return dA, dX
 
 
+def sddmm_norm(idx, ahat, w, rs, X, dY, row0, part, skip_zero=True):
+    """dA = <dY_i, X_j> and da (phase 1 of the normalisation backward) in one pass over the rows; None when the fused
+    kernel does not cover the shape (then: spmm_bwd + norm_bwd_da)."""
+    N, K = idx.shape
+    X, dY = _chk(X), _chk(dY)
+    F = X.shape[1]
+    if part is None or F not in (128, 256) or X.data_ptr() % 16 or dY.data_ptr() % 16:
+        return None
+    dA = torch.empty((N, K), device=idx.device, dtype=torch.float32)
+    coef = torch.empty((N, K), device=idx.device, dtype=torch.float32)
+    da = torch.zeros_like(rs)
+    _lib.check(_lib.lib().dgg_ell_sddmm_norm_part(_ptr(idx), _ptr(_chk(ahat)), _ptr(_chk(w)), _ptr(_chk(rs)), _ptr(X), _ptr(dY), N, K, F,
+                                                  row0, int(skip_zero), _ptr(part), rs.shape[0], _ptr(coef), _ptr(dA), _ptr(da),
+                                                  _stream()), "ell_sddmm_norm_part")
+    return dA, da
+
+
 def part_build(idx, w, ncols):
     """Bucket-partition of the active ELL entries by destination node (dgg_scatter.hip), built once per forward and
     reused by the column-side terms of the backward.  Returns None when the partitioned path does not apply."""

@@ -100,10 +100,16 @@ class ShardedDGGConv:
         kern, s = self.kern, self.saved
         g = {}
         dY, g["Wc"], _ = kern.linear_bwd(s["Y"], P["Wc"], s["Z"], dZ, 2, 1, True, False)
-        dA, dX = kern.spmm_bwd(s["idx"], s["ahat"], s["X"], dY, self.x_grad, True)
         part = s.get("part")
-        da = kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0, part) if part is not None else \
-            kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0)
+        fused = None
+        if not self.x_grad and part is not None and hasattr(kern, "sddmm_norm"):
+            fused = kern.sddmm_norm(s["idx"], s["ahat"], s["w"], s["rs"], s["X"], dY, self.r0, part, True)
+        if fused is not None:                            # SDDMM + row side of the normalisation backward in one pass
+            (dA, da), dX = fused, None
+        else:
+            dA, dX = kern.spmm_bwd(s["idx"], s["ahat"], s["X"], dY, self.x_grad, True)
+            da = kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0, part) if part is not None else \
+                kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0)
         if self.world > 1:
             dist.all_reduce(da, group=self.group)
         dval, dk = kern.softk_bwd(s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.mode, True)

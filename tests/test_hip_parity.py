@@ -634,3 +634,27 @@ def test_gcn_dgg_00_matches_reference_golden(dev):
         assert err <= 2e-4, f"grad {k_}: {err:.3e}"
         checked += 1
     assert checked >= 8
+
+
+@pytest.mark.parametrize("F", [128, 256])
+def test_sddmm_fused_with_normalisation_backward(dev, F):
+    """dgg_ell_sddmm_norm_part == dgg_ell_spmm_bwd + dgg_norm_bwd_da (oracle: spmm_bwd + the da of softk_norm_bwd)"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(41)
+    N, h = 600, 32
+    xp = rng.standard_normal((N, h)).astype(np.float32)
+    k = (3 + 30 * rng.random(N)).astype(np.float32)
+    idx, val = O.allpairs_topk(xp, K=K, noise_mode=O.NOISE_HASH, seed=(8, 8))
+    w, rs = O.softk(idx, val, k)
+    ahat = O.normalize(idx, w, rs)
+    X = rng.standard_normal((N, F)).astype(np.float32)
+    dY = rng.standard_normal((N, F)).astype(np.float32)
+    part = ops.part_build(T(idx, dev), T(w, dev), N)
+    got = ops.sddmm_norm(T(idx, dev), T(ahat, dev), T(w, dev), T(rs, dev), T(X, dev), T(dY, dev), 0, part, True)
+    assert got is not None
+    dA, da = got
+    rdA, _ = O.spmm_bwd(idx, ahat, X, dY, need_dx=False)
+    rdA = np.where(ahat == 0, 0.0, rdA).astype(np.float32)
+    np.testing.assert_allclose(Nn(dA), rdA, rtol=1e-4, atol=1e-4 * np.abs(rdA).max())
+    da_ref = ops.norm_bwd_da(T(idx, dev), T(w, dev), T(rs, dev), T(rdA, dev))          # atomic path, itself oracle-checked
+    np.testing.assert_allclose(Nn(da), Nn(da_ref), rtol=3e-4, atol=3e-4 * np.abs(Nn(da_ref)).max())
