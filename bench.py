@@ -190,6 +190,67 @@ def bench_edgelist(a, dev):
     print(json.dumps(out))
 
 
+def bench_ppi(a, dev):
+    """BASELINE.json configs[4] (PPI shape: graphs of 591..3480 nodes, d=50, hidden 2048, 9 GCNII layers, 121 labels,
+    train_ppi.py:43-44): dgg_amd.GCNIIppi_DGG under autograd, one forward + backward per graph, fp32 (the bf16 variant
+    of the GCNII GEMMs is a "next" row).  The DGG runs at latent_dim = hidden = 2048 (model.py:907-910)."""
+    import dgg_amd
+    from argparse import Namespace
+    d, hid, C, L = 50, 2048, 121, 9
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(591, 3481, size=a.graphs)
+    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
+    torch.manual_seed(0)
+    m = dgg_amd.GCNIIppi_DGG(nfeat=d, nlayers=L, nhidden=hid, nclass=C, dropout=0.2, lamda=0.5, alpha=0.5, variant=True,
+                             args=args).to(dev)
+    with torch.no_grad():
+        for dg in m.dggs:
+            dg.k_net.k_project.weight.mul_(0.1)
+    m.train()
+    graphs = []
+    for n in sizes:
+        rows, cols = pubmed_graph(int(n), int(n) * 14, seed=int(n))
+        keep = rows != cols                                      # the wrapper adds the self loops (model.py:935-938)
+        A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows[keep], cols[keep]])), torch.ones(int(keep.sum())),
+                                    (int(n), int(n))).coalesce().to(dev)
+        graphs.append((torch.randn(int(n), d).to(dev), A, (torch.rand(int(n), C) < 0.3).float().to(dev)))
+    params = list(m.parameters())
+
+    def step():
+        nsel = 0.0
+        for x, A, y in graphs:
+            for p_ in params:
+                p_.grad = None
+            out = m(x, A)
+            torch.nn.functional.binary_cross_entropy(out, y).backward()
+            nsel += float(A._nnz() + x.shape[0])
+        return nsel
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cand = step()
+    torch.cuda.synchronize()
+    T = (time.perf_counter() - t0) / a.steps
+    gemm_flop = sum(3 * 2.0 * int(n) * (2 * hid) * hid * L for n in sizes)       # fwd + dX + dW of the variant GCNII layers
+    print(json.dumps({
+        "metric": "DGG adj-build+SpMM fwd/bwd selected-edges/s", "value": cand / T, "unit": "edges/s", "n_gpus": 1,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": T * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"PPI-shape multi-graph GCNIIppi_DGG: {len(sizes)} graphs of {int(sizes.min())}..{int(sizes.max())} nodes, "
+                               f"d={d}, hidden={hid}, {L} variant GCNII layers, {C} labels, DGG latent {hid} on edge-list candidates "
+                               "(value counts candidate edges), module API under autograd, fwd+bwd, fp32",
+                   "graphs": len(sizes), "nodes_total": int(sizes.sum()), "graphs_per_s": len(sizes) / T,
+                   "gcnii_gemm_tflops": gemm_flop / T / 1e12},
+        "roofline": {"bound": "mfma", "kernel": "linear_fwd_mfma/gemm (GCNII layers)", "achieved": gemm_flop / T / 1e12,
+                     "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_flop / T / 1e12 / FP32_PEAK_TFLOPS, "traffic": None,
+                     "note": "whole-step GEMM flops of the GCNII layers / step time (not a single kernel)"}}))
+
+
 def cpu_baseline_edgelist(N, d, h, rows, cols, x, vals, dgg, conv, threads):
     """The oracle's edge-list pipeline (forward + backward) on the whole Pubmed-shape problem, all host cores."""
     from oracle import oracle as O
@@ -230,8 +291,10 @@ def cpu_baseline_edgelist(N, d, h, rows, cols, x, vals, dgg, conv, threads):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["synthetic", "pubmed"], default="synthetic",
-                    help="synthetic = the BASELINE.json metric config (default); pubmed = configs[1], edge-list candidates")
+    ap.add_argument("--workload", choices=["synthetic", "pubmed", "ppi"], default="synthetic",
+                    help="synthetic = the BASELINE.json metric config (default); pubmed = configs[1], edge-list candidates; "
+                         "ppi = configs[4], multi-graph GCNIIppi_DGG (fp32)")
+    ap.add_argument("--graphs", type=int, default=4, help="--workload ppi: number of graphs per step")
     ap.add_argument("--edge-mode", default="u-v-dist", choices=["u-v-dist", "u-v-deg", "u-v-A_uv", "u-v-deg-dist", "edge_conv", "A_uv"],
                     help="--workload pubmed: edge scorer (dgm.py:1607-1725)")
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,6 +332,9 @@ def main():
     if a.workload == "pubmed":
         assert world == 1, "--workload pubmed is a single-GPU measurement"
         return bench_edgelist(a, dev)
+    if a.workload == "ppi":
+        assert world == 1, "--workload ppi is a single-GPU measurement (graphs are independent: replicas across GPUs)"
+        return bench_ppi(a, dev)
 
     # weak scaling (default): every GPU owns --nodes rows of an (--nodes * world)-node graph; --strong keeps N fixed
     N, d, h = (a.nodes if a.strong else a.nodes * world), a.feat, a.latent

@@ -20,6 +20,9 @@ PROTOTYPES = {
     "dgg_knet_x_fwd": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_knet_x_bwd_nodes": [_i64, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_knet_input_deg_fwd": [_vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
+    "dgg_knet_feat": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
+    "dgg_knet_out_fwd": [_vp, _vp, _i64, _vp, _vp, _vp],
+    "dgg_knet_out_bwd": [_vp, _vp, _vp, _i64, _vp, _vp],
     "dgg_knet_deg_fwd": [_vp, _i64, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "dgg_knet_deg_bwd_sums": [_vp, _i64, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
     "dgg_allpairs_topk": [_vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _vp, _vp, _i32, _vp, _sz, _vp],

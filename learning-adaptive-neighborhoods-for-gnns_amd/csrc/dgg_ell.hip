@@ -307,6 +307,43 @@ __global__ __launch_bounds__(WPB * 64) void edge_bwd_kernel(const float *__restr
     if (c1 < h) atomicAdd(dxp + gi * h + c1, acc1);
 }
 
+// same for any latent width (the PPI configuration runs the DGG at latent_dim = hidden = 2048, train_ppi.py:44,
+// model.py:907-910): features strided over the lanes, two passes over the (L1-resident) neighbour row
+__global__ __launch_bounds__(WPB * 64) void edge_bwd_wide_kernel(const float *__restrict__ xp, int64_t N, int h,
+                                                                const int32_t *__restrict__ idx, const float *__restrict__ val,
+                                                                const float *__restrict__ dval, int K, int64_t row0, float t,
+                                                                int perturb, float *__restrict__ dxp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int64_t gi = row0 + i;
+    const float *xi = xp + gi * h;
+    int32_t jl = lane < K ? idx[i * K + lane] : -1;
+    float gl = lane < K ? dval[i * K + lane] : 0.0f;
+    float vl = lane < K ? val[i * K + lane] : 0.0f;
+    for (int r = 0; r < K; r++) {
+        const int32_t j = bcast(jl, r);
+        const float g = bcast(gl, r);
+        if (j < 0 || g == 0.0f) continue;
+        const float v = bcast(vl, r);
+        const float *xj = xp + (int64_t)j * h;
+        float d2 = 0.0f;
+        for (int c = lane; c < h; c += 64) { const float d = xi[c] - xj[c]; d2 = fmaf(d, d, d2); }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) d2 += __shfl_xor(d2, off, 64);
+        if (d2 == 0.0f) continue;
+        const float dist = sqrtf(d2);
+        const float p = c_exp(t * dist);
+        const float dp = perturb ? g * v / (p + 1e-8f) : g;
+        const float dd = dp * t * p / dist;
+        for (int c = lane; c < h; c += 64) {
+            const float e = dd * (xi[c] - xj[c]);
+            atomicAdd(dxp + gi * h + c, e);
+            atomicAdd(dxp + (int64_t)j * h + c, -e);
+        }
+    }
+}
+
 inline unsigned rows_grid(int64_t N) { return (unsigned)((N + WPB - 1) / WPB); }
 
 }  // namespace
@@ -408,10 +445,13 @@ int dgg_softk_bwd(const int32_t *idx, const float *val, const float *k, const fl
 
 int dgg_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval, int K,
                  int64_t row0, float t, int perturb, float *dxp, void *stream) {
-    if (h > 128) return dgg_set_error(DGG_ERR_UNSUPPORTED, "edge_bwd supports latent_dim <= 128");
     if (N == 0) return 0;
-    hipLaunchKernelGGL(edge_bwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, xp, N, h, idx, val, dval,
-                       K, row0, t, perturb, dxp);
+    if (h > 128)
+        hipLaunchKernelGGL(edge_bwd_wide_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, xp, N, h, idx, val,
+                           dval, K, row0, t, perturb, dxp);
+    else
+        hipLaunchKernelGGL(edge_bwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, xp, N, h, idx, val, dval,
+                           K, row0, t, perturb, dxp);
     return dgg_check_launch("edge_bwd");
 }
 

@@ -311,6 +311,32 @@ __global__ __launch_bounds__(256) void knet_deg_bwd_sums_kernel(const float *__r
     if (threadIdx.x == 0) { atomicAdd(S, (float)r0[0]); atomicAdd(S + 1, (float)r1[0]); }
 }
 
+// ---- building blocks of the k-net for latent widths beyond the register-resident kernels (latent_dim > 128, e.g. the
+// PPI configuration's 2048): the three layers run as MFMA GEMMs (dgg_linear_fwd / dgg_linear_bwd on feat = [xk | nd]:
+// the same k-ordered fmaf chains as above), with these elementwise ends
+__global__ void knet_feat_kernel(const float *__restrict__ xk, const float *__restrict__ deg, const float *__restrict__ mu_sd,
+                                 int64_t N, int h, float *__restrict__ feat) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * (h + 1)) return;
+    const int64_t i = e / (h + 1);
+    const int c = (int)(e % (h + 1));
+    feat[e] = c < h ? xk[i * h + c] : __fdiv_rn(__fadd_rn(deg[i], -mu_sd[0]), __fadd_rn(mu_sd[1], 1e-5f));
+}
+__global__ void knet_out_fwd_kernel(const float *__restrict__ kp, const float *__restrict__ mu_sd, int64_t N,
+                                    float *__restrict__ k, float *__restrict__ u) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float uu = __fadd_rn(__fmul_rn(kp[i], mu_sd[1]), mu_sd[0]);
+    k[i] = __fadd_rn(uu > 0.0f ? uu : 0.0f, 1.0f);
+    u[i] = uu;
+}
+__global__ void knet_out_bwd_kernel(const float *__restrict__ u, const float *__restrict__ dk, const float *__restrict__ mu_sd,
+                                    int64_t N, float *__restrict__ dkp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    dkp[i] = u[i] > 0.0f ? dk[i] * mu_sd[1] : 0.0f;
+}
+
 }  // namespace dggk
 using namespace dggk;
 
@@ -380,6 +406,23 @@ int dgg_knet_x_bwd_nodes(int64_t N, int h, const float *mu_sd, const float *W1, 
     hipLaunchKernelGGL(knet_x_bwd_kernel, dim3(blocks), dim3(WPB * 64), lds, (hipStream_t)stream, N, h, mu_sd, W1, h2, Wmu,
                        h4, Wp, z, u, dk, dkp, dm, dpre1, dxk, m_out, bmu);
     return dgg_check_launch("knet_x_bwd_nodes");
+}
+
+int dgg_knet_feat(const float *xk, const float *deg, const float *mu_sd, int64_t N, int h, float *feat, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(knet_feat_kernel, dim3((unsigned)((N * (h + 1) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xk, deg, mu_sd,
+                       N, h, feat);
+    return dgg_check_launch("knet_feat");
+}
+int dgg_knet_out_fwd(const float *kp, const float *mu_sd, int64_t N, float *k, float *u, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(knet_out_fwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kp, mu_sd, N, k, u);
+    return dgg_check_launch("knet_out_fwd");
+}
+int dgg_knet_out_bwd(const float *u, const float *dk, const float *mu_sd, int64_t N, float *dkp, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(knet_out_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, dk, mu_sd, N, dkp);
+    return dgg_check_launch("knet_out_bwd");
 }
 
 int dgg_knet_deg_fwd(const float *deg, int64_t N, const float *mu_sd, float dmean, float dstd, float eps, const float *Wd,

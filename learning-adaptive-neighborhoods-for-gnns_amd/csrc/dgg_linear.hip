@@ -268,8 +268,9 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce(const float *__restrict__ 
                                                       int nchunks, int M1, int M2, int M1p, int M2p,
                                                       float *__restrict__ Cout, int c_layout, float *__restrict__ colsum) {
     const int e = blockIdx.x * 256 + threadIdx.x;                // element of the padded [M1p][M2p] block
-    const int per = (nchunks + GT_SPLIT - 1) / GT_SPLIT;
+    const int per = (nchunks + (int)gridDim.y - 1) / (int)gridDim.y;
     const int k0 = blockIdx.y * per, k1 = k0 + per < nchunks ? k0 + per : nchunks;
+    if (k0 >= k1) return;
     if (e < M1p * M2p) {
         const int o = e / M2p, c = e % M2p;
         if (o < M1 && c < M2) {
@@ -298,12 +299,26 @@ int launch_linear_fwd(const float *x, int64_t N, int d, const float *W, const fl
     return dgg_check_launch("linear_fwd");
 }
 
-inline int gemm_tn_grid(int64_t N) {
+// block shape per wavefront and the number of row-streaming workgroups per output block: the tiny weights of the hot
+// path get GT_GRID streams (one output block, all CUs share the rows); large outputs (GCNII layers, 2048 x 4096) already
+// have hundreds of output blocks, so each is streamed by ONE workgroup and the slab holds a single partial
+inline void gemm_tn_shape(int M1p, int M2p, int &mb, int &nb) {
+    mb = M1p / 32 >= 2 ? 2 : 1;
+    nb = M2p / 32 >= 3 ? 4 : M2p / 32;
+}
+inline int gemm_tn_grid(int64_t N, int M1p, int M2p) {
+    int mb, nb;
+    gemm_tn_shape(M1p, M2p, mb, nb);
+    const int64_t blocks = (int64_t)((M1p / 32 + mb - 1) / mb) * ((M2p / 32 + nb - 1) / nb);
+    int64_t g = (4 * GT_GRID + blocks - 1) / blocks;             // ~1024 workgroups in total
+    if (g > GT_GRID) g = GT_GRID;
     const int64_t need = (N + 4 * 2 * GT_PF - 1) / (4 * 2 * GT_PF);
-    return (int)(need < GT_GRID ? (need < 1 ? 1 : need) : GT_GRID);
+    if (g > need) g = need;
+    return (int)(g < 1 ? 1 : g);
 }
 size_t gemm_tn_ws_floats(int64_t N, int M1, int M2) {
-    const size_t g = (size_t)gemm_tn_grid(N), M1p = (size_t)(M1 + 31) / 32 * 32, M2p = (size_t)(M2 + 31) / 32 * 32;
+    const size_t M1p = (size_t)(M1 + 31) / 32 * 32, M2p = (size_t)(M2 + 31) / 32 * 32;
+    const size_t g = (size_t)gemm_tn_grid(N, (int)M1p, (int)M2p);
     return g * M1p * M2p + g * M1p;
 }
 
@@ -318,17 +333,19 @@ void launch_gemm_tn_persist(const float *A, const float *B, int64_t N, int M1, i
 int launch_gemm_tn(const float *A, const float *B, int64_t N, int M1, int M2, float *C, int c_layout, float *colsum,
                    float *ws, hipStream_t st) {
     if (!ws) return dgg_set_error(DGG_ERR_ARG, "gemm_tn: workspace is NULL (dgg_gemm_tn_ws_floats)");
-    const int g = gemm_tn_grid(N), M1p = (M1 + 31) / 32 * 32, M2p = (M2 + 31) / 32 * 32;
+    const int M1p = (M1 + 31) / 32 * 32, M2p = (M2 + 31) / 32 * 32;
+    const int g = gemm_tn_grid(N, M1p, M2p);
     float *slab = ws, *cs_slab = ws + (size_t)g * M1p * M2p;
     float *csl = colsum ? cs_slab : nullptr;
-    const int mb = M1p / 32 >= 2 ? 2 : 1, nb = M2p / 32 >= 3 ? 4 : M2p / 32;
+    int mb, nb;
+    gemm_tn_shape(M1p, M2p, mb, nb);
     if (mb == 2 && nb == 4) launch_gemm_tn_persist<2, 4>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
     else if (mb == 2 && nb == 2) launch_gemm_tn_persist<2, 2>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
     else if (mb == 2) launch_gemm_tn_persist<2, 1>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
     else if (nb == 4) launch_gemm_tn_persist<1, 4>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
     else if (nb == 2) launch_gemm_tn_persist<1, 2>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
     else launch_gemm_tn_persist<1, 1>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
-    hipLaunchKernelGGL(gemm_tn_reduce, dim3((unsigned)((M1p * M2p + 255) / 256), GT_SPLIT), dim3(256), 0, st, slab, csl, g, M1,
+    hipLaunchKernelGGL(gemm_tn_reduce, dim3((unsigned)((M1p * M2p + 255) / 256), (unsigned)(g < GT_SPLIT ? g : GT_SPLIT)), dim3(256), 0, st, slab, csl, g, M1,
                        M2, M1p, M2p, C, c_layout, colsum);
     return dgg_check_launch("gemm_tn");
 }

@@ -354,10 +354,38 @@ def edge_bwd(xp, idx, val, dval, row0=0, t=T_DIST, perturb=False, part=None):
     return dxp
 
 
+def _knet_wide_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp):
+    """latent_dim > 128: the three layers as MFMA GEMMs on feat = [xk | nd] (same fmaf chains as the fused kernels)"""
+    N, h = xk.shape
+    feat = torch.empty((N, h + 1), device=xk.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_knet_feat(_ptr(xk), _ptr(_chk(deg)), _ptr(mu_sd), N, h, _ptr(feat), _stream()), "knet_feat")
+    z = linear_fwd(feat, W1, b1, ACT_LEAKY)
+    m = linear_fwd(z, Wmu, bmu, ACT_NONE)
+    kp = linear_fwd(m, Wp.reshape(1, -1), bp, ACT_NONE)
+    k = torch.empty((N,), device=xk.device, dtype=torch.float32)
+    u = torch.empty((N,), device=xk.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_knet_out_fwd(_ptr(kp), _ptr(mu_sd), N, _ptr(k), _ptr(u), _stream()), "knet_out_fwd")
+    return k, z, u, feat
+
+
+def _knet_wide_bwd(h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk):
+    N = z.shape[0]
+    dkp = torch.empty((N, 1), device=z.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_knet_out_bwd(_ptr(u), _ptr(_chk(dk)), _ptr(mu_sd), N, _ptr(dkp), _stream()), "knet_out_bwd")
+    m = linear_fwd(z, Wmu, bmu, ACT_NONE)                        # recomputed (k_project weight gradient)
+    Wp2 = Wp.reshape(1, -1)
+    dm, dWp, dbp = linear_bwd(m, Wp2, None, dkp, ACT_NONE)
+    dz, dWmu, dbmu = linear_bwd(z, Wmu, None, dm, ACT_NONE)
+    dfeat, dW1, db1 = linear_bwd(feat, W1, z, dz, ACT_LEAKY)
+    return dfeat[:, :h].contiguous(), dW1, db1, dWmu, dbmu, dWp, dbp
+
+
 def knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, save=True):
     xk = _chk(xk)
     N, h = xk.shape
     h2, h4 = W1.shape[0], Wmu.shape[0]
+    if h > 128:
+        return _knet_wide_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp)
     dev = xk.device
     k = torch.empty((N,), device=dev, dtype=torch.float32)
     z = torch.empty((N, h2), device=dev, dtype=torch.float32) if save else None
@@ -373,6 +401,8 @@ def knet_x_bwd(h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk):
     """-> dxk [N,h], dW1, db1, dWmu, dbmu, dWp ([1,h4]), dbp ([1])"""
     N = z.shape[0]
     h2, h4 = W1.shape[0], Wmu.shape[0]
+    if h > 128:
+        return _knet_wide_bwd(h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk)
     dev = z.device
     dkp = torch.empty((N, 1), device=dev, dtype=torch.float32)
     dm = torch.empty((N, h4), device=dev, dtype=torch.float32)

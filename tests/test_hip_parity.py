@@ -192,7 +192,7 @@ def test_softk_normalize_spmm_bit_exact(dev):
 def test_knet_bit_exact_and_bwd(dev):
     from dgg_amd import ops
     rng = np.random.default_rng(8)
-    for N, h in [(700, 64), (300, 16), (150, 128)]:
+    for N, h in [(700, 64), (300, 16), (150, 128), (333, 256), (90, 40)]:   # 256: GEMM composition; 40: wave-per-node
         h2, h4 = h // 2, h // 4
         xk = rng.standard_normal((N, h)).astype(np.float32)
         deg = (5 + 30 * rng.random(N)).astype(np.float32)
@@ -658,3 +658,62 @@ def test_sddmm_fused_with_normalisation_backward(dev, F):
     np.testing.assert_allclose(Nn(dA), rdA, rtol=1e-4, atol=1e-4 * np.abs(rdA).max())
     da_ref = ops.norm_bwd_da(T(idx, dev), T(w, dev), T(rs, dev), T(rdA, dev))          # atomic path, itself oracle-checked
     np.testing.assert_allclose(Nn(da), Nn(da_ref), rtol=3e-4, atol=3e-4 * np.abs(Nn(da_ref)).max())
+
+
+def test_wide_latent_edge_list_pipeline(dev):
+    """latent_dim > 128 (the PPI configuration runs the DGG at latent_dim = hidden = 2048): edge-list scoring, wide score
+    backward and the GEMM-composed k-net against the oracle, through the module"""
+    import dgg_amd
+    from argparse import Namespace
+    rng = np.random.default_rng(51)
+    N, d, h = 300, 24, 256
+    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
+    torch.manual_seed(3)
+    m = dgg_amd.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=args).to(dev)
+    m.set_seed(11, 12)
+    dens = rng.random((N, N)) < 0.08
+    dens |= dens.T
+    np.fill_diagonal(dens, True)
+    rows, cols = np.nonzero(dens)
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.ones(len(rows)), (N, N)).coalesce().to(dev)
+    x = T(rng.standard_normal((N, d)).astype(np.float32), dev).requires_grad_(True)
+    adj = m(x, A)
+    cot = rng.standard_normal((N, K)).astype(np.float32)
+    (adj.values() * T(cot, dev)).sum().backward()
+    # oracle on the same inputs
+    sd = {k_: Nn(v) for k_, v in m.state_dict().items()}
+    fx = {"x": Nn(x), "rows": rows.astype(np.int32), "cols": cols.astype(np.int32), "deg": Nn(dgg_amd.csr_candidates(A)[2]),
+          "meta": {"N": N, "h": h, "args": vars(args)}}
+    fx.update({"p." + k_: v for k_, v in sd.items()})
+    # hash noise keyed like the module's seed (edge-list candidates use the per-pair hash generator)
+    from test_oracle_golden import csr_from_coo as _csr
+    r = {}
+    P = lambda s_: fx["p." + s_]  # noqa: E731
+    r["xp"] = O.linear(fx["x"], P("node_encode_for_edges.0.weight"), P("node_encode_for_edges.0.bias"), O.ACT_LEAKY)
+    r["xk"] = O.linear(fx["x"], P("node_encode_for_k.0.weight"), P("node_encode_for_k.0.bias"), O.ACT_LEAKY)
+    mu, sdv = O.degree_stats(fx["deg"])
+    r["k"], r["z"], r["m"], r["u"] = O.knet_x(r["xk"], fx["deg"], mu, sdv, P("k_embed.0.weight"), P("k_embed.0.bias"),
+                                              P("k_net.k_mu.weight"), P("k_net.k_mu.bias"), P("k_net.k_project.weight").reshape(-1),
+                                              P("k_net.k_project.bias"), save=True)
+    rowptr, col = _csr(fx["rows"], fx["cols"], N)
+    r["idx"], r["val"] = O.edgelist_topk(r["xp"], rowptr, col, K=K, noise_mode=O.NOISE_HASH, seed=(11, 12))
+    assert np.array_equal(Nn(adj.idx), r["idx"]) and np.array_equal(Nn(adj.score), r["val"]) and np.array_equal(Nn(adj.k), r["k"])
+    w, _ = O.softk(r["idx"], r["val"], r["k"], 0)
+    assert np.array_equal(Nn(adj.values()), w)
+    dval, dk = O.softk_bwd(r["idx"], r["val"], r["k"], np.where(r["idx"] >= 0, cot, 0).astype(np.float32), 0)
+    dxp = O.edge_bwd(r["xp"], r["idx"], r["val"], dval, perturb=True)
+    dx1, gWe, gbe = O.linear_bwd(fx["x"], P("node_encode_for_edges.0.weight"), r["xp"], dxp, act=O.ACT_LEAKY)
+    dxk, gW1, gb1, gWmu, gbmu, gWp, gbp = O.knet_x_bwd(r["xk"], fx["deg"], mu, sdv, P("k_embed.0.weight"), P("k_net.k_mu.weight"),
+                                                       P("k_net.k_project.weight").reshape(-1), r["z"], r["m"], r["u"], dk)
+    dx2, gWk, gbk = O.linear_bwd(fx["x"], P("node_encode_for_k.0.weight"), r["xk"], dxk, act=O.ACT_LEAKY)
+    ref = {"node_encode_for_edges.0.weight": gWe, "node_encode_for_edges.0.bias": gbe, "node_encode_for_k.0.weight": gWk,
+           "node_encode_for_k.0.bias": gbk, "k_embed.0.weight": gW1, "k_embed.0.bias": gb1, "k_net.k_mu.weight": gWmu,
+           "k_net.k_mu.bias": gbmu, "k_net.k_project.weight": gWp, "k_net.k_project.bias": gbp}
+    got = {n_: p_.grad for n_, p_ in m.named_parameters() if p_.grad is not None}
+    for key, rv in ref.items():
+        err = np.abs(Nn(got[key]).reshape(rv.shape) - rv).max() / max(np.abs(rv).max(), 1e-6)
+        assert err <= 3e-4, f"grad {key}: {err:.3e}"
+    rx = dx1 + dx2
+    assert np.abs(Nn(x.grad) - rx).max() <= 3e-4 * np.abs(rx).max()
