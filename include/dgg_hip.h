@@ -89,6 +89,12 @@ int dgg_knet_x_bwd_nodes(int64_t N, int h, const float *mu_sd, const float *W1, 
 int dgg_knet_deg_fwd(const float *deg, int64_t N, const float *mu_sd, float dmean, float dstd, float eps, const float *Wd,
                      const float *bd, const float *Wmu, const float *bmu, int h4, const float *Wp, const float *bp, float *k,
                      float *u_save, void *stream);
+/* latent_dim > 128 (PPI configuration: 2048): the three layers of mode "x" run as GEMMs (dgg_linear_fwd/bwd) on
+ * feat [N,h+1] = [xk | nd] -- the same k-ordered fmaf chains -- between these elementwise ends:
+ * feat assembly; u = kp*sd + mu, k = relu(u) + 1; dkp = dk * sd * [u > 0] */
+int dgg_knet_feat(const float *xk, const float *deg, const float *mu_sd, int64_t N, int h, float *feat, void *stream);
+int dgg_knet_out_fwd(const float *kp, const float *mu_sd, int64_t N, float *k, float *u, void *stream);
+int dgg_knet_out_bwd(const float *u, const float *dk, const float *mu_sd, int64_t N, float *dkp, void *stream);
 /* backward: S[0] += sum_i dkp_i, S[1] += sum_i dkp_i nd_i with dkp = dk * sd * [u > 0]; the net is affine in nd, so every
  * parameter gradient is a combination of these two sums (see dgg_amd/dgm.py, _KnetDegFn) */
 int dgg_knet_deg_bwd_sums(const float *deg, int64_t N, const float *mu_sd, float dmean, float dstd, float eps, const float *u,
