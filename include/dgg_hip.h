@@ -82,7 +82,6 @@ int dgg_knet_x_fwd(const float *xk, int64_t N, int h, const float *deg, const fl
 int dgg_knet_x_bwd_nodes(int64_t N, int h, const float *mu_sd, const float *W1, int h2, const float *Wmu, int h4,
                          const float *Wp, const float *bmu, const float *z, const float *u, const float *dk, float *dkp,
                          float *dm, float *dpre1, float *dxk, float *m_out, void *stream);
-/* mode "input_deg" (dgm.py:1509-1526): Wd/bd = input_degree_project [3]/[3];
 /* degree-only modes in general (dgm.py:1492-1526): nd = (deg - mu) / (sd + eps), k = relu(k_project(k_mu(
  * input_degree_project(nd))) * sd + mu) + 1.  "input_deg": mu_sd = NULL, constants dmean/dstd = args.deg_mean/deg_std,
  * eps = 1e-5; "learn_normalized_degree": mu_sd = device [2] from dgg_degree_stats, eps = 0.  u_save (nullable): pre-relu */
@@ -98,7 +97,8 @@ int dgg_knet_out_bwd(const float *u, const float *dk, const float *mu_sd, int64_
 /* backward: S[0] += sum_i dkp_i, S[1] += sum_i dkp_i nd_i with dkp = dk * sd * [u > 0]; the net is affine in nd, so every
  * parameter gradient is a combination of these two sums (see dgg_amd/dgm.py, _KnetDegFn) */
 int dgg_knet_deg_bwd_sums(const float *deg, int64_t N, const float *mu_sd, float dmean, float dstd, float eps, const float *u,
-                          const float *dk, float *S, void *stream); Wmu [h4][3] */
+                          const float *dk, float *S, void *stream);
+/* mode "input_deg" (dgm.py:1509-1526) alone: Wd/bd = input_degree_project [3]/[3]; Wmu [h4][3] */
 int dgg_knet_input_deg_fwd(const float *deg, int64_t N, float dmean, float dstd, const float *Wd, const float *bd,
                            const float *Wmu, const float *bmu, int h4, const float *Wp, const float *bp, float *k,
                            void *stream);

@@ -29,6 +29,17 @@ def test_library_exports_every_declared_symbol():
     assert dgg_amd._lib.lib().dgg_abi_version() == 2
 
 
+def test_public_header_is_valid_c():
+    """include/dgg_hip.h must compile as plain C (it is what a cgo / JNI / ctypes binding generator would read)"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    r = subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", os.path.join(ROOT, "include", "dgg_hip.h")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_state_dict_contract_matches_reference_fixture():
     """keys/shapes of the reference's DGG_LearnableK_debug.state_dict() (captured in the golden fixture)"""
     import dgg_amd
