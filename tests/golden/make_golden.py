@@ -220,6 +220,47 @@ def dggclass_cases():
     print("model_gcn_dgg_00 ok", tuple(logp.shape))
 
 
+def cora_cases():
+    """BASELINE configs[0] (SURVEY 8b'): Cora through the reference's own loader + add_noisy_edges, one eval-mode forward of
+    GCN_DGG_00 (the wrapper the small-graph script can drive as shipped: it accepts the script's edge_index kwarg)."""
+    import utils as refutils
+    cwd = os.getcwd()
+    os.chdir("/root/reference")                                  # load_citation opens data/ind.*.test.index relatively
+    try:
+        adj, feats, labels, itr, iva, ite = refutils.load_citation("cora", "/root/reference")
+    finally:
+        os.chdir(cwd)
+    adj = adj.coalesce()
+    N = feats.shape[0]
+    keep = adj.values() != 0                                     # the loader stores explicit zeros on the diagonal
+    ei = adj.indices()[:, keep]
+    A0 = scipy.sparse.coo_matrix((np.ones(ei.shape[1], np.float32), (ei[0].numpy(), ei[1].numpy())), shape=(N, N))
+    noisy = refutils.add_noisy_edges(A0, noise_level=0.00014).tocoo()             # train_small_graphs.py default level
+    order = np.lexsort((noisy.col, noisy.row))
+    nr, nc, nv = noisy.row[order].astype(np.int32), noisy.col[order].astype(np.int32), noisy.data[order].astype(np.float32)
+    fnz = feats.to_sparse().coalesce()
+    h, C = 16, int(labels.max()) + 1
+    a = base_args()
+    torch.manual_seed(4321)
+    m = refmodel.GCN_DGG_00(nfeat=feats.shape[1], nlayers=2, nhidden=h, nclass=C, args=a)
+    m.eval()
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([nr, nc]).astype(np.int64)), torch.from_numpy(nv), (N, N)).coalesce()
+    with torch.no_grad():
+        logp, unnorm, x_dgg = m(feats, A)
+    loss = torch.nn.functional.nll_loss(logp[itr], labels[itr])
+    fx = {"feat_rows": fnz.indices()[0].numpy().astype(np.int16), "feat_cols": fnz.indices()[1].numpy().astype(np.int16),
+          "feat_vals": fnz.values().numpy(), "rows": ei[0].numpy().astype(np.int32), "cols": ei[1].numpy().astype(np.int32),
+          "noisy_rows": nr, "noisy_cols": nc, "labels": labels.numpy().astype(np.int16), "train_idx": itr.numpy(),
+          "val_idx": iva.numpy(), "test_idx": ite.numpy(), "out": logp.numpy(), "loss": np.float32(loss.item())}
+    for k_, v in m.state_dict().items():
+        fx["p." + k_] = v.detach().numpy()
+    meta = dict(name="cora_gcn_dgg_00", N=N, d=int(feats.shape[1]), h=h, C=C, torch=torch.__version__, args=vars(a),
+                edge_noise_level=0.00014, reference="utils.load_citation + add_noisy_edges + model.GCN_DGG_00 (eval)")
+    fx["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "cora_gcn_dgg_00.npz"), **fx)
+    print("cora ok: edges", ei.shape[1], "noisy", len(nr), "loss", float(loss), "max row", int(np.bincount(nr).max()))
+
+
 def allpairs_cases():
     N, d, h = 256, 32, 16
     gen = torch.Generator().manual_seed(8)
@@ -302,6 +343,8 @@ if __name__ == "__main__":
         edgemlp_cases()
     if "dggclass" in which:
         dggclass_cases()
+    if "cora" in which:
+        cora_cases()
 
 
 def model_cases():
