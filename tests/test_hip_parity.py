@@ -750,3 +750,50 @@ def test_cora_small_graph_harness_matches_reference(dev):
     tr = torch.from_numpy(fx["train_idx"]).to(dev)
     loss = float(torch.nn.functional.nll_loss(logp[tr], y[tr]))
     assert abs(loss - float(fx["loss"])) < 1e-4
+
+
+def test_small_graph_harness_trains_on_planetoid_files(dev, tmp_path):
+    """the harness end to end (reader -> noisy edges -> model by name -> Adam steps) on a synthetic data set written in
+    the Planetoid file format; the loss must go down"""
+    import pickle
+    import scipy.sparse as sp
+    from collections import defaultdict
+    from dgg_amd import train_small_graphs as H
+    rng = np.random.default_rng(0)
+    N, d, C, n_train, n_test = 900, 40, 3, 30, 100          # the public split takes 500 validation nodes after the train set
+    y = rng.integers(0, C, N)
+    X = (rng.random((N, d)) < 0.08).astype(np.float32)
+    for c in range(C):
+        X[y == c, c * 10:(c + 1) * 10] += (rng.random((int((y == c).sum()), 10)) < 0.5)       # class-dependent words
+    onehot = np.eye(C, dtype=np.int32)[y]
+    graph = defaultdict(list)
+    for u in range(N):
+        same = np.flatnonzero(y == y[u])
+        for v in rng.choice(same, 3):
+            graph[u].append(int(v))
+    n_all = N - n_test
+    files = {"x": sp.csr_matrix(X[:n_train]), "y": onehot[:n_train], "allx": sp.csr_matrix(X[:n_all]), "ally": onehot[:n_all],
+             "tx": sp.csr_matrix(X[n_all:]), "ty": onehot[n_all:], "graph": dict(graph)}
+    for k_, v in files.items():
+        with open(tmp_path / f"ind.toy.{k_}", "wb") as f:
+            pickle.dump(v, f)
+    with open(tmp_path / "ind.toy.test.index", "w") as f:
+        f.write("\n".join(str(i) for i in rng.permutation(np.arange(n_all, N))))
+    losses = []
+    orig = torch.nn.functional.nll_loss
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        if out.requires_grad:
+            losses.append(float(out.detach()))
+        return out
+
+    H.F.nll_loss = spy
+    try:
+        for model, extra in [("GCN_DGG_00", []), ("GCN_DGG", ["--dgg_mode_edge_net", "u-v-deg", "--extra_edge_dim", "2"])]:
+            losses.clear()
+            H.main(["--data", "toy", "--data_dir", str(tmp_path), "--model", model, "--hidden", "16", "--epochs", "12",
+                    "--edge_noise_level", "0.001", "--lr", "0.02"] + extra)
+            assert len(losses) == 12 and losses[-1] < losses[0], (model, losses)
+    finally:
+        H.F.nll_loss = orig
