@@ -131,6 +131,65 @@ class GCN_DGG(nn.Module):
         return self.dggs[i](x=x, in_adj=unnorm_adj, noise=False, writer=writer, epoch=epoch)
 
 
+class DenseGraphConv(nn.Module):
+    """`torch_geometric.nn.DenseGraphConv` as used by SAGE_DGG (reference model.py:84-85, 128-129; README pins
+    torch_geometric 2.1.0, which is not vendored and not installed here: PARITY UNPINNED -- this is a restatement of the
+    published layer, checked only against a dense torch evaluation of the same formula):
+        out = lin_rel(aggr_j adj_ij x_j) + lin_root(x),  aggr "add": adj @ x;  "mean": (adj @ x) / clamp(sum_j adj_ij, min=1)
+    with lin_rel = Linear(in, out, bias), lin_root = Linear(in, out, bias=False) (state_dict keys lin_rel.*, lin_root.weight).
+    The aggregation runs on the sparse adjacency (ELL / CSR SpMM), the two projections on the MFMA linear kernel."""
+
+    def __init__(self, in_channels, out_channels, aggr="add", bias=True):
+        super().__init__()
+        assert aggr in ("add", "mean"), "aggr 'max' needs a dense masked maximum: not on the HIP path"
+        self.in_channels, self.out_channels, self.aggr = in_channels, out_channels, aggr
+        self.lin_rel = nn.Linear(in_channels, out_channels, bias=bias)
+        self.lin_root = nn.Linear(in_channels, out_channels, bias=False)
+
+    def forward(self, x, adj, mask=None):
+        assert mask is None, "node masks belong to the batched dense layout, which this path does not use"
+        adj = _as_ell(adj)
+        out = adj.matmul(x)
+        if self.aggr == "mean":
+            v = adj.values()
+            if isinstance(adj, CsrAdjacency):    # differentiable row sums of the CSR values
+                rs = torch.zeros(adj.shape[0], device=v.device, dtype=v.dtype).index_add(0, adj.erow.long(), v)
+            else:
+                rs = v.sum(1)
+            out = out / rs.clamp(min=1).unsqueeze(1)
+        return ops.LinearFn.apply(out, self.lin_rel.weight, self.lin_rel.bias, ops.ACT_NONE, 0) + \
+            ops.LinearFn.apply(x, self.lin_root.weight, None, ops.ACT_NONE, 0)
+
+
+class SAGE_DGG(nn.Module):
+    """Two DenseGraphConv(mean) layers, one DGG in front of the first (reference model.py:122-193).  Returns log_probs."""
+
+    def __init__(self, nfeat=32, nlayers=None, nhidden=32, nclass=10, args=None, **kwargs):
+        super().__init__()
+        self.convs = nn.ModuleList([DenseGraphConv(nfeat, nhidden, aggr="mean"), DenseGraphConv(nhidden, nclass, aggr="mean")])
+        self.dgg_adj_input = args.dgg_adj_input
+        self.dggs = nn.ModuleList([DGG_LearnableK_debug(in_dim=nfeat, latent_dim=nhidden, args=args)])
+
+    normalize_adj = staticmethod(_normalize_adj)
+
+    def dgg_net(self, x, i, unnorm_adj, writer, epoch):
+        return self.dggs[i](x=x, in_adj=unnorm_adj, noise=False, writer=writer, epoch=epoch)
+
+    def forward(self, x, in_adj, noise=True, epoch=None, writer=None, **kwargs):
+        in_adj = _with_self_loops(in_adj)
+        unnorm_adj = in_adj
+        norm_adj = None
+        for i, conv in enumerate(self.convs):
+            if i < len(self.dggs):
+                src = in_adj if self.dgg_adj_input == "input_adj" else unnorm_adj
+                unnorm_adj = self.dgg_net(x, i, src, writer, epoch)
+                norm_adj = _normalize_adj(unnorm_adj)
+            x = conv(x, norm_adj)
+            if i < len(self.convs) - 1:
+                x = F.dropout(torch.relu(x), p=0.5, training=self.training)
+        return F.log_softmax(x, dim=-1)
+
+
 class GCN_DGG_00(nn.Module):
     """Two GCNConv layers on the encoded features of a `DGG` generator (reference model.py:1314-1433).  Returns
     (log_probs, unnorm_adj, x_dgg)."""

@@ -797,3 +797,38 @@ def test_small_graph_harness_trains_on_planetoid_files(dev, tmp_path):
             assert len(losses) == 12 and losses[-1] < losses[0], (model, losses)
     finally:
         H.F.nll_loss = orig
+
+
+def test_sage_dgg_matches_dense_restatement(dev):
+    """SAGE_DGG (model.py:122-193).  torch_geometric is not available, so DenseGraphConv(mean) is checked against a dense
+    torch evaluation of the published formula on the SAME learned adjacency (parity with PyG itself is unpinned)."""
+    import dgg_amd
+    from argparse import Namespace
+    fx = load_fixture("model_gcn_dgg")                    # graph, features and DGG configuration of the GCN_DGG fixture
+    meta = fx["meta"]
+    N, d, h, C = meta["N"], meta["d"], meta["h"], meta["C"]
+    torch.manual_seed(5)
+    m = dgg_amd.SAGE_DGG(nfeat=d, nlayers=2, nhidden=h, nclass=C, args=Namespace(**meta["args"])).to(dev).eval()
+    assert sorted(k_ for k_ in m.state_dict() if k_.startswith("convs.")) == [
+        "convs.0.lin_rel.bias", "convs.0.lin_rel.weight", "convs.0.lin_root.weight", "convs.1.lin_rel.bias",
+        "convs.1.lin_rel.weight", "convs.1.lin_root.weight"]
+    m.dggs[0].set_noise(T(fx["G"], dev))
+    ind = torch.from_numpy(np.stack([fx["rows"], fx["cols"]]).astype(np.int64))
+    A = torch.sparse_coo_tensor(ind, torch.from_numpy(fx["adj_vals"]), (N, N)).coalesce().to(dev)
+    x = T(fx["x"], dev).requires_grad_(True)
+    logp = m(x, A)
+    (logp * T(fx["cot"], dev)).sum().backward()
+    got = {n_: p_.grad.clone() for n_, p_ in m.named_parameters() if p_.grad is not None}
+    gx = x.grad.clone()
+    # dense restatement on the adjacency the DGG produced (detached graph, same parameters)
+    from dgg_amd.model import _with_self_loops
+    adj = m.dggs[0](x.detach(), _with_self_loops(A)).normalize().to_dense().detach()
+    xx = x.detach()
+    for i, conv in enumerate(m.convs):
+        agg = (adj @ xx) / adj.sum(-1, keepdim=True).clamp(min=1)
+        xx = agg @ conv.lin_rel.weight.t() + conv.lin_rel.bias + xx @ conv.lin_root.weight.t()
+        if i == 0:
+            xx = torch.relu(xx)
+    ref = torch.log_softmax(xx, -1)
+    np.testing.assert_allclose(Nn(logp), Nn(ref), rtol=1e-5, atol=2e-5)
+    assert all(torch.isfinite(g).all() for g in got.values()) and torch.isfinite(gx).all() and len(got) >= 14
