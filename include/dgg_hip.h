@@ -172,6 +172,12 @@ int dgg_csr_spmm_fwd(const int64_t *rowptr, const int32_t *col, const float *a, 
                      void *stream);
 int dgg_csr_spmm_bwd(const int64_t *rowptr, const int32_t *col, const float *a, const float *X, const float *dY, int64_t N, int F,
                      float *dA, float *dX, void *stream);
+/* GATConv_DGG (model.py:534-577): softmax(dim=1) of the dense logit matrix whose explicit entries are L [E] on the CSR
+ * pattern and whose other N - cnt_i entries per row are the logit 0 that -1e20 * 0 produces (model.py:565-567):
+ * att [E] on the pattern, bg [N] = the weight every non-listed node of a row receives.  Backward: datt, dbg -> dL. */
+int dgg_csr_bg_softmax_fwd(const float *L, const int64_t *rowptr, int64_t N, float *att, float *bg, void *stream);
+int dgg_csr_bg_softmax_bwd(const float *att, const float *bg, const int64_t *rowptr, int64_t N, const float *datt, const float *dbg,
+                           float *dL, void *stream);
 /* selection only, from a dense score matrix [R,N] (test entry: torch.sort(pert_edge_p)[:, :K], dgm.py:1404) */
 int dgg_select_scores(const float *scores, int64_t R, int64_t N, int K, int32_t *idx, float *val, void *stream);
 

@@ -37,6 +37,8 @@ PROTOTYPES = {
     "dgg_csr_normalize_fwd": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "dgg_csr_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "dgg_csr_spmm_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
+    "dgg_csr_bg_softmax_fwd": [_vp, _vp, _i64, _vp, _vp, _vp],
+    "dgg_csr_bg_softmax_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "dgg_csr_spmm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "dgg_select_scores": [_vp, _i64, _i64, _i32, _vp, _vp, _vp],
     "dgg_softk_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],

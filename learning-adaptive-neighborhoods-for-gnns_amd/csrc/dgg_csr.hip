@@ -185,9 +185,65 @@ __global__ __launch_bounds__(WPB * 64) void csr_rank_ramp_bwd_kernel(const float
     }
 }
 
+// ---- GATConv_DGG (reference model.py:534-577): row softmax with a uniform background ---------------------------------
+// The reference builds a dense [N,N] logit matrix: e_ij on the entries of edge_index, -1e20 elsewhere, multiplied by the
+// dense learned adjacency.  Every pair that is in neither list gets logit -1e20 * 0 = -0, i.e. exp(0) = 1 in the softmax:
+// all non-neighbours attend with the same weight.  So a row is `cnt` explicit logits plus (N - cnt) background entries of
+// logit 0:  M = max(max_u L_u, 0), Z = sum_u exp(L_u - M) + (N - cnt) exp(-M), att_u = exp(L_u - M) / Z, bg = exp(-M) / Z
+// (bg = 0 and M = max_u L_u when the row has no background entry).
+__global__ __launch_bounds__(WPB * 64) void bg_softmax_fwd_kernel(const float *__restrict__ L, const int64_t *__restrict__ rowptr,
+                                                                 int64_t N, float *__restrict__ att, float *__restrict__ bg) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
+    const float nbg = (float)(N - (e1 - e0));
+    float m = nbg > 0.0f ? 0.0f : -INFINITY;
+    for (int64_t e = e0 + lane; e < e1; e += 64) m = fmaxf(m, L[e]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float z = 0.0f;
+    for (int64_t e = e0 + lane; e < e1; e += 64) z += __expf(L[e] - m);
+    z = wave_sum_butterfly(z);
+    const float eb = nbg > 0.0f ? __expf(-m) : 0.0f;
+    z += nbg * eb;
+    const float iz = 1.0f / z;
+    for (int64_t e = e0 + lane; e < e1; e += 64) att[e] = __expf(L[e] - m) * iz;
+    if (lane == 0) bg[i] = eb * iz;
+}
+// dL_u = att_u (datt_u - S_i),  S_i = sum_v att_v datt_v + bg_i dbg_i
+__global__ __launch_bounds__(WPB * 64) void bg_softmax_bwd_kernel(const float *__restrict__ att, const float *__restrict__ bg,
+                                                                 const int64_t *__restrict__ rowptr, int64_t N,
+                                                                 const float *__restrict__ datt, const float *__restrict__ dbg,
+                                                                 float *__restrict__ dL) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
+    float s = 0.0f;
+    for (int64_t e = e0 + lane; e < e1; e += 64) s = fmaf(att[e], datt[e], s);
+    s = wave_sum_butterfly(s) + bg[i] * dbg[i];
+    for (int64_t e = e0 + lane; e < e1; e += 64) dL[e] = att[e] * (datt[e] - s);
+}
+
 }  // namespace
 
 extern "C" {
+
+int dgg_csr_bg_softmax_fwd(const float *L, const int64_t *rowptr, int64_t N, float *att, float *bg, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(bg_softmax_fwd_kernel, dim3((unsigned)((N + WPB - 1) / WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, L, rowptr, N,
+                       att, bg);
+    return dgg_check_launch("csr_bg_softmax_fwd");
+}
+int dgg_csr_bg_softmax_bwd(const float *att, const float *bg, const int64_t *rowptr, int64_t N, const float *datt, const float *dbg,
+                           float *dL, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(bg_softmax_bwd_kernel, dim3((unsigned)((N + WPB - 1) / WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, att, bg,
+                       rowptr, N, datt, dbg, dL);
+    return dgg_check_launch("csr_bg_softmax_bwd");
+}
+
 
 int dgg_csr_row_sum(const float *vals, const int64_t *rowptr, int64_t N, float *rs, void *stream) {
     if (N == 0) return 0;

@@ -190,6 +190,100 @@ class SAGE_DGG(nn.Module):
         return F.log_softmax(x, dim=-1)
 
 
+class GATConv_DGG(nn.Module):
+    """Attention layer of the GAT_DGG variants (reference model.py:534-577), evaluated WITHOUT the dense [N,N] matrices.
+    The reference sets logit e_ij = leaky_relu(a^T [h_i, h_j]) on the entries of `edge_list`, -1e20 elsewhere, and multiplies
+    by the dense learned adjacency (model.py:564-567).  Consequences that this implementation reproduces exactly:
+      * listed edge that the learned adjacency also holds:  logit e_ij * A_ij
+      * adjacency entry that is NOT in edge_list (e.g. a noisy edge): logit -1e20 * A_ij -> weight 0
+      * every other pair: -1e20 * 0 = -0, i.e. ALL non-neighbours attend with the weight of logit 0
+    so out_i = sum_{u in row i} att_u h_j + bg_i * (sum_all h - sum_{u in row i} h_j) with the row softmax taken over the
+    explicit logits plus N - cnt_i zeros (dgg_csr_bg_softmax_fwd).
+    Dropout (training): on the input, on h and on the explicit attention entries as in the reference; the uniform
+    background weight is kept at its expectation instead of being masked pair by pair."""
+
+    def __init__(self, in_features, out_features, dropout, alpha, bias=True):
+        super().__init__()
+        self.dropout, self.in_features, self.out_features, self.alpha = dropout, in_features, out_features, alpha
+        self.weight = nn.Parameter(torch.FloatTensor(in_features, out_features))
+        self.a = nn.Parameter(torch.zeros(size=(2 * out_features, 1)))
+        if bias:
+            self.bias = nn.Parameter(torch.FloatTensor(out_features))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.weight.data, gain=1.414)
+        if self.bias is not None:
+            self.bias.data.fill_(0)
+        nn.init.xavier_uniform_(self.a.data, gain=1.414)
+
+    @staticmethod
+    def union_pattern(edge_list, adj):
+        """CSR pattern of edge_list UNION the adjacency's pattern; per entry: is it listed, and where is its adjacency value"""
+        N = adj.shape[0]
+        k1 = torch.unique(edge_list[0].long() * N + edge_list[1].long())
+        k2 = adj.erow.long() * N + adj.col.long()                # coalesced: sorted, unique
+        ku = torch.unique(torch.cat([k1, k2]))
+        p1 = torch.searchsorted(k1, ku).clamp(max=k1.numel() - 1)
+        p2 = torch.searchsorted(k2, ku).clamp(max=k2.numel() - 1)
+        listed = k1[p1] == ku
+        apos = torch.where(k2[p2] == ku, p2, torch.full_like(p2, -1))
+        rows, cols = ku // N, (ku % N).to(torch.int32)
+        rowptr = torch._convert_indices_from_coo_to_csr(rows, N, out_int32=False)
+        return rowptr, cols.contiguous(), rows, listed, apos
+
+    def forward(self, x, edge_list, adj, pattern=None):
+        N, Fo = x.shape[0], self.out_features
+        x = F.dropout(x, self.dropout, training=self.training)
+        h = ops.LinearFn.apply(x, self.weight, None, ops.ACT_NONE, 1)
+        rowptr, cols, rows, listed, apos = pattern if pattern is not None else self.union_pattern(edge_list, adj)
+        s = ops.LinearFn.apply(h, self.a.reshape(2, Fo), None, ops.ACT_NONE, 0)             # [N,2]: a1.h_i, a2.h_j
+        e = F.leaky_relu(s[rows, 0] + s[cols.long(), 1], negative_slope=self.alpha)
+        w = torch.where(apos >= 0, adj.values()[apos.clamp(min=0)], torch.zeros_like(e))
+        L = torch.where(listed, e * w, -1e20 * w)
+        att, bg = ops.CsrBgSoftmaxFn.apply(L, rowptr)
+        att = F.dropout(att, self.dropout, training=self.training)
+        h = F.dropout(h, self.dropout, training=self.training)
+        h_prime = ops.CsrSpmmFn.apply(att - bg[rows], rowptr, cols, h) + bg.unsqueeze(1) * h.sum(0, keepdim=True)
+        return h_prime + self.bias if self.bias is not None else h_prime
+
+
+class GAT_DGG_00(nn.Module):
+    """8 attention heads + output head on the encoded features of a `DGG` generator (reference model.py:323-403).  Returns
+    (log_probs, unnorm_adj, x_dgg).  `edge_index` [2,E] is the ORIGINAL edge list (self loops are replaced as by
+    torch_geometric's remove_self_loops / add_self_loops, model.py:386-387); default: the stored entries of in_adj."""
+
+    def __init__(self, nfeat=32, nlayers=None, nhidden=32, nclass=10, args=None, nhead=8, nhead_out=1, alpha=0.2, dropout=0.6,
+                 **kwargs):
+        super().__init__()
+        self.attentions = [GATConv_DGG(nhidden, nhidden, dropout=dropout, alpha=alpha) for _ in range(nhead)]
+        self.out_atts = [GATConv_DGG(nhidden * nhead, nclass, dropout=dropout, alpha=alpha) for _ in range(nhead_out)]
+        self.dgg = DGG(in_dim=nfeat, latent_dim=nhidden, args=args)
+        for i, attention in enumerate(self.attentions):
+            self.add_module("attention_{}".format(i), attention)
+        for i, attention in enumerate(self.out_atts):
+            self.add_module("out_att{}".format(i), attention)
+
+    normalize_adj = staticmethod(_normalize_adj)
+
+    def forward(self, x, in_adj=None, edge_index=None, epoch=None, writer=None):
+        N = x.size(0)
+        if edge_index is None:
+            edge_index = in_adj.coalesce().indices()
+        edge_index = edge_index[:, edge_index[0] != edge_index[1]]
+        loops = torch.arange(N, device=edge_index.device, dtype=edge_index.dtype)
+        edge_index = torch.cat([edge_index, torch.stack([loops, loops])], 1)
+        in_adj = _with_self_loops(in_adj)
+        unnorm_adj, x_dgg = self.dgg(x=x, adj=in_adj)
+        pattern = GATConv_DGG.union_pattern(edge_index, unnorm_adj)          # shared by every head
+        x = torch.cat([att(x_dgg, edge_index, unnorm_adj, pattern) for att in self.attentions], dim=1)
+        x = F.elu(x)
+        x = torch.sum(torch.stack([att(x, edge_index, unnorm_adj, pattern) for att in self.out_atts]), dim=0) / len(self.out_atts)
+        return F.log_softmax(x, dim=1), unnorm_adj, x_dgg
+
+
 class GCN_DGG_00(nn.Module):
     """Two GCNConv layers on the encoded features of a `DGG` generator (reference model.py:1314-1433).  Returns
     (log_probs, unnorm_adj, x_dgg)."""

@@ -535,3 +535,26 @@ class CsrSpmmFn(torch.autograd.Function):
         a, rowptr, col, X = ctx.saved_tensors
         dA, dX = csr_spmm_bwd(rowptr, col, a, X, dY.contiguous(), need_dx=ctx.needs_input_grad[3])
         return dA, None, None, dX
+
+
+class CsrBgSoftmaxFn(torch.autograd.Function):
+    """Row softmax of a dense logit matrix given by explicit logits L [E] on a CSR pattern plus N - cnt_i background
+    logits of 0 per row (GATConv_DGG, model.py:565-569) -> att [E], bg [N]."""
+
+    @staticmethod
+    def forward(ctx, L, rowptr):
+        L = _chk(L)
+        N = rowptr.shape[0] - 1
+        att = torch.empty_like(L)
+        bg = torch.empty((N,), device=L.device, dtype=torch.float32)
+        _lib.check(_lib.lib().dgg_csr_bg_softmax_fwd(_ptr(L), _ptr(rowptr), N, _ptr(att), _ptr(bg), _stream()), "csr_bg_softmax_fwd")
+        ctx.save_for_backward(att, bg, rowptr)
+        return att, bg
+
+    @staticmethod
+    def backward(ctx, datt, dbg):
+        att, bg, rowptr = ctx.saved_tensors
+        dL = torch.empty_like(att)
+        _lib.check(_lib.lib().dgg_csr_bg_softmax_bwd(_ptr(att), _ptr(bg), _ptr(rowptr), bg.shape[0], _ptr(_chk(datt.contiguous())),
+                                                     _ptr(_chk(dbg.contiguous())), _ptr(dL), _stream()), "csr_bg_softmax_bwd")
+        return dL, None

@@ -75,11 +75,15 @@ def accuracy(out, y):
 
 
 def forward(model, x, adj, **kw):
-    """the wrappers differ in what their forward accepts and returns (reference model.py:1236 vs 1368)"""
-    try:
-        out = model(x, adj, **kw)
-    except TypeError:
-        out = model(x, adj)
+    """the wrappers differ in what their forward accepts and returns (reference model.py:1236 vs 1368): the script's call
+    (features, adj, edge_index=..., epoch=..., writer=...) is tried first, then without the keywords a wrapper rejects"""
+    for drop in ((), ("edge_index",), ("edge_index", "epoch", "writer")):
+        try:
+            out = model(x, adj, **{k: v for k, v in kw.items() if k not in drop})
+            break
+        except TypeError as e:
+            if "unexpected keyword" not in str(e):
+                raise
     return out[0] if isinstance(out, tuple) else out
 
 
@@ -95,6 +99,7 @@ def main(argv=None):
     y = torch.from_numpy(d["y"]).to(device)
     idx = {k: torch.from_numpy(d[k]).to(device) for k in ("train_idx", "val_idx", "test_idx")}
     adj = make_adjacency(d, args.edge_noise_level, device)
+    edge_index = torch.from_numpy(np.stack([d["rows"], d["cols"]]).astype(np.int64)).to(device)      # data.edge_index
     model = models.__dict__[args.model](nfeat=x.shape[1], nlayers=args.layer, nhidden=args.hidden, nclass=d["num_classes"],
                                         dropout=args.dropout, lamda=args.lamda, alpha=args.alpha, variant=args.variant,
                                         args=args).to(device)
@@ -110,13 +115,13 @@ def main(argv=None):
     for epoch in range(args.epochs):
         model.train()
         opt.zero_grad()
-        out = forward(model, x, adj, epoch=epoch)
+        out = forward(model, x, adj, edge_index=edge_index, epoch=epoch, writer=None)
         loss = F.nll_loss(out[idx["train_idx"]], y[idx["train_idx"]])
         loss.backward()
         opt.step()
         model.eval()
         with torch.no_grad():
-            out = forward(model, x, adj)
+            out = forward(model, x, adj, edge_index=edge_index)
             lv = float(F.nll_loss(out[idx["val_idx"]], y[idx["val_idx"]]))
             print("Epoch:{:04d}".format(epoch + 1), "train", "loss:{:.3f}".format(float(loss)),
                   "| val loss:{:.3f} acc:{:.2f}".format(lv, 100 * accuracy(out[idx["val_idx"]], y[idx["val_idx"]])),

@@ -261,6 +261,40 @@ def cora_cases():
     print("cora ok: edges", ei.shape[1], "noisy", len(nr), "loss", float(loss), "max row", int(np.bincount(nr).max()))
 
 
+def gat_cases():
+    """GAT_DGG_00 (model.py:323-403) with its dense [N,N] attention; in_adj carries noisy edges that edge_index lacks."""
+    refmodel.remove_self_loops = lambda ei: (ei[:, ei[0] != ei[1]], None)                     # torch_geometric.utils stand-ins
+    refmodel.add_self_loops = lambda ei, num_nodes=None: (torch.cat([ei, torch.arange(num_nodes).repeat(2, 1)], 1), None)
+    N, d, h, C = 140, 20, 8, 4
+    gen = torch.Generator().manual_seed(37)
+    A = random_graph(N, 8, gen).to_dense() - torch.eye(N)
+    ei = A.to_sparse().coalesce().indices()
+    extra = (torch.rand(N, N, generator=gen) < 0.01).float() * (1 - torch.eye(N))
+    in_adj = ((A + extra) > 0).float().to_sparse().coalesce()
+    x = torch.randn(N, d, generator=gen)
+    a = base_args()
+    torch.manual_seed(777)
+    m = refmodel.GAT_DGG_00(nfeat=d, nhidden=h, nclass=C, args=a, nhead=3)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.ndim == 1 and p_.numel() in (h, C):
+                p_.add_(0.1 * torch.randn(p_.shape, generator=gen))     # biases are zero-initialised: make them matter
+    m.eval()
+    logp, unnorm, x_dgg = m(x, in_adj=in_adj, edge_index=ei)
+    cot = torch.from_numpy(grid_normal(81, (N, C)))
+    (logp * cot).sum().backward()
+    fx = {"x": x.numpy(), "rows": in_adj.indices()[0].numpy().astype(np.int32), "cols": in_adj.indices()[1].numpy().astype(np.int32),
+          "adj_vals": in_adj.values().numpy(), "ei": ei.numpy().astype(np.int32), "cot": cot.numpy(), "out": logp.detach().numpy()}
+    for k_, v in m.state_dict().items():
+        fx["p." + k_] = v.detach().numpy()
+    for k_, p_ in m.named_parameters():
+        fx["g." + k_] = p_.grad.numpy() if p_.grad is not None else np.zeros_like(p_.detach().numpy())
+    meta = dict(name="model_gat_dgg_00", N=N, d=d, h=h, C=C, nhead=3, torch=torch.__version__, args=vars(a))
+    fx["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "model_gat_dgg_00.npz"), **fx)
+    print("model_gat_dgg_00 ok", tuple(logp.shape), "keys", len(m.state_dict()))
+
+
 def allpairs_cases():
     N, d, h = 256, 32, 16
     gen = torch.Generator().manual_seed(8)
@@ -345,6 +379,8 @@ if __name__ == "__main__":
         dggclass_cases()
     if "cora" in which:
         cora_cases()
+    if "gat" in which:
+        gat_cases()
 
 
 def model_cases():

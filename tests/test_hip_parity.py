@@ -790,7 +790,8 @@ def test_small_graph_harness_trains_on_planetoid_files(dev, tmp_path):
 
     H.F.nll_loss = spy
     try:
-        for model, extra in [("GCN_DGG_00", []), ("GCN_DGG", ["--dgg_mode_edge_net", "u-v-deg", "--extra_edge_dim", "2"])]:
+        for model, extra in [("GCN_DGG_00", []), ("GCN_DGG", ["--dgg_mode_edge_net", "u-v-deg", "--extra_edge_dim", "2"]),
+                             ("GAT_DGG_00", []), ("SAGE_DGG", ["--dgg_mode_edge_net", "u-v-dist"])]:
             losses.clear()
             H.main(["--data", "toy", "--data_dir", str(tmp_path), "--model", model, "--hidden", "16", "--epochs", "12",
                     "--edge_noise_level", "0.001", "--lr", "0.02"] + extra)
@@ -832,3 +833,32 @@ def test_sage_dgg_matches_dense_restatement(dev):
     ref = torch.log_softmax(xx, -1)
     np.testing.assert_allclose(Nn(logp), Nn(ref), rtol=1e-5, atol=2e-5)
     assert all(torch.isfinite(g).all() for g in got.values()) and torch.isfinite(gx).all() and len(got) >= 14
+
+
+def test_gat_dgg_00_matches_reference_golden(dev):
+    """GAT_DGG_00 / GATConv_DGG (model.py:323-403, 534-577): the reference's dense [N,N] attention -- including the
+    -1e20 * 0 = -0 logit that makes every non-neighbour attend -- against the sparse evaluation (explicit entries + uniform
+    background); in_adj carries noisy edges that edge_index lacks (-1e20 * w logits)"""
+    import dgg_amd
+    from argparse import Namespace
+    fx = load_fixture("model_gat_dgg_00")
+    meta = fx["meta"]
+    N, d, h, C = meta["N"], meta["d"], meta["h"], meta["C"]
+    m = dgg_amd.GAT_DGG_00(nfeat=d, nhidden=h, nclass=C, args=Namespace(**meta["args"]), nhead=meta["nhead"])
+    m.load_state_dict({k_[2:]: torch.from_numpy(v) for k_, v in fx.items() if k_.startswith("p.")}, strict=True)
+    m = m.to(dev).eval()
+    ind = torch.from_numpy(np.stack([fx["rows"], fx["cols"]]).astype(np.int64))
+    A = torch.sparse_coo_tensor(ind, torch.from_numpy(fx["adj_vals"]), (N, N)).coalesce().to(dev)
+    ei = torch.from_numpy(fx["ei"].astype(np.int64)).to(dev)
+    logp, unnorm, x_dgg = m(T(fx["x"], dev), in_adj=A, edge_index=ei)
+    np.testing.assert_allclose(Nn(logp), fx["out"], rtol=1e-5, atol=2e-5)
+    (logp * T(fx["cot"], dev)).sum().backward()
+    checked = 0
+    for k_, p_ in m.named_parameters():
+        ref = fx["g." + k_]
+        if np.abs(ref).max() == 0:
+            continue
+        err = np.abs(Nn(p_.grad).reshape(ref.shape) - ref).max() / np.abs(ref).max()
+        assert err <= 3e-4, f"grad {k_}: {err:.3e}"
+        checked += 1
+    assert checked >= 15
