@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
     uint64_t list = DGG_EMPTY_KEY;
     uint64_t S = 0;                                              // fixed-point prefix sum carried across blocks
     uint32_t scount = 0;                                         // ranks assigned so far
+    float thr_log = -INFINITY;                                   // log of the L-th best score so far (-inf: list not full)
     for (uint64_t rb = 0; rb < D; rb += 64) {
         const uint32_t c = ranked_sigma((uint32_t)(rb + lane), k1, k2, k3, b);
         const bool valid = (int64_t)c < N;
@@ -58,7 +59,9 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
         uint64_t pre = wave_inclusive_scan_u64(term, lane) + S;
         float G = ranked_gumbel(pre);
         uint64_t key = DGG_EMPTY_KEY;
-        if (valid) {
+        // per-candidate version of the stop test: a rank whose noise cannot reach the L-th log-score found so far is
+        // not gathered at all (ranks come in decreasing noise order, so these are the tail lanes of the block)
+        if (valid && !(G + 1e-8f + 1e-3f < thr_log)) {
             const float4 *xj = reinterpret_cast<const float4 *>(xp + (int64_t)c * H);
             float d2 = 0.0f;
 #pragma unroll
@@ -85,10 +88,11 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
         // stop test: the lowest noise of this block bounds every rank still to come
         const uint64_t k63 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(list >> 32), L - 1) << 32) |
                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)list, L - 1);
+        if (k63 != DGG_EMPTY_KEY) thr_log = __logf(key_val(k63));
         if (k63 != DGG_EMPTY_KEY && nvalid > 0) {
             const int last = 63 - __builtin_clzll(m);            // last valid lane = highest rank in the block
             const float gmin = __shfl(G, last, 64);
-            if (gmin + 1e-8f + 1e-3f < __logf(key_val(k63))) break;
+            if (gmin + 1e-8f + 1e-3f < thr_log) break;
         }
     }
     const bool empty = list == DGG_EMPTY_KEY || lane >= L;
