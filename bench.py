@@ -208,6 +208,9 @@ def bench_ppi(a, dev):
     with torch.no_grad():
         for dg in m.dggs:
             dg.k_net.k_project.weight.mul_(0.1)
+    if a.bf16:
+        for conv in m.convs:
+            conv.gemm_dtype = torch.bfloat16
     m.train()
     graphs = []
     for n in sizes:
@@ -240,14 +243,15 @@ def bench_ppi(a, dev):
     print(json.dumps({
         "metric": "DGG adj-build+SpMM fwd/bwd selected-edges/s", "value": cand / T, "unit": "edges/s", "n_gpus": 1,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": T * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16 GEMMs / f32 DGG" if a.bf16 else "f32", "data": "synthetic",
         "config": {"workload": f"PPI-shape multi-graph GCNIIppi_DGG: {len(sizes)} graphs of {int(sizes.min())}..{int(sizes.max())} nodes, "
                                f"d={d}, hidden={hid}, {L} variant GCNII layers, {C} labels, DGG latent {hid} on edge-list candidates "
-                               "(value counts candidate edges), module API under autograd, fwd+bwd, fp32",
+                               "(value counts candidate edges), module API under autograd, fwd+bwd, " + ("bf16 GCNII GEMMs" if a.bf16 else "fp32"),
                    "graphs": len(sizes), "nodes_total": int(sizes.sum()), "graphs_per_s": len(sizes) / T,
                    "gcnii_gemm_tflops": gemm_flop / T / 1e12},
-        "roofline": {"bound": "mfma", "kernel": "linear_fwd_mfma/gemm (GCNII layers)", "achieved": gemm_flop / T / 1e12,
-                     "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_flop / T / 1e12 / FP32_PEAK_TFLOPS, "traffic": None,
+        "roofline": {"bound": "mfma", "kernel": "GCNII layer GEMMs", "achieved": gemm_flop / T / 1e12,
+                     "peak": 2500.0 if a.bf16 else FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": gemm_flop / T / 1e12 / (2500.0 if a.bf16 else FP32_PEAK_TFLOPS), "traffic": None,
                      "note": "whole-step GEMM flops of the GCNII layers / step time (not a single kernel)"}}))
 
 
@@ -295,6 +299,8 @@ def main():
                     help="synthetic = the BASELINE.json metric config (default); pubmed = configs[1], edge-list candidates; "
                          "ppi = configs[4], multi-graph GCNIIppi_DGG (fp32)")
     ap.add_argument("--graphs", type=int, default=4, help="--workload ppi: number of graphs per step")
+    ap.add_argument("--bf16", action="store_true", help="--workload ppi: GCNII layer GEMMs on bf16 operands (library GEMM, fp32 "
+                                                        "accumulate); the DGG path stays fp32")
     ap.add_argument("--edge-mode", default="u-v-dist", choices=["u-v-dist", "u-v-deg", "u-v-A_uv", "u-v-deg-dist", "edge_conv", "A_uv"],
                     help="--workload pubmed: edge scorer (dgm.py:1607-1725)")
     ap.add_argument("--gpus", type=int, default=1)

@@ -48,6 +48,7 @@ class GraphConvolution(nn.Module):
         self.out_features = out_features
         self.residual = residual
         self.weight = Parameter(torch.FloatTensor(self.in_features, self.out_features))
+        self.gemm_dtype = None                     # None: fp32 HIP kernel; torch.bfloat16: library GEMM on bf16 operands
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -63,7 +64,13 @@ class GraphConvolution(nn.Module):
         else:
             support = (1 - alpha) * hi + alpha * h0
             r = support
-        output = theta * ops.LinearFn.apply(support, self.weight, None, ops.ACT_NONE, 1) + (1 - theta) * r
+        if self.gemm_dtype is None:
+            sw = ops.LinearFn.apply(support, self.weight, None, ops.ACT_NONE, 1)          # fp32 matrix cores (HIP)
+        else:
+            # reduced-precision variant (BASELINE configs[4]: "bf16 fwd+bwd"): `support @ weight` is a plain GEMM, run by the
+            # vendor library on bf16 operands with fp32 accumulation; everything around it stays fp32
+            sw = torch.matmul(support.to(self.gemm_dtype), self.weight.to(self.gemm_dtype)).float()
+        output = theta * sw + (1 - theta) * r
         if self.residual:
             output = output + input
         return output
