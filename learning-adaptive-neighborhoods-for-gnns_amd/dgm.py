@@ -206,7 +206,10 @@ class DGG_LearnableK_debug(nn.Module):
             seed = (int(s[0]), int(s[1]))
         # asymmetric noise: the ranked generator (rows produced in decreasing order -> early-stopping top-k search);
         # symmetric noise (dgm.py:1216-1223) must be keyed on the unordered pair -> per-pair hash
-        return (ops.NOISE_HASH_SYM if self.args.symmetric_noise else ops.NOISE_RANKED), None, seed
+        if self.args.symmetric_noise:
+            return ops.NOISE_HASH_SYM, None, seed
+        # the ranked generator's row search is written for the full 64-wide list
+        return (ops.NOISE_RANKED if self.ell_width == 64 else ops.NOISE_HASH), None, seed
 
     def _edge_mlp_terms(self, avals):
         """The reference's scorer parameters in the per-node / per-edge form of dgg_edge_mlp_fwd (differentiable slicing).

@@ -862,3 +862,34 @@ def test_gat_dgg_00_matches_reference_golden(dev):
         assert err <= 3e-4, f"grad {k_}: {err:.3e}"
         checked += 1
     assert checked >= 15
+
+
+@pytest.mark.parametrize("N,width", [(5, 64), (70, 64), (200, 32), (131, 16)])
+def test_module_small_graphs_and_narrow_ell(dev, N, width):
+    """all-pairs module on tiny graphs (N < 64: rows hold fewer than K entries) and with a narrower ELL (dgg_ell_width):
+    forward finite, padding consistent, backward finite, weights identical to the oracle's soft top-k on the same scores"""
+    import dgg_amd
+    from argparse import Namespace
+    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1, dgg_ell_width=width)
+    torch.manual_seed(N)
+    m = dgg_amd.DGG_LearnableK_debug(in_dim=12, latent_dim=16, args=args).to(dev)
+    with torch.no_grad():
+        m.k_net.k_project.weight.mul_(0.05)
+    m.set_seed(3, 4)
+    x = torch.randn(N, 12, device=dev, requires_grad=True)
+    deg = 3 + 2 * torch.rand(N, device=dev)
+    adj = m(x, dgg_amd.AllPairs(deg))
+    idx, w, val = Nn(adj.idx), Nn(adj.values()), Nn(adj.score)
+    assert idx.shape == (N, width) and np.isfinite(w).all()
+    valid = idx >= 0
+    assert (valid.sum(1) <= min(N, width)).all() and (w[~valid] == 0).all() and (idx[valid] < N).all()
+    for i in range(N):                                            # no duplicate neighbour in a row
+        assert len(set(idx[i][valid[i]].tolist())) == int(valid[i].sum())
+    rw, _ = O.softk(idx, val, Nn(adj.k), 0)
+    assert np.array_equal(w, rw)
+    norm = adj.normalize()
+    out = norm.matmul(x)
+    out.sum().backward()
+    assert torch.isfinite(x.grad).all() and all(torch.isfinite(p_.grad).all() for p_ in m.parameters() if p_.grad is not None)
