@@ -658,6 +658,16 @@ def test_sddmm_fused_with_normalisation_backward(dev, F):
     np.testing.assert_allclose(Nn(dA), rdA, rtol=1e-4, atol=1e-4 * np.abs(rdA).max())
     da_ref = ops.norm_bwd_da(T(idx, dev), T(w, dev), T(rs, dev), T(rdA, dev))          # atomic path, itself oracle-checked
     np.testing.assert_allclose(Nn(da), Nn(da_ref), rtol=3e-4, atol=3e-4 * np.abs(Nn(da_ref)).max())
+    # sharded use: two row ranges with their own partitions, global columns / row sums; partial da's add up
+    r0 = 217
+    tot = 0
+    for lo, hi in [(0, r0), (r0, N)]:
+        pt = ops.part_build(T(idx[lo:hi], dev), T(w[lo:hi], dev), N)
+        dA_s, da_s = ops.sddmm_norm(T(idx[lo:hi], dev), T(ahat[lo:hi], dev), T(w[lo:hi], dev), T(rs, dev), T(X, dev), T(dY[lo:hi], dev),
+                                    lo, pt, True)
+        np.testing.assert_allclose(Nn(dA_s), rdA[lo:hi], rtol=1e-4, atol=1e-4 * np.abs(rdA).max())
+        tot = tot + da_s
+    np.testing.assert_allclose(Nn(tot), Nn(da_ref), rtol=3e-4, atol=3e-4 * np.abs(Nn(da_ref)).max())
 
 
 def test_wide_latent_edge_list_pipeline(dev):
