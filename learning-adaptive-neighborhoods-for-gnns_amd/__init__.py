@@ -10,4 +10,4 @@ from . import _lib, ops  # noqa: F401
 from .adjacency import AllPairs, CsrAdjacency, EllAdjacency, csr_candidates, csr_pattern, ell_from_dense  # noqa: F401
 from .dgm import DGG, DGG_LearnableK_debug, LearnableKEncoder  # noqa: F401
 from .model import (DenseGraphConv, DenseGraphConvolution, GAT_DGG_00, GATConv_DGG, GCN_DGG, GCN_DGG_00, GCNConv, GCNII_DGG, GCNIIppi_DGG,  # noqa: F401
-                    GraphConvolution, SAGE_DGG)
+                    GraphConvolution, SAGE_DGG, SAGE_DGG_00)

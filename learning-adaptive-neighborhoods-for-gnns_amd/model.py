@@ -291,6 +291,37 @@ class GAT_DGG_00(nn.Module):
         return F.log_softmax(x, dim=1), unnorm_adj, x_dgg
 
 
+class SAGE_DGG_00(nn.Module):
+    """Two DenseGraphConv(mean) layers on the encoded features of a `DGG` generator (reference model.py:196-283; the PyG
+    layer is restated, see DenseGraphConv).  Returns (log_probs, unnorm_adj, x_dgg)."""
+
+    def __init__(self, nfeat=32, nlayers=None, nhidden=32, nclass=10, args=None, **kwargs):
+        super().__init__()
+        self.convs = nn.ModuleList([DenseGraphConv(nhidden, nhidden, aggr="mean"), DenseGraphConv(nhidden, nclass, aggr="mean")])
+        self.dgg_adj_input = args.dgg_adj_input
+        self.dggs = nn.ModuleList([DGG(in_dim=nfeat, latent_dim=nhidden, args=args)])
+
+    normalize_adj = staticmethod(_normalize_adj)
+
+    def dgg_net(self, x, i, unnorm_adj, writer, epoch):
+        return self.dggs[i](x=x, adj=unnorm_adj, noise=False, writer=writer, epoch=epoch)
+
+    def forward(self, x, in_adj, noise=True, epoch=None, writer=None, **kwargs):
+        in_adj = _with_self_loops(in_adj)
+        unnorm_adj = in_adj
+        norm_adj = x_dgg = None
+        for i, conv in enumerate(self.convs):
+            if i < len(self.dggs):
+                src = in_adj if self.dgg_adj_input == "input_adj" else unnorm_adj
+                unnorm_adj, x_dgg = self.dgg_net(x, i, src, writer, epoch)
+                norm_adj = _normalize_adj(unnorm_adj)
+                x = x_dgg
+            x = conv(x, norm_adj)
+            if i < len(self.convs) - 1:
+                x = F.dropout(torch.relu(x), p=0.5, training=self.training)
+        return F.log_softmax(x, dim=-1), unnorm_adj, x_dgg
+
+
 class GCN_DGG_00(nn.Module):
     """Two GCNConv layers on the encoded features of a `DGG` generator (reference model.py:1314-1433).  Returns
     (log_probs, unnorm_adj, x_dgg)."""

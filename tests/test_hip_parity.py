@@ -801,7 +801,7 @@ def test_small_graph_harness_trains_on_planetoid_files(dev, tmp_path):
     H.F.nll_loss = spy
     try:
         for model, extra in [("GCN_DGG_00", []), ("GCN_DGG", ["--dgg_mode_edge_net", "u-v-deg", "--extra_edge_dim", "2"]),
-                             ("GAT_DGG_00", []), ("SAGE_DGG", ["--dgg_mode_edge_net", "u-v-dist"])]:
+                             ("GAT_DGG_00", []), ("SAGE_DGG", ["--dgg_mode_edge_net", "u-v-dist"]), ("SAGE_DGG_00", [])]:
             losses.clear()
             H.main(["--data", "toy", "--data_dir", str(tmp_path), "--model", model, "--hidden", "16", "--epochs", "12",
                     "--edge_noise_level", "0.001", "--lr", "0.02"] + extra)
