@@ -7,6 +7,9 @@
  *     Gumbel perturbation                   dgm.py:1211-1231, gumbel_sample 14-29
  *     k_estimate_net mode "x" / "input_deg" dgm.py:1562-1586 / 1509-1526, LearnableKEncoder 2029-2063
  *     select_top_k   "k_times_edge_prob" / "k_only"   dgm.py:1402-1435
+ *     edge_prob_net  edge-MLP modes          dgm.py:1628-1725 (u-v-A_uv, u-v-deg, u-v-deg-dist, edge_conv, A_uv)
+ *     k_estimate_net "learn_normalized_degree" / "gcn-x-deg"   dgm.py:1492-1507 / 1528-1560
+ *   DGG.forward ("for ICLR", every edge kept) dgm.py:1758-1815 on a CSR-valued adjacency
  *   normalize_adj                           model.py:1205-1219
  *   GCNConv / GraphConvolution aggregation  model.py:580-599, 32-44
  * in the sparse "top-K per row" formulation that SURVEY.md section 0/8(a) shows to be bit-identical to the
