@@ -152,7 +152,55 @@ __global__ __launch_bounds__(64) void gv_sweep(int64_t N, int64_t row0, int64_t 
         }
         for (int64_t j = NB; j < c_hi; j++) col_step((uint32_t)j);
     } else {
-        for (int64_t j = c_lo; j < c_hi; j++) col_step((uint32_t)j);
+        // symmetric noise is keyed on (min, max) (dgm.py:1216-1223).  For the 64 rows of this wavefront the columns split
+        // into j < every row (key = the COLUMN's: wave-uniform, computed on the scalar unit; the row id is hashed),
+        // j > every row (key = the row's: the asymmetric loop) and the <= 64 columns in between (generic step).
+        const int64_t i_first = row0 + (int64_t)blockIdx.x * 64, i_last = i_first + 63;
+        const int64_t below_hi = c_hi < i_first ? c_hi : (i_first > c_lo ? i_first : c_lo);      // [c_lo, below_hi): j < i
+        const int64_t above_lo = i_last + 1 > c_lo ? (i_last + 1 < c_hi ? i_last + 1 : c_hi) : c_lo;   // [above_lo, c_hi): j > i
+        int64_t j0 = c_lo;
+        for (; j0 + UB <= below_hi; j0 += UB) {
+            uint32_t x[UB];
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                uint32_t kj1, kj2;
+                rowkey(s0, s1, (uint32_t)(j0 + u), kj1, kj2);    // scalar ALU
+                uint32_t v = iu ^ kj1;
+                v *= 0x7feb352dU; v ^= v >> 15; v += kj2; v *= 0x846ca68bU;
+                x[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; u++) asm volatile("" : "+v"(x[u]));
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                if (x[u] >= ta) {
+                    if (cnt < CAPS) pend[cnt] = (int)(j0 + u);
+                    cnt++;
+                }
+            }
+        }
+        int64_t mid_hi = above_lo > j0 ? above_lo : j0;
+        // align the start of the "above" loop so that its unrolled body covers whole groups; leftovers go generic
+        for (; j0 < mid_hi; j0++) col_step((uint32_t)j0);
+        for (; j0 + UB <= c_hi; j0 += UB) {
+            uint32_t x[UB];
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                uint32_t v = (uint32_t)(j0 + u) ^ k1;
+                v *= 0x7feb352dU; v ^= v >> 15; v += k2; v *= 0x846ca68bU;
+                x[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; u++) asm volatile("" : "+v"(x[u]));
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                if (x[u] >= ta) {
+                    if (cnt < CAPS) pend[cnt] = (int)(j0 + u);
+                    cnt++;
+                }
+            }
+        }
+        for (; j0 < c_hi; j0++) col_step((uint32_t)j0);
     }
     if (rvalid) cnt_g[lrow * NSEG + seg] = cnt;
 }
@@ -213,80 +261,47 @@ __global__ __launch_bounds__(256) void gv_finalize(const float *__restrict__ xp,
     }
 }
 
-// K3: adaptive noise prefilter on the rows of the fail list (lane = listed row); same algorithm as dgg_topk_np.hip
-constexpr int STEP = 8, FLUSH_AT = 56;
-__device__ __forceinline__ uint32_t noise_threshold_gv(float pp63) { return hash_threshold_from_gmin(__logf(pp63)); }
-
+// K3: the rows of the fail list are redone from scratch, one workgroup per row with LANE = COLUMN: every wavefront sweeps
+// a quarter of the columns 64 at a time -- noise first, exact score only while the noise can still reach the wavefront's
+// 64th log-score -- and the four lists are merged through LDS.  (A failing row is rare -- a handful in 100 000 -- but a
+// serial per-row sweep of all N columns would put milliseconds on the critical path for it.)
 template <int H, bool SYM>
-__global__ __launch_bounds__(64) void gv_fallback(const float *__restrict__ xp, int64_t N, int64_t row0, float t,
-                                                  uint32_t s0, uint32_t s1, const GvCtl *ctl, int *__restrict__ pend_g,
+__global__ __launch_bounds__(256) void gv_fallback(const float *__restrict__ xp, int64_t N, int64_t row0, float t,
+                                                  uint32_t s0, uint32_t s1, const GvCtl *ctl,
                                                   const int *__restrict__ faillist, int32_t *__restrict__ idx,
                                                   float *__restrict__ val) {
-    const int lane = threadIdx.x;
+    __shared__ uint64_t lists[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nfail = ctl->nfail;
-    const int base = blockIdx.x * 64;
-    if (base >= nfail) return;                                   // the usual case: nothing to redo
-    const bool rvalid = base + lane < nfail;
-    const int lrow = faillist[rvalid ? base + lane : base];
-    const uint32_t iu = (uint32_t)(row0 + lrow);
-    int *pend = pend_g + (int64_t)lrow * CAPF;
-    uint32_t k1, k2;
-    rowkey(s0, s1, iu, k1, k2);
-    uint32_t ta = rvalid ? 0u : 0xffffffffu;
-    int cnt = 0;
-    if (rvalid) { /* empty list */ }
-    for (int e = 0; e < 64; e++) {
-        int lr = __shfl(lrow, e, 64);
-        bool v = e + base < nfail;
-        if (v) { idx[(int64_t)lr * 64 + lane] = -1; val[(int64_t)lr * 64 + lane] = 0.0f; }
-    }
-    auto do_flush = [&](int fl) {
-        const int frow = __shfl(lrow, fl, 64);
-        const int64_t fi = row0 + frow;
-        const int n = __shfl(cnt, fl, 64);
-        const int *pl = pend_g + (int64_t)frow * CAPF;
-        int32_t li = idx[(int64_t)frow * 64 + lane];
-        float lv = val[(int64_t)frow * 64 + lane];
-        uint64_t list = li >= 0 ? make_key(lv, li) : DGG_EMPTY_KEY;
-        int32_t j = lane < n ? pl[lane] : -1;
-        uint64_t key = DGG_EMPTY_KEY;
-        if (j >= 0) key = make_key(exact_score_gv<H>(xp, fi, j, t, SYM, s0, s1), j);
-        key = wave_sort<false>(key, lane);
-        list = wave_merge_top64_asc(list, key, lane);
-        bool empty = list == DGG_EMPTY_KEY;
-        idx[(int64_t)frow * 64 + lane] = empty ? -1 : key_col(list);
-        val[(int64_t)frow * 64 + lane] = empty ? 0.0f : key_val(list);
-        uint64_t k63 = shfl_u64(list, 63);
-        if (lane == fl) {
-            cnt = 0;
-            if (k63 != DGG_EMPTY_KEY) ta = noise_threshold_gv(key_val(k63));
+    for (int f = blockIdx.x; f < nfail; f += gridDim.x) {
+        const int lrow = faillist[f];
+        const int64_t i = row0 + lrow;
+        uint64_t list = DGG_EMPTY_KEY;
+        float thr = -INFINITY;
+        for (int64_t j0 = (int64_t)wave * 64; j0 < N; j0 += 256) {
+            const int64_t j = j0 + lane;
+            uint64_t key = DGG_EMPTY_KEY;
+            if (j < N) {
+                const float g = pair_noise(s0, s1, (uint32_t)i, (uint32_t)j, SYM);
+                if (!(g + 1e-8f + 1e-3f < thr)) key = make_key(exact_score_gv<H>(xp, i, (int32_t)j, t, SYM, s0, s1), (int32_t)j);
+            }
+            if (__ballot(key != DGG_EMPTY_KEY) != 0ull) {
+                key = wave_sort<false>(key, lane);
+                list = wave_merge_top64_asc(list, key, lane);
+                const uint64_t k63 = shfl_u64(list, 63);
+                if (k63 != DGG_EMPTY_KEY) thr = __logf(key_val(k63));
+            }
         }
-    };
-    auto col_step = [&](uint32_t j) {
-        uint32_t x;
-        if (!SYM) {
-            x = j ^ k1;
-            x *= 0x7feb352dU; x ^= x >> 15; x += k2; x *= 0x846ca68bU;
-        } else {
-            uint32_t kj1, kj2;
-            rowkey(s0, s1, j, kj1, kj2);
-            uint32_t xa = pair_u24_keyed(k1, k2, j) << 8;
-            uint32_t xb = pair_u24_keyed(kj1, kj2, iu) << 8;
-            x = j > iu ? xa : xb;
-            if (j == iu) x = 0xffffffffu;
+        lists[wave][lane] = list;
+        __syncthreads();
+        if (wave == 0) {
+            for (int w = 1; w < 4; w++) list = wave_merge_top64_asc(list, wave_sort<false>(lists[w][lane], lane), lane);
+            const bool empty = list == DGG_EMPTY_KEY;
+            idx[(int64_t)lrow * 64 + lane] = empty ? -1 : key_col(list);
+            val[(int64_t)lrow * 64 + lane] = empty ? 0.0f : key_val(list);
         }
-        if (x >= ta && rvalid) { pend[cnt] = (int)j; cnt++; }   // rvalid: padding lanes alias a listed row's buffer
-    };
-    const int64_t Nfull = N / STEP * STEP;
-    for (int64_t j0 = 0; j0 < Nfull; j0 += STEP) {
-#pragma unroll
-        for (int u = 0; u < STEP; u++) col_step((uint32_t)(j0 + u));
-        uint64_t need = __ballot(cnt >= FLUSH_AT);
-        while (need) { int fl = __builtin_ctzll(need); need &= need - 1; do_flush(fl); }
+        __syncthreads();
     }
-    for (int64_t j = Nfull; j < N; j++) col_step((uint32_t)j);
-    uint64_t need = __ballot(cnt > 0 && rvalid);
-    while (need) { int fl = __builtin_ctzll(need); need &= need - 1; do_flush(fl); }
 }
 
 template <int H>
@@ -308,8 +323,8 @@ int launch_gv(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, i
     dim3 gfin((unsigned)((R + 3) / 4));
     if (sym) hipLaunchKernelGGL((gv_finalize<H, true>), gfin, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, ctl, pend, cnt, faillist, idx, val);
     else hipLaunchKernelGGL((gv_finalize<H, false>), gfin, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, ctl, pend, cnt, faillist, idx, val);
-    if (sym) hipLaunchKernelGGL((gv_fallback<H, true>), gsweep, dim3(64), 0, st, xp, N, row0, t, s0, s1, ctl, pend, faillist, idx, val);
-    else hipLaunchKernelGGL((gv_fallback<H, false>), gsweep, dim3(64), 0, st, xp, N, row0, t, s0, s1, ctl, pend, faillist, idx, val);
+    if (sym) hipLaunchKernelGGL((gv_fallback<H, true>), gsweep, dim3(256), 0, st, xp, N, row0, t, s0, s1, ctl, faillist, idx, val);
+    else hipLaunchKernelGGL((gv_fallback<H, false>), gsweep, dim3(256), 0, st, xp, N, row0, t, s0, s1, ctl, faillist, idx, val);
     return dgg_check_launch("allpairs_topk_gv");
 }
 
