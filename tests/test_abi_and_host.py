@@ -83,3 +83,14 @@ def test_ops_refuse_cpu_tensors_and_unsupported_modes():
     m = dgg_amd.DGG_LearnableK_debug(8, 16, args)
     with pytest.raises(Exception, match="mode not found"):      # reference dgm.py:1726-1727
         m(torch.zeros(4, 8), dgg_amd.AllPairs(torch.ones(4)))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """no CPU fallback: importing the package without libdgg_hip.so must raise as soon as a kernel is requested"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import dgg_amd; "
+            "\ntry:\n    dgg_amd._lib.lib()\n    print('LOADED')\nexcept dgg_amd._lib.DggHipError as e:\n    print('RAISED', 'no CPU fallback' in str(e))") % ROOT
+    env = dict(os.environ, DGG_HIP_SO=str(tmp_path / "nope" / "libdgg_hip.so"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert "RAISED True" in r.stdout, r.stdout + r.stderr
