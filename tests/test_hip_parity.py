@@ -903,3 +903,41 @@ def test_module_small_graphs_and_narrow_ell(dev, N, width):
     out = norm.matmul(x)
     out.sum().backward()
     assert torch.isfinite(x.grad).all() and all(torch.isfinite(p_.grad).all() for p_ in m.parameters() if p_.grad is not None)
+
+
+def test_full_size_ranked_step_properties(dev):
+    """BASELINE-size (N=100k, d=128, h=64, k~32) step of the bench: ranked-noise search with k_limit checked on sampled rows
+    against the oracle (which generates the row's full noise vector and scores all N columns), list invariants, finite
+    gradients, and the SpMM output checked on sampled rows"""
+    import bench
+    from dgg_amd import ops
+    from dgg_amd.parallel import ShardedDGGConv
+    N, d, h = 100_000, 128, 64
+    P = bench.make_params(d, h, dev)
+    g = torch.Generator(device="cpu").manual_seed(1000)
+    x = torch.randn(N, d, generator=g).to(dev)
+    deg = (24 + 16 * torch.rand(N, generator=torch.Generator().manual_seed(7))).to(dev)
+    layer = ShardedDGGConv(ops, N, K=64, noise_mode=ops.NOISE_RANKED, seed=(1234, 0))
+    Z = layer.forward(x, deg, P)
+    grads = layer.backward(torch.ones_like(Z), x, P)
+    assert torch.isfinite(Z).all() and all(torch.isfinite(v).all() for v in grads.values())
+    s = layer.saved
+    idx, val, k = s["idx"], s["val"], s["k"]
+    kept = idx >= 0
+    L = torch.clamp(torch.ceil(k + 8.5) + 1, max=64)
+    assert torch.equal(kept.sum(1).float(), L), "every row keeps exactly the ranks that can carry weight"
+    vv = torch.where(kept, val, torch.full_like(val, -1.0))
+    assert (vv[:, :-1] >= vv[:, 1:]).all(), "scores are sorted"
+    srt = torch.where(kept, idx, torch.arange(64, device=dev, dtype=idx.dtype)[None, :] - 100).sort(dim=1).values
+    assert (srt[:, 1:] != srt[:, :-1]).all(), "duplicate column in a row"
+    xp_c, X_c = s["xp"].cpu().numpy(), x.cpu().numpy()
+    ah, Y = s["ahat"].cpu().numpy(), s["Y"].cpu().numpy()
+    for r in [0, 77, 4097, 50_001, 99_999]:
+        ri, rv = O.allpairs_topk(xp_c, K=K, noise_mode=O.NOISE_RANKED, seed=(1234, 0), rows=(r, r + 1))
+        m = Nn(kept[r])
+        assert np.array_equal(Nn(idx[r])[m], ri[0][m]) and np.array_equal(Nn(val[r])[m], rv[0][m])
+        yr = np.zeros(d, np.float32)
+        for q in range(64):                                        # fmaf chain in rank order, as the oracle's SpMM
+            if Nn(idx[r])[q] >= 0:
+                yr = np.float32(ah[r, q]) * X_c[Nn(idx[r])[q]] + yr
+        np.testing.assert_allclose(Y[r], yr, rtol=1e-5, atol=1e-6)
