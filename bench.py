@@ -192,6 +192,51 @@ def bench_edgelist(a, dev):
     print(json.dumps(out))
 
 
+def bench_module_api(a, dev):
+    """The headline configuration through the DROP-IN MODULES under torch autograd (DGG_LearnableK_debug with all-pairs
+    candidates -> normalize -> GCNConv, forward + backward): what a training script that swaps the imports gets, next to
+    the hand-scheduled step of the default workload.  Run with --workload synthetic-module."""
+    import dgg_amd
+    from argparse import Namespace
+    N, d, h = a.nodes, a.feat, a.latent
+    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
+    torch.manual_seed(0)
+    dgg = dgg_amd.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=args)
+    conv = dgg_amd.GCNConv(d, 64)
+    with torch.no_grad():
+        dgg.k_net.k_project.weight.mul_(0.1)
+    dgg, conv = dgg.to(dev), conv.to(dev)
+    dgg.set_seed(1234, 0)
+    x = torch.randn(N, d, generator=torch.Generator().manual_seed(1000)).to(dev)
+    cand = dgg_amd.AllPairs((24 + 16 * torch.rand(N, generator=torch.Generator().manual_seed(7))).to(dev))
+    params = list(dgg.parameters()) + list(conv.parameters())
+
+    def step():
+        for p_ in params:
+            p_.grad = None
+        adj = dgg(x, cand)
+        conv(x, adj.normalize()).sum().backward()
+        return adj
+
+    for _ in range(a.warmup):
+        adj = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        adj = step()
+    torch.cuda.synchronize()
+    T = (time.perf_counter() - t0) / a.steps
+    kmean = float(adj.k.mean().item())
+    print(json.dumps({
+        "metric": METRIC, "value": N * kmean / T, "unit": "edges/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": T * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"synthetic all-pairs DGG N={N} d={d} h={h} k~{kmean:.1f} through the drop-in modules under torch "
+                               "autograd (DGG_LearnableK_debug + normalize + GCNConv), fwd+bwd, eager launches",
+                   "nodes": N, "feat": d, "latent": h}, "roofline": None}))
+
+
 def bench_ppi(a, dev):
     """BASELINE.json configs[4] (PPI shape: graphs of 591..3480 nodes, d=50, hidden 2048, 9 GCNII layers, 121 labels,
     train_ppi.py:43-44): dgg_amd.GCNIIppi_DGG under autograd, one forward + backward per graph, fp32 (the bf16 variant
@@ -297,7 +342,7 @@ def cpu_baseline_edgelist(N, d, h, rows, cols, x, vals, dgg, conv, threads):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["synthetic", "pubmed", "ppi"], default="synthetic",
+    ap.add_argument("--workload", choices=["synthetic", "synthetic-module", "pubmed", "ppi"], default="synthetic",
                     help="synthetic = the BASELINE.json metric config (default); pubmed = configs[1], edge-list candidates; "
                          "ppi = configs[4], multi-graph GCNIIppi_DGG (fp32)")
     ap.add_argument("--graphs", type=int, default=4, help="--workload ppi: number of graphs per step")
@@ -340,6 +385,9 @@ def main():
     if a.workload == "pubmed":
         assert world == 1, "--workload pubmed is a single-GPU measurement"
         return bench_edgelist(a, dev)
+    if a.workload == "synthetic-module":
+        assert world == 1, "--workload synthetic-module is a single-GPU measurement"
+        return bench_module_api(a, dev)
     if a.workload == "ppi":
         assert world == 1, "--workload ppi is a single-GPU measurement (graphs are independent: replicas across GPUs)"
         return bench_ppi(a, dev)

@@ -24,9 +24,10 @@ class AllPairs:
 class EllAdjacency:
     """Row-major fixed-width sparse matrix: entry (i, idx[i,r]) = values[i,r]; idx == -1 marks padding."""
 
-    def __init__(self, idx, values, n_cols, rs=None, k=None, score=None, normalized=False):
+    def __init__(self, idx, values, n_cols, rs=None, k=None, score=None, normalized=False, part=None):
         self.idx, self._values, self.n_cols = idx, values, n_cols
         self.rs, self.k, self.score, self.normalized = rs, k, score, normalized
+        self.part = part            # destination-ordered partition of the active entries (ops.part_build), if one was built
         self.shape = (idx.shape[0], n_cols)
         self.device = idx.device
 
@@ -61,8 +62,8 @@ class EllAdjacency:
     def normalize(self):
         """D^-1/2 A D^-1/2 with ROW sums on both sides (normalize_adj, model.py:1205-1219)."""
         rs = self.row_sums()
-        ahat = ops.EllNormalizeFn.apply(self._values, self.idx, rs)
-        return EllAdjacency(self.idx, ahat, self.n_cols, rs=None, k=self.k, score=self.score, normalized=True)
+        ahat = ops.EllNormalizeFn.apply(self._values, self.idx, rs, self.part)
+        return EllAdjacency(self.idx, ahat, self.n_cols, rs=None, k=self.k, score=self.score, normalized=True, part=self.part)
 
     def matmul(self, X):
         """A @ X (torch.mm(adj, x), model.py:594)."""

@@ -95,6 +95,9 @@ class _DGGSoftAdjFn(torch.autograd.Function):
             idx, val = ops.edgelist_topk(xp, rowptr, col, cfg["K"], cfg["t"], cfg["noise_mode"], cfg["G"], cfg["seed"])
         w, rs = ops.softk_fwd(idx, val, k, cfg["mode"])
         ctx.cfg = cfg
+        # destination-ordered partition of the active entries: the column-side terms of the backward run on it instead of
+        # entry-wise float atomics (built only when a backward can follow)
+        cfg["part"] = ops.part_build(idx, w, x.shape[0]) if any(ctx.needs_input_grad) else None
         ctx.save_for_backward(x, We, xp, k, idx, val)
         ctx.mark_non_differentiable(idx, val, rs)
         return w, idx, val, rs
@@ -104,7 +107,7 @@ class _DGGSoftAdjFn(torch.autograd.Function):
         x, We, xp, k, idx, val = ctx.saved_tensors
         cfg = ctx.cfg
         dval, dk = ops.softk_bwd(idx, val, k, dw.contiguous(), mode=cfg["mode"], normalized=False)
-        dxp = ops.edge_bwd(xp, idx, val, dval, t=cfg["t"], perturb=cfg["noise_mode"] != ops.NOISE_NONE)
+        dxp = ops.edge_bwd(xp, idx, val, dval, t=cfg["t"], perturb=cfg["noise_mode"] != ops.NOISE_NONE, part=cfg.get("part"))
         dx, dWe, dbe = ops.linear_bwd(x, We, xp, dxp, ops.ACT_LEAKY, need_dx=ctx.needs_input_grad[0])
         return dx, dk, dWe, dbe, None
 
@@ -310,7 +313,7 @@ class DGG_LearnableK_debug(nn.Module):
             f = w.detach() if cfg["mode"] == ops.MODE_K_ONLY else (w.detach() / val.clamp(min=1e-30))
             writer.add_scalar("values/first_k_std", f.sum(-1).std(), epoch)
             writer.add_scalar("values/first_k_mean", f.sum(-1).mean(), epoch)
-        return EllAdjacency(idx, w, x.shape[0], rs=rs, k=k, score=val)
+        return EllAdjacency(idx, w, x.shape[0], rs=rs, k=k, score=val, part=cfg.get("part"))
 
 
 class _DGGClassFn(torch.autograd.Function):

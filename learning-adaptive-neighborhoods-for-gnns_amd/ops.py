@@ -472,19 +472,20 @@ class EllNormalizeFn(torch.autograd.Function):
     """D^-1/2 A D^-1/2 with row sums on both sides (normalize_adj, model.py:1205-1219) on ELL values."""
 
     @staticmethod
-    def forward(ctx, w, idx, rs):
+    def forward(ctx, w, idx, rs, part=None):
         ahat = normalize_fwd(idx, w, rs)
         ctx.save_for_backward(w, idx, rs)
+        ctx.part = part if (part is not None and idx.shape[0] == rs.shape[0]) else None
         return ahat
 
     @staticmethod
     def backward(ctx, dA):
         w, idx, rs = ctx.saved_tensors
         dA = dA.contiguous()
-        da = norm_bwd_da(idx, w, rs, dA)
+        da = norm_bwd_da(idx, w, rs, dA, part=ctx.part)          # neighbour-side sums through the partition when there is one
         # mode 2 = no ramp: dw = dA a_i a_j - 0.5 da_i a_i / rs_i
         dw, _ = softk_bwd(idx, None, None, dA, rs=rs, da=da, mode=2, normalized=True)
-        return dw, None, None
+        return dw, None, None, None
 
 
 class EllSpmmFn(torch.autograd.Function):
