@@ -17,7 +17,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BM = 128, BK = 32, LDP = BK + 1;
+constexpr int BK = 32, LDP = BK + 1;
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == 1) return v > 0.0f ? v : __fmul_rn(0.01f, v);
@@ -27,11 +27,11 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 
 // y[N,out] = act(x[N,d] * W^T + b);  w_layout 0: W[out][d], 1: W[d][out].  NACC 32-column accumulators per wave
 // (tile width BN = 32*NACC is matched to `out`, so narrow layers do not pay for 128 columns of MFMAs)
-template <int NACC>
-__global__ __launch_bounds__(256) void linear_fwd_mfma(const float *__restrict__ x, int64_t N, int d,
+template <int NACC, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void linear_fwd_mfma(const float *__restrict__ x, int64_t N, int d,
                                                        const float *__restrict__ W, const float *__restrict__ b,
                                                        int out, int w_layout, int act, float *__restrict__ y) {
-    constexpr int BN = 32 * NACC;
+    constexpr int BN = 32 * NACC, BM = 32 * WAVES, NT = 64 * WAVES;   // small N: fewer rows per workgroup, more workgroups
     __shared__ float xs[BM * LDP];
     __shared__ float ws[BN * LDP];   // [j][k] (+pad)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -46,15 +46,15 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma(const float *__restrict__
     const bool vec4 = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);   // wave-uniform
     // Register prefetch: the global loads of K-block i+1 are issued before the MFMAs of block i and written to LDS after
     // them, so that HBM latency overlaps the matrix-core work of the same workgroup.
-    constexpr int XQ = BM * BK / 4 / 256;                        // float4 per thread and K-block (x tile)
-    constexpr int WQ = BN * BK / 256;                            // floats per thread and K-block (W tile)
+    constexpr int XQ = BM * BK / 4 / NT;                        // float4 per thread and K-block (x tile)
+    constexpr int WQ = BN * BK / NT;                            // floats per thread and K-block (W tile)
     float4 xr[XQ];
     float wr[WQ];
     auto load_block = [&](int k0) {
         if (vec4) {   // 16-byte loads: 8 lanes cover one 128-byte row segment
 #pragma unroll
             for (int q = 0; q < XQ; q++) {
-                const int e = tid + q * 256, r = e >> 3, c4 = (e & 7) * 4;
+                const int e = tid + q * NT, r = e >> 3, c4 = (e & 7) * 4;
                 const int64_t gi = m0 + r;
                 xr[q] = (gi < N && k0 + c4 < d) ? *reinterpret_cast<const float4 *>(x + gi * d + k0 + c4)
                                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma(const float *__restrict__
         } else {
 #pragma unroll
             for (int q = 0; q < XQ; q++) {
-                const int e = tid + q * 256, r = e >> 3, c4 = (e & 7) * 4;
+                const int e = tid + q * NT, r = e >> 3, c4 = (e & 7) * 4;
                 const int64_t gi = m0 + r;
                 float t[4];
 #pragma unroll
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma(const float *__restrict__
         }
 #pragma unroll
         for (int q = 0; q < WQ; q++) {
-            const int e = tid + q * 256;
+            const int e = tid + q * NT;
             if (w_layout == 0) {
                 const int j = e / BK, c = e % BK, gj = n0 + j, gk = k0 + c;
                 wr[q] = (gj < out && gk < d) ? W[(int64_t)gj * d + gk] : 0.0f;
@@ -87,13 +87,13 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma(const float *__restrict__
         __syncthreads();                                         // previous block's LDS reads are done
 #pragma unroll
         for (int q = 0; q < XQ; q++) {
-            const int e = tid + q * 256, r = e >> 3, c4 = (e & 7) * 4;
+            const int e = tid + q * NT, r = e >> 3, c4 = (e & 7) * 4;
             float *dst = xs + r * LDP + c4;
             dst[0] = xr[q].x; dst[1] = xr[q].y; dst[2] = xr[q].z; dst[3] = xr[q].w;
         }
 #pragma unroll
         for (int q = 0; q < WQ; q++) {
-            const int e = tid + q * 256;
+            const int e = tid + q * NT;
             if (w_layout == 0) ws[(e / BK) * LDP + e % BK] = wr[q];
             else ws[(e % BN) * LDP + e / BN] = wr[q];
         }
@@ -287,15 +287,20 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce(const float *__restrict__ 
     }
 }
 
+template <int NACC>
+void launch_linear_fwd_n(const float *x, int64_t N, int d, const float *W, const float *b, int out, int w_layout, int act, float *y,
+                         hipStream_t st) {
+    const unsigned gy = (unsigned)((out + 32 * NACC - 1) / (32 * NACC));
+    // 128 rows per workgroup.  (64- and 32-row workgroups -- more workgroups for Pubmed-size inputs -- measured slower:
+    // fewer threads then stage the same weight tile per K-block.)
+    hipLaunchKernelGGL((linear_fwd_mfma<NACC, 4>), dim3((unsigned)((N + 127) / 128), gy), dim3(256), 0, st, x, N, d, W, b, out, w_layout, act, y);
+}
+
 int launch_linear_fwd(const float *x, int64_t N, int d, const float *W, const float *b, int out, int w_layout, int act,
                       float *y, hipStream_t st) {
-    const unsigned gx = (unsigned)((N + BM - 1) / BM);
-    if (out <= 32)
-        hipLaunchKernelGGL(linear_fwd_mfma<1>, dim3(gx, (unsigned)((out + 31) / 32)), dim3(256), 0, st, x, N, d, W, b, out, w_layout, act, y);
-    else if (out <= 64)
-        hipLaunchKernelGGL(linear_fwd_mfma<2>, dim3(gx, (unsigned)((out + 63) / 64)), dim3(256), 0, st, x, N, d, W, b, out, w_layout, act, y);
-    else
-        hipLaunchKernelGGL(linear_fwd_mfma<4>, dim3(gx, (unsigned)((out + 127) / 128)), dim3(256), 0, st, x, N, d, W, b, out, w_layout, act, y);
+    if (out <= 32) launch_linear_fwd_n<1>(x, N, d, W, b, out, w_layout, act, y, st);
+    else if (out <= 64) launch_linear_fwd_n<2>(x, N, d, W, b, out, w_layout, act, y, st);
+    else launch_linear_fwd_n<4>(x, N, d, W, b, out, w_layout, act, y, st);
     return dgg_check_launch("linear_fwd");
 }
 
