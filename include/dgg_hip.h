@@ -215,6 +215,11 @@ int dgg_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const fl
  * per bucket in LDS.  Same results as dgg_edge_bwd / dgg_norm_bwd_da up to summation order. */
 size_t dgg_part_ws_bytes(int64_t rows, int K, int64_t ncols);   /* 0: partitioned path not applicable */
 int dgg_part_build(const int32_t *idx, const float *w, int64_t rows, int K, int64_t ncols, void *ws, void *stream);
+/* dX [ncols,F] += A^T dY through the partition (autograd of torch.mm(adj, x) w.r.t. x, model.py:594, when the conv input is
+ * a learned activation): runs of equal destination are reduced in registers, one flush per run.  a [rows,K] on the pattern
+ * the partition was built from; F a multiple of 64 (else DGG_ERR_UNSUPPORTED: use dgg_ell_spmm_bwd's atomic dX). */
+int dgg_ell_spmm_t_part(const float *a, const float *dY, int64_t rows, int K, int F, const void *part_ws, int64_t ncols, float *dX,
+                        void *stream);
 /* coef_ws: rows*K (+ ncols for dgg_edge_bwd_part) floats; dxp [ncols,h] / da [ncols] zeroed by the caller;
  * latent_dim in {16,32,64} */
 int dgg_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *dval, int K,

@@ -68,7 +68,7 @@ class EllAdjacency:
     def matmul(self, X):
         """A @ X (torch.mm(adj, x), model.py:594)."""
         # weights produced by the DGG ramp: an exact zero is a saturated ramp whose gradient vanishes too
-        return ops.EllSpmmFn.apply(self._values, self.idx, X, self.k is not None)
+        return ops.EllSpmmFn.apply(self._values, self.idx, X, self.k is not None, self.part)
 
     __matmul__ = matmul
 

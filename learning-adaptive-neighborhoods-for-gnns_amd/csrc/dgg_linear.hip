@@ -320,8 +320,9 @@ inline int gemm_tn_grid(int64_t N, int M1p, int M2p) {
     const int64_t need = (N + 4 * 2 * GT_PF - 1) / (4 * 2 * GT_PF);
     if (g > need) g = need;
     // every stream writes (and the reduce re-reads) a full M1p x M2p partial: keep that below ~1/4 of the operand bytes
-    const int64_t cap = N * (int64_t)(M1p + M2p) / (4 * (int64_t)M1p * M2p);
-    if (g > cap) g = cap < 8 ? 8 : cap;
+    int64_t cap = N * (int64_t)(M1p + M2p) / (4 * (int64_t)M1p * M2p);
+    if (cap < 8) cap = 8;
+    if (g > cap) g = cap;                                        // an upper limit only
     if (g > need) g = need;
     return (int)(g < 1 ? 1 : g);
 }

@@ -281,6 +281,63 @@ __global__ __launch_bounds__(256) void edge_bwd_cols(const float *__restrict__ x
     }
     flush();
 }
+// ---- transposed SpMM through the partition: dX_j += sum_{(i,r) -> j} a_ir dY_i ------------------------------------------
+// (autograd of torch.mm(adj, x) w.r.t. x, model.py:594; needed whenever the conv input is itself a learned activation: second
+// GCNConv of GCN_DGG, every GCNII layer).  Same walk as edge_bwd_cols: fixed chunks of destination-ordered records per
+// 16-lane group, runs of equal destination reduced in registers, one flush per run; grid.y = blocks of 64 features.
+__global__ __launch_bounds__(256) void spmm_t_cols(const float *__restrict__ dY, int F, const int *__restrict__ bstart, int nb,
+                                                   const int2 *__restrict__ recs, const float *__restrict__ a, int K,
+                                                   float *__restrict__ dX) {
+    constexpr int LPR = 16;
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, gbase = lane - c4;
+    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int f0 = blockIdx.y * 64 + 4 * c4;
+    const int nnz = bstart[nb];
+    const int64_t cbeg = gid * CH;
+    if (cbeg >= nnz) return;
+    const int cend = cbeg + CH < nnz ? (int)cbeg + CH : nnz;
+    int cur = -1;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto flush = [&]() {
+        if (cur >= 0) {
+            float *o = dX + (int64_t)cur * F + f0;
+            atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
+        }
+    };
+    for (int eb = (int)cbeg; eb < cend; eb += LPR) {
+        const int e = eb + c4;
+        const int2 myrec = e < cend ? recs[e] : make_int2(0, -1);
+        // record source = row*64 + r: the coefficient lives at a[row*K + r]
+        const float mycf = e < cend ? a[(int64_t)(myrec.x >> 6) * K + (myrec.x & 63)] : 0.0f;
+#pragma unroll
+        for (int u0 = 0; u0 < LPR; u0 += 4) {
+            int src[4], dst[4];
+            float cf[4];
+            float4 g[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                src[u] = __shfl(myrec.x, gbase + u0 + u, 64);
+                dst[u] = __shfl(myrec.y, gbase + u0 + u, 64);
+                cf[u] = __shfl(mycf, gbase + u0 + u, 64);
+                g[u] = cf[u] != 0.0f ? *reinterpret_cast<const float4 *>(dY + (int64_t)(src[u] >> 6) * F + f0)
+                                     : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (dst[u] < 0) continue;
+                if (dst[u] != cur) {
+                    flush();
+                    cur = dst[u];
+                    acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+                acc.x = fmaf(cf[u], g[u].x, acc.x); acc.y = fmaf(cf[u], g[u].y, acc.y);
+                acc.z = fmaf(cf[u], g[u].z, acc.z); acc.w = fmaf(cf[u], g[u].w, acc.w);
+            }
+        }
+    }
+    flush();
+}
+
 template <int H>
 __global__ __launch_bounds__(256) void edge_cols_finish(const float *__restrict__ xp, const float *__restrict__ ssum,
                                                         int64_t ncols, float *__restrict__ dxp) {
@@ -412,6 +469,21 @@ int dgg_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, 
     }
 #undef DGG_EDGE_PART
     return dgg_check_launch("edge_bwd_part");
+}
+
+// dX [ncols,F] += A^T dY for an ELL block (a [rows,K] on the pattern the partition was built from); F a multiple of 64,
+// dY rows 16-byte aligned.  dX is ACCUMULATED into (caller zeroes).
+int dgg_ell_spmm_t_part(const float *a, const float *dY, int64_t rows, int K, int F, const void *part_ws, int64_t ncols, float *dX,
+                        void *stream) {
+    if (F % 64 != 0 || (reinterpret_cast<uintptr_t>(dY) % 16) != 0)
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "ell_spmm_t_part: feature width must be a multiple of 64 (16-byte aligned rows)");
+    if (rows == 0) return 0;
+    const int64_t nb = nbuckets(ncols);
+    PartHdr p = part_layout(const_cast<void *>(part_ws), nb, rows * K);
+    const int64_t ngroups = (rows * K + CH - 1) / CH;
+    hipLaunchKernelGGL(spmm_t_cols, dim3((unsigned)((ngroups * 16 + 255) / 256), (unsigned)(F / 64)), dim3(256), 0, (hipStream_t)stream, dY,
+                       F, p.bstart, (int)nb, p.recs, a, K, dX);
+    return dgg_check_launch("ell_spmm_t_part");
 }
 
 // normalisation backward phase 1 through the partition; da [ncols] zeroed by the caller

@@ -277,11 +277,21 @@ def spmm_fwd(idx, ahat, X):
     return Y
 
 
-def spmm_bwd(idx, ahat, X, dY, need_dx=True, skip_zero=False):
+def spmm_bwd(idx, ahat, X, dY, need_dx=True, skip_zero=False, part=None):
+    """dA = <dY_i, X_j> and (optionally) dX = A^T dY.  With a partition of the pattern (part_build) and F a multiple of 64,
+    dX goes through the destination-ordered records (runs reduced in registers) instead of entry-wise float atomics."""
     N, K = idx.shape
     X, dY = _chk(X), _chk(dY)
     F = X.shape[1]
     dA = torch.empty((N, K), device=idx.device, dtype=torch.float32)
+    if need_dx and part is not None and F % 64 == 0 and dY.data_ptr() % 16 == 0 and X.shape[0] == N:
+        ahat = _chk(ahat)
+        _lib.check(_lib.lib().dgg_ell_spmm_bwd(_ptr(idx), _ptr(ahat), _ptr(X), _ptr(dY), N, K, F, int(skip_zero), _ptr(dA), _ptr(None),
+                                               _stream()), "ell_spmm_bwd")
+        dX = torch.zeros_like(X)
+        _lib.check(_lib.lib().dgg_ell_spmm_t_part(_ptr(ahat), _ptr(dY), N, K, F, _ptr(part), X.shape[0], _ptr(dX), _stream()),
+                   "ell_spmm_t_part")
+        return dA, dX
     dX = torch.zeros_like(X) if need_dx else None
     _lib.check(_lib.lib().dgg_ell_spmm_bwd(_ptr(idx), _ptr(_chk(ahat)), _ptr(X), _ptr(dY), N, K, F, int(skip_zero), _ptr(dA), _ptr(dX), _stream()), "ell_spmm_bwd")
     return dA, dX
@@ -492,17 +502,17 @@ class EllSpmmFn(torch.autograd.Function):
     """Y = A X on the ELL adjacency (torch.mm(adj, x) model.py:594, 67 / torch.spmm model.py:34)."""
 
     @staticmethod
-    def forward(ctx, ahat, idx, X, skip_zero=False):
+    def forward(ctx, ahat, idx, X, skip_zero=False, part=None):
         Y = spmm_fwd(idx, ahat, X)
         ctx.save_for_backward(ahat, idx, X)
-        ctx.skip_zero = skip_zero
+        ctx.skip_zero, ctx.part = skip_zero, part
         return Y
 
     @staticmethod
     def backward(ctx, dY):
         ahat, idx, X = ctx.saved_tensors
-        dA, dX = spmm_bwd(idx, ahat, X, dY.contiguous(), need_dx=ctx.needs_input_grad[2], skip_zero=ctx.skip_zero)
-        return dA, None, dX, None
+        dA, dX = spmm_bwd(idx, ahat, X, dY.contiguous(), need_dx=ctx.needs_input_grad[2], skip_zero=ctx.skip_zero, part=ctx.part)
+        return dA, None, dX, None, None
 
 
 class CsrNormalizeFn(torch.autograd.Function):

@@ -941,3 +941,23 @@ def test_full_size_ranked_step_properties(dev):
             if Nn(idx[r])[q] >= 0:
                 yr = np.float32(ah[r, q]) * X_c[Nn(idx[r])[q]] + yr
         np.testing.assert_allclose(Y[r], yr, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("F", [64, 128, 320])
+def test_transposed_spmm_through_partition(dev, F):
+    """dX = A^T dY through the destination-ordered partition == the oracle's transposed SpMM (and the atomic kernel)"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(61)
+    N, h = 700, 32
+    xp = rng.standard_normal((N, h)).astype(np.float32)
+    k = (3 + 30 * rng.random(N)).astype(np.float32)
+    idx, val = O.allpairs_topk(xp, K=K, noise_mode=O.NOISE_HASH, seed=(2, 9))
+    w, rs = O.softk(idx, val, k)
+    ahat = O.normalize(idx, w, rs)
+    X = rng.standard_normal((N, F)).astype(np.float32)
+    dY = rng.standard_normal((N, F)).astype(np.float32)
+    rdA, rdX = O.spmm_bwd(idx, ahat, X, dY)
+    part = ops.part_build(T(idx, dev), T(w, dev), N)
+    dA, dX = ops.spmm_bwd(T(idx, dev), T(ahat, dev), T(X, dev), T(dY, dev), need_dx=True, skip_zero=False, part=part)
+    np.testing.assert_allclose(Nn(dA), rdA, rtol=1e-4, atol=1e-4 * np.abs(rdA).max())
+    np.testing.assert_allclose(Nn(dX), rdX, rtol=1e-4, atol=1e-4 * np.abs(rdX).max())
