@@ -277,14 +277,15 @@ def spmm_fwd(idx, ahat, X):
     return Y
 
 
-def spmm_bwd(idx, ahat, X, dY, need_dx=True, skip_zero=False, part=None):
+def spmm_bwd(idx, ahat, X, dY, need_dx=True, skip_zero=False, part=None, part_cols=None):
     """dA = <dY_i, X_j> and (optionally) dX = A^T dY.  With a partition of the pattern (part_build) and F a multiple of 64,
     dX goes through the destination-ordered records (runs reduced in registers) instead of entry-wise float atomics."""
     N, K = idx.shape
     X, dY = _chk(X), _chk(dY)
     F = X.shape[1]
     dA = torch.empty((N, K), device=idx.device, dtype=torch.float32)
-    if need_dx and part is not None and F % 64 == 0 and dY.data_ptr() % 16 == 0 and X.shape[0] == N:
+    # the partition must have been built over the same destination set as X's rows (part_cols; default: a square block)
+    if need_dx and part is not None and F % 64 == 0 and dY.data_ptr() % 16 == 0 and X.shape[0] == (N if part_cols is None else part_cols):
         ahat = _chk(ahat)
         _lib.check(_lib.lib().dgg_ell_spmm_bwd(_ptr(idx), _ptr(ahat), _ptr(X), _ptr(dY), N, K, F, int(skip_zero), _ptr(dA), _ptr(None),
                                                _stream()), "ell_spmm_bwd")

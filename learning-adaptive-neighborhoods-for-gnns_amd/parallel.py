@@ -107,7 +107,10 @@ class ShardedDGGConv:
         if fused is not None:                            # SDDMM + row side of the normalisation backward in one pass
             (dA, da), dX = fused, None
         else:
-            dA, dX = kern.spmm_bwd(s["idx"], s["ahat"], s["X"], dY, self.x_grad, True)
+            if part is not None and self.x_grad:         # dX through the destination-ordered partition (no entry-wise atomics)
+                dA, dX = kern.spmm_bwd(s["idx"], s["ahat"], s["X"], dY, True, True, part=part, part_cols=self.N)
+            else:
+                dA, dX = kern.spmm_bwd(s["idx"], s["ahat"], s["X"], dY, self.x_grad, True)
             da = kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0, part) if part is not None else \
                 kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0)
         if self.world > 1:
