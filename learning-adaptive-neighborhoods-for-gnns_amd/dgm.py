@@ -260,6 +260,11 @@ class DGG_LearnableK_debug(nn.Module):
             # "pass" returns k = None, which the reference's own select_top_k cannot consume (dgm.py:1485, 1412)
             raise NotImplementedError(f"k-net mode {self.k_net_mode!r}: the HIP path implements 'x', 'gcn-x-deg', 'input_deg' "
                                       "and 'learn_normalized_degree'")
+        if getattr(self.args, "stochastic_k", False) and self.training:
+            # dgm.py:2041-2049: in training mode the latent of the k-net is sampled (mu + eps * exp(logvar / 2)); eval mode and
+            # stochastic_k=False (the default) use mu, which is what the HIP k-net computes
+            raise NotImplementedError("stochastic_k=True in training mode (reparameterised k) is not on the HIP path; "
+                                      "use stochastic_k=False (the reference's default) or eval mode")
         if self.k_select_mode not in ("k_times_edge_prob", "k_only"):
             raise NotImplementedError(f"k-select mode {self.k_select_mode!r} is dead code in the reference")
         if self.hard:
