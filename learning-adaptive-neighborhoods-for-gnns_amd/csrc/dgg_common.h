@@ -165,6 +165,40 @@ __device__ __forceinline__ float ranked_gumbel(uint64_t S) {
     return __fmul_rn(-0.3f, c_log(L));
 }
 
+// squared distance of two rows in the canonical accumulation order, evaluated by ONE thread: a single ascending fmaf chain
+// for h <= 128; for wider latents 64 interleaved chains (feature c -> chain c mod 64) combined by the xor butterfly of a
+// wavefront -- the order the wave-parallel kernels produce with coalesced loads (oracle: pair_dist)
+__device__ __forceinline__ float pair_d2_thread(const float *__restrict__ a, const float *__restrict__ b, int h) {
+    if (h <= 128) {
+        float d2 = 0.0f;
+        for (int c = 0; c < h; c++) {
+            const float df = __fadd_rn(a[c], -b[c]);
+            d2 = __fmaf_rn(df, df, d2);
+        }
+        return d2;
+    }
+    float s[64];
+#pragma unroll
+    for (int l = 0; l < 64; l++) s[l] = 0.0f;
+    for (int c0 = 0; c0 < h; c0 += 64) {
+#pragma unroll
+        for (int l = 0; l < 64; l++) {
+            if (c0 + l < h) {
+                const float df = __fadd_rn(a[c0 + l], -b[c0 + l]);
+                s[l] = __fmaf_rn(df, df, s[l]);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int l = 0; l < 64; l++) {
+            if ((l & off) == 0) { const float t = __fadd_rn(s[l], s[l ^ off]); s[l] = t; s[l ^ off] = t; }
+        }
+    }
+    return s[0];
+}
+
 // score of a pair given the distance (reference dgm.py:1623, 1213-1229)
 __device__ __forceinline__ float score_from_dist(float dist, float t, bool perturb, float G) {
     float p = c_exp(__fmul_rn(t, dist));

@@ -29,13 +29,7 @@ __global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(
     if (ex_mode == 1) {
         ex = ex_in[e];
     } else if (ex_mode == 2) {                                    // exp(t ||xp_u - xp_v||), canonical chain (dgm.py:1684-1686)
-        const float *a = xp + u * h, *b = xp + v * h;
-        float d2 = 0.0f;
-        for (int c = 0; c < h; c++) {
-            const float df = __fadd_rn(a[c], -b[c]);
-            d2 = __fmaf_rn(df, df, d2);
-        }
-        ex = c_exp(__fmul_rn(t_ex, c_sqrt(d2)));
+        ex = c_exp(__fmul_rn(t_ex, c_sqrt(pair_d2_thread(xp + u * h, xp + v * h, h))));
     }
     if (ex_out) ex_out[e] = ex;
     const float *A = AB + u * 2 * hw, *B = AB + v * 2 * hw + hw;

@@ -321,25 +321,53 @@ __global__ __launch_bounds__(WPB * 64) void edge_bwd_wide_kernel(const float *__
     int32_t jl = lane < K ? idx[i * K + lane] : -1;
     float gl = lane < K ? dval[i * K + lane] : 0.0f;
     float vl = lane < K ? val[i * K + lane] : 0.0f;
-    for (int r = 0; r < K; r++) {
-        const int32_t j = bcast(jl, r);
-        const float g = bcast(gl, r);
-        if (j < 0 || g == 0.0f) continue;
-        const float v = bcast(vl, r);
-        const float *xj = xp + (int64_t)j * h;
-        float d2 = 0.0f;
-        for (int c = lane; c < h; c += 64) { const float d = xi[c] - xj[c]; d2 = fmaf(d, d, d2); }
+    constexpr int EQ = 4;                                        // entries in flight per pass over the features
+    for (int r0 = 0; r0 < K; r0 += EQ) {
+        int32_t j[EQ];
+        float g[EQ], v[EQ], d2[EQ], dd[EQ];
+        const float *xj[EQ];
+        bool any = false;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) d2 += __shfl_xor(d2, off, 64);
-        if (d2 == 0.0f) continue;
-        const float dist = sqrtf(d2);
-        const float p = c_exp(t * dist);
-        const float dp = perturb ? g * v / (p + 1e-8f) : g;
-        const float dd = dp * t * p / dist;
+        for (int u = 0; u < EQ; u++) {
+            const int r = r0 + u < K ? r0 + u : K - 1;
+            j[u] = bcast(jl, r);
+            g[u] = r0 + u < K ? bcast(gl, r) : 0.0f;
+            v[u] = bcast(vl, r);
+            if (j[u] < 0) g[u] = 0.0f;
+            xj[u] = xp + (int64_t)(j[u] < 0 ? 0 : j[u]) * h;
+            d2[u] = 0.0f;
+            any = any || g[u] != 0.0f;
+        }
+        if (!any) continue;                                      // wave-uniform
         for (int c = lane; c < h; c += 64) {
-            const float e = dd * (xi[c] - xj[c]);
-            atomicAdd(dxp + gi * h + c, e);
-            atomicAdd(dxp + (int64_t)j * h + c, -e);
+            const float xv = xi[c];
+#pragma unroll
+            for (int u = 0; u < EQ; u++) { const float d = xv - xj[u][c]; d2[u] = fmaf(d, d, d2[u]); }
+        }
+#pragma unroll
+        for (int u = 0; u < EQ; u++) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) d2[u] += __shfl_xor(d2[u], off, 64);
+            dd[u] = 0.0f;
+            if (g[u] != 0.0f && d2[u] != 0.0f) {
+                const float dist = sqrtf(d2[u]);
+                const float p = c_exp(t * dist);
+                const float dp = perturb ? g[u] * v[u] / (p + 1e-8f) : g[u];
+                dd[u] = dp * t * p / dist;
+            }
+        }
+        for (int c = lane; c < h; c += 64) {
+            const float xv = xi[c];
+            float own = 0.0f;
+#pragma unroll
+            for (int u = 0; u < EQ; u++) {
+                if (dd[u] != 0.0f) {
+                    const float e = dd[u] * (xv - xj[u][c]);
+                    own += e;
+                    atomicAdd(dxp + (int64_t)j[u] * h + c, -e);
+                }
+            }
+            if (own != 0.0f) atomicAdd(dxp + gi * h + c, own);
         }
     }
 }

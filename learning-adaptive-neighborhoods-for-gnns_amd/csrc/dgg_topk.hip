@@ -139,6 +139,64 @@ __global__ __launch_bounds__(256) void edgelist_topk_kernel(
     }
 }
 
+// same for latent widths beyond 128 (PPI: 2048): the candidates of a row are scored ONE AT A TIME by the whole wavefront --
+// lanes over the features, coalesced 256-byte segments, 64 interleaved fmaf chains + xor butterfly (the canonical order for
+// wide latents, oracle pair_dist) -- and the score of candidate q of a batch is kept by lane q for the sort / merge
+__global__ __launch_bounds__(256) void edgelist_topk_wide_kernel(
+    const float *__restrict__ xp, int64_t N, int h, const int64_t *__restrict__ rowptr,
+    const int32_t *__restrict__ col, float t, int noise_mode, const float *__restrict__ G, int64_t ldG,
+    uint32_t s0, uint32_t s1, int K, int32_t *__restrict__ idx, float *__restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const bool perturb = noise_mode != 0, sym = noise_mode == 3;
+    const float *xi = xp + i * h;
+    uint64_t list = DGG_EMPTY_KEY;
+    const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
+    for (int64_t eb = e0; eb < e1; eb += 64) {
+        const int n = e1 - eb < 64 ? (int)(e1 - eb) : 64;
+        const int32_t jl = eb + lane < e1 ? col[eb + lane] : 0;
+        float mine = 0.0f;
+        constexpr int CQ = 8;                                    // candidate rows in flight per pass over the features
+        for (int q0 = 0; q0 < n; q0 += CQ) {
+            const float *xj[CQ];
+            float d2[CQ];
+#pragma unroll
+            for (int u = 0; u < CQ; u++) {
+                xj[u] = xp + (int64_t)bcast(jl, q0 + u < n ? q0 + u : n - 1) * h;
+                d2[u] = 0.0f;
+            }
+            for (int c = lane; c < h; c += 64) {
+                const float xv = xi[c];
+#pragma unroll
+                for (int u = 0; u < CQ; u++) {
+                    const float df = __fadd_rn(xv, -xj[u][c]);
+                    d2[u] = __fmaf_rn(df, df, d2[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CQ; u++) {
+                const float tot = wave_sum_butterfly(d2[u]);
+                if (lane == q0 + u) mine = tot;
+            }
+        }
+        uint64_t key = DGG_EMPTY_KEY;
+        if (lane < n) {
+            float g = 0.0f;
+            if (noise_mode == 1) g = G[i * ldG + jl];
+            else if (noise_mode >= 2) g = pair_noise(s0, s1, (uint32_t)i, (uint32_t)jl, sym);
+            key = make_key(score_from_dist(c_sqrt(mine), t, perturb, g), jl);
+        }
+        key = wave_sort_desc(key, lane);
+        list = wave_merge_top64(list, key, lane);
+    }
+    if (lane < K) {
+        bool empty = list == DGG_EMPTY_KEY;
+        idx[i * K + lane] = empty ? -1 : key_col(list);
+        val[i * K + lane] = empty ? 0.0f : key_val(list);
+    }
+}
+
 // ---- selection only: dense score rows -> top-K (test entry; bit-exact target) ------------------------
 __global__ __launch_bounds__(256) void select_scores_kernel(const float *__restrict__ scores, int64_t R, int64_t N,
                                                             int K, int32_t *__restrict__ idx, float *__restrict__ val) {
@@ -199,8 +257,12 @@ int dgg_edgelist_topk(const float *xp, int64_t N, int h, const int64_t *rowptr, 
     if (noise_mode < 0 || noise_mode > 3)
         return dgg_set_error(DGG_ERR_UNSUPPORTED, "edgelist_topk: noise_mode must be none / explicit / hash / symmetric hash");
     if (N == 0) return 0;
-    hipLaunchKernelGGL(edgelist_topk_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, xp, N, h,
-                       rowptr, col, t, noise_mode, G, ldG, s0, s1, K, idx, val);
+    if (h > 128)
+        hipLaunchKernelGGL(edgelist_topk_wide_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, xp, N, h,
+                           rowptr, col, t, noise_mode, G, ldG, s0, s1, K, idx, val);
+    else
+        hipLaunchKernelGGL(edgelist_topk_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, xp, N, h,
+                           rowptr, col, t, noise_mode, G, ldG, s0, s1, K, idx, val);
     return dgg_check_launch("edgelist_topk");
 }
 

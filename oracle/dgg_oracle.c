@@ -345,10 +345,23 @@ ORA_API void ora_knet_input_deg(const float *deg, int64_t N, float dmean, float 
 /* ------------------------------------------------------------------------------------------ */
 /* pair score (dgm.py:1613-1623 + 1211-1229)                                                   */
 /* ------------------------------------------------------------------------------------------ */
+/* squared-distance accumulation order: one fmaf chain over the features in ascending order for h <= 128; for wider
+ * latents (the PPI configuration runs the DGG at 2048) 64 interleaved chains -- feature c goes to chain c mod 64 -- combined
+ * by the xor butterfly of a wavefront, i.e. what 64 lanes reading coalesced 256-byte segments compute */
 static inline float pair_dist(const float *a, const float *b, int h) {
-    float d2 = 0.0f;
-    for (int c = 0; c < h; c++) { float df = a[c] - b[c]; d2 = fmaf(df, df, d2); }
-    return sqrtf(d2);
+    if (h <= 128) {
+        float d2 = 0.0f;
+        for (int c = 0; c < h; c++) { float df = a[c] - b[c]; d2 = fmaf(df, df, d2); }
+        return sqrtf(d2);
+    }
+    float s[64], t[64];
+    for (int l = 0; l < 64; l++) s[l] = 0.0f;
+    for (int c = 0; c < h; c++) { float df = a[c] - b[c]; s[c & 63] = fmaf(df, df, s[c & 63]); }
+    for (int off = 32; off >= 1; off >>= 1) {
+        for (int l = 0; l < 64; l++) t[l] = s[l] + s[l ^ off];
+        memcpy(s, t, sizeof(s));
+    }
+    return sqrtf(s[0]);
 }
 ORA_API float ora_pair_score(const float *xi, const float *xj, int h, float t, int perturb, float G) {
     float p = ora_exp(t * pair_dist(xi, xj, h));

@@ -509,6 +509,12 @@ def test_edge_mlp_kernels(dev, hw, use_deg, ex_mode, act, noise):
     assert np.array_equal(Nn(p_e), rp), "edge probabilities differ from the oracle"
     if ex_mode:
         assert np.array_equal(Nn(ex), rex)
+    if ex_mode == 2:                                          # wide latent: 64 interleaved chains + butterfly (oracle pair_dist)
+        xw = rng.standard_normal((N, 192)).astype(np.float32) * 0.2
+        _, exw = ops.edge_mlp_fwd(T(AB, dev), T(xw, dev), T(rows, dev), T(col, dev), o(deg), None, 2, t_ex, o(wdu), o(wdv), o(wex),
+                                  T(b1, dev), T(w2, dev), T(b2, dev), act)
+        _, rexw = O.edge_mlp_fwd(AB, xw, rows, col, deg, None, 2, t_ex, wdu, wdv, wex, b1, w2, b2[0], act)
+        assert np.array_equal(Nn(exw), rexw)
     mode = {"none": O.NOISE_NONE, "hash": O.NOISE_HASH, "sym": O.NOISE_HASH_SYM}[noise]
     idx, val, eid = ops.edgelist_topk_p(p_e, N, T(rowptr, dev), T(col, dev), K, mode, seed=(9, 4))
     ridx, rval, reid = O.edgelist_topk_p(rp, N, rowptr, col, K, mode, seed=(9, 4))
