@@ -141,6 +141,56 @@ __global__ __launch_bounds__(WPB * 64) void spmm_bwd_kernel(const int32_t *__res
     if (lane < K) dA[i * K + lane] = mine;
 }
 
+// SDDMM only (no dX) for wide rows (F > 256, a multiple of 4; GCNII layers of the PPI configuration: 2048): the wavefront
+// walks the row's cotangent ONCE per batch of four neighbours -- 16-byte loads, four gathered rows in flight -- instead of
+// once per neighbour.
+__global__ __launch_bounds__(WPB * 64) void sddmm_wide_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
+                                                             const float *__restrict__ X, const float *__restrict__ dY,
+                                                             int64_t N, int K, int F, int skip_zero, float *__restrict__ dA) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int32_t jl = lane < K ? idx[i * K + lane] : -1;
+    const float al = lane < K ? ahat[i * K + lane] : 0.0f;
+    const float4 *gy = reinterpret_cast<const float4 *>(dY + i * F);
+    const int F4 = F / 4;
+    float mine = 0.0f;
+    constexpr int NQ = 4;
+    for (int r0 = 0; r0 < K; r0 += NQ) {
+        const float4 *xr[NQ];
+        bool v[NQ];
+        bool any = false;
+        float part[NQ];
+#pragma unroll
+        for (int u = 0; u < NQ; u++) {
+            const int r = r0 + u < K ? r0 + u : K - 1;
+            const int32_t j = bcast(jl, r);
+            v[u] = r0 + u < K && j >= 0 && !(skip_zero && bcast(al, r) == 0.0f);
+            xr[u] = reinterpret_cast<const float4 *>(X + (int64_t)(j < 0 ? 0 : j) * F);
+            part[u] = 0.0f;
+            any = any || v[u];
+        }
+        if (!any) continue;                                      // wave-uniform
+        for (int c = lane; c < F4; c += 64) {
+            const float4 g = gy[c];
+#pragma unroll
+            for (int u = 0; u < NQ; u++) {
+                if (v[u]) {
+                    const float4 xv = xr[u][c];
+                    part[u] = fmaf(g.x, xv.x, part[u]); part[u] = fmaf(g.y, xv.y, part[u]);
+                    part[u] = fmaf(g.z, xv.z, part[u]); part[u] = fmaf(g.w, xv.w, part[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; u++) {
+            const float tot = wave_sum_dpp(part[u], lane);
+            if (lane == r0 + u) mine = tot;
+        }
+    }
+    if (lane < K) dA[i * K + lane] = mine;
+}
+
 // SDDMM only (no dX), F = 128*NV4: TWO neighbours per wave-instruction.  Each 32-lane half owns one neighbour and each
 // lane 4*NV4 features (16-byte loads: a 128-feature row is one 512-byte coalesced segment per half), so the per-edge
 // reduction is a 5-step DPP butterfly inside the half and the instruction count per edge halves.
@@ -428,6 +478,8 @@ int dgg_ell_spmm_bwd(const int32_t *idx, const float *ahat, const float *X, cons
     else if (!dX && al16 && F == 256)
         hipLaunchKernelGGL((sddmm_pair_kernel<2, false>), dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, N, K, skip_zero, dA,
                            nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+    else if (!dX && al16 && F > 256 && F % 4 == 0)
+        hipLaunchKernelGGL(sddmm_wide_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, N, K, F, skip_zero, dA);
     else
         hipLaunchKernelGGL(spmm_bwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, N, K, F, skip_zero, dA, dX);
     return dgg_check_launch("ell_spmm_bwd");

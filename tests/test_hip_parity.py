@@ -949,7 +949,7 @@ def test_full_size_ranked_step_properties(dev):
         np.testing.assert_allclose(Y[r], yr, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("F", [64, 128, 320])
+@pytest.mark.parametrize("F", [64, 128, 320, 1024])
 def test_transposed_spmm_through_partition(dev, F):
     """dX = A^T dY through the destination-ordered partition == the oracle's transposed SpMM (and the atomic kernel)"""
     from dgg_amd import ops
