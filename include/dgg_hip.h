@@ -215,6 +215,12 @@ int dgg_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const fl
  * per bucket in LDS.  Same results as dgg_edge_bwd / dgg_norm_bwd_da up to summation order. */
 size_t dgg_part_ws_bytes(int64_t rows, int K, int64_t ncols);   /* 0: partitioned path not applicable */
 int dgg_part_build(const int32_t *idx, const float *w, int64_t rows, int K, int64_t ncols, void *ws, void *stream);
+/* GCNII layer epilogue (GraphConvolution.forward, model.py:36-44): out = theta * sw + (1 - theta) * r (+ inp), sw = support W,
+ * r = (1 - alpha) * hi + alpha * h0 (h0 NULL: r = hi; inp NULL: no residual).  Backward: dsw = theta g, dhi, dh0 (NULL with h0);
+ * the residual input's gradient is g itself. */
+int dgg_gcnii_epilogue_fwd(const float *sw, const float *hi, const float *h0, const float *inp, int64_t n, float theta, float alpha,
+                           float *out, void *stream);
+int dgg_gcnii_epilogue_bwd(const float *g, int64_t n, float theta, float alpha, float *dsw, float *dhi, float *dh0, void *stream);
 /* dX [ncols,F] += A^T dY through the partition (autograd of torch.mm(adj, x) w.r.t. x, model.py:594, when the conv input is
  * a learned activation): runs of equal destination are reduced in registers, one flush per run.  a [rows,K] on the pattern
  * the partition was built from; F a multiple of 64 (else DGG_ERR_UNSUPPORTED: use dgg_ell_spmm_bwd's atomic dX). */

@@ -51,6 +51,8 @@ PROTOTYPES = {
     "dgg_part_build": [_vp, _vp, _i64, _i32, _i64, _vp, _vp],
     "dgg_edge_bwd_part": [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _i64, _vp, _vp, _vp],
     "dgg_norm_bwd_da_part": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp],
+    "dgg_gcnii_epilogue_fwd": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp],
+    "dgg_gcnii_epilogue_bwd": [_vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp],
     "dgg_ell_spmm_t_part": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp],
     "dgg_ell_sddmm_norm_part": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp],
     "dgg_edge_bwd": [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _vp],

@@ -422,6 +422,28 @@ __global__ __launch_bounds__(WPB * 64) void edge_bwd_wide_kernel(const float *__
     }
 }
 
+// GCNII layer epilogue (reference model.py:36-44 / 69-77): out = theta * (support W) + (1 - theta) * r (+ input), with
+// r = (1 - alpha) * hi + alpha * h0 folded in (h0 == NULL: r = hi, the non-variant layer whose support IS r).  One pass
+// instead of five elementwise launches; the backward is three scaled copies of the cotangent.
+__global__ void gcnii_epilogue_fwd_kernel(const float *__restrict__ sw, const float *__restrict__ hi, const float *__restrict__ h0,
+                                          const float *__restrict__ inp, int64_t n, float theta, float alpha, float *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float r = h0 ? (1.0f - alpha) * hi[e] + alpha * h0[e] : hi[e];
+    float o = theta * sw[e] + (1.0f - theta) * r;
+    if (inp) o += inp[e];
+    out[e] = o;
+}
+__global__ void gcnii_epilogue_bwd_kernel(const float *__restrict__ g, int64_t n, float theta, float alpha, float *__restrict__ dsw,
+                                          float *__restrict__ dhi, float *__restrict__ dh0) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float gv = g[e];
+    dsw[e] = theta * gv;
+    if (dh0) { dhi[e] = (1.0f - theta) * (1.0f - alpha) * gv; dh0[e] = (1.0f - theta) * alpha * gv; }
+    else dhi[e] = (1.0f - theta) * gv;
+}
+
 inline unsigned rows_grid(int64_t N) { return (unsigned)((N + WPB - 1) / WPB); }
 
 }  // namespace
@@ -505,6 +527,20 @@ int dgg_ell_sddmm_norm_part(const int32_t *idx, const float *ahat, const float *
         hipLaunchKernelGGL((sddmm_pair_kernel<2, true>), dim3(rows_grid(rows)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, rows, K,
                            skip_zero, dA, w, rs, row0, slotmap, coef_ws, da);
     return dgg_norm_da_cols_impl(part_ws, rows, K, ncols, coef_ws, da, st);
+}
+
+int dgg_gcnii_epilogue_fwd(const float *sw, const float *hi, const float *h0, const float *inp, int64_t n, float theta, float alpha,
+                           float *out, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gcnii_epilogue_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sw, hi, h0, inp, n,
+                       theta, alpha, out);
+    return dgg_check_launch("gcnii_epilogue_fwd");
+}
+int dgg_gcnii_epilogue_bwd(const float *g, int64_t n, float theta, float alpha, float *dsw, float *dhi, float *dh0, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gcnii_epilogue_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, n, theta,
+                       alpha, dsw, dhi, dh0);
+    return dgg_check_launch("gcnii_epilogue_bwd");
 }
 
 int dgg_norm_bwd_da(const int32_t *idx, const float *w, const float *rs, const float *dA, int64_t N, int K, int64_t row0,

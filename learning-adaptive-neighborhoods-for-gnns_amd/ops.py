@@ -570,3 +570,28 @@ class CsrBgSoftmaxFn(torch.autograd.Function):
         _lib.check(_lib.lib().dgg_csr_bg_softmax_bwd(_ptr(att), _ptr(bg), _ptr(rowptr), bg.shape[0], _ptr(_chk(datt.contiguous())),
                                                      _ptr(_chk(dbg.contiguous())), _ptr(dL), _stream()), "csr_bg_softmax_bwd")
         return dL, None
+
+
+class GcniiEpilogueFn(torch.autograd.Function):
+    """out = theta * sw + (1 - theta) * ((1 - alpha) * hi + alpha * h0) (+ inp)  (GraphConvolution.forward, model.py:36-44);
+    h0 None: r = hi (the non-variant layer, whose support is r itself)."""
+
+    @staticmethod
+    def forward(ctx, sw, hi, h0, inp, theta, alpha):
+        sw, hi = _chk(sw), _chk(hi)
+        h0 = _chk(h0) if h0 is not None else None
+        inp = _chk(inp) if inp is not None else None
+        out = torch.empty_like(sw)
+        _lib.check(_lib.lib().dgg_gcnii_epilogue_fwd(_ptr(sw), _ptr(hi), _ptr(h0), _ptr(inp), sw.numel(), float(theta), float(alpha),
+                                                     _ptr(out), _stream()), "gcnii_epilogue_fwd")
+        ctx.theta, ctx.alpha, ctx.has_h0, ctx.has_inp = float(theta), float(alpha), h0 is not None, inp is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _chk(g.contiguous())
+        dsw, dhi = torch.empty_like(g), torch.empty_like(g)
+        dh0 = torch.empty_like(g) if ctx.has_h0 else None
+        _lib.check(_lib.lib().dgg_gcnii_epilogue_bwd(_ptr(g), g.numel(), ctx.theta, ctx.alpha, _ptr(dsw), _ptr(dhi), _ptr(dh0),
+                                                     _stream()), "gcnii_epilogue_bwd")
+        return dsw, dhi, dh0, (g if ctx.has_inp else None), None, None
