@@ -967,3 +967,22 @@ def test_transposed_spmm_through_partition(dev, F):
     dA, dX = ops.spmm_bwd(T(idx, dev), T(ahat, dev), T(X, dev), T(dY, dev), need_dx=True, skip_zero=False, part=part)
     np.testing.assert_allclose(Nn(dA), rdA, rtol=1e-4, atol=1e-4 * np.abs(rdA).max())
     np.testing.assert_allclose(Nn(dX), rdX, rtol=1e-4, atol=1e-4 * np.abs(rdX).max())
+
+
+@pytest.mark.parametrize("N", [64, 65, 127, 128, 129, 1023, 1024, 1025, 2048, 4097, 10_000])
+def test_ranked_search_stress_around_power_of_two_sizes(dev, N):
+    """the keyed bijection of the ranked generator lives on [0, 2^b): sizes at and around powers of two, two latent
+    widths, random k_limit -- kept ranks must equal the oracle's (which scores every column) bit for bit"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(N)
+    for h, seed in [(16, (1, 2)), (64, (77, 123456))]:
+        xp = rng.standard_normal((N, h)).astype(np.float32)
+        xp[xp < 0] *= 0.01
+        k = rng.uniform(1.0, 60.0, N).astype(np.float32)
+        idx, val = ops.allpairs_topk(T(xp, dev), K, noise_mode=ops.NOISE_RANKED, seed=seed, k_limit=T(k, dev))
+        ridx, rval = O.allpairs_topk(xp, K=K, noise_mode=O.NOISE_RANKED, seed=seed)
+        idx, val = Nn(idx), Nn(val)
+        kept = idx >= 0
+        want = (np.arange(K)[None, :] < np.minimum(np.ceil(k + np.float32(8.5)) + 1, K)[:, None]) & (ridx >= 0)
+        assert np.array_equal(kept, want)
+        assert np.array_equal(idx[kept], ridx[kept]) and np.array_equal(val[kept], rval[kept])
