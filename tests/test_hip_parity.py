@@ -986,3 +986,4 @@ def test_ranked_search_stress_around_power_of_two_sizes(dev, N):
         want = (np.arange(K)[None, :] < np.minimum(np.ceil(k + np.float32(8.5)) + 1, K)[:, None]) & (ridx >= 0)
         assert np.array_equal(kept, want)
         assert np.array_equal(idx[kept], ridx[kept]) and np.array_equal(val[kept], rval[kept])
+
