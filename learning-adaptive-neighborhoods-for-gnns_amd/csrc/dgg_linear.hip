@@ -50,36 +50,43 @@ __global__ __launch_bounds__(64 * WAVES) void linear_fwd_mfma(const float *__res
     constexpr int WQ = BN * BK / NT;                            // floats per thread and K-block (W tile)
     float4 xr[XQ];
     float wr[WQ];
+    // every load is UNCONDITIONAL (clamped address, multiplied by a 0/1 mask afterwards; operands are finite): a predicated
+    // load becomes a branch with its own wait and serialises the staging; straight-line loads issue back to back
     auto load_block = [&](int k0) {
         if (vec4) {   // 16-byte loads: 8 lanes cover one 128-byte row segment
 #pragma unroll
             for (int q = 0; q < XQ; q++) {
                 const int e = tid + q * NT, r = e >> 3, c4 = (e & 7) * 4;
                 const int64_t gi = m0 + r;
-                xr[q] = (gi < N && k0 + c4 < d) ? *reinterpret_cast<const float4 *>(x + gi * d + k0 + c4)
-                                                : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                const bool ok = gi < N && k0 + c4 < d;
+                const int64_t gic = gi < N ? gi : N - 1;
+                const int kc = k0 + c4 < d ? k0 + c4 : d - 4;
+                const float4 v = *reinterpret_cast<const float4 *>(x + gic * d + kc);
+                const float m = ok ? 1.0f : 0.0f;                // arithmetic mask: no control dependence on the load
+                xr[q] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
             }
         } else {
 #pragma unroll
             for (int q = 0; q < XQ; q++) {
                 const int e = tid + q * NT, r = e >> 3, c4 = (e & 7) * 4;
                 const int64_t gi = m0 + r;
+                const int64_t gic = gi < N ? gi : N - 1;
                 float t[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) t[u] = (gi < N && k0 + c4 + u < d) ? x[gi * d + k0 + c4 + u] : 0.0f;
+                for (int u = 0; u < 4; u++) {
+                    const int kk = k0 + c4 + u;
+                    t[u] = x[gic * d + (kk < d ? kk : d - 1)] * ((gi < N && kk < d) ? 1.0f : 0.0f);
+                }
                 xr[q] = make_float4(t[0], t[1], t[2], t[3]);
             }
         }
 #pragma unroll
         for (int q = 0; q < WQ; q++) {
             const int e = tid + q * NT;
-            if (w_layout == 0) {
-                const int j = e / BK, c = e % BK, gj = n0 + j, gk = k0 + c;
-                wr[q] = (gj < out && gk < d) ? W[(int64_t)gj * d + gk] : 0.0f;
-            } else {
-                const int c = e / BN, j = e % BN, gj = n0 + j, gk = k0 + c;
-                wr[q] = (gj < out && gk < d) ? W[(int64_t)gk * out + gj] : 0.0f;
-            }
+            const int j = w_layout == 0 ? e / BK : e % BN, c = w_layout == 0 ? e % BK : e / BN;
+            const int gj = n0 + j, gk = k0 + c;
+            const int gjc = gj < out ? gj : out - 1, gkc = gk < d ? gk : d - 1;
+            wr[q] = W[w_layout == 0 ? (int64_t)gjc * d + gkc : (int64_t)gkc * out + gjc] * ((gj < out && gk < d) ? 1.0f : 0.0f);
         }
     };
     load_block(0);
