@@ -262,8 +262,8 @@ __global__ __launch_bounds__(256) void edge_bwd_cols(const float *__restrict__ x
                 src[u] = __shfl(myrec.x, gbase + u0 + u, 64);
                 dst[u] = __shfl(myrec.y, gbase + u0 + u, 64);
                 cf[u] = __shfl(mycf, gbase + u0 + u, 64);
-                xi[u] = cf[u] != 0.0f ? *reinterpret_cast<const float4 *>(xp + (row0 + (src[u] >> 6)) * H + 4 * c4)
-                                      : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                // unconditional (padding records point at row 0 and carry coefficient 0): four loads back to back
+                xi[u] = *reinterpret_cast<const float4 *>(xp + (row0 + (src[u] >> 6)) * H + 4 * c4);
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -319,8 +319,7 @@ __global__ __launch_bounds__(256) void spmm_t_cols(const float *__restrict__ dY,
                 src[u] = __shfl(myrec.x, gbase + u0 + u, 64);
                 dst[u] = __shfl(myrec.y, gbase + u0 + u, 64);
                 cf[u] = __shfl(mycf, gbase + u0 + u, 64);
-                g[u] = cf[u] != 0.0f ? *reinterpret_cast<const float4 *>(dY + (int64_t)(src[u] >> 6) * F + f0)
-                                     : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                g[u] = *reinterpret_cast<const float4 *>(dY + (int64_t)(src[u] >> 6) * F + f0);     // unconditional
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
