@@ -64,8 +64,7 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
         if (valid && !(G + 1e-8f + 1e-3f < thr_log)) {
             const float4 *xj = reinterpret_cast<const float4 *>(xp + (int64_t)c * H);
             float d2 = 0.0f;
-#pragma unroll
-            for (int c8 = 0; c8 < H / 8; c8++) {
+            auto chain = [&](int c8) {
                 float4 b0 = xj[2 * c8], b1 = xj[2 * c8 + 1];
                 float df;
                 df = __fadd_rn(xi[8 * c8 + 0], -b0.x); d2 = __fmaf_rn(df, df, d2);
@@ -76,8 +75,21 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
                 df = __fadd_rn(xi[8 * c8 + 5], -b1.y); d2 = __fmaf_rn(df, df, d2);
                 df = __fadd_rn(xi[8 * c8 + 6], -b1.z); d2 = __fmaf_rn(df, df, d2);
                 df = __fadd_rn(xi[8 * c8 + 7], -b1.w); d2 = __fmaf_rn(df, df, d2);
+            };
+            // first cache line of the row (32 features): the running sum of the fmaf chain only grows, so sqrt of the
+            // partial sum is a rigorous lower bound of the distance -- if even that cannot reach the L-th log-score, the
+            // second line is never fetched
+            constexpr int HEAD = H >= 64 ? 4 : H / 8;
+#pragma unroll
+            for (int c8 = 0; c8 < HEAD; c8++) chain(c8);
+            bool alive = true;
+            // log p' = G + log(exp(t dist) + 1e-8) is decreasing in dist: evaluate it at the lower bound (fast math + margin)
+            if (HEAD < H / 8) alive = !(G + __logf(__expf(t * sqrtf(d2)) + 1e-8f) + 1e-3f < thr_log);
+            if (alive) {
+#pragma unroll
+                for (int c8 = HEAD; c8 < H / 8; c8++) chain(c8);
+                key = make_key(score_from_dist(c_sqrt(d2), t, true, G), (int32_t)c);
             }
-            key = make_key(score_from_dist(c_sqrt(d2), t, true, G), (int32_t)c);
         }
         key = wave_sort<false>(key, lane);
         list = wave_merge_top64_asc(list, key, lane);
