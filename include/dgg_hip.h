@@ -234,11 +234,13 @@ int dgg_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, 
 int dgg_norm_bwd_da_part(const int32_t *idx, const float *w, const float *rs, const float *dA, int64_t rows, int K, int64_t row0,
                          const void *part_ws, int64_t ncols, float *coef_ws, float *da, void *stream);
 /* SDDMM of dgg_ell_spmm_bwd (dA only) fused with the row side of dgg_norm_bwd_da_part: one pass over the row instead of
- * two.  dA [rows,K] overwritten, da [ncols] zeroed by the caller, coef_ws rows*K floats.  Returns DGG_ERR_UNSUPPORTED
- * unless F is 128 or 256 with 16-byte aligned rows (then use the two separate calls). */
+ * two (ONE launch).  dA [rows,K] overwritten, da [ncols] zeroed by the caller, coef_ws rows*K floats.  Returns
+ * DGG_ERR_UNSUPPORTED unless F is 128 or 256 with 16-byte aligned rows (then use the two separate calls).  Follow with
+ * dgg_norm_da_cols_part (the neighbour-side sums of the coefficients, through the partition). */
 int dgg_ell_sddmm_norm_part(const int32_t *idx, const float *ahat, const float *w, const float *rs, const float *X,
                             const float *dY, int64_t rows, int K, int F, int64_t row0, int skip_zero, const void *part_ws,
                             int64_t ncols, float *coef_ws, float *dA, float *da, void *stream);
+int dgg_norm_da_cols_part(const void *part_ws, int64_t rows, int K, int64_t ncols, const float *coef_ws, float *da, void *stream);
 
 #ifdef __cplusplus
 }

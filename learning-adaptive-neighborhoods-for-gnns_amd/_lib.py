@@ -54,6 +54,7 @@ PROTOTYPES = {
     "dgg_gcnii_epilogue_fwd": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp],
     "dgg_gcnii_epilogue_bwd": [_vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp],
     "dgg_ell_spmm_t_part": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp],
+    "dgg_norm_da_cols_part": [_vp, _i64, _i32, _i64, _vp, _vp, _vp],
     "dgg_ell_sddmm_norm_part": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp],
     "dgg_edge_bwd": [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _vp],
 }

@@ -507,8 +507,9 @@ int dgg_ell_spmm_bwd(const int32_t *idx, const float *ahat, const float *X, cons
     return dgg_check_launch("ell_spmm_bwd");
 }
 
-// SDDMM (dA = <dY_i, X_j>, no dX) fused with the normalisation backward's phase 1 through the partition of the forward:
-// dA [rows,K] and da [ncols] (zeroed by the caller) out; coef_ws: rows*K floats.  DGG_ERR_UNSUPPORTED when the fused
+// SDDMM (dA = <dY_i, X_j>, no dX) fused with the ROW side of the normalisation backward's phase 1 (one launch): dA [rows,K],
+// da[row0 + i] (da [ncols] zeroed by the caller) and the per-entry coefficients coef_ws [rows*K] in partition order; follow
+// with dgg_norm_da_cols_part for the neighbour-side sums.  DGG_ERR_UNSUPPORTED when the fused
 // kernel does not cover the shape (F not in {128, 256} or unaligned rows): use dgg_ell_spmm_bwd + dgg_norm_bwd_da_part.
 int dgg_ell_sddmm_norm_part(const int32_t *idx, const float *ahat, const float *w, const float *rs, const float *X,
                             const float *dY, int64_t rows, int K, int F, int64_t row0, int skip_zero, const void *part_ws,
@@ -526,7 +527,15 @@ int dgg_ell_sddmm_norm_part(const int32_t *idx, const float *ahat, const float *
     else
         hipLaunchKernelGGL((sddmm_pair_kernel<2, true>), dim3(rows_grid(rows)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, rows, K,
                            skip_zero, dA, w, rs, row0, slotmap, coef_ws, da);
-    return dgg_norm_da_cols_impl(part_ws, rows, K, ncols, coef_ws, da, st);
+    return dgg_check_launch("ell_sddmm_norm_part");
+}
+
+// second half of the normalisation backward's phase 1: da_j += column sums of the coefficients written by
+// dgg_ell_sddmm_norm_part (or dgg_norm_bwd_da_part's row pass), through the partition
+int dgg_norm_da_cols_part(const void *part_ws, int64_t rows, int K, int64_t ncols, const float *coef_ws, float *da, void *stream) {
+    if (rows == 0) return 0;
+    if (!dgg_part_slotmap(part_ws, rows, K, ncols)) return dgg_set_error(DGG_ERR_ARG, "norm_da_cols_part: no partition");
+    return dgg_norm_da_cols_impl(part_ws, rows, K, ncols, coef_ws, da, (hipStream_t)stream);
 }
 
 int dgg_gcnii_epilogue_fwd(const float *sw, const float *hi, const float *h0, const float *inp, int64_t n, float theta, float alpha,

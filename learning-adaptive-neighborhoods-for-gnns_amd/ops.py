@@ -298,7 +298,7 @@ def spmm_bwd(idx, ahat, X, dY, need_dx=True, skip_zero=False, part=None, part_co
     return dA, dX
 
 
-def sddmm_norm(idx, ahat, w, rs, X, dY, row0, part, skip_zero=True):
+def sddmm_norm(idx, ahat, w, rs, X, dY, row0, part, skip_zero=True, cols=True):
     """dA = <dY_i, X_j> and da (phase 1 of the normalisation backward) in one pass over the rows; None when the fused
     kernel does not cover the shape (then: spmm_bwd + norm_bwd_da)."""
     N, K = idx.shape
@@ -312,6 +312,8 @@ def sddmm_norm(idx, ahat, w, rs, X, dY, row0, part, skip_zero=True):
     _lib.check(_lib.lib().dgg_ell_sddmm_norm_part(_ptr(idx), _ptr(_chk(ahat)), _ptr(_chk(w)), _ptr(_chk(rs)), _ptr(X), _ptr(dY), N, K, F,
                                                   row0, int(skip_zero), _ptr(part), rs.shape[0], _ptr(coef), _ptr(dA), _ptr(da),
                                                   _stream()), "ell_sddmm_norm_part")
+    if cols:     # neighbour-side sums (cols=False: diagnostics that time the fused kernel alone)
+        _lib.check(_lib.lib().dgg_norm_da_cols_part(_ptr(part), N, K, rs.shape[0], _ptr(coef), _ptr(da), _stream()), "norm_da_cols_part")
     return dA, da
 
 
