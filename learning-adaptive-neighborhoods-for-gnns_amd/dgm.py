@@ -249,6 +249,25 @@ class DGG_LearnableK_debug(nn.Module):
             ex_in = avals
         return d, ex_in
 
+    @staticmethod
+    def _norm_deg(deg, consts, eps):
+        """normalised degree and the (mean, std) it was normalised with: batch statistics (unbiased std) or constants"""
+        mu, sd = (deg.mean(), deg.std()) if consts is None else (deg.new_tensor(consts[0]), deg.new_tensor(consts[1]))
+        return (deg - mu) / (sd + eps), mu, sd
+
+    def _stochastic_k(self, feat, deg, consts, embed):
+        """stochastic_k in TRAINING mode (reference dgm.py:2041-2056): the latent of the k-net is sampled with the
+        reparameterisation trick, latent = k_mu(z) + eps * exp(k_logvar(z) / 2), eps ~ N(0, 1).  The dense layers run on the
+        MFMA linear kernel (autograd through ops.LinearFn); the sampling and the [N]-sized tail are elementwise torch ops."""
+        kn = self.k_net
+        z = ops.LinearFn.apply(feat.contiguous(), self.k_embed[0].weight, self.k_embed[0].bias, ops.ACT_LEAKY, 0) if embed else feat.contiguous()
+        mu_l = ops.LinearFn.apply(z, kn.k_mu.weight, kn.k_mu.bias, ops.ACT_NONE, 0)
+        logvar = ops.LinearFn.apply(z, kn.k_logvar.weight, kn.k_logvar.bias, ops.ACT_NONE, 0)
+        latent = mu_l + torch.randn_like(mu_l) * torch.exp(0.5 * logvar)
+        kp = ops.LinearFn.apply(latent.contiguous(), kn.k_project.weight, kn.k_project.bias, ops.ACT_NONE, 0).reshape(-1)
+        _, mu, sd = self._norm_deg(deg, consts, 0.0)
+        return torch.relu(kp * sd + mu) + 1.0
+
     def forward(self, x, in_adj, noise=True, writer=None, epoch=None):
         """x [N,dim] fp32 on the GPU; in_adj: sparse COO [N,N] (coalesced, self loops added by the caller) whose
         stored entries are the candidate edges, or `AllPairs(prior_degree)`.  `noise` is accepted and ignored
@@ -260,11 +279,6 @@ class DGG_LearnableK_debug(nn.Module):
             # "pass" returns k = None, which the reference's own select_top_k cannot consume (dgm.py:1485, 1412)
             raise NotImplementedError(f"k-net mode {self.k_net_mode!r}: the HIP path implements 'x', 'gcn-x-deg', 'input_deg' "
                                       "and 'learn_normalized_degree'")
-        if getattr(self.args, "stochastic_k", False) and self.training:
-            # dgm.py:2041-2049: in training mode the latent of the k-net is sampled (mu + eps * exp(logvar / 2)); eval mode and
-            # stochastic_k=False (the default) use mu, which is what the HIP k-net computes
-            raise NotImplementedError("stochastic_k=True in training mode (reparameterised k) is not on the HIP path; "
-                                      "use stochastic_k=False (the reference's default) or eval mode")
         if self.k_select_mode not in ("k_times_edge_prob", "k_only"):
             raise NotImplementedError(f"k-select mode {self.k_select_mode!r} is dead code in the reference")
         if self.hard:
@@ -300,8 +314,16 @@ class DGG_LearnableK_debug(nn.Module):
                 pat = csr_pattern(in_adj)
                 nadj = CsrAdjacency(pat[0], pat[1], pat[2], in_adj.coalesce().values().float(), x.shape[0]).normalize()
                 xk = ops.LinearFn.apply(nadj.matmul(xk), self.k_W, None, ops.ACT_RELU, 1)
-            k = _KnetFeatFn.apply(xk, deg, self.k_embed[0].weight, self.k_embed[0].bias, kn.k_mu.weight, kn.k_mu.bias,
-                                  kn.k_project.weight, kn.k_project.bias)
+            if getattr(self.args, "stochastic_k", False) and self.training:
+                k = self._stochastic_k(torch.cat([xk, self._norm_deg(deg, None, 1e-5)[0].unsqueeze(1)], 1), deg, None, embed=True)
+            else:
+                k = _KnetFeatFn.apply(xk, deg, self.k_embed[0].weight, self.k_embed[0].bias, kn.k_mu.weight, kn.k_mu.bias,
+                                      kn.k_project.weight, kn.k_project.bias)
+        elif getattr(self.args, "stochastic_k", False) and self.training:
+            consts = (float(self.deg_mean), float(self.deg_std)) if self.k_net_mode == "input_deg" else None
+            nd, _, _ = self._norm_deg(deg, consts, 1e-5 if consts is not None else 0.0)
+            in3 = nd.unsqueeze(1) * self.input_degree_project.weight.reshape(1, -1) + self.input_degree_project.bias
+            k = self._stochastic_k(in3, deg, consts, embed=False)
         else:
             consts = (float(self.deg_mean), float(self.deg_std)) if self.k_net_mode == "input_deg" else None
             k = _KnetDegFn.apply(deg, self.input_degree_project.weight, self.input_degree_project.bias, kn.k_mu.weight,

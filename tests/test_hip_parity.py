@@ -987,3 +987,35 @@ def test_ranked_search_stress_around_power_of_two_sizes(dev, N):
         assert np.array_equal(kept, want)
         assert np.array_equal(idx[kept], ridx[kept]) and np.array_equal(val[kept], rval[kept])
 
+
+
+@pytest.mark.parametrize("knet", ["x", "input_deg", "learn_normalized_degree"])
+def test_stochastic_k_training_mode(dev, knet, monkeypatch):
+    """stochastic_k in training mode (dgm.py:2041-2056): with eps forced to 0 the sampled latent is mu, so k must equal
+    the deterministic (eval-mode) k; with eps = 1 it differs and k_logvar receives a gradient"""
+    import dgg_amd
+    from argparse import Namespace
+    rng = np.random.default_rng(71)
+    N, d, h = 300, 20, 16
+    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=6.0, deg_std=2.0, dgg_mode_edge_net="u-v-dist",
+                     dgg_mode_k_net=knet, dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=False,
+                     symmetric_noise=False, stochastic_k=True, dgg_adj_input="input_adj", n_dgg_layers=1)
+    torch.manual_seed(1)
+    m = dgg_amd.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=args).to(dev)
+    dens = rng.random((N, N)) < 0.05
+    np.fill_diagonal(dens, True)
+    rows, cols = np.nonzero(dens)
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.ones(len(rows)), (N, N)).coalesce().to(dev)
+    x = T(rng.standard_normal((N, d)).astype(np.float32), dev)
+    m.eval()
+    k_det = Nn(m(x, A).k)
+    m.train()
+    monkeypatch.setattr(torch, "randn_like", lambda t: torch.zeros_like(t))
+    k0 = Nn(m(x, A).k)
+    np.testing.assert_allclose(k0, k_det, rtol=1e-5, atol=1e-5)
+    monkeypatch.setattr(torch, "randn_like", lambda t: torch.ones_like(t))
+    adj = m(x, A)
+    assert np.abs(Nn(adj.k) - k_det).max() > 1e-3
+    adj.values().sum().backward()
+    g = m.k_net.k_logvar.weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
