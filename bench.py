@@ -535,6 +535,18 @@ def main():
             # the north-star pair stage: SURVEY 8(d) algorithmic flops (232/pair over all N^2 pairs) per second; the
             # ranked / pruned kernels score only the pairs that can still enter a row's top-64, so this exceeds the
             # fp32 peak by construction (the exhaustive kernel, which executes every pair, reaches frac 0.07)
+            # the three whole-step fractions it asks to be published, labelled.  F = 232 flop/pair over all N^2
+            # pairs (the dense formulation's arithmetic), B = compulsory bytes (12 kB per node: every array touched once),
+            # B_virt = the N^2 fp32 score matrix scanned once.  T_roof = F/P_fp32 + B/BW_HBM is the roofline time of the DENSE
+            # formulation; this build's search never executes the unreachable pairs, so T < T_roof.
+            "survey_8d": {"F_flop": FLOP_PER_PAIR * N * float(N), "B_bytes": 12e3 * N * (d / 128.0), "B_virt_bytes": 4.0 * N * float(N),
+                          "T_s": T, "T_roof_dense_s": FLOP_PER_PAIR * N * float(N) / (FP32_PEAK_TFLOPS * 1e12) + 12e3 * N / (HBM_PEAK_GBPS * 1e9),
+                          "frac_dense_roofline": (FLOP_PER_PAIR * N * float(N) / (FP32_PEAK_TFLOPS * 1e12) + 12e3 * N / (HBM_PEAK_GBPS * 1e9)) / T,
+                          "frac_hbm_compulsory": 12e3 * N / T / (HBM_PEAK_GBPS * 1e9),
+                          "frac_hbm_virtual_stream": 4.0 * N * float(N) / T / (HBM_PEAK_GBPS * 1e9),
+                          "frac_hbm_gathered": sum(v["bytes"] for v in kern.values()) / T / (HBM_PEAK_GBPS * 1e9),
+                          "note": "fractions above 1 mean the step beats that (dense-formulation) bound; frac_hbm_gathered counts the "
+                                  "gathered rows of the five gather kernels once per use over the whole step time"},
             "pair_stage": {"kernel": "allpairs_topk(" + a.noise + ")", "kernel_ms": t_pair * 1e3,
                            "algorithmic_tflops": FLOP_PER_PAIR * pairs / t_pair / 1e12, "fp32_peak_tflops": FP32_PEAK_TFLOPS,
                            "pairs_per_s": pairs / t_pair},
