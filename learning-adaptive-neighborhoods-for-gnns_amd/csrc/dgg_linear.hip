@@ -160,10 +160,10 @@ __global__ void act_bwd_kernel(const float *__restrict__ y, const float *__restr
 // "Global float atomics").
 // Stage 2: gemm_tn_reduce sums the slab over workgroups (32-way split, 32 atomics per output) into C / colsum.
 constexpr int GT_GRID = 256, GT_PF = 8;
-template <int MB, int NB>
+template <int MB, int NB, int PFK, bool ACT>
 __global__ __launch_bounds__(256) void gemm_tn_persist(const float *__restrict__ A, const float *__restrict__ B, int64_t N,
                                                        int M1, int M2, int M1p, int M2p, float *__restrict__ slab,
-                                                       float *__restrict__ cs_slab) {
+                                                       float *__restrict__ cs_slab, const float *__restrict__ Yact, int act) {
     extern __shared__ float red[];                               // [MB*NB*16*64] + [MB*32]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, hh = lane >> 5;
     const int o0 = blockIdx.y * 32 * MB, c0 = blockIdx.z * 32 * NB;
@@ -185,9 +185,11 @@ __global__ __launch_bounds__(256) void gemm_tn_persist(const float *__restrict__
     float csum[MB];
 #pragma unroll
     for (int m = 0; m < MB; m++) csum[m] = 0.0f;
-    constexpr int PF = GT_PF;
+    constexpr int PF = PFK;                                      // k-steps per batch (fewer with the activation mask: registers)
     const int64_t step = (int64_t)gridDim.x * 4 * 2 * PF;         // node rows per sweep of the whole grid
-    float av[2][PF][MB], bv[2][PF][NB], rmask[2][PF];
+    // Yact != NULL: A is a cotangent that still has to pass through the activation of the forward (dp = dy * act'(y)); the mask
+    // is applied to the operand on the fly, which saves the separate act_bwd pass and its [N, M1] buffer
+    float av[2][PF][MB], bv[2][PF][NB], rmask[2][PF], yv[2][PF][MB];
     auto load = [&](int buf, int64_t base) {
 #pragma unroll
         for (int u = 0; u < PF; u++) {
@@ -195,7 +197,10 @@ __global__ __launch_bounds__(256) void gemm_tn_persist(const float *__restrict__
             const int64_t nc = n < N ? n : N - 1;
             rmask[buf][u] = n < N ? 1.0f : 0.0f;
 #pragma unroll
-            for (int m = 0; m < MB; m++) av[buf][u][m] = A[nc * M1 + acol[m]];
+            for (int m = 0; m < MB; m++) {
+                av[buf][u][m] = A[nc * M1 + acol[m]];
+                if (ACT) yv[buf][u][m] = Yact[nc * M1 + acol[m]];
+            }
 #pragma unroll
             for (int a = 0; a < NB; a++) bv[buf][u][a] = B[nc * M2 + bcol[a]];
         }
@@ -205,7 +210,10 @@ __global__ __launch_bounds__(256) void gemm_tn_persist(const float *__restrict__
         for (int u = 0; u < PF; u++) {
 #pragma unroll
             for (int m = 0; m < MB; m++) {
-                av[buf][u][m] *= rmask[buf][u];
+                float am = rmask[buf][u];
+                if (ACT && act == 1) am = yv[buf][u][m] > 0.0f ? am : 0.01f * am;    // LeakyReLU'
+                else if (ACT && act == 2) am = yv[buf][u][m] > 0.0f ? am : 0.0f;     // ReLU'
+                av[buf][u][m] *= am;
                 csum[m] += av[buf][u][m];
 #pragma unroll
                 for (int a = 0; a < NB; a++)
@@ -341,14 +349,19 @@ size_t gemm_tn_ws_floats(int64_t N, int M1, int M2) {
 
 template <int MB, int NB>
 void launch_gemm_tn_persist(const float *A, const float *B, int64_t N, int M1, int M2, int M1p, int M2p, float *slab,
-                            float *cs_slab, int g, hipStream_t st) {
+                            float *cs_slab, int g, const float *Yact, int act, hipStream_t st) {
     const unsigned gy = (unsigned)((M1p / 32 + MB - 1) / MB), gz = (unsigned)((M2p / 32 + NB - 1) / NB);
     const size_t lds = (size_t)(MB * NB * 16 * 64 + MB * 64) * sizeof(float);
-    hipLaunchKernelGGL((gemm_tn_persist<MB, NB>), dim3(g, gy, gz), dim3(256), lds, st, A, B, N, M1, M2, M1p, M2p, slab, cs_slab);
+    if (Yact)
+        hipLaunchKernelGGL((gemm_tn_persist<MB, NB, GT_PF / 2, true>), dim3(g, gy, gz), dim3(256), lds, st, A, B, N, M1, M2, M1p, M2p, slab,
+                           cs_slab, Yact, act);
+    else
+        hipLaunchKernelGGL((gemm_tn_persist<MB, NB, GT_PF, false>), dim3(g, gy, gz), dim3(256), lds, st, A, B, N, M1, M2, M1p, M2p, slab,
+                           cs_slab, Yact, act);
 }
 
 int launch_gemm_tn(const float *A, const float *B, int64_t N, int M1, int M2, float *C, int c_layout, float *colsum,
-                   float *ws, hipStream_t st) {
+                   float *ws, hipStream_t st, const float *Yact = nullptr, int act = 0) {
     if (!ws) return dgg_set_error(DGG_ERR_ARG, "gemm_tn: workspace is NULL (dgg_gemm_tn_ws_floats)");
     const int M1p = (M1 + 31) / 32 * 32, M2p = (M2 + 31) / 32 * 32;
     const int g = gemm_tn_grid(N, M1p, M2p);
@@ -356,12 +369,13 @@ int launch_gemm_tn(const float *A, const float *B, int64_t N, int M1, int M2, fl
     float *csl = colsum ? cs_slab : nullptr;
     int mb, nb;
     gemm_tn_shape(M1p, M2p, mb, nb);
-    if (mb == 2 && nb == 4) launch_gemm_tn_persist<2, 4>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
-    else if (mb == 2 && nb == 2) launch_gemm_tn_persist<2, 2>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
-    else if (mb == 2) launch_gemm_tn_persist<2, 1>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
-    else if (nb == 4) launch_gemm_tn_persist<1, 4>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
-    else if (nb == 2) launch_gemm_tn_persist<1, 2>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
-    else launch_gemm_tn_persist<1, 1>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, st);
+    if (Yact) mb = 1;                                            // the masked variant carries the y operand too: 32-row blocks
+    if (mb == 2 && nb == 4) launch_gemm_tn_persist<2, 4>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, Yact, act, st);
+    else if (mb == 2 && nb == 2) launch_gemm_tn_persist<2, 2>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, Yact, act, st);
+    else if (mb == 2) launch_gemm_tn_persist<2, 1>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, Yact, act, st);
+    else if (nb == 4) launch_gemm_tn_persist<1, 4>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, Yact, act, st);
+    else if (nb == 2) launch_gemm_tn_persist<1, 2>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, Yact, act, st);
+    else launch_gemm_tn_persist<1, 1>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, Yact, act, st);
     hipLaunchKernelGGL(gemm_tn_reduce, dim3((unsigned)((M1p * M2p + 255) / 256), (unsigned)(g < GT_SPLIT ? g : GT_SPLIT)), dim3(256), 0, st, slab, csl, g, M1,
                        M2, M1p, M2p, C, c_layout, colsum);
     return dgg_check_launch("gemm_tn");
@@ -391,6 +405,8 @@ int dgg_linear_bwd(const float *x, int64_t N, int d, const float *W, int out, in
     if (N == 0) return 0;
     if (!ws) return dgg_set_error(DGG_ERR_ARG, "linear_bwd: workspace is NULL (dgg_linear_bwd_ws_floats)");
     const float *dp = dy;
+    if (act != 0 && !dx && dW)      // only the weight gradient is wanted: the activation mask rides on the GEMM's operand load
+        return launch_gemm_tn(dy, x, N, out, d, dW, w_layout == 0 ? 0 : 1, db, ws + (size_t)N * out, st, y, act);
     if (act != 0) {
         int64_t n = N * out;
         unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
