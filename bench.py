@@ -512,6 +512,9 @@ def main():
     # the roofline object describes ONE launch (so that its duration can be checked against the rocprofv3 kernel
     # stats under profiles/): the longest single kernel of the step
     dom = max((n for n in kern if "composite" not in kern[n]), key=lambda n: kern[n]["ms"])
+    # the row of profiles/*_kernel_stats.csv each bench name corresponds to at the default shape
+    ROCPROF_NAME = {"allpairs_topk": "allpairs_topk_ranked<64>", "spmm_bwd": "sddmm_pair_kernel<1, true>",
+                    "spmm_fwd": "spmm_fwd_kernel<2>"}
     for n_, v in kern.items():
         v["GBps"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
     pairs = float(rows_loc) * N
@@ -526,7 +529,7 @@ def main():
                        "nodes": N, "feat": d, "latent": h, "ell_width": 64, "pairs_per_s": N * float(N) / T,
                        "x_grad": a.x_grad, "topk_algo": a.algo, "noise": a.noise, "hipgraph": graph is not None, "parallelism": f"row-shard x{world}"},
             # dominant kernel BY TIME of the step (an O(N*K) gather/scatter kernel since the pair stage became O(N*150))
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dom, "rocprof_kernel": ROCPROF_NAME.get(dom), "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": kern[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": traffic.get(dom),
                          "kernel_ms": kern[dom]["ms"], "algorithmic_bytes": kern[dom]["bytes"],
                          "note": "algorithmic bytes per launch / event-timed duration; gathered rows count once per use"},
