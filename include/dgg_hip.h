@@ -160,6 +160,16 @@ int dgg_csr_rank_ramp_fwd(const float *p, const int64_t *rowptr, const int32_t *
 /* g = d loss / d out -> dp [E] (direct + through S -> k), dkz [N] = d loss / d (S_i w + b) (dw = <dkz, S>, db = sum dkz) */
 int dgg_csr_rank_ramp_bwd(const float *p, const int64_t *rowptr, int64_t N, const float *w, const float *b, const float *S,
                           const float *k, const int32_t *pos, const float *g, float *dp, float *dkz, void *stream);
+/* `DGG_Ablations.forward` (dgm.py:1927-1962): edge_rank = sigmoid(sigmoid(score) + noise), noise ~ U(-1,1) per stored edge
+ * (dgm.py:1930-1933; the caller draws the noise); out [E] */
+int dgg_csr_noisy_sigmoid_fwd(const float *p, const float *noise, int64_t E, float *out, void *stream);
+/* dp_e = g_e out_e (1 - out_e) */
+int dgg_csr_noisy_sigmoid_bwd(const float *out, const float *g, int64_t E, float *dp, void *stream);
+/* fixed k (dgm.py:1940-1942, `srt_edge_rank[:, k:] = 0`): out_e = p_e if fewer than kcut entries of the row sort before e
+ * under (rank desc, column asc), else 0; pos as in dgg_csr_rank_ramp_fwd */
+int dgg_csr_rank_cut_fwd(const float *p, const int64_t *rowptr, const int32_t *col, int64_t N, int kcut, float *out, int32_t *pos,
+                         void *stream);
+int dgg_csr_rank_cut_bwd(const int32_t *pos, const float *g, int64_t E, int kcut, float *dp, void *stream);
 /* normalize_adj of the *_DGG_00 wrappers (model.py:1340-1352): rs = row sums, ahat_e = rs_i^-1/2 w_e rs_j^-1/2 */
 int dgg_csr_row_sum(const float *vals, const int64_t *rowptr, int64_t N, float *rs, void *stream);
 int dgg_csr_normalize_fwd(const int64_t *rowptr, const int32_t *col, const float *w, const float *rs, int64_t N, float *ahat,

@@ -33,6 +33,10 @@ PROTOTYPES = {
     "dgg_edge_mlp_bwd": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
     "dgg_csr_rank_ramp_fwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_csr_rank_ramp_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "dgg_csr_noisy_sigmoid_fwd": [_vp, _vp, _i64, _vp, _vp],
+    "dgg_csr_noisy_sigmoid_bwd": [_vp, _vp, _i64, _vp, _vp],
+    "dgg_csr_rank_cut_fwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
+    "dgg_csr_rank_cut_bwd": [_vp, _vp, _i64, _i32, _vp, _vp],
     "dgg_csr_row_sum": [_vp, _vp, _i64, _vp, _vp],
     "dgg_csr_normalize_fwd": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "dgg_csr_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],

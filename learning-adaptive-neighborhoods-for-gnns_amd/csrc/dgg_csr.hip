@@ -185,6 +185,49 @@ __global__ __launch_bounds__(WPB * 64) void csr_rank_ramp_bwd_kernel(const float
     }
 }
 
+// ---- `DGG_Ablations.forward` (dgm.py:1927-1962): noisy second sigmoid and the fixed-k truncation -----------------------
+// edge_rank = sigmoid(sigmoid(score) + noise), noise ~ U(-1,1) per stored edge (dgm.py:1930-1933)
+__global__ __launch_bounds__(256) void csr_noisy_sigmoid_fwd_kernel(const float *__restrict__ p, const float *__restrict__ noise,
+                                                                  int64_t E, float *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < E) out[e] = 1.0f / (1.0f + c_exp(-__fadd_rn(p[e], noise[e])));
+}
+__global__ __launch_bounds__(256) void csr_noisy_sigmoid_bwd_kernel(const float *__restrict__ out, const float *__restrict__ g,
+                                                                  int64_t E, float *__restrict__ dp) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < E) dp[e] = g[e] * out[e] * (1.0f - out[e]);
+}
+// srt_edge_rank[:, k:] = 0 (dgm.py:1940-1942): an entry survives iff fewer than kcut entries of its row sort before it
+__global__ __launch_bounds__(WPB * 64) void csr_rank_cut_fwd_kernel(const float *__restrict__ p, const int64_t *__restrict__ rowptr,
+                                                                   const int32_t *__restrict__ col, int64_t N, int kcut,
+                                                                   float *__restrict__ out, int32_t *__restrict__ pos) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
+    for (int64_t mb = e0; mb < e1; mb += 64) {
+        const int64_t me = mb + lane;
+        const bool have = me < e1;
+        const uint64_t mykey = have ? make_key(p[me], col[me]) : 0ull;
+        int cnt = 0;
+        for (int64_t qb = e0; qb < e1; qb += 64) {
+            const int64_t q = qb + lane;
+            const uint64_t qk = q < e1 ? make_key(p[q], col[q]) : 0ull;
+            const int n = e1 - qb < 64 ? (int)(e1 - qb) : 64;
+            for (int r = 0; r < n; r++) cnt += shfl_u64(qk, r) > mykey ? 1 : 0;
+        }
+        if (have) {
+            pos[me] = cnt;
+            out[me] = cnt < kcut ? p[me] : 0.0f;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void csr_rank_cut_bwd_kernel(const int32_t *__restrict__ pos, const float *__restrict__ g, int64_t E,
+                                                             int kcut, float *__restrict__ dp) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < E) dp[e] = pos[e] < kcut ? g[e] : 0.0f;
+}
+
 // ---- GATConv_DGG (reference model.py:534-577): row softmax with a uniform background ---------------------------------
 // The reference builds a dense [N,N] logit matrix: e_ij on the entries of edge_index, -1e20 elsewhere, multiplied by the
 // dense learned adjacency.  Every pair that is in neither list gets logit -1e20 * 0 = -0, i.e. exp(0) = 1 in the softmax:
@@ -300,6 +343,33 @@ int dgg_csr_rank_ramp_bwd(const float *p, const int64_t *rowptr, int64_t N, cons
     hipLaunchKernelGGL(csr_rank_ramp_bwd_kernel, dim3((unsigned)((N + WPB - 1) / WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, p, rowptr,
                        N, w, b, S, k, pos, g, dp, dkz);
     return dgg_check_launch("csr_rank_ramp_bwd");
+}
+
+int dgg_csr_noisy_sigmoid_fwd(const float *p, const float *noise, int64_t E, float *out, void *stream) {
+    if (E == 0) return 0;
+    hipLaunchKernelGGL(csr_noisy_sigmoid_fwd_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, noise, E, out);
+    return dgg_check_launch("csr_noisy_sigmoid_fwd");
+}
+
+int dgg_csr_noisy_sigmoid_bwd(const float *out, const float *g, int64_t E, float *dp, void *stream) {
+    if (E == 0) return 0;
+    hipLaunchKernelGGL(csr_noisy_sigmoid_bwd_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, g, E, dp);
+    return dgg_check_launch("csr_noisy_sigmoid_bwd");
+}
+
+int dgg_csr_rank_cut_fwd(const float *p, const int64_t *rowptr, const int32_t *col, int64_t N, int kcut, float *out, int32_t *pos,
+                         void *stream) {
+    if (N == 0) return 0;
+    if (kcut < 0) return dgg_set_error(DGG_ERR_ARG, "csr_rank_cut_fwd: kcut must be >= 0");
+    hipLaunchKernelGGL(csr_rank_cut_fwd_kernel, dim3((unsigned)((N + WPB - 1) / WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, p, rowptr,
+                       col, N, kcut, out, pos);
+    return dgg_check_launch("csr_rank_cut_fwd");
+}
+
+int dgg_csr_rank_cut_bwd(const int32_t *pos, const float *g, int64_t E, int kcut, float *dp, void *stream) {
+    if (E == 0) return 0;
+    hipLaunchKernelGGL(csr_rank_cut_bwd_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, g, E, kcut, dp);
+    return dgg_check_launch("csr_rank_cut_bwd");
 }
 
 }  // extern "C"

@@ -349,28 +349,41 @@ class _DGGClassFn(torch.autograd.Function):
     w2 = 1, b2 = 0 (edge_feat.sum(-1), dgm.py:1786)."""
 
     @staticmethod
-    def forward(ctx, xe, We, be, wdd, bdd, pattern):
+    def forward(ctx, xe, We, be, wdd, bdd, pattern, noise=None, kcut=None):
         rowptr, col, erow = pattern
         h = We.shape[0]
         Wcat = torch.cat([We, -We], 0)
         AB = ops.linear_fwd(xe, Wcat, None, ops.ACT_NONE)
         ones, zero = torch.ones(h, device=xe.device), torch.zeros(1, device=xe.device)
         p, _ = ops.edge_mlp_fwd(AB, xe, erow, col, None, None, 0, 0.0, None, None, None, be, ones, zero, ops.ACT_LEAKY)
-        out, S, k, pos = ops.csr_rank_ramp_fwd(p, rowptr, col, wdd.reshape(-1), bdd)
-        ctx.save_for_backward(xe, We, be, wdd, bdd, rowptr, col, Wcat, AB, ones, zero, p, S, k, pos)
+        # DGG_Ablations (dgm.py:1930-1933): a second sigmoid over rank + U(-1,1) noise
+        p2 = p if noise is None else ops.csr_noisy_sigmoid_fwd(p, noise)
+        if kcut is None:
+            out, S, k, pos = ops.csr_rank_ramp_fwd(p2, rowptr, col, wdd.reshape(-1), bdd)
+        else:                                                       # fixed k (dgm.py:1940-1942): no degree estimator
+            out, pos = ops.csr_rank_cut_fwd(p2, rowptr, col, kcut)
+            S = k = torch.full((xe.shape[0],), float(kcut), device=xe.device)
+        ctx.noisy, ctx.kcut = noise is not None, kcut
+        ctx.save_for_backward(xe, We, be, wdd, bdd, rowptr, col, Wcat, AB, ones, zero, p, p2, S, k, pos)
         ctx.mark_non_differentiable(k)
         return out, k
 
     @staticmethod
     def backward(ctx, g, _dk):
-        xe, We, be, wdd, bdd, rowptr, col, Wcat, AB, ones, zero, p, S, k, pos = ctx.saved_tensors
+        xe, We, be, wdd, bdd, rowptr, col, Wcat, AB, ones, zero, p, p2, S, k, pos = ctx.saved_tensors
         h = We.shape[0]
-        dp, dkz = ops.csr_rank_ramp_bwd(p, rowptr, wdd.reshape(-1), bdd, S, k, pos, g.contiguous())
+        if ctx.kcut is None:
+            dp, dkz = ops.csr_rank_ramp_bwd(p2, rowptr, wdd.reshape(-1), bdd, S, k, pos, g.contiguous())
+            dwdd, dbdd = torch.dot(dkz, S).reshape(wdd.shape), dkz.sum().reshape(bdd.shape)
+        else:
+            dp = ops.csr_rank_cut_bwd(pos, g.contiguous(), ctx.kcut)
+            dwdd, dbdd = torch.zeros_like(wdd), torch.zeros_like(bdd)
+        if ctx.noisy:
+            dp = ops.csr_noisy_sigmoid_bwd(p2, dp)
         dAB, dpar, _ = ops.edge_mlp_bwd(AB, col, None, p, dp, None, None, None, None, None, be, ones, zero, ops.ACT_LEAKY, False,
                                         rowptr=rowptr)
         dxe, dWcat, _ = ops.linear_bwd(xe, Wcat, AB, dAB, ops.ACT_NONE, need_dx=True, need_db=False)
-        return (dxe, dWcat[:h] - dWcat[h:], dpar[3 * h:4 * h], torch.dot(dkz, S).reshape(wdd.shape), dkz.sum().reshape(bdd.shape),
-                None)
+        return dxe, dWcat[:h] - dWcat[h:], dpar[3 * h:4 * h], dwdd, dbdd, None, None, None
 
 
 class DGG(nn.Module):
@@ -397,3 +410,35 @@ class DGG(nn.Module):
         out, k = _DGGClassFn.apply(xe, self.edge_encoder[0].weight, self.edge_encoder[0].bias, self.degree_decoder[0].weight,
                                    self.degree_decoder[0].bias, pattern)
         return CsrAdjacency(pattern[0], pattern[1], pattern[2], out, x.shape[0], k=k), xe
+
+
+class DGG_Ablations(DGG):
+    """Drop-in for the reference's `DGG_Ablations` (dgm.py:1876-1968; behind GCN_DGG_Ablations / GAT_DGG_Ablations,
+    model.py:406-486, 1436-1561): the `DGG` generator with edge_rank = sigmoid(sigmoid(score) + noise), noise ~ U(-1,1) drawn per
+    stored edge on every call (dgm.py:1930-1933), and an optional FIXED k: `k=int` keeps the k best-ranked edges of each row
+    with their rank and zeroes the others (dgm.py:1940-1942) instead of the learned degree + ramp.
+    `set_noise(t)` pins the noise tensor of the next call (parity tests); otherwise it comes from torch's generator like the
+    reference's `torch.rand`."""
+
+    _noise = None
+
+    def set_noise(self, noise):
+        self._noise = noise
+
+    def forward(self, x, adj, k=None, writer=None, epoch=None):
+        assert x.ndim == 2 and len(adj.shape) == 2
+        assert self.edge_encoder[0].weight.shape[1] == self.node_encoder[0].weight.shape[0], \
+            "DGG_Ablations feeds x'_u - x'_v (latent_dim features) to edge_encoder: extra_edge_dim must be 0 (dgm.py:1924-1927)"
+        if isinstance(adj, (CsrAdjacency, EllAdjacency)):
+            adj = adj.to_sparse().detach()
+        pattern = csr_pattern(adj)
+        E = pattern[1].shape[0]
+        noise, self._noise = self._noise, None
+        if noise is None:
+            noise = torch.rand(E, device=x.device) * 2 - 1
+        assert noise.shape == (E,)
+        xe = ops.LinearFn.apply(x, self.node_encoder[0].weight, self.node_encoder[0].bias, ops.ACT_LEAKY, 0)
+        out, kk = _DGGClassFn.apply(xe, self.edge_encoder[0].weight, self.edge_encoder[0].bias, self.degree_decoder[0].weight,
+                                    self.degree_decoder[0].bias, pattern, noise.to(torch.float32).contiguous(),
+                                    None if k is None else int(k))
+        return CsrAdjacency(pattern[0], pattern[1], pattern[2], out, x.shape[0], k=kk), xe

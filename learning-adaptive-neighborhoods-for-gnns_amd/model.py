@@ -14,7 +14,7 @@ from torch.nn.parameter import Parameter
 
 from . import ops
 from .adjacency import CsrAdjacency, EllAdjacency, ell_from_dense
-from .dgm import DGG, DGG_LearnableK_debug
+from .dgm import DGG, DGG_Ablations, DGG_LearnableK_debug
 
 
 def _as_ell(adj):
@@ -356,6 +356,29 @@ class GCN_DGG_00(nn.Module):
 
     def dgg_net(self, x, i, unnorm_adj, writer, epoch):
         return self.dggs[i](x=x, adj=unnorm_adj, noise=False, writer=writer, epoch=epoch)
+
+
+class GCN_DGG_Ablations(GCN_DGG_00):
+    """GCN_DGG_00 on a `DGG_Ablations` generator (reference model.py:1436-1561): same two-layer body, the generator is called
+    with k=None (learned degree), fresh U(-1,1) rank noise on every call."""
+
+    def __init__(self, nfeat=32, nlayers=None, nhidden=32, nclass=10, args=None, **kwargs):
+        super().__init__(nfeat, nlayers, nhidden, nclass, args, **kwargs)
+        self.dggs = nn.ModuleList([DGG_Ablations(in_dim=nfeat, latent_dim=nhidden, args=args)])
+        self.params2 = list(self.conv2.parameters())
+        self.params2.extend(list(self.dggs.parameters()))
+
+    def dgg_net(self, x, i, unnorm_adj, writer, epoch):
+        return self.dggs[i](x=x, adj=unnorm_adj, k=None, writer=writer, epoch=epoch)
+
+
+class GAT_DGG_Ablations(GAT_DGG_00):
+    """GAT_DGG_00 on a `DGG_Ablations` generator (reference model.py:406-486)."""
+
+    def __init__(self, nfeat=32, nlayers=None, nhidden=32, nclass=10, args=None, nhead=8, nhead_out=1, alpha=0.2, dropout=0.6,
+                 **kwargs):
+        super().__init__(nfeat, nlayers, nhidden, nclass, args, nhead, nhead_out, alpha, dropout, **kwargs)
+        self.dgg = DGG_Ablations(in_dim=nfeat, latent_dim=nhidden, args=args)
 
 
 class GCNII_DGG(nn.Module):

@@ -204,6 +204,37 @@ def csr_rank_ramp_bwd(p, rowptr, w, b, S, k, pos, g):
     return dp, dkz
 
 
+def csr_noisy_sigmoid_fwd(p, noise):
+    """dgm.py:1930-1933: sigmoid(p + noise) per stored edge"""
+    out = torch.empty_like(p)
+    _lib.check(_lib.lib().dgg_csr_noisy_sigmoid_fwd(_ptr(_chk(p)), _ptr(_chk(noise)), p.shape[0], _ptr(out), _stream()),
+               "csr_noisy_sigmoid_fwd")
+    return out
+
+
+def csr_noisy_sigmoid_bwd(out, g):
+    dp = torch.empty_like(out)
+    _lib.check(_lib.lib().dgg_csr_noisy_sigmoid_bwd(_ptr(_chk(out)), _ptr(_chk(g)), out.shape[0], _ptr(dp), _stream()),
+               "csr_noisy_sigmoid_bwd")
+    return dp
+
+
+def csr_rank_cut_fwd(p, rowptr, col, kcut):
+    """dgm.py:1940-1942 -> out [E] (p on the kcut best entries of each row, 0 elsewhere), pos [E] (int32)"""
+    p = _chk(p)
+    out = torch.empty_like(p)
+    pos = torch.empty(p.shape, device=p.device, dtype=torch.int32)
+    _lib.check(_lib.lib().dgg_csr_rank_cut_fwd(_ptr(p), _ptr(rowptr), _ptr(col), rowptr.shape[0] - 1, int(kcut), _ptr(out), _ptr(pos),
+                                               _stream()), "csr_rank_cut_fwd")
+    return out, pos
+
+
+def csr_rank_cut_bwd(pos, g, kcut):
+    dp = torch.empty_like(g)
+    _lib.check(_lib.lib().dgg_csr_rank_cut_bwd(_ptr(pos), _ptr(_chk(g)), g.shape[0], int(kcut), _ptr(dp), _stream()), "csr_rank_cut_bwd")
+    return dp
+
+
 def csr_row_sum(vals, rowptr):
     N = rowptr.shape[0] - 1
     rs = torch.empty((N,), device=vals.device, dtype=torch.float32)

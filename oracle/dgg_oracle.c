@@ -840,6 +840,20 @@ ORA_API void ora_csr_rank_ramp_bwd(const float *p, const int64_t *rowptr, int64_
         }
     }
 }
+/* `DGG_Ablations.forward` (dgm.py:1930-1933): edge_rank = sigmoid(sigmoid(score) + noise) */
+ORA_API void ora_csr_noisy_sigmoid(const float *p, const float *noise, int64_t E, float *out) {
+    for (int64_t e = 0; e < E; e++) { float z = p[e] + noise[e]; out[e] = 1.0f / (1.0f + ora_exp(-z)); }
+}
+/* fixed k (dgm.py:1940-1942): the kcut best entries of a row keep their rank, the others become 0 */
+ORA_API void ora_csr_rank_cut(const float *p, const int64_t *rowptr, const int32_t *col, int64_t N, int kcut, float *out,
+                              int32_t *pos) {
+    for (int64_t i = 0; i < N; i++) for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
+        int c = 0;
+        for (int64_t q = rowptr[i]; q < rowptr[i + 1]; q++) c += better(p[q], col[q], p[e], col[e]);
+        pos[e] = c;
+        out[e] = c < kcut ? p[e] : 0.0f;
+    }
+}
 /* ora_edge_mlp_bwd on a CSR-valued adjacency: entry e of row i is (i, col[e]) with cotangent dval[e] */
 ORA_API void ora_edge_mlp_bwd_csr(const float *AB, int64_t N, int hw, const int64_t *rowptr, const int32_t *col,
                                   const float *dval, const float *b1, const float *w2, float b2, int act, float *dAB,

@@ -388,6 +388,21 @@ def csr_rank_ramp_bwd(p, rowptr, w, b, S, k, pos, g):
     return dp, dkz
 
 
+def csr_noisy_sigmoid(p, noise):
+    p, noise = f32(p), f32(noise)
+    out = np.empty_like(p)
+    lib().ora_csr_noisy_sigmoid(_p(p), _p(noise), C.c_int64(p.shape[0]), _p(out))
+    return out
+
+
+def csr_rank_cut(p, rowptr, col, kcut):
+    """-> out [E], pos [E]"""
+    p, rowptr, col = f32(p), _rp(rowptr), i32(col)
+    out, pos = np.empty_like(p), np.empty(p.shape[0], np.int32)
+    lib().ora_csr_rank_cut(_p(p), _p(rowptr), _p(col), C.c_int64(rowptr.shape[0] - 1), C.c_int(int(kcut)), _p(out), _p(pos))
+    return out, pos
+
+
 def edge_mlp_bwd_csr(AB, rowptr, col, dval, b1, w2, b2, act=1):
     AB, rowptr, col, dval = f32(AB), _rp(rowptr), i32(col), f32(dval)
     hw = AB.shape[1] // 2

@@ -295,6 +295,93 @@ def gat_cases():
     print("model_gat_dgg_00 ok", tuple(logp.shape), "keys", len(m.state_dict()))
 
 
+def ablations_cases():
+    """`DGG_Ablations` (dgm.py:1876-1968) with learned k and with k=int, and its wrappers GCN_DGG_Ablations (model.py:1436-1561)
+    and GAT_DGG_Ablations (model.py:406-486).  The per-edge U(-1,1) rank noise (dgm.py:1932) is captured from torch.rand."""
+    N, d, h, C = 150, 20, 16, 5
+    gen = torch.Generator().manual_seed(41)
+    A = random_graph(N, 10, gen).to_dense()
+    A[:2, :] = (torch.rand(2, N, generator=gen) < 0.55).float()      # two hubs wider than the ELL width
+    A = ((A + A.T) > 0).float()
+    A.fill_diagonal_(1.0)
+    in_adj = A.to_sparse().coalesce()
+    x = torch.randn(N, d, generator=gen)
+    a = base_args()
+    real_rand = torch.rand
+    captured = []
+
+    def rec_rand(*args, **kw):
+        kw.pop("device", None)
+        r = real_rand(*args, **kw)
+        captured.append(r.clone())
+        return r
+
+    def common(mod, extra):
+        fx = dict(extra)
+        for k_, v in mod.state_dict().items():
+            fx["p." + k_] = v.detach().numpy()
+        for k_, p_ in mod.named_parameters():
+            fx["g." + k_] = p_.grad.numpy() if p_.grad is not None else np.zeros_like(p_.detach().numpy())
+        return fx
+
+    ii = in_adj.indices().numpy().astype(np.int32)
+    for tag, kfix in [("learnk", None), ("k5", 5)]:
+        torch.manual_seed(99)
+        m = dgm.DGG_Ablations(in_dim=d, latent_dim=h, args=a)
+        m.eval()
+        xr = x.clone().requires_grad_(True)
+        captured.clear()
+        torch.manual_seed(1234)
+        torch.rand = rec_rand
+        try:
+            out, xe = m(xr, in_adj, k=kfix)
+        finally:
+            torch.rand = real_rand
+        assert len(captured) == 1
+        outd = out.to_dense()
+        cot = torch.from_numpy(grid_normal(91, (N, N)))
+        cote = torch.from_numpy(grid_normal(92, (N, h)))
+        ((outd * cot).sum() + (xe * cote).sum()).backward()
+        fx = common(m, {"x": x.numpy(), "rows": ii[0], "cols": ii[1], "adj_vals": in_adj.values().numpy(),
+                        "noise": (captured[0] * 2 - 1).numpy(), "out": outd.detach().numpy(), "xe": xe.detach().numpy(),
+                        "cot": cot.numpy(), "cote": cote.numpy(), "g.x": xr.grad.numpy()})
+        meta = dict(name="ablations_" + tag, N=N, d=d, h=h, k=kfix, torch=torch.__version__, args=vars(a),
+                    reference="dgm.py:1904-1968 DGG_Ablations.forward")
+        fx["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, f"ablations_{tag}.npz"), **fx)
+        print("ablations", tag, "ok: nnz/row max", int((outd != 0).sum(-1).max()), "min", int((outd != 0).sum(-1).min()))
+    # wrappers: in_adj WITHOUT self loops (the wrappers add them)
+    A2 = (A - torch.eye(N)).to_sparse().coalesce()
+    refmodel.remove_self_loops = lambda ei: (ei[:, ei[0] != ei[1]], None)                     # torch_geometric.utils stand-ins
+    refmodel.add_self_loops = lambda ei, num_nodes=None: (torch.cat([ei, torch.arange(num_nodes).repeat(2, 1)], 1), None)
+    for name, ctor, kw in [("model_gcn_dgg_ablations", refmodel.GCN_DGG_Ablations, {}),
+                           ("model_gat_dgg_ablations", refmodel.GAT_DGG_Ablations, {"nhead": 2})]:
+        torch.manual_seed(4321)
+        mm = ctor(nfeat=d, nlayers=2, nhidden=h, nclass=C, args=a, **kw)
+        mm.eval()
+        captured.clear()
+        torch.manual_seed(1235)
+        torch.rand = rec_rand
+        try:
+            if "gat" in name:
+                logp, unnorm, x_dgg = mm(x, in_adj=A2, edge_index=A2.indices())
+            else:
+                logp, unnorm, x_dgg = mm(x, A2, epoch=1)
+        finally:
+            torch.rand = real_rand
+        assert len(captured) == 1
+        cot2 = torch.from_numpy(grid_normal(93, (N, C)))
+        (logp * cot2).sum().backward()
+        fx = common(mm, {"x": x.numpy(), "rows": A2.indices()[0].numpy().astype(np.int32),
+                         "cols": A2.indices()[1].numpy().astype(np.int32), "adj_vals": A2.values().numpy(),
+                         "noise": (captured[0] * 2 - 1).numpy(), "cot": cot2.numpy(), "out": logp.detach().numpy(),
+                         "unnorm": unnorm.detach().to_dense().numpy(), "x_dgg": x_dgg.detach().numpy()})
+        meta = dict(name=name, N=N, d=d, h=h, C=C, torch=torch.__version__, args=vars(a), **kw)
+        fx["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+        print(name, "ok", tuple(logp.shape))
+
+
 def allpairs_cases():
     N, d, h = 256, 32, 16
     gen = torch.Generator().manual_seed(8)
@@ -381,6 +468,8 @@ if __name__ == "__main__":
         cora_cases()
     if "gat" in which:
         gat_cases()
+    if "ablations" in which:
+        ablations_cases()
 
 
 def model_cases():
