@@ -212,7 +212,7 @@ def bench_edgelist(a, dev):
     if a.cpu_rows >= 0 and a.edge_mode == "u-v-dist":
         out["cpu_baseline"] = cpu_baseline_edgelist(N, d, h, rows, cols, x.cpu().numpy(), vals.numpy(), dgg, conv,
                                                     os.cpu_count() or 1)
-    print(json.dumps(out))
+    emit_json((out))
 
 
 def bench_module_api(a, dev):
@@ -252,7 +252,7 @@ def bench_module_api(a, dev):
     torch.cuda.synchronize()
     T = (time.perf_counter() - t0) / a.steps
     kmean = float(adj.k.mean().item())
-    print(json.dumps({
+    emit_json(({
         "metric": METRIC, "value": N * kmean / T, "unit": "edges/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": T * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"synthetic all-pairs DGG N={N} d={d} h={h} k~{kmean:.1f} through the drop-in modules under torch "
@@ -310,7 +310,7 @@ def bench_ppi(a, dev):
     torch.cuda.synchronize()
     T = (time.perf_counter() - t0) / a.steps
     gemm_flop = sum(3 * 2.0 * int(n) * (2 * hid) * hid * L for n in sizes)       # fwd + dX + dW of the variant GCNII layers
-    print(json.dumps({
+    emit_json(({
         "metric": "DGG adj-build+SpMM fwd/bwd edges/sec (multi-graph, PPI shape)", "value": cand / T, "unit": "edges/s", "n_gpus": 1,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": T * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16 GEMMs / f32 DGG" if a.bf16 else "f32", "data": "synthetic",
@@ -363,6 +363,27 @@ def cpu_baseline_edgelist(N, d, h, rows, cols, x, vals, dgg, conv, threads):
                 sample=f"oracle edge-list pipeline fwd+bwd on the whole problem ({dt:.2f}s)")
 
 
+_JSON_FD = None
+
+
+def isolate_stdout():
+    """Native libraries write banners to fd 1 (RCCL prints its version block there when the process group is torn down, AFTER
+    the result line): send everything that is not the result line to stderr and keep the real stdout for emit_json()."""
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit_json(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=["synthetic", "synthetic-module", "pubmed", "ppi"], default="synthetic",
@@ -392,6 +413,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="row sample of the cpu_baseline leg: 0 = auto (64 rows per host core, ~10-20 s), <0 = skip")
     a = ap.parse_args()
+    isolate_stdout()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -400,6 +422,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    force = os.environ.get("DGG_FORCE_COLLECTIVES") == "1"     # 1-rank RCCL group: every collective of the N>1 path on one GPU
+    if force and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     import dgg_amd
@@ -436,7 +463,7 @@ def main():
     # allocates nor synchronises), so it can be captured once into a hipGraph and replayed: same kernels, same work,
     # no per-launch host latency.  Falls back to eager launches if capture is unavailable (e.g. with collectives).
     graph = None
-    if a.hipgraph and world == 1:
+    if a.hipgraph and (world == 1 and not force or os.environ.get("DGG_BENCH_GRAPH_DIST") == "1"):
         try:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
@@ -447,7 +474,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             print(f"hipGraph capture failed ({e!r}); timing eager launches", file=sys.stderr)
             graph = None
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -457,13 +484,13 @@ def main():
         else:
             grads = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev)
     ksum = layer.saved["k"].sum().reshape(1).double()
     kmaxv = layer.saved["k"].max().reshape(1)
-    if world > 1:
+    if world > 1 or force:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(ksum)
         dist.all_reduce(kmaxv, op=dist.ReduceOp.MAX)
@@ -562,8 +589,8 @@ def main():
             except Exception as e:  # the baseline leg must never take the measurement down
                 out["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
-        print(json.dumps(out))
-    if world > 1:
+        emit_json((out))
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

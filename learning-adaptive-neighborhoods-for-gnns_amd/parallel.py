@@ -21,6 +21,8 @@ all-reduce, so the [N,h] gradient itself never crosses the fabric.
 `kern` is the kernel namespace (dgg_amd.ops on the GPU; tests substitute a CPU stand-in built on the oracle so
 that the partition / collective logic is exercised with gloo, world_size 2, without a GPU).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -51,7 +53,7 @@ class _Gather:
 
 def _all_gather_rows(t_local, N, per, group):
     """[n_loc, ...] -> [N, ...]"""
-    if dist.get_world_size(group) == 1:
+    if dist.get_world_size(group) == 1 and os.environ.get("DGG_FORCE_COLLECTIVES") != "1":
         return t_local
     return _Gather(t_local, N, per, group, False).get()
 
@@ -67,13 +69,15 @@ class ShardedDGGConv:
         self.K, self.t, self.noise_mode, self.seed, self.mode, self.algo, self.x_grad = K, t, noise_mode, seed, mode, algo, x_grad
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # DGG_FORCE_COLLECTIVES=1 issues every collective even in a 1-rank group (exercises the RCCL calls on a 1-GPU box)
+        self.coll = self.world > 1 or (dist.is_initialized() and os.environ.get("DGG_FORCE_COLLECTIVES") == "1")
         self.r0, self.r1, self.per = shard_bounds(N, self.world, self.rank)
 
     def forward(self, x_local, deg_full, P):
         kern = self.kern
         s = {}
         xp = kern.linear_fwd(x_local, P["We"], P["be"], 1, 0)
-        if self.world > 1:                               # xp first (the top-k waits for it), X streams in behind it
+        if self.coll:                               # xp first (the top-k waits for it), X streams in behind it
             g_xp = _Gather(xp, self.N, self.per, self.group, True)
             g_X = _Gather(x_local, self.N, self.per, self.group, True)
         s["xk"] = xk = kern.linear_fwd(x_local, P["Wk"], P["bk"], 1, 0)
@@ -81,15 +85,15 @@ class ShardedDGGConv:
         deg_local = deg_full[self.r0:self.r1].contiguous()
         s["k"], s["z"], s["u"], s["feat"] = kern.knet_x_fwd(xk, deg_local, mu_sd, P["W1"], P["b1"], P["Wmu"], P["bmu"],
                                                           P["Wp"].reshape(-1), P["bp"])
-        s["xp"] = xp = g_xp.get() if self.world > 1 else xp
+        s["xp"] = xp = g_xp.get() if self.coll else xp
         s["idx"], s["val"] = kern.allpairs_topk(xp, self.K, self.t, self.noise_mode, None, self.seed,
                                                 rows=(self.r0, self.r1), algo=self.algo, k_limit=s["k"])
         s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
         # destination-bucket partition of the active entries: the backward's column-side terms run on it (no atomics)
         s["part"] = kern.part_build(s["idx"], s["w"], self.N) if hasattr(kern, "part_build") else None
-        s["rs"] = rs = _all_gather_rows(rs_local, self.N, self.per, self.group) if self.world > 1 else rs_local
+        s["rs"] = rs = _all_gather_rows(rs_local, self.N, self.per, self.group) if self.coll else rs_local
         s["ahat"] = kern.normalize_fwd(s["idx"], s["w"], rs, self.r0)
-        s["X"] = X = g_X.get() if self.world > 1 else x_local
+        s["X"] = X = g_X.get() if self.coll else x_local
         s["Y"] = kern.spmm_fwd(s["idx"], s["ahat"], X)
         s["Z"] = kern.linear_fwd(s["Y"], P["Wc"], None, 2, 1)
         self.saved = s
@@ -113,7 +117,7 @@ class ShardedDGGConv:
                 dA, dX = kern.spmm_bwd(s["idx"], s["ahat"], s["X"], dY, self.x_grad, True)
             da = kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0, part) if part is not None else \
                 kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0)
-        if self.world > 1:
+        if self.coll:
             dist.all_reduce(da, group=self.group)
         dval, dk = kern.softk_bwd(s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.mode, True)
         s["dval"] = dval                                 # kept for diagnostics (bench.py times edge_bwd alone)
@@ -124,7 +128,7 @@ class ShardedDGGConv:
             s["xk"].shape[1], s["mu_sd"], P["W1"], P["Wmu"], P["bmu"], P["Wp"].reshape(-1), s["z"], s["u"], s["feat"], dk)
         g["Wp"] = dWp.reshape(P["Wp"].shape)
         dx2, g["Wk"], g["bk"] = kern.linear_bwd(x_local, P["Wk"], s["xk"], dxk, 1, 0, self.x_grad, True)
-        if self.world > 1:
+        if self.coll:
             flat = torch.cat([g[k].reshape(-1) for k in self.PARAM_KEYS])
             dist.all_reduce(flat, group=self.group)
             o = 0
@@ -134,7 +138,7 @@ class ShardedDGGConv:
                 o += n
         if self.x_grad:
             dXf = dX + dX1                               # [N,d] partial: neighbour-side terms of every rank
-            if self.world > 1:
+            if self.coll:
                 pad = self.world * self.per - self.N
                 if pad:
                     dXf = torch.cat([dXf, dXf.new_zeros((pad, dXf.shape[1]))])

@@ -88,3 +88,51 @@ def test_two_ranks_on_one_gpu_match_single_process(x_grad):
         ref = g1[k].numpy()
         err = np.abs(got.reshape(ref.shape) - ref).max() / max(np.abs(ref).max(), 1e-30)
         assert err <= 3e-4, f"grad {k}: {err:.3e}"
+
+
+def _rccl_worker(port, x_grad, ret):
+    """ONE rank, backend nccl (= RCCL), DGG_FORCE_COLLECTIVES=1: every collective of the N>1 path is issued through RCCL on
+    this GPU (asynchronous all_gather_into_tensor of xp / X, all-gather of the row sums, all-reduce of da and of the flat
+    weight gradients, reduce_scatter_tensor of dX)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DGG_FORCE_COLLECTIVES="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    x, deg, P, cot = make_inputs()
+    Z, g, idx = run_step(x, deg, P, cot, x.shape[0], x_grad)
+    ret[0] = (Z.numpy(), {k: v.numpy() for k, v in g.items()}, idx.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("x_grad", [False, True])
+def test_rccl_collectives_single_rank_match_plain_step(x_grad):
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        p = ctx.Process(target=_rccl_worker, args=(29571 + int(x_grad), x_grad, ret))
+        p.start()
+        p.join(300)
+        assert p.exitcode == 0
+        Z, g, idx = ret[0]
+    x, deg, P, cot = make_inputs()
+    os.environ.pop("DGG_FORCE_COLLECTIVES", None)
+    Z0, g0, idx0 = run_step(x, deg, P, cot, x.shape[0], x_grad)
+    assert np.array_equal(idx, idx0.numpy())
+    assert np.array_equal(Z, Z0.numpy())
+    for k in g0:
+        ref = g0[k].numpy()
+        np.testing.assert_allclose(g[k], ref, rtol=2e-4, atol=2e-4 * max(np.abs(ref).max(), 1e-6), err_msg=k)
+
+
+def test_bench_prints_exactly_one_json_line_with_rccl_initialised():
+    """the driver parses bench.py's stdout: RCCL writes a version banner to fd 1 when the process group is destroyed, which
+    must not reach stdout"""
+    import json
+    import subprocess
+    env = dict(os.environ, DGG_FORCE_COLLECTIVES="1", MASTER_PORT="29575")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--nodes", "20000", "--steps", "3", "--warmup", "1",
+                        "--cpu-rows", "-1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-1000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
