@@ -884,3 +884,119 @@ ORA_API void ora_edge_mlp_bwd_csr(const float *AB, int64_t N, int hw, const int6
     for (int q = 0; q < 5 * hw + 1; q++) dpar[q] = (float)par[q];
     free(acc); free(par); free(z); free(hid);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Dense all-pairs alternates: DGG_LearnableK_SDD (dgm.py:259-351, dist_fn="metric", noise off) */
+/* and DGG_StraightThrough (dgm.py:140-182 + 63-100).  Both return a DENSE [B,N,N] adjacency    */
+/* whose rows are a softmax over ALL N columns, so the backward couples every pair: these are   */
+/* O(N^2) by definition (the reference's use is B small graphs of few nodes).                   */
+/*   prob = exp(-t dist); log_p = log(prob); y = softmax(log_p / temp) over the row             */
+/*   pos_j = position of column j in the row sorted by (y desc, column asc)                     */
+/*   ramp 0 (SDD, dgm.py:315-346): f = sigmoid((hs_start - interval pos) + interval (k_i - 1)); */
+/*            soft: out = y f; hard: out = (f - y f) + y f                                      */
+/*   ramp 1 (ST, dgm.py:83-98): soft: out = y; hard: out = (1[pos < kfix] - y) + y              */
+/* Row reductions in the order of a 64-lane wavefront (strided partial sums + xor butterfly).   */
+/* ------------------------------------------------------------------------------------------ */
+static float strided_butterfly_max(const float *v, int64_t n) {
+    float m = -INFINITY;
+    for (int64_t e = 0; e < n; e++) m = v[e] > m ? v[e] : m;
+    return m;
+}
+ORA_API void ora_dense_rows_fwd(const float *xq, int B, int64_t N, int h, float t, float temp, int ramp, const float *k,
+                                int kfix, float hs_start, float interval, int hard, float *out, float *y, int32_t *pos) {
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t bi = 0; bi < (int64_t)B * N; bi++) {
+        const float *X = xq + (bi / N) * N * h, *xi = xq + bi * h;
+        float *yr = y + bi * N, *orow = out + bi * N;
+        int32_t *pr = pos + bi * N;
+        for (int64_t j = 0; j < N; j++) {
+            float d = pair_dist(xi, X + j * h, h);
+            float p = ora_exp(-t * d);
+            yr[j] = ora_log(p) / temp;
+        }
+        float m = strided_butterfly_max(yr, N);
+        for (int64_t j = 0; j < N; j++) yr[j] = ora_exp(yr[j] - m);
+        float Z = strided_butterfly_sum(yr, N);
+        for (int64_t j = 0; j < N; j++) yr[j] = yr[j] / Z;
+        for (int64_t j = 0; j < N; j++) {
+            int c = 0;
+            for (int64_t q = 0; q < N; q++) c += better(yr[q], (int32_t)q, yr[j], (int32_t)j);
+            pr[j] = c;
+            if (ramp == 0) {
+                float xs = hs_start - interval * (float)c;
+                float sh = (k[bi] - 1.0f) * interval;
+                float z = xs + sh;
+                float f = 1.0f / (1.0f + ora_exp(-z));
+                float a = yr[j] * f;
+                orow[j] = hard ? (f - a) + a : a;
+            } else {
+                float ind = c < kfix ? 1.0f : 0.0f;
+                orow[j] = hard ? (ind - yr[j]) + yr[j] : yr[j];
+            }
+        }
+    }
+}
+/* g = d loss / d out -> Cm [B,N,N] (coefficient of (x_i - x_j) in d loss / d xq_i contributed by row i), dk [B*N] (ramp 0),
+ * dt_rows [B*N] (sum = d loss / d t) */
+ORA_API void ora_dense_rows_bwd(const float *xq, int B, int64_t N, int h, float t, float temp, int ramp, const float *k,
+                                float hs_start, float interval, const float *y, const int32_t *pos, const float *g, float *Cm,
+                                float *dk, float *dt_rows) {
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t bi = 0; bi < (int64_t)B * N; bi++) {
+        const float *X = xq + (bi / N) * N * h, *xi = xq + bi * h;
+        const float *yr = y + bi * N, *gr = g + bi * N;
+        const int32_t *pr = pos + bi * N;
+        double S = 0.0, dkk = 0.0;
+        double *dy = malloc(sizeof(double) * N);
+        for (int64_t j = 0; j < N; j++) {
+            if (ramp == 0) {
+                double z = ((double)hs_start - (double)interval * pr[j]) + ((double)k[bi] - 1.0) * interval;
+                double f = 1.0 / (1.0 + exp(-z));
+                dy[j] = gr[j] * f;
+                dkk += (double)gr[j] * yr[j] * f * (1.0 - f) * interval;
+            } else dy[j] = gr[j];
+            S += yr[j] * dy[j];
+        }
+        double dt = 0.0;
+        for (int64_t j = 0; j < N; j++) {
+            double dlp = yr[j] * (dy[j] - S) / temp;       /* = d loss / d (-t d_ij): log(exp(.)) is the identity */
+            double d = pair_dist(xi, X + j * h, h);
+            dt += dlp * (-d);
+            Cm[bi * N + j] = d > 0.0 ? (float)(-t * dlp / d) : 0.0f;
+        }
+        if (dk) dk[bi] = (float)dkk;
+        dt_rows[bi] = (float)dt;
+        free(dy);
+    }
+}
+/* d loss / d xq_i = sum_j (C_ij + C_ji) (xq_i - xq_j)   (row i's own terms + its appearances as a column) */
+ORA_API void ora_dense_pairs_dx(const float *xq, int B, int64_t N, int h, const float *Cm, float *dxq) {
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t bi = 0; bi < (int64_t)B * N; bi++) {
+        int64_t b = bi / N, i = bi % N;
+        const float *X = xq + b * N * h, *C0 = Cm + b * N * N;
+        for (int c = 0; c < h; c++) {
+            double s = 0.0;
+            for (int64_t j = 0; j < N; j++) s += ((double)C0[i * N + j] + C0[j * N + i]) * ((double)X[i * h + c] - X[j * h + c]);
+            dxq[bi * h + c] = (float)s;
+        }
+    }
+}
+/* nn.Softmax(dim=-1) over the latent features (input_project of the SDD class, dgm.py:217-221) */
+ORA_API void ora_feat_softmax(const float *z, int64_t rows, int h, float *out) {
+    for (int64_t r = 0; r < rows; r++) {
+        const float *zr = z + r * h;
+        float *o = out + r * h;
+        float m = strided_butterfly_max(zr, h);
+        for (int c = 0; c < h; c++) o[c] = ora_exp(zr[c] - m);
+        float Z = strided_butterfly_sum(o, h);
+        for (int c = 0; c < h; c++) o[c] = o[c] / Z;
+    }
+}
+ORA_API void ora_feat_softmax_bwd(const float *out, const float *g, int64_t rows, int h, float *dz) {
+    for (int64_t r = 0; r < rows; r++) {
+        double S = 0.0;
+        for (int c = 0; c < h; c++) S += (double)out[r * h + c] * g[r * h + c];
+        for (int c = 0; c < h; c++) dz[r * h + c] = (float)(out[r * h + c] * (g[r * h + c] - S));
+    }
+}

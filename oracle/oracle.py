@@ -410,3 +410,51 @@ def edge_mlp_bwd_csr(AB, rowptr, col, dval, b1, w2, b2, act=1):
     lib().ora_edge_mlp_bwd_csr(_p(AB), C.c_int64(AB.shape[0]), C.c_int(hw), _p(rowptr), _p(col), _p(dval), _p(f32(b1)), _p(f32(w2)),
                                C.c_float(float(b2)), C.c_int(act), _p(dAB), _p(dpar))
     return dAB, dpar
+
+
+# ---- dense all-pairs alternates (DGG_LearnableK_SDD / DGG_StraightThrough, dgm.py:103-351) ----------------------------
+def dense_rows_fwd(xq, t, temp, ramp, k=None, kfix=0, hs_start=2.0, interval=7.0, hard=False):
+    """xq [B,N,h] -> out, y [B,N,N] fp32, pos [B,N,N] int32"""
+    xq = f32(xq)
+    B, N, h = xq.shape
+    out, y, pos = np.empty((B, N, N), np.float32), np.empty((B, N, N), np.float32), np.empty((B, N, N), np.int32)
+    kk = f32(k).reshape(-1) if k is not None else None
+    lib().ora_dense_rows_fwd(_p(xq), C.c_int(B), C.c_int64(N), C.c_int(h), C.c_float(float(t)), C.c_float(float(temp)), C.c_int(ramp),
+                             _p(kk) if kk is not None else None, C.c_int(int(kfix)), C.c_float(hs_start), C.c_float(interval),
+                             C.c_int(int(hard)), _p(out), _p(y), _p(pos))
+    return out, y, pos
+
+
+def dense_rows_bwd(xq, t, temp, ramp, k, hs_start, interval, y, pos, g):
+    """-> Cm [B,N,N], dk [B,N] (ramp 0) or None, dt (scalar, float64 sum of the row terms)"""
+    xq, y, pos, g = f32(xq), f32(y), i32(pos), f32(g)
+    B, N, h = xq.shape
+    Cm, dt = np.empty((B, N, N), np.float32), np.empty(B * N, np.float32)
+    kk = f32(k).reshape(-1) if k is not None else None
+    dk = np.empty(B * N, np.float32) if ramp == 0 else None
+    lib().ora_dense_rows_bwd(_p(xq), C.c_int(B), C.c_int64(N), C.c_int(h), C.c_float(float(t)), C.c_float(float(temp)), C.c_int(ramp),
+                             _p(kk) if kk is not None else None, C.c_float(hs_start), C.c_float(interval), _p(y), _p(pos), _p(g),
+                             _p(Cm), _p(dk) if dk is not None else None, _p(dt))
+    return Cm, (dk.reshape(B, N) if dk is not None else None), float(dt.astype(np.float64).sum())
+
+
+def dense_pairs_dx(xq, Cm):
+    xq, Cm = f32(xq), f32(Cm)
+    B, N, h = xq.shape
+    dx = np.empty_like(xq)
+    lib().ora_dense_pairs_dx(_p(xq), C.c_int(B), C.c_int64(N), C.c_int(h), _p(Cm), _p(dx))
+    return dx
+
+
+def feat_softmax(z):
+    z = f32(z)
+    out = np.empty_like(z)
+    lib().ora_feat_softmax(_p(z), C.c_int64(z.size // z.shape[-1]), C.c_int(z.shape[-1]), _p(out))
+    return out
+
+
+def feat_softmax_bwd(out, g):
+    out, g = f32(out), f32(g)
+    dz = np.empty_like(out)
+    lib().ora_feat_softmax_bwd(_p(out), _p(g), C.c_int64(out.size // out.shape[-1]), C.c_int(out.shape[-1]), _p(dz))
+    return dz

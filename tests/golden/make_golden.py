@@ -9,6 +9,7 @@ gradients for a fixed cotangent.  Fixtures are data only; no reference source is
 
     python tests/golden/make_golden.py            # writes tests/golden/*.npz
 """
+import copy
 import json
 import os
 import sys
@@ -382,6 +383,78 @@ def ablations_cases():
         print(name, "ok", tuple(logp.shape))
 
 
+def dense_cases():
+    """Dense all-pairs alternates (goldens G5/G6): DGG_LearnableK_SDD(dist_fn="metric", noise=False,
+    hard in {F,T}) (dgm.py:259-351; needs k_net.args from the harness) and DGG_StraightThrough(dist_fn="metric",
+    noise=False, hard in {T,F}) (dgm.py:140-182).  N=24 keeps torch.cdist on its direct-difference path (<= 25 rows),
+    N=160 uses its matmul form."""
+    for N, B, d, h in [(24, 3, 12, 16), (160, 2, 20, 32)]:
+        gen = torch.Generator().manual_seed(1000 + N)
+        x = torch.randn(B, N, d, generator=gen)
+        cot = torch.from_numpy(grid_normal(300 + N, (B, N, N)))
+        cotk = torch.from_numpy(grid_normal(301 + N, (B, N, 1)))
+        for hard in (False, True):
+            m = dgm.DGG_LearnableK_SDD(in_dim=d, latent_dim=h, k_bias=3.0, hard=hard, dist_fn="metric")
+            m.k_net.args = Namespace(stochastic_k=False)
+            with torch.no_grad():
+                m.t.fill_(6.0)                           # softmax-projected features are close together: make distances matter
+                m.k_net.k_project.weight.mul_(4.0)
+            m.eval()
+            xr = x.clone().requires_grad_(True)
+            temp = 0.5
+            adj, k = m(xr, temp, noise=False)
+            ((adj * cot).sum() + (k * cotk).sum()).backward()
+            fx = {"x": x.numpy(), "out": adj.detach().numpy(), "k": k.detach().numpy(), "cot": cot.numpy(), "cotk": cotk.numpy(),
+                  "g.x": xr.grad.numpy()}
+            for k_, v in m.state_dict().items():
+                fx["p." + k_] = v.detach().numpy()
+            for k_, p_ in m.named_parameters():
+                fx["g." + k_] = p_.grad.numpy() if p_.grad is not None else np.zeros_like(p_.detach().numpy())
+            # the same module evaluated in float64: torch.cdist's matmul form (> 25 rows) loses ~1e-4 on near-zero distances
+            # in fp32, so the fp32 reference output is itself ~2e-4 away from this one on the diagonal
+            m64 = copy.deepcopy(m).double()
+            m64.zero_grad()
+            x64 = x.double().requires_grad_(True)
+            adj64, k64 = m64(x64, temp, noise=False)
+            ((adj64 * cot.double()).sum() + (k64 * cotk.double()).sum()).backward()
+            fx["out64"], fx["g64.x"] = adj64.detach().float().numpy(), x64.grad.float().numpy()
+            for k_, p_ in m64.named_parameters():
+                fx["g64." + k_] = p_.grad.float().numpy() if p_.grad is not None else np.zeros(tuple(p_.shape), np.float32)
+            meta = dict(name=f"sdd_n{N}_h{int(hard)}", B=B, N=N, d=d, h=h, hard=hard, temp=temp, k_bias=3.0, torch=torch.__version__,
+                        reference="dgm.py:259-351 DGG_LearnableK_SDD.forward(noise=False)")
+            fx["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+            np.savez_compressed(os.path.join(HERE, f"sdd_n{N}_h{int(hard)}.npz"), **fx)
+            print("sdd", N, hard, "ok: k range", float(k.min()), float(k.max()), "nnz>1e-6 per row", float((adj > 1e-6).sum(-1).float().mean()))
+        for hard in (True, False):
+            torch.manual_seed(5)
+            m = dgm.DGG_StraightThrough(in_dim=d, latent_dim=h, k=5, hard=hard, dist_fn="metric")
+            with torch.no_grad():
+                m.t.fill_(0.7)
+            m.eval()
+            xr = x.clone().requires_grad_(True)
+            temp = 0.8
+            adj = m(xr, temp, noise=False)
+            (adj * cot).sum().backward()
+            fx = {"x": x.numpy(), "out": adj.detach().numpy(), "cot": cot.numpy(), "g.x": xr.grad.numpy()}
+            for k_, v in m.state_dict().items():
+                fx["p." + k_] = v.detach().numpy()
+            for k_, p_ in m.named_parameters():
+                fx["g." + k_] = p_.grad.numpy() if p_.grad is not None else np.zeros_like(p_.detach().numpy())
+            m64 = copy.deepcopy(m).double()
+            m64.zero_grad()
+            x64 = x.double().requires_grad_(True)
+            adj64 = m64(x64, temp, noise=False)
+            (adj64 * cot.double()).sum().backward()
+            fx["out64"], fx["g64.x"] = adj64.detach().float().numpy(), x64.grad.float().numpy()
+            for k_, p_ in m64.named_parameters():
+                fx["g64." + k_] = p_.grad.float().numpy() if p_.grad is not None else np.zeros(tuple(p_.shape), np.float32)
+            meta = dict(name=f"st_n{N}_h{int(hard)}", B=B, N=N, d=d, h=h, hard=hard, temp=temp, k=5, torch=torch.__version__,
+                        reference="dgm.py:140-182 DGG_StraightThrough.forward(noise=False)")
+            fx["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+            np.savez_compressed(os.path.join(HERE, f"st_n{N}_h{int(hard)}.npz"), **fx)
+            print("st", N, hard, "ok", float(adj.sum(-1).mean()))
+
+
 def allpairs_cases():
     N, d, h = 256, 32, 16
     gen = torch.Generator().manual_seed(8)
@@ -470,6 +543,8 @@ if __name__ == "__main__":
         gat_cases()
     if "ablations" in which:
         ablations_cases()
+    if "dense" in which:
+        dense_cases()
 
 
 def model_cases():
