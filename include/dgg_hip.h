@@ -252,6 +252,26 @@ int dgg_ell_sddmm_norm_part(const int32_t *idx, const float *ahat, const float *
                             int64_t ncols, float *coef_ws, float *dA, float *da, void *stream);
 int dgg_norm_da_cols_part(const void *part_ws, int64_t rows, int K, int64_t ncols, const float *coef_ws, float *da, void *stream);
 
+/* ---- dense all-pairs alternates: DGG_LearnableK_SDD (dgm.py:259-351, dist_fn="metric") and DGG_StraightThrough
+ * (dgm.py:140-182 + 63-100), noise off.  Rows are a softmax over ALL N columns, outputs are dense [B,N,N]: O(N^2) by
+ * definition, written for batches of small graphs (N <= 8192).
+ *   prob = exp(-t dist(xq_i, xq_j)); y = softmax_j(log(prob) / temp); pos = position under (y desc, column asc)
+ *   ramp 0 (SDD, dgm.py:315-346): f = sigmoid((hs_start - interval pos) + interval (k_i - 1)); out = y f, hard: (f - y f) + y f
+ *   ramp 1 (ST, dgm.py:83-98):    out = y, hard: (1[pos < kfix] - y) + y
+ * xq [B,N,h]; t device scalar (nn.Parameter); k [B*N] (ramp 0); out, y [B,N,N] fp32, pos [B,N,N] int32 */
+int dgg_dense_rows_fwd(const float *xq, int B, int64_t N, int h, const float *t, float temp, int ramp, const float *k, int kfix,
+                       float hs_start, float interval, int hard, float *out, float *y, int32_t *pos, void *stream);
+/* g = d loss / d out [B,N,N] -> Cm [B,N,N] (coefficient of (xq_i - xq_j) from row i; feeds dgg_dense_pairs_dx),
+ * dk [B*N] (ramp 0, else NULL), dt_rows [B*N] (their sum = d loss / d t) */
+int dgg_dense_rows_bwd(const float *xq, int B, int64_t N, int h, const float *t, float temp, int ramp, const float *k, float hs_start,
+                       float interval, const float *y, const int32_t *pos, const float *g, float *Cm, float *dk, float *dt_rows,
+                       void *stream);
+/* d loss / d xq_i = sum_j (C_ij + C_ji)(xq_i - xq_j)  (autograd of torch.cdist, dgm.py:275 / 157) */
+int dgg_dense_pairs_dx(const float *xq, int B, int64_t N, int h, const float *Cm, float *dxq, void *stream);
+/* nn.Softmax(dim=-1) over the latent features (SDD input_project, dgm.py:217-221): out [rows,h]; dz = out (g - <out, g>) */
+int dgg_feat_softmax_fwd(const float *z, int64_t rows, int h, float *out, void *stream);
+int dgg_feat_softmax_bwd(const float *out, const float *g, int64_t rows, int h, float *dz, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

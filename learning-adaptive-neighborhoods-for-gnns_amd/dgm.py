@@ -442,3 +442,85 @@ class DGG_Ablations(DGG):
                                     self.degree_decoder[0].bias, pattern, noise.to(torch.float32).contiguous(),
                                     None if k is None else int(k))
         return CsrAdjacency(pattern[0], pattern[1], pattern[2], out, x.shape[0], k=kk), xe
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# dense all-pairs alternates.  Dense [B,N,N] in and out as in the reference; the softmax over all N
+# columns makes them O(N^2) by definition -- batches of small graphs, N <= 8192.
+# ---------------------------------------------------------------------------------------------------------------------------
+class _KMuProject(nn.Module):
+    """LearnableKEncoder as the SDD class builds it (dgm.py:248-251, 2024-2063): k_mu / k_logvar Linear(in_dim, latent_dim),
+    k_project Linear(latent_dim, 1); deterministic path k = k_project(k_mu(x))"""
+
+    def __init__(self, in_dim, latent_dim):
+        super().__init__()
+        self.k_mu = nn.Linear(in_dim, latent_dim)
+        self.k_logvar = nn.Linear(in_dim, latent_dim)
+        self.k_project = nn.Linear(latent_dim, 1)
+
+    def forward(self, x2):
+        lat = ops.LinearFn.apply(x2, self.k_mu.weight, self.k_mu.bias, ops.ACT_NONE, 0)
+        return ops.LinearFn.apply(lat, self.k_project.weight, self.k_project.bias, ops.ACT_NONE, 0)
+
+
+class DGG_LearnableK_SDD(nn.Module):
+    """Drop-in for the reference's `DGG_LearnableK_SDD` (dgm.py:185-351) on its runnable configuration: dist_fn="metric",
+    k_net_input="raw", noise=False (`noise=True` calls gumbel_sample with three arguments and raises in the reference,
+    SURVEY 2.2; dist_fn="mlp" ends in nn.Softmax over a size-1 dimension, i.e. a constant 1).
+    forward(x [B,N,in_dim], temp, noise=False) -> (adj [B,N,N], k [B,N,1]):
+        xq = softmax(leaky(x W + b)); y = softmax_j(log(exp(-t |xq_i - xq_j|)) / temp); rows sorted descending;
+        k = k_net(x) + k_bias; first_k = sigmoid((hs_start - interval r) + interval (k - 1)); adj = y first_k at the sorted
+        columns; hard: (first_k - adj).detach() + adj (dgm.py:343-346).
+    Distances are direct differences (torch.cdist's matmul form above 25 rows adds ~1e-4 of cancellation noise to near-zero
+    distances in fp32; parity is pinned on the reference evaluated in float64)."""
+
+    def __init__(self, in_dim=32, latent_dim=64, k_bias=1.0, hard=False, self_loops_noise=False, dist_fn="metric", k_net_input="raw",
+                 hs_start=2, hs_end=-5, n_agents=None, learn_k_bias=None):
+        super().__init__()
+        if dist_fn != "metric" or k_net_input != "raw":
+            raise Exception("DGG_LearnableK_SDD: only dist_fn='metric', k_net_input='raw' run in the reference (SURVEY 2.2)")
+        torch.manual_seed(0)                                                       # dgm.py:207
+        self.in_dim, self.latent_dim, self.hard, self.self_loops_noise = in_dim, latent_dim, hard, self_loops_noise
+        self.dist_fn, self.k_net_input = dist_fn, k_net_input
+        self.input_project = nn.Sequential(nn.Linear(in_dim, latent_dim), nn.LeakyReLU(), nn.Softmax(dim=-1))
+        self.t = nn.Parameter(torch.ones(1))
+        interval = hs_start - hs_end
+        self.register_buffer("interval", torch.tensor(interval))
+        self.register_buffer("k_bias", torch.tensor(k_bias))
+        self.register_buffer("hs_start", torch.tensor(hs_start))
+        self.register_buffer("hs_end", torch.tensor(hs_end))
+        self.k_net = _KMuProject(in_dim, latent_dim)
+
+    def forward(self, x, temp, noise=False):
+        if noise:
+            raise Exception("DGG_LearnableK_SDD: noise=True is not runnable in the reference (gumbel_sample arity, dgm.py:295)")
+        assert x.ndim == 3
+        B, N, d = x.shape
+        x2 = x.reshape(B * N, d)
+        z = ops.LinearFn.apply(x2, self.input_project[0].weight, self.input_project[0].bias, ops.ACT_LEAKY, 0)
+        xq = ops.FeatSoftmaxFn.apply(z).reshape(B, N, -1)
+        k = self.k_net(x2).reshape(B, N) + self.k_bias
+        adj = ops.DenseRowsFn.apply(xq, self.t, k, float(temp), ops.RAMP_SDD, 0, float(self.hs_start), float(self.interval),
+                                    bool(self.hard))
+        return adj, k.unsqueeze(-1)
+
+
+class DGG_StraightThrough(nn.Module):
+    """Drop-in for the reference's `DGG_StraightThrough` (dgm.py:103-182) with dist_fn="metric", noise=False:
+    y = softmax_j(log(exp(-t |x_i - x_j|)) / temp) on the RAW inputs (dgm.py:157); hard: ones at the k largest entries of each
+    row, gradient of y (dgm.py:83-98); soft: y.  `project` is constructed (state_dict parity) but, as in the reference, its
+    output does not reach the metric distance."""
+
+    def __init__(self, in_dim=32, latent_dim=64, k=3, hard=True, self_loops_noise=False, dist_fn="mlp"):
+        super().__init__()
+        if dist_fn != "metric":
+            raise Exception("DGG_StraightThrough: dist_fn='mlp' ends in nn.Softmax over a size-1 dimension (constant 1); use 'metric'")
+        self.in_dim, self.latent_dim, self.k, self.hard, self.self_loops_noise, self.dist_fn = in_dim, latent_dim, k, hard, self_loops_noise, dist_fn
+        self.project = nn.Sequential(nn.Linear(in_dim, latent_dim), nn.LeakyReLU(), nn.Softmax(dim=-1))
+        self.t = nn.Parameter(torch.ones(1))
+
+    def forward(self, x, temp, noise=False):
+        if noise:
+            raise Exception("DGG_StraightThrough: noise=True is not runnable in the reference (gumbel_sample arity, dgm.py:80)")
+        assert x.ndim == 3
+        return ops.DenseRowsFn.apply(x, self.t, None, float(temp), ops.RAMP_TOPK, int(self.k), 0.0, 0.0, bool(self.hard))

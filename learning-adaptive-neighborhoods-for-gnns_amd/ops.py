@@ -235,6 +235,91 @@ def csr_rank_cut_bwd(pos, g, kcut):
     return dp
 
 
+# ---- dense all-pairs alternates (dgg_dense.hip) ------------------------------------------------------------------------
+RAMP_SDD, RAMP_TOPK = 0, 1
+
+
+def dense_rows_fwd(xq, t, temp, ramp, k=None, kfix=0, hs_start=2.0, interval=7.0, hard=False):
+    """xq [B,N,h], t device scalar -> out, y [B,N,N], pos [B,N,N] int32 (dgm.py:273-346 / 157-176 + 83-98)"""
+    xq = _chk(xq)
+    B, N, h = xq.shape
+    out = torch.empty((B, N, N), device=xq.device, dtype=torch.float32)
+    y = torch.empty_like(out)
+    pos = torch.empty((B, N, N), device=xq.device, dtype=torch.int32)
+    _lib.check(_lib.lib().dgg_dense_rows_fwd(_ptr(xq), B, N, h, _ptr(_chk(t)), float(temp), int(ramp), _ptr(_chk(k)) if k is not None else None,
+                                             int(kfix), float(hs_start), float(interval), int(bool(hard)), _ptr(out), _ptr(y), _ptr(pos),
+                                             _stream()), "dense_rows_fwd")
+    return out, y, pos
+
+
+def dense_rows_bwd(xq, t, temp, ramp, k, hs_start, interval, y, pos, g):
+    """-> Cm [B,N,N], dk [B,N] or None, dt_rows [B*N]"""
+    xq = _chk(xq)
+    B, N, h = xq.shape
+    Cm = torch.empty((B, N, N), device=xq.device, dtype=torch.float32)
+    dk = torch.empty((B, N), device=xq.device, dtype=torch.float32) if ramp == RAMP_SDD else None
+    dt_rows = torch.empty((B * N,), device=xq.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_dense_rows_bwd(_ptr(xq), B, N, h, _ptr(_chk(t)), float(temp), int(ramp), _ptr(_chk(k)) if k is not None else None,
+                                             float(hs_start), float(interval), _ptr(y), _ptr(pos), _ptr(_chk(g)), _ptr(Cm),
+                                             _ptr(dk) if dk is not None else None, _ptr(dt_rows), _stream()), "dense_rows_bwd")
+    return Cm, dk, dt_rows
+
+
+def dense_pairs_dx(xq, Cm):
+    xq = _chk(xq)
+    B, N, h = xq.shape
+    dx = torch.empty_like(xq)
+    _lib.check(_lib.lib().dgg_dense_pairs_dx(_ptr(xq), B, N, h, _ptr(Cm), _ptr(dx), _stream()), "dense_pairs_dx")
+    return dx
+
+
+def feat_softmax_fwd(z):
+    z = _chk(z)
+    out = torch.empty_like(z)
+    _lib.check(_lib.lib().dgg_feat_softmax_fwd(_ptr(z), z.numel() // z.shape[-1], z.shape[-1], _ptr(out), _stream()), "feat_softmax_fwd")
+    return out
+
+
+def feat_softmax_bwd(out, g):
+    dz = torch.empty_like(out)
+    _lib.check(_lib.lib().dgg_feat_softmax_bwd(_ptr(_chk(out)), _ptr(_chk(g)), out.numel() // out.shape[-1], out.shape[-1], _ptr(dz),
+                                               _stream()), "feat_softmax_bwd")
+    return dz
+
+
+class FeatSoftmaxFn(torch.autograd.Function):
+    """nn.Softmax(dim=-1) over the last dimension"""
+
+    @staticmethod
+    def forward(ctx, z):
+        out = feat_softmax_fwd(z)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return feat_softmax_bwd(ctx.saved_tensors[0], g.contiguous())
+
+
+class DenseRowsFn(torch.autograd.Function):
+    """[B,N,h] features (+ k for the SDD ramp) -> dense [B,N,N] adjacency; backward to the features, t and k"""
+
+    @staticmethod
+    def forward(ctx, xq, t, k, temp, ramp, kfix, hs_start, interval, hard):
+        xq = xq.contiguous()
+        out, y, pos = dense_rows_fwd(xq, t, temp, ramp, k, kfix, hs_start, interval, hard)
+        ctx.cfg = (temp, ramp, hs_start, interval)
+        ctx.save_for_backward(xq, t, k if k is not None else t, y, pos)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xq, t, k, y, pos = ctx.saved_tensors
+        temp, ramp, hs_start, interval = ctx.cfg
+        Cm, dk, dt_rows = dense_rows_bwd(xq, t, temp, ramp, k if ramp == RAMP_SDD else None, hs_start, interval, y, pos, g.contiguous())
+        return dense_pairs_dx(xq, Cm), dt_rows.sum().reshape(t.shape), dk, None, None, None, None, None, None
+
+
 def csr_row_sum(vals, rowptr):
     N = rowptr.shape[0] - 1
     rs = torch.empty((N,), device=vals.device, dtype=torch.float32)

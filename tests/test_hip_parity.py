@@ -1123,3 +1123,108 @@ def test_stochastic_k_training_mode(dev, knet, monkeypatch):
     adj.values().sum().backward()
     g = m.k_net.k_logvar.weight.grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dense all-pairs alternates: DGG_LearnableK_SDD / DGG_StraightThrough
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,N,h", [(1, 1, 4), (2, 7, 5), (3, 70, 16), (1, 300, 130), (1, 2100, 8)])
+def test_dense_rows_kernels_match_oracle(dev, B, N, h):
+    """dgg_dense_rows_fwd: out / y / pos bit-for-bit (both ramps, hard and soft, duplicate points = tied weights);
+    dgg_dense_rows_bwd + dgg_dense_pairs_dx within 2e-4 of the float64 oracle; dgg_feat_softmax fwd bit-for-bit"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(B * 1000 + N)
+    xq = (rng.standard_normal((B, N, h)) * 0.3).astype(np.float32)
+    if N > 5:
+        xq[:, 3] = xq[:, 1]                                  # duplicate points: zero distance, tied weights
+    t = np.float32([1.3])
+    k = (1 + 6 * rng.random((B, N))).astype(np.float32)
+    g = rng.standard_normal((B, N, N)).astype(np.float32)
+    for ramp, hard in [(0, False), (0, True), (1, True), (1, False)]:
+        out, y, pos = ops.dense_rows_fwd(T(xq, dev), T(t, dev), 0.7, ramp, T(k, dev) if ramp == 0 else None, 4, 2.0, 7.0, hard)
+        rout, ry, rpos = O.dense_rows_fwd(xq, t[0], 0.7, ramp, k if ramp == 0 else None, 4, 2.0, 7.0, hard)
+        assert np.array_equal(Nn(pos), rpos) and np.array_equal(Nn(y), ry) and np.array_equal(Nn(out), rout)
+        Cm, dk, dt_rows = ops.dense_rows_bwd(T(xq, dev), T(t, dev), 0.7, ramp, T(k, dev) if ramp == 0 else None, 2.0, 7.0, y, pos, T(g, dev))
+        rC, rdk, rdt = O.dense_rows_bwd(xq, t[0], 0.7, ramp, k if ramp == 0 else None, 2.0, 7.0, ry, rpos, g)
+        np.testing.assert_allclose(Nn(Cm), rC, rtol=2e-4, atol=2e-4 * max(np.abs(rC).max(), 1e-9))
+        if ramp == 0:
+            np.testing.assert_allclose(Nn(dk), rdk, rtol=2e-4, atol=2e-4 * max(np.abs(rdk).max(), 1e-9))
+        assert abs(float(dt_rows.double().sum()) - rdt) <= 2e-4 * max(abs(rdt), 1e-3) + 1e-6
+        dx = ops.dense_pairs_dx(T(xq, dev), T(rC, dev))
+        rdx = O.dense_pairs_dx(xq, rC)
+        np.testing.assert_allclose(Nn(dx), rdx, rtol=2e-4, atol=2e-4 * max(np.abs(rdx).max(), 1e-9))
+    z = rng.standard_normal((B * N, h)).astype(np.float32) * 3
+    sm = ops.feat_softmax_fwd(T(z, dev))
+    assert np.array_equal(Nn(sm), O.feat_softmax(z))
+    gz = rng.standard_normal((B * N, h)).astype(np.float32)
+    np.testing.assert_allclose(Nn(ops.feat_softmax_bwd(sm, T(gz, dev))), O.feat_softmax_bwd(Nn(sm), gz), rtol=1e-4, atol=1e-6)
+
+
+def _load_dense(m, fx, dev):
+    m.load_state_dict({k_[2:]: torch.from_numpy(v) for k_, v in fx.items() if k_.startswith("p.")}, strict=True)
+    return m.to(dev).eval()
+
+
+def _check_module_grads(m, x, fx, pre, tol):
+    grads = {n_: p_.grad for n_, p_ in m.named_parameters()}
+    grads["x"] = x.grad
+    checked = 0
+    for key, got in grads.items():
+        ref = fx[pre + key]
+        if np.abs(ref).max() == 0:
+            assert got is None or float(got.abs().max()) == 0
+            continue
+        err = np.abs(Nn(got).reshape(ref.shape) - ref).max() / np.abs(ref).max()
+        assert err <= tol, f"grad {key}: {err:.3e}"
+        checked += 1
+    return checked
+
+
+@pytest.mark.parametrize("N", [24, 160])
+@pytest.mark.parametrize("hard", [0, 1])
+def test_sdd_module_matches_reference_golden(dev, N, hard):
+    """dgg_amd.DGG_LearnableK_SDD (dgm.py:185-351): reference state_dict loads strict (buffers included); adj == oracle
+    bit-for-bit, within 1e-5 of the reference evaluated in float64 (and of its fp32 run when torch.cdist uses direct differences,
+    N <= 25); gradients of x, t, the projection and the k-net within 3e-4"""
+    import dgg_amd
+    from test_oracle_golden import oracle_sdd
+    fx = load_fixture(f"sdd_n{N}_h{hard}")
+    meta = fx["meta"]
+    m = _load_dense(dgg_amd.DGG_LearnableK_SDD(in_dim=meta["d"], latent_dim=meta["h"], k_bias=meta["k_bias"], hard=bool(hard),
+                                               dist_fn="metric"), fx, dev)
+    x = T(fx["x"], dev).requires_grad_(True)
+    adj, k = m(x, meta["temp"], noise=False)
+    r = oracle_sdd(fx["x"], lambda s_: fx["p." + s_], meta["temp"], bool(hard))
+    assert np.array_equal(Nn(adj), r["out"])
+    np.testing.assert_allclose(Nn(k), fx["k"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(Nn(adj), fx["out64"], rtol=0, atol=1e-5)
+    ((adj * T(fx["cot"], dev)).sum() + (k * T(fx["cotk"], dev)).sum()).backward()
+    assert _check_module_grads(m, x, fx, "g64.", 3e-4) >= 7
+    if N <= 25:
+        np.testing.assert_allclose(Nn(adj), fx["out"], rtol=0, atol=1e-5)
+        _check_module_grads(m, x, fx, "g.", 3e-4)
+    with pytest.raises(Exception):
+        m(x, meta["temp"], noise=True)
+
+
+@pytest.mark.parametrize("N", [24, 160])
+@pytest.mark.parametrize("hard", [0, 1])
+def test_straight_through_module_matches_reference_golden(dev, N, hard):
+    """dgg_amd.DGG_StraightThrough (dgm.py:103-182), dist_fn="metric", noise=False"""
+    import dgg_amd
+    from test_oracle_golden import oracle_st
+    fx = load_fixture(f"st_n{N}_h{hard}")
+    meta = fx["meta"]
+    m = _load_dense(dgg_amd.DGG_StraightThrough(in_dim=meta["d"], latent_dim=meta["h"], k=meta["k"], hard=bool(hard), dist_fn="metric"),
+                    fx, dev)
+    x = T(fx["x"], dev).requires_grad_(True)
+    adj = m(x, meta["temp"], noise=False)
+    assert np.array_equal(Nn(adj), oracle_st(fx["x"], lambda s_: fx["p." + s_], meta["temp"], meta["k"], bool(hard)))
+    np.testing.assert_allclose(Nn(adj), fx["out64"], rtol=0, atol=1e-5)
+    if hard:
+        assert bool(((adj > 0.5).sum(-1) == meta["k"]).all())
+    (adj * T(fx["cot"], dev)).sum().backward()
+    assert _check_module_grads(m, x, fx, "g64.", 3e-4) >= 2
+    if N <= 25:
+        np.testing.assert_allclose(Nn(adj), fx["out"], rtol=0, atol=1e-5)
+        _check_module_grads(m, x, fx, "g.", 3e-4)
