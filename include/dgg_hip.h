@@ -193,7 +193,9 @@ int dgg_select_scores(const float *scores, int64_t R, int64_t N, int K, int32_t 
 
 /* ---- smooth first-k ramp, normalisation, aggregation ---------------------------------------------------------
  * w_ir = val_ir * (1 - 0.5(1 + tanh(r - k_i)))  (mode 0, dgm.py:1410-1420)  or the ramp alone (mode 1, 1427-1434);
- * rs_i = sum_r w_ir. */
+ * mode 3: the forward value of the straight-through hard adjacency `(hard - soft).detach() + soft` with hard = the ramp
+ * mask at the selected columns (the well-defined form of dgg_hard, dgm.py:343-346; its gradient is mode 0's, so
+ * dgg_softk_bwd is called with mode 0);  rs_i = sum_r w_ir. */
 int dgg_softk_fwd(const int32_t *idx, const float *val, const float *k, int64_t N, int K, int mode, float *w, float *rs,
                   void *stream);
 /* ahat_ir = rs_i^-1/2 w_ir rs_j^-1/2   (normalize_adj, model.py:1205-1219; rs has GLOBAL length, rows are

@@ -18,7 +18,8 @@ constexpr int WPB = 4;   // wavefronts (rows) per workgroup
 
 __device__ __forceinline__ float inv_sqrt_c(float rs) { return __fdiv_rn(1.0f, c_sqrt(rs)); }
 
-// w = score * ramp (mode 0) or ramp (mode 1); rs = row sum (butterfly order)
+// w = score * ramp (mode 0), ramp (mode 1) or the straight-through value (ramp - score * ramp) + score * ramp (mode 3: forward
+// value of `(hard - soft).detach() + soft` with hard = the ramp mask, dgm.py:343-346); rs = row sum (butterfly order)
 __global__ __launch_bounds__(WPB * 64) void softk_fwd_kernel(const int32_t *__restrict__ idx, const float *__restrict__ val,
                                                             const float *__restrict__ k, int64_t N, int K, int mode,
                                                             float *__restrict__ w, float *__restrict__ rs) {
@@ -28,7 +29,11 @@ __global__ __launch_bounds__(WPB * 64) void softk_fwd_kernel(const int32_t *__re
     float wv = 0.0f;
     if (lane < K) {
         float f = c_ramp((float)lane, k[i]);
-        float v = mode == 0 ? __fmul_rn(val[i * K + lane], f) : f;
+        float v = f;
+        if (mode == 0 || mode == 3) {
+            const float a = __fmul_rn(val[i * K + lane], f);
+            v = mode == 0 ? a : __fadd_rn(__fadd_rn(f, -a), a);
+        }
         wv = idx[i * K + lane] >= 0 ? v : 0.0f;
         w[i * K + lane] = wv;
     }
@@ -453,6 +458,7 @@ extern "C" {
 int dgg_softk_fwd(const int32_t *idx, const float *val, const float *k, int64_t N, int K, int mode, float *w, float *rs,
                   void *stream) {
     if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    if (mode != 0 && mode != 1 && mode != 3) return dgg_set_error(DGG_ERR_ARG, "softk_fwd: mode must be 0 (k_times), 1 (k_only) or 3 (hard)");
     if (N == 0) return 0;
     hipLaunchKernelGGL(softk_fwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, idx, val, k, N, K,
                        mode, w, rs);

@@ -93,7 +93,7 @@ class _DGGSoftAdjFn(torch.autograd.Function):
         else:
             rowptr, col = cfg["cand"]
             idx, val = ops.edgelist_topk(xp, rowptr, col, cfg["K"], cfg["t"], cfg["noise_mode"], cfg["G"], cfg["seed"])
-        w, rs = ops.softk_fwd(idx, val, k, cfg["mode"])
+        w, rs = ops.softk_fwd(idx, val, k, cfg.get("fwd_mode", cfg["mode"]))
         ctx.cfg = cfg
         # destination-ordered partition of the active entries: the column-side terms of the backward run on it instead of
         # entry-wise float atomics (built only when a backward can follow)
@@ -127,7 +127,7 @@ class _DGGEdgeMlpAdjFn(torch.autograd.Function):
         p_edge, ex = ops.edge_mlp_fwd(AB, xp, erow, col, sdeg, ex_in, cfg["ex_mode"], cfg["t_ex"], wdu, wdv, wex, eb1, w2, b2,
                                       cfg["act"])
         idx, val, eid = ops.edgelist_topk_p(p_edge, x.shape[0], rowptr, col, cfg["K"], cfg["noise_mode"], cfg["G"], cfg["seed"])
-        w, rs = ops.softk_fwd(idx, val, k, cfg["mode"])
+        w, rs = ops.softk_fwd(idx, val, k, cfg.get("fwd_mode", cfg["mode"]))
         ctx.cfg = cfg
         # optional tensors (None allowed): kept outside save_for_backward, detached
         ctx.opt = tuple(None if t_ is None else t_.detach() for t_ in (sdeg, ex, wdu, wdv, wex))
@@ -281,8 +281,6 @@ class DGG_LearnableK_debug(nn.Module):
                                       "and 'learn_normalized_degree'")
         if self.k_select_mode not in ("k_times_edge_prob", "k_only"):
             raise NotImplementedError(f"k-select mode {self.k_select_mode!r} is dead code in the reference")
-        if self.hard:
-            raise NotImplementedError("dgg_hard=True: the reference's hard path is index-confused (SURVEY.md section 7)")
         if self.args.debug_step in (0, 1):
             raise NotImplementedError("debug_step 0/1 return dense [N,N] intermediates in the reference")
         avals = erow = None
@@ -304,6 +302,12 @@ class DGG_LearnableK_debug(nn.Module):
             noise_mode = ops.NOISE_HASH              # edge-list candidates: every candidate is scored, per-pair hash noise
         cfg = dict(cand=cand, K=self.ell_width, t=ops.T_DIST, noise_mode=noise_mode, G=G, seed=seed, algo=self.topk_algo,
                    mode=ops.MODE_K_TIMES_EDGE_PROB if self.k_select_mode == "k_times_edge_prob" else ops.MODE_K_ONLY)
+        if self.hard and cfg["mode"] == ops.MODE_K_TIMES_EDGE_PROB:
+            # dgg_hard: straight-through adjacency `(hard - soft).detach() + soft` with hard = the ramp mask at the selected
+            # columns (the SDD class's definition, dgm.py:343-346; for k_only hard == soft).  The debug class's own
+            # return_hard_or_soft (dgm.py:1294-1311) scatters an already-unsorted matrix through the sort permutation, which is
+            # not a function of the graph and is not reproduced.
+            cfg["fwd_mode"] = ops.MODE_HARD_ST
         We, be = self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias
         kn = self.k_net
         if self.k_net_mode in ("x", "gcn-x-deg"):
@@ -337,7 +341,7 @@ class DGG_LearnableK_debug(nn.Module):
                                                      mlp["b1"], mlp["w2"], mlp["b2"], cfg)
         k = k.detach()
         if writer is not None:   # the two scalars the reference logs from inside the DGG (dgm.py:1259-1261)
-            f = w.detach() if cfg["mode"] == ops.MODE_K_ONLY else (w.detach() / val.clamp(min=1e-30))
+            f = w.detach() if (cfg["mode"] == ops.MODE_K_ONLY or "fwd_mode" in cfg) else (w.detach() / val.clamp(min=1e-30))
             writer.add_scalar("values/first_k_std", f.sum(-1).std(), epoch)
             writer.add_scalar("values/first_k_mean", f.sum(-1).mean(), epoch)
         return EllAdjacency(idx, w, x.shape[0], rs=rs, k=k, score=val, part=cfg.get("part"))

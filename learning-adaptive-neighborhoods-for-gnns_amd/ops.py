@@ -13,6 +13,7 @@ from . import _lib
 NOISE_NONE, NOISE_EXPLICIT, NOISE_HASH, NOISE_HASH_SYM, NOISE_RANKED = 0, 1, 2, 3, 4
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 MODE_K_TIMES_EDGE_PROB, MODE_K_ONLY = 0, 1
+MODE_HARD_ST = 3          # softk_fwd only: value (ramp - score*ramp) + score*ramp, gradient of MODE_K_TIMES_EDGE_PROB
 DEFAULT_K = 64
 T_DIST = -0.05  # reference dgm.py:1618
 

@@ -472,7 +472,11 @@ ORA_API void ora_softk(const int32_t *idx, const float *val, const float *k, int
     for (int64_t i = 0; i < N; i++) {
         for (int r = 0; r < K; r++) {
             float f = ramp((float)r, k[i]);
-            float v = (mode == 0) ? val[i * K + r] * f : f;
+            float v = f;                                   /* mode 1: the ramp alone */
+            if (mode == 0 || mode == 3) {                  /* mode 3: straight-through value (hard - soft) + soft, hard = ramp */
+                float a = val[i * K + r] * f;
+                v = mode == 0 ? a : (f - a) + a;
+            }
             w[i * K + r] = idx[i * K + r] >= 0 ? v : 0.0f;
         }
         rs[i] = butterfly_sum(w + i * K, K);

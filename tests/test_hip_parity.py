@@ -1228,3 +1228,39 @@ def test_straight_through_module_matches_reference_golden(dev, N, hard):
     if N <= 25:
         np.testing.assert_allclose(Nn(adj), fx["out"], rtol=0, atol=1e-5)
         _check_module_grads(m, x, fx, "g.", 3e-4)
+
+
+def test_dgg_hard_is_straight_through_over_the_soft_adjacency(dev):
+    """args.dgg_hard=True: values = (ramp - soft) + soft (oracle softk mode 3, bit-for-bit), neighbour lists and every gradient
+    identical to the soft module's (straight-through: backward of the soft adjacency)"""
+    import dgg_amd
+    from argparse import Namespace
+    base = dict(extra_edge_dim=0, extra_k_dim=1, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist", dgg_mode_k_net="x",
+                dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True, symmetric_noise=False, stochastic_k=False,
+                dgg_adj_input="input_adj", n_dgg_layers=1)
+    rng = np.random.default_rng(9)
+    N, d = 700, 24
+    x0 = rng.standard_normal((N, d)).astype(np.float32)
+    prior = (6 + 10 * rng.random(N)).astype(np.float32)
+    cot = rng.standard_normal((N, K)).astype(np.float32)
+    res = {}
+    for hard in (False, True):
+        torch.manual_seed(1)
+        m = dgg_amd.DGG_LearnableK_debug(in_dim=d, latent_dim=32, args=Namespace(dgg_hard=hard, **base)).to(dev)
+        m.set_seed(3, 4)
+        x = T(x0, dev).requires_grad_(True)
+        adj = m(x, dgg_amd.AllPairs(T(prior, dev)))
+        (adj.values() * T(cot, dev)).sum().backward()
+        res[hard] = (adj, x.grad.clone(), {n_: p_.grad.clone() for n_, p_ in m.named_parameters() if p_.grad is not None})
+    soft, hardr = res[False], res[True]
+    assert torch.equal(soft[0].idx, hardr[0].idx)
+    w3, _ = O.softk(Nn(soft[0].idx), Nn(soft[0].score), Nn(soft[0].k), 3)
+    assert np.array_equal(Nn(hardr[0].values()), w3)
+    assert not torch.equal(soft[0].values(), hardr[0].values())
+    same = lambda a, b: float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-6)  # noqa: E731  (float atomics reorder)
+    assert same(soft[1], hardr[1])
+    for n_ in soft[2]:
+        assert same(soft[2][n_], hardr[2][n_]), n_
+    # the hard adjacency still normalises and aggregates like any other
+    Y = hardr[0].normalize().matmul(T(x0, dev))
+    assert bool(torch.isfinite(Y).all())
