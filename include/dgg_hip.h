@@ -170,6 +170,12 @@ int dgg_csr_noisy_sigmoid_bwd(const float *out, const float *g, int64_t E, float
 int dgg_csr_rank_cut_fwd(const float *p, const int64_t *rowptr, const int32_t *col, int64_t N, int kcut, float *out, int32_t *pos,
                          void *stream);
 int dgg_csr_rank_cut_bwd(const int32_t *pos, const float *g, int64_t E, int kcut, float *dp, void *stream);
+/* raw edge probabilities as the adjacency -- debug_step 0/1 (dgm.py:1202-1209, 1240-1246) and k-select mode `edge_p-cdf`
+ * (dgm.py:1368-1401 scatters the unsorted probabilities back) of DGG_LearnableK_debug.  u-v-dist scorer on the stored
+ * entries (dgm.py:1613-1627): p_e = exp(t ||xp_u - xp_v||); backward: dxp [N,h] accumulated (caller zeroes) */
+int dgg_csr_uvdist_fwd(const float *xp, const int64_t *rowptr, const int32_t *col, int64_t N, int h, float t, float *p, void *stream);
+int dgg_csr_uvdist_bwd(const float *xp, const int64_t *rowptr, const int32_t *col, int64_t N, int h, float t, const float *p,
+                       const float *dp, float *dxp, void *stream);
 /* normalize_adj of the *_DGG_00 wrappers (model.py:1340-1352): rs = row sums, ahat_e = rs_i^-1/2 w_e rs_j^-1/2 */
 int dgg_csr_row_sum(const float *vals, const int64_t *rowptr, int64_t N, float *rs, void *stream);
 int dgg_csr_normalize_fwd(const int64_t *rowptr, const int32_t *col, const float *w, const float *rs, int64_t N, float *ahat,

@@ -42,6 +42,8 @@ PROTOTYPES = {
     "dgg_dense_pairs_dx": [_vp, _i32, _i64, _i32, _vp, _vp, _vp],
     "dgg_feat_softmax_fwd": [_vp, _i64, _i32, _vp, _vp],
     "dgg_feat_softmax_bwd": [_vp, _vp, _i64, _i32, _vp, _vp],
+    "dgg_csr_uvdist_fwd": [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp],
+    "dgg_csr_uvdist_bwd": [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp],
     "dgg_csr_row_sum": [_vp, _vp, _i64, _vp, _vp],
     "dgg_csr_normalize_fwd": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "dgg_csr_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],

@@ -228,6 +228,51 @@ __global__ __launch_bounds__(256) void csr_rank_cut_bwd_kernel(const int32_t *__
     if (e < E) dp[e] = pos[e] < kcut ? g[e] : 0.0f;
 }
 
+// ---- raw edge probabilities as the adjacency (debug_step 0/1 and k-select mode edge_p-cdf of DGG_LearnableK_debug) --------
+// dgm.py:1202-1209, 1240-1246: the forward returns edge_p itself; dgm.py:1368-1401: `edge_p-cdf` scatters the UNSORTED
+// probabilities back (src = s_edge_p), so its output is edge_p as well.  u-v-dist scorer on the stored entries of in_adj
+// (dgm.py:1613-1627): p_e = exp(t ||xp_u - xp_v||), lane = entry, canonical distance.
+__global__ __launch_bounds__(WPB * 64) void csr_uvdist_fwd_kernel(const float *__restrict__ xp, const int64_t *__restrict__ rowptr,
+                                                                 const int32_t *__restrict__ col, int64_t N, int h, float t,
+                                                                 float *__restrict__ p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const float *xi = xp + i * h;
+    for (int64_t e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64) {
+        const float d = c_sqrt(pair_d2_thread(xi, xp + (int64_t)col[e] * h, h));
+        p[e] = c_exp(__fmul_rn(t, d));
+    }
+}
+// dp -> dxp (accumulated, caller zeroes): lane = feature, entries of the row in sequence; own row by plain accumulation in
+// registers, neighbour rows by float atomics (edge lists are small: the 100k-node path never comes here)
+__global__ __launch_bounds__(WPB * 64) void csr_uvdist_bwd_kernel(const float *__restrict__ xp, const int64_t *__restrict__ rowptr,
+                                                                 const int32_t *__restrict__ col, int64_t N, int h, float t,
+                                                                 const float *__restrict__ p, const float *__restrict__ dp,
+                                                                 float *__restrict__ dxp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const float *xi = xp + i * h;
+    for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
+        const float g = dp[e] * p[e] * t;                          // d loss / d dist
+        if (g == 0.0f) continue;
+        const int64_t j = col[e];
+        const float *xj = xp + j * h;
+        float d2 = 0.0f;
+        for (int c = lane; c < h; c += 64) { const float df = xi[c] - xj[c]; d2 += df * df; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) d2 += __shfl_xor(d2, off, 64);
+        if (!(d2 > 0.0f)) continue;                                // zero distance: torch's norm backward yields 0
+        const float coef = g / sqrtf(d2);
+        for (int c = lane; c < h; c += 64) {
+            const float v = coef * (xi[c] - xj[c]);
+            atomicAdd(dxp + i * h + c, v);
+            atomicAdd(dxp + j * h + c, -v);
+        }
+    }
+}
+
 // ---- GATConv_DGG (reference model.py:534-577): row softmax with a uniform background ---------------------------------
 // The reference builds a dense [N,N] logit matrix: e_ij on the entries of edge_index, -1e20 elsewhere, multiplied by the
 // dense learned adjacency.  Every pair that is in neither list gets logit -1e20 * 0 = -0, i.e. exp(0) = 1 in the softmax:
@@ -370,6 +415,22 @@ int dgg_csr_rank_cut_bwd(const int32_t *pos, const float *g, int64_t E, int kcut
     if (E == 0) return 0;
     hipLaunchKernelGGL(csr_rank_cut_bwd_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, g, E, kcut, dp);
     return dgg_check_launch("csr_rank_cut_bwd");
+}
+
+int dgg_csr_uvdist_fwd(const float *xp, const int64_t *rowptr, const int32_t *col, int64_t N, int h, float t, float *p, void *stream) {
+    if (N == 0) return 0;
+    if (h < 1) return dgg_set_error(DGG_ERR_ARG, "csr_uvdist_fwd: h must be positive");
+    hipLaunchKernelGGL(csr_uvdist_fwd_kernel, dim3((unsigned)((N + WPB - 1) / WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, xp, rowptr, col,
+                       N, h, t, p);
+    return dgg_check_launch("csr_uvdist_fwd");
+}
+
+int dgg_csr_uvdist_bwd(const float *xp, const int64_t *rowptr, const int32_t *col, int64_t N, int h, float t, const float *p,
+                       const float *dp, float *dxp, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(csr_uvdist_bwd_kernel, dim3((unsigned)((N + WPB - 1) / WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, xp, rowptr, col,
+                       N, h, t, p, dp, dxp);
+    return dgg_check_launch("csr_uvdist_bwd");
 }
 
 }  // extern "C"

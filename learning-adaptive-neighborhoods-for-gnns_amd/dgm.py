@@ -153,6 +153,52 @@ class _DGGEdgeMlpAdjFn(torch.autograd.Function):
                 g(wex, 2 * hw, 3 * hw), dpar[3 * hw:4 * hw], dpar[4 * hw:5 * hw], dpar[5 * hw:5 * hw + 1], None)
 
 
+class _DGGScoresFn(torch.autograd.Function):
+    """Raw edge probabilities on the stored entries of in_adj, CSR order (reference edge_prob_net, dgm.py:1607-1725), for the
+    forward variants that return them as the adjacency: debug_step 0 / 1 (dgm.py:1202-1209, 1240-1246) and the k-select mode
+    `edge_p-cdf`, which scatters the unsorted probabilities back (dgm.py:1400)."""
+
+    @staticmethod
+    def forward(ctx, x, deg, ex_in, We, be, Wcat, wdu, wdv, wex, eb1, w2, b2, cfg):
+        xp = ops.linear_fwd(x, We, be, ops.ACT_LEAKY)
+        rowptr, col, erow = cfg["cand"]
+        ctx.cfg = cfg
+        if Wcat is None:                                  # u-v-dist
+            p = ops.csr_uvdist_fwd(xp, rowptr, col, cfg["t"])
+            ctx.opt = ()
+            ctx.save_for_backward(x, We, xp, p)
+            return p
+        AB = ops.linear_fwd(xp, Wcat, None, ops.ACT_NONE)
+        sdeg = deg if wdu is not None else None
+        p, ex = ops.edge_mlp_fwd(AB, xp, erow, col, sdeg, ex_in, cfg["ex_mode"], cfg["t_ex"], wdu, wdv, wex, eb1, w2, b2, cfg["act"])
+        ctx.opt = tuple(None if t_ is None else t_.detach() for t_ in (sdeg, ex, wdu, wdv, wex))
+        ctx.save_for_backward(x, We, xp, p, AB, Wcat, eb1, w2, b2)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        cfg = ctx.cfg
+        rowptr, col, _ = cfg["cand"]
+        dp = dp.contiguous()
+        if not ctx.opt:
+            x, We, xp, p = ctx.saved_tensors
+            dxp = ops.csr_uvdist_bwd(xp, rowptr, col, p, dp, cfg["t"])
+            dx, dWe, dbe = ops.linear_bwd(x, We, xp, dxp, ops.ACT_LEAKY, need_dx=ctx.needs_input_grad[0])
+            return (dx, None, None, dWe, dbe) + (None,) * 8
+        x, We, xp, p, AB, Wcat, eb1, w2, b2 = ctx.saved_tensors
+        sdeg, ex, wdu, wdv, wex = ctx.opt
+        hw = Wcat.shape[0] // 2
+        dAB, dpar, dex = ops.edge_mlp_bwd(AB, col, None, p, dp, sdeg, ex, wdu, wdv, wex, eb1, w2, b2, cfg["act"], False,
+                                          need_dex=cfg["ex_mode"] == 2, rowptr=rowptr)
+        dxp, dWcat, _ = ops.linear_bwd(xp, Wcat, AB, dAB, ops.ACT_NONE, need_dx=True, need_db=False)
+        if cfg["ex_mode"] == 2:                          # exp(t ||xp_u - xp_v||) also depends on the projection
+            dxp = dxp + ops.csr_uvdist_bwd(xp, rowptr, col, ex, dex, cfg["t_ex"])
+        dx, dWe, dbe = ops.linear_bwd(x, We, xp, dxp, ops.ACT_LEAKY, need_dx=ctx.needs_input_grad[0])
+        g = lambda t_, a, b: None if t_ is None else dpar[a:b]  # noqa: E731
+        return (dx, None, None, dWe, dbe, dWcat if ctx.needs_input_grad[5] else None, g(wdu, 0, hw), g(wdv, hw, 2 * hw),
+                g(wex, 2 * hw, 3 * hw), dpar[3 * hw:4 * hw], dpar[4 * hw:5 * hw], dpar[5 * hw:5 * hw + 1], None)
+
+
 class DGG_LearnableK_debug(nn.Module):
     """Drop-in for reference dgm.py:1077-1727 (modes u-v-dist / x / {k_times_edge_prob, k_only}, soft output)."""
 
@@ -268,6 +314,35 @@ class DGG_LearnableK_debug(nn.Module):
         _, mu, sd = self._norm_deg(deg, consts, 0.0)
         return torch.relu(kp * sd + mu) + 1.0
 
+    def _scores_adjacency(self, x, in_adj):
+        """debug_step 0 (dgm.py:1202-1209), debug_step 1 (dgm.py:1240-1246) and k-select `edge_p-cdf` (dgm.py:1368-1401, whose
+        scatter puts the UNSORTED probabilities back and whose learned k never reaches the output): the adjacency IS the edge
+        probability of every stored entry of in_adj -> CsrAdjacency on its pattern.  Perturbed probabilities (debug_step 1 /
+        edge_p-cdf with perturb_edge_prob) are dense in the reference (every non-edge becomes 1e-8 exp(G) > 0) and are not
+        produced; dgg_hard turns these outputs into all-ones matrices there (dgm.py:1301-1306 with idxs=None)."""
+        if self.hard:
+            raise NotImplementedError("dgg_hard with debug_step 0/1 or edge_p-cdf is a dense all-ones matrix in the reference")
+        if self.args.perturb_edge_prob and self.args.debug_step != 0:
+            raise NotImplementedError("perturbed edge probabilities are returned as a DENSE [N,N] matrix by the reference "
+                                      "(debug_step 1 / edge_p-cdf with perturb_edge_prob=True)")
+        if isinstance(in_adj, AllPairs):
+            raise NotImplementedError("all-pairs candidates: the raw probability matrix is dense [N,N]")
+        if isinstance(in_adj, (EllAdjacency, CsrAdjacency)):
+            in_adj = in_adj.to_sparse().detach()
+        in_adj = in_adj.coalesce()
+        pattern = csr_pattern(in_adj)
+        _, _, deg = csr_candidates(in_adj)
+        We, be = self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias
+        cfg = dict(cand=pattern, t=ops.T_DIST)
+        if self.edge_prob_net_mode == "u-v-dist":
+            p = _DGGScoresFn.apply(x, None, None, We, be, None, None, None, None, None, None, None, cfg)
+        else:
+            mlp, ex_in = self._edge_mlp_terms(in_adj.values().to(torch.float32))
+            cfg.update(ex_mode=mlp["ex_mode"], t_ex=mlp["t_ex"], act=mlp["act"])
+            p = _DGGScoresFn.apply(x, deg, ex_in, We, be, mlp["Wcat"], mlp["wdu"], mlp["wdv"], mlp["wex"], mlp["b1"], mlp["w2"],
+                                   mlp["b2"], cfg)
+        return CsrAdjacency(pattern[0], pattern[1], pattern[2], p, x.shape[0])
+
     def forward(self, x, in_adj, noise=True, writer=None, epoch=None):
         """x [N,dim] fp32 on the GPU; in_adj: sparse COO [N,N] (coalesced, self loops added by the caller) whose
         stored entries are the candidate edges, or `AllPairs(prior_degree)`.  `noise` is accepted and ignored
@@ -279,10 +354,10 @@ class DGG_LearnableK_debug(nn.Module):
             # "pass" returns k = None, which the reference's own select_top_k cannot consume (dgm.py:1485, 1412)
             raise NotImplementedError(f"k-net mode {self.k_net_mode!r}: the HIP path implements 'x', 'gcn-x-deg', 'input_deg' "
                                       "and 'learn_normalized_degree'")
-        if self.k_select_mode not in ("k_times_edge_prob", "k_only"):
-            raise NotImplementedError(f"k-select mode {self.k_select_mode!r} is dead code in the reference")
-        if self.args.debug_step in (0, 1):
-            raise NotImplementedError("debug_step 0/1 return dense [N,N] intermediates in the reference")
+        if self.k_select_mode not in ("k_times_edge_prob", "k_only", "edge_p-cdf"):
+            raise Exception("mode not found")
+        if self.args.debug_step in (0, 1) or self.k_select_mode == "edge_p-cdf":
+            return self._scores_adjacency(x, in_adj)
         avals = erow = None
         if isinstance(in_adj, AllPairs):
             if self.edge_prob_net_mode != "u-v-dist":

@@ -321,6 +321,23 @@ class DenseRowsFn(torch.autograd.Function):
         return dense_pairs_dx(xq, Cm), dt_rows.sum().reshape(t.shape), dk, None, None, None, None, None, None
 
 
+def csr_uvdist_fwd(xp, rowptr, col, t=T_DIST):
+    """dgm.py:1613-1627 on the stored entries: p_e = exp(t ||xp_u - xp_v||) -> [E]"""
+    xp = _chk(xp)
+    p = torch.empty((col.shape[0],), device=xp.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_csr_uvdist_fwd(_ptr(xp), _ptr(rowptr), _ptr(col), xp.shape[0], xp.shape[1], float(t), _ptr(p), _stream()),
+               "csr_uvdist_fwd")
+    return p
+
+
+def csr_uvdist_bwd(xp, rowptr, col, p, dp, t=T_DIST):
+    xp = _chk(xp)
+    dxp = torch.zeros_like(xp)
+    _lib.check(_lib.lib().dgg_csr_uvdist_bwd(_ptr(xp), _ptr(rowptr), _ptr(col), xp.shape[0], xp.shape[1], float(t), _ptr(_chk(p)),
+                                             _ptr(_chk(dp)), _ptr(dxp), _stream()), "csr_uvdist_bwd")
+    return dxp
+
+
 def csr_row_sum(vals, rowptr):
     N = rowptr.shape[0] - 1
     rs = torch.empty((N,), device=vals.device, dtype=torch.float32)

@@ -4,7 +4,10 @@ coalesced COO fp32, model looked up by class name, nll_loss on the public split.
 
     python -m dgg_amd.train_small_graphs --data cora --data_dir /path/to/planetoid --model GCN_DGG_00 --epochs 5
 
-Only the flags the model constructors / DGG read are kept (no tensorboard, no code snapshots, no checkpoints).
+Only the flags the model constructors / DGG read are kept (no tensorboard, no code snapshots).  `--checkpoint FILE` saves
+the best-validation state in the reference's `save_checkpoint` layout (train_small_graphs.py:210-220: args, epoch,
+model_state_dict, optimizer_state_dict); `--resume FILE` loads `model_state_dict` as its `test_best` does (line 330) -- the
+modules keep the reference's state_dict keys, so files written by either side load in the other.
 """
 import argparse
 import random
@@ -56,7 +59,15 @@ def build_parser():
                    choices=["u-v-dist", "u-v-A_uv", "u-v-deg", "edge_conv", "A_uv", "u-v-deg-dist"])
     p.add_argument("--dgg_mode_k_net", default="x", choices=["pass", "learn_normalized_degree", "input_deg", "gcn-x-deg", "x"])
     p.add_argument("--dgg_mode_k_select", default="k_times_edge_prob", choices=["edge_p-cdf", "k_only", "k_times_edge_prob"])
+    p.add_argument("--checkpoint", default=None, help="write the best-validation checkpoint here (reference save_checkpoint layout)")
+    p.add_argument("--resume", default=None, help="load model_state_dict from a checkpoint before training")
     return p
+
+
+def save_checkpoint(fn, args, epoch, model, optimizer, lr_scheduler=None):
+    """reference train_small_graphs.py:210-220"""
+    torch.save({"args": args.__dict__, "epoch": epoch, "model_state_dict": model.state_dict(),
+                "optimizer_state_dict": optimizer.state_dict()}, fn)
 
 
 def make_adjacency(d, noise_level, device):
@@ -111,6 +122,8 @@ def main(argv=None):
                                lr=args.lr)
     else:
         opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    if args.resume:
+        model.load_state_dict(torch.load(args.resume, map_location=device)["model_state_dict"])
     best, bad, t0 = float("inf"), 0, time.time()
     for epoch in range(args.epochs):
         model.train()
@@ -128,6 +141,8 @@ def main(argv=None):
                   "| test acc:{:.2f}".format(100 * accuracy(out[idx["test_idx"]], y[idx["test_idx"]])))
         if lv < best:
             best, bad = lv, 0
+            if args.checkpoint:
+                save_checkpoint(args.checkpoint, args, epoch, model, opt)
         else:
             bad += 1
         if bad == args.patience:

@@ -858,6 +858,28 @@ ORA_API void ora_csr_rank_cut(const float *p, const int64_t *rowptr, const int32
         out[e] = c < kcut ? p[e] : 0.0f;
     }
 }
+/* raw edge probabilities as the adjacency (debug_step 0/1, edge_p-cdf): u-v-dist scorer on the stored entries */
+ORA_API void ora_csr_uvdist(const float *xp, const int64_t *rowptr, const int32_t *col, int64_t N, int h, float t, float *p) {
+    for (int64_t i = 0; i < N; i++) for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++)
+        p[e] = ora_exp(t * pair_dist(xp + i * h, xp + (int64_t)col[e] * h, h));
+}
+ORA_API void ora_csr_uvdist_bwd(const float *xp, const int64_t *rowptr, const int32_t *col, int64_t N, int h, float t,
+                                const float *p, const float *dp, float *dxp) {
+    double *acc = calloc((size_t)N * h, 8);
+    for (int64_t i = 0; i < N; i++) for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
+        int64_t j = col[e];
+        double d2 = 0.0;
+        for (int c = 0; c < h; c++) { double df = (double)xp[i * h + c] - xp[j * h + c]; d2 += df * df; }
+        if (!(d2 > 0.0)) continue;
+        double coef = (double)dp[e] * p[e] * t / sqrt(d2);
+        for (int c = 0; c < h; c++) {
+            double v = coef * ((double)xp[i * h + c] - xp[j * h + c]);
+            acc[i * h + c] += v; acc[j * h + c] -= v;
+        }
+    }
+    for (int64_t q = 0; q < N * h; q++) dxp[q] = (float)acc[q];
+    free(acc);
+}
 /* ora_edge_mlp_bwd on a CSR-valued adjacency: entry e of row i is (i, col[e]) with cotangent dval[e] */
 ORA_API void ora_edge_mlp_bwd_csr(const float *AB, int64_t N, int hw, const int64_t *rowptr, const int32_t *col,
                                   const float *dval, const float *b1, const float *w2, float b2, int act, float *dAB,

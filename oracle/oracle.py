@@ -403,6 +403,21 @@ def csr_rank_cut(p, rowptr, col, kcut):
     return out, pos
 
 
+def csr_uvdist(xp, rowptr, col, t=-0.05):
+    xp, rowptr, col = f32(xp), _rp(rowptr), i32(col)
+    p = np.empty(col.shape[0], np.float32)
+    lib().ora_csr_uvdist(_p(xp), _p(rowptr), _p(col), C.c_int64(xp.shape[0]), C.c_int(xp.shape[1]), C.c_float(t), _p(p))
+    return p
+
+
+def csr_uvdist_bwd(xp, rowptr, col, p, dp, t=-0.05):
+    xp, rowptr, col, p, dp = f32(xp), _rp(rowptr), i32(col), f32(p), f32(dp)
+    dxp = np.empty_like(xp)
+    lib().ora_csr_uvdist_bwd(_p(xp), _p(rowptr), _p(col), C.c_int64(xp.shape[0]), C.c_int(xp.shape[1]), C.c_float(t), _p(p), _p(dp),
+                             _p(dxp))
+    return dxp
+
+
 def edge_mlp_bwd_csr(AB, rowptr, col, dval, b1, w2, b2, act=1):
     AB, rowptr, col, dval = f32(AB), _rp(rowptr), i32(col), f32(dval)
     hw = AB.shape[1] // 2

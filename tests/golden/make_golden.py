@@ -455,6 +455,46 @@ def dense_cases():
             print("st", N, hard, "ok", float(adj.sum(-1).mean()))
 
 
+def scores_cases():
+    """The forward variants of the live class that return the raw edge probabilities as the adjacency: debug_step 0
+    (dgm.py:1202-1209), debug_step 1 (dgm.py:1240-1246) and the k-select mode `edge_p-cdf` (dgm.py:1368-1401, which scatters the
+    UNSORTED probabilities back, so its output is edge_p too)."""
+    N, d, h = 96, 24, 16
+    gen = torch.Generator().manual_seed(19)
+    A = random_graph(N, 20, gen).to_dense()
+    A[0, :] = (torch.rand(N, generator=gen) < 0.8).float()          # one row wider than the ELL width
+    A[0, 0] = 1.0
+    Wt = 0.5 + torch.rand(N, N, generator=gen)
+    in_adj = (A * Wt).to_sparse().coalesce()
+    x = torch.randn(N, d, generator=gen)
+    cot = torch.from_numpy(grid_normal(161, (N, N)))
+    for tag, kw in [("debug0_uvdist", dict(debug_step=0, dgg_mode_edge_net="u-v-dist", perturb_edge_prob=True)),
+                    ("cdf_uvdeg", dict(dgg_mode_k_select="edge_p-cdf", dgg_mode_edge_net="u-v-deg", extra_edge_dim=2,
+                                       perturb_edge_prob=False)),
+                    ("debug1_uvdegdist", dict(debug_step=1, dgg_mode_edge_net="u-v-deg-dist", extra_edge_dim=3,
+                                              perturb_edge_prob=False)),
+                    ("cdf_edgeconv", dict(dgg_mode_k_select="edge_p-cdf", dgg_mode_edge_net="edge_conv", perturb_edge_prob=False)),
+                    ("debug0_uvAuv", dict(debug_step=0, dgg_mode_edge_net="u-v-A_uv", extra_edge_dim=1, perturb_edge_prob=False))]:
+        a = base_args(**kw)
+        torch.manual_seed(1234)
+        m = dgm.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=a)
+        m.eval()
+        xr = x.clone().requires_grad_(True)
+        out = m(xr, in_adj).to_dense()
+        (out * cot).sum().backward()
+        ii = in_adj.indices().numpy().astype(np.int32)
+        fx = {"x": x.numpy(), "rows": ii[0], "cols": ii[1], "adj_vals": in_adj.values().numpy(), "out": out.detach().numpy(),
+              "cot": cot.numpy(), "g.x": xr.grad.numpy()}
+        for k_, v in m.state_dict().items():
+            fx["p." + k_] = v.detach().numpy()
+        for k_, p_ in m.named_parameters():
+            fx["g." + k_] = p_.grad.numpy() if p_.grad is not None else np.zeros_like(p_.detach().numpy())
+        meta = dict(name="scores_" + tag, N=N, d=d, h=h, torch=torch.__version__, args=vars(a))
+        fx["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, f"scores_{tag}.npz"), **fx)
+        print("scores", tag, "ok: nnz", int((out != 0).sum()), "of", in_adj._nnz(), "stored")
+
+
 def allpairs_cases():
     N, d, h = 256, 32, 16
     gen = torch.Generator().manual_seed(8)
@@ -545,6 +585,8 @@ if __name__ == "__main__":
         ablations_cases()
     if "dense" in which:
         dense_cases()
+    if "scores" in which:
+        scores_cases()
 
 
 def model_cases():

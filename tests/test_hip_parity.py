@@ -916,6 +916,15 @@ def test_small_graph_harness_trains_on_planetoid_files(dev, tmp_path):
             H.main(["--data", "toy", "--data_dir", str(tmp_path), "--model", model, "--hidden", "16", "--epochs", "12",
                     "--edge_noise_level", "0.001", "--lr", "0.02"] + extra)
             assert len(losses) == 12 and losses[-1] < losses[0], (model, losses)
+        # checkpoint in the reference's save_checkpoint layout (train_small_graphs.py:210-220) and resume from it
+        ck = str(tmp_path / "best.pt")
+        common = ["--data", "toy", "--data_dir", str(tmp_path), "--model", "GCN_DGG_00", "--hidden", "16", "--edge_noise_level", "0.001"]
+        best = H.main(common + ["--epochs", "6", "--lr", "0.02", "--checkpoint", ck])
+        saved = torch.load(ck, map_location="cpu")
+        assert set(saved) == {"args", "epoch", "model_state_dict", "optimizer_state_dict"} and saved["args"]["model"] == "GCN_DGG_00"
+        assert "dggs.0.node_encoder.0.weight" in saved["model_state_dict"] and "conv1.W" in saved["model_state_dict"]
+        resumed = H.main(common + ["--epochs", "1", "--lr", "0.0", "--resume", ck])      # lr 0: evaluates the loaded weights
+        assert abs(resumed - best) <= 1e-4 * max(1.0, abs(best)), (resumed, best)
     finally:
         H.F.nll_loss = orig
 
@@ -1264,3 +1273,42 @@ def test_dgg_hard_is_straight_through_over_the_soft_adjacency(dev):
     # the hard adjacency still normalises and aggregates like any other
     Y = hardr[0].normalize().matmul(T(x0, dev))
     assert bool(torch.isfinite(Y).all())
+
+
+@pytest.mark.parametrize("tag", ["debug0_uvdist", "cdf_uvdeg", "debug1_uvdegdist", "cdf_edgeconv", "debug0_uvAuv"])
+def test_scores_adjacency_module_matches_reference_golden(dev, tag):
+    """DGG_LearnableK_debug with debug_step 0 / 1 or dgg_mode_k_select='edge_p-cdf': the adjacency is the edge probability of
+    every stored entry of in_adj (CsrAdjacency; one row is wider than the ELL).  == oracle bit-for-bit, reference to 1e-5,
+    gradients of x and of every parameter that receives one to 3e-4"""
+    import dgg_amd
+    from argparse import Namespace
+    from test_oracle_golden import oracle_scores
+    fx = load_fixture("scores_" + tag)
+    meta = fx["meta"]
+    N = meta["N"]
+    m = dgg_amd.DGG_LearnableK_debug(in_dim=meta["d"], latent_dim=meta["h"], args=Namespace(**meta["args"]))
+    m.load_state_dict({k_[2:]: torch.from_numpy(v) for k_, v in fx.items() if k_.startswith("p.")}, strict=True)
+    m = m.to(dev).eval()
+    ind = torch.from_numpy(np.stack([fx["rows"], fx["cols"]]).astype(np.int64))
+    A = torch.sparse_coo_tensor(ind, torch.from_numpy(fx["adj_vals"]), (N, N)).coalesce().to(dev)
+    x = T(fx["x"], dev).requires_grad_(True)
+    adj = m(x, A)
+    assert isinstance(adj, dgg_amd.CsrAdjacency)
+    p, _ = oracle_scores(fx)
+    assert np.array_equal(Nn(adj.values()), p)
+    np.testing.assert_allclose(Nn(adj.to_dense()), fx["out"], rtol=0, atol=1e-5)
+    (adj.to_dense() * T(fx["cot"], dev)).sum().backward()
+    grads = {n_: p_.grad for n_, p_ in m.named_parameters()}
+    grads["x"] = x.grad
+    checked = 0
+    for key, got in grads.items():
+        ref = fx["g." + key]
+        if np.abs(ref).max() == 0:
+            assert got is None or float(got.abs().max()) == 0, key
+            continue
+        err = np.abs(Nn(got).reshape(ref.shape) - ref).max() / np.abs(ref).max()
+        assert err <= 3e-4, f"grad {key}: {err:.3e}"
+        checked += 1
+    assert checked >= 3
+    # the adjacency feeds the layers like any other: normalise + aggregate
+    assert bool(torch.isfinite(adj.normalize().matmul(T(fx["x"], dev))).all())
