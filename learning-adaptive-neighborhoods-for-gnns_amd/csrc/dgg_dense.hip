@@ -200,6 +200,7 @@ int dgg_dense_rows_fwd(const float *xq, int B, int64_t N, int h, const float *t,
                        float hs_start, float interval, int hard, float *out, float *y, int32_t *pos, void *stream) {
     if (B < 0 || N < 0 || h < 1) return dgg_set_error(DGG_ERR_ARG, "dense_rows_fwd: bad shape");
     if (ramp != 0 && ramp != 1) return dgg_set_error(DGG_ERR_ARG, "dense_rows_fwd: ramp must be 0 (SDD sigmoid) or 1 (fixed top-k)");
+    if ((int64_t)B * N == 0) return 0;
     if (ramp == 0 && !k) return dgg_set_error(DGG_ERR_ARG, "dense_rows_fwd: the SDD ramp needs k");
     if (!(temp > 0.0f)) return dgg_set_error(DGG_ERR_ARG, "dense_rows_fwd: temp must be positive");
     if (N > DENSE_MAX_N) return dgg_set_error(DGG_ERR_UNSUPPORTED, "dense_rows: N > 8192 (dense [B,N,N] path; use the sparse all-pairs path)");
@@ -219,9 +220,9 @@ int dgg_dense_rows_bwd(const float *xq, int B, int64_t N, int h, const float *t,
                        float interval, const float *y, const int32_t *pos, const float *g, float *Cm, float *dk, float *dt_rows,
                        void *stream) {
     if (ramp != 0 && ramp != 1) return dgg_set_error(DGG_ERR_ARG, "dense_rows_bwd: ramp must be 0 or 1");
-    if (ramp == 0 && (!k || !dk)) return dgg_set_error(DGG_ERR_ARG, "dense_rows_bwd: the SDD ramp needs k and dk");
     const int64_t rows = (int64_t)B * N;
     if (rows == 0) return 0;
+    if (ramp == 0 && (!k || !dk)) return dgg_set_error(DGG_ERR_ARG, "dense_rows_bwd: the SDD ramp needs k and dk");
     hipLaunchKernelGGL(dense_rows_bwd_kernel, dim3((unsigned)((rows + WPB - 1) / WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, xq, rows, N,
                        h, t, temp, ramp, k, hs_start, interval, y, pos, g, Cm, ramp == 0 ? dk : nullptr, dt_rows);
     return dgg_check_launch("dense_rows_bwd");

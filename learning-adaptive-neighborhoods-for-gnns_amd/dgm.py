@@ -577,7 +577,7 @@ class DGG_LearnableK_SDD(nn.Module):
         B, N, d = x.shape
         x2 = x.reshape(B * N, d)
         z = ops.LinearFn.apply(x2, self.input_project[0].weight, self.input_project[0].bias, ops.ACT_LEAKY, 0)
-        xq = ops.FeatSoftmaxFn.apply(z).reshape(B, N, -1)
+        xq = ops.FeatSoftmaxFn.apply(z).reshape(B, N, self.latent_dim)
         k = self.k_net(x2).reshape(B, N) + self.k_bias
         adj = ops.DenseRowsFn.apply(xq, self.t, k, float(temp), ops.RAMP_SDD, 0, float(self.hs_start), float(self.interval),
                                     bool(self.hard))

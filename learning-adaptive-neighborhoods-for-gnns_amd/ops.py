@@ -141,6 +141,8 @@ def edge_mlp_fwd(AB, xp, erow, col, deg, ex_in, ex_mode, t_ex, wdu, wdv, wex, b1
     E = col.shape[0]
     p_edge = torch.empty((E,), device=xp.device, dtype=torch.float32)
     ex_out = torch.empty((E,), device=xp.device, dtype=torch.float32) if ex_mode else None
+    if E == 0:                                           # no candidate edge at all (empty tensors have no data pointer)
+        return p_edge, ex_out
     o = lambda t_: None if t_ is None else _chk(t_)  # noqa: E731
     _lib.check(_lib.lib().dgg_edge_mlp_fwd(_ptr(AB), _ptr(xp), N, h, hw, _ptr(erow), _ptr(col), E, _ptr(o(deg)), _ptr(o(ex_in)), ex_mode,
                                            float(t_ex), _ptr(o(wdu)), _ptr(o(wdv)), _ptr(o(wex)), _ptr(_chk(b1)), _ptr(_chk(w2)),

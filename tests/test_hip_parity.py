@@ -1312,3 +1312,66 @@ def test_scores_adjacency_module_matches_reference_golden(dev, tag):
     assert checked >= 3
     # the adjacency feeds the layers like any other: normalise + aggregate
     assert bool(torch.isfinite(adj.normalize().matmul(T(fx["x"], dev))).all())
+
+
+def test_degenerate_inputs_through_the_modules(dev):
+    """tiny / empty inputs through the drop-in modules (forward + backward): graphs of 2..65 nodes (rows shorter than the ELL),
+    self loops only, no candidate edge at all, a fixed k of 0, empty batches; N=1 all-pairs is rejected loudly (the reference's
+    unbiased std of one degree is NaN)"""
+    import dgg_amd
+    from argparse import Namespace
+    base = dict(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+                dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True, symmetric_noise=False,
+                stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
+
+    def mk(**kw):
+        torch.manual_seed(0)
+        return dgg_amd.DGG_LearnableK_debug(in_dim=8, latent_dim=16, args=Namespace(**dict(base, **kw))).to(dev)
+
+    def coo(rows, cols, N):
+        ind = torch.tensor([rows, cols], dtype=torch.int64).reshape(2, -1)
+        return torch.sparse_coo_tensor(ind, torch.ones(ind.shape[1]), (N, N)).coalesce().to(dev)
+
+    def fwd_bwd(m, x, A):
+        x = x.clone().requires_grad_(True)
+        out = m(x, A).normalize().matmul(x)
+        out.sum().backward()
+        torch.cuda.synchronize()
+        assert out.shape == x.shape and bool(torch.isfinite(out).all()) and bool(torch.isfinite(x.grad).all())
+
+    for N in (2, 3, 63, 64, 65):
+        x = torch.randn(N, 8, device=dev)
+        prior = dgg_amd.AllPairs(torch.full((N,), 3.0, device=dev))
+        for kw in (dict(), dict(symmetric_noise=True), dict(perturb_edge_prob=False)):
+            fwd_bwd(mk(**kw), x, prior)
+    with pytest.raises(Exception, match="N >= 2"):
+        mk()(torch.randn(1, 8, device=dev), dgg_amd.AllPairs(torch.full((1,), 3.0, device=dev)))
+    N = 10
+    x = torch.randn(N, 8, device=dev)
+    loops = list(range(N))
+    for kw in (dict(), dict(dgg_mode_edge_net="u-v-deg", extra_edge_dim=2), dict(dgg_mode_edge_net="edge_conv"),
+               dict(dgg_mode_edge_net="A_uv"), dict(dgg_mode_k_select="edge_p-cdf", perturb_edge_prob=False)):
+        fwd_bwd(mk(**kw), x, coo(loops, loops, N))
+        fwd_bwd(mk(**kw), x, coo([], [], N))                      # no candidate edge at all
+    for cls_, kw in ((dgg_amd.DGG, {}), (dgg_amd.DGG_Ablations, {}), (dgg_amd.DGG_Ablations, {"k": 3})):
+        for A in (coo(loops, loops, N), coo([], [], N)):
+            torch.manual_seed(0)
+            m = cls_(in_dim=8, latent_dim=16, args=Namespace(**base)).to(dev)
+            xx = x.clone().requires_grad_(True)
+            adj, xe = m(xx, A, **kw)
+            adj.normalize().matmul(xe).sum().backward()
+            assert bool(torch.isfinite(xx.grad).all())
+    for B, Nn in [(1, 1), (0, 5), (2, 0), (2, 2)]:
+        xx = torch.randn(B, Nn, 8, device=dev)
+        adj, k = dgg_amd.DGG_LearnableK_SDD(8, 16).to(dev)(xx, 0.5)
+        assert adj.shape == (B, Nn, Nn) and k.shape == (B, Nn, 1) and bool(torch.isfinite(adj).all())
+        st = dgg_amd.DGG_StraightThrough(8, 16, k=3, dist_fn="metric").to(dev)(xx, 0.5)
+        assert st.shape == (B, Nn, Nn) and bool(torch.isfinite(st).all())
+    A3, x3 = coo([0, 1, 1, 2], [1, 0, 2, 1], 3), torch.rand(3, 8, device=dev)
+    for name in ["GCN_DGG", "GCN_DGG_00", "GCN_DGG_Ablations", "GAT_DGG_00", "GAT_DGG_Ablations", "SAGE_DGG", "SAGE_DGG_00"]:
+        torch.manual_seed(0)
+        m = getattr(dgg_amd, name)(nfeat=8, nlayers=2, nhidden=16, nclass=3, args=Namespace(**base)).to(dev)
+        out = m(x3, A3)
+        out = out[0] if isinstance(out, tuple) else out
+        out.sum().backward()
+        assert out.shape == (3, 3) and bool(torch.isfinite(out).all())
