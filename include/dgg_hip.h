@@ -245,7 +245,7 @@ int dgg_gcnii_epilogue_bwd(const float *g, int64_t n, float theta, float alpha, 
 int dgg_ell_spmm_t_part(const float *a, const float *dY, int64_t rows, int K, int F, const void *part_ws, int64_t ncols, float *dX,
                         void *stream);
 /* coef_ws: rows*K (+ ncols for dgg_edge_bwd_part) floats; dxp [ncols,h] / da [ncols] zeroed by the caller;
- * latent_dim in {16,32,64} */
+ * latent_dim in {16,32,64,128} */
 int dgg_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *dval, int K,
                       int64_t row0, float t, int perturb, const void *part_ws, int64_t ncols, float *coef_ws, float *dxp,
                       void *stream);

@@ -464,7 +464,8 @@ int dgg_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, 
         case 16: DGG_EDGE_PART(16); break;
         case 32: DGG_EDGE_PART(32); break;
         case 64: DGG_EDGE_PART(64); break;
-        default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "edge_bwd_part supports latent_dim in {16,32,64}");
+        case 128: DGG_EDGE_PART(128); break;
+        default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "edge_bwd_part supports latent_dim in {16,32,64,128}");
     }
 #undef DGG_EDGE_PART
     return dgg_check_launch("edge_bwd_part");

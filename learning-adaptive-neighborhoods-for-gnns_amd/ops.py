@@ -493,7 +493,7 @@ def edge_bwd(xp, idx, val, dval, row0=0, t=T_DIST, perturb=False, part=None):
     Ng, h = xp.shape
     N, K = idx.shape
     dxp = torch.zeros_like(xp)
-    if part is not None and h in (16, 32, 64):
+    if part is not None and h in (16, 32, 64, 128):
         coef = torch.empty(N * K + Ng, device=xp.device, dtype=torch.float32)   # per-record coefficients + column sums
         _lib.check(_lib.lib().dgg_edge_bwd_part(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(dval)), K, row0, t, int(perturb),
                                                 _ptr(part), Ng, _ptr(coef), _ptr(dxp), _stream()), "edge_bwd_part")
@@ -503,8 +503,13 @@ def edge_bwd(xp, idx, val, dval, row0=0, t=T_DIST, perturb=False, part=None):
     return dxp
 
 
+# latent dims from here on run the k-net as MFMA GEMMs (bit-identical to the thread-per-node kernels, which hold a node's
+# whole row in registers and slow down steeply beyond 64 features: 0.57 ms vs 0.2 ms per step at h = 128, N = 100k)
+KNET_WIDE_FROM = int(__import__("os").environ.get("DGG_KNET_WIDE_FROM", "128"))
+
+
 def _knet_wide_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp):
-    """latent_dim > 128: the three layers as MFMA GEMMs on feat = [xk | nd] (same fmaf chains as the fused kernels)"""
+    """wide latents: the three layers as MFMA GEMMs on feat = [xk | nd] (same fmaf chains as the fused kernels)"""
     N, h = xk.shape
     feat = torch.empty((N, h + 1), device=xk.device, dtype=torch.float32)
     _lib.check(_lib.lib().dgg_knet_feat(_ptr(xk), _ptr(_chk(deg)), _ptr(mu_sd), N, h, _ptr(feat), _stream()), "knet_feat")
@@ -533,7 +538,7 @@ def knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, save=True):
     xk = _chk(xk)
     N, h = xk.shape
     h2, h4 = W1.shape[0], Wmu.shape[0]
-    if h > 128:
+    if h >= KNET_WIDE_FROM:
         return _knet_wide_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp)
     dev = xk.device
     k = torch.empty((N,), device=dev, dtype=torch.float32)
@@ -550,7 +555,7 @@ def knet_x_bwd(h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk):
     """-> dxk [N,h], dW1, db1, dWmu, dbmu, dWp ([1,h4]), dbp ([1])"""
     N = z.shape[0]
     h2, h4 = W1.shape[0], Wmu.shape[0]
-    if h > 128:
+    if h >= KNET_WIDE_FROM:
         return _knet_wide_bwd(h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk)
     dev = z.device
     dkp = torch.empty((N, 1), device=dev, dtype=torch.float32)

@@ -192,7 +192,10 @@ def test_softk_normalize_spmm_bit_exact(dev):
 def test_knet_bit_exact_and_bwd(dev):
     from dgg_amd import ops
     rng = np.random.default_rng(8)
-    for N, h in [(700, 64), (300, 16), (150, 128), (333, 256), (90, 40)]:   # 256: GEMM composition; 40: wave-per-node
+    # 128, 256: GEMM composition; (151, -128): the thread-per-node kernels at 128 features; 40: wave-per-node
+    for N, h in [(700, 64), (300, 16), (150, 128), (151, -128), (333, 256), (90, 40)]:
+        ops.KNET_WIDE_FROM = 129 if h < 0 else 128
+        h = abs(h)
         h2, h4 = h // 2, h // 4
         xk = rng.standard_normal((N, h)).astype(np.float32)
         deg = (5 + 30 * rng.random(N)).astype(np.float32)
@@ -456,7 +459,7 @@ def test_model_wrappers_match_reference_golden(dev, name):
     assert checked >= 8
 
 
-@pytest.mark.parametrize("N,d,h,noise", [(700, 24, 16, "hash"), (2500, 128, 64, "ranked")])
+@pytest.mark.parametrize("N,d,h,noise", [(700, 24, 16, "hash"), (2500, 128, 64, "ranked"), (1300, 40, 128, "ranked")])
 def test_sharded_layer_step_matches_cpu_restatement(dev, N, d, h, noise):
     """The step bench.py times (dgg_amd.parallel.ShardedDGGConv on the HIP kernels: k_limit, destination-ordered
     partition, fused backward) against the same step on the numpy/oracle stand-in of tests/test_parallel_gloo.py"""
