@@ -409,6 +409,13 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="multi-GPU: keep the graph at --nodes nodes in total (default: --nodes nodes PER GPU, weak scaling; "
                          "with the O(N*K) pair search a rank's work depends on its rows, not on the total column count)")
+    ap.add_argument("--exchange", choices=["replicate", "gather"], default="replicate",
+                    help="multi-GPU, features as data (no --x-grad): 'replicate' = the node features are placed on every GPU once at "
+                         "load and each rank projects all rows itself (per-step collectives: row sums, da, weight gradients); "
+                         "'gather' = all-gather xp and X every step (the path for inputs that are activations)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="DIAGNOSTIC, single GPU: time the per-step COMPUTE of one rank of a W-GPU weak-scaling run (own --nodes rows "
+                         "against W * --nodes columns, replicated features, no collectives); not a throughput measurement")
     ap.add_argument("--no-hipgraph", dest="hipgraph", action="store_false", help="time eager launches instead of a captured hipGraph")
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="row sample of the cpu_baseline leg: 0 = auto (64 rows per host core, ~10-20 s), <0 = skip")
@@ -443,15 +450,28 @@ def main():
         return bench_ppi(a, dev)
 
     # weak scaling (default): every GPU owns --nodes rows of an (--nodes * world)-node graph; --strong keeps N fixed
-    N, d, h = (a.nodes if a.strong else a.nodes * world), a.feat, a.latent
+    emu = a.emulate_world if (a.emulate_world > 1 and world == 1 and not force) else 0
+    N, d, h = (a.nodes if a.strong else a.nodes * max(world, emu, 1)), a.feat, a.latent
     P = make_params(d, h, dev)
-    r0, r1, _ = shard_bounds(N, world, rank)
+    erank = emu // 2
+    r0, r1, _ = shard_bounds(N, emu, erank) if emu else shard_bounds(N, world, rank)
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     x_local = torch.randn(r1 - r0, d, generator=g).to(dev)
     gd = torch.Generator(device="cpu").manual_seed(7)
     deg = (24 + 16 * torch.rand(N, generator=gd)).to(dev)
     noise_mode = ops.NOISE_RANKED if a.noise == "ranked" else ops.NOISE_HASH
-    layer = ShardedDGGConv(ops, N, group=None, K=64, noise_mode=noise_mode, seed=(1234, 0), algo=a.algo, x_grad=a.x_grad)
+    # features are DATA unless --x-grad: with more than one rank they are replicated once, here, outside the timed region (data
+    # placement: 4*N*d bytes per GPU), and no feature tensor crosses the fabric per step (dgg_amd/parallel.py)
+    x_full = None
+    if (world > 1 or force) and not a.x_grad and a.exchange == "replicate":
+        from dgg_amd.parallel import _all_gather_rows
+        x_full = _all_gather_rows(x_local, N, shard_bounds(N, world, rank)[2], None).contiguous()
+    if emu:
+        x_full = torch.randn(N, d, generator=g).to(dev)
+        x_full[r0:r1] = x_local
+    layer = ShardedDGGConv(ops, N, group=None, K=64, noise_mode=noise_mode, seed=(1234, 0), algo=a.algo, x_grad=a.x_grad, x_full=x_full)
+    if emu:
+        layer.emulate_rank(emu, erank)
 
     def step():
         Z = layer.forward(x_local, deg, P)
@@ -495,7 +515,8 @@ def main():
         dist.all_reduce(ksum)
         dist.all_reduce(kmaxv, op=dist.ReduceOp.MAX)
     T = float(tmax.item()) / a.steps
-    kmean = float(ksum.item()) / N
+    Nval = (r1 - r0) if emu else N                            # emulation: one rank's rows only
+    kmean = float(ksum.item()) / Nval
     assert float(kmaxv.item()) + 8.5 <= 64, "learned degree exceeds the ELL width: results would be truncated"
     assert all(torch.isfinite(v).all() for v in grads.values())
 
@@ -548,13 +569,19 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": METRIC, "value": N * kmean / T, "unit": "edges/s",
+            "metric": METRIC, "value": Nval * kmean / T, "unit": "edges/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": T * 1e3, "higher_is_better": True,
             "scaling": "strong" if a.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic all-pairs DGG N={N} d={d} h={h} k~{kmean:.1f} K=64, u-v-dist/x/"
                                    f"k_times_edge_prob, Gumbel(0,0.3) perturbation, + normalize + GCNConv({d},64), fwd+bwd",
                        "nodes": N, "feat": d, "latent": h, "ell_width": 64, "pairs_per_s": N * float(N) / T,
-                       "x_grad": a.x_grad, "topk_algo": a.algo, "noise": a.noise, "hipgraph": graph is not None, "parallelism": f"row-shard x{world}"},
+                       "x_grad": a.x_grad, "topk_algo": a.algo, "noise": a.noise, "hipgraph": graph is not None,
+                       "parallelism": f"row-shard x{world}" if not emu else f"DIAGNOSTIC: compute of rank {erank} of {emu}, no collectives",
+                       "feature_exchange": ("single GPU" if world == 1 and not force else
+                                            "features replicated at load, every rank projects all rows; per-step collectives: all-gather row sums, "
+                                            "all-reduce da + weight gradients" if x_full is not None else
+                                            "per step: all-gather xp, all-gather X, all-gather row sums, all-reduce da + weight gradients"
+                                            + (", reduce-scatter dX" if a.x_grad else ""))},
             # dominant kernel BY TIME of the step (an O(N*K) gather/scatter kernel since the pair stage became O(N*150))
             "roofline": {"bound": "hbm", "kernel": dom, "rocprof_kernel": ROCPROF_NAME.get(dom), "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": kern[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": traffic.get(dom),

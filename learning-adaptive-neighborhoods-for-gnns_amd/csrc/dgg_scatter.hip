@@ -241,11 +241,23 @@ __global__ __launch_bounds__(256) void edge_bwd_cols(const float *__restrict__ x
     int cur = -1;
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float sacc = 0.0f;
+    // Records are globally ordered by destination, so only the FIRST and the LAST run of a chunk can continue in a neighbouring
+    // chunk (another lane group): those are flushed with float atomics, every other run has this group as its only writer and
+    // is flushed with one 16-byte read-modify-write per lane.  (With G ranks a rank's records spread over G times more
+    // destinations -- ~4 records per run instead of ~30 at G = 8 -- and atomics for every run would dominate the kernel.)
+    const int shared_lo = cbeg > 0 ? recs[cbeg - 1].y : -1, shared_hi = cend < nnz ? recs[cend].y : -1;
     auto flush = [&]() {
         if (cur >= 0) {
             float *o = dxp + (int64_t)cur * H + 4 * c4;
-            atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
-            if (c4 == 0 && sacc != 0.0f) atomicAdd(ssum + cur, sacc);
+            if (cur == shared_lo || cur == shared_hi) {
+                atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
+                if (c4 == 0 && sacc != 0.0f) atomicAdd(ssum + cur, sacc);
+            } else {
+                float4 v = *reinterpret_cast<float4 *>(o);
+                v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += acc.w;
+                *reinterpret_cast<float4 *>(o) = v;
+                if (c4 == 0 && sacc != 0.0f) ssum[cur] += sacc;
+            }
         }
     };
     for (int eb = (int)cbeg; eb < cend; eb += LPR) {             // LPR records per batch, one per lane of the group
@@ -298,10 +310,17 @@ __global__ __launch_bounds__(256) void spmm_t_cols(const float *__restrict__ dY,
     const int cend = cbeg + CH < nnz ? (int)cbeg + CH : nnz;
     int cur = -1;
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int shared_lo = cbeg > 0 ? recs[cbeg - 1].y : -1, shared_hi = cend < nnz ? recs[cend].y : -1;   // see edge_bwd_cols
     auto flush = [&]() {
         if (cur >= 0) {
             float *o = dX + (int64_t)cur * F + f0;
-            atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
+            if (cur == shared_lo || cur == shared_hi) {
+                atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
+            } else {
+                float4 v = *reinterpret_cast<float4 *>(o);
+                v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += acc.w;
+                *reinterpret_cast<float4 *>(o) = v;
+            }
         }
     };
     for (int eb = (int)cbeg; eb < cend; eb += LPR) {

@@ -13,10 +13,15 @@ adjacency and of the conv output.  Collectives per step:
             all-reduce of the replicated weight gradients (one flat bucket, ~35k floats)
             [reduce-scatter dX [N,d] only when the input features need a gradient]
 
-Every rank projects only its own rows (xp = leaky(X We^T + be)) and gathers the rest: with the ranked noise a row
-costs O(150) pair scores, so re-projecting all N rows on every rank would no longer be negligible.  The weight
+Every rank projects only its own rows (xp = leaky(X We^T + be)) and gathers the rest.  The weight
 gradient of the projection is formed from each rank's PARTIAL dxp against the full X / xp and summed by the weight
 all-reduce, so the [N,h] gradient itself never crosses the fabric.
+
+REPLICATED FEATURES (`x_full=`): when the DGG input is DATA (GCN_DGG / SAGE_DGG / GCNII_DGG all feed it the raw node
+features, model.py:1266, 720) it never changes between steps, so it is placed on every GPU once at load (N*d*4 bytes:
+0.4 GB of the 288 GB for 800k nodes) and NO feature tensor crosses the fabric per step: every rank projects all N rows
+itself (N*d*h*2 flop: cheaper than receiving (G-1)/G of xp over xGMI) and the forward's only collective is the all-gather
+of the row sums.  The gathers above remain the path for inputs that are activations (`x_grad`, DGG on hidden layers).
 
 `kern` is the kernel namespace (dgg_amd.ops on the GPU; tests substitute a CPU stand-in built on the oracle so
 that the partition / collective logic is exercised with gloo, world_size 2, without a GPU).
@@ -64,20 +69,32 @@ class ShardedDGGConv:
 
     PARAM_KEYS = ("We", "be", "Wk", "bk", "W1", "b1", "Wmu", "bmu", "Wp", "bp", "Wc")
 
-    def __init__(self, kern, N, group=None, K=64, t=-0.05, noise_mode=2, seed=(1234, 0), mode=0, algo=0, x_grad=False):
+    def __init__(self, kern, N, group=None, K=64, t=-0.05, noise_mode=2, seed=(1234, 0), mode=0, algo=0, x_grad=False, x_full=None):
         self.kern, self.N, self.group = kern, N, group
+        assert x_full is None or not x_grad, "replicated features are data: they cannot take a gradient"
+        self.x_full = x_full                                 # [N,d] static node features present on every rank, or None
         self.K, self.t, self.noise_mode, self.seed, self.mode, self.algo, self.x_grad = K, t, noise_mode, seed, mode, algo, x_grad
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # DGG_FORCE_COLLECTIVES=1 issues every collective even in a 1-rank group (exercises the RCCL calls on a 1-GPU box)
         self.coll = self.world > 1 or (dist.is_initialized() and os.environ.get("DGG_FORCE_COLLECTIVES") == "1")
+        self.emulate = None
         self.r0, self.r1, self.per = shard_bounds(N, self.world, self.rank)
+
+    def emulate_rank(self, world, rank):
+        """TIMING DIAGNOSTIC (bench.py --emulate-world): do the work of `rank` of `world` in a single process -- own row range
+        against all N columns, replicated features -- with the collectives left out and the other ranks' row sums faked by
+        tiling the own ones.  Results are not meaningful; the kernel sequence and sizes are those of the real rank."""
+        assert self.x_full is not None and not dist.is_initialized()
+        self.world, self.rank, self.coll, self.emulate = world, rank, False, (world, rank)
+        self.r0, self.r1, self.per = shard_bounds(self.N, world, rank)
 
     def forward(self, x_local, deg_full, P):
         kern = self.kern
         s = {}
-        xp = kern.linear_fwd(x_local, P["We"], P["be"], 1, 0)
-        if self.coll:                               # xp first (the top-k waits for it), X streams in behind it
+        repl = self.x_full is not None
+        xp = kern.linear_fwd(self.x_full if repl else x_local, P["We"], P["be"], 1, 0)
+        if self.coll and not repl:                  # xp first (the top-k waits for it), X streams in behind it
             g_xp = _Gather(xp, self.N, self.per, self.group, True)
             g_X = _Gather(x_local, self.N, self.per, self.group, True)
         s["xk"] = xk = kern.linear_fwd(x_local, P["Wk"], P["bk"], 1, 0)
@@ -85,15 +102,17 @@ class ShardedDGGConv:
         deg_local = deg_full[self.r0:self.r1].contiguous()
         s["k"], s["z"], s["u"], s["feat"] = kern.knet_x_fwd(xk, deg_local, mu_sd, P["W1"], P["b1"], P["Wmu"], P["bmu"],
                                                           P["Wp"].reshape(-1), P["bp"])
-        s["xp"] = xp = g_xp.get() if self.coll else xp
+        s["xp"] = xp = g_xp.get() if (self.coll and not repl) else xp
         s["idx"], s["val"] = kern.allpairs_topk(xp, self.K, self.t, self.noise_mode, None, self.seed,
                                                 rows=(self.r0, self.r1), algo=self.algo, k_limit=s["k"])
         s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
         # destination-bucket partition of the active entries: the backward's column-side terms run on it (no atomics)
         s["part"] = kern.part_build(s["idx"], s["w"], self.N) if hasattr(kern, "part_build") else None
         s["rs"] = rs = _all_gather_rows(rs_local, self.N, self.per, self.group) if self.coll else rs_local
+        if self.emulate is not None:
+            s["rs"] = rs = rs_local.repeat(self.world)[:self.N].contiguous()
         s["ahat"] = kern.normalize_fwd(s["idx"], s["w"], rs, self.r0)
-        s["X"] = X = g_X.get() if self.coll else x_local
+        s["X"] = X = self.x_full if repl else (g_X.get() if self.coll else x_local)
         s["Y"] = kern.spmm_fwd(s["idx"], s["ahat"], X)
         s["Z"] = kern.linear_fwd(s["Y"], P["Wc"], None, 2, 1)
         self.saved = s

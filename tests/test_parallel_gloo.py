@@ -171,16 +171,16 @@ def make_inputs(N=150, d=12, h=16):
     return x, deg, P, cot
 
 
-def run_step(x_local, deg, P, cot_local, N, group):
+def run_step(x_local, deg, P, cot_local, N, group, x_full=None):
     sys.path.insert(0, ROOT)
     from dgg_amd.parallel import ShardedDGGConv
-    layer = ShardedDGGConv(CpuKern(), N, group=group, K=64, noise_mode=2, seed=(5, 6), x_grad=True)
+    layer = ShardedDGGConv(CpuKern(), N, group=group, K=64, noise_mode=2, seed=(5, 6), x_grad=x_full is None, x_full=x_full)
     Z = layer.forward(x_local, deg, P)
     g = layer.backward(cot_local, x_local, P)
     return Z, g
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, replicated=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
@@ -188,19 +188,24 @@ def _worker(rank, world, port, ret):
     x, deg, P, cot = make_inputs()
     N = x.shape[0]
     r0, r1, _ = shard_bounds(N, world, rank)
-    Z, g = run_step(x[r0:r1].contiguous(), deg, P, cot[r0:r1].contiguous(), N, None)
+    Z, g = run_step(x[r0:r1].contiguous(), deg, P, cot[r0:r1].contiguous(), N, None, x if replicated else None)
     ret[rank] = (r0, r1, Z.numpy(), {k: v.numpy() for k, v in g.items()})
     dist.destroy_process_group()
 
 
-def test_sharded_step_matches_single_process():
+@pytest.mark.parametrize("replicated", [False, True])
+def test_sharded_step_matches_single_process(replicated):
+    """replicated=True: the node features are data present on every rank (no per-step exchange of X / xp, every rank projects
+    all rows); the only forward collective left is the all-gather of the row sums"""
     x, deg, P, cot = make_inputs()
     N = x.shape[0]
     Z1, g1 = run_step(x, deg, P, cot, N, None)          # world 1 (no process group)
-    port = 29500 + os.getpid() % 2000
+    if replicated:
+        g1.pop("x")
+    port = 29500 + os.getpid() % 2000 + int(replicated)
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, replicated)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

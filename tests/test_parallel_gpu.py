@@ -29,12 +29,13 @@ def make_inputs(N=1500, d=128, h=64):
     return x, deg, P, cot
 
 
-def run_step(x_local, deg, P, cot_local, N, x_grad):
+def run_step(x_local, deg, P, cot_local, N, x_grad, x_full=None):
     sys.path.insert(0, ROOT)
     from dgg_amd import ops
     from dgg_amd.parallel import ShardedDGGConv
     dev = torch.device("cuda", 0)
-    layer = ShardedDGGConv(ops, N, group=None, K=64, noise_mode=ops.NOISE_RANKED, seed=(5, 6), x_grad=x_grad)
+    layer = ShardedDGGConv(ops, N, group=None, K=64, noise_mode=ops.NOISE_RANKED, seed=(5, 6), x_grad=x_grad,
+                           x_full=None if x_full is None else x_full.to(dev))
     Pd = {k: v.to(dev) for k, v in P.items()}
     xl = x_local.to(dev)
     Z = layer.forward(xl, deg.to(dev), Pd)
@@ -51,18 +52,19 @@ def _worker(rank, world, port, x_grad, ret):
     x, deg, P, cot = make_inputs()
     N = x.shape[0]
     r0, r1, _ = shard_bounds(N, world, rank)
-    Z, g, idx = run_step(x[r0:r1].contiguous(), deg, P, cot[r0:r1].contiguous(), N, x_grad)
+    # x_grad == "replicated": features are data present on every rank, no per-step exchange of X / xp
+    Z, g, idx = run_step(x[r0:r1].contiguous(), deg, P, cot[r0:r1].contiguous(), N, x_grad is True, x if x_grad == "replicated" else None)
     ret[rank] = (r0, r1, Z.numpy(), {k: v.numpy() for k, v in g.items()}, idx.numpy())
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("x_grad", [False, True])
+@pytest.mark.parametrize("x_grad", [False, True, "replicated"])
 def test_two_ranks_on_one_gpu_match_single_process(x_grad):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     x, deg, P, cot = make_inputs()
     N = x.shape[0]
-    Z1, g1, idx1 = run_step(x, deg, P, cot, N, x_grad)
+    Z1, g1, idx1 = run_step(x, deg, P, cot, N, x_grad is True)
     port = 29500 + os.getpid() % 2000
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()

@@ -48,7 +48,8 @@ def worker(rank, world, port, a, ret):
     P = bench.make_params(a.feat, a.latent, dev)
     bounds = [shard_bounds(N, world, r) for r in range(world)]
     xs, deg = inputs(N, a.feat, [b[1] - b[0] for b in bounds])
-    layer = ShardedDGGConv(ops, N, group=None, K=64, noise_mode=ops.NOISE_RANKED, seed=(1234, 0), x_grad=a.x_grad)
+    x_full = torch.cat(xs).to(dev) if a.replicate else None     # features as data, present on every rank (bench.py's default)
+    layer = ShardedDGGConv(ops, N, group=None, K=64, noise_mode=ops.NOISE_RANKED, seed=(1234, 0), x_grad=a.x_grad, x_full=x_full)
     Z, g = step(layer, xs[rank].to(dev), deg.to(dev), P)
     s = layer.saved
     ret[rank] = dict(idx_crc=int(s["idx"].long().sum().item()), Z_sum=float(Z.double().sum().item()),
@@ -66,6 +67,7 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--sample", type=int, default=97, help="row stride of the compared sample")
     ap.add_argument("--x-grad", action="store_true")
+    ap.add_argument("--replicate", action="store_true", help="replicated features (bench.py --exchange replicate)")
     a = ap.parse_args()
     world = a.world
     ctx = mp.get_context("spawn")
