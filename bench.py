@@ -556,7 +556,7 @@ def main():
         # SpMM Y_i = sum_r A_ir X_j: per active edge one gathered row of X; per row idx, ahat and the output row
         "spmm_fwd": dict(ms=t_spmm * 1e3, bytes=active * 4 * d + rows_loc * (4 * d + 2 * 256)),
     }
-    kern["edge_bwd"]["composite"] = "edge_bwd_rows + edge_bwd_cols + edge_cols_finish (one C-ABI call, three launches)"
+    kern["edge_bwd"]["composite"] = "edge_bwd_rows + edge_bwd_cols (one C-ABI call, two launches)"
     # the roofline object describes ONE launch (so that its duration can be checked against the rocprofv3 kernel
     # stats under profiles/): the longest single kernel of the step
     dom = max((n for n in kern if "composite" not in kern[n]), key=lambda n: kern[n]["ms"])

@@ -224,13 +224,13 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
 }
 
 // ---- score backward, column side: chunks of CH destination-ordered records per group of H/4 lanes --------------------
-// acc_j = -sum_e dd_e xp_{i_e} over the run of records with destination j, flushed with H float atomics per run;
-// s_j = sum_e dd_e goes to ssum (one scalar atomic per run) and is applied by edge_cols_finish: dxp_j += s_j xp_j.
+// acc_j = sum_e dd_e (xp_j - xp_{i_e}) over the run of records with destination j: -sum_e dd_e xp_{i_e} accumulated record by
+// record, (sum_e dd_e) xp_j added at the flush (one extra row gather per run).
 constexpr int CH = 64;
 template <int H>
 __global__ __launch_bounds__(256) void edge_bwd_cols(const float *__restrict__ xp, const int *__restrict__ bstart, int nb,
                                                      const int2 *__restrict__ recs, const float *__restrict__ coef,
-                                                     int64_t row0, float *__restrict__ ssum, float *__restrict__ dxp) {
+                                                     int64_t row0, float *__restrict__ dxp) {
     constexpr int LPR = H / 4;
     const int lane = threadIdx.x & 63, c4 = lane % LPR, gbase = lane - c4;
     const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
@@ -248,15 +248,17 @@ __global__ __launch_bounds__(256) void edge_bwd_cols(const float *__restrict__ x
     const int shared_lo = cbeg > 0 ? recs[cbeg - 1].y : -1, shared_hi = cend < nnz ? recs[cend].y : -1;
     auto flush = [&]() {
         if (cur >= 0) {
+            // the run's share of  dxp_j += (sum_e dd_e) xp_j  is linear in the partial sum, so every group adds its own part here
+            const float4 xj = *reinterpret_cast<const float4 *>(xp + (int64_t)cur * H + 4 * c4);
+            acc.x = fmaf(sacc, xj.x, acc.x); acc.y = fmaf(sacc, xj.y, acc.y);
+            acc.z = fmaf(sacc, xj.z, acc.z); acc.w = fmaf(sacc, xj.w, acc.w);
             float *o = dxp + (int64_t)cur * H + 4 * c4;
             if (cur == shared_lo || cur == shared_hi) {
                 atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
-                if (c4 == 0 && sacc != 0.0f) atomicAdd(ssum + cur, sacc);
             } else {
                 float4 v = *reinterpret_cast<float4 *>(o);
                 v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += acc.w;
                 *reinterpret_cast<float4 *>(o) = v;
-                if (c4 == 0 && sacc != 0.0f) ssum[cur] += sacc;
             }
         }
     };
@@ -356,23 +358,6 @@ __global__ __launch_bounds__(256) void spmm_t_cols(const float *__restrict__ dY,
     flush();
 }
 
-template <int H>
-__global__ __launch_bounds__(256) void edge_cols_finish(const float *__restrict__ xp, const float *__restrict__ ssum,
-                                                        int64_t ncols, float *__restrict__ dxp) {
-    constexpr int LPR = H / 4;
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t j = g / LPR;
-    const int c4 = (int)(g % LPR);
-    if (j >= ncols) return;
-    const float sj = ssum[j];
-    if (sj == 0.0f) return;
-    const float4 x = *reinterpret_cast<const float4 *>(xp + j * H + 4 * c4);
-    float4 *o = reinterpret_cast<float4 *>(dxp + j * H + 4 * c4);
-    float4 v = *o;
-    v.x += sj * x.x; v.y += sj * x.y; v.z += sj * x.z; v.w += sj * x.w;
-    *o = v;
-}
-
 // ---- normalisation backward: row side (da_i, per-entry coefficient), column side (bucket sums) -----------------------
 __global__ __launch_bounds__(256) void norm_da_rows(const int32_t *__restrict__ idx, const float *__restrict__ w,
                                                     const float *__restrict__ rs, const float *__restrict__ dA, int64_t rows,
@@ -470,15 +455,12 @@ int dgg_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, 
     const int64_t nb = nbuckets(ncols);
     PartHdr p = part_layout(const_cast<void *>(part_ws), nb, rows * K);
     const unsigned gr = (unsigned)((rows + 3) / 4);
-    float *ssum = coef_ws + rows * K;
-    if (dgg_check_hip(hipMemsetAsync(ssum, 0, (size_t)ncols * 4, st), "edge_bwd_part memset") != 0) return DGG_ERR_HIP;
     // upper bound of the chunk count (the live count bstart[nb] is read on the device: no host sync)
     const int64_t ngroups = (rows * K + CH - 1) / CH;
 #define DGG_EDGE_PART(HH)                                                                                                  \
     hipLaunchKernelGGL(edge_bwd_rows<HH>, dim3(gr), dim3(256), 0, st, xp, rows, idx, val, dval, K, row0, t, perturb, p.slot, coef_ws, dxp); \
     hipLaunchKernelGGL(edge_bwd_cols<HH>, dim3((unsigned)((ngroups * (HH / 4) + 255) / 256)), dim3(256), 0, st, xp, p.bstart,   \
-                       (int)nb, p.recs, coef_ws, row0, ssum, dxp);                                                         \
-    hipLaunchKernelGGL(edge_cols_finish<HH>, dim3((unsigned)((ncols * (HH / 4) + 255) / 256)), dim3(256), 0, st, xp, ssum, ncols, dxp)
+                       (int)nb, p.recs, coef_ws, row0, dxp)
     switch (h) {
         case 16: DGG_EDGE_PART(16); break;
         case 32: DGG_EDGE_PART(32); break;

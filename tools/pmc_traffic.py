@@ -15,7 +15,7 @@ from collections import defaultdict
 
 # bench.py kernel key -> rocprof kernel-name substrings (several = one C-ABI call made of several launches: summed)
 NAMES = {"allpairs_topk": ["allpairs_topk_ranked"], "spmm_fwd": ["spmm_fwd_kernel"], "spmm_bwd": ["sddmm_pair_kernel"],
-         "edge_bwd": ["edge_bwd_rows", "edge_bwd_cols", "edge_cols_finish"], "edge_bwd_rows": ["edge_bwd_rows"],
+         "edge_bwd": ["edge_bwd_rows", "edge_bwd_cols"], "edge_bwd_rows": ["edge_bwd_rows"],
          "edge_bwd_cols": ["edge_bwd_cols"], "norm_da_cols": ["norm_da_cols"],
          "part_build": ["part_pass", "part_sort", "part_scan"], "gemm_tn_partial": ["gemm_tn_partial"],
          "linear_fwd": ["linear_fwd_mfma"], "knet_x_fwd": ["knet_x_fwd_tpn"], "knet_x_bwd": ["knet_x_bwd_tpn"],
