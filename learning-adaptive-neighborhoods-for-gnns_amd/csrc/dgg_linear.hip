@@ -50,8 +50,11 @@ __global__ __launch_bounds__(64 * WAVES) void linear_fwd_mfma(const float *__res
     constexpr int WQ = BN * BK / NT;                            // floats per thread and K-block (W tile)
     float4 xr[XQ];
     float wr[WQ];
-    // every load is UNCONDITIONAL (clamped address, multiplied by a 0/1 mask afterwards; operands are finite): a predicated
-    // load becomes a branch with its own wait and serialises the staging; straight-line loads issue back to back
+    float wm[WQ];                                                // 0/1 masks of the W tile
+    unsigned xm[XQ];                                             // per-element validity bits of the x tile
+    // Loads are UNCONDITIONAL (clamped addresses) and their values are NOT touched here: the 0/1 masks are applied when the
+    // registers are written to LDS, one K-block later.  (Multiplying by the mask right after the load -- or predicating the
+    // load -- makes the compiler wait for the data BEFORE the MFMAs of the current block, i.e. no overlap at all.)
     auto load_block = [&](int k0) {
         if (vec4) {   // 16-byte loads: 8 lanes cover one 128-byte row segment
 #pragma unroll
@@ -61,9 +64,8 @@ __global__ __launch_bounds__(64 * WAVES) void linear_fwd_mfma(const float *__res
                 const bool ok = gi < N && k0 + c4 < d;
                 const int64_t gic = gi < N ? gi : N - 1;
                 const int kc = k0 + c4 < d ? k0 + c4 : d - 4;
-                const float4 v = *reinterpret_cast<const float4 *>(x + gic * d + kc);
-                const float m = ok ? 1.0f : 0.0f;                // arithmetic mask: no control dependence on the load
-                xr[q] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
+                xr[q] = *reinterpret_cast<const float4 *>(x + gic * d + kc);
+                xm[q] = ok ? 15u : 0u;
             }
         } else {
 #pragma unroll
@@ -72,12 +74,15 @@ __global__ __launch_bounds__(64 * WAVES) void linear_fwd_mfma(const float *__res
                 const int64_t gi = m0 + r;
                 const int64_t gic = gi < N ? gi : N - 1;
                 float t[4];
+                unsigned bits = 0;
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int kk = k0 + c4 + u;
-                    t[u] = x[gic * d + (kk < d ? kk : d - 1)] * ((gi < N && kk < d) ? 1.0f : 0.0f);
+                    t[u] = x[gic * d + (kk < d ? kk : d - 1)];
+                    bits |= (gi < N && kk < d) ? (1u << u) : 0u;
                 }
                 xr[q] = make_float4(t[0], t[1], t[2], t[3]);
+                xm[q] = bits;
             }
         }
 #pragma unroll
@@ -86,9 +91,18 @@ __global__ __launch_bounds__(64 * WAVES) void linear_fwd_mfma(const float *__res
             const int j = w_layout == 0 ? e / BK : e % BN, c = w_layout == 0 ? e % BK : e / BN;
             const int gj = n0 + j, gk = k0 + c;
             const int gjc = gj < out ? gj : out - 1, gkc = gk < d ? gk : d - 1;
-            wr[q] = W[w_layout == 0 ? (int64_t)gjc * d + gkc : (int64_t)gkc * out + gjc] * ((gj < out && gk < d) ? 1.0f : 0.0f);
+            wr[q] = W[w_layout == 0 ? (int64_t)gjc * d + gkc : (int64_t)gkc * out + gjc];
+            wm[q] = (gj < out && gk < d) ? 1.0f : 0.0f;
         }
     };
+    // bias of this lane's columns, fetched before the K loop so that the epilogue has no load to wait for (a wait on a load
+    // there would also wait for every earlier STORE: vmcnt counts both)
+    float bj[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+        const int gj = n0 + a * 32 + li;
+        bj[a] = b ? b[gj < out ? gj : out - 1] : 0.0f;
+    }
     load_block(0);
     for (int k0 = 0; k0 < d; k0 += BK) {
         __syncthreads();                                         // previous block's LDS reads are done
@@ -96,13 +110,14 @@ __global__ __launch_bounds__(64 * WAVES) void linear_fwd_mfma(const float *__res
         for (int q = 0; q < XQ; q++) {
             const int e = tid + q * NT, r = e >> 3, c4 = (e & 7) * 4;
             float *dst = xs + r * LDP + c4;
-            dst[0] = xr[q].x; dst[1] = xr[q].y; dst[2] = xr[q].z; dst[3] = xr[q].w;
+            dst[0] = (xm[q] & 1u) ? xr[q].x : 0.0f; dst[1] = (xm[q] & 2u) ? xr[q].y : 0.0f;
+            dst[2] = (xm[q] & 4u) ? xr[q].z : 0.0f; dst[3] = (xm[q] & 8u) ? xr[q].w : 0.0f;
         }
 #pragma unroll
         for (int q = 0; q < WQ; q++) {
             const int e = tid + q * NT;
-            if (w_layout == 0) ws[(e / BK) * LDP + e % BK] = wr[q];
-            else ws[(e % BN) * LDP + e / BN] = wr[q];
+            const int off = w_layout == 0 ? (e / BK) * LDP + e % BK : (e % BN) * LDP + e / BN;
+            ws[off] = wm[q] != 0.0f ? wr[q] : 0.0f;
         }
         __syncthreads();
         if (k0 + BK < d) load_block(k0 + BK);                    // in flight during the MFMAs below
@@ -117,20 +132,33 @@ __global__ __launch_bounds__(64 * WAVES) void linear_fwd_mfma(const float *__res
             }
         }
     }
+    const bool hasb = b != nullptr;
+    auto finish = [&](float v, float bias) {
+        const float vb = __fadd_rn(v, bias);
+        v = hasb ? vb : v;
+        const float lk = v > 0.0f ? v : __fmul_rn(0.01f, v), rl = v > 0.0f ? v : 0.0f;
+        return act == 1 ? lk : (act == 2 ? rl : v);
+    };
+    // Interior tiles (all but the last row / column block) store without per-element predicates: a predicated store is a
+    // branch, and after every branch the compiler re-waits for ALL outstanding memory operations -- earlier stores included --
+    // which serialises the 16 * NACC stores of a wavefront.
+    if (m0 + BM <= N && n0 + BN <= out) {
+        float *yb = y + (m0 + wave * 32 + 4 * hh) * out + n0 + li;
+#pragma unroll
+        for (int a = 0; a < NACC; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) yb[(int64_t)((r & 3) + 8 * (r >> 2)) * out + a * 32] = finish(acc[a][r], bj[a]);
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < NACC; a++) {
-        int gj = n0 + a * 32 + li;
-        if (gj >= out) continue;
-        float bj = b ? b[gj] : 0.0f;
+        const int gj = n0 + a * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            int64_t gi = m0 + wave * 32 + row;
-            if (gi < N) {
-                float v = acc[a][r];
-                if (b) v = __fadd_rn(v, bj);
-                y[gi * out + gj] = act_apply(v, act);
-            }
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const int64_t gi = m0 + wave * 32 + row;
+            const float v = finish(acc[a][r], bj[a]);
+            if (gi < N && gj < out) y[gi * out + gj] = v;
         }
     }
 }
