@@ -50,17 +50,34 @@ __global__ __launch_bounds__(256) void part_pass(const int32_t *__restrict__ idx
     __syncthreads();
     const int64_t r0 = (int64_t)blockIdx.x * PR + wave * 64;
     constexpr int UQ = 8;                                        // rows in flight per wavefront (loads before LDS atomics)
-    for (int q0 = 0; q0 < 64; q0 += UQ) {
-        int32_t jj[UQ];
+    // A wavefront whose 64 rows all exist (every one but the last) loads WITHOUT predicates: a predicated load is compiled
+    // into a branch with its own s_waitcnt vmcnt(0), i.e. one load in flight at a time instead of 2*UQ.
+    const bool full = r0 + 64 <= rows && K == 64;                // wave-uniform
+    // entry code: destination j >= 0 (active), -1 (inactive entry), -2 (no entry)
+    auto load_rows = [&](int q0, int32_t(&jj)[UQ]) {
+        if (full) {
 #pragma unroll
-        for (int u = 0; u < UQ; u++) {
-            const int64_t i = r0 + q0 + u;
-            jj[u] = -1;
-            if (i < rows && lane < K) {
-                const int32_t j = idx[i * K + lane];
-                jj[u] = w[i * K + lane] != 0.0f ? j : -1;
+            for (int u = 0; u < UQ; u++) {
+                const int64_t e = (r0 + q0 + u) * 64 + lane;
+                const int32_t j = idx[e];
+                const float wv = w[e];
+                jj[u] = (j >= 0 && wv != 0.0f) ? j : -1;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < UQ; u++) {
+                const int64_t i = r0 + q0 + u;
+                jj[u] = -2;
+                if (i < rows && lane < K) {
+                    const int32_t j = idx[i * K + lane];
+                    jj[u] = (j >= 0 && w[i * K + lane] != 0.0f) ? j : -1;
+                }
             }
         }
+    };
+    for (int q0 = 0; q0 < 64; q0 += UQ) {
+        int32_t jj[UQ];
+        load_rows(q0, jj);
 #pragma unroll
         for (int u = 0; u < UQ; u++)
             if (jj[u] >= 0) atomicAdd(&hist[jj[u] / BS], 1);
@@ -75,15 +92,7 @@ __global__ __launch_bounds__(256) void part_pass(const int32_t *__restrict__ idx
     __syncthreads();
     for (int q0 = 0; q0 < 64; q0 += UQ) {
         int32_t jj[UQ];
-#pragma unroll
-        for (int u = 0; u < UQ; u++) {
-            const int64_t i = r0 + q0 + u;
-            jj[u] = -2;                                          // -2: no entry, -1: inactive entry
-            if (i < rows && lane < K) {
-                const int32_t j = idx[i * K + lane];
-                jj[u] = (j >= 0 && w[i * K + lane] != 0.0f) ? j : -1;
-            }
-        }
+        load_rows(q0, jj);
 #pragma unroll
         for (int u = 0; u < UQ; u++) {
             const int64_t i = r0 + q0 + u;
