@@ -186,37 +186,49 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
     const float4 xi = *reinterpret_cast<const float4 *>(xp + gi * H + 4 * c4);
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float mycoef = 0.0f;
-    for (int r0 = 0; r0 < K; r0 += NPI) {
-        const int r = r0 + slot;
-        const int rr = r < 64 ? r : 63;
-        const int32_t j = __shfl(jl, rr, 64);
-        const float g = __shfl(gl, rr, 64), v = __shfl(vl, rr, 64);
-        const bool act = r < K && j >= 0 && g != 0.0f;
-        if (__ballot(act) == 0ull) continue;                     // wave-uniform
-        float4 d = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (act) {
-            const float4 xj = *reinterpret_cast<const float4 *>(xp + (int64_t)j * H + 4 * c4);
-            d = make_float4(xi.x - xj.x, xi.y - xj.y, xi.z - xj.z, xi.w - xj.w);
-        }
-        float d2 = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
-        if (LPR > 16) d2 += __uint_as_float(xor_shfl<16>(__float_as_uint(d2), lane));
-        if (LPR > 8) d2 += __uint_as_float(xor_shfl<8>(__float_as_uint(d2), lane));
-        if (LPR > 4) d2 += __uint_as_float(xor_shfl<4>(__float_as_uint(d2), lane));
-        if (LPR > 2) d2 += __uint_as_float(xor_shfl<2>(__float_as_uint(d2), lane));
-        d2 += __uint_as_float(xor_shfl<1>(__float_as_uint(d2), lane));
-        float dd = 0.0f;
-        if (act && d2 != 0.0f) {                                 // vector_norm backward at 0 is 0 (self loop)
-            const float dist = sqrtf(d2);
-            const float p = c_exp(t * dist);
-            const float dp = perturb ? g * v / (p + 1e-8f) : g;
-            dd = dp * t * p / dist;
-        }
-        acc.x += dd * d.x; acc.y += dd * d.y; acc.z += dd * d.z; acc.w += dd * d.w;
-        // hand the coefficient to the lane that owns entry r (lane r): gather from the first lane of each slot
+    // Two batches of NPI neighbours per iteration, both gathers issued UNCONDITIONALLY (inactive slots re-read the own row and
+    // are masked arithmetically) before either is consumed: a predicated gather is a branch + s_waitcnt vmcnt(0), i.e. one
+    // gather in flight per wavefront.
+    for (int r0 = 0; r0 < K; r0 += 2 * NPI) {
+        int32_t j[2];
+        float g[2], v[2];
+        bool act[2];
 #pragma unroll
-        for (int s = 0; s < NPI; s++) {
-            const float cs = bcast(dd, s * LPR);
-            if (lane == r0 + s) mycoef = cs;
+        for (int b = 0; b < 2; b++) {
+            const int r = r0 + b * NPI + slot;
+            const int rr = r < 64 ? r : 63;
+            j[b] = __shfl(jl, rr, 64);
+            g[b] = __shfl(gl, rr, 64);
+            v[b] = __shfl(vl, rr, 64);
+            act[b] = r < K && j[b] >= 0 && g[b] != 0.0f;
+        }
+        if (__ballot(act[0] || act[1]) == 0ull) continue;        // wave-uniform
+        float4 xj[2];
+#pragma unroll
+        for (int b = 0; b < 2; b++) xj[b] = *reinterpret_cast<const float4 *>(xp + (act[b] ? (int64_t)j[b] : gi) * H + 4 * c4);
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const float4 d = make_float4(xi.x - xj[b].x, xi.y - xj[b].y, xi.z - xj[b].z, xi.w - xj[b].w);   // 0 when inactive
+            float d2 = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+            if (LPR > 16) d2 += __uint_as_float(xor_shfl<16>(__float_as_uint(d2), lane));
+            if (LPR > 8) d2 += __uint_as_float(xor_shfl<8>(__float_as_uint(d2), lane));
+            if (LPR > 4) d2 += __uint_as_float(xor_shfl<4>(__float_as_uint(d2), lane));
+            if (LPR > 2) d2 += __uint_as_float(xor_shfl<2>(__float_as_uint(d2), lane));
+            d2 += __uint_as_float(xor_shfl<1>(__float_as_uint(d2), lane));
+            float dd = 0.0f;
+            if (act[b] && d2 != 0.0f) {                          // vector_norm backward at 0 is 0 (self loop)
+                const float dist = sqrtf(d2);
+                const float p = c_exp(t * dist);
+                const float dp = perturb ? g[b] * v[b] / (p + 1e-8f) : g[b];
+                dd = dp * t * p / dist;
+            }
+            acc.x += dd * d.x; acc.y += dd * d.y; acc.z += dd * d.z; acc.w += dd * d.w;
+            // hand the coefficient to the lane that owns entry r (lane r): gather from the first lane of each slot
+#pragma unroll
+            for (int s2 = 0; s2 < NPI; s2++) {
+                const float cs = bcast(dd, s2 * LPR);
+                if (lane == r0 + b * NPI + s2) mycoef = cs;
+            }
         }
     }
     // sum the NPI neighbour slots (lanes with equal c4)
