@@ -17,6 +17,26 @@ MODE_HARD_ST = 3          # softk_fwd only: value (ramp - score*ramp) + score*ra
 DEFAULT_K = 64
 T_DIST = -0.05  # reference dgm.py:1618
 
+# Measurement hook (bench.py): when PROBE is a dict, the wrappers of the four gather kernels record a pair of events on the
+# launch stream around their C-ABI call, so that per-kernel durations are taken INSIDE a running step (same cache state as
+# the timed region) rather than from stand-alone launches.  None: no events, no overhead.
+PROBE = None
+
+
+def _probe_begin():
+    if PROBE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _probe_end(name, e0):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROBE.setdefault(name, []).append((e0, e1))
+
 
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
@@ -109,9 +129,11 @@ def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed
         ws_bytes = int(_lib.lib().dgg_allpairs_workspace_bytes(N, h, noise_mode, K))
         if ws_bytes:
             ws = torch.empty((ws_bytes,), device=xp.device, dtype=torch.uint8)
+    pe = _probe_begin()
     _lib.check(_lib.lib().dgg_allpairs_topk(_ptr(xp), N, h, r0, r1, t, noise_mode, _ptr(G), ldG, seed[0], seed[1], K,
                                             _ptr(idx), _ptr(val), _ptr(None if k_limit is None else _chk(k_limit)), algo, _ptr(ws),
                                             ws_bytes, _stream()), "allpairs_topk")
+    _probe_end("allpairs_topk", pe)
     if return_ws:      # diagnostics: the guess-and-verify control block is ws[:16] = (msum f32, nfail i32, gmin0 f32)
         return idx, val, ws
     return idx, val
@@ -409,7 +431,10 @@ def spmm_fwd(idx, ahat, X):
     X = _chk(X)
     F = X.shape[1]
     Y = torch.empty((N, F), device=idx.device, dtype=torch.float32)
-    _lib.check(_lib.lib().dgg_ell_spmm_fwd(_ptr(idx), _ptr(_chk(ahat)), _ptr(X), N, K, F, _ptr(Y), _stream()), "ell_spmm_fwd")
+    ahat = _chk(ahat)
+    pe = _probe_begin()
+    _lib.check(_lib.lib().dgg_ell_spmm_fwd(_ptr(idx), _ptr(ahat), _ptr(X), N, K, F, _ptr(Y), _stream()), "ell_spmm_fwd")
+    _probe_end("spmm_fwd", pe)
     return Y
 
 
@@ -445,9 +470,12 @@ def sddmm_norm(idx, ahat, w, rs, X, dY, row0, part, skip_zero=True, cols=True):
     dA = torch.empty((N, K), device=idx.device, dtype=torch.float32)
     coef = torch.empty((N, K), device=idx.device, dtype=torch.float32)
     da = torch.zeros_like(rs)
-    _lib.check(_lib.lib().dgg_ell_sddmm_norm_part(_ptr(idx), _ptr(_chk(ahat)), _ptr(_chk(w)), _ptr(_chk(rs)), _ptr(X), _ptr(dY), N, K, F,
+    ahat, w, rs = _chk(ahat), _chk(w), _chk(rs)
+    pe = _probe_begin()
+    _lib.check(_lib.lib().dgg_ell_sddmm_norm_part(_ptr(idx), _ptr(ahat), _ptr(w), _ptr(rs), _ptr(X), _ptr(dY), N, K, F,
                                                   row0, int(skip_zero), _ptr(part), rs.shape[0], _ptr(coef), _ptr(dA), _ptr(da),
                                                   _stream()), "ell_sddmm_norm_part")
+    _probe_end("spmm_bwd", pe)
     if cols:     # neighbour-side sums (cols=False: diagnostics that time the fused kernel alone)
         _lib.check(_lib.lib().dgg_norm_da_cols_part(_ptr(part), N, K, rs.shape[0], _ptr(coef), _ptr(da), _stream()), "norm_da_cols_part")
     return dA, da
@@ -495,8 +523,11 @@ def edge_bwd(xp, idx, val, dval, row0=0, t=T_DIST, perturb=False, part=None):
     dxp = torch.zeros_like(xp)
     if part is not None and h in (16, 32, 64, 128):
         coef = torch.empty(N * K + Ng, device=xp.device, dtype=torch.float32)   # per-record coefficients + column sums
-        _lib.check(_lib.lib().dgg_edge_bwd_part(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(dval)), K, row0, t, int(perturb),
+        val, dval = _chk(val), _chk(dval)
+        pe = _probe_begin()
+        _lib.check(_lib.lib().dgg_edge_bwd_part(_ptr(xp), N, h, _ptr(idx), _ptr(val), _ptr(dval), K, row0, t, int(perturb),
                                                 _ptr(part), Ng, _ptr(coef), _ptr(dxp), _stream()), "edge_bwd_part")
+        _probe_end("edge_bwd", pe)
         return dxp
     _lib.check(_lib.lib().dgg_edge_bwd(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(dval)), K, row0, t, int(perturb), _ptr(dxp),
                                        _stream()), "edge_bwd")
