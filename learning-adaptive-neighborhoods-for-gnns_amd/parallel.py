@@ -121,6 +121,15 @@ class ShardedDGGConv:
     def backward(self, dZ, x_local, P):
         """-> dict of parameter gradients (summed over ranks) and, if x_grad, 'x' = d loss / d x_local."""
         kern, s = self.kern, self.saved
+        if hasattr(kern, "zero_pool"):                   # every zero-initialised accumulator of the backward from ONE filled buffer
+            ncols, h, d = s["xp"].shape[0], s["xp"].shape[1], s["X"].shape[1]
+            need = ncols * (h + 2) + 2 * sum(int(v.numel()) for v in P.values()) + (ncols * d if self.x_grad else 0) + 65536
+            with kern.zero_pool(s["xp"].device, need):
+                return self._backward(dZ, x_local, P)
+        return self._backward(dZ, x_local, P)
+
+    def _backward(self, dZ, x_local, P):
+        kern, s = self.kern, self.saved
         g = {}
         dY, g["Wc"], _ = kern.linear_bwd(s["Y"], P["Wc"], s["Z"], dZ, 2, 1, True, False)
         part = s.get("part")
