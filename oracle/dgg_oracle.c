@@ -9,7 +9,12 @@
  *     select_top_k   "k_times_edge_prob" / "k_only"   dgm.py:1402-1435
  *     edge_prob_net  edge-MLP modes          dgm.py:1628-1725 (u-v-A_uv, u-v-deg, u-v-deg-dist, edge_conv, A_uv)
  *     k_estimate_net "learn_normalized_degree" / "gcn-x-deg"   dgm.py:1492-1507 / 1528-1560
+ *     debug_step 0 / 1, select_top_k "edge_p-cdf": raw edge probabilities returned   dgm.py:1202-1209, 1240-1246, 1368-1401
+ *     dgg_hard as the straight-through value (ramp - soft) + soft                     dgm.py:343-346 (the
+ *                                             debug class's own return_hard_or_soft is NOT restated, parity unpinned for it)
  *   DGG.forward ("for ICLR", every edge kept) dgm.py:1758-1815 on a CSR-valued adjacency
+ *   DGG_Ablations.forward                    dgm.py:1904-1968 (noisy second sigmoid, learned or fixed k)
+ *   DGG_LearnableK_SDD.forward / DGG_StraightThrough.forward (dist_fn="metric", noise off)   dgm.py:259-351 / 140-182
  *   normalize_adj                           model.py:1205-1219
  *   GCNConv / GraphConvolution aggregation  model.py:580-599, 32-44
  * in the sparse "top-K per row" formulation that SURVEY.md section 0/8(a) shows to be bit-identical to the
