@@ -17,7 +17,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 32, LDP = BK + 1;
+constexpr int LIN_BK(int nacc) { return 32; }   // 64 for narrow tiles measured slower (224 VGPRs: two wavefronts per SIMD)
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == 1) return v > 0.0f ? v : __fmul_rn(0.01f, v);
@@ -28,10 +28,15 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 // y[N,out] = act(x[N,d] * W^T + b);  w_layout 0: W[out][d], 1: W[d][out].  NACC 32-column accumulators per wave
 // (tile width BN = 32*NACC is matched to `out`, so narrow layers do not pay for 128 columns of MFMAs)
 template <int NACC, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void linear_fwd_mfma(const float *__restrict__ x, int64_t N, int d,
+// narrow tiles: at most 128 registers, i.e. four workgroups per CU -- with three, the 782 workgroups of a 100k-row input no longer
+// fit the 768 slots of the chip in one round
+__global__ __launch_bounds__(64 * WAVES, NACC <= 2 ? 4 : 2) void linear_fwd_mfma(const float *__restrict__ x, int64_t N, int d,
                                                        const float *__restrict__ W, const float *__restrict__ b,
                                                        int out, int w_layout, int act, float *__restrict__ y) {
     constexpr int BN = 32 * NACC, BM = 32 * WAVES, NT = 64 * WAVES;   // small N: fewer rows per workgroup, more workgroups
+    // K-block: one block of MFMAs must last longer than an HBM round trip for the register prefetch of the next block to
+    // hide it (32 steps x 2 accumulators x 64 cycles = 1.7 us); the wide tile keeps 32 (static LDS limit)
+    constexpr int BK = LIN_BK(NACC), LDP = BK + 1, F4R = BK / 4;
     __shared__ float xs[BM * LDP];
     __shared__ float ws[BN * LDP];   // [j][k] (+pad)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(64 * WAVES) void linear_fwd_mfma(const float *__res
         if (vec4) {   // 16-byte loads: 8 lanes cover one 128-byte row segment
 #pragma unroll
             for (int q = 0; q < XQ; q++) {
-                const int e = tid + q * NT, r = e >> 3, c4 = (e & 7) * 4;
+                const int e = tid + q * NT, r = e / F4R, c4 = (e % F4R) * 4;
                 const int64_t gi = m0 + r;
                 const bool ok = gi < N && k0 + c4 < d;
                 const int64_t gic = gi < N ? gi : N - 1;
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(64 * WAVES) void linear_fwd_mfma(const float *__res
         } else {
 #pragma unroll
             for (int q = 0; q < XQ; q++) {
-                const int e = tid + q * NT, r = e >> 3, c4 = (e & 7) * 4;
+                const int e = tid + q * NT, r = e / F4R, c4 = (e % F4R) * 4;
                 const int64_t gi = m0 + r;
                 const int64_t gic = gi < N ? gi : N - 1;
                 float t[4];
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(64 * WAVES) void linear_fwd_mfma(const float *__res
         __syncthreads();                                         // previous block's LDS reads are done
 #pragma unroll
         for (int q = 0; q < XQ; q++) {
-            const int e = tid + q * NT, r = e >> 3, c4 = (e & 7) * 4;
+            const int e = tid + q * NT, r = e / F4R, c4 = (e % F4R) * 4;
             float *dst = xs + r * LDP + c4;
             dst[0] = (xm[q] & 1u) ? xr[q].x : 0.0f; dst[1] = (xm[q] & 2u) ? xr[q].y : 0.0f;
             dst[2] = (xm[q] & 4u) ? xr[q].z : 0.0f; dst[3] = (xm[q] & 8u) ? xr[q].w : 0.0f;
