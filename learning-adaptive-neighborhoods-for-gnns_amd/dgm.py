@@ -569,6 +569,11 @@ class DGG_LearnableK_SDD(nn.Module):
         self.register_buffer("hs_start", torch.tensor(hs_start))
         self.register_buffer("hs_end", torch.tensor(hs_end))
         self.k_net = _KMuProject(in_dim, latent_dim)
+        self._consts = (float(hs_start), float(interval))           # host copies of the ramp buffers (no device sync per forward)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        self._consts = (float(self.hs_start), float(self.interval))
 
     def forward(self, x, temp, noise=False):
         if noise:
@@ -579,8 +584,7 @@ class DGG_LearnableK_SDD(nn.Module):
         z = ops.LinearFn.apply(x2, self.input_project[0].weight, self.input_project[0].bias, ops.ACT_LEAKY, 0)
         xq = ops.FeatSoftmaxFn.apply(z).reshape(B, N, self.latent_dim)
         k = self.k_net(x2).reshape(B, N) + self.k_bias
-        adj = ops.DenseRowsFn.apply(xq, self.t, k, float(temp), ops.RAMP_SDD, 0, float(self.hs_start), float(self.interval),
-                                    bool(self.hard))
+        adj = ops.DenseRowsFn.apply(xq, self.t, k, float(temp), ops.RAMP_SDD, 0, self._consts[0], self._consts[1], bool(self.hard))
         return adj, k.unsqueeze(-1)
 
 
