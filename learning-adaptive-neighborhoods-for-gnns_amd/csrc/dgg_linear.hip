@@ -409,7 +409,11 @@ int launch_gemm_tn(const float *A, const float *B, int64_t N, int M1, int M2, fl
     else if (nb == 4) launch_gemm_tn_persist<1, 4>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, Yact, act, st);
     else if (nb == 2) launch_gemm_tn_persist<1, 2>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, Yact, act, st);
     else launch_gemm_tn_persist<1, 1>(A, B, N, M1, M2, M1p, M2p, slab, csl, g, Yact, act, st);
-    hipLaunchKernelGGL(gemm_tn_reduce, dim3((unsigned)((M1p * M2p + 255) / 256), (unsigned)(g < GT_SPLIT ? g : GT_SPLIT)), dim3(256), 0, st, slab, csl, g, M1,
+    // slabs per reducing workgroup: ~8 (each output then takes g/8 <= 32 float atomics); small outputs keep the 32-way split so
+    // that the launch still has a few hundred workgroups
+    int split = (M1p * M2p >= 16384) ? (g + 7) / 8 : g;
+    split = split < 1 ? 1 : (split > GT_SPLIT ? GT_SPLIT : split);
+    hipLaunchKernelGGL(gemm_tn_reduce, dim3((unsigned)((M1p * M2p + 255) / 256), (unsigned)split), dim3(256), 0, st, slab, csl, g, M1,
                        M2, M1p, M2p, C, c_layout, colsum);
     return dgg_check_launch("gemm_tn");
 }
