@@ -410,10 +410,22 @@ __global__ __launch_bounds__(256) void norm_da_cols(int64_t ncols, const int *__
     const int tid = threadIdx.x, b = blockIdx.x;
     if (tid < BS) ssum[tid] = 0.0f;
     __syncthreads();
-    const int e1 = bstart[b + 1];
-    for (int e = bstart[b] + tid; e < e1; e += 256) {
-        const float cf = coef[e];
-        if (cf != 0.0f) atomicAdd(&ssum[recs[e].y - b * BS], cf);
+    // records are ordered by destination: the 64 consecutive records of a wavefront form a few runs (~30 records per destination),
+    // summed by a segmented scan across the lanes; only the last lane of a run touches the LDS counter
+    const int e0 = bstart[b], e1 = bstart[b + 1], lane = tid & 63;
+    for (int eb = e0 + (tid - lane); eb < e1; eb += 256) {      // eb: first record of this wavefront's batch (wave-uniform)
+        const int e = eb + lane;
+        const bool have = e < e1;
+        const int dst = have ? recs[e].y : -1;
+        float v = have ? coef[e] : 0.0f;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float vo = __shfl_up(v, off, 64);
+            const int dd = __shfl_up(dst, off, 64);
+            if (lane >= off && dd == dst) v += vo;
+        }
+        const int dn = __shfl_down(dst, 1, 64);
+        if (have && (lane == 63 || dn != dst) && v != 0.0f) atomicAdd(&ssum[dst - b * BS], v);
     }
     __syncthreads();
     if (tid < BS) {
