@@ -295,27 +295,29 @@ __global__ __launch_bounds__(WPB * 64) void softk_bwd_kernel(const int32_t *__re
     const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     if (i >= N) return;
     float skp = 0.0f;
-    if (lane < K) {
-        int32_t j = idx[i * K + lane];
-        float dv = 0.0f;
-        if (j >= 0) {
-            float dw = dA[i * K + lane];
-            if (normalized) {
-                float rsi = rs[row0 + i];
-                float ai = inv_sqrt_c(rsi), aj = inv_sqrt_c(rs[j]);
-                float drs = -0.5f * da[row0 + i] * ai / rsi;
-                dw = dw * ai * aj + drs;
-            }
-            if (mode == 2) dv = dw;                   // no ramp: plain normalisation backward (dval = dw, dk = 0)
-            else {
-                float th = c_tanh((float)lane - k[i]);
-                float f = 1.0f - 0.5f * (1.0f + th);
-                float dfdk = 0.5f * (1.0f - th * th);
-                if (mode == 0) { dv = dw * f; skp = dw * val[i * K + lane] * dfdk; }
-                else skp = dw * dfdk;
-            }
+    {
+        // every load is unconditional (clamped lane / neighbour): predicated loads would be issued one dependent branch at a time
+        const int lc = lane < K ? lane : K - 1;
+        const int64_t e = i * K + lc;
+        const int32_t j = idx[e];
+        float dw = dA[e];
+        const float v = mode == 0 ? val[e] : 0.0f;          // kernel-uniform branch (val may be NULL in the other modes)
+        const bool live = lane < K && j >= 0;
+        if (normalized) {
+            const float rsi = rs[row0 + i];
+            const float ai = inv_sqrt_c(rsi), aj = inv_sqrt_c(rs[j >= 0 ? j : row0 + i]);
+            const float drs = -0.5f * da[row0 + i] * ai / rsi;
+            dw = dw * ai * aj + drs;
         }
-        dval[i * K + lane] = dv;
+        float dv = dw;                                // mode 2: no ramp, plain normalisation backward (dval = dw, dk = 0)
+        if (mode != 2) {
+            const float th = c_tanh((float)lane - k[i]);
+            const float f = 1.0f - 0.5f * (1.0f + th);
+            const float dfdk = 0.5f * (1.0f - th * th);
+            dv = mode == 0 ? dw * f : 0.0f;
+            skp = live ? (mode == 0 ? dw * v * dfdk : dw * dfdk) : 0.0f;
+        }
+        if (lane < K) dval[e] = live ? dv : 0.0f;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) skp += __shfl_xor(skp, off, 64);
