@@ -545,12 +545,15 @@ def main():
         return ev[0].elapsed_time(ev[1]) / reps * 1e-3
 
     t_pair = tk["allpairs_topk"]
-    t_edge = tk["edge_bwd"] if "edge_bwd" in tk else timed(
-        lambda: ops.edge_bwd(sv["xp"], sv["idx"], sv["val"], sv["dval"], r0, ops.T_DIST, True, sv["part"]))
+    if "edge_bwd" in tk:
+        t_edge = tk["edge_bwd"]
+    else:                                                         # shapes outside the destination-ordered path: atomic kernel, stand-alone
+        dv_ = ops.softk_bwd(sv["idx"], sv["val"], sv["k"], torch.ones_like(sv["w"]), mode=0, normalized=False)[0]
+        t_edge = timed(lambda: ops.edge_bwd(sv["xp"], sv["idx"], sv["val"], dv_, r0, ops.T_DIST, True, sv["part"]))
     # the fused SDDMM launch alone (its companion norm_da_cols is a separate 0.04 ms launch outside the probe)
     t_sddmm = tk["spmm_bwd"] if "spmm_bwd" in tk else timed(lambda: ops.spmm_bwd(sv["idx"], sv["ahat"], sv["X"], sv["Y"], False, True))
     t_spmm = tk["spmm_fwd"]
-    active = float((sv["dval"] != 0).sum().item())                # edges with a non-saturated ramp (~ k + 8.5 per row)
+    active = float((sv["w"] != 0).sum().item())                   # edges with a non-saturated ramp (~ k + 8.5 per row)
     traffic = load_traffic()
     kept = float((sv["idx"] >= 0).sum().item())                   # ranks kept by k_limit (~ k + 9.5 per row)
     kern = {
@@ -566,7 +569,7 @@ def main():
         # SpMM Y_i = sum_r A_ir X_j: per active edge one gathered row of X; per row idx, ahat and the output row
         "spmm_fwd": dict(ms=t_spmm * 1e3, bytes=active * 4 * d + rows_loc * (4 * d + 2 * 256)),
     }
-    kern["edge_bwd"]["composite"] = "edge_bwd_rows + edge_bwd_cols (one C-ABI call, two launches)"
+    kern["edge_bwd"]["composite"] = "edge_bwd_rows (with the ramp / normalisation backward inside) + edge_bwd_cols (one C-ABI call, two launches)"
     # the roofline object describes ONE launch (so that its duration can be checked against the rocprofv3 kernel
     # stats under profiles/): the longest single kernel of the step
     dom = max((n for n in kern if "composite" not in kern[n]), key=lambda n: kern[n]["ms"])

@@ -249,6 +249,12 @@ int dgg_ell_spmm_t_part(const float *a, const float *dY, int64_t rows, int K, in
 int dgg_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *dval, int K,
                       int64_t row0, float t, int perturb, const void *part_ws, int64_t ncols, float *coef_ws, float *dxp,
                       void *stream);
+/* dgg_softk_bwd (modes 0 / 1) and dgg_edge_bwd_part in one call: lane r of a row's wavefront owns entry r in both kernels, so
+ * d loss / d score is formed in registers inside the row kernel of the score backward.  dval (nullable) [rows,K] receives it
+ * as well; dk [rows] is written; the other arguments as in the two separate calls */
+int dgg_softk_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *k, const float *rs,
+                            const float *dA, const float *da, int K, int64_t row0, float t, int perturb, int mode, int normalized,
+                            const void *part_ws, int64_t ncols, float *coef_ws, float *dval, float *dk, float *dxp, void *stream);
 int dgg_norm_bwd_da_part(const int32_t *idx, const float *w, const float *rs, const float *dA, int64_t rows, int K, int64_t row0,
                          const void *part_ws, int64_t ncols, float *coef_ws, float *da, void *stream);
 /* SDDMM of dgg_ell_spmm_bwd (dA only) fused with the row side of dgg_norm_bwd_da_part: one pass over the row instead of

@@ -169,11 +169,18 @@ __global__ __launch_bounds__(1024) void part_scan(int *__restrict__ bstart, int 
 
 // ---- score backward, row side: coefficient dd_ir for every entry, dxp_i (own row: plain store) -----------------------
 // H/4 lanes per neighbour (16-byte loads), 256/H neighbours per wave-instruction
-template <int H>
+// Arguments of the ramp + normalisation backward (dgg_softk_bwd) when it is evaluated inside edge_bwd_rows (FUSE): lane r of a
+// row's wavefront owns entry r in both kernels, so d loss / d score is formed in registers instead of a [rows,K] round trip.
+struct SoftkArgs {
+    const float *k, *rs, *dA, *da;
+    int mode, normalized;
+    float *dval_out, *dk;                                        // dval_out nullable (diagnostics)
+};
+template <int H, bool FUSE>
 __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ xp, int64_t rows, const int32_t *__restrict__ idx,
                                                      const float *__restrict__ val, const float *__restrict__ dval, int K,
                                                      int64_t row0, float t, int perturb, const int *__restrict__ slotmap,
-                                                     float *__restrict__ coef, float *__restrict__ dxp) {
+                                                     float *__restrict__ coef, float *__restrict__ dxp, SoftkArgs sk) {
     constexpr int LPR = H / 4;                                   // lanes per neighbour
     constexpr int NPI = 64 / LPR;                                // neighbours per wave-instruction
     const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
@@ -181,8 +188,30 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
     if (i >= rows) return;
     const int64_t gi = row0 + i;
     const int32_t jl = lane < K ? idx[i * K + lane] : -1;
-    const float gl = lane < K ? dval[i * K + lane] : 0.0f;
     const float vl = lane < K ? val[i * K + lane] : 0.0f;
+    float gl;
+    if (FUSE) {                                                  // same arithmetic as softk_bwd_kernel (dgg_ell.hip), modes 0 / 1
+        const int lc = lane < K ? lane : K - 1;
+        float dw = sk.dA[i * K + lc];
+        const bool live = lane < K && jl >= 0;
+        if (sk.normalized) {
+            const float rsi = sk.rs[gi];
+            const float ai = __fdiv_rn(1.0f, c_sqrt(rsi)), aj = __fdiv_rn(1.0f, c_sqrt(sk.rs[jl >= 0 ? jl : gi]));
+            const float drs = -0.5f * sk.da[gi] * ai / rsi;
+            dw = dw * ai * aj + drs;
+        }
+        const float th = c_tanh((float)lane - sk.k[i]);
+        const float f = 1.0f - 0.5f * (1.0f + th);
+        const float dfdk = 0.5f * (1.0f - th * th);
+        gl = (live && sk.mode == 0) ? dw * f : 0.0f;
+        float skp = live ? (sk.mode == 0 ? dw * vl * dfdk : dw * dfdk) : 0.0f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) skp += __shfl_xor(skp, off, 64);
+        if (lane == 0) sk.dk[i] = skp;
+        if (sk.dval_out && lane < K) sk.dval_out[i * K + lane] = gl;
+    } else {
+        gl = lane < K ? dval[i * K + lane] : 0.0f;
+    }
     const float4 xi = *reinterpret_cast<const float4 *>(xp + gi * H + 4 * c4);
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float mycoef = 0.0f;
@@ -480,9 +509,9 @@ int dgg_part_build(const int32_t *idx, const float *w, int64_t rows, int K, int6
 
 // score backward through the partition: same result as dgg_edge_bwd (up to summation order), no global float atomics.
 // coef_ws: rows*K + ncols floats.  dxp [ncols,h] zeroed by the caller.
-int dgg_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *dval, int K,
-                      int64_t row0, float t, int perturb, const void *part_ws, int64_t ncols, float *coef_ws, float *dxp,
-                      void *stream) {
+static int edge_bwd_part_impl(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *dval, int K,
+                              int64_t row0, float t, int perturb, const void *part_ws, int64_t ncols, float *coef_ws, float *dxp,
+                              const SoftkArgs *sk, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0) return 0;
     const int64_t nb = nbuckets(ncols);
@@ -491,7 +520,8 @@ int dgg_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, 
     // upper bound of the chunk count (the live count bstart[nb] is read on the device: no host sync)
     const int64_t ngroups = (rows * K + CH - 1) / CH;
 #define DGG_EDGE_PART(HH)                                                                                                  \
-    hipLaunchKernelGGL(edge_bwd_rows<HH>, dim3(gr), dim3(256), 0, st, xp, rows, idx, val, dval, K, row0, t, perturb, p.slot, coef_ws, dxp); \
+    if (sk) hipLaunchKernelGGL((edge_bwd_rows<HH, true>), dim3(gr), dim3(256), 0, st, xp, rows, idx, val, dval, K, row0, t, perturb, p.slot, coef_ws, dxp, *sk); \
+    else hipLaunchKernelGGL((edge_bwd_rows<HH, false>), dim3(gr), dim3(256), 0, st, xp, rows, idx, val, dval, K, row0, t, perturb, p.slot, coef_ws, dxp, SoftkArgs{}); \
     hipLaunchKernelGGL(edge_bwd_cols<HH>, dim3((unsigned)((ngroups * (HH / 4) + 255) / 256)), dim3(256), 0, st, xp, p.bstart,   \
                        (int)nb, p.recs, coef_ws, row0, dxp)
     switch (h) {
@@ -503,6 +533,23 @@ int dgg_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, 
     }
 #undef DGG_EDGE_PART
     return dgg_check_launch("edge_bwd_part");
+}
+
+int dgg_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *dval, int K,
+                      int64_t row0, float t, int perturb, const void *part_ws, int64_t ncols, float *coef_ws, float *dxp,
+                      void *stream) {
+    return edge_bwd_part_impl(xp, rows, h, idx, val, dval, K, row0, t, perturb, part_ws, ncols, coef_ws, dxp, nullptr, stream);
+}
+
+// dgg_softk_bwd (modes 0 / 1) + dgg_edge_bwd_part in one call: d loss / d score is formed inside the row kernel of the score
+// backward.  dval (nullable) receives it as well; dk [rows] is written.
+int dgg_softk_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *k, const float *rs,
+                            const float *dA, const float *da, int K, int64_t row0, float t, int perturb, int mode, int normalized,
+                            const void *part_ws, int64_t ncols, float *coef_ws, float *dval, float *dk, float *dxp, void *stream) {
+    if (mode != 0 && mode != 1) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_part: mode must be 0 (k_times) or 1 (k_only)");
+    if (!k || !dA || !dk || (normalized && (!rs || !da))) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_part: missing operand");
+    const SoftkArgs sk{k, rs, dA, da, mode, normalized, dval, dk};
+    return edge_bwd_part_impl(xp, rows, h, idx, val, nullptr, K, row0, t, perturb, part_ws, ncols, coef_ws, dxp, &sk, stream);
 }
 
 // dX [ncols,F] += A^T dY for an ELL block (a [rows,K] on the pattern the partition was built from); F a multiple of 64,

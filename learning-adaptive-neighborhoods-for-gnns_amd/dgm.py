@@ -106,8 +106,13 @@ class _DGGSoftAdjFn(torch.autograd.Function):
     def backward(ctx, dw, *_):
         x, We, xp, k, idx, val = ctx.saved_tensors
         cfg = ctx.cfg
-        dval, dk = ops.softk_bwd(idx, val, k, dw.contiguous(), mode=cfg["mode"], normalized=False)
-        dxp = ops.edge_bwd(xp, idx, val, dval, t=cfg["t"], perturb=cfg["noise_mode"] != ops.NOISE_NONE, part=cfg.get("part"))
+        fused = ops.softk_edge_bwd(xp, idx, val, k, dw.contiguous(), t=cfg["t"], perturb=cfg["noise_mode"] != ops.NOISE_NONE,
+                                   mode=cfg["mode"], normalized=False, part=cfg.get("part"))
+        if fused is not None:
+            dxp, dk, _ = fused
+        else:
+            dval, dk = ops.softk_bwd(idx, val, k, dw.contiguous(), mode=cfg["mode"], normalized=False)
+            dxp = ops.edge_bwd(xp, idx, val, dval, t=cfg["t"], perturb=cfg["noise_mode"] != ops.NOISE_NONE, part=cfg.get("part"))
         dx, dWe, dbe = ops.linear_bwd(x, We, xp, dxp, ops.ACT_LEAKY, need_dx=ctx.needs_input_grad[0])
         return dx, dk, dWe, dbe, None
 

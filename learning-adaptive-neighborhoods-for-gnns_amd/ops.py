@@ -552,6 +552,28 @@ def softk_bwd(idx, val, k, dA, rs=None, da=None, row0=0, mode=MODE_K_TIMES_EDGE_
     return dval, dk
 
 
+def softk_edge_bwd(xp, idx, val, k, dA, rs=None, da=None, row0=0, t=T_DIST, perturb=False, mode=MODE_K_TIMES_EDGE_PROB, normalized=False,
+                   part=None, want_dval=False):
+    """softk_bwd + edge_bwd in one call when the destination-ordered path applies (d loss / d score never leaves the registers
+    of the row kernel) -> dxp [Nglobal,h], dk [N], dval [N,K] or None; None when it does not apply (then: the two calls)."""
+    xp = _chk(xp)
+    Ng, h = xp.shape
+    N, K = idx.shape
+    if part is None or h not in (16, 32, 64, 128) or mode not in (MODE_K_TIMES_EDGE_PROB, MODE_K_ONLY):
+        return None
+    dxp = _zeros(tuple(xp.shape), xp.device)
+    coef = torch.empty(N * K + Ng, device=xp.device, dtype=torch.float32)
+    dk = torch.empty((N,), device=xp.device, dtype=torch.float32)
+    dval = torch.empty((N, K), device=xp.device, dtype=torch.float32) if want_dval else None
+    val, k, dA = _chk(val), _chk(k), _chk(dA)
+    pe = _probe_begin()
+    _lib.check(_lib.lib().dgg_softk_edge_bwd_part(_ptr(xp), N, h, _ptr(idx), _ptr(val), _ptr(k), _ptr(rs), _ptr(dA), _ptr(da), K, row0, t,
+                                                  int(perturb), mode, int(normalized), _ptr(part), Ng, _ptr(coef), _ptr(dval), _ptr(dk),
+                                                  _ptr(dxp), _stream()), "softk_edge_bwd_part")
+    _probe_end("edge_bwd", pe)
+    return dxp, dk, dval
+
+
 def edge_bwd(xp, idx, val, dval, row0=0, t=T_DIST, perturb=False, part=None):
     xp = _chk(xp)
     Ng, h = xp.shape

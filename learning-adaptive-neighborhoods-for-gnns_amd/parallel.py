@@ -147,10 +147,14 @@ class ShardedDGGConv:
                 kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0)
         if self.coll:
             dist.all_reduce(da, group=self.group)
-        dval, dk = kern.softk_bwd(s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.mode, True)
-        s["dval"] = dval                                 # kept for diagnostics (bench.py times edge_bwd alone)
-        dxp = kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0, part) \
-            if part is not None else kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0)
+        fused = kern.softk_edge_bwd(s["xp"], s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.t, self.noise_mode != 0,
+                                    self.mode, True, part) if (part is not None and hasattr(kern, "softk_edge_bwd")) else None
+        if fused is not None:                            # ramp + normalisation backward inside the row kernel of the score backward
+            dxp, dk, _ = fused
+        else:
+            dval, dk = kern.softk_bwd(s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.mode, True)
+            dxp = kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0, part) \
+                if part is not None else kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0)
         dX1, g["We"], g["be"] = kern.linear_bwd(s["X"], P["We"], s["xp"], dxp, 1, 0, self.x_grad, True)
         dxk, g["W1"], g["b1"], g["Wmu"], g["bmu"], dWp, g["bp"] = kern.knet_x_bwd(
             s["xk"].shape[1], s["mu_sd"], P["W1"], P["Wmu"], P["bmu"], P["Wp"].reshape(-1), s["z"], s["u"], s["feat"], dk)

@@ -1378,3 +1378,29 @@ def test_degenerate_inputs_through_the_modules(dev):
         out = out[0] if isinstance(out, tuple) else out
         out.sum().backward()
         assert out.shape == (3, 3) and bool(torch.isfinite(out).all())
+
+
+@pytest.mark.parametrize("h,mode,normalized", [(64, 0, True), (32, 1, False), (128, 0, False), (16, 0, True)])
+def test_softk_edge_bwd_fused_matches_the_two_calls(dev, h, mode, normalized):
+    """dgg_softk_edge_bwd_part == dgg_softk_bwd followed by dgg_edge_bwd_part: d loss / d score and dk bit-for-bit, dxp up to
+    summation order; row-sharded use (row0 > 0, global columns) included"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(h + mode)
+    N = 900
+    xp = T(rng.standard_normal((N, h)).astype(np.float32), dev)
+    kk = T((3 + 30 * rng.random(N)).astype(np.float32), dev)
+    idx, val = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_HASH, seed=(4, 2), k_limit=kk)
+    w, rs = ops.softk_fwd(idx, val, kk, mode)
+    dA = T(rng.standard_normal((N, K)).astype(np.float32), dev)
+    da = T(rng.standard_normal(N).astype(np.float32), dev)
+    for lo, hi in [(0, N), (311, 700)]:
+        sl = slice(lo, hi)
+        part = ops.part_build(idx[sl].contiguous(), w[sl].contiguous(), N)
+        a = (idx[sl].contiguous(), val[sl].contiguous(), kk[sl].contiguous(), dA[sl].contiguous())
+        dval, dk = ops.softk_bwd(a[0], a[1], a[2], a[3], rs if normalized else None, da if normalized else None, lo, mode, normalized)
+        dxp = ops.edge_bwd(xp, a[0], a[1], dval, lo, ops.T_DIST, True, part)
+        got = ops.softk_edge_bwd(xp, a[0], a[1], a[2], a[3], rs if normalized else None, da if normalized else None, lo, ops.T_DIST, True,
+                                 mode, normalized, part, want_dval=True)
+        assert got is not None
+        assert torch.equal(got[2], dval) and torch.equal(got[1], dk)
+        np.testing.assert_allclose(Nn(got[0]), Nn(dxp), rtol=1e-5, atol=1e-5 * max(float(dxp.abs().max()), 1e-9))
