@@ -215,15 +215,16 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
     const float4 xi = *reinterpret_cast<const float4 *>(xp + gi * H + 4 * c4);
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float mycoef = 0.0f;
-    // Two batches of NPI neighbours per iteration, both gathers issued UNCONDITIONALLY (inactive slots re-read the own row and
+    constexpr int NBT = 2;                                       // batches (gathers in flight per lane) per iteration; 4 measured the same
+    // NBT batches of NPI neighbours per iteration, all gathers issued UNCONDITIONALLY (inactive slots re-read the own row and
     // are masked arithmetically) before either is consumed: a predicated gather is a branch + s_waitcnt vmcnt(0), i.e. one
     // gather in flight per wavefront.
-    for (int r0 = 0; r0 < K; r0 += 2 * NPI) {
-        int32_t j[2];
-        float g[2], v[2];
-        bool act[2];
+    for (int r0 = 0; r0 < K; r0 += NBT * NPI) {
+        int32_t j[NBT];
+        float g[NBT], v[NBT];
+        bool act[NBT];
 #pragma unroll
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < NBT; b++) {
             const int r = r0 + b * NPI + slot;
             const int rr = r < 64 ? r : 63;
             j[b] = __shfl(jl, rr, 64);
@@ -231,12 +232,15 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
             v[b] = __shfl(vl, rr, 64);
             act[b] = r < K && j[b] >= 0 && g[b] != 0.0f;
         }
-        if (__ballot(act[0] || act[1]) == 0ull) continue;        // wave-uniform
-        float4 xj[2];
+        bool any = false;
 #pragma unroll
-        for (int b = 0; b < 2; b++) xj[b] = *reinterpret_cast<const float4 *>(xp + (act[b] ? (int64_t)j[b] : gi) * H + 4 * c4);
+        for (int b = 0; b < NBT; b++) any = any || act[b];
+        if (__ballot(any) == 0ull) continue;        // wave-uniform
+        float4 xj[NBT];
 #pragma unroll
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < NBT; b++) xj[b] = *reinterpret_cast<const float4 *>(xp + (act[b] ? (int64_t)j[b] : gi) * H + 4 * c4);
+#pragma unroll
+        for (int b = 0; b < NBT; b++) {
             const float4 d = make_float4(xi.x - xj[b].x, xi.y - xj[b].y, xi.z - xj[b].z, xi.w - xj[b].w);   // 0 when inactive
             float d2 = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
             if (LPR > 16) d2 += __uint_as_float(xor_shfl<16>(__float_as_uint(d2), lane));
