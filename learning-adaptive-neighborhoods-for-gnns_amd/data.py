@@ -19,10 +19,32 @@ def _pkl(path):
         return pickle.load(f, encoding="latin1")
 
 
-def load_planetoid(name, data_dir):
+def _cache_key(paths):
+    """cache validity: size and mtime of every source file"""
+    return "|".join(f"{os.path.basename(p_)}:{os.path.getsize(p_)}:{int(os.path.getmtime(p_))}" for p_ in paths)
+
+
+def load_planetoid(name, data_dir, cache_dir=None):
     """-> dict(x float32 [N,d] row-normalised (dense), rows/cols int32 [E] (symmetric, no self loops, row-major),
-    y int64 [N], train_idx / val_idx / test_idx int64)"""
+    y int64 [N], train_idx / val_idx / test_idx int64).
+    cache_dir: the parsed arrays are kept there as `<name>.planetoid.npz` (the pickled scipy / networkx-style sources take
+    seconds to parse for Pubmed) and reused while size and mtime of every source file are unchanged."""
     name = name.lower()
+    if cache_dir is not None:
+        srcs = [os.path.join(data_dir, f"ind.{name}.{s_}") for s_ in ("x", "y", "tx", "ty", "allx", "ally", "graph", "test.index")]
+        key, cfile = _cache_key(srcs), os.path.join(cache_dir, f"{name}.planetoid.npz")
+        if os.path.exists(cfile):
+            with np.load(cfile, allow_pickle=False) as z:
+                if str(z["cache_key"]) == key:
+                    out = {k_: z[k_] for k_ in z.files if k_ != "cache_key"}
+                    out["num_classes"] = int(out["num_classes"])
+                    return out
+        out = load_planetoid(name, data_dir)
+        os.makedirs(cache_dir, exist_ok=True)
+        tmp = cfile + f".tmp{os.getpid()}.npz"
+        np.savez(tmp, cache_key=np.array(key), **out)
+        os.replace(tmp, cfile)
+        return out
     p = lambda s: os.path.join(data_dir, f"ind.{name}.{s}")  # noqa: E731
     x, y, tx, ty, allx, ally, graph = (_pkl(p(s)) for s in ("x", "y", "tx", "ty", "allx", "ally", "graph"))
     test_idx = np.array([int(line.strip()) for line in open(p("test.index"))], dtype=np.int64)

@@ -59,6 +59,7 @@ def build_parser():
                    choices=["u-v-dist", "u-v-A_uv", "u-v-deg", "edge_conv", "A_uv", "u-v-deg-dist"])
     p.add_argument("--dgg_mode_k_net", default="x", choices=["pass", "learn_normalized_degree", "input_deg", "gcn-x-deg", "x"])
     p.add_argument("--dgg_mode_k_select", default="k_times_edge_prob", choices=["edge_p-cdf", "k_only", "k_times_edge_prob"])
+    p.add_argument("--cache_dir", default=None, help="keep the parsed data set here (npz) and reuse it while the source files are unchanged")
     p.add_argument("--checkpoint", default=None, help="write the best-validation checkpoint here (reference save_checkpoint layout)")
     p.add_argument("--resume", default=None, help="load model_state_dict from a checkpoint before training")
     return p
@@ -105,7 +106,7 @@ def main(argv=None):
     torch.manual_seed(args.seed)
     torch.cuda.manual_seed(args.seed)
     device = torch.device("cuda")
-    d = D.load_planetoid(args.data, args.data_dir)
+    d = D.load_planetoid(args.data, args.data_dir, cache_dir=args.cache_dir)
     x = torch.from_numpy(d["x"]).to(device)
     y = torch.from_numpy(d["y"]).to(device)
     idx = {k: torch.from_numpy(d[k]).to(device) for k in ("train_idx", "val_idx", "test_idx")}
