@@ -211,6 +211,14 @@ int dgg_ell_normalize_fwd(const int32_t *idx, const float *w, const float *rs, i
 /* Y[N,F] = A X   (torch.mm(adj, x) model.py:594, 67; torch.spmm model.py:34); X has GLOBAL rows */
 int dgg_ell_spmm_fwd(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, float *Y,
                      void *stream);
+/* Y = act(A X) with the activation fused into the aggregation: act 0 none, 2 ReLU.  This is GCNConv evaluated as
+ * relu(A (x W)) instead of relu((A x) W) (model.py:594-598; equal up to fp32 reassociation): when out_features <
+ * in_features the F = out_features wide projected rows are gathered instead of the in_features wide inputs.  Rows of
+ * 16 / 32 / 64 features are gathered four / two / ... per wave-instruction (F/4 lanes each, 16-byte loads). */
+int dgg_ell_spmm_act_fwd(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, int act, float *Y,
+                         void *stream);
+/* dp = dy * act'(y) elementwise (cotangent of a fused activation epilogue; act as in dgg_linear_fwd) */
+int dgg_act_bwd(const float *y, const float *dy, int64_t n, int act, float *dp, void *stream);
 /* dA_ir = <dY_i, X_j> (overwritten); dX_j += ahat_ir dY_i (nullable; accumulated with fp32 atomics).
  * skip_zero != 0: entries whose value is exactly 0 get dA = 0 without the dot product (valid when the adjacency
  * comes from dgg_softk_fwd: a zero weight is a saturated ramp, whose gradient is zero as well) */
@@ -252,9 +260,19 @@ int dgg_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, 
 /* dgg_softk_bwd (modes 0 / 1) and dgg_edge_bwd_part in one call: lane r of a row's wavefront owns entry r in both kernels, so
  * d loss / d score is formed in registers inside the row kernel of the score backward.  dval (nullable) [rows,K] receives it
  * as well; dk [rows] is written; the other arguments as in the two separate calls */
+/* ahat_rows (nullable, [rows,K]; normalized only): `da` then holds the NEIGHBOUR-side sums alone (as written by
+ * dgg_ell_conv_bwd_part) and the row side, sqrt(rs_i) sum_r dA_ir ahat_ir, is added inside the kernel */
 int dgg_softk_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *k, const float *rs,
-                            const float *dA, const float *da, int K, int64_t row0, float t, int perturb, int mode, int normalized,
-                            const void *part_ws, int64_t ncols, float *coef_ws, float *dval, float *dk, float *dxp, void *stream);
+                            const float *dA, const float *da, const float *ahat_rows, int K, int64_t row0, float t, int perturb,
+                            int mode, int normalized, const void *part_ws, int64_t ncols, float *coef_ws, float *dval, float *dk,
+                            float *dxp, void *stream);
+/* Backward of Z = A H (H [ncols,F] = projected features, G [rows,F] = d loss / d (A H)) through the partition, ONE gathered
+ * row of G per active entry for all three column-walking terms: dA_ir = <G_i, H_j> (autograd of torch.mm(adj, x) wrt adj,
+ * model.py:594), dH_j += ahat_ir G_i (wrt x) and da_j += dA_ir w_ir a_i (neighbour side of the normalize_adj backward,
+ * model.py:1215-1218; nullable, needs rs).  dA [rows,K] is written for the ACTIVE entries only (caller zeroes), dH [ncols,F]
+ * and da [ncols] are accumulated into (caller zeroes).  F in {16,32,64,128}, 16-byte aligned rows. */
+int dgg_ell_conv_bwd_part(const float *G, const float *H, const float *ahat, int64_t rows, int K, int F, const void *part_ws,
+                          int64_t ncols, const float *rs, float *dA, float *dH, float *da, void *stream);
 int dgg_norm_bwd_da_part(const int32_t *idx, const float *w, const float *rs, const float *dA, int64_t rows, int K, int64_t row0,
                          const void *part_ws, int64_t ncols, float *coef_ws, float *da, void *stream);
 /* SDDMM of dgg_ell_spmm_bwd (dA only) fused with the row side of dgg_norm_bwd_da_part: one pass over the row instead of

@@ -61,8 +61,11 @@ PROTOTYPES = {
     "dgg_part_ws_bytes": [_i64, _i32, _i64],
     "dgg_part_build": [_vp, _vp, _i64, _i32, _i64, _vp, _vp],
     "dgg_edge_bwd_part": [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _i64, _vp, _vp, _vp],
-    "dgg_softk_edge_bwd_part": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp,
-                                _vp, _vp],
+    "dgg_softk_edge_bwd_part": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _i32, _i32, _vp, _i64, _vp, _vp,
+                                _vp, _vp, _vp],
+    "dgg_ell_conv_bwd_part": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
+    "dgg_ell_spmm_act_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp],
+    "dgg_act_bwd": [_vp, _vp, _i64, _i32, _vp, _vp],
     "dgg_norm_bwd_da_part": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp],
     "dgg_gcnii_epilogue_fwd": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp],
     "dgg_gcnii_epilogue_bwd": [_vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp],

@@ -65,10 +65,10 @@ class EllAdjacency:
         ahat = ops.EllNormalizeFn.apply(self._values, self.idx, rs, self.part)
         return EllAdjacency(self.idx, ahat, self.n_cols, rs=None, k=self.k, score=self.score, normalized=True, part=self.part)
 
-    def matmul(self, X):
-        """A @ X (torch.mm(adj, x), model.py:594)."""
+    def matmul(self, X, act=ops.ACT_NONE):
+        """act(A @ X) (torch.mm(adj, x), model.py:594; act = ReLU fuses GCNConv's activation into the aggregation)."""
         # weights produced by the DGG ramp: an exact zero is a saturated ramp whose gradient vanishes too
-        return ops.EllSpmmFn.apply(self._values, self.idx, X, self.k is not None, self.part)
+        return ops.EllSpmmFn.apply(self._values, self.idx, X, self.k is not None, self.part, act)
 
     __matmul__ = matmul
 

@@ -96,6 +96,63 @@ __global__ __launch_bounds__(WPB * 64) void spmm_fwd_kernel(const int32_t *__res
     }
 }
 
+// Same aggregation for NARROW feature rows (F = 16, 32, 64: the projected features H = X W of a GCNConv whose output is
+// narrower than its input, aggregated after the projection).  F/4 lanes per gathered row (16-byte loads), 256/F rows per
+// wave-instruction and NBT such batches in flight, so that one load instruction still moves 1 KiB; the 256/F partial sums
+// of a feature are combined by an xor butterfly at the end (order: entry r goes to slot r mod (256/F), slots summed pairwise).
+// ACT 2 applies the ReLU of GCNConv (model.py:598) in the epilogue.
+template <int F>
+__global__ __launch_bounds__(WPB * 64) void spmm_fwd_narrow(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
+                                                           const float *__restrict__ X, int64_t N, int K, int act,
+                                                           float *__restrict__ Y) {
+    constexpr int LPR = F / 4, NPI = 64 / LPR, NBT = 4;
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
+    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int32_t jl = lane < K ? idx[i * K + lane] : -1;
+    const float al = lane < K ? ahat[i * K + lane] : 0.0f;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int r0 = 0; r0 < K; r0 += NBT * NPI) {
+        int32_t j[NBT];
+        float a[NBT];
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < NBT; b++) {
+            const int r = r0 + b * NPI + slot;
+            const int rr = r < 64 ? r : 63;
+            j[b] = __shfl(jl, rr, 64);
+            a[b] = __shfl(al, rr, 64);
+            if (r >= K || j[b] < 0) a[b] = 0.0f;
+            any = any || a[b] != 0.0f;
+        }
+        if (__ballot(any) == 0ull) continue;                     // wave-uniform
+        float4 xv[NBT];
+#pragma unroll
+        for (int b = 0; b < NBT; b++)                            // unconditional gathers (inactive: row 0, weight 0)
+            xv[b] = *reinterpret_cast<const float4 *>(X + (int64_t)(a[b] != 0.0f ? j[b] : 0) * F + 4 * c4);
+#pragma unroll
+        for (int b = 0; b < NBT; b++) {
+            acc.x = fmaf(a[b], xv[b].x, acc.x); acc.y = fmaf(a[b], xv[b].y, acc.y);
+            acc.z = fmaf(a[b], xv[b].z, acc.z); acc.w = fmaf(a[b], xv[b].w, acc.w);
+        }
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
+        acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+    }
+    if (slot == 0) {
+        if (act == 2) { acc.x = fmaxf(acc.x, 0.0f); acc.y = fmaxf(acc.y, 0.0f); acc.z = fmaxf(acc.z, 0.0f); acc.w = fmaxf(acc.w, 0.0f); }
+        *reinterpret_cast<float4 *>(Y + i * F + 4 * c4) = acc;
+    }
+}
+
+// y = act(y) in place (wide rows, where the aggregation kernels have no fused epilogue)
+__global__ void act_inplace_kernel(float *__restrict__ y, int64_t n, int act) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n && act == 2) y[e] = fmaxf(y[e], 0.0f);
+}
+
 // dA_ir = <dY_i, X_j>;  dX_j += ahat_ir * dY_i (fp32 atomics, optional).  One wavefront per row, features on lanes.
 __global__ __launch_bounds__(WPB * 64) void spmm_bwd_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
                                                            const float *__restrict__ X, const float *__restrict__ dY,
@@ -457,6 +514,9 @@ inline unsigned rows_grid(int64_t N) { return (unsigned)((N + WPB - 1) / WPB); }
 
 extern "C" {
 
+int dgg_ell_spmm_act_fwd(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, int act, float *Y,
+                         void *stream);
+
 int dgg_softk_fwd(const int32_t *idx, const float *val, const float *k, int64_t N, int K, int mode, float *w, float *rs,
                   void *stream) {
     if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
@@ -478,10 +538,23 @@ int dgg_ell_normalize_fwd(const int32_t *idx, const float *w, const float *rs, i
 
 int dgg_ell_spmm_fwd(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, float *Y,
                      void *stream) {
+    return dgg_ell_spmm_act_fwd(idx, ahat, X, N, K, F, 0, Y, stream);
+}
+
+// Y = act(A X), act 0 (none) or 2 (ReLU: GCNConv's activation when the aggregation runs AFTER the projection)
+int dgg_ell_spmm_act_fwd(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, int act, float *Y,
+                         void *stream) {
     if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    if (act != 0 && act != 2) return dgg_set_error(DGG_ERR_ARG, "ell_spmm_act_fwd: act must be 0 (none) or 2 (ReLU)");
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    bool al16 = ((uintptr_t)X % 16 == 0), al8 = ((uintptr_t)X % 8 == 0);
+    bool al16 = ((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0), al8 = ((uintptr_t)X % 8 == 0);
+    if (al16 && (F == 16 || F == 32 || F == 64)) {
+        if (F == 64) hipLaunchKernelGGL(spmm_fwd_narrow<64>, dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, N, K, act, Y);
+        else if (F == 32) hipLaunchKernelGGL(spmm_fwd_narrow<32>, dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, N, K, act, Y);
+        else hipLaunchKernelGGL(spmm_fwd_narrow<16>, dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, N, K, act, Y);
+        return dgg_check_launch("ell_spmm_fwd");
+    }
     if (F % 4 == 0 && F >= 256 && al16) {
         dim3 grid(rows_grid(N), (unsigned)((F + 255) / 256));
         hipLaunchKernelGGL(spmm_fwd_kernel<4>, grid, dim3(WPB * 64), 0, st, idx, ahat, X, N, K, F, Y);
@@ -491,6 +564,10 @@ int dgg_ell_spmm_fwd(const int32_t *idx, const float *ahat, const float *X, int6
     } else {
         dim3 grid(rows_grid(N), (unsigned)((F + 63) / 64));
         hipLaunchKernelGGL(spmm_fwd_kernel<1>, grid, dim3(WPB * 64), 0, st, idx, ahat, X, N, K, F, Y);
+    }
+    if (act != 0) {
+        const int64_t n = N * F;
+        hipLaunchKernelGGL(act_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Y, n, act);
     }
     return dgg_check_launch("ell_spmm_fwd");
 }

@@ -459,6 +459,14 @@ int dgg_linear_bwd(const float *x, int64_t N, int d, const float *W, int out, in
     return dgg_check_launch("linear_bwd");
 }
 
+// dp = dy * act'(y), elementwise (the cotangent of a fused activation epilogue, e.g. the ReLU of dgg_ell_spmm_act_fwd)
+int dgg_act_bwd(const float *y, const float *dy, int64_t n, int act, float *dp, void *stream) {
+    if (n == 0) return 0;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, dy, n, act, dp);
+    return dgg_check_launch("act_bwd");
+}
+
 // C[M1,M2] += A[N,M1]^T B[N,M2]  (c_layout 1: C stored [M2][M1]); colsum (nullable, [M1]) += column sums of A;
 // ws: dgg_gemm_tn_ws_floats(N, M1, M2) floats
 int dgg_gemm_tn_acc(const float *A, const float *B, int64_t N, int M1, int M2, float *C, int c_layout, float *colsum,

@@ -175,6 +175,9 @@ struct SoftkArgs {
     const float *k, *rs, *dA, *da;
     int mode, normalized;
     float *dval_out, *dk;                                        // dval_out nullable (diagnostics)
+    // ahat_rows != NULL: `da` holds only the NEIGHBOUR-side sums (conv_bwd_cols); the row side
+    // da_i += sum_r dA_ir w_ir a_j = sqrt(rs_i) sum_r dA_ir ahat_ir is added here, in registers
+    const float *ahat_rows;
 };
 template <int H, bool FUSE>
 __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ xp, int64_t rows, const int32_t *__restrict__ idx,
@@ -197,7 +200,13 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
         if (sk.normalized) {
             const float rsi = sk.rs[gi];
             const float ai = __fdiv_rn(1.0f, c_sqrt(rsi)), aj = __fdiv_rn(1.0f, c_sqrt(sk.rs[jl >= 0 ? jl : gi]));
-            const float drs = -0.5f * sk.da[gi] * ai / rsi;
+            float dai = sk.da[gi];
+            if (sk.ahat_rows) {
+                float rp = lane < K ? dw * sk.ahat_rows[i * K + lane] : 0.0f;
+                rp = wave_sum_dpp(rp, lane);
+                dai += rp * sqrtf(rsi);
+            }
+            const float drs = -0.5f * dai * ai / rsi;
             dw = dw * ai * aj + drs;
         }
         const float th = c_tanh((float)lane - sk.k[i]);
@@ -412,6 +421,96 @@ __global__ __launch_bounds__(256) void spmm_t_cols(const float *__restrict__ dY,
     flush();
 }
 
+// ---- graph-conv backward on PROJECTED features through the partition -------------------------------------------------------
+// Z = act(A H) with H = X W aggregated AFTER the projection ((A X) W = A (X W): reference model.py:594-598 aggregates the
+// d-wide X and projects afterwards; here the F-wide H, F = out_features <= d, is gathered instead -- half the bytes at
+// 128 -> 64, 22x fewer on Cora's 1433 -> 64).  For the cotangent G = dZ * act'(Z) and every destination-ordered record
+// e = (i, r) -> j, ONE gathered row G_i serves all three column-walking terms of the backward:
+//     dA_ir  = <G_i, H_j>                      (SDDMM: autograd wrt the adjacency values; H_j is the same line for a whole run)
+//     dH_j  += ahat_ir G_i                     (transposed SpMM: autograd wrt the aggregated features)
+//     da_j  += dA_ir w_ir a_i = sqrt(rs_j) sum_e dA_e ahat_e   (neighbour side of the normalize_adj backward, model.py:1215-1218)
+// F/4 lanes per record (16-byte loads), 256/F records per wave-instruction, chunks of CH records per lane group as in
+// edge_bwd_cols: runs of equal destination are reduced in registers, one flush per run, float atomics only for the two runs of
+// a chunk that can continue in a neighbouring chunk.
+template <int F>
+__global__ __launch_bounds__(256) void conv_bwd_cols(const float *__restrict__ G, const float *__restrict__ Hm,
+                                                     const float *__restrict__ a, int K, const int *__restrict__ bstart, int nb,
+                                                     const int2 *__restrict__ recs, const float *__restrict__ rs,
+                                                     float *__restrict__ dA, float *__restrict__ dH, float *__restrict__ da) {
+    constexpr int LPR = F / 4;
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, gbase = lane - c4;
+    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int nnz = bstart[nb];
+    const int64_t cbeg = gid * CH;
+    if (cbeg >= nnz) return;
+    const int cend = cbeg + CH < nnz ? (int)cbeg + CH : nnz;
+    int cur = -1;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float sda = 0.0f;
+    const int shared_lo = cbeg > 0 ? recs[cbeg - 1].y : -1, shared_hi = cend < nnz ? recs[cend].y : -1;   // see edge_bwd_cols
+    auto flush = [&]() {
+        if (cur >= 0) {
+            float *o = dH + (int64_t)cur * F + 4 * c4;
+            const bool shared = cur == shared_lo || cur == shared_hi;
+            if (shared) {
+                atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
+            } else {
+                float4 v = *reinterpret_cast<float4 *>(o);
+                v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += acc.w;
+                *reinterpret_cast<float4 *>(o) = v;
+            }
+            if (da && c4 == 0) {
+                const float v = sda * sqrtf(rs[cur]);
+                if (shared) atomicAdd(da + cur, v);
+                else da[cur] += v;
+            }
+        }
+    };
+    for (int eb = (int)cbeg; eb < cend; eb += LPR) {
+        const int e = eb + c4;
+        const int2 myrec = e < cend ? recs[e] : make_int2(0, -1);
+        const float mycf = e < cend ? a[(int64_t)(myrec.x >> 6) * K + (myrec.x & 63)] : 0.0f;
+#pragma unroll
+        for (int u0 = 0; u0 < LPR; u0 += 4) {
+            int src[4], dst[4];
+            float cf[4];
+            float4 g[4], hj[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                src[u] = __shfl(myrec.x, gbase + u0 + u, 64);
+                dst[u] = __shfl(myrec.y, gbase + u0 + u, 64);
+                cf[u] = __shfl(mycf, gbase + u0 + u, 64);
+                // both unconditional (padding records: row 0 / node 0, coefficient 0): eight loads back to back; the H_j line is
+                // the same for a whole run of records, i.e. an L1 hit after the run's first record
+                g[u] = *reinterpret_cast<const float4 *>(G + (int64_t)(src[u] >> 6) * F + 4 * c4);
+                hj[u] = *reinterpret_cast<const float4 *>(Hm + (int64_t)(dst[u] < 0 ? 0 : dst[u]) * F + 4 * c4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                float dot = g[u].x * hj[u].x;
+                dot = fmaf(g[u].y, hj[u].y, dot); dot = fmaf(g[u].z, hj[u].z, dot); dot = fmaf(g[u].w, hj[u].w, dot);
+                if (LPR > 16) dot += __uint_as_float(xor_shfl<16>(__float_as_uint(dot), lane));
+                if (LPR > 8) dot += __uint_as_float(xor_shfl<8>(__float_as_uint(dot), lane));
+                if (LPR > 4) dot += __uint_as_float(xor_shfl<4>(__float_as_uint(dot), lane));
+                dot += __uint_as_float(xor_shfl<2>(__float_as_uint(dot), lane));
+                dot += __uint_as_float(xor_shfl<1>(__float_as_uint(dot), lane));
+                if (dst[u] < 0) continue;
+                if (dst[u] != cur) {
+                    flush();
+                    cur = dst[u];
+                    acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    sda = 0.0f;
+                }
+                if (c4 == 0) dA[(int64_t)(src[u] >> 6) * K + (src[u] & 63)] = dot;
+                acc.x = fmaf(cf[u], g[u].x, acc.x); acc.y = fmaf(cf[u], g[u].y, acc.y);
+                acc.z = fmaf(cf[u], g[u].z, acc.z); acc.w = fmaf(cf[u], g[u].w, acc.w);
+                sda = fmaf(dot, cf[u], sda);
+            }
+        }
+    }
+    flush();
+}
+
 // ---- normalisation backward: row side (da_i, per-entry coefficient), column side (bucket sums) -----------------------
 __global__ __launch_bounds__(256) void norm_da_rows(const int32_t *__restrict__ idx, const float *__restrict__ w,
                                                     const float *__restrict__ rs, const float *__restrict__ dA, int64_t rows,
@@ -548,11 +647,13 @@ int dgg_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, 
 // dgg_softk_bwd (modes 0 / 1) + dgg_edge_bwd_part in one call: d loss / d score is formed inside the row kernel of the score
 // backward.  dval (nullable) receives it as well; dk [rows] is written.
 int dgg_softk_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *k, const float *rs,
-                            const float *dA, const float *da, int K, int64_t row0, float t, int perturb, int mode, int normalized,
-                            const void *part_ws, int64_t ncols, float *coef_ws, float *dval, float *dk, float *dxp, void *stream) {
+                            const float *dA, const float *da, const float *ahat_rows, int K, int64_t row0, float t, int perturb,
+                            int mode, int normalized, const void *part_ws, int64_t ncols, float *coef_ws, float *dval, float *dk,
+                            float *dxp, void *stream) {
     if (mode != 0 && mode != 1) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_part: mode must be 0 (k_times) or 1 (k_only)");
     if (!k || !dA || !dk || (normalized && (!rs || !da))) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_part: missing operand");
-    const SoftkArgs sk{k, rs, dA, da, mode, normalized, dval, dk};
+    if (ahat_rows && !normalized) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_part: ahat_rows is an operand of the normalised form");
+    const SoftkArgs sk{k, rs, dA, da, mode, normalized, dval, dk, ahat_rows};
     return edge_bwd_part_impl(xp, rows, h, idx, val, nullptr, K, row0, t, perturb, part_ws, ncols, coef_ws, dxp, &sk, stream);
 }
 
@@ -569,6 +670,33 @@ int dgg_ell_spmm_t_part(const float *a, const float *dY, int64_t rows, int K, in
     hipLaunchKernelGGL(spmm_t_cols, dim3((unsigned)((ngroups * 16 + 255) / 256), (unsigned)(F / 64)), dim3(256), 0, (hipStream_t)stream, dY,
                        F, p.bstart, (int)nb, p.recs, a, K, dX);
     return dgg_check_launch("ell_spmm_t_part");
+}
+
+// Backward of Z = A H through the partition, one gather of G per record (conv_bwd_cols): dA [rows,K] (entries outside the
+// partition are NOT written: caller zeroes), dH [ncols,F] and da [ncols] (nullable) accumulated into (caller zeroes).
+int dgg_ell_conv_bwd_part(const float *G, const float *H, const float *ahat, int64_t rows, int K, int F, const void *part_ws,
+                          int64_t ncols, const float *rs, float *dA, float *dH, float *da, void *stream) {
+    if ((F != 16 && F != 32 && F != 64 && F != 128) || (reinterpret_cast<uintptr_t>(G) % 16) || (reinterpret_cast<uintptr_t>(H) % 16) ||
+        (reinterpret_cast<uintptr_t>(dH) % 16))
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "ell_conv_bwd_part: feature width must be 16, 32, 64 or 128 (16-byte aligned rows)");
+    if (da && !rs) return dgg_set_error(DGG_ERR_ARG, "ell_conv_bwd_part: da needs the row sums");
+    if (!dgg_part_slotmap(part_ws, rows, K, ncols)) return dgg_set_error(DGG_ERR_ARG, "ell_conv_bwd_part: no partition");
+    if (rows == 0) return 0;
+    const int64_t nb = nbuckets(ncols);
+    PartHdr p = part_layout(const_cast<void *>(part_ws), nb, rows * K);
+    const int64_t ngroups = (rows * K + CH - 1) / CH;
+    hipStream_t st = (hipStream_t)stream;
+#define DGG_CONV_COLS(FF)                                                                                                  \
+    hipLaunchKernelGGL(conv_bwd_cols<FF>, dim3((unsigned)((ngroups * (FF / 4) + 255) / 256)), dim3(256), 0, st, G, H, ahat, K, \
+                       p.bstart, (int)nb, p.recs, rs, dA, dH, da)
+    switch (F) {
+        case 16: DGG_CONV_COLS(16); break;
+        case 32: DGG_CONV_COLS(32); break;
+        case 64: DGG_CONV_COLS(64); break;
+        default: DGG_CONV_COLS(128); break;
+    }
+#undef DGG_CONV_COLS
+    return dgg_check_launch("ell_conv_bwd_part");
 }
 
 // normalisation backward phase 1 through the partition; da [ncols] zeroed by the caller

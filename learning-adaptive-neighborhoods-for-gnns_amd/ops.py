@@ -462,16 +462,50 @@ def normalize_fwd(idx, w, rs, row0=0):
     return ahat
 
 
-def spmm_fwd(idx, ahat, X):
+def spmm_fwd(idx, ahat, X, act=ACT_NONE):
+    """Y = act(A X); act = ACT_RELU is GCNConv's activation when the aggregation runs after the projection"""
     N, K = idx.shape
     X = _chk(X)
     F = X.shape[1]
     Y = torch.empty((N, F), device=idx.device, dtype=torch.float32)
     ahat = _chk(ahat)
     pe = _probe_begin()
-    _lib.check(_lib.lib().dgg_ell_spmm_fwd(_ptr(idx), _ptr(ahat), _ptr(X), N, K, F, _ptr(Y), _stream()), "ell_spmm_fwd")
+    _lib.check(_lib.lib().dgg_ell_spmm_act_fwd(_ptr(idx), _ptr(ahat), _ptr(X), N, K, F, act, _ptr(Y), _stream()), "ell_spmm_act_fwd")
     _probe_end("spmm_fwd", pe)
     return Y
+
+
+def act_bwd(y, dy, act):
+    """dy * act'(y), elementwise"""
+    y, dy = _chk(y), _chk(dy)
+    dp = torch.empty_like(dy)
+    _lib.check(_lib.lib().dgg_act_bwd(_ptr(y), _ptr(dy), y.numel(), act, _ptr(dp), _stream()), "act_bwd")
+    return dp
+
+
+CONV_BWD_WIDTHS = (16, 32, 64, 128)
+
+
+def conv_bwd_cols(idx, ahat, H, G, part, rs=None, want_da=False):
+    """Backward of Z = A H through the partition with ONE gathered row of G per active entry: -> dA [rows,K] (zero outside
+    the partition), dH [ncols,F], da [ncols] (neighbour-side sums of the normalisation backward; None unless want_da).
+    None when the kernel does not cover the shape."""
+    N, K = idx.shape
+    H, G = _chk(H), _chk(G)
+    F = H.shape[1]
+    if part is None or F not in CONV_BWD_WIDTHS or H.data_ptr() % 16 or G.data_ptr() % 16:
+        return None
+    ncols = H.shape[0]
+    zz = _zeros((N * K + ncols * F + (ncols if want_da else 0),), H.device)      # one fill for the three accumulators
+    dA = zz[:N * K].view(N, K)
+    dH = zz[N * K:N * K + ncols * F].view(ncols, F)
+    da = zz[N * K + ncols * F:] if want_da else None
+    pe = _probe_begin()
+    _lib.check(_lib.lib().dgg_ell_conv_bwd_part(_ptr(G), _ptr(H), _ptr(_chk(ahat)), N, K, F, _ptr(part), ncols,
+                                                _ptr(_chk(rs)) if want_da else None, _ptr(dA), _ptr(dH), _ptr(da), _stream()),
+               "ell_conv_bwd_part")
+    _probe_end("conv_bwd", pe)
+    return dA, dH, da
 
 
 def spmm_bwd(idx, ahat, X, dY, need_dx=True, skip_zero=False, part=None, part_cols=None):
@@ -553,7 +587,7 @@ def softk_bwd(idx, val, k, dA, rs=None, da=None, row0=0, mode=MODE_K_TIMES_EDGE_
 
 
 def softk_edge_bwd(xp, idx, val, k, dA, rs=None, da=None, row0=0, t=T_DIST, perturb=False, mode=MODE_K_TIMES_EDGE_PROB, normalized=False,
-                   part=None, want_dval=False):
+                   part=None, want_dval=False, ahat_rows=None):
     """softk_bwd + edge_bwd in one call when the destination-ordered path applies (d loss / d score never leaves the registers
     of the row kernel) -> dxp [Nglobal,h], dk [N], dval [N,K] or None; None when it does not apply (then: the two calls)."""
     xp = _chk(xp)
@@ -567,7 +601,9 @@ def softk_edge_bwd(xp, idx, val, k, dA, rs=None, da=None, row0=0, t=T_DIST, pert
     dval = torch.empty((N, K), device=xp.device, dtype=torch.float32) if want_dval else None
     val, k, dA = _chk(val), _chk(k), _chk(dA)
     pe = _probe_begin()
-    _lib.check(_lib.lib().dgg_softk_edge_bwd_part(_ptr(xp), N, h, _ptr(idx), _ptr(val), _ptr(k), _ptr(rs), _ptr(dA), _ptr(da), K, row0, t,
+    # ahat_rows: `da` holds the neighbour-side sums only (conv_bwd_cols); the row side is formed inside the kernel
+    _lib.check(_lib.lib().dgg_softk_edge_bwd_part(_ptr(xp), N, h, _ptr(idx), _ptr(val), _ptr(k), _ptr(rs), _ptr(dA), _ptr(da),
+                                                  _ptr(None if ahat_rows is None else _chk(ahat_rows)), K, row0, t,
                                                   int(perturb), mode, int(normalized), _ptr(part), Ng, _ptr(coef), _ptr(dval), _ptr(dk),
                                                   _ptr(dxp), _stream()), "softk_edge_bwd_part")
     _probe_end("edge_bwd", pe)
@@ -732,20 +768,29 @@ class EllNormalizeFn(torch.autograd.Function):
 
 
 class EllSpmmFn(torch.autograd.Function):
-    """Y = A X on the ELL adjacency (torch.mm(adj, x) model.py:594, 67 / torch.spmm model.py:34)."""
+    """Y = act(A X) on the ELL adjacency (torch.mm(adj, x) model.py:594, 67 / torch.spmm model.py:34; act = ReLU when GCNConv
+    aggregates the projected features, relu(A (x W)))."""
 
     @staticmethod
-    def forward(ctx, ahat, idx, X, skip_zero=False, part=None):
-        Y = spmm_fwd(idx, ahat, X)
-        ctx.save_for_backward(ahat, idx, X)
-        ctx.skip_zero, ctx.part = skip_zero, part
+    def forward(ctx, ahat, idx, X, skip_zero=False, part=None, act=ACT_NONE):
+        Y = spmm_fwd(idx, ahat, X, act)
+        ctx.save_for_backward(ahat, idx, X, Y if act != ACT_NONE else X)
+        ctx.skip_zero, ctx.part, ctx.act = skip_zero, part, act
         return Y
 
     @staticmethod
     def backward(ctx, dY):
-        ahat, idx, X = ctx.saved_tensors
-        dA, dX = spmm_bwd(idx, ahat, X, dY.contiguous(), need_dx=ctx.needs_input_grad[2], skip_zero=ctx.skip_zero, part=ctx.part)
-        return dA, None, dX, None, None
+        ahat, idx, X, Y = ctx.saved_tensors
+        dY = dY.contiguous()
+        if ctx.act != ACT_NONE:
+            dY = act_bwd(Y, dY, ctx.act)
+        if ctx.needs_input_grad[2] and ctx.skip_zero and X.shape[0] == idx.shape[0]:
+            # learned input on a DGG adjacency: SDDMM and transposed SpMM from ONE gathered cotangent row per entry
+            got = conv_bwd_cols(idx, ahat, X, dY, ctx.part)
+            if got is not None:
+                return got[0], None, got[1], None, None, None
+        dA, dX = spmm_bwd(idx, ahat, X, dY, need_dx=ctx.needs_input_grad[2], skip_zero=ctx.skip_zero, part=ctx.part)
+        return dA, None, dX, None, None, None
 
 
 class CsrNormalizeFn(torch.autograd.Function):

@@ -3,28 +3,31 @@
 The reference has no distributed code; the all-pairs similarity shards by rows: every
 output row i needs x_i, all candidate x_j, k_i and the row sums rs_j of its selected neighbours, and nothing else
 (sort / ramp act on dim=-1, reference dgm.py:1404-1420).  Rank r owns rows [r*ceil(N/G), ...) of X, of the ELL
-adjacency and of the conv output.  Collectives per step:
+adjacency and of the conv output.
 
-  forward   all-gather xp [N,h]  (projected features of the OWN rows; the scoring needs every candidate's xp_j)
-            all-gather X  [N,d]  (needed only by the SpMM gather: issued asynchronously behind xp, it crosses the
-                                  fabric while the top-k, soft-k and partition kernels run)
-            all-gather rs [N]    (row sums for the symmetric-ish normalisation, model.py:1215-1218)
-  backward  all-reduce da [N]   (d loss / d rs^-1/2: neighbour-side terms land on non-owner ranks)
-            all-reduce of the replicated weight gradients (one flat bucket, ~35k floats)
-            [reduce-scatter dX [N,d] only when the input features need a gradient]
+The graph conv is evaluated as relu(A (x W)) instead of the reference's relu((A x) W) (model.py:594-598; equal up to
+fp32 reassociation): the aggregation gathers the out_features-wide projected rows H = X Wc, not the d-wide inputs, and
+the backward's three column-walking terms (SDDMM, transposed SpMM, neighbour side of the normalisation backward) share
+ONE gathered cotangent row per edge (ops.conv_bwd_cols).  Every per-node array a rank gathers from is therefore a
+PROJECTION of the features: xp (scoring) and H (aggregation).
 
-Every rank projects only its own rows (xp = leaky(X We^T + be)) and gathers the rest.  The weight
-gradient of the projection is formed from each rank's PARTIAL dxp against the full X / xp and summed by the weight
-all-reduce, so the [N,h] gradient itself never crosses the fabric.
+Two exchange schemes:
 
 REPLICATED FEATURES (`x_full=`): when the DGG input is DATA (GCN_DGG / SAGE_DGG / GCNII_DGG all feed it the raw node
 features, model.py:1266, 720) it never changes between steps, so it is placed on every GPU once at load (N*d*4 bytes:
 0.4 GB of the 288 GB for 800k nodes) and NO feature tensor crosses the fabric per step: every rank projects all N rows
-itself (N*d*h*2 flop: cheaper than receiving (G-1)/G of xp over xGMI) and the forward's only collective is the all-gather
-of the row sums.  The gathers above remain the path for inputs that are activations (`x_grad`, DGG on hidden layers).
+itself ([xp | H] = one GEMM that reads X once) and forms the weight gradients from its PARTIAL [dxp | dH] against the
+full X (summed by the weight all-reduce).  Per-step collectives: all-gather of the row sums (N*4 B), all-reduce of da
+(N*4 B), one flat all-reduce of the replicated weight gradients (~35k floats).
+
+GATHERED PROJECTIONS (inputs that are activations, `x_grad`; or data that is not replicated): every rank projects its
+own rows and all-gathers [xp | H] (xp first -- the top-k waits for it -- H asynchronously behind it: it is needed only
+by the aggregation, so it crosses xGMI while the top-k, soft-k, partition and normalisation kernels run); the backward
+reduce-scatters the partial [dxp | dH] (the adjoint of that all-gather) and forms weight and input gradients from the
+rank's own rows.
 
 `kern` is the kernel namespace (dgg_amd.ops on the GPU; tests substitute a CPU stand-in built on the oracle so
-that the partition / collective logic is exercised with gloo, world_size 2, without a GPU).
+that the partition / collective logic is exercised with gloo, world_size 2 and 3, without a GPU).
 """
 import os
 
@@ -40,14 +43,32 @@ def shard_bounds(N, world, rank):
 
 class _Gather:
     """A (possibly still running) all-gather of row shards: .get() waits and returns the [N, ...] tensor.  On RCCL the
-    wait is a stream dependency (no host block); shards are padded to `per` rows for the fixed-size collective."""
+    wait is a stream dependency (no host block); shards are padded to `per` rows for the fixed-size collective.  `bufs`
+    (a dict owned by the layer) keeps the padded source and the gathered output between steps: no allocation, no
+    torch.cat per step."""
 
-    def __init__(self, t_local, N, per, group, async_op):
-        pad = per - t_local.shape[0]
-        self.src = t_local.contiguous() if pad == 0 else torch.cat([t_local, t_local.new_zeros((pad,) + tuple(t_local.shape[1:]))])
-        self.out = self.src.new_empty((dist.get_world_size(group) * per,) + tuple(t_local.shape[1:]))
+    def __init__(self, t_local, N, per, group, async_op, bufs=None, key=None):
+        world = dist.get_world_size(group)
+        tail = tuple(t_local.shape[1:])
+        n_loc = t_local.shape[0]
+        if n_loc == per:
+            src = t_local.contiguous()
+        else:
+            src = self._buf(bufs, (key, "src"), (per,) + tail, t_local)
+            src[:n_loc].copy_(t_local)
+            src[n_loc:].zero_()
+        self.out = self._buf(bufs, (key, "out"), (world * per,) + tail, t_local)
         self.N = N
-        self.work = dist.all_gather_into_tensor(self.out, self.src, group=group, async_op=async_op)
+        self.work = dist.all_gather_into_tensor(self.out, src, group=group, async_op=async_op)
+
+    @staticmethod
+    def _buf(bufs, key, shape, like):
+        if bufs is None or key[0] is None:
+            return like.new_empty(shape)
+        b = bufs.get(key)
+        if b is None or tuple(b.shape) != tuple(shape) or b.device != like.device:
+            b = bufs[key] = like.new_empty(shape)
+        return b
 
     def get(self):
         if self.work is not None:
@@ -56,11 +77,11 @@ class _Gather:
         return self.out[:self.N]
 
 
-def _all_gather_rows(t_local, N, per, group):
+def _all_gather_rows(t_local, N, per, group, bufs=None, key=None):
     """[n_loc, ...] -> [N, ...]"""
     if dist.get_world_size(group) == 1 and os.environ.get("DGG_FORCE_COLLECTIVES") != "1":
         return t_local
-    return _Gather(t_local, N, per, group, False).get()
+    return _Gather(t_local, N, per, group, False, bufs, key).get()
 
 
 class ShardedDGGConv:
@@ -80,6 +101,7 @@ class ShardedDGGConv:
         self.coll = self.world > 1 or (dist.is_initialized() and os.environ.get("DGG_FORCE_COLLECTIVES") == "1")
         self.emulate = None
         self.r0, self.r1, self.per = shard_bounds(N, self.world, self.rank)
+        self.bufs = {}                                       # collective staging buffers, kept between steps
 
     def emulate_rank(self, world, rank):
         """TIMING DIAGNOSTIC (bench.py --emulate-world): do the work of `rank` of `world` in a single process -- own row range
@@ -89,15 +111,34 @@ class ShardedDGGConv:
         self.world, self.rank, self.coll, self.emulate = world, rank, False, (world, rank)
         self.r0, self.r1, self.per = shard_bounds(self.N, world, rank)
 
+    # ------------------------------------------------------------------------------------------------------------------
+    def _project(self, x_local, P):
+        """-> xp (rows of `Xall`), H (rows of `Xall`), xk (own rows).  One GEMM that reads X once when the kernel namespace
+        offers it (ops.linear_fwd_multi), three plain calls otherwise."""
+        kern = self.kern
+        repl = self.x_full is not None
+        Xall = self.x_full if repl else x_local
+        single = not repl or (self.world == 1 and self.emulate is None)      # the own rows are all the rows that are projected
+        if hasattr(kern, "linear_fwd_multi"):
+            if single:
+                xp, xk, H = kern.linear_fwd_multi(Xall, [(P["We"], P["be"], 1, 0), (P["Wk"], P["bk"], 1, 0), (P["Wc"], None, 0, 1)])
+                return xp, H, xk
+            xp, H = kern.linear_fwd_multi(Xall, [(P["We"], P["be"], 1, 0), (P["Wc"], None, 0, 1)])
+            return xp, H, kern.linear_fwd(x_local, P["Wk"], P["bk"], 1, 0)
+        xp = kern.linear_fwd(Xall, P["We"], P["be"], 1, 0)
+        H = kern.linear_fwd(Xall, P["Wc"], None, 0, 1)
+        return xp, H, kern.linear_fwd(x_local, P["Wk"], P["bk"], 1, 0)
+
     def forward(self, x_local, deg_full, P):
         kern = self.kern
         s = {}
         repl = self.x_full is not None
-        xp = kern.linear_fwd(self.x_full if repl else x_local, P["We"], P["be"], 1, 0)
-        if self.coll and not repl:                  # xp first (the top-k waits for it), X streams in behind it
-            g_xp = _Gather(xp, self.N, self.per, self.group, True)
-            g_X = _Gather(x_local, self.N, self.per, self.group, True)
-        s["xk"] = xk = kern.linear_fwd(x_local, P["Wk"], P["bk"], 1, 0)
+        xp, H, xk = self._project(x_local, P)
+        s["xp_loc"], s["H_loc"] = xp, H
+        if self.coll and not repl:                  # xp first (the top-k waits for it), H streams in behind it
+            g_xp = _Gather(xp, self.N, self.per, self.group, True, self.bufs, "xp")
+            g_H = _Gather(H, self.N, self.per, self.group, True, self.bufs, "H")
+        s["xk"] = xk
         s["mu_sd"] = mu_sd = kern.degree_stats(deg_full)
         deg_local = deg_full[self.r0:self.r1].contiguous()
         s["k"], s["z"], s["u"], s["feat"] = kern.knet_x_fwd(xk, deg_local, mu_sd, P["W1"], P["b1"], P["Wmu"], P["bmu"],
@@ -108,13 +149,12 @@ class ShardedDGGConv:
         s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
         # destination-bucket partition of the active entries: the backward's column-side terms run on it (no atomics)
         s["part"] = kern.part_build(s["idx"], s["w"], self.N) if hasattr(kern, "part_build") else None
-        s["rs"] = rs = _all_gather_rows(rs_local, self.N, self.per, self.group) if self.coll else rs_local
+        s["rs"] = rs = _all_gather_rows(rs_local, self.N, self.per, self.group, self.bufs, "rs") if self.coll else rs_local
         if self.emulate is not None:
             s["rs"] = rs = rs_local.repeat(self.world)[:self.N].contiguous()
         s["ahat"] = kern.normalize_fwd(s["idx"], s["w"], rs, self.r0)
-        s["X"] = X = self.x_full if repl else (g_X.get() if self.coll else x_local)
-        s["Y"] = kern.spmm_fwd(s["idx"], s["ahat"], X)
-        s["Z"] = kern.linear_fwd(s["Y"], P["Wc"], None, 2, 1)
+        s["H"] = H = g_H.get() if (self.coll and not repl) else H
+        s["Z"] = kern.spmm_fwd(s["idx"], s["ahat"], H, 2)    # relu(A (x Wc))
         self.saved = s
         return s["Z"]
 
@@ -122,46 +162,91 @@ class ShardedDGGConv:
         """-> dict of parameter gradients (summed over ranks) and, if x_grad, 'x' = d loss / d x_local."""
         kern, s = self.kern, self.saved
         if hasattr(kern, "zero_pool"):                   # every zero-initialised accumulator of the backward from ONE filled buffer
-            ncols, h, d = s["xp"].shape[0], s["xp"].shape[1], s["X"].shape[1]
-            need = ncols * (h + 2) + 2 * sum(int(v.numel()) for v in P.values()) + (ncols * d if self.x_grad else 0) + 65536
+            ncols, h, F = s["xp"].shape[0], s["xp"].shape[1], s["H"].shape[1]
+            rows = s["idx"].shape[0]
+            need = ncols * (h + F + 2) + rows * self.K + 2 * sum(int(v.numel()) for v in P.values()) + 65536
             with kern.zero_pool(s["xp"].device, need):
                 return self._backward(dZ, x_local, P)
         return self._backward(dZ, x_local, P)
 
+    def _reduce_scatter_rows(self, t, key):
+        """[N, c] partial sums on every rank -> the rank's own rows [r1-r0, c], summed over ranks"""
+        pad = self.world * self.per - self.N
+        src = t
+        if pad:
+            src = _Gather._buf(self.bufs, (key, "rs_src"), (self.world * self.per, t.shape[1]), t)
+            src[:self.N].copy_(t)
+            src[self.N:].zero_()
+        out = _Gather._buf(self.bufs, (key, "rs_out"), (self.per, t.shape[1]), t)
+        dist.reduce_scatter_tensor(out, src.contiguous(), group=self.group)
+        return out[: self.r1 - self.r0]
+
     def _backward(self, dZ, x_local, P):
         kern, s = self.kern, self.saved
         g = {}
-        dY, g["Wc"], _ = kern.linear_bwd(s["Y"], P["Wc"], s["Z"], dZ, 2, 1, True, False)
+        repl = self.x_full is not None
         part = s.get("part")
-        fused = None
-        if not self.x_grad and part is not None and hasattr(kern, "sddmm_norm"):
-            fused = kern.sddmm_norm(s["idx"], s["ahat"], s["w"], s["rs"], s["X"], dY, self.r0, part, True)
-        if fused is not None:                            # SDDMM + row side of the normalisation backward in one pass
-            (dA, da), dX = fused, None
+        G = kern.act_bwd(s["Z"], dZ, 2)                  # cotangent of A H
+        # one gather of G per edge for SDDMM + transposed SpMM + neighbour side of da; its companion is the fused score backward
+        # (which adds the row side of da in registers), so both must cover the shape
+        cols = None
+        if part is not None and hasattr(kern, "conv_bwd_cols") and hasattr(kern, "softk_edge_bwd") and \
+                s["xp"].shape[1] in (16, 32, 64, 128) and self.mode in (0, 1):
+            cols = kern.conv_bwd_cols(s["idx"], s["ahat"], s["H"], G, part, s["rs"], True)
+        if cols is not None:
+            dA, dH, da = cols
+            ahat_rows = s["ahat"]
         else:
-            if part is not None and self.x_grad:         # dX through the destination-ordered partition (no entry-wise atomics)
-                dA, dX = kern.spmm_bwd(s["idx"], s["ahat"], s["X"], dY, True, True, part=part, part_cols=self.N)
-            else:
-                dA, dX = kern.spmm_bwd(s["idx"], s["ahat"], s["X"], dY, self.x_grad, True)
+            dA, dH = kern.spmm_bwd(s["idx"], s["ahat"], s["H"], G, True, True)
             da = kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0, part) if part is not None else \
                 kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0)
+            ahat_rows = None
         if self.coll:
             dist.all_reduce(da, group=self.group)
-        fused = kern.softk_edge_bwd(s["xp"], s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.t, self.noise_mode != 0,
-                                    self.mode, True, part) if (part is not None and hasattr(kern, "softk_edge_bwd")) else None
+        fused = None
+        if part is not None and hasattr(kern, "softk_edge_bwd"):
+            fused = kern.softk_edge_bwd(s["xp"], s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.t, self.noise_mode != 0,
+                                        self.mode, True, part, ahat_rows=ahat_rows)
         if fused is not None:                            # ramp + normalisation backward inside the row kernel of the score backward
             dxp, dk, _ = fused
         else:
+            assert ahat_rows is None
             dval, dk = kern.softk_bwd(s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.mode, True)
             dxp = kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0, part) \
                 if part is not None else kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0)
-        dX1, g["We"], g["be"] = kern.linear_bwd(s["X"], P["We"], s["xp"], dxp, 1, 0, self.x_grad, True)
+        # weight gradients of the two projections.  Replicated features: partial [dxp | dH] of all N nodes against the full X (the
+        # weight all-reduce sums the ranks); gathered projections: reduce-scatter the partials, then the rank's own rows only.
+        if self.coll and not repl:
+            both = self._reduce_scatter_rows(torch.cat([dxp, dH], 1), "dproj")
+            h = dxp.shape[1]
+            dxp_g, dH_g, Xg, xp_g = both[:, :h].contiguous(), both[:, h:].contiguous(), x_local, s["xp_loc"]
+        else:
+            dxp_g, dH_g, Xg, xp_g = dxp, dH, (self.x_full if repl else x_local), s["xp"]
         dxk, g["W1"], g["b1"], g["Wmu"], g["bmu"], dWp, g["bp"] = kern.knet_x_bwd(
             s["xk"].shape[1], s["mu_sd"], P["W1"], P["Wmu"], P["bmu"], P["Wp"].reshape(-1), s["z"], s["u"], s["feat"], dk)
         g["Wp"] = dWp.reshape(P["Wp"].shape)
-        dx2, g["Wk"], g["bk"] = kern.linear_bwd(x_local, P["Wk"], s["xk"], dxk, 1, 0, self.x_grad, True)
+        same_rows = Xg.shape[0] == x_local.shape[0] and (not repl or self.world == 1) and self.emulate is None
+        if hasattr(kern, "linear_bwd_multi") and not self.x_grad and same_rows:
+            # one pass over X for the three weight gradients (leaky masks applied on the operand load)
+            (g["We"], g["be"]), (g["Wk"], g["bk"]), (g["Wc"], _) = kern.linear_bwd_multi(
+                Xg, [(P["We"], xp_g, dxp_g, 1, 0, True), (P["Wk"], s["xk"], dxk, 1, 0, True), (P["Wc"], None, dH_g, 0, 1, False)])
+            dX1 = dX2 = dX3 = None
+        elif hasattr(kern, "linear_bwd_multi") and not self.x_grad:
+            (g["We"], g["be"]), (g["Wc"], _) = kern.linear_bwd_multi(
+                Xg, [(P["We"], xp_g, dxp_g, 1, 0, True), (P["Wc"], None, dH_g, 0, 1, False)])
+            _, g["Wk"], g["bk"] = kern.linear_bwd(x_local, P["Wk"], s["xk"], dxk, 1, 0, False, True)
+            dX1 = dX2 = dX3 = None
+        else:
+            dX1, g["We"], g["be"] = kern.linear_bwd(Xg, P["We"], xp_g, dxp_g, 1, 0, self.x_grad, True)
+            dX3, g["Wc"], _ = kern.linear_bwd(Xg, P["Wc"], None, dH_g, 0, 1, self.x_grad, False)
+            dX2, g["Wk"], g["bk"] = kern.linear_bwd(x_local, P["Wk"], s["xk"], dxk, 1, 0, self.x_grad, True)
         if self.coll:
-            flat = torch.cat([g[k].reshape(-1) for k in self.PARAM_KEYS])
+            flat = _Gather._buf(self.bufs, ("wgrad", "flat"), (sum(int(g[k].numel()) for k in self.PARAM_KEYS),), g["We"])
+            o = 0
+            for k in self.PARAM_KEYS:
+                n = g[k].numel()
+                flat[o:o + n].copy_(g[k].reshape(-1))
+                o += n
             dist.all_reduce(flat, group=self.group)
             o = 0
             for k in self.PARAM_KEYS:
@@ -169,13 +254,5 @@ class ShardedDGGConv:
                 g[k] = flat[o:o + n].view_as(g[k])
                 o += n
         if self.x_grad:
-            dXf = dX + dX1                               # [N,d] partial: neighbour-side terms of every rank
-            if self.coll:
-                pad = self.world * self.per - self.N
-                if pad:
-                    dXf = torch.cat([dXf, dXf.new_zeros((pad, dXf.shape[1]))])
-                out = dXf.new_empty((self.per, dXf.shape[1]))
-                dist.reduce_scatter_tensor(out, dXf.contiguous(), group=self.group)
-                dXf = out[: self.r1 - self.r0]
-            g["x"] = dXf + dx2
+            g["x"] = dX1 + dX3 + dX2                     # all three on the rank's own rows
         return g

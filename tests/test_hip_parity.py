@@ -1052,17 +1052,20 @@ def test_full_size_ranked_step_properties(dev):
     assert (vv[:, :-1] >= vv[:, 1:]).all(), "scores are sorted"
     srt = torch.where(kept, idx, torch.arange(64, device=dev, dtype=idx.dtype)[None, :] - 100).sort(dim=1).values
     assert (srt[:, 1:] != srt[:, :-1]).all(), "duplicate column in a row"
+    # the step aggregates the PROJECTED features: Z = relu(A (x Wc)); the reference order relu((A x) Wc) is restated here in
+    # float64 from the raw inputs, so this also pins the reassociation (bar: 1e-5 on activations)
     xp_c, X_c = s["xp"].cpu().numpy(), x.cpu().numpy()
-    ah, Y = s["ahat"].cpu().numpy(), s["Y"].cpu().numpy()
+    ah, Zc, Wc = s["ahat"].cpu().numpy(), s["Z"].cpu().numpy(), P["Wc"].cpu().numpy().astype(np.float64)
     for r in [0, 77, 4097, 50_001, 99_999]:
         ri, rv = O.allpairs_topk(xp_c, K=K, noise_mode=O.NOISE_RANKED, seed=(1234, 0), rows=(r, r + 1))
         m = Nn(kept[r])
         assert np.array_equal(Nn(idx[r])[m], ri[0][m]) and np.array_equal(Nn(val[r])[m], rv[0][m])
-        yr = np.zeros(d, np.float32)
-        for q in range(64):                                        # fmaf chain in rank order, as the oracle's SpMM
+        yr = np.zeros(d, np.float64)
+        for q in range(64):
             if Nn(idx[r])[q] >= 0:
-                yr = np.float32(ah[r, q]) * X_c[Nn(idx[r])[q]] + yr
-        np.testing.assert_allclose(Y[r], yr, rtol=1e-5, atol=1e-6)
+                yr = np.float64(ah[r, q]) * X_c[Nn(idx[r])[q]] + yr
+        zr = np.maximum(yr @ Wc, 0)                                # reference order: relu((A x) W), model.py:594-598
+        np.testing.assert_allclose(Zc[r], zr, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("F", [64, 128, 320, 1024])

@@ -100,9 +100,14 @@ class CpuKern:
         out = np.where(idx.numpy() >= 0, a[row0:row0 + n, None] * w.numpy() * a[j], 0.0)
         return self._t(out.astype(np.float32))
 
-    def spmm_fwd(self, idx, ahat, X):
+    def spmm_fwd(self, idx, ahat, X, act=0):
         j = np.maximum(idx.numpy(), 0)
-        return self._t(np.einsum("nk,nkf->nf", ahat.numpy().astype(np.float64), X.numpy()[j]).astype(np.float32))
+        y = np.einsum("nk,nkf->nf", ahat.numpy().astype(np.float64), X.numpy()[j])
+        return self._t((np.maximum(y, 0) if act == 2 else y).astype(np.float32))
+
+    def act_bwd(self, y, dy, act):
+        assert act == 2
+        return self._t(np.where(y.numpy() > 0, dy.numpy(), 0.0).astype(np.float32))
 
     def spmm_bwd(self, idx, ahat, X, dY, need_dx=True, skip_zero=False):
         j = np.maximum(idx.numpy(), 0)
@@ -180,13 +185,12 @@ def run_step(x_local, deg, P, cot_local, N, group, x_full=None):
     return Z, g
 
 
-def _worker(rank, world, port, ret, replicated=False):
+def _worker(rank, world, port, ret, replicated=False, N=150):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
     from dgg_amd.parallel import shard_bounds
-    x, deg, P, cot = make_inputs()
-    N = x.shape[0]
+    x, deg, P, cot = make_inputs(N)
     r0, r1, _ = shard_bounds(N, world, rank)
     Z, g = run_step(x[r0:r1].contiguous(), deg, P, cot[r0:r1].contiguous(), N, None, x if replicated else None)
     ret[rank] = (r0, r1, Z.numpy(), {k: v.numpy() for k, v in g.items()})
@@ -194,32 +198,34 @@ def _worker(rank, world, port, ret, replicated=False):
 
 
 @pytest.mark.parametrize("replicated", [False, True])
-def test_sharded_step_matches_single_process(replicated):
-    """replicated=True: the node features are data present on every rank (no per-step exchange of X / xp, every rank projects
-    all rows); the only forward collective left is the all-gather of the row sums"""
-    x, deg, P, cot = make_inputs()
-    N = x.shape[0]
+@pytest.mark.parametrize("world,N", [(2, 150), (3, 151)])
+def test_sharded_step_matches_single_process(replicated, world, N):
+    """replicated=True: the node features are data present on every rank (no per-step exchange of projections, every rank
+    projects all rows); replicated=False: every rank projects its own rows, all-gathers [xp | H] and reduce-scatters the
+    partial [dxp | dH].  world 3 with N = 151: uneven shards (51 + 51 + 49), padded collectives."""
+    x, deg, P, cot = make_inputs(N)
     Z1, g1 = run_step(x, deg, P, cot, N, None)          # world 1 (no process group)
     if replicated:
         g1.pop("x")
-    port = 29500 + os.getpid() % 2000 + int(replicated)
+    port = 29500 + os.getpid() % 2000 + int(replicated) + 2 * world
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, replicated)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, replicated, N)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
-    assert ret[0][1] == ret[1][0] and ret[0][0] == 0 and ret[1][1] == N      # uneven split (75 + 75; per = 75)
-    Z2 = np.concatenate([ret[0][2], ret[1][2]])
+    assert ret[0][0] == 0 and ret[world - 1][1] == N and all(ret[r][1] == ret[r + 1][0] for r in range(world - 1))
+    Z2 = np.concatenate([ret[r][2] for r in range(world)])
     np.testing.assert_allclose(Z2, Z1.numpy(), rtol=1e-5, atol=1e-6)
     for k in g1:
         if k == "x":
-            got = np.concatenate([ret[0][3]["x"], ret[1][3]["x"]])
+            got = np.concatenate([ret[r][3]["x"] for r in range(world)])
         else:
             got = ret[0][3][k]
-            np.testing.assert_allclose(ret[1][3][k], got, rtol=0, atol=0)   # all-reduced: identical on both ranks
+            for r in range(1, world):
+                np.testing.assert_allclose(ret[r][3][k], got, rtol=0, atol=0)   # all-reduced: identical on every rank
         ref = g1[k].numpy()
         np.testing.assert_allclose(got.reshape(ref.shape), ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()))
 
