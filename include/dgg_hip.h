@@ -61,6 +61,21 @@ int dgg_linear_fwd(const float *x, int64_t N, int d, const float *W, const float
 size_t dgg_linear_bwd_ws_floats(int64_t N, int d, int out);
 int dgg_linear_bwd(const float *x, int64_t N, int d, const float *W, int out, int w_layout, int act, const float *y,
                    const float *dy, float *dx, float *dW, float *db, float *ws, void *stream);
+/* Several layers that read the SAME input in one pass over it (node_encode_for_edges + node_encode_for_k of one DGG,
+ * dgm.py:1097-1100 / 1123-1126 applied at 1609 / 1566, and the GCNConv projection x W, model.py:596): Wcat [sum out_s, d] /
+ * bcat [sum out_s] (nullable) = the layers' weights in nn.Linear layout stacked by rows; layer s has out_s outputs (multiples
+ * of 32, at most 256 in total, not 224), activation act_s and destination y_s [N,out_s].  seg_out / seg_act / y are HOST arrays.
+ * Bit-identical to nseg calls of dgg_linear_fwd. */
+int dgg_linear_fwd_multi(const float *x, int64_t N, int d, const float *Wcat, const float *bcat, int nseg, const int *seg_out,
+                         const int *seg_act, float *const *y, void *stream);
+/* Their weight gradients in one pass over the shared input B [N,M2] (M2 <= 128):
+ *   C_s[M1_s,M2] += (A_s * act_s'(Y_s))^T B,  colsum_s[M1_s] += column sums of the masked A_s (bias gradient; nullable)
+ * A_s = d loss / d y_s [N,M1_s] (M1_s multiples of 32, at most 256 in total), Y_s = y_s (nullable: no activation),
+ * c_layout_s 0: C_s stored [M1_s][M2], 1: [M2][M1_s] (GCNConv.W).  A / M1 / Y / act / C / c_layout / colsum are HOST arrays.
+ * ws: dgg_gemm_tn_multi_ws_floats(N, sum M1_s, M2) floats. */
+size_t dgg_gemm_tn_multi_ws_floats(int64_t N, int M1_total, int M2);
+int dgg_gemm_tn_multi(int nseg, const float *const *A, const int *M1, const float *const *Y, const int *act, const float *B,
+                      int64_t N, int M2, float *const *C, const int *c_layout, float *const *colsum, float *ws, void *stream);
 /* C[M1,M2] += A[N,M1]^T B[N,M2] (c_layout 1: C stored [M2][M1]); colsum (nullable,[M1]) += column sums of A.
  * Weight gradients of the per-node layers (autograd of dgm.py:1576-1577).  ws: dgg_gemm_tn_ws_floats(N, M1, M2)
  * floats (per-chunk partial blocks, summed by a second kernel: no same-address atomics storm). */
@@ -241,6 +256,23 @@ int dgg_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const fl
  * per bucket in LDS.  Same results as dgg_edge_bwd / dgg_norm_bwd_da up to summation order. */
 size_t dgg_part_ws_bytes(int64_t rows, int K, int64_t ncols);   /* 0: partitioned path not applicable */
 int dgg_part_build(const int32_t *idx, const float *w, int64_t rows, int K, int64_t ncols, void *ws, void *stream);
+/* PAYLOAD partition: 16-byte records (row*64 + r, j, w_ir rs_i^-1/2, score_ir), no slot map.  With the two per-entry scalars in
+ * the record every column-walking kernel of the backward works from its own coalesced record stream; the only value that
+ * still crosses between row order and record order is dA.  val [rows,K]: the scores; rs_rows [rows]: row sums of the block's
+ * own rows.  dgg_partp_ws_bytes: 0 = not applicable (more than 2^20 destination nodes or 2^25 rows). */
+size_t dgg_partp_ws_bytes(int64_t rows, int K, int64_t ncols);
+int dgg_partp_build(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
+                    void *ws, void *stream);
+/* dgg_ell_conv_bwd_part on a payload partition (ahat_ir = record payload * rs_j^-1/2, bit-identical to dgg_ell_normalize_fwd);
+ * also writes dA_rec [rows*K] = dA in record order.  dA, dH, da: caller zeroes. */
+int dgg_ell_conv_bwd_partp(const float *G, const float *H, int64_t rows, int K, int F, const void *partp_ws, int64_t ncols,
+                           const float *rs, float *dA, float *dA_rec, float *dH, float *da, void *stream);
+/* dgg_softk_edge_bwd_part on a payload partition: the column kernel recomputes d loss / d score (ramp + normalisation chain,
+ * dgm.py:1410-1420, model.py:1215-1218) from dA_rec and the per-row scalars the row kernel leaves in rowinfo_ws (4*rows floats) */
+int dgg_softk_edge_bwd_partp(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *k, const float *rs,
+                             const float *dA, const float *dA_rec, const float *da, const float *ahat_rows, int K, int64_t row0, float t,
+                             int perturb, int mode, int normalized, const void *partp_ws, int64_t ncols, float *rowinfo_ws, float *dk,
+                             float *dxp, void *stream);
 /* GCNII layer epilogue (GraphConvolution.forward, model.py:36-44): out = theta * sw + (1 - theta) * r (+ inp), sw = support W,
  * r = (1 - alpha) * hi + alpha * h0 (h0 NULL: r = hi; inp NULL: no residual).  Backward: dsw = theta g, dhi, dh0 (NULL with h0);
  * the residual input's gradient is g itself. */

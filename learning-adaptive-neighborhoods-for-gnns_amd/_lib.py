@@ -14,6 +14,9 @@ PROTOTYPES = {
     "dgg_linear_bwd": [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_gemm_tn_acc": [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
     "dgg_gemm_tn_ws_floats": [_i64, _i32, _i32],
+    "dgg_linear_fwd_multi": [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
+    "dgg_gemm_tn_multi": [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
+    "dgg_gemm_tn_multi_ws_floats": [_i64, _i32, _i32],
     "dgg_linear_bwd_ws_floats": [_i64, _i32, _i32],
     "dgg_degree_stats": [_vp, _i64, _vp, _vp, _vp],
     "dgg_degree_stats_ws_bytes": [],
@@ -64,6 +67,11 @@ PROTOTYPES = {
     "dgg_softk_edge_bwd_part": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _i32, _i32, _vp, _i64, _vp, _vp,
                                 _vp, _vp, _vp],
     "dgg_ell_conv_bwd_part": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
+    "dgg_partp_ws_bytes": [_i64, _i32, _i64],
+    "dgg_partp_build": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp],
+    "dgg_ell_conv_bwd_partp": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "dgg_softk_edge_bwd_partp": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _i32, _i32, _vp, _i64,
+                                 _vp, _vp, _vp, _vp],
     "dgg_ell_spmm_act_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp],
     "dgg_act_bwd": [_vp, _vp, _i64, _i32, _vp, _vp],
     "dgg_norm_bwd_da_part": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp],
@@ -97,7 +105,7 @@ def lib():
             fn = getattr(L, name)      # AttributeError if the library does not export a declared symbol
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        for name in ("dgg_allpairs_workspace_bytes", "dgg_gemm_tn_ws_floats", "dgg_linear_bwd_ws_floats", "dgg_part_ws_bytes",
+        for name in ("dgg_allpairs_workspace_bytes", "dgg_gemm_tn_ws_floats", "dgg_gemm_tn_multi_ws_floats", "dgg_linear_bwd_ws_floats", "dgg_part_ws_bytes", "dgg_partp_ws_bytes",
                      "dgg_degree_stats_ws_bytes"):
             getattr(L, name).restype = C.c_size_t
         _lib = L

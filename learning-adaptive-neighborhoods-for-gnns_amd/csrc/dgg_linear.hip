@@ -25,14 +25,23 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     return v;
 }
 
+// MULTI: several layers that read the SAME input in one pass (node_encode_for_edges + node_encode_for_k + the GCNConv
+// projection, dgm.py:1097-1100, 1123-1126, model.py:596): W / b are the row-concatenation of the layers' weights (layout 0),
+// and every 32-column block of the concatenated output goes to its own destination with its own activation.
+struct LinSegs {
+    float *y[8];       // destination of column block cb (already offset to the block's first column)
+    int ld[8];         // row stride of that destination
+    int act[8];        // its activation
+};
+
 // y[N,out] = act(x[N,d] * W^T + b);  w_layout 0: W[out][d], 1: W[d][out].  NACC 32-column accumulators per wave
 // (tile width BN = 32*NACC is matched to `out`, so narrow layers do not pay for 128 columns of MFMAs)
-template <int NACC, int WAVES>
+template <int NACC, int WAVES, bool MULTI = false>
 // narrow tiles: at most 128 registers, i.e. four workgroups per CU -- with three, the 782 workgroups of a 100k-row input no longer
 // fit the 768 slots of the chip in one round
 __global__ __launch_bounds__(64 * WAVES, NACC <= 2 ? 4 : 2) void linear_fwd_mfma(const float *__restrict__ x, int64_t N, int d,
                                                        const float *__restrict__ W, const float *__restrict__ b,
-                                                       int out, int w_layout, int act, float *__restrict__ y) {
+                                                       int out, int w_layout, int act, float *__restrict__ y, LinSegs segs) {
     constexpr int BN = 32 * NACC, BM = 32 * WAVES, NT = 64 * WAVES;   // small N: fewer rows per workgroup, more workgroups
     // K-block: one block of MFMAs must last longer than an HBM round trip for the register prefetch of the next block to
     // hide it (32 steps x 2 accumulators x 64 cycles = 1.7 us); the wide tile keeps 32 (static LDS limit)
@@ -54,8 +63,7 @@ __global__ __launch_bounds__(64 * WAVES, NACC <= 2 ? 4 : 2) void linear_fwd_mfma
     constexpr int XQ = BM * BK / 4 / NT;                        // float4 per thread and K-block (x tile)
     constexpr int WQ = BN * BK / NT;                            // floats per thread and K-block (W tile)
     float4 xr[XQ];
-    float wr[WQ];
-    float wm[WQ];                                                // 0/1 masks of the W tile
+    float wr[WQ];                                                // (validity of a W element is recomputed from its indices at the LDS write)
     unsigned xm[XQ];                                             // per-element validity bits of the x tile
     // Loads are UNCONDITIONAL (clamped addresses) and their values are NOT touched here: the 0/1 masks are applied when the
     // registers are written to LDS, one K-block later.  (Multiplying by the mask right after the load -- or predicating the
@@ -97,7 +105,6 @@ __global__ __launch_bounds__(64 * WAVES, NACC <= 2 ? 4 : 2) void linear_fwd_mfma
             const int gj = n0 + j, gk = k0 + c;
             const int gjc = gj < out ? gj : out - 1, gkc = gk < d ? gk : d - 1;
             wr[q] = W[w_layout == 0 ? (int64_t)gjc * d + gkc : (int64_t)gkc * out + gjc];
-            wm[q] = (gj < out && gk < d) ? 1.0f : 0.0f;
         }
     };
     // bias of this lane's columns, fetched before the K loop so that the epilogue has no load to wait for (a wait on a load
@@ -121,8 +128,8 @@ __global__ __launch_bounds__(64 * WAVES, NACC <= 2 ? 4 : 2) void linear_fwd_mfma
 #pragma unroll
         for (int q = 0; q < WQ; q++) {
             const int e = tid + q * NT;
-            const int off = w_layout == 0 ? (e / BK) * LDP + e % BK : (e % BN) * LDP + e / BN;
-            ws[off] = wm[q] != 0.0f ? wr[q] : 0.0f;
+            const int j = w_layout == 0 ? e / BK : e % BN, c = w_layout == 0 ? e % BK : e / BN;
+            ws[j * LDP + c] = (n0 + j < out && k0 + c < d) ? wr[q] : 0.0f;
         }
         __syncthreads();
         if (k0 + BK < d) load_block(k0 + BK);                    // in flight during the MFMAs below
@@ -138,12 +145,29 @@ __global__ __launch_bounds__(64 * WAVES, NACC <= 2 ? 4 : 2) void linear_fwd_mfma
         }
     }
     const bool hasb = b != nullptr;
-    auto finish = [&](float v, float bias) {
+    auto finish_act = [&](float v, float bias, int actv) {
         const float vb = __fadd_rn(v, bias);
         v = hasb ? vb : v;
         const float lk = v > 0.0f ? v : __fmul_rn(0.01f, v), rl = v > 0.0f ? v : 0.0f;
-        return act == 1 ? lk : (act == 2 ? rl : v);
+        return actv == 1 ? lk : (actv == 2 ? rl : v);
     };
+    auto finish = [&](float v, float bias) { return finish_act(v, bias, act); };
+    if constexpr (MULTI) {
+        // out is a multiple of 32 * NACC here (host-checked), so only the row edge needs predicates
+        const bool full = m0 + BM <= N;
+#pragma unroll
+        for (int a = 0; a < NACC; a++) {
+            const int cb = n0 / 32 + a;
+            float *yb = segs.y[cb] + (m0 + wave * 32 + 4 * hh) * (int64_t)segs.ld[cb] + li;
+            const int av = segs.act[cb];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2);
+                if (full || m0 + wave * 32 + 4 * hh + row < N) yb[(int64_t)row * segs.ld[cb]] = finish_act(acc[a][r], bj[a], av);
+            }
+        }
+        return;
+    }
     // Interior tiles (all but the last row / column block) store without per-element predicates: a predicated store is a
     // branch, and after every branch the compiler re-waits for ALL outstanding memory operations -- earlier stores included --
     // which serialises the 16 * NACC stores of a wavefront.
@@ -311,10 +335,124 @@ __global__ __launch_bounds__(256) void gemm_tn_persist(const float *__restrict__
     }
 }
 
+// Several weight gradients that share the streamed operand B (= the layer input X) in ONE pass:
+//   C_s[M1_s, M2] += (A_s * act_s'(Y_s))^T B   for s = 0..nseg-1   (node_encode_for_edges, node_encode_for_k, GCNConv weight:
+// autograd of dgm.py:1097-1100, 1123-1126 and model.py:596 -- three GEMMs over the same 51 MB of node features).
+// blockIdx.x enumerates (row stream g, 32-column block yb of the concatenated A operands); the mapping keeps the blocks of one
+// row stream on ONE XCD (block ids that differ by multiples of 8 share an XCD's L2) and adjacent in dispatch order, so the rows
+// of B leave the fabric once and the other yb blocks hit them in L2.  Structure otherwise as gemm_tn_persist<1, NB>.
+struct TnSegs {
+    const float *A[8];     // per column block: operand, the forward output that carries its activation mask (or NULL),
+    const float *Y[8];
+    int ld[8];             // row stride of the operand (its M1),
+    int o0[8];             // first column of this block inside the operand,
+    int act[8];            // activation of the forward (0 none, 1 LeakyReLU, 2 ReLU)
+    int nyb;
+};
+template <int NB, int PF>
+__global__ __launch_bounds__(256) void gemm_tn_multi(TnSegs segs, const float *__restrict__ B, int64_t N, int M2, int M2p, int G,
+                                                     float *__restrict__ slab, float *__restrict__ cs_slab) {
+    extern __shared__ float red[];                               // [NB*16*64] + [64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, hh = lane >> 5;
+    const int nyb = segs.nyb;
+    const int bid = blockIdx.x, tt = bid / (8 * nyb), rem = bid % (8 * nyb);
+    const int yb = rem / 8, g = tt * 8 + (rem % 8);
+    if (g >= G) return;
+    const float *__restrict__ A = segs.A[yb];
+    const float *__restrict__ Yact = segs.Y[yb];
+    const int M1 = segs.ld[yb], act = Yact ? segs.act[yb] : 0;
+    const int64_t acol = segs.o0[yb] + li < M1 ? segs.o0[yb] + li : M1 - 1;
+    int64_t bcol[NB];
+#pragma unroll
+    for (int a = 0; a < NB; a++) bcol[a] = a * 32 + li < M2 ? a * 32 + li : M2 - 1;
+    f32x16 acc[NB];
+#pragma unroll
+    for (int a = 0; a < NB; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[a][r] = 0.0f;
+    float csum = 0.0f;
+    const int64_t step = (int64_t)G * 4 * 2 * PF;
+    float av[2][PF], bv[2][PF][NB], rmask[2][PF], yv[2][PF];
+    auto load = [&](int buf, int64_t base) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int64_t n = base + 2 * u + hh;
+            const int64_t nc = n < N ? n : N - 1;
+            rmask[buf][u] = n < N ? 1.0f : 0.0f;
+            av[buf][u] = A[nc * M1 + acol];
+            yv[buf][u] = 1.0f;
+#pragma unroll
+            for (int a = 0; a < NB; a++) bv[buf][u][a] = B[nc * M2 + bcol[a]];
+        }
+        if (act != 0) {                                          // block-uniform
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int64_t n = base + 2 * u + hh;
+                yv[buf][u] = Yact[(n < N ? n : N - 1) * M1 + acol];
+            }
+        }
+    };
+    auto mma = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            float am = rmask[buf][u];
+            if (act == 1) am = yv[buf][u] > 0.0f ? am : 0.01f * am;
+            else if (act == 2) am = yv[buf][u] > 0.0f ? am : 0.0f;
+            const float a_ = av[buf][u] * am;
+            csum += a_;
+#pragma unroll
+            for (int a = 0; a < NB; a++) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, bv[buf][u][a], acc[a], 0, 0, 0);
+        }
+    };
+    int64_t base = ((int64_t)g * 4 + wave) * 2 * PF;
+    if (base < N) load(0, base);
+    while (base < N) {
+        if (base + step < N) load(1, base + step);
+        mma(0);
+        base += step;
+        if (base >= N) break;
+        if (base + step < N) load(0, base + step);
+        mma(1);
+        base += step;
+    }
+    float *cred = red + NB * 16 * 64;
+    for (int w = 1; w < 4; w++) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < NB; a++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) red[(a * 16 + r) * 64 + lane] = acc[a][r];
+            cred[lane] = csum;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int a = 0; a < NB; a++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][r] += red[(a * 16 + r) * 64 + lane];
+            csum += cred[lane];
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+    const int M1tp = nyb * 32;
+    float *sl = slab + ((int64_t)g * M1tp + yb * 32) * M2p;
+#pragma unroll
+    for (int a = 0; a < NB; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int go = (r & 3) + 8 * (r >> 2) + 4 * hh, gc = a * 32 + li;
+            if (gc < M2p) sl[(int64_t)go * M2p + gc] = acc[a][r];
+        }
+    const float t = csum + __uint_as_float(dgg::xor_shfl<32>(__float_as_uint(csum), lane));
+    if (hh == 0) cs_slab[(int64_t)g * M1tp + yb * 32 + li] = t;
+}
+
 constexpr int GT_SPLIT = 32;
 __global__ __launch_bounds__(256) void gemm_tn_reduce(const float *__restrict__ slab, const float *__restrict__ cs_slab,
                                                       int nchunks, int M1, int M2, int M1p, int M2p,
-                                                      float *__restrict__ Cout, int c_layout, float *__restrict__ colsum) {
+                                                      float *__restrict__ Cout, int c_layout, float *__restrict__ colsum,
+                                                      int64_t chunk_stride, int64_t cs_stride) {
     const int e = blockIdx.x * 256 + threadIdx.x;                // element of the padded [M1p][M2p] block
     const int per = (nchunks + (int)gridDim.y - 1) / (int)gridDim.y;
     const int k0 = blockIdx.y * per, k1 = k0 + per < nchunks ? k0 + per : nchunks;
@@ -323,14 +461,14 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce(const float *__restrict__ 
         const int o = e / M2p, c = e % M2p;
         if (o < M1 && c < M2) {
             float s = 0.0f;
-            for (int k = k0; k < k1; k++) s += slab[(int64_t)k * M1p * M2p + e];
+            for (int k = k0; k < k1; k++) s += slab[(int64_t)k * chunk_stride + e];
             float *dst = c_layout == 0 ? Cout + (int64_t)o * M2 + c : Cout + (int64_t)c * M1 + o;
             atomicAdd(dst, s);
         }
     }
     if (colsum && cs_slab && e < M1) {
         float s = 0.0f;
-        for (int k = k0; k < k1; k++) s += cs_slab[(int64_t)k * M1p + e];
+        for (int k = k0; k < k1; k++) s += cs_slab[(int64_t)k * cs_stride + e];
         atomicAdd(colsum + e, s);
     }
 }
@@ -341,7 +479,7 @@ void launch_linear_fwd_n(const float *x, int64_t N, int d, const float *W, const
     const unsigned gy = (unsigned)((out + 32 * NACC - 1) / (32 * NACC));
     // 128 rows per workgroup.  (64- and 32-row workgroups -- more workgroups for Pubmed-size inputs -- measured slower:
     // fewer threads then stage the same weight tile per K-block.)
-    hipLaunchKernelGGL((linear_fwd_mfma<NACC, 4>), dim3((unsigned)((N + 127) / 128), gy), dim3(256), 0, st, x, N, d, W, b, out, w_layout, act, y);
+    hipLaunchKernelGGL((linear_fwd_mfma<NACC, 4>), dim3((unsigned)((N + 127) / 128), gy), dim3(256), 0, st, x, N, d, W, b, out, w_layout, act, y, LinSegs{});
 }
 
 int launch_linear_fwd(const float *x, int64_t N, int d, const float *W, const float *b, int out, int w_layout, int act,
@@ -350,6 +488,12 @@ int launch_linear_fwd(const float *x, int64_t N, int d, const float *W, const fl
     else if (out <= 64) launch_linear_fwd_n<2>(x, N, d, W, b, out, w_layout, act, y, st);
     else launch_linear_fwd_n<4>(x, N, d, W, b, out, w_layout, act, y, st);
     return dgg_check_launch("linear_fwd");
+}
+
+template <int NACC>
+void launch_linear_fwd_multi_n(const float *x, int64_t N, int d, const float *W, const float *b, int out, const LinSegs &segs, hipStream_t st) {
+    hipLaunchKernelGGL((linear_fwd_mfma<NACC, 4, true>), dim3((unsigned)((N + 127) / 128), (unsigned)(out / (32 * NACC))), dim3(256), 0, st, x, N,
+                       d, W, b, out, 0, 0, nullptr, segs);
 }
 
 // block shape per wavefront and the number of row-streaming workgroups per output block: the tiny weights of the hot
@@ -414,7 +558,7 @@ int launch_gemm_tn(const float *A, const float *B, int64_t N, int M1, int M2, fl
     int split = (M1p * M2p >= 16384) ? (g + 7) / 8 : g;
     split = split < 1 ? 1 : (split > GT_SPLIT ? GT_SPLIT : split);
     hipLaunchKernelGGL(gemm_tn_reduce, dim3((unsigned)((M1p * M2p + 255) / 256), (unsigned)split), dim3(256), 0, st, slab, csl, g, M1,
-                       M2, M1p, M2p, C, c_layout, colsum);
+                       M2, M1p, M2p, C, c_layout, colsum, (int64_t)M1p * M2p, (int64_t)M1p);
     return dgg_check_launch("gemm_tn");
 }
 
@@ -427,6 +571,40 @@ int dgg_linear_fwd(const float *x, int64_t N, int d, const float *W, const float
     if (N < 0 || d < 1 || out < 1) return dgg_set_error(DGG_ERR_ARG, "linear_fwd: bad shape");
     if (N == 0) return 0;
     return launch_linear_fwd(x, N, d, W, b, out, w_layout, act, y, (hipStream_t)stream);
+}
+
+// Several layers on one input, X read once: Wcat [sum out_s, d] / bcat [sum out_s] (nullable) = the layers' nn.Linear weights
+// (layout 0) stacked by rows; layer s has out_s outputs (a multiple of 32; sum <= 256), activation act_s and destination
+// y_s [N, out_s].  Bit-identical to nseg calls of dgg_linear_fwd (same k-ordered fmaf chains).
+int dgg_linear_fwd_multi(const float *x, int64_t N, int d, const float *Wcat, const float *bcat, int nseg, const int *seg_out,
+                         const int *seg_act, float *const *y, void *stream) {
+    if (N < 0 || d < 1 || nseg < 1 || nseg > 8) return dgg_set_error(DGG_ERR_ARG, "linear_fwd_multi: bad shape");
+    LinSegs segs{};
+    int cb = 0;
+    for (int sgi = 0; sgi < nseg; sgi++) {
+        if (seg_out[sgi] < 32 || seg_out[sgi] % 32 != 0 || cb + seg_out[sgi] / 32 > 8)
+            return dgg_set_error(DGG_ERR_UNSUPPORTED, "linear_fwd_multi: layer widths must be multiples of 32 with a total of at most 256");
+        for (int q = 0; q < seg_out[sgi] / 32; q++, cb++) {
+            segs.y[cb] = y[sgi] + q * 32;
+            segs.ld[cb] = seg_out[sgi];
+            segs.act[cb] = seg_act[sgi];
+        }
+    }
+    if (cb == 7) return dgg_set_error(DGG_ERR_UNSUPPORTED, "linear_fwd_multi: 7 column blocks (224 outputs) are not tiled");
+    if (N == 0) return 0;
+    const int out = cb * 32;
+    hipStream_t st = (hipStream_t)stream;
+    // one workgroup computes ALL columns of its 128 rows whenever the accumulators fit (<= 6 blocks): X is then read once
+    switch (cb) {
+        case 1: launch_linear_fwd_multi_n<1>(x, N, d, Wcat, bcat, out, segs, st); break;
+        case 2: launch_linear_fwd_multi_n<2>(x, N, d, Wcat, bcat, out, segs, st); break;
+        case 3: launch_linear_fwd_multi_n<3>(x, N, d, Wcat, bcat, out, segs, st); break;
+        case 4: launch_linear_fwd_multi_n<4>(x, N, d, Wcat, bcat, out, segs, st); break;
+        case 5: launch_linear_fwd_multi_n<5>(x, N, d, Wcat, bcat, out, segs, st); break;
+        case 6: launch_linear_fwd_multi_n<6>(x, N, d, Wcat, bcat, out, segs, st); break;
+        default: launch_linear_fwd_multi_n<4>(x, N, d, Wcat, bcat, out, segs, st); break;   // 8 blocks = two column tiles of 4
+    }
+    return dgg_check_launch("linear_fwd_multi");
 }
 
 // floats of workspace dgg_linear_bwd needs: N*out for the activation backward + the weight-gradient slab
@@ -465,6 +643,59 @@ int dgg_act_bwd(const float *y, const float *dy, int64_t n, int act, float *dp, 
     const unsigned blocks = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, dy, n, act, dp);
     return dgg_check_launch("act_bwd");
+}
+
+// nseg weight gradients over one streamed input (see gemm_tn_multi): C_s (c_layout_s 0: [M1_s][M2], 1: [M2][M1_s]) and colsum_s
+// (nullable: bias gradient) are ACCUMULATED into (caller zeroes).  M1_s multiples of 32 with a total of at most 256, M2 <= 128.
+// Y_s (nullable) / act_s: the forward output and activation whose derivative masks A_s on the fly.
+// ws: dgg_gemm_tn_multi_ws_floats(N, total M1, M2) floats.
+size_t dgg_gemm_tn_multi_ws_floats(int64_t N, int M1_total, int M2) {
+    const size_t M2p = (size_t)(M2 + 31) / 32 * 32;
+    return (size_t)128 * ((size_t)M1_total * M2p + (size_t)M1_total);
+}
+int dgg_gemm_tn_multi(int nseg, const float *const *A, const int *M1, const float *const *Y, const int *act, const float *B, int64_t N,
+                      int M2, float *const *C, const int *c_layout, float *const *colsum, float *ws, void *stream) {
+    if (nseg < 1 || nseg > 8 || M2 < 1 || M2 > 128) return dgg_set_error(DGG_ERR_UNSUPPORTED, "gemm_tn_multi: 1..8 operands, M2 <= 128");
+    if (!ws) return dgg_set_error(DGG_ERR_ARG, "gemm_tn_multi: workspace is NULL (dgg_gemm_tn_multi_ws_floats)");
+    TnSegs segs{};
+    int yb = 0;
+    for (int sgi = 0; sgi < nseg; sgi++) {
+        if (M1[sgi] < 32 || M1[sgi] % 32 != 0 || yb + M1[sgi] / 32 > 8)
+            return dgg_set_error(DGG_ERR_UNSUPPORTED, "gemm_tn_multi: operand widths must be multiples of 32 with a total of at most 256");
+        for (int q = 0; q < M1[sgi] / 32; q++, yb++) {
+            segs.A[yb] = A[sgi];
+            segs.Y[yb] = Y ? Y[sgi] : nullptr;
+            segs.ld[yb] = M1[sgi];
+            segs.o0[yb] = q * 32;
+            segs.act[yb] = act ? act[sgi] : 0;
+        }
+    }
+    segs.nyb = yb;
+    if (N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int M2p = (M2 + 31) / 32 * 32, M1tp = yb * 32;
+    constexpr int PF = 4;
+    int G = 128;                                                 // row streams (a multiple of 8): G * nyb workgroups
+    const int64_t need = (N + 4 * 2 * PF - 1) / (4 * 2 * PF);
+    while (G > 8 && G / 2 >= need) G /= 2;
+    float *slab = ws, *cs_slab = ws + (size_t)G * M1tp * M2p;
+    const unsigned grid = (unsigned)(G * yb);
+    const int nb = M2p / 32 == 3 ? 4 : M2p / 32;
+    const size_t lds = (size_t)(nb * 16 * 64 + 64) * sizeof(float);
+    if (nb == 4) hipLaunchKernelGGL((gemm_tn_multi<4, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);
+    else if (nb == 2) hipLaunchKernelGGL((gemm_tn_multi<2, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);
+    else hipLaunchKernelGGL((gemm_tn_multi<1, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);
+    int rb = 0;
+    for (int sgi = 0; sgi < nseg; sgi++) {
+        int split = (M1[sgi] * M2p >= 16384) ? (G + 7) / 8 : G;
+        split = split < 1 ? 1 : (split > GT_SPLIT ? GT_SPLIT : split);
+        float *cs = colsum ? colsum[sgi] : nullptr;
+        hipLaunchKernelGGL(gemm_tn_reduce, dim3((unsigned)((M1[sgi] * M2p + 255) / 256), (unsigned)split), dim3(256), 0, st,
+                           slab + (size_t)rb * M2p, cs ? cs_slab + rb : nullptr, G, M1[sgi], M2, M1[sgi], M2p, C[sgi], c_layout[sgi], cs,
+                           (int64_t)M1tp * M2p, (int64_t)M1tp);
+        rb += M1[sgi];
+    }
+    return dgg_check_launch("gemm_tn_multi");
 }
 
 // C[M1,M2] += A[N,M1]^T B[N,M2]  (c_layout 1: C stored [M2][M1]); colsum (nullable, [M1]) += column sums of A;

@@ -38,11 +38,35 @@ inline PartHdr part_layout(void *ws, int64_t nb, int64_t nrec) {
     return p;
 }
 
+// PAYLOAD partition (dgg_partp_*): 16-byte records (src = row*64 + r, dst = j, wa = w_ir * rs_i^-1/2, score val_ir) and NO slot
+// map.  With the two per-entry scalars in the record, every column-walking kernel of the backward forms what it needs from
+// its own coalesced record stream: ahat_ir = wa * rs_j^-1/2 (conv_bwd_cols_p) and d loss / d dist (edge_bwd_cols_p, which
+// recomputes the ramp / normalisation chain from dA in record order) -- no per-entry random 4-byte gather of ahat, no
+// per-entry scattered write of a coefficient, no slot map to build.  The one remaining crossing between row order and
+// record order is dA (written row-major by conv_bwd_cols_p for the row kernel).
+struct PartPHdr {                  // workspace: [bstart NB+1][cursor NB][nodeptr NB*BS+1][tmp rows*K int4][recs rows*K int4]
+    int *bstart, *cursor;
+    int *nodeptr;                  // CSC pointer: the records of destination node j are recs[nodeptr[j] .. nodeptr[j+1])
+    int4 *tmp, *recs;
+};
+inline PartPHdr partp_layout(void *ws, int64_t nb, int64_t nrec) {
+    char *w = reinterpret_cast<char *>(ws);
+    PartPHdr p;
+    p.bstart = reinterpret_cast<int *>(w);
+    p.cursor = reinterpret_cast<int *>(w + align256((size_t)(nb + 1) * 4));
+    p.nodeptr = reinterpret_cast<int *>(reinterpret_cast<char *>(p.cursor) + align256((size_t)nb * 4));
+    p.tmp = reinterpret_cast<int4 *>(reinterpret_cast<char *>(p.nodeptr) + align256((size_t)(nb * BS + 1) * 4));
+    p.recs = reinterpret_cast<int4 *>(reinterpret_cast<char *>(p.tmp) + align256((size_t)nrec * sizeof(int4)));
+    return p;
+}
+
 // pass 1 (FILL = false): per-bucket totals.  pass 2 (FILL = true): bucket-sorted records (src = row*64 + r, dst = j)
-template <bool FILL>
+// PAY: 16-byte payload records (val, rs_rows give the payload; no slot map)
+template <bool FILL, bool PAY = false>
 __global__ __launch_bounds__(256) void part_pass(const int32_t *__restrict__ idx, const float *__restrict__ w, int64_t rows,
                                                  int K, int nb, int *__restrict__ gcount, int2 *__restrict__ recs,
-                                                 int *__restrict__ slotmap) {
+                                                 int *__restrict__ slotmap, const float *__restrict__ val = nullptr,
+                                                 const float *__restrict__ rs_rows = nullptr, int4 *__restrict__ recs4 = nullptr) {
     extern __shared__ int lds[];                                 // hist[nb] (+ base[nb] when filling)
     int *hist = lds, *base = lds + nb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -99,8 +123,15 @@ __global__ __launch_bounds__(256) void part_pass(const int32_t *__restrict__ idx
             if (jj[u] >= 0) {
                 const int b = jj[u] / BS;
                 const int slot = base[b] + atomicAdd(&hist[b], 1);
-                recs[slot] = make_int2((int)(i * 64 + lane), jj[u]);
-            } else if (jj[u] == -1) {
+                if (PAY) {
+                    // wa = a_i * w exactly as normalize_fwd_kernel forms it (dgg_ell.hip), so that wa * a_j == ahat bit for bit
+                    const float ai = __fdiv_rn(1.0f, c_sqrt(rs_rows[i]));
+                    const float wa = __fmul_rn(ai, w[i * K + lane]);
+                    recs4[slot] = make_int4((int)(i * 64 + lane), jj[u], (int)__float_as_uint(wa), (int)__float_as_uint(val[i * K + lane]));
+                } else {
+                    recs[slot] = make_int2((int)(i * 64 + lane), jj[u]);
+                }
+            } else if (!PAY && jj[u] == -1) {
                 slotmap[i * K + lane] = -1;                      // active entries: written by part_sort
             }
         }
@@ -141,6 +172,41 @@ __global__ __launch_bounds__(1024) void part_sort(const int *__restrict__ bstart
     }
 }
 
+// pass 3 for payload records: same counting sort, 16-byte records, no slot map
+__global__ __launch_bounds__(1024) void part_sort_p(const int *__restrict__ bstart, const int4 *__restrict__ tmp, int4 *__restrict__ recs,
+                                                   int *__restrict__ nodeptr, int nb) {
+    __shared__ int cnt[BS], base[BS];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int e0 = bstart[b], e1 = bstart[b + 1];
+    if (tid < BS) cnt[tid] = 0;
+    __syncthreads();
+    for (int e = e0 + tid; e < e1; e += 1024) atomicAdd(&cnt[tmp[e].y - b * BS], 1);
+    __syncthreads();
+    if (tid < 64) {
+        const int c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
+        int incl = c0 + c1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (tid >= off) incl += v;
+        }
+        base[2 * tid] = incl - c0 - c1;
+        base[2 * tid + 1] = incl - c1;
+    }
+    __syncthreads();
+    if (tid < BS) {
+        nodeptr[b * BS + tid] = e0 + base[tid];
+        cnt[tid] = 0;
+    }
+    if (b == nb - 1 && tid == 0) nodeptr[nb * BS] = e1;
+    __syncthreads();
+    for (int e = e0 + tid; e < e1; e += 1024) {
+        const int4 rec = tmp[e];
+        const int jl = rec.y - b * BS;
+        recs[e0 + base[jl] + atomicAdd(&cnt[jl], 1)] = rec;
+    }
+}
+
 // exclusive scan of the bucket totals (single workgroup): bstart[0..nb], cursor[b] = bstart[b]
 __global__ __launch_bounds__(1024) void part_scan(int *__restrict__ bstart, int *__restrict__ cursor, int nb) {
     __shared__ int part[1024];
@@ -178,8 +244,10 @@ struct SoftkArgs {
     // ahat_rows != NULL: `da` holds only the NEIGHBOUR-side sums (conv_bwd_cols); the row side
     // da_i += sum_r dA_ir w_ir a_j = sqrt(rs_i) sum_r dA_ir ahat_ir is added here, in registers
     const float *ahat_rows;
+    // payload partition: no slot map, no coefficient hand-over; instead (a_i, d loss / d rs_i, k_i, 0) per row for edge_bwd_cols_p
+    float4 *rowinfo;
 };
-template <int H, bool FUSE>
+template <int H, bool FUSE, bool PAY = false>
 __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ xp, int64_t rows, const int32_t *__restrict__ idx,
                                                      const float *__restrict__ val, const float *__restrict__ dval, int K,
                                                      int64_t row0, float t, int perturb, const int *__restrict__ slotmap,
@@ -208,6 +276,9 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
             }
             const float drs = -0.5f * dai * ai / rsi;
             dw = dw * ai * aj + drs;
+            if (PAY && lane == 0) sk.rowinfo[i] = make_float4(ai, drs, sk.k[i], 0.0f);
+        } else if (PAY && lane == 0) {
+            sk.rowinfo[i] = make_float4(1.0f, 0.0f, sk.k[i], 0.0f);
         }
         const float th = c_tanh((float)lane - sk.k[i]);
         const float f = 1.0f - 0.5f * (1.0f + th);
@@ -265,11 +336,13 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
                 dd = dp * t * p / dist;
             }
             acc.x += dd * d.x; acc.y += dd * d.y; acc.z += dd * d.z; acc.w += dd * d.w;
-            // hand the coefficient to the lane that owns entry r (lane r): gather from the first lane of each slot
+            if (!PAY) {
+                // hand the coefficient to the lane that owns entry r (lane r): gather from the first lane of each slot
 #pragma unroll
-            for (int s2 = 0; s2 < NPI; s2++) {
-                const float cs = bcast(dd, s2 * LPR);
-                if (lane == r0 + b * NPI + s2) mycoef = cs;
+                for (int s2 = 0; s2 < NPI; s2++) {
+                    const float cs = bcast(dd, s2 * LPR);
+                    if (lane == r0 + b * NPI + s2) mycoef = cs;
+                }
             }
         }
     }
@@ -280,7 +353,7 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
         acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
     }
     if (slot == 0) *reinterpret_cast<float4 *>(dxp + gi * H + 4 * c4) = acc;
-    if (lane < K) {
+    if (!PAY && lane < K) {
         const int sl = slotmap[i * K + lane];
         if (sl >= 0) coef[sl] = mycoef;                          // record order
     }
@@ -511,6 +584,332 @@ __global__ __launch_bounds__(256) void conv_bwd_cols(const float *__restrict__ G
     flush();
 }
 
+// ---- the same on PAYLOAD records (see PartPHdr): ahat_ir = wa * rs_j^-1/2 comes from the record, dA is also written in record
+// order (coalesced) for edge_bwd_cols_p ------------------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(256) void conv_bwd_cols_p(const float *__restrict__ G, const float *__restrict__ Hm, int K,
+                                                       const int *__restrict__ bstart, int nb, const int4 *__restrict__ recs,
+                                                       const float *__restrict__ rs, float *__restrict__ dA,
+                                                       float *__restrict__ dA_rec, float *__restrict__ dH, float *__restrict__ da) {
+    constexpr int LPR = F / 4;
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, gbase = lane - c4;
+    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int nnz = bstart[nb];
+    const int64_t cbeg = gid * CH;
+    if (cbeg >= nnz) return;
+    const int cend = cbeg + CH < nnz ? (int)cbeg + CH : nnz;
+    int cur = -1;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float sda = 0.0f, aj = 0.0f, rscur = 1.0f;
+    const int shared_lo = cbeg > 0 ? recs[cbeg - 1].y : -1, shared_hi = cend < nnz ? recs[cend].y : -1;   // see edge_bwd_cols
+    auto flush = [&]() {
+        if (cur >= 0) {
+            float *o = dH + (int64_t)cur * F + 4 * c4;
+            const bool shared = cur == shared_lo || cur == shared_hi;
+            if (shared) {
+                atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
+            } else {
+                float4 v = *reinterpret_cast<float4 *>(o);
+                v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += acc.w;
+                *reinterpret_cast<float4 *>(o) = v;
+            }
+            if (da && c4 == 0) {
+                const float v = sda * sqrtf(rscur);
+                if (shared) atomicAdd(da + cur, v);
+                else da[cur] += v;
+            }
+        }
+    };
+    for (int eb = (int)cbeg; eb < cend; eb += LPR) {
+        const int e = eb + c4;
+        const int4 myrec = e < cend ? recs[e] : make_int4(0, -1, 0, 0);
+        float mydot = 0.0f;
+#pragma unroll
+        for (int u0 = 0; u0 < LPR; u0 += 4) {
+            int src[4], dst[4];
+            float wa[4], rsj[4];
+            float4 g[4], hj[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                src[u] = __shfl(myrec.x, gbase + u0 + u, 64);
+                dst[u] = __shfl(myrec.y, gbase + u0 + u, 64);
+                wa[u] = __int_as_float(__shfl(myrec.z, gbase + u0 + u, 64));
+                const int64_t dj = dst[u] < 0 ? 0 : dst[u];
+                // all unconditional (padding records: row 0 / node 0): the H_j line and rs_j are the same for a whole run of
+                // records, i.e. L1 hits after the run's first record
+                g[u] = *reinterpret_cast<const float4 *>(G + (int64_t)(src[u] >> 6) * F + 4 * c4);
+                hj[u] = *reinterpret_cast<const float4 *>(Hm + dj * F + 4 * c4);
+                rsj[u] = rs[dj];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                float dot = g[u].x * hj[u].x;
+                dot = fmaf(g[u].y, hj[u].y, dot); dot = fmaf(g[u].z, hj[u].z, dot); dot = fmaf(g[u].w, hj[u].w, dot);
+                if (LPR > 16) dot += __uint_as_float(xor_shfl<16>(__float_as_uint(dot), lane));
+                if (LPR > 8) dot += __uint_as_float(xor_shfl<8>(__float_as_uint(dot), lane));
+                if (LPR > 4) dot += __uint_as_float(xor_shfl<4>(__float_as_uint(dot), lane));
+                dot += __uint_as_float(xor_shfl<2>(__float_as_uint(dot), lane));
+                dot += __uint_as_float(xor_shfl<1>(__float_as_uint(dot), lane));
+                if (dst[u] < 0) continue;
+                if (dst[u] != cur) {
+                    flush();
+                    cur = dst[u];
+                    acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    sda = 0.0f;
+                    rscur = rsj[u];
+                    aj = __fdiv_rn(1.0f, c_sqrt(rscur));         // as normalize_fwd_kernel: wa * aj == ahat bit for bit
+                }
+                const float cf = __fmul_rn(wa[u], aj);
+                if (c4 == 0) dA[(int64_t)(src[u] >> 6) * K + (src[u] & 63)] = dot;
+                if (c4 == u0 + u) mydot = dot;
+                acc.x = fmaf(cf, g[u].x, acc.x); acc.y = fmaf(cf, g[u].y, acc.y);
+                acc.z = fmaf(cf, g[u].z, acc.z); acc.w = fmaf(cf, g[u].w, acc.w);
+                sda = fmaf(dot, cf, sda);
+            }
+        }
+        if (e < cend) dA_rec[e] = mydot;
+    }
+    flush();
+}
+
+// ---- score backward, column side, on payload records: d loss / d dist is RECOMPUTED here from dA in record order ------------
+// For record e = (i, r) -> j the lane that loaded it forms, for ITS record (16 records per group in parallel),
+//     dw = dA_e a_i a_j + drs_i,  dval = dw * ramp(r - k_i)                 (softk_bwd_kernel, dgg_ell.hip; dgm.py:1410-1420)
+// from the per-row scalars (a_i, drs_i, k_i) that edge_bwd_rows<PAY> left in rowinfo; the distance part
+//     dd = dval [v / (p + 1e-8)] t p / dist,  p = exp(t dist)               (autograd of dgm.py:1213-1229, 1618-1623)
+// needs the gathered row xp_i and the run's xp_j (L1 hit).  acc_j = sum_e dd_e (xp_j - xp_i).
+template <int H>
+__global__ __launch_bounds__(256) void edge_bwd_cols_p(const float *__restrict__ xp, const int *__restrict__ bstart, int nb,
+                                                       const int4 *__restrict__ recs, const float *__restrict__ dA_rec,
+                                                       const float4 *__restrict__ rowinfo, const float *__restrict__ rs,
+                                                       int normalized, int64_t row0, float t, int perturb, float *__restrict__ dxp) {
+    constexpr int LPR = H / 4;
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, gbase = lane - c4;
+    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int nnz = bstart[nb];
+    const int64_t cbeg = gid * CH;
+    if (cbeg >= nnz) return;
+    const int cend = cbeg + CH < nnz ? (int)cbeg + CH : nnz;
+    int cur = -1;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int shared_lo = cbeg > 0 ? recs[cbeg - 1].y : -1, shared_hi = cend < nnz ? recs[cend].y : -1;   // see edge_bwd_cols
+    auto flush = [&]() {
+        if (cur >= 0) {
+            float *o = dxp + (int64_t)cur * H + 4 * c4;
+            if (cur == shared_lo || cur == shared_hi) {
+                atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
+            } else {
+                float4 v = *reinterpret_cast<float4 *>(o);
+                v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += acc.w;
+                *reinterpret_cast<float4 *>(o) = v;
+            }
+        }
+    };
+    for (int eb = (int)cbeg; eb < cend; eb += LPR) {
+        const int e = eb + c4;
+        const bool have = e < cend;
+        const int4 myrec = have ? recs[e] : make_int4(0, -1, 0, 0);
+        // this lane's own record: d loss / d score (unconditional loads; clamped)
+        const float4 info = rowinfo[myrec.x >> 6];
+        const float rsj = rs[myrec.y < 0 ? 0 : myrec.y];
+        float mydval = have ? dA_rec[e] : 0.0f;
+        {
+            const float aj = normalized ? __fdiv_rn(1.0f, c_sqrt(rsj)) : 1.0f;
+            const float dw = mydval * info.x * aj + info.y;
+            const float th = c_tanh((float)(myrec.x & 63) - info.z);
+            mydval = have ? dw * (1.0f - 0.5f * (1.0f + th)) : 0.0f;
+        }
+#pragma unroll
+        for (int u0 = 0; u0 < LPR; u0 += 4) {
+            int src[4], dst[4];
+            float gv[4], vv[4];
+            float4 xi[4], xj[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                src[u] = __shfl(myrec.x, gbase + u0 + u, 64);
+                dst[u] = __shfl(myrec.y, gbase + u0 + u, 64);
+                gv[u] = __shfl(mydval, gbase + u0 + u, 64);
+                vv[u] = __int_as_float(__shfl(myrec.w, gbase + u0 + u, 64));
+                xi[u] = *reinterpret_cast<const float4 *>(xp + (row0 + (src[u] >> 6)) * H + 4 * c4);          // unconditional
+                xj[u] = *reinterpret_cast<const float4 *>(xp + (int64_t)(dst[u] < 0 ? 0 : dst[u]) * H + 4 * c4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float4 d = make_float4(xi[u].x - xj[u].x, xi[u].y - xj[u].y, xi[u].z - xj[u].z, xi[u].w - xj[u].w);
+                float d2 = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+                if (LPR > 16) d2 += __uint_as_float(xor_shfl<16>(__float_as_uint(d2), lane));
+                if (LPR > 8) d2 += __uint_as_float(xor_shfl<8>(__float_as_uint(d2), lane));
+                if (LPR > 4) d2 += __uint_as_float(xor_shfl<4>(__float_as_uint(d2), lane));
+                d2 += __uint_as_float(xor_shfl<2>(__float_as_uint(d2), lane));
+                d2 += __uint_as_float(xor_shfl<1>(__float_as_uint(d2), lane));
+                if (dst[u] < 0) continue;
+                if (dst[u] != cur) {
+                    flush();
+                    cur = dst[u];
+                    acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+                float dd = 0.0f;
+                if (gv[u] != 0.0f && d2 != 0.0f) {               // vector_norm backward at 0 is 0 (self loop)
+                    const float dist = sqrtf(d2);
+                    const float p = c_exp(t * dist);
+                    const float dp = perturb ? gv[u] * vv[u] / (p + 1e-8f) : gv[u];
+                    dd = dp * t * p / dist;
+                }
+                acc.x -= dd * d.x; acc.y -= dd * d.y; acc.z -= dd * d.z; acc.w -= dd * d.w;
+            }
+        }
+    }
+    flush();
+}
+
+// ---- one wavefront per DESTINATION node (CSC walk of the payload records) ------------------------------------------------
+// The chunked kernels above keep ~100 registers of run-tracking state per lane, i.e. 4 wavefronts per SIMD and ~64 KB of
+// gathers in flight per CU; a gather from the Infinity Cache needs about twice that to reach its ceiling (the 38-register
+// spmm_fwd_narrow runs at 8 TB/s).  With the CSC pointer of the payload partition a wavefront owns ALL records of one
+// destination j: H_j / xp_j are loaded once, there is no run logic, the sums are plain stores (no atomics, no zero fill for
+// dH / da), and the kernel has the shape of the forward SpMM: F/4 lanes per record, 256/F records per wave-instruction,
+// NBT batches in flight.  (In-degree skew: a node with thousands of incoming edges is walked by one wavefront.)
+template <int F>
+__global__ __launch_bounds__(256) void conv_bwd_node(const float *__restrict__ G, const float *__restrict__ Hm, int K, int64_t ncols,
+                                                     const int *__restrict__ nodeptr, const int4 *__restrict__ recs,
+                                                     const float *__restrict__ rs, float *__restrict__ dA, float *__restrict__ dA_rec,
+                                                     float *__restrict__ dH, float *__restrict__ da) {
+    constexpr int LPR = F / 4, NPI = 64 / LPR, NBT = 4, PER = NBT * NPI;          // PER records per iteration (<= 64)
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= ncols) return;
+    const int p0 = nodeptr[j], p1 = nodeptr[j + 1];
+    const float4 hj = *reinterpret_cast<const float4 *>(Hm + j * F + 4 * c4);
+    const float rsj = rs[j];
+    const float aj = __fdiv_rn(1.0f, c_sqrt(rsj));                // as normalize_fwd_kernel: wa * aj == ahat bit for bit
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float sda = 0.0f;
+    for (int e0 = p0; e0 < p1; e0 += PER) {
+        // lane l: record e0 + l (unconditional, clamped load; a lane past the node's range marks its copy invalid)
+        const bool have = lane < PER && e0 + lane < p1;
+        int4 myrec = recs[have ? e0 + lane : p1 - 1];
+        if (!have) myrec.y = -1;
+        int src[NBT];
+        float cf[NBT];
+        float4 g[NBT];
+#pragma unroll
+        for (int b = 0; b < NBT; b++) {
+            const int q = b * NPI + slot;                        // record of this lane's group in batch b
+            src[b] = __shfl(myrec.x, q, 64);
+            const int dst = __shfl(myrec.y, q, 64);
+            // (every shuffle OUTSIDE the select: `c ? shfl : 0` would run the shuffle under a divergent mask, and a lane that is
+            // masked off there hands 0 to the lanes that read from it)
+            const float wa = __int_as_float(__shfl(myrec.z, q, 64));
+            cf[b] = dst >= 0 ? __fmul_rn(wa, aj) : 0.0f;
+            if (dst < 0) src[b] = -1;
+            g[b] = *reinterpret_cast<const float4 *>(G + (int64_t)(src[b] < 0 ? 0 : (src[b] >> 6)) * F + 4 * c4);   // unconditional
+        }
+        float mydot = 0.0f;
+#pragma unroll
+        for (int b = 0; b < NBT; b++) {
+            float dot = g[b].x * hj.x;
+            dot = fmaf(g[b].y, hj.y, dot); dot = fmaf(g[b].z, hj.z, dot); dot = fmaf(g[b].w, hj.w, dot);
+            if (LPR > 16) dot += __uint_as_float(xor_shfl<16>(__float_as_uint(dot), lane));
+            if (LPR > 8) dot += __uint_as_float(xor_shfl<8>(__float_as_uint(dot), lane));
+            if (LPR > 4) dot += __uint_as_float(xor_shfl<4>(__float_as_uint(dot), lane));
+            dot += __uint_as_float(xor_shfl<2>(__float_as_uint(dot), lane));
+            dot += __uint_as_float(xor_shfl<1>(__float_as_uint(dot), lane));
+            if (src[b] >= 0 && c4 == 0) dA[(int64_t)(src[b] >> 6) * K + (src[b] & 63)] = dot;
+            // back to the lane that loaded the record (lane q = b*NPI + slot): record order, one coalesced store per iteration
+            const float tq = __shfl(dot, (lane % NPI) * LPR, 64);
+            if (lane / NPI == b) mydot = tq;
+            acc.x = fmaf(cf[b], g[b].x, acc.x); acc.y = fmaf(cf[b], g[b].y, acc.y);
+            acc.z = fmaf(cf[b], g[b].z, acc.z); acc.w = fmaf(cf[b], g[b].w, acc.w);
+            sda = fmaf(dot, cf[b], sda);
+        }
+        if (have) dA_rec[e0 + lane] = mydot;
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
+        acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+        sda += __shfl_xor(sda, off, 64);
+    }
+    if (slot == 0) *reinterpret_cast<float4 *>(dH + j * F + 4 * c4) = acc;
+    if (da && lane == 0) da[j] = sda * sqrtf(rsj);
+}
+
+// score backward, column side, one wavefront per destination node (see edge_bwd_cols_p for the arithmetic): the lane that
+// loaded a record forms d loss / d score for it (PER records in parallel), the distance part runs per lane group.
+// dxp_j is the exclusive property of this wavefront: rows inside [row0, row0 + rows) already hold the row-side term written by
+// edge_bwd_rows (read-modify-write), the others are written plainly (no zero fill needed).
+template <int H>
+__global__ __launch_bounds__(256) void edge_bwd_node(const float *__restrict__ xp, int64_t ncols, const int *__restrict__ nodeptr,
+                                                     const int4 *__restrict__ recs, const float *__restrict__ dA_rec,
+                                                     const float4 *__restrict__ rowinfo, const float *__restrict__ rs, int normalized,
+                                                     int64_t row0, int64_t rows, float t, int perturb, float *__restrict__ dxp) {
+    constexpr int LPR = H / 4, NPI = 64 / LPR, NBT = 4, PER = NBT * NPI;
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= ncols) return;
+    const int p0 = nodeptr[j], p1 = nodeptr[j + 1];
+    const float4 xj = *reinterpret_cast<const float4 *>(xp + j * H + 4 * c4);
+    const float aj = normalized ? __fdiv_rn(1.0f, c_sqrt(rs[j])) : 1.0f;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int e0 = p0; e0 < p1; e0 += PER) {
+        const bool have = lane < PER && e0 + lane < p1;
+        const int ec = have ? e0 + lane : p1 - 1;                // unconditional, clamped loads
+        int4 myrec = recs[ec];
+        if (!have) myrec.y = -1;
+        float mydval;
+        {                                                        // d loss / d score of this lane's own record
+            const float4 info = rowinfo[myrec.x >> 6];
+            const float dw = dA_rec[ec] * info.x * aj + info.y;
+            const float th = c_tanh((float)(myrec.x & 63) - info.z);
+            mydval = have ? dw * (1.0f - 0.5f * (1.0f + th)) : 0.0f;
+        }
+        float gv[NBT], vv[NBT];
+        float4 xi[NBT];
+#pragma unroll
+        for (int b = 0; b < NBT; b++) {
+            const int q = b * NPI + slot;
+            const int src = __shfl(myrec.x, q, 64);
+            const int dst = __shfl(myrec.y, q, 64);
+            const float gq = __shfl(mydval, q, 64);             // outside the select (see conv_bwd_node)
+            gv[b] = dst >= 0 ? gq : 0.0f;
+            vv[b] = __int_as_float(__shfl(myrec.w, q, 64));
+            // unconditional gather; an inactive slot re-reads xp_j, whose distance to itself is 0 (dd = 0)
+            xi[b] = *reinterpret_cast<const float4 *>(xp + (dst >= 0 ? row0 + (src >> 6) : j) * H + 4 * c4);
+        }
+#pragma unroll
+        for (int b = 0; b < NBT; b++) {
+            const float4 d = make_float4(xi[b].x - xj.x, xi[b].y - xj.y, xi[b].z - xj.z, xi[b].w - xj.w);
+            float d2 = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+            if (LPR > 16) d2 += __uint_as_float(xor_shfl<16>(__float_as_uint(d2), lane));
+            if (LPR > 8) d2 += __uint_as_float(xor_shfl<8>(__float_as_uint(d2), lane));
+            if (LPR > 4) d2 += __uint_as_float(xor_shfl<4>(__float_as_uint(d2), lane));
+            d2 += __uint_as_float(xor_shfl<2>(__float_as_uint(d2), lane));
+            d2 += __uint_as_float(xor_shfl<1>(__float_as_uint(d2), lane));
+            float dd = 0.0f;
+            if (gv[b] != 0.0f && d2 != 0.0f) {                   // vector_norm backward at 0 is 0 (self loop)
+                const float dist = sqrtf(d2);
+                const float p = c_exp(t * dist);
+                const float dp = perturb ? gv[b] * vv[b] / (p + 1e-8f) : gv[b];
+                dd = dp * t * p / dist;
+            }
+            acc.x -= dd * d.x; acc.y -= dd * d.y; acc.z -= dd * d.z; acc.w -= dd * d.w;
+        }
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
+        acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+    }
+    if (slot == 0) {
+        float4 *o = reinterpret_cast<float4 *>(dxp + j * H + 4 * c4);
+        if (j >= row0 && j < row0 + rows) {
+            float4 v = *o;
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *o = acc;
+    }
+}
+
 // ---- normalisation backward: row side (da_i, per-entry coefficient), column side (bucket sums) -----------------------
 __global__ __launch_bounds__(256) void norm_da_rows(const int32_t *__restrict__ idx, const float *__restrict__ w,
                                                     const float *__restrict__ rs, const float *__restrict__ dA, int64_t rows,
@@ -589,7 +988,8 @@ extern "C" {
 // 0 when the partitioned path does not apply (too many buckets for an LDS histogram)
 size_t dgg_part_ws_bytes(int64_t rows, int K, int64_t ncols) {
     const int64_t nb = nbuckets(ncols);
-    if (nb > 16384 || K > 64) return 0;
+    // 8 bytes of dynamic LDS per bucket in the fill pass (64 KiB without opting in to more); record ids are 32-bit
+    if (nb > 8192 || K > 64 || K < 1 || rows * 64 >= ((int64_t)1 << 31)) return 0;
     return align256((size_t)(nb + 1) * 4) + align256((size_t)nb * 4) + align256((size_t)rows * K * sizeof(int2)) +
            align256((size_t)rows * K * sizeof(int)) + (size_t)rows * K * sizeof(int2);
 }
@@ -653,7 +1053,7 @@ int dgg_softk_edge_bwd_part(const float *xp, int64_t rows, int h, const int32_t 
     if (mode != 0 && mode != 1) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_part: mode must be 0 (k_times) or 1 (k_only)");
     if (!k || !dA || !dk || (normalized && (!rs || !da))) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_part: missing operand");
     if (ahat_rows && !normalized) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_part: ahat_rows is an operand of the normalised form");
-    const SoftkArgs sk{k, rs, dA, da, mode, normalized, dval, dk, ahat_rows};
+    const SoftkArgs sk{k, rs, dA, da, mode, normalized, dval, dk, ahat_rows, nullptr};
     return edge_bwd_part_impl(xp, rows, h, idx, val, nullptr, K, row0, t, perturb, part_ws, ncols, coef_ws, dxp, &sk, stream);
 }
 
@@ -697,6 +1097,96 @@ int dgg_ell_conv_bwd_part(const float *G, const float *H, const float *ahat, int
     }
 #undef DGG_CONV_COLS
     return dgg_check_launch("ell_conv_bwd_part");
+}
+
+// ---- payload partition (16-byte records carrying wa = w * rs_i^-1/2 and the score; no slot map) ---------------------------
+size_t dgg_partp_ws_bytes(int64_t rows, int K, int64_t ncols) {
+    const int64_t nb = nbuckets(ncols);
+    if (nb > 8192 || K > 64 || K < 1 || rows * 64 >= ((int64_t)1 << 31)) return 0;   // LDS histogram (64 KiB) / 32-bit record ids
+    return align256((size_t)(nb + 1) * 4) + align256((size_t)nb * 4) + align256((size_t)(nb * BS + 1) * 4) +
+           align256((size_t)rows * K * sizeof(int4)) + (size_t)rows * K * sizeof(int4);
+}
+
+// Partition the ACTIVE entries (idx >= 0, w != 0) of an ELL block by destination, records = (row*64 + r, j, w * rs_i^-1/2, val).
+// val [rows,K] = the scores (dgg_allpairs_topk / dgg_edgelist_topk), rs_rows [rows] = the row sums of the block's OWN rows.
+int dgg_partp_build(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
+                    void *ws, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nb = nbuckets(ncols);
+    if (dgg_partp_ws_bytes(rows, K, ncols) == 0 || !ws) return dgg_set_error(DGG_ERR_UNSUPPORTED, "partp_build: unsupported size or NULL workspace");
+    if (!val || !rs_rows) return dgg_set_error(DGG_ERR_ARG, "partp_build: the payload needs the scores and the row sums");
+    if (rows == 0) return 0;
+    PartPHdr p = partp_layout(ws, nb, rows * K);
+    if (dgg_check_hip(hipMemsetAsync(p.cursor, 0, (size_t)nb * 4, st), "partp memset") != 0) return DGG_ERR_HIP;
+    const unsigned grid = (unsigned)((rows + PR - 1) / PR);
+    hipLaunchKernelGGL((part_pass<false, true>), dim3(grid), dim3(256), (size_t)nb * 4, st, idx, w, rows, K, (int)nb, p.cursor, nullptr, nullptr,
+                       val, rs_rows, p.tmp);
+    hipLaunchKernelGGL(part_scan, dim3(1), dim3(1024), 0, st, p.bstart, p.cursor, (int)nb);
+    hipLaunchKernelGGL((part_pass<true, true>), dim3(grid), dim3(256), (size_t)nb * 8, st, idx, w, rows, K, (int)nb, p.cursor, nullptr, nullptr,
+                       val, rs_rows, p.tmp);
+    hipLaunchKernelGGL(part_sort_p, dim3((unsigned)nb), dim3(1024), 0, st, p.bstart, p.tmp, p.recs, p.nodeptr, (int)nb);
+    return dgg_check_launch("partp_build");
+}
+
+// dgg_ell_conv_bwd_part on a payload partition: ahat comes from the records; additionally dA_rec [rows*K] = dA in record order
+// (for dgg_softk_edge_bwd_partp).  dA [rows,K], dH [ncols,F], da [ncols] as in dgg_ell_conv_bwd_part (caller zeroes all three).
+int dgg_ell_conv_bwd_partp(const float *G, const float *H, int64_t rows, int K, int F, const void *partp_ws, int64_t ncols,
+                           const float *rs, float *dA, float *dA_rec, float *dH, float *da, void *stream) {
+    if ((F != 16 && F != 32 && F != 64 && F != 128) || (reinterpret_cast<uintptr_t>(G) % 16) || (reinterpret_cast<uintptr_t>(H) % 16) ||
+        (reinterpret_cast<uintptr_t>(dH) % 16))
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "ell_conv_bwd_partp: feature width must be 16, 32, 64 or 128 (16-byte aligned rows)");
+    if (!rs || !partp_ws || !dA_rec || dgg_partp_ws_bytes(rows, K, ncols) == 0) return dgg_set_error(DGG_ERR_ARG, "ell_conv_bwd_partp: missing operand");
+    if (rows == 0) return 0;
+    const int64_t nb = nbuckets(ncols);
+    PartPHdr p = partp_layout(const_cast<void *>(partp_ws), nb, rows * K);
+    const int64_t ngroups = (rows * K + CH - 1) / CH;
+    hipStream_t st = (hipStream_t)stream;
+    (void)ngroups;
+#define DGG_CONV_COLS_P(FF)                                                                                                \
+    hipLaunchKernelGGL(conv_bwd_node<FF>, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, G, H, K, ncols, p.nodeptr, p.recs, rs, dA, \
+                       dA_rec, dH, da)
+    switch (F) {
+        case 16: DGG_CONV_COLS_P(16); break;
+        case 32: DGG_CONV_COLS_P(32); break;
+        case 64: DGG_CONV_COLS_P(64); break;
+        default: DGG_CONV_COLS_P(128); break;
+    }
+#undef DGG_CONV_COLS_P
+    return dgg_check_launch("ell_conv_bwd_partp");
+}
+
+// dgg_softk_edge_bwd_part on a payload partition: the row kernel hands (a_i, d loss / d rs_i, k_i) per row to the column kernel
+// (rowinfo_ws: 4*rows floats), which recomputes d loss / d score from dA_rec in record order -- no slot map, no per-entry
+// coefficient hand-over.  dk [rows] written, dxp [ncols,h] zeroed by the caller.
+int dgg_softk_edge_bwd_partp(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *k, const float *rs,
+                             const float *dA, const float *dA_rec, const float *da, const float *ahat_rows, int K, int64_t row0, float t,
+                             int perturb, int mode, int normalized, const void *partp_ws, int64_t ncols, float *rowinfo_ws, float *dk,
+                             float *dxp, void *stream) {
+    if (mode != 0 && mode != 1) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: mode must be 0 (k_times) or 1 (k_only)");
+    if (!k || !dA || !dA_rec || !dk || !rowinfo_ws || (normalized && (!rs || !da))) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: missing operand");
+    if (ahat_rows && !normalized) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: ahat_rows is an operand of the normalised form");
+    if (!partp_ws || dgg_partp_ws_bytes(rows, K, ncols) == 0) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: no partition");
+    if (rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nb = nbuckets(ncols);
+    PartPHdr p = partp_layout(const_cast<void *>(partp_ws), nb, rows * K);
+    const SoftkArgs sk{k, rs, dA, da, mode, normalized, nullptr, dk, ahat_rows, reinterpret_cast<float4 *>(rowinfo_ws)};
+    const unsigned gr = (unsigned)((rows + 3) / 4);
+#define DGG_EDGE_PARTP(HH)                                                                                                  \
+    hipLaunchKernelGGL((edge_bwd_rows<HH, true, true>), dim3(gr), dim3(256), 0, st, xp, rows, idx, val, nullptr, K, row0, t, perturb, nullptr, \
+                       nullptr, dxp, sk);                                                                                    \
+    if (mode == 0)                                                                                                           \
+        hipLaunchKernelGGL(edge_bwd_node<HH>, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, xp, ncols, p.nodeptr, p.recs, dA_rec, \
+                           reinterpret_cast<const float4 *>(rowinfo_ws), rs, normalized, row0, rows, t, perturb, dxp)
+    switch (h) {
+        case 16: DGG_EDGE_PARTP(16); break;
+        case 32: DGG_EDGE_PARTP(32); break;
+        case 64: DGG_EDGE_PARTP(64); break;
+        case 128: DGG_EDGE_PARTP(128); break;
+        default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "softk_edge_bwd_partp supports latent_dim in {16,32,64,128}");
+    }
+#undef DGG_EDGE_PARTP
+    return dgg_check_launch("softk_edge_bwd_partp");
 }
 
 // normalisation backward phase 1 through the partition; da [ncols] zeroed by the caller

@@ -126,6 +126,65 @@ def linear_bwd(x, W, y, dy, act=ACT_NONE, w_layout=0, need_dx=True, need_db=True
     return dx, dW, db
 
 
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+def _int_array(vs):
+    return (C.c_int * len(vs))(*[int(v) for v in vs])
+
+
+def linear_fwd_multi(x, layers):
+    """Several layers on ONE input, x read once: layers = [(W, b or None, act, w_layout), ...] -> [y_s].  Same fmaf chains as
+    one linear_fwd per layer (bit-identical); falls back to those calls for shapes the fused kernel does not tile."""
+    x = _chk(x)
+    N, d = x.shape
+    outs = [(W.shape[0] if lay == 0 else W.shape[1]) for W, _, _, lay in layers]
+    if len(layers) > 8 or any(o % 32 for o in outs) or sum(outs) > 256 or sum(outs) == 224:
+        return [linear_fwd(x, W, b, act, lay) for W, b, act, lay in layers]
+    # nn.Linear layout [out, d] stacked by rows (a [d, out] weight enters transposed); missing biases are zeros
+    Wcat = torch.cat([(_chk(W) if lay == 0 else _chk(W).t()) for W, _, _, lay in layers], 0).contiguous()
+    bcat = None
+    if any(b is not None for _, b, _, _ in layers):
+        bcat = torch.cat([(_chk(b) if b is not None else x.new_zeros(o)) for (_, b, _, _), o in zip(layers, outs)])
+    ys = [torch.empty((N, o), device=x.device, dtype=torch.float32) for o in outs]
+    _lib.check(_lib.lib().dgg_linear_fwd_multi(_ptr(x), N, d, _ptr(Wcat), _ptr(bcat), len(layers), _int_array(outs),
+                                               _int_array([a for _, _, a, _ in layers]), _ptr_array(ys), _stream()), "linear_fwd_multi")
+    return ys
+
+
+def linear_bwd_multi(x, layers):
+    """Weight (and bias) gradients of several layers that share the input x, in ONE pass over x:
+    layers = [(W, y or None, dy, act, w_layout, need_db), ...] -> [(dW_s, db_s or None)].  The activation derivative of layer s
+    is applied to dy_s on the operand load (y_s = the layer's forward output)."""
+    x = _chk(x)
+    N, d = x.shape
+    outs = [(W.shape[0] if lay == 0 else W.shape[1]) for W, _, _, _, lay, _ in layers]
+    if len(layers) > 8 or any(o % 32 for o in outs) or sum(outs) > 256 or d > 128:
+        res = []
+        for W, y, dy, act, lay, need_db in layers:
+            _, dW, db = linear_bwd(x, W, y, dy, act, lay, need_dx=False, need_db=need_db)
+            res.append((dW, db))
+        return res
+    nW = [int(W.numel()) for W, *_ in layers]
+    zz = _zeros((sum(nW) + sum(o for o, l_ in zip(outs, layers) if l_[5]),), x.device)                 # one fill for all outputs
+    dWs, dbs, o_ = [], [], 0
+    for (W, *_), n_ in zip(layers, nW):
+        dWs.append(zz[o_:o_ + n_].view(W.shape))
+        o_ += n_
+    for (_, _, _, _, _, need_db), o in zip(layers, outs):
+        dbs.append(zz[o_:o_ + o] if need_db else None)
+        o_ += o if need_db else 0
+    ws = torch.empty((int(_lib.lib().dgg_gemm_tn_multi_ws_floats(N, sum(outs), d)),), device=x.device, dtype=torch.float32)
+    dys = [_chk(l_[2]) for l_ in layers]
+    ysv = [(_chk(l_[1]) if (l_[1] is not None and l_[3] != ACT_NONE) else None) for l_ in layers]
+    _lib.check(_lib.lib().dgg_gemm_tn_multi(len(layers), _ptr_array(dys), _int_array(outs), _ptr_array(ysv),
+                                            _int_array([l_[3] for l_ in layers]), _ptr(x), N, d, _ptr_array(dWs),
+                                            _int_array([0 if l_[4] == 0 else 1 for l_ in layers]), _ptr_array(dbs), _ptr(ws), _stream()),
+               "gemm_tn_multi")
+    return list(zip(dWs, dbs))
+
+
 def gemm_tn(A, B, colsum=False):
     """A[N,M1]^T B[N,M2] -> [M1,M2] (+ column sums of A)."""
     A, B = _chk(A), _chk(B)
@@ -561,6 +620,67 @@ def part_build(idx, w, ncols):
     ws = torch.empty((nbytes,), device=idx.device, dtype=torch.uint8)
     _lib.check(_lib.lib().dgg_part_build(_ptr(idx), _ptr(_chk(w)), N, K, ncols, _ptr(ws), _stream()), "part_build")
     return ws
+
+
+class PartP:
+    """payload partition (dgg_partp_build): workspace + the shape it was built for"""
+
+    def __init__(self, ws, rows, K, ncols):
+        self.ws, self.rows, self.K, self.ncols = ws, rows, K, ncols
+
+
+def partp_build(idx, w, val, rs_rows, ncols):
+    """Payload partition of the active ELL entries by destination node: records carry w * rs_i^-1/2 and the score, there is no
+    slot map.  Returns None when it does not apply."""
+    N, K = idx.shape
+    nbytes = int(_lib.lib().dgg_partp_ws_bytes(N, K, ncols))
+    if nbytes == 0:
+        return None
+    ws = torch.empty((nbytes,), device=idx.device, dtype=torch.uint8)
+    _lib.check(_lib.lib().dgg_partp_build(_ptr(idx), _ptr(_chk(w)), _ptr(_chk(val)), _ptr(_chk(rs_rows)), N, K, ncols, _ptr(ws), _stream()),
+               "partp_build")
+    return PartP(ws, N, K, ncols)
+
+
+def conv_bwd_cols_p(idx, H, G, partp, rs):
+    """conv_bwd_cols on a payload partition -> dA [rows,K], dA_rec [rows*K], dH [ncols,F], da [ncols] (neighbour side); None when
+    the kernel does not cover the shape"""
+    N, K = idx.shape
+    H, G = _chk(H), _chk(G)
+    F = H.shape[1]
+    if partp is None or F not in CONV_BWD_WIDTHS or H.data_ptr() % 16 or G.data_ptr() % 16 or H.shape[0] != partp.ncols:
+        return None
+    ncols = H.shape[0]
+    dA = _zeros((N, K), H.device)                                                # entries outside the partition stay 0
+    # one wavefront per destination node owns dH_j / da_j: plain stores for every node, no zero fill
+    dH = torch.empty((ncols, F), device=H.device, dtype=torch.float32)
+    da = torch.empty((ncols,), device=H.device, dtype=torch.float32)
+    dA_rec = torch.empty((N * K,), device=H.device, dtype=torch.float32)
+    pe = _probe_begin()
+    _lib.check(_lib.lib().dgg_ell_conv_bwd_partp(_ptr(G), _ptr(H), N, K, F, _ptr(partp.ws), ncols, _ptr(_chk(rs)), _ptr(dA), _ptr(dA_rec),
+                                                 _ptr(dH), _ptr(da), _stream()), "ell_conv_bwd_partp")
+    _probe_end("conv_bwd", pe)
+    return dA, dA_rec, dH, da
+
+
+def softk_edge_bwd_p(xp, idx, val, k, dA, dA_rec, rs, da, row0, t, perturb, mode, normalized, partp, ahat_rows=None):
+    """softk_edge_bwd on a payload partition -> dxp [Nglobal,h], dk [N]; None when it does not apply"""
+    xp = _chk(xp)
+    Ng, h = xp.shape
+    N, K = idx.shape
+    if partp is None or h not in (16, 32, 64, 128) or mode not in (MODE_K_TIMES_EDGE_PROB, MODE_K_ONLY) or Ng != partp.ncols:
+        return None
+    # mode 0: every row of dxp is written (own rows by the row kernel, the others by the per-node kernel): no zero fill
+    dxp = torch.empty_like(xp) if mode == MODE_K_TIMES_EDGE_PROB else _zeros(tuple(xp.shape), xp.device)
+    rowinfo = torch.empty((N, 4), device=xp.device, dtype=torch.float32)
+    dk = torch.empty((N,), device=xp.device, dtype=torch.float32)
+    pe = _probe_begin()
+    _lib.check(_lib.lib().dgg_softk_edge_bwd_partp(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(k)), _ptr(rs), _ptr(_chk(dA)),
+                                                   _ptr(dA_rec), _ptr(da), _ptr(None if ahat_rows is None else _chk(ahat_rows)), K, row0, t,
+                                                   int(perturb), mode, int(normalized), _ptr(partp.ws), Ng, _ptr(rowinfo), _ptr(dk), _ptr(dxp),
+                                                   _stream()), "softk_edge_bwd_partp")
+    _probe_end("edge_bwd", pe)
+    return dxp, dk
 
 
 def norm_bwd_da(idx, w, rs, dA, row0=0, part=None):

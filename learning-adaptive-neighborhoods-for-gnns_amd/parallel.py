@@ -148,7 +148,11 @@ class ShardedDGGConv:
                                                 rows=(self.r0, self.r1), algo=self.algo, k_limit=s["k"])
         s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
         # destination-bucket partition of the active entries: the backward's column-side terms run on it (no atomics)
-        s["part"] = kern.part_build(s["idx"], s["w"], self.N) if hasattr(kern, "part_build") else None
+        # (payload form -- records carry w rs_i^-1/2 and the score, no slot map -- when the namespace offers it and covers the shape)
+        s["partp"] = kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N) \
+            if (hasattr(kern, "partp_build") and xp.shape[1] in (16, 32, 64, 128) and H.shape[1] in (16, 32, 64, 128)
+                and self.mode in (0, 1)) else None
+        s["part"] = kern.part_build(s["idx"], s["w"], self.N) if (s["partp"] is None and hasattr(kern, "part_build")) else None
         s["rs"] = rs = _all_gather_rows(rs_local, self.N, self.per, self.group, self.bufs, "rs") if self.coll else rs_local
         if self.emulate is not None:
             s["rs"] = rs = rs_local.repeat(self.world)[:self.N].contiguous()
@@ -189,6 +193,16 @@ class ShardedDGGConv:
         G = kern.act_bwd(s["Z"], dZ, 2)                  # cotangent of A H
         # one gather of G per edge for SDDMM + transposed SpMM + neighbour side of da; its companion is the fused score backward
         # (which adds the row side of da in registers), so both must cover the shape
+        partp = s.get("partp")
+        if partp is not None:
+            pc = kern.conv_bwd_cols_p(s["idx"], s["H"], G, partp, s["rs"])
+            assert pc is not None
+            dA, dA_rec, dH, da = pc
+            if self.coll:
+                dist.all_reduce(da, group=self.group)
+            dxp, dk = kern.softk_edge_bwd_p(s["xp"], s["idx"], s["val"], s["k"], dA, dA_rec, s["rs"], da, self.r0, self.t,
+                                            self.noise_mode != 0, self.mode, True, partp, ahat_rows=s["ahat"])
+            return self._weight_grads(g, dxp, dH, dk, x_local, P)
         cols = None
         if part is not None and hasattr(kern, "conv_bwd_cols") and hasattr(kern, "softk_edge_bwd") and \
                 s["xp"].shape[1] in (16, 32, 64, 128) and self.mode in (0, 1):
@@ -214,6 +228,11 @@ class ShardedDGGConv:
             dval, dk = kern.softk_bwd(s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.mode, True)
             dxp = kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0, part) \
                 if part is not None else kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0)
+        return self._weight_grads(g, dxp, dH, dk, x_local, P)
+
+    def _weight_grads(self, g, dxp, dH, dk, x_local, P):
+        kern, s = self.kern, self.saved
+        repl = self.x_full is not None
         # weight gradients of the two projections.  Replicated features: partial [dxp | dH] of all N nodes against the full X (the
         # weight all-reduce sums the ranks); gathered projections: reduce-scatter the partials, then the rank's own rows only.
         if self.coll and not repl:

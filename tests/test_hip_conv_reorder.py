@@ -130,3 +130,81 @@ def test_row_side_of_da_inside_the_score_backward(dev, h):
         got = ops.softk_edge_bwd(*args, T(da_cols, dev), lo, ops.T_DIST, True, 0, True, part, want_dval=True, ahat_rows=T(ahat[sl], dev))
         for g_, r_ in zip(got, ref):
             np.testing.assert_allclose(Nn(g_), Nn(r_), rtol=2e-4, atol=2e-4 * max(float(r_.abs().max()), 1e-9))
+
+
+@pytest.mark.parametrize("N,d,outs", [(1000, 128, (64, 64, 64)), (333, 70, (32, 64)), (257, 128, (64, 64)), (130, 24, (32,)),
+                                      (500, 128, (128, 128)), (77, 40, (64, 96, 32))])
+def test_fused_projections_are_bit_identical_to_separate_calls(dev, N, d, outs):
+    """dgg_linear_fwd_multi (X read once) == one dgg_linear_fwd per layer, bit for bit; mixed layouts / activations / biases"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(N + d)
+    x = T(rng.standard_normal((N, d)).astype(np.float32), dev)
+    layers = []
+    for s_, o in enumerate(outs):
+        lay = s_ % 2 if len(outs) > 1 else 0
+        W = T((rng.standard_normal((o, d) if lay == 0 else (d, o)) * 0.2).astype(np.float32), dev)
+        b = T((rng.standard_normal(o) * 0.1).astype(np.float32), dev) if s_ != 1 else None
+        layers.append((W, b, [ops.ACT_LEAKY, ops.ACT_NONE, ops.ACT_RELU][s_ % 3], lay))
+    got = ops.linear_fwd_multi(x, layers)
+    for y, (W, b, act, lay) in zip(got, layers):
+        ref = ops.linear_fwd(x, W, b, act, lay)
+        assert torch.equal(y, ref)
+        xo = O.linear(Nn(x), Nn(W), None if b is None else Nn(b), act, w_layout=lay)
+        assert np.array_equal(Nn(y), xo)
+
+
+@pytest.mark.parametrize("N,d,outs", [(2100, 128, (64, 64, 64)), (700, 128, (64, 64)), (300, 40, (32, 64, 32)), (65, 128, (128, 128))])
+def test_fused_weight_gradients_match_separate_calls(dev, N, d, outs):
+    """dgg_gemm_tn_multi == one dgg_linear_bwd (weight / bias gradient) per layer, up to summation order"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(N + d + len(outs))
+    x = T(rng.standard_normal((N, d)).astype(np.float32), dev)
+    layers = []
+    for s_, o in enumerate(outs):
+        lay = s_ % 2
+        act = [ops.ACT_LEAKY, ops.ACT_NONE, ops.ACT_RELU][s_ % 3]
+        W = T((rng.standard_normal((o, d) if lay == 0 else (d, o)) * 0.2).astype(np.float32), dev)
+        y = ops.linear_fwd(x, W, None, act, lay)
+        dy = T(rng.standard_normal((N, o)).astype(np.float32), dev)
+        layers.append((W, y if act != ops.ACT_NONE else None, dy, act, lay, s_ != 1))
+    got = ops.linear_bwd_multi(x, layers)
+    for (dW, db), (W, y, dy, act, lay, need_db) in zip(got, layers):
+        _, rdW, rdb = ops.linear_bwd(x, W, y, dy, act, lay, need_dx=False, need_db=need_db)
+        np.testing.assert_allclose(Nn(dW), Nn(rdW), rtol=2e-4, atol=2e-4 * float(rdW.abs().max()))
+        assert (db is None) == (not need_db)
+        if need_db:
+            np.testing.assert_allclose(Nn(db), Nn(rdb), rtol=2e-4, atol=2e-4 * float(rdb.abs().max()))
+
+
+@pytest.mark.parametrize("h,F", [(64, 64), (16, 32), (128, 128), (32, 16)])
+def test_payload_partition_matches_the_slot_map_path(dev, h, F):
+    """16-byte payload records (no slot map): conv backward and fused ramp / normalisation / score backward == the slot-map
+    kernels (themselves oracle-checked above), whole block and a row shard (local rows, global columns)"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(400 + h + F)
+    N = 1100
+    xp, k, idx, val, w, rs, ahat = _graph(rng, N, h)
+    H = rng.standard_normal((N, F)).astype(np.float32)
+    G = rng.standard_normal((N, F)).astype(np.float32)
+    for lo, hi in [(0, N), (300, 811)]:
+        sl = slice(lo, hi)
+        a = dict(idx=T(idx[sl], dev), w=T(w[sl], dev), val=T(val[sl], dev), ahat=T(ahat[sl], dev), k=T(k[sl], dev), G=T(G[sl], dev))
+        part = ops.part_build(a["idx"], a["w"], N)
+        partp = ops.partp_build(a["idx"], a["w"], a["val"], T(rs[sl], dev), N)
+        assert partp is not None
+        dA0, dH0, da0 = ops.conv_bwd_cols(a["idx"], a["ahat"], T(H, dev), a["G"], part, T(rs, dev), want_da=True)
+        dA1, dArec, dH1, da1 = ops.conv_bwd_cols_p(a["idx"], T(H, dev), a["G"], partp, T(rs, dev))
+        assert torch.equal(dA0, dA1)                                 # same dot products, same order
+        np.testing.assert_allclose(Nn(dH1), Nn(dH0), rtol=1e-5, atol=1e-5 * float(dH0.abs().max()))
+        np.testing.assert_allclose(Nn(da1), Nn(da0), rtol=1e-4, atol=1e-4 * float(da0.abs().max()))
+        # dA_rec is a permutation of the active entries of dA
+        act = Nn(a["w"]) != 0
+        assert np.allclose(np.sort(Nn(dArec)[: act.sum()]), np.sort(Nn(dA1)[act]))
+        for mode in (0, 1):
+            ref = ops.softk_edge_bwd(T(xp, dev), a["idx"], a["val"], a["k"], dA0, T(rs, dev), da0, lo, ops.T_DIST, True, mode, True, part,
+                                     ahat_rows=a["ahat"])
+            got = ops.softk_edge_bwd_p(T(xp, dev), a["idx"], a["val"], a["k"], dA1, dArec, T(rs, dev), da1, lo, ops.T_DIST, True, mode, True,
+                                       partp, ahat_rows=a["ahat"])
+            assert got is not None
+            np.testing.assert_allclose(Nn(got[1]), Nn(ref[1]), rtol=2e-4, atol=2e-4 * max(float(ref[1].abs().max()), 1e-9))
+            np.testing.assert_allclose(Nn(got[0]), Nn(ref[0]), rtol=2e-4, atol=2e-4 * max(float(ref[0].abs().max()), 1e-9))
