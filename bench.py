@@ -2,16 +2,20 @@
 """bench.py -- DGG adjacency build + normalise + graph-conv aggregation, forward AND backward, on synthetic
 N-node x d-feature graphs (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W] [--nodes 100000 --feat 128 --latent 64]
+    python bench.py [--gpus N --steps K --warmup W] [--nodes N --feat 128 --latent 64]
 
-One step = one pass of the hot path over the whole graph: node projection (MFMA) -> learned degree k ->
-all-pairs Gumbel-perturbed scores + per-row top-64 -> smooth first-k ramp -> D^-1/2 A D^-1/2 -> A X W (+relu),
-then the full backward with a ones cotangent (all DGG parameters + conv weight; the input features are data, as in
-the reference's training loop, unless --x-grad).  Inputs are resident in HBM before the timed region.
-Multi-GPU (torchrun, one rank per GPU, RCCL): rows are sharded by node range; WEAK scaling by default (--nodes rows
-per GPU, graph of --nodes * GPUs nodes), --strong for a fixed graph.
+One step = one pass of the hot path over the whole graph: node projections (one fp32 MFMA GEMM: [xp | xk | x Wc]) ->
+learned degree k -> all-pairs Gumbel-perturbed scores + per-row top-64 -> smooth first-k ramp -> D^-1/2 A D^-1/2 ->
+relu(A (x Wc)), then the full backward with a ones cotangent (all DGG parameters + conv weight; the input features are
+data, as in the reference's training loop, unless --x-grad).  Inputs are resident in HBM before the timed region; every
+step draws fresh noise (seed cycled over NGRAPH values).
+W warm-up steps, then `--repeats` windows of exactly K steps, each bracketed by barrier + synchronize (max over ranks);
+`value` / `ms_per_step` come from the median window.
+One GPU: N = 100 000 (the BASELINE.json metric config).  Several GPUs (torchrun, one rank per GPU, RCCL): BASELINE.json
+configs[3], ONE graph of 500 000 nodes node-range sharded (strong scaling); --weak: 100 000 rows per GPU.
 
-Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (dominant kernel) and `cpu_baseline`.
+Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (dominant kernel), `kernels`, `variants`
+(symmetric / unperturbed / hash noise, latent 128, x-grad) and `cpu_baseline`.
 """
 import argparse
 import json
@@ -226,7 +230,7 @@ def bench_module_api(a, dev):
     the hand-scheduled step of the default workload.  Run with --workload synthetic-module."""
     import dgg_amd
     from argparse import Namespace
-    N, d, h = a.nodes, a.feat, a.latent
+    N, d, h = (a.nodes or 100_000), a.feat, a.latent
     args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
                      dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
                      symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
@@ -402,7 +406,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--nodes", type=int, default=100_000)
+    ap.add_argument("--nodes", type=int, default=0, help="node count: total (one GPU, or several with strong scaling) or per GPU (--weak); "
+                                                          "0 = 100 000 on one GPU, 500 000 in total on several (BASELINE.json configs[3])")
+    ap.add_argument("--weak", action="store_true", help="multi-GPU: --nodes (default 100 000) rows PER GPU of a (nodes x GPUs)-node graph")
+    ap.add_argument("--repeats", type=int, default=11, help="timed windows of --steps steps each; value = median window")
+    ap.add_argument("--no-variants", dest="variants", action="store_false",
+                    help="skip the symmetric / unperturbed / hash / latent-128 / x-grad variants of the step (one GPU only)")
+    ap.add_argument("--no-cpu-dense", dest="cpu_dense", action="store_false",
+                    help="skip the dense reference-shaped CPU formulation at N = 2 708 / 4 000 (BASELINE.md section 3)")
     ap.add_argument("--feat", type=int, default=128)
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--algo", type=int, default=0, help="all-pairs kernel for --noise hash: 0 auto, 1 exhaustive, 2 MFMA-bounded, "
@@ -411,9 +422,7 @@ def main():
                     help="counter-based Gumbel generator: ranked (per-row order statistics, O(N*150) search) or hash "
                          "(per-pair hash, N^2 sweep); both iid Gumbel(0,0.3)")
     ap.add_argument("--x-grad", action="store_true", help="also compute d loss / d x (reduce-scatter across ranks)")
-    ap.add_argument("--strong", action="store_true",
-                    help="multi-GPU: keep the graph at --nodes nodes in total (default: --nodes nodes PER GPU, weak scaling; "
-                         "with the O(N*K) pair search a rank's work depends on its rows, not on the total column count)")
+    ap.add_argument("--strong", action="store_true", help="(default for several GPUs; kept for compatibility)")
     ap.add_argument("--exchange", choices=["replicate", "gather"], default="replicate",
                     help="multi-GPU, features as data (no --x-grad): 'replicate' = the node features are placed on every GPU once at "
                          "load and each rank projects all rows itself (per-step collectives: row sums, da, weight gradients); "
@@ -454,105 +463,163 @@ def main():
         assert world == 1, "--workload ppi is a single-GPU measurement (graphs are independent: replicas across GPUs)"
         return bench_ppi(a, dev)
 
-    # weak scaling (default): every GPU owns --nodes rows of an (--nodes * world)-node graph; --strong keeps N fixed
-    emu = a.emulate_world if (a.emulate_world > 1 and world == 1 and not force) else 0
-    N, d, h = (a.nodes if a.strong else a.nodes * max(world, emu, 1)), a.feat, a.latent
-    P = make_params(d, h, dev)
-    erank = emu // 2
-    r0, r1, _ = shard_bounds(N, emu, erank) if emu else shard_bounds(N, world, rank)
-    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    x_local = torch.randn(r1 - r0, d, generator=g).to(dev)
-    gd = torch.Generator(device="cpu").manual_seed(7)
-    deg = (24 + 16 * torch.rand(N, generator=gd)).to(dev)
-    noise_mode = ops.NOISE_RANKED if a.noise == "ranked" else ops.NOISE_HASH
-    # features are DATA unless --x-grad: with more than one rank they are replicated once, here, outside the timed region (data
-    # placement: 4*N*d bytes per GPU), and no feature tensor crosses the fabric per step (dgg_amd/parallel.py)
-    x_full = None
-    if (world > 1 or force) and not a.x_grad and a.exchange == "replicate":
-        from dgg_amd.parallel import _all_gather_rows
-        x_full = _all_gather_rows(x_local, N, shard_bounds(N, world, rank)[2], None).contiguous()
-    if emu:
-        x_full = torch.randn(N, d, generator=g).to(dev)
-        x_full[r0:r1] = x_local
-    layer = ShardedDGGConv(ops, N, group=None, K=64, noise_mode=noise_mode, seed=(1234, 0), algo=a.algo, x_grad=a.x_grad, x_full=x_full)
-    if emu:
-        layer.emulate_rank(emu, erank)
+    return bench_synthetic(a, dev, world, rank, force)
 
-    def step():
-        Z = layer.forward(x_local, deg, P)
-        return layer.backward(torch.ones_like(Z), x_local, P)
 
-    for _ in range(a.warmup):
-        grads = step()
-    # The step is a fixed sequence of ~50 asynchronous launches with caller-provided buffers (the C ABI neither
-    # allocates nor synchronises), so it can be captured once into a hipGraph and replayed: same kernels, same work,
-    # no per-launch host latency.  Falls back to eager launches if capture is unavailable (e.g. with collectives).
-    graph = None
-    if a.hipgraph and (world == 1 and not force or os.environ.get("DGG_BENCH_GRAPH_DIST") == "1"):
+class SyntheticRun:
+    """One configuration of the synthetic all-pairs workload: inputs resident in HBM, the layer, and the step function."""
+
+    def __init__(self, a, dev, world, rank, force, N, d, h, noise_mode, x_grad=False, emu=0, exchange="replicate"):
+        from dgg_amd import ops
+        from dgg_amd.parallel import ShardedDGGConv, shard_bounds, _all_gather_rows
+        self.N, self.d, self.h, self.world, self.rank, self.emu = N, d, h, world, rank, emu
+        self.P = make_params(d, h, dev)
+        self.erank = emu // 2
+        self.r0, self.r1, _ = shard_bounds(N, emu, self.erank) if emu else shard_bounds(N, world, rank)
+        g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+        self.x_local = torch.randn(self.r1 - self.r0, d, generator=g).to(dev)
+        self.deg = (24 + 16 * torch.rand(N, generator=torch.Generator(device="cpu").manual_seed(7))).to(dev)
+        # features are DATA unless x_grad: with more than one rank they are replicated once, here, outside the timed region (data
+        # placement: 4*N*d bytes per GPU), and no feature tensor crosses the fabric per step (dgg_amd/parallel.py)
+        x_full = None
+        if (world > 1 or force) and not x_grad and exchange == "replicate":
+            x_full = _all_gather_rows(self.x_local, N, shard_bounds(N, world, rank)[2], None).contiguous()
+        if emu:
+            x_full = torch.randn(N, d, generator=g).to(dev)
+            x_full[self.r0:self.r1] = self.x_local
+        self.x_full = x_full
+        self.layer = ShardedDGGConv(ops, N, group=None, K=64, noise_mode=noise_mode, seed=(1234, 0), algo=a.algo, x_grad=x_grad, x_full=x_full)
+        if emu:
+            self.layer.emulate_rank(emu, self.erank)
+        self.grads = None
+
+    def step(self, seed_lo=0):
+        """one pass of the hot path over the whole graph, forward + backward; a different noise realisation per seed_lo"""
+        self.layer.seed = (1234, seed_lo)
+        Z = self.layer.forward(self.x_local, self.deg, self.P)
+        self.grads = self.layer.backward(torch.ones_like(Z), self.x_local, self.P)
+        return self.grads
+
+
+NGRAPH = 4      # captured hipGraphs, one per noise seed: consecutive steps see different graphs (idx / partition / gather pattern)
+
+
+def time_windows(run, a, world, force, dev, use_graph, repeats):
+    """W untimed warm-up steps, then `repeats` windows of EXACTLY a.steps steps, each bracketed by barrier + synchronize;
+    returns (per-window seconds, max over ranks), whether hipGraphs were used.  Step s uses noise seed (1234, s mod NGRAPH)."""
+    for s_ in range(max(a.warmup, 1)):
+        run.step(s_ % NGRAPH)
+    graphs = None
+    if use_graph:
         try:
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                grads = step()
-            graph.replay()
+            graphs = []
+            for s_ in range(NGRAPH):
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph):
+                    run.step(s_)
+                graphs.append(gph)
+            for gph in graphs:
+                gph.replay()
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
             print(f"hipGraph capture failed ({e!r}); timing eager launches", file=sys.stderr)
-            graph = None
-    if world > 1 or force:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        if graph is not None:
-            graph.replay()
-        else:
-            grads = step()
-    torch.cuda.synchronize()
-    if world > 1 or force:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev)
+            graphs = None
+    coll = world > 1 or force
+    times = []
+    sidx = 0
+    for _ in range(repeats):
+        if coll:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            if graphs is not None:
+                graphs[sidx % NGRAPH].replay()
+            else:
+                run.step(sidx % NGRAPH)
+            sidx += 1
+        torch.cuda.synchronize()
+        if coll:
+            dist.barrier()
+        times.append(time.perf_counter() - t0)
+    tm = torch.tensor(times, device=dev, dtype=torch.float64)
+    if coll:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    return [float(v) for v in tm.tolist()], graphs is not None
+
+
+def cpu_dense_formulation(sizes, threads):
+    """the dense, reference-shaped formulation (oracle/dense_ref.py: one [N,N] torch tensor per stage, as
+    the reference computes) timed on the host for the sizes where it can be allocated.  One forward + backward each."""
+    from oracle import dense_ref as D
+    torch.set_num_threads(threads)
+    out = []
+    for kind, N, d, h in sizes:
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(N, d, generator=g)
+        P = {k_: v.cpu() for k_, v in make_params(d, h, torch.device("cpu")).items()}
+        if kind == "allpairs":
+            rows = cols = None
+            deg = 24 + 16 * torch.rand(N, generator=g)
+            npairs = float(N) * N
+        else:                                                    # edge-list candidates, Cora / Pubmed shaped
+            und = {2708: 5278, 19717: 44324}.get(N, 2 * N)
+            r_, c_ = pubmed_graph(N, und)
+            rows, cols = torch.from_numpy(r_.astype(np.int64)), torch.from_numpy(c_.astype(np.int64))
+            deg = torch.zeros(N).index_add_(0, rows, torch.ones(rows.shape[0]))
+            npairs = float(N) * N                               # the dense formulation still sweeps N^2 entries per stage
+        try:
+            dt, kmean = D.timed_step(x, rows, cols, deg, P)
+            out.append({"candidates": kind, "nodes": N, "feat": d, "latent": h, "threads": threads, "seconds_fwd_bwd": dt, "dense_entries_per_s": npairs / dt,
+                        "edges_per_s": N * kmean / dt})
+        except Exception as e:  # noqa: BLE001
+            out.append({"candidates": kind, "nodes": N, "error": repr(e)})
+    return out
+
+
+def bench_synthetic(a, dev, world, rank, force):
+    from dgg_amd import ops
+    d, h = a.feat, a.latent
+    emu = a.emulate_world if (a.emulate_world > 1 and world == 1 and not force) else 0
+    # Graph size.  One GPU: the BASELINE.json metric configuration, N = 100 000.  Several GPUs: BASELINE.json configs[3] -- ONE
+    # graph of 500 000 nodes, node-range sharded (strong scaling: 62 500 rows per rank at 8 GPUs); --weak gives every rank
+    # 100 000 rows of a (100 000 x GPUs)-node graph instead.  --nodes overrides the count (total if strong, per GPU if weak).
+    if world > 1 or emu:
+        weak = a.weak or bool(emu)
+        per = a.nodes if a.nodes else 100_000
+        N = per * max(world, emu) if weak else (a.nodes if a.nodes else 500_000)
+    else:
+        weak, N = True, (a.nodes if a.nodes else 100_000)
+    noise_mode = ops.NOISE_RANKED if a.noise == "ranked" else ops.NOISE_HASH
+    run = SyntheticRun(a, dev, world, rank, force, N, d, h, noise_mode, a.x_grad, emu, a.exchange)
+    use_graph = a.hipgraph and (world == 1 and not force or os.environ.get("DGG_BENCH_GRAPH_DIST") == "1")
+    times, graphed = time_windows(run, a, world, force, dev, use_graph, a.repeats)
+    T = float(np.median(times)) / a.steps
+    layer, P, r0, r1 = run.layer, run.P, run.r0, run.r1
     ksum = layer.saved["k"].sum().reshape(1).double()
     kmaxv = layer.saved["k"].max().reshape(1)
     if world > 1 or force:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(ksum)
         dist.all_reduce(kmaxv, op=dist.ReduceOp.MAX)
-    T = float(tmax.item()) / a.steps
     Nval = (r1 - r0) if emu else N                            # emulation: one rank's rows only
     kmean = float(ksum.item()) / Nval
     assert float(kmaxv.item()) + 8.5 <= 64, "learned degree exceeds the ELL width: results would be truncated"
-    assert all(torch.isfinite(v).all() for v in grads.values())
+    assert all(torch.isfinite(v).all() for v in run.grads.values())
 
     # Per-kernel roofline figures: durations taken INSIDE running steps.  dgg_amd.ops records a pair of events on the launch
     # stream around the C-ABI call of each gather kernel (ops.PROBE); PROBE_STEPS eager steps are run for that after the timed
     # region (same kernels, same inputs, same cache state as in the timed steps; the events themselves are not in `value`).
     PROBE_STEPS = 10
-    step()
+    run.step(0)
     ops.PROBE = {}
-    for _ in range(PROBE_STEPS):
-        step()
+    for s_ in range(PROBE_STEPS):
+        run.step(s_ % NGRAPH)
     torch.cuda.synchronize()
     probe, ops.PROBE = ops.PROBE, None
     tk = {n: sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev) * 1e-3 for n, ev in probe.items()}
     sv = layer.saved
     rows_loc = r1 - r0
-
-    def timed(fn, reps=5):                                        # stand-alone launches (only for shapes the probes do not cover)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        fn()
-        ev[0].record()
-        for _ in range(reps):
-            fn()
-        ev[1].record()
-        torch.cuda.synchronize()
-        return ev[0].elapsed_time(ev[1]) / reps * 1e-3
-
-    t_pair = tk["allpairs_topk"]
-    t_edge = tk["edge_bwd"]
-    t_conv = tk["conv_bwd"]
-    t_spmm = tk["spmm_fwd"]
     F = int(sv["H"].shape[1])                                     # width of the aggregated (projected) rows
     active = float((sv["w"] != 0).sum().item())                   # edges with a non-saturated ramp (~ k + 8.5 per row)
     kept = float((sv["idx"] >= 0).sum().item())                   # ranks kept by k_limit (~ k + 9.5 per row)
@@ -562,48 +629,85 @@ def main():
     # Infinity-Cache resident, the XCD L2 is 4 MB), compared with the guide's measured random-row ceiling.
     kern = {
         # pair scoring + top-k: xp read once, idx / score written for the kept ranks; gathered: one xp row per KEPT entry
-        "allpairs_topk": dict(ms=t_pair * 1e3, compulsory=N * 4.0 * h + kept * 8 + rows_loc * 4,
+        "allpairs_topk": dict(ms=tk["allpairs_topk"] * 1e3, compulsory=N * 4.0 * h + kept * 8 + rows_loc * 4,
                               gathered=kept * 4 * h + rows_loc * (4 * h + 2 * 256)),
         # aggregation Z = relu(A H): idx, ahat per active entry, H read once, Z written
-        "spmm_fwd": dict(ms=t_spmm * 1e3, compulsory=active * 8 + N * 4.0 * F + rows_loc * 4.0 * F,
+        "spmm_fwd": dict(ms=tk["spmm_fwd"] * 1e3, compulsory=active * 8 + N * 4.0 * F + rows_loc * 4.0 * F,
                          gathered=active * 4 * F + rows_loc * (4 * F + 2 * 256)),
-        # conv backward through the partition: record (8) + ahat (4) + dA (4) per active entry, G and H read once, dH and da
-        # written; gathered: one G row per entry (the H row of a run is an L1 hit)
-        "conv_bwd": dict(ms=t_conv * 1e3, compulsory=active * 16 + rows_loc * 4.0 * F + 2 * N * 4.0 * F + N * 4,
-                         gathered=active * (4 * F + 16) + N * 8.0 * F),
-        # score backward (row pass + destination-ordered column pass): idx, score, dA, ahat, slot, coefficient (w + r), record per
-        # entry, xp read once per pass, dxp written; gathered: xp_j (row pass) and xp_i (column pass) per active entry
-        "edge_bwd": dict(ms=t_edge * 1e3, compulsory=active * 36 + 2 * N * 4.0 * h + 2 * N * 4.0 * h,
-                         gathered=active * (8 * h + 16) + rows_loc * (5 * 256 + 12 * h)),
+        # conv backward, one wavefront per destination node: record (16) + dA row-major and in record order (8) per active entry,
+        # G and H read once, dH and da written; gathered: one G row per entry
+        "conv_bwd": dict(ms=tk["conv_bwd"] * 1e3, compulsory=active * 24 + rows_loc * 4.0 * F + 2 * N * 4.0 * F + N * 4,
+                         gathered=active * (4 * F + 24) + N * 8.0 * F),
+        # score backward (row kernel + per-destination kernel): idx, score, dA, ahat per entry in row order, record + dA in record
+        # order, xp read once per pass, dxp written; gathered: xp_j (row pass) and xp_i (column pass) per active entry
+        "edge_bwd": dict(ms=tk["edge_bwd"] * 1e3, compulsory=active * 36 + 4 * N * 4.0 * h,
+                         gathered=active * (8 * h + 36) + rows_loc * (4 * 256 + 8 * h) + N * 8.0 * h),
     }
+    kern["edge_bwd"]["composite"] = "edge_bwd_rows (ramp / normalisation backward inside) + edge_bwd_node (one C-ABI call, two launches)"
     traffic = load_traffic(N, d, h) if not emu and world == 1 else {}
-    kern["edge_bwd"]["composite"] = "edge_bwd_rows (with the ramp / normalisation backward inside) + edge_bwd_cols (one C-ABI call, two launches)"
     # the roofline object describes ONE launch (so that its duration can be checked against the rocprofv3 kernel
     # stats under profiles/): the longest single kernel of the step
     dom = max((n for n in kern if "composite" not in kern[n]), key=lambda n: kern[n]["ms"])
-    # the row of profiles/*_kernel_stats.csv each bench name corresponds to at the default shape
-    ROCPROF_NAME = {"allpairs_topk": "allpairs_topk_ranked<64>", "conv_bwd": "conv_bwd_cols<64>", "spmm_fwd": "spmm_fwd_narrow<64>"}
-    for n_, v in kern.items():
+    ROCPROF_NAME = {"allpairs_topk": "allpairs_topk_ranked<64>", "conv_bwd": "conv_bwd_node<64>", "spmm_fwd": "spmm_fwd_narrow<64>"}
+    for v in kern.values():
         v["GBps"] = v["compulsory"] / (v["ms"] * 1e-3) / 1e9
         v["gather_GBps"] = v["gathered"] / (v["ms"] * 1e-3) / 1e9
     pairs = float(rows_loc) * N
+    t_pair = tk["allpairs_topk"]
+
+    # ---- variants of the same step ("and a symmetric run", "also report h=128"; the reference script's own defaults
+    # are perturb_edge_prob=False / symmetric_noise=True, train_small_graphs.py:153-163): one window each, eager launches
+    variants = None
+    if world == 1 and not force and not emu and a.variants:
+        variants = {}
+        vsteps = max(5, a.steps // 2)
+        for name, (nm, lat, xg) in {"symmetric": (ops.NOISE_HASH_SYM, h, False), "unperturbed": (ops.NOISE_NONE, h, False),
+                                    "hash_asymmetric": (ops.NOISE_HASH, h, False), "latent128": (noise_mode, 128, False),
+                                    "x_grad": (noise_mode, h, True)}.items():
+            try:
+                rv = SyntheticRun(a, dev, 1, 0, False, N, d, lat, nm, xg)
+                for s_ in range(2):
+                    rv.step(s_)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for s_ in range(vsteps):
+                    rv.step(s_ % NGRAPH)
+                torch.cuda.synchronize()
+                tv = (time.perf_counter() - t0) / vsteps
+                ops.PROBE = {}
+                rv.step(0)
+                torch.cuda.synchronize()
+                pv, ops.PROBE = ops.PROBE, None
+                e0, e1 = pv["allpairs_topk"][0]
+                kv = float(rv.layer.saved["k"].mean().item())
+                variants[name] = {"ms_per_step": tv * 1e3, "edges_per_s": N * kv / tv, "pair_kernel_ms": e0.elapsed_time(e1), "steps": vsteps}
+                del rv
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001
+                variants[name] = {"error": repr(e)}
 
     if rank == 0:
+        coll = world > 1 or force
         out = {
             "metric": METRIC, "value": Nval * kmean / T, "unit": "edges/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": T * 1e3, "higher_is_better": True,
-            "scaling": "strong" if a.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeats": {"windows": len(times), "steps_per_window": a.steps, "value_from": "median window",
+                        "window_ms_per_step": [t_ / a.steps * 1e3 for t_ in times], "timed_seconds_total": float(sum(times))},
             "config": {"workload": f"synthetic all-pairs DGG N={N} d={d} h={h} k~{kmean:.1f} K=64, u-v-dist/x/"
                                    f"k_times_edge_prob, Gumbel(0,0.3) perturbation, + normalize + GCNConv({d},64), fwd+bwd",
                        "nodes": N, "feat": d, "latent": h, "ell_width": 64, "pairs_per_s": N * float(N) / T,
-                       "x_grad": a.x_grad, "topk_algo": a.algo, "noise": a.noise, "hipgraph": graph is not None,
-                       "parallelism": f"row-shard x{world}" if not emu else f"DIAGNOSTIC: compute of rank {erank} of {emu}, no collectives",
-                       "feature_exchange": ("single GPU" if world == 1 and not force else
+                       "x_grad": a.x_grad, "topk_algo": a.algo, "noise": a.noise, "noise_seeds_cycled": NGRAPH, "hipgraph": graphed,
+                       "hipgraph_note": None if graphed or not coll else "steps with collectives are launched eagerly (set "
+                                        "DGG_BENCH_GRAPH_DIST=1 to try capturing the RCCL calls)",
+                       "parallelism": f"row-shard x{world}" if not emu else f"DIAGNOSTIC: compute of rank {run.erank} of {emu}, no collectives",
+                       "rows_per_rank": rows_loc,
+                       "feature_exchange": ("single GPU" if not coll else
                                             "features replicated at load, every rank projects all rows; per-step collectives: all-gather row sums, "
-                                            "all-reduce da + weight gradients" if x_full is not None else
-                                            "per step: all-gather xp, all-gather X, all-gather row sums, all-reduce da + weight gradients"
-                                            + (", reduce-scatter dX" if a.x_grad else ""))},
-            # dominant kernel BY TIME of the step (an O(N*K) gather/scatter kernel since the pair stage became O(N*150))
+                                            "all-reduce da + weight gradients" if run.x_full is not None else
+                                            "per step: all-gather [xp | H] (projections of the own rows), all-gather row sums, all-reduce da, "
+                                            "reduce-scatter [dxp | dH], all-reduce weight gradients")},
+            # dominant kernel BY TIME of the step (an O(N*K) gather kernel since the pair stage became O(N*150))
             "roofline": {"bound": "hbm", "kernel": dom, "rocprof_kernel": ROCPROF_NAME.get(dom), "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": traffic.get(dom),
                          "kernel_ms": kern[dom]["ms"], "algorithmic_bytes": kern[dom]["compulsory"],
@@ -612,28 +716,28 @@ def main():
                          "note": "frac = SURVEY 8(d) compulsory bytes (every array touched once) / event-timed duration / 8 TB/s; the kernel "
                                  "is a random-row gather from an Infinity-Cache-resident 25.6 MB table, whose ceiling is the guide's "
                                  "measured 8.6 TB/s (MI355X_MICROARCH.md, 'Indexed rows'): frac_gather_ceiling counts every gathered row "
-                                 "once per use against that"},
+                                 "once per use against that; traffic = fabric bytes per launch from the PMC passes (null when not "
+                                 "measured for this shape)"},
             "kernels": {n_: {"ms": v["ms"], "GBps": v["GBps"], "frac_hbm": v["GBps"] / HBM_PEAK_GBPS, "gather_GBps": v["gather_GBps"],
-                             "frac_gather_ceiling": v["gather_GBps"] / GATHER_CEILING_GBPS,
+                             "frac_gather_ceiling": v["gather_GBps"] / GATHER_CEILING_GBPS, "fabric_bytes_per_launch": traffic.get(n_),
                              **({"composite": v["composite"]} if "composite" in v else {})} for n_, v in kern.items()},
-            # the north-star pair stage: SURVEY 8(d) algorithmic flops (232/pair over all N^2 pairs) per second; the
-            # ranked / pruned kernels score only the pairs that can still enter a row's top-64, so this exceeds the
-            # fp32 peak by construction (the exhaustive kernel, which executes every pair, reaches frac 0.07)
-            # the three whole-step fractions it asks to be published, labelled.  F = 232 flop/pair over all N^2
-            # pairs (the dense formulation's arithmetic), B = compulsory bytes (12 kB per node: every array touched once),
-            # B_virt = the N^2 fp32 score matrix scanned once.  T_roof = F/P_fp32 + B/BW_HBM is the roofline time of the DENSE
-            # formulation; this build's search never executes the unreachable pairs, so T < T_roof.
+            # the whole-step fractions it asks to be published, labelled.  F = 232 flop/pair over all N^2 pairs (the
+            # dense formulation's arithmetic), B = compulsory bytes (12 kB per node: every array touched once), B_virt = the N^2 fp32
+            # score matrix scanned once.  T_roof = F/P_fp32 + B/BW_HBM is the roofline time of the DENSE formulation; this build's
+            # search never executes the unreachable pairs, so T < T_roof (a fraction above 1 is NOT a kernel-efficiency claim).
             "survey_8d": {"F_flop": FLOP_PER_PAIR * N * float(N), "B_bytes": 12e3 * N * (d / 128.0), "B_virt_bytes": 4.0 * N * float(N),
                           "T_s": T, "T_roof_dense_s": FLOP_PER_PAIR * N * float(N) / (FP32_PEAK_TFLOPS * 1e12) + 12e3 * N / (HBM_PEAK_GBPS * 1e9),
                           "frac_dense_roofline": (FLOP_PER_PAIR * N * float(N) / (FP32_PEAK_TFLOPS * 1e12) + 12e3 * N / (HBM_PEAK_GBPS * 1e9)) / T,
                           "frac_hbm_compulsory": 12e3 * N / T / (HBM_PEAK_GBPS * 1e9),
                           "frac_hbm_virtual_stream": 4.0 * N * float(N) / T / (HBM_PEAK_GBPS * 1e9),
                           "frac_hbm_gathered": sum(v["gathered"] for v in kern.values()) / T / (HBM_PEAK_GBPS * 1e9),
-                          "note": "fractions above 1 mean the step beats that (dense-formulation) bound; frac_hbm_gathered counts the "
-                                  "gathered rows of the five gather kernels once per use over the whole step time"},
-            "pair_stage": {"kernel": "allpairs_topk(" + a.noise + ")", "kernel_ms": t_pair * 1e3,
-                           "algorithmic_tflops": FLOP_PER_PAIR * pairs / t_pair / 1e12, "fp32_peak_tflops": FP32_PEAK_TFLOPS,
-                           "pairs_per_s": pairs / t_pair},
+                          "note": "whole-step figures against the DENSE formulation's bounds; frac_hbm_compulsory is the honest HBM fraction "
+                                  "of the step (every array once); frac_hbm_gathered counts the gathered rows of the gather kernels once "
+                                  "per use over the whole step time"},
+            "pair_stage": {"kernel": "allpairs_topk(" + a.noise + ")", "kernel_ms": t_pair * 1e3, "pairs_per_s": pairs / t_pair,
+                           "note": "the ranked-noise search scores ~80 candidates per row, not N: N^2 flop counts do not apply to it; the "
+                                   "kernels that sweep all N^2 pairs are the `symmetric` / `unperturbed` / `hash_asymmetric` variants"},
+            "variants": variants,
         }
         if a.cpu_rows >= 0 and world == 1:
             cores = os.cpu_count() or 1
@@ -643,6 +747,15 @@ def main():
             except Exception as e:  # the baseline leg must never take the measurement down
                 out["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
+            if a.cpu_dense:
+                # BASELINE.md section 3 sizes of the dense reference-shaped formulation (Cora-size edge list, 4 000-node all-pairs);
+                # N = 19 717 runs with --workload pubmed.  Extrapolation to N = 100 000 from the all-pairs rate, labelled as such.
+                # (32 threads: the [N,N] elementwise stages of these sizes do not scale beyond that; more threads only add overhead)
+                dense = cpu_dense_formulation([("edgelist", 2708, d, h), ("allpairs", 4000, d, h)], min(cores, 32))
+                out["cpu_baseline"]["dense_formulation"] = dense
+                ap_ = [q for q in dense if q.get("candidates") == "allpairs" and "dense_entries_per_s" in q]
+                if ap_:
+                    out["cpu_baseline"]["dense_formulation_extrapolated_s_at_this_N"] = float(N) * N / ap_[0]["dense_entries_per_s"]
         emit_json((out))
     if dist.is_initialized():
         dist.destroy_process_group()
