@@ -24,8 +24,9 @@ class AllPairs:
 class EllAdjacency:
     """Row-major fixed-width sparse matrix: entry (i, idx[i,r]) = values[i,r]; idx == -1 marks padding."""
 
-    def __init__(self, idx, values, n_cols, rs=None, k=None, score=None, normalized=False, part=None):
+    def __init__(self, idx, values, n_cols, rs=None, k=None, score=None, normalized=False, part=None, owner=None):
         self.idx, self._values, self.n_cols = idx, values, n_cols
+        self.owner = owner          # the DGG module that produced it (its ELL-width bound is checked when the matrix is densified)
         self.rs, self.k, self.score, self.normalized = rs, k, score, normalized
         self.part = part            # destination-ordered partition of the active entries (ops.part_build), if one was built
         self.shape = (idx.shape[0], n_cols)
@@ -43,12 +44,16 @@ class EllAdjacency:
 
     def to_dense(self):
         """Differentiable densification (small graphs / tests only)."""
+        if self.owner is not None:
+            self.owner.check_ell_bound()
         valid = self.idx >= 0
         cols = self.idx.clamp(min=0).long()
         out = torch.zeros(self.shape, device=self.device, dtype=self._values.dtype)
         return out.scatter_add(1, cols, torch.where(valid, self._values, torch.zeros_like(self._values)))
 
     def to_sparse(self):
+        if self.owner is not None:
+            self.owner.check_ell_bound()
         valid = self.idx >= 0
         rows = torch.arange(self.shape[0], device=self.device).unsqueeze(1).expand_as(self.idx)[valid]
         return torch.sparse_coo_tensor(torch.stack([rows, self.idx[valid].long()]), self._values[valid], self.shape)
@@ -63,7 +68,8 @@ class EllAdjacency:
         """D^-1/2 A D^-1/2 with ROW sums on both sides (normalize_adj, model.py:1205-1219)."""
         rs = self.row_sums()
         ahat = ops.EllNormalizeFn.apply(self._values, self.idx, rs, self.part)
-        return EllAdjacency(self.idx, ahat, self.n_cols, rs=None, k=self.k, score=self.score, normalized=True, part=self.part)
+        return EllAdjacency(self.idx, ahat, self.n_cols, rs=None, k=self.k, score=self.score, normalized=True, part=self.part,
+                            owner=self.owner)
 
     def matmul(self, X, act=ops.ACT_NONE):
         """act(A @ X) (torch.mm(adj, x), model.py:594; act = ReLU fuses GCNConv's activation into the aggregation)."""

@@ -97,8 +97,14 @@ def add_noisy_edges(rows, cols, N, noise_level, reference_stream=None, seed=0):
         hit = np.flatnonzero(np.random.rand(N, N).reshape(-1) < p)
     else:
         rng = np.random.default_rng(seed)
-        n_noise = rng.binomial(N * N, p)
-        hit = np.unique(rng.integers(0, N * N, size=int(n_noise * 1.02) + 16))[:n_noise]
+        n_noise = int(rng.binomial(N * N, p))
+        # uniform positions WITHOUT replacement: draw until n_noise distinct ones exist, then drop the excess at random (np.unique
+        # sorts: cutting its tail would always remove the largest flat indices, i.e. thin out the last rows)
+        hit = np.unique(rng.integers(0, N * N, size=int(n_noise * 1.02) + 16))
+        while hit.shape[0] < n_noise:
+            hit = np.unique(np.concatenate([hit, rng.integers(0, N * N, size=n_noise - hit.shape[0] + 16)]))
+        if hit.shape[0] > n_noise:
+            hit = np.sort(rng.permutation(hit)[:n_noise])
     hit = hit[(hit // N) != (hit % N)]
     hit = np.setdiff1d(hit, have, assume_unique=False)
     key = np.concatenate([have, hit])

@@ -240,6 +240,7 @@ class DGG_LearnableK_debug(nn.Module):
         self.topk_algo = getattr(args, "dgg_topk_algo", 0)
         self._explicit_noise = None          # test hook: the G that gumbel_sample(log_p, G) would receive
         self._seed = None
+        self._overflow = None                # device bool: a row's ramp support k_i + 8.5 exceeded the ELL width (see check_ell_bound)
 
     # test / reproducibility hooks ---------------------------------------------------------------------------
     def set_noise(self, G):
@@ -248,6 +249,29 @@ class DGG_LearnableK_debug(nn.Module):
 
     def set_seed(self, s0, s1=0):
         self._seed = (int(s0) & 0xFFFFFFFF, int(s1) & 0xFFFFFFFF)
+
+    def check_ell_bound(self):
+        """The sparse formulation keeps `ell_width` (64) entries per row, which is EXACT while every row's ramp support fits:
+        k_i + 8.5 <= ell_width, or the row has no more candidates than the width.  The learned k is
+        unbounded (k = relu(kp sd + mu) + 1, dgm.py:1580-1584), so every forward ORs the violation into a device flag (no
+        sync on the hot path); this method reads it (one sync) and raises.  Called by `EllAdjacency.to_dense()/to_sparse()`,
+        by the training harness once per epoch, and on every forward when DGG_STRICT_BOUND=1."""
+        if self._overflow is not None and bool(self._overflow):
+            self._overflow = None
+            raise RuntimeError(
+                f"DGG_LearnableK_debug: a row's learned degree satisfies k + 8.5 > ell_width = {self.ell_width} while it has more "
+                "candidates than that: ranks the reference still weights were dropped (row sums, normalisation and gradients "
+                "differ from the reference from here on).  Rescale the degree prior / k_project, or lower the learning rate of the "
+                "k-net; wider rows are not supported by the ELL kernels.")
+
+    def _track_overflow(self, k, ncand):
+        over = k.detach() + 8.5 > float(self.ell_width)
+        if ncand is not None:
+            over = over & (ncand > self.ell_width)
+        flag = over.any()
+        self._overflow = flag if self._overflow is None else (self._overflow | flag)
+        if __import__("os").environ.get("DGG_STRICT_BOUND") == "1":
+            self.check_ell_bound()
 
     def _noise_cfg(self):
         if not self.args.perturb_edge_prob:
@@ -420,11 +444,12 @@ class DGG_LearnableK_debug(nn.Module):
             w, idx, val, rs = _DGGEdgeMlpAdjFn.apply(x, k, deg, ex_in, We, be, mlp["Wcat"], mlp["wdu"], mlp["wdv"], mlp["wex"],
                                                      mlp["b1"], mlp["w2"], mlp["b2"], cfg)
         k = k.detach()
+        self._track_overflow(k, None if cand is None else (rowptr[1:] - rowptr[:-1]))
         if writer is not None:   # the two scalars the reference logs from inside the DGG (dgm.py:1259-1261)
             f = w.detach() if (cfg["mode"] == ops.MODE_K_ONLY or "fwd_mode" in cfg) else (w.detach() / val.clamp(min=1e-30))
             writer.add_scalar("values/first_k_std", f.sum(-1).std(), epoch)
             writer.add_scalar("values/first_k_mean", f.sum(-1).mean(), epoch)
-        return EllAdjacency(idx, w, x.shape[0], rs=rs, k=k, score=val, part=cfg.get("part"))
+        return EllAdjacency(idx, w, x.shape[0], rs=rs, k=k, score=val, part=cfg.get("part"), owner=self)
 
 
 class _DGGClassFn(torch.autograd.Function):

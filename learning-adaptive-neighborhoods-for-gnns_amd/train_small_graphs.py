@@ -4,6 +4,11 @@ coalesced COO fp32, model looked up by class name, nll_loss on the public split.
 
     python -m dgg_amd.train_small_graphs --data cora --data_dir /path/to/planetoid --model GCN_DGG_00 --epochs 5
 
+Flag DEFAULTS are the reference script's (train_small_graphs.py:20-207), with two exceptions that the reference cannot run
+as shipped: `--extra_edge_dim` defaults to 2 (the default scorer `u-v-deg` concatenates two degree
+features, dgm.py:1660-1662; the reference's default 0 shape-mismatches) and the script's `edge_index=` keyword is dropped
+for wrappers that reject it (reference GCN_DGG.forward raises TypeError on it).  Optimiser groups follow
+train_small_graphs.py:399-418 (GCNII / GCN / SAGE / GAT branches).
 Only the flags the model constructors / DGG read are kept (no tensorboard, no code snapshots).  `--checkpoint FILE` saves
 the best-validation state in the reference's `save_checkpoint` layout (train_small_graphs.py:210-220: args, epoch,
 model_state_dict, optimizer_state_dict); `--resume FILE` loads `model_state_dict` as its `test_best` does (line 330) -- the
@@ -41,17 +46,17 @@ def build_parser():
     p.add_argument("--alpha", type=float, default=0.1)
     p.add_argument("--lamda", type=float, default=0.5)
     p.add_argument("--variant", type=str2bool, default=False)
-    p.add_argument("--model", default="GCN_DGG_00")
+    p.add_argument("--model", default="GCN_DGG")                      # reference default (train_small_graphs.py:69-73)
     p.add_argument("--edge_noise_level", type=float, default=0.00014)
     # DGG flags (reference train_small_graphs.py:92-207)
-    p.add_argument("--extra_edge_dim", type=int, default=0)
+    p.add_argument("--extra_edge_dim", type=int, default=2)          # reference: 0, which its default scorer cannot run with
     p.add_argument("--extra_k_dim", type=int, default=1)
     p.add_argument("--dgg_hard", type=str2bool, default=False)
     p.add_argument("--deg_mean", type=float, default=3.899)
     p.add_argument("--deg_std", type=float, default=5.288)
-    p.add_argument("--n_dgg_layers", type=int, default=1)
+    p.add_argument("--n_dgg_layers", type=int, default=2)            # reference default (only GCNII-type wrappers read it)
     p.add_argument("--debug_step", type=int, default=3)
-    p.add_argument("--symmetric_noise", type=str2bool, default=False)
+    p.add_argument("--symmetric_noise", type=str2bool, default=True)  # reference default (train_small_graphs.py:153-156)
     p.add_argument("--perturb_edge_prob", type=str2bool, default=False)
     p.add_argument("--stochastic_k", type=str2bool, default=False)
     p.add_argument("--dgg_adj_input", default="input_adj")
@@ -115,12 +120,17 @@ def main(argv=None):
     model = models.__dict__[args.model](nfeat=x.shape[1], nlayers=args.layer, nhidden=args.hidden, nclass=d["num_classes"],
                                         dropout=args.dropout, lamda=args.lamda, alpha=args.alpha, variant=args.variant,
                                         args=args).to(device)
-    if "II" in args.model:
+    # optimiser groups by model-name substring, as reference train_small_graphs.py:399-418
+    if "GCN" in args.model and "II" in args.model:
         opt = torch.optim.Adam([{"params": model.params1, "weight_decay": args.wd1},
                                 {"params": model.params2, "weight_decay": args.wd2}], lr=args.lr)
-    elif hasattr(model, "params1"):
+    elif "GCN" in args.model:
         opt = torch.optim.Adam([dict(params=model.params1, weight_decay=5e-4), dict(params=model.params2, weight_decay=0)],
-                               lr=args.lr)
+                               lr=args.lr)                      # weight decay on the first convolution only
+    elif "SAGE" in args.model:
+        opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    elif "GAT" in args.model:
+        opt = torch.optim.Adam(model.parameters(), lr=0.005, weight_decay=5e-4)
     else:
         opt = torch.optim.Adam(model.parameters(), lr=args.lr)
     if args.resume:
@@ -133,6 +143,9 @@ def main(argv=None):
         loss = F.nll_loss(out[idx["train_idx"]], y[idx["train_idx"]])
         loss.backward()
         opt.step()
+        for dg in getattr(model, "dggs", []):                    # learned k must stay inside the ELL width (one sync per epoch)
+            if hasattr(dg, "check_ell_bound"):
+                dg.check_ell_bound()
         model.eval()
         with torch.no_grad():
             out = forward(model, x, adj, edge_index=edge_index)

@@ -262,6 +262,116 @@ def cora_cases():
     print("cora ok: edges", ei.shape[1], "noisy", len(nr), "loss", float(loss), "max row", int(np.bincount(nr).max()))
 
 
+def edgelist512_cases():
+    """SURVEY 8(c) G2 at N = 512: sparse candidates (avg degree 40: rows wider than the ramp support), noise / cotangent
+    regenerated from seeds at test time, outputs stored as the top-64 of every row (exact: the rest is zero)"""
+    N, d, h = 512, 48, 32
+    gen = torch.Generator().manual_seed(71)
+    in_adj = random_graph(N, 40, gen)
+    x = torch.from_numpy(grid_normal(72, (N, d)))
+    G = grid_gumbel(73, (N, N))
+    cotn = grid_normal(74, (N, N))
+    for nz in ["none", "asym"]:
+        a = base_args(perturb_edge_prob=(nz != "none"))
+        run_dgg(f"edgelist_n512_{nz}", N, d, h, a, in_adj, x, None if nz == "none" else G, torch.from_numpy(cotn), 1.0, False,
+                seed_info=dict(x_seed=72, G_seed=73, cot_seed=74, G_crc=crc(G), cot_crc=crc(cotn)))
+
+
+def hard_cases():
+    """dgg_hard=True through the live class's LITERAL return_hard_or_soft (dgm.py:1294-1311) with k_times_edge_prob -- the one
+    select mode it runs for.  Stored: the dense hard output, the soft adjacency it was derived from, the sort
+    permutation select_top_k returned (idxs) and the gradients of a fixed cotangent."""
+    for tag, N, d, h, allp in [("edgelist", 96, 24, 16, False), ("allpairs", 128, 32, 16, True)]:
+        gen = torch.Generator().manual_seed(81 + N)
+        x = torch.randn(N, d, generator=gen)
+        if allp:
+            c = 8 + 10 * torch.rand(N, 1, generator=gen)
+            in_adj = (c / N * torch.ones(N, N)).to_sparse().coalesce()
+        else:
+            in_adj = random_graph(N, 24, gen)
+        G = grid_gumbel(83 + N, (N, N))
+        cot = torch.from_numpy(grid_normal(84 + N, (N, N)))
+        a = base_args(dgg_hard=True)
+        torch.manual_seed(1234)
+        m = dgm.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=a)
+        with torch.no_grad():
+            m.k_net.k_project.weight.mul_(30.0 if allp else 1.0)
+        m.eval()
+        Gt = torch.from_numpy(G)
+        m.gumbel.sample = lambda shape: Gt.reshape(shape)
+        cap = {}
+        _sel, _ret = m.select_top_k, m.return_hard_or_soft
+
+        def sel(Nn, k, pert, **kw):
+            cap["pert"], cap["k"] = pert.detach().squeeze(0).clone(), k.detach().flatten().clone()
+            out = _sel(Nn, k, pert, **kw)
+            cap["soft"], cap["idxs"] = out[0].detach().squeeze(0).clone(), out[2].detach().squeeze(0).clone()
+            return out
+
+        m.select_top_k = sel
+        xg = x.clone().requires_grad_(True)
+        out = m(xg, in_adj).to_dense()
+        (out * cot).sum().backward()
+        fx = {"x": x.numpy(), "deg": in_adj.to_dense().sum(-1).numpy(), "k": cap["k"].numpy(), "G": G, "cot": cot.numpy(),
+              "out": out.detach().numpy(), "soft": cap["soft"].numpy(), "idxs": cap["idxs"].numpy().astype(np.int16),
+              "pert": cap["pert"].numpy(), "g.x": xg.grad.numpy()}
+        if not allp:
+            ii = in_adj.indices().numpy().astype(np.int32)
+            fx["rows"], fx["cols"], fx["adj_vals"] = ii[0], ii[1], in_adj.values().numpy()
+        for k_, v in m.state_dict().items():
+            fx["p." + k_] = v.detach().numpy()
+        for k_, p_ in m.named_parameters():
+            fx["g." + k_] = p_.grad.numpy() if p_.grad is not None else np.zeros_like(p_.detach().numpy())
+        meta = dict(name=f"hard_{tag}", N=N, d=d, h=h, torch=torch.__version__, args=vars(a), k_scale=30.0 if allp else 1.0,
+                    reference="dgm.py:1294-1311 return_hard_or_soft (dgg_hard=True) after select_top_k k_times_edge_prob")
+        fx["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, f"hard_{tag}.npz"), **fx)
+        print(f"hard_{tag}: ones/row {float((out != 0).sum(-1).float().mean()):.2f}, soft>0.5/row "
+              f"{float((cap['soft'] > 0.5).sum(-1).float().mean()):.2f}, |g.We| {np.abs(fx['g.node_encode_for_edges.0.weight']).max():.3e}")
+
+
+def cora_model_cases():
+    """SURVEY 8(c) G8 / BASELINE configs[0] in its NAMED form: the reference's own Cora tensors (cora_gcn_dgg_00.npz holds the
+    inputs: features, clean and noisy edges, split) through `--model GCN_DGG` with the script's default scorer made runnable
+    (u-v-deg needs extra_edge_dim=2; perturb_edge_prob False as in train_small_graphs.py:157-163), through
+    GCNII_DGG with nlayers=4 and through GCNIIppi_DGG; eval mode, h = 16.  Only outputs + state_dicts are stored here."""
+    z = np.load(os.path.join(HERE, "cora_gcn_dgg_00.npz"))
+    N, dF = 2708, 1433
+    feats = torch.zeros(N, dF)
+    feats[z["feat_rows"].astype(np.int64), z["feat_cols"].astype(np.int64)] = torch.from_numpy(z["feat_vals"])
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([z["noisy_rows"], z["noisy_cols"]]).astype(np.int64)),
+                                torch.ones(len(z["noisy_rows"])), (N, N)).coalesce()
+    labels, itr = torch.from_numpy(z["labels"].astype(np.int64)), torch.from_numpy(z["train_idx"])
+    h, C = 16, 7
+    for name, a, ctor in [
+        ("cora_gcn_dgg", base_args(dgg_mode_edge_net="u-v-deg", extra_edge_dim=2, perturb_edge_prob=False, symmetric_noise=True),
+         lambda a: refmodel.GCN_DGG(nfeat=dF, nlayers=2, nhidden=h, nclass=C, args=a)),
+        ("cora_gcnii_dgg", base_args(perturb_edge_prob=False),
+         lambda a: refmodel.GCNII_DGG(nfeat=dF, nlayers=4, nhidden=h, nclass=C, dropout=0.5, lamda=0.5, alpha=0.1, variant=False, args=a)),
+        ("cora_gcniippi_dgg", base_args(perturb_edge_prob=False),
+         lambda a: refmodel.GCNIIppi_DGG(nfeat=dF, nlayers=4, nhidden=h, nclass=C, dropout=0.5, lamda=0.5, alpha=0.1, variant=True, args=a)),
+    ]:
+        torch.manual_seed(4321)
+        m = ctor(a)
+        m.eval()
+        with torch.no_grad():
+            out = m(feats, A)
+        logp = out[0] if isinstance(out, tuple) else out
+        fx = {"out": logp.numpy()}
+        if name == "cora_gcn_dgg":
+            fx["loss"] = np.float32(torch.nn.functional.nll_loss(logp[itr], labels[itr]).item())
+            un = out[1].to_dense()
+            fx["unnorm_rowsum"] = un.sum(-1).numpy()
+            fx["unnorm_nnz"] = (un != 0).sum(-1).numpy().astype(np.int32)
+        for k_, v in m.state_dict().items():
+            fx["p." + k_] = v.detach().numpy()
+        meta = dict(name=name, N=N, d=dF, h=h, C=C, torch=torch.__version__, args=vars(a), inputs="cora_gcn_dgg_00.npz",
+                    reference="model.py GCN_DGG 1183-1311 / GCNII_DGG 649-740 (nlayers=4) / GCNIIppi_DGG 887-965 on utils.load_citation('cora')")
+        fx["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+        print(name, "ok", tuple(logp.shape), float(logp.abs().max()))
+
+
 def gat_cases():
     """GAT_DGG_00 (model.py:323-403) with its dense [N,N] attention; in_adj carries noisy edges that edge_index lacks."""
     refmodel.remove_self_loops = lambda ei: (ei[:, ei[0] != ei[1]], None)                     # torch_geometric.utils stand-ins
@@ -587,6 +697,12 @@ if __name__ == "__main__":
         dense_cases()
     if "scores" in which:
         scores_cases()
+    if "edgelist512" in which:
+        edgelist512_cases()
+    if "hard" in which:
+        hard_cases()
+    if "cora_models" in which:
+        cora_model_cases()
 
 
 def model_cases():
