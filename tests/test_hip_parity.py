@@ -913,15 +913,18 @@ def test_small_graph_harness_trains_on_planetoid_files(dev, tmp_path):
 
     H.F.nll_loss = spy
     try:
-        for model, extra in [("GCN_DGG_00", []), ("GCN_DGG", ["--dgg_mode_edge_net", "u-v-deg", "--extra_edge_dim", "2"]),
-                             ("GAT_DGG_00", []), ("SAGE_DGG", ["--dgg_mode_edge_net", "u-v-dist"]), ("SAGE_DGG_00", [])]:
+        # the *_00 wrappers use the `DGG` class, whose edge encoder takes latent_dim features: extra_edge_dim 0 (dgm.py:1784-1785);
+        # GCN_DGG runs with the harness defaults (= the reference script's, u-v-deg made runnable with extra_edge_dim 2)
+        z0 = ["--extra_edge_dim", "0"]
+        for model, extra in [("GCN_DGG_00", z0), ("GCN_DGG", []), ("GAT_DGG_00", z0),
+                             ("SAGE_DGG", ["--dgg_mode_edge_net", "u-v-dist"] + z0), ("SAGE_DGG_00", z0)]:
             losses.clear()
             H.main(["--data", "toy", "--data_dir", str(tmp_path), "--model", model, "--hidden", "16", "--epochs", "12",
                     "--edge_noise_level", "0.001", "--lr", "0.02"] + extra)
             assert len(losses) == 12 and losses[-1] < losses[0], (model, losses)
         # checkpoint in the reference's save_checkpoint layout (train_small_graphs.py:210-220) and resume from it
         ck = str(tmp_path / "best.pt")
-        common = ["--data", "toy", "--data_dir", str(tmp_path), "--model", "GCN_DGG_00", "--hidden", "16", "--edge_noise_level", "0.001"]
+        common = ["--data", "toy", "--data_dir", str(tmp_path), "--model", "GCN_DGG_00", "--hidden", "16", "--edge_noise_level", "0.001"] + z0
         best = H.main(common + ["--epochs", "6", "--lr", "0.02", "--checkpoint", ck])
         saved = torch.load(ck, map_location="cpu")
         assert set(saved) == {"args", "epoch", "model_state_dict", "optimizer_state_dict"} and saved["args"]["model"] == "GCN_DGG_00"
@@ -1487,11 +1490,28 @@ def test_cora_named_models_match_reference(dev, name):
         dg.check_ell_bound()                                      # Cora hubs have up to 168 candidates: k + 8.5 must stay <= 64
     err = np.abs(Nn(logp) - fx["out"]) / (np.abs(fx["out"]) + 2.0)
     bad_rows = (err > 1e-5).any(1)
-    print(name, "rows touched by a near-tie swap:", int(bad_rows.sum()), "max err", float(err.max()))
-    assert bad_rows.sum() <= 8 and err.max() <= 5e-4
+    # Row-normalised bag-of-words features give many EXACTLY tied scores (fixture `tie_gap`: smallest relative gap between two
+    # consecutive ranks that carry ramp weight; hundreds of rows have 0).  The reference orders ties by an unstable sort, this
+    # build by column: where a tie straddles the ramp, two neighbours exchange their weights (the row SUM is unchanged: checked
+    # below to 1e-6) and the row's output moves; every later layer spreads that to the rows aggregating it.  So: rows that no
+    # tied row can reach must match to 1e-5, the others are bounded.
+    tie = torch.from_numpy(fx["tie_gap"] < 1e-5).to(dev)
+    adj0 = m.dggs[0](T(x, dev), dgg_amd.model._with_self_loops(A))
+    nb = adj0.idx.long().clamp(min=0)
+    live = (adj0.idx >= 0) & (adj0.values() != 0)
+    reach = tie.clone()
+    for _ in range({"cora_gcn_dgg": 1, "cora_gcnii_dgg": 3, "cora_gcniippi_dgg": 3}[name]):
+        reach = reach | (reach[nb] & live).any(1)
+    clean = ~Nn(reach)
+    print(name, "tied rows", int(tie.sum()), "rows a tie can reach", int(reach.sum()), "deviating rows", int(bad_rows.sum()),
+          "max err", float(err.max()))
+    assert not bad_rows[clean].any(), "a row that no tied row reaches deviates from the reference"
+    assert err.max() <= 2e-3 and bad_rows.sum() <= 0.05 * N
     if name == "cora_gcn_dgg":
         un = out[1]
-        np.testing.assert_allclose(Nn(un.values().sum(1)), fx["unnorm_rowsum"], rtol=1e-4, atol=1e-5)
+        assert clean.sum() > 0.1 * N
+        np.testing.assert_allclose(Nn(un.values().sum(1)), fx["unnorm_rowsum"], rtol=1e-6, atol=1e-6)
+        assert np.array_equal(Nn((un.values() != 0).sum(1)), fx["unnorm_nnz"])
         y = torch.from_numpy(inp["labels"].astype(np.int64)).to(dev)
         tr = torch.from_numpy(inp["train_idx"]).to(dev)
         assert abs(float(torch.nn.functional.nll_loss(logp[tr], y[tr])) - float(fx["loss"])) < 1e-4
