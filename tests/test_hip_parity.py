@@ -1543,3 +1543,100 @@ def test_ell_width_bound_is_enforced(dev):
     A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows[o], cols[o]])), torch.full((2048,), 12.0), (256, 256)).coalesce().to(dev)
     m(x, A)                                                       # k ~ 97, but 8 candidates per row
     m.check_ell_bound()
+
+
+def test_config1_pubmed_shape_edge_list_step(dev):
+    """BASELINE configs[1]: Pubmed shape (N = 19 717, d = 500, 44 324 undirected edges + self loops, k ~ 16), the drop-in modules
+    forward + backward; neighbour lists and scores bit-exact against the oracle's edge-list pipeline on EVERY row, weights 1e-5,
+    gradients of the DGG parameters against the oracle's backward (2e-4 of max)"""
+    import bench
+    import dgg_amd
+    from argparse import Namespace
+    N, d, h = 19_717, 500, 64
+    rows, cols = bench.pubmed_graph(N, 44_324)
+    o = np.lexsort((cols, rows))
+    rows, cols = rows[o], cols[o]
+    E = rows.shape[0]
+    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
+    torch.manual_seed(0)
+    dgg = dgg_amd.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=args)
+    conv = dgg_amd.GCNConv(d, 64)
+    with torch.no_grad():
+        dgg.k_net.k_project.weight.mul_(0.1)
+    dgg, conv = dgg.to(dev), conv.to(dev)
+    dgg.set_seed(1234, 0)
+    # non-negative features (Pubmed's are TF-IDF): with W ~ U[0,1) no activation sits at the ReLU kink, where the two summation
+    # orders relu(A (x W)) / relu((A x) W) could fall on different sides and the gradient comparison would be discontinuous
+    x = torch.rand(N, d, generator=torch.Generator().manual_seed(1))
+    vals = torch.full((E,), 16.0 * N / E)
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), vals, (N, N)).coalesce().to(dev)
+    adj = dgg(x.to(dev), A)
+    out = conv(x.to(dev), adj.normalize())
+    out.sum().backward()
+    dgg.check_ell_bound()
+    assert torch.isfinite(out).all()
+    # oracle: the whole edge-list pipeline (O(E))
+    sd = {k_: Nn(v) for k_, v in dgg.state_dict().items()}
+    rowptr, col = csr_from_coo(rows, cols, N)
+    deg = Nn(dgg_amd.csr_candidates(A)[2])
+    xn = x.numpy()
+    xp = O.linear(xn, sd["node_encode_for_edges.0.weight"], sd["node_encode_for_edges.0.bias"], O.ACT_LEAKY)
+    xk = O.linear(xn, sd["node_encode_for_k.0.weight"], sd["node_encode_for_k.0.bias"], O.ACT_LEAKY)
+    mu, sdv = O.degree_stats(deg)
+    k = O.knet_x(xk, deg, mu, sdv, sd["k_embed.0.weight"], sd["k_embed.0.bias"], sd["k_net.k_mu.weight"], sd["k_net.k_mu.bias"],
+                 sd["k_net.k_project.weight"].reshape(-1), sd["k_net.k_project.bias"])
+    assert 15.0 < float(k.mean()) < 20.0                           # k ~ 16 (+1, + the k-net output at default init)
+    np.testing.assert_allclose(Nn(adj.k), k, rtol=1e-6, atol=1e-6)
+    ridx, rval = O.edgelist_topk(xp, rowptr, col, K=K, noise_mode=O.NOISE_HASH, seed=(1234, 0))
+    assert np.array_equal(Nn(adj.idx), ridx) and np.array_equal(Nn(adj.score), rval)
+    rw, rrs = O.softk(ridx, rval, k)
+    np.testing.assert_allclose(Nn(adj.values()), rw, rtol=0, atol=1e-5)
+    rah = O.normalize(ridx, rw, rrs)
+    Y = O.spmm(ridx, rah, xn)
+    Z = O.linear(Y, Nn(conv.W), None, O.ACT_RELU, w_layout=1)      # reference order relu((A x) W); the module aggregates x W
+    np.testing.assert_allclose(Nn(out), Z, rtol=1e-5, atol=1e-5 * np.abs(Z).max())
+    dY, dWc, _ = O.linear_bwd(Y, Nn(conv.W), Z, np.ones_like(Z), act=O.ACT_RELU, w_layout=1)
+    dA, _ = O.spmm_bwd(ridx, rah, xn, dY, need_dx=False)
+    dval, dk = O.softk_norm_bwd(ridx, rval, k, rw, rrs, dA)
+    dxp = O.edge_bwd(xp, ridx, rval, dval, perturb=True)
+    _, dWe, dbe = O.linear_bwd(xn, sd["node_encode_for_edges.0.weight"], xp, dxp, act=O.ACT_LEAKY, need_dx=False)
+    for got, ref in [(conv.W.grad, dWc), (dgg.node_encode_for_edges[0].weight.grad, dWe), (dgg.node_encode_for_edges[0].bias.grad, dbe)]:
+        np.testing.assert_allclose(Nn(got).reshape(ref.shape), ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+
+
+def test_config3_500k_nodes_in_eight_row_shards(dev):
+    """BASELINE configs[3]: ONE graph of 500 000 nodes, node-range sharded 8 ways.  The eight shards' kernels run one after the
+    other on this GPU (own rows, GLOBAL columns / row sums) and must reproduce the single-shard run bit for bit: neighbour
+    lists, scores, ramp weights, normalised weights and the aggregated output.  (The collectives of the real 8-rank run are
+    covered by tests/test_parallel_gloo.py / test_parallel_gpu.py and tools/dist_scale_check.py.)"""
+    import bench
+    from dgg_amd import ops
+    from dgg_amd.parallel import ShardedDGGConv, shard_bounds
+    N, d, h, G = 500_000, 128, 64, 8
+    P = bench.make_params(d, h, dev)
+    x = torch.randn(N, d, generator=torch.Generator().manual_seed(1000)).to(dev)
+    deg = (24 + 16 * torch.rand(N, generator=torch.Generator().manual_seed(7))).to(dev)
+    layer = ShardedDGGConv(ops, N, K=64, noise_mode=ops.NOISE_RANKED, seed=(1234, 0))
+    Z = layer.forward(x, deg, P)
+    s = layer.saved
+    grads = layer.backward(torch.ones_like(Z), x, P)
+    assert all(torch.isfinite(v).all() for v in grads.values())
+    assert int((s["idx"] >= 0).sum()) > 40 * N
+    for r in range(G):
+        r0, r1, per = shard_bounds(N, G, r)
+        assert per == 62_500
+        idx, val = ops.allpairs_topk(s["xp"], 64, ops.T_DIST, ops.NOISE_RANKED, None, (1234, 0), rows=(r0, r1), k_limit=s["k"][r0:r1].contiguous())
+        assert torch.equal(idx, s["idx"][r0:r1]) and torch.equal(val, s["val"][r0:r1])
+        w, rs = ops.softk_fwd(idx, val, s["k"][r0:r1].contiguous(), 0)
+        assert torch.equal(w, s["w"][r0:r1]) and torch.equal(rs, s["rs"][r0:r1])
+        ahat = ops.normalize_fwd(idx, w, s["rs"], r0)
+        assert torch.equal(ahat, s["ahat"][r0:r1])
+        assert torch.equal(ops.spmm_fwd(idx, ahat, s["H"], 2), Z[r0:r1])
+    # sampled rows against the oracle (it generates the row's complete noise vector and scores all N columns)
+    xp_c = Nn(s["xp"])
+    for r in [0, 62_499, 62_500, 333_333, 499_999]:
+        ri, rv = O.allpairs_topk(xp_c, K=K, noise_mode=O.NOISE_RANKED, seed=(1234, 0), rows=(r, r + 1))
+        m = Nn(s["idx"][r]) >= 0
+        assert np.array_equal(Nn(s["idx"][r])[m], ri[0][m]) and np.array_equal(Nn(s["val"][r])[m], rv[0][m])
