@@ -141,6 +141,18 @@ def pubmed_graph(N, n_und, seed=0):
     return rows, cols
 
 
+def probe_steps(step_fn, nsteps=5):
+    """per-kernel time INSIDE running steps (ops.PROBE events around the C-ABI calls): {name: (ms per step, calls per step)}"""
+    from dgg_amd import ops
+    step_fn()
+    ops.PROBE = {}
+    for _ in range(nsteps):
+        step_fn()
+    torch.cuda.synchronize()
+    probe, ops.PROBE = ops.PROBE, None
+    return {n: (sum(e0.elapsed_time(e1) for e0, e1 in ev) / nsteps, len(ev) / nsteps) for n, ev in probe.items()}
+
+
 def bench_edgelist(a, dev):
     """BASELINE.json configs[1] (Pubmed shape: N=19 717, d=500, edge-list candidates, k~16): the drop-in MODULES
     (DGG_LearnableK_debug -> normalize -> GCNConv) under autograd, forward + backward, one GPU; the oracle pipeline on
@@ -218,9 +230,27 @@ def bench_edgelist(a, dev):
                       "nodes": N, "feat": d, "latent": h, "candidate_edges": E, "selected_edges": nsel,
                       "candidate_edges_per_s": E / T, "edge_mode": a.edge_mode, "hipgraph": graph is not None},
            "roofline": None}
+    # dominant kernel of the step from event probes in eager steps; its compulsory bytes (every operand once)
+    pk = probe_steps(step)
+    dom = max(pk, key=lambda n: pk[n][0])
+    nsel_i = int(nsel)
+    comp = {"linear_fwd": 4.0 * (N * d + N * h + d * h) * pk.get("linear_fwd", (0, 0))[1],
+            "linear_bwd": 4.0 * (N * d + N * h + d * h) * pk.get("linear_bwd", (0, 0))[1],
+            "spmm_fwd": nsel_i * 8 + 2 * N * 4.0 * 64, "conv_bwd": nsel_i * 16 + 3 * N * 4.0 * 64, "edge_bwd": nsel_i * 36 + 4 * N * 4.0 * h}
+    ms = pk[dom][0]
+    cb = comp.get(dom)
+    out["roofline"] = {"bound": "hbm", "kernel": dom, "calls_per_step": pk[dom][1], "kernel_ms": ms,
+                       "achieved": (cb / (ms * 1e-3) / 1e9) if cb else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": (cb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if cb else None, "traffic": None, "algorithmic_bytes": cb,
+                       "note": "event-timed inside eager steps; bytes = every operand of the named kernel's calls touched once; the step is "
+                               "~80 launches of a few microseconds at this size (latency-, not bandwidth-bound)"}
+    out["kernels_ms_per_step"] = {n: v[0] for n, v in pk.items()}
     if a.cpu_rows >= 0 and a.edge_mode == "u-v-dist":
         out["cpu_baseline"] = cpu_baseline_edgelist(N, d, h, rows, cols, x.cpu().numpy(), vals.numpy(), dgg, conv,
                                                     os.cpu_count() or 1)
+        if a.cpu_dense:
+            # the dense reference-shaped formulation at the Pubmed size (about 26 GB of host memory)
+            out["cpu_baseline"]["dense_formulation"] = cpu_dense_formulation([("edgelist", N, d, h)], min(os.cpu_count() or 1, 32))
     emit_json((out))
 
 

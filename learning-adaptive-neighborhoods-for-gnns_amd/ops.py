@@ -107,7 +107,9 @@ def linear_fwd(x, W, b=None, act=ACT_NONE, w_layout=0):
     assert (W.shape[1] if w_layout == 0 else W.shape[0]) == d
     y = torch.empty((N, out), device=x.device, dtype=torch.float32)
     bb = _chk(b) if b is not None else None
+    pe = _probe_begin()
     _lib.check(_lib.lib().dgg_linear_fwd(_ptr(x), N, d, _ptr(W), _ptr(bb), out, w_layout, act, _ptr(y), _stream()), "linear_fwd")
+    _probe_end("linear_fwd", pe)
     return y
 
 
@@ -121,8 +123,10 @@ def linear_bwd(x, W, y, dy, act=ACT_NONE, w_layout=0, need_dx=True, need_db=True
     db = zz[W.numel():] if need_db else None
     ws = torch.empty((int(_lib.lib().dgg_linear_bwd_ws_floats(N, d, out)),), device=x.device, dtype=torch.float32)
     yy = _chk(y) if act != ACT_NONE else None
+    pe = _probe_begin()
     _lib.check(_lib.lib().dgg_linear_bwd(_ptr(x), N, d, _ptr(W), out, w_layout, act, _ptr(yy), _ptr(dy), _ptr(dx), _ptr(dW),
                                          _ptr(db), _ptr(ws), _stream()), "linear_bwd")
+    _probe_end("linear_bwd", pe)
     return dx, dW, db
 
 
