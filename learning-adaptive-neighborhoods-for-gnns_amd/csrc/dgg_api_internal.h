@@ -30,7 +30,7 @@ bool dgg_allpairs_np_supported(int h, int noise_mode, int K);
 int dgg_allpairs_topk_gv_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode,
                               uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, void *workspace, size_t ws_bytes,
                               hipStream_t st);
-size_t dgg_allpairs_gv_ws_bytes(int64_t rows);
+size_t dgg_allpairs_gv_ws_bytes(int64_t rows, int64_t N);
 bool dgg_allpairs_gv_supported(int h, int noise_mode, int K);
 
 int dgg_allpairs_topk_ranked_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0,

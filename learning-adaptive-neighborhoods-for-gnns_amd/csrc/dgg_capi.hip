@@ -37,13 +37,14 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
                           ws_bytes >= dgg_allpairs_fast_ws_bytes(N, h);
     const bool can_np = dgg_allpairs_np_supported(h, noise_mode, K) && workspace && ws_bytes >= dgg_allpairs_np_ws_bytes(N);
     const bool can_gv = dgg_allpairs_gv_supported(h, noise_mode, K) && workspace &&
-                        ws_bytes >= dgg_allpairs_gv_ws_bytes(row1 - row0);
+                        ws_bytes >= dgg_allpairs_gv_ws_bytes(row1 - row0, N);
     int rc;
     if (algo == 4 || (algo == 0 && can_gv && N >= 1024))
         rc = dgg_allpairs_topk_gv_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
     else if (algo == 3 || (algo == 0 && can_np && N >= 1024))
         rc = dgg_allpairs_topk_np_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
-    else if (algo == 2 || (algo == 0 && can_fast && N >= 1024))
+    // (unperturbed scores: the MFMA-bounded kernel needs its pilot, i.e. N >= 8192; below that every pair is scored)
+    else if (algo == 2 || (algo == 0 && can_fast && N >= (noise_mode == 0 ? 8192 : 1024)))
         rc = dgg_allpairs_topk_fast_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
     else
         rc = dgg_allpairs_topk_exhaustive_impl(xp, N, h, row0, row1, t, noise_mode, G, ldG, s0, s1, K, idx, val, st);
@@ -55,7 +56,7 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
 size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K) {
     size_t a = dgg_allpairs_fast_supported(h, noise_mode, K) ? dgg_allpairs_fast_ws_bytes(N, h) : 0;
     size_t b = dgg_allpairs_np_supported(h, noise_mode, K) ? dgg_allpairs_np_ws_bytes(N) : 0;
-    size_t c = dgg_allpairs_gv_supported(h, noise_mode, K) ? dgg_allpairs_gv_ws_bytes(N) : 0;
+    size_t c = dgg_allpairs_gv_supported(h, noise_mode, K) ? dgg_allpairs_gv_ws_bytes(N, N) : 0;
     a = a > b ? a : b;
     return a > c ? a : c;
 }

@@ -88,10 +88,21 @@ __global__ __launch_bounds__(256) void gv_pilot(const float *__restrict__ xp, in
     if (lane == 0) atomicAdd(&ctl->msum, m);
 }
 
+// row keys of every node (symmetric noise: a pair below the diagonal is keyed by its COLUMN, dgm.py:1216-1223): computed once
+// instead of two mix32 per column and per wavefront on the scalar unit
+__global__ void gv_rowkeys(int64_t N, uint32_t s0, uint32_t s1, uint2 *__restrict__ keys) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    uint32_t k1, k2;
+    rowkey(s0, s1, (uint32_t)j, k1, k2);
+    keys[j] = make_uint2(k1, k2);
+}
+
 // K1: fixed-threshold sweep.  lane = row; pend/cnt are indexed by LOCAL row (i - row0)
 template <bool SYM>
 __global__ __launch_bounds__(64) void gv_sweep(int64_t N, int64_t row0, int64_t row1, uint32_t s0, uint32_t s1,
-                                               GvCtl *ctl, int *__restrict__ pend_g, int *__restrict__ cnt_g) {
+                                               GvCtl *ctl, int *__restrict__ pend_g, int *__restrict__ cnt_g,
+                                               const uint2 *__restrict__ colkeys) {
     const int lane = threadIdx.x;
     const int64_t i = row0 + (int64_t)blockIdx.x * 64 + lane;
     const bool rvalid = i < row1;
@@ -163,10 +174,9 @@ __global__ __launch_bounds__(64) void gv_sweep(int64_t N, int64_t row0, int64_t 
             uint32_t x[UB];
 #pragma unroll
             for (int u = 0; u < UB; u++) {
-                uint32_t kj1, kj2;
-                rowkey(s0, s1, (uint32_t)(j0 + u), kj1, kj2);    // scalar ALU
-                uint32_t v = iu ^ kj1;
-                v *= 0x7feb352dU; v ^= v >> 15; v += kj2; v *= 0x846ca68bU;
+                const uint2 kj = colkeys[j0 + u];                // wave-uniform address: scalar loads (s_load_dwordx16)
+                uint32_t v = iu ^ kj.x;
+                v *= 0x7feb352dU; v ^= v >> 15; v += kj.y; v *= 0x846ca68bU;
                 x[u] = v;
             }
 #pragma unroll
@@ -313,13 +323,16 @@ int launch_gv(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, i
     int *cnt = reinterpret_cast<int *>(w + 256);
     int *faillist = cnt + R64 * NSEG;
     int *pend = faillist + R64;
+    uint2 *colkeys = reinterpret_cast<uint2 *>(pend + R64 * (size_t)CAPF);
     if (dgg_check_hip(hipMemsetAsync(ctl, 0, sizeof(GvCtl), st), "gv memset") != 0) return DGG_ERR_HIP;
     const bool sym = noise_mode == 3;
     hipLaunchKernelGGL(gv_pilot<H>, dim3(PILOT_PAIRS / 256), dim3(256), 0, st, xp, N, t, s0, s1, ctl);
     dim3 gsweep((unsigned)(R64 / 64));
     dim3 gsweep2((unsigned)(R64 / 64), NSEG);
-    if (sym) hipLaunchKernelGGL(gv_sweep<true>, gsweep2, dim3(64), 0, st, N, row0, row1, s0, s1, ctl, pend, cnt);
-    else hipLaunchKernelGGL(gv_sweep<false>, gsweep2, dim3(64), 0, st, N, row0, row1, s0, s1, ctl, pend, cnt);
+    if (sym) {
+        hipLaunchKernelGGL(gv_rowkeys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, s0, s1, colkeys);
+        hipLaunchKernelGGL(gv_sweep<true>, gsweep2, dim3(64), 0, st, N, row0, row1, s0, s1, ctl, pend, cnt, colkeys);
+    } else hipLaunchKernelGGL(gv_sweep<false>, gsweep2, dim3(64), 0, st, N, row0, row1, s0, s1, ctl, pend, cnt, colkeys);
     dim3 gfin((unsigned)((R + 3) / 4));
     if (sym) hipLaunchKernelGGL((gv_finalize<H, true>), gfin, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, ctl, pend, cnt, faillist, idx, val);
     else hipLaunchKernelGGL((gv_finalize<H, false>), gfin, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, ctl, pend, cnt, faillist, idx, val);
@@ -330,9 +343,9 @@ int launch_gv(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, i
 
 }  // namespace
 
-size_t dgg_allpairs_gv_ws_bytes(int64_t rows) {
+size_t dgg_allpairs_gv_ws_bytes(int64_t rows, int64_t N) {
     size_t R64 = ((size_t)rows + 63) / 64 * 64;
-    return 256 + R64 * 4 * (NSEG + 1) + R64 * (size_t)CAPF * 4;
+    return 256 + R64 * 4 * (NSEG + 1) + R64 * (size_t)CAPF * 4 + ((size_t)N + 64) * sizeof(uint2);   // + the column keys (symmetric noise)
 }
 
 bool dgg_allpairs_gv_supported(int h, int noise_mode, int K) {
@@ -344,7 +357,7 @@ int dgg_allpairs_topk_gv_impl(const float *xp, int64_t N, int h, int64_t row0, i
                               hipStream_t st) {
     if (!dgg_allpairs_gv_supported(h, noise_mode, K))
         return dgg_set_error(DGG_ERR_UNSUPPORTED, "guess-and-verify path needs K=64, in-kernel noise, latent_dim in {8,...,128}");
-    if (!workspace || ws_bytes < dgg_allpairs_gv_ws_bytes(row1 - row0))
+    if (!workspace || ws_bytes < dgg_allpairs_gv_ws_bytes(row1 - row0, N))
         return dgg_set_error(DGG_ERR_ARG, "guess-and-verify path: workspace too small (dgg_allpairs_workspace_bytes)");
     if (row1 <= row0) return 0;
     switch (h) {

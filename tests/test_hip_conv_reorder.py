@@ -208,3 +208,19 @@ def test_payload_partition_matches_the_slot_map_path(dev, h, F):
             assert got is not None
             np.testing.assert_allclose(Nn(got[1]), Nn(ref[1]), rtol=2e-4, atol=2e-4 * max(float(ref[1].abs().max()), 1e-9))
             np.testing.assert_allclose(Nn(got[0]), Nn(ref[0]), rtol=2e-4, atol=2e-4 * max(float(ref[0].abs().max()), 1e-9))
+
+
+@pytest.mark.parametrize("N,h,clustered", [(12_000, 64, False), (9_000, 16, True)])
+def test_unperturbed_allpairs_with_pilot_guess_is_bit_exact(dev, N, h, clustered):
+    """dgg_allpairs_topk, no perturbation, MFMA-bounded kernel (algo 2) at sizes where the pilot guesses each row's 64-NN
+    radius (N >= 8192): neighbour lists and scores equal the oracle's bit for bit -- uniform data and a mixture of a dense
+    cluster, a sparse halo and isolated points (rows whose guess must come out very differently)"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(N + h)
+    xp = (rng.standard_normal((N, h)) * 0.6).astype(np.float32)
+    if clustered:
+        xp[:3000] *= 0.05                                            # tight cluster: its 64-NN radius is tiny
+        xp[3000:3040] = xp[3000:3040] * 0.01 + 7.0                   # 40 far-away points: fewer than 64 close neighbours
+    idx, val = ops.allpairs_topk(T(xp, dev), K, noise_mode=ops.NOISE_NONE, algo=2)
+    ridx, rval = O.allpairs_topk(xp, K=K, noise_mode=O.NOISE_NONE)
+    assert np.array_equal(Nn(idx), ridx) and np.array_equal(Nn(val), rval)
