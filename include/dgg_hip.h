@@ -316,6 +316,19 @@ int dgg_ell_sddmm_norm_part(const int32_t *idx, const float *ahat, const float *
                             int64_t ncols, float *coef_ws, float *dA, float *da, void *stream);
 int dgg_norm_da_cols_part(const void *part_ws, int64_t rows, int K, int64_t ncols, const float *coef_ws, float *da, void *stream);
 
+/* ---- bf16 matrix-core path of the GCNII layer product (BASELINE configs[4]: "bf16 fwd+bwd, MFMA feature-projection GEMM") ----
+ * GraphConvolution.forward (model.py:32-44): out = theta * (support @ weight) + (1 - theta) * r (+ input).  The product (and its
+ * autograd) runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; operands are bf16 copies made by dgg_pack_bf16.
+ * dgg_pack_bf16: fp32 src [R,C] -> bf16 dst; transpose 0: dst [R][ld] (ld >= C), 1: dst [C][ld] (ld >= R); padding is zeroed.
+ * dgg_gemm_nt_bf16: C[M,N] (fp32) = scale * A[M,K] B[N,K]^T, both operands bf16 with K contiguous, K a multiple of 64
+ *   (d support = theta g W^T: A = g, B = weight as stored;  d weight = theta support^T g: A = support^T, B = g^T, K = padded n).
+ * dgg_gcnii_gemm_bf16: the forward with the epilogue fused; S bf16 [n,K], Wt bf16 [F,K] = weight^T; hi/h0/inp fp32 [n,F]
+ *   (r = h0 ? (1 - alpha) hi + alpha h0 : hi;  h0, inp nullable). */
+int dgg_pack_bf16(const float *src, int64_t R, int64_t C, int transpose, void *dst, int64_t ld, void *stream);
+int dgg_gemm_nt_bf16(const void *A, const void *B, int64_t M, int64_t N, int64_t K, float scale, float *C, void *stream);
+int dgg_gcnii_gemm_bf16(const void *S, const void *Wt, int64_t n, int64_t F, int64_t K, const float *hi, const float *h0, const float *inp,
+                        float theta, float alpha, float *out, void *stream);
+
 /* ---- dense all-pairs alternates: DGG_LearnableK_SDD (dgm.py:259-351, dist_fn="metric") and DGG_StraightThrough
  * (dgm.py:140-182 + 63-100), noise off.  Rows are a softmax over ALL N columns, outputs are dense [B,N,N]: O(N^2) by
  * definition, written for batches of small graphs (N <= 8192).

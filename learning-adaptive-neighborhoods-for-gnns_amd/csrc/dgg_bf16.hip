@@ -1,0 +1,193 @@
+// dgg_bf16.hip -- bf16 matrix-core path of the GCNII layer product (BASELINE configs[4]: "PPI multi-graph batched GCNII_DGG,
+// bf16 fwd+bwd, MFMA feature-projection GEMM").
+//
+// Replaces, for the reduced-precision variant of GraphConvolution / DenseGraphConvolution (reference model.py:32-44, 65-77;
+// train_ppi.py:43-44: hidden 2048, 9 layers, variant => support is [n, 4096]):
+//     out = theta * (support @ weight) + (1 - theta) * r (+ input)            model.py:41-44
+// and its autograd (d support = theta g W^T, d weight = theta support^T g).  Operands are rounded to bf16 (8 significant bits),
+// products accumulate in fp32 on v_mfma_f32_32x32x16_bf16; the epilogue and every tensor outside the product stay fp32.
+//
+// One kernel shape serves all three products: C[M,N] = scale * A[M,K] B[N,K]^T with both operands K-CONTIGUOUS in bf16
+// ("NT").  The operands are produced by dgg_pack_bf16 (fp32 -> bf16 copy, optionally transposed, rows zero-padded to a
+// multiple of 64 so that the contraction never needs a tail):
+//     forward     A = support       [n, K]        B = weight^T [out, K]
+//     d support   A = g             [n, out]      B = weight   [K, out]   (as stored)
+//     d weight    A = support^T     [K, n_pad]    B = g^T      [out, n_pad]
+// Tile: 256 threads = 4 wavefronts compute 128 x 128, each wavefront 64 x 64 (2 x 2 MFMA blocks of 32 x 32, four f32x16
+// accumulators); K in steps of 64 staged through a double-buffered LDS image (row stride 144 B: conflict-free ds_read_b128
+// of the 8-bf16 MFMA fragments), the next step's 16-byte global loads in flight during the 16 MFMAs of the current one.
+#include "dgg_common.h"
+#include "dgg_api_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int BN = 128, BK = 64, LDS_STRIDE = BK + 8;   // bf16 elements per staged row (144 bytes)
+
+struct GcniiEpi {
+    const float *hi, *h0, *inp;    // r = h0 ? (1 - alpha) hi + alpha h0 : hi;  out = theta C + (1 - theta) r (+ inp)
+    float theta, alpha;
+};
+
+// AM: 32-row MFMA blocks per wavefront (2: 128-row tiles; 1: 64-row tiles, used when 128-row tiles would not fill the chip twice)
+template <bool EPI, int AM>
+__global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A, const __bf16 *__restrict__ B, int M, int N, int K,
+                                                    float scale, float *__restrict__ C, GcniiEpi ep) {
+    constexpr int BM = 64 * AM;
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * LDS_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hh = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * (64 * AM), n0 = blockIdx.x * BN;
+    f32x16 acc[AM][2];
+#pragma unroll
+    for (int a = 0; a < AM; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[a][b][q] = 0.0f;
+    uint4 ra[2 * AM], rb[4];
+    // 128 rows x 8 chunks of 16 bytes per operand and K-step: 4 chunks per thread (rows beyond M / N read row 0 and are zeroed)
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c = tid + q * 256, row = c >> 3, kc = c & 7;
+            const bool vb = n0 + row < N;
+            rb[q] = *reinterpret_cast<const uint4 *>(B + (int64_t)(vb ? n0 + row : 0) * K + k0 + kc * 8);
+            if (!vb) rb[q] = make_uint4(0, 0, 0, 0);
+            if (q < 2 * AM) {
+                const bool va = m0 + row < M;
+                ra[q] = *reinterpret_cast<const uint4 *>(A + (int64_t)(va ? m0 + row : 0) * K + k0 + kc * 8);
+                if (!va) ra[q] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c = tid + q * 256, row = c >> 3, kc = c & 7;
+            if (q < 2 * AM) *reinterpret_cast<uint4 *>(&As[buf][row * LDS_STRIDE + kc * 8]) = ra[q];
+            *reinterpret_cast<uint4 *>(&Bs[buf][row * LDS_STRIDE + kc * 8]) = rb[q];
+        }
+    };
+    load(0);
+    store(0);
+    __syncthreads();
+    const int nk = K / BK;
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load((kt + 1) * BK);
+        const __bf16 *as = &As[buf][(wr * 32 * AM + li) * LDS_STRIDE + hh * 8];
+        const __bf16 *bs = &Bs[buf][(wc * 64 + li) * LDS_STRIDE + hh * 8];
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ks++) {
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(bs + ks * 16);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(bs + 32 * LDS_STRIDE + ks * 16);
+#pragma unroll
+            for (int a = 0; a < AM; a++) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(as + a * 32 * LDS_STRIDE + ks * 16);
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[a][0], 0, 0, 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[a][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) store(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: accumulator register q of block (a, b) holds C[row = (q & 3) + 8 (q >> 2) + 4 hh][col = li] of the 32 x 32 block
+    const float omt = 1.0f - ep.theta, oma = 1.0f - ep.alpha;
+#pragma unroll
+    for (int a = 0; a < AM; a++) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int row = m0 + wr * 32 * AM + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
+            if (row >= M) continue;
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const int col = n0 + wc * 64 + b * 32 + li;
+                if (col >= N) continue;
+                const int64_t o = (int64_t)row * N + col;
+                float v = scale * acc[a][b][q];
+                if (EPI) {
+                    const float r = ep.h0 ? oma * ep.hi[o] + ep.alpha * ep.h0[o] : ep.hi[o];
+                    v = ep.theta * v + omt * r;
+                    if (ep.inp) v += ep.inp[o];
+                }
+                C[o] = v;
+            }
+        }
+    }
+}
+
+// fp32 [R, Cc] -> bf16.  transpose 0: dst [R][ld] (ld >= Cc, columns Cc..ld-1 zero);  transpose 1: dst [Cc][ld] (ld >= R, zero padded)
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float *__restrict__ src, int R, int Cc, int transpose, __bf16 *__restrict__ dst,
+                                                        int ld) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    if (!transpose) {
+        const int c = blockIdx.x * 32 + tx;
+        for (int r = blockIdx.y * 32 + ty; r < R && r < blockIdx.y * 32 + 32; r += 8)
+            if (c < ld) dst[(int64_t)r * ld + c] = (__bf16)(c < Cc ? src[(int64_t)r * Cc + c] : 0.0f);
+        return;
+    }
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Cc) ? src[(int64_t)r * Cc + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;                       // dst row = source column
+        if (c < Cc && r < ld) dst[(int64_t)c * ld + r] = (__bf16)tile[tx][i];
+    }
+}
+
+int launch_gemm(const __bf16 *A, const __bf16 *B, int M, int N, int K, float scale, float *C, const GcniiEpi *ep, hipStream_t st) {
+    if (K % BK != 0 || K < BK) return dgg_set_error(DGG_ERR_UNSUPPORTED, "gemm_nt_bf16: the contraction length must be a multiple of 64 (pack with padding)");
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16) return dgg_set_error(DGG_ERR_ARG, "gemm_nt_bf16: operands must be 16-byte aligned");
+    if (M == 0 || N == 0) return 0;
+    // 128-row tiles unless they would leave the 256 CUs with fewer than two rounds of workgroups
+    const int64_t big = (int64_t)((N + BN - 1) / BN) * ((M + 127) / 128);
+    const bool small = big < 512;
+    const dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + (small ? 63 : 127)) / (small ? 64 : 128)));
+    const GcniiEpi e0 = ep ? *ep : GcniiEpi{};
+    if (ep && small) hipLaunchKernelGGL((gemm_nt_bf16<true, 1>), grid, dim3(256), 0, st, A, B, M, N, K, scale, C, e0);
+    else if (ep) hipLaunchKernelGGL((gemm_nt_bf16<true, 2>), grid, dim3(256), 0, st, A, B, M, N, K, scale, C, e0);
+    else if (small) hipLaunchKernelGGL((gemm_nt_bf16<false, 1>), grid, dim3(256), 0, st, A, B, M, N, K, scale, C, e0);
+    else hipLaunchKernelGGL((gemm_nt_bf16<false, 2>), grid, dim3(256), 0, st, A, B, M, N, K, scale, C, e0);
+    return dgg_check_launch("gemm_nt_bf16");
+}
+
+}  // namespace
+
+extern "C" {
+
+int dgg_pack_bf16(const float *src, int64_t R, int64_t Cc, int transpose, void *dst, int64_t ld, void *stream) {
+    if (R <= 0 || Cc <= 0) return 0;
+    if (ld < (transpose ? R : Cc)) return dgg_set_error(DGG_ERR_ARG, "pack_bf16: leading dimension smaller than the row length");
+    const int64_t cols = transpose ? Cc : ld;                    // plain copy also writes the zero padding columns
+    const dim3 grid((unsigned)((cols + 31) / 32), (unsigned)(((transpose ? (ld > R ? ld : R) : R) + 31) / 32));
+    hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (int)R, (int)Cc, transpose,
+                       reinterpret_cast<__bf16 *>(dst), (int)ld);
+    return dgg_check_launch("pack_bf16");
+}
+
+// C[M,N] (fp32) = scale * A[M,K] B[N,K]^T, A and B bf16 with K contiguous (K a multiple of 64)
+int dgg_gemm_nt_bf16(const void *A, const void *B, int64_t M, int64_t N, int64_t K, float scale, float *C, void *stream) {
+    return launch_gemm(reinterpret_cast<const __bf16 *>(A), reinterpret_cast<const __bf16 *>(B), (int)M, (int)N, (int)K, scale, C, nullptr,
+                       (hipStream_t)stream);
+}
+
+// GCNII layer (model.py:36-44) with the product on the bf16 matrix cores and the epilogue fused:
+//   out[n,F] = theta * (S Wt^T) + (1 - theta) * r (+ inp),  r = h0 ? (1 - alpha) hi + alpha h0 : hi
+// S bf16 [n,K], Wt bf16 [F,K] (the weight transposed), hi / h0 / inp fp32 [n,F] (h0, inp nullable)
+int dgg_gcnii_gemm_bf16(const void *S, const void *Wt, int64_t n, int64_t F, int64_t K, const float *hi, const float *h0, const float *inp,
+                        float theta, float alpha, float *out, void *stream) {
+    if (!hi) return dgg_set_error(DGG_ERR_ARG, "gcnii_gemm_bf16: hi is required");
+    const GcniiEpi ep{hi, h0, inp, theta, alpha};
+    return launch_gemm(reinterpret_cast<const __bf16 *>(S), reinterpret_cast<const __bf16 *>(Wt), (int)n, (int)F, (int)K, 1.0f, out, &ep,
+                       (hipStream_t)stream);
+}
+
+}  // extern "C"

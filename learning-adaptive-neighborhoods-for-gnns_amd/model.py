@@ -68,13 +68,15 @@ class GraphConvolution(nn.Module):
         hi = _as_ell(adj).matmul(input)
         # variant: the GEMM input is cat[hi, h0] and r only feeds the epilogue (folded into it); otherwise support = r
         support = torch.cat([hi, h0], 1) if self.variant else (1 - alpha) * hi + alpha * h0
-        if self.gemm_dtype is None:
-            sw = ops.LinearFn.apply(support, self.weight, None, ops.ACT_NONE, 1)          # fp32 matrix cores (HIP)
-        else:
-            # reduced-precision variant (BASELINE configs[4]: "bf16 fwd+bwd"): `support @ weight` is a plain GEMM, run by the
-            # vendor library on bf16 operands with fp32 accumulation; everything around it stays fp32
-            sw = torch.matmul(support.to(self.gemm_dtype), self.weight.to(self.gemm_dtype)).float()
         res = input if self.residual else None
+        if self.gemm_dtype is not None:
+            # reduced-precision variant (BASELINE configs[4]: "bf16 fwd+bwd"): the layer product and its autograd run on the bf16
+            # matrix cores (dgg_bf16.hip: v_mfma_f32_32x32x16_bf16, fp32 accumulation), epilogue fused; everything else fp32
+            assert self.gemm_dtype == torch.bfloat16
+            if self.variant:
+                return ops.GcniiBf16Fn.apply(support, self.weight, hi, h0, res, theta, alpha)
+            return ops.GcniiBf16Fn.apply(support, self.weight, support, None, res, theta, alpha)
+        sw = ops.LinearFn.apply(support, self.weight, None, ops.ACT_NONE, 1)              # fp32 matrix cores (HIP)
         if self.variant:
             return ops.GcniiEpilogueFn.apply(sw, hi, h0, res, theta, alpha)
         return ops.GcniiEpilogueFn.apply(sw, support, None, res, theta, alpha)

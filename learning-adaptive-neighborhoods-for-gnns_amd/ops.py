@@ -973,6 +973,90 @@ class CsrBgSoftmaxFn(torch.autograd.Function):
         return dL, None
 
 
+# ---- bf16 matrix-core path of the GCNII layer product (dgg_bf16.hip) ------------------------------------------------------
+def pack_bf16(src, transpose=False):
+    """fp32 [R,C] -> bf16 [R, C64] or (transpose) [C, R64]: the row length padded with zeros to a multiple of 64"""
+    src = _chk(src)
+    R, Cc = src.shape
+    ld = ((R if transpose else Cc) + 63) // 64 * 64
+    dst = torch.empty((Cc if transpose else R, ld), device=src.device, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().dgg_pack_bf16(_ptr(src), R, Cc, int(transpose), _ptr(dst), ld, _stream()), "pack_bf16")
+    return dst
+
+
+def gemm_nt_bf16(A, B, scale=1.0):
+    """A [M,K] bf16, B [N,K] bf16 (K contiguous, a multiple of 64) -> fp32 scale * A B^T"""
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.shape[1] == B.shape[1] and A.is_contiguous() and B.is_contiguous()
+    M, K = A.shape
+    N = B.shape[0]
+    out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    pe = _probe_begin()
+    _lib.check(_lib.lib().dgg_gemm_nt_bf16(_ptr(A), _ptr(B), M, N, K, float(scale), _ptr(out), _stream()), "gemm_nt_bf16")
+    _probe_end("gemm_bf16_bwd", pe)
+    return out
+
+
+_WPACK = {}
+
+
+def _packed_weight(weight, transpose):
+    """bf16 copy of a weight, kept until the parameter changes (its version counter moves): the graphs of one step share it"""
+    key = (weight.data_ptr(), bool(transpose))
+    hit = _WPACK.get(key)
+    if hit is not None and hit[0] == weight._version and hit[1].device == weight.device:
+        return hit[1]
+    if len(_WPACK) > 256:
+        _WPACK.clear()
+    p = pack_bf16(weight.detach(), transpose=transpose)
+    _WPACK[key] = (weight._version, p)
+    return p
+
+
+class GcniiBf16Fn(torch.autograd.Function):
+    """GCNII layer with the product on the bf16 matrix cores and the epilogue fused (model.py:36-44):
+    out = theta * (support @ weight) + (1 - theta) * r (+ inp), r = (1 - alpha) hi + alpha h0 (h0 None: r = hi).
+    support [n,K] and weight [K,F] are rounded to bf16 for the product (fp32 accumulation); everything else is fp32.
+    Backward: d support = theta g W^T, d weight = theta support^T g on the same kernel; d hi / d h0 / d inp elementwise."""
+
+    @staticmethod
+    def forward(ctx, support, weight, hi, h0, inp, theta, alpha):
+        n, K = support.shape
+        F = weight.shape[1]
+        assert K % 64 == 0, "gcnii bf16: in_features must be a multiple of 64"
+        S = pack_bf16(support)                                   # [n, K]
+        Wt = _packed_weight(weight, True)                        # [F, K]
+        hi = _chk(hi)
+        h0c = _chk(h0) if h0 is not None else None
+        inpc = _chk(inp) if inp is not None else None
+        out = torch.empty((n, F), device=support.device, dtype=torch.float32)
+        pe = _probe_begin()
+        _lib.check(_lib.lib().dgg_gcnii_gemm_bf16(_ptr(S), _ptr(Wt), n, F, K, _ptr(hi), _ptr(h0c), _ptr(inpc), float(theta), float(alpha),
+                                                  _ptr(out), _stream()), "gcnii_gemm_bf16")
+        _probe_end("gemm_bf16_fwd", pe)
+        ctx.save_for_backward(S, weight)
+        ctx.theta, ctx.alpha, ctx.has_h0, ctx.has_inp = float(theta), float(alpha), h0 is not None, inp is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        S, weight = ctx.saved_tensors
+        g = _chk(g.contiguous())
+        n, F = g.shape
+        K = weight.shape[0]
+        dS = dW = None
+        if ctx.needs_input_grad[0]:
+            dS = gemm_nt_bf16(pack_bf16(g), _packed_weight(weight, False), ctx.theta)     # [n,F] x [K,F]^T
+        if ctx.needs_input_grad[1]:
+            # contraction over the n nodes: both operands transposed, n zero-padded to a multiple of 64
+            St = pack_bf16(S.float(), transpose=True)            # bf16 -> fp32 is exact: the transposed operand is re-packed from it
+            dW = gemm_nt_bf16(St, pack_bf16(g, transpose=True), ctx.theta)               # [K,n] x [F,n]^T
+        dsw, dhi = torch.empty_like(g), torch.empty_like(g)
+        dh0 = torch.empty_like(g) if ctx.has_h0 else None
+        _lib.check(_lib.lib().dgg_gcnii_epilogue_bwd(_ptr(g), g.numel(), ctx.theta, ctx.alpha, _ptr(dsw), _ptr(dhi), _ptr(dh0), _stream()),
+                   "gcnii_epilogue_bwd")
+        return dS, dW, dhi, dh0, (g if ctx.has_inp else None), None, None
+
+
 class GcniiEpilogueFn(torch.autograd.Function):
     """out = theta * sw + (1 - theta) * ((1 - alpha) * hi + alpha * h0) (+ inp)  (GraphConvolution.forward, model.py:36-44);
     h0 None: r = hi (the non-variant layer, whose support is r itself)."""

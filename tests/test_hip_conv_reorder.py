@@ -224,3 +224,55 @@ def test_unperturbed_allpairs_with_pilot_guess_is_bit_exact(dev, N, h, clustered
     idx, val = ops.allpairs_topk(T(xp, dev), K, noise_mode=ops.NOISE_NONE, algo=2)
     ridx, rval = O.allpairs_topk(xp, K=K, noise_mode=O.NOISE_NONE)
     assert np.array_equal(Nn(idx), ridx) and np.array_equal(Nn(val), rval)
+
+
+@pytest.mark.parametrize("n,K,F,variant,residual", [(700, 256, 128, True, True), (333, 128, 128, False, True), (1500, 4096, 2048, True, True)])
+def test_bf16_gcnii_layer_product(dev, n, K, F, variant, residual):
+    """BASELINE configs[4] (bf16 fwd+bwd): GraphConvolution with gemm_dtype=bfloat16 runs the layer product and its autograd on the
+    hand-written bf16 MFMA kernel (dgg_bf16.hip).  Tolerance against the fp32 layer: 1e-2 of the tensor's max (bf16 rounds both
+    operands to 8 significant bits: ~4e-3 relative per product, averaged down over the contraction); and against a float64
+    product of the bf16-ROUNDED operands: 1e-5 (the kernel itself adds only fp32 accumulation error)."""
+    import dgg_amd
+    from dgg_amd import ops
+    rng = np.random.default_rng(n + K)
+    S = T(rng.standard_normal((n, K)).astype(np.float32), dev)
+    W = T((rng.standard_normal((K, F)) / np.sqrt(K)).astype(np.float32), dev)
+    # the raw kernel against float64 on the rounded operands (padding of an odd contraction length included)
+    A16, B16 = ops.pack_bf16(S), ops.pack_bf16(W, transpose=True)
+    got = ops.gemm_nt_bf16(A16, B16, 0.5)
+    ref = 0.5 * (A16.double() @ B16.double().t())
+    assert float((got.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6
+    At, Gt = ops.pack_bf16(S, transpose=True), ops.pack_bf16(got, transpose=True)      # contraction over n (padded to 64)
+    dW = ops.gemm_nt_bf16(At, Gt)
+    refW = At.double() @ Gt.double().t()
+    assert float((dW.double() - refW).abs().max()) <= 1e-5 * float(refW.abs().max()) + 1e-6
+    # the layer, bf16 vs fp32, forward and gradients
+    in_f = K // 2 if variant else K
+    if variant and in_f != F or (not variant and residual and K != F):
+        residual = False
+    layers = []
+    for dt in (None, torch.bfloat16):
+        torch.manual_seed(3)
+        L = dgg_amd.GraphConvolution(in_f, F, residual=residual, variant=variant).to(dev)
+        L.gemm_dtype = dt
+        layers.append(L)
+    N0 = n
+    idx = torch.arange(N0, device=dev, dtype=torch.int32)[:, None].repeat(1, 64)
+    idx[:, 1:] = -1
+    from dgg_amd.adjacency import EllAdjacency
+    vals = torch.zeros((N0, 64), device=dev)
+    vals[:, 0] = 1.0
+    outs, grads = [], []
+    for L in layers:
+        x = T(rng.standard_normal((N0, in_f)).astype(np.float32), dev) if not outs else xin.detach().clone()
+        xin = x
+        x = x.requires_grad_(True)
+        h0 = (x * 0.5).detach().requires_grad_(True)
+        out = L(x, EllAdjacency(idx, vals, N0), h0, 0.5, 0.1, 1)
+        out.square().sum().backward()
+        outs.append(out.detach())
+        grads.append((x.grad.detach(), h0.grad.detach(), L.weight.grad.detach()))
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())  # noqa: E731
+    assert rel(outs[1], outs[0]) <= 1e-2
+    for g16, g32 in zip(grads[1], grads[0]):
+        assert rel(g16, g32) <= 2e-2
