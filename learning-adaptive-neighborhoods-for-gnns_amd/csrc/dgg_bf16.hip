@@ -149,7 +149,7 @@ int launch_gemm(const __bf16 *A, const __bf16 *B, int M, int N, int K, float sca
     if (M == 0 || N == 0) return 0;
     // 128-row tiles unless they would leave the 256 CUs with fewer than two rounds of workgroups
     const int64_t big = (int64_t)((N + BN - 1) / BN) * ((M + 127) / 128);
-    const bool small = big < 512;
+    const bool small = big < 192;   // (64-row tiles carry 1.5x the LDS traffic per MFMA: only when 128-row tiles would leave CUs idle)
     const dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + (small ? 63 : 127)) / (small ? 64 : 128)));
     const GcniiEpi e0 = ep ? *ep : GcniiEpi{};
     if (ep && small) hipLaunchKernelGGL((gemm_nt_bf16<true, 1>), grid, dim3(256), 0, st, A, B, M, N, K, scale, C, e0);

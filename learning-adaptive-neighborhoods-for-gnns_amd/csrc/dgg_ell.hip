@@ -427,16 +427,16 @@ __global__ __launch_bounds__(WPB * 64) void edge_bwd_wide_kernel(const float *__
                                                                 const int32_t *__restrict__ idx, const float *__restrict__ val,
                                                                 const float *__restrict__ dval, int K, int64_t row0, float t,
                                                                 int perturb, float *__restrict__ dxp) {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
-    if (i >= N) return;
+    // ONE WORKGROUP PER ROW (small graphs, wide latents): the row's entries are dealt to the four wavefronts in groups of EQ
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = blockIdx.x;
     const int64_t gi = row0 + i;
     const float *xi = xp + gi * h;
     int32_t jl = lane < K ? idx[i * K + lane] : -1;
     float gl = lane < K ? dval[i * K + lane] : 0.0f;
     float vl = lane < K ? val[i * K + lane] : 0.0f;
     constexpr int EQ = 4;                                        // entries in flight per pass over the features
-    for (int r0 = 0; r0 < K; r0 += EQ) {
+    for (int r0 = wave * EQ; r0 < K; r0 += WPB * EQ) {
         int32_t j[EQ];
         float g[EQ], v[EQ], d2[EQ], dd[EQ];
         const float *xj[EQ];
@@ -657,7 +657,7 @@ int dgg_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const fl
                  int64_t row0, float t, int perturb, float *dxp, void *stream) {
     if (N == 0) return 0;
     if (h > 128)
-        hipLaunchKernelGGL(edge_bwd_wide_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, xp, N, h, idx, val,
+        hipLaunchKernelGGL(edge_bwd_wide_kernel, dim3((unsigned)N), dim3(WPB * 64), 0, (hipStream_t)stream, xp, N, h, idx, val,
                            dval, K, row0, t, perturb, dxp);
     else
         hipLaunchKernelGGL(edge_bwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, xp, N, h, idx, val, dval,

@@ -146,9 +146,14 @@ __global__ __launch_bounds__(256) void edgelist_topk_wide_kernel(
     const float *__restrict__ xp, int64_t N, int h, const int64_t *__restrict__ rowptr,
     const int32_t *__restrict__ col, float t, int noise_mode, const float *__restrict__ G, int64_t ldG,
     uint32_t s0, uint32_t s1, int K, int32_t *__restrict__ idx, float *__restrict__ val) {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (i >= N) return;
+    // ONE WORKGROUP PER ROW: graphs of this regime are small (PPI: ~2 000 nodes, latent 2048), so a wavefront per row leaves
+    // most of the chip idle.  The candidates of a 64-candidate batch are dealt to the four wavefronts in groups of CQ; every
+    // wavefront streams its candidates' 8 KB rows (lanes over the features, UF x CQ coalesced 256-byte loads in flight) and
+    // leaves the squared distances in LDS; wavefront 0 turns them into scores and merges.  The arithmetic per pair is the
+    // canonical one (64 interleaved fmaf chains + butterfly): same bits as before.
+    __shared__ float d2s[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = blockIdx.x;
     const bool perturb = noise_mode != 0, sym = noise_mode == 3;
     const float *xi = xp + i * h;
     uint64_t list = DGG_EMPTY_KEY;
@@ -156,9 +161,8 @@ __global__ __launch_bounds__(256) void edgelist_topk_wide_kernel(
     for (int64_t eb = e0; eb < e1; eb += 64) {
         const int n = e1 - eb < 64 ? (int)(e1 - eb) : 64;
         const int32_t jl = eb + lane < e1 ? col[eb + lane] : 0;
-        float mine = 0.0f;
-        constexpr int CQ = 8;                                    // candidate rows in flight per pass over the features
-        for (int q0 = 0; q0 < n; q0 += CQ) {
+        constexpr int CQ = 4, UF = 4;                            // candidates per group, feature blocks of 64 per iteration
+        for (int q0 = wave * CQ; q0 < n; q0 += 4 * CQ) {
             const float *xj[CQ];
             float d2[CQ];
 #pragma unroll
@@ -166,7 +170,24 @@ __global__ __launch_bounds__(256) void edgelist_topk_wide_kernel(
                 xj[u] = xp + (int64_t)bcast(jl, q0 + u < n ? q0 + u : n - 1) * h;
                 d2[u] = 0.0f;
             }
-            for (int c = lane; c < h; c += 64) {
+            int c = lane;
+            for (; c + 64 * (UF - 1) < h; c += 64 * UF) {        // UF * (CQ + 1) loads issued before the first use
+                float xv[UF], xw[UF][CQ];
+#pragma unroll
+                for (int f = 0; f < UF; f++) {
+                    xv[f] = xi[c + 64 * f];
+#pragma unroll
+                    for (int u = 0; u < CQ; u++) xw[f][u] = xj[u][c + 64 * f];
+                }
+#pragma unroll
+                for (int f = 0; f < UF; f++)                     // ascending feature order inside every lane's chain
+#pragma unroll
+                    for (int u = 0; u < CQ; u++) {
+                        const float df = __fadd_rn(xv[f], -xw[f][u]);
+                        d2[u] = __fmaf_rn(df, df, d2[u]);
+                    }
+            }
+            for (; c < h; c += 64) {
                 const float xv = xi[c];
 #pragma unroll
                 for (int u = 0; u < CQ; u++) {
@@ -177,20 +198,24 @@ __global__ __launch_bounds__(256) void edgelist_topk_wide_kernel(
 #pragma unroll
             for (int u = 0; u < CQ; u++) {
                 const float tot = wave_sum_butterfly(d2[u]);
-                if (lane == q0 + u) mine = tot;
+                if (lane == 0 && q0 + u < n) d2s[q0 + u] = tot;
             }
         }
-        uint64_t key = DGG_EMPTY_KEY;
-        if (lane < n) {
-            float g = 0.0f;
-            if (noise_mode == 1) g = G[i * ldG + jl];
-            else if (noise_mode >= 2) g = pair_noise(s0, s1, (uint32_t)i, (uint32_t)jl, sym);
-            key = make_key(score_from_dist(c_sqrt(mine), t, perturb, g), jl);
+        __syncthreads();
+        if (wave == 0) {
+            uint64_t key = DGG_EMPTY_KEY;
+            if (lane < n) {
+                float g = 0.0f;
+                if (noise_mode == 1) g = G[i * ldG + jl];
+                else if (noise_mode >= 2) g = pair_noise(s0, s1, (uint32_t)i, (uint32_t)jl, sym);
+                key = make_key(score_from_dist(c_sqrt(d2s[lane]), t, perturb, g), jl);
+            }
+            key = wave_sort_desc(key, lane);
+            list = wave_merge_top64(list, key, lane);
         }
-        key = wave_sort_desc(key, lane);
-        list = wave_merge_top64(list, key, lane);
+        __syncthreads();
     }
-    if (lane < K) {
+    if (wave == 0 && lane < K) {
         bool empty = list == DGG_EMPTY_KEY;
         idx[i * K + lane] = empty ? -1 : key_col(list);
         val[i * K + lane] = empty ? 0.0f : key_val(list);
@@ -258,7 +283,7 @@ int dgg_edgelist_topk(const float *xp, int64_t N, int h, const int64_t *rowptr, 
         return dgg_set_error(DGG_ERR_UNSUPPORTED, "edgelist_topk: noise_mode must be none / explicit / hash / symmetric hash");
     if (N == 0) return 0;
     if (h > 128)
-        hipLaunchKernelGGL(edgelist_topk_wide_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, xp, N, h,
+        hipLaunchKernelGGL(edgelist_topk_wide_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, xp, N, h,
                            rowptr, col, t, noise_mode, G, ldG, s0, s1, K, idx, val);
     else
         hipLaunchKernelGGL(edgelist_topk_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, xp, N, h,
