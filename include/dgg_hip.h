@@ -76,6 +76,12 @@ int dgg_linear_fwd_multi(const float *x, int64_t N, int d, const float *Wcat, co
 size_t dgg_gemm_tn_multi_ws_floats(int64_t N, int M1_total, int M2);
 int dgg_gemm_tn_multi(int nseg, const float *const *A, const int *M1, const float *const *Y, const int *act, const float *B,
                       int64_t N, int M2, float *const *C, const int *c_layout, float *const *colsum, float *ws, void *stream);
+/* Several independent small products over the same N rows in ONE launch: C_p[M1_p,M2_p] += A_p[N,M1_p]^T B_p[N,M2_p], colsum_p
+ * (nullable) += column sums of A_p -- the k-net's three weight gradients (k_embed 32x65, k_mu 16x32, k_project 1x16 at h = 64:
+ * autograd of dgm.py:1576-1577, 2051-2063).  At most 256 rows of output in total (each M1_p padded to 32), M2_p <= 128;
+ * A / M1 / B / M2 / C / colsum are HOST arrays; ws: dgg_gemm_tn_multi_ws_floats(N, padded total M1, 128) floats. */
+int dgg_gemm_tn_pairs(int npair, const float *const *A, const int *M1, const float *const *B, const int *M2, int64_t N, float *const *C,
+                      float *const *colsum, float *ws, void *stream);
 /* C[M1,M2] += A[N,M1]^T B[N,M2] (c_layout 1: C stored [M2][M1]); colsum (nullable,[M1]) += column sums of A.
  * Weight gradients of the per-node layers (autograd of dgm.py:1576-1577).  ws: dgg_gemm_tn_ws_floats(N, M1, M2)
  * floats (per-chunk partial blocks, summed by a second kernel: no same-address atomics storm). */

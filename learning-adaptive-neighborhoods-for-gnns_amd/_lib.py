@@ -17,6 +17,7 @@ PROTOTYPES = {
     "dgg_linear_fwd_multi": [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "dgg_gemm_tn_multi": [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "dgg_gemm_tn_multi_ws_floats": [_i64, _i32, _i32],
+    "dgg_gemm_tn_pairs": [_i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "dgg_linear_bwd_ws_floats": [_i64, _i32, _i32],
     "dgg_degree_stats": [_vp, _i64, _vp, _vp, _vp],
     "dgg_degree_stats_ws_bytes": [],

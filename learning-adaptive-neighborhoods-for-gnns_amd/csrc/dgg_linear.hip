@@ -347,10 +347,12 @@ struct TnSegs {
     int ld[8];             // row stride of the operand (its M1),
     int o0[8];             // first column of this block inside the operand,
     int act[8];            // activation of the forward (0 none, 1 LeakyReLU, 2 ReLU)
+    const float *Bp[8];    // per column block: its own streamed operand (NULL: the kernel's common B) and that operand's width
+    int m2[8];
     int nyb;
 };
 template <int NB, int PF>
-__global__ __launch_bounds__(256) void gemm_tn_multi(TnSegs segs, const float *__restrict__ B, int64_t N, int M2, int M2p, int G,
+__global__ __launch_bounds__(256) void gemm_tn_multi(TnSegs segs, const float *B, int64_t N, int M2, int M2p, int G,
                                                      float *__restrict__ slab, float *__restrict__ cs_slab) {
     extern __shared__ float red[];                               // [NB*16*64] + [64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, hh = lane >> 5;
@@ -361,6 +363,8 @@ __global__ __launch_bounds__(256) void gemm_tn_multi(TnSegs segs, const float *_
     const float *__restrict__ A = segs.A[yb];
     const float *__restrict__ Yact = segs.Y[yb];
     const int M1 = segs.ld[yb], act = Yact ? segs.act[yb] : 0;
+    if (segs.Bp[yb]) { B = segs.Bp[yb]; M2 = segs.m2[yb]; }     // a pair with its own streamed operand (dgg_gemm_tn_pairs)
+    const int nbu = (M2 + 31) / 32;                              // column blocks of B that exist (block-uniform): the others are skipped
     const int64_t acol = segs.o0[yb] + li < M1 ? segs.o0[yb] + li : M1 - 1;
     int64_t bcol[NB];
 #pragma unroll
@@ -382,7 +386,8 @@ __global__ __launch_bounds__(256) void gemm_tn_multi(TnSegs segs, const float *_
             av[buf][u] = A[nc * M1 + acol];
             yv[buf][u] = 1.0f;
 #pragma unroll
-            for (int a = 0; a < NB; a++) bv[buf][u][a] = B[nc * M2 + bcol[a]];
+            for (int a = 0; a < NB; a++)
+                if (a < nbu) bv[buf][u][a] = B[nc * M2 + bcol[a]];
         }
         if (act != 0) {                                          // block-uniform
 #pragma unroll
@@ -401,7 +406,8 @@ __global__ __launch_bounds__(256) void gemm_tn_multi(TnSegs segs, const float *_
             const float a_ = av[buf][u] * am;
             csum += a_;
 #pragma unroll
-            for (int a = 0; a < NB; a++) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, bv[buf][u][a], acc[a], 0, 0, 0);
+            for (int a = 0; a < NB; a++)
+                if (a < nbu) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, bv[buf][u][a], acc[a], 0, 0, 0);
         }
     };
     int64_t base = ((int64_t)g * 4 + wave) * 2 * PF;
@@ -446,6 +452,37 @@ __global__ __launch_bounds__(256) void gemm_tn_multi(TnSegs segs, const float *_
         }
     const float t = csum + __uint_as_float(dgg::xor_shfl<32>(__float_as_uint(csum), lane));
     if (hh == 0) cs_slab[(int64_t)g * M1tp + yb * 32 + li] = t;
+}
+
+// all segments of a gemm_tn_multi / gemm_tn_pairs slab in ONE launch (blockIdx.z = segment)
+struct RedSegs {
+    float *C[8];
+    float *colsum[8];
+    int M1[8], M2[8], M1p[8], rowbase[8], c_layout[8];
+};
+__global__ __launch_bounds__(256) void gemm_tn_reduce_multi(const float *__restrict__ slab, const float *__restrict__ cs_slab, int nchunks,
+                                                            int M2p, int64_t chunk_stride, int64_t cs_stride, RedSegs rs) {
+    const int sgi = blockIdx.z;
+    const int M1 = rs.M1[sgi], M2 = rs.M2[sgi], M1p = rs.M1p[sgi];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int per = (nchunks + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int k0 = blockIdx.y * per, k1 = k0 + per < nchunks ? k0 + per : nchunks;
+    if (k0 >= k1) return;
+    const float *sl = slab + (int64_t)rs.rowbase[sgi] * M2p;
+    if (e < M1p * M2p) {
+        const int o = e / M2p, c = e % M2p;
+        if (o < M1 && c < M2) {
+            float s_ = 0.0f;
+            for (int k = k0; k < k1; k++) s_ += sl[(int64_t)k * chunk_stride + e];
+            float *dst = rs.c_layout[sgi] == 0 ? rs.C[sgi] + (int64_t)o * M2 + c : rs.C[sgi] + (int64_t)c * M1 + o;
+            atomicAdd(dst, s_);
+        }
+    }
+    if (rs.colsum[sgi] && e < M1) {
+        float s_ = 0.0f;
+        for (int k = k0; k < k1; k++) s_ += cs_slab[(int64_t)k * cs_stride + rs.rowbase[sgi] + e];
+        atomicAdd(rs.colsum[sgi] + e, s_);
+    }
 }
 
 constexpr int GT_SPLIT = 32;
@@ -685,17 +722,60 @@ int dgg_gemm_tn_multi(int nseg, const float *const *A, const int *M1, const floa
     if (nb == 4) hipLaunchKernelGGL((gemm_tn_multi<4, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);
     else if (nb == 2) hipLaunchKernelGGL((gemm_tn_multi<2, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);
     else hipLaunchKernelGGL((gemm_tn_multi<1, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);
-    int rb = 0;
+    RedSegs rsg{};
+    int rb = 0, m1max = 0;
     for (int sgi = 0; sgi < nseg; sgi++) {
-        int split = (M1[sgi] * M2p >= 16384) ? (G + 7) / 8 : G;
-        split = split < 1 ? 1 : (split > GT_SPLIT ? GT_SPLIT : split);
-        float *cs = colsum ? colsum[sgi] : nullptr;
-        hipLaunchKernelGGL(gemm_tn_reduce, dim3((unsigned)((M1[sgi] * M2p + 255) / 256), (unsigned)split), dim3(256), 0, st,
-                           slab + (size_t)rb * M2p, cs ? cs_slab + rb : nullptr, G, M1[sgi], M2, M1[sgi], M2p, C[sgi], c_layout[sgi], cs,
-                           (int64_t)M1tp * M2p, (int64_t)M1tp);
+        rsg.C[sgi] = C[sgi]; rsg.colsum[sgi] = colsum ? colsum[sgi] : nullptr; rsg.M1[sgi] = M1[sgi]; rsg.M2[sgi] = M2; rsg.M1p[sgi] = M1[sgi];
+        rsg.rowbase[sgi] = rb; rsg.c_layout[sgi] = c_layout[sgi];
         rb += M1[sgi];
+        m1max = M1[sgi] > m1max ? M1[sgi] : m1max;
     }
+    hipLaunchKernelGGL(gemm_tn_reduce_multi, dim3((unsigned)((m1max * M2p + 255) / 256), (unsigned)((G + 7) / 8), (unsigned)nseg), dim3(256), 0, st,
+                       slab, cs_slab, G, M2p, (int64_t)M1tp * M2p, (int64_t)M1tp, rsg);
     return dgg_check_launch("gemm_tn_multi");
+}
+
+// Several INDEPENDENT small products C_p[M1_p, M2_p] += A_p[N, M1_p]^T B_p[N, M2_p] over the same N rows in one launch (+ one
+// reduce per product): the three weight gradients of the k-net (k_embed, k_mu, k_project: autograd of dgm.py:1576-1577, 2051-2063)
+// are 32x65, 16x32 and 1x16 -- as three launches each is a latency-bound kernel on an empty chip.  M1_p <= 256 in total
+// (padded to 32), M2_p <= 128.  colsum_p (nullable) += column sums of A_p.  ws: dgg_gemm_tn_multi_ws_floats(N, padded total M1, 128).
+int dgg_gemm_tn_pairs(int npair, const float *const *A, const int *M1, const float *const *B, const int *M2, int64_t N, float *const *C,
+                      float *const *colsum, float *ws, void *stream) {
+    if (npair < 1 || npair > 8) return dgg_set_error(DGG_ERR_UNSUPPORTED, "gemm_tn_pairs: 1..8 products");
+    if (!ws) return dgg_set_error(DGG_ERR_ARG, "gemm_tn_pairs: workspace is NULL");
+    TnSegs segs{};
+    int yb = 0, rb[8], m2max = 1;
+    for (int p = 0; p < npair; p++) {
+        if (M1[p] < 1 || M2[p] < 1 || M2[p] > 128) return dgg_set_error(DGG_ERR_UNSUPPORTED, "gemm_tn_pairs: M2 <= 128");
+        rb[p] = yb * 32;
+        for (int q = 0; q < (M1[p] + 31) / 32; q++, yb++) {
+            if (yb >= 8) return dgg_set_error(DGG_ERR_UNSUPPORTED, "gemm_tn_pairs: at most 256 (padded) rows of output in total");
+            segs.A[yb] = A[p]; segs.Y[yb] = nullptr; segs.ld[yb] = M1[p]; segs.o0[yb] = q * 32; segs.act[yb] = 0;
+            segs.Bp[yb] = B[p]; segs.m2[yb] = M2[p];
+        }
+        m2max = M2[p] > m2max ? M2[p] : m2max;
+    }
+    segs.nyb = yb;
+    if (N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int M2p = 128, M1tp = yb * 32;                         // one slab geometry for all pairs (outputs are tiny)
+    constexpr int PF = 4;
+    int G = 128;
+    const int64_t need = (N + 4 * 2 * PF - 1) / (4 * 2 * PF);
+    while (G > 8 && G / 2 >= need) G /= 2;
+    float *slab = ws, *cs_slab = ws + (size_t)G * M1tp * M2p;
+    const size_t lds = (size_t)(4 * 16 * 64 + 64) * sizeof(float);
+    hipLaunchKernelGGL((gemm_tn_multi<4, PF>), dim3((unsigned)(G * yb)), dim3(256), lds, st, segs, A[0], N, m2max, M2p, G, slab, cs_slab);
+    RedSegs rsg{};
+    int m1pmax = 0;
+    for (int p = 0; p < npair; p++) {
+        rsg.C[p] = C[p]; rsg.colsum[p] = colsum ? colsum[p] : nullptr; rsg.M1[p] = M1[p]; rsg.M2[p] = M2[p];
+        rsg.M1p[p] = (M1[p] + 31) / 32 * 32; rsg.rowbase[p] = rb[p]; rsg.c_layout[p] = 0;
+        m1pmax = rsg.M1p[p] > m1pmax ? rsg.M1p[p] : m1pmax;
+    }
+    hipLaunchKernelGGL(gemm_tn_reduce_multi, dim3((unsigned)((m1pmax * M2p + 255) / 256), (unsigned)((G + 7) / 8), (unsigned)npair), dim3(256), 0, st,
+                       slab, cs_slab, G, M2p, (int64_t)M1tp * M2p, (int64_t)M1tp, rsg);
+    return dgg_check_launch("gemm_tn_pairs");
 }
 
 // C[M1,M2] += A[N,M1]^T B[N,M2]  (c_layout 1: C stored [M2][M1]); colsum (nullable, [M1]) += column sums of A;

@@ -202,6 +202,27 @@ def gemm_tn(A, B, colsum=False):
     return (Cm, cs) if colsum else Cm
 
 
+def gemm_tn_pairs(pairs):
+    """[(A_p [N,M1_p], B_p [N,M2_p]), ...] -> [(A_p^T B_p, column sums of A_p)] in one launch (+ one reduce per product); falls
+    back to one gemm_tn per product for shapes the batched kernel does not cover"""
+    As, Bs = [_chk(a) for a, _ in pairs], [_chk(b) for _, b in pairs]
+    N = As[0].shape[0]
+    M1s, M2s = [a.shape[1] for a in As], [b.shape[1] for b in Bs]
+    tot = sum((m + 31) // 32 * 32 for m in M1s)
+    if len(pairs) > 8 or tot > 256 or max(M2s) > 128:
+        return [gemm_tn(a, b, colsum=True) for a, b in zip(As, Bs)]
+    zz = _zeros((sum(m1 * m2 + m1 for m1, m2 in zip(M1s, M2s)),), As[0].device)
+    Cs, css, o = [], [], 0
+    for m1, m2 in zip(M1s, M2s):
+        Cs.append(zz[o:o + m1 * m2].view(m1, m2))
+        css.append(zz[o + m1 * m2:o + m1 * m2 + m1])
+        o += m1 * m2 + m1
+    ws = torch.empty((int(_lib.lib().dgg_gemm_tn_multi_ws_floats(N, tot, 128)),), device=As[0].device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_gemm_tn_pairs(len(pairs), _ptr_array(As), _int_array(M1s), _ptr_array(Bs), _int_array(M2s), N, _ptr_array(Cs),
+                                            _ptr_array(css), _ptr(ws), _stream()), "gemm_tn_pairs")
+    return list(zip(Cs, css))
+
+
 def degree_stats(deg):
     deg = _chk(deg)
     out = torch.empty((2,), device=deg.device, dtype=torch.float32)
@@ -815,9 +836,7 @@ def knet_x_bwd(h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk):
     _lib.check(_lib.lib().dgg_knet_x_bwd_nodes(N, h, _ptr(mu_sd), _ptr(_chk(W1)), h2, _ptr(_chk(Wmu)), h4, _ptr(_chk(Wp)), _ptr(_chk(bmu)),
                                                _ptr(z), _ptr(u), _ptr(_chk(dk)), _ptr(dkp), _ptr(dm), _ptr(dpre1), _ptr(dxk), _ptr(m),
                                                _stream()), "knet_x_bwd_nodes")
-    dW1, db1 = gemm_tn(dpre1, feat, colsum=True)
-    dWmu, dbmu = gemm_tn(dm, z, colsum=True)
-    dWp, dbp = gemm_tn(dkp, m, colsum=True)
+    (dW1, db1), (dWmu, dbmu), (dWp, dbp) = gemm_tn_pairs([(dpre1, feat), (dm, z), (dkp, m)])    # three tiny products, one launch
     return dxk, dW1, db1, dWmu, dbmu, dWp, dbp
 
 

@@ -168,7 +168,10 @@ class ShardedDGGConv:
         if hasattr(kern, "zero_pool"):                   # every zero-initialised accumulator of the backward from ONE filled buffer
             ncols, h, F = s["xp"].shape[0], s["xp"].shape[1], s["H"].shape[1]
             rows = s["idx"].shape[0]
-            need = ncols * (h + F + 2) + rows * self.K + 2 * sum(int(v.numel()) for v in P.values()) + 65536
+            # (payload path: dH / da / dxp are written by their owner wavefronts, only dA and the weight gradients are accumulated into)
+            need = rows * self.K + 2 * sum(int(v.numel()) for v in P.values()) + 65536
+            if s.get("partp") is None:
+                need += ncols * (h + F + 2)
             with kern.zero_pool(s["xp"].device, need):
                 return self._backward(dZ, x_local, P)
         return self._backward(dZ, x_local, P)
