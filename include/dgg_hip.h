@@ -136,6 +136,10 @@ int dgg_knet_input_deg_fwd(const float *deg, int64_t N, float dmean, float dstd,
 int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode,
                       const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val,
                       const float *k_limit, int algo, void *workspace, size_t ws_bytes, void *stream);
+/* dgg_allpairs_topk (noise_mode DGG_NOISE_RANKED, K = 64, learned k required) fused with dgg_softk_fwd: the ramp is applied to the
+ * settled list while it is still in registers; additionally writes w [row1-row0,64] and rs [row1-row0].  Same bits as the two calls. */
+int dgg_allpairs_topk_ranked_softk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
+                                   const float *k, int mode, int32_t *idx, float *val, float *w, float *rs, void *stream);
 /* bytes of device workspace the pruned path needs for (N, h): a bf16 copy of xp plus discounted squared norms;
  * 0 when the pruned path does not apply (explicit noise, K != 64, latent_dim not in {16,32,64,128}) */
 size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K);
@@ -269,6 +273,9 @@ int dgg_part_build(const int32_t *idx, const float *w, int64_t rows, int K, int6
 size_t dgg_partp_ws_bytes(int64_t rows, int K, int64_t ncols);
 int dgg_partp_build(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
                     void *ws, void *stream);
+/* dgg_partp_build with dgg_ell_normalize_fwd fused: rs_all [ncols] = row sums of every node -> ahat [rows,K] (same bits) */
+int dgg_partp_build_norm(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
+                         const float *rs_all, float *ahat, void *ws, void *stream);
 /* dgg_ell_conv_bwd_part on a payload partition (ahat_ir = record payload * rs_j^-1/2, bit-identical to dgg_ell_normalize_fwd);
  * also writes dA_rec [rows*K] = dA in record order.  dA, dH, da: caller zeroes. */
 int dgg_ell_conv_bwd_partp(const float *G, const float *H, int64_t rows, int K, int F, const void *partp_ws, int64_t ncols,

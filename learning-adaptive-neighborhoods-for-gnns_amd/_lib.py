@@ -31,6 +31,7 @@ PROTOTYPES = {
     "dgg_knet_deg_bwd_sums": [_vp, _i64, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
     "dgg_allpairs_topk": [_vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _vp, _vp, _i32, _vp, _sz, _vp],
     "dgg_allpairs_workspace_bytes": [_i64, _i32, _i32, _i32],
+    "dgg_allpairs_topk_ranked_softk": [_vp, _i64, _i32, _i64, _i64, _f32, _u32, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "dgg_edgelist_topk": [_vp, _i64, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _vp, _vp],
     "dgg_edge_mlp_fwd": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "dgg_edgelist_topk_p": [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
@@ -70,6 +71,7 @@ PROTOTYPES = {
     "dgg_ell_conv_bwd_part": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "dgg_partp_ws_bytes": [_i64, _i32, _i64],
     "dgg_partp_build": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp],
+    "dgg_partp_build_norm": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp],
     "dgg_ell_conv_bwd_partp": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_softk_edge_bwd_partp": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _i32, _i32, _vp, _i64,
                                  _vp, _vp, _vp, _vp],

@@ -66,7 +66,8 @@ template <bool FILL, bool PAY = false>
 __global__ __launch_bounds__(256) void part_pass(const int32_t *__restrict__ idx, const float *__restrict__ w, int64_t rows,
                                                  int K, int nb, int *__restrict__ gcount, int2 *__restrict__ recs,
                                                  int *__restrict__ slotmap, const float *__restrict__ val = nullptr,
-                                                 const float *__restrict__ rs_rows = nullptr, int4 *__restrict__ recs4 = nullptr) {
+                                                 const float *__restrict__ rs_rows = nullptr, int4 *__restrict__ recs4 = nullptr,
+                                                 const float *__restrict__ rs_all = nullptr, float *__restrict__ ahat_out = nullptr) {
     extern __shared__ int lds[];                                 // hist[nb] (+ base[nb] when filling)
     int *hist = lds, *base = lds + nb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -128,11 +129,15 @@ __global__ __launch_bounds__(256) void part_pass(const int32_t *__restrict__ idx
                     const float ai = __fdiv_rn(1.0f, c_sqrt(rs_rows[i]));
                     const float wa = __fmul_rn(ai, w[i * K + lane]);
                     recs4[slot] = make_int4((int)(i * 64 + lane), jj[u], (int)__float_as_uint(wa), (int)__float_as_uint(val[i * K + lane]));
+                    // normalize_adj fused (dgg_ell_normalize_fwd): ahat = (a_i w) a_j while w and a_i are at hand
+                    if (ahat_out) ahat_out[i * K + lane] = __fmul_rn(wa, __fdiv_rn(1.0f, c_sqrt(rs_all[jj[u]])));
                 } else {
                     recs[slot] = make_int2((int)(i * 64 + lane), jj[u]);
                 }
             } else if (!PAY && jj[u] == -1) {
                 slotmap[i * K + lane] = -1;                      // active entries: written by part_sort
+            } else if (PAY && ahat_out && jj[u] == -1) {
+                ahat_out[i * K + lane] = 0.0f;                   // inactive entry (empty slot or saturated ramp)
             }
         }
     }
@@ -1100,6 +1105,8 @@ int dgg_ell_conv_bwd_part(const float *G, const float *H, const float *ahat, int
 }
 
 // ---- payload partition (16-byte records carrying wa = w * rs_i^-1/2 and the score; no slot map) ---------------------------
+int dgg_partp_build_norm(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
+                         const float *rs_all, float *ahat, void *ws, void *stream);
 size_t dgg_partp_ws_bytes(int64_t rows, int K, int64_t ncols) {
     const int64_t nb = nbuckets(ncols);
     if (nb > 8192 || K > 64 || K < 1 || rows * 64 >= ((int64_t)1 << 31)) return 0;   // LDS histogram (64 KiB) / 32-bit record ids
@@ -1111,6 +1118,13 @@ size_t dgg_partp_ws_bytes(int64_t rows, int K, int64_t ncols) {
 // val [rows,K] = the scores (dgg_allpairs_topk / dgg_edgelist_topk), rs_rows [rows] = the row sums of the block's OWN rows.
 int dgg_partp_build(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
                     void *ws, void *stream) {
+    return dgg_partp_build_norm(idx, w, val, rs_rows, rows, K, ncols, nullptr, nullptr, ws, stream);
+}
+
+// the same with normalize_adj fused: rs_all [ncols] (row sums of EVERY node) -> ahat [rows,K] = rs_i^-1/2 w rs_j^-1/2, the bits
+// of dgg_ell_normalize_fwd (entries outside the partition: 0)
+int dgg_partp_build_norm(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
+                         const float *rs_all, float *ahat, void *ws, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const int64_t nb = nbuckets(ncols);
     if (dgg_partp_ws_bytes(rows, K, ncols) == 0 || !ws) return dgg_set_error(DGG_ERR_UNSUPPORTED, "partp_build: unsupported size or NULL workspace");
@@ -1122,8 +1136,9 @@ int dgg_partp_build(const int32_t *idx, const float *w, const float *val, const 
     hipLaunchKernelGGL((part_pass<false, true>), dim3(grid), dim3(256), (size_t)nb * 4, st, idx, w, rows, K, (int)nb, p.cursor, nullptr, nullptr,
                        val, rs_rows, p.tmp);
     hipLaunchKernelGGL(part_scan, dim3(1), dim3(1024), 0, st, p.bstart, p.cursor, (int)nb);
+    if ((rs_all == nullptr) != (ahat == nullptr)) return dgg_set_error(DGG_ERR_ARG, "partp_build_norm: rs_all and ahat go together");
     hipLaunchKernelGGL((part_pass<true, true>), dim3(grid), dim3(256), (size_t)nb * 8, st, idx, w, rows, K, (int)nb, p.cursor, nullptr, nullptr,
-                       val, rs_rows, p.tmp);
+                       val, rs_rows, p.tmp, rs_all, ahat);
     hipLaunchKernelGGL(part_sort_p, dim3((unsigned)nb), dim3(1024), 0, st, p.bstart, p.tmp, p.recs, p.nodeptr, (int)nb);
     return dgg_check_launch("partp_build");
 }

@@ -32,7 +32,8 @@ template <int H>
 __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restrict__ xp, int64_t N, int64_t row0,
                                                             int64_t row1, float t, uint32_t s0, uint32_t s1,
                                                             const float *__restrict__ klim, int32_t *__restrict__ idx,
-                                                            float *__restrict__ val) {
+                                                            float *__restrict__ val, int softk_mode, float *__restrict__ w_out,
+                                                            float *__restrict__ rs_out) {
     const int lane = threadIdx.x & 63;
     const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t i = row0 + lrow;
@@ -109,14 +110,29 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
     }
     const bool empty = list == DGG_EMPTY_KEY || lane >= L;
     idx[lrow * 64 + lane] = empty ? -1 : key_col(list);
-    val[lrow * 64 + lane] = empty ? 0.0f : key_val(list);
+    const float sv = empty ? 0.0f : key_val(list);
+    val[lrow * 64 + lane] = sv;
+    if (w_out) {
+        // smooth first-k ramp on the settled list (softk_fwd_kernel, dgg_ell.hip; reference dgm.py:1410-1420) while the scores are
+        // still in registers: same operations, same bits; saves re-reading idx / val and a launch
+        const float f = c_ramp((float)lane, klim[lrow]);
+        float v = f;
+        if (softk_mode == 0 || softk_mode == 3) {
+            const float a = __fmul_rn(sv, f);
+            v = softk_mode == 0 ? a : __fadd_rn(__fadd_rn(f, -a), a);
+        }
+        const float wv = empty ? 0.0f : v;
+        w_out[lrow * 64 + lane] = wv;
+        const float s_ = wave_sum_butterfly(wv);
+        if (lane == 0) rs_out[lrow] = s_;
+    }
 }
 
 template <int H>
 int launch_ranked(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
-                  const float *klim, int32_t *idx, float *val, hipStream_t st) {
+                  const float *klim, int32_t *idx, float *val, hipStream_t st, int softk_mode = 0, float *w = nullptr, float *rs = nullptr) {
     dim3 grid((unsigned)((row1 - row0 + 3) / 4));
-    hipLaunchKernelGGL(allpairs_topk_ranked<H>, grid, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, klim, idx, val);
+    hipLaunchKernelGGL(allpairs_topk_ranked<H>, grid, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, klim, idx, val, softk_mode, w, rs);
     return dgg_check_launch("allpairs_topk_ranked");
 }
 
@@ -137,16 +153,30 @@ int dgg_klimit_truncate_impl(const float *klim, int64_t rows, int K, int32_t *id
 }
 
 int dgg_allpairs_topk_ranked_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0,
-                                  uint32_t s1, int K, const float *klim, int32_t *idx, float *val, hipStream_t st) {
+                                  uint32_t s1, int K, const float *klim, int32_t *idx, float *val, hipStream_t st, int softk_mode,
+                                  float *w, float *rs) {
     if (K != 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path needs K = 64");
     if (N >= ((int64_t)1 << 31)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path needs N < 2^31");
+    if (w && (!klim || !rs)) return dgg_set_error(DGG_ERR_ARG, "ranked-noise path: the fused ramp needs the learned k and the row-sum output");
     if (row1 <= row0) return 0;
     switch (h) {
-        case 8: return launch_ranked<8>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st);
-        case 16: return launch_ranked<16>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st);
-        case 32: return launch_ranked<32>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st);
-        case 64: return launch_ranked<64>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st);
-        case 128: return launch_ranked<128>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st);
+        case 8: return launch_ranked<8>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs);
+        case 16: return launch_ranked<16>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs);
+        case 32: return launch_ranked<32>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs);
+        case 64: return launch_ranked<64>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs);
+        case 128: return launch_ranked<128>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs);
         default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path supports latent_dim in {8,16,32,64,128}");
     }
+}
+
+extern "C" {
+// dgg_allpairs_topk (noise_mode DGG_NOISE_RANKED, K = 64, k_limit required) FUSED with dgg_softk_fwd: also w [rows,64] and
+// rs [rows] (mode as dgg_softk_fwd: 0 k_times_edge_prob, 1 k_only, 3 straight-through hard).  Same bits as the two calls.
+int dgg_allpairs_topk_ranked_softk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
+                                   const float *k, int mode, int32_t *idx, float *val, float *w, float *rs, void *stream) {
+    if (row0 < 0 || row1 > N || row0 > row1) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_softk: bad row range");
+    if (mode != 0 && mode != 1 && mode != 3) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_softk: mode must be 0, 1 or 3");
+    if (!k || !w || !rs) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_softk: k, w and rs are required");
+    return dgg_allpairs_topk_ranked_impl(xp, N, h, row0, row1, t, s0, s1, 64, k, idx, val, (hipStream_t)stream, mode, w, rs);
+}
 }

@@ -259,6 +259,23 @@ def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed
     return idx, val
 
 
+def allpairs_topk_softk(xp, k, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, seed=(0, 0), rows=None):
+    """ranked-noise all-pairs top-64 with the first-k ramp fused (allpairs_topk(k_limit=k) + softk_fwd in one launch)
+    -> idx, val, w [rows,64], rs [rows]"""
+    xp, k = _chk(xp), _chk(k)
+    N, h = xp.shape
+    r0, r1 = (0, N) if rows is None else rows
+    idx = torch.empty((r1 - r0, 64), device=xp.device, dtype=torch.int32)
+    val = torch.empty((r1 - r0, 64), device=xp.device, dtype=torch.float32)
+    w = torch.empty((r1 - r0, 64), device=xp.device, dtype=torch.float32)
+    rs = torch.empty((r1 - r0,), device=xp.device, dtype=torch.float32)
+    pe = _probe_begin()
+    _lib.check(_lib.lib().dgg_allpairs_topk_ranked_softk(_ptr(xp), N, h, r0, r1, t, seed[0], seed[1], _ptr(k), mode, _ptr(idx), _ptr(val),
+                                                         _ptr(w), _ptr(rs), _stream()), "allpairs_topk_ranked_softk")
+    _probe_end("allpairs_topk", pe)
+    return idx, val, w, rs
+
+
 def edgelist_topk(xp, rowptr, col, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed=(0, 0)):
     xp = _chk(xp)
     N, h = xp.shape
@@ -654,17 +671,23 @@ class PartP:
         self.ws, self.rows, self.K, self.ncols = ws, rows, K, ncols
 
 
-def partp_build(idx, w, val, rs_rows, ncols):
+def partp_build(idx, w, val, rs_rows, ncols, rs_all=None):
     """Payload partition of the active ELL entries by destination node: records carry w * rs_i^-1/2 and the score, there is no
-    slot map.  Returns None when it does not apply."""
+    slot map.  Returns None when it does not apply.  rs_all [ncols] (row sums of every node): normalize_adj is fused and the
+    result is (partition, ahat [rows,K])."""
     N, K = idx.shape
     nbytes = int(_lib.lib().dgg_partp_ws_bytes(N, K, ncols))
     if nbytes == 0:
         return None
     ws = torch.empty((nbytes,), device=idx.device, dtype=torch.uint8)
-    _lib.check(_lib.lib().dgg_partp_build(_ptr(idx), _ptr(_chk(w)), _ptr(_chk(val)), _ptr(_chk(rs_rows)), N, K, ncols, _ptr(ws), _stream()),
-               "partp_build")
-    return PartP(ws, N, K, ncols)
+    if rs_all is None:
+        _lib.check(_lib.lib().dgg_partp_build(_ptr(idx), _ptr(_chk(w)), _ptr(_chk(val)), _ptr(_chk(rs_rows)), N, K, ncols, _ptr(ws), _stream()),
+                   "partp_build")
+        return PartP(ws, N, K, ncols)
+    ahat = torch.empty((N, K), device=idx.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_partp_build_norm(_ptr(idx), _ptr(_chk(w)), _ptr(_chk(val)), _ptr(_chk(rs_rows)), N, K, ncols, _ptr(_chk(rs_all)),
+                                               _ptr(ahat), _ptr(ws), _stream()), "partp_build_norm")
+    return PartP(ws, N, K, ncols), ahat
 
 
 def conv_bwd_cols_p(idx, H, G, partp, rs):

@@ -144,19 +144,25 @@ class ShardedDGGConv:
         s["k"], s["z"], s["u"], s["feat"] = kern.knet_x_fwd(xk, deg_local, mu_sd, P["W1"], P["b1"], P["Wmu"], P["bmu"],
                                                           P["Wp"].reshape(-1), P["bp"])
         s["xp"] = xp = g_xp.get() if (self.coll and not repl) else xp
-        s["idx"], s["val"] = kern.allpairs_topk(xp, self.K, self.t, self.noise_mode, None, self.seed,
-                                                rows=(self.r0, self.r1), algo=self.algo, k_limit=s["k"])
-        s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
-        # destination-bucket partition of the active entries: the backward's column-side terms run on it (no atomics)
-        # (payload form -- records carry w rs_i^-1/2 and the score, no slot map -- when the namespace offers it and covers the shape)
-        s["partp"] = kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N) \
-            if (hasattr(kern, "partp_build") and xp.shape[1] in (16, 32, 64, 128) and H.shape[1] in (16, 32, 64, 128)
-                and self.mode in (0, 1)) else None
-        s["part"] = kern.part_build(s["idx"], s["w"], self.N) if (s["partp"] is None and hasattr(kern, "part_build")) else None
+        if self.noise_mode == 4 and self.K == 64 and hasattr(kern, "allpairs_topk_softk") and xp.shape[1] in (8, 16, 32, 64, 128):
+            # ranked noise: the ramp is applied inside the search kernel, while the settled list is still in registers
+            s["idx"], s["val"], s["w"], rs_local = kern.allpairs_topk_softk(xp, s["k"], self.mode, self.t, self.seed, rows=(self.r0, self.r1))
+        else:
+            s["idx"], s["val"] = kern.allpairs_topk(xp, self.K, self.t, self.noise_mode, None, self.seed,
+                                                    rows=(self.r0, self.r1), algo=self.algo, k_limit=s["k"])
+            s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
         s["rs"] = rs = _all_gather_rows(rs_local, self.N, self.per, self.group, self.bufs, "rs") if self.coll else rs_local
         if self.emulate is not None:
             s["rs"] = rs = rs_local.repeat(self.world)[:self.N].contiguous()
-        s["ahat"] = kern.normalize_fwd(s["idx"], s["w"], rs, self.r0)
+        # destination-bucket partition of the active entries: the backward's column-side terms run on it (no atomics)
+        # (payload form -- records carry w rs_i^-1/2 and the score, no slot map, normalize_adj fused into its fill pass -- when the
+        # namespace offers it and covers the shape)
+        use_p = hasattr(kern, "partp_build") and xp.shape[1] in (16, 32, 64, 128) and H.shape[1] in (16, 32, 64, 128) and self.mode in (0, 1)
+        got = kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs) if use_p else None
+        s["partp"], s["ahat"] = got if got is not None else (None, None)
+        s["part"] = kern.part_build(s["idx"], s["w"], self.N) if (s["partp"] is None and hasattr(kern, "part_build")) else None
+        if s["ahat"] is None:
+            s["ahat"] = kern.normalize_fwd(s["idx"], s["w"], rs, self.r0)
         s["H"] = H = g_H.get() if (self.coll and not repl) else H
         s["Z"] = kern.spmm_fwd(s["idx"], s["ahat"], H, 2)    # relu(A (x Wc))
         self.saved = s

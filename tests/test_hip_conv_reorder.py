@@ -276,3 +276,35 @@ def test_bf16_gcnii_layer_product(dev, n, K, F, variant, residual):
     assert rel(outs[1], outs[0]) <= 1e-2
     for g16, g32 in zip(grads[1], grads[0]):
         assert rel(g16, g32) <= 2e-2
+
+
+@pytest.mark.parametrize("mode", [0, 1, 3])
+def test_ramp_fused_into_the_ranked_search(dev, mode):
+    """dgg_allpairs_topk_ranked_softk == dgg_allpairs_topk(k_limit) followed by dgg_softk_fwd, bit for bit (whole block and a row shard)"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(17 + mode)
+    N, h = 3000, 64
+    xp = T((rng.standard_normal((N, h)) * 0.6).astype(np.float32), dev)
+    k = T((3 + 40 * rng.random(N)).astype(np.float32), dev)
+    for r0, r1 in [(0, N), (700, 1901)]:
+        kk = k[r0:r1].contiguous()
+        idx, val = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_RANKED, seed=(5, 9), rows=(r0, r1), k_limit=kk)
+        w, rs = ops.softk_fwd(idx, val, kk, mode)
+        got = ops.allpairs_topk_softk(xp, kk, mode, seed=(5, 9), rows=(r0, r1))
+        for a, b in zip(got, (idx, val, w, rs)):
+            assert torch.equal(a, b)
+
+
+def test_normalisation_fused_into_the_partition_build(dev):
+    """dgg_partp_build_norm writes the bits of dgg_ell_normalize_fwd (row shard: own rows, global row sums)"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(23)
+    N = 1300
+    xp, k, idx, val, w, rs, ahat = _graph(rng, N, 32)
+    for lo, hi in [(0, N), (400, 977)]:
+        sl = slice(lo, hi)
+        got = ops.partp_build(T(idx[sl], dev), T(w[sl], dev), T(val[sl], dev), T(rs[sl], dev), N, T(rs, dev))
+        assert got is not None
+        ref = ops.normalize_fwd(T(idx[sl], dev), T(w[sl], dev), T(rs, dev), lo)
+        assert torch.equal(got[1], ref)
+        assert np.array_equal(Nn(got[1]), ahat[sl])
