@@ -915,6 +915,135 @@ __global__ __launch_bounds__(256) void edge_bwd_node(const float *__restrict__ x
     }
 }
 
+// ---- F/4 lanes per DESTINATION node (64/(F/4) nodes per wavefront) ---------------------------------------------------------
+// The one-wavefront-per-node kernels above pay a fixed cost per node (pointer, H_j, stores, a 16-slot batch however short the
+// list): right when a node has tens of records, wasteful when it has a handful -- a rank of 8 holds 1/8 of the rows but the
+// destination set stays all N nodes, ~5 records each.  Here a group of F/4 lanes walks one node's records NBT at a time, so a
+// wavefront covers 64/(F/4) nodes per instruction and needs no cross-group reduction.  Same arithmetic per record; the sums of
+// a node accumulate in record order (a different order from the wavefront kernel: equal within rounding, not bit for bit).
+template <int F, int NBT>
+__global__ __launch_bounds__(256) void conv_bwd_nodeg(const float *__restrict__ G, const float *__restrict__ Hm, int K, int64_t ncols,
+                                                      const int *__restrict__ nodeptr, const int4 *__restrict__ recs,
+                                                      const float *__restrict__ rs, float *__restrict__ dA, float *__restrict__ dA_rec,
+                                                      float *__restrict__ dH, float *__restrict__ da) {
+    constexpr int LPR = F / 4, NPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, c4 = lane % LPR;
+    const int64_t jraw = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * NPW + lane / LPR;
+    const bool live = jraw < ncols;
+    const int64_t j = live ? jraw : ncols - 1;                    // a group past the end shadows the last node and stores nothing
+    const int p0 = nodeptr[j], p1 = live ? nodeptr[j + 1] : p0;
+    const float4 hj = *reinterpret_cast<const float4 *>(Hm + j * F + 4 * c4);
+    const float rsj = rs[j];
+    const float aj = __fdiv_rn(1.0f, c_sqrt(rsj));
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float sda = 0.0f;
+    int trips = (p1 - p0 + NBT - 1) / NBT;                         // the wavefront runs the longest list of its groups (DPP reductions
+#pragma unroll                                                    //  below want every lane in the loop)
+    for (int off = LPR; off < 64; off <<= 1) trips = max(trips, __shfl_xor(trips, off, 64));
+    for (int it = 0, e0 = p0; it < trips; it++, e0 += NBT) {
+        int src[NBT];
+        float cf[NBT];
+        float4 g[NBT];
+#pragma unroll
+        for (int b = 0; b < NBT; b++) {
+            const bool have = e0 + b < p1;
+            const int4 r = recs[have ? e0 + b : (p1 > p0 ? p1 - 1 : 0)];      // same address across the group; clamped, unconditional
+            src[b] = have ? r.x : -1;
+            cf[b] = have ? __fmul_rn(__int_as_float(r.z), aj) : 0.0f;
+            g[b] = *reinterpret_cast<const float4 *>(G + (int64_t)(have ? (r.x >> 6) : 0) * F + 4 * c4);
+        }
+#pragma unroll
+        for (int b = 0; b < NBT; b++) {
+            float dot = g[b].x * hj.x;
+            dot = fmaf(g[b].y, hj.y, dot); dot = fmaf(g[b].z, hj.z, dot); dot = fmaf(g[b].w, hj.w, dot);
+            if (LPR > 16) dot += __uint_as_float(xor_shfl<16>(__float_as_uint(dot), lane));
+            if (LPR > 8) dot += __uint_as_float(xor_shfl<8>(__float_as_uint(dot), lane));
+            if (LPR > 4) dot += __uint_as_float(xor_shfl<4>(__float_as_uint(dot), lane));
+            dot += __uint_as_float(xor_shfl<2>(__float_as_uint(dot), lane));
+            dot += __uint_as_float(xor_shfl<1>(__float_as_uint(dot), lane));
+            if (src[b] >= 0 && c4 == (b % LPR)) {
+                dA[(int64_t)(src[b] >> 6) * K + (src[b] & 63)] = dot;
+                dA_rec[e0 + b] = dot;
+            }
+            acc.x = fmaf(cf[b], g[b].x, acc.x); acc.y = fmaf(cf[b], g[b].y, acc.y);
+            acc.z = fmaf(cf[b], g[b].z, acc.z); acc.w = fmaf(cf[b], g[b].w, acc.w);
+            sda = fmaf(dot, cf[b], sda);
+        }
+    }
+    if (!live) return;
+    *reinterpret_cast<float4 *>(dH + j * F + 4 * c4) = acc;
+    if (da && c4 == 0) da[j] = sda * sqrtf(rsj);
+}
+
+template <int H, int NBT>
+__global__ __launch_bounds__(256) void edge_bwd_nodeg(const float *__restrict__ xp, int64_t ncols, const int *__restrict__ nodeptr,
+                                                      const int4 *__restrict__ recs, const float *__restrict__ dA_rec,
+                                                      const float4 *__restrict__ rowinfo, const float *__restrict__ rs, int normalized,
+                                                      int64_t row0, int64_t rows, float t, int perturb, float *__restrict__ dxp) {
+    constexpr int LPR = H / 4, NPW = 64 / LPR;
+    static_assert(NBT <= LPR, "one lane of the group per record of a batch");
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, gbase = lane - c4;
+    const int64_t jraw = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * NPW + lane / LPR;
+    const bool live = jraw < ncols;
+    const int64_t j = live ? jraw : ncols - 1;
+    const int p0 = nodeptr[j], p1 = live ? nodeptr[j + 1] : p0;
+    const float4 xj = *reinterpret_cast<const float4 *>(xp + j * H + 4 * c4);
+    const float aj = normalized ? __fdiv_rn(1.0f, c_sqrt(rs[j])) : 1.0f;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int trips = (p1 - p0 + NBT - 1) / NBT;
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) trips = max(trips, __shfl_xor(trips, off, 64));
+    for (int it = 0, e0 = p0; it < trips; it++, e0 += NBT) {
+        // lane c4 of the group forms d loss / d score of record e0 + c4 % NBT (lanes >= NBT repeat one: harmless, same value)
+        const int eb = e0 + c4 % NBT;
+        const bool mine = eb < p1;
+        const int ec = mine ? eb : (p1 > p0 ? p1 - 1 : 0);
+        const int4 myrec = recs[ec];
+        float mydval;
+        {
+            const float4 info = rowinfo[myrec.x >> 6];
+            const float dw = dA_rec[ec] * info.x * aj + info.y;
+            const float th = c_tanh((float)(myrec.x & 63) - info.z);
+            mydval = mine ? dw * (1.0f - 0.5f * (1.0f + th)) : 0.0f;
+        }
+        float gv[NBT], vv[NBT];
+        float4 xi[NBT];
+#pragma unroll
+        for (int b = 0; b < NBT; b++) {
+            const int src = __shfl(myrec.x, gbase + b, 64);      // every shuffle outside a select (see conv_bwd_node)
+            gv[b] = __shfl(mydval, gbase + b, 64);
+            vv[b] = __int_as_float(__shfl(myrec.w, gbase + b, 64));
+            // unconditional gather; an inactive slot (gv == 0) reads xp_j, whose distance to itself is 0
+            xi[b] = *reinterpret_cast<const float4 *>(xp + (e0 + b < p1 ? row0 + (src >> 6) : j) * H + 4 * c4);
+        }
+#pragma unroll
+        for (int b = 0; b < NBT; b++) {
+            const float4 d = make_float4(xi[b].x - xj.x, xi[b].y - xj.y, xi[b].z - xj.z, xi[b].w - xj.w);
+            float d2 = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+            if (LPR > 16) d2 += __uint_as_float(xor_shfl<16>(__float_as_uint(d2), lane));
+            if (LPR > 8) d2 += __uint_as_float(xor_shfl<8>(__float_as_uint(d2), lane));
+            if (LPR > 4) d2 += __uint_as_float(xor_shfl<4>(__float_as_uint(d2), lane));
+            d2 += __uint_as_float(xor_shfl<2>(__float_as_uint(d2), lane));
+            d2 += __uint_as_float(xor_shfl<1>(__float_as_uint(d2), lane));
+            float dd = 0.0f;
+            if (gv[b] != 0.0f && d2 != 0.0f) {
+                const float dist = sqrtf(d2);
+                const float p = c_exp(t * dist);
+                const float dp = perturb ? gv[b] * vv[b] / (p + 1e-8f) : gv[b];
+                dd = dp * t * p / dist;
+            }
+            acc.x -= dd * d.x; acc.y -= dd * d.y; acc.z -= dd * d.z; acc.w -= dd * d.w;
+        }
+    }
+    if (!live) return;
+    float4 *o = reinterpret_cast<float4 *>(dxp + j * H + 4 * c4);
+    if (j >= row0 && j < row0 + rows) {
+        const float4 v = *o;
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *o = acc;
+}
+
 // ---- normalisation backward: row side (da_i, per-entry coefficient), column side (bucket sums) -----------------------
 __global__ __launch_bounds__(256) void norm_da_rows(const int32_t *__restrict__ idx, const float *__restrict__ w,
                                                     const float *__restrict__ rs, const float *__restrict__ dA, int64_t rows,
@@ -1143,6 +1272,13 @@ int dgg_partp_build_norm(const int32_t *idx, const float *w, const float *val, c
     return dgg_check_launch("partp_build");
 }
 
+// which node kernel: a group of lanes per node when the lists are short (fewer than 16 records per node on average; a rank of G
+// holds 64/G of them), a wavefront per node otherwise.  DGG_NODE_GROUPS=0/1 forces one (measurement only).
+static bool node_groups(int64_t nrec, int64_t ncols) {
+    static const int forced = [] { const char *e = getenv("DGG_NODE_GROUPS"); return e ? atoi(e) : -1; }();
+    return forced >= 0 ? forced != 0 : nrec < 16 * ncols;
+}
+
 // dgg_ell_conv_bwd_part on a payload partition: ahat comes from the records; additionally dA_rec [rows*K] = dA in record order
 // (for dgg_softk_edge_bwd_partp).  dA [rows,K], dH [ncols,F], da [ncols] as in dgg_ell_conv_bwd_part (caller zeroes all three).
 int dgg_ell_conv_bwd_partp(const float *G, const float *H, int64_t rows, int K, int F, const void *partp_ws, int64_t ncols,
@@ -1157,9 +1293,14 @@ int dgg_ell_conv_bwd_partp(const float *G, const float *H, int64_t rows, int K, 
     const int64_t ngroups = (rows * K + CH - 1) / CH;
     hipStream_t st = (hipStream_t)stream;
     (void)ngroups;
+    const bool grouped = node_groups(rows * K, ncols);
 #define DGG_CONV_COLS_P(FF)                                                                                                \
-    hipLaunchKernelGGL(conv_bwd_node<FF>, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, G, H, K, ncols, p.nodeptr, p.recs, rs, dA, \
-                       dA_rec, dH, da)
+    if (grouped)                                                                                                           \
+        hipLaunchKernelGGL((conv_bwd_nodeg<FF, 4>), dim3((unsigned)((ncols + 4 * (256 / FF) - 1) / (4 * (256 / FF)))), dim3(256), 0, st, G, H, K, \
+                           ncols, p.nodeptr, p.recs, rs, dA, dA_rec, dH, da);                                              \
+    else                                                                                                                   \
+        hipLaunchKernelGGL(conv_bwd_node<FF>, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, G, H, K, ncols, p.nodeptr, p.recs, rs, dA, \
+                           dA_rec, dH, da)
     switch (F) {
         case 16: DGG_CONV_COLS_P(16); break;
         case 32: DGG_CONV_COLS_P(32); break;
@@ -1187,10 +1328,15 @@ int dgg_softk_edge_bwd_partp(const float *xp, int64_t rows, int h, const int32_t
     PartPHdr p = partp_layout(const_cast<void *>(partp_ws), nb, rows * K);
     const SoftkArgs sk{k, rs, dA, da, mode, normalized, nullptr, dk, ahat_rows, reinterpret_cast<float4 *>(rowinfo_ws)};
     const unsigned gr = (unsigned)((rows + 3) / 4);
+    const bool grouped = node_groups(rows * K, ncols);
 #define DGG_EDGE_PARTP(HH)                                                                                                  \
     hipLaunchKernelGGL((edge_bwd_rows<HH, true, true>), dim3(gr), dim3(256), 0, st, xp, rows, idx, val, nullptr, K, row0, t, perturb, nullptr, \
                        nullptr, dxp, sk);                                                                                    \
-    if (mode == 0)                                                                                                           \
+    if (mode == 0 && grouped)                                                                                                \
+        hipLaunchKernelGGL((edge_bwd_nodeg<HH, 4>), dim3((unsigned)((ncols + 4 * (256 / HH) - 1) / (4 * (256 / HH)))), dim3(256), 0, st, xp, \
+                           ncols, p.nodeptr, p.recs, dA_rec, reinterpret_cast<const float4 *>(rowinfo_ws), rs, normalized, row0, rows, t, \
+                           perturb, dxp);                                                                                    \
+    else if (mode == 0)                                                                                                      \
         hipLaunchKernelGGL(edge_bwd_node<HH>, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, xp, ncols, p.nodeptr, p.recs, dA_rec, \
                            reinterpret_cast<const float4 *>(rowinfo_ws), rs, normalized, row0, rows, t, perturb, dxp)
     switch (h) {
