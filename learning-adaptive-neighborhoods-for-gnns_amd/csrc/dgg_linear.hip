@@ -194,58 +194,71 @@ __global__ __launch_bounds__(64 * WAVES, NACC <= 2 ? 4 : 2) void linear_fwd_mfma
 
 // ---- large-N forward: weights resident in LDS, rows straight from HBM into the MFMA operand registers ---------------------
 // linear_fwd_mfma restages the weight tile for every 128-row tile and walks K in synchronised blocks; at N >= 10^5 the
-// matrix cores are busy ~30 % of the time.  Here a workgroup (8 wavefronts, two per SIMD) is PERSISTENT: the whole weight
-// matrix (all column blocks) is written to LDS once, in MFMA operand order, and every wavefront then walks 32-row blocks on
-// its own -- no barrier after the prologue; while one wavefront of a SIMD loads rows or stores results the other one feeds
-// the matrix core.  The A operand of step s is (lane row, k = 2s + lane/32); lane (row, half) loads the CONTIGUOUS half
-// [half*D/2, (half+1)*D/2) of its row with 16-byte loads, and one v_permlane32_swap per register pair turns
-// (reg 2t, reg 2t+1) into the operands of steps t and D/4 + t -- X never touches LDS.
-// Work split: `nmain` row blocks (a multiple of the SIMD count) are dealt whole, so every SIMD gets the same number; the
-// remaining < #SIMD blocks are dealt one (row block, column block) unit at a time -- a whole extra block on a few SIMDs would
-// cost a full round (3125 blocks of a 100k-row input on 1024 SIMDs: 3 rounds + 53 blocks).
+// matrix cores are busy ~30 % of the time.  Here a workgroup (4 wavefronts, one per SIMD, the full register file each) is
+// PERSISTENT: the whole weight matrix (all column blocks) is written to LDS once, in MFMA operand order, and every wavefront
+// then walks 32-row blocks on its own -- no barrier after the prologue.
+//  * A operand of step s = (lane row, k = 2s + lane/32): lane (row, half) loads the CONTIGUOUS half [half*D/2, (half+1)*D/2)
+//    of its row with 16-byte loads, and one v_permlane32_swap per register pair turns (reg 2t, reg 2t+1) into the operands of
+//    steps t and D/4 + t -- X never touches LDS.  The next block's rows are in flight during the current block's MFMAs.
+//  * B operands of step s + PD are read from LDS before the MFMAs of step s issue (left alone the compiler reads them right
+//    before their use and waits out the LDS latency between every two MFMAs).
+//  * Epilogue: an accumulator holds one COLUMN per lane, so a direct store is 4 bytes per lane, 16 instructions per column
+//    block -- 96 per row block, more than a wavefront may have in flight (vmcnt is 6 bits): measured 45 of 100 us.  The 32x32
+//    block is turned through a 4 KB LDS tile private to the wavefront (LDS operations of one wavefront execute in order: no
+//    barrier) and leaves as four 16-byte-per-lane stores of 8 full 128-byte rows each.  (Measured and rejected: keeping the
+//    finished block in registers and issuing its epilogue in slices between the next block's MFMA steps -- the VALU / LDS
+//    work between the steps slows the MFMA stream by more than the 5 of 19 us per block it hides; two wavefronts per SIMD
+//    without the register prefetch -- same time.)
+//  * Work split: `nmain` row blocks (a multiple of the wavefront count) are dealt whole; the remaining < #wavefronts blocks are
+//    dealt one (row block, column block) unit at a time -- a whole extra block on a few SIMDs would cost a full round (3125
+//    blocks of a 100k-row input on 1024 SIMDs: 3 rounds + 53 blocks).
 // Same k-ordered fmaf chain per output as linear_fwd_mfma: bit-identical results.
-template <int D, int NACC, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 1) void linear_fwd_reg(const float *__restrict__ x, int64_t N, const float *__restrict__ W,
-                                                         const float *__restrict__ b, LinSegs segs, int64_t nrb, int dbg, long long *ts) {
-    constexpr int S = D / 2, XR = D / 2;
-    int tsn = 0;
-#define TS() do { if (ts && blockIdx.x == 7 && threadIdx.x == 64 && tsn < 60) ts[tsn++] = wall_clock64(); } while (0)
-    TS();                         // MFMA steps per output; operand registers per lane
+template <int D, int NACC>
+__global__ __launch_bounds__(256, 1) void linear_fwd_reg(const float *__restrict__ x, int64_t N, const float *__restrict__ W,
+                                                         const float *__restrict__ b, LinSegs segs, int64_t nrb) {
+    constexpr int S = D / 2, XR = D / 2;                         // MFMA steps per output; operand registers per lane
     __shared__ float wsf[S * NACC * 64];                         // [step][column block][lane]
-    constexpr bool PREF = WAVES == 4;                            // one wavefront per SIMD: the next block's rows are prefetched into registers
-    __shared__ __attribute__((aligned(16))) float obuf[WAVES * 1024];   // output tile of each wavefront
+    __shared__ __attribute__((aligned(16))) float obuf[4 * 1024];   // output tile of each wavefront
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hh = lane >> 5;
-#pragma unroll                                                    // (all loads in flight: a rolled loop pays one L2 round trip per pass)
-    for (int it = 0; it < NACC * 32 * (D / 4) / (64 * WAVES); it++) {   // lanes along the output index: conflict-free LDS writes
-        const int e = tid + it * 64 * WAVES;
-        const int j = e % (NACC * 32), q = e / (NACC * 32);
-        const float4 v = *reinterpret_cast<const float4 *>(W + (int64_t)j * D + 4 * q);
-        float *dst = wsf + ((2 * q) * NACC + (j >> 5)) * 64 + (j & 31);
-        dst[0] = v.x; dst[32] = v.y; dst[NACC * 64] = v.z; dst[NACC * 64 + 32] = v.w;
-    }
-    const bool hasb = b != nullptr;
-    __syncthreads();
-    TS();
-    const int64_t nsimd = (int64_t)gridDim.x * 4, nw = nsimd * (WAVES / 4);
-    const int64_t slot = (int64_t)(wave >> 2) * nsimd + (int64_t)blockIdx.x * 4 + (wave & 3);   // first wavefronts of all SIMDs, then second
-    const int64_t nmain = nrb - nrb % nw;
-    const int64_t R = nrb - nmain, nunits = nmain / nw + (slot < R * NACC ? (R * NACC - slot + nw - 1) / nw : 0);
-    float xc[XR], xn[PREF ? XR : 1];
-    auto load_rows = [&](int64_t rb, auto &dst) {
+    const int64_t nw = (int64_t)gridDim.x * 4, slot = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t nrbf = N / 32;                                 // FULL row blocks (a partial last block is a remainder unit)
+    const int64_t nmain = nrbf - nrbf % nw, nfull = nmain / nw;
+    const int64_t R = nrb - nmain, nunits = nfull + (slot < R * NACC ? (R * NACC - slot + nw - 1) / nw : 0);
+    // unit t of this wavefront: a whole row block while t < nfull, then one (row block, column block) of the remainder
+    auto unit_rb = [&](int64_t t) {
+        if (t < nfull) return slot + t * nw;
+        const int64_t u = slot + (t - nfull) * nw;
+        return nmain + u % (R > 0 ? R : 1);
+    };
+    float xc[XR], xn[XR];
+    auto load_rows = [&](int64_t rb, float(&dst)[XR]) {
         int64_t row = rb * 32 + li;
         row = row < N ? row : N - 1;
         const float4 *p = reinterpret_cast<const float4 *>(x + row * D + hh * (D / 2));
-        if (dbg & 1) {
-#pragma unroll
-            for (int q = 0; q < XR; q++) dst[q] = (float)(row + q);
-            return;
-        }
 #pragma unroll
         for (int q = 0; q < XR / 4; q++) {
             const float4 v = p[q];
             dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
         }
     };
+    if (nunits > 0) load_rows(unit_rb(0), xc);                   // in flight while the weights are staged
+#pragma unroll                                                    // (all loads in flight: a rolled loop pays one L2 round trip per pass)
+    for (int it = 0; it < NACC * 32 * (D / 4) / 256; it++) {     // lanes along the output index: conflict-free LDS writes
+        const int e = tid + it * 256;
+        const int j = e % (NACC * 32), q = e / (NACC * 32);
+        const float4 v = *reinterpret_cast<const float4 *>(W + (int64_t)j * D + 4 * q);
+        float *dst = wsf + ((2 * q) * NACC + (j >> 5)) * 64 + (j & 31);
+        dst[0] = v.x; dst[32] = v.y; dst[NACC * 64] = v.z; dst[NACC * 64 + 32] = v.w;
+    }
+    const bool hasb = b != nullptr;
+    float bj[NACC];
+    int actv[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+        bj[a] = hasb ? b[a * 32 + li] : 0.0f;
+        actv[a] = segs.act[a];
+    }
+    __syncthreads();
     auto swap_rows = [&]() {
 #pragma unroll
         for (int t = 0; t < XR / 2; t++) {
@@ -260,105 +273,94 @@ __global__ __launch_bounds__(64 * WAVES, 1) void linear_fwd_reg(const float *__r
         const float lk = v > 0.0f ? v : __fmul_rn(0.01f, v), rl = v > 0.0f ? v : 0.0f;
         return av == 1 ? lk : (av == 2 ? rl : v);
     };
-    // Epilogue: an accumulator holds one COLUMN per lane (16 rows in 16 registers), i.e. a direct store is 4 bytes per lane and
-    // 16 instructions per column block -- 96 per row block, more than a wavefront may have in flight (vmcnt is 6 bits), so the
-    // next block's MFMAs wait for HBM write acknowledgements (measured: 45 of 100 us).  The 32x32 block is turned through a
-    // 4 KB LDS tile private to the wavefront (LDS operations of one wavefront execute in order: no barrier) and leaves as four
-    // 16-byte-per-lane stores of 8 full 128-byte rows each.
     float *ot = obuf + wave * 1024;
-    auto store_block = [&](const f32x16 &acc, int a, int64_t rb, bool full) {
-        const int av = segs.act[a], ld = segs.ld[a];
-        const float bj = hasb ? b[a * 32 + li] : 0.0f;
+    // epilogue of one column block in 6 slices: 0-3 four accumulator registers each -> LDS tile, 4 tile -> registers, 5 stores
+    float4 ov[4];
+    auto epi_slice = [&](const f32x16 &acc, int a, int j, int64_t rb, bool full) {
+        if (j < 4) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) ot[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + li] = finish(acc[r], bj, av);
-        float *yb = segs.y[a] + rb * 32 * (int64_t)ld + 4 * (lane & 7);
+            for (int r = 4 * j; r < 4 * j + 4; r++) ot[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + li] = finish(acc[r], bj[a], actv[a]);
+        } else if (j == 4) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int row = (lane >> 3) + 8 * j;
-            const float4 v = *reinterpret_cast<const float4 *>(ot + row * 32 + 4 * (lane & 7));
-            if (full || rb * 32 + row < N) *reinterpret_cast<float4 *>(yb + (int64_t)row * ld) = v;
+            for (int u = 0; u < 4; u++) ov[u] = *reinterpret_cast<const float4 *>(ot + ((lane >> 3) + 8 * u) * 32 + 4 * (lane & 7));
+        } else if (j == 5) {
+            const int ld = segs.ld[a];
+            float *yb = segs.y[a] + rb * 32 * (int64_t)ld + 4 * (lane & 7);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int row = (lane >> 3) + 8 * u;
+                if (full || rb * 32 + row < N) *reinterpret_cast<float4 *>(yb + (int64_t)row * ld) = ov[u];
+            }
         }
     };
-    // unit t of this wavefront: a whole row block while t < nmain / nw, then one (row block, column block) of the remainder
-    auto unit_rb = [&](int64_t t) {
-        if (t < nmain / nw) return slot + t * nw;
-        const int64_t u = slot + (t - nmain / nw) * nw;
-        return nmain + u % (R > 0 ? R : 1);
+    // one whole row block (always a FULL block: unconditional stores; a partial last block is a remainder unit)
+    auto main_block = [&](int64_t rb) {
+        f32x16 acc[NACC];
+#pragma unroll
+        for (int a = 0; a < NACC; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][r] = 0.0f;
+        constexpr int PD = NACC >= 4 ? 1 : (NACC >= 2 ? 2 : 4), RING = PD + 1;
+        float bw[RING][NACC];
+#pragma unroll
+        for (int s = 0; s < PD; s++)
+#pragma unroll
+            for (int a = 0; a < NACC; a++) bw[s][a] = wsf[(s * NACC + a) * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if (s + PD < S) {
+#pragma unroll
+                for (int a = 0; a < NACC; a++) bw[(s + PD) % RING][a] = wsf[((s + PD) * NACC + a) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float av = s < S / 2 ? xc[2 * s] : xc[2 * (s - S / 2) + 1];
+#pragma unroll
+            for (int a = 0; a < NACC; a++) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[s % RING][a], acc[a], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int a = 0; a < NACC; a++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) epi_slice(acc[a], a, j, rb, true);
     };
-    if (WAVES == 8 && (wave >> 2)) for (int i = 0; i < (dbg >> 8); i++) __builtin_amdgcn_s_sleep(64);   // (experiment: stagger the second wavefront of a SIMD)
-    if (PREF && nunits > 0) load_rows(unit_rb(0), xc);
-    for (int64_t t = 0; t < nunits; t++) {
-        const int64_t rb = unit_rb(t);
-        if constexpr (PREF) load_rows(unit_rb(t + 1 < nunits ? t + 1 : t), xn);      // unconditional; in flight during the MFMAs below
-        else load_rows(rb, xc);
+    int64_t t = 0;
+    for (; t < nfull; t++) {
+        load_rows(unit_rb(t + 1 < nunits ? t + 1 : t), xn);      // unconditional; in flight during the MFMAs below
         asm volatile("" ::: "memory");                           // the weights are re-read from LDS per block (hoisted out of this loop
                                                                  //  they would need S*NACC registers and spill)
-        TS();
         swap_rows();
-        TS();
-        if (t < nmain / nw) {
-            f32x16 acc[NACC];
+        main_block(unit_rb(t));
 #pragma unroll
-            for (int a = 0; a < NACC; a++)
+        for (int q = 0; q < XR; q++) xc[q] = xn[q];
+    }
+    for (; t < nunits; t++) {                                    // remainder: one (row block, column block) per unit
+        const int64_t rb = unit_rb(t);
+        load_rows(unit_rb(t + 1 < nunits ? t + 1 : t), xn);
+        asm volatile("" ::: "memory");
+        swap_rows();
+        const int a = (int)((slot + (t - nfull) * nw) / R);
+        f32x16 acc;
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[a][r] = 0.0f;
-            // the weight operands of step s + PD are read from LDS before the MFMAs of step s are issued (left alone, the
-            // compiler reads them right before their use and waits out the LDS latency between every two MFMAs)
-            constexpr int PD = NACC >= 4 ? 1 : (NACC >= 2 ? 2 : 4), RING = PD + 1;
-            float bw[RING][NACC];
-            if (!(dbg & 4)) {
-#pragma unroll
-            for (int s = 0; s < PD; s++)
-#pragma unroll
-                for (int a = 0; a < NACC; a++) bw[s][a] = wsf[(s * NACC + a) * 64 + lane];
-#pragma unroll
-            for (int s = 0; s < S; s++) {
-                if (s + PD < S) {
-#pragma unroll
-                    for (int a = 0; a < NACC; a++) bw[(s + PD) % RING][a] = wsf[((s + PD) * NACC + a) * 64 + lane];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const float av = s < S / 2 ? xc[2 * s] : xc[2 * (s - S / 2) + 1];
-#pragma unroll
-                for (int a = 0; a < NACC; a++) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[s % RING][a], acc[a], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            } else {
-#pragma unroll
-                for (int a = 0; a < NACC; a++) acc[a][0] = xc[a] + xc[63 - a];
-            }
-            TS();
-            const bool full = rb * 32 + 32 <= N;
-            if (!(dbg & 2)) {
-#pragma unroll
-            for (int a = 0; a < NACC; a++) store_block(acc[a], a, rb, full);
-            } else {
-                float sacc = 0.0f;
-#pragma unroll
-                for (int a = 0; a < NACC; a++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) sacc += acc[a][r];
-                if (sacc == 1.2345f) segs.y[0][0] = sacc;
-            }
-        } else {
-            const int a = (int)((slot + (t - nmain / nw) * nw) / R);
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-            const float *wa = wsf + a * 64 + lane;
+        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+        const float *wa = wsf + a * 64 + lane;
 #pragma unroll                                                    // (full: xc must stay in registers)
-            for (int s = 0; s < S; s++) {
-                const float av = s < S / 2 ? xc[2 * s] : xc[2 * (s - S / 2) + 1];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wa[s * NACC * 64], acc, 0, 0, 0);
-            }
-            store_block(acc, a, rb, false);
+        for (int s = 0; s < S; s++) {
+            const float av = s < S / 2 ? xc[2 * s] : xc[2 * (s - S / 2) + 1];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wa[s * NACC * 64], acc, 0, 0, 0);
         }
-        TS();
-        if constexpr (PREF) {
+        const int ld = segs.ld[a], av = segs.act[a];
+        const float bias = hasb ? b[a * 32 + li] : 0.0f;
 #pragma unroll
-            for (int q = 0; q < XR; q++) xc[q] = xn[q];
+        for (int r = 0; r < 16; r++) ot[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + li] = finish(acc[r], bias, av);
+        float *yb = segs.y[a] + rb * 32 * (int64_t)ld + 4 * (lane & 7);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int row = (lane >> 3) + 8 * u;
+            const float4 v = *reinterpret_cast<const float4 *>(ot + row * 32 + 4 * (lane & 7));
+            if (rb * 32 + row < N) *reinterpret_cast<float4 *>(yb + (int64_t)row * ld) = v;
         }
-        TS();
+#pragma unroll
+        for (int q = 0; q < XR; q++) xc[q] = xn[q];
     }
 }
 
@@ -807,27 +809,10 @@ int dgg_linear_fwd_multi(const float *x, int64_t N, int d, const float *Wcat, co
     if (d == 128 && aligned && cb <= 6 && (forced >= 0 ? forced != 0 : N >= 32768)) {
         const int64_t nrb = (N + 31) / 32;
         const unsigned grid = (unsigned)std::min<int64_t>(256, (nrb + 3) / 4);   // one workgroup per CU
-        static const int dbg = [] { const char *e = getenv("DGG_LINEAR_DBG"); return e ? atoi(e) : 0; }();
-        static const bool w8 = [] { const char *e = getenv("DGG_LINEAR_W8"); return e ? atoi(e) != 0 : false; }();
-        static long long *tsb = [] { long long *p = nullptr; if (getenv("DGG_LINEAR_TS")) { (void)hipMalloc(&p, 64 * 8); (void)hipMemset(p, 0, 64 * 8); } return p; }();
         switch (cb) {
-#define DGG_LIN_REG(NA) case NA:                                                                                            \
-    if (w8) hipLaunchKernelGGL((linear_fwd_reg<128, NA, 8>), dim3(grid), dim3(512), 0, st, x, N, Wcat, bcat, segs, nrb, dbg, tsb);       \
-    else hipLaunchKernelGGL((linear_fwd_reg<128, NA, 4>), dim3(grid), dim3(256), 0, st, x, N, Wcat, bcat, segs, nrb, dbg, tsb);          \
-    break
+#define DGG_LIN_REG(NA) case NA: hipLaunchKernelGGL((linear_fwd_reg<128, NA>), dim3(grid), dim3(256), 0, st, x, N, Wcat, bcat, segs, nrb); break
             DGG_LIN_REG(1); DGG_LIN_REG(2); DGG_LIN_REG(3); DGG_LIN_REG(4); DGG_LIN_REG(5); DGG_LIN_REG(6);
 #undef DGG_LIN_REG
-        }
-        if (tsb) {
-            static int calls = 0;
-            if (++calls == 8) {
-                long long h[64];
-                (void)hipDeviceSynchronize();
-                (void)hipMemcpy(h, tsb, sizeof(h), hipMemcpyDeviceToHost);
-                fprintf(stderr, "TS (10 ns ticks since first):");
-                for (int i = 1; i < 60 && h[i]; i++) fprintf(stderr, " %lld", h[i] - h[0]);
-                fprintf(stderr, "\n");
-            }
         }
         return dgg_check_launch("linear_fwd_multi");
     }
