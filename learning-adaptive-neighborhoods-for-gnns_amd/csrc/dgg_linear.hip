@@ -626,6 +626,113 @@ __global__ __launch_bounds__(256) void gemm_tn_multi(TnSegs segs, const float *B
     if (hh == 0) cs_slab[(int64_t)g * M1tp + yb * 32 + li] = t;
 }
 
+// gemm_tn_multi for the shape of the hot path (B = the layer input, exactly 128 wide; every A operand a multiple of 64 wide):
+// a wavefront owns 64 columns of A x all 128 columns of B (eight accumulators) and reads its operands with ONE 8-byte load
+// (A, and the activation mask's Y) and ONE 16-byte load (B) per two rows -- 2-3 load instructions per 8 MFMAs where
+// gemm_tn_multi issues 5-6 per 4, and B is re-read per 64 instead of per 32 columns of A.  That needs lane l to hold columns
+// (2l, 2l+1) of A and (4l .. 4l+3) of B, i.e. accumulator (m, a) holds output rows 2i+m and columns 4j+a: a permutation that is
+// undone when the partial result is written (16-byte stores).  Loads run PF row pairs ahead in a ring that is refilled slot
+// by slot (every slot's next load is issued right after its MFMAs).  Partial results and reduce as gemm_tn_multi.
+template <int PF, bool ACT>
+__device__ __forceinline__ void tn_wide_stream(const float *__restrict__ A, const float *__restrict__ Yact, int act, const float *__restrict__ B,
+                                               int64_t N, int M1, int acol, int li, int hh, int64_t base, int64_t stride,
+                                               f32x16 (&acc)[2][4], float (&csum)[2]) {
+    float2 av[PF], yv[PF];
+    float4 bv[PF];
+    auto load = [&](int u, int64_t b0) {
+        const int64_t n = b0 + 2 * u + hh, nc = n < N ? n : N - 1;          // unconditional, clamped
+        av[u] = *reinterpret_cast<const float2 *>(A + nc * M1 + acol);
+        if (ACT) yv[u] = *reinterpret_cast<const float2 *>(Yact + nc * M1 + acol);
+        bv[u] = *reinterpret_cast<const float4 *>(B + nc * 128 + 4 * li);
+    };
+#pragma unroll
+    for (int u = 0; u < PF; u++) load(u, base);
+    for (; base < N; base += stride) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const float rm = base + 2 * u + hh < N ? 1.0f : 0.0f;
+            float m0 = rm, m1 = rm;
+            if (ACT) {
+                if (act == 1) { m0 = yv[u].x > 0.0f ? rm : 0.01f * rm; m1 = yv[u].y > 0.0f ? rm : 0.01f * rm; }
+                else { m0 = yv[u].x > 0.0f ? rm : 0.0f; m1 = yv[u].y > 0.0f ? rm : 0.0f; }
+            }
+            const float a0 = av[u].x * m0, a1 = av[u].y * m1;
+            const float4 b = bv[u];
+            load(u, base + stride);                              // this slot's next row pair: in flight for PF steps
+            csum[0] += a0; csum[1] += a1;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.y, acc[0][1], 0, 0, 0);
+            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.z, acc[0][2], 0, 0, 0);
+            acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.w, acc[0][3], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y, acc[1][1], 0, 0, 0);
+            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.z, acc[1][2], 0, 0, 0);
+            acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.w, acc[1][3], 0, 0, 0);
+        }
+    }
+}
+
+template <int PF>
+__global__ __launch_bounds__(256, 2) void gemm_tn_wide(TnSegs segs, const float *__restrict__ B, int64_t N, int G,
+                                                       float *__restrict__ slab, float *__restrict__ cs_slab) {
+    extern __shared__ float red[];                               // [8*16*64] + [2*64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, hh = lane >> 5;
+    const int npair = segs.nyb / 2;
+    const int bid = blockIdx.x, tt = bid / (8 * npair), rem = bid % (8 * npair);
+    const int yb = 2 * (rem / 8), g = tt * 8 + (rem % 8);         // the pair blocks of one row stream stay on one XCD (see gemm_tn_multi)
+    if (g >= G) return;
+    const float *__restrict__ A = segs.A[yb];
+    const float *__restrict__ Yact = segs.Y[yb];
+    const int M1 = segs.ld[yb], act = Yact ? segs.act[yb] : 0, acol = segs.o0[yb] + 2 * li;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][a][r] = 0.0f;
+    float csum[2] = {0.0f, 0.0f};
+    const int64_t base = ((int64_t)g * 4 + wave) * 2 * PF, stride = (int64_t)G * 4 * 2 * PF;
+    if (act != 0) tn_wide_stream<PF, true>(A, Yact, act, B, N, M1, acol, li, hh, base, stride, acc, csum);
+    else tn_wide_stream<PF, false>(A, Yact, act, B, N, M1, acol, li, hh, base, stride, acc, csum);
+    float *cred = red + 8 * 16 * 64;
+    for (int w = 1; w < 4; w++) {
+        if (wave == w) {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) red[(q * 16 + r) * 64 + lane] = acc[q >> 2][q & 3][r];
+            cred[lane] = csum[0];
+            cred[64 + lane] = csum[1];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[q >> 2][q & 3][r] += red[(q * 16 + r) * 64 + lane];
+            csum[0] += cred[lane];
+            csum[1] += cred[64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+    const int M1tp = segs.nyb * 32;
+    float *sl = slab + ((int64_t)g * M1tp + yb * 32) * 128 + 4 * li;
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int go = (r & 3) + 8 * (r >> 2) + 4 * hh;      // accumulator row -> column 2*go + m of this A pair block
+            *reinterpret_cast<float4 *>(sl + (int64_t)(2 * go + m) * 128) = make_float4(acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]);
+        }
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const float t = csum[m] + __uint_as_float(dgg::xor_shfl<32>(__float_as_uint(csum[m]), lane));
+        if (hh == 0) cs_slab[(int64_t)g * M1tp + yb * 32 + 2 * li + m] = t;
+    }
+}
+
 // all segments of a gemm_tn_multi / gemm_tn_pairs slab in ONE launch (blockIdx.z = segment)
 struct RedSegs {
     float *C[8];
@@ -873,7 +980,7 @@ int dgg_act_bwd(const float *y, const float *dy, int64_t n, int act, float *dp, 
 // ws: dgg_gemm_tn_multi_ws_floats(N, total M1, M2) floats.
 size_t dgg_gemm_tn_multi_ws_floats(int64_t N, int M1_total, int M2) {
     const size_t M2p = (size_t)(M2 + 31) / 32 * 32;
-    return (size_t)128 * ((size_t)M1_total * M2p + (size_t)M1_total);
+    return (size_t)256 * ((size_t)M1_total * M2p + (size_t)M1_total);     // up to 256 row streams
 }
 int dgg_gemm_tn_multi(int nseg, const float *const *A, const int *M1, const float *const *Y, const int *act, const float *B, int64_t N,
                       int M2, float *const *C, const int *c_layout, float *const *colsum, float *ws, void *stream) {
@@ -900,11 +1007,29 @@ int dgg_gemm_tn_multi(int nseg, const float *const *A, const int *M1, const floa
     int G = 128;                                                 // row streams (a multiple of 8): G * nyb workgroups
     const int64_t need = (N + 4 * 2 * PF - 1) / (4 * 2 * PF);
     while (G > 8 && G / 2 >= need) G /= 2;
+    // the hot-path shape (128-wide input, operands in multiples of 64 columns, 16-byte aligned rows): wide tiles
+    bool wide = M2 == 128 && N >= 4096 && reinterpret_cast<uintptr_t>(B) % 16 == 0;
+    for (int sgi = 0; sgi < nseg; sgi++)
+        wide = wide && M1[sgi] % 64 == 0 && reinterpret_cast<uintptr_t>(A[sgi]) % 8 == 0 && (!Y || !Y[sgi] || reinterpret_cast<uintptr_t>(Y[sgi]) % 8 == 0);
+    static const int force_wide = [] { const char *e = getenv("DGG_TN_WIDE"); return e ? atoi(e) : -1; }();
+    if (force_wide == 0) wide = false;
+    if (wide) {
+        constexpr int PFW = 6;
+        const int npair = yb / 2;
+        G = 512 / npair / 8 * 8;                                 // ~512 workgroups: two per CU (<= 256 registers); measured: 256 / 384 /
+                                                                 //  768 workgroups and prefetch depths 4..10 are equal or slower
+        G = G > 256 ? 256 : G;
+        const int64_t needw = (N + 4 * 2 * PFW - 1) / (4 * 2 * PFW);
+        while (G > 8 && G - 8 >= needw) G -= 8;
+    }
     float *slab = ws, *cs_slab = ws + (size_t)G * M1tp * M2p;
     const unsigned grid = (unsigned)(G * yb);
     const int nb = M2p / 32 == 3 ? 4 : M2p / 32;
     const size_t lds = (size_t)(nb * 16 * 64 + 64) * sizeof(float);
-    if (nb == 4) hipLaunchKernelGGL((gemm_tn_multi<4, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);
+    const size_t ldsw = (size_t)(8 * 16 * 64 + 128) * sizeof(float);
+    const dim3 gridw((unsigned)(G * (yb / 2)));
+    if (wide) hipLaunchKernelGGL((gemm_tn_wide<6>), gridw, dim3(256), ldsw, st, segs, B, N, G, slab, cs_slab);
+    else if (nb == 4) hipLaunchKernelGGL((gemm_tn_multi<4, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);
     else if (nb == 2) hipLaunchKernelGGL((gemm_tn_multi<2, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);
     else hipLaunchKernelGGL((gemm_tn_multi<1, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);
     RedSegs rsg{};

@@ -156,7 +156,9 @@ def test_fused_projections_are_bit_identical_to_separate_calls(dev, N, d, outs):
         assert np.array_equal(Nn(y)[sel], xo)
 
 
-@pytest.mark.parametrize("N,d,outs", [(2100, 128, (64, 64, 64)), (700, 128, (64, 64)), (300, 40, (32, 64, 32)), (65, 128, (128, 128))])
+@pytest.mark.parametrize("N,d,outs", [(2100, 128, (64, 64, 64)), (700, 128, (64, 64)), (300, 40, (32, 64, 32)), (65, 128, (128, 128)),
+                                      # d = 128, widths in multiples of 64, N >= 4096: the wide-tile kernel (permuted operands, 16-byte loads)
+                                      (40_000, 128, (64, 64, 64)), (5_001, 128, (64, 128)), (100_003, 128, (64, 64)), (4_100, 128, (64,))])
 def test_fused_weight_gradients_match_separate_calls(dev, N, d, outs):
     """dgg_gemm_tn_multi == one dgg_linear_bwd (weight / bias gradient) per layer, up to summation order"""
     from dgg_amd import ops
