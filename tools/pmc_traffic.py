@@ -17,7 +17,7 @@ from collections import defaultdict
 # bench.py kernel key -> rocprof kernel-name substrings (several = one C-ABI call made of several launches: summed)
 NAMES = {"allpairs_topk": ["allpairs_topk_ranked"], "spmm_fwd": ["spmm_fwd_narrow"], "conv_bwd": ["conv_bwd_node"],
          "edge_bwd": ["edge_bwd_rows", "edge_bwd_node"], "edge_bwd_rows": ["edge_bwd_rows"], "edge_bwd_node": ["edge_bwd_node"],
-         "part_build": ["part_pass", "part_sort_p", "part_scan"], "linear_fwd": ["linear_fwd_mfma"], "gemm_tn_multi": ["gemm_tn_multi"],
+         "part_build": ["part_pass", "part_sort_p", "part_scan"], "linear_fwd": ["linear_fwd_mfma", "linear_fwd_reg"], "gemm_tn_multi": ["gemm_tn_multi", "gemm_tn_wide"],
          "knet_x_fwd": ["knet_x_fwd_tpn"], "knet_x_bwd": ["knet_x_bwd_tpn"], "softk_fwd": ["softk_fwd_kernel"],
          "normalize_fwd": ["normalize_fwd_kernel"]}
 
