@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
     constexpr int BM = 64 * AM;
     __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * LDS_STRIDE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), li = lane & 31, hh = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
     const int m0 = blockIdx.y * (64 * AM), n0 = blockIdx.x * BN;
     f32x16 acc[AM][2];

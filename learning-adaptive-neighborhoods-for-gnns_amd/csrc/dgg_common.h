@@ -15,6 +15,13 @@
 
 namespace dgg {
 
+// Index of this wavefront inside its workgroup, as a SCALAR: `threadIdx.x >> 6` is the same value in every lane, but the compiler
+// cannot know that, so everything derived from it (row index, row pointers) lives in vector registers and "wave-uniform" loads
+// become vector loads (the row's own 64 features of allpairs_topk_ranked: 64 registers and 16 vector loads per block; the kernel
+// went from 334 to 257 us with this one change).  readfirstlane makes the uniformity explicit.
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+
 __device__ __forceinline__ float f_from_bits(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t bits_from_f(float f) { return __float_as_uint(f); }
 

@@ -27,7 +27,7 @@ __device__ __forceinline__ float row_sum_strided(const float *__restrict__ v, in
 __global__ __launch_bounds__(WPB * 64) void csr_row_sum_kernel(const float *__restrict__ vals, const int64_t *__restrict__ rowptr,
                                                               int64_t N, float *__restrict__ rs) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const float s = row_sum_strided(vals, rowptr[i], rowptr[i + 1], lane);
     if (lane == 0) rs[i] = s;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(WPB * 64) void csr_normalize_kernel(const int64_t *
                                                                 const float *__restrict__ w, const float *__restrict__ rs,
                                                                 int64_t N, float *__restrict__ ahat) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const float ai = __fdiv_rn(1.0f, c_sqrt(rs[i]));
     for (int64_t e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64)
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(WPB * 64) void csr_spmm_fwd_kernel(const int64_t *_
                                                                const float *__restrict__ a, const float *__restrict__ X, int64_t N,
                                                                int F, float *__restrict__ Y) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const int c = blockIdx.y * 64 + lane;
     float acc = 0.0f;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(WPB * 64) void csr_spmm_bwd_kernel(const int64_t *_
                                                                const float *__restrict__ dY, int64_t N, int F,
                                                                float *__restrict__ dA, float *__restrict__ dX) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
         const int64_t j = col[e];
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(WPB * 64) void csr_norm_bwd_da_kernel(const int64_t
                                                                   const float *__restrict__ w, const float *__restrict__ rs,
                                                                   const float *__restrict__ dA, int64_t N, float *__restrict__ da) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const float ai = 1.0f / sqrtf(rs[i]);
     float rowpart = 0.0f;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(WPB * 64) void csr_norm_bwd_dw_kernel(const int64_t
                                                                   const float *__restrict__ rs, const float *__restrict__ dA,
                                                                   const float *__restrict__ da, int64_t N, float *__restrict__ dw) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const float ai = 1.0f / sqrtf(rs[i]);
     const float drs = -0.5f * da[i] * ai / rs[i];
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(WPB * 64) void csr_rank_ramp_fwd_kernel(const float
                                                                     float *__restrict__ out, float *__restrict__ S,
                                                                     float *__restrict__ k, int32_t *__restrict__ pos) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
     const float s = row_sum_strided(p, e0, e1, lane);
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(WPB * 64) void csr_rank_ramp_bwd_kernel(const float
                                                                     const float *__restrict__ g, float *__restrict__ dp,
                                                                     float *__restrict__ dkz) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
     const float ki = k[i], w = wb[0];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(WPB * 64) void csr_rank_cut_fwd_kernel(const float 
                                                                    const int32_t *__restrict__ col, int64_t N, int kcut,
                                                                    float *__restrict__ out, int32_t *__restrict__ pos) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
     for (int64_t mb = e0; mb < e1; mb += 64) {
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(WPB * 64) void csr_uvdist_fwd_kernel(const float *_
                                                                  const int32_t *__restrict__ col, int64_t N, int h, float t,
                                                                  float *__restrict__ p) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const float *xi = xp + i * h;
     for (int64_t e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64) {
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(WPB * 64) void csr_uvdist_bwd_kernel(const float *_
                                                                  const float *__restrict__ p, const float *__restrict__ dp,
                                                                  float *__restrict__ dxp) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const float *xi = xp + i * h;
     for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(WPB * 64) void csr_uvdist_bwd_kernel(const float *_
 __global__ __launch_bounds__(WPB * 64) void bg_softmax_fwd_kernel(const float *__restrict__ L, const int64_t *__restrict__ rowptr,
                                                                  int64_t N, float *__restrict__ att, float *__restrict__ bg) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
     const float nbg = (float)(N - (e1 - e0));
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(WPB * 64) void bg_softmax_bwd_kernel(const float *_
                                                                  const float *__restrict__ datt, const float *__restrict__ dbg,
                                                                  float *__restrict__ dL) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
     float s = 0.0f;

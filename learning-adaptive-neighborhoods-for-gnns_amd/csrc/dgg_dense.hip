@@ -46,7 +46,7 @@ __global__ __launch_bounds__(WPB * 64) void dense_rows_fwd_kernel(const float *_
                                                                  float interval, int hard, float *__restrict__ out,
                                                                  float *__restrict__ y, int32_t *__restrict__ pos) {
     extern __shared__ float lds[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = dgg::wave_id();
     float *ys = lds + (size_t)wv * N;
     int64_t bi = (int64_t)blockIdx.x * WPB + wv;
     const bool live = bi < rows;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(WPB * 64) void dense_rows_bwd_kernel(const float *_
                                                                  const float *__restrict__ g, float *__restrict__ Cm,
                                                                  float *__restrict__ dk, float *__restrict__ dt_rows) {
     const int lane = threadIdx.x & 63;
-    const int64_t bi = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t bi = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (bi >= rows) return;
     const float *X = xq + (bi / N) * N * h, *xi = xq + bi * h;
     const float *yr = y + bi * N, *gr = g + bi * N;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(WPB * 64) void dense_rows_bwd_kernel(const float *_
 __global__ __launch_bounds__(WPB * 64) void dense_pairs_dx_kernel(const float *__restrict__ xq, int64_t rows, int64_t N, int h,
                                                                  const float *__restrict__ Cm, float *__restrict__ dxq) {
     extern __shared__ float lds[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = dgg::wave_id();
     float *cf = lds + (size_t)wv * N;
     int64_t bi = (int64_t)blockIdx.x * WPB + wv;
     const bool live = bi < rows;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(WPB * 64) void dense_pairs_dx_kernel(const float *_
 __global__ __launch_bounds__(WPB * 64) void feat_softmax_fwd_kernel(const float *__restrict__ z, int64_t rows, int h,
                                                                    float *__restrict__ out) {
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t r = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (r >= rows) return;
     const float *zr = z + r * h;
     float *o = out + r * h;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(WPB * 64) void feat_softmax_fwd_kernel(const float 
 __global__ __launch_bounds__(WPB * 64) void feat_softmax_bwd_kernel(const float *__restrict__ out, const float *__restrict__ g,
                                                                    int64_t rows, int h, float *__restrict__ dz) {
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t r = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (r >= rows) return;
     float S = 0.0f;
     for (int c = lane; c < h; c += 64) S += out[r * h + c] * g[r * h + c];

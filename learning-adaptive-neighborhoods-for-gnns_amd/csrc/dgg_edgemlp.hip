@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void edgelist_topk_p_kernel(
     int noise_mode, const float *__restrict__ G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *__restrict__ idx,
     float *__restrict__ val, int32_t *__restrict__ eid) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * 4 + dgg::wave_id();
     if (i >= N) return;
     const bool sym = noise_mode == 3;
     uint64_t list = DGG_EMPTY_KEY;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
     float *__restrict__ dex) {
     extern __shared__ float red[];                               // [4 waves][5*hw + 1]
     const int LPE = hw / VEC, EPI = 64 / LPE;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane % LPE, slot = lane / LPE;
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id(), c = lane % LPE, slot = lane / LPE;
     const int o0 = c * VEC;
     float wdu_r[VEC], wdv_r[VEC], wex_r[VEC], b1_r[VEC], w2_r[VEC];
 #pragma unroll

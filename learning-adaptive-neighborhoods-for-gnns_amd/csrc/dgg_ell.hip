@@ -24,7 +24,7 @@ __global__ __launch_bounds__(WPB * 64) void softk_fwd_kernel(const int32_t *__re
                                                             const float *__restrict__ k, int64_t N, int K, int mode,
                                                             float *__restrict__ w, float *__restrict__ rs) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     float wv = 0.0f;
     if (lane < K) {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(WPB * 64) void spmm_fwd_kernel(const int32_t *__res
                                                            const float *__restrict__ X, int64_t N, int K, int F,
                                                            float *__restrict__ Y) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const int c0 = (blockIdx.y * 64 + lane) * VEC;
     int32_t jl = lane < K ? idx[i * K + lane] : -1;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(WPB * 64) void spmm_fwd_narrow(const int32_t *__res
                                                            float *__restrict__ Y) {
     constexpr int LPR = F / 4, NPI = 64 / LPR, NBT = 4;
     const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const int32_t jl = lane < K ? idx[i * K + lane] : -1;
     const float al = lane < K ? ahat[i * K + lane] : 0.0f;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(WPB * 64) void spmm_bwd_kernel(const int32_t *__res
                                                            int64_t N, int K, int F, int skip_zero,
                                                            float *__restrict__ dA, float *__restrict__ dX) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     int32_t jl = lane < K ? idx[i * K + lane] : -1;
     float al = lane < K ? ahat[i * K + lane] : 0.0f;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(WPB * 64) void sddmm_wide_kernel(const int32_t *__r
                                                              const float *__restrict__ X, const float *__restrict__ dY,
                                                              int64_t N, int K, int F, int skip_zero, float *__restrict__ dA) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const int32_t jl = lane < K ? idx[i * K + lane] : -1;
     const float al = lane < K ? ahat[i * K + lane] : 0.0f;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(WPB * 64) void sddmm_pair_kernel(const int32_t *__r
                                                              float *__restrict__ coef, float *__restrict__ da) {
     constexpr int F = 128 * NV4;
     const int lane = threadIdx.x & 63, sub = lane & 31, hh = lane >> 5;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     int32_t jl = lane < K ? idx[i * K + lane] : -1;
     float al = lane < K ? ahat[i * K + lane] : 0.0f;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(WPB * 64) void norm_bwd_da_kernel(const int32_t *__
                                                               const float *__restrict__ rs, const float *__restrict__ dA,
                                                               int64_t N, int K, int64_t row0, float *__restrict__ da) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     float rowpart = 0.0f;
     if (lane < K) {
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(WPB * 64) void softk_bwd_kernel(const int32_t *__re
                                                             int64_t N, int K, int64_t row0, int mode, int normalized,
                                                             float *__restrict__ dval, float *__restrict__ dk) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     float skp = 0.0f;
     {
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(WPB * 64) void edge_bwd_kernel(const float *__restr
                                                            const float *__restrict__ dval, int K, int64_t row0, float t,
                                                            int perturb, float *__restrict__ dxp) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const int64_t gi = row0 + i;
     int32_t jl = lane < K ? idx[i * K + lane] : -1;
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(WPB * 64) void edge_bwd_wide_kernel(const float *__
                                                                 const float *__restrict__ dval, int K, int64_t row0, float t,
                                                                 int perturb, float *__restrict__ dxp) {
     // ONE WORKGROUP PER ROW (small graphs, wide latents): the row's entries are dealt to the four wavefronts in groups of EQ
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id();
     const int64_t i = blockIdx.x;
     const int64_t gi = row0 + i;
     const float *xi = xp + gi * h;

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(WPB * 64) void knet_x_fwd_kernel(
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const float mu = mu_sd[0], sd = mu_sd[1];
-    for (int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); i < N; i += (int64_t)gridDim.x * WPB) {
+    for (int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id(); i < N; i += (int64_t)gridDim.x * WPB) {
         float nd = __fdiv_rn(__fadd_rn(deg[i], -mu), __fadd_rn(sd, 1e-5f));
         float x0 = lane < h ? xk[i * h + lane] : 0.0f;
         float x1 = lane + 64 < h ? xk[i * h + lane + 64] : 0.0f;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(WPB * 64) void knet_x_bwd_kernel(
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const float sd = mu_sd[1];
-    for (int64_t i = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); i < N; i += (int64_t)gridDim.x * WPB) {
+    for (int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id(); i < N; i += (int64_t)gridDim.x * WPB) {
         float dkp = u[i] > 0.0f ? dk[i] * sd : 0.0f;
         float zl = lane < h2 ? z[i * h2 + lane] : 0.0f;
         // recompute m (needed by the k_project weight gradient)

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64 * WAVES, NACC <= 2 ? 4 : 2) void linear_fwd_mfma
     constexpr int BK = LIN_BK(NACC), LDP = BK + 1, F4R = BK / 4;
     __shared__ float xs[BM * LDP];
     __shared__ float ws[BN * LDP];   // [j][k] (+pad)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id();
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     f32x16 acc[NACC];
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void linear_fwd_reg(const float *__restrict
     constexpr int S = D / 2, XR = D / 2;                         // MFMA steps per output; operand registers per lane
     __shared__ float wsf[S * NACC * 64];                         // [step][column block][lane]
     __shared__ __attribute__((aligned(16))) float obuf[4 * 1024];   // output tile of each wavefront
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), li = lane & 31, hh = lane >> 5;
     const int64_t nw = (int64_t)gridDim.x * 4, slot = (int64_t)blockIdx.x * 4 + wave;
     const int64_t nrbf = N / 32;                                 // FULL row blocks (a partial last block is a remainder unit)
     const int64_t nmain = nrbf - nrbf % nw, nfull = nmain / nw;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void gemm_tn_persist(const float *__restrict__
                                                        int M1, int M2, int M1p, int M2p, float *__restrict__ slab,
                                                        float *__restrict__ cs_slab, const float *__restrict__ Yact, int act) {
     extern __shared__ float red[];                               // [MB*NB*16*64] + [MB*32]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, hh = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id(), li = lane & 31, hh = lane >> 5;
     const int o0 = blockIdx.y * 32 * MB, c0 = blockIdx.z * 32 * NB;
     // Loads are UNCONDITIONAL (clamped addresses) so that the compiler can keep two batches in flight (a predicated load
     // forces s_waitcnt vmcnt(0)): columns beyond M1 / M2 land in padded slab rows / columns that the reduce ignores;
@@ -527,7 +527,7 @@ template <int NB, int PF>
 __global__ __launch_bounds__(256) void gemm_tn_multi(TnSegs segs, const float *B, int64_t N, int M2, int M2p, int G,
                                                      float *__restrict__ slab, float *__restrict__ cs_slab) {
     extern __shared__ float red[];                               // [NB*16*64] + [64]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, hh = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id(), li = lane & 31, hh = lane >> 5;
     const int nyb = segs.nyb;
     const int bid = blockIdx.x, tt = bid / (8 * nyb), rem = bid % (8 * nyb);
     const int yb = rem / 8, g = tt * 8 + (rem % 8);
@@ -676,7 +676,7 @@ template <int PF>
 __global__ __launch_bounds__(256, 2) void gemm_tn_wide(TnSegs segs, const float *__restrict__ B, int64_t N, int G,
                                                        float *__restrict__ slab, float *__restrict__ cs_slab) {
     extern __shared__ float red[];                               // [8*16*64] + [2*64]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, hh = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id(), li = lane & 31, hh = lane >> 5;
     const int npair = segs.nyb / 2;
     const int bid = blockIdx.x, tt = bid / (8 * npair), rem = bid % (8 * npair);
     const int yb = 2 * (rem / 8), g = tt * 8 + (rem % 8);         // the pair blocks of one row stream stay on one XCD (see gemm_tn_multi)

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void part_pass(const int32_t *__restrict__ idx
                                                  const float *__restrict__ rs_all = nullptr, float *__restrict__ ahat_out = nullptr) {
     extern __shared__ int lds[];                                 // hist[nb] (+ base[nb] when filling)
     int *hist = lds, *base = lds + nb;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id();
     for (int b = tid; b < nb; b += 256) hist[b] = 0;
     __syncthreads();
     const int64_t r0 = (int64_t)blockIdx.x * PR + wave * 64;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
     constexpr int LPR = H / 4;                                   // lanes per neighbour
     constexpr int NPI = 64 / LPR;                                // neighbours per wave-instruction
     const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * 4 + dgg::wave_id();
     if (i >= rows) return;
     const int64_t gi = row0 + i;
     const int32_t jl = lane < K ? idx[i * K + lane] : -1;
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(256) void conv_bwd_node(const float *__restrict__ G
                                                      float *__restrict__ dH, float *__restrict__ da) {
     constexpr int LPR = F / 4, NPI = 64 / LPR, NBT = 4, PER = NBT * NPI;          // PER records per iteration (<= 64)
     const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
-    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t j = (int64_t)blockIdx.x * 4 + dgg::wave_id();
     if (j >= ncols) return;
     const int p0 = nodeptr[j], p1 = nodeptr[j + 1];
     const float4 hj = *reinterpret_cast<const float4 *>(Hm + j * F + 4 * c4);
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(256) void edge_bwd_node(const float *__restrict__ x
                                                      int64_t row0, int64_t rows, float t, int perturb, float *__restrict__ dxp) {
     constexpr int LPR = H / 4, NPI = 64 / LPR, NBT = 4, PER = NBT * NPI;
     const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
-    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t j = (int64_t)blockIdx.x * 4 + dgg::wave_id();
     if (j >= ncols) return;
     const int p0 = nodeptr[j], p1 = nodeptr[j + 1];
     const float4 xj = *reinterpret_cast<const float4 *>(xp + j * H + 4 * c4);
@@ -928,7 +928,7 @@ __global__ __launch_bounds__(256) void conv_bwd_nodeg(const float *__restrict__ 
                                                       float *__restrict__ dH, float *__restrict__ da) {
     constexpr int LPR = F / 4, NPW = 64 / LPR;
     const int lane = threadIdx.x & 63, c4 = lane % LPR;
-    const int64_t jraw = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * NPW + lane / LPR;
+    const int64_t jraw = ((int64_t)blockIdx.x * 4 + dgg::wave_id()) * NPW + lane / LPR;
     const bool live = jraw < ncols;
     const int64_t j = live ? jraw : ncols - 1;                    // a group past the end shadows the last node and stores nothing
     const int p0 = nodeptr[j], p1 = live ? nodeptr[j + 1] : p0;
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(256) void edge_bwd_nodeg(const float *__restrict__ 
     constexpr int LPR = H / 4, NPW = 64 / LPR;
     static_assert(NBT <= LPR, "one lane of the group per record of a batch");
     const int lane = threadIdx.x & 63, c4 = lane % LPR, gbase = lane - c4;
-    const int64_t jraw = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * NPW + lane / LPR;
+    const int64_t jraw = ((int64_t)blockIdx.x * 4 + dgg::wave_id()) * NPW + lane / LPR;
     const bool live = jraw < ncols;
     const int64_t j = live ? jraw : ncols - 1;
     const int p0 = nodeptr[j], p1 = live ? nodeptr[j + 1] : p0;
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(256) void norm_da_rows(const int32_t *__restrict__ 
                                                     int K, int64_t row0, const int *__restrict__ slotmap,
                                                     float *__restrict__ coef, float *__restrict__ da) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * 4 + dgg::wave_id();
     if (i >= rows) return;
     float rowpart = 0.0f, cf = 0.0f;
     if (lane < K) {

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(WAVES * 64) void allpairs_topk_exhaustive(
     int32_t *__restrict__ idx, float *__restrict__ val) {
     __shared__ float colT[H * TN];
     __shared__ float rowsL[RB * H];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id();
     const int64_t rbase = row0 + (int64_t)blockIdx.x * RB;
 
     for (int e = tid; e < RB * H; e += WAVES * 64) {
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void edgelist_topk_kernel(
     const int32_t *__restrict__ col, float t, int noise_mode, const float *__restrict__ G, int64_t ldG,
     uint32_t s0, uint32_t s1, int K, int32_t *__restrict__ idx, float *__restrict__ val) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + dgg::wave_id();
     if (i >= N) return;
     const bool perturb = noise_mode != 0, sym = noise_mode == 3;
     const float *xi = xp + i * h;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void edgelist_topk_wide_kernel(
     // leaves the squared distances in LDS; wavefront 0 turns them into scores and merges.  The arithmetic per pair is the
     // canonical one (64 interleaved fmaf chains + butterfly): same bits as before.
     __shared__ float d2s[64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id();
     const int64_t i = blockIdx.x;
     const bool perturb = noise_mode != 0, sym = noise_mode == 3;
     const float *xi = xp + i * h;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void edgelist_topk_wide_kernel(
 __global__ __launch_bounds__(256) void select_scores_kernel(const float *__restrict__ scores, int64_t R, int64_t N,
                                                             int K, int32_t *__restrict__ idx, float *__restrict__ val) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + dgg::wave_id();
     if (i >= R) return;
     uint64_t list = DGG_EMPTY_KEY, thr = DGG_EMPTY_KEY;
     for (int64_t j0 = 0; j0 < N; j0 += 64) {

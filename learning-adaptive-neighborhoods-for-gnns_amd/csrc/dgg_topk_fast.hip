@@ -62,7 +62,7 @@ constexpr float EPS_BF16 = 0.0040f;   // 2^-8 (1 + 2^-9) bf16 rounding of both o
 __global__ __launch_bounds__(256) void prep_kernel(const float *__restrict__ xp, int64_t N, int h,
                                                    __bf16 *__restrict__ xb, float *__restrict__ nb) {
     const int lane = threadIdx.x & 63;
-    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t j = (int64_t)blockIdx.x * 4 + dgg::wave_id();
     if (j >= N) return;
     float s = 0.0f;
     for (int c = lane; c < h; c += 64) {
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void np_sweep(const __bf16 *__restrict__ xb, c
     __shared__ __attribute__((aligned(16))) unsigned char colA[2][NPC * STRIDE];
     __shared__ __attribute__((aligned(16))) float nbt[2][NPC];
     __shared__ int cnt[128];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), r = lane & 31, hh = lane >> 5;
     const int lr = wave * 32 + r;                                    // row of this lane inside the workgroup
     const int64_t i = row0 + (int64_t)blockIdx.x * 128 + lr;
     const bool rvalid = i < row1;
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void fast_finalize(const float *__restrict__ x
                                                      const float *__restrict__ cand_guess, FastCtl *__restrict__ ctl,
                                                      int *__restrict__ faillist, int32_t *__restrict__ idx, float *__restrict__ val) {
     const int lane = threadIdx.x & 63;
-    const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
     const int64_t i = row0 + lrow;
     if (i >= row1) return;
     const int n = cand_cnt[lrow];
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256) void topk_fast_fallback(const float *__restric
                                                          const FastCtl *__restrict__ ctl, const int *__restrict__ faillist,
                                                          int32_t *__restrict__ idx, float *__restrict__ val) {
     __shared__ uint64_t lists[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id();
     const int nfail = ctl->nfail;
     for (int f = blockIdx.x; f < nfail; f += gridDim.x) {
         const int lrow = faillist[f];

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void gv_finalize(const float *__restrict__ xp,
                                                    int *__restrict__ faillist, int32_t *__restrict__ idx,
                                                    float *__restrict__ val) {
     const int lane = threadIdx.x & 63;
-    const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
     const int64_t i = row0 + lrow;
     if (i >= row1) return;
     // the row's candidates sit in NSEG segment lists; view them as one concatenated list of n entries
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void gv_fallback(const float *__restrict__ xp,
                                                   const int *__restrict__ faillist, int32_t *__restrict__ idx,
                                                   float *__restrict__ val) {
     __shared__ uint64_t lists[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id();
     const int nfail = ctl->nfail;
     for (int f = blockIdx.x; f < nfail; f += gridDim.x) {
         const int lrow = faillist[f];

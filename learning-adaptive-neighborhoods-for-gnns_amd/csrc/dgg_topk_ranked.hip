@@ -35,7 +35,9 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
                                                             float *__restrict__ val, int softk_mode, float *__restrict__ w_out,
                                                             float *__restrict__ rs_out) {
     const int lane = threadIdx.x & 63;
-    const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // (readfirstlane: the compiler cannot know that dgg::wave_id() is wave-uniform; without it the row's own features are
+    //  fetched with VECTOR loads into 64 registers instead of scalar loads)
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
     const int64_t i = row0 + lrow;
     if (i >= row1) return;
     // ranks beyond L cannot receive weight (klimit_len): the search only has to settle the first L of the list
@@ -62,7 +64,10 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
         uint64_t key = DGG_EMPTY_KEY;
         // per-candidate version of the stop test: a rank whose noise cannot reach the L-th log-score found so far is
         // not gathered at all (ranks come in decreasing noise order, so these are the tail lanes of the block)
-        if (valid && !(G + 1e-8f + 1e-3f < thr_log)) {
+        const bool want = valid && !(G + 1e-8f + 1e-3f < thr_log);
+        // (Measured and rejected: staging the candidate rows through LDS so that 8 lanes read one 128-byte line -- 8x fewer L1 tag
+        //  lookups, same bits -- costs two LDS round trips per block: 658 us against 257.)
+        if (want) {
             const float4 *xj = reinterpret_cast<const float4 *>(xp + (int64_t)c * H);
             float d2 = 0.0f;
             auto chain = [&](int c8) {
