@@ -300,30 +300,28 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
     const float4 xi = *reinterpret_cast<const float4 *>(xp + gi * H + 4 * c4);
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float mycoef = 0.0f;
-    constexpr int NBT = 2;                                       // batches (gathers in flight per lane) per iteration; 4 measured the same
-    // NBT batches of NPI neighbours per iteration, all gathers issued UNCONDITIONALLY (inactive slots re-read the own row and
-    // are masked arithmetically) before either is consumed: a predicated gather is a branch + s_waitcnt vmcnt(0), i.e. one
-    // gather in flight per wavefront.
+    // Per iteration: NBT batches of NPI neighbours, all gathers issued UNCONDITIONALLY (inactive slots re-read the own row and
+    // are masked arithmetically) before any is consumed: a predicated gather is a branch + s_waitcnt vmcnt(0), i.e. one gather
+    // in flight per wavefront.  Three passes over the batch registers: (1) squared distances, each handed to the lane that OWNS
+    // the entry (lane r = entry r: it already holds the entry's cotangent and score); (2) the scalar chain sqrt / exp / two
+    // divisions ONCE per entry -- evaluated per batch it ran on all H/4 lanes of a neighbour, 16 times per row, and made this
+    // kernel VALU-bound (435 VALU instructions per 8 entries, 200 us); (3) the coefficient goes back to the neighbour's lanes.
+    // Same operations per entry and the same accumulation order: identical bits.
+    constexpr int NBT = (32 / NPI) < 1 ? 1 : 32 / NPI;           // 32 entries per iteration (two iterations for K = 64)
+    const bool myact = lane < K && jl >= 0 && gl != 0.0f;
     for (int r0 = 0; r0 < K; r0 += NBT * NPI) {
-        int32_t j[NBT];
-        float g[NBT], v[NBT];
-        bool act[NBT];
+        const bool mine = lane >= r0 && lane < r0 + NBT * NPI;
+        if (__ballot(mine && myact) == 0ull) continue;           // wave-uniform: no active entry in this group
+        float4 xj[NBT];
 #pragma unroll
         for (int b = 0; b < NBT; b++) {
             const int r = r0 + b * NPI + slot;
             const int rr = r < 64 ? r : 63;
-            j[b] = __shfl(jl, rr, 64);
-            g[b] = __shfl(gl, rr, 64);
-            v[b] = __shfl(vl, rr, 64);
-            act[b] = r < K && j[b] >= 0 && g[b] != 0.0f;
+            const int32_t jb = __shfl(jl, rr, 64);
+            const bool ab = __shfl((int)myact, rr, 64) != 0 && r < K;
+            xj[b] = *reinterpret_cast<const float4 *>(xp + (ab ? (int64_t)jb : gi) * H + 4 * c4);
         }
-        bool any = false;
-#pragma unroll
-        for (int b = 0; b < NBT; b++) any = any || act[b];
-        if (__ballot(any) == 0ull) continue;        // wave-uniform
-        float4 xj[NBT];
-#pragma unroll
-        for (int b = 0; b < NBT; b++) xj[b] = *reinterpret_cast<const float4 *>(xp + (act[b] ? (int64_t)j[b] : gi) * H + 4 * c4);
+        float myd2 = 0.0f;
 #pragma unroll
         for (int b = 0; b < NBT; b++) {
             const float4 d = make_float4(xi.x - xj[b].x, xi.y - xj[b].y, xi.z - xj[b].z, xi.w - xj[b].w);   // 0 when inactive
@@ -333,22 +331,24 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
             if (LPR > 4) d2 += __uint_as_float(xor_shfl<4>(__float_as_uint(d2), lane));
             if (LPR > 2) d2 += __uint_as_float(xor_shfl<2>(__float_as_uint(d2), lane));
             d2 += __uint_as_float(xor_shfl<1>(__float_as_uint(d2), lane));
-            float dd = 0.0f;
-            if (act[b] && d2 != 0.0f) {                          // vector_norm backward at 0 is 0 (self loop)
-                const float dist = sqrtf(d2);
-                const float p = c_exp(t * dist);
-                const float dp = perturb ? g[b] * v[b] / (p + 1e-8f) : g[b];
-                dd = dp * t * p / dist;
-            }
-            acc.x += dd * d.x; acc.y += dd * d.y; acc.z += dd * d.z; acc.w += dd * d.w;
-            if (!PAY) {
-                // hand the coefficient to the lane that owns entry r (lane r): gather from the first lane of each slot
+            // entry r0 + b*NPI + s was reduced by slot s: its owner lane fetches it from that slot's first lane
+            const float tq = __shfl(d2, (lane % NPI) * LPR, 64);
+            if ((lane - r0) / NPI == b && mine) myd2 = tq;
+        }
+        float mydd = 0.0f;
+        if (mine && myact && myd2 != 0.0f) {                     // vector_norm backward at 0 is 0 (self loop)
+            const float dist = sqrtf(myd2);
+            const float p = c_exp(t * dist);
+            const float dp = perturb ? gl * vl / (p + 1e-8f) : gl;
+            mydd = dp * t * p / dist;
+        }
+        if (!PAY && mine) mycoef = mydd;                         // lane r owns entry r
 #pragma unroll
-                for (int s2 = 0; s2 < NPI; s2++) {
-                    const float cs = bcast(dd, s2 * LPR);
-                    if (lane == r0 + b * NPI + s2) mycoef = cs;
-                }
-            }
+        for (int b = 0; b < NBT; b++) {
+            const int r = r0 + b * NPI + slot;
+            const float dd = __shfl(mydd, r < 64 ? r : 63, 64);  // (outside any select: see conv_bwd_node)
+            const float4 d = make_float4(xi.x - xj[b].x, xi.y - xj[b].y, xi.z - xj[b].z, xi.w - xj[b].w);
+            acc.x += dd * d.x; acc.y += dd * d.y; acc.z += dd * d.z; acc.w += dd * d.w;
         }
     }
     // sum the NPI neighbour slots (lanes with equal c4)
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(256) void edge_bwd_node(const float *__restrict__ x
                                                      const int4 *__restrict__ recs, const float *__restrict__ dA_rec,
                                                      const float4 *__restrict__ rowinfo, const float *__restrict__ rs, int normalized,
                                                      int64_t row0, int64_t rows, float t, int perturb, float *__restrict__ dxp) {
-    constexpr int LPR = H / 4, NPI = 64 / LPR, NBT = 4, PER = NBT * NPI;
+    constexpr int LPR = H / 4, NPI = 64 / LPR, NBT = (32 / NPI) < 1 ? 1 : 32 / NPI, PER = NBT * NPI;   // 32 records per iteration
     const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
     const int64_t j = (int64_t)blockIdx.x * 4 + dgg::wave_id();
     if (j >= ncols) return;
@@ -868,19 +868,18 @@ __global__ __launch_bounds__(256) void edge_bwd_node(const float *__restrict__ x
             const float th = c_tanh((float)(myrec.x & 63) - info.z);
             mydval = have ? dw * (1.0f - 0.5f * (1.0f + th)) : 0.0f;
         }
-        float gv[NBT], vv[NBT];
         float4 xi[NBT];
 #pragma unroll
         for (int b = 0; b < NBT; b++) {
             const int q = b * NPI + slot;
-            const int src = __shfl(myrec.x, q, 64);
+            const int src = __shfl(myrec.x, q, 64);             // every shuffle outside a select (see conv_bwd_node)
             const int dst = __shfl(myrec.y, q, 64);
-            const float gq = __shfl(mydval, q, 64);             // outside the select (see conv_bwd_node)
-            gv[b] = dst >= 0 ? gq : 0.0f;
-            vv[b] = __int_as_float(__shfl(myrec.w, q, 64));
             // unconditional gather; an inactive slot re-reads xp_j, whose distance to itself is 0 (dd = 0)
             xi[b] = *reinterpret_cast<const float4 *>(xp + (dst >= 0 ? row0 + (src >> 6) : j) * H + 4 * c4);
         }
+        // squared distances, each handed to the lane that loaded the record; the scalar chain (sqrt, exp, two divisions) then runs
+        // ONCE per record instead of on all H/4 lanes of every batch (the kernel was VALU-bound: 515 VALU per 16 records)
+        float myd2 = 0.0f;
 #pragma unroll
         for (int b = 0; b < NBT; b++) {
             const float4 d = make_float4(xi[b].x - xj.x, xi[b].y - xj.y, xi[b].z - xj.z, xi[b].w - xj.w);
@@ -890,13 +889,20 @@ __global__ __launch_bounds__(256) void edge_bwd_node(const float *__restrict__ x
             if (LPR > 4) d2 += __uint_as_float(xor_shfl<4>(__float_as_uint(d2), lane));
             d2 += __uint_as_float(xor_shfl<2>(__float_as_uint(d2), lane));
             d2 += __uint_as_float(xor_shfl<1>(__float_as_uint(d2), lane));
-            float dd = 0.0f;
-            if (gv[b] != 0.0f && d2 != 0.0f) {                   // vector_norm backward at 0 is 0 (self loop)
-                const float dist = sqrtf(d2);
-                const float p = c_exp(t * dist);
-                const float dp = perturb ? gv[b] * vv[b] / (p + 1e-8f) : gv[b];
-                dd = dp * t * p / dist;
-            }
+            const float tq = __shfl(d2, (lane % NPI) * LPR, 64);
+            if (lane / NPI == b) myd2 = tq;
+        }
+        float mydd = 0.0f;
+        if (mydval != 0.0f && myd2 != 0.0f) {                    // vector_norm backward at 0 is 0 (self loop)
+            const float dist = sqrtf(myd2);
+            const float p = c_exp(t * dist);
+            const float dp = perturb ? mydval * __int_as_float(myrec.w) / (p + 1e-8f) : mydval;
+            mydd = dp * t * p / dist;
+        }
+#pragma unroll
+        for (int b = 0; b < NBT; b++) {
+            const float dd = __shfl(mydd, b * NPI + slot, 64);
+            const float4 d = make_float4(xi[b].x - xj.x, xi[b].y - xj.y, xi[b].z - xj.z, xi[b].w - xj.w);
             acc.x -= dd * d.x; acc.y -= dd * d.y; acc.z -= dd * d.z; acc.w -= dd * d.w;
         }
     }
@@ -1006,16 +1012,16 @@ __global__ __launch_bounds__(256) void edge_bwd_nodeg(const float *__restrict__ 
             const float th = c_tanh((float)(myrec.x & 63) - info.z);
             mydval = mine ? dw * (1.0f - 0.5f * (1.0f + th)) : 0.0f;
         }
-        float gv[NBT], vv[NBT];
         float4 xi[NBT];
 #pragma unroll
         for (int b = 0; b < NBT; b++) {
             const int src = __shfl(myrec.x, gbase + b, 64);      // every shuffle outside a select (see conv_bwd_node)
-            gv[b] = __shfl(mydval, gbase + b, 64);
-            vv[b] = __int_as_float(__shfl(myrec.w, gbase + b, 64));
-            // unconditional gather; an inactive slot (gv == 0) reads xp_j, whose distance to itself is 0
+            // unconditional gather; an inactive slot reads xp_j, whose distance to itself is 0
             xi[b] = *reinterpret_cast<const float4 *>(xp + (e0 + b < p1 ? row0 + (src >> 6) : j) * H + 4 * c4);
         }
+        // lane c4 of the group owns record e0 + c4 % NBT: it takes that record's squared distance (every lane of the group holds
+        // all NBT of them after the reduction) and runs the scalar chain once
+        float myd2 = 0.0f;
 #pragma unroll
         for (int b = 0; b < NBT; b++) {
             const float4 d = make_float4(xi[b].x - xj.x, xi[b].y - xj.y, xi[b].z - xj.z, xi[b].w - xj.w);
@@ -1025,13 +1031,19 @@ __global__ __launch_bounds__(256) void edge_bwd_nodeg(const float *__restrict__ 
             if (LPR > 4) d2 += __uint_as_float(xor_shfl<4>(__float_as_uint(d2), lane));
             d2 += __uint_as_float(xor_shfl<2>(__float_as_uint(d2), lane));
             d2 += __uint_as_float(xor_shfl<1>(__float_as_uint(d2), lane));
-            float dd = 0.0f;
-            if (gv[b] != 0.0f && d2 != 0.0f) {
-                const float dist = sqrtf(d2);
-                const float p = c_exp(t * dist);
-                const float dp = perturb ? gv[b] * vv[b] / (p + 1e-8f) : gv[b];
-                dd = dp * t * p / dist;
-            }
+            if (c4 % NBT == b) myd2 = d2;
+        }
+        float mydd = 0.0f;
+        if (mydval != 0.0f && myd2 != 0.0f) {
+            const float dist = sqrtf(myd2);
+            const float p = c_exp(t * dist);
+            const float dp = perturb ? mydval * __int_as_float(myrec.w) / (p + 1e-8f) : mydval;
+            mydd = dp * t * p / dist;
+        }
+#pragma unroll
+        for (int b = 0; b < NBT; b++) {
+            const float dd = __shfl(mydd, gbase + b, 64);
+            const float4 d = make_float4(xi[b].x - xj.x, xi[b].y - xj.y, xi[b].z - xj.z, xi[b].w - xj.w);
             acc.x -= dd * d.x; acc.y -= dd * d.y; acc.z -= dd * d.z; acc.w -= dd * d.w;
         }
     }
