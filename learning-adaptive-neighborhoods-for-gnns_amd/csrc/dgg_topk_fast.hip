@@ -479,14 +479,13 @@ __global__ __launch_bounds__(64) void allpairs_topk_fast(
 // ONE compare of their minimum against the row's radius.  782 workgroups at N = 100k: three per CU.
 constexpr int NPC = 128;           // columns per staged tile
 template <int H>
-__global__ __launch_bounds__(256) void np_sweep(const __bf16 *__restrict__ xb, const float *__restrict__ nb, int64_t N, int64_t row0,
+__global__ __launch_bounds__(256, 4) void np_sweep(const __bf16 *__restrict__ xb, const float *__restrict__ nb, int64_t N, int64_t row0,
                                                 int64_t row1, float gscale, int2 *__restrict__ cand, int *__restrict__ cand_cnt,
                                                 float *__restrict__ cand_guess) {
     constexpr int KS = H / 16, STRIDE = H * 2 + 16, CPT = H / 8;     // 16-byte chunks per column
     constexpr int LQ = NPC * CPT / 256;                              // chunks per thread and tile
     __shared__ __attribute__((aligned(16))) unsigned char colA[2][NPC * STRIDE];
     __shared__ __attribute__((aligned(16))) float nbt[2][NPC];
-    __shared__ int cnt[128];
     const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), r = lane & 31, hh = lane >> 5;
     const int lr = wave * 32 + r;                                    // row of this lane inside the workgroup
     const int64_t i = row0 + (int64_t)blockIdx.x * 128 + lr;
@@ -496,9 +495,9 @@ __global__ __launch_bounds__(256) void np_sweep(const __bf16 *__restrict__ xb, c
 #pragma unroll
     for (int s = 0; s < KS; s++) bfr[s] = *reinterpret_cast<const bf16x8 *>(xb + ic * H + 16 * s + 8 * hh);
     const float nbi = nb[ic];
-    if (tid < 128) cnt[tid] = 0;
-    uint4 stg[LQ];
-    float stg_nb = 0.0f;
+    uint4 stg[LQ];                                                   // (plain arrays: a struct passed by reference to the lambdas is not
+    float stg_nb = 0.0f;                                             //  promoted to registers and round-trips through scratch memory)
+    // (zero + conditional load: the unconditional clamped form makes the compiler keep `stg` in scratch memory -- 80 bytes per lane)
     auto tile_load = [&](int64_t c0) {
 #pragma unroll
         for (int q = 0; q < LQ; q++) {
@@ -567,9 +566,25 @@ __global__ __launch_bounds__(256) void np_sweep(const __bf16 *__restrict__ xb, c
         guess = fmaxf(fmaxf(tm[PILOT_M - 1], other), 0.0f) * gscale + 1e-6f;
         __syncthreads();
     }
-    const float rad2 = rvalid ? guess : -1.0f;
-    int2 *cl = cand + ((int64_t)blockIdx.x * 128 + lr) * CAPF;
-    // ---- sweep
+    // Candidate appends: the two lanes of a row (columns 4*hh.. of every 8) each own HALF of the row's list and a private counter
+    // in a register.  (A shared LDS counter per row -- atomicAdd with return -- put one LDS round trip on every append site a
+    // wavefront entered: ~16 sites per tile, most of the 9000 cycles a tile took; 5.9 -> 5.3 ms.)
+    int2 *cl = cand + ((int64_t)blockIdx.x * 128 + lr) * CAPF + hh * (CAPF / 2);
+    int mycnt = 0;
+    // ---- sweep  (measured and rejected: two register stages, i.e. the loads of tile tl + 3 in flight while tile tl + 1 waits
+    // in registers -- 7.0 ms against 5.3)
+    // Candidate test.  A lane holds 16 bounds per 32x32 block and a wavefront ~4 hits among its 1024: testing the 16 positions
+    // one by one costs a compare + divergent branch each, and the wavefront enters whenever ANY lane hits (5.3 -> 4.4 ms).
+    // The loop is VALU-bound: ~570 dynamic VALU instructions per wavefront and 128-column tile (16 fma + 16 tags + 32 min/med3
+    // per block, the append paths, the rescans), 4 wavefronts per SIMD; the staging skeleton alone takes 0.9 ms.  Instead the column position q is written into the 4 low mantissa bits of each bound (a slightly SMALLER bound:
+    // still a lower bound) and the lane's two smallest tagged bounds come out of a min / med3 chain: one test per block for
+    // the first hit, one for the second (12 % of blocks for some lane), and only a lane with two hits rescans its 16 values.
+    const float rad2f = rvalid ? __int_as_float(__float_as_int(guess) | 15) : -INFINITY;
+    auto append = [&](float tagged, uint32_t colbase) {
+        const int bits = __float_as_int(tagged), q = bits & 15;
+        if (mycnt < CAPF / 2) cl[mycnt] = make_int2((int)(colbase + (uint32_t)((q & 3) + 8 * (q >> 2))), bits & ~15);
+        mycnt++;
+    };
     tile_load(0);
     tile_store(0);
     __syncthreads();
@@ -577,30 +592,27 @@ __global__ __launch_bounds__(256) void np_sweep(const __bf16 *__restrict__ xb, c
         const int buf = tl & 1;
         if (tl + 1 < ntiles) tile_load((int64_t)(tl + 1) * NPC);         // in flight during the MFMAs below
         const uint32_t cbase = (uint32_t)tl * NPC + (uint32_t)(4 * hh);
-        // all four 32-column blocks of the tile FIRST (16 independent MFMAs, their LDS reads and the bound arithmetic can be
-        // interleaved by the scheduler), the rare candidate appends afterwards: a branch between the blocks would serialise every
-        // block's read -> MFMA -> compare chain (~1400 cycles of latency per block for one wavefront)
-        float L2[NPC / 32][16];
-        float lmin[NPC / 32];
 #pragma unroll
         for (int sub = 0; sub < NPC / 32; sub++) {
-            bounds(buf, sub, L2[sub]);
-            lmin[sub] = L2[sub][0];
+            float vb[16];
+            bounds(buf, sub, vb);
+            float m1 = INFINITY, m2 = INFINITY;                      // the two smallest tagged bounds (m1 <= m2)
 #pragma unroll
-            for (int q = 1; q < 16; q++) lmin[sub] = fminf(lmin[sub], L2[sub][q]);
-        }
-        const float tmin = fminf(fminf(lmin[0], lmin[1]), fminf(lmin[2], lmin[3]));
-        if (tmin <= rad2) {
+            for (int q = 0; q < 16; q++) {
+                vb[q] = __int_as_float((__float_as_int(vb[q]) & ~15) | q);
+                m2 = __builtin_amdgcn_fmed3f(m1, m2, vb[q]);
+                m1 = fminf(m1, vb[q]);
+            }
+            if (__ballot(m1 <= rad2f) != 0ull) {                     // wave-uniform
+                const uint32_t colbase = cbase + (uint32_t)(sub * 32);
+                if (m1 <= rad2f) append(m1, colbase);
+                if (__ballot(m2 <= rad2f) != 0ull) {
+                    if (m2 <= rad2f) {
+                        append(m2, colbase);
+                        const int q1 = __float_as_int(m1) & 15, q2 = __float_as_int(m2) & 15;
 #pragma unroll
-            for (int sub = 0; sub < NPC / 32; sub++) {
-                if (lmin[sub] <= rad2) {
-#pragma unroll
-                    for (int q = 0; q < 16; q++) {
-                        if (L2[sub][q] <= rad2) {
-                            const int slot = atomicAdd(&cnt[lr], 1);
-                            if (slot < CAPF)
-                                cl[slot] = make_int2((int)(cbase + (uint32_t)(sub * 32 + (q & 3) + 8 * (q >> 2))), (int)__float_as_uint(L2[sub][q]));
-                        }
+                        for (int q = 0; q < 16; q++)
+                            if (q != q1 && q != q2 && vb[q] <= rad2f) append(vb[q], colbase);
                     }
                 }
             }
@@ -608,8 +620,10 @@ __global__ __launch_bounds__(256) void np_sweep(const __bf16 *__restrict__ xb, c
         if (tl + 1 < ntiles) tile_store(buf ^ 1);
         __syncthreads();
     }
-    if (rvalid && hh == 0) {
-        cand_cnt[(int64_t)blockIdx.x * 128 + lr] = cnt[lr];
+    const int c1 = __shfl_xor(mycnt, 32, 64);                    // the other half's count
+    if (rvalid && hh == 0) {                                     // packed (low 16 bits: half 0, high: half 1; 0xffff = overflow)
+        const int n0 = mycnt <= CAPF / 2 ? mycnt : 0xffff, n1 = c1 <= CAPF / 2 ? c1 : 0xffff;
+        cand_cnt[(int64_t)blockIdx.x * 128 + lr] = n0 | (n1 << 16);
         cand_guess[(int64_t)blockIdx.x * 128 + lr] = guess;
     }
 }
@@ -628,10 +642,12 @@ __global__ __launch_bounds__(256) void fast_finalize(const float *__restrict__ x
     const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
     const int64_t i = row0 + lrow;
     if (i >= row1) return;
-    const int n = cand_cnt[lrow];
+    const int packed = cand_cnt[lrow], n0 = packed & 0xffff, n1 = (packed >> 16) & 0xffff;   // two half lists (np_sweep)
+    const int n = n0 + n1;
     const float guess = cand_guess[lrow];
-    const int2 *cl = cand + lrow * CAPF;
-    bool ok = n >= 64 && n <= CAPF;
+    const int2 *cl0 = cand + lrow * CAPF;
+    auto cand_at = [&](int e) { return cl0[e < n0 ? e : CAPF / 2 + (e - n0)]; };
+    bool ok = n0 <= CAPF / 2 && n1 <= CAPF / 2 && n >= 64;
     uint64_t list = DGG_EMPTY_KEY;
     if (ok) {
         const float ni = nb[i];                                  // discounted norms: n (1 - eps)
@@ -642,7 +658,7 @@ __global__ __launch_bounds__(256) void fast_finalize(const float *__restrict__ x
             const int e = base + lane;
             uint64_t key = DGG_EMPTY_KEY;
             if (e < n) {
-                const int2 c = cl[e];
+                const int2 c = cand_at(e);
                 const float L = __int_as_float(c.y);
                 const float U = fmaxf(L + SL * (ni + nb[c.x]), 0.0f) * 1.00001f + 1e-7f;
                 key = ((uint64_t)(~__float_as_uint(U)) << 32) | (uint32_t)(e + 1);
@@ -656,7 +672,7 @@ __global__ __launch_bounds__(256) void fast_finalize(const float *__restrict__ x
             const int e = base + lane;
             int32_t j = -1;
             if (e < n) {
-                const int2 c = cl[e];
+                const int2 c = cand_at(e);
                 if (__int_as_float(c.y) <= tau) j = c.x;
             }
             if (__ballot(j >= 0) == 0ull) continue;
