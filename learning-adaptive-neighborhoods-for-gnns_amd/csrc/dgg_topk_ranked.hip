@@ -97,8 +97,30 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
                 key = make_key(score_from_dist(c_sqrt(d2), t, true, G), (int32_t)c);
             }
         }
-        key = wave_sort<false>(key, lane);
-        list = wave_merge_top64_asc(list, key, lane);
+        // Settle the block's keys into the list (descending, one entry per lane).  The kernel is bound by vector-instruction issue
+        // and the 64-lane bitonic sort + merge is ~270 of its ~650 instructions per block, whatever the number of live keys:
+        //  * first block: the list is empty -- sort descending, no merge;
+        //  * a later block with few live keys (the usual case: the per-candidate cuts leave a handful): insert them one by one
+        //    (position = number of larger entries, the tail shifts down one lane) -- ~10 instructions per key;
+        //  * otherwise sort + merge.  All three produce the same list (keys are unique).
+        uint64_t live = __ballot(key != DGG_EMPTY_KEY);
+        const int nlive = __builtin_popcountll(live);
+        if (rb == 0) {
+            list = wave_sort<true>(key, lane);
+        } else if (nlive <= 16) {
+            while (live != 0ull) {                               // wave-uniform
+                const int src = __builtin_ctzll(live);
+                live &= live - 1;
+                const uint64_t kk = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), src) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, src);
+                const int pos = __builtin_popcountll(__ballot(list > kk));
+                const uint64_t prev = ((uint64_t)(uint32_t)__shfl_up((int)(list >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)list, 1, 64);
+                list = lane < pos ? list : (lane == pos ? kk : prev);
+            }
+        } else {
+            key = wave_sort<false>(key, lane);
+            list = wave_merge_top64_asc(list, key, lane);
+        }
         const int nvalid = __builtin_popcountll(m);
         S = shfl_u64(pre, 63);                                   // inclusive sum at the last lane = block total + carry
         scount += (uint32_t)nvalid;
