@@ -40,10 +40,10 @@ inline PartHdr part_layout(void *ws, int64_t nb, int64_t nrec) {
 
 // PAYLOAD partition (dgg_partp_*): 16-byte records (src = row*64 + r, dst = j, wa = w_ir * rs_i^-1/2, score val_ir) and NO slot
 // map.  With the two per-entry scalars in the record, every column-walking kernel of the backward forms what it needs from
-// its own coalesced record stream: ahat_ir = wa * rs_j^-1/2 (conv_bwd_cols_p) and d loss / d dist (edge_bwd_cols_p, which
+// its own coalesced record stream: ahat_ir = wa * rs_j^-1/2 (conv_bwd_node) and d loss / d dist (edge_bwd_node, which
 // recomputes the ramp / normalisation chain from dA in record order) -- no per-entry random 4-byte gather of ahat, no
 // per-entry scattered write of a coefficient, no slot map to build.  The one remaining crossing between row order and
-// record order is dA (written row-major by conv_bwd_cols_p for the row kernel).
+// record order is dA (written row-major by conv_bwd_node for the row kernel).
 struct PartPHdr {                  // workspace: [bstart NB+1][cursor NB][nodeptr NB*BS+1][tmp rows*K int4][recs rows*K int4]
     int *bstart, *cursor;
     int *nodeptr;                  // CSC pointer: the records of destination node j are recs[nodeptr[j] .. nodeptr[j+1])
@@ -249,7 +249,7 @@ struct SoftkArgs {
     // ahat_rows != NULL: `da` holds only the NEIGHBOUR-side sums (conv_bwd_cols); the row side
     // da_i += sum_r dA_ir w_ir a_j = sqrt(rs_i) sum_r dA_ir ahat_ir is added here, in registers
     const float *ahat_rows;
-    // payload partition: no slot map, no coefficient hand-over; instead (a_i, d loss / d rs_i, k_i, 0) per row for edge_bwd_cols_p
+    // payload partition: no slot map, no coefficient hand-over; instead (a_i, d loss / d rs_i, k_i, 0) per row for edge_bwd_node
     float4 *rowinfo;
 };
 template <int H, bool FUSE, bool PAY = false>
@@ -589,188 +589,10 @@ __global__ __launch_bounds__(256) void conv_bwd_cols(const float *__restrict__ G
     flush();
 }
 
-// ---- the same on PAYLOAD records (see PartPHdr): ahat_ir = wa * rs_j^-1/2 comes from the record, dA is also written in record
-// order (coalesced) for edge_bwd_cols_p ------------------------------------------------------------------------------------
-template <int F>
-__global__ __launch_bounds__(256) void conv_bwd_cols_p(const float *__restrict__ G, const float *__restrict__ Hm, int K,
-                                                       const int *__restrict__ bstart, int nb, const int4 *__restrict__ recs,
-                                                       const float *__restrict__ rs, float *__restrict__ dA,
-                                                       float *__restrict__ dA_rec, float *__restrict__ dH, float *__restrict__ da) {
-    constexpr int LPR = F / 4;
-    const int lane = threadIdx.x & 63, c4 = lane % LPR, gbase = lane - c4;
-    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
-    const int nnz = bstart[nb];
-    const int64_t cbeg = gid * CH;
-    if (cbeg >= nnz) return;
-    const int cend = cbeg + CH < nnz ? (int)cbeg + CH : nnz;
-    int cur = -1;
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float sda = 0.0f, aj = 0.0f, rscur = 1.0f;
-    const int shared_lo = cbeg > 0 ? recs[cbeg - 1].y : -1, shared_hi = cend < nnz ? recs[cend].y : -1;   // see edge_bwd_cols
-    auto flush = [&]() {
-        if (cur >= 0) {
-            float *o = dH + (int64_t)cur * F + 4 * c4;
-            const bool shared = cur == shared_lo || cur == shared_hi;
-            if (shared) {
-                atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
-            } else {
-                float4 v = *reinterpret_cast<float4 *>(o);
-                v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += acc.w;
-                *reinterpret_cast<float4 *>(o) = v;
-            }
-            if (da && c4 == 0) {
-                const float v = sda * sqrtf(rscur);
-                if (shared) atomicAdd(da + cur, v);
-                else da[cur] += v;
-            }
-        }
-    };
-    for (int eb = (int)cbeg; eb < cend; eb += LPR) {
-        const int e = eb + c4;
-        const int4 myrec = e < cend ? recs[e] : make_int4(0, -1, 0, 0);
-        float mydot = 0.0f;
-#pragma unroll
-        for (int u0 = 0; u0 < LPR; u0 += 4) {
-            int src[4], dst[4];
-            float wa[4], rsj[4];
-            float4 g[4], hj[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                src[u] = __shfl(myrec.x, gbase + u0 + u, 64);
-                dst[u] = __shfl(myrec.y, gbase + u0 + u, 64);
-                wa[u] = __int_as_float(__shfl(myrec.z, gbase + u0 + u, 64));
-                const int64_t dj = dst[u] < 0 ? 0 : dst[u];
-                // all unconditional (padding records: row 0 / node 0): the H_j line and rs_j are the same for a whole run of
-                // records, i.e. L1 hits after the run's first record
-                g[u] = *reinterpret_cast<const float4 *>(G + (int64_t)(src[u] >> 6) * F + 4 * c4);
-                hj[u] = *reinterpret_cast<const float4 *>(Hm + dj * F + 4 * c4);
-                rsj[u] = rs[dj];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                float dot = g[u].x * hj[u].x;
-                dot = fmaf(g[u].y, hj[u].y, dot); dot = fmaf(g[u].z, hj[u].z, dot); dot = fmaf(g[u].w, hj[u].w, dot);
-                if (LPR > 16) dot += __uint_as_float(xor_shfl<16>(__float_as_uint(dot), lane));
-                if (LPR > 8) dot += __uint_as_float(xor_shfl<8>(__float_as_uint(dot), lane));
-                if (LPR > 4) dot += __uint_as_float(xor_shfl<4>(__float_as_uint(dot), lane));
-                dot += __uint_as_float(xor_shfl<2>(__float_as_uint(dot), lane));
-                dot += __uint_as_float(xor_shfl<1>(__float_as_uint(dot), lane));
-                if (dst[u] < 0) continue;
-                if (dst[u] != cur) {
-                    flush();
-                    cur = dst[u];
-                    acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    sda = 0.0f;
-                    rscur = rsj[u];
-                    aj = __fdiv_rn(1.0f, c_sqrt(rscur));         // as normalize_fwd_kernel: wa * aj == ahat bit for bit
-                }
-                const float cf = __fmul_rn(wa[u], aj);
-                if (c4 == 0) dA[(int64_t)(src[u] >> 6) * K + (src[u] & 63)] = dot;
-                if (c4 == u0 + u) mydot = dot;
-                acc.x = fmaf(cf, g[u].x, acc.x); acc.y = fmaf(cf, g[u].y, acc.y);
-                acc.z = fmaf(cf, g[u].z, acc.z); acc.w = fmaf(cf, g[u].w, acc.w);
-                sda = fmaf(dot, cf, sda);
-            }
-        }
-        if (e < cend) dA_rec[e] = mydot;
-    }
-    flush();
-}
-
-// ---- score backward, column side, on payload records: d loss / d dist is RECOMPUTED here from dA in record order ------------
-// For record e = (i, r) -> j the lane that loaded it forms, for ITS record (16 records per group in parallel),
-//     dw = dA_e a_i a_j + drs_i,  dval = dw * ramp(r - k_i)                 (softk_bwd_kernel, dgg_ell.hip; dgm.py:1410-1420)
-// from the per-row scalars (a_i, drs_i, k_i) that edge_bwd_rows<PAY> left in rowinfo; the distance part
-//     dd = dval [v / (p + 1e-8)] t p / dist,  p = exp(t dist)               (autograd of dgm.py:1213-1229, 1618-1623)
-// needs the gathered row xp_i and the run's xp_j (L1 hit).  acc_j = sum_e dd_e (xp_j - xp_i).
-template <int H>
-__global__ __launch_bounds__(256) void edge_bwd_cols_p(const float *__restrict__ xp, const int *__restrict__ bstart, int nb,
-                                                       const int4 *__restrict__ recs, const float *__restrict__ dA_rec,
-                                                       const float4 *__restrict__ rowinfo, const float *__restrict__ rs,
-                                                       int normalized, int64_t row0, float t, int perturb, float *__restrict__ dxp) {
-    constexpr int LPR = H / 4;
-    const int lane = threadIdx.x & 63, c4 = lane % LPR, gbase = lane - c4;
-    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
-    const int nnz = bstart[nb];
-    const int64_t cbeg = gid * CH;
-    if (cbeg >= nnz) return;
-    const int cend = cbeg + CH < nnz ? (int)cbeg + CH : nnz;
-    int cur = -1;
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const int shared_lo = cbeg > 0 ? recs[cbeg - 1].y : -1, shared_hi = cend < nnz ? recs[cend].y : -1;   // see edge_bwd_cols
-    auto flush = [&]() {
-        if (cur >= 0) {
-            float *o = dxp + (int64_t)cur * H + 4 * c4;
-            if (cur == shared_lo || cur == shared_hi) {
-                atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
-            } else {
-                float4 v = *reinterpret_cast<float4 *>(o);
-                v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += acc.w;
-                *reinterpret_cast<float4 *>(o) = v;
-            }
-        }
-    };
-    for (int eb = (int)cbeg; eb < cend; eb += LPR) {
-        const int e = eb + c4;
-        const bool have = e < cend;
-        const int4 myrec = have ? recs[e] : make_int4(0, -1, 0, 0);
-        // this lane's own record: d loss / d score (unconditional loads; clamped)
-        const float4 info = rowinfo[myrec.x >> 6];
-        const float rsj = rs[myrec.y < 0 ? 0 : myrec.y];
-        float mydval = have ? dA_rec[e] : 0.0f;
-        {
-            const float aj = normalized ? __fdiv_rn(1.0f, c_sqrt(rsj)) : 1.0f;
-            const float dw = mydval * info.x * aj + info.y;
-            const float th = c_tanh((float)(myrec.x & 63) - info.z);
-            mydval = have ? dw * (1.0f - 0.5f * (1.0f + th)) : 0.0f;
-        }
-#pragma unroll
-        for (int u0 = 0; u0 < LPR; u0 += 4) {
-            int src[4], dst[4];
-            float gv[4], vv[4];
-            float4 xi[4], xj[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                src[u] = __shfl(myrec.x, gbase + u0 + u, 64);
-                dst[u] = __shfl(myrec.y, gbase + u0 + u, 64);
-                gv[u] = __shfl(mydval, gbase + u0 + u, 64);
-                vv[u] = __int_as_float(__shfl(myrec.w, gbase + u0 + u, 64));
-                xi[u] = *reinterpret_cast<const float4 *>(xp + (row0 + (src[u] >> 6)) * H + 4 * c4);          // unconditional
-                xj[u] = *reinterpret_cast<const float4 *>(xp + (int64_t)(dst[u] < 0 ? 0 : dst[u]) * H + 4 * c4);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const float4 d = make_float4(xi[u].x - xj[u].x, xi[u].y - xj[u].y, xi[u].z - xj[u].z, xi[u].w - xj[u].w);
-                float d2 = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
-                if (LPR > 16) d2 += __uint_as_float(xor_shfl<16>(__float_as_uint(d2), lane));
-                if (LPR > 8) d2 += __uint_as_float(xor_shfl<8>(__float_as_uint(d2), lane));
-                if (LPR > 4) d2 += __uint_as_float(xor_shfl<4>(__float_as_uint(d2), lane));
-                d2 += __uint_as_float(xor_shfl<2>(__float_as_uint(d2), lane));
-                d2 += __uint_as_float(xor_shfl<1>(__float_as_uint(d2), lane));
-                if (dst[u] < 0) continue;
-                if (dst[u] != cur) {
-                    flush();
-                    cur = dst[u];
-                    acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
-                float dd = 0.0f;
-                if (gv[u] != 0.0f && d2 != 0.0f) {               // vector_norm backward at 0 is 0 (self loop)
-                    const float dist = sqrtf(d2);
-                    const float p = c_exp(t * dist);
-                    const float dp = perturb ? gv[u] * vv[u] / (p + 1e-8f) : gv[u];
-                    dd = dp * t * p / dist;
-                }
-                acc.x -= dd * d.x; acc.y -= dd * d.y; acc.z -= dd * d.z; acc.w -= dd * d.w;
-            }
-        }
-    }
-    flush();
-}
-
 // ---- one wavefront per DESTINATION node (CSC walk of the payload records) ------------------------------------------------
-// The chunked kernels above keep ~100 registers of run-tracking state per lane, i.e. 4 wavefronts per SIMD and ~64 KB of
-// gathers in flight per CU; a gather from the Infinity Cache needs about twice that to reach its ceiling (the 38-register
-// spmm_fwd_narrow runs at 8 TB/s).  With the CSC pointer of the payload partition a wavefront owns ALL records of one
+// (A chunked walk of the payload records -- fixed chunks of 64 records per lane group, runs of equal destination reduced in
+// registers, as conv_bwd_cols / edge_bwd_cols do on the slot-map partition -- was built first: ~100 registers of run-tracking
+// state per lane, 4 wavefronts per SIMD, 258 + 190 us; removed.)  With the CSC pointer of the payload partition a wavefront owns ALL records of one
 // destination j: H_j / xp_j are loaded once, there is no run logic, the sums are plain stores (no atomics, no zero fill for
 // dH / da), and the kernel has the shape of the forward SpMM: F/4 lanes per record, 256/F records per wave-instruction,
 // NBT batches in flight.  (In-degree skew: a node with thousands of incoming edges is walked by one wavefront.)
@@ -839,7 +661,11 @@ __global__ __launch_bounds__(256) void conv_bwd_node(const float *__restrict__ G
     if (da && lane == 0) da[j] = sda * sqrtf(rsj);
 }
 
-// score backward, column side, one wavefront per destination node (see edge_bwd_cols_p for the arithmetic): the lane that
+// score backward, column side, one wavefront per destination node.  For record e = (i, r) -> j the lane that loaded it forms
+//     dw = dA_e a_i a_j + drs_i,  dval = dw * ramp(r - k_i)                 (softk_bwd_kernel, dgg_ell.hip; dgm.py:1410-1420)
+// from the per-row scalars (a_i, drs_i, k_i) that edge_bwd_rows<PAY> left in rowinfo; the distance part
+//     dd = dval [v / (p + 1e-8)] t p / dist,  p = exp(t dist)               (autograd of dgm.py:1213-1229, 1618-1623)
+// needs the gathered row xp_i; acc_j = sum_e dd_e (xp_j - xp_i).  The lane that
 // loaded a record forms d loss / d score for it (PER records in parallel), the distance part runs per lane group.
 // dxp_j is the exclusive property of this wavefront: rows inside [row0, row0 + rows) already hold the row-side term written by
 // edge_bwd_rows (read-modify-write), the others are written plainly (no zero fill needed).

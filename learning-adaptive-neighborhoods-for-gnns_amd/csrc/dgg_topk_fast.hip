@@ -291,61 +291,6 @@ __global__ __launch_bounds__(64) void allpairs_topk_fast(
     };
 
     const int ntiles = (int)((N + CT - 1) / CT);
-    float guess[RBLK];
-#pragma unroll
-    for (int b = 0; b < RBLK; b++) guess[b] = 3.0e38f;
-    if (NOISE == 0 && ntiles >= 4 * PILOT_T) {
-        // pilot: PILOT_T column tiles spread over the whole range (per-wavefront offset), bounds only
-        float t4[RBLK][PILOT_M];
-#pragma unroll
-        for (int b = 0; b < RBLK; b++)
-#pragma unroll
-            for (int q = 0; q < PILOT_M; q++) t4[b][q] = 3.0e38f;
-        const int stride_t = ntiles / PILOT_T;
-        const int first_t = (int)(((uint32_t)blockIdx.x * 2654435761u) % (uint32_t)stride_t);
-        for (int pt = 0; pt < PILOT_T; pt++) {
-            const int64_t cb = (int64_t)(first_t + pt * stride_t) * CT;
-            tile_load(cb);
-            __syncthreads();
-            tile_store();
-            __syncthreads();
-            bf16x8 af[KS];
-#pragma unroll
-            for (int s_ = 0; s_ < KS; s_++) af[s_] = *reinterpret_cast<const bf16x8 *>(&colA[r * STRIDE + (16 * s_ + 8 * hh) * 2]);
-#pragma unroll
-            for (int b = 0; b < RBLK; b++) {
-                f32x16 acc;
-#pragma unroll
-                for (int q = 0; q < 16; q++) acc[q] = 0.0f;
-#pragma unroll
-                for (int s_ = 0; s_ < KS; s_++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s_], bfr[b][s_], acc, 0, 0, 0);
-#pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) {
-                    float4 nj4 = *reinterpret_cast<const float4 *>(&nbt[8 * g4 + 4 * hh]);
-                    float njs[4] = {nj4.x, nj4.y, nj4.z, nj4.w};
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        float v = __fmaf_rn(-2.0f, acc[4 * g4 + u], nbi[b] + njs[u]);
-                        // keep the PILOT_M smallest of this half-row (branch-free insertion; skipped when v cannot enter)
-                        if (v < t4[b][PILOT_M - 1]) {
-#pragma unroll
-                            for (int q = 0; q < PILOT_M; q++) { const float lo = fminf(v, t4[b][q]); v = fmaxf(v, t4[b][q]); t4[b][q] = lo; }
-                        }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < RBLK; b++) {
-            // the two lanes of a row (hh = 0 / 1) saw different columns: the larger of their 4th smallest bounds covers >= 8 samples
-            const float other = __shfl_xor(t4[b][PILOT_M - 1], 32, 64);
-            float g = fmaxf(fmaxf(t4[b][PILOT_M - 1], other), 0.0f);
-            g = g * gscale + 1e-6f;                              // bounds are lower bounds of d^2 (bf16 slack): a little headroom
-            guess[b] = g;
-            if (rvalid[b]) ta[b] = __float_as_uint(g);
-        }
-        __syncthreads();
-    }
     tile_load(0);
     for (int tl = 0; tl < ntiles; tl++) {
         const int64_t cb = (int64_t)tl * CT;
@@ -367,38 +312,7 @@ __global__ __launch_bounds__(64) void allpairs_topk_fast(
             for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bfr[b][s], acc, 0, 0, 0);
             const int lr = b * 32 + r;
             STAMP(0);
-            if (NOISE == 0) {
-                const float rad2 = __uint_as_float(ta[b]);
-                // all 16 bounds first, ONE compare of their minimum: about two of the 1024 pairs of a tile pass, so nearly every
-                // lane skips the per-column tests (a compare + branch per column was half of the kernel's cycles)
-                float L2[16];
-                float lmin = 3.0e38f;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) {
-                    float4 nj4 = *reinterpret_cast<const float4 *>(&nbt[8 * g4 + 4 * hh]);
-                    float njs[4] = {nj4.x, nj4.y, nj4.z, nj4.w};
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        L2[4 * g4 + u] = __fmaf_rn(-2.0f, acc[4 * g4 + u], nbi[b] + njs[u]);
-                        lmin = fminf(lmin, L2[4 * g4 + u]);
-                    }
-                }
-                const bool hit = lmin <= rad2;
-                STAMP(1);
-                if (hit) {
-                    // candidate (column, bound) appended to the row's list; nothing is scored here: the sweep never stops
-                    // (the lists are settled by fast_finalize, one wavefront per row, 100k of them in flight)
-                    int2 *cl = cand + (int64_t)(blockIdx.x * RW + lr) * CAPF;
-#pragma unroll
-                    for (int q = 0; q < 16; q++) {
-                        if (L2[q] <= rad2) {
-                            const int slot = atomicAdd(&cnt[lr], 1);
-                            if (slot < CAPF) cl[slot] = make_int2((int)(jbase + (uint32_t)((q & 3) + 8 * (q >> 2))), (int)__float_as_uint(L2[q]));
-                        }
-                    }
-                }
-                STAMP(3);
-            } else {
+            {
                 const uint32_t base = jbase ^ k1[b];
                 unsigned long long pm[16];
                 unsigned long long anym = 0ull;
@@ -448,20 +362,7 @@ __global__ __launch_bounds__(64) void allpairs_topk_fast(
         }
     }
     // drain the ring, then flush everything still pending
-    if (NOISE != 0) {
-        while (qtail != qhead) drain();
-    }
-    if (NOISE == 0) {
-        __syncthreads();
-#pragma unroll
-        for (int b = 0; b < RBLK; b++) {
-            if (rvalid[b] && hh == 0) {
-                cand_cnt[blockIdx.x * RW + b * 32 + r] = cnt[b * 32 + r];
-                cand_guess[blockIdx.x * RW + b * 32 + r] = guess[b];
-            }
-        }
-        return;
-    }
+    while (qtail != qhead) drain();
     flush_ready(1);
 #ifdef DGG_STAMPS
     STAMP(3);
@@ -479,7 +380,7 @@ __global__ __launch_bounds__(64) void allpairs_topk_fast(
 // ONE compare of their minimum against the row's radius.  782 workgroups at N = 100k: three per CU.
 constexpr int NPC = 128;           // columns per staged tile
 template <int H>
-__global__ __launch_bounds__(256, 4) void np_sweep(const __bf16 *__restrict__ xb, const float *__restrict__ nb, int64_t N, int64_t row0,
+__global__ __launch_bounds__(256, H <= 64 ? 4 : 2) void np_sweep(const __bf16 *__restrict__ xb, const float *__restrict__ nb, int64_t N, int64_t row0,
                                                 int64_t row1, float gscale, int2 *__restrict__ cand, int *__restrict__ cand_cnt,
                                                 float *__restrict__ cand_guess) {
     constexpr int KS = H / 16, STRIDE = H * 2 + 16, CPT = H / 8;     // 16-byte chunks per column
