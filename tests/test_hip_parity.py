@@ -420,6 +420,29 @@ def test_full_size_properties(dev):
     assert torch.equal(sub_i, idx[70_000:70_512]) and torch.equal(sub_v, val[70_000:70_512])
 
 
+def test_full_size_symmetric_noise_triangular_sweep(dev):
+    """N = 100k, symmetric hash noise (the reference's default symmetry, dgm.py:1216-1223) on the WHOLE graph: the guess-and-verify
+    path sweeps only j > i and fills transposed lists.  Checked against the oracle on sampled rows and, bit for bit, against the
+    rectangular sweep that a row-range call takes."""
+    from dgg_amd import ops
+    N, h = 100_000, 64
+    g = torch.Generator(device="cpu").manual_seed(3)
+    xp = (torch.randn(N, h, generator=g) * 0.6).to(dev)
+    idx, val, ws = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_HASH_SYM, seed=(99, 7), return_ws=True)
+    nfail = int(ws[4:8].view(torch.int32).item())
+    assert nfail <= N // 200, f"{nfail} rows went through the fallback"
+    assert (val[:, :-1] >= val[:, 1:]).all() and (idx >= 0).all() and (idx < N).all()
+    srt = idx.sort(dim=1).values
+    assert (srt[:, 1:] != srt[:, :-1]).all(), "duplicate column in a row"
+    xp_c = xp.cpu().numpy()
+    for r in [0, 1, 63, 64, 65, 31_337, 50_000, 99_936, 99_999]:           # first / last rows: only a transposed / only an own list
+        ri, rv = O.allpairs_topk(xp_c, K=K, noise_mode=O.NOISE_HASH_SYM, seed=(99, 7), rows=(r, r + 1))
+        assert np.array_equal(Nn(idx[r]), ri[0]) and np.array_equal(Nn(val[r]), rv[0]), r
+    for lo, hi in [(0, 300), (49_900, 50_412), (99_700, N)]:
+        sub_i, sub_v = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_HASH_SYM, seed=(99, 7), rows=(lo, hi))
+        assert torch.equal(sub_i, idx[lo:hi]) and torch.equal(sub_v, val[lo:hi])
+
+
 @pytest.mark.parametrize("name", ["model_gcn_dgg", "model_gcn_dgg_uvdeg", "model_gcnii_dgg", "model_gcniippi_dgg"])
 def test_model_wrappers_match_reference_golden(dev, name):
     """dgg_amd.GCN_DGG / GCNII_DGG / GCNIIppi_DGG (eval mode, explicit noise) against the reference's own wrappers
