@@ -31,6 +31,7 @@ constexpr float TARGET_MAX = 128.0f;   // expected number of pairs per row above
 constexpr float TARGET_MIN = 80.0f;    // ... lowered when distances matter (small M) so the candidate lists still fit
 constexpr float ADMIT_MAX = 0.8f * CAPF;
 constexpr int PILOT_PAIRS = 262144;
+constexpr float DTIGHT = 0.1124f;      // 0.3 ln(128 / 88): gv_finalize's first stage aims at an expected 88 pairs above its threshold
 
 struct GvCtl {                     // device-side control block (workspace head)
     float msum;                    // sum over pilot pairs of p^(1/0.3)
@@ -61,6 +62,27 @@ __device__ __forceinline__ float exact_score_gv(const float *__restrict__ xp, in
     float dist = c_sqrt(d2);
     float g = pair_noise(s0, s1, (uint32_t)i, (uint32_t)j, sym);
     return score_from_dist(dist, t, true, g);
+}
+// the same with the pair's 24-bit uniform already at hand (gv_finalize hashes every candidate before it decides to gather it)
+template <int H>
+__device__ __forceinline__ float exact_score_gv_u(const float *__restrict__ xp, int64_t i, int32_t j, float t, bool diag, uint32_t u24) {
+    const float *xi = xp + i * H;
+    const float4 *xj = reinterpret_cast<const float4 *>(xp + (int64_t)j * H);
+    float d2 = 0.0f;
+#pragma unroll
+    for (int c8 = 0; c8 < H / 8; c8++) {
+        float4 b0 = xj[2 * c8], b1 = xj[2 * c8 + 1];
+        float df;
+        df = __fadd_rn(xi[8 * c8 + 0], -b0.x); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 1], -b0.y); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 2], -b0.z); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 3], -b0.w); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 4], -b1.x); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 5], -b1.y); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 6], -b1.z); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 7], -b1.w); d2 = __fmaf_rn(df, df, d2);
+    }
+    return score_from_dist(c_sqrt(d2), t, true, diag ? 0.0f : gumbel_u24(u24));
 }
 
 // pairs whose raw hash is below the result have noise G < gmin (with margin): they cannot reach log-score gmin + 1e-8
@@ -332,26 +354,46 @@ __global__ __launch_bounds__(256) void gv_finalize(const float *__restrict__ xp,
     uint64_t list = DGG_EMPTY_KEY;
     ok = ok && n >= 64;
     if (ok) {
-        for (int base = 0; base < n; base += 64) {
-            int e = base + lane;
-            int32_t j = -1;
-            if (e < n) {
-                int s = 0;
+        // Two stages.  The sweep admitted every pair whose noise can reach gmin0 (an expected TARGET_MAX of them clear it with their
+        // distance).  Stage A gathers and scores only the candidates whose noise can reach the TIGHTER g_tight = gmin0 + DTIGHT
+        // (an expected TARGET_TIGHT clear that) and verifies the 64th score against g_tight: true for most rows, and 1/3 of the
+        // 256-byte gathers never happen.  A row that fails stage A scores the rest (stage B) and is verified against gmin0 as before.
+        const float gmin0 = ctl->gmin0, g_tight = gmin0 + DTIGHT;
+        const uint32_t ta_tight = hash_threshold_from_gmin(g_tight);
+        auto cand_at = [&](int e) {
+            int s = 0;
 #pragma unroll
-                for (int q = 1; q < NSEG; q++) s += (e >= off[q]) ? 1 : 0;
-                int o = off[0];
+            for (int q = 1; q < NSEG; q++) s += (e >= off[q]) ? 1 : 0;
+            int o = off[0];
 #pragma unroll
-                for (int q = 1; q < NSEG; q++) o = (s == q) ? off[q] : o;
-                j = e >= off[NSEG] ? pendT[i * CAPT + (e - off[NSEG])] : pl[s * CAPS + (e - o)];
+            for (int q = 1; q < NSEG; q++) o = (s == q) ? off[q] : o;
+            return e >= off[NSEG] ? pendT[i * CAPT + (e - off[NSEG])] : pl[s * CAPS + (e - o)];
+        };
+        auto stage = [&](bool tight_part) {
+            for (int base = 0; base < n; base += 64) {
+                const int e = base + lane;
+                uint64_t key = DGG_EMPTY_KEY;
+                if (e < n) {
+                    const int32_t j = cand_at(e);
+                    const bool diag = SYM && (int64_t)j == i;
+                    const uint32_t u24 = pair_u24(s0, s1, (uint32_t)i, (uint32_t)j, SYM);
+                    const bool tight = diag || (u24 << 8) >= ta_tight;
+                    if (tight == tight_part) key = make_key(exact_score_gv_u<H>(xp, i, j, t, diag, u24), j);
+                }
+                if (__ballot(key != DGG_EMPTY_KEY) == 0ull) continue;
+                key = wave_sort<false>(key, lane);
+                list = wave_merge_top64_asc(list, key, lane);
             }
-            uint64_t key = DGG_EMPTY_KEY;
-            if (j >= 0) key = make_key(exact_score_gv<H>(xp, i, j, t, SYM, s0, s1), j);
-            key = wave_sort<false>(key, lane);
-            list = wave_merge_top64_asc(list, key, lane);
-        }
+        };
+        stage(true);
         uint64_t k63 = shfl_u64(list, 63);
-        // rejected pairs have log-score < gmin0 + 1e-8: the list is exact iff its 64th entry clears that with margin
-        ok = k63 != DGG_EMPTY_KEY && __logf(key_val(k63)) >= ctl->gmin0 + 1e-3f;
+        const bool okA = k63 != DGG_EMPTY_KEY && __logf(key_val(k63)) >= g_tight + 1e-3f;
+        if (!okA) {
+            stage(false);
+            k63 = shfl_u64(list, 63);
+            // rejected pairs have log-score < gmin0 + 1e-8: the list is exact iff its 64th entry clears that with margin
+            ok = k63 != DGG_EMPTY_KEY && __logf(key_val(k63)) >= gmin0 + 1e-3f;
+        }
     }
     if (ok) {
         idx[lrow * 64 + lane] = key_col(list);
