@@ -143,6 +143,11 @@ int dgg_allpairs_topk_ranked_softk(const float *xp, int64_t N, int h, int64_t ro
 /* bytes of device workspace the pruned path needs for (N, h): a bf16 copy of xp plus discounted squared norms;
  * 0 when the pruned path does not apply (explicit noise, K != 64, latent_dim not in {16,32,64,128}) */
 size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K);
+/* diagnostics of the unperturbed path (noise_mode 0, N >= 8192; the reference default perturb_edge_prob=False, dgm.py:1230-1231):
+ * byte offset inside the workspace of its control block { int32 rows_redone_by_the_fallback; int32 stats_on; uint64 phase_a_hits,
+ * phase_a_hits_inside_the_tight_radius, phase_b_hits } (the three sums only with DGG_SWEEP_STATS=1), readable after the stream
+ * has drained */
+size_t dgg_allpairs_sweep_ctl_offset_bytes(int64_t rows, int64_t N, int h);
 /* candidates = stored entries of in_adj as CSR (the live class's semantics, dgm.py:1613-1614) */
 int dgg_edgelist_topk(const float *xp, int64_t N, int h, const int64_t *rowptr, const int32_t *col, float t,
                       int noise_mode, const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx,

@@ -38,13 +38,18 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
     const bool can_np = dgg_allpairs_np_supported(h, noise_mode, K) && workspace && ws_bytes >= dgg_allpairs_np_ws_bytes(N);
     const bool can_gv = dgg_allpairs_gv_supported(h, noise_mode, K) && workspace &&
                         ws_bytes >= dgg_allpairs_gv_ws_bytes(row1 - row0, N);
+    const bool can_sweep = dgg_allpairs_sweep_supported(h, noise_mode, K) && workspace &&
+                           ws_bytes >= dgg_allpairs_sweep_ws_bytes(row1 - row0, N, h);
     int rc;
-    if (algo == 4 || (algo == 0 && can_gv && N >= 1024))
+    // unperturbed scores: two-phase guess-sweep-verify (its pilot needs N >= 8192; below that every pair is scored)
+    if (noise_mode == 0 && (algo == 2 || (algo == 0 && N >= 8192)) && can_sweep)
+        rc = dgg_allpairs_topk_sweep_impl(xp, N, h, row0, row1, t, K, idx, val, workspace, ws_bytes, st);
+    else if (algo == 4 || (algo == 0 && can_gv && N >= 1024))
         rc = dgg_allpairs_topk_gv_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
     else if (algo == 3 || (algo == 0 && can_np && N >= 1024))
         rc = dgg_allpairs_topk_np_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
     // (unperturbed scores: the MFMA-bounded kernel needs its pilot, i.e. N >= 8192; below that every pair is scored)
-    else if (algo == 2 || (algo == 0 && can_fast && N >= (noise_mode == 0 ? 8192 : 1024)))
+    else if (algo == 2 || algo == 5 || (algo == 0 && can_fast && N >= (noise_mode == 0 ? 8192 : 1024)))   // 5: round-2 unperturbed sweep
         rc = dgg_allpairs_topk_fast_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
     else
         rc = dgg_allpairs_topk_exhaustive_impl(xp, N, h, row0, row1, t, noise_mode, G, ldG, s0, s1, K, idx, val, st);
@@ -57,8 +62,13 @@ size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K) {
     size_t a = dgg_allpairs_fast_supported(h, noise_mode, K) ? dgg_allpairs_fast_ws_bytes(N, h) : 0;
     size_t b = dgg_allpairs_np_supported(h, noise_mode, K) ? dgg_allpairs_np_ws_bytes(N) : 0;
     size_t c = dgg_allpairs_gv_supported(h, noise_mode, K) ? dgg_allpairs_gv_ws_bytes(N, N) : 0;
+    size_t d = dgg_allpairs_sweep_supported(h, noise_mode, K) ? dgg_allpairs_sweep_ws_bytes(N, N, h) : 0;
     a = a > b ? a : b;
-    return a > c ? a : c;
+    a = a > c ? a : c;
+    return a > d ? a : d;
 }
+
+// diagnostics of the unperturbed sweep: byte offset inside the workspace of {int nfail; int stats_on; u64 nA, nAkept, nB}
+size_t dgg_allpairs_sweep_ctl_offset_bytes(int64_t rows, int64_t N, int h) { return dgg_allpairs_sweep_ctl_offset(rows, N, h); }
 
 }  // extern "C"

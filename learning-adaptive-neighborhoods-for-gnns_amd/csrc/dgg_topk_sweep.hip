@@ -1,0 +1,708 @@
+// dgg_topk_sweep.hip -- UNPERTURBED all-pairs scoring + per-row top-64 (noise_mode 0): the reference's own default
+// (`perturb_edge_prob=False`, train_small_graphs.py:158-163; scores dgm.py:1618-1623, sort dgm.py:1404).  The only path whose
+// result depends on all N^2 distances; identical bits to the exhaustive kernel (dgg_topk.hip).
+//
+// Guess, sweep, verify -- in two phases, so that the radius each row is swept with is TIGHT:
+//
+//   sw_prep      xw[j] = [ bf16(xp_j) | c_hi c_mid c_lo 1 1 1 0.. ]  (H + 16 bf16 per node), c_j = -nb_j / 2,
+//                nb_j = ||xp_j||^2 (1 - eps): the "augmented" K-step folds the norms and the row's radius INTO the MFMA chain:
+//                D_ij = <x^_i, x^_j> + c_j + t_i  with the row side [ 1 1 1 t_hi t_mid t_lo 0.. ];   t_i = (R_i - nb_i) / 2
+//                => D_ij >= 0  <=>  L_ij := nb_i + nb_j - 2 <x^_i, x^_j>  <=  R_i    (L_ij: rigorous lower bound of d^2_ij)
+//                so "is (i, j) inside row i's radius" is the SIGN BIT of an accumulator register: no VALU arithmetic per pair.
+//   sw_pilot     loose radius per row from ~N/22 sampled columns (8th smallest bound per half row), as before.
+//   sw_sweep<A>  phase A: every 4th column tile, loose radius; hits recorded WITH their bound value (~100 per row).
+//   sw_select    per row: the m-th smallest bound among the phase-A hits (m = 36 of a 1/4 sample => ~144 expected in N) becomes
+//                the TIGHT radius R_i (never above the loose one).
+//   sw_sweep<B>  phase B: the other 3/4 of the tiles, tight radius; hits recorded as bare columns (~100 per row).
+//   sw_finalize  per row: phase-A hits inside the tight radius + all phase-B hits (~140 columns) scored with the canonical fp32
+//                arithmetic, sorted, top-64 kept; VERIFIED: the list is exact iff it is full and its 64th distance lies inside
+//                R_i (every pair the sweeps rejected has d^2 >= L > R_i).  Rows that fail are redone by sw_fallback (every
+//                column scored): the result is exact whatever the guesses were.
+//
+// Sweep kernel: a workgroup of 4 wavefronts owns 128 * RBLK rows (RBLK 32-row MFMA blocks per wavefront, B operands in
+// registers for the whole kernel) and streams its share of the column tiles (128 columns, interleaved over CS workgroups per
+// row block) through a double-buffered, padded LDS image; per 32 x 32 block: KS + 1 bf16 MFMAs (v_mfma_f32_32x32x16_bf16),
+// 16 v_alignbit (sign bits -> one 16-bit hit mask per lane), one compare + branch; a lane appends its hits to PRIVATE lists
+// (row, column half, segment), so there are no atomics and no LDS traffic on the hit path.
+#include "dgg_common.h"
+#include "dgg_api_internal.h"
+#include <stdlib.h>
+
+using namespace dgg;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int TC = 128;                 // columns per staged tile
+constexpr float EPS_BF16 = 0.00405f;    // 2^-8 (1 + 2^-10) = 0.0039101 covers the bf16 rounding of both operands; the rest
+                                        // (1.4e-4 of n_i + n_j) covers fp32 accumulation order, the norm sums, the split of c/t
+constexpr int CAPA_ROW = 512;           // phase-A record slots per row (all its sub-lists together; expected ~100)
+constexpr int CAPB_ROW = 384;           // phase-B record slots per row (expected ~110)
+constexpr int LOOSE_TARGET = 350;       // columns the loose radius should admit per row (of N)
+constexpr int PILOT_M = 8;              // order statistic kept per half row by the pilot
+
+struct SweepCtl {
+    int nfail;
+    int stats_on;
+    unsigned long long nA, nAkept, nB;  // diagnostics (stats_on): recorded phase-A hits, those inside the tight radius, phase-B hits
+    int pad[8];
+};
+
+struct Plan {            // host-side launch geometry, also what the workspace layout depends on
+    int64_t rows, N, npad;
+    int ntiles, nA, nB, rblk, rw, nrb, rbx, csa, csb, capa, capb, pt;
+};
+
+__host__ __device__ inline int tileA(int w) { return 4 * w; }
+__host__ __device__ inline int tileB(int w) { return w + w / 3 + 1; }
+
+// exact split of an fp32 value into three bf16 pieces (hi + mid + lo == c)
+__device__ __forceinline__ void split3(float c, __bf16 &hi, __bf16 &mid, __bf16 &lo) {
+    const float fh = __uint_as_float(__float_as_uint(c) & 0xffff0000u);
+    const float r1 = c - fh;
+    const float fm = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    const float fl = r1 - fm;
+    hi = (__bf16)fh; mid = (__bf16)fm; lo = (__bf16)fl;
+}
+
+// ---- prologue: bf16 copy + augmented K-step of every node, discounted norms ------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(256) void sw_prep(const float *__restrict__ xp, int64_t N, int64_t npad, __bf16 *__restrict__ xw,
+                                               float *__restrict__ nb) {
+    constexpr int HW = H + 16;
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + dgg::wave_id();
+    if (j >= npad) return;
+    float s = 0.0f;
+    for (int c = lane; c < H; c += 64) {
+        const float v = j < N ? xp[j * H + c] : 0.0f;
+        xw[j * HW + c] = (__bf16)v;
+        s += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane < 16) {
+        const float nbj = s * (1.0f - EPS_BF16);
+        const float c = j < N ? -0.5f * nbj : -3.0e38f;
+        __bf16 p[3];
+        split3(c, p[0], p[1], p[2]);
+        __bf16 v = (__bf16)0.0f;
+        if (lane < 3) v = p[lane];
+        else if (lane < 6) v = (__bf16)1.0f;
+        xw[j * HW + H + lane] = v;
+        if (lane == 0 && j < N) nb[j] = nbj;
+    }
+}
+
+// B operand (row side) of the augmented K-step for the lane's row: [1 1 1 t_hi t_mid t_lo 0 0] in the lower half of the K range
+__device__ __forceinline__ bf16x8 aug_row(float t, int hh) {
+    bf16x8 v;
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = (__bf16)0.0f;
+    if (hh == 0) {
+        __bf16 a, b, c;
+        split3(t, a, b, c);
+        v[0] = v[1] = v[2] = (__bf16)1.0f;
+        v[3] = a; v[4] = b; v[5] = c;
+    }
+    return v;
+}
+
+// staged column tiles: TC columns x (H + 16) bf16, padded to a stride of (H + 16) * 2 + 16 bytes (odd multiple of 16:
+// conflict-free ds_read_b128 by the 16-lane groups of the LDS)
+template <int H>
+struct Tile {
+    static constexpr int HW = H + 16, KS1 = H / 16 + 1, STRIDE = HW * 2 + 16, CPC = HW / 8, LQ = TC * CPC / 256;
+    static constexpr int BYTES = TC * STRIDE;
+};
+
+// ---- pilot: loose radius -----------------------------------------------------------------------------------------------------
+// one wavefront per 32-row block (4 per workgroup); PT sampled tiles (stride over the whole column range, per-workgroup offset).
+// Per lane the PILOT_M largest block maxima of E = <x^_i, x^_j> + c_j are kept (a block's second-largest value is ignored: the
+// pilot is a heuristic, exactness comes from the verification) -> L = nb_i - 2 E, radius = max over the two half rows * gscale.
+template <int H>
+__global__ __launch_bounds__(256) void sw_pilot(const __bf16 *__restrict__ xw, const float *__restrict__ nb, int64_t row0, int64_t row1,
+                                                int ntiles, int pt_tiles, float gscale, float *__restrict__ tloose) {
+    using TL = Tile<H>;
+    constexpr int HW = TL::HW, KS1 = TL::KS1, STRIDE = TL::STRIDE, CPC = TL::CPC, LQ = TL::LQ;
+    __shared__ __attribute__((aligned(16))) unsigned char colA[TL::BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), r = lane & 31, hh = lane >> 5;
+    const int64_t i = row0 + (int64_t)blockIdx.x * 128 + wave * 32 + r;
+    const bool rvalid = i < row1;
+    const int64_t ic = rvalid ? i : row1 - 1;
+    bf16x8 bfr[KS1];
+#pragma unroll
+    for (int s = 0; s < KS1 - 1; s++) bfr[s] = *reinterpret_cast<const bf16x8 *>(xw + ic * HW + 16 * s + 8 * hh);
+    bfr[KS1 - 1] = aug_row(0.0f, hh);
+    float tm[PILOT_M];
+#pragma unroll
+    for (int q = 0; q < PILOT_M; q++) tm[q] = -3.0e38f;
+    const int stride_t = ntiles / pt_tiles;
+    const int first_t = (int)(((uint32_t)blockIdx.x * 2654435761u) % (uint32_t)stride_t);
+    for (int pt = 0; pt < pt_tiles; pt++) {
+        const int64_t c0 = (int64_t)(first_t + pt * stride_t) * TC;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < LQ; q++) {
+            const int ch = q * 256 + tid;
+            const uint4 v = *reinterpret_cast<const uint4 *>(xw + c0 * HW + (int64_t)ch * 8);
+            *reinterpret_cast<uint4 *>(&colA[(ch / CPC) * STRIDE + (ch % CPC) * 16]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < TC / 32; sub++) {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[q] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KS1; s++) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(&colA[(sub * 32 + r) * STRIDE + (16 * s + 8 * hh) * 2]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[s], acc, 0, 0, 0);
+            }
+            float m = acc[0];
+#pragma unroll
+            for (int q = 1; q < 15; q += 2) m = fmaxf(fmaxf(m, acc[q]), acc[q + 1]);
+            m = fmaxf(m, acc[15]);
+            if (m > tm[PILOT_M - 1]) {
+#pragma unroll
+                for (int q = 0; q < PILOT_M; q++) { const float hi = fmaxf(m, tm[q]); m = fminf(m, tm[q]); tm[q] = hi; }
+            }
+        }
+    }
+    // L of the PILOT_M-th best of this half row; the radius covers both halves
+    const float nbi = nb[ic];
+    float L = fmaf(-2.0f, tm[PILOT_M - 1], nbi);
+    L = fmaxf(L, __shfl_xor(L, 32, 64));
+    const float R = fmaxf(L, 0.0f) * gscale + 1e-6f;
+    if (rvalid && hh == 0) tloose[i - row0] = 0.5f * (R - nbi) + 1e-6f * (fabsf(R) + fabsf(nbi)) + 1e-7f;
+}
+
+// ---- sweep ---------------------------------------------------------------------------------------------------------------------
+// VALUES = true (phase A): tiles 4w, records (column, D bits); false (phase B): the other tiles, records bare columns.
+// Workgroup -> (row block, segment): same-XCD workgroups (blockIdx % 8, observed round-robin placement; speed only) walk the same
+// segment's tiles at about the same time, so a staged tile is an L2 hit for all but the first of them.
+template <int H, int RBLK, bool VALUES>
+__global__ __launch_bounds__(256, 2) void sw_sweep(const __bf16 *__restrict__ xw, const float *__restrict__ trow, int64_t npad, int64_t row0, int64_t row1,
+                                                   int nset, int nrb, int rbx, int CS, int cap, void *__restrict__ lists,
+                                                   unsigned short *__restrict__ cnts) {
+    using TL = Tile<H>;
+    constexpr int HW = TL::HW, KS1 = TL::KS1, STRIDE = TL::STRIDE, CPC = TL::CPC, LQ = TL::LQ;
+    constexpr int QC = H == 128 ? 1 : 2;                                // queue slots per lane and row block (LDS budget: 2 workgroups per CU)
+    __shared__ __attribute__((aligned(16))) unsigned char colA[2][TL::BYTES];
+    __shared__ int32_t hq[RBLK][QC][256];
+    __shared__ float hv[VALUES ? RBLK : 1][VALUES ? QC : 1][VALUES ? 256 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), r = lane & 31, hh = lane >> 5;
+    const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int seg = kk / rbx, rowblk = (kk % rbx) * 8 + xcd;
+    if (rowblk >= nrb) return;                                          // (uniform per workgroup)
+    const int64_t rbase = row0 + (int64_t)rowblk * (128 * RBLK) + (int64_t)wave * (32 * RBLK);
+
+    bf16x8 bfr[RBLK][KS1];
+    uint32_t pos[RBLK], lim[RBLK];                                      // byte offsets (next free slot / end) of this lane's private lists,
+    bool rvalid[RBLK];                                                  // relative to the workgroup's first row (always < 2^32)
+    constexpr uint32_t REC = VALUES ? 8u : 4u;
+    const int64_t wg_lrow0 = (int64_t)rowblk * (128 * RBLK);
+    char *const wg_lists = reinterpret_cast<char *>(lists) + wg_lrow0 * CS * 2 * cap * REC;
+#pragma unroll
+    for (int b = 0; b < RBLK; b++) {
+        const int64_t i = rbase + b * 32 + r;
+        rvalid[b] = i < row1;
+        const int64_t ic = rvalid[b] ? i : row1 - 1;
+#pragma unroll
+        for (int s = 0; s < KS1 - 1; s++) bfr[b][s] = *reinterpret_cast<const bf16x8 *>(xw + ic * HW + 16 * s + 8 * hh);
+        bfr[b][KS1 - 1] = aug_row(rvalid[b] ? trow[ic - row0] : -3.0e38f, hh);
+        pos[b] = (uint32_t)((((ic - row0 - wg_lrow0) * CS + seg) * 2 + hh) * cap) * REC;
+        lim[b] = pos[b] + (uint32_t)cap * REC;
+    }
+    uint32_t pos0[RBLK];
+    int qn[RBLK];
+#pragma unroll
+    for (int b = 0; b < RBLK; b++) { pos0[b] = pos[b]; qn[b] = 0; }
+
+    uint4 stg[LQ];
+    auto tile_load = [&](int w) {
+        const int64_t c0 = (int64_t)(VALUES ? tileA(w) : tileB(w)) * TC;
+#pragma unroll
+        for (int q = 0; q < LQ; q++) {      // (zero + conditional load: the unconditional form makes the compiler keep `stg` in scratch memory)
+            stg[q] = make_uint4(0, 0, 0, 0);
+            if (c0 < npad) stg[q] = *reinterpret_cast<const uint4 *>(xw + c0 * HW + (int64_t)(q * 256 + tid) * 8);
+        }
+    };
+    auto tile_store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < LQ; q++) {
+            const int ch = q * 256 + tid;
+            *reinterpret_cast<uint4 *>(&colA[buf][(ch / CPC) * STRIDE + (ch % CPC) * 16]) = stg[q];
+        }
+    };
+    auto chain = [&](const bf16x8 (&af)[KS1], int b) {
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[q] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS1; s++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bfr[b][s], acc, 0, 0, 0);
+        return acc;
+    };
+    // hits of one 32 x 32 block: sign bits of the 16 accumulators -> bit q of a per-lane mask (two independent chains), one
+    // wave-uniform branch.  A lane with hits parks them in its LDS queue (QC slots per row block); the queues are flushed to the
+    // lane's private global lists once per tile, BEFORE the next tile's loads are issued: vector-memory operations retire in
+    // order, so a store issued per hit inside the tile made the s_waitcnt on the tile loads wait for the youngest hit store
+    // (wait share 0.37 of the wavefront cycles, 1.08 ms); stores at the top of a tile are long done when that wait comes.
+    auto append = [&](int b, int col, float best) {
+        if (pos[b] < lim[b]) {
+            if (VALUES) *reinterpret_cast<int2 *>(wg_lists + pos[b]) = make_int2(col, __float_as_int(best));
+            else *reinterpret_cast<int32_t *>(wg_lists + pos[b]) = col;
+        }
+        pos[b] += REC;
+    };
+    auto process = [&](const f32x16 &acc, int b, uint32_t colb) {
+        uint32_t m0 = 0u, m1 = 0u;
+#pragma unroll
+        for (int q = 7; q >= 0; q--) {
+            m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(acc[q]), 31u);
+            m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(acc[q + 8]), 31u);
+        }
+#ifdef DGG_SW_NOTEST     // timing experiment only (wrong results): one sign bit instead of 16
+        const uint32_t mask = (__float_as_uint(acc[0]) >> 31) | ((__float_as_uint(acc[15]) >> 31) << 20);
+#else
+        const uint32_t mask = m0 | (m1 << 8);                           // 1 = outside the radius
+#endif
+#ifdef DGG_SW_NOHIT      // timing experiment only (wrong results): hits are never recorded
+        if (mask == (uint32_t)nset + 0x12345u) {
+#else
+        if (__ballot(mask != 0xffffu) != 0ull) {
+#endif                        // wave-uniform: some lane has a hit in this block
+            uint32_t hm = ~mask & 0xffffu;
+            float best = 0.0f;
+            if (VALUES) {       // the lane's LARGEST D of the block stands for each of its hits (a lane with two hits in one block --
+                                // 3 % of the hitting lanes -- gets the better value twice; sw_select allows for it)
+                best = acc[0];
+#pragma unroll
+                for (int q = 1; q < 15; q += 2) best = fmaxf(fmaxf(best, acc[q]), acc[q + 1]);
+                best = fmaxf(best, acc[15]);
+            }
+            while (hm != 0u) {
+                const int q = __builtin_ctz(hm);
+                hm &= hm - 1u;
+                const int col = (int)(colb + (uint32_t)((q & 3) | ((q & 12) << 1)));
+                if (qn[b] < QC) {
+                    hq[b][qn[b]][tid] = col;
+                    if (VALUES) hv[VALUES ? b : 0][VALUES ? qn[b] : 0][tid] = best;
+                } else append(b, col, best);                            // queue full (rare): straight to the list
+                qn[b]++;
+            }
+        }
+    };
+    auto flush = [&]() {
+#pragma unroll
+        for (int b = 0; b < RBLK; b++) {
+#pragma unroll
+            for (int e = 0; e < QC; e++) {
+                if (__ballot(qn[b] > e) != 0ull) {
+                    if (qn[b] > e) append(b, hq[b][e][tid], VALUES ? hv[VALUES ? b : 0][VALUES ? e : 0][tid] : 0.0f);
+                }
+            }
+            qn[b] = 0;
+        }
+    };
+    auto load_af = [&](bf16x8 (&af)[KS1], int buf, int sub) {
+#pragma unroll
+        for (int s = 0; s < KS1; s++) af[s] = *reinterpret_cast<const bf16x8 *>(&colA[buf][(sub * 32 + r) * STRIDE + (16 * s + 8 * hh) * 2]);
+    };
+
+    int w = seg;
+    if (w < nset) { tile_load(w); tile_store(0); }
+    __syncthreads();
+    for (int it = 0; w < nset; w += CS, it++) {
+#ifdef DGG_SW_NOSTAGE
+        const int buf = 0;
+#else
+        const int buf = it & 1;
+#endif
+        const bool more = w + CS < nset;
+        flush();                                                        // the previous tile's hits
+#ifndef DGG_SW_NOSTAGE
+        if (more) tile_load(w + CS);                                    // in flight during the MFMAs below
+#endif
+        const uint32_t cbase = (uint32_t)(VALUES ? tileA(w) : tileB(w)) * TC + (uint32_t)(4 * hh);
+        // software pipeline over the tile's 4 x RBLK blocks: the MFMA chain of block n + 1 is issued before the sign tests of
+        // block n, so the matrix pipe runs while the wavefront does its vector work
+        bf16x8 afA[KS1], afB[KS1];
+        load_af(afA, buf, 0);
+        f32x16 cur = chain(afA, 0);
+#pragma unroll
+        for (int sub = 0; sub < TC / 32; sub++) {
+            bf16x8 (&af)[KS1] = (sub & 1) ? afB : afA;
+            bf16x8 (&afn)[KS1] = (sub & 1) ? afA : afB;
+            if (sub + 1 < TC / 32) load_af(afn, buf, sub + 1);
+#pragma unroll
+            for (int b = 0; b < RBLK; b++) {
+                f32x16 nxt;
+                const bool last = (sub + 1 == TC / 32) && (b + 1 == RBLK);
+                if (!last) nxt = (b + 1 < RBLK) ? chain(af, b + 1) : chain(afn, 0);
+                process(cur, b, cbase + (uint32_t)(sub * 32));
+                if (!last) cur = nxt;
+            }
+        }
+#ifndef DGG_SW_NOSTAGE
+        if (more) tile_store(buf ^ 1);
+        __syncthreads();
+#endif
+    }
+    flush();
+#pragma unroll
+    for (int b = 0; b < RBLK; b++) {
+        if (rvalid[b]) {
+            const int64_t lrow = rbase + b * 32 + r - row0;
+            const uint32_t n = (pos[b] - pos0[b]) / REC;
+            cnts[(lrow * CS + seg) * 2 + hh] = (unsigned short)(n > 0xffffu ? 0xffffu : n);
+        }
+    }
+}
+
+// ---- select: tight radius from the phase-A hits -------------------------------------------------------------------------------
+// one wavefront per row.  D (loose) = <.,.> + c_j + t_loose is what phase A recorded; L = R_loose - 2 D is the pair's LOWER bound
+// and U = L + SL (nb_i + nb_j) an UPPER bound of d^2 (both roundings of the bf16 products the other way).  The verification
+// needs 64 columns with TRUE distance inside the radius, so the tight radius is the m-th smallest UPPER bound of the sample
+// (m = 26 of a 1/4 sample: >= 64 in N with probability 0.995, whatever the density of the shell the radius falls into):
+// D' = D - SL (nb_i + nb_j) / 2, cut = m-th largest D' (>= 0: never looser than the loose radius), t_tight = t_loose - cut.
+// A phase-A hit lies inside the tight radius iff D >= cut.
+constexpr float SL_UPPER = (EPS_BF16 + 0.0039102f) / (1.0f - EPS_BF16) * 1.0001f;
+__global__ __launch_bounds__(256) void sw_select(const int2 *__restrict__ listA, const unsigned short *__restrict__ cntA, int64_t rows, int64_t row0,
+                                                 int CSA, int capA, int m, const float *__restrict__ nb, const float *__restrict__ tloose,
+                                                 float *__restrict__ ttight, float *__restrict__ selA) {
+    const int lane = threadIdx.x & 63;
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
+    if (lrow >= rows) return;
+    const float nbi = nb[row0 + lrow];
+    uint64_t list = 0ull;                                              // descending; keys = (order-preserving bits of D') << 32 | 1
+    int total = 0;
+    bool over = false;
+    for (int s = 0; s < 2 * CSA; s++) {
+        int n = cntA[lrow * 2 * CSA + s];
+        if (n > capA) { over = true; n = capA; }
+        total += n;
+        const int2 *l = listA + (lrow * 2 * CSA + s) * capA;
+        for (int base = 0; base < n; base += 64) {
+            const int e = base + lane;
+            uint64_t key = 0ull;
+            if (e < n) {
+                const int2 c = l[e];
+                const float dp = __int_as_float(c.y) - 0.5f * SL_UPPER * (nbi + nb[c.x]);
+                const uint32_t u = __float_as_uint(dp);
+                key = ((uint64_t)(u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u)) << 32) | 1ull;
+            }
+            key = wave_sort<false>(key, lane);
+            list = wave_merge_top64_asc(list, key, lane);
+        }
+    }
+    const float tl = tloose[lrow];
+    float tt = tl, sel = 0.0f;
+    if (!over && total >= m) {
+        const uint32_t ku = (uint32_t)(shfl_u64(list, m - 1) >> 32);
+        const float cut = fmaxf(__uint_as_float(ku ^ ((ku >> 31) ? 0x80000000u : 0xffffffffu)), 0.0f);
+        const float slack = 1e-6f * (fabsf(tl) + cut) + 1e-7f;
+        tt = fminf(tl, tl - cut + slack);
+        sel = fmaxf(cut - 2.0f * slack, 0.0f);
+    }
+    if (lane == 0) { ttight[lrow] = tt; selA[lrow] = sel; }
+}
+
+// exact canonical score of pair (i, j); i is wave-uniform (its features come through the scalar cache)
+template <int H>
+__device__ __forceinline__ float exact_score0(const float *__restrict__ xp, int64_t i, int32_t j, float t) {
+    const float *xi = xp + i * H;
+    const float4 *xj = reinterpret_cast<const float4 *>(xp + (int64_t)j * H);
+    float4 b[H / 4];
+#pragma unroll
+    for (int c4 = 0; c4 < H / 4; c4++) b[c4] = xj[c4];
+    float d2 = 0.0f;
+#pragma unroll
+    for (int c4 = 0; c4 < H / 4; c4++) {
+        float df;
+        df = __fadd_rn(xi[4 * c4 + 0], -b[c4].x); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[4 * c4 + 1], -b[c4].y); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[4 * c4 + 2], -b[c4].z); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[4 * c4 + 3], -b[c4].w); d2 = __fmaf_rn(df, df, d2);
+    }
+    return score_from_dist(c_sqrt(d2), t, false, 0.0f);
+}
+
+// ---- finalize -----------------------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp, const float *__restrict__ nb, int64_t row0, int64_t row1, float t,
+                                                   const int2 *__restrict__ listA, const unsigned short *__restrict__ cntA, int CSA, int capA,
+                                                   const float *__restrict__ selA, const int32_t *__restrict__ listB,
+                                                   const unsigned short *__restrict__ cntB, int CSB, int capB,
+                                                   const float *__restrict__ ttight, SweepCtl *__restrict__ ctl, int *__restrict__ faillist,
+                                                   int32_t *__restrict__ idx, float *__restrict__ val) {
+    __shared__ int32_t ring[4][128];
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id();
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t i = row0 + lrow;
+    if (i >= row1) return;
+    int32_t *rg = ring[wave];
+    uint64_t list = DGG_EMPTY_KEY;
+    int head = 0, tail = 0;                                            // wave-uniform, monotone; slot = index & 127
+    bool ok = true;
+    int nA = 0, nAk = 0, nB = 0;
+    auto score_batch = [&](int n) {                                    // the n (<= 64) oldest columns of the ring
+        const int32_t j = lane < n ? rg[(head + lane) & 127] : -1;
+        head += n;
+        uint64_t key = DGG_EMPTY_KEY;
+        if (j >= 0) key = make_key(exact_score0<H>(xp, i, j, t), j);
+        key = wave_sort<false>(key, lane);
+        list = wave_merge_top64_asc(list, key, lane);
+    };
+    auto push = [&](bool keep, int32_t col) {
+        const unsigned long long m = __ballot(keep);
+        if (keep) rg[(tail + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & 127] = col;
+        tail += __builtin_popcountll(m);
+        if (tail - head >= 64) score_batch(64);
+    };
+    const float sel = selA[lrow];
+    for (int s = 0; s < 2 * CSA; s++) {
+        int n = cntA[lrow * 2 * CSA + s];
+        if (n > capA) { ok = false; n = capA; }
+        nA += n;
+        const int2 *l = listA + (lrow * 2 * CSA + s) * capA;
+        for (int base = 0; base < n; base += 64) {
+            const int e = base + lane;
+            bool keep = false;
+            int32_t col = 0;
+            if (e < n) { const int2 c = l[e]; col = c.x; keep = __int_as_float(c.y) >= sel; }
+            nAk += __builtin_popcountll(__ballot(keep));
+            push(keep, col);
+        }
+    }
+    for (int s = 0; s < 2 * CSB; s++) {
+        int n = cntB[lrow * 2 * CSB + s];
+        if (n > capB) { ok = false; n = capB; }
+        nB += n;
+        const int32_t *l = listB + (lrow * 2 * CSB + s) * capB;
+        for (int base = 0; base < n; base += 64) {
+            const int e = base + lane;
+            push(e < n, e < n ? l[e] : 0);
+        }
+    }
+    if (tail != head) score_batch(tail - head);
+    // verification: full list, and its 64th distance (+ margins for the log and the rounding of the canonical exp) inside the
+    // radius the sweeps tested against: R = nb_i + 2 t_tight
+    const uint64_t k63 = shfl_u64(list, 63);
+    if (k63 == DGG_EMPTY_KEY) ok = false;
+    if (ok) {
+        const float d63 = c_log(fmaxf(key_val(k63), 1e-37f)) / t + 1e-5f;
+        const float R = fmaf(2.0f, ttight[lrow], nb[i]);
+        ok = d63 * d63 * (1.0f + 1e-5f) <= R * (1.0f - 1e-5f) - 1e-7f * nb[i];
+    }
+    if (ok) {
+        idx[lrow * 64 + lane] = key_col(list);
+        val[lrow * 64 + lane] = key_val(list);
+    } else if (lane == 0) {
+        faillist[atomicAdd(&ctl->nfail, 1)] = (int)lrow;
+    }
+    if (ctl->stats_on && lane == 0) {
+        atomicAdd(&ctl->nA, (unsigned long long)nA);
+        atomicAdd(&ctl->nAkept, (unsigned long long)nAk);
+        atomicAdd(&ctl->nB, (unsigned long long)nB);
+    }
+}
+
+// ---- fallback: rows whose radius failed verification, every column scored exactly ------------------------------------------------
+// The first FB_MAX failed rows are split over FB_NCH column chunks each (a handful of failed rows must not run as a handful of
+// workgroups: 3 rows took 0.69 ms that way): sw_fallback_part keeps a chunk's best 64, sw_fallback_merge merges a row's chunks.
+// Rows beyond FB_MAX (every guess wrong: adversarial input) are redone by sw_fallback_rows, one workgroup per row at a time.
+constexpr int FB_MAX = 4096, FB_NCH = 32;
+template <int H>
+__device__ __forceinline__ uint64_t fallback_scan(const float *__restrict__ xp, int64_t i, int64_t c0, int64_t c1, float t, uint64_t (&lists)[4][64],
+                                                  int lane, int wave) {
+    uint64_t list = DGG_EMPTY_KEY;
+    for (int64_t j0 = c0 + (int64_t)wave * 64; j0 < c1; j0 += 256) {
+        const int64_t j = j0 + lane;
+        uint64_t key = DGG_EMPTY_KEY;
+        if (j < c1) key = make_key(exact_score0<H>(xp, i, (int32_t)j, t), (int32_t)j);
+        key = wave_sort<false>(key, lane);
+        list = wave_merge_top64_asc(list, key, lane);
+    }
+    lists[wave][lane] = list;
+    __syncthreads();
+    if (wave == 0)
+        for (int w = 1; w < 4; w++) list = wave_merge_top64_asc(list, wave_sort<false>(lists[w][lane], lane), lane);
+    __syncthreads();
+    return list;                                                       // valid in wavefront 0
+}
+template <int H>
+__global__ __launch_bounds__(256) void sw_fallback_part(const float *__restrict__ xp, int64_t N, int64_t row0, float t, const SweepCtl *__restrict__ ctl,
+                                                        const int *__restrict__ faillist, uint64_t *__restrict__ partial) {
+    __shared__ uint64_t lists[4][64];
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id();
+    const int nf = ctl->nfail < FB_MAX ? ctl->nfail : FB_MAX;
+    const int64_t chunk = (N + FB_NCH - 1) / FB_NCH;
+    for (int item = blockIdx.x; item < nf * FB_NCH; item += gridDim.x) {
+        const int f = item / FB_NCH, c = item % FB_NCH;
+        const int64_t c0 = c * chunk, c1 = (c0 + chunk < N) ? c0 + chunk : N;
+        const uint64_t list = fallback_scan<H>(xp, row0 + faillist[f], c0, c1 > c0 ? c1 : c0, t, lists, lane, wave);
+        if (wave == 0) partial[(int64_t)item * 64 + lane] = list;
+    }
+}
+__global__ __launch_bounds__(256) void sw_fallback_merge(const SweepCtl *__restrict__ ctl, const int *__restrict__ faillist,
+                                                         const uint64_t *__restrict__ partial, int32_t *__restrict__ idx, float *__restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    const int nf = ctl->nfail < FB_MAX ? ctl->nfail : FB_MAX;
+    for (int f = blockIdx.x * 4 + dgg::wave_id(); f < nf; f += gridDim.x * 4) {
+        uint64_t list = DGG_EMPTY_KEY;
+        for (int c = 0; c < FB_NCH; c++) list = wave_merge_top64_asc(list, wave_sort<false>(partial[((int64_t)f * FB_NCH + c) * 64 + lane], lane), lane);
+        const int lrow = faillist[f];
+        const bool empty = list == DGG_EMPTY_KEY;
+        idx[(int64_t)lrow * 64 + lane] = empty ? -1 : key_col(list);
+        val[(int64_t)lrow * 64 + lane] = empty ? 0.0f : key_val(list);
+    }
+}
+template <int H>
+__global__ __launch_bounds__(256) void sw_fallback_rows(const float *__restrict__ xp, int64_t N, int64_t row0, float t, const SweepCtl *__restrict__ ctl,
+                                                        const int *__restrict__ faillist, int32_t *__restrict__ idx, float *__restrict__ val) {
+    __shared__ uint64_t lists[4][64];
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id();
+    const int nfail = ctl->nfail;
+    for (int f = FB_MAX + blockIdx.x; f < nfail; f += gridDim.x) {
+        const int lrow = faillist[f];
+        const uint64_t list = fallback_scan<H>(xp, row0 + lrow, 0, N, t, lists, lane, wave);
+        if (wave == 0) {
+            const bool empty = list == DGG_EMPTY_KEY;
+            idx[(int64_t)lrow * 64 + lane] = empty ? -1 : key_col(list);
+            val[(int64_t)lrow * 64 + lane] = empty ? 0.0f : key_val(list);
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------
+static float env_float(const char *name, float dflt) {
+    const char *e = getenv(name);
+    return e ? (float)atof(e) : dflt;
+}
+// headroom on the pilot's radius; tests shrink it (DGG_FAST_GUESS_SCALE) to force the verification / fallback path
+static const float g_guess_scale = env_float("DGG_FAST_GUESS_SCALE", 1.02f);
+// order statistic (of the UPPER bounds) of the phase-A sample that becomes the tight radius (<= 64); 0 disables the tightening (B runs with the loose radius)
+static const int g_select_m = (int)env_float("DGG_SWEEP_M", 32.0f);
+static const int g_stats = (int)env_float("DGG_SWEEP_STATS", 0.0f);
+
+Plan make_plan(int64_t rows, int64_t N, int h) {
+    Plan p;
+    p.rows = rows; p.N = N;
+    p.ntiles = (int)((N + TC - 1) / TC);
+    p.npad = (int64_t)p.ntiles * TC;
+    p.nA = (p.ntiles + 3) / 4;
+    p.nB = p.ntiles - p.nA;
+#ifdef DGG_SW_RBLK
+    p.rblk = DGG_SW_RBLK;
+#else
+    p.rblk = h <= 64 ? 4 : 2;
+#endif
+    p.rw = 128 * p.rblk;
+    p.nrb = (int)((rows + p.rw - 1) / p.rw);
+    p.rbx = (p.nrb + 7) / 8;
+    // column segments per row block: ~2 x 512 resident workgroups for the long phase, its share for the short one
+    auto segs = [&](int target, int nset) {
+        int cs = (target + p.nrb / 2) / (p.nrb > 0 ? p.nrb : 1);
+        cs = cs < 1 ? 1 : cs;
+        cs = cs > 16 ? 16 : cs;
+        while (cs > 1 && nset / cs < 4) cs--;                           // at least a few tiles per workgroup
+        return cs;
+    };
+    p.csb = segs(1000, p.nB);
+    p.csa = segs(500, p.nA);
+    p.capa = CAPA_ROW / (2 * p.csa);
+    p.capb = CAPB_ROW / (2 * p.csb);
+    int pt = (int)((int64_t)p.ntiles * 2 * PILOT_M / LOOSE_TARGET);
+    p.pt = pt < 1 ? 1 : pt;
+    return p;
+}
+
+struct Layout {
+    size_t xw, nb, ctl, fail, tl, tt, sel, cnta, cntb, la, lb, part, total;
+};
+Layout make_layout(const Plan &p, int h) {
+    Layout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    L.xw = take((size_t)p.npad * (h + 16) * 2);
+    L.nb = take((size_t)p.N * 4);
+    L.ctl = take(sizeof(SweepCtl));
+    L.fail = take((size_t)p.rows * 4);
+    L.tl = take((size_t)p.rows * 4);
+    L.tt = take((size_t)p.rows * 4);
+    L.sel = take((size_t)p.rows * 4);
+    // (per-row arrays at their worst case over the segment counts, so that the size depends on rows and N only)
+    L.cnta = take((size_t)p.rows * 2 * 16 * 2);
+    L.cntb = take((size_t)p.rows * 2 * 16 * 2);
+    L.la = take((size_t)p.rows * CAPA_ROW * 8);
+    L.lb = take((size_t)p.rows * CAPB_ROW * 4);
+    L.part = take((size_t)(p.rows < FB_MAX ? p.rows : FB_MAX) * FB_NCH * 64 * 8);
+    L.total = off;
+    return L;
+}
+
+template <int H, int RBLK>
+int launch_sweep(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, int32_t *idx, float *val, void *ws, hipStream_t st) {
+    const Plan p = make_plan(row1 - row0, N, H);
+    const Layout L = make_layout(p, H);
+    char *w = reinterpret_cast<char *>(ws);
+    __bf16 *xw = reinterpret_cast<__bf16 *>(w + L.xw);
+    float *nb = reinterpret_cast<float *>(w + L.nb);
+    SweepCtl *ctl = reinterpret_cast<SweepCtl *>(w + L.ctl);
+    int *faillist = reinterpret_cast<int *>(w + L.fail);
+    float *tl = reinterpret_cast<float *>(w + L.tl), *tt = reinterpret_cast<float *>(w + L.tt), *sel = reinterpret_cast<float *>(w + L.sel);
+    unsigned short *cnta = reinterpret_cast<unsigned short *>(w + L.cnta), *cntb = reinterpret_cast<unsigned short *>(w + L.cntb);
+    int2 *la = reinterpret_cast<int2 *>(w + L.la);
+    int32_t *lb = reinterpret_cast<int32_t *>(w + L.lb);
+    uint64_t *part = reinterpret_cast<uint64_t *>(w + L.part);
+    // (the control block is set by a memset + a 4-byte memset pattern: no host memory is read asynchronously)
+    if (dgg_check_hip(hipMemsetAsync(ctl, 0, sizeof(SweepCtl), st), "sweep memset") != 0) return DGG_ERR_HIP;
+    if (g_stats && dgg_check_hip(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&ctl->stats_on), 1, 1, st), "sweep memset") != 0) return DGG_ERR_HIP;
+    const int64_t rows = row1 - row0;
+    hipLaunchKernelGGL(sw_prep<H>, dim3((unsigned)((p.npad + 3) / 4)), dim3(256), 0, st, xp, N, p.npad, xw, nb);
+    hipLaunchKernelGGL(sw_pilot<H>, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, st, xw, nb, row0, row1, p.ntiles, p.pt, g_guess_scale, tl);
+    hipLaunchKernelGGL((sw_sweep<H, RBLK, true>), dim3((unsigned)(8 * p.rbx * p.csa)), dim3(256), 0, st, xw, tl, p.npad, row0, row1, p.nA, p.nrb, p.rbx, p.csa,
+                       p.capa, (void *)la, cnta);
+    const int m = g_select_m > 64 ? 64 : g_select_m;
+    hipLaunchKernelGGL(sw_select, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, la, cnta, rows, row0, p.csa, p.capa, m > 0 ? m : (1 << 30), nb, tl, tt, sel);
+    hipLaunchKernelGGL((sw_sweep<H, RBLK, false>), dim3((unsigned)(8 * p.rbx * p.csb)), dim3(256), 0, st, xw, tt, p.npad, row0, row1, p.nB, p.nrb, p.rbx, p.csb,
+                       p.capb, (void *)lb, cntb);
+    hipLaunchKernelGGL(sw_finalize<H>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xp, nb, row0, row1, t, la, cnta, p.csa, p.capa, sel, lb,
+                       cntb, p.csb, p.capb, tt, ctl, faillist, idx, val);
+    hipLaunchKernelGGL(sw_fallback_part<H>, dim3(1024), dim3(256), 0, st, xp, N, row0, t, ctl, faillist, part);
+    hipLaunchKernelGGL(sw_fallback_merge, dim3(256), dim3(256), 0, st, ctl, faillist, part, idx, val);
+    hipLaunchKernelGGL(sw_fallback_rows<H>, dim3(512), dim3(256), 0, st, xp, N, row0, t, ctl, faillist, idx, val);
+    return dgg_check_launch("allpairs_topk_sweep");
+}
+
+}  // namespace
+
+size_t dgg_allpairs_sweep_ws_bytes(int64_t rows, int64_t N, int h) { return make_layout(make_plan(rows, N, h), h).total; }
+// byte offset of the control block {int nfail; int stats_on; u64 nA, nAkept, nB} inside the workspace (diagnostics)
+size_t dgg_allpairs_sweep_ctl_offset(int64_t rows, int64_t N, int h) { return make_layout(make_plan(rows, N, h), h).ctl; }
+
+bool dgg_allpairs_sweep_supported(int h, int noise_mode, int K) {
+    return K == 64 && (h == 16 || h == 32 || h == 64 || h == 128) && noise_mode == 0;
+}
+
+int dgg_allpairs_topk_sweep_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int K, int32_t *idx, float *val,
+                                 void *workspace, size_t ws_bytes, hipStream_t st) {
+    if (!dgg_allpairs_sweep_supported(h, 0, K))
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "unperturbed sweep needs K=64 and latent_dim in {16,32,64,128}");
+    if (row1 <= row0) return 0;
+    if (!workspace || ws_bytes < dgg_allpairs_sweep_ws_bytes(row1 - row0, N, h))
+        return dgg_set_error(DGG_ERR_ARG, "unperturbed sweep: workspace too small (dgg_allpairs_workspace_bytes)");
+    switch (h) {
+        case 16: return launch_sweep<16, 4>(xp, N, row0, row1, t, idx, val, workspace, st);
+        case 32: return launch_sweep<32, 4>(xp, N, row0, row1, t, idx, val, workspace, st);
+#ifdef DGG_SW_RBLK
+        case 64: return launch_sweep<64, DGG_SW_RBLK>(xp, N, row0, row1, t, idx, val, workspace, st);
+#else
+        case 64: return launch_sweep<64, 4>(xp, N, row0, row1, t, idx, val, workspace, st);
+#endif
+        default: return launch_sweep<128, 2>(xp, N, row0, row1, t, idx, val, workspace, st);
+    }
+}

@@ -259,6 +259,18 @@ def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed
     return idx, val
 
 
+def fast_path_failed_rows(ws, N, h, rows=None, stats=False):
+    """diagnostics of the unperturbed sweep (noise_mode 0, N >= 8192): rows of the last call that failed the verification of
+    their guessed radius and were redone by the exhaustive fallback (synchronises); stats=True also returns the candidate
+    sums (phase-A hits, those inside the tight radius, phase-B hits; collected only under DGG_SWEEP_STATS=1)"""
+    off = int(_lib.lib().dgg_allpairs_sweep_ctl_offset_bytes(N if rows is None else rows, N, h))
+    blk = ws[off:off + 32].cpu()
+    nfail = int(blk[0:4].view(torch.int32).item())
+    if not stats:
+        return nfail
+    return nfail, [int(v) for v in blk[8:32].view(torch.int64)]
+
+
 def allpairs_topk_softk(xp, k, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, seed=(0, 0), rows=None):
     """ranked-noise all-pairs top-64 with the first-k ramp fused (allpairs_topk(k_limit=k) + softk_fwd in one launch)
     -> idx, val, w [rows,64], rs [rows]"""

@@ -443,6 +443,77 @@ def test_full_size_symmetric_noise_triangular_sweep(dev):
         assert torch.equal(sub_i, idx[lo:hi]) and torch.equal(sub_v, val[lo:hi])
 
 
+@pytest.mark.parametrize("clustered", [False, True])
+def test_full_size_unperturbed_sweep(dev, clustered):
+    """N = 100k, NO perturbation -- the reference script's own default (`perturb_edge_prob=False`, train_small_graphs.py:158-163;
+    dgm.py:1230-1231, sort at 1404): the only path whose result depends on all N^2 distances.  Two-phase guess-sweep-verify
+    (bf16 MFMA bounds, exact finalize, dgg_topk_sweep.hip) at the size where its many-workgroup / candidate-overflow / fallback
+    regime is reached: list invariants, self loop first (distance 0), oracle on sampled rows, row-range consistency.
+    Uniform data: at most 0.1 % of the rows may need the exhaustive fallback (the speed contract of the radius guesses).
+    Clustered data (a tight blob of 3000 nodes + 40 far outliers): every row that has the blob inside its 64-NN shell holds
+    thousands of candidates that bf16 bounds cannot separate -- its lists overflow and the fallback settles it; results must
+    still be exact."""
+    from dgg_amd import ops
+    N, d, h = 100_000, 128, 64
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(N, d, generator=g)
+    rows = [0, 1, 63, 64, 127, 128, 4097, 20_000, 21_500, 22_999, 23_000, 23_039, 23_040, 50_000, 99_872, 99_999]
+    if clustered:
+        x[20_000:23_000] *= 0.05                                  # tight cluster: tiny 64-NN radius
+        x[23_000:23_040] = x[23_000:23_040] * 0.01 + 3.0          # 40 far-away points: fewer than 64 close neighbours
+    x = x.to(dev)
+    W = (torch.randn(h, d, generator=g) * 0.1).to(dev)
+    b = (torch.randn(h, generator=g) * 0.1).to(dev)
+    xp = ops.linear_fwd(x, W, b, ops.ACT_LEAKY)
+    idx, val, ws = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_NONE, return_ws=True)
+    nfail = ops.fast_path_failed_rows(ws, N, h)
+    print(f"clustered={clustered}: {nfail} rows redone by the exhaustive fallback")
+    if not clustered:
+        assert nfail <= N // 1000, f"radius guess failed verification on {nfail} rows (results stay exact, speed suffers)"
+    assert (val[:, :-1] >= val[:, 1:]).all()
+    assert (idx >= 0).all() and (idx < N).all()
+    srt = idx.sort(dim=1).values
+    assert (srt[:, 1:] != srt[:, :-1]).all(), "duplicate column in a row"
+    assert torch.equal(idx[:, 0], torch.arange(N, device=dev, dtype=idx.dtype)), "the self loop (distance 0) ranks first"
+    xp_c = xp.cpu().numpy()
+    for r in rows:
+        ri, rv = O.allpairs_topk(xp_c, K=K, noise_mode=O.NOISE_NONE, rows=(r, r + 1))
+        assert np.array_equal(Nn(idx[r]), ri[0]) and np.array_equal(Nn(val[r]), rv[0]), r
+    for lo, hi in [(0, 300), (22_900, 23_412), (99_700, N)]:
+        sub_i, sub_v = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_NONE, rows=(lo, hi))
+        assert torch.equal(sub_i, idx[lo:hi]) and torch.equal(sub_v, val[lo:hi])
+
+
+@pytest.mark.parametrize("N,h", [(1000, 64), (1537, 32)])
+def test_ranked_search_equals_explicit_noise_path_on_its_own_noise(dev, N, h):
+    """Closes the loop for the benchmarked kernel ON THE DEVICE: the ranked generator's noise matrix G is materialised on the host
+    (ora_ranked_row: the generator written out column by column), handed to the HIP EXPLICIT-noise path -- the one the reference
+    goldens pin (gumbel_sample(log_p, G), dgm.py:14-29, 1226-1229) -- and the result must equal the early-stopping ranked search
+    bit for bit: same indices, same scores."""
+    import ctypes as C
+    from dgg_amd import ops
+    rng = np.random.default_rng(N)
+    xp = rng.standard_normal((N, h)).astype(np.float32)
+    xp[xp < 0] *= 0.01
+    seed = (4321, 17)
+    G = np.empty((N, N), np.float32)
+    L = O.lib()
+    for i in range(N):
+        L.ora_ranked_row(C.c_uint32(seed[0]), C.c_uint32(seed[1]), C.c_uint32(i), C.c_int64(N), O._p(G[i]))
+    ei, ev = ops.allpairs_topk(T(xp, dev), K, noise_mode=ops.NOISE_EXPLICIT, G=T(G, dev))
+    ri, rv = ops.allpairs_topk(T(xp, dev), K, noise_mode=ops.NOISE_RANKED, seed=seed)
+    assert torch.equal(ei, ri), "ranked search and explicit-noise path disagree on the neighbour lists"
+    assert torch.equal(ev, rv), "ranked search and explicit-noise path disagree on the scores"
+    # and with the ramp fused in (the bench's entry point), against the explicit path + softk_fwd
+    k = T(rng.uniform(2.0, 50.0, N).astype(np.float32), dev)
+    fi, fv, fw, frs = ops.allpairs_topk_ranked_softk(T(xp, dev), k, seed=seed)
+    w, rs = ops.softk_fwd(ei, ev, k, 0)
+    kept = fi >= 0
+    assert torch.equal(fi[kept], ei[kept]) and torch.equal(fv[kept], ev[kept])
+    assert torch.equal(torch.where(kept, fw, torch.zeros_like(fw)), w * kept) and (w[~kept] == 0).all()
+    assert torch.equal(frs, rs)
+
+
 @pytest.mark.parametrize("name", ["model_gcn_dgg", "model_gcn_dgg_uvdeg", "model_gcnii_dgg", "model_gcniippi_dgg"])
 def test_model_wrappers_match_reference_golden(dev, name):
     """dgg_amd.GCN_DGG / GCNII_DGG / GCNIIppi_DGG (eval mode, explicit noise) against the reference's own wrappers
