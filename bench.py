@@ -34,6 +34,9 @@ FLOP_PER_PAIR = 232.0        # 3h (sub, mul, add) + ~40 (sqrt, e
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak fp32 vector = fp32 matrix
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s achievable
 GATHER_CEILING_GBPS = 8600.0 # MI355X_MICROARCH.md "Indexed rows": uniformly random rows of a 38 MB (Infinity-Cache resident) table
+BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (32 cycles per v_mfma_f32_32x32x16_bf16 per SIMD at 2.4 GHz)
+HASH_CYCLES_PER_WAVE_COLUMN = 21.0   # measured floor of the 6-VALU pair hash, cycles per wavefront and 64 pairs
+SIMD_CYCLES_PER_S = 1024 * 2.4e9     # 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
 # BASELINE.json's metric string (value = the edges/sec part; the HBM GB/s part is the `roofline` object)
 METRIC = "DGG adj-build+SpMM fwd/bwd edges/sec & achieved HBM GB/s, N=100k d=128 k=32"
 
@@ -461,9 +464,10 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--algo", type=int, default=0, help="all-pairs kernel for --noise hash: 0 auto, 1 exhaustive, 2 MFMA-bounded, "
                                                          "3 adaptive noise prefilter, 4 guess-and-verify")
-    ap.add_argument("--noise", choices=["ranked", "hash"], default="ranked",
-                    help="counter-based Gumbel generator: ranked (per-row order statistics, O(N*150) search) or hash "
-                         "(per-pair hash, N^2 sweep); both iid Gumbel(0,0.3)")
+    ap.add_argument("--noise", choices=["ranked", "hash", "sym", "none"], default="ranked",
+                    help="counter-based Gumbel generator: ranked (per-row order statistics, O(N*150) search), hash (per-pair hash, "
+                         "N^2 sweep), sym (symmetric per-pair hash: the reference's symmetric_noise=True), all iid Gumbel(0,0.3); "
+                         "none = unperturbed scores (the reference's perturb_edge_prob=False: bf16-MFMA-bounded N^2 sweep)")
     ap.add_argument("--x-grad", action="store_true", help="also compute d loss / d x (reduce-scatter across ranks)")
     ap.add_argument("--strong", action="store_true", help="(default for several GPUs; kept for compatibility)")
     ap.add_argument("--exchange", choices=["replicate", "gather"], default="replicate",
@@ -634,7 +638,7 @@ def bench_synthetic(a, dev, world, rank, force):
         N = per * max(world, emu) if weak else (a.nodes if a.nodes else 500_000)
     else:
         weak, N = True, (a.nodes if a.nodes else 100_000)
-    noise_mode = ops.NOISE_RANKED if a.noise == "ranked" else ops.NOISE_HASH
+    noise_mode = {"ranked": ops.NOISE_RANKED, "hash": ops.NOISE_HASH, "sym": ops.NOISE_HASH_SYM, "none": ops.NOISE_NONE}[a.noise]
     run = SyntheticRun(a, dev, world, rank, force, N, d, h, noise_mode, a.x_grad, emu, a.exchange)
     use_graph = a.hipgraph and (world == 1 and not force or os.environ.get("DGG_BENCH_GRAPH_DIST") == "1")
     times, graphed = time_windows(run, a, world, force, dev, use_graph, a.repeats)
@@ -723,7 +727,29 @@ def bench_synthetic(a, dev, world, rank, force):
                 pv, ops.PROBE = ops.PROBE, None
                 e0, e1 = pv["allpairs_topk"][0]
                 kv = float(rv.layer.saved["k"].mean().item())
-                variants[name] = {"ms_per_step": tv * 1e3, "edges_per_s": N * kv / tv, "pair_kernel_ms": e0.elapsed_time(e1), "steps": vsteps}
+                pk = e0.elapsed_time(e1)
+                variants[name] = {"ms_per_step": tv * 1e3, "edges_per_s": N * kv / tv, "pair_kernel_ms": pk, "steps": vsteps}
+                # roofline of the pair stage of the variants that sweep all N^2 pairs (one C-ABI call = several launches, event-timed as a
+                # whole; per-launch durations: profiles/r03_*_kernel_stats.csv)
+                if name == "unperturbed":
+                    flop = 2.0 * N * float(N) * lat                # ALGORITHMIC: one h-long dot product per ordered pair
+                    variants[name]["roofline"] = {
+                        "bound": "mfma", "kernel": "pair stage: sw_prep + sw_pilot + sw_sweep<A> + sw_select + sw_sweep<B> + sw_finalize (+ fallback)",
+                        "achieved": flop / (pk * 1e-3) / 1e12, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / (pk * 1e-3) / 1e12 / BF16_PEAK_TFLOPS,
+                        "algorithmic_flop": flop, "executed_mfma_flop": 2.0 * N * float(N) * (lat + 16), "traffic": None,
+                        "note": "algorithmic flop = 2 N^2 h (the bf16 Gram bound of every ordered pair); executed = 2 N^2 (h + 16): the K-step "
+                                "that folds the norms and the row's radius into the accumulator; the two sweeps alone: see "
+                                "profiles/r03_unperturbed_kernel_stats.csv"}
+                elif name in ("symmetric", "hash_asymmetric"):
+                    npair = N * float(N) * (0.5 if name == "symmetric" else 1.0)
+                    floor_s = npair / 64.0 * HASH_CYCLES_PER_WAVE_COLUMN / SIMD_CYCLES_PER_S
+                    variants[name]["roofline"] = {
+                        "bound": "valu", "kernel": "pair stage: gv_pilot + gv_sweep" + ("_tri" if name == "symmetric" else "") + " + gv_finalize",
+                        "achieved": npair / (pk * 1e-3) / 1e12, "peak": npair / floor_s / 1e12, "unit": "Tpair/s (hash + compare)",
+                        "frac": floor_s / (pk * 1e-3), "algorithmic_pairs": npair, "traffic": None,
+                        "note": "integer-VALU bound: every (unordered, for symmetric noise) pair costs one 6-instruction hash + compare per "
+                                "64 pairs and wavefront; peak = the measured hashing floor of 21 cycles per wavefront-column on 1024 SIMDs "
+                                "at 2.4 GHz; frac = floor time / event-timed pair stage"}
                 del rv
                 torch.cuda.empty_cache()
             except Exception as e:  # noqa: BLE001

@@ -22,11 +22,14 @@
 // Sweep kernel: a workgroup of 4 wavefronts owns 128 * RBLK rows (RBLK 32-row MFMA blocks per wavefront, B operands in
 // registers for the whole kernel) and streams its share of the column tiles (128 columns, interleaved over CS workgroups per
 // row block) through a double-buffered, padded LDS image; per 32 x 32 block: KS + 1 bf16 MFMAs (v_mfma_f32_32x32x16_bf16),
-// 16 v_alignbit (sign bits -> one 16-bit hit mask per lane), one compare + branch; a lane appends its hits to PRIVATE lists
-// (row, column half, segment), so there are no atomics and no LDS traffic on the hit path.
+// 16 v_alignbit (sign bits -> one 16-bit hit mask per lane); the masks of the RBLK blocks that share a column block are packed
+// and tested with ONE wave-uniform branch (a branch per block was entered for 72 % of the blocks and cost 0.3 of the 1.2 ms).
+// A lane appends its hits to its PRIVATE list (lane, segment; the record carries the row block), so there are no atomics and
+// no LDS traffic on the hit path.
 #include "dgg_common.h"
 #include "dgg_api_internal.h"
 #include <stdlib.h>
+#include <stdint.h>
 
 using namespace dgg;
 
@@ -189,10 +192,8 @@ __global__ __launch_bounds__(256, 2) void sw_sweep(const __bf16 *__restrict__ xw
                                                    unsigned short *__restrict__ cnts) {
     using TL = Tile<H>;
     constexpr int HW = TL::HW, KS1 = TL::KS1, STRIDE = TL::STRIDE, CPC = TL::CPC, LQ = TL::LQ;
-    constexpr int QC = H == 128 ? 1 : 2;                                // queue slots per lane and row block (LDS budget: 2 workgroups per CU)
+    static_assert(RBLK == 2 || RBLK == 4, "row blocks per wavefront");
     __shared__ __attribute__((aligned(16))) unsigned char colA[2][TL::BYTES];
-    __shared__ int32_t hq[RBLK][QC][256];
-    __shared__ float hv[VALUES ? RBLK : 1][VALUES ? QC : 1][VALUES ? 256 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), r = lane & 31, hh = lane >> 5;
     const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
     const int seg = kk / rbx, rowblk = (kk % rbx) * 8 + xcd;
@@ -200,26 +201,23 @@ __global__ __launch_bounds__(256, 2) void sw_sweep(const __bf16 *__restrict__ xw
     const int64_t rbase = row0 + (int64_t)rowblk * (128 * RBLK) + (int64_t)wave * (32 * RBLK);
 
     bf16x8 bfr[RBLK][KS1];
-    uint32_t pos[RBLK], lim[RBLK];                                      // byte offsets (next free slot / end) of this lane's private lists,
-    bool rvalid[RBLK];                                                  // relative to the workgroup's first row (always < 2^32)
-    constexpr uint32_t REC = VALUES ? 8u : 4u;
-    const int64_t wg_lrow0 = (int64_t)rowblk * (128 * RBLK);
-    char *const wg_lists = reinterpret_cast<char *>(lists) + wg_lrow0 * CS * 2 * cap * REC;
 #pragma unroll
     for (int b = 0; b < RBLK; b++) {
         const int64_t i = rbase + b * 32 + r;
-        rvalid[b] = i < row1;
-        const int64_t ic = rvalid[b] ? i : row1 - 1;
+        const bool rvalid = i < row1;
+        const int64_t ic = rvalid ? i : row1 - 1;
 #pragma unroll
         for (int s = 0; s < KS1 - 1; s++) bfr[b][s] = *reinterpret_cast<const bf16x8 *>(xw + ic * HW + 16 * s + 8 * hh);
-        bfr[b][KS1 - 1] = aug_row(rvalid[b] ? trow[ic - row0] : -3.0e38f, hh);
-        pos[b] = (uint32_t)((((ic - row0 - wg_lrow0) * CS + seg) * 2 + hh) * cap) * REC;
-        lim[b] = pos[b] + (uint32_t)cap * REC;
+        bfr[b][KS1 - 1] = aug_row(rvalid ? trow[ic - row0] : -3.0e38f, hh);
     }
-    uint32_t pos0[RBLK];
-    int qn[RBLK];
-#pragma unroll
-    for (int b = 0; b < RBLK; b++) { pos0[b] = pos[b]; qn[b] = 0; }
+    // this lane's private list: (row group = the wavefront's RBLK x 32 rows, lane, segment); byte offsets relative to the workgroup's
+    // first list (always < 2^32)
+    constexpr uint32_t REC = VALUES ? 8u : 4u;
+    const int64_t grp = (int64_t)rowblk * 4 + wave;
+    char *const wg_lists = reinterpret_cast<char *>(lists) + (int64_t)rowblk * 4 * 64 * CS * cap * REC;
+    const uint32_t pos0 = (uint32_t)(((wave * 64 + lane) * CS + seg) * cap) * REC;
+    uint32_t pos = pos0;
+    const uint32_t lim = pos0 + (uint32_t)cap * REC;
 
     uint4 stg[LQ];
     auto tile_load = [&](int w) {
@@ -245,66 +243,37 @@ __global__ __launch_bounds__(256, 2) void sw_sweep(const __bf16 *__restrict__ xw
         for (int s = 0; s < KS1; s++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bfr[b][s], acc, 0, 0, 0);
         return acc;
     };
-    // hits of one 32 x 32 block: sign bits of the 16 accumulators -> bit q of a per-lane mask (two independent chains), one
-    // wave-uniform branch.  A lane with hits parks them in its LDS queue (QC slots per row block); the queues are flushed to the
-    // lane's private global lists once per tile, BEFORE the next tile's loads are issued: vector-memory operations retire in
-    // order, so a store issued per hit inside the tile made the s_waitcnt on the tile loads wait for the youngest hit store
-    // (wait share 0.37 of the wavefront cycles, 1.08 ms); stores at the top of a tile are long done when that wait comes.
-    auto append = [&](int b, int col, float best) {
-        if (pos[b] < lim[b]) {
-            if (VALUES) *reinterpret_cast<int2 *>(wg_lists + pos[b]) = make_int2(col, __float_as_int(best));
-            else *reinterpret_cast<int32_t *>(wg_lists + pos[b]) = col;
-        }
-        pos[b] += REC;
-    };
-    auto process = [&](const f32x16 &acc, int b, uint32_t colb) {
+    // sign bits of the 16 accumulators of a block -> bit q of a 16-bit mask (1 = outside the radius); two independent chains
+    auto signs = [&](const f32x16 &acc) {
         uint32_t m0 = 0u, m1 = 0u;
 #pragma unroll
         for (int q = 7; q >= 0; q--) {
             m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(acc[q]), 31u);
             m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(acc[q + 8]), 31u);
         }
-#ifdef DGG_SW_NOTEST     // timing experiment only (wrong results): one sign bit instead of 16
-        const uint32_t mask = (__float_as_uint(acc[0]) >> 31) | ((__float_as_uint(acc[15]) >> 31) << 20);
-#else
-        const uint32_t mask = m0 | (m1 << 8);                           // 1 = outside the radius
-#endif
-#ifdef DGG_SW_NOHIT      // timing experiment only (wrong results): hits are never recorded
-        if (mask == (uint32_t)nset + 0x12345u) {
-#else
-        if (__ballot(mask != 0xffffu) != 0ull) {
-#endif                        // wave-uniform: some lane has a hit in this block
-            uint32_t hm = ~mask & 0xffffu;
-            float best = 0.0f;
-            if (VALUES) {       // the lane's LARGEST D of the block stands for each of its hits (a lane with two hits in one block --
-                                // 3 % of the hitting lanes -- gets the better value twice; sw_select allows for it)
-                best = acc[0];
-#pragma unroll
-                for (int q = 1; q < 15; q += 2) best = fmaxf(fmaxf(best, acc[q]), acc[q + 1]);
-                best = fmaxf(best, acc[15]);
-            }
-            while (hm != 0u) {
-                const int q = __builtin_ctz(hm);
-                hm &= hm - 1u;
-                const int col = (int)(colb + (uint32_t)((q & 3) | ((q & 12) << 1)));
-                if (qn[b] < QC) {
-                    hq[b][qn[b]][tid] = col;
-                    if (VALUES) hv[VALUES ? b : 0][VALUES ? qn[b] : 0][tid] = best;
-                } else append(b, col, best);                            // queue full (rare): straight to the list
-                qn[b]++;
-            }
-        }
+        return m0 | (m1 << 8);
     };
-    auto flush = [&]() {
+    // the lane's LARGEST D of a block stands for each of its hits in that block (a lane with two hits in one block -- 3 % of the
+    // hitting lanes -- gets the better value twice; sw_select allows for it)
+    auto block_best = [&](const f32x16 &acc) {
+        float best = acc[0];
 #pragma unroll
-        for (int b = 0; b < RBLK; b++) {
-#pragma unroll
-            for (int e = 0; e < QC; e++) {
-                if (__ballot(qn[b] > e) != 0ull) {
-                    if (qn[b] > e) append(b, hq[b][e][tid], VALUES ? hv[VALUES ? b : 0][VALUES ? e : 0][tid] : 0.0f);
-                }
+        for (int q = 1; q < 15; q += 2) best = fmaxf(fmaxf(best, acc[q]), acc[q + 1]);
+        return fmaxf(best, acc[15]);
+    };
+    // hits of two row blocks (b0, b0 + 1) against one column block: pm = mask(b0) | mask(b0 + 1) << 16
+    auto record = [&](uint32_t pm, int b0, uint32_t colb, float best0, float best1) {
+        uint32_t hm = ~pm;
+        while (hm != 0u) {
+            const int p = __builtin_ctz(hm);
+            hm &= hm - 1u;
+            const uint32_t q = (uint32_t)p & 15u, up = (uint32_t)p >> 4;
+            const uint32_t rec = (colb + ((q & 3u) | ((q & 12u) << 1))) | (((uint32_t)b0 + up) << 28);
+            if (pos < lim) {
+                if (VALUES) *reinterpret_cast<int2 *>(wg_lists + pos) = make_int2((int)rec, __float_as_int(up ? best1 : best0));
+                else *reinterpret_cast<uint32_t *>(wg_lists + pos) = rec;
             }
-            qn[b] = 0;
+            pos += REC;
         }
     };
     auto load_af = [&](bf16x8 (&af)[KS1], int buf, int sub) {
@@ -316,16 +285,9 @@ __global__ __launch_bounds__(256, 2) void sw_sweep(const __bf16 *__restrict__ xw
     if (w < nset) { tile_load(w); tile_store(0); }
     __syncthreads();
     for (int it = 0; w < nset; w += CS, it++) {
-#ifdef DGG_SW_NOSTAGE
-        const int buf = 0;
-#else
         const int buf = it & 1;
-#endif
         const bool more = w + CS < nset;
-        flush();                                                        // the previous tile's hits
-#ifndef DGG_SW_NOSTAGE
         if (more) tile_load(w + CS);                                    // in flight during the MFMAs below
-#endif
         const uint32_t cbase = (uint32_t)(VALUES ? tileA(w) : tileB(w)) * TC + (uint32_t)(4 * hh);
         // software pipeline over the tile's 4 x RBLK blocks: the MFMA chain of block n + 1 is issued before the sign tests of
         // block n, so the matrix pipe runs while the wavefront does its vector work
@@ -337,29 +299,34 @@ __global__ __launch_bounds__(256, 2) void sw_sweep(const __bf16 *__restrict__ xw
             bf16x8 (&af)[KS1] = (sub & 1) ? afB : afA;
             bf16x8 (&afn)[KS1] = (sub & 1) ? afA : afB;
             if (sub + 1 < TC / 32) load_af(afn, buf, sub + 1);
+            uint32_t pm[RBLK / 2];
+            float best[VALUES ? RBLK : 1];
 #pragma unroll
             for (int b = 0; b < RBLK; b++) {
                 f32x16 nxt;
                 const bool last = (sub + 1 == TC / 32) && (b + 1 == RBLK);
                 if (!last) nxt = (b + 1 < RBLK) ? chain(af, b + 1) : chain(afn, 0);
-                process(cur, b, cbase + (uint32_t)(sub * 32));
+                const uint32_t m = signs(cur);
+                if (b & 1) pm[b / 2] |= m << 16; else pm[b / 2] = m;
+                if (VALUES) best[VALUES ? b : 0] = block_best(cur);
                 if (!last) cur = nxt;
             }
+            uint32_t all = pm[0];
+#pragma unroll
+            for (int g = 1; g < RBLK / 2; g++) all &= pm[g];
+            if (__ballot(all != 0xffffffffu) != 0ull) {                 // wave-uniform: some lane has a hit in these RBLK blocks
+                const uint32_t colb = cbase + (uint32_t)(sub * 32);
+#pragma unroll
+                for (int g = 0; g < RBLK / 2; g++)
+                    if (RBLK == 2 || __ballot(pm[g] != 0xffffffffu) != 0ull)
+                        record(pm[g], 2 * g, colb, VALUES ? best[VALUES ? 2 * g : 0] : 0.0f, VALUES ? best[VALUES ? 2 * g + 1 : 0] : 0.0f);
+            }
         }
-#ifndef DGG_SW_NOSTAGE
         if (more) tile_store(buf ^ 1);
         __syncthreads();
-#endif
     }
-    flush();
-#pragma unroll
-    for (int b = 0; b < RBLK; b++) {
-        if (rvalid[b]) {
-            const int64_t lrow = rbase + b * 32 + r - row0;
-            const uint32_t n = (pos[b] - pos0[b]) / REC;
-            cnts[(lrow * CS + seg) * 2 + hh] = (unsigned short)(n > 0xffffu ? 0xffffu : n);
-        }
-    }
+    const uint32_t n = (pos - pos0) / REC;
+    cnts[((grp * 64 + lane) * CS) + seg] = (unsigned short)(n > 0xffffu ? 0xffffu : n);
 }
 
 // ---- select: tight radius from the phase-A hits -------------------------------------------------------------------------------
@@ -370,49 +337,113 @@ __global__ __launch_bounds__(256, 2) void sw_sweep(const __bf16 *__restrict__ xw
 // D' = D - SL (nb_i + nb_j) / 2, cut = m-th largest D' (>= 0: never looser than the loose radius), t_tight = t_loose - cut.
 // A phase-A hit lies inside the tight radius iff D >= cut.
 constexpr float SL_UPPER = (EPS_BF16 + 0.0039102f) / (1.0f - EPS_BF16) * 1.0001f;
+constexpr int KCAP = 128;               // phase-A hits inside the tight radius kept per row (expected ~40)
+constexpr uint32_t COLMASK = 0x0fffffffu;   // record = column | row block << 28
+
+// the 2 * CS lane lists that hold a row's records (see sw_sweep): list id of (half h, segment g) and the row's block tag
+struct RowLists {
+    int64_t base;      // (grp * 64 + r) : list id = (base + 32 * h) * CS + g
+    uint32_t tag;
+};
+__device__ __forceinline__ RowLists row_lists(int64_t lrow, int rblk) {
+    RowLists rl;
+    const int64_t grp = lrow / (32 * rblk);
+    rl.base = grp * 64 + (lrow & 31);
+    rl.tag = (uint32_t)((lrow >> 5) % rblk);
+    return rl;
+}
+
+constexpr int SELCAP = CAPA_ROW;        // phase-A hits of one row that sw_select can hold (expected ~140; the loose radius has a heavy tail)
 __global__ __launch_bounds__(256) void sw_select(const int2 *__restrict__ listA, const unsigned short *__restrict__ cntA, int64_t rows, int64_t row0,
-                                                 int CSA, int capA, int m, const float *__restrict__ nb, const float *__restrict__ tloose,
-                                                 float *__restrict__ ttight, float *__restrict__ selA) {
-    const int lane = threadIdx.x & 63;
-    const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
+                                                 int CSA, int capA, int rblk, int m, const float *__restrict__ nb, const float *__restrict__ tloose,
+                                                 float *__restrict__ ttight, int32_t *__restrict__ kept, int *__restrict__ keptn,
+                                                 SweepCtl *__restrict__ ctl) {
+    // one wavefront per row.  Pass over the row's 2 * CSA lane lists: its own records (tag) are compacted into LDS as (column, D, D');
+    // the cut is found by BISECTION on D' (count of D' >= cut by ballots; any cut is valid -- the verification decides -- so 14
+    // halvings replace three 64-lane sorts); the records with D >= cut go to the row's kept list.
+    __shared__ int32_t scol[4][SELCAP];
+    __shared__ float sd[4][SELCAP], sdp[4][SELCAP];
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id();
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + wave;
     if (lrow >= rows) return;
+    const RowLists rl = row_lists(lrow, rblk);
     const float nbi = nb[row0 + lrow];
-    uint64_t list = 0ull;                                              // descending; keys = (order-preserving bits of D') << 32 | 1
     int total = 0;
     bool over = false;
     for (int s = 0; s < 2 * CSA; s++) {
-        int n = cntA[lrow * 2 * CSA + s];
+        const int64_t id = (rl.base + 32 * (s / CSA)) * CSA + (s % CSA);
+        int n = cntA[id];
         if (n > capA) { over = true; n = capA; }
-        total += n;
-        const int2 *l = listA + (lrow * 2 * CSA + s) * capA;
+        const int2 *l = listA + id * capA;
         for (int base = 0; base < n; base += 64) {
             const int e = base + lane;
-            uint64_t key = 0ull;
-            if (e < n) {
-                const int2 c = l[e];
-                const float dp = __int_as_float(c.y) - 0.5f * SL_UPPER * (nbi + nb[c.x]);
-                const uint32_t u = __float_as_uint(dp);
-                key = ((uint64_t)(u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u)) << 32) | 1ull;
+            bool mine = false;
+            int2 c = make_int2(0, 0);
+            if (e < n) { c = l[e]; mine = ((uint32_t)c.x >> 28) == rl.tag; }
+            const unsigned long long mk = __ballot(mine);
+            const int at = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            if (mine && at < SELCAP) {
+                const int32_t col = (int32_t)((uint32_t)c.x & COLMASK);
+                const float d = __int_as_float(c.y);
+                scol[wave][at] = col;
+                sd[wave][at] = d;
+                sdp[wave][at] = d - 0.5f * SL_UPPER * (nbi + nb[col]);
             }
-            key = wave_sort<false>(key, lane);
-            list = wave_merge_top64_asc(list, key, lane);
+            total += __builtin_popcountll(mk);
         }
     }
     const float tl = tloose[lrow];
     float tt = tl, sel = 0.0f;
-    if (!over && total >= m) {
-        const uint32_t ku = (uint32_t)(shfl_u64(list, m - 1) >> 32);
-        const float cut = fmaxf(__uint_as_float(ku ^ ((ku >> 31) ? 0x80000000u : 0xffffffffu)), 0.0f);
-        const float slack = 1e-6f * (fabsf(tl) + cut) + 1e-7f;
-        tt = fminf(tl, tl - cut + slack);
-        sel = fmaxf(cut - 2.0f * slack, 0.0f);
+    int nk = 0;
+    if (!over && total <= SELCAP) {
+        float v[SELCAP / 64];
+        float hi = 0.0f;
+#pragma unroll
+        for (int k = 0; k < SELCAP / 64; k++) {
+            v[k] = (k * 64 + lane < total) ? sdp[wave][k * 64 + lane] : -3.0e38f;
+            hi = fmaxf(hi, v[k]);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+        auto count_ge = [&](float x) {
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < SELCAP / 64; k++) c += __builtin_popcountll(__ballot(v[k] >= x));
+            return c;
+        };
+        if (total >= m && count_ge(0.0f) >= m) {
+            float lo = 0.0f;                                            // invariant: count(D' >= lo) >= m
+            hi = hi * 1.0001f + 1e-30f;
+            for (int it = 0; it < 14; it++) {
+                const float mid = 0.5f * (lo + hi);
+                if (count_ge(mid) >= m) lo = mid; else hi = mid;
+            }
+            const float cut = lo;
+            const float slack = 1e-6f * (fabsf(tl) + cut) + 1e-7f;
+            tt = fminf(tl, tl - cut + slack);
+            sel = fmaxf(cut - 2.0f * slack, 0.0f);
+        }
+        // the row's phase-A hits inside the tight radius (D >= sel), compacted for sw_finalize
+        for (int base = 0; base < total; base += 64) {
+            const int e = base + lane;
+            const bool keep = e < total && sd[wave][e] >= sel;
+            const unsigned long long mk = __ballot(keep);
+            const int at = nk + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            if (keep && at < KCAP) kept[lrow * KCAP + at] = scol[wave][e];
+            nk += __builtin_popcountll(mk);
+        }
+    } else over = true;
+    if (lane == 0) {
+        ttight[lrow] = tt;
+        keptn[lrow] = over ? (KCAP + 1) : nk;                          // > KCAP: the row goes to the fallback
+        if (ctl->stats_on) { atomicAdd(&ctl->nA, (unsigned long long)total); atomicAdd(&ctl->nAkept, (unsigned long long)nk); }
     }
-    if (lane == 0) { ttight[lrow] = tt; selA[lrow] = sel; }
 }
 
-// exact canonical score of pair (i, j); i is wave-uniform (its features come through the scalar cache)
+// exact canonical squared distance of pair (i, j) (the fmaf chain of the oracle's pair_dist); i is wave-uniform: its features
+// come through the scalar cache
 template <int H>
-__device__ __forceinline__ float exact_score0(const float *__restrict__ xp, int64_t i, int32_t j, float t) {
+__device__ __forceinline__ float exact_d2(const float *__restrict__ xp, int64_t i, int32_t j) {
     const float *xi = xp + i * H;
     const float4 *xj = reinterpret_cast<const float4 *>(xp + (int64_t)j * H);
     float4 b[H / 4];
@@ -427,75 +458,131 @@ __device__ __forceinline__ float exact_score0(const float *__restrict__ xp, int6
         df = __fadd_rn(xi[4 * c4 + 2], -b[c4].z); d2 = __fmaf_rn(df, df, d2);
         df = __fadd_rn(xi[4 * c4 + 3], -b[c4].w); d2 = __fmaf_rn(df, df, d2);
     }
-    return score_from_dist(c_sqrt(d2), t, false, 0.0f);
+    return d2;
+}
+template <int H>
+__device__ __forceinline__ float exact_score0(const float *__restrict__ xp, int64_t i, int32_t j, float t) {
+    return score_from_dist(c_sqrt(exact_d2<H>(xp, i, j)), t, false, 0.0f);
 }
 
 // ---- finalize -----------------------------------------------------------------------------------------------------------------
+// one wavefront per row: the row's candidates (phase-A hits inside the tight radius + its phase-B records, ~160 columns) get
+// their EXACT squared distance (one candidate per lane and batch, FCAP / 64 batches held in registers); the 64th smallest is
+// found by bisection on the bit patterns (ballot counts; ~10 halvings: it stops as soon as exactly 64 lie below), and only the
+// candidates within dist_64 + 4e-6 (the margin covers ties and the 1-ulp non-monotonicity of the canonical exp) -- 64 to ~66
+// columns -- go through sqrt / exp and the ONE 64-lane sort.  (Scoring, sorting and merging every batch of 64 candidates
+// was 2.5 sorts + merges per row: 0.63 ms.)
+constexpr int FCAP = 320;               // candidates of one row that sw_finalize can hold; more: the row goes to the fallback
 template <int H>
 __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp, const float *__restrict__ nb, int64_t row0, int64_t row1, float t,
-                                                   const int2 *__restrict__ listA, const unsigned short *__restrict__ cntA, int CSA, int capA,
-                                                   const float *__restrict__ selA, const int32_t *__restrict__ listB,
-                                                   const unsigned short *__restrict__ cntB, int CSB, int capB,
-                                                   const float *__restrict__ ttight, SweepCtl *__restrict__ ctl, int *__restrict__ faillist,
-                                                   int32_t *__restrict__ idx, float *__restrict__ val) {
-    __shared__ int32_t ring[4][128];
+                                                   const int32_t *__restrict__ kept, const int *__restrict__ keptn,
+                                                   const uint32_t *__restrict__ listB, const unsigned short *__restrict__ cntB, int CSB, int capB,
+                                                   int rblk, const float *__restrict__ ttight, SweepCtl *__restrict__ ctl,
+                                                   int *__restrict__ faillist, int32_t *__restrict__ idx, float *__restrict__ val) {
+    __shared__ int32_t ccol[4][FCAP];
+    __shared__ float cd2[4][FCAP];
     const int lane = threadIdx.x & 63, wave = dgg::wave_id();
     const int64_t lrow = (int64_t)blockIdx.x * 4 + wave;
     const int64_t i = row0 + lrow;
     if (i >= row1) return;
-    int32_t *rg = ring[wave];
-    uint64_t list = DGG_EMPTY_KEY;
-    int head = 0, tail = 0;                                            // wave-uniform, monotone; slot = index & 127
+    const RowLists rl = row_lists(lrow, rblk);
+    int32_t *cc = ccol[wave];
+    int total = 0, nB = 0;                                             // wave-uniform
     bool ok = true;
-    int nA = 0, nAk = 0, nB = 0;
-    auto score_batch = [&](int n) {                                    // the n (<= 64) oldest columns of the ring
-        const int32_t j = lane < n ? rg[(head + lane) & 127] : -1;
-        head += n;
-        uint64_t key = DGG_EMPTY_KEY;
-        if (j >= 0) key = make_key(exact_score0<H>(xp, i, j, t), j);
-        key = wave_sort<false>(key, lane);
-        list = wave_merge_top64_asc(list, key, lane);
-    };
     auto push = [&](bool keep, int32_t col) {
         const unsigned long long m = __ballot(keep);
-        if (keep) rg[(tail + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & 127] = col;
-        tail += __builtin_popcountll(m);
-        if (tail - head >= 64) score_batch(64);
+        const int at = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (keep && at < FCAP) cc[at] = col;
+        total += __builtin_popcountll(m);
     };
-    const float sel = selA[lrow];
-    for (int s = 0; s < 2 * CSA; s++) {
-        int n = cntA[lrow * 2 * CSA + s];
-        if (n > capA) { ok = false; n = capA; }
-        nA += n;
-        const int2 *l = listA + (lrow * 2 * CSA + s) * capA;
+    {   // phase-A hits inside the tight radius (compacted by sw_select)
+        int n = keptn[lrow];
+        if (n > KCAP) { ok = false; n = 0; }                            // overflow (of the kept list or of a phase-A lane list)
         for (int base = 0; base < n; base += 64) {
             const int e = base + lane;
-            bool keep = false;
-            int32_t col = 0;
-            if (e < n) { const int2 c = l[e]; col = c.x; keep = __int_as_float(c.y) >= sel; }
-            nAk += __builtin_popcountll(__ballot(keep));
-            push(keep, col);
+            push(e < n, e < n ? kept[lrow * KCAP + e] : 0);
         }
     }
-    for (int s = 0; s < 2 * CSB; s++) {
-        int n = cntB[lrow * 2 * CSB + s];
-        if (n > capB) { ok = false; n = capB; }
-        nB += n;
-        const int32_t *l = listB + (lrow * 2 * CSB + s) * capB;
+    const int nkept = total;
+    for (int s = 0; ok && s < 2 * CSB; s++) {
+        const int64_t id = (rl.base + 32 * (s / CSB)) * CSB + (s % CSB);
+        const int n = cntB[id];
+        if (n > capB) { ok = false; break; }
+        const uint32_t *l = listB + id * capB;
         for (int base = 0; base < n; base += 64) {
             const int e = base + lane;
-            push(e < n, e < n ? l[e] : 0);
+            const uint32_t rec = e < n ? l[e] : 0xffffffffu;
+            const bool mine = e < n && (rec >> 28) == rl.tag;
+            push(mine, (int32_t)(rec & COLMASK));
         }
     }
-    if (tail != head) score_batch(tail - head);
-    // verification: full list, and its 64th distance (+ margins for the log and the rounding of the canonical exp) inside the
-    // radius the sweeps tested against: R = nb_i + 2 t_tight
-    const uint64_t k63 = shfl_u64(list, 63);
-    if (k63 == DGG_EMPTY_KEY) ok = false;
+    nB = total - nkept;
+    if (total > FCAP || total < 64) ok = false;
+    uint64_t list = DGG_EMPTY_KEY;
     if (ok) {
-        const float d63 = c_log(fmaxf(key_val(k63), 1e-37f)) / t + 1e-5f;
-        const float R = fmaf(2.0f, ttight[lrow], nb[i]);
-        ok = d63 * d63 * (1.0f + 1e-5f) <= R * (1.0f - 1e-5f) - 1e-7f * nb[i];
+        // exact squared distances, FCAP / 64 candidates per lane
+        uint32_t u[FCAP / 64];
+#pragma unroll
+        for (int k = 0; k < FCAP / 64; k++) {
+            u[k] = 0xffffffffu;
+            if (k * 64 < total) {                                       // wave-uniform
+                const int e = k * 64 + lane;
+                if (e < total) {
+                    const float d2 = exact_d2<H>(xp, i, cc[e]);
+                    cd2[wave][e] = d2;
+                    u[k] = __float_as_uint(d2);                         // d2 >= 0: the bit patterns are ordered like the values
+                }
+            }
+        }
+        auto count_le = [&](uint32_t x) {
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < FCAP / 64; k++) c += __builtin_popcountll(__ballot(u[k] <= x));
+            return c;
+        };
+        // bisection: smallest tau with count(d2 <= tau) >= 64 -- stopped early once a value with exactly 64 below is met
+        uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+        for (int k = 0; k < FCAP / 64; k++) hi = max(hi, u[k] == 0xffffffffu ? 0u : u[k]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+        uint32_t tau = hi;                                              // count(<= hi) = total >= 64
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            const int c = count_le(mid);
+            if (c >= 64) { hi = mid; tau = mid; if (c == 64) break; } else lo = mid + 1u;
+        }
+        const float dcut = c_sqrt(__uint_as_float(tau)) + 4e-6f;
+        const float d2cut = dcut * dcut * (1.0f + 1e-6f);
+        // the candidates inside the cut: compacted, scored, sorted (one batch unless there are ties at the cut)
+        int nin = 0;
+        int32_t *sel = cc;                                              // compacted in place (positions only move down)
+        for (int base = 0; base < total; base += 64) {
+            const int e = base + lane;
+            const float d2 = e < total ? cd2[wave][e] : 0.0f;
+            const int32_t col = e < total ? cc[e] : 0;
+            const bool in = e < total && d2 <= d2cut;
+            const unsigned long long m = __ballot(in);
+            const int at = nin + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (in) { sel[at] = col; cd2[wave][at] = d2; }
+            nin += __builtin_popcountll(m);
+        }
+        for (int base = 0; base < nin; base += 64) {
+            const int e = base + lane;
+            uint64_t key = DGG_EMPTY_KEY;
+            if (e < nin) key = make_key(score_from_dist(c_sqrt(cd2[wave][e]), t, false, 0.0f), sel[e]);
+            key = wave_sort<false>(key, lane);
+            list = wave_merge_top64_asc(list, key, lane);
+        }
+        // verification: full list, and its 64th distance (+ margins for the log and the rounding of the canonical exp) inside the
+        // radius the sweeps tested against: R = nb_i + 2 t_tight
+        const uint64_t k63 = shfl_u64(list, 63);
+        if (k63 == DGG_EMPTY_KEY) ok = false;
+        else {
+            const float d63 = c_log(fmaxf(key_val(k63), 1e-37f)) / t + 1e-5f;
+            const float R = fmaf(2.0f, ttight[lrow], nb[i]);
+            ok = d63 * d63 * (1.0f + 1e-5f) <= R * (1.0f - 1e-5f) - 1e-7f * nb[i];
+        }
     }
     if (ok) {
         idx[lrow * 64 + lane] = key_col(list);
@@ -503,11 +590,7 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
     } else if (lane == 0) {
         faillist[atomicAdd(&ctl->nfail, 1)] = (int)lrow;
     }
-    if (ctl->stats_on && lane == 0) {
-        atomicAdd(&ctl->nA, (unsigned long long)nA);
-        atomicAdd(&ctl->nAkept, (unsigned long long)nAk);
-        atomicAdd(&ctl->nB, (unsigned long long)nB);
-    }
+    if (ctl->stats_on && lane == 0) atomicAdd(&ctl->nB, (unsigned long long)nB);
 }
 
 // ---- fallback: rows whose radius failed verification, every column scored exactly ------------------------------------------------
@@ -595,33 +678,34 @@ Plan make_plan(int64_t rows, int64_t N, int h) {
     p.npad = (int64_t)p.ntiles * TC;
     p.nA = (p.ntiles + 3) / 4;
     p.nB = p.ntiles - p.nA;
-#ifdef DGG_SW_RBLK
-    p.rblk = DGG_SW_RBLK;
-#else
     p.rblk = h <= 64 ? 4 : 2;
-#endif
     p.rw = 128 * p.rblk;
     p.nrb = (int)((rows + p.rw - 1) / p.rw);
     p.rbx = (p.nrb + 7) / 8;
-    // column segments per row block: ~2 x 512 resident workgroups for the long phase, its share for the short one
-    auto segs = [&](int target, int nset) {
-        int cs = (target + p.nrb / 2) / (p.nrb > 0 ? p.nrb : 1);
-        cs = cs < 1 ? 1 : cs;
-        cs = cs > 16 ? 16 : cs;
-        while (cs > 1 && nset / cs < 4) cs--;                           // at least a few tiles per workgroup
-        return cs;
+    // column segments per row block: the count that minimises (rounds of 512 resident workgroups) x (tiles per workgroup) --
+    // a phase of 588 workgroups runs a second round at 15 % occupancy (phase A took 0.57 ms with 3 segments, 0.36 with 5)
+    auto segs = [&](int nset) {
+        int best = 1;
+        int64_t best_cost = INT64_MAX;
+        for (int cs = 1; cs <= 16; cs++) {
+            if (cs > 1 && nset / cs < 4) break;                         // at least a few tiles per workgroup
+            const int64_t rounds = ((int64_t)p.nrb * cs + 511) / 512;
+            const int64_t cost = rounds * ((nset + cs - 1) / cs + 2);   // + 2: per-workgroup prologue, in tiles
+            if (cost < best_cost) { best_cost = cost; best = cs; }
+        }
+        return best;
     };
-    p.csb = segs(1000, p.nB);
-    p.csa = segs(500, p.nA);
-    p.capa = CAPA_ROW / (2 * p.csa);
-    p.capb = CAPB_ROW / (2 * p.csb);
+    p.csb = segs(p.nB);
+    p.csa = segs(p.nA);
+    p.capa = p.rblk * CAPA_ROW / (2 * p.csa);                          // per lane list: the records of the lane's RBLK rows
+    p.capb = p.rblk * CAPB_ROW / (2 * p.csb);
     int pt = (int)((int64_t)p.ntiles * 2 * PILOT_M / LOOSE_TARGET);
     p.pt = pt < 1 ? 1 : pt;
     return p;
 }
 
 struct Layout {
-    size_t xw, nb, ctl, fail, tl, tt, sel, cnta, cntb, la, lb, part, total;
+    size_t xw, nb, ctl, fail, tl, tt, kept, keptn, cnta, cntb, la, lb, part, total;
 };
 Layout make_layout(const Plan &p, int h) {
     Layout L;
@@ -633,12 +717,14 @@ Layout make_layout(const Plan &p, int h) {
     L.fail = take((size_t)p.rows * 4);
     L.tl = take((size_t)p.rows * 4);
     L.tt = take((size_t)p.rows * 4);
-    L.sel = take((size_t)p.rows * 4);
+    L.keptn = take((size_t)p.rows * 4);
+    L.kept = take((size_t)p.rows * KCAP * 4);
     // (per-row arrays at their worst case over the segment counts, so that the size depends on rows and N only)
-    L.cnta = take((size_t)p.rows * 2 * 16 * 2);
-    L.cntb = take((size_t)p.rows * 2 * 16 * 2);
-    L.la = take((size_t)p.rows * CAPA_ROW * 8);
-    L.lb = take((size_t)p.rows * CAPB_ROW * 4);
+    const size_t rpad = (size_t)p.nrb * p.rw;                          // the lane lists cover whole workgroups of rows
+    L.cnta = take(rpad * 2 * 16 * 2);
+    L.cntb = take(rpad * 2 * 16 * 2);
+    L.la = take(rpad * CAPA_ROW * 8);
+    L.lb = take(rpad * CAPB_ROW * 4);
     L.part = take((size_t)(p.rows < FB_MAX ? p.rows : FB_MAX) * FB_NCH * 64 * 8);
     L.total = off;
     return L;
@@ -653,10 +739,12 @@ int launch_sweep(const float *xp, int64_t N, int64_t row0, int64_t row1, float t
     float *nb = reinterpret_cast<float *>(w + L.nb);
     SweepCtl *ctl = reinterpret_cast<SweepCtl *>(w + L.ctl);
     int *faillist = reinterpret_cast<int *>(w + L.fail);
-    float *tl = reinterpret_cast<float *>(w + L.tl), *tt = reinterpret_cast<float *>(w + L.tt), *sel = reinterpret_cast<float *>(w + L.sel);
+    float *tl = reinterpret_cast<float *>(w + L.tl), *tt = reinterpret_cast<float *>(w + L.tt);
+    int32_t *kept = reinterpret_cast<int32_t *>(w + L.kept);
+    int *keptn = reinterpret_cast<int *>(w + L.keptn);
     unsigned short *cnta = reinterpret_cast<unsigned short *>(w + L.cnta), *cntb = reinterpret_cast<unsigned short *>(w + L.cntb);
     int2 *la = reinterpret_cast<int2 *>(w + L.la);
-    int32_t *lb = reinterpret_cast<int32_t *>(w + L.lb);
+    uint32_t *lb = reinterpret_cast<uint32_t *>(w + L.lb);
     uint64_t *part = reinterpret_cast<uint64_t *>(w + L.part);
     // (the control block is set by a memset + a 4-byte memset pattern: no host memory is read asynchronously)
     if (dgg_check_hip(hipMemsetAsync(ctl, 0, sizeof(SweepCtl), st), "sweep memset") != 0) return DGG_ERR_HIP;
@@ -667,11 +755,11 @@ int launch_sweep(const float *xp, int64_t N, int64_t row0, int64_t row1, float t
     hipLaunchKernelGGL((sw_sweep<H, RBLK, true>), dim3((unsigned)(8 * p.rbx * p.csa)), dim3(256), 0, st, xw, tl, p.npad, row0, row1, p.nA, p.nrb, p.rbx, p.csa,
                        p.capa, (void *)la, cnta);
     const int m = g_select_m > 64 ? 64 : g_select_m;
-    hipLaunchKernelGGL(sw_select, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, la, cnta, rows, row0, p.csa, p.capa, m > 0 ? m : (1 << 30), nb, tl, tt, sel);
+    hipLaunchKernelGGL(sw_select, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, la, cnta, rows, row0, p.csa, p.capa, p.rblk, m > 0 ? m : (1 << 30), nb, tl, tt, kept, keptn, ctl);
     hipLaunchKernelGGL((sw_sweep<H, RBLK, false>), dim3((unsigned)(8 * p.rbx * p.csb)), dim3(256), 0, st, xw, tt, p.npad, row0, row1, p.nB, p.nrb, p.rbx, p.csb,
                        p.capb, (void *)lb, cntb);
-    hipLaunchKernelGGL(sw_finalize<H>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xp, nb, row0, row1, t, la, cnta, p.csa, p.capa, sel, lb,
-                       cntb, p.csb, p.capb, tt, ctl, faillist, idx, val);
+    hipLaunchKernelGGL(sw_finalize<H>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xp, nb, row0, row1, t, kept, keptn, lb, cntb, p.csb, p.capb,
+                       p.rblk, tt, ctl, faillist, idx, val);
     hipLaunchKernelGGL(sw_fallback_part<H>, dim3(1024), dim3(256), 0, st, xp, N, row0, t, ctl, faillist, part);
     hipLaunchKernelGGL(sw_fallback_merge, dim3(256), dim3(256), 0, st, ctl, faillist, part, idx, val);
     hipLaunchKernelGGL(sw_fallback_rows<H>, dim3(512), dim3(256), 0, st, xp, N, row0, t, ctl, faillist, idx, val);
@@ -698,11 +786,7 @@ int dgg_allpairs_topk_sweep_impl(const float *xp, int64_t N, int h, int64_t row0
     switch (h) {
         case 16: return launch_sweep<16, 4>(xp, N, row0, row1, t, idx, val, workspace, st);
         case 32: return launch_sweep<32, 4>(xp, N, row0, row1, t, idx, val, workspace, st);
-#ifdef DGG_SW_RBLK
-        case 64: return launch_sweep<64, DGG_SW_RBLK>(xp, N, row0, row1, t, idx, val, workspace, st);
-#else
         case 64: return launch_sweep<64, 4>(xp, N, row0, row1, t, idx, val, workspace, st);
-#endif
         default: return launch_sweep<128, 2>(xp, N, row0, row1, t, idx, val, workspace, st);
     }
 }
