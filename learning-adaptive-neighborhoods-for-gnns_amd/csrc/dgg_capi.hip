@@ -48,8 +48,7 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
         rc = dgg_allpairs_topk_gv_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
     else if (algo == 3 || (algo == 0 && can_np && N >= 1024))
         rc = dgg_allpairs_topk_np_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
-    // (unperturbed scores: the MFMA-bounded kernel needs its pilot, i.e. N >= 8192; below that every pair is scored)
-    else if (algo == 2 || algo == 5 || (algo == 0 && can_fast && N >= (noise_mode == 0 ? 8192 : 1024)))   // 5: round-2 unperturbed sweep
+    else if ((algo == 2 && noise_mode != 0) || (algo == 0 && can_fast && N >= 1024))
         rc = dgg_allpairs_topk_fast_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
     else
         rc = dgg_allpairs_topk_exhaustive_impl(xp, N, h, row0, row1, t, noise_mode, G, ldG, s0, s1, K, idx, val, st);

@@ -139,20 +139,10 @@ __device__ __forceinline__ float score_upper_bound(float dot, float ni, float nj
     return lpub + G + (3e-5f + 2e-5f * fabsf(lpub));
 }
 
-// Unperturbed scores: the radius of a row's 64 nearest neighbours is GUESSED from a pilot (PILOT_T sampled column tiles: the
-// larger of the two half-rows' PILOT_M-th smallest bf16 distance bounds, i.e. about the 16th smallest of 5120 sampled columns,
-// which admits a few hundred of the N columns with a relative spread of ~25 %) instead of starting at infinity, where the branch-and-bound would exact-score ~64 (1 + ln(N/64))
-// = 535 candidates per row at N = 100k before its threshold has converged (that, not the MFMA sweep, was 80 % of the kernel).
-// A guess that turns out too tight is DETECTED (fewer than 64 entries, or a 64th distance beyond the guess) and the row is
-// redone without pruning by topk_fast_fallback, so the result stays exact.
 struct FastCtl {
     int nfail;
     int pad[3];
 };
-constexpr int PILOT_T = 160;         // sampled column tiles (5120 columns)
-constexpr int PILOT_M = 8;           // order statistic kept per half-row: the radius covers >= 2 * PILOT_M samples
-constexpr int TAU_SAMPLE = 256;     // candidates fast_finalize looks at for its pruning threshold
-constexpr int CAPF = 2048;          // candidate slots per row of the unperturbed two-phase path (expected ~400 at the pilot's radius)
 
 template <int H, int NOISE, int RBLK>   // NOISE: 0 none, 2 hash, 3 symmetric hash
 __global__ __launch_bounds__(64) void allpairs_topk_fast(
@@ -372,275 +362,7 @@ __global__ __launch_bounds__(64) void allpairs_topk_fast(
 #endif
 }
 
-// ---- unperturbed scores: dedicated candidate sweep ---------------------------------------------------------------------------
-// The branch-and-bound kernel above is built around wavefronts that stop to flush; without flushes (the unperturbed path
-// collects candidates at the pilot's radius and settles them in fast_finalize) nothing stops, so the sweep is restructured as
-// a plain tiled kernel: a workgroup of 4 wavefronts owns 128 rows (one 32-row MFMA block per wavefront) and streams ALL
-// columns in tiles of 128, staged ONCE per workgroup through a double-buffered, padded LDS image (register prefetch of the next
-// tile during the MFMAs of the current one, one barrier per tile); per 32x32 Gram block: 4 bf16 MFMAs, 16 bounds per lane,
-// ONE compare of their minimum against the row's radius.  782 workgroups at N = 100k: three per CU.
-constexpr int NPC = 128;           // columns per staged tile
-template <int H>
-__global__ __launch_bounds__(256, H <= 64 ? 4 : 2) void np_sweep(const __bf16 *__restrict__ xb, const float *__restrict__ nb, int64_t N, int64_t row0,
-                                                int64_t row1, float gscale, int2 *__restrict__ cand, int *__restrict__ cand_cnt,
-                                                float *__restrict__ cand_guess) {
-    constexpr int KS = H / 16, STRIDE = H * 2 + 16, CPT = H / 8;     // 16-byte chunks per column
-    constexpr int LQ = NPC * CPT / 256;                              // chunks per thread and tile
-    __shared__ __attribute__((aligned(16))) unsigned char colA[2][NPC * STRIDE];
-    __shared__ __attribute__((aligned(16))) float nbt[2][NPC];
-    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), r = lane & 31, hh = lane >> 5;
-    const int lr = wave * 32 + r;                                    // row of this lane inside the workgroup
-    const int64_t i = row0 + (int64_t)blockIdx.x * 128 + lr;
-    const bool rvalid = i < row1;
-    const int64_t ic = rvalid ? i : row1 - 1;
-    bf16x8 bfr[KS];
-#pragma unroll
-    for (int s = 0; s < KS; s++) bfr[s] = *reinterpret_cast<const bf16x8 *>(xb + ic * H + 16 * s + 8 * hh);
-    const float nbi = nb[ic];
-    uint4 stg[LQ];                                                   // (plain arrays: a struct passed by reference to the lambdas is not
-    float stg_nb = 0.0f;                                             //  promoted to registers and round-trips through scratch memory)
-    // (zero + conditional load: the unconditional clamped form makes the compiler keep `stg` in scratch memory -- 80 bytes per lane)
-    auto tile_load = [&](int64_t c0) {
-#pragma unroll
-        for (int q = 0; q < LQ; q++) {
-            const int ch = q * 256 + tid;
-            stg[q] = make_uint4(0, 0, 0, 0);
-            if (c0 + ch / CPT < N) stg[q] = *reinterpret_cast<const uint4 *>(xb + c0 * H + (int64_t)ch * 8);
-        }
-        if (tid < NPC) stg_nb = (c0 + tid < N) ? nb[c0 + tid] : 3.0e38f;
-    };
-    auto tile_store = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < LQ; q++) {
-            const int ch = q * 256 + tid;
-            *reinterpret_cast<uint4 *>(&colA[buf][(ch / CPT) * STRIDE + (ch % CPT) * 16]) = stg[q];
-        }
-        if (tid < NPC) nbt[buf][tid] = stg_nb;
-    };
-    // bounds of one 32-column block of the staged tile against this wavefront's 32 rows
-    auto bounds = [&](int buf, int sub, float (&L2)[16]) {
-        bf16x8 af[KS];
-#pragma unroll
-        for (int s = 0; s < KS; s++) af[s] = *reinterpret_cast<const bf16x8 *>(&colA[buf][(sub * 32 + r) * STRIDE + (16 * s + 8 * hh) * 2]);
-        f32x16 acc;
-#pragma unroll
-        for (int q = 0; q < 16; q++) acc[q] = 0.0f;
-#pragma unroll
-        for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bfr[s], acc, 0, 0, 0);
-#pragma unroll
-        for (int g4 = 0; g4 < 4; g4++) {
-            const float4 nj4 = *reinterpret_cast<const float4 *>(&nbt[buf][sub * 32 + 8 * g4 + 4 * hh]);
-            const float njs[4] = {nj4.x, nj4.y, nj4.z, nj4.w};
-#pragma unroll
-            for (int u = 0; u < 4; u++) L2[4 * g4 + u] = __fmaf_rn(-2.0f, acc[4 * g4 + u], nbi + njs[u]);
-        }
-    };
-    const int ntiles = (int)((N + NPC - 1) / NPC);
-    // ---- pilot: PILOT_T / 4 tiles spread over the column range (per-workgroup offset) -> radius guess (see allpairs_topk_fast)
-    float guess = 3.0e38f;
-    constexpr int PT = PILOT_T / 4;
-    if (ntiles >= 2 * PT) {
-        float tm[PILOT_M];
-#pragma unroll
-        for (int q = 0; q < PILOT_M; q++) tm[q] = 3.0e38f;
-        const int stride_t = ntiles / PT;
-        const int first_t = (int)(((uint32_t)blockIdx.x * 2654435761u) % (uint32_t)stride_t);
-        for (int pt = 0; pt < PT; pt++) {
-            tile_load((int64_t)(first_t + pt * stride_t) * NPC);
-            __syncthreads();
-            tile_store(0);
-            __syncthreads();
-#pragma unroll
-            for (int sub = 0; sub < NPC / 32; sub++) {
-                float L2[16];
-                bounds(0, sub, L2);
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    float v = L2[q];
-                    if (v < tm[PILOT_M - 1]) {
-#pragma unroll
-                        for (int m = 0; m < PILOT_M; m++) { const float lo = fminf(v, tm[m]); v = fmaxf(v, tm[m]); tm[m] = lo; }
-                    }
-                }
-            }
-        }
-        const float other = __shfl_xor(tm[PILOT_M - 1], 32, 64);
-        guess = fmaxf(fmaxf(tm[PILOT_M - 1], other), 0.0f) * gscale + 1e-6f;
-        __syncthreads();
-    }
-    // Candidate appends: the two lanes of a row (columns 4*hh.. of every 8) each own HALF of the row's list and a private counter
-    // in a register.  (A shared LDS counter per row -- atomicAdd with return -- put one LDS round trip on every append site a
-    // wavefront entered: ~16 sites per tile, most of the 9000 cycles a tile took; 5.9 -> 5.3 ms.)
-    int2 *cl = cand + ((int64_t)blockIdx.x * 128 + lr) * CAPF + hh * (CAPF / 2);
-    int mycnt = 0;
-    // ---- sweep  (measured and rejected: two register stages, i.e. the loads of tile tl + 3 in flight while tile tl + 1 waits
-    // in registers -- 7.0 ms against 5.3)
-    // Candidate test.  A lane holds 16 bounds per 32x32 block and a wavefront ~4 hits among its 1024: testing the 16 positions
-    // one by one costs a compare + divergent branch each, and the wavefront enters whenever ANY lane hits (5.3 -> 4.4 ms).
-    // The loop is VALU-bound: ~570 dynamic VALU instructions per wavefront and 128-column tile (16 fma + 16 tags + 32 min/med3
-    // per block, the append paths, the rescans), 4 wavefronts per SIMD; the staging skeleton alone takes 0.9 ms.  Instead the column position q is written into the 4 low mantissa bits of each bound (a slightly SMALLER bound:
-    // still a lower bound) and the lane's two smallest tagged bounds come out of a min / med3 chain: one test per block for
-    // the first hit, one for the second (12 % of blocks for some lane), and only a lane with two hits rescans its 16 values.
-    const float rad2f = rvalid ? __int_as_float(__float_as_int(guess) | 15) : -INFINITY;
-    auto append = [&](float tagged, uint32_t colbase) {
-        const int bits = __float_as_int(tagged), q = bits & 15;
-        if (mycnt < CAPF / 2) cl[mycnt] = make_int2((int)(colbase + (uint32_t)((q & 3) + 8 * (q >> 2))), bits & ~15);
-        mycnt++;
-    };
-    tile_load(0);
-    tile_store(0);
-    __syncthreads();
-    for (int tl = 0; tl < ntiles; tl++) {
-        const int buf = tl & 1;
-        if (tl + 1 < ntiles) tile_load((int64_t)(tl + 1) * NPC);         // in flight during the MFMAs below
-        const uint32_t cbase = (uint32_t)tl * NPC + (uint32_t)(4 * hh);
-#pragma unroll
-        for (int sub = 0; sub < NPC / 32; sub++) {
-            float vb[16];
-            bounds(buf, sub, vb);
-            float m1 = INFINITY, m2 = INFINITY;                      // the two smallest tagged bounds (m1 <= m2)
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                vb[q] = __int_as_float((__float_as_int(vb[q]) & ~15) | q);
-                m2 = __builtin_amdgcn_fmed3f(m1, m2, vb[q]);
-                m1 = fminf(m1, vb[q]);
-            }
-            if (__ballot(m1 <= rad2f) != 0ull) {                     // wave-uniform
-                const uint32_t colbase = cbase + (uint32_t)(sub * 32);
-                if (m1 <= rad2f) append(m1, colbase);
-                if (__ballot(m2 <= rad2f) != 0ull) {
-                    if (m2 <= rad2f) {
-                        append(m2, colbase);
-                        const int q1 = __float_as_int(m1) & 15, q2 = __float_as_int(m2) & 15;
-#pragma unroll
-                        for (int q = 0; q < 16; q++)
-                            if (q != q1 && q != q2 && vb[q] <= rad2f) append(vb[q], colbase);
-                    }
-                }
-            }
-        }
-        if (tl + 1 < ntiles) tile_store(buf ^ 1);
-        __syncthreads();
-    }
-    const int c1 = __shfl_xor(mycnt, 32, 64);                    // the other half's count
-    if (rvalid && hh == 0) {                                     // packed (low 16 bits: half 0, high: half 1; 0xffff = overflow)
-        const int n0 = mycnt <= CAPF / 2 ? mycnt : 0xffff, n1 = c1 <= CAPF / 2 ? c1 : 0xffff;
-        cand_cnt[(int64_t)blockIdx.x * 128 + lr] = n0 | (n1 << 16);
-        cand_guess[(int64_t)blockIdx.x * 128 + lr] = guess;
-    }
-}
-
-// settle one row's candidate list (unperturbed scores): (1) tau = 64th smallest UPPER bound of d^2 over the candidates
-// (U = L + 2 eps (n_i + n_j) with L the stored bf16 lower bound): at least 64 candidates have d^2 <= tau, so a candidate with
-// L > tau cannot be among the 64 nearest; (2) exact canonical score of the survivors (typically 70-100 of ~400), sorted and
-// merged; (3) verification of the pilot's guess: the list is exact iff it is full and its 64th exact distance lies inside
-// the guessed radius (every pair the sweep pruned had d^2 >= L > guess).  Rows that fail go to the fail list.
-template <int H>
-__global__ __launch_bounds__(256) void fast_finalize(const float *__restrict__ xp, const float *__restrict__ nb, int64_t N, int64_t row0,
-                                                     int64_t row1, float t, const int2 *__restrict__ cand, const int *__restrict__ cand_cnt,
-                                                     const float *__restrict__ cand_guess, FastCtl *__restrict__ ctl,
-                                                     int *__restrict__ faillist, int32_t *__restrict__ idx, float *__restrict__ val) {
-    const int lane = threadIdx.x & 63;
-    const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
-    const int64_t i = row0 + lrow;
-    if (i >= row1) return;
-    const int packed = cand_cnt[lrow], n0 = packed & 0xffff, n1 = (packed >> 16) & 0xffff;   // two half lists (np_sweep)
-    const int n = n0 + n1;
-    const float guess = cand_guess[lrow];
-    const int2 *cl0 = cand + lrow * CAPF;
-    auto cand_at = [&](int e) { return cl0[e < n0 ? e : CAPF / 2 + (e - n0)]; };
-    bool ok = n0 <= CAPF / 2 && n1 <= CAPF / 2 && n >= 64;
-    uint64_t list = DGG_EMPTY_KEY;
-    if (ok) {
-        const float ni = nb[i];                                  // discounted norms: n (1 - eps)
-        constexpr float SL = 2.0f * EPS_BF16 / (1.0f - EPS_BF16) * 1.0001f;
-        // (1) 64 smallest upper bounds: keys ordered by the COMPLEMENT of the bound's bits (bounds clamped at 0: bit-monotone)
-        // (any subset gives a valid tau -- 64 of ITS upper bounds lie below it: the first 256 candidates cost four sort + merge
-        //  rounds instead of seven and leave ~20 more survivors for stage 2)
-        uint64_t ub = DGG_EMPTY_KEY;
-        const int n1s = n < TAU_SAMPLE ? n : TAU_SAMPLE;
-        for (int base = 0; base < n1s; base += 64) {
-            const int e = base + lane;
-            uint64_t key = DGG_EMPTY_KEY;
-            if (e < n1s) {
-                const int2 c = cand_at(e);
-                const float L = __int_as_float(c.y);
-                const float U = fmaxf(L + SL * (ni + nb[c.x]), 0.0f) * 1.00001f + 1e-7f;
-                key = ((uint64_t)(~__float_as_uint(U)) << 32) | (uint32_t)(e + 1);
-            }
-            key = wave_sort<false>(key, lane);
-            ub = wave_merge_top64_asc(ub, key, lane);
-        }
-        const float tau = __uint_as_float(~(uint32_t)(shfl_u64(ub, 63) >> 32));
-        // (2) exact scores of the candidates whose lower bound can still reach tau
-        for (int base = 0; base < n; base += 64) {
-            const int e = base + lane;
-            int32_t j = -1;
-            if (e < n) {
-                const int2 c = cand_at(e);
-                if (__int_as_float(c.y) <= tau) j = c.x;
-            }
-            if (__ballot(j >= 0) == 0ull) continue;
-            uint64_t key = DGG_EMPTY_KEY;
-            if (j >= 0) key = make_key(exact_score<H>(xp, i, j, t, 0, 0u, 0u), j);
-            key = wave_sort<false>(key, lane);
-            list = wave_merge_top64_asc(list, key, lane);
-        }
-        // (3) verify the guess
-        const uint64_t k63 = shfl_u64(list, 63);
-        if (k63 == DGG_EMPTY_KEY) ok = false;
-        else if (guess < 1.0e38f) {
-            const float d63 = __logf(fmaxf(key_val(k63), 1e-37f)) / t;
-            ok = d63 * d63 * (1.0f + 1e-4f) + 1e-6f <= guess;
-        }
-    }
-    if (ok) {
-        idx[lrow * 64 + lane] = key_col(list);
-        val[lrow * 64 + lane] = key_val(list);
-    } else if (lane == 0) {
-        faillist[atomicAdd(&ctl->nfail, 1)] = (int)lrow;
-    }
-}
-
-// rows whose guessed radius failed verification: redone from scratch, one workgroup per row, LANE = COLUMN, every column scored
-// exactly (25 MB of gathers per row at N = 100k; a handful of rows)
-template <int H>
-__global__ __launch_bounds__(256) void topk_fast_fallback(const float *__restrict__ xp, int64_t N, int64_t row0, float t,
-                                                         const FastCtl *__restrict__ ctl, const int *__restrict__ faillist,
-                                                         int32_t *__restrict__ idx, float *__restrict__ val) {
-    __shared__ uint64_t lists[4][64];
-    const int lane = threadIdx.x & 63, wave = dgg::wave_id();
-    const int nfail = ctl->nfail;
-    for (int f = blockIdx.x; f < nfail; f += gridDim.x) {
-        const int lrow = faillist[f];
-        const int64_t i = row0 + lrow;
-        uint64_t list = DGG_EMPTY_KEY;
-        for (int64_t j0 = (int64_t)wave * 64; j0 < N; j0 += 256) {
-            const int64_t j = j0 + lane;
-            uint64_t key = DGG_EMPTY_KEY;
-            if (j < N) key = make_key(exact_score<H>(xp, i, (int32_t)j, t, 0, 0u, 0u), (int32_t)j);
-            key = wave_sort<false>(key, lane);
-            list = wave_merge_top64_asc(list, key, lane);
-        }
-        lists[wave][lane] = list;
-        __syncthreads();
-        if (wave == 0) {
-            for (int w = 1; w < 4; w++) list = wave_merge_top64_asc(list, wave_sort<false>(lists[w][lane], lane), lane);
-            const bool empty = list == DGG_EMPTY_KEY;
-            idx[(int64_t)lrow * 64 + lane] = empty ? -1 : key_col(list);
-            val[(int64_t)lrow * 64 + lane] = empty ? 0.0f : key_val(list);
-        }
-        __syncthreads();
-    }
-}
-
 constexpr int RBLK_DEFAULT = 2;
-// headroom factor on the pilot's radius guess; tests shrink it (DGG_FAST_GUESS_SCALE) to force the verification / fallback path
-static float g_fast_guess_scale = [] {
-    const char *e = getenv("DGG_FAST_GUESS_SCALE");
-    return e ? (float)atof(e) : 1.02f;
-}();
-
 template <int H>
 int launch_fast(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, int noise_mode, uint32_t s0, uint32_t s1,
                 int32_t *idx, float *val, void *ws, hipStream_t st) {
@@ -658,16 +380,7 @@ int launch_fast(const float *xp, int64_t N, int64_t row0, int64_t row1, float t,
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, xp, N, H, xb, nb);
     dim3 grid((unsigned)((row1 - row0 + 32 * RBLK - 1) / (32 * RBLK)));
     if (noise_mode == 0) {
-        // two-phase: sweep (candidate lists at the pilot's radius) -> finalize (one wavefront per row) -> fallback (failed rows)
-        char *w2 = reinterpret_cast<char *>(faillist) + rows64 * 4;
-        int *cand_cnt = reinterpret_cast<int *>(w2);
-        float *cand_guess = reinterpret_cast<float *>(w2 + rows64 * 4);
-        int2 *cand = reinterpret_cast<int2 *>(w2 + 2 * rows64 * 4);
-        hipLaunchKernelGGL(np_sweep<H>, dim3((unsigned)((row1 - row0 + 127) / 128)), dim3(256), 0, st, xb, nb, N, row0, row1, g_fast_guess_scale,
-                           cand, cand_cnt, cand_guess);
-        hipLaunchKernelGGL(fast_finalize<H>, dim3((unsigned)((row1 - row0 + 3) / 4)), dim3(256), 0, st, xp, nb, N, row0, row1, t, cand, cand_cnt,
-                           cand_guess, ctl, faillist, idx, val);
-        hipLaunchKernelGGL(topk_fast_fallback<H>, dim3(256), dim3(256), 0, st, xp, N, row0, t, ctl, faillist, idx, val);
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "unperturbed scores: dgg_topk_sweep.hip (N >= 8192) or the exhaustive kernel");
     } else if (noise_mode == 2)
         hipLaunchKernelGGL((allpairs_topk_fast<H, 2, RBLK>), grid, dim3(64), 0, st, xp, xb, nb, pend, N, row0, row1, t, s0, s1, idx, val, ctl,
                            faillist, 1.0f, nullptr, nullptr, nullptr);
@@ -692,12 +405,11 @@ extern "C" int dgg_debug_read_stamps(unsigned long long *out8, int reset) {
 
 size_t dgg_allpairs_fast_ws_bytes(int64_t N, int h) {
     size_t rows = ((size_t)N + 127) / 128 * 128;
-    return (((size_t)N * h * 2 + 255) / 256) * 256 + (((size_t)N * 4 + 255) / 256) * 256 + rows * CAP * 4 + 256 + rows * 4 +
-           2 * rows * 4 + rows * (size_t)CAPF * sizeof(int2);    // + counts, guesses and candidate lists of the unperturbed path
+    return (((size_t)N * h * 2 + 255) / 256) * 256 + (((size_t)N * 4 + 255) / 256) * 256 + rows * CAP * 4 + 256 + rows * 4;
 }
 
 bool dgg_allpairs_fast_supported(int h, int noise_mode, int K) {
-    return K == 64 && (h == 16 || h == 32 || h == 64 || h == 128) && noise_mode != 1;
+    return K == 64 && (h == 16 || h == 32 || h == 64 || h == 128) && noise_mode >= 2;   // (unperturbed scores: dgg_topk_sweep.hip)
 }
 
 int dgg_allpairs_topk_fast_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode,

@@ -4,24 +4,26 @@
 //
 // Guess, sweep, verify -- in two phases, so that the radius each row is swept with is TIGHT:
 //
-//   sw_prep      xw[j] = [ bf16(xp_j) | c_hi c_mid c_lo 1 1 1 0.. ]  (H + 16 bf16 per node), c_j = -nb_j / 2,
-//                nb_j = ||xp_j||^2 (1 - eps): the "augmented" K-step folds the norms and the row's radius INTO the MFMA chain:
+//   sw_prep      xw[j] = [ fp16(xp_j) | c_hi c_mid c_lo 1 1 1 0.. ]  (H + 16 16-bit values per node), c_j = -nb_j / 2, nb_j = the
+//                discounted squared norm: the "augmented" K-step (bf16) folds the norms and the row's radius INTO the MFMA chain:
 //                D_ij = <x^_i, x^_j> + c_j + t_i  with the row side [ 1 1 1 t_hi t_mid t_lo 0.. ];   t_i = (R_i - nb_i) / 2
 //                => D_ij >= 0  <=>  L_ij := nb_i + nb_j - 2 <x^_i, x^_j>  <=  R_i    (L_ij: rigorous lower bound of d^2_ij)
 //                so "is (i, j) inside row i's radius" is the SIGN BIT of an accumulator register: no VALU arithmetic per pair.
-//   sw_pilot     loose radius per row from ~N/22 sampled columns (8th smallest bound per half row), as before.
-//   sw_sweep<A>  phase A: every 4th column tile, loose radius; hits recorded WITH their bound value (~100 per row).
-//   sw_select    per row: the m-th smallest bound among the phase-A hits (m = 36 of a 1/4 sample => ~144 expected in N) becomes
-//                the TIGHT radius R_i (never above the loose one).
+//   sw_pilot     loose radius per row from ~N/22 sampled columns (8th smallest bound per half row).
+//   sw_sweep<A>  phase A: every 4th column tile, loose radius; hits recorded WITH a bound value (~140 per row).
+//   sw_select    per row: the cut at which m = 32 of the phase-A hits have their UPPER bound inside (a 1/4 sample: >= 64 true
+//                neighbours in N with probability ~0.9999) becomes the TIGHT radius R_i (never above the loose one); the phase-A
+//                hits inside it are compacted for sw_finalize.
 //   sw_sweep<B>  phase B: the other 3/4 of the tiles, tight radius; hits recorded as bare columns (~100 per row).
-//   sw_finalize  per row: phase-A hits inside the tight radius + all phase-B hits (~140 columns) scored with the canonical fp32
-//                arithmetic, sorted, top-64 kept; VERIFIED: the list is exact iff it is full and its 64th distance lies inside
-//                R_i (every pair the sweeps rejected has d^2 >= L > R_i).  Rows that fail are redone by sw_fallback (every
-//                column scored): the result is exact whatever the guesses were.
+//   sw_finalize  per row: kept phase-A hits + phase-B hits (~135 columns): exact fp32 squared distances, the 64th smallest by
+//                bisection, the ~65 columns inside it scored canonically and sorted once; VERIFIED: the list is exact iff it is
+//                full and its 64th distance lies inside R_i (every pair the sweeps rejected has d^2 >= L > R_i).  Rows that fail
+//                are redone by sw_fallback_* (every column scored): the result is exact whatever the guesses were.
 //
 // Sweep kernel: a workgroup of 4 wavefronts owns 128 * RBLK rows (RBLK 32-row MFMA blocks per wavefront, B operands in
 // registers for the whole kernel) and streams its share of the column tiles (128 columns, interleaved over CS workgroups per
-// row block) through a double-buffered, padded LDS image; per 32 x 32 block: KS + 1 bf16 MFMAs (v_mfma_f32_32x32x16_bf16),
+// row block) through a double-buffered, padded LDS image; per 32 x 32 block: KS fp16 MFMAs + the augmented bf16 one
+// (v_mfma_f32_32x32x16_f16 / _bf16; the chain of block n + 1 is issued before the sign tests of block n),
 // 16 v_alignbit (sign bits -> one 16-bit hit mask per lane); the masks of the RBLK blocks that share a column block are packed
 // and tested with ONE wave-uniform branch (a branch per block was entered for 72 % of the blocks and cost 0.3 of the 1.2 ms).
 // A lane appends its hits to its PRIVATE list (lane, segment; the record carries the row block), so there are no atomics and
@@ -35,16 +37,27 @@ using namespace dgg;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
 constexpr int TC = 128;                 // columns per staged tile
-constexpr float EPS_BF16 = 0.00405f;    // 2^-8 (1 + 2^-10) = 0.0039101 covers the bf16 rounding of both operands; the rest
-                                        // (1.4e-4 of n_i + n_j) covers fp32 accumulation order, the norm sums, the split of c/t
+// The Gram products run on FP16 operands (v_mfma_f32_32x32x16_f16: the bf16 rate, 11 significant bits instead of 8): the bound
+//   d^2 >= (n_i + n_j)(1 - eps) - 2 delta sqrt(H) (sqrt n_i + sqrt n_j) - 2 <x^_i, x^_j>
+// is 8 x tighter than with bf16 operands (a row's candidate shell shrinks from 0.8 % to 0.2 % of n_i + n_j).
+//   eps   = 2^-10 (1 + 2^-12) = 0.00097681 for the rounding of both operands, rest (7e-5) for fp32 accumulation order, the
+//           norm sums and the splits of c and t;
+//   delta = 2^-14: an operand below the smallest normal fp16 may be flushed to zero by the matrix pipe.
+// A node with a feature beyond the fp16 range ("wild", |x| > 60000) is handled conservatively: as a column it is a hit for
+// every row (c = +3e38), as a row it accepts every column (t = +3e38: its lists overflow and the fallback settles it).
+constexpr float EPS_F16 = 0.00105f;
+constexpr float DELTA_F16 = 6.103515625e-5f;
+constexpr float WILD = 60000.0f;
 constexpr int CAPA_ROW = 512;           // phase-A record slots per row (all its sub-lists together; expected ~100)
 constexpr int CAPB_ROW = 384;           // phase-B record slots per row (expected ~110)
 constexpr int LOOSE_TARGET = 350;       // columns the loose radius should admit per row (of N)
-constexpr int PILOT_M = 8;              // order statistic kept per half row by the pilot
+constexpr int PILOT_M = 8;              // order statistic kept per half row by the pilot (sample = N * 2 * PILOT_M / LOOSE_TARGET columns;
+                                        // measured: 5 of 220 saves 0.03 ms in sw_select and fails 20 x more rows at N = 500k)
 
 struct SweepCtl {
     int nfail;
@@ -63,6 +76,7 @@ __host__ __device__ inline int tileB(int w) { return w + w / 3 + 1; }
 
 // exact split of an fp32 value into three bf16 pieces (hi + mid + lo == c)
 __device__ __forceinline__ void split3(float c, __bf16 &hi, __bf16 &mid, __bf16 &lo) {
+    if (!(fabsf(c) < 2.9e38f)) { hi = (__bf16)c; mid = lo = (__bf16)0.0f; return; }      // the +-3e38 / -inf markers
     const float fh = __uint_as_float(__float_as_uint(c) & 0xffff0000u);
     const float r1 = c - fh;
     const float fm = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
@@ -70,31 +84,37 @@ __device__ __forceinline__ void split3(float c, __bf16 &hi, __bf16 &mid, __bf16 
     hi = (__bf16)fh; mid = (__bf16)fm; lo = (__bf16)fl;
 }
 
-// ---- prologue: bf16 copy + augmented K-step of every node, discounted norms ------------------------------------------------
+// ---- prologue: fp16 copy + augmented K-step (bf16) of every node, discounted norms --------------------------------------------
 template <int H>
-__global__ __launch_bounds__(256) void sw_prep(const float *__restrict__ xp, int64_t N, int64_t npad, __bf16 *__restrict__ xw,
+__global__ __launch_bounds__(256) void sw_prep(const float *__restrict__ xp, int64_t N, int64_t npad, uint16_t *__restrict__ xw,
                                                float *__restrict__ nb) {
     constexpr int HW = H + 16;
     const int lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * 4 + dgg::wave_id();
     if (j >= npad) return;
     float s = 0.0f;
+    bool wild = false;
     for (int c = lane; c < H; c += 64) {
-        const float v = j < N ? xp[j * H + c] : 0.0f;
-        xw[j * HW + c] = (__bf16)v;
+        float v = j < N ? xp[j * H + c] : 0.0f;
         s += v * v;
+        if (!(fabsf(v) <= WILD)) { wild = true; v = v > 0.0f ? WILD : (v < 0.0f ? -WILD : 0.0f); }
+        const _Float16 hv = (_Float16)v;
+        xw[j * HW + c] = __builtin_bit_cast(uint16_t, hv);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    wild = __ballot(wild) != 0ull;
     if (lane < 16) {
-        const float nbj = s * (1.0f - EPS_BF16);
-        const float c = j < N ? -0.5f * nbj : -3.0e38f;
+        float nbj = s * (1.0f - EPS_F16) - 2.0f * DELTA_F16 * sqrtf((float)H) * sqrtf(s) * 1.0001f;
+        float c = -0.5f * nbj;
+        if (wild) { nbj = INFINITY; c = 3.0e38f; }
+        if (j >= N) c = -INFINITY;
         __bf16 p[3];
         split3(c, p[0], p[1], p[2]);
         __bf16 v = (__bf16)0.0f;
         if (lane < 3) v = p[lane];
         else if (lane < 6) v = (__bf16)1.0f;
-        xw[j * HW + H + lane] = v;
+        xw[j * HW + H + lane] = __builtin_bit_cast(uint16_t, v);
         if (lane == 0 && j < N) nb[j] = nbj;
     }
 }
@@ -113,7 +133,15 @@ __device__ __forceinline__ bf16x8 aug_row(float t, int hh) {
     return v;
 }
 
-// staged column tiles: TC columns x (H + 16) bf16, padded to a stride of (H + 16) * 2 + 16 bytes (odd multiple of 16:
+// one K-step of the chain: the data steps on fp16 operands, the last (augmented) step on bf16 (its entries need the fp32 exponent
+// range); the registers are 128-bit containers either way
+template <bool AUG>
+__device__ __forceinline__ f32x16 mfma_step(const bf16x8 &a, const bf16x8 &b, const f32x16 &acc) {
+    if constexpr (AUG) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+
+// staged column tiles: TC columns x (H + 16) 16-bit values, padded to a stride of (H + 16) * 2 + 16 bytes (odd multiple of 16:
 // conflict-free ds_read_b128 by the 16-lane groups of the LDS)
 template <int H>
 struct Tile {
@@ -126,7 +154,7 @@ struct Tile {
 // Per lane the PILOT_M largest block maxima of E = <x^_i, x^_j> + c_j are kept (a block's second-largest value is ignored: the
 // pilot is a heuristic, exactness comes from the verification) -> L = nb_i - 2 E, radius = max over the two half rows * gscale.
 template <int H>
-__global__ __launch_bounds__(256) void sw_pilot(const __bf16 *__restrict__ xw, const float *__restrict__ nb, int64_t row0, int64_t row1,
+__global__ __launch_bounds__(256) void sw_pilot(const uint16_t *__restrict__ xw, const float *__restrict__ nb, int64_t row0, int64_t row1,
                                                 int ntiles, int pt_tiles, float gscale, float *__restrict__ tloose) {
     using TL = Tile<H>;
     constexpr int HW = TL::HW, KS1 = TL::KS1, STRIDE = TL::STRIDE, CPC = TL::CPC, LQ = TL::LQ;
@@ -144,16 +172,27 @@ __global__ __launch_bounds__(256) void sw_pilot(const __bf16 *__restrict__ xw, c
     for (int q = 0; q < PILOT_M; q++) tm[q] = -3.0e38f;
     const int stride_t = ntiles / pt_tiles;
     const int first_t = (int)(((uint32_t)blockIdx.x * 2654435761u) % (uint32_t)stride_t);
-    for (int pt = 0; pt < pt_tiles; pt++) {
+    // (the next sampled tile is fetched into registers while the current one is worked on: the tiles are scattered over the
+    //  column range, and a load -> store -> compute loop paid a full memory latency per tile, 0.10 ms in all)
+    uint4 stg[LQ];
+    auto tile_load = [&](int pt) {
         const int64_t c0 = (int64_t)(first_t + pt * stride_t) * TC;
+#pragma unroll
+        for (int q = 0; q < LQ; q++) {
+            stg[q] = make_uint4(0, 0, 0, 0);
+            if (pt < pt_tiles) stg[q] = *reinterpret_cast<const uint4 *>(xw + c0 * HW + (int64_t)(q * 256 + tid) * 8);
+        }
+    };
+    tile_load(0);
+    for (int pt = 0; pt < pt_tiles; pt++) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < LQ; q++) {
             const int ch = q * 256 + tid;
-            const uint4 v = *reinterpret_cast<const uint4 *>(xw + c0 * HW + (int64_t)ch * 8);
-            *reinterpret_cast<uint4 *>(&colA[(ch / CPC) * STRIDE + (ch % CPC) * 16]) = v;
+            *reinterpret_cast<uint4 *>(&colA[(ch / CPC) * STRIDE + (ch % CPC) * 16]) = stg[q];
         }
         __syncthreads();
+        tile_load(pt + 1);
 #pragma unroll
         for (int sub = 0; sub < TC / 32; sub++) {
             f32x16 acc;
@@ -162,7 +201,7 @@ __global__ __launch_bounds__(256) void sw_pilot(const __bf16 *__restrict__ xw, c
 #pragma unroll
             for (int s = 0; s < KS1; s++) {
                 const bf16x8 af = *reinterpret_cast<const bf16x8 *>(&colA[(sub * 32 + r) * STRIDE + (16 * s + 8 * hh) * 2]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[s], acc, 0, 0, 0);
+                acc = (s == KS1 - 1) ? mfma_step<true>(af, bfr[s], acc) : mfma_step<false>(af, bfr[s], acc);
             }
             float m = acc[0];
 #pragma unroll
@@ -179,7 +218,7 @@ __global__ __launch_bounds__(256) void sw_pilot(const __bf16 *__restrict__ xw, c
     float L = fmaf(-2.0f, tm[PILOT_M - 1], nbi);
     L = fmaxf(L, __shfl_xor(L, 32, 64));
     const float R = fmaxf(L, 0.0f) * gscale + 1e-6f;
-    if (rvalid && hh == 0) tloose[i - row0] = 0.5f * (R - nbi) + 1e-6f * (fabsf(R) + fabsf(nbi)) + 1e-7f;
+    if (rvalid && hh == 0) tloose[i - row0] = nbi < 3.0e38f ? 0.5f * (R - nbi) + 1e-6f * (fabsf(R) + fabsf(nbi)) + 1e-7f : 3.0e38f;   // (wild row)
 }
 
 // ---- sweep ---------------------------------------------------------------------------------------------------------------------
@@ -187,7 +226,7 @@ __global__ __launch_bounds__(256) void sw_pilot(const __bf16 *__restrict__ xw, c
 // Workgroup -> (row block, segment): same-XCD workgroups (blockIdx % 8, observed round-robin placement; speed only) walk the same
 // segment's tiles at about the same time, so a staged tile is an L2 hit for all but the first of them.
 template <int H, int RBLK, bool VALUES>
-__global__ __launch_bounds__(256, 2) void sw_sweep(const __bf16 *__restrict__ xw, const float *__restrict__ trow, int64_t npad, int64_t row0, int64_t row1,
+__global__ __launch_bounds__(256, 2) void sw_sweep(const uint16_t *__restrict__ xw, const float *__restrict__ trow, int64_t npad, int64_t row0, int64_t row1,
                                                    int nset, int nrb, int rbx, int CS, int cap, void *__restrict__ lists,
                                                    unsigned short *__restrict__ cnts) {
     using TL = Tile<H>;
@@ -208,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void sw_sweep(const __bf16 *__restrict__ xw
         const int64_t ic = rvalid ? i : row1 - 1;
 #pragma unroll
         for (int s = 0; s < KS1 - 1; s++) bfr[b][s] = *reinterpret_cast<const bf16x8 *>(xw + ic * HW + 16 * s + 8 * hh);
-        bfr[b][KS1 - 1] = aug_row(rvalid ? trow[ic - row0] : -3.0e38f, hh);
+        bfr[b][KS1 - 1] = aug_row(rvalid ? trow[ic - row0] : -INFINITY, hh);
     }
     // this lane's private list: (row group = the wavefront's RBLK x 32 rows, lane, segment); byte offsets relative to the workgroup's
     // first list (always < 2^32)
@@ -240,8 +279,8 @@ __global__ __launch_bounds__(256, 2) void sw_sweep(const __bf16 *__restrict__ xw
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[q] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < KS1; s++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bfr[b][s], acc, 0, 0, 0);
-        return acc;
+        for (int s = 0; s < KS1 - 1; s++) acc = mfma_step<false>(af[s], bfr[b][s], acc);
+        return mfma_step<true>(af[KS1 - 1], bfr[b][KS1 - 1], acc);
     };
     // sign bits of the 16 accumulators of a block -> bit q of a 16-bit mask (1 = outside the radius); two independent chains
     auto signs = [&](const f32x16 &acc) {
@@ -336,7 +375,9 @@ __global__ __launch_bounds__(256, 2) void sw_sweep(const __bf16 *__restrict__ xw
 // (m = 26 of a 1/4 sample: >= 64 in N with probability 0.995, whatever the density of the shell the radius falls into):
 // D' = D - SL (nb_i + nb_j) / 2, cut = m-th largest D' (>= 0: never looser than the loose radius), t_tight = t_loose - cut.
 // A phase-A hit lies inside the tight radius iff D >= cut.
-constexpr float SL_UPPER = (EPS_BF16 + 0.0039102f) / (1.0f - EPS_BF16) * 1.0001f;
+// U = L + SL_UPPER (nb_i + nb_j) is an upper bound of d^2 (both roundings the other way)
+constexpr float SL_UPPER = (EPS_F16 + 0.00097682f) / (1.0f - EPS_F16) * 1.0001f;
+// (only the choice of the tight radius uses U -- it decides speed, not exactness -- so the flush-to-zero allowance is left out)
 constexpr int KCAP = 128;               // phase-A hits inside the tight radius kept per row (expected ~40)
 constexpr uint32_t COLMASK = 0x0fffffffu;   // record = column | row block << 28
 
@@ -347,19 +388,19 @@ struct RowLists {
 };
 __device__ __forceinline__ RowLists row_lists(int64_t lrow, int rblk) {
     RowLists rl;
-    const int64_t grp = lrow / (32 * rblk);
+    const int64_t grp = lrow >> (rblk == 4 ? 7 : 6);                   // rblk is 2 or 4: no division
     rl.base = grp * 64 + (lrow & 31);
-    rl.tag = (uint32_t)((lrow >> 5) % rblk);
+    rl.tag = (uint32_t)((lrow >> 5) & (rblk - 1));
     return rl;
 }
 
 constexpr int SELCAP = CAPA_ROW;        // phase-A hits of one row that sw_select can hold (expected ~140; the loose radius has a heavy tail)
 __global__ __launch_bounds__(256) void sw_select(const int2 *__restrict__ listA, const unsigned short *__restrict__ cntA, int64_t rows, int64_t row0,
-                                                 int CSA, int capA, int rblk, int m, const float *__restrict__ nb, const float *__restrict__ tloose,
-                                                 float *__restrict__ ttight, int32_t *__restrict__ kept, int *__restrict__ keptn,
-                                                 SweepCtl *__restrict__ ctl) {
+                                                 int CSA, int capA, int rblk, int m, const float *__restrict__ nb,
+                                                 const float *__restrict__ tloose, float *__restrict__ ttight, int32_t *__restrict__ kept,
+                                                 int *__restrict__ keptn, SweepCtl *__restrict__ ctl) {
     // one wavefront per row.  Pass over the row's 2 * CSA lane lists: its own records (tag) are compacted into LDS as (column, D, D');
-    // the cut is found by BISECTION on D' (count of D' >= cut by ballots; any cut is valid -- the verification decides -- so 14
+    // the cut is found by BISECTION on D' (count of D' >= cut by ballots; any cut is valid -- the verification decides -- so 11
     // halvings replace three 64-lane sorts); the records with D >= cut go to the row's kept list.
     __shared__ int32_t scol[4][SELCAP];
     __shared__ float sd[4][SELCAP], sdp[4][SELCAP];
@@ -370,26 +411,53 @@ __global__ __launch_bounds__(256) void sw_select(const int2 *__restrict__ listA,
     const float nbi = nb[row0 + lrow];
     int total = 0;
     bool over = false;
-    for (int s = 0; s < 2 * CSA; s++) {
-        const int64_t id = (rl.base + 32 * (s / CSA)) * CSA + (s % CSA);
-        int n = cntA[id];
-        if (n > capA) { over = true; n = capA; }
-        const int2 *l = listA + id * capA;
-        for (int base = 0; base < n; base += 64) {
-            const int e = base + lane;
-            bool mine = false;
-            int2 c = make_int2(0, 0);
-            if (e < n) { c = l[e]; mine = ((uint32_t)c.x >> 28) == rl.tag; }
-            const unsigned long long mk = __ballot(mine);
-            const int at = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-            if (mine && at < SELCAP) {
-                const int32_t col = (int32_t)((uint32_t)c.x & COLMASK);
-                const float d = __int_as_float(c.y);
-                scol[wave][at] = col;
-                sd[wave][at] = d;
-                sdp[wave][at] = d - 0.5f * SL_UPPER * (nbi + nb[col]);
+    auto take = [&](bool mine, const int2 &c, float nbj) {            // compaction of the row's own records into LDS
+        const unsigned long long mk = __ballot(mine);
+        const int at = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+        if (mine && at < SELCAP) {
+            const float d = __int_as_float(c.y);
+            scol[wave][at] = (int32_t)((uint32_t)c.x & COLMASK);
+            sd[wave][at] = d;
+            sdp[wave][at] = d - 0.5f * SL_UPPER * (nbi + nbj);
+        }
+        total += __builtin_popcountll(mk);
+    };
+    // The lane lists are read LG at a time: counts, first chunks and norm gathers of a group are each ONE round trip (a loop
+    // over the lists paid three dependent memory latencies per list: 0.29 ms, all of it waiting).
+    constexpr int LG = 8;
+    const int nl = 2 * CSA;
+    auto list_id = [&](int s) { const int h2 = s >= CSA ? 1 : 0; return (rl.base + 32 * h2) * CSA + (s - h2 * CSA); };   // (no division)
+    const int myc = lane < nl ? (int)cntA[list_id(lane)] : 0;
+    for (int g0 = 0; g0 < nl; g0 += LG) {
+        int n[LG];
+        int2 c[LG];
+        float nbj[LG];
+        bool mine[LG];
+#pragma unroll
+        for (int k = 0; k < LG; k++) {
+            const int s = g0 + k;
+            n[k] = s < nl ? __builtin_amdgcn_readlane(myc, s < nl ? s : 0) : 0;
+            if (n[k] > capA) { over = true; n[k] = capA; }
+            c[k] = make_int2(0, 0);
+            if (lane < n[k]) c[k] = listA[list_id(s) * capA + lane];
+        }
+#pragma unroll
+        for (int k = 0; k < LG; k++) {
+            mine[k] = lane < n[k] && ((uint32_t)c[k].x >> 28) == rl.tag;
+            nbj[k] = mine[k] ? nb[(uint32_t)c[k].x & COLMASK] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < LG; k++)
+            if (n[k] > 0) take(mine[k], c[k], nbj[k]);                  // (wave-uniform)
+#pragma unroll
+        for (int k = 0; k < LG; k++) {                                  // lists longer than one chunk
+            for (int base = 64; base < n[k]; base += 64) {
+                const int e = base + lane;
+                int2 cc = make_int2(0, 0);
+                if (e < n[k]) cc = listA[list_id(g0 + k) * capA + e];
+                const bool m2 = e < n[k] && ((uint32_t)cc.x >> 28) == rl.tag;
+                take(m2, cc, m2 ? nb[(uint32_t)cc.x & COLMASK] : 0.0f);
             }
-            total += __builtin_popcountll(mk);
         }
     }
     const float tl = tloose[lrow];
@@ -405,16 +473,18 @@ __global__ __launch_bounds__(256) void sw_select(const int2 *__restrict__ listA,
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+        const int nch = (total + 63) >> 6;                              // chunks that hold data (wave-uniform)
         auto count_ge = [&](float x) {
             int c = 0;
 #pragma unroll
-            for (int k = 0; k < SELCAP / 64; k++) c += __builtin_popcountll(__ballot(v[k] >= x));
+            for (int k = 0; k < SELCAP / 64; k++)
+                if (k < nch) c += __builtin_popcountll(__ballot(v[k] >= x));
             return c;
         };
         if (total >= m && count_ge(0.0f) >= m) {
             float lo = 0.0f;                                            // invariant: count(D' >= lo) >= m
             hi = hi * 1.0001f + 1e-30f;
-            for (int it = 0; it < 14; it++) {
+            for (int it = 0; it < 11; it++) {
                 const float mid = 0.5f * (lo + hi);
                 if (count_ge(mid) >= m) lo = mid; else hi = mid;
             }
@@ -504,16 +574,33 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
         }
     }
     const int nkept = total;
-    for (int s = 0; ok && s < 2 * CSB; s++) {
-        const int64_t id = (rl.base + 32 * (s / CSB)) * CSB + (s % CSB);
-        const int n = cntB[id];
-        if (n > capB) { ok = false; break; }
-        const uint32_t *l = listB + id * capB;
-        for (int base = 0; base < n; base += 64) {
-            const int e = base + lane;
-            const uint32_t rec = e < n ? l[e] : 0xffffffffu;
-            const bool mine = e < n && (rec >> 28) == rl.tag;
-            push(mine, (int32_t)(rec & COLMASK));
+    {   // phase-B records: the lane lists are read LG at a time (counts and first chunks of a group: one round trip each)
+        constexpr int LG = 8;
+        const int nl = 2 * CSB;
+        auto list_id = [&](int s) { const int h2 = s >= CSB ? 1 : 0; return (rl.base + 32 * h2) * CSB + (s - h2 * CSB); };   // (no division)
+        const int myc = lane < nl ? (int)cntB[list_id(lane)] : 0;
+        if (__ballot(myc > capB) != 0ull) ok = false;
+        for (int g0 = 0; ok && g0 < nl; g0 += LG) {
+            int n[LG];
+            uint32_t rec[LG];
+#pragma unroll
+            for (int k = 0; k < LG; k++) {
+                const int s = g0 + k;
+                n[k] = s < nl ? __builtin_amdgcn_readlane(myc, s < nl ? s : 0) : 0;
+                rec[k] = 0xffffffffu;
+                if (lane < n[k]) rec[k] = listB[list_id(s) * capB + lane];
+            }
+#pragma unroll
+            for (int k = 0; k < LG; k++)
+                if (n[k] > 0) push(lane < n[k] && (rec[k] >> 28) == rl.tag, (int32_t)(rec[k] & COLMASK));
+#pragma unroll
+            for (int k = 0; k < LG; k++) {
+                for (int base = 64; base < n[k]; base += 64) {
+                    const int e = base + lane;
+                    const uint32_t r2 = e < n[k] ? listB[list_id(g0 + k) * capB + e] : 0xffffffffu;
+                    push(e < n[k] && (r2 >> 28) == rl.tag, (int32_t)(r2 & COLMASK));
+                }
+            }
         }
     }
     nB = total - nkept;
@@ -534,10 +621,12 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
                 }
             }
         }
+        const int nch = (total + 63) >> 6;                              // chunks that hold data (wave-uniform)
         auto count_le = [&](uint32_t x) {
             int c = 0;
 #pragma unroll
-            for (int k = 0; k < FCAP / 64; k++) c += __builtin_popcountll(__ballot(u[k] <= x));
+            for (int k = 0; k < FCAP / 64; k++)
+                if (k < nch) c += __builtin_popcountll(__ballot(u[k] <= x));
             return c;
         };
         // bisection: smallest tau with count(d2 <= tau) >= 64 -- stopped early once a value with exactly 64 below is met
@@ -735,7 +824,7 @@ int launch_sweep(const float *xp, int64_t N, int64_t row0, int64_t row1, float t
     const Plan p = make_plan(row1 - row0, N, H);
     const Layout L = make_layout(p, H);
     char *w = reinterpret_cast<char *>(ws);
-    __bf16 *xw = reinterpret_cast<__bf16 *>(w + L.xw);
+    uint16_t *xw = reinterpret_cast<uint16_t *>(w + L.xw);
     float *nb = reinterpret_cast<float *>(w + L.nb);
     SweepCtl *ctl = reinterpret_cast<SweepCtl *>(w + L.ctl);
     int *faillist = reinterpret_cast<int *>(w + L.fail);

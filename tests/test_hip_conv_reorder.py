@@ -216,7 +216,7 @@ def test_payload_partition_matches_the_slot_map_path(dev, h, F):
             np.testing.assert_allclose(Nn(got[0]), Nn(ref[0]), rtol=2e-4, atol=2e-4 * max(float(ref[0].abs().max()), 1e-9))
 
 
-@pytest.mark.parametrize("N,h,clustered", [(12_000, 64, False), (9_000, 16, True)])
+@pytest.mark.parametrize("N,h,clustered", [(12_000, 64, False), (9_000, 16, True), (10_000, 32, "wild"), (8_200, 128, False)])
 def test_unperturbed_allpairs_with_pilot_guess_is_bit_exact(dev, N, h, clustered):
     """dgg_allpairs_topk, no perturbation, MFMA-bounded kernel (algo 2) at sizes where the pilot guesses each row's 64-NN
     radius (N >= 8192): neighbour lists and scores equal the oracle's bit for bit -- uniform data and a mixture of a dense
@@ -224,7 +224,11 @@ def test_unperturbed_allpairs_with_pilot_guess_is_bit_exact(dev, N, h, clustered
     from dgg_amd import ops
     rng = np.random.default_rng(N + h)
     xp = (rng.standard_normal((N, h)) * 0.6).astype(np.float32)
-    if clustered:
+    if clustered == "wild":                                          # features outside the fp16 range of the Gram bound, tiny norms
+        xp[17, 3] = 1.0e5
+        xp[4000:4003] *= 3.0e4
+        xp[5000:5100] *= 1e-6
+    elif clustered:
         xp[:3000] *= 0.05                                            # tight cluster: its 64-NN radius is tiny
         xp[3000:3040] = xp[3000:3040] * 0.01 + 7.0                   # 40 far-away points: fewer than 64 close neighbours
     idx, val = ops.allpairs_topk(T(xp, dev), K, noise_mode=ops.NOISE_NONE, algo=2)
@@ -282,6 +286,122 @@ def test_bf16_gcnii_layer_product(dev, n, K, F, variant, residual):
     assert rel(outs[1], outs[0]) <= 1e-2
     for g16, g32 in zip(grads[1], grads[0]):
         assert rel(g16, g32) <= 2e-2
+
+
+def test_config4_ppi_gcniippi_dgg_bf16_end_to_end(dev):
+    """BASELINE configs[4] end to end: GCNIIppi_DGG (hidden 2048, 9 variant GCNII layers with residual, DGG at latent 2048 on
+    edge-list candidates; reference model.py:887-965, train_ppi.py:43-44, 204-219) on two PPI-shaped graphs, forward + backward,
+    with the GCNII layer products on the bf16 MFMA kernel (gemm_dtype = bfloat16):
+      (a) against the SAME model in fp32 (same parameters, same noise seed, identical neighbour lists): outputs within 1e-2 and
+          every gradient within 3e-2 of the tensor's max (bf16 rounds both GEMM operands to 8 significant bits; the gradient of
+          the first layer has passed through the bf16 backward products of all nine layers);
+      (b) against a float64 restatement of the layer stack (model.py:32-44, 942-957) that rounds the GEMM operands to bf16 exactly
+          as the kernel does, on the adjacency the module produced: EVERY LAYER, fed the module's own fp32 input of that layer,
+          within 1e-5 of its output's max (the kernel adds only fp32 accumulation error), and the whole 9-layer stack end to end
+          within 1e-4 (fp32 aggregation / epilogue / fc layers against float64 through nine residual layers: measured 3.6e-5)."""
+    import math
+    from argparse import Namespace
+    import dgg_amd
+    from bench import pubmed_graph
+    d, hid, C, L = 50, 2048, 121, 9
+    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
+    models = []
+    for dt in (None, torch.bfloat16):
+        torch.manual_seed(0)
+        m = dgg_amd.GCNIIppi_DGG(nfeat=d, nlayers=L, nhidden=hid, nclass=C, dropout=0.0, lamda=0.5, alpha=0.5, variant=True, args=args).to(dev)
+        with torch.no_grad():
+            for dg in m.dggs:
+                dg.k_net.k_project.weight.mul_(0.1)
+        for conv in m.convs:
+            conv.gemm_dtype = dt
+        m.train()                                                   # training mode: the DGG perturbs the scores (noise=True)
+        models.append(m)
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())  # noqa: E731
+    for n in (1300, 640):
+        rows, cols = pubmed_graph(n, n * 14, seed=n)
+        keep = rows != cols
+        A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows[keep], cols[keep]])), torch.ones(int(keep.sum())), (n, n)).coalesce().to(dev)
+        g = torch.Generator().manual_seed(n)
+        x = torch.randn(n, d, generator=g).to(dev)
+        y = (torch.rand(n, C, generator=g) < 0.3).float().to(dev)
+        outs, grads, adjs, taps = [], [], [], []
+        hooks = [con.register_forward_hook(lambda mod, inp, out: taps.append((inp[0].detach(), inp[2].detach(), out.detach())))
+                 for con in models[1].convs]
+        for m in models:
+            for p_ in m.parameters():
+                p_.grad = None
+            torch.manual_seed(77)                                   # the module draws its noise seed from torch's generator
+            out, unnorm = m._body(x, A, None, None)
+            prob = torch.sigmoid(out)
+            torch.nn.functional.binary_cross_entropy(prob, y).backward()
+            outs.append(prob.detach())
+            grads.append({k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None})
+            adjs.append(unnorm)
+        assert torch.equal(adjs[0].idx, adjs[1].idx), "the two runs must select the same graph (same seed, fp32 DGG in both)"
+        assert rel(outs[1], outs[0]) <= 1e-2
+        assert set(grads[0]) == set(grads[1]) and len(grads[0]) >= L + 4
+        for k in grads[0]:
+            assert rel(grads[1][k], grads[0][k]) <= 3e-2, k          # (measured: up to 2.2e-2, on the first layer's weight)
+        # (b) float64 restatement with bf16-rounded GEMM operands, on the module's own normalised adjacency
+        for hk in hooks:
+            hk.remove()
+        m = models[1]
+        Ahat = adjs[1].normalize().to_dense().double()
+        r16 = lambda t_: t_.float().bfloat16().double()            # noqa: E731  (round to nearest even, as pack_bf16)
+        assert len(taps) == L
+        with torch.no_grad():
+            for i, (con, (inp, h0t, outt)) in enumerate(zip(m.convs, taps)):      # layer by layer, on the module's own inputs
+                theta = math.log(m.lamda / (i + 1) + 1)
+                hi = Ahat @ inp.double()
+                want = theta * (r16(torch.cat([hi, h0t.double()], 1)) @ r16(con.weight)) + (1 - theta) * ((1 - m.alpha) * hi + m.alpha * h0t.double()) + inp.double()
+                assert rel(outt, want) <= 1e-5, (i, rel(outt, want))
+        with torch.no_grad():
+            h = torch.relu(x.double() @ m.fcs[0].weight.double().t() + m.fcs[0].bias.double())
+            h0 = h
+            for i, con in enumerate(m.convs):
+                theta = math.log(m.lamda / (i + 1) + 1)
+                hi = Ahat @ h
+                support = torch.cat([hi, h0], 1)
+                r = (1 - m.alpha) * hi + m.alpha * h0
+                h = torch.relu(theta * (r16(support) @ r16(con.weight)) + (1 - theta) * r + h)
+            ref = torch.sigmoid(h @ m.fcs[-1].weight.double().t() + m.fcs[-1].bias.double())
+        assert rel(outs[1], ref) <= 1e-4, rel(outs[1], ref)
+
+
+def test_bf16_weight_packs_are_never_stale(dev):
+    """two GraphConvolution layers of different size built back to back (the second parameter may land on the first one's freed
+    address, both at the same autograd version) and an update through `p.data` (which does not move the version counter): the bf16
+    product must use the CURRENT weights every time"""
+    import dgg_amd
+    from dgg_amd.adjacency import EllAdjacency
+    n = 200
+    idx = torch.arange(n, device=dev, dtype=torch.int32)[:, None].repeat(1, 64)
+    idx[:, 1:] = -1
+    vals = torch.zeros((n, 64), device=dev)
+    vals[:, 0] = 1.0
+    adj = EllAdjacency(idx, vals, n)
+
+    def run(L, x):
+        return L(x, adj, x * 0.5, 0.5, 0.1, 1)
+
+    for width in (128, 64, 256, 128):
+        L = dgg_amd.GraphConvolution(width, width, residual=True, variant=True).to(dev)
+        L.gemm_dtype = torch.bfloat16
+        x = torch.randn(n, width, device=dev)
+        a = run(L, x)
+        L.gemm_dtype = None
+        b = run(L, x)
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()), width
+        L.gemm_dtype = torch.bfloat16
+        L.weight.data.mul_(-2.0)                                    # does not bump L.weight._version
+        L.gemm_dtype = None
+        b2 = run(L, x)
+        L.gemm_dtype = torch.bfloat16
+        a2 = run(L, x)
+        assert float((a2 - b2).abs().max()) <= 2e-2 * float(b2.abs().max()), "stale bf16 pack after an update through .data"
+        del L
 
 
 @pytest.mark.parametrize("mode", [0, 1, 3])

@@ -506,7 +506,7 @@ def test_ranked_search_equals_explicit_noise_path_on_its_own_noise(dev, N, h):
     assert torch.equal(ev, rv), "ranked search and explicit-noise path disagree on the scores"
     # and with the ramp fused in (the bench's entry point), against the explicit path + softk_fwd
     k = T(rng.uniform(2.0, 50.0, N).astype(np.float32), dev)
-    fi, fv, fw, frs = ops.allpairs_topk_ranked_softk(T(xp, dev), k, seed=seed)
+    fi, fv, fw, frs = ops.allpairs_topk_softk(T(xp, dev), k, seed=seed)
     w, rs = ops.softk_fwd(ei, ev, k, 0)
     kept = fi >= 0
     assert torch.equal(fi[kept], ei[kept]) and torch.equal(fv[kept], ev[kept])
