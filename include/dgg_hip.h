@@ -148,6 +148,17 @@ size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K);
  * phase_a_hits_inside_the_tight_radius, phase_b_hits } (the three sums only with DGG_SWEEP_STATS=1), readable after the stream
  * has drained */
 size_t dgg_allpairs_sweep_ctl_offset_bytes(int64_t rows, int64_t N, int h);
+/* The debug class's LITERAL dgg_hard output, reference dgm.py:1294-1311 (return_hard_or_soft): ones.scatter_(-1, idxs, edge_p > 0.5)
+ * with edge_p the already unsorted soft adjacency and idxs the sort permutation of the perturbed scores over ALL N columns, then
+ * (hard - soft).detach() + soft.  Opt-in compatibility path, N <= 8192 (full per-row ranking; O(N^2 log^2 N)).  Candidates: all pairs
+ * (rowptr NULL) or the CSR entries (non-candidates: probability 0, perturbed exp(log(1e-8) + G)); scorer u-v-dist (dgm.py:1618-1623).
+ * idx / w [N,K]: the soft ELL adjacency (dgg_softk_fwd).  Outputs [N,K], compacted to the front, -1 / 0 padded: hidx = columns of the
+ * ones, hval = their forward value (1 - s) + s, hsrc = the soft ELL slot at that column (-1: none) that receives the gradient. */
+int dgg_literal_hard_fwd(const float *xp, int64_t N, int h, const int64_t *rowptr, const int32_t *col, float t, int noise_mode,
+                         const float *G, int64_t ldG, uint32_t s0, uint32_t s1, const int32_t *idx, const float *w, int K, float threshold,
+                         int32_t *hidx, float *hval, int32_t *hsrc, void *stream);
+/* its backward: dw [N,K] (OVERWRITTEN) = cotangent of hval routed to the soft slots hsrc */
+int dgg_literal_hard_bwd(const int32_t *hsrc, const float *g, int64_t N, int K, float *dw, void *stream);
 /* candidates = stored entries of in_adj as CSR (the live class's semantics, dgm.py:1613-1614) */
 int dgg_edgelist_topk(const float *xp, int64_t N, int h, const int64_t *rowptr, const int32_t *col, float t,
                       int noise_mode, const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx,

@@ -402,15 +402,20 @@ class DGG_LearnableK_debug(nn.Module):
                 in_adj = in_adj.coalesce()
                 erow, avals = in_adj.indices()[0].to(torch.int32), in_adj.values().to(torch.float32)
         noise_mode, G, seed = self._noise_cfg()
-        if noise_mode == ops.NOISE_RANKED and cand is not None:
+        literal = bool(self.hard and getattr(self.args, "dgg_hard_literal", False))
+        if noise_mode == ops.NOISE_RANKED and (cand is not None or literal):
             noise_mode = ops.NOISE_HASH              # edge-list candidates: every candidate is scored, per-pair hash noise
+                                                     # (literal dgg_hard: the full ranking of a row needs per-pair noise as well)
         cfg = dict(cand=cand, K=self.ell_width, t=ops.T_DIST, noise_mode=noise_mode, G=G, seed=seed, algo=self.topk_algo,
                    mode=ops.MODE_K_TIMES_EDGE_PROB if self.k_select_mode == "k_times_edge_prob" else ops.MODE_K_ONLY)
-        if self.hard and cfg["mode"] == ops.MODE_K_TIMES_EDGE_PROB:
+        if literal and (self.edge_prob_net_mode != "u-v-dist" or x.shape[0] > 8192):
+            raise NotImplementedError("dgg_hard_literal: the literal return_hard_or_soft needs the full ranking of every row's N scores "
+                                      "(u-v-dist scorer, N <= 8192); use the default straight-through dgg_hard otherwise")
+        if self.hard and cfg["mode"] == ops.MODE_K_TIMES_EDGE_PROB and not literal:
             # dgg_hard: straight-through adjacency `(hard - soft).detach() + soft` with hard = the ramp mask at the selected
             # columns (the SDD class's definition, dgm.py:343-346; for k_only hard == soft).  The debug class's own
             # return_hard_or_soft (dgm.py:1294-1311) scatters an already-unsorted matrix through the sort permutation, which is
-            # not a function of the graph and is not reproduced.
+            # not a function of the graph; args.dgg_hard_literal=True reproduces it (small graphs).
             cfg["fwd_mode"] = ops.MODE_HARD_ST
         We, be = self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias
         kn = self.k_net
@@ -449,6 +454,11 @@ class DGG_LearnableK_debug(nn.Module):
             f = w.detach() if (cfg["mode"] == ops.MODE_K_ONLY or "fwd_mode" in cfg) else (w.detach() / val.clamp(min=1e-30))
             writer.add_scalar("values/first_k_std", f.sum(-1).std(), epoch)
             writer.add_scalar("values/first_k_mean", f.sum(-1).mean(), epoch)
+        if literal:
+            # reference dgm.py:1294-1311 to the letter: ones where the RANK of a column equals the column INDEX of a strong neighbour
+            xp = ops.linear_fwd(x.detach(), We.detach(), be.detach(), ops.ACT_LEAKY)
+            hval, hidx = ops.LiteralHardFn.apply(w, idx, xp, cand, cfg["t"], noise_mode, G, seed)
+            return EllAdjacency(hidx, hval, x.shape[0], owner=self)
         return EllAdjacency(idx, w, x.shape[0], rs=rs, k=k, score=val, part=cfg.get("part"), owner=self)
 
 

@@ -303,6 +303,49 @@ def edgelist_topk(xp, rowptr, col, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE,
     return idx, val
 
 
+def literal_hard_fwd(xp, cand, idx, w, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed=(0, 0), threshold=0.5):
+    """the debug class's literal dgg_hard output (dgm.py:1294-1311) from the soft ELL adjacency (idx, w): -> hidx, hval, hsrc [N,K];
+    cand = None (all pairs) or (rowptr, col); N <= 8192"""
+    xp, idx, w = _chk(xp), _chk(idx, torch.int32), _chk(w)
+    N, h = xp.shape
+    K = idx.shape[1]
+    rowptr = col = None
+    if cand is not None:
+        rowptr, col = _chk(cand[0], torch.int64), _chk(cand[1], torch.int32)
+    ldG = 0
+    if G is not None:
+        G = _chk(G)
+        ldG = N
+    hidx = torch.empty((N, K), device=xp.device, dtype=torch.int32)
+    hval = torch.empty((N, K), device=xp.device, dtype=torch.float32)
+    hsrc = torch.empty((N, K), device=xp.device, dtype=torch.int32)
+    _lib.check(_lib.lib().dgg_literal_hard_fwd(_ptr(xp), N, h, _ptr(rowptr), _ptr(col), float(t), noise_mode, _ptr(G), ldG, seed[0], seed[1],
+                                               _ptr(idx), _ptr(w), K, float(threshold), _ptr(hidx), _ptr(hval), _ptr(hsrc), _stream()),
+               "literal_hard_fwd")
+    return hidx, hval, hsrc
+
+
+class LiteralHardFn(torch.autograd.Function):
+    """soft ELL weights -> values of the literal hard adjacency; the cotangent of a one goes to the soft weight AT ITS COLUMN
+    (the reference's `(hard - soft).detach() + soft` followed by `.to_sparse()`: only stored entries carry gradient)"""
+
+    @staticmethod
+    def forward(ctx, w, idx, xp, cand, t, noise_mode, G, seed):
+        hidx, hval, hsrc = literal_hard_fwd(xp, cand, idx, w.detach(), t, noise_mode, G, seed)
+        ctx.save_for_backward(hsrc)
+        ctx.mark_non_differentiable(hidx)
+        return hval, hidx
+
+    @staticmethod
+    def backward(ctx, g, _):
+        (hsrc,) = ctx.saved_tensors
+        g = _chk(g.contiguous())
+        N, K = g.shape
+        dw = torch.empty_like(g)
+        _lib.check(_lib.lib().dgg_literal_hard_bwd(_ptr(hsrc), _ptr(g), N, K, _ptr(dw), _stream()), "literal_hard_bwd")
+        return dw, None, None, None, None, None, None, None
+
+
 def edge_mlp_fwd(AB, xp, erow, col, deg, ex_in, ex_mode, t_ex, wdu, wdv, wex, b1, w2, b2, act=ACT_LEAKY):
     """edge-MLP scorer on the candidate edges (dgm.py:1628-1725) -> p_edge [E], ex [E] (the per-edge extra used)"""
     AB, xp = _chk(AB), _chk(xp)
