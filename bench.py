@@ -455,7 +455,8 @@ def main():
     ap.add_argument("--nodes", type=int, default=0, help="node count: total (one GPU, or several with strong scaling) or per GPU (--weak); "
                                                           "0 = 100 000 on one GPU, 500 000 in total on several (BASELINE.json configs[3])")
     ap.add_argument("--weak", action="store_true", help="multi-GPU: --nodes (default 100 000) rows PER GPU of a (nodes x GPUs)-node graph")
-    ap.add_argument("--repeats", type=int, default=11, help="timed windows of --steps steps each; value = median window")
+    ap.add_argument("--repeats", type=int, default=0, help="timed windows of --steps steps each; value = median window; 0 = as many "
+                                                            "as make the timed region last >= 3 s (at least 11)")
     ap.add_argument("--no-variants", dest="variants", action="store_false",
                     help="skip the symmetric / unperturbed / hash / latent-128 / x-grad variants of the step (one GPU only)")
     ap.add_argument("--no-cpu-dense", dest="cpu_dense", action="store_false",
@@ -539,29 +540,63 @@ class SyntheticRun:
         if emu:
             self.layer.emulate_rank(emu, self.erank)
         self.grads = None
+        # ranked noise: the seed lives in DEVICE memory and is advanced by a (captured) increment at the top of every step, so ONE
+        # hipGraph draws fresh noise on every replay -- what training does per forward (reference dgm.py:1226); the other
+        # generators take the seed by value and cycle NGRAPH captured graphs
+        self.seed_dev = self.seed_inc = None
+        if noise_mode == ops.NOISE_RANKED and hasattr(ops, "allpairs_topk_softk"):
+            self.seed_dev = torch.tensor([1234, 0], dtype=torch.int32, device=dev)
+            self.seed_inc = torch.tensor([0, 1], dtype=torch.int32, device=dev)
+        self.cot = None
 
     def step(self, seed_lo=0):
-        """one pass of the hot path over the whole graph, forward + backward; a different noise realisation per seed_lo"""
-        self.layer.seed = (1234, seed_lo)
+        """one pass of the hot path over the whole graph, forward + backward; a different noise realisation per step"""
+        if self.seed_dev is not None:
+            self.seed_dev.add_(self.seed_inc)
+            self.layer.seed = self.seed_dev
+        else:
+            self.layer.seed = (1234, seed_lo)
         Z = self.layer.forward(self.x_local, self.deg, self.P)
-        self.grads = self.layer.backward(torch.ones_like(Z), self.x_local, self.P)
+        if self.cot is None or self.cot.shape != Z.shape:
+            self.cot = torch.ones_like(Z)                            # the cotangent is an INPUT of the backward: resident, not refilled
+        self.grads = self.layer.backward(self.cot, self.x_local, self.P)
         return self.grads
 
 
+MIN_TIMED_S = 3.0   # the timed region (all windows) lasts at least this long
 NGRAPH = 4      # captured hipGraphs, one per noise seed: consecutive steps see different graphs (idx / partition / gather pattern)
 
 
 def time_windows(run, a, world, force, dev, use_graph, repeats):
-    """W untimed warm-up steps, then `repeats` windows of EXACTLY a.steps steps, each bracketed by barrier + synchronize;
-    returns (per-window seconds, max over ranks), whether hipGraphs were used.  Step s uses noise seed (1234, s mod NGRAPH)."""
+    """W untimed warm-up steps, then windows of EXACTLY a.steps steps, each bracketed by barrier + synchronize; returns
+    (per-window seconds, max over ranks), whether hipGraphs were used, and the per-step time of one EAGER window.
+    Noise: a fresh realisation every step -- device-resident seed advanced inside the step (ONE captured graph), or, for the
+    generators that take the seed by value, NGRAPH captured graphs cycled.  `repeats` <= 0: as many windows as make the timed
+    region last >= MIN_TIMED_S seconds (so that the driver's GPU-busy sampler sees it), at least 11."""
+    coll = world > 1 or force
+    ngraph = 1 if getattr(run, "seed_dev", None) is not None else NGRAPH
     for s_ in range(max(a.warmup, 1)):
         run.step(s_ % NGRAPH)
+
+    def window(launch):
+        if coll:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s_ in range(a.steps):
+            launch(s_)
+        torch.cuda.synchronize()
+        if coll:
+            dist.barrier()
+        return time.perf_counter() - t0
+
+    eager_s = window(lambda s_: run.step(s_ % NGRAPH))              # one eager window (also the estimate for the window count)
     graphs = None
     if use_graph:
         try:
             torch.cuda.synchronize()
             graphs = []
-            for s_ in range(NGRAPH):
+            for s_ in range(ngraph):
                 gph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gph):
                     run.step(s_)
@@ -572,28 +607,19 @@ def time_windows(run, a, world, force, dev, use_graph, repeats):
         except Exception as e:  # noqa: BLE001
             print(f"hipGraph capture failed ({e!r}); timing eager launches", file=sys.stderr)
             graphs = None
-    coll = world > 1 or force
-    times = []
-    sidx = 0
-    for _ in range(repeats):
-        if coll:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            if graphs is not None:
-                graphs[sidx % NGRAPH].replay()
-            else:
-                run.step(sidx % NGRAPH)
-            sidx += 1
-        torch.cuda.synchronize()
-        if coll:
-            dist.barrier()
-        times.append(time.perf_counter() - t0)
-    tm = torch.tensor(times, device=dev, dtype=torch.float64)
+    launch = (lambda s_: graphs[s_ % ngraph].replay()) if graphs is not None else (lambda s_: run.step(s_ % NGRAPH))
+    first = window(launch)
+    est = torch.tensor([first], device=dev, dtype=torch.float64)
+    if coll:
+        dist.all_reduce(est, op=dist.ReduceOp.MAX)
+    if repeats <= 0:
+        repeats = int(min(max(11, np.ceil(MIN_TIMED_S / max(float(est.item()), 1e-6))), 400))
+    times = [window(launch) for _ in range(repeats)]
+    tm = torch.tensor(times + [eager_s], device=dev, dtype=torch.float64)
     if coll:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-    return [float(v) for v in tm.tolist()], graphs is not None
+    tm = [float(v) for v in tm.tolist()]
+    return tm[:-1], graphs is not None, tm[-1] / a.steps
 
 
 def cpu_dense_formulation(sizes, threads):
@@ -641,7 +667,7 @@ def bench_synthetic(a, dev, world, rank, force):
     noise_mode = {"ranked": ops.NOISE_RANKED, "hash": ops.NOISE_HASH, "sym": ops.NOISE_HASH_SYM, "none": ops.NOISE_NONE}[a.noise]
     run = SyntheticRun(a, dev, world, rank, force, N, d, h, noise_mode, a.x_grad, emu, a.exchange)
     use_graph = a.hipgraph and (world == 1 and not force or os.environ.get("DGG_BENCH_GRAPH_DIST") == "1")
-    times, graphed = time_windows(run, a, world, force, dev, use_graph, a.repeats)
+    times, graphed, eager_T = time_windows(run, a, world, force, dev, use_graph, a.repeats)
     T = float(np.median(times)) / a.steps
     layer, P, r0, r1 = run.layer, run.P, run.r0, run.r1
     ksum = layer.saved["k"].sum().reshape(1).double()
@@ -762,11 +788,15 @@ def bench_synthetic(a, dev, world, rank, force):
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": T * 1e3, "higher_is_better": True,
             "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "repeats": {"windows": len(times), "steps_per_window": a.steps, "value_from": "median window",
-                        "window_ms_per_step": [t_ / a.steps * 1e3 for t_ in times], "timed_seconds_total": float(sum(times))},
+                        "window_ms_per_step_min_median_max": [float(np.min(times)) / a.steps * 1e3, float(np.median(times)) / a.steps * 1e3,
+                                                               float(np.max(times)) / a.steps * 1e3],
+                        "timed_seconds_total": float(sum(times)), "eager_ms_per_step": eager_T * 1e3,
+                        "noise": "fresh seed every step: device-resident seed advanced inside the captured step (one hipGraph)"
+                                 if getattr(run, "seed_dev", None) is not None else f"{NGRAPH} captured graphs with different seeds, cycled"},
             "config": {"workload": f"synthetic all-pairs DGG N={N} d={d} h={h} k~{kmean:.1f} K=64, u-v-dist/x/"
                                    f"k_times_edge_prob, Gumbel(0,0.3) perturbation, + normalize + GCNConv({d},64), fwd+bwd",
                        "nodes": N, "feat": d, "latent": h, "ell_width": 64, "pairs_per_s": N * float(N) / T,
-                       "x_grad": a.x_grad, "topk_algo": a.algo, "noise": a.noise, "noise_seeds_cycled": NGRAPH, "hipgraph": graphed,
+                       "x_grad": a.x_grad, "topk_algo": a.algo, "noise": a.noise, "hipgraph": graphed,
                        "hipgraph_note": None if graphed or not coll else "steps with collectives are launched eagerly (set "
                                         "DGG_BENCH_GRAPH_DIST=1 to try capturing the RCCL calls)",
                        "parallelism": f"row-shard x{world}" if not emu else f"DIAGNOSTIC: compute of rank {run.erank} of {emu}, no collectives",

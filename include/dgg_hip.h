@@ -61,6 +61,10 @@ int dgg_linear_fwd(const float *x, int64_t N, int d, const float *W, const float
 size_t dgg_linear_bwd_ws_floats(int64_t N, int d, int out);
 int dgg_linear_bwd(const float *x, int64_t N, int d, const float *W, int out, int w_layout, int act, const float *y,
                    const float *dy, float *dx, float *dW, float *db, float *ws, void *stream);
+/* stacks the weights of nseg <= 8 layers (layout 0: [out, d] nn.Linear; 1: [d, out] GCNConv, model.py:583) and their biases (NULL:
+ * zeros) into the row-stacked form dgg_linear_fwd_multi reads: Wcat [sum out, d], bcat [sum out]; one launch */
+int dgg_linear_pack_weights(int nseg, const float *const *W, const float *const *b, const int *seg_out, const int *seg_layout, int d,
+                            float *Wcat, float *bcat, void *stream);
 /* Several layers that read the SAME input in one pass over it (node_encode_for_edges + node_encode_for_k of one DGG,
  * dgm.py:1097-1100 / 1123-1126 applied at 1609 / 1566, and the GCNConv projection x W, model.py:596): Wcat [sum out_s, d] /
  * bcat [sum out_s] (nullable) = the layers' weights in nn.Linear layout stacked by rows; layer s has out_s outputs (multiples
@@ -140,6 +144,10 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
  * settled list while it is still in registers; additionally writes w [row1-row0,64] and rs [row1-row0].  Same bits as the two calls. */
 int dgg_allpairs_topk_ranked_softk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
                                    const float *k, int mode, int32_t *idx, float *val, float *w, float *rs, void *stream);
+/* the same, with the noise seed {s0, s1} read from DEVICE memory when the kernel starts: a captured hipGraph of the step draws fresh
+ * noise on every replay once the caller advances seed_dev between replays (the reference samples fresh noise per forward, dgm.py:1226) */
+int dgg_allpairs_topk_ranked_softk_dseed(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, const uint32_t *seed_dev,
+                                         const float *k, int mode, int32_t *idx, float *val, float *w, float *rs, void *stream);
 /* bytes of device workspace the pruned path needs for (N, h): a bf16 copy of xp plus discounted squared norms;
  * 0 when the pruned path does not apply (explicit noise, K != 64, latent_dim not in {16,32,64,128}) */
 size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K);

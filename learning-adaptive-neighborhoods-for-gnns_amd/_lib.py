@@ -14,6 +14,7 @@ PROTOTYPES = {
     "dgg_linear_bwd": [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_gemm_tn_acc": [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
     "dgg_gemm_tn_ws_floats": [_i64, _i32, _i32],
+    "dgg_linear_pack_weights": [_i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "dgg_linear_fwd_multi": [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "dgg_gemm_tn_multi": [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "dgg_gemm_tn_multi_ws_floats": [_i64, _i32, _i32],
@@ -35,6 +36,7 @@ PROTOTYPES = {
     "dgg_allpairs_topk_ranked_softk": [_vp, _i64, _i32, _i64, _i64, _f32, _u32, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "dgg_literal_hard_fwd": [_vp, _i64, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _u32, _u32, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp],
     "dgg_literal_hard_bwd": [_vp, _vp, _i64, _i32, _vp, _vp],
+    "dgg_allpairs_topk_ranked_softk_dseed": [_vp, _i64, _i32, _i64, _i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "dgg_edgelist_topk": [_vp, _i64, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _vp, _vp],
     "dgg_edge_mlp_fwd": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "dgg_edgelist_topk_p": [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _vp, _vp, _vp],

@@ -889,6 +889,41 @@ int dgg_linear_fwd(const float *x, int64_t N, int d, const float *W, const float
     return launch_linear_fwd(x, N, d, W, b, out, w_layout, act, y, (hipStream_t)stream);
 }
 
+// Stacks the weights (and biases) of up to 8 layers into the row-stacked nn.Linear layout dgg_linear_fwd_multi reads, in ONE launch
+// (the host wrapper used two torch.cat, a fill and the transposes of the [d, out] weights: five launches per forward).
+struct PackSegs {
+    const float *W[8];
+    const float *b[8];
+    int out[8], layout[8], first[8];
+};
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackSegs sg, int nseg, int d, int total, float *__restrict__ Wcat,
+                                                           float *__restrict__ bcat) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total * (d + 1)) return;
+    const int c = e / (d + 1), k = e % (d + 1);
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < 8; q++)
+        if (q < nseg && c >= sg.first[q]) s = q;
+    const int lc = c - sg.first[s];
+    if (k == d) { bcat[c] = sg.b[s] ? sg.b[s][lc] : 0.0f; return; }
+    Wcat[(int64_t)c * d + k] = sg.layout[s] == 0 ? sg.W[s][(int64_t)lc * d + k] : sg.W[s][(int64_t)k * sg.out[s] + lc];
+}
+
+extern "C" int dgg_linear_pack_weights(int nseg, const float *const *W, const float *const *b, const int *seg_out, const int *seg_layout,
+                                       int d, float *Wcat, float *bcat, void *stream) {
+    if (nseg < 1 || nseg > 8 || d < 1) return dgg_set_error(DGG_ERR_ARG, "linear_pack_weights: 1..8 layers");
+    PackSegs sg{};
+    int total = 0;
+    for (int s = 0; s < nseg; s++) {
+        sg.W[s] = W[s]; sg.b[s] = b ? b[s] : nullptr; sg.out[s] = seg_out[s]; sg.layout[s] = seg_layout[s]; sg.first[s] = total;
+        total += seg_out[s];
+    }
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total * (d + 1) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sg, nseg, d, total,
+                       Wcat, bcat);
+    return dgg_check_launch("linear_pack_weights");
+}
+
 // Several layers on one input, X read once: Wcat [sum out_s, d] / bcat [sum out_s] (nullable) = the layers' nn.Linear weights
 // (layout 0) stacked by rows; layer s has out_s outputs (a multiple of 32; sum <= 256), activation act_s and destination
 // y_s [N, out_s].  Bit-identical to nseg calls of dgg_linear_fwd (same k-ordered fmaf chains).

@@ -33,8 +33,9 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
                                                             int64_t row1, float t, uint32_t s0, uint32_t s1,
                                                             const float *__restrict__ klim, int32_t *__restrict__ idx,
                                                             float *__restrict__ val, int softk_mode, float *__restrict__ w_out,
-                                                            float *__restrict__ rs_out) {
+                                                            float *__restrict__ rs_out, const uint32_t *__restrict__ seed_dev) {
     const int lane = threadIdx.x & 63;
+    if (seed_dev) { s0 = seed_dev[0]; s1 = seed_dev[1]; }       // seed in device memory: ONE captured hipGraph serves fresh seeds
     // (readfirstlane: the compiler cannot know that dgg::wave_id() is wave-uniform; without it the row's own features are
     //  fetched with VECTOR loads into 64 registers instead of scalar loads)
     const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
@@ -157,9 +158,10 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
 
 template <int H>
 int launch_ranked(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
-                  const float *klim, int32_t *idx, float *val, hipStream_t st, int softk_mode = 0, float *w = nullptr, float *rs = nullptr) {
+                  const float *klim, int32_t *idx, float *val, hipStream_t st, int softk_mode = 0, float *w = nullptr, float *rs = nullptr,
+                  const uint32_t *seed_dev = nullptr) {
     dim3 grid((unsigned)((row1 - row0 + 3) / 4));
-    hipLaunchKernelGGL(allpairs_topk_ranked<H>, grid, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, klim, idx, val, softk_mode, w, rs);
+    hipLaunchKernelGGL(allpairs_topk_ranked<H>, grid, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, klim, idx, val, softk_mode, w, rs, seed_dev);
     return dgg_check_launch("allpairs_topk_ranked");
 }
 
@@ -181,17 +183,17 @@ int dgg_klimit_truncate_impl(const float *klim, int64_t rows, int K, int32_t *id
 
 int dgg_allpairs_topk_ranked_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0,
                                   uint32_t s1, int K, const float *klim, int32_t *idx, float *val, hipStream_t st, int softk_mode,
-                                  float *w, float *rs) {
+                                  float *w, float *rs, const uint32_t *seed_dev) {
     if (K != 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path needs K = 64");
     if (N >= ((int64_t)1 << 31)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path needs N < 2^31");
     if (w && (!klim || !rs)) return dgg_set_error(DGG_ERR_ARG, "ranked-noise path: the fused ramp needs the learned k and the row-sum output");
     if (row1 <= row0) return 0;
     switch (h) {
-        case 8: return launch_ranked<8>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs);
-        case 16: return launch_ranked<16>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs);
-        case 32: return launch_ranked<32>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs);
-        case 64: return launch_ranked<64>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs);
-        case 128: return launch_ranked<128>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs);
+        case 8: return launch_ranked<8>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs, seed_dev);
+        case 16: return launch_ranked<16>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs, seed_dev);
+        case 32: return launch_ranked<32>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs, seed_dev);
+        case 64: return launch_ranked<64>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs, seed_dev);
+        case 128: return launch_ranked<128>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs, seed_dev);
         default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path supports latent_dim in {8,16,32,64,128}");
     }
 }
@@ -205,5 +207,14 @@ int dgg_allpairs_topk_ranked_softk(const float *xp, int64_t N, int h, int64_t ro
     if (mode != 0 && mode != 1 && mode != 3) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_softk: mode must be 0, 1 or 3");
     if (!k || !w || !rs) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_softk: k, w and rs are required");
     return dgg_allpairs_topk_ranked_impl(xp, N, h, row0, row1, t, s0, s1, 64, k, idx, val, (hipStream_t)stream, mode, w, rs);
+}
+// the same with the noise seed (s0, s1) read from DEVICE memory at launch time: a captured hipGraph of the step then draws fresh
+// noise on every replay (the caller advances seed_dev between replays, e.g. by a captured increment), as training does per forward
+int dgg_allpairs_topk_ranked_softk_dseed(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, const uint32_t *seed_dev,
+                                         const float *k, int mode, int32_t *idx, float *val, float *w, float *rs, void *stream) {
+    if (row0 < 0 || row1 > N || row0 > row1) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_softk: bad row range");
+    if (mode != 0 && mode != 1 && mode != 3) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_softk: mode must be 0, 1 or 3");
+    if (!k || !w || !rs || !seed_dev) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_softk_dseed: k, w, rs and seed_dev are required");
+    return dgg_allpairs_topk_ranked_impl(xp, N, h, row0, row1, t, 0u, 0u, 64, k, idx, val, (hipStream_t)stream, mode, w, rs, seed_dev);
 }
 }

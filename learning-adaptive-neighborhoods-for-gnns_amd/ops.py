@@ -147,10 +147,13 @@ def linear_fwd_multi(x, layers):
     if len(layers) > 8 or any(o % 32 for o in outs) or sum(outs) > 256 or sum(outs) == 224:
         return [linear_fwd(x, W, b, act, lay) for W, b, act, lay in layers]
     # nn.Linear layout [out, d] stacked by rows (a [d, out] weight enters transposed); missing biases are zeros
-    Wcat = torch.cat([(_chk(W) if lay == 0 else _chk(W).t()) for W, _, _, lay in layers], 0).contiguous()
-    bcat = None
-    if any(b is not None for _, b, _, _ in layers):
-        bcat = torch.cat([(_chk(b) if b is not None else x.new_zeros(o)) for (_, b, _, _), o in zip(layers, outs)])
+    # (one launch stacks the weights: torch.cat x 2 + a fill + the transposes of the [d, out] weights were five)
+    Wcat = torch.empty((sum(outs), d), device=x.device, dtype=torch.float32)
+    bcat = torch.empty((sum(outs),), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_linear_pack_weights(len(layers), _ptr_array([_chk(W) for W, *_ in layers]),
+                                                  _ptr_array([None if b is None else _chk(b) for _, b, _, _ in layers]), _int_array(outs),
+                                                  _int_array([lay for *_, lay in layers]), d, _ptr(Wcat), _ptr(bcat), _stream()),
+               "linear_pack_weights")
     ys = [torch.empty((N, o), device=x.device, dtype=torch.float32) for o in outs]
     _lib.check(_lib.lib().dgg_linear_fwd_multi(_ptr(x), N, d, _ptr(Wcat), _ptr(bcat), len(layers), _int_array(outs),
                                                _int_array([a for _, _, a, _ in layers]), _ptr_array(ys), _stream()), "linear_fwd_multi")
@@ -282,8 +285,13 @@ def allpairs_topk_softk(xp, k, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, seed=(0, 0
     w = torch.empty((r1 - r0, 64), device=xp.device, dtype=torch.float32)
     rs = torch.empty((r1 - r0,), device=xp.device, dtype=torch.float32)
     pe = _probe_begin()
-    _lib.check(_lib.lib().dgg_allpairs_topk_ranked_softk(_ptr(xp), N, h, r0, r1, t, seed[0], seed[1], _ptr(k), mode, _ptr(idx), _ptr(val),
-                                                         _ptr(w), _ptr(rs), _stream()), "allpairs_topk_ranked_softk")
+    if isinstance(seed, torch.Tensor):       # device seed [2] (int32 / uint32 bits): one captured graph, fresh noise per replay
+        assert seed.is_cuda and seed.numel() == 2 and seed.element_size() == 4
+        _lib.check(_lib.lib().dgg_allpairs_topk_ranked_softk_dseed(_ptr(xp), N, h, r0, r1, t, _ptr(seed), _ptr(k), mode, _ptr(idx), _ptr(val),
+                                                                   _ptr(w), _ptr(rs), _stream()), "allpairs_topk_ranked_softk_dseed")
+    else:
+        _lib.check(_lib.lib().dgg_allpairs_topk_ranked_softk(_ptr(xp), N, h, r0, r1, t, seed[0], seed[1], _ptr(k), mode, _ptr(idx), _ptr(val),
+                                                             _ptr(w), _ptr(rs), _stream()), "allpairs_topk_ranked_softk")
     _probe_end("allpairs_topk", pe)
     return idx, val, w, rs
 

@@ -30,6 +30,7 @@ rank's own rows.
 that the partition / collective logic is exercised with gloo, world_size 2 and 3, without a GPU).
 """
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -139,7 +140,12 @@ class ShardedDGGConv:
             g_xp = _Gather(xp, self.N, self.per, self.group, True, self.bufs, "xp")
             g_H = _Gather(H, self.N, self.per, self.group, True, self.bufs, "H")
         s["xk"] = xk
-        s["mu_sd"] = mu_sd = kern.degree_stats(deg_full)
+        # mean / std of the prior degrees (dgm.py:1569-1570): an INPUT statistic -- recomputed only when the degree tensor changes
+        # (keyed on the tensor OBJECT and its version counter, not on its address: a new tensor is always re-read)
+        ref = getattr(self, "_stats_ref", None)
+        if ref is None or ref() is not deg_full or self._stats_ver != deg_full._version:
+            self._stats_ref, self._stats_ver, self._stats = weakref.ref(deg_full), deg_full._version, kern.degree_stats(deg_full)
+        s["mu_sd"] = mu_sd = self._stats
         deg_local = deg_full[self.r0:self.r1].contiguous()
         s["k"], s["z"], s["u"], s["feat"] = kern.knet_x_fwd(xk, deg_local, mu_sd, P["W1"], P["b1"], P["Wmu"], P["bmu"],
                                                           P["Wp"].reshape(-1), P["bp"])
