@@ -103,6 +103,17 @@ size_t dgg_degree_stats_ws_bytes(void); /* device workspace of dgg_degree_stats 
 int dgg_knet_x_fwd(const float *xk, int64_t N, int h, const float *deg, const float *mu_sd, const float *W1,
                    const float *b1, int h2, const float *Wmu, const float *bmu, int h4, const float *Wp, const float *bp,
                    float *k, float *z_save, float *u_save, float *feat_save, void *stream);
+/* The k-net of mode "x" (k_estimate_net dgm.py:1562-1586 + LearnableKEncoder dgm.py:2051-2063) on the fp32 matrix cores, latent_dim h
+ * in {16, 32, 64}; h2 = h/2, h4 = h/4.  Forward: k [N] and u [N] (the pre-ReLU output: all the backward needs besides xk); same bits
+ * as dgg_knet_x_fwd. */
+int dgg_knet_x_fwd_mfma(const float *xk, int64_t N, int h, const float *deg, const float *mu_sd, const float *W1, const float *b1,
+                        const float *Wmu, const float *bmu, const float *Wp, const float *bp, float *k, float *u_save, void *stream);
+/* Backward in ONE pass over xk (layer 1 is re-run): dxk [N,h] is OVERWRITTEN and every parameter gradient is formed inside the kernel:
+ * gW1 [h2, h+1] (k_embed.0.weight), gb1 [h2], gWmu [h4, h2] are ACCUMULATED into (caller zeroes them and the scratch gv [h2], gS0 [1]);
+ * gbmu [h4], gWp [h4], gbp [1] are OVERWRITTEN. */
+int dgg_knet_x_bwd_mfma(const float *xk, int64_t N, int h, const float *deg, const float *mu_sd, const float *W1, const float *b1,
+                        const float *Wmu, const float *bmu, const float *Wp, const float *u, const float *dk, float *dxk, float *gW1,
+                        float *gb1, float *gWmu, float *gbmu, float *gWp, float *gbp, float *gv, float *gS0, void *stream);
 /* per-node part of the backward: dk -> dkp [N], dm [N,h4], dpre1 [N,h2], dxk [N,h], m [N,h4] (recomputed) */
 int dgg_knet_x_bwd_nodes(int64_t N, int h, const float *mu_sd, const float *W1, int h2, const float *Wmu, int h4,
                          const float *Wp, const float *bmu, const float *z, const float *u, const float *dk, float *dkp,

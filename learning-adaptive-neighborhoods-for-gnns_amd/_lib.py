@@ -23,6 +23,8 @@ PROTOTYPES = {
     "dgg_degree_stats": [_vp, _i64, _vp, _vp, _vp],
     "dgg_degree_stats_ws_bytes": [],
     "dgg_knet_x_fwd": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "dgg_knet_x_fwd_mfma": [_vp, _i64, _i32] + [_vp] * 10 + [_vp],
+    "dgg_knet_x_bwd_mfma": [_vp, _i64, _i32] + [_vp] * 18 + [_vp],
     "dgg_knet_x_bwd_nodes": [_i64, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_knet_input_deg_fwd": [_vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "dgg_knet_feat": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],

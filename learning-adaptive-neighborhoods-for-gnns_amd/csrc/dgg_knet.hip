@@ -12,6 +12,7 @@
 // node's activations in registers, the (wave-uniform) weights through scalar loads -- full-rate v_fma, no cross-lane
 // traffic.  Other shapes: one wavefront per node, lane o computes output unit o.
 #include "dgg_common.h"
+#include <algorithm>
 #include "dgg_api_internal.h"
 
 using namespace dgg;
@@ -262,6 +263,317 @@ __global__ __launch_bounds__(64) void knet_x_bwd_tpn(
     }
 }
 
+// ---- the k-net (mode "x") on the fp32 MATRIX cores ---------------------------------------------------------------------------
+// k_embed (Linear(h+1, h/2) + LeakyReLU) -> k_mu (Linear(h/2, h/4)) -> k_project (Linear(h/4, 1)) is a small MLP over N nodes: the
+// thread-per-node kernels above run it at 9 % of the fp32 vector peak (52 + 45 us per step at N = 100k) and hand z, [xk | nd], dkp,
+// dm, dpre1 and m through HBM to three weight-gradient GEMMs (+ 45 us, 160 MB in all).  Here a wavefront owns 64 nodes at a time
+// and every layer is a chain of v_mfma_f32_32x32x2_f32 (an exact k-ordered fmaf chain, so k comes out bit-identical):
+//   D[o][n] += W[o][c] * act[n][c]:  first operand = the layer's weights, held in registers in operand order for the whole kernel
+//   (lane (li, hh) of step s holds W[li][2s + hh]; the bias rides as one more contraction step against a column of ones);
+//   second operand = the activations, read from an LDS tile; an accumulator register r of lane (li, hh) is output feature
+//   (r & 3) + 8 (r >> 2) + 4 hh of node li.
+// Backward (knet_x_bwd_mfma): layer 1 is re-run from xk (the forward saves only u); dz and d feat are MFMA chains whose second
+// operands are computed on the fly / ARE the previous chain's accumulator registers (the contraction index is walked in the
+// accumulator's own order); the weight gradients are contractions over the 64 nodes of the group, accumulated in registers over all
+// the groups of a wavefront:
+//   G1 [h/2 x (h+2)]   = sum_n dpre1_n (x) [xk_n | nd_n | 1]   -> dW1 and (ones column) db1
+//   G2 [(h/4+1) x h/2] = sum_n [dm_n ; dkp_n] (x) z_n          -> dWmu and v = sum_n dkp_n z_n
+//   dbp = S0 = sum dkp,  dbmu = Wp S0,  dWp = Wmu v + bmu S0   (dm_n = dkp_n Wp, m_n = Wmu z_n + bmu; knet_mfma_finish)
+typedef float kf32x16 __attribute__((ext_vector_type(16)));
+template <int H>
+struct KnetTile {
+    static constexpr int H2 = H / 2, H4 = H / 4;
+    static constexpr int KS1 = (H + 2) / 2;                       // contraction steps of layer 1: h features, nd, bias
+    static constexpr int KS2 = (H2 + 2) / 2;                      // layer 2: h/2 features, bias (+ a zero)
+    static constexpr int NB = (H + 2 + 31) / 32;                  // 32-column blocks of [xk | nd | 1]
+    static constexpr int XS = NB * 32 + 1, ZS = 35;               // LDS row strides (odd: conflict-free row-per-lane accesses; 34 columns of z)
+    static_assert(H == 16 || H == 32 || H == 64, "MFMA k-net: latent_dim in {16, 32, 64}");
+};
+
+// the 64 x [xk | nd | 1 | 0..] tile of a node group, staged with coalesced 16-byte loads
+template <int H, int XS>
+__device__ __forceinline__ void knet_stage(const float *__restrict__ xk, const float *__restrict__ deg, int64_t N, int64_t g, float mu,
+                                            float sd, float *__restrict__ xt, int lane) {
+    constexpr int V4 = H / 4;
+#pragma unroll
+    for (int q = 0; q < V4; q++) {
+        const int e = q * 64 + lane, row = e / V4, c4 = e % V4;
+        const int64_t n = g * 64 + row;
+        const float4 v = n < N ? *reinterpret_cast<const float4 *>(xk + n * H + c4 * 4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float *d = xt + row * XS + c4 * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    const int64_t n = g * 64 + lane;
+    xt[lane * XS + H] = n < N ? __fdiv_rn(__fadd_rn(deg[n], -mu), __fadd_rn(sd, 1e-5f)) : 0.0f;
+    xt[lane * XS + H + 1] = 1.0f;
+#pragma unroll
+    for (int c = H + 2; c < XS - 1; c++) xt[lane * XS + c] = 0.0f;
+}
+
+template <int H>
+__global__ __launch_bounds__(256, 1) void knet_x_fwd_mfma(const float *__restrict__ xk, int64_t N, const float *__restrict__ deg,
+                                                         const float *__restrict__ mu_sd, const float *__restrict__ W1,
+                                                         const float *__restrict__ b1, const float *__restrict__ Wmu,
+                                                         const float *__restrict__ bmu, const float *__restrict__ Wp,
+                                                         const float *__restrict__ bp, float *__restrict__ k, float *__restrict__ u_save) {
+    using KT = KnetTile<H>;
+    constexpr int H2 = KT::H2, H4 = KT::H4, KS1 = KT::KS1, KS2 = KT::KS2, XS = H + 3, ZS = KT::ZS;
+    // (measured: two-wavefront workgroups, three per CU, are 3 us slower than this persistent form, one workgroup per CU)
+    __shared__ float sm[4 * (64 * XS + 64 * ZS)];
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id(), li = lane & 31, hh = lane >> 5;
+    float *xt = sm + wave * (64 * XS + 64 * ZS), *zt = xt + 64 * XS;
+    const float mu = mu_sd[0], sd = mu_sd[1];
+    // weights in operand order (first operand: lane (li, hh) of step s supplies W[li][2 s + hh])
+    float w1[KS1], w2[KS2];
+#pragma unroll
+    for (int sI = 0; sI < KS1; sI++) {
+        const int c = 2 * sI + hh;
+        w1[sI] = li < H2 ? (c <= H ? W1[li * (H + 1) + c] : b1[li]) : 0.0f;
+    }
+#pragma unroll
+    for (int sI = 0; sI < KS2; sI++) {
+        const int c = 2 * sI + hh;
+        w2[sI] = li < H4 ? (c < H2 ? Wmu[li * H2 + c] : (c == H2 ? bmu[li] : 0.0f)) : 0.0f;
+    }
+    const int64_t ngroups = (N + 63) / 64;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < ngroups; g += (int64_t)gridDim.x * 4) {
+        knet_stage<H, XS>(xk, deg, N, g, mu, sd, xt, lane);
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++) {
+            kf32x16 a1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) a1[r] = 0.0f;
+            float xb[KS1];                                        // operands first, then the chain: the LDS latency is paid once
+#pragma unroll
+            for (int sI = 0; sI < KS1; sI++) xb[sI] = xt[(blk * 32 + li) * XS + 2 * sI + hh];
+#pragma unroll
+            for (int sI = 0; sI < KS1; sI++) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[sI], xb[sI], a1, 0, 0, 0);
+            // z = leaky(pre1), transposed through LDS into operand order for layer 2 (+ the ones column of its bias step)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int o = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float z = a1[r] > 0.0f ? a1[r] : __fmul_rn(0.01f, a1[r]);
+                if (o < H2) zt[(blk * 32 + li) * ZS + o] = z;
+            }
+            if (hh == 0) zt[(blk * 32 + li) * ZS + H2] = 1.0f;
+            if (hh == 1 && H2 + 1 < 2 * KS2) zt[(blk * 32 + li) * ZS + H2 + 1] = 0.0f;
+            kf32x16 a2;
+#pragma unroll
+            for (int r = 0; r < 16; r++) a2[r] = 0.0f;
+            float zb[KS2];
+#pragma unroll
+            for (int sI = 0; sI < KS2; sI++) zb[sI] = zt[(blk * 32 + li) * ZS + 2 * sI + hh];
+#pragma unroll
+            for (int sI = 0; sI < KS2; sI++) a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[sI], zb[sI], a2, 0, 0, 0);
+            // k_project: one lane per node gathers the h/4 values of m (its own rows and the other half's) and runs the ascending chain
+            float m[16];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const float other = __uint_as_float(dgg::xor_shfl<32>(__float_as_uint(a2[r]), lane));
+                const int a_mine = (r & 3) + 8 * (r >> 2) + 4 * hh, a_oth = (r & 3) + 8 * (r >> 2) + 4 * (1 - hh);
+                m[a_mine & 15] = a2[r];
+                m[a_oth & 15] = other;
+            }
+            float ak = 0.0f;
+#pragma unroll
+            for (int o = 0; o < H4; o++) ak = __fmaf_rn(m[o], Wp[o], ak);
+            const float kp = __fadd_rn(ak, bp[0]);
+            const float u = __fadd_rn(__fmul_rn(kp, sd), mu);
+            const int64_t n = g * 64 + blk * 32 + li;
+            if (hh == 0 && n < N) {
+                k[n] = __fadd_rn(u > 0.0f ? u : 0.0f, 1.0f);
+                if (u_save) u_save[n] = u;
+            }
+        }
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(256, 1) void knet_x_bwd_mfma(const float *__restrict__ xk, int64_t N, const float *__restrict__ deg,
+                                                         const float *__restrict__ mu_sd, const float *__restrict__ W1,
+                                                         const float *__restrict__ b1, const float *__restrict__ Wmu,
+                                                         const float *__restrict__ Wp, const float *__restrict__ u,
+                                                         const float *__restrict__ dk, float *__restrict__ dxk, float *__restrict__ gW1,
+                                                         float *__restrict__ gb1, float *__restrict__ gWmu, float *__restrict__ gv,
+                                                         float *__restrict__ gS0) {
+    using KT = KnetTile<H>;
+    constexpr int H2 = KT::H2, H4 = KT::H4, KS1 = KT::KS1, NB = KT::NB, XS = KT::XS, ZS = KT::ZS;
+    constexpr int NBX = H / 32 > 0 ? H / 32 : 1;                  // 32-column blocks of dxk (h = 16: one, half used)
+    constexpr int KS3 = (H4 + 1) / 2;                             // dz: contraction over the h/4 outputs of k_mu
+    constexpr int PER = (NB + 1) * 16 + 1;
+    constexpr int TILE = 64 * XS + 64 * ZS + 64;
+    __shared__ float sm[(4 * TILE > 4 * PER * 64) ? 4 * TILE : 4 * PER * 64];
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id(), li = lane & 31, hh = lane >> 5;
+    float *xt = sm + wave * TILE, *tt = xt + 64 * XS, *dkl = tt + 64 * ZS;
+    const float mu = mu_sd[0], sd = mu_sd[1];
+    float w1[KS1];                                                // layer 1, forward order
+#pragma unroll
+    for (int sI = 0; sI < KS1; sI++) {
+        const int c = 2 * sI + hh;
+        w1[sI] = li < H2 ? (c <= H ? W1[li * (H + 1) + c] : b1[li]) : 0.0f;
+    }
+    float wmt[KS3], wp2[KS3];                                     // dz[o][n] += Wmu[a][o] * dm[n][a]: first operand Wmu^T, second dkp * Wp[a]
+#pragma unroll
+    for (int sI = 0; sI < KS3; sI++) {
+        const int a = 2 * sI + hh;
+        wmt[sI] = (li < H2 && a < H4) ? Wmu[a * H2 + li] : 0.0f;
+        wp2[sI] = a < H4 ? Wp[a] : 0.0f;
+    }
+    float w1b[NBX][16];                                           // d feat[c][n] += W1[o][c] * dpre1[n][o], o walked in accumulator order
+#pragma unroll
+    for (int cb = 0; cb < NBX; cb++)
+#pragma unroll
+        for (int sI = 0; sI < 16; sI++) {
+            const int o = (sI & 3) + 8 * (sI >> 2) + 4 * hh, c = cb * 32 + li;
+            w1b[cb][sI] = (o < H2 && c < H) ? W1[o * (H + 1) + c] : 0.0f;
+        }
+    const float fa = li < H4 ? Wp[li] : (li == H4 ? 1.0f : 0.0f);   // G2 first operand = fa * dkp[n]: rows dm (a < h/4) and dkp (a = h/4)
+    kf32x16 g1[NB], g2;
+#pragma unroll
+    for (int a = 0; a < NB; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) g1[a][r] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) g2[r] = 0.0f;
+    float s0 = 0.0f;
+    const int64_t ngroups = (N + 63) / 64;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < ngroups; g += (int64_t)gridDim.x * 4) {
+        knet_stage<H, XS>(xk, deg, N, g, mu, sd, xt, lane);
+        kf32x16 zacc[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++) {
+            const int64_t n = g * 64 + blk * 32 + li;
+            const bool valid = n < N;
+            kf32x16 a1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) a1[r] = 0.0f;
+            float xb[KS1];                                        // operands first, then the chain: the LDS latency is paid once
+#pragma unroll
+            for (int sI = 0; sI < KS1; sI++) xb[sI] = xt[(blk * 32 + li) * XS + 2 * sI + hh];
+#pragma unroll
+            for (int sI = 0; sI < KS1; sI++) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[sI], xb[sI], a1, 0, 0, 0);
+            const float dkp = (valid && u[valid ? n : 0] > 0.0f) ? dk[n] * sd : 0.0f;
+            if (hh == 0) { s0 += dkp; dkl[blk * 32 + li] = dkp; }
+            kf32x16 dz;
+#pragma unroll
+            for (int r = 0; r < 16; r++) dz[r] = 0.0f;
+#pragma unroll
+            for (int sI = 0; sI < KS3; sI++) dz = __builtin_amdgcn_mfma_f32_32x32x2f32(wmt[sI], dkp * wp2[sI], dz, 0, 0, 0);
+            kf32x16 dp1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float z = a1[r] > 0.0f ? a1[r] : 0.01f * a1[r];
+                zacc[blk][r] = z;
+                dp1[r] = a1[r] > 0.0f ? dz[r] : 0.01f * dz[r];
+                const int o = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                tt[(blk * 32 + li) * ZS + o] = o < H2 ? dp1[r] : 0.0f;      // dpre1, node-major: first operand of G1
+            }
+            // dxk = W1[:, :h]^T dpre1: the contraction runs over the accumulator registers themselves
+#pragma unroll
+            for (int cb = 0; cb < NBX; cb++) {
+                kf32x16 df;
+#pragma unroll
+                for (int r = 0; r < 16; r++) df[r] = 0.0f;
+#pragma unroll
+                for (int sI = 0; sI < 16; sI++) df = __builtin_amdgcn_mfma_f32_32x32x2f32(w1b[cb][sI], dp1[sI], df, 0, 0, 0);
+                if (valid) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        const int c = cb * 32 + 8 * q4 + 4 * hh;
+                        if (c < H) *reinterpret_cast<float4 *>(dxk + n * H + c) = make_float4(df[4 * q4], df[4 * q4 + 1], df[4 * q4 + 2], df[4 * q4 + 3]);
+                    }
+                }
+            }
+        }
+        // G1: contraction over the group's 64 nodes (2 per step)
+        for (int s8 = 0; s8 < 32; s8 += 8) {                      // 8 steps' operands in flight, then their 8 * NB MFMAs
+            float av[8], bv[8][NB];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int nn = 2 * (s8 + q) + hh;
+                av[q] = tt[nn * ZS + li];
+#pragma unroll
+                for (int a = 0; a < NB; a++) bv[q][a] = xt[nn * XS + a * 32 + li];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+#pragma unroll
+                for (int a = 0; a < NB; a++) g1[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q][a], g1[a], 0, 0, 0);
+        }
+        // G2: z (node-major) overwrites the dpre1 tile
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int o = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                tt[(blk * 32 + li) * ZS + o] = o < H2 ? zacc[blk][r] : 0.0f;
+            }
+        for (int s8 = 0; s8 < 32; s8 += 16) {
+            float av[16], bv[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int nn = 2 * (s8 + q) + hh;
+                av[q] = fa * dkl[nn];
+                bv[q] = tt[nn * ZS + li];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) g2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], g2, 0, 0, 0);
+        }
+    }
+    // the workgroup's four wavefronts summed through LDS, then one float atomic per element
+    __syncthreads();
+    float *red = sm;                                               // [4][PER][64]
+#pragma unroll
+    for (int a = 0; a < NB; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[(wave * PER + a * 16 + r) * 64 + lane] = g1[a][r];
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[(wave * PER + NB * 16 + r) * 64 + lane] = g2[r];
+    red[(wave * PER + PER - 1) * 64 + lane] = s0;
+    __syncthreads();
+    if (wave != 0) return;
+    float tot_s0 = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) tot_s0 += red[(w * PER + PER - 1) * 64 + lane];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) tot_s0 += __shfl_xor(tot_s0, off, 64);
+    if (lane == 0) atomicAdd(gS0, tot_s0);
+#pragma unroll
+    for (int a = 0; a <= NB; a++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) v += red[(w * PER + a * 16 + r) * 64 + lane];
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh, col = (a < NB ? a * 32 : 0) + li;
+            if (a < NB) {
+                if (row < H2) {
+                    if (col <= H) atomicAdd(&gW1[row * (H + 1) + col], v);
+                    else if (col == H + 1) atomicAdd(&gb1[row], v);
+                }
+            } else if (col < H2) {
+                if (row < H4) atomicAdd(&gWmu[row * H2 + col], v);
+                else if (row == H4) atomicAdd(&gv[col], v);
+            }
+        }
+    }
+}
+
+// dbp = S0, dbmu = Wp S0, dWp = Wmu v + bmu S0  (see knet_x_bwd_mfma)
+__global__ void knet_mfma_finish(int h2, int h4, const float *__restrict__ Wmu, const float *__restrict__ bmu, const float *__restrict__ Wp,
+                                 const float *__restrict__ gv, const float *__restrict__ gS0, float *__restrict__ gbmu,
+                                 float *__restrict__ gWp, float *__restrict__ gbp) {
+    const int o = threadIdx.x;
+    const float S0 = gS0[0];
+    if (o == 0) gbp[0] = S0;
+    if (o < h4) {
+        gbmu[o] = Wp[o] * S0;
+        float acc = bmu[o] * S0;
+        for (int c = 0; c < h2; c++) acc = fmaf(Wmu[o * h2 + c], gv[c], acc);
+        gWp[o] = acc;
+    }
+}
+
 // degree-only modes (dgm.py:1492-1526): nd = (deg - mu) / (sd + eps); mu/sd are constants ("input_deg", eps 1e-5) or the
 // batch statistics read from device memory ("learn_normalized_degree", eps 0)
 __global__ void knet_deg_fwd_kernel(const float *__restrict__ deg, int64_t N, const float *__restrict__ mu_sd, float dmean,
@@ -406,6 +718,43 @@ int dgg_knet_x_bwd_nodes(int64_t N, int h, const float *mu_sd, const float *W1, 
     hipLaunchKernelGGL(knet_x_bwd_kernel, dim3(blocks), dim3(WPB * 64), lds, (hipStream_t)stream, N, h, mu_sd, W1, h2, Wmu,
                        h4, Wp, z, u, dk, dkp, dm, dpre1, dxk, m_out, bmu);
     return dgg_check_launch("knet_x_bwd_nodes");
+}
+
+// k-net, mode "x", on the fp32 matrix cores (latent_dim h in {16, 32, 64}): forward -> k [N] and u [N] (the pre-ReLU output, the only
+// tensor the backward needs besides xk); same bits as dgg_knet_x_fwd
+int dgg_knet_x_fwd_mfma(const float *xk, int64_t N, int h, const float *deg, const float *mu_sd, const float *W1, const float *b1,
+                        const float *Wmu, const float *bmu, const float *Wp, const float *bp, float *k, float *u_save, void *stream) {
+    if (h != 16 && h != 32 && h != 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "MFMA k-net: latent_dim in {16, 32, 64}");
+    if (N == 0) return 0;
+    const int64_t ngroups = (N + 63) / 64;
+    const unsigned grid = (unsigned)std::min<int64_t>(256, (ngroups + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    switch (h) {
+        case 16: hipLaunchKernelGGL(knet_x_fwd_mfma<16>, dim3(grid), dim3(256), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, k, u_save); break;
+        case 32: hipLaunchKernelGGL(knet_x_fwd_mfma<32>, dim3(grid), dim3(256), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, k, u_save); break;
+        default: hipLaunchKernelGGL(knet_x_fwd_mfma<64>, dim3(grid), dim3(256), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, k, u_save); break;
+    }
+    return dgg_check_launch("knet_x_fwd_mfma");
+}
+
+// its backward, ONE pass over xk: dxk [N,h] OVERWRITTEN; gW1 [h2, h+1], gb1 [h2], gWmu [h4, h2] ACCUMULATED into (caller zeroes them
+// and the scratch gv [h2], gS0 [1]); gbmu [h4], gWp [h4], gbp [1] OVERWRITTEN
+int dgg_knet_x_bwd_mfma(const float *xk, int64_t N, int h, const float *deg, const float *mu_sd, const float *W1, const float *b1,
+                        const float *Wmu, const float *bmu, const float *Wp, const float *u, const float *dk, float *dxk, float *gW1,
+                        float *gb1, float *gWmu, float *gbmu, float *gWp, float *gbp, float *gv, float *gS0, void *stream) {
+    if (h != 16 && h != 32 && h != 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "MFMA k-net: latent_dim in {16, 32, 64}");
+    hipStream_t st = (hipStream_t)stream;
+    if (N > 0) {
+        const int64_t ngroups = (N + 63) / 64;
+        const unsigned grid = (unsigned)std::min<int64_t>(256, (ngroups + 3) / 4);
+        switch (h) {
+            case 16: hipLaunchKernelGGL(knet_x_bwd_mfma<16>, dim3(grid), dim3(256), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, Wp, u, dk, dxk, gW1, gb1, gWmu, gv, gS0); break;
+            case 32: hipLaunchKernelGGL(knet_x_bwd_mfma<32>, dim3(grid), dim3(256), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, Wp, u, dk, dxk, gW1, gb1, gWmu, gv, gS0); break;
+            default: hipLaunchKernelGGL(knet_x_bwd_mfma<64>, dim3(grid), dim3(256), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, Wp, u, dk, dxk, gW1, gb1, gWmu, gv, gS0); break;
+        }
+    }
+    hipLaunchKernelGGL(knet_mfma_finish, dim3(1), dim3(64), 0, st, h / 2, h / 4, Wmu, bmu, Wp, gv, gS0, gbmu, gWp, gbp);
+    return dgg_check_launch("knet_x_bwd_mfma");
 }
 
 int dgg_knet_feat(const float *xk, const float *deg, const float *mu_sd, int64_t N, int h, float *feat, void *stream) {

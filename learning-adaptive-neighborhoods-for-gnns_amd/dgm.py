@@ -41,13 +41,22 @@ class _KnetFeatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xk, deg, W1, b1, Wmu, bmu, Wp, bp):
         mu_sd = ops.degree_stats(deg)
-        k, z, u, feat = ops.knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp.reshape(-1), bp)
         ctx.h = xk.shape[1]
+        ctx.mfma = ctx.h in ops.KNET_MFMA_WIDTHS and W1.shape[0] * 2 == ctx.h and Wmu.shape[0] * 4 == ctx.h
+        if ctx.mfma:        # matrix-core k-net: only u is saved, the backward re-runs layer 1 from xk (same bits for k)
+            k, u = ops.knet_x_fwd_slim(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp.reshape(-1), bp)
+            ctx.save_for_backward(W1, Wmu, bmu, Wp, mu_sd, u, xk, deg, b1)
+            return k
+        k, z, u, feat = ops.knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp.reshape(-1), bp)
         ctx.save_for_backward(W1, Wmu, bmu, Wp, mu_sd, z, u, feat)
         return k
 
     @staticmethod
     def backward(ctx, dk):
+        if ctx.mfma:
+            W1, Wmu, bmu, Wp, mu_sd, u, xk, deg, b1 = ctx.saved_tensors
+            dxk, dW1, db1, dWmu, dbmu, dWp, dbp = ops.knet_x_bwd_fused(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp.reshape(-1), u, dk.contiguous())
+            return dxk, None, dW1, db1, dWmu, dbmu, dWp.reshape(Wp.shape), dbp
         W1, Wmu, bmu, Wp, mu_sd, z, u, feat = ctx.saved_tensors
         dxk, dW1, db1, dWmu, dbmu, dWp, dbp = ops.knet_x_bwd(ctx.h, mu_sd, W1, Wmu, bmu, Wp.reshape(-1), z, u, feat, dk.contiguous())
         return dxk, None, dW1, db1, dWmu, dbmu, dWp.reshape(Wp.shape), dbp

@@ -907,6 +907,45 @@ def knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, save=True):
     return k, z, u, feat
 
 
+KNET_MFMA_WIDTHS = (16, 32, 64)
+
+
+def knet_x_fwd_slim(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp):
+    """k-net forward on the matrix cores, saving only u (the fused backward re-runs layer 1): -> k [N], u [N]; same bits as knet_x_fwd"""
+    xk = _chk(xk)
+    N, h = xk.shape
+    assert h in KNET_MFMA_WIDTHS and W1.shape[0] * 2 == h and Wmu.shape[0] * 4 == h
+    k = torch.empty((N,), device=xk.device, dtype=torch.float32)
+    u = torch.empty((N,), device=xk.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_knet_x_fwd_mfma(_ptr(xk), N, h, _ptr(_chk(deg)), _ptr(mu_sd), _ptr(_chk(W1)), _ptr(_chk(b1)), _ptr(_chk(Wmu)),
+                                              _ptr(_chk(bmu)), _ptr(_chk(Wp)), _ptr(_chk(bp)), _ptr(k), _ptr(u), _stream()), "knet_x_fwd_mfma")
+    return k, u
+
+
+def knet_x_bwd_fused(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, u, dk):
+    """one pass over xk -> dxk [N,h], dW1, db1, dWmu, dbmu, dWp ([h4]), dbp ([1])  (dgg_knet_x_bwd_mfma)"""
+    xk = _chk(xk)
+    N, h = xk.shape
+    h2, h4 = W1.shape[0], Wmu.shape[0]
+    assert h in KNET_MFMA_WIDTHS and h2 * 2 == h and h4 * 4 == h
+    dev = xk.device
+    zz = _zeros((h2 * (h + 1) + h2 + h4 * h2 + h2 + 1,), dev)              # accumulated into: one fill
+    o = 0
+    gW1 = zz[o:o + h2 * (h + 1)].view(h2, h + 1); o += h2 * (h + 1)
+    gb1 = zz[o:o + h2]; o += h2
+    gWmu = zz[o:o + h4 * h2].view(h4, h2); o += h4 * h2
+    gv = zz[o:o + h2]; o += h2
+    gS0 = zz[o:o + 1]
+    out = torch.empty((2 * h4 + 1,), device=dev, dtype=torch.float32)
+    gbmu, gWp, gbp = out[:h4], out[h4:2 * h4], out[2 * h4:]
+    dxk = torch.empty((N, h), device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_knet_x_bwd_mfma(_ptr(xk), N, h, _ptr(_chk(deg)), _ptr(mu_sd), _ptr(_chk(W1)), _ptr(_chk(b1)), _ptr(_chk(Wmu)),
+                                              _ptr(_chk(bmu)), _ptr(_chk(Wp)), _ptr(_chk(u)), _ptr(_chk(dk)), _ptr(dxk), _ptr(gW1), _ptr(gb1),
+                                              _ptr(gWmu), _ptr(gbmu), _ptr(gWp), _ptr(gbp), _ptr(gv), _ptr(gS0), _stream()),
+               "knet_x_bwd_mfma")
+    return dxk, gW1, gb1, gWmu, gbmu, gWp, gbp
+
+
 def knet_x_bwd(h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk):
     """-> dxk [N,h], dW1, db1, dWmu, dbmu, dWp ([1,h4]), dbp ([1])"""
     N = z.shape[0]

@@ -147,8 +147,14 @@ class ShardedDGGConv:
             self._stats_ref, self._stats_ver, self._stats = weakref.ref(deg_full), deg_full._version, kern.degree_stats(deg_full)
         s["mu_sd"] = mu_sd = self._stats
         deg_local = deg_full[self.r0:self.r1].contiguous()
-        s["k"], s["z"], s["u"], s["feat"] = kern.knet_x_fwd(xk, deg_local, mu_sd, P["W1"], P["b1"], P["Wmu"], P["bmu"],
-                                                          P["Wp"].reshape(-1), P["bp"])
+        s["deg_local"] = deg_local
+        if hasattr(kern, "knet_x_bwd_fused") and xk.shape[1] in getattr(kern, "KNET_MFMA_WIDTHS", ()):
+            # k-net on the matrix cores: the forward saves only u; the backward re-runs layer 1 from xk and forms every gradient in one pass
+            s["k"], s["u"] = kern.knet_x_fwd_slim(xk, deg_local, mu_sd, P["W1"], P["b1"], P["Wmu"], P["bmu"], P["Wp"].reshape(-1), P["bp"])
+            s["z"] = s["feat"] = None
+        else:
+            s["k"], s["z"], s["u"], s["feat"] = kern.knet_x_fwd(xk, deg_local, mu_sd, P["W1"], P["b1"], P["Wmu"], P["bmu"],
+                                                              P["Wp"].reshape(-1), P["bp"])
         s["xp"] = xp = g_xp.get() if (self.coll and not repl) else xp
         if self.noise_mode == 4 and self.K == 64 and hasattr(kern, "allpairs_topk_softk") and xp.shape[1] in (8, 16, 32, 64, 128):
             # ranked noise: the ramp is applied inside the search kernel, while the settled list is still in registers
@@ -181,7 +187,7 @@ class ShardedDGGConv:
             ncols, h, F = s["xp"].shape[0], s["xp"].shape[1], s["H"].shape[1]
             rows = s["idx"].shape[0]
             # (payload path: dH / da / dxp are written by their owner wavefronts, only dA and the weight gradients are accumulated into)
-            need = rows * self.K + 2 * sum(int(v.numel()) for v in P.values()) + 65536
+            need = rows * self.K + 3 * sum(int(v.numel()) for v in P.values()) + 65536
             if s.get("partp") is None:
                 need += ncols * (h + F + 2)
             with kern.zero_pool(s["xp"].device, need):
@@ -256,8 +262,12 @@ class ShardedDGGConv:
             dxp_g, dH_g, Xg, xp_g = both[:, :h].contiguous(), both[:, h:].contiguous(), x_local, s["xp_loc"]
         else:
             dxp_g, dH_g, Xg, xp_g = dxp, dH, (self.x_full if repl else x_local), s["xp"]
-        dxk, g["W1"], g["b1"], g["Wmu"], g["bmu"], dWp, g["bp"] = kern.knet_x_bwd(
-            s["xk"].shape[1], s["mu_sd"], P["W1"], P["Wmu"], P["bmu"], P["Wp"].reshape(-1), s["z"], s["u"], s["feat"], dk)
+        if s["z"] is None:
+            dxk, g["W1"], g["b1"], g["Wmu"], g["bmu"], dWp, g["bp"] = kern.knet_x_bwd_fused(
+                s["xk"], s["deg_local"], s["mu_sd"], P["W1"], P["b1"], P["Wmu"], P["bmu"], P["Wp"].reshape(-1), s["u"], dk)
+        else:
+            dxk, g["W1"], g["b1"], g["Wmu"], g["bmu"], dWp, g["bp"] = kern.knet_x_bwd(
+                s["xk"].shape[1], s["mu_sd"], P["W1"], P["Wmu"], P["bmu"], P["Wp"].reshape(-1), s["z"], s["u"], s["feat"], dk)
         g["Wp"] = dWp.reshape(P["Wp"].shape)
         same_rows = Xg.shape[0] == x_local.shape[0] and (not repl or self.world == 1) and self.emulate is None
         if hasattr(kern, "linear_bwd_multi") and not self.x_grad and same_rows:

@@ -193,7 +193,7 @@ def test_knet_bit_exact_and_bwd(dev):
     from dgg_amd import ops
     rng = np.random.default_rng(8)
     # 128, 256: GEMM composition; (151, -128): the thread-per-node kernels at 128 features; 40: wave-per-node
-    for N, h in [(700, 64), (300, 16), (150, 128), (151, -128), (333, 256), (90, 40)]:
+    for N, h in [(700, 64), (300, 16), (2, 64), (4133, 32), (150, 128), (151, -128), (333, 256), (90, 40)]:
         ops.KNET_WIDE_FROM = 129 if h < 0 else 128
         h = abs(h)
         h2, h4 = h // 2, h // 4
@@ -217,6 +217,16 @@ def test_knet_bit_exact_and_bwd(dev):
         ref = O.knet_x_bwd(xk, deg, mu, sd, W1, Wmu, Wp, rz, rm, ru, dk)
         for a, b in zip(got, ref):
             np.testing.assert_allclose(Nn(a).reshape(b.shape), b, rtol=2e-4, atol=2e-4 * max(np.abs(b).max(), 1e-6))
+        if h in ops.KNET_MFMA_WIDTHS:
+            # the k-net on the matrix cores (the headline step's path): k and u bit-identical to the thread-per-node kernel and the
+            # oracle; the one-pass backward (layer 1 re-run, gradients formed in the kernel) against the oracle's
+            k2, u2 = ops.knet_x_fwd_slim(T(xk, dev), T(deg, dev), T(np.array([mu, sd], np.float32), dev), T(W1, dev), T(b1, dev),
+                                         T(Wmu, dev), T(bmu, dev), T(Wp, dev), T(bp, dev))
+            assert np.array_equal(Nn(k2), rk) and np.array_equal(Nn(u2), ru)
+            got2 = ops.knet_x_bwd_fused(T(xk, dev), T(deg, dev), T(np.array([mu, sd], np.float32), dev), T(W1, dev), T(b1, dev), T(Wmu, dev),
+                                        T(bmu, dev), T(Wp, dev), u2, T(dk, dev))
+            for a, b in zip(got2, ref):
+                np.testing.assert_allclose(Nn(a).reshape(b.shape), b, rtol=2e-4, atol=2e-4 * max(np.abs(b).max(), 1e-6))
 
 
 def test_ell_backward_kernels(dev):
