@@ -56,7 +56,7 @@ class GraphConvolution(nn.Module):
         self.out_features = out_features
         self.residual = residual
         self.weight = Parameter(torch.FloatTensor(self.in_features, self.out_features))
-        self.gemm_dtype = None                     # None: fp32 HIP kernel; torch.bfloat16: library GEMM on bf16 operands
+        self.gemm_dtype = None                     # None: fp32 MFMA kernel; torch.bfloat16: hand-written bf16 MFMA kernel (dgg_bf16.hip)
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -69,10 +69,10 @@ class GraphConvolution(nn.Module):
         # variant: the GEMM input is cat[hi, h0] and r only feeds the epilogue (folded into it); otherwise support = r
         support = torch.cat([hi, h0], 1) if self.variant else (1 - alpha) * hi + alpha * h0
         res = input if self.residual else None
-        if self.gemm_dtype is not None:
+        if self.gemm_dtype == torch.bfloat16 and support.shape[1] % 64 == 0:
             # reduced-precision variant (BASELINE configs[4]: "bf16 fwd+bwd"): the layer product and its autograd run on the bf16
             # matrix cores (dgg_bf16.hip: v_mfma_f32_32x32x16_bf16, fp32 accumulation), epilogue fused; everything else fp32
-            assert self.gemm_dtype == torch.bfloat16
+            # (other dtypes / contraction lengths that are not a multiple of 64: the fp32 matrix-core path below)
             if self.variant:
                 return ops.GcniiBf16Fn.apply(support, self.weight, hi, h0, res, theta, alpha)
             return ops.GcniiBf16Fn.apply(support, self.weight, support, None, res, theta, alpha)

@@ -764,8 +764,10 @@ def conv_bwd_cols_p(idx, H, G, partp, rs):
     ncols = H.shape[0]
     dA = _zeros((N, K), H.device)                                                # entries outside the partition stay 0
     # one wavefront per destination node owns dH_j / da_j: plain stores for every node, no zero fill
-    dH = torch.empty((ncols, F), device=H.device, dtype=torch.float32)
-    da = torch.empty((ncols,), device=H.device, dtype=torch.float32)
+    # (an EMPTY row shard launches nothing: the outputs the other ranks reduce must then be zeros, not uninitialised memory)
+    alloc = torch.zeros if N == 0 else torch.empty
+    dH = alloc((ncols, F), device=H.device, dtype=torch.float32)
+    da = alloc((ncols,), device=H.device, dtype=torch.float32)
     dA_rec = torch.empty((N * K,), device=H.device, dtype=torch.float32)
     pe = _probe_begin()
     _lib.check(_lib.lib().dgg_ell_conv_bwd_partp(_ptr(G), _ptr(H), N, K, F, _ptr(partp.ws), ncols, _ptr(_chk(rs)), _ptr(dA), _ptr(dA_rec),
@@ -782,7 +784,7 @@ def softk_edge_bwd_p(xp, idx, val, k, dA, dA_rec, rs, da, row0, t, perturb, mode
     if partp is None or h not in (16, 32, 64, 128) or mode not in (MODE_K_TIMES_EDGE_PROB, MODE_K_ONLY) or Ng != partp.ncols:
         return None
     # mode 0: every row of dxp is written (own rows by the row kernel, the others by the per-node kernel): no zero fill
-    dxp = torch.empty_like(xp) if mode == MODE_K_TIMES_EDGE_PROB else _zeros(tuple(xp.shape), xp.device)
+    dxp = torch.empty_like(xp) if (mode == MODE_K_TIMES_EDGE_PROB and N > 0) else _zeros(tuple(xp.shape), xp.device)   # (N == 0: see conv_bwd_cols_p)
     rowinfo = torch.empty((N, 4), device=xp.device, dtype=torch.float32)
     dk = torch.empty((N,), device=xp.device, dtype=torch.float32)
     pe = _probe_begin()

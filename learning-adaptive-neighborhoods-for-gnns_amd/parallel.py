@@ -131,8 +131,11 @@ class ShardedDGGConv:
         return xp, H, kern.linear_fwd(x_local, P["Wk"], P["bk"], 1, 0)
 
     def forward(self, x_local, deg_full, P):
+        """One forward per backward: `saved` holds views of the persistent collective buffers (the gathered xp / H / row sums),
+        which the next forward overwrites."""
         kern = self.kern
         s = {}
+        self._fwd_gen = getattr(self, "_fwd_gen", 0) + 1
         repl = self.x_full is not None
         xp, H, xk = self._project(x_local, P)
         s["xp_loc"], s["H_loc"] = xp, H
@@ -177,12 +180,15 @@ class ShardedDGGConv:
             s["ahat"] = kern.normalize_fwd(s["idx"], s["w"], rs, self.r0)
         s["H"] = H = g_H.get() if (self.coll and not repl) else H
         s["Z"] = kern.spmm_fwd(s["idx"], s["ahat"], H, 2)    # relu(A (x Wc))
+        s["gen"] = self._fwd_gen
         self.saved = s
         return s["Z"]
 
     def backward(self, dZ, x_local, P):
         """-> dict of parameter gradients (summed over ranks) and, if x_grad, 'x' = d loss / d x_local."""
         kern, s = self.kern, self.saved
+        assert s.get("gen") == getattr(self, "_fwd_gen", None), "ShardedDGGConv: backward() must follow the forward() it differentiates " \
+            "(a second forward has overwritten the gathered buffers)"
         if hasattr(kern, "zero_pool"):                   # every zero-initialised accumulator of the backward from ONE filled buffer
             ncols, h, F = s["xp"].shape[0], s["xp"].shape[1], s["H"].shape[1]
             rows = s["idx"].shape[0]
@@ -293,9 +299,9 @@ class ShardedDGGConv:
                 o += n
             dist.all_reduce(flat, group=self.group)
             o = 0
-            for k in self.PARAM_KEYS:
+            for k in self.PARAM_KEYS:              # (copies: `flat` is a persistent bucket, overwritten by the next step's all-reduce)
                 n = g[k].numel()
-                g[k] = flat[o:o + n].view_as(g[k])
+                g[k] = flat[o:o + n].view_as(g[k]).clone()
                 o += n
         if self.x_grad:
             g["x"] = dX1 + dX3 + dX2                     # all three on the rank's own rows

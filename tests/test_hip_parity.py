@@ -634,6 +634,38 @@ def test_sharded_layer_step_matches_cpu_restatement(dev, N, d, h, noise):
         assert err <= 3e-4, f"grad {k_}: {err:.3e}"
 
 
+@pytest.mark.parametrize("rank", [0, 3, 7])
+def test_rank_of_eight_step_matches_cpu_restatement(dev, rank):
+    """The per-rank step of an 8-GPU run (62 500-row shards in BASELINE configs[3]; here 500 of 4 000 rows): own row range against ALL
+    columns, replicated features, payload partition with SHORT destination lists -- the lane-group node kernels conv_bwd_nodeg /
+    edge_bwd_nodeg are selected when rows * 64 < 16 * ncols, i.e. only in this regime -- against the numpy/oracle stand-in running the
+    same rank (ShardedDGGConv.emulate_rank: collectives left out, the other ranks' row sums tiled from the own ones in both)."""
+    from dgg_amd import ops
+    from dgg_amd.parallel import ShardedDGGConv
+    from test_parallel_gloo import CpuKern, make_inputs
+    N, d, h = 4000, 128, 64
+    x, deg, P, cot = make_inputs(N, d, h)
+    deg = 20 + 12 * torch.rand(N, generator=torch.Generator().manual_seed(1))
+    outs = []
+    for kern, to in ((CpuKern(), lambda t_: t_), (ops, lambda t_: t_.to(dev))):
+        lay = ShardedDGGConv(kern, N, K=64, noise_mode=ops.NOISE_RANKED, seed=(5, 6), x_full=to(x))
+        lay.emulate_rank(8, rank)
+        r0, r1 = lay.r0, lay.r1
+        assert (r1 - r0) * 64 < 16 * N
+        Pd = {k_: to(v) for k_, v in P.items()}
+        Z = lay.forward(to(x[r0:r1].contiguous()), to(deg), Pd)
+        g = lay.backward(to(cot[r0:r1].contiguous()), to(x[r0:r1].contiguous()), Pd)
+        outs.append((lay, Z, g))
+    (lr, Zr, gr), (lg, Zg, gg) = outs
+    kept = Nn(lg.saved["idx"]) >= 0
+    assert np.array_equal(Nn(lg.saved["idx"])[kept], lr.saved["idx"].numpy()[kept])
+    np.testing.assert_allclose(Nn(Zg), Zr.numpy(), rtol=1e-5, atol=1e-5 * float(Zr.abs().max()))
+    for k_ in gr:
+        r_ = gr[k_].numpy()
+        err = np.abs(Nn(gg[k_]).reshape(r_.shape) - r_).max() / max(np.abs(r_).max(), 1e-30)
+        assert err <= 3e-4, f"grad {k_}: {err:.3e}"
+
+
 @pytest.mark.parametrize("hw,use_deg,ex_mode,act,noise", [(64, True, 0, 1, "hash"), (16, False, 1, 1, "none"), (32, True, 2, 1, "sym"),
                                                         (8, False, 0, 0, "none"), (1, False, 1, 0, "hash"), (128, True, 2, 1, "none")])
 def test_edge_mlp_kernels(dev, hw, use_deg, ex_mode, act, noise):

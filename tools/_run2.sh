@@ -1,5 +1,5 @@
 set -x
-D=gpurun_out/r3m
+D=gpurun_out/r3n
 mkdir -p $D
 timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_conv_reorder.py -q -m gpu -k "test_allpairs_topk_bit_exact or test_full_size_unperturbed_sweep or test_allpairs_topk_k_limit or row_range or unperturbed" -x 2>&1 | tail -4
 for M in 28 32; do DGG_SWEEP_M=$M DGG_SWEEP_STATS=1 timeout 300 python tools/time_sweep.py 100000 64 2 2>&1 | tail -1; done
