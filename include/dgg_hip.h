@@ -220,6 +220,16 @@ int dgg_csr_rank_ramp_fwd(const float *p, const int64_t *rowptr, const int32_t *
 /* g = d loss / d out -> dp [E] (direct + through S -> k), dkz [N] = d loss / d (S_i w + b) (dw = <dkz, S>, db = sum dkz) */
 int dgg_csr_rank_ramp_bwd(const float *p, const int64_t *rowptr, int64_t N, const float *w, const float *b, const float *S,
                           const float *k, const int32_t *pos, const float *g, float *dp, float *dkz, void *stream);
+/* select_top_k of DGG_LearnableK_debug (dgm.py:1402-1435) on rows of ANY width: the CSR counterpart of dgg_edgelist_topk_p +
+ * dgg_softk_fwd for graphs whose rows have more candidates than the ELL width and whose learned degrees may exceed it.
+ * p [E] edge probabilities (edge_prob_net, dgm.py:1607-1725), k [N]; noise_mode DGG_NOISE_NONE / EXPLICIT (G [N, ldG]) / HASH / HASH_SYM
+ * (dgm.py:1213-1229); mode 0 k_times_edge_prob, 1 k_only.  -> w [E] = p' * ramp(pos - k) (mode 0) or the ramp, pp [E] = p', pos [E]
+ * = position of the entry in its row's descending sort (ties: lower column first). */
+int dgg_csr_softk_fwd(const float *p, const int64_t *rowptr, const int32_t *col, int64_t N, const float *k, int noise_mode, const float *G,
+                      int64_t ldG, uint32_t s0, uint32_t s1, int mode, float *w, float *pp, int32_t *pos, void *stream);
+/* g = d loss / d w -> dp [E] (through the perturbation when perturb != 0), dk [N] */
+int dgg_csr_softk_bwd(const float *p, const float *pp, const int64_t *rowptr, int64_t N, const float *k, const int32_t *pos, int perturb,
+                      int mode, const float *g, float *dp, float *dk, void *stream);
 /* `DGG_Ablations.forward` (dgm.py:1927-1962): edge_rank = sigmoid(sigmoid(score) + noise), noise ~ U(-1,1) per stored edge
  * (dgm.py:1930-1933; the caller draws the noise); out [E] */
 int dgg_csr_noisy_sigmoid_fwd(const float *p, const float *noise, int64_t E, float *out, void *stream);

@@ -185,6 +185,73 @@ __global__ __launch_bounds__(WPB * 64) void csr_rank_ramp_bwd_kernel(const float
     }
 }
 
+// ---- `DGG_LearnableK_debug.select_top_k` on rows of ANY width (dgm.py:1402-1435) ---------------------------------------------
+// The 64-wide ELL of the fast path is exact only while ceil(k_i + 8.5) <= 64 (or the row has no more candidates than that).  For
+// graphs whose rows are wider and whose learned degrees may exceed the bound, the same computation runs on the CSR pattern of
+// in_adj: perturbation (dgm.py:1213-1229), position of every candidate in its row's sort (counting; ties: lower column first),
+// ramp 1 - 0.5 (1 + tanh(pos - k_i)), w = p' * ramp (k_times_edge_prob) or ramp (k_only).  One wavefront per row.
+__global__ __launch_bounds__(WPB * 64) void csr_softk_fwd_kernel(const float *__restrict__ p, const int64_t *__restrict__ rowptr,
+                                                                const int32_t *__restrict__ col, int64_t N, const float *__restrict__ k,
+                                                                int noise_mode, const float *__restrict__ G, int64_t ldG, uint32_t s0,
+                                                                uint32_t s1, int mode, float *__restrict__ w, float *__restrict__ pp,
+                                                                int32_t *__restrict__ pos) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
+    if (i >= N) return;
+    const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
+    const float ki = k[i];
+    auto perturbed = [&](int64_t e) {
+        const float pe = p[e];
+        if (noise_mode == 0) return pe;
+        const int32_t j = col[e];
+        const float g = noise_mode == 1 ? G[i * ldG + j] : pair_noise(s0, s1, (uint32_t)i, (uint32_t)j, noise_mode == 3);
+        return c_exp(__fadd_rn(c_log(__fadd_rn(pe, 1e-8f)), g));
+    };
+    for (int64_t e = e0 + lane; e < e1; e += 64) pp[e] = perturbed(e);
+    // (same wavefront wrote pp: the loads below are ordered behind the stores)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int64_t mb = e0; mb < e1; mb += 64) {
+        const int64_t me = mb + lane;
+        const bool have = me < e1;
+        const uint64_t mykey = have ? make_key(pp[me], col[me]) : 0ull;
+        int cnt = 0;
+        for (int64_t qb = e0; qb < e1; qb += 64) {
+            const int64_t q = qb + lane;
+            const uint64_t qk = q < e1 ? make_key(pp[q], col[q]) : 0ull;
+            const int n = e1 - qb < 64 ? (int)(e1 - qb) : 64;
+            for (int r = 0; r < n; r++) cnt += shfl_u64(qk, r) > mykey ? 1 : 0;
+        }
+        if (have) {
+            pos[me] = cnt;
+            const float f = c_ramp((float)cnt, ki);
+            w[me] = mode == 0 ? __fmul_rn(pp[me], f) : f;
+        }
+    }
+}
+
+// g = d loss / d w -> dp [E] (through the perturbation: d p' / d p = p' / (p + 1e-8)), dk [N]
+__global__ __launch_bounds__(WPB * 64) void csr_softk_bwd_kernel(const float *__restrict__ p, const float *__restrict__ pp,
+                                                                const int64_t *__restrict__ rowptr, int64_t N, const float *__restrict__ k,
+                                                                const int32_t *__restrict__ pos, int perturb, int mode,
+                                                                const float *__restrict__ g, float *__restrict__ dp, float *__restrict__ dk) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
+    if (i >= N) return;
+    const float ki = k[i];
+    float acc = 0.0f;
+    for (int64_t e = rowptr[i] + lane; e < rowptr[i + 1]; e += 64) {
+        const float th = c_tanh((float)pos[e] - ki);
+        const float f = 1.0f - 0.5f * (1.0f + th), dfdk = 0.5f * (1.0f - th * th);
+        float dpp = 0.0f;
+        if (mode == 0) { dpp = g[e] * f; acc += g[e] * pp[e] * dfdk; }
+        else acc += g[e] * dfdk;
+        dp[e] = perturb ? dpp * pp[e] / (p[e] + 1e-8f) : dpp;
+    }
+    acc = wave_sum_butterfly(acc);
+    if (lane == 0) dk[i] = acc;
+}
+
 // ---- `DGG_Ablations.forward` (dgm.py:1927-1962): noisy second sigmoid and the fixed-k truncation -----------------------
 // edge_rank = sigmoid(sigmoid(score) + noise), noise ~ U(-1,1) per stored edge (dgm.py:1930-1933)
 __global__ __launch_bounds__(256) void csr_noisy_sigmoid_fwd_kernel(const float *__restrict__ p, const float *__restrict__ noise,
@@ -372,6 +439,26 @@ int dgg_csr_norm_bwd(const int64_t *rowptr, const int32_t *col, const float *w, 
     hipLaunchKernelGGL(csr_norm_bwd_da_kernel, grid, dim3(WPB * 64), 0, (hipStream_t)stream, rowptr, col, w, rs, dA, N, da_ws);
     hipLaunchKernelGGL(csr_norm_bwd_dw_kernel, grid, dim3(WPB * 64), 0, (hipStream_t)stream, rowptr, col, rs, dA, da_ws, N, dw);
     return dgg_check_launch("csr_norm_bwd");
+}
+
+// select_top_k on the CSR pattern (rows of any width; dgm.py:1402-1435): p [E] edge probabilities, k [N] learned degrees;
+// noise_mode 0 none / 1 explicit G [N, ldG] / 2 hash / 3 symmetric hash; mode 0 k_times_edge_prob, 1 k_only.
+// -> w [E], pp [E] (perturbed probabilities), pos [E] (rank of the entry in its row)
+int dgg_csr_softk_fwd(const float *p, const int64_t *rowptr, const int32_t *col, int64_t N, const float *k, int noise_mode, const float *G,
+                      int64_t ldG, uint32_t s0, uint32_t s1, int mode, float *w, float *pp, int32_t *pos, void *stream) {
+    if (noise_mode < 0 || noise_mode > 3 || (noise_mode == 1 && !G)) return dgg_set_error(DGG_ERR_ARG, "csr_softk_fwd: bad noise arguments");
+    if (mode != 0 && mode != 1) return dgg_set_error(DGG_ERR_ARG, "csr_softk_fwd: mode must be 0 (k_times_edge_prob) or 1 (k_only)");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(csr_softk_fwd_kernel, dim3((unsigned)((N + WPB - 1) / WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, p, rowptr, col, N, k,
+                       noise_mode, G, ldG, s0, s1, mode, w, pp, pos);
+    return dgg_check_launch("csr_softk_fwd");
+}
+int dgg_csr_softk_bwd(const float *p, const float *pp, const int64_t *rowptr, int64_t N, const float *k, const int32_t *pos, int perturb,
+                      int mode, const float *g, float *dp, float *dk, void *stream) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(csr_softk_bwd_kernel, dim3((unsigned)((N + WPB - 1) / WPB)), dim3(WPB * 64), 0, (hipStream_t)stream, p, pp, rowptr, N, k,
+                       pos, perturb, mode, g, dp, dk);
+    return dgg_check_launch("csr_softk_bwd");
 }
 
 int dgg_csr_rank_ramp_fwd(const float *p, const int64_t *rowptr, const int32_t *col, int64_t N, const float *w, const float *b,

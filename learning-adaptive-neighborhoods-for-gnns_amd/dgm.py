@@ -13,6 +13,8 @@ Edge scorers: `u-v-dist` (all-pairs or edge-list candidates) and the edge-MLP fa
 (`u-v-deg` -- the reference's default, train_small_graphs.py:184-191 -- `u-v-A_uv`, `u-v-deg-dist`, `edge_conv`, `A_uv`;
 reference dgm.py:1628-1725).
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -270,8 +272,8 @@ class DGG_LearnableK_debug(nn.Module):
             raise RuntimeError(
                 f"DGG_LearnableK_debug: a row's learned degree satisfies k + 8.5 > ell_width = {self.ell_width} while it has more "
                 "candidates than that: ranks the reference still weights were dropped (row sums, normalisation and gradients "
-                "differ from the reference from here on).  Rescale the degree prior / k_project, or lower the learning rate of the "
-                "k-net; wider rows are not supported by the ELL kernels.")
+                "differ from the reference from here on).  Edge-list candidates: set args.dgg_wide_rows = 'csr' (rows of any width; "
+                "'auto' picks it when the degree prior is near the width).  All-pairs candidates: rescale the degree prior / k_project.")
 
     def _track_overflow(self, k, ncand):
         over = k.detach() + 8.5 > float(self.ell_width)
@@ -281,6 +283,47 @@ class DGG_LearnableK_debug(nn.Module):
         self._overflow = flag if self._overflow is None else (self._overflow | flag)
         if __import__("os").environ.get("DGG_STRICT_BOUND") == "1":
             self.check_ell_bound()
+
+    def _wide_rows(self, in_adj, rowptr, deg):
+        """Should this graph go through the CSR form of select_top_k (rows of any width) instead of the 64-wide ELL?
+        args.dgg_wide_rows: "csr" always (edge-list candidates), "ell" never, "auto" (default): when some row has more candidates
+        than the ELL width AND the degree prior says that learned degrees near the width are to be expected (mean + 2 std + 8.5 >
+        width; k = relu(kp sd + mu) + 1 is centred on the prior, dgm.py:1580-1584).  The statistics cost one synchronisation per
+        GRAPH OBJECT (cached by identity), not per forward."""
+        policy = getattr(self.args, "dgg_wide_rows", "auto")
+        if policy == "ell":
+            return False
+        if policy == "csr":
+            return True
+        ref = getattr(self, "_wide_ref", None)
+        if ref is None or ref() is not in_adj:
+            lens = rowptr[1:] - rowptr[:-1]
+            stats = torch.stack([lens.max().float(), deg.mean(), deg.std() if deg.numel() > 1 else deg.new_zeros(())]).tolist()
+            self._wide_ref, self._wide_stats = weakref.ref(in_adj), stats
+        maxlen, mu, sd = self._wide_stats
+        if self.k_net_mode == "input_deg":
+            mu, sd = float(self.deg_mean), float(self.deg_std)
+        return maxlen > self.ell_width and mu + 2.0 * sd + 8.5 > self.ell_width
+
+    def _csr_soft_adjacency(self, x, in_adj, k, noise_mode, G, seed, mode):
+        """select_top_k on the CSR pattern of in_adj (ops.CsrSoftkFn: rows of any width, exact for any learned degree): edge
+        probabilities as in _scores_adjacency, then perturbation + rank + ramp per row."""
+        in_adj = in_adj.coalesce()
+        pattern = csr_pattern(in_adj)
+        _, _, deg = csr_candidates(in_adj)
+        We, be = self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias
+        cfg = dict(cand=pattern, t=ops.T_DIST)
+        if self.edge_prob_net_mode == "u-v-dist":
+            p = _DGGScoresFn.apply(x, None, None, We, be, None, None, None, None, None, None, None, cfg)
+        else:
+            mlp, ex_in = self._edge_mlp_terms(in_adj.values().to(torch.float32))
+            cfg.update(ex_mode=mlp["ex_mode"], t_ex=mlp["t_ex"], act=mlp["act"])
+            p = _DGGScoresFn.apply(x, deg, ex_in, We, be, mlp["Wcat"], mlp["wdu"], mlp["wdv"], mlp["wex"], mlp["b1"], mlp["w2"], mlp["b2"], cfg)
+        w = ops.CsrSoftkFn.apply(p, k, pattern[0], pattern[1], noise_mode, G, seed, mode)
+        if self.hard and mode == ops.MODE_K_TIMES_EDGE_PROB:      # straight-through (see forward): ramp mask forward, soft gradient
+            ramp = ops.CsrSoftkFn.apply(p.detach(), k.detach(), pattern[0], pattern[1], noise_mode, G, seed, ops.MODE_K_ONLY)
+            w = (ramp - w).detach() + w
+        return CsrAdjacency(pattern[0], pattern[1], pattern[2], w, x.shape[0], k=k.detach())
 
     def _noise_cfg(self):
         if not self.args.perturb_edge_prob:
@@ -450,6 +493,9 @@ class DGG_LearnableK_debug(nn.Module):
             consts = (float(self.deg_mean), float(self.deg_std)) if self.k_net_mode == "input_deg" else None
             k = _KnetDegFn.apply(deg, self.input_degree_project.weight, self.input_degree_project.bias, kn.k_mu.weight,
                                  kn.k_mu.bias, kn.k_project.weight, kn.k_project.bias, consts)
+        if cand is not None and not literal and self._wide_rows(in_adj, rowptr, deg):
+            # rows wider than the ELL and learned degrees that may exceed it: the CSR form (no width limit)
+            return self._csr_soft_adjacency(x, in_adj, k, noise_mode, G, seed, cfg["mode"])
         if self.edge_prob_net_mode == "u-v-dist":
             w, idx, val, rs = _DGGSoftAdjFn.apply(x, k, We, be, cfg)
         else:

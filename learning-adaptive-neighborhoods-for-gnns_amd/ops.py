@@ -408,6 +408,38 @@ def edge_mlp_bwd(AB, idx, eid, val, dval, deg, ex, wdu, wdv, wex, b1, w2, b2, ac
 
 
 # ---- CSR-valued adjacency (variable row length): the `DGG` class and the *_DGG_00 wrappers ----------------------------
+class CsrSoftkFn(torch.autograd.Function):
+    """select_top_k (dgm.py:1402-1435) on the CSR pattern: (p [E], k [N]) -> w [E]; rows of any width"""
+
+    @staticmethod
+    def forward(ctx, p, k, rowptr, col, noise_mode, G, seed, mode):
+        p, k = _chk(p), _chk(k)
+        N = rowptr.shape[0] - 1
+        w, pp = torch.empty_like(p), torch.empty_like(p)
+        pos = torch.empty(p.shape, device=p.device, dtype=torch.int32)
+        ldG = 0
+        if G is not None:
+            G = _chk(G)
+            ldG = G.shape[-1]
+        if p.numel():
+            _lib.check(_lib.lib().dgg_csr_softk_fwd(_ptr(p), _ptr(rowptr), _ptr(col), N, _ptr(k), noise_mode, _ptr(G), ldG, seed[0], seed[1], mode,
+                                                    _ptr(w), _ptr(pp), _ptr(pos), _stream()), "csr_softk_fwd")
+        ctx.save_for_backward(p, pp, k, pos, rowptr)
+        ctx.cfg = (noise_mode != NOISE_NONE, mode)
+        return w
+
+    @staticmethod
+    def backward(ctx, g):
+        p, pp, k, pos, rowptr = ctx.saved_tensors
+        perturb, mode = ctx.cfg
+        N = rowptr.shape[0] - 1
+        dp, dk = torch.empty_like(p), torch.zeros_like(k)
+        if p.numel():
+            _lib.check(_lib.lib().dgg_csr_softk_bwd(_ptr(p), _ptr(pp), _ptr(rowptr), N, _ptr(k), _ptr(pos), int(perturb), mode, _ptr(_chk(g.contiguous())),
+                                                    _ptr(dp), _ptr(dk), _stream()), "csr_softk_bwd")
+        return dp, dk, None, None, None, None, None, None
+
+
 def csr_rank_ramp_fwd(p, rowptr, col, w, b):
     """dgm.py:1791-1812 -> out [E], S [N], k [N], pos [E] (int32)"""
     p = _chk(p)

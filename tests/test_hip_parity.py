@@ -1726,6 +1726,71 @@ def test_ell_width_bound_is_enforced(dev):
     m.check_ell_bound()
 
 
+@pytest.mark.parametrize("perturb", [False, True])
+def test_rows_wider_than_the_ell_go_through_csr(dev, perturb):
+    """Hubs with 168 candidates (Cora's widest rows) and a degree prior of 90: ceil(k + 8.5) ~ 100 ranks carry weight, more than the
+    64-wide ELL holds.  The reference has no such limit (dense rows, dgm.py:1404-1420); the module routes the graph through the CSR
+    form of select_top_k (dgg_csr_softk_fwd / _bwd) -- automatically, from the degree prior -- and must reproduce the dense
+    reference-shaped formulation (oracle/dense_ref.py, float64, pinned on the goldens): weights on the candidate entries within
+    1e-5, gradients within 2e-4.  A low-degree prior on the same pattern stays on the ELL fast path."""
+    import dgg_amd
+    from argparse import Namespace
+    from oracle import dense_ref as D
+    N, d, h = 600, 24, 16
+    rng = np.random.default_rng(3)
+    rows, cols = [], []
+    for i in range(N):
+        c = rng.choice(N, 168 if i < 12 else 30, replace=False)
+        c = np.unique(np.append(c, i))
+        rows += [i] * len(c)
+        cols += list(c)
+    rows, cols = np.array(rows), np.array(cols)
+    lens = np.bincount(rows, minlength=N)
+    vals = (90.0 / lens[rows] * (1 + 0.2 * rng.standard_normal(len(rows)))).astype(np.float32)      # row sums (prior degrees) ~ 90
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(vals), (N, N)).coalesce().to(dev)
+    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=perturb,
+                     symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
+    torch.manual_seed(1)
+    m = dgg_amd.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=args).to(dev)
+    with torch.no_grad():
+        m.k_net.k_project.weight.mul_(0.3)
+    x = torch.randn(N, d, generator=torch.Generator().manual_seed(2)).to(dev).requires_grad_(True)
+    G = None
+    if perturb:
+        G = T(grid_gumbel(9, (N, N)), dev)
+        m.set_noise(G)
+    adj = m(x, A)
+    assert isinstance(adj, dgg_amd.CsrAdjacency), "the degree prior (90) and 168-wide rows must select the CSR path"
+    kk = Nn(adj.k)
+    assert kk.max() + 8.5 > 64, "the test must exercise learned degrees beyond the ELL width"
+    dense = adj.to_dense()
+    cot = torch.randn(N, N, generator=torch.Generator().manual_seed(4)).to(dev)
+    (dense * cot).sum().backward()
+    # the dense formulation in float64 with the module's parameters
+    P = {"We": m.node_encode_for_edges[0].weight, "be": m.node_encode_for_edges[0].bias, "Wk": m.node_encode_for_k[0].weight,
+         "bk": m.node_encode_for_k[0].bias, "W1": m.k_embed[0].weight, "b1": m.k_embed[0].bias, "Wmu": m.k_net.k_mu.weight,
+         "bmu": m.k_net.k_mu.bias, "Wp": m.k_net.k_project.weight, "bp": m.k_net.k_project.bias}
+    Pd = {k_: v.detach().cpu().double().requires_grad_(True) for k_, v in P.items()}
+    xd = x.detach().cpu().double().requires_grad_(True)
+    deg = torch.zeros(N, dtype=torch.float64).index_add_(0, torch.from_numpy(rows), torch.from_numpy(vals).double())
+    Ad, kd = D.dgg_dense(xd, torch.from_numpy(rows), torch.from_numpy(cols), deg, Pd, None if G is None else G.cpu().double())
+    cand = torch.zeros((N, N), dtype=torch.bool)
+    cand[rows, cols] = True
+    np.testing.assert_allclose(kk, kd.detach().numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(Nn(dense)[cand.numpy()], Ad.detach().numpy()[cand.numpy()], rtol=0, atol=1e-5)
+    (Ad * cot.cpu().double() * cand).sum().backward()             # (the reference's spare ranks on non-edges are not produced)
+    for k_, v in P.items():
+        ref = Pd[k_].grad.numpy()
+        err = np.abs(Nn(v.grad).reshape(ref.shape) - ref).max() / max(np.abs(ref).max(), 1e-12)
+        assert err <= 2e-4, f"grad {k_}: {err:.3e}"
+    err = np.abs(Nn(x.grad) - xd.grad.numpy()).max() / np.abs(xd.grad.numpy()).max()
+    assert err <= 2e-4, f"grad x: {err:.3e}"
+    # a low prior on the same pattern: the ELL fast path (exact while k + 8.5 <= 64)
+    A2 = torch.sparse_coo_tensor(A.indices(), A.values() * 0.1, (N, N)).coalesce()
+    assert isinstance(m(x.detach(), A2), dgg_amd.EllAdjacency)
+
+
 def test_config1_pubmed_shape_edge_list_step(dev):
     """BASELINE configs[1]: Pubmed shape (N = 19 717, d = 500, 44 324 undirected edges + self loops, k ~ 16), the drop-in modules
     forward + backward; neighbour lists and scores bit-exact against the oracle's edge-list pipeline on EVERY row, weights 1e-5,
