@@ -46,7 +46,8 @@ def load_traffic(N, d, h):
     rocprofv3 PMC passes (FETCH_SIZE doubled as the gfx950 guide prescribes + WRITE_SIZE), committed under profiles/ by
     tools/pmc_traffic.py together with the shape they were measured on; {} when there is no file FOR THIS SHAPE."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+        names = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_traffic.json"))     # newest round last
+        with open(os.path.join(ROOT, "profiles", names[-1])) as f:
             t = json.load(f)
         if t.get("shape") != {"nodes": N, "feat": d, "latent": h}:
             return {}
