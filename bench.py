@@ -564,7 +564,7 @@ class SyntheticRun:
         return self.grads
 
 
-MIN_TIMED_S = 3.0   # the timed region (all windows) lasts at least this long
+MIN_TIMED_S = 3.3   # the timed region (all windows) lasts at least this long
 NGRAPH = 4      # captured hipGraphs, one per noise seed: consecutive steps see different graphs (idx / partition / gather pattern)
 
 

@@ -273,7 +273,7 @@ class DGG_LearnableK_debug(nn.Module):
                 f"DGG_LearnableK_debug: a row's learned degree satisfies k + 8.5 > ell_width = {self.ell_width} while it has more "
                 "candidates than that: ranks the reference still weights were dropped (row sums, normalisation and gradients "
                 "differ from the reference from here on).  Edge-list candidates: set args.dgg_wide_rows = 'csr' (rows of any width; "
-                "'auto' picks it when the degree prior is near the width).  All-pairs candidates: rescale the degree prior / k_project.")
+                "'auto' picks it whenever a row would lose weight, except inside a hipGraph capture).  All-pairs candidates: rescale the degree prior / k_project.")
 
     def _track_overflow(self, k, ncand):
         over = k.detach() + 8.5 > float(self.ell_width)
@@ -284,26 +284,34 @@ class DGG_LearnableK_debug(nn.Module):
         if __import__("os").environ.get("DGG_STRICT_BOUND") == "1":
             self.check_ell_bound()
 
-    def _wide_rows(self, in_adj, rowptr, deg):
-        """Should this graph go through the CSR form of select_top_k (rows of any width) instead of the 64-wide ELL?
-        args.dgg_wide_rows: "csr" always (edge-list candidates), "ell" never, "auto" (default): when some row has more candidates
-        than the ELL width AND the degree prior says that learned degrees near the width are to be expected (mean + 2 std + 8.5 >
-        width; k = relu(kp sd + mu) + 1 is centred on the prior, dgm.py:1580-1584).  The statistics cost one synchronisation per
-        GRAPH OBJECT (cached by identity), not per forward."""
+    def _wide_rows(self, in_adj, rowptr, k):
+        """Should this forward go through the CSR form of select_top_k (rows of any width) instead of the 64-wide ELL?
+        args.dgg_wide_rows: "csr" always (edge-list candidates), "ell" never, "auto" (default): exactly when the ELL would lose a
+        non-zero weight, i.e. some row has more candidates than the ELL width AND a learned degree k_i + 8.5 above it (the
+        condition _track_overflow flags).  The widest row is read back once per GRAPH OBJECT (cached by identity); graphs whose
+        rows all fit never synchronise.  For the others the learned degrees are tested on the device and ONE flag is read back
+        per forward (the k-net has finished by then; the edge-list step is tens of launches long).  While a hipGraph is being
+        captured nothing can be read back: the decision of the last eager forward on the same graph object is replayed."""
         policy = getattr(self.args, "dgg_wide_rows", "auto")
         if policy == "ell":
             return False
         if policy == "csr":
             return True
-        ref = getattr(self, "_wide_ref", None)
-        if ref is None or ref() is not in_adj:
+        cache = self.__dict__.setdefault("_wide_cache", {})
+        ent = cache.get(id(in_adj))
+        if ent is None or ent[0]() is not in_adj:
+            if torch.cuda.is_current_stream_capturing():
+                return False
+            for key in [k_ for k_, v in cache.items() if v[0]() is None]:
+                del cache[key]
             lens = rowptr[1:] - rowptr[:-1]
-            stats = torch.stack([lens.max().float(), deg.mean(), deg.std() if deg.numel() > 1 else deg.new_zeros(())]).tolist()
-            self._wide_ref, self._wide_stats = weakref.ref(in_adj), stats
-        maxlen, mu, sd = self._wide_stats
-        if self.k_net_mode == "input_deg":
-            mu, sd = float(self.deg_mean), float(self.deg_std)
-        return maxlen > self.ell_width and mu + 2.0 * sd + 8.5 > self.ell_width
+            ent = cache[id(in_adj)] = [weakref.ref(in_adj), int(lens.max().item()) if lens.numel() else 0, False]
+        if ent[1] <= self.ell_width:
+            return False
+        if not torch.cuda.is_current_stream_capturing():
+            lens = rowptr[1:] - rowptr[:-1]
+            ent[2] = bool(((k.detach() + 8.5 > float(self.ell_width)) & (lens > self.ell_width)).any().item())
+        return ent[2]
 
     def _csr_soft_adjacency(self, x, in_adj, k, noise_mode, G, seed, mode):
         """select_top_k on the CSR pattern of in_adj (ops.CsrSoftkFn: rows of any width, exact for any learned degree): edge
@@ -493,7 +501,7 @@ class DGG_LearnableK_debug(nn.Module):
             consts = (float(self.deg_mean), float(self.deg_std)) if self.k_net_mode == "input_deg" else None
             k = _KnetDegFn.apply(deg, self.input_degree_project.weight, self.input_degree_project.bias, kn.k_mu.weight,
                                  kn.k_mu.bias, kn.k_project.weight, kn.k_project.bias, consts)
-        if cand is not None and not literal and self._wide_rows(in_adj, rowptr, deg):
+        if cand is not None and not literal and self._wide_rows(in_adj, rowptr, k):
             # rows wider than the ELL and learned degrees that may exceed it: the CSR form (no width limit)
             return self._csr_soft_adjacency(x, in_adj, k, noise_mode, G, seed, cfg["mode"])
         if self.edge_prob_net_mode == "u-v-dist":

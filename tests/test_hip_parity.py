@@ -1730,7 +1730,7 @@ def test_ell_width_bound_is_enforced(dev):
 def test_rows_wider_than_the_ell_go_through_csr(dev, perturb):
     """Hubs with 168 candidates (Cora's widest rows) and a degree prior of 90: ceil(k + 8.5) ~ 100 ranks carry weight, more than the
     64-wide ELL holds.  The reference has no such limit (dense rows, dgm.py:1404-1420); the module routes the graph through the CSR
-    form of select_top_k (dgg_csr_softk_fwd / _bwd) -- automatically, from the degree prior -- and must reproduce the dense
+    form of select_top_k (dgg_csr_softk_fwd / _bwd) -- automatically, from the learned degrees -- and must reproduce the dense
     reference-shaped formulation (oracle/dense_ref.py, float64, pinned on the goldens): weights on the candidate entries within
     1e-5, gradients within 2e-4.  A low-degree prior on the same pattern stays on the ELL fast path."""
     import dgg_amd
@@ -1761,7 +1761,7 @@ def test_rows_wider_than_the_ell_go_through_csr(dev, perturb):
         G = T(grid_gumbel(9, (N, N)), dev)
         m.set_noise(G)
     adj = m(x, A)
-    assert isinstance(adj, dgg_amd.CsrAdjacency), "the degree prior (90) and 168-wide rows must select the CSR path"
+    assert isinstance(adj, dgg_amd.CsrAdjacency), "learned degrees near 90 on 168-wide rows must select the CSR path"
     kk = Nn(adj.k)
     assert kk.max() + 8.5 > 64, "the test must exercise learned degrees beyond the ELL width"
     dense = adj.to_dense()
