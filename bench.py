@@ -466,9 +466,10 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--algo", type=int, default=0, help="all-pairs kernel for --noise hash: 0 auto, 1 exhaustive, 2 MFMA-bounded, "
                                                          "3 adaptive noise prefilter, 4 guess-and-verify")
-    ap.add_argument("--noise", choices=["ranked", "hash", "sym", "none"], default="ranked",
+    ap.add_argument("--noise", choices=["ranked", "hash", "sym", "rsym", "none"], default="ranked",
                     help="counter-based Gumbel generator: ranked (per-row order statistics, O(N*150) search), hash (per-pair hash, "
-                         "N^2 sweep), sym (symmetric per-pair hash: the reference's symmetric_noise=True), all iid Gumbel(0,0.3); "
+                         "N^2 sweep), sym (symmetric per-pair hash: the reference's symmetric_noise=True), rsym (the ranked symmetric generator: "
+                         "same symmetric law, owners list their largest noises first, O(N*300)), all iid Gumbel(0,0.3); "
                          "none = unperturbed scores (the reference's perturb_edge_prob=False: bf16-MFMA-bounded N^2 sweep)")
     ap.add_argument("--x-grad", action="store_true", help="also compute d loss / d x (reduce-scatter across ranks)")
     ap.add_argument("--strong", action="store_true", help="(default for several GPUs; kept for compatibility)")
@@ -665,7 +666,8 @@ def bench_synthetic(a, dev, world, rank, force):
         N = per * max(world, emu) if weak else (a.nodes if a.nodes else 500_000)
     else:
         weak, N = True, (a.nodes if a.nodes else 100_000)
-    noise_mode = {"ranked": ops.NOISE_RANKED, "hash": ops.NOISE_HASH, "sym": ops.NOISE_HASH_SYM, "none": ops.NOISE_NONE}[a.noise]
+    noise_mode = {"ranked": ops.NOISE_RANKED, "hash": ops.NOISE_HASH, "sym": ops.NOISE_HASH_SYM, "rsym": ops.NOISE_RANKED_SYM,
+                  "none": ops.NOISE_NONE}[a.noise]
     run = SyntheticRun(a, dev, world, rank, force, N, d, h, noise_mode, a.x_grad, emu, a.exchange)
     use_graph = a.hipgraph and (world == 1 and not force or os.environ.get("DGG_BENCH_GRAPH_DIST") == "1")
     times, graphed, eager_T = time_windows(run, a, world, force, dev, use_graph, a.repeats)
@@ -735,7 +737,8 @@ def bench_synthetic(a, dev, world, rank, force):
     if world == 1 and not force and not emu and a.variants:
         variants = {}
         vsteps = max(5, a.steps // 2)
-        for name, (nm, lat, xg) in {"symmetric": (ops.NOISE_HASH_SYM, h, False), "unperturbed": (ops.NOISE_NONE, h, False),
+        for name, (nm, lat, xg) in {"symmetric": (ops.NOISE_RANKED_SYM, h, False), "hash_symmetric": (ops.NOISE_HASH_SYM, h, False),
+                                    "unperturbed": (ops.NOISE_NONE, h, False),
                                     "hash_asymmetric": (ops.NOISE_HASH, h, False), "latent128": (noise_mode, 128, False),
                                     "x_grad": (noise_mode, h, True)}.items():
             try:
@@ -767,11 +770,32 @@ def bench_synthetic(a, dev, world, rank, force):
                         "note": "algorithmic flop = 2 N^2 h (the bf16 Gram bound of every ordered pair); executed = 2 N^2 (h + 16): the K-step "
                                 "that folds the norms and the row's radius into the accumulator; the two sweeps alone: see "
                                 "profiles/r03_unperturbed_kernel_stats.csv"}
-                elif name in ("symmetric", "hash_asymmetric"):
-                    npair = N * float(N) * (0.5 if name == "symmetric" else 1.0)
+                elif name == "symmetric":
+                    # ranked symmetric generator (the product default for symmetric_noise=True): owners walk their largest noises,
+                    # score each emitted pair once (one gathered row of xp), rows merge.  Counters from one call with statistics on.
+                    os.environ["DGG_RSYM_STATS"] = "1"
+                    sv = rv.layer.saved
+                    _, _, ws_ = ops.allpairs_topk(sv["xp"], 64, noise_mode=nm, seed=(1234, 0), return_ws=True, k_limit=sv["k"])
+                    st_ = ops.rsym_status(ws_, N)
+                    os.environ.pop("DGG_RSYM_STATS", None)
+                    del ws_
+                    comp = N * 4.0 * lat + N * 64 * 8.0
+                    gath = (st_["emitted"] + st_["tier2_delivered"]) * 4.0 * lat
+                    variants[name]["roofline"] = {
+                        "bound": "hbm", "kernel": "pair stage: rs_pilot + rs_emit<1> + rs_finalize + rs_emit<2> + rs_finalize2 (+ tier 3)",
+                        "achieved": comp / (pk * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": comp / (pk * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "algorithmic_bytes": comp, "gathered_bytes": gath, "gather_GBps": gath / (pk * 1e-3) / 1e9,
+                        "frac_gather_ceiling": gath / (pk * 1e-3) / 1e9 / GATHER_CEILING_GBPS, "traffic": None,
+                        "scored_pairs_per_row": st_["emitted"] / N, "inbox_deliveries_per_row": st_["delivered"] / N,
+                        "tier2_rows": st_["tier2_rows"], "tier3_rows": st_["tier3_rows"],
+                        "note": "frac = compulsory bytes (xp once + idx/val) / event-timed pair stage / 8 TB/s; the stage is a random-row "
+                                "gather (one 4h-byte row per scored pair, every unordered pair scored ONCE for both endpoints) plus one "
+                                "memory-side atomic per inbox delivery and a second, deeper walk for the rows that fail verification"}
+                elif name in ("hash_symmetric", "hash_asymmetric"):
+                    npair = N * float(N) * (0.5 if name == "hash_symmetric" else 1.0)
                     floor_s = npair / 64.0 * HASH_CYCLES_PER_WAVE_COLUMN / SIMD_CYCLES_PER_S
                     variants[name]["roofline"] = {
-                        "bound": "valu", "kernel": "pair stage: gv_pilot + gv_sweep" + ("_tri" if name == "symmetric" else "") + " + gv_finalize",
+                        "bound": "valu", "kernel": "pair stage: gv_pilot + gv_sweep" + ("_tri" if name == "hash_symmetric" else "") + " + gv_finalize",
                         "achieved": npair / (pk * 1e-3) / 1e12, "peak": npair / floor_s / 1e12, "unit": "Tpair/s (hash + compare)",
                         "frac": floor_s / (pk * 1e-3), "algorithmic_pairs": npair, "traffic": None,
                         "note": "integer-VALU bound: every (unordered, for symmetric noise) pair costs one 6-instruction hash + compare per "

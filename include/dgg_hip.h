@@ -37,6 +37,10 @@ extern "C" {
 #define DGG_NOISE_HASH_SYM 3  /* keyed on (seed, min(i,j), max(i,j)), zero diagonal (dgm.py:1216-1223) */
 #define DGG_NOISE_RANKED 4    /* counter-based, same iid Gumbel(0,0.3) law, generated per row in decreasing order
                                * (Renyi spacings + keyed column permutation): all-pairs top-K in O(N*~150) */
+#define DGG_NOISE_RANKED_SYM 5 /* symmetric (G_ij = G_ji, zero diagonal: symmetric_noise=True, dgm.py:1216-1223), same law per unordered
+                               * pair; every pair is owned by one endpoint, which generates the noises of its pairs in decreasing
+                               * order: all-pairs top-K in O(N*~300) instead of the N^2 hash sweep of DGG_NOISE_HASH_SYM.
+                               * All-pairs candidates only (dgg_allpairs_topk) */
 
 /* activations of dgg_linear_*: */
 #define DGG_ACT_NONE 0
@@ -167,6 +171,11 @@ size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K);
  * phase_a_hits_inside_the_tight_radius, phase_b_hits } (the three sums only with DGG_SWEEP_STATS=1), readable after the stream
  * has drained */
 size_t dgg_allpairs_sweep_ctl_offset_bytes(int64_t rows, int64_t N, int h);
+/* diagnostics of the ranked symmetric path (noise_mode 5): byte offset inside the workspace of its control block { float pilot_sum;
+ * int32 rows_redone_by_tier_2; float guessed_threshold; int32 rows_redone_by_tier_3; int32 err; int32 pad[3]; uint64 emitted_pairs,
+ * scored_candidates (both only with DGG_RSYM_STATS=1), ... }, readable after the stream has drained.  err != 0: more rows needed the
+ * dense tier than the workspace holds -- their idx is -1 and the caller must not use the result (the host mirror raises) */
+size_t dgg_allpairs_rsym_ctl_offset_bytes(int64_t rows, int64_t N);
 /* The debug class's LITERAL dgg_hard output, reference dgm.py:1294-1311 (return_hard_or_soft): ones.scatter_(-1, idxs, edge_p > 0.5)
  * with edge_p the already unsorted soft adjacency and idxs the sort permutation of the perturbed scores over ALL N columns, then
  * (hard - soft).detach() + soft.  Opt-in compatibility path, N <= 8192 (full per-row ranking; O(N^2 log^2 N)).  Candidates: all pairs

@@ -35,6 +35,7 @@ PROTOTYPES = {
     "dgg_allpairs_topk": [_vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _vp, _vp, _i32, _vp, _sz, _vp],
     "dgg_allpairs_workspace_bytes": [_i64, _i32, _i32, _i32],
     "dgg_allpairs_sweep_ctl_offset_bytes": [_i64, _i64, _i32],
+    "dgg_allpairs_rsym_ctl_offset_bytes": [_i64, _i64],
     "dgg_allpairs_topk_ranked_softk": [_vp, _i64, _i32, _i64, _i64, _f32, _u32, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "dgg_literal_hard_fwd": [_vp, _i64, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _u32, _u32, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp],
     "dgg_literal_hard_bwd": [_vp, _vp, _i64, _i32, _vp, _vp],
@@ -120,7 +121,7 @@ def lib():
             fn = getattr(L, name)      # AttributeError if the library does not export a declared symbol
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        for name in ("dgg_allpairs_workspace_bytes", "dgg_allpairs_sweep_ctl_offset_bytes", "dgg_gemm_tn_ws_floats", "dgg_gemm_tn_multi_ws_floats", "dgg_linear_bwd_ws_floats", "dgg_part_ws_bytes", "dgg_partp_ws_bytes",
+        for name in ("dgg_allpairs_workspace_bytes", "dgg_allpairs_sweep_ctl_offset_bytes", "dgg_allpairs_rsym_ctl_offset_bytes", "dgg_gemm_tn_ws_floats", "dgg_gemm_tn_multi_ws_floats", "dgg_linear_bwd_ws_floats", "dgg_part_ws_bytes", "dgg_partp_ws_bytes",
                      "dgg_degree_stats_ws_bytes"):
             getattr(L, name).restype = C.c_size_t
         _lib = L

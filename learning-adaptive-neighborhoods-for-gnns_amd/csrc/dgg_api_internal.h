@@ -40,6 +40,12 @@ int dgg_allpairs_topk_gv_impl(const float *xp, int64_t N, int h, int64_t row0, i
 size_t dgg_allpairs_gv_ws_bytes(int64_t rows, int64_t N);
 bool dgg_allpairs_gv_supported(int h, int noise_mode, int K);
 
+// ranked symmetric noise (dgg_topk_rsym.hip)
+int dgg_allpairs_topk_rsym_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1, int K,
+                                const float *klim, int32_t *idx, float *val, void *workspace, size_t ws_bytes, hipStream_t st);
+size_t dgg_allpairs_rsym_ws_bytes(int64_t rows, int64_t N);
+bool dgg_allpairs_rsym_supported(int h, int K);
+
 int dgg_allpairs_topk_ranked_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0,
                                   uint32_t s1, int K, const float *klim, int32_t *idx, float *val, hipStream_t st, int softk_mode = 0,
                                   float *w = nullptr, float *rs = nullptr, const uint32_t *seed_dev = nullptr);

@@ -28,11 +28,13 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
                       const float *k_limit, int algo, void *workspace, size_t ws_bytes, void *stream) {
     if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
     if (row0 < 0 || row1 > N || row0 > row1) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk: bad row range");
-    if (noise_mode < 0 || noise_mode > 4) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk: bad noise_mode");
+    if (noise_mode < 0 || noise_mode > 5) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk: bad noise_mode");
     if (noise_mode == 1 && !G) return dgg_set_error(DGG_ERR_ARG, "explicit noise requested but G is NULL");
     hipStream_t st = (hipStream_t)stream;
     if (noise_mode == 4)   // ranked generator: the row-wise early-stopping search is the only (and exact) evaluator
         return dgg_allpairs_topk_ranked_impl(xp, N, h, row0, row1, t, s0, s1, K, k_limit, idx, val, st);
+    if (noise_mode == 5)   // ranked symmetric generator: owners emit their largest noises, rows verify (dgg_topk_rsym.hip)
+        return dgg_allpairs_topk_rsym_impl(xp, N, h, row0, row1, t, s0, s1, K, k_limit, idx, val, workspace, ws_bytes, st);
     const bool can_fast = dgg_allpairs_fast_supported(h, noise_mode, K) && workspace &&
                           ws_bytes >= dgg_allpairs_fast_ws_bytes(N, h);
     const bool can_np = dgg_allpairs_np_supported(h, noise_mode, K) && workspace && ws_bytes >= dgg_allpairs_np_ws_bytes(N);
@@ -58,6 +60,7 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
 
 // bytes of workspace the pruned path needs (bf16 copy of xp + discounted norms); 0 when it cannot be used
 size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K) {
+    if (noise_mode == 5) return dgg_allpairs_rsym_supported(h, K) ? dgg_allpairs_rsym_ws_bytes(N, N) : 0;
     size_t a = dgg_allpairs_fast_supported(h, noise_mode, K) ? dgg_allpairs_fast_ws_bytes(N, h) : 0;
     size_t b = dgg_allpairs_np_supported(h, noise_mode, K) ? dgg_allpairs_np_ws_bytes(N) : 0;
     size_t c = dgg_allpairs_gv_supported(h, noise_mode, K) ? dgg_allpairs_gv_ws_bytes(N, N) : 0;
@@ -69,5 +72,7 @@ size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K) {
 
 // diagnostics of the unperturbed sweep: byte offset inside the workspace of {int nfail; int stats_on; u64 nA, nAkept, nB}
 size_t dgg_allpairs_sweep_ctl_offset_bytes(int64_t rows, int64_t N, int h) { return dgg_allpairs_sweep_ctl_offset(rows, N, h); }
+// diagnostics of the ranked symmetric path: its control block heads the workspace
+size_t dgg_allpairs_rsym_ctl_offset_bytes(int64_t rows, int64_t N) { (void)rows; (void)N; return 0; }
 
 }  // extern "C"

@@ -100,7 +100,7 @@ class _DGGSoftAdjFn(torch.autograd.Function):
         xp = ops.linear_fwd(x, We, be, ops.ACT_LEAKY)
         if cfg["cand"] is None:
             idx, val = ops.allpairs_topk(xp, cfg["K"], cfg["t"], cfg["noise_mode"], cfg["G"], cfg["seed"], algo=cfg["algo"],
-                                         k_limit=k)
+                                         k_limit=k, status=cfg)
         else:
             rowptr, col = cfg["cand"]
             idx, val = ops.edgelist_topk(xp, rowptr, col, cfg["K"], cfg["t"], cfg["noise_mode"], cfg["G"], cfg["seed"])
@@ -266,7 +266,15 @@ class DGG_LearnableK_debug(nn.Module):
         k_i + 8.5 <= ell_width, or the row has no more candidates than the width.  The learned k is
         unbounded (k = relu(kp sd + mu) + 1, dgm.py:1580-1584), so every forward ORs the violation into a device flag (no
         sync on the hot path); this method reads it (one sync) and raises.  Called by `EllAdjacency.to_dense()/to_sparse()`,
-        by the training harness once per epoch, and on every forward when DGG_STRICT_BOUND=1."""
+        by the training harness once per epoch, and on every forward when DGG_STRICT_BOUND=1.
+        The same call reports the ranked symmetric noise generator running out of workspace for its dense tier (rows that could
+        not be settled come back empty; dgg_topk_rsym.hip)."""
+        err = self.__dict__.get("_rsym_err")
+        if err is not None:
+            self._rsym_err = None
+            if bool(err.any()):
+                raise RuntimeError("DGG_LearnableK_debug: the ranked symmetric noise generator could not settle every row inside its "
+                                   "workspace (too many rows far from everything else); set args.dgg_sym_generator = 'hash'")
         if self._overflow is not None and bool(self._overflow):
             self._overflow = None
             raise RuntimeError(
@@ -343,9 +351,12 @@ class DGG_LearnableK_debug(nn.Module):
             s = torch.randint(0, 2 ** 31 - 1, (2,))
             seed = (int(s[0]), int(s[1]))
         # asymmetric noise: the ranked generator (rows produced in decreasing order -> early-stopping top-k search);
-        # symmetric noise (dgm.py:1216-1223) must be keyed on the unordered pair -> per-pair hash
+        # symmetric noise (dgm.py:1216-1223) is keyed on the unordered pair: the ranked symmetric generator (every pair owned by
+        # one endpoint, which lists its largest noises first; args.dgg_sym_generator = "hash" selects the per-pair hash + N^2 sweep)
         if self.args.symmetric_noise:
-            return ops.NOISE_HASH_SYM, None, seed
+            ranked = (self.ell_width == 64 and self.latent_dim in ops.RSYM_WIDTHS and
+                      getattr(self.args, "dgg_sym_generator", "ranked") == "ranked")
+            return (ops.NOISE_RANKED_SYM if ranked else ops.NOISE_HASH_SYM), None, seed
         # the ranked generator's row search is written for the full 64-wide list
         return (ops.NOISE_RANKED if self.ell_width == 64 else ops.NOISE_HASH), None, seed
 
@@ -463,6 +474,8 @@ class DGG_LearnableK_debug(nn.Module):
                 erow, avals = in_adj.indices()[0].to(torch.int32), in_adj.values().to(torch.float32)
         noise_mode, G, seed = self._noise_cfg()
         literal = bool(self.hard and getattr(self.args, "dgg_hard_literal", False))
+        if noise_mode == ops.NOISE_RANKED_SYM and (cand is not None or literal):
+            noise_mode = ops.NOISE_HASH_SYM
         if noise_mode == ops.NOISE_RANKED and (cand is not None or literal):
             noise_mode = ops.NOISE_HASH              # edge-list candidates: every candidate is scored, per-pair hash noise
                                                      # (literal dgg_hard: the full ranking of a row needs per-pair noise as well)
@@ -513,6 +526,9 @@ class DGG_LearnableK_debug(nn.Module):
                                                      mlp["b1"], mlp["w2"], mlp["b2"], cfg)
         k = k.detach()
         self._track_overflow(k, None if cand is None else (rowptr[1:] - rowptr[:-1]))
+        if cfg.get("rsym_err") is not None:
+            prev = self.__dict__.get("_rsym_err")
+            self._rsym_err = cfg["rsym_err"] if prev is None else (prev | cfg["rsym_err"])
         if writer is not None:   # the two scalars the reference logs from inside the DGG (dgm.py:1259-1261)
             f = w.detach() if (cfg["mode"] == ops.MODE_K_ONLY or "fwd_mode" in cfg) else (w.detach() / val.clamp(min=1e-30))
             writer.add_scalar("values/first_k_std", f.sum(-1).std(), epoch)

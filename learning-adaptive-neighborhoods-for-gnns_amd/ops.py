@@ -10,7 +10,8 @@ import torch
 
 from . import _lib
 
-NOISE_NONE, NOISE_EXPLICIT, NOISE_HASH, NOISE_HASH_SYM, NOISE_RANKED = 0, 1, 2, 3, 4
+NOISE_NONE, NOISE_EXPLICIT, NOISE_HASH, NOISE_HASH_SYM, NOISE_RANKED, NOISE_RANKED_SYM = 0, 1, 2, 3, 4, 5
+RSYM_WIDTHS = (8, 16, 32, 64, 128)     # latent widths of the ranked symmetric generator's kernels
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 MODE_K_TIMES_EDGE_PROB, MODE_K_ONLY = 0, 1
 MODE_HARD_ST = 3          # softk_fwd only: value (ramp - score*ramp) + score*ramp, gradient of MODE_K_TIMES_EDGE_PROB
@@ -235,8 +236,10 @@ def degree_stats(deg):
 
 
 def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed=(0, 0), rows=None, algo=0,
-                  return_ws=False, k_limit=None):
-    """k_limit: learned k of the rows (optional): ranks that the soft top-k ramp zeroes exactly come back as idx = -1."""
+                  return_ws=False, k_limit=None, status=None):
+    """k_limit: learned k of the rows (optional): ranks that the soft top-k ramp zeroes exactly come back as idx = -1.
+    status (dict, optional): receives "rsym_err", a 1-element int32 DEVICE tensor that is non-zero when the ranked symmetric
+    generator (noise_mode 5) could not settle every row inside its workspace (no synchronisation here; the caller checks it)."""
     xp = _chk(xp)
     N, h = xp.shape
     r0, r1 = (0, N) if rows is None else rows
@@ -257,9 +260,21 @@ def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed
                                             _ptr(idx), _ptr(val), _ptr(None if k_limit is None else _chk(k_limit)), algo, _ptr(ws),
                                             ws_bytes, _stream()), "allpairs_topk")
     _probe_end("allpairs_topk", pe)
+    if status is not None and noise_mode == NOISE_RANKED_SYM:
+        off = int(_lib.lib().dgg_allpairs_rsym_ctl_offset_bytes(r1 - r0, N))
+        status["rsym_err"] = ws[off + 16:off + 20].view(torch.int32).clone()
     if return_ws:      # diagnostics: the guess-and-verify control block is ws[:16] = (msum f32, nfail i32, gmin0 f32)
         return idx, val, ws
     return idx, val
+
+
+def rsym_status(ws, N, rows=None):
+    """diagnostics of the ranked symmetric path (noise_mode 5; synchronises): rows redone by tier 2 / tier 3, the error flag, the
+    guessed threshold, and (under DGG_RSYM_STATS=1) emitted pairs and scored candidates of tier 1"""
+    off = int(_lib.lib().dgg_allpairs_rsym_ctl_offset_bytes(N if rows is None else rows, N))
+    blk = ws[off:off + 64].cpu()
+    i32, f32, i64 = blk.view(torch.int32), blk.view(torch.float32), blk.view(torch.int64)
+    return dict(tier2_rows=int(i32[1]), gmin0=float(f32[2]), tier3_rows=int(i32[3]), err=int(i32[4]), emitted=int(i64[4]), delivered=int(i64[5]), tier2_delivered=int(i64[6]))
 
 
 def fast_path_failed_rows(ws, N, h, rows=None, stats=False):

@@ -387,11 +387,61 @@ static void topk_insert(cand_t *list, int *cnt, int K, float v, int32_t j) {
     if (n < K) *cnt = n + 1;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* "ranked symmetric" counter-based noise (noise_mode 5): G_ij = G_ji iid Gumbel(0,0.3) per     */
+/* UNORDERED pair, zero diagonal (the reference's symmetric_noise=True, dgm.py:1216-1223),      */
+/* generated so that every node can list its largest noises first:                              */
+/*   - the pair {i,j} is OWNED by one endpoint: with delta = (j - i) mod N and hmax = (N-1)/2,  */
+/*     i owns it when delta <= hmax, j owns it when delta >= N - hmax, and for even N the       */
+/*     antipodal pair (delta = N/2) belongs to the smaller index.  Node o owns the offsets      */
+/*     1..n_o, n_o = hmax (+1 for even N and o < N/2): partner (o + delta) mod N;               */
+/*   - the n_o noises of an owner are the ranked generator above on n_o "columns" (Renyi order  */
+/*     statistics in 2^-40 fixed point, rank s placed at offset sigma_o(.) + 1), keyed by o.    */
+/* Owners are independent and each unordered pair has exactly one, so the matrix is iid on its  */
+/* upper triangle and symmetric.                                                                */
+/* ------------------------------------------------------------------------------------------ */
+static inline int64_t rsym_owned(int64_t N, int64_t o) {
+    return (N - 1) / 2 + ((((N & 1) == 0) && o < N / 2) ? 1 : 0);
+}
+/* rows [row0,row1) of the noise matrix, G[(i-row0)*N + j].  Every owner's whole sequence is walked (the rank of a pair
+ * inside its owner's sequence has no closed form): O(N^2 / 2) whatever the number of rows. */
+ORA_API void ora_ranked_sym_block(uint32_t s0, uint32_t s1, int64_t N, int64_t row0, int64_t row1, float *G) {
+    for (int64_t i = row0; i < row1; i++) G[(i - row0) * N + i] = 0.0f;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t o = 0; o < N; o++) {
+        const int64_t n = rsym_owned(N, o);
+        if (n <= 0) continue;
+        uint32_t k1, k2;
+        ora_rowkey(s0, s1, (uint32_t)o, &k1, &k2);
+        const uint32_t k3 = mix32(k2 ^ 0x68E31DA4u);
+        const int b = ranked_bits(n);
+        const int own = o >= row0 && o < row1;
+        uint64_t S = 0;
+        uint32_t s = 0;
+        for (uint64_t r = 0; r < ((uint64_t)1 << b); r++) {
+            uint32_t c = ranked_sigma((uint32_t)r, k1, k2, k3, b);
+            if ((int64_t)c >= n) continue;
+            s++;
+            S += ranked_term(k1, k3, s, n);
+            int64_t p = o + (int64_t)c + 1;
+            if (p >= N) p -= N;
+            const float g = ranked_gumbel(S);
+            if (own) G[(o - row0) * N + p] = g;
+            if (p >= row0 && p < row1) G[(p - row0) * N + o] = g;
+        }
+    }
+}
+
 /* noise_mode: 0 none (perturb_edge_prob False), 1 explicit G (row-major [N][N], row i at G + i*N), 4 ranked counter-based,
- *             2 counter-based (s0,s1), 3 counter-based symmetric */
+ *             2 counter-based (s0,s1), 3 counter-based symmetric, 5 ranked symmetric */
 ORA_API void ora_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t,
                                int noise_mode, const float *G, uint32_t s0, uint32_t s1,
                                int K, int32_t *idx, float *val) {
+    float *gsym = NULL;
+    if (noise_mode == 5 && row1 > row0) {
+        gsym = (float *)malloc(sizeof(float) * (size_t)(row1 - row0) * (size_t)N);
+        ora_ranked_sym_block(s0, s1, N, row0, row1, gsym);
+    }
 #pragma omp parallel for schedule(dynamic, 8)
     for (int64_t i = row0; i < row1; i++) {
         cand_t list[512];
@@ -402,6 +452,7 @@ ORA_API void ora_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, 
             float g = 0.0f;
             if (noise_mode == 1) g = G[i * N + j];
             else if (noise_mode == 4) g = grow[j];
+            else if (noise_mode == 5) g = gsym[(i - row0) * N + j];
             else if (noise_mode >= 2) g = ora_noise(s0, s1, (uint32_t)i, (uint32_t)j, noise_mode == 3);
             float v = ora_pair_score(xp + i * h, xp + j * h, h, t, noise_mode != 0, g);
             topk_insert(list, &cnt, K, v, (int32_t)j);
@@ -412,6 +463,7 @@ ORA_API void ora_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, 
             val[(i - row0) * K + r] = r < cnt ? list[r].v : 0.0f;
         }
     }
+    free(gsym);
 }
 
 /* candidates restricted to a CSR graph (the live class's in_adj semantics, dgm.py:1613-1627).

@@ -60,7 +60,7 @@ def i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
-NOISE_NONE, NOISE_EXPLICIT, NOISE_HASH, NOISE_HASH_SYM, NOISE_RANKED = 0, 1, 2, 3, 4
+NOISE_NONE, NOISE_EXPLICIT, NOISE_HASH, NOISE_HASH_SYM, NOISE_RANKED, NOISE_RANKED_SYM = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 
 

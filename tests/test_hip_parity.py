@@ -101,6 +101,93 @@ def test_allpairs_topk_ranked_noise_bit_exact(dev, N, h):
         assert np.array_equal(Nn(sub_i), ridx[N // 3:N // 3 + 50]) and np.array_equal(Nn(sub_v), rval[N // 3:N // 3 + 50])
 
 
+def _rsym_env(**kw):
+    """context: DGG_RSYM_* knobs of the ranked symmetric path (read per call by the library)"""
+    import contextlib, os
+
+    @contextlib.contextmanager
+    def cm():
+        old = {k_: os.environ.get(k_) for k_ in kw}
+        os.environ.update({k_: str(v) for k_, v in kw.items()})
+        try:
+            yield
+        finally:
+            for k_, v in old.items():
+                if v is None:
+                    os.environ.pop(k_, None)
+                else:
+                    os.environ[k_] = v
+    return cm()
+
+
+@pytest.mark.parametrize("N,h", [(1, 16), (2, 8), (3, 16), (64, 16), (65, 32), (700, 64), (1024, 64), (1025, 64), (2500, 32),
+                                 (4099, 128), (9000, 64)])
+def test_allpairs_topk_ranked_symmetric_noise_bit_exact(dev, N, h):
+    """ranked SYMMETRIC noise generator (noise_mode 5; the reference's symmetric_noise=True, dgm.py:1216-1223): owners emit their
+    largest noises, rows settle own list + inbox and verify (dgg_topk_rsym.hip) against the oracle, which writes out the whole
+    symmetric noise matrix (ora_ranked_sym_block) and scores every column.  Sizes up to 1024 take the dense tier directly, the
+    larger ones the guess-and-verify tiers.  Row shards (keyed on global ids; owners outside the shard still emit into it) and
+    the learned-degree limit included."""
+    from dgg_amd import ops
+    rng = np.random.default_rng(13)
+    xp = rng.standard_normal((N, h)).astype(np.float32)
+    xp[xp < 0] *= 0.01
+    idx, val, ws = ops.allpairs_topk(T(xp, dev), K, noise_mode=ops.NOISE_RANKED_SYM, seed=(31, 7), return_ws=True)
+    ridx, rval = O.allpairs_topk(xp, K=K, noise_mode=O.NOISE_RANKED_SYM, seed=(31, 7))
+    st = ops.rsym_status(ws, N)
+    assert st["err"] == 0, st
+    assert np.array_equal(Nn(idx), ridx), f"top-k indices differ from the oracle ({st})"
+    assert np.array_equal(Nn(val), rval), "scores differ from the oracle"
+    if N > 1024 and h <= 64:        # (h = 128 here: distances so large that the own lists fill and most rows take tier 2)
+        assert st["tier2_rows"] <= N // 8 and st["tier3_rows"] <= 2, f"the guessed threshold fails too many rows: {st}"
+    if N > 100:
+        lo, hi = N // 3, N // 3 + 77
+        sub_i, sub_v = ops.allpairs_topk(T(xp, dev), K, noise_mode=ops.NOISE_RANKED_SYM, seed=(31, 7), rows=(lo, hi))
+        assert np.array_equal(Nn(sub_i), ridx[lo:hi]) and np.array_equal(Nn(sub_v), rval[lo:hi]), "row shard differs"
+        kl = (3.0 + 40.0 * rng.random(N)).astype(np.float32)
+        ki, kv = ops.allpairs_topk(T(xp, dev), K, noise_mode=ops.NOISE_RANKED_SYM, seed=(31, 7), k_limit=T(kl, dev))
+        keep = np.arange(K)[None, :] < np.minimum(np.ceil(kl + 8.5) + 1, K)[:, None]
+        assert np.array_equal(Nn(ki), np.where(keep, ridx, -1)) and np.array_equal(Nn(kv), np.where(keep, rval, 0.0).astype(np.float32))
+
+
+@pytest.mark.parametrize("knobs,expect", [(dict(DGG_RSYM_TARGET=66), "tier2"), (dict(DGG_RSYM_TARGET=84, DGG_RSYM_DEPTH2=1), "tier3"),
+                                          (dict(DGG_RSYM_SMALL=0), "tiers_on_a_small_graph"), (dict(DGG_RSYM_TARGET=4, DGG_RSYM_DEPTH2=1), "err")])
+def test_ranked_symmetric_noise_fallback_tiers(dev, knobs, expect):
+    """The tiers behind the guessed threshold, forced by the tuning knobs: a threshold that is too high sends many rows to tier 2
+    (owners walk further, deliver only to the failing rows, each above its own threshold), a tier 2 that may not walk further sends
+    them on to tier 3 (dense noise rows), and a graph small enough for the direct dense path run through the tiers.  Every variant must return the oracle's bits; when
+    more rows reach tier 3 than the workspace holds, the error flag is set and the module raises instead of returning the result."""
+    from dgg_amd import ops
+    N, h = (900, 32) if expect == "tiers_on_a_small_graph" else (3000, 64)
+    rng = np.random.default_rng(17)
+    xp = rng.standard_normal((N, h)).astype(np.float32)
+    xp[xp < 0] *= 0.01
+    with _rsym_env(**knobs):
+        idx, val, ws = ops.allpairs_topk(T(xp, dev), K, noise_mode=ops.NOISE_RANKED_SYM, seed=(5, 9), return_ws=True)
+        st = ops.rsym_status(ws, N)
+    if expect == "err":
+        assert st["err"] == 1, st
+        import dgg_amd
+        from argparse import Namespace
+        args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+                         dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                         symmetric_noise=True, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
+        m = dgg_amd.DGG_LearnableK_debug(in_dim=24, latent_dim=h, args=args).to(dev)
+        with _rsym_env(**knobs):
+            m(torch.randn(N, 24, device=dev), dgg_amd.AllPairs(torch.full((N,), 30.0, device=dev)))
+        with pytest.raises(RuntimeError, match="ranked symmetric noise generator"):
+            m.check_ell_bound()
+        return
+    ridx, rval = O.allpairs_topk(xp, K=K, noise_mode=O.NOISE_RANKED_SYM, seed=(5, 9))
+    assert st["err"] == 0, st
+    if expect == "tier2":
+        assert st["tier2_rows"] >= 100 and st["tier3_rows"] <= st["tier2_rows"] // 4, st
+    if expect == "tier3":
+        assert st["tier3_rows"] >= 1, st
+    assert np.array_equal(Nn(idx), ridx), f"top-k indices differ from the oracle ({st})"
+    assert np.array_equal(Nn(val), rval), "scores differ from the oracle"
+
+
 @pytest.mark.parametrize("noise,algo", [("ranked", 0), ("hash", 1), ("hash", 4), ("none", 1)])
 def test_allpairs_topk_k_limit(dev, noise, algo):
     """k_limit: the kept ranks equal the unrestricted result; the cut ranks are exactly those the oracle's soft

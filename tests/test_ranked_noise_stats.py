@@ -132,3 +132,81 @@ def test_ranked_and_hash_generators_select_statistically_equal_graphs(dev):
         tol = {"max in-degree": 25.0}.get(nme, max(6 * spread, 2e-3 * abs(a.mean())))
         print(f"{nme:20s} hash {a.mean():.5f} ranked {b.mean():.5f} (seed spread {spread:.2e})")
         assert abs(a.mean() - b.mean()) <= tol, (nme, a, b)
+
+
+def _mutual_fraction(idx, N, dev):
+    """fraction of the selected edges i -> j whose reverse j -> i is selected as well"""
+    j = idx.long()
+    i = torch.arange(N, device=dev)[:, None].expand_as(j)
+    back = (idx[j.reshape(-1)].long() == i.reshape(-1, 1)).any(1)
+    return back.double().mean().item()
+
+
+def test_ranked_symmetric_generator_selected_graph(dev):
+    """The RANKED SYMMETRIC generator (noise_mode 5; the reference's symmetric_noise=True, dgm.py:1216-1223) on the selected graph
+    at N = 100 000, features constant (the noise alone decides):
+      * the noise a row sees is iid Gumbel(0, 0.3): row maximum ~ Gumbel(0.3 ln(N-1), 0.3), N exp(-G_(64)/0.3) ~ Gamma(64);
+      * symmetry on the device: the score of (i, j) IS the score of (j, i) bit for bit, so whenever i -> j is selected with a
+        score above j's 64th, j -> i must be selected too, with the same bits;
+      * the in-degree / mutual-edge statistics equal those under the per-pair hash generator of the same law (noise_mode 3),
+        which is iid per unordered pair by construction."""
+    from dgg_amd import ops
+    N = 100_000
+    xp = torch.zeros((N, 64), device=dev)
+    res = {}
+    for name, nm in [("ranked_sym", ops.NOISE_RANKED_SYM), ("hash_sym", ops.NOISE_HASH_SYM)]:
+        idx, val, ws = ops.allpairs_topk(xp, K, noise_mode=nm, seed=(4321, 1), return_ws=True)
+        assert int((idx < 0).sum()) == 0
+        if nm == ops.NOISE_RANKED_SYM:
+            st = ops.rsym_status(ws, N)
+            assert st["err"] == 0 and st["tier3_rows"] == 0, st
+            # symmetry of the selection
+            j = idx.long()
+            i = torch.arange(N, device=dev)[:, None].expand_as(j)
+            must = val > val[j.reshape(-1), 63].reshape(N, K)               # strictly above the partner's 64th score
+            rev = (idx[j[must]].long() == i[must].unsqueeze(1))
+            assert bool(rev.any(1).all()), "an edge above its partner's 64th score is missing from the partner's list"
+            back_val = (val[j[must]] * rev).sum(1)
+            assert torch.equal(back_val, val[must]), "the two directions of an edge carry different scores"
+            G = torch.log(val.double()).cpu().numpy() - np.log1p(1e-8)
+            assert (np.diff(G, axis=1) <= 1e-12).all()
+            ks_max = stats.kstest(G[::7, 0], "gumbel_r", args=(0.3 * np.log(N - 1), 0.3))        # (a subsample: rows sharing their top pair have equal maxima)
+            ks_64 = stats.kstest((N - 1) * np.exp(-G[::7, 63] / 0.3), "gamma", args=(64,))
+            print(f"KS max: D = {ks_max.statistic:.4f} p = {ks_max.pvalue:.3g}; KS 64th: D = {ks_64.statistic:.4f} p = {ks_64.pvalue:.3g}")
+            assert ks_max.pvalue > 1e-4 and ks_64.pvalue > 1e-4
+        indeg = torch.bincount(idx.reshape(-1).long(), minlength=N).double()
+        res[name] = (indeg.var().item(), indeg.max().item(), _mutual_fraction(idx, N, dev),
+                     (idx == torch.arange(N, device=dev, dtype=torch.int32)[:, None]).any(1).double().mean().item())
+    a, b = res["ranked_sym"], res["hash_sym"]
+    print("ranked_sym (var in-degree, max in-degree, mutual fraction, self-loop fraction):", a, "hash_sym:", b)
+    assert abs(a[0] - b[0]) < 0.05 * b[0] and abs(a[1] - b[1]) <= 12 and abs(a[2] - b[2]) < 0.01 and a[3] == b[3] == 0.0
+
+
+def test_ranked_symmetric_and_hash_symmetric_generators_select_statistically_equal_graphs(dev):
+    """N = 20 000 random features: selected-neighbour distance, score, in-degree and mutual-edge statistics under the two symmetric
+    generators agree within sampling error"""
+    from dgg_amd import ops
+    N, h = 20_000, 64
+    g = torch.Generator(device="cpu").manual_seed(11)
+    xp = (torch.randn(N, h, generator=g) * 0.6).to(dev)
+    res = {}
+    for name, nm in [("hash", ops.NOISE_HASH_SYM), ("ranked", ops.NOISE_RANKED_SYM)]:
+        per_seed = []
+        for seed in range(3):
+            idx, val = ops.allpairs_topk(xp, K, noise_mode=nm, seed=(77 + seed, seed))
+            j = idx.long()
+            dist = (xp.unsqueeze(1) - xp[j]).norm(dim=2)
+            indeg = torch.bincount(j.reshape(-1), minlength=N).double()
+            self_frac = (j == torch.arange(N, device=dev)[:, None]).any(1).double().mean()
+            per_seed.append(np.array([dist.double().mean().item(), dist.double().var().item(), torch.log(val.double()).mean().item(),
+                                      torch.log(val.double()).var().item(), indeg.var().item(), indeg.max().item(), self_frac.item(),
+                                      dist[:, 0].double().mean().item(), dist[:, 63].double().mean().item(), _mutual_fraction(idx, N, dev)]))
+        res[name] = np.array(per_seed)
+    names = ["mean dist", "var dist", "mean log-score", "var log-score", "var in-degree", "max in-degree", "self-loop fraction",
+             "mean dist rank 0", "mean dist rank 63", "mutual fraction"]
+    for q, nme in enumerate(names):
+        a, b = res["hash"][:, q], res["ranked"][:, q]
+        spread = max(a.std(), b.std(), 1e-12)
+        tol = {"max in-degree": 25.0}.get(nme, max(6 * spread, 2e-3 * abs(a.mean())))
+        print(f"{nme:20s} hash-sym {a.mean():.5f} ranked-sym {b.mean():.5f} (seed spread {spread:.2e})")
+        assert abs(a.mean() - b.mean()) <= tol, (nme, a, b)
