@@ -626,6 +626,78 @@ def test_full_size_unperturbed_sweep(dev, clustered):
         assert torch.equal(sub_i, idx[lo:hi]) and torch.equal(sub_v, val[lo:hi])
 
 
+@pytest.mark.parametrize("clustered", [False, True])
+def test_full_size_ranked_symmetric_noise(dev, clustered):
+    """N = 100k under the ranked SYMMETRIC generator (the reference's symmetric_noise=True) with the learned-degree limit, as the
+    bench's `symmetric` variant runs it: list invariants, the symmetry of the selection (a selected edge whose score beats the
+    partner's last kept score is selected there too, same bits), the oracle on two blocks of rows (the oracle walks EVERY owner's
+    whole sequence for them), row-range consistency, and the tier counters.  Clustered data (a tight blob of 3000 nodes + 40
+    far outliers whose scores are 10x smaller): the outliers cannot be settled at the guessed threshold and take the deeper
+    tiers; results must stay exact."""
+    from dgg_amd import ops
+    N, d, h = 100_000, 128, 64
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(N, d, generator=g)
+    if clustered:
+        x[20_000:23_000] *= 0.05
+        x[23_000:23_040] = x[23_000:23_040] * 0.01 + 3.0
+    x = x.to(dev)
+    W = (torch.randn(h, d, generator=g) * 0.1).to(dev)
+    b = (torch.randn(h, generator=g) * 0.1).to(dev)
+    xp = ops.linear_fwd(x, W, b, ops.ACT_LEAKY)
+    k = (24 + 16 * torch.rand(N, generator=g)).to(dev)
+    seed = (2024, 3)
+    idx, val, ws = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_RANKED_SYM, seed=seed, k_limit=k, return_ws=True)
+    st = ops.rsym_status(ws, N)
+    print(f"clustered={clustered}: {st}")
+    assert st["err"] == 0, st
+    if not clustered:
+        assert st["tier2_rows"] <= N // 12 and st["tier3_rows"] == 0, f"the guessed threshold fails too many rows: {st}"
+    L = torch.minimum(torch.ceil(k + 8.5) + 1, torch.tensor(float(K), device=dev)).long()
+    live = torch.arange(K, device=dev)[None, :] < L[:, None]
+    assert bool(((idx >= 0) == live).all()) and bool((idx < N).all())
+    assert bool((val[:, :-1] >= val[:, 1:]).all())
+    srt = torch.where(live, idx, torch.arange(K, device=dev, dtype=idx.dtype)[None, :] + N).sort(dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all()), "duplicate column in a row"
+    # symmetry: score(i, j) == score(j, i) bit for bit; an edge above the partner's last kept score must be in the partner's list
+    j = idx.long().clamp(min=0)
+    i = torch.arange(N, device=dev)[:, None].expand_as(j)
+    last = val.gather(1, (L - 1)[:, None]).squeeze(1)
+    must = live & (val > last[j])
+    rev = idx[j[must]].long() == i[must].unsqueeze(1)
+    assert bool(rev.any(1).all()), "an edge above its partner's last kept score is missing from the partner's list"
+    assert torch.equal((val[j[must]] * rev).sum(1), val[must]), "the two directions of an edge carry different scores"
+    xp_c, k_c = xp.cpu().numpy(), k.cpu().numpy()
+    for lo, hi in [(23_036, 23_044), (99_994, N)] if clustered else [(0, 6), (50_001, 50_007)]:
+        ri, rv = O.allpairs_topk(xp_c, K=K, noise_mode=O.NOISE_RANKED_SYM, seed=seed, rows=(lo, hi))
+        keep = np.arange(K)[None, :] < np.minimum(np.ceil(k_c[lo:hi] + 8.5) + 1, K)[:, None]
+        assert np.array_equal(Nn(idx[lo:hi]), np.where(keep, ri, -1)), (lo, hi)
+        assert np.array_equal(Nn(val[lo:hi]), np.where(keep, rv, 0.0).astype(np.float32)), (lo, hi)
+    for lo, hi in [(0, 300), (22_900, 23_412), (99_700, N)]:
+        sub_i, sub_v = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_RANKED_SYM, seed=seed, rows=(lo, hi), k_limit=k[lo:hi].contiguous())
+        assert torch.equal(sub_i, idx[lo:hi]) and torch.equal(sub_v, val[lo:hi])
+
+
+@pytest.mark.parametrize("N,h", [(1100, 64), (1537, 32)])
+def test_ranked_symmetric_search_equals_explicit_noise_path_on_its_own_noise(dev, N, h):
+    """The same loop closure as for the asymmetric ranked generator, on the device: the ranked symmetric generator's noise matrix
+    (ora_ranked_sym_block) handed to the HIP EXPLICIT-noise path -- the one the reference goldens pin for symmetric noise as well
+    (allpairs_n256_sym) -- must give the lists and scores of the owner-emits / row-verifies search, bit for bit."""
+    import ctypes as C
+    from dgg_amd import ops
+    rng = np.random.default_rng(N)
+    xp = rng.standard_normal((N, h)).astype(np.float32)
+    xp[xp < 0] *= 0.01
+    seed = (4321, 17)
+    G = np.empty((N, N), np.float32)
+    O.lib().ora_ranked_sym_block(C.c_uint32(seed[0]), C.c_uint32(seed[1]), C.c_int64(N), C.c_int64(0), C.c_int64(N), O._p(G))
+    assert np.array_equal(G, G.T)
+    ei, ev = ops.allpairs_topk(T(xp, dev), K, noise_mode=ops.NOISE_EXPLICIT, G=T(G, dev))
+    ri, rv = ops.allpairs_topk(T(xp, dev), K, noise_mode=ops.NOISE_RANKED_SYM, seed=seed)
+    assert torch.equal(ei, ri), "ranked symmetric search and explicit-noise path disagree on the neighbour lists"
+    assert torch.equal(ev, rv), "ranked symmetric search and explicit-noise path disagree on the scores"
+
+
 @pytest.mark.parametrize("N,h", [(1000, 64), (1537, 32)])
 def test_ranked_search_equals_explicit_noise_path_on_its_own_noise(dev, N, h):
     """Closes the loop for the benchmarked kernel ON THE DEVICE: the ranked generator's noise matrix G is materialised on the host
