@@ -305,8 +305,10 @@ def bench_module_api(a, dev):
 
 def bench_ppi(a, dev):
     """BASELINE.json configs[4] (PPI shape: graphs of 591..3480 nodes, d=50, hidden 2048, 9 GCNII layers, 121 labels,
-    train_ppi.py:43-44): dgg_amd.GCNIIppi_DGG under autograd, one forward + backward per graph, fp32 (the bf16 variant
-    of the GCNII GEMMs is a "next" row).  The DGG runs at latent_dim = hidden = 2048 (model.py:907-910)."""
+    train_ppi.py:43-44): dgg_amd.GCNIIppi_DGG under autograd, one forward + backward per graph; fp32, or with --bf16 the GCNII
+    layer products on the hand-written bf16 MFMA kernel (dgg_bf16.hip).  The DGG runs at latent_dim = hidden = 2048
+    (model.py:907-910).  cpu_baseline: the reference-shaped DENSE formulation of the same model in torch CPU ops on the smallest
+    graph of the batch (cpu_baseline_ppi)."""
     import dgg_amd
     from argparse import Namespace
     d, hid, C, L = 50, 2048, 121, 9
@@ -378,7 +380,46 @@ def bench_ppi(a, dev):
                      "frac": gemm_flop / t_g / 1e12 / (2500.0 if a.bf16 else FP32_PEAK_TFLOPS), "traffic": None,
                      "kernel_ms_per_step": t_g * 1e3, "per_kernel": per_kernel, "whole_step_gemm_tflops": gemm_flop / T / 1e12,
                      "note": "GEMM flops of the GCNII layers / summed event-timed duration of the GEMM calls inside running steps"},
-        "kernels_ms_per_step": {n_: v[0] for n_, v in pk.items()}}))
+        "kernels_ms_per_step": {n_: v[0] for n_, v in pk.items()},
+        "cpu_baseline": (cpu_baseline_ppi(m, min(graphs, key=lambda g_: g_[0].shape[0]), min(os.cpu_count() or 1, 32))
+                         if a.cpu_rows >= 0 else None)}))
+
+
+def cpu_baseline_ppi(m, graph, threads, lamda=0.5, alpha=0.5):
+    """BASELINE.md section 3 for configs[4]: the reference-shaped dense formulation (oracle/dense_ref.py: [N,N] adjacency, torch.mm
+    per layer, autograd) of GCNIIppi_DGG on ONE graph of the batch, forward + backward, torch CPU ops on `threads` threads, eval-mode
+    dropout and no perturbation (the same arithmetic volume).  Bounded sample: the smallest graph."""
+    import math
+    from oracle import dense_ref as D
+    torch.set_num_threads(threads)
+    x, A, y = (t_.cpu() for t_ in graph)
+    n = x.shape[0]
+    A = A.coalesce()
+    eye = torch.arange(n)
+    rows, cols = torch.cat([A.indices()[0], eye]), torch.cat([A.indices()[1], eye])
+    dg = m.dggs[0]
+    P = {"We": dg.node_encode_for_edges[0].weight, "be": dg.node_encode_for_edges[0].bias, "Wk": dg.node_encode_for_k[0].weight,
+         "bk": dg.node_encode_for_k[0].bias, "W1": dg.k_embed[0].weight, "b1": dg.k_embed[0].bias, "Wmu": dg.k_net.k_mu.weight,
+         "bmu": dg.k_net.k_mu.bias, "Wp": dg.k_net.k_project.weight, "bp": dg.k_net.k_project.bias}
+    P = {k_: v.detach().cpu().clone().requires_grad_(True) for k_, v in P.items()}
+    Ws = [c.weight.detach().cpu().clone().requires_grad_(True) for c in m.convs]
+    f0w, f0b, f1w, f1b = (t_.detach().cpu().clone().requires_grad_(True) for t_ in (m.fcs[0].weight, m.fcs[0].bias, m.fcs[1].weight, m.fcs[1].bias))
+    deg = torch.zeros(n).index_add_(0, rows, torch.ones(rows.shape[0]))
+    t0 = time.perf_counter()
+    h0 = torch.relu(x @ f0w.t() + f0b)
+    Adense, _ = D.dgg_dense(x, rows, cols, deg, P, None)
+    Ahat = D.normalize_dense(Adense)
+    hcur = h0
+    for l, W in enumerate(Ws):
+        theta = math.log(lamda / (l + 1) + 1)
+        hi = Ahat @ hcur
+        hcur = torch.relu(theta * (torch.cat([hi, h0], 1) @ W) + (1 - theta) * ((1 - alpha) * hi + alpha * h0) + hcur)
+    out = torch.sigmoid(hcur @ f1w.t() + f1b)
+    torch.nn.functional.binary_cross_entropy(out, y).backward()
+    dt = time.perf_counter() - t0
+    return dict(value=float(rows.shape[0]) / dt, unit="edges/s", cores=threads, kind="port",
+                sample=f"dense torch-CPU formulation of GCNIIppi_DGG on the smallest graph of the batch ({n} nodes, {rows.shape[0]} candidate "
+                       f"entries), forward + backward, {dt:.2f} s")
 
 
 def cpu_baseline_edgelist(N, d, h, rows, cols, x, vals, dgg, conv, threads):
