@@ -797,6 +797,7 @@ def bench_synthetic(a, dev, world, rank, force):
                 torch.cuda.synchronize()
                 pv, ops.PROBE = ops.PROBE, None
                 e0, e1 = pv["allpairs_topk"][0]
+                rv.layer.check_generator()
                 kv = float(rv.layer.saved["k"].mean().item())
                 pk = e0.elapsed_time(e1)
                 variants[name] = {"ms_per_step": tv * 1e3, "edges_per_s": N * kv / tv, "pair_kernel_ms": pk, "steps": vsteps}

@@ -104,6 +104,14 @@ class ShardedDGGConv:
         self.r0, self.r1, self.per = shard_bounds(N, self.world, self.rank)
         self.bufs = {}                                       # collective staging buffers, kept between steps
 
+    def check_generator(self):
+        """raises if the ranked symmetric noise generator (noise_mode 5) could not settle every row inside its workspace in any
+        forward since the last call (one synchronisation; the rows concerned came back empty)"""
+        err, self.rsym_err = getattr(self, "rsym_err", None), None
+        if err is not None and bool(err.any()):
+            raise RuntimeError("ShardedDGGConv: the ranked symmetric noise generator ran out of workspace for its dense tier; "
+                               "use noise_mode 3 (per-pair hash) for this data")
+
     def emulate_rank(self, world, rank):
         """TIMING DIAGNOSTIC (bench.py --emulate-world): do the work of `rank` of `world` in a single process -- own row range
         against all N columns, replicated features -- with the collectives left out and the other ranks' row sums faked by
@@ -163,8 +171,15 @@ class ShardedDGGConv:
             # ranked noise: the ramp is applied inside the search kernel, while the settled list is still in registers
             s["idx"], s["val"], s["w"], rs_local = kern.allpairs_topk_softk(xp, s["k"], self.mode, self.t, self.seed, rows=(self.r0, self.r1))
         else:
+            if self.noise_mode == 5 and not hasattr(kern, "rsym_status"):      # (a stand-in kernel namespace without the status plumbing)
+                st = None
+            else:
+                st = {} if self.noise_mode == 5 else None
+            kw = {} if st is None else {"status": st}
             s["idx"], s["val"] = kern.allpairs_topk(xp, self.K, self.t, self.noise_mode, None, self.seed,
-                                                    rows=(self.r0, self.r1), algo=self.algo, k_limit=s["k"])
+                                                    rows=(self.r0, self.r1), algo=self.algo, k_limit=s["k"], **kw)
+            if st and st.get("rsym_err") is not None:      # ranked symmetric generator out of workspace: device flag, read by check_generator()
+                self.rsym_err = st["rsym_err"] if getattr(self, "rsym_err", None) is None else (self.rsym_err | st["rsym_err"])
             s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
         s["rs"] = rs = _all_gather_rows(rs_local, self.N, self.per, self.group, self.bufs, "rs") if self.coll else rs_local
         if self.emulate is not None:

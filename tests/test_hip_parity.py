@@ -767,7 +767,7 @@ def test_model_wrappers_match_reference_golden(dev, name):
     assert checked >= 8
 
 
-@pytest.mark.parametrize("N,d,h,noise", [(700, 24, 16, "hash"), (2500, 128, 64, "ranked"), (1300, 40, 128, "ranked")])
+@pytest.mark.parametrize("N,d,h,noise", [(700, 24, 16, "hash"), (2500, 128, 64, "ranked"), (1300, 40, 128, "ranked"), (2100, 64, 64, "ranked_sym")])
 def test_sharded_layer_step_matches_cpu_restatement(dev, N, d, h, noise):
     """The step bench.py times (dgg_amd.parallel.ShardedDGGConv on the HIP kernels: k_limit, destination-ordered
     partition, fused backward) against the same step on the numpy/oracle stand-in of tests/test_parallel_gloo.py"""
@@ -776,7 +776,7 @@ def test_sharded_layer_step_matches_cpu_restatement(dev, N, d, h, noise):
     from test_parallel_gloo import CpuKern, make_inputs
     x, deg, P, cot = make_inputs(N, d, h)
     deg = 20 + 12 * torch.rand(N, generator=torch.Generator().manual_seed(1))
-    mode = {"hash": ops.NOISE_HASH, "ranked": ops.NOISE_RANKED}[noise]
+    mode = {"hash": ops.NOISE_HASH, "ranked": ops.NOISE_RANKED, "ranked_sym": ops.NOISE_RANKED_SYM}[noise]
     ref = ShardedDGGConv(CpuKern(), N, K=64, noise_mode=mode, seed=(5, 6), x_grad=True)
     Zr = ref.forward(x, deg, P)
     gr = ref.backward(cot, x, P)
@@ -784,6 +784,7 @@ def test_sharded_layer_step_matches_cpu_restatement(dev, N, d, h, noise):
     Pd = {k_: v.to(dev) for k_, v in P.items()}
     Z = lay.forward(x.to(dev), deg.to(dev), Pd)
     g = lay.backward(cot.to(dev), x.to(dev), Pd)
+    lay.check_generator()
     kept = Nn(lay.saved["idx"]) >= 0
     assert np.array_equal(Nn(lay.saved["idx"])[kept], ref.saved["idx"].numpy()[kept])
     np.testing.assert_allclose(Nn(Z), Zr.numpy(), rtol=1e-5, atol=1e-5 * float(Zr.abs().max()))

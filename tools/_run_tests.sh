@@ -1,3 +1,2 @@
-mkdir -p gpurun_out/tests
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > gpurun_out/tests/gpu_tests.txt
-cat gpurun_out/tests/gpu_tests.txt
+cd $GRAFT_REPO_ROOT
+timeout 3000 python -m pytest tests -q -m gpu -x 2>&1 | tail -15
