@@ -686,22 +686,51 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
 // The first FB_MAX failed rows are split over FB_NCH column chunks each (a handful of failed rows must not run as a handful of
 // workgroups: 3 rows took 0.69 ms that way): sw_fallback_part keeps a chunk's best 64, sw_fallback_merge merges a row's chunks.
 // Rows beyond FB_MAX (every guess wrong: adversarial input) are redone by sw_fallback_rows, one workgroup per row at a time.
-constexpr int FB_MAX = 4096, FB_NCH = 32;
+constexpr int FB_MAX = 4096, FB_NCH = 32, FB_CHUNK_CAP = 32;     // FB_MAX * FB_NCH partial lists in the workspace
+// chunks per failed row: few failed rows (the usual handful) are cut finer, so that the scan of a row is spread over more workgroups
+__device__ __forceinline__ int fb_chunks(int nf) { const int c = (FB_MAX * FB_NCH) / (nf > 0 ? nf : 1); return c > FB_CHUNK_CAP ? FB_CHUNK_CAP : (c < FB_NCH ? FB_NCH : c); }
+// merge a block of keys into a descending 64-entry list: keys that cannot enter (below the current 64th) are dropped first, a
+// handful of survivors is inserted one by one, otherwise sort + merge.  (The fallback's blocks after the first few hold 0-2 keys that
+// still enter: the full 64-lane sort + merge per block was most of its time.)
+__device__ __noinline__ uint64_t fb_merge(uint64_t list, uint64_t key, int lane) {      // (noinline: ONE copy of the unrolled sort + merge network -- a kernel that runs for microseconds pays ~0.1 us per 64 bytes of code it touches for the first time)
+    const uint64_t k63 = shfl_u64(list, 63);
+    if (key <= k63) key = DGG_EMPTY_KEY;                              // (k63 == DGG_EMPTY_KEY while the list is not full: nothing dropped)
+    uint64_t live = __ballot(key != DGG_EMPTY_KEY);
+    if (live == 0ull) return list;
+    if (__builtin_popcountll(live) <= 12 && k63 != DGG_EMPTY_KEY) {
+        while (live != 0ull) {                                          // wave-uniform
+            const int src = __builtin_ctzll(live);
+            live &= live - 1;
+            const uint64_t kk = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), src) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, src);
+            const int pos = __builtin_popcountll(__ballot(list > kk));
+            const uint64_t prev = ((uint64_t)(uint32_t)__shfl_up((int)(list >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)list, 1, 64);
+            list = lane < pos ? list : (lane == pos ? kk : prev);
+        }
+        return list;
+    }
+    return wave_merge_top64_asc(list, wave_sort<false>(key, lane), lane);
+}
 template <int H>
 __device__ __forceinline__ uint64_t fallback_scan(const float *__restrict__ xp, int64_t i, int64_t c0, int64_t c1, float t, uint64_t (&lists)[4][64],
                                                   int lane, int wave) {
     uint64_t list = DGG_EMPTY_KEY;
-    for (int64_t j0 = c0 + (int64_t)wave * 64; j0 < c1; j0 += 256) {
-        const int64_t j = j0 + lane;
-        uint64_t key = DGG_EMPTY_KEY;
-        if (j < c1) key = make_key(exact_score0<H>(xp, i, (int32_t)j, t), (int32_t)j);
-        key = wave_sort<false>(key, lane);
-        list = wave_merge_top64_asc(list, key, lane);
+    // four 64-column blocks per step: their gathers are independent and in flight together (a block per step paid one memory latency
+    // per block)
+    for (int64_t j0 = c0 + (int64_t)wave * 64; j0 < c1; j0 += 4 * 256) {
+        uint64_t key[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int64_t j = j0 + (int64_t)q * 256 + lane;
+            key[q] = j < c1 ? make_key(exact_score0<H>(xp, i, (int32_t)j, t), (int32_t)j) : DGG_EMPTY_KEY;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) list = fb_merge(list, key[q], lane);
     }
     lists[wave][lane] = list;
     __syncthreads();
     if (wave == 0)
-        for (int w = 1; w < 4; w++) list = wave_merge_top64_asc(list, wave_sort<false>(lists[w][lane], lane), lane);
+        for (int w = 1; w < 4; w++) list = fb_merge(list, lists[w][lane], lane);
     __syncthreads();
     return list;                                                       // valid in wavefront 0
 }
@@ -711,9 +740,10 @@ __global__ __launch_bounds__(256) void sw_fallback_part(const float *__restrict_
     __shared__ uint64_t lists[4][64];
     const int lane = threadIdx.x & 63, wave = dgg::wave_id();
     const int nf = ctl->nfail < FB_MAX ? ctl->nfail : FB_MAX;
-    const int64_t chunk = (N + FB_NCH - 1) / FB_NCH;
-    for (int item = blockIdx.x; item < nf * FB_NCH; item += gridDim.x) {
-        const int f = item / FB_NCH, c = item % FB_NCH;
+    const int nch = fb_chunks(nf);
+    const int64_t chunk = (N + nch - 1) / nch;
+    for (int item = blockIdx.x; item < nf * nch; item += gridDim.x) {
+        const int f = item / nch, c = item % nch;
         const int64_t c0 = c * chunk, c1 = (c0 + chunk < N) ? c0 + chunk : N;
         const uint64_t list = fallback_scan<H>(xp, row0 + faillist[f], c0, c1 > c0 ? c1 : c0, t, lists, lane, wave);
         if (wave == 0) partial[(int64_t)item * 64 + lane] = list;
@@ -721,15 +751,32 @@ __global__ __launch_bounds__(256) void sw_fallback_part(const float *__restrict_
 }
 __global__ __launch_bounds__(256) void sw_fallback_merge(const SweepCtl *__restrict__ ctl, const int *__restrict__ faillist,
                                                          const uint64_t *__restrict__ partial, int32_t *__restrict__ idx, float *__restrict__ val) {
-    const int lane = threadIdx.x & 63;
+    // one WORKGROUP per failed row: each wavefront merges a quarter of the row's partial lists (loaded eight at a time: independent
+    // loads, one round trip), wavefront 0 merges the four results
+    __shared__ uint64_t lists[4][64];
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id();
     const int nf = ctl->nfail < FB_MAX ? ctl->nfail : FB_MAX;
-    for (int f = blockIdx.x * 4 + dgg::wave_id(); f < nf; f += gridDim.x * 4) {
+    const int nch = fb_chunks(nf);
+    for (int f = blockIdx.x; f < nf; f += gridDim.x) {
         uint64_t list = DGG_EMPTY_KEY;
-        for (int c = 0; c < FB_NCH; c++) list = wave_merge_top64_asc(list, wave_sort<false>(partial[((int64_t)f * FB_NCH + c) * 64 + lane], lane), lane);
-        const int lrow = faillist[f];
-        const bool empty = list == DGG_EMPTY_KEY;
-        idx[(int64_t)lrow * 64 + lane] = empty ? -1 : key_col(list);
-        val[(int64_t)lrow * 64 + lane] = empty ? 0.0f : key_val(list);
+        const uint64_t *pf = partial + (int64_t)f * nch * 64 + lane;
+        for (int c0 = wave * 8; c0 < nch; c0 += 32) {
+            uint64_t key[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) key[q] = c0 + q < nch ? pf[(int64_t)(c0 + q) * 64] : DGG_EMPTY_KEY;
+#pragma unroll
+            for (int q = 0; q < 8; q++) list = fb_merge(list, key[q], lane);
+        }
+        lists[wave][lane] = list;
+        __syncthreads();
+        if (wave == 0) {
+            for (int w = 1; w < 4; w++) list = fb_merge(list, lists[w][lane], lane);
+            const int lrow = faillist[f];
+            const bool empty = list == DGG_EMPTY_KEY;
+            idx[(int64_t)lrow * 64 + lane] = empty ? -1 : key_col(list);
+            val[(int64_t)lrow * 64 + lane] = empty ? 0.0f : key_val(list);
+        }
+        __syncthreads();
     }
 }
 template <int H>
@@ -850,7 +897,7 @@ int launch_sweep(const float *xp, int64_t N, int64_t row0, int64_t row1, float t
     hipLaunchKernelGGL(sw_finalize<H>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xp, nb, row0, row1, t, kept, keptn, lb, cntb, p.csb, p.capb,
                        p.rblk, tt, ctl, faillist, idx, val);
     hipLaunchKernelGGL(sw_fallback_part<H>, dim3(1024), dim3(256), 0, st, xp, N, row0, t, ctl, faillist, part);
-    hipLaunchKernelGGL(sw_fallback_merge, dim3(256), dim3(256), 0, st, ctl, faillist, part, idx, val);
+    hipLaunchKernelGGL(sw_fallback_merge, dim3(1024), dim3(256), 0, st, ctl, faillist, part, idx, val);
     hipLaunchKernelGGL(sw_fallback_rows<H>, dim3(512), dim3(256), 0, st, xp, N, row0, t, ctl, faillist, idx, val);
     return dgg_check_launch("allpairs_topk_sweep");
 }
