@@ -94,20 +94,28 @@ __device__ __forceinline__ uint32_t hash_threshold_from_gmin(float gmin) {
     return (uint32_t)um << 8;
 }
 
-// K0: moment of the score distribution from random pairs
+// K0: moment of the score distribution from random pairs.  PILOT_PER_THREAD pairs per thread, one atomic per WORKGROUP (same-address
+// atomics serialise at ~15 ns each: one per wavefront of 1024 workgroups was 60 us of a kernel with 5 us of work)
+constexpr int PILOT_PER_THREAD = 4;
 template <int H>
 __global__ __launch_bounds__(256) void gv_pilot(const float *__restrict__ xp, int64_t N, float t, uint32_t s0, uint32_t s1,
                                                 GvCtl *ctl) {
-    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
-    uint32_t a = mix32(gid * 2u + 1u + s0), b = mix32(gid * 2u + 2u + s1 * 0x9E3779B9u);
-    int64_t i = (int64_t)(((uint64_t)a * (uint64_t)N) >> 32), j = (int64_t)(((uint64_t)b * (uint64_t)N) >> 32);
-    float d2 = 0.0f;
-    for (int c = 0; c < H; c++) { float df = xp[i * H + c] - xp[j * H + c]; d2 = fmaf(df, df, d2); }
-    float lp = __logf(__expf(t * sqrtf(d2)) + 1e-8f);
-    float m = (i == j) ? 0.0f : __expf(lp * (1.0f / 0.3f));
+    __shared__ float part[4];
+    float m = 0.0f;
+    for (int q = 0; q < PILOT_PER_THREAD; q++) {
+        const uint32_t gid = (blockIdx.x * PILOT_PER_THREAD + q) * 256 + threadIdx.x;
+        uint32_t a = mix32(gid * 2u + 1u + s0), b = mix32(gid * 2u + 2u + s1 * 0x9E3779B9u);
+        int64_t i = (int64_t)(((uint64_t)a * (uint64_t)N) >> 32), j = (int64_t)(((uint64_t)b * (uint64_t)N) >> 32);
+        float d2 = 0.0f;
+        for (int c = 0; c < H; c++) { float df = xp[i * H + c] - xp[j * H + c]; d2 = fmaf(df, df, d2); }
+        float lp = __logf(__expf(t * sqrtf(d2)) + 1e-8f);
+        m += (i == j) ? 0.0f : __expf(lp * (1.0f / 0.3f));
+    }
     const int lane = threadIdx.x & 63;
     m = wave_sum_dpp(m, lane);
-    if (lane == 0) atomicAdd(&ctl->msum, m);
+    if (lane == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&ctl->msum, part[0] + part[1] + part[2] + part[3]);
 }
 
 // row keys of every node (symmetric noise: a pair below the diagonal is keyed by its COLUMN, dgm.py:1216-1223): computed once
@@ -459,7 +467,7 @@ int launch_gv(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, i
     uint2 *colkeys = reinterpret_cast<uint2 *>(pend + R64 * (size_t)CAPF);
     if (dgg_check_hip(hipMemsetAsync(ctl, 0, sizeof(GvCtl), st), "gv memset") != 0) return DGG_ERR_HIP;
     const bool sym = noise_mode == 3;
-    hipLaunchKernelGGL(gv_pilot<H>, dim3(PILOT_PAIRS / 256), dim3(256), 0, st, xp, N, t, s0, s1, ctl);
+    hipLaunchKernelGGL(gv_pilot<H>, dim3(PILOT_PAIRS / 256 / PILOT_PER_THREAD), dim3(256), 0, st, xp, N, t, s0, s1, ctl);
     dim3 gsweep((unsigned)(R64 / 64));
     dim3 gsweep2((unsigned)(R64 / 64), NSEG);
     // whole graph + symmetric noise: triangular sweep with transposed lists (after the column keys in the workspace)

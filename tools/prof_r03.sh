@@ -9,19 +9,22 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -- python3 $R/b
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -- python3 $R/bench.py $BA > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_sq -- python3 $R/bench.py $BA > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/trace -o h -- python3 $R/bench.py --steps 20 --warmup 5 --repeats 3 --cpu-rows -1 --no-variants > $O/bench_under_profiler.json 2>/dev/null
-for nz in none sym hash; do
+for nz in none sym rsym hash; do
   rocprofv3 --kernel-trace --stats -d /tmp/trace_$nz -o h -- python3 $R/bench.py --noise $nz --steps 10 --warmup 3 --repeats 2 --cpu-rows -1 --no-variants > /dev/null 2>&1
 done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_sq_none -- python3 $R/bench.py --noise none $BA > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma_none -- python3 $R/bench.py --noise none $BA > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_sq_sym -- python3 $R/bench.py --noise sym $BA > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_sq_sym -- python3 $R/bench.py --noise rsym $BA > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/trace_ppi -o h -- python3 $R/bench.py --steps 4 --warmup 2 --workload ppi --bf16 --cpu-rows -1 > /dev/null 2>&1
 cd $R
 python3 tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write $O/r03_traffic.json 100000 128 64 > /dev/null
 python3 tools/mfma_busy.py /tmp/pmc_mfma $O/r03_mfma_busy.csv > /dev/null
 python3 tools/sq_breakdown.py /tmp/pmc_sq $O/r03_sq_breakdown.csv > /dev/null
 python3 tools/kernel_stats.py /tmp/trace/h_results.db $O/r03_kernel_stats.csv --skip-first 8 > /dev/null
 python3 tools/kernel_stats.py /tmp/trace_none/h_results.db $O/r03_unperturbed_kernel_stats.csv --skip-first 3 > /dev/null
-python3 tools/kernel_stats.py /tmp/trace_sym/h_results.db $O/r03_symmetric_kernel_stats.csv --skip-first 3 > /dev/null
+python3 tools/kernel_stats.py /tmp/trace_rsym/h_results.db $O/r03_symmetric_kernel_stats.csv --skip-first 3 > /dev/null
+python3 tools/kernel_stats.py /tmp/trace_sym/h_results.db $O/r03_hash_symmetric_kernel_stats.csv --skip-first 3 > /dev/null
+python3 tools/kernel_stats.py /tmp/trace_ppi/h_results.db $O/r03_ppi_bf16_kernel_stats.csv --skip-first 0 > /dev/null
 python3 tools/kernel_stats.py /tmp/trace_hash/h_results.db $O/r03_hash_kernel_stats.csv --skip-first 3 > /dev/null
 python3 tools/sq_breakdown.py /tmp/pmc_sq_none $O/r03_unperturbed_sq_breakdown.csv > /dev/null
 python3 tools/mfma_busy.py /tmp/pmc_mfma_none $O/r03_unperturbed_mfma_busy.csv > /dev/null
