@@ -271,10 +271,18 @@ class DGG_LearnableK_debug(nn.Module):
         not be settled come back empty; dgg_topk_rsym.hip)."""
         err = self.__dict__.get("_rsym_err")
         if err is not None:
-            self._rsym_err = None
+            t3 = self.__dict__.get("_rsym_t3")
+            self._rsym_err = self._rsym_t3 = None
             if bool(err.any()):
                 raise RuntimeError("DGG_LearnableK_debug: the ranked symmetric noise generator could not settle every row inside its "
                                    "workspace (too many rows far from everything else); set args.dgg_sym_generator = 'hash'")
+            if t3 is not None and int(t3) > 0 and getattr(self.args, "dgg_sym_generator", "ranked") == "ranked":
+                # nodes so far from everything else that their noise rows had to be written out in full: exact, but every such row
+                # costs a complete walk of all owners' sequences -- on this data the per-pair hash generator (same law) is cheaper
+                import warnings
+                warnings.warn(f"DGG_LearnableK_debug: {int(t3)} rows needed the dense tier of the ranked symmetric noise generator; "
+                              "switching to the per-pair hash generator (same law, N^2 sweep) for the following forwards")
+                self.args.dgg_sym_generator = "hash"
         if self._overflow is not None and bool(self._overflow):
             self._overflow = None
             raise RuntimeError(
@@ -529,6 +537,9 @@ class DGG_LearnableK_debug(nn.Module):
         if cfg.get("rsym_err") is not None:
             prev = self.__dict__.get("_rsym_err")
             self._rsym_err = cfg["rsym_err"] if prev is None else (prev | cfg["rsym_err"])
+            if x.shape[0] > 1024:                  # (smaller graphs take the dense tier by design: dgg_topk_rsym.hip, SMALL_N)
+                prev3 = self.__dict__.get("_rsym_t3")
+                self._rsym_t3 = cfg["rsym_tier3"] if prev3 is None else torch.maximum(prev3, cfg["rsym_tier3"])
         if writer is not None:   # the two scalars the reference logs from inside the DGG (dgm.py:1259-1261)
             f = w.detach() if (cfg["mode"] == ops.MODE_K_ONLY or "fwd_mode" in cfg) else (w.detach() / val.clamp(min=1e-30))
             writer.add_scalar("values/first_k_std", f.sum(-1).std(), epoch)

@@ -239,7 +239,8 @@ def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed
                   return_ws=False, k_limit=None, status=None):
     """k_limit: learned k of the rows (optional): ranks that the soft top-k ramp zeroes exactly come back as idx = -1.
     status (dict, optional): receives "rsym_err", a 1-element int32 DEVICE tensor that is non-zero when the ranked symmetric
-    generator (noise_mode 5) could not settle every row inside its workspace (no synchronisation here; the caller checks it)."""
+    generator (noise_mode 5) could not settle every row inside its workspace, and "rsym_tier3", the number of rows that took its
+    dense tier (no synchronisation here; the caller checks them)."""
     xp = _chk(xp)
     N, h = xp.shape
     r0, r1 = (0, N) if rows is None else rows
@@ -262,7 +263,9 @@ def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed
     _probe_end("allpairs_topk", pe)
     if status is not None and noise_mode == NOISE_RANKED_SYM:
         off = int(_lib.lib().dgg_allpairs_rsym_ctl_offset_bytes(r1 - r0, N))
-        status["rsym_err"] = ws[off + 16:off + 20].view(torch.int32).clone()
+        ctl = ws[off:off + 32].view(torch.int32)
+        status["rsym_err"] = ctl[4:5].clone()
+        status["rsym_tier3"] = ctl[3:4].clone()       # rows that needed the dense tier (each one costs a full walk of every owner's sequence)
     if return_ws:      # diagnostics: the guess-and-verify control block is ws[:16] = (msum f32, nfail i32, gmin0 f32)
         return idx, val, ws
     return idx, val

@@ -177,6 +177,15 @@ def test_ranked_symmetric_noise_fallback_tiers(dev, knobs, expect):
             m(torch.randn(N, 24, device=dev), dgg_amd.AllPairs(torch.full((N,), 30.0, device=dev)))
         with pytest.raises(RuntimeError, match="ranked symmetric noise generator"):
             m.check_ell_bound()
+        # rows in the dense tier without an overflow: exact, but each costs a full walk -- the module says so and moves to the hash generator
+        m2 = dgg_amd.DGG_LearnableK_debug(in_dim=24, latent_dim=h, args=Namespace(**vars(args))).to(dev)
+        with _rsym_env(DGG_RSYM_TARGET=58, DGG_RSYM_DEPTH2=1):      # (the module passes the learned degrees: ~41 ranks to settle)
+            m2(torch.randn(N, 24, device=dev), dgg_amd.AllPairs(torch.full((N,), 30.0, device=dev)))
+        with pytest.warns(UserWarning, match="dense tier"):
+            m2.check_ell_bound()
+        assert m2.args.dgg_sym_generator == "hash"
+        m2(torch.randn(N, 24, device=dev), dgg_amd.AllPairs(torch.full((N,), 30.0, device=dev)))
+        m2.check_ell_bound()
         return
     ridx, rval = O.allpairs_topk(xp, K=K, noise_mode=O.NOISE_RANKED_SYM, seed=(5, 9))
     assert st["err"] == 0, st
