@@ -15,6 +15,8 @@ reference dgm.py:1628-1725).
 """
 import weakref
 
+import math
+
 import torch
 import torch.nn as nn
 
@@ -271,17 +273,19 @@ class DGG_LearnableK_debug(nn.Module):
         not be settled come back empty; dgg_topk_rsym.hip)."""
         err = self.__dict__.get("_rsym_err")
         if err is not None:
-            t3 = self.__dict__.get("_rsym_t3")
-            self._rsym_err = self._rsym_t3 = None
+            t3, depth = self.__dict__.get("_rsym_t3"), self.__dict__.get("_rsym_depth")
+            self._rsym_err = self._rsym_t3 = self._rsym_depth = None
             if bool(err.any()):
                 raise RuntimeError("DGG_LearnableK_debug: the ranked symmetric noise generator could not settle every row inside its "
                                    "workspace (too many rows far from everything else); set args.dgg_sym_generator = 'hash'")
-            if t3 is not None and int(t3) > 0 and getattr(self.args, "dgg_sym_generator", "ranked") == "ranked":
+            deep = depth is not None and float(depth) > 0.3 * math.log(8.0)       # tier 2 walked > 8x the pairs of tier 1 (all owners)
+            if t3 is not None and (int(t3) > 0 or deep) and getattr(self.args, "dgg_sym_generator", "ranked") == "ranked":
                 # nodes so far from everything else that their noise rows had to be written out in full: exact, but every such row
                 # costs a complete walk of all owners' sequences -- on this data the per-pair hash generator (same law) is cheaper
                 import warnings
-                warnings.warn(f"DGG_LearnableK_debug: {int(t3)} rows needed the dense tier of the ranked symmetric noise generator; "
-                              "switching to the per-pair hash generator (same law, N^2 sweep) for the following forwards")
+                warnings.warn(f"DGG_LearnableK_debug: {int(t3)} rows needed the dense tier of the ranked symmetric noise generator"
+                              + (" and its second tier walked more than 8x deeper than the first" if deep else "") +
+                              "; switching to the per-pair hash generator (same law, N^2 sweep) for the following forwards")
                 self.args.dgg_sym_generator = "hash"
         if self._overflow is not None and bool(self._overflow):
             self._overflow = None
@@ -540,6 +544,8 @@ class DGG_LearnableK_debug(nn.Module):
             if x.shape[0] > 1024:                  # (smaller graphs take the dense tier by design: dgg_topk_rsym.hip, SMALL_N)
                 prev3 = self.__dict__.get("_rsym_t3")
                 self._rsym_t3 = cfg["rsym_tier3"] if prev3 is None else torch.maximum(prev3, cfg["rsym_tier3"])
+                prevd = self.__dict__.get("_rsym_depth")
+                self._rsym_depth = cfg["rsym_depth"] if prevd is None else torch.maximum(prevd, cfg["rsym_depth"])
         if writer is not None:   # the two scalars the reference logs from inside the DGG (dgm.py:1259-1261)
             f = w.detach() if (cfg["mode"] == ops.MODE_K_ONLY or "fwd_mode" in cfg) else (w.detach() / val.clamp(min=1e-30))
             writer.add_scalar("values/first_k_std", f.sum(-1).std(), epoch)

@@ -266,6 +266,10 @@ def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed
         ctl = ws[off:off + 32].view(torch.int32)
         status["rsym_err"] = ctl[4:5].clone()
         status["rsym_tier3"] = ctl[3:4].clone()       # rows that needed the dense tier (each one costs a full walk of every owner's sequence)
+        # how far below the tier-1 threshold tier 2 had to walk (log-score units; -inf: no row failed): every owner walks that deep
+        nm = ctl[6:7]
+        need = torch.where(nm >= 0, nm, nm ^ 0x7fffffff).view(torch.float32)
+        status["rsym_depth"] = ctl[2:3].view(torch.float32) - need
     if return_ws:      # diagnostics: the guess-and-verify control block is ws[:16] = (msum f32, nfail i32, gmin0 f32)
         return idx, val, ws
     return idx, val

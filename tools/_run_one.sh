@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python tools/time_rsym_clustered.py 2>&1 | tail -2
-OUTLIERS=1 python tools/time_rsym_clustered.py 2>&1 | tail -2
+timeout 1500 python -m pytest tests/test_hip_parity.py -q -m gpu -k "fallback_tiers or full_size_ranked_symmetric or module_matches or edge_cases or degenerate" 2>&1 | tail -3
