@@ -13,9 +13,8 @@ Edge scorers: `u-v-dist` (all-pairs or edge-list candidates) and the edge-MLP fa
 (`u-v-deg` -- the reference's default, train_small_graphs.py:184-191 -- `u-v-A_uv`, `u-v-deg-dist`, `edge_conv`, `A_uv`;
 reference dgm.py:1628-1725).
 """
-import weakref
-
 import math
+import weakref
 
 import torch
 import torch.nn as nn
