@@ -1133,6 +1133,61 @@ def test_sddmm_fused_with_normalisation_backward(dev, F):
     np.testing.assert_allclose(Nn(tot), Nn(da_ref), rtol=3e-4, atol=3e-4 * np.abs(Nn(da_ref)).max())
 
 
+@pytest.mark.parametrize("generator,omode", [("ranked", "NOISE_RANKED_SYM"), ("hash", "NOISE_HASH_SYM")])
+def test_module_symmetric_noise_all_pairs_matches_oracle(dev, generator, omode):
+    """`symmetric_noise=True` (the reference default when it perturbs, train_small_graphs.py:152-163; dgm.py:1216-1223) on all-pairs
+    candidates through the module: the selected lists, scores, learned degrees and soft weights must be the oracle's for the
+    generator the module picks (ranked symmetric by default, per-pair hash with args.dgg_sym_generator = "hash"), the selection is
+    symmetric where both directions clear their rows, and the backward matches the oracle's."""
+    import dgg_amd
+    from argparse import Namespace
+    rng = np.random.default_rng(77)
+    N, d, h = 2100, 40, 32
+    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     symmetric_noise=True, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1, dgg_sym_generator=generator)
+    torch.manual_seed(3)
+    m = dgg_amd.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=args).to(dev)
+    with torch.no_grad():
+        m.k_net.k_project.weight.mul_(0.1)
+    m.set_seed(21, 22)
+    x = T(rng.standard_normal((N, d)).astype(np.float32), dev).requires_grad_(True)
+    deg = T((20 + 10 * rng.random(N)).astype(np.float32), dev)
+    adj = m(x, dgg_amd.AllPairs(deg))
+    m.check_ell_bound()
+    cot = rng.standard_normal((N, K)).astype(np.float32)
+    (adj.values() * T(cot, dev)).sum().backward()
+    P = {k_: Nn(v) for k_, v in m.state_dict().items()}
+    xp = O.linear(Nn(x), P["node_encode_for_edges.0.weight"], P["node_encode_for_edges.0.bias"], O.ACT_LEAKY)
+    xk = O.linear(Nn(x), P["node_encode_for_k.0.weight"], P["node_encode_for_k.0.bias"], O.ACT_LEAKY)
+    mu, sdv = O.degree_stats(Nn(deg))
+    k, z, mm, u = O.knet_x(xk, Nn(deg), mu, sdv, P["k_embed.0.weight"], P["k_embed.0.bias"], P["k_net.k_mu.weight"], P["k_net.k_mu.bias"],
+                           P["k_net.k_project.weight"].reshape(-1), P["k_net.k_project.bias"], save=True)
+    ridx, rval = O.allpairs_topk(xp, K=K, noise_mode=getattr(O, omode), seed=(21, 22))
+    keep = np.arange(K)[None, :] < np.minimum(np.ceil(k + 8.5) + 1, K)[:, None]
+    assert np.array_equal(Nn(adj.k), k)
+    assert np.array_equal(Nn(adj.idx), np.where(keep, ridx, -1)), "selected lists differ from the oracle"
+    assert np.array_equal(Nn(adj.score), np.where(keep, rval, 0).astype(np.float32))
+    w, _ = O.softk(np.where(keep, ridx, -1).astype(np.int32), np.where(keep, rval, 0).astype(np.float32), k, 0)
+    assert np.array_equal(Nn(adj.values()), w)
+    # symmetry of the noise shows in the scores: (i -> j) and (j -> i), where both are listed, carry the same bits
+    idx_t, val_t = adj.idx.long().clamp(min=0), adj.score
+    rev = (adj.idx[idx_t].long() == torch.arange(N, device=dev)[:, None, None]) & (adj.idx[idx_t] >= 0)
+    both = rev.any(2) & (adj.idx >= 0)
+    assert int(both.sum()) > N, "the test must see mutual edges"
+    assert torch.equal((val_t[idx_t] * rev).sum(2)[both], val_t[both])
+    idx_k = np.where(keep, ridx, -1).astype(np.int32)
+    dval, dk = O.softk_bwd(idx_k, np.where(keep, rval, 0).astype(np.float32), k, np.where(idx_k >= 0, cot, 0).astype(np.float32), 0)
+    dxp = O.edge_bwd(xp, idx_k, np.where(keep, rval, 0).astype(np.float32), dval, perturb=True)
+    dx1, gWe, gbe = O.linear_bwd(Nn(x), P["node_encode_for_edges.0.weight"], xp, dxp, act=O.ACT_LEAKY)
+    g = m.node_encode_for_edges[0].weight.grad
+    assert np.abs(Nn(g) - gWe).max() <= 3e-4 * np.abs(gWe).max()
+    dxk = O.knet_x_bwd(xk, Nn(deg), mu, sdv, P["k_embed.0.weight"], P["k_net.k_mu.weight"], P["k_net.k_project.weight"].reshape(-1), z, mm, u, dk)[0]
+    dx2 = O.linear_bwd(Nn(x), P["node_encode_for_k.0.weight"], xk, dxk, act=O.ACT_LEAKY)[0]
+    rx = dx1 + dx2
+    assert np.abs(Nn(x.grad) - rx).max() <= 3e-4 * np.abs(rx).max()
+
+
 def test_wide_latent_edge_list_pipeline(dev):
     """latent_dim > 128 (the PPI configuration runs the DGG at latent_dim = hidden = 2048): edge-list scoring, wide score
     backward and the GEMM-composed k-net against the oracle, through the module"""
