@@ -395,6 +395,21 @@ int dgg_pack_bf16(const float *src, int64_t R, int64_t C, int transpose, void *d
 int dgg_gemm_nt_bf16(const void *A, const void *B, int64_t M, int64_t N, int64_t K, float scale, float *C, void *stream);
 int dgg_gcnii_gemm_bf16(const void *S, const void *Wt, int64_t n, int64_t F, int64_t K, const float *hi, const float *h0, const float *inp,
                         float theta, float alpha, float *out, void *stream);
+/* The VARIANT layer (support = cat[hi, h0], model.py:37-40) without forming the concatenation: the contraction range [0,F1) of the
+ * A operand is S1 = bf16(hi) [n,F1], the range [F1,K) is S2 = bf16(h0) [n,K-F1] (F1 a multiple of 64; h0 is the same tensor in every
+ * layer of a GCNII stack, model.py:724, so the caller packs it once per forward).  Otherwise as dgg_gcnii_gemm_bf16. */
+int dgg_gcnii_gemm_bf16_split(const void *S1, const void *S2, const void *Wt, int64_t n, int64_t F, int64_t K, int64_t F1, const float *hi,
+                              const float *h0, const float *inp, float theta, float alpha, float *out, void *stream);
+/* Backward of the variant layer w.r.t. hi and h0 in ONE product (autograd of model.py:37-44):
+ *   [dhi | dh0] = theta * Gp W^T + [(1-theta)(1-alpha) | (1-theta) alpha] * g
+ * Gp bf16 [n,F] = bf16(g), Wp bf16 [2F,F] = the weight as stored, g fp32 [n,F]; dhi, dh0 fp32 [n,F]: no [n,2F] intermediate, no
+ * slicing adds, no separate epilogue pass. */
+/* C[M,N] = scale * [A ; A2] B^T: rows [0,M1) of the A operand in A [M1,K], rows [M1,M) in A2 [M-M1,K] (M1 a multiple of 128): the weight
+ * gradient of the variant layer, theta * cat[hi, h0]^T g (autograd of model.py:41), from the two transposed halves in one product. */
+int dgg_gemm_nt_bf16_rows2(const void *A, const void *A2, int64_t M1, const void *B, int64_t M, int64_t N, int64_t K, float scale, float *C,
+                           void *stream);
+int dgg_gcnii_dsupport_bf16(const void *Gp, const void *Wp, int64_t n, int64_t F, const float *g, float theta, float alpha, float *dhi,
+                            float *dh0, void *stream);
 
 /* ---- dense all-pairs alternates: DGG_LearnableK_SDD (dgm.py:259-351, dist_fn="metric") and DGG_StraightThrough
  * (dgm.py:140-182 + 63-100), noise off.  Rows are a softmax over ALL N columns, outputs are dense [B,N,N]: O(N^2) by

@@ -19,6 +19,8 @@
 #include "dgg_common.h"
 #include "dgg_api_internal.h"
 
+#include <cstdlib>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -27,14 +29,24 @@ namespace {
 constexpr int BN = 128, BK = 64, LDS_STRIDE = BK + 8;   // bf16 elements per staged row (144 bytes)
 
 struct GcniiEpi {
-    const float *hi, *h0, *inp;    // r = h0 ? (1 - alpha) hi + alpha h0 : hi;  out = theta C + (1 - theta) r (+ inp)
+    const float *hi, *h0, *inp;    // EPI 1: r = h0 ? (1 - alpha) hi + alpha h0 : hi;  out = theta C + (1 - theta) r (+ inp)
     float theta, alpha;
+    // EPI 2 (d support of the variant layer, C = theta g W^T is [n, 2F]): columns < F go to C [n,F] as C + c1 g, columns >= F to
+    // out2 [n,F] as C + c2 g -- d hi and d h0 complete, no [n,2F] intermediate, no slicing adds
+    const float *g;
+    float *out2;
+    float c1, c2;
+    int F;
 };
 
 // AM: 32-row MFMA blocks per wavefront (2: 128-row tiles; 1: 64-row tiles, used when 128-row tiles would not fill the chip twice)
-template <bool EPI, int AM>
+// A2 / ksplit > 0: the contraction range [ksplit, K) of the A operand comes from a SECOND matrix A2 [M, K - ksplit] (A is then
+// [M, ksplit]): the variant layer's support cat[hi, h0] (model.py:37-40) is never formed.
+// A2 / ksplit < 0: the ROWS [-ksplit, M) of the A operand come from A2 [M + ksplit, K] (the weight gradient [hi | h0]^T g as one
+// product over the two transposed halves).  Splits are multiples of the tile (64 in K, 128 in M).
+template <int EPI, int AM>
 __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A, const __bf16 *__restrict__ B, int M, int N, int K,
-                                                    float scale, float *__restrict__ C, GcniiEpi ep) {
+                                                    float scale, float *__restrict__ C, GcniiEpi ep, const __bf16 *__restrict__ A2, int ksplit) {
     constexpr int BM = 64 * AM;
     __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * LDS_STRIDE];
@@ -59,7 +71,12 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
             if (!vb) rb[q] = make_uint4(0, 0, 0, 0);
             if (q < 2 * AM) {
                 const bool va = m0 + row < M;
-                ra[q] = *reinterpret_cast<const uint4 *>(A + (int64_t)(va ? m0 + row : 0) * K + k0 + kc * 8);
+                const bool ksec = A2 != nullptr && ksplit > 0 && k0 >= ksplit;       // (block-uniform: the splits are tile multiples)
+                const bool msec = A2 != nullptr && ksplit < 0 && m0 >= -ksplit;
+                const __bf16 *Ab = (ksec || msec) ? A2 : A;
+                const int lda = (A2 && ksplit > 0) ? (ksec ? K - ksplit : ksplit) : K, ka = ksec ? k0 - ksplit : k0;
+                const int ra_row = (va ? m0 + row : (msec ? -ksplit : 0)) - (msec ? -ksplit : 0);
+                ra[q] = *reinterpret_cast<const uint4 *>(Ab + (int64_t)ra_row * lda + ka + kc * 8);
                 if (!va) ra[q] = make_uint4(0, 0, 0, 0);
             }
         }
@@ -95,26 +112,56 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
         if (kt + 1 < nk) store(buf ^ 1);
         __syncthreads();
     }
-    // epilogue: accumulator register q of block (a, b) holds C[row = (q & 3) + 8 (q >> 2) + 4 hh][col = li] of the 32 x 32 block
+    // epilogue: accumulator register q of block (a, b) holds C[row = (q & 3) + 8 (q >> 2) + 4 hh][col = li] of the 32 x 32 block.
+    // The fp32 operands of the fused epilogues are loaded for a whole 32-row block FIRST and stored afterwards: written as one
+    // load-compute-store per element the compiler keeps the order (the stores may alias the loads), and every element pays a
+    // memory round trip -- the forward product ran at half the rate of the plain one.
     const float omt = 1.0f - ep.theta, oma = 1.0f - ep.alpha;
+    const float *__restrict__ e_hi = ep.hi, *__restrict__ e_h0 = ep.h0, *__restrict__ e_inp = ep.inp, *__restrict__ e_g = ep.g;
+    float *__restrict__ e_out2 = ep.out2;
 #pragma unroll
     for (int a = 0; a < AM; a++) {
+        const int rbase = m0 + wr * 32 * AM + a * 32 + 4 * hh;
+        float add[16][2];
+        if (EPI != 0) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int row = rbase + (q & 3) + 8 * (q >> 2);
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const int col = n0 + wc * 64 + b * 32 + li;
+                    float t_ = 0.0f;
+                    if (row < M && col < N) {
+                        if (EPI == 2) {
+                            const bool left = col < ep.F;
+                            t_ = (left ? ep.c1 : ep.c2) * e_g[(int64_t)row * ep.F + (left ? col : col - ep.F)];
+                        } else {
+                            const int64_t o = (int64_t)row * N + col;
+                            const float r = e_h0 ? oma * e_hi[o] + ep.alpha * e_h0[o] : e_hi[o];
+                            t_ = omt * r + (e_inp ? e_inp[o] : 0.0f);
+                        }
+                    }
+                    add[q][b] = t_;
+                }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            const int row = m0 + wr * 32 * AM + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
+            const int row = rbase + (q & 3) + 8 * (q >> 2);
             if (row >= M) continue;
 #pragma unroll
             for (int b = 0; b < 2; b++) {
                 const int col = n0 + wc * 64 + b * 32 + li;
                 if (col >= N) continue;
-                const int64_t o = (int64_t)row * N + col;
-                float v = scale * acc[a][b][q];
-                if (EPI) {
-                    const float r = ep.h0 ? oma * ep.hi[o] + ep.alpha * ep.h0[o] : ep.hi[o];
-                    v = ep.theta * v + omt * r;
-                    if (ep.inp) v += ep.inp[o];
+                const float v = scale * acc[a][b][q];
+                if (EPI == 2) {
+                    const bool left = col < ep.F;
+                    (left ? C : e_out2)[(int64_t)row * ep.F + (left ? col : col - ep.F)] = v + add[q][b];
+                } else if (EPI == 1) {
+                    C[(int64_t)row * N + col] = ep.theta * v + add[q][b];
+                } else {
+                    C[(int64_t)row * N + col] = v;
                 }
-                C[o] = v;
             }
         }
     }
@@ -143,19 +190,25 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float *__restrict_
     }
 }
 
-int launch_gemm(const __bf16 *A, const __bf16 *B, int M, int N, int K, float scale, float *C, const GcniiEpi *ep, hipStream_t st) {
+int launch_gemm(const __bf16 *A, const __bf16 *B, int M, int N, int K, float scale, float *C, const GcniiEpi *ep, hipStream_t st,
+                int epi = -1, const __bf16 *A2 = nullptr, int ksplit = 0) {
     if (K % BK != 0 || K < BK) return dgg_set_error(DGG_ERR_UNSUPPORTED, "gemm_nt_bf16: the contraction length must be a multiple of 64 (pack with padding)");
-    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) % 16) return dgg_set_error(DGG_ERR_ARG, "gemm_nt_bf16: operands must be 16-byte aligned");
+    if (A2 && ksplit > 0 && (ksplit % BK != 0 || ksplit >= K)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "gemm_nt_bf16: the operand split must be a multiple of 64 inside (0, K)");
+    if (A2 && ksplit <= 0 && (ksplit == 0 || (-ksplit) % 128 != 0 || -ksplit >= M)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "gemm_nt_bf16: the row split must be a multiple of 128 inside (0, M)");
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(A2)) % 16) return dgg_set_error(DGG_ERR_ARG, "gemm_nt_bf16: operands must be 16-byte aligned");
     if (M == 0 || N == 0) return 0;
+    if (epi < 0) epi = ep ? 1 : 0;
     // 128-row tiles unless they would leave the 256 CUs with fewer than two rounds of workgroups
     const int64_t big = (int64_t)((N + BN - 1) / BN) * ((M + 127) / 128);
-    const bool small = big < 192;   // (64-row tiles carry 1.5x the LDS traffic per MFMA: only when 128-row tiles would leave CUs idle)
+    bool small = big < 192;   // (64-row tiles carry 1.5x the LDS traffic per MFMA: only when 128-row tiles would leave CUs idle)
+    { const char *e = getenv("DGG_BF16_TILE"); if (e) small = atoi(e) == 64 ? true : (atoi(e) == 128 ? false : small); }
     const dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + (small ? 63 : 127)) / (small ? 64 : 128)));
     const GcniiEpi e0 = ep ? *ep : GcniiEpi{};
-    if (ep && small) hipLaunchKernelGGL((gemm_nt_bf16<true, 1>), grid, dim3(256), 0, st, A, B, M, N, K, scale, C, e0);
-    else if (ep) hipLaunchKernelGGL((gemm_nt_bf16<true, 2>), grid, dim3(256), 0, st, A, B, M, N, K, scale, C, e0);
-    else if (small) hipLaunchKernelGGL((gemm_nt_bf16<false, 1>), grid, dim3(256), 0, st, A, B, M, N, K, scale, C, e0);
-    else hipLaunchKernelGGL((gemm_nt_bf16<false, 2>), grid, dim3(256), 0, st, A, B, M, N, K, scale, C, e0);
+#define DGG_BF16_LAUNCH(E, AMV) hipLaunchKernelGGL((gemm_nt_bf16<E, AMV>), grid, dim3(256), 0, st, A, B, M, N, K, scale, C, e0, A2, ksplit)
+    if (epi == 2) { if (small) DGG_BF16_LAUNCH(2, 1); else DGG_BF16_LAUNCH(2, 2); }
+    else if (epi == 1) { if (small) DGG_BF16_LAUNCH(1, 1); else DGG_BF16_LAUNCH(1, 2); }
+    else { if (small) DGG_BF16_LAUNCH(0, 1); else DGG_BF16_LAUNCH(0, 2); }
+#undef DGG_BF16_LAUNCH
     return dgg_check_launch("gemm_nt_bf16");
 }
 
@@ -188,6 +241,37 @@ int dgg_gcnii_gemm_bf16(const void *S, const void *Wt, int64_t n, int64_t F, int
     const GcniiEpi ep{hi, h0, inp, theta, alpha};
     return launch_gemm(reinterpret_cast<const __bf16 *>(S), reinterpret_cast<const __bf16 *>(Wt), (int)n, (int)F, (int)K, 1.0f, out, &ep,
                        (hipStream_t)stream);
+}
+
+// The VARIANT layer (support = cat[hi, h0], model.py:37-40) without forming the concatenation: S1 = bf16(hi) [n,F1], S2 = bf16(h0)
+// [n,K-F1] are the two halves of the A operand (F1 a multiple of 64); otherwise as dgg_gcnii_gemm_bf16
+int dgg_gcnii_gemm_bf16_split(const void *S1, const void *S2, const void *Wt, int64_t n, int64_t F, int64_t K, int64_t F1, const float *hi,
+                              const float *h0, const float *inp, float theta, float alpha, float *out, void *stream) {
+    if (!hi || !S2) return dgg_set_error(DGG_ERR_ARG, "gcnii_gemm_bf16_split: hi and the second operand half are required");
+    const GcniiEpi ep{hi, h0, inp, theta, alpha, nullptr, nullptr, 0.0f, 0.0f, 0};
+    return launch_gemm(reinterpret_cast<const __bf16 *>(S1), reinterpret_cast<const __bf16 *>(Wt), (int)n, (int)F, (int)K, 1.0f, out, &ep,
+                       (hipStream_t)stream, 1, reinterpret_cast<const __bf16 *>(S2), (int)F1);
+}
+
+// Backward of the variant layer w.r.t. its two inputs in ONE product: [d hi | d h0] = theta * Gp W^T + [c1 | c2] * g with
+// c1 = (1 - theta)(1 - alpha), c2 = (1 - theta) alpha (model.py:41-44): Gp bf16 [n,F] (= bf16(g)), Wp bf16 [2F, F] (the weight as
+// stored), g fp32 [n,F]; dhi, dh0 fp32 [n,F]
+int dgg_gcnii_dsupport_bf16(const void *Gp, const void *Wp, int64_t n, int64_t F, const float *g, float theta, float alpha, float *dhi,
+                            float *dh0, void *stream) {
+    if (!g || !dhi || !dh0) return dgg_set_error(DGG_ERR_ARG, "gcnii_dsupport_bf16: g, dhi and dh0 are required");
+    GcniiEpi ep{};
+    ep.g = g; ep.out2 = dh0; ep.c1 = (1.0f - theta) * (1.0f - alpha); ep.c2 = (1.0f - theta) * alpha; ep.F = (int)F;
+    return launch_gemm(reinterpret_cast<const __bf16 *>(Gp), reinterpret_cast<const __bf16 *>(Wp), (int)n, (int)(2 * F), (int)F, theta, dhi, &ep,
+                       (hipStream_t)stream, 2);
+}
+
+// C[M,N] = scale * [A ; A2] B^T with the rows [0, M1) of the A operand in A [M1,K] and the rows [M1, M) in A2 [M-M1,K] (M1 a multiple
+// of 128): the weight gradient of the variant layer, theta * [hi | h0]^T g, from the two transposed halves in one product
+int dgg_gemm_nt_bf16_rows2(const void *A, const void *A2, int64_t M1, const void *B, int64_t M, int64_t N, int64_t K, float scale, float *C,
+                           void *stream) {
+    if (!A2) return dgg_set_error(DGG_ERR_ARG, "gemm_nt_bf16_rows2: the second operand block is required");
+    return launch_gemm(reinterpret_cast<const __bf16 *>(A), reinterpret_cast<const __bf16 *>(B), (int)M, (int)N, (int)K, scale, C, nullptr,
+                       (hipStream_t)stream, 0, reinterpret_cast<const __bf16 *>(A2), -(int)M1);
 }
 
 }  // extern "C"

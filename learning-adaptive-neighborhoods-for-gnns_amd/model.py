@@ -66,9 +66,14 @@ class GraphConvolution(nn.Module):
     def forward(self, input, adj, h0, lamda, alpha, l):
         theta = math.log(lamda / l + 1)
         hi = _as_ell(adj).matmul(input)
+        res = input if self.residual else None
+        if (self.variant and self.gemm_dtype == torch.bfloat16 and hi.shape[1] % 64 == 0 and self.out_features == hi.shape[1]
+                and h0.shape == hi.shape):
+            # reduced-precision variant layer: cat[hi, h0] is never formed (the product takes the two halves of its A operand from
+            # two matrices, h0 is packed once per stack) and the backward leaves d hi / d h0 complete from one product
+            return ops.GcniiVariantBf16Fn.apply(hi, h0, self.weight, res, theta, alpha)
         # variant: the GEMM input is cat[hi, h0] and r only feeds the epilogue (folded into it); otherwise support = r
         support = torch.cat([hi, h0], 1) if self.variant else (1 - alpha) * hi + alpha * h0
-        res = input if self.residual else None
         if self.gemm_dtype == torch.bfloat16 and support.shape[1] % 64 == 0:
             # reduced-precision variant (BASELINE configs[4]: "bf16 fwd+bwd"): the layer product and its autograd run on the bf16
             # matrix cores (dgg_bf16.hip: v_mfma_f32_32x32x16_bf16, fp32 accumulation), epilogue fused; everything else fp32

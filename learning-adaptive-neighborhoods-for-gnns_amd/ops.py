@@ -1248,6 +1248,77 @@ class GcniiBf16Fn(torch.autograd.Function):
         return dS, dW, dhi, dh0, (g if ctx.has_inp else None), None, None
 
 
+def _h0_packs(h0):
+    """bf16 copies of h0 -- plain for the forward product, transposed for the weight gradient -- made ONCE per forward of a GCNII
+    stack: h0 is the same tensor object in every layer (model.py:724), the packs ride on it as an attribute and die with it; the
+    version counter guards against an in-place update in between"""
+    ent = getattr(h0, "_dgg_bf16_packs", None)
+    if ent is None or ent[0] != h0._version or ent[1] != h0.data_ptr():
+        hd = h0.detach()
+        ent = (h0._version, h0.data_ptr(), pack_bf16(hd), pack_bf16(hd, transpose=True))
+        h0._dgg_bf16_packs = ent
+    return ent[2], ent[3]
+
+
+class GcniiVariantBf16Fn(torch.autograd.Function):
+    """The VARIANT GCNII layer (support = cat[hi, h0], model.py:37-44) on the bf16 matrix cores without the concatenation:
+    out = theta * ([hi | h0] @ weight) + (1 - theta) * ((1 - alpha) hi + alpha h0) (+ inp).
+    Forward: the A operand of the product is split (bf16(hi) packed here, bf16(h0) once per stack); backward: [d hi | d h0] in one
+    product with the elementwise terms in its epilogue, d weight as two products hi^T g and h0^T g written into the two row blocks
+    of the gradient.  Same operand rounding as GcniiBf16Fn on cat[hi, h0]."""
+
+    @staticmethod
+    def forward(ctx, hi, h0, weight, inp, theta, alpha):
+        n, F = hi.shape
+        assert weight.shape[0] == 2 * F and F % 64 == 0
+        hi, h0c = _chk(hi), _chk(h0)
+        inpc = _chk(inp) if inp is not None else None
+        S1 = pack_bf16(hi)
+        S2, _ = _h0_packs(h0)
+        Wt = _packed_weight(weight, True)                        # [Fout, 2F]
+        Fo = weight.shape[1]
+        out = torch.empty((n, Fo), device=hi.device, dtype=torch.float32)
+        pe = _probe_begin()
+        _lib.check(_lib.lib().dgg_gcnii_gemm_bf16_split(_ptr(S1), _ptr(S2), _ptr(Wt), n, Fo, 2 * F, F, _ptr(hi), _ptr(h0c), _ptr(inpc),
+                                                        float(theta), float(alpha), _ptr(out), _stream()), "gcnii_gemm_bf16_split")
+        _probe_end("gemm_bf16_fwd", pe)
+        ctx.save_for_backward(hi, h0, weight)
+        ctx.theta, ctx.alpha, ctx.has_inp = float(theta), float(alpha), inp is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        hi, h0, weight = ctx.saved_tensors
+        g = _chk(g.contiguous())
+        n, Fo = g.shape
+        F = hi.shape[1]
+        assert Fo == F, "the variant layer is square (nhidden -> nhidden)"
+        dhi = dh0 = dW = None
+        Gp = pack_bf16(g)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dhi, dh0 = torch.empty_like(g), torch.empty_like(g)
+            pe = _probe_begin()
+            _lib.check(_lib.lib().dgg_gcnii_dsupport_bf16(_ptr(Gp), _ptr(_packed_weight(weight, False)), n, F, _ptr(g), ctx.theta, ctx.alpha,
+                                                          _ptr(dhi), _ptr(dh0), _stream()), "gcnii_dsupport_bf16")
+            _probe_end("gemm_bf16_bwd", pe)
+        if ctx.needs_input_grad[2]:
+            # contraction over the n nodes: operands transposed, n zero-padded to a multiple of 64
+            GT = pack_bf16(g, transpose=True)                    # [F, n64]
+            hiT = pack_bf16(hi, transpose=True)
+            _, h0T = _h0_packs(h0)
+            dW = torch.empty_like(weight)
+            pe = _probe_begin()
+            if F % 128 == 0:
+                _lib.check(_lib.lib().dgg_gemm_nt_bf16_rows2(_ptr(hiT), _ptr(h0T), F, _ptr(GT), 2 * F, Fo, hiT.shape[1], ctx.theta, _ptr(dW),
+                                                             _stream()), "gemm_nt_bf16_rows2")
+            else:
+                for r0_, AT in ((0, hiT), (F, h0T)):
+                    _lib.check(_lib.lib().dgg_gemm_nt_bf16(_ptr(AT), _ptr(GT), F, Fo, AT.shape[1], ctx.theta,
+                                                           C.c_void_p(dW.data_ptr() + 4 * r0_ * Fo), _stream()), "gemm_nt_bf16")
+            _probe_end("gemm_bf16_bwd", pe)
+        return dhi, dh0, dW, (g if ctx.has_inp else None), None, None
+
+
 class GcniiEpilogueFn(torch.autograd.Function):
     """out = theta * sw + (1 - theta) * ((1 - alpha) * hi + alpha * h0) (+ inp)  (GraphConvolution.forward, model.py:36-44);
     h0 None: r = hi (the non-variant layer, whose support is r itself)."""
