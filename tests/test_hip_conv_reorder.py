@@ -236,6 +236,41 @@ def test_unperturbed_allpairs_with_pilot_guess_is_bit_exact(dev, N, h, clustered
     assert np.array_equal(Nn(idx), ridx) and np.array_equal(Nn(val), rval)
 
 
+@pytest.mark.parametrize("n,F,residual", [(700, 128, True), (1333, 256, False), (2257, 2048, True)])
+def test_bf16_variant_layer_without_the_concatenation(dev, n, F, residual):
+    """The variant GCNII layer (support = cat[hi, h0], model.py:37-44) through ops.GcniiVariantBf16Fn -- split A operand, h0 packed once,
+    [d hi | d h0] from one product with the elementwise terms in its epilogue, weight gradient over the two transposed halves --
+    against ops.GcniiBf16Fn on the explicit concatenation: the same bf16 operands in the same contraction order, so the output is
+    bit-identical and so are the gradients (the old path adds the same two fp32 terms in the same order)."""
+    from dgg_amd import ops
+    rng = np.random.default_rng(n + F)
+    theta, alpha = 0.405, 0.5
+
+    def run(fn):
+        hi = T(rng0.standard_normal((n, F)).astype(np.float32), dev).requires_grad_(True)
+        h0 = T(rng0.standard_normal((n, F)).astype(np.float32), dev).requires_grad_(True)
+        W = T((rng0.standard_normal((2 * F, F)) / np.sqrt(2 * F)).astype(np.float32), dev).requires_grad_(True)
+        inp = T(rng0.standard_normal((n, F)).astype(np.float32), dev).requires_grad_(True) if residual else None
+        cot = T(rng0.standard_normal((n, F)).astype(np.float32), dev)
+        out = fn(hi, h0, W, inp)
+        (out * cot).sum().backward()
+        return [out.detach(), hi.grad, h0.grad, W.grad] + ([inp.grad] if residual else [])
+
+    rng0 = np.random.default_rng(5)
+    a = run(lambda hi, h0, W, inp: ops.GcniiVariantBf16Fn.apply(hi, h0, W, inp, theta, alpha))
+    rng0 = np.random.default_rng(5)
+    b = run(lambda hi, h0, W, inp: ops.GcniiBf16Fn.apply(torch.cat([hi, h0], 1), W, hi, h0, inp, theta, alpha))
+    for name, x, y in zip(["out", "d hi", "d h0", "d weight", "d input"], a, b):
+        assert torch.equal(x, y), f"{name}: max difference {float((x - y).abs().max()):.3e}"
+    # the packs of h0 ride on the tensor: a second layer of the stack reuses them, an in-place update invalidates them
+    h0 = T(rng.standard_normal((n, F)).astype(np.float32), dev)
+    p1 = ops._h0_packs(h0)
+    assert ops._h0_packs(h0)[0] is p1[0]
+    h0.mul_(2.0)
+    p2 = ops._h0_packs(h0)
+    assert p2[0] is not p1[0] and torch.equal(p2[0].float(), h0.bfloat16().float())
+
+
 @pytest.mark.parametrize("n,K,F,variant,residual", [(700, 256, 128, True, True), (333, 128, 128, False, True), (1500, 4096, 2048, True, True)])
 def test_bf16_gcnii_layer_product(dev, n, K, F, variant, residual):
     """BASELINE configs[4] (bf16 fwd+bwd): GraphConvolution with gemm_dtype=bfloat16 runs the layer product and its autograd on the

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python tools/prof_ppi_copies.py 2>&1 | tail -25
+timeout 1500 python -m pytest tests/test_hip_conv_reorder.py -q -m gpu -k "variant_layer_without" 2>&1 | grep -E "^E  |passed|failed|FAILED|Error" | cut -c1-300 | head
