@@ -14,7 +14,7 @@ m = dgg_amd.GCNIIppi_DGG(nfeat=d, nlayers=L, nhidden=hid, nclass=C, dropout=0.2,
 for conv in m.convs:
     conv.gemm_dtype = torch.bfloat16
 m.train()
-n = 1500
+n = int(os.environ.get('N', 2925))
 rows, cols = pubmed_graph(n, n * 14, seed=n)
 keep = rows != cols
 A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows[keep], cols[keep]])), torch.ones(int(keep.sum())), (n, n)).coalesce().to(dev)
@@ -29,6 +29,8 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False, record_shapes=True) as prof:
     step()
     torch.cuda.synchronize()
-rowsP = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::add", "aten::add_", "aten::cat", "aten::to", "aten::_to_copy")]
-for e in sorted(rowsP, key=lambda e: -e.count):
-    print(e.key, e.count, e.input_shapes, round(e.device_time_total / 1e3, 3), "ms")
+for e in sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:25]:
+    print(e.key[:70].ljust(72), e.count, round(e.device_time_total / 1e3, 3), "ms")
+for ev in prof.events():
+    if "emcpy" in ev.name or "copyBuffer" in ev.name:
+        print("MEMCPY", ev.name, round(ev.device_time_total / 1e3, 3), "ms", "parent:", ev.cpu_parent.name if ev.cpu_parent else None)
