@@ -92,6 +92,65 @@ class _KnetDegFn(torch.autograd.Function):
                 (alpha * S1 + beta * S0).reshape(Wp.shape), S0.reshape(1), None)
 
 
+class _DualProjFn(torch.autograd.Function):
+    """The two input projections of the generator on ONE pass over x: xp = leaky(x We^T + be) (node_encode_for_edges, dgm.py:1097-1100)
+    and xk = leaky(x Wk^T + bk) (node_encode_for_k, 1123-1126).  x is the widest tensor of the edge-list configurations (Pubmed: 500
+    columns, Cora: 1433) and two separate layers read it twice forward and twice backward.  Forward: dgg_linear_fwd_multi (the same
+    fmaf chains as one dgg_linear_fwd per layer: bit-identical); backward: the two activation derivatives, then ONE product
+    [dxp' | dxk']^T x for both weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, We, be, Wk, bk):
+        xp, xk = ops.linear_fwd_multi(x, [(We, be, ops.ACT_LEAKY, 0), (Wk, bk, ops.ACT_LEAKY, 0)])
+        ctx.save_for_backward(x, We, Wk, xp, xk)
+        return xp, xk
+
+    @staticmethod
+    def backward(ctx, dxp, dxk):
+        x, We, Wk, xp, xk = ctx.saved_tensors
+        h1, h2 = We.shape[0], Wk.shape[0]
+        parts = [torch.zeros_like(y) if g is None else ops.act_bwd(y, g.contiguous(), ops.ACT_LEAKY) for y, g in ((xp, dxp), (xk, dxk))]
+        dP = torch.cat(parts, 1)
+        dW, db = ops.gemm_tn(dP, x, colsum=True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_fwd(dP, torch.cat([We, Wk], 0), None, ops.ACT_NONE, 1)          # dP [N, h1+h2] @ [h1+h2, d]
+        return dx, dW[:h1], db[:h1], dW[h1:], db[h1:]
+
+
+class _DGGSoftAdjXpFn(torch.autograd.Function):
+    """_DGGSoftAdjFn on an already projected xp (see _DualProjFn): u-v-dist scoring + perturbation + top-K + ramp; the gradient
+    goes back to xp."""
+
+    @staticmethod
+    def forward(ctx, xp, k, cfg):
+        if cfg["cand"] is None:
+            idx, val = ops.allpairs_topk(xp, cfg["K"], cfg["t"], cfg["noise_mode"], cfg["G"], cfg["seed"], algo=cfg["algo"],
+                                         k_limit=k, status=cfg)
+        else:
+            rowptr, col = cfg["cand"]
+            idx, val = ops.edgelist_topk(xp, rowptr, col, cfg["K"], cfg["t"], cfg["noise_mode"], cfg["G"], cfg["seed"])
+        w, rs = ops.softk_fwd(idx, val, k, cfg.get("fwd_mode", cfg["mode"]))
+        ctx.cfg = cfg
+        cfg["part"] = ops.part_build(idx, w, xp.shape[0]) if any(ctx.needs_input_grad) else None
+        ctx.save_for_backward(xp, k, idx, val)
+        ctx.mark_non_differentiable(idx, val, rs)
+        return w, idx, val, rs
+
+    @staticmethod
+    def backward(ctx, dw, *_):
+        xp, k, idx, val = ctx.saved_tensors
+        cfg = ctx.cfg
+        fused = ops.softk_edge_bwd(xp, idx, val, k, dw.contiguous(), t=cfg["t"], perturb=cfg["noise_mode"] != ops.NOISE_NONE,
+                                   mode=cfg["mode"], normalized=False, part=cfg.get("part"))
+        if fused is not None:
+            dxp, dk, _ = fused
+        else:
+            dval, dk = ops.softk_bwd(idx, val, k, dw.contiguous(), mode=cfg["mode"], normalized=False)
+            dxp = ops.edge_bwd(xp, idx, val, dval, t=cfg["t"], perturb=cfg["noise_mode"] != ops.NOISE_NONE, part=cfg.get("part"))
+        return dxp, dk, None
+
+
 class _DGGSoftAdjFn(torch.autograd.Function):
     """x, learned k, projection parameters -> soft (unnormalised) ELL adjacency values: projection, u-v-dist scoring +
     perturbation + top-K, ramp (reference dgm.py:1197-1292)."""
@@ -503,8 +562,14 @@ class DGG_LearnableK_debug(nn.Module):
             cfg["fwd_mode"] = ops.MODE_HARD_ST
         We, be = self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias
         kn = self.k_net
+        xp_dual = None
         if self.k_net_mode in ("x", "gcn-x-deg"):
-            xk = ops.LinearFn.apply(x, self.node_encode_for_k[0].weight, self.node_encode_for_k[0].bias, ops.ACT_LEAKY, 0)
+            Wk, bk = self.node_encode_for_k[0].weight, self.node_encode_for_k[0].bias
+            if (self.edge_prob_net_mode == "u-v-dist" and not literal and We.shape[0] % 32 == 0 and Wk.shape[0] % 32 == 0
+                    and We.shape[0] + Wk.shape[0] <= 256 and getattr(self.args, "dgg_fused_projections", True)):
+                xp_dual, xk = _DualProjFn.apply(x, We, be, Wk, bk)       # both projections on one pass over x
+            else:
+                xk = ops.LinearFn.apply(x, Wk, bk, ops.ACT_LEAKY, 0)
             if self.k_net_mode == "gcn-x-deg":       # relu(normalize_adj(in_adj) @ xk @ k_W)   (dgm.py:1528-1540)
                 if cand is None:
                     raise NotImplementedError("k-net mode 'gcn-x-deg' aggregates over the stored entries of in_adj")
@@ -528,7 +593,9 @@ class DGG_LearnableK_debug(nn.Module):
         if cand is not None and not literal and self._wide_rows(in_adj, rowptr, k):
             # rows wider than the ELL and learned degrees that may exceed it: the CSR form (no width limit)
             return self._csr_soft_adjacency(x, in_adj, k, noise_mode, G, seed, cfg["mode"])
-        if self.edge_prob_net_mode == "u-v-dist":
+        if self.edge_prob_net_mode == "u-v-dist" and xp_dual is not None:
+            w, idx, val, rs = _DGGSoftAdjXpFn.apply(xp_dual, k, cfg)
+        elif self.edge_prob_net_mode == "u-v-dist":
             w, idx, val, rs = _DGGSoftAdjFn.apply(x, k, We, be, cfg)
         else:
             mlp, ex_in = self._edge_mlp_terms(avals)

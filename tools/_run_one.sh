@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
-python bench.py --noise rsym --steps 10 --warmup 3 --no-variants --cpu-rows -1 > gpurun_out/bench_rsym_main.json 2> gpurun_out/bench_rsym_main.err; tail -2 gpurun_out/bench_rsym_main.err; python -c "
-import json; j=json.load(open('gpurun_out/bench_rsym_main.json')); print(j['ms_per_step'], j['config']['hipgraph'], j['repeats']['eager_ms_per_step'], j['roofline']['kernel_ms'])"
-python bench.py --noise rsym --nodes 500000 --steps 10 --warmup 3 --no-variants --cpu-rows -1 > gpurun_out/bench_rsym_500k.json 2> /dev/null; python -c "
-import json; j=json.load(open('gpurun_out/bench_rsym_500k.json')); print('500k', j['ms_per_step'], j['roofline']['kernel_ms'])"
-python bench.py --noise rsym --emulate-world 8 --nodes 62500 --steps 10 --warmup 3 --no-variants --cpu-rows -1 > gpurun_out/bench_rsym_emu.json 2> /dev/null; python -c "
-import json; j=json.load(open('gpurun_out/bench_rsym_emu.json')); print('rank of 8', j['ms_per_step'], j['roofline']['kernel_ms'])"
+for r in 128 64; do
+DGG_LINEAR_MULTI_ROWS=$r python3 bench.py --steps 20 --warmup 5 --workload pubmed --cpu-rows -1 > gpurun_out/pubmed_$r.json 2> /dev/null; python -c "
+import json; j=json.load(open('gpurun_out/pubmed_$r.json')); print($r, j['ms_per_step'])"
+done
+timeout 900 python -m pytest tests/test_hip_parity.py -q -m gpu -k "linear or module_matches" 2>&1 | tail -2
