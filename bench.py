@@ -184,12 +184,15 @@ def bench_edgelist(a, dev):
     A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), vals, (N, N)).coalesce().to(dev)
     params = [p_ for p_ in list(dgg.parameters()) + list(conv.parameters())]
 
+    from dgg_amd import ops as _ops
+
     def step():
         for p_ in params:
             p_.grad = None
-        adj = dgg(x, A)
-        out = conv(x, adj.normalize())
-        out.sum().backward()
+        with _ops.step_zero_pool(dev, N, 64, 64, params):        # the step's zeroed accumulators from one filled buffer
+            adj = dgg(x, A)
+            out = conv(x, adj.normalize())
+            out.sum().backward()
         return adj
 
     # ~70 launches of a few microseconds each: launch latency dominates at this size, so the whole autograd step (forward,

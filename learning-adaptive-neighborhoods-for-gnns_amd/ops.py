@@ -46,6 +46,14 @@ class zero_pool:
         _POOL = self.prev
 
 
+def step_zero_pool(device, nodes, width=64, feat=64, params=()):
+    """zero_pool sized for one forward + backward of a generator + graph-convolution step on `nodes` nodes (ELL width `width`,
+    conv width `feat`): the ~10 zero-initialised accumulators of the step then cost ONE fill launch instead of one each.  A pool
+    that turns out too small is not an error: the remaining buffers are zero-filled one by one as without a pool."""
+    nparam = sum(int(p_.numel()) for p_ in params)
+    return zero_pool(device, 4 * nodes * width + 3 * nodes * max(feat, width) + 8 * nodes + 3 * nparam + (1 << 16))
+
+
 def _zeros(shape, device):
     n = 1
     for s_ in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)):

@@ -23,6 +23,7 @@ import torch
 import torch.nn.functional as F
 
 from . import data as D
+from . import ops
 from . import model as models
 
 
@@ -139,9 +140,10 @@ def main(argv=None):
     for epoch in range(args.epochs):
         model.train()
         opt.zero_grad()
-        out = forward(model, x, adj, edge_index=edge_index, epoch=epoch, writer=None)
-        loss = F.nll_loss(out[idx["train_idx"]], y[idx["train_idx"]])
-        loss.backward()
+        with ops.step_zero_pool(device, x.shape[0], 64, max(args.hidden, 64), list(model.parameters())):   # one fill for the step's accumulators
+            out = forward(model, x, adj, edge_index=edge_index, epoch=epoch, writer=None)
+            loss = F.nll_loss(out[idx["train_idx"]], y[idx["train_idx"]])
+            loss.backward()
         opt.step()
         for dg in getattr(model, "dggs", []):                    # learned k must stay inside the ELL width (one sync per epoch)
             if hasattr(dg, "check_ell_bound"):
