@@ -45,7 +45,7 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
     int rc;
     // unperturbed scores: two-phase guess-sweep-verify (its pilot needs N >= 8192; below that every pair is scored)
     if (noise_mode == 0 && (algo == 2 || (algo == 0 && N >= 8192)) && can_sweep)
-        rc = dgg_allpairs_topk_sweep_impl(xp, N, h, row0, row1, t, K, idx, val, workspace, ws_bytes, st);
+        rc = dgg_allpairs_topk_sweep_impl(xp, N, h, row0, row1, t, K, k_limit, idx, val, workspace, ws_bytes, st);   // (settles only the ranks k_limit keeps)
     else if (algo == 4 || (algo == 0 && can_gv && N >= 1024))
         rc = dgg_allpairs_topk_gv_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
     else if (algo == 3 || (algo == 0 && can_np && N >= 1024))

@@ -155,7 +155,8 @@ struct Tile {
 // pilot is a heuristic, exactness comes from the verification) -> L = nb_i - 2 E, radius = max over the two half rows * gscale.
 template <int H>
 __global__ __launch_bounds__(256) void sw_pilot(const uint16_t *__restrict__ xw, const float *__restrict__ nb, int64_t row0, int64_t row1,
-                                                int ntiles, int pt_tiles, float gscale, float *__restrict__ tloose) {
+                                                int ntiles, int pt_tiles, float gscale, float *__restrict__ tloose,
+                                                const float *__restrict__ klim, int kpad) {
     using TL = Tile<H>;
     constexpr int HW = TL::HW, KS1 = TL::KS1, STRIDE = TL::STRIDE, CPC = TL::CPC, LQ = TL::LQ;
     __shared__ __attribute__((aligned(16))) unsigned char colA[TL::BYTES];
@@ -213,9 +214,19 @@ __global__ __launch_bounds__(256) void sw_pilot(const uint16_t *__restrict__ xw,
             }
         }
     }
-    // L of the PILOT_M-th best of this half row; the radius covers both halves
+    // L of the PILOT_M-th best of this half row; the radius covers both halves.  With the learned degrees only the first
+    // Lr = ceil(k_i + 8.5) + 1 ranks of a row carry weight (k_limit, include/dgg_hip.h): the radius is taken from the
+    // ceil(PILOT_M Lr / 64)-th best instead -- proportionally fewer candidates in every later stage.
     const float nbi = nb[ic];
-    float L = fmaf(-2.0f, tm[PILOT_M - 1], nbi);
+    float tsel = tm[PILOT_M - 1];
+    if (klim) {
+        const int Lr = klimit_len(klim[ic - row0], 64);
+        int mi = (PILOT_M * Lr + 63) / 64 + kpad;
+        mi = mi < 3 ? 3 : (mi > PILOT_M ? PILOT_M : mi);
+#pragma unroll
+        for (int q = 0; q < PILOT_M - 1; q++) tsel = (q == mi - 1) ? tm[q] : tsel;
+    }
+    float L = fmaf(-2.0f, tsel, nbi);
     L = fmaxf(L, __shfl_xor(L, 32, 64));
     const float R = fmaxf(L, 0.0f) * gscale + 1e-6f;
     if (rvalid && hh == 0) tloose[i - row0] = nbi < 3.0e38f ? 0.5f * (R - nbi) + 1e-6f * (fabsf(R) + fabsf(nbi)) + 1e-7f : 3.0e38f;   // (wild row)
@@ -398,7 +409,7 @@ constexpr int SELCAP = CAPA_ROW;        // phase-A hits of one row that sw_selec
 __global__ __launch_bounds__(256) void sw_select(const int2 *__restrict__ listA, const unsigned short *__restrict__ cntA, int64_t rows, int64_t row0,
                                                  int CSA, int capA, int rblk, int m, const float *__restrict__ nb,
                                                  const float *__restrict__ tloose, float *__restrict__ ttight, int32_t *__restrict__ kept,
-                                                 int *__restrict__ keptn, SweepCtl *__restrict__ ctl) {
+                                                 int *__restrict__ keptn, SweepCtl *__restrict__ ctl, const float *__restrict__ klim, int mpad) {
     // one wavefront per row.  Pass over the row's 2 * CSA lane lists: its own records (tag) are compacted into LDS as (column, D, D');
     // the cut is found by BISECTION on D' (count of D' >= cut by ballots; any cut is valid -- the verification decides -- so 11
     // halvings replace three 64-lane sorts); the records with D >= cut go to the row's kept list.
@@ -409,6 +420,12 @@ __global__ __launch_bounds__(256) void sw_select(const int2 *__restrict__ listA,
     if (lrow >= rows) return;
     const RowLists rl = row_lists(lrow, rblk);
     const float nbi = nb[row0 + lrow];
+    if (klim && m <= 64) {                                              // k_limit: the order statistic scales with the ranks the row has to settle
+        const int Lr = __builtin_amdgcn_readfirstlane(klimit_len(klim[lrow], 64));
+        const int mfull = m;
+        m = (m * Lr + 63) / 64 + mpad;
+        m = m < 8 ? 8 : (m > mfull ? mfull : m);
+    }
     int total = 0;
     bool over = false;
     auto take = [&](bool mine, const int2 &c, float nbj) {            // compaction of the row's own records into LDS
@@ -548,7 +565,8 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
                                                    const int32_t *__restrict__ kept, const int *__restrict__ keptn,
                                                    const uint32_t *__restrict__ listB, const unsigned short *__restrict__ cntB, int CSB, int capB,
                                                    int rblk, const float *__restrict__ ttight, SweepCtl *__restrict__ ctl,
-                                                   int *__restrict__ faillist, int32_t *__restrict__ idx, float *__restrict__ val) {
+                                                   int *__restrict__ faillist, int32_t *__restrict__ idx, float *__restrict__ val,
+                                                   const float *__restrict__ klim) {
     __shared__ int32_t ccol[4][FCAP];
     __shared__ float cd2[4][FCAP];
     const int lane = threadIdx.x & 63, wave = dgg::wave_id();
@@ -557,6 +575,8 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
     if (i >= row1) return;
     const RowLists rl = row_lists(lrow, rblk);
     int32_t *cc = ccol[wave];
+    // ranks the row has to settle: 64, or ceil(k_i + 8.5) + 1 with the learned degrees (the others come back as idx = -1)
+    const int Lr = klim ? __builtin_amdgcn_readfirstlane(klimit_len(klim[lrow], 64)) : 64;
     int total = 0, nB = 0;                                             // wave-uniform
     bool ok = true;
     auto push = [&](bool keep, int32_t col) {
@@ -604,7 +624,7 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
         }
     }
     nB = total - nkept;
-    if (total > FCAP || total < 64) ok = false;
+    if (total > FCAP || total < Lr) ok = false;
     uint64_t list = DGG_EMPTY_KEY;
     if (ok) {
         // exact squared distances, FCAP / 64 candidates per lane
@@ -629,17 +649,17 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
                 if (k < nch) c += __builtin_popcountll(__ballot(u[k] <= x));
             return c;
         };
-        // bisection: smallest tau with count(d2 <= tau) >= 64 -- stopped early once a value with exactly 64 below is met
+        // bisection: smallest tau with count(d2 <= tau) >= Lr -- stopped early once a value with exactly Lr below is met
         uint32_t lo = 0u, hi = 0u;
 #pragma unroll
         for (int k = 0; k < FCAP / 64; k++) hi = max(hi, u[k] == 0xffffffffu ? 0u : u[k]);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
-        uint32_t tau = hi;                                              // count(<= hi) = total >= 64
+        uint32_t tau = hi;                                              // count(<= hi) = total >= Lr
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
             const int c = count_le(mid);
-            if (c >= 64) { hi = mid; tau = mid; if (c == 64) break; } else lo = mid + 1u;
+            if (c >= Lr) { hi = mid; tau = mid; if (c == Lr) break; } else lo = mid + 1u;
         }
         const float dcut = c_sqrt(__uint_as_float(tau)) + 4e-6f;
         const float d2cut = dcut * dcut * (1.0f + 1e-6f);
@@ -665,7 +685,7 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
         }
         // verification: full list, and its 64th distance (+ margins for the log and the rounding of the canonical exp) inside the
         // radius the sweeps tested against: R = nb_i + 2 t_tight
-        const uint64_t k63 = shfl_u64(list, 63);
+        const uint64_t k63 = shfl_u64(list, Lr - 1);                    // the last rank that carries weight
         if (k63 == DGG_EMPTY_KEY) ok = false;
         else {
             const float d63 = c_log(fmaxf(key_val(k63), 1e-37f)) / t + 1e-5f;
@@ -674,8 +694,9 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
         }
     }
     if (ok) {
-        idx[lrow * 64 + lane] = key_col(list);
-        val[lrow * 64 + lane] = key_val(list);
+        const bool live = lane < Lr;                                    // (ranks beyond Lr are not settled: idx = -1, as dgg_klimit_truncate leaves them)
+        idx[lrow * 64 + lane] = live ? key_col(list) : -1;
+        val[lrow * 64 + lane] = live ? key_val(list) : 0.0f;
     } else if (lane == 0) {
         faillist[atomicAdd(&ctl->nfail, 1)] = (int)lrow;
     }
@@ -867,7 +888,7 @@ Layout make_layout(const Plan &p, int h) {
 }
 
 template <int H, int RBLK>
-int launch_sweep(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, int32_t *idx, float *val, void *ws, hipStream_t st) {
+int launch_sweep(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, const float *klim, int32_t *idx, float *val, void *ws, hipStream_t st) {
     const Plan p = make_plan(row1 - row0, N, H);
     const Layout L = make_layout(p, H);
     char *w = reinterpret_cast<char *>(ws);
@@ -887,15 +908,15 @@ int launch_sweep(const float *xp, int64_t N, int64_t row0, int64_t row1, float t
     if (g_stats && dgg_check_hip(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&ctl->stats_on), 1, 1, st), "sweep memset") != 0) return DGG_ERR_HIP;
     const int64_t rows = row1 - row0;
     hipLaunchKernelGGL(sw_prep<H>, dim3((unsigned)((p.npad + 3) / 4)), dim3(256), 0, st, xp, N, p.npad, xw, nb);
-    hipLaunchKernelGGL(sw_pilot<H>, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, st, xw, nb, row0, row1, p.ntiles, p.pt, g_guess_scale, tl);
+    hipLaunchKernelGGL(sw_pilot<H>, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, st, xw, nb, row0, row1, p.ntiles, p.pt, g_guess_scale, tl, klim, (int)env_float("DGG_SWEEP_KPAD", 0.0f));
     hipLaunchKernelGGL((sw_sweep<H, RBLK, true>), dim3((unsigned)(8 * p.rbx * p.csa)), dim3(256), 0, st, xw, tl, p.npad, row0, row1, p.nA, p.nrb, p.rbx, p.csa,
                        p.capa, (void *)la, cnta);
     const int m = g_select_m > 64 ? 64 : g_select_m;
-    hipLaunchKernelGGL(sw_select, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, la, cnta, rows, row0, p.csa, p.capa, p.rblk, m > 0 ? m : (1 << 30), nb, tl, tt, kept, keptn, ctl);
+    hipLaunchKernelGGL(sw_select, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, la, cnta, rows, row0, p.csa, p.capa, p.rblk, m > 0 ? m : (1 << 30), nb, tl, tt, kept, keptn, ctl, klim, (int)env_float("DGG_SWEEP_MPAD", 8.0f));
     hipLaunchKernelGGL((sw_sweep<H, RBLK, false>), dim3((unsigned)(8 * p.rbx * p.csb)), dim3(256), 0, st, xw, tt, p.npad, row0, row1, p.nB, p.nrb, p.rbx, p.csb,
                        p.capb, (void *)lb, cntb);
     hipLaunchKernelGGL(sw_finalize<H>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xp, nb, row0, row1, t, kept, keptn, lb, cntb, p.csb, p.capb,
-                       p.rblk, tt, ctl, faillist, idx, val);
+                       p.rblk, tt, ctl, faillist, idx, val, klim);
     hipLaunchKernelGGL(sw_fallback_part<H>, dim3(1024), dim3(256), 0, st, xp, N, row0, t, ctl, faillist, part);
     hipLaunchKernelGGL(sw_fallback_merge, dim3(1024), dim3(256), 0, st, ctl, faillist, part, idx, val);
     hipLaunchKernelGGL(sw_fallback_rows<H>, dim3(512), dim3(256), 0, st, xp, N, row0, t, ctl, faillist, idx, val);
@@ -912,7 +933,7 @@ bool dgg_allpairs_sweep_supported(int h, int noise_mode, int K) {
     return K == 64 && (h == 16 || h == 32 || h == 64 || h == 128) && noise_mode == 0;
 }
 
-int dgg_allpairs_topk_sweep_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int K, int32_t *idx, float *val,
+int dgg_allpairs_topk_sweep_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int K, const float *klim, int32_t *idx, float *val,
                                  void *workspace, size_t ws_bytes, hipStream_t st) {
     if (!dgg_allpairs_sweep_supported(h, 0, K))
         return dgg_set_error(DGG_ERR_UNSUPPORTED, "unperturbed sweep needs K=64 and latent_dim in {16,32,64,128}");
@@ -920,9 +941,9 @@ int dgg_allpairs_topk_sweep_impl(const float *xp, int64_t N, int h, int64_t row0
     if (!workspace || ws_bytes < dgg_allpairs_sweep_ws_bytes(row1 - row0, N, h))
         return dgg_set_error(DGG_ERR_ARG, "unperturbed sweep: workspace too small (dgg_allpairs_workspace_bytes)");
     switch (h) {
-        case 16: return launch_sweep<16, 4>(xp, N, row0, row1, t, idx, val, workspace, st);
-        case 32: return launch_sweep<32, 4>(xp, N, row0, row1, t, idx, val, workspace, st);
-        case 64: return launch_sweep<64, 4>(xp, N, row0, row1, t, idx, val, workspace, st);
-        default: return launch_sweep<128, 2>(xp, N, row0, row1, t, idx, val, workspace, st);
+        case 16: return launch_sweep<16, 4>(xp, N, row0, row1, t, klim, idx, val, workspace, st);
+        case 32: return launch_sweep<32, 4>(xp, N, row0, row1, t, klim, idx, val, workspace, st);
+        case 64: return launch_sweep<64, 4>(xp, N, row0, row1, t, klim, idx, val, workspace, st);
+        default: return launch_sweep<128, 2>(xp, N, row0, row1, t, klim, idx, val, workspace, st);
     }
 }

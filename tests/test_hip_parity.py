@@ -633,6 +633,19 @@ def test_full_size_unperturbed_sweep(dev, clustered):
     for lo, hi in [(0, 300), (22_900, 23_412), (99_700, N)]:
         sub_i, sub_v = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_NONE, rows=(lo, hi))
         assert torch.equal(sub_i, idx[lo:hi]) and torch.equal(sub_v, val[lo:hi])
+    # with the learned degrees (k_limit) the sweep settles only the ranks that carry weight -- radius, candidate lists and the
+    # verification scale with ceil(k_i + 8.5) + 1 -- and must return exactly the leading ranks of the full result
+    k = (4 + 40 * torch.rand(N, generator=g)).to(dev)
+    ki, kv, ws2 = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_NONE, k_limit=k, return_ws=True)
+    nfail2 = ops.fast_path_failed_rows(ws2, N, h)
+    print(f"clustered={clustered}, k_limit: {nfail2} rows redone by the exhaustive fallback")
+    if not clustered:
+        assert nfail2 <= N // 500
+    live = torch.arange(K, device=dev)[None, :] < torch.minimum(torch.ceil(k + 8.5) + 1, torch.tensor(float(K), device=dev))[:, None]
+    assert torch.equal(ki, torch.where(live, idx, torch.full_like(idx, -1))), "k_limit changed the leading ranks"
+    assert torch.equal(kv, torch.where(live, val, torch.zeros_like(val)))
+    sub_i, sub_v = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_NONE, rows=(22_900, 23_412), k_limit=k[22_900:23_412].contiguous())
+    assert torch.equal(sub_i, ki[22_900:23_412]) and torch.equal(sub_v, kv[22_900:23_412])
 
 
 @pytest.mark.parametrize("clustered", [False, True])
