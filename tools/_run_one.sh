@@ -1,4 +1,7 @@
-cd $GRAFT_REPO_ROOT
-timeout 2000 python -m pytest tests -q -m gpu -k "unperturbed or k_limit or klimit or allpairs_topk_bit_exact or sharded or parallel" -s 2>&1 | grep -E "clustered=|passed|failed|^E  " | cut -c1-200
-python bench.py --noise none --steps 10 --warmup 3 --no-variants --cpu-rows -1 > gpurun_out/bench_none.json 2> /dev/null; python -c "
-import json; j=json.load(open('gpurun_out/bench_none.json')); print(j['ms_per_step'], j['roofline']['kernel_ms'])"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d /tmp/tr -o h -- python3 $GRAFT_REPO_ROOT/bench.py --noise none --steps 10 --warmup 3 --repeats 2 --cpu-rows -1 --no-variants > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT; python3 tools/kernel_stats.py /tmp/tr/h_results.db /tmp/ks.csv --skip-first 3 > /dev/null; python3 - <<'PY'
+import csv
+for r in list(csv.reader(open('/tmp/ks.csv')))[1:40]:
+    if 'sw_' in r[0]: print(r[0][18:50], r[1], r[3])
+PY
