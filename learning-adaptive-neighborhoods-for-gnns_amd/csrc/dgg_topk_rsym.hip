@@ -148,6 +148,35 @@ __device__ __forceinline__ float exact_score_known(const float *__restrict__ xi,
     return score_from_dist(c_sqrt(d2), t, true, G);
 }
 
+// exact score, or 0 when the partial distance over the first 32 features already puts the log-score below `bar`
+template <int H>
+__device__ __forceinline__ float exact_score_cut(const float *__restrict__ xi, const float *__restrict__ xp, int32_t j, float t, float G, float bar) {
+    const float4 *xj = reinterpret_cast<const float4 *>(xp + (int64_t)j * H);
+    float d2 = 0.0f;
+    auto chain = [&](int c8) {
+        float4 b0 = xj[2 * c8], b1 = xj[2 * c8 + 1];
+        float df;
+        df = __fadd_rn(xi[8 * c8 + 0], -b0.x); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 1], -b0.y); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 2], -b0.z); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 3], -b0.w); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 4], -b1.x); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 5], -b1.y); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 6], -b1.z); d2 = __fmaf_rn(df, df, d2);
+        df = __fadd_rn(xi[8 * c8 + 7], -b1.w); d2 = __fmaf_rn(df, df, d2);
+    };
+    constexpr int HEAD = H >= 64 ? 4 : H / 8;
+#pragma unroll
+    for (int c8 = 0; c8 < HEAD; c8++) chain(c8);
+    if (HEAD < H / 8) {
+        // log p' = G + log(exp(t dist) + 1e-8) decreases with the distance: evaluated at the lower bound (fast math; `bar` carries the margin)
+        if (G + __logf(__expf(t * sqrtf(d2)) + 1e-8f) < bar) return 0.0f;
+#pragma unroll
+        for (int c8 = HEAD; c8 < H / 8; c8++) chain(c8);
+    }
+    return score_from_dist(c_sqrt(d2), t, true, G);
+}
+
 // K1 / K3 / K5: one wavefront per owner walks its sequence in decreasing noise order.
 //   TIER 1: while G >= gminA (margin 1e-3): exact score of the pair -> own list of o (if o is a row of the shard); inbox of the
 //           partner (if it is one) when the log-score reaches gminA
@@ -203,7 +232,10 @@ __global__ __launch_bounds__(256) void rs_emit(const float *__restrict__ xp, int
             if (TIER == 1) {
                 const bool p_in = p >= row0 && p < row1;
                 if (own_in || p_in) {
-                    const float v = exact_score_known<H>(xo, xp, (int32_t)p, t, G);
+                    // the first 128 bytes of the partner's row bound the distance from below (the fmaf chain only grows): a pair whose
+                    // log-score cannot reach gminA even at that distance is of no use to either endpoint at this tier -- a row that
+                    // needs it has failed tier 1 and gets it again in tier 2 -- so its second half is never fetched (score 0)
+                    const float v = exact_score_cut<H>(xo, xp, (int32_t)p, t, G, gminA - 2e-3f);
                     if (own_in && s <= (uint32_t)CAPO) own[(o - row0) * CAPO + (s - 1)] = make_int2((int)p, __float_as_int(v));
                     if (p_in && __logf(v) >= gminA - 1e-3f) {
                         const int slot = atomicAdd(&cntT[p - row0], 1);
