@@ -200,6 +200,12 @@ __global__ __launch_bounds__(256) void rs_emit(const float *__restrict__ xp, int
         if (TIER == 1 && own_in && lane == 0) cntO[o - row0] = 0;
         return;
     }
+    // row shards: an owner outside the shard matters only if one of its partners o + 1 .. o + n (mod N) is a row of the shard, i.e.
+    // if the shard's first row lies within n steps ahead of it -- the other owners (up to 3/8 of them on a rank of 8) do not walk
+    if (!own_in) {
+        const int64_t d0 = row0 > o ? row0 - o : row0 - o + N;
+        if (d0 > n) return;
+    }
     const float gminA = ctl->gminA;
     const float tau = TIER == 3 ? -INFINITY : (TIER == 2 ? from_ordered_int(ctl->need_min) : gminA) - 1e-3f;
     int so = -1;
