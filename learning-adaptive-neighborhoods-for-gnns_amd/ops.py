@@ -153,6 +153,16 @@ def linear_fwd_multi(x, layers):
     x = _chk(x)
     N, d = x.shape
     outs = [(W.shape[0] if lay == 0 else W.shape[1]) for W, _, _, lay in layers]
+    if len(layers) > 1 and sum(outs) > 256 and not any(o % 32 for o in outs) and max(outs) <= 256:
+        # wider than one fused pass (latent 128: xp 128 + H 64 + xk 128): consecutive groups of at most 256 columns, one pass each
+        res, grp, tot = [], [], 0
+        for lay_, o in zip(layers, outs):
+            if grp and tot + o > 256:
+                res += linear_fwd_multi(x, grp)
+                grp, tot = [], 0
+            grp.append(lay_)
+            tot += o
+        return res + linear_fwd_multi(x, grp)
     if len(layers) > 8 or any(o % 32 for o in outs) or sum(outs) > 256 or sum(outs) == 224:
         return [linear_fwd(x, W, b, act, lay) for W, b, act, lay in layers]
     # nn.Linear layout [out, d] stacked by rows (a [d, out] weight enters transposed); missing biases are zeros
@@ -176,6 +186,15 @@ def linear_bwd_multi(x, layers):
     x = _chk(x)
     N, d = x.shape
     outs = [(W.shape[0] if lay == 0 else W.shape[1]) for W, _, _, _, lay, _ in layers]
+    if len(layers) > 1 and sum(outs) > 256 and d <= 128 and not any(o % 32 for o in outs) and max(outs) <= 256:
+        res, grp, tot = [], [], 0                            # (as linear_fwd_multi: groups of at most 256 columns)
+        for lay_, o in zip(layers, outs):
+            if grp and tot + o > 256:
+                res += linear_bwd_multi(x, grp)
+                grp, tot = [], 0
+            grp.append(lay_)
+            tot += o
+        return res + linear_bwd_multi(x, grp)
     if len(layers) > 8 or any(o % 32 for o in outs) or sum(outs) > 256 or d > 128:
         res = []
         for W, y, dy, act, lay, need_db in layers:
