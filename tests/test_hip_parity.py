@@ -121,7 +121,7 @@ def _rsym_env(**kw):
 
 
 @pytest.mark.parametrize("N,h", [(1, 16), (2, 8), (3, 16), (64, 16), (65, 32), (700, 64), (1024, 64), (1025, 64), (2500, 32),
-                                 (4099, 128), (9000, 64)])
+                                 (4099, 128), (9000, 64), (3001, 16), (2048, 8)])
 def test_allpairs_topk_ranked_symmetric_noise_bit_exact(dev, N, h):
     """ranked SYMMETRIC noise generator (noise_mode 5; the reference's symmetric_noise=True, dgm.py:1216-1223): owners emit their
     largest noises, rows settle own list + inbox and verify (dgg_topk_rsym.hip) against the oracle, which writes out the whole
