@@ -112,12 +112,14 @@ int dgg_knet_x_fwd(const float *xk, int64_t N, int h, const float *deg, const fl
  * as dgg_knet_x_fwd. */
 int dgg_knet_x_fwd_mfma(const float *xk, int64_t N, int h, const float *deg, const float *mu_sd, const float *W1, const float *b1,
                         const float *Wmu, const float *bmu, const float *Wp, const float *bp, float *k, float *u_save, void *stream);
-/* Backward in ONE pass over xk (layer 1 is re-run): dxk [N,h] is OVERWRITTEN and every parameter gradient is formed inside the kernel:
- * gW1 [h2, h+1] (k_embed.0.weight), gb1 [h2], gWmu [h4, h2] are ACCUMULATED into (caller zeroes them and the scratch gv [h2], gS0 [1]);
- * gbmu [h4], gWp [h4], gbp [1] are OVERWRITTEN. */
-int dgg_knet_x_bwd_mfma(const float *xk, int64_t N, int h, const float *deg, const float *mu_sd, const float *W1, const float *b1,
-                        const float *Wmu, const float *bmu, const float *Wp, const float *u, const float *dk, float *dxk, float *gW1,
-                        float *gb1, float *gWmu, float *gbmu, float *gWp, float *gbp, float *gv, float *gS0, void *stream);
+/* Backward in ONE pass over xk (layer 1 is re-run): dxk [N,h] and every parameter gradient -- gW1 [h2, h+1] (k_embed.0.weight), gb1 [h2],
+ * gWmu [h4, h2], gbmu [h4], gWp [h4], gbp [1] -- are OVERWRITTEN (weight-gradient partials leave the kernel as one plain-store slab per
+ * workgroup, a reduce launch sums them and runs the parameter-sized tail; no float atomics, nothing to zero).  ws:
+ * dgg_knet_x_bwd_ws_bytes bytes of scratch (0: width not supported).  xk, dxk 16-byte aligned. */
+size_t dgg_knet_x_bwd_ws_bytes(int64_t N, int h);
+int dgg_knet_x_bwd_reg(const float *xk, int64_t N, int h, const float *deg, const float *mu_sd, const float *W1, const float *b1,
+                       const float *Wmu, const float *bmu, const float *Wp, const float *u, const float *dk, float *dxk, float *gW1,
+                       float *gb1, float *gWmu, float *gbmu, float *gWp, float *gbp, void *ws, void *stream);
 /* per-node part of the backward: dk -> dkp [N], dm [N,h4], dpre1 [N,h2], dxk [N,h], m [N,h4] (recomputed) */
 int dgg_knet_x_bwd_nodes(int64_t N, int h, const float *mu_sd, const float *W1, int h2, const float *Wmu, int h4,
                          const float *Wp, const float *bmu, const float *z, const float *u, const float *dk, float *dkp,
@@ -330,6 +332,11 @@ int dgg_partp_build(const int32_t *idx, const float *w, const float *val, const 
 /* dgg_partp_build with dgg_ell_normalize_fwd fused: rs_all [ncols] = row sums of every node -> ahat [rows,K] (same bits) */
 int dgg_partp_build_norm(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
                          const float *rs_all, float *ahat, void *ws, void *stream);
+/* Where the pieces of a built payload partition live inside its workspace (byte offsets; for tests and tools that want to look at the
+ * records): out[0] = bucket starts (int32 [nb+1]), out[1] = CSC node pointer (int32 [ncols+1]: the records of destination node j are
+ * recs[nodeptr[j] .. nodeptr[j+1])), out[2] = records in node order (16 bytes each: row*64 + r, j, bits of w_ir rs_i^-1/2, bits of the
+ * score), out[3] = number of buckets, out[4] = log2 of the bucket width in nodes, out[5] = rows per counting workgroup. */
+int dgg_partp_describe(int64_t rows, int K, int64_t ncols, int64_t *out6);
 /* dgg_ell_conv_bwd_part on a payload partition (ahat_ir = record payload * rs_j^-1/2, bit-identical to dgg_ell_normalize_fwd);
  * also writes dA_rec [rows*K] = dA in record order.  dA, dH, da: caller zeroes. */
 int dgg_ell_conv_bwd_partp(const float *G, const float *H, int64_t rows, int K, int F, const void *partp_ws, int64_t ncols,

@@ -24,7 +24,8 @@ PROTOTYPES = {
     "dgg_degree_stats_ws_bytes": [],
     "dgg_knet_x_fwd": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_knet_x_fwd_mfma": [_vp, _i64, _i32] + [_vp] * 10 + [_vp],
-    "dgg_knet_x_bwd_mfma": [_vp, _i64, _i32] + [_vp] * 18 + [_vp],
+    "dgg_knet_x_bwd_reg": [_vp, _i64, _i32] + [_vp] * 16 + [_vp, _vp],
+    "dgg_knet_x_bwd_ws_bytes": [_i64, _i32],
     "dgg_knet_x_bwd_nodes": [_i64, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_knet_input_deg_fwd": [_vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "dgg_knet_feat": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
@@ -80,6 +81,7 @@ PROTOTYPES = {
                                 _vp, _vp, _vp],
     "dgg_ell_conv_bwd_part": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "dgg_partp_ws_bytes": [_i64, _i32, _i64],
+    "dgg_partp_describe": [_i64, _i32, _i64, _vp],
     "dgg_partp_build": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp],
     "dgg_partp_build_norm": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp],
     "dgg_ell_conv_bwd_partp": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -124,7 +126,7 @@ def lib():
             fn = getattr(L, name)      # AttributeError if the library does not export a declared symbol
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        for name in ("dgg_allpairs_workspace_bytes", "dgg_allpairs_sweep_ctl_offset_bytes", "dgg_allpairs_rsym_ctl_offset_bytes", "dgg_gemm_tn_ws_floats", "dgg_gemm_tn_multi_ws_floats", "dgg_linear_bwd_ws_floats", "dgg_part_ws_bytes", "dgg_partp_ws_bytes",
+        for name in ("dgg_allpairs_workspace_bytes", "dgg_allpairs_sweep_ctl_offset_bytes", "dgg_allpairs_rsym_ctl_offset_bytes", "dgg_gemm_tn_ws_floats", "dgg_gemm_tn_multi_ws_floats", "dgg_linear_bwd_ws_floats", "dgg_part_ws_bytes", "dgg_partp_ws_bytes", "dgg_knet_x_bwd_ws_bytes",
                      "dgg_degree_stats_ws_bytes"):
             getattr(L, name).restype = C.c_size_t
         _lib = L

@@ -266,168 +266,189 @@ __global__ __launch_bounds__(64) void knet_x_bwd_tpn(
 // ---- the k-net (mode "x") on the fp32 MATRIX cores ---------------------------------------------------------------------------
 // k_embed (Linear(h+1, h/2) + LeakyReLU) -> k_mu (Linear(h/2, h/4)) -> k_project (Linear(h/4, 1)) is a small MLP over N nodes: the
 // thread-per-node kernels above run it at 9 % of the fp32 vector peak (52 + 45 us per step at N = 100k) and hand z, [xk | nd], dkp,
-// dm, dpre1 and m through HBM to three weight-gradient GEMMs (+ 45 us, 160 MB in all).  Here a wavefront owns 64 nodes at a time
+// dm, dpre1 and m through HBM to three weight-gradient GEMMs (+ 45 us, 160 MB in all).  Here a wavefront owns 32 nodes at a time
 // and every layer is a chain of v_mfma_f32_32x32x2_f32 (an exact k-ordered fmaf chain, so k comes out bit-identical):
-//   D[o][n] += W[o][c] * act[n][c]:  first operand = the layer's weights, held in registers in operand order for the whole kernel
-//   (lane (li, hh) of step s holds W[li][2s + hh]; the bias rides as one more contraction step against a column of ones);
-//   second operand = the activations, read from an LDS tile; an accumulator register r of lane (li, hh) is output feature
-//   (r & 3) + 8 (r >> 2) + 4 hh of node li.
-// Backward (knet_x_bwd_mfma): layer 1 is re-run from xk (the forward saves only u); dz and d feat are MFMA chains whose second
+//   D[o][n] += W[o][c] * act[n][c]:  first operand = the layer's weights in operand order (lane (li, hh) of step s holds
+//   W[li][2s + hh]; the bias rides as one more contraction step against a column of ones); second operand = the activations of node
+//   li; an accumulator register r of lane (li, hh) is output feature (r & 3) + 8 (r >> 2) + 4 hh of node li.
+// Backward (knet_x_bwd_reg): layer 1 is re-run from xk (the forward saves only u); dz and d feat are MFMA chains whose second
 // operands are computed on the fly / ARE the previous chain's accumulator registers (the contraction index is walked in the
-// accumulator's own order); the weight gradients are contractions over the 64 nodes of the group, accumulated in registers over all
-// the groups of a wavefront:
+// accumulator's own order); the weight gradients are contractions over the 32 nodes of the block, accumulated in registers over all
+// the blocks of a wavefront:
 //   G1 [h/2 x (h+2)]   = sum_n dpre1_n (x) [xk_n | nd_n | 1]   -> dW1 and (ones column) db1
 //   G2 [(h/4+1) x h/2] = sum_n [dm_n ; dkp_n] (x) z_n          -> dWmu and v = sum_n dkp_n z_n
-//   dbp = S0 = sum dkp,  dbmu = Wp S0,  dWp = Wmu v + bmu S0   (dm_n = dkp_n Wp, m_n = Wmu z_n + bmu; knet_mfma_finish)
+//   dbp = S0 = sum dkp,  dbmu = Wp S0,  dWp = Wmu v + bmu S0   (dm_n = dkp_n Wp, m_n = Wmu z_n + bmu; knet_bwd_reduce)
 typedef float kf32x16 __attribute__((ext_vector_type(16)));
+// Round 4: the forward with the node rows in REGISTERS.  Round 3 staged every 64-node group through a 26 KB LDS tile per wavefront (one
+// workgroup per CU, one wavefront per SIMD, nothing to hide the load -> LDS -> MFMA chain behind: MFMA-busy 0.11, 29 us for a
+// 33 MB stream).  Here a wavefront owns ONE block of 32 nodes:
+//  * layer-1 operand (node li, k = 2s + half): lane (li, half) loads the contiguous half row [half*H/2, (half+1)*H/2) with 16-byte
+//    loads; one v_permlane32_swap per register pair turns (reg 2t, reg 2t+1) into the operands of steps t and H/4 + t
+//    (linear_fwd_reg's trick, dgg_linear.hip);
+//  * layer-2 operand (node li, k = 2s + half) out of the layer-1 ACCUMULATOR: lane (li, half) holds outputs o = (r&3) + 8(r>>2) +
+//    4 half; after one swap per register pair (r, r+1), r even, the lower half holds the even outputs o(r), o(r) + 4 and the
+//    upper half the odd ones o(r) + 1, o(r) + 5 -- exactly what the k-ordered chain of the next layer wants from each half.
+// Same k-ordered fmaf chains as the thread-per-node kernels: the same bits.  One block per wavefront, eight wavefronts per workgroup
+// (the weights reach the lanes through 13 KB of LDS, staged once per workgroup).  Measured at N = 100 000 (us): 18.7 against 29 for the
+// LDS-staged persistent form of round 3; of those, ~5 are the MFMA chain (not overlapped: every wavefront walks the same phases at the
+// same time), ~3 the row loads, ~5 launch + staging; a coalesced-load + LDS-transpose variant measured the same (20.1).
 template <int H>
-struct KnetTile {
-    static constexpr int H2 = H / 2, H4 = H / 4;
-    static constexpr int KS1 = (H + 2) / 2;                       // contraction steps of layer 1: h features, nd, bias
-    static constexpr int KS2 = (H2 + 2) / 2;                      // layer 2: h/2 features, bias (+ a zero)
-    static constexpr int NB = (H + 2 + 31) / 32;                  // 32-column blocks of [xk | nd | 1]
-    static constexpr int XS = NB * 32 + 1, ZS = 35;               // LDS row strides (odd: conflict-free row-per-lane accesses; 34 columns of z)
-    static_assert(H == 16 || H == 32 || H == 64, "MFMA k-net: latent_dim in {16, 32, 64}");
-};
-
-// the 64 x [xk | nd | 1 | 0..] tile of a node group, staged with coalesced 16-byte loads
-template <int H, int XS>
-__device__ __forceinline__ void knet_stage(const float *__restrict__ xk, const float *__restrict__ deg, int64_t N, int64_t g, float mu,
-                                            float sd, float *__restrict__ xt, int lane) {
-    constexpr int V4 = H / 4;
-#pragma unroll
-    for (int q = 0; q < V4; q++) {
-        const int e = q * 64 + lane, row = e / V4, c4 = e % V4;
-        const int64_t n = g * 64 + row;
-        const float4 v = n < N ? *reinterpret_cast<const float4 *>(xk + n * H + c4 * 4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        float *d = xt + row * XS + c4 * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    const int64_t n = g * 64 + lane;
-    xt[lane * XS + H] = n < N ? __fdiv_rn(__fadd_rn(deg[n], -mu), __fadd_rn(sd, 1e-5f)) : 0.0f;
-    xt[lane * XS + H + 1] = 1.0f;
-#pragma unroll
-    for (int c = H + 2; c < XS - 1; c++) xt[lane * XS + c] = 0.0f;
-}
-
-template <int H>
-__global__ __launch_bounds__(256, 1) void knet_x_fwd_mfma(const float *__restrict__ xk, int64_t N, const float *__restrict__ deg,
-                                                         const float *__restrict__ mu_sd, const float *__restrict__ W1,
-                                                         const float *__restrict__ b1, const float *__restrict__ Wmu,
-                                                         const float *__restrict__ bmu, const float *__restrict__ Wp,
-                                                         const float *__restrict__ bp, float *__restrict__ k, float *__restrict__ u_save) {
-    using KT = KnetTile<H>;
-    constexpr int H2 = KT::H2, H4 = KT::H4, KS1 = KT::KS1, KS2 = KT::KS2, XS = H + 3, ZS = KT::ZS;
-    // (measured: two-wavefront workgroups, three per CU, are 3 us slower than this persistent form, one workgroup per CU)
-    __shared__ float sm[4 * (64 * XS + 64 * ZS)];
+__global__ __launch_bounds__(512) void knet_x_fwd_reg(const float *__restrict__ xk, int64_t N, const float *__restrict__ deg,
+                                                      const float *__restrict__ mu_sd, const float *__restrict__ W1,
+                                                      const float *__restrict__ b1, const float *__restrict__ Wmu,
+                                                      const float *__restrict__ bmu, const float *__restrict__ Wp,
+                                                      const float *__restrict__ bp, float *__restrict__ k, float *__restrict__ u_save) {
+    constexpr int H2 = H / 2, H4 = H / 4, XR = H / 2, S1 = H / 2 + 1, S2 = H2 / 2 + 1;
+    // the weights in operand order, once per workgroup of eight wavefronts
+    __shared__ float wsh[(S1 + S2) * 64];
     const int lane = threadIdx.x & 63, wave = dgg::wave_id(), li = lane & 31, hh = lane >> 5;
-    float *xt = sm + wave * (64 * XS + 64 * ZS), *zt = xt + 64 * XS;
-    const float mu = mu_sd[0], sd = mu_sd[1];
-    // weights in operand order (first operand: lane (li, hh) of step s supplies W[li][2 s + hh])
-    float w1[KS1], w2[KS2];
+    constexpr int WAVES = 8;
+    const int64_t blk = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t n = blk * 32 + li;
+    const bool valid = n < N;
+    const int64_t nc = valid ? n : N - 1;
+    float xc[XR];
+    {                                                            // (in flight across the staging and its barrier)
+        const float4 *p = reinterpret_cast<const float4 *>(xk + nc * H + hh * (H / 2));
 #pragma unroll
-    for (int sI = 0; sI < KS1; sI++) {
-        const int c = 2 * sI + hh;
-        w1[sI] = li < H2 ? (c <= H ? W1[li * (H + 1) + c] : b1[li]) : 0.0f;
-    }
-#pragma unroll
-    for (int sI = 0; sI < KS2; sI++) {
-        const int c = 2 * sI + hh;
-        w2[sI] = li < H4 ? (c < H2 ? Wmu[li * H2 + c] : (c == H2 ? bmu[li] : 0.0f)) : 0.0f;
-    }
-    const int64_t ngroups = (N + 63) / 64;
-    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < ngroups; g += (int64_t)gridDim.x * 4) {
-        knet_stage<H, XS>(xk, deg, N, g, mu, sd, xt, lane);
-#pragma unroll
-        for (int blk = 0; blk < 2; blk++) {
-            kf32x16 a1;
-#pragma unroll
-            for (int r = 0; r < 16; r++) a1[r] = 0.0f;
-            float xb[KS1];                                        // operands first, then the chain: the LDS latency is paid once
-#pragma unroll
-            for (int sI = 0; sI < KS1; sI++) xb[sI] = xt[(blk * 32 + li) * XS + 2 * sI + hh];
-#pragma unroll
-            for (int sI = 0; sI < KS1; sI++) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[sI], xb[sI], a1, 0, 0, 0);
-            // z = leaky(pre1), transposed through LDS into operand order for layer 2 (+ the ones column of its bias step)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int o = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float z = a1[r] > 0.0f ? a1[r] : __fmul_rn(0.01f, a1[r]);
-                if (o < H2) zt[(blk * 32 + li) * ZS + o] = z;
-            }
-            if (hh == 0) zt[(blk * 32 + li) * ZS + H2] = 1.0f;
-            if (hh == 1 && H2 + 1 < 2 * KS2) zt[(blk * 32 + li) * ZS + H2 + 1] = 0.0f;
-            kf32x16 a2;
-#pragma unroll
-            for (int r = 0; r < 16; r++) a2[r] = 0.0f;
-            float zb[KS2];
-#pragma unroll
-            for (int sI = 0; sI < KS2; sI++) zb[sI] = zt[(blk * 32 + li) * ZS + 2 * sI + hh];
-#pragma unroll
-            for (int sI = 0; sI < KS2; sI++) a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[sI], zb[sI], a2, 0, 0, 0);
-            // k_project: one lane per node gathers the h/4 values of m (its own rows and the other half's) and runs the ascending chain
-            float m[16];
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const float other = __uint_as_float(dgg::xor_shfl<32>(__float_as_uint(a2[r]), lane));
-                const int a_mine = (r & 3) + 8 * (r >> 2) + 4 * hh, a_oth = (r & 3) + 8 * (r >> 2) + 4 * (1 - hh);
-                m[a_mine & 15] = a2[r];
-                m[a_oth & 15] = other;
-            }
-            float ak = 0.0f;
-#pragma unroll
-            for (int o = 0; o < H4; o++) ak = __fmaf_rn(m[o], Wp[o], ak);
-            const float kp = __fadd_rn(ak, bp[0]);
-            const float u = __fadd_rn(__fmul_rn(kp, sd), mu);
-            const int64_t n = g * 64 + blk * 32 + li;
-            if (hh == 0 && n < N) {
-                k[n] = __fadd_rn(u > 0.0f ? u : 0.0f, 1.0f);
-                if (u_save) u_save[n] = u;
-            }
+        for (int q = 0; q < XR / 4; q++) {
+            const float4 v = p[q];
+            xc[4 * q] = v.x; xc[4 * q + 1] = v.y; xc[4 * q + 2] = v.z; xc[4 * q + 3] = v.w;
         }
     }
+    const float dg = deg[nc];
+    const float mu = mu_sd[0], sd = mu_sd[1];
+    for (int e = threadIdx.x; e < (S1 + S2) * 64; e += WAVES * 64) {
+        const int l = e & 63, sI = e >> 6, o = l & 31, c = 2 * (sI < S1 ? sI : sI - S1) + (l >> 5);
+        float v;
+        if (sI < S1) v = o < H2 ? (c <= H ? W1[o * (H + 1) + c] : b1[o]) : 0.0f;
+        else v = o < H4 ? (c < H2 ? Wmu[o * H2 + c] : (c == H2 ? bmu[o] : 0.0f)) : 0.0f;
+        wsh[e] = v;
+    }
+    __syncthreads();
+    if (blk * 32 >= N) return;
+    float w1[S1], w2[S2];
+#pragma unroll
+    for (int sI = 0; sI < S1; sI++) w1[sI] = wsh[sI * 64 + lane];
+#pragma unroll
+    for (int sI = 0; sI < S2; sI++) w2[sI] = wsh[(S1 + sI) * 64 + lane];
+    float wp[H4];
+#pragma unroll
+    for (int o = 0; o < H4; o++) wp[o] = Wp[o];
+    const float bpv = bp[0];
+#pragma unroll
+    for (int t = 0; t < XR / 2; t++) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(xc[2 * t]), __float_as_uint(xc[2 * t + 1]), false, false);
+        xc[2 * t] = __uint_as_float(r[0]);                       // operand of step t        (k = 2t + half)
+        xc[2 * t + 1] = __uint_as_float(r[1]);                   // operand of step H/4 + t  (k = H/2 + 2t + half)
+    }
+    const float nd = __fdiv_rn(__fadd_rn(dg, -mu), __fadd_rn(sd, 1e-5f));
+    kf32x16 a1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) a1[r] = 0.0f;
+#pragma unroll
+    for (int sI = 0; sI < S1 - 1; sI++)
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[sI], sI < H / 4 ? xc[2 * sI] : xc[2 * (sI - H / 4) + 1], a1, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[S1 - 1], hh == 0 ? nd : 1.0f, a1, 0, 0, 0);      // k = H: nd, k = H + 1: the bias
+    float zs[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) zs[r] = a1[r] > 0.0f ? a1[r] : __fmul_rn(0.01f, a1[r]);
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(zs[r]), __float_as_uint(zs[r + 1]), false, false);
+        zs[r] = __uint_as_float(q[0]);                           // lower half: o(r)      upper half: o(r) + 1
+        zs[r + 1] = __uint_as_float(q[1]);                       // lower half: o(r) + 4  upper half: o(r) + 5
+    }
+    kf32x16 a2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) a2[r] = 0.0f;
+#pragma unroll
+    for (int sI = 0; sI < S2 - 1; sI++) {
+        const int o = 2 * sI;                                    // (the lower half's k; the upper half's k = o + 1 sits in the same register)
+        const int pr = 4 * (o >> 3) + (o & 2);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[sI], (o & 4) ? zs[pr + 1] : zs[pr], a2, 0, 0, 0);
+    }
+    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[S2 - 1], hh == 0 ? 1.0f : 0.0f, a2, 0, 0, 0);     // k = H2: the bias
+    // k_project: one lane per node gathers the h/4 values of m (its own rows and the other half's) and runs the ascending chain
+    float m[16];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float other = __uint_as_float(dgg::xor_shfl<32>(__float_as_uint(a2[r]), lane));
+        const int a_mine = (r & 3) + 8 * (r >> 2) + 4 * hh, a_oth = (r & 3) + 8 * (r >> 2) + 4 * (1 - hh);
+        m[a_mine & 15] = a2[r];
+        m[a_oth & 15] = other;
+    }
+    float ak = 0.0f;
+#pragma unroll
+    for (int o = 0; o < H4; o++) ak = __fmaf_rn(m[o], wp[o], ak);
+    const float kp = __fadd_rn(ak, bpv);
+    const float u = __fadd_rn(__fmul_rn(kp, sd), mu);
+    if (hh == 0 && valid) {
+        k[n] = __fadd_rn(u > 0.0f ? u : 0.0f, 1.0f);
+        if (u_save) u_save[n] = u;
+    }
 }
 
+// The backward with the layer-1 operands in registers (as knet_x_fwd_reg), 32-node blocks, two wavefronts per SIMD, and the
+// weight-gradient partials leaving the kernel as PLAIN stores (one slab per workgroup; round 3: 2.2k same-address float atomics from
+// each of 256 workgroups); knet_bwd_reduce sums the slabs and runs the parameter-sized tail (dbp, dbmu, dWp).
+// Measured at N = 100 000 (us): 32.2 + 7.5 against 67.6 + 4.8 for round 3's LDS-staged, one-wavefront-per-SIMD form.
+// LDS per wavefront: the two 32 x 33 transposition tiles (dpre1 / z, node-major: first operands of G1 / G2), the block's rows
+// [32][68] (second operand of G1, read by column) and nd / dkp of its 32 nodes; W1 in accumulator order once per workgroup.
 template <int H>
-__global__ __launch_bounds__(256, 1) void knet_x_bwd_mfma(const float *__restrict__ xk, int64_t N, const float *__restrict__ deg,
+struct KnetBwd {
+    static constexpr int H2 = H / 2, H4 = H / 4, NB = (H + 2 + 31) / 32, NBX = H / 32 > 0 ? H / 32 : 1;
+    static constexpr int XS = H + 4;                              // row stride of the X tile (16-byte aligned rows, conflict-free b128 writes)
+    static constexpr int WAVE_F = 2 * 32 * 33 + 32 * XS + 64;     // floats of LDS per wavefront
+    static constexpr int W1B_F = NBX * 16 * 64;                   // W1 in accumulator order, shared by the workgroup
+    static constexpr int NREG = (NB + 1) * 16;                    // accumulator registers of a wavefront's partial sums (G1 blocks, G2)
+    static constexpr int SLAB_F = (NREG + 1) * 64;                // + the per-lane partial of S0
+};
+
+template <int H>
+__global__ __launch_bounds__(256, 2) void knet_x_bwd_reg(const float *__restrict__ xk, int64_t N, const float *__restrict__ deg,
                                                          const float *__restrict__ mu_sd, const float *__restrict__ W1,
                                                          const float *__restrict__ b1, const float *__restrict__ Wmu,
                                                          const float *__restrict__ Wp, const float *__restrict__ u,
-                                                         const float *__restrict__ dk, float *__restrict__ dxk, float *__restrict__ gW1,
-                                                         float *__restrict__ gb1, float *__restrict__ gWmu, float *__restrict__ gv,
-                                                         float *__restrict__ gS0) {
-    using KT = KnetTile<H>;
-    constexpr int H2 = KT::H2, H4 = KT::H4, KS1 = KT::KS1, NB = KT::NB, XS = KT::XS, ZS = KT::ZS;
-    constexpr int NBX = H / 32 > 0 ? H / 32 : 1;                  // 32-column blocks of dxk (h = 16: one, half used)
+                                                         const float *__restrict__ dk, float *__restrict__ dxk, float *__restrict__ slab) {
+    using KB = KnetBwd<H>;
+    constexpr int H2 = KB::H2, H4 = KB::H4, NB = KB::NB, NBX = KB::NBX, XS = KB::XS, XR = H / 2, S1 = H / 2 + 1;
     constexpr int KS3 = (H4 + 1) / 2;                             // dz: contraction over the h/4 outputs of k_mu
-    constexpr int PER = (NB + 1) * 16 + 1;
-    constexpr int TILE = 64 * XS + 64 * ZS + 64;
-    __shared__ float sm[(4 * TILE > 4 * PER * 64) ? 4 * TILE : 4 * PER * 64];
-    const int lane = threadIdx.x & 63, wave = dgg::wave_id(), li = lane & 31, hh = lane >> 5;
-    float *xt = sm + wave * TILE, *tt = xt + 64 * XS, *dkl = tt + 64 * ZS;
-    const float mu = mu_sd[0], sd = mu_sd[1];
-    float w1[KS1];                                                // layer 1, forward order
-#pragma unroll
-    for (int sI = 0; sI < KS1; sI++) {
-        const int c = 2 * sI + hh;
-        w1[sI] = li < H2 ? (c <= H ? W1[li * (H + 1) + c] : b1[li]) : 0.0f;
+    constexpr int RED_F = 4 * KB::SLAB_F;
+    constexpr int LDS_F = (4 * KB::WAVE_F + KB::W1B_F) > RED_F ? (4 * KB::WAVE_F + KB::W1B_F) : RED_F;
+    __shared__ __attribute__((aligned(16))) float sm[LDS_F];
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), li = lane & 31, hh = lane >> 5;
+    float *t1 = sm + wave * KB::WAVE_F, *t2 = t1 + 32 * 33, *xt = t2 + 32 * 33, *ndl = xt + 32 * XS, *dkl = ndl + 32;
+    float *w1b = sm + 4 * KB::WAVE_F;                             // [cb][sI][lane] = W1[o(sI, half)][cb*32 + li]
+    for (int e = tid; e < KB::W1B_F; e += 256) {
+        const int l = e & 63, sI = (e >> 6) & 15, cb = e >> 10;
+        const int o = (sI & 3) + 8 * (sI >> 2) + 4 * (l >> 5), c = cb * 32 + (l & 31);
+        w1b[e] = (o < H2 && c < H) ? W1[o * (H + 1) + c] : 0.0f;
     }
+    const float mu = mu_sd[0], sd = mu_sd[1];
+    // layer 1 (forward order) and Wmu^T in operand order, staged once per workgroup in the wavefronts' tile space (read back into
+    // registers before the first block overwrites it)
+    float *stg = sm;                                              // [S1 + KS3][64]
+    for (int e = tid; e < (S1 + KS3) * 64; e += 256) {
+        const int l = e & 63, sI = e >> 6, o = l & 31, hq = l >> 5;
+        float v;
+        if (sI < S1) { const int c = 2 * sI + hq; v = o < H2 ? (c <= H ? W1[o * (H + 1) + c] : b1[o]) : 0.0f; }
+        else { const int a = 2 * (sI - S1) + hq; v = (o < H2 && a < H4) ? Wmu[a * H2 + o] : 0.0f; }
+        stg[e] = v;
+    }
+    __syncthreads();
+    float w1[S1];
+#pragma unroll
+    for (int sI = 0; sI < S1; sI++) w1[sI] = stg[sI * 64 + lane];
     float wmt[KS3], wp2[KS3];                                     // dz[o][n] += Wmu[a][o] * dm[n][a]: first operand Wmu^T, second dkp * Wp[a]
 #pragma unroll
     for (int sI = 0; sI < KS3; sI++) {
         const int a = 2 * sI + hh;
-        wmt[sI] = (li < H2 && a < H4) ? Wmu[a * H2 + li] : 0.0f;
+        wmt[sI] = stg[(S1 + sI) * 64 + lane];
         wp2[sI] = a < H4 ? Wp[a] : 0.0f;
     }
-    float w1b[NBX][16];                                           // d feat[c][n] += W1[o][c] * dpre1[n][o], o walked in accumulator order
-#pragma unroll
-    for (int cb = 0; cb < NBX; cb++)
-#pragma unroll
-        for (int sI = 0; sI < 16; sI++) {
-            const int o = (sI & 3) + 8 * (sI >> 2) + 4 * hh, c = cb * 32 + li;
-            w1b[cb][sI] = (o < H2 && c < H) ? W1[o * (H + 1) + c] : 0.0f;
-        }
     const float fa = li < H4 ? Wp[li] : (li == H4 ? 1.0f : 0.0f);   // G2 first operand = fa * dkp[n]: rows dm (a < h/4) and dkp (a = h/4)
+    __syncthreads();                                              // staging space is tile space from here on
     kf32x16 g1[NB], g2;
 #pragma unroll
     for (int a = 0; a < NB; a++)
@@ -436,141 +457,185 @@ __global__ __launch_bounds__(256, 1) void knet_x_bwd_mfma(const float *__restric
 #pragma unroll
     for (int r = 0; r < 16; r++) g2[r] = 0.0f;
     float s0 = 0.0f;
-    const int64_t ngroups = (N + 63) / 64;
-    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < ngroups; g += (int64_t)gridDim.x * 4) {
-        knet_stage<H, XS>(xk, deg, N, g, mu, sd, xt, lane);
-        kf32x16 zacc[2];
+    __syncthreads();                                              // w1b
+    const int64_t nblk = (N + 31) / 32;
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + wave; blk < nblk; blk += (int64_t)gridDim.x * 4) {
+        const int64_t n = blk * 32 + li;
+        const bool valid = n < N;
+        const int64_t nc = valid ? n : N - 1;
+        float xc[XR];
+        {
+            const float4 *p = reinterpret_cast<const float4 *>(xk + nc * H + hh * (H / 2));
 #pragma unroll
-        for (int blk = 0; blk < 2; blk++) {
-            const int64_t n = g * 64 + blk * 32 + li;
-            const bool valid = n < N;
-            kf32x16 a1;
-#pragma unroll
-            for (int r = 0; r < 16; r++) a1[r] = 0.0f;
-            float xb[KS1];                                        // operands first, then the chain: the LDS latency is paid once
-#pragma unroll
-            for (int sI = 0; sI < KS1; sI++) xb[sI] = xt[(blk * 32 + li) * XS + 2 * sI + hh];
-#pragma unroll
-            for (int sI = 0; sI < KS1; sI++) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[sI], xb[sI], a1, 0, 0, 0);
-            const float dkp = (valid && u[valid ? n : 0] > 0.0f) ? dk[n] * sd : 0.0f;
-            if (hh == 0) { s0 += dkp; dkl[blk * 32 + li] = dkp; }
-            kf32x16 dz;
-#pragma unroll
-            for (int r = 0; r < 16; r++) dz[r] = 0.0f;
-#pragma unroll
-            for (int sI = 0; sI < KS3; sI++) dz = __builtin_amdgcn_mfma_f32_32x32x2f32(wmt[sI], dkp * wp2[sI], dz, 0, 0, 0);
-            kf32x16 dp1;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float z = a1[r] > 0.0f ? a1[r] : 0.01f * a1[r];
-                zacc[blk][r] = z;
-                dp1[r] = a1[r] > 0.0f ? dz[r] : 0.01f * dz[r];
-                const int o = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                tt[(blk * 32 + li) * ZS + o] = o < H2 ? dp1[r] : 0.0f;      // dpre1, node-major: first operand of G1
+            for (int q = 0; q < XR / 4; q++) {
+                const float4 v = p[q];
+                xc[4 * q] = v.x; xc[4 * q + 1] = v.y; xc[4 * q + 2] = v.z; xc[4 * q + 3] = v.w;
             }
-            // dxk = W1[:, :h]^T dpre1: the contraction runs over the accumulator registers themselves
+        }
+        const float dg = deg[nc], uu = u[nc], dkv = dk[nc];
+        // the block's rows, row-major, for the column reads of G1 (before the operand swap: the half row is contiguous)
 #pragma unroll
-            for (int cb = 0; cb < NBX; cb++) {
-                kf32x16 df;
+        for (int q = 0; q < XR / 4; q++)
+            *reinterpret_cast<float4 *>(xt + li * XS + hh * (H / 2) + 4 * q) = make_float4(xc[4 * q], xc[4 * q + 1], xc[4 * q + 2], xc[4 * q + 3]);
+        const float nd = __fdiv_rn(__fadd_rn(dg, -mu), __fadd_rn(sd, 1e-5f));
+        const float dkp = (valid && uu > 0.0f) ? dkv * sd : 0.0f;
+        if (hh == 0) { s0 += dkp; ndl[li] = nd; dkl[li] = dkp; }
 #pragma unroll
-                for (int r = 0; r < 16; r++) df[r] = 0.0f;
+        for (int t = 0; t < XR / 2; t++) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(xc[2 * t]), __float_as_uint(xc[2 * t + 1]), false, false);
+            xc[2 * t] = __uint_as_float(r[0]);
+            xc[2 * t + 1] = __uint_as_float(r[1]);
+        }
+        kf32x16 a1;
 #pragma unroll
-                for (int sI = 0; sI < 16; sI++) df = __builtin_amdgcn_mfma_f32_32x32x2f32(w1b[cb][sI], dp1[sI], df, 0, 0, 0);
-                if (valid) {
+        for (int r = 0; r < 16; r++) a1[r] = 0.0f;
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; q4++) {
-                        const int c = cb * 32 + 8 * q4 + 4 * hh;
-                        if (c < H) *reinterpret_cast<float4 *>(dxk + n * H + c) = make_float4(df[4 * q4], df[4 * q4 + 1], df[4 * q4 + 2], df[4 * q4 + 3]);
-                    }
+        for (int sI = 0; sI < S1 - 1; sI++)
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[sI], sI < H / 4 ? xc[2 * sI] : xc[2 * (sI - H / 4) + 1], a1, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[S1 - 1], hh == 0 ? nd : 1.0f, a1, 0, 0, 0);
+        kf32x16 dz;
+#pragma unroll
+        for (int r = 0; r < 16; r++) dz[r] = 0.0f;
+#pragma unroll
+        for (int sI = 0; sI < KS3; sI++) dz = __builtin_amdgcn_mfma_f32_32x32x2f32(wmt[sI], dkp * wp2[sI], dz, 0, 0, 0);
+        kf32x16 dp1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float z = a1[r] > 0.0f ? a1[r] : 0.01f * a1[r];
+            dp1[r] = a1[r] > 0.0f ? dz[r] : 0.01f * dz[r];
+            const int o = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            t1[li * 33 + o] = o < H2 ? dp1[r] : 0.0f;             // dpre1, node-major: first operand of G1
+            t2[li * 33 + o] = o < H2 ? z : 0.0f;                  // z, node-major: second operand of G2
+        }
+        // dxk = W1[:, :h]^T dpre1: the contraction runs over the accumulator registers themselves
+#pragma unroll
+        for (int cb = 0; cb < NBX; cb++) {
+            kf32x16 df;
+#pragma unroll
+            for (int r = 0; r < 16; r++) df[r] = 0.0f;
+            float wv[16];
+#pragma unroll
+            for (int sI = 0; sI < 16; sI++) wv[sI] = w1b[(cb * 16 + sI) * 64 + lane];
+#pragma unroll
+            for (int sI = 0; sI < 16; sI++) df = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[sI], dp1[sI], df, 0, 0, 0);
+            if (valid) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    const int c = cb * 32 + 8 * q4 + 4 * hh;
+                    if (c < H) *reinterpret_cast<float4 *>(dxk + n * H + c) = make_float4(df[4 * q4], df[4 * q4 + 1], df[4 * q4 + 2], df[4 * q4 + 3]);
                 }
             }
         }
-        // G1: contraction over the group's 64 nodes (2 per step)
-        for (int s8 = 0; s8 < 32; s8 += 8) {                      // 8 steps' operands in flight, then their 8 * NB MFMAs
+        // G1 [o][c] += sum_n dpre1[n][o] * [xk | nd | 1][n][c]: contraction over the block's 32 nodes (2 per step)
+#pragma unroll
+        for (int s8 = 0; s8 < 16; s8 += 8) {                      // 8 steps' operands in flight, then their 8 * NB MFMAs
             float av[8], bv[8][NB];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const int nn = 2 * (s8 + q) + hh;
-                av[q] = tt[nn * ZS + li];
+                av[q] = t1[nn * 33 + li];
 #pragma unroll
-                for (int a = 0; a < NB; a++) bv[q][a] = xt[nn * XS + a * 32 + li];
+                for (int a = 0; a < NB; a++) {
+                    const int c = a * 32 + li;
+                    bv[q][a] = (a + 1) * 32 <= H ? xt[nn * XS + c] : (c < H ? xt[nn * XS + c] : (c == H ? ndl[nn] : (c == H + 1 ? 1.0f : 0.0f)));
+                }
             }
 #pragma unroll
             for (int q = 0; q < 8; q++)
 #pragma unroll
                 for (int a = 0; a < NB; a++) g1[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q][a], g1[a], 0, 0, 0);
         }
-        // G2: z (node-major) overwrites the dpre1 tile
-#pragma unroll
-        for (int blk = 0; blk < 2; blk++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int o = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                tt[(blk * 32 + li) * ZS + o] = o < H2 ? zacc[blk][r] : 0.0f;
-            }
-        for (int s8 = 0; s8 < 32; s8 += 16) {
+        // G2 [(dm ; dkp)][c] += sum_n (fa * dkp[n]) * z[n][c]
+        {
             float av[16], bv[16];
 #pragma unroll
             for (int q = 0; q < 16; q++) {
-                const int nn = 2 * (s8 + q) + hh;
+                const int nn = 2 * q + hh;
                 av[q] = fa * dkl[nn];
-                bv[q] = tt[nn * ZS + li];
+                bv[q] = t2[nn * 33 + li];
             }
 #pragma unroll
             for (int q = 0; q < 16; q++) g2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], g2, 0, 0, 0);
         }
     }
-    // the workgroup's four wavefronts summed through LDS, then one float atomic per element
+    // the workgroup's four wavefronts summed through LDS, one slab of plain stores per workgroup
     __syncthreads();
-    float *red = sm;                                               // [4][PER][64]
+    float *red = sm;                                               // [4][NREG + 1][64]
 #pragma unroll
     for (int a = 0; a < NB; a++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) red[(wave * PER + a * 16 + r) * 64 + lane] = g1[a][r];
+        for (int r = 0; r < 16; r++) red[(wave * (KB::NREG + 1) + a * 16 + r) * 64 + lane] = g1[a][r];
 #pragma unroll
-    for (int r = 0; r < 16; r++) red[(wave * PER + NB * 16 + r) * 64 + lane] = g2[r];
-    red[(wave * PER + PER - 1) * 64 + lane] = s0;
+    for (int r = 0; r < 16; r++) red[(wave * (KB::NREG + 1) + NB * 16 + r) * 64 + lane] = g2[r];
+    red[(wave * (KB::NREG + 1) + KB::NREG) * 64 + lane] = s0;
     __syncthreads();
-    if (wave != 0) return;
-    float tot_s0 = 0.0f;
-#pragma unroll
-    for (int w = 0; w < 4; w++) tot_s0 += red[(w * PER + PER - 1) * 64 + lane];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) tot_s0 += __shfl_xor(tot_s0, off, 64);
-    if (lane == 0) atomicAdd(gS0, tot_s0);
-#pragma unroll
-    for (int a = 0; a <= NB; a++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            float v = 0.0f;
-#pragma unroll
-            for (int w = 0; w < 4; w++) v += red[(w * PER + a * 16 + r) * 64 + lane];
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh, col = (a < NB ? a * 32 : 0) + li;
-            if (a < NB) {
-                if (row < H2) {
-                    if (col <= H) atomicAdd(&gW1[row * (H + 1) + col], v);
-                    else if (col == H + 1) atomicAdd(&gb1[row], v);
-                }
-            } else if (col < H2) {
-                if (row < H4) atomicAdd(&gWmu[row * H2 + col], v);
-                else if (row == H4) atomicAdd(&gv[col], v);
-            }
-        }
-    }
+    float *out = slab + (int64_t)blockIdx.x * KB::SLAB_F;
+    for (int e = tid; e < KB::SLAB_F; e += 256)
+        out[e] = (red[e] + red[KB::SLAB_F + e]) + (red[2 * KB::SLAB_F + e] + red[3 * KB::SLAB_F + e]);
 }
 
-// dbp = S0, dbmu = Wp S0, dWp = Wmu v + bmu S0  (see knet_x_bwd_mfma)
-__global__ void knet_mfma_finish(int h2, int h4, const float *__restrict__ Wmu, const float *__restrict__ bmu, const float *__restrict__ Wp,
-                                 const float *__restrict__ gv, const float *__restrict__ gS0, float *__restrict__ gbmu,
-                                 float *__restrict__ gWp, float *__restrict__ gbp) {
-    const int o = threadIdx.x;
-    const float S0 = gS0[0];
-    if (o == 0) gbp[0] = S0;
-    if (o < h4) {
-        gbmu[o] = Wp[o] * S0;
-        float acc = bmu[o] * S0;
-        for (int c = 0; c < h2; c++) acc = fmaf(Wmu[o * h2 + c], gv[c], acc);
-        gWp[o] = acc;
+// sums the workgroup slabs of knet_x_bwd_reg: block q < NREG reduces accumulator register q (64 values) over all slabs and writes
+// them to their places in gW1 / gb1 / gWmu; the block of G2's register 8 (row h/4: v = sum_n dkp_n z_n) also sums S0 and runs the
+// parameter-sized tail dbp = S0, dbmu = Wp S0, dWp = Wmu v + bmu S0
+template <int H>
+__global__ __launch_bounds__(1024) void knet_bwd_reduce(const float *__restrict__ slab, int nslab, const float *__restrict__ Wmu,
+                                                        const float *__restrict__ bmu, const float *__restrict__ Wp, float *__restrict__ gW1,
+                                                        float *__restrict__ gb1, float *__restrict__ gWmu, float *__restrict__ gbmu,
+                                                        float *__restrict__ gWp, float *__restrict__ gbp) {
+    using KB = KnetBwd<H>;
+    constexpr int H2 = KB::H2, H4 = KB::H4, NB = KB::NB;
+    __shared__ float part[16][64], vsh[64], s0sh;
+    const int tid = threadIdx.x, lane = tid & 63, pw = tid >> 6, li = lane & 31, hh = lane >> 5;
+    const int q = blockIdx.x, a = q >> 4, r = q & 15;
+    auto column = [&](int reg) {                                 // 16 wavefronts x 8 loads in flight over the slabs
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = 0.0f;
+        for (int s0 = pw; s0 < nslab; s0 += 128) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int sI = s0 + 16 * j;
+                acc[j] += sI < nslab ? slab[(int64_t)sI * KB::SLAB_F + reg * 64 + lane] : 0.0f;
+            }
+        }
+        part[pw][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        __syncthreads();
+        float v = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) v += part[j][lane];
+        __syncthreads();
+        return v;
+    };
+    const float v = column(q);
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hh, col = (a < NB ? a * 32 : 0) + li;
+    if (pw == 0) {
+        if (a < NB) {
+            if (row < H2) {
+                if (col <= H) gW1[row * (H + 1) + col] = v;
+                else if (col == H + 1) gb1[row] = v;
+            }
+        } else if (col < H2) {
+            if (row < H4) gWmu[row * H2 + col] = v;
+        }
+    }
+    // row h/4 of G2 lives in register (h/4 & 3) + 4 (h/4 >> 3) of the half (h/4 >> 2) & 1
+    constexpr int VR = (H4 & 3) + 4 * (H4 >> 3), VH = (H4 >> 2) & 1;
+    if (q == NB * 16 + VR) {
+        if (pw == 0 && hh == VH) vsh[li] = v;
+        const float sv = column(KB::NREG);
+        float tot = sv;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
+        if (tid == 0) s0sh = tot;
+        __syncthreads();
+        const float S0 = s0sh;
+        if (tid == 0) gbp[0] = S0;
+        if (tid < H4) {
+            gbmu[tid] = Wp[tid] * S0;
+            float acc = bmu[tid] * S0;
+            for (int c = 0; c < H2; c++) acc = fmaf(Wmu[tid * H2 + c], vsh[c], acc);
+            gWp[tid] = acc;
+        }
     }
 }
 
@@ -726,35 +791,49 @@ int dgg_knet_x_fwd_mfma(const float *xk, int64_t N, int h, const float *deg, con
                         const float *Wmu, const float *bmu, const float *Wp, const float *bp, float *k, float *u_save, void *stream) {
     if (h != 16 && h != 32 && h != 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "MFMA k-net: latent_dim in {16, 32, 64}");
     if (N == 0) return 0;
-    const int64_t ngroups = (N + 63) / 64;
-    const unsigned grid = (unsigned)std::min<int64_t>(256, (ngroups + 3) / 4);
+    if (reinterpret_cast<uintptr_t>(xk) % 16) return dgg_set_error(DGG_ERR_ARG, "knet_x_fwd_mfma: xk must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((N + 255) / 256);          // one 32-node block per wavefront, eight wavefronts per workgroup
     switch (h) {
-        case 16: hipLaunchKernelGGL(knet_x_fwd_mfma<16>, dim3(grid), dim3(256), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, k, u_save); break;
-        case 32: hipLaunchKernelGGL(knet_x_fwd_mfma<32>, dim3(grid), dim3(256), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, k, u_save); break;
-        default: hipLaunchKernelGGL(knet_x_fwd_mfma<64>, dim3(grid), dim3(256), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, k, u_save); break;
+        case 16: hipLaunchKernelGGL(knet_x_fwd_reg<16>, dim3(grid), dim3(512), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, k, u_save); break;
+        case 32: hipLaunchKernelGGL(knet_x_fwd_reg<32>, dim3(grid), dim3(512), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, k, u_save); break;
+        default: hipLaunchKernelGGL(knet_x_fwd_reg<64>, dim3(grid), dim3(512), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, k, u_save); break;
     }
     return dgg_check_launch("knet_x_fwd_mfma");
 }
 
-// its backward, ONE pass over xk: dxk [N,h] OVERWRITTEN; gW1 [h2, h+1], gb1 [h2], gWmu [h4, h2] ACCUMULATED into (caller zeroes them
-// and the scratch gv [h2], gS0 [1]); gbmu [h4], gWp [h4], gbp [1] OVERWRITTEN
-int dgg_knet_x_bwd_mfma(const float *xk, int64_t N, int h, const float *deg, const float *mu_sd, const float *W1, const float *b1,
-                        const float *Wmu, const float *bmu, const float *Wp, const float *u, const float *dk, float *dxk, float *gW1,
-                        float *gb1, float *gWmu, float *gbmu, float *gWp, float *gbp, float *gv, float *gS0, void *stream) {
+// its backward, ONE pass over xk (knet_x_bwd_reg + knet_bwd_reduce): every output is OVERWRITTEN, nothing to zero;
+// ws: dgg_knet_x_bwd_ws_bytes(N, h) bytes of scratch
+static int knet_bwd_grid(int64_t N) {
+    const int64_t nblk = (N + 31) / 32;
+    return (int)std::min<int64_t>(512, (nblk + 3) / 4);
+}
+size_t dgg_knet_x_bwd_ws_bytes(int64_t N, int h) {
+    if (h != 16 && h != 32 && h != 64) return 0;
+    const size_t slab_f = h == 16 ? KnetBwd<16>::SLAB_F : (h == 32 ? KnetBwd<32>::SLAB_F : KnetBwd<64>::SLAB_F);
+    return (size_t)std::max(knet_bwd_grid(N), 1) * slab_f * sizeof(float);
+}
+int dgg_knet_x_bwd_reg(const float *xk, int64_t N, int h, const float *deg, const float *mu_sd, const float *W1, const float *b1,
+                       const float *Wmu, const float *bmu, const float *Wp, const float *u, const float *dk, float *dxk, float *gW1,
+                       float *gb1, float *gWmu, float *gbmu, float *gWp, float *gbp, void *ws, void *stream) {
     if (h != 16 && h != 32 && h != 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "MFMA k-net: latent_dim in {16, 32, 64}");
+    if (!ws || (reinterpret_cast<uintptr_t>(xk) % 16) || (reinterpret_cast<uintptr_t>(dxk) % 16))
+        return dgg_set_error(DGG_ERR_ARG, "knet_x_bwd_reg: workspace missing or xk / dxk not 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (N > 0) {
-        const int64_t ngroups = (N + 63) / 64;
-        const unsigned grid = (unsigned)std::min<int64_t>(256, (ngroups + 3) / 4);
-        switch (h) {
-            case 16: hipLaunchKernelGGL(knet_x_bwd_mfma<16>, dim3(grid), dim3(256), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, Wp, u, dk, dxk, gW1, gb1, gWmu, gv, gS0); break;
-            case 32: hipLaunchKernelGGL(knet_x_bwd_mfma<32>, dim3(grid), dim3(256), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, Wp, u, dk, dxk, gW1, gb1, gWmu, gv, gS0); break;
-            default: hipLaunchKernelGGL(knet_x_bwd_mfma<64>, dim3(grid), dim3(256), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, Wp, u, dk, dxk, gW1, gb1, gWmu, gv, gS0); break;
-        }
+    const int grid = N > 0 ? knet_bwd_grid(N) : 0;
+    float *slab = reinterpret_cast<float *>(ws);
+#define DGG_KNET_BWD_REG(HH)                                                                                               \
+    if (grid > 0)                                                                                                          \
+        hipLaunchKernelGGL(knet_x_bwd_reg<HH>, dim3((unsigned)grid), dim3(256), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, Wp, u, dk, dxk, slab); \
+    hipLaunchKernelGGL(knet_bwd_reduce<HH>, dim3((unsigned)KnetBwd<HH>::NREG), dim3(1024), 0, st, slab, grid, Wmu, bmu, Wp, gW1, gb1, gWmu, gbmu, \
+                       gWp, gbp)
+    switch (h) {
+        case 16: DGG_KNET_BWD_REG(16); break;
+        case 32: DGG_KNET_BWD_REG(32); break;
+        default: DGG_KNET_BWD_REG(64); break;
     }
-    hipLaunchKernelGGL(knet_mfma_finish, dim3(1), dim3(64), 0, st, h / 2, h / 4, Wmu, bmu, Wp, gv, gS0, gbmu, gWp, gbp);
-    return dgg_check_launch("knet_x_bwd_mfma");
+#undef DGG_KNET_BWD_REG
+    return dgg_check_launch("knet_x_bwd_reg");
 }
 
 int dgg_knet_feat(const float *xk, const float *deg, const float *mu_sd, int64_t N, int h, float *feat, void *stream) {

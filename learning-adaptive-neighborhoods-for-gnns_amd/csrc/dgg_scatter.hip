@@ -38,36 +38,11 @@ inline PartHdr part_layout(void *ws, int64_t nb, int64_t nrec) {
     return p;
 }
 
-// PAYLOAD partition (dgg_partp_*): 16-byte records (src = row*64 + r, dst = j, wa = w_ir * rs_i^-1/2, score val_ir) and NO slot
-// map.  With the two per-entry scalars in the record, every column-walking kernel of the backward forms what it needs from
-// its own coalesced record stream: ahat_ir = wa * rs_j^-1/2 (conv_bwd_node) and d loss / d dist (edge_bwd_node, which
-// recomputes the ramp / normalisation chain from dA in record order) -- no per-entry random 4-byte gather of ahat, no
-// per-entry scattered write of a coefficient, no slot map to build.  The one remaining crossing between row order and
-// record order is dA (written row-major by conv_bwd_node for the row kernel).
-struct PartPHdr {                  // workspace: [bstart NB+1][cursor NB][nodeptr NB*BS+1][tmp rows*K int4][recs rows*K int4]
-    int *bstart, *cursor;
-    int *nodeptr;                  // CSC pointer: the records of destination node j are recs[nodeptr[j] .. nodeptr[j+1])
-    int4 *tmp, *recs;
-};
-inline PartPHdr partp_layout(void *ws, int64_t nb, int64_t nrec) {
-    char *w = reinterpret_cast<char *>(ws);
-    PartPHdr p;
-    p.bstart = reinterpret_cast<int *>(w);
-    p.cursor = reinterpret_cast<int *>(w + align256((size_t)(nb + 1) * 4));
-    p.nodeptr = reinterpret_cast<int *>(reinterpret_cast<char *>(p.cursor) + align256((size_t)nb * 4));
-    p.tmp = reinterpret_cast<int4 *>(reinterpret_cast<char *>(p.nodeptr) + align256((size_t)(nb * BS + 1) * 4));
-    p.recs = reinterpret_cast<int4 *>(reinterpret_cast<char *>(p.tmp) + align256((size_t)nrec * sizeof(int4)));
-    return p;
-}
-
 // pass 1 (FILL = false): per-bucket totals.  pass 2 (FILL = true): bucket-sorted records (src = row*64 + r, dst = j)
-// PAY: 16-byte payload records (val, rs_rows give the payload; no slot map)
-template <bool FILL, bool PAY = false>
+template <bool FILL>
 __global__ __launch_bounds__(256) void part_pass(const int32_t *__restrict__ idx, const float *__restrict__ w, int64_t rows,
                                                  int K, int nb, int *__restrict__ gcount, int2 *__restrict__ recs,
-                                                 int *__restrict__ slotmap, const float *__restrict__ val = nullptr,
-                                                 const float *__restrict__ rs_rows = nullptr, int4 *__restrict__ recs4 = nullptr,
-                                                 const float *__restrict__ rs_all = nullptr, float *__restrict__ ahat_out = nullptr) {
+                                                 int *__restrict__ slotmap) {
     extern __shared__ int lds[];                                 // hist[nb] (+ base[nb] when filling)
     int *hist = lds, *base = lds + nb;
     const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id();
@@ -124,20 +99,9 @@ __global__ __launch_bounds__(256) void part_pass(const int32_t *__restrict__ idx
             if (jj[u] >= 0) {
                 const int b = jj[u] / BS;
                 const int slot = base[b] + atomicAdd(&hist[b], 1);
-                if (PAY) {
-                    // wa = a_i * w exactly as normalize_fwd_kernel forms it (dgg_ell.hip), so that wa * a_j == ahat bit for bit
-                    const float ai = __fdiv_rn(1.0f, c_sqrt(rs_rows[i]));
-                    const float wa = __fmul_rn(ai, w[i * K + lane]);
-                    recs4[slot] = make_int4((int)(i * 64 + lane), jj[u], (int)__float_as_uint(wa), (int)__float_as_uint(val[i * K + lane]));
-                    // normalize_adj fused (dgg_ell_normalize_fwd): ahat = (a_i w) a_j while w and a_i are at hand
-                    if (ahat_out) ahat_out[i * K + lane] = __fmul_rn(wa, __fdiv_rn(1.0f, c_sqrt(rs_all[jj[u]])));
-                } else {
-                    recs[slot] = make_int2((int)(i * 64 + lane), jj[u]);
-                }
-            } else if (!PAY && jj[u] == -1) {
+                recs[slot] = make_int2((int)(i * 64 + lane), jj[u]);
+            } else if (jj[u] == -1) {
                 slotmap[i * K + lane] = -1;                      // active entries: written by part_sort
-            } else if (PAY && ahat_out && jj[u] == -1) {
-                ahat_out[i * K + lane] = 0.0f;                   // inactive entry (empty slot or saturated ramp)
             }
         }
     }
@@ -174,41 +138,6 @@ __global__ __launch_bounds__(1024) void part_sort(const int *__restrict__ bstart
         const int pos = e0 + base[jl] + atomicAdd(&cnt[jl], 1);
         recs[pos] = rec;
         slotmap[(int64_t)(rec.x >> 6) * K + (rec.x & 63)] = pos;
-    }
-}
-
-// pass 3 for payload records: same counting sort, 16-byte records, no slot map
-__global__ __launch_bounds__(1024) void part_sort_p(const int *__restrict__ bstart, const int4 *__restrict__ tmp, int4 *__restrict__ recs,
-                                                   int *__restrict__ nodeptr, int nb) {
-    __shared__ int cnt[BS], base[BS];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    const int e0 = bstart[b], e1 = bstart[b + 1];
-    if (tid < BS) cnt[tid] = 0;
-    __syncthreads();
-    for (int e = e0 + tid; e < e1; e += 1024) atomicAdd(&cnt[tmp[e].y - b * BS], 1);
-    __syncthreads();
-    if (tid < 64) {
-        const int c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
-        int incl = c0 + c1;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off, 64);
-            if (tid >= off) incl += v;
-        }
-        base[2 * tid] = incl - c0 - c1;
-        base[2 * tid + 1] = incl - c1;
-    }
-    __syncthreads();
-    if (tid < BS) {
-        nodeptr[b * BS + tid] = e0 + base[tid];
-        cnt[tid] = 0;
-    }
-    if (b == nb - 1 && tid == 0) nodeptr[nb * BS] = e1;
-    __syncthreads();
-    for (int e = e0 + tid; e < e1; e += 1024) {
-        const int4 rec = tmp[e];
-        const int jl = rec.y - b * BS;
-        recs[e0 + base[jl] + atomicAdd(&cnt[jl], 1)] = rec;
     }
 }
 
@@ -939,6 +868,309 @@ __global__ __launch_bounds__(256) void norm_da_cols(int64_t ncols, const int *__
 
 inline int64_t nbuckets(int64_t ncols) { return (ncols + BS - 1) / BS; }
 
+// ---- payload partition, second form (round 4): table-driven offsets, no global atomics, one LDS atomic per record and pass ----
+// The first form (part_pass<.., true> + part_scan + part_sort_p) was latency-bound: 391 workgroups of four wavefronts with a chain
+// of dependent loads each (wait share 0.76, 186 us for 360 MB).  Here
+//   pp_count   every workgroup of PPR rows leaves its per-bucket counts in a table T [nwg][nb]         (reads idx, w)
+//   pp_scan    per bucket: exclusive prefix of T over the workgroups (in place) and the bucket total   (table-sized)
+//   pp_fill    bucket starts = scan of the totals (every workgroup for itself, nb is a few hundred), then each active entry takes
+//              its rank inside (workgroup, bucket) from ONE returning LDS add and is stored at start[b] + T[wg][b] + rank; ahat fused
+//   pp_sort    one workgroup per bucket holds the bucket's records in REGISTERS, ranks them inside their node with one returning
+//              LDS add, scans the node counts and stores every record once (buckets beyond the register budget re-read)
+// Buckets are PBS nodes wide, a power of two chosen from the column count so that a bucket of the expected size fits the register
+// path and the table stays small.  Record order inside a node depends on the arrival order of the LDS adds, as before.
+constexpr int PP_T = 1024;                                       // threads of a pp_sort workgroup
+constexpr int PP_RPT = 16;                                       // records per thread held in registers by pp_sort
+inline int pp_threads() {                                        // threads of a pp_count / pp_fill workgroup (16 rows per wavefront)
+    static const int t = [] { const char *e = getenv("DGG_PP_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 1024; }();
+    return t;
+}
+inline int pp_shift(int64_t rows, int K, int64_t ncols) {        // log2 of the bucket width
+    static const int forced = [] { const char *e = getenv("DGG_PP_SHIFT"); return e ? atoi(e) : 0; }();
+    // expected records per bucket ~ rows * 0.7 K * PBS / ncols <= 3/4 of the register path's capacity; at least 128 nodes
+    int s = 7;
+    const double per_node = (double)rows * (0.7 * K) / (double)(ncols > 0 ? ncols : 1);
+    while (s < 12 && per_node * (double)(2 << s) <= 0.75 * PP_T * PP_RPT) s++;
+    if (forced >= 5 && forced <= 12) s = forced;
+    while (((ncols + ((int64_t)1 << s) - 1) >> s) > 4096) s++;  // LDS histograms: at most 4096 buckets
+    return s;
+}
+struct PartP2 {                    // workspace: [bstart NB+1][totals NB][nodeptr NB*PBS+1][T nwg*NB][ainv ncols][tmp][recs]
+    int *bstart, *totals, *nodeptr, *T;
+    float *ainv;                   // rs_j^-1/2 of every destination node (normalize_adj fused into the fill pass)
+    int4 *tmp, *recs;
+    int shift;
+    int64_t nb, nwg;
+};
+inline size_t partp2_layout(PartP2 &p, void *ws, int64_t rows, int K, int64_t ncols) {
+    p.shift = pp_shift(rows, K, ncols);
+    p.nb = (ncols + ((int64_t)1 << p.shift) - 1) >> p.shift;
+    p.nwg = (rows + pp_threads() / 4 - 1) / (pp_threads() / 4);
+    char *w = reinterpret_cast<char *>(ws);
+    size_t o = 0;
+    p.bstart = reinterpret_cast<int *>(w + o); o += align256((size_t)(p.nb + 1) * 4);
+    p.totals = reinterpret_cast<int *>(w + o); o += align256((size_t)p.nb * 4);
+    p.nodeptr = reinterpret_cast<int *>(w + o); o += align256((size_t)((p.nb << p.shift) + 1) * 4);
+    p.T = reinterpret_cast<int *>(w + o); o += align256((size_t)p.nwg * p.nb * 4);
+    p.ainv = reinterpret_cast<float *>(w + o); o += align256((size_t)ncols * 4);
+    p.tmp = reinterpret_cast<int4 *>(w + o); o += align256((size_t)rows * K * sizeof(int4));
+    p.recs = reinterpret_cast<int4 *>(w + o); o += (size_t)rows * K * sizeof(int4);
+    return o;
+}
+
+// rows [r0, r0 + 16) of one wavefront as 4 x (16 bytes per lane): lane l of load u holds entries 4*(l%16) .. +3 of row r0 + 4u + l/16
+__device__ __forceinline__ void pp_load16(const int32_t *__restrict__ idx, const float *__restrict__ w, int64_t rows, int64_t r0, int lane,
+                                          int4 (&ji)[4], float4 (&wv)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int64_t i = r0 + 4 * u + (lane >> 4);
+        const int64_t e = (i < rows ? i : rows - 1) * 64 + 4 * (lane & 15);
+        ji[u] = *reinterpret_cast<const int4 *>(idx + e);
+        wv[u] = *reinterpret_cast<const float4 *>(w + e);
+        if (i >= rows) ji[u] = make_int4(-1, -1, -1, -1);
+    }
+}
+__device__ __forceinline__ int pp_get(const int4 &v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+__device__ __forceinline__ float pp_getf(const float4 &v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void pp_count(const int32_t *__restrict__ idx, const float *__restrict__ w, int64_t rows, int K, int nb,
+                                                    int shift, int *__restrict__ T, const float *__restrict__ rs_all, int64_t ncols,
+                                                    float *__restrict__ ainv) {
+    extern __shared__ int lds[];
+    int *hist = lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id();
+    for (int b = tid; b < nb; b += THREADS) hist[b] = 0;
+    if (rs_all) {                                                // this workgroup's slice of a_j = rs_j^-1/2 (the bits normalize_fwd_kernel forms)
+        const int64_t per = (ncols + gridDim.x - 1) / gridDim.x;
+        const int64_t j1 = ((int64_t)blockIdx.x + 1) * per < ncols ? ((int64_t)blockIdx.x + 1) * per : ncols;
+        for (int64_t j = (int64_t)blockIdx.x * per + tid; j < j1; j += THREADS) ainv[j] = __fdiv_rn(1.0f, c_sqrt(rs_all[j]));
+    }
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * (THREADS / 4) + wave * 16;
+    if (K == 64) {
+        int4 ji[4];
+        float4 wv[4];
+        pp_load16(idx, w, rows, r0, lane, ji, wv);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int j = pp_get(ji[u], c);
+                if (j >= 0 && pp_getf(wv[u], c) != 0.0f) atomicAdd(&hist[j >> shift], 1);
+            }
+    } else {
+        for (int q = 0; q < 16; q++) {
+            const int64_t i = r0 + q;
+            if (i < rows && lane < K) {
+                const int j = idx[i * K + lane];
+                if (j >= 0 && w[i * K + lane] != 0.0f) atomicAdd(&hist[j >> shift], 1);
+            }
+        }
+    }
+    __syncthreads();
+    int *row = T + (int64_t)blockIdx.x * nb;
+    for (int b = tid; b < nb; b += THREADS) row[b] = hist[b];
+}
+
+// per bucket: T[wg][b] <- sum of T[wg'][b] over wg' < wg; totals[b] = sum over all workgroups.  One workgroup of 1024 threads
+// covers 32 buckets (a 128-byte segment of every table row) x 32 slices of the workgroup range.
+__global__ __launch_bounds__(1024) void pp_scan(int *__restrict__ T, int nwg, int nb, int *__restrict__ totals) {
+    __shared__ int part[32][33];
+    const int c = threadIdx.x & 31, s = threadIdx.x >> 5;
+    const int b = blockIdx.x * 32 + c;
+    const int per = (nwg + 31) / 32;
+    const int lo = s * per, hi = lo + per < nwg ? lo + per : nwg;
+    constexpr int CHK = 16;                                      // table entries in flight per thread (independent loads)
+    int v[CHK];
+    int sum = 0;
+    for (int g0 = lo; g0 < hi; g0 += CHK) {
+#pragma unroll
+        for (int q = 0; q < CHK; q++) v[q] = (b < nb && g0 + q < hi) ? T[(int64_t)(g0 + q) * nb + b] : 0;
+#pragma unroll
+        for (int q = 0; q < CHK; q++) sum += v[q];
+    }
+    part[s][c] = sum;
+    __syncthreads();
+    int run = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const int pv = part[q][c];
+        if (q < s) run += pv;
+        tot += pv;
+    }
+    if (b < nb && s == 0) totals[b] = tot;
+    for (int g0 = lo; g0 < hi; g0 += CHK) {
+        if (per > CHK) {                                         // (a slice longer than one chunk: re-read, still CHK loads in flight)
+#pragma unroll
+            for (int q = 0; q < CHK; q++) v[q] = (b < nb && g0 + q < hi) ? T[(int64_t)(g0 + q) * nb + b] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < CHK; q++) {
+            if (b < nb && g0 + q < hi) T[(int64_t)(g0 + q) * nb + b] = run;
+            run += v[q];
+        }
+    }
+}
+
+// exclusive scan of nb values in LDS by the whole workgroup: out[b] = sum of in[< b]; returns the grand total in every thread
+template <int THREADS>
+__device__ __forceinline__ int pp_block_scan(const int *__restrict__ in_g, int *__restrict__ out, int nb, int *__restrict__ scratch) {
+    const int tid = threadIdx.x;
+    const int per = (nb + THREADS - 1) / THREADS;
+    const int lo = tid * per, hi = lo + per < nb ? lo + per : nb;
+    int s = 0;
+    for (int b = lo; b < hi; b++) s += in_g[b];
+    // wave scan, then the wave totals
+    int incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if ((tid & 63) >= off) incl += v;
+    }
+    if ((tid & 63) == 63) scratch[tid >> 6] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+    for (int q = 0; q < THREADS / 64; q++) {
+        const int v = scratch[q];
+        if (q < (tid >> 6)) wbase += v;
+        total += v;
+    }
+    int run = wbase + incl - s;
+    for (int b = lo; b < hi; b++) {
+        const int v = in_g[b];
+        out[b] = run;
+        run += v;
+    }
+    __syncthreads();
+    return total;
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void pp_fill(const int32_t *__restrict__ idx, const float *__restrict__ w, const float *__restrict__ val,
+                                                   const float *__restrict__ rs_rows, int64_t rows, int K, int nb, int shift,
+                                                   const int *__restrict__ T, const int *__restrict__ totals, int *__restrict__ bstart,
+                                                   int4 *__restrict__ recs4, const float *__restrict__ ainv, float *__restrict__ ahat_out) {
+    extern __shared__ int lds[];                                 // hist[nb], base[nb], scratch[16]
+    int *hist = lds, *base = lds + nb, *scratch = lds + 2 * nb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id();
+    const int64_t r0 = (int64_t)blockIdx.x * (THREADS / 4) + wave * 16;
+    int4 ji[4];
+    if (K == 64) {                                               // the wavefront's 16 rows of idx: in flight across the scan below
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t i = r0 + 4 * u + (lane >> 4);
+            ji[u] = *reinterpret_cast<const int4 *>(idx + (i < rows ? i : rows - 1) * 64 + 4 * (lane & 15));
+            if (i >= rows) ji[u] = make_int4(-1, -1, -1, -1);
+        }
+    }
+    for (int b = tid; b < nb; b += THREADS) hist[b] = 0;
+    const int total = pp_block_scan<THREADS>(totals, base, nb, scratch);
+    if (blockIdx.x == 0) {
+        for (int b = tid; b < nb; b += THREADS) bstart[b] = base[b];
+        if (tid == 0) bstart[nb] = total;
+    }
+    const int *trow = T + (int64_t)blockIdx.x * nb;
+    for (int b = tid; b < nb; b += THREADS) base[b] += trow[b];
+    __syncthreads();
+    if (K == 64) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t i = r0 + 4 * u + (lane >> 4);
+            const bool row_ok = i < rows;
+            const int64_t e = (row_ok ? i : rows - 1) * 64 + 4 * (lane & 15);
+            const float4 wv = *reinterpret_cast<const float4 *>(w + e);
+            const float4 vv = *reinterpret_cast<const float4 *>(val + e);
+            const float ai = __fdiv_rn(1.0f, c_sqrt(rs_rows[row_ok ? i : rows - 1]));
+            // a_j of the four entries gathered BEFORE the entry loop: inside it there is then no load to wait for (a wait there
+            // would also wait for the record store of the previous entry: one memory round trip per entry)
+            float4 aj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (ahat_out) {
+                aj.x = ainv[ji[u].x >= 0 ? ji[u].x : 0]; aj.y = ainv[ji[u].y >= 0 ? ji[u].y : 0];
+                aj.z = ainv[ji[u].z >= 0 ? ji[u].z : 0]; aj.w = ainv[ji[u].w >= 0 ? ji[u].w : 0];
+            }
+            float4 ah = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll 1
+            for (int c = 0; c < 4; c++) {                        // (not unrolled: 16 entries in flight cost 130 registers and an occupancy step)
+                const int j = pp_get(ji[u], c);
+                const float wx = pp_getf(wv, c);
+                if (j >= 0 && wx != 0.0f) {
+                    const int b = j >> shift;
+                    const int slot = base[b] + atomicAdd(&hist[b], 1);
+                    // wa = a_i * w exactly as normalize_fwd_kernel forms it (dgg_ell.hip), so that wa * a_j == ahat bit for bit
+                    const float wa = __fmul_rn(ai, wx);
+                    recs4[slot] = make_int4((int)(i * 64 + 4 * (lane & 15) + c), j, (int)__float_as_uint(wa), (int)__float_as_uint(pp_getf(vv, c)));
+                    const float a = __fmul_rn(wa, pp_getf(aj, c));
+                    if (c == 0) ah.x = a; else if (c == 1) ah.y = a; else if (c == 2) ah.z = a; else ah.w = a;
+                }
+            }
+            if (ahat_out && row_ok) *reinterpret_cast<float4 *>(ahat_out + i * 64 + 4 * (lane & 15)) = ah;
+        }
+    } else {
+        for (int q = 0; q < 16; q++) {
+            const int64_t i = r0 + q;
+            if (i < rows && lane < K) {
+                const int j = idx[i * K + lane];
+                const float wx = w[i * K + lane];
+                float a = 0.0f;
+                if (j >= 0 && wx != 0.0f) {
+                    const int b = j >> shift;
+                    const int slot = base[b] + atomicAdd(&hist[b], 1);
+                    const float wa = __fmul_rn(__fdiv_rn(1.0f, c_sqrt(rs_rows[i])), wx);
+                    recs4[slot] = make_int4((int)(i * 64 + lane), j, (int)__float_as_uint(wa), (int)__float_as_uint(val[i * K + lane]));
+                    if (ahat_out) a = __fmul_rn(wa, ainv[j]);
+                }
+                if (ahat_out) ahat_out[i * K + lane] = a;
+            }
+        }
+    }
+}
+
+// one workgroup per bucket: records -> node order; nodeptr for the bucket's nodes
+__global__ __launch_bounds__(PP_T) void pp_sort(const int *__restrict__ bstart, const int4 *__restrict__ tmp, int4 *__restrict__ recs,
+                                                int *__restrict__ nodeptr, int nb, int shift) {
+    extern __shared__ int lds[];                                 // cnt[PBS], base[PBS], scratch[16]
+    const int PBS = 1 << shift;
+    int *cnt = lds, *base = lds + PBS, *scratch = lds + 2 * PBS;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int e0 = bstart[b], e1 = bstart[b + 1], n = e1 - e0;
+    const int o0 = e0, o1 = e1;
+    for (int q = tid; q < PBS; q += PP_T) cnt[q] = 0;
+    __syncthreads();
+    const bool inreg = n <= PP_T * PP_RPT;                       // workgroup-uniform
+    int4 rec[PP_RPT];
+    int rank[PP_RPT];
+    if (inreg) {
+#pragma unroll
+        for (int u = 0; u < PP_RPT; u++) {
+            const int e = e0 + u * PP_T + tid;
+            rec[u] = tmp[e < e1 ? e : (n > 0 ? e1 - 1 : 0)];
+            if (e >= e1) rec[u].y = -1;
+        }
+#pragma unroll
+        for (int u = 0; u < PP_RPT; u++) rank[u] = rec[u].y >= 0 ? atomicAdd(&cnt[rec[u].y - (b << shift)], 1) : 0;
+    } else {
+        for (int e = e0 + tid; e < e1; e += PP_T) atomicAdd(&cnt[tmp[e].y - (b << shift)], 1);
+    }
+    __syncthreads();
+    pp_block_scan<PP_T>(cnt, base, PBS, scratch);
+    for (int q = tid; q < PBS; q += PP_T) nodeptr[((int64_t)b << shift) + q] = o0 + base[q];
+    if (b == nb - 1 && tid == 0) nodeptr[(int64_t)nb << shift] = o1;
+    if (inreg) {
+#pragma unroll
+        for (int u = 0; u < PP_RPT; u++)
+            if (rec[u].y >= 0) recs[o0 + base[rec[u].y - (b << shift)] + rank[u]] = rec[u];
+    } else {
+        for (int q = tid; q < PBS; q += PP_T) cnt[q] = 0;
+        __syncthreads();
+        for (int e = e0 + tid; e < e1; e += PP_T) {
+            const int4 r = tmp[e];
+            const int jl = r.y - (b << shift);
+            recs[o0 + base[jl] + atomicAdd(&cnt[jl], 1)] = r;
+        }
+    }
+}
+
 }  // namespace
 
 const int *dgg_part_slotmap(const void *part_ws, int64_t rows, int K, int64_t ncols) {
@@ -1075,10 +1307,11 @@ int dgg_ell_conv_bwd_part(const float *G, const float *H, const float *ahat, int
 int dgg_partp_build_norm(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
                          const float *rs_all, float *ahat, void *ws, void *stream);
 size_t dgg_partp_ws_bytes(int64_t rows, int K, int64_t ncols) {
-    const int64_t nb = nbuckets(ncols);
-    if (nb > 8192 || K > 64 || K < 1 || rows * 64 >= ((int64_t)1 << 31)) return 0;   // LDS histogram (64 KiB) / 32-bit record ids
-    return align256((size_t)(nb + 1) * 4) + align256((size_t)nb * 4) + align256((size_t)(nb * BS + 1) * 4) +
-           align256((size_t)rows * K * sizeof(int4)) + (size_t)rows * K * sizeof(int4);
+    if (K > 64 || K < 1 || rows * 64 >= ((int64_t)1 << 31) || ncols < 1) return 0;          // 32-bit record ids
+    PartP2 p;
+    const size_t bytes = partp2_layout(p, nullptr, rows, K, ncols);
+    if (p.nb > 4096 || (1 << p.shift) > 4096) return 0;                                      // LDS histograms / node counters
+    return bytes;
 }
 
 // Partition the ACTIVE entries (idx >= 0, w != 0) of an ELL block by destination, records = (row*64 + r, j, w * rs_i^-1/2, val).
@@ -1093,21 +1326,43 @@ int dgg_partp_build(const int32_t *idx, const float *w, const float *val, const 
 int dgg_partp_build_norm(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
                          const float *rs_all, float *ahat, void *ws, void *stream) {
     hipStream_t st = (hipStream_t)stream;
-    const int64_t nb = nbuckets(ncols);
     if (dgg_partp_ws_bytes(rows, K, ncols) == 0 || !ws) return dgg_set_error(DGG_ERR_UNSUPPORTED, "partp_build: unsupported size or NULL workspace");
     if (!val || !rs_rows) return dgg_set_error(DGG_ERR_ARG, "partp_build: the payload needs the scores and the row sums");
-    if (rows == 0) return 0;
-    PartPHdr p = partp_layout(ws, nb, rows * K);
-    if (dgg_check_hip(hipMemsetAsync(p.cursor, 0, (size_t)nb * 4, st), "partp memset") != 0) return DGG_ERR_HIP;
-    const unsigned grid = (unsigned)((rows + PR - 1) / PR);
-    hipLaunchKernelGGL((part_pass<false, true>), dim3(grid), dim3(256), (size_t)nb * 4, st, idx, w, rows, K, (int)nb, p.cursor, nullptr, nullptr,
-                       val, rs_rows, p.tmp);
-    hipLaunchKernelGGL(part_scan, dim3(1), dim3(1024), 0, st, p.bstart, p.cursor, (int)nb);
     if ((rs_all == nullptr) != (ahat == nullptr)) return dgg_set_error(DGG_ERR_ARG, "partp_build_norm: rs_all and ahat go together");
-    hipLaunchKernelGGL((part_pass<true, true>), dim3(grid), dim3(256), (size_t)nb * 8, st, idx, w, rows, K, (int)nb, p.cursor, nullptr, nullptr,
-                       val, rs_rows, p.tmp, rs_all, ahat);
-    hipLaunchKernelGGL(part_sort_p, dim3((unsigned)nb), dim3(1024), 0, st, p.bstart, p.tmp, p.recs, p.nodeptr, (int)nb);
+    if (K == 64 && ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(val) |
+                     reinterpret_cast<uintptr_t>(ahat)) % 16))
+        return dgg_set_error(DGG_ERR_ARG, "partp_build: idx / w / val / ahat must be 16-byte aligned");
+    if (rows == 0) return 0;
+    PartP2 p;
+    partp2_layout(p, ws, rows, K, ncols);
+    const int nb = (int)p.nb, nwg = (int)p.nwg, pbs = 1 << p.shift;
+#define DGG_PP_PASS(TT)                                                                                                      \
+    hipLaunchKernelGGL(pp_count<TT>, dim3((unsigned)nwg), dim3(TT), (size_t)nb * 4, st, idx, w, rows, K, nb, p.shift, p.T, rs_all, ncols, \
+                       p.ainv);                                                                                              \
+    hipLaunchKernelGGL(pp_scan, dim3((unsigned)((nb + 31) / 32)), dim3(1024), 0, st, p.T, nwg, nb, p.totals);                \
+    hipLaunchKernelGGL(pp_fill<TT>, dim3((unsigned)nwg), dim3(TT), (size_t)(2 * nb + 16) * 4, st, idx, w, val, rs_rows, rows, K, nb, p.shift, \
+                       p.T, p.totals, p.bstart, p.tmp, p.ainv, ahat)
+    switch (pp_threads()) {
+        case 256: DGG_PP_PASS(256); break;
+        case 512: DGG_PP_PASS(512); break;
+        default: DGG_PP_PASS(1024); break;
+    }
+#undef DGG_PP_PASS
+    hipLaunchKernelGGL(pp_sort, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr, nb, p.shift);
     return dgg_check_launch("partp_build");
+}
+
+int dgg_partp_describe(int64_t rows, int K, int64_t ncols, int64_t *out6) {
+    if (!out6 || dgg_partp_ws_bytes(rows, K, ncols) == 0) return dgg_set_error(DGG_ERR_UNSUPPORTED, "partp_describe: no payload partition for this shape");
+    PartP2 p;
+    partp2_layout(p, nullptr, rows, K, ncols);
+    out6[0] = reinterpret_cast<char *>(p.bstart) - static_cast<char *>(nullptr);
+    out6[1] = reinterpret_cast<char *>(p.nodeptr) - static_cast<char *>(nullptr);
+    out6[2] = reinterpret_cast<char *>(p.recs) - static_cast<char *>(nullptr);
+    out6[3] = p.nb;
+    out6[4] = p.shift;
+    out6[5] = pp_threads() / 4;
+    return 0;
 }
 
 // which node kernel: a group of lanes per node when the lists are short (fewer than 16 records per node on average; a rank of G
@@ -1126,11 +1381,9 @@ int dgg_ell_conv_bwd_partp(const float *G, const float *H, int64_t rows, int K, 
         return dgg_set_error(DGG_ERR_UNSUPPORTED, "ell_conv_bwd_partp: feature width must be 16, 32, 64 or 128 (16-byte aligned rows)");
     if (!rs || !partp_ws || !dA_rec || dgg_partp_ws_bytes(rows, K, ncols) == 0) return dgg_set_error(DGG_ERR_ARG, "ell_conv_bwd_partp: missing operand");
     if (rows == 0) return 0;
-    const int64_t nb = nbuckets(ncols);
-    PartPHdr p = partp_layout(const_cast<void *>(partp_ws), nb, rows * K);
-    const int64_t ngroups = (rows * K + CH - 1) / CH;
+    PartP2 p;
+    partp2_layout(p, const_cast<void *>(partp_ws), rows, K, ncols);
     hipStream_t st = (hipStream_t)stream;
-    (void)ngroups;
     const bool grouped = node_groups(rows * K, ncols);
 #define DGG_CONV_COLS_P(FF)                                                                                                \
     if (grouped)                                                                                                           \
@@ -1162,8 +1415,8 @@ int dgg_softk_edge_bwd_partp(const float *xp, int64_t rows, int h, const int32_t
     if (!partp_ws || dgg_partp_ws_bytes(rows, K, ncols) == 0) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: no partition");
     if (rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t nb = nbuckets(ncols);
-    PartPHdr p = partp_layout(const_cast<void *>(partp_ws), nb, rows * K);
+    PartP2 p;
+    partp2_layout(p, const_cast<void *>(partp_ws), rows, K, ncols);
     const SoftkArgs sk{k, rs, dA, da, mode, normalized, nullptr, dk, ahat_rows, reinterpret_cast<float4 *>(rowinfo_ws)};
     const unsigned gr = (unsigned)((rows + 3) / 4);
     const bool grouped = node_groups(rows * K, ncols);

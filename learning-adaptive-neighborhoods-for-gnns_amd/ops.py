@@ -4,6 +4,7 @@ torch is used for device memory, streams and autograd bookkeeping only: every FL
 libdgg_hip.so.  Naming follows the reference (dgm.py / model.py) and include/dgg_hip.h.
 """
 import collections
+import os
 import ctypes as C
 
 import torch
@@ -815,6 +816,18 @@ class PartP:
         self.ws, self.rows, self.K, self.ncols = ws, rows, K, ncols
 
 
+def partp_records(partp):
+    """(nodeptr int32 [ncols+1], records int32 [nrec,4] = (row*64 + r, j, bits of w rs_i^-1/2, bits of the score)) of a built payload
+    partition, read back from its workspace (dgg_partp_describe); tests and tools only (one synchronisation)."""
+    out = (C.c_int64 * 6)()
+    _lib.check(_lib.lib().dgg_partp_describe(partp.rows, partp.K, partp.ncols, out), "partp_describe")
+    ws = partp.ws
+    nodeptr = ws[out[1]: out[1] + 4 * (partp.ncols + 1)].view(torch.int32)
+    nrec = int(nodeptr[-1].item())
+    recs = ws[out[2]: out[2] + 16 * nrec].view(torch.int32).reshape(nrec, 4)
+    return nodeptr, recs
+
+
 def partp_build(idx, w, val, rs_rows, ncols, rs_all=None):
     """Payload partition of the active ELL entries by destination node: records carry w * rs_i^-1/2 and the score, there is no
     slot map.  Returns None when it does not apply.  rs_all [ncols] (row sums of every node): normalize_adj is fused and the
@@ -1006,26 +1019,26 @@ def knet_x_fwd_slim(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp):
 
 
 def knet_x_bwd_fused(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, u, dk):
-    """one pass over xk -> dxk [N,h], dW1, db1, dWmu, dbmu, dWp ([h4]), dbp ([1])  (dgg_knet_x_bwd_mfma)"""
+    """one pass over xk -> dxk [N,h], dW1, db1, dWmu, dbmu, dWp ([h4]), dbp ([1])  (dgg_knet_x_bwd_reg: per-workgroup slabs + one
+    reduce launch, nothing accumulated into)"""
     xk = _chk(xk)
     N, h = xk.shape
     h2, h4 = W1.shape[0], Wmu.shape[0]
     assert h in KNET_MFMA_WIDTHS and h2 * 2 == h and h4 * 4 == h
     dev = xk.device
-    zz = _zeros((h2 * (h + 1) + h2 + h4 * h2 + h2 + 1,), dev)              # accumulated into: one fill
-    o = 0
-    gW1 = zz[o:o + h2 * (h + 1)].view(h2, h + 1); o += h2 * (h + 1)
-    gb1 = zz[o:o + h2]; o += h2
-    gWmu = zz[o:o + h4 * h2].view(h4, h2); o += h4 * h2
-    gv = zz[o:o + h2]; o += h2
-    gS0 = zz[o:o + 1]
-    out = torch.empty((2 * h4 + 1,), device=dev, dtype=torch.float32)
-    gbmu, gWp, gbp = out[:h4], out[h4:2 * h4], out[2 * h4:]
     dxk = torch.empty((N, h), device=dev, dtype=torch.float32)
-    _lib.check(_lib.lib().dgg_knet_x_bwd_mfma(_ptr(xk), N, h, _ptr(_chk(deg)), _ptr(mu_sd), _ptr(_chk(W1)), _ptr(_chk(b1)), _ptr(_chk(Wmu)),
-                                              _ptr(_chk(bmu)), _ptr(_chk(Wp)), _ptr(_chk(u)), _ptr(_chk(dk)), _ptr(dxk), _ptr(gW1), _ptr(gb1),
-                                              _ptr(gWmu), _ptr(gbmu), _ptr(gWp), _ptr(gbp), _ptr(gv), _ptr(gS0), _stream()),
-               "knet_x_bwd_mfma")
+    out = torch.empty((h2 * (h + 1) + h2 + h4 * h2 + 2 * h4 + 1,), device=dev, dtype=torch.float32)
+    o = 0
+    gW1 = out[o:o + h2 * (h + 1)].view(h2, h + 1); o += h2 * (h + 1)
+    gb1 = out[o:o + h2]; o += h2
+    gWmu = out[o:o + h4 * h2].view(h4, h2); o += h4 * h2
+    gbmu = out[o:o + h4]; o += h4
+    gWp = out[o:o + h4]; o += h4
+    gbp = out[o:o + 1]
+    ws = torch.empty((int(_lib.lib().dgg_knet_x_bwd_ws_bytes(N, h)),), device=dev, dtype=torch.uint8)
+    _lib.check(_lib.lib().dgg_knet_x_bwd_reg(_ptr(xk), N, h, _ptr(_chk(deg)), _ptr(mu_sd), _ptr(_chk(W1)), _ptr(_chk(b1)), _ptr(_chk(Wmu)),
+                                             _ptr(_chk(bmu)), _ptr(_chk(Wp)), _ptr(_chk(u)), _ptr(_chk(dk)), _ptr(dxk), _ptr(gW1), _ptr(gb1),
+                                             _ptr(gWmu), _ptr(gbmu), _ptr(gWp), _ptr(gbp), _ptr(ws), _stream()), "knet_x_bwd_reg")
     return dxk, gW1, gb1, gWmu, gbmu, gWp, gbp
 
 

@@ -456,6 +456,43 @@ def test_ramp_fused_into_the_ranked_search(dev, mode):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("N,lo,hi,hub", [(1300, 0, 1300, False), (1300, 400, 977, False), (5000, 0, 5000, True), (70, 0, 70, False)])
+def test_payload_partition_is_a_csc_view_of_the_active_entries(dev, N, lo, hi, hub):
+    """dgg_partp_build_norm: the records are exactly the active entries (idx >= 0, w != 0) of the block, grouped by destination node
+    (nodeptr), each carrying w rs_i^-1/2 and the score.  `hub`: one node receives an edge from every row, so that its bucket
+    exceeds what the sort keeps in registers (the re-reading form of pp_sort)."""
+    from dgg_amd import ops
+    rng = np.random.default_rng(5 + N)
+    rows = hi - lo
+    idx = rng.integers(0, N, size=(rows, K)).astype(np.int32)
+    idx[rng.random((rows, K)) < 0.3] = -1
+    w = rng.random((rows, K)).astype(np.float32)
+    w[rng.random((rows, K)) < 0.2] = 0.0
+    if hub:
+        idx[:, 7] = 1234
+        w[:, 7] = 0.5
+        idx[:, 8:40] = rng.integers(1152, 1280, size=(rows, 32)).astype(np.int32)      # ~ 160 000 records in one 128-node range
+        w[:, 8:40] = 0.25
+    val = rng.random((rows, K)).astype(np.float32)
+    rs = (0.5 + rng.random(N)).astype(np.float32)
+    part, ahat = ops.partp_build(T(idx, dev), T(w, dev), T(val, dev), T(rs[lo:hi], dev), N, T(rs, dev))
+    nodeptr, recs = ops.partp_records(part)
+    nodeptr, recs = Nn(nodeptr), Nn(recs)
+    act = (idx >= 0) & (w != 0)
+    assert nodeptr[0] == 0 and nodeptr[-1] == act.sum() and np.all(np.diff(nodeptr) >= 0)
+    assert np.array_equal(np.repeat(np.arange(N), np.diff(nodeptr)), recs[:, 1]), "records are not grouped by destination node"
+    ai = (np.float32(1.0) / np.sqrt(rs[lo:hi])).astype(np.float32)
+    wa = (ai[:, None] * w).astype(np.float32)
+    r_, c_ = np.nonzero(act)
+    exp = np.stack([(r_ * 64 + c_).astype(np.int32), idx[r_, c_], wa[r_, c_].view(np.int32), val[r_, c_].view(np.int32)], 1)
+    order = np.lexsort((exp[:, 0], exp[:, 1]))
+    got_order = np.lexsort((recs[:, 0], recs[:, 1]))
+    assert np.array_equal(exp[order], recs[got_order])
+    aj = (np.float32(1.0) / np.sqrt(rs)).astype(np.float32)
+    exp_ahat = np.where(act, (wa * aj[np.where(act, idx, 0)]).astype(np.float32), np.float32(0.0))
+    assert np.array_equal(Nn(ahat), exp_ahat)
+
+
 def test_normalisation_fused_into_the_partition_build(dev):
     """dgg_partp_build_norm writes the bits of dgg_ell_normalize_fwd (row shard: own rows, global row sums)"""
     from dgg_amd import ops

@@ -289,7 +289,8 @@ def test_knet_bit_exact_and_bwd(dev):
     from dgg_amd import ops
     rng = np.random.default_rng(8)
     # 128, 256: GEMM composition; (151, -128): the thread-per-node kernels at 128 features; 40: wave-per-node
-    for N, h in [(700, 64), (300, 16), (2, 64), (4133, 32), (150, 128), (151, -128), (333, 256), (90, 40)]:
+    # (70 001, 64): more 32-node blocks than the persistent backward has wavefronts (every wavefront walks several blocks)
+    for N, h in [(700, 64), (300, 16), (2, 64), (4133, 32), (70001, 64), (150, 128), (151, -128), (333, 256), (90, 40)]:
         ops.KNET_WIDE_FROM = 129 if h < 0 else 128
         h = abs(h)
         h2, h4 = h // 2, h // 4
