@@ -115,11 +115,13 @@ int dgg_knet_x_fwd_mfma(const float *xk, int64_t N, int h, const float *deg, con
 /* Backward in ONE pass over xk (layer 1 is re-run): dxk [N,h] and every parameter gradient -- gW1 [h2, h+1] (k_embed.0.weight), gb1 [h2],
  * gWmu [h4, h2], gbmu [h4], gWp [h4], gbp [1] -- are OVERWRITTEN (weight-gradient partials leave the kernel as one plain-store slab per
  * workgroup, a reduce launch sums them and runs the parameter-sized tail; no float atomics, nothing to zero).  ws:
- * dgg_knet_x_bwd_ws_bytes bytes of scratch (0: width not supported).  xk, dxk 16-byte aligned. */
+ * dgg_knet_x_bwd_ws_bytes bytes of scratch (0: width not supported).  xk, dxk 16-byte aligned.  out_act = 1: dxk is returned multiplied by
+ * LeakyReLU'(xk), i.e. as the gradient of the PRE-activation of the layer that produced xk (node_encode_for_k, dgm.py:1123-1126), so
+ * that its weight-gradient product needs no second pass over xk for the mask. */
 size_t dgg_knet_x_bwd_ws_bytes(int64_t N, int h);
 int dgg_knet_x_bwd_reg(const float *xk, int64_t N, int h, const float *deg, const float *mu_sd, const float *W1, const float *b1,
                        const float *Wmu, const float *bmu, const float *Wp, const float *u, const float *dk, float *dxk, float *gW1,
-                       float *gb1, float *gWmu, float *gbmu, float *gWp, float *gbp, void *ws, void *stream);
+                       float *gb1, float *gWmu, float *gbmu, float *gWp, float *gbp, int out_act, void *ws, void *stream);
 /* per-node part of the backward: dk -> dkp [N], dm [N,h4], dpre1 [N,h2], dxk [N,h], m [N,h4] (recomputed) */
 int dgg_knet_x_bwd_nodes(int64_t N, int h, const float *mu_sd, const float *W1, int h2, const float *Wmu, int h4,
                          const float *Wp, const float *bmu, const float *z, const float *u, const float *dk, float *dkp,
@@ -342,11 +344,13 @@ int dgg_partp_describe(int64_t rows, int K, int64_t ncols, int64_t *out6);
 int dgg_ell_conv_bwd_partp(const float *G, const float *H, int64_t rows, int K, int F, const void *partp_ws, int64_t ncols,
                            const float *rs, float *dA, float *dA_rec, float *dH, float *da, void *stream);
 /* dgg_softk_edge_bwd_part on a payload partition: the column kernel recomputes d loss / d score (ramp + normalisation chain,
- * dgm.py:1410-1420, model.py:1215-1218) from dA_rec and the per-row scalars the row kernel leaves in rowinfo_ws (4*rows floats) */
+ * dgm.py:1410-1420, model.py:1215-1218) from dA_rec and the per-row scalars the row kernel leaves in rowinfo_ws (4*rows floats).
+ * out_act = 1 (mode 0 only): dxp is returned multiplied by LeakyReLU'(xp) -- the gradient of the pre-activation of node_encode_for_edges
+ * (dgm.py:1097-1100) -- so that the weight-gradient product needs no pass over xp for the mask. */
 int dgg_softk_edge_bwd_partp(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *k, const float *rs,
                              const float *dA, const float *dA_rec, const float *da, const float *ahat_rows, int K, int64_t row0, float t,
                              int perturb, int mode, int normalized, const void *partp_ws, int64_t ncols, float *rowinfo_ws, float *dk,
-                             float *dxp, void *stream);
+                             float *dxp, int out_act, void *stream);
 /* GCNII layer epilogue (GraphConvolution.forward, model.py:36-44): out = theta * sw + (1 - theta) * r (+ inp), sw = support W,
  * r = (1 - alpha) * hi + alpha * h0 (h0 NULL: r = hi; inp NULL: no residual).  Backward: dsw = theta g, dhi, dh0 (NULL with h0);
  * the residual input's gradient is g itself. */

@@ -24,7 +24,7 @@ PROTOTYPES = {
     "dgg_degree_stats_ws_bytes": [],
     "dgg_knet_x_fwd": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_knet_x_fwd_mfma": [_vp, _i64, _i32] + [_vp] * 10 + [_vp],
-    "dgg_knet_x_bwd_reg": [_vp, _i64, _i32] + [_vp] * 16 + [_vp, _vp],
+    "dgg_knet_x_bwd_reg": [_vp, _i64, _i32] + [_vp] * 16 + [_i32, _vp, _vp],
     "dgg_knet_x_bwd_ws_bytes": [_i64, _i32],
     "dgg_knet_x_bwd_nodes": [_i64, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_knet_input_deg_fwd": [_vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
@@ -86,7 +86,7 @@ PROTOTYPES = {
     "dgg_partp_build_norm": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp],
     "dgg_ell_conv_bwd_partp": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_softk_edge_bwd_partp": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _i32, _i32, _vp, _i64,
-                                 _vp, _vp, _vp, _vp],
+                                 _vp, _vp, _vp, _i32, _vp],
     "dgg_pack_bf16": [_vp, _i64, _i64, _i32, _vp, _i64, _vp],
     "dgg_gemm_nt_bf16": [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp],
     "dgg_gcnii_gemm_bf16": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _f32, _vp, _vp],

@@ -410,7 +410,8 @@ __global__ __launch_bounds__(256, 2) void knet_x_bwd_reg(const float *__restrict
                                                          const float *__restrict__ mu_sd, const float *__restrict__ W1,
                                                          const float *__restrict__ b1, const float *__restrict__ Wmu,
                                                          const float *__restrict__ Wp, const float *__restrict__ u,
-                                                         const float *__restrict__ dk, float *__restrict__ dxk, float *__restrict__ slab) {
+                                                         const float *__restrict__ dk, float *__restrict__ dxk, float *__restrict__ slab,
+                                                         int out_act) {
     using KB = KnetBwd<H>;
     constexpr int H2 = KB::H2, H4 = KB::H4, NB = KB::NB, NBX = KB::NBX, XS = KB::XS, XR = H / 2, S1 = H / 2 + 1;
     constexpr int KS3 = (H4 + 1) / 2;                             // dz: contraction over the h/4 outputs of k_mu
@@ -522,7 +523,15 @@ __global__ __launch_bounds__(256, 2) void knet_x_bwd_reg(const float *__restrict
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++) {
                     const int c = cb * 32 + 8 * q4 + 4 * hh;
-                    if (c < H) *reinterpret_cast<float4 *>(dxk + n * H + c) = make_float4(df[4 * q4], df[4 * q4 + 1], df[4 * q4 + 2], df[4 * q4 + 3]);
+                    if (c < H) {
+                        float4 v = make_float4(df[4 * q4], df[4 * q4 + 1], df[4 * q4 + 2], df[4 * q4 + 3]);
+                        if (out_act == 1) {                      // d loss / d (pre-activation of xk): LeakyReLU'(xk), the row is in the tile
+                            const float4 xv = *reinterpret_cast<const float4 *>(xt + li * XS + c);
+                            v.x *= xv.x > 0.0f ? 1.0f : 0.01f; v.y *= xv.y > 0.0f ? 1.0f : 0.01f;
+                            v.z *= xv.z > 0.0f ? 1.0f : 0.01f; v.w *= xv.w > 0.0f ? 1.0f : 0.01f;
+                        }
+                        *reinterpret_cast<float4 *>(dxk + n * H + c) = v;
+                    }
                 }
             }
         }
@@ -815,8 +824,9 @@ size_t dgg_knet_x_bwd_ws_bytes(int64_t N, int h) {
 }
 int dgg_knet_x_bwd_reg(const float *xk, int64_t N, int h, const float *deg, const float *mu_sd, const float *W1, const float *b1,
                        const float *Wmu, const float *bmu, const float *Wp, const float *u, const float *dk, float *dxk, float *gW1,
-                       float *gb1, float *gWmu, float *gbmu, float *gWp, float *gbp, void *ws, void *stream) {
+                       float *gb1, float *gWmu, float *gbmu, float *gWp, float *gbp, int out_act, void *ws, void *stream) {
     if (h != 16 && h != 32 && h != 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "MFMA k-net: latent_dim in {16, 32, 64}");
+    if (out_act != 0 && out_act != 1) return dgg_set_error(DGG_ERR_ARG, "knet_x_bwd_reg: out_act is 0 or 1 (LeakyReLU)");
     if (!ws || (reinterpret_cast<uintptr_t>(xk) % 16) || (reinterpret_cast<uintptr_t>(dxk) % 16))
         return dgg_set_error(DGG_ERR_ARG, "knet_x_bwd_reg: workspace missing or xk / dxk not 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -824,7 +834,7 @@ int dgg_knet_x_bwd_reg(const float *xk, int64_t N, int h, const float *deg, cons
     float *slab = reinterpret_cast<float *>(ws);
 #define DGG_KNET_BWD_REG(HH)                                                                                               \
     if (grid > 0)                                                                                                          \
-        hipLaunchKernelGGL(knet_x_bwd_reg<HH>, dim3((unsigned)grid), dim3(256), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, Wp, u, dk, dxk, slab); \
+        hipLaunchKernelGGL(knet_x_bwd_reg<HH>, dim3((unsigned)grid), dim3(256), 0, st, xk, N, deg, mu_sd, W1, b1, Wmu, Wp, u, dk, dxk, slab, out_act); \
     hipLaunchKernelGGL(knet_bwd_reduce<HH>, dim3((unsigned)KnetBwd<HH>::NREG), dim3(1024), 0, st, slab, grid, Wmu, bmu, Wp, gW1, gb1, gWmu, gbmu, \
                        gWp, gbp)
     switch (h) {

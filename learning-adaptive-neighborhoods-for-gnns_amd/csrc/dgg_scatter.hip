@@ -204,7 +204,11 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
             const float ai = __fdiv_rn(1.0f, c_sqrt(rsi)), aj = __fdiv_rn(1.0f, c_sqrt(sk.rs[jl >= 0 ? jl : gi]));
             float dai = sk.da[gi];
             if (sk.ahat_rows) {
-                float rp = lane < K ? dw * sk.ahat_rows[i * K + lane] : 0.0f;
+                const float ah = lane < K ? sk.ahat_rows[i * K + lane] : 0.0f;
+                // entries outside the partition (ahat == 0: empty slot or saturated ramp) were never written by conv_bwd_node:
+                // with the payload partition dA is NOT zero-filled by the caller, so their dA is masked here
+                if (PAY && ah == 0.0f) dw = 0.0f;
+                float rp = dw * ah;
                 rp = wave_sum_dpp(rp, lane);
                 dai += rp * sqrtf(rsi);
             }
@@ -602,7 +606,7 @@ template <int H>
 __global__ __launch_bounds__(256) void edge_bwd_node(const float *__restrict__ xp, int64_t ncols, const int *__restrict__ nodeptr,
                                                      const int4 *__restrict__ recs, const float *__restrict__ dA_rec,
                                                      const float4 *__restrict__ rowinfo, const float *__restrict__ rs, int normalized,
-                                                     int64_t row0, int64_t rows, float t, int perturb, float *__restrict__ dxp) {
+                                                     int64_t row0, int64_t rows, float t, int perturb, float *__restrict__ dxp, int out_act) {
     constexpr int LPR = H / 4, NPI = 64 / LPR, NBT = (32 / NPI) < 1 ? 1 : 32 / NPI, PER = NBT * NPI;   // 32 records per iteration
     const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
     const int64_t j = (int64_t)blockIdx.x * 4 + dgg::wave_id();
@@ -672,6 +676,10 @@ __global__ __launch_bounds__(256) void edge_bwd_node(const float *__restrict__ x
             float4 v = *o;
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
+        if (out_act == 1) {                                      // d loss / d (pre-activation of xp): LeakyReLU'(xp_j), xp_j is at hand
+            acc.x *= xj.x > 0.0f ? 1.0f : 0.01f; acc.y *= xj.y > 0.0f ? 1.0f : 0.01f;
+            acc.z *= xj.z > 0.0f ? 1.0f : 0.01f; acc.w *= xj.w > 0.0f ? 1.0f : 0.01f;
+        }
         *o = acc;
     }
 }
@@ -740,7 +748,7 @@ template <int H, int NBT>
 __global__ __launch_bounds__(256) void edge_bwd_nodeg(const float *__restrict__ xp, int64_t ncols, const int *__restrict__ nodeptr,
                                                       const int4 *__restrict__ recs, const float *__restrict__ dA_rec,
                                                       const float4 *__restrict__ rowinfo, const float *__restrict__ rs, int normalized,
-                                                      int64_t row0, int64_t rows, float t, int perturb, float *__restrict__ dxp) {
+                                                      int64_t row0, int64_t rows, float t, int perturb, float *__restrict__ dxp, int out_act) {
     constexpr int LPR = H / 4, NPW = 64 / LPR;
     static_assert(NBT <= LPR, "one lane of the group per record of a batch");
     const int lane = threadIdx.x & 63, c4 = lane % LPR, gbase = lane - c4;
@@ -807,6 +815,10 @@ __global__ __launch_bounds__(256) void edge_bwd_nodeg(const float *__restrict__ 
     if (j >= row0 && j < row0 + rows) {
         const float4 v = *o;
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (out_act == 1) {
+        acc.x *= xj.x > 0.0f ? 1.0f : 0.01f; acc.y *= xj.y > 0.0f ? 1.0f : 0.01f;
+        acc.z *= xj.z > 0.0f ? 1.0f : 0.01f; acc.w *= xj.w > 0.0f ? 1.0f : 0.01f;
     }
     *o = acc;
 }
@@ -1408,8 +1420,10 @@ int dgg_ell_conv_bwd_partp(const float *G, const float *H, int64_t rows, int K, 
 int dgg_softk_edge_bwd_partp(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *k, const float *rs,
                              const float *dA, const float *dA_rec, const float *da, const float *ahat_rows, int K, int64_t row0, float t,
                              int perturb, int mode, int normalized, const void *partp_ws, int64_t ncols, float *rowinfo_ws, float *dk,
-                             float *dxp, void *stream) {
+                             float *dxp, int out_act, void *stream) {
     if (mode != 0 && mode != 1) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: mode must be 0 (k_times) or 1 (k_only)");
+    if (out_act != 0 && (out_act != 1 || mode != 0))             // (mode 1 launches no node kernel: nothing would apply the mask)
+        return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: out_act is 0 or 1 (LeakyReLU), mode 0 only");
     if (!k || !dA || !dA_rec || !dk || !rowinfo_ws || (normalized && (!rs || !da))) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: missing operand");
     if (ahat_rows && !normalized) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: ahat_rows is an operand of the normalised form");
     if (!partp_ws || dgg_partp_ws_bytes(rows, K, ncols) == 0) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: no partition");
@@ -1426,10 +1440,10 @@ int dgg_softk_edge_bwd_partp(const float *xp, int64_t rows, int h, const int32_t
     if (mode == 0 && grouped)                                                                                                \
         hipLaunchKernelGGL((edge_bwd_nodeg<HH, 4>), dim3((unsigned)((ncols + 4 * (256 / HH) - 1) / (4 * (256 / HH)))), dim3(256), 0, st, xp, \
                            ncols, p.nodeptr, p.recs, dA_rec, reinterpret_cast<const float4 *>(rowinfo_ws), rs, normalized, row0, rows, t, \
-                           perturb, dxp);                                                                                    \
+                           perturb, dxp, out_act);                                                                           \
     else if (mode == 0)                                                                                                      \
         hipLaunchKernelGGL(edge_bwd_node<HH>, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, xp, ncols, p.nodeptr, p.recs, dA_rec, \
-                           reinterpret_cast<const float4 *>(rowinfo_ws), rs, normalized, row0, rows, t, perturb, dxp)
+                           reinterpret_cast<const float4 *>(rowinfo_ws), rs, normalized, row0, rows, t, perturb, dxp, out_act)
     switch (h) {
         case 16: DGG_EDGE_PARTP(16); break;
         case 32: DGG_EDGE_PARTP(32); break;

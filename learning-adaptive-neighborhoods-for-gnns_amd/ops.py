@@ -847,16 +847,17 @@ def partp_build(idx, w, val, rs_rows, ncols, rs_all=None):
     return PartP(ws, N, K, ncols), ahat
 
 
-def conv_bwd_cols_p(idx, H, G, partp, rs):
+def conv_bwd_cols_p(idx, H, G, partp, rs, zero_dA=True):
     """conv_bwd_cols on a payload partition -> dA [rows,K], dA_rec [rows*K], dH [ncols,F], da [ncols] (neighbour side); None when
-    the kernel does not cover the shape"""
+    the kernel does not cover the shape.  zero_dA=False: entries outside the partition are left UNINITIALISED -- for a consumer that
+    masks them itself (softk_edge_bwd_p with ahat_rows does)"""
     N, K = idx.shape
     H, G = _chk(H), _chk(G)
     F = H.shape[1]
     if partp is None or F not in CONV_BWD_WIDTHS or H.data_ptr() % 16 or G.data_ptr() % 16 or H.shape[0] != partp.ncols:
         return None
     ncols = H.shape[0]
-    dA = _zeros((N, K), H.device)                                                # entries outside the partition stay 0
+    dA = _zeros((N, K), H.device) if zero_dA else torch.empty((N, K), device=H.device, dtype=torch.float32)   # entries outside the partition stay 0
     # one wavefront per destination node owns dH_j / da_j: plain stores for every node, no zero fill
     # (an EMPTY row shard launches nothing: the outputs the other ranks reduce must then be zeros, not uninitialised memory)
     alloc = torch.zeros if N == 0 else torch.empty
@@ -870,8 +871,9 @@ def conv_bwd_cols_p(idx, H, G, partp, rs):
     return dA, dA_rec, dH, da
 
 
-def softk_edge_bwd_p(xp, idx, val, k, dA, dA_rec, rs, da, row0, t, perturb, mode, normalized, partp, ahat_rows=None):
-    """softk_edge_bwd on a payload partition -> dxp [Nglobal,h], dk [N]; None when it does not apply"""
+def softk_edge_bwd_p(xp, idx, val, k, dA, dA_rec, rs, da, row0, t, perturb, mode, normalized, partp, ahat_rows=None, out_act=ACT_NONE):
+    """softk_edge_bwd on a payload partition -> dxp [Nglobal,h], dk [N]; None when it does not apply.  out_act=ACT_LEAKY (mode 0):
+    dxp comes back multiplied by LeakyReLU'(xp), the gradient of the pre-activation of the layer that produced xp"""
     xp = _chk(xp)
     Ng, h = xp.shape
     N, K = idx.shape
@@ -885,7 +887,7 @@ def softk_edge_bwd_p(xp, idx, val, k, dA, dA_rec, rs, da, row0, t, perturb, mode
     _lib.check(_lib.lib().dgg_softk_edge_bwd_partp(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(k)), _ptr(rs), _ptr(_chk(dA)),
                                                    _ptr(dA_rec), _ptr(da), _ptr(None if ahat_rows is None else _chk(ahat_rows)), K, row0, t,
                                                    int(perturb), mode, int(normalized), _ptr(partp.ws), Ng, _ptr(rowinfo), _ptr(dk), _ptr(dxp),
-                                                   _stream()), "softk_edge_bwd_partp")
+                                                   int(out_act), _stream()), "softk_edge_bwd_partp")
     _probe_end("edge_bwd", pe)
     return dxp, dk
 
@@ -1004,6 +1006,7 @@ def knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, save=True):
 
 
 KNET_MFMA_WIDTHS = (16, 32, 64)
+PREMASK = True      # softk_edge_bwd_p / knet_x_bwd_fused can return gradients of the PRE-activation (out_act): see ShardedDGGConv._premask
 
 
 def knet_x_fwd_slim(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp):
@@ -1018,9 +1021,9 @@ def knet_x_fwd_slim(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp):
     return k, u
 
 
-def knet_x_bwd_fused(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, u, dk):
+def knet_x_bwd_fused(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, u, dk, out_act=ACT_NONE):
     """one pass over xk -> dxk [N,h], dW1, db1, dWmu, dbmu, dWp ([h4]), dbp ([1])  (dgg_knet_x_bwd_reg: per-workgroup slabs + one
-    reduce launch, nothing accumulated into)"""
+    reduce launch, nothing accumulated into).  out_act=ACT_LEAKY: dxk comes back multiplied by LeakyReLU'(xk)"""
     xk = _chk(xk)
     N, h = xk.shape
     h2, h4 = W1.shape[0], Wmu.shape[0]
@@ -1038,7 +1041,7 @@ def knet_x_bwd_fused(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, u, dk):
     ws = torch.empty((int(_lib.lib().dgg_knet_x_bwd_ws_bytes(N, h)),), device=dev, dtype=torch.uint8)
     _lib.check(_lib.lib().dgg_knet_x_bwd_reg(_ptr(xk), N, h, _ptr(_chk(deg)), _ptr(mu_sd), _ptr(_chk(W1)), _ptr(_chk(b1)), _ptr(_chk(Wmu)),
                                              _ptr(_chk(bmu)), _ptr(_chk(Wp)), _ptr(_chk(u)), _ptr(_chk(dk)), _ptr(dxk), _ptr(gW1), _ptr(gb1),
-                                             _ptr(gWmu), _ptr(gbmu), _ptr(gWp), _ptr(gbp), _ptr(ws), _stream()), "knet_x_bwd_reg")
+                                             _ptr(gWmu), _ptr(gbmu), _ptr(gWp), _ptr(gbp), int(out_act), _ptr(ws), _stream()), "knet_x_bwd_reg")
     return dxk, gW1, gb1, gWmu, gbmu, gWp, gbp
 
 

@@ -207,10 +207,10 @@ class ShardedDGGConv:
         if hasattr(kern, "zero_pool"):                   # every zero-initialised accumulator of the backward from ONE filled buffer
             ncols, h, F = s["xp"].shape[0], s["xp"].shape[1], s["H"].shape[1]
             rows = s["idx"].shape[0]
-            # (payload path: dH / da / dxp are written by their owner wavefronts, only dA and the weight gradients are accumulated into)
-            need = rows * self.K + 3 * sum(int(v.numel()) for v in P.values()) + 65536
+            # (payload path: dH / da / dxp / dA are written by their owner wavefronts, only the weight gradients are accumulated into)
+            need = 3 * sum(int(v.numel()) for v in P.values()) + 65536
             if s.get("partp") is None:
-                need += ncols * (h + F + 2)
+                need += rows * self.K + ncols * (h + F + 2)
             with kern.zero_pool(s["xp"].device, need):
                 return self._backward(dZ, x_local, P)
         return self._backward(dZ, x_local, P)
@@ -237,14 +237,18 @@ class ShardedDGGConv:
         # (which adds the row side of da in registers), so both must cover the shape
         partp = s.get("partp")
         if partp is not None:
-            pc = kern.conv_bwd_cols_p(s["idx"], s["H"], G, partp, s["rs"])
+            # (dA of the entries outside the partition is masked by the row kernel -- ahat_rows is 0 there -- so it is not zero-filled)
+            pc = kern.conv_bwd_cols_p(s["idx"], s["H"], G, partp, s["rs"], zero_dA=False)
             assert pc is not None
             dA, dA_rec, dH, da = pc
             if self.coll:
                 dist.all_reduce(da, group=self.group)
+            # the activation derivative of the two LeakyReLU projections is applied by the kernels that PRODUCE dxp / dxk (they hold
+            # xp_j / xk in registers): the fused weight-gradient product then reads no forward output for the mask (51 MB less)
+            pre = self._premask(x_local)
             dxp, dk = kern.softk_edge_bwd_p(s["xp"], s["idx"], s["val"], s["k"], dA, dA_rec, s["rs"], da, self.r0, self.t,
-                                            self.noise_mode != 0, self.mode, True, partp, ahat_rows=s["ahat"])
-            return self._weight_grads(g, dxp, dH, dk, x_local, P)
+                                            self.noise_mode != 0, self.mode, True, partp, ahat_rows=s["ahat"], out_act=1 if pre else 0)
+            return self._weight_grads(g, dxp, dH, dk, x_local, P, premasked=pre)
         cols = None
         if part is not None and hasattr(kern, "conv_bwd_cols") and hasattr(kern, "softk_edge_bwd") and \
                 s["xp"].shape[1] in (16, 32, 64, 128) and self.mode in (0, 1):
@@ -272,7 +276,14 @@ class ShardedDGGConv:
                 if part is not None else kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0)
         return self._weight_grads(g, dxp, dH, dk, x_local, P)
 
-    def _weight_grads(self, g, dxp, dH, dk, x_local, P):
+    def _premask(self, x_local):
+        """True when the step's weight gradients go through linear_bwd_multi (no input gradient) and the producers of dxp / dxk can
+        apply LeakyReLU' themselves (ranked / k_times_edge_prob path on the HIP kernels)"""
+        kern = self.kern
+        return bool(getattr(kern, "PREMASK", False)) and hasattr(kern, "linear_bwd_multi") and not self.x_grad and self.mode == 0 and \
+            self.saved["z"] is None and not (self.coll and self.x_full is None)
+
+    def _weight_grads(self, g, dxp, dH, dk, x_local, P, premasked=False):
         kern, s = self.kern, self.saved
         repl = self.x_full is not None
         # weight gradients of the two projections.  Replicated features: partial [dxp | dH] of all N nodes against the full X (the
@@ -283,7 +294,10 @@ class ShardedDGGConv:
             dxp_g, dH_g, Xg, xp_g = both[:, :h].contiguous(), both[:, h:].contiguous(), x_local, s["xp_loc"]
         else:
             dxp_g, dH_g, Xg, xp_g = dxp, dH, (self.x_full if repl else x_local), s["xp"]
-        if s["z"] is None:
+        if s["z"] is None and premasked:
+            dxk, g["W1"], g["b1"], g["Wmu"], g["bmu"], dWp, g["bp"] = kern.knet_x_bwd_fused(
+                s["xk"], s["deg_local"], s["mu_sd"], P["W1"], P["b1"], P["Wmu"], P["bmu"], P["Wp"].reshape(-1), s["u"], dk, out_act=1)
+        elif s["z"] is None:
             dxk, g["W1"], g["b1"], g["Wmu"], g["bmu"], dWp, g["bp"] = kern.knet_x_bwd_fused(
                 s["xk"], s["deg_local"], s["mu_sd"], P["W1"], P["b1"], P["Wmu"], P["bmu"], P["Wp"].reshape(-1), s["u"], dk)
         else:
@@ -293,13 +307,16 @@ class ShardedDGGConv:
         same_rows = Xg.shape[0] == x_local.shape[0] and (not repl or self.world == 1) and self.emulate is None
         if hasattr(kern, "linear_bwd_multi") and not self.x_grad and same_rows:
             # one pass over X for the three weight gradients (leaky masks applied on the operand load)
+            ym, am = (None, 0) if premasked else (True, 1)          # premasked: dxp / dxk already carry LeakyReLU'
             (g["We"], g["be"]), (g["Wk"], g["bk"]), (g["Wc"], _) = kern.linear_bwd_multi(
-                Xg, [(P["We"], xp_g, dxp_g, 1, 0, True), (P["Wk"], s["xk"], dxk, 1, 0, True), (P["Wc"], None, dH_g, 0, 1, False)])
+                Xg, [(P["We"], xp_g if ym else None, dxp_g, am, 0, True), (P["Wk"], s["xk"] if ym else None, dxk, am, 0, True),
+                     (P["Wc"], None, dH_g, 0, 1, False)])
             dX1 = dX2 = dX3 = None
         elif hasattr(kern, "linear_bwd_multi") and not self.x_grad:
+            ym, am = (None, 0) if premasked else (True, 1)
             (g["We"], g["be"]), (g["Wc"], _) = kern.linear_bwd_multi(
-                Xg, [(P["We"], xp_g, dxp_g, 1, 0, True), (P["Wc"], None, dH_g, 0, 1, False)])
-            _, g["Wk"], g["bk"] = kern.linear_bwd(x_local, P["Wk"], s["xk"], dxk, 1, 0, False, True)
+                Xg, [(P["We"], xp_g if ym else None, dxp_g, am, 0, True), (P["Wc"], None, dH_g, 0, 1, False)])
+            _, g["Wk"], g["bk"] = kern.linear_bwd(x_local, P["Wk"], s["xk"] if ym else None, dxk, am, 0, False, True)
             dX1 = dX2 = dX3 = None
         else:
             dX1, g["We"], g["be"] = kern.linear_bwd(Xg, P["We"], xp_g, dxp_g, 1, 0, self.x_grad, True)
