@@ -158,6 +158,10 @@ def probe_steps(step_fn, nsteps=5):
 
 
 def bench_edgelist(a, dev):
+    emit_json(run_edgelist(a, dev))
+
+
+def run_edgelist(a, dev):
     """BASELINE.json configs[1] (Pubmed shape: N=19 717, d=500, edge-list candidates, k~16): the drop-in MODULES
     (DGG_LearnableK_debug -> normalize -> GCNConv) under autograd, forward + backward, one GPU; the oracle pipeline on
     all host cores beside it.  Not the headline metric (that is the default workload): run with --workload pubmed."""
@@ -258,7 +262,7 @@ def bench_edgelist(a, dev):
         if a.cpu_dense:
             # the dense reference-shaped formulation at the Pubmed size (about 26 GB of host memory)
             out["cpu_baseline"]["dense_formulation"] = cpu_dense_formulation([("edgelist", N, d, h)], min(os.cpu_count() or 1, 32))
-    emit_json((out))
+    return out
 
 
 def bench_module_api(a, dev):
@@ -307,6 +311,10 @@ def bench_module_api(a, dev):
 
 
 def bench_ppi(a, dev):
+    emit_json(run_ppi(a, dev))
+
+
+def run_ppi(a, dev):
     """BASELINE.json configs[4] (PPI shape: graphs of 591..3480 nodes, d=50, hidden 2048, 9 GCNII layers, 121 labels,
     train_ppi.py:43-44): dgg_amd.GCNIIppi_DGG under autograd, one forward + backward per graph; fp32, or with --bf16 the GCNII
     layer products on the hand-written bf16 MFMA kernel (dgg_bf16.hip).  The DGG runs at latent_dim = hidden = 2048
@@ -368,7 +376,7 @@ def bench_ppi(a, dev):
     else:
         t_g = (pk["linear_fwd"][0] + pk["linear_bwd"][0]) * 1e-3      # includes the (small) DGG projections
         per_kernel = {"linear_fwd": {"ms_per_step": pk["linear_fwd"][0]}, "linear_bwd": {"ms_per_step": pk["linear_bwd"][0]}}
-    emit_json(({
+    return ({
         "metric": "DGG adj-build+SpMM fwd/bwd edges/sec (multi-graph, PPI shape)", "value": cand / T, "unit": "edges/s", "n_gpus": 1,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": T * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16 GEMMs / f32 DGG" if a.bf16 else "f32", "data": "synthetic",
@@ -385,7 +393,7 @@ def bench_ppi(a, dev):
                      "note": "GEMM flops of the GCNII layers / summed event-timed duration of the GEMM calls inside running steps"},
         "kernels_ms_per_step": {n_: v[0] for n_, v in pk.items()},
         "cpu_baseline": (cpu_baseline_ppi(m, min(graphs, key=lambda g_: g_[0].shape[0]), min(os.cpu_count() or 1, 32))
-                         if a.cpu_rows >= 0 else None)}))
+                         if a.cpu_rows >= 0 else None)})
 
 
 def cpu_baseline_ppi(m, graph, threads, lamda=0.5, alpha=0.5):
@@ -504,6 +512,9 @@ def main():
                                                             "as make the timed region last >= 3 s (at least 11)")
     ap.add_argument("--no-variants", dest="variants", action="store_false",
                     help="skip the symmetric / unperturbed / hash / latent-128 / x-grad variants of the step (one GPU only)")
+    ap.add_argument("--no-configs", dest="configs", action="store_false",
+                    help="skip the compact lines of the other BASELINE.json configs (Pubmed shape, PPI bf16, N = 500 000 on one GPU) "
+                         "that the default run appends under `configs`")
     ap.add_argument("--no-cpu-dense", dest="cpu_dense", action="store_false",
                     help="skip the dense reference-shaped CPU formulation at N = 2 708 / 4 000 (BASELINE.md section 3)")
     ap.add_argument("--feat", type=int, default=128)
@@ -515,6 +526,11 @@ def main():
                          "N^2 sweep), sym (symmetric per-pair hash: the reference's symmetric_noise=True), rsym (the ranked symmetric generator: "
                          "same symmetric law, owners list their largest noises first, O(N*300)), all iid Gumbel(0,0.3); "
                          "none = unperturbed scores (the reference's perturb_edge_prob=False: bf16-MFMA-bounded N^2 sweep)")
+    ap.add_argument("--feat-scale", type=float, default=1.0,
+                    help="multiply the synthetic node features by this factor (the ranked search's walk depth grows like "
+                         "exp(spread of 0.05 ||xp_i - xp_j|| / 0.3): see `data_regimes` in the output line)")
+    ap.add_argument("--data", choices=["randn", "clustered"], default="randn",
+                    help="clustered: a tight blob of 3 000 nodes + 40 far outliers inside randn features (tests/test_hip_parity.py)")
     ap.add_argument("--x-grad", action="store_true", help="also compute d loss / d x (reduce-scatter across ranks)")
     ap.add_argument("--strong", action="store_true", help="(default for several GPUs; kept for compatibility)")
     ap.add_argument("--exchange", choices=["replicate", "gather"], default="replicate",
@@ -563,7 +579,8 @@ def main():
 class SyntheticRun:
     """One configuration of the synthetic all-pairs workload: inputs resident in HBM, the layer, and the step function."""
 
-    def __init__(self, a, dev, world, rank, force, N, d, h, noise_mode, x_grad=False, emu=0, exchange="replicate"):
+    def __init__(self, a, dev, world, rank, force, N, d, h, noise_mode, x_grad=False, emu=0, exchange="replicate", feat_scale=None,
+                 data=None):
         from dgg_amd import ops
         from dgg_amd.parallel import ShardedDGGConv, shard_bounds, _all_gather_rows
         self.N, self.d, self.h, self.world, self.rank, self.emu = N, d, h, world, rank, emu
@@ -571,7 +588,12 @@ class SyntheticRun:
         self.erank = emu // 2
         self.r0, self.r1, _ = shard_bounds(N, emu, self.erank) if emu else shard_bounds(N, world, rank)
         g = torch.Generator(device="cpu").manual_seed(1000 + rank)
-        self.x_local = torch.randn(self.r1 - self.r0, d, generator=g).to(dev)
+        x_cpu = torch.randn(self.r1 - self.r0, d, generator=g)
+        if (data or getattr(a, "data", "randn")) == "clustered" and N >= 30_000 and world == 1 and not emu:
+            x_cpu[20_000:23_000] *= 0.05                          # tight cluster: tiny neighbour radius
+            x_cpu[23_000:23_040] = x_cpu[23_000:23_040] * 0.01 + 3.0   # 40 outliers far from everything
+        fs = float(feat_scale if feat_scale is not None else getattr(a, "feat_scale", 1.0))
+        self.x_local = (x_cpu * fs).to(dev)
         self.deg = (24 + 16 * torch.rand(N, generator=torch.Generator(device="cpu").manual_seed(7))).to(dev)
         # features are DATA unless x_grad: with more than one rank they are replicated once, here, outside the timed region (data
         # placement: 4*N*d bytes per GPU), and no feature tensor crosses the fabric per step (dgg_amd/parallel.py)
@@ -697,6 +719,69 @@ def cpu_dense_formulation(sizes, threads):
     return out
 
 
+def other_configs(a, dev):
+    """Compact results of BASELINE.json configs[1], [4] and [3] (single GPU) for the default run's JSON line: ms per step, value,
+    roofline of the dominant kernel / GEMMs, CPU baseline.  Short windows (these are secondary lines; the full ones: --workload
+    pubmed / --workload ppi --bf16 / --nodes 500000)."""
+    import copy
+    from dgg_amd import ops
+    res = {}
+
+    def pick(o, extra=()):
+        keep = ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "roofline", "cpu_baseline", "kernels_ms_per_step") + tuple(extra)
+        d_ = {k_: o.get(k_) for k_ in keep if k_ in o}
+        d_["workload"] = o["config"]["workload"]
+        return d_
+    try:
+        b = copy.copy(a)
+        b.steps, b.warmup, b.edge_mode, b.cpu_dense = 20, 3, "u-v-dist", False
+        res["pubmed_uvdist"] = pick(run_edgelist(b, dev))
+    except Exception as e:  # noqa: BLE001
+        res["pubmed_uvdist"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    try:
+        b = copy.copy(a)
+        b.steps, b.warmup, b.graphs, b.bf16 = 3, 2, 4, True
+        res["ppi_bf16"] = pick(run_ppi(b, dev))
+    except Exception as e:  # noqa: BLE001
+        res["ppi_bf16"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    try:
+        N5 = 500_000
+        r5 = SyntheticRun(a, dev, 1, 0, False, N5, a.feat, a.latent, ops.NOISE_RANKED, feat_scale=1.0, data="randn")
+        for s_ in range(3):
+            r5.step(s_)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s_ in range(10):
+            r5.step(s_ % NGRAPH)
+        torch.cuda.synchronize()
+        T5 = (time.perf_counter() - t0) / 10
+        ops.PROBE = {}
+        r5.step(0)
+        torch.cuda.synchronize()
+        pv, ops.PROBE = ops.PROBE, None
+        km = float(r5.layer.saved["k"].mean().item())
+        kern5 = {n_: sum(e0.elapsed_time(e1) for e0, e1 in ev) for n_, ev in pv.items()}
+        kept5 = float((r5.layer.saved["idx"] >= 0).sum().item())
+        dom5 = max(kern5, key=kern5.get)
+        comp5 = N5 * 4.0 * a.latent + kept5 * 8 + N5 * 4
+        res["n500k_one_gpu"] = {"workload": f"synthetic all-pairs DGG N={N5} d={a.feat} h={a.latent} k~{km:.1f} on ONE GPU (BASELINE configs[3]'s graph), "
+                                            "eager launches", "ms_per_step": T5 * 1e3, "value": N5 * km / T5, "unit": "edges/s", "steps": 10,
+                                "dtype": "f32", "kernels_ms_per_step": kern5,
+                                "roofline": {"bound": "hbm", "kernel": "allpairs_topk", "kernel_ms": kern5.get("allpairs_topk"),
+                                             "algorithmic_bytes": comp5, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
+                                             "achieved": comp5 / (kern5["allpairs_topk"] * 1e-3) / 1e9,
+                                             "frac": comp5 / (kern5["allpairs_topk"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                             "dominant_by_time": dom5},
+                                "cpu_baseline": None}
+        del r5
+    except Exception as e:  # noqa: BLE001
+        res["n500k_one_gpu"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    return res
+
+
 def bench_synthetic(a, dev, world, rank, force):
     from dgg_amd import ops
     d, h = a.feat, a.latent
@@ -774,6 +859,53 @@ def bench_synthetic(a, dev, world, rank, force):
         v["gather_GBps"] = v["gathered"] / (v["ms"] * 1e-3) / 1e9
     pairs = float(rows_loc) * N
     t_pair = tk["allpairs_topk"]
+
+    # ---- the ranked search's walk, MEASURED on this run's data (not a literal): one probe launch over every row
+    walk = None
+    if noise_mode == ops.NOISE_RANKED:
+        walk = ops.ranked_probe(sv["xp"], sv["k"], layer.t, (1234, 0), rows=(r0, r1))
+    # ---- data regimes: the same step on features scaled x4 / x16 and on clustered data.  Per regime: the measured walk (every 16th
+    # row, no budget), the PILOT's estimate (~1000 sampled rows, 64-block budget: what DGG_LearnableK_debug runs under
+    # args.dgg_asym_generator = "auto"), the step time under the ranked generator and, for comparison, the pair stage of the per-pair
+    # hash evaluator (guess-and-verify) on the same data: it depends on the regime as much and is slower wherever the ranked search is.
+    regimes = None
+    if world == 1 and not force and not emu and a.variants and noise_mode == ops.NOISE_RANKED:
+        regimes = {}
+        for name, (fs_, dat_) in {"randn_x1": (1.0, "randn"), "randn_x4": (4.0, "randn"), "randn_x16": (16.0, "randn"),
+                                   "clustered": (1.0, "clustered")}.items():
+            try:
+                rr = SyntheticRun(a, dev, 1, 0, False, N, d, h, ops.NOISE_RANKED, feat_scale=fs_, data=dat_)
+                xp_r = ops.linear_fwd(rr.x_local, rr.P["We"], rr.P["be"], ops.ACT_LEAKY)
+                pilot = ops.ranked_probe(xp_r, None, rr.layer.t, (1234, 0), stride=max(1, N // 1024), max_blocks=64)
+                est = ops.ranked_cost_estimate(pilot, N)
+                meas = ops.ranked_probe(xp_r, None, rr.layer.t, (1234, 0), stride=16)
+                nst = 3 if meas["blocks_per_row"] > 50 else 10
+                rr.step(0)
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for s_ in range(nst):
+                    rr.step(s_ % NGRAPH)
+                torch.cuda.synchronize()
+                ms_ranked = (time.perf_counter() - t0_) / nst * 1e3
+                kk = rr.layer.saved["k"]
+                ops.allpairs_topk(xp_r, 64, noise_mode=ops.NOISE_HASH, seed=(1234, 0), algo=4, k_limit=kk)
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                ops.allpairs_topk(xp_r, 64, noise_mode=ops.NOISE_HASH, seed=(1234, 1), algo=4, k_limit=kk)
+                torch.cuda.synchronize()
+                ms_hash_pair = (time.perf_counter() - t0_) * 1e3
+                ops.PROBE = {}
+                rr.step(0)
+                torch.cuda.synchronize()
+                pv, ops.PROBE = ops.PROBE, None
+                e0, e1 = pv["allpairs_topk"][0]
+                regimes[name] = {"feat_scale": fs_, "data": dat_, "pilot": pilot, "pilot_estimate_ms": est * 1e-3,
+                                 "measured_walk_every_16th_row": meas, "ms_per_step_ranked": ms_ranked,
+                                 "pair_stage_ms_ranked": e0.elapsed_time(e1), "pair_stage_ms_hash_guess_and_verify": ms_hash_pair}
+                del rr, xp_r
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001
+                regimes[name] = {"error": repr(e)}
 
     # ---- variants of the same step ("and a symmetric run", "also report h=128"; the reference script's own defaults
     # are perturb_edge_prob=False / symmetric_noise=True, train_small_graphs.py:153-163): one window each, eager launches
@@ -926,10 +1058,19 @@ def bench_synthetic(a, dev, world, rank, force):
                                   "of the step (every array once); frac_hbm_gathered counts the gathered rows of the gather kernels once "
                                   "per use over the whole step time"},
             "pair_stage": {"kernel": "allpairs_topk(" + a.noise + ")", "kernel_ms": t_pair * 1e3, "pairs_per_s": pairs / t_pair,
-                           "note": "the ranked-noise search scores ~80 candidates per row, not N: N^2 flop counts do not apply to it; the "
-                                   "kernels that sweep all N^2 pairs are the `symmetric` / `unperturbed` / `hash_asymmetric` variants"},
+                           "measured_walk": walk,
+                           "note": "measured_walk: dgg_allpairs_ranked_probe over EVERY row of this run's projected features (blocks of 64 "
+                                   "ranks visited, candidate rows gathered, candidates scored in full, per row): the ranked-noise search "
+                                   "scores that many candidates per row, not N, so N^2 flop counts do not apply to it -- and the depth "
+                                   "is a property of the DATA (see data_regimes); the kernels that sweep all N^2 pairs are the "
+                                   "`symmetric` / `unperturbed` / `hash_asymmetric` variants"},
+            "data_regimes": regimes,
             "variants": variants,
         }
+        # ---- the other BASELINE.json configs, compact, in the SAME line (the driver runs only this default command): configs[1] Pubmed
+        # shape through the drop-in modules, configs[4] PPI shape with bf16 layer products, configs[3]'s 500 000-node graph on one GPU
+        if world == 1 and not force and not emu and a.configs and a.variants and N == 100_000:
+            out["configs"] = other_configs(a, dev)
         if a.cpu_rows >= 0 and world == 1:
             cores = os.cpu_count() or 1
             crow = a.cpu_rows if a.cpu_rows > 0 else 64 * cores

@@ -159,6 +159,14 @@ int dgg_knet_input_deg_fwd(const float *deg, int64_t N, float dmean, float dstd,
 int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode,
                       const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val,
                       const float *k_limit, int algo, void *workspace, size_t ws_bytes, void *stream);
+/* Walk statistics of the ranked search (noise_mode DGG_NOISE_RANKED): how deep a row walks depends on the DATA -- about
+ * L exp(spread of 0.05 ||xp_i - xp_j|| over the row / 0.3) ranks -- so callers measure it, or estimate it on a row sample before they
+ * choose this generator over the per-pair hash sweep.  Runs the search of dgg_allpairs_topk on every `stride`-th row of [row0, row1),
+ * each walk cut after `max_blocks` blocks of 64 ranks (0: no cut), and writes nothing but six 64-bit counters:
+ * probe[0..4] += rows walked, blocks visited, candidates gathered, candidates scored in full, rows cut by the budget;
+ * probe[5] = max(probe[5], blocks of a row).  The caller zeroes probe. */
+int dgg_allpairs_ranked_probe(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
+                              const float *k_limit, int stride, int max_blocks, unsigned long long *probe, void *stream);
 /* dgg_allpairs_topk (noise_mode DGG_NOISE_RANKED, K = 64, learned k required) fused with dgg_softk_fwd: the ramp is applied to the
  * settled list while it is still in registers; additionally writes w [row1-row0,64] and rs [row1-row0].  Same bits as the two calls. */
 int dgg_allpairs_topk_ranked_softk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,

@@ -37,6 +37,7 @@ PROTOTYPES = {
     "dgg_allpairs_workspace_bytes": [_i64, _i32, _i32, _i32],
     "dgg_allpairs_sweep_ctl_offset_bytes": [_i64, _i64, _i32],
     "dgg_allpairs_rsym_ctl_offset_bytes": [_i64, _i64],
+    "dgg_allpairs_ranked_probe": [_vp, _i64, _i32, _i64, _i64, _f32, _u32, _u32, _vp, _i32, _i32, _vp, _vp],
     "dgg_allpairs_topk_ranked_softk": [_vp, _i64, _i32, _i64, _i64, _f32, _u32, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "dgg_literal_hard_fwd": [_vp, _i64, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _u32, _u32, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp],
     "dgg_literal_hard_bwd": [_vp, _vp, _i64, _i32, _vp, _vp],

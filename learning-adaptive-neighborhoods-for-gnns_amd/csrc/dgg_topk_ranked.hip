@@ -28,19 +28,27 @@ __device__ __forceinline__ uint64_t wave_inclusive_scan_u64(uint64_t v, int lane
     return v;
 }
 
-template <int H>
+// PROBE (dgg_allpairs_ranked_probe): the same walk on every `stride`-th row with a budget of `max_blocks` blocks, NO list written;
+// probe[0..5] += rows walked, blocks visited, candidates gathered, candidates scored in full, rows that hit the budget; probe[5] =
+// max blocks of a row.  The walk depth depends on the DATA -- a row visits ~ L exp(spread of 0.05 dist / 0.3) ranks -- and this is
+// how callers measure it (bench.py) or estimate it before choosing this generator (dgm.py, args.dgg_asym_generator = "auto").
+template <int H, bool PROBE = false>
 __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restrict__ xp, int64_t N, int64_t row0,
                                                             int64_t row1, float t, uint32_t s0, uint32_t s1,
                                                             const float *__restrict__ klim, int32_t *__restrict__ idx,
                                                             float *__restrict__ val, int softk_mode, float *__restrict__ w_out,
-                                                            float *__restrict__ rs_out, const uint32_t *__restrict__ seed_dev) {
+                                                            float *__restrict__ rs_out, const uint32_t *__restrict__ seed_dev,
+                                                            int stride = 1, int max_blocks = 0,
+                                                            unsigned long long *__restrict__ probe = nullptr) {
     const int lane = threadIdx.x & 63;
     if (seed_dev) { s0 = seed_dev[0]; s1 = seed_dev[1]; }       // seed in device memory: ONE captured hipGraph serves fresh seeds
     // (readfirstlane: the compiler cannot know that dgg::wave_id() is wave-uniform; without it the row's own features are
     //  fetched with VECTOR loads into 64 registers instead of scalar loads)
-    const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
+    const int64_t lrow = ((int64_t)blockIdx.x * 4 + dgg::wave_id()) * (PROBE ? stride : 1);
     const int64_t i = row0 + lrow;
     if (i >= row1) return;
+    unsigned long long nblk = 0, ngath = 0, nsc = 0;
+    bool budget_hit = false;
     // ranks beyond L cannot receive weight (klimit_len): the search only has to settle the first L of the list
     const int L = klim ? __builtin_amdgcn_readfirstlane(klimit_len(klim[lrow], 64)) : 64;
     uint32_t k1, k2;
@@ -66,6 +74,7 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
         // per-candidate version of the stop test: a rank whose noise cannot reach the L-th log-score found so far is
         // not gathered at all (ranks come in decreasing noise order, so these are the tail lanes of the block)
         const bool want = valid && !(G + 1e-8f + 1e-3f < thr_log);
+        if (PROBE) { nblk++; ngath += __builtin_popcountll(__ballot(want)); }
         // (Measured and rejected: staging the candidate rows through LDS so that 8 lanes read one 128-byte line -- 8x fewer L1 tag
         //  lookups, same bits -- costs two LDS round trips per block: 658 us against 257.)
         if (want) {
@@ -106,6 +115,7 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
         //  * otherwise sort + merge.  All three produce the same list (keys are unique).
         uint64_t live = __ballot(key != DGG_EMPTY_KEY);
         const int nlive = __builtin_popcountll(live);
+        if (PROBE) nsc += nlive;
         if (rb == 0) {
             list = wave_sort<true>(key, lane);
         } else if (nlive <= 16) {
@@ -135,6 +145,15 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
             const float gmin = __shfl(G, last, 64);
             if (gmin + 1e-8f + 1e-3f < thr_log) break;
         }
+        if (PROBE && max_blocks > 0 && nblk >= (unsigned long long)max_blocks) { budget_hit = true; break; }
+    }
+    if (PROBE) {
+        if (lane == 0) {
+            atomicAdd(&probe[0], 1ull); atomicAdd(&probe[1], nblk); atomicAdd(&probe[2], ngath); atomicAdd(&probe[3], nsc);
+            if (budget_hit) atomicAdd(&probe[4], 1ull);
+            atomicMax(&probe[5], nblk);
+        }
+        return;
     }
     const bool empty = list == DGG_EMPTY_KEY || lane >= L;
     idx[lrow * 64 + lane] = empty ? -1 : key_col(list);
@@ -199,6 +218,33 @@ int dgg_allpairs_topk_ranked_impl(const float *xp, int64_t N, int h, int64_t row
 }
 
 extern "C" {
+// Walk statistics of the ranked search (noise_mode 4) on every `stride`-th row of [row0, row1), each walk cut after `max_blocks`
+// blocks of 64 ranks (0: no cut); nothing but the six counters is written: probe[0..4] += rows walked, blocks visited, candidates
+// gathered, candidates scored in full, rows cut by the budget; probe[5] = max(probe[5], blocks of a row).  Caller zeroes probe.
+int dgg_allpairs_ranked_probe(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
+                              const float *k_limit, int stride, int max_blocks, unsigned long long *probe, void *stream) {
+    if (row0 < 0 || row1 > N || row0 > row1 || stride < 1 || max_blocks < 0 || !probe)
+        return dgg_set_error(DGG_ERR_ARG, "allpairs_ranked_probe: bad row range, stride, budget or NULL counters");
+    if (N >= ((int64_t)1 << 31)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path needs N < 2^31");
+    if (row1 == row0) return 0;
+    const int64_t nrows = (row1 - row0 + stride - 1) / stride;
+    const dim3 grid((unsigned)((nrows + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+#define DGG_RANKED_PROBE(HH)                                                                                               \
+    hipLaunchKernelGGL((allpairs_topk_ranked<HH, true>), grid, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, k_limit, nullptr, nullptr, 0, \
+                       nullptr, nullptr, nullptr, stride, max_blocks, probe)
+    switch (h) {
+        case 8: DGG_RANKED_PROBE(8); break;
+        case 16: DGG_RANKED_PROBE(16); break;
+        case 32: DGG_RANKED_PROBE(32); break;
+        case 64: DGG_RANKED_PROBE(64); break;
+        case 128: DGG_RANKED_PROBE(128); break;
+        default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path supports latent_dim in {8,16,32,64,128}");
+    }
+#undef DGG_RANKED_PROBE
+    return dgg_check_launch("allpairs_ranked_probe");
+}
+
 // dgg_allpairs_topk (noise_mode DGG_NOISE_RANKED, K = 64, k_limit required) FUSED with dgg_softk_fwd: also w [rows,64] and
 // rs [rows] (mode as dgg_softk_fwd: 0 k_times_edge_prob, 1 k_only, 3 straight-through hard).  Same bits as the two calls.
 int dgg_allpairs_topk_ranked_softk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,

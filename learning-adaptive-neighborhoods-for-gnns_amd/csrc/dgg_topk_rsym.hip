@@ -576,7 +576,12 @@ int dgg_allpairs_topk_rsym_impl(const float *xp, int64_t N, int h, int64_t row0,
     if (N >= ((int64_t)1 << 31)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked symmetric noise needs N < 2^31");
     if (!workspace || ws_bytes < dgg_allpairs_rsym_ws_bytes(row1 - row0, N))
         return dgg_set_error(DGG_ERR_ARG, "ranked symmetric noise: workspace too small (dgg_allpairs_workspace_bytes)");
-    if (row1 <= row0) return 0;
+    if (row1 <= row0) {
+        // an empty row shard launches nothing, but the caller reads the status words (error flag, tier-3 count, walk depth) out of
+        // the workspace it just allocated: they must read "nothing happened", not uninitialised memory
+        const RsLayout L = make_layout(0, N);
+        return dgg_check_hip(hipMemsetAsync(reinterpret_cast<char *>(workspace) + L.ctl, 0, sizeof(RsCtl), st), "rsym memset");
+    }
     switch (h) {
         case 8: return launch_rsym<8>(xp, N, row0, row1, t, s0, s1, klim, idx, val, workspace, st);
         case 16: return launch_rsym<16>(xp, N, row0, row1, t, s0, s1, klim, idx, val, workspace, st);

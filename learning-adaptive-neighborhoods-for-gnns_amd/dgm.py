@@ -337,14 +337,23 @@ class DGG_LearnableK_debug(nn.Module):
                 raise RuntimeError("DGG_LearnableK_debug: the ranked symmetric noise generator could not settle every row inside its "
                                    "workspace (too many rows far from everything else); set args.dgg_sym_generator = 'hash'")
             deep = depth is not None and float(depth) > 0.3 * math.log(8.0)       # tier 2 walked > 8x the pairs of tier 1 (all owners)
-            if t3 is not None and (int(t3) > 0 or deep) and getattr(self.args, "dgg_sym_generator", "ranked") == "ranked":
+            nt3 = int(t3) if t3 is not None else 0
+            if (nt3 > 0 or deep) and self._sym_generator_now() == "ranked":
                 # nodes so far from everything else that their noise rows had to be written out in full: exact, but every such row
-                # costs a complete walk of all owners' sequences -- on this data the per-pair hash generator (same law) is cheaper
+                # costs a complete walk of all owners' sequences -- on this data the per-pair hash generator (same law) is cheaper.
+                # The decision belongs to THIS module (args is usually shared by every DGG of a model) and is taken only when the
+                # caller asked for it (args.dgg_sym_generator = "auto"): a health check must not silently change the noise stream
+                # of a seeded run.  Captured hipGraphs keep replaying the generator they were captured with.
                 import warnings
-                warnings.warn(f"DGG_LearnableK_debug: {int(t3)} rows needed the dense tier of the ranked symmetric noise generator"
+                auto = getattr(self.args, "dgg_sym_generator", "ranked") == "auto"
+                many = nt3 > max(4, self.__dict__.get("_rsym_rows", 0) // 4000) or deep
+                warnings.warn(f"DGG_LearnableK_debug: {nt3} rows needed the dense tier of the ranked symmetric noise generator"
                               + (" and its second tier walked more than 8x deeper than the first" if deep else "") +
-                              "; switching to the per-pair hash generator (same law, N^2 sweep) for the following forwards")
-                self.args.dgg_sym_generator = "hash"
+                              ("; this module switches to the per-pair hash generator (same law, N^2 sweep) for the following forwards"
+                               if auto and many else "; the per-pair hash generator (args.dgg_sym_generator = 'hash', or 'auto' to let "
+                               "the module switch by itself) is cheaper on such data"))
+                if auto and many:
+                    self._sym_generator = "hash"
         if self._overflow is not None and bool(self._overflow):
             self._overflow = None
             raise RuntimeError(
@@ -352,6 +361,54 @@ class DGG_LearnableK_debug(nn.Module):
                 "candidates than that: ranks the reference still weights were dropped (row sums, normalisation and gradients "
                 "differ from the reference from here on).  Edge-list candidates: set args.dgg_wide_rows = 'csr' (rows of any width; "
                 "'auto' picks it whenever a row would lose weight, except inside a hipGraph capture).  All-pairs candidates: rescale the degree prior / k_project.")
+
+    def _sym_generator_now(self):
+        """generator for symmetric noise in the next forward: "ranked" | "hash".  args.dgg_sym_generator: "ranked" (default), "hash", or
+        "auto" = ranked until check_ell_bound() finds this module's data in the ranked generator's slow regime"""
+        own = self.__dict__.get("_sym_generator")
+        if own is not None:
+            return own
+        return "hash" if getattr(self.args, "dgg_sym_generator", "ranked") == "hash" else "ranked"
+
+    def _asym_generator_now(self, x, seed):
+        """NOISE_RANKED or NOISE_HASH for this forward's asymmetric noise on all-pairs candidates, and the watch on the ranked search's
+        DATA-DEPENDENT cost.  The search visits about L exp(D / 0.3) ranks of a row, D = the spread of 0.05 ||xp_i - xp_j|| the row
+        sees: ~80 on unit-scale features (0.25 ms at N = 100 000), thousands once learned / unnormalised latents spread the
+        distances several times wider -- on ONE wavefront per row.  Measured at N = 100 000 (tools/time_topk.py, ms; feature scale
+        x1 / x4 / x16): ranked 0.35 / 9.0 / 170; the per-pair hash evaluators depend on the regime just as much and are SLOWER where
+        the ranked search is slow (guess-and-verify 3.5 / 198 / 318, adaptive 13.7 / 143 / 435, MFMA-bounded 41 / 123 / 226) --
+        when distances and noise both matter, every pair has to be scored, which is what the exhaustive kernel costs (~200 ms).
+        So there is no cheaper exact evaluator to route to; args.dgg_asym_generator:
+          "auto" (default)  the ranked generator, WATCHED: every `args.dgg_pilot_every` (16) forwards -- and on the first -- a pilot
+                            walks ~1000 sampled rows with a budget of 64 blocks (ops.ranked_probe: one small launch, one readback);
+                            when its estimate exceeds `args.dgg_ranked_warn_us` (5000) the module warns, once per regime change,
+                            with the measured depth (graphs below 8192 nodes and hipGraph captures are not probed);
+          "ranked" / "hash" no pilot; "hash" = the per-pair hash generator (same law, another realisation)."""
+        policy = getattr(self.args, "dgg_asym_generator", "auto")
+        if policy == "hash":
+            return ops.NOISE_HASH
+        N = x.shape[0]
+        if policy != "auto" or N < 8192:
+            return ops.NOISE_RANKED
+        st = self.__dict__.setdefault("_asym_state", {"n": 0, "slow": False, "probe": None})
+        every = max(1, int(getattr(self.args, "dgg_pilot_every", 16)))
+        if st["n"] % every == 0 and not torch.cuda.is_current_stream_capturing():
+            with torch.no_grad():
+                xp = ops.linear_fwd(x.detach(), self.node_encode_for_edges[0].weight.detach(), self.node_encode_for_edges[0].bias.detach(),
+                                    ops.ACT_LEAKY)
+                pr = ops.ranked_probe(xp, None, ops.T_DIST, seed, stride=max(1, N // 1024), max_blocks=64)
+            est = ops.ranked_cost_estimate(pr, N)
+            slow = est > float(getattr(self.args, "dgg_ranked_warn_us", 5000.0))
+            if slow and not st["slow"]:
+                import warnings
+                warnings.warn(f"DGG_LearnableK_debug: the ranked noise search walks deep on this data: {pr['blocks_per_row']:.1f} blocks of 64 "
+                              f"ranks per sampled row ({100 * pr['budget_hit_frac']:.1f} % of them beyond the 64-block budget), estimated "
+                              f"{est / 1e3:.1f} ms per forward at N = {N} (0.25 ms on unit-scale features).  The latent distances "
+                              "0.05 ||xp_i - xp_j|| spread over more than the noise scale 0.3; results stay exact, and no evaluator of this "
+                              "build is faster in that regime (see _asym_generator_now)")
+            st.update(slow=slow, probe=dict(pr, ranked_us_estimate=est))
+        st["n"] += 1
+        return ops.NOISE_RANKED
 
     def _track_overflow(self, k, ncand):
         over = k.detach() + 8.5 > float(self.ell_width)
@@ -368,8 +425,8 @@ class DGG_LearnableK_debug(nn.Module):
         non-zero weight, i.e. some row has more candidates than the ELL width AND a learned degree k_i + 8.5 above it (the
         condition _track_overflow flags).  The widest row is read back once per GRAPH OBJECT (cached by identity); graphs whose
         rows all fit never synchronise.  For the others the learned degrees are tested on the device and ONE flag is read back
-        per forward (the k-net has finished by then; the edge-list step is tens of launches long).  While a hipGraph is being
-        captured nothing can be read back: the decision of the last eager forward on the same graph object is replayed."""
+        every few forwards (below).  While a hipGraph is being captured nothing can be read back: the decision of the last eager
+        forward on the same graph object is replayed."""
         policy = getattr(self.args, "dgg_wide_rows", "auto")
         if policy == "ell":
             return False
@@ -386,9 +443,19 @@ class DGG_LearnableK_debug(nn.Module):
             ent = cache[id(in_adj)] = [weakref.ref(in_adj), int(lens.max().item()) if lens.numel() else 0, False]
         if ent[1] <= self.ell_width:
             return False
-        if not torch.cuda.is_current_stream_capturing():
-            lens = rowptr[1:] - rowptr[:-1]
-            ent[2] = bool(((k.detach() + 8.5 > float(self.ell_width)) & (lens > self.ell_width)).any().item())
+        # The readback is one host synchronisation: it is taken on the first forward of a graph and then every
+        # `args.dgg_wide_rows_every` (default 16) forwards, not on each one; a graph that once needed the CSR form keeps it (the CSR
+        # form is exact for every degree; the learned degrees of such a graph rarely come back under the ELL width), so the returned
+        # adjacency type does not flip from one forward to the next.  Between two evaluations an ELL forward that would lose
+        # weight still sets the overflow flag (check_ell_bound raises), exactly as under policy "ell".
+        every = max(1, int(getattr(self.args, "dgg_wide_rows_every", 16)))
+        if len(ent) < 4:
+            ent.append(0)
+        if not ent[2] and not torch.cuda.is_current_stream_capturing():
+            if ent[3] % every == 0:
+                lens = rowptr[1:] - rowptr[:-1]
+                ent[2] = bool(((k.detach() + 8.5 > float(self.ell_width)) & (lens > self.ell_width)).any().item())
+            ent[3] += 1
         return ent[2]
 
     def _csr_soft_adjacency(self, x, in_adj, k, noise_mode, G, seed, mode):
@@ -424,8 +491,7 @@ class DGG_LearnableK_debug(nn.Module):
         # symmetric noise (dgm.py:1216-1223) is keyed on the unordered pair: the ranked symmetric generator (every pair owned by
         # one endpoint, which lists its largest noises first; args.dgg_sym_generator = "hash" selects the per-pair hash + N^2 sweep)
         if self.args.symmetric_noise:
-            ranked = (self.ell_width == 64 and self.latent_dim in ops.RSYM_WIDTHS and
-                      getattr(self.args, "dgg_sym_generator", "ranked") == "ranked")
+            ranked = self.ell_width == 64 and self.latent_dim in ops.RSYM_WIDTHS and self._sym_generator_now() == "ranked"
             return (ops.NOISE_RANKED_SYM if ranked else ops.NOISE_HASH_SYM), None, seed
         # the ranked generator's row search is written for the full 64-wide list
         return (ops.NOISE_RANKED if self.ell_width == 64 else ops.NOISE_HASH), None, seed
@@ -544,6 +610,8 @@ class DGG_LearnableK_debug(nn.Module):
                 erow, avals = in_adj.indices()[0].to(torch.int32), in_adj.values().to(torch.float32)
         noise_mode, G, seed = self._noise_cfg()
         literal = bool(self.hard and getattr(self.args, "dgg_hard_literal", False))
+        if noise_mode == ops.NOISE_RANKED and cand is None and not literal:
+            noise_mode = self._asym_generator_now(x, seed)       # the ranked search's depth is a property of the data: guarded
         if noise_mode == ops.NOISE_RANKED_SYM and (cand is not None or literal):
             noise_mode = ops.NOISE_HASH_SYM
         if noise_mode == ops.NOISE_RANKED and (cand is not None or literal):
@@ -608,6 +676,7 @@ class DGG_LearnableK_debug(nn.Module):
             prev = self.__dict__.get("_rsym_err")
             self._rsym_err = cfg["rsym_err"] if prev is None else (prev | cfg["rsym_err"])
             if x.shape[0] > 1024:                  # (smaller graphs take the dense tier by design: dgg_topk_rsym.hip, SMALL_N)
+                self._rsym_rows = int(x.shape[0])
                 prev3 = self.__dict__.get("_rsym_t3")
                 self._rsym_t3 = cfg["rsym_tier3"] if prev3 is None else torch.maximum(prev3, cfg["rsym_tier3"])
                 prevd = self.__dict__.get("_rsym_depth")

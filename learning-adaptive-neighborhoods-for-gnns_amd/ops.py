@@ -280,7 +280,7 @@ def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed
         assert G.shape[-1] == N and G.shape[0] == N, "explicit noise must be [N, N]"
         ldG = N
     ws, ws_bytes = None, 0
-    if algo != 1:
+    if algo != 1 or noise_mode == NOISE_RANKED_SYM:      # (the ranked symmetric generator has no workspace-free form, whatever `algo` says)
         ws_bytes = int(_lib.lib().dgg_allpairs_workspace_bytes(N, h, noise_mode, K))
         if ws_bytes:
             ws = torch.empty((ws_bytes,), device=xp.device, dtype=torch.uint8)
@@ -289,7 +289,7 @@ def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed
                                             _ptr(idx), _ptr(val), _ptr(None if k_limit is None else _chk(k_limit)), algo, _ptr(ws),
                                             ws_bytes, _stream()), "allpairs_topk")
     _probe_end("allpairs_topk", pe)
-    if status is not None and noise_mode == NOISE_RANKED_SYM:
+    if status is not None and noise_mode == NOISE_RANKED_SYM and ws is not None:
         off = int(_lib.lib().dgg_allpairs_rsym_ctl_offset_bytes(r1 - r0, N))
         ctl = ws[off:off + 32].view(torch.int32)
         status["rsym_err"] = ctl[4:5].clone()
@@ -301,6 +301,42 @@ def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed
     if return_ws:      # diagnostics: the guess-and-verify control block is ws[:16] = (msum f32, nfail i32, gmin0 f32)
         return idx, val, ws
     return idx, val
+
+
+def ranked_probe(xp, k_limit=None, t=T_DIST, seed=(0, 0), rows=None, stride=1, max_blocks=0):
+    """Walk statistics of the ranked search (NOISE_RANKED) on every `stride`-th row, each walk cut after `max_blocks` blocks of 64
+    ranks (0: none): dict(rows, blocks_per_row, gathered_per_row, scored_per_row, budget_hit_frac, max_blocks).  One
+    synchronisation; the search's depth is a property of the data (dgg_allpairs_ranked_probe)."""
+    xp = _chk(xp)
+    N, h = xp.shape
+    r0, r1 = (0, N) if rows is None else rows
+    cnt = torch.zeros((6,), device=xp.device, dtype=torch.int64)
+    if torch.is_tensor(seed):
+        sd = seed.cpu()
+        seed = (int(sd[0]) & 0xFFFFFFFF, int(sd[1]) & 0xFFFFFFFF)
+    _lib.check(_lib.lib().dgg_allpairs_ranked_probe(_ptr(xp), N, h, r0, r1, t, seed[0], seed[1], _ptr(None if k_limit is None else _chk(k_limit)),
+                                                    int(stride), int(max_blocks), _ptr(cnt), _stream()), "allpairs_ranked_probe")
+    c = [int(v) for v in cnt.cpu()]
+    n = max(c[0], 1)
+    return {"rows": c[0], "blocks_per_row": c[1] / n, "gathered_per_row": c[2] / n, "scored_per_row": c[3] / n,
+            "budget_hit_frac": c[4] / n, "max_blocks": c[5], "stride": int(stride), "block_budget": int(max_blocks)}
+
+
+# Cost model of the ranked search (DGG_LearnableK_debug._asym_generator_now, bench.py): ~1.44 ns of chip time per visited block of 64
+# ranks (0.23 ms for 1.6 blocks per row at N = 100 000); its slowest row ~3 us per block on ONE wavefront.
+RANKED_NS_PER_BLOCK, RANKED_US_PER_SERIAL_BLOCK = 1.44, 3.0
+
+
+def ranked_cost_estimate(probe, N, rows=None):
+    """Estimated time (us) of the ranked search from a (sampled, budgeted) ranked_probe: mean blocks per row over all rows, a row
+    that hit the budget taken to the middle of the rest of its N / 0.76 / 64 blocks; at least one serial deep walk if any did."""
+    rows = N if rows is None else rows
+    full_walk_blocks = N / 0.76 / 64.0
+    mean_blocks = probe["blocks_per_row"] + probe["budget_hit_frac"] * max(full_walk_blocks - probe["block_budget"], 0.0) * 0.5
+    us = rows * mean_blocks * RANKED_NS_PER_BLOCK * 1e-3
+    if probe["budget_hit_frac"] > 0:
+        us = max(us, 0.5 * full_walk_blocks * RANKED_US_PER_SERIAL_BLOCK)
+    return us
 
 
 def rsym_status(ws, N, rows=None):

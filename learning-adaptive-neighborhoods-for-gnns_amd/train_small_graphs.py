@@ -144,10 +144,12 @@ def main(argv=None):
             out = forward(model, x, adj, edge_index=edge_index, epoch=epoch, writer=None)
             loss = F.nll_loss(out[idx["train_idx"]], y[idx["train_idx"]])
             loss.backward()
-        opt.step()
-        for dg in getattr(model, "dggs", []):                    # learned k must stay inside the ELL width (one sync per epoch)
+        # BEFORE the optimiser step: the learned k must have stayed inside the ELL width and the noise generator must have settled
+        # every row -- otherwise this step's adjacency was wrong and its gradients must not reach the weights (one sync per epoch)
+        for dg in getattr(model, "dggs", []):
             if hasattr(dg, "check_ell_bound"):
                 dg.check_ell_bound()
+        opt.step()
         model.eval()
         with torch.no_grad():
             out = forward(model, x, adj, edge_index=edge_index)

@@ -178,12 +178,22 @@ def test_ranked_symmetric_noise_fallback_tiers(dev, knobs, expect):
         with pytest.raises(RuntimeError, match="ranked symmetric noise generator"):
             m.check_ell_bound()
         # rows in the dense tier without an overflow: exact, but each costs a full walk -- the module says so and moves to the hash generator
-        m2 = dgg_amd.DGG_LearnableK_debug(in_dim=24, latent_dim=h, args=Namespace(**vars(args))).to(dev)
+        # Default policy ("ranked"): the module only WARNS and keeps its generator (a health check must not change the noise stream of
+        # a seeded run); "auto": this module -- not the shared args -- moves to the hash generator.
+        shared = Namespace(**vars(args))
+        m2 = dgg_amd.DGG_LearnableK_debug(in_dim=24, latent_dim=h, args=shared).to(dev)
         with _rsym_env(DGG_RSYM_TARGET=58, DGG_RSYM_DEPTH2=1):      # (the module passes the learned degrees: ~41 ranks to settle)
             m2(torch.randn(N, 24, device=dev), dgg_amd.AllPairs(torch.full((N,), 30.0, device=dev)))
         with pytest.warns(UserWarning, match="dense tier"):
             m2.check_ell_bound()
-        assert m2.args.dgg_sym_generator == "hash"
+        assert m2._sym_generator_now() == "ranked" and not hasattr(shared, "dgg_sym_generator")
+        shared.dgg_sym_generator = "auto"
+        m3 = dgg_amd.DGG_LearnableK_debug(in_dim=24, latent_dim=h, args=shared).to(dev)      # a second module on the same args
+        with _rsym_env(DGG_RSYM_TARGET=58, DGG_RSYM_DEPTH2=1):
+            m2(torch.randn(N, 24, device=dev), dgg_amd.AllPairs(torch.full((N,), 30.0, device=dev)))
+        with pytest.warns(UserWarning, match="switches to the per-pair hash generator"):
+            m2.check_ell_bound()
+        assert m2._sym_generator_now() == "hash" and m3._sym_generator_now() == "ranked" and shared.dgg_sym_generator == "auto"
         m2(torch.randn(N, 24, device=dev), dgg_amd.AllPairs(torch.full((N,), 30.0, device=dev)))
         m2.check_ell_bound()
         return
@@ -195,6 +205,27 @@ def test_ranked_symmetric_noise_fallback_tiers(dev, knobs, expect):
         assert st["tier3_rows"] >= 1, st
     assert np.array_equal(Nn(idx), ridx), f"top-k indices differ from the oracle ({st})"
     assert np.array_equal(Nn(val), rval), "scores differ from the oracle"
+
+
+def test_ranked_symmetric_noise_empty_shard_and_debug_algo(dev):
+    """An EMPTY row shard (rank beyond the last row: shard_bounds gives r0 == r1 == N) launches nothing; the status words the caller
+    reads out of the fresh workspace must say so (they used to be uninitialised memory: spurious errors / generator switches).
+    And topk_algo = 1 (the exhaustive debug knob, no workspace of its own) still gets the workspace the ranked symmetric generator
+    needs."""
+    from dgg_amd import ops
+    N, h = 1500, 32
+    xp = torch.randn(N, h, device=dev)
+    for _ in range(3):
+        junk = torch.full((64 << 20,), 0x7f, dtype=torch.uint8, device=dev)      # dirty the allocator's cache
+        del junk
+        st = {}
+        idx, val = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_RANKED_SYM, seed=(1, 2), rows=(N, N), status=st)
+        assert idx.shape == (0, K) and val.shape == (0, K)
+        assert int(st["rsym_err"]) == 0 and int(st["rsym_tier3"]) == 0 and float(st["rsym_depth"]) == 0.0
+    st = {}
+    i1, v1 = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_RANKED_SYM, seed=(1, 2), algo=1, status=st)
+    i0, v0 = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_RANKED_SYM, seed=(1, 2))
+    assert torch.equal(i0, i1) and torch.equal(v0, v1) and int(st["rsym_err"]) == 0
 
 
 @pytest.mark.parametrize("noise,algo", [("ranked", 0), ("hash", 1), ("hash", 4), ("none", 1)])
@@ -1449,10 +1480,43 @@ def test_module_small_graphs_and_narrow_ell(dev, N, width):
     assert torch.isfinite(x.grad).all() and all(torch.isfinite(p_.grad).all() for p_ in m.parameters() if p_.grad is not None)
 
 
+def _full_size_gradient_parity(s, grads, x, deg, P, tol=2e-4):
+    """Gradients of EVERY parameter of the benchmarked step against the oracle's backward (O(N K) C code, float64 accumulation) run on
+    the forward state the device saved -- idx / val / k / w / ahat / row sums / xp / H / xk -- over the WHOLE graph: the aggregation
+    backward (autograd of model.py:594-598), normalisation + ramp (model.py:1205-1219, dgm.py:1402-1421), the score backward
+    (dgm.py:1607-1627), the k-net (dgm.py:1562-1586, 2051-2063) and the three projections' weight gradients, each within `tol` of
+    its own maximum."""
+    c = lambda t_: t_.detach().cpu().numpy()          # noqa: E731
+    idx, val, k, w, rs, ahat = c(s["idx"]), c(s["val"]), c(s["k"]), c(s["w"]), c(s["rs"]), c(s["ahat"])
+    xp, H, xk, Z = c(s["xp"]), c(s["H"]), c(s["xk"]), c(s["Z"])
+    X, dg = c(x), c(deg)
+    Pn = {k_: c(v) for k_, v in P.items()}
+    G = (Z > 0).astype(np.float32)                                       # cotangent ones through the ReLU
+    dA, dH = O.spmm_bwd(idx, ahat, H, G)                                # Z = relu(A H), H = X Wc
+    dval, dk = O.softk_norm_bwd(idx, val, k, w, rs, dA)
+    dxp = O.edge_bwd(xp, idx, val, dval, perturb=True)
+    mu, sd = O.degree_stats(dg)
+    k2, z, m, u = O.knet_x(xk, dg, mu, sd, Pn["W1"], Pn["b1"], Pn["Wmu"], Pn["bmu"], Pn["Wp"].reshape(-1), Pn["bp"], save=True)
+    assert np.array_equal(k2, k), "learned degrees differ from the oracle's k-net on the device's xk"
+    dxk, dW1, db1, dWmu, dbmu, dWp, dbp = O.knet_x_bwd(xk, dg, mu, sd, Pn["W1"], Pn["Wmu"], Pn["Wp"].reshape(-1), z, m, u, dk)
+    _, dWe, dbe = O.linear_bwd(X, Pn["We"], xp, dxp, act=O.ACT_LEAKY, need_dx=False)
+    _, dWk, dbk = O.linear_bwd(X, Pn["Wk"], xk, dxk, act=O.ACT_LEAKY, need_dx=False)
+    _, dWc, _ = O.linear_bwd(X, Pn["Wc"], H, dH, act=O.ACT_NONE, w_layout=1, need_dx=False)
+    ref = dict(We=dWe, be=dbe, Wk=dWk, bk=dbk, Wc=dWc, W1=dW1, b1=db1, Wmu=dWmu, bmu=dbmu, Wp=dWp, bp=dbp)
+    worst = {}
+    for name, r_ in ref.items():
+        g_ = c(grads[name]).reshape(r_.shape)
+        assert np.isfinite(g_).all(), name
+        worst[name] = float(np.abs(g_ - r_).max() / max(np.abs(r_).max(), 1e-30))
+    print("full-size gradient parity, max |g - ref| / max |ref|:", {k_: f"{v:.1e}" for k_, v in worst.items()})
+    bad = {k_: v for k_, v in worst.items() if v > tol}
+    assert not bad, f"gradients off the oracle's backward: {bad}"
+
+
 def test_full_size_ranked_step_properties(dev):
     """BASELINE-size (N=100k, d=128, h=64, k~32) step of the bench: ranked-noise search with k_limit checked on sampled rows
-    against the oracle (which generates the row's full noise vector and scores all N columns), list invariants, finite
-    gradients, and the SpMM output checked on sampled rows"""
+    against the oracle (which generates the row's full noise vector and scores all N columns), list invariants, the gradient of
+    EVERY parameter against the oracle's backward over the whole graph (2e-4 of max), and the SpMM output checked on sampled rows"""
     import bench
     from dgg_amd import ops
     from dgg_amd.parallel import ShardedDGGConv
@@ -1464,8 +1528,9 @@ def test_full_size_ranked_step_properties(dev):
     layer = ShardedDGGConv(ops, N, K=64, noise_mode=ops.NOISE_RANKED, seed=(1234, 0))
     Z = layer.forward(x, deg, P)
     grads = layer.backward(torch.ones_like(Z), x, P)
-    assert torch.isfinite(Z).all() and all(torch.isfinite(v).all() for v in grads.values())
+    assert torch.isfinite(Z).all()
     s = layer.saved
+    _full_size_gradient_parity(s, grads, x, deg, P)
     idx, val, k = s["idx"], s["val"], s["k"]
     kept = idx >= 0
     L = torch.clamp(torch.ceil(k + 8.5) + 1, max=64)
@@ -1488,6 +1553,62 @@ def test_full_size_ranked_step_properties(dev):
                 yr = np.float64(ah[r, q]) * X_c[Nn(idx[r])[q]] + yr
         zr = np.maximum(yr @ Wc, 0)                                # reference order: relu((A x) W), model.py:594-598
         np.testing.assert_allclose(Zc[r], zr, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("regime", ["randn_x1", "randn_x4", "clustered"])
+def test_ranked_search_walk_depth_is_watched(dev, regime):
+    """The ranked search visits ~ L exp(spread of 0.05 dist / 0.3) ranks of a row: ~80 on unit-scale random features, ten times as
+    many once the features are 4x larger, every column at 16x (one wavefront per row).  No evaluator of this build is faster in
+    that regime (tools/time_topk.py: the per-pair hash sweeps collapse on the same data), so the module WATCHES instead of
+    switching: under args.dgg_asym_generator = "auto" (the default) a pilot walks ~1000 sampled rows with a block budget and warns
+    when its estimate passes args.dgg_ranked_warn_us.  At N = 100 000: randn x1 and the clustered set (a tight blob + 40 far
+    outliers) stay quiet and fast; randn x4 warns and stays exact.  Sampled rows equal the oracle's bit for bit in every regime,
+    and every forward meets a time bound (x4: the measured ~10 ms with a wide margin)."""
+    import time
+    import warnings
+    import dgg_amd
+    from argparse import Namespace
+    from dgg_amd import ops
+    N, d, h = 100_000, 128, 64
+    g = torch.Generator().manual_seed(1000)
+    x = torch.randn(N, d, generator=g)
+    if regime == "clustered":
+        x[20_000:23_000] *= 0.05
+        x[23_000:23_040] = x[23_000:23_040] * 0.01 + 3.0
+    if regime == "randn_x4":
+        x *= 4.0
+    x = x.to(dev)
+    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1, dgg_ranked_warn_us=1500.0)
+    torch.manual_seed(0)
+    m = dgg_amd.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=args).to(dev)
+    with torch.no_grad():
+        m.k_net.k_project.weight.mul_(0.1)
+        if regime == "randn_x4":
+            m.node_encode_for_k[0].weight.mul_(0.25)            # (keeps the k-net's input, hence the learned degrees, as in the x1 run)
+    m.set_seed(1234, 5)
+    prior = dgg_amd.AllPairs((24 + 16 * torch.rand(N, generator=g)).to(dev))
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        adj = m(x, prior)                                      # first forward: pilot
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        adj = m(x, prior)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    st = m._asym_state
+    warned = any("walks deep" in str(w_.message) for w_ in rec)
+    print(f"{regime}: pilot {st['probe']}, warned {warned}, forward {dt * 1e3:.2f} ms")
+    assert warned == (regime == "randn_x4") and st["slow"] == warned, st
+    assert dt < (0.060 if regime == "randn_x4" else 0.008), f"forward took {dt * 1e3:.1f} ms"
+    xp = ops.linear_fwd(x, m.node_encode_for_edges[0].weight.detach(), m.node_encode_for_edges[0].bias.detach(), ops.ACT_LEAKY)
+    xp_c = Nn(xp)
+    idx, val = Nn(adj.idx), Nn(adj.score)
+    for r in [0, 20_500, 23_010, 50_001, 99_999]:
+        ri, rv = O.allpairs_topk(xp_c, K=K, noise_mode=O.NOISE_RANKED, seed=(1234, 5), rows=(r, r + 1))
+        keep = idx[r] >= 0
+        assert np.array_equal(idx[r][keep], ri[0][keep]) and np.array_equal(val[r][keep], rv[0][keep]), (regime, r)
 
 
 @pytest.mark.parametrize("F", [64, 128, 320, 1024])
@@ -2106,7 +2227,7 @@ def test_config3_500k_nodes_in_eight_row_shards(dev):
     Z = layer.forward(x, deg, P)
     s = layer.saved
     grads = layer.backward(torch.ones_like(Z), x, P)
-    assert all(torch.isfinite(v).all() for v in grads.values())
+    _full_size_gradient_parity(s, grads, x, deg, P)             # every parameter gradient against the oracle's backward, whole graph
     assert int((s["idx"] >= 0).sum()) > 40 * N
     for r in range(G):
         r0, r1, per = shard_bounds(N, G, r)

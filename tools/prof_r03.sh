@@ -1,7 +1,8 @@
 # round-3 profile collection (run on the GPU box): bash tools/prof_r03.sh  -> gpurun_out/r03/
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03
-rm -rf $O; mkdir -p $O
+set -eu
+R="${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
+O="$R/gpurun_out/r03"
+rm -rf -- "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 BA="--steps 3 --warmup 1 --repeats 1 --cpu-rows -1 --no-hipgraph --no-variants"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 $R/bench.py $BA > /dev/null 2>&1
