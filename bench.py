@@ -533,10 +533,13 @@ def main():
                     help="clustered: a tight blob of 3 000 nodes + 40 far outliers inside randn features (tests/test_hip_parity.py)")
     ap.add_argument("--x-grad", action="store_true", help="also compute d loss / d x (reduce-scatter across ranks)")
     ap.add_argument("--strong", action="store_true", help="(default for several GPUs; kept for compatibility)")
-    ap.add_argument("--exchange", choices=["replicate", "gather"], default="replicate",
-                    help="multi-GPU, features as data (no --x-grad): 'replicate' = the node features are placed on every GPU once at "
-                         "load and each rank projects all rows itself (per-step collectives: row sums, da, weight gradients); "
-                         "'gather' = all-gather xp and X every step (the path for inputs that are activations)")
+    ap.add_argument("--exchange", choices=["hybrid", "replicate", "gather"], default="hybrid",
+                    help="multi-GPU, features as data (no --x-grad): 'hybrid' (default) = the node features are placed on every GPU "
+                         "once at load, each rank projects xp of all rows itself but H = X Wc of its own rows only: H is all-gathered "
+                         "behind the k-net / search / partition and the partial dH reduce-scattered behind the score backward; "
+                         "'replicate' = each rank projects [xp | H] of all rows and forms every weight gradient from full-N partials "
+                         "(per-step collectives: row sums, da, weight gradients only); 'gather' = all-gather [xp | H] every step (the "
+                         "path for inputs that are activations)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="DIAGNOSTIC, single GPU: time the per-step COMPUTE of one rank of a W-GPU weak-scaling run (own --nodes rows "
                          "against W * --nodes columns, replicated features, no collectives); not a throughput measurement")
@@ -598,13 +601,14 @@ class SyntheticRun:
         # features are DATA unless x_grad: with more than one rank they are replicated once, here, outside the timed region (data
         # placement: 4*N*d bytes per GPU), and no feature tensor crosses the fabric per step (dgg_amd/parallel.py)
         x_full = None
-        if (world > 1 or force) and not x_grad and exchange == "replicate":
+        if (world > 1 or force) and not x_grad and exchange in ("replicate", "hybrid"):
             x_full = _all_gather_rows(self.x_local, N, shard_bounds(N, world, rank)[2], None).contiguous()
         if emu:
             x_full = torch.randn(N, d, generator=g).to(dev)
             x_full[self.r0:self.r1] = self.x_local
         self.x_full = x_full
-        self.layer = ShardedDGGConv(ops, N, group=None, K=64, noise_mode=noise_mode, seed=(1234, 0), algo=a.algo, x_grad=x_grad, x_full=x_full)
+        self.layer = ShardedDGGConv(ops, N, group=None, K=64, noise_mode=noise_mode, seed=(1234, 0), algo=a.algo, x_grad=x_grad, x_full=x_full,
+                                    hybrid=(exchange == "hybrid" and x_full is not None))
         if emu:
             self.layer.emulate_rank(emu, self.erank)
         self.grads = None
@@ -1026,6 +1030,10 @@ def bench_synthetic(a, dev, world, rank, force):
                        "parallelism": f"row-shard x{world}" if not emu else f"DIAGNOSTIC: compute of rank {run.erank} of {emu}, no collectives",
                        "rows_per_rank": rows_loc,
                        "feature_exchange": ("single GPU" if not coll else
+                                            "hybrid: features replicated at load, every rank projects xp of all rows and H of its own rows; per step: "
+                                            "async all-gather of H (N*F*4 B, behind k-net + search + partition), all-gather row sums, async "
+                                            "reduce-scatter of the partial dH (behind the score backward), all-reduce da + weight gradients"
+                                            if (run.x_full is not None and run.layer.hybrid) else
                                             "features replicated at load, every rank projects all rows; per-step collectives: all-gather row sums, "
                                             "all-reduce da + weight gradients" if run.x_full is not None else
                                             "per step: all-gather [xp | H] (projections of the own rows), all-gather row sums, all-reduce da, "

@@ -20,6 +20,14 @@ itself ([xp | H] = one GEMM that reads X once) and forms the weight gradients fr
 full X (summed by the weight all-reduce).  Per-step collectives: all-gather of the row sums (N*4 B), all-reduce of da
 (N*4 B), one flat all-reduce of the replicated weight gradients (~35k floats).
 
+HYBRID (`x_full=` with `hybrid=True`; bench.py's default for several GPUs): as REPLICATED FEATURES for the scoring side -- every
+rank projects xp of all N nodes itself (the search needs it at once, and N*d*h*2 flop is cheaper than receiving 7/8 of it over
+xGMI) and forms dWe from its partial dxp against the full X -- but the AGGREGATION side is sharded: every rank projects H = X Wc
+for its own rows only and all-gathers it ASYNCHRONOUSLY (H is first read by the aggregation, after the k-net, the search and the
+partition: ~0.3 ms of kernels at 62 500 rows per rank to hide N*F*4 bytes behind), and the partial dH [N,F] -- complete after the
+first backward kernel, needed only by the last -- is reduce-scattered behind the score backward, so that dWc is a product over
+the rank's own rows.  Half of the replicated full-N GEMM work (projection and weight gradient) leaves the critical path.
+
 GATHERED PROJECTIONS (inputs that are activations, `x_grad`; or data that is not replicated): every rank projects its
 own rows and all-gathers [xp | H] (xp first -- the top-k waits for it -- H asynchronously behind it: it is needed only
 by the aggregation, so it crosses xGMI while the top-k, soft-k, partition and normalisation kernels run); the backward
@@ -91,10 +99,13 @@ class ShardedDGGConv:
 
     PARAM_KEYS = ("We", "be", "Wk", "bk", "W1", "b1", "Wmu", "bmu", "Wp", "bp", "Wc")
 
-    def __init__(self, kern, N, group=None, K=64, t=-0.05, noise_mode=2, seed=(1234, 0), mode=0, algo=0, x_grad=False, x_full=None):
+    def __init__(self, kern, N, group=None, K=64, t=-0.05, noise_mode=2, seed=(1234, 0), mode=0, algo=0, x_grad=False, x_full=None,
+                 hybrid=False):
         self.kern, self.N, self.group = kern, N, group
         assert x_full is None or not x_grad, "replicated features are data: they cannot take a gradient"
+        assert not hybrid or x_full is not None, "the hybrid scheme replicates the features for the scoring side"
         self.x_full = x_full                                 # [N,d] static node features present on every rank, or None
+        self.hybrid = bool(hybrid)                           # replicated xp, all-gathered H, reduce-scattered dH (module docstring)
         self.K, self.t, self.noise_mode, self.seed, self.mode, self.algo, self.x_grad = K, t, noise_mode, seed, mode, algo, x_grad
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -122,12 +133,19 @@ class ShardedDGGConv:
 
     # ------------------------------------------------------------------------------------------------------------------
     def _project(self, x_local, P):
-        """-> xp (rows of `Xall`), H (rows of `Xall`), xk (own rows).  One GEMM that reads X once when the kernel namespace
-        offers it (ops.linear_fwd_multi), three plain calls otherwise."""
+        """-> xp (rows of `Xall`), H (rows of `Xall`; hybrid: the rank's OWN rows), xk (own rows).  One GEMM that reads X once when
+        the kernel namespace offers it (ops.linear_fwd_multi), three plain calls otherwise."""
         kern = self.kern
         repl = self.x_full is not None
         Xall = self.x_full if repl else x_local
         single = not repl or (self.world == 1 and self.emulate is None)      # the own rows are all the rows that are projected
+        if self.hybrid and not single:
+            if hasattr(kern, "linear_fwd_multi"):            # (the multi entry reaches the persistent register kernel for large N)
+                (xp,) = kern.linear_fwd_multi(Xall, [(P["We"], P["be"], 1, 0)])
+                xk, H = kern.linear_fwd_multi(x_local, [(P["Wk"], P["bk"], 1, 0), (P["Wc"], None, 0, 1)])
+                return xp, H, xk
+            xp = kern.linear_fwd(Xall, P["We"], P["be"], 1, 0)
+            return xp, kern.linear_fwd(x_local, P["Wc"], None, 0, 1), kern.linear_fwd(x_local, P["Wk"], P["bk"], 1, 0)
         if hasattr(kern, "linear_fwd_multi"):
             if single:
                 xp, xk, H = kern.linear_fwd_multi(Xall, [(P["We"], P["be"], 1, 0), (P["Wk"], P["bk"], 1, 0), (P["Wc"], None, 0, 1)])
@@ -138,6 +156,10 @@ class ShardedDGGConv:
         H = kern.linear_fwd(Xall, P["Wc"], None, 0, 1)
         return xp, H, kern.linear_fwd(x_local, P["Wk"], P["bk"], 1, 0)
 
+    def _hyb(self):
+        """the hybrid exchange is live: several ranks (or their single-process emulation) on replicated features"""
+        return self.hybrid and self.x_full is not None and (self.coll or self.emulate is not None)
+
     def forward(self, x_local, deg_full, P):
         """One forward per backward: `saved` holds views of the persistent collective buffers (the gathered xp / H / row sums),
         which the next forward overwrites."""
@@ -147,8 +169,11 @@ class ShardedDGGConv:
         repl = self.x_full is not None
         xp, H, xk = self._project(x_local, P)
         s["xp_loc"], s["H_loc"] = xp, H
+        hyb = self._hyb()
         if self.coll and not repl:                  # xp first (the top-k waits for it), H streams in behind it
             g_xp = _Gather(xp, self.N, self.per, self.group, True, self.bufs, "xp")
+            g_H = _Gather(H, self.N, self.per, self.group, True, self.bufs, "H")
+        elif hyb and self.coll:                     # H of the own rows only: gathered behind the k-net, the search and the partition
             g_H = _Gather(H, self.N, self.per, self.group, True, self.bufs, "H")
         s["xk"] = xk
         # mean / std of the prior degrees (dgm.py:1569-1570): an INPUT statistic -- recomputed only when the degree tensor changes
@@ -193,7 +218,16 @@ class ShardedDGGConv:
         s["part"] = kern.part_build(s["idx"], s["w"], self.N) if (s["partp"] is None and hasattr(kern, "part_build")) else None
         if s["ahat"] is None:
             s["ahat"] = kern.normalize_fwd(s["idx"], s["w"], rs, self.r0)
-        s["H"] = H = g_H.get() if (self.coll and not repl) else H
+        if self.coll and (not repl or hyb):
+            H = g_H.get()
+        elif hyb:                                   # emulation: the other ranks' rows of H are stale filler in a persistent buffer
+            Hf = _Gather._buf(self.bufs, ("H", "emu"), (self.N, H.shape[1]), H)
+            if not self.bufs.get(("H", "emu_init")):
+                Hf.copy_(H.repeat((self.N + H.shape[0] - 1) // H.shape[0], 1)[:self.N])
+                self.bufs[("H", "emu_init")] = True
+            Hf[self.r0:self.r1].copy_(H)
+            H = Hf
+        s["H"] = H
         s["Z"] = kern.spmm_fwd(s["idx"], s["ahat"], H, 2)    # relu(A (x Wc))
         s["gen"] = self._fwd_gen
         self.saved = s
@@ -215,8 +249,9 @@ class ShardedDGGConv:
                 return self._backward(dZ, x_local, P)
         return self._backward(dZ, x_local, P)
 
-    def _reduce_scatter_rows(self, t, key):
-        """[N, c] partial sums on every rank -> the rank's own rows [r1-r0, c], summed over ranks"""
+    def _reduce_scatter_rows(self, t, key, async_op=False):
+        """[N, c] partial sums on every rank -> the rank's own rows [r1-r0, c], summed over ranks.  async_op: returns a callable
+        that waits (a stream dependency on RCCL) and yields the rows -- the transfer runs behind the kernels issued meanwhile."""
         pad = self.world * self.per - self.N
         src = t
         if pad:
@@ -224,8 +259,15 @@ class ShardedDGGConv:
             src[:self.N].copy_(t)
             src[self.N:].zero_()
         out = _Gather._buf(self.bufs, (key, "rs_out"), (self.per, t.shape[1]), t)
-        dist.reduce_scatter_tensor(out, src.contiguous(), group=self.group)
-        return out[: self.r1 - self.r0]
+        src = src.contiguous()
+        work = dist.reduce_scatter_tensor(out, src, group=self.group, async_op=async_op)
+        if not async_op:
+            return out[: self.r1 - self.r0]
+
+        def get(_keep=src):
+            work.wait()
+            return out[: self.r1 - self.r0]
+        return get
 
     def _backward(self, dZ, x_local, P):
         kern, s = self.kern, self.saved
@@ -241,6 +283,8 @@ class ShardedDGGConv:
             pc = kern.conv_bwd_cols_p(s["idx"], s["H"], G, partp, s["rs"], zero_dA=False)
             assert pc is not None
             dA, dA_rec, dH, da = pc
+            if self._hyb() and self.coll:           # dH [N,F] partial is complete here and needed only by the last kernel of the step
+                dH = self._reduce_scatter_rows(dH, "dH", async_op=True)
             if self.coll:
                 dist.all_reduce(da, group=self.group)
             # the activation derivative of the two LeakyReLU projections is applied by the kernels that PRODUCE dxp / dxk (they hold
@@ -261,6 +305,8 @@ class ShardedDGGConv:
             da = kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0, part) if part is not None else \
                 kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0)
             ahat_rows = None
+        if self._hyb() and self.coll:
+            dH = self._reduce_scatter_rows(dH, "dH", async_op=True)
         if self.coll:
             dist.all_reduce(da, group=self.group)
         fused = None
@@ -288,6 +334,7 @@ class ShardedDGGConv:
         repl = self.x_full is not None
         # weight gradients of the two projections.  Replicated features: partial [dxp | dH] of all N nodes against the full X (the
         # weight all-reduce sums the ranks); gathered projections: reduce-scatter the partials, then the rank's own rows only.
+        hyb = self._hyb()
         if self.coll and not repl:
             both = self._reduce_scatter_rows(torch.cat([dxp, dH], 1), "dproj")
             h = dxp.shape[1]
@@ -305,7 +352,23 @@ class ShardedDGGConv:
                 s["xk"].shape[1], s["mu_sd"], P["W1"], P["Wmu"], P["bmu"], P["Wp"].reshape(-1), s["z"], s["u"], s["feat"], dk)
         g["Wp"] = dWp.reshape(P["Wp"].shape)
         same_rows = Xg.shape[0] == x_local.shape[0] and (not repl or self.world == 1) and self.emulate is None
-        if hasattr(kern, "linear_bwd_multi") and not self.x_grad and same_rows:
+        if hyb:
+            # hybrid: dWe from the rank's PARTIAL dxp of all N nodes against the full X (summed by the weight all-reduce); dWk and dWc
+            # from the rank's own rows -- dH_own = the reduce-scattered sum over ranks (emulation: the rank's own rows of its partial)
+            dH_own = dH_g() if callable(dH_g) else dH_g[self.r0:self.r1]
+            ym, am = (None, 0) if premasked else (True, 1)
+            if hasattr(kern, "linear_bwd_multi"):
+                ((g["We"], g["be"]),) = kern.linear_bwd_multi(Xg, [(P["We"], xp_g if ym else None, dxp_g, am, 0, True)])
+                (g["Wk"], g["bk"]), (g["Wc"], _) = kern.linear_bwd_multi(
+                    x_local, [(P["Wk"], s["xk"] if ym else None, dxk, am, 0, True), (P["Wc"], None, dH_own, 0, 1, False)])
+            else:
+                _, g["We"], g["be"] = kern.linear_bwd(Xg, P["We"], xp_g if ym else None, dxp_g, am, 0, False, True)
+                _, g["Wk"], g["bk"] = kern.linear_bwd(x_local, P["Wk"], s["xk"] if ym else None, dxk, am, 0, False, True)
+                _, g["Wc"], _ = kern.linear_bwd(x_local, P["Wc"], None, dH_own, 0, 1, False, False)
+            # (dWc comes from the ALREADY SUMMED dH of the own rows: in the flat weight all-reduce below every rank's part is its share
+            # of the total, so the sum over ranks is the whole gradient -- as for every other weight)
+            dX1 = dX2 = dX3 = None
+        elif hasattr(kern, "linear_bwd_multi") and not self.x_grad and same_rows:
             # one pass over X for the three weight gradients (leaky masks applied on the operand load)
             ym, am = (None, 0) if premasked else (True, 1)          # premasked: dxp / dxk already carry LeakyReLU'
             (g["We"], g["be"]), (g["Wk"], g["bk"]), (g["Wc"], _) = kern.linear_bwd_multi(

@@ -176,39 +176,43 @@ def make_inputs(N=150, d=12, h=16):
     return x, deg, P, cot
 
 
-def run_step(x_local, deg, P, cot_local, N, group, x_full=None, noise_mode=2):
+def run_step(x_local, deg, P, cot_local, N, group, x_full=None, noise_mode=2, hybrid=False):
     sys.path.insert(0, ROOT)
     from dgg_amd.parallel import ShardedDGGConv
-    layer = ShardedDGGConv(CpuKern(), N, group=group, K=64, noise_mode=noise_mode, seed=(5, 6), x_grad=x_full is None, x_full=x_full)
+    layer = ShardedDGGConv(CpuKern(), N, group=group, K=64, noise_mode=noise_mode, seed=(5, 6), x_grad=x_full is None, x_full=x_full,
+                           hybrid=hybrid)
     Z = layer.forward(x_local, deg, P)
     g = layer.backward(cot_local, x_local, P)
     return Z, g
 
 
 def _worker(rank, world, port, ret, replicated=False, N=150, noise_mode=2):
+    hybrid = replicated == "hybrid"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
     from dgg_amd.parallel import shard_bounds
     x, deg, P, cot = make_inputs(N)
     r0, r1, _ = shard_bounds(N, world, rank)
-    Z, g = run_step(x[r0:r1].contiguous(), deg, P, cot[r0:r1].contiguous(), N, None, x if replicated else None, noise_mode)
+    Z, g = run_step(x[r0:r1].contiguous(), deg, P, cot[r0:r1].contiguous(), N, None, x if replicated else None, noise_mode, hybrid)
     ret[rank] = (r0, r1, Z.numpy(), {k: v.numpy() for k, v in g.items()})
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("replicated", [False, True])
+@pytest.mark.parametrize("replicated", [False, True, "hybrid"])
 @pytest.mark.parametrize("world,N,noise_mode", [(2, 150, 2), (3, 151, 2), (2, 150, 5)])
 def test_sharded_step_matches_single_process(replicated, world, N, noise_mode):
     """replicated=True: the node features are data present on every rank (no per-step exchange of projections, every rank
     projects all rows); replicated=False: every rank projects its own rows, all-gathers [xp | H] and reduce-scatters the
-    partial [dxp | dH].  world 3 with N = 151: uneven shards (51 + 51 + 49), padded collectives.  noise_mode 5: the ranked
+    partial [dxp | dH]; "hybrid" (bench.py's default for several GPUs): replicated features, every rank projects xp of all rows
+    but H of its own rows only -- H is all-gathered asynchronously, the partial dH reduce-scattered asynchronously, dWc formed
+    from the own rows.  world 3 with N = 151: uneven shards (51 + 51 + 49), padded collectives.  noise_mode 5: the ranked
     symmetric generator -- a rank's rows take noise from owners on the other rank; keyed on global ids, nothing is exchanged."""
     x, deg, P, cot = make_inputs(N)
     Z1, g1 = run_step(x, deg, P, cot, N, None, None, noise_mode)          # world 1 (no process group)
     if replicated:
         g1.pop("x")
-    port = 29500 + os.getpid() % 2000 + int(replicated) + 2 * world + 7 * noise_mode
+    port = 29500 + os.getpid() % 2000 + {False: 0, True: 1, "hybrid": 23}[replicated] + 2 * world + 7 * noise_mode
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     procs = [ctx.Process(target=_worker, args=(r, world, port, ret, replicated, N, noise_mode)) for r in range(world)]

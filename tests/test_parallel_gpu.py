@@ -29,13 +29,13 @@ def make_inputs(N=1500, d=128, h=64):
     return x, deg, P, cot
 
 
-def run_step(x_local, deg, P, cot_local, N, x_grad, x_full=None):
+def run_step(x_local, deg, P, cot_local, N, x_grad, x_full=None, hybrid=False):
     sys.path.insert(0, ROOT)
     from dgg_amd import ops
     from dgg_amd.parallel import ShardedDGGConv
     dev = torch.device("cuda", 0)
     layer = ShardedDGGConv(ops, N, group=None, K=64, noise_mode=ops.NOISE_RANKED, seed=(5, 6), x_grad=x_grad,
-                           x_full=None if x_full is None else x_full.to(dev))
+                           x_full=None if x_full is None else x_full.to(dev), hybrid=hybrid)
     Pd = {k: v.to(dev) for k, v in P.items()}
     xl = x_local.to(dev)
     Z = layer.forward(xl, deg.to(dev), Pd)
@@ -52,13 +52,15 @@ def _worker(rank, world, port, x_grad, ret):
     x, deg, P, cot = make_inputs()
     N = x.shape[0]
     r0, r1, _ = shard_bounds(N, world, rank)
-    # x_grad == "replicated": features are data present on every rank, no per-step exchange of X / xp
-    Z, g, idx = run_step(x[r0:r1].contiguous(), deg, P, cot[r0:r1].contiguous(), N, x_grad is True, x if x_grad == "replicated" else None)
+    # x_grad == "replicated": features are data present on every rank, no per-step exchange of X / xp; "hybrid": the same with H
+    # all-gathered and dH reduce-scattered asynchronously (bench.py's default for several GPUs)
+    Z, g, idx = run_step(x[r0:r1].contiguous(), deg, P, cot[r0:r1].contiguous(), N, x_grad is True,
+                         x if x_grad in ("replicated", "hybrid") else None, x_grad == "hybrid")
     ret[rank] = (r0, r1, Z.numpy(), {k: v.numpy() for k, v in g.items()}, idx.numpy())
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("x_grad", [False, True, "replicated"])
+@pytest.mark.parametrize("x_grad", [False, True, "replicated", "hybrid"])
 def test_two_ranks_on_one_gpu_match_single_process(x_grad):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -100,24 +102,27 @@ def _rccl_worker(port, x_grad, ret):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     x, deg, P, cot = make_inputs()
-    Z, g, idx = run_step(x, deg, P, cot, x.shape[0], x_grad)
+    if x_grad == "hybrid":      # asynchronous all_gather_into_tensor of H and reduce_scatter_tensor of dH through RCCL
+        Z, g, idx = run_step(x, deg, P, cot, x.shape[0], False, x, True)
+    else:
+        Z, g, idx = run_step(x, deg, P, cot, x.shape[0], x_grad)
     ret[0] = (Z.numpy(), {k: v.numpy() for k, v in g.items()}, idx.numpy())
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("x_grad", [False, True])
+@pytest.mark.parametrize("x_grad", [False, True, "hybrid"])
 def test_rccl_collectives_single_rank_match_plain_step(x_grad):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         ret = mgr.dict()
-        p = ctx.Process(target=_rccl_worker, args=(29571 + int(x_grad), x_grad, ret))
+        p = ctx.Process(target=_rccl_worker, args=(29571 + {False: 0, True: 1, "hybrid": 2}[x_grad], x_grad, ret))
         p.start()
         p.join(300)
         assert p.exitcode == 0
         Z, g, idx = ret[0]
     x, deg, P, cot = make_inputs()
     os.environ.pop("DGG_FORCE_COLLECTIVES", None)
-    Z0, g0, idx0 = run_step(x, deg, P, cot, x.shape[0], x_grad)
+    Z0, g0, idx0 = run_step(x, deg, P, cot, x.shape[0], x_grad is True)
     assert np.array_equal(idx, idx0.numpy())
     assert np.array_equal(Z, Z0.numpy())
     for k in g0:

@@ -48,8 +48,9 @@ def worker(rank, world, port, a, ret):
     P = bench.make_params(a.feat, a.latent, dev)
     bounds = [shard_bounds(N, world, r) for r in range(world)]
     xs, deg = inputs(N, a.feat, [b[1] - b[0] for b in bounds])
-    x_full = torch.cat(xs).to(dev) if a.replicate else None     # features as data, present on every rank (bench.py's default)
-    layer = ShardedDGGConv(ops, N, group=None, K=64, noise_mode=ops.NOISE_RANKED, seed=(1234, 0), x_grad=a.x_grad, x_full=x_full)
+    x_full = torch.cat(xs).to(dev) if (a.replicate or a.hybrid) else None     # features as data, present on every rank
+    layer = ShardedDGGConv(ops, N, group=None, K=64, noise_mode=ops.NOISE_RANKED, seed=(1234, 0), x_grad=a.x_grad, x_full=x_full,
+                           hybrid=a.hybrid)
     Z, g = step(layer, xs[rank].to(dev), deg.to(dev), P)
     s = layer.saved
     ret[rank] = dict(idx_crc=int(s["idx"].long().sum().item()), Z_sum=float(Z.double().sum().item()),
@@ -68,6 +69,7 @@ def main():
     ap.add_argument("--sample", type=int, default=97, help="row stride of the compared sample")
     ap.add_argument("--x-grad", action="store_true")
     ap.add_argument("--replicate", action="store_true", help="replicated features (bench.py --exchange replicate)")
+    ap.add_argument("--hybrid", action="store_true", help="replicated features, H all-gathered / dH reduce-scattered (bench.py's default)")
     a = ap.parse_args()
     world = a.world
     ctx = mp.get_context("spawn")
