@@ -827,6 +827,8 @@ def bench_synthetic(a, dev, world, rank, force):
     torch.cuda.synchronize()
     probe, ops.PROBE = ops.PROBE, None
     tk = {n: sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev) * 1e-3 for n, ev in probe.items()}
+    if "edge_bwd" not in tk:                                      # two-stream step: the score backward is probed as its two launches
+        tk["edge_bwd"] = tk["edge_bwd_rows"] + tk["edge_bwd_node"]
     sv = layer.saved
     rows_loc = r1 - r0
     F = int(sv["H"].shape[1])                                     # width of the aggregated (projected) rows

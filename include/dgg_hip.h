@@ -342,6 +342,11 @@ int dgg_partp_build(const int32_t *idx, const float *w, const float *val, const 
 /* dgg_partp_build with dgg_ell_normalize_fwd fused: rs_all [ncols] = row sums of every node -> ahat [rows,K] (same bits) */
 int dgg_partp_build_norm(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
                          const float *rs_all, float *ahat, void *ws, void *stream);
+/* dgg_partp_build_norm in two parts (phase 1: count + scan + fill -- ahat complete, records in bucket order; phase 2: the per-bucket
+ * sort -- records in node order + the CSC pointer, read only by the backward; phase 0: both), so that the sort can run on a second
+ * stream beside the forward aggregation */
+int dgg_partp_build_phase(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
+                          const float *rs_all, float *ahat, void *ws, int phase, void *stream);
 /* Where the pieces of a built payload partition live inside its workspace (byte offsets; for tests and tools that want to look at the
  * records): out[0] = bucket starts (int32 [nb+1]), out[1] = CSC node pointer (int32 [ncols+1]: the records of destination node j are
  * recs[nodeptr[j] .. nodeptr[j+1])), out[2] = records in node order (16 bytes each: row*64 + r, j, bits of w_ir rs_i^-1/2, bits of the
@@ -359,6 +364,12 @@ int dgg_softk_edge_bwd_partp(const float *xp, int64_t rows, int h, const int32_t
                              const float *dA, const float *dA_rec, const float *da, const float *ahat_rows, int K, int64_t row0, float t,
                              int perturb, int mode, int normalized, const void *partp_ws, int64_t ncols, float *rowinfo_ws, float *dk,
                              float *dxp, int out_act, void *stream);
+/* dgg_softk_edge_bwd_partp in two parts (phase 1: the row kernel -- dk and the rows' own side of dxp complete; phase 2: the
+ * per-destination kernel; phase 0: both), so that the k-net backward, which needs only dk, can run on a second stream beside phase 2 */
+int dgg_softk_edge_bwd_partp_phase(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *k, const float *rs,
+                                   const float *dA, const float *dA_rec, const float *da, const float *ahat_rows, int K, int64_t row0, float t,
+                                   int perturb, int mode, int normalized, const void *partp_ws, int64_t ncols, float *rowinfo_ws, float *dk,
+                                   float *dxp, int out_act, int phase, void *stream);
 /* GCNII layer epilogue (GraphConvolution.forward, model.py:36-44): out = theta * sw + (1 - theta) * r (+ inp), sw = support W,
  * r = (1 - alpha) * hi + alpha * h0 (h0 NULL: r = hi; inp NULL: no residual).  Backward: dsw = theta g, dhi, dh0 (NULL with h0);
  * the residual input's gradient is g itself. */

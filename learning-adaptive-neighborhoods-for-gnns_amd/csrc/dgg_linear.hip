@@ -199,18 +199,15 @@ __global__ __launch_bounds__(64 * WAVES, NACC <= 2 ? 4 : 2) void linear_fwd_mfma
 // matrix cores are busy ~30 % of the time.  Here a workgroup (4 wavefronts, one per SIMD, the full register file each) is
 // PERSISTENT: the whole weight matrix (all column blocks) is written to LDS once, in MFMA operand order, and every wavefront
 // then walks 32-row blocks on its own -- no barrier after the prologue.
-//  * A operand of step s = (lane row, k = 2s + lane/32): lane (row, half) loads the CONTIGUOUS half [half*D/2, (half+1)*D/2)
+//  * Row operand of step s = (lane row, k = 2s + lane/32): lane (row, half) loads the CONTIGUOUS half [half*D/2, (half+1)*D/2)
 //    of its row with 16-byte loads, and one v_permlane32_swap per register pair turns (reg 2t, reg 2t+1) into the operands of
 //    steps t and D/4 + t -- X never touches LDS.  The next block's rows are in flight during the current block's MFMAs.
-//  * B operands of step s + PD are read from LDS before the MFMAs of step s issue (left alone the compiler reads them right
+//  * Weight operands of step s + PD are read from LDS before the MFMAs of step s issue (left alone the compiler reads them right
 //    before their use and waits out the LDS latency between every two MFMAs).
-//  * Epilogue: an accumulator holds one COLUMN per lane, so a direct store is 4 bytes per lane, 16 instructions per column
-//    block -- 96 per row block, more than a wavefront may have in flight (vmcnt is 6 bits): measured 45 of 100 us.  The 32x32
-//    block is turned through a 4 KB LDS tile private to the wavefront (LDS operations of one wavefront execute in order: no
-//    barrier) and leaves as four 16-byte-per-lane stores of 8 full 128-byte rows each.  (Measured and rejected: keeping the
-//    finished block in registers and issuing its epilogue in slices between the next block's MFMA steps -- the VALU / LDS
-//    work between the steps slows the MFMA stream by more than the 5 of 19 us per block it hides; two wavefronts per SIMD
-//    without the register prefetch -- same time.)
+//  * The product is formed TRANSPOSED (weights first, rows second): a lane then holds ONE node and, per group of four accumulator
+//    registers, four consecutive output columns -- the block leaves as four 16-byte stores per column block straight from the
+//    accumulator, with the bias as one more contraction step (see store_block).  Round 3 computed it the other way round (one
+//    column per lane) and turned every block through an LDS tile: 35 of 90 us in the epilogue.
 //  * Work split: `nmain` row blocks (a multiple of the wavefront count) are dealt whole; the remaining < #wavefronts blocks are
 //    dealt one (row block, column block) unit at a time -- a whole extra block on a few SIMDs would cost a full round (3125
 //    blocks of a 100k-row input on 1024 SIMDs: 3 rounds + 53 blocks).
@@ -220,7 +217,6 @@ __global__ __launch_bounds__(256, 1) void linear_fwd_reg(const float *__restrict
                                                          const float *__restrict__ b, LinSegs segs, int64_t nrb) {
     constexpr int S = D / 2, XR = D / 2;                         // MFMA steps per output; operand registers per lane
     __shared__ float wsf[S * NACC * 64];                         // [step][column block][lane]
-    __shared__ __attribute__((aligned(16))) float obuf[4 * 1024];   // output tile of each wavefront
     const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), li = lane & 31, hh = lane >> 5;
     const int64_t nw = (int64_t)gridDim.x * 4, slot = (int64_t)blockIdx.x * 4 + wave;
     const int64_t nrbf = N / 32;                                 // FULL row blocks (a partial last block is a remainder unit)
@@ -269,33 +265,32 @@ __global__ __launch_bounds__(256, 1) void linear_fwd_reg(const float *__restrict
             xc[2 * t + 1] = __uint_as_float(r[1]);               // operand of step D/4 + t  (k = D/2 + 2t + half)
         }
     };
-    auto finish = [&](float v, float bias, int av) {
-        const float vb = __fadd_rn(v, bias);
-        v = hasb ? vb : v;
-        const float lk = v > 0.0f ? v : __fmul_rn(0.01f, v), rl = v > 0.0f ? v : 0.0f;
-        return av == 1 ? lk : (av == 2 ? rl : v);
-    };
-    float *ot = obuf + wave * 1024;
-    // epilogue of one column block in 6 slices: 0-3 four accumulator registers each -> LDS tile, 4 tile -> registers, 5 stores
-    float4 ov[4];
-    auto epi_slice = [&](const f32x16 &acc, int a, int j, int64_t rb, bool full) {
-        if (j < 4) {
-#pragma unroll
-            for (int r = 4 * j; r < 4 * j + 4; r++) ot[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + li] = finish(acc[r], bj[a], actv[a]);
-        } else if (j == 4) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) ov[u] = *reinterpret_cast<const float4 *>(ot + ((lane >> 3) + 8 * u) * 32 + 4 * (lane & 7));
-        } else if (j == 5) {
-            const int ld = segs.ld[a];
-            float *yb = segs.y[a] + rb * 32 * (int64_t)ld + 4 * (lane & 7);
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int row = (lane >> 3) + 8 * u;
-                if (full || rb * 32 + row < N) *reinterpret_cast<float4 *>(yb + (int64_t)row * ld) = ov[u];
-            }
+    // An accumulator is computed TRANSPOSED -- first operand = the weights (lane li = output column), second = the rows (lane li = node)
+    // -- so that lane (li, hh) ends up with node rb*32 + li and, in registers 4q .. 4q+3, the four CONSECUTIVE columns 8q + 4hh + (0..3)
+    // of the block: the output leaves as four 16-byte stores per column block straight from the accumulator (consecutive stores
+    // complete each row's 128-byte line), no LDS turn, no waits.  The bias rides as ONE more contraction step against a column of
+    // ones: fma(1, b, acc) is the correctly rounded acc + b, the same bits as the separate add.  (Round 3 turned each 32 x 32 block
+    // through an LDS tile behind 11 vector instructions per element -- bias, three activation selects: 35 of the kernel's 90 us.)
+    auto act4 = [&](float4 v, int av) {
+        if (av == 1) {                                           // LeakyReLU(0.01): max(v, 0.01 v) == v > 0 ? v : 0.01 v
+            v.x = fmaxf(v.x, __fmul_rn(0.01f, v.x)); v.y = fmaxf(v.y, __fmul_rn(0.01f, v.y));
+            v.z = fmaxf(v.z, __fmul_rn(0.01f, v.z)); v.w = fmaxf(v.w, __fmul_rn(0.01f, v.w));
+        } else if (av == 2) {
+            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
         }
+        return v;
     };
-    // one whole row block (always a FULL block: unconditional stores; a partial last block is a remainder unit)
+    auto store_block = [&](const f32x16 &acc, int a, int64_t rb) {
+        const int64_t n = rb * 32 + li;
+        if (n >= N) return;
+        const int av = actv[a];                                  // (wave-uniform)
+        float *yb = segs.y[a] + n * (int64_t)segs.ld[a] + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            *reinterpret_cast<float4 *>(yb + 8 * q) = act4(make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]), av);
+    };
+    const float one_or_zero = hh == 0 ? 1.0f : 0.0f;
+    // one whole row block
     auto main_block = [&](int64_t rb) {
         f32x16 acc[NACC];
 #pragma unroll
@@ -317,13 +312,15 @@ __global__ __launch_bounds__(256, 1) void linear_fwd_reg(const float *__restrict
             __builtin_amdgcn_sched_barrier(0);
             const float av = s < S / 2 ? xc[2 * s] : xc[2 * (s - S / 2) + 1];
 #pragma unroll
-            for (int a = 0; a < NACC; a++) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[s % RING][a], acc[a], 0, 0, 0);
+            for (int a = 0; a < NACC; a++) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[s % RING][a], av, acc[a], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (hasb) {
 #pragma unroll
-        for (int a = 0; a < NACC; a++)
+            for (int a = 0; a < NACC; a++) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(bj[a] * one_or_zero, one_or_zero, acc[a], 0, 0, 0);
+        }
 #pragma unroll
-            for (int j = 0; j < 6; j++) epi_slice(acc[a], a, j, rb, true);
+        for (int a = 0; a < NACC; a++) store_block(acc[a], a, rb);
     };
     int64_t t = 0;
     for (; t < nfull; t++) {
@@ -348,19 +345,10 @@ __global__ __launch_bounds__(256, 1) void linear_fwd_reg(const float *__restrict
 #pragma unroll                                                    // (full: xc must stay in registers)
         for (int s = 0; s < S; s++) {
             const float av = s < S / 2 ? xc[2 * s] : xc[2 * (s - S / 2) + 1];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wa[s * NACC * 64], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s * NACC * 64], av, acc, 0, 0, 0);
         }
-        const int ld = segs.ld[a], av = segs.act[a];
-        const float bias = hasb ? b[a * 32 + li] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; r++) ot[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + li] = finish(acc[r], bias, av);
-        float *yb = segs.y[a] + rb * 32 * (int64_t)ld + 4 * (lane & 7);
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int row = (lane >> 3) + 8 * u;
-            const float4 v = *reinterpret_cast<const float4 *>(ot + row * 32 + 4 * (lane & 7));
-            if (rb * 32 + row < N) *reinterpret_cast<float4 *>(yb + (int64_t)row * ld) = v;
-        }
+        if (hasb) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b[a * 32 + li] * one_or_zero, one_or_zero, acc, 0, 0, 0);
+        store_block(acc, a, rb);
 #pragma unroll
         for (int q = 0; q < XR; q++) xc[q] = xn[q];
     }
@@ -643,9 +631,14 @@ __device__ __forceinline__ void tn_wide_stream(const float *__restrict__ A, cons
     float4 bv[PF];
     auto load = [&](int u, int64_t b0) {
         const int64_t n = b0 + 2 * u + hh, nc = n < N ? n : N - 1;          // unconditional, clamped
+#ifdef DGG_TNW_NOLOAD
+        av[u] = make_float2((float)nc, 1.0f); bv[u] = make_float4(1.0f, (float)nc, 2.0f, 3.0f);
+        if (ACT) yv[u] = av[u];
+#else
         av[u] = *reinterpret_cast<const float2 *>(A + nc * M1 + acol);
         if (ACT) yv[u] = *reinterpret_cast<const float2 *>(Yact + nc * M1 + acol);
         bv[u] = *reinterpret_cast<const float4 *>(B + nc * 128 + 4 * li);
+#endif
     };
 #pragma unroll
     for (int u = 0; u < PF; u++) load(u, base);
@@ -662,6 +655,12 @@ __device__ __forceinline__ void tn_wide_stream(const float *__restrict__ A, cons
             const float4 b = bv[u];
             load(u, base + stride);                              // this slot's next row pair: in flight for PF steps
             csum[0] += a0; csum[1] += a1;
+#ifdef DGG_TNW_NOMFMA
+            acc[0][0][0] = fmaf(a0, b.x, acc[0][0][0]); acc[0][1][0] = fmaf(a0, b.y, acc[0][1][0]);
+            acc[0][2][0] = fmaf(a0, b.z, acc[0][2][0]); acc[0][3][0] = fmaf(a0, b.w, acc[0][3][0]);
+            acc[1][0][0] = fmaf(a1, b.x, acc[1][0][0]); acc[1][1][0] = fmaf(a1, b.y, acc[1][1][0]);
+            acc[1][2][0] = fmaf(a1, b.z, acc[1][2][0]); acc[1][3][0] = fmaf(a1, b.w, acc[1][3][0]);
+#else
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.x, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.y, acc[0][1], 0, 0, 0);
             acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.z, acc[0][2], 0, 0, 0);
@@ -670,6 +669,7 @@ __device__ __forceinline__ void tn_wide_stream(const float *__restrict__ A, cons
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y, acc[1][1], 0, 0, 0);
             acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.z, acc[1][2], 0, 0, 0);
             acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.w, acc[1][3], 0, 0, 0);
+#endif
         }
     }
 }

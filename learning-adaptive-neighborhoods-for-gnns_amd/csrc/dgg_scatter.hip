@@ -1318,6 +1318,8 @@ int dgg_ell_conv_bwd_part(const float *G, const float *H, const float *ahat, int
 // ---- payload partition (16-byte records carrying wa = w * rs_i^-1/2 and the score; no slot map) ---------------------------
 int dgg_partp_build_norm(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
                          const float *rs_all, float *ahat, void *ws, void *stream);
+int dgg_partp_build_phase(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
+                          const float *rs_all, float *ahat, void *ws, int phase, void *stream);
 size_t dgg_partp_ws_bytes(int64_t rows, int K, int64_t ncols) {
     if (K > 64 || K < 1 || rows * 64 >= ((int64_t)1 << 31) || ncols < 1) return 0;          // 32-bit record ids
     PartP2 p;
@@ -1337,7 +1339,16 @@ int dgg_partp_build(const int32_t *idx, const float *w, const float *val, const 
 // of dgg_ell_normalize_fwd (entries outside the partition: 0)
 int dgg_partp_build_norm(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
                          const float *rs_all, float *ahat, void *ws, void *stream) {
+    return dgg_partp_build_phase(idx, w, val, rs_rows, rows, K, ncols, rs_all, ahat, ws, 0, stream);
+}
+
+// the same in two parts, so that a caller can run the second beside other work on another stream: phase 1 = count + scan + fill
+// (ahat is complete, the records sit in bucket order), phase 2 = the per-bucket sort (records in node order + nodeptr: what the
+// backward's column kernels read; the forward aggregation does not need it); phase 0 = both
+int dgg_partp_build_phase(const int32_t *idx, const float *w, const float *val, const float *rs_rows, int64_t rows, int K, int64_t ncols,
+                          const float *rs_all, float *ahat, void *ws, int phase, void *stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (phase < 0 || phase > 2) return dgg_set_error(DGG_ERR_ARG, "partp_build_phase: phase is 0 (all), 1 (count + fill) or 2 (sort)");
     if (dgg_partp_ws_bytes(rows, K, ncols) == 0 || !ws) return dgg_set_error(DGG_ERR_UNSUPPORTED, "partp_build: unsupported size or NULL workspace");
     if (!val || !rs_rows) return dgg_set_error(DGG_ERR_ARG, "partp_build: the payload needs the scores and the row sums");
     if ((rs_all == nullptr) != (ahat == nullptr)) return dgg_set_error(DGG_ERR_ARG, "partp_build_norm: rs_all and ahat go together");
@@ -1348,6 +1359,10 @@ int dgg_partp_build_norm(const int32_t *idx, const float *w, const float *val, c
     PartP2 p;
     partp2_layout(p, ws, rows, K, ncols);
     const int nb = (int)p.nb, nwg = (int)p.nwg, pbs = 1 << p.shift;
+    if (phase == 2) {
+        hipLaunchKernelGGL(pp_sort, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr, nb, p.shift);
+        return dgg_check_launch("partp_build");
+    }
 #define DGG_PP_PASS(TT)                                                                                                      \
     hipLaunchKernelGGL(pp_count<TT>, dim3((unsigned)nwg), dim3(TT), (size_t)nb * 4, st, idx, w, rows, K, nb, p.shift, p.T, rs_all, ncols, \
                        p.ainv);                                                                                              \
@@ -1360,6 +1375,7 @@ int dgg_partp_build_norm(const int32_t *idx, const float *w, const float *val, c
         default: DGG_PP_PASS(1024); break;
     }
 #undef DGG_PP_PASS
+    if (phase == 1) return dgg_check_launch("partp_build");
     hipLaunchKernelGGL(pp_sort, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr, nb, p.shift);
     return dgg_check_launch("partp_build");
 }
@@ -1414,6 +1430,10 @@ int dgg_ell_conv_bwd_partp(const float *G, const float *H, int64_t rows, int K, 
     return dgg_check_launch("ell_conv_bwd_partp");
 }
 
+int dgg_softk_edge_bwd_partp_phase(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *k, const float *rs,
+                                   const float *dA, const float *dA_rec, const float *da, const float *ahat_rows, int K, int64_t row0, float t,
+                                   int perturb, int mode, int normalized, const void *partp_ws, int64_t ncols, float *rowinfo_ws, float *dk,
+                                   float *dxp, int out_act, int phase, void *stream);
 // dgg_softk_edge_bwd_part on a payload partition: the row kernel hands (a_i, d loss / d rs_i, k_i) per row to the column kernel
 // (rowinfo_ws: 4*rows floats), which recomputes d loss / d score from dA_rec in record order -- no slot map, no per-entry
 // coefficient hand-over.  dk [rows] written, dxp [ncols,h] zeroed by the caller.
@@ -1421,6 +1441,17 @@ int dgg_softk_edge_bwd_partp(const float *xp, int64_t rows, int h, const int32_t
                              const float *dA, const float *dA_rec, const float *da, const float *ahat_rows, int K, int64_t row0, float t,
                              int perturb, int mode, int normalized, const void *partp_ws, int64_t ncols, float *rowinfo_ws, float *dk,
                              float *dxp, int out_act, void *stream) {
+    return dgg_softk_edge_bwd_partp_phase(xp, rows, h, idx, val, k, rs, dA, dA_rec, da, ahat_rows, K, row0, t, perturb, mode, normalized,
+                                          partp_ws, ncols, rowinfo_ws, dk, dxp, out_act, 0, stream);
+}
+
+// the same in two parts: phase 1 = the row kernel (dk and the rows' own side of dxp are complete: the k-net backward can start on
+// another stream), phase 2 = the per-destination kernel (dxp complete); phase 0 = both
+int dgg_softk_edge_bwd_partp_phase(const float *xp, int64_t rows, int h, const int32_t *idx, const float *val, const float *k, const float *rs,
+                                   const float *dA, const float *dA_rec, const float *da, const float *ahat_rows, int K, int64_t row0, float t,
+                                   int perturb, int mode, int normalized, const void *partp_ws, int64_t ncols, float *rowinfo_ws, float *dk,
+                                   float *dxp, int out_act, int phase, void *stream) {
+    if (phase < 0 || phase > 2) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp_phase: phase is 0 (all), 1 (rows) or 2 (nodes)");
     if (mode != 0 && mode != 1) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: mode must be 0 (k_times) or 1 (k_only)");
     if (out_act != 0 && (out_act != 1 || mode != 0))             // (mode 1 launches no node kernel: nothing would apply the mask)
         return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: out_act is 0 or 1 (LeakyReLU), mode 0 only");
@@ -1435,9 +1466,11 @@ int dgg_softk_edge_bwd_partp(const float *xp, int64_t rows, int h, const int32_t
     const unsigned gr = (unsigned)((rows + 3) / 4);
     const bool grouped = node_groups(rows * K, ncols);
 #define DGG_EDGE_PARTP(HH)                                                                                                  \
-    hipLaunchKernelGGL((edge_bwd_rows<HH, true, true>), dim3(gr), dim3(256), 0, st, xp, rows, idx, val, nullptr, K, row0, t, perturb, nullptr, \
-                       nullptr, dxp, sk);                                                                                    \
-    if (mode == 0 && grouped)                                                                                                \
+    if (phase != 2)                                                                                                          \
+        hipLaunchKernelGGL((edge_bwd_rows<HH, true, true>), dim3(gr), dim3(256), 0, st, xp, rows, idx, val, nullptr, K, row0, t, perturb, nullptr, \
+                           nullptr, dxp, sk);                                                                                \
+    if (phase == 1) {                                                                                                        \
+    } else if (mode == 0 && grouped)                                                                                         \
         hipLaunchKernelGGL((edge_bwd_nodeg<HH, 4>), dim3((unsigned)((ncols + 4 * (256 / HH) - 1) / (4 * (256 / HH)))), dim3(256), 0, st, xp, \
                            ncols, p.nodeptr, p.recs, dA_rec, reinterpret_cast<const float4 *>(rowinfo_ws), rs, normalized, row0, rows, t, \
                            perturb, dxp, out_act);                                                                           \

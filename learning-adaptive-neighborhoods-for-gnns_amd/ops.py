@@ -864,23 +864,35 @@ def partp_records(partp):
     return nodeptr, recs
 
 
-def partp_build(idx, w, val, rs_rows, ncols, rs_all=None):
+def partp_build(idx, w, val, rs_rows, ncols, rs_all=None, phase=0):
     """Payload partition of the active ELL entries by destination node: records carry w * rs_i^-1/2 and the score, there is no
     slot map.  Returns None when it does not apply.  rs_all [ncols] (row sums of every node): normalize_adj is fused and the
-    result is (partition, ahat [rows,K])."""
+    result is (partition, ahat [rows,K]).  phase=1: count + scan + fill only (ahat complete); finish with partp_sort(), possibly on
+    another stream -- the sorted records are read by the backward's column kernels only."""
     N, K = idx.shape
     nbytes = int(_lib.lib().dgg_partp_ws_bytes(N, K, ncols))
     if nbytes == 0:
         return None
     ws = torch.empty((nbytes,), device=idx.device, dtype=torch.uint8)
     if rs_all is None:
+        assert phase == 0
         _lib.check(_lib.lib().dgg_partp_build(_ptr(idx), _ptr(_chk(w)), _ptr(_chk(val)), _ptr(_chk(rs_rows)), N, K, ncols, _ptr(ws), _stream()),
                    "partp_build")
         return PartP(ws, N, K, ncols)
     ahat = torch.empty((N, K), device=idx.device, dtype=torch.float32)
-    _lib.check(_lib.lib().dgg_partp_build_norm(_ptr(idx), _ptr(_chk(w)), _ptr(_chk(val)), _ptr(_chk(rs_rows)), N, K, ncols, _ptr(_chk(rs_all)),
-                                               _ptr(ahat), _ptr(ws), _stream()), "partp_build_norm")
-    return PartP(ws, N, K, ncols), ahat
+    _lib.check(_lib.lib().dgg_partp_build_phase(_ptr(idx), _ptr(_chk(w)), _ptr(_chk(val)), _ptr(_chk(rs_rows)), N, K, ncols, _ptr(_chk(rs_all)),
+                                                _ptr(ahat), _ptr(ws), int(phase), _stream()), "partp_build_norm")
+    part = PartP(ws, N, K, ncols)
+    part.args = (idx, w, val, rs_rows, rs_all, ahat) if phase == 1 else None
+    return part, ahat
+
+
+def partp_sort(part):
+    """second part of partp_build(phase=1): the per-bucket sort, on the CURRENT stream"""
+    idx, w, val, rs_rows, rs_all, ahat = part.args
+    _lib.check(_lib.lib().dgg_partp_build_phase(_ptr(idx), _ptr(w), _ptr(val), _ptr(rs_rows), part.rows, part.K, part.ncols, _ptr(rs_all),
+                                                _ptr(ahat), _ptr(part.ws), 2, _stream()), "partp_sort")
+    part.args = None
 
 
 def conv_bwd_cols_p(idx, H, G, partp, rs, zero_dA=True):
@@ -907,24 +919,32 @@ def conv_bwd_cols_p(idx, H, G, partp, rs, zero_dA=True):
     return dA, dA_rec, dH, da
 
 
-def softk_edge_bwd_p(xp, idx, val, k, dA, dA_rec, rs, da, row0, t, perturb, mode, normalized, partp, ahat_rows=None, out_act=ACT_NONE):
+def softk_edge_bwd_p(xp, idx, val, k, dA, dA_rec, rs, da, row0, t, perturb, mode, normalized, partp, ahat_rows=None, out_act=ACT_NONE,
+                     phase=0, state=None):
     """softk_edge_bwd on a payload partition -> dxp [Nglobal,h], dk [N]; None when it does not apply.  out_act=ACT_LEAKY (mode 0):
-    dxp comes back multiplied by LeakyReLU'(xp), the gradient of the pre-activation of the layer that produced xp"""
+    dxp comes back multiplied by LeakyReLU'(xp), the gradient of the pre-activation of the layer that produced xp.
+    phase=1: the row kernel only -> (dxp, dk, state): dk is complete (the k-net backward can start, e.g. on another stream);
+    phase=2 with that `state`: the per-destination kernel completes dxp."""
     xp = _chk(xp)
     Ng, h = xp.shape
     N, K = idx.shape
     if partp is None or h not in (16, 32, 64, 128) or mode not in (MODE_K_TIMES_EDGE_PROB, MODE_K_ONLY) or Ng != partp.ncols:
         return None
-    # mode 0: every row of dxp is written (own rows by the row kernel, the others by the per-node kernel): no zero fill
-    dxp = torch.empty_like(xp) if (mode == MODE_K_TIMES_EDGE_PROB and N > 0) else _zeros(tuple(xp.shape), xp.device)   # (N == 0: see conv_bwd_cols_p)
-    rowinfo = torch.empty((N, 4), device=xp.device, dtype=torch.float32)
-    dk = torch.empty((N,), device=xp.device, dtype=torch.float32)
+    if phase == 2:
+        dxp, dk, rowinfo = state
+    else:
+        # mode 0: every row of dxp is written (own rows by the row kernel, the others by the per-node kernel): no zero fill
+        dxp = torch.empty_like(xp) if (mode == MODE_K_TIMES_EDGE_PROB and N > 0) else _zeros(tuple(xp.shape), xp.device)   # (N == 0: see conv_bwd_cols_p)
+        rowinfo = torch.empty((N, 4), device=xp.device, dtype=torch.float32)
+        dk = torch.empty((N,), device=xp.device, dtype=torch.float32)
     pe = _probe_begin()
-    _lib.check(_lib.lib().dgg_softk_edge_bwd_partp(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(k)), _ptr(rs), _ptr(_chk(dA)),
-                                                   _ptr(dA_rec), _ptr(da), _ptr(None if ahat_rows is None else _chk(ahat_rows)), K, row0, t,
-                                                   int(perturb), mode, int(normalized), _ptr(partp.ws), Ng, _ptr(rowinfo), _ptr(dk), _ptr(dxp),
-                                                   int(out_act), _stream()), "softk_edge_bwd_partp")
-    _probe_end("edge_bwd", pe)
+    _lib.check(_lib.lib().dgg_softk_edge_bwd_partp_phase(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(k)), _ptr(rs), _ptr(_chk(dA)),
+                                                         _ptr(dA_rec), _ptr(da), _ptr(None if ahat_rows is None else _chk(ahat_rows)), K, row0, t,
+                                                         int(perturb), mode, int(normalized), _ptr(partp.ws), Ng, _ptr(rowinfo), _ptr(dk),
+                                                         _ptr(dxp), int(out_act), int(phase), _stream()), "softk_edge_bwd_partp")
+    _probe_end("edge_bwd" if phase == 0 else ("edge_bwd_rows" if phase == 1 else "edge_bwd_node"), pe)
+    if phase == 1:
+        return dxp, dk, (dxp, dk, rowinfo)
     return dxp, dk
 
 

@@ -106,6 +106,11 @@ class ShardedDGGConv:
         assert not hybrid or x_full is not None, "the hybrid scheme replicates the features for the scoring side"
         self.x_full = x_full                                 # [N,d] static node features present on every rank, or None
         self.hybrid = bool(hybrid)                           # replicated xp, all-gathered H, reduce-scattered dH (module docstring)
+        # Two independent kernels of the step run beside their neighbours on a SECOND stream (captured into the same hipGraph): the
+        # partition's sort (read by the backward only) beside the forward aggregation, and the k-net backward (needs only dk, MFMA-
+        # bound) beside the per-destination kernel of the score backward (gather-bound).  DGG_OVERLAP=0 keeps everything on one stream.
+        self.overlap = os.environ.get("DGG_OVERLAP", "1") != "0" and hasattr(kern, "partp_sort")
+        self._side = None
         self.K, self.t, self.noise_mode, self.seed, self.mode, self.algo, self.x_grad = K, t, noise_mode, seed, mode, algo, x_grad
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -155,6 +160,11 @@ class ShardedDGGConv:
         xp = kern.linear_fwd(Xall, P["We"], P["be"], 1, 0)
         H = kern.linear_fwd(Xall, P["Wc"], None, 0, 1)
         return xp, H, kern.linear_fwd(x_local, P["Wk"], P["bk"], 1, 0)
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
 
     def _hyb(self):
         """the hybrid exchange is live: several ranks (or their single-process emulation) on replicated features"""
@@ -213,8 +223,19 @@ class ShardedDGGConv:
         # (payload form -- records carry w rs_i^-1/2 and the score, no slot map, normalize_adj fused into its fill pass -- when the
         # namespace offers it and covers the shape)
         use_p = hasattr(kern, "partp_build") and xp.shape[1] in (16, 32, 64, 128) and H.shape[1] in (16, 32, 64, 128) and self.mode in (0, 1)
-        got = kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs) if use_p else None
+        ov = use_p and self.overlap and s["idx"].is_cuda
+        got = (kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs, phase=1) if ov else
+               kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs)) if use_p else None
         s["partp"], s["ahat"] = got if got is not None else (None, None)
+        s["side_join"] = False
+        if ov and got is not None:                  # the sort runs beside the aggregation; the backward joins before its first column kernel
+            main, side = torch.cuda.current_stream(), self._side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                kern.partp_sort(s["partp"])
+            if not torch.cuda.is_current_stream_capturing():
+                s["partp"].ws.record_stream(side)
+            s["side_join"] = True
         s["part"] = kern.part_build(s["idx"], s["w"], self.N) if (s["partp"] is None and hasattr(kern, "part_build")) else None
         if s["ahat"] is None:
             s["ahat"] = kern.normalize_fwd(s["idx"], s["w"], rs, self.r0)
@@ -279,6 +300,9 @@ class ShardedDGGConv:
         # (which adds the row side of da in registers), so both must cover the shape
         partp = s.get("partp")
         if partp is not None:
+            if s.get("side_join"):                  # the partition's sort ran on the side stream
+                torch.cuda.current_stream().wait_stream(self._side_stream())
+                s["side_join"] = False
             # (dA of the entries outside the partition is masked by the row kernel -- ahat_rows is 0 there -- so it is not zero-filled)
             pc = kern.conv_bwd_cols_p(s["idx"], s["H"], G, partp, s["rs"], zero_dA=False)
             assert pc is not None
@@ -290,6 +314,25 @@ class ShardedDGGConv:
             # the activation derivative of the two LeakyReLU projections is applied by the kernels that PRODUCE dxp / dxk (they hold
             # xp_j / xk in registers): the fused weight-gradient product then reads no forward output for the mask (51 MB less)
             pre = self._premask(x_local)
+            if self.overlap and self.mode == 0 and s["z"] is None and s["idx"].is_cuda:
+                # row kernel -> dk; then the k-net backward on the side stream beside the per-destination kernel on this one
+                dxp, dk, st = kern.softk_edge_bwd_p(s["xp"], s["idx"], s["val"], s["k"], dA, dA_rec, s["rs"], da, self.r0, self.t,
+                                                    self.noise_mode != 0, self.mode, True, partp, ahat_rows=s["ahat"],
+                                                    out_act=1 if pre else 0, phase=1)
+                main, side = torch.cuda.current_stream(), self._side_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    kn = kern.knet_x_bwd_fused(s["xk"], s["deg_local"], s["mu_sd"], P["W1"], P["b1"], P["Wmu"], P["bmu"],
+                                               P["Wp"].reshape(-1), s["u"], dk, out_act=1 if pre else 0)
+                kern.softk_edge_bwd_p(s["xp"], s["idx"], s["val"], s["k"], dA, dA_rec, s["rs"], da, self.r0, self.t,
+                                      self.noise_mode != 0, self.mode, True, partp, ahat_rows=s["ahat"], out_act=1 if pre else 0,
+                                      phase=2, state=st)
+                main.wait_stream(side)
+                if not torch.cuda.is_current_stream_capturing():
+                    dk.record_stream(side)
+                    for t_ in kn:
+                        t_.record_stream(main)
+                return self._weight_grads(g, dxp, dH, dk, x_local, P, premasked=pre, knet=kn)
             dxp, dk = kern.softk_edge_bwd_p(s["xp"], s["idx"], s["val"], s["k"], dA, dA_rec, s["rs"], da, self.r0, self.t,
                                             self.noise_mode != 0, self.mode, True, partp, ahat_rows=s["ahat"], out_act=1 if pre else 0)
             return self._weight_grads(g, dxp, dH, dk, x_local, P, premasked=pre)
@@ -329,7 +372,7 @@ class ShardedDGGConv:
         return bool(getattr(kern, "PREMASK", False)) and hasattr(kern, "linear_bwd_multi") and not self.x_grad and self.mode == 0 and \
             self.saved["z"] is None and not (self.coll and self.x_full is None)
 
-    def _weight_grads(self, g, dxp, dH, dk, x_local, P, premasked=False):
+    def _weight_grads(self, g, dxp, dH, dk, x_local, P, premasked=False, knet=None):
         kern, s = self.kern, self.saved
         repl = self.x_full is not None
         # weight gradients of the two projections.  Replicated features: partial [dxp | dH] of all N nodes against the full X (the
@@ -341,7 +384,9 @@ class ShardedDGGConv:
             dxp_g, dH_g, Xg, xp_g = both[:, :h].contiguous(), both[:, h:].contiguous(), x_local, s["xp_loc"]
         else:
             dxp_g, dH_g, Xg, xp_g = dxp, dH, (self.x_full if repl else x_local), s["xp"]
-        if s["z"] is None and premasked:
+        if knet is not None:                         # already run (beside the score backward's column kernel)
+            dxk, g["W1"], g["b1"], g["Wmu"], g["bmu"], dWp, g["bp"] = knet
+        elif s["z"] is None and premasked:
             dxk, g["W1"], g["b1"], g["Wmu"], g["bmu"], dWp, g["bp"] = kern.knet_x_bwd_fused(
                 s["xk"], s["deg_local"], s["mu_sd"], P["W1"], P["b1"], P["Wmu"], P["bmu"], P["Wp"].reshape(-1), s["u"], dk, out_act=1)
         elif s["z"] is None:
