@@ -17,8 +17,9 @@ from collections import defaultdict
 # bench.py kernel key -> rocprof kernel-name substrings (several = one C-ABI call made of several launches: summed)
 NAMES = {"allpairs_topk": ["allpairs_topk_ranked"], "spmm_fwd": ["spmm_fwd_narrow"], "conv_bwd": ["conv_bwd_node"],
          "edge_bwd": ["edge_bwd_rows", "edge_bwd_node"], "edge_bwd_rows": ["edge_bwd_rows"], "edge_bwd_node": ["edge_bwd_node"],
-         "part_build": ["part_pass", "part_sort_p", "part_scan"], "linear_fwd": ["linear_fwd_mfma", "linear_fwd_reg"], "gemm_tn_multi": ["gemm_tn_multi", "gemm_tn_wide"],
-         "knet_x_fwd": ["knet_x_fwd_tpn"], "knet_x_bwd": ["knet_x_bwd_tpn"], "softk_fwd": ["softk_fwd_kernel"],
+         "part_build": ["pp_count", "pp_scan", "pp_fill", "pp_sort"], "linear_fwd": ["linear_fwd_mfma", "linear_fwd_reg"],
+         "gemm_tn_multi": ["gemm_tn_multi", "gemm_tn_wide", "gemm_tn_reduce_multi"],
+         "knet_x_fwd": ["knet_x_fwd_reg"], "knet_x_bwd": ["knet_x_bwd_reg", "knet_bwd_reduce"], "softk_fwd": ["softk_fwd_kernel"],
          "normalize_fwd": ["normalize_fwd_kernel"]}
 
 
@@ -34,7 +35,7 @@ def per_kernel(d, counter):
                         acc[pat] += float(r["Counter_Value"])
                         cnt[pat] += 1
     # average per launch of each kernel; launches of one call summed (part_pass runs twice per call: count both)
-    mult = {"part_pass": 2.0}
+    mult = {}
     return {k: sum(acc[p_] / cnt[p_] * mult.get(p_, 1.0) for p_ in pats if cnt[p_]) for k, pats in NAMES.items()
             if any(cnt[p_] for p_ in pats)}
 

@@ -1,0 +1,42 @@
+# round-4 profile collection (run on the GPU box): bash tools/prof_r04.sh  -> gpurun_out/r04/
+set -eu
+R="${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
+O="$R/gpurun_out/r04"
+rm -rf -- "$O"; mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp
+BA="--steps 3 --warmup 1 --repeats 1 --cpu-rows -1 --no-hipgraph --no-variants"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -- python3 "$R/bench.py" $BA > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -- python3 "$R/bench.py" $BA > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -- python3 "$R/bench.py" $BA > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_sq -- python3 "$R/bench.py" $BA > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/trace -o h -- python3 "$R/bench.py" --steps 20 --warmup 5 --repeats 3 --cpu-rows -1 --no-variants > "$O/bench_under_profiler.json" 2>/dev/null
+for nz in none rsym hash; do
+  rocprofv3 --kernel-trace --stats -d /tmp/trace_$nz -o h -- python3 "$R/bench.py" --noise $nz --steps 10 --warmup 3 --repeats 2 --cpu-rows -1 --no-variants > /dev/null 2>&1
+done
+rocprofv3 --kernel-trace --stats -d /tmp/trace_ppi -o h -- python3 "$R/bench.py" --steps 4 --warmup 2 --workload ppi --bf16 --cpu-rows -1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/trace_pub -o h -- python3 "$R/bench.py" --steps 20 --warmup 5 --workload pubmed --cpu-rows -1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/trace_emu -o h -- python3 "$R/bench.py" --steps 20 --warmup 5 --repeats 2 --emulate-world 8 --nodes 62500 --cpu-rows -1 --no-variants > /dev/null 2>&1
+cd "$R"
+python3 tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write "$O/r04_traffic.json" 100000 128 64 > /dev/null
+python3 tools/mfma_busy.py /tmp/pmc_mfma "$O/r04_mfma_busy.csv" > /dev/null
+python3 tools/sq_breakdown.py /tmp/pmc_sq "$O/r04_sq_breakdown.csv" > /dev/null
+python3 tools/kernel_stats.py /tmp/trace/h_results.db "$O/r04_kernel_stats.csv" --skip-first 8 > /dev/null
+python3 tools/kernel_stats.py /tmp/trace_none/h_results.db "$O/r04_unperturbed_kernel_stats.csv" --skip-first 3 > /dev/null
+python3 tools/kernel_stats.py /tmp/trace_rsym/h_results.db "$O/r04_symmetric_kernel_stats.csv" --skip-first 3 > /dev/null
+python3 tools/kernel_stats.py /tmp/trace_hash/h_results.db "$O/r04_hash_kernel_stats.csv" --skip-first 3 > /dev/null
+python3 tools/kernel_stats.py /tmp/trace_ppi/h_results.db "$O/r04_ppi_bf16_kernel_stats.csv" --skip-first 0 > /dev/null
+python3 tools/kernel_stats.py /tmp/trace_pub/h_results.db "$O/r04_pubmed_kernel_stats.csv" --skip-first 0 > /dev/null
+python3 tools/kernel_stats.py /tmp/trace_emu/h_results.db "$O/r04_emulated_rank_of_8_kernel_stats.csv" --skip-first 8 > /dev/null
+cp "$O/r04_traffic.json" profiles/r04_traffic.json     # bench.py reads the newest traffic file from here
+python3 bench.py --steps 20 --warmup 5 > "$O/r04_bench.json" 2> "$O/bench.err"
+python3 bench.py --steps 20 --warmup 5 --workload pubmed > "$O/r04_pubmed_uvdist_bench.json" 2>> "$O/bench.err"
+python3 bench.py --steps 10 --warmup 3 --workload ppi --bf16 > "$O/r04_ppi_bf16_bench.json" 2>> "$O/bench.err"
+python3 bench.py --steps 20 --warmup 5 --nodes 500000 --no-variants --cpu-rows -1 > "$O/r04_bench_n500k_1gpu.json" 2>> "$O/bench.err"
+python3 bench.py --steps 20 --warmup 5 --emulate-world 8 --nodes 62500 --no-variants --cpu-rows -1 > "$O/r04_emulated_rank_of_8_strong_500k.json" 2>> "$O/bench.err"
+python3 bench.py --steps 20 --warmup 5 --emulate-world 8 --nodes 62500 --exchange replicate --no-variants --cpu-rows -1 > "$O/r04_emulated_rank_of_8_strong_500k_replicate.json" 2>> "$O/bench.err"
+ls -la "$O"; tail -c 400 "$O/bench.err"
+python3 - <<'PY'
+import json
+j=json.load(open('gpurun_out/r04/r04_bench.json'))
+print(j['ms_per_step'], j['roofline']['frac'], {k:(v.get('ms_per_step'), v.get('pair_kernel_ms'), (v.get('roofline') or {}).get('frac')) for k,v in j['variants'].items()})
+PY
