@@ -114,12 +114,36 @@ class CsrAdjacency:
     __matmul__ = matmul
 
 
+# The candidate graph is DATA: the same sparse tensor object comes in on every forward (train_small_graphs.py builds it once), and
+# turning it into the CSR arrays costs ~15 tiny launches (coalesce, coo -> csr, casts, a float64 cumsum, two index ops) -- a sixth of
+# the Pubmed-shape step.  Both conversions are cached per tensor OBJECT (weak reference) and version of its values: a new tensor,
+# or one modified in place, is converted again.  Not during a hipGraph capture of an unseen tensor (nothing is cached from there).
+_CSR_CACHE = {}
+
+
+def _cached(kind, in_adj, make):
+    import weakref
+    key = (kind, id(in_adj))
+    ver = in_adj._values()._version if in_adj.is_sparse else in_adj._version
+    ent = _CSR_CACHE.get(key)
+    if ent is not None and ent[0]() is in_adj and ent[1] == ver:
+        return ent[2]
+    out = make()
+    if not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
+        for k_ in [k_ for k_, v in _CSR_CACHE.items() if v[0]() is None]:
+            del _CSR_CACHE[k_]
+        _CSR_CACHE[key] = (weakref.ref(in_adj), ver, out)
+    return out
+
+
 def csr_pattern(in_adj):
     """coalesced sparse COO -> (rowptr int64, col int32, erow int32)"""
-    in_adj = in_adj.coalesce()
-    ind = in_adj.indices()
-    rowptr = torch._convert_indices_from_coo_to_csr(ind[0], in_adj.shape[0], out_int32=False)
-    return rowptr, ind[1].to(torch.int32).contiguous(), ind[0].to(torch.int32).contiguous()
+    def make():
+        a = in_adj.coalesce()
+        ind = a.indices()
+        rowptr = torch._convert_indices_from_coo_to_csr(ind[0], a.shape[0], out_int32=False)
+        return rowptr, ind[1].to(torch.int32).contiguous(), ind[0].to(torch.int32).contiguous()
+    return _cached("pattern", in_adj, make)
 
 
 def ell_from_dense(A, K=ops.DEFAULT_K):
@@ -135,13 +159,15 @@ def ell_from_dense(A, K=ops.DEFAULT_K):
 def csr_candidates(in_adj):
     """torch sparse COO [N,N] (coalesced, self loops included by the caller as in model.py:1249-1264) ->
     (rowptr int64 [N+1], col int32 [E], deg fp32 [N] = row sums of the stored values)."""
-    in_adj = in_adj.coalesce()
-    N = in_adj.shape[0]
-    ind = in_adj.indices()
-    rowptr = torch._convert_indices_from_coo_to_csr(ind[0], N, out_int32=False)
-    col = ind[1].to(torch.int32).contiguous()
-    # row sums, deterministic (index_add_ uses float atomics: the last bit would change from call to call, and the raw
-    # degrees are an input of the u-v-deg scorers): differences of a float64 running sum at the row boundaries
-    cs = torch.cat([in_adj.values().new_zeros(1, dtype=torch.float64), in_adj.values().double().cumsum(0)])
-    deg = (cs[rowptr[1:]] - cs[rowptr[:-1]]).float()
-    return rowptr, col, deg
+    def make():
+        a = in_adj.coalesce()
+        N = a.shape[0]
+        ind = a.indices()
+        rowptr = torch._convert_indices_from_coo_to_csr(ind[0], N, out_int32=False)
+        col = ind[1].to(torch.int32).contiguous()
+        # row sums, deterministic (index_add_ uses float atomics: the last bit would change from call to call, and the raw
+        # degrees are an input of the u-v-deg scorers): differences of a float64 running sum at the row boundaries
+        cs = torch.cat([a.values().new_zeros(1, dtype=torch.float64), a.values().double().cumsum(0)])
+        deg = (cs[rowptr[1:]] - cs[rowptr[:-1]]).float()
+        return rowptr, col, deg
+    return _cached("candidates", in_adj, make)
