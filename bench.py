@@ -944,15 +944,18 @@ def bench_synthetic(a, dev, world, rank, force):
                     except Exception as e:  # noqa: BLE001
                         print(f"variant {name}: hipGraph capture failed ({e!r}); timing eager launches", file=sys.stderr)
                         vgraphs = None
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for s_ in range(vsteps):
-                    if vgraphs is not None:
-                        vgraphs[s_ % 2].replay()
-                    else:
-                        rv.step(s_ % NGRAPH)
-                torch.cuda.synchronize()
-                tv = (time.perf_counter() - t0) / vsteps
+                tws = []
+                for _w in range(3):                                 # median of three windows
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for s_ in range(vsteps):
+                        if vgraphs is not None:
+                            vgraphs[s_ % 2].replay()
+                        else:
+                            rv.step(s_ % NGRAPH)
+                    torch.cuda.synchronize()
+                    tws.append((time.perf_counter() - t0) / vsteps)
+                tv = float(np.median(tws))
                 vgraphs = None
                 ops.PROBE = {}
                 rv.step(0)
@@ -963,7 +966,8 @@ def bench_synthetic(a, dev, world, rank, force):
                 kv = float(rv.layer.saved["k"].mean().item())
                 pk = e0.elapsed_time(e1)
                 variants[name] = {"ms_per_step": tv * 1e3, "edges_per_s": N * kv / tv, "pair_kernel_ms": pk, "steps": vsteps,
-                                  "note": "ms_per_step: hipGraph replay (two seeds alternating); pair_kernel_ms: events around the C-ABI call in one eager step"}
+                                  "window_ms_min_median_max": [min(tws) * 1e3, tv * 1e3, max(tws) * 1e3],
+                                  "note": "ms_per_step: median of three windows of hipGraph replay (two seeds alternating); pair_kernel_ms: events around the C-ABI call in one eager step"}
                 # roofline of the pair stage of the variants that sweep all N^2 pairs (one C-ABI call = several launches, event-timed as a
                 # whole; per-launch durations: profiles/r03_*_kernel_stats.csv)
                 if name == "unperturbed":
