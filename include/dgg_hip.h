@@ -350,7 +350,7 @@ int dgg_partp_build_phase(const int32_t *idx, const float *w, const float *val, 
 /* Where the pieces of a built payload partition live inside its workspace (byte offsets; for tests and tools that want to look at the
  * records): out[0] = bucket starts (int32 [nb+1]), out[1] = CSC node pointer (int32 [ncols+1]: the records of destination node j are
  * recs[nodeptr[j] .. nodeptr[j+1])), out[2] = records in node order (16 bytes each: row*64 + r, j, bits of w_ir rs_i^-1/2, bits of the
- * score), out[3] = number of buckets, out[4] = log2 of the bucket width in nodes, out[5] = rows per counting workgroup. */
+ * score), out[3] = number of buckets, out[4] = bucket width in nodes, out[5] = rows per counting workgroup. */
 int dgg_partp_describe(int64_t rows, int K, int64_t ncols, int64_t *out6);
 /* dgg_ell_conv_bwd_part on a payload partition (ahat_ir = record payload * rs_j^-1/2, bit-identical to dgg_ell_normalize_fwd);
  * also writes dA_rec [rows*K] = dA in record order.  dA, dH, da: caller zeroes. */

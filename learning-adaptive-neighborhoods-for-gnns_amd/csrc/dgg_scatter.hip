@@ -889,40 +889,57 @@ inline int64_t nbuckets(int64_t ncols) { return (ncols + BS - 1) / BS; }
 //              its rank inside (workgroup, bucket) from ONE returning LDS add and is stored at start[b] + T[wg][b] + rank; ahat fused
 //   pp_sort    one workgroup per bucket holds the bucket's records in REGISTERS, ranks them inside their node with one returning
 //              LDS add, scans the node counts and stores every record once (buckets beyond the register budget re-read)
-// Buckets are PBS nodes wide, a power of two chosen from the column count so that a bucket of the expected size fits the register
-// path and the table stays small.  Record order inside a node depends on the arrival order of the LDS adds, as before.
+// Buckets are `width` nodes wide (pp_width).  Record order inside a node depends on the arrival order of the LDS adds, as before.
 constexpr int PP_T = 1024;                                       // threads of a pp_sort workgroup
 constexpr int PP_RPT = 16;                                       // records per thread held in registers by pp_sort
 inline int pp_threads() {                                        // threads of a pp_count / pp_fill workgroup (16 rows per wavefront)
     static const int t = [] { const char *e = getenv("DGG_PP_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 1024; }();
     return t;
 }
-inline int pp_shift(int64_t rows, int K, int64_t ncols) {        // log2 of the bucket width
-    static const int forced = [] { const char *e = getenv("DGG_PP_SHIFT"); return e ? atoi(e) : 0; }();
-    // expected records per bucket ~ rows * 0.7 K * PBS / ncols <= 3/4 of the register path's capacity; at least 128 nodes
-    int s = 7;
+// Bucket width in destination nodes.  One pp_sort workgroup per bucket and CU: the bucket count is made a MULTIPLE OF THE CU COUNT
+// (from below) so that the last round of sort workgroups is full -- 391 power-of-two buckets on 256 CUs ran a 1.5-round tail -- with
+// the expected records of a bucket (~ rows * 0.7 K * width / ncols) within 3/4 of what the sort keeps in registers.  The bucket of a
+// node is j / width = umulhi(j, ceil(2^32 / width)) (exact while ncols * width < 2^32; wider problems take a power of two).
+inline int pp_width(int64_t rows, int K, int64_t ncols) {
+    static const int forced = [] { const char *e = getenv("DGG_PP_WIDTH"); return e ? atoi(e) : 0; }();
     const double per_node = (double)rows * (0.7 * K) / (double)(ncols > 0 ? ncols : 1);
-    while (s < 12 && per_node * (double)(2 << s) <= 0.75 * PP_T * PP_RPT) s++;
-    if (forced >= 5 && forced <= 12) s = forced;
-    while (((ncols + ((int64_t)1 << s) - 1) >> s) > 4096) s++;  // LDS histograms: at most 4096 buckets
-    return s;
+    int64_t wmax = (int64_t)(0.75 * PP_T * PP_RPT / (per_node > 1e-9 ? per_node : 1e-9));
+    wmax = wmax < 32 ? 32 : (wmax > 4096 ? 4096 : wmax);
+    int64_t w = wmax;
+    for (int m = 1; m <= 16; m++) {                               // smallest multiple of 256 buckets whose width fits
+        const int64_t cand = (ncols + 256 * m - 1) / (256 * m);
+        if (cand <= wmax) { w = cand < 32 ? 32 : cand; break; }
+    }
+    if (forced >= 32 && forced <= 4096) w = forced;
+    while ((ncols + w - 1) / w > 4096) w *= 2;                   // LDS histograms: at most 4096 buckets
+    if ((double)ncols * (double)w >= 4.0e9) {                    // the reciprocal multiply would not be exact: power of two
+        int64_t p2 = 32;
+        while (p2 < w) p2 *= 2;
+        w = p2;
+    }
+    return (int)w;
 }
+inline uint32_t pp_recip(int width) { return (uint32_t)((((uint64_t)1 << 32) + (uint64_t)width - 1) / (uint64_t)width); }
+__device__ __forceinline__ int pp_bucket(int j, uint32_t rcp) { return (int)__umulhi((uint32_t)j, rcp); }
+
 struct PartP2 {                    // workspace: [bstart NB+1][totals NB][nodeptr NB*PBS+1][T nwg*NB][ainv ncols][tmp][recs]
     int *bstart, *totals, *nodeptr, *T;
     float *ainv;                   // rs_j^-1/2 of every destination node (normalize_adj fused into the fill pass)
     int4 *tmp, *recs;
-    int shift;
+    int width;                     // destination nodes per bucket
+    uint32_t rcp;                  // ceil(2^32 / width)
     int64_t nb, nwg;
 };
 inline size_t partp2_layout(PartP2 &p, void *ws, int64_t rows, int K, int64_t ncols) {
-    p.shift = pp_shift(rows, K, ncols);
-    p.nb = (ncols + ((int64_t)1 << p.shift) - 1) >> p.shift;
+    p.width = pp_width(rows, K, ncols);
+    p.rcp = pp_recip(p.width);
+    p.nb = (ncols + p.width - 1) / p.width;
     p.nwg = (rows + pp_threads() / 4 - 1) / (pp_threads() / 4);
     char *w = reinterpret_cast<char *>(ws);
     size_t o = 0;
     p.bstart = reinterpret_cast<int *>(w + o); o += align256((size_t)(p.nb + 1) * 4);
     p.totals = reinterpret_cast<int *>(w + o); o += align256((size_t)p.nb * 4);
-    p.nodeptr = reinterpret_cast<int *>(w + o); o += align256((size_t)((p.nb << p.shift) + 1) * 4);
+    p.nodeptr = reinterpret_cast<int *>(w + o); o += align256((size_t)(p.nb * p.width + 1) * 4);
     p.T = reinterpret_cast<int *>(w + o); o += align256((size_t)p.nwg * p.nb * 4);
     p.ainv = reinterpret_cast<float *>(w + o); o += align256((size_t)ncols * 4);
     p.tmp = reinterpret_cast<int4 *>(w + o); o += align256((size_t)rows * K * sizeof(int4));
@@ -947,7 +964,7 @@ __device__ __forceinline__ float pp_getf(const float4 &v, int c) { return c == 0
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void pp_count(const int32_t *__restrict__ idx, const float *__restrict__ w, int64_t rows, int K, int nb,
-                                                    int shift, int *__restrict__ T, const float *__restrict__ rs_all, int64_t ncols,
+                                                    uint32_t rcp, int *__restrict__ T, const float *__restrict__ rs_all, int64_t ncols,
                                                     float *__restrict__ ainv) {
     extern __shared__ int lds[];
     int *hist = lds;
@@ -969,14 +986,14 @@ __global__ __launch_bounds__(THREADS) void pp_count(const int32_t *__restrict__ 
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const int j = pp_get(ji[u], c);
-                if (j >= 0 && pp_getf(wv[u], c) != 0.0f) atomicAdd(&hist[j >> shift], 1);
+                if (j >= 0 && pp_getf(wv[u], c) != 0.0f) atomicAdd(&hist[pp_bucket(j, rcp)], 1);
             }
     } else {
         for (int q = 0; q < 16; q++) {
             const int64_t i = r0 + q;
             if (i < rows && lane < K) {
                 const int j = idx[i * K + lane];
-                if (j >= 0 && w[i * K + lane] != 0.0f) atomicAdd(&hist[j >> shift], 1);
+                if (j >= 0 && w[i * K + lane] != 0.0f) atomicAdd(&hist[pp_bucket(j, rcp)], 1);
             }
         }
     }
@@ -1060,7 +1077,7 @@ __device__ __forceinline__ int pp_block_scan(const int *__restrict__ in_g, int *
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void pp_fill(const int32_t *__restrict__ idx, const float *__restrict__ w, const float *__restrict__ val,
-                                                   const float *__restrict__ rs_rows, int64_t rows, int K, int nb, int shift,
+                                                   const float *__restrict__ rs_rows, int64_t rows, int K, int nb, uint32_t rcp,
                                                    const int *__restrict__ T, const int *__restrict__ totals, int *__restrict__ bstart,
                                                    int4 *__restrict__ recs4, const float *__restrict__ ainv, float *__restrict__ ahat_out) {
     extern __shared__ int lds[];                                 // hist[nb], base[nb], scratch[16]
@@ -1107,7 +1124,7 @@ __global__ __launch_bounds__(THREADS) void pp_fill(const int32_t *__restrict__ i
                 const int j = pp_get(ji[u], c);
                 const float wx = pp_getf(wv, c);
                 if (j >= 0 && wx != 0.0f) {
-                    const int b = j >> shift;
+                    const int b = pp_bucket(j, rcp);
                     const int slot = base[b] + atomicAdd(&hist[b], 1);
                     // wa = a_i * w exactly as normalize_fwd_kernel forms it (dgg_ell.hip), so that wa * a_j == ahat bit for bit
                     const float wa = __fmul_rn(ai, wx);
@@ -1126,7 +1143,7 @@ __global__ __launch_bounds__(THREADS) void pp_fill(const int32_t *__restrict__ i
                 const float wx = w[i * K + lane];
                 float a = 0.0f;
                 if (j >= 0 && wx != 0.0f) {
-                    const int b = j >> shift;
+                    const int b = pp_bucket(j, rcp);
                     const int slot = base[b] + atomicAdd(&hist[b], 1);
                     const float wa = __fmul_rn(__fdiv_rn(1.0f, c_sqrt(rs_rows[i])), wx);
                     recs4[slot] = make_int4((int)(i * 64 + lane), j, (int)__float_as_uint(wa), (int)__float_as_uint(val[i * K + lane]));
@@ -1140,9 +1157,8 @@ __global__ __launch_bounds__(THREADS) void pp_fill(const int32_t *__restrict__ i
 
 // one workgroup per bucket: records -> node order; nodeptr for the bucket's nodes
 __global__ __launch_bounds__(PP_T) void pp_sort(const int *__restrict__ bstart, const int4 *__restrict__ tmp, int4 *__restrict__ recs,
-                                                int *__restrict__ nodeptr, int nb, int shift) {
+                                                int *__restrict__ nodeptr, int nb, int PBS) {
     extern __shared__ int lds[];                                 // cnt[PBS], base[PBS], scratch[16]
-    const int PBS = 1 << shift;
     int *cnt = lds, *base = lds + PBS, *scratch = lds + 2 * PBS;
     const int tid = threadIdx.x, b = blockIdx.x;
     const int e0 = bstart[b], e1 = bstart[b + 1], n = e1 - e0;
@@ -1160,24 +1176,24 @@ __global__ __launch_bounds__(PP_T) void pp_sort(const int *__restrict__ bstart, 
             if (e >= e1) rec[u].y = -1;
         }
 #pragma unroll
-        for (int u = 0; u < PP_RPT; u++) rank[u] = rec[u].y >= 0 ? atomicAdd(&cnt[rec[u].y - (b << shift)], 1) : 0;
+        for (int u = 0; u < PP_RPT; u++) rank[u] = rec[u].y >= 0 ? atomicAdd(&cnt[rec[u].y - b * PBS], 1) : 0;
     } else {
-        for (int e = e0 + tid; e < e1; e += PP_T) atomicAdd(&cnt[tmp[e].y - (b << shift)], 1);
+        for (int e = e0 + tid; e < e1; e += PP_T) atomicAdd(&cnt[tmp[e].y - b * PBS], 1);
     }
     __syncthreads();
     pp_block_scan<PP_T>(cnt, base, PBS, scratch);
-    for (int q = tid; q < PBS; q += PP_T) nodeptr[((int64_t)b << shift) + q] = o0 + base[q];
-    if (b == nb - 1 && tid == 0) nodeptr[(int64_t)nb << shift] = o1;
+    for (int q = tid; q < PBS; q += PP_T) nodeptr[(int64_t)b * PBS + q] = o0 + base[q];
+    if (b == nb - 1 && tid == 0) nodeptr[(int64_t)nb * PBS] = o1;
     if (inreg) {
 #pragma unroll
         for (int u = 0; u < PP_RPT; u++)
-            if (rec[u].y >= 0) recs[o0 + base[rec[u].y - (b << shift)] + rank[u]] = rec[u];
+            if (rec[u].y >= 0) recs[o0 + base[rec[u].y - b * PBS] + rank[u]] = rec[u];
     } else {
         for (int q = tid; q < PBS; q += PP_T) cnt[q] = 0;
         __syncthreads();
         for (int e = e0 + tid; e < e1; e += PP_T) {
             const int4 r = tmp[e];
-            const int jl = r.y - (b << shift);
+            const int jl = r.y - b * PBS;
             recs[o0 + base[jl] + atomicAdd(&cnt[jl], 1)] = r;
         }
     }
@@ -1324,7 +1340,7 @@ size_t dgg_partp_ws_bytes(int64_t rows, int K, int64_t ncols) {
     if (K > 64 || K < 1 || rows * 64 >= ((int64_t)1 << 31) || ncols < 1) return 0;          // 32-bit record ids
     PartP2 p;
     const size_t bytes = partp2_layout(p, nullptr, rows, K, ncols);
-    if (p.nb > 4096 || (1 << p.shift) > 4096) return 0;                                      // LDS histograms / node counters
+    if (p.nb > 4096 || p.width > 4096) return 0;                                             // LDS histograms / node counters
     return bytes;
 }
 
@@ -1358,16 +1374,16 @@ int dgg_partp_build_phase(const int32_t *idx, const float *w, const float *val, 
     if (rows == 0) return 0;
     PartP2 p;
     partp2_layout(p, ws, rows, K, ncols);
-    const int nb = (int)p.nb, nwg = (int)p.nwg, pbs = 1 << p.shift;
+    const int nb = (int)p.nb, nwg = (int)p.nwg, pbs = p.width;
     if (phase == 2) {
-        hipLaunchKernelGGL(pp_sort, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr, nb, p.shift);
+        hipLaunchKernelGGL(pp_sort, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr, nb, pbs);
         return dgg_check_launch("partp_build");
     }
 #define DGG_PP_PASS(TT)                                                                                                      \
-    hipLaunchKernelGGL(pp_count<TT>, dim3((unsigned)nwg), dim3(TT), (size_t)nb * 4, st, idx, w, rows, K, nb, p.shift, p.T, rs_all, ncols, \
+    hipLaunchKernelGGL(pp_count<TT>, dim3((unsigned)nwg), dim3(TT), (size_t)nb * 4, st, idx, w, rows, K, nb, p.rcp, p.T, rs_all, ncols, \
                        p.ainv);                                                                                              \
     hipLaunchKernelGGL(pp_scan, dim3((unsigned)((nb + 31) / 32)), dim3(1024), 0, st, p.T, nwg, nb, p.totals);                \
-    hipLaunchKernelGGL(pp_fill<TT>, dim3((unsigned)nwg), dim3(TT), (size_t)(2 * nb + 16) * 4, st, idx, w, val, rs_rows, rows, K, nb, p.shift, \
+    hipLaunchKernelGGL(pp_fill<TT>, dim3((unsigned)nwg), dim3(TT), (size_t)(2 * nb + 16) * 4, st, idx, w, val, rs_rows, rows, K, nb, p.rcp, \
                        p.T, p.totals, p.bstart, p.tmp, p.ainv, ahat)
     switch (pp_threads()) {
         case 256: DGG_PP_PASS(256); break;
@@ -1376,7 +1392,7 @@ int dgg_partp_build_phase(const int32_t *idx, const float *w, const float *val, 
     }
 #undef DGG_PP_PASS
     if (phase == 1) return dgg_check_launch("partp_build");
-    hipLaunchKernelGGL(pp_sort, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr, nb, p.shift);
+    hipLaunchKernelGGL(pp_sort, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr, nb, pbs);
     return dgg_check_launch("partp_build");
 }
 
@@ -1388,7 +1404,7 @@ int dgg_partp_describe(int64_t rows, int K, int64_t ncols, int64_t *out6) {
     out6[1] = reinterpret_cast<char *>(p.nodeptr) - static_cast<char *>(nullptr);
     out6[2] = reinterpret_cast<char *>(p.recs) - static_cast<char *>(nullptr);
     out6[3] = p.nb;
-    out6[4] = p.shift;
+    out6[4] = p.width;
     out6[5] = pp_threads() / 4;
     return 0;
 }

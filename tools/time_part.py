@@ -29,5 +29,5 @@ for _ in range(R):
 e1.record()
 torch.cuda.synchronize()
 act = int(((idx >= 0) & (w != 0)).sum().item())
-print(f"N={N} active={act} threads={os.environ.get('DGG_PP_THREADS', 'default')} shift={os.environ.get('DGG_PP_SHIFT', 'auto')} pad={os.environ.get('DGG_PP_PAD', 'default')}: "
+print(f"N={N} active={act} threads={os.environ.get('DGG_PP_THREADS', 'default')} width={os.environ.get('DGG_PP_WIDTH', 'auto')}: "
       f"{e0.elapsed_time(e1) / R * 1e3:.1f} us per build (incl. workspace + ahat allocation)")
