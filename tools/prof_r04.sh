@@ -40,3 +40,9 @@ import json
 j=json.load(open('gpurun_out/r04/r04_bench.json'))
 print(j['ms_per_step'], j['roofline']['frac'], {k:(v.get('ms_per_step'), v.get('pair_kernel_ms'), (v.get('roofline') or {}).get('frac')) for k,v in j['variants'].items()})
 PY
+# single-stream trace of the headline step (per-kernel durations that add up to the step: the default step runs two kernels beside their neighbours)
+cd /tmp
+DGG_OVERLAP=0 rocprofv3 --kernel-trace --stats -d /tmp/trace_ss -o h -- python3 "$R/bench.py" --steps 20 --warmup 5 --repeats 3 --cpu-rows -1 --no-variants > /dev/null 2>&1
+cd "$R"
+python3 tools/kernel_stats.py /tmp/trace_ss/h_results.db "$O/r04_kernel_stats_single_stream.csv" --skip-first 8 > /dev/null
+DGG_OVERLAP=0 python3 bench.py --steps 20 --warmup 5 --no-variants --cpu-rows -1 > "$O/r04_bench_single_stream.json" 2>> "$O/bench.err"
