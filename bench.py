@@ -190,9 +190,15 @@ def run_edgelist(a, dev):
 
     from dgg_amd import ops as _ops
 
+    fused = getattr(a, "edgelist_api", "fused") == "fused" and a.edge_mode == "u-v-dist"
+
     def step():
         for p_ in params:
             p_.grad = None
+        if fused:                                                 # generator + normalisation + GCNConv as one autograd node
+            out, adj = dgg.forward_conv(x, A, conv.W)
+            out.sum().backward()
+            return adj
         with _ops.step_zero_pool(dev, N, 64, 64, params):        # the step's zeroed accumulators from one filled buffer
             adj = dgg(x, A)
             out = conv(x, adj.normalize())
@@ -237,7 +243,9 @@ def run_edgelist(a, dev):
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"Pubmed-shape edge-list DGG N={N} d={d} h={h} E={E} (incl. self loops) k~{kmean:.1f}, "
                                   f"{a.edge_mode}/x/k_times_edge_prob, Gumbel(0,0.3) hash noise, module API under autograd "
-                                  "(DGG_LearnableK_debug + normalize + GCNConv), fwd+bwd",
+                                  + ("(DGG_LearnableK_debug.forward_conv: generator + normalize + GCNConv as one autograd node)" if fused
+                                     else "(DGG_LearnableK_debug + normalize + GCNConv)") + ", fwd+bwd",
+                      "api": "fused layer" if fused else "separate modules",
                       "nodes": N, "feat": d, "latent": h, "candidate_edges": E, "selected_edges": nsel,
                       "candidate_edges_per_s": E / T, "edge_mode": a.edge_mode, "hipgraph": graph is not None},
            "roofline": None}
@@ -250,11 +258,32 @@ def run_edgelist(a, dev):
             "spmm_fwd": nsel_i * 8 + 2 * N * 4.0 * 64, "conv_bwd": nsel_i * 16 + 3 * N * 4.0 * 64, "edge_bwd": nsel_i * 36 + 4 * N * 4.0 * h}
     ms = pk[dom][0]
     cb = comp.get(dom)
-    out["roofline"] = {"bound": "hbm", "kernel": dom, "calls_per_step": pk[dom][1], "kernel_ms": ms,
-                       "achieved": (cb / (ms * 1e-3) / 1e9) if cb else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                       "frac": (cb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if cb else None, "traffic": None, "algorithmic_bytes": cb,
-                       "note": "event-timed inside eager steps; bytes = every operand of the named kernel's calls touched once; the step is "
-                               "~80 launches of a few microseconds at this size (latency-, not bandwidth-bound)"}
+    if fused:
+        # the STEP against the HBM roofline: every operand of every stage touched once (projection and weight gradients read x once
+        # each; 64-wide ELL arrays idx / score / w / ahat / dA; one h- or F-wide gathered row per selected edge in the search, the
+        # aggregation and the three backward kernels; 16-byte partition records written once and read twice)
+        F = 64
+        step_bytes = (4.0 * (N * d + 3 * 64 * d + N * (2 * h + F)) * 2            # projection + weight gradients
+                      + 4.0 * N * h * 3 + 16.0 * N                                 # k-net forward + backward (xk twice, dxk)
+                      + 8.0 * N + 4.0 * E + 4.0 * E * h + 4.0 * N * h + 12.0 * N * 64 + 4.0 * N     # search + ramp
+                      + 12.0 * N * 64 + 4.0 * N * 64 + 16.0 * nsel_i                            # partition + normalisation
+                      + 8.0 * N * 64 + 4.0 * nsel_i * F + 4.0 * N * F                           # aggregation
+                      + 12.0 * N * F                                                          # ReLU backward
+                      + 16.0 * nsel_i + 4.0 * nsel_i * F + 8.0 * N * F + 8.0 * nsel_i           # aggregation backward (per destination)
+                      + 16.0 * N * 64 + 4.0 * N * h + 8.0 * N                                  # score backward, row side
+                      + 16.0 * nsel_i + 4.0 * nsel_i * h + 4.0 * N * h)                         # score backward, per destination
+        out["roofline"] = {"bound": "hbm", "kernel": "whole step (about 25 launches)", "calls_per_step": 1.0, "kernel_ms": T * 1e3,
+                           "achieved": step_bytes / T / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": step_bytes / T / 1e9 / HBM_PEAK_GBPS,
+                           "traffic": None, "algorithmic_bytes": step_bytes,
+                           "note": "bytes = every operand of every stage of the step touched once; at this size the step is bound by launch "
+                                   "and dependency latency (25 kernels of 5-70 us, the two MFMA products over the 500-wide input are 40 %), "
+                                   f"not by bandwidth; slowest probed call: {dom} {ms * 1e3:.0f} us"}
+    else:
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "calls_per_step": pk[dom][1], "kernel_ms": ms,
+                           "achieved": (cb / (ms * 1e-3) / 1e9) if cb else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": (cb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if cb else None, "traffic": None, "algorithmic_bytes": cb,
+                           "note": "event-timed inside eager steps; bytes = every operand of the named kernel's calls touched once; the step is "
+                                   "~80 launches of a few microseconds at this size (latency-, not bandwidth-bound)"}
     out["kernels_ms_per_step"] = {n: v[0] for n, v in pk.items()}
     if a.cpu_rows >= 0 and a.edge_mode == "u-v-dist":
         out["cpu_baseline"] = cpu_baseline_edgelist(N, d, h, rows, cols, x.cpu().numpy(), vals.numpy(), dgg, conv,
@@ -500,6 +529,8 @@ def main():
     ap.add_argument("--graphs", type=int, default=4, help="--workload ppi: number of graphs per step")
     ap.add_argument("--bf16", action="store_true", help="--workload ppi: GCNII layer GEMMs on bf16 operands (library GEMM, fp32 "
                                                         "accumulate); the DGG path stays fp32")
+    ap.add_argument("--edgelist-api", default="fused", choices=["fused", "modules"],
+                    help="--workload pubmed: the fused layer (DGG_LearnableK_debug.forward_conv, u-v-dist scorer) or the separate modules")
     ap.add_argument("--edge-mode", default="u-v-dist", choices=["u-v-dist", "u-v-deg", "u-v-A_uv", "u-v-deg-dist", "edge_conv", "A_uv"],
                     help="--workload pubmed: edge scorer (dgm.py:1607-1725)")
     ap.add_argument("--gpus", type=int, default=1)

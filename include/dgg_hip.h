@@ -203,6 +203,13 @@ int dgg_literal_hard_bwd(const int32_t *hsrc, const float *g, int64_t N, int K, 
 int dgg_edgelist_topk(const float *xp, int64_t N, int h, const int64_t *rowptr, const int32_t *col, float t,
                       int noise_mode, const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx,
                       float *val, void *stream);
+/* dgg_edgelist_topk + dgg_softk_fwd in ONE launch (same bits as the two calls; dgm.py:1404-1420 on the sorted list while it is
+ * still in registers): k [N] learned degrees, mode as dgg_softk_fwd -> additionally w [N,K], rs [N].  latent_dim 16 / 32 / 64 / 128.
+ * overflow (nullable, int32[1] on the device, ORed into, never cleared): becomes 1 when some row has more than K candidates AND a
+ * learned degree with k + 8.5 > K, i.e. when the K-wide list dropped a rank the reference still weights (dgm.py:1410-1420). */
+int dgg_edgelist_topk_softk(const float *xp, int64_t N, int h, const int64_t *rowptr, const int32_t *col, float t,
+                            int noise_mode, const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, const float *k,
+                            int mode, int32_t *idx, float *val, float *w, float *rs, int32_t *overflow, void *stream);
 
 /* ---- edge-MLP scorers on a candidate edge list (dgm.py:1628-1725: u-v-A_uv, u-v-deg, u-v-deg-dist, edge_conv, A_uv) --
  * The reference evaluates sigmoid(W2 act(W1 [x_u, x_v, extras] + b1) + b2) per edge (edge_encode, dgm.py:1101-1105;

@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void gemm_tn_multi(TnSegs segs, const float *B
 // by slot (every slot's next load is issued right after its MFMAs).  Partial results and reduce as gemm_tn_multi.
 template <int PF, bool ACT>
 __device__ __forceinline__ void tn_wide_stream(const float *__restrict__ A, const float *__restrict__ Yact, int act, const float *__restrict__ B,
-                                               int64_t N, int M1, int acol, int li, int hh, int64_t base, int64_t stride,
+                                               int64_t N, int M1, int acol, int ldb, int bcol, int hh, int64_t base, int64_t stride,
                                                f32x16 (&acc)[2][4], float (&csum)[2]) {
     float2 av[PF], yv[PF];
     float4 bv[PF];
@@ -637,7 +637,7 @@ __device__ __forceinline__ void tn_wide_stream(const float *__restrict__ A, cons
 #else
         av[u] = *reinterpret_cast<const float2 *>(A + nc * M1 + acol);
         if (ACT) yv[u] = *reinterpret_cast<const float2 *>(Yact + nc * M1 + acol);
-        bv[u] = *reinterpret_cast<const float4 *>(B + nc * 128 + 4 * li);
+        bv[u] = *reinterpret_cast<const float4 *>(B + nc * ldb + bcol);
 #endif
     };
 #pragma unroll
@@ -674,15 +674,20 @@ __device__ __forceinline__ void tn_wide_stream(const float *__restrict__ A, cons
     }
 }
 
+// B wider than 128 columns (M2 a multiple of 4; Pubmed's 500 input features): the workgroups of a row stream additionally enumerate
+// the 128-column tiles of B (`ntile`); a lane whose four columns lie beyond M2 reads the last valid group instead and its output
+// columns are dropped by the reduce (they sit in the padding of the M2p-wide slab, or beyond it and are not stored).
 template <int PF>
-__global__ __launch_bounds__(256, 2) void gemm_tn_wide(TnSegs segs, const float *__restrict__ B, int64_t N, int G,
+__global__ __launch_bounds__(256, 2) void gemm_tn_wide(TnSegs segs, const float *__restrict__ B, int64_t N, int G, int M2, int M2p, int ntile,
                                                        float *__restrict__ slab, float *__restrict__ cs_slab) {
     extern __shared__ float red[];                               // [8*16*64] + [2*64]
     const int lane = threadIdx.x & 63, wave = dgg::wave_id(), li = lane & 31, hh = lane >> 5;
-    const int npair = segs.nyb / 2;
-    const int bid = blockIdx.x, tt = bid / (8 * npair), rem = bid % (8 * npair);
-    const int yb = 2 * (rem / 8), g = tt * 8 + (rem % 8);         // the pair blocks of one row stream stay on one XCD (see gemm_tn_multi)
+    const int npair = segs.nyb / 2, nblk = npair * ntile;
+    const int bid = blockIdx.x, tt = bid / (8 * nblk), rem = bid % (8 * nblk);
+    const int yb = 2 * ((rem / 8) % npair), tile = (rem / 8) / npair;
+    const int g = tt * 8 + (rem % 8);                             // the blocks of one row stream stay on one XCD (see gemm_tn_multi)
     if (g >= G) return;
+    const int col0 = tile * 128 + 4 * li, bcol = col0 + 4 <= M2 ? col0 : M2 - 4;
     const float *__restrict__ A = segs.A[yb];
     const float *__restrict__ Yact = segs.Y[yb];
     const int M1 = segs.ld[yb], act = Yact ? segs.act[yb] : 0, acol = segs.o0[yb] + 2 * li;
@@ -695,8 +700,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_wide(TnSegs segs, const float 
             for (int r = 0; r < 16; r++) acc[m][a][r] = 0.0f;
     float csum[2] = {0.0f, 0.0f};
     const int64_t base = ((int64_t)g * 4 + wave) * 2 * PF, stride = (int64_t)G * 4 * 2 * PF;
-    if (act != 0) tn_wide_stream<PF, true>(A, Yact, act, B, N, M1, acol, li, hh, base, stride, acc, csum);
-    else tn_wide_stream<PF, false>(A, Yact, act, B, N, M1, acol, li, hh, base, stride, acc, csum);
+    if (act != 0) tn_wide_stream<PF, true>(A, Yact, act, B, N, M1, acol, M2, bcol, hh, base, stride, acc, csum);
+    else tn_wide_stream<PF, false>(A, Yact, act, B, N, M1, acol, M2, bcol, hh, base, stride, acc, csum);
     float *cred = red + 8 * 16 * 64;
     for (int w = 1; w < 4; w++) {
         if (wave == w) {
@@ -720,14 +725,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_wide(TnSegs segs, const float 
     }
     if (wave != 0) return;
     const int M1tp = segs.nyb * 32;
-    float *sl = slab + ((int64_t)g * M1tp + yb * 32) * 128 + 4 * li;
+    float *sl = slab + ((int64_t)g * M1tp + yb * 32) * M2p + col0;
+    if (col0 < M2p) {
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+        for (int m = 0; m < 2; m++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int go = (r & 3) + 8 * (r >> 2) + 4 * hh;      // accumulator row -> column 2*go + m of this A pair block
-            *reinterpret_cast<float4 *>(sl + (int64_t)(2 * go + m) * 128) = make_float4(acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]);
-        }
+            for (int r = 0; r < 16; r++) {
+                const int go = (r & 3) + 8 * (r >> 2) + 4 * hh;  // accumulator row -> column 2*go + m of this A pair block
+                *reinterpret_cast<float4 *>(sl + (int64_t)(2 * go + m) * M2p) = make_float4(acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]);
+            }
+    }
+    if (tile != 0) return;                                       // (every tile of B sees the same A: the column sums are written once)
 #pragma unroll
     for (int m = 0; m < 2; m++) {
         const float t = csum[m] + __uint_as_float(dgg::xor_shfl<32>(__float_as_uint(csum[m]), lane));
@@ -830,7 +838,7 @@ int launch_linear_fwd(const float *x, int64_t N, int d, const float *W, const fl
 template <int NACC>
 void launch_linear_fwd_multi_n(const float *x, int64_t N, int d, const float *W, const float *b, int out, const LinSegs &segs, hipStream_t st) {
     // 128 rows per workgroup.  (64-row workgroups for inputs that give fewer 128-row tiles than CUs -- Pubmed: 155 -- measured slower
-    // for the fused projections as well: 0.770 against 0.697 ms per Pubmed step.)
+    // for the fused projections as well: 0.770 against 0.697 ms per Pubmed step; narrower COLUMN tiles are what helps there.)
     hipLaunchKernelGGL((linear_fwd_mfma<NACC, 4, true>), dim3((unsigned)((N + 127) / 128), (unsigned)(out / (32 * NACC))), dim3(256), 0, st, x, N,
                        d, W, b, out, 0, 0, nullptr, segs);
 }
@@ -981,6 +989,23 @@ int dgg_linear_fwd_multi(const float *x, int64_t N, int d, const float *Wcat, co
         }
         return dgg_check_launch("linear_fwd_multi");
     }
+    // Inputs with fewer 128-row tiles than CUs (Pubmed: 155): all columns in one workgroup would leave a third of the chip idle and
+    // every wavefront alone on its SIMD with nothing to cover its LDS staging -- the columns are split into tiles of 64 (32 for an
+    // odd number of blocks) instead, x is then re-read from L2 by the other column tiles (measured at N = 19 717, d = 500, 192
+    // outputs: 92 -> 73 us; tiles of 32: 83, of 96: 92).  DGG_LIN_NACC=<blocks per tile> forces a shape (measurement).
+    static const int nacc_env = [] { const char *e = getenv("DGG_LIN_NACC"); return e ? atoi(e) : 0; }();
+    int nacc_small = 0;
+    if ((N + 127) / 128 < 256 && cb > 2) nacc_small = cb % 2 == 0 ? 2 : 1;
+    if (nacc_env > 0 && cb % nacc_env == 0) nacc_small = nacc_env;
+    if (nacc_small > 0) {
+        switch (nacc_small) {
+            case 1: launch_linear_fwd_multi_n<1>(x, N, d, Wcat, bcat, out, segs, st); break;
+            case 2: launch_linear_fwd_multi_n<2>(x, N, d, Wcat, bcat, out, segs, st); break;
+            case 3: launch_linear_fwd_multi_n<3>(x, N, d, Wcat, bcat, out, segs, st); break;
+            default: launch_linear_fwd_multi_n<4>(x, N, d, Wcat, bcat, out, segs, st); break;
+        }
+        return dgg_check_launch("linear_fwd_multi");
+    }
     // one workgroup computes ALL columns of its 128 rows whenever the accumulators fit (<= 6 blocks): X is then read once
     switch (cb) {
         case 1: launch_linear_fwd_multi_n<1>(x, N, d, Wcat, bcat, out, segs, st); break;
@@ -1042,7 +1067,7 @@ size_t dgg_gemm_tn_multi_ws_floats(int64_t N, int M1_total, int M2) {
 }
 int dgg_gemm_tn_multi(int nseg, const float *const *A, const int *M1, const float *const *Y, const int *act, const float *B, int64_t N,
                       int M2, float *const *C, const int *c_layout, float *const *colsum, float *ws, void *stream) {
-    if (nseg < 1 || nseg > 8 || M2 < 1 || M2 > 128) return dgg_set_error(DGG_ERR_UNSUPPORTED, "gemm_tn_multi: 1..8 operands, M2 <= 128");
+    if (nseg < 1 || nseg > 8 || M2 < 1) return dgg_set_error(DGG_ERR_UNSUPPORTED, "gemm_tn_multi: 1..8 operands");
     if (!ws) return dgg_set_error(DGG_ERR_ARG, "gemm_tn_multi: workspace is NULL (dgg_gemm_tn_multi_ws_floats)");
     TnSegs segs{};
     int yb = 0;
@@ -1066,15 +1091,21 @@ int dgg_gemm_tn_multi(int nseg, const float *const *A, const int *M1, const floa
     const int64_t need = (N + 4 * 2 * PF - 1) / (4 * 2 * PF);
     while (G > 8 && G / 2 >= need) G /= 2;
     // the hot-path shape (128-wide input, operands in multiples of 64 columns, 16-byte aligned rows): wide tiles
-    bool wide = M2 == 128 && N >= 4096 && reinterpret_cast<uintptr_t>(B) % 16 == 0;
+    // (and inputs WIDER than 128 columns -- a multiple of 4 -- as several 128-column tiles of the same kernel: the only form for them)
+    bool wide = (M2 == 128 || (M2 > 128 && M2 % 4 == 0)) && (N >= 4096 || M2 > 128) && reinterpret_cast<uintptr_t>(B) % 16 == 0;
     for (int sgi = 0; sgi < nseg; sgi++)
         wide = wide && M1[sgi] % 64 == 0 && reinterpret_cast<uintptr_t>(A[sgi]) % 8 == 0 && (!Y || !Y[sgi] || reinterpret_cast<uintptr_t>(Y[sgi]) % 8 == 0);
     static const int force_wide = [] { const char *e = getenv("DGG_TN_WIDE"); return e ? atoi(e) : -1; }();
-    if (force_wide == 0) wide = false;
+    if (force_wide == 0 && M2 <= 128) wide = false;
+    if (M2 > 128 && !wide)
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "gemm_tn_multi: an input wider than 128 columns needs M2 % 4 == 0, operand widths in "
+                                                  "multiples of 64 and 16-byte aligned rows");
+    const int ntile = (M2 + 127) / 128;
     if (wide) {
         constexpr int PFW = 6;
-        const int npair = yb / 2;
-        G = 512 / npair / 8 * 8;                                 // ~512 workgroups: two per CU (<= 256 registers); measured: 256 / 384 /
+        const int npair = yb / 2 * ntile;
+        G = 512 / npair / 8 * 8;
+        G = G < 8 ? 8 : G;                                 // ~512 workgroups: two per CU (<= 256 registers); measured: 256 / 384 /
                                                                  //  768 workgroups and prefetch depths 4..10 are equal or slower
         G = G > 256 ? 256 : G;
         const int64_t needw = (N + 4 * 2 * PFW - 1) / (4 * 2 * PFW);
@@ -1085,8 +1116,8 @@ int dgg_gemm_tn_multi(int nseg, const float *const *A, const int *M1, const floa
     const int nb = M2p / 32 == 3 ? 4 : M2p / 32;
     const size_t lds = (size_t)(nb * 16 * 64 + 64) * sizeof(float);
     const size_t ldsw = (size_t)(8 * 16 * 64 + 128) * sizeof(float);
-    const dim3 gridw((unsigned)(G * (yb / 2)));
-    if (wide) hipLaunchKernelGGL((gemm_tn_wide<6>), gridw, dim3(256), ldsw, st, segs, B, N, G, slab, cs_slab);
+    const dim3 gridw((unsigned)(G * (yb / 2) * ntile));
+    if (wide) hipLaunchKernelGGL((gemm_tn_wide<6>), gridw, dim3(256), ldsw, st, segs, B, N, G, M2, M2p, ntile, slab, cs_slab);
     else if (nb == 4) hipLaunchKernelGGL((gemm_tn_multi<4, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);
     else if (nb == 2) hipLaunchKernelGGL((gemm_tn_multi<2, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);
     else hipLaunchKernelGGL((gemm_tn_multi<1, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);

@@ -139,6 +139,84 @@ __global__ __launch_bounds__(256) void edgelist_topk_kernel(
     }
 }
 
+// the same rows for the latent widths the generator is built with (16 / 32 / 64 / 128): a lane fetches ITS candidate's row as H/4
+// sixteen-byte loads that are all in flight before the first subtraction (the loop above issues h dependent four-byte gathers: on
+// a citation graph -- Pubmed: 5.5 candidates a row -- its time is h load latencies, not bandwidth); the chain over the features is
+// the same ascending fmaf chain, so the bits do not change.  With `kk` the ramp of select_top_k (dgm.py:1410-1420, softk_fwd_kernel's
+// arithmetic) is applied while the sorted list is still in registers: w and the row sums come out of the same launch.
+template <int H>
+__global__ __launch_bounds__(256) void edgelist_topk_vec(
+    const float *__restrict__ xp, int64_t N, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, float t,
+    int noise_mode, const float *__restrict__ G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *__restrict__ idx,
+    float *__restrict__ val, const float *__restrict__ kk, int mode, float *__restrict__ w, float *__restrict__ rs,
+    int32_t *__restrict__ overflow) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + dgg::wave_id();
+    if (i >= N) return;
+    const bool perturb = noise_mode != 0, sym = noise_mode == 3;
+    const float4 *xi4 = reinterpret_cast<const float4 *>(xp + i * H);
+    uint64_t list = DGG_EMPTY_KEY;
+    const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
+    for (int64_t eb = e0; eb < e1; eb += 64) {
+        const int64_t e = eb + lane;
+        uint64_t key = DGG_EMPTY_KEY;
+        if (e < e1) {
+            const int32_t j = col[e];
+            const float4 *xj4 = reinterpret_cast<const float4 *>(xp + (int64_t)j * H);
+            float d2 = 0.0f;
+            constexpr int CH = H / 4 < 16 ? H / 4 : 16;      // float4s in flight per lane
+#pragma unroll
+            for (int c0 = 0; c0 < H / 4; c0 += CH) {
+                float4 v[CH];
+#pragma unroll
+                for (int u = 0; u < CH; u++) v[u] = xj4[c0 + u];
+#pragma unroll
+                for (int u = 0; u < CH; u++) {
+                    const float4 a = xi4[c0 + u];
+                    float df = __fadd_rn(a.x, -v[u].x);
+                    d2 = __fmaf_rn(df, df, d2);
+                    df = __fadd_rn(a.y, -v[u].y);
+                    d2 = __fmaf_rn(df, df, d2);
+                    df = __fadd_rn(a.z, -v[u].z);
+                    d2 = __fmaf_rn(df, df, d2);
+                    df = __fadd_rn(a.w, -v[u].w);
+                    d2 = __fmaf_rn(df, df, d2);
+                }
+            }
+            const float dist = c_sqrt(d2);
+            float g = 0.0f;
+            if (noise_mode == 1) g = G[i * ldG + j];
+            else if (noise_mode >= 2) g = pair_noise(s0, s1, (uint32_t)i, (uint32_t)j, sym);
+            key = make_key(score_from_dist(dist, t, perturb, g), j);
+        }
+        key = wave_sort_desc(key, lane);
+        list = wave_merge_top64(list, key, lane);
+    }
+    const bool empty = list == DGG_EMPTY_KEY;
+    const float sc = empty ? 0.0f : key_val(list);
+    if (lane < K) {
+        idx[i * K + lane] = empty ? -1 : key_col(list);
+        val[i * K + lane] = sc;
+    }
+    if (kk) {
+        float wv = 0.0f;
+        if (lane < K) {
+            const float f = c_ramp((float)lane, kk[i]);
+            float v = f;
+            if (mode == 0 || mode == 3) {
+                const float a = __fmul_rn(sc, f);
+                v = mode == 0 ? a : __fadd_rn(__fadd_rn(f, -a), a);
+            }
+            wv = empty ? 0.0f : v;
+            w[i * K + lane] = wv;
+        }
+        const float s = wave_sum_butterfly(wv);
+        if (lane == 0) rs[i] = s;
+        // the ELL keeps K candidates of a row: exact while the ramp's support k + 8.5 fits or the row has no more candidates than that
+        if (overflow && lane == 0 && e1 - e0 > K && kk[i] + 8.5f > (float)K) atomicOr(overflow, 1);
+    }
+}
+
 // same for latent widths beyond 128 (PPI: 2048): the candidates of a row are scored ONE AT A TIME by the whole wavefront --
 // lanes over the features, coalesced 256-byte segments, 64 interleaved fmaf chains + xor butterfly (the canonical order for
 // wide latents, oracle pair_dist) -- and the score of candidate q of a batch is kept by lane q for the sort / merge
@@ -272,6 +350,24 @@ int dgg_allpairs_topk_exhaustive_impl(const float *xp, int64_t N, int h, int64_t
     }
 }
 
+namespace {
+inline bool edgelist_vec_ok(const float *xp, int h) {
+    return (h == 16 || h == 32 || h == 64 || h == 128) && (uintptr_t)xp % 16 == 0;
+}
+void launch_edgelist_vec(const float *xp, int64_t N, int h, const int64_t *rowptr, const int32_t *col, float t, int noise_mode,
+                         const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, const float *k,
+                         int mode, float *w, float *rs, int32_t *overflow, hipStream_t st) {
+    const dim3 grid((unsigned)((N + 3) / 4)), block(256);
+#define DGG_EL_VEC(HH) hipLaunchKernelGGL(edgelist_topk_vec<HH>, grid, block, 0, st, xp, N, rowptr, col, t, noise_mode, G, ldG, s0, s1, K, \
+                                          idx, val, k, mode, w, rs, overflow)
+    if (h == 16) DGG_EL_VEC(16);
+    else if (h == 32) DGG_EL_VEC(32);
+    else if (h == 64) DGG_EL_VEC(64);
+    else DGG_EL_VEC(128);
+#undef DGG_EL_VEC
+}
+}  // namespace
+
 extern "C" {
 
 int dgg_edgelist_topk(const float *xp, int64_t N, int h, const int64_t *rowptr, const int32_t *col, float t,
@@ -285,10 +381,31 @@ int dgg_edgelist_topk(const float *xp, int64_t N, int h, const int64_t *rowptr, 
     if (h > 128)
         hipLaunchKernelGGL(edgelist_topk_wide_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, xp, N, h,
                            rowptr, col, t, noise_mode, G, ldG, s0, s1, K, idx, val);
+    else if (edgelist_vec_ok(xp, h))
+        launch_edgelist_vec(xp, N, h, rowptr, col, t, noise_mode, G, ldG, s0, s1, K, idx, val, nullptr, 0, nullptr, nullptr, nullptr,
+                            (hipStream_t)stream);
     else
         hipLaunchKernelGGL(edgelist_topk_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, xp, N, h,
                            rowptr, col, t, noise_mode, G, ldG, s0, s1, K, idx, val);
     return dgg_check_launch("edgelist_topk");
+}
+
+// dgg_edgelist_topk followed by dgg_softk_fwd in one launch (same bits as the two calls): latent widths 16 / 32 / 64 / 128 only.
+// overflow (nullable, int32[1], ORed into): set when a row has more than K candidates AND a learned degree with k + 8.5 > K
+int dgg_edgelist_topk_softk(const float *xp, int64_t N, int h, const int64_t *rowptr, const int32_t *col, float t,
+                            int noise_mode, const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, const float *k,
+                            int mode, int32_t *idx, float *val, float *w, float *rs, int32_t *overflow, void *stream) {
+    if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    if (noise_mode == 1 && !G) return dgg_set_error(DGG_ERR_ARG, "explicit noise requested but G is NULL");
+    if (noise_mode < 0 || noise_mode > 3)
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "edgelist_topk: noise_mode must be none / explicit / hash / symmetric hash");
+    if (mode != 0 && mode != 1 && mode != 3) return dgg_set_error(DGG_ERR_ARG, "edgelist_topk_softk: mode must be 0 (k_times), 1 (k_only) or 3 (hard)");
+    if (!k || !w || !rs) return dgg_set_error(DGG_ERR_ARG, "edgelist_topk_softk: k, w and rs are required");
+    if (!edgelist_vec_ok(xp, h))
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "edgelist_topk_softk: latent_dim must be 16, 32, 64 or 128 (16-byte aligned rows)");
+    if (N == 0) return 0;
+    launch_edgelist_vec(xp, N, h, rowptr, col, t, noise_mode, G, ldG, s0, s1, K, idx, val, k, mode, w, rs, overflow, (hipStream_t)stream);
+    return dgg_check_launch("edgelist_topk_softk");
 }
 
 int dgg_select_scores(const float *scores, int64_t R, int64_t N, int K, int32_t *idx, float *val, void *stream) {

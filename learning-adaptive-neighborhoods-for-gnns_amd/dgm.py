@@ -275,6 +275,32 @@ class _DGGScoresFn(torch.autograd.Function):
                 g(wex, 2 * hw, 3 * hw), dpar[3 * hw:4 * hw], dpar[4 * hw:5 * hw], dpar[5 * hw:5 * hw + 1], None)
 
 
+class _FusedDGGConvFn(torch.autograd.Function):
+    """generator -> normalize_adj -> relu(A (x Wc)) as ONE autograd node on the hand-scheduled step of dgg_amd.parallel.ShardedDGGConv
+    (reference dgm.py:1178-1292, model.py:1205-1219, 580-599): x is read ONCE for the three projections [xp | xk | x Wc] and once for
+    their weight gradients, the ramp is applied inside the search, normalisation is folded into the partition of the active entries,
+    and none of the intermediate adjacency tensors is an autograd edge (no per-edge tensors are allocated, filled or concatenated
+    by torch between the kernels).  Same kernels and bits as the separate modules wherever those run the same kernels."""
+
+    @staticmethod
+    def forward(ctx, x, deg, layer, *params):
+        P = dict(zip(layer.PARAM_KEYS, params))
+        Z = layer.forward(x, deg, P)
+        ctx.layer, ctx.state = layer, layer.saved
+        ctx.save_for_backward(x, *params)
+        return Z
+
+    @staticmethod
+    def backward(ctx, dZ):
+        x, *params = ctx.saved_tensors
+        layer = ctx.layer
+        P = dict(zip(layer.PARAM_KEYS, params))
+        layer.saved, layer._fwd_gen = ctx.state, ctx.state["gen"]       # (another forward of the same module may have run since)
+        layer.x_grad = bool(ctx.needs_input_grad[0])
+        g = layer.backward(dZ.contiguous(), x, P)
+        return (g.get("x"), None, None) + tuple(g[k_].reshape(P[k_].shape) for k_ in layer.PARAM_KEYS)
+
+
 class DGG_LearnableK_debug(nn.Module):
     """Drop-in for reference dgm.py:1077-1727 (modes u-v-dist / x / {k_times_edge_prob, k_only}, soft output)."""
 
@@ -354,6 +380,10 @@ class DGG_LearnableK_debug(nn.Module):
                                "the module switch by itself) is cheaper on such data"))
                 if auto and many:
                     self._sym_generator = "hash"
+        flag = self.__dict__.get("_overflow_dev")
+        if flag is not None and not torch.cuda.is_current_stream_capturing() and bool(flag.item()):
+            flag.zero_()
+            self._overflow = torch.ones((), dtype=torch.bool, device=flag.device)
         if self._overflow is not None and bool(self._overflow):
             self._overflow = None
             raise RuntimeError(
@@ -409,6 +439,64 @@ class DGG_LearnableK_debug(nn.Module):
             st.update(slow=slow, probe=dict(pr, ranked_us_estimate=est))
         st["n"] += 1
         return ops.NOISE_RANKED
+
+    def forward_conv(self, x, in_adj, conv_weight):
+        """`GCNConv(x, normalize_adj(self(x, in_adj)))` with conv_weight = GCNConv.W [in, out] as one fused autograd node
+        (_FusedDGGConvFn) -> (Z, unnormalised EllAdjacency, DETACHED: its values carry no autograd edge -- the loss of the
+        reference's training scripts reads the class scores only, train_small_graphs.py:226-230), or None when this configuration
+        is outside the fused step (the caller then runs the modules one after the other): scorer u-v-dist, k-net "x", soft
+        k_times_edge_prob / k_only output, widths the partitioned backward covers, rows that fit the ELL width."""
+        from .parallel import ShardedDGGConv
+        a = self.args
+        h = self.latent_dim
+        fin, fout = conv_weight.shape
+        if (self.edge_prob_net_mode != "u-v-dist" or self.k_net_mode != "x" or self.k_select_mode not in ("k_times_edge_prob", "k_only")
+                or self.hard or a.debug_step in (0, 1) or (getattr(a, "stochastic_k", False) and self.training)
+                or self._explicit_noise is not None or not getattr(a, "dgg_fused_layer", True) or not x.is_cuda
+                or h not in (16, 32, 64, 128) or fout not in (16, 32, 64, 128) or fout > fin or self.ell_width != 64
+                or h not in ops.KNET_MFMA_WIDTHS or x.dtype != torch.float32):
+            return None
+        if isinstance(in_adj, AllPairs):
+            cand, deg, rowptr = None, in_adj.prior_degree, None
+        else:
+            if isinstance(in_adj, EllAdjacency):
+                in_adj = in_adj.to_sparse().detach()
+            rowptr, col, deg = csr_candidates(in_adj)
+            cand = (rowptr, col)
+        noise_mode, _, seed = self._noise_cfg()
+        if cand is None and noise_mode == ops.NOISE_RANKED:
+            noise_mode = self._asym_generator_now(x, seed)
+        elif cand is None and noise_mode == ops.NOISE_RANKED_SYM:
+            return None                                       # (its workspace status is reported through the module path)
+        elif cand is not None:
+            noise_mode = {ops.NOISE_RANKED: ops.NOISE_HASH, ops.NOISE_RANKED_SYM: ops.NOISE_HASH_SYM}.get(noise_mode, noise_mode)
+        mode = ops.MODE_K_TIMES_EDGE_PROB if self.k_select_mode == "k_times_edge_prob" else ops.MODE_K_ONLY
+        N = x.shape[0]
+        layer = self.__dict__.get("_fused_layer")
+        if layer is None or layer.N != N:
+            layer = self.__dict__["_fused_layer"] = ShardedDGGConv(ops, N, K=64, t=ops.T_DIST)
+        layer.cand, layer.noise_mode, layer.seed, layer.mode = cand, noise_mode, seed, mode
+        layer.x_grad = bool(x.requires_grad)
+        if cand is not None:                                  # the ELL-width bound is tested inside the search kernel (no extra launches)
+            flag = self.__dict__.get("_overflow_dev")
+            if flag is None or flag.device != x.device:
+                flag = self.__dict__["_overflow_dev"] = torch.zeros((1,), device=x.device, dtype=torch.int32)
+            layer.overflow = flag
+        kn = self.k_net
+        Z = _FusedDGGConvFn.apply(x, deg, layer, self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias,
+                                  self.node_encode_for_k[0].weight, self.node_encode_for_k[0].bias, self.k_embed[0].weight,
+                                  self.k_embed[0].bias, kn.k_mu.weight, kn.k_mu.bias, kn.k_project.weight, kn.k_project.bias, conv_weight)
+        st = layer.saved
+        k = st["k"]
+        if cand is not None and self._wide_rows(in_adj, rowptr, k):
+            # rows wider than the ELL with learned degrees beyond it: the CSR form from here on (this discarded forward raised the flag)
+            layer.overflow.zero_()
+            return None
+        if cand is None:
+            self._track_overflow(k, None)
+        elif __import__("os").environ.get("DGG_STRICT_BOUND") == "1":
+            self.check_ell_bound()
+        return Z, EllAdjacency(st["idx"], st["w"], N, rs=st["rs"], k=k, score=st["val"], owner=self)
 
     def _track_overflow(self, k, ncand):
         over = k.detach() + 8.5 > float(self.ell_width)

@@ -196,7 +196,9 @@ def linear_bwd_multi(x, layers):
             grp.append(lay_)
             tot += o
         return res + linear_bwd_multi(x, grp)
-    if len(layers) > 8 or any(o % 32 for o in outs) or sum(outs) > 256 or d > 128:
+    # inputs wider than 128 columns (Pubmed: 500): the 128-column tiles of the wide kernel -- widths in multiples of 64, d % 4 == 0
+    wide_in = d > 128 and d % 4 == 0 and not any(o % 64 for o in outs) and x.data_ptr() % 16 == 0
+    if len(layers) > 8 or any(o % 32 for o in outs) or sum(outs) > 256 or (d > 128 and not wide_in):
         res = []
         for W, y, dy, act, lay, need_db in layers:
             _, dW, db = linear_bwd(x, W, y, dy, act, lay, need_dx=False, need_db=need_db)
@@ -409,6 +411,30 @@ def edgelist_topk(xp, rowptr, col, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE,
     _lib.check(_lib.lib().dgg_edgelist_topk(_ptr(xp), N, h, _ptr(rowptr), _ptr(col), t, noise_mode, _ptr(G), ldG, seed[0],
                                             seed[1], K, _ptr(idx), _ptr(val), _stream()), "edgelist_topk")
     return idx, val
+
+
+def edgelist_topk_softk(xp, rowptr, col, k, mode=MODE_K_TIMES_EDGE_PROB, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed=(0, 0),
+                        overflow=None):
+    """edgelist_topk + softk_fwd in one launch (same bits): -> idx, val, w, rs; None when the latent width is not 16 / 32 / 64 / 128.
+    overflow (int32[1] device tensor, optional): ORed with 1 when a row with more than K candidates has k + 8.5 > K."""
+    xp = _chk(xp)
+    N, h = xp.shape
+    if h not in (16, 32, 64, 128):
+        return None
+    rowptr, col, k = _chk(rowptr, torch.int64), _chk(col, torch.int32), _chk(k)
+    idx = torch.empty((N, K), device=xp.device, dtype=torch.int32)
+    val = torch.empty((N, K), device=xp.device, dtype=torch.float32)
+    w = torch.empty((N, K), device=xp.device, dtype=torch.float32)
+    rs = torch.empty((N,), device=xp.device, dtype=torch.float32)
+    ldG = 0
+    if G is not None:
+        G = _chk(G)
+        ldG = N
+    pe = _probe_begin()
+    _lib.check(_lib.lib().dgg_edgelist_topk_softk(_ptr(xp), N, h, _ptr(rowptr), _ptr(col), t, noise_mode, _ptr(G), ldG, seed[0], seed[1],
+                                                  K, _ptr(k), mode, _ptr(idx), _ptr(val), _ptr(w), _ptr(rs), _ptr(overflow), _stream()), "edgelist_topk_softk")
+    _probe_end("edgelist_topk", pe)
+    return idx, val, w, rs
 
 
 def literal_hard_fwd(xp, cand, idx, w, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed=(0, 0), threshold=0.5):

@@ -100,8 +100,13 @@ class ShardedDGGConv:
     PARAM_KEYS = ("We", "be", "Wk", "bk", "W1", "b1", "Wmu", "bmu", "Wp", "bp", "Wc")
 
     def __init__(self, kern, N, group=None, K=64, t=-0.05, noise_mode=2, seed=(1234, 0), mode=0, algo=0, x_grad=False, x_full=None,
-                 hybrid=False):
+                 hybrid=False, cand=None):
         self.kern, self.N, self.group = kern, N, group
+        # cand = (rowptr int64 [N+1], col int32 [E]): the candidates of row i are the stored entries of in_adj (edge-list mode, the
+        # live class's semantics dgm.py:1613-1614) instead of all N columns; every candidate is scored (per-pair hash noise), the rest
+        # of the step is the same.  One rank only: a citation graph's step is launch-bound, not something to shard.
+        self.cand = cand
+        assert cand is None or noise_mode in (0, 2, 3), "edge-list candidates: noise_mode none / hash / symmetric hash"
         assert x_full is None or not x_grad, "replicated features are data: they cannot take a gradient"
         assert not hybrid or x_full is not None, "the hybrid scheme replicates the features for the scoring side"
         self.x_full = x_full                                 # [N,d] static node features present on every rank, or None
@@ -118,6 +123,7 @@ class ShardedDGGConv:
         self.coll = self.world > 1 or (dist.is_initialized() and os.environ.get("DGG_FORCE_COLLECTIVES") == "1")
         self.emulate = None
         self.r0, self.r1, self.per = shard_bounds(N, self.world, self.rank)
+        assert cand is None or self.world == 1, "edge-list candidates run on one rank"
         self.bufs = {}                                       # collective staging buffers, kept between steps
 
     def check_generator(self):
@@ -202,7 +208,17 @@ class ShardedDGGConv:
             s["k"], s["z"], s["u"], s["feat"] = kern.knet_x_fwd(xk, deg_local, mu_sd, P["W1"], P["b1"], P["Wmu"], P["bmu"],
                                                               P["Wp"].reshape(-1), P["bp"])
         s["xp"] = xp = g_xp.get() if (self.coll and not repl) else xp
-        if self.noise_mode == 4 and self.K == 64 and hasattr(kern, "allpairs_topk_softk") and xp.shape[1] in (8, 16, 32, 64, 128):
+        if self.cand is not None:
+            rowptr, col = self.cand
+            # (self.overflow: optional int32[1] device flag the caller owns -- set when the K-wide list drops a weighted rank)
+            got = kern.edgelist_topk_softk(xp, rowptr, col, s["k"], self.mode, self.K, self.t, self.noise_mode, None, self.seed,
+                                           overflow=getattr(self, "overflow", None)) if hasattr(kern, "edgelist_topk_softk") else None
+            if got is not None:                     # search + ramp in one launch
+                s["idx"], s["val"], s["w"], rs_local = got
+            else:
+                s["idx"], s["val"] = kern.edgelist_topk(xp, rowptr, col, self.K, self.t, self.noise_mode, None, self.seed)
+                s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
+        elif self.noise_mode == 4 and self.K == 64 and hasattr(kern, "allpairs_topk_softk") and xp.shape[1] in (8, 16, 32, 64, 128):
             # ranked noise: the ramp is applied inside the search kernel, while the settled list is still in registers
             s["idx"], s["val"], s["w"], rs_local = kern.allpairs_topk_softk(xp, s["k"], self.mode, self.t, self.seed, rows=(self.r0, self.r1))
         else:

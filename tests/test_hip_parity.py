@@ -280,10 +280,12 @@ def test_select_scores_bit_exact_on_reference_scores(dev):
     assert np.array_equal(Nn(idx), ridx) and np.array_equal(Nn(val), rval)
 
 
-def test_edgelist_topk_bit_exact(dev):
+@pytest.mark.parametrize("h", [64, 16, 32, 128, 24])
+def test_edgelist_topk_bit_exact(dev, h):
+    """(24: the scalar-gather kernel; the others: the vector-load kernel, alone and with the ramp fused -- dgg_edgelist_topk_softk)"""
     from dgg_amd import ops
     rng = np.random.default_rng(6)
-    N, h = 500, 64
+    N = 500
     xp = rng.standard_normal((N, h)).astype(np.float32)
     deg = rng.integers(0, 200, N)          # includes empty rows and rows longer than the ELL width
     rows = np.repeat(np.arange(N), deg)
@@ -293,6 +295,14 @@ def test_edgelist_topk_bit_exact(dev):
         idx, val = ops.edgelist_topk(T(xp, dev), T(rowptr, dev), T(col, dev), K, noise_mode=mode, seed=(9, 1))
         ridx, rval = O.edgelist_topk(xp, rowptr, col, K=K, noise_mode=mode, seed=(9, 1))
         assert np.array_equal(Nn(idx), ridx) and np.array_equal(Nn(val), rval)
+        kk = (3 + 60 * rng.random(N)).astype(np.float32)
+        got = ops.edgelist_topk_softk(T(xp, dev), T(rowptr, dev), T(col, dev), T(kk, dev), 0, K, noise_mode=mode, seed=(9, 1))
+        if h == 24:
+            assert got is None
+            continue
+        w2, rs2 = ops.softk_fwd(idx, val, T(kk, dev), 0)
+        assert np.array_equal(Nn(got[0]), ridx) and np.array_equal(Nn(got[1]), rval)
+        assert torch.equal(got[2], w2) and torch.equal(got[3], rs2), "fused ramp differs from dgg_softk_fwd"
 
 
 def test_softk_normalize_spmm_bit_exact(dev):
@@ -846,6 +856,41 @@ def test_sharded_layer_step_matches_cpu_restatement(dev, N, d, h, noise):
         r_ = gr[k_].numpy()
         err = np.abs(Nn(g[k_]).reshape(r_.shape) - r_).max() / max(np.abs(r_).max(), 1e-30)
         assert err <= 3e-4, f"grad {k_}: {err:.3e}"
+
+
+@pytest.mark.parametrize("N,d,h,noise", [(700, 24, 16, 2), (1500, 500, 64, 2), (900, 40, 128, 3), (800, 33, 32, 0)])
+def test_edge_list_layer_step_matches_cpu_restatement(dev, N, d, h, noise):
+    """ShardedDGGConv with edge-list candidates (the step behind DGG_LearnableK_debug.forward_conv) on the HIP kernels against the
+    same step on the numpy/oracle stand-in: lists bit-exact, activations 1e-5, every gradient (parameters and x) 3e-4 of its max.
+    Rows with no candidate besides themselves, and one with more candidates than the ELL width."""
+    from dgg_amd import ops
+    from dgg_amd.parallel import ShardedDGGConv
+    from test_parallel_gloo import CpuKern, make_inputs, random_candidates
+    x, deg, P, cot = make_inputs(N, d, h)
+    deg = 4 + 8 * torch.rand(N, generator=torch.Generator().manual_seed(1))
+    rowptr, col = random_candidates(N, wide=(11,))
+    ref = ShardedDGGConv(CpuKern(), N, K=64, noise_mode=noise, seed=(5, 6), x_grad=True, cand=(rowptr, col))
+    Zr = ref.forward(x, deg, P)
+    gr = ref.backward(cot, x, P)
+    lay = ShardedDGGConv(ops, N, K=64, noise_mode=noise, seed=(5, 6), x_grad=True, cand=(rowptr.to(dev), col.to(dev)))
+    Pd = {k_: v.to(dev) for k_, v in P.items()}
+    Z = lay.forward(x.to(dev), deg.to(dev), Pd)
+    g = lay.backward(cot.to(dev), x.to(dev), Pd)
+    assert np.array_equal(Nn(lay.saved["idx"]), ref.saved["idx"].numpy())
+    np.testing.assert_allclose(Nn(Z), Zr.numpy(), rtol=1e-5, atol=1e-5 * float(Zr.abs().max()))
+    for k_ in gr:
+        r_ = gr[k_].numpy()
+        err = np.abs(Nn(g[k_]).reshape(r_.shape) - r_).max() / max(np.abs(r_).max(), 1e-30)
+        assert err <= 3e-4, f"grad {k_}: {err:.3e}"
+    # and without the input gradient: the step's usual form (pre-activation cotangents, one weight-gradient product)
+    lay2 = ShardedDGGConv(ops, N, K=64, noise_mode=noise, seed=(5, 6), cand=(rowptr.to(dev), col.to(dev)))
+    Z2 = lay2.forward(x.to(dev), deg.to(dev), Pd)
+    g2 = lay2.backward(cot.to(dev), x.to(dev), Pd)
+    assert torch.equal(Z2, Z)
+    for k_ in g2:
+        r_ = gr[k_].numpy()
+        err = np.abs(Nn(g2[k_]).reshape(r_.shape) - r_).max() / max(np.abs(r_).max(), 1e-30)
+        assert err <= 3e-4, f"grad {k_} (no input gradient): {err:.3e}"
 
 
 @pytest.mark.parametrize("rank", [0, 3, 7])
@@ -2083,6 +2128,24 @@ def test_ell_width_bound_is_enforced(dev):
     A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows[o], cols[o]])), torch.full((2048,), 12.0), (256, 256)).coalesce().to(dev)
     m(x, A)                                                       # k ~ 97, but 8 candidates per row
     m.check_ell_bound()
+    # the fused layer tests the bound inside its search kernel (one device flag, no extra launches)
+    d_, h_ = fx["meta"]["d"], fx["meta"]["h"]
+    if h_ in (16, 32, 64):
+        Wc = torch.rand(d_, 16, device=dev)
+        assert m.forward_conv(x, A, Wc) is not None
+        m.check_ell_bound()                                       # 8 candidates per row: exact whatever k is
+        rows = np.repeat(np.arange(256), 100)
+        cols = (rows + np.tile(np.arange(100), 256)) % 256
+        o = np.lexsort((cols, rows))
+        Aw = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows[o], cols[o]])), torch.full((25600,), 0.9), (256, 256)).coalesce().to(dev)
+        m.args.dgg_wide_rows = "ell"                              # ("auto" would leave the fused layer for the CSR form)
+        assert m.forward_conv(x, Aw, Wc) is not None              # 100 candidates per row, k ~ 91
+        with pytest.raises(RuntimeError, match="ell_width"):
+            m.check_ell_bound()
+        m.check_ell_bound()
+        m.args.dgg_wide_rows = "auto"
+        assert m.forward_conv(x, Aw, Wc) is None, "rows that would lose weight leave the fused layer (the caller takes the CSR form)"
+        m.check_ell_bound()                                       # (the discarded forward's flag does not survive)
 
 
 @pytest.mark.parametrize("perturb", [False, True])
@@ -2150,10 +2213,12 @@ def test_rows_wider_than_the_ell_go_through_csr(dev, perturb):
     assert isinstance(m(x.detach(), A2), dgg_amd.EllAdjacency)
 
 
-def test_config1_pubmed_shape_edge_list_step(dev):
+@pytest.mark.parametrize("fused", [False, True])
+def test_config1_pubmed_shape_edge_list_step(dev, fused):
     """BASELINE configs[1]: Pubmed shape (N = 19 717, d = 500, 44 324 undirected edges + self loops, k ~ 16), the drop-in modules
-    forward + backward; neighbour lists and scores bit-exact against the oracle's edge-list pipeline on EVERY row, weights 1e-5,
-    gradients of the DGG parameters against the oracle's backward (2e-4 of max)"""
+    forward + backward -- one after the other, and as the fused layer DGG_LearnableK_debug.forward_conv (the step bench.py times for
+    this config); neighbour lists and scores bit-exact against the oracle's edge-list pipeline on EVERY row, weights 1e-5,
+    gradients of the DGG parameters against the oracle's backward (2e-4 of max; fused: EVERY parameter)"""
     import bench
     import dgg_amd
     from argparse import Namespace
@@ -2177,11 +2242,27 @@ def test_config1_pubmed_shape_edge_list_step(dev):
     x = torch.rand(N, d, generator=torch.Generator().manual_seed(1))
     vals = torch.full((E,), 16.0 * N / E)
     A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), vals, (N, N)).coalesce().to(dev)
-    adj = dgg(x.to(dev), A)
-    out = conv(x.to(dev), adj.normalize())
+    if fused:
+        got = dgg.forward_conv(x.to(dev), A, conv.W)
+        assert got is not None, "the Pubmed configuration is inside the fused layer's coverage"
+        out, adj = got
+    else:
+        adj = dgg(x.to(dev), A)
+        out = conv(x.to(dev), adj.normalize())
     out.sum().backward()
     dgg.check_ell_bound()
     assert torch.isfinite(out).all()
+    if fused:
+        lay = dgg._fused_layer
+        kn = dgg.k_net
+        grads = dict(We=dgg.node_encode_for_edges[0].weight.grad, be=dgg.node_encode_for_edges[0].bias.grad,
+                     Wk=dgg.node_encode_for_k[0].weight.grad, bk=dgg.node_encode_for_k[0].bias.grad, W1=dgg.k_embed[0].weight.grad,
+                     b1=dgg.k_embed[0].bias.grad, Wmu=kn.k_mu.weight.grad, bmu=kn.k_mu.bias.grad, Wp=kn.k_project.weight.grad,
+                     bp=kn.k_project.bias.grad, Wc=conv.W.grad)
+        Pm = dict(We=dgg.node_encode_for_edges[0].weight, be=dgg.node_encode_for_edges[0].bias, Wk=dgg.node_encode_for_k[0].weight,
+                  bk=dgg.node_encode_for_k[0].bias, W1=dgg.k_embed[0].weight, b1=dgg.k_embed[0].bias, Wmu=kn.k_mu.weight,
+                  bmu=kn.k_mu.bias, Wp=kn.k_project.weight, bp=kn.k_project.bias, Wc=conv.W)
+        _full_size_gradient_parity(lay.saved, grads, x, dgg_amd.csr_candidates(A)[2], Pm)
     # oracle: the whole edge-list pipeline (O(E))
     sd = {k_: Nn(v) for k_, v in dgg.state_dict().items()}
     rowptr, col = csr_from_coo(rows, cols, N)

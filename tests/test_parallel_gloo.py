@@ -82,6 +82,12 @@ class CpuKern:
             idx[cut], val[cut] = -1, 0.0
         return self._t(idx), self._t(val)
 
+    def edgelist_topk(self, xp, rowptr, col, K, t, noise_mode, G, seed):
+        sys.path.insert(0, ROOT)
+        from oracle import oracle as O
+        idx, val = O.edgelist_topk(xp.numpy(), rowptr.numpy(), col.numpy(), K=K, t=t, noise_mode=noise_mode, seed=seed)
+        return self._t(idx), self._t(val)
+
     @staticmethod
     def _ramp(K, k):
         r = np.arange(K, dtype=np.float64)[None, :]
@@ -246,3 +252,69 @@ def test_shard_bounds_cover_every_row_once():
                 assert r0 == min(seen, N) and r1 >= r0 and r1 - r0 <= per
                 seen = r1
             assert seen == N
+
+
+def random_candidates(N, seed=3, lo=0, hi=12, wide=()):
+    """CSR candidate lists with self loops: `lo..hi` neighbours a row, rows in `wide` get 100 (more than the ELL width)"""
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(lo, hi + 1, N)
+    for r in wide:
+        deg[r] = min(100, N - 1)
+    rows, cols = [], []
+    for i in range(N):
+        c = np.unique(np.append(rng.choice(N, deg[i], replace=False), i)).astype(np.int32)
+        rows.append(np.full(c.shape, i))
+        cols.append(c)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    rowptr = np.zeros(N + 1, np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    return torch.from_numpy(np.cumsum(rowptr)), torch.from_numpy(cols.astype(np.int32))
+
+
+@pytest.mark.parametrize("noise_mode", [0, 2, 3])
+def test_edge_list_step_matches_dense_autograd(noise_mode):
+    """ShardedDGGConv with edge-list candidates (cand = CSR of in_adj; dgm.py:1613-1614) on the oracle stand-in against torch autograd
+    of the dense formulation restricted to the lists the step selected: relu(D^-1/2 A D^-1/2 (x Wc)) with A = score * ramp on the
+    selected entries, gradients of every parameter and of x."""
+    sys.path.insert(0, ROOT)
+    from dgg_amd.parallel import ShardedDGGConv
+    N, d, h = 90, 12, 16
+    x, deg, P, cot = make_inputs(N, d, h)
+    rowptr, col = random_candidates(N, wide=(7,))
+    lay = ShardedDGGConv(CpuKern(), N, K=64, noise_mode=noise_mode, seed=(5, 6), x_grad=True, cand=(rowptr, col))
+    Z = lay.forward(x, deg, P)
+    g = lay.backward(cot, x, P)
+    s = lay.saved
+    idx = s["idx"].numpy()
+    lens = (rowptr[1:] - rowptr[:-1]).numpy()
+    assert np.array_equal((idx >= 0).sum(1), np.minimum(lens, 64)), "every candidate of a row is selected (up to the ELL width)"
+    for i in (0, 7, 50):
+        assert set(idx[i][idx[i] >= 0]) <= set(col[rowptr[i]:rowptr[i + 1]].numpy())
+    # dense autograd restatement on the selected pattern, float64
+    xd = x.double().requires_grad_(True)
+    Pd = {k_: v.double().requires_grad_(True) for k_, v in P.items()}
+    lk = lambda t_: torch.where(t_ > 0, t_, 0.01 * t_)  # noqa: E731
+    xp, xk = lk(xd @ Pd["We"].T + Pd["be"]), lk(xd @ Pd["Wk"].T + Pd["bk"])
+    mu, sd = deg.double().mean(), deg.double().std()
+    feat = torch.cat([xk, ((deg.double() - mu) / (sd + 1e-5))[:, None]], 1)
+    m = lk(feat @ Pd["W1"].T + Pd["b1"]) @ Pd["Wmu"].T + Pd["bmu"]
+    k = torch.relu((m @ Pd["Wp"].reshape(-1) + Pd["bp"][0]) * sd + mu) + 1
+    np.testing.assert_allclose(k.detach().numpy(), s["k"].numpy(), rtol=1e-5)
+    valid = torch.from_numpy(idx >= 0)
+    j = torch.from_numpy(np.maximum(idx, 0)).long()
+    dist = ((xp[:, None, :] - xp[j]) ** 2).sum(-1).clamp_min(1e-30).sqrt()
+    p = torch.exp(-0.05 * dist)
+    sel_p = p if noise_mode == 0 else torch.exp(torch.log(p + 1e-8) + (torch.log(s["val"].double().clamp_min(1e-300)) - torch.log(p + 1e-8)).detach())
+    r = torch.arange(64, dtype=torch.float64)[None, :]
+    ramp = 1 - 0.5 * (1 + torch.tanh(r - k[:, None]))
+    w = torch.where(valid, sel_p * ramp, torch.zeros_like(p))
+    np.testing.assert_allclose(w.detach().numpy(), s["w"].numpy(), rtol=2e-5, atol=1e-7)
+    a = w.sum(1).rsqrt()
+    ahat = a[:, None] * w * a[j]
+    H = xd @ Pd["Wc"]
+    Zd = torch.relu((ahat[:, :, None] * H[j]).sum(1))
+    np.testing.assert_allclose(Zd.detach().numpy(), Z.numpy(), rtol=1e-4, atol=1e-5)
+    (Zd * cot.double()).sum().backward()
+    for k_, v in g.items():
+        ref = (xd.grad if k_ == "x" else Pd[k_].grad).numpy()
+        np.testing.assert_allclose(v.numpy().reshape(ref.shape), ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k_)
