@@ -363,6 +363,11 @@ int dgg_partp_describe(int64_t rows, int K, int64_t ncols, int64_t *out6);
  * also writes dA_rec [rows*K] = dA in record order.  dA, dH, da: caller zeroes. */
 int dgg_ell_conv_bwd_partp(const float *G, const float *H, int64_t rows, int K, int F, const void *partp_ws, int64_t ncols,
                            const float *rs, float *dA, float *dA_rec, float *dH, float *da, void *stream);
+/* the same when the normalised adjacency has OTHER consumers besides this aggregation (GCN_DGG hands it to its second layer as well,
+ * reference model.py:1266-1290): dA_ext [rows,K] (nullable) = their cotangent, slot for slot; it is added per record, so dA, dA_rec
+ * and da hold the totals and the score backward runs once.  Entries outside the partition (weight 0) are not read. */
+int dgg_ell_conv_bwd_partp_ext(const float *G, const float *H, int64_t rows, int K, int F, const void *partp_ws, int64_t ncols,
+                               const float *rs, const float *dA_ext, float *dA, float *dA_rec, float *dH, float *da, void *stream);
 /* dgg_softk_edge_bwd_part on a payload partition: the column kernel recomputes d loss / d score (ramp + normalisation chain,
  * dgm.py:1410-1420, model.py:1215-1218) from dA_rec and the per-row scalars the row kernel leaves in rowinfo_ws (4*rows floats).
  * out_act = 1 (mode 0 only): dxp is returned multiplied by LeakyReLU'(xp) -- the gradient of the pre-activation of node_encode_for_edges

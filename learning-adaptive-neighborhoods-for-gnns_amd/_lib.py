@@ -90,6 +90,7 @@ PROTOTYPES = {
     "dgg_partp_build": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp],
     "dgg_partp_build_norm": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp],
     "dgg_ell_conv_bwd_partp": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "dgg_ell_conv_bwd_partp_ext": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_softk_edge_bwd_partp": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _i32, _i32, _vp, _i64,
                                  _vp, _vp, _vp, _i32, _vp],
     "dgg_pack_bf16": [_vp, _i64, _i64, _i32, _vp, _i64, _vp],

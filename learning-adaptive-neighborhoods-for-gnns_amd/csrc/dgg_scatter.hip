@@ -529,11 +529,14 @@ __global__ __launch_bounds__(256) void conv_bwd_cols(const float *__restrict__ G
 // destination j: H_j / xp_j are loaded once, there is no run logic, the sums are plain stores (no atomics, no zero fill for
 // dH / da), and the kernel has the shape of the forward SpMM: F/4 lanes per record, 256/F records per wave-instruction,
 // NBT batches in flight.  (In-degree skew: a node with thousands of incoming edges is walked by one wavefront.)
-template <int F>
+// EXT: the adjacency is read by MORE consumers than this aggregation (GCN_DGG feeds the same normalised adjacency to its second
+// layer, model.py:1266-1290): their cotangent dA_ext [rows,K] (same slots as dA) is added to G_i . H_j per record, so that dA,
+// dA_rec and da carry the total and the score backward needs no second pass.
+template <int F, bool EXT = false>
 __global__ __launch_bounds__(256) void conv_bwd_node(const float *__restrict__ G, const float *__restrict__ Hm, int K, int64_t ncols,
                                                      const int *__restrict__ nodeptr, const int4 *__restrict__ recs,
                                                      const float *__restrict__ rs, float *__restrict__ dA, float *__restrict__ dA_rec,
-                                                     float *__restrict__ dH, float *__restrict__ da) {
+                                                     float *__restrict__ dH, float *__restrict__ da, const float *__restrict__ dA_ext = nullptr) {
     constexpr int LPR = F / 4, NPI = 64 / LPR, NBT = 4, PER = NBT * NPI;          // PER records per iteration (<= 64)
     const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
     const int64_t j = (int64_t)blockIdx.x * 4 + dgg::wave_id();
@@ -564,6 +567,11 @@ __global__ __launch_bounds__(256) void conv_bwd_node(const float *__restrict__ G
             if (dst < 0) src[b] = -1;
             g[b] = *reinterpret_cast<const float4 *>(G + (int64_t)(src[b] < 0 ? 0 : (src[b] >> 6)) * F + 4 * c4);   // unconditional
         }
+        float ext[NBT];
+        if constexpr (EXT) {
+#pragma unroll
+            for (int b = 0; b < NBT; b++) ext[b] = src[b] >= 0 ? dA_ext[(int64_t)(src[b] >> 6) * K + (src[b] & 63)] : 0.0f;
+        }
         float mydot = 0.0f;
 #pragma unroll
         for (int b = 0; b < NBT; b++) {
@@ -574,6 +582,7 @@ __global__ __launch_bounds__(256) void conv_bwd_node(const float *__restrict__ G
             if (LPR > 4) dot += __uint_as_float(xor_shfl<4>(__float_as_uint(dot), lane));
             dot += __uint_as_float(xor_shfl<2>(__float_as_uint(dot), lane));
             dot += __uint_as_float(xor_shfl<1>(__float_as_uint(dot), lane));
+            if constexpr (EXT) dot += ext[b];
             // (write-through store that does not stay in the XCD's L2: these 4.1 M scattered dwords are never touched again by this
             //  kernel, and left in L2 they push out the G rows the gathers hit: 202 -> 193 us; nontemporal: 196)
             if (src[b] >= 0 && c4 == 0)
@@ -1421,8 +1430,16 @@ static bool node_groups(int64_t nrec, int64_t ncols) {
 
 // dgg_ell_conv_bwd_part on a payload partition: ahat comes from the records; additionally dA_rec [rows*K] = dA in record order
 // (for dgg_softk_edge_bwd_partp).  dA [rows,K], dH [ncols,F], da [ncols] as in dgg_ell_conv_bwd_part (caller zeroes all three).
+int dgg_ell_conv_bwd_partp_ext(const float *G, const float *H, int64_t rows, int K, int F, const void *partp_ws, int64_t ncols,
+                               const float *rs, const float *dA_ext, float *dA, float *dA_rec, float *dH, float *da, void *stream);
 int dgg_ell_conv_bwd_partp(const float *G, const float *H, int64_t rows, int K, int F, const void *partp_ws, int64_t ncols,
                            const float *rs, float *dA, float *dA_rec, float *dH, float *da, void *stream) {
+    return dgg_ell_conv_bwd_partp_ext(G, H, rows, K, F, partp_ws, ncols, rs, nullptr, dA, dA_rec, dH, da, stream);
+}
+// the same with an additional cotangent of the normalised adjacency from its other consumers (dA_ext [rows,K], nullable; entries
+// outside the partition are not read): dA / dA_rec / da then hold the totals
+int dgg_ell_conv_bwd_partp_ext(const float *G, const float *H, int64_t rows, int K, int F, const void *partp_ws, int64_t ncols,
+                               const float *rs, const float *dA_ext, float *dA, float *dA_rec, float *dH, float *da, void *stream) {
     if ((F != 16 && F != 32 && F != 64 && F != 128) || (reinterpret_cast<uintptr_t>(G) % 16) || (reinterpret_cast<uintptr_t>(H) % 16) ||
         (reinterpret_cast<uintptr_t>(dH) % 16))
         return dgg_set_error(DGG_ERR_UNSUPPORTED, "ell_conv_bwd_partp: feature width must be 16, 32, 64 or 128 (16-byte aligned rows)");
@@ -1431,14 +1448,17 @@ int dgg_ell_conv_bwd_partp(const float *G, const float *H, int64_t rows, int K, 
     PartP2 p;
     partp2_layout(p, const_cast<void *>(partp_ws), rows, K, ncols);
     hipStream_t st = (hipStream_t)stream;
-    const bool grouped = node_groups(rows * K, ncols);
+    const bool grouped = !dA_ext && node_groups(rows * K, ncols);
 #define DGG_CONV_COLS_P(FF)                                                                                                \
-    if (grouped)                                                                                                           \
+    if (dA_ext)                                                                                                            \
+        hipLaunchKernelGGL((conv_bwd_node<FF, true>), dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, G, H, K, ncols, p.nodeptr, p.recs, \
+                           rs, dA, dA_rec, dH, da, dA_ext);                                                                \
+    else if (grouped)                                                                                                      \
         hipLaunchKernelGGL((conv_bwd_nodeg<FF, 4>), dim3((unsigned)((ncols + 4 * (256 / FF) - 1) / (4 * (256 / FF)))), dim3(256), 0, st, G, H, K, \
                            ncols, p.nodeptr, p.recs, rs, dA, dA_rec, dH, da);                                              \
     else                                                                                                                   \
-        hipLaunchKernelGGL(conv_bwd_node<FF>, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, G, H, K, ncols, p.nodeptr, p.recs, rs, dA, \
-                           dA_rec, dH, da)
+        hipLaunchKernelGGL((conv_bwd_node<FF, false>), dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, G, H, K, ncols, p.nodeptr, p.recs, \
+                           rs, dA, dA_rec, dH, da, (const float *)nullptr)
     switch (F) {
         case 16: DGG_CONV_COLS_P(16); break;
         case 32: DGG_CONV_COLS_P(32); break;

@@ -288,16 +288,21 @@ class _FusedDGGConvFn(torch.autograd.Function):
         Z = layer.forward(x, deg, P)
         ctx.layer, ctx.state = layer, layer.saved
         ctx.save_for_backward(x, *params)
-        return Z
+        ctx.set_materialize_grads(False)
+        # second output: the NORMALISED adjacency values [N,K] -- differentiable, for the layers after this one that read the same
+        # adjacency (model.py:1266-1290); its cotangent joins the aggregation's own inside the backward
+        return Z, layer.saved["ahat"]
 
     @staticmethod
-    def backward(ctx, dZ):
+    def backward(ctx, dZ, dahat):
         x, *params = ctx.saved_tensors
         layer = ctx.layer
         P = dict(zip(layer.PARAM_KEYS, params))
         layer.saved, layer._fwd_gen = ctx.state, ctx.state["gen"]       # (another forward of the same module may have run since)
         layer.x_grad = bool(ctx.needs_input_grad[0])
-        g = layer.backward(dZ.contiguous(), x, P)
+        if dZ is None:
+            dZ = torch.zeros_like(ctx.state["Z"])
+        g = layer.backward(dZ.contiguous(), x, P, dA_ext=dahat)
         return (g.get("x"), None, None) + tuple(g[k_].reshape(P[k_].shape) for k_ in layer.PARAM_KEYS)
 
 
@@ -440,12 +445,14 @@ class DGG_LearnableK_debug(nn.Module):
         st["n"] += 1
         return ops.NOISE_RANKED
 
-    def forward_conv(self, x, in_adj, conv_weight):
+    def forward_conv(self, x, in_adj, conv_weight, want_norm=False):
         """`GCNConv(x, normalize_adj(self(x, in_adj)))` with conv_weight = GCNConv.W [in, out] as one fused autograd node
         (_FusedDGGConvFn) -> (Z, unnormalised EllAdjacency, DETACHED: its values carry no autograd edge -- the loss of the
         reference's training scripts reads the class scores only, train_small_graphs.py:226-230), or None when this configuration
         is outside the fused step (the caller then runs the modules one after the other): scorer u-v-dist, k-net "x", soft
-        k_times_edge_prob / k_only output, widths the partitioned backward covers, rows that fit the ELL width."""
+        k_times_edge_prob / k_only output, widths the partitioned backward covers, rows that fit the ELL width.
+        want_norm: additionally return the NORMALISED adjacency as a differentiable EllAdjacency for the layers that read the same
+        graph after this one (GCN_DGG's second layer): its gradient flows back into the generator through the same node."""
         from .parallel import ShardedDGGConv
         a = self.args
         h = self.latent_dim
@@ -483,10 +490,12 @@ class DGG_LearnableK_debug(nn.Module):
                 flag = self.__dict__["_overflow_dev"] = torch.zeros((1,), device=x.device, dtype=torch.int32)
             layer.overflow = flag
         kn = self.k_net
-        Z = _FusedDGGConvFn.apply(x, deg, layer, self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias,
+        Z, ahat = _FusedDGGConvFn.apply(x, deg, layer, self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias,
                                   self.node_encode_for_k[0].weight, self.node_encode_for_k[0].bias, self.k_embed[0].weight,
-                                  self.k_embed[0].bias, kn.k_mu.weight, kn.k_mu.bias, kn.k_project.weight, kn.k_project.bias, conv_weight)
+                                        self.k_embed[0].bias, kn.k_mu.weight, kn.k_mu.bias, kn.k_project.weight, kn.k_project.bias, conv_weight)
         st = layer.saved
+        if st.get("partp") is None:                           # (shape outside the partitioned backward: the separate modules)
+            return None
         k = st["k"]
         if cand is not None and self._wide_rows(in_adj, rowptr, k):
             # rows wider than the ELL with learned degrees beyond it: the CSR form from here on (this discarded forward raised the flag)
@@ -496,7 +505,10 @@ class DGG_LearnableK_debug(nn.Module):
             self._track_overflow(k, None)
         elif __import__("os").environ.get("DGG_STRICT_BOUND") == "1":
             self.check_ell_bound()
-        return Z, EllAdjacency(st["idx"], st["w"], N, rs=st["rs"], k=k, score=st["val"], owner=self)
+        unnorm = EllAdjacency(st["idx"], st["w"], N, rs=st["rs"], k=k, score=st["val"], owner=self)
+        if not want_norm:
+            return Z, unnorm
+        return Z, unnorm, EllAdjacency(st["idx"], ahat, N, k=k, score=st["val"], normalized=True, owner=self)
 
     def _track_overflow(self, k, ncand):
         over = k.detach() + 8.5 > float(self.ell_width)

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
 from . import ops
-from .adjacency import CsrAdjacency, EllAdjacency, ell_from_dense
+from .adjacency import AllPairs, CsrAdjacency, EllAdjacency, ell_from_dense
 from .dgm import DGG, DGG_Ablations, DGG_LearnableK_debug
 
 
@@ -134,11 +134,20 @@ class GCN_DGG(nn.Module):
         unnorm_adj = in_adj
         norm_adj = None
         for i, conv in enumerate(self.convs):
+            fused = None
             if i < len(self.dggs):
                 src = in_adj if self.dgg_adj_input == "input_adj" else unnorm_adj
-                unnorm_adj = self.dgg_net(x, i, src, writer, epoch)
-                norm_adj = _normalize_adj(unnorm_adj)
-            x = conv(x, norm_adj)
+                if writer is None and isinstance(conv, GCNConv) and isinstance(src, (torch.Tensor, AllPairs)) and x.is_cuda:
+                    # generator + normalize_adj + this layer as one autograd node (one pass over x for the three projections and
+                    # one for their weight gradients); None when the configuration is outside its coverage
+                    fused = self.dggs[i].forward_conv(x, src, conv.W, want_norm=True)
+                if fused is not None:
+                    x, unnorm_adj, norm_adj = fused
+                else:
+                    unnorm_adj = self.dgg_net(x, i, src, writer, epoch)
+                    norm_adj = _normalize_adj(unnorm_adj)
+            if fused is None:
+                x = conv(x, norm_adj)
             if i < len(self.convs) - 1:
                 x = F.dropout(x, training=self.training)
             if writer is not None:

@@ -935,10 +935,11 @@ def partp_sort(part):
     part.args = None
 
 
-def conv_bwd_cols_p(idx, H, G, partp, rs, zero_dA=True):
+def conv_bwd_cols_p(idx, H, G, partp, rs, zero_dA=True, dA_ext=None):
     """conv_bwd_cols on a payload partition -> dA [rows,K], dA_rec [rows*K], dH [ncols,F], da [ncols] (neighbour side); None when
     the kernel does not cover the shape.  zero_dA=False: entries outside the partition are left UNINITIALISED -- for a consumer that
-    masks them itself (softk_edge_bwd_p with ahat_rows does)"""
+    masks them itself (softk_edge_bwd_p with ahat_rows does).  dA_ext [rows,K] (optional): cotangent of the normalised adjacency from its
+    other consumers, added per record (dA / dA_rec / da then hold the totals)"""
     N, K = idx.shape
     H, G = _chk(H), _chk(G)
     F = H.shape[1]
@@ -953,8 +954,11 @@ def conv_bwd_cols_p(idx, H, G, partp, rs, zero_dA=True):
     da = alloc((ncols,), device=H.device, dtype=torch.float32)
     dA_rec = torch.empty((N * K,), device=H.device, dtype=torch.float32)
     pe = _probe_begin()
-    _lib.check(_lib.lib().dgg_ell_conv_bwd_partp(_ptr(G), _ptr(H), N, K, F, _ptr(partp.ws), ncols, _ptr(_chk(rs)), _ptr(dA), _ptr(dA_rec),
-                                                 _ptr(dH), _ptr(da), _stream()), "ell_conv_bwd_partp")
+    if dA_ext is not None:
+        dA_ext = _chk(dA_ext.contiguous())
+        assert tuple(dA_ext.shape) == (N, K)
+    _lib.check(_lib.lib().dgg_ell_conv_bwd_partp_ext(_ptr(G), _ptr(H), N, K, F, _ptr(partp.ws), ncols, _ptr(_chk(rs)), _ptr(dA_ext), _ptr(dA),
+                                                     _ptr(dA_rec), _ptr(dH), _ptr(da), _stream()), "ell_conv_bwd_partp")
     _probe_end("conv_bwd", pe)
     return dA, dA_rec, dH, da
 

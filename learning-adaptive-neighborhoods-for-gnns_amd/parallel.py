@@ -270,8 +270,10 @@ class ShardedDGGConv:
         self.saved = s
         return s["Z"]
 
-    def backward(self, dZ, x_local, P):
-        """-> dict of parameter gradients (summed over ranks) and, if x_grad, 'x' = d loss / d x_local."""
+    def backward(self, dZ, x_local, P, dA_ext=None):
+        """-> dict of parameter gradients (summed over ranks) and, if x_grad, 'x' = d loss / d x_local.
+        dA_ext [rows,K] (optional): cotangent of the NORMALISED adjacency (saved["ahat"]) from consumers other than this layer's own
+        aggregation (GCN_DGG's second layer reads the same adjacency); added to the aggregation's own before the score backward."""
         kern, s = self.kern, self.saved
         assert s.get("gen") == getattr(self, "_fwd_gen", None), "ShardedDGGConv: backward() must follow the forward() it differentiates " \
             "(a second forward has overwritten the gathered buffers)"
@@ -283,8 +285,8 @@ class ShardedDGGConv:
             if s.get("partp") is None:
                 need += rows * self.K + ncols * (h + F + 2)
             with kern.zero_pool(s["xp"].device, need):
-                return self._backward(dZ, x_local, P)
-        return self._backward(dZ, x_local, P)
+                return self._backward(dZ, x_local, P, dA_ext)
+        return self._backward(dZ, x_local, P, dA_ext)
 
     def _reduce_scatter_rows(self, t, key, async_op=False):
         """[N, c] partial sums on every rank -> the rank's own rows [r1-r0, c], summed over ranks.  async_op: returns a callable
@@ -306,7 +308,7 @@ class ShardedDGGConv:
             return out[: self.r1 - self.r0]
         return get
 
-    def _backward(self, dZ, x_local, P):
+    def _backward(self, dZ, x_local, P, dA_ext=None):
         kern, s = self.kern, self.saved
         g = {}
         repl = self.x_full is not None
@@ -320,7 +322,8 @@ class ShardedDGGConv:
                 torch.cuda.current_stream().wait_stream(self._side_stream())
                 s["side_join"] = False
             # (dA of the entries outside the partition is masked by the row kernel -- ahat_rows is 0 there -- so it is not zero-filled)
-            pc = kern.conv_bwd_cols_p(s["idx"], s["H"], G, partp, s["rs"], zero_dA=False)
+            pc = kern.conv_bwd_cols_p(s["idx"], s["H"], G, partp, s["rs"], zero_dA=False) if dA_ext is None else \
+                kern.conv_bwd_cols_p(s["idx"], s["H"], G, partp, s["rs"], zero_dA=False, dA_ext=dA_ext)
             assert pc is not None
             dA, dA_rec, dH, da = pc
             if self._hyb() and self.coll:           # dH [N,F] partial is complete here and needed only by the last kernel of the step
@@ -353,7 +356,7 @@ class ShardedDGGConv:
                                             self.noise_mode != 0, self.mode, True, partp, ahat_rows=s["ahat"], out_act=1 if pre else 0)
             return self._weight_grads(g, dxp, dH, dk, x_local, P, premasked=pre)
         cols = None
-        if part is not None and hasattr(kern, "conv_bwd_cols") and hasattr(kern, "softk_edge_bwd") and \
+        if dA_ext is None and part is not None and hasattr(kern, "conv_bwd_cols") and hasattr(kern, "softk_edge_bwd") and \
                 s["xp"].shape[1] in (16, 32, 64, 128) and self.mode in (0, 1):
             cols = kern.conv_bwd_cols(s["idx"], s["ahat"], s["H"], G, part, s["rs"], True)
         if cols is not None:
@@ -361,6 +364,8 @@ class ShardedDGGConv:
             ahat_rows = s["ahat"]
         else:
             dA, dH = kern.spmm_bwd(s["idx"], s["ahat"], s["H"], G, True, True)
+            if dA_ext is not None:                       # (the slot-wise total; the masked entries carry no weight either way)
+                dA = dA + torch.where(s["idx"] >= 0, dA_ext, torch.zeros_like(dA_ext))
             da = kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0, part) if part is not None else \
                 kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0)
             ahat_rows = None

@@ -882,6 +882,17 @@ def test_edge_list_layer_step_matches_cpu_restatement(dev, N, d, h, noise):
         r_ = gr[k_].numpy()
         err = np.abs(Nn(g[k_]).reshape(r_.shape) - r_).max() / max(np.abs(r_).max(), 1e-30)
         assert err <= 3e-4, f"grad {k_}: {err:.3e}"
+    # a second consumer of the normalised adjacency: its cotangent enters through dA_ext (added per record in the column kernel)
+    cotA = torch.randn(N, 64, generator=torch.Generator().manual_seed(9))
+    ref.forward(x, deg, P)
+    gre = ref.backward(cot, x, P, dA_ext=cotA)
+    lay.forward(x.to(dev), deg.to(dev), Pd)
+    ge = lay.backward(cot.to(dev), x.to(dev), Pd, dA_ext=cotA.to(dev))
+    for k_ in gre:
+        r_ = gre[k_].numpy()
+        err = np.abs(Nn(ge[k_]).reshape(r_.shape) - r_).max() / max(np.abs(r_).max(), 1e-30)
+        assert err <= 3e-4, f"grad {k_} (second consumer of the adjacency): {err:.3e}"
+    assert max(float((gre[k_] - gr[k_]).abs().max()) for k_ in ("We", "Wk")) > 0, "the extra cotangent changes the generator's gradients"
     # and without the input gradient: the step's usual form (pre-activation cotangents, one weight-gradient product)
     lay2 = ShardedDGGConv(ops, N, K=64, noise_mode=noise, seed=(5, 6), cand=(rowptr.to(dev), col.to(dev)))
     Z2 = lay2.forward(x.to(dev), deg.to(dev), Pd)
@@ -891,6 +902,58 @@ def test_edge_list_layer_step_matches_cpu_restatement(dev, N, d, h, noise):
         r_ = gr[k_].numpy()
         err = np.abs(Nn(g2[k_]).reshape(r_.shape) - r_).max() / max(np.abs(r_).max(), 1e-30)
         assert err <= 3e-4, f"grad {k_} (no input gradient): {err:.3e}"
+
+
+@pytest.mark.parametrize("cand", ["edgelist", "allpairs"])
+def test_gcn_dgg_fused_first_layer_matches_the_separate_modules(dev, cand):
+    """GCN_DGG runs generator + normalize_adj + conv1 as one autograd node (DGG_LearnableK_debug.forward_conv) and hands the normalised
+    adjacency -- a differentiable output of that node -- to conv2 (reference model.py:1266-1290: both layers read the same graph).
+    Against the same model with args.dgg_fused_layer = False (every module on its own): identical neighbour lists, log-probabilities
+    1e-5, gradients of EVERY parameter 3e-4 of max (both paths aggregate the projected features; summation orders differ)."""
+    import copy
+    import dgg_amd
+    from argparse import Namespace
+    from test_parallel_gloo import random_candidates
+    N, d, h, C = 1200, 40, 32, 7
+    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
+    torch.manual_seed(3)
+    m1 = dgg_amd.GCN_DGG(nfeat=d, nhidden=h, nclass=C, args=args).to(dev).eval()        # eval: no dropout between the layers
+    with torch.no_grad():
+        m1.dggs[0].k_net.k_project.weight.mul_(0.1)
+        m1.conv2.W.mul_(0.2)
+    m2 = copy.deepcopy(m1)
+    m2.dggs[0].args = Namespace(**dict(vars(args), dgg_fused_layer=False))
+    for m in (m1, m2):
+        m.dggs[0].set_seed(77, 5)
+    x = torch.rand(N, d, generator=torch.Generator().manual_seed(1)).to(dev)
+    if cand == "edgelist":
+        rowptr, col = random_candidates(N, hi=10)
+        rows = torch.repeat_interleave(torch.arange(N), rowptr[1:] - rowptr[:-1])
+        keep = rows != col                                          # (the wrapper adds the self loops itself)
+        A = torch.sparse_coo_tensor(torch.stack([rows[keep], col[keep].long()]), torch.full((int(keep.sum()),), 2.5), (N, N)).coalesce().to(dev)
+    else:
+        A = dgg_amd.AllPairs(torch.full((N,), 14.0, device=dev))
+    y = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(2)).to(dev)
+    outs = []
+    for m in (m1, m2):
+        logp, adj, _ = m(x, A)
+        torch.nn.functional.nll_loss(logp, y).backward()
+        outs.append((logp, adj))
+    assert m1.dggs[0].__dict__.get("_fused_layer") is not None and m2.dggs[0].__dict__.get("_fused_layer") is None
+    kept = outs[1][1].idx >= 0
+    assert torch.equal(outs[0][1].idx[kept & (outs[0][1].values() != 0)], outs[1][1].idx[kept & (outs[0][1].values() != 0)])
+    np.testing.assert_allclose(Nn(outs[0][1].values()), Nn(outs[1][1].values()), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(Nn(outs[0][0]), Nn(outs[1][0]), rtol=1e-5, atol=1e-5)
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p2.grad is None:
+            assert p1.grad is None or float(p1.grad.abs().max()) == 0.0, n1
+            continue
+        ref = Nn(p2.grad)
+        assert p1.grad is not None, n1
+        err = np.abs(Nn(p1.grad) - ref).max() / max(np.abs(ref).max(), 1e-30)
+        assert err <= 3e-4, f"{n1}: {err:.2e}"
 
 
 @pytest.mark.parametrize("rank", [0, 3, 7])

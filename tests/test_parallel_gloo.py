@@ -271,11 +271,12 @@ def random_candidates(N, seed=3, lo=0, hi=12, wide=()):
     return torch.from_numpy(np.cumsum(rowptr)), torch.from_numpy(cols.astype(np.int32))
 
 
-@pytest.mark.parametrize("noise_mode", [0, 2, 3])
-def test_edge_list_step_matches_dense_autograd(noise_mode):
+@pytest.mark.parametrize("noise_mode,ext", [(0, False), (2, False), (3, False), (2, True)])
+def test_edge_list_step_matches_dense_autograd(noise_mode, ext):
     """ShardedDGGConv with edge-list candidates (cand = CSR of in_adj; dgm.py:1613-1614) on the oracle stand-in against torch autograd
     of the dense formulation restricted to the lists the step selected: relu(D^-1/2 A D^-1/2 (x Wc)) with A = score * ramp on the
-    selected entries, gradients of every parameter and of x."""
+    selected entries, gradients of every parameter and of x.  ext: the normalised adjacency has a second consumer whose cotangent
+    enters the backward as dA_ext (GCN_DGG's second layer)."""
     sys.path.insert(0, ROOT)
     from dgg_amd.parallel import ShardedDGGConv
     N, d, h = 90, 12, 16
@@ -283,7 +284,8 @@ def test_edge_list_step_matches_dense_autograd(noise_mode):
     rowptr, col = random_candidates(N, wide=(7,))
     lay = ShardedDGGConv(CpuKern(), N, K=64, noise_mode=noise_mode, seed=(5, 6), x_grad=True, cand=(rowptr, col))
     Z = lay.forward(x, deg, P)
-    g = lay.backward(cot, x, P)
+    cotA = torch.randn(N, 64, generator=torch.Generator().manual_seed(9)) if ext else None
+    g = lay.backward(cot, x, P, dA_ext=cotA)
     s = lay.saved
     idx = s["idx"].numpy()
     lens = (rowptr[1:] - rowptr[:-1]).numpy()
@@ -314,7 +316,10 @@ def test_edge_list_step_matches_dense_autograd(noise_mode):
     H = xd @ Pd["Wc"]
     Zd = torch.relu((ahat[:, :, None] * H[j]).sum(1))
     np.testing.assert_allclose(Zd.detach().numpy(), Z.numpy(), rtol=1e-4, atol=1e-5)
-    (Zd * cot.double()).sum().backward()
+    loss = (Zd * cot.double()).sum()
+    if ext:
+        loss = loss + (ahat * cotA.double()).sum()
+    loss.backward()
     for k_, v in g.items():
         ref = (xd.grad if k_ == "x" else Pd[k_].grad).numpy()
         np.testing.assert_allclose(v.numpy().reshape(ref.shape), ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k_)
