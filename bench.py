@@ -205,39 +205,68 @@ def run_edgelist(a, dev):
             out.sum().backward()
         return adj
 
-    # ~70 launches of a few microseconds each: launch latency dominates at this size, so the whole autograd step (forward,
+    # a few dozen launches of a few microseconds each: launch latency dominates at this size, so the whole autograd step (forward,
     # backward, fresh gradient tensors) is captured once into a hipGraph and replayed -- same kernels, same work.  The
     # warm-up runs on a side stream, as torch's whole-network capture recipe requires (AccumulateGrad nodes remember the
     # stream they were created on).
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(max(a.warmup, 3)):
-            adj = step()
-    torch.cuda.current_stream().wait_stream(side)
-    graph = None
-    if a.hipgraph:
-        try:
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                adj = step()
-            graph.replay()
-            torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001
-            print(f"hipGraph capture failed ({e!r}); timing eager launches", file=sys.stderr)
-            graph = None
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        if graph is not None:
-            graph.replay()
-        else:
-            adj = step()
-    torch.cuda.synchronize()
-    T = (time.perf_counter() - t0) / a.steps
+    def timed(step_fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(a.warmup, 3)):
+                res = step_fn()
+        torch.cuda.current_stream().wait_stream(side)
+        gr = None
+        if a.hipgraph:
+            try:
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    res = step_fn()
+                gr.replay()
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                print(f"hipGraph capture failed ({e!r}); timing eager launches", file=sys.stderr)
+                gr = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            if gr is not None:
+                gr.replay()
+            else:
+                res = step_fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / a.steps, gr, res
+
+    T, graph, adj = timed(step)
     kmean = float(adj.k.mean().item())
     nsel = float((adj.values() != 0).sum().item())
+    # the whole two-layer model of this config (GCN_DGG, reference model.py:1183-1311: generator + conv1 fused as above, dropout,
+    # conv2 on the same adjacency, log-softmax, NLL loss on 60 training nodes), forward + backward, beside the layer step
+    model_ms = None
+    if fused:
+        try:
+            torch.manual_seed(0)
+            net = dgg_amd.GCN_DGG(nfeat=d, nhidden=h, nclass=3, args=args).to(dev).train()
+            with torch.no_grad():
+                net.dggs[0].k_net.k_project.weight.mul_(0.1)
+            net.dggs[0].set_seed(1234, 0)
+            keep = rows != cols                                    # (the wrapper adds the self loops itself)
+            A2 = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows[keep], cols[keep]])), torch.full((int(keep.sum()),), 16.0 * N / E),
+                                         (N, N)).coalesce().to(dev)
+            ytr = torch.randint(0, 3, (60,), generator=g).to(dev)
+            itr = torch.randperm(N, generator=g)[:60].to(dev)
+            nparams = list(net.parameters())
+
+            def model_step():
+                for p_ in nparams:
+                    p_.grad = None
+                logp, _, _ = net(x, A2)
+                torch.nn.functional.nll_loss(logp[itr], ytr).backward()
+
+            model_ms = timed(model_step)[0] * 1e3
+        except Exception as e:  # noqa: BLE001
+            print(f"GCN_DGG model timing failed: {e!r}", file=sys.stderr)
     out = {"metric": "DGG adj-build+SpMM fwd/bwd edges/sec (edge-list candidates, Pubmed shape)", "value": nsel / T, "unit": "edges/s", "n_gpus": 1,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": T * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -245,7 +274,7 @@ def run_edgelist(a, dev):
                                   f"{a.edge_mode}/x/k_times_edge_prob, Gumbel(0,0.3) hash noise, module API under autograd "
                                   + ("(DGG_LearnableK_debug.forward_conv: generator + normalize + GCNConv as one autograd node)" if fused
                                      else "(DGG_LearnableK_debug + normalize + GCNConv)") + ", fwd+bwd",
-                      "api": "fused layer" if fused else "separate modules",
+                      "api": "fused layer" if fused else "separate modules", "gcn_dgg_model_ms_per_step": model_ms,
                       "nodes": N, "feat": d, "latent": h, "candidate_edges": E, "selected_edges": nsel,
                       "candidate_edges_per_s": E / T, "edge_mode": a.edge_mode, "hipgraph": graph is not None},
            "roofline": None}

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
 from . import ops
-from .adjacency import AllPairs, CsrAdjacency, EllAdjacency, ell_from_dense
+from .adjacency import AllPairs, CsrAdjacency, EllAdjacency, _cached, ell_from_dense
 from .dgm import DGG, DGG_Ablations, DGG_LearnableK_debug
 
 
@@ -102,12 +102,19 @@ def _with_self_loops(in_adj):
     """in_adj + I as coalesced sparse COO (reference model.py:1249-1251, 1264) without the dense round trip."""
     if not isinstance(in_adj, torch.Tensor):
         return in_adj          # AllPairs etc.
-    N = in_adj.shape[0]
-    if not in_adj.is_sparse:
-        in_adj = in_adj.to_sparse()
-    eye_i = torch.arange(N, device=in_adj.device)
-    eye = torch.sparse_coo_tensor(torch.stack([eye_i, eye_i]), torch.ones(N, device=in_adj.device), (N, N))
-    return (in_adj + eye).coalesce()
+
+    def make():
+        a = in_adj if in_adj.is_sparse else in_adj.to_sparse()
+        N = a.shape[0]
+        eye_i = torch.arange(N, device=a.device)
+        eye = torch.sparse_coo_tensor(torch.stack([eye_i, eye_i]), torch.ones(N, device=a.device), (N, N))
+        return (a + eye).coalesce()
+    # the input graph is data: the same tensor object on every forward of a training loop (train_small_graphs.py:226).  The sum is
+    # cached per object and version of its values (adjacency._cached), so the CSR conversions cached on ITS result hit as well and a
+    # forward on a known graph launches nothing here (which is also what lets a whole model step be captured into a hipGraph)
+    if in_adj.requires_grad or (in_adj.is_sparse and in_adj._values().requires_grad):
+        return make()
+    return _cached("selfloops", in_adj, make)
 
 
 class GCN_DGG(nn.Module):
