@@ -904,6 +904,7 @@ inline int64_t nbuckets(int64_t ncols) { return (ncols + BS - 1) / BS; }
 // Buckets are `width` nodes wide (pp_width).  Record order inside a node depends on the arrival order of the LDS adds, as before.
 constexpr int PP_T = 1024;                                       // threads of a pp_sort workgroup
 constexpr int PP_RPT = 16;                                       // records per thread held in registers by pp_sort
+constexpr int PP_UF = 8;                                         // loads in flight per thread on its over-capacity path
 inline int pp_threads() {                                        // threads of a pp_count / pp_fill workgroup (16 rows per wavefront)
     static const int t = [] { const char *e = getenv("DGG_PP_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 1024; }();
     return t;
@@ -1190,7 +1191,20 @@ __global__ __launch_bounds__(PP_T) void pp_sort(const int *__restrict__ bstart, 
 #pragma unroll
         for (int u = 0; u < PP_RPT; u++) rank[u] = rec[u].y >= 0 ? atomicAdd(&cnt[rec[u].y - b * PBS], 1) : 0;
     } else {
-        for (int e = e0 + tid; e < e1; e += PP_T) atomicAdd(&cnt[tmp[e].y - b * PBS], 1);
+        // a bucket beyond the register capacity (full 64-entry lists -- the hash / unperturbed generators keep every rank -- or
+        // a few nodes that very many rows select): two passes over its records, PP_UF loads of a thread in flight at a time
+        // (one load per iteration made this path 4x the in-register one: 35 -> 140-170 us for those generators)
+        for (int eb = e0; eb < e1; eb += PP_T * PP_UF) {
+            int jy[PP_UF];
+#pragma unroll
+            for (int u = 0; u < PP_UF; u++) {
+                const int e = eb + u * PP_T + tid;
+                jy[u] = e < e1 ? tmp[e].y : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < PP_UF; u++)
+                if (jy[u] >= 0) atomicAdd(&cnt[jy[u] - b * PBS], 1);
+        }
     }
     __syncthreads();
     pp_block_scan<PP_T>(cnt, base, PBS, scratch);
@@ -1203,10 +1217,20 @@ __global__ __launch_bounds__(PP_T) void pp_sort(const int *__restrict__ bstart, 
     } else {
         for (int q = tid; q < PBS; q += PP_T) cnt[q] = 0;
         __syncthreads();
-        for (int e = e0 + tid; e < e1; e += PP_T) {
-            const int4 r = tmp[e];
-            const int jl = r.y - b * PBS;
-            recs[o0 + base[jl] + atomicAdd(&cnt[jl], 1)] = r;
+        for (int eb = e0; eb < e1; eb += PP_T * PP_UF) {
+            int4 r[PP_UF];
+#pragma unroll
+            for (int u = 0; u < PP_UF; u++) {
+                const int e = eb + u * PP_T + tid;
+                r[u] = tmp[e < e1 ? e : e1 - 1];
+                if (e >= e1) r[u].y = -1;
+            }
+#pragma unroll
+            for (int u = 0; u < PP_UF; u++)
+                if (r[u].y >= 0) {
+                    const int jl = r[u].y - b * PBS;
+                    recs[o0 + base[jl] + atomicAdd(&cnt[jl], 1)] = r[u];
+                }
         }
     }
 }
