@@ -2211,6 +2211,63 @@ def test_ell_width_bound_is_enforced(dev):
         m.check_ell_bound()                                       # (the discarded forward's flag does not survive)
 
 
+@pytest.mark.parametrize("prior", ["bounded", "cora"])
+def test_learned_degrees_of_a_trained_model_and_the_all_pairs_list(dev, prior):
+    """The all-pairs generator keeps 64 ranks per row, exact while k_i + 8.5 <= 64; k = relu(kp sd + mu) + 1
+    with (mu, sd) the statistics of the prior degrees (dgm.py:1569-1584).  Two regimes of GCN_DGG on all-pairs candidates, trained
+    with the script's optimiser settings (train_small_graphs.py:399-418; labels that correlate with the features, so the loss really
+    moves the generator):
+      bounded   prior degrees 24..40 (the synthetic configs of BASELINE.json): inside the bound at initialisation; the learned degree
+                is unbounded, and the loss of this toy problem drives it up (observed: 33 -> 320 within 60 steps at lr 0.01) -- at the
+                step where a row first needs more than 64 ranks check_ell_bound() raises, never silently truncating;
+      cora      a heavy-tailed prior with Cora's statistics (mean 3.90, std 5.29, hubs of 168 = 31 sigma, train_small_graphs.py:
+                122-133): the k-net sees the normalised degree of a hub as an input of 31; within a few steps its learned degree is
+                in the hundreds (observed: 650 after 60 steps) -- no fixed list width covers that (the reference ramps over its
+                dense row).  The module refuses instead of truncating: check_ell_bound() raises.  On such graphs the candidates are
+                the graph's edges (the reference's configs), where rows wider than the list take the CSR form, exact for any degree
+                (test_rows_wider_than_the_ell_go_through_csr)."""
+    import dgg_amd
+    from argparse import Namespace
+    N, d, h, C = 3000, 64, 64, 7
+    g = torch.Generator().manual_seed(5)
+    if prior == "bounded":
+        mean, std = 3.899, 5.288
+        deg = 24 + 16 * torch.rand(N, generator=g)
+    else:
+        mean, std, dmax = 3.899, 5.288, 168
+        s2 = np.log(1.0 + (std / mean) ** 2)                           # log-normal with the data set's mean / std, clipped at its maximum
+        deg = torch.exp(torch.randn(N, generator=g) * np.sqrt(s2) + (np.log(mean) - 0.5 * s2)).clamp(1.0, float(dmax))
+        deg[:3] = float(dmax)                                          # the hubs are there
+    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=mean, deg_std=std, dgg_mode_edge_net="u-v-dist",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
+    torch.manual_seed(11)
+    m = dgg_amd.GCN_DGG(nfeat=d, nhidden=h, nclass=C, args=args).to(dev).train()
+    x = torch.randn(N, d, generator=g)
+    y = (x[:, :C] + 0.3 * torch.randn(N, C, generator=g)).argmax(1).to(dev)
+    x = x.to(dev)
+    A = dgg_amd.AllPairs(deg.to(dev))
+    opt = torch.optim.Adam([{"params": m.params1, "weight_decay": 0.01}, {"params": m.params2, "weight_decay": 5e-4}], lr=0.01)
+    first_over = None
+    for step in range(60):
+        opt.zero_grad()
+        logp, adj, _ = m(x, A)
+        torch.nn.functional.nll_loss(logp, y).backward()
+        over = bool((adj.k.detach() + 8.5 > 64.0).any())
+        if over:                                                       # the step at which a row first loses a weighted rank: not silent
+            with pytest.raises(RuntimeError, match="ell_width"):
+                m.dggs[0].check_ell_bound()
+            first_over = (step, float(adj.k.max()))
+            break
+        m.dggs[0].check_ell_bound()
+        opt.step()
+    print(prior, "prior: learned degrees first exceed the list at (step, k_max) =", first_over)
+    if prior == "bounded":
+        assert first_over is None or first_over[0] >= 1, "at initialisation the bounded prior is inside the list"
+    else:
+        assert first_over is not None, "hubs at 31 sigma of the degree prior outgrow any fixed list within a few steps"
+
+
 @pytest.mark.parametrize("perturb", [False, True])
 def test_rows_wider_than_the_ell_go_through_csr(dev, perturb):
     """Hubs with 168 candidates (Cora's widest rows) and a degree prior of 90: ceil(k + 8.5) ~ 100 ranks carry weight, more than the
