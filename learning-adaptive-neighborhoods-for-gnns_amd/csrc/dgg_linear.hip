@@ -829,8 +829,12 @@ void launch_linear_fwd_n(const float *x, int64_t N, int d, const float *W, const
 
 int launch_linear_fwd(const float *x, int64_t N, int d, const float *W, const float *b, int out, int w_layout, int act,
                       float *y, hipStream_t st) {
+    // (wide layers on few rows -- the latent-2048 k-net of a 2 000-node PPI graph: 18 row tiles x 8 column tiles of 128 = 144
+    //  workgroups for 256 CUs -- take 64-column tiles: twice the workgroups, x re-read from L2; DGG_LIN_NACC1=<blocks> forces a shape)
+    static const int nacc_env = [] { const char *e = getenv("DGG_LIN_NACC1"); return e ? atoi(e) : 0; }();
+    const int64_t wg4 = ((N + 127) / 128) * ((out + 127) / 128);
     if (out <= 32) launch_linear_fwd_n<1>(x, N, d, W, b, out, w_layout, act, y, st);
-    else if (out <= 64) launch_linear_fwd_n<2>(x, N, d, W, b, out, w_layout, act, y, st);
+    else if (out <= 64 || nacc_env == 2 || (nacc_env == 0 && wg4 < 256)) launch_linear_fwd_n<2>(x, N, d, W, b, out, w_layout, act, y, st);
     else launch_linear_fwd_n<4>(x, N, d, W, b, out, w_layout, act, y, st);
     return dgg_check_launch("linear_fwd");
 }

@@ -1700,11 +1700,13 @@ def test_ranked_search_walk_depth_is_watched(dev, regime):
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
         adj = m(x, prior)                                      # first forward: pilot
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        adj = m(x, prior)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        dt = 1e9
+        for _ in range(3):                                     # (best of three: the bound is on the kernels, not on a cold allocator)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            adj = m(x, prior)
+            torch.cuda.synchronize()
+            dt = min(dt, time.perf_counter() - t0)
     st = m._asym_state
     warned = any("walks deep" in str(w_.message) for w_ in rec)
     print(f"{regime}: pilot {st['probe']}, warned {warned}, forward {dt * 1e3:.2f} ms")
