@@ -359,8 +359,13 @@ int dgg_partp_build_phase(const int32_t *idx, const float *w, const float *val, 
  * recs[nodeptr[j] .. nodeptr[j+1])), out[2] = records in node order (16 bytes each: row*64 + r, j, bits of w_ir rs_i^-1/2, bits of the
  * score), out[3] = number of buckets, out[4] = bucket width in nodes, out[5] = rows per counting workgroup. */
 int dgg_partp_describe(int64_t rows, int K, int64_t ncols, int64_t *out6);
+/* 1 when the partition of a block of `rows` rows carries the slot -> record map (blocks whose record-ordered dA fits an XCD's L2): the
+ * backward may then skip the row-major dA (dA = NULL in dgg_ell_conv_bwd_partp[_ext] and dgg_softk_edge_bwd_partp[_phase]) */
+int dgg_partp_has_map(int64_t rows);
 /* dgg_ell_conv_bwd_part on a payload partition (ahat_ir = record payload * rs_j^-1/2, bit-identical to dgg_ell_normalize_fwd);
- * also writes dA_rec [rows*K] = dA in record order.  dA, dH, da: caller zeroes. */
+ * also writes dA_rec [rows*K] = dA in record order.  dA, dH, da: caller zeroes.  dA may be NULL: the row-major copy (one scattered
+ * 4-byte store per entry) is then not written, and dgg_softk_edge_bwd_partp -- called with dA = NULL as well -- reads dA_rec through the
+ * slot -> record map the partition's sort leaves in its workspace. */
 int dgg_ell_conv_bwd_partp(const float *G, const float *H, int64_t rows, int K, int F, const void *partp_ws, int64_t ncols,
                            const float *rs, float *dA, float *dA_rec, float *dH, float *da, void *stream);
 /* the same when the normalised adjacency has OTHER consumers besides this aggregation (GCN_DGG hands it to its second layer as well,

@@ -83,6 +83,7 @@ PROTOTYPES = {
                                 _vp, _vp, _vp],
     "dgg_ell_conv_bwd_part": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "dgg_partp_ws_bytes": [_i64, _i32, _i64],
+    "dgg_partp_has_map": [_i64],
     "dgg_partp_describe": [_i64, _i32, _i64, _vp],
     "dgg_partp_build_phase": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _i32, _vp],
     "dgg_softk_edge_bwd_partp_phase": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _i32, _i32, _vp, _i64,

@@ -180,6 +180,10 @@ struct SoftkArgs {
     const float *ahat_rows;
     // payload partition: no slot map, no coefficient hand-over; instead (a_i, d loss / d rs_i, k_i, 0) per row for edge_bwd_node
     float4 *rowinfo;
+    // payload partition, dA == NULL: the row-major dA was never written (conv_bwd_node's 4.1 M scattered stores); entry (i, r) reads
+    // dA_rec[recpos[i*64 + r]] instead -- the map is written by pp_sort, which runs beside the forward aggregation
+    const int *recpos;
+    const float *dA_rec;
 };
 template <int H, bool FUSE, bool PAY = false>
 __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ xp, int64_t rows, const int32_t *__restrict__ idx,
@@ -197,7 +201,9 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
     float gl;
     if (FUSE) {                                                  // same arithmetic as softk_bwd_kernel (dgg_ell.hip), modes 0 / 1
         const int lc = lane < K ? lane : K - 1;
-        float dw = sk.dA[i * K + lc];
+        const bool viamap = PAY && sk.recpos != nullptr;         // (kernel-uniform)
+        float dw = viamap ? 0.0f : sk.dA[i * K + lc];
+        const int rpos = viamap ? sk.recpos[i * 64 + lc] : 0;
         const bool live = lane < K && jl >= 0;
         if (sk.normalized) {
             const float rsi = sk.rs[gi];
@@ -207,6 +213,7 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
                 const float ah = lane < K ? sk.ahat_rows[i * K + lane] : 0.0f;
                 // entries outside the partition (ahat == 0: empty slot or saturated ramp) were never written by conv_bwd_node:
                 // with the payload partition dA is NOT zero-filled by the caller, so their dA is masked here
+                if (viamap) dw = sk.dA_rec[ah != 0.0f ? rpos : 0];   // (unconditional gather; entries outside the partition have no map entry)
                 if (PAY && ah == 0.0f) dw = 0.0f;
                 float rp = dw * ah;
                 rp = wave_sum_dpp(rp, lane);
@@ -585,7 +592,7 @@ __global__ __launch_bounds__(256) void conv_bwd_node(const float *__restrict__ G
             if constexpr (EXT) dot += ext[b];
             // (write-through store that does not stay in the XCD's L2: these 4.1 M scattered dwords are never touched again by this
             //  kernel, and left in L2 they push out the G rows the gathers hit: 202 -> 193 us; nontemporal: 196)
-            if (src[b] >= 0 && c4 == 0)
+            if (dA && src[b] >= 0 && c4 == 0)                    // (dA == NULL: the row kernel reads dA_rec through the slot -> record map)
                 __hip_atomic_store(&dA[(int64_t)(src[b] >> 6) * K + (src[b] & 63)], dot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // back to the lane that loaded the record (lane q = b*NPI + slot): record order, one coalesced store per iteration
             const float tq = __shfl(dot, (lane % NPI) * LPR, 64);
@@ -743,7 +750,7 @@ __global__ __launch_bounds__(256) void conv_bwd_nodeg(const float *__restrict__ 
             dot += __uint_as_float(xor_shfl<2>(__float_as_uint(dot), lane));
             dot += __uint_as_float(xor_shfl<1>(__float_as_uint(dot), lane));
             if (src[b] >= 0 && c4 == (b % LPR)) {
-                __hip_atomic_store(&dA[(int64_t)(src[b] >> 6) * K + (src[b] & 63)], dot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (see conv_bwd_node)
+                if (dA) __hip_atomic_store(&dA[(int64_t)(src[b] >> 6) * K + (src[b] & 63)], dot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (see conv_bwd_node)
                 dA_rec[e0 + b] = dot;
             }
             acc.x = fmaf(cf[b], g[b].x, acc.x); acc.y = fmaf(cf[b], g[b].y, acc.y);
@@ -935,14 +942,22 @@ inline int pp_width(int64_t rows, int K, int64_t ncols) {
 inline uint32_t pp_recip(int width) { return (uint32_t)((((uint64_t)1 << 32) + (uint64_t)width - 1) / (uint64_t)width); }
 __device__ __forceinline__ int pp_bucket(int j, uint32_t rcp) { return (int)__umulhi((uint32_t)j, rcp); }
 
-struct PartP2 {                    // workspace: [bstart NB+1][totals NB][nodeptr NB*PBS+1][T nwg*NB][ainv ncols][tmp][recs]
+struct PartP2 {                    // workspace: [bstart NB+1][totals NB][nodeptr NB*PBS+1][T nwg*NB][ainv ncols][tmp][recs][recpos]
     int *bstart, *totals, *nodeptr, *T;
+    int *recpos;                   // [rows*64]: position of entry (row, r) among the node-ordered records (written by pp_sort for the
+                                   // active entries only): the row kernel of the score backward reads dA_rec through it
     float *ainv;                   // rs_j^-1/2 of every destination node (normalize_adj fused into the fill pass)
     int4 *tmp, *recs;
     int width;                     // destination nodes per bucket
     uint32_t rcp;                  // ceil(2^32 / width)
     int64_t nb, nwg;
 };
+// The slot -> record map is built (one more scattered 4-byte store per record in pp_sort) only for blocks whose record-ordered dA
+// fits an XCD's L2 -- where gathering through it beats the row-major scatter (see ShardedDGGConv._backward); DGG_DA_MAP=0/1 forces.
+static bool pp_builds_map(int64_t rows) {
+    static const int forced = [] { const char *e = getenv("DGG_DA_MAP"); return e ? atoi(e) : -1; }();
+    return forced >= 0 ? forced != 0 : rows * 64 * 4 <= (8 << 20);
+}
 inline size_t partp2_layout(PartP2 &p, void *ws, int64_t rows, int K, int64_t ncols) {
     p.width = pp_width(rows, K, ncols);
     p.rcp = pp_recip(p.width);
@@ -956,7 +971,8 @@ inline size_t partp2_layout(PartP2 &p, void *ws, int64_t rows, int K, int64_t nc
     p.T = reinterpret_cast<int *>(w + o); o += align256((size_t)p.nwg * p.nb * 4);
     p.ainv = reinterpret_cast<float *>(w + o); o += align256((size_t)ncols * 4);
     p.tmp = reinterpret_cast<int4 *>(w + o); o += align256((size_t)rows * K * sizeof(int4));
-    p.recs = reinterpret_cast<int4 *>(w + o); o += (size_t)rows * K * sizeof(int4);
+    p.recs = reinterpret_cast<int4 *>(w + o); o += align256((size_t)rows * K * sizeof(int4));
+    p.recpos = reinterpret_cast<int *>(w + o); o += (size_t)rows * 64 * sizeof(int);
     return o;
 }
 
@@ -1170,7 +1186,7 @@ __global__ __launch_bounds__(THREADS) void pp_fill(const int32_t *__restrict__ i
 
 // one workgroup per bucket: records -> node order; nodeptr for the bucket's nodes
 __global__ __launch_bounds__(PP_T) void pp_sort(const int *__restrict__ bstart, const int4 *__restrict__ tmp, int4 *__restrict__ recs,
-                                                int *__restrict__ nodeptr, int nb, int PBS) {
+                                                int *__restrict__ nodeptr, int *__restrict__ recpos, int nb, int PBS) {
     extern __shared__ int lds[];                                 // cnt[PBS], base[PBS], scratch[16]
     int *cnt = lds, *base = lds + PBS, *scratch = lds + 2 * PBS;
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -1213,7 +1229,11 @@ __global__ __launch_bounds__(PP_T) void pp_sort(const int *__restrict__ bstart, 
     if (inreg) {
 #pragma unroll
         for (int u = 0; u < PP_RPT; u++)
-            if (rec[u].y >= 0) recs[o0 + base[rec[u].y - b * PBS] + rank[u]] = rec[u];
+            if (rec[u].y >= 0) {
+                const int pos = o0 + base[rec[u].y - b * PBS] + rank[u];
+                recs[pos] = rec[u];
+                if (recpos) recpos[rec[u].x] = pos;
+            }
     } else {
         for (int q = tid; q < PBS; q += PP_T) cnt[q] = 0;
         __syncthreads();
@@ -1229,7 +1249,9 @@ __global__ __launch_bounds__(PP_T) void pp_sort(const int *__restrict__ bstart, 
             for (int u = 0; u < PP_UF; u++)
                 if (r[u].y >= 0) {
                     const int jl = r[u].y - b * PBS;
-                    recs[o0 + base[jl] + atomicAdd(&cnt[jl], 1)] = r[u];
+                    const int pos = o0 + base[jl] + atomicAdd(&cnt[jl], 1);
+                    recs[pos] = r[u];
+                    if (recpos) recpos[r[u].x] = pos;
                 }
         }
     }
@@ -1412,7 +1434,7 @@ int dgg_partp_build_phase(const int32_t *idx, const float *w, const float *val, 
     partp2_layout(p, ws, rows, K, ncols);
     const int nb = (int)p.nb, nwg = (int)p.nwg, pbs = p.width;
     if (phase == 2) {
-        hipLaunchKernelGGL(pp_sort, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr, nb, pbs);
+        hipLaunchKernelGGL(pp_sort, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr, pp_builds_map(rows) ? p.recpos : nullptr, nb, pbs);
         return dgg_check_launch("partp_build");
     }
 #define DGG_PP_PASS(TT)                                                                                                      \
@@ -1428,9 +1450,13 @@ int dgg_partp_build_phase(const int32_t *idx, const float *w, const float *val, 
     }
 #undef DGG_PP_PASS
     if (phase == 1) return dgg_check_launch("partp_build");
-    hipLaunchKernelGGL(pp_sort, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr, nb, pbs);
+    hipLaunchKernelGGL(pp_sort, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr, pp_builds_map(rows) ? p.recpos : nullptr, nb, pbs);
     return dgg_check_launch("partp_build");
 }
+
+// 1 when dgg_partp_build leaves the slot -> record map for a block of `rows` rows (then dgg_ell_conv_bwd_partp / dgg_softk_edge_bwd_partp
+// may be called with dA = NULL)
+int dgg_partp_has_map(int64_t rows) { return pp_builds_map(rows) ? 1 : 0; }
 
 int dgg_partp_describe(int64_t rows, int K, int64_t ncols, int64_t *out6) {
     if (!out6 || dgg_partp_ws_bytes(rows, K, ncols) == 0) return dgg_set_error(DGG_ERR_UNSUPPORTED, "partp_describe: no payload partition for this shape");
@@ -1518,14 +1544,20 @@ int dgg_softk_edge_bwd_partp_phase(const float *xp, int64_t rows, int h, const i
     if (mode != 0 && mode != 1) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: mode must be 0 (k_times) or 1 (k_only)");
     if (out_act != 0 && (out_act != 1 || mode != 0))             // (mode 1 launches no node kernel: nothing would apply the mask)
         return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: out_act is 0 or 1 (LeakyReLU), mode 0 only");
-    if (!k || !dA || !dA_rec || !dk || !rowinfo_ws || (normalized && (!rs || !da))) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: missing operand");
+    if (!k || !dA_rec || !dk || !rowinfo_ws || (normalized && (!rs || !da))) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: missing operand");
+    if (!dA && !(normalized && ahat_rows))       // (the slot -> record map covers the partition's entries; ahat_rows tells which those are)
+        return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: dA may be NULL only in the normalised form with ahat_rows");
+    if (!dA && !pp_builds_map(rows))
+        return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: dA is NULL but the partition of a block this large carries no slot -> record "
+                                          "map (dgg_partp_has_map)");
     if (ahat_rows && !normalized) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: ahat_rows is an operand of the normalised form");
     if (!partp_ws || dgg_partp_ws_bytes(rows, K, ncols) == 0) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp: no partition");
     if (rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     PartP2 p;
     partp2_layout(p, const_cast<void *>(partp_ws), rows, K, ncols);
-    const SoftkArgs sk{k, rs, dA, da, mode, normalized, nullptr, dk, ahat_rows, reinterpret_cast<float4 *>(rowinfo_ws)};
+    const SoftkArgs sk{k, rs, dA, da, mode, normalized, nullptr, dk, ahat_rows, reinterpret_cast<float4 *>(rowinfo_ws),
+                       dA ? nullptr : p.recpos, dA_rec};
     const unsigned gr = (unsigned)((rows + 3) / 4);
     const bool grouped = node_groups(rows * K, ncols);
 #define DGG_EDGE_PARTP(HH)                                                                                                  \

@@ -935,18 +935,21 @@ def partp_sort(part):
     part.args = None
 
 
-def conv_bwd_cols_p(idx, H, G, partp, rs, zero_dA=True, dA_ext=None):
+def conv_bwd_cols_p(idx, H, G, partp, rs, zero_dA=True, dA_ext=None, want_dA=True):
     """conv_bwd_cols on a payload partition -> dA [rows,K], dA_rec [rows*K], dH [ncols,F], da [ncols] (neighbour side); None when
     the kernel does not cover the shape.  zero_dA=False: entries outside the partition are left UNINITIALISED -- for a consumer that
     masks them itself (softk_edge_bwd_p with ahat_rows does).  dA_ext [rows,K] (optional): cotangent of the normalised adjacency from its
-    other consumers, added per record (dA / dA_rec / da then hold the totals)"""
+    other consumers, added per record (dA / dA_rec / da then hold the totals).  want_dA=False: the row-major dA is not written (returned
+    as None): softk_edge_bwd_p, given dA=None, reads dA_rec through the partition's slot -> record map"""
     N, K = idx.shape
     H, G = _chk(H), _chk(G)
     F = H.shape[1]
     if partp is None or F not in CONV_BWD_WIDTHS or H.data_ptr() % 16 or G.data_ptr() % 16 or H.shape[0] != partp.ncols:
         return None
     ncols = H.shape[0]
-    dA = _zeros((N, K), H.device) if zero_dA else torch.empty((N, K), device=H.device, dtype=torch.float32)   # entries outside the partition stay 0
+    dA = None
+    if want_dA:
+        dA = _zeros((N, K), H.device) if zero_dA else torch.empty((N, K), device=H.device, dtype=torch.float32)   # entries outside the partition stay 0
     # one wavefront per destination node owns dH_j / da_j: plain stores for every node, no zero fill
     # (an EMPTY row shard launches nothing: the outputs the other ranks reduce must then be zeros, not uninitialised memory)
     alloc = torch.zeros if N == 0 else torch.empty
@@ -968,7 +971,8 @@ def softk_edge_bwd_p(xp, idx, val, k, dA, dA_rec, rs, da, row0, t, perturb, mode
     """softk_edge_bwd on a payload partition -> dxp [Nglobal,h], dk [N]; None when it does not apply.  out_act=ACT_LEAKY (mode 0):
     dxp comes back multiplied by LeakyReLU'(xp), the gradient of the pre-activation of the layer that produced xp.
     phase=1: the row kernel only -> (dxp, dk, state): dk is complete (the k-net backward can start, e.g. on another stream);
-    phase=2 with that `state`: the per-destination kernel completes dxp."""
+    phase=2 with that `state`: the per-destination kernel completes dxp.  dA=None (normalised form with ahat_rows): the row kernel
+    takes an entry's cotangent from dA_rec through the partition's slot -> record map (conv_bwd_cols_p(want_dA=False))."""
     xp = _chk(xp)
     Ng, h = xp.shape
     N, K = idx.shape
@@ -982,7 +986,7 @@ def softk_edge_bwd_p(xp, idx, val, k, dA, dA_rec, rs, da, row0, t, perturb, mode
         rowinfo = torch.empty((N, 4), device=xp.device, dtype=torch.float32)
         dk = torch.empty((N,), device=xp.device, dtype=torch.float32)
     pe = _probe_begin()
-    _lib.check(_lib.lib().dgg_softk_edge_bwd_partp_phase(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(k)), _ptr(rs), _ptr(_chk(dA)),
+    _lib.check(_lib.lib().dgg_softk_edge_bwd_partp_phase(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(k)), _ptr(rs), _ptr(None if dA is None else _chk(dA)),
                                                          _ptr(dA_rec), _ptr(da), _ptr(None if ahat_rows is None else _chk(ahat_rows)), K, row0, t,
                                                          int(perturb), mode, int(normalized), _ptr(partp.ws), Ng, _ptr(rowinfo), _ptr(dk),
                                                          _ptr(dxp), int(out_act), int(phase), _stream()), "softk_edge_bwd_partp")
@@ -1106,6 +1110,12 @@ def knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, save=True):
 
 
 KNET_MFMA_WIDTHS = (16, 32, 64)
+DA_MAP = True       # conv_bwd_cols_p(want_dA=False) + softk_edge_bwd_p(dA=None): see ShardedDGGConv._backward
+
+
+def partp_has_map(rows):
+    """the payload partition of a block of `rows` rows carries the slot -> record map (small blocks; DGG_DA_MAP=0/1 forces)"""
+    return bool(_lib.lib().dgg_partp_has_map(int(rows)))
 PREMASK = True      # softk_edge_bwd_p / knet_x_bwd_fused can return gradients of the PRE-activation (out_act): see ShardedDGGConv._premask
 
 

@@ -322,8 +322,15 @@ class ShardedDGGConv:
                 torch.cuda.current_stream().wait_stream(self._side_stream())
                 s["side_join"] = False
             # (dA of the entries outside the partition is masked by the row kernel -- ahat_rows is 0 there -- so it is not zero-filled)
-            pc = kern.conv_bwd_cols_p(s["idx"], s["H"], G, partp, s["rs"], zero_dA=False) if dA_ext is None else \
-                kern.conv_bwd_cols_p(s["idx"], s["H"], G, partp, s["rs"], zero_dA=False, dA_ext=dA_ext)
+            # Small graphs (the record-ordered dA fits an XCD's L2: Pubmed, 5 MB): no row-major dA -- the row kernel gathers the
+            # record-ordered copy through the slot -> record map the partition's sort left (Pubmed step 0.359 -> 0.349 ms).  At
+            # N = 100 000 (25.6 MB) the 4.1 M four-byte gathers cost the row kernel more (+70 us) than the scattered stores cost the
+            # node kernel (-47 us): 1.264 -> 1.285 ms, so large graphs keep the scattered row-major copy.  DGG_DA_MAP=0/1 forces one.
+            use_map = getattr(kern, "DA_MAP", False) and kern.partp_has_map(s["idx"].shape[0])
+            kw = {"want_dA": False} if use_map else {}
+            if dA_ext is not None:
+                kw["dA_ext"] = dA_ext
+            pc = kern.conv_bwd_cols_p(s["idx"], s["H"], G, partp, s["rs"], zero_dA=False, **kw)
             assert pc is not None
             dA, dA_rec, dH, da = pc
             if self._hyb() and self.coll:           # dH [N,F] partial is complete here and needed only by the last kernel of the step
