@@ -13,6 +13,8 @@
 #include "dgg_common.h"
 #include "dgg_api_internal.h"
 
+#include <cstdlib>
+
 using namespace dgg;
 
 namespace {
@@ -145,14 +147,11 @@ __global__ __launch_bounds__(256) void edgelist_topk_kernel(
 // the same ascending fmaf chain, so the bits do not change.  With `kk` the ramp of select_top_k (dgm.py:1410-1420, softk_fwd_kernel's
 // arithmetic) is applied while the sorted list is still in registers: w and the row sums come out of the same launch.
 template <int H>
-__global__ __launch_bounds__(256) void edgelist_topk_vec(
-    const float *__restrict__ xp, int64_t N, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, float t,
+__device__ __forceinline__ void edgelist_row_full(
+    const int64_t i, const int lane, const float *__restrict__ xp, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, float t,
     int noise_mode, const float *__restrict__ G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *__restrict__ idx,
     float *__restrict__ val, const float *__restrict__ kk, int mode, float *__restrict__ w, float *__restrict__ rs,
     int32_t *__restrict__ overflow) {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + dgg::wave_id();
-    if (i >= N) return;
     const bool perturb = noise_mode != 0, sym = noise_mode == 3;
     const float4 *xi4 = reinterpret_cast<const float4 *>(xp + i * H);
     uint64_t list = DGG_EMPTY_KEY;
@@ -215,6 +214,119 @@ __global__ __launch_bounds__(256) void edgelist_topk_vec(
         // the ELL keeps K candidates of a row: exact while the ramp's support k + 8.5 fits or the row has no more candidates than that
         if (overflow && lane == 0 && e1 - e0 > K && kk[i] + 8.5f > (float)K) atomicOr(overflow, 1);
     }
+}
+
+// A citation graph has ~5 candidates a row: a wavefront per row keeps 5 of 64 lanes busy and the launch is 20 000 wavefronts of
+// dependent loads (rowptr -> col -> rows) -- 28 us on the Pubmed shape.  Here the first `npack` workgroups take FOUR rows per
+// wavefront, sixteen lanes each, and settle the rows with at most 16 candidates: the sort is the 16-lane part of the bitonic
+// network (DPP only), the ramp and the row sum stay inside the group -- adding the zeros of lanes 16..63 in the full butterfly
+// is exact, so the row sums keep their bits.  The remaining workgroups are one wavefront per row with the full-width code above and
+// leave at once unless their row is wider than 16 (5 % of Pubmed's rows; walking those inside the packed wavefronts, one after
+// the other, made the slowest wavefront -- four rows, one of them a hub of 300 -- the whole launch: 45 us).
+template <int H>
+__global__ __launch_bounds__(256) void edgelist_topk_pack4(
+    const float *__restrict__ xp, int64_t N, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, float t,
+    int noise_mode, const float *__restrict__ G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *__restrict__ idx,
+    float *__restrict__ val, const float *__restrict__ kk, int mode, float *__restrict__ w, float *__restrict__ rs,
+    int32_t *__restrict__ overflow, unsigned npack) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15;
+    if (blockIdx.x >= npack) {                                    // one wavefront per row: the rows wider than a lane group
+        const int64_t iw = (int64_t)(blockIdx.x - npack) * (blockDim.x >> 6) + dgg::wave_id();
+        if (iw >= N || rowptr[iw + 1] - rowptr[iw] <= 16) return;
+        edgelist_row_full<H>(iw, lane, xp, rowptr, col, t, noise_mode, G, ldG, s0, s1, K, idx, val, kk, mode, w, rs, overflow);
+        return;
+    }
+    const int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + dgg::wave_id()) * 4;
+    if (i0 >= N) return;
+    const int64_t i = i0 + g;
+    const int64_t e0 = i < N ? rowptr[i] : 0;
+    const int n = i < N ? (int)(rowptr[i + 1] - e0) : 17;
+    const bool rowok = n <= 16;                                   // this group's row is settled here (else: by its own wavefront, or beyond N)
+    const bool perturb = noise_mode != 0, sym = noise_mode == 3;
+    const bool have = rowok && l < n;
+    const int32_t j = have ? col[e0 + l] : 0;
+    const float4 *xi4 = reinterpret_cast<const float4 *>(xp + (rowok ? i : 0) * H);
+    const float4 *xj4 = reinterpret_cast<const float4 *>(xp + (int64_t)j * H);
+    float d2 = 0.0f;
+    constexpr int CH = H / 4 < 8 ? H / 4 : 8;                     // float4s of each operand in flight per lane
+#pragma unroll
+    for (int c0 = 0; c0 < H / 4; c0 += CH) {
+        float4 v[CH], a[CH];
+#pragma unroll
+        for (int u = 0; u < CH; u++) { v[u] = xj4[c0 + u]; a[u] = xi4[c0 + u]; }
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+            float df = __fadd_rn(a[u].x, -v[u].x);
+            d2 = __fmaf_rn(df, df, d2);
+            df = __fadd_rn(a[u].y, -v[u].y);
+            d2 = __fmaf_rn(df, df, d2);
+            df = __fadd_rn(a[u].z, -v[u].z);
+            d2 = __fmaf_rn(df, df, d2);
+            df = __fadd_rn(a[u].w, -v[u].w);
+            d2 = __fmaf_rn(df, df, d2);
+        }
+    }
+    uint64_t key = DGG_EMPTY_KEY;
+    if (have) {
+        const float dist = c_sqrt(d2);
+        float gn = 0.0f;
+        if (noise_mode == 1) gn = G[i * ldG + j];
+        else if (noise_mode >= 2) gn = pair_noise(s0, s1, (uint32_t)i, (uint32_t)j, sym);
+        key = make_key(score_from_dist(dist, t, perturb, gn), j);
+    }
+    // descending sort inside every group of 16 lanes: blocks of 2, 4, 8 as in wave_sort, the last merge with the final direction
+    key = bitonic_block<2, 1, true>(key, lane);
+    key = bitonic_block<4, 2, true>(key, lane);
+    key = bitonic_block<8, 4, true>(key, lane);
+    key = bitonic_block<64, 8, true>(key, lane);                  // (KB = 64: "up" everywhere; distances 8, 4, 2, 1 stay inside the group)
+    const bool empty = key == DGG_EMPTY_KEY;
+    const float sc = empty ? 0.0f : key_val(key);
+    if (rowok) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {                             // the group's 16 ranks, then the empty tail of the row
+            const int r = l + 16 * q;
+            if (r < K) {
+                idx[i * K + r] = (q == 0 && !empty) ? key_col(key) : -1;
+                val[i * K + r] = q == 0 ? sc : 0.0f;
+            }
+        }
+    }
+    if (kk) {
+        float wv = 0.0f;
+        if (rowok && l < K) {
+            const float f = c_ramp((float)l, kk[i]);
+            float v = f;
+            if (mode == 0 || mode == 3) {
+                const float a = __fmul_rn(sc, f);
+                v = mode == 0 ? a : __fadd_rn(__fadd_rn(f, -a), a);
+            }
+            wv = empty ? 0.0f : v;
+        }
+        if (rowok) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int r = l + 16 * q;
+                if (r < K) w[i * K + r] = q == 0 ? wv : 0.0f;
+            }
+        }
+        float sm = wv;                                            // wave_sum_butterfly's last four steps (the first two add exact zeros)
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) sm = __fadd_rn(sm, __shfl_xor(sm, off, 64));
+        if (rowok && l == 0) rs[i] = sm;
+        if (overflow && rowok && l == 0 && n > K && kk[i] + 8.5f > (float)K) atomicOr(overflow, 1);      // (lists narrower than 16)
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void edgelist_topk_vec(
+    const float *__restrict__ xp, int64_t N, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, float t,
+    int noise_mode, const float *__restrict__ G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *__restrict__ idx,
+    float *__restrict__ val, const float *__restrict__ kk, int mode, float *__restrict__ w, float *__restrict__ rs,
+    int32_t *__restrict__ overflow) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + dgg::wave_id();
+    if (i >= N) return;
+    edgelist_row_full<H>(i, lane, xp, rowptr, col, t, noise_mode, G, ldG, s0, s1, K, idx, val, kk, mode, w, rs, overflow);
 }
 
 // same for latent widths beyond 128 (PPI: 2048): the candidates of a row are scored ONE AT A TIME by the whole wavefront --
@@ -357,13 +469,19 @@ inline bool edgelist_vec_ok(const float *xp, int h) {
 void launch_edgelist_vec(const float *xp, int64_t N, int h, const int64_t *rowptr, const int32_t *col, float t, int noise_mode,
                          const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, const float *k,
                          int mode, float *w, float *rs, int32_t *overflow, hipStream_t st) {
-    const dim3 grid((unsigned)((N + 3) / 4)), block(256);
-#define DGG_EL_VEC(HH) hipLaunchKernelGGL(edgelist_topk_vec<HH>, grid, block, 0, st, xp, N, rowptr, col, t, noise_mode, G, ldG, s0, s1, K, \
-                                          idx, val, k, mode, w, rs, overflow)
-    if (h == 16) DGG_EL_VEC(16);
-    else if (h == 32) DGG_EL_VEC(32);
-    else if (h == 64) DGG_EL_VEC(64);
-    else DGG_EL_VEC(128);
+    // (four rows per wavefront -- see edgelist_topk_pack4; DGG_EL_PACK=0 keeps a wavefront per row)
+    static const bool pack = [] { const char *e = getenv("DGG_EL_PACK"); return !e || atoi(e) != 0; }();
+    const unsigned npack = (unsigned)((N + 15) / 16);
+    const dim3 grid((unsigned)(pack ? npack + (N + 3) / 4 : (N + 3) / 4)), block(256);
+#define DGG_EL_VEC(HH)                                                                                                       \
+    if (pack) hipLaunchKernelGGL(edgelist_topk_pack4<HH>, grid, block, 0, st, xp, N, rowptr, col, t, noise_mode, G, ldG, s0, s1, K, idx, val, \
+                                 k, mode, w, rs, overflow, npack);                                                           \
+    else hipLaunchKernelGGL(edgelist_topk_vec<HH>, grid, block, 0, st, xp, N, rowptr, col, t, noise_mode, G, ldG, s0, s1, K, idx, val, k, \
+                            mode, w, rs, overflow)
+    if (h == 16) { DGG_EL_VEC(16); }
+    else if (h == 32) { DGG_EL_VEC(32); }
+    else if (h == 64) { DGG_EL_VEC(64); }
+    else { DGG_EL_VEC(128); }
 #undef DGG_EL_VEC
 }
 }  // namespace
