@@ -465,6 +465,9 @@ class DGG_LearnableK_debug(nn.Module):
             return None
         if isinstance(in_adj, AllPairs):
             cand, deg, rowptr = None, in_adj.prior_degree, None
+            if self.__dict__.get("_ap_wide", {}).get("on") or (getattr(a, "dgg_wide_rows", "auto") == "csr" and
+                                                               x.shape[0] <= int(getattr(a, "dgg_allpairs_csr_max", 8192))):
+                return None                                   # (already known: this graph's learned degrees need every column ranked)
         else:
             if isinstance(in_adj, EllAdjacency):
                 in_adj = in_adj.to_sparse().detach()
@@ -501,6 +504,8 @@ class DGG_LearnableK_debug(nn.Module):
             # rows wider than the ELL with learned degrees beyond it: the CSR form from here on (this discarded forward raised the flag)
             layer.overflow.zero_()
             return None
+        if cand is None and self._allpairs_wide(N, k):
+            return None                                       # learned degrees beyond the list: the modules' CSR form (every column ranked)
         if cand is None:
             self._track_overflow(k, None)
         elif __import__("os").environ.get("DGG_STRICT_BOUND") == "1":
@@ -558,12 +563,43 @@ class DGG_LearnableK_debug(nn.Module):
             ent[3] += 1
         return ent[2]
 
-    def _csr_soft_adjacency(self, x, in_adj, k, noise_mode, G, seed, mode):
+    # ---- all-pairs candidates whose learned degrees outgrow the 64-wide list --------------------------------------------------
+    def _allpairs_pattern(self, N, device):
+        """the complete candidate set as a CSR pattern (rowptr, col, erow): what the reference's dense [N,N] rows are"""
+        ent = self.__dict__.get("_ap_pattern")
+        if ent is None or ent[0] != (N, device):
+            ar = torch.arange(N, device=device, dtype=torch.int32)
+            pat = (torch.arange(N + 1, device=device, dtype=torch.int64) * N, ar.repeat(N), ar.repeat_interleave(N))
+            ent = self.__dict__["_ap_pattern"] = ((N, device), pat)
+        return ent[1]
+
+    def _allpairs_wide(self, N, k):
+        """All-pairs candidates keep 64 ranks per row, exact while k_i + 8.5 <= 64; the learned degree is unbounded (dgm.py:1580-1584)
+        and training moves it past that within a few steps (test_learned_degrees_of_a_trained_model_and_the_all_pairs_list).  Graphs
+        of at most `args.dgg_allpairs_csr_max` (8192) nodes -- the sizes at which the reference's dense [N,N] formulation runs at
+        all -- then take select_top_k on the COMPLETE candidate pattern in CSR form (every column ranked, any degree: N^2 entries,
+        a few milliseconds at N = 3000), as rows wider than the list do for edge-list candidates.  args.dgg_wide_rows: "auto"
+        (default: from the forward in which some k_i + 8.5 first exceeds the width, and from then on -- one flag read back per forward
+        while the list is still in use; a hipGraph capture replays the last decision), "csr" (always), "ell" (never: the bound is
+        enforced by check_ell_bound).  Larger graphs keep the list and the enforced bound."""
+        policy = getattr(self.args, "dgg_wide_rows", "auto")
+        if policy == "ell" or N > int(getattr(self.args, "dgg_allpairs_csr_max", 8192)):
+            return False
+        if policy == "csr":
+            return True
+        st = self.__dict__.setdefault("_ap_wide", {"on": False})
+        if not st["on"] and not torch.cuda.is_current_stream_capturing():
+            st["on"] = bool((k.detach() + 8.5 > float(self.ell_width)).any().item())
+        return st["on"]
+
+    def _csr_soft_adjacency(self, x, in_adj, k, noise_mode, G, seed, mode, pattern=None, deg=None):
         """select_top_k on the CSR pattern of in_adj (ops.CsrSoftkFn: rows of any width, exact for any learned degree): edge
-        probabilities as in _scores_adjacency, then perturbation + rank + ramp per row."""
-        in_adj = in_adj.coalesce()
-        pattern = csr_pattern(in_adj)
-        _, _, deg = csr_candidates(in_adj)
+        probabilities as in _scores_adjacency, then perturbation + rank + ramp per row.  pattern / deg given (all-pairs candidates):
+        the complete pattern, no in_adj."""
+        if pattern is None:
+            in_adj = in_adj.coalesce()
+            pattern = csr_pattern(in_adj)
+            _, _, deg = csr_candidates(in_adj)
         We, be = self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias
         cfg = dict(cand=pattern, t=ops.T_DIST)
         if self.edge_prob_net_mode == "u-v-dist":
@@ -761,6 +797,11 @@ class DGG_LearnableK_debug(nn.Module):
         if cand is not None and not literal and self._wide_rows(in_adj, rowptr, k):
             # rows wider than the ELL and learned degrees that may exceed it: the CSR form (no width limit)
             return self._csr_soft_adjacency(x, in_adj, k, noise_mode, G, seed, cfg["mode"])
+        if cand is None and not literal and self.edge_prob_net_mode == "u-v-dist" and self._allpairs_wide(x.shape[0], k):
+            # learned degrees beyond the list on all-pairs candidates: every column ranked, CSR form (per-pair hash noise: the ranked
+            # generators produce a row's noise in decreasing order for a search that stops early -- here nothing stops early)
+            nm = {ops.NOISE_RANKED: ops.NOISE_HASH, ops.NOISE_RANKED_SYM: ops.NOISE_HASH_SYM}.get(noise_mode, noise_mode)
+            return self._csr_soft_adjacency(x, None, k, nm, G, seed, cfg["mode"], pattern=self._allpairs_pattern(x.shape[0], x.device), deg=deg)
         if self.edge_prob_net_mode == "u-v-dist" and xp_dual is not None:
             w, idx, val, rs = _DGGSoftAdjXpFn.apply(xp_dual, k, cfg)
         elif self.edge_prob_net_mode == "u-v-dist":
