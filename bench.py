@@ -796,6 +796,9 @@ def other_configs(a, dev):
         keep = ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "roofline", "cpu_baseline", "kernels_ms_per_step") + tuple(extra)
         d_ = {k_: o.get(k_) for k_ in keep if k_ in o}
         d_["workload"] = o["config"]["workload"]
+        for k_ in ("api", "gcn_dgg_model_ms_per_step", "selected_edges", "candidate_edges"):
+            if k_ in o["config"]:
+                d_[k_] = o["config"][k_]
         return d_
     try:
         if "pubmed" in only:
