@@ -539,24 +539,22 @@ __global__ __launch_bounds__(256) void conv_bwd_cols(const float *__restrict__ G
 // EXT: the adjacency is read by MORE consumers than this aggregation (GCN_DGG feeds the same normalised adjacency to its second
 // layer, model.py:1266-1290): their cotangent dA_ext [rows,K] (same slots as dA) is added to G_i . H_j per record, so that dA,
 // dA_rec and da carry the total and the score backward needs no second pass.
-template <int F, bool EXT = false>
-__global__ __launch_bounds__(256) void conv_bwd_node(const float *__restrict__ G, const float *__restrict__ Hm, int K, int64_t ncols,
-                                                     const int *__restrict__ nodeptr, const int4 *__restrict__ recs,
-                                                     const float *__restrict__ rs, float *__restrict__ dA, float *__restrict__ dA_rec,
-                                                     float *__restrict__ dH, float *__restrict__ da, const float *__restrict__ dA_ext = nullptr) {
+// Nodes with very many incoming edges (a citation graph's hubs: 300 on the Pubmed shape, where the whole kernel is 20 000 wavefronts
+// of ~5 records): `nmain` > 0 appends one WORKGROUP per node to the grid; the wavefront-per-node part then skips nodes with more than
+// NODE_LONG records and the appended workgroup of such a node (the others leave at once) walks a quarter of the records per wavefront
+// and meets in LDS.  Used for graphs of at most NODE_SPLIT_MAX nodes (the appended workgroups cost ~5 us per 100 000 nodes).
+constexpr int NODE_LONG = 128;
+constexpr int64_t NODE_SPLIT_MAX = 65536;
+
+template <int F, bool EXT>
+__device__ __forceinline__ void conv_bwd_walk(const float *__restrict__ G, int K, int pb, int pe, int p1, const int4 *__restrict__ recs,
+                                              const float4 hj, const float aj, float *__restrict__ dA, float *__restrict__ dA_rec,
+                                              const float *__restrict__ dA_ext, int lane, float4 &acc, float &sda) {
     constexpr int LPR = F / 4, NPI = 64 / LPR, NBT = 4, PER = NBT * NPI;          // PER records per iteration (<= 64)
-    const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
-    const int64_t j = (int64_t)blockIdx.x * 4 + dgg::wave_id();
-    if (j >= ncols) return;
-    const int p0 = nodeptr[j], p1 = nodeptr[j + 1];
-    const float4 hj = *reinterpret_cast<const float4 *>(Hm + j * F + 4 * c4);
-    const float rsj = rs[j];
-    const float aj = __fdiv_rn(1.0f, c_sqrt(rsj));                // as normalize_fwd_kernel: wa * aj == ahat bit for bit
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float sda = 0.0f;
-    for (int e0 = p0; e0 < p1; e0 += PER) {
-        // lane l: record e0 + l (unconditional, clamped load; a lane past the node's range marks its copy invalid)
-        const bool have = lane < PER && e0 + lane < p1;
+    const int c4 = lane % LPR, slot = lane / LPR;
+    for (int e0 = pb; e0 < pe; e0 += PER) {
+        // lane l: record e0 + l (unconditional, clamped load; a lane past the range marks its copy invalid)
+        const bool have = lane < PER && e0 + lane < pe;
         int4 myrec = recs[have ? e0 + lane : p1 - 1];
         if (!have) myrec.y = -1;
         int src[NBT];
@@ -609,6 +607,48 @@ __global__ __launch_bounds__(256) void conv_bwd_node(const float *__restrict__ G
         acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
         sda += __shfl_xor(sda, off, 64);
     }
+}
+
+template <int F, bool EXT = false>
+__global__ __launch_bounds__(256) void conv_bwd_node(const float *__restrict__ G, const float *__restrict__ Hm, int K, int64_t ncols,
+                                                     const int *__restrict__ nodeptr, const int4 *__restrict__ recs,
+                                                     const float *__restrict__ rs, float *__restrict__ dA, float *__restrict__ dA_rec,
+                                                     float *__restrict__ dH, float *__restrict__ da, const float *__restrict__ dA_ext = nullptr,
+                                                     unsigned nmain = 0) {
+    constexpr int LPR = F / 4, PER = 4 * (64 / LPR);
+    __shared__ float4 part[4][LPR];
+    __shared__ float parts[4];
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR, wave = dgg::wave_id();
+    const bool longmode = nmain != 0 && blockIdx.x >= nmain;      // (block-uniform)
+    const int64_t j = longmode ? (int64_t)(blockIdx.x - nmain) : (int64_t)blockIdx.x * 4 + wave;
+    if (j >= ncols) return;
+    const int p0 = nodeptr[j], p1 = nodeptr[j + 1];
+    const bool islong = nmain != 0 && p1 - p0 > NODE_LONG;
+    if (islong != longmode) return;                               // (a long node belongs to its appended workgroup; block-uniform there)
+    const float4 hj = *reinterpret_cast<const float4 *>(Hm + j * F + 4 * c4);
+    const float rsj = rs[j];
+    const float aj = __fdiv_rn(1.0f, c_sqrt(rsj));                // as normalize_fwd_kernel: wa * aj == ahat bit for bit
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float sda = 0.0f;
+    if (!longmode) {
+        conv_bwd_walk<F, EXT>(G, K, p0, p1, p1, recs, hj, aj, dA, dA_rec, dA_ext, lane, acc, sda);
+    } else {
+        const int chunk = ((p1 - p0 + 4 * PER - 1) / (4 * PER)) * PER;
+        const int pb = p0 + wave * chunk, pe = pb + chunk < p1 ? pb + chunk : p1;
+        conv_bwd_walk<F, EXT>(G, K, pb < p1 ? pb : p1, pe, p1, recs, hj, aj, dA, dA_rec, dA_ext, lane, acc, sda);
+        if (slot == 0) part[wave][c4] = acc;
+        if (lane == 0) parts[wave] = sda;
+        __syncthreads();
+        if (wave != 0) return;
+        acc = part[0][c4];
+        sda = parts[0];
+#pragma unroll
+        for (int w_ = 1; w_ < 4; w_++) {
+            const float4 v = part[w_][c4];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            sda += parts[w_];
+        }
+    }
     if (slot == 0) *reinterpret_cast<float4 *>(dH + j * F + 4 * c4) = acc;
     if (da && lane == 0) da[j] = sda * sqrtf(rsj);
 }
@@ -622,20 +662,13 @@ __global__ __launch_bounds__(256) void conv_bwd_node(const float *__restrict__ G
 // dxp_j is the exclusive property of this wavefront: rows inside [row0, row0 + rows) already hold the row-side term written by
 // edge_bwd_rows (read-modify-write), the others are written plainly (no zero fill needed).
 template <int H>
-__global__ __launch_bounds__(256) void edge_bwd_node(const float *__restrict__ xp, int64_t ncols, const int *__restrict__ nodeptr,
-                                                     const int4 *__restrict__ recs, const float *__restrict__ dA_rec,
-                                                     const float4 *__restrict__ rowinfo, const float *__restrict__ rs, int normalized,
-                                                     int64_t row0, int64_t rows, float t, int perturb, float *__restrict__ dxp, int out_act) {
+__device__ __forceinline__ void edge_bwd_walk(const float *__restrict__ xp, int64_t j, int pb, int pe, int p1, const int4 *__restrict__ recs,
+                                              const float *__restrict__ dA_rec, const float4 *__restrict__ rowinfo, const float4 xj, const float aj,
+                                              int64_t row0, float t, int perturb, int lane, float4 &acc) {
     constexpr int LPR = H / 4, NPI = 64 / LPR, NBT = (32 / NPI) < 1 ? 1 : 32 / NPI, PER = NBT * NPI;   // 32 records per iteration
-    const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
-    const int64_t j = (int64_t)blockIdx.x * 4 + dgg::wave_id();
-    if (j >= ncols) return;
-    const int p0 = nodeptr[j], p1 = nodeptr[j + 1];
-    const float4 xj = *reinterpret_cast<const float4 *>(xp + j * H + 4 * c4);
-    const float aj = normalized ? __fdiv_rn(1.0f, c_sqrt(rs[j])) : 1.0f;
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (int e0 = p0; e0 < p1; e0 += PER) {
-        const bool have = lane < PER && e0 + lane < p1;
+    const int c4 = lane % LPR, slot = lane / LPR;
+    for (int e0 = pb; e0 < pe; e0 += PER) {
+        const bool have = lane < PER && e0 + lane < pe;
         const int ec = have ? e0 + lane : p1 - 1;                // unconditional, clamped loads
         int4 myrec = recs[ec];
         if (!have) myrec.y = -1;
@@ -688,6 +721,43 @@ __global__ __launch_bounds__(256) void edge_bwd_node(const float *__restrict__ x
     for (int off = LPR; off < 64; off <<= 1) {
         acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
         acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+    }
+}
+
+// (nmain: long nodes in appended workgroups, as conv_bwd_node)
+template <int H>
+__global__ __launch_bounds__(256) void edge_bwd_node(const float *__restrict__ xp, int64_t ncols, const int *__restrict__ nodeptr,
+                                                     const int4 *__restrict__ recs, const float *__restrict__ dA_rec,
+                                                     const float4 *__restrict__ rowinfo, const float *__restrict__ rs, int normalized,
+                                                     int64_t row0, int64_t rows, float t, int perturb, float *__restrict__ dxp, int out_act,
+                                                     unsigned nmain = 0) {
+    constexpr int LPR = H / 4, NPI = 64 / LPR, NBT = (32 / NPI) < 1 ? 1 : 32 / NPI, PER = NBT * NPI;
+    __shared__ float4 part[4][LPR];
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR, wave = dgg::wave_id();
+    const bool longmode = nmain != 0 && blockIdx.x >= nmain;      // (block-uniform)
+    const int64_t j = longmode ? (int64_t)(blockIdx.x - nmain) : (int64_t)blockIdx.x * 4 + wave;
+    if (j >= ncols) return;
+    const int p0 = nodeptr[j], p1 = nodeptr[j + 1];
+    const bool islong = nmain != 0 && p1 - p0 > NODE_LONG;
+    if (islong != longmode) return;
+    const float4 xj = *reinterpret_cast<const float4 *>(xp + j * H + 4 * c4);
+    const float aj = normalized ? __fdiv_rn(1.0f, c_sqrt(rs[j])) : 1.0f;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (!longmode) {
+        edge_bwd_walk<H>(xp, j, p0, p1, p1, recs, dA_rec, rowinfo, xj, aj, row0, t, perturb, lane, acc);
+    } else {
+        const int chunk = ((p1 - p0 + 4 * PER - 1) / (4 * PER)) * PER;
+        const int pb = p0 + wave * chunk, pe = pb + chunk < p1 ? pb + chunk : p1;
+        edge_bwd_walk<H>(xp, j, pb < p1 ? pb : p1, pe, p1, recs, dA_rec, rowinfo, xj, aj, row0, t, perturb, lane, acc);
+        if (slot == 0) part[wave][c4] = acc;
+        __syncthreads();
+        if (wave != 0) return;
+        acc = part[0][c4];
+#pragma unroll
+        for (int w_ = 1; w_ < 4; w_++) {
+            const float4 v = part[w_][c4];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
     }
     if (slot == 0) {
         float4 *o = reinterpret_cast<float4 *>(dxp + j * H + 4 * c4);
@@ -1473,6 +1543,11 @@ int dgg_partp_describe(int64_t rows, int K, int64_t ncols, int64_t *out6) {
 
 // which node kernel: a group of lanes per node when the lists are short (fewer than 16 records per node on average; a rank of G
 // holds 64/G of them), a wavefront per node otherwise.  DGG_NODE_GROUPS=0/1 forces one (measurement only).
+// long nodes in appended workgroups (conv_bwd_node / edge_bwd_node): graphs of at most NODE_SPLIT_MAX nodes; DGG_NODE_SPLIT=0/1 forces
+static bool node_split(int64_t ncols) {
+    static const int forced = [] { const char *e = getenv("DGG_NODE_SPLIT"); return e ? atoi(e) : -1; }();
+    return forced >= 0 ? forced != 0 : ncols <= NODE_SPLIT_MAX;
+}
 static bool node_groups(int64_t nrec, int64_t ncols) {
     static const int forced = [] { const char *e = getenv("DGG_NODE_GROUPS"); return e ? atoi(e) : -1; }();
     return forced >= 0 ? forced != 0 : nrec < 16 * ncols;
@@ -1499,16 +1574,19 @@ int dgg_ell_conv_bwd_partp_ext(const float *G, const float *H, int64_t rows, int
     partp2_layout(p, const_cast<void *>(partp_ws), rows, K, ncols);
     hipStream_t st = (hipStream_t)stream;
     const bool grouped = !dA_ext && node_groups(rows * K, ncols);
+    const unsigned nmain = (unsigned)((ncols + 3) / 4);
+    const bool split = node_split(ncols);                         // long nodes in appended workgroups (see conv_bwd_node)
+    const dim3 gridn(split ? nmain + (unsigned)ncols : nmain);
 #define DGG_CONV_COLS_P(FF)                                                                                                \
     if (dA_ext)                                                                                                            \
-        hipLaunchKernelGGL((conv_bwd_node<FF, true>), dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, G, H, K, ncols, p.nodeptr, p.recs, \
-                           rs, dA, dA_rec, dH, da, dA_ext);                                                                \
+        hipLaunchKernelGGL((conv_bwd_node<FF, true>), gridn, dim3(256), 0, st, G, H, K, ncols, p.nodeptr, p.recs,          \
+                           rs, dA, dA_rec, dH, da, dA_ext, split ? nmain : 0u);                                            \
     else if (grouped)                                                                                                      \
         hipLaunchKernelGGL((conv_bwd_nodeg<FF, 4>), dim3((unsigned)((ncols + 4 * (256 / FF) - 1) / (4 * (256 / FF)))), dim3(256), 0, st, G, H, K, \
                            ncols, p.nodeptr, p.recs, rs, dA, dA_rec, dH, da);                                              \
     else                                                                                                                   \
-        hipLaunchKernelGGL((conv_bwd_node<FF, false>), dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, G, H, K, ncols, p.nodeptr, p.recs, \
-                           rs, dA, dA_rec, dH, da, (const float *)nullptr)
+        hipLaunchKernelGGL((conv_bwd_node<FF, false>), gridn, dim3(256), 0, st, G, H, K, ncols, p.nodeptr, p.recs,         \
+                           rs, dA, dA_rec, dH, da, (const float *)nullptr, split ? nmain : 0u)
     switch (F) {
         case 16: DGG_CONV_COLS_P(16); break;
         case 32: DGG_CONV_COLS_P(32); break;
@@ -1560,6 +1638,8 @@ int dgg_softk_edge_bwd_partp_phase(const float *xp, int64_t rows, int h, const i
                        dA ? nullptr : p.recpos, dA_rec};
     const unsigned gr = (unsigned)((rows + 3) / 4);
     const bool grouped = node_groups(rows * K, ncols);
+    const unsigned nmain = (unsigned)((ncols + 3) / 4);
+    const bool split = node_split(ncols);
 #define DGG_EDGE_PARTP(HH)                                                                                                  \
     if (phase != 2)                                                                                                          \
         hipLaunchKernelGGL((edge_bwd_rows<HH, true, true>), dim3(gr), dim3(256), 0, st, xp, rows, idx, val, nullptr, K, row0, t, perturb, nullptr, \
@@ -1570,8 +1650,9 @@ int dgg_softk_edge_bwd_partp_phase(const float *xp, int64_t rows, int h, const i
                            ncols, p.nodeptr, p.recs, dA_rec, reinterpret_cast<const float4 *>(rowinfo_ws), rs, normalized, row0, rows, t, \
                            perturb, dxp, out_act);                                                                           \
     else if (mode == 0)                                                                                                      \
-        hipLaunchKernelGGL(edge_bwd_node<HH>, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st, xp, ncols, p.nodeptr, p.recs, dA_rec, \
-                           reinterpret_cast<const float4 *>(rowinfo_ws), rs, normalized, row0, rows, t, perturb, dxp, out_act)
+        hipLaunchKernelGGL(edge_bwd_node<HH>, dim3(split ? nmain + (unsigned)ncols : nmain), dim3(256), 0, st, xp, ncols, p.nodeptr, p.recs, \
+                           dA_rec, reinterpret_cast<const float4 *>(rowinfo_ws), rs, normalized, row0, rows, t, perturb, dxp, out_act,  \
+                           split ? nmain : 0u)
     switch (h) {
         case 16: DGG_EDGE_PARTP(16); break;
         case 32: DGG_EDGE_PARTP(32); break;
