@@ -427,7 +427,13 @@ def run_ppi(a, dev):
     # in-kernel rate of the layer GEMMs (event probes around the C-ABI calls inside running steps): flops of the probed calls /
     # their summed duration -- the figure to hold against the dense bf16 / fp32 MFMA peak
     pk = probe_steps(step, 2)
-    if a.bf16:
+    stack = a.bf16 and "gcnii_stack_fwd" in pk          # the fused stack (ops.GcniiStackBf16Fn): probes around the whole forward / backward of the stack
+    if stack:
+        # the stack's launches are not probed one by one (the GEMM share: profiles/r04_ppi_bf16_kernel_stats.csv): the line holds the
+        # layer-product flops against the stack's own forward + backward time
+        t_g = (pk["gcnii_stack_fwd"][0] + pk["gcnii_stack_bwd"][0]) * 1e-3
+        per_kernel = {"gcnii_stack_fwd": {"ms_per_step": pk["gcnii_stack_fwd"][0]}, "gcnii_stack_bwd": {"ms_per_step": pk["gcnii_stack_bwd"][0]}}
+    elif a.bf16:
         t_g = (pk["gemm_bf16_fwd"][0] + pk["gemm_bf16_bwd"][0]) * 1e-3
         per_kernel = {"gemm_bf16_fwd": {"ms_per_step": pk["gemm_bf16_fwd"][0], "tflops": gemm_flop / 3 / (pk["gemm_bf16_fwd"][0] * 1e-3) / 1e12},
                       "gemm_bf16_bwd": {"ms_per_step": pk["gemm_bf16_bwd"][0], "tflops": 2 * gemm_flop / 3 / (pk["gemm_bf16_bwd"][0] * 1e-3) / 1e12}}
@@ -440,10 +446,13 @@ def run_ppi(a, dev):
         "vs_baseline": None, "dtype": "bf16 GEMMs / f32 DGG" if a.bf16 else "f32", "data": "synthetic",
         "config": {"workload": f"PPI-shape multi-graph GCNIIppi_DGG: {len(sizes)} graphs of {int(sizes.min())}..{int(sizes.max())} nodes, "
                                f"d={d}, hidden={hid}, {L} variant GCNII layers, {C} labels, DGG latent {hid} on edge-list candidates "
-                               "(value counts candidate edges), module API under autograd, fwd+bwd, " + ("bf16 GCNII GEMMs" if a.bf16 else "fp32"),
+                               "(value counts candidate edges), module API under autograd, fwd+bwd, " +
+                               (("fused bf16 GCNII stack (ops.GcniiStackBf16Fn)" if stack else "bf16 GCNII GEMMs") if a.bf16 else "fp32"),
                    "graphs": len(sizes), "nodes_total": int(sizes.sum()), "graphs_per_s": len(sizes) / T,
                    "gcnii_gemm_tflops": gemm_flop / T / 1e12},
-        "roofline": {"bound": "mfma", "kernel": "GCNII layer GEMMs (gemm_nt_bf16: fwd with fused epilogue, d support, d weight)" if a.bf16 else
+        "roofline": {"bound": "mfma", "kernel": ("fused GCNII stack (ops.GcniiStackBf16Fn: aggregation, gemm_nt_bf16 products with fused epilogues, SDDMM, transposed "
+                                                 "SpMM of all layers): the layer-product flops over the stack's whole time" if stack else
+                                                 "GCNII layer GEMMs (gemm_nt_bf16: fwd with fused epilogue, d support, d weight)") if a.bf16 else
                                "linear_fwd_mfma / gemm_tn (fp32 MFMA)",
                      "achieved": gemm_flop / t_g / 1e12, "peak": 2500.0 if a.bf16 else FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": gemm_flop / t_g / 1e12 / (2500.0 if a.bf16 else FP32_PEAK_TFLOPS), "traffic": None,

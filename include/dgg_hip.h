@@ -458,6 +458,27 @@ int dgg_gemm_nt_bf16_rows2(const void *A, const void *A2, int64_t M1, const void
 int dgg_gcnii_dsupport_bf16(const void *Gp, const void *Wp, int64_t n, int64_t F, const float *g, float theta, float alpha, float *dhi,
                             float *dh0, void *stream);
 
+/* ---- the fused GCNII stack on bf16 operands (reference model.py:32-44 layer, 716-731 / 942-957 stack loop:
+ * dropout -> layer -> ReLU, h0 = the first activation, one adjacency for every layer).  Per layer, forward:
+ *   dgg_ell_spmm_fwd_bf16          hi = A xd and bf16(hi) in the same pass (no pack of the product operand)
+ *   dgg_gcnii_gemm_bf16_split_act  xd' = dropout(relu(theta [hi|h0] W + (1-theta)((1-alpha) hi + alpha h0) + xd)) -- the layer's
+ *                                  ReLU (model.py:724) and the NEXT layer's dropout (model.py:722) in the product's epilogue; the
+ *                                  dropout mask is counter-based (element e kept iff hash24(s0, s1, e) >= drop_p 2^24): the backward
+ *                                  reads it off the stored output (xd' != 0), nothing else is saved
+ *   dgg_dropout_hash               the same mask on a tensor no product produces (the stack's input h0; `accumulate`: out += ...,
+ *                                  used with the same seeds for the gradient flowing back through that dropout)
+ * backward:
+ *   dgg_gcnii_gout_pack            g = g_in * (xd' != 0 ? 1/(1-p) : 0) as fp32 and as the two bf16 operand packs (plain, transposed)
+ * ([d hi | d h0] is dgg_gcnii_dsupport_bf16 -- accumulating d h0 inside its epilogue measured 40 us slower per product than a separate
+ * add --, the weight gradient dgg_gemm_nt_bf16_rows2; d A and A^T d hi are dgg_ell_spmm_bwd / dgg_ell_spmm_t_part) */
+int dgg_ell_spmm_fwd_bf16(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, float *Y, void *Yb, void *stream);
+int dgg_gcnii_gemm_bf16_split_act(const void *S1, const void *S2, const void *Wt, int64_t n, int64_t F, int64_t K, int64_t F1, const float *hi,
+                                  const float *h0, const float *inp, float theta, float alpha, int relu, float drop_p, uint32_t s0,
+                                  uint32_t s1, float *out, void *stream);
+int dgg_dropout_hash(const float *x, int64_t n, float p, uint32_t s0, uint32_t s1, int accumulate, float *out, void *stream);
+int dgg_gcnii_gout_pack(const float *gin, const float *xd, float scale, int64_t n, int64_t F, float *g, void *Gp, void *GT, int64_t ldT,
+                        void *stream);
+
 /* ---- dense all-pairs alternates: DGG_LearnableK_SDD (dgm.py:259-351, dist_fn="metric") and DGG_StraightThrough
  * (dgm.py:140-182 + 63-100), noise off.  Rows are a softmax over ALL N columns, outputs are dense [B,N,N]: O(N^2) by
  * definition, written for batches of small graphs (N <= 8192).

@@ -37,6 +37,11 @@ struct GcniiEpi {
     float *out2;
     float c1, c2;
     int F;
+    // fused GCNII stack (EPI 1): the layer's activation and the NEXT layer's dropout in the same store --
+    // out = keep(e) ? relu(.) / (1 - p) : 0 with the counter-based mask of dgg_common.h (drop_keep); relu 0: neither
+    int relu;
+    uint32_t drop_thr24, s0, s1;
+    float drop_scale;
 };
 
 // AM: 32-row MFMA blocks per wavefront (2: 128-row tiles; 1: 64-row tiles, used when 128-row tiles would not fill the chip twice)
@@ -158,7 +163,13 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
                     const bool left = col < ep.F;
                     (left ? C : e_out2)[(int64_t)row * ep.F + (left ? col : col - ep.F)] = v + add[q][b];
                 } else if (EPI == 1) {
-                    C[(int64_t)row * N + col] = ep.theta * v + add[q][b];
+                    float o_ = ep.theta * v + add[q][b];
+                    if (ep.relu) {
+                        o_ = o_ > 0.0f ? o_ : 0.0f;
+                        if (ep.drop_thr24)
+                            o_ = dgg::drop_keep(ep.s0, ep.s1, (uint32_t)((int64_t)row * N + col), ep.drop_thr24) ? o_ * ep.drop_scale : 0.0f;
+                    }
+                    C[(int64_t)row * N + col] = o_;
                 } else {
                     C[(int64_t)row * N + col] = v;
                 }
@@ -187,6 +198,35 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float *__restrict_
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + tx;                       // dst row = source column
         if (c < Cc && r < ld) dst[(int64_t)c * ld + r] = (__bf16)tile[tx][i];
+    }
+}
+
+// Backward through a stack layer's relu + dropout, and the operand packs of the two products that follow, in ONE pass over the
+// gradient: g = g_in * (xd != 0 ? scale : 0) (xd = the layer's stored output: zero where the ReLU or the dropout zeroed it), written as
+// fp32 [n,F], as bf16 [n,F] (A operand of [d hi | d h0]) and as bf16 transposed [F, ldT] (B operand of the weight gradient; columns
+// n..ldT-1 zero).  Replaces threshold_backward + masked_scale + two pack_bf16 launches (+ the residual add, which the caller gets
+// for free by accumulating A^T d hi into a copy of g).
+__global__ __launch_bounds__(256) void gcnii_gout_pack_kernel(const float *__restrict__ gin, const float *__restrict__ xd, float scale, int n,
+                                                             int F, float *__restrict__ g, __bf16 *__restrict__ Gp, __bf16 *__restrict__ GT,
+                                                             int ldT) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        float v = 0.0f;
+        if (r < n && c < F) {
+            const int64_t o = (int64_t)r * F + c;
+            v = xd[o] != 0.0f ? gin[o] * scale : 0.0f;
+            g[o] = v;
+            Gp[o] = (__bf16)v;
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;                       // GT row = feature, column = node
+        if (c < F && r < ldT) GT[(int64_t)c * ldT + r] = (__bf16)tile[tx][i];
     }
 }
 
@@ -251,6 +291,30 @@ int dgg_gcnii_gemm_bf16_split(const void *S1, const void *S2, const void *Wt, in
     const GcniiEpi ep{hi, h0, inp, theta, alpha, nullptr, nullptr, 0.0f, 0.0f, 0};
     return launch_gemm(reinterpret_cast<const __bf16 *>(S1), reinterpret_cast<const __bf16 *>(Wt), (int)n, (int)F, (int)K, 1.0f, out, &ep,
                        (hipStream_t)stream, 1, reinterpret_cast<const __bf16 *>(S2), (int)F1);
+}
+
+// dgg_gcnii_gemm_bf16_split with the layer's ReLU and the next layer's dropout in the epilogue (fused GCNII stack): relu 0 = neither;
+// drop_p in [0,1): out = keep(e) ? relu(.) / (1 - drop_p) : 0, keep(e) the counter-based mask of seeds (s0, s1) on element e = row*F + col
+int dgg_gcnii_gemm_bf16_split_act(const void *S1, const void *S2, const void *Wt, int64_t n, int64_t F, int64_t K, int64_t F1, const float *hi,
+                                  const float *h0, const float *inp, float theta, float alpha, int relu, float drop_p, uint32_t s0,
+                                  uint32_t s1, float *out, void *stream) {
+    if (!hi || !S2) return dgg_set_error(DGG_ERR_ARG, "gcnii_gemm_bf16_split_act: hi and the second operand half are required");
+    if (!(drop_p >= 0.0f && drop_p < 1.0f) || n * F >= ((int64_t)1 << 32)) return dgg_set_error(DGG_ERR_ARG, "gcnii_gemm_bf16_split_act: drop_p in [0,1), n*F < 2^32");
+    GcniiEpi ep{hi, h0, inp, theta, alpha, nullptr, nullptr, 0.0f, 0.0f, 0};
+    ep.relu = relu; ep.drop_thr24 = relu ? (uint32_t)(drop_p * 16777216.0f) : 0u; ep.s0 = s0; ep.s1 = s1; ep.drop_scale = 1.0f / (1.0f - drop_p);
+    return launch_gemm(reinterpret_cast<const __bf16 *>(S1), reinterpret_cast<const __bf16 *>(Wt), (int)n, (int)F, (int)K, 1.0f, out, &ep,
+                       (hipStream_t)stream, 1, reinterpret_cast<const __bf16 *>(S2), (int)F1);
+}
+
+// see gcnii_gout_pack_kernel: gin, xd, g fp32 [n,F]; Gp bf16 [n,F]; GT bf16 [F, ldT], ldT >= n a multiple of 64 (columns beyond n zeroed)
+int dgg_gcnii_gout_pack(const float *gin, const float *xd, float scale, int64_t n, int64_t F, float *g, void *Gp, void *GT, int64_t ldT,
+                        void *stream) {
+    if (n <= 0 || F <= 0) return 0;
+    if (ldT < n || ldT % 64 != 0 || F % 64 != 0) return dgg_set_error(DGG_ERR_ARG, "gcnii_gout_pack: F and ldT multiples of 64, ldT >= n");
+    const dim3 grid((unsigned)((F + 31) / 32), (unsigned)((ldT + 31) / 32));
+    hipLaunchKernelGGL(gcnii_gout_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, gin, xd, scale, (int)n, (int)F, g,
+                       reinterpret_cast<__bf16 *>(Gp), reinterpret_cast<__bf16 *>(GT), (int)ldT);
+    return dgg_check_launch("gcnii_gout_pack");
 }
 
 // Backward of the variant layer w.r.t. its two inputs in ONE product: [d hi | d h0] = theta * Gp W^T + [c1 | c2] * g with

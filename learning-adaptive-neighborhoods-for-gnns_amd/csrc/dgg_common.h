@@ -109,6 +109,12 @@ __device__ __forceinline__ float c_ramp(float r, float k) {
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
 }
+// dropout mask of the fused GCNII stack: element e of a layer's activation is KEPT iff its 24-bit hash reaches thr24 = p * 2^24
+// (counter-based: the backward recomputes the mask instead of storing it)
+__device__ __forceinline__ bool drop_keep(uint32_t s0, uint32_t s1, uint32_t e, uint32_t thr24) {
+    const uint32_t x = mix32(mix32(e ^ s0) ^ s1);
+    return (x >> 8) >= thr24;
+}
 __device__ __forceinline__ void rowkey(uint32_t s0, uint32_t s1, uint32_t i, uint32_t &k1, uint32_t &k2) {
     k1 = mix32(i ^ s0);
     k2 = mix32(k1 ^ s1 ^ 0x9E3779B9U);

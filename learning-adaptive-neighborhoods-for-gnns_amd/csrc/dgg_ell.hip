@@ -62,7 +62,7 @@ __global__ void normalize_fwd_kernel(const int32_t *__restrict__ idx, const floa
 template <int VEC>
 __global__ __launch_bounds__(WPB * 64) void spmm_fwd_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
                                                            const float *__restrict__ X, int64_t N, int K, int F,
-                                                           float *__restrict__ Y) {
+                                                           float *__restrict__ Y, __bf16 *__restrict__ Yb = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
@@ -93,6 +93,10 @@ __global__ __launch_bounds__(WPB * 64) void spmm_fwd_kernel(const int32_t *__res
     if (c0 < F) {
 #pragma unroll
         for (int v = 0; v < VEC; v++) Y[i * F + c0 + v] = acc[v];
+        if (Yb) {                                    // the bf16 copy the layer product reads (GCNII stack: no separate pack pass)
+#pragma unroll
+            for (int v = 0; v < VEC; v++) Yb[i * F + c0 + v] = (__bf16)acc[v];
+        }
     }
 }
 
@@ -508,6 +512,16 @@ __global__ void gcnii_epilogue_bwd_kernel(const float *__restrict__ g, int64_t n
     else dhi[e] = (1.0f - theta) * gv;
 }
 
+// out = x * keep(e) / (1 - p) (accumulate: out += ...): the dropout of the fused GCNII stack on a tensor that no product produces
+// (the stack's input h0, and -- with the same seeds -- the gradient that flows back through it)
+__global__ void dropout_hash_kernel(const float *__restrict__ x, int64_t n, uint32_t thr24, float scale, uint32_t s0, uint32_t s1,
+                                    int accumulate, float *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float v = drop_keep(s0, s1, (uint32_t)e, thr24) ? x[e] * scale : 0.0f;
+    out[e] = accumulate ? out[e] + v : v;
+}
+
 inline unsigned rows_grid(int64_t N) { return (unsigned)((N + WPB - 1) / WPB); }
 
 }  // namespace
@@ -516,6 +530,15 @@ extern "C" {
 
 int dgg_ell_spmm_act_fwd(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, int act, float *Y,
                          void *stream);
+
+int dgg_dropout_hash(const float *x, int64_t n, float p, uint32_t s0, uint32_t s1, int accumulate, float *out, void *stream) {
+    if (!(p >= 0.0f && p < 1.0f) || n >= ((int64_t)1 << 32)) return dgg_set_error(DGG_ERR_ARG, "dropout_hash: p in [0,1), n < 2^32");
+    if (n == 0) return 0;
+    const uint32_t thr = (uint32_t)(p * 16777216.0f);
+    hipLaunchKernelGGL(dropout_hash_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, thr,
+                       1.0f / (1.0f - p), s0, s1, accumulate, out);
+    return dgg_check_launch("dropout_hash");
+}
 
 int dgg_softk_fwd(const int32_t *idx, const float *val, const float *k, int64_t N, int K, int mode, float *w, float *rs,
                   void *stream) {
@@ -534,6 +557,20 @@ int dgg_ell_normalize_fwd(const int32_t *idx, const float *w, const float *rs, i
     hipLaunchKernelGGL(normalize_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, w,
                        rs, N, K, row0, ahat);
     return dgg_check_launch("ell_normalize_fwd");
+}
+
+// Y = A X and, in the same pass, Yb = bf16(Y) [N, F] (F a multiple of 256, 16-byte aligned rows): the aggregation of a GCNII layer
+// on the bf16 matrix cores hands its product operand over without a pack pass (model.py:34 + the operand rounding of dgg_bf16.hip)
+int dgg_ell_spmm_fwd_bf16(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, float *Y, void *Yb,
+                          void *stream) {
+    if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    if (F % 256 != 0 || ((uintptr_t)X % 16) || ((uintptr_t)Y % 16) || !Yb)
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "ell_spmm_fwd_bf16: F must be a multiple of 256, rows 16-byte aligned, Yb given");
+    if (N == 0) return 0;
+    dim3 grid(rows_grid(N), (unsigned)(F / 256));
+    hipLaunchKernelGGL(spmm_fwd_kernel<4>, grid, dim3(WPB * 64), 0, (hipStream_t)stream, idx, ahat, X, N, K, F, Y,
+                       reinterpret_cast<__bf16 *>(Yb));
+    return dgg_check_launch("ell_spmm_fwd_bf16");
 }
 
 int dgg_ell_spmm_fwd(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, float *Y,

@@ -452,6 +452,25 @@ class GCNII_DGG(nn.Module):
         in_adj = _with_self_loops(in_adj)
         unnorm_adj = in_adj
         norm_adj = None
+        if self._stack_ok(layer_inner):
+            # ONE adjacency for every layer (a single generator in front of the first one), variant layers on the bf16 matrix cores:
+            # the whole loop below -- dropout, aggregation, layer, ReLU, and the dropout in front of the output layer -- as one
+            # autograd node (ops.GcniiStackBf16Fn)
+            unnorm_adj = self.dgg_net(x, 0, in_adj, writer, epoch)
+            norm_adj = _normalize_adj(unnorm_adj)
+            if isinstance(norm_adj, EllAdjacency):
+                seed = torch.randint(0, 2 ** 31 - 1, (2,))        # (CPU generator: reproducible under torch.manual_seed, no sync)
+                p_ = float(self.dropout) if self.training else 0.0
+                y = ops.GcniiStackBf16Fn.apply(layer_inner, norm_adj.values(), norm_adj.idx, norm_adj.part, norm_adj.k is not None,
+                                               self._residual, p_, float(self.lamda), float(self.alpha), (int(seed[0]), int(seed[1])),
+                                               *[con.weight for con in self.convs])
+                return self.fcs[-1](y), unnorm_adj
+            # (rows wider than the list: a CSR adjacency -- the layers one by one, below)
+            for i, con in enumerate(self.convs):
+                layer_inner = F.dropout(layer_inner, self.dropout, training=self.training)
+                layer_inner = self.act_fn(con(layer_inner, norm_adj, _layers[0], self.lamda, self.alpha, i + 1))
+            layer_inner = F.dropout(layer_inner, self.dropout, training=self.training)
+            return self.fcs[-1](layer_inner), unnorm_adj
         for i, con in enumerate(self.convs):
             if i < len(self.dggs):
                 src = in_adj if self.dgg_adj_input == "input_adj" else unnorm_adj
@@ -463,6 +482,16 @@ class GCNII_DGG(nn.Module):
             layer_inner = self.act_fn(con(layer_inner, norm_adj, _layers[0], self.lamda, self.alpha, i + 1))
         layer_inner = F.dropout(layer_inner, self.dropout, training=self.training)
         return self.fcs[-1](layer_inner), unnorm_adj
+
+    def _stack_ok(self, h0):
+        """the fused stack covers: one generator, every layer a variant GCNII layer of the same square width (a multiple of 256) with
+        the bf16 product switched on, activations on the GPU; `self.fused_stack = False` keeps the layers one by one"""
+        if not getattr(self, "fused_stack", True) or len(self.dggs) != 1 or not h0.is_cuda or h0.dtype != torch.float32 or len(self.convs) == 0:
+            return False
+        Fw = h0.shape[1]
+        return Fw % 256 == 0 and all(isinstance(c, GraphConvolution) and c.variant and c.gemm_dtype == torch.bfloat16 and
+                                      tuple(c.weight.shape) == (2 * Fw, Fw) and c.residual == self._residual for c in self.convs) and \
+            isinstance(self.act_fn, nn.ReLU)
 
     def forward(self, x, in_adj, epoch=None, writer=None):
         out, _ = self._body(x, in_adj, epoch, writer)

@@ -4,6 +4,7 @@ torch is used for device memory, streams and autograd bookkeeping only: every FL
 libdgg_hip.so.  Naming follows the reference (dgm.py / model.py) and include/dgg_hip.h.
 """
 import collections
+import math
 import os
 import ctypes as C
 
@@ -1470,6 +1471,115 @@ class GcniiVariantBf16Fn(torch.autograd.Function):
                                                            C.c_void_p(dW.data_ptr() + 4 * r0_ * Fo), _stream()), "gemm_nt_bf16")
             _probe_end("gemm_bf16_bwd", pe)
         return dhi, dh0, dW, (g if ctx.has_inp else None), None, None
+
+
+def dropout_hash(x, p, s0, s1, accumulate_into=None):
+    """x * keep / (1 - p) with the counter-based mask of the fused GCNII stack (dgg_dropout_hash); accumulate_into: += instead"""
+    x = _chk(x)
+    out = torch.empty_like(x) if accumulate_into is None else accumulate_into
+    _lib.check(_lib.lib().dgg_dropout_hash(_ptr(x), x.numel(), float(p), int(s0) & 0xFFFFFFFF, int(s1) & 0xFFFFFFFF,
+                                           int(accumulate_into is not None), _ptr(out), _stream()), "dropout_hash")
+    return out
+
+
+_STACK_KEY = 0x9E3779B9
+
+
+class GcniiStackBf16Fn(torch.autograd.Function):
+    """A whole stack of VARIANT GCNII layers on ONE adjacency as a single autograd node, products on the bf16 matrix cores
+    (reference model.py:716-731 / 942-957: `for con: x = dropout(x); x = relu(con(x, adj, h0, ...))`, then the
+    dropout in front of the output layer; layer = model.py:32-44 with support = cat[hi, h0]):
+
+        xd_0 = dropout(h0);   hi_l = A xd_{l-1};   xd_l = dropout(relu(theta_l [hi_l | h0] W_l + (1 - theta_l)((1 - alpha) hi_l + alpha h0) + xd_{l-1}))
+
+    returns xd_L.  What the per-layer modules launch and this does not: the bf16 pack of hi (written by the aggregation itself), the
+    ReLU and the dropout (in the product's epilogue; the mask is counter-based and read back off the stored activation, xd != 0), their
+    two backward kernels and the two packs of the gradient (one pass: dgg_gcnii_gout_pack), the residual add (A^T d hi accumulates
+    into a copy of the gradient).  Same operand rounding as
+    GcniiVariantBf16Fn; the dropout draws from its own counter-based stream (seeded per forward from torch's CPU generator)."""
+
+    @staticmethod
+    def forward(ctx, h0, ahat, idx, part, skip_zero, residual, p, lamda, alpha, seed, *weights):
+        n, F = h0.shape
+        L = len(weights)
+        assert F % 256 == 0 and all(tuple(W.shape) == (2 * F, F) for W in weights)
+        h0c, ahat = _chk(h0), _chk(ahat)
+        s0, s1 = int(seed[0]) & 0xFFFFFFFF, int(seed[1]) & 0xFFFFFFFF
+        K = idx.shape[1]
+        S2, _ = _h0_packs(h0)
+        xd = dropout_hash(h0c, p, s0, s1) if p > 0 else h0c
+        his, xds = [], [xd]
+        pe = _probe_begin()
+        for l, W in enumerate(weights, 1):
+            theta = math.log(lamda / l + 1)
+            hi = torch.empty((n, F), device=h0.device, dtype=torch.float32)
+            hib = torch.empty((n, F), device=h0.device, dtype=torch.bfloat16)
+            _lib.check(_lib.lib().dgg_ell_spmm_fwd_bf16(_ptr(idx), _ptr(ahat), _ptr(xd), n, K, F, _ptr(hi), _ptr(hib), _stream()), "ell_spmm_fwd_bf16")
+            Wt = _packed_weight(W, True)                         # [F, 2F]
+            out = torch.empty((n, F), device=h0.device, dtype=torch.float32)
+            _lib.check(_lib.lib().dgg_gcnii_gemm_bf16_split_act(_ptr(hib), _ptr(S2), _ptr(Wt), n, F, 2 * F, F, _ptr(hi), _ptr(h0c),
+                                                                _ptr(xd if residual else None), float(theta), float(alpha), 1, float(p), s0,
+                                                                (s1 ^ (_STACK_KEY * l)) & 0xFFFFFFFF, _ptr(out), _stream()),
+                       "gcnii_gemm_bf16_split_act")
+            his.append(hi)
+            xds.append(out)
+            xd = out
+        _probe_end("gcnii_stack_fwd", pe)
+        ctx.save_for_backward(h0, ahat, idx, *weights, *his, *xds)
+        ctx.cfg = (L, part, bool(skip_zero), bool(residual), float(p), float(lamda), float(alpha), s0, s1)
+        return xd
+
+    @staticmethod
+    def backward(ctx, g):
+        L, part, skip_zero, residual, p, lamda, alpha, s0, s1 = ctx.cfg
+        sv = ctx.saved_tensors
+        h0, ahat, idx = sv[0], sv[1], sv[2]
+        weights, his, xds = sv[3:3 + L], sv[3 + L:3 + 2 * L], sv[3 + 2 * L:]
+        n, F = h0.shape
+        K = idx.shape[1]
+        n64 = (n + 63) // 64 * 64
+        dev = h0.device
+        if part is None:
+            part = part_build(idx, ahat, n)
+        _, h0T = _h0_packs(h0)
+        scale = 1.0 / (1.0 - p)
+        gx = _chk(g.contiguous())
+        dh0 = torch.empty((n, F), device=dev, dtype=torch.float32)
+        dA = None
+        dWs = [None] * L
+        pe = _probe_begin()
+        for l in range(L, 0, -1):
+            theta = math.log(lamda / l + 1)
+            W, hi, xd_l, xd_prev = weights[l - 1], his[l - 1], xds[l], xds[l - 1]
+            gout = torch.empty((n, F), device=dev, dtype=torch.float32)
+            Gp = torch.empty((n, F), device=dev, dtype=torch.bfloat16)
+            GT = torch.empty((F, n64), device=dev, dtype=torch.bfloat16)
+            _lib.check(_lib.lib().dgg_gcnii_gout_pack(_ptr(gx), _ptr(xd_l), float(scale), n, F, _ptr(gout), _ptr(Gp), _ptr(GT), n64, _stream()),
+                       "gcnii_gout_pack")
+            dhi = torch.empty((n, F), device=dev, dtype=torch.float32)
+            dh0_l = dh0 if l == L else torch.empty((n, F), device=dev, dtype=torch.float32)
+            _lib.check(_lib.lib().dgg_gcnii_dsupport_bf16(_ptr(Gp), _ptr(_packed_weight(W, False)), n, F, _ptr(gout), float(theta), float(alpha),
+                                                          _ptr(dhi), _ptr(dh0_l), _stream()), "gcnii_dsupport_bf16")
+            if l != L:
+                dh0.add_(dh0_l)
+            if ctx.needs_input_grad[10 + l - 1]:
+                hiT = pack_bf16(hi, transpose=True)
+                dW = torch.empty_like(W)
+                _lib.check(_lib.lib().dgg_gemm_nt_bf16_rows2(_ptr(hiT), _ptr(h0T), F, _ptr(GT), 2 * F, F, n64, float(theta), _ptr(dW), _stream()),
+                           "gemm_nt_bf16_rows2")
+                dWs[l - 1] = dW
+            dA_l = torch.empty((n, K), device=dev, dtype=torch.float32)
+            _lib.check(_lib.lib().dgg_ell_spmm_bwd(_ptr(idx), _ptr(ahat), _ptr(xd_prev), _ptr(dhi), n, K, F, int(skip_zero), _ptr(dA_l), _ptr(None),
+                                                   _stream()), "ell_spmm_bwd")
+            dA = dA_l if dA is None else dA.add_(dA_l)
+            gx = gout.clone() if residual else torch.zeros_like(gout)       # + g through the residual; A^T d hi accumulates into it
+            _lib.check(_lib.lib().dgg_ell_spmm_t_part(_ptr(ahat), _ptr(dhi), n, K, F, _ptr(part), n, _ptr(gx), _stream()), "ell_spmm_t_part")
+        if p > 0:
+            dropout_hash(gx, p, s0, s1, accumulate_into=dh0)     # back through xd_0 = dropout(h0): the same mask
+        else:
+            dh0.add_(gx)
+        _probe_end("gcnii_stack_bwd", pe)
+        return (dh0, dA, None, None, None, None, None, None, None, None) + tuple(dWs)
 
 
 class GcniiEpilogueFn(torch.autograd.Function):

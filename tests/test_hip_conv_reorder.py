@@ -323,6 +323,121 @@ def test_bf16_gcnii_layer_product(dev, n, K, F, variant, residual):
         assert rel(g16, g32) <= 2e-2
 
 
+def _stack_inputs(n, F, L, dev, seed=3):
+    """h0, a normalised ELL adjacency with a few empty slots / zero weights, L variant weights, a cotangent"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(seed)
+    K = 64
+    h0 = np.maximum(rng.standard_normal((n, F)), 0).astype(np.float32)
+    idx = np.stack([rng.choice(n, K, replace=False) for _ in range(n)]).astype(np.int32)
+    w = rng.random((n, K)).astype(np.float32)
+    w[:, 20:] = 0.0                                               # saturated ramp beyond rank 20
+    idx[:, 40:] = -1                                              # empty slots
+    w[idx < 0] = 0.0
+    rs = w.sum(1)
+    ahat = (w / np.sqrt(rs)[:, None] / np.sqrt(rs)[np.maximum(idx, 0)]).astype(np.float32)
+    Ws = [(rng.standard_normal((2 * F, F)) / np.sqrt(2 * F)).astype(np.float32) for _ in range(L)]
+    cot = rng.standard_normal((n, F)).astype(np.float32)
+    idx_t = T(idx, dev)
+    part = ops.part_build(idx_t, T(w, dev), n)
+    return T(h0, dev), T(ahat, dev), idx_t, part, [T(W, dev) for W in Ws], T(cot, dev)
+
+
+@pytest.mark.parametrize("n,F,L,residual", [(700, 256, 4, True), (1100, 512, 3, False)])
+def test_gcnii_stack_bf16_matches_the_layers_one_by_one(dev, n, F, L, residual):
+    """ops.GcniiStackBf16Fn (dropout off) against the same stack through the per-layer pieces it replaces -- EllSpmmFn, GcniiVariantBf16Fn,
+    torch.relu under torch autograd: the same bf16 operands in the same contraction order, so the forward is identical up to the order
+    of the fp32 epilogue terms (1e-6), and every gradient (h0, the adjacency values, each weight) agrees to 1e-4 of its max (d h0 is
+    accumulated over the layers in another order; the ReLU mask is read off the activation)."""
+    import math
+    from dgg_amd import ops
+    h0, ahat, idx, part, Ws, cot = _stack_inputs(n, F, L, dev)
+    lamda, alpha = 0.5, 0.3
+
+    def leaves():
+        return h0.clone().requires_grad_(True), ahat.clone().requires_grad_(True), [W.clone().requires_grad_(True) for W in Ws]
+
+    a_h0, a_ah, a_W = leaves()
+    y = ops.GcniiStackBf16Fn.apply(a_h0, a_ah, idx, part, True, residual, 0.0, lamda, alpha, (1, 2), *a_W)
+    (y * cot).sum().backward()
+    b_h0, b_ah, b_W = leaves()
+    x = b_h0
+    for l, W in enumerate(b_W, 1):
+        hi = ops.EllSpmmFn.apply(b_ah, idx, x, True, part, ops.ACT_NONE)
+        x = torch.relu(ops.GcniiVariantBf16Fn.apply(hi, b_h0, W, x if residual else None, math.log(lamda / l + 1), alpha))
+    (x * cot).sum().backward()
+    rel = lambda u, v: float((u.double() - v.double()).abs().max() / v.double().abs().max())  # noqa: E731
+    assert rel(y, x) <= 1e-6, rel(y, x)
+    assert rel(a_h0.grad, b_h0.grad) <= 1e-4 and rel(a_ah.grad, b_ah.grad) <= 1e-4
+    for u, v in zip(a_W, b_W):
+        assert rel(u.grad, v.grad) <= 1e-4
+
+
+def _np_drop_keep(s0, s1, n_elem, p):
+    """numpy restatement of dgg_common.h drop_keep (mix32 twice, 24-bit threshold)"""
+    def mix32(x):
+        x = x.astype(np.uint32)
+        x ^= x >> np.uint32(16); x = (x * np.uint32(0x7feb352d)).astype(np.uint32)
+        x ^= x >> np.uint32(15); x = (x * np.uint32(0x846ca68b)).astype(np.uint32)
+        x ^= x >> np.uint32(16)
+        return x
+    e = np.arange(n_elem, dtype=np.uint32)
+    x = mix32(mix32(e ^ np.uint32(s0)) ^ np.uint32(s1))
+    return (x >> np.uint32(8)) >= np.uint32(int(p * 16777216.0))
+
+
+def test_gcnii_stack_bf16_dropout_is_the_counter_based_mask(dev):
+    """Training mode: the stack applies dropout(h0) in front of the first layer and dropout(relu(.)) in every layer's epilogue with the
+    counter-based mask of dgg_common.h (element e of layer l kept iff hash24(s0, s1 ^ l*0x9E3779B9, e) >= p 2^24).  The masks are
+    restated in numpy, the stack in torch (float64, GEMM operands rounded to bf16 as the kernel rounds them) with those masks under
+    torch autograd: output 1e-4, gradients of h0 / adjacency values / weights 3e-2 of max (the kernel's backward products round the
+    cotangent to bf16 as well), keep rate 1 - p to 1 %."""
+    import math
+    from dgg_amd import ops
+    n, F, L, p, lamda, alpha = 600, 256, 3, 0.3, 0.5, 0.4
+    s0, s1 = 12345, 678
+    h0, ahat, idx, part, Ws, cot = _stack_inputs(n, F, L, dev, seed=8)
+    a_h0, a_ah = h0.clone().requires_grad_(True), ahat.clone().requires_grad_(True)
+    a_W = [W.clone().requires_grad_(True) for W in Ws]
+    y = ops.GcniiStackBf16Fn.apply(a_h0, a_ah, idx, part, True, True, p, lamda, alpha, (s0, s1), *a_W)
+    (y * cot).sum().backward()
+    y2 = ops.GcniiStackBf16Fn.apply(h0, ahat, idx, part, True, True, p, lamda, alpha, (s0, s1), *Ws)
+    assert torch.equal(y, y2), "same seeds, same mask"
+    masks = [torch.from_numpy(_np_drop_keep(s0, (s1 ^ (0x9E3779B9 * l)) & 0xFFFFFFFF, n * F, p).reshape(n, F)) for l in range(L + 1)]
+    assert abs(float(masks[1].double().mean()) - (1 - p)) < 0.01
+    r16 = lambda t_: t_.float().bfloat16().double()                # noqa: E731
+    d_h0 = h0.detach().cpu().double().requires_grad_(True)
+    d_ah = ahat.detach().cpu().double().requires_grad_(True)
+    d_W = [W.detach().cpu().double().requires_grad_(True) for W in Ws]
+    idc = idx.cpu().long()
+    valid = idc >= 0
+    A = torch.zeros(n, n, dtype=torch.float64).index_put((torch.arange(n)[:, None].expand_as(idc)[valid], idc[valid]), d_ah[valid], accumulate=True)
+
+    class R16(torch.autograd.Function):                            # rounding with a straight-through gradient
+        @staticmethod
+        def forward(ctx, t_):
+            return r16(t_)
+
+        @staticmethod
+        def backward(ctx, g_):
+            return g_
+
+    x = d_h0 * masks[0] / (1 - p)
+    for l, W in enumerate(d_W, 1):
+        theta = math.log(lamda / l + 1)
+        hi = A @ x
+        out = theta * (R16.apply(torch.cat([hi, d_h0], 1)) @ R16.apply(W)) + (1 - theta) * ((1 - alpha) * hi + alpha * d_h0) + x
+        x = torch.relu(out) * masks[l] / (1 - p)
+    (x * cot.cpu().double()).sum().backward()
+    rel = lambda u, v: float((u.detach().cpu().double() - v).abs().max() / v.abs().max())  # noqa: E731
+    assert rel(y, x.detach()) <= 1e-4, rel(y, x.detach())
+    live = (ahat != 0).cpu()                                       # (skip_zero: an exact zero weight is a saturated ramp, its gradient is dropped)
+    assert float(a_ah.grad.cpu()[~live].abs().max()) == 0.0
+    assert rel(a_h0.grad, d_h0.grad) <= 3e-2 and rel(a_ah.grad.cpu()[live], d_ah.grad[live]) <= 3e-2
+    for u, v in zip(a_W, d_W):
+        assert rel(u.grad, v.grad) <= 3e-2
+
+
 def test_config4_ppi_gcniippi_dgg_bf16_end_to_end(dev):
     """BASELINE configs[4] end to end: GCNIIppi_DGG (hidden 2048, 9 variant GCNII layers with residual, DGG at latent 2048 on
     edge-list candidates; reference model.py:887-965, train_ppi.py:43-44, 204-219) on two PPI-shaped graphs, forward + backward,
@@ -343,14 +458,15 @@ def test_config4_ppi_gcniippi_dgg_bf16_end_to_end(dev):
                      dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
                      symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
     models = []
-    for dt in (None, torch.bfloat16):
+    for dt in (None, torch.bfloat16, "stack"):
         torch.manual_seed(0)
         m = dgg_amd.GCNIIppi_DGG(nfeat=d, nlayers=L, nhidden=hid, nclass=C, dropout=0.0, lamda=0.5, alpha=0.5, variant=True, args=args).to(dev)
         with torch.no_grad():
             for dg in m.dggs:
                 dg.k_net.k_project.weight.mul_(0.1)
         for conv in m.convs:
-            conv.gemm_dtype = dt
+            conv.gemm_dtype = torch.bfloat16 if dt == "stack" else dt
+        m.fused_stack = dt == "stack"                               # models[1]: the layers one by one (forward hooks below); [2]: ops.GcniiStackBf16Fn
         m.train()                                                   # training mode: the DGG perturbs the scores (noise=True)
         models.append(m)
     rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())  # noqa: E731
@@ -375,6 +491,11 @@ def test_config4_ppi_gcniippi_dgg_bf16_end_to_end(dev):
             grads.append({k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None})
             adjs.append(unnorm)
         assert torch.equal(adjs[0].idx, adjs[1].idx), "the two runs must select the same graph (same seed, fp32 DGG in both)"
+        # the fused stack (dropout 0): the same products on the same operands as the layers one by one
+        assert torch.equal(adjs[2].idx, adjs[1].idx) and rel(outs[2], outs[1]) <= 1e-5, rel(outs[2], outs[1])
+        assert set(grads[2]) == set(grads[1])
+        for k in grads[1]:
+            assert rel(grads[2][k], grads[1][k]) <= 2e-3, (k, rel(grads[2][k], grads[1][k]))
         assert rel(outs[1], outs[0]) <= 1e-2
         assert set(grads[0]) == set(grads[1]) and len(grads[0]) >= L + 4
         for k in grads[0]:
