@@ -42,6 +42,9 @@ struct GcniiEpi {
     int relu;
     uint32_t drop_thr24, s0, s1;
     float drop_scale;
+    // bf16 copy of the output for the kernels that GATHER it afterwards (the next layer's aggregation and the SDDMM read the
+    // activation, the transposed aggregation reads d hi): EPI 1: of `out` [n,N]; EPI 2: of the left half (d hi) [n,F].  Nullable.
+    __bf16 *outb;
 };
 
 // AM: 32-row MFMA blocks per wavefront (2: 128-row tiles; 1: 64-row tiles, used when 128-row tiles would not fill the chip twice)
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
                 if (EPI == 2) {
                     const bool left = col < ep.F;
                     (left ? C : e_out2)[(int64_t)row * ep.F + (left ? col : col - ep.F)] = v + add[q][b];
+                    if (left && ep.outb) ep.outb[(int64_t)row * ep.F + col] = (__bf16)(v + add[q][b]);
                 } else if (EPI == 1) {
                     float o_ = ep.theta * v + add[q][b];
                     if (ep.relu) {
@@ -170,6 +174,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
                             o_ = dgg::drop_keep(ep.s0, ep.s1, (uint32_t)((int64_t)row * N + col), ep.drop_thr24) ? o_ * ep.drop_scale : 0.0f;
                     }
                     C[(int64_t)row * N + col] = o_;
+                    if (ep.outb) ep.outb[(int64_t)row * N + col] = (__bf16)o_;
                 } else {
                     C[(int64_t)row * N + col] = v;
                 }
@@ -297,11 +302,12 @@ int dgg_gcnii_gemm_bf16_split(const void *S1, const void *S2, const void *Wt, in
 // drop_p in [0,1): out = keep(e) ? relu(.) / (1 - drop_p) : 0, keep(e) the counter-based mask of seeds (s0, s1) on element e = row*F + col
 int dgg_gcnii_gemm_bf16_split_act(const void *S1, const void *S2, const void *Wt, int64_t n, int64_t F, int64_t K, int64_t F1, const float *hi,
                                   const float *h0, const float *inp, float theta, float alpha, int relu, float drop_p, uint32_t s0,
-                                  uint32_t s1, float *out, void *stream) {
+                                  uint32_t s1, float *out, void *outb, void *stream) {
     if (!hi || !S2) return dgg_set_error(DGG_ERR_ARG, "gcnii_gemm_bf16_split_act: hi and the second operand half are required");
     if (!(drop_p >= 0.0f && drop_p < 1.0f) || n * F >= ((int64_t)1 << 32)) return dgg_set_error(DGG_ERR_ARG, "gcnii_gemm_bf16_split_act: drop_p in [0,1), n*F < 2^32");
     GcniiEpi ep{hi, h0, inp, theta, alpha, nullptr, nullptr, 0.0f, 0.0f, 0};
     ep.relu = relu; ep.drop_thr24 = relu ? (uint32_t)(drop_p * 16777216.0f) : 0u; ep.s0 = s0; ep.s1 = s1; ep.drop_scale = 1.0f / (1.0f - drop_p);
+    ep.outb = reinterpret_cast<__bf16 *>(outb);
     return launch_gemm(reinterpret_cast<const __bf16 *>(S1), reinterpret_cast<const __bf16 *>(Wt), (int)n, (int)F, (int)K, 1.0f, out, &ep,
                        (hipStream_t)stream, 1, reinterpret_cast<const __bf16 *>(S2), (int)F1);
 }
@@ -315,6 +321,17 @@ int dgg_gcnii_gout_pack(const float *gin, const float *xd, float scale, int64_t 
     hipLaunchKernelGGL(gcnii_gout_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, gin, xd, scale, (int)n, (int)F, g,
                        reinterpret_cast<__bf16 *>(Gp), reinterpret_cast<__bf16 *>(GT), (int)ldT);
     return dgg_check_launch("gcnii_gout_pack");
+}
+
+// dgg_gcnii_dsupport_bf16 that also leaves bf16(d hi) [n,F] (dhib, nullable) for the transposed aggregation that gathers it next
+int dgg_gcnii_dsupport_bf16_b(const void *Gp, const void *Wp, int64_t n, int64_t F, const float *g, float theta, float alpha, float *dhi,
+                              float *dh0, void *dhib, void *stream) {
+    if (!g || !dhi || !dh0) return dgg_set_error(DGG_ERR_ARG, "gcnii_dsupport_bf16_b: g, dhi and dh0 are required");
+    GcniiEpi ep{};
+    ep.g = g; ep.out2 = dh0; ep.c1 = (1.0f - theta) * (1.0f - alpha); ep.c2 = (1.0f - theta) * alpha; ep.F = (int)F;
+    ep.outb = reinterpret_cast<__bf16 *>(dhib);
+    return launch_gemm(reinterpret_cast<const __bf16 *>(Gp), reinterpret_cast<const __bf16 *>(Wp), (int)n, (int)(2 * F), (int)F, theta, dhi, &ep,
+                       (hipStream_t)stream, 2);
 }
 
 // Backward of the variant layer w.r.t. its two inputs in ONE product: [d hi | d h0] = theta * Gp W^T + [c1 | c2] * g with

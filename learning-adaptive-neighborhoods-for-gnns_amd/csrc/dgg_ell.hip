@@ -100,6 +100,101 @@ __global__ __launch_bounds__(WPB * 64) void spmm_fwd_kernel(const int32_t *__res
     }
 }
 
+// bf16 helpers: two values per 32-bit word, low half first
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// The aggregation of the fused GCNII stack on a bf16 COPY of the activation (half the gathered bytes: the stack's gather kernels
+// are bound by L2 bandwidth at F = 2048): lane l owns 8 consecutive features (one 16-byte load per neighbour), grid.y walks blocks
+// of 512 features; fp32 accumulation in entry order; writes Y fp32 and, if asked, bf16(Y).
+__global__ __launch_bounds__(WPB * 64) void spmm_fwd_b16_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
+                                                               const uint4 *__restrict__ Xb, int64_t N, int K, int F,
+                                                               float *__restrict__ Y, __bf16 *__restrict__ Yb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
+    if (i >= N) return;
+    const int c8 = blockIdx.y * 64 + lane;                        // index of this lane's group of 8 features
+    const int F8 = F / 8;
+    int32_t jl = lane < K ? idx[i * K + lane] : -1;
+    float al = lane < K ? ahat[i * K + lane] : 0.0f;
+    float acc[8];
+#pragma unroll
+    for (int v = 0; v < 8; v++) acc[v] = 0.0f;
+    for (int r = 0; r < K; r++) {
+        const int32_t j = bcast(jl, r);
+        const float a = bcast(al, r);
+        if (j < 0 || a == 0.0f) continue;                         // wave-uniform
+        if (c8 < F8) {
+            const uint4 xv = Xb[(int64_t)j * F8 + c8];
+            acc[0] = __fmaf_rn(a, bf_lo(xv.x), acc[0]); acc[1] = __fmaf_rn(a, bf_hi(xv.x), acc[1]);
+            acc[2] = __fmaf_rn(a, bf_lo(xv.y), acc[2]); acc[3] = __fmaf_rn(a, bf_hi(xv.y), acc[3]);
+            acc[4] = __fmaf_rn(a, bf_lo(xv.z), acc[4]); acc[5] = __fmaf_rn(a, bf_hi(xv.z), acc[5]);
+            acc[6] = __fmaf_rn(a, bf_lo(xv.w), acc[6]); acc[7] = __fmaf_rn(a, bf_hi(xv.w), acc[7]);
+        }
+    }
+    if (c8 < F8) {
+        float4 *yo = reinterpret_cast<float4 *>(Y + i * F + 8 * c8);
+        yo[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        yo[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        if (Yb) {
+#pragma unroll
+            for (int v = 0; v < 8; v++) Yb[i * F + 8 * c8 + v] = (__bf16)acc[v];
+        }
+    }
+}
+
+// sddmm_wide_kernel on bf16 copies of both operands (X gathered, dY the row's own cotangent), fp32 accumulation
+__global__ __launch_bounds__(WPB * 64) void sddmm_wide_b16_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
+                                                                 const uint4 *__restrict__ Xb, const uint4 *__restrict__ dYb,
+                                                                 int64_t N, int K, int F, int skip_zero, float *__restrict__ dA) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
+    if (i >= N) return;
+    const int32_t jl = lane < K ? idx[i * K + lane] : -1;
+    const float al = lane < K ? ahat[i * K + lane] : 0.0f;
+    const int F8 = F / 8;
+    const uint4 *gy = dYb + i * F8;
+    float mine = 0.0f;
+    constexpr int NQ = 4;
+    for (int r0 = 0; r0 < K; r0 += NQ) {
+        const uint4 *xr[NQ];
+        bool v[NQ];
+        bool any = false;
+        float part[NQ];
+#pragma unroll
+        for (int u = 0; u < NQ; u++) {
+            const int r = r0 + u < K ? r0 + u : K - 1;
+            const int32_t j = bcast(jl, r);
+            v[u] = r0 + u < K && j >= 0 && !(skip_zero && bcast(al, r) == 0.0f);
+            xr[u] = Xb + (int64_t)(j < 0 ? 0 : j) * F8;
+            part[u] = 0.0f;
+            any = any || v[u];
+        }
+        if (!any) continue;                                      // wave-uniform
+        for (int c = lane; c < F8; c += 64) {
+            const uint4 g = gy[c];
+            const float g0 = bf_lo(g.x), g1 = bf_hi(g.x), g2 = bf_lo(g.y), g3 = bf_hi(g.y), g4 = bf_lo(g.z), g5 = bf_hi(g.z), g6 = bf_lo(g.w),
+                        g7 = bf_hi(g.w);
+#pragma unroll
+            for (int u = 0; u < NQ; u++) {
+                if (v[u]) {
+                    const uint4 xv = xr[u][c];
+                    float p_ = part[u];
+                    p_ = fmaf(g0, bf_lo(xv.x), p_); p_ = fmaf(g1, bf_hi(xv.x), p_); p_ = fmaf(g2, bf_lo(xv.y), p_); p_ = fmaf(g3, bf_hi(xv.y), p_);
+                    p_ = fmaf(g4, bf_lo(xv.z), p_); p_ = fmaf(g5, bf_hi(xv.z), p_); p_ = fmaf(g6, bf_lo(xv.w), p_); p_ = fmaf(g7, bf_hi(xv.w), p_);
+                    part[u] = p_;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; u++) {
+            const float tot = wave_sum_dpp(part[u], lane);
+            if (lane == r0 + u) mine = tot;
+        }
+    }
+    if (lane < K) dA[i * K + lane] = mine;
+}
+
 // Same aggregation for NARROW feature rows (F = 16, 32, 64: the projected features H = X W of a GCNConv whose output is
 // narrower than its input, aggregated after the projection).  F/4 lanes per gathered row (16-byte loads), 256/F rows per
 // wave-instruction and NBT such batches in flight, so that one load instruction still moves 1 KiB; the 256/F partial sums
@@ -515,11 +610,13 @@ __global__ void gcnii_epilogue_bwd_kernel(const float *__restrict__ g, int64_t n
 // out = x * keep(e) / (1 - p) (accumulate: out += ...): the dropout of the fused GCNII stack on a tensor that no product produces
 // (the stack's input h0, and -- with the same seeds -- the gradient that flows back through it)
 __global__ void dropout_hash_kernel(const float *__restrict__ x, int64_t n, uint32_t thr24, float scale, uint32_t s0, uint32_t s1,
-                                    int accumulate, float *__restrict__ out) {
+                                    int accumulate, float *__restrict__ out, __bf16 *__restrict__ outb) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
-    const float v = drop_keep(s0, s1, (uint32_t)e, thr24) ? x[e] * scale : 0.0f;
-    out[e] = accumulate ? out[e] + v : v;
+    float v = (thr24 == 0 || drop_keep(s0, s1, (uint32_t)e, thr24)) ? x[e] * scale : 0.0f;
+    if (accumulate) v += out[e];
+    out[e] = v;
+    if (outb) outb[e] = (__bf16)v;                               // (the copy the stack's gather kernels read)
 }
 
 inline unsigned rows_grid(int64_t N) { return (unsigned)((N + WPB - 1) / WPB); }
@@ -531,12 +628,12 @@ extern "C" {
 int dgg_ell_spmm_act_fwd(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, int act, float *Y,
                          void *stream);
 
-int dgg_dropout_hash(const float *x, int64_t n, float p, uint32_t s0, uint32_t s1, int accumulate, float *out, void *stream) {
+int dgg_dropout_hash(const float *x, int64_t n, float p, uint32_t s0, uint32_t s1, int accumulate, float *out, void *outb, void *stream) {
     if (!(p >= 0.0f && p < 1.0f) || n >= ((int64_t)1 << 32)) return dgg_set_error(DGG_ERR_ARG, "dropout_hash: p in [0,1), n < 2^32");
     if (n == 0) return 0;
     const uint32_t thr = (uint32_t)(p * 16777216.0f);
     hipLaunchKernelGGL(dropout_hash_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, thr,
-                       1.0f / (1.0f - p), s0, s1, accumulate, out);
+                       1.0f / (1.0f - p), s0, s1, accumulate, out, reinterpret_cast<__bf16 *>(outb));
     return dgg_check_launch("dropout_hash");
 }
 
@@ -571,6 +668,27 @@ int dgg_ell_spmm_fwd_bf16(const int32_t *idx, const float *ahat, const float *X,
     hipLaunchKernelGGL(spmm_fwd_kernel<4>, grid, dim3(WPB * 64), 0, (hipStream_t)stream, idx, ahat, X, N, K, F, Y,
                        reinterpret_cast<__bf16 *>(Yb));
     return dgg_check_launch("ell_spmm_fwd_bf16");
+}
+
+// dgg_ell_spmm_fwd_bf16 gathering a bf16 COPY of X (Xb [N, F] bf16, F a multiple of 512, 16-byte aligned rows): half the gathered bytes
+int dgg_ell_spmm_fwd_b16(const int32_t *idx, const float *ahat, const void *Xb, int64_t N, int K, int F, float *Y, void *Yb, void *stream) {
+    if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    if (F % 512 != 0 || ((uintptr_t)Xb % 16) || ((uintptr_t)Y % 16)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ell_spmm_fwd_b16: F must be a multiple of 512, rows 16-byte aligned");
+    if (N == 0) return 0;
+    dim3 grid(rows_grid(N), (unsigned)(F / 512));
+    hipLaunchKernelGGL(spmm_fwd_b16_kernel, grid, dim3(WPB * 64), 0, (hipStream_t)stream, idx, ahat, reinterpret_cast<const uint4 *>(Xb), N, K, F,
+                       Y, reinterpret_cast<__bf16 *>(Yb));
+    return dgg_check_launch("ell_spmm_fwd_b16");
+}
+// dA = <dY_i, X_j> on bf16 copies of both operands (Xb, dYb [N, F] bf16, F a multiple of 8; fp32 accumulation): the SDDMM of the stack
+int dgg_ell_sddmm_b16(const int32_t *idx, const float *ahat, const void *Xb, const void *dYb, int64_t N, int K, int F, int skip_zero, float *dA,
+                      void *stream) {
+    if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    if (F % 8 != 0 || ((uintptr_t)Xb % 16) || ((uintptr_t)dYb % 16)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ell_sddmm_b16: F must be a multiple of 8, rows 16-byte aligned");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(sddmm_wide_b16_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, idx, ahat, reinterpret_cast<const uint4 *>(Xb),
+                       reinterpret_cast<const uint4 *>(dYb), N, K, F, skip_zero, dA);
+    return dgg_check_launch("ell_sddmm_b16");
 }
 
 int dgg_ell_spmm_fwd(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, float *Y,

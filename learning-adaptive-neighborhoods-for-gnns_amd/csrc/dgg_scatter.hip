@@ -380,9 +380,13 @@ __global__ __launch_bounds__(256) void edge_bwd_cols(const float *__restrict__ x
 // (autograd of torch.mm(adj, x) w.r.t. x, model.py:594; needed whenever the conv input is itself a learned activation: second
 // GCNConv of GCN_DGG, every GCNII layer).  Same walk as edge_bwd_cols: fixed chunks of destination-ordered records per
 // 16-lane group, runs of equal destination reduced in registers, one flush per run; grid.y = blocks of 64 features.
-__global__ __launch_bounds__(256) void spmm_t_cols(const float *__restrict__ dY, int F, const int *__restrict__ bstart, int nb,
+// B16: dY is a bf16 copy [rows, F] of the cotangent (the fused GCNII stack: half the gathered bytes), accumulation in fp32 as before
+template <bool B16 = false>
+__global__ __launch_bounds__(256) void spmm_t_cols(const void *__restrict__ dYv, int F, const int *__restrict__ bstart, int nb,
                                                    const int2 *__restrict__ recs, const float *__restrict__ a, int K,
                                                    float *__restrict__ dX) {
+    const float *__restrict__ dY = static_cast<const float *>(dYv);
+    const uint16_t *__restrict__ dYb = static_cast<const uint16_t *>(dYv);
     constexpr int LPR = 16;
     const int lane = threadIdx.x & 63, c4 = lane % LPR, gbase = lane - c4;
     const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
@@ -421,7 +425,13 @@ __global__ __launch_bounds__(256) void spmm_t_cols(const float *__restrict__ dY,
                 src[u] = __shfl(myrec.x, gbase + u0 + u, 64);
                 dst[u] = __shfl(myrec.y, gbase + u0 + u, 64);
                 cf[u] = __shfl(mycf, gbase + u0 + u, 64);
-                g[u] = *reinterpret_cast<const float4 *>(dY + (int64_t)(src[u] >> 6) * F + f0);     // unconditional
+                if constexpr (B16) {
+                    const uint2 h_ = *reinterpret_cast<const uint2 *>(dYb + (int64_t)(src[u] >> 6) * F + f0);   // unconditional
+                    g[u] = make_float4(__uint_as_float(h_.x << 16), __uint_as_float(h_.x & 0xffff0000u), __uint_as_float(h_.y << 16),
+                                       __uint_as_float(h_.y & 0xffff0000u));
+                } else {
+                    g[u] = *reinterpret_cast<const float4 *>(dY + (int64_t)(src[u] >> 6) * F + f0);     // unconditional
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -1427,9 +1437,22 @@ int dgg_ell_spmm_t_part(const float *a, const float *dY, int64_t rows, int K, in
     const int64_t nb = nbuckets(ncols);
     PartHdr p = part_layout(const_cast<void *>(part_ws), nb, rows * K);
     const int64_t ngroups = (rows * K + CH - 1) / CH;
-    hipLaunchKernelGGL(spmm_t_cols, dim3((unsigned)((ngroups * 16 + 255) / 256), (unsigned)(F / 64)), dim3(256), 0, (hipStream_t)stream, dY,
-                       F, p.bstart, (int)nb, p.recs, a, K, dX);
+    hipLaunchKernelGGL(spmm_t_cols<false>, dim3((unsigned)((ngroups * 16 + 255) / 256), (unsigned)(F / 64)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const void *>(dY), F, p.bstart, (int)nb, p.recs, a, K, dX);
     return dgg_check_launch("ell_spmm_t_part");
+}
+// the same gathering a bf16 COPY of the cotangent (dYb [rows, F] bf16, 8-byte aligned rows)
+int dgg_ell_spmm_t_part_b16(const float *a, const void *dYb, int64_t rows, int K, int F, const void *part_ws, int64_t ncols, float *dX,
+                            void *stream) {
+    if (F % 64 != 0 || (reinterpret_cast<uintptr_t>(dYb) % 8) != 0)
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "ell_spmm_t_part_b16: feature width must be a multiple of 64 (8-byte aligned rows)");
+    if (rows == 0) return 0;
+    const int64_t nb = nbuckets(ncols);
+    PartHdr p = part_layout(const_cast<void *>(part_ws), nb, rows * K);
+    const int64_t ngroups = (rows * K + CH - 1) / CH;
+    hipLaunchKernelGGL(spmm_t_cols<true>, dim3((unsigned)((ngroups * 16 + 255) / 256), (unsigned)(F / 64)), dim3(256), 0, (hipStream_t)stream, dYb,
+                       F, p.bstart, (int)nb, p.recs, a, K, dX);
+    return dgg_check_launch("ell_spmm_t_part_b16");
 }
 
 // Backward of Z = A H through the partition, one gather of G per record (conv_bwd_cols): dA [rows,K] (entries outside the

@@ -1473,16 +1473,19 @@ class GcniiVariantBf16Fn(torch.autograd.Function):
         return dhi, dh0, dW, (g if ctx.has_inp else None), None, None
 
 
-def dropout_hash(x, p, s0, s1, accumulate_into=None):
-    """x * keep / (1 - p) with the counter-based mask of the fused GCNII stack (dgg_dropout_hash); accumulate_into: += instead"""
+def dropout_hash(x, p, s0, s1, accumulate_into=None, bf16_copy=False):
+    """x * keep / (1 - p) with the counter-based mask of the fused GCNII stack (dgg_dropout_hash); accumulate_into: += instead;
+    bf16_copy: -> (out, bf16(out)) (p = 0: a plain copy with its bf16 twin)"""
     x = _chk(x)
     out = torch.empty_like(x) if accumulate_into is None else accumulate_into
+    outb = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if bf16_copy else None
     _lib.check(_lib.lib().dgg_dropout_hash(_ptr(x), x.numel(), float(p), int(s0) & 0xFFFFFFFF, int(s1) & 0xFFFFFFFF,
-                                           int(accumulate_into is not None), _ptr(out), _stream()), "dropout_hash")
-    return out
+                                           int(accumulate_into is not None), _ptr(out), _ptr(outb), _stream()), "dropout_hash")
+    return (out, outb) if bf16_copy else out
 
 
 _STACK_KEY = 0x9E3779B9
+STACK_BF16_GATHERS = os.environ.get("DGG_STACK_BF16_GATHERS", "1") != "0"      # see GcniiStackBf16Fn
 
 
 class GcniiStackBf16Fn(torch.autograd.Function):
@@ -1496,7 +1499,12 @@ class GcniiStackBf16Fn(torch.autograd.Function):
     ReLU and the dropout (in the product's epilogue; the mask is counter-based and read back off the stored activation, xd != 0), their
     two backward kernels and the two packs of the gradient (one pass: dgg_gcnii_gout_pack), the residual add (A^T d hi accumulates
     into a copy of the gradient).  Same operand rounding as
-    GcniiVariantBf16Fn; the dropout draws from its own counter-based stream (seeded per forward from torch's CPU generator)."""
+    GcniiVariantBf16Fn; the dropout draws from its own counter-based stream (seeded per forward from torch's CPU generator).
+    STACK_BF16_GATHERS (default on; F a multiple of 512): the three kernels that GATHER 2048-wide rows -- the aggregation, the SDDMM
+    (both read the layer's input activation) and the transposed aggregation (reads d hi) -- work on bf16 copies that the producing
+    epilogues write beside the fp32 tensors: they are bound by L2 bandwidth at this width, the copies halve their bytes (fp32
+    accumulation; the residual, the epilogue terms and every saved tensor stay fp32).  This rounds the AGGREGATED activations to 8
+    significant bits as well -- BASELINE configs[4] is "bf16 fwd+bwd" -- where GcniiVariantBf16Fn rounds only the product operands."""
 
     @staticmethod
     def forward(ctx, h0, ahat, idx, part, skip_zero, residual, p, lamda, alpha, seed, *weights):
@@ -1507,25 +1515,35 @@ class GcniiStackBf16Fn(torch.autograd.Function):
         s0, s1 = int(seed[0]) & 0xFFFFFFFF, int(seed[1]) & 0xFFFFFFFF
         K = idx.shape[1]
         S2, _ = _h0_packs(h0)
-        xd = dropout_hash(h0c, p, s0, s1) if p > 0 else h0c
-        his, xds = [], [xd]
+        b16 = STACK_BF16_GATHERS and F % 512 == 0
         pe = _probe_begin()
+        if b16:
+            xd, xdb = dropout_hash(h0c, p, s0, s1, bf16_copy=True)
+        else:
+            xd, xdb = (dropout_hash(h0c, p, s0, s1) if p > 0 else h0c), None
+        his, xds, xdbs = [], [xd], [xdb]
         for l, W in enumerate(weights, 1):
             theta = math.log(lamda / l + 1)
             hi = torch.empty((n, F), device=h0.device, dtype=torch.float32)
             hib = torch.empty((n, F), device=h0.device, dtype=torch.bfloat16)
-            _lib.check(_lib.lib().dgg_ell_spmm_fwd_bf16(_ptr(idx), _ptr(ahat), _ptr(xd), n, K, F, _ptr(hi), _ptr(hib), _stream()), "ell_spmm_fwd_bf16")
+            if b16:
+                _lib.check(_lib.lib().dgg_ell_spmm_fwd_b16(_ptr(idx), _ptr(ahat), _ptr(xdb), n, K, F, _ptr(hi), _ptr(hib), _stream()), "ell_spmm_fwd_b16")
+            else:
+                _lib.check(_lib.lib().dgg_ell_spmm_fwd_bf16(_ptr(idx), _ptr(ahat), _ptr(xd), n, K, F, _ptr(hi), _ptr(hib), _stream()), "ell_spmm_fwd_bf16")
             Wt = _packed_weight(W, True)                         # [F, 2F]
             out = torch.empty((n, F), device=h0.device, dtype=torch.float32)
+            outb = torch.empty((n, F), device=h0.device, dtype=torch.bfloat16) if (b16 and l < L) else None      # (the last output is gathered by no one)
             _lib.check(_lib.lib().dgg_gcnii_gemm_bf16_split_act(_ptr(hib), _ptr(S2), _ptr(Wt), n, F, 2 * F, F, _ptr(hi), _ptr(h0c),
                                                                 _ptr(xd if residual else None), float(theta), float(alpha), 1, float(p), s0,
-                                                                (s1 ^ (_STACK_KEY * l)) & 0xFFFFFFFF, _ptr(out), _stream()),
+                                                                (s1 ^ (_STACK_KEY * l)) & 0xFFFFFFFF, _ptr(out), _ptr(outb), _stream()),
                        "gcnii_gemm_bf16_split_act")
             his.append(hi)
             xds.append(out)
-            xd = out
+            xdbs.append(outb)
+            xd, xdb = out, outb
         _probe_end("gcnii_stack_fwd", pe)
         ctx.save_for_backward(h0, ahat, idx, *weights, *his, *xds)
+        ctx.xdbs = xdbs[:L] if b16 else None                     # bf16 copies of xd_0 .. xd_{L-1} (plain tensors, no autograd edge)
         ctx.cfg = (L, part, bool(skip_zero), bool(residual), float(p), float(lamda), float(alpha), s0, s1)
         return xd
 
@@ -1543,6 +1561,7 @@ class GcniiStackBf16Fn(torch.autograd.Function):
             part = part_build(idx, ahat, n)
         _, h0T = _h0_packs(h0)
         scale = 1.0 / (1.0 - p)
+        b16 = ctx.xdbs is not None
         gx = _chk(g.contiguous())
         dh0 = torch.empty((n, F), device=dev, dtype=torch.float32)
         dA = None
@@ -1557,9 +1576,10 @@ class GcniiStackBf16Fn(torch.autograd.Function):
             _lib.check(_lib.lib().dgg_gcnii_gout_pack(_ptr(gx), _ptr(xd_l), float(scale), n, F, _ptr(gout), _ptr(Gp), _ptr(GT), n64, _stream()),
                        "gcnii_gout_pack")
             dhi = torch.empty((n, F), device=dev, dtype=torch.float32)
+            dhib = torch.empty((n, F), device=dev, dtype=torch.bfloat16) if b16 else None
             dh0_l = dh0 if l == L else torch.empty((n, F), device=dev, dtype=torch.float32)
-            _lib.check(_lib.lib().dgg_gcnii_dsupport_bf16(_ptr(Gp), _ptr(_packed_weight(W, False)), n, F, _ptr(gout), float(theta), float(alpha),
-                                                          _ptr(dhi), _ptr(dh0_l), _stream()), "gcnii_dsupport_bf16")
+            _lib.check(_lib.lib().dgg_gcnii_dsupport_bf16_b(_ptr(Gp), _ptr(_packed_weight(W, False)), n, F, _ptr(gout), float(theta), float(alpha),
+                                                            _ptr(dhi), _ptr(dh0_l), _ptr(dhib), _stream()), "gcnii_dsupport_bf16")
             if l != L:
                 dh0.add_(dh0_l)
             if ctx.needs_input_grad[10 + l - 1]:
@@ -1569,11 +1589,16 @@ class GcniiStackBf16Fn(torch.autograd.Function):
                            "gemm_nt_bf16_rows2")
                 dWs[l - 1] = dW
             dA_l = torch.empty((n, K), device=dev, dtype=torch.float32)
-            _lib.check(_lib.lib().dgg_ell_spmm_bwd(_ptr(idx), _ptr(ahat), _ptr(xd_prev), _ptr(dhi), n, K, F, int(skip_zero), _ptr(dA_l), _ptr(None),
-                                                   _stream()), "ell_spmm_bwd")
-            dA = dA_l if dA is None else dA.add_(dA_l)
             gx = gout.clone() if residual else torch.zeros_like(gout)       # + g through the residual; A^T d hi accumulates into it
-            _lib.check(_lib.lib().dgg_ell_spmm_t_part(_ptr(ahat), _ptr(dhi), n, K, F, _ptr(part), n, _ptr(gx), _stream()), "ell_spmm_t_part")
+            if b16:
+                _lib.check(_lib.lib().dgg_ell_sddmm_b16(_ptr(idx), _ptr(ahat), _ptr(ctx.xdbs[l - 1]), _ptr(dhib), n, K, F, int(skip_zero), _ptr(dA_l),
+                                                        _stream()), "ell_sddmm_b16")
+                _lib.check(_lib.lib().dgg_ell_spmm_t_part_b16(_ptr(ahat), _ptr(dhib), n, K, F, _ptr(part), n, _ptr(gx), _stream()), "ell_spmm_t_part_b16")
+            else:
+                _lib.check(_lib.lib().dgg_ell_spmm_bwd(_ptr(idx), _ptr(ahat), _ptr(xd_prev), _ptr(dhi), n, K, F, int(skip_zero), _ptr(dA_l), _ptr(None),
+                                                       _stream()), "ell_spmm_bwd")
+                _lib.check(_lib.lib().dgg_ell_spmm_t_part(_ptr(ahat), _ptr(dhi), n, K, F, _ptr(part), n, _ptr(gx), _stream()), "ell_spmm_t_part")
+            dA = dA_l if dA is None else dA.add_(dA_l)
         if p > 0:
             dropout_hash(gx, p, s0, s1, accumulate_into=dh0)     # back through xd_0 = dropout(h0): the same mask
         else:

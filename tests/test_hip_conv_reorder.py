@@ -343,14 +343,18 @@ def _stack_inputs(n, F, L, dev, seed=3):
     return T(h0, dev), T(ahat, dev), idx_t, part, [T(W, dev) for W in Ws], T(cot, dev)
 
 
-@pytest.mark.parametrize("n,F,L,residual", [(700, 256, 4, True), (1100, 512, 3, False)])
-def test_gcnii_stack_bf16_matches_the_layers_one_by_one(dev, n, F, L, residual):
+@pytest.mark.parametrize("n,F,L,residual,gathers", [(700, 256, 4, True, False), (1100, 512, 3, False, False), (1100, 512, 3, True, True)])
+def test_gcnii_stack_bf16_matches_the_layers_one_by_one(dev, n, F, L, residual, gathers, monkeypatch):
     """ops.GcniiStackBf16Fn (dropout off) against the same stack through the per-layer pieces it replaces -- EllSpmmFn, GcniiVariantBf16Fn,
-    torch.relu under torch autograd: the same bf16 operands in the same contraction order, so the forward is identical up to the order
-    of the fp32 epilogue terms (1e-6), and every gradient (h0, the adjacency values, each weight) agrees to 1e-4 of its max (d h0 is
-    accumulated over the layers in another order; the ReLU mask is read off the activation)."""
+    torch.relu under torch autograd.  gathers False: the same bf16 operands in the same contraction order, so the forward is identical up
+    to the order of the fp32 epilogue terms (1e-6), and every gradient (h0, the adjacency values, each weight) agrees to 1e-4 of its max
+    (d h0 is accumulated over the layers in another order; the ReLU mask is read off the activation).  gathers True (the default for
+    widths in multiples of 512): the aggregation, the SDDMM and the transposed aggregation read bf16 copies of what they gather -- the
+    aggregated activations are rounded to 8 significant bits as well: forward 1e-2, gradients 3e-2 of max."""
     import math
     from dgg_amd import ops
+    monkeypatch.setattr(ops, "STACK_BF16_GATHERS", gathers)
+    ftol, gtol = (1e-2, 3e-2) if gathers else (1e-6, 1e-4)
     h0, ahat, idx, part, Ws, cot = _stack_inputs(n, F, L, dev)
     lamda, alpha = 0.5, 0.3
 
@@ -367,10 +371,15 @@ def test_gcnii_stack_bf16_matches_the_layers_one_by_one(dev, n, F, L, residual):
         x = torch.relu(ops.GcniiVariantBf16Fn.apply(hi, b_h0, W, x if residual else None, math.log(lamda / l + 1), alpha))
     (x * cot).sum().backward()
     rel = lambda u, v: float((u.double() - v.double()).abs().max() / v.double().abs().max())  # noqa: E731
-    assert rel(y, x) <= 1e-6, rel(y, x)
-    assert rel(a_h0.grad, b_h0.grad) <= 1e-4 and rel(a_ah.grad, b_ah.grad) <= 1e-4
+    if gathers:
+        # (8-bit rounding of the aggregated activations moves pre-activations that sit at the ReLU's kink across it: single elements of
+        #  the gradients then differ by a whole term, so the gradients are held in the Frobenius norm)
+        rel = lambda u, v: float((u.double() - v.double()).norm() / v.double().norm())  # noqa: E731,F811
+    assert rel(y, x) <= ftol, rel(y, x)
+    assert gathers == (rel(y, x) > 1e-5), "the bf16 gather copies are in use exactly when asked for"
+    assert rel(a_h0.grad, b_h0.grad) <= gtol and rel(a_ah.grad, b_ah.grad) <= gtol, (rel(a_h0.grad, b_h0.grad), rel(a_ah.grad, b_ah.grad))
     for u, v in zip(a_W, b_W):
-        assert rel(u.grad, v.grad) <= 1e-4
+        assert rel(u.grad, v.grad) <= gtol, rel(u.grad, v.grad)
 
 
 def _np_drop_keep(s0, s1, n_elem, p):
@@ -491,11 +500,13 @@ def test_config4_ppi_gcniippi_dgg_bf16_end_to_end(dev):
             grads.append({k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None})
             adjs.append(unnorm)
         assert torch.equal(adjs[0].idx, adjs[1].idx), "the two runs must select the same graph (same seed, fp32 DGG in both)"
-        # the fused stack (dropout 0): the same products on the same operands as the layers one by one
-        assert torch.equal(adjs[2].idx, adjs[1].idx) and rel(outs[2], outs[1]) <= 1e-5, rel(outs[2], outs[1])
+        # the fused stack (dropout 0): the same products as the layers one by one, its three gather kernels on bf16 copies of the
+        # activations / of d hi (ops.STACK_BF16_GATHERS: one more 8-bit rounding per layer)
+        assert torch.equal(adjs[2].idx, adjs[1].idx) and rel(outs[2], outs[1]) <= 1e-2, rel(outs[2], outs[1])
         assert set(grads[2]) == set(grads[1])
         for k in grads[1]:
-            assert rel(grads[2][k], grads[1][k]) <= 2e-3, (k, rel(grads[2][k], grads[1][k]))
+            assert rel(grads[2][k], grads[1][k]) <= 3e-2, (k, rel(grads[2][k], grads[1][k]))
+        assert rel(outs[2], outs[0]) <= 1e-2
         assert rel(outs[1], outs[0]) <= 1e-2
         assert set(grads[0]) == set(grads[1]) and len(grads[0]) >= L + 4
         for k in grads[0]:
