@@ -468,10 +468,16 @@ int dgg_gcnii_dsupport_bf16(const void *Gp, const void *Wp, int64_t n, int64_t F
  *   dgg_dropout_hash               the same mask on a tensor no product produces (the stack's input h0; `accumulate`: out += ...,
  *                                  used with the same seeds for the gradient flowing back through that dropout)
  * backward:
- *   dgg_gcnii_gout_pack            g = g_in * (xd' != 0 ? 1/(1-p) : 0) as fp32 and as the two bf16 operand packs (plain, transposed)
+ *   dgg_gcnii_gout_pack            g = g_in * (xd' != 0 ? 1/(1-p) : 0) as fp32 (twice on request: the second copy is the buffer the
+ *                                  transposed aggregation accumulates into -- the residual add) and as the two bf16 operand packs
  * ([d hi | d h0] is dgg_gcnii_dsupport_bf16 -- accumulating d h0 inside its epilogue measured 40 us slower per product than a separate
  * add --, the weight gradient dgg_gemm_nt_bf16_rows2; d A and A^T d hi are dgg_ell_spmm_bwd / dgg_ell_spmm_t_part) */
-int dgg_ell_spmm_fwd_bf16(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, float *Y, void *Yb, void *stream);
+/* (Yb rows have stride ldyb >= F bf16 elements: the copy can be written straight into the left half of a [n, 2F] product operand) */
+int dgg_ell_spmm_fwd_bf16(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, float *Y, void *Yb, int64_t ldyb,
+                          void *stream);
+/* the layer's epilogue as a separate pass after the plain product dgg_gemm_nt_bf16 (measured faster than inside the product's epilogue) */
+int dgg_gcnii_stack_epilogue(const float *sw, const float *hi, const float *h0, const float *inp, int64_t n, float theta, float alpha,
+                             float drop_p, uint32_t s0, uint32_t s1, float *out, void *outb, void *stream);
 /* `outb` (nullable): bf16 copy of the output, for the kernels that gather it next */
 int dgg_gcnii_gemm_bf16_split_act(const void *S1, const void *S2, const void *Wt, int64_t n, int64_t F, int64_t K, int64_t F1, const float *hi,
                                   const float *h0, const float *inp, float theta, float alpha, int relu, float drop_p, uint32_t s0,
@@ -481,7 +487,8 @@ int dgg_dropout_hash(const float *x, int64_t n, float p, uint32_t s0, uint32_t s
  * transposed aggregation): at F = 2048 they are bound by L2 bandwidth, the copies halve their bytes; accumulation stays fp32.
  *   dgg_ell_spmm_fwd_b16     Y = A Xb (+ bf16(Y));  dgg_ell_sddmm_b16   dA = <dYb_i, Xb_j>;  dgg_ell_spmm_t_part_b16   dX += A^T dYb
  *   dgg_gcnii_dsupport_bf16_b  dgg_gcnii_dsupport_bf16 that also leaves bf16(d hi) */
-int dgg_ell_spmm_fwd_b16(const int32_t *idx, const float *ahat, const void *Xb, int64_t N, int K, int F, float *Y, void *Yb, void *stream);
+int dgg_ell_spmm_fwd_b16(const int32_t *idx, const float *ahat, const void *Xb, int64_t N, int K, int F, float *Y, void *Yb, int64_t ldyb,
+                         void *stream);
 int dgg_ell_sddmm_b16(const int32_t *idx, const float *ahat, const void *Xb, const void *dYb, int64_t N, int K, int F, int skip_zero, float *dA,
                       void *stream);
 int dgg_ell_spmm_t_part_b16(const float *a, const void *dYb, int64_t rows, int K, int F, const void *part_ws, int64_t ncols, float *dX,
@@ -489,7 +496,7 @@ int dgg_ell_spmm_t_part_b16(const float *a, const void *dYb, int64_t rows, int K
 int dgg_gcnii_dsupport_bf16_b(const void *Gp, const void *Wp, int64_t n, int64_t F, const float *g, float theta, float alpha, float *dhi,
                               float *dh0, void *dhib, void *stream);
 int dgg_gcnii_gout_pack(const float *gin, const float *xd, float scale, int64_t n, int64_t F, float *g, void *Gp, void *GT, int64_t ldT,
-                        void *stream);
+                        float *g2, void *stream);
 
 /* ---- dense all-pairs alternates: DGG_LearnableK_SDD (dgm.py:259-351, dist_fn="metric") and DGG_StraightThrough
  * (dgm.py:140-182 + 63-100), noise off.  Rows are a softmax over ALL N columns, outputs are dense [B,N,N]: O(N^2) by

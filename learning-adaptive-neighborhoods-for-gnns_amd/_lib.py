@@ -100,14 +100,15 @@ PROTOTYPES = {
     "dgg_gcnii_gemm_bf16_split": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _f32, _vp, _vp],
     "dgg_gemm_nt_bf16_rows2": [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _f32, _vp, _vp],
     "dgg_gcnii_dsupport_bf16": [_vp, _vp, _i64, _i64, _vp, _f32, _f32, _vp, _vp, _vp],
-    "dgg_ell_spmm_fwd_bf16": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
+    "dgg_ell_spmm_fwd_bf16": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp],
+    "dgg_gcnii_stack_epilogue": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _u32, _u32, _vp, _vp, _vp],
     "dgg_gcnii_gemm_bf16_split_act": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _f32, _i32, _f32, _u32, _u32, _vp, _vp, _vp],
     "dgg_dropout_hash": [_vp, _i64, _f32, _u32, _u32, _i32, _vp, _vp, _vp],
-    "dgg_ell_spmm_fwd_b16": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],
+    "dgg_ell_spmm_fwd_b16": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp],
     "dgg_ell_sddmm_b16": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp],
     "dgg_ell_spmm_t_part_b16": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp],
     "dgg_gcnii_dsupport_bf16_b": [_vp, _vp, _i64, _i64, _vp, _f32, _f32, _vp, _vp, _vp, _vp],
-    "dgg_gcnii_gout_pack": [_vp, _vp, _f32, _i64, _i64, _vp, _vp, _vp, _i64, _vp],
+    "dgg_gcnii_gout_pack": [_vp, _vp, _f32, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp],
     "dgg_ell_spmm_act_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp],
     "dgg_act_bwd": [_vp, _vp, _i64, _i32, _vp, _vp],
     "dgg_norm_bwd_da_part": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp],

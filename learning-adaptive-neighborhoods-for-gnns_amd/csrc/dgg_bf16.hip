@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float *__restrict_
 // for free by accumulating A^T d hi into a copy of g).
 __global__ __launch_bounds__(256) void gcnii_gout_pack_kernel(const float *__restrict__ gin, const float *__restrict__ xd, float scale, int n,
                                                              int F, float *__restrict__ g, __bf16 *__restrict__ Gp, __bf16 *__restrict__ GT,
-                                                             int ldT) {
+                                                             int ldT, float *__restrict__ g2) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256) void gcnii_gout_pack_kernel(const float *__res
             const int64_t o = (int64_t)r * F + c;
             v = xd[o] != 0.0f ? gin[o] * scale : 0.0f;
             g[o] = v;
+            if (g2) g2[o] = v;                                   // (a second fp32 copy: the buffer A^T d hi accumulates into -- the residual)
             Gp[o] = (__bf16)v;
         }
         tile[i][tx] = v;
@@ -312,14 +313,15 @@ int dgg_gcnii_gemm_bf16_split_act(const void *S1, const void *S2, const void *Wt
                        (hipStream_t)stream, 1, reinterpret_cast<const __bf16 *>(S2), (int)F1);
 }
 
-// see gcnii_gout_pack_kernel: gin, xd, g fp32 [n,F]; Gp bf16 [n,F]; GT bf16 [F, ldT], ldT >= n a multiple of 64 (columns beyond n zeroed)
+// see gcnii_gout_pack_kernel: gin, xd, g fp32 [n,F]; Gp bf16 [n,F]; GT bf16 [F, ldT], ldT >= n a multiple of 64 (columns beyond n zeroed);
+// g2 (nullable): a second fp32 copy of g
 int dgg_gcnii_gout_pack(const float *gin, const float *xd, float scale, int64_t n, int64_t F, float *g, void *Gp, void *GT, int64_t ldT,
-                        void *stream) {
+                        float *g2, void *stream) {
     if (n <= 0 || F <= 0) return 0;
     if (ldT < n || ldT % 64 != 0 || F % 64 != 0) return dgg_set_error(DGG_ERR_ARG, "gcnii_gout_pack: F and ldT multiples of 64, ldT >= n");
     const dim3 grid((unsigned)((F + 31) / 32), (unsigned)((ldT + 31) / 32));
     hipLaunchKernelGGL(gcnii_gout_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, gin, xd, scale, (int)n, (int)F, g,
-                       reinterpret_cast<__bf16 *>(Gp), reinterpret_cast<__bf16 *>(GT), (int)ldT);
+                       reinterpret_cast<__bf16 *>(Gp), reinterpret_cast<__bf16 *>(GT), (int)ldT, g2);
     return dgg_check_launch("gcnii_gout_pack");
 }
 

@@ -62,7 +62,7 @@ __global__ void normalize_fwd_kernel(const int32_t *__restrict__ idx, const floa
 template <int VEC>
 __global__ __launch_bounds__(WPB * 64) void spmm_fwd_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
                                                            const float *__restrict__ X, int64_t N, int K, int F,
-                                                           float *__restrict__ Y, __bf16 *__restrict__ Yb = nullptr) {
+                                                           float *__restrict__ Y, __bf16 *__restrict__ Yb = nullptr, int64_t ldyb = 0) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(WPB * 64) void spmm_fwd_kernel(const int32_t *__res
         for (int v = 0; v < VEC; v++) Y[i * F + c0 + v] = acc[v];
         if (Yb) {                                    // the bf16 copy the layer product reads (GCNII stack: no separate pack pass)
 #pragma unroll
-            for (int v = 0; v < VEC; v++) Yb[i * F + c0 + v] = (__bf16)acc[v];
+            for (int v = 0; v < VEC; v++) Yb[i * ldyb + c0 + v] = (__bf16)acc[v];
         }
     }
 }
@@ -109,7 +109,7 @@ __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 
 // of 512 features; fp32 accumulation in entry order; writes Y fp32 and, if asked, bf16(Y).
 __global__ __launch_bounds__(WPB * 64) void spmm_fwd_b16_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
                                                                const uint4 *__restrict__ Xb, int64_t N, int K, int F,
-                                                               float *__restrict__ Y, __bf16 *__restrict__ Yb) {
+                                                               float *__restrict__ Y, __bf16 *__restrict__ Yb, int64_t ldyb) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(WPB * 64) void spmm_fwd_b16_kernel(const int32_t *_
         yo[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
         if (Yb) {
 #pragma unroll
-            for (int v = 0; v < 8; v++) Yb[i * F + 8 * c8 + v] = (__bf16)acc[v];
+            for (int v = 0; v < 8; v++) Yb[i * ldyb + 8 * c8 + v] = (__bf16)acc[v];
         }
     }
 }
@@ -597,6 +597,30 @@ __global__ void gcnii_epilogue_fwd_kernel(const float *__restrict__ sw, const fl
     if (inp) o += inp[e];
     out[e] = o;
 }
+// the same with the layer's ReLU, the next layer's counter-based dropout and a bf16 copy of the result (fused GCNII stack): as a
+// SEPARATE pass after the plain product it measured faster than inside the product's epilogue (91 + 17 us against 133 at n = 2250:
+// the product kernel with a fused epilogue waits for its operand loads before every K-step's MFMAs)
+__global__ void gcnii_stack_epilogue_kernel(const float4 *__restrict__ sw, const float4 *__restrict__ hi, const float4 *__restrict__ h0,
+                                            const float4 *__restrict__ inp, int64_t n4, float theta, float alpha, uint32_t thr24, float scale,
+                                            uint32_t s0, uint32_t s1, float4 *__restrict__ out, uint2 *__restrict__ outb) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n4) return;
+    const float4 a = sw[e], b = hi[e], c = h0[e];
+    const float4 d = inp ? inp[e] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float omt = 1.0f - theta, oma = 1.0f - alpha;
+    float o[4] = {theta * a.x + omt * (oma * b.x + alpha * c.x) + d.x, theta * a.y + omt * (oma * b.y + alpha * c.y) + d.y,
+                  theta * a.z + omt * (oma * b.z + alpha * c.z) + d.z, theta * a.w + omt * (oma * b.w + alpha * c.w) + d.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        o[q] = o[q] > 0.0f ? o[q] : 0.0f;
+        if (thr24) o[q] = drop_keep(s0, s1, (uint32_t)(4 * e + q), thr24) ? o[q] * scale : 0.0f;
+    }
+    out[e] = make_float4(o[0], o[1], o[2], o[3]);
+    if (outb) {
+        const __bf16 h_[4] = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+        outb[e] = *reinterpret_cast<const uint2 *>(h_);
+    }
+}
 __global__ void gcnii_epilogue_bwd_kernel(const float *__restrict__ g, int64_t n, float theta, float alpha, float *__restrict__ dsw,
                                           float *__restrict__ dhi, float *__restrict__ dh0) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -658,26 +682,27 @@ int dgg_ell_normalize_fwd(const int32_t *idx, const float *w, const float *rs, i
 
 // Y = A X and, in the same pass, Yb = bf16(Y) [N, F] (F a multiple of 256, 16-byte aligned rows): the aggregation of a GCNII layer
 // on the bf16 matrix cores hands its product operand over without a pack pass (model.py:34 + the operand rounding of dgg_bf16.hip)
-int dgg_ell_spmm_fwd_bf16(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, float *Y, void *Yb,
+int dgg_ell_spmm_fwd_bf16(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, float *Y, void *Yb, int64_t ldyb,
                           void *stream) {
     if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
-    if (F % 256 != 0 || ((uintptr_t)X % 16) || ((uintptr_t)Y % 16) || !Yb)
-        return dgg_set_error(DGG_ERR_UNSUPPORTED, "ell_spmm_fwd_bf16: F must be a multiple of 256, rows 16-byte aligned, Yb given");
+    if (F % 256 != 0 || ((uintptr_t)X % 16) || ((uintptr_t)Y % 16) || !Yb || ldyb < F)
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "ell_spmm_fwd_bf16: F must be a multiple of 256, rows 16-byte aligned, Yb given with ldyb >= F");
     if (N == 0) return 0;
     dim3 grid(rows_grid(N), (unsigned)(F / 256));
     hipLaunchKernelGGL(spmm_fwd_kernel<4>, grid, dim3(WPB * 64), 0, (hipStream_t)stream, idx, ahat, X, N, K, F, Y,
-                       reinterpret_cast<__bf16 *>(Yb));
+                       reinterpret_cast<__bf16 *>(Yb), ldyb);
     return dgg_check_launch("ell_spmm_fwd_bf16");
 }
 
 // dgg_ell_spmm_fwd_bf16 gathering a bf16 COPY of X (Xb [N, F] bf16, F a multiple of 512, 16-byte aligned rows): half the gathered bytes
-int dgg_ell_spmm_fwd_b16(const int32_t *idx, const float *ahat, const void *Xb, int64_t N, int K, int F, float *Y, void *Yb, void *stream) {
+int dgg_ell_spmm_fwd_b16(const int32_t *idx, const float *ahat, const void *Xb, int64_t N, int K, int F, float *Y, void *Yb, int64_t ldyb,
+                         void *stream) {
     if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
     if (F % 512 != 0 || ((uintptr_t)Xb % 16) || ((uintptr_t)Y % 16)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ell_spmm_fwd_b16: F must be a multiple of 512, rows 16-byte aligned");
     if (N == 0) return 0;
     dim3 grid(rows_grid(N), (unsigned)(F / 512));
     hipLaunchKernelGGL(spmm_fwd_b16_kernel, grid, dim3(WPB * 64), 0, (hipStream_t)stream, idx, ahat, reinterpret_cast<const uint4 *>(Xb), N, K, F,
-                       Y, reinterpret_cast<__bf16 *>(Yb));
+                       Y, reinterpret_cast<__bf16 *>(Yb), ldyb);
     return dgg_check_launch("ell_spmm_fwd_b16");
 }
 // dA = <dY_i, X_j> on bf16 copies of both operands (Xb, dYb [N, F] bf16, F a multiple of 8; fp32 accumulation): the SDDMM of the stack
@@ -784,6 +809,19 @@ int dgg_gcnii_epilogue_fwd(const float *sw, const float *hi, const float *h0, co
     hipLaunchKernelGGL(gcnii_epilogue_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sw, hi, h0, inp, n,
                        theta, alpha, out);
     return dgg_check_launch("gcnii_epilogue_fwd");
+}
+// out = dropout(relu(theta sw + (1 - theta)((1 - alpha) hi + alpha h0) (+ inp))) and bf16(out) (outb nullable); n a multiple of 4,
+// 16-byte aligned operands; the mask as dgg_gcnii_gemm_bf16_split_act (element e kept iff hash24(s0, s1, e) >= drop_p 2^24)
+int dgg_gcnii_stack_epilogue(const float *sw, const float *hi, const float *h0, const float *inp, int64_t n, float theta, float alpha,
+                             float drop_p, uint32_t s0, uint32_t s1, float *out, void *outb, void *stream) {
+    if (n % 4 != 0 || !(drop_p >= 0.0f && drop_p < 1.0f) || n >= ((int64_t)1 << 32) || !hi || !h0)
+        return dgg_set_error(DGG_ERR_ARG, "gcnii_stack_epilogue: n a multiple of 4 below 2^32, drop_p in [0,1), hi and h0 given");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gcnii_stack_epilogue_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(sw), reinterpret_cast<const float4 *>(hi), reinterpret_cast<const float4 *>(h0),
+                       reinterpret_cast<const float4 *>(inp), n / 4, theta, alpha, (uint32_t)(drop_p * 16777216.0f), 1.0f / (1.0f - drop_p), s0, s1,
+                       reinterpret_cast<float4 *>(out), reinterpret_cast<uint2 *>(outb));
+    return dgg_check_launch("gcnii_stack_epilogue");
 }
 int dgg_gcnii_epilogue_bwd(const float *g, int64_t n, float theta, float alpha, float *dsw, float *dhi, float *dh0, void *stream) {
     if (n == 0) return 0;

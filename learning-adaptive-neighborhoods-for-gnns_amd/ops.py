@@ -1486,6 +1486,7 @@ def dropout_hash(x, p, s0, s1, accumulate_into=None, bf16_copy=False):
 
 _STACK_KEY = 0x9E3779B9
 STACK_BF16_GATHERS = os.environ.get("DGG_STACK_BF16_GATHERS", "1") != "0"      # see GcniiStackBf16Fn
+STACK_SPLIT_EPILOGUE = os.environ.get("DGG_STACK_SPLIT_EPILOGUE", "1") != "0"  # forward product + one elementwise pass instead of the fused epilogue
 
 
 class GcniiStackBf16Fn(torch.autograd.Function):
@@ -1522,21 +1523,32 @@ class GcniiStackBf16Fn(torch.autograd.Function):
         else:
             xd, xdb = (dropout_hash(h0c, p, s0, s1) if p > 0 else h0c), None
         his, xds, xdbs = [], [xd], [xdb]
+        # the product operand cat[bf16(hi) | bf16(h0)] [n, 2F]: the right half once per stack, the left half by every layer's aggregation
+        if STACK_SPLIT_EPILOGUE:
+            hib, ldh = torch.empty((n, 2 * F), device=h0.device, dtype=torch.bfloat16), 2 * F
+            hib[:, F:].copy_(S2)
+            sw = torch.empty((n, F), device=h0.device, dtype=torch.float32)
+        else:
+            hib, ldh = torch.empty((n, F), device=h0.device, dtype=torch.bfloat16), F
         for l, W in enumerate(weights, 1):
             theta = math.log(lamda / l + 1)
             hi = torch.empty((n, F), device=h0.device, dtype=torch.float32)
-            hib = torch.empty((n, F), device=h0.device, dtype=torch.bfloat16)
             if b16:
-                _lib.check(_lib.lib().dgg_ell_spmm_fwd_b16(_ptr(idx), _ptr(ahat), _ptr(xdb), n, K, F, _ptr(hi), _ptr(hib), _stream()), "ell_spmm_fwd_b16")
+                _lib.check(_lib.lib().dgg_ell_spmm_fwd_b16(_ptr(idx), _ptr(ahat), _ptr(xdb), n, K, F, _ptr(hi), _ptr(hib), ldh, _stream()), "ell_spmm_fwd_b16")
             else:
-                _lib.check(_lib.lib().dgg_ell_spmm_fwd_bf16(_ptr(idx), _ptr(ahat), _ptr(xd), n, K, F, _ptr(hi), _ptr(hib), _stream()), "ell_spmm_fwd_bf16")
+                _lib.check(_lib.lib().dgg_ell_spmm_fwd_bf16(_ptr(idx), _ptr(ahat), _ptr(xd), n, K, F, _ptr(hi), _ptr(hib), ldh, _stream()), "ell_spmm_fwd_bf16")
             Wt = _packed_weight(W, True)                         # [F, 2F]
             out = torch.empty((n, F), device=h0.device, dtype=torch.float32)
             outb = torch.empty((n, F), device=h0.device, dtype=torch.bfloat16) if (b16 and l < L) else None      # (the last output is gathered by no one)
-            _lib.check(_lib.lib().dgg_gcnii_gemm_bf16_split_act(_ptr(hib), _ptr(S2), _ptr(Wt), n, F, 2 * F, F, _ptr(hi), _ptr(h0c),
-                                                                _ptr(xd if residual else None), float(theta), float(alpha), 1, float(p), s0,
-                                                                (s1 ^ (_STACK_KEY * l)) & 0xFFFFFFFF, _ptr(out), _ptr(outb), _stream()),
-                       "gcnii_gemm_bf16_split_act")
+            sl = (s1 ^ (_STACK_KEY * l)) & 0xFFFFFFFF
+            if STACK_SPLIT_EPILOGUE:       # plain product, then ONE elementwise pass (faster than the product with the epilogue inside)
+                _lib.check(_lib.lib().dgg_gemm_nt_bf16(_ptr(hib), _ptr(Wt), n, F, 2 * F, 1.0, _ptr(sw), _stream()), "gemm_nt_bf16")
+                _lib.check(_lib.lib().dgg_gcnii_stack_epilogue(_ptr(sw), _ptr(hi), _ptr(h0c), _ptr(xd if residual else None), n * F, float(theta),
+                                                               float(alpha), float(p), s0, sl, _ptr(out), _ptr(outb), _stream()), "gcnii_stack_epilogue")
+            else:
+                _lib.check(_lib.lib().dgg_gcnii_gemm_bf16_split_act(_ptr(hib), _ptr(S2), _ptr(Wt), n, F, 2 * F, F, _ptr(hi), _ptr(h0c),
+                                                                    _ptr(xd if residual else None), float(theta), float(alpha), 1, float(p), s0,
+                                                                    sl, _ptr(out), _ptr(outb), _stream()), "gcnii_gemm_bf16_split_act")
             his.append(hi)
             xds.append(out)
             xdbs.append(outb)
@@ -1573,8 +1585,9 @@ class GcniiStackBf16Fn(torch.autograd.Function):
             gout = torch.empty((n, F), device=dev, dtype=torch.float32)
             Gp = torch.empty((n, F), device=dev, dtype=torch.bfloat16)
             GT = torch.empty((F, n64), device=dev, dtype=torch.bfloat16)
-            _lib.check(_lib.lib().dgg_gcnii_gout_pack(_ptr(gx), _ptr(xd_l), float(scale), n, F, _ptr(gout), _ptr(Gp), _ptr(GT), n64, _stream()),
-                       "gcnii_gout_pack")
+            gnext = torch.empty((n, F), device=dev, dtype=torch.float32) if residual else None       # becomes g + A^T d hi below
+            _lib.check(_lib.lib().dgg_gcnii_gout_pack(_ptr(gx), _ptr(xd_l), float(scale), n, F, _ptr(gout), _ptr(Gp), _ptr(GT), n64, _ptr(gnext),
+                                                      _stream()), "gcnii_gout_pack")
             dhi = torch.empty((n, F), device=dev, dtype=torch.float32)
             dhib = torch.empty((n, F), device=dev, dtype=torch.bfloat16) if b16 else None
             dh0_l = dh0 if l == L else torch.empty((n, F), device=dev, dtype=torch.float32)
@@ -1589,7 +1602,7 @@ class GcniiStackBf16Fn(torch.autograd.Function):
                            "gemm_nt_bf16_rows2")
                 dWs[l - 1] = dW
             dA_l = torch.empty((n, K), device=dev, dtype=torch.float32)
-            gx = gout.clone() if residual else torch.zeros_like(gout)       # + g through the residual; A^T d hi accumulates into it
+            gx = gnext if residual else torch.zeros_like(gout)              # + g through the residual; A^T d hi accumulates into it
             if b16:
                 _lib.check(_lib.lib().dgg_ell_sddmm_b16(_ptr(idx), _ptr(ahat), _ptr(ctx.xdbs[l - 1]), _ptr(dhib), n, K, F, int(skip_zero), _ptr(dA_l),
                                                         _stream()), "ell_sddmm_b16")

@@ -347,14 +347,14 @@ def _stack_inputs(n, F, L, dev, seed=3):
 def test_gcnii_stack_bf16_matches_the_layers_one_by_one(dev, n, F, L, residual, gathers, monkeypatch):
     """ops.GcniiStackBf16Fn (dropout off) against the same stack through the per-layer pieces it replaces -- EllSpmmFn, GcniiVariantBf16Fn,
     torch.relu under torch autograd.  gathers False: the same bf16 operands in the same contraction order, so the forward is identical up
-    to the order of the fp32 epilogue terms (1e-6), and every gradient (h0, the adjacency values, each weight) agrees to 1e-4 of its max
+    to the order of the fp32 epilogue terms (5e-5), and every gradient (h0, the adjacency values, each weight) agrees to 5e-4 of its max
     (d h0 is accumulated over the layers in another order; the ReLU mask is read off the activation).  gathers True (the default for
     widths in multiples of 512): the aggregation, the SDDMM and the transposed aggregation read bf16 copies of what they gather -- the
     aggregated activations are rounded to 8 significant bits as well: forward 1e-2, gradients 3e-2 of max."""
     import math
     from dgg_amd import ops
     monkeypatch.setattr(ops, "STACK_BF16_GATHERS", gathers)
-    ftol, gtol = (1e-2, 3e-2) if gathers else (1e-6, 1e-4)
+    ftol, gtol = (1e-2, 3e-2) if gathers else (5e-5, 5e-4)       # (the epilogue runs as its own pass: another order of its fp32 terms)
     h0, ahat, idx, part, Ws, cot = _stack_inputs(n, F, L, dev)
     lamda, alpha = 0.5, 0.3
 
@@ -376,7 +376,7 @@ def test_gcnii_stack_bf16_matches_the_layers_one_by_one(dev, n, F, L, residual, 
         #  the gradients then differ by a whole term, so the gradients are held in the Frobenius norm)
         rel = lambda u, v: float((u.double() - v.double()).norm() / v.double().norm())  # noqa: E731,F811
     assert rel(y, x) <= ftol, rel(y, x)
-    assert gathers == (rel(y, x) > 1e-5), "the bf16 gather copies are in use exactly when asked for"
+    assert gathers == (rel(y, x) > 2e-4), "the bf16 gather copies are in use exactly when asked for"
     assert rel(a_h0.grad, b_h0.grad) <= gtol and rel(a_ah.grad, b_ah.grad) <= gtol, (rel(a_h0.grad, b_h0.grad), rel(a_ah.grad, b_ah.grad))
     for u, v in zip(a_W, b_W):
         assert rel(u.grad, v.grad) <= gtol, rel(u.grad, v.grad)
