@@ -395,6 +395,8 @@ def run_ppi(a, dev):
     if a.bf16:
         for conv in m.convs:
             conv.gemm_dtype = torch.bfloat16
+        for dg in m.dggs:                                        # the latent-2048 k-net's two wide products on the bf16 matrix cores as well
+            dg.gemm_dtype = torch.bfloat16
     m.train()
     graphs = []
     for n in sizes:

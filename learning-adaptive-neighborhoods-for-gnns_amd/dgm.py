@@ -42,15 +42,16 @@ class _KnetFeatFn(torch.autograd.Function):
     per-node features xk [N,h], prior degree -> learned k [N]."""
 
     @staticmethod
-    def forward(ctx, xk, deg, W1, b1, Wmu, bmu, Wp, bp):
+    def forward(ctx, xk, deg, W1, b1, Wmu, bmu, Wp, bp, bf16=False):
         mu_sd = ops.degree_stats(deg)
         ctx.h = xk.shape[1]
+        ctx.bf16 = bool(bf16)                  # wide latents only: the two wide products on the bf16 matrix cores (module.gemm_dtype)
         ctx.mfma = ctx.h in ops.KNET_MFMA_WIDTHS and W1.shape[0] * 2 == ctx.h and Wmu.shape[0] * 4 == ctx.h
         if ctx.mfma:        # matrix-core k-net: only u is saved, the backward re-runs layer 1 from xk (same bits for k)
             k, u = ops.knet_x_fwd_slim(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp.reshape(-1), bp)
             ctx.save_for_backward(W1, Wmu, bmu, Wp, mu_sd, u, xk, deg, b1)
             return k
-        k, z, u, feat = ops.knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp.reshape(-1), bp)
+        k, z, u, feat = ops.knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp.reshape(-1), bp, bf16=ctx.bf16)
         ctx.save_for_backward(W1, Wmu, bmu, Wp, mu_sd, z, u, feat)
         return k
 
@@ -59,10 +60,10 @@ class _KnetFeatFn(torch.autograd.Function):
         if ctx.mfma:
             W1, Wmu, bmu, Wp, mu_sd, u, xk, deg, b1 = ctx.saved_tensors
             dxk, dW1, db1, dWmu, dbmu, dWp, dbp = ops.knet_x_bwd_fused(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp.reshape(-1), u, dk.contiguous())
-            return dxk, None, dW1, db1, dWmu, dbmu, dWp.reshape(Wp.shape), dbp
+            return dxk, None, dW1, db1, dWmu, dbmu, dWp.reshape(Wp.shape), dbp, None
         W1, Wmu, bmu, Wp, mu_sd, z, u, feat = ctx.saved_tensors
-        dxk, dW1, db1, dWmu, dbmu, dWp, dbp = ops.knet_x_bwd(ctx.h, mu_sd, W1, Wmu, bmu, Wp.reshape(-1), z, u, feat, dk.contiguous())
-        return dxk, None, dW1, db1, dWmu, dbmu, dWp.reshape(Wp.shape), dbp
+        dxk, dW1, db1, dWmu, dbmu, dWp, dbp = ops.knet_x_bwd(ctx.h, mu_sd, W1, Wmu, bmu, Wp.reshape(-1), z, u, feat, dk.contiguous(), bf16=ctx.bf16)
+        return dxk, None, dW1, db1, dWmu, dbmu, dWp.reshape(Wp.shape), dbp, None
 
 
 class _KnetDegFn(torch.autograd.Function):
@@ -784,7 +785,7 @@ class DGG_LearnableK_debug(nn.Module):
                 k = self._stochastic_k(torch.cat([xk, self._norm_deg(deg, None, 1e-5)[0].unsqueeze(1)], 1), deg, None, embed=True)
             else:
                 k = _KnetFeatFn.apply(xk, deg, self.k_embed[0].weight, self.k_embed[0].bias, kn.k_mu.weight, kn.k_mu.bias,
-                                      kn.k_project.weight, kn.k_project.bias)
+                                      kn.k_project.weight, kn.k_project.bias, getattr(self, "gemm_dtype", None) == torch.bfloat16)
         elif getattr(self.args, "stochastic_k", False) and self.training:
             consts = (float(self.deg_mean), float(self.deg_std)) if self.k_net_mode == "input_deg" else None
             nd, _, _ = self._norm_deg(deg, consts, 1e-5 if consts is not None else 0.0)

@@ -1067,13 +1067,29 @@ def edge_bwd(xp, idx, val, dval, row0=0, t=T_DIST, perturb=False, part=None):
 KNET_WIDE_FROM = int(__import__("os").environ.get("DGG_KNET_WIDE_FROM", "128"))
 
 
-def _knet_wide_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp):
-    """wide latents: the three layers as MFMA GEMMs on feat = [xk | nd] (same fmaf chains as the fused kernels)"""
+def _lin_bf16(x, W, b, act):
+    """act(x W^T + b) with the product on the bf16 matrix cores (operands rounded to bf16, fp32 accumulation); W [out, d] as stored"""
+    y = gemm_nt_bf16(pack_bf16(x), pack_bf16(W))
+    if b is not None:
+        y.add_(b)
+    if act == ACT_LEAKY:
+        y = torch.where(y > 0, y, 0.01 * y)
+    return y
+
+
+def _knet_wide_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, bf16=False):
+    """wide latents: the three layers as MFMA GEMMs on feat = [xk | nd] (same fmaf chains as the fused kernels).  bf16 (the module's
+    `gemm_dtype = torch.bfloat16`, BASELINE configs[4]): the two wide products -- k_embed 2049 -> 1024 and k_mu 1024 -> 512 at latent
+    2048, 12 GFLOP per PPI graph and three times that with the backward -- on the bf16 matrix cores instead of the fp32 ones."""
     N, h = xk.shape
     feat = torch.empty((N, h + 1), device=xk.device, dtype=torch.float32)
     _lib.check(_lib.lib().dgg_knet_feat(_ptr(xk), _ptr(_chk(deg)), _ptr(mu_sd), N, h, _ptr(feat), _stream()), "knet_feat")
-    z = linear_fwd(feat, W1, b1, ACT_LEAKY)
-    m = linear_fwd(z, Wmu, bmu, ACT_NONE)
+    if bf16:
+        z = _lin_bf16(feat, W1, b1, ACT_LEAKY)
+        m = _lin_bf16(z, Wmu, bmu, ACT_NONE)
+    else:
+        z = linear_fwd(feat, W1, b1, ACT_LEAKY)
+        m = linear_fwd(z, Wmu, bmu, ACT_NONE)
     kp = linear_fwd(m, Wp.reshape(1, -1), bp, ACT_NONE)
     k = torch.empty((N,), device=xk.device, dtype=torch.float32)
     u = torch.empty((N,), device=xk.device, dtype=torch.float32)
@@ -1081,24 +1097,36 @@ def _knet_wide_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp):
     return k, z, u, feat
 
 
-def _knet_wide_bwd(h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk):
+def _lin_bf16_bwd(x, W, dy):
+    """backward of y = x W^T + b on the bf16 matrix cores -> dx = dy W, dW = dy^T x, db"""
+    dyb = pack_bf16(dy)
+    dx = gemm_nt_bf16(dyb, pack_bf16(W, transpose=True))                          # [N,out] x [d,out]^T
+    dW = gemm_nt_bf16(pack_bf16(dy, transpose=True), pack_bf16(x, transpose=True))  # [out,N] x [d,N]^T
+    return dx, dW, dy.sum(0)
+
+
+def _knet_wide_bwd(h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk, bf16=False):
     N = z.shape[0]
     dkp = torch.empty((N, 1), device=z.device, dtype=torch.float32)
     _lib.check(_lib.lib().dgg_knet_out_bwd(_ptr(u), _ptr(_chk(dk)), _ptr(mu_sd), N, _ptr(dkp), _stream()), "knet_out_bwd")
-    m = linear_fwd(z, Wmu, bmu, ACT_NONE)                        # recomputed (k_project weight gradient)
+    m = _lin_bf16(z, Wmu, bmu, ACT_NONE) if bf16 else linear_fwd(z, Wmu, bmu, ACT_NONE)       # recomputed (k_project weight gradient)
     Wp2 = Wp.reshape(1, -1)
     dm, dWp, dbp = linear_bwd(m, Wp2, None, dkp, ACT_NONE)
-    dz, dWmu, dbmu = linear_bwd(z, Wmu, None, dm, ACT_NONE)
-    dfeat, dW1, db1 = linear_bwd(feat, W1, z, dz, ACT_LEAKY)
+    if bf16:
+        dz, dWmu, dbmu = _lin_bf16_bwd(z, Wmu, dm)
+        dfeat, dW1, db1 = _lin_bf16_bwd(feat, W1, torch.where(z > 0, dz, 0.01 * dz))
+    else:
+        dz, dWmu, dbmu = linear_bwd(z, Wmu, None, dm, ACT_NONE)
+        dfeat, dW1, db1 = linear_bwd(feat, W1, z, dz, ACT_LEAKY)
     return dfeat[:, :h].contiguous(), dW1, db1, dWmu, dbmu, dWp, dbp
 
 
-def knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, save=True):
+def knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, save=True, bf16=False):
     xk = _chk(xk)
     N, h = xk.shape
     h2, h4 = W1.shape[0], Wmu.shape[0]
     if h >= KNET_WIDE_FROM:
-        return _knet_wide_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp)
+        return _knet_wide_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, bf16=bf16 and h % 64 == 0)
     dev = xk.device
     k = torch.empty((N,), device=dev, dtype=torch.float32)
     z = torch.empty((N, h2), device=dev, dtype=torch.float32) if save else None
@@ -1156,12 +1184,12 @@ def knet_x_bwd_fused(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, u, dk, out_act=ACT_NO
     return dxk, gW1, gb1, gWmu, gbmu, gWp, gbp
 
 
-def knet_x_bwd(h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk):
+def knet_x_bwd(h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk, bf16=False):
     """-> dxk [N,h], dW1, db1, dWmu, dbmu, dWp ([1,h4]), dbp ([1])"""
     N = z.shape[0]
     h2, h4 = W1.shape[0], Wmu.shape[0]
     if h >= KNET_WIDE_FROM:
-        return _knet_wide_bwd(h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk)
+        return _knet_wide_bwd(h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk, bf16=bf16 and h % 64 == 0)
     dev = z.device
     dkp = torch.empty((N, 1), device=dev, dtype=torch.float32)
     dm = torch.empty((N, h4), device=dev, dtype=torch.float32)

@@ -323,6 +323,32 @@ def test_bf16_gcnii_layer_product(dev, n, K, F, variant, residual):
         assert rel(g16, g32) <= 2e-2
 
 
+def test_wide_knet_products_on_the_bf16_matrix_cores(dev):
+    """latent 256 (the k-net of wide latents runs layer by layer as GEMMs): `bf16=True` moves k_embed and k_mu, forward and backward, to
+    the bf16 kernel -- learned degrees within 1e-2 of the fp32 path's, gradients within 1e-1 in the Frobenius norm (measured 4-7e-2: pre-activations that cross the LeakyReLU kink)"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(4)
+    N, h = 900, 256
+    xk = T(rng.standard_normal((N, h)).astype(np.float32), dev)
+    deg = T((10 + 5 * rng.random(N)).astype(np.float32), dev)
+    W1, b1 = T((rng.standard_normal((h // 2, h + 1)) / 16).astype(np.float32), dev), T((0.1 * rng.standard_normal(h // 2)).astype(np.float32), dev)
+    Wmu, bmu = T((rng.standard_normal((h // 4, h // 2)) / 11).astype(np.float32), dev), T((0.1 * rng.standard_normal(h // 4)).astype(np.float32), dev)
+    Wp, bp = T((rng.standard_normal(h // 4) / 8).astype(np.float32), dev), T(np.array([0.05], np.float32), dev)
+    mu_sd = ops.degree_stats(deg)
+    dk = T(rng.standard_normal(N).astype(np.float32), dev)
+    outs = []
+    for bf in (False, True):
+        k, z, u, feat = ops.knet_x_fwd(xk, deg, mu_sd, W1, b1, Wmu, bmu, Wp, bp, bf16=bf)
+        outs.append((k,) + tuple(ops.knet_x_bwd(h, mu_sd, W1, Wmu, bmu, Wp, z, u, feat, dk, bf16=bf)))
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())  # noqa: E731
+    assert 1e-6 < rel(outs[1][0], outs[0][0]) <= 1e-2
+    # (pre-activations at the LeakyReLU's kink land on the other side under 8-bit operands: single gradient entries then differ by the
+    #  factor 100 of the two slopes, so the gradients are held in the Frobenius norm)
+    nrm = lambda a, b: float((a - b).norm() / b.norm())           # noqa: E731
+    for a, b in zip(outs[1][1:], outs[0][1:]):
+        assert nrm(a.reshape(b.shape), b) <= 1e-1, nrm(a.reshape(b.shape), b)
+
+
 def _stack_inputs(n, F, L, dev, seed=3):
     """h0, a normalised ELL adjacency with a few empty slots / zero weights, L variant weights, a cotangent"""
     from dgg_amd import ops
@@ -476,6 +502,9 @@ def test_config4_ppi_gcniippi_dgg_bf16_end_to_end(dev):
         for conv in m.convs:
             conv.gemm_dtype = torch.bfloat16 if dt == "stack" else dt
         m.fused_stack = dt == "stack"                               # models[1]: the layers one by one (forward hooks below); [2]: ops.GcniiStackBf16Fn
+        if dt == "stack":                                           # ... and the generator's latent-2048 k-net products in bf16 as well
+            for dg in m.dggs:
+                dg.gemm_dtype = torch.bfloat16
         m.train()                                                   # training mode: the DGG perturbs the scores (noise=True)
         models.append(m)
     rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())  # noqa: E731
@@ -504,8 +533,8 @@ def test_config4_ppi_gcniippi_dgg_bf16_end_to_end(dev):
         # activations / of d hi (ops.STACK_BF16_GATHERS: one more 8-bit rounding per layer)
         assert torch.equal(adjs[2].idx, adjs[1].idx) and rel(outs[2], outs[1]) <= 1e-2, rel(outs[2], outs[1])
         assert set(grads[2]) == set(grads[1])
-        for k in grads[1]:
-            assert rel(grads[2][k], grads[1][k]) <= 3e-2, (k, rel(grads[2][k], grads[1][k]))
+        for k in grads[1]:       # (the k-net's own weights: its two wide products run on bf16 operands in model [2], on fp32 in [1])
+            assert rel(grads[2][k], grads[1][k]) <= (1e-1 if ".k_" in k else 3e-2), (k, rel(grads[2][k], grads[1][k]))
         assert rel(outs[2], outs[0]) <= 1e-2
         assert rel(outs[1], outs[0]) <= 1e-2
         assert set(grads[0]) == set(grads[1]) and len(grads[0]) >= L + 4
