@@ -329,6 +329,11 @@ int dgg_norm_bwd_da(const int32_t *idx, const float *w, const float *rs, const f
  * mode 2: no ramp (dval = dw, dk untouched, val/k may be NULL): plain normalize_adj backward */
 int dgg_softk_bwd(const int32_t *idx, const float *val, const float *k, const float *rs, const float *dA, const float *da,
                   int64_t N, int K, int64_t row0, int mode, int normalized, float *dval, float *dk, void *stream);
+/* the same for a NORMALISED adjacency whose `da_cols` (GLOBAL length) holds the neighbour-side sums only -- what the column
+ * kernels of the partitioned backward leave (dgg_ell_conv_bwd_partp) -- the row side rs_i^1/2 sum_r dA_ir ahat_ir is formed inside
+ * (ahat_rows [N,K]: the normalised values).  Reference: autograd of normalize_adj + select_top_k, model.py:1205-1219, dgm.py:1402-1421 */
+int dgg_softk_bwd_rows(const int32_t *idx, const float *val, const float *k, const float *rs, const float *dA, const float *da_cols,
+                       const float *ahat_rows, int64_t N, int K, int64_t row0, int mode, float *dval, float *dk, void *stream);
 /* score backward to the projected features: dxp [Nglobal,h] += ... (zeroed by caller; fp32 atomics) */
 int dgg_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval, int K,
                  int64_t row0, float t, int perturb, float *dxp, void *stream);

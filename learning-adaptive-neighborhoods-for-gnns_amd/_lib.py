@@ -76,6 +76,7 @@ PROTOTYPES = {
     "dgg_ell_spmm_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
     "dgg_norm_bwd_da": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp],
     "dgg_softk_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _vp],
+    "dgg_softk_bwd_rows": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp],
     "dgg_part_ws_bytes": [_i64, _i32, _i64],
     "dgg_part_build": [_vp, _vp, _i64, _i32, _i64, _vp, _vp],
     "dgg_edge_bwd_part": [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _i64, _vp, _vp, _vp],

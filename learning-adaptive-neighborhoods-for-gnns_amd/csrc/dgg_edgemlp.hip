@@ -7,6 +7,7 @@
 // in exactly the operation order of oracle/dgg_oracle.c (mlp_edge_p).  The scorer writes one probability per candidate
 // edge; perturbation + top-K (edgelist_topk_p) and the soft top-k are shared with the u-v-dist path.
 #include "dgg_common.h"
+#include <stdlib.h>
 #include "dgg_api_internal.h"
 
 using namespace dgg;
@@ -113,15 +114,34 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
         const float du = deg ? deg[i] : 0.0f;
         // entries of the row: ELL [i*K, i*K+K) or, with rowptr, the CSR range of a variable-width adjacency
         const int64_t base = rowptr ? rowptr[i] : i * K;
-        const int cnt = rowptr ? (int)(rowptr[i + 1] - base) : K;
+        int cnt = rowptr ? (int)(rowptr[i + 1] - base) : K;
+        // ELL rows (K <= 64): one coalesced load of the row's columns and cotangents, then only the batches that hold an entry with
+        // a non-zero cotangent are visited (a citation graph fills ~6 of the 64 slots: 2 batches of dependent gathers instead of 16)
+        const bool ellrow = !rowptr && K <= 64;
+        int32_t jrow = -1;
+        float grow = 0.0f;
+        if (ellrow) {
+            if (lane < K) { jrow = idx[base + lane]; grow = dval[base + lane]; }
+            const uint64_t am = __ballot(jrow >= 0 && grow != 0.0f);
+            if (dex && lane < K) dex[base + lane] = 0.0f;           // (the visited batches overwrite their entries below)
+            cnt = am ? 64 - __builtin_clzll(am) : 0;
+        }
         for (int r0 = 0; r0 < cnt; r0 += EPI) {
             const int r = r0 + slot;
             const int64_t en = base + r;
-            const int32_t j = r < cnt ? idx[en] : -1;
-            const float g = r < cnt ? dval[en] : 0.0f;
+            int32_t j;
+            float g;
+            if (ellrow) {
+                j = __shfl(jrow, r & 63, 64);
+                g = __shfl(grow, r & 63, 64);
+                if (r >= cnt) { j = -1; g = 0.0f; }
+            } else {
+                j = r < cnt ? idx[en] : -1;
+                g = r < cnt ? dval[en] : 0.0f;
+            }
             const bool actv = j >= 0 && g != 0.0f;
             if (__ballot(actv) == 0ull) {
-                if (dex && c == 0 && r < cnt) dex[en] = 0.0f;
+                if (!ellrow && dex && c == 0 && r < cnt) dex[en] = 0.0f;
                 continue;
             }
             float z[VEC], hid[VEC], part = 0.0f;
@@ -251,7 +271,8 @@ int dgg_edge_mlp_bwd(const float *AB, int64_t N, int hw, const int64_t *rowptr, 
     if ((ex && (!wex || (!eid && !rowptr))) || (deg && (!wdu || !wdv)))
         return dgg_set_error(DGG_ERR_ARG, "edge_mlp_bwd: missing extras / weights");
     if (N == 0) return 0;
-    const unsigned grid = (unsigned)((N + 3) / 4 < 2048 ? (N + 3) / 4 : 2048);
+    static const int64_t gmax = getenv("DGG_EMLP_GRID") ? atoll(getenv("DGG_EMLP_GRID")) : 1024;   // (Pubmed shape: 103 us at 2048 workgroups, 85-89 at 512-1024, 123 at 128: row latency against contended parameter sums)
+    const unsigned grid = (unsigned)((N + 3) / 4 < gmax ? (N + 3) / 4 : gmax);
     const size_t lds = (size_t)4 * (5 * hw + 1) * sizeof(float);
     if (vec == 4)
         hipLaunchKernelGGL(edge_mlp_bwd_kernel<4>, dim3(grid), dim3(256), lds, (hipStream_t)stream, AB, N, hw, rowptr, idx, eid, val, dval, K,

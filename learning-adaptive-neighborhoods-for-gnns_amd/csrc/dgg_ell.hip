@@ -446,11 +446,21 @@ __global__ __launch_bounds__(WPB * 64) void softk_bwd_kernel(const int32_t *__re
                                                             const float *__restrict__ k, const float *__restrict__ rs,
                                                             const float *__restrict__ dA, const float *__restrict__ da,
                                                             int64_t N, int K, int64_t row0, int mode, int normalized,
-                                                            float *__restrict__ dval, float *__restrict__ dk) {
+                                                            float *__restrict__ dval, float *__restrict__ dk,
+                                                            const float *__restrict__ ahat_rows) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     float skp = 0.0f;
+    // ahat_rows: `da` carries the neighbour-side sums only (the column kernels of the partitioned backward); the row side
+    // sum_r dA_ir w_ir a_j = rs_i^1/2 sum_r dA_ir ahat_ir is formed here (lane r owns entry r)
+    float darow = 0.0f;
+    if (normalized && ahat_rows) {
+        for (int r = lane; r < K; r += 64) darow = fmaf(dA[i * K + r], ahat_rows[i * K + r], darow);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) darow += __shfl_xor(darow, off, 64);
+        darow *= sqrtf(rs[row0 + i]);
+    }
     {
         // every load is unconditional (clamped lane / neighbour): predicated loads would be issued one dependent branch at a time
         const int lc = lane < K ? lane : K - 1;
@@ -462,7 +472,7 @@ __global__ __launch_bounds__(WPB * 64) void softk_bwd_kernel(const int32_t *__re
         if (normalized) {
             const float rsi = rs[row0 + i];
             const float ai = inv_sqrt_c(rsi), aj = inv_sqrt_c(rs[j >= 0 ? j : row0 + i]);
-            const float drs = -0.5f * da[row0 + i] * ai / rsi;
+            const float drs = -0.5f * (da[row0 + i] + darow) * ai / rsi;
             dw = dw * ai * aj + drs;
         }
         float dv = dw;                                // mode 2: no ramp, plain normalisation backward (dval = dw, dk = 0)
@@ -842,8 +852,17 @@ int dgg_softk_bwd(const int32_t *idx, const float *val, const float *k, const fl
                   int64_t N, int K, int64_t row0, int mode, int normalized, float *dval, float *dk, void *stream) {
     if (N == 0) return 0;
     hipLaunchKernelGGL(softk_bwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, idx, val, k, rs, dA, da,
-                       N, K, row0, mode, normalized, dval, dk);
+                       N, K, row0, mode, normalized, dval, dk, (const float *)nullptr);
     return dgg_check_launch("softk_bwd");
+}
+
+int dgg_softk_bwd_rows(const int32_t *idx, const float *val, const float *k, const float *rs, const float *dA, const float *da_cols,
+                       const float *ahat_rows, int64_t N, int K, int64_t row0, int mode, float *dval, float *dk, void *stream) {
+    if (!rs || !da_cols || !ahat_rows) return dgg_set_error(DGG_ERR_ARG, "softk_bwd_rows: rs, da_cols and ahat_rows are required");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(softk_bwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, idx, val, k, rs, dA, da_cols,
+                       N, K, row0, mode, 1, dval, dk, ahat_rows);
+    return dgg_check_launch("softk_bwd_rows");
 }
 
 int dgg_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval, int K,

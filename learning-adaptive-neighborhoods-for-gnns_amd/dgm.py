@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .adjacency import AllPairs, CsrAdjacency, EllAdjacency, csr_candidates, csr_pattern
+from .adjacency import AllPairs, CsrAdjacency, EllAdjacency, _cached, csr_candidates, csr_pattern
 
 _EDGE_MLP_MODES = ("u-v-A_uv", "u-v-deg", "u-v-deg-dist", "edge_conv", "A_uv")
 
@@ -307,6 +307,54 @@ class _FusedDGGConvFn(torch.autograd.Function):
         return (g.get("x"), None, None) + tuple(g[k_].reshape(P[k_].shape) for k_ in layer.PARAM_KEYS)
 
 
+class _FusedDGGMlpConvFn(torch.autograd.Function):
+    """_FusedDGGConvFn with an edge-MLP scorer (u-v-deg, u-v-A_uv, u-v-deg-dist, edge_conv; reference dgm.py:1628-1719) on edge-list
+    candidates: the scorer's terms arrive in the per-node / per-edge form of DGG_LearnableK_debug._edge_mlp_terms (sliced from the
+    reference's parameters by differentiable torch ops outside this node) and get their gradients from the same backward."""
+    SC_KEYS = ("Wcat", "wdu", "wdv", "wex", "b1", "w2", "b2")
+
+    @staticmethod
+    def forward(ctx, x, deg, layer, sc_static, Wcat, wdu, wdv, wex, b1, w2, b2, *params):
+        P = dict(zip(layer.PARAM_KEYS, params))
+        det = lambda t_: None if t_ is None else t_.detach()  # noqa: E731
+        ctx.packed = packed = sc_static.get("packed")
+        if packed is not None:
+            # `Wcat` is edge_encode.0.weight [h, 2h + extras] itself (columns [u | v | extras], dgm.py:1101-1105): sliced here, outside
+            # autograd (the slices of the separate-modules path cost a dozen tiny copy / zero-fill launches per step in their backward)
+            h_, cols = packed
+            W0 = Wcat.detach()
+            pick = lambda c_: None if c_ is None else W0[:, c_].contiguous()  # noqa: E731
+            Wcat, wdu, wdv, wex = torch.cat([W0[:, :h_], W0[:, h_:2 * h_]], 0), pick(cols[0]), pick(cols[1]), pick(cols[2])
+            w2 = w2.detach().reshape(-1)
+        layer.scorer = dict(sc_static, Wcat=det(Wcat), wdu=det(wdu), wdv=det(wdv), wex=det(wex), b1=det(b1), w2=det(w2), b2=det(b2))
+        Z = layer.forward(x, deg, P)
+        ctx.layer, ctx.state, ctx.scorer = layer, layer.saved, layer.scorer
+        ctx.save_for_backward(x, *params)
+        ctx.set_materialize_grads(False)
+        return Z, layer.saved["ahat"]
+
+    @staticmethod
+    def backward(ctx, dZ, dahat):
+        x, *params = ctx.saved_tensors
+        layer = ctx.layer
+        P = dict(zip(layer.PARAM_KEYS, params))
+        layer.saved, layer._fwd_gen, layer.scorer = ctx.state, ctx.state["gen"], ctx.scorer
+        layer.x_grad = bool(ctx.needs_input_grad[0])
+        if dZ is None:
+            dZ = torch.zeros_like(ctx.state["Z"])
+        g = layer.backward(dZ.contiguous(), x, P, dA_ext=dahat)
+        gs = g["scorer"]
+        if ctx.packed is not None:                       # d loss / d edge_encode.0.weight in ONE concatenation
+            hw = gs["Wcat"].shape[0] // 2
+            extras = [gs[k_][:, None] for k_, c_ in zip(("wdu", "wdv", "wex"), ctx.packed[1]) if c_ is not None]
+            order = sorted(range(len(extras)), key=[c_ for c_ in ctx.packed[1] if c_ is not None].__getitem__)
+            dW0 = torch.cat([gs["Wcat"][:hw], gs["Wcat"][hw:]] + [extras[o_] for o_ in order], 1)
+            sc_grads = (dW0, None, None, None, gs["b1"], gs["w2"].reshape(1, -1), gs["b2"])
+        else:
+            sc_grads = tuple(gs[k_] for k_ in _FusedDGGMlpConvFn.SC_KEYS)
+        return (g.get("x"), None, None, None) + sc_grads + tuple(g[k_].reshape(P[k_].shape) for k_ in layer.PARAM_KEYS)
+
+
 class DGG_LearnableK_debug(nn.Module):
     """Drop-in for reference dgm.py:1077-1727 (modes u-v-dist / x / {k_times_edge_prob, k_only}, soft output)."""
 
@@ -450,7 +498,8 @@ class DGG_LearnableK_debug(nn.Module):
         """`GCNConv(x, normalize_adj(self(x, in_adj)))` with conv_weight = GCNConv.W [in, out] as one fused autograd node
         (_FusedDGGConvFn) -> (Z, unnormalised EllAdjacency, DETACHED: its values carry no autograd edge -- the loss of the
         reference's training scripts reads the class scores only, train_small_graphs.py:226-230), or None when this configuration
-        is outside the fused step (the caller then runs the modules one after the other): scorer u-v-dist, k-net "x", soft
+        is outside the fused step (the caller then runs the modules one after the other): scorer u-v-dist (any candidates) or an
+        edge-MLP scorer (u-v-deg, u-v-A_uv, u-v-deg-dist, edge_conv; edge-list candidates), k-net "x", soft
         k_times_edge_prob / k_only output, widths the partitioned backward covers, rows that fit the ELL width.
         want_norm: additionally return the NORMALISED adjacency as a differentiable EllAdjacency for the layers that read the same
         graph after this one (GCN_DGG's second layer): its gradient flows back into the generator through the same node."""
@@ -458,7 +507,9 @@ class DGG_LearnableK_debug(nn.Module):
         a = self.args
         h = self.latent_dim
         fin, fout = conv_weight.shape
-        if (self.edge_prob_net_mode != "u-v-dist" or self.k_net_mode != "x" or self.k_select_mode not in ("k_times_edge_prob", "k_only")
+        mlp_mode = self.edge_prob_net_mode in ("u-v-deg", "u-v-A_uv", "u-v-deg-dist", "edge_conv")
+        if ((self.edge_prob_net_mode != "u-v-dist" and not mlp_mode) or (mlp_mode and isinstance(in_adj, AllPairs))
+                or self.k_net_mode != "x" or self.k_select_mode not in ("k_times_edge_prob", "k_only")
                 or self.hard or a.debug_step in (0, 1) or (getattr(a, "stochastic_k", False) and self.training)
                 or self._explicit_noise is not None or not getattr(a, "dgg_fused_layer", True) or not x.is_cuda
                 or h not in (16, 32, 64, 128) or fout not in (16, 32, 64, 128) or fout > fin or self.ell_width != 64
@@ -474,6 +525,23 @@ class DGG_LearnableK_debug(nn.Module):
                 in_adj = in_adj.to_sparse().detach()
             rowptr, col, deg = csr_candidates(in_adj)
             cand = (rowptr, col)
+        sc_static = None
+        if mlp_mode:                                          # per-edge inputs of the scorer, in the CSR order of the candidates
+            avals = _cached("values_f32", in_adj, lambda: in_adj.coalesce().values().to(torch.float32).contiguous())
+            if self.edge_prob_net_mode == "edge_conv":
+                mlp, ex_in = self._edge_mlp_terms(avals)
+                packed = None
+            else:                                             # edge_encode.0.weight goes into the node whole (sliced inside it)
+                need = {"u-v-deg": 2, "u-v-A_uv": 1, "u-v-deg-dist": 3}[self.edge_prob_net_mode]
+                W0 = self.edge_encode[0].weight
+                assert W0.shape[1] == 2 * h + need, f"edge mode {self.edge_prob_net_mode!r} needs extra_edge_dim={need} (edge_encode.0 is {tuple(W0.shape)})"
+                cols = {"u-v-deg": (2 * h, 2 * h + 1, None), "u-v-A_uv": (None, None, 2 * h), "u-v-deg-dist": (2 * h, 2 * h + 1, 2 * h + 2)}
+                packed = (h, cols[self.edge_prob_net_mode])
+                mlp = dict(Wcat=W0, wdu=None, wdv=None, wex=None, b1=self.edge_encode[0].bias, w2=self.edge_encode[2].weight,
+                           b2=self.edge_encode[2].bias, act=ops.ACT_LEAKY, ex_mode={"u-v-deg": 0, "u-v-A_uv": 1, "u-v-deg-dist": 2}[self.edge_prob_net_mode],
+                           t_ex=-1.0 if self.edge_prob_net_mode == "u-v-deg-dist" else 0.0)
+                ex_in = avals if self.edge_prob_net_mode == "u-v-A_uv" else None
+            sc_static = dict(erow=csr_pattern(in_adj)[2], ex_in=ex_in, ex_mode=mlp["ex_mode"], t_ex=mlp["t_ex"], act=mlp["act"], packed=packed)
         noise_mode, _, seed = self._noise_cfg()
         if cand is None and noise_mode == ops.NOISE_RANKED:
             noise_mode = self._asym_generator_now(x, seed)
@@ -486,29 +554,39 @@ class DGG_LearnableK_debug(nn.Module):
         layer = self.__dict__.get("_fused_layer")
         if layer is None or layer.N != N:
             layer = self.__dict__["_fused_layer"] = ShardedDGGConv(ops, N, K=64, t=ops.T_DIST)
-        layer.cand, layer.noise_mode, layer.seed, layer.mode = cand, noise_mode, seed, mode
+        layer.cand, layer.noise_mode, layer.seed, layer.mode, layer.scorer = cand, noise_mode, seed, mode, None
         layer.x_grad = bool(x.requires_grad)
-        if cand is not None:                                  # the ELL-width bound is tested inside the search kernel (no extra launches)
+        if cand is not None and not mlp_mode:                 # the ELL-width bound is tested inside the search kernel (no extra launches)
             flag = self.__dict__.get("_overflow_dev")
             if flag is None or flag.device != x.device:
                 flag = self.__dict__["_overflow_dev"] = torch.zeros((1,), device=x.device, dtype=torch.int32)
             layer.overflow = flag
         kn = self.k_net
-        Z, ahat = _FusedDGGConvFn.apply(x, deg, layer, self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias,
-                                  self.node_encode_for_k[0].weight, self.node_encode_for_k[0].bias, self.k_embed[0].weight,
-                                        self.k_embed[0].bias, kn.k_mu.weight, kn.k_mu.bias, kn.k_project.weight, kn.k_project.bias, conv_weight)
+        params = (self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias, self.node_encode_for_k[0].weight,
+                  self.node_encode_for_k[0].bias, self.k_embed[0].weight, self.k_embed[0].bias, kn.k_mu.weight, kn.k_mu.bias,
+                  kn.k_project.weight, kn.k_project.bias, conv_weight)
+        if mlp_mode:
+            Z, ahat = _FusedDGGMlpConvFn.apply(x, deg, layer, sc_static, mlp["Wcat"], mlp["wdu"], mlp["wdv"], mlp["wex"], mlp["b1"],
+                                               mlp["w2"], mlp["b2"], *params)
+        else:
+            Z, ahat = _FusedDGGConvFn.apply(x, deg, layer, *params)
         st = layer.saved
         if st.get("partp") is None:                           # (shape outside the partitioned backward: the separate modules)
             return None
         k = st["k"]
         if cand is not None and self._wide_rows(in_adj, rowptr, k):
             # rows wider than the ELL with learned degrees beyond it: the CSR form from here on (this discarded forward raised the flag)
-            layer.overflow.zero_()
+            if not mlp_mode:
+                layer.overflow.zero_()
             return None
         if cand is None and self._allpairs_wide(N, k):
             return None                                       # learned degrees beyond the list: the modules' CSR form (every column ranked)
         if cand is None:
             self._track_overflow(k, None)
+        elif mlp_mode:
+            ent = self.__dict__.get("_wide_cache", {}).get(id(in_adj))
+            if not (ent is not None and ent[0]() is in_adj and ent[1] <= self.ell_width):     # (no row can outgrow the list otherwise)
+                self._track_overflow(k, rowptr[1:] - rowptr[:-1])
         elif __import__("os").environ.get("DGG_STRICT_BOUND") == "1":
             self.check_ell_bound()
         unnorm = EllAdjacency(st["idx"], st["w"], N, rs=st["rs"], k=k, score=st["val"], owner=self)

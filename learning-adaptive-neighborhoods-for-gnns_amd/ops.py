@@ -1009,12 +1009,18 @@ def norm_bwd_da(idx, w, rs, dA, row0=0, part=None):
     return da
 
 
-def softk_bwd(idx, val, k, dA, rs=None, da=None, row0=0, mode=MODE_K_TIMES_EDGE_PROB, normalized=False):
+def softk_bwd(idx, val, k, dA, rs=None, da=None, row0=0, mode=MODE_K_TIMES_EDGE_PROB, normalized=False, ahat_rows=None):
+    """ahat_rows [N,K] (normalized only): `da` holds the neighbour-side sums (conv_bwd_cols_p); the row side is formed inside"""
     N, K = idx.shape
     dval = torch.empty((N, K), device=idx.device, dtype=torch.float32)
     dk = torch.empty((N,), device=idx.device, dtype=torch.float32) if mode != 2 else None
     val = _chk(val) if val is not None else None
     k = _chk(k) if k is not None else None
+    if ahat_rows is not None:
+        assert normalized
+        _lib.check(_lib.lib().dgg_softk_bwd_rows(_ptr(idx), _ptr(val), _ptr(k), _ptr(_chk(rs)), _ptr(_chk(dA)), _ptr(_chk(da)), _ptr(_chk(ahat_rows)),
+                                                 N, K, row0, mode, _ptr(dval), _ptr(dk), _stream()), "softk_bwd_rows")
+        return dval, dk
     _lib.check(_lib.lib().dgg_softk_bwd(_ptr(idx), _ptr(val), _ptr(k), _ptr(rs), _ptr(_chk(dA)), _ptr(da), N, K, row0, mode,
                                         int(normalized), _ptr(dval), _ptr(dk), _stream()), "softk_bwd")
     return dval, dk

@@ -106,6 +106,11 @@ class ShardedDGGConv:
         # live class's semantics dgm.py:1613-1614) instead of all N columns; every candidate is scored (per-pair hash noise), the rest
         # of the step is the same.  One rank only: a citation graph's step is launch-bound, not something to shard.
         self.cand = cand
+        # scorer (edge-list candidates only): None = exp(t ||xp_i - xp_j||) (u-v-dist), or a dict with the edge-MLP scorer's terms in
+        # the per-node / per-edge form of dgg_edge_mlp_fwd (reference dgm.py:1628-1719): Wcat [2hw,h], wdu / wdv / wex [hw] or None,
+        # b1 [hw], w2 [hw], b2 [1], erow int32 [E], ex_in [E] or None, ex_mode, t_ex, act.  backward() then also returns
+        # g["scorer"] = {Wcat, wdu, wdv, wex, b1, w2, b2} (the rest of the step is the same)
+        self.scorer = None
         assert cand is None or noise_mode in (0, 2, 3), "edge-list candidates: noise_mode none / hash / symmetric hash"
         assert x_full is None or not x_grad, "replicated features are data: they cannot take a gradient"
         assert not hybrid or x_full is not None, "the hybrid scheme replicates the features for the scoring side"
@@ -208,7 +213,17 @@ class ShardedDGGConv:
             s["k"], s["z"], s["u"], s["feat"] = kern.knet_x_fwd(xk, deg_local, mu_sd, P["W1"], P["b1"], P["Wmu"], P["bmu"],
                                                               P["Wp"].reshape(-1), P["bp"])
         s["xp"] = xp = g_xp.get() if (self.coll and not repl) else xp
-        if self.cand is not None:
+        if self.cand is not None and self.scorer is not None:
+            # edge-MLP scorer: first layer split into per-node products AB = xp [Wa | Wb]^T (MFMA GEMM) + per-edge terms
+            rowptr, col = self.cand
+            sc = self.scorer
+            s["AB"] = AB = kern.linear_fwd(xp, sc["Wcat"], None, 0, 0)
+            s["sdeg"] = sdeg = deg_full if sc["wdu"] is not None else None
+            p_edge, s["ex"] = kern.edge_mlp_fwd(AB, xp, sc["erow"], col, sdeg, sc["ex_in"], sc["ex_mode"], sc["t_ex"], sc["wdu"], sc["wdv"],
+                                                sc["wex"], sc["b1"], sc["w2"], sc["b2"], sc["act"])
+            s["idx"], s["val"], s["eid"] = kern.edgelist_topk_p(p_edge, self.N, rowptr, col, self.K, self.noise_mode, None, self.seed)
+            s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
+        elif self.cand is not None:
             rowptr, col = self.cand
             # (self.overflow: optional int32[1] device flag the caller owns -- set when the K-wide list drops a weighted rank)
             got = kern.edgelist_topk_softk(xp, rowptr, col, s["k"], self.mode, self.K, self.t, self.noise_mode, None, self.seed,
@@ -284,6 +299,8 @@ class ShardedDGGConv:
             need = 3 * sum(int(v.numel()) for v in P.values()) + 65536
             if s.get("partp") is None:
                 need += rows * self.K + ncols * (h + F + 2)
+            if self.scorer is not None:                  # row-major dA (zero outside the partition), dAB + parameter sums, dWcat, dxp
+                need += rows * self.K + ncols * (2 * self.scorer["Wcat"].shape[0] + h) + 4 * int(self.scorer["Wcat"].numel()) + 4096
             with kern.zero_pool(s["xp"].device, need):
                 return self._backward(dZ, x_local, P, dA_ext)
         return self._backward(dZ, x_local, P, dA_ext)
@@ -326,13 +343,15 @@ class ShardedDGGConv:
             # record-ordered copy through the slot -> record map the partition's sort left (Pubmed step 0.359 -> 0.349 ms).  At
             # N = 100 000 (25.6 MB) the 4.1 M four-byte gathers cost the row kernel more (+70 us) than the scattered stores cost the
             # node kernel (-47 us): 1.264 -> 1.285 ms, so large graphs keep the scattered row-major copy.  DGG_DA_MAP=0/1 forces one.
-            use_map = getattr(kern, "DA_MAP", False) and kern.partp_has_map(s["idx"].shape[0])
+            use_map = getattr(kern, "DA_MAP", False) and kern.partp_has_map(s["idx"].shape[0]) and self.scorer is None
             kw = {"want_dA": False} if use_map else {}
             if dA_ext is not None:
                 kw["dA_ext"] = dA_ext
-            pc = kern.conv_bwd_cols_p(s["idx"], s["H"], G, partp, s["rs"], zero_dA=False, **kw)
+            pc = kern.conv_bwd_cols_p(s["idx"], s["H"], G, partp, s["rs"], zero_dA=self.scorer is not None, **kw)
             assert pc is not None
             dA, dA_rec, dH, da = pc
+            if self.scorer is not None:          # (`da` holds the neighbour-side sums; the row side: sqrt(rs_i) sum_r dA_ir ahat_ir)
+                return self._scorer_backward(g, dA, dH, da, x_local, P, cols_only=True)
             if self._hyb() and self.coll:           # dH [N,F] partial is complete here and needed only by the last kernel of the step
                 dH = self._reduce_scatter_rows(dH, "dH", async_op=True)
             if self.coll:
@@ -363,7 +382,7 @@ class ShardedDGGConv:
                                             self.noise_mode != 0, self.mode, True, partp, ahat_rows=s["ahat"], out_act=1 if pre else 0)
             return self._weight_grads(g, dxp, dH, dk, x_local, P, premasked=pre)
         cols = None
-        if dA_ext is None and part is not None and hasattr(kern, "conv_bwd_cols") and hasattr(kern, "softk_edge_bwd") and \
+        if self.scorer is None and dA_ext is None and part is not None and hasattr(kern, "conv_bwd_cols") and hasattr(kern, "softk_edge_bwd") and \
                 s["xp"].shape[1] in (16, 32, 64, 128) and self.mode in (0, 1):
             cols = kern.conv_bwd_cols(s["idx"], s["ahat"], s["H"], G, part, s["rs"], True)
         if cols is not None:
@@ -376,6 +395,8 @@ class ShardedDGGConv:
             da = kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0, part) if part is not None else \
                 kern.norm_bwd_da(s["idx"], s["w"], s["rs"], dA, self.r0)
             ahat_rows = None
+        if self.scorer is not None:
+            return self._scorer_backward(g, dA, dH, da, x_local, P)
         if self._hyb() and self.coll:
             dH = self._reduce_scatter_rows(dH, "dH", async_op=True)
         if self.coll:
@@ -392,6 +413,27 @@ class ShardedDGGConv:
             dxp = kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0, part) \
                 if part is not None else kern.edge_bwd(s["xp"], s["idx"], s["val"], dval, self.r0, self.t, self.noise_mode != 0)
         return self._weight_grads(g, dxp, dH, dk, x_local, P)
+
+    def _scorer_backward(self, g, dA, dH, da, x_local, P, cols_only=False):
+        """score backward of the edge-MLP scorer (one rank): ramp + normalisation backward by rows, the MLP's backward on the selected
+        edges (dgg_edge_mlp_bwd: per-node dAB, parameter sums), AB's GEMM backward into dxp; the k-net and the fused weight gradients
+        as for the distance scorer.  da [N]: d loss / d (rs^-1/2), both sides (dgg_norm_bwd_da), or with cols_only the neighbour-side
+        sums (the row side is then formed inside the row kernel, dgg_softk_bwd_rows)."""
+        kern, s, sc = self.kern, self.saved, self.scorer
+        if cols_only:
+            dval, dk = kern.softk_bwd(s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.mode, True, ahat_rows=s["ahat"])
+        else:
+            dval, dk = kern.softk_bwd(s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.mode, True)
+        dAB, dpar, dex = kern.edge_mlp_bwd(s["AB"], s["idx"], s["eid"], s["val"], dval, s["sdeg"], s["ex"], sc["wdu"], sc["wdv"], sc["wex"],
+                                           sc["b1"], sc["w2"], sc["b2"], sc["act"], self.noise_mode != 0, need_dex=sc["ex_mode"] == 2)
+        dxp, dWcat, _ = kern.linear_bwd(s["xp"], sc["Wcat"], s["AB"], dAB, 0, 0, True, False)
+        if sc["ex_mode"] == 2:                              # exp(t ||xp_u - xp_v||) as an edge feature also depends on the projection
+            dxp = dxp + kern.edge_bwd(s["xp"], s["idx"], s["val"], dex, self.r0, sc["t_ex"], False)
+        hw = sc["Wcat"].shape[0] // 2
+        pick = lambda t_, a: None if t_ is None else dpar[a * hw:(a + 1) * hw]  # noqa: E731
+        g["scorer"] = dict(Wcat=dWcat, wdu=pick(sc["wdu"], 0), wdv=pick(sc["wdv"], 1), wex=pick(sc["wex"], 2), b1=dpar[3 * hw:4 * hw],
+                           w2=dpar[4 * hw:5 * hw], b2=dpar[5 * hw:5 * hw + 1])
+        return self._weight_grads(g, dxp, dH, dk, x_local, P, premasked=False)
 
     def _premask(self, x_local):
         """True when the step's weight gradients go through linear_bwd_multi (no input gradient) and the producers of dxp / dxk can

@@ -904,18 +904,22 @@ def test_edge_list_layer_step_matches_cpu_restatement(dev, N, d, h, noise):
         assert err <= 3e-4, f"grad {k_} (no input gradient): {err:.3e}"
 
 
-@pytest.mark.parametrize("cand", ["edgelist", "allpairs"])
+@pytest.mark.parametrize("cand", ["edgelist", "allpairs", "edgelist:u-v-deg", "edgelist:u-v-deg-dist", "edgelist:u-v-A_uv", "edgelist:edge_conv"])
 def test_gcn_dgg_fused_first_layer_matches_the_separate_modules(dev, cand):
     """GCN_DGG runs generator + normalize_adj + conv1 as one autograd node (DGG_LearnableK_debug.forward_conv) and hands the normalised
     adjacency -- a differentiable output of that node -- to conv2 (reference model.py:1266-1290: both layers read the same graph).
     Against the same model with args.dgg_fused_layer = False (every module on its own): identical neighbour lists, log-probabilities
-    1e-5, gradients of EVERY parameter 3e-4 of max (both paths aggregate the projected features; summation orders differ)."""
+    1e-5, gradients of EVERY parameter 3e-4 of max (both paths aggregate the projected features; summation orders differ).
+    edgelist:<mode>: the edge-MLP scorers (reference dgm.py:1628-1719; u-v-deg is the training script's default) through the same node."""
     import copy
     import dgg_amd
     from argparse import Namespace
     from test_parallel_gloo import random_candidates
     N, d, h, C = 1200, 40, 32, 7
-    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+    cand, _, edge_mode = cand.partition(":")
+    edge_mode = edge_mode or "u-v-dist"
+    args = Namespace(extra_edge_dim={"u-v-deg": 2, "u-v-deg-dist": 3, "u-v-A_uv": 1}.get(edge_mode, 0), extra_k_dim=1, dgg_hard=False,
+                     deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net=edge_mode,
                      dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
                      symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
     torch.manual_seed(3)

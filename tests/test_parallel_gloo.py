@@ -88,6 +88,29 @@ class CpuKern:
         idx, val = O.edgelist_topk(xp.numpy(), rowptr.numpy(), col.numpy(), K=K, t=t, noise_mode=noise_mode, seed=seed)
         return self._t(idx), self._t(val)
 
+    # edge-MLP scorer (oracle/oracle.c, ora_edge_mlp_*)
+    @staticmethod
+    def _n(a):
+        return None if a is None else a.detach().numpy()
+
+    def edge_mlp_fwd(self, AB, xp, erow, col, deg, ex_in, ex_mode, t_ex, wdu, wdv, wex, b1, w2, b2, act=1):
+        from oracle import oracle as O
+        n = self._n
+        p, ex = O.edge_mlp_fwd(n(AB), n(xp), n(erow), n(col), n(deg), n(ex_in), ex_mode, t_ex, n(wdu), n(wdv), n(wex), n(b1), n(w2),
+                               float(b2.reshape(-1)[0]), act)
+        return self._t(p), (self._t(ex) if ex_mode else None)
+
+    def edgelist_topk_p(self, p_edge, N, rowptr, col, K, noise_mode, G, seed):
+        from oracle import oracle as O
+        return tuple(self._t(a) for a in O.edgelist_topk_p(p_edge.numpy(), N, rowptr.numpy(), col.numpy(), K, noise_mode, None, seed))
+
+    def edge_mlp_bwd(self, AB, idx, eid, val, dval, deg, ex, wdu, wdv, wex, b1, w2, b2, act=1, perturb=False, need_dex=False):
+        from oracle import oracle as O
+        n = self._n
+        dAB, dpar, dex = O.edge_mlp_bwd(n(AB), n(idx), n(eid), n(val), n(dval), n(deg), n(ex), n(wdu), n(wdv), n(wex), n(b1), n(w2),
+                                        float(b2.reshape(-1)[0]), act, perturb)
+        return self._t(dAB), self._t(dpar), (self._t(dex) if need_dex else None)
+
     @staticmethod
     def _ramp(K, k):
         r = np.arange(K, dtype=np.float64)[None, :]
@@ -320,6 +343,76 @@ def test_edge_list_step_matches_dense_autograd(noise_mode, ext):
     if ext:
         loss = loss + (ahat * cotA.double()).sum()
     loss.backward()
+    for k_, v in g.items():
+        ref = (xd.grad if k_ == "x" else Pd[k_].grad).numpy()
+        np.testing.assert_allclose(v.numpy().reshape(ref.shape), ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k_)
+
+
+@pytest.mark.parametrize("mode_name,noise_mode", [("u-v-deg", 0), ("u-v-deg", 2), ("u-v-deg-dist", 2), ("u-v-A_uv", 0), ("edge_conv", 2)])
+def test_edge_list_step_with_edge_mlp_scorer_matches_dense_autograd(mode_name, noise_mode):
+    """ShardedDGGConv with an edge-MLP scorer on edge-list candidates (reference dgm.py:1628-1719; the scorer the training script
+    defaults to) on the oracle stand-in against torch autograd of the same formulas on the selected entries: every layer parameter, the
+    scorer's own terms (Wcat, wdu, wdv, wex, b1, w2, b2) and x."""
+    sys.path.insert(0, ROOT)
+    from dgg_amd.parallel import ShardedDGGConv
+    N, d, h = 90, 12, 16
+    x, deg, P, cot = make_inputs(N, d, h)
+    rowptr, col = random_candidates(N)
+    E = col.shape[0]
+    erow = torch.repeat_interleave(torch.arange(N, dtype=torch.int32), (rowptr[1:] - rowptr[:-1]))
+    gen = torch.Generator().manual_seed(21)
+    hw = h // 2 if mode_name == "edge_conv" else h
+    rnd = lambda *sh: torch.randn(*sh, generator=gen) * 0.3  # noqa: E731
+    sc = dict(Wcat=rnd(2 * hw, h), wdu=None, wdv=None, wex=None, b1=rnd(hw), w2=rnd(hw), b2=rnd(1), erow=erow, ex_in=None, ex_mode=0, t_ex=0.0,
+              act=0 if mode_name == "edge_conv" else 1)
+    if mode_name in ("u-v-deg", "u-v-deg-dist"):
+        sc.update(wdu=rnd(hw) * 0.1, wdv=rnd(hw) * 0.1)
+    if mode_name == "u-v-deg-dist":
+        sc.update(wex=rnd(hw), ex_mode=2, t_ex=-1.0)
+    if mode_name == "u-v-A_uv":
+        sc.update(wex=rnd(hw), ex_mode=1, ex_in=torch.rand(E, generator=gen))
+    lay = ShardedDGGConv(CpuKern(), N, K=64, noise_mode=noise_mode, seed=(5, 6), x_grad=True, cand=(rowptr, col))
+    lay.scorer = sc
+    Z = lay.forward(x, deg, P)
+    g = lay.backward(cot, x, P)
+    s = lay.saved
+    idx, eid = s["idx"].numpy(), s["eid"].numpy()
+    # dense autograd restatement on the selected entries, float64
+    xd = x.double().requires_grad_(True)
+    Pd = {k_: v.double().requires_grad_(True) for k_, v in P.items()}
+    Sd = {k_: sc[k_].double().requires_grad_(True) for k_ in ("Wcat", "wdu", "wdv", "wex", "b1", "w2", "b2") if sc[k_] is not None}
+    lk = lambda t_: torch.where(t_ > 0, t_, 0.01 * t_)  # noqa: E731
+    xp, xk = lk(xd @ Pd["We"].T + Pd["be"]), lk(xd @ Pd["Wk"].T + Pd["bk"])
+    mu, sd = deg.double().mean(), deg.double().std()
+    feat = torch.cat([xk, ((deg.double() - mu) / (sd + 1e-5))[:, None]], 1)
+    m = lk(feat @ Pd["W1"].T + Pd["b1"]) @ Pd["Wmu"].T + Pd["bmu"]
+    k = torch.relu((m @ Pd["Wp"].reshape(-1) + Pd["bp"][0]) * sd + mu) + 1
+    valid = torch.from_numpy(idx >= 0)
+    j = torch.from_numpy(np.maximum(idx, 0)).long()
+    AB = xp @ Sd["Wcat"].T
+    z = AB[:, None, :hw] + AB[j][:, :, hw:] + Sd["b1"]
+    if "wdu" in Sd:
+        z = z + deg.double()[:, None, None] * Sd["wdu"] + deg.double()[j][:, :, None] * Sd["wdv"]
+    if sc["ex_mode"] == 1:
+        z = z + sc["ex_in"].double()[torch.from_numpy(np.maximum(eid, 0)).long()][:, :, None] * Sd["wex"]
+    if sc["ex_mode"] == 2:
+        dist = ((xp[:, None, :] - xp[j]) ** 2).sum(-1).clamp_min(1e-30).sqrt()
+        z = z + torch.exp(sc["t_ex"] * dist)[:, :, None] * Sd["wex"]
+    hid = lk(z) if sc["act"] == 1 else z
+    p = torch.sigmoid((hid * Sd["w2"]).sum(-1) + Sd["b2"])
+    sel_p = p if noise_mode == 0 else torch.exp(torch.log(p + 1e-8) + (torch.log(s["val"].double().clamp_min(1e-300)) - torch.log(p + 1e-8)).detach())
+    r = torch.arange(64, dtype=torch.float64)[None, :]
+    w = torch.where(valid, sel_p * (1 - 0.5 * (1 + torch.tanh(r - k[:, None]))), torch.zeros_like(p))
+    np.testing.assert_allclose(w.detach().numpy(), s["w"].numpy(), rtol=2e-5, atol=1e-7)
+    a = w.sum(1).rsqrt()
+    ahat = a[:, None] * w * a[j]
+    Zd = torch.relu((ahat[:, :, None] * (xd @ Pd["Wc"])[j]).sum(1))
+    np.testing.assert_allclose(Zd.detach().numpy(), Z.numpy(), rtol=1e-4, atol=1e-5)
+    (Zd * cot.double()).sum().backward()
+    gs = g.pop("scorer")
+    for k_, v in Sd.items():
+        ref = v.grad.numpy()
+        np.testing.assert_allclose(gs[k_].numpy().reshape(ref.shape), ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg="scorer " + k_)
     for k_, v in g.items():
         ref = (xd.grad if k_ == "x" else Pd[k_].grad).numpy()
         np.testing.assert_allclose(v.numpy().reshape(ref.shape), ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k_)
