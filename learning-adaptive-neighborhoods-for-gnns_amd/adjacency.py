@@ -24,8 +24,11 @@ class AllPairs:
 class EllAdjacency:
     """Row-major fixed-width sparse matrix: entry (i, idx[i,r]) = values[i,r]; idx == -1 marks padding."""
 
-    def __init__(self, idx, values, n_cols, rs=None, k=None, score=None, normalized=False, part=None, owner=None):
+    def __init__(self, idx, values, n_cols, rs=None, k=None, score=None, normalized=False, part=None, owner=None, partp=None):
         self.idx, self._values, self.n_cols = idx, values, n_cols
+        # (payload partition, row sums of the unnormalised weights) when `values` are the normalised values that partition was
+        # built with (DGG_LearnableK_debug.forward_conv): the backward of A @ X then runs by destination, without atomics
+        self.partp = partp
         self.owner = owner          # the DGG module that produced it (its ELL-width bound is checked when the matrix is densified)
         self.rs, self.k, self.score, self.normalized = rs, k, score, normalized
         self.part = part            # destination-ordered partition of the active entries (ops.part_build), if one was built
@@ -74,7 +77,7 @@ class EllAdjacency:
     def matmul(self, X, act=ops.ACT_NONE):
         """act(A @ X) (torch.mm(adj, x), model.py:594; act = ReLU fuses GCNConv's activation into the aggregation)."""
         # weights produced by the DGG ramp: an exact zero is a saturated ramp whose gradient vanishes too
-        return ops.EllSpmmFn.apply(self._values, self.idx, X, self.k is not None, self.part, act)
+        return ops.EllSpmmFn.apply(self._values, self.idx, X, self.k is not None, self.part, act, self.partp)
 
     __matmul__ = matmul
 

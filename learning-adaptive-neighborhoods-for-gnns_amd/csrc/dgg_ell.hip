@@ -302,6 +302,37 @@ __global__ __launch_bounds__(WPB * 64) void spmm_bwd_kernel(const int32_t *__res
     if (lane < K) dA[i * K + lane] = mine;
 }
 
+// The same for a handful of features (F <= 8: the class scores of a model's LAST graph convolution, model.py:1290): entries on
+// lanes -- each lane forms its entry's dot product and its F atomics itself; no per-entry wavefront reduction, no serial walk of
+// the 64 slots (38 -> 9 us on the Pubmed shape with F = 3).
+template <int FMAX>
+__global__ __launch_bounds__(WPB * 64) void spmm_bwd_tiny_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
+                                                                const float *__restrict__ X, const float *__restrict__ dY,
+                                                                int64_t N, int K, int F, int skip_zero,
+                                                                float *__restrict__ dA, float *__restrict__ dX) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
+    if (i >= N) return;
+    float g[FMAX];
+#pragma unroll
+    for (int q = 0; q < FMAX; q++) g[q] = q < F ? dY[i * F + q] : 0.0f;      // (one address for the whole wavefront)
+    for (int r = lane; r < K; r += 64) {
+        const int32_t j = idx[i * K + r];
+        const float a = ahat[i * K + r];
+        float dot = 0.0f;
+        if (j >= 0 && !(skip_zero && a == 0.0f)) {
+#pragma unroll
+            for (int q = 0; q < FMAX; q++) {
+                if (q < F) {
+                    dot = fmaf(g[q], X[(int64_t)j * F + q], dot);
+                    if (dX && a != 0.0f) atomicAdd(dX + (int64_t)j * F + q, a * g[q]);
+                }
+            }
+        }
+        dA[i * K + r] = dot;
+    }
+}
+
 // SDDMM only (no dX) for wide rows (F > 256, a multiple of 4; GCNII layers of the PPI configuration: 2048): the wavefront
 // walks the row's cotangent ONCE per batch of four neighbours -- 16-byte loads, four gathered rows in flight -- instead of
 // once per neighbour.
@@ -777,6 +808,8 @@ int dgg_ell_spmm_bwd(const int32_t *idx, const float *ahat, const float *X, cons
                            nullptr, nullptr, 0, nullptr, nullptr, nullptr);
     else if (!dX && al16 && F > 256 && F % 4 == 0)
         hipLaunchKernelGGL(sddmm_wide_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, N, K, F, skip_zero, dA);
+    else if (F <= 8)
+        hipLaunchKernelGGL(spmm_bwd_tiny_kernel<8>, dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, N, K, F, skip_zero, dA, dX);
     else
         hipLaunchKernelGGL(spmm_bwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, st, idx, ahat, X, dY, N, K, F, skip_zero, dA, dX);
     return dgg_check_launch("ell_spmm_bwd");

@@ -592,7 +592,10 @@ class DGG_LearnableK_debug(nn.Module):
         unnorm = EllAdjacency(st["idx"], st["w"], N, rs=st["rs"], k=k, score=st["val"], owner=self)
         if not want_norm:
             return Z, unnorm
-        return Z, unnorm, EllAdjacency(st["idx"], ahat, N, k=k, score=st["val"], normalized=True, owner=self)
+        if st.get("side_join"):                               # the partition's sort ran on the layer's side stream: a later layer's
+            torch.cuda.current_stream().wait_stream(layer._side_stream())     # backward reads it BEFORE this node's own backward joins
+            st["side_join"] = False
+        return Z, unnorm, EllAdjacency(st["idx"], ahat, N, k=k, score=st["val"], normalized=True, owner=self, partp=(st["partp"], st["rs"]))
 
     def _track_overflow(self, k, ncand):
         over = k.detach() + 8.5 > float(self.ell_width)

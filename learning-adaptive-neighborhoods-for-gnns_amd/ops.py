@@ -1284,10 +1284,10 @@ class EllSpmmFn(torch.autograd.Function):
     aggregates the projected features, relu(A (x W)))."""
 
     @staticmethod
-    def forward(ctx, ahat, idx, X, skip_zero=False, part=None, act=ACT_NONE):
+    def forward(ctx, ahat, idx, X, skip_zero=False, part=None, act=ACT_NONE, partp=None):
         Y = spmm_fwd(idx, ahat, X, act)
         ctx.save_for_backward(ahat, idx, X, Y if act != ACT_NONE else X)
-        ctx.skip_zero, ctx.part, ctx.act = skip_zero, part, act
+        ctx.skip_zero, ctx.part, ctx.act, ctx.partp = skip_zero, part, act, partp
         return Y
 
     @staticmethod
@@ -1296,13 +1296,19 @@ class EllSpmmFn(torch.autograd.Function):
         dY = dY.contiguous()
         if ctx.act != ACT_NONE:
             dY = act_bwd(Y, dY, ctx.act)
+        if ctx.needs_input_grad[2] and ctx.skip_zero and ctx.partp is not None and X.shape[0] == idx.shape[0]:
+            # the adjacency of the fused layer, read by a later layer: the same per-destination kernel as the layer's own aggregation
+            # backward (the records carry the normalised values): dA by plain stores, dX owned by the destination's wavefront
+            got = conv_bwd_cols_p(idx, X, dY, ctx.partp[0], ctx.partp[1], zero_dA=True)
+            if got is not None:
+                return got[0], None, got[2], None, None, None, None
         if ctx.needs_input_grad[2] and ctx.skip_zero and X.shape[0] == idx.shape[0]:
             # learned input on a DGG adjacency: SDDMM and transposed SpMM from ONE gathered cotangent row per entry
             got = conv_bwd_cols(idx, ahat, X, dY, ctx.part)
             if got is not None:
-                return got[0], None, got[1], None, None, None
+                return got[0], None, got[1], None, None, None, None
         dA, dX = spmm_bwd(idx, ahat, X, dY, need_dx=ctx.needs_input_grad[2], skip_zero=ctx.skip_zero, part=ctx.part)
-        return dA, None, dX, None, None, None
+        return dA, None, dX, None, None, None, None
 
 
 class CsrNormalizeFn(torch.autograd.Function):

@@ -391,9 +391,28 @@ def test_ell_backward_kernels(dev):
             want = np.where(ahat == 0, 0.0, ref2) if skip else ref2
             assert none is None
             np.testing.assert_allclose(Nn(got2), want, rtol=1e-4, atol=1e-4 * np.abs(ref2).max())
+    for F3 in (1, 3, 7, 8):                                # entries-on-lanes kernel of the narrow last layer (class scores)
+        X3 = rng.standard_normal((N, F3)).astype(np.float32)
+        dY3 = rng.standard_normal((N, F3)).astype(np.float32)
+        for skip, need_dx in ((False, True), (True, True), (False, False)):
+            r3A, r3X = O.spmm_bwd(idx, ahat, X3, dY3)
+            g3A, g3X = ops.spmm_bwd(T(idx, dev), T(ahat, dev), T(X3, dev), T(dY3, dev), need_dx=need_dx, skip_zero=skip)
+            np.testing.assert_allclose(Nn(g3A), np.where(ahat == 0, 0.0, r3A) if skip else r3A, rtol=1e-4, atol=1e-4 * np.abs(r3A).max())
+            if need_dx:
+                np.testing.assert_allclose(Nn(g3X), r3X, rtol=1e-4, atol=1e-4 * np.abs(r3X).max())
     da = ops.norm_bwd_da(T(idx, dev), T(w, dev), T(rs, dev), T(rdA, dev))
     dval, dk = ops.softk_bwd(T(idx, dev), T(val, dev), T(k, dev), T(rdA, dev), rs=T(rs, dev), da=da, normalized=True)
     rdval, rdk = O.softk_norm_bwd(idx, val, k, w, rs, rdA)
+    # the same with the neighbour-side sums only in `da` and the row side formed inside the kernel (dgg_softk_bwd_rows)
+    j_ = np.maximum(idx, 0)
+    a_ = 1.0 / np.sqrt(rs.astype(np.float64))
+    g_ = rdA.astype(np.float64) * w * (idx >= 0)
+    da_cols = np.zeros(N, np.float64)
+    np.add.at(da_cols, j_.reshape(-1), (g_ * a_[:, None]).reshape(-1))
+    dval2, dk2 = ops.softk_bwd(T(idx, dev), T(val, dev), T(k, dev), T(rdA, dev), rs=T(rs, dev), da=T(da_cols.astype(np.float32), dev),
+                               normalized=True, ahat_rows=T(ahat, dev))
+    np.testing.assert_allclose(Nn(dval2), rdval, rtol=2e-4, atol=2e-4 * np.abs(rdval).max())
+    np.testing.assert_allclose(Nn(dk2), rdk, rtol=2e-4, atol=2e-4 * np.abs(rdk).max())
     np.testing.assert_allclose(Nn(dval), rdval, rtol=2e-4, atol=2e-4 * np.abs(rdval).max())
     np.testing.assert_allclose(Nn(dk), rdk, rtol=2e-4, atol=2e-4 * np.abs(rdk).max())
     part = ops.part_build(T(idx, dev), T(w, dev), N)          # destination-bucket partition (no global float atomics)
