@@ -820,6 +820,13 @@ def other_configs(a, dev):
             res["pubmed_uvdist"] = pick(run_edgelist(b, dev))
     except Exception as e:  # noqa: BLE001
         res["pubmed_uvdist"] = {"error": repr(e)}
+    try:
+        if "pubmed" in only:                                 # the same shape with the reference script's DEFAULT scorer (train_small_graphs.py:184-191)
+            b = copy.copy(a)
+            b.steps, b.warmup, b.edge_mode, b.cpu_dense, b.cpu_rows = 20, 3, "u-v-deg", False, -1
+            res["pubmed_uvdeg"] = pick(run_edgelist(b, dev))
+    except Exception as e:  # noqa: BLE001
+        res["pubmed_uvdeg"] = {"error": repr(e)}
     torch.cuda.empty_cache()
     try:
         if "ppi" in only:
