@@ -2499,6 +2499,80 @@ def test_config1_pubmed_shape_edge_list_step(dev, fused):
         np.testing.assert_allclose(Nn(got).reshape(ref.shape), ref, rtol=0, atol=2e-4 * np.abs(ref).max())
 
 
+def test_config1_pubmed_shape_default_scorer_fused_step(dev):
+    """BASELINE configs[1] with the reference script's DEFAULT scorer (`u-v-deg`, train_small_graphs.py:184-191; edge_encode on
+    [u, v, deg_u, deg_v], dgm.py:1645-1670) through the fused layer: neighbour lists and scores bit-exact against the oracle's
+    edge-MLP pipeline on EVERY row, weights / output 1e-5, gradients of the scorer (edge_encode.*), of node_encode_for_edges and of
+    the convolution against the oracle's backward, 2e-4 of max."""
+    import bench
+    import dgg_amd
+    from argparse import Namespace
+    N, d, h = 19_717, 500, 64
+    rows, cols = bench.pubmed_graph(N, 44_324)
+    o = np.lexsort((cols, rows))
+    rows, cols = rows[o], cols[o]
+    E = rows.shape[0]
+    args = Namespace(extra_edge_dim=2, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-deg",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
+    torch.manual_seed(0)
+    dgg = dgg_amd.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=args)
+    conv = dgg_amd.GCNConv(d, 64)
+    with torch.no_grad():
+        dgg.k_net.k_project.weight.mul_(0.1)
+        dgg.edge_encode[0].weight[:, 2 * h:].mul_(0.05)            # (raw degrees ~16 enter the scorer: keep the sigmoid off its rails)
+    dgg, conv = dgg.to(dev), conv.to(dev)
+    dgg.set_seed(1234, 0)
+    x = torch.rand(N, d, generator=torch.Generator().manual_seed(1))
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.full((E,), 16.0 * N / E), (N, N)).coalesce().to(dev)
+    got = dgg.forward_conv(x.to(dev), A, conv.W)
+    assert got is not None and dgg._fused_layer.scorer is not None, "the default scorer is inside the fused layer's coverage"
+    out, adj = got
+    out.sum().backward()
+    dgg.check_ell_bound()
+    # oracle: the whole edge-list pipeline (O(E))
+    sd = {k_: Nn(v) for k_, v in dgg.state_dict().items()}
+    rowptr, col = csr_from_coo(rows, cols, N)
+    deg = Nn(dgg_amd.csr_candidates(A)[2])
+    xn = x.numpy()
+    xp = O.linear(xn, sd["node_encode_for_edges.0.weight"], sd["node_encode_for_edges.0.bias"], O.ACT_LEAKY)
+    xk = O.linear(xn, sd["node_encode_for_k.0.weight"], sd["node_encode_for_k.0.bias"], O.ACT_LEAKY)
+    mu, sdv = O.degree_stats(deg)
+    k = O.knet_x(xk, deg, mu, sdv, sd["k_embed.0.weight"], sd["k_embed.0.bias"], sd["k_net.k_mu.weight"], sd["k_net.k_mu.bias"],
+                 sd["k_net.k_project.weight"].reshape(-1), sd["k_net.k_project.bias"])
+    np.testing.assert_allclose(Nn(adj.k), k, rtol=1e-6, atol=1e-6)
+    W0 = sd["edge_encode.0.weight"]
+    Wcat = np.ascontiguousarray(np.concatenate([W0[:, :h], W0[:, h:2 * h]], 0))
+    wdu, wdv = np.ascontiguousarray(W0[:, 2 * h]), np.ascontiguousarray(W0[:, 2 * h + 1])
+    b1, w2, b2 = sd["edge_encode.0.bias"], sd["edge_encode.2.weight"].reshape(-1), float(sd["edge_encode.2.bias"][0])
+    AB = O.linear(xp, Wcat, None, O.ACT_NONE)
+    p_edge, _ = O.edge_mlp_fwd(AB, xp, rows.astype(np.int32), col, deg, None, 0, 0.0, wdu, wdv, None, b1, w2, b2, 1)
+    assert 0.02 < float(p_edge.min()) and float(p_edge.max()) < 0.98
+    ridx, rval, reid = O.edgelist_topk_p(p_edge, N, rowptr, col, K, O.NOISE_HASH, None, (1234, 0))
+    assert np.array_equal(Nn(adj.idx), ridx) and np.array_equal(Nn(adj.score), rval)
+    rw, rrs = O.softk(ridx, rval, k)
+    np.testing.assert_allclose(Nn(adj.values()), rw, rtol=0, atol=1e-5)
+    rah = O.normalize(ridx, rw, rrs)
+    Y = O.spmm(ridx, rah, xn)
+    Z = O.linear(Y, Nn(conv.W), None, O.ACT_RELU, w_layout=1)      # reference order relu((A x) W); the layer aggregates x W
+    np.testing.assert_allclose(Nn(out), Z, rtol=1e-5, atol=1e-5 * np.abs(Z).max())
+    dY, dWc, _ = O.linear_bwd(Y, Nn(conv.W), Z, np.ones_like(Z), act=O.ACT_RELU, w_layout=1)
+    dA, _ = O.spmm_bwd(ridx, rah, xn, dY, need_dx=False)
+    dval, dk = O.softk_norm_bwd(ridx, rval, k, rw, rrs, dA)
+    dAB, dpar, _ = O.edge_mlp_bwd(AB, ridx, reid, rval, dval, deg, None, wdu, wdv, None, b1, w2, b2, 1, True)
+    dxp, dWcat, _ = O.linear_bwd(xp, Wcat, AB, dAB, act=O.ACT_NONE)
+    _, dWe, dbe = O.linear_bwd(xn, sd["node_encode_for_edges.0.weight"], xp, dxp, act=O.ACT_LEAKY, need_dx=False)
+    dW0 = np.concatenate([dWcat[:h], dWcat[h:], dpar[0:h, None], dpar[h:2 * h, None]], 1)
+    for name, got_, ref in [("conv.W", conv.W.grad, dWc), ("edge_encode.0.weight", dgg.edge_encode[0].weight.grad, dW0),
+                            ("edge_encode.0.bias", dgg.edge_encode[0].bias.grad, dpar[3 * h:4 * h]),
+                            ("edge_encode.2.weight", dgg.edge_encode[2].weight.grad, dpar[4 * h:5 * h]),
+                            ("edge_encode.2.bias", dgg.edge_encode[2].bias.grad, dpar[5 * h:5 * h + 1]),
+                            ("node_encode_for_edges.0.weight", dgg.node_encode_for_edges[0].weight.grad, dWe),
+                            ("node_encode_for_edges.0.bias", dgg.node_encode_for_edges[0].bias.grad, dbe)]:
+        err = np.abs(Nn(got_).reshape(ref.shape) - ref).max() / max(np.abs(ref).max(), 1e-30)
+        assert err <= 2e-4, f"{name}: {err:.2e}"
+
+
 def test_config3_500k_nodes_in_eight_row_shards(dev):
     """BASELINE configs[3]: ONE graph of 500 000 nodes, node-range sharded 8 ways.  The eight shards' kernels run one after the
     other on this GPU (own rows, GLOBAL columns / row sums) and must reproduce the single-shard run bit for bit: neighbour
