@@ -337,6 +337,12 @@ int dgg_softk_bwd_rows(const int32_t *idx, const float *val, const float *k, con
 /* score backward to the projected features: dxp [Nglobal,h] += ... (zeroed by caller; fp32 atomics) */
 int dgg_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval, int K,
                  int64_t row0, float t, int perturb, float *dxp, void *stream);
+/* ROW pass of the same for wide latents (h a multiple of 64, <= 2048; the PPI configuration runs the generator at latent 2048,
+ * train_ppi.py:44) without float atomics: dxp_rows [N,h] (OVERWRITTEN) = sum_r dd_ir (xp_i - xp_j), dd [N,K] (overwritten) = the
+ * per-entry coefficient (d loss / d dist_ir) / dist_ir.  The neighbour side follows from dd with the transposed aggregation:
+ * dxp_j -= (DD^T xp)_j - (sum_i dd_ij) xp_j  (dgg_ell_spmm_t_part(a = dd, dY = xp)).  Autograd of dgm.py:1618-1623. */
+int dgg_edge_bwd_wide_rows(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval, int K,
+                           int64_t row0, float t, int perturb, float *dxp_rows, float *dd, void *stream);
 
 /* ---- column-side backward terms without global float atomics (dgg_scatter.hip) -----------------------------------
  * The ACTIVE entries (idx >= 0, w != 0) of an ELL block are partitioned once per forward by destination bucket; the two

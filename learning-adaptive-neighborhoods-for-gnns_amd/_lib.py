@@ -119,6 +119,7 @@ PROTOTYPES = {
     "dgg_norm_da_cols_part": [_vp, _i64, _i32, _i64, _vp, _vp, _vp],
     "dgg_ell_sddmm_norm_part": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp],
     "dgg_edge_bwd": [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _vp],
+    "dgg_edge_bwd_wide_rows": [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _vp, _vp],
 }
 
 _lib = None

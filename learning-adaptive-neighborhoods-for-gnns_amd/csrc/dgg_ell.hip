@@ -626,6 +626,82 @@ __global__ __launch_bounds__(WPB * 64) void edge_bwd_wide_kernel(const float *__
     }
 }
 
+// ROW pass of the wide score backward without float atomics (h <= 2048, a multiple of 64): the row's own side
+//   own_i = sum_r dd_ir (xp_i - xp_j)  accumulates per wavefront in LDS and is STORED (dxp_rows [N,h], overwritten);
+// the coefficient dd_ir = (d loss / d dist_ir) / dist_ir of every entry goes to dd [N,K] for the transposed pass
+//   dxp_j -= sum_i dd_ij (xp_i - xp_j)  =  -(DD^T xp)_j + (sum_i dd_ij) xp_j      (dgg_ell_spmm_t_part with a = dd, dY = xp).
+// 98 M atomics per 2 400-node graph at latent 2048 (PPI configuration) were 482 us; the two gather passes take ~1/3 of that.
+constexpr int EBW_HMAX = 2048;
+__global__ __launch_bounds__(WPB * 64) void edge_bwd_wide_rows_kernel(const float *__restrict__ xp, int64_t N, int h,
+                                                                     const int32_t *__restrict__ idx, const float *__restrict__ val,
+                                                                     const float *__restrict__ dval, int K, int64_t row0, float t,
+                                                                     int perturb, float *__restrict__ dxp_rows, float *__restrict__ dd_out) {
+    __shared__ float own_s[WPB][EBW_HMAX];
+    const int lane = threadIdx.x & 63, wave = dgg::wave_id();
+    const int64_t i = blockIdx.x;
+    const int64_t gi = row0 + i;
+    const float *xi = xp + gi * h;
+    int32_t jl = lane < K ? idx[i * K + lane] : -1;
+    float gl = lane < K ? dval[i * K + lane] : 0.0f;
+    float vl = lane < K ? val[i * K + lane] : 0.0f;
+    for (int c = lane; c < h; c += 64) own_s[wave][c] = 0.0f;
+    constexpr int EQ = 4;                                        // entries in flight per pass over the features
+    for (int r0 = wave * EQ; r0 < K; r0 += WPB * EQ) {
+        int32_t j[EQ];
+        float g[EQ], v[EQ], d2[EQ], dd[EQ];
+        const float *xj[EQ];
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < EQ; u++) {
+            const int r = r0 + u < K ? r0 + u : K - 1;
+            j[u] = bcast(jl, r);
+            g[u] = r0 + u < K ? bcast(gl, r) : 0.0f;
+            v[u] = bcast(vl, r);
+            if (j[u] < 0) g[u] = 0.0f;
+            xj[u] = xp + (int64_t)(j[u] < 0 ? 0 : j[u]) * h;
+            d2[u] = 0.0f;
+            any = any || g[u] != 0.0f;
+        }
+        if (!any) {                                              // wave-uniform
+            if (lane < EQ && r0 + lane < K) dd_out[i * K + r0 + lane] = 0.0f;
+            continue;
+        }
+        for (int c = lane; c < h; c += 64) {
+            const float xv = xi[c];
+#pragma unroll
+            for (int u = 0; u < EQ; u++) { const float d = xv - xj[u][c]; d2[u] = fmaf(d, d, d2[u]); }
+        }
+#pragma unroll
+        for (int u = 0; u < EQ; u++) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) d2[u] += __shfl_xor(d2[u], off, 64);
+            dd[u] = 0.0f;
+            if (g[u] != 0.0f && d2[u] != 0.0f) {
+                const float dist = sqrtf(d2[u]);
+                const float p = c_exp(t * dist);
+                const float dp = perturb ? g[u] * v[u] / (p + 1e-8f) : g[u];
+                dd[u] = dp * t * p / dist;
+            }
+            if (lane == u && r0 + u < K) dd_out[i * K + r0 + u] = dd[u];
+        }
+        for (int c = lane; c < h; c += 64) {
+            const float xv = xi[c];
+            float own = 0.0f;
+#pragma unroll
+            for (int u = 0; u < EQ; u++)
+                if (dd[u] != 0.0f) own += dd[u] * (xv - xj[u][c]);
+            own_s[wave][c] += own;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < h; c += WPB * 64) {
+        float tot = own_s[0][c];
+#pragma unroll
+        for (int w = 1; w < WPB; w++) tot += own_s[w][c];
+        dxp_rows[i * h + c] = tot;
+    }
+}
+
 // GCNII layer epilogue (reference model.py:36-44 / 69-77): out = theta * (support W) + (1 - theta) * r (+ input), with
 // r = (1 - alpha) * hi + alpha * h0 folded in (h0 == NULL: r = hi, the non-variant layer whose support IS r).  One pass
 // instead of five elementwise launches; the backward is three scaled copies of the cotangent.
@@ -896,6 +972,16 @@ int dgg_softk_bwd_rows(const int32_t *idx, const float *val, const float *k, con
     hipLaunchKernelGGL(softk_bwd_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, idx, val, k, rs, dA, da_cols,
                        N, K, row0, mode, 1, dval, dk, ahat_rows);
     return dgg_check_launch("softk_bwd_rows");
+}
+
+int dgg_edge_bwd_wide_rows(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval, int K,
+                           int64_t row0, float t, int perturb, float *dxp_rows, float *dd, void *stream) {
+    if (h % 64 != 0 || h > EBW_HMAX || K < 1 || K > 64)
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "edge_bwd_wide_rows: latent_dim a multiple of 64 up to 2048, K in [1,64]");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(edge_bwd_wide_rows_kernel, dim3((unsigned)N), dim3(WPB * 64), 0, (hipStream_t)stream, xp, N, h, idx, val, dval, K,
+                       row0, t, perturb, dxp_rows, dd);
+    return dgg_check_launch("edge_bwd_wide_rows");
 }
 
 int dgg_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval, int K,

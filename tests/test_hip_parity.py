@@ -1364,6 +1364,29 @@ def test_module_symmetric_noise_all_pairs_matches_oracle(dev, generator, omode):
     assert np.abs(Nn(x.grad) - rx).max() <= 3e-4 * np.abs(rx).max()
 
 
+@pytest.mark.parametrize("h,perturb", [(256, True), (2048, True), (192, False)])
+def test_wide_score_backward_without_atomics(dev, h, perturb):
+    """latent widths beyond 128 (PPI: 2048): the row pass + transposed aggregation form of the score backward (dgg_edge_bwd_wide_rows +
+    dgg_ell_spmm_t_part on the destination-ordered partition) against the oracle's edge_bwd and against the atomic kernel"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(h)
+    N = 260
+    xp = (rng.standard_normal((N, h)) * 0.3).astype(np.float32)
+    k = (3 + 20 * rng.random(N)).astype(np.float32)
+    idx, val = O.allpairs_topk(xp, K=K, noise_mode=O.NOISE_HASH if perturb else O.NOISE_NONE, seed=(3, 3))
+    idx[5, 40:] = -1                                       # a short row, an empty tail
+    val[5, 40:] = 0.0
+    w, _ = O.softk(idx, val, k)
+    dval = (rng.standard_normal((N, K)) * (w != 0)).astype(np.float32)
+    ref = O.edge_bwd(xp, idx, val, dval, perturb=perturb)
+    part = ops.part_build(T(idx, dev), T(w, dev), N)
+    assert part is not None
+    got = ops.edge_bwd(T(xp, dev), T(idx, dev), T(val, dev), T(dval, dev), perturb=perturb, part=part)
+    old = ops.edge_bwd(T(xp, dev), T(idx, dev), T(val, dev), T(dval, dev), perturb=perturb)
+    np.testing.assert_allclose(Nn(got), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+    np.testing.assert_allclose(Nn(old), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+
+
 def test_wide_latent_edge_list_pipeline(dev):
     """latent_dim > 128 (the PPI configuration runs the DGG at latent_dim = hidden = 2048): edge-list scoring, wide score
     backward and the GEMM-composed k-net against the oracle, through the module"""
