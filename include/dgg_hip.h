@@ -292,6 +292,13 @@ int dgg_csr_spmm_bwd(const int64_t *rowptr, const int32_t *col, const float *a, 
 int dgg_csr_bg_softmax_fwd(const float *L, const int64_t *rowptr, int64_t N, float *att, float *bg, void *stream);
 int dgg_csr_bg_softmax_bwd(const float *att, const float *bg, const int64_t *rowptr, int64_t N, const float *datt, const float *dbg,
                            float *dL, void *stream);
+/* Training-mode dropout of that dense attention matrix (model.py:570, F.dropout(attention, p)): every one of the N x N pairs is kept
+ * with probability 1 - p -- the non-listed pairs, which all carry bg_i, included.  The mask is counter-based (pair (i, j) kept iff
+ * hash24(s0, s1 ^ 0x9E3779B9 (i + 1), j) >= p 2^24; the reference draws from torch's generator: same law, another realisation), so
+ * no N x N tensor exists: out_r = sum_s keep(r, s) X_s (transpose 0; the forward's sum of the kept rows of h) or sum_s keep(s, r) X_s
+ * (transpose 1; its backward).  X, out [N,F], F <= 64.  dgg_pair_keep: the same mask on listed pairs (erow, col) [E] -> 1.0 / 0.0. */
+int dgg_masked_dense_sum(const float *X, int64_t N, int F, float p, uint32_t s0, uint32_t s1, int transpose, float *out, void *stream);
+int dgg_pair_keep(const int32_t *erow, const int32_t *col, int64_t E, float p, uint32_t s0, uint32_t s1, float *out, void *stream);
 /* selection only, from a dense score matrix [R,N] (test entry: torch.sort(pert_edge_p)[:, :K], dgm.py:1404) */
 int dgg_select_scores(const float *scores, int64_t R, int64_t N, int K, int32_t *idx, float *val, void *stream);
 

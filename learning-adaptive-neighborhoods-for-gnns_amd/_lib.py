@@ -68,6 +68,8 @@ PROTOTYPES = {
     "dgg_csr_spmm_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
     "dgg_csr_bg_softmax_fwd": [_vp, _vp, _i64, _vp, _vp, _vp],
     "dgg_csr_bg_softmax_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "dgg_masked_dense_sum": [_vp, _i64, _i32, _f32, _u32, _u32, _i32, _vp, _vp],
+    "dgg_pair_keep": [_vp, _vp, _i64, _f32, _u32, _u32, _vp, _vp],
     "dgg_csr_spmm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
     "dgg_select_scores": [_vp, _i64, _i64, _i32, _vp, _vp, _vp],
     "dgg_softk_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp],

@@ -381,6 +381,37 @@ __global__ __launch_bounds__(WPB * 64) void bg_softmax_bwd_kernel(const float *_
     for (int64_t e = e0 + lane; e < e1; e += 64) dL[e] = att[e] * (datt[e] - s);
 }
 
+// ---- GATConv_DGG, training mode: dropout of the DENSE attention matrix (reference model.py:570, F.dropout(attention)) -------------
+// Every pair (i, j) of the N x N matrix is kept with probability 1 - p, the non-listed pairs (weight bg_i each) included.  The mask
+// is counter-based -- pair (i, j) is kept iff drop_keep(s0, s1 ^ 0x9E3779B9 (i + 1), j) -- so nothing N x N is stored: the forward
+// sums the kept rows of h per node, the backward regenerates the mask transposed.
+__device__ __forceinline__ bool pair_keep(uint32_t s0, uint32_t s1, uint32_t i, uint32_t j, uint32_t thr24) {
+    return drop_keep(s0, s1 ^ (0x9E3779B9u * (i + 1u)), j, thr24);
+}
+// out_r = sum_s keep(r, s) X_s (transpose 0) or sum_s keep(s, r) X_s (transpose 1); X, out [N,F], F <= FP <= 64 (FP lanes per
+// column, 64 / FP columns per wave-instruction); one wavefront per output row
+template <int FP>
+__global__ __launch_bounds__(WPB * 64) void masked_dense_sum_kernel(const float *__restrict__ X, int64_t N, int F, uint32_t thr24,
+                                                                   uint32_t s0, uint32_t s1, int transpose, float *__restrict__ out) {
+    constexpr int CPI = 64 / FP;
+    const int lane = threadIdx.x & 63, f = lane % FP, sub = lane / FP;
+    const int64_t r = (int64_t)blockIdx.x * WPB + dgg::wave_id();
+    if (r >= N) return;
+    float acc = 0.0f;
+    for (int64_t s = sub; s < N; s += CPI) {
+        const bool keep = transpose ? pair_keep(s0, s1, (uint32_t)s, (uint32_t)r, thr24) : pair_keep(s0, s1, (uint32_t)r, (uint32_t)s, thr24);
+        if (keep && f < F) acc += X[s * F + f];
+    }
+#pragma unroll
+    for (int off = FP; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
+    if (sub == 0 && f < F) out[r * F + f] = acc;
+}
+__global__ void pair_keep_kernel(const int32_t *__restrict__ erow, const int32_t *__restrict__ col, int64_t E, uint32_t thr24, uint32_t s0,
+                                 uint32_t s1, float *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) out[e] = pair_keep(s0, s1, (uint32_t)erow[e], (uint32_t)col[e], thr24) ? 1.0f : 0.0f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -399,6 +430,27 @@ int dgg_csr_bg_softmax_bwd(const float *att, const float *bg, const int64_t *row
     return dgg_check_launch("csr_bg_softmax_bwd");
 }
 
+int dgg_masked_dense_sum(const float *X, int64_t N, int F, float p, uint32_t s0, uint32_t s1, int transpose, float *out, void *stream) {
+    if (F < 1 || F > 64 || !(p >= 0.0f && p < 1.0f) || N >= ((int64_t)1 << 32))
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "masked_dense_sum: F in [1,64], p in [0,1), N < 2^32");
+    if (N == 0) return 0;
+    const uint32_t thr = (uint32_t)(p * 16777216.0f);
+    const dim3 grid((unsigned)((N + WPB - 1) / WPB)), blk(WPB * 64);
+    hipStream_t st = (hipStream_t)stream;
+    if (F <= 8) hipLaunchKernelGGL(masked_dense_sum_kernel<8>, grid, blk, 0, st, X, N, F, thr, s0, s1, transpose, out);
+    else if (F <= 16) hipLaunchKernelGGL(masked_dense_sum_kernel<16>, grid, blk, 0, st, X, N, F, thr, s0, s1, transpose, out);
+    else if (F <= 32) hipLaunchKernelGGL(masked_dense_sum_kernel<32>, grid, blk, 0, st, X, N, F, thr, s0, s1, transpose, out);
+    else hipLaunchKernelGGL(masked_dense_sum_kernel<64>, grid, blk, 0, st, X, N, F, thr, s0, s1, transpose, out);
+    return dgg_check_launch("masked_dense_sum");
+}
+
+int dgg_pair_keep(const int32_t *erow, const int32_t *col, int64_t E, float p, uint32_t s0, uint32_t s1, float *out, void *stream) {
+    if (!(p >= 0.0f && p < 1.0f)) return dgg_set_error(DGG_ERR_ARG, "pair_keep: p in [0,1)");
+    if (E == 0) return 0;
+    hipLaunchKernelGGL(pair_keep_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, erow, col, E,
+                       (uint32_t)(p * 16777216.0f), s0, s1, out);
+    return dgg_check_launch("pair_keep");
+}
 
 int dgg_csr_row_sum(const float *vals, const int64_t *rowptr, int64_t N, float *rs, void *stream) {
     if (N == 0) return 0;

@@ -233,8 +233,12 @@ class GATConv_DGG(nn.Module):
       * every other pair: -1e20 * 0 = -0, i.e. ALL non-neighbours attend with the weight of logit 0
     so out_i = sum_{u in row i} att_u h_j + bg_i * (sum_all h - sum_{u in row i} h_j) with the row softmax taken over the
     explicit logits plus N - cnt_i zeros (dgg_csr_bg_softmax_fwd).
-    Dropout (training): on the input, on h and on the explicit attention entries as in the reference; the uniform
-    background weight is kept at its expectation instead of being masked pair by pair."""
+    Dropout (training): on the input and on h as in the reference; F.dropout(attention) (model.py:570) masks every one of the N x N
+    pairs, the non-listed ones included -- here with ONE counter-based pair mask (ops.pair_keep / ops.MaskedDenseSumFn: same law as
+    torch's generator, another realisation; no N x N tensor):
+        out_i = q sum_{u in row i} m_u att_u h_j + q bg_i (sum_j m_ij h_j - sum_{u in row i} m_u h_j),   q = 1 / (1 - p).
+    Output widths beyond 64 keep the background at its expectation (`exact_attention_dropout = False` forces that form)."""
+    exact_attention_dropout = True
 
     def __init__(self, in_features, out_features, dropout, alpha, bias=True):
         super().__init__()
@@ -278,10 +282,23 @@ class GATConv_DGG(nn.Module):
         w = torch.where(apos >= 0, adj.values()[apos.clamp(min=0)], torch.zeros_like(e))
         L = torch.where(listed, e * w, -1e20 * w)
         att, bg = ops.CsrBgSoftmaxFn.apply(L, rowptr)
-        att = F.dropout(att, self.dropout, training=self.training)
-        h = F.dropout(h, self.dropout, training=self.training)
-        h_prime = ops.CsrSpmmFn.apply(att - bg[rows], rowptr, cols, h) + bg.unsqueeze(1) * h.sum(0, keepdim=True)
+        if self.training and self.dropout > 0 and self.exact_attention_dropout and Fo <= 64:
+            h = F.dropout(h, self.dropout, training=True)
+            seed = tuple(int(v) for v in torch.randint(0, 2 ** 31 - 1, (2,)).tolist())      # (torch's CPU generator: no device sync)
+            h_prime = self.attend_dropped(h, att, bg, rowptr, cols, rows, self.dropout, seed)
+        else:
+            att = F.dropout(att, self.dropout, training=self.training)
+            h = F.dropout(h, self.dropout, training=self.training)
+            h_prime = ops.CsrSpmmFn.apply(att - bg[rows], rowptr, cols, h) + bg.unsqueeze(1) * h.sum(0, keepdim=True)
         return h_prime + self.bias if self.bias is not None else h_prime
+
+    @staticmethod
+    def attend_dropped(h, att, bg, rowptr, cols, rows, p, seed):
+        """dropout(attention) @ h with the dense attention = att on the listed pairs, bg_i everywhere else, and one pair mask over all N^2"""
+        q = 1.0 / (1.0 - p)
+        m = ops.pair_keep(rows.to(torch.int32), cols, p, seed)
+        listed = ops.CsrSpmmFn.apply(q * m * (att - bg[rows]), rowptr, cols, h)
+        return listed + (q * bg).unsqueeze(1) * ops.MaskedDenseSumFn.apply(h, p, seed)
 
 
 class GAT_DGG_00(nn.Module):

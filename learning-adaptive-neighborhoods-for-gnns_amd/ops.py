@@ -1371,6 +1371,38 @@ class CsrSpmmFn(torch.autograd.Function):
         return dA, None, None, dX
 
 
+def pair_keep(erow, col, p, seed):
+    """counter-based dropout mask of the dense attention matrix on the listed pairs -> float [E] of 1.0 (kept) / 0.0 (dgg_pair_keep)"""
+    erow, col = _chk(erow, torch.int32), _chk(col, torch.int32)
+    out = torch.empty(col.shape, device=col.device, dtype=torch.float32)
+    if col.numel():
+        _lib.check(_lib.lib().dgg_pair_keep(_ptr(erow), _ptr(col), col.numel(), float(p), seed[0], seed[1], _ptr(out), _stream()), "pair_keep")
+    return out
+
+
+class MaskedDenseSumFn(torch.autograd.Function):
+    """out_i = sum_j keep(i, j) X_j over ALL N columns with the counter-based pair mask (GATConv_DGG's F.dropout(attention) on the pairs
+    that are not listed: they all carry the row's background weight, model.py:564-570); backward: the transposed masked sum."""
+
+    @staticmethod
+    def forward(ctx, X, p, seed):
+        X = _chk(X)
+        N, F = X.shape
+        out = torch.empty_like(X)
+        _lib.check(_lib.lib().dgg_masked_dense_sum(_ptr(X), N, F, float(p), seed[0], seed[1], 0, _ptr(out), _stream()), "masked_dense_sum")
+        ctx.cfg = (float(p), seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _chk(g.contiguous())
+        N, F = g.shape
+        p, seed = ctx.cfg
+        dX = torch.empty_like(g)
+        _lib.check(_lib.lib().dgg_masked_dense_sum(_ptr(g), N, F, p, seed[0], seed[1], 1, _ptr(dX), _stream()), "masked_dense_sum")
+        return dX, None, None
+
+
 class CsrBgSoftmaxFn(torch.autograd.Function):
     """Row softmax of a dense logit matrix given by explicit logits L [E] on a CSR pattern plus N - cnt_i background
     logits of 0 per row (GATConv_DGG, model.py:565-569) -> att [E], bg [N]."""

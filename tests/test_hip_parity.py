@@ -923,7 +923,8 @@ def test_edge_list_layer_step_matches_cpu_restatement(dev, N, d, h, noise):
         assert err <= 3e-4, f"grad {k_} (no input gradient): {err:.3e}"
 
 
-@pytest.mark.parametrize("cand", ["edgelist", "allpairs", "edgelist:u-v-deg", "edgelist:u-v-deg-dist", "edgelist:u-v-A_uv", "edgelist:edge_conv"])
+@pytest.mark.parametrize("cand", ["edgelist", "allpairs", "edgelist:u-v-deg", "edgelist:u-v-deg-dist", "edgelist:u-v-A_uv", "edgelist:edge_conv",
+                                  "edgelist:u-v-deg:script-defaults"])
 def test_gcn_dgg_fused_first_layer_matches_the_separate_modules(dev, cand):
     """GCN_DGG runs generator + normalize_adj + conv1 as one autograd node (DGG_LearnableK_debug.forward_conv) and hands the normalised
     adjacency -- a differentiable output of that node -- to conv2 (reference model.py:1266-1290: both layers read the same graph).
@@ -936,10 +937,12 @@ def test_gcn_dgg_fused_first_layer_matches_the_separate_modules(dev, cand):
     from test_parallel_gloo import random_candidates
     N, d, h, C = 1200, 40, 32, 7
     cand, _, edge_mode = cand.partition(":")
+    edge_mode, _, flavour = edge_mode.partition(":")
     edge_mode = edge_mode or "u-v-dist"
+    perturb = flavour != "script-defaults"              # the reference script's own defaults: no perturbation (train_small_graphs.py:158-163)
     args = Namespace(extra_edge_dim={"u-v-deg": 2, "u-v-deg-dist": 3, "u-v-A_uv": 1}.get(edge_mode, 0), extra_k_dim=1, dgg_hard=False,
                      deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net=edge_mode,
-                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=perturb,
                      symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
     torch.manual_seed(3)
     m1 = dgg_amd.GCN_DGG(nfeat=d, nhidden=h, nclass=C, args=args).to(dev).eval()        # eval: no dropout between the layers
@@ -1601,6 +1604,89 @@ def test_gat_dgg_00_matches_reference_golden(dev):
         assert err <= 3e-4, f"grad {k_}: {err:.3e}"
         checked += 1
     assert checked >= 15
+
+
+def _np_pair_keep(s0, s1, N, p):
+    """numpy restatement of the pair mask of GATConv_DGG's attention dropout (dgg_csr.hip pair_keep): row i = drop_keep(s0,
+    s1 ^ 0x9E3779B9 (i + 1), j) -> bool [N,N]"""
+    from test_hip_conv_reorder import _np_drop_keep
+    return np.stack([_np_drop_keep(s0, (s1 ^ ((0x9E3779B9 * (i + 1)) & 0xFFFFFFFF)) & 0xFFFFFFFF, N, p) for i in range(N)])
+
+
+@pytest.mark.parametrize("F", [7, 8, 24, 64])
+def test_gat_attention_dropout_masks_every_pair(dev, F):
+    """GATConv_DGG in training mode (reference model.py:570: F.dropout on the dense [N,N] attention, non-listed pairs included): the
+    sparse evaluation with the counter-based pair mask against a dense float64 restatement with the SAME mask (numpy restatement of
+    the hash) -- forward, and the gradients of h, of the listed attention entries and of the background weight; the mask keeps 1 - p
+    of the pairs; p = 0 is the evaluation-mode formula."""
+    import dgg_amd
+    from dgg_amd import ops
+    rng = np.random.default_rng(F)
+    N, p, seed = 210, 0.4, (12345, 678)
+    M = _np_pair_keep(seed[0], seed[1], N, p)
+    assert abs(M.mean() - (1 - p)) < 0.01
+    dens = rng.random((N, N)) < 0.05
+    np.fill_diagonal(dens, True)
+    rows, cols = np.nonzero(dens)
+    rowptr, col = csr_from_coo(rows, cols, N)
+    E = rows.shape[0]
+    att0 = rng.random(E).astype(np.float32) * 0.1
+    bg0 = (rng.random(N) * 1e-3).astype(np.float32)
+    h0 = rng.standard_normal((N, F)).astype(np.float32)
+    cot = rng.standard_normal((N, F)).astype(np.float32)
+    m = ops.pair_keep(T(rows.astype(np.int32), dev), T(col, dev), p, seed)
+    assert np.array_equal(Nn(m) != 0, M[rows, cols])
+    h, att, bg = (T(a, dev).requires_grad_(True) for a in (h0, att0, bg0))
+    out = dgg_amd.GATConv_DGG.attend_dropped(h, att, bg, T(rowptr, dev), T(col, dev), T(rows.astype(np.int64), dev), p, seed)
+    (out * T(cot, dev)).sum().backward()
+    # dense restatement, float64
+    hd, ad, bd = (torch.from_numpy(a).double().requires_grad_(True) for a in (h0, att0, bg0))
+    A = bd[:, None].expand(N, N).clone()
+    A = A.index_put((torch.from_numpy(rows), torch.from_numpy(cols)), ad)
+    ref = (A * torch.from_numpy(M).double() / (1 - p)) @ hd
+    (ref * torch.from_numpy(cot).double()).sum().backward()
+    np.testing.assert_allclose(Nn(out), ref.detach().numpy(), rtol=1e-4, atol=1e-5 * np.abs(ref.detach().numpy()).max())
+    for name, g, r in (("h", h.grad, hd.grad), ("att", att.grad, ad.grad), ("bg", bg.grad, bd.grad)):
+        r = r.numpy()
+        assert np.abs(Nn(g) - r).max() <= 2e-4 * np.abs(r).max(), name
+    # p = 0: nothing is dropped -- the evaluation-mode formula
+    out0 = dgg_amd.GATConv_DGG.attend_dropped(h, att, bg, T(rowptr, dev), T(col, dev), T(rows.astype(np.int64), dev), 0.0, seed)
+    ev = ops.CsrSpmmFn.apply(att - bg[T(rows.astype(np.int64), dev)], T(rowptr, dev), T(col, dev), h) + bg.unsqueeze(1) * h.sum(0, keepdim=True)
+    np.testing.assert_allclose(Nn(out0), Nn(ev), rtol=1e-4, atol=1e-5 * float(ev.detach().abs().max()))
+
+
+def test_gat_layer_training_mode_is_unbiased(dev):
+    """the whole layer in training mode: the mean over many mask draws approaches the same layer with dropout applied to its input and
+    to h only (the attention dropout is unbiased: E[mask] / (1 - p) = 1)"""
+    import dgg_amd
+    torch.manual_seed(0)
+    N, Fi, Fo = 150, 12, 8
+    layer = dgg_amd.GATConv_DGG(Fi, Fo, dropout=0.5, alpha=0.2).to(dev).train()
+    rng = np.random.default_rng(1)
+    dens = rng.random((N, N)) < 0.06
+    np.fill_diagonal(dens, True)
+    rows, cols = np.nonzero(dens)
+    ei = torch.from_numpy(np.stack([rows, cols]).astype(np.int64)).to(dev)
+    A = torch.sparse_coo_tensor(ei, torch.ones(rows.shape[0], device=dev), (N, N)).coalesce()
+    adj = dgg_amd.CsrAdjacency(*dgg_amd.csr_pattern(A), A.values(), N)
+    x = torch.randn(N, Fi, device=dev)
+    pat = layer.union_pattern(ei, adj)
+    import torch.nn.functional as Fnn
+    orig = Fnn.dropout
+    Fnn.dropout = lambda t_, p_=0.5, training=True, inplace=False: t_          # input / h dropout off: isolate the attention mask
+    try:
+        acc = torch.zeros(N, Fo, device=dev)
+        R = 300
+        with torch.no_grad():
+            for _ in range(R):
+                acc += layer(x, ei, adj, pattern=pat)
+            mean = acc / R
+            layer.eval()
+            ref = layer(x, ei, adj, pattern=pat)
+    finally:
+        Fnn.dropout = orig
+    err = float((mean - ref).abs().max() / ref.abs().max())
+    assert err < 0.25, err                                        # (N = 150 background terms of variance ~1 each, 300 draws)
 
 
 @pytest.mark.parametrize("N,width", [(5, 64), (70, 64), (200, 32), (131, 16)])
