@@ -190,7 +190,7 @@ def run_edgelist(a, dev):
 
     from dgg_amd import ops as _ops
 
-    fused = getattr(a, "edgelist_api", "fused") == "fused" and a.edge_mode in ("u-v-dist", "u-v-deg", "u-v-A_uv", "u-v-deg-dist", "edge_conv")
+    fused = getattr(a, "edgelist_api", "fused") == "fused" and a.edge_mode in ("u-v-dist", "u-v-deg", "u-v-A_uv", "u-v-deg-dist", "edge_conv", "A_uv")
 
     def step():
         for p_ in params:
@@ -572,7 +572,7 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="--workload ppi: GCNII layer GEMMs on bf16 operands (library GEMM, fp32 "
                                                         "accumulate); the DGG path stays fp32")
     ap.add_argument("--edgelist-api", default="fused", choices=["fused", "modules"],
-                    help="--workload pubmed: the fused layer (DGG_LearnableK_debug.forward_conv; every scorer but A_uv) or the separate modules")
+                    help="--workload pubmed: the fused layer (DGG_LearnableK_debug.forward_conv) or the separate modules")
     ap.add_argument("--edge-mode", default="u-v-dist", choices=["u-v-dist", "u-v-deg", "u-v-A_uv", "u-v-deg-dist", "edge_conv", "A_uv"],
                     help="--workload pubmed: edge scorer (dgm.py:1607-1725)")
     ap.add_argument("--gpus", type=int, default=1)

@@ -499,7 +499,7 @@ class DGG_LearnableK_debug(nn.Module):
         (_FusedDGGConvFn) -> (Z, unnormalised EllAdjacency, DETACHED: its values carry no autograd edge -- the loss of the
         reference's training scripts reads the class scores only, train_small_graphs.py:226-230), or None when this configuration
         is outside the fused step (the caller then runs the modules one after the other): scorer u-v-dist (any candidates) or an
-        edge-MLP scorer (u-v-deg, u-v-A_uv, u-v-deg-dist, edge_conv; edge-list candidates), k-net "x", soft
+        edge-MLP scorer (u-v-deg, u-v-A_uv, u-v-deg-dist, edge_conv, A_uv; edge-list candidates), k-net "x", soft
         k_times_edge_prob / k_only output, widths the partitioned backward covers, rows that fit the ELL width.
         want_norm: additionally return the NORMALISED adjacency as a differentiable EllAdjacency for the layers that read the same
         graph after this one (GCN_DGG's second layer): its gradient flows back into the generator through the same node."""
@@ -507,7 +507,7 @@ class DGG_LearnableK_debug(nn.Module):
         a = self.args
         h = self.latent_dim
         fin, fout = conv_weight.shape
-        mlp_mode = self.edge_prob_net_mode in ("u-v-deg", "u-v-A_uv", "u-v-deg-dist", "edge_conv")
+        mlp_mode = self.edge_prob_net_mode in ("u-v-deg", "u-v-A_uv", "u-v-deg-dist", "edge_conv", "A_uv")
         if ((self.edge_prob_net_mode != "u-v-dist" and not mlp_mode) or (mlp_mode and isinstance(in_adj, AllPairs))
                 or self.k_net_mode != "x" or self.k_select_mode not in ("k_times_edge_prob", "k_only")
                 or self.hard or a.debug_step in (0, 1) or (getattr(a, "stochastic_k", False) and self.training)
@@ -528,7 +528,7 @@ class DGG_LearnableK_debug(nn.Module):
         sc_static = None
         if mlp_mode:                                          # per-edge inputs of the scorer, in the CSR order of the candidates
             avals = _cached("values_f32", in_adj, lambda: in_adj.coalesce().values().to(torch.float32).contiguous())
-            if self.edge_prob_net_mode == "edge_conv":
+            if self.edge_prob_net_mode in ("edge_conv", "A_uv"):
                 mlp, ex_in = self._edge_mlp_terms(avals)
                 packed = None
             else:                                             # edge_encode.0.weight goes into the node whole (sliced inside it)

@@ -924,7 +924,7 @@ def test_edge_list_layer_step_matches_cpu_restatement(dev, N, d, h, noise):
 
 
 @pytest.mark.parametrize("cand", ["edgelist", "allpairs", "edgelist:u-v-deg", "edgelist:u-v-deg-dist", "edgelist:u-v-A_uv", "edgelist:edge_conv",
-                                  "edgelist:u-v-deg:script-defaults"])
+                                  "edgelist:u-v-deg:script-defaults", "edgelist:A_uv"])
 def test_gcn_dgg_fused_first_layer_matches_the_separate_modules(dev, cand):
     """GCN_DGG runs generator + normalize_adj + conv1 as one autograd node (DGG_LearnableK_debug.forward_conv) and hands the normalised
     adjacency -- a differentiable output of that node -- to conv2 (reference model.py:1266-1290: both layers read the same graph).
