@@ -36,12 +36,31 @@ __global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(
     const float *A = AB + u * 2 * hw, *B = AB + v * 2 * hw + hw;
     const float du = deg ? deg[u] : 0.0f, dv = deg ? deg[v] : 0.0f;
     float s = 0.0f;
-    for (int o = 0; o < hw; o++) {
-        float z = __fadd_rn(A[o], B[o]);
+    auto term = [&](float a, float b, int o) {                     // (one hidden unit; the sum over o stays in the oracle's order)
+        float z = __fadd_rn(a, b);
         if (deg) { z = __fmaf_rn(du, wdu[o], z); z = __fmaf_rn(dv, wdv[o], z); }
         if (ex_mode != 0) z = __fmaf_rn(ex, wex[o], z);
         z = __fadd_rn(z, b1[o]);
         s = __fmaf_rn(act_apply(z, act), w2[o], s);
+    };
+    if ((hw & 15) == 0 && (reinterpret_cast<uintptr_t>(AB) & 15) == 0) {
+        // 16-byte loads, sixteen hidden units (8 loads) in flight: a thread's two rows are its own cache lines, and one 4-byte load per
+        // unit and operand left the 1.6 wavefronts per SIMD of a citation graph waiting on 128 dependent round trips (41 -> 12 us)
+        for (int o = 0; o < hw; o += 16) {
+            float4 a4[4], b4[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                a4[c] = *reinterpret_cast<const float4 *>(A + o + 4 * c);
+                b4[c] = *reinterpret_cast<const float4 *>(B + o + 4 * c);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                term(a4[c].x, b4[c].x, o + 4 * c); term(a4[c].y, b4[c].y, o + 4 * c + 1);
+                term(a4[c].z, b4[c].z, o + 4 * c + 2); term(a4[c].w, b4[c].w, o + 4 * c + 3);
+            }
+        }
+    } else {
+        for (int o = 0; o < hw; o++) term(A[o], B[o], o);
     }
     s = __fadd_rn(s, b2[0]);
     p_edge[e] = __fdiv_rn(1.0f, __fadd_rn(1.0f, c_exp(-s)));
