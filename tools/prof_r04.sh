@@ -15,6 +15,7 @@ for nz in none rsym hash; do
 done
 rocprofv3 --kernel-trace --stats -d /tmp/trace_ppi -o h -- python3 "$R/bench.py" --steps 4 --warmup 2 --workload ppi --bf16 --cpu-rows -1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/trace_pub -o h -- python3 "$R/bench.py" --steps 20 --warmup 5 --workload pubmed --cpu-rows -1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/trace_pubdeg -o h -- python3 "$R/bench.py" --steps 20 --warmup 5 --workload pubmed --edge-mode u-v-deg --cpu-rows -1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/trace_emu -o h -- python3 "$R/bench.py" --steps 20 --warmup 5 --repeats 2 --emulate-world 8 --nodes 62500 --cpu-rows -1 --no-variants > /dev/null 2>&1
 cd "$R"
 python3 tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write "$O/r04_traffic.json" 100000 128 64 > /dev/null
@@ -26,6 +27,7 @@ python3 tools/kernel_stats.py /tmp/trace_rsym/h_results.db "$O/r04_symmetric_ker
 python3 tools/kernel_stats.py /tmp/trace_hash/h_results.db "$O/r04_hash_kernel_stats.csv" --skip-first 3 > /dev/null
 python3 tools/kernel_stats.py /tmp/trace_ppi/h_results.db "$O/r04_ppi_bf16_kernel_stats.csv" --skip-first 0 > /dev/null
 python3 tools/kernel_stats.py /tmp/trace_pub/h_results.db "$O/r04_pubmed_kernel_stats.csv" --skip-first 0 > /dev/null
+python3 tools/kernel_stats.py /tmp/trace_pubdeg/h_results.db "$O/r04_pubmed_uvdeg_kernel_stats.csv" --skip-first 0 > /dev/null
 python3 tools/kernel_stats.py /tmp/trace_emu/h_results.db "$O/r04_emulated_rank_of_8_kernel_stats.csv" --skip-first 8 > /dev/null
 cp "$O/r04_traffic.json" profiles/r04_traffic.json     # bench.py reads the newest traffic file from here
 python3 bench.py --steps 20 --warmup 5 > "$O/r04_bench.json" 2> "$O/bench.err"
