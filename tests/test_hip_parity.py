@@ -2350,6 +2350,47 @@ def test_ell_width_bound_is_enforced(dev):
         m.check_ell_bound()                                       # (the discarded forward's flag does not survive)
 
 
+def test_fused_layer_with_edge_mlp_scorer_and_wide_rows(dev):
+    """the edge-MLP scorer through the fused layer on rows wider than the list: the bound is tracked on the device (no kernel flag on
+    this path), raised by check_ell_bound under dgg_wide_rows = "ell", and under the default "auto" such a graph leaves the fused
+    layer for the CSR form of the separate modules (GCN_DGG still runs, forward and backward)"""
+    import dgg_amd
+    from argparse import Namespace
+    N, d, h = 256, 40, 32                                          # (the fused layer aggregates the projected features: out <= in)
+    args = Namespace(extra_edge_dim=2, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-deg",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
+    torch.manual_seed(0)
+    net = dgg_amd.GCN_DGG(nfeat=d, nhidden=h, nclass=3, args=args).to(dev).train()
+    m = net.dggs[0]
+    x = torch.rand(N, d, device=dev)
+    Wc = net.conv1.W
+    rows = np.repeat(np.arange(N), 8)
+    cols = (rows + np.tile(np.arange(8), N)) % N
+    o = np.lexsort((cols, rows))
+    A8 = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows[o], cols[o]])), torch.full((8 * N,), 12.0), (N, N)).coalesce().to(dev)
+    assert m.forward_conv(x, A8, Wc) is not None                  # k ~ 97 on 8 candidates per row: exact whatever k is
+    m.check_ell_bound()
+    rows = np.repeat(np.arange(N), 100)
+    cols = (rows + np.tile(np.arange(100), N)) % N
+    o = np.lexsort((cols, rows))
+    Aw = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows[o], cols[o]])), torch.full((100 * N,), 0.9), (N, N)).coalesce().to(dev)
+    m.args.dgg_wide_rows = "ell"
+    assert m.forward_conv(x, Aw, Wc) is not None                  # 100 candidates per row, prior degree 90 -> k ~ 91 > 64 - 8.5
+    with pytest.raises(RuntimeError, match="ell_width"):
+        m.check_ell_bound()
+    m.args.dgg_wide_rows = "auto"
+    assert m.forward_conv(x, Aw, Wc) is None, "rows that would lose weight leave the fused layer"
+    m.check_ell_bound()
+    keep = rows != cols                                           # (the wrapper adds the self loops itself)
+    An = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows[o][keep[o]], cols[o][keep[o]]])), torch.full((int(keep.sum()),), 0.9), (N, N)).coalesce().to(dev)
+    logp, adj, _ = net(x, An)
+    assert isinstance(adj, dgg_amd.CsrAdjacency)
+    logp[:, 0].sum().backward()
+    assert all(torch.isfinite(p_.grad).all() for p_ in net.parameters() if p_.grad is not None)
+    assert m.edge_encode[0].weight.grad is not None and float(m.edge_encode[0].weight.grad.abs().max()) > 0
+
+
 @pytest.mark.parametrize("prior", ["bounded", "cora"])
 def test_learned_degrees_of_a_trained_model_and_the_all_pairs_list(dev, prior):
     """The all-pairs generator keeps 64 ranks per row, exact while k_i + 8.5 <= 64; k = relu(kp sd + mu) + 1
