@@ -167,8 +167,10 @@ def run_edgelist(a, dev):
     all host cores beside it.  Not the headline metric (that is the default workload): run with --workload pubmed."""
     import dgg_amd
     from argparse import Namespace
-    N, d, h = 19_717, 500, a.latent
-    rows, cols = pubmed_graph(N, 44_324)
+    shape = getattr(a, "graph", "pubmed")
+    N, d, nund, ncls = {"pubmed": (19_717, 500, 44_324, 3), "cora": (2_708, 1_433, 5_278, 7)}[shape]   # nodes, features, undirected edges, classes
+    h = a.latent
+    rows, cols = pubmed_graph(N, nund)
     E = rows.shape[0]
     extra = {"u-v-dist": 0, "u-v-deg": 2, "u-v-A_uv": 1, "u-v-deg-dist": 3, "edge_conv": 0, "A_uv": 0}[a.edge_mode]
     args = Namespace(extra_edge_dim=extra, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288,
@@ -249,14 +251,14 @@ def run_edgelist(a, dev):
     if fused:
         try:
             torch.manual_seed(0)
-            net = dgg_amd.GCN_DGG(nfeat=d, nhidden=h, nclass=3, args=args).to(dev).train()
+            net = dgg_amd.GCN_DGG(nfeat=d, nhidden=h, nclass=ncls, args=args).to(dev).train()
             with torch.no_grad():
                 net.dggs[0].k_net.k_project.weight.mul_(0.1)
             net.dggs[0].set_seed(1234, 0)
             keep = rows != cols                                    # (the wrapper adds the self loops itself)
             A2 = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows[keep], cols[keep]])), torch.full((int(keep.sum()),), 16.0 * N / E),
                                          (N, N)).coalesce().to(dev)
-            ytr = torch.randint(0, 3, (60,), generator=g).to(dev)
+            ytr = torch.randint(0, ncls, (60,), generator=g).to(dev)
             itr = torch.randperm(N, generator=g)[:60].to(dev)
             nparams = list(net.parameters())
 
@@ -269,10 +271,10 @@ def run_edgelist(a, dev):
             model_ms = timed(model_step)[0] * 1e3
         except Exception as e:  # noqa: BLE001
             print(f"GCN_DGG model timing failed: {e!r}", file=sys.stderr)
-    out = {"metric": "DGG adj-build+SpMM fwd/bwd edges/sec (edge-list candidates, Pubmed shape)", "value": nsel / T, "unit": "edges/s", "n_gpus": 1,
+    out = {"metric": f"DGG adj-build+SpMM fwd/bwd edges/sec (edge-list candidates, {shape.capitalize()} shape)", "value": nsel / T, "unit": "edges/s", "n_gpus": 1,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": T * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"Pubmed-shape edge-list DGG N={N} d={d} h={h} E={E} (incl. self loops) k~{kmean:.1f}, "
+           "config": {"workload": f"{shape.capitalize()}-shape edge-list DGG N={N} d={d} h={h} E={E} (incl. self loops) k~{kmean:.1f}, "
                                   f"{a.edge_mode}/x/k_times_edge_prob, Gumbel(0,0.3) hash noise, module API under autograd "
                                   + ("(DGG_LearnableK_debug.forward_conv: generator + normalize + GCNConv as one autograd node)" if fused
                                      else "(DGG_LearnableK_debug + normalize + GCNConv)") + ", fwd+bwd",
@@ -571,6 +573,9 @@ def main():
     ap.add_argument("--graphs", type=int, default=4, help="--workload ppi: number of graphs per step")
     ap.add_argument("--bf16", action="store_true", help="--workload ppi: GCNII layer GEMMs on bf16 operands (library GEMM, fp32 "
                                                         "accumulate); the DGG path stays fp32")
+    ap.add_argument("--graph", default="pubmed", choices=["pubmed", "cora"],
+                    help="--workload pubmed: the synthetic edge list's shape -- Pubmed (19 717 nodes, 500 features; BASELINE configs[1]) or Cora "
+                         "(2 708 nodes, 1 433 features; configs[0]'s graph)")
     ap.add_argument("--edgelist-api", default="fused", choices=["fused", "modules"],
                     help="--workload pubmed: the fused layer (DGG_LearnableK_debug.forward_conv) or the separate modules")
     ap.add_argument("--edge-mode", default="u-v-dist", choices=["u-v-dist", "u-v-deg", "u-v-A_uv", "u-v-deg-dist", "edge_conv", "A_uv"],
