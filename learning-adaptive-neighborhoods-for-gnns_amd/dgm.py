@@ -276,6 +276,51 @@ class _DGGScoresFn(torch.autograd.Function):
                 g(wex, 2 * hw, 3 * hw), dpar[3 * hw:4 * hw], dpar[4 * hw:5 * hw], dpar[5 * hw:5 * hw + 1], None)
 
 
+_PAD_CACHE = {}
+
+
+def _pad_features(x, params, keys):
+    """Feature counts that are not a multiple of 4 (Cora 1 433, Citeseer 3 703) keep the 16-byte loads and the one-pass weight-gradient
+    kernel away from x: the fused layer then works on a zero-padded copy of x (the features are data: cached per tensor object and
+    version) and zero-padded input weights -- the extra columns contribute exact zeros at the END of every k-ordered chain, so every
+    result keeps its bits -- and slices the gradients back.  -> (x_eff, params_eff, d) with d = 0 when nothing was padded."""
+    d = x.shape[1]
+    pad = (-d) % 4
+    if pad == 0 or not PAD_ODD_FEATURES:
+        return x, params, 0
+    key = id(x)
+    ent = _PAD_CACHE.get(key)
+    if ent is None or ent[0]() is not x or ent[1] != x._version or x.requires_grad:
+        xpad = torch.nn.functional.pad(x.detach(), (0, pad))
+        if not x.requires_grad and not torch.cuda.is_current_stream_capturing():
+            for k_ in [k_ for k_, v in _PAD_CACHE.items() if v[0]() is None]:
+                del _PAD_CACHE[k_]
+            _PAD_CACHE[key] = (weakref.ref(x), x._version, xpad)
+    else:
+        xpad = ent[2]
+    out = []
+    for k_, p_ in zip(keys, params):
+        if k_ in ("We", "Wk"):
+            p_ = torch.nn.functional.pad(p_.detach(), (0, pad))             # [h, d] -> [h, d + pad]
+        elif k_ == "Wc":
+            p_ = torch.nn.functional.pad(p_.detach(), (0, 0, 0, pad))       # [d, out] -> [d + pad, out]
+        out.append(p_)
+    return xpad, tuple(out), d
+
+
+def _unpad_grads(g, keys, d):
+    if d:
+        for k_ in ("We", "Wk"):
+            g[k_] = g[k_].reshape(-1, g[k_].shape[-1])[:, :d]
+        g["Wc"] = g["Wc"][:d]
+        if g.get("x") is not None:
+            g["x"] = g["x"][:, :d]
+    return g
+
+
+PAD_ODD_FEATURES = __import__("os").environ.get("DGG_PAD_ODD_FEATURES", "1") != "0"
+
+
 class _FusedDGGConvFn(torch.autograd.Function):
     """generator -> normalize_adj -> relu(A (x Wc)) as ONE autograd node on the hand-scheduled step of dgg_amd.parallel.ShardedDGGConv
     (reference dgm.py:1178-1292, model.py:1205-1219, 580-599): x is read ONCE for the three projections [xp | xk | x Wc] and once for
@@ -285,6 +330,7 @@ class _FusedDGGConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, deg, layer, *params):
+        x, params, ctx.d_orig = _pad_features(x, params, layer.PARAM_KEYS)
         P = dict(zip(layer.PARAM_KEYS, params))
         Z = layer.forward(x, deg, P)
         ctx.layer, ctx.state = layer, layer.saved
@@ -304,7 +350,10 @@ class _FusedDGGConvFn(torch.autograd.Function):
         if dZ is None:
             dZ = torch.zeros_like(ctx.state["Z"])
         g = layer.backward(dZ.contiguous(), x, P, dA_ext=dahat)
-        return (g.get("x"), None, None) + tuple(g[k_].reshape(P[k_].shape) for k_ in layer.PARAM_KEYS)
+        for k_ in layer.PARAM_KEYS:
+            g[k_] = g[k_].reshape(P[k_].shape)
+        g = _unpad_grads(g, layer.PARAM_KEYS, ctx.d_orig)
+        return (g.get("x"), None, None) + tuple(g[k_] for k_ in layer.PARAM_KEYS)
 
 
 class _FusedDGGMlpConvFn(torch.autograd.Function):
@@ -315,6 +364,7 @@ class _FusedDGGMlpConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, deg, layer, sc_static, Wcat, wdu, wdv, wex, b1, w2, b2, *params):
+        x, params, ctx.d_orig = _pad_features(x, params, layer.PARAM_KEYS)
         P = dict(zip(layer.PARAM_KEYS, params))
         det = lambda t_: None if t_ is None else t_.detach()  # noqa: E731
         ctx.packed = packed = sc_static.get("packed")
@@ -352,7 +402,10 @@ class _FusedDGGMlpConvFn(torch.autograd.Function):
             sc_grads = (dW0, None, None, None, gs["b1"], gs["w2"].reshape(1, -1), gs["b2"])
         else:
             sc_grads = tuple(gs[k_] for k_ in _FusedDGGMlpConvFn.SC_KEYS)
-        return (g.get("x"), None, None, None) + sc_grads + tuple(g[k_].reshape(P[k_].shape) for k_ in layer.PARAM_KEYS)
+        for k_ in layer.PARAM_KEYS:
+            g[k_] = g[k_].reshape(P[k_].shape)
+        g = _unpad_grads(g, layer.PARAM_KEYS, ctx.d_orig)
+        return (g.get("x"), None, None, None) + sc_grads + tuple(g[k_] for k_ in layer.PARAM_KEYS)
 
 
 class DGG_LearnableK_debug(nn.Module):

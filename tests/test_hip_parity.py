@@ -924,7 +924,7 @@ def test_edge_list_layer_step_matches_cpu_restatement(dev, N, d, h, noise):
 
 
 @pytest.mark.parametrize("cand", ["edgelist", "allpairs", "edgelist:u-v-deg", "edgelist:u-v-deg-dist", "edgelist:u-v-A_uv", "edgelist:edge_conv",
-                                  "edgelist:u-v-deg:script-defaults", "edgelist:A_uv"])
+                                  "edgelist:u-v-deg:script-defaults", "edgelist:A_uv", "edgelist:u-v-dist:odd-width", "edgelist:u-v-deg:odd-width"])
 def test_gcn_dgg_fused_first_layer_matches_the_separate_modules(dev, cand):
     """GCN_DGG runs generator + normalize_adj + conv1 as one autograd node (DGG_LearnableK_debug.forward_conv) and hands the normalised
     adjacency -- a differentiable output of that node -- to conv2 (reference model.py:1266-1290: both layers read the same graph).
@@ -940,6 +940,8 @@ def test_gcn_dgg_fused_first_layer_matches_the_separate_modules(dev, cand):
     edge_mode, _, flavour = edge_mode.partition(":")
     edge_mode = edge_mode or "u-v-dist"
     perturb = flavour != "script-defaults"              # the reference script's own defaults: no perturbation (train_small_graphs.py:158-163)
+    if flavour == "odd-width":                          # (Cora has 1 433 features: the fused layer works on a zero-padded copy of x)
+        d = 41
     args = Namespace(extra_edge_dim={"u-v-deg": 2, "u-v-deg-dist": 3, "u-v-A_uv": 1}.get(edge_mode, 0), extra_k_dim=1, dgg_hard=False,
                      deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net=edge_mode,
                      dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=perturb,
