@@ -34,6 +34,8 @@ python3 bench.py --steps 20 --warmup 5 > "$O/r04_bench.json" 2> "$O/bench.err"
 python3 bench.py --steps 20 --warmup 5 --workload pubmed > "$O/r04_pubmed_uvdist_bench.json" 2>> "$O/bench.err"
 python3 bench.py --steps 20 --warmup 5 --workload pubmed --edgelist-api modules --cpu-rows -1 > "$O/r04_pubmed_uvdist_separate_modules_bench.json" 2>> "$O/bench.err"
 python3 bench.py --steps 20 --warmup 5 --workload pubmed --edge-mode u-v-deg --cpu-rows -1 > "$O/r04_pubmed_uvdeg_bench.json" 2>> "$O/bench.err"
+python3 bench.py --steps 20 --warmup 5 --workload pubmed --graph cora --cpu-rows -1 > "$O/r04_cora_uvdist_bench.json" 2>> "$O/bench.err"
+python3 bench.py --steps 20 --warmup 5 --workload pubmed --graph cora --edge-mode u-v-deg --cpu-rows -1 > "$O/r04_cora_uvdeg_bench.json" 2>> "$O/bench.err"
 python3 bench.py --steps 20 --warmup 5 --workload pubmed --edge-mode u-v-deg --edgelist-api modules --cpu-rows -1 > "$O/r04_pubmed_uvdeg_separate_modules_bench.json" 2>> "$O/bench.err"
 python3 bench.py --steps 10 --warmup 3 --workload ppi --bf16 > "$O/r04_ppi_bf16_bench.json" 2>> "$O/bench.err"
 python3 bench.py --steps 20 --warmup 5 --nodes 500000 --no-variants --cpu-rows -1 > "$O/r04_bench_n500k_1gpu.json" 2>> "$O/bench.err"
