@@ -832,6 +832,13 @@ def other_configs(a, dev):
             res["pubmed_uvdeg"] = pick(run_edgelist(b, dev))
     except Exception as e:  # noqa: BLE001
         res["pubmed_uvdeg"] = {"error": repr(e)}
+    try:
+        if "pubmed" in only:                                 # configs[0]'s graph (Cora: 2 708 nodes, 1 433 features) through the same layer
+            b = copy.copy(a)
+            b.steps, b.warmup, b.edge_mode, b.cpu_dense, b.cpu_rows, b.graph = 20, 3, "u-v-dist", False, -1, "cora"
+            res["cora_uvdist"] = pick(run_edgelist(b, dev))
+    except Exception as e:  # noqa: BLE001
+        res["cora_uvdist"] = {"error": repr(e)}
     torch.cuda.empty_cache()
     try:
         if "ppi" in only:
