@@ -175,6 +175,24 @@ int dgg_allpairs_topk_ranked_softk(const float *xp, int64_t N, int h, int64_t ro
  * noise on every replay once the caller advances seed_dev between replays (the reference samples fresh noise per forward, dgm.py:1226) */
 int dgg_allpairs_topk_ranked_softk_dseed(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, const uint32_t *seed_dev,
                                          const float *k, int mode, int32_t *idx, float *val, float *w, float *rs, void *stream);
+/* ---- rows wider than 64 ranks: CHUNKED rows ------------------------------------------------------------------------------------
+ * The learned degree k = relu(k_net * std + mean) + 1 is unbounded (dgm.py:1580-1584) and select_top_k ramps over the whole dense row
+ * (dgm.py:1402-1421): a row carries weight on its first ceil(k_i + 8.5) ranks whatever k_i.  Node i then owns the M_i = ceil(L_i / 64)
+ * consecutive 64-entry CHUNKS [cptr[i], cptr[i+1]) of idx / val / w / ahat ([chunks, 64] arrays), L_i = ceil(k_i + 8.5) + 1; rank r of the
+ * row is entry r % 64 of its chunk r / 64.  With every M_i = 1 the layout IS the [rows, 64] list of the calls above, and every chunk is
+ * a row of that layout to the entry points that take `cnode` (node of every chunk) below.
+ * dgg_chunk_layout: k [rows] -> cptr int32 [rows+1], cnode int32 [ccap], meta int32 [4] = {chunks in total, max M_i, flags, 0};
+ * flags bit 0: a row needs more than 64 * maxm ranks (maxm <= 32; the row is cut there: callers must raise), bit 1: more than ccap
+ * chunks (arrays too small: call again with a larger capacity). */
+int dgg_chunk_layout(const float *k, int64_t rows, int maxm, int64_t ccap, int32_t *cptr, int32_t *cnode, int32_t *meta, void *stream);
+/* dgg_allpairs_topk_ranked_softk[_dseed] on chunked rows: the ranked search settles L_i ranks of row i in up to `maxm` descending 64-lane
+ * lists per wavefront (maxm >= max M_i); idx / val / w [chunks,64], rs [row1-row0] (lane-wise sums over the chunks, then the wavefront
+ * butterfly).  ccap >= cptr[rows]: the chunks the arrays hold (a capacity fixed ahead of the learned degrees, e.g. inside a captured
+ * hipGraph); chunks beyond the last one are written empty (idx -1, weight 0) and dgg_chunk_layout gives them node 0, so every consumer
+ * may walk all ccap chunks.  seed_dev != NULL: the seed is read from device memory, s0 / s1 are ignored.  w (and rs) may be NULL. */
+int dgg_allpairs_topk_ranked_wide(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
+                                  const uint32_t *seed_dev, const float *k, int mode, int maxm, const int32_t *cptr, int64_t ccap, int32_t *idx,
+                                  float *val, float *w, float *rs, void *stream);
 /* bytes of device workspace the pruned path needs for (N, h): a bf16 copy of xp plus discounted squared norms;
  * 0 when the pruned path does not apply (explicit noise, K != 64, latent_dim not in {16,32,64,128}) */
 size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K);

@@ -8,6 +8,8 @@
 #define DGG_ERR_UNSUPPORTED 2  // shape/mode outside what the kernels implement (reference: Exception("mode not found"), dgm.py:1727)
 #define DGG_ERR_HIP 3          // a HIP runtime call or kernel launch failed
 
+#define DGG_CHUNK_MAXM 32       // chunked rows: at most 32 chunks of 64 ranks per row (2048 ranks: learned degrees up to 2038)
+
 int dgg_set_error(int code, const char *msg);
 int dgg_check_launch(const char *what);
 int dgg_check_hip(hipError_t e, const char *what);

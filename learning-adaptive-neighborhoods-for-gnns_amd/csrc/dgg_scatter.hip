@@ -559,7 +559,8 @@ constexpr int64_t NODE_SPLIT_MAX = 65536;
 template <int F, bool EXT>
 __device__ __forceinline__ void conv_bwd_walk(const float *__restrict__ G, int K, int pb, int pe, int p1, const int4 *__restrict__ recs,
                                               const float4 hj, const float aj, float *__restrict__ dA, float *__restrict__ dA_rec,
-                                              const float *__restrict__ dA_ext, int lane, float4 &acc, float &sda) {
+                                              const float *__restrict__ dA_ext, int lane, float4 &acc, float &sda, const int wide = 0) {
+    // (wide: chunked rows -- a record's first word is chunk * 64 + entry and its second word the SOURCE NODE of the chunk, see pp_sort)
     constexpr int LPR = F / 4, NPI = 64 / LPR, NBT = 4, PER = NBT * NPI;          // PER records per iteration (<= 64)
     const int c4 = lane % LPR, slot = lane / LPR;
     for (int e0 = pb; e0 < pe; e0 += PER) {
@@ -580,7 +581,7 @@ __device__ __forceinline__ void conv_bwd_walk(const float *__restrict__ G, int K
             const float wa = __int_as_float(__shfl(myrec.z, q, 64));
             cf[b] = dst >= 0 ? __fmul_rn(wa, aj) : 0.0f;
             if (dst < 0) src[b] = -1;
-            g[b] = *reinterpret_cast<const float4 *>(G + (int64_t)(src[b] < 0 ? 0 : (src[b] >> 6)) * F + 4 * c4);   // unconditional
+            g[b] = *reinterpret_cast<const float4 *>(G + (int64_t)(src[b] < 0 ? 0 : (wide ? dst : (src[b] >> 6))) * F + 4 * c4);   // unconditional
         }
         float ext[NBT];
         if constexpr (EXT) {
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(256) void conv_bwd_node(const float *__restrict__ G
                                                      const int *__restrict__ nodeptr, const int4 *__restrict__ recs,
                                                      const float *__restrict__ rs, float *__restrict__ dA, float *__restrict__ dA_rec,
                                                      float *__restrict__ dH, float *__restrict__ da, const float *__restrict__ dA_ext = nullptr,
-                                                     unsigned nmain = 0) {
+                                                     unsigned nmain = 0, int wide = 0) {
     constexpr int LPR = F / 4, PER = 4 * (64 / LPR);
     __shared__ float4 part[4][LPR];
     __shared__ float parts[4];
@@ -641,11 +642,11 @@ __global__ __launch_bounds__(256) void conv_bwd_node(const float *__restrict__ G
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float sda = 0.0f;
     if (!longmode) {
-        conv_bwd_walk<F, EXT>(G, K, p0, p1, p1, recs, hj, aj, dA, dA_rec, dA_ext, lane, acc, sda);
+        conv_bwd_walk<F, EXT>(G, K, p0, p1, p1, recs, hj, aj, dA, dA_rec, dA_ext, lane, acc, sda, wide);
     } else {
         const int chunk = ((p1 - p0 + 4 * PER - 1) / (4 * PER)) * PER;
         const int pb = p0 + wave * chunk, pe = pb + chunk < p1 ? pb + chunk : p1;
-        conv_bwd_walk<F, EXT>(G, K, pb < p1 ? pb : p1, pe, p1, recs, hj, aj, dA, dA_rec, dA_ext, lane, acc, sda);
+        conv_bwd_walk<F, EXT>(G, K, pb < p1 ? pb : p1, pe, p1, recs, hj, aj, dA, dA_rec, dA_ext, lane, acc, sda, wide);
         if (slot == 0) part[wave][c4] = acc;
         if (lane == 0) parts[wave] = sda;
         __syncthreads();
@@ -674,7 +675,9 @@ __global__ __launch_bounds__(256) void conv_bwd_node(const float *__restrict__ G
 template <int H>
 __device__ __forceinline__ void edge_bwd_walk(const float *__restrict__ xp, int64_t j, int pb, int pe, int p1, const int4 *__restrict__ recs,
                                               const float *__restrict__ dA_rec, const float4 *__restrict__ rowinfo, const float4 xj, const float aj,
-                                              int64_t row0, float t, int perturb, int lane, float4 &acc) {
+                                              int64_t row0, float t, int perturb, int lane, float4 &acc, const int wide = 0) {
+    // (wide: chunked rows -- rowinfo is per CHUNK with the degree shifted by the chunk's first rank, k_i - 64 m, so that the entry's
+    //  index inside its chunk still gives rank - k; the record's second word is the source node of the chunk, see pp_sort)
     constexpr int LPR = H / 4, NPI = 64 / LPR, NBT = (32 / NPI) < 1 ? 1 : 32 / NPI, PER = NBT * NPI;   // 32 records per iteration
     const int c4 = lane % LPR, slot = lane / LPR;
     for (int e0 = pb; e0 < pe; e0 += PER) {
@@ -696,7 +699,7 @@ __device__ __forceinline__ void edge_bwd_walk(const float *__restrict__ xp, int6
             const int src = __shfl(myrec.x, q, 64);             // every shuffle outside a select (see conv_bwd_node)
             const int dst = __shfl(myrec.y, q, 64);
             // unconditional gather; an inactive slot re-reads xp_j, whose distance to itself is 0 (dd = 0)
-            xi[b] = *reinterpret_cast<const float4 *>(xp + (dst >= 0 ? row0 + (src >> 6) : j) * H + 4 * c4);
+            xi[b] = *reinterpret_cast<const float4 *>(xp + (dst >= 0 ? row0 + (wide ? dst : (src >> 6)) : j) * H + 4 * c4);
         }
         // squared distances, each handed to the lane that loaded the record; the scalar chain (sqrt, exp, two divisions) then runs
         // ONCE per record instead of on all H/4 lanes of every batch (the kernel was VALU-bound: 515 VALU per 16 records)
@@ -740,7 +743,7 @@ __global__ __launch_bounds__(256) void edge_bwd_node(const float *__restrict__ x
                                                      const int4 *__restrict__ recs, const float *__restrict__ dA_rec,
                                                      const float4 *__restrict__ rowinfo, const float *__restrict__ rs, int normalized,
                                                      int64_t row0, int64_t rows, float t, int perturb, float *__restrict__ dxp, int out_act,
-                                                     unsigned nmain = 0) {
+                                                     unsigned nmain = 0, int wide = 0) {
     constexpr int LPR = H / 4, NPI = 64 / LPR, NBT = (32 / NPI) < 1 ? 1 : 32 / NPI, PER = NBT * NPI;
     __shared__ float4 part[4][LPR];
     const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR, wave = dgg::wave_id();
@@ -754,11 +757,11 @@ __global__ __launch_bounds__(256) void edge_bwd_node(const float *__restrict__ x
     const float aj = normalized ? __fdiv_rn(1.0f, c_sqrt(rs[j])) : 1.0f;
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (!longmode) {
-        edge_bwd_walk<H>(xp, j, p0, p1, p1, recs, dA_rec, rowinfo, xj, aj, row0, t, perturb, lane, acc);
+        edge_bwd_walk<H>(xp, j, p0, p1, p1, recs, dA_rec, rowinfo, xj, aj, row0, t, perturb, lane, acc, wide);
     } else {
         const int chunk = ((p1 - p0 + 4 * PER - 1) / (4 * PER)) * PER;
         const int pb = p0 + wave * chunk, pe = pb + chunk < p1 ? pb + chunk : p1;
-        edge_bwd_walk<H>(xp, j, pb < p1 ? pb : p1, pe, p1, recs, dA_rec, rowinfo, xj, aj, row0, t, perturb, lane, acc);
+        edge_bwd_walk<H>(xp, j, pb < p1 ? pb : p1, pe, p1, recs, dA_rec, rowinfo, xj, aj, row0, t, perturb, lane, acc, wide);
         if (slot == 0) part[wave][c4] = acc;
         __syncthreads();
         if (wave != 0) return;
@@ -1188,7 +1191,9 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void pp_fill(const int32_t *__restrict__ idx, const float *__restrict__ w, const float *__restrict__ val,
                                                    const float *__restrict__ rs_rows, int64_t rows, int K, int nb, uint32_t rcp,
                                                    const int *__restrict__ T, const int *__restrict__ totals, int *__restrict__ bstart,
-                                                   int4 *__restrict__ recs4, const float *__restrict__ ainv, float *__restrict__ ahat_out) {
+                                                   int4 *__restrict__ recs4, const float *__restrict__ ainv, float *__restrict__ ahat_out,
+                                                   const int32_t *__restrict__ cnode = nullptr) {
+    // (cnode != NULL: chunked rows -- every "row" of idx / w / val is a 64-entry chunk of node cnode[row]; rs_rows is indexed by node)
     extern __shared__ int lds[];                                 // hist[nb], base[nb], scratch[16]
     int *hist = lds, *base = lds + nb, *scratch = lds + 2 * nb;
     const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id();
@@ -1219,7 +1224,8 @@ __global__ __launch_bounds__(THREADS) void pp_fill(const int32_t *__restrict__ i
             const int64_t e = (row_ok ? i : rows - 1) * 64 + 4 * (lane & 15);
             const float4 wv = *reinterpret_cast<const float4 *>(w + e);
             const float4 vv = *reinterpret_cast<const float4 *>(val + e);
-            const float ai = __fdiv_rn(1.0f, c_sqrt(rs_rows[row_ok ? i : rows - 1]));
+            const int64_t ic = row_ok ? i : rows - 1;
+            const float ai = __fdiv_rn(1.0f, c_sqrt(rs_rows[cnode ? (int64_t)cnode[ic] : ic]));
             // a_j of the four entries gathered BEFORE the entry loop: inside it there is then no load to wait for (a wait there
             // would also wait for the record store of the previous entry: one memory round trip per entry)
             float4 aj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1254,7 +1260,7 @@ __global__ __launch_bounds__(THREADS) void pp_fill(const int32_t *__restrict__ i
                 if (j >= 0 && wx != 0.0f) {
                     const int b = pp_bucket(j, rcp);
                     const int slot = base[b] + atomicAdd(&hist[b], 1);
-                    const float wa = __fmul_rn(__fdiv_rn(1.0f, c_sqrt(rs_rows[i])), wx);
+                    const float wa = __fmul_rn(__fdiv_rn(1.0f, c_sqrt(rs_rows[cnode ? (int64_t)cnode[i] : i])), wx);
                     recs4[slot] = make_int4((int)(i * 64 + lane), j, (int)__float_as_uint(wa), (int)__float_as_uint(val[i * K + lane]));
                     if (ahat_out) a = __fmul_rn(wa, ainv[j]);
                 }
@@ -1265,8 +1271,12 @@ __global__ __launch_bounds__(THREADS) void pp_fill(const int32_t *__restrict__ i
 }
 
 // one workgroup per bucket: records -> node order; nodeptr for the bucket's nodes
+// WIDE (chunked rows): the destination j of a sorted record is implied by its position (nodeptr), so its second word is rewritten to
+// the SOURCE NODE cnode[chunk] -- what the per-destination kernels need to find G_i / xp_i of a chunk (no lookup there)
+template <bool WIDE>
 __global__ __launch_bounds__(PP_T) void pp_sort(const int *__restrict__ bstart, const int4 *__restrict__ tmp, int4 *__restrict__ recs,
-                                                int *__restrict__ nodeptr, int *__restrict__ recpos, int nb, int PBS) {
+                                                int *__restrict__ nodeptr, int *__restrict__ recpos, int nb, int PBS,
+                                                const int32_t *__restrict__ cnode = nullptr) {
     extern __shared__ int lds[];                                 // cnt[PBS], base[PBS], scratch[16]
     int *cnt = lds, *base = lds + PBS, *scratch = lds + 2 * PBS;
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -1311,6 +1321,7 @@ __global__ __launch_bounds__(PP_T) void pp_sort(const int *__restrict__ bstart, 
         for (int u = 0; u < PP_RPT; u++)
             if (rec[u].y >= 0) {
                 const int pos = o0 + base[rec[u].y - b * PBS] + rank[u];
+                if (WIDE) rec[u].y = cnode[rec[u].x >> 6];
                 recs[pos] = rec[u];
                 if (recpos) recpos[rec[u].x] = pos;
             }
@@ -1330,6 +1341,7 @@ __global__ __launch_bounds__(PP_T) void pp_sort(const int *__restrict__ bstart, 
                 if (r[u].y >= 0) {
                     const int jl = r[u].y - b * PBS;
                     const int pos = o0 + base[jl] + atomicAdd(&cnt[jl], 1);
+                    if (WIDE) r[u].y = cnode[r[u].x >> 6];
                     recs[pos] = r[u];
                     if (recpos) recpos[r[u].x] = pos;
                 }
@@ -1527,7 +1539,7 @@ int dgg_partp_build_phase(const int32_t *idx, const float *w, const float *val, 
     partp2_layout(p, ws, rows, K, ncols);
     const int nb = (int)p.nb, nwg = (int)p.nwg, pbs = p.width;
     if (phase == 2) {
-        hipLaunchKernelGGL(pp_sort, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr, pp_builds_map(rows) ? p.recpos : nullptr, nb, pbs);
+        hipLaunchKernelGGL(pp_sort<false>, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr, pp_builds_map(rows) ? p.recpos : nullptr, nb, pbs, (const int32_t *)nullptr);
         return dgg_check_launch("partp_build");
     }
 #define DGG_PP_PASS(TT)                                                                                                      \
@@ -1543,7 +1555,7 @@ int dgg_partp_build_phase(const int32_t *idx, const float *w, const float *val, 
     }
 #undef DGG_PP_PASS
     if (phase == 1) return dgg_check_launch("partp_build");
-    hipLaunchKernelGGL(pp_sort, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr, pp_builds_map(rows) ? p.recpos : nullptr, nb, pbs);
+    hipLaunchKernelGGL(pp_sort<false>, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr, pp_builds_map(rows) ? p.recpos : nullptr, nb, pbs, (const int32_t *)nullptr);
     return dgg_check_launch("partp_build");
 }
 

@@ -184,6 +184,246 @@ int launch_ranked(const float *xp, int64_t N, int64_t row0, int64_t row1, float 
     return dgg_check_launch("allpairs_topk_ranked");
 }
 
+// ---- rows WIDER than 64 ranks ("chunked rows") -----------------------------------------------------------------------------
+// The learned degree is unbounded (k = relu(kp sd + mu) + 1, reference dgm.py:1580-1584) and the reference ramps over the whole dense
+// row (dgm.py:1402-1421): a row needs its first L_i = ceil(k_i + 8.5) + 1 ranks, whatever k_i.  Chunked layout: node i owns the
+// M_i = ceil(L_i / 64) consecutive 64-entry CHUNKS [cptr[i], cptr[i+1]) of idx / val / w; rank r of the row is lane r % 64 of its chunk
+// r / 64.  With every M_i = 1 this IS the [rows,64] list of the kernels above, and every chunk is a row of that layout to the
+// kernels downstream (partition, aggregation, backward), which only need the node of a chunk (cnode).
+//
+// chunk_layout: k -> cptr (exclusive scan of M_i), cnode, meta = {total chunks, max M_i, flags}; flags bit 0: some row's ramp
+// support exceeds 64 * maxm ranks (it is cut there -- callers raise, never truncate silently), bit 1: more chunks than `ccap`
+// (cnode holds the first ccap; the caller's arrays are too small: re-run with a larger capacity).  One workgroup: rows / 1024
+// consecutive nodes per thread.
+__global__ __launch_bounds__(1024) void chunk_layout(const float *__restrict__ k, int64_t rows, int maxm, int64_t ccap,
+                                                     int32_t *__restrict__ cptr, int32_t *__restrict__ cnode, int32_t *__restrict__ meta) {
+    __shared__ int wsum[16], wmax[16], wflag[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t per = (rows + 1023) / 1024;
+    const int64_t lo = (int64_t)tid * per, hi = lo + per < rows ? lo + per : rows;
+    const int kcap = 64 * maxm;
+    int s = 0, mx = 0, flag = 0;
+    for (int64_t i = lo; i < hi; i++) {
+        const float kk = k[i];
+        const int L = klimit_len(kk, kcap);
+        if (!(ceilf(kk + 8.5f) + 1.0f <= (float)kcap)) flag = 1;        // (also NaN)
+        const int m = (L + 63) >> 6;
+        s += m;
+        mx = m > mx ? m : mx;
+    }
+    int incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int v = __shfl_xor(mx, off, 64);
+        mx = v > mx ? v : mx;
+        flag |= __shfl_xor(flag, off, 64);
+    }
+    if (lane == 63) wsum[wave] = incl;
+    if (lane == 0) { wmax[wave] = mx; wflag[wave] = flag; }
+    __syncthreads();
+    int base = 0, total = 0, tmax = 0, tflag = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int v = wsum[q];
+        if (q < wave) base += v;
+        total += v;
+        tmax = wmax[q] > tmax ? wmax[q] : tmax;
+        tflag |= wflag[q];
+    }
+    int run = base + incl - s;
+    for (int64_t i = lo; i < hi; i++) {
+        const int m = (klimit_len(k[i], kcap) + 63) >> 6;
+        cptr[i] = run;
+        for (int c = 0; c < m; c++)
+            if (run + c < ccap) cnode[run + c] = (int32_t)i;
+        run += m;
+    }
+    for (int64_t c = (int64_t)total + tid; c < ccap; c += 1024) cnode[c] = 0;      // chunks beyond the last one: defined (node 0), empty
+    if (tid == 0) {
+        cptr[rows] = total;
+        meta[0] = total;
+        meta[1] = tmax;
+        meta[2] = tflag | (total > ccap ? 2 : 0);
+        meta[3] = 0;
+    }
+}
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int uniform_lane) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), uniform_lane) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, uniform_lane);
+}
+
+// The search of allpairs_topk_ranked with M_i <= MAXM descending 64-lane lists per row in registers (list[0] holds ranks 0..63, list[1]
+// ranks 64..127, ...).  A block's live keys are sorted and cascaded down the lists: merged with list[m] by one bitonic half-cleaner
+// (upper 64 stay, lower 64 carry on to list[m+1]); a list whose smallest key beats the carry's largest is skipped, and the cascade ends
+// when the carry is empty.  Stop test, per-candidate cut and partial-distance bound as above, against the row's L_i-th log-score.
+// Output: chunk c = cptr[i] + m takes list[m] (idx -1 / val 0 beyond L_i), w = ramp(64 m + lane - k_i) x score, rs_i = the wavefront's
+// butterfly over the per-lane sums of its chunks (the oracle's butterfly_sum for K > 64).
+template <int H, int MAXM>
+__global__ __launch_bounds__(256) void allpairs_topk_ranked_wide(const float *__restrict__ xp, int64_t N, int64_t row0, int64_t row1, float t,
+                                                                 uint32_t s0, uint32_t s1, const float *__restrict__ klim,
+                                                                 const int32_t *__restrict__ cptr, int32_t *__restrict__ idx,
+                                                                 float *__restrict__ val, int softk_mode, float *__restrict__ w_out,
+                                                                 float *__restrict__ rs_out, const uint32_t *__restrict__ seed_dev,
+                                                                 unsigned nrow_blocks, int64_t ccap) {
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x >= nrow_blocks) {
+        // arrays allocated for `ccap` chunks (a capacity fixed ahead of the learned degrees, e.g. inside a captured hipGraph): the
+        // chunks beyond the last one are written EMPTY, so that every consumer may walk all ccap chunks
+        const int64_t q = (int64_t)cptr[row1 - row0] + (int64_t)(blockIdx.x - nrow_blocks) * 4 + dgg::wave_id();
+        if (q < ccap) {
+            idx[q * 64 + lane] = -1;
+            val[q * 64 + lane] = 0.0f;
+            if (w_out) w_out[q * 64 + lane] = 0.0f;
+        }
+        return;
+    }
+    if (seed_dev) { s0 = seed_dev[0]; s1 = seed_dev[1]; }
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
+    const int64_t i = row0 + lrow;
+    if (i >= row1) return;
+    const int c0 = __builtin_amdgcn_readfirstlane(cptr[lrow]);
+    int Mi = __builtin_amdgcn_readfirstlane(cptr[lrow + 1]) - c0;
+    Mi = Mi > MAXM ? MAXM : Mi;
+    const float ki = klim[lrow];
+    const int L = __builtin_amdgcn_readfirstlane(klimit_len(ki, 64 * Mi));
+    const int mL = (L - 1) >> 6, laneL = (L - 1) & 63;
+    uint32_t k1, k2;
+    rowkey(s0, s1, (uint32_t)i, k1, k2);
+    const uint32_t k3 = mix32(k2 ^ 0x68E31DA4u);
+    const int b = ranked_bits(N);
+    const uint64_t D = (uint64_t)1 << b;
+    const float *xi = xp + i * H;
+    uint64_t list[MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; m++) list[m] = DGG_EMPTY_KEY;
+    uint64_t S = 0;
+    uint32_t scount = 0;
+    float thr_log = -INFINITY;
+    for (uint64_t rb = 0; rb < D; rb += 64) {
+        const uint32_t c = ranked_sigma((uint32_t)(rb + lane), k1, k2, k3, b);
+        const bool valid = (int64_t)c < N;
+        const uint64_t mv = __ballot(valid);
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mv, 0u));
+        const uint32_t s = scount + pos + 1;
+        uint64_t term = valid ? ranked_term(k1, k3, s, N) : 0ull;
+        uint64_t pre = wave_inclusive_scan_u64(term, lane) + S;
+        float G = ranked_gumbel(pre);
+        uint64_t key = DGG_EMPTY_KEY;
+        const bool want = valid && !(G + 1e-8f + 1e-3f < thr_log);
+        if (want) {
+            const float4 *xj = reinterpret_cast<const float4 *>(xp + (int64_t)c * H);
+            float d2 = 0.0f;
+            auto chain = [&](int c8) {
+                float4 b0 = xj[2 * c8], b1 = xj[2 * c8 + 1];
+                float df;
+                df = __fadd_rn(xi[8 * c8 + 0], -b0.x); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(xi[8 * c8 + 1], -b0.y); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(xi[8 * c8 + 2], -b0.z); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(xi[8 * c8 + 3], -b0.w); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(xi[8 * c8 + 4], -b1.x); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(xi[8 * c8 + 5], -b1.y); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(xi[8 * c8 + 6], -b1.z); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(xi[8 * c8 + 7], -b1.w); d2 = __fmaf_rn(df, df, d2);
+            };
+            constexpr int HEAD = H >= 64 ? 4 : H / 8;
+#pragma unroll
+            for (int c8 = 0; c8 < HEAD; c8++) chain(c8);
+            bool alive = true;
+            if (HEAD < H / 8) alive = !(G + __logf(__expf(t * sqrtf(d2)) + 1e-8f) + 1e-3f < thr_log);
+            if (alive) {
+#pragma unroll
+                for (int c8 = HEAD; c8 < H / 8; c8++) chain(c8);
+                key = make_key(score_from_dist(c_sqrt(d2), t, true, G), (int32_t)c);
+            }
+        }
+        if (__ballot(key != DGG_EMPTY_KEY) != 0ull) {
+            uint64_t carry = wave_sort<true>(key, lane);
+            if (rb == 0) {
+                list[0] = carry;
+            } else {
+#pragma unroll
+                for (int m = 0; m < MAXM; m++) {
+                    if (m < Mi) {                                    // (wave-uniform)
+                        const uint64_t cmax = readlane_u64(carry, 0);
+                        if (cmax == DGG_EMPTY_KEY) break;            // nothing left to place
+                        if (cmax > readlane_u64(list[m], 63)) {      // (else: list[m] keeps all of its entries, the carry goes on whole)
+                            const uint64_t rc = shfl_u64(carry, 63 - lane);          // ascending
+                            const uint64_t hi = list[m] > rc ? list[m] : rc, lo = list[m] > rc ? rc : list[m];
+                            list[m] = bitonic_block<64, 32, true>(hi, lane);
+                            carry = bitonic_block<64, 32, true>(lo, lane);
+                        }
+                    }
+                }
+            }
+        }
+        const int nvalid = __builtin_popcountll(mv);
+        S = shfl_u64(pre, 63);
+        scount += (uint32_t)nvalid;
+        if (scount >= (uint32_t)N) break;
+        uint64_t kL = DGG_EMPTY_KEY;
+#pragma unroll
+        for (int m = 0; m < MAXM; m++)
+            if (m == mL) kL = readlane_u64(list[m], laneL);
+        if (kL != DGG_EMPTY_KEY) thr_log = __logf(key_val(kL));
+        if (kL != DGG_EMPTY_KEY && nvalid > 0) {
+            const int last = 63 - __builtin_clzll(mv);
+            const float gmin = __shfl(G, last, 64);
+            if (gmin + 1e-8f + 1e-3f < thr_log) break;
+        }
+    }
+    float rsum = 0.0f;
+#pragma unroll
+    for (int m = 0; m < MAXM; m++) {
+        if (m < Mi) {
+            const int r = 64 * m + lane;
+            const bool empty = list[m] == DGG_EMPTY_KEY || r >= L;
+            const int64_t e = ((int64_t)c0 + m) * 64 + lane;
+            idx[e] = empty ? -1 : key_col(list[m]);
+            const float sv = empty ? 0.0f : key_val(list[m]);
+            val[e] = sv;
+            if (w_out) {
+                const float f = c_ramp((float)r, ki);
+                float v = f;
+                if (softk_mode == 0 || softk_mode == 3) {
+                    const float a = __fmul_rn(sv, f);
+                    v = softk_mode == 0 ? a : __fadd_rn(__fadd_rn(f, -a), a);
+                }
+                const float wv = empty ? 0.0f : v;
+                w_out[e] = wv;
+                rsum = m == 0 ? wv : __fadd_rn(rsum, wv);
+            }
+        }
+    }
+    if (w_out) {
+        const float s_ = wave_sum_butterfly(rsum);
+        if (lane == 0) rs_out[lrow] = s_;
+    }
+}
+
+template <int H>
+int launch_ranked_wide(int maxm, const float *xp, int64_t N, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1, const float *klim,
+                       const int32_t *cptr, int32_t *idx, float *val, hipStream_t st, int softk_mode, float *w, float *rs, const uint32_t *seed_dev,
+                       int64_t ccap) {
+    const unsigned nrow_blocks = (unsigned)((row1 - row0 + 3) / 4);
+    const int64_t tail = ccap > row1 - row0 ? ccap - (row1 - row0) : 0;         // (every row has at least one chunk)
+    dim3 grid(nrow_blocks + (unsigned)((tail + 3) / 4));
+#define DGG_RW(MM) hipLaunchKernelGGL((allpairs_topk_ranked_wide<H, MM>), grid, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, klim, cptr, idx, val, \
+                                      softk_mode, w, rs, seed_dev, nrow_blocks, ccap)
+    if (maxm <= 2) DGG_RW(2);
+    else if (maxm <= 4) DGG_RW(4);
+    else if (maxm <= 8) DGG_RW(8);
+    else if (maxm <= 16) DGG_RW(16);
+    else DGG_RW(32);
+#undef DGG_RW
+    return dgg_check_launch("allpairs_topk_ranked_wide");
+}
+
 // same cut for the evaluators that always settle all K ranks
 __global__ void klimit_truncate(const float *__restrict__ klim, int64_t rows, int K, int32_t *__restrict__ idx,
                                 float *__restrict__ val) {
@@ -262,5 +502,38 @@ int dgg_allpairs_topk_ranked_softk_dseed(const float *xp, int64_t N, int h, int6
     if (mode != 0 && mode != 1 && mode != 3) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_softk: mode must be 0, 1 or 3");
     if (!k || !w || !rs || !seed_dev) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_softk_dseed: k, w, rs and seed_dev are required");
     return dgg_allpairs_topk_ranked_impl(xp, N, h, row0, row1, t, 0u, 0u, 64, k, idx, val, (hipStream_t)stream, mode, w, rs, seed_dev);
+}
+
+// ---- chunked rows (rows wider than 64 ranks) ----
+// Layout of the chunked rows from the learned degrees: cptr [rows+1] (first chunk of every node), cnode [ccap] (node of every chunk),
+// meta int32[4] = {total chunks, max chunks of a row, flags (1: a row needs more than 64*maxm ranks, 2: more than ccap chunks), 0}.
+int dgg_chunk_layout(const float *k, int64_t rows, int maxm, int64_t ccap, int32_t *cptr, int32_t *cnode, int32_t *meta, void *stream) {
+    if (rows < 0 || maxm < 1 || maxm > DGG_CHUNK_MAXM || ccap < 0 || !k || !cptr || !cnode || !meta)
+        return dgg_set_error(DGG_ERR_ARG, "chunk_layout: bad sizes or NULL arrays (maxm in 1..32)");
+    if (rows >= ((int64_t)1 << 25)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "chunk_layout: rows < 2^25");
+    hipLaunchKernelGGL(chunk_layout, dim3(1), dim3(1024), 0, (hipStream_t)stream, k, rows, maxm, ccap, cptr, cnode, meta);
+    return dgg_check_launch("chunk_layout");
+}
+// dgg_allpairs_topk_ranked_softk[_dseed] for chunked rows: idx / val / w are [chunks, 64] (chunk c of node i = ranks 64 (c - cptr[i]) ...),
+// rs [rows]; maxm = the largest chunk count of a row (meta[1] of dgg_chunk_layout, or the capacity it was called with); ccap = chunks the
+// arrays were allocated for (>= cptr[rows]; the chunks beyond the last one are written empty).  seed_dev != NULL: the seed is read from
+// device memory (s0, s1 ignored).
+int dgg_allpairs_topk_ranked_wide(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
+                                  const uint32_t *seed_dev, const float *k, int mode, int maxm, const int32_t *cptr, int64_t ccap, int32_t *idx,
+                                  float *val, float *w, float *rs, void *stream) {
+    if (row0 < 0 || row1 > N || row0 > row1) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_wide: bad row range");
+    if (mode != 0 && mode != 1 && mode != 3) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_wide: mode must be 0, 1 or 3");
+    if (!k || !cptr || !idx || !val || (w && !rs)) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_wide: k, cptr, idx, val (and rs with w) are required");
+    if (maxm < 1 || maxm > DGG_CHUNK_MAXM) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_wide: maxm in 1..32");
+    if (N >= ((int64_t)1 << 31)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path needs N < 2^31");
+    if (row1 == row0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    switch (h) {
+        case 16: return launch_ranked_wide<16>(maxm, xp, N, row0, row1, t, s0, s1, k, cptr, idx, val, st, mode, w, rs, seed_dev, ccap);
+        case 32: return launch_ranked_wide<32>(maxm, xp, N, row0, row1, t, s0, s1, k, cptr, idx, val, st, mode, w, rs, seed_dev, ccap);
+        case 64: return launch_ranked_wide<64>(maxm, xp, N, row0, row1, t, s0, s1, k, cptr, idx, val, st, mode, w, rs, seed_dev, ccap);
+        case 128: return launch_ranked_wide<128>(maxm, xp, N, row0, row1, t, s0, s1, k, cptr, idx, val, st, mode, w, rs, seed_dev, ccap);
+        default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "chunked ranked-noise path supports latent_dim in {16,32,64,128}");
+    }
 }
 }

@@ -399,6 +399,80 @@ def allpairs_topk_softk(xp, k, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, seed=(0, 0
     return idx, val, w, rs
 
 
+# ---- rows wider than 64 ranks: chunked rows ------------------------------------------------------------------------------------------
+CHUNK_MAXM = 32          # at most 32 chunks of 64 ranks per row (learned degrees up to 2038)
+
+
+class ChunkLayout:
+    """Chunked rows (include/dgg_hip.h, dgg_chunk_layout): node i owns the chunks [cptr[i], cptr[i+1]) of the [chunks,64] arrays, rank r
+    of its row is entry r % 64 of chunk r / 64.  cptr int32 [rows+1], cnode int32 [chunks] (node of every chunk), meta int32 [4] on the
+    device = {chunks in use, widest row in chunks, flags, 0}; `chunks` = rows of the arrays (>= chunks in use), `maxm` = list count the
+    search is launched with (>= widest row)."""
+
+    def __init__(self, cptr, cnode, meta, chunks, maxm, rows):
+        self.cptr, self.cnode, self.meta, self.chunks, self.maxm, self.rows = cptr, cnode, meta, int(chunks), int(maxm), int(rows)
+
+    @property
+    def wide(self):
+        return self.chunks != self.rows
+
+    def ranks(self):
+        """rank of every entry inside its row, int64 [chunks,64] (tests / densification)"""
+        first = self.cptr[:-1].long()[self.cnode.long()]
+        c = torch.arange(self.chunks, device=self.cptr.device)
+        return ((c - first) * 64)[:, None] + torch.arange(64, device=self.cptr.device)[None, :]
+
+
+def chunk_layout(k, maxm=CHUNK_MAXM, ccap=None):
+    """Layout of the chunked rows for the learned degrees k [rows].  ccap=None: ONE host synchronisation (the chunk count sizes the
+    arrays) -> ChunkLayout with exactly the chunks in use, and `maxm` = the widest row; raises when a row needs more than 64 * maxm
+    ranks.  ccap given (a fixed capacity, e.g. under hipGraph capture): no synchronisation; meta[2] carries the overflow flags."""
+    k = _chk(k)
+    rows = k.shape[0]
+    dev = k.device
+    meta = torch.empty((4,), device=dev, dtype=torch.int32)
+    cptr = torch.empty((rows + 1,), device=dev, dtype=torch.int32)
+    if ccap is not None:
+        cnode = torch.empty((int(ccap),), device=dev, dtype=torch.int32)
+        _lib.check(_lib.lib().dgg_chunk_layout(_ptr(k), rows, int(maxm), int(ccap), _ptr(cptr), _ptr(cnode), _ptr(meta), _stream()), "chunk_layout")
+        return ChunkLayout(cptr, cnode, meta, ccap, maxm, rows)
+    cap = rows + rows // 4 + 64
+    while True:
+        cnode = torch.empty((cap,), device=dev, dtype=torch.int32)
+        _lib.check(_lib.lib().dgg_chunk_layout(_ptr(k), rows, int(maxm), cap, _ptr(cptr), _ptr(cnode), _ptr(meta), _stream()), "chunk_layout")
+        total, widest, flags, _ = (int(v) for v in meta.cpu())
+        if flags & 1:
+            raise RuntimeError(f"chunk_layout: a learned degree needs more than {64 * maxm} ranks (k + 9.5 > {64 * maxm}): beyond the "
+                               "chunked rows' capacity (or not finite)")
+        if not (flags & 2):
+            return ChunkLayout(cptr, cnode[:total], meta, total, max(widest, 1), rows)
+        cap = total
+
+
+def allpairs_topk_wide(xp, k, layout, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, seed=(0, 0), rows=None, ramp=True):
+    """allpairs_topk_softk on chunked rows (rows wider than 64 ranks): -> idx, val, w [chunks,64], rs [rows] (w / rs None with
+    ramp=False).  `layout` = chunk_layout(k of these rows)."""
+    xp, k = _chk(xp), _chk(k)
+    N, h = xp.shape
+    r0, r1 = (0, N) if rows is None else rows
+    assert layout.rows == r1 - r0
+    C_ = layout.chunks
+    idx = torch.empty((C_, 64), device=xp.device, dtype=torch.int32)
+    val = torch.empty((C_, 64), device=xp.device, dtype=torch.float32)
+    w = torch.empty((C_, 64), device=xp.device, dtype=torch.float32) if ramp else None
+    rs = torch.empty((r1 - r0,), device=xp.device, dtype=torch.float32) if ramp else None
+    dseed = None
+    if isinstance(seed, torch.Tensor):
+        assert seed.is_cuda and seed.numel() == 2 and seed.element_size() == 4
+        dseed, seed = seed, (0, 0)
+    pe = _probe_begin()
+    _lib.check(_lib.lib().dgg_allpairs_topk_ranked_wide(_ptr(xp), N, h, r0, r1, t, seed[0], seed[1], _ptr(dseed), _ptr(k), mode, layout.maxm,
+                                                        _ptr(layout.cptr), C_, _ptr(idx), _ptr(val), _ptr(w), _ptr(rs), _stream()),
+               "allpairs_topk_ranked_wide")
+    _probe_end("allpairs_topk", pe)
+    return idx, val, w, rs
+
+
 def edgelist_topk(xp, rowptr, col, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed=(0, 0)):
     xp = _chk(xp)
     N, h = xp.shape

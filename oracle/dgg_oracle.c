@@ -444,7 +444,7 @@ ORA_API void ora_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, 
     }
 #pragma omp parallel for schedule(dynamic, 8)
     for (int64_t i = row0; i < row1; i++) {
-        cand_t list[512];
+        cand_t *list = (cand_t *)malloc(sizeof(cand_t) * (size_t)(K > 0 ? K : 1));   /* (rows wider than the 64-wide list: any K) */
         int cnt = 0;
         float *grow = NULL;
         if (noise_mode == 4) { grow = (float *)malloc(sizeof(float) * (size_t)N); ora_ranked_row(s0, s1, (uint32_t)i, N, grow); }
@@ -462,6 +462,7 @@ ORA_API void ora_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, 
             idx[(i - row0) * K + r] = r < cnt ? list[r].j : -1;
             val[(i - row0) * K + r] = r < cnt ? list[r].v : 0.0f;
         }
+        free(list);
     }
     free(gsym);
 }
@@ -473,7 +474,7 @@ ORA_API void ora_edgelist_topk(const float *xp, int64_t N, int h, const int64_t 
                                int K, int32_t *idx, float *val) {
 #pragma omp parallel for schedule(dynamic, 64)
     for (int64_t i = 0; i < N; i++) {
-        cand_t list[512];
+        cand_t *list = (cand_t *)malloc(sizeof(cand_t) * (size_t)(K > 0 ? K : 1));   /* (rows wider than the 64-wide list: any K) */
         int cnt = 0;
         for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
             int32_t j = col[e];
@@ -487,6 +488,7 @@ ORA_API void ora_edgelist_topk(const float *xp, int64_t N, int h, const int64_t 
             idx[i * K + r] = r < cnt ? list[r].j : -1;
             val[i * K + r] = r < cnt ? list[r].v : 0.0f;
         }
+        free(list);
     }
 }
 
@@ -494,10 +496,11 @@ ORA_API void ora_edgelist_topk(const float *xp, int64_t N, int h, const int64_t 
 ORA_API void ora_select_scores(const float *scores, int64_t R, int64_t N, int K, int32_t *idx, float *val) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < R; i++) {
-        cand_t list[512];
+        cand_t *list = (cand_t *)malloc(sizeof(cand_t) * (size_t)(K > 0 ? K : 1));   /* (rows wider than the 64-wide list: any K) */
         int cnt = 0;
         for (int64_t j = 0; j < N; j++) topk_insert(list, &cnt, K, scores[i * N + j], (int32_t)j);
         for (int r = 0; r < K; r++) { idx[i * K + r] = r < cnt ? list[r].j : -1; val[i * K + r] = r < cnt ? list[r].v : 0.0f; }
+        free(list);
     }
 }
 
@@ -515,7 +518,8 @@ static inline float ramp(float r, float k) {
 static float butterfly_sum(const float *w, int K) {
     float s[64], t[64];
     for (int l = 0; l < 64; l++) s[l] = 0.0f;
-    /* K <= 64: slot l holds w[l]; K == 128: slot l holds w[l] + w[l+64] */
+    /* slot l holds w[l] + w[l+64] + w[l+128] + ... (a row wider than 64 ranks: lane l of the wavefront adds its entry of every
+     * 64-rank chunk in chunk order, then the butterfly) */
     for (int l = 0; l < K; l++) s[l & 63] = (l < 64) ? w[l] : s[l & 63] + w[l];
     for (int off = 32; off >= 1; off >>= 1) {
         for (int l = 0; l < 64; l++) t[l] = s[l] + s[l ^ off];
@@ -697,7 +701,7 @@ ORA_API void ora_edgelist_topk_p(const float *p_edge, int64_t N, const int64_t *
                                  const float *G, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, int32_t *eid) {
 #pragma omp parallel for schedule(dynamic, 64)
     for (int64_t i = 0; i < N; i++) {
-        cand_t list[512];
+        cand_t *list = (cand_t *)malloc(sizeof(cand_t) * (size_t)(K > 0 ? K : 1));   /* (rows wider than the 64-wide list: any K) */
         int cnt = 0;
         for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) {
             int32_t j = col[e];
@@ -712,6 +716,7 @@ ORA_API void ora_edgelist_topk_p(const float *p_edge, int64_t N, const int64_t *
             val[i * K + r] = r < cnt ? list[r].v : 0.0f;
             eid[i * K + r] = r < cnt ? (int32_t)(rowptr[i] + list[r].j) : -1;
         }
+        free(list);
     }
 }
 /* backward of the scorer for the selected entries: dval (wrt the stored score) -> dAB [N, 2*hw], parameter gradients
