@@ -423,6 +423,27 @@ int dgg_softk_edge_bwd_partp_phase(const float *xp, int64_t rows, int h, const i
                                    const float *dA, const float *dA_rec, const float *da, const float *ahat_rows, int K, int64_t row0, float t,
                                    int perturb, int mode, int normalized, const void *partp_ws, int64_t ncols, float *rowinfo_ws, float *dk,
                                    float *dxp, int out_act, int phase, void *stream);
+/* ---- the same steps on CHUNKED rows (rows wider than 64 ranks: dgg_chunk_layout / dgg_allpairs_topk_ranked_wide) -----------------------
+ * idx / w / val / ahat / dA / dA_ext are [chunks,64]; `cnode` int32 [chunks] = node of every chunk, `cptr` int32 [rows+1] = first chunk of
+ * every node; per-node arrays (rs, k, dk, G, Y) are [rows] / [rows,F].  The reference has no width limit (select_top_k ramps over the dense
+ * row, dgm.py:1402-1421; normalize_adj and torch.mm(adj, x) act on dense [N,N] tensors, model.py:1205-1219, 594).
+ * dgg_partp_build_chunked = dgg_partp_build_phase; the SORTED records carry (chunk*64 + entry, SOURCE NODE of the chunk, w rs_i^-1/2,
+ * score): the destination of a record is implied by the CSC pointer, and the per-destination kernels read G_i / xp_i at the source node. */
+int dgg_partp_build_chunked(const int32_t *idx, const float *w, const float *val, const float *rs_nodes, int64_t chunks, const int32_t *cnode,
+                            int64_t ncols, const float *rs_all, float *ahat, void *ws, int phase, void *stream);
+/* Y [rows,F] = act(A X) with row i = the chunks [cptr[i], cptr[i+1]), walked in rank order (dgg_ell_spmm_act_fwd) */
+int dgg_ell_spmm_act_fwd_chunked(const int32_t *idx, const float *ahat, const float *X, int64_t rows, const int32_t *cptr, int F, int act, float *Y,
+                                 void *stream);
+/* dgg_ell_conv_bwd_partp_ext on a partition built by dgg_partp_build_chunked; dA is required (no slot -> record map) */
+int dgg_ell_conv_bwd_partp_chunked(const float *G, const float *H, int64_t chunks, int F, const void *partp_ws, int64_t ncols, const float *rs,
+                                   const float *dA_ext, float *dA, float *dA_rec, float *dH, float *da, void *stream);
+/* dgg_softk_edge_bwd_partp_phase on chunked rows: one wavefront per NODE walks its chunks (the normalised form first sums dA ahat over
+ * the whole row); rowinfo_ws: 4 * chunks floats, per chunk (rs_i^-1/2, d loss / d rs_i, k_i - 64 m, 0) with m the chunk's position in its
+ * row, so that the per-destination kernel forms rank - k from an entry's index inside its chunk; k, dk [rows] */
+int dgg_softk_edge_bwd_partp_chunked(const float *xp, int64_t rows, const int32_t *cptr, int64_t chunks, int h, const int32_t *idx, const float *val,
+                                     const float *k, const float *rs, const float *dA, const float *dA_rec, const float *da, const float *ahat_rows,
+                                     int64_t row0, float t, int perturb, int mode, int normalized, const void *partp_ws, int64_t ncols,
+                                     float *rowinfo_ws, float *dk, float *dxp, int out_act, int phase, void *stream);
 /* GCNII layer epilogue (GraphConvolution.forward, model.py:36-44): out = theta * sw + (1 - theta) * r (+ inp), sw = support W,
  * r = (1 - alpha) * hi + alpha * h0 (h0 NULL: r = hi; inp NULL: no residual).  Backward: dsw = theta g, dhi, dh0 (NULL with h0);
  * the residual input's gradient is g itself. */

@@ -62,16 +62,20 @@ __global__ void normalize_fwd_kernel(const int32_t *__restrict__ idx, const floa
 template <int VEC>
 __global__ __launch_bounds__(WPB * 64) void spmm_fwd_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
                                                            const float *__restrict__ X, int64_t N, int K, int F,
-                                                           float *__restrict__ Y, __bf16 *__restrict__ Yb = nullptr, int64_t ldyb = 0) {
+                                                           float *__restrict__ Y, __bf16 *__restrict__ Yb = nullptr, int64_t ldyb = 0,
+                                                           const int32_t *__restrict__ cptr = nullptr) {
+    // (cptr != NULL: chunked rows, K = 64 -- row i is the chunks [cptr[i], cptr[i+1]) of idx / ahat, walked in rank order)
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
     const int c0 = (blockIdx.y * 64 + lane) * VEC;
-    int32_t jl = lane < K ? idx[i * K + lane] : -1;
-    float al = lane < K ? ahat[i * K + lane] : 0.0f;
+    const int64_t cb = cptr ? (int64_t)cptr[i] : i, ce = cptr ? (int64_t)cptr[i + 1] : i + 1;
     float acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; v++) acc[v] = 0.0f;
+    for (int64_t ch = cb; ch < ce; ch++) {
+    int32_t jl = lane < K ? idx[ch * K + lane] : -1;
+    float al = lane < K ? ahat[ch * K + lane] : 0.0f;
     for (int r = 0; r < K; r++) {
         int32_t j = bcast(jl, r);
         float a = bcast(al, r);
@@ -89,6 +93,7 @@ __global__ __launch_bounds__(WPB * 64) void spmm_fwd_kernel(const int32_t *__res
                 acc[0] = __fmaf_rn(a, xr[0], acc[0]);
             }
         }
+    }
     }
     if (c0 < F) {
 #pragma unroll
@@ -200,17 +205,20 @@ __global__ __launch_bounds__(WPB * 64) void sddmm_wide_b16_kernel(const int32_t 
 // wave-instruction and NBT such batches in flight, so that one load instruction still moves 1 KiB; the 256/F partial sums
 // of a feature are combined by an xor butterfly at the end (order: entry r goes to slot r mod (256/F), slots summed pairwise).
 // ACT 2 applies the ReLU of GCNConv (model.py:598) in the epilogue.
-template <int F>
+// CHUNKED (rows wider than 64 ranks, K = 64): row i is the chunks [cptr[i], cptr[i+1]) of idx / ahat, walked in rank order.
+template <int F, bool CHUNKED = false>
 __global__ __launch_bounds__(WPB * 64) void spmm_fwd_narrow(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
                                                            const float *__restrict__ X, int64_t N, int K, int act,
-                                                           float *__restrict__ Y) {
+                                                           float *__restrict__ Y, const int32_t *__restrict__ cptr = nullptr) {
     constexpr int LPR = F / 4, NPI = 64 / LPR, NBT = 4;
     const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
     const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
-    const int32_t jl = lane < K ? idx[i * K + lane] : -1;
-    const float al = lane < K ? ahat[i * K + lane] : 0.0f;
+    const int64_t cb = CHUNKED ? (int64_t)cptr[i] : i, ce = CHUNKED ? (int64_t)cptr[i + 1] : i + 1;
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int64_t ch = cb; ch < ce; ch++) {
+    const int32_t jl = lane < K ? idx[ch * K + lane] : -1;
+    const float al = lane < K ? ahat[ch * K + lane] : 0.0f;
     for (int r0 = 0; r0 < K; r0 += NBT * NPI) {
         int32_t j[NBT];
         float a[NBT];
@@ -234,6 +242,7 @@ __global__ __launch_bounds__(WPB * 64) void spmm_fwd_narrow(const int32_t *__res
             acc.x = fmaf(a[b], xv[b].x, acc.x); acc.y = fmaf(a[b], xv[b].y, acc.y);
             acc.z = fmaf(a[b], xv[b].z, acc.z); acc.w = fmaf(a[b], xv[b].w, acc.w);
         }
+    }
     }
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) {
@@ -867,6 +876,39 @@ int dgg_ell_spmm_act_fwd(const int32_t *idx, const float *ahat, const float *X, 
         hipLaunchKernelGGL(act_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Y, n, act);
     }
     return dgg_check_launch("ell_spmm_fwd");
+}
+
+// dgg_ell_spmm_act_fwd on chunked rows (rows wider than 64 ranks, dgg_chunk_layout): idx / ahat [chunks,64], row i = the chunks
+// [cptr[i], cptr[i+1]), Y [rows,F]
+int dgg_ell_spmm_act_fwd_chunked(const int32_t *idx, const float *ahat, const float *X, int64_t rows, const int32_t *cptr, int F, int act, float *Y,
+                                 void *stream) {
+    if (act != 0 && act != 2) return dgg_set_error(DGG_ERR_ARG, "ell_spmm_act_fwd_chunked: act must be 0 (none) or 2 (ReLU)");
+    if (!cptr) return dgg_set_error(DGG_ERR_ARG, "ell_spmm_act_fwd_chunked: cptr is required");
+    if (rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int K = 64;
+    bool al16 = ((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0), al8 = ((uintptr_t)X % 8 == 0);
+    if (al16 && (F == 16 || F == 32 || F == 64)) {
+        if (F == 64) hipLaunchKernelGGL((spmm_fwd_narrow<64, true>), dim3(rows_grid(rows)), dim3(WPB * 64), 0, st, idx, ahat, X, rows, K, act, Y, cptr);
+        else if (F == 32) hipLaunchKernelGGL((spmm_fwd_narrow<32, true>), dim3(rows_grid(rows)), dim3(WPB * 64), 0, st, idx, ahat, X, rows, K, act, Y, cptr);
+        else hipLaunchKernelGGL((spmm_fwd_narrow<16, true>), dim3(rows_grid(rows)), dim3(WPB * 64), 0, st, idx, ahat, X, rows, K, act, Y, cptr);
+        return dgg_check_launch("ell_spmm_fwd_chunked");
+    }
+    if (F % 4 == 0 && F >= 256 && al16) {
+        dim3 grid(rows_grid(rows), (unsigned)((F + 255) / 256));
+        hipLaunchKernelGGL(spmm_fwd_kernel<4>, grid, dim3(WPB * 64), 0, st, idx, ahat, X, rows, K, F, Y, (__bf16 *)nullptr, (int64_t)0, cptr);
+    } else if (F % 2 == 0 && F >= 128 && al8) {
+        dim3 grid(rows_grid(rows), (unsigned)((F + 127) / 128));
+        hipLaunchKernelGGL(spmm_fwd_kernel<2>, grid, dim3(WPB * 64), 0, st, idx, ahat, X, rows, K, F, Y, (__bf16 *)nullptr, (int64_t)0, cptr);
+    } else {
+        dim3 grid(rows_grid(rows), (unsigned)((F + 63) / 64));
+        hipLaunchKernelGGL(spmm_fwd_kernel<1>, grid, dim3(WPB * 64), 0, st, idx, ahat, X, rows, K, F, Y, (__bf16 *)nullptr, (int64_t)0, cptr);
+    }
+    if (act != 0) {
+        const int64_t n = rows * F;
+        hipLaunchKernelGGL(act_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Y, n, act);
+    }
+    return dgg_check_launch("ell_spmm_fwd_chunked");
 }
 
 // dA [N,K] overwritten; dX (nullable, [Nglobal,F]) accumulated into with atomics

@@ -304,6 +304,119 @@ __global__ __launch_bounds__(256) void edge_bwd_rows(const float *__restrict__ x
     }
 }
 
+// ---- the row kernel on CHUNKED rows (rows wider than 64 ranks; dgg_chunk_layout) ---------------------------------------------------
+// edge_bwd_rows<H, FUSE = true, PAY = true> for a node whose row is the chunks [cptr[i], cptr[i+1]) of the [chunks,64] arrays: one
+// wavefront per NODE walks its chunks.  The normalisation backward needs the row's complete sum_r dA_ir ahat_ir before any entry's
+// cotangent can be formed, so the normalised form makes a first pass over dA / ahat of all chunks (two streamed arrays), then the main
+// pass per chunk (ramp backward in registers, gathers as above).  rowinfo is written per CHUNK as (a_i, d loss / d rs_i, k_i - 64 m,
+// 0): the per-destination kernel forms rank - k from the entry's index inside its chunk (64 m and k_i - 64 m are exact in fp32, so
+// (float)lane - (k_i - 64 m) and (float)(64 m + lane) - k_i are the same rounding of the same real number).
+template <int H>
+__global__ __launch_bounds__(256) void edge_bwd_rows_chunked(const float *__restrict__ xp, int64_t rows, const int32_t *__restrict__ cptr,
+                                                             const int32_t *__restrict__ idx, const float *__restrict__ val, int64_t row0,
+                                                             float t, int perturb, float *__restrict__ dxp, SoftkArgs sk) {
+    constexpr int LPR = H / 4;
+    constexpr int NPI = 64 / LPR;
+    constexpr int NBT = (32 / NPI) < 1 ? 1 : 32 / NPI;
+    const int lane = threadIdx.x & 63, c4 = lane % LPR, slot = lane / LPR;
+    const int64_t i = (int64_t)blockIdx.x * 4 + dgg::wave_id();
+    if (i >= rows) return;
+    const int64_t gi = row0 + i;
+    const int cb = __builtin_amdgcn_readfirstlane(cptr[i]), ce = __builtin_amdgcn_readfirstlane(cptr[i + 1]);
+    const float ki = sk.k[i];
+    float ai = 1.0f, drs = 0.0f;
+    if (sk.normalized) {
+        const float rsi = sk.rs[gi];
+        ai = __fdiv_rn(1.0f, c_sqrt(rsi));
+        float dai = sk.da[gi];
+        if (sk.ahat_rows) {
+            float rp = 0.0f;
+            for (int c = cb; c < ce; c++) {
+                const float ah = sk.ahat_rows[(int64_t)c * 64 + lane];
+                float dw = sk.dA[(int64_t)c * 64 + lane];
+                if (ah == 0.0f) dw = 0.0f;                       // (entries outside the partition were never written)
+                rp += dw * ah;
+            }
+            rp = wave_sum_dpp(rp, lane);
+            dai += rp * sqrtf(rsi);
+        }
+        drs = -0.5f * dai * ai / rsi;
+    }
+    const float4 xi = *reinterpret_cast<const float4 *>(xp + gi * H + 4 * c4);
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float skp = 0.0f;
+    for (int c = cb; c < ce; c++) {
+        const int64_t e = (int64_t)c * 64 + lane;
+        const int32_t jl = idx[e];
+        const float vl = val[e];
+        const bool live = jl >= 0;
+        float dw = sk.dA[e];
+        const float kshift = ki - (float)(64 * (c - cb));
+        if (sk.normalized) {
+            const float aj = __fdiv_rn(1.0f, c_sqrt(sk.rs[live ? jl : gi]));
+            if (sk.ahat_rows && sk.ahat_rows[e] == 0.0f) dw = 0.0f;
+            dw = dw * ai * aj + drs;
+        }
+        if (lane == 0) sk.rowinfo[c] = make_float4(ai, drs, kshift, 0.0f);
+        const float th = c_tanh((float)lane - kshift);
+        const float f = 1.0f - 0.5f * (1.0f + th);
+        const float dfdk = 0.5f * (1.0f - th * th);
+        const float gl = (live && sk.mode == 0) ? dw * f : 0.0f;
+        skp += live ? (sk.mode == 0 ? dw * vl * dfdk : dw * dfdk) : 0.0f;
+        const bool myact = live && gl != 0.0f;
+        if (__ballot(myact) == 0ull) continue;                   // (wave-uniform: a chunk of saturated ranks or beyond the ramp)
+        for (int r0 = 0; r0 < 64; r0 += NBT * NPI) {
+            const bool mine = lane >= r0 && lane < r0 + NBT * NPI;
+            if (__ballot(mine && myact) == 0ull) continue;
+            float4 xj[NBT];
+#pragma unroll
+            for (int b = 0; b < NBT; b++) {
+                const int r = r0 + b * NPI + slot;
+                const int rr = r < 64 ? r : 63;
+                const int32_t jb = __shfl(jl, rr, 64);
+                const bool ab = __shfl((int)myact, rr, 64) != 0 && r < 64;
+                xj[b] = *reinterpret_cast<const float4 *>(xp + (ab ? (int64_t)jb : gi) * H + 4 * c4);
+            }
+            float myd2 = 0.0f;
+#pragma unroll
+            for (int b = 0; b < NBT; b++) {
+                const float4 d = make_float4(xi.x - xj[b].x, xi.y - xj[b].y, xi.z - xj[b].z, xi.w - xj[b].w);
+                float d2 = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+                if (LPR > 16) d2 += __uint_as_float(xor_shfl<16>(__float_as_uint(d2), lane));
+                if (LPR > 8) d2 += __uint_as_float(xor_shfl<8>(__float_as_uint(d2), lane));
+                if (LPR > 4) d2 += __uint_as_float(xor_shfl<4>(__float_as_uint(d2), lane));
+                if (LPR > 2) d2 += __uint_as_float(xor_shfl<2>(__float_as_uint(d2), lane));
+                d2 += __uint_as_float(xor_shfl<1>(__float_as_uint(d2), lane));
+                const float tq = __shfl(d2, (lane % NPI) * LPR, 64);
+                if ((lane - r0) / NPI == b && mine) myd2 = tq;
+            }
+            float mydd = 0.0f;
+            if (mine && myact && myd2 != 0.0f) {
+                const float dist = sqrtf(myd2);
+                const float p = c_exp(t * dist);
+                const float dp = perturb ? gl * vl / (p + 1e-8f) : gl;
+                mydd = dp * t * p / dist;
+            }
+#pragma unroll
+            for (int b = 0; b < NBT; b++) {
+                const int r = r0 + b * NPI + slot;
+                const float dd = __shfl(mydd, r < 64 ? r : 63, 64);
+                const float4 d = make_float4(xi.x - xj[b].x, xi.y - xj[b].y, xi.z - xj[b].z, xi.w - xj[b].w);
+                acc.x += dd * d.x; acc.y += dd * d.y; acc.z += dd * d.z; acc.w += dd * d.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) skp += __shfl_xor(skp, off, 64);
+    if (lane == 0) sk.dk[i] = skp;
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
+        acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+    }
+    if (slot == 0) *reinterpret_cast<float4 *>(dxp + gi * H + 4 * c4) = acc;
+}
+
 // ---- score backward, column side: chunks of CH destination-ordered records per group of H/4 lanes --------------------
 // acc_j = sum_e dd_e (xp_j - xp_{i_e}) over the run of records with destination j: -sum_e dd_e xp_{i_e} accumulated record by
 // record, (sum_e dd_e) xp_j added at the flush (one extra row gather per run).
@@ -1697,6 +1810,116 @@ int dgg_softk_edge_bwd_partp_phase(const float *xp, int64_t rows, int h, const i
     }
 #undef DGG_EDGE_PARTP
     return dgg_check_launch("softk_edge_bwd_partp");
+}
+
+// ---- chunked rows (rows wider than 64 ranks, dgg_chunk_layout): the same three steps with the node of every chunk -----------------
+// dgg_partp_build_phase on the [chunks,64] arrays of chunked rows: rs_nodes [nodes of the block] is indexed through cnode [chunks];
+// the SORTED records carry (chunk * 64 + entry, SOURCE NODE of the chunk, w rs_i^-1/2, score) -- the destination is implied by nodeptr
+int dgg_partp_build_chunked(const int32_t *idx, const float *w, const float *val, const float *rs_nodes, int64_t chunks, const int32_t *cnode,
+                            int64_t ncols, const float *rs_all, float *ahat, void *ws, int phase, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int K = 64;
+    if (phase < 0 || phase > 2) return dgg_set_error(DGG_ERR_ARG, "partp_build_chunked: phase is 0 (all), 1 (count + fill) or 2 (sort)");
+    if (dgg_partp_ws_bytes(chunks, K, ncols) == 0 || !ws) return dgg_set_error(DGG_ERR_UNSUPPORTED, "partp_build_chunked: unsupported size or NULL workspace");
+    if (!val || !rs_nodes || !cnode) return dgg_set_error(DGG_ERR_ARG, "partp_build_chunked: the payload needs the scores, the row sums and the chunk nodes");
+    if ((rs_all == nullptr) != (ahat == nullptr)) return dgg_set_error(DGG_ERR_ARG, "partp_build_chunked: rs_all and ahat go together");
+    if ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(val) | reinterpret_cast<uintptr_t>(ahat)) % 16)
+        return dgg_set_error(DGG_ERR_ARG, "partp_build_chunked: idx / w / val / ahat must be 16-byte aligned");
+    if (chunks == 0) return 0;
+    PartP2 p;
+    partp2_layout(p, ws, chunks, K, ncols);
+    const int nb = (int)p.nb, nwg = (int)p.nwg, pbs = p.width;
+    if (phase != 2) {
+#define DGG_PP_PASS(TT)                                                                                                      \
+    hipLaunchKernelGGL(pp_count<TT>, dim3((unsigned)nwg), dim3(TT), (size_t)nb * 4, st, idx, w, chunks, K, nb, p.rcp, p.T, rs_all, ncols, \
+                       p.ainv);                                                                                              \
+    hipLaunchKernelGGL(pp_scan, dim3((unsigned)((nb + 31) / 32)), dim3(1024), 0, st, p.T, nwg, nb, p.totals);                \
+    hipLaunchKernelGGL(pp_fill<TT>, dim3((unsigned)nwg), dim3(TT), (size_t)(2 * nb + 16) * 4, st, idx, w, val, rs_nodes, chunks, K, nb, p.rcp, \
+                       p.T, p.totals, p.bstart, p.tmp, p.ainv, ahat, cnode)
+        switch (pp_threads()) {
+            case 256: DGG_PP_PASS(256); break;
+            case 512: DGG_PP_PASS(512); break;
+            default: DGG_PP_PASS(1024); break;
+        }
+#undef DGG_PP_PASS
+    }
+    if (phase != 1)
+        hipLaunchKernelGGL(pp_sort<true>, dim3((unsigned)nb), dim3(PP_T), (size_t)(2 * pbs + 16) * 4, st, p.bstart, p.tmp, p.recs, p.nodeptr,
+                           (int *)nullptr, nb, pbs, cnode);
+    return dgg_check_launch("partp_build_chunked");
+}
+
+// dgg_ell_conv_bwd_partp_ext on a partition built by dgg_partp_build_chunked: G [nodes of the block, F] is read at the record's source
+// node; dA [chunks,64] (entries outside the partition are not written), dA_rec [chunks*64], dA_ext [chunks,64] (nullable)
+int dgg_ell_conv_bwd_partp_chunked(const float *G, const float *H, int64_t chunks, int F, const void *partp_ws, int64_t ncols, const float *rs,
+                                   const float *dA_ext, float *dA, float *dA_rec, float *dH, float *da, void *stream) {
+    const int K = 64;
+    if ((F != 16 && F != 32 && F != 64 && F != 128) || (reinterpret_cast<uintptr_t>(G) % 16) || (reinterpret_cast<uintptr_t>(H) % 16) ||
+        (reinterpret_cast<uintptr_t>(dH) % 16))
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "ell_conv_bwd_partp_chunked: feature width must be 16, 32, 64 or 128 (16-byte aligned rows)");
+    if (!rs || !partp_ws || !dA_rec || !dA || dgg_partp_ws_bytes(chunks, K, ncols) == 0) return dgg_set_error(DGG_ERR_ARG, "ell_conv_bwd_partp_chunked: missing operand");
+    if (chunks == 0) return 0;
+    PartP2 p;
+    partp2_layout(p, const_cast<void *>(partp_ws), chunks, K, ncols);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nmain = (unsigned)((ncols + 3) / 4);
+    const bool split = node_split(ncols);
+    const dim3 gridn(split ? nmain + (unsigned)ncols : nmain);
+#define DGG_CONV_COLS_C(FF)                                                                                                \
+    if (dA_ext)                                                                                                            \
+        hipLaunchKernelGGL((conv_bwd_node<FF, true>), gridn, dim3(256), 0, st, G, H, K, ncols, p.nodeptr, p.recs,          \
+                           rs, dA, dA_rec, dH, da, dA_ext, split ? nmain : 0u, 1);                                         \
+    else                                                                                                                   \
+        hipLaunchKernelGGL((conv_bwd_node<FF, false>), gridn, dim3(256), 0, st, G, H, K, ncols, p.nodeptr, p.recs,         \
+                           rs, dA, dA_rec, dH, da, (const float *)nullptr, split ? nmain : 0u, 1)
+    switch (F) {
+        case 16: DGG_CONV_COLS_C(16); break;
+        case 32: DGG_CONV_COLS_C(32); break;
+        case 64: DGG_CONV_COLS_C(64); break;
+        default: DGG_CONV_COLS_C(128); break;
+    }
+#undef DGG_CONV_COLS_C
+    return dgg_check_launch("ell_conv_bwd_partp_chunked");
+}
+
+// dgg_softk_edge_bwd_partp_phase on chunked rows: `rows` NODES with chunks [cptr[i], cptr[i+1]) of idx / val / dA / ahat_rows [chunks,64];
+// k, dk [rows]; rowinfo_ws 4 * chunks floats; dA is required (no slot -> record map for chunked rows)
+int dgg_softk_edge_bwd_partp_chunked(const float *xp, int64_t rows, const int32_t *cptr, int64_t chunks, int h, const int32_t *idx, const float *val,
+                                     const float *k, const float *rs, const float *dA, const float *dA_rec, const float *da, const float *ahat_rows,
+                                     int64_t row0, float t, int perturb, int mode, int normalized, const void *partp_ws, int64_t ncols,
+                                     float *rowinfo_ws, float *dk, float *dxp, int out_act, int phase, void *stream) {
+    const int K = 64;
+    if (phase < 0 || phase > 2) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp_chunked: phase is 0 (all), 1 (rows) or 2 (nodes)");
+    if (mode != 0 && mode != 1) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp_chunked: mode must be 0 (k_times) or 1 (k_only)");
+    if (out_act != 0 && (out_act != 1 || mode != 0)) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp_chunked: out_act is 0 or 1 (LeakyReLU), mode 0 only");
+    if (!k || !cptr || !dA || !dA_rec || !dk || !rowinfo_ws || (normalized && (!rs || !da)))
+        return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp_chunked: missing operand");
+    if (ahat_rows && !normalized) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp_chunked: ahat_rows is an operand of the normalised form");
+    if (!partp_ws || dgg_partp_ws_bytes(chunks, K, ncols) == 0) return dgg_set_error(DGG_ERR_ARG, "softk_edge_bwd_partp_chunked: no partition");
+    if (rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    PartP2 p;
+    partp2_layout(p, const_cast<void *>(partp_ws), chunks, K, ncols);
+    const SoftkArgs sk{k, rs, dA, da, mode, normalized, nullptr, dk, ahat_rows, reinterpret_cast<float4 *>(rowinfo_ws), nullptr, dA_rec};
+    const unsigned gr = (unsigned)((rows + 3) / 4);
+    const unsigned nmain = (unsigned)((ncols + 3) / 4);
+    const bool split = node_split(ncols);
+#define DGG_EDGE_PARTC(HH)                                                                                                   \
+    if (phase != 2)                                                                                                          \
+        hipLaunchKernelGGL((edge_bwd_rows_chunked<HH>), dim3(gr), dim3(256), 0, st, xp, rows, cptr, idx, val, row0, t, perturb, dxp, sk); \
+    if (phase != 1 && mode == 0)                                                                                             \
+        hipLaunchKernelGGL(edge_bwd_node<HH>, dim3(split ? nmain + (unsigned)ncols : nmain), dim3(256), 0, st, xp, ncols, p.nodeptr, p.recs, \
+                           dA_rec, reinterpret_cast<const float4 *>(rowinfo_ws), rs, normalized, row0, rows, t, perturb, dxp, out_act,  \
+                           split ? nmain : 0u, 1)
+    switch (h) {
+        case 16: DGG_EDGE_PARTC(16); break;
+        case 32: DGG_EDGE_PARTC(32); break;
+        case 64: DGG_EDGE_PARTC(64); break;
+        case 128: DGG_EDGE_PARTC(128); break;
+        default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "softk_edge_bwd_partp_chunked supports latent_dim in {16,32,64,128}");
+    }
+#undef DGG_EDGE_PARTC
+    return dgg_check_launch("softk_edge_bwd_partp_chunked");
 }
 
 // normalisation backward phase 1 through the partition; da [ncols] zeroed by the caller

@@ -859,15 +859,22 @@ def normalize_fwd(idx, w, rs, row0=0):
     return ahat
 
 
-def spmm_fwd(idx, ahat, X, act=ACT_NONE):
-    """Y = act(A X); act = ACT_RELU is GCNConv's activation when the aggregation runs after the projection"""
+def spmm_fwd(idx, ahat, X, act=ACT_NONE, layout=None):
+    """Y = act(A X); act = ACT_RELU is GCNConv's activation when the aggregation runs after the projection.
+    layout (ChunkLayout): idx / ahat are the [chunks,64] arrays of chunked rows -> Y [layout.rows, F]"""
     N, K = idx.shape
     X = _chk(X)
     F = X.shape[1]
-    Y = torch.empty((N, F), device=idx.device, dtype=torch.float32)
     ahat = _chk(ahat)
     pe = _probe_begin()
-    _lib.check(_lib.lib().dgg_ell_spmm_act_fwd(_ptr(idx), _ptr(ahat), _ptr(X), N, K, F, act, _ptr(Y), _stream()), "ell_spmm_act_fwd")
+    if layout is not None and layout.wide:
+        assert K == 64 and N == layout.chunks
+        Y = torch.empty((layout.rows, F), device=idx.device, dtype=torch.float32)
+        _lib.check(_lib.lib().dgg_ell_spmm_act_fwd_chunked(_ptr(idx), _ptr(ahat), _ptr(X), layout.rows, _ptr(layout.cptr), F, act, _ptr(Y), _stream()),
+                   "ell_spmm_act_fwd_chunked")
+    else:
+        Y = torch.empty((N, F), device=idx.device, dtype=torch.float32)
+        _lib.check(_lib.lib().dgg_ell_spmm_act_fwd(_ptr(idx), _ptr(ahat), _ptr(X), N, K, F, act, _ptr(Y), _stream()), "ell_spmm_act_fwd")
     _probe_end("spmm_fwd", pe)
     return Y
 
@@ -963,8 +970,9 @@ def part_build(idx, w, ncols):
 class PartP:
     """payload partition (dgg_partp_build): workspace + the shape it was built for"""
 
-    def __init__(self, ws, rows, K, ncols):
+    def __init__(self, ws, rows, K, ncols, layout=None):
         self.ws, self.rows, self.K, self.ncols = ws, rows, K, ncols
+        self.layout = layout                 # ChunkLayout when the block is the [chunks,64] arrays of chunked rows (rows = chunks)
 
 
 def partp_records(partp):
@@ -979,16 +987,27 @@ def partp_records(partp):
     return nodeptr, recs
 
 
-def partp_build(idx, w, val, rs_rows, ncols, rs_all=None, phase=0):
+def partp_build(idx, w, val, rs_rows, ncols, rs_all=None, phase=0, layout=None):
     """Payload partition of the active ELL entries by destination node: records carry w * rs_i^-1/2 and the score, there is no
     slot map.  Returns None when it does not apply.  rs_all [ncols] (row sums of every node): normalize_adj is fused and the
     result is (partition, ahat [rows,K]).  phase=1: count + scan + fill only (ahat complete); finish with partp_sort(), possibly on
-    another stream -- the sorted records are read by the backward's column kernels only."""
+    another stream -- the sorted records are read by the backward's column kernels only.
+    layout (ChunkLayout, wide): idx / w / val are [chunks,64], rs_rows [layout.rows] per NODE; the sorted records then carry the
+    source node of their chunk in place of the destination (dgg_partp_build_chunked)."""
     N, K = idx.shape
     nbytes = int(_lib.lib().dgg_partp_ws_bytes(N, K, ncols))
     if nbytes == 0:
         return None
     ws = torch.empty((nbytes,), device=idx.device, dtype=torch.uint8)
+    if layout is not None and layout.wide:
+        assert K == 64 and N == layout.chunks and rs_rows.shape[0] == layout.rows
+        ahat = torch.empty((N, K), device=idx.device, dtype=torch.float32) if rs_all is not None else None
+        _lib.check(_lib.lib().dgg_partp_build_chunked(_ptr(idx), _ptr(_chk(w)), _ptr(_chk(val)), _ptr(_chk(rs_rows)), N, _ptr(layout.cnode), ncols,
+                                                      _ptr(None if rs_all is None else _chk(rs_all)), _ptr(ahat), _ptr(ws), int(phase), _stream()),
+                   "partp_build_chunked")
+        part = PartP(ws, N, K, ncols, layout)
+        part.args = (idx, w, val, rs_rows, rs_all, ahat) if phase == 1 else None
+        return part if rs_all is None else (part, ahat)
     if rs_all is None:
         assert phase == 0
         _lib.check(_lib.lib().dgg_partp_build(_ptr(idx), _ptr(_chk(w)), _ptr(_chk(val)), _ptr(_chk(rs_rows)), N, K, ncols, _ptr(ws), _stream()),
@@ -1005,6 +1024,11 @@ def partp_build(idx, w, val, rs_rows, ncols, rs_all=None, phase=0):
 def partp_sort(part):
     """second part of partp_build(phase=1): the per-bucket sort, on the CURRENT stream"""
     idx, w, val, rs_rows, rs_all, ahat = part.args
+    if part.layout is not None:
+        _lib.check(_lib.lib().dgg_partp_build_chunked(_ptr(idx), _ptr(w), _ptr(val), _ptr(rs_rows), part.rows, _ptr(part.layout.cnode), part.ncols,
+                                                      _ptr(rs_all), _ptr(ahat), _ptr(part.ws), 2, _stream()), "partp_sort")
+        part.args = None
+        return
     _lib.check(_lib.lib().dgg_partp_build_phase(_ptr(idx), _ptr(w), _ptr(val), _ptr(rs_rows), part.rows, part.K, part.ncols, _ptr(rs_all),
                                                 _ptr(ahat), _ptr(part.ws), 2, _stream()), "partp_sort")
     part.args = None
@@ -1035,6 +1059,12 @@ def conv_bwd_cols_p(idx, H, G, partp, rs, zero_dA=True, dA_ext=None, want_dA=Tru
     if dA_ext is not None:
         dA_ext = _chk(dA_ext.contiguous())
         assert tuple(dA_ext.shape) == (N, K)
+    if partp.layout is not None:                 # chunked rows: G [layout.rows, F] is read at the source node of a record's chunk
+        assert want_dA and G.shape[0] == partp.layout.rows
+        _lib.check(_lib.lib().dgg_ell_conv_bwd_partp_chunked(_ptr(G), _ptr(H), N, F, _ptr(partp.ws), ncols, _ptr(_chk(rs)), _ptr(dA_ext), _ptr(dA),
+                                                             _ptr(dA_rec), _ptr(dH), _ptr(da), _stream()), "ell_conv_bwd_partp_chunked")
+        _probe_end("conv_bwd", pe)
+        return dA, dA_rec, dH, da
     _lib.check(_lib.lib().dgg_ell_conv_bwd_partp_ext(_ptr(G), _ptr(H), N, K, F, _ptr(partp.ws), ncols, _ptr(_chk(rs)), _ptr(dA_ext), _ptr(dA),
                                                      _ptr(dA_rec), _ptr(dH), _ptr(da), _stream()), "ell_conv_bwd_partp")
     _probe_end("conv_bwd", pe)
@@ -1053,14 +1083,26 @@ def softk_edge_bwd_p(xp, idx, val, k, dA, dA_rec, rs, da, row0, t, perturb, mode
     N, K = idx.shape
     if partp is None or h not in (16, 32, 64, 128) or mode not in (MODE_K_TIMES_EDGE_PROB, MODE_K_ONLY) or Ng != partp.ncols:
         return None
+    lay = partp.layout
+    nrows = N if lay is None else lay.rows
     if phase == 2:
         dxp, dk, rowinfo = state
     else:
         # mode 0: every row of dxp is written (own rows by the row kernel, the others by the per-node kernel): no zero fill
         dxp = torch.empty_like(xp) if (mode == MODE_K_TIMES_EDGE_PROB and N > 0) else _zeros(tuple(xp.shape), xp.device)   # (N == 0: see conv_bwd_cols_p)
         rowinfo = torch.empty((N, 4), device=xp.device, dtype=torch.float32)
-        dk = torch.empty((N,), device=xp.device, dtype=torch.float32)
+        dk = torch.empty((nrows,), device=xp.device, dtype=torch.float32)
     pe = _probe_begin()
+    if lay is not None:                          # chunked rows: one wavefront per node walks its chunks; rowinfo per chunk
+        assert dA is not None and K == 64
+        _lib.check(_lib.lib().dgg_softk_edge_bwd_partp_chunked(_ptr(xp), nrows, _ptr(lay.cptr), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(k)), _ptr(rs),
+                                                               _ptr(_chk(dA)), _ptr(dA_rec), _ptr(da), _ptr(None if ahat_rows is None else _chk(ahat_rows)),
+                                                               row0, t, int(perturb), mode, int(normalized), _ptr(partp.ws), Ng, _ptr(rowinfo), _ptr(dk),
+                                                               _ptr(dxp), int(out_act), int(phase), _stream()), "softk_edge_bwd_partp_chunked")
+        _probe_end("edge_bwd" if phase == 0 else ("edge_bwd_rows" if phase == 1 else "edge_bwd_node"), pe)
+        if phase == 1:
+            return dxp, dk, (dxp, dk, rowinfo)
+        return dxp, dk
     _lib.check(_lib.lib().dgg_softk_edge_bwd_partp_phase(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(k)), _ptr(rs), _ptr(None if dA is None else _chk(dA)),
                                                          _ptr(dA_rec), _ptr(da), _ptr(None if ahat_rows is None else _chk(ahat_rows)), K, row0, t,
                                                          int(perturb), mode, int(normalized), _ptr(partp.ws), Ng, _ptr(rowinfo), _ptr(dk),

@@ -130,6 +130,15 @@ class ShardedDGGConv:
         self.r0, self.r1, self.per = shard_bounds(N, self.world, self.rank)
         assert cand is None or self.world == 1, "edge-list candidates run on one rank"
         self.bufs = {}                                       # collective staging buffers, kept between steps
+        # Rows wider than the 64-rank list (all-pairs candidates, ranked noise): the learned degree is unbounded (dgm.py:1580-1584) and
+        # the reference ramps over the whole dense row (dgm.py:1402-1421).  wide_rows: "off" = the [rows,64] list whatever k (exact
+        # while k_i + 9.5 <= 64; callers enforce the bound), "auto" = chunked rows (ops.chunk_layout: ceil(k_i + 8.5) + 1 ranks of every
+        # row in chunks of 64) from the forward in which some row needs them -- ONE readback of the chunk count per forward --, "on" =
+        # chunked rows always.  wide_cap = (chunks, lists per wavefront): a FIXED capacity instead of the readback (hipGraph capture;
+        # the flags of the last forward are in self.wide_meta, read by check_wide()).
+        self.wide_rows = "off"
+        self.wide_cap = None
+        self.wide_meta = None
 
     def check_generator(self):
         """raises if the ranked symmetric noise generator (noise_mode 5) could not settle every row inside its workspace in any
@@ -138,6 +147,32 @@ class ShardedDGGConv:
         if err is not None and bool(err.any()):
             raise RuntimeError("ShardedDGGConv: the ranked symmetric noise generator ran out of workspace for its dense tier; "
                                "use noise_mode 3 (per-pair hash) for this data")
+
+    def check_wide(self):
+        """raises if a forward under a fixed chunk capacity (wide_cap) could not hold every row's ranks (one synchronisation)"""
+        meta, self.wide_meta = self.wide_meta, None
+        if meta is not None:
+            total, widest, flags, _ = (int(v) for v in meta.cpu())
+            if flags:
+                raise RuntimeError(f"ShardedDGGConv: the chunked rows outgrew their fixed capacity {self.wide_cap} (chunks needed {total}, widest "
+                                   f"row {widest} chunks, flags {flags}): re-capture with a larger wide_cap")
+
+    def _chunk_layout(self, k):
+        """-> ops.ChunkLayout for this forward's learned degrees, or None: every row fits the 64-rank list (or wide_rows is off)"""
+        kern = self.kern
+        if self.wide_rows == "off" or not hasattr(kern, "chunk_layout") or self.noise_mode != 4 or self.cand is not None or self.K != 64:
+            return None
+        if self.wide_cap is not None:
+            lay = kern.chunk_layout(k, maxm=int(self.wide_cap[1]), ccap=int(self.wide_cap[0]))
+            self.wide_meta = lay.meta
+            return lay
+        assert not (k.is_cuda and torch.cuda.is_current_stream_capturing()), \
+            "ShardedDGGConv: chunked rows inside a hipGraph capture need a fixed capacity (wide_cap = (chunks, lists))"
+        lay = kern.chunk_layout(k)
+        self.last_layout = (lay.chunks, lay.maxm)
+        if not lay.wide and self.wide_rows == "auto":
+            return None
+        return lay
 
     def emulate_rank(self, world, rank):
         """TIMING DIAGNOSTIC (bench.py --emulate-world): do the work of `rank` of `world` in a single process -- own row range
@@ -235,7 +270,11 @@ class ShardedDGGConv:
                 s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
         elif self.noise_mode == 4 and self.K == 64 and hasattr(kern, "allpairs_topk_softk") and xp.shape[1] in (8, 16, 32, 64, 128):
             # ranked noise: the ramp is applied inside the search kernel, while the settled list is still in registers
-            s["idx"], s["val"], s["w"], rs_local = kern.allpairs_topk_softk(xp, s["k"], self.mode, self.t, self.seed, rows=(self.r0, self.r1))
+            s["layout"] = lay = self._chunk_layout(s["k"]) if xp.shape[1] in (16, 32, 64, 128) else None
+            if lay is not None:                     # rows wider than 64 ranks: ceil(k_i + 8.5) + 1 ranks of every row, in chunks of 64
+                s["idx"], s["val"], s["w"], rs_local = kern.allpairs_topk_wide(xp, s["k"], lay, self.mode, self.t, self.seed, rows=(self.r0, self.r1))
+            else:
+                s["idx"], s["val"], s["w"], rs_local = kern.allpairs_topk_softk(xp, s["k"], self.mode, self.t, self.seed, rows=(self.r0, self.r1))
         else:
             if self.noise_mode == 5 and not hasattr(kern, "rsym_status"):      # (a stand-in kernel namespace without the status plumbing)
                 st = None
@@ -255,8 +294,11 @@ class ShardedDGGConv:
         # namespace offers it and covers the shape)
         use_p = hasattr(kern, "partp_build") and xp.shape[1] in (16, 32, 64, 128) and H.shape[1] in (16, 32, 64, 128) and self.mode in (0, 1)
         ov = use_p and self.overlap and s["idx"].is_cuda
-        got = (kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs, phase=1) if ov else
-               kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs)) if use_p else None
+        lay = s.get("layout")
+        lkw = {} if lay is None else {"layout": lay}
+        assert lay is None or use_p, "chunked rows run on the payload partition (latent / conv widths 16, 32, 64, 128; soft modes)"
+        got = (kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs, phase=1, **lkw) if ov else
+               kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs, **lkw)) if use_p else None
         s["partp"], s["ahat"] = got if got is not None else (None, None)
         s["side_join"] = False
         if ov and got is not None:                  # the sort runs beside the aggregation; the backward joins before its first column kernel
@@ -280,7 +322,7 @@ class ShardedDGGConv:
             Hf[self.r0:self.r1].copy_(H)
             H = Hf
         s["H"] = H
-        s["Z"] = kern.spmm_fwd(s["idx"], s["ahat"], H, 2)    # relu(A (x Wc))
+        s["Z"] = kern.spmm_fwd(s["idx"], s["ahat"], H, 2, **lkw)    # relu(A (x Wc))
         s["gen"] = self._fwd_gen
         self.saved = s
         return s["Z"]
@@ -343,7 +385,7 @@ class ShardedDGGConv:
             # record-ordered copy through the slot -> record map the partition's sort left (Pubmed step 0.359 -> 0.349 ms).  At
             # N = 100 000 (25.6 MB) the 4.1 M four-byte gathers cost the row kernel more (+70 us) than the scattered stores cost the
             # node kernel (-47 us): 1.264 -> 1.285 ms, so large graphs keep the scattered row-major copy.  DGG_DA_MAP=0/1 forces one.
-            use_map = getattr(kern, "DA_MAP", False) and kern.partp_has_map(s["idx"].shape[0]) and self.scorer is None
+            use_map = getattr(kern, "DA_MAP", False) and kern.partp_has_map(s["idx"].shape[0]) and self.scorer is None and s.get("layout") is None
             kw = {"want_dA": False} if use_map else {}
             if dA_ext is not None:
                 kw["dA_ext"] = dA_ext

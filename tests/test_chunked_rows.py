@@ -98,3 +98,61 @@ def test_chunked_search_with_single_chunk_rows_equals_the_list(dev):
     b = ops.allpairs_topk_softk(xp, k, seed=(5, 6))
     for x_, y_ in zip(a, b):
         assert torch.equal(x_, y_)
+
+
+def _wide_step(dev, N, d, h, scale=150.0, seed=(1234, 0), cap=None):
+    import bench
+    from dgg_amd import ops
+    from dgg_amd.parallel import ShardedDGGConv
+    P = bench.make_params(d, h, dev)
+    P["Wp"] = (P["Wp"] * scale).contiguous()                      # a spread of learned degrees: half the rows narrow, the rest 2-4 chunks
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, d, generator=g).to(dev)
+    deg = (2 + 100 * torch.rand(N, generator=g) ** 3).to(dev)
+    layer = ShardedDGGConv(ops, N, K=64, noise_mode=ops.NOISE_RANKED, seed=seed)
+    layer.wide_rows = "auto"
+    layer.wide_cap = cap
+    Z = layer.forward(x, deg, P)
+    grads = layer.backward(torch.ones_like(Z), x, P)
+    return layer, x, deg, P, Z, grads
+
+
+def test_chunked_step_matches_the_oracle(dev):
+    """generator -> normalize_adj -> relu(A (x Wc)), forward and backward, with rows of 1-4 chunks through ShardedDGGConv (the engine of
+    the fused layer and of bench.py): lists / scores / weights / row sums / normalised weights bit-exact against the oracle on the
+    dense-by-rank arrays, Z to 1e-5, EVERY parameter gradient against the oracle's backward (2e-4 of max)"""
+    from test_hip_parity import _full_size_gradient_parity
+    N, d, h = 2500, 48, 32
+    layer, x, deg, P, Z, grads = _wide_step(dev, N, d, h)
+    s = layer.saved
+    lay = s["layout"]
+    assert lay is not None and lay.wide and lay.maxm >= 3
+    kc = Nn(s["k"])
+    assert (kc < 54.5).mean() > 0.2 and kc.max() > 150, (kc.min(), kc.max())
+    L = rank_limit(kc, 64 * lay.maxm)
+    K = 64 * lay.maxm
+    xp_c = Nn(s["xp"])
+    ri, rv = O.allpairs_topk(xp_c, K=K, noise_mode=O.NOISE_RANKED, seed=(1234, 0))
+    keep = np.arange(K)[None, :] < L[:, None]
+    ri = np.where(keep, ri, -1).astype(np.int32)
+    rv = np.where(keep, rv, np.float32(0)).astype(np.float32)
+    gi, gv = chunked_to_rows(lay, s["idx"], -1), chunked_to_rows(lay, s["val"], 0.0)
+    gw, ga = chunked_to_rows(lay, s["w"], 0.0), chunked_to_rows(lay, s["ahat"], 0.0)
+    assert np.array_equal(gi, ri) and np.array_equal(gv, rv)
+    wo, rso = O.softk(ri, rv, kc)
+    assert np.array_equal(gw, wo) and np.array_equal(Nn(s["rs"]), rso)
+    # (entries whose ramp is exactly 0 are outside the partition: their normalised weight is written 0, as the oracle's product is)
+    assert np.array_equal(ga, O.normalize(ri, wo, rso))
+    Zo = np.maximum(O.spmm(ri, ga, Nn(s["H"])), 0)
+    np.testing.assert_allclose(Nn(Z), Zo, rtol=1e-5, atol=1e-5)
+    dense = dict(s, idx=torch.from_numpy(gi), val=torch.from_numpy(gv), w=torch.from_numpy(gw), ahat=torch.from_numpy(ga))
+    _full_size_gradient_parity(dense, grads, x, deg, P)
+    # a fixed capacity (hipGraph capture): the same step, the spare chunks empty; too small a capacity is reported, not truncated
+    layer2, _, _, _, Z2, grads2 = _wide_step(dev, N, d, h, cap=(lay.chunks + 100, 4))
+    layer2.check_wide()
+    assert torch.equal(Z2, Z)
+    for k_ in grads:
+        np.testing.assert_allclose(Nn(grads2[k_]), Nn(grads[k_]), rtol=0, atol=2e-4 * float(grads[k_].abs().max()))
+    layer3, *_ = _wide_step(dev, N, d, h, cap=(lay.chunks - 5, 4))
+    with pytest.raises(RuntimeError, match="capacity"):
+        layer3.check_wide()
