@@ -595,6 +595,7 @@ def main():
                          "that the default run appends under `configs`")
     ap.add_argument("--no-cpu-dense", dest="cpu_dense", action="store_false",
                     help="skip the dense reference-shaped CPU formulation at N = 2 708 / 4 000 (BASELINE.md section 3)")
+    ap.add_argument("--prior", default="24,40", help="synthetic workload: prior degrees lo,hi (uniform); 24,40 = SURVEY 8(d) (k ~ 32); 100,164: k ~ 128")
     ap.add_argument("--feat", type=int, default=128)
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--algo", type=int, default=0, help="all-pairs kernel for --noise hash: 0 auto, 1 exhaustive, 2 MFMA-bounded, "
@@ -661,7 +662,7 @@ class SyntheticRun:
     """One configuration of the synthetic all-pairs workload: inputs resident in HBM, the layer, and the step function."""
 
     def __init__(self, a, dev, world, rank, force, N, d, h, noise_mode, x_grad=False, emu=0, exchange="replicate", feat_scale=None,
-                 data=None):
+                 data=None, prior=None):
         from dgg_amd import ops
         from dgg_amd.parallel import ShardedDGGConv, shard_bounds, _all_gather_rows
         self.N, self.d, self.h, self.world, self.rank, self.emu = N, d, h, world, rank, emu
@@ -675,7 +676,10 @@ class SyntheticRun:
             x_cpu[23_000:23_040] = x_cpu[23_000:23_040] * 0.01 + 3.0   # 40 outliers far from everything
         fs = float(feat_scale if feat_scale is not None else getattr(a, "feat_scale", 1.0))
         self.x_local = (x_cpu * fs).to(dev)
-        self.deg = (24 + 16 * torch.rand(N, generator=torch.Generator(device="cpu").manual_seed(7))).to(dev)
+        # prior degrees c_i = lo + (hi - lo) U(0,1): SURVEY 8(d)'s 24..40 (mean 32) unless --prior says otherwise (100,164: learned
+        # degrees ~128, rows of three 64-rank chunks)
+        lo, hi = prior if prior is not None else tuple(float(v) for v in getattr(a, "prior", "24,40").split(","))
+        self.deg = (lo + (hi - lo) * torch.rand(N, generator=torch.Generator(device="cpu").manual_seed(7))).to(dev)
         # features are DATA unless x_grad: with more than one rank they are replicated once, here, outside the timed region (data
         # placement: 4*N*d bytes per GPU), and no feature tensor crosses the fabric per step (dgg_amd/parallel.py)
         x_full = None
@@ -689,6 +693,13 @@ class SyntheticRun:
                                     hybrid=(exchange == "hybrid" and x_full is not None))
         if emu:
             self.layer.emulate_rank(emu, self.erank)
+        # rows wider than the 64-rank list (learned degrees k_i + 9.5 > 64) are kept in CHUNKED rows -- the configuration a model can be
+        # TRAINED in (the learned degree is unbounded, dgm.py:1580-1584).  One rank: the eager warm-up steps read the chunk count back,
+        # the captured graph replays that layout as a fixed capacity (no wide row at this prior: the plain [N,64] list, same graph as
+        # without the option).  Several ranks run eagerly: the list with its enforced bound (no readback per step).
+        self.wide = noise_mode == ops.NOISE_RANKED and world == 1 and not force and not emu and hasattr(ops, "chunk_layout") and h in (16, 32, 64, 128)
+        if self.wide:
+            self.layer.wide_rows = "auto"
         self.grads = None
         # ranked noise: the seed lives in DEVICE memory and is advanced by a (captured) increment at the top of every step, so ONE
         # hipGraph draws fresh noise on every replay -- what training does per forward (reference dgm.py:1226); the other
@@ -706,6 +717,12 @@ class SyntheticRun:
             self.layer.seed = self.seed_dev
         else:
             self.layer.seed = (1234, seed_lo)
+        if self.wide and self.layer.wide_cap is None and torch.cuda.is_current_stream_capturing():
+            c_, m_ = self.layer.last_layout                      # (layout of the last eager step; + 6 % spare chunks)
+            if c_ == self.r1 - self.r0:
+                self.layer.wide_rows = "off"
+            else:
+                self.layer.wide_cap = (c_ + c_ // 16 + 64, m_)
         Z = self.layer.forward(self.x_local, self.deg, self.P)
         if self.cot is None or self.cot.shape != Z.shape:
             self.cot = torch.ones_like(Z)                            # the cotangent is an INPUT of the backward: resident, not refilled
@@ -801,6 +818,38 @@ def cpu_dense_formulation(sizes, threads):
     return out
 
 
+def wide_rows_config(a, dev, prior, N=100_000):
+    """The headline step with learned degrees BEYOND the 64-rank list (prior degrees `prior`: k ~ 128, every row three chunks of 64
+    ranks -- where a model sits after some tens of Adam steps, tests/test_chunked_rows.py): chunked rows through the same engine,
+    captured into one hipGraph with the chunk count of the warm-up steps as its capacity."""
+    import copy
+    from dgg_amd import ops
+    b = copy.copy(a)
+    b.steps, b.warmup, b.repeats = 10, 3, 5
+    run = SyntheticRun(b, dev, 1, 0, False, N, a.feat, a.latent, ops.NOISE_RANKED, prior=prior)
+    times, graphed, eager_T = time_windows(run, b, 1, False, dev, a.hipgraph, b.repeats)
+    T = float(np.median(times)) / b.steps
+    run.layer.check_wide()
+    sv = run.layer.saved
+    lay = sv["layout"]
+    k = sv["k"]
+    ops.PROBE = {}
+    run.step(0)
+    torch.cuda.synchronize()
+    pv, ops.PROBE = ops.PROBE, None
+    kern = {n_: sum(e0.elapsed_time(e1) for e0, e1 in ev) for n_, ev in pv.items()}
+    kept = float((sv["idx"] >= 0).sum().item())
+    active = float((sv["w"] != 0).sum().item())
+    h, F = a.latent, int(sv["H"].shape[1])
+    # compulsory bytes of the step as SURVEY 8(d) counts them (every array once), with K' = kept ranks per row instead of 41
+    comp = N * 4.0 * (a.feat + 3 * 64 + 2) + kept * 12 + active * (8 + 24 + 36) + N * 4.0 * (3 * F + 4 * h)
+    return {"workload": f"synthetic all-pairs DGG N={N} d={a.feat} h={h}, prior degrees {prior[0]:.0f}..{prior[1]:.0f}: learned k ~ {float(k.mean()):.1f} "
+                        f"(max {float(k.max()):.1f}), chunked rows ({'no wide row' if lay is None else f'{int(lay.meta[0])} chunks, widest row {int(lay.meta[1])}'})",
+            "ms_per_step": T * 1e3, "eager_ms_per_step": eager_T * 1e3, "hipgraph": graphed, "value": N * float(k.mean()) / T, "unit": "edges/s",
+            "steps": b.steps, "windows": len(times), "dtype": "f32", "kept_ranks_per_row": kept / N, "active_edges_per_row": active / N,
+            "kernels_ms_per_step": kern, "step_compulsory_bytes": comp, "step_frac_hbm": comp / T / 1e9 / HBM_PEAK_GBPS}
+
+
 def other_configs(a, dev):
     """Compact results of BASELINE.json configs[1], [4] and [3] (single GPU) for the default run's JSON line: ms per step, value,
     roofline of the dominant kernel / GEMMs, CPU baseline.  Short windows (these are secondary lines; the full ones: --workload
@@ -808,7 +857,7 @@ def other_configs(a, dev):
     import copy
     from dgg_amd import ops
     res = {}
-    only = [c_ for c_ in os.environ.get("DGG_BENCH_CONFIGS", "pubmed,ppi,n500k").split(",") if c_]     # (diagnostic: a subset)
+    only = [c_ for c_ in os.environ.get("DGG_BENCH_CONFIGS", "pubmed,ppi,k128,n500k").split(",") if c_]     # (diagnostic: a subset)
 
     def pick(o, extra=()):
         keep = ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "roofline", "cpu_baseline", "kernels_ms_per_step") + tuple(extra)
@@ -847,6 +896,12 @@ def other_configs(a, dev):
             res["ppi_bf16"] = pick(run_ppi(b, dev))
     except Exception as e:  # noqa: BLE001
         res["ppi_bf16"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    try:
+        if "k128" in only:
+            res["k128_chunked_rows"] = wide_rows_config(a, dev, (100.0, 164.0))
+    except Exception as e:  # noqa: BLE001
+        res["k128_chunked_rows"] = {"error": repr(e)}
     torch.cuda.empty_cache()
     try:
         if "n500k" not in only:
@@ -916,7 +971,10 @@ def bench_synthetic(a, dev, world, rank, force):
         dist.all_reduce(kmaxv, op=dist.ReduceOp.MAX)
     Nval = (r1 - r0) if emu else N                            # emulation: one rank's rows only
     kmean = float(ksum.item()) / Nval
-    assert float(kmaxv.item()) + 8.5 <= 64, "learned degree exceeds the ELL width: results would be truncated"
+    lay = layer.saved.get("layout")
+    assert lay is not None or float(kmaxv.item()) + 8.5 <= 64, "learned degree exceeds the ELL width: results would be truncated"
+    if lay is not None:
+        layer.check_wide()                                        # (a captured step's fixed chunk capacity held every row)
     assert all(torch.isfinite(v).all() for v in run.grads.values())
 
     # Per-kernel roofline figures: durations taken INSIDE running steps.  dgg_amd.ops records a pair of events on the launch
@@ -971,7 +1029,7 @@ def bench_synthetic(a, dev, world, rank, force):
 
     # ---- the ranked search's walk, MEASURED on this run's data (not a literal): one probe launch over every row
     walk = None
-    if noise_mode == ops.NOISE_RANKED:
+    if noise_mode == ops.NOISE_RANKED and lay is None:            # (the probe walks the 64-rank list)
         walk = ops.ranked_probe(sv["xp"], sv["k"], layer.t, (1234, 0), rows=(r0, r1))
     # ---- data regimes: the same step on features scaled x4 / x16 and on clustered data.  Per regime: the measured walk (every 16th
     # row, no budget), the PILOT's estimate (~1000 sampled rows, 64-block budget: what DGG_LearnableK_debug runs under

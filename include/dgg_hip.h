@@ -444,6 +444,10 @@ int dgg_softk_edge_bwd_partp_chunked(const float *xp, int64_t rows, const int32_
                                      const float *k, const float *rs, const float *dA, const float *dA_rec, const float *da, const float *ahat_rows,
                                      int64_t row0, float t, int perturb, int mode, int normalized, const void *partp_ws, int64_t ncols,
                                      float *rowinfo_ws, float *dk, float *dxp, int out_act, int phase, void *stream);
+/* dA [rows,64] by rows (chunked rows: [chunks,64]) -> dA_rec [rows*64] in the record order of a built payload partition (K = 64): for a
+ * caller that holds d loss / d w row-major -- the generator used as a separate module, whose output feeds other layers -- and runs the
+ * score backward (dgg_softk_edge_bwd_partp[_chunked], normalized = 0) on it */
+int dgg_partp_gather_rec(const float *dA, int64_t rows, int64_t ncols, const void *partp_ws, float *dA_rec, void *stream);
 /* GCNII layer epilogue (GraphConvolution.forward, model.py:36-44): out = theta * sw + (1 - theta) * r (+ inp), sw = support W,
  * r = (1 - alpha) * hi + alpha * h0 (h0 NULL: r = hi; inp NULL: no residual).  Backward: dsw = theta g, dhi, dh0 (NULL with h0);
  * the residual input's gradient is g itself. */

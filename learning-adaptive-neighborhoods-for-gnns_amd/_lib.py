@@ -49,6 +49,7 @@ PROTOTYPES = {
     "dgg_ell_conv_bwd_partp_chunked": [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_softk_edge_bwd_partp_chunked": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _i32, _i32, _i32, _vp,
                                          _i64, _vp, _vp, _vp, _i32, _i32, _vp],
+    "dgg_partp_gather_rec": [_vp, _i64, _i64, _vp, _vp, _vp],
     "dgg_edgelist_topk": [_vp, _i64, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _vp, _vp],
     "dgg_edgelist_topk_softk": [_vp, _i64, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_edge_mlp_fwd": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],

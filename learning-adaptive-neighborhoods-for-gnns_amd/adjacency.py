@@ -22,17 +22,21 @@ class AllPairs:
 
 
 class EllAdjacency:
-    """Row-major fixed-width sparse matrix: entry (i, idx[i,r]) = values[i,r]; idx == -1 marks padding."""
+    """Row-major fixed-width sparse matrix: entry (i, idx[i,r]) = values[i,r]; idx == -1 marks padding.
+    layout (ops.ChunkLayout, optional): CHUNKED rows -- the learned degrees of an all-pairs graph outgrew the 64-rank list, so row i is
+    the chunks [cptr[i], cptr[i+1]) of idx / values [chunks,64] (rank r of the row = entry r % 64 of its chunk r / 64); the reference
+    has no width limit (dense [N,N] rows, dgm.py:1402-1421)."""
 
-    def __init__(self, idx, values, n_cols, rs=None, k=None, score=None, normalized=False, part=None, owner=None, partp=None):
+    def __init__(self, idx, values, n_cols, rs=None, k=None, score=None, normalized=False, part=None, owner=None, partp=None, layout=None):
         self.idx, self._values, self.n_cols = idx, values, n_cols
+        self.layout = layout if (layout is not None and layout.wide) else None
         # (payload partition, row sums of the unnormalised weights) when `values` are the normalised values that partition was
         # built with (DGG_LearnableK_debug.forward_conv): the backward of A @ X then runs by destination, without atomics
         self.partp = partp
         self.owner = owner          # the DGG module that produced it (its ELL-width bound is checked when the matrix is densified)
         self.rs, self.k, self.score, self.normalized = rs, k, score, normalized
         self.part = part            # destination-ordered partition of the active entries (ops.part_build), if one was built
-        self.shape = (idx.shape[0], n_cols)
+        self.shape = (idx.shape[0] if self.layout is None else self.layout.rows, n_cols)
         self.device = idx.device
 
     # --- reference-style accessors ---------------------------------------------------------------------------
@@ -52,23 +56,44 @@ class EllAdjacency:
         valid = self.idx >= 0
         cols = self.idx.clamp(min=0).long()
         out = torch.zeros(self.shape, device=self.device, dtype=self._values.dtype)
-        return out.scatter_add(1, cols, torch.where(valid, self._values, torch.zeros_like(self._values)))
+        vals = torch.where(valid, self._values, torch.zeros_like(self._values))
+        if self.layout is not None:              # chunked rows: a chunk's entries land in the row of its node
+            rows = self._chunk_rows().unsqueeze(1).expand_as(self.idx)
+            return out.index_put((rows.reshape(-1), cols.reshape(-1)), vals.reshape(-1), accumulate=True)
+        return out.scatter_add(1, cols, vals)
+
+    def _chunk_rows(self):
+        return self.layout.cnode.long()[:self.idx.shape[0]]
 
     def to_sparse(self):
         if self.owner is not None:
             self.owner.check_ell_bound()
         valid = self.idx >= 0
-        rows = torch.arange(self.shape[0], device=self.device).unsqueeze(1).expand_as(self.idx)[valid]
+        base = torch.arange(self.shape[0], device=self.device) if self.layout is None else self._chunk_rows()
+        rows = base.unsqueeze(1).expand_as(self.idx)[valid]
         return torch.sparse_coo_tensor(torch.stack([rows, self.idx[valid].long()]), self._values[valid], self.shape)
+
+    def to_csr(self):
+        """CsrAdjacency with the stored entries (idx >= 0) as its pattern and the same (differentiable) values: rows of any width for
+        the layers that take the learned graph as a separate module"""
+        valid = self.idx >= 0
+        base = torch.arange(self.idx.shape[0], device=self.device) if self.layout is None else self._chunk_rows()
+        erow = base.unsqueeze(1).expand_as(self.idx)[valid]
+        rowptr = torch.zeros(self.shape[0] + 1, device=self.device, dtype=torch.int64)
+        rowptr[1:] = torch.bincount(erow, minlength=self.shape[0]).cumsum(0)
+        return CsrAdjacency(rowptr, self.idx[valid].contiguous(), erow.to(torch.int32).contiguous(), self._values[valid], self.shape[0], k=self.k)
 
     # --- fast path -------------------------------------------------------------------------------------------
     def row_sums(self):
         if self.rs is None:
-            self.rs = self._values.detach().sum(1)
+            per = self._values.detach().sum(1)
+            self.rs = per if self.layout is None else torch.zeros(self.shape[0], device=self.device, dtype=per.dtype).index_add_(0, self._chunk_rows(), per)
         return self.rs
 
     def normalize(self):
         """D^-1/2 A D^-1/2 with ROW sums on both sides (normalize_adj, model.py:1205-1219)."""
+        if self.layout is not None:              # chunked rows as a separate module: the CSR kernels (rows of any width)
+            return self.to_csr().normalize()
         rs = self.row_sums()
         ahat = ops.EllNormalizeFn.apply(self._values, self.idx, rs, self.part)
         return EllAdjacency(self.idx, ahat, self.n_cols, rs=None, k=self.k, score=self.score, normalized=True, part=self.part,
@@ -77,7 +102,10 @@ class EllAdjacency:
     def matmul(self, X, act=ops.ACT_NONE):
         """act(A @ X) (torch.mm(adj, x), model.py:594; act = ReLU fuses GCNConv's activation into the aggregation)."""
         # weights produced by the DGG ramp: an exact zero is a saturated ramp whose gradient vanishes too
-        return ops.EllSpmmFn.apply(self._values, self.idx, X, self.k is not None, self.part, act, self.partp)
+        if self.layout is not None and self.partp is None:
+            out = self.to_csr().matmul(X)
+            return torch.relu(out) if act == ops.ACT_RELU else out
+        return ops.EllSpmmFn.apply(self._values, self.idx, X, self.k is not None, self.part, act, self.partp, self.layout)
 
     __matmul__ = matmul
 

@@ -1462,6 +1462,14 @@ __global__ __launch_bounds__(PP_T) void pp_sort(const int *__restrict__ bstart, 
     }
 }
 
+// dA_rec[e] = dA[slot of record e]: a row-major cotangent [rows,64] brought into the record order of a built payload partition (for
+// callers that hold d loss / d w by rows -- the generator as a separate module -- and want the per-destination score backward)
+__global__ void pp_gather_rec(const int *__restrict__ bstart, int nb, const int4 *__restrict__ recs, const float *__restrict__ dA,
+                              float *__restrict__ dA_rec) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < bstart[nb]) dA_rec[e] = dA[recs[e].x];
+}
+
 }  // namespace
 
 const int *dgg_part_slotmap(const void *part_ws, int64_t rows, int K, int64_t ncols) {
@@ -1920,6 +1928,16 @@ int dgg_softk_edge_bwd_partp_chunked(const float *xp, int64_t rows, const int32_
     }
 #undef DGG_EDGE_PARTC
     return dgg_check_launch("softk_edge_bwd_partp_chunked");
+}
+
+// dA [rows,64] (row-major; chunked rows: [chunks,64]) -> dA_rec [rows*64] in the record order of a built payload partition (K = 64)
+int dgg_partp_gather_rec(const float *dA, int64_t rows, int64_t ncols, const void *partp_ws, float *dA_rec, void *stream) {
+    if (!dA || !dA_rec || !partp_ws || dgg_partp_ws_bytes(rows, 64, ncols) == 0) return dgg_set_error(DGG_ERR_ARG, "partp_gather_rec: missing operand or no partition");
+    if (rows == 0) return 0;
+    PartP2 p;
+    partp2_layout(p, const_cast<void *>(partp_ws), rows, 64, ncols);
+    hipLaunchKernelGGL(pp_gather_rec, dim3((unsigned)((rows * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.bstart, (int)p.nb, p.recs, dA, dA_rec);
+    return dgg_check_launch("partp_gather_rec");
 }
 
 // normalisation backward phase 1 through the partition; da [ncols] zeroed by the caller

@@ -152,6 +152,33 @@ class _DGGSoftAdjXpFn(torch.autograd.Function):
         return dxp, dk, None
 
 
+class _DGGWideAdjFn(torch.autograd.Function):
+    """_DGGSoftAdjXpFn on CHUNKED rows: all-pairs candidates under the ranked noise generator whose learned degrees outgrew the 64-rank
+    list.  The reference ramps over the whole dense row with an unbounded learned degree (dgm.py:1402-1421, 1580-1584); here row i
+    keeps its ceil(k_i + 8.5) + 1 ranks in chunks of 64 (cfg["layout"], ops.chunk_layout).  Backward: the row-major cotangent is
+    brought into the record order of the payload partition and the score backward runs by rows and by destination (no atomics)."""
+
+    @staticmethod
+    def forward(ctx, xp, k, cfg):
+        lay = cfg["layout"]
+        idx, val, w, rs = ops.allpairs_topk_wide(xp, k, lay, cfg.get("fwd_mode", cfg["mode"]), cfg["t"], cfg["seed"])
+        ctx.cfg = cfg
+        cfg["partp"] = ops.partp_build(idx, w, val, rs, xp.shape[0], layout=lay) if any(ctx.needs_input_grad) else None
+        ctx.save_for_backward(xp, k, idx, val)
+        ctx.mark_non_differentiable(idx, val, rs)
+        return w, idx, val, rs
+
+    @staticmethod
+    def backward(ctx, dw, *_):
+        xp, k, idx, val = ctx.saved_tensors
+        cfg = ctx.cfg
+        partp = cfg["partp"]
+        assert partp is not None, "chunked rows: no payload partition for this shape"
+        dw = dw.contiguous()
+        dxp, dk = ops.softk_edge_bwd_p(xp, idx, val, k, dw, ops.partp_gather(partp, dw), None, None, 0, cfg["t"], True, cfg["mode"], False, partp)
+        return dxp, dk, None
+
+
 class _DGGSoftAdjFn(torch.autograd.Function):
     """x, learned k, projection parameters -> soft (unnormalised) ELL adjacency values: projection, u-v-dist scoring +
     perturbation + top-K, ramp (reference dgm.py:1197-1292)."""
@@ -487,6 +514,12 @@ class DGG_LearnableK_debug(nn.Module):
                                "the module switch by itself) is cheaper on such data"))
                 if auto and many:
                     self._sym_generator = "hash"
+        wm = self.__dict__.get("_wide_meta")
+        if wm is not None and not torch.cuda.is_current_stream_capturing():
+            self._wide_meta = None
+            if int(wm[2]) != 0:
+                raise RuntimeError("DGG_LearnableK_debug: the chunked rows of a captured step outgrew the capacity they were captured with "
+                                   f"(chunks needed {int(wm[0])}, widest row {int(wm[1])} chunks): run one eager forward and capture again")
         flag = self.__dict__.get("_overflow_dev")
         if flag is not None and not torch.cuda.is_current_stream_capturing() and bool(flag.item()):
             flag.zero_()
@@ -497,7 +530,8 @@ class DGG_LearnableK_debug(nn.Module):
                 f"DGG_LearnableK_debug: a row's learned degree satisfies k + 8.5 > ell_width = {self.ell_width} while it has more "
                 "candidates than that: ranks the reference still weights were dropped (row sums, normalisation and gradients "
                 "differ from the reference from here on).  Edge-list candidates: set args.dgg_wide_rows = 'csr' (rows of any width; "
-                "'auto' picks it whenever a row would lose weight, except inside a hipGraph capture).  All-pairs candidates: rescale the degree prior / k_project.")
+                "'auto' picks it whenever a row would lose weight, except inside a hipGraph capture).  All-pairs candidates: "
+                "args.dgg_wide_rows = 'auto' keeps every weighted rank in chunked rows (ranked noise generator; one eager forward before a capture).")
 
     def _sym_generator_now(self):
         """generator for symmetric noise in the next forward: "ranked" | "hash".  args.dgg_sym_generator: "ranked" (default), "hash", or
@@ -572,7 +606,7 @@ class DGG_LearnableK_debug(nn.Module):
             cand, deg, rowptr = None, in_adj.prior_degree, None
             if self.__dict__.get("_ap_wide", {}).get("on") or (getattr(a, "dgg_wide_rows", "auto") == "csr" and
                                                                x.shape[0] <= int(getattr(a, "dgg_allpairs_csr_max", 8192))):
-                return None                                   # (already known: this graph's learned degrees need every column ranked)
+                return None                                   # (policy "csr": every column ranked, the modules' CSR form)
         else:
             if isinstance(in_adj, EllAdjacency):
                 in_adj = in_adj.to_sparse().detach()
@@ -609,6 +643,19 @@ class DGG_LearnableK_debug(nn.Module):
             layer = self.__dict__["_fused_layer"] = ShardedDGGConv(ops, N, K=64, t=ops.T_DIST)
         layer.cand, layer.noise_mode, layer.seed, layer.mode, layer.scorer = cand, noise_mode, seed, mode, None
         layer.x_grad = bool(x.requires_grad)
+        # all-pairs rows wider than the 64-rank list (learned degrees k_i + 9.5 > 64): chunked rows inside the engine, from the forward
+        # that first needs them (one readback of the chunk count per forward; a hipGraph capture replays the last eager layout)
+        chunked = cand is None and self._chunk_policy(noise_mode)
+        layer.wide_rows = "auto" if chunked else "off"
+        layer.wide_cap = None
+        if chunked and torch.cuda.is_current_stream_capturing():
+            # nothing can be read back under capture: the layout of the last eager forward on this module, with some slack, becomes a
+            # FIXED capacity whose overflow flags check_ell_bound() reads; no wide row then: the list, with its enforced bound
+            last = getattr(layer, "last_layout", None)
+            layer.wide_cap = None if last is None or last[0] == N else (last[0] + last[0] // 8 + 64, min(ops.CHUNK_MAXM, last[1] + 1))
+            if layer.wide_cap is None:
+                layer.wide_rows = "off"
+        chunk_active = chunked and layer.wide_rows == "auto" and layer.wide_cap is None    # (this forward reads the layout back)
         if cand is not None and not mlp_mode:                 # the ELL-width bound is tested inside the search kernel (no extra launches)
             flag = self.__dict__.get("_overflow_dev")
             if flag is None or flag.device != x.device:
@@ -632,23 +679,39 @@ class DGG_LearnableK_debug(nn.Module):
             if not mlp_mode:
                 layer.overflow.zero_()
             return None
-        if cand is None and self._allpairs_wide(N, k):
+        lay = st.get("layout")
+        if cand is None and lay is None and not chunk_active and self._allpairs_wide(N, k):
             return None                                       # learned degrees beyond the list: the modules' CSR form (every column ranked)
-        if cand is None:
+        if cand is None and lay is None and not chunk_active:
             self._track_overflow(k, None)
+        elif cand is None and layer.wide_cap is not None:     # fixed capacity (capture): its overflow flags join the module's
+            prev = self.__dict__.get("_wide_meta")
+            self._wide_meta = layer.wide_meta if prev is None else torch.maximum(prev, layer.wide_meta)
         elif mlp_mode:
             ent = self.__dict__.get("_wide_cache", {}).get(id(in_adj))
             if not (ent is not None and ent[0]() is in_adj and ent[1] <= self.ell_width):     # (no row can outgrow the list otherwise)
                 self._track_overflow(k, rowptr[1:] - rowptr[:-1])
         elif __import__("os").environ.get("DGG_STRICT_BOUND") == "1":
             self.check_ell_bound()
-        unnorm = EllAdjacency(st["idx"], st["w"], N, rs=st["rs"], k=k, score=st["val"], owner=self)
+        unnorm = EllAdjacency(st["idx"], st["w"], N, rs=st["rs"], k=k, score=st["val"], owner=self, layout=lay)
         if not want_norm:
             return Z, unnorm
         if st.get("side_join"):                               # the partition's sort ran on the layer's side stream: a later layer's
             torch.cuda.current_stream().wait_stream(layer._side_stream())     # backward reads it BEFORE this node's own backward joins
             st["side_join"] = False
-        return Z, unnorm, EllAdjacency(st["idx"], ahat, N, k=k, score=st["val"], normalized=True, owner=self, partp=(st["partp"], st["rs"]))
+        return Z, unnorm, EllAdjacency(st["idx"], ahat, N, k=k, score=st["val"], normalized=True, owner=self, partp=(st["partp"], st["rs"]),
+                                       layout=lay)
+
+    def _chunk_policy(self, noise_mode):
+        """All-pairs rows wider than the 64-rank list as CHUNKED rows (ops.chunk_layout; any learned degree up to 2038, any graph size)?
+        They need the ranked generator (asymmetric noise: the search settles ceil(k_i + 8.5) + 1 ranks per row) on latent widths 16-128.
+        args.dgg_wide_rows: "auto" (default) / "chunked" yes; "csr": the complete candidate pattern in CSR form instead (graphs of at
+        most args.dgg_allpairs_csr_max nodes, every column ranked; "csr_auto": from the forward that first needs it); "ell": the
+        64-rank list with the enforced bound.  Explicit noise, the per-pair hash generators and unperturbed scores keep the CSR form
+        (they have no early-stopping search to widen)."""
+        policy = getattr(self.args, "dgg_wide_rows", "auto")
+        return (policy in ("auto", "chunked") and noise_mode == ops.NOISE_RANKED and self.ell_width == 64
+                and self.latent_dim in (16, 32, 64, 128) and self.edge_prob_net_mode == "u-v-dist")
 
     def _track_overflow(self, k, ncand):
         over = k.detach() + 8.5 > float(self.ell_width)
@@ -718,7 +781,7 @@ class DGG_LearnableK_debug(nn.Module):
         while the list is still in use; a hipGraph capture replays the last decision), "csr" (always), "ell" (never: the bound is
         enforced by check_ell_bound).  Larger graphs keep the list and the enforced bound."""
         policy = getattr(self.args, "dgg_wide_rows", "auto")
-        if policy == "ell" or N > int(getattr(self.args, "dgg_allpairs_csr_max", 8192)):
+        if policy in ("ell", "chunked") or N > int(getattr(self.args, "dgg_allpairs_csr_max", 8192)):
             return False
         if policy == "csr":
             return True
@@ -932,7 +995,23 @@ class DGG_LearnableK_debug(nn.Module):
         if cand is not None and not literal and self._wide_rows(in_adj, rowptr, k):
             # rows wider than the ELL and learned degrees that may exceed it: the CSR form (no width limit)
             return self._csr_soft_adjacency(x, in_adj, k, noise_mode, G, seed, cfg["mode"])
-        if cand is None and not literal and self.edge_prob_net_mode == "u-v-dist" and self._allpairs_wide(x.shape[0], k):
+        if cand is None and not literal and self._chunk_policy(noise_mode) and not torch.cuda.is_current_stream_capturing():
+            # learned degrees beyond the 64-rank list: chunked rows (same generator, same search, ceil(k_i + 8.5) + 1 ranks per row)
+            lay = ops.chunk_layout(k.detach())                # (one readback: the chunk count sizes the arrays)
+            if lay.wide:
+                cfg["layout"] = lay
+                xp = xp_dual if xp_dual is not None else ops.LinearFn.apply(x, We, be, ops.ACT_LEAKY, 0)
+                w, idx, val, rs = _DGGWideAdjFn.apply(xp, k, cfg)
+                if writer is not None:
+                    f = w.detach() if (cfg["mode"] == ops.MODE_K_ONLY or "fwd_mode" in cfg) else (w.detach() / val.clamp(min=1e-30))
+                    fs = torch.zeros(x.shape[0], device=x.device).index_add_(0, lay.cnode.long(), f.sum(-1))
+                    writer.add_scalar("values/first_k_std", fs.std(), epoch)
+                    writer.add_scalar("values/first_k_mean", fs.mean(), epoch)
+                return EllAdjacency(idx, w, x.shape[0], rs=rs, k=k.detach(), score=val, owner=self, layout=lay)
+            chunk_checked = True
+        else:
+            chunk_checked = False
+        if cand is None and not literal and self.edge_prob_net_mode == "u-v-dist" and not chunk_checked and self._allpairs_wide(x.shape[0], k):
             # learned degrees beyond the list on all-pairs candidates: every column ranked, CSR form (per-pair hash noise: the ranked
             # generators produce a row's noise in decreasing order for a search that stops early -- here nothing stops early)
             nm = {ops.NOISE_RANKED: ops.NOISE_HASH, ops.NOISE_RANKED_SYM: ops.NOISE_HASH_SYM}.get(noise_mode, noise_mode)
@@ -947,7 +1026,8 @@ class DGG_LearnableK_debug(nn.Module):
             w, idx, val, rs = _DGGEdgeMlpAdjFn.apply(x, k, deg, ex_in, We, be, mlp["Wcat"], mlp["wdu"], mlp["wdv"], mlp["wex"],
                                                      mlp["b1"], mlp["w2"], mlp["b2"], cfg)
         k = k.detach()
-        self._track_overflow(k, None if cand is None else (rowptr[1:] - rowptr[:-1]))
+        if not chunk_checked:                    # (chunk_checked: the layout just read back says every row fits the list)
+            self._track_overflow(k, None if cand is None else (rowptr[1:] - rowptr[:-1]))
         if cfg.get("rsym_err") is not None:
             prev = self.__dict__.get("_rsym_err")
             self._rsym_err = cfg["rsym_err"] if prev is None else (prev | cfg["rsym_err"])

@@ -1034,6 +1034,15 @@ def partp_sort(part):
     part.args = None
 
 
+def partp_gather(partp, dA):
+    """row-major dA [rows,64] (chunked rows: [chunks,64]) -> the same values in the record order of the payload partition [rows*64]"""
+    dA = _chk(dA)
+    assert tuple(dA.shape) == (partp.rows, 64) and partp.K == 64
+    dA_rec = torch.empty((partp.rows * 64,), device=dA.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dgg_partp_gather_rec(_ptr(dA), partp.rows, partp.ncols, _ptr(partp.ws), _ptr(dA_rec), _stream()), "partp_gather_rec")
+    return dA_rec
+
+
 def conv_bwd_cols_p(idx, H, G, partp, rs, zero_dA=True, dA_ext=None, want_dA=True):
     """conv_bwd_cols on a payload partition -> dA [rows,K], dA_rec [rows*K], dH [ncols,F], da [ncols] (neighbour side); None when
     the kernel does not cover the shape.  zero_dA=False: entries outside the partition are left UNINITIALISED -- for a consumer that
@@ -1427,10 +1436,11 @@ class EllSpmmFn(torch.autograd.Function):
     aggregates the projected features, relu(A (x W)))."""
 
     @staticmethod
-    def forward(ctx, ahat, idx, X, skip_zero=False, part=None, act=ACT_NONE, partp=None):
-        Y = spmm_fwd(idx, ahat, X, act)
+    def forward(ctx, ahat, idx, X, skip_zero=False, part=None, act=ACT_NONE, partp=None, layout=None):
+        # layout (ChunkLayout): ahat / idx are the [chunks,64] arrays of chunked rows (rows wider than 64 ranks), Y [layout.rows, F]
+        Y = spmm_fwd(idx, ahat, X, act, layout=layout)
         ctx.save_for_backward(ahat, idx, X, Y if act != ACT_NONE else X)
-        ctx.skip_zero, ctx.part, ctx.act, ctx.partp = skip_zero, part, act, partp
+        ctx.skip_zero, ctx.part, ctx.act, ctx.partp, ctx.layout = skip_zero, part, act, partp, layout
         return Y
 
     @staticmethod
@@ -1439,19 +1449,29 @@ class EllSpmmFn(torch.autograd.Function):
         dY = dY.contiguous()
         if ctx.act != ACT_NONE:
             dY = act_bwd(Y, dY, ctx.act)
+        lay = ctx.layout
+        if lay is not None and lay.wide:
+            if ctx.skip_zero and ctx.partp is not None and X.shape[0] == lay.rows:
+                got = conv_bwd_cols_p(idx, X, dY, ctx.partp[0], ctx.partp[1], zero_dA=True)       # (chunk-aware through the partition's layout)
+                if got is not None:
+                    return got[0], None, (got[2] if ctx.needs_input_grad[2] else None), None, None, None, None, None
+            # every chunk as a row of its own against the cotangent row of its node
+            dYc = dY.index_select(0, lay.cnode.long()[:idx.shape[0]])
+            dA, dX = spmm_bwd(idx, ahat, X, dYc, need_dx=ctx.needs_input_grad[2], skip_zero=ctx.skip_zero)
+            return dA, None, dX, None, None, None, None, None
         if ctx.needs_input_grad[2] and ctx.skip_zero and ctx.partp is not None and X.shape[0] == idx.shape[0]:
             # the adjacency of the fused layer, read by a later layer: the same per-destination kernel as the layer's own aggregation
             # backward (the records carry the normalised values): dA by plain stores, dX owned by the destination's wavefront
             got = conv_bwd_cols_p(idx, X, dY, ctx.partp[0], ctx.partp[1], zero_dA=True)
             if got is not None:
-                return got[0], None, got[2], None, None, None, None
+                return got[0], None, got[2], None, None, None, None, None
         if ctx.needs_input_grad[2] and ctx.skip_zero and X.shape[0] == idx.shape[0]:
             # learned input on a DGG adjacency: SDDMM and transposed SpMM from ONE gathered cotangent row per entry
             got = conv_bwd_cols(idx, ahat, X, dY, ctx.part)
             if got is not None:
-                return got[0], None, got[1], None, None, None, None
+                return got[0], None, got[1], None, None, None, None, None
         dA, dX = spmm_bwd(idx, ahat, X, dY, need_dx=ctx.needs_input_grad[2], skip_zero=ctx.skip_zero, part=ctx.part)
-        return dA, None, dX, None, None, None, None
+        return dA, None, dX, None, None, None, None, None
 
 
 class CsrNormalizeFn(torch.autograd.Function):

@@ -156,3 +156,150 @@ def test_chunked_step_matches_the_oracle(dev):
     layer3, *_ = _wide_step(dev, N, d, h, cap=(lay.chunks - 5, 4))
     with pytest.raises(RuntimeError, match="capacity"):
         layer3.check_wide()
+
+
+def _args(**kw):
+    from argparse import Namespace
+    base = dict(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+                dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True, symmetric_noise=False,
+                stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
+    base.update(kw)
+    return Namespace(**base)
+
+
+def _ranked_noise(N, seed):
+    import ctypes as C
+    G = np.empty((N, N), np.float32)
+    L = O.lib()
+    for i in range(N):
+        L.ora_ranked_row(C.c_uint32(seed[0]), C.c_uint32(seed[1]), C.c_uint32(i), C.c_int64(N), O._p(G[i]))
+    return G
+
+
+@pytest.mark.parametrize("mode", ["k_times_edge_prob", "k_only"])
+def test_module_chunked_rows_match_the_dense_formulation(dev, mode):
+    """DGG_LearnableK_debug on all-pairs candidates with a degree prior of ~90 (ceil(k + 8.5) ~ 100 ranks per row: two chunks) as a
+    SEPARATE module: the returned adjacency (EllAdjacency with a chunk layout) densified, and its autograd, against the reference-
+    shaped dense formulation in float64 (oracle/dense_ref.py: sort of the whole row + ramp, dgm.py:1402-1435) fed with the ranked
+    generator's own noise matrix: every entry 1e-5 (near-tie rank swaps excepted, as for the CSR form), every gradient 2e-4.  A prior
+    of ~19 on the same nodes stays on the 64-rank list."""
+    import dgg_amd
+    from oracle import dense_ref as D
+    N, d, h = 400, 24, 16
+    torch.manual_seed(1)
+    m = dgg_amd.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=_args(dgg_mode_k_select=mode)).to(dev)
+    with torch.no_grad():
+        m.k_net.k_project.weight.mul_(0.3)
+    m.set_seed(4321, 17)
+    x = torch.randn(N, d, generator=torch.Generator().manual_seed(2)).to(dev).requires_grad_(True)
+    deg = 90.0 * (1 + 0.1 * torch.randn(N, generator=torch.Generator().manual_seed(3)))
+    small = m(x.detach(), dgg_amd.AllPairs((deg * 0.2).to(dev)))
+    assert isinstance(small, dgg_amd.EllAdjacency) and small.layout is None
+    m.check_ell_bound()
+    adj = m(x, dgg_amd.AllPairs(deg.to(dev)))
+    assert isinstance(adj, dgg_amd.EllAdjacency) and adj.layout is not None and adj.layout.maxm == 2
+    kk = Nn(adj.k)
+    assert kk.max() + 8.5 > 64
+    dense = adj.to_dense()
+    assert tuple(dense.shape) == (N, N)
+    cot = torch.randn(N, N, generator=torch.Generator().manual_seed(4)).to(dev)
+    (dense * cot).sum().backward()
+    P = {"We": m.node_encode_for_edges[0].weight, "be": m.node_encode_for_edges[0].bias, "Wk": m.node_encode_for_k[0].weight,
+         "bk": m.node_encode_for_k[0].bias, "W1": m.k_embed[0].weight, "b1": m.k_embed[0].bias, "Wmu": m.k_net.k_mu.weight,
+         "bmu": m.k_net.k_mu.bias, "Wp": m.k_net.k_project.weight, "bp": m.k_net.k_project.bias}
+    Pd = {k_: v.detach().cpu().double().requires_grad_(True) for k_, v in P.items()}
+    xd = x.detach().cpu().double().requires_grad_(True)
+    G = torch.from_numpy(_ranked_noise(N, (4321, 17))).double()
+    rows, cols = torch.arange(N).repeat_interleave(N), torch.arange(N).repeat(N)
+    Ad, kd = D.dgg_dense(xd, rows, cols, deg.double(), Pd, G)
+    if mode == "k_only":                                     # (dgm.py:1423-1435: the ramp alone at the sorted positions)
+        p = torch.exp(torch.log(torch.exp(-0.05 * torch.cdist(torch.nn.functional.leaky_relu(torch.nn.functional.linear(xd, Pd["We"], Pd["be"])),
+                                                             torch.nn.functional.leaky_relu(torch.nn.functional.linear(xd, Pd["We"], Pd["be"])),
+                                                             compute_mode="donot_use_mm_for_euclid_dist")) + 1e-8) + G)
+        order = torch.sort(p, dim=-1, descending=True).indices
+        ramp = 1 - 0.5 * (1 + torch.tanh(torch.arange(N, dtype=torch.float64)[None, :] - kd[:, None]))
+        Ad = torch.zeros_like(p).scatter(1, order, ramp)
+    np.testing.assert_allclose(kk, kd.detach().numpy(), rtol=1e-5, atol=1e-4)
+    diff = np.abs(Nn(dense) - Ad.detach().numpy())
+    nswap = int((diff > 1e-5).sum())
+    assert nswap <= 4 and diff.max() < 2e-2, (nswap, diff.max())
+    gtol = 2e-4 if nswap == 0 else 2e-3
+    (Ad * cot.cpu().double()).sum().backward()
+    for k_, v in P.items():
+        if Pd[k_].grad is None:
+            continue
+        ref = Pd[k_].grad.numpy()
+        err = np.abs(Nn(v.grad).reshape(ref.shape) - ref).max() / max(np.abs(ref).max(), 1e-12)
+        assert err <= gtol, f"grad {k_}: {err:.3e}"
+    err = np.abs(Nn(x.grad) - xd.grad.numpy()).max() / np.abs(xd.grad.numpy()).max()
+    assert err <= gtol, f"grad x: {err:.3e}"
+    # the same adjacency through the layers that take it as a separate module: normalize_adj + aggregation on the CSR kernels
+    na = adj.normalize()
+    y = na.matmul(x.detach())
+    Ahat = D.normalize_dense(Ad.detach())
+    np.testing.assert_allclose(Nn(y), (Ahat @ xd.detach()).numpy(), rtol=1e-4, atol=2e-5 + 1e-3 * (nswap > 0))
+
+
+@pytest.mark.parametrize("hard", [False, True])
+def test_gcn_dgg_chunked_fused_layer_matches_the_separate_modules(dev, hard):
+    """GCN_DGG on all-pairs candidates whose learned degrees need two to three chunks: the fused first layer (generator + normalize_adj
+    + GCNConv as one node on the step engine, the second layer reading the same chunked adjacency) against the separate modules
+    (chunked generator -> CSR normalise / aggregate): same lists, log-probabilities 1e-5, every parameter gradient 3e-4"""
+    import dgg_amd
+    N, d, h, C = 1800, 48, 32, 7
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, d, generator=g).to(dev)
+    deg = (60 + 90 * torch.rand(N, generator=g)).to(dev)
+    y = torch.randint(0, C, (N,), generator=g).to(dev)
+    outs = []
+    for fused in ([True, False] if not hard else [False]):
+        torch.manual_seed(11)
+        m = dgg_amd.GCN_DGG(nfeat=d, nhidden=h, nclass=C, args=_args(dgg_fused_layer=fused, dgg_hard=hard)).to(dev).eval()
+        m.dggs[0].set_seed(99, 1)
+        logp, adj, _ = m(x, dgg_amd.AllPairs(deg))
+        assert isinstance(adj, dgg_amd.EllAdjacency) and adj.layout is not None and adj.layout.maxm >= 2
+        loss = torch.nn.functional.nll_loss(logp, y)
+        loss.backward()
+        m.dggs[0].check_ell_bound()
+        assert torch.isfinite(logp).all()
+        outs.append((logp.detach(), adj, {n_: p_.grad.detach().clone() for n_, p_ in m.named_parameters() if p_.grad is not None}))
+    if hard:
+        return                                               # (straight-through values on chunked rows: runs, finite)
+    (lf, af, gf), (ls, as_, gs) = outs
+    assert torch.equal(af.idx, as_.idx), "fused layer and separate modules disagree on the neighbour lists"
+    np.testing.assert_allclose(Nn(lf), Nn(ls), rtol=1e-5, atol=1e-5)
+    assert set(gf) == set(gs)
+    for n_ in gf:
+        err = float((gf[n_] - gs[n_]).abs().max() / gs[n_].abs().max().clamp(min=1e-30))
+        assert err <= 3e-4, f"grad {n_}: {err:.3e}"
+
+
+def test_learned_degrees_keep_training_on_chunked_rows(dev):
+    """GCN_DGG on all-pairs candidates, the script's optimiser groups (train_small_graphs.py:399-418): Adam moves the learned degrees
+    past the 64-rank list within a few steps (k = relu(kp sd + mu) + 1 is unbounded, dgm.py:1580-1584).  From that forward on the
+    rows are chunked -- same generator, same search -- and training goes on: no bound, nothing raised, the loss falls."""
+    import dgg_amd
+    N, d, h, C = 3000, 64, 64, 7
+    g = torch.Generator().manual_seed(5)
+    deg = 24 + 16 * torch.rand(N, generator=g)
+    x = torch.randn(N, d, generator=g)
+    y = (x[:, :C] + 0.3 * torch.randn(N, C, generator=g)).argmax(1).to(dev)
+    x = x.to(dev)
+    A = dgg_amd.AllPairs(deg.to(dev))
+    torch.manual_seed(11)
+    m = dgg_amd.GCN_DGG(nfeat=d, nhidden=h, nclass=C, args=_args()).to(dev).train()
+    opt = torch.optim.Adam([{"params": m.params1, "weight_decay": 0.01}, {"params": m.params2, "weight_decay": 5e-4}], lr=0.01)
+    hist = []
+    for step in range(40):
+        opt.zero_grad()
+        logp, adj, _ = m(x, A)
+        loss = torch.nn.functional.nll_loss(logp, y)
+        loss.backward()
+        hist.append((float(adj.k.max()), adj.layout is not None, float(loss.detach())))
+        m.dggs[0].check_ell_bound()
+        opt.step()
+    first = next((s_ for s_, (km, _, _) in enumerate(hist) if km + 9.5 > 64), None)
+    print("learned degrees exceed the list from step", first, "; k_max after 40 steps", hist[-1][0], "; loss", hist[0][2], "->", hist[-1][2])
+    assert first is not None and 1 <= first < 20
+    assert all(not w_ for _, w_, _ in hist[:first]) and all(w_ for _, w_, _ in hist[first:])
+    assert hist[-1][0] > 100 and np.isfinite(hist[-1][2]) and hist[-1][2] < hist[0][2]

@@ -2321,10 +2321,15 @@ def test_ell_width_bound_is_enforced(dev):
     with pytest.raises(RuntimeError, match="ell_width"):
         m.check_ell_bound()
     m.check_ell_bound()                                           # the flag is cleared once reported
-    m.args.dgg_wide_rows = "auto"                                 # the default: a graph of this size ranks every column instead (CSR form)
+    m.args.dgg_wide_rows = "auto"                                 # the default: chunked rows (ceil(k + 8.5) + 1 ranks of every row)
+    adj = m(x, dgg_amd.AllPairs(torch.full((256,), 90.0, device=dev)))
+    assert isinstance(adj, dgg_amd.EllAdjacency) and adj.layout is not None
+    m.check_ell_bound()
+    m.args.dgg_wide_rows = "csr_auto"                             # or: a graph of this size ranks every column (CSR form)
     assert isinstance(m(x, dgg_amd.AllPairs(torch.full((256,), 90.0, device=dev))), dgg_amd.CsrAdjacency)
     m.check_ell_bound()
     m.__dict__.pop("_ap_wide")                                    # (the decision is sticky per module)
+    m.args.dgg_wide_rows = "auto"
     # edge-list candidates: rows with at most 64 candidates are exact whatever k is
     rows = np.repeat(np.arange(256), 8)
     cols = (rows + np.tile(np.arange(8), 256)) % 256
@@ -2395,17 +2400,18 @@ def test_fused_layer_with_edge_mlp_scorer_and_wide_rows(dev):
 
 @pytest.mark.parametrize("prior", ["bounded", "cora"])
 def test_learned_degrees_of_a_trained_model_and_the_all_pairs_list(dev, prior):
-    """The all-pairs generator keeps 64 ranks per row, exact while k_i + 8.5 <= 64; k = relu(kp sd + mu) + 1
+    """The all-pairs generator's 64-rank list is exact while k_i + 8.5 <= 64; k = relu(kp sd + mu) + 1
     with (mu, sd) the statistics of the prior degrees (dgm.py:1569-1584) is unbounded and the loss moves it.  GCN_DGG on all-pairs
     candidates, the script's optimiser settings (train_small_graphs.py:399-418; labels that correlate with the features):
       bounded   prior degrees 24..40 (the synthetic configs of BASELINE.json): inside the bound at initialisation, past it within a
                 few steps (observed: step 6, k_max 61);
       cora      a heavy-tailed prior with Cora's statistics (mean 3.90, std 5.29, hubs of 168 = 31 sigma of the k-net's degree
                 input, train_small_graphs.py:122-133): past it just as fast, in the hundreds after 60 steps.
-    A graph of this size (N <= args.dgg_allpairs_csr_max = 8192) then takes select_top_k on the COMPLETE candidate pattern in CSR form
-    -- every column ranked, as the reference's dense rows are -- from the forward in which the bound is first exceeded: training goes on,
-    the returned adjacency becomes a CsrAdjacency, check_ell_bound() never fires.  Larger graphs keep the list: there the same
-    forward raises instead of truncating (forced here with dgg_allpairs_csr_max = 100)."""
+    Default policy (args.dgg_wide_rows = "auto"): CHUNKED rows from that forward on (tests/test_chunked_rows.py).  Policy "csr" (this
+    test): a graph of at most args.dgg_allpairs_csr_max = 8192 nodes takes select_top_k on the COMPLETE candidate pattern in CSR form
+    -- every column ranked, as the reference's dense rows are -- from the forward in which the bound is first exceeded: training goes
+    on, the returned adjacency becomes a CsrAdjacency, check_ell_bound() never fires.  Policy "ell" keeps the list: there the same
+    forward raises instead of truncating."""
     import dgg_amd
     from argparse import Namespace
     N, d, h, C = 3000, 64, 64, 7
@@ -2422,10 +2428,10 @@ def test_learned_degrees_of_a_trained_model_and_the_all_pairs_list(dev, prior):
     x = x.to(dev)
     A = dgg_amd.AllPairs(deg.to(dev))
 
-    def run(csr_max, steps):
+    def run(policy, steps):
         args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=mean, deg_std=std, dgg_mode_edge_net="u-v-dist",
                          dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
-                         symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1, dgg_allpairs_csr_max=csr_max)
+                         symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1, dgg_wide_rows=policy)
         torch.manual_seed(11)
         m = dgg_amd.GCN_DGG(nfeat=d, nhidden=h, nclass=C, args=args).to(dev).train()
         opt = torch.optim.Adam([{"params": m.params1, "weight_decay": 0.01}, {"params": m.params2, "weight_decay": 5e-4}], lr=0.01)
@@ -2440,14 +2446,14 @@ def test_learned_degrees_of_a_trained_model_and_the_all_pairs_list(dev, prior):
             opt.step()
         return hist
 
-    hist = run(8192, 40)
+    hist = run("csr_auto", 40)
     first = next((s_ for s_, (km, _, _) in enumerate(hist) if km + 8.5 > 64), None)
     print(prior, "prior: learned degrees exceed the list from step", first, "; k_max after 40 steps", hist[-1][0], "; loss", hist[0][2], "->", hist[-1][2])
     assert first is not None and first >= 1, "inside the list at initialisation, past it within 40 steps"
     assert all(t_ == "EllAdjacency" for _, t_, _ in hist[:first]) and all(t_ == "CsrAdjacency" for _, t_, _ in hist[first:])
     assert np.isfinite(hist[-1][2]) and hist[-1][2] < hist[0][2]
-    with pytest.raises(RuntimeError, match="ell_width"):               # a graph too large for the complete pattern: not silent
-        run(100, first + 1)
+    with pytest.raises(RuntimeError, match="ell_width"):               # the list alone: not silent
+        run("ell", first + 1)
 
 
 @pytest.mark.parametrize("perturb", [False, True])
