@@ -303,3 +303,106 @@ def test_learned_degrees_keep_training_on_chunked_rows(dev):
     assert first is not None and 1 <= first < 20
     assert all(not w_ for _, w_, _ in hist[:first]) and all(w_ for _, w_, _ in hist[first:])
     assert hist[-1][0] > 100 and np.isfinite(hist[-1][2]) and hist[-1][2] < hist[0][2]
+
+
+def test_full_size_chunked_step(dev):
+    """BASELINE size (N = 100 000, d = 128, h = 64) with learned degrees far beyond the list (k ~ 134 on average, k_max > 256: rows of
+    1-5 chunks): 256 sampled rows of the chunked search against the oracle (which scores all N columns of a row) bit for bit --
+    indices, scores, weights, row sums --, list invariants over the whole graph, Z on the sampled rows, and the gradient of EVERY
+    parameter against the oracle's backward over the WHOLE graph (2e-4 of max)."""
+    import bench
+    from dgg_amd import ops
+    from dgg_amd.parallel import ShardedDGGConv
+    from test_hip_parity import _full_size_gradient_parity
+    N, d, h = 100_000, 128, 64
+    P = bench.make_params(d, h, dev)
+    P["Wp"] = (P["Wp"] * 40.0).contiguous()
+    g = torch.Generator(device="cpu").manual_seed(1000)
+    x = torch.randn(N, d, generator=g).to(dev)
+    deg = (20 + 800 * torch.rand(N, generator=torch.Generator().manual_seed(7)) ** 4).to(dev)
+    layer = ShardedDGGConv(ops, N, K=64, noise_mode=ops.NOISE_RANKED, seed=(1234, 0))
+    layer.wide_rows = "auto"
+    Z = layer.forward(x, deg, P)
+    grads = layer.backward(torch.ones_like(Z), x, P)
+    s = layer.saved
+    lay = s["layout"]
+    kc = Nn(s["k"])
+    print(f"k mean {kc.mean():.1f} max {kc.max():.1f}; {lay.chunks} chunks, widest row {lay.maxm}")
+    assert lay is not None and kc.max() >= 256 and (kc < 54.5).any()
+    K = 64 * lay.maxm
+    L = rank_limit(kc, K)
+    gi, gv = chunked_to_rows(lay, s["idx"], -1), chunked_to_rows(lay, s["val"], 0.0)
+    gw, ga = chunked_to_rows(lay, s["w"], 0.0), chunked_to_rows(lay, s["ahat"], 0.0)
+    keep = np.arange(K)[None, :] < L[:, None]
+    assert np.array_equal(gi >= 0, keep), "every row keeps exactly the ranks that can carry weight"
+    vv = np.where(keep, gv, -1.0)
+    assert (vv[:, :-1] >= vv[:, 1:]).all(), "scores are sorted"
+    srt = np.sort(np.where(keep, gi, -np.arange(1, K + 1)[None, :]), axis=1)
+    assert (srt[:, 1:] != srt[:, :-1]).all(), "duplicate column in a row"
+    xp_c, H_c, rs_c = Nn(s["xp"]), Nn(s["H"]), Nn(s["rs"])
+    rng = np.random.default_rng(0)
+    rows = np.unique(np.concatenate([[0, N - 1, int(kc.argmax()), int(kc.argmin())], rng.integers(0, N, 256)]))
+    assert len(rows) >= 200
+    for r in rows:
+        ri, rv = O.allpairs_topk(xp_c, K=K, noise_mode=O.NOISE_RANKED, seed=(1234, 0), rows=(int(r), int(r) + 1))
+        m_ = keep[r]
+        assert np.array_equal(gi[r][m_], ri[0][m_]) and np.array_equal(gv[r][m_], rv[0][m_]), f"row {r} (k = {kc[r]:.2f})"
+        wo, rso = O.softk(np.where(m_, ri[0], -1)[None, :].astype(np.int32), rv, kc[r:r + 1])
+        assert np.array_equal(gw[r], wo[0]) and rs_c[r] == rso[0], f"row {r}: weights / row sum"
+        ai = np.float32(1.0) / np.sqrt(rs_c[r])
+        aj = (np.float32(1.0) / np.sqrt(rs_c[np.where(m_, ri[0], 0)])).astype(np.float32)
+        assert np.array_equal(ga[r], np.where(m_ & (wo[0] != 0), ((ai * wo[0]).astype(np.float32) * aj).astype(np.float32), np.float32(0)))
+        zr = np.zeros(H_c.shape[1], np.float64)
+        for q in np.nonzero(m_)[0]:
+            zr += np.float64(ga[r, q]) * H_c[gi[r, q]]
+        np.testing.assert_allclose(Nn(Z[r]), np.maximum(zr, 0), rtol=1e-5, atol=1e-5)
+    dense = dict(s, idx=torch.from_numpy(gi), val=torch.from_numpy(gv), w=torch.from_numpy(gw), ahat=torch.from_numpy(ga))
+    _full_size_gradient_parity(dense, grads, x, deg, P)
+
+
+def test_full_size_gcn_dgg_trains_past_the_list(dev):
+    """GCN_DGG on all-pairs candidates at N = 100 000 with the script's optimiser groups
+    (train_small_graphs.py:399-418) takes 40 Adam steps without raising: the learned degrees leave the 64-rank list within a few
+    steps and the rows become chunked; the loss falls, every weighted rank is kept (check_ell_bound), and a hipGraph capture of the
+    trained model's forward replays the chunked layout"""
+    import dgg_amd
+    N, d, h, C = 100_000, 128, 64, 7
+    g = torch.Generator().manual_seed(5)
+    deg = 24 + 16 * torch.rand(N, generator=g)
+    x = torch.randn(N, d, generator=g)
+    y = (x[:, :C] + 0.3 * torch.randn(N, C, generator=g)).argmax(1).to(dev)
+    x = x.to(dev)
+    A = dgg_amd.AllPairs(deg.to(dev))
+    torch.manual_seed(11)
+    m = dgg_amd.GCN_DGG(nfeat=d, nhidden=h, nclass=C, args=_args()).to(dev).train()
+    with torch.no_grad():
+        m.dggs[0].k_net.k_project.weight.mul_(0.1)               # the benchmark's initialisation: k in ~[24, 41] at step 0
+    opt = torch.optim.Adam([{"params": m.params1, "weight_decay": 0.01}, {"params": m.params2, "weight_decay": 5e-4}], lr=0.01)
+    hist = []
+    for step in range(40):
+        opt.zero_grad()
+        logp, adj, _ = m(x, A)
+        loss = torch.nn.functional.nll_loss(logp, y)
+        loss.backward()
+        hist.append((float(adj.k.max()), None if adj.layout is None else adj.layout.maxm, float(loss.detach())))
+        m.dggs[0].check_ell_bound()
+        opt.step()
+    first = next((s_ for s_, (km, _, _) in enumerate(hist) if km + 9.5 > 64), None)
+    print("N = 100 000: learned degrees exceed the list from step", first, "; (k_max, chunks of the widest row) after 40 steps", hist[-1][:2],
+          "; loss", hist[0][2], "->", hist[-1][2])
+    assert hist[0][1] is None, "inside the list at initialisation"
+    assert first is not None and all(w_ is not None for _, w_, _ in hist[first:])
+    assert np.isfinite(hist[-1][2]) and hist[-1][2] < hist[0][2]
+    # inference under a hipGraph: the capture replays the last eager layout as a fixed capacity
+    m.eval()
+    m.dggs[0].set_seed(7, 7)
+    with torch.no_grad():
+        ref = m(x, A)[0]
+        torch.cuda.synchronize()
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph):
+            out = m(x, A)[0]
+        gph.replay()
+        torch.cuda.synchronize()
+    m.dggs[0].check_ell_bound()
+    assert torch.equal(out, ref)
