@@ -197,51 +197,58 @@ int launch_ranked(const float *xp, int64_t N, int64_t row0, int64_t row1, float 
 // consecutive nodes per thread.
 __global__ __launch_bounds__(1024) void chunk_layout(const float *__restrict__ k, int64_t rows, int maxm, int64_t ccap,
                                                      int32_t *__restrict__ cptr, int32_t *__restrict__ cnode, int32_t *__restrict__ meta) {
+    // each of the 16 wavefronts owns a contiguous segment of the rows and walks it in tiles of 64 (coalesced loads, a 64-lane scan per
+    // tile, the running sum carried): pass 1 = segment totals, pass 2 = the same walk from the segment's base, writing cptr and cnode
     __shared__ int wsum[16], wmax[16], wflag[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t per = (rows + 1023) / 1024;
-    const int64_t lo = (int64_t)tid * per, hi = lo + per < rows ? lo + per : rows;
+    const int64_t per = ((rows + 15) / 16 + 63) / 64 * 64;       // rows per wavefront, a multiple of 64
+    const int64_t lo = (int64_t)wave * per, hi = lo + per < rows ? lo + per : rows;
     const int kcap = 64 * maxm;
     int s = 0, mx = 0, flag = 0;
-    for (int64_t i = lo; i < hi; i++) {
-        const float kk = k[i];
-        const int L = klimit_len(kk, kcap);
-        if (!(ceilf(kk + 8.5f) + 1.0f <= (float)kcap)) flag = 1;        // (also NaN)
-        const int m = (L + 63) >> 6;
-        s += m;
-        mx = m > mx ? m : mx;
-    }
-    int incl = s;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
+    for (int64_t i0 = lo; i0 < hi; i0 += 64) {
+        const int64_t i = i0 + lane;
+        if (i < hi) {
+            const float kk = k[i];
+            if (!(ceilf(kk + 8.5f) + 1.0f <= (float)kcap)) flag = 1;    // (also NaN)
+            const int m = (klimit_len(kk, kcap) + 63) >> 6;
+            s += m;
+            mx = m > mx ? m : mx;
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
+        s += __shfl_xor(s, off, 64);
         const int v = __shfl_xor(mx, off, 64);
         mx = v > mx ? v : mx;
         flag |= __shfl_xor(flag, off, 64);
     }
-    if (lane == 63) wsum[wave] = incl;
-    if (lane == 0) { wmax[wave] = mx; wflag[wave] = flag; }
+    if (lane == 0) { wsum[wave] = s; wmax[wave] = mx; wflag[wave] = flag; }
     __syncthreads();
-    int base = 0, total = 0, tmax = 0, tflag = 0;
+    int run = 0, total = 0, tmax = 0, tflag = 0;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const int v = wsum[q];
-        if (q < wave) base += v;
+        if (q < wave) run += v;
         total += v;
         tmax = wmax[q] > tmax ? wmax[q] : tmax;
         tflag |= wflag[q];
     }
-    int run = base + incl - s;
-    for (int64_t i = lo; i < hi; i++) {
-        const int m = (klimit_len(k[i], kcap) + 63) >> 6;
-        cptr[i] = run;
-        for (int c = 0; c < m; c++)
-            if (run + c < ccap) cnode[run + c] = (int32_t)i;
-        run += m;
+    for (int64_t i0 = lo; i0 < hi; i0 += 64) {
+        const int64_t i = i0 + lane;
+        const int m = i < hi ? (klimit_len(k[i], kcap) + 63) >> 6 : 0;
+        int incl = m;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        const int first = run + incl - m;
+        if (i < hi) {
+            cptr[i] = first;
+            for (int c = 0; c < m; c++)
+                if (first + c < ccap) cnode[first + c] = (int32_t)i;
+        }
+        run += __shfl(incl, 63, 64);
     }
     for (int64_t c = (int64_t)total + tid; c < ccap; c += 1024) cnode[c] = 0;      // chunks beyond the last one: defined (node 0), empty
     if (tid == 0) {

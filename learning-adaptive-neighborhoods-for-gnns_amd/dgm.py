@@ -359,6 +359,7 @@ class _FusedDGGConvFn(torch.autograd.Function):
     def forward(ctx, x, deg, layer, *params):
         x, params, ctx.d_orig = _pad_features(x, params, layer.PARAM_KEYS)
         P = dict(zip(layer.PARAM_KEYS, params))
+        layer.want_backward = any(ctx.needs_input_grad)          # (False under torch.no_grad(): the partition's sort is skipped)
         Z = layer.forward(x, deg, P)
         ctx.layer, ctx.state = layer, layer.saved
         ctx.save_for_backward(x, *params)
@@ -404,6 +405,7 @@ class _FusedDGGMlpConvFn(torch.autograd.Function):
             Wcat, wdu, wdv, wex = torch.cat([W0[:, :h_], W0[:, h_:2 * h_]], 0), pick(cols[0]), pick(cols[1]), pick(cols[2])
             w2 = w2.detach().reshape(-1)
         layer.scorer = dict(sc_static, Wcat=det(Wcat), wdu=det(wdu), wdv=det(wdv), wex=det(wex), b1=det(b1), w2=det(w2), b2=det(b2))
+        layer.want_backward = any(ctx.needs_input_grad)
         Z = layer.forward(x, deg, P)
         ctx.layer, ctx.state, ctx.scorer = layer, layer.saved, layer.scorer
         ctx.save_for_backward(x, *params)
@@ -612,6 +614,9 @@ class DGG_LearnableK_debug(nn.Module):
                 in_adj = in_adj.to_sparse().detach()
             rowptr, col, deg = csr_candidates(in_adj)
             cand = (rowptr, col)
+            wide_state = self._wide_rows_state(in_adj, rowptr)
+            if wide_state is True:
+                return None                                   # (known before any kernel runs: this graph takes the CSR form -- no discarded forward)
         sc_static = None
         if mlp_mode:                                          # per-edge inputs of the scorer, in the CSR order of the candidates
             avals = _cached("values_f32", in_adj, lambda: in_adj.coalesce().values().to(torch.float32).contiguous())
@@ -657,9 +662,12 @@ class DGG_LearnableK_debug(nn.Module):
                 layer.wide_rows = "off"
         chunk_active = chunked and layer.wide_rows == "auto" and layer.wide_cap is None    # (this forward reads the layout back)
         if cand is not None and not mlp_mode:                 # the ELL-width bound is tested inside the search kernel (no extra launches)
-            flag = self.__dict__.get("_overflow_dev")
+            # (a forward whose fate is decided from its own learned degrees -- wide_state None -- raises a SCRATCH flag: if it is
+            #  discarded for the CSR form its flag must not reach check_ell_bound, and flags of earlier forwards must survive it)
+            name = "_overflow_scratch" if (wide_state is None and not torch.cuda.is_current_stream_capturing()) else "_overflow_dev"
+            flag = self.__dict__.get(name)
             if flag is None or flag.device != x.device:
-                flag = self.__dict__["_overflow_dev"] = torch.zeros((1,), device=x.device, dtype=torch.int32)
+                flag = self.__dict__[name] = torch.zeros((1,), device=x.device, dtype=torch.int32)
             layer.overflow = flag
         kn = self.k_net
         params = (self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias, self.node_encode_for_k[0].weight,
@@ -675,9 +683,9 @@ class DGG_LearnableK_debug(nn.Module):
             return None
         k = st["k"]
         if cand is not None and self._wide_rows(in_adj, rowptr, k):
-            # rows wider than the ELL with learned degrees beyond it: the CSR form from here on (this discarded forward raised the flag)
-            if not mlp_mode:
-                layer.overflow.zero_()
+            # rows wider than the ELL with learned degrees beyond it: the CSR form from here on (this forward is discarded, once per graph)
+            if not mlp_mode and "_overflow_scratch" in self.__dict__:
+                self._overflow_scratch.zero_()
             return None
         lay = st.get("layout")
         if cand is None and lay is None and not chunk_active and self._allpairs_wide(N, k):
@@ -699,8 +707,11 @@ class DGG_LearnableK_debug(nn.Module):
         if st.get("side_join"):                               # the partition's sort ran on the layer's side stream: a later layer's
             torch.cuda.current_stream().wait_stream(layer._side_stream())     # backward reads it BEFORE this node's own backward joins
             st["side_join"] = False
-        return Z, unnorm, EllAdjacency(st["idx"], ahat, N, k=k, score=st["val"], normalized=True, owner=self, partp=(st["partp"], st["rs"]),
-                                       layout=lay)
+        # (the partition's records reach a later layer's backward only when the sort ran: a forward without a backward skips it)
+        pp = (st["partp"], st["rs"]) if st.get("partp_sorted", True) else None
+        if lay is not None and pp is None:                    # (chunked rows as a separate module: the CSR kernels)
+            return Z, unnorm, EllAdjacency(st["idx"], ahat.detach(), N, k=k, score=st["val"], normalized=True, owner=self, layout=lay)
+        return Z, unnorm, EllAdjacency(st["idx"], ahat, N, k=k, score=st["val"], normalized=True, owner=self, partp=pp, layout=lay)
 
     def _chunk_policy(self, noise_mode):
         """All-pairs rows wider than the 64-rank list as CHUNKED rows (ops.chunk_layout; any learned degree up to 2038, any graph size)?
@@ -722,14 +733,13 @@ class DGG_LearnableK_debug(nn.Module):
         if __import__("os").environ.get("DGG_STRICT_BOUND") == "1":
             self.check_ell_bound()
 
-    def _wide_rows(self, in_adj, rowptr, k):
-        """Should this forward go through the CSR form of select_top_k (rows of any width) instead of the 64-wide ELL?
+    def _wide_rows_state(self, in_adj, rowptr):
+        """What is known BEFORE this forward's learned degrees: True = the CSR form of select_top_k (rows of any width), False = the
+        64-wide ELL is exact whatever k is (or is forced), None = it depends on this forward's k (_wide_rows decides).
         args.dgg_wide_rows: "csr" always (edge-list candidates), "ell" never, "auto" (default): exactly when the ELL would lose a
-        non-zero weight, i.e. some row has more candidates than the ELL width AND a learned degree k_i + 8.5 above it (the
-        condition _track_overflow flags).  The widest row is read back once per GRAPH OBJECT (cached by identity); graphs whose
-        rows all fit never synchronise.  For the others the learned degrees are tested on the device and ONE flag is read back
-        every few forwards (below).  While a hipGraph is being captured nothing can be read back: the decision of the last eager
-        forward on the same graph object is replayed."""
+        non-zero weight, i.e. some row has more candidates than the ELL width AND a learned degree k_i + 8.5 above it.  The widest row
+        is read back once per GRAPH OBJECT (cached by identity); graphs whose rows all fit never synchronise again.  A graph that once
+        needed the CSR form keeps it (exact for every degree; the adjacency type does not flip from one forward to the next)."""
         policy = getattr(self.args, "dgg_wide_rows", "auto")
         if policy == "ell":
             return False
@@ -746,19 +756,22 @@ class DGG_LearnableK_debug(nn.Module):
             ent = cache[id(in_adj)] = [weakref.ref(in_adj), int(lens.max().item()) if lens.numel() else 0, False]
         if ent[1] <= self.ell_width:
             return False
-        # The readback is one host synchronisation: it is taken on the first forward of a graph and then every
-        # `args.dgg_wide_rows_every` (default 16) forwards, not on each one; a graph that once needed the CSR form keeps it (the CSR
-        # form is exact for every degree; the learned degrees of such a graph rarely come back under the ELL width), so the returned
-        # adjacency type does not flip from one forward to the next.  Between two evaluations an ELL forward that would lose
-        # weight still sets the overflow flag (check_ell_bound raises), exactly as under policy "ell".
-        every = max(1, int(getattr(self.args, "dgg_wide_rows_every", 16)))
-        if len(ent) < 4:
-            ent.append(0)
-        if not ent[2] and not torch.cuda.is_current_stream_capturing():
-            if ent[3] % every == 0:
-                lens = rowptr[1:] - rowptr[:-1]
-                ent[2] = bool(((k.detach() + 8.5 > float(self.ell_width)) & (lens > self.ell_width)).any().item())
-            ent[3] += 1
+        return True if ent[2] else None
+
+    def _wide_rows(self, in_adj, rowptr, k):
+        """Should this forward go through the CSR form of select_top_k instead of the 64-wide ELL?  While a graph with rows wider than
+        the ELL is UNDECIDED the learned degrees are tested on the device and one flag is read back on EVERY forward (one host
+        synchronisation; round 4 read it every 16th forward only, and the forwards in between could truncate a row -- ADVICE round 4);
+        the first forward that needs the CSR form makes the decision sticky.  While a hipGraph is being captured nothing can be read
+        back: the list is used and its bound enforced (check_ell_bound)."""
+        st = self._wide_rows_state(in_adj, rowptr)
+        if st is not None:
+            return st
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        ent = self._wide_cache[id(in_adj)]
+        lens = rowptr[1:] - rowptr[:-1]
+        ent[2] = bool(((k.detach() + 8.5 > float(self.ell_width)) & (lens > self.ell_width)).any().item())
         return ent[2]
 
     # ---- all-pairs candidates whose learned degrees outgrow the 64-wide list --------------------------------------------------

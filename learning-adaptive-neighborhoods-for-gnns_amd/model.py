@@ -119,7 +119,13 @@ def _with_self_loops(in_adj):
 
 class GCN_DGG(nn.Module):
     """Two GCNConv layers, one DGG in front of the first (reference model.py:1183-1311).  Returns
-    (log_probs, unnorm_adj, None)."""
+    (log_probs, unnorm_adj, None).
+
+    `unnorm_adj` on the fused path (the default on the GPU: generator + normalize_adj + first layer as one autograd node) is
+    DETACHED -- the reference returns the differentiable output of dgg_net (model.py:1290), but its scripts only log it
+    (train_small_graphs.py:226-230, 268-270).  A loss term on the returned adjacency (a sparsity or degree regulariser) needs
+    args.dgg_differentiable_adj = True (or args.dgg_fused_layer = False): the separate modules, whose unnorm_adj carries autograd
+    into the generator."""
 
     def __init__(self, nfeat=32, nlayers=None, nhidden=32, nclass=10, args=None, **kwargs):
         super().__init__()
@@ -129,6 +135,7 @@ class GCN_DGG(nn.Module):
         self.convs.append(self.conv1)
         self.convs.append(self.conv2)
         self.dgg_adj_input = args.dgg_adj_input
+        self.differentiable_adj = bool(getattr(args, "dgg_differentiable_adj", False))
         self.dggs = nn.ModuleList([DGG_LearnableK_debug(in_dim=nfeat, latent_dim=nhidden, args=args)])
         self.params1 = list(self.conv1.parameters())
         self.params2 = list(self.conv2.parameters())
@@ -144,7 +151,7 @@ class GCN_DGG(nn.Module):
             fused = None
             if i < len(self.dggs):
                 src = in_adj if self.dgg_adj_input == "input_adj" else unnorm_adj
-                if writer is None and isinstance(conv, GCNConv) and isinstance(src, (torch.Tensor, AllPairs)) and x.is_cuda:
+                if writer is None and isinstance(conv, GCNConv) and isinstance(src, (torch.Tensor, AllPairs)) and x.is_cuda and not self.differentiable_adj:
                     # generator + normalize_adj + this layer as one autograd node (one pass over x for the three projections and
                     # one for their weight gradients); None when the configuration is outside its coverage
                     fused = self.dggs[i].forward_conv(x, src, conv.W, want_norm=True)

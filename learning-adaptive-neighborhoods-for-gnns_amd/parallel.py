@@ -294,14 +294,28 @@ class ShardedDGGConv:
         # namespace offers it and covers the shape)
         use_p = hasattr(kern, "partp_build") and xp.shape[1] in (16, 32, 64, 128) and H.shape[1] in (16, 32, 64, 128) and self.mode in (0, 1)
         ov = use_p and self.overlap and s["idx"].is_cuda
+        # want_backward = False (set by the autograd node under torch.no_grad() / frozen parameters): the per-bucket sort of the
+        # partition -- read by the backward's column kernels only -- is not launched at all (an eval forward used to
+        # leave it running on the side stream with nothing ever joining it)
+        nobwd = use_p and not getattr(self, "want_backward", True)
         lay = s.get("layout")
         lkw = {} if lay is None else {"layout": lay}
         assert lay is None or use_p, "chunked rows run on the payload partition (latent / conv widths 16, 32, 64, 128; soft modes)"
-        got = (kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs, phase=1, **lkw) if ov else
-               kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs, **lkw)) if use_p else None
+        # large graphs: the BUCKET partition (no node sort, no row-major dA; the backward walks source-ordered buckets: ops.partb_build)
+        got = None
+        if use_p and hasattr(kern, "partb_build") and self.scorer is None and self.cand is None:
+            got = kern.partb_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs, max(xp.shape[1], H.shape[1]), **lkw)
+            if got is not None:
+                ov = nobwd = False                  # (nothing left to sort)
+        if got is None:
+            got = (kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs, phase=1, **lkw) if (ov or nobwd) else
+                   kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs, **lkw)) if use_p else None
         s["partp"], s["ahat"] = got if got is not None else (None, None)
         s["side_join"] = False
-        if ov and got is not None:                  # the sort runs beside the aggregation; the backward joins before its first column kernel
+        s["partp_sorted"] = not nobwd
+        if nobwd and got is not None:
+            s["partp"].args = None                  # (phase 1 only: ahat is complete, the records stay in bucket order, unread)
+        elif ov and got is not None:                # the sort runs beside the aggregation; the backward joins before its first column kernel
             main, side = torch.cuda.current_stream(), self._side_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -334,6 +348,7 @@ class ShardedDGGConv:
         kern, s = self.kern, self.saved
         assert s.get("gen") == getattr(self, "_fwd_gen", None), "ShardedDGGConv: backward() must follow the forward() it differentiates " \
             "(a second forward has overwritten the gathered buffers)"
+        assert s.get("partp_sorted", True), "ShardedDGGConv: this forward ran with want_backward = False (its partition was not sorted)"
         if hasattr(kern, "zero_pool"):                   # every zero-initialised accumulator of the backward from ONE filled buffer
             ncols, h, F = s["xp"].shape[0], s["xp"].shape[1], s["H"].shape[1]
             rows = s["idx"].shape[0]
@@ -394,10 +409,12 @@ class ShardedDGGConv:
             dA, dA_rec, dH, da = pc
             if self.scorer is not None:          # (`da` holds the neighbour-side sums; the row side: sqrt(rs_i) sum_r dA_ir ahat_ir)
                 return self._scorer_backward(g, dA, dH, da, x_local, P, cols_only=True)
-            if self._hyb() and self.coll:           # dH [N,F] partial is complete here and needed only by the last kernel of the step
-                dH = self._reduce_scatter_rows(dH, "dH", async_op=True)
+            # (da first: both collectives share one RCCL stream and da is an operand of the very next kernel; behind the 25-128 MB
+            #  reduce-scatter it would wait for that transfer -- ADVICE round 4)
             if self.coll:
                 dist.all_reduce(da, group=self.group)
+            if self._hyb() and self.coll:           # dH [N,F] partial is complete here and needed only by the last kernel of the step
+                dH = self._reduce_scatter_rows(dH, "dH", async_op=True)
             # the activation derivative of the two LeakyReLU projections is applied by the kernels that PRODUCE dxp / dxk (they hold
             # xp_j / xk in registers): the fused weight-gradient product then reads no forward output for the mask (51 MB less)
             pre = self._premask(x_local)
@@ -439,10 +456,10 @@ class ShardedDGGConv:
             ahat_rows = None
         if self.scorer is not None:
             return self._scorer_backward(g, dA, dH, da, x_local, P)
-        if self._hyb() and self.coll:
-            dH = self._reduce_scatter_rows(dH, "dH", async_op=True)
         if self.coll:
             dist.all_reduce(da, group=self.group)
+        if self._hyb() and self.coll:
+            dH = self._reduce_scatter_rows(dH, "dH", async_op=True)
         fused = None
         if part is not None and hasattr(kern, "softk_edge_bwd"):
             fused = kern.softk_edge_bwd(s["xp"], s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.t, self.noise_mode != 0,

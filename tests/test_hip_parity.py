@@ -2357,6 +2357,64 @@ def test_ell_width_bound_is_enforced(dev):
         m.check_ell_bound()                                       # (the discarded forward's flag does not survive)
 
 
+def test_wide_rows_decision_is_taken_on_every_forward(dev, monkeypatch):
+    """on a graph with rows wider than the list the decision "ELL or CSR form" is taken from the learned degrees of
+    EVERY forward while it is open (round 4 looked every 16th forward: up to 15 truncated forwards, then check_ell_bound aborted the
+    training).  Here the degrees cross the bound between two consecutive forwards: the second one already takes the CSR form, nothing
+    is truncated, check_ell_bound never fires -- through the module and through GCN_DGG's fused layer, whose later forwards leave for
+    the separate modules BEFORE running the fused step (no discarded forward per step)."""
+    import dgg_amd
+    from argparse import Namespace
+    from dgg_amd import parallel
+    N, d, h = 256, 32, 16
+    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
+    rows = np.repeat(np.arange(N), 100)
+    cols = (rows + np.tile(np.arange(100), N)) % N
+    o = np.lexsort((cols, rows))
+    g = torch.Generator().manual_seed(3)
+    vals = 0.2 * (1 + 0.3 * torch.rand(100 * N, generator=g))                          # prior degrees ~ 23 +- 1
+    A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows[o], cols[o]])), vals, (N, N)).coalesce().to(dev)
+    x = torch.randn(N, d, generator=g).to(dev)
+    torch.manual_seed(2)
+    model = dgg_amd.GCN_DGG(nfeat=d, nhidden=h, nclass=4, args=args).to(dev).train()
+    m = model.dggs[0]
+    calls = []
+    orig = parallel.ShardedDGGConv.forward
+    monkeypatch.setattr(parallel.ShardedDGGConv, "forward", lambda self, *a_, **k_: (calls.append(1), orig(self, *a_, **k_))[1])
+
+    def step():
+        n0 = len(calls)
+        logp, adj, _ = model(x, A)
+        logp.sum().backward()
+        m.check_ell_bound()                                        # must never fire: no forward may truncate
+        return type(adj).__name__, float(adj.k.max()), len(calls) - n0
+
+    t1, k1, c1 = step()
+    assert t1 == "EllAdjacency" and k1 + 8.5 < 64 and c1 == 1
+    with torch.no_grad():                                          # what a few optimiser steps do: the degrees move past the list
+        m.k_net.k_project.bias.add_(60.0 / float(torch.std(torch.zeros(N).index_add_(0, torch.from_numpy(rows[o]), vals))))
+    t2, k2, c2 = step()
+    assert t2 == "CsrAdjacency" and k2 + 8.5 > 64 and c2 == 1, "the forward that crosses the bound is discarded once and redone in CSR form"
+    t3, _, c3 = step()
+    assert t3 == "CsrAdjacency" and c3 == 0, "a graph known to need the CSR form no longer runs (and discards) the fused step"
+    # the module on its own: same decision per forward
+    torch.manual_seed(2)
+    m2 = dgg_amd.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=args).to(dev)
+    assert isinstance(m2(x, A), dgg_amd.EllAdjacency)
+    with torch.no_grad():
+        m2.k_net.k_project.bias.add_(60.0 / float(torch.std(torch.zeros(N).index_add_(0, torch.from_numpy(rows[o]), vals))))
+    assert isinstance(m2(x, A), dgg_amd.CsrAdjacency)
+    m2.check_ell_bound()
+    # and an inference forward (no backward can follow) leaves no unsorted partition behind for a later layer
+    with torch.no_grad():
+        args2 = Namespace(**{**vars(args), "dgg_wide_rows": "ell"})
+        m3 = dgg_amd.GCN_DGG(nfeat=d, nhidden=h, nclass=4, args=args2).to(dev).eval()
+        out = m3(x, A)[0]
+    assert torch.isfinite(out).all()
+
+
 def test_fused_layer_with_edge_mlp_scorer_and_wide_rows(dev):
     """the edge-MLP scorer through the fused layer on rows wider than the list: the bound is tracked on the device (no kernel flag on
     this path), raised by check_ell_bound under dgg_wide_rows = "ell", and under the default "auto" such a graph leaves the fused
