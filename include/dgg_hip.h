@@ -181,7 +181,8 @@ int dgg_allpairs_topk_ranked_softk_dseed(const float *xp, int64_t N, int h, int6
  * consecutive 64-entry CHUNKS [cptr[i], cptr[i+1]) of idx / val / w / ahat ([chunks, 64] arrays), L_i = ceil(k_i + 8.5) + 1; rank r of the
  * row is entry r % 64 of its chunk r / 64.  With every M_i = 1 the layout IS the [rows, 64] list of the calls above, and every chunk is
  * a row of that layout to the entry points that take `cnode` (node of every chunk) below.
- * dgg_chunk_layout: k [rows] -> cptr int32 [rows+1], cnode int32 [ccap], meta int32 [4] = {chunks in total, max M_i, flags, 0};
+ * dgg_chunk_layout: k [rows] -> cptr int32 [rows+1], cnode int32 [ccap], meta int32 [4 + 384] = {chunks in total, max M_i, flags, 0,
+ * scratch of the two-pass scan};
  * flags bit 0: a row needs more than 64 * maxm ranks (maxm <= 32; the row is cut there: callers must raise), bit 1: more than ccap
  * chunks (arrays too small: call again with a larger capacity). */
 int dgg_chunk_layout(const float *k, int64_t rows, int maxm, int64_t ccap, int32_t *cptr, int32_t *cnode, int32_t *meta, void *stream);
@@ -444,26 +445,6 @@ int dgg_softk_edge_bwd_partp_chunked(const float *xp, int64_t rows, const int32_
                                      const float *k, const float *rs, const float *dA, const float *dA_rec, const float *da, const float *ahat_rows,
                                      int64_t row0, float t, int perturb, int mode, int normalized, const void *partp_ws, int64_t ncols,
                                      float *rowinfo_ws, float *dk, float *dxp, int out_act, int phase, void *stream);
-/* ---- BUCKET partition: the per-destination backward without the node sort (large graphs) ---------------------------------------------
- * dgg_partb_build = count + scan + fill of dgg_partp_build: the records of a bucket of `width` destination nodes lie in the order of
- * their SOURCE rows.  The backward walks every bucket front to back with the sums of its `width` nodes in LDS (width * max(F, h) floats
- * <= 64 KB), so at any moment the whole launch gathers G_i / xp_i from a narrow band of source rows (cache hits instead of random rows
- * of the whole table), needs neither the per-node sort nor the scattered row-major dA: dA_rec [rows*64] is in bucket order and the row
- * kernel reaches it through recpos (slot -> record position, written by the fill pass).  Same arithmetic per record as the per-node
- * kernels (autograd of torch.mm(adj, x) model.py:594, normalize_adj model.py:1215-1218, the ramp dgm.py:1410-1420, the scorer
- * dgm.py:1613-1623); sums in arrival order.  cnode / cptr: chunked rows (else NULL). */
-size_t dgg_partb_ws_bytes(int64_t rows, int64_t ncols, int width);
-int dgg_partb_build(const int32_t *idx, const float *w, const float *val, const float *rs_nodes, int64_t rows, const int32_t *cnode,
-                    int64_t ncols, int width, const float *rs_all, float *ahat, void *ws, void *stream);
-int dgg_partb_conv_bwd(const float *G, const float *H, int64_t rows, int F, const void *ws, int64_t ncols, int width, const float *rs,
-                       const int32_t *cnode, const float *dA_ext, float *dA_rec, float *dH, float *da, void *stream);
-int dgg_partb_softk_edge_bwd(const float *xp, int64_t nrows, const int32_t *cptr, int64_t rows, int h, const int32_t *idx, const float *val,
-                             const float *k, const float *rs, const float *dA_rec, const float *da, const float *ahat_rows, int64_t row0, float t,
-                             int perturb, int mode, int normalized, const void *ws, int64_t ncols, int width, const int32_t *cnode,
-                             float *rowinfo_ws, float *dk, float *dxp, int out_act, int phase, void *stream);
-/* byte offsets of the pieces of a bucket partition inside its workspace: out[0] bucket starts (int32 [nb+1]), out[1] records (16 bytes
- * each, bucket order), out[2] recpos (int32 [rows*64]), out[3] number of buckets */
-int dgg_partb_describe(int64_t rows, int64_t ncols, int width, int64_t *out4);
 /* dA [rows,64] by rows (chunked rows: [chunks,64]) -> dA_rec [rows*64] in the record order of a built payload partition (K = 64): for a
  * caller that holds d loss / d w row-major -- the generator used as a separate module, whose output feeds other layers -- and runs the
  * score backward (dgg_softk_edge_bwd_partp[_chunked], normalized = 0) on it */

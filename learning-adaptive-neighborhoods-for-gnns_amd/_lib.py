@@ -50,12 +50,6 @@ PROTOTYPES = {
     "dgg_softk_edge_bwd_partp_chunked": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _i32, _i32, _i32, _vp,
                                          _i64, _vp, _vp, _vp, _i32, _i32, _vp],
     "dgg_partp_gather_rec": [_vp, _i64, _i64, _vp, _vp, _vp],
-    "dgg_partb_ws_bytes": [_i64, _i64, _i32],
-    "dgg_partb_build": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp],
-    "dgg_partb_conv_bwd": [_vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "dgg_partb_softk_edge_bwd": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _i32, _i32, _i32, _vp, _i64, _i32,
-                                 _vp, _vp, _vp, _vp, _i32, _i32, _vp],
-    "dgg_partb_describe": [_i64, _i64, _i32, _vp],
     "dgg_edgelist_topk": [_vp, _i64, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _vp, _vp],
     "dgg_edgelist_topk_softk": [_vp, _i64, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_edge_mlp_fwd": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
@@ -160,7 +154,7 @@ def lib():
             fn = getattr(L, name)      # AttributeError if the library does not export a declared symbol
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        for name in ("dgg_allpairs_workspace_bytes", "dgg_allpairs_sweep_ctl_offset_bytes", "dgg_allpairs_rsym_ctl_offset_bytes", "dgg_gemm_tn_ws_floats", "dgg_gemm_tn_multi_ws_floats", "dgg_linear_bwd_ws_floats", "dgg_part_ws_bytes", "dgg_partp_ws_bytes", "dgg_partb_ws_bytes", "dgg_knet_x_bwd_ws_bytes",
+        for name in ("dgg_allpairs_workspace_bytes", "dgg_allpairs_sweep_ctl_offset_bytes", "dgg_allpairs_rsym_ctl_offset_bytes", "dgg_gemm_tn_ws_floats", "dgg_gemm_tn_multi_ws_floats", "dgg_linear_bwd_ws_floats", "dgg_part_ws_bytes", "dgg_partp_ws_bytes", "dgg_knet_x_bwd_ws_bytes",
                      "dgg_degree_stats_ws_bytes"):
             getattr(L, name).restype = C.c_size_t
         _lib = L

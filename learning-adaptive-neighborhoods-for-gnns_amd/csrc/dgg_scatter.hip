@@ -333,13 +333,7 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_chunked(const float *__rest
             float rp = 0.0f;
             for (int c = cb; c < ce; c++) {
                 const float ah = sk.ahat_rows[(int64_t)c * 64 + lane];
-                float dw;
-                if (sk.recpos) {                                 // (bucket partition: dA in record order, reached through the slot map)
-                    const int rpos = sk.recpos[(int64_t)c * 64 + lane];
-                    dw = sk.dA_rec[rpos >= 0 ? rpos : 0];
-                } else {
-                    dw = sk.dA[(int64_t)c * 64 + lane];
-                }
+                float dw = sk.dA[(int64_t)c * 64 + lane];
                 if (ah == 0.0f) dw = 0.0f;                       // (entries outside the partition were never written)
                 rp += dw * ah;
             }
@@ -356,13 +350,7 @@ __global__ __launch_bounds__(256) void edge_bwd_rows_chunked(const float *__rest
         const int32_t jl = idx[e];
         const float vl = val[e];
         const bool live = jl >= 0;
-        float dw;
-        if (sk.recpos) {
-            const int rpos = sk.recpos[e];
-            dw = rpos >= 0 ? sk.dA_rec[rpos] : 0.0f;
-        } else {
-            dw = sk.dA[e];
-        }
+        float dw = sk.dA[e];
         const float kshift = ki - (float)(64 * (c - cb));
         if (sk.normalized) {
             const float aj = __fdiv_rn(1.0f, c_sqrt(sk.rs[live ? jl : gi]));
@@ -1317,8 +1305,7 @@ __global__ __launch_bounds__(THREADS) void pp_fill(const int32_t *__restrict__ i
                                                    const float *__restrict__ rs_rows, int64_t rows, int K, int nb, uint32_t rcp,
                                                    const int *__restrict__ T, const int *__restrict__ totals, int *__restrict__ bstart,
                                                    int4 *__restrict__ recs4, const float *__restrict__ ainv, float *__restrict__ ahat_out,
-                                                   const int32_t *__restrict__ cnode = nullptr, int *__restrict__ recpos = nullptr) {
-    // (recpos != NULL, K = 64: recpos[row*64 + r] = position of entry (row, r)'s record in BUCKET order, -1 for inactive entries)
+                                                   const int32_t *__restrict__ cnode = nullptr) {
     // (cnode != NULL: chunked rows -- every "row" of idx / w / val is a 64-entry chunk of node cnode[row]; rs_rows is indexed by node)
     extern __shared__ int lds[];                                 // hist[nb], base[nb], scratch[16]
     int *hist = lds, *base = lds + nb, *scratch = lds + 2 * nb;
@@ -1360,7 +1347,6 @@ __global__ __launch_bounds__(THREADS) void pp_fill(const int32_t *__restrict__ i
                 aj.z = ainv[ji[u].z >= 0 ? ji[u].z : 0]; aj.w = ainv[ji[u].w >= 0 ? ji[u].w : 0];
             }
             float4 ah = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            int4 rp = make_int4(-1, -1, -1, -1);
 #pragma unroll 1
             for (int c = 0; c < 4; c++) {                        // (not unrolled: 16 entries in flight cost 130 registers and an occupancy step)
                 const int j = pp_get(ji[u], c);
@@ -1368,7 +1354,6 @@ __global__ __launch_bounds__(THREADS) void pp_fill(const int32_t *__restrict__ i
                 if (j >= 0 && wx != 0.0f) {
                     const int b = pp_bucket(j, rcp);
                     const int slot = base[b] + atomicAdd(&hist[b], 1);
-                    if (c == 0) rp.x = slot; else if (c == 1) rp.y = slot; else if (c == 2) rp.z = slot; else rp.w = slot;
                     // wa = a_i * w exactly as normalize_fwd_kernel forms it (dgg_ell.hip), so that wa * a_j == ahat bit for bit
                     const float wa = __fmul_rn(ai, wx);
                     recs4[slot] = make_int4((int)(i * 64 + 4 * (lane & 15) + c), j, (int)__float_as_uint(wa), (int)__float_as_uint(pp_getf(vv, c)));
@@ -1377,7 +1362,6 @@ __global__ __launch_bounds__(THREADS) void pp_fill(const int32_t *__restrict__ i
                 }
             }
             if (ahat_out && row_ok) *reinterpret_cast<float4 *>(ahat_out + i * 64 + 4 * (lane & 15)) = ah;
-            if (recpos && row_ok) *reinterpret_cast<int4 *>(recpos + i * 64 + 4 * (lane & 15)) = rp;
         }
     } else {
         for (int q = 0; q < 16; q++) {
@@ -1475,207 +1459,6 @@ __global__ __launch_bounds__(PP_T) void pp_sort(const int *__restrict__ bstart, 
                     if (recpos) recpos[r[u].x] = pos;
                 }
         }
-    }
-}
-
-// ---- BUCKET partition ("partb"): the per-destination backward WITHOUT the node sort ---------------------------------------------------
-// pp_fill stores a bucket's records in the order of the source workgroups, i.e. SORTED BY SOURCE ROW (granularity: the 256 rows of a
-// fill workgroup).  A kernel that walks a bucket front to back therefore gathers G_i / xp_i from a band of rows that moves from row 0 to
-// row N, and every workgroup of the launch is at about the same place of its own walk: the rows the chip gathers at any moment are a
-// narrow band of the table (L2 / Infinity-Cache hits instead of random 256-byte rows from the whole table), and so are the dA_rec
-// entries the row kernel reaches through the slot -> record map (recpos, written by pp_fill): the scattered row-major dA (4.1 M
-// 4-byte stores, 54 of conv_bwd_node's 193 us) and pp_sort (35 us) are not needed at all.  The sums of a destination node meet in LDS
-// (one workgroup per bucket of `width` nodes, float atomics on LDS: ds_add_f32), so a node costs nothing per se -- short lists (row
-// shards) and long ones alike.  Same arithmetic per record as conv_bwd_node / edge_bwd_node; sums in arrival order (within rounding).
-struct PartB {
-    int *bstart, *totals, *T, *recpos;
-    float *ainv;
-    int4 *recs;
-    int width;
-    uint32_t rcp;
-    int64_t nb, nwg;
-};
-inline size_t partb_layout(PartB &p, void *ws, int64_t rows, int64_t ncols, int width) {
-    p.width = width;
-    p.rcp = pp_recip(width);
-    p.nb = (ncols + width - 1) / width;
-    p.nwg = (rows + pp_threads() / 4 - 1) / (pp_threads() / 4);
-    char *w = reinterpret_cast<char *>(ws);
-    size_t o = 0;
-    p.bstart = reinterpret_cast<int *>(w + o); o += align256((size_t)(p.nb + 1) * 4);
-    p.totals = reinterpret_cast<int *>(w + o); o += align256((size_t)p.nb * 4);
-    p.T = reinterpret_cast<int *>(w + o); o += align256((size_t)p.nwg * p.nb * 4);
-    p.ainv = reinterpret_cast<float *>(w + o); o += align256((size_t)ncols * 4);
-    p.recs = reinterpret_cast<int4 *>(w + o); o += align256((size_t)rows * 64 * sizeof(int4));
-    p.recpos = reinterpret_cast<int *>(w + o); o += align256((size_t)rows * 64 * sizeof(int));
-    return o;
-}
-
-constexpr int PB_T = 1024;                                       // threads of a bucket workgroup
-constexpr int PB_NBT = 4;                                        // batches of gathered rows in flight per wavefront
-
-// dA_e = <G_i, H_j> (+ dA_ext), dH_j = a_j sum_e wa_e G_i, da_j = sqrt(rs_j) sum_e dA_e wa_e a_j  over the records of one bucket
-template <int F, bool EXT>
-__global__ __launch_bounds__(PB_T) void conv_bwd_bucket(const float *__restrict__ G, const float *__restrict__ Hm, int64_t ncols, int W,
-                                                        const int *__restrict__ bstart, const int4 *__restrict__ recs,
-                                                        const float *__restrict__ ainv, const float *__restrict__ rs,
-                                                        const int32_t *__restrict__ cnode, const float *__restrict__ dA_ext,
-                                                        float *__restrict__ dA_rec, float *__restrict__ dH, float *__restrict__ da) {
-    constexpr int LPR = F / 4, NPI = 64 / LPR, PER = PB_NBT * NPI;
-    extern __shared__ float ldsf[];                              // acc [W][F], sda [W]
-    float *lds = ldsf, *acc = ldsf, *sda = ldsf + (size_t)W * F;
-    const int tid = threadIdx.x, lane = tid & 63, c4 = lane % LPR, slot = lane / LPR, wave = dgg::wave_id();
-    const int64_t j0 = (int64_t)blockIdx.x * W;
-    const int e0 = bstart[blockIdx.x], e1 = bstart[blockIdx.x + 1];
-    for (int q = tid; q < W * F + W; q += PB_T) lds[q] = 0.0f;
-    __syncthreads();
-    for (int eb = e0 + wave * PER; eb < e1; eb += (PB_T / 64) * PER) {
-        const bool have = lane < PER && eb + lane < e1;
-        int4 myrec = recs[have ? eb + lane : e1 - 1];
-        if (!have) myrec.y = -1;
-        int dstl[PB_NBT];
-        float cf[PB_NBT];
-        float4 g[PB_NBT], hj[PB_NBT];
-        float ext[PB_NBT];
-#pragma unroll
-        for (int b = 0; b < PB_NBT; b++) {
-            const int q = b * NPI + slot;
-            const int src = __shfl(myrec.x, q, 64);
-            const int dst = __shfl(myrec.y, q, 64);
-            const float wa = __int_as_float(__shfl(myrec.z, q, 64));
-            const bool ok = dst >= 0;
-            const int64_t node = ok ? (cnode ? (int64_t)cnode[src >> 6] : (int64_t)(src >> 6)) : 0;
-            const int64_t jj = ok ? (int64_t)dst : j0;
-            g[b] = *reinterpret_cast<const float4 *>(G + node * F + 4 * c4);
-            hj[b] = *reinterpret_cast<const float4 *>(Hm + jj * F + 4 * c4);
-            cf[b] = ok ? __fmul_rn(wa, ainv[jj]) : 0.0f;
-            dstl[b] = ok ? (int)(dst - j0) : -1;
-            if constexpr (EXT) ext[b] = ok ? dA_ext[src] : 0.0f;
-        }
-        float mydot = 0.0f;
-#pragma unroll
-        for (int b = 0; b < PB_NBT; b++) {
-            float dot = g[b].x * hj[b].x;
-            dot = fmaf(g[b].y, hj[b].y, dot); dot = fmaf(g[b].z, hj[b].z, dot); dot = fmaf(g[b].w, hj[b].w, dot);
-            if (LPR > 16) dot += __uint_as_float(xor_shfl<16>(__float_as_uint(dot), lane));
-            if (LPR > 8) dot += __uint_as_float(xor_shfl<8>(__float_as_uint(dot), lane));
-            if (LPR > 4) dot += __uint_as_float(xor_shfl<4>(__float_as_uint(dot), lane));
-            dot += __uint_as_float(xor_shfl<2>(__float_as_uint(dot), lane));
-            dot += __uint_as_float(xor_shfl<1>(__float_as_uint(dot), lane));
-            if constexpr (EXT) dot += ext[b];
-            const float tq = __shfl(dot, (lane % NPI) * LPR, 64);
-            if (lane / NPI == b) mydot = tq;
-            if (dstl[b] >= 0) {
-                float *a = acc + (size_t)dstl[b] * F + 4 * c4;
-                atomicAdd(a + 0, cf[b] * g[b].x); atomicAdd(a + 1, cf[b] * g[b].y);
-                atomicAdd(a + 2, cf[b] * g[b].z); atomicAdd(a + 3, cf[b] * g[b].w);
-                if (c4 == 0) atomicAdd(sda + dstl[b], dot * cf[b]);
-            }
-        }
-        if (have) dA_rec[eb + lane] = mydot;
-    }
-    __syncthreads();
-    for (int q = tid; q < W * LPR; q += PB_T) {
-        const int jl = q / LPR, c = q % LPR;
-        const int64_t j = j0 + jl;
-        if (j < ncols) *reinterpret_cast<float4 *>(dH + j * F + 4 * c) = *reinterpret_cast<const float4 *>(acc + (size_t)jl * F + 4 * c);
-    }
-    if (da)
-        for (int q = tid; q < W; q += PB_T) {
-            const int64_t j = j0 + q;
-            if (j < ncols) da[j] = sda[q] * sqrtf(rs[j]);
-        }
-}
-
-// score backward, column side (edge_bwd_node's arithmetic) over the records of one bucket: dxp_j -= sum_e dd_e (xp_i - xp_j)
-template <int H>
-__global__ __launch_bounds__(PB_T) void edge_bwd_bucket(const float *__restrict__ xp, int64_t ncols, int W, const int *__restrict__ bstart,
-                                                        const int4 *__restrict__ recs, const float *__restrict__ dA_rec,
-                                                        const float4 *__restrict__ rowinfo, const float *__restrict__ ainv, int normalized,
-                                                        const int32_t *__restrict__ cnode, int64_t row0, int64_t rows, float t, int perturb,
-                                                        float *__restrict__ dxp, int out_act) {
-    constexpr int LPR = H / 4, NPI = 64 / LPR, NBT = (32 / NPI) < 1 ? 1 : 32 / NPI, PER = NBT * NPI;   // 32 records per wavefront iteration
-    extern __shared__ float ldsf[];                              // acc [W][H]
-    float *lds = ldsf, *acc = ldsf;
-    const int tid = threadIdx.x, lane = tid & 63, c4 = lane % LPR, slot = lane / LPR, wave = dgg::wave_id();
-    const int64_t j0 = (int64_t)blockIdx.x * W;
-    const int e0 = bstart[blockIdx.x], e1 = bstart[blockIdx.x + 1];
-    for (int q = tid; q < W * H; q += PB_T) lds[q] = 0.0f;
-    __syncthreads();
-    for (int eb = e0 + wave * PER; eb < e1; eb += (PB_T / 64) * PER) {
-        const bool have = lane < PER && eb + lane < e1;
-        const int ec = have ? eb + lane : e1 - 1;
-        int4 myrec = recs[ec];
-        if (!have) myrec.y = -1;
-        float mydval;
-        {
-            const float4 info = rowinfo[myrec.x >> 6];
-            const float aj = normalized ? ainv[have ? myrec.y : (int)j0] : 1.0f;
-            const float dw = dA_rec[ec] * info.x * aj + info.y;
-            const float th = c_tanh((float)(myrec.x & 63) - info.z);
-            mydval = have ? dw * (1.0f - 0.5f * (1.0f + th)) : 0.0f;
-        }
-        float4 xi[NBT], xj[NBT];
-        int dstl[NBT];
-#pragma unroll
-        for (int b = 0; b < NBT; b++) {
-            const int q = b * NPI + slot;
-            const int src = __shfl(myrec.x, q, 64);
-            const int dst = __shfl(myrec.y, q, 64);
-            const bool ok = dst >= 0;
-            const int64_t jj = ok ? (int64_t)dst : j0;
-            const int64_t node = ok ? row0 + (cnode ? (int64_t)cnode[src >> 6] : (int64_t)(src >> 6)) : jj;
-            xi[b] = *reinterpret_cast<const float4 *>(xp + node * H + 4 * c4);
-            xj[b] = *reinterpret_cast<const float4 *>(xp + jj * H + 4 * c4);
-            dstl[b] = ok ? (int)(dst - j0) : -1;
-        }
-        float myd2 = 0.0f;
-#pragma unroll
-        for (int b = 0; b < NBT; b++) {
-            const float4 d = make_float4(xi[b].x - xj[b].x, xi[b].y - xj[b].y, xi[b].z - xj[b].z, xi[b].w - xj[b].w);
-            float d2 = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
-            if (LPR > 16) d2 += __uint_as_float(xor_shfl<16>(__float_as_uint(d2), lane));
-            if (LPR > 8) d2 += __uint_as_float(xor_shfl<8>(__float_as_uint(d2), lane));
-            if (LPR > 4) d2 += __uint_as_float(xor_shfl<4>(__float_as_uint(d2), lane));
-            d2 += __uint_as_float(xor_shfl<2>(__float_as_uint(d2), lane));
-            d2 += __uint_as_float(xor_shfl<1>(__float_as_uint(d2), lane));
-            const float tq = __shfl(d2, (lane % NPI) * LPR, 64);
-            if (lane / NPI == b) myd2 = tq;
-        }
-        float mydd = 0.0f;
-        if (mydval != 0.0f && myd2 != 0.0f) {
-            const float dist = sqrtf(myd2);
-            const float p = c_exp(t * dist);
-            const float dp = perturb ? mydval * __int_as_float(myrec.w) / (p + 1e-8f) : mydval;
-            mydd = dp * t * p / dist;
-        }
-#pragma unroll
-        for (int b = 0; b < NBT; b++) {
-            const float dd = __shfl(mydd, b * NPI + slot, 64);
-            if (dstl[b] >= 0 && dd != 0.0f) {
-                const float4 d = make_float4(xi[b].x - xj[b].x, xi[b].y - xj[b].y, xi[b].z - xj[b].z, xi[b].w - xj[b].w);
-                float *a = acc + (size_t)dstl[b] * H + 4 * c4;
-                atomicAdd(a + 0, -dd * d.x); atomicAdd(a + 1, -dd * d.y); atomicAdd(a + 2, -dd * d.z); atomicAdd(a + 3, -dd * d.w);
-            }
-        }
-    }
-    __syncthreads();
-    for (int q = tid; q < W * LPR; q += PB_T) {
-        const int jl = q / LPR, c = q % LPR;
-        const int64_t j = j0 + jl;
-        if (j >= ncols) continue;
-        float4 v = *reinterpret_cast<const float4 *>(acc + (size_t)jl * H + 4 * c);
-        float4 *o = reinterpret_cast<float4 *>(dxp + j * H + 4 * c);
-        if (j >= row0 && j < row0 + rows) {                       // the row kernel's own-side term is already there
-            const float4 u = *o;
-            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-        }
-        if (out_act == 1) {
-            const float4 x_ = *reinterpret_cast<const float4 *>(xp + j * H + 4 * c);
-            v.x *= x_.x > 0.0f ? 1.0f : 0.01f; v.y *= x_.y > 0.0f ? 1.0f : 0.01f;
-            v.z *= x_.z > 0.0f ? 1.0f : 0.01f; v.w *= x_.w > 0.0f ? 1.0f : 0.01f;
-        }
-        *o = v;
     }
 }
 
@@ -2155,129 +1938,6 @@ int dgg_partp_gather_rec(const float *dA, int64_t rows, int64_t ncols, const voi
     partp2_layout(p, const_cast<void *>(partp_ws), rows, 64, ncols);
     hipLaunchKernelGGL(pp_gather_rec, dim3((unsigned)((rows * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.bstart, (int)p.nb, p.recs, dA, dA_rec);
     return dgg_check_launch("partp_gather_rec");
-}
-
-// ---- BUCKET partition: build + the two per-destination steps of the backward (see PartB) -------------------------------------------
-// width: destination nodes per bucket (the per-bucket sums live in LDS: width * max(F, h) floats, at most ~56 KB); 0 bytes: not applicable
-size_t dgg_partb_ws_bytes(int64_t rows, int64_t ncols, int width) {
-    if (width < 8 || width > 4096 || rows < 0 || rows * 64 >= ((int64_t)1 << 31) || ncols < 1 || (double)ncols * (double)width >= 4.0e9) return 0;
-    PartB p;
-    const size_t bytes = partb_layout(p, nullptr, rows, ncols, width);
-    if (p.nb > 4096) return 0;                                   // LDS histograms of the count / fill passes
-    return bytes;
-}
-// count + scan + fill of the ACTIVE entries (idx >= 0, w != 0) of idx / w / val [rows,64] by destination bucket; records =
-// (row*64 + r, j, w rs_i^-1/2, score) in the order of the source rows; recpos [rows*64] = position of every entry's record (-1: none);
-// rs_all / ahat (both or neither): normalize_adj fused as in dgg_partp_build_norm.  cnode (nullable): chunked rows -- a "row" is a
-// 64-entry chunk of node cnode[row], rs_nodes is indexed by node.
-int dgg_partb_build(const int32_t *idx, const float *w, const float *val, const float *rs_nodes, int64_t rows, const int32_t *cnode,
-                    int64_t ncols, int width, const float *rs_all, float *ahat, void *ws, void *stream) {
-    hipStream_t st = (hipStream_t)stream;
-    if (dgg_partb_ws_bytes(rows, ncols, width) == 0 || !ws) return dgg_set_error(DGG_ERR_UNSUPPORTED, "partb_build: unsupported size or NULL workspace");
-    if (!val || !rs_nodes) return dgg_set_error(DGG_ERR_ARG, "partb_build: the payload needs the scores and the row sums");
-    if ((rs_all == nullptr) != (ahat == nullptr)) return dgg_set_error(DGG_ERR_ARG, "partb_build: rs_all and ahat go together");
-    if ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(val) | reinterpret_cast<uintptr_t>(ahat)) % 16)
-        return dgg_set_error(DGG_ERR_ARG, "partb_build: idx / w / val / ahat must be 16-byte aligned");
-    if (rows == 0) return 0;
-    PartB p;
-    partb_layout(p, ws, rows, ncols, width);
-    const int nb = (int)p.nb, nwg = (int)p.nwg, K = 64;
-#define DGG_PB_PASS(TT)                                                                                                      \
-    hipLaunchKernelGGL(pp_count<TT>, dim3((unsigned)nwg), dim3(TT), (size_t)nb * 4, st, idx, w, rows, K, nb, p.rcp, p.T, rs_all, ncols, \
-                       p.ainv);                                                                                              \
-    hipLaunchKernelGGL(pp_scan, dim3((unsigned)((nb + 31) / 32)), dim3(1024), 0, st, p.T, nwg, nb, p.totals);                \
-    hipLaunchKernelGGL(pp_fill<TT>, dim3((unsigned)nwg), dim3(TT), (size_t)(2 * nb + 16) * 4, st, idx, w, val, rs_nodes, rows, K, nb, p.rcp, \
-                       p.T, p.totals, p.bstart, p.recs, p.ainv, ahat, cnode, p.recpos)
-    switch (pp_threads()) {
-        case 256: DGG_PB_PASS(256); break;
-        case 512: DGG_PB_PASS(512); break;
-        default: DGG_PB_PASS(1024); break;
-    }
-#undef DGG_PB_PASS
-    return dgg_check_launch("partb_build");
-}
-
-// backward of Z = A H over the buckets: dA_rec [rows*64] in RECORD (bucket) order -- there is no row-major dA: the row kernel reads
-// dA_rec through recpos --, dH [ncols,F] and da [ncols] by plain stores (every node of every bucket is written).  rs_all must have
-// been given to dgg_partb_build (the records' a_j table).  G [nodes of the block, F]; dA_ext [rows,64] nullable.
-int dgg_partb_conv_bwd(const float *G, const float *H, int64_t rows, int F, const void *ws, int64_t ncols, int width, const float *rs,
-                       const int32_t *cnode, const float *dA_ext, float *dA_rec, float *dH, float *da, void *stream) {
-    if ((F != 16 && F != 32 && F != 64 && F != 128) || (reinterpret_cast<uintptr_t>(G) % 16) || (reinterpret_cast<uintptr_t>(H) % 16) ||
-        (reinterpret_cast<uintptr_t>(dH) % 16))
-        return dgg_set_error(DGG_ERR_UNSUPPORTED, "partb_conv_bwd: feature width must be 16, 32, 64 or 128 (16-byte aligned rows)");
-    if (!rs || !ws || !dA_rec || !dH || dgg_partb_ws_bytes(rows, ncols, width) == 0) return dgg_set_error(DGG_ERR_ARG, "partb_conv_bwd: missing operand");
-    const size_t ldsb = ((size_t)width * F + width) * 4;
-    if (ldsb > 64 * 1024) return dgg_set_error(DGG_ERR_UNSUPPORTED, "partb_conv_bwd: width * F floats exceed the LDS of a workgroup");
-    if (rows == 0) return 0;
-    PartB p;
-    partb_layout(p, const_cast<void *>(ws), rows, ncols, width);
-    hipStream_t st = (hipStream_t)stream;
-#define DGG_CONV_B(FF)                                                                                                     \
-    if (dA_ext)                                                                                                            \
-        hipLaunchKernelGGL((conv_bwd_bucket<FF, true>), dim3((unsigned)p.nb), dim3(PB_T), ldsb, st, G, H, ncols, width, p.bstart, p.recs, \
-                           p.ainv, rs, cnode, dA_ext, dA_rec, dH, da);                                                     \
-    else                                                                                                                   \
-        hipLaunchKernelGGL((conv_bwd_bucket<FF, false>), dim3((unsigned)p.nb), dim3(PB_T), ldsb, st, G, H, ncols, width, p.bstart, p.recs, \
-                           p.ainv, rs, cnode, (const float *)nullptr, dA_rec, dH, da)
-    switch (F) {
-        case 16: DGG_CONV_B(16); break;
-        case 32: DGG_CONV_B(32); break;
-        case 64: DGG_CONV_B(64); break;
-        default: DGG_CONV_B(128); break;
-    }
-#undef DGG_CONV_B
-    return dgg_check_launch("partb_conv_bwd");
-}
-
-// dgg_softk_edge_bwd_partp_phase on a bucket partition: the row kernel takes an entry's cotangent from dA_rec through recpos; the
-// column side runs per bucket.  cptr / cnode (both or neither): chunked rows (`nrows` nodes, `rows` chunks); else rows == nrows.
-int dgg_partb_softk_edge_bwd(const float *xp, int64_t nrows, const int32_t *cptr, int64_t rows, int h, const int32_t *idx, const float *val,
-                             const float *k, const float *rs, const float *dA_rec, const float *da, const float *ahat_rows, int64_t row0, float t,
-                             int perturb, int mode, int normalized, const void *ws, int64_t ncols, int width, const int32_t *cnode,
-                             float *rowinfo_ws, float *dk, float *dxp, int out_act, int phase, void *stream) {
-    if (phase < 0 || phase > 2) return dgg_set_error(DGG_ERR_ARG, "partb_softk_edge_bwd: phase is 0 (all), 1 (rows) or 2 (buckets)");
-    if (mode != 0 && mode != 1) return dgg_set_error(DGG_ERR_ARG, "partb_softk_edge_bwd: mode must be 0 (k_times) or 1 (k_only)");
-    if (out_act != 0 && (out_act != 1 || mode != 0)) return dgg_set_error(DGG_ERR_ARG, "partb_softk_edge_bwd: out_act is 0 or 1 (LeakyReLU), mode 0 only");
-    if (!k || !dA_rec || !dk || !rowinfo_ws || (normalized && (!rs || !da || !ahat_rows)) || ((cptr == nullptr) != (cnode == nullptr)))
-        return dgg_set_error(DGG_ERR_ARG, "partb_softk_edge_bwd: missing operand");
-    if (!ws || dgg_partb_ws_bytes(rows, ncols, width) == 0) return dgg_set_error(DGG_ERR_ARG, "partb_softk_edge_bwd: no partition");
-    const size_t ldsb = (size_t)width * h * 4;
-    if (ldsb > 64 * 1024) return dgg_set_error(DGG_ERR_UNSUPPORTED, "partb_softk_edge_bwd: width * h floats exceed the LDS of a workgroup");
-    if (nrows == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    PartB p;
-    partb_layout(p, const_cast<void *>(ws), rows, ncols, width);
-    const SoftkArgs sk{k, rs, nullptr, da, mode, normalized, nullptr, dk, ahat_rows, reinterpret_cast<float4 *>(rowinfo_ws), p.recpos, dA_rec};
-    const unsigned gr = (unsigned)((nrows + 3) / 4);
-#define DGG_EDGE_B(HH)                                                                                                       \
-    if (phase != 2) {                                                                                                        \
-        if (cptr) hipLaunchKernelGGL((edge_bwd_rows_chunked<HH>), dim3(gr), dim3(256), 0, st, xp, nrows, cptr, idx, val, row0, t, perturb, dxp, sk); \
-        else hipLaunchKernelGGL((edge_bwd_rows<HH, true, true>), dim3(gr), dim3(256), 0, st, xp, nrows, idx, val, nullptr, 64, row0, t, perturb, \
-                                nullptr, nullptr, dxp, sk);                                                                  \
-    }                                                                                                                        \
-    if (phase != 1 && mode == 0)                                                                                             \
-        hipLaunchKernelGGL(edge_bwd_bucket<HH>, dim3((unsigned)p.nb), dim3(PB_T), ldsb, st, xp, ncols, width, p.bstart, p.recs, dA_rec, \
-                           reinterpret_cast<const float4 *>(rowinfo_ws), p.ainv, normalized, cnode, row0, nrows, t, perturb, dxp, out_act)
-    switch (h) {
-        case 16: DGG_EDGE_B(16); break;
-        case 32: DGG_EDGE_B(32); break;
-        case 64: DGG_EDGE_B(64); break;
-        case 128: DGG_EDGE_B(128); break;
-        default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "partb_softk_edge_bwd supports latent_dim in {16,32,64,128}");
-    }
-#undef DGG_EDGE_B
-    return dgg_check_launch("partb_softk_edge_bwd");
-}
-
-int dgg_partb_describe(int64_t rows, int64_t ncols, int width, int64_t *out4) {
-    if (!out4 || dgg_partb_ws_bytes(rows, ncols, width) == 0) return dgg_set_error(DGG_ERR_UNSUPPORTED, "partb_describe: no bucket partition for this shape");
-    PartB p;
-    partb_layout(p, nullptr, rows, ncols, width);
-    out4[0] = reinterpret_cast<char *>(p.bstart) - static_cast<char *>(nullptr);
-    out4[1] = reinterpret_cast<char *>(p.recs) - static_cast<char *>(nullptr);
-    out4[2] = reinterpret_cast<char *>(p.recpos) - static_cast<char *>(nullptr);
-    out4[3] = p.nb;
-    return 0;
 }
 
 // normalisation backward phase 1 through the partition; da [ncols] zeroed by the caller

@@ -191,29 +191,26 @@ int launch_ranked(const float *xp, int64_t N, int64_t row0, int64_t row1, float 
 // r / 64.  With every M_i = 1 this IS the [rows,64] list of the kernels above, and every chunk is a row of that layout to the
 // kernels downstream (partition, aggregation, backward), which only need the node of a chunk (cnode).
 //
-// chunk_layout: k -> cptr (exclusive scan of M_i), cnode, meta = {total chunks, max M_i, flags}; flags bit 0: some row's ramp
-// support exceeds 64 * maxm ranks (it is cut there -- callers raise, never truncate silently), bit 1: more chunks than `ccap`
-// (cnode holds the first ccap; the caller's arrays are too small: re-run with a larger capacity).  One workgroup: rows / 1024
-// consecutive nodes per thread.
-__global__ __launch_bounds__(1024) void chunk_layout(const float *__restrict__ k, int64_t rows, int maxm, int64_t ccap,
-                                                     int32_t *__restrict__ cptr, int32_t *__restrict__ cnode, int32_t *__restrict__ meta) {
-    // each of the 16 wavefronts owns a contiguous segment of the rows and walks it in tiles of 64 (coalesced loads, a 64-lane scan per
-    // tile, the running sum carried): pass 1 = segment totals, pass 2 = the same walk from the segment's base, writing cptr and cnode
-    __shared__ int wsum[16], wmax[16], wflag[16];
+// chunk_partial + chunk_layout: k -> cptr (exclusive scan of M_i), cnode, meta = {total chunks, max M_i, flags}; flags bit 0: some
+// row's ramp support exceeds 64 * maxm ranks (it is cut there -- callers raise, never truncate silently), bit 1: more chunks than
+// `ccap` (cnode holds the first ccap; the caller's arrays are too small: re-run with a larger capacity).  Two passes of 128
+// workgroups (segment totals, then the scan of each segment from its base): ~10 us at 100 000 rows (one workgroup: 96 us).
+constexpr int CL_NB = 128, CL_T = 256;                          // workgroups / threads of the two layout passes
+__device__ __forceinline__ int64_t cl_segment(int64_t rows) { return ((rows + CL_NB - 1) / CL_NB + CL_T - 1) / CL_T * CL_T; }
+
+// pass 1: per-segment totals of M_i, the widest row, the "beyond 64 * maxm ranks" flag -> part[3 * CL_NB]
+__global__ __launch_bounds__(CL_T) void chunk_partial(const float *__restrict__ k, int64_t rows, int maxm, int32_t *__restrict__ part) {
+    __shared__ int ws[CL_T / 64][3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t per = ((rows + 15) / 16 + 63) / 64 * 64;       // rows per wavefront, a multiple of 64
-    const int64_t lo = (int64_t)wave * per, hi = lo + per < rows ? lo + per : rows;
+    const int64_t per = cl_segment(rows), lo = (int64_t)blockIdx.x * per, hi = lo + per < rows ? lo + per : rows;
     const int kcap = 64 * maxm;
     int s = 0, mx = 0, flag = 0;
-    for (int64_t i0 = lo; i0 < hi; i0 += 64) {
-        const int64_t i = i0 + lane;
-        if (i < hi) {
-            const float kk = k[i];
-            if (!(ceilf(kk + 8.5f) + 1.0f <= (float)kcap)) flag = 1;    // (also NaN)
-            const int m = (klimit_len(kk, kcap) + 63) >> 6;
-            s += m;
-            mx = m > mx ? m : mx;
-        }
+    for (int64_t i = lo + tid; i < hi; i += CL_T) {
+        const float kk = k[i];
+        if (!(ceilf(kk + 8.5f) + 1.0f <= (float)kcap)) flag = 1;        // (also NaN)
+        const int m = (klimit_len(kk, kcap) + 63) >> 6;
+        s += m;
+        mx = m > mx ? m : mx;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -222,19 +219,49 @@ __global__ __launch_bounds__(1024) void chunk_layout(const float *__restrict__ k
         mx = v > mx ? v : mx;
         flag |= __shfl_xor(flag, off, 64);
     }
-    if (lane == 0) { wsum[wave] = s; wmax[wave] = mx; wflag[wave] = flag; }
+    if (lane == 0) { ws[wave][0] = s; ws[wave][1] = mx; ws[wave][2] = flag; }
     __syncthreads();
-    int run = 0, total = 0, tmax = 0, tflag = 0;
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const int v = wsum[q];
-        if (q < wave) run += v;
-        total += v;
-        tmax = wmax[q] > tmax ? wmax[q] : tmax;
-        tflag |= wflag[q];
+    if (tid == 0) {
+        int ts = 0, tm = 0, tf = 0;
+        for (int q = 0; q < CL_T / 64; q++) { ts += ws[q][0]; tm = ws[q][1] > tm ? ws[q][1] : tm; tf |= ws[q][2]; }
+        part[3 * blockIdx.x] = ts; part[3 * blockIdx.x + 1] = tm; part[3 * blockIdx.x + 2] = tf;
     }
-    for (int64_t i0 = lo; i0 < hi; i0 += 64) {
-        const int64_t i = i0 + lane;
+}
+// pass 2: every workgroup scans the segment totals for its base, then its own segment in tiles of CL_T rows (coalesced loads, a
+// workgroup scan per tile, the running sum carried): cptr, cnode; workgroup 0 writes the totals; all zero cnode beyond the last chunk
+__global__ __launch_bounds__(CL_T) void chunk_layout(const float *__restrict__ k, int64_t rows, int maxm, int64_t ccap,
+                                                     const int32_t *__restrict__ part, int32_t *__restrict__ cptr,
+                                                     int32_t *__restrict__ cnode, int32_t *__restrict__ meta) {
+    __shared__ int wsum[CL_T / 64], sbase, stotal, smax, sflag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t per = cl_segment(rows), lo = (int64_t)blockIdx.x * per, hi = lo + per < rows ? lo + per : rows;
+    const int kcap = 64 * maxm;
+    if (wave == 0) {                                             // CL_NB = 128 partial sums: two per lane
+        int b0 = 0, tot = 0, tm = 0, tf = 0;
+#pragma unroll
+        for (int q = 0; q < CL_NB / 64; q++) {
+            const int g = q * 64 + lane;
+            const int v = part[3 * g];
+            if (g < (int)blockIdx.x) b0 += v;
+            tot += v;
+            tm = part[3 * g + 1] > tm ? part[3 * g + 1] : tm;
+            tf |= part[3 * g + 2];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            b0 += __shfl_xor(b0, off, 64);
+            tot += __shfl_xor(tot, off, 64);
+            const int v = __shfl_xor(tm, off, 64);
+            tm = v > tm ? v : tm;
+            tf |= __shfl_xor(tf, off, 64);
+        }
+        if (lane == 0) { sbase = b0; stotal = tot; smax = tm; sflag = tf; }
+    }
+    __syncthreads();
+    int run = sbase;
+    const int total = stotal;
+    for (int64_t i0 = lo; i0 < hi; i0 += CL_T) {
+        const int64_t i = i0 + tid;
         const int m = i < hi ? (klimit_len(k[i], kcap) + 63) >> 6 : 0;
         int incl = m;
 #pragma unroll
@@ -242,20 +269,30 @@ __global__ __launch_bounds__(1024) void chunk_layout(const float *__restrict__ k
             const int v = __shfl_up(incl, off, 64);
             if (lane >= off) incl += v;
         }
-        const int first = run + incl - m;
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int wbase = 0, tsum = 0;
+#pragma unroll
+        for (int q = 0; q < CL_T / 64; q++) {
+            const int v = wsum[q];
+            if (q < wave) wbase += v;
+            tsum += v;
+        }
+        const int first = run + wbase + incl - m;
         if (i < hi) {
             cptr[i] = first;
             for (int c = 0; c < m; c++)
                 if (first + c < ccap) cnode[first + c] = (int32_t)i;
         }
-        run += __shfl(incl, 63, 64);
+        run += tsum;
+        __syncthreads();
     }
-    for (int64_t c = (int64_t)total + tid; c < ccap; c += 1024) cnode[c] = 0;      // chunks beyond the last one: defined (node 0), empty
-    if (tid == 0) {
+    for (int64_t c = (int64_t)total + (int64_t)blockIdx.x * CL_T + tid; c < ccap; c += (int64_t)CL_NB * CL_T) cnode[c] = 0;   // chunks beyond the last one: node 0, empty
+    if (blockIdx.x == 0 && tid == 0) {
         cptr[rows] = total;
         meta[0] = total;
-        meta[1] = tmax;
-        meta[2] = tflag | (total > ccap ? 2 : 0);
+        meta[1] = smax;
+        meta[2] = sflag | (total > ccap ? 2 : 0);
         meta[3] = 0;
     }
 }
@@ -513,12 +550,15 @@ int dgg_allpairs_topk_ranked_softk_dseed(const float *xp, int64_t N, int h, int6
 
 // ---- chunked rows (rows wider than 64 ranks) ----
 // Layout of the chunked rows from the learned degrees: cptr [rows+1] (first chunk of every node), cnode [ccap] (node of every chunk),
-// meta int32[4] = {total chunks, max chunks of a row, flags (1: a row needs more than 64*maxm ranks, 2: more than ccap chunks), 0}.
+// meta int32[4 + 384] = {total chunks, max chunks of a row, flags (1: a row needs more than 64*maxm ranks, 2: more than ccap chunks), 0,
+// scratch of the two-pass scan}.
 int dgg_chunk_layout(const float *k, int64_t rows, int maxm, int64_t ccap, int32_t *cptr, int32_t *cnode, int32_t *meta, void *stream) {
     if (rows < 0 || maxm < 1 || maxm > DGG_CHUNK_MAXM || ccap < 0 || !k || !cptr || !cnode || !meta)
         return dgg_set_error(DGG_ERR_ARG, "chunk_layout: bad sizes or NULL arrays (maxm in 1..32)");
     if (rows >= ((int64_t)1 << 25)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "chunk_layout: rows < 2^25");
-    hipLaunchKernelGGL(chunk_layout, dim3(1), dim3(1024), 0, (hipStream_t)stream, k, rows, maxm, ccap, cptr, cnode, meta);
+    // (the segment totals of the first pass live in meta[4 .. 4 + 3 * 128): meta is int32 [4 + 384])
+    hipLaunchKernelGGL(chunk_partial, dim3(CL_NB), dim3(CL_T), 0, (hipStream_t)stream, k, rows, maxm, meta + 4);
+    hipLaunchKernelGGL(chunk_layout, dim3(CL_NB), dim3(CL_T), 0, (hipStream_t)stream, k, rows, maxm, ccap, meta + 4, cptr, cnode, meta);
     return dgg_check_launch("chunk_layout");
 }
 // dgg_allpairs_topk_ranked_softk[_dseed] for chunked rows: idx / val / w are [chunks, 64] (chunk c of node i = ranks 64 (c - cptr[i]) ...),

@@ -430,7 +430,7 @@ def chunk_layout(k, maxm=CHUNK_MAXM, ccap=None):
     k = _chk(k)
     rows = k.shape[0]
     dev = k.device
-    meta = torch.empty((4,), device=dev, dtype=torch.int32)
+    meta = torch.empty((4 + 384,), device=dev, dtype=torch.int32)          # {chunks, widest row, flags, 0} + scratch of the two-pass scan
     cptr = torch.empty((rows + 1,), device=dev, dtype=torch.int32)
     if ccap is not None:
         cnode = torch.empty((int(ccap),), device=dev, dtype=torch.int32)
@@ -440,7 +440,7 @@ def chunk_layout(k, maxm=CHUNK_MAXM, ccap=None):
     while True:
         cnode = torch.empty((cap,), device=dev, dtype=torch.int32)
         _lib.check(_lib.lib().dgg_chunk_layout(_ptr(k), rows, int(maxm), cap, _ptr(cptr), _ptr(cnode), _ptr(meta), _stream()), "chunk_layout")
-        total, widest, flags, _ = (int(v) for v in meta.cpu())
+        total, widest, flags, _ = (int(v) for v in meta[:4].cpu())
         if flags & 1:
             raise RuntimeError(f"chunk_layout: a learned degree needs more than {64 * maxm} ranks (k + 9.5 > {64 * maxm}): beyond the "
                                "chunked rows' capacity (or not finite)")
@@ -1034,52 +1034,6 @@ def partp_sort(part):
     part.args = None
 
 
-# ---- bucket partition (include/dgg_hip.h, dgg_partb_*): the per-destination backward without the node sort -------------------------
-BUCKET_BWD = os.environ.get("DGG_BUCKET_BWD", "1") != "0"
-BUCKET_MIN_NODES = int(os.environ.get("DGG_BUCKET_MIN_NODES", "32768"))      # smaller graphs are launch-bound: the per-node kernels
-
-
-class PartB:
-    """bucket partition (dgg_partb_build): workspace + the shape and bucket width it was built for"""
-    bucket = True
-
-    def __init__(self, ws, rows, ncols, width, layout=None):
-        self.ws, self.rows, self.K, self.ncols, self.width, self.layout = ws, rows, 64, ncols, width, layout
-        self.args = None
-
-    def recpos(self):
-        """int32 [rows,64]: position of every entry's record in the bucket-ordered record array (-1: not in the partition)"""
-        out = (C.c_int64 * 4)()
-        _lib.check(_lib.lib().dgg_partb_describe(self.rows, self.ncols, self.width, out), "partb_describe")
-        return self.ws[out[2]: out[2] + 4 * self.rows * 64].view(torch.int32).view(self.rows, 64)
-
-
-def partb_width(maxfeat, ncols):
-    """destination nodes per bucket: the bucket's sums live in LDS (width * (maxfeat + 1) floats <= 56 KB), at most 4096 buckets"""
-    w = min(256, (14336 // (int(maxfeat) + 1)) // 8 * 8)
-    if w < 8 or (ncols + w - 1) // w > 4096:
-        return 0
-    return w
-
-
-def partb_build(idx, w, val, rs_rows, ncols, rs_all, maxfeat, layout=None):
-    """-> (PartB, ahat [rows,64]) or None when the bucket partition does not apply (K != 64, too many buckets, small graphs)"""
-    N, K = idx.shape
-    width = partb_width(maxfeat, ncols) if (K == 64 and BUCKET_BWD and ncols >= BUCKET_MIN_NODES) else 0
-    if width == 0:
-        return None
-    nbytes = int(_lib.lib().dgg_partb_ws_bytes(N, ncols, width))
-    if nbytes == 0:
-        return None
-    wide = layout is not None and layout.wide
-    assert not wide or (N == layout.chunks and rs_rows.shape[0] == layout.rows)
-    ws = torch.empty((nbytes,), device=idx.device, dtype=torch.uint8)
-    ahat = torch.empty((N, K), device=idx.device, dtype=torch.float32)
-    _lib.check(_lib.lib().dgg_partb_build(_ptr(idx), _ptr(_chk(w)), _ptr(_chk(val)), _ptr(_chk(rs_rows)), N, _ptr(layout.cnode) if wide else None,
-                                          ncols, width, _ptr(_chk(rs_all)), _ptr(ahat), _ptr(ws), _stream()), "partb_build")
-    return PartB(ws, N, ncols, width, layout if wide else None), ahat
-
-
 def partp_gather(partp, dA):
     """row-major dA [rows,64] (chunked rows: [chunks,64]) -> the same values in the record order of the payload partition [rows*64]"""
     dA = _chk(dA)
@@ -1101,22 +1055,6 @@ def conv_bwd_cols_p(idx, H, G, partp, rs, zero_dA=True, dA_ext=None, want_dA=Tru
     if partp is None or F not in CONV_BWD_WIDTHS or H.data_ptr() % 16 or G.data_ptr() % 16 or H.shape[0] != partp.ncols:
         return None
     ncols = H.shape[0]
-    if getattr(partp, "bucket", False):              # bucket partition: no row-major dA at all (the row kernel goes through recpos)
-        lay = partp.layout
-        assert G.shape[0] == (N if lay is None else lay.rows)
-        alloc = torch.zeros if N == 0 else torch.empty
-        dH = alloc((ncols, F), device=H.device, dtype=torch.float32)
-        da = alloc((ncols,), device=H.device, dtype=torch.float32)
-        dA_rec = torch.empty((N * K,), device=H.device, dtype=torch.float32)
-        if dA_ext is not None:
-            dA_ext = _chk(dA_ext.contiguous())
-            assert tuple(dA_ext.shape) == (N, K)
-        pe = _probe_begin()
-        _lib.check(_lib.lib().dgg_partb_conv_bwd(_ptr(G), _ptr(H), N, F, _ptr(partp.ws), ncols, partp.width, _ptr(_chk(rs)),
-                                                 _ptr(None if lay is None else lay.cnode), _ptr(dA_ext), _ptr(dA_rec), _ptr(dH), _ptr(da), _stream()),
-                   "partb_conv_bwd")
-        _probe_end("conv_bwd", pe)
-        return None, dA_rec, dH, da
     dA = None
     if want_dA:
         dA = _zeros((N, K), H.device) if zero_dA else torch.empty((N, K), device=H.device, dtype=torch.float32)   # entries outside the partition stay 0
@@ -1164,16 +1102,6 @@ def softk_edge_bwd_p(xp, idx, val, k, dA, dA_rec, rs, da, row0, t, perturb, mode
         rowinfo = torch.empty((N, 4), device=xp.device, dtype=torch.float32)
         dk = torch.empty((nrows,), device=xp.device, dtype=torch.float32)
     pe = _probe_begin()
-    if getattr(partp, "bucket", False):
-        _lib.check(_lib.lib().dgg_partb_softk_edge_bwd(_ptr(xp), nrows, _ptr(None if lay is None else lay.cptr), N, h, _ptr(idx), _ptr(_chk(val)),
-                                                       _ptr(_chk(k)), _ptr(rs), _ptr(dA_rec), _ptr(da), _ptr(None if ahat_rows is None else _chk(ahat_rows)),
-                                                       row0, t, int(perturb), mode, int(normalized), _ptr(partp.ws), Ng, partp.width,
-                                                       _ptr(None if lay is None else lay.cnode), _ptr(rowinfo), _ptr(dk), _ptr(dxp), int(out_act),
-                                                       int(phase), _stream()), "partb_softk_edge_bwd")
-        _probe_end("edge_bwd" if phase == 0 else ("edge_bwd_rows" if phase == 1 else "edge_bwd_node"), pe)
-        if phase == 1:
-            return dxp, dk, (dxp, dk, rowinfo)
-        return dxp, dk
     if lay is not None:                          # chunked rows: one wavefront per node walks its chunks; rowinfo per chunk
         assert dA is not None and K == 64
         _lib.check(_lib.lib().dgg_softk_edge_bwd_partp_chunked(_ptr(xp), nrows, _ptr(lay.cptr), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(k)), _ptr(rs),
@@ -1503,14 +1431,6 @@ class EllNormalizeFn(torch.autograd.Function):
         return dw, None, None, None
 
 
-def _rows_dA(got, partp):
-    """row-major dA [rows,64] of a conv_bwd_cols_p result: with a bucket partition the kernel leaves dA in record order only"""
-    if got[0] is not None:
-        return got[0]
-    rp = partp.recpos()
-    return torch.where(rp >= 0, got[1][rp.clamp(min=0).long()], torch.zeros((), device=rp.device))
-
-
 class EllSpmmFn(torch.autograd.Function):
     """Y = act(A X) on the ELL adjacency (torch.mm(adj, x) model.py:594, 67 / torch.spmm model.py:34; act = ReLU when GCNConv
     aggregates the projected features, relu(A (x W)))."""
@@ -1534,7 +1454,7 @@ class EllSpmmFn(torch.autograd.Function):
             if ctx.skip_zero and ctx.partp is not None and X.shape[0] == lay.rows:
                 got = conv_bwd_cols_p(idx, X, dY, ctx.partp[0], ctx.partp[1], zero_dA=True)       # (chunk-aware through the partition's layout)
                 if got is not None:
-                    return _rows_dA(got, ctx.partp[0]), None, (got[2] if ctx.needs_input_grad[2] else None), None, None, None, None, None
+                    return got[0], None, (got[2] if ctx.needs_input_grad[2] else None), None, None, None, None, None
             # every chunk as a row of its own against the cotangent row of its node
             dYc = dY.index_select(0, lay.cnode.long()[:idx.shape[0]])
             dA, dX = spmm_bwd(idx, ahat, X, dYc, need_dx=ctx.needs_input_grad[2], skip_zero=ctx.skip_zero)
@@ -1544,7 +1464,7 @@ class EllSpmmFn(torch.autograd.Function):
             # backward (the records carry the normalised values): dA by plain stores, dX owned by the destination's wavefront
             got = conv_bwd_cols_p(idx, X, dY, ctx.partp[0], ctx.partp[1], zero_dA=True)
             if got is not None:
-                return _rows_dA(got, ctx.partp[0]), None, got[2], None, None, None, None, None
+                return got[0], None, got[2], None, None, None, None, None
         if ctx.needs_input_grad[2] and ctx.skip_zero and X.shape[0] == idx.shape[0]:
             # learned input on a DGG adjacency: SDDMM and transposed SpMM from ONE gathered cotangent row per entry
             got = conv_bwd_cols(idx, ahat, X, dY, ctx.part)

@@ -152,7 +152,7 @@ class ShardedDGGConv:
         """raises if a forward under a fixed chunk capacity (wide_cap) could not hold every row's ranks (one synchronisation)"""
         meta, self.wide_meta = self.wide_meta, None
         if meta is not None:
-            total, widest, flags, _ = (int(v) for v in meta.cpu())
+            total, widest, flags, _ = (int(v) for v in meta[:4].cpu())
             if flags:
                 raise RuntimeError(f"ShardedDGGConv: the chunked rows outgrew their fixed capacity {self.wide_cap} (chunks needed {total}, widest "
                                    f"row {widest} chunks, flags {flags}): re-capture with a larger wide_cap")
@@ -301,15 +301,8 @@ class ShardedDGGConv:
         lay = s.get("layout")
         lkw = {} if lay is None else {"layout": lay}
         assert lay is None or use_p, "chunked rows run on the payload partition (latent / conv widths 16, 32, 64, 128; soft modes)"
-        # large graphs: the BUCKET partition (no node sort, no row-major dA; the backward walks source-ordered buckets: ops.partb_build)
-        got = None
-        if use_p and hasattr(kern, "partb_build") and self.scorer is None and self.cand is None:
-            got = kern.partb_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs, max(xp.shape[1], H.shape[1]), **lkw)
-            if got is not None:
-                ov = nobwd = False                  # (nothing left to sort)
-        if got is None:
-            got = (kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs, phase=1, **lkw) if (ov or nobwd) else
-                   kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs, **lkw)) if use_p else None
+        got = (kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs, phase=1, **lkw) if (ov or nobwd) else
+               kern.partp_build(s["idx"], s["w"], s["val"], rs_local, self.N, rs, **lkw)) if use_p else None
         s["partp"], s["ahat"] = got if got is not None else (None, None)
         s["side_join"] = False
         s["partp_sorted"] = not nobwd
