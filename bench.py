@@ -51,7 +51,9 @@ def load_traffic(N, d, h):
             t = json.load(f)
         if t.get("shape") != {"nodes": N, "feat": d, "latent": h}:
             return {}
-        return {k: v["fabric_bytes_per_launch"] for k, v in t["kernels"].items()}
+        out = {k: v["fabric_bytes_per_launch"] for k, v in t["kernels"].items()}
+        out["_source"] = "replayed:profiles/" + names[-1]        # (PMC passes cannot run inside a timed bench: the numbers are REPLAYED)
+        return out
     except Exception:  # noqa: BLE001
         return {}
 
@@ -327,6 +329,52 @@ def run_edgelist(a, dev):
     return out
 
 
+def allpairs_module_api(a, dev, N, steps, warmup, windows=5):
+    """BASELINE configs[2] through the nn.Module API north_star names: GCN_DGG's first layer = DGG_LearnableK_debug.forward_conv
+    (generator + normalize_adj + GCNConv as ONE autograd node, _FusedDGGConvFn) on AllPairs candidates, under torch autograd, eager
+    launches: loss.backward() through the node, gradients into the nn.Parameters.  -> ms per step (median window), k mean."""
+    import dgg_amd
+    from argparse import Namespace
+    d, h = a.feat, a.latent
+    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     symmetric_noise=False, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
+    torch.manual_seed(0)
+    dgg = dgg_amd.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=args)
+    conv = dgg_amd.GCNConv(d, 64)
+    with torch.no_grad():
+        dgg.k_net.k_project.weight.mul_(0.1)
+    dgg, conv = dgg.to(dev), conv.to(dev)
+    x = torch.randn(N, d, generator=torch.Generator().manual_seed(1000)).to(dev)
+    cand = dgg_amd.AllPairs((24 + 16 * torch.rand(N, generator=torch.Generator().manual_seed(7))).to(dev))
+    params = list(dgg.parameters()) + list(conv.parameters())
+
+    def step():
+        for p_ in params:
+            p_.grad = None
+        Z, adj = dgg.forward_conv(x, cand, conv.W)
+        Z.sum().backward()
+        return adj
+
+    for _ in range(warmup):
+        adj = step()
+    tws = []
+    for _ in range(windows):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            adj = step()
+        torch.cuda.synchronize()
+        tws.append((time.perf_counter() - t0) / steps)
+    dgg.check_ell_bound()
+    T = float(np.median(tws))
+    km = float(adj.k.mean().item())
+    return {"workload": f"synthetic all-pairs DGG N={N} d={d} h={h} k~{km:.1f} through DGG_LearnableK_debug.forward_conv (_FusedDGGConvFn: "
+                        "generator + normalize_adj + GCNConv as one autograd node) under torch autograd, eager launches, one readback of "
+                        "the chunk layout per forward (rows wider than the list would be chunked)",
+            "ms_per_step": T * 1e3, "windows_ms": [w_ * 1e3 for w_ in tws], "steps": steps, "value": N * km / T, "unit": "edges/s", "dtype": "f32"}
+
+
 def bench_module_api(a, dev):
     """The headline configuration through the DROP-IN MODULES under torch autograd (DGG_LearnableK_debug with all-pairs
     candidates -> normalize -> GCNConv, forward + backward): what a training script that swaps the imports gets, next to
@@ -380,8 +428,8 @@ def run_ppi(a, dev):
     """BASELINE.json configs[4] (PPI shape: graphs of 591..3480 nodes, d=50, hidden 2048, 9 GCNII layers, 121 labels,
     train_ppi.py:43-44): dgg_amd.GCNIIppi_DGG under autograd, one forward + backward per graph; fp32, or with --bf16 the GCNII
     layer products on the hand-written bf16 MFMA kernel (dgg_bf16.hip).  The DGG runs at latent_dim = hidden = 2048
-    (model.py:907-910).  cpu_baseline: the reference-shaped DENSE formulation of the same model in torch CPU ops on the smallest
-    graph of the batch (cpu_baseline_ppi)."""
+    (model.py:907-910).  cpu_baseline: the reference-shaped DENSE formulation of the same model in torch CPU ops on (up to) four
+    graphs of the batch (cpu_baseline_ppi)."""
     import dgg_amd
     from argparse import Namespace
     d, hid, C, L = 50, 2048, 121, 9
@@ -465,14 +513,27 @@ def run_ppi(a, dev):
                      "kernel_ms_per_step": t_g * 1e3, "per_kernel": per_kernel, "whole_step_gemm_tflops": gemm_flop / T / 1e12,
                      "note": "GEMM flops of the GCNII layers / summed event-timed duration of the GEMM calls inside running steps"},
         "kernels_ms_per_step": {n_: v[0] for n_, v in pk.items()},
-        "cpu_baseline": (cpu_baseline_ppi(m, min(graphs, key=lambda g_: g_[0].shape[0]), min(os.cpu_count() or 1, 32))
+        # (bounded sample: the whole batch when it has at most four graphs, else its four smallest)
+        "cpu_baseline": (cpu_baseline_ppi(m, sorted(graphs, key=lambda g_: g_[0].shape[0])[:4], min(os.cpu_count() or 1, 32))
                          if a.cpu_rows >= 0 else None)})
 
 
-def cpu_baseline_ppi(m, graph, threads, lamda=0.5, alpha=0.5):
+def cpu_baseline_ppi(m, graphs, threads, lamda=0.5, alpha=0.5):
     """BASELINE.md section 3 for configs[4]: the reference-shaped dense formulation (oracle/dense_ref.py: [N,N] adjacency, torch.mm
-    per layer, autograd) of GCNIIppi_DGG on ONE graph of the batch, forward + backward, torch CPU ops on `threads` threads, eval-mode
-    dropout and no perturbation (the same arithmetic volume).  Bounded sample: the smallest graph."""
+    per layer, autograd) of GCNIIppi_DGG on the given graphs of the batch one after the other (train_ppi.py:204-219 steps per graph),
+    forward + backward, torch CPU ops on `threads` threads, eval-mode dropout and no perturbation (the same arithmetic volume)."""
+    tot_e, tot_t, sizes = 0.0, 0.0, []
+    for g_ in graphs:
+        r_ = _cpu_baseline_ppi_one(m, g_, threads, lamda, alpha)
+        tot_e += r_[0]
+        tot_t += r_[1]
+        sizes.append(r_[2])
+    return dict(value=tot_e / tot_t, unit="edges/s", cores=threads, kind="port",
+                sample=f"dense torch-CPU formulation of GCNIIppi_DGG on {len(graphs)} graphs of the batch ({sizes} nodes, {int(tot_e)} candidate "
+                       f"entries in all), forward + backward per graph, {tot_t:.2f} s")
+
+
+def _cpu_baseline_ppi_one(m, graph, threads, lamda, alpha):
     import math
     from oracle import dense_ref as D
     torch.set_num_threads(threads)
@@ -501,9 +562,7 @@ def cpu_baseline_ppi(m, graph, threads, lamda=0.5, alpha=0.5):
     out = torch.sigmoid(hcur @ f1w.t() + f1b)
     torch.nn.functional.binary_cross_entropy(out, y).backward()
     dt = time.perf_counter() - t0
-    return dict(value=float(rows.shape[0]) / dt, unit="edges/s", cores=threads, kind="port",
-                sample=f"dense torch-CPU formulation of GCNIIppi_DGG on the smallest graph of the batch ({n} nodes, {rows.shape[0]} candidate "
-                       f"entries), forward + backward, {dt:.2f} s")
+    return float(rows.shape[0]), dt, int(n)
 
 
 def cpu_baseline_edgelist(N, d, h, rows, cols, x, vals, dgg, conv, threads):
@@ -857,7 +916,7 @@ def other_configs(a, dev):
     import copy
     from dgg_amd import ops
     res = {}
-    only = [c_ for c_ in os.environ.get("DGG_BENCH_CONFIGS", "pubmed,ppi,k128,n500k").split(",") if c_]     # (diagnostic: a subset)
+    only = [c_ for c_ in os.environ.get("DGG_BENCH_CONFIGS", "pubmed,ppi,module,k128,n500k").split(",") if c_]     # (diagnostic: a subset)
 
     def pick(o, extra=()):
         keep = ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "roofline", "cpu_baseline", "kernels_ms_per_step") + tuple(extra)
@@ -892,10 +951,16 @@ def other_configs(a, dev):
     try:
         if "ppi" in only:
             b = copy.copy(a)
-            b.steps, b.warmup, b.graphs, b.bf16 = 3, 2, 4, True
+            b.steps, b.warmup, b.graphs, b.bf16 = 10, 2, 20, True       # 20 graphs of 591..3480 nodes
             res["ppi_bf16"] = pick(run_ppi(b, dev))
     except Exception as e:  # noqa: BLE001
         res["ppi_bf16"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    try:
+        if "module" in only:
+            res["allpairs_module_api"] = allpairs_module_api(a, dev, 100_000, 20, 5)
+    except Exception as e:  # noqa: BLE001
+        res["allpairs_module_api"] = {"error": repr(e)}
     torch.cuda.empty_cache()
     try:
         if "k128" in only:
@@ -928,6 +993,11 @@ def other_configs(a, dev):
         kept5 = float((r5.layer.saved["idx"] >= 0).sum().item())
         dom5 = max(kern5, key=kern5.get)
         comp5 = N5 * 4.0 * a.latent + kept5 * 8 + N5 * 4
+        try:                                                 # the oracle on a bounded row sample of the same 500 000-node problem
+            cores5 = os.cpu_count() or 1
+            cpu5 = cpu_baseline(N5, a.feat, a.latent, r5.P, min(16 * cores5, N5), cores5, ops.NOISE_RANKED) if a.cpu_rows >= 0 else None
+        except Exception as e:  # noqa: BLE001
+            cpu5 = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
         res["n500k_one_gpu"] = {"workload": f"synthetic all-pairs DGG N={N5} d={a.feat} h={a.latent} k~{km:.1f} on ONE GPU (BASELINE configs[3]'s graph), "
                                             "eager launches", "ms_per_step": T5 * 1e3, "windows_ms": [w_ * 1e3 for w_ in w5], "value": N5 * km / T5, "unit": "edges/s", "steps": 5,
                                 "dtype": "f32", "kernels_ms_per_step": kern5,
@@ -936,7 +1006,7 @@ def other_configs(a, dev):
                                              "achieved": comp5 / (kern5["allpairs_topk"] * 1e-3) / 1e9,
                                              "frac": comp5 / (kern5["allpairs_topk"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                              "dominant_by_time": dom5},
-                                "cpu_baseline": None}
+                                "cpu_baseline": cpu5}
         del r5
     except Exception as e:  # noqa: BLE001
         res["n500k_one_gpu"] = {"error": repr(e)}
@@ -1106,7 +1176,7 @@ def bench_synthetic(a, dev, world, rank, force):
                         print(f"variant {name}: hipGraph capture failed ({e!r}); timing eager launches", file=sys.stderr)
                         vgraphs = None
                 tws = []
-                for _w in range(3):                                 # median of three windows
+                for _w in range(7):                                 # median of seven windows
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     for s_ in range(vsteps):
@@ -1128,7 +1198,7 @@ def bench_synthetic(a, dev, world, rank, force):
                 pk = e0.elapsed_time(e1)
                 variants[name] = {"ms_per_step": tv * 1e3, "edges_per_s": N * kv / tv, "pair_kernel_ms": pk, "steps": vsteps,
                                   "window_ms_min_median_max": [min(tws) * 1e3, tv * 1e3, max(tws) * 1e3],
-                                  "note": "ms_per_step: median of three windows of hipGraph replay (two seeds alternating); pair_kernel_ms: events around the C-ABI call in one eager step"}
+                                  "note": "ms_per_step: median of seven windows of hipGraph replay (two seeds alternating); pair_kernel_ms: events around the C-ABI call in one eager step"}
                 # roofline of the pair stage of the variants that sweep all N^2 pairs (one C-ABI call = several launches, event-timed as a
                 # whole; per-launch durations: profiles/r03_*_kernel_stats.csv)
                 if name == "unperturbed":
@@ -1207,15 +1277,17 @@ def bench_synthetic(a, dev, world, rank, force):
                                             "reduce-scatter [dxp | dH], all-reduce weight gradients")},
             # dominant kernel BY TIME of the step (an O(N*K) gather kernel since the pair stage became O(N*150))
             "roofline": {"bound": "hbm", "kernel": dom, "rocprof_kernel": ROCPROF_NAME.get(dom), "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": traffic.get(dom),
+                         "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBPS, "traffic": traffic.get(dom) if lay is None else None,
+                         "traffic_source": (traffic.get("_source") if (lay is None and traffic.get(dom) is not None) else None),
                          "kernel_ms": kern[dom]["ms"], "algorithmic_bytes": kern[dom]["compulsory"],
                          "gathered_bytes": kern[dom]["gathered"], "gather_GBps": kern[dom]["gather_GBps"],
                          "gather_ceiling_GBps": GATHER_CEILING_GBPS, "frac_gather_ceiling": kern[dom]["gather_GBps"] / GATHER_CEILING_GBPS,
                          "note": "frac = SURVEY 8(d) compulsory bytes (every array touched once) / event-timed duration / 8 TB/s; the kernel "
                                  "is a random-row gather from an Infinity-Cache-resident 25.6 MB table, whose ceiling is the guide's "
                                  "measured 8.6 TB/s (MI355X_MICROARCH.md, 'Indexed rows'): frac_gather_ceiling counts every gathered row "
-                                 "once per use against that; traffic = fabric bytes per launch from the PMC passes (null when not "
-                                 "measured for this shape)"},
+                                 "once per use against that; traffic = fabric bytes per launch from the rocprofv3 PMC passes, NOT measured "
+                                 "in this run: replayed from the committed file named in traffic_source (null when there is none for "
+                                 "this shape)"},
             "kernels": {n_: {"ms": v["ms"], "GBps": v["GBps"], "frac_hbm": v["GBps"] / HBM_PEAK_GBPS, "gather_GBps": v["gather_GBps"],
                              "frac_gather_ceiling": v["gather_GBps"] / GATHER_CEILING_GBPS, "fabric_bytes_per_launch": traffic.get(n_),
                              **({"composite": v["composite"]} if "composite" in v else {})} for n_, v in kern.items()},

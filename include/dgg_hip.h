@@ -151,7 +151,8 @@ int dgg_knet_input_deg_fwd(const float *deg, int64_t N, float dmean, float dstd,
  * edge_prob_net "u-v-dist" (dgm.py:1607-1627) + perturbation (dgm.py:1211-1229) + torch.sort (dgm.py:1404), kept
  * to the K best per row.  xp [N,h] = leaky(node_encode_for_edges(x)); t = -0.05 (dgm.py:1618).
  * All-pairs candidates (complete in_adj): rows [row0,row1) of the N x N score matrix; outputs [row1-row0, K].
- * algo: 0 auto, 1 exhaustive, 2 pruned (identical results).  workspace: dgg_allpairs_workspace_bytes().
+ * algo: 0 auto, 1 exhaustive, 2 the MFMA sweep (unperturbed scores), 4 guess-and-verify (per-pair hash noise); identical results.
+ * workspace: dgg_allpairs_workspace_bytes().
  * k_limit (nullable, [row1-row0]): the learned k of each row.  The soft top-k ramp (dgm.py:1412-1420) is exactly 0.0f
  * for ranks r >= ceil(k + 8.5), so with k_limit the ranks from ceil(k + 8.5) + 1 on are returned as idx = -1, val = 0
  * (weights, outputs and gradients are unchanged) and the ranked-noise search stops as soon as the kept ranks are

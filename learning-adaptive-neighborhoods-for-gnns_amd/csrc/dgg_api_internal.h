@@ -17,24 +17,12 @@ int dgg_check_hip(hipError_t e, const char *what);
 int dgg_allpairs_topk_exhaustive_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t,
                                       int noise_mode, const float *G, int64_t ldG, uint32_t s0, uint32_t s1, int K,
                                       int32_t *idx, float *val, hipStream_t st);
-int dgg_allpairs_topk_fast_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t,
-                                int noise_mode, uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val,
-                                void *workspace, size_t ws_bytes, hipStream_t st);
-size_t dgg_allpairs_fast_ws_bytes(int64_t N, int h);
-bool dgg_allpairs_fast_supported(int h, int noise_mode, int K);
-
 // unperturbed scores, two-phase guess-sweep-verify (dgg_topk_sweep.hip)
 int dgg_allpairs_topk_sweep_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int K, const float *klim, int32_t *idx, float *val,
                                  void *workspace, size_t ws_bytes, hipStream_t st);
 size_t dgg_allpairs_sweep_ws_bytes(int64_t rows, int64_t N, int h);
 size_t dgg_allpairs_sweep_ctl_offset(int64_t rows, int64_t N, int h);
 bool dgg_allpairs_sweep_supported(int h, int noise_mode, int K);
-
-int dgg_allpairs_topk_np_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode,
-                              uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, void *workspace, size_t ws_bytes,
-                              hipStream_t st);
-size_t dgg_allpairs_np_ws_bytes(int64_t N);
-bool dgg_allpairs_np_supported(int h, int noise_mode, int K);
 
 int dgg_allpairs_topk_gv_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode,
                               uint32_t s0, uint32_t s1, int K, int32_t *idx, float *val, void *workspace, size_t ws_bytes,

@@ -35,9 +35,6 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
         return dgg_allpairs_topk_ranked_impl(xp, N, h, row0, row1, t, s0, s1, K, k_limit, idx, val, st);
     if (noise_mode == 5)   // ranked symmetric generator: owners emit their largest noises, rows verify (dgg_topk_rsym.hip)
         return dgg_allpairs_topk_rsym_impl(xp, N, h, row0, row1, t, s0, s1, K, k_limit, idx, val, workspace, ws_bytes, st);
-    const bool can_fast = dgg_allpairs_fast_supported(h, noise_mode, K) && workspace &&
-                          ws_bytes >= dgg_allpairs_fast_ws_bytes(N, h);
-    const bool can_np = dgg_allpairs_np_supported(h, noise_mode, K) && workspace && ws_bytes >= dgg_allpairs_np_ws_bytes(N);
     const bool can_gv = dgg_allpairs_gv_supported(h, noise_mode, K) && workspace &&
                         ws_bytes >= dgg_allpairs_gv_ws_bytes(row1 - row0, N);
     const bool can_sweep = dgg_allpairs_sweep_supported(h, noise_mode, K) && workspace &&
@@ -48,10 +45,11 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
         rc = dgg_allpairs_topk_sweep_impl(xp, N, h, row0, row1, t, K, k_limit, idx, val, workspace, ws_bytes, st);   // (settles only the ranks k_limit keeps)
     else if (algo == 4 || (algo == 0 && can_gv && N >= 1024))
         rc = dgg_allpairs_topk_gv_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
-    else if (algo == 3 || (algo == 0 && can_np && N >= 1024))
-        rc = dgg_allpairs_topk_np_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
-    else if ((algo == 2 && noise_mode != 0) || (algo == 0 && can_fast && N >= 1024))
-        rc = dgg_allpairs_topk_fast_impl(xp, N, h, row0, row1, t, noise_mode, s0, s1, K, idx, val, workspace, ws_bytes, st);
+    else if (algo == 3 || (algo == 2 && noise_mode != 0))
+        // (round 5: the adaptive noise prefilter (3) and the MFMA-bounded pruning under noise (2) were reachable through this knob
+        //  only -- the automatic choice never took them: guess-and-verify covers the same shapes and was 3-4x faster -- and were retired)
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "allpairs_topk: algo 2 applies to unperturbed scores only and algo 3 was retired "
+                                                  "(0 auto, 1 exhaustive, 2 unperturbed sweep, 4 guess-and-verify)");
     else
         rc = dgg_allpairs_topk_exhaustive_impl(xp, N, h, row0, row1, t, noise_mode, G, ldG, s0, s1, K, idx, val, st);
     if (rc == 0 && k_limit) rc = dgg_klimit_truncate_impl(k_limit, row1 - row0, K, idx, val, st);
@@ -61,13 +59,9 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
 // bytes of workspace the pruned path needs (bf16 copy of xp + discounted norms); 0 when it cannot be used
 size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K) {
     if (noise_mode == 5) return dgg_allpairs_rsym_supported(h, K) ? dgg_allpairs_rsym_ws_bytes(N, N) : 0;
-    size_t a = dgg_allpairs_fast_supported(h, noise_mode, K) ? dgg_allpairs_fast_ws_bytes(N, h) : 0;
-    size_t b = dgg_allpairs_np_supported(h, noise_mode, K) ? dgg_allpairs_np_ws_bytes(N) : 0;
-    size_t c = dgg_allpairs_gv_supported(h, noise_mode, K) ? dgg_allpairs_gv_ws_bytes(N, N) : 0;
-    size_t d = dgg_allpairs_sweep_supported(h, noise_mode, K) ? dgg_allpairs_sweep_ws_bytes(N, N, h) : 0;
-    a = a > b ? a : b;
-    a = a > c ? a : c;
-    return a > d ? a : d;
+    const size_t c = dgg_allpairs_gv_supported(h, noise_mode, K) ? dgg_allpairs_gv_ws_bytes(N, N) : 0;
+    const size_t d = dgg_allpairs_sweep_supported(h, noise_mode, K) ? dgg_allpairs_sweep_ws_bytes(N, N, h) : 0;
+    return c > d ? c : d;
 }
 
 // diagnostics of the unperturbed sweep: byte offset inside the workspace of {int nfail; int stats_on; u64 nA, nAkept, nB}

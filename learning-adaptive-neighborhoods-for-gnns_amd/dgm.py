@@ -597,13 +597,29 @@ class DGG_LearnableK_debug(nn.Module):
         h = self.latent_dim
         fin, fout = conv_weight.shape
         mlp_mode = self.edge_prob_net_mode in ("u-v-deg", "u-v-A_uv", "u-v-deg-dist", "edge_conv", "A_uv")
-        if ((self.edge_prob_net_mode != "u-v-dist" and not mlp_mode) or (mlp_mode and isinstance(in_adj, AllPairs))
-                or self.k_net_mode != "x" or self.k_select_mode not in ("k_times_edge_prob", "k_only")
-                or self.hard or a.debug_step in (0, 1) or (getattr(a, "stochastic_k", False) and self.training)
-                or self._explicit_noise is not None or not getattr(a, "dgg_fused_layer", True) or not x.is_cuda
-                or h not in (16, 32, 64, 128) or fout not in (16, 32, 64, 128) or fout > fin or self.ell_width != 64
-                or h not in ops.KNET_MFMA_WIDTHS or x.dtype != torch.float32):
-            return None
+        # which clause sends a forward to the separate modules is LOGGED, once per module and clause (logger "dgg_amd", level INFO),
+        # and counted in self.fused_fallback: the separate modules are ~1.7x slower at Pubmed size, and a silent fall-back looks like a
+        # performance bug of the fused layer
+        clauses = (
+            ("scorer outside u-v-dist / the edge-MLP family", self.edge_prob_net_mode != "u-v-dist" and not mlp_mode),
+            ("edge-MLP scorer on all-pairs candidates", mlp_mode and isinstance(in_adj, AllPairs)),
+            ("k-net mode other than 'x'", self.k_net_mode != "x"),
+            ("k-select mode other than k_times_edge_prob / k_only", self.k_select_mode not in ("k_times_edge_prob", "k_only")),
+            ("dgg_hard", bool(self.hard)),
+            ("debug_step 0 / 1", a.debug_step in (0, 1)),
+            ("stochastic_k in training mode", bool(getattr(a, "stochastic_k", False) and self.training)),
+            ("explicit noise tensor", self._explicit_noise is not None),
+            ("args.dgg_fused_layer = False", not getattr(a, "dgg_fused_layer", True)),
+            ("input not on the GPU", not x.is_cuda),
+            ("latent width outside {16, 32, 64, 128}", h not in (16, 32, 64, 128) or h not in ops.KNET_MFMA_WIDTHS),
+            ("conv width outside {16, 32, 64, 128}", fout not in (16, 32, 64, 128)),
+            ("conv wider than its input (fout > fin)", fout > fin),
+            ("ell_width other than 64", self.ell_width != 64),
+            ("input dtype other than float32", x.dtype != torch.float32),
+        )
+        for why, hit in clauses:
+            if hit:
+                return self._fused_fallback(why)
         if isinstance(in_adj, AllPairs):
             cand, deg, rowptr = None, in_adj.prior_degree, None
             if self.__dict__.get("_ap_wide", {}).get("on") or (getattr(a, "dgg_wide_rows", "auto") == "csr" and
@@ -615,8 +631,8 @@ class DGG_LearnableK_debug(nn.Module):
             rowptr, col, deg = csr_candidates(in_adj)
             cand = (rowptr, col)
             wide_state = self._wide_rows_state(in_adj, rowptr)
-            if wide_state is True:
-                return None                                   # (known before any kernel runs: this graph takes the CSR form -- no discarded forward)
+            if wide_state is True:                            # (known before any kernel runs: this graph takes the CSR form -- no discarded forward)
+                return self._fused_fallback("rows wider than the list with learned degrees beyond it (CSR form)")
         sc_static = None
         if mlp_mode:                                          # per-edge inputs of the scorer, in the CSR order of the candidates
             avals = _cached("values_f32", in_adj, lambda: in_adj.coalesce().values().to(torch.float32).contiguous())
@@ -637,8 +653,6 @@ class DGG_LearnableK_debug(nn.Module):
         noise_mode, _, seed = self._noise_cfg()
         if cand is None and noise_mode == ops.NOISE_RANKED:
             noise_mode = self._asym_generator_now(x, seed)
-        elif cand is None and noise_mode == ops.NOISE_RANKED_SYM:
-            return None                                       # (its workspace status is reported through the module path)
         elif cand is not None:
             noise_mode = {ops.NOISE_RANKED: ops.NOISE_HASH, ops.NOISE_RANKED_SYM: ops.NOISE_HASH_SYM}.get(noise_mode, noise_mode)
         mode = ops.MODE_K_TIMES_EDGE_PROB if self.k_select_mode == "k_times_edge_prob" else ops.MODE_K_ONLY
@@ -679,8 +693,10 @@ class DGG_LearnableK_debug(nn.Module):
         else:
             Z, ahat = _FusedDGGConvFn.apply(x, deg, layer, *params)
         st = layer.saved
+        if noise_mode == ops.NOISE_RANKED_SYM:                # the reference's DEFAULT noise (symmetric_noise=True, dgm.py:1216-1223): the
+            self._note_rsym(getattr(layer, "rsym_last", None), N)     # generator's status words, checked by check_ell_bound as for the modules
         if st.get("partp") is None:                           # (shape outside the partitioned backward: the separate modules)
-            return None
+            return self._fused_fallback("shape outside the partitioned backward")
         k = st["k"]
         if cand is not None and self._wide_rows(in_adj, rowptr, k):
             # rows wider than the ELL with learned degrees beyond it: the CSR form from here on (this forward is discarded, once per graph)
@@ -712,6 +728,30 @@ class DGG_LearnableK_debug(nn.Module):
         if lay is not None and pp is None:                    # (chunked rows as a separate module: the CSR kernels)
             return Z, unnorm, EllAdjacency(st["idx"], ahat.detach(), N, k=k, score=st["val"], normalized=True, owner=self, layout=lay)
         return Z, unnorm, EllAdjacency(st["idx"], ahat, N, k=k, score=st["val"], normalized=True, owner=self, partp=pp, layout=lay)
+
+    def _fused_fallback(self, why):
+        """forward_conv leaves for the separate modules: counted per reason, logged once per module and reason -> None"""
+        fb = self.__dict__.setdefault("fused_fallback", {})
+        if why not in fb:
+            import logging
+            logging.getLogger("dgg_amd").info("DGG_LearnableK_debug.forward_conv: the fused layer does not cover this configuration (%s): "
+                                              "the generator, normalize_adj and the layer run as separate modules", why)
+        fb[why] = fb.get(why, 0) + 1
+        return None
+
+    def _note_rsym(self, st, N):
+        """status words of the ranked symmetric generator (noise_mode 5) of one forward, ORed / maxed into the module's (read by
+        check_ell_bound: rows it could not settle, rows of its dense tier, depth of its second tier)"""
+        if not st or st.get("rsym_err") is None:
+            return
+        prev = self.__dict__.get("_rsym_err")
+        self._rsym_err = st["rsym_err"] if prev is None else (prev | st["rsym_err"])
+        if N > 1024:                                 # (smaller graphs take the dense tier by design: dgg_topk_rsym.hip, SMALL_N)
+            self._rsym_rows = int(N)
+            prev3 = self.__dict__.get("_rsym_t3")
+            self._rsym_t3 = st["rsym_tier3"] if prev3 is None else torch.maximum(prev3, st["rsym_tier3"])
+            prevd = self.__dict__.get("_rsym_depth")
+            self._rsym_depth = st["rsym_depth"] if prevd is None else torch.maximum(prevd, st["rsym_depth"])
 
     def _chunk_policy(self, noise_mode):
         """All-pairs rows wider than the 64-rank list as CHUNKED rows (ops.chunk_layout; any learned degree up to 2038, any graph size)?
@@ -1041,15 +1081,7 @@ class DGG_LearnableK_debug(nn.Module):
         k = k.detach()
         if not chunk_checked:                    # (chunk_checked: the layout just read back says every row fits the list)
             self._track_overflow(k, None if cand is None else (rowptr[1:] - rowptr[:-1]))
-        if cfg.get("rsym_err") is not None:
-            prev = self.__dict__.get("_rsym_err")
-            self._rsym_err = cfg["rsym_err"] if prev is None else (prev | cfg["rsym_err"])
-            if x.shape[0] > 1024:                  # (smaller graphs take the dense tier by design: dgg_topk_rsym.hip, SMALL_N)
-                self._rsym_rows = int(x.shape[0])
-                prev3 = self.__dict__.get("_rsym_t3")
-                self._rsym_t3 = cfg["rsym_tier3"] if prev3 is None else torch.maximum(prev3, cfg["rsym_tier3"])
-                prevd = self.__dict__.get("_rsym_depth")
-                self._rsym_depth = cfg["rsym_depth"] if prevd is None else torch.maximum(prevd, cfg["rsym_depth"])
+        self._note_rsym(cfg, x.shape[0])
         if writer is not None:   # the two scalars the reference logs from inside the DGG (dgm.py:1259-1261)
             f = w.detach() if (cfg["mode"] == ops.MODE_K_ONLY or "fwd_mode" in cfg) else (w.detach() / val.clamp(min=1e-30))
             writer.add_scalar("values/first_k_std", f.sum(-1).std(), epoch)

@@ -285,6 +285,7 @@ class ShardedDGGConv:
                                                     rows=(self.r0, self.r1), algo=self.algo, k_limit=s["k"], **kw)
             if st and st.get("rsym_err") is not None:      # ranked symmetric generator out of workspace: device flag, read by check_generator()
                 self.rsym_err = st["rsym_err"] if getattr(self, "rsym_err", None) is None else (self.rsym_err | st["rsym_err"])
+                self.rsym_last = st                 # (all three status words of this forward: the module mirror keeps its own tally)
             s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
         s["rs"] = rs = _all_gather_rows(rs_local, self.N, self.per, self.group, self.bufs, "rs") if self.coll else rs_local
         if self.emulate is not None:
