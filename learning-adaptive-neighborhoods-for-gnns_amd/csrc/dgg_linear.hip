@@ -674,10 +674,76 @@ __device__ __forceinline__ void tn_wide_stream(const float *__restrict__ A, cons
     }
 }
 
+// The same stream on the bf16 matrix cores with SPLIT operands: x = hi + lo + O(2^-17 x), hi = bf16(x), lo = bf16(x - hi), and
+// a b ~ hi_a hi_b + hi_a lo_b + lo_a hi_b (the dropped lo_a lo_b term is 2^-16 of the product) -- three v_mfma_f32_32x32x16_bf16 per
+// 16 rows where the exact form needs eight v_mfma_f32_32x32x2_f32: 3/16 of the matrix-pipe time for a relative error of ~2e-5 per
+// term (fp32 accumulation), far inside the 2e-4 the weight gradients are held to.  The products feed GRADIENTS only: nothing on the
+// score path (whose bits decide the neighbour lists) goes through here.  A lane holds rows base + 8 hh + r (r = 0..7) of its two A
+// and four B columns: eight 8-byte and eight 16-byte loads per 16 rows, the next block's in flight during the MFMAs.
+typedef __bf16 tn_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void tn_split(const float (&x)[8], tn_bf16x8 &hi, tn_bf16x8 &lo) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        hi[r] = (__bf16)x[r];
+        lo[r] = (__bf16)(x[r] - (float)hi[r]);
+    }
+}
+template <bool ACT>
+__device__ __forceinline__ void tn_wide_stream_b3(const float *__restrict__ A, const float *__restrict__ Yact, int act, const float *__restrict__ B,
+                                                  int64_t N, int M1, int acol, int ldb, int bcol, int hh, int64_t base, int64_t stride,
+                                                  f32x16 (&acc)[2][4], float (&csum)[2]) {
+    float2 av[8], yv[8];
+    float4 bv[8];
+    auto load = [&](int64_t b0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int64_t n = b0 + 8 * hh + r, nc = n < N ? n : N - 1;      // unconditional, clamped
+            av[r] = *reinterpret_cast<const float2 *>(A + nc * M1 + acol);
+            if (ACT) yv[r] = *reinterpret_cast<const float2 *>(Yact + nc * M1 + acol);
+            bv[r] = *reinterpret_cast<const float4 *>(B + nc * ldb + bcol);
+        }
+    };
+    load(base);
+    for (; base < N; base += stride) {
+        float a0[8], a1[8], b0[8], b1[8], b2[8], b3[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const float rm = base + 8 * hh + r < N ? 1.0f : 0.0f;
+            float m0 = rm, m1 = rm;
+            if (ACT) {
+                if (act == 1) { m0 = yv[r].x > 0.0f ? rm : 0.01f * rm; m1 = yv[r].y > 0.0f ? rm : 0.01f * rm; }
+                else { m0 = yv[r].x > 0.0f ? rm : 0.0f; m1 = yv[r].y > 0.0f ? rm : 0.0f; }
+            }
+            a0[r] = av[r].x * m0; a1[r] = av[r].y * m1;
+            b0[r] = bv[r].x; b1[r] = bv[r].y; b2[r] = bv[r].z; b3[r] = bv[r].w;
+            csum[0] += a0[r]; csum[1] += a1[r];
+        }
+#ifdef DGG_TN_B3_EARLY
+        load(base + stride);
+#endif
+        tn_bf16x8 ah[2], al[2], bh[4], bl[4];
+        tn_split(a0, ah[0], al[0]); tn_split(a1, ah[1], al[1]);
+        tn_split(b0, bh[0], bl[0]); tn_split(b1, bh[1], bl[1]); tn_split(b2, bh[2], bl[2]); tn_split(b3, bh[3], bl[3]);
+#ifndef DGG_TN_B3_EARLY
+        // the next block's loads go out once this block lives in its packed form (48 registers instead of 96: issued before the
+        // conversions the kernel spills), in flight during the 24 MFMAs of this block and the other wavefront's whole block
+        load(base + stride);
+#endif
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                acc[m][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[a], acc[m][a], 0, 0, 0);       // (small terms first)
+                acc[m][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[a], acc[m][a], 0, 0, 0);
+                acc[m][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[a], acc[m][a], 0, 0, 0);
+            }
+    }
+}
+
 // B wider than 128 columns (M2 a multiple of 4; Pubmed's 500 input features): the workgroups of a row stream additionally enumerate
 // the 128-column tiles of B (`ntile`); a lane whose four columns lie beyond M2 reads the last valid group instead and its output
 // columns are dropped by the reduce (they sit in the padding of the M2p-wide slab, or beyond it and are not stored).
-template <int PF>
+template <int PF, bool B3 = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_wide(TnSegs segs, const float *__restrict__ B, int64_t N, int G, int M2, int M2p, int ntile,
                                                        float *__restrict__ slab, float *__restrict__ cs_slab) {
     extern __shared__ float red[];                               // [8*16*64] + [2*64]
@@ -699,9 +765,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_wide(TnSegs segs, const float 
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][a][r] = 0.0f;
     float csum[2] = {0.0f, 0.0f};
-    const int64_t base = ((int64_t)g * 4 + wave) * 2 * PF, stride = (int64_t)G * 4 * 2 * PF;
-    if (act != 0) tn_wide_stream<PF, true>(A, Yact, act, B, N, M1, acol, M2, bcol, hh, base, stride, acc, csum);
-    else tn_wide_stream<PF, false>(A, Yact, act, B, N, M1, acol, M2, bcol, hh, base, stride, acc, csum);
+    if constexpr (B3) {                                          // split-bf16 products: blocks of 16 rows per wavefront
+        const int64_t base = ((int64_t)g * 4 + wave) * 16, stride = (int64_t)G * 4 * 16;
+        if (act != 0) tn_wide_stream_b3<true>(A, Yact, act, B, N, M1, acol, M2, bcol, hh, base, stride, acc, csum);
+        else tn_wide_stream_b3<false>(A, Yact, act, B, N, M1, acol, M2, bcol, hh, base, stride, acc, csum);
+    } else {
+        const int64_t base = ((int64_t)g * 4 + wave) * 2 * PF, stride = (int64_t)G * 4 * 2 * PF;
+        if (act != 0) tn_wide_stream<PF, true>(A, Yact, act, B, N, M1, acol, M2, bcol, hh, base, stride, acc, csum);
+        else tn_wide_stream<PF, false>(A, Yact, act, B, N, M1, acol, M2, bcol, hh, base, stride, acc, csum);
+    }
     float *cred = red + 8 * 16 * 64;
     for (int w = 1; w < 4; w++) {
         if (wave == w) {
@@ -1124,7 +1196,11 @@ int dgg_gemm_tn_multi(int nseg, const float *const *A, const int *M1, const floa
     const size_t lds = (size_t)(nb * 16 * 64 + 64) * sizeof(float);
     const size_t ldsw = (size_t)(8 * 16 * 64 + 128) * sizeof(float);
     const dim3 gridw((unsigned)(G * (yb / 2) * ntile));
-    if (wide) hipLaunchKernelGGL((gemm_tn_wide<6>), gridw, dim3(256), ldsw, st, segs, B, N, G, M2, M2p, ntile, slab, cs_slab);
+    // weight gradients (2e-4 of max is what they are held to): split-bf16 products on the bf16 matrix cores; DGG_TN_B3=0 keeps the exact
+    // fp32 products (v_mfma_f32_32x32x2_f32)
+    static const bool tn_b3 = [] { const char *e = getenv("DGG_TN_B3"); return !(e && atoi(e) == 0); }();
+    if (wide && tn_b3) hipLaunchKernelGGL((gemm_tn_wide<6, true>), gridw, dim3(256), ldsw, st, segs, B, N, G, M2, M2p, ntile, slab, cs_slab);
+    else if (wide) hipLaunchKernelGGL((gemm_tn_wide<6>), gridw, dim3(256), ldsw, st, segs, B, N, G, M2, M2p, ntile, slab, cs_slab);
     else if (nb == 4) hipLaunchKernelGGL((gemm_tn_multi<4, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);
     else if (nb == 2) hipLaunchKernelGGL((gemm_tn_multi<2, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);
     else hipLaunchKernelGGL((gemm_tn_multi<1, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);

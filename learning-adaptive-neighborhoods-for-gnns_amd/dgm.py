@@ -691,7 +691,14 @@ class DGG_LearnableK_debug(nn.Module):
             Z, ahat = _FusedDGGMlpConvFn.apply(x, deg, layer, sc_static, mlp["Wcat"], mlp["wdu"], mlp["wdv"], mlp["wex"], mlp["b1"],
                                                mlp["w2"], mlp["b2"], *params)
         else:
-            Z, ahat = _FusedDGGConvFn.apply(x, deg, layer, *params)
+            try:
+                Z, ahat = _FusedDGGConvFn.apply(x, deg, layer, *params)
+            except ops.ChunkCapacityError:
+                # a learned degree beyond 2038: more ranks than the chunked rows hold.  Graphs small enough for the complete candidate
+                # pattern (args.dgg_allpairs_csr_max) rank every column in CSR form from here on; larger ones have no exact evaluator
+                if not self._chunks_exhausted(N):
+                    raise
+                return self._fused_fallback("learned degrees beyond the chunked rows' 2048 ranks (CSR form)")
         st = layer.saved
         if noise_mode == ops.NOISE_RANKED_SYM:                # the reference's DEFAULT noise (symmetric_noise=True, dgm.py:1216-1223): the
             self._note_rsym(getattr(layer, "rsym_last", None), N)     # generator's status words, checked by check_ell_bound as for the modules
@@ -729,6 +736,15 @@ class DGG_LearnableK_debug(nn.Module):
             return Z, unnorm, EllAdjacency(st["idx"], ahat.detach(), N, k=k, score=st["val"], normalized=True, owner=self, layout=lay)
         return Z, unnorm, EllAdjacency(st["idx"], ahat, N, k=k, score=st["val"], normalized=True, owner=self, partp=pp, layout=lay)
 
+    def _chunks_exhausted(self, N):
+        """a learned degree exceeded the chunked rows' capacity: switch this module to the CSR form of select_top_k on the complete
+        candidate pattern if the graph is small enough for it (-> True), else leave the error to the caller (-> False)"""
+        if N > int(getattr(self.args, "dgg_allpairs_csr_max", 8192)) or getattr(self.args, "dgg_wide_rows", "auto") in ("ell", "chunked"):
+            return False
+        self.__dict__.setdefault("_ap_wide", {"on": False})["on"] = True
+        self.__dict__["_chunks_off"] = True
+        return True
+
     def _fused_fallback(self, why):
         """forward_conv leaves for the separate modules: counted per reason, logged once per module and reason -> None"""
         fb = self.__dict__.setdefault("fused_fallback", {})
@@ -761,7 +777,7 @@ class DGG_LearnableK_debug(nn.Module):
         64-rank list with the enforced bound.  Explicit noise, the per-pair hash generators and unperturbed scores keep the CSR form
         (they have no early-stopping search to widen)."""
         policy = getattr(self.args, "dgg_wide_rows", "auto")
-        return (policy in ("auto", "chunked") and noise_mode == ops.NOISE_RANKED and self.ell_width == 64
+        return (policy in ("auto", "chunked") and noise_mode == ops.NOISE_RANKED and self.ell_width == 64 and not self.__dict__.get("_chunks_off")
                 and self.latent_dim in (16, 32, 64, 128) and self.edge_prob_net_mode == "u-v-dist")
 
     def _track_overflow(self, k, ncand):
@@ -1050,8 +1066,13 @@ class DGG_LearnableK_debug(nn.Module):
             return self._csr_soft_adjacency(x, in_adj, k, noise_mode, G, seed, cfg["mode"])
         if cand is None and not literal and self._chunk_policy(noise_mode) and not torch.cuda.is_current_stream_capturing():
             # learned degrees beyond the 64-rank list: chunked rows (same generator, same search, ceil(k_i + 8.5) + 1 ranks per row)
-            lay = ops.chunk_layout(k.detach())                # (one readback: the chunk count sizes the arrays)
-            if lay.wide:
+            try:
+                lay = ops.chunk_layout(k.detach())            # (one readback: the chunk count sizes the arrays)
+            except ops.ChunkCapacityError:                    # a learned degree beyond 2038: the CSR form if the graph allows it
+                if not self._chunks_exhausted(x.shape[0]):
+                    raise
+                lay = None
+            if lay is not None and lay.wide:
                 cfg["layout"] = lay
                 xp = xp_dual if xp_dual is not None else ops.LinearFn.apply(x, We, be, ops.ACT_LEAKY, 0)
                 w, idx, val, rs = _DGGWideAdjFn.apply(xp, k, cfg)
@@ -1061,7 +1082,7 @@ class DGG_LearnableK_debug(nn.Module):
                     writer.add_scalar("values/first_k_std", fs.std(), epoch)
                     writer.add_scalar("values/first_k_mean", fs.mean(), epoch)
                 return EllAdjacency(idx, w, x.shape[0], rs=rs, k=k.detach(), score=val, owner=self, layout=lay)
-            chunk_checked = True
+            chunk_checked = lay is not None
         else:
             chunk_checked = False
         if cand is None and not literal and self.edge_prob_net_mode == "u-v-dist" and not chunk_checked and self._allpairs_wide(x.shape[0], k):

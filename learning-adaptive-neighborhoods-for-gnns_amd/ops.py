@@ -403,6 +403,10 @@ def allpairs_topk_softk(xp, k, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, seed=(0, 0
 CHUNK_MAXM = 32          # at most 32 chunks of 64 ranks per row (learned degrees up to 2038)
 
 
+class ChunkCapacityError(RuntimeError):
+    """a learned degree needs more ranks than the chunked rows hold (64 * CHUNK_MAXM), or is not finite"""
+
+
 class ChunkLayout:
     """Chunked rows (include/dgg_hip.h, dgg_chunk_layout): node i owns the chunks [cptr[i], cptr[i+1]) of the [chunks,64] arrays, rank r
     of its row is entry r % 64 of chunk r / 64.  cptr int32 [rows+1], cnode int32 [chunks] (node of every chunk), meta int32 [4] on the
@@ -442,8 +446,8 @@ def chunk_layout(k, maxm=CHUNK_MAXM, ccap=None):
         _lib.check(_lib.lib().dgg_chunk_layout(_ptr(k), rows, int(maxm), cap, _ptr(cptr), _ptr(cnode), _ptr(meta), _stream()), "chunk_layout")
         total, widest, flags, _ = (int(v) for v in meta[:4].cpu())
         if flags & 1:
-            raise RuntimeError(f"chunk_layout: a learned degree needs more than {64 * maxm} ranks (k + 9.5 > {64 * maxm}): beyond the "
-                               "chunked rows' capacity (or not finite)")
+            raise ChunkCapacityError(f"chunk_layout: a learned degree needs more than {64 * maxm} ranks (k + 9.5 > {64 * maxm}): beyond the "
+                                     "chunked rows' capacity (or not finite)")
         if not (flags & 2):
             return ChunkLayout(cptr, cnode[:total], meta, total, max(widest, 1), rows)
         cap = total
