@@ -743,7 +743,9 @@ __device__ __forceinline__ void tn_wide_stream_b3(const float *__restrict__ A, c
 // B wider than 128 columns (M2 a multiple of 4; Pubmed's 500 input features): the workgroups of a row stream additionally enumerate
 // the 128-column tiles of B (`ntile`); a lane whose four columns lie beyond M2 reads the last valid group instead and its output
 // columns are dropped by the reduce (they sit in the padding of the M2p-wide slab, or beyond it and are not stored).
-template <int PF, bool B3 = false>
+// (HASACT = false: no segment carries an activation mask -- the headline step's cotangents arrive premasked -- and the kernel is
+//  compiled without that path: with it the split-bf16 stream needs 16 more registers than a wavefront has and spills)
+template <int PF, bool B3 = false, bool HASACT = true>
 __global__ __launch_bounds__(256, 2) void gemm_tn_wide(TnSegs segs, const float *__restrict__ B, int64_t N, int G, int M2, int M2p, int ntile,
                                                        float *__restrict__ slab, float *__restrict__ cs_slab) {
     extern __shared__ float red[];                               // [8*16*64] + [2*64]
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_wide(TnSegs segs, const float 
     float csum[2] = {0.0f, 0.0f};
     if constexpr (B3) {                                          // split-bf16 products: blocks of 16 rows per wavefront
         const int64_t base = ((int64_t)g * 4 + wave) * 16, stride = (int64_t)G * 4 * 16;
-        if (act != 0) tn_wide_stream_b3<true>(A, Yact, act, B, N, M1, acol, M2, bcol, hh, base, stride, acc, csum);
+        if (HASACT && act != 0) tn_wide_stream_b3<true>(A, Yact, act, B, N, M1, acol, M2, bcol, hh, base, stride, acc, csum);
         else tn_wide_stream_b3<false>(A, Yact, act, B, N, M1, acol, M2, bcol, hh, base, stride, acc, csum);
     } else {
         const int64_t base = ((int64_t)g * 4 + wave) * 2 * PF, stride = (int64_t)G * 4 * 2 * PF;
@@ -1199,7 +1201,10 @@ int dgg_gemm_tn_multi(int nseg, const float *const *A, const int *M1, const floa
     // weight gradients (2e-4 of max is what they are held to): split-bf16 products on the bf16 matrix cores; DGG_TN_B3=0 keeps the exact
     // fp32 products (v_mfma_f32_32x32x2_f32)
     static const bool tn_b3 = [] { const char *e = getenv("DGG_TN_B3"); return !(e && atoi(e) == 0); }();
-    if (wide && tn_b3) hipLaunchKernelGGL((gemm_tn_wide<6, true>), gridw, dim3(256), ldsw, st, segs, B, N, G, M2, M2p, ntile, slab, cs_slab);
+    bool hasact = false;
+    for (int sgi = 0; sgi < nseg; sgi++) hasact = hasact || (Y && Y[sgi] && act && act[sgi] != 0);
+    if (wide && tn_b3 && !hasact) hipLaunchKernelGGL((gemm_tn_wide<6, true, false>), gridw, dim3(256), ldsw, st, segs, B, N, G, M2, M2p, ntile, slab, cs_slab);
+    else if (wide && tn_b3) hipLaunchKernelGGL((gemm_tn_wide<6, true, true>), gridw, dim3(256), ldsw, st, segs, B, N, G, M2, M2p, ntile, slab, cs_slab);
     else if (wide) hipLaunchKernelGGL((gemm_tn_wide<6>), gridw, dim3(256), ldsw, st, segs, B, N, G, M2, M2p, ntile, slab, cs_slab);
     else if (nb == 4) hipLaunchKernelGGL((gemm_tn_multi<4, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);
     else if (nb == 2) hipLaunchKernelGGL((gemm_tn_multi<2, PF>), dim3(grid), dim3(256), lds, st, segs, B, N, M2, M2p, G, slab, cs_slab);

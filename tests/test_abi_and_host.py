@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), f"libdgg_hip.so does not export {s}"
     # the ctypes prototype table covers the same set (minus the two info functions)
     assert set(dgg_amd._lib.PROTOTYPES) | {"dgg_last_error", "dgg_abi_version"} == set(syms)
-    assert dgg_amd._lib.lib().dgg_abi_version() == 4
+    assert dgg_amd._lib.lib().dgg_abi_version() == 5
 
 
 def test_public_header_is_valid_c():
