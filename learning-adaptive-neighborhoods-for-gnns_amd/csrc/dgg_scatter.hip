@@ -1400,12 +1400,19 @@ __global__ __launch_bounds__(PP_T) void pp_sort(const int *__restrict__ bstart, 
     const bool inreg = n <= PP_T * PP_RPT;                       // workgroup-uniform
     int4 rec[PP_RPT];
     int rank[PP_RPT];
+    int srcnode[PP_RPT];
     if (inreg) {
 #pragma unroll
         for (int u = 0; u < PP_RPT; u++) {
             const int e = e0 + u * PP_T + tid;
             rec[u] = tmp[e < e1 ? e : (n > 0 ? e1 - 1 : 0)];
             if (e >= e1) rec[u].y = -1;
+        }
+        // (WIDE: the source node of every record's chunk, all 16 lookups of a thread in flight together -- fetched one by one in front
+        //  of each record's store they were sixteen dependent round trips: the wide sort took 607 us at k ~ 130)
+        if (WIDE) {
+#pragma unroll
+            for (int u = 0; u < PP_RPT; u++) srcnode[u] = cnode[rec[u].y >= 0 ? (rec[u].x >> 6) : 0];
         }
 #pragma unroll
         for (int u = 0; u < PP_RPT; u++) rank[u] = rec[u].y >= 0 ? atomicAdd(&cnt[rec[u].y - b * PBS], 1) : 0;
@@ -1434,7 +1441,7 @@ __global__ __launch_bounds__(PP_T) void pp_sort(const int *__restrict__ bstart, 
         for (int u = 0; u < PP_RPT; u++)
             if (rec[u].y >= 0) {
                 const int pos = o0 + base[rec[u].y - b * PBS] + rank[u];
-                if (WIDE) rec[u].y = cnode[rec[u].x >> 6];
+                if (WIDE) rec[u].y = srcnode[u];
                 recs[pos] = rec[u];
                 if (recpos) recpos[rec[u].x] = pos;
             }

@@ -25,6 +25,11 @@ from .adjacency import AllPairs, CsrAdjacency, EllAdjacency, _cached, csr_candid
 _EDGE_MLP_MODES = ("u-v-A_uv", "u-v-deg", "u-v-deg-dist", "edge_conv", "A_uv")
 
 
+def _capturing():
+    """a hipGraph is being captured on the current stream (nothing can be read back, no host decision can depend on device data)"""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 class LearnableKEncoder(nn.Module):
     """k_mu / k_logvar / k_project head (reference dgm.py:2029-2063); deterministic branch on the GPU path."""
 
@@ -319,7 +324,7 @@ def _pad_features(x, params, keys):
     ent = _PAD_CACHE.get(key)
     if ent is None or ent[0]() is not x or ent[1] != x._version or x.requires_grad:
         xpad = torch.nn.functional.pad(x.detach(), (0, pad))
-        if not x.requires_grad and not torch.cuda.is_current_stream_capturing():
+        if not x.requires_grad and not _capturing():
             for k_ in [k_ for k_, v in _PAD_CACHE.items() if v[0]() is None]:
                 del _PAD_CACHE[k_]
             _PAD_CACHE[key] = (weakref.ref(x), x._version, xpad)
@@ -517,13 +522,13 @@ class DGG_LearnableK_debug(nn.Module):
                 if auto and many:
                     self._sym_generator = "hash"
         wm = self.__dict__.get("_wide_meta")
-        if wm is not None and not torch.cuda.is_current_stream_capturing():
+        if wm is not None and not _capturing():
             self._wide_meta = None
             if int(wm[2]) != 0:
                 raise RuntimeError("DGG_LearnableK_debug: the chunked rows of a captured step outgrew the capacity they were captured with "
                                    f"(chunks needed {int(wm[0])}, widest row {int(wm[1])} chunks): run one eager forward and capture again")
         flag = self.__dict__.get("_overflow_dev")
-        if flag is not None and not torch.cuda.is_current_stream_capturing() and bool(flag.item()):
+        if flag is not None and not _capturing() and bool(flag.item()):
             flag.zero_()
             self._overflow = torch.ones((), dtype=torch.bool, device=flag.device)
         if self._overflow is not None and bool(self._overflow):
@@ -565,7 +570,7 @@ class DGG_LearnableK_debug(nn.Module):
             return ops.NOISE_RANKED
         st = self.__dict__.setdefault("_asym_state", {"n": 0, "slow": False, "probe": None})
         every = max(1, int(getattr(self.args, "dgg_pilot_every", 16)))
-        if st["n"] % every == 0 and not torch.cuda.is_current_stream_capturing():
+        if st["n"] % every == 0 and not _capturing():
             with torch.no_grad():
                 xp = ops.linear_fwd(x.detach(), self.node_encode_for_edges[0].weight.detach(), self.node_encode_for_edges[0].bias.detach(),
                                     ops.ACT_LEAKY)
@@ -667,7 +672,7 @@ class DGG_LearnableK_debug(nn.Module):
         chunked = cand is None and self._chunk_policy(noise_mode)
         layer.wide_rows = "auto" if chunked else "off"
         layer.wide_cap = None
-        if chunked and torch.cuda.is_current_stream_capturing():
+        if chunked and _capturing():
             # nothing can be read back under capture: the layout of the last eager forward on this module, with some slack, becomes a
             # FIXED capacity whose overflow flags check_ell_bound() reads; no wide row then: the list, with its enforced bound
             last = getattr(layer, "last_layout", None)
@@ -678,7 +683,7 @@ class DGG_LearnableK_debug(nn.Module):
         if cand is not None and not mlp_mode:                 # the ELL-width bound is tested inside the search kernel (no extra launches)
             # (a forward whose fate is decided from its own learned degrees -- wide_state None -- raises a SCRATCH flag: if it is
             #  discarded for the CSR form its flag must not reach check_ell_bound, and flags of earlier forwards must survive it)
-            name = "_overflow_scratch" if (wide_state is None and not torch.cuda.is_current_stream_capturing()) else "_overflow_dev"
+            name = "_overflow_scratch" if (wide_state is None and not _capturing()) else "_overflow_dev"
             flag = self.__dict__.get(name)
             if flag is None or flag.device != x.device:
                 flag = self.__dict__[name] = torch.zeros((1,), device=x.device, dtype=torch.int32)
@@ -804,7 +809,7 @@ class DGG_LearnableK_debug(nn.Module):
         cache = self.__dict__.setdefault("_wide_cache", {})
         ent = cache.get(id(in_adj))
         if ent is None or ent[0]() is not in_adj:
-            if torch.cuda.is_current_stream_capturing():
+            if _capturing():
                 return False
             for key in [k_ for k_, v in cache.items() if v[0]() is None]:
                 del cache[key]
@@ -823,7 +828,7 @@ class DGG_LearnableK_debug(nn.Module):
         st = self._wide_rows_state(in_adj, rowptr)
         if st is not None:
             return st
-        if torch.cuda.is_current_stream_capturing():
+        if _capturing():
             return False
         ent = self._wide_cache[id(in_adj)]
         lens = rowptr[1:] - rowptr[:-1]
@@ -855,7 +860,7 @@ class DGG_LearnableK_debug(nn.Module):
         if policy == "csr":
             return True
         st = self.__dict__.setdefault("_ap_wide", {"on": False})
-        if not st["on"] and not torch.cuda.is_current_stream_capturing():
+        if not st["on"] and not _capturing():
             st["on"] = bool((k.detach() + 8.5 > float(self.ell_width)).any().item())
         return st["on"]
 
@@ -1064,7 +1069,7 @@ class DGG_LearnableK_debug(nn.Module):
         if cand is not None and not literal and self._wide_rows(in_adj, rowptr, k):
             # rows wider than the ELL and learned degrees that may exceed it: the CSR form (no width limit)
             return self._csr_soft_adjacency(x, in_adj, k, noise_mode, G, seed, cfg["mode"])
-        if cand is None and not literal and self._chunk_policy(noise_mode) and not torch.cuda.is_current_stream_capturing():
+        if cand is None and not literal and self._chunk_policy(noise_mode) and not _capturing():
             # learned degrees beyond the 64-rank list: chunked rows (same generator, same search, ceil(k_i + 8.5) + 1 ranks per row)
             try:
                 lay = ops.chunk_layout(k.detach())            # (one readback: the chunk count sizes the arrays)

@@ -94,3 +94,67 @@ def test_missing_library_fails_loudly(tmp_path):
     env = dict(os.environ, DGG_HIP_SO=str(tmp_path / "nope" / "libdgg_hip.so"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert "RAISED True" in r.stdout, r.stdout + r.stderr
+
+
+def test_chunked_adjacency_container_on_the_host():
+    """EllAdjacency with a chunk layout (rows wider than 64 ranks: node i owns the chunks [cptr[i], cptr[i+1])): densification, COO and
+    CSR views and row sums are plain torch ops on the container -- checked here without a GPU against a hand-built matrix"""
+    import torch
+    import dgg_amd
+    from dgg_amd import ops
+    N = 200
+    lens = [40, 150, 64, 100, 3] + [7] * (N - 5)                       # entries per row
+    M = torch.tensor([(n + 63) // 64 for n in lens])                   # chunks per row: 1, 3, 1, 2, 1, 1, ...
+    cptr = torch.cat([torch.zeros(1, dtype=torch.int64), M.cumsum(0)]).to(torch.int32)
+    cnode = torch.repeat_interleave(torch.arange(N), M).to(torch.int32)
+    C_ = int(M.sum())
+    lay = ops.ChunkLayout(cptr, cnode, torch.tensor([C_, 3, 0, 0], dtype=torch.int32), C_, 3, N)
+    assert lay.wide and lay.ranks().shape == (C_, 64) and int(lay.ranks()[2, 5]) == 64 + 5      # chunk 2 = second chunk of node 1
+    g = torch.Generator().manual_seed(0)
+    dense = torch.zeros(N, N)
+    idx = torch.full((C_, 64), -1, dtype=torch.int32)
+    val = torch.zeros(C_, 64)
+    for i in range(N):
+        n = lens[i]
+        cols = torch.randperm(N, generator=g)[:n]
+        v = torch.rand(n, generator=g) + 0.1
+        dense[i, cols] = v
+        c0 = int(cptr[i])
+        idx[c0:c0 + int(M[i])].view(-1)[:n] = cols.to(torch.int32)
+        val[c0:c0 + int(M[i])].view(-1)[:n] = v
+    adj = dgg_amd.EllAdjacency(idx, val, N, layout=lay)
+    assert adj.shape == (N, N)
+    assert torch.equal(adj.to_dense(), dense) and torch.equal(adj.to_sparse().to_dense(), dense)
+    csr = adj.to_csr()
+    assert torch.equal(csr.to_dense(), dense) and csr.rowptr.tolist()[:6] == [0, 40, 190, 254, 354, 357]
+    assert torch.allclose(adj.row_sums(), dense.sum(1))
+    flat = dgg_amd.EllAdjacency(idx[:1], val[:1], N, layout=ops.ChunkLayout(cptr[:2], cnode[:1], None, 1, 1, 1))
+    assert flat.layout is None, "a layout without a wide row is the plain list"
+
+
+def test_wide_row_policies_on_the_host():
+    """args.dgg_wide_rows: what rows that need more than 64 ranks do, decided on the host (no kernel involved)"""
+    import torch
+    import dgg_amd
+    from argparse import Namespace
+    from dgg_amd import ops
+    base = dict(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.9, deg_std=5.3, dgg_mode_edge_net="u-v-dist", dgg_mode_k_net="x",
+                dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True, symmetric_noise=False, stochastic_k=False,
+                dgg_adj_input="input_adj", n_dgg_layers=1)
+    m = dgg_amd.DGG_LearnableK_debug(in_dim=8, latent_dim=16, args=Namespace(**base))
+    assert m._chunk_policy(ops.NOISE_RANKED) and not m._chunk_policy(ops.NOISE_HASH) and not m._chunk_policy(ops.NOISE_RANKED_SYM)
+    for pol, want in (("chunked", True), ("csr", False), ("csr_auto", False), ("ell", False)):
+        m.args = Namespace(**base, dgg_wide_rows=pol)
+        assert m._chunk_policy(ops.NOISE_RANKED) == want, pol
+    m.args = Namespace(**base)
+    assert m._chunks_exhausted(3000) and not m._chunk_policy(ops.NOISE_RANKED) and m._ap_wide["on"], "beyond 2048 ranks: the CSR form on small graphs"
+    m2 = dgg_amd.DGG_LearnableK_debug(in_dim=8, latent_dim=16, args=Namespace(**base))
+    assert not m2._chunks_exhausted(100_000), "no exact evaluator for such a row on a large graph: the caller sees the error"
+    # edge lists: known before the forward / decided from its learned degrees
+    rows = torch.arange(10).repeat_interleave(70)
+    A = torch.sparse_coo_tensor(torch.stack([rows, torch.arange(70).repeat(10)]), torch.ones(700), (10, 80)).coalesce()
+    rowptr = torch.arange(11) * 70
+    assert m2._wide_rows_state(A, rowptr) is None, "rows wider than the list: depends on the learned degrees"
+    assert m2._wide_rows(A, rowptr, torch.full((10,), 20.0)) is False and m2._wide_rows_state(A, rowptr) is None
+    assert m2._wide_rows(A, rowptr, torch.full((10,), 60.0)) is True and m2._wide_rows_state(A, rowptr) is True, "sticky once needed"
+    assert m2._fused_fallback("x") is None and m2.fused_fallback == {"x": 1}
