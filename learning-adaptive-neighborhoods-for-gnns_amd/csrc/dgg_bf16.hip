@@ -14,12 +14,21 @@
 //     d support   A = g             [n, out]      B = weight   [K, out]   (as stored)
 //     d weight    A = support^T     [K, n_pad]    B = g^T      [out, n_pad]
 // Tile: 256 threads = 4 wavefronts compute 128 x 128, each wavefront 64 x 64 (2 x 2 MFMA blocks of 32 x 32, four f32x16
-// accumulators); K in steps of 64 staged through a double-buffered LDS image (row stride 144 B: conflict-free ds_read_b128
-// of the 8-bf16 MFMA fragments), the next step's 16-byte global loads in flight during the 16 MFMAs of the current one.
+// accumulators); K in steps of 64.  Two main loops:
+//   RING (default)  the operands go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into a ring of
+//                   three stages, two K-steps in flight ahead of the one being multiplied: a K-step is 16 MFMAs per wavefront
+//                   (~0.3 us) and one workgroup per CU is all the 224-576 tiles of a PPI graph give, so a one-step-ahead
+//                   register prefetch paid a memory round trip per step (1.3 us per step on the forward product).  An LDS-DMA
+//                   instruction writes its wavefront's 64 x 16 B contiguously, so the stage is an UNPADDED [row][8 chunks] image
+//                   and the bank spread comes from an XOR swizzle applied to the SOURCE chunk and again on the read:
+//                   slot = chunk ^ ((row >> 1) & 7) -- conflict-free for the lane groups of ds_read_b128.
+//   staged          double-buffered LDS image filled through registers (row stride 144 B), the next step's loads in flight
+//                   during the current step's MFMAs (DGG_BF16_RING=0).
 #include "dgg_common.h"
 #include "dgg_api_internal.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -52,15 +61,43 @@ struct GcniiEpi {
 // [M, ksplit]): the variant layer's support cat[hi, h0] (model.py:37-40) is never formed.
 // A2 / ksplit < 0: the ROWS [-ksplit, M) of the A operand come from A2 [M + ksplit, K] (the weight gradient [hi | h0]^T g as one
 // product over the two transposed halves).  Splits are multiples of the tile (64 in K, 128 in M).
-template <int EPI, int AM>
+#ifndef DGG_BF16_ABL
+#define DGG_BF16_ABL 0
+#endif
+#ifndef DGG_BF16_NST
+#define DGG_BF16_NST 4
+#endif
+// One LDS-DMA wave-instruction: lane l's 16 bytes at `gsrc` go to LDS byte address lds_dst + 16 l (lds_dst wave-uniform, in M0).
+// Written as inline assembly, not __builtin_amdgcn_global_load_lds: the compiler books the builtin as a possible LDS access of a
+// FLAT instruction and from then on waits lgkmcnt(0) before every use of a ds_read result -- the fragment prefetch below would
+// be serialised again.  The compiler does not count these loads: the s_waitcnt vmcnt(N) that retire them are written out below.
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int EPI, int AM, bool RING>
 __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A, const __bf16 *__restrict__ B, int M, int N, int K,
-                                                    float scale, float *__restrict__ C, GcniiEpi ep, const __bf16 *__restrict__ A2, int ksplit) {
+                                                    float scale, float *__restrict__ C, GcniiEpi ep, const __bf16 *__restrict__ A2, int ksplit,
+                                                    int xcdmap) {
     constexpr int BM = 64 * AM;
-    __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * LDS_STRIDE];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * LDS_STRIDE];
+    constexpr int NST = DGG_BF16_NST, STAGE = (BM + BN) * 128;             // ring: stages of [BM + BN rows][8 chunks of 16 B]
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING ? NST * STAGE : 2 * (BM + BN) * LDS_STRIDE * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), li = lane & 31, hh = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * (64 * AM), n0 = blockIdx.x * BN;
+    // Workgroups go to the 8 XCDs round-robin in launch order (observed; speed only).  xcdmap: XCD x works on the column tiles
+    // [x gx/8, (x+1) gx/8) of B -- a slice that stays in its 4 MB L2 -- and walks the row tiles of A in order, so B comes over the
+    // fabric once in all and A once per XCD (plain order: every XCD fetches both operands whole).
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (xcdmap) {
+        const int id = blockIdx.y * gridDim.x + blockIdx.x, per = gridDim.x >> 3, slot = id >> 3;
+        bx = (id & 7) * per + slot % per;
+        by = slot / per;
+    }
+    const int m0 = by * (64 * AM), n0 = bx * BN;
     f32x16 acc[AM][2];
 #pragma unroll
     for (int a = 0; a < AM; a++)
@@ -68,6 +105,147 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
         for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int q = 0; q < 16; q++) acc[a][b][q] = 0.0f;
+    // fp32 terms of the fused epilogues, fetched BEFORE the main loop (rows / columns beyond the matrix clamped: no branches):
+    // one workgroup per CU leaves nothing to overlap an epilogue's loads with, and fetched after the loop they cost 20 us per tile
+    float add[EPI != 0 ? AM : 1][16][2];
+    // EPI 2: whether a 32-column block lies in the left half (d hi) is the same for all lanes: a scalar test keeps the loads /
+    // stores of a block together (as a per-lane select the compiler made one exec-masked branch per element)
+    auto left_half = [&](int b) { return __builtin_amdgcn_readfirstlane(n0 + wc * 64 + b * 32) < ep.F; };
+    auto epi_terms = [&]() {
+      if constexpr (EPI != 0) {
+        const float omt = 1.0f - ep.theta, oma = 1.0f - ep.alpha;
+        const float *__restrict__ e_hi = ep.hi, *__restrict__ e_h0 = ep.h0, *__restrict__ e_inp = ep.inp, *__restrict__ e_g = ep.g;
+#pragma unroll
+        for (int a = 0; a < AM; a++) {
+            const int rbase = m0 + wr * 32 * AM + a * 32 + 4 * hh;
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                int col = n0 + wc * 64 + b * 32 + li;
+                col = col < N ? col : N - 1;
+                const bool left = EPI == 2 && left_half(b);
+                const float cg = left ? ep.c1 : ep.c2;
+                const int gcol = left ? col : col - ep.F;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    int row = rbase + (q & 3) + 8 * (q >> 2);
+                    row = row < M ? row : M - 1;
+                    if constexpr (EPI == 2) {
+                        add[a][q][b] = cg * e_g[(int64_t)row * ep.F + gcol];
+                    } else {
+                        const int64_t o = (int64_t)row * N + col;
+                        const float r = e_h0 ? oma * e_hi[o] + ep.alpha * e_h0[o] : e_hi[o];
+                        add[a][q][b] = omt * r + (e_inp ? e_inp[o] : 0.0f);
+                    }
+                }
+            }
+        }
+        // (pins the terms HERE: left alone the compiler sinks every load to its use after the main loop, one memory round trip per element)
+#pragma unroll
+        for (int a = 0; a < AM; a++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) asm volatile("" ::"v"(add[a][q][0]), "v"(add[a][q][1]));
+      }
+    };
+    if constexpr (RING) {
+        // piece = 8 rows x 128 B = one LDS-DMA wave-instruction; wavefront w fills the pieces w, w + 4, ... of either operand.
+        // lane -> (row lane / 8 of the piece, slot lane % 8); it fetches the chunk that belongs in that slot: slot ^ ((row >> 1) & 7).
+        // Rows beyond M / N are clamped to a valid row: they only reach accumulators that are never stored.
+        constexpr int PA = BM / 32, PB = BN / 32;               // pieces per wavefront and stage
+        const bool msec = A2 != nullptr && ksplit < 0 && m0 >= -ksplit;             // (block-uniform: the splits are tile multiples)
+        int rowA[PA], rowB[PB], chA[PA], chB[PB];
+#pragma unroll
+        for (int q = 0; q < PA; q++) {
+            const int r = (wave + 4 * q) * 8 + (lane >> 3);
+            int gr = m0 + r < M ? m0 + r : M - 1;
+            if (msec) gr -= -ksplit;
+            rowA[q] = gr;
+            chA[q] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+        }
+#pragma unroll
+        for (int q = 0; q < PB; q++) {
+            const int r = (wave + 4 * q) * 8 + (lane >> 3);
+            rowB[q] = n0 + r < N ? n0 + r : N - 1;
+            chB[q] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+        }
+        const unsigned lds0 = (unsigned)(uintptr_t)smem, wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+        auto issue = [&](int kt, int st) {
+            const int k0 = kt * BK;
+            const bool ksec = A2 != nullptr && ksplit > 0 && k0 >= ksplit;
+            const __bf16 *Ab = (ksec || msec) ? A2 : A;
+            const int lda = (A2 && ksplit > 0) ? (ksec ? K - ksplit : ksplit) : K, ka = ksec ? k0 - ksplit : k0;
+            const unsigned sa = lds0 + (unsigned)(st * STAGE) + wave_u * 1024u, sb = sa + BM * 128;
+#pragma unroll
+            for (int q = 0; q < PA; q++) glds16(Ab + (int64_t)rowA[q] * lda + ka + chA[q], sa + q * 4096);
+#pragma unroll
+            for (int q = 0; q < PB; q++) glds16(B + (int64_t)rowB[q] * K + k0 + chB[q], sb + q * 4096);
+        };
+        // fragment reads: lane (li, hh) of K-sub-step ks wants chunk 2 ks + hh of row R = 32 x + li; (R >> 1) & 7 = (li >> 1) & 7
+        const int swz = (li >> 1) & 7;
+        int ko[BK / 16];
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ks++) ko[ks] = ((2 * ks + hh) ^ swz) * 16;
+        const int arow = (wr * 32 * AM + li) * 128, brow = BM * 128 + (wc * 64 + li) * 128;
+        const int nk = K / BK;
+        static_assert(NST == 3 || NST == 4, "ring depth");
+        static_assert(BK / 16 == 4, "the K-step is four MFMA sub-steps");
+        // fragments of one sub-step: AM row blocks of A, two column blocks of B.  Two sets: the reads of sub-step s + 1 are issued
+        // before the MFMAs of sub-step s (with one set the compiler could only re-issue a read after the MFMAs that consume the
+        // register, and every sub-step exposed an LDS round trip: 0.58 us per K-step against 0.3 us of matrix time).
+        struct Frags { bf16x8 a[AM], b[2]; };
+        auto rd = [&](Frags &f, const unsigned char *sb, int ks) {
+            f.b[0] = *reinterpret_cast<const bf16x8 *>(sb + brow + ko[ks]);
+            f.b[1] = *reinterpret_cast<const bf16x8 *>(sb + brow + 32 * 128 + ko[ks]);
+#pragma unroll
+            for (int a = 0; a < AM; a++) f.a[a] = *reinterpret_cast<const bf16x8 *>(sb + arow + a * 32 * 128 + ko[ks]);
+        };
+        auto mm = [&](const Frags &f) {
+#if DGG_BF16_ABL != 1
+#pragma unroll
+            for (int a = 0; a < AM; a++) {
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a], f.b[0], acc[a][0], 0, 0, 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a], f.b[1], acc[a][1], 0, 0, 0);
+            }
+#endif
+        };
+#pragma unroll
+        for (int q = 0; q < NST - 1; q++)
+            if (q < nk) issue(q, q);
+        epi_terms();                                            // (behind the first stages' loads: one memory round trip for both)
+        // stage 0 has landed once all but the loads of the newer stages of every wavefront are done; the barrier publishes it
+        if (nk >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (PA + PB)) : "memory");
+        else if (NST > 3 && nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        Frags f0, f1;
+        rd(f0, smem, 0);
+        int st = 0;
+        for (int kt = 0; kt < nk; kt++) {
+            const unsigned char *sb = smem + st * STAGE;
+            const int stn = st == NST - 1 ? 0 : st + 1;
+            rd(f1, sb, 1);
+            mm(f0);
+            rd(f0, sb, 2);
+            mm(f1);
+            // MID-step: publish stage kt + 1 (every wavefront waits for its own pieces, then the barrier) so that its first
+            // fragments can be fetched during the last sub-step below; every wavefront is also through with stage kt - 1, whose
+            // slot the loads of stage kt + NST - 1 now overwrite
+            if (kt + 1 < nk) {
+                if (NST > 3 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#if DGG_BF16_ABL != 2
+                if (kt + NST - 1 < nk) issue(kt + NST - 1, st == 0 ? NST - 1 : st - 1);
+#endif
+            }
+            rd(f1, sb, 3);
+            mm(f0);
+            if (kt + 1 < nk) rd(f0, smem + stn * STAGE, 0);
+            mm(f1);
+            st = stn;
+        }
+    } else {
+    __bf16 (*As)[BM * LDS_STRIDE] = reinterpret_cast<__bf16 (*)[BM * LDS_STRIDE]>(smem);
+    __bf16 (*Bs)[BN * LDS_STRIDE] = reinterpret_cast<__bf16 (*)[BN * LDS_STRIDE]>(smem + 2 * BM * LDS_STRIDE * 2);
     uint4 ra[2 * AM], rb[4];
     // 128 rows x 8 chunks of 16 bytes per operand and K-step: 4 chunks per thread (rows beyond M / N read row 0 and are zeroed)
     auto load = [&](int k0) {
@@ -98,6 +276,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
         }
     };
     load(0);
+    epi_terms();
     store(0);
     __syncthreads();
     const int nk = K / BK;
@@ -120,67 +299,49 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
         if (kt + 1 < nk) store(buf ^ 1);
         __syncthreads();
     }
-    // epilogue: accumulator register q of block (a, b) holds C[row = (q & 3) + 8 (q >> 2) + 4 hh][col = li] of the 32 x 32 block.
-    // The fp32 operands of the fused epilogues are loaded for a whole 32-row block FIRST and stored afterwards: written as one
-    // load-compute-store per element the compiler keeps the order (the stores may alias the loads), and every element pays a
-    // memory round trip -- the forward product ran at half the rate of the plain one.
-    const float omt = 1.0f - ep.theta, oma = 1.0f - ep.alpha;
-    const float *__restrict__ e_hi = ep.hi, *__restrict__ e_h0 = ep.h0, *__restrict__ e_inp = ep.inp, *__restrict__ e_g = ep.g;
+    }
+    // epilogue: accumulator register q of block (a, b) holds C[row = (q & 3) + 8 (q >> 2) + 4 hh][col = li] of the 32 x 32 block;
+    // the fp32 terms of the fused epilogues were fetched before the main loop (epi_terms).  A tile that lies inside the matrix -- all
+    // but the last row of tiles -- stores without per-element bounds tests (224 branches in the other form).
     float *__restrict__ e_out2 = ep.out2;
+    auto store_tile = [&](auto fullc) {
+        constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
-    for (int a = 0; a < AM; a++) {
-        const int rbase = m0 + wr * 32 * AM + a * 32 + 4 * hh;
-        float add[16][2];
-        if (EPI != 0) {
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int row = rbase + (q & 3) + 8 * (q >> 2);
-#pragma unroll
-                for (int b = 0; b < 2; b++) {
-                    const int col = n0 + wc * 64 + b * 32 + li;
-                    float t_ = 0.0f;
-                    if (row < M && col < N) {
-                        if (EPI == 2) {
-                            const bool left = col < ep.F;
-                            t_ = (left ? ep.c1 : ep.c2) * e_g[(int64_t)row * ep.F + (left ? col : col - ep.F)];
-                        } else {
-                            const int64_t o = (int64_t)row * N + col;
-                            const float r = e_h0 ? oma * e_hi[o] + ep.alpha * e_h0[o] : e_hi[o];
-                            t_ = omt * r + (e_inp ? e_inp[o] : 0.0f);
-                        }
-                    }
-                    add[q][b] = t_;
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int row = rbase + (q & 3) + 8 * (q >> 2);
-            if (row >= M) continue;
+        for (int a = 0; a < AM; a++) {
+            const int rbase = m0 + wr * 32 * AM + a * 32 + 4 * hh;
 #pragma unroll
             for (int b = 0; b < 2; b++) {
                 const int col = n0 + wc * 64 + b * 32 + li;
-                if (col >= N) continue;
-                const float v = scale * acc[a][b][q];
-                if (EPI == 2) {
-                    const bool left = col < ep.F;
-                    (left ? C : e_out2)[(int64_t)row * ep.F + (left ? col : col - ep.F)] = v + add[q][b];
-                    if (left && ep.outb) ep.outb[(int64_t)row * ep.F + col] = (__bf16)(v + add[q][b]);
-                } else if (EPI == 1) {
-                    float o_ = ep.theta * v + add[q][b];
-                    if (ep.relu) {
-                        o_ = o_ > 0.0f ? o_ : 0.0f;
-                        if (ep.drop_thr24)
-                            o_ = dgg::drop_keep(ep.s0, ep.s1, (uint32_t)((int64_t)row * N + col), ep.drop_thr24) ? o_ * ep.drop_scale : 0.0f;
+                if (!FULL && col >= N) continue;
+                const bool left = EPI == 2 && left_half(b);
+                float *__restrict__ dst2 = left ? C : e_out2;
+                const int col2 = left ? col : col - ep.F;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int row = rbase + (q & 3) + 8 * (q >> 2);
+                    if (!FULL && row >= M) continue;
+                    const float v = scale * acc[a][b][q];
+                    if constexpr (EPI == 2) {
+                        dst2[(int64_t)row * ep.F + col2] = v + add[a][q][b];
+                        if (left && ep.outb) ep.outb[(int64_t)row * ep.F + col] = (__bf16)(v + add[a][q][b]);
+                    } else if constexpr (EPI == 1) {
+                        float o_ = ep.theta * v + add[a][q][b];
+                        if (ep.relu) {
+                            o_ = o_ > 0.0f ? o_ : 0.0f;
+                            if (ep.drop_thr24)
+                                o_ = dgg::drop_keep(ep.s0, ep.s1, (uint32_t)((int64_t)row * N + col), ep.drop_thr24) ? o_ * ep.drop_scale : 0.0f;
+                        }
+                        C[(int64_t)row * N + col] = o_;
+                        if (ep.outb) ep.outb[(int64_t)row * N + col] = (__bf16)o_;
+                    } else {
+                        C[(int64_t)row * N + col] = v;
                     }
-                    C[(int64_t)row * N + col] = o_;
-                    if (ep.outb) ep.outb[(int64_t)row * N + col] = (__bf16)o_;
-                } else {
-                    C[(int64_t)row * N + col] = v;
                 }
             }
         }
-    }
+    };
+    if (m0 + BM <= M && n0 + BN <= N) store_tile(std::true_type{});
+    else store_tile(std::false_type{});
 }
 
 // fp32 [R, Cc] -> bf16.  transpose 0: dst [R][ld] (ld >= Cc, columns Cc..ld-1 zero);  transpose 1: dst [Cc][ld] (ld >= R, zero padded)
@@ -250,11 +411,17 @@ int launch_gemm(const __bf16 *A, const __bf16 *B, int M, int N, int K, float sca
     { const char *e = getenv("DGG_BF16_TILE"); if (e) small = atoi(e) == 64 ? true : (atoi(e) == 128 ? false : small); }
     const dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + (small ? 63 : 127)) / (small ? 64 : 128)));
     const GcniiEpi e0 = ep ? *ep : GcniiEpi{};
-#define DGG_BF16_LAUNCH(E, AMV) hipLaunchKernelGGL((gemm_nt_bf16<E, AMV>), grid, dim3(256), 0, st, A, B, M, N, K, scale, C, e0, A2, ksplit)
+    bool ring = true;
+    { const char *e = getenv("DGG_BF16_RING"); if (e && atoi(e) == 0) ring = false; }
+    int xcdmap = grid.x % 8 == 0 ? 1 : 0;
+    { const char *e = getenv("DGG_BF16_XCD"); if (e && atoi(e) == 0) xcdmap = 0; }
+#define DGG_BF16_LAUNCH2(E, AMV, RG) hipLaunchKernelGGL((gemm_nt_bf16<E, AMV, RG>), grid, dim3(256), 0, st, A, B, M, N, K, scale, C, e0, A2, ksplit, xcdmap)
+#define DGG_BF16_LAUNCH(E, AMV) do { if (ring) DGG_BF16_LAUNCH2(E, AMV, true); else DGG_BF16_LAUNCH2(E, AMV, false); } while (0)
     if (epi == 2) { if (small) DGG_BF16_LAUNCH(2, 1); else DGG_BF16_LAUNCH(2, 2); }
     else if (epi == 1) { if (small) DGG_BF16_LAUNCH(1, 1); else DGG_BF16_LAUNCH(1, 2); }
     else { if (small) DGG_BF16_LAUNCH(0, 1); else DGG_BF16_LAUNCH(0, 2); }
 #undef DGG_BF16_LAUNCH
+#undef DGG_BF16_LAUNCH2
     return dgg_check_launch("gemm_nt_bf16");
 }
 

@@ -44,7 +44,7 @@ hiT, h0T, GT = ops.pack_bf16(hi, transpose=True), ops.pack_bf16(h0, transpose=Tr
 dW = torch.empty_like(W)
 print(f"n = {n}, F = {F} (37.7 GFLOP per product at n = 2250)")
 print("forward, fused epilogue (split A)      %.1f us" % timed(lambda: L.dgg_gcnii_gemm_bf16_split(p(S1), p(S2), p(Wt), n, F, 2 * F, F, p(hi), p(h0), p(x), C.c_float(0.4), C.c_float(0.5), p(out), st)))
-print("forward, fused + relu + dropout        %.1f us" % timed(lambda: L.dgg_gcnii_gemm_bf16_split_act(p(S1), p(S2), p(Wt), n, F, 2 * F, F, p(hi), p(h0), p(x), C.c_float(0.4), C.c_float(0.5), 1, C.c_float(0.2), 1, 2, p(out), st)))
+print("forward, fused + relu + dropout        %.1f us" % timed(lambda: L.dgg_gcnii_gemm_bf16_split_act(p(S1), p(S2), p(Wt), n, F, 2 * F, F, p(hi), p(h0), p(x), C.c_float(0.4), C.c_float(0.5), 1, C.c_float(0.2), 1, 2, p(out), None, st)))
 print("forward product alone (plain, cat A)   %.1f us" % timed(lambda: L.dgg_gemm_nt_bf16(p(Scat), p(Wt), n, F, 2 * F, C.c_float(1.0), p(out), st)))
 print("  + separate epilogue pass             %.1f us" % timed(lambda: L.dgg_gcnii_epilogue_fwd(p(out), p(hi), p(h0), p(x), n * F, C.c_float(0.4), C.c_float(0.5), p(dhi), st)))
 print("[d hi | d h0], fused epilogue          %.1f us" % timed(lambda: L.dgg_gcnii_dsupport_bf16(p(Gp), p(Wp), n, F, p(gr), C.c_float(0.4), C.c_float(0.5), p(dhi), p(dh0), st)))
