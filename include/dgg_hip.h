@@ -502,6 +502,9 @@ int dgg_norm_da_cols_part(const void *part_ws, int64_t rows, int K, int64_t ncol
  * dgg_gcnii_gemm_bf16: the forward with the epilogue fused; S bf16 [n,K], Wt bf16 [F,K] = weight^T; hi/h0/inp fp32 [n,F]
  *   (r = h0 ? (1 - alpha) hi + alpha h0 : hi;  h0, inp nullable). */
 int dgg_pack_bf16(const float *src, int64_t R, int64_t C, int transpose, void *dst, int64_t ld, void *stream);
+/* both layouts from one read of src (a weight is the B operand of the forward as W^T and of d support as stored):
+ * dst [R][ld] (ld >= C) and dstT [C][ldT] (ldT >= R) */
+int dgg_pack_bf16_both(const float *src, int64_t R, int64_t C, void *dst, int64_t ld, void *dstT, int64_t ldT, void *stream);
 int dgg_gemm_nt_bf16(const void *A, const void *B, int64_t M, int64_t N, int64_t K, float scale, float *C, void *stream);
 int dgg_gcnii_gemm_bf16(const void *S, const void *Wt, int64_t n, int64_t F, int64_t K, const float *hi, const float *h0, const float *inp,
                         float theta, float alpha, float *out, void *stream);
@@ -549,15 +552,21 @@ int dgg_dropout_hash(const float *x, int64_t n, float p, uint32_t s0, uint32_t s
 /* The stack's three gather kernels on bf16 COPIES of what they gather (the activation in the aggregation and the SDDMM, d hi in the
  * transposed aggregation): at F = 2048 they are bound by L2 bandwidth, the copies halve their bytes; accumulation stays fp32.
  *   dgg_ell_spmm_fwd_b16     Y = A Xb (+ bf16(Y));  dgg_ell_sddmm_b16   dA = <dYb_i, Xb_j>;  dgg_ell_spmm_t_part_b16   dX += A^T dYb
- *   dgg_gcnii_dsupport_bf16_b  dgg_gcnii_dsupport_bf16 that also leaves bf16(d hi) */
+ *   dgg_gcnii_dsupport_bf16_b  dgg_gcnii_dsupport_bf16 that also leaves bf16(d hi) in dhib (dhi may then be NULL); accumulate_dh0:
+ *                              dh0 += its half (the sum over the stack's layers without an add pass per layer) */
 int dgg_ell_spmm_fwd_b16(const int32_t *idx, const float *ahat, const void *Xb, int64_t N, int K, int F, float *Y, void *Yb, int64_t ldyb,
                          void *stream);
 int dgg_ell_sddmm_b16(const int32_t *idx, const float *ahat, const void *Xb, const void *dYb, int64_t N, int K, int F, int skip_zero, float *dA,
                       void *stream);
 int dgg_ell_spmm_t_part_b16(const float *a, const void *dYb, int64_t rows, int K, int F, const void *part_ws, int64_t ncols, float *dX,
                             void *stream);
+/* dgg_ell_sddmm_b16 one 512-feature slice of the gathered rows at a time (F a multiple of 512; a slice of a PPI graph's activation
+ * stays in an XCD's L2, whole rows do not); ws: dgg_ell_sddmm_b16_ws_floats(N, K, F) floats; accumulate: dA += instead of = */
+size_t dgg_ell_sddmm_b16_ws_floats(int64_t N, int K, int F);
+int dgg_ell_sddmm_b16_sliced(const int32_t *idx, const float *ahat, const void *Xb, const void *dYb, int64_t N, int K, int F, int skip_zero,
+                             float *ws, float *dA, int accumulate, void *stream);
 int dgg_gcnii_dsupport_bf16_b(const void *Gp, const void *Wp, int64_t n, int64_t F, const float *g, float theta, float alpha, float *dhi,
-                              float *dh0, void *dhib, void *stream);
+                              float *dh0, void *dhib, int accumulate_dh0, void *stream);
 int dgg_gcnii_gout_pack(const float *gin, const float *xd, float scale, int64_t n, int64_t F, float *g, void *Gp, void *GT, int64_t ldT,
                         float *g2, void *stream);
 

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "dgg_softk_edge_bwd_partp": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _i32, _i32, _vp, _i64,
                                  _vp, _vp, _vp, _i32, _vp],
     "dgg_pack_bf16": [_vp, _i64, _i64, _i32, _vp, _i64, _vp],
+    "dgg_pack_bf16_both": [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp],
     "dgg_gemm_nt_bf16": [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp],
     "dgg_gcnii_gemm_bf16": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _f32, _vp, _vp],
     "dgg_gcnii_gemm_bf16_split": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _f32, _f32, _vp, _vp],
@@ -117,8 +118,10 @@ PROTOTYPES = {
     "dgg_dropout_hash": [_vp, _i64, _f32, _u32, _u32, _i32, _vp, _vp, _vp],
     "dgg_ell_spmm_fwd_b16": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp],
     "dgg_ell_sddmm_b16": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp],
+    "dgg_ell_sddmm_b16_ws_floats": [_i64, _i32, _i32],
+    "dgg_ell_sddmm_b16_sliced": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
     "dgg_ell_spmm_t_part_b16": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp],
-    "dgg_gcnii_dsupport_bf16_b": [_vp, _vp, _i64, _i64, _vp, _f32, _f32, _vp, _vp, _vp, _vp],
+    "dgg_gcnii_dsupport_bf16_b": [_vp, _vp, _i64, _i64, _vp, _f32, _f32, _vp, _vp, _vp, _i32, _vp],
     "dgg_gcnii_gout_pack": [_vp, _vp, _f32, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp],
     "dgg_ell_spmm_act_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp],
     "dgg_act_bwd": [_vp, _vp, _i64, _i32, _vp, _vp],
@@ -155,7 +158,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = C.c_int
         for name in ("dgg_allpairs_workspace_bytes", "dgg_allpairs_sweep_ctl_offset_bytes", "dgg_allpairs_rsym_ctl_offset_bytes", "dgg_gemm_tn_ws_floats", "dgg_gemm_tn_multi_ws_floats", "dgg_linear_bwd_ws_floats", "dgg_part_ws_bytes", "dgg_partp_ws_bytes", "dgg_knet_x_bwd_ws_bytes",
-                     "dgg_degree_stats_ws_bytes"):
+                     "dgg_degree_stats_ws_bytes", "dgg_ell_sddmm_b16_ws_floats"):
             getattr(L, name).restype = C.c_size_t
         _lib = L
     return _lib

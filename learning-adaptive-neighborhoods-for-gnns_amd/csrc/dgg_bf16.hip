@@ -40,19 +40,18 @@ constexpr int BN = 128, BK = 64, LDS_STRIDE = BK + 8;   // bf16 elements per sta
 struct GcniiEpi {
     const float *hi, *h0, *inp;    // EPI 1: r = h0 ? (1 - alpha) hi + alpha h0 : hi;  out = theta C + (1 - theta) r (+ inp)
     float theta, alpha;
-    // EPI 2 (d support of the variant layer, C = theta g W^T is [n, 2F]): columns < F go to C [n,F] as C + c1 g, columns >= F to
-    // out2 [n,F] as C + c2 g -- d hi and d h0 complete, no [n,2F] intermediate, no slicing adds
+    // EPI 2 / 3 (one half of d support of the variant layer, [d hi | d h0] = theta g W^T + [c1 | c2] g; a launch per half, the half's
+    // rows of W as the B operand): out = scale * acc + c1 * g (EPI 3: + the value C holds -- d h0 summed over the stack's layers
+    // without an add pass per layer); fp32 to C (nullable in EPI 2), bf16 to outb (nullable).  g, C, outb are [M, N].
     const float *g;
-    float *out2;
-    float c1, c2;
-    int F;
+    float c1;
     // fused GCNII stack (EPI 1): the layer's activation and the NEXT layer's dropout in the same store --
     // out = keep(e) ? relu(.) / (1 - p) : 0 with the counter-based mask of dgg_common.h (drop_keep); relu 0: neither
     int relu;
     uint32_t drop_thr24, s0, s1;
     float drop_scale;
     // bf16 copy of the output for the kernels that GATHER it afterwards (the next layer's aggregation and the SDDMM read the
-    // activation, the transposed aggregation reads d hi): EPI 1: of `out` [n,N]; EPI 2: of the left half (d hi) [n,F].  Nullable.
+    // activation, the transposed aggregation reads d hi): EPI 1: of `out` [n,N]; EPI 2: of d hi.  Nullable.
     __bf16 *outb;
 };
 
@@ -108,9 +107,6 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
     // fp32 terms of the fused epilogues, fetched BEFORE the main loop (rows / columns beyond the matrix clamped: no branches):
     // one workgroup per CU leaves nothing to overlap an epilogue's loads with, and fetched after the loop they cost 20 us per tile
     float add[EPI != 0 ? AM : 1][16][2];
-    // EPI 2: whether a 32-column block lies in the left half (d hi) is the same for all lanes: a scalar test keeps the loads /
-    // stores of a block together (as a per-lane select the compiler made one exec-masked branch per element)
-    auto left_half = [&](int b) { return __builtin_amdgcn_readfirstlane(n0 + wc * 64 + b * 32) < ep.F; };
     auto epi_terms = [&]() {
       if constexpr (EPI != 0) {
         const float omt = 1.0f - ep.theta, oma = 1.0f - ep.alpha;
@@ -122,15 +118,13 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
             for (int b = 0; b < 2; b++) {
                 int col = n0 + wc * 64 + b * 32 + li;
                 col = col < N ? col : N - 1;
-                const bool left = EPI == 2 && left_half(b);
-                const float cg = left ? ep.c1 : ep.c2;
-                const int gcol = left ? col : col - ep.F;
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     int row = rbase + (q & 3) + 8 * (q >> 2);
                     row = row < M ? row : M - 1;
-                    if constexpr (EPI == 2) {
-                        add[a][q][b] = cg * e_g[(int64_t)row * ep.F + gcol];
+                    if constexpr (EPI >= 2) {
+                        add[a][q][b] = ep.c1 * e_g[(int64_t)row * N + col];
+                        if constexpr (EPI == 3) add[a][q][b] += C[(int64_t)row * N + col];
                     } else {
                         const int64_t o = (int64_t)row * N + col;
                         const float r = e_h0 ? oma * e_hi[o] + ep.alpha * e_h0[o] : e_hi[o];
@@ -303,7 +297,6 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
     // epilogue: accumulator register q of block (a, b) holds C[row = (q & 3) + 8 (q >> 2) + 4 hh][col = li] of the 32 x 32 block;
     // the fp32 terms of the fused epilogues were fetched before the main loop (epi_terms).  A tile that lies inside the matrix -- all
     // but the last row of tiles -- stores without per-element bounds tests (224 branches in the other form).
-    float *__restrict__ e_out2 = ep.out2;
     auto store_tile = [&](auto fullc) {
         constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
@@ -313,17 +306,15 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
             for (int b = 0; b < 2; b++) {
                 const int col = n0 + wc * 64 + b * 32 + li;
                 if (!FULL && col >= N) continue;
-                const bool left = EPI == 2 && left_half(b);
-                float *__restrict__ dst2 = left ? C : e_out2;
-                const int col2 = left ? col : col - ep.F;
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const int row = rbase + (q & 3) + 8 * (q >> 2);
                     if (!FULL && row >= M) continue;
                     const float v = scale * acc[a][b][q];
-                    if constexpr (EPI == 2) {
-                        dst2[(int64_t)row * ep.F + col2] = v + add[a][q][b];
-                        if (left && ep.outb) ep.outb[(int64_t)row * ep.F + col] = (__bf16)(v + add[a][q][b]);
+                    if constexpr (EPI >= 2) {
+                        const float o_ = v + add[a][q][b];
+                        if (EPI == 3 || C) C[(int64_t)row * N + col] = o_;
+                        if (ep.outb) ep.outb[(int64_t)row * N + col] = (__bf16)o_;
                     } else if constexpr (EPI == 1) {
                         float o_ = ep.theta * v + add[a][q][b];
                         if (ep.relu) {
@@ -364,6 +355,25 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float *__restrict_
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + tx;                       // dst row = source column
         if (c < Cc && r < ld) dst[(int64_t)c * ld + r] = (__bf16)tile[tx][i];
+    }
+}
+
+// both layouts of one fp32 matrix in one pass: dst [R][ld] and dstT [Cc][ldT] (zero padded as pack_bf16_kernel does)
+__global__ __launch_bounds__(256) void pack_bf16_both_kernel(const float *__restrict__ src, int R, int Cc, __bf16 *__restrict__ dst, int ld,
+                                                             __bf16 *__restrict__ dstT, int ldT) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        const float v = (r < R && c < Cc) ? src[(int64_t)r * Cc + c] : 0.0f;
+        tile[i][tx] = v;
+        if (r < R && c < ld) dst[(int64_t)r * ld + c] = (__bf16)v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;                       // dstT row = source column
+        if (c < Cc && r < ldT) dstT[(int64_t)c * ldT + r] = (__bf16)tile[tx][i];
     }
 }
 
@@ -417,7 +427,8 @@ int launch_gemm(const __bf16 *A, const __bf16 *B, int M, int N, int K, float sca
     { const char *e = getenv("DGG_BF16_XCD"); if (e && atoi(e) == 0) xcdmap = 0; }
 #define DGG_BF16_LAUNCH2(E, AMV, RG) hipLaunchKernelGGL((gemm_nt_bf16<E, AMV, RG>), grid, dim3(256), 0, st, A, B, M, N, K, scale, C, e0, A2, ksplit, xcdmap)
 #define DGG_BF16_LAUNCH(E, AMV) do { if (ring) DGG_BF16_LAUNCH2(E, AMV, true); else DGG_BF16_LAUNCH2(E, AMV, false); } while (0)
-    if (epi == 2) { if (small) DGG_BF16_LAUNCH(2, 1); else DGG_BF16_LAUNCH(2, 2); }
+    if (epi == 3) { if (small) DGG_BF16_LAUNCH(3, 1); else DGG_BF16_LAUNCH(3, 2); }
+    else if (epi == 2) { if (small) DGG_BF16_LAUNCH(2, 1); else DGG_BF16_LAUNCH(2, 2); }
     else if (epi == 1) { if (small) DGG_BF16_LAUNCH(1, 1); else DGG_BF16_LAUNCH(1, 2); }
     else { if (small) DGG_BF16_LAUNCH(0, 1); else DGG_BF16_LAUNCH(0, 2); }
 #undef DGG_BF16_LAUNCH
@@ -437,6 +448,16 @@ int dgg_pack_bf16(const float *src, int64_t R, int64_t Cc, int transpose, void *
     hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (int)R, (int)Cc, transpose,
                        reinterpret_cast<__bf16 *>(dst), (int)ld);
     return dgg_check_launch("pack_bf16");
+}
+
+// dgg_pack_bf16 in both layouts from ONE read of src: dst [R][ld] (ld >= Cc) and dstT [Cc][ldT] (ldT >= R), zero padded
+int dgg_pack_bf16_both(const float *src, int64_t R, int64_t Cc, void *dst, int64_t ld, void *dstT, int64_t ldT, void *stream) {
+    if (R <= 0 || Cc <= 0) return 0;
+    if (ld < Cc || ldT < R) return dgg_set_error(DGG_ERR_ARG, "pack_bf16_both: leading dimension smaller than the row length");
+    const dim3 grid((unsigned)((ld + 31) / 32), (unsigned)((ldT + 31) / 32));
+    hipLaunchKernelGGL(pack_bf16_both_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (int)R, (int)Cc, reinterpret_cast<__bf16 *>(dst),
+                       (int)ld, reinterpret_cast<__bf16 *>(dstT), (int)ldT);
+    return dgg_check_launch("pack_bf16_both");
 }
 
 // C[M,N] (fp32) = scale * A[M,K] B[N,K]^T, A and B bf16 with K contiguous (K a multiple of 64)
@@ -461,7 +482,7 @@ int dgg_gcnii_gemm_bf16(const void *S, const void *Wt, int64_t n, int64_t F, int
 int dgg_gcnii_gemm_bf16_split(const void *S1, const void *S2, const void *Wt, int64_t n, int64_t F, int64_t K, int64_t F1, const float *hi,
                               const float *h0, const float *inp, float theta, float alpha, float *out, void *stream) {
     if (!hi || !S2) return dgg_set_error(DGG_ERR_ARG, "gcnii_gemm_bf16_split: hi and the second operand half are required");
-    const GcniiEpi ep{hi, h0, inp, theta, alpha, nullptr, nullptr, 0.0f, 0.0f, 0};
+    const GcniiEpi ep{hi, h0, inp, theta, alpha};
     return launch_gemm(reinterpret_cast<const __bf16 *>(S1), reinterpret_cast<const __bf16 *>(Wt), (int)n, (int)F, (int)K, 1.0f, out, &ep,
                        (hipStream_t)stream, 1, reinterpret_cast<const __bf16 *>(S2), (int)F1);
 }
@@ -473,7 +494,7 @@ int dgg_gcnii_gemm_bf16_split_act(const void *S1, const void *S2, const void *Wt
                                   uint32_t s1, float *out, void *outb, void *stream) {
     if (!hi || !S2) return dgg_set_error(DGG_ERR_ARG, "gcnii_gemm_bf16_split_act: hi and the second operand half are required");
     if (!(drop_p >= 0.0f && drop_p < 1.0f) || n * F >= ((int64_t)1 << 32)) return dgg_set_error(DGG_ERR_ARG, "gcnii_gemm_bf16_split_act: drop_p in [0,1), n*F < 2^32");
-    GcniiEpi ep{hi, h0, inp, theta, alpha, nullptr, nullptr, 0.0f, 0.0f, 0};
+    GcniiEpi ep{hi, h0, inp, theta, alpha};
     ep.relu = relu; ep.drop_thr24 = relu ? (uint32_t)(drop_p * 16777216.0f) : 0u; ep.s0 = s0; ep.s1 = s1; ep.drop_scale = 1.0f / (1.0f - drop_p);
     ep.outb = reinterpret_cast<__bf16 *>(outb);
     return launch_gemm(reinterpret_cast<const __bf16 *>(S1), reinterpret_cast<const __bf16 *>(Wt), (int)n, (int)F, (int)K, 1.0f, out, &ep,
@@ -492,27 +513,33 @@ int dgg_gcnii_gout_pack(const float *gin, const float *xd, float scale, int64_t 
     return dgg_check_launch("gcnii_gout_pack");
 }
 
-// dgg_gcnii_dsupport_bf16 that also leaves bf16(d hi) [n,F] (dhib, nullable) for the transposed aggregation that gathers it next
-int dgg_gcnii_dsupport_bf16_b(const void *Gp, const void *Wp, int64_t n, int64_t F, const float *g, float theta, float alpha, float *dhi,
-                              float *dh0, void *dhib, void *stream) {
-    if (!g || !dhi || !dh0) return dgg_set_error(DGG_ERR_ARG, "gcnii_dsupport_bf16_b: g, dhi and dh0 are required");
-    GcniiEpi ep{};
-    ep.g = g; ep.out2 = dh0; ep.c1 = (1.0f - theta) * (1.0f - alpha); ep.c2 = (1.0f - theta) * alpha; ep.F = (int)F;
-    ep.outb = reinterpret_cast<__bf16 *>(dhib);
-    return launch_gemm(reinterpret_cast<const __bf16 *>(Gp), reinterpret_cast<const __bf16 *>(Wp), (int)n, (int)(2 * F), (int)F, theta, dhi, &ep,
-                       (hipStream_t)stream, 2);
-}
-
-// Backward of the variant layer w.r.t. its two inputs in ONE product: [d hi | d h0] = theta * Gp W^T + [c1 | c2] * g with
+// Backward of the variant layer w.r.t. its two inputs: [d hi | d h0] = theta * Gp W^T + [c1 | c2] * g with
 // c1 = (1 - theta)(1 - alpha), c2 = (1 - theta) alpha (model.py:41-44): Gp bf16 [n,F] (= bf16(g)), Wp bf16 [2F, F] (the weight as
-// stored), g fp32 [n,F]; dhi, dh0 fp32 [n,F]
+// stored), g fp32 [n,F].  One product per half (rows [0,F) / [F,2F) of Wp as the B operand), epilogue fused: no [n,2F] intermediate,
+// no slicing adds.  dhi fp32 [n,F] (nullable when dhib is given), dhib = bf16(d hi) (nullable) for the transposed aggregation that
+// gathers it next, dh0 fp32 [n,F]; accumulate_dh0: dh0 += its half instead of =.
+static int dsupport_halves(const void *Gp, const void *Wp, int64_t n, int64_t F, const float *g, float theta, float alpha, float *dhi, float *dh0,
+                           void *dhib, int accumulate_dh0, void *stream) {
+    if (!g || !dh0 || (!dhi && !dhib)) return dgg_set_error(DGG_ERR_ARG, "gcnii_dsupport_bf16: g, dh0 and one of dhi / dhib are required");
+    GcniiEpi ep{};
+    ep.g = g; ep.c1 = (1.0f - theta) * (1.0f - alpha);
+    ep.outb = reinterpret_cast<__bf16 *>(dhib);
+    const __bf16 *W = reinterpret_cast<const __bf16 *>(Wp);
+    int rc = launch_gemm(reinterpret_cast<const __bf16 *>(Gp), W, (int)n, (int)F, (int)F, theta, dhi, &ep, (hipStream_t)stream, 2);
+    if (rc) return rc;
+    ep.c1 = (1.0f - theta) * alpha;
+    ep.outb = nullptr;
+    return launch_gemm(reinterpret_cast<const __bf16 *>(Gp), W + F * F, (int)n, (int)F, (int)F, theta, dh0, &ep, (hipStream_t)stream,
+                       accumulate_dh0 ? 3 : 2);
+}
+int dgg_gcnii_dsupport_bf16_b(const void *Gp, const void *Wp, int64_t n, int64_t F, const float *g, float theta, float alpha, float *dhi,
+                              float *dh0, void *dhib, int accumulate_dh0, void *stream) {
+    return dsupport_halves(Gp, Wp, n, F, g, theta, alpha, dhi, dh0, dhib, accumulate_dh0, stream);
+}
 int dgg_gcnii_dsupport_bf16(const void *Gp, const void *Wp, int64_t n, int64_t F, const float *g, float theta, float alpha, float *dhi,
                             float *dh0, void *stream) {
-    if (!g || !dhi || !dh0) return dgg_set_error(DGG_ERR_ARG, "gcnii_dsupport_bf16: g, dhi and dh0 are required");
-    GcniiEpi ep{};
-    ep.g = g; ep.out2 = dh0; ep.c1 = (1.0f - theta) * (1.0f - alpha); ep.c2 = (1.0f - theta) * alpha; ep.F = (int)F;
-    return launch_gemm(reinterpret_cast<const __bf16 *>(Gp), reinterpret_cast<const __bf16 *>(Wp), (int)n, (int)(2 * F), (int)F, theta, dhi, &ep,
-                       (hipStream_t)stream, 2);
+    if (!dhi) return dgg_set_error(DGG_ERR_ARG, "gcnii_dsupport_bf16: dhi is required");
+    return dsupport_halves(Gp, Wp, n, F, g, theta, alpha, dhi, dh0, nullptr, 0, stream);
 }
 
 // C[M,N] = scale * [A ; A2] B^T with the rows [0, M1) of the A operand in A [M1,K] and the rows [M1, M) in A2 [M-M1,K] (M1 a multiple

@@ -200,6 +200,58 @@ __global__ __launch_bounds__(WPB * 64) void sddmm_wide_b16_kernel(const int32_t 
     if (lane < K) dA[i * K + lane] = mine;
 }
 
+// The SDDMM of the stack one 512-feature SLICE at a time (grid.y; x runs fastest, so the whole chip works on one slice before the
+// next): a slice of the gathered activation is 1 KB per node -- 1.8 MB for a PPI graph, resident in an XCD's 4 MB L2 -- where whole
+// 4 KB rows (7.3 MB) are not: the unsliced kernel gathered at 3.4 TB/s.  One 16-byte load per lane and neighbour; the slice's partial
+// dot products go to part[slice][N*K] and sddmm_slices_sum adds the slices in slice order (deterministic, no float atomics).
+__global__ __launch_bounds__(WPB * 64) void sddmm_slice_b16_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
+                                                                  const uint4 *__restrict__ Xb, const uint4 *__restrict__ dYb,
+                                                                  int64_t N, int K, int F, int skip_zero, float *__restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
+    if (i >= N) return;
+    const int32_t jl = lane < K ? idx[i * K + lane] : -1;
+    const float al = lane < K ? ahat[i * K + lane] : 0.0f;
+    const int F8 = F / 8, c = blockIdx.y * 64 + lane;
+    const uint4 g = dYb[i * F8 + c];
+    const float g0 = bf_lo(g.x), g1 = bf_hi(g.x), g2 = bf_lo(g.y), g3 = bf_hi(g.y), g4 = bf_lo(g.z), g5 = bf_hi(g.z), g6 = bf_lo(g.w),
+                g7 = bf_hi(g.w);
+    float mine = 0.0f;
+    constexpr int NQ = 8;
+    for (int r0 = 0; r0 < K; r0 += NQ) {
+        uint4 xv[NQ];
+        bool v[NQ];
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < NQ; u++) {
+            const int r = r0 + u < K ? r0 + u : K - 1;
+            const int32_t j = bcast(jl, r);
+            v[u] = r0 + u < K && j >= 0 && !(skip_zero && bcast(al, r) == 0.0f);
+            any = any || v[u];
+            xv[u] = make_uint4(0, 0, 0, 0);
+            if (v[u]) xv[u] = Xb[(int64_t)j * F8 + c];             // (wave-uniform predicate)
+        }
+        if (!any) continue;                                      // wave-uniform
+#pragma unroll
+        for (int u = 0; u < NQ; u++) {
+            float p_ = 0.0f;
+            p_ = fmaf(g0, bf_lo(xv[u].x), p_); p_ = fmaf(g1, bf_hi(xv[u].x), p_); p_ = fmaf(g2, bf_lo(xv[u].y), p_); p_ = fmaf(g3, bf_hi(xv[u].y), p_);
+            p_ = fmaf(g4, bf_lo(xv[u].z), p_); p_ = fmaf(g5, bf_hi(xv[u].z), p_); p_ = fmaf(g6, bf_lo(xv[u].w), p_); p_ = fmaf(g7, bf_hi(xv[u].w), p_);
+            const float tot = wave_sum_dpp(p_, lane);
+            if (lane == r0 + u) mine = tot;
+        }
+    }
+    if (lane < K) part[(int64_t)blockIdx.y * N * K + i * K + lane] = mine;
+}
+// dA[e] (+)= sum over the slices, in slice order
+__global__ void sddmm_slices_sum(const float *__restrict__ part, int64_t n, int S, int accumulate, float *__restrict__ dA) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float s_ = part[e];
+    for (int q = 1; q < S; q++) s_ += part[(int64_t)q * n + e];
+    dA[e] = accumulate ? dA[e] + s_ : s_;
+}
+
 // Same aggregation for NARROW feature rows (F = 16, 32, 64: the projected features H = X W of a GCNConv whose output is
 // narrower than its input, aggregated after the projection).  F/4 lanes per gathered row (16-byte loads), 256/F rows per
 // wave-instruction and NBT such batches in flight, so that one load instruction still moves 1 KiB; the 256/F partial sums
@@ -840,6 +892,23 @@ int dgg_ell_sddmm_b16(const int32_t *idx, const float *ahat, const void *Xb, con
     hipLaunchKernelGGL(sddmm_wide_b16_kernel, dim3(rows_grid(N)), dim3(WPB * 64), 0, (hipStream_t)stream, idx, ahat, reinterpret_cast<const uint4 *>(Xb),
                        reinterpret_cast<const uint4 *>(dYb), N, K, F, skip_zero, dA);
     return dgg_check_launch("ell_sddmm_b16");
+}
+
+// dgg_ell_sddmm_b16 one 512-feature slice at a time (F a multiple of 512): dA (+)= <dY_i, X_j>; ws: dgg_ell_sddmm_b16_ws_floats(N, K, F)
+// floats of scratch (the slices' partial sums); accumulate: dA += (the stack sums dA over its layers) instead of =
+size_t dgg_ell_sddmm_b16_ws_floats(int64_t N, int K, int F) { return (size_t)(F / 512) * (size_t)N * (size_t)K; }
+int dgg_ell_sddmm_b16_sliced(const int32_t *idx, const float *ahat, const void *Xb, const void *dYb, int64_t N, int K, int F, int skip_zero,
+                             float *ws, float *dA, int accumulate, void *stream) {
+    if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    if (F % 512 != 0 || ((uintptr_t)Xb % 16) || ((uintptr_t)dYb % 16)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ell_sddmm_b16_sliced: F must be a multiple of 512, rows 16-byte aligned");
+    if (!ws || !dA) return dgg_set_error(DGG_ERR_ARG, "ell_sddmm_b16_sliced: workspace and dA are required");
+    if (N == 0) return 0;
+    const int S = F / 512;
+    hipLaunchKernelGGL(sddmm_slice_b16_kernel, dim3(rows_grid(N), (unsigned)S), dim3(WPB * 64), 0, (hipStream_t)stream, idx, ahat,
+                       reinterpret_cast<const uint4 *>(Xb), reinterpret_cast<const uint4 *>(dYb), N, K, F, skip_zero, ws);
+    const int64_t n = N * K;
+    hipLaunchKernelGGL(sddmm_slices_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, n, S, accumulate, dA);
+    return dgg_check_launch("ell_sddmm_b16_sliced");
 }
 
 int dgg_ell_spmm_fwd(const int32_t *idx, const float *ahat, const float *X, int64_t N, int K, int F, float *Y,

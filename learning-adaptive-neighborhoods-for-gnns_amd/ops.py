@@ -1577,6 +1577,17 @@ def pack_bf16(src, transpose=False):
     return dst
 
 
+def pack_bf16_both(src):
+    """fp32 [R,C] -> (bf16 [R, C64], bf16 [C, R64]) from one read of src: a weight's two operand layouts"""
+    src = _chk(src)
+    R, Cc = src.shape
+    ld, ldT = (Cc + 63) // 64 * 64, (R + 63) // 64 * 64
+    dst = torch.empty((R, ld), device=src.device, dtype=torch.bfloat16)
+    dstT = torch.empty((Cc, ldT), device=src.device, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().dgg_pack_bf16_both(_ptr(src), R, Cc, _ptr(dst), ld, _ptr(dstT), ldT, _stream()), "pack_bf16_both")
+    return dst, dstT
+
+
 def gemm_nt_bf16(A, B, scale=1.0):
     """A [M,K] bf16, B [N,K] bf16 (K contiguous, a multiple of 64) -> fp32 scale * A B^T"""
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.shape[1] == B.shape[1] and A.is_contiguous() and B.is_contiguous()
@@ -1761,7 +1772,8 @@ class GcniiStackBf16Fn(torch.autograd.Function):
             xd, xdb = dropout_hash(h0c, p, s0, s1, bf16_copy=True)
         else:
             xd, xdb = (dropout_hash(h0c, p, s0, s1) if p > 0 else h0c), None
-        his, xds, xdbs = [], [xd], [xdb]
+        his, xds, xdbs, wps = [], [xd], [xdb], []
+        train = any(ctx.needs_input_grad)                        # a backward will follow: it re-uses this forward's weight packs
         # the product operand cat[bf16(hi) | bf16(h0)] [n, 2F]: the right half once per stack, the left half by every layer's aggregation
         if STACK_SPLIT_EPILOGUE:
             hib, ldh = torch.empty((n, 2 * F), device=h0.device, dtype=torch.bfloat16), 2 * F
@@ -1776,7 +1788,11 @@ class GcniiStackBf16Fn(torch.autograd.Function):
                 _lib.check(_lib.lib().dgg_ell_spmm_fwd_b16(_ptr(idx), _ptr(ahat), _ptr(xdb), n, K, F, _ptr(hi), _ptr(hib), ldh, _stream()), "ell_spmm_fwd_b16")
             else:
                 _lib.check(_lib.lib().dgg_ell_spmm_fwd_bf16(_ptr(idx), _ptr(ahat), _ptr(xd), n, K, F, _ptr(hi), _ptr(hib), ldh, _stream()), "ell_spmm_fwd_bf16")
-            Wt = _packed_weight(W, True)                         # [F, 2F]
+            if train:                                            # both layouts from one read; the plain one is d support's operand
+                Wp, Wt = pack_bf16_both(W.detach())
+                wps.append(Wp)
+            else:
+                Wt = _packed_weight(W, True)                     # [F, 2F]
             out = torch.empty((n, F), device=h0.device, dtype=torch.float32)
             outb = torch.empty((n, F), device=h0.device, dtype=torch.bfloat16) if (b16 and l < L) else None      # (the last output is gathered by no one)
             sl = (s1 ^ (_STACK_KEY * l)) & 0xFFFFFFFF
@@ -1795,6 +1811,7 @@ class GcniiStackBf16Fn(torch.autograd.Function):
         _probe_end("gcnii_stack_fwd", pe)
         ctx.save_for_backward(h0, ahat, idx, *weights, *his, *xds)
         ctx.xdbs = xdbs[:L] if b16 else None                     # bf16 copies of xd_0 .. xd_{L-1} (plain tensors, no autograd edge)
+        ctx.wps = wps if train else None                         # bf16(W_l) as stored: made with this forward's W_l, which autograd's version check on the saved weights keeps unchanged until the backward
         ctx.cfg = (L, part, bool(skip_zero), bool(residual), float(p), float(lamda), float(alpha), s0, s1)
         return xd
 
@@ -1827,30 +1844,31 @@ class GcniiStackBf16Fn(torch.autograd.Function):
             gnext = torch.empty((n, F), device=dev, dtype=torch.float32) if residual else None       # becomes g + A^T d hi below
             _lib.check(_lib.lib().dgg_gcnii_gout_pack(_ptr(gx), _ptr(xd_l), float(scale), n, F, _ptr(gout), _ptr(Gp), _ptr(GT), n64, _ptr(gnext),
                                                       _stream()), "gcnii_gout_pack")
-            dhi = torch.empty((n, F), device=dev, dtype=torch.float32)
+            dhi = None if b16 else torch.empty((n, F), device=dev, dtype=torch.float32)          # (the bf16 gathers read only the copy)
             dhib = torch.empty((n, F), device=dev, dtype=torch.bfloat16) if b16 else None
-            dh0_l = dh0 if l == L else torch.empty((n, F), device=dev, dtype=torch.float32)
-            _lib.check(_lib.lib().dgg_gcnii_dsupport_bf16_b(_ptr(Gp), _ptr(_packed_weight(W, False)), n, F, _ptr(gout), float(theta), float(alpha),
-                                                            _ptr(dhi), _ptr(dh0_l), _ptr(dhib), _stream()), "gcnii_dsupport_bf16")
-            if l != L:
-                dh0.add_(dh0_l)
+            Wp = ctx.wps[l - 1] if ctx.wps is not None else _packed_weight(W, False)
+            _lib.check(_lib.lib().dgg_gcnii_dsupport_bf16_b(_ptr(Gp), _ptr(Wp), n, F, _ptr(gout), float(theta), float(alpha),
+                                                            _ptr(dhi), _ptr(dh0), _ptr(dhib), int(l != L), _stream()), "gcnii_dsupport_bf16")   # d h0: summed over the layers in the epilogue
             if ctx.needs_input_grad[10 + l - 1]:
                 hiT = pack_bf16(hi, transpose=True)
                 dW = torch.empty_like(W)
                 _lib.check(_lib.lib().dgg_gemm_nt_bf16_rows2(_ptr(hiT), _ptr(h0T), F, _ptr(GT), 2 * F, F, n64, float(theta), _ptr(dW), _stream()),
                            "gemm_nt_bf16_rows2")
                 dWs[l - 1] = dW
-            dA_l = torch.empty((n, K), device=dev, dtype=torch.float32)
             gx = gnext if residual else torch.zeros_like(gout)              # + g through the residual; A^T d hi accumulates into it
-            if b16:
-                _lib.check(_lib.lib().dgg_ell_sddmm_b16(_ptr(idx), _ptr(ahat), _ptr(ctx.xdbs[l - 1]), _ptr(dhib), n, K, F, int(skip_zero), _ptr(dA_l),
-                                                        _stream()), "ell_sddmm_b16")
+            if b16:                                                          # d A summed over the layers by the SDDMM's own reduction
+                if dA is None:
+                    dA = torch.empty((n, K), device=dev, dtype=torch.float32)
+                    sd_ws = torch.empty((int(_lib.lib().dgg_ell_sddmm_b16_ws_floats(n, K, F)),), device=dev, dtype=torch.float32)
+                _lib.check(_lib.lib().dgg_ell_sddmm_b16_sliced(_ptr(idx), _ptr(ahat), _ptr(ctx.xdbs[l - 1]), _ptr(dhib), n, K, F, int(skip_zero), _ptr(sd_ws),
+                                                               _ptr(dA), int(l != L), _stream()), "ell_sddmm_b16_sliced")
                 _lib.check(_lib.lib().dgg_ell_spmm_t_part_b16(_ptr(ahat), _ptr(dhib), n, K, F, _ptr(part), n, _ptr(gx), _stream()), "ell_spmm_t_part_b16")
             else:
+                dA_l = torch.empty((n, K), device=dev, dtype=torch.float32)
                 _lib.check(_lib.lib().dgg_ell_spmm_bwd(_ptr(idx), _ptr(ahat), _ptr(xd_prev), _ptr(dhi), n, K, F, int(skip_zero), _ptr(dA_l), _ptr(None),
                                                        _stream()), "ell_spmm_bwd")
                 _lib.check(_lib.lib().dgg_ell_spmm_t_part(_ptr(ahat), _ptr(dhi), n, K, F, _ptr(part), n, _ptr(gx), _stream()), "ell_spmm_t_part")
-            dA = dA_l if dA is None else dA.add_(dA_l)
+                dA = dA_l if dA is None else dA.add_(dA_l)
         if p > 0:
             dropout_hash(gx, p, s0, s1, accumulate_into=dh0)     # back through xd_0 = dropout(h0): the same mask
         else:

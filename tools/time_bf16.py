@@ -48,5 +48,8 @@ print("forward, fused + relu + dropout        %.1f us" % timed(lambda: L.dgg_gcn
 print("forward product alone (plain, cat A)   %.1f us" % timed(lambda: L.dgg_gemm_nt_bf16(p(Scat), p(Wt), n, F, 2 * F, C.c_float(1.0), p(out), st)))
 print("  + separate epilogue pass             %.1f us" % timed(lambda: L.dgg_gcnii_epilogue_fwd(p(out), p(hi), p(h0), p(x), n * F, C.c_float(0.4), C.c_float(0.5), p(dhi), st)))
 print("[d hi | d h0], fused epilogue          %.1f us" % timed(lambda: L.dgg_gcnii_dsupport_bf16(p(Gp), p(Wp), n, F, p(gr), C.c_float(0.4), C.c_float(0.5), p(dhi), p(dh0), st)))
+dhib = torch.empty(n, F, device=dev, dtype=torch.bfloat16)
+for ob, ac in ((0, 0), (1, 0), (0, 1), (1, 1), (2, 1)):
+    print("[d hi | d h0] fused, bf16 copy %d (2: no fp32 d hi), accumulate %d  %.1f us" % (ob, ac, timed(lambda: L.dgg_gcnii_dsupport_bf16_b(p(Gp), p(Wp), n, F, p(gr), C.c_float(0.4), C.c_float(0.5), None if ob == 2 else p(dhi), p(dh0), p(dhib) if ob else None, ac, st))))
 print("[d hi | d h0] product alone (plain)    %.1f us" % timed(lambda: L.dgg_gemm_nt_bf16(p(Gp), p(Wp), n, 2 * F, F, C.c_float(0.4), p(out2), st)))
 print("weight gradient (rows2, plain)         %.1f us" % timed(lambda: L.dgg_gemm_nt_bf16_rows2(p(hiT), p(h0T), F, p(GT), 2 * F, F, n64, C.c_float(0.4), p(dW), st)))
