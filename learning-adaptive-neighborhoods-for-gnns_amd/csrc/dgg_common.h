@@ -8,6 +8,7 @@
 //   1 - 0.5*(1 + tanh(r - k))                      reference dgm.py:1410-1414
 // (the reference evaluates them with torch CPU kernels; agreement with it is to a few ulp).
 #pragma once
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -249,6 +250,14 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
     hi = __shfl_xor(hi, mask, 64);
     return ((uint64_t)hi << 32) | lo;
 }
+
+// v of lane U of every 16-lane row (DPP row_share: one vector instruction, no LDS crossbar -- __shfl is a ds_bpermute), for all
+// U = 0..15 at once: out[U] = v[16 (lane / 16) + U]
+template <int... U>
+__device__ __forceinline__ void row16_all_impl(int v, int (&out)[16], std::integer_sequence<int, U...>) {
+    ((out[U] = __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xF, 0xF, false)), ...);
+}
+__device__ __forceinline__ void row16_all(int v, int (&out)[16]) { row16_all_impl(v, out, std::make_integer_sequence<int, 16>{}); }
 
 // lane ^ D exchange without the LDS crossbar: DPP quad_perm / row shifts / row_ror for D < 16,
 // v_permlane16_swap / v_permlane32_swap (gfx950) for D = 16 / 32.  ~1-3 VALU ops instead of a ds_bpermute round trip.

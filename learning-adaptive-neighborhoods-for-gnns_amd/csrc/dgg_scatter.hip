@@ -20,12 +20,13 @@ namespace {
 constexpr int BS = 128;            // destination nodes per bucket
 constexpr int PR = 256;            // rows per partition workgroup (4 wavefronts x 64 rows)
 
-struct PartHdr {                   // workspace: [bstart NB+1][cursor NB][tmp rows*K int2][slot rows*K int][recs rows*K int2]
+struct PartHdr {                   // workspace: [bstart NB+1][cursor NB][tmp rows*K int2][slot rows*K int][recs rows*K int2][cstart]
     int *bstart, *cursor;
     int2 *tmp;                     // bucket-ordered records (src = row*64 + r, dst = j)
     int *slot;                     // slot[row*K + r] = position of the entry in recs, -1 if inactive: lets the row-side
     int2 *recs;                    // kernels write their per-entry coefficient in RECORD order (coalesced reads later)
-};                                 // recs: the records ordered by destination node
+    int *cstart;                   // recs: the records ordered by destination node; cstart[c]: first record in [64 c, 64 c + 48] that
+};                                 // starts a RUN of equal destination, else 64 c (rows*K/64 + 2 entries): chunks that split only hubs' runs
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 inline PartHdr part_layout(void *ws, int64_t nb, int64_t nrec) {
     char *w = reinterpret_cast<char *>(ws);
@@ -35,6 +36,7 @@ inline PartHdr part_layout(void *ws, int64_t nb, int64_t nrec) {
     p.tmp = reinterpret_cast<int2 *>(w + align256((size_t)(nb + 1) * 4) + align256((size_t)nb * 4));
     p.slot = reinterpret_cast<int *>(reinterpret_cast<char *>(p.tmp) + align256((size_t)nrec * sizeof(int2)));
     p.recs = reinterpret_cast<int2 *>(reinterpret_cast<char *>(p.slot) + align256((size_t)nrec * sizeof(int)));
+    p.cstart = reinterpret_cast<int *>(reinterpret_cast<char *>(p.recs) + align256((size_t)nrec * sizeof(int2)));
     return p;
 }
 
@@ -139,6 +141,23 @@ __global__ __launch_bounds__(1024) void part_sort(const int *__restrict__ bstart
         recs[pos] = rec;
         slotmap[(int64_t)(rec.x >> 6) * K + (rec.x & 63)] = pos;
     }
+}
+
+// run-aligned chunk starts (see PartHdr::cstart): one thread per chunk.  A run that goes on for more than 48 records past the
+// nominal start (a hub's) is SPLIT there instead: the consumer adds the pieces of such a run atomically.
+__global__ void part_chunk_starts(const int *__restrict__ bstart, int nb, const int2 *__restrict__ recs, int nchunks, int chunk,
+                                  int *__restrict__ cstart) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > nchunks) return;
+    const int nnz = bstart[nb];
+    const int64_t x = (int64_t)c * chunk;
+    int e = x < nnz ? (int)x : nnz;
+    if (e > 0) {
+        const int lim = e + 48 < nnz ? e + 48 : nnz;
+        while (e < lim && recs[e].y == recs[e - 1].y) e++;
+        if (e < nnz && recs[e].y == recs[e - 1].y) e = (int)x;
+    }
+    cstart[c] = e;
 }
 
 // exclusive scan of the bucket totals (single workgroup): bstart[0..nb], cursor[b] = bstart[b]
@@ -495,22 +514,27 @@ __global__ __launch_bounds__(256) void edge_bwd_cols(const float *__restrict__ x
 // 16-lane group, runs of equal destination reduced in registers, one flush per run; grid.y = blocks of 64 features.
 // B16: dY is a bf16 copy [rows, F] of the cotangent (the fused GCNII stack: half the gathered bytes), accumulation in fp32 as before
 template <bool B16 = false>
-__global__ __launch_bounds__(256) void spmm_t_cols(const void *__restrict__ dYv, int F, const int *__restrict__ bstart, int nb,
+__global__ __launch_bounds__(256) void spmm_t_cols(const void *__restrict__ dYv, int F, const int *__restrict__ cstart, int nchunks,
                                                    const int2 *__restrict__ recs, const float *__restrict__ a, int K,
                                                    float *__restrict__ dX) {
     const float *__restrict__ dY = static_cast<const float *>(dYv);
     const uint16_t *__restrict__ dYb = static_cast<const uint16_t *>(dYv);
     constexpr int LPR = 16;
-    const int lane = threadIdx.x & 63, c4 = lane % LPR, gbase = lane - c4;
+    const int lane = threadIdx.x & 63, c4 = lane % LPR;
     const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
     const int f0 = blockIdx.y * 64 + 4 * c4;
-    const int nnz = bstart[nb];
-    const int64_t cbeg = gid * CH;
-    if (cbeg >= nnz) return;
-    const int cend = cbeg + CH < nnz ? (int)cbeg + CH : nnz;
+    if (gid >= nchunks) return;
+    // run-aligned chunk (PartHdr::cstart): but for the pieces of a hub's run, every destination row is written by exactly one lane
+    // group -- a plain add.  (With fixed chunks of 64 records the two runs at a chunk's ends were added atomically: two thirds of all
+    // runs at PPI's ~29 records per destination, and those atomics, not the gathers, were the kernel's time: 56 of 59 us.)
+    const int cbeg = cstart[gid], cend = cstart[gid + 1];
+    if (cbeg >= cend) return;
+    const int nnz = cstart[nchunks];
+    const int first = recs[cbeg].y, last = recs[cend - 1].y;
+    const int shared_lo = (cbeg > 0 && recs[cbeg - 1].y == first) ? first : -1;
+    const int shared_hi = (cend < nnz && recs[cend].y == last) ? last : -1;
     int cur = -1;
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const int shared_lo = cbeg > 0 ? recs[cbeg - 1].y : -1, shared_hi = cend < nnz ? recs[cend].y : -1;   // see edge_bwd_cols
     auto flush = [&]() {
         if (cur >= 0) {
             float *o = dX + (int64_t)cur * F + f0;
@@ -523,40 +547,38 @@ __global__ __launch_bounds__(256) void spmm_t_cols(const void *__restrict__ dYv,
             }
         }
     };
-    for (int eb = (int)cbeg; eb < cend; eb += LPR) {
+    for (int eb = cbeg; eb < cend; eb += LPR) {
         const int e = eb + c4;
         const int2 myrec = e < cend ? recs[e] : make_int2(0, -1);
         // record source = row*64 + r: the coefficient lives at a[row*K + r]
         const float mycf = e < cend ? a[(int64_t)(myrec.x >> 6) * K + (myrec.x & 63)] : 0.0f;
+        // all 16 rows of the batch are requested before the first is used
+        int src[LPR], dst[LPR], cfb[LPR];                         // (row broadcasts: the shuffles of this loop were 3 ds_bpermute per record and slice)
+        float4 g[LPR];
+        dgg::row16_all(myrec.x, src);
+        dgg::row16_all(myrec.y, dst);
+        dgg::row16_all(__float_as_int(mycf), cfb);
 #pragma unroll
-        for (int u0 = 0; u0 < LPR; u0 += 4) {
-            int src[4], dst[4];
-            float cf[4];
-            float4 g[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                src[u] = __shfl(myrec.x, gbase + u0 + u, 64);
-                dst[u] = __shfl(myrec.y, gbase + u0 + u, 64);
-                cf[u] = __shfl(mycf, gbase + u0 + u, 64);
-                if constexpr (B16) {
-                    const uint2 h_ = *reinterpret_cast<const uint2 *>(dYb + (int64_t)(src[u] >> 6) * F + f0);   // unconditional
-                    g[u] = make_float4(__uint_as_float(h_.x << 16), __uint_as_float(h_.x & 0xffff0000u), __uint_as_float(h_.y << 16),
-                                       __uint_as_float(h_.y & 0xffff0000u));
-                } else {
-                    g[u] = *reinterpret_cast<const float4 *>(dY + (int64_t)(src[u] >> 6) * F + f0);     // unconditional
-                }
+        for (int u = 0; u < LPR; u++) {
+            if constexpr (B16) {
+                const uint2 h_ = *reinterpret_cast<const uint2 *>(dYb + (int64_t)(src[u] >> 6) * F + f0);   // unconditional
+                g[u] = make_float4(__uint_as_float(h_.x << 16), __uint_as_float(h_.x & 0xffff0000u), __uint_as_float(h_.y << 16),
+                                   __uint_as_float(h_.y & 0xffff0000u));
+            } else {
+                g[u] = *reinterpret_cast<const float4 *>(dY + (int64_t)(src[u] >> 6) * F + f0);          // unconditional
             }
+        }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (dst[u] < 0) continue;
-                if (dst[u] != cur) {
-                    flush();
-                    cur = dst[u];
-                    acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
-                acc.x = fmaf(cf[u], g[u].x, acc.x); acc.y = fmaf(cf[u], g[u].y, acc.y);
-                acc.z = fmaf(cf[u], g[u].z, acc.z); acc.w = fmaf(cf[u], g[u].w, acc.w);
+        for (int u = 0; u < LPR; u++) {
+            if (dst[u] < 0) continue;
+            if (dst[u] != cur) {
+                flush();
+                cur = dst[u];
+                acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
+            const float cf = __int_as_float(cfb[u]);
+            acc.x = fmaf(cf, g[u].x, acc.x); acc.y = fmaf(cf, g[u].y, acc.y);
+            acc.z = fmaf(cf, g[u].z, acc.z); acc.w = fmaf(cf, g[u].w, acc.w);
         }
     }
     flush();
@@ -1501,7 +1523,7 @@ size_t dgg_part_ws_bytes(int64_t rows, int K, int64_t ncols) {
     // 8 bytes of dynamic LDS per bucket in the fill pass (64 KiB without opting in to more); record ids are 32-bit
     if (nb > 8192 || K > 64 || K < 1 || rows * 64 >= ((int64_t)1 << 31)) return 0;
     return align256((size_t)(nb + 1) * 4) + align256((size_t)nb * 4) + align256((size_t)rows * K * sizeof(int2)) +
-           align256((size_t)rows * K * sizeof(int)) + (size_t)rows * K * sizeof(int2);
+           align256((size_t)rows * K * sizeof(int)) + align256((size_t)rows * K * sizeof(int2)) + (size_t)(rows * K / CH + 2) * sizeof(int);
 }
 
 // Partition the ACTIVE entries (idx >= 0, w != 0) of idx [rows,K] by destination bucket.
@@ -1517,6 +1539,8 @@ int dgg_part_build(const int32_t *idx, const float *w, int64_t rows, int K, int6
     hipLaunchKernelGGL(part_scan, dim3(1), dim3(1024), 0, st, p.bstart, p.cursor, (int)nb);
     hipLaunchKernelGGL(part_pass<true>, dim3(grid), dim3(256), (size_t)nb * 8, st, idx, w, rows, K, (int)nb, p.cursor, p.tmp, p.slot);
     hipLaunchKernelGGL(part_sort, dim3((unsigned)nb), dim3(1024), 0, st, p.bstart, p.tmp, K, p.recs, p.slot);
+    const int nchunks = (int)((rows * K + CH - 1) / CH);
+    hipLaunchKernelGGL(part_chunk_starts, dim3((unsigned)(nchunks / 256 + 1)), dim3(256), 0, st, p.bstart, (int)nb, p.recs, nchunks, CH, p.cstart);
     return dgg_check_launch("part_build");
 }
 
@@ -1578,7 +1602,7 @@ int dgg_ell_spmm_t_part(const float *a, const float *dY, int64_t rows, int K, in
     PartHdr p = part_layout(const_cast<void *>(part_ws), nb, rows * K);
     const int64_t ngroups = (rows * K + CH - 1) / CH;
     hipLaunchKernelGGL(spmm_t_cols<false>, dim3((unsigned)((ngroups * 16 + 255) / 256), (unsigned)(F / 64)), dim3(256), 0, (hipStream_t)stream,
-                       static_cast<const void *>(dY), F, p.bstart, (int)nb, p.recs, a, K, dX);
+                       static_cast<const void *>(dY), F, p.cstart, (int)ngroups, p.recs, a, K, dX);
     return dgg_check_launch("ell_spmm_t_part");
 }
 // the same gathering a bf16 COPY of the cotangent (dYb [rows, F] bf16, 8-byte aligned rows)
@@ -1591,7 +1615,7 @@ int dgg_ell_spmm_t_part_b16(const float *a, const void *dYb, int64_t rows, int K
     PartHdr p = part_layout(const_cast<void *>(part_ws), nb, rows * K);
     const int64_t ngroups = (rows * K + CH - 1) / CH;
     hipLaunchKernelGGL(spmm_t_cols<true>, dim3((unsigned)((ngroups * 16 + 255) / 256), (unsigned)(F / 64)), dim3(256), 0, (hipStream_t)stream, dYb,
-                       F, p.bstart, (int)nb, p.recs, a, K, dX);
+                       F, p.cstart, (int)ngroups, p.recs, a, K, dX);
     return dgg_check_launch("ell_spmm_t_part_b16");
 }
 
