@@ -78,35 +78,28 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
-template <int EPI, int AM, bool RING>
-__global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A, const __bf16 *__restrict__ B, int M, int N, int K,
-                                                    float scale, float *__restrict__ C, GcniiEpi ep, const __bf16 *__restrict__ A2, int ksplit,
-                                                    int xcdmap) {
-    constexpr int BM = 64 * AM;
+// WC: wavefronts across the tile's 128 columns (2: four wavefronts of 32 AM x 64, 256 threads; 4: eight of 32 AM x 32, 512 threads --
+// two per SIMD, so that one's fragment reads and barrier waits run under the other's MFMAs; ring only)
+template <int EPI, int AM, bool RING, int WC = 2>
+__global__ __launch_bounds__(128 * WC) void gemm_nt_bf16(const __bf16 *__restrict__ A, const __bf16 *__restrict__ B, int M, int N, int K,
+                                                         float scale, float *__restrict__ C, GcniiEpi ep, const __bf16 *__restrict__ A2, int ksplit) {
+    static_assert(WC == 2 || (WC == 4 && RING), "eight wavefronts: ring loop only");
+    constexpr int BM = 64 * AM, NB = 4 / WC, NW = 2 * WC;
     constexpr int NST = DGG_BF16_NST, STAGE = (BM + BN) * 128;             // ring: stages of [BM + BN rows][8 chunks of 16 B]
     __shared__ __attribute__((aligned(1024))) unsigned char smem[RING ? NST * STAGE : 2 * (BM + BN) * LDS_STRIDE * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), li = lane & 31, hh = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
-    // Workgroups go to the 8 XCDs round-robin in launch order (observed; speed only).  xcdmap: XCD x works on the column tiles
-    // [x gx/8, (x+1) gx/8) of B -- a slice that stays in its 4 MB L2 -- and walks the row tiles of A in order, so B comes over the
-    // fabric once in all and A once per XCD (plain order: every XCD fetches both operands whole).
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (xcdmap) {
-        const int id = blockIdx.y * gridDim.x + blockIdx.x, per = gridDim.x >> 3, slot = id >> 3;
-        bx = (id & 7) * per + slot % per;
-        by = slot / per;
-    }
-    const int m0 = by * (64 * AM), n0 = bx * BN;
-    f32x16 acc[AM][2];
+    const int wr = wave / WC, wc = wave % WC;
+    const int m0 = blockIdx.y * (64 * AM), n0 = blockIdx.x * BN;
+    f32x16 acc[AM][NB];
 #pragma unroll
     for (int a = 0; a < AM; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < NB; b++)
 #pragma unroll
             for (int q = 0; q < 16; q++) acc[a][b][q] = 0.0f;
     // fp32 terms of the fused epilogues, fetched BEFORE the main loop (rows / columns beyond the matrix clamped: no branches):
     // one workgroup per CU leaves nothing to overlap an epilogue's loads with, and fetched after the loop they cost 20 us per tile
-    float add[EPI != 0 ? AM : 1][16][2];
+    float add[EPI != 0 ? AM : 1][16][NB];
     auto epi_terms = [&]() {
       if constexpr (EPI != 0) {
         const float omt = 1.0f - ep.theta, oma = 1.0f - ep.alpha;
@@ -115,8 +108,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
         for (int a = 0; a < AM; a++) {
             const int rbase = m0 + wr * 32 * AM + a * 32 + 4 * hh;
 #pragma unroll
-            for (int b = 0; b < 2; b++) {
-                int col = n0 + wc * 64 + b * 32 + li;
+            for (int b = 0; b < NB; b++) {
+                int col = n0 + wc * 32 * NB + b * 32 + li;
                 col = col < N ? col : N - 1;
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
@@ -137,19 +130,21 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
 #pragma unroll
         for (int a = 0; a < AM; a++)
 #pragma unroll
-            for (int q = 0; q < 16; q++) asm volatile("" ::"v"(add[a][q][0]), "v"(add[a][q][1]));
+            for (int q = 0; q < 16; q++)
+#pragma unroll
+                for (int b = 0; b < NB; b++) asm volatile("" ::"v"(add[a][q][b]));
       }
     };
     if constexpr (RING) {
         // piece = 8 rows x 128 B = one LDS-DMA wave-instruction; wavefront w fills the pieces w, w + 4, ... of either operand.
         // lane -> (row lane / 8 of the piece, slot lane % 8); it fetches the chunk that belongs in that slot: slot ^ ((row >> 1) & 7).
         // Rows beyond M / N are clamped to a valid row: they only reach accumulators that are never stored.
-        constexpr int PA = BM / 32, PB = BN / 32;               // pieces per wavefront and stage
+        constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;       // pieces per wavefront and stage
         const bool msec = A2 != nullptr && ksplit < 0 && m0 >= -ksplit;             // (block-uniform: the splits are tile multiples)
         int rowA[PA], rowB[PB], chA[PA], chB[PB];
 #pragma unroll
         for (int q = 0; q < PA; q++) {
-            const int r = (wave + 4 * q) * 8 + (lane >> 3);
+            const int r = (wave + NW * q) * 8 + (lane >> 3);
             int gr = m0 + r < M ? m0 + r : M - 1;
             if (msec) gr -= -ksplit;
             rowA[q] = gr;
@@ -157,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
         }
 #pragma unroll
         for (int q = 0; q < PB; q++) {
-            const int r = (wave + 4 * q) * 8 + (lane >> 3);
+            const int r = (wave + NW * q) * 8 + (lane >> 3);
             rowB[q] = n0 + r < N ? n0 + r : N - 1;
             chB[q] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
         }
@@ -169,36 +164,35 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
             const int lda = (A2 && ksplit > 0) ? (ksec ? K - ksplit : ksplit) : K, ka = ksec ? k0 - ksplit : k0;
             const unsigned sa = lds0 + (unsigned)(st * STAGE) + wave_u * 1024u, sb = sa + BM * 128;
 #pragma unroll
-            for (int q = 0; q < PA; q++) glds16(Ab + (int64_t)rowA[q] * lda + ka + chA[q], sa + q * 4096);
+            for (int q = 0; q < PA; q++) glds16(Ab + (int64_t)rowA[q] * lda + ka + chA[q], sa + q * (NW * 1024));
 #pragma unroll
-            for (int q = 0; q < PB; q++) glds16(B + (int64_t)rowB[q] * K + k0 + chB[q], sb + q * 4096);
+            for (int q = 0; q < PB; q++) glds16(B + (int64_t)rowB[q] * K + k0 + chB[q], sb + q * (NW * 1024));
         };
         // fragment reads: lane (li, hh) of K-sub-step ks wants chunk 2 ks + hh of row R = 32 x + li; (R >> 1) & 7 = (li >> 1) & 7
         const int swz = (li >> 1) & 7;
         int ko[BK / 16];
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ks++) ko[ks] = ((2 * ks + hh) ^ swz) * 16;
-        const int arow = (wr * 32 * AM + li) * 128, brow = BM * 128 + (wc * 64 + li) * 128;
+        const int arow = (wr * 32 * AM + li) * 128, brow = BM * 128 + (wc * 32 * NB + li) * 128;
         const int nk = K / BK;
         static_assert(NST == 3 || NST == 4, "ring depth");
         static_assert(BK / 16 == 4, "the K-step is four MFMA sub-steps");
         // fragments of one sub-step: AM row blocks of A, two column blocks of B.  Two sets: the reads of sub-step s + 1 are issued
         // before the MFMAs of sub-step s (with one set the compiler could only re-issue a read after the MFMAs that consume the
         // register, and every sub-step exposed an LDS round trip: 0.58 us per K-step against 0.3 us of matrix time).
-        struct Frags { bf16x8 a[AM], b[2]; };
+        struct Frags { bf16x8 a[AM], b[NB]; };
         auto rd = [&](Frags &f, const unsigned char *sb, int ks) {
-            f.b[0] = *reinterpret_cast<const bf16x8 *>(sb + brow + ko[ks]);
-            f.b[1] = *reinterpret_cast<const bf16x8 *>(sb + brow + 32 * 128 + ko[ks]);
+#pragma unroll
+            for (int b = 0; b < NB; b++) f.b[b] = *reinterpret_cast<const bf16x8 *>(sb + brow + b * 32 * 128 + ko[ks]);
 #pragma unroll
             for (int a = 0; a < AM; a++) f.a[a] = *reinterpret_cast<const bf16x8 *>(sb + arow + a * 32 * 128 + ko[ks]);
         };
         auto mm = [&](const Frags &f) {
 #if DGG_BF16_ABL != 1
 #pragma unroll
-            for (int a = 0; a < AM; a++) {
-                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a], f.b[0], acc[a][0], 0, 0, 0);
-                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a], f.b[1], acc[a][1], 0, 0, 0);
-            }
+            for (int a = 0; a < AM; a++)
+#pragma unroll
+                for (int b = 0; b < NB; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a], f.b[b], acc[a][b], 0, 0, 0);
 #endif
         };
 #pragma unroll
@@ -303,8 +297,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16(const __bf16 *__restrict__ A
         for (int a = 0; a < AM; a++) {
             const int rbase = m0 + wr * 32 * AM + a * 32 + 4 * hh;
 #pragma unroll
-            for (int b = 0; b < 2; b++) {
-                const int col = n0 + wc * 64 + b * 32 + li;
+            for (int b = 0; b < NB; b++) {
+                const int col = n0 + wc * 32 * NB + b * 32 + li;
                 if (!FULL && col >= N) continue;
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
@@ -423,10 +417,10 @@ int launch_gemm(const __bf16 *A, const __bf16 *B, int M, int N, int K, float sca
     const GcniiEpi e0 = ep ? *ep : GcniiEpi{};
     bool ring = true;
     { const char *e = getenv("DGG_BF16_RING"); if (e && atoi(e) == 0) ring = false; }
-    int xcdmap = grid.x % 8 == 0 ? 1 : 0;
-    { const char *e = getenv("DGG_BF16_XCD"); if (e && atoi(e) == 0) xcdmap = 0; }
-#define DGG_BF16_LAUNCH2(E, AMV, RG) hipLaunchKernelGGL((gemm_nt_bf16<E, AMV, RG>), grid, dim3(256), 0, st, A, B, M, N, K, scale, C, e0, A2, ksplit, xcdmap)
-#define DGG_BF16_LAUNCH(E, AMV) do { if (ring) DGG_BF16_LAUNCH2(E, AMV, true); else DGG_BF16_LAUNCH2(E, AMV, false); } while (0)
+    bool eight = ring;                                           // eight wavefronts per workgroup (ring loop only)
+    { const char *e = getenv("DGG_BF16_WAVES"); if (e && atoi(e) == 4) eight = false; }
+#define DGG_BF16_LAUNCH2(E, AMV, RG, WCV) hipLaunchKernelGGL((gemm_nt_bf16<E, AMV, RG, WCV>), grid, dim3(128 * WCV), 0, st, A, B, M, N, K, scale, C, e0, A2, ksplit)
+#define DGG_BF16_LAUNCH(E, AMV) do { if (eight) DGG_BF16_LAUNCH2(E, AMV, true, 4); else if (ring) DGG_BF16_LAUNCH2(E, AMV, true, 2); else DGG_BF16_LAUNCH2(E, AMV, false, 2); } while (0)
     if (epi == 3) { if (small) DGG_BF16_LAUNCH(3, 1); else DGG_BF16_LAUNCH(3, 2); }
     else if (epi == 2) { if (small) DGG_BF16_LAUNCH(2, 1); else DGG_BF16_LAUNCH(2, 2); }
     else if (epi == 1) { if (small) DGG_BF16_LAUNCH(1, 1); else DGG_BF16_LAUNCH(1, 2); }
