@@ -667,3 +667,22 @@ def test_normalisation_fused_into_the_partition_build(dev):
         ref = ops.normalize_fwd(T(idx[sl], dev), T(w[sl], dev), T(rs, dev), lo)
         assert torch.equal(got[1], ref)
         assert np.array_equal(Nn(got[1]), ahat[sl])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,Cc", [(130, 200), (64, 64), (257, 36), (33, 50), (4096, 2048), (7, 3)])
+def test_bf16_packs_are_the_rounded_copies(dev, R, Cc):
+    """dgg_pack_bf16 / dgg_pack_bf16_both: plain and transposed bf16 copies, zero padded to multiples of 64, bit for bit the
+    round-to-nearest-even conversion torch makes -- on shapes that take the 64 x 64-tile kernels and on shapes that do not"""
+    from dgg_amd import ops
+    g = torch.Generator().manual_seed(R * 1000 + Cc)
+    x = torch.randn(R, Cc, generator=g).to(dev)
+    xb = x.to(torch.bfloat16)
+    plain, tr = ops.pack_bf16(x), ops.pack_bf16(x, transpose=True)
+    both = ops.pack_bf16_both(x)
+    for p_ in (plain, both[0]):
+        assert p_.shape == (R, (Cc + 63) // 64 * 64)
+        assert torch.equal(p_[:, :Cc], xb) and not bool(p_[:, Cc:].any())
+    for t_ in (tr, both[1]):
+        assert t_.shape == (Cc, (R + 63) // 64 * 64)
+        assert torch.equal(t_[:, :R], xb.t()) and not bool(t_[:, R:].any())
