@@ -686,3 +686,110 @@ def test_bf16_packs_are_the_rounded_copies(dev, R, Cc):
     for t_ in (tr, both[1]):
         assert t_.shape == (Cc, (R + 63) // 64 * 64)
         assert torch.equal(t_[:, :R], xb.t()) and not bool(t_[:, R:].any())
+
+
+def _hub_graph(n, K, deg, hubs, seed):
+    """ELL block [n,K] whose first `deg` entries per row are valid; the columns in `hubs` receive an entry from EVERY row (in-degree n:
+    runs of the destination-ordered partition far longer than a chunk), the rest are uniform"""
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.randint(0, n, (n, K), generator=g, dtype=torch.int32)
+    for q, hcol in enumerate(hubs):
+        idx[:, q] = hcol
+    idx[:, deg:] = -1
+    a = torch.rand(n, K, generator=g) + 0.1
+    a[:, deg:] = 0
+    return idx, a
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b16", [False, True])
+@pytest.mark.parametrize("n,deg,hubs", [(300, 9, (5, 250)), (1000, 29, ()), (700, 3, (0,)), (65, 1, ())])
+def test_transposed_aggregation_with_hub_columns(dev, n, deg, hubs, b16):
+    """dX += A^T dY on run-aligned chunks of the partition (dgg_ell_spmm_t_part / _b16): columns whose runs are longer than a chunk
+    (split, added atomically), runs that end exactly at a chunk's end, short graphs -- against the dense product, into a non-zero dX"""
+    import ctypes as C
+    from dgg_amd import _lib, ops
+    F, K = 512, 32
+    idx, a = _hub_graph(n, K, deg, hubs, seed=n + deg)
+    g = torch.Generator().manual_seed(3)
+    dY = torch.randn(n, F, generator=g)
+    dX0 = torch.randn(n, F, generator=g)
+    if b16:
+        dY = dY.to(torch.bfloat16).float()                      # (so that the bf16 copy is exact)
+    A = torch.zeros(n, n, dtype=torch.float64)
+    rows = torch.arange(n)[:, None].expand(n, K)
+    valid = idx >= 0
+    A.index_put_((rows[valid], idx[valid].long()), a[valid].double(), accumulate=True)
+    ref = dX0.double() + A.t() @ dY.double()
+    idx_d, a_d, dX = idx.to(dev), a.to(dev), dX0.to(dev).clone()
+    part = ops.part_build(idx_d, a_d, n)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if b16:
+        dyb = dY.to(dev).to(torch.bfloat16)
+        _lib.check(_lib.lib().dgg_ell_spmm_t_part_b16(p(a_d), p(dyb), n, K, F, p(part), n, p(dX), st), "spmm_t_b16")
+    else:
+        dyd = dY.to(dev)
+        _lib.check(_lib.lib().dgg_ell_spmm_t_part(p(a_d), p(dyd), n, K, F, p(part), n, p(dX), st), "spmm_t")
+    err = float((dX.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err <= 1e-5, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,deg,F", [(300, 9, 512), (1000, 29, 2048), (65, 1, 1024)])
+def test_sliced_sddmm_matches_the_whole_row_kernel(dev, n, deg, F):
+    """dgg_ell_sddmm_b16_sliced (512-feature slices + the slice sum; overwrite and accumulate) == dgg_ell_sddmm_b16 up to the fp32
+    summation order, padding entries 0"""
+    import ctypes as C
+    from dgg_amd import _lib
+    K = 32
+    idx, a = _hub_graph(n, K, deg, (), seed=n)
+    a[:, 0] = 0                                                  # a zero-weight entry: skipped by skip_zero, its dA is 0
+    g = torch.Generator().manual_seed(4)
+    xb = torch.randn(n, F, generator=g).to(dev).to(torch.bfloat16)
+    dyb = torch.randn(n, F, generator=g).to(dev).to(torch.bfloat16)
+    idx_d, a_d = idx.to(dev), a.to(dev)
+    L = _lib.lib()
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ref = torch.empty(n, K, device=dev)
+    _lib.check(L.dgg_ell_sddmm_b16(p(idx_d), p(a_d), p(xb), p(dyb), n, K, F, 1, p(ref), st), "sddmm")
+    ws = torch.empty(int(L.dgg_ell_sddmm_b16_ws_floats(n, K, F)), device=dev)
+    got = torch.full((n, K), 7.0, device=dev)
+    _lib.check(L.dgg_ell_sddmm_b16_sliced(p(idx_d), p(a_d), p(xb), p(dyb), n, K, F, 1, p(ws), p(got), 0, st), "sddmm_sliced")
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 1e-5 * scale
+    assert not bool(got[:, deg:].any()) and not bool(got[:, 0].any())
+    _lib.check(L.dgg_ell_sddmm_b16_sliced(p(idx_d), p(a_d), p(xb), p(dyb), n, K, F, 1, p(ws), p(got), 1, st), "sddmm_sliced")
+    assert float((got - 2 * ref).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,F", [(200, 256), (333, 512)])
+def test_dsupport_halves_accumulate_into_dh0(dev, n, F):
+    """dgg_gcnii_dsupport_bf16_b: [d hi | d h0] = theta g W^T + [c1 | c2] g as one product per half; bf16 copy of d hi with and without
+    the fp32 one; accumulate_dh0 adds to what dh0 holds"""
+    import ctypes as C
+    from dgg_amd import _lib, ops
+    g_ = torch.Generator().manual_seed(n)
+    g = torch.randn(n, F, generator=g_).to(dev)
+    W = (torch.randn(2 * F, F, generator=g_) / 16).to(dev)
+    theta, alpha = 0.37, 0.2
+    Gp, Wp = ops.pack_bf16(g), ops.pack_bf16(W)
+    full = theta * (Gp.float() @ Wp.float().t())               # [n, 2F] on the rounded operands
+    c1, c2 = (1 - theta) * (1 - alpha), (1 - theta) * alpha
+    ref_hi, ref_h0 = full[:, :F] + c1 * g, full[:, F:] + c2 * g
+    L = _lib.lib()
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dhi, dh0 = torch.empty(n, F, device=dev), torch.empty(n, F, device=dev)
+    dhib = torch.empty(n, F, device=dev, dtype=torch.bfloat16)
+    _lib.check(L.dgg_gcnii_dsupport_bf16_b(p(Gp), p(Wp), n, F, p(g), theta, alpha, p(dhi), p(dh0), p(dhib), 0, st), "dsupport")
+    tol = 2e-3 * float(ref_hi.abs().max())
+    assert float((dhi - ref_hi).abs().max()) <= tol and float((dh0 - ref_h0).abs().max()) <= tol
+    assert torch.equal(dhib, dhi.to(torch.bfloat16))
+    base = torch.randn(n, F, generator=g_).to(dev)
+    dh0b, dhib2 = base.clone(), torch.empty_like(dhib)
+    _lib.check(L.dgg_gcnii_dsupport_bf16_b(p(Gp), p(Wp), n, F, p(g), theta, alpha, None, p(dh0b), p(dhib2), 1, st), "dsupport")
+    assert torch.equal(dhib2, dhib)
+    assert float((dh0b - (base + dh0)).abs().max()) <= 1e-5 * float(dh0.abs().max())
