@@ -793,3 +793,28 @@ def test_dsupport_halves_accumulate_into_dh0(dev, n, F):
     _lib.check(L.dgg_gcnii_dsupport_bf16_b(p(Gp), p(Wp), n, F, p(g), theta, alpha, None, p(dh0b), p(dhib2), 1, st), "dsupport")
     assert torch.equal(dhib2, dhib)
     assert float((dh0b - (base + dh0)).abs().max()) <= 1e-5 * float(dh0.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["ring8", "ring4", "staged"])
+def test_bf16_product_shapes_and_pipeline_edges(dev, mode, monkeypatch):
+    """dgg_gemm_nt_bf16 over contraction lengths of 1-5 K-steps (the ring's prologue holds three stages: every way of starting and
+    draining it), row / column counts inside, at and across tile edges, both tile heights -- against the fp32 product of the bf16
+    operands; the eight- and four-wavefront ring loops and the register-staged loop"""
+    from dgg_amd import ops
+    if mode == "ring4":
+        monkeypatch.setenv("DGG_BF16_WAVES", "4")
+    if mode == "staged":
+        monkeypatch.setenv("DGG_BF16_RING", "0")
+    g = torch.Generator().manual_seed(11)
+    for tile in ("64", "128"):
+        monkeypatch.setenv("DGG_BF16_TILE", tile)
+        for M in (1, 63, 64, 130, 257):
+            for N in (32, 128, 200):
+                for Kc in (64, 128, 192, 256, 320):
+                    A = torch.randn(M, Kc, generator=g).to(dev).to(torch.bfloat16)
+                    B = torch.randn(N, Kc, generator=g).to(dev).to(torch.bfloat16)
+                    got = ops.gemm_nt_bf16(A, B, 0.5)
+                    ref = 0.5 * (A.float() @ B.float().t())
+                    assert got.shape == (M, N)
+                    assert float((got - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0), (mode, tile, M, N, Kc)
