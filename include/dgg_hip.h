@@ -370,6 +370,11 @@ int dgg_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const fl
  * dxp_j -= (DD^T xp)_j - (sum_i dd_ij) xp_j  (dgg_ell_spmm_t_part(a = dd, dY = xp)).  Autograd of dgm.py:1618-1623. */
 int dgg_edge_bwd_wide_rows(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval, int K,
                            int64_t row0, float t, int perturb, float *dxp_rows, float *dd, void *stream);
+/* the same one 256-feature slice of the gathered rows at a time (h a multiple of 256; a slice of a PPI graph's xp stays in an XCD's
+ * L2, whole 8 KB rows do not); ws: dgg_edge_bwd_wide_rows_ws_floats(N, K, h) floats */
+size_t dgg_edge_bwd_wide_rows_ws_floats(int64_t N, int K, int h);
+int dgg_edge_bwd_wide_rows_sliced(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval, int K,
+                                  int64_t row0, float t, int perturb, float *ws, float *dxp_rows, float *dd, void *stream);
 
 /* ---- column-side backward terms without global float atomics (dgg_scatter.hip) -----------------------------------
  * The ACTIVE entries (idx >= 0, w != 0) of an ELL block are partitioned once per forward by destination bucket; the two

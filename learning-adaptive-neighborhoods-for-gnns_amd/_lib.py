@@ -133,6 +133,8 @@ PROTOTYPES = {
     "dgg_ell_sddmm_norm_part": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp],
     "dgg_edge_bwd": [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _vp],
     "dgg_edge_bwd_wide_rows": [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _vp, _vp],
+    "dgg_edge_bwd_wide_rows_ws_floats": [_i64, _i32, _i32],
+    "dgg_edge_bwd_wide_rows_sliced": [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _vp, _vp, _vp, _vp],
 }
 
 _lib = None
@@ -158,7 +160,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = C.c_int
         for name in ("dgg_allpairs_workspace_bytes", "dgg_allpairs_sweep_ctl_offset_bytes", "dgg_allpairs_rsym_ctl_offset_bytes", "dgg_gemm_tn_ws_floats", "dgg_gemm_tn_multi_ws_floats", "dgg_linear_bwd_ws_floats", "dgg_part_ws_bytes", "dgg_partp_ws_bytes", "dgg_knet_x_bwd_ws_bytes",
-                     "dgg_degree_stats_ws_bytes", "dgg_ell_sddmm_b16_ws_floats"):
+                     "dgg_degree_stats_ws_bytes", "dgg_ell_sddmm_b16_ws_floats", "dgg_edge_bwd_wide_rows_ws_floats"):
             getattr(L, name).restype = C.c_size_t
         _lib = L
     return _lib

@@ -763,6 +763,94 @@ __global__ __launch_bounds__(WPB * 64) void edge_bwd_wide_rows_kernel(const floa
     }
 }
 
+// The same row pass one 256-feature SLICE at a time (h a multiple of 256; grid.y = slice, x fastest: the whole chip works on one slice
+// before the next, and a slice of xp -- 1 KB per node, 1.8 MB for a PPI graph -- stays in an XCD's L2 where 8 KB rows do not: the
+// unsliced kernel gathers its 2 x 0.43 GB at 5 TB/s).  Pass 1: the slice's share of every entry's squared distance -> part[slice][N*K].
+// Pass 2: a wavefront sums its row's shares (slice order), forms dd, and accumulates its 256 features of own_i in registers.
+__global__ __launch_bounds__(WPB * 64) void edge_bwd_wide_d2_slice(const float *__restrict__ xp, int64_t N, int h, const int32_t *__restrict__ idx,
+                                                                  const float *__restrict__ dval, int K, int64_t row0,
+                                                                  float *__restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
+    if (i >= N) return;
+    const int c4 = blockIdx.y * 64 + lane;                       // this lane's float4 of the row
+    const int32_t jl = lane < K ? idx[i * K + lane] : -1;
+    const float gl = lane < K ? dval[i * K + lane] : 0.0f;
+    const float4 xi = reinterpret_cast<const float4 *>(xp + (row0 + i) * h)[c4];
+    float mine = 0.0f;
+    constexpr int NQ = 8;
+    for (int r0 = 0; r0 < K; r0 += NQ) {
+        float4 xj[NQ];
+        bool v[NQ];
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < NQ; u++) {
+            const int r = r0 + u < K ? r0 + u : K - 1;
+            const int32_t j = bcast(jl, r);
+            v[u] = r0 + u < K && j >= 0 && bcast(gl, r) != 0.0f;  // (an entry without a gradient needs no distance: dd = 0)
+            any = any || v[u];
+            xj[u] = xi;
+            if (v[u]) xj[u] = reinterpret_cast<const float4 *>(xp + (int64_t)j * h)[c4];   // (wave-uniform predicate)
+        }
+        if (!any) continue;                                      // wave-uniform
+#pragma unroll
+        for (int u = 0; u < NQ; u++) {
+            const float dx = xi.x - xj[u].x, dy = xi.y - xj[u].y, dz = xi.z - xj[u].z, dw = xi.w - xj[u].w;
+            const float p_ = fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+            const float tot = wave_sum_dpp(p_, lane);
+            if (lane == r0 + u) mine = tot;
+        }
+    }
+    if (lane < K) part[(int64_t)blockIdx.y * N * K + i * K + lane] = mine;
+}
+__global__ __launch_bounds__(WPB * 64) void edge_bwd_wide_own_slice(const float *__restrict__ xp, int64_t N, int h, const int32_t *__restrict__ idx,
+                                                                   const float *__restrict__ val, const float *__restrict__ dval, int K,
+                                                                   int64_t row0, float t, int perturb, const float *__restrict__ part, int S,
+                                                                   float *__restrict__ dxp_rows, float *__restrict__ dd_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
+    if (i >= N) return;
+    const int c4 = blockIdx.y * 64 + lane;                       // this lane's float4 of the row
+    const int32_t jl = lane < K ? idx[i * K + lane] : -1;
+    float ddl = 0.0f;                                            // lane r: the coefficient of entry r
+    if (lane < K && jl >= 0) {
+        const float g = dval[i * K + lane];
+        float d2 = 0.0f;
+        for (int s_ = 0; s_ < S; s_++) d2 += part[(int64_t)s_ * N * K + i * K + lane];
+        if (g != 0.0f && d2 != 0.0f) {
+            const float dist = sqrtf(d2);
+            const float p = c_exp(t * dist);
+            const float dp = perturb ? g * val[i * K + lane] / (p + 1e-8f) : g;
+            ddl = dp * t * p / dist;
+        }
+    }
+    if (blockIdx.y == 0 && lane < K) dd_out[i * K + lane] = ddl;
+    const float4 xi = reinterpret_cast<const float4 *>(xp + (row0 + i) * h)[c4];
+    float4 own = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    constexpr int NQ = 8;
+    for (int r0 = 0; r0 < K; r0 += NQ) {
+        float4 xj[NQ];
+        float dd[NQ];
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < NQ; u++) {
+            const int r = r0 + u < K ? r0 + u : K - 1;
+            const int32_t j = bcast(jl, r);
+            dd[u] = r0 + u < K ? bcast(ddl, r) : 0.0f;
+            any = any || dd[u] != 0.0f;
+            xj[u] = xi;
+            if (dd[u] != 0.0f) xj[u] = reinterpret_cast<const float4 *>(xp + (int64_t)j * h)[c4];   // (wave-uniform predicate)
+        }
+        if (!any) continue;                                      // wave-uniform
+#pragma unroll
+        for (int u = 0; u < NQ; u++) {
+            own.x = fmaf(dd[u], xi.x - xj[u].x, own.x); own.y = fmaf(dd[u], xi.y - xj[u].y, own.y);
+            own.z = fmaf(dd[u], xi.z - xj[u].z, own.z); own.w = fmaf(dd[u], xi.w - xj[u].w, own.w);
+        }
+    }
+    reinterpret_cast<float4 *>(dxp_rows + i * h)[c4] = own;
+}
+
 // GCNII layer epilogue (reference model.py:36-44 / 69-77): out = theta * (support W) + (1 - theta) * r (+ input), with
 // r = (1 - alpha) * hi + alpha * h0 folded in (h0 == NULL: r = hi, the non-variant layer whose support IS r).  One pass
 // instead of five elementwise launches; the backward is three scaled copies of the cotangent.
@@ -1093,6 +1181,23 @@ int dgg_edge_bwd_wide_rows(const float *xp, int64_t N, int h, const int32_t *idx
     hipLaunchKernelGGL(edge_bwd_wide_rows_kernel, dim3((unsigned)N), dim3(WPB * 64), 0, (hipStream_t)stream, xp, N, h, idx, val, dval, K,
                        row0, t, perturb, dxp_rows, dd);
     return dgg_check_launch("edge_bwd_wide_rows");
+}
+
+// dgg_edge_bwd_wide_rows one 256-feature slice at a time (h a multiple of 256, xp rows 16-byte aligned); ws: dgg_edge_bwd_wide_rows_ws_floats
+// floats (the slices' shares of the squared distances)
+size_t dgg_edge_bwd_wide_rows_ws_floats(int64_t N, int K, int h) { return (size_t)(h / 256) * (size_t)N * (size_t)K; }
+int dgg_edge_bwd_wide_rows_sliced(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval, int K,
+                                  int64_t row0, float t, int perturb, float *ws, float *dxp_rows, float *dd, void *stream) {
+    if (h % 256 != 0 || K < 1 || K > 64 || ((uintptr_t)xp % 16) || ((uintptr_t)dxp_rows % 16))
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "edge_bwd_wide_rows_sliced: latent_dim a multiple of 256, K in [1,64], 16-byte aligned rows");
+    if (!ws || !dd || !dxp_rows) return dgg_set_error(DGG_ERR_ARG, "edge_bwd_wide_rows_sliced: workspace, dd and dxp_rows are required");
+    if (N == 0) return 0;
+    const int S = h / 256;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(edge_bwd_wide_d2_slice, dim3(rows_grid(N), (unsigned)S), dim3(WPB * 64), 0, st, xp, N, h, idx, dval, K, row0, ws);
+    hipLaunchKernelGGL(edge_bwd_wide_own_slice, dim3(rows_grid(N), (unsigned)S), dim3(WPB * 64), 0, st, xp, N, h, idx, val, dval, K, row0, t, perturb,
+                       ws, S, dxp_rows, dd);
+    return dgg_check_launch("edge_bwd_wide_rows_sliced");
 }
 
 int dgg_edge_bwd(const float *xp, int64_t N, int h, const int32_t *idx, const float *val, const float *dval, int K,

@@ -1191,6 +1191,7 @@ def _ones64(n, device):
 
 
 WIDE_EDGE_BWD_PART = __import__("os").environ.get("DGG_WIDE_EDGE_BWD_PART", "1") != "0"
+WIDE_EDGE_BWD_SLICED = __import__("os").environ.get("DGG_WIDE_EDGE_BWD_SLICED", "1") != "0"   # its row pass one 256-feature slice at a time
 
 
 def edge_bwd(xp, idx, val, dval, row0=0, t=T_DIST, perturb=False, part=None):
@@ -1211,8 +1212,13 @@ def edge_bwd(xp, idx, val, dval, row0=0, t=T_DIST, perturb=False, part=None):
         # transposed aggregation of xp with the coefficients through the destination-ordered partition
         own = torch.empty((N, h), device=xp.device, dtype=torch.float32)
         dd = torch.empty((N, K), device=xp.device, dtype=torch.float32)
-        _lib.check(_lib.lib().dgg_edge_bwd_wide_rows(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(dval)), K, row0, t, int(perturb),
-                                                     _ptr(own), _ptr(dd), _stream()), "edge_bwd_wide_rows")
+        if h % 256 == 0 and WIDE_EDGE_BWD_SLICED:               # one 256-feature slice of the gathered rows at a time (L2-resident)
+            ws = torch.empty((int(_lib.lib().dgg_edge_bwd_wide_rows_ws_floats(N, K, h)),), device=xp.device, dtype=torch.float32)
+            _lib.check(_lib.lib().dgg_edge_bwd_wide_rows_sliced(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(dval)), K, row0, t, int(perturb),
+                                                                _ptr(ws), _ptr(own), _ptr(dd), _stream()), "edge_bwd_wide_rows_sliced")
+        else:
+            _lib.check(_lib.lib().dgg_edge_bwd_wide_rows(_ptr(xp), N, h, _ptr(idx), _ptr(_chk(val)), _ptr(_chk(dval)), K, row0, t, int(perturb),
+                                                         _ptr(own), _ptr(dd), _stream()), "edge_bwd_wide_rows")
         _lib.check(_lib.lib().dgg_ell_spmm_t_part(_ptr(dd), _ptr(xp), N, K, h, _ptr(part), Ng, _ptr(dxp), _stream()), "ell_spmm_t_part")
         # column sums of the coefficients through the same partition (a 64-wide aggregation of ones: torch's index_add_ took 1.1 ms here)
         cs64 = _zeros((Ng, 64), xp.device)

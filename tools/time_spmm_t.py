@@ -53,3 +53,14 @@ t = timed(lambda: L.dgg_ell_sddmm_b16_sliced(p(idx), p(ahat), p(xb), p(dyb), n, 
 print("SDDMM, sliced + sum                   %.1f us  %.1f TB/s" % (t, gb / t * 1e3))
 t = timed(lambda: L.dgg_ell_spmm_t_part_b16(p(ahat), p(dyb), n, K, F, p(part), n, p(dX), st))
 print("transposed aggregation (spmm_t_cols)  %.1f us  %.1f TB/s" % (t, gb / t * 1e3))
+# the wide score backward's row pass (latent 2048, fp32 rows of 8 KB): whole rows against 256-feature slices
+xp = torch.randn(n, F, generator=g).to(dev) * 0.3
+val = torch.rand(n, K, generator=g).to(dev)
+dval = (torch.randn(n, K, generator=g) * (idx.cpu() >= 0)).to(dev)
+own, dd = torch.empty(n, F, device=dev), torch.empty(n, K, device=dev)
+ws2 = torch.empty(int(L.dgg_edge_bwd_wide_rows_ws_floats(n, K, F)), device=dev)
+gb2 = 2 * n * deg * F * 4 / 1e9
+t = timed(lambda: L.dgg_edge_bwd_wide_rows(p(xp), n, F, p(idx), p(val), p(dval), K, 0, C.c_float(1.0), 1, p(own), p(dd), st))
+print("wide score backward, row pass         %.1f us  %.1f TB/s" % (t, gb2 / t * 1e3))
+t = timed(lambda: L.dgg_edge_bwd_wide_rows_sliced(p(xp), n, F, p(idx), p(val), p(dval), K, 0, C.c_float(1.0), 1, p(ws2), p(own), p(dd), st))
+print("  the same by 256-feature slices      %.1f us  %.1f TB/s" % (t, gb2 / t * 1e3))
