@@ -258,6 +258,13 @@ __device__ __forceinline__ void row16_all_impl(int v, int (&out)[16], std::integ
     ((out[U] = __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xF, 0xF, false)), ...);
 }
 __device__ __forceinline__ void row16_all(int v, int (&out)[16]) { row16_all_impl(v, out, std::make_integer_sequence<int, 16>{}); }
+// the first N of them: out[U] = v of lane U of the caller's 16-lane row, U < N
+template <int N, int... U>
+__device__ __forceinline__ void row16_first_impl(int v, int (&out)[N], std::integer_sequence<int, U...>) {
+    ((out[U] = __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xF, 0xF, false)), ...);
+}
+template <int N>
+__device__ __forceinline__ void row16_first(int v, int (&out)[N]) { row16_first_impl<N>(v, out, std::make_integer_sequence<int, N>{}); }
 
 // lane ^ D exchange without the LDS crossbar: DPP quad_perm / row shifts / row_ror for D < 16,
 // v_permlane16_swap / v_permlane32_swap (gfx950) for D = 16 / 32.  ~1-3 VALU ops instead of a ds_bpermute round trip.

@@ -698,22 +698,30 @@ __device__ __forceinline__ void conv_bwd_walk(const float *__restrict__ G, int K
     // (wide: chunked rows -- a record's first word is chunk * 64 + entry and its second word the SOURCE NODE of the chunk, see pp_sort)
     constexpr int LPR = F / 4, NPI = 64 / LPR, NBT = 4, PER = NBT * NPI;          // PER records per iteration (<= 64)
     const int c4 = lane % LPR, slot = lane / LPR;
+    // ROWSHARE (groups of 16 lanes = DPP rows, F = 64): record q = b * NPI + slot of an iteration is LOADED by lane 16 slot + b, a lane
+    // of the group that works on it in batch b -- its fields then reach the group by DPP row_share (one vector instruction each) instead
+    // of ds_bpermute through the LDS crossbar, and the reduced dot product is already in the lane that stores it (203 -> 199 us at
+    // N = 100k; the same change in edge_bwd_walk measured nothing and was not kept)
+    constexpr bool ROWSHARE = LPR == 16;
     for (int e0 = pb; e0 < pe; e0 += PER) {
-        // lane l: record e0 + l (unconditional, clamped load; a lane past the range marks its copy invalid)
-        const bool have = lane < PER && e0 + lane < pe;
-        int4 myrec = recs[have ? e0 + lane : p1 - 1];
+        // lane l: record e0 + l (ROWSHARE: e0 + (l % 16) * NPI + l / 16; unconditional, clamped load; a lane past the range marks its copy invalid)
+        const int myq = ROWSHARE ? c4 * NPI + slot : lane;
+        const bool have = (ROWSHARE ? c4 < NBT : lane < PER) && e0 + myq < pe;
+        int4 myrec = recs[have ? e0 + myq : p1 - 1];
         if (!have) myrec.y = -1;
         int src[NBT];
         float cf[NBT];
         float4 g[NBT];
+        int bx[NBT], by[NBT], bz[NBT];
+        if constexpr (ROWSHARE) { dgg::row16_first<NBT>(myrec.x, bx); dgg::row16_first<NBT>(myrec.y, by); dgg::row16_first<NBT>(myrec.z, bz); }
 #pragma unroll
         for (int b = 0; b < NBT; b++) {
             const int q = b * NPI + slot;                        // record of this lane's group in batch b
-            src[b] = __shfl(myrec.x, q, 64);
-            const int dst = __shfl(myrec.y, q, 64);
+            src[b] = ROWSHARE ? bx[b] : __shfl(myrec.x, q, 64);
+            const int dst = ROWSHARE ? by[b] : __shfl(myrec.y, q, 64);
             // (every shuffle OUTSIDE the select: `c ? shfl : 0` would run the shuffle under a divergent mask, and a lane that is
             // masked off there hands 0 to the lanes that read from it)
-            const float wa = __int_as_float(__shfl(myrec.z, q, 64));
+            const float wa = __int_as_float(ROWSHARE ? bz[b] : __shfl(myrec.z, q, 64));
             cf[b] = dst >= 0 ? __fmul_rn(wa, aj) : 0.0f;
             if (dst < 0) src[b] = -1;
             g[b] = *reinterpret_cast<const float4 *>(G + (int64_t)(src[b] < 0 ? 0 : (wide ? dst : (src[b] >> 6))) * F + 4 * c4);   // unconditional
@@ -738,14 +746,18 @@ __device__ __forceinline__ void conv_bwd_walk(const float *__restrict__ G, int K
             //  kernel, and left in L2 they push out the G rows the gathers hit: 202 -> 193 us; nontemporal: 196)
             if (dA && src[b] >= 0 && c4 == 0)                    // (dA == NULL: the row kernel reads dA_rec through the slot -> record map)
                 __hip_atomic_store(&dA[(int64_t)(src[b] >> 6) * K + (src[b] & 63)], dot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // back to the lane that loaded the record (lane q = b*NPI + slot): record order, one coalesced store per iteration
-            const float tq = __shfl(dot, (lane % NPI) * LPR, 64);
-            if (lane / NPI == b) mydot = tq;
+            // back to the lane that loaded the record: record order, one store per iteration
+            if constexpr (ROWSHARE) {
+                if (c4 == b) mydot = dot;                        // (every lane of the group holds the reduced value)
+            } else {
+                const float tq = __shfl(dot, (lane % NPI) * LPR, 64);
+                if (lane / NPI == b) mydot = tq;
+            }
             acc.x = fmaf(cf[b], g[b].x, acc.x); acc.y = fmaf(cf[b], g[b].y, acc.y);
             acc.z = fmaf(cf[b], g[b].z, acc.z); acc.w = fmaf(cf[b], g[b].w, acc.w);
             sda = fmaf(dot, cf[b], sda);
         }
-        if (have) dA_rec[e0 + lane] = mydot;
+        if (have) dA_rec[e0 + myq] = mydot;
     }
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) {
