@@ -566,7 +566,10 @@ int dgg_ell_sddmm_b16(const int32_t *idx, const float *ahat, const void *Xb, con
 int dgg_ell_spmm_t_part_b16(const float *a, const void *dYb, int64_t rows, int K, int F, const void *part_ws, int64_t ncols, float *dX,
                             void *stream);
 /* dgg_ell_sddmm_b16 one 512-feature slice of the gathered rows at a time (F a multiple of 512; a slice of a PPI graph's activation
- * stays in an XCD's L2, whole rows do not); ws: dgg_ell_sddmm_b16_ws_floats(N, K, F) floats; accumulate: dA += instead of = */
+ * stays in an XCD's L2, whole rows do not); ws: dgg_ell_sddmm_b16_ws_floats(N, K, F) floats; accumulate: dA += instead of =.
+ * dA == NULL: the slices' sums stay in ws (overwritten, or added to what it holds: accumulate) and dgg_ell_sddmm_slices_sum adds the
+ * slices into dA after the last call of a series */
+int dgg_ell_sddmm_slices_sum(const float *ws, int64_t N, int K, int F, float *dA, int accumulate, void *stream);
 size_t dgg_ell_sddmm_b16_ws_floats(int64_t N, int K, int F);
 int dgg_ell_sddmm_b16_sliced(const int32_t *idx, const float *ahat, const void *Xb, const void *dYb, int64_t N, int K, int F, int skip_zero,
                              float *ws, float *dA, int accumulate, void *stream);

@@ -119,6 +119,7 @@ PROTOTYPES = {
     "dgg_ell_spmm_fwd_b16": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp],
     "dgg_ell_sddmm_b16": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp],
     "dgg_ell_sddmm_b16_ws_floats": [_i64, _i32, _i32],
+    "dgg_ell_sddmm_slices_sum": [_vp, _i64, _i32, _i32, _vp, _i32, _vp],
     "dgg_ell_sddmm_b16_sliced": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
     "dgg_ell_spmm_t_part_b16": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp],
     "dgg_gcnii_dsupport_bf16_b": [_vp, _vp, _i64, _i64, _vp, _f32, _f32, _vp, _vp, _vp, _i32, _vp],

@@ -206,7 +206,8 @@ __global__ __launch_bounds__(WPB * 64) void sddmm_wide_b16_kernel(const int32_t 
 // dot products go to part[slice][N*K] and sddmm_slices_sum adds the slices in slice order (deterministic, no float atomics).
 __global__ __launch_bounds__(WPB * 64) void sddmm_slice_b16_kernel(const int32_t *__restrict__ idx, const float *__restrict__ ahat,
                                                                   const uint4 *__restrict__ Xb, const uint4 *__restrict__ dYb,
-                                                                  int64_t N, int K, int F, int skip_zero, float *__restrict__ part) {
+                                                                  int64_t N, int K, int F, int skip_zero, float *__restrict__ part,
+                                                                  int accumulate) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * WPB + dgg::wave_id();
     if (i >= N) return;
@@ -241,7 +242,10 @@ __global__ __launch_bounds__(WPB * 64) void sddmm_slice_b16_kernel(const int32_t
             if (lane == r0 + u) mine = tot;
         }
     }
-    if (lane < K) part[(int64_t)blockIdx.y * N * K + i * K + lane] = mine;
+    if (lane < K) {                                              // (accumulate: this wavefront is the only writer of its (slice, row) words)
+        float *o = part + (int64_t)blockIdx.y * N * K + i * K + lane;
+        *o = accumulate ? *o + mine : mine;
+    }
 }
 // dA[e] (+)= sum over the slices, in slice order
 __global__ void sddmm_slices_sum(const float *__restrict__ part, int64_t n, int S, int accumulate, float *__restrict__ dA) {
@@ -983,19 +987,27 @@ int dgg_ell_sddmm_b16(const int32_t *idx, const float *ahat, const void *Xb, con
 }
 
 // dgg_ell_sddmm_b16 one 512-feature slice at a time (F a multiple of 512): dA (+)= <dY_i, X_j>; ws: dgg_ell_sddmm_b16_ws_floats(N, K, F)
-// floats of scratch (the slices' partial sums); accumulate: dA += (the stack sums dA over its layers) instead of =
+// floats of scratch (the slices' partial sums); accumulate: dA += (the stack sums dA over its layers) instead of =.
+// dA == NULL: the slice sums stay in ws -- overwritten, or ADDED to what ws holds (accumulate) -- and dgg_ell_sddmm_slices_sum adds the
+// slices once, after the last of a series of calls (the GCNII stack: nine layers, one sum).
 size_t dgg_ell_sddmm_b16_ws_floats(int64_t N, int K, int F) { return (size_t)(F / 512) * (size_t)N * (size_t)K; }
+int dgg_ell_sddmm_slices_sum(const float *ws, int64_t N, int K, int F, float *dA, int accumulate, void *stream) {
+    if (F % 512 != 0 || !ws || !dA) return dgg_set_error(DGG_ERR_ARG, "ell_sddmm_slices_sum: F a multiple of 512, workspace and dA required");
+    const int64_t n = N * K;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sddmm_slices_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, n, F / 512, accumulate, dA);
+    return dgg_check_launch("ell_sddmm_slices_sum");
+}
 int dgg_ell_sddmm_b16_sliced(const int32_t *idx, const float *ahat, const void *Xb, const void *dYb, int64_t N, int K, int F, int skip_zero,
                              float *ws, float *dA, int accumulate, void *stream) {
     if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
     if (F % 512 != 0 || ((uintptr_t)Xb % 16) || ((uintptr_t)dYb % 16)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ell_sddmm_b16_sliced: F must be a multiple of 512, rows 16-byte aligned");
-    if (!ws || !dA) return dgg_set_error(DGG_ERR_ARG, "ell_sddmm_b16_sliced: workspace and dA are required");
+    if (!ws) return dgg_set_error(DGG_ERR_ARG, "ell_sddmm_b16_sliced: the workspace is required");
     if (N == 0) return 0;
     const int S = F / 512;
     hipLaunchKernelGGL(sddmm_slice_b16_kernel, dim3(rows_grid(N), (unsigned)S), dim3(WPB * 64), 0, (hipStream_t)stream, idx, ahat,
-                       reinterpret_cast<const uint4 *>(Xb), reinterpret_cast<const uint4 *>(dYb), N, K, F, skip_zero, ws);
-    const int64_t n = N * K;
-    hipLaunchKernelGGL(sddmm_slices_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, n, S, accumulate, dA);
+                       reinterpret_cast<const uint4 *>(Xb), reinterpret_cast<const uint4 *>(dYb), N, K, F, skip_zero, ws, dA ? 0 : accumulate);
+    if (dA) return dgg_ell_sddmm_slices_sum(ws, N, K, F, dA, accumulate, stream);
     return dgg_check_launch("ell_sddmm_b16_sliced");
 }
 

@@ -1838,7 +1838,7 @@ class GcniiStackBf16Fn(torch.autograd.Function):
         b16 = ctx.xdbs is not None
         gx = _chk(g.contiguous())
         dh0 = torch.empty((n, F), device=dev, dtype=torch.float32)
-        dA = None
+        dA, sd_ws = None, None
         dWs = [None] * L
         pe = _probe_begin()
         for l in range(L, 0, -1):
@@ -1862,12 +1862,11 @@ class GcniiStackBf16Fn(torch.autograd.Function):
                            "gemm_nt_bf16_rows2")
                 dWs[l - 1] = dW
             gx = gnext if residual else torch.zeros_like(gout)              # + g through the residual; A^T d hi accumulates into it
-            if b16:                                                          # d A summed over the layers by the SDDMM's own reduction
-                if dA is None:
-                    dA = torch.empty((n, K), device=dev, dtype=torch.float32)
+            if b16:                                                          # d A: the slices' sums pile up over the layers, ONE slice reduction after the loop
+                if sd_ws is None:
                     sd_ws = torch.empty((int(_lib.lib().dgg_ell_sddmm_b16_ws_floats(n, K, F)),), device=dev, dtype=torch.float32)
                 _lib.check(_lib.lib().dgg_ell_sddmm_b16_sliced(_ptr(idx), _ptr(ahat), _ptr(ctx.xdbs[l - 1]), _ptr(dhib), n, K, F, int(skip_zero), _ptr(sd_ws),
-                                                               _ptr(dA), int(l != L), _stream()), "ell_sddmm_b16_sliced")
+                                                               None, int(l != L), _stream()), "ell_sddmm_b16_sliced")
                 _lib.check(_lib.lib().dgg_ell_spmm_t_part_b16(_ptr(ahat), _ptr(dhib), n, K, F, _ptr(part), n, _ptr(gx), _stream()), "ell_spmm_t_part_b16")
             else:
                 dA_l = torch.empty((n, K), device=dev, dtype=torch.float32)
@@ -1875,6 +1874,9 @@ class GcniiStackBf16Fn(torch.autograd.Function):
                                                        _stream()), "ell_spmm_bwd")
                 _lib.check(_lib.lib().dgg_ell_spmm_t_part(_ptr(ahat), _ptr(dhi), n, K, F, _ptr(part), n, _ptr(gx), _stream()), "ell_spmm_t_part")
                 dA = dA_l if dA is None else dA.add_(dA_l)
+        if sd_ws is not None:
+            dA = torch.empty((n, K), device=dev, dtype=torch.float32)
+            _lib.check(_lib.lib().dgg_ell_sddmm_slices_sum(_ptr(sd_ws), n, K, F, _ptr(dA), 0, _stream()), "ell_sddmm_slices_sum")
         if p > 0:
             dropout_hash(gx, p, s0, s1, accumulate_into=dh0)     # back through xd_0 = dropout(h0): the same mask
         else:

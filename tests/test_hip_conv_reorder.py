@@ -762,6 +762,11 @@ def test_sliced_sddmm_matches_the_whole_row_kernel(dev, n, deg, F):
     assert not bool(got[:, deg:].any()) and not bool(got[:, 0].any())
     _lib.check(L.dgg_ell_sddmm_b16_sliced(p(idx_d), p(a_d), p(xb), p(dyb), n, K, F, 1, p(ws), p(got), 1, st), "sddmm_sliced")
     assert float((got - 2 * ref).abs().max()) <= 2e-5 * scale
+    # a series of calls that leave their slice sums in the workspace (dA NULL), one reduction at the end
+    for acc in (0, 1, 1):
+        _lib.check(L.dgg_ell_sddmm_b16_sliced(p(idx_d), p(a_d), p(xb), p(dyb), n, K, F, 1, p(ws), None, acc, st), "sddmm_sliced")
+    _lib.check(L.dgg_ell_sddmm_slices_sum(p(ws), n, K, F, p(got), 0, st), "slices_sum")
+    assert float((got - 3 * ref).abs().max()) <= 3e-5 * scale
 
 
 @pytest.mark.gpu
