@@ -441,6 +441,41 @@ __global__ __launch_bounds__(256) void gcnii_gout_pack_kernel(const float *__res
     }
 }
 
+// gcnii_gout_pack_kernel on 64 x 64 tiles with 16-byte accesses (F and ldT multiples of 64, 16-byte aligned pointers), as pack_bf16_t64
+__global__ __launch_bounds__(256) void gcnii_gout_pack_t64(const float *__restrict__ gin, const float *__restrict__ xd, float scale, int n, int F,
+                                                           float *__restrict__ g, __bf16 *__restrict__ Gp, __bf16 *__restrict__ GT, int ldT,
+                                                           float *__restrict__ g2) {
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x, c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int rl = (tid >> 4) + 16 * i, cl = (tid & 15) * 4, r = r0 + rl, c = c0 + cl;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (r < n) {
+            const int64_t o = (int64_t)r * F + c;
+            const float4 gi = *reinterpret_cast<const float4 *>(gin + o), x = *reinterpret_cast<const float4 *>(xd + o);
+            v = make_float4(x.x != 0.0f ? gi.x * scale : 0.0f, x.y != 0.0f ? gi.y * scale : 0.0f, x.z != 0.0f ? gi.z * scale : 0.0f,
+                            x.w != 0.0f ? gi.w * scale : 0.0f);
+            *reinterpret_cast<float4 *>(g + o) = v;
+            if (g2) *reinterpret_cast<float4 *>(g2 + o) = v;
+            union { __bf16 h[4]; uint2 u; } b;
+            b.h[0] = (__bf16)v.x; b.h[1] = (__bf16)v.y; b.h[2] = (__bf16)v.z; b.h[3] = (__bf16)v.w;
+            *reinterpret_cast<uint2 *>(Gp + o) = b.u;
+        }
+        tile[rl][cl] = v.x; tile[rl][cl + 1] = v.y; tile[rl][cl + 2] = v.z; tile[rl][cl + 3] = v.w;
+    }
+    __syncthreads();
+    const int cT = c0 + (tid >> 2), rb = (tid & 3) * 16;          // GT row = feature; 16 consecutive nodes (zeros beyond n)
+    if (r0 + rb < ldT) {
+        union { __bf16 h[16]; uint4 u[2]; } o;
+#pragma unroll
+        for (int k = 0; k < 16; k++) o.h[k] = (__bf16)tile[rb + k][tid >> 2];
+        uint4 *d = reinterpret_cast<uint4 *>(GT + (int64_t)cT * ldT + r0 + rb);
+        d[0] = o.u[0];
+        d[1] = o.u[1];
+    }
+}
+
 int launch_gemm(const __bf16 *A, const __bf16 *B, int M, int N, int K, float scale, float *C, const GcniiEpi *ep, hipStream_t st,
                 int epi = -1, const __bf16 *A2 = nullptr, int ksplit = 0) {
     if (K % BK != 0 || K < BK) return dgg_set_error(DGG_ERR_UNSUPPORTED, "gemm_nt_bf16: the contraction length must be a multiple of 64 (pack with padding)");
@@ -557,6 +592,13 @@ int dgg_gcnii_gout_pack(const float *gin, const float *xd, float scale, int64_t 
                         float *g2, void *stream) {
     if (n <= 0 || F <= 0) return 0;
     if (ldT < n || ldT % 64 != 0 || F % 64 != 0) return dgg_set_error(DGG_ERR_ARG, "gcnii_gout_pack: F and ldT multiples of 64, ldT >= n");
+    const uintptr_t al = reinterpret_cast<uintptr_t>(gin) | reinterpret_cast<uintptr_t>(xd) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(g2) |
+                         reinterpret_cast<uintptr_t>(GT) | (reinterpret_cast<uintptr_t>(Gp) << 1);
+    if (al % 16 == 0 && !getenv("DGG_PACK_SLOW")) {
+        hipLaunchKernelGGL(gcnii_gout_pack_t64, dim3((unsigned)(F / 64), (unsigned)(ldT / 64)), dim3(256), 0, (hipStream_t)stream, gin, xd, scale, (int)n,
+                           (int)F, g, reinterpret_cast<__bf16 *>(Gp), reinterpret_cast<__bf16 *>(GT), (int)ldT, g2);
+        return dgg_check_launch("gcnii_gout_pack");
+    }
     const dim3 grid((unsigned)((F + 31) / 32), (unsigned)((ldT + 31) / 32));
     hipLaunchKernelGGL(gcnii_gout_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, gin, xd, scale, (int)n, (int)F, g,
                        reinterpret_cast<__bf16 *>(Gp), reinterpret_cast<__bf16 *>(GT), (int)ldT, g2);
