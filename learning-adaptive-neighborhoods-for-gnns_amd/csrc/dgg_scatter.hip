@@ -584,73 +584,6 @@ __global__ __launch_bounds__(256) void spmm_t_cols(const void *__restrict__ dYv,
     flush();
 }
 
-// spmm_t_cols<true> with 16-byte loads: 8 features per lane, grid.y = blocks of 128 features -- half the walks of the records per
-// byte gathered (tried again once the float atomics were gone: with them it had measured slower)
-__global__ __launch_bounds__(256) void spmm_t_cols_b16w(const uint4 *__restrict__ dYb, int F, const int *__restrict__ cstart, int nchunks,
-                                                        const int2 *__restrict__ recs, const float *__restrict__ a, int K,
-                                                        float *__restrict__ dX) {
-    constexpr int LPR = 16;
-    const int lane = threadIdx.x & 63, c4 = lane % LPR;
-    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
-    const int F8 = F / 8, c8 = blockIdx.y * 16 + c4;
-    if (gid >= nchunks) return;
-    const int cbeg = cstart[gid], cend = cstart[gid + 1];
-    if (cbeg >= cend) return;
-    const int nnz = cstart[nchunks];
-    const int first = recs[cbeg].y, last = recs[cend - 1].y;
-    const int shared_lo = (cbeg > 0 && recs[cbeg - 1].y == first) ? first : -1;
-    const int shared_hi = (cend < nnz && recs[cend].y == last) ? last : -1;
-    int cur = -1;
-    float acc[8];
-#pragma unroll
-    for (int v = 0; v < 8; v++) acc[v] = 0.0f;
-    auto flush = [&]() {
-        if (cur >= 0) {
-            float *o = dX + (int64_t)cur * F + 8 * c8;
-            if (cur == shared_lo || cur == shared_hi) {
-#pragma unroll
-                for (int v = 0; v < 8; v++) atomicAdd(o + v, acc[v]);
-            } else {
-                float4 v0 = reinterpret_cast<float4 *>(o)[0], v1 = reinterpret_cast<float4 *>(o)[1];
-                v0.x += acc[0]; v0.y += acc[1]; v0.z += acc[2]; v0.w += acc[3];
-                v1.x += acc[4]; v1.y += acc[5]; v1.z += acc[6]; v1.w += acc[7];
-                reinterpret_cast<float4 *>(o)[0] = v0;
-                reinterpret_cast<float4 *>(o)[1] = v1;
-            }
-        }
-    };
-    for (int eb = cbeg; eb < cend; eb += LPR) {
-        const int e = eb + c4;
-        const int2 myrec = e < cend ? recs[e] : make_int2(0, -1);
-        const float mycf = e < cend ? a[(int64_t)(myrec.x >> 6) * K + (myrec.x & 63)] : 0.0f;
-        int src[LPR], dst[LPR], cfb[LPR];
-        uint4 g[LPR];
-        dgg::row16_all(myrec.x, src);
-        dgg::row16_all(myrec.y, dst);
-        dgg::row16_all(__float_as_int(mycf), cfb);
-#pragma unroll
-        for (int u = 0; u < LPR; u++) g[u] = dYb[(int64_t)(src[u] >> 6) * F8 + c8];                       // unconditional
-#pragma unroll
-        for (int u = 0; u < LPR; u++) {
-            if (dst[u] < 0) continue;
-            if (dst[u] != cur) {
-                flush();
-                cur = dst[u];
-#pragma unroll
-                for (int v = 0; v < 8; v++) acc[v] = 0.0f;
-            }
-            const float cf = __int_as_float(cfb[u]);
-            const uint32_t w[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                acc[2 * v] = fmaf(cf, __uint_as_float(w[v] << 16), acc[2 * v]);
-                acc[2 * v + 1] = fmaf(cf, __uint_as_float(w[v] & 0xffff0000u), acc[2 * v + 1]);
-            }
-        }
-    }
-    flush();
-}
-
 // ---- graph-conv backward on PROJECTED features through the partition -------------------------------------------------------
 // Z = act(A H) with H = X W aggregated AFTER the projection ((A X) W = A (X W): reference model.py:594-598 aggregates the
 // d-wide X and projects afterwards; here the F-wide H, F = out_features <= d, is gathered instead -- half the bytes at
@@ -1693,13 +1626,8 @@ int dgg_ell_spmm_t_part_b16(const float *a, const void *dYb, int64_t rows, int K
     const int64_t nb = nbuckets(ncols);
     PartHdr p = part_layout(const_cast<void *>(part_ws), nb, rows * K);
     const int64_t ngroups = (rows * K + CH - 1) / CH;
-    static const int wide = [] { const char *e = getenv("DGG_SPMM_T_B16_WIDE"); return e ? atoi(e) : 1; }();
-    if (wide && F % 128 == 0 && (reinterpret_cast<uintptr_t>(dYb) % 16) == 0)
-        hipLaunchKernelGGL(spmm_t_cols_b16w, dim3((unsigned)((ngroups * 16 + 255) / 256), (unsigned)(F / 128)), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<const uint4 *>(dYb), F, p.cstart, (int)ngroups, p.recs, a, K, dX);
-    else
-        hipLaunchKernelGGL(spmm_t_cols<true>, dim3((unsigned)((ngroups * 16 + 255) / 256), (unsigned)(F / 64)), dim3(256), 0, (hipStream_t)stream, dYb,
-                           F, p.cstart, (int)ngroups, p.recs, a, K, dX);
+    hipLaunchKernelGGL(spmm_t_cols<true>, dim3((unsigned)((ngroups * 16 + 255) / 256), (unsigned)(F / 64)), dim3(256), 0, (hipStream_t)stream, dYb,
+                       F, p.cstart, (int)ngroups, p.recs, a, K, dX);
     return dgg_check_launch("ell_spmm_t_part_b16");
 }
 
