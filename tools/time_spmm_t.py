@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Times the three gather kernels of the fused GCNII stack on one PPI-size graph (diagnostic): python tools/time_spmm_t.py [n] [deg]"""
+"""Times the gather kernels of the fused GCNII stack on one PPI-size graph (diagnostic): python tools/time_spmm_t.py [n] [deg] [skew]
+   skew > 1 draws the neighbours as n * u^skew (hub columns, as the bench's PPI-shaped graphs have: kernels that walk destination-ordered
+   records behave differently there -- the default uniform graph flattered a variant that lost in the step)"""
 import ctypes as C
 import os
 import sys
@@ -14,7 +16,8 @@ deg = int(sys.argv[2]) if len(sys.argv) > 2 else 29
 F, K = 2048, 32
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(0)
-idx = torch.randint(0, n, (n, K), generator=g, dtype=torch.int32)
+skew = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+idx = (n * torch.rand(n, K, generator=g) ** skew).to(torch.int32).clamp_(0, n - 1)
 idx[:, deg:] = -1
 ahat = torch.rand(n, K, generator=g)
 ahat[:, deg:] = 0
