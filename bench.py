@@ -18,6 +18,7 @@ Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (dominant
 (symmetric / unperturbed / hash noise, latent 128, x-grad) and `cpu_baseline`.
 """
 import argparse
+import copy
 import json
 import os
 import sys
@@ -348,8 +349,11 @@ def allpairs_module_api(a, dev, N, steps, warmup, windows=5):
     x = torch.randn(N, d, generator=torch.Generator().manual_seed(1000)).to(dev)
     cand = dgg_amd.AllPairs((24 + 16 * torch.rand(N, generator=torch.Generator().manual_seed(7))).to(dev))
     params = list(dgg.parameters()) + list(conv.parameters())
+    # (a second set of modules for the captured measurement below: torch's whole-network capture recipe wants the parameters'
+    #  AccumulateGrad nodes created on a side stream, and the eager steps here create them on the default one)
+    dgg_c, conv_c = copy.deepcopy(dgg), copy.deepcopy(conv)
 
-    def step():
+    def step(dgg=dgg, conv=conv, params=params):
         for p_ in params:
             p_.grad = None
         Z, adj = dgg.forward_conv(x, cand, conv.W)
@@ -369,7 +373,34 @@ def allpairs_module_api(a, dev, N, steps, warmup, windows=5):
     dgg.check_ell_bound()
     T = float(np.median(tws))
     km = float(adj.k.mean().item())
-    return {"workload": f"synthetic all-pairs DGG N={N} d={d} h={h} k~{km:.1f} through DGG_LearnableK_debug.forward_conv (_FusedDGGConvFn: "
+    # the same autograd step captured ONCE into a hipGraph and replayed: warm-up on a side stream, then capture; the node takes the
+    # last eager forward's chunk layout as a fixed capacity (device-side flags say if a replay outgrew it: check_ell_bound)
+    params_c = list(dgg_c.parameters()) + list(conv_c.parameters())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step(dgg_c, conv_c, params_c)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        step(dgg_c, conv_c, params_c)
+    for _ in range(warmup):
+        gr.replay()
+    cws = []
+    for _ in range(windows):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gr.replay()
+        torch.cuda.synchronize()
+        cws.append((time.perf_counter() - t0) / steps)
+    dgg_c.check_ell_bound()
+    captured = {"ms_per_step": float(np.median(cws)) * 1e3, "windows_ms": [w_ * 1e3 for w_ in cws],
+                "note": "the whole autograd step (forward_conv, loss, backward, fresh gradients) as one replayed hipGraph"}
+    return {"captured_hipgraph": captured,
+            "workload": f"synthetic all-pairs DGG N={N} d={d} h={h} k~{km:.1f} through DGG_LearnableK_debug.forward_conv (_FusedDGGConvFn: "
                         "generator + normalize_adj + GCNConv as one autograd node) under torch autograd, eager launches, one readback of "
                         "the chunk layout per forward (rows wider than the list would be chunked)",
             "ms_per_step": T * 1e3, "windows_ms": [w_ * 1e3 for w_ in tws], "steps": steps, "value": N * km / T, "unit": "edges/s", "dtype": "f32"}
