@@ -197,6 +197,8 @@ def run_edgelist(a, dev):
 
     fused = getattr(a, "edgelist_api", "fused") == "fused" and a.edge_mode in ("u-v-dist", "u-v-deg", "u-v-A_uv", "u-v-deg-dist", "edge_conv", "A_uv")
 
+    cot = torch.ones((N, 64), device=dev)                         # the cotangent is an INPUT of the backward: resident, as in the headline step
+
     def step():
         for p_ in params:
             p_.grad = None
@@ -204,12 +206,12 @@ def run_edgelist(a, dev):
             got = dgg.forward_conv(x, A, conv.W)
             assert got is not None, "this configuration is outside the fused layer: use --edgelist-api modules"
             out, adj = got
-            out.sum().backward()
+            out.backward(cot)
             return adj
         with _ops.step_zero_pool(dev, N, 64, 64, params):        # the step's zeroed accumulators from one filled buffer
             adj = dgg(x, A)
             out = conv(x, adj.normalize())
-            out.sum().backward()
+            out.backward(cot)
         return adj
 
     # a few dozen launches of a few microseconds each: launch latency dominates at this size, so the whole autograd step (forward,
@@ -280,7 +282,7 @@ def run_edgelist(a, dev):
            "config": {"workload": f"{shape.capitalize()}-shape edge-list DGG N={N} d={d} h={h} E={E} (incl. self loops) k~{kmean:.1f}, "
                                   f"{a.edge_mode}/x/k_times_edge_prob, Gumbel(0,0.3) hash noise, module API under autograd "
                                   + ("(DGG_LearnableK_debug.forward_conv: generator + normalize + GCNConv as one autograd node)" if fused
-                                     else "(DGG_LearnableK_debug + normalize + GCNConv)") + ", fwd+bwd",
+                                     else "(DGG_LearnableK_debug + normalize + GCNConv)") + ", fwd+bwd (out.backward(cotangent), the cotangent resident as in the headline step)",
                       "api": "fused layer" if fused else "separate modules", "gcn_dgg_model_ms_per_step": model_ms,
                       "nodes": N, "feat": d, "latent": h, "candidate_edges": E, "selected_edges": nsel,
                       "candidate_edges_per_s": E / T, "edge_mode": a.edge_mode, "hipgraph": graph is not None},
@@ -353,11 +355,13 @@ def allpairs_module_api(a, dev, N, steps, warmup, windows=5):
     #  AccumulateGrad nodes created on a side stream, and the eager steps here create them on the default one)
     dgg_c, conv_c = copy.deepcopy(dgg), copy.deepcopy(conv)
 
+    cot = torch.ones((N, 64), device=dev)                         # the cotangent is an INPUT of the backward: resident, as in the headline step
+
     def step(dgg=dgg, conv=conv, params=params):
         for p_ in params:
             p_.grad = None
         Z, adj = dgg.forward_conv(x, cand, conv.W)
-        Z.sum().backward()
+        Z.backward(cot)
         return adj
 
     for _ in range(warmup):
@@ -402,7 +406,7 @@ def allpairs_module_api(a, dev, N, steps, warmup, windows=5):
     return {"captured_hipgraph": captured,
             "workload": f"synthetic all-pairs DGG N={N} d={d} h={h} k~{km:.1f} through DGG_LearnableK_debug.forward_conv (_FusedDGGConvFn: "
                         "generator + normalize_adj + GCNConv as one autograd node) under torch autograd, eager launches, one readback of "
-                        "the chunk layout per forward (rows wider than the list would be chunked)",
+                        "the chunk layout per forward (rows wider than the list would be chunked); Z.backward(cotangent), the cotangent resident",
             "ms_per_step": T * 1e3, "windows_ms": [w_ * 1e3 for w_ in tws], "steps": steps, "value": N * km / T, "unit": "edges/s", "dtype": "f32"}
 
 
