@@ -255,6 +255,15 @@ int dgg_edge_mlp_bwd(const float *AB, int64_t N, int hw, const int64_t *rowptr, 
                      const float *val, const float *dval, int K, const float *deg, const float *ex, const float *wdu,
                      const float *wdv, const float *wex, const float *b1, const float *w2, const float *b2, int act,
                      int perturb, float *dAB, float *dpar, float *dex, void *stream);
+/* the same for an ELL block whose payload partition (dgg_partp_build of (idx, w), with its entry -> record map: dgg_partp_has_map(N))
+ * is at hand: the neighbour-side sums d B_j WITHOUT float atomics -- every selected entry's term is stored as a row of dz_rec in
+ * record order (the records of a destination node are consecutive) and a second kernel adds each node's rows.  w [N,K]: the weights
+ * the partition was built from; dz_rec: dz_rows * hw floats of scratch, dz_rows >= the number of records (the number of candidate
+ * edges bounds it); hw a multiple of 4. */
+int dgg_edge_mlp_bwd_partp(const float *AB, int64_t N, int hw, const int32_t *idx, const int32_t *eid, const float *val, const float *dval,
+                           const float *w, int K, const float *deg, const float *ex, const float *wdu, const float *wdv, const float *wex,
+                           const float *b1, const float *w2, const float *b2, int act, int perturb, const void *partp_ws, int64_t ncols,
+                           float *dz_rec, int64_t dz_rows, float *dAB, float *dpar, float *dex, void *stream);
 
 /* ---- CSR-valued adjacency (variable row length) + the `DGG` class "for ICLR" (dgm.py:1730-1815) ---------------------
  * `DGG.forward` keeps every candidate edge (weight rank * (ramp + 1), dgm.py:1804-1807), so its output has the sparsity

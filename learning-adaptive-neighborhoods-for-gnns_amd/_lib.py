@@ -55,6 +55,7 @@ PROTOTYPES = {
     "dgg_edge_mlp_fwd": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "dgg_edgelist_topk_p": [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
     "dgg_edge_mlp_bwd": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
+    "dgg_edge_mlp_bwd_partp": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
     "dgg_csr_softk_fwd": [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
     "dgg_csr_softk_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
     "dgg_csr_rank_ramp_fwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -44,4 +44,7 @@ const int *dgg_part_slotmap(const void *part_ws, int64_t rows, int K, int64_t nc
 int dgg_norm_da_cols_impl(const void *part_ws, int64_t rows, int K, int64_t ncols, const float *coef_ws, float *da,
                           hipStream_t st);
 extern "C" size_t dgg_part_ws_bytes(int64_t rows, int K, int64_t ncols);
+// payload partition (dgg_scatter.hip): nodeptr [ncols + 1] and the entry -> record map recpos [rows * 64] inside a built workspace
+// (0 on success; recpos is there only when dgg_partp_has_map(rows))
+int dgg_partp_internal_ptrs(const void *partp_ws, int64_t rows, int K, int64_t ncols, const int **nodeptr, const int **recpos);
 int dgg_klimit_truncate_impl(const float *klim, int64_t rows, int K, int32_t *idx, float *val, hipStream_t st);

@@ -102,6 +102,35 @@ __global__ __launch_bounds__(256) void edgelist_topk_p_kernel(
     }
 }
 
+__device__ __forceinline__ bool ellrow_ok(const int64_t *rowptr, int K) { return rowptr == nullptr && K <= 64; }
+
+// d B_j += sum of the rows of dz_rec that belong to node j's records (consecutive: nodeptr); hw / 4 lanes per node, 16-byte loads
+__global__ __launch_bounds__(256) void edge_mlp_colsum(const int *__restrict__ nodeptr, int64_t ncols, const float *__restrict__ dz_rec,
+                                                       int64_t dz_rows, int hw, float *__restrict__ dAB) {
+    const int LPE = hw / 4;
+    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPE;
+    const int c = threadIdx.x % LPE;
+    if (g >= ncols) return;
+    const int p0 = nodeptr[g];
+    int p1 = nodeptr[g + 1];
+    if (p1 > dz_rows) p1 = (int)dz_rows;                         // (records beyond the buffer went the atomic way)
+    if (p0 >= p1) return;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    constexpr int UQ = 8;                                        // rows in flight (a hub's few hundred rows are walked by one lane group)
+    for (int pb = p0; pb < p1; pb += UQ) {
+        float4 v[UQ];
+#pragma unroll
+        for (int u = 0; u < UQ; u++) v[u] = reinterpret_cast<const float4 *>(dz_rec + (int64_t)(pb + u < p1 ? pb + u : p1 - 1) * hw)[c];
+#pragma unroll
+        for (int u = 0; u < UQ; u++)
+            if (pb + u < p1) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    float4 *o = reinterpret_cast<float4 *>(dAB + g * 2 * hw + hw) + c;
+    float4 t = *o;
+    t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
+    *o = t;
+}
+
 // ---- backward: one wavefront per row, LPE = hw/VEC lanes per selected entry -------------------------------------------
 // dA_i: registers -> plain store; dB_j: float atomics (256-B rows at hw = 64); parameter gradients: registers across the
 // rows of a persistent workgroup -> LDS -> one atomic per workgroup and element.
@@ -113,7 +142,13 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
     const float *__restrict__ ex, const float *__restrict__ wdu, const float *__restrict__ wdv,
     const float *__restrict__ wex, const float *__restrict__ b1, const float *__restrict__ w2,
     const float *__restrict__ b2, int act, int perturb, float *__restrict__ dAB, float *__restrict__ dpar,
-    float *__restrict__ dex) {
+    float *__restrict__ dex, const float *__restrict__ wrow = nullptr, const int *__restrict__ recpos = nullptr,
+    float *__restrict__ dz_rec = nullptr, int64_t dz_rows = 0) {
+    // dz_rec (VEC 4, ELL rows; dgg_edge_mlp_bwd_partp): the neighbour-side term d z of every selected entry goes, as ONE 16-byte store
+    // per lane, to row recpos[entry] of dz_rec -- the entry's place among the destination-ordered records of the payload partition,
+    // where the records of a node are consecutive -- and edge_mlp_colsum adds each node's rows; without it: hw float atomics per entry
+    // onto dAB (6.9 M at the Pubmed shape: most of the kernel's time).  wrow: the weights the partition was built from (an entry has a
+    // record iff idx >= 0 and w != 0); an entry with a record but no cotangent gets a zero row.
     extern __shared__ float red[];                               // [4 waves][5*hw + 1]
     const int LPE = hw / VEC, EPI = 64 / LPE;
     const int lane = threadIdx.x & 63, wave = dgg::wave_id(), c = lane % LPE, slot = lane / LPE;
@@ -139,11 +174,23 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
         const bool ellrow = !rowptr && K <= 64;
         int32_t jrow = -1;
         float grow = 0.0f;
+        const bool recs_on = VEC == 4 && dz_rec != nullptr && ellrow_ok(rowptr, K);
         if (ellrow) {
             if (lane < K) { jrow = idx[base + lane]; grow = dval[base + lane]; }
             const uint64_t am = __ballot(jrow >= 0 && grow != 0.0f);
             if (dex && lane < K) dex[base + lane] = 0.0f;           // (the visited batches overwrite their entries below)
             cnt = am ? 64 - __builtin_clzll(am) : 0;
+            if (recs_on) {                                           // recorded entries without a cotangent: zero rows (rare)
+                const float wl = lane < K ? wrow[base + lane] : 0.0f;
+                uint64_t zm = __ballot(jrow >= 0 && wl != 0.0f && grow == 0.0f);
+                while (zm != 0ull) {                                 // wave-uniform
+                    const int r = __builtin_ctzll(zm);
+                    zm &= zm - 1;
+                    const int rp = recpos[i * 64 + r];
+                    if (rp >= 0 && rp < dz_rows && lane < hw / 4)
+                        reinterpret_cast<float4 *>(dz_rec + (int64_t)rp * hw)[lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
         }
         for (int r0 = 0; r0 < cnt; r0 += EPI) {
             const int r = r0 + slot;
@@ -189,16 +236,32 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
                 ds = dp * p * (1.0f - p);
             }
             float de = 0.0f;
+            float dzv[VEC];
 #pragma unroll
             for (int q = 0; q < VEC; q++) {
                 const float dh = ds * w2_r[q];
                 const float dz = act == 1 ? (z[q] > 0.0f ? dh : 0.01f * dh) : dh;
+                dzv[q] = dz;
                 dA[q] += dz;
                 g_wdu[q] = fmaf(dz, du, g_wdu[q]); g_wdv[q] = fmaf(dz, dv, g_wdv[q]); g_wex[q] = fmaf(dz, exv, g_wex[q]);
                 g_b1[q] += dz;
                 g_w2[q] = fmaf(ds, hid[q], g_w2[q]);
                 de = fmaf(dz, wex_r[q], de);
-                if (actv && dz != 0.0f) atomicAdd(dAB + (int64_t)j * 2 * hw + hw + o0 + q, dz);
+            }
+            bool stored = false;
+            if constexpr (VEC == 4) {
+                if (recs_on && actv) {                               // (an active entry has w != 0: it has a record)
+                    const int rp = recpos[i * 64 + r];
+                    if (rp >= 0 && rp < dz_rows) {
+                        *reinterpret_cast<float4 *>(dz_rec + (int64_t)rp * hw + o0) = make_float4(dzv[0], dzv[1], dzv[2], dzv[3]);
+                        stored = true;
+                    }
+                }
+            }
+            if (actv && !stored) {
+#pragma unroll
+                for (int q = 0; q < VEC; q++)
+                    if (dzv[q] != 0.0f) atomicAdd(dAB + (int64_t)j * 2 * hw + hw + o0 + q, dzv[q]);
             }
             if (c == 0) g_b2 += ds;
             if (dex) {
@@ -300,6 +363,34 @@ int dgg_edge_mlp_bwd(const float *AB, int64_t N, int hw, const int64_t *rowptr, 
         hipLaunchKernelGGL(edge_mlp_bwd_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, AB, N, hw, rowptr, idx, eid, val, dval, K,
                            deg, ex, wdu, wdv, wex, b1, w2, b2, act, perturb, dAB, dpar, dex);
     return dgg_check_launch("edge_mlp_bwd");
+}
+
+// dgg_edge_mlp_bwd for an ELL block whose PAYLOAD PARTITION is at hand (dgg_partp_build of (idx, w) with the entry -> record map:
+// dgg_partp_has_map(N)): the neighbour-side sums d B_j without float atomics -- the row kernel stores every selected entry's d z as a
+// row of dz_rec in record order, edge_mlp_colsum adds each destination node's (consecutive) rows.  w [N,K]: the weights the partition
+// was built from; dz_rec: dz_rows * hw floats of scratch, dz_rows >= the number of records (e.g. the number of candidate edges).
+// hw a multiple of 4 (power-of-two lane groups), K <= 64; otherwise as dgg_edge_mlp_bwd.
+int dgg_edge_mlp_bwd_partp(const float *AB, int64_t N, int hw, const int32_t *idx, const int32_t *eid, const float *val, const float *dval,
+                           const float *w, int K, const float *deg, const float *ex, const float *wdu, const float *wdv, const float *wex,
+                           const float *b1, const float *w2, const float *b2, int act, int perturb, const void *partp_ws, int64_t ncols,
+                           float *dz_rec, int64_t dz_rows, float *dAB, float *dpar, float *dex, void *stream) {
+    if (K < 1 || K > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ELL width K must be in [1,64]");
+    const int lpe = hw / 4;
+    if (hw % 4 != 0 || !pow2(lpe) || lpe > 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "edge_mlp_bwd_partp: hidden width must be 4 x a power of two (<= 256)");
+    if ((ex && (!wex || !eid)) || (deg && (!wdu || !wdv)) || !w || !dz_rec || dz_rows <= 0)
+        return dgg_set_error(DGG_ERR_ARG, "edge_mlp_bwd_partp: missing extras / weights / scratch");
+    const int *nodeptr = nullptr, *recpos = nullptr;
+    if (dgg_partp_internal_ptrs(partp_ws, N, K, ncols, &nodeptr, &recpos) != 0)
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "edge_mlp_bwd_partp: no payload partition with an entry -> record map for this block");
+    if (N == 0) return 0;
+    static const int64_t gmax = getenv("DGG_EMLP_GRID") ? atoll(getenv("DGG_EMLP_GRID")) : 1024;
+    const unsigned grid = (unsigned)((N + 3) / 4 < gmax ? (N + 3) / 4 : gmax);
+    const size_t lds = (size_t)4 * (5 * hw + 1) * sizeof(float);
+    hipLaunchKernelGGL(edge_mlp_bwd_kernel<4>, dim3(grid), dim3(256), lds, (hipStream_t)stream, AB, N, hw, (const int64_t *)nullptr, idx, eid, val, dval,
+                       K, deg, ex, wdu, wdv, wex, b1, w2, b2, act, perturb, dAB, dpar, dex, w, recpos, dz_rec, dz_rows);
+    hipLaunchKernelGGL(edge_mlp_colsum, dim3((unsigned)((ncols * lpe + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nodeptr, ncols, dz_rec, dz_rows,
+                       hw, dAB);
+    return dgg_check_launch("edge_mlp_bwd_partp");
 }
 
 }  // extern "C"

@@ -1727,6 +1727,16 @@ int dgg_partp_build_phase(const int32_t *idx, const float *w, const float *val, 
 // may be called with dA = NULL)
 int dgg_partp_has_map(int64_t rows) { return pp_builds_map(rows) ? 1 : 0; }
 
+}  // extern "C"
+int dgg_partp_internal_ptrs(const void *partp_ws, int64_t rows, int K, int64_t ncols, const int **nodeptr, const int **recpos) {
+    if (!partp_ws || dgg_partp_ws_bytes(rows, K, ncols) == 0 || !pp_builds_map(rows)) return 1;
+    PartP2 p;
+    partp2_layout(p, const_cast<void *>(partp_ws), rows, K, ncols);
+    *nodeptr = p.nodeptr;
+    *recpos = p.recpos;
+    return 0;
+}
+extern "C" {
 int dgg_partp_describe(int64_t rows, int K, int64_t ncols, int64_t *out6) {
     if (!out6 || dgg_partp_ws_bytes(rows, K, ncols) == 0) return dgg_set_error(DGG_ERR_UNSUPPORTED, "partp_describe: no payload partition for this shape");
     PartP2 p;

@@ -594,9 +594,11 @@ def edgelist_topk_p(p_edge, N, rowptr, col, K=DEFAULT_K, noise_mode=NOISE_NONE, 
 
 
 def edge_mlp_bwd(AB, idx, eid, val, dval, deg, ex, wdu, wdv, wex, b1, w2, b2, act=ACT_LEAKY, perturb=False, need_dex=False,
-                 rowptr=None):
+                 rowptr=None, partp=None, w=None, nrec_max=0):
     """-> dAB [N,2hw], dpar [5hw+1] = [dwdu|dwdv|dwex|db1|dw2|db2], dex (shape of dval) or None.
-    ELL adjacency: idx/eid/val/dval [N,K]; CSR-valued adjacency: rowptr given, idx = col [E], val/dval [E], eid None."""
+    ELL adjacency: idx/eid/val/dval [N,K]; CSR-valued adjacency: rowptr given, idx = col [E], val/dval [E], eid None.
+    partp (+ w, the weights it was built from, and nrec_max >= its number of records, e.g. the number of candidate edges): the
+    neighbour-side sums without float atomics (dgg_edge_mlp_bwd_partp)"""
     AB = _chk(AB)
     N = AB.shape[0]
     K = idx.shape[1] if rowptr is None else 0
@@ -605,6 +607,14 @@ def edge_mlp_bwd(AB, idx, eid, val, dval, deg, ex, wdu, wdv, wex, b1, w2, b2, ac
     dAB, dpar = zz[:N * 2 * hw].view(N, 2 * hw), zz[N * 2 * hw:]
     dex = torch.empty(tuple(dval.shape), device=AB.device, dtype=torch.float32) if need_dex else None
     o = lambda t_: None if t_ is None else _chk(t_)  # noqa: E731
+    if (EMLP_BWD_PARTP and partp is not None and w is not None and nrec_max > 0 and rowptr is None and hw % 4 == 0 and partp.layout is None
+            and partp.rows == N and partp_has_map(N)):
+        dz = torch.empty((int(nrec_max) * hw,), device=AB.device, dtype=torch.float32)
+        _lib.check(_lib.lib().dgg_edge_mlp_bwd_partp(_ptr(AB), N, hw, _ptr(idx), _ptr(eid), _ptr(_chk(val)), _ptr(_chk(dval)), _ptr(_chk(w)), K,
+                                                     _ptr(o(deg)), _ptr(o(ex)), _ptr(o(wdu)), _ptr(o(wdv)), _ptr(o(wex)), _ptr(_chk(b1)),
+                                                     _ptr(_chk(w2)), _ptr(_chk(b2)), act, int(perturb), _ptr(partp.ws), partp.ncols, _ptr(dz),
+                                                     int(nrec_max), _ptr(dAB), _ptr(dpar), _ptr(dex), _stream()), "edge_mlp_bwd_partp")
+        return dAB, dpar, dex
     _lib.check(_lib.lib().dgg_edge_mlp_bwd(_ptr(AB), N, hw, _ptr(rowptr), _ptr(idx), _ptr(eid), _ptr(_chk(val)), _ptr(_chk(dval)), K, _ptr(o(deg)),
                                            _ptr(o(ex)), _ptr(o(wdu)), _ptr(o(wdv)), _ptr(o(wex)), _ptr(_chk(b1)), _ptr(_chk(w2)),
                                            _ptr(_chk(b2)), act, int(perturb), _ptr(dAB), _ptr(dpar), _ptr(dex), _stream()),
@@ -1191,6 +1201,7 @@ def _ones64(n, device):
 
 
 WIDE_EDGE_BWD_PART = __import__("os").environ.get("DGG_WIDE_EDGE_BWD_PART", "1") != "0"
+EMLP_BWD_PARTP = __import__("os").environ.get("DGG_EMLP_BWD_PARTP", "1") != "0"   # edge-MLP backward: neighbour sums through the payload partition
 WIDE_EDGE_BWD_SLICED = __import__("os").environ.get("DGG_WIDE_EDGE_BWD_SLICED", "1") != "0"   # its row pass one 256-feature slice at a time
 
 

@@ -477,8 +477,11 @@ class ShardedDGGConv:
             dval, dk = kern.softk_bwd(s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.mode, True, ahat_rows=s["ahat"])
         else:
             dval, dk = kern.softk_bwd(s["idx"], s["val"], s["k"], dA, s["rs"], da, self.r0, self.mode, True)
+        kw = {}
+        if s.get("partp") is not None and self.cand is not None and getattr(kern, "EMLP_BWD_PARTP", False):
+            kw = dict(partp=s["partp"], w=s["w"], nrec_max=int(self.cand[1].numel()))       # (a selected entry is a candidate edge)
         dAB, dpar, dex = kern.edge_mlp_bwd(s["AB"], s["idx"], s["eid"], s["val"], dval, s["sdeg"], s["ex"], sc["wdu"], sc["wdv"], sc["wex"],
-                                           sc["b1"], sc["w2"], sc["b2"], sc["act"], self.noise_mode != 0, need_dex=sc["ex_mode"] == 2)
+                                           sc["b1"], sc["w2"], sc["b2"], sc["act"], self.noise_mode != 0, need_dex=sc["ex_mode"] == 2, **kw)
         dxp, dWcat, _ = kern.linear_bwd(s["xp"], sc["Wcat"], s["AB"], dAB, 0, 0, True, False)
         if sc["ex_mode"] == 2:                              # exp(t ||xp_u - xp_v||) as an edge feature also depends on the projection
             dxp = dxp + kern.edge_bwd(s["xp"], s["idx"], s["val"], dex, self.r0, sc["t_ex"], False)

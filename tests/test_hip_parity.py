@@ -1029,7 +1029,9 @@ def test_edge_mlp_kernels(dev, hw, use_deg, ex_mode, act, noise):
     from dgg_amd import ops
     rng = np.random.default_rng(21)
     N, h = 900, 32
-    rows, cols = np.nonzero(rng.random((N, N)) < 0.06)
+    dens_ = rng.random((N, N)) < 0.06
+    dens_[:, 3] = True                                        # a hub column: a candidate of every row
+    rows, cols = np.nonzero(dens_)
     rows, cols = rows.astype(np.int32), cols.astype(np.int32)
     rowptr, col = csr_from_coo(rows, cols, N)
     E = col.shape[0]
@@ -1071,6 +1073,19 @@ def test_edge_mlp_kernels(dev, hw, use_deg, ex_mode, act, noise):
         ref = rdpar[b_ * hw:(b_ + 1) * hw]
         np.testing.assert_allclose(Nn(dpar)[b_ * hw:(b_ + 1) * hw], ref, rtol=5e-4, atol=5e-4 * max(np.abs(ref).max(), 1e-30))
     np.testing.assert_allclose(Nn(dpar)[5 * hw], rdpar[5 * hw], rtol=5e-4, atol=1e-5)
+    if hw % 4 == 0 and ops.partp_has_map(N):
+        # the same through the payload partition (no float atomics for the neighbour-side sums): the weights the partition is built
+        # from leave some selected entries WITHOUT a record (w = 0) and some recorded entries without a cotangent (zero rows), and
+        # column 3 is a hub (every row selects it: a run of N records summed by one lane group)
+        w = ((rng.random((N, K)) < 0.8) * (ridx >= 0)).astype(np.float32)
+        dval2 = (dval * (w != 0) * (rng.random((N, K)) < 0.9)).astype(np.float32)
+        partp = ops.partp_build(idx, T(w, dev), val, T(np.ones(N, np.float32), dev), N)
+        a_ = ops.edge_mlp_bwd(T(AB, dev), idx, eid, val, T(dval2, dev), o(deg), ex, o(wdu), o(wdv), o(wex), T(b1, dev), T(w2, dev), T(b2, dev), act,
+                              noise != "none", need_dex=True, partp=partp, w=T(w, dev), nrec_max=int((w != 0).sum()))
+        b_ = ops.edge_mlp_bwd(T(AB, dev), idx, eid, val, T(dval2, dev), o(deg), ex, o(wdu), o(wdv), o(wex), T(b1, dev), T(w2, dev), T(b2, dev), act,
+                              noise != "none", need_dex=True)
+        for got, ref in zip(a_, b_):
+            np.testing.assert_allclose(Nn(got), Nn(ref), rtol=2e-4, atol=2e-5 * max(float(ref.abs().max()), 1e-30))
 
 
 # ---------------------------------------------------------------------------------------------------------------
