@@ -13,15 +13,16 @@
 //     forward     A = support       [n, K]        B = weight^T [out, K]
 //     d support   A = g             [n, out]      B = weight   [K, out]   (as stored)
 //     d weight    A = support^T     [K, n_pad]    B = g^T      [out, n_pad]
-// Tile: 256 threads = 4 wavefronts compute 128 x 128, each wavefront 64 x 64 (2 x 2 MFMA blocks of 32 x 32, four f32x16
-// accumulators); K in steps of 64.  Two main loops:
-//   RING (default)  the operands go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into a ring of
-//                   three stages, two K-steps in flight ahead of the one being multiplied: a K-step is 16 MFMAs per wavefront
+// Tile: 128 x 128 (or 64 x 128), K in steps of 64; 512 threads = 8 wavefronts of 64 x 32 in the ring loop (two per SIMD), 256 threads =
+// 4 wavefronts of 64 x 64 otherwise.  Two main loops:
+//   RING (default)  the operands go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into a ring of FOUR
+//                   stages, three K-steps in flight ahead of the one being multiplied: a K-step is 16 MFMAs per wavefront
 //                   (~0.3 us) and one workgroup per CU is all the 224-576 tiles of a PPI graph give, so a one-step-ahead
 //                   register prefetch paid a memory round trip per step (1.3 us per step on the forward product).  An LDS-DMA
 //                   instruction writes its wavefront's 64 x 16 B contiguously, so the stage is an UNPADDED [row][8 chunks] image
 //                   and the bank spread comes from an XOR swizzle applied to the SOURCE chunk and again on the read:
-//                   slot = chunk ^ ((row >> 1) & 7) -- conflict-free for the lane groups of ds_read_b128.
+//                   slot = chunk ^ ((row >> 1) & 7) -- conflict-free for the lane groups of ds_read_b128.  The fragment reads of
+//                   sub-step s + 1 are issued before the MFMAs of sub-step s; ONE barrier per K-step, placed mid-step.
 //   staged          double-buffered LDS image filled through registers (row stride 144 B), the next step's loads in flight
 //                   during the current step's MFMAs (DGG_BF16_RING=0).
 #include "dgg_common.h"
