@@ -14,8 +14,9 @@ W warm-up steps, then `--repeats` windows of exactly K steps, each bracketed by 
 One GPU: N = 100 000 (the BASELINE.json metric config).  Several GPUs (torchrun, one rank per GPU, RCCL): BASELINE.json
 configs[3], ONE graph of 500 000 nodes node-range sharded (strong scaling); --weak: 100 000 rows per GPU.
 
-Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (dominant kernel), `kernels`, `variants`
-(symmetric / unperturbed / hash noise, latent 128, x-grad) and `cpu_baseline`.
+Prints ONE JSON line (rank 0), at most LINE_LIMIT bytes: the driver's fields, `roofline` (dominant kernel), `cpu_baseline`, `repeats` and a
+compact `configs` map ({ms_per_step, value, frac} per secondary BASELINE config).  The full result -- `kernels`, `variants` (symmetric /
+unperturbed / hash noise, latent 128, x-grad), `data_regimes`, per-config detail -- goes to gpurun_out/bench_detail.json and to stderr.
 """
 import argparse
 import copy
@@ -403,7 +404,7 @@ def allpairs_module_api(a, dev, N, steps, warmup, windows=5):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr):
+    with torch.cuda.graph(gr, stream=side):                      # capture ON the stream the parameters' AccumulateGrad nodes were made on
         step(dgg_c, conv_c, params_c)
     for _ in range(warmup):
         gr.replay()
@@ -665,8 +666,73 @@ def isolate_stdout():
     os.dup2(2, 1)
 
 
+LINE_LIMIT = 6000         # bytes: the driver keeps only a tail of stdout; the result line must fit in it with room to spare
+DETAIL_PATH = os.path.join("gpurun_out", "bench_detail.json")
+_TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+_SUB = {"config": ("workload", "nodes", "feat", "latent", "parallelism", "rows_per_rank", "hipgraph", "noise", "api", "graphs", "selected_edges",
+                   "candidate_edges"),
+        "roofline": ("bound", "kernel", "rocprof_kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel_ms",
+                     "algorithmic_bytes", "algorithmic_flop"),
+        "cpu_baseline": ("value", "unit", "cores", "kind", "sample"),
+        "repeats": ("windows", "steps_per_window", "value_from", "window_ms_per_step_min_median_max", "eager_ms_per_step")}
+
+
+def _sig(v, digits=6):
+    """floats to `digits` significant figures, strings cut at 200 characters (recursively): the line is a summary"""
+    if isinstance(v, float):
+        return float(f"{v:.{digits}g}") if np.isfinite(v) else None
+    if isinstance(v, str):
+        return v if len(v) <= 200 else v[:197] + "..."
+    if isinstance(v, dict):
+        return {k_: _sig(x, digits) for k_, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_sig(x, digits) for x in v]
+    if isinstance(v, (np.floating, np.integer)):
+        return _sig(v.item(), digits)
+    return v
+
+
+def compact_result(obj):
+    """The driver's line: the contract's fields, `roofline`, `cpu_baseline`, `repeats` and ONE map of {ms_per_step, value, frac} per
+    secondary config.  Everything else (variants, data regimes, per-kernel tables, notes) lives in the detail file only."""
+    out = {k_: obj[k_] for k_ in _TOP if k_ in obj}
+    for name, keys in _SUB.items():
+        if isinstance(obj.get(name), dict):
+            out[name] = {k_: obj[name][k_] for k_ in keys if k_ in obj[name]}
+    if isinstance(obj.get("configs"), dict):
+        cfg = {}
+        for name, c_ in obj["configs"].items():
+            if not isinstance(c_, dict):
+                continue
+            if "error" in c_:
+                cfg[name] = {"error": str(c_["error"])[:120]}
+                continue
+            rf = c_.get("roofline") if isinstance(c_.get("roofline"), dict) else {}
+            cfg[name] = {"ms_per_step": c_.get("ms_per_step"), "value": c_.get("value"), "frac": rf.get("frac", c_.get("step_frac_hbm"))}
+        out["configs"] = cfg
+    out["detail"] = DETAIL_PATH
+    out = _sig(out)
+    line = json.dumps(out, separators=(",", ":"))
+    for drop in ("configs", "repeats"):                         # (never expected: a guard, so that the line ALWAYS parses)
+        if len(line) > LINE_LIMIT and drop in out:
+            out.pop(drop)
+            line = json.dumps(out, separators=(",", ":"))
+    assert len(line) <= LINE_LIMIT, f"result line of {len(line)} bytes"
+    return line
+
+
 def emit_json(obj):
-    line = (json.dumps(obj) + "\n").encode()
+    """Full result -> gpurun_out/bench_detail.json and stderr; compact summary (<= LINE_LIMIT bytes) -> the ONE stdout line, last."""
+    full = json.dumps(obj, default=lambda v: v.item() if hasattr(v, "item") else repr(v))
+    try:
+        os.makedirs(os.path.join(ROOT, os.path.dirname(DETAIL_PATH)), exist_ok=True)
+        with open(os.path.join(ROOT, DETAIL_PATH), "w") as f:
+            f.write(full + "\n")
+    except OSError as e:
+        print(f"bench detail file not written: {e!r}", file=sys.stderr)
+    sys.stderr.write("BENCH_DETAIL " + full + "\n")
+    sys.stderr.flush()
+    line = (compact_result(json.loads(full)) + "\n").encode()
     if _JSON_FD is None:
         sys.stdout.write(line.decode())
         sys.stdout.flush()

@@ -182,19 +182,35 @@ int dgg_allpairs_topk_ranked_softk_dseed(const float *xp, int64_t N, int h, int6
  * consecutive 64-entry CHUNKS [cptr[i], cptr[i+1]) of idx / val / w / ahat ([chunks, 64] arrays), L_i = ceil(k_i + 8.5) + 1; rank r of the
  * row is entry r % 64 of its chunk r / 64.  With every M_i = 1 the layout IS the [rows, 64] list of the calls above, and every chunk is
  * a row of that layout to the entry points that take `cnode` (node of every chunk) below.
- * dgg_chunk_layout: k [rows] -> cptr int32 [rows+1], cnode int32 [ccap], meta int32 [4 + 384] = {chunks in total, max M_i, flags, 0,
+ * dgg_chunk_layout: k [rows] -> cptr int32 [rows+1], cnode int32 [ccap], meta int32 [4 + 384] = {chunks NEEDED in total, max M_i, flags, 0,
  * scratch of the two-pass scan};
- * flags bit 0: a row needs more than 64 * maxm ranks (maxm <= 32; the row is cut there: callers must raise), bit 1: more than ccap
- * chunks (arrays too small: call again with a larger capacity). */
-int dgg_chunk_layout(const float *k, int64_t rows, int maxm, int64_t ccap, int32_t *cptr, int32_t *cnode, int32_t *meta, void *stream);
+ * flags bit 0: a row needs more than 64 * maxm ranks (the row is cut there: harmless when 64 * maxm covers every column of the graph,
+ * otherwise callers must raise; maxm <= 2^20), bit 2: a learned degree is NaN, bit 1: more than ccap chunks -- cptr is then CLAMPED to
+ * ccap (rows beyond it own no chunk, a row that straddles it is cut), so that no consumer of the layout leaves arrays of ccap chunks;
+ * call again with a larger capacity.  sticky (nullable, int32[1]): the flags are also ORed into it -- meta is rewritten by every call
+ * (every replay of a captured hipGraph), sticky keeps every overflow until the host clears it. */
+int dgg_chunk_layout(const float *k, int64_t rows, int maxm, int64_t ccap, int32_t *cptr, int32_t *cnode, int32_t *meta, int32_t *sticky,
+                     void *stream);
 /* dgg_allpairs_topk_ranked_softk[_dseed] on chunked rows: the ranked search settles L_i ranks of row i in up to `maxm` descending 64-lane
- * lists per wavefront (maxm >= max M_i); idx / val / w [chunks,64], rs [row1-row0] (lane-wise sums over the chunks, then the wavefront
+ * lists per wavefront (maxm >= max M_i; rows of more than 32 chunks are SKIPPED: dgg_allpairs_topk_anywide settles them); idx / val / w [chunks,64], rs [row1-row0] (lane-wise sums over the chunks, then the wavefront
  * butterfly).  ccap >= cptr[rows]: the chunks the arrays hold (a capacity fixed ahead of the learned degrees, e.g. inside a captured
  * hipGraph); chunks beyond the last one are written empty (idx -1, weight 0) and dgg_chunk_layout gives them node 0, so every consumer
  * may walk all ccap chunks.  seed_dev != NULL: the seed is read from device memory, s0 / s1 are ignored.  w (and rs) may be NULL. */
 int dgg_allpairs_topk_ranked_wide(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
                                   const uint32_t *seed_dev, const float *k, int mode, int maxm, const int32_t *cptr, int64_t ccap, int32_t *idx,
                                   float *val, float *w, float *rs, void *stream);
+/* Chunked rows of ANY width and every noise generator (dgg_topk_anywide.hip; reference dgm.py:1402-1421 on the dense row, 1580-1584 the
+ * unbounded learned degree, 1211-1231 perturb_edge_prob / symmetric_noise): row i keeps its L_i = ceil(k_i + 8.5) + 1 best columns by the
+ * perturbed score in the chunks [cptr[i], cptr[i+1]) of idx / val / w [ccap,64], rs [row1-row0], with the ramp and the row sums of
+ * dgg_allpairs_topk_ranked_wide (same bits as the oracle).  noise_mode 0 (unperturbed), 2 (per-pair hash), 3 (symmetric per-pair hash):
+ * every row of [row0,row1), min_m = 0, spare chunks of a fixed capacity written empty.  noise_mode 4 (ranked generator): only the rows of
+ * MORE than min_m chunks (call dgg_allpairs_topk_ranked_wide for the others: with maxm > 32 it leaves the rows beyond 32 chunks to this
+ * entry, min_m = 32).  Every row owns a threshold buffer of 128 keys per chunk in `workspace` (dgg_allpairs_anywide_ws_bytes(ccap, rows)
+ * bytes); a candidate is dropped only once L_i better ones of its row are known.  maxm >= max M_i (sizes the sort's LDS). */
+size_t dgg_allpairs_anywide_ws_bytes(int64_t ccap, int64_t rows);
+int dgg_allpairs_topk_anywide(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode, uint32_t s0, uint32_t s1,
+                              const uint32_t *seed_dev, const float *k, int mode, int maxm, int min_m, const int32_t *cptr, int64_t ccap,
+                              int32_t *idx, float *val, float *w, float *rs, void *workspace, size_t ws_bytes, void *stream);
 /* bytes of device workspace the pruned path needs for (N, h): a bf16 copy of xp plus discounted squared norms;
  * 0 when the pruned path does not apply (explicit noise, K != 64, latent_dim not in {16,32,64,128}) */
 size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K);

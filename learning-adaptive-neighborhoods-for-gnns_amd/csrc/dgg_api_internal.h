@@ -8,7 +8,8 @@
 #define DGG_ERR_UNSUPPORTED 2  // shape/mode outside what the kernels implement (reference: Exception("mode not found"), dgm.py:1727)
 #define DGG_ERR_HIP 3          // a HIP runtime call or kernel launch failed
 
-#define DGG_CHUNK_MAXM 32       // chunked rows: at most 32 chunks of 64 ranks per row (2048 ranks: learned degrees up to 2038)
+#define DGG_CHUNK_MAXM 32       // chunked rows, ranked search with register lists: at most 32 chunks of 64 ranks per row (2048 ranks)
+#define DGG_CHUNK_MAXM_ANY (1 << 20)   // chunked rows of ANY width (dgg_topk_anywide.hip: threshold buffers in memory): up to 2^26 ranks
 
 int dgg_set_error(int code, const char *msg);
 int dgg_check_launch(const char *what);

@@ -19,7 +19,7 @@ int dgg_check_launch(const char *what) { return dgg_check_hip(hipGetLastError(),
 extern "C" {
 
 const char *dgg_last_error(void) { return g_err; }
-int dgg_abi_version(void) { return 5; }
+int dgg_abi_version(void) { return 6; }
 
 // algo: 0 auto, 1 exhaustive (every pair scored with the canonical arithmetic), 2 MFMA-bounded pruning,
 //       3 noise-prefilter pruning (perturbed scores only).  All return identical bits.

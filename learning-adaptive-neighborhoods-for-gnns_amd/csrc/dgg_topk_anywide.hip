@@ -1,0 +1,638 @@
+// dgg_topk_anywide.hip -- all-pairs top-L_i for CHUNKED rows of ANY width, under every noise generator with random access to a pair's
+// noise (none / per-pair hash / symmetric per-pair hash) and, for the rows the register lists of dgg_topk_ranked.hip cannot hold
+// (more than 32 chunks = 2048 ranks), under the ranked generator.
+//
+// Contract (reference dgm.py:1402-1421 select_top_k on the dense row, 1580-1584 the unbounded learned degree, 1211-1231 the
+// perturbation, 1618-1623 the scores): row i keeps the L_i = ceil(k_i + 8.5) + 1 best columns by
+//   p'_ij = exp(log(exp(-0.05 ||xp_i - xp_j||) + 1e-8) + G_ij)      (G = 0 and no log round trip when unperturbed)
+// in (score desc, column asc) order, in the M_i = ceil(L_i / 64) chunks [cptr[i], cptr[i+1]) of idx / val / w (dgg_chunk_layout), with
+// the first-k ramp and the row sums of dgg_allpairs_topk_ranked_wide: same bits as the oracle's ora_allpairs_topk(K = 64 M) + ora_softk.
+//
+// How.  Every row owns a THRESHOLD BUFFER of 128 keys per chunk (cap_i = 128 M_i >= 2 L_i) in the workspace.  A producer streams the
+// row's candidates, appends every key above the row's current threshold, and when the buffer is full SELECTS the L_i-th largest key
+// (bisection on the 64-bit keys: a count pass per step over an L2-resident buffer), keeps the L_i keys above it and raises the
+// threshold: a row of N candidates is compacted ~log2(N / L_i) times and admits ~L_i log2(N / L_i) keys in all.  Producers:
+//   aw_scan_plain    unperturbed scores: every pair scored canonically, 16 rows per wavefront over LDS-staged column tiles (the
+//                    exhaustive kernel's loop, dgg_topk.hip, with the running top-64 replaced by the buffer)
+//   aw_scan_hash     per-pair hash noise (symmetric or not): log p' <= G + 1e-8 whatever the distance, so a pair whose RAW HASH lies
+//                    below the integer image of the row's threshold is dropped by one unsigned compare (dgg_topk_gv.hip's filter, here
+//                    against the row's own moving threshold); the survivors of a tile (a few per cent) are queued in LDS as (row,
+//                    column) pairs and scored 64 at a time with full lanes -- the N^2 part of the kernel is ~10 integer instructions
+//                    per 64 pairs
+//   aw_ranked_walk   ranked generator, rows of more than 32 chunks: the walk of allpairs_topk_ranked_wide (ranks in decreasing noise
+//                    order, stop when the next rank's noise cannot reach the threshold) with the buffer in place of the register lists
+// aw_emit (one workgroup per row) sorts the surviving <= L_i keys in LDS (bitonic; rows beyond 4096 keys in buckets of 4096 split off
+// by further selections), writes idx / val / w per chunk and the row sum in the chunk-ordered, lane-wise + butterfly order.
+// Exactness: a key is dropped only when L_i better keys of the same row are known; the hash filter and the walk's stop test drop a
+// pair only when its noise alone, with margins, cannot reach a threshold that is itself the score of a known L_i-th best key.
+#include "dgg_common.h"
+#include "dgg_api_internal.h"
+
+using namespace dgg;
+
+namespace {
+
+constexpr int KSLOT = 128;              // keys of threshold buffer per chunk of 64 ranks
+
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const uint64_t o = shfl_xor_u64(v, off); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const uint64_t o = shfl_xor_u64(v, off); v = o > v ? o : v; }
+    return v;
+}
+
+// the L-th largest (1-based) of buf[0..n), n >= L >= 1, keys distinct and non-zero; one wavefront, buf in global memory (L2-resident)
+__device__ __noinline__ uint64_t wave_select_lth(const uint64_t *__restrict__ buf, int n, int L, int lane) {
+    uint64_t mn = ~0ull, mx = 0ull;
+    for (int e = lane; e < n; e += 64) { const uint64_t k = buf[e]; mn = k < mn ? k : mn; mx = k > mx ? k : mx; }
+    mn = wave_min_u64(mn);
+    mx = wave_max_u64(mx);
+    if (L >= n) return mn;
+    uint64_t lo = mn, hi = mx + 1ull;                            // count(>= lo) >= L, count(>= hi) < L
+    while (hi - lo > 1ull) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+        uint64_t m2 = ~0ull;
+        int e = lane;
+        for (; e + 192 < n; e += 256) {                          // four independent loads in flight
+            const uint64_t k0 = buf[e], k1 = buf[e + 64], k2 = buf[e + 128], k3 = buf[e + 192];
+            c += (k0 >= mid) + (k1 >= mid) + (k2 >= mid) + (k3 >= mid);
+            if (k0 >= mid && k0 < m2) m2 = k0;
+            if (k1 >= mid && k1 < m2) m2 = k1;
+            if (k2 >= mid && k2 < m2) m2 = k2;
+            if (k3 >= mid && k3 < m2) m2 = k3;
+        }
+        for (; e < n; e += 64) { const uint64_t k = buf[e]; c += k >= mid; if (k >= mid && k < m2) m2 = k; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+        if (c == L) return wave_min_u64(m2);                     // exactly L keys at or above mid: the smallest of them is the L-th
+        if (c > L) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+// keeps the keys >= tau at the front of buf (order preserved) -> their count
+__device__ __noinline__ int wave_compact_ge(uint64_t *__restrict__ buf, int n, uint64_t tau, int lane) {
+    int at = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int e = base + lane;
+        const uint64_t k = e < n ? buf[e] : 0ull;
+        const bool keep = e < n && k >= tau;
+        const uint64_t m = __ballot(keep);
+        const int pos = at + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (keep) buf[pos] = k;                                  // pos <= e: only positions already read are written
+        at += __builtin_popcountll(m);
+    }
+    return at;
+}
+
+// pairs whose raw 32-bit hash is below the result have noise G < gmin - 1e-3 (dgg_topk_gv.hip, hash_threshold_from_gmin): P(G >= g) =
+// 1 - exp(-e^(-g / 0.3)) <= e^(-g / 0.3) =: e1, i.e. G >= g needs U >= 1 - e1; two units of 2^-24 and 1e-3 of margin cover the rounding
+__device__ __forceinline__ uint32_t hash_threshold_from_gmin(float gmin) {
+    const float e1 = __expf((gmin - 1e-3f) * (-1.0f / 0.3f));
+    const float c = fminf(e1 * 16777216.0f, 16777216.0f);
+    int um = 16777216 - (int)c - 2;
+    um = um < 0 ? 0 : um;
+    return (uint32_t)um << 8;
+}
+// integer image of a row's key threshold tau (the score of its L-th best key so far): a pair can only beat tau if its log-score
+// reaches log(score(tau)); log p' <= G + 1e-8, so its noise has to reach that minus the margins (fast-math log: 1e-3 covers it)
+__device__ __forceinline__ uint32_t uthr_from_key(uint64_t tau) {
+    if (tau == DGG_EMPTY_KEY) return 0u;
+    return hash_threshold_from_gmin(__logf(fmaxf(key_val(tau), 1e-37f)) - 1e-8f - 1e-3f);
+}
+
+struct RowGeom { int64_t base; int cap, L; };                    // buffer of a row: keys[base .. base + cap), L ranks to settle
+__device__ __forceinline__ RowGeom row_geom(const int32_t *__restrict__ cptr, const float *__restrict__ klim, int64_t lrow) {
+    RowGeom g;
+    const int c0 = cptr[lrow], M = cptr[lrow + 1] - c0;
+    g.base = (int64_t)c0 * KSLOT;
+    g.cap = M * KSLOT;
+    g.L = M > 0 ? klimit_len(klim[lrow], 64 * M) : 0;
+    return g;
+}
+
+// ---- unperturbed scores: every pair scored, 16 rows per wavefront ---------------------------------------------------------------
+constexpr int RW = 16, WAVES = 4, RB = RW * WAVES, TN = 64;
+template <int H>
+__global__ __launch_bounds__(WAVES * 64) void aw_scan_plain(const float *__restrict__ xp, int64_t N, int64_t row0, int64_t row1, float t,
+                                                            const float *__restrict__ klim, const int32_t *__restrict__ cptr,
+                                                            uint64_t *__restrict__ keys, int32_t *__restrict__ cnt_out) {
+    __shared__ float colT[H * TN];
+    __shared__ float rowsL[RB * H];
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id();
+    const int64_t rbase = row0 + (int64_t)blockIdx.x * RB;
+    for (int e = tid; e < RB * H; e += WAVES * 64) {
+        const int r = e / H, c = e % H;
+        const int64_t gi = rbase + r;
+        rowsL[e] = gi < row1 ? xp[gi * H + c] : 0.0f;
+    }
+    uint64_t thr[RW];
+    int cnt[RW];
+#pragma unroll
+    for (int r = 0; r < RW; r++) { thr[r] = DGG_EMPTY_KEY; cnt[r] = 0; }
+    for (int64_t j0 = 0; j0 < N; j0 += TN) {
+        __syncthreads();
+        for (int e = tid; e < TN * H; e += WAVES * 64) {
+            const int jj = e / H, c = e % H;
+            const int64_t gj = j0 + jj;
+            colT[c * TN + jj] = gj < N ? xp[gj * H + c] : 0.0f;
+        }
+        __syncthreads();
+        float xj[H];
+#pragma unroll
+        for (int c = 0; c < H; c++) xj[c] = colT[c * TN + lane];
+        const int64_t j = j0 + lane;
+        const bool jvalid = j < N;
+#pragma unroll
+        for (int r = 0; r < RW; r++) {
+            const int lr = wave * RW + r;
+            const int64_t i = rbase + lr;
+            if (i >= row1) continue;                             // wave-uniform
+            const float *xi = rowsL + lr * H;
+            float d2 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < H; c++) {
+                const float df = __fadd_rn(xi[c], -xj[c]);
+                d2 = __fmaf_rn(df, df, d2);
+            }
+            const float v = score_from_dist(c_sqrt(d2), t, false, 0.0f);
+            const uint64_t key = jvalid ? make_key(v, (int32_t)j) : DGG_EMPTY_KEY;
+            bool pass = key > thr[r];
+            uint64_t m = __ballot(pass);
+            if (m != 0ull) {                                     // wave-uniform
+                const RowGeom g = row_geom(cptr, klim, i - row0);
+                if (g.cap == 0) continue;                        // (a fixed capacity ran out before this row: no chunk)
+                uint64_t *buf = keys + g.base;
+                if (cnt[r] + __builtin_popcountll(m) > g.cap) {  // full: keep the L best, raise the threshold
+                    thr[r] = wave_select_lth(buf, cnt[r], g.L, lane);
+                    cnt[r] = wave_compact_ge(buf, cnt[r], thr[r], lane);
+                    pass = key > thr[r];
+                    m = __ballot(pass);
+                }
+                const int pos = cnt[r] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (pass) buf[pos] = key;
+                cnt[r] += __builtin_popcountll(m);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+        const int64_t i = rbase + wave * RW + r;
+        if (i >= row1) continue;
+        const RowGeom g = row_geom(cptr, klim, i - row0);
+        int n = cnt[r];
+        if (n > g.L && g.cap > 0) {
+            uint64_t *buf = keys + g.base;
+            const uint64_t tau = wave_select_lth(buf, n, g.L, lane);
+            n = wave_compact_ge(buf, n, tau, lane);
+        }
+        if (lane == 0) cnt_out[i - row0] = n;
+    }
+}
+
+// ---- per-pair hash noise: integer filter on every pair, exact scores for the survivors -----------------------------------------------
+template <int H, bool SYM>
+__global__ __launch_bounds__(WAVES * 64) void aw_scan_hash(const float *__restrict__ xp, int64_t N, int64_t row0, int64_t row1, float t,
+                                                           uint32_t s0, uint32_t s1, const uint32_t *__restrict__ seed_dev,
+                                                           const float *__restrict__ klim, const int32_t *__restrict__ cptr,
+                                                           uint64_t *__restrict__ keys, int32_t *__restrict__ cnt_out) {
+    constexpr int RS = H + 4;                                    // padded row stride (floats): 16-byte aligned, rows 4 banks apart
+    __shared__ __attribute__((aligned(16))) float colR[TN * RS];
+    __shared__ __attribute__((aligned(16))) float rowsL[RB * RS];
+    __shared__ uint64_t s_thr[WAVES][RW];
+    __shared__ int64_t s_base[WAVES][RW];
+    __shared__ int s_cnt[WAVES][RW], s_cap[WAVES][RW], s_L[WAVES][RW];
+    __shared__ unsigned short s_q[WAVES][RW * 64];        // (row, column) pairs of the current tile that passed the integer filter
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id();
+    if (seed_dev) { s0 = seed_dev[0]; s1 = seed_dev[1]; }
+    const int64_t rbase = row0 + (int64_t)blockIdx.x * RB;
+    for (int e = tid; e < RB * H; e += WAVES * 64) {
+        const int r = e / H, c = e % H;
+        const int64_t gi = rbase + r;
+        rowsL[r * RS + c] = gi < row1 ? xp[gi * H + c] : 0.0f;
+    }
+    if (lane < RW) {
+        s_thr[wave][lane] = DGG_EMPTY_KEY;
+        s_cnt[wave][lane] = 0;
+        const int64_t li = rbase + wave * RW + lane - row0;
+        const RowGeom g0 = li < row1 - row0 ? row_geom(cptr, klim, li) : RowGeom{0, 0, 0};
+        s_base[wave][lane] = g0.base; s_cap[wave][lane] = g0.cap; s_L[wave][lane] = g0.L;
+    }
+    __syncthreads();
+    volatile uint64_t *vthr = s_thr[wave];
+    volatile int *vcnt = s_cnt[wave];
+    volatile unsigned short *vq = s_q[wave];
+    uint32_t uthr[RW];                                           // integer image of the rows' thresholds (wave-uniform)
+    uint32_t rk1[RW], rk2[RW];                                   // the rows' hash keys (wave-uniform)
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+        uthr[r] = 0u;
+        rowkey(s0, s1, (uint32_t)(rbase + wave * RW + r), rk1[r], rk2[r]);
+    }
+    int qn = 0;                                                  // queued (row, column) pairs of this wavefront (wave-uniform)
+
+    // score up to 64 queued pairs (lane e < nd takes queue entry off + e) and append the keys above their rows' thresholds
+    auto drain = [&](int nd, int off, int64_t j0) {
+        const bool have = lane < nd;
+        const int ent = have ? (int)vq[off + lane] : 0;
+        const int r = ent >> 6, jj = ent & 63;
+        const int64_t i = rbase + wave * RW + r, j = j0 + jj;
+        uint64_t key = DGG_EMPTY_KEY;
+        if (have) {
+            const float4 *xi = reinterpret_cast<const float4 *>(rowsL + (wave * RW + r) * RS);
+            const float4 *xj = reinterpret_cast<const float4 *>(colR + jj * RS);
+            float d2 = 0.0f;
+#pragma unroll
+            for (int c4 = 0; c4 < H / 4; c4++) {
+                const float4 a = xi[c4], b = xj[c4];
+                float df;
+                df = __fadd_rn(a.x, -b.x); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(a.y, -b.y); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(a.z, -b.z); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(a.w, -b.w); d2 = __fmaf_rn(df, df, d2);
+            }
+            const float g = pair_noise(s0, s1, (uint32_t)i, (uint32_t)j, SYM);
+            key = make_key(score_from_dist(c_sqrt(d2), t, true, g), (int32_t)j);
+        }
+        bool valid = have && key > vthr[r];
+        int pos = valid ? atomicAdd(&s_cnt[wave][r], 1) : 0;
+        const RowGeom g = RowGeom{s_base[wave][r], s_cap[wave][r], s_L[wave][r]};
+        if (valid && pos < g.cap) keys[g.base + pos] = key;
+        bool over = valid && pos >= g.cap;
+        uint64_t pend = __ballot(over);
+        while (pend != 0ull) {                                   // a row's buffer is full: keep its L best, raise its threshold, retry its keys
+            const int src = __builtin_ctzll(pend);
+            const int R = __builtin_amdgcn_readlane(r, src);
+            const RowGeom gR = RowGeom{s_base[wave][R], s_cap[wave][R], s_L[wave][R]};
+            const bool mine = over && r == R;
+            uint64_t tau = DGG_EMPTY_KEY;
+            int kept = 0;
+            if (gR.cap > 0) {
+                uint64_t *buf = keys + gR.base;
+                tau = wave_select_lth(buf, gR.cap, gR.L, lane);
+                kept = wave_compact_ge(buf, gR.cap, tau, lane);
+            } else {
+                tau = ~0ull;                                     // (no chunk: nothing can be kept)
+            }
+            if (lane == 0) { vthr[R] = tau; vcnt[R] = kept; }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t ut = uthr_from_key(tau);
+#pragma unroll
+            for (int q = 0; q < RW; q++) uthr[q] = q == R ? ut : uthr[q];
+            if (mine && key > tau) {
+                const int p2 = atomicAdd(&s_cnt[wave][R], 1);
+                if (p2 < gR.cap) keys[gR.base + p2] = key;       // (kept <= cap / 2 and at most 64 retries: always true)
+            }
+            over = over && r != R;
+            pend = __ballot(over);
+        }
+    };
+
+    for (int64_t j0 = 0; j0 < N; j0 += TN) {
+        __syncthreads();
+        for (int e = tid; e < TN * H; e += WAVES * 64) {
+            const int jj = e / H, c = e % H;
+            const int64_t gj = j0 + jj;
+            colR[jj * RS + c] = gj < N ? xp[gj * H + c] : 0.0f;
+        }
+        __syncthreads();
+        const int64_t j = j0 + lane;
+        const bool jvalid = j < N;
+        uint32_t ck1 = 0u, ck2 = 0u;                             // symmetric noise: a pair below the diagonal is keyed by its COLUMN
+        if (SYM) rowkey(s0, s1, (uint32_t)j, ck1, ck2);
+#pragma unroll
+        for (int r = 0; r < RW; r++) {
+            const int64_t i = rbase + wave * RW + r;
+            if (i >= row1) continue;                             // wave-uniform
+            uint32_t k1 = rk1[r], k2 = rk2[r], b = (uint32_t)j;
+            if (SYM && j < i) { k1 = ck1; k2 = ck2; b = (uint32_t)i; }
+            uint32_t x = b ^ k1;                                 // pair_u24_keyed before the shift
+            x *= 0x7feb352dU; x ^= x >> 15; x += k2; x *= 0x846ca68bU;
+            const bool pass = jvalid && (x >= uthr[r] || (SYM && j == i));
+            const uint64_t m = __ballot(pass);
+            if (m != 0ull) {
+                const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (pass) vq[pos] = (unsigned short)(r * 64 + lane);
+                qn += __builtin_popcountll(m);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int off = 0; off < qn; off += 64) drain(qn - off < 64 ? qn - off : 64, off, j0);     // (the queue refers to this tile's columns)
+        qn = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+        const int64_t i = rbase + wave * RW + r;
+        if (i >= row1) continue;
+        const RowGeom g = RowGeom{s_base[wave][r], s_cap[wave][r], s_L[wave][r]};
+        int n = vcnt[r];
+        n = n > g.cap ? g.cap : n;
+        if (n > g.L && g.cap > 0) {
+            uint64_t *buf = keys + g.base;
+            const uint64_t tau = wave_select_lth(buf, n, g.L, lane);
+            n = wave_compact_ge(buf, n, tau, lane);
+        }
+        if (lane == 0) cnt_out[i - row0] = n;
+    }
+}
+
+// ---- ranked generator, rows of more than `min_m` chunks: the walk of allpairs_topk_ranked_wide on the threshold buffer -----------------
+__device__ __forceinline__ uint64_t scan_u64(uint64_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t lo = __shfl_up((uint32_t)v, off, 64), hi = __shfl_up((uint32_t)(v >> 32), off, 64);
+        const uint64_t t = ((uint64_t)hi << 32) | lo;
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+template <int H>
+__global__ __launch_bounds__(256) void aw_ranked_walk(const float *__restrict__ xp, int64_t N, int64_t row0, int64_t row1, float t, uint32_t s0,
+                                                      uint32_t s1, const uint32_t *__restrict__ seed_dev, const float *__restrict__ klim,
+                                                      const int32_t *__restrict__ cptr, int min_m, uint64_t *__restrict__ keys,
+                                                      int32_t *__restrict__ cnt_out) {
+    const int lane = threadIdx.x & 63;
+    if (seed_dev) { s0 = seed_dev[0]; s1 = seed_dev[1]; }
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
+    const int64_t i = row0 + lrow;
+    if (i >= row1) return;
+    const int M = __builtin_amdgcn_readfirstlane(cptr[lrow + 1] - cptr[lrow]);
+    if (M <= min_m) return;
+    const RowGeom g = row_geom(cptr, klim, lrow);
+    uint64_t *buf = keys + g.base;
+    uint32_t k1, k2;
+    rowkey(s0, s1, (uint32_t)i, k1, k2);
+    const uint32_t k3 = mix32(k2 ^ 0x68E31DA4u);
+    const int b = ranked_bits(N);
+    const uint64_t D = (uint64_t)1 << b;
+    const float *xi = xp + i * H;
+    uint64_t S = 0, thr = DGG_EMPTY_KEY;
+    uint32_t scount = 0;
+    int cnt = 0;
+    float thr_log = -INFINITY;
+    for (uint64_t rb = 0; rb < D; rb += 64) {
+        const uint32_t c = ranked_sigma((uint32_t)(rb + lane), k1, k2, k3, b);
+        const bool valid = (int64_t)c < N;
+        const uint64_t mv = __ballot(valid);
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mv, 0u));
+        const uint32_t s = scount + pos + 1;
+        const uint64_t term = valid ? ranked_term(k1, k3, s, N) : 0ull;
+        const uint64_t pre = scan_u64(term, lane) + S;
+        const float G = ranked_gumbel(pre);
+        uint64_t key = DGG_EMPTY_KEY;
+        const bool want = valid && !(G + 1e-8f + 1e-3f < thr_log);
+        if (want) {
+            const float4 *xj = reinterpret_cast<const float4 *>(xp + (int64_t)c * H);
+            float d2 = 0.0f;
+#pragma unroll
+            for (int c4 = 0; c4 < H / 4; c4++) {
+                const float4 bq = xj[c4];
+                float df;
+                df = __fadd_rn(xi[4 * c4 + 0], -bq.x); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(xi[4 * c4 + 1], -bq.y); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(xi[4 * c4 + 2], -bq.z); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(xi[4 * c4 + 3], -bq.w); d2 = __fmaf_rn(df, df, d2);
+            }
+            key = make_key(score_from_dist(c_sqrt(d2), t, true, G), (int32_t)c);
+        }
+        bool pass = key != DGG_EMPTY_KEY && key > thr;
+        uint64_t m = __ballot(pass);
+        if (m != 0ull) {
+            if (cnt + __builtin_popcountll(m) > g.cap) {
+                thr = wave_select_lth(buf, cnt, g.L, lane);
+                cnt = wave_compact_ge(buf, cnt, thr, lane);
+                thr_log = __logf(fmaxf(key_val(thr), 1e-37f));
+                pass = pass && key > thr;
+                m = __ballot(pass);
+            }
+            const int p = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (pass) buf[p] = key;
+            cnt += __builtin_popcountll(m);
+        }
+        const int nvalid = __builtin_popcountll(mv);
+        S = shfl_u64(pre, 63);
+        scount += (uint32_t)nvalid;
+        if (scount >= (uint32_t)N) break;
+        if (thr != DGG_EMPTY_KEY && nvalid > 0) {                // the lowest noise of this block bounds every rank still to come
+            const int last = 63 - __builtin_clzll(mv);
+            const float gmin = __shfl(G, last, 64);
+            if (gmin + 1e-8f + 1e-3f < thr_log) break;
+        }
+    }
+    if (cnt > g.L) {
+        const uint64_t tau = wave_select_lth(buf, cnt, g.L, lane);
+        cnt = wave_compact_ge(buf, cnt, tau, lane);
+    }
+    if (lane == 0) cnt_out[lrow] = cnt;
+}
+
+// ---- emit: sort a row's surviving keys, write chunks, ramp, row sum ---------------------------------------------------------------------
+constexpr int ET = 256;                                          // threads of an emit workgroup
+// descending bitonic sort of sk[0..P2) (P2 a power of two >= 64) by the workgroup
+__device__ __forceinline__ void wg_sort_desc(uint64_t *sk, int P2, int tid) {
+    for (int kb = 2; kb <= P2; kb <<= 1) {
+        for (int j = kb >> 1; j > 0; j >>= 1) {
+            for (int q = tid; q < (P2 >> 1); q += ET) {
+                const int a = ((q & ~(j - 1)) << 1) | (q & (j - 1)), bq = a + j;
+                const bool down = (a & kb) == 0 || kb == P2;     // this block ends descending
+                const uint64_t ka = sk[a], kbv = sk[bq];
+                if ((ka < kbv) == down) { sk[a] = kbv; sk[bq] = ka; }
+            }
+            __syncthreads();
+        }
+    }
+}
+// count of keys in [lo_incl, hi_excl) over buf[0..n) by the workgroup (result in every thread); *mn = the smallest such key
+__device__ __forceinline__ int wg_count_range(const uint64_t *__restrict__ buf, int n, uint64_t lo_incl, uint64_t hi_excl, int tid,
+                                              int *s_red, unsigned long long *s_min, uint64_t *mn) {
+    int c = 0;
+    uint64_t m2 = ~0ull;
+    for (int e = tid; e < n; e += ET) {
+        const uint64_t k = buf[e];
+        const bool in = k >= lo_incl && k < hi_excl;
+        c += in;
+        if (in && k < m2) m2 = k;
+    }
+    __syncthreads();
+    if (tid == 0) { *s_red = 0; *s_min = ~0ull; }
+    __syncthreads();
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+    m2 = wave_min_u64(m2);
+    if ((tid & 63) == 0) { atomicAdd(s_red, c); atomicMin(s_min, (unsigned long long)m2); }
+    __syncthreads();
+    *mn = (uint64_t)*s_min;
+    return *s_red;
+}
+template <int P>
+__global__ __launch_bounds__(ET) void aw_emit(const uint64_t *__restrict__ keys, const int32_t *__restrict__ cnt, const float *__restrict__ klim,
+                                              const int32_t *__restrict__ cptr, int64_t rows, int min_m, int64_t ccap, int32_t *__restrict__ idx,
+                                              float *__restrict__ val, int softk_mode, float *__restrict__ w_out, float *__restrict__ rs_out) {
+    __shared__ uint64_t sk[P];
+    __shared__ int s_red;
+    __shared__ unsigned long long s_min;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if ((int64_t)blockIdx.x >= rows) {
+        // arrays allocated for `ccap` chunks (a fixed capacity): the chunks beyond the last one are written EMPTY (min_m = 0 only: with
+        // the ranked generator dgg_allpairs_topk_ranked_wide does it)
+        const int64_t q = (int64_t)cptr[rows] + ((int64_t)blockIdx.x - rows) * 4 + (tid >> 6);
+        if (q < ccap) {
+            idx[q * 64 + lane] = -1;
+            val[q * 64 + lane] = 0.0f;
+            if (w_out) w_out[q * 64 + lane] = 0.0f;
+        }
+        return;
+    }
+    const int64_t lrow = blockIdx.x;
+    const int c0 = cptr[lrow], M = cptr[lrow + 1] - c0;
+    if (M <= min_m) {
+        if (M <= 0 && min_m == 0 && w_out && tid == 0) rs_out[lrow] = 0.0f;     // (a fixed capacity ran out before this row)
+        return;
+    }
+    const float ki = klim[lrow];
+    const int L = klimit_len(ki, 64 * M);
+    int n = cnt[lrow];
+    n = n > L ? L : n;
+    const uint64_t *buf = keys + (int64_t)c0 * KSLOT;
+    auto emit = [&](int r, uint64_t key) {                       // rank r of the row <- key (DGG_EMPTY_KEY: no entry)
+        const bool empty = key == DGG_EMPTY_KEY || r >= L;
+        const int64_t e = ((int64_t)c0 + (r >> 6)) * 64 + (r & 63);
+        idx[e] = empty ? -1 : key_col(key);
+        const float sv = empty ? 0.0f : key_val(key);
+        val[e] = sv;
+        if (w_out) {
+            const float f = c_ramp((float)r, ki);
+            float v = f;
+            if (softk_mode == 0 || softk_mode == 3) {
+                const float a = __fmul_rn(sv, f);
+                v = softk_mode == 0 ? a : __fadd_rn(__fadd_rn(f, -a), a);
+            }
+            w_out[e] = empty ? 0.0f : v;
+        }
+    };
+    int done = 0;
+    uint64_t hi = ~0ull;                                         // keys at or above `hi` are emitted already
+    while (done < n) {
+        const int rest = n - done;
+        int take = rest;
+        uint64_t tau = 0ull;
+        if (rest > P) {                                          // the next P ranks: tau = the P-th largest key below hi
+            take = P;
+            uint64_t lo = 0ull, up = hi, mn;                     // count[lo, hi) >= take, count[up, hi) < take
+            while (up - lo > 1ull) {
+                const uint64_t mid = lo + ((up - lo) >> 1);
+                const int c = wg_count_range(buf, n, mid, hi, tid, &s_red, &s_min, &mn);
+                if (c == take) { lo = mn; break; }
+                if (c > take) lo = mid; else up = mid;
+            }
+            tau = lo;
+        }
+        // the keys of [tau, hi) into LDS (their count is `take`), padded to a power of two with empty keys
+        int P2 = 64;
+        while (P2 < take) P2 <<= 1;
+        __syncthreads();
+        if (tid == 0) s_red = 0;
+        for (int e = tid; e < P2; e += ET) sk[e] = DGG_EMPTY_KEY;
+        __syncthreads();
+        for (int e = tid; e < n; e += ET) {
+            const uint64_t k = buf[e];
+            if (k >= tau && k < hi) {
+                const int p = atomicAdd(&s_red, 1);
+                if (p < P2) sk[p] = k;
+            }
+        }
+        __syncthreads();
+        wg_sort_desc(sk, P2, tid);
+        for (int q = tid; q < take; q += ET) emit(done + q, sk[q]);
+        done += take;
+        hi = tau;
+    }
+    for (int r = n + tid; r < 64 * M; r += ET) emit(r, DGG_EMPTY_KEY);          // ranks without a candidate (fewer than L columns exist)
+    if (w_out) {
+        // row sum in the order of allpairs_topk_ranked_wide / the oracle's butterfly_sum for K > 64: every lane adds its entry of each
+        // chunk in chunk order, then the 64-lane butterfly
+        __threadfence_block();
+        __syncthreads();
+        if (tid < 64) {
+            float rsum = 0.0f;
+            for (int m = 0; m < M; m++) {
+                const float wv = w_out[((int64_t)c0 + m) * 64 + lane];
+                rsum = m == 0 ? wv : __fadd_rn(rsum, wv);
+            }
+            const float s_ = wave_sum_butterfly(rsum);
+            if (lane == 0) rs_out[lrow] = s_;
+        }
+    }
+}
+
+template <int H>
+int launch_anywide(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, int noise_mode, uint32_t s0, uint32_t s1, const uint32_t *seed_dev,
+                   const float *k, int mode, int maxm, int min_m, const int32_t *cptr, int64_t ccap, int32_t *idx, float *val, float *w, float *rs,
+                   uint64_t *keys, int32_t *cnt, hipStream_t st) {
+    const int64_t rows = row1 - row0;
+    const dim3 gscan((unsigned)((rows + RB - 1) / RB));
+    if (noise_mode == 0)
+        hipLaunchKernelGGL(aw_scan_plain<H>, gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, k, cptr, keys, cnt);
+    else if (noise_mode == 2)
+        hipLaunchKernelGGL((aw_scan_hash<H, false>), gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr, keys, cnt);
+    else if (noise_mode == 3)
+        hipLaunchKernelGGL((aw_scan_hash<H, true>), gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr, keys, cnt);
+    else
+        hipLaunchKernelGGL(aw_ranked_walk<H>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr,
+                           min_m, keys, cnt);
+    int rc = dgg_check_launch("allpairs_topk_anywide: candidate pass");
+    if (rc) return rc;
+    const int64_t tail = (min_m == 0 && ccap > rows) ? ccap - rows : 0;        // (every row has at least one chunk)
+    const dim3 gemit((unsigned)(rows + (tail + 3) / 4));
+    if ((int64_t)maxm * 64 <= 1024)
+        hipLaunchKernelGGL(aw_emit<1024>, gemit, dim3(ET), 0, st, keys, cnt, k, cptr, rows, min_m, ccap, idx, val, mode, w, rs);
+    else
+        hipLaunchKernelGGL(aw_emit<4096>, gemit, dim3(ET), 0, st, keys, cnt, k, cptr, rows, min_m, ccap, idx, val, mode, w, rs);
+    return dgg_check_launch("allpairs_topk_anywide: emit");
+}
+
+}  // namespace
+
+extern "C" {
+
+// bytes of workspace dgg_allpairs_topk_anywide needs for arrays of `ccap` chunks and `rows` rows: 128 keys of 8 bytes per chunk + a count per row
+size_t dgg_allpairs_anywide_ws_bytes(int64_t ccap, int64_t rows) {
+    if (ccap < 0 || rows < 0) return 0;
+    return (size_t)ccap * KSLOT * sizeof(uint64_t) + (((size_t)rows * sizeof(int32_t) + 255) & ~(size_t)255) + 256;
+}
+
+// All-pairs top-L_i on CHUNKED rows of any width (include/dgg_hip.h).  noise_mode 0 (unperturbed), 2 (per-pair hash), 3 (symmetric per-pair
+// hash): every row of [row0, row1), min_m must be 0.  noise_mode 4 (ranked generator): only the rows of MORE than min_m chunks (the others
+// belong to dgg_allpairs_topk_ranked_wide, which also writes the spare chunks of a fixed capacity).
+int dgg_allpairs_topk_anywide(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode, uint32_t s0, uint32_t s1,
+                              const uint32_t *seed_dev, const float *k, int mode, int maxm, int min_m, const int32_t *cptr, int64_t ccap,
+                              int32_t *idx, float *val, float *w, float *rs, void *workspace, size_t ws_bytes, void *stream) {
+    if (row0 < 0 || row1 > N || row0 > row1) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_anywide: bad row range");
+    if (mode != 0 && mode != 1 && mode != 3) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_anywide: mode must be 0, 1 or 3");
+    if (!xp || !k || !cptr || !idx || !val || (w && !rs)) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_anywide: xp, k, cptr, idx, val (and rs with w) are required");
+    if (noise_mode != 0 && noise_mode != 2 && noise_mode != 3 && noise_mode != 4)
+        return dgg_set_error(DGG_ERR_UNSUPPORTED, "allpairs_topk_anywide: noise_mode none (0), hash (2), symmetric hash (3) or ranked (4)");
+    if (maxm < 1 || maxm > DGG_CHUNK_MAXM_ANY || min_m < 0 || (noise_mode != 4 && min_m != 0))
+        return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_anywide: maxm in 1..2^20; min_m = 0 unless the generator is the ranked one");
+    if (N >= ((int64_t)1 << 31) || ccap >= ((int64_t)1 << 24)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "allpairs_topk_anywide: N < 2^31, ccap < 2^24");
+    if (!workspace || ws_bytes < dgg_allpairs_anywide_ws_bytes(ccap, row1 - row0))
+        return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_anywide: workspace missing or smaller than dgg_allpairs_anywide_ws_bytes");
+    if (row1 == row0) return 0;
+    uint64_t *keys = reinterpret_cast<uint64_t *>(workspace);
+    int32_t *cnt = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(workspace) + (size_t)ccap * KSLOT * sizeof(uint64_t));
+    hipStream_t st = (hipStream_t)stream;
+    switch (h) {
+        case 16: return launch_anywide<16>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, st);
+        case 32: return launch_anywide<32>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, st);
+        case 64: return launch_anywide<64>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, st);
+        case 128: return launch_anywide<128>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, st);
+        default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "allpairs_topk_anywide supports latent_dim in {16,32,64,128}");
+    }
+}
+
+}  // extern "C"

@@ -192,8 +192,9 @@ int launch_ranked(const float *xp, int64_t N, int64_t row0, int64_t row1, float 
 // kernels downstream (partition, aggregation, backward), which only need the node of a chunk (cnode).
 //
 // chunk_partial + chunk_layout: k -> cptr (exclusive scan of M_i), cnode, meta = {total chunks, max M_i, flags}; flags bit 0: some
-// row's ramp support exceeds 64 * maxm ranks (it is cut there -- callers raise, never truncate silently), bit 1: more chunks than
-// `ccap` (cnode holds the first ccap; the caller's arrays are too small: re-run with a larger capacity).  Two passes of 128
+// row's ramp support exceeds 64 * maxm ranks (it is cut there -- harmless when 64 * maxm covers every column of the graph, otherwise
+// callers raise, never truncate silently), bit 2: some learned degree is NaN, bit 1: more chunks than
+// `ccap` (cptr is CLAMPED to ccap -- rows beyond it own no chunk -- so no consumer leaves the arrays; re-run with a larger capacity).  Two passes of 128
 // workgroups (segment totals, then the scan of each segment from its base): ~10 us at 100 000 rows (one workgroup: 96 us).
 constexpr int CL_NB = 128, CL_T = 256;                          // workgroups / threads of the two layout passes
 __device__ __forceinline__ int64_t cl_segment(int64_t rows) { return ((rows + CL_NB - 1) / CL_NB + CL_T - 1) / CL_T * CL_T; }
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(CL_T) void chunk_partial(const float *__restrict__ 
     int s = 0, mx = 0, flag = 0;
     for (int64_t i = lo + tid; i < hi; i += CL_T) {
         const float kk = k[i];
-        if (!(ceilf(kk + 8.5f) + 1.0f <= (float)kcap)) flag = 1;        // (also NaN)
+        if (!(ceilf(kk + 8.5f) + 1.0f <= (float)kcap)) flag |= 1;       // (also NaN)
+        if (kk != kk) flag |= 4;                                         // a learned degree that is not a number
         const int m = (klimit_len(kk, kcap) + 63) >> 6;
         s += m;
         mx = m > mx ? m : mx;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(CL_T) void chunk_partial(const float *__restrict__ 
 // workgroup scan per tile, the running sum carried): cptr, cnode; workgroup 0 writes the totals; all zero cnode beyond the last chunk
 __global__ __launch_bounds__(CL_T) void chunk_layout(const float *__restrict__ k, int64_t rows, int maxm, int64_t ccap,
                                                      const int32_t *__restrict__ part, int32_t *__restrict__ cptr,
-                                                     int32_t *__restrict__ cnode, int32_t *__restrict__ meta) {
+                                                     int32_t *__restrict__ cnode, int32_t *__restrict__ meta, int32_t *__restrict__ sticky) {
     __shared__ int wsum[CL_T / 64], sbase, stotal, smax, sflag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t per = cl_segment(rows), lo = (int64_t)blockIdx.x * per, hi = lo + per < rows ? lo + per : rows;
@@ -280,7 +282,9 @@ __global__ __launch_bounds__(CL_T) void chunk_layout(const float *__restrict__ k
         }
         const int first = run + wbase + incl - m;
         if (i < hi) {
-            cptr[i] = first;
+            // MEMORY SAFETY under a fixed capacity: a row that starts beyond ccap owns no chunk, one that straddles it is cut there --
+            // every consumer walks [cptr[i], cptr[i+1]) and stays inside arrays of ccap chunks; flags bit 1 reports the overflow
+            cptr[i] = first < ccap ? first : (int)ccap;
             for (int c = 0; c < m; c++)
                 if (first + c < ccap) cnode[first + c] = (int32_t)i;
         }
@@ -289,11 +293,15 @@ __global__ __launch_bounds__(CL_T) void chunk_layout(const float *__restrict__ k
     }
     for (int64_t c = (int64_t)total + (int64_t)blockIdx.x * CL_T + tid; c < ccap; c += (int64_t)CL_NB * CL_T) cnode[c] = 0;   // chunks beyond the last one: node 0, empty
     if (blockIdx.x == 0 && tid == 0) {
-        cptr[rows] = total;
-        meta[0] = total;
+        const int flags = sflag | (total > ccap ? 2 : 0);
+        cptr[rows] = total < ccap ? total : (int)ccap;
+        meta[0] = total;                                         // (the chunks NEEDED: what a caller re-sizes its arrays to)
         meta[1] = smax;
-        meta[2] = sflag | (total > ccap ? 2 : 0);
+        meta[2] = flags;
         meta[3] = 0;
+        // the flags of THIS call are overwritten by the next one (a replayed hipGraph); `sticky` is only ever ORed into and keeps
+        // every overflow since the host last cleared it
+        if (sticky && flags) atomicOr(sticky, flags);
     }
 }
 
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked_wide(const float *__
                                                                  const int32_t *__restrict__ cptr, int32_t *__restrict__ idx,
                                                                  float *__restrict__ val, int softk_mode, float *__restrict__ w_out,
                                                                  float *__restrict__ rs_out, const uint32_t *__restrict__ seed_dev,
-                                                                 unsigned nrow_blocks, int64_t ccap) {
+                                                                 unsigned nrow_blocks, int64_t ccap, int skip_heavy) {
     const int lane = threadIdx.x & 63;
     if (blockIdx.x >= nrow_blocks) {
         // arrays allocated for `ccap` chunks (a capacity fixed ahead of the learned degrees, e.g. inside a captured hipGraph): the
@@ -333,7 +341,14 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked_wide(const float *__
     if (i >= row1) return;
     const int c0 = __builtin_amdgcn_readfirstlane(cptr[lrow]);
     int Mi = __builtin_amdgcn_readfirstlane(cptr[lrow + 1]) - c0;
-    Mi = Mi > MAXM ? MAXM : Mi;
+    if (Mi <= 0) {                                               // (a fixed capacity ran out before this row: it owns no chunk; flagged by chunk_layout)
+        if (w_out && lane == 0) rs_out[lrow] = 0.0f;
+        return;
+    }
+    if (Mi > MAXM) {
+        if (skip_heavy) return;                                  // more lists than a wavefront holds in registers: dgg_allpairs_topk_anywide settles the row
+        Mi = MAXM;
+    }
     const float ki = klim[lrow];
     const int L = __builtin_amdgcn_readfirstlane(klimit_len(ki, 64 * Mi));
     const int mL = (L - 1) >> 6, laneL = (L - 1) & 63;
@@ -454,11 +469,12 @@ template <int H>
 int launch_ranked_wide(int maxm, const float *xp, int64_t N, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1, const float *klim,
                        const int32_t *cptr, int32_t *idx, float *val, hipStream_t st, int softk_mode, float *w, float *rs, const uint32_t *seed_dev,
                        int64_t ccap) {
+    const int skip_heavy = maxm > DGG_CHUNK_MAXM ? 1 : 0;
     const unsigned nrow_blocks = (unsigned)((row1 - row0 + 3) / 4);
     const int64_t tail = ccap > row1 - row0 ? ccap - (row1 - row0) : 0;         // (every row has at least one chunk)
     dim3 grid(nrow_blocks + (unsigned)((tail + 3) / 4));
 #define DGG_RW(MM) hipLaunchKernelGGL((allpairs_topk_ranked_wide<H, MM>), grid, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, klim, cptr, idx, val, \
-                                      softk_mode, w, rs, seed_dev, nrow_blocks, ccap)
+                                      softk_mode, w, rs, seed_dev, nrow_blocks, ccap, skip_heavy)
     if (maxm <= 2) DGG_RW(2);
     else if (maxm <= 4) DGG_RW(4);
     else if (maxm <= 8) DGG_RW(8);
@@ -552,13 +568,14 @@ int dgg_allpairs_topk_ranked_softk_dseed(const float *xp, int64_t N, int h, int6
 // Layout of the chunked rows from the learned degrees: cptr [rows+1] (first chunk of every node), cnode [ccap] (node of every chunk),
 // meta int32[4 + 384] = {total chunks, max chunks of a row, flags (1: a row needs more than 64*maxm ranks, 2: more than ccap chunks), 0,
 // scratch of the two-pass scan}.
-int dgg_chunk_layout(const float *k, int64_t rows, int maxm, int64_t ccap, int32_t *cptr, int32_t *cnode, int32_t *meta, void *stream) {
-    if (rows < 0 || maxm < 1 || maxm > DGG_CHUNK_MAXM || ccap < 0 || !k || !cptr || !cnode || !meta)
-        return dgg_set_error(DGG_ERR_ARG, "chunk_layout: bad sizes or NULL arrays (maxm in 1..32)");
+int dgg_chunk_layout(const float *k, int64_t rows, int maxm, int64_t ccap, int32_t *cptr, int32_t *cnode, int32_t *meta, int32_t *sticky,
+                     void *stream) {
+    if (rows < 0 || maxm < 1 || maxm > DGG_CHUNK_MAXM_ANY || ccap < 0 || ccap >= ((int64_t)1 << 31) || !k || !cptr || !cnode || !meta)
+        return dgg_set_error(DGG_ERR_ARG, "chunk_layout: bad sizes or NULL arrays (maxm in 1..2^20, ccap < 2^31)");
     if (rows >= ((int64_t)1 << 25)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "chunk_layout: rows < 2^25");
     // (the segment totals of the first pass live in meta[4 .. 4 + 3 * 128): meta is int32 [4 + 384])
     hipLaunchKernelGGL(chunk_partial, dim3(CL_NB), dim3(CL_T), 0, (hipStream_t)stream, k, rows, maxm, meta + 4);
-    hipLaunchKernelGGL(chunk_layout, dim3(CL_NB), dim3(CL_T), 0, (hipStream_t)stream, k, rows, maxm, ccap, meta + 4, cptr, cnode, meta);
+    hipLaunchKernelGGL(chunk_layout, dim3(CL_NB), dim3(CL_T), 0, (hipStream_t)stream, k, rows, maxm, ccap, meta + 4, cptr, cnode, meta, sticky);
     return dgg_check_launch("chunk_layout");
 }
 // dgg_allpairs_topk_ranked_softk[_dseed] for chunked rows: idx / val / w are [chunks, 64] (chunk c of node i = ranks 64 (c - cptr[i]) ...),
@@ -571,7 +588,8 @@ int dgg_allpairs_topk_ranked_wide(const float *xp, int64_t N, int h, int64_t row
     if (row0 < 0 || row1 > N || row0 > row1) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_wide: bad row range");
     if (mode != 0 && mode != 1 && mode != 3) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_wide: mode must be 0, 1 or 3");
     if (!k || !cptr || !idx || !val || (w && !rs)) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_wide: k, cptr, idx, val (and rs with w) are required");
-    if (maxm < 1 || maxm > DGG_CHUNK_MAXM) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_wide: maxm in 1..32");
+    // maxm > 32: the rows of up to 32 chunks are settled here, the wider ones are LEFT to dgg_allpairs_topk_anywide (noise_mode 4)
+    if (maxm < 1 || maxm > DGG_CHUNK_MAXM_ANY) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_wide: maxm in 1..2^20");
     if (N >= ((int64_t)1 << 31)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path needs N < 2^31");
     if (row1 == row0) return 0;
     hipStream_t st = (hipStream_t)stream;

@@ -166,7 +166,8 @@ class _DGGWideAdjFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xp, k, cfg):
         lay = cfg["layout"]
-        idx, val, w, rs = ops.allpairs_topk_wide(xp, k, lay, cfg.get("fwd_mode", cfg["mode"]), cfg["t"], cfg["seed"])
+        idx, val, w, rs = ops.allpairs_topk_wide(xp, k, lay, cfg.get("fwd_mode", cfg["mode"]), cfg["t"], cfg["seed"],
+                                                 noise_mode=cfg.get("wide_noise", ops.NOISE_RANKED))
         ctx.cfg = cfg
         cfg["partp"] = ops.partp_build(idx, w, val, rs, xp.shape[0], layout=lay) if any(ctx.needs_input_grad) else None
         ctx.save_for_backward(xp, k, idx, val)
@@ -180,7 +181,8 @@ class _DGGWideAdjFn(torch.autograd.Function):
         partp = cfg["partp"]
         assert partp is not None, "chunked rows: no payload partition for this shape"
         dw = dw.contiguous()
-        dxp, dk = ops.softk_edge_bwd_p(xp, idx, val, k, dw, ops.partp_gather(partp, dw), None, None, 0, cfg["t"], True, cfg["mode"], False, partp)
+        dxp, dk = ops.softk_edge_bwd_p(xp, idx, val, k, dw, ops.partp_gather(partp, dw), None, None, 0, cfg["t"],
+                                       cfg.get("wide_noise", ops.NOISE_RANKED) != ops.NOISE_NONE, cfg["mode"], False, partp)
         return dxp, dk, None
 
 
@@ -521,12 +523,14 @@ class DGG_LearnableK_debug(nn.Module):
                                "the module switch by itself) is cheaper on such data"))
                 if auto and many:
                     self._sym_generator = "hash"
-        wm = self.__dict__.get("_wide_meta")
-        if wm is not None and not _capturing():
-            self._wide_meta = None
-            if int(wm[2]) != 0:
-                raise RuntimeError("DGG_LearnableK_debug: the chunked rows of a captured step outgrew the capacity they were captured with "
-                                   f"(chunks needed {int(wm[0])}, widest row {int(wm[1])} chunks): run one eager forward and capture again")
+        fl = self.__dict__.get("_fused_layer")
+        if fl is not None and fl.wide_sticky is not None and not _capturing():
+            # (a device word the layout kernel ORs into on every forward -- every replay of a captured step -- under a fixed capacity)
+            try:
+                fl.check_wide()
+            except RuntimeError as e:
+                raise RuntimeError("DGG_LearnableK_debug: the chunked rows of a captured step outgrew the capacity they were captured with: run "
+                                   f"one eager forward and capture again ({e})") from None
         flag = self.__dict__.get("_overflow_dev")
         if flag is not None and not _capturing() and bool(flag.item()):
             flag.zero_()
@@ -676,7 +680,7 @@ class DGG_LearnableK_debug(nn.Module):
             # nothing can be read back under capture: the layout of the last eager forward on this module, with some slack, becomes a
             # FIXED capacity whose overflow flags check_ell_bound() reads; no wide row then: the list, with its enforced bound
             last = getattr(layer, "last_layout", None)
-            layer.wide_cap = None if last is None or last[0] == N else (last[0] + last[0] // 8 + 64, min(ops.CHUNK_MAXM, last[1] + 1))
+            layer.wide_cap = None if last is None or last[0] == N else (last[0] + last[0] // 8 + 64, min(ops.chunk_maxm_for(N), last[1] + max(1, last[1] // 8)))
             if layer.wide_cap is None:
                 layer.wide_rows = "off"
         chunk_active = chunked and layer.wide_rows == "auto" and layer.wide_cap is None    # (this forward reads the layout back)
@@ -696,14 +700,7 @@ class DGG_LearnableK_debug(nn.Module):
             Z, ahat = _FusedDGGMlpConvFn.apply(x, deg, layer, sc_static, mlp["Wcat"], mlp["wdu"], mlp["wdv"], mlp["wex"], mlp["b1"],
                                                mlp["w2"], mlp["b2"], *params)
         else:
-            try:
-                Z, ahat = _FusedDGGConvFn.apply(x, deg, layer, *params)
-            except ops.ChunkCapacityError:
-                # a learned degree beyond 2038: more ranks than the chunked rows hold.  Graphs small enough for the complete candidate
-                # pattern (args.dgg_allpairs_csr_max) rank every column in CSR form from here on; larger ones have no exact evaluator
-                if not self._chunks_exhausted(N):
-                    raise
-                return self._fused_fallback("learned degrees beyond the chunked rows' 2048 ranks (CSR form)")
+            Z, ahat = _FusedDGGConvFn.apply(x, deg, layer, *params)       # (ops.ChunkCapacityError: a learned degree is NaN)
         st = layer.saved
         if noise_mode == ops.NOISE_RANKED_SYM:                # the reference's DEFAULT noise (symmetric_noise=True, dgm.py:1216-1223): the
             self._note_rsym(getattr(layer, "rsym_last", None), N)     # generator's status words, checked by check_ell_bound as for the modules
@@ -720,9 +717,8 @@ class DGG_LearnableK_debug(nn.Module):
             return None                                       # learned degrees beyond the list: the modules' CSR form (every column ranked)
         if cand is None and lay is None and not chunk_active:
             self._track_overflow(k, None)
-        elif cand is None and layer.wide_cap is not None:     # fixed capacity (capture): its overflow flags join the module's
-            prev = self.__dict__.get("_wide_meta")
-            self._wide_meta = layer.wide_meta if prev is None else torch.maximum(prev, layer.wide_meta)
+        elif cand is None and layer.wide_cap is not None:     # fixed capacity (capture): overflow flags in layer.wide_sticky (check_ell_bound)
+            pass
         elif mlp_mode:
             ent = self.__dict__.get("_wide_cache", {}).get(id(in_adj))
             if not (ent is not None and ent[0]() is in_adj and ent[1] <= self.ell_width):     # (no row can outgrow the list otherwise)
@@ -740,15 +736,6 @@ class DGG_LearnableK_debug(nn.Module):
         if lay is not None and pp is None:                    # (chunked rows as a separate module: the CSR kernels)
             return Z, unnorm, EllAdjacency(st["idx"], ahat.detach(), N, k=k, score=st["val"], normalized=True, owner=self, layout=lay)
         return Z, unnorm, EllAdjacency(st["idx"], ahat, N, k=k, score=st["val"], normalized=True, owner=self, partp=pp, layout=lay)
-
-    def _chunks_exhausted(self, N):
-        """a learned degree exceeded the chunked rows' capacity: switch this module to the CSR form of select_top_k on the complete
-        candidate pattern if the graph is small enough for it (-> True), else leave the error to the caller (-> False)"""
-        if N > int(getattr(self.args, "dgg_allpairs_csr_max", 8192)) or getattr(self.args, "dgg_wide_rows", "auto") in ("ell", "chunked"):
-            return False
-        self.__dict__.setdefault("_ap_wide", {"on": False})["on"] = True
-        self.__dict__["_chunks_off"] = True
-        return True
 
     def _fused_fallback(self, why):
         """forward_conv leaves for the separate modules: counted per reason, logged once per module and reason -> None"""
@@ -775,14 +762,17 @@ class DGG_LearnableK_debug(nn.Module):
             self._rsym_depth = st["rsym_depth"] if prevd is None else torch.maximum(prevd, st["rsym_depth"])
 
     def _chunk_policy(self, noise_mode):
-        """All-pairs rows wider than the 64-rank list as CHUNKED rows (ops.chunk_layout; any learned degree up to 2038, any graph size)?
-        They need the ranked generator (asymmetric noise: the search settles ceil(k_i + 8.5) + 1 ranks per row) on latent widths 16-128.
+        """All-pairs rows wider than the 64-rank list as CHUNKED rows (ops.chunk_layout; any learned degree, any graph size, every
+        counter-based noise generator and unperturbed scores)?  The ranked generator settles rows of up to 32 chunks in register lists and
+        wider ones through threshold buffers; unperturbed scores and the per-pair hash generators take the threshold buffers for every
+        row; the ranked SYMMETRIC generator has no wide-row form of its own -- wide rows are evaluated under the symmetric per-pair hash
+        (the same law, another realisation: ops.allpairs_topk_wide).  Latent widths 16-128.
         args.dgg_wide_rows: "auto" (default) / "chunked" yes; "csr": the complete candidate pattern in CSR form instead (graphs of at
         most args.dgg_allpairs_csr_max nodes, every column ranked; "csr_auto": from the forward that first needs it); "ell": the
-        64-rank list with the enforced bound.  Explicit noise, the per-pair hash generators and unperturbed scores keep the CSR form
-        (they have no early-stopping search to widen)."""
+        64-rank list with the enforced bound.  Explicit noise tensors keep the CSR form."""
         policy = getattr(self.args, "dgg_wide_rows", "auto")
-        return (policy in ("auto", "chunked") and noise_mode == ops.NOISE_RANKED and self.ell_width == 64 and not self.__dict__.get("_chunks_off")
+        return (policy in ("auto", "chunked") and noise_mode in (ops.NOISE_NONE, ops.NOISE_HASH, ops.NOISE_HASH_SYM, ops.NOISE_RANKED, ops.NOISE_RANKED_SYM)
+                and self.ell_width == 64
                 and self.latent_dim in (16, 32, 64, 128) and self.edge_prob_net_mode == "u-v-dist")
 
     def _track_overflow(self, k, ncand):
@@ -1071,14 +1061,10 @@ class DGG_LearnableK_debug(nn.Module):
             return self._csr_soft_adjacency(x, in_adj, k, noise_mode, G, seed, cfg["mode"])
         if cand is None and not literal and self._chunk_policy(noise_mode) and not _capturing():
             # learned degrees beyond the 64-rank list: chunked rows (same generator, same search, ceil(k_i + 8.5) + 1 ranks per row)
-            try:
-                lay = ops.chunk_layout(k.detach())            # (one readback: the chunk count sizes the arrays)
-            except ops.ChunkCapacityError:                    # a learned degree beyond 2038: the CSR form if the graph allows it
-                if not self._chunks_exhausted(x.shape[0]):
-                    raise
-                lay = None
+            lay = ops.chunk_layout(k.detach(), ncols=x.shape[0])          # (one readback: the chunk count sizes the arrays)
             if lay is not None and lay.wide:
                 cfg["layout"] = lay
+                cfg["wide_noise"] = {ops.NOISE_RANKED_SYM: ops.NOISE_HASH_SYM}.get(noise_mode, noise_mode)
                 xp = xp_dual if xp_dual is not None else ops.LinearFn.apply(x, We, be, ops.ACT_LEAKY, 0)
                 w, idx, val, rs = _DGGWideAdjFn.apply(xp, k, cfg)
                 if writer is not None:

@@ -400,17 +400,19 @@ def allpairs_topk_softk(xp, k, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, seed=(0, 0
 
 
 # ---- rows wider than 64 ranks: chunked rows ------------------------------------------------------------------------------------------
-CHUNK_MAXM = 32          # at most 32 chunks of 64 ranks per row (learned degrees up to 2038)
+CHUNK_MAXM = 32          # chunks of 64 ranks per row that the ranked search holds in REGISTER lists (2048 ranks); wider rows and the other
+                         # noise generators go through threshold buffers in memory (dgg_allpairs_topk_anywide): any width
+CHUNK_MAXM_ANY = 1 << 20
 
 
 class ChunkCapacityError(RuntimeError):
-    """a learned degree needs more ranks than the chunked rows hold (64 * CHUNK_MAXM), or is not finite"""
+    """a learned degree needs more ranks than the caller allowed for the chunked rows (64 * maxm), or is not a number"""
 
 
 class ChunkLayout:
     """Chunked rows (include/dgg_hip.h, dgg_chunk_layout): node i owns the chunks [cptr[i], cptr[i+1]) of the [chunks,64] arrays, rank r
     of its row is entry r % 64 of chunk r / 64.  cptr int32 [rows+1], cnode int32 [chunks] (node of every chunk), meta int32 [4] on the
-    device = {chunks in use, widest row in chunks, flags, 0}; `chunks` = rows of the arrays (>= chunks in use), `maxm` = list count the
+    device = {chunks needed, widest row in chunks, flags, 0}; `chunks` = rows of the arrays (>= chunks in use), `maxm` = list count the
     search is launched with (>= widest row)."""
 
     def __init__(self, cptr, cnode, meta, chunks, maxm, rows):
@@ -427,39 +429,59 @@ class ChunkLayout:
         return ((c - first) * 64)[:, None] + torch.arange(64, device=self.cptr.device)[None, :]
 
 
-def chunk_layout(k, maxm=CHUNK_MAXM, ccap=None):
+def chunk_maxm_for(ncols):
+    """chunks per row that hold EVERY column of a graph of `ncols` nodes (+ one: the ramp's margin): a row never needs more"""
+    return int(min(CHUNK_MAXM_ANY, (int(ncols) + 63) // 64 + 1))
+
+
+def chunk_layout(k, maxm=None, ccap=None, ncols=None, sticky=None):
     """Layout of the chunked rows for the learned degrees k [rows].  ccap=None: ONE host synchronisation (the chunk count sizes the
-    arrays) -> ChunkLayout with exactly the chunks in use, and `maxm` = the widest row; raises when a row needs more than 64 * maxm
-    ranks.  ccap given (a fixed capacity, e.g. under hipGraph capture): no synchronisation; meta[2] carries the overflow flags."""
+    arrays) -> ChunkLayout with exactly the chunks in use, and `maxm` = the widest row.  ccap given (a fixed capacity, e.g. under
+    hipGraph capture): no synchronisation; meta[2] carries the flags of this call, `sticky` (int32[1] device tensor, optional) collects
+    them over calls -- an overflowing layout is CUT to the capacity on the device (no consumer leaves the arrays).
+    maxm=None: rows of any width -- up to every column of the graph (`ncols`, default = rows; a learned degree beyond that keeps them
+    all, as the reference's dense row does); maxm given: raises ChunkCapacityError when a row needs more than 64 * maxm ranks.  A learned
+    degree that is NaN always raises (synchronising form) / sets flag 4."""
     k = _chk(k)
     rows = k.shape[0]
     dev = k.device
+    limit = maxm is not None
+    if maxm is None:
+        maxm = chunk_maxm_for(rows if ncols is None else ncols)
     meta = torch.empty((4 + 384,), device=dev, dtype=torch.int32)          # {chunks, widest row, flags, 0} + scratch of the two-pass scan
     cptr = torch.empty((rows + 1,), device=dev, dtype=torch.int32)
     if ccap is not None:
         cnode = torch.empty((int(ccap),), device=dev, dtype=torch.int32)
-        _lib.check(_lib.lib().dgg_chunk_layout(_ptr(k), rows, int(maxm), int(ccap), _ptr(cptr), _ptr(cnode), _ptr(meta), _stream()), "chunk_layout")
+        _lib.check(_lib.lib().dgg_chunk_layout(_ptr(k), rows, int(maxm), int(ccap), _ptr(cptr), _ptr(cnode), _ptr(meta), _ptr(sticky), _stream()),
+                   "chunk_layout")
         return ChunkLayout(cptr, cnode, meta, ccap, maxm, rows)
     cap = rows + rows // 4 + 64
     while True:
         cnode = torch.empty((cap,), device=dev, dtype=torch.int32)
-        _lib.check(_lib.lib().dgg_chunk_layout(_ptr(k), rows, int(maxm), cap, _ptr(cptr), _ptr(cnode), _ptr(meta), _stream()), "chunk_layout")
+        _lib.check(_lib.lib().dgg_chunk_layout(_ptr(k), rows, int(maxm), cap, _ptr(cptr), _ptr(cnode), _ptr(meta), None, _stream()), "chunk_layout")
         total, widest, flags, _ = (int(v) for v in meta[:4].cpu())
-        if flags & 1:
+        if flags & 4:
+            raise ChunkCapacityError("chunk_layout: a learned degree is NaN")
+        if (flags & 1) and limit:
             raise ChunkCapacityError(f"chunk_layout: a learned degree needs more than {64 * maxm} ranks (k + 9.5 > {64 * maxm}): beyond the "
-                                     "chunked rows' capacity (or not finite)")
+                                     "capacity the caller allowed")
         if not (flags & 2):
             return ChunkLayout(cptr, cnode[:total], meta, total, max(widest, 1), rows)
         cap = total
 
 
-def allpairs_topk_wide(xp, k, layout, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, seed=(0, 0), rows=None, ramp=True):
-    """allpairs_topk_softk on chunked rows (rows wider than 64 ranks): -> idx, val, w [chunks,64], rs [rows] (w / rs None with
-    ramp=False).  `layout` = chunk_layout(k of these rows)."""
+def allpairs_topk_wide(xp, k, layout, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, seed=(0, 0), rows=None, ramp=True, noise_mode=None):
+    """All-pairs top-L_i on chunked rows (rows wider than 64 ranks, ANY width): -> idx, val, w [chunks,64], rs [rows] (w / rs None with
+    ramp=False).  `layout` = chunk_layout(k of these rows).  noise_mode: NOISE_RANKED (default: the register-list search for the rows
+    of up to 32 chunks + the threshold-buffer walk for the wider ones), NOISE_NONE / NOISE_HASH / NOISE_HASH_SYM (threshold buffers,
+    every row; include/dgg_hip.h, dgg_allpairs_topk_anywide).  NOISE_RANKED_SYM has no wide-row form of its own: callers evaluate wide
+    rows under NOISE_HASH_SYM (the same law, another realisation)."""
     xp, k = _chk(xp), _chk(k)
     N, h = xp.shape
     r0, r1 = (0, N) if rows is None else rows
     assert layout.rows == r1 - r0
+    nm = NOISE_RANKED if noise_mode is None else int(noise_mode)
+    assert nm in (NOISE_NONE, NOISE_HASH, NOISE_HASH_SYM, NOISE_RANKED), f"chunked rows: noise_mode {nm} has no wide-row evaluator"
     C_ = layout.chunks
     idx = torch.empty((C_, 64), device=xp.device, dtype=torch.int32)
     val = torch.empty((C_, 64), device=xp.device, dtype=torch.float32)
@@ -470,9 +492,16 @@ def allpairs_topk_wide(xp, k, layout, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, see
         assert seed.is_cuda and seed.numel() == 2 and seed.element_size() == 4
         dseed, seed = seed, (0, 0)
     pe = _probe_begin()
-    _lib.check(_lib.lib().dgg_allpairs_topk_ranked_wide(_ptr(xp), N, h, r0, r1, t, seed[0], seed[1], _ptr(dseed), _ptr(k), mode, layout.maxm,
-                                                        _ptr(layout.cptr), C_, _ptr(idx), _ptr(val), _ptr(w), _ptr(rs), _stream()),
-               "allpairs_topk_ranked_wide")
+    if nm == NOISE_RANKED:
+        _lib.check(_lib.lib().dgg_allpairs_topk_ranked_wide(_ptr(xp), N, h, r0, r1, t, seed[0], seed[1], _ptr(dseed), _ptr(k), mode, layout.maxm,
+                                                            _ptr(layout.cptr), C_, _ptr(idx), _ptr(val), _ptr(w), _ptr(rs), _stream()),
+                   "allpairs_topk_ranked_wide")
+    if nm != NOISE_RANKED or layout.maxm > CHUNK_MAXM:
+        nb = int(_lib.lib().dgg_allpairs_anywide_ws_bytes(C_, r1 - r0))
+        ws = torch.empty((nb,), device=xp.device, dtype=torch.uint8)
+        _lib.check(_lib.lib().dgg_allpairs_topk_anywide(_ptr(xp), N, h, r0, r1, t, nm, seed[0], seed[1], _ptr(dseed), _ptr(k), mode, layout.maxm,
+                                                        CHUNK_MAXM if nm == NOISE_RANKED else 0, _ptr(layout.cptr), C_, _ptr(idx), _ptr(val),
+                                                        _ptr(w), _ptr(rs), _ptr(ws), nb, _stream()), "allpairs_topk_anywide")
     _probe_end("allpairs_topk", pe)
     return idx, val, w, rs
 

@@ -139,6 +139,7 @@ class ShardedDGGConv:
         self.wide_rows = "off"
         self.wide_cap = None
         self.wide_meta = None
+        self.wide_sticky = None                              # int32[1] on the device: overflow flags of every forward under wide_cap
 
     def check_generator(self):
         """raises if the ranked symmetric noise generator (noise_mode 5) could not settle every row inside its workspace in any
@@ -149,26 +150,41 @@ class ShardedDGGConv:
                                "use noise_mode 3 (per-pair hash) for this data")
 
     def check_wide(self):
-        """raises if a forward under a fixed chunk capacity (wide_cap) could not hold every row's ranks (one synchronisation)"""
+        """raises if a forward under a fixed chunk capacity (wide_cap) could not hold every row's ranks since the last call (one
+        synchronisation).  The flags come from a device word that the layout kernel only ever ORs into (`wide_sticky`): every replay of a
+        captured step is covered, not just the last one.  An overflowing forward is memory-safe -- the layout is cut to the capacity on
+        the device -- but its cut rows are wrong: re-capture with a larger wide_cap."""
+        st = self.wide_sticky
         meta, self.wide_meta = self.wide_meta, None
-        if meta is not None:
-            total, widest, flags, _ = (int(v) for v in meta[:4].cpu())
-            if flags:
-                raise RuntimeError(f"ShardedDGGConv: the chunked rows outgrew their fixed capacity {self.wide_cap} (chunks needed {total}, widest "
-                                   f"row {widest} chunks, flags {flags}): re-capture with a larger wide_cap")
+        if st is None:
+            return
+        flags = int(st.item())
+        if flags:
+            st.zero_()
+            total, widest = (int(v) for v in meta[:2].cpu()) if meta is not None else (-1, -1)
+            raise RuntimeError(f"ShardedDGGConv: the chunked rows outgrew their fixed capacity {self.wide_cap} (flags {flags}: 2 = more chunks than "
+                               f"the capacity, 1 = a row wider than its lists, 4 = a learned degree is NaN; last forward: {total} chunks needed, "
+                               f"widest row {widest}): re-capture with a larger wide_cap")
+
+    WIDE_NOISE = {0: 0, 2: 2, 3: 3, 4: 4, 5: 3}      # noise_mode -> the generator wide rows are evaluated under (ranked symmetric: the
+                                                     # symmetric per-pair hash -- same law, another realisation; no wide-row form of its own)
 
     def _chunk_layout(self, k):
         """-> ops.ChunkLayout for this forward's learned degrees, or None: every row fits the 64-rank list (or wide_rows is off)"""
         kern = self.kern
-        if self.wide_rows == "off" or not hasattr(kern, "chunk_layout") or self.noise_mode != 4 or self.cand is not None or self.K != 64:
+        if self.wide_rows == "off" or not hasattr(kern, "chunk_layout") or self.noise_mode not in self.WIDE_NOISE or self.cand is not None or self.K != 64:
             return None
         if self.wide_cap is not None:
-            lay = kern.chunk_layout(k, maxm=int(self.wide_cap[1]), ccap=int(self.wide_cap[0]))
+            if self.wide_sticky is None or self.wide_sticky.device != k.device:
+                # (allocated by the first forward that runs with a capacity -- normally an eager warm-up; inside a capture the fill below
+                #  would be replayed, i.e. the word would only cover one replay)
+                self.wide_sticky = torch.zeros((1,), device=k.device, dtype=torch.int32)
+            lay = kern.chunk_layout(k, maxm=int(self.wide_cap[1]), ccap=int(self.wide_cap[0]), sticky=self.wide_sticky)
             self.wide_meta = lay.meta
             return lay
         assert not (k.is_cuda and torch.cuda.is_current_stream_capturing()), \
             "ShardedDGGConv: chunked rows inside a hipGraph capture need a fixed capacity (wide_cap = (chunks, lists))"
-        lay = kern.chunk_layout(k)
+        lay = kern.chunk_layout(k, ncols=self.N)
         self.last_layout = (lay.chunks, lay.maxm)
         if not lay.wide and self.wide_rows == "auto":
             return None
@@ -276,17 +292,26 @@ class ShardedDGGConv:
             else:
                 s["idx"], s["val"], s["w"], rs_local = kern.allpairs_topk_softk(xp, s["k"], self.mode, self.t, self.seed, rows=(self.r0, self.r1))
         else:
-            if self.noise_mode == 5 and not hasattr(kern, "rsym_status"):      # (a stand-in kernel namespace without the status plumbing)
-                st = None
+            # the generators without a row-wise early-stopping search (unperturbed scores, per-pair hash noise, the ranked symmetric
+            # generator).  Rows wider than 64 ranks: chunked rows through the threshold-buffer evaluator (any width; the reference's
+            # defaults symmetric_noise=True / perturb_edge_prob=False train into this regime like every other configuration)
+            lay = self._chunk_layout(s["k"]) if (xp.shape[1] in (16, 32, 64, 128) and self.mode in (0, 1)) else None
+            s["layout"] = lay
+            if lay is not None:
+                s["idx"], s["val"], s["w"], rs_local = kern.allpairs_topk_wide(xp, s["k"], lay, self.mode, self.t, self.seed, rows=(self.r0, self.r1),
+                                                                             noise_mode=self.WIDE_NOISE[self.noise_mode])
             else:
-                st = {} if self.noise_mode == 5 else None
-            kw = {} if st is None else {"status": st}
-            s["idx"], s["val"] = kern.allpairs_topk(xp, self.K, self.t, self.noise_mode, None, self.seed,
-                                                    rows=(self.r0, self.r1), algo=self.algo, k_limit=s["k"], **kw)
-            if st and st.get("rsym_err") is not None:      # ranked symmetric generator out of workspace: device flag, read by check_generator()
-                self.rsym_err = st["rsym_err"] if getattr(self, "rsym_err", None) is None else (self.rsym_err | st["rsym_err"])
-                self.rsym_last = st                 # (all three status words of this forward: the module mirror keeps its own tally)
-            s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
+                if self.noise_mode == 5 and not hasattr(kern, "rsym_status"):      # (a stand-in kernel namespace without the status plumbing)
+                    st = None
+                else:
+                    st = {} if self.noise_mode == 5 else None
+                kw = {} if st is None else {"status": st}
+                s["idx"], s["val"] = kern.allpairs_topk(xp, self.K, self.t, self.noise_mode, None, self.seed,
+                                                        rows=(self.r0, self.r1), algo=self.algo, k_limit=s["k"], **kw)
+                if st and st.get("rsym_err") is not None:      # ranked symmetric generator out of workspace: device flag, read by check_generator()
+                    self.rsym_err = st["rsym_err"] if getattr(self, "rsym_err", None) is None else (self.rsym_err | st["rsym_err"])
+                    self.rsym_last = st                 # (all three status words of this forward: the module mirror keeps its own tally)
+                s["w"], rs_local = kern.softk_fwd(s["idx"], s["val"], s["k"], self.mode)
         s["rs"] = rs = _all_gather_rows(rs_local, self.N, self.per, self.group, self.bufs, "rs") if self.coll else rs_local
         if self.emulate is not None:
             s["rs"] = rs = rs_local.repeat(self.world)[:self.N].contiguous()

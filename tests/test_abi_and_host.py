@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), f"libdgg_hip.so does not export {s}"
     # the ctypes prototype table covers the same set (minus the two info functions)
     assert set(dgg_amd._lib.PROTOTYPES) | {"dgg_last_error", "dgg_abi_version"} == set(syms)
-    assert dgg_amd._lib.lib().dgg_abi_version() == 5
+    assert dgg_amd._lib.lib().dgg_abi_version() == 6
 
 
 def test_public_header_is_valid_c():
@@ -142,14 +142,16 @@ def test_wide_row_policies_on_the_host():
                 dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True, symmetric_noise=False, stochastic_k=False,
                 dgg_adj_input="input_adj", n_dgg_layers=1)
     m = dgg_amd.DGG_LearnableK_debug(in_dim=8, latent_dim=16, args=Namespace(**base))
-    assert m._chunk_policy(ops.NOISE_RANKED) and not m._chunk_policy(ops.NOISE_HASH) and not m._chunk_policy(ops.NOISE_RANKED_SYM)
+    # every counter-based generator and unperturbed scores have a wide-row form (round 6); explicit noise tensors keep the CSR form
+    for nm in (ops.NOISE_RANKED, ops.NOISE_HASH, ops.NOISE_HASH_SYM, ops.NOISE_RANKED_SYM, ops.NOISE_NONE):
+        assert m._chunk_policy(nm), nm
+    assert not m._chunk_policy(ops.NOISE_EXPLICIT)
     for pol, want in (("chunked", True), ("csr", False), ("csr_auto", False), ("ell", False)):
         m.args = Namespace(**base, dgg_wide_rows=pol)
-        assert m._chunk_policy(ops.NOISE_RANKED) == want, pol
+        assert m._chunk_policy(ops.NOISE_RANKED) == want and m._chunk_policy(ops.NOISE_NONE) == want, pol
     m.args = Namespace(**base)
-    assert m._chunks_exhausted(3000) and not m._chunk_policy(ops.NOISE_RANKED) and m._ap_wide["on"], "beyond 2048 ranks: the CSR form on small graphs"
+    assert ops.chunk_maxm_for(100_000) == 1564 and ops.chunk_maxm_for(64) == 2, "a row never needs more chunks than hold every column (+ the margin)"
     m2 = dgg_amd.DGG_LearnableK_debug(in_dim=8, latent_dim=16, args=Namespace(**base))
-    assert not m2._chunks_exhausted(100_000), "no exact evaluator for such a row on a large graph: the caller sees the error"
     # edge lists: known before the forward / decided from its learned degrees
     rows = torch.arange(10).repeat_interleave(70)
     A = torch.sparse_coo_tensor(torch.stack([rows, torch.arange(70).repeat(10)]), torch.ones(700), (10, 80)).coalesce()

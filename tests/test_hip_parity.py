@@ -1743,7 +1743,7 @@ def test_module_small_graphs_and_narrow_ell(dev, N, width):
     assert torch.isfinite(x.grad).all() and all(torch.isfinite(p_.grad).all() for p_ in m.parameters() if p_.grad is not None)
 
 
-def _full_size_gradient_parity(s, grads, x, deg, P, tol=2e-4):
+def _full_size_gradient_parity(s, grads, x, deg, P, tol=2e-4, perturb=True):
     """Gradients of EVERY parameter of the benchmarked step against the oracle's backward (O(N K) C code, float64 accumulation) run on
     the forward state the device saved -- idx / val / k / w / ahat / row sums / xp / H / xk -- over the WHOLE graph: the aggregation
     backward (autograd of model.py:594-598), normalisation + ramp (model.py:1205-1219, dgm.py:1402-1421), the score backward
@@ -1757,7 +1757,7 @@ def _full_size_gradient_parity(s, grads, x, deg, P, tol=2e-4):
     G = (Z > 0).astype(np.float32)                                       # cotangent ones through the ReLU
     dA, dH = O.spmm_bwd(idx, ahat, H, G)                                # Z = relu(A H), H = X Wc
     dval, dk = O.softk_norm_bwd(idx, val, k, w, rs, dA)
-    dxp = O.edge_bwd(xp, idx, val, dval, perturb=True)
+    dxp = O.edge_bwd(xp, idx, val, dval, perturb=perturb)
     mu, sd = O.degree_stats(dg)
     k2, z, m, u = O.knet_x(xk, dg, mu, sd, Pn["W1"], Pn["b1"], Pn["Wmu"], Pn["bmu"], Pn["Wp"].reshape(-1), Pn["bp"], save=True)
     assert np.array_equal(k2, k), "learned degrees differ from the oracle's k-net on the device's xk"
