@@ -231,7 +231,7 @@ def run_edgelist(a, dev):
             try:
                 torch.cuda.synchronize()
                 gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr):
+                with torch.cuda.graph(gr, stream=side):               # (capture ON the warm-up's stream: the AccumulateGrad nodes' stream)
                     res = step_fn()
                 gr.replay()
                 torch.cuda.synchronize()

@@ -372,8 +372,11 @@ class _FusedDGGConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, *params)
         ctx.set_materialize_grads(False)
         # second output: the NORMALISED adjacency values [N,K] -- differentiable, for the layers after this one that read the same
-        # adjacency (model.py:1266-1290); its cotangent joins the aggregation's own inside the backward
-        return Z, layer.saved["ahat"]
+        # adjacency (model.py:1266-1290); its cotangent joins the aggregation's own inside the backward.
+        # Both outputs leave as fresh VIEWS: autograd hangs this node on the returned objects, and the tensors kept in `saved` (which the
+        # node's ctx holds) must not be those objects -- output -> grad_fn -> ctx -> saved -> output is a reference cycle that only the
+        # cyclic collector frees, i.e. a step's whole state (gigabytes on chunked rows) stays allocated for an unbounded number of steps
+        return Z.view(Z.shape), layer.saved["ahat"].view(layer.saved["ahat"].shape)
 
     @staticmethod
     def backward(ctx, dZ, dahat):
@@ -417,7 +420,7 @@ class _FusedDGGMlpConvFn(torch.autograd.Function):
         ctx.layer, ctx.state, ctx.scorer = layer, layer.saved, layer.scorer
         ctx.save_for_backward(x, *params)
         ctx.set_materialize_grads(False)
-        return Z, layer.saved["ahat"]
+        return Z.view(Z.shape), layer.saved["ahat"].view(layer.saved["ahat"].shape)       # (fresh views: see _FusedDGGConvFn.forward)
 
     @staticmethod
     def backward(ctx, dZ, dahat):
@@ -670,6 +673,7 @@ class DGG_LearnableK_debug(nn.Module):
         if layer is None or layer.N != N:
             layer = self.__dict__["_fused_layer"] = ShardedDGGConv(ops, N, K=64, t=ops.T_DIST)
         layer.cand, layer.noise_mode, layer.seed, layer.mode, layer.scorer = cand, noise_mode, seed, mode, None
+        layer.sym_fallback, layer.sym_hash = getattr(a, "dgg_sym_generator", "auto") != "ranked", False
         layer.x_grad = bool(x.requires_grad)
         # all-pairs rows wider than the 64-rank list (learned degrees k_i + 9.5 > 64): chunked rows inside the engine, from the forward
         # that first needs them (one readback of the chunk count per forward; a hipGraph capture replays the last eager layout)
@@ -704,6 +708,8 @@ class DGG_LearnableK_debug(nn.Module):
         st = layer.saved
         if noise_mode == ops.NOISE_RANKED_SYM:                # the reference's DEFAULT noise (symmetric_noise=True, dgm.py:1216-1223): the
             self._note_rsym(getattr(layer, "rsym_last", None), N)     # generator's status words, checked by check_ell_bound as for the modules
+            if layer.sym_hash:
+                self._sym_switch()
         if st.get("partp") is None:                           # (shape outside the partitioned backward: the separate modules)
             return self._fused_fallback("shape outside the partitioned backward")
         k = st["k"]
@@ -746,6 +752,17 @@ class DGG_LearnableK_debug(nn.Module):
                                               "the generator, normalize_adj and the layer run as separate modules", why)
         fb[why] = fb.get(why, 0) + 1
         return None
+
+    def _sym_switch(self):
+        """the ranked symmetric generator could not settle a forward on this module's data (redone under the symmetric per-pair hash):
+        the following forwards use the per-pair hash generator directly (same law, another realisation); said once"""
+        if self.__dict__.get("_sym_generator") != "hash":
+            import warnings
+            warnings.warn("DGG_LearnableK_debug: the ranked symmetric noise generator could not settle every row of this forward inside its "
+                          "workspace (rows far from everything else: a property of the latent features); the forward was evaluated under the "
+                          "symmetric per-pair hash generator instead (same law) and this module stays with it "
+                          "(args.dgg_sym_generator = 'ranked' keeps the ranked generator and raises instead)")
+            self._sym_generator = "hash"
 
     def _note_rsym(self, st, N):
         """status words of the ranked symmetric generator (noise_mode 5) of one forward, ORed / maxed into the module's (read by
@@ -1016,6 +1033,7 @@ class DGG_LearnableK_debug(nn.Module):
             noise_mode = ops.NOISE_HASH              # edge-list candidates: every candidate is scored, per-pair hash noise
                                                      # (literal dgg_hard: the full ranking of a row needs per-pair noise as well)
         cfg = dict(cand=cand, K=self.ell_width, t=ops.T_DIST, noise_mode=noise_mode, G=G, seed=seed, algo=self.topk_algo,
+                   sym_fallback=getattr(self.args, "dgg_sym_generator", "auto") != "ranked",
                    mode=ops.MODE_K_TIMES_EDGE_PROB if self.k_select_mode == "k_times_edge_prob" else ops.MODE_K_ONLY)
         if literal and (self.edge_prob_net_mode != "u-v-dist" or x.shape[0] > 8192):
             raise NotImplementedError("dgg_hard_literal: the literal return_hard_or_soft needs the full ranking of every row's N scores "
@@ -1093,6 +1111,8 @@ class DGG_LearnableK_debug(nn.Module):
         k = k.detach()
         if not chunk_checked:                    # (chunk_checked: the layout just read back says every row fits the list)
             self._track_overflow(k, None if cand is None else (rowptr[1:] - rowptr[:-1]))
+        if cfg.get("rsym_fell_back"):
+            self._sym_switch()
         self._note_rsym(cfg, x.shape[0])
         if writer is not None:   # the two scalars the reference logs from inside the DGG (dgm.py:1259-1261)
             f = w.detach() if (cfg["mode"] == ops.MODE_K_ONLY or "fwd_mode" in cfg) else (w.detach() / val.clamp(min=1e-30))

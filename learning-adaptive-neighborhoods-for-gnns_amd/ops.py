@@ -285,7 +285,8 @@ def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed
     """k_limit: learned k of the rows (optional): ranks that the soft top-k ramp zeroes exactly come back as idx = -1.
     status (dict, optional): receives "rsym_err", a 1-element int32 DEVICE tensor that is non-zero when the ranked symmetric
     generator (noise_mode 5) could not settle every row inside its workspace, and "rsym_tier3", the number of rows that took its
-    dense tier (no synchronisation here; the caller checks them)."""
+    dense tier (no synchronisation here; the caller checks them).  status["sym_fallback"] = True on entry: the error word IS read back
+    (one synchronisation, never inside a capture) and a failed forward is redone under NOISE_HASH_SYM, status["rsym_fell_back"] = True."""
     xp = _chk(xp)
     N, h = xp.shape
     r0, r1 = (0, N) if rows is None else rows
@@ -309,6 +310,14 @@ def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed
     if status is not None and noise_mode == NOISE_RANKED_SYM and ws is not None:
         off = int(_lib.lib().dgg_allpairs_rsym_ctl_offset_bytes(r1 - r0, N))
         ctl = ws[off:off + 32].view(torch.int32)
+        if status.get("sym_fallback") and not torch.cuda.is_current_stream_capturing() and bool(ctl[4].item()):
+            # The ranked symmetric generator could not settle every row inside its workspace (more rows far from everything else than
+            # its dense tier holds: a property of the DATA -- latents a few Adam steps into training already do it at N = 100 000): the
+            # rows concerned came back empty.  On request the SAME forward is evaluated again under the symmetric per-pair hash
+            # generator (the same law, another realisation; exact on any data) and the caller is told to stay with it.
+            status["rsym_fell_back"] = True
+            status["rsym_err"] = None
+            return allpairs_topk(xp, K, t, NOISE_HASH_SYM, None, seed, rows, 0, return_ws, k_limit, None)
         status["rsym_err"] = ctl[4:5].clone()
         status["rsym_tier3"] = ctl[3:4].clone()       # rows that needed the dense tier (each one costs a full walk of every owner's sequence)
         # how far below the tier-1 threshold tier 2 had to walk (log-score units; -inf: no row failed): every owner walks that deep

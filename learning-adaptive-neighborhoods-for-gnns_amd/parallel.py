@@ -140,6 +140,11 @@ class ShardedDGGConv:
         self.wide_cap = None
         self.wide_meta = None
         self.wide_sticky = None                              # int32[1] on the device: overflow flags of every forward under wide_cap
+        # symmetric noise (noise_mode 5, the ranked symmetric generator): sym_fallback = redo a forward it cannot settle under the
+        # symmetric per-pair hash (noise_mode 3) and stay there (sym_hash); off by default for the bare engine (bench.py times the
+        # generator it names), on for the nn.Module mirror
+        self.sym_fallback = False
+        self.sym_hash = False
 
     def check_generator(self):
         """raises if the ranked symmetric noise generator (noise_mode 5) could not settle every row inside its workspace in any
@@ -301,13 +306,19 @@ class ShardedDGGConv:
                 s["idx"], s["val"], s["w"], rs_local = kern.allpairs_topk_wide(xp, s["k"], lay, self.mode, self.t, self.seed, rows=(self.r0, self.r1),
                                                                              noise_mode=self.WIDE_NOISE[self.noise_mode])
             else:
-                if self.noise_mode == 5 and not hasattr(kern, "rsym_status"):      # (a stand-in kernel namespace without the status plumbing)
+                nm = 3 if (self.noise_mode == 5 and self.sym_hash) else self.noise_mode
+                if nm == 5 and not hasattr(kern, "rsym_status"):      # (a stand-in kernel namespace without the status plumbing)
                     st = None
                 else:
-                    st = {} if self.noise_mode == 5 else None
+                    # sym_fallback: a forward the ranked symmetric generator cannot settle (its dense tier overflows: data-dependent)
+                    # is redone under the symmetric per-pair hash, and the layer stays with it (one flag read back per forward; not
+                    # inside a capture, not across ranks -- every rank would have to take the same decision)
+                    st = {"sym_fallback": self.sym_fallback and self.world == 1} if nm == 5 else None
                 kw = {} if st is None else {"status": st}
-                s["idx"], s["val"] = kern.allpairs_topk(xp, self.K, self.t, self.noise_mode, None, self.seed,
+                s["idx"], s["val"] = kern.allpairs_topk(xp, self.K, self.t, nm, None, self.seed,
                                                         rows=(self.r0, self.r1), algo=self.algo, k_limit=s["k"], **kw)
+                if st and st.get("rsym_fell_back"):
+                    self.sym_hash = True
                 if st and st.get("rsym_err") is not None:      # ranked symmetric generator out of workspace: device flag, read by check_generator()
                     self.rsym_err = st["rsym_err"] if getattr(self, "rsym_err", None) is None else (self.rsym_err | st["rsym_err"])
                     self.rsym_last = st                 # (all three status words of this forward: the module mirror keeps its own tally)
