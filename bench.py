@@ -872,7 +872,7 @@ class SyntheticRun:
         # TRAINED in (the learned degree is unbounded, dgm.py:1580-1584).  One rank: the eager warm-up steps read the chunk count back,
         # the captured graph replays that layout as a fixed capacity (no wide row at this prior: the plain [N,64] list, same graph as
         # without the option).  Several ranks run eagerly: the list with its enforced bound (no readback per step).
-        self.wide = noise_mode == ops.NOISE_RANKED and world == 1 and not force and not emu and hasattr(ops, "chunk_layout") and h in (16, 32, 64, 128)
+        self.wide = world == 1 and not force and not emu and hasattr(ops, "chunk_layout") and h in (16, 32, 64, 128)
         if self.wide:
             self.layer.wide_rows = "auto"
         self.grads = None
@@ -993,15 +993,19 @@ def cpu_dense_formulation(sizes, threads):
     return out
 
 
-def wide_rows_config(a, dev, prior, N=100_000):
+def wide_rows_config(a, dev, prior, N=100_000, noise_mode=None):
     """The headline step with learned degrees BEYOND the 64-rank list (prior degrees `prior`: k ~ 128, every row three chunks of 64
     ranks -- where a model sits after some tens of Adam steps, tests/test_chunked_rows.py): chunked rows through the same engine,
-    captured into one hipGraph with the chunk count of the warm-up steps as its capacity."""
+    captured into one hipGraph with the chunk count of the warm-up steps as its capacity.  noise_mode: the ranked generator (default),
+    or the reference's own defaults -- symmetric noise (NOISE_RANKED_SYM: wide rows are evaluated under the symmetric per-pair hash),
+    unperturbed scores (NOISE_NONE) -- through the threshold-buffer evaluator (dgg_allpairs_topk_anywide)."""
     import copy
     from dgg_amd import ops
     b = copy.copy(a)
     b.steps, b.warmup, b.repeats = 10, 3, 5
-    run = SyntheticRun(b, dev, 1, 0, False, N, a.feat, a.latent, ops.NOISE_RANKED, prior=prior)
+    if noise_mode is not None:
+        b.steps, b.repeats = 5, 3
+    run = SyntheticRun(b, dev, 1, 0, False, N, a.feat, a.latent, ops.NOISE_RANKED if noise_mode is None else noise_mode, prior=prior)
     times, graphed, eager_T = time_windows(run, b, 1, False, dev, a.hipgraph, b.repeats)
     T = float(np.median(times)) / b.steps
     run.layer.check_wide()
@@ -1082,12 +1086,16 @@ def other_configs(a, dev):
     gc.collect()                                             # (the PPI models' cycles: collected here, not inside the next config's windows)
     torch.cuda.empty_cache()
     torch.set_num_threads(nthreads)                          # (the PPI CPU baseline sets its own count)
-    try:
-        if "k128" in only:
-            res["k128_chunked_rows"] = wide_rows_config(a, dev, (100.0, 164.0))
-    except Exception as e:  # noqa: BLE001
-        res["k128_chunked_rows"] = {"error": repr(e)}
-    torch.cuda.empty_cache()
+    for name, nm_ in (("k128_chunked_rows", None), ("k128_chunked_rows_symmetric", ops.NOISE_RANKED_SYM), ("k128_chunked_rows_unperturbed", ops.NOISE_NONE)):
+        try:
+            if "k128" in only:
+                res[name] = wide_rows_config(a, dev, (100.0, 164.0), noise_mode=nm_)
+                if nm_ is not None:
+                    res[name]["workload"] += {ops.NOISE_RANKED_SYM: "; symmetric noise (symmetric_noise=True): wide rows under the symmetric per-pair hash generator",
+                                              ops.NOISE_NONE: "; unperturbed scores (perturb_edge_prob=False)"}[nm_]
+        except Exception as e:  # noqa: BLE001
+            res[name] = {"error": repr(e)}
+        torch.cuda.empty_cache()
     try:
         if "n500k" not in only:
             return res

@@ -103,6 +103,8 @@ class EllAdjacency:
         """act(A @ X) (torch.mm(adj, x), model.py:594; act = ReLU fuses GCNConv's activation into the aggregation)."""
         # weights produced by the DGG ramp: an exact zero is a saturated ramp whose gradient vanishes too
         if self.layout is not None and self.partp is None:
+            if not ops.backward_will_follow(self._values, X):      # inference (no_grad / a hipGraph capture): the chunked aggregation kernel
+                return ops.spmm_fwd(self.idx, self._values.detach(), X.detach().contiguous(), act, layout=self.layout)
             out = self.to_csr().matmul(X)
             return torch.relu(out) if act == ops.ACT_RELU else out
         return ops.EllSpmmFn.apply(self._values, self.idx, X, self.k is not None, self.part, act, self.partp, self.layout)

@@ -16,11 +16,18 @@
 //                    exhaustive kernel's loop, dgg_topk.hip, with the running top-64 replaced by the buffer)
 //   aw_scan_hash     per-pair hash noise (symmetric or not): log p' <= G + 1e-8 whatever the distance, so a pair whose RAW HASH lies
 //                    below the integer image of the row's threshold is dropped by one unsigned compare (dgg_topk_gv.hip's filter, here
-//                    against the row's own moving threshold); the survivors of a tile (a few per cent) are queued in LDS as (row,
-//                    column) pairs and scored 64 at a time with full lanes -- the N^2 part of the kernel is ~10 integer instructions
-//                    per 64 pairs
+//                    against the row's own moving threshold); the survivors (a fraction of a per cent) are queued in LDS as (row,
+//                    column) pairs and scored 64 at a time with full lanes, their features gathered from global memory -- the N^2
+//                    part of the kernel is ~12 integer instructions per 64 pairs and touches no feature
 //   aw_ranked_walk   ranked generator, rows of more than 32 chunks: the walk of allpairs_topk_ranked_wide (ranks in decreasing noise
 //                    order, stop when the next rank's noise cannot reach the threshold) with the buffer in place of the register lists
+// Measured and not kept for the hash generators (round 6): a per-row guess-and-verify front end in the manner of dgg_topk_gv.hip (threshold
+// from a 64-column pilot of the row, fixed-threshold integer sweep into candidate lists, one scoring pass, verification, this kernel for
+// the rows that fail).  The integer filter can only use log p' <= G + 1e-8 -- it cannot see the distance term -- so at the benchmark's
+// features it admits 1 / E[p^(1/0.3)] = 4.5 candidates for every pair that is really above the threshold: the candidate lists outgrew
+// every capacity that is a small multiple of L_i and all rows fell back (31 ms against 24).  What the moving threshold pays for the same
+// reason: ~3 800 gathered and scored candidates per row at L = 140.  The fix on both sides is a rigorous per-row LOWER BOUND of the
+// distance to any other node (an fp16-MFMA row-minimum sweep), which would tighten the filter to G >= v - t d_min(i); not built.
 // aw_emit (one workgroup per row) sorts the surviving <= L_i keys in LDS (bitonic; rows beyond 4096 keys in buckets of 4096 split off
 // by further selections), writes idx / val / w per chunk and the row sum in the chunk-ordered, lane-wise + butterfly order.
 // Exactness: a key is dropped only when L_i better keys of the same row are known; the hash filter and the walk's stop test drop a
@@ -45,14 +52,17 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
     return v;
 }
 
-// the L-th largest (1-based) of buf[0..n), n >= L >= 1, keys distinct and non-zero; one wavefront, buf in global memory (L2-resident)
-__device__ __noinline__ uint64_t wave_select_lth(const uint64_t *__restrict__ buf, int n, int L, int lane) {
+// A threshold tau (one of the keys) with L <= #{keys >= tau} <= Lmax over buf[0..n), n >= L >= 1, keys distinct and non-zero; Lmax = L:
+// the L-th largest key exactly.  One wavefront, buf in global memory (L2-resident).  Bisection on the key values with a count pass per
+// step, each a round trip to L2: mid-scan compactions take a WINDOW (any threshold that keeps at least L and leaves room in the buffer is
+// as good: the step count falls from ~log2(n) + 1 to ~log2(n / (Lmax - L))), the final one of a row is exact.
+__device__ __noinline__ uint64_t wave_select_lth(const uint64_t *__restrict__ buf, int n, int L, int Lmax, int lane) {
     uint64_t mn = ~0ull, mx = 0ull;
     for (int e = lane; e < n; e += 64) { const uint64_t k = buf[e]; mn = k < mn ? k : mn; mx = k > mx ? k : mx; }
     mn = wave_min_u64(mn);
     mx = wave_max_u64(mx);
-    if (L >= n) return mn;
-    uint64_t lo = mn, hi = mx + 1ull;                            // count(>= lo) >= L, count(>= hi) < L
+    if (L >= n || Lmax >= n) return mn;
+    uint64_t lo = mn, hi = mx + 1ull;                            // count(>= lo) > Lmax, count(>= hi) < L
     while (hi - lo > 1ull) {
         const uint64_t mid = lo + ((hi - lo) >> 1);
         int c = 0;
@@ -69,24 +79,39 @@ __device__ __noinline__ uint64_t wave_select_lth(const uint64_t *__restrict__ bu
         for (; e < n; e += 64) { const uint64_t k = buf[e]; c += k >= mid; if (k >= mid && k < m2) m2 = k; }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
-        if (c == L) return wave_min_u64(m2);                     // exactly L keys at or above mid: the smallest of them is the L-th
-        if (c > L) lo = mid; else hi = mid;
+        if (c >= L && c <= Lmax) return wave_min_u64(m2);        // the smallest key at or above mid keeps exactly c keys
+        if (c > Lmax) lo = mid; else hi = mid;
     }
     return lo;
 }
-// keeps the keys >= tau at the front of buf (order preserved) -> their count
+// keeps the keys >= tau at the front of buf (order preserved) -> their count.  Four batches of 64 keys per step, the next step's loads
+// issued before this step's stores (they land on positions already read: a store never reaches a key that is still to be loaded)
 __device__ __noinline__ int wave_compact_ge(uint64_t *__restrict__ buf, int n, uint64_t tau, int lane) {
     int at = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int e = base + lane;
-        const uint64_t k = e < n ? buf[e] : 0ull;
-        const bool keep = e < n && k >= tau;
-        const uint64_t m = __ballot(keep);
-        const int pos = at + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (keep) buf[pos] = k;                                  // pos <= e: only positions already read are written
-        at += __builtin_popcountll(m);
+    uint64_t cur[4], nxt[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int e = 64 * q + lane; cur[q] = e < n ? buf[e] : 0ull; }
+    for (int base = 0; base < n; base += 256) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int e = base + 256 + 64 * q + lane; nxt[q] = e < n ? buf[e] : 0ull; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const bool keep = cur[q] >= tau && cur[q] != 0ull;   // (positions beyond n were loaded as 0, no key is 0)
+            const uint64_t m = __ballot(keep);
+            const int pos = at + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (keep) buf[pos] = cur[q];
+            at += __builtin_popcountll(m);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur[q] = nxt[q];
     }
     return at;
+}
+// window of a mid-scan compaction: keep between L and L + L / 4 + 16 keys, never more than leaves 64 free slots
+__device__ __forceinline__ int keep_window(int L, int cap) {
+    int hi = L + (L >> 2) + 16;
+    hi = hi > cap - 64 ? cap - 64 : hi;
+    return hi < L ? L : hi;
 }
 
 // pairs whose raw 32-bit hash is below the result have noise G < gmin - 1e-3 (dgg_topk_gv.hip, hash_threshold_from_gmin): P(G >= g) =
@@ -168,7 +193,7 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_plain(const float *__restr
                 if (g.cap == 0) continue;                        // (a fixed capacity ran out before this row: no chunk)
                 uint64_t *buf = keys + g.base;
                 if (cnt[r] + __builtin_popcountll(m) > g.cap) {  // full: keep the L best, raise the threshold
-                    thr[r] = wave_select_lth(buf, cnt[r], g.L, lane);
+                    thr[r] = wave_select_lth(buf, cnt[r], g.L, keep_window(g.L, g.cap), lane);
                     cnt[r] = wave_compact_ge(buf, cnt[r], thr[r], lane);
                     pass = key > thr[r];
                     m = __ballot(pass);
@@ -187,7 +212,7 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_plain(const float *__restr
         int n = cnt[r];
         if (n > g.L && g.cap > 0) {
             uint64_t *buf = keys + g.base;
-            const uint64_t tau = wave_select_lth(buf, n, g.L, lane);
+            const uint64_t tau = wave_select_lth(buf, n, g.L, g.L, lane);
             n = wave_compact_ge(buf, n, tau, lane);
         }
         if (lane == 0) cnt_out[i - row0] = n;
@@ -195,60 +220,79 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_plain(const float *__restr
 }
 
 // ---- per-pair hash noise: integer filter on every pair, exact scores for the survivors -----------------------------------------------
+// A wavefront owns 16 rows and walks ALL columns 64 at a time (lane = column) with integer work only: the raw hash of (row, column)
+// against the integer image of the row's threshold.  No feature is touched in that loop and there is no barrier in it -- the first
+// form of this kernel staged every column tile through LDS for the handful of survivors it holds and spent 9/10 of its time there
+// (41 ms at N = 100 000, k ~ 130).  Survivors are queued as (row, column) in LDS across column blocks and scored 64 at a time with
+// full lanes: the row's features from LDS, the column's as sixteen independent 16-byte gathers (the ranked search's access pattern).
+#define WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+constexpr int QCAP = RW * 64 + 64;                               // queue slots per wavefront: < 64 left over + at most 16 x 64 new
 template <int H, bool SYM>
 __global__ __launch_bounds__(WAVES * 64) void aw_scan_hash(const float *__restrict__ xp, int64_t N, int64_t row0, int64_t row1, float t,
                                                            uint32_t s0, uint32_t s1, const uint32_t *__restrict__ seed_dev,
                                                            const float *__restrict__ klim, const int32_t *__restrict__ cptr,
                                                            uint64_t *__restrict__ keys, int32_t *__restrict__ cnt_out) {
     constexpr int RS = H + 4;                                    // padded row stride (floats): 16-byte aligned, rows 4 banks apart
-    __shared__ __attribute__((aligned(16))) float colR[TN * RS];
     __shared__ __attribute__((aligned(16))) float rowsL[RB * RS];
+    __shared__ int s_row[RB];                                    // local row id of every row slot of the workgroup, -1: none
+    // (NOT volatile: hipcc turns volatile LDS accesses into FLAT instructions with system-scope cache bits and a full memory wait
+    //  behind each -- 43 of them in the first form of this kernel.  The lanes of a wavefront exchange data through these arrays;
+    //  wavefront-scope fences keep the compiler from caching across the exchanges, the hardware executes a wavefront's LDS
+    //  instructions in order)
     __shared__ uint64_t s_thr[WAVES][RW];
     __shared__ int64_t s_base[WAVES][RW];
     __shared__ int s_cnt[WAVES][RW], s_cap[WAVES][RW], s_L[WAVES][RW];
-    __shared__ unsigned short s_q[WAVES][RW * 64];        // (row, column) pairs of the current tile that passed the integer filter
+    __shared__ uint32_t s_q[WAVES][QCAP];                        // (row << 28 | column) of the pairs that passed the integer filter
     const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id();
     if (seed_dev) { s0 = seed_dev[0]; s1 = seed_dev[1]; }
-    const int64_t rbase = row0 + (int64_t)blockIdx.x * RB;
+    if (tid < RB) {
+        const int64_t q = (int64_t)blockIdx.x * RB + tid;
+        s_row[tid] = q < row1 - row0 ? (int)q : -1;
+    }
+    __syncthreads();
     for (int e = tid; e < RB * H; e += WAVES * 64) {
         const int r = e / H, c = e % H;
-        const int64_t gi = rbase + r;
-        rowsL[r * RS + c] = gi < row1 ? xp[gi * H + c] : 0.0f;
+        const int lr_ = s_row[r];
+        rowsL[r * RS + c] = lr_ >= 0 ? xp[(row0 + lr_) * H + c] : 0.0f;
     }
     if (lane < RW) {
         s_thr[wave][lane] = DGG_EMPTY_KEY;
         s_cnt[wave][lane] = 0;
-        const int64_t li = rbase + wave * RW + lane - row0;
-        const RowGeom g0 = li < row1 - row0 ? row_geom(cptr, klim, li) : RowGeom{0, 0, 0};
+        const int li = s_row[wave * RW + lane];
+        const RowGeom g0 = li >= 0 ? row_geom(cptr, klim, li) : RowGeom{0, 0, 0};
         s_base[wave][lane] = g0.base; s_cap[wave][lane] = g0.cap; s_L[wave][lane] = g0.L;
     }
-    __syncthreads();
-    volatile uint64_t *vthr = s_thr[wave];
-    volatile int *vcnt = s_cnt[wave];
-    volatile unsigned short *vq = s_q[wave];
+    __syncthreads();                                             // (the last barrier: the wavefronts are independent from here on)
     uint32_t uthr[RW];                                           // integer image of the rows' thresholds (wave-uniform)
-    uint32_t rk1[RW], rk2[RW];                                   // the rows' hash keys (wave-uniform)
+    uint32_t rk1[RW], rk2[RW], rid[RW];                          // the rows' hash keys and global ids (wave-uniform; id 0xffffffff: no row)
 #pragma unroll
     for (int r = 0; r < RW; r++) {
         uthr[r] = 0u;
-        rowkey(s0, s1, (uint32_t)(rbase + wave * RW + r), rk1[r], rk2[r]);
+        const int li = __builtin_amdgcn_readfirstlane(s_row[wave * RW + r]);
+        rid[r] = li >= 0 ? (uint32_t)(row0 + li) : 0xffffffffu;
+        rowkey(s0, s1, rid[r], rk1[r], rk2[r]);
     }
-    int qn = 0;                                                  // queued (row, column) pairs of this wavefront (wave-uniform)
+    const bool anyrow = rid[0] != 0xffffffffu;                   // (row slots fill from the front)
+    int qn = 0;                                                  // queued pairs of this wavefront (wave-uniform)
 
     // score up to 64 queued pairs (lane e < nd takes queue entry off + e) and append the keys above their rows' thresholds
-    auto drain = [&](int nd, int off, int64_t j0) {
+    auto drain = [&](int nd, int off) {
+        WAVE_FENCE();
         const bool have = lane < nd;
-        const int ent = have ? (int)vq[off + lane] : 0;
-        const int r = ent >> 6, jj = ent & 63;
-        const int64_t i = rbase + wave * RW + r, j = j0 + jj;
+        const uint32_t ent = have ? s_q[wave][off + lane] : 0u;
+        const int r = (int)(ent >> 28);
+        const int64_t i = row0 + s_row[wave * RW + r], j = (int64_t)(ent & 0x0fffffffu);
         uint64_t key = DGG_EMPTY_KEY;
         if (have) {
             const float4 *xi = reinterpret_cast<const float4 *>(rowsL + (wave * RW + r) * RS);
-            const float4 *xj = reinterpret_cast<const float4 *>(colR + jj * RS);
+            const float4 *xj = reinterpret_cast<const float4 *>(xp + j * H);
+            float4 bq[H / 4];
+#pragma unroll
+            for (int c4 = 0; c4 < H / 4; c4++) bq[c4] = xj[c4];  // all gathers of the candidate in flight before the first use
             float d2 = 0.0f;
 #pragma unroll
             for (int c4 = 0; c4 < H / 4; c4++) {
-                const float4 a = xi[c4], b = xj[c4];
+                const float4 a = xi[c4], b = bq[c4];
                 float df;
                 df = __fadd_rn(a.x, -b.x); d2 = __fmaf_rn(df, df, d2);
                 df = __fadd_rn(a.y, -b.y); d2 = __fmaf_rn(df, df, d2);
@@ -258,8 +302,8 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_hash(const float *__restri
             const float g = pair_noise(s0, s1, (uint32_t)i, (uint32_t)j, SYM);
             key = make_key(score_from_dist(c_sqrt(d2), t, true, g), (int32_t)j);
         }
-        bool valid = have && key > vthr[r];
-        int pos = valid ? atomicAdd(&s_cnt[wave][r], 1) : 0;
+        const bool valid = have && key > s_thr[wave][r];
+        const int pos = valid ? atomicAdd(&s_cnt[wave][r], 1) : 0;
         const RowGeom g = RowGeom{s_base[wave][r], s_cap[wave][r], s_L[wave][r]};
         if (valid && pos < g.cap) keys[g.base + pos] = key;
         bool over = valid && pos >= g.cap;
@@ -269,17 +313,15 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_hash(const float *__restri
             const int R = __builtin_amdgcn_readlane(r, src);
             const RowGeom gR = RowGeom{s_base[wave][R], s_cap[wave][R], s_L[wave][R]};
             const bool mine = over && r == R;
-            uint64_t tau = DGG_EMPTY_KEY;
+            uint64_t tau = ~0ull;                                // (a row without a chunk keeps nothing)
             int kept = 0;
             if (gR.cap > 0) {
                 uint64_t *buf = keys + gR.base;
-                tau = wave_select_lth(buf, gR.cap, gR.L, lane);
+                tau = wave_select_lth(buf, gR.cap, gR.L, keep_window(gR.L, gR.cap), lane);
                 kept = wave_compact_ge(buf, gR.cap, tau, lane);
-            } else {
-                tau = ~0ull;                                     // (no chunk: nothing can be kept)
             }
-            if (lane == 0) { vthr[R] = tau; vcnt[R] = kept; }
-            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) { s_thr[wave][R] = tau; s_cnt[wave][R] = kept; }
+            WAVE_FENCE();
             const uint32_t ut = uthr_from_key(tau);
 #pragma unroll
             for (int q = 0; q < RW; q++) uthr[q] = q == R ? ut : uthr[q];
@@ -292,52 +334,66 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_hash(const float *__restri
         }
     };
 
-    for (int64_t j0 = 0; j0 < N; j0 += TN) {
-        __syncthreads();
-        for (int e = tid; e < TN * H; e += WAVES * 64) {
-            const int jj = e / H, c = e % H;
-            const int64_t gj = j0 + jj;
-            colR[jj * RS + c] = gj < N ? xp[gj * H + c] : 0.0f;
-        }
-        __syncthreads();
-        const int64_t j = j0 + lane;
-        const bool jvalid = j < N;
-        uint32_t ck1 = 0u, ck2 = 0u;                             // symmetric noise: a pair below the diagonal is keyed by its COLUMN
-        if (SYM) rowkey(s0, s1, (uint32_t)j, ck1, ck2);
+    if (anyrow) {
+        for (int64_t j0 = 0; j0 < N; j0 += 64) {
+            const uint32_t j = (uint32_t)j0 + (uint32_t)lane;
+            const bool jvalid = (int64_t)j < N;
+            uint32_t ck1 = 0u, ck2 = 0u;                         // symmetric noise: a pair below the diagonal is keyed by its COLUMN
+            if (SYM) rowkey(s0, s1, j, ck1, ck2);
+            // the 16 rows' filters back to back (no control flow between the independent hash chains), ONE test for "any survivor"
+            uint64_t m[RW];
+            uint64_t any = 0ull;
 #pragma unroll
-        for (int r = 0; r < RW; r++) {
-            const int64_t i = rbase + wave * RW + r;
-            if (i >= row1) continue;                             // wave-uniform
-            uint32_t k1 = rk1[r], k2 = rk2[r], b = (uint32_t)j;
-            if (SYM && j < i) { k1 = ck1; k2 = ck2; b = (uint32_t)i; }
-            uint32_t x = b ^ k1;                                 // pair_u24_keyed before the shift
-            x *= 0x7feb352dU; x ^= x >> 15; x += k2; x *= 0x846ca68bU;
-            const bool pass = jvalid && (x >= uthr[r] || (SYM && j == i));
-            const uint64_t m = __ballot(pass);
-            if (m != 0ull) {
-                const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (pass) vq[pos] = (unsigned short)(r * 64 + lane);
-                qn += __builtin_popcountll(m);
+            for (int r = 0; r < RW; r++) {
+                const uint32_t i = rid[r];
+                uint32_t k1 = rk1[r], k2 = rk2[r], b = j;
+                if (SYM && j < i) { k1 = ck1; k2 = ck2; b = i; }
+                uint32_t x = b ^ k1;                             // pair_u24_keyed before the shift
+                x *= 0x7feb352dU; x ^= x >> 15; x += k2; x *= 0x846ca68bU;
+                const bool pass = jvalid && i != 0xffffffffu && (x >= uthr[r] || (SYM && j == i));
+                m[r] = __ballot(pass);
+                any |= m[r];
+            }
+            if (any != 0ull) {
+#pragma unroll
+                for (int r = 0; r < RW; r++) {
+                    if (m[r] != 0ull) {                          // wave-uniform
+                        const bool pass = (m[r] >> lane) & 1ull;
+                        const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[r], 0u));
+                        if (pass) s_q[wave][pos] = ((uint32_t)r << 28) | j;
+                        qn += __builtin_popcountll(m[r]);
+                    }
+                }
+            }
+            if (qn >= 64) {
+                WAVE_FENCE();
+                int off = 0;
+                for (; off + 64 <= qn; off += 64) drain(64, off);
+                const int rest = qn - off;                       // < 64 pairs stay queued: moved to the front
+                const uint32_t mv = lane < rest ? s_q[wave][off + lane] : 0u;
+                WAVE_FENCE();
+                if (lane < rest) s_q[wave][lane] = mv;
+                qn = rest;
+                WAVE_FENCE();
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        for (int off = 0; off < qn; off += 64) drain(qn - off < 64 ? qn - off : 64, off, j0);     // (the queue refers to this tile's columns)
-        qn = 0;
+        WAVE_FENCE();
+        if (qn > 0) drain(qn, 0);
     }
-    __builtin_amdgcn_wave_barrier();
+    WAVE_FENCE();
 #pragma unroll
     for (int r = 0; r < RW; r++) {
-        const int64_t i = rbase + wave * RW + r;
-        if (i >= row1) continue;
+        const int li = __builtin_amdgcn_readfirstlane(s_row[wave * RW + r]);
+        if (li < 0) continue;
         const RowGeom g = RowGeom{s_base[wave][r], s_cap[wave][r], s_L[wave][r]};
-        int n = vcnt[r];
+        int n = s_cnt[wave][r];
         n = n > g.cap ? g.cap : n;
         if (n > g.L && g.cap > 0) {
             uint64_t *buf = keys + g.base;
-            const uint64_t tau = wave_select_lth(buf, n, g.L, lane);
+            const uint64_t tau = wave_select_lth(buf, n, g.L, g.L, lane);
             n = wave_compact_ge(buf, n, tau, lane);
         }
-        if (lane == 0) cnt_out[i - row0] = n;
+        if (lane == 0) cnt_out[li] = n;
     }
 }
 
@@ -404,7 +460,7 @@ __global__ __launch_bounds__(256) void aw_ranked_walk(const float *__restrict__ 
         uint64_t m = __ballot(pass);
         if (m != 0ull) {
             if (cnt + __builtin_popcountll(m) > g.cap) {
-                thr = wave_select_lth(buf, cnt, g.L, lane);
+                thr = wave_select_lth(buf, cnt, g.L, keep_window(g.L, g.cap), lane);
                 cnt = wave_compact_ge(buf, cnt, thr, lane);
                 thr_log = __logf(fmaxf(key_val(thr), 1e-37f));
                 pass = pass && key > thr;
@@ -425,7 +481,7 @@ __global__ __launch_bounds__(256) void aw_ranked_walk(const float *__restrict__ 
         }
     }
     if (cnt > g.L) {
-        const uint64_t tau = wave_select_lth(buf, cnt, g.L, lane);
+        const uint64_t tau = wave_select_lth(buf, cnt, g.L, g.L, lane);
         cnt = wave_compact_ge(buf, cnt, tau, lane);
     }
     if (lane == 0) cnt_out[lrow] = cnt;
@@ -601,9 +657,11 @@ int launch_anywide(const float *xp, int64_t N, int64_t row0, int64_t row1, float
 extern "C" {
 
 // bytes of workspace dgg_allpairs_topk_anywide needs for arrays of `ccap` chunks and `rows` rows: 128 keys of 8 bytes per chunk + a count per row
+static inline size_t aw_al(size_t b) { return (b + 255) & ~(size_t)255; }
+// bytes of workspace dgg_allpairs_topk_anywide needs for arrays of `ccap` chunks and `rows` rows: 128 keys of 8 bytes per chunk + a count per row
 size_t dgg_allpairs_anywide_ws_bytes(int64_t ccap, int64_t rows) {
     if (ccap < 0 || rows < 0) return 0;
-    return (size_t)ccap * KSLOT * sizeof(uint64_t) + (((size_t)rows * sizeof(int32_t) + 255) & ~(size_t)255) + 256;
+    return aw_al((size_t)ccap * KSLOT * sizeof(uint64_t)) + aw_al((size_t)rows * 4) + 256;
 }
 
 // All-pairs top-L_i on CHUNKED rows of any width (include/dgg_hip.h).  noise_mode 0 (unperturbed), 2 (per-pair hash), 3 (symmetric per-pair
@@ -619,12 +677,12 @@ int dgg_allpairs_topk_anywide(const float *xp, int64_t N, int h, int64_t row0, i
         return dgg_set_error(DGG_ERR_UNSUPPORTED, "allpairs_topk_anywide: noise_mode none (0), hash (2), symmetric hash (3) or ranked (4)");
     if (maxm < 1 || maxm > DGG_CHUNK_MAXM_ANY || min_m < 0 || (noise_mode != 4 && min_m != 0))
         return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_anywide: maxm in 1..2^20; min_m = 0 unless the generator is the ranked one");
-    if (N >= ((int64_t)1 << 31) || ccap >= ((int64_t)1 << 24)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "allpairs_topk_anywide: N < 2^31, ccap < 2^24");
+    if (N >= ((int64_t)1 << 28) || ccap >= ((int64_t)1 << 24)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "allpairs_topk_anywide: N < 2^28, ccap < 2^24");
     if (!workspace || ws_bytes < dgg_allpairs_anywide_ws_bytes(ccap, row1 - row0))
         return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_anywide: workspace missing or smaller than dgg_allpairs_anywide_ws_bytes");
     if (row1 == row0) return 0;
     uint64_t *keys = reinterpret_cast<uint64_t *>(workspace);
-    int32_t *cnt = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(workspace) + (size_t)ccap * KSLOT * sizeof(uint64_t));
+    int32_t *cnt = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(workspace) + aw_al((size_t)ccap * KSLOT * sizeof(uint64_t)));
     hipStream_t st = (hipStream_t)stream;
     switch (h) {
         case 16: return launch_anywide<16>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, st);

@@ -138,7 +138,7 @@ class _DGGSoftAdjXpFn(torch.autograd.Function):
             idx, val = ops.edgelist_topk(xp, rowptr, col, cfg["K"], cfg["t"], cfg["noise_mode"], cfg["G"], cfg["seed"])
         w, rs = ops.softk_fwd(idx, val, k, cfg.get("fwd_mode", cfg["mode"]))
         ctx.cfg = cfg
-        cfg["part"] = ops.part_build(idx, w, xp.shape[0]) if any(ctx.needs_input_grad) else None
+        cfg["part"] = ops.part_build(idx, w, xp.shape[0]) if cfg.get("want_bwd", any(ctx.needs_input_grad)) else None
         ctx.save_for_backward(xp, k, idx, val)
         ctx.mark_non_differentiable(idx, val, rs)
         return w, idx, val, rs
@@ -169,7 +169,7 @@ class _DGGWideAdjFn(torch.autograd.Function):
         idx, val, w, rs = ops.allpairs_topk_wide(xp, k, lay, cfg.get("fwd_mode", cfg["mode"]), cfg["t"], cfg["seed"],
                                                  noise_mode=cfg.get("wide_noise", ops.NOISE_RANKED))
         ctx.cfg = cfg
-        cfg["partp"] = ops.partp_build(idx, w, val, rs, xp.shape[0], layout=lay) if any(ctx.needs_input_grad) else None
+        cfg["partp"] = ops.partp_build(idx, w, val, rs, xp.shape[0], layout=lay) if cfg.get("want_bwd", any(ctx.needs_input_grad)) else None
         ctx.save_for_backward(xp, k, idx, val)
         ctx.mark_non_differentiable(idx, val, rs)
         return w, idx, val, rs
@@ -203,7 +203,7 @@ class _DGGSoftAdjFn(torch.autograd.Function):
         ctx.cfg = cfg
         # destination-ordered partition of the active entries: the column-side terms of the backward run on it instead of
         # entry-wise float atomics (built only when a backward can follow)
-        cfg["part"] = ops.part_build(idx, w, x.shape[0]) if any(ctx.needs_input_grad) else None
+        cfg["part"] = ops.part_build(idx, w, x.shape[0]) if cfg.get("want_bwd", any(ctx.needs_input_grad)) else None
         ctx.save_for_backward(x, We, xp, k, idx, val)
         ctx.mark_non_differentiable(idx, val, rs)
         return w, idx, val, rs
@@ -366,7 +366,8 @@ class _FusedDGGConvFn(torch.autograd.Function):
     def forward(ctx, x, deg, layer, *params):
         x, params, ctx.d_orig = _pad_features(x, params, layer.PARAM_KEYS)
         P = dict(zip(layer.PARAM_KEYS, params))
-        layer.want_backward = any(ctx.needs_input_grad)          # (False under torch.no_grad(): the partition's sort is skipped)
+        # (layer.want_backward was set by forward_conv BEFORE .apply(): grad mode is always off in here, and ctx.needs_input_grad says
+        #  (True, ...) under torch.no_grad() too)
         Z = layer.forward(x, deg, P)
         ctx.layer, ctx.state = layer, layer.saved
         ctx.save_for_backward(x, *params)
@@ -415,7 +416,6 @@ class _FusedDGGMlpConvFn(torch.autograd.Function):
             Wcat, wdu, wdv, wex = torch.cat([W0[:, :h_], W0[:, h_:2 * h_]], 0), pick(cols[0]), pick(cols[1]), pick(cols[2])
             w2 = w2.detach().reshape(-1)
         layer.scorer = dict(sc_static, Wcat=det(Wcat), wdu=det(wdu), wdv=det(wdv), wex=det(wex), b1=det(b1), w2=det(w2), b2=det(b2))
-        layer.want_backward = any(ctx.needs_input_grad)
         Z = layer.forward(x, deg, P)
         ctx.layer, ctx.state, ctx.scorer = layer, layer.saved, layer.scorer
         ctx.save_for_backward(x, *params)
@@ -700,6 +700,8 @@ class DGG_LearnableK_debug(nn.Module):
         params = (self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias, self.node_encode_for_k[0].weight,
                   self.node_encode_for_k[0].bias, self.k_embed[0].weight, self.k_embed[0].bias, kn.k_mu.weight, kn.k_mu.bias,
                   kn.k_project.weight, kn.k_project.bias, conv_weight)
+        # no backward can follow (torch.no_grad(), frozen parameters): the partition's sort -- read by the backward only -- is skipped
+        layer.want_backward = ops.backward_will_follow(x, *params, *([mlp["Wcat"], mlp["b1"], mlp["w2"], mlp["b2"]] if mlp_mode else []))
         if mlp_mode:
             Z, ahat = _FusedDGGMlpConvFn.apply(x, deg, layer, sc_static, mlp["Wcat"], mlp["wdu"], mlp["wdv"], mlp["wex"], mlp["b1"],
                                                mlp["w2"], mlp["b2"], *params)
@@ -1084,6 +1086,7 @@ class DGG_LearnableK_debug(nn.Module):
                 cfg["layout"] = lay
                 cfg["wide_noise"] = {ops.NOISE_RANKED_SYM: ops.NOISE_HASH_SYM}.get(noise_mode, noise_mode)
                 xp = xp_dual if xp_dual is not None else ops.LinearFn.apply(x, We, be, ops.ACT_LEAKY, 0)
+                cfg["want_bwd"] = ops.backward_will_follow(xp, k)
                 w, idx, val, rs = _DGGWideAdjFn.apply(xp, k, cfg)
                 if writer is not None:
                     f = w.detach() if (cfg["mode"] == ops.MODE_K_ONLY or "fwd_mode" in cfg) else (w.detach() / val.clamp(min=1e-30))
@@ -1100,8 +1103,10 @@ class DGG_LearnableK_debug(nn.Module):
             nm = {ops.NOISE_RANKED: ops.NOISE_HASH, ops.NOISE_RANKED_SYM: ops.NOISE_HASH_SYM}.get(noise_mode, noise_mode)
             return self._csr_soft_adjacency(x, None, k, nm, G, seed, cfg["mode"], pattern=self._allpairs_pattern(x.shape[0], x.device), deg=deg)
         if self.edge_prob_net_mode == "u-v-dist" and xp_dual is not None:
+            cfg["want_bwd"] = ops.backward_will_follow(xp_dual, k)
             w, idx, val, rs = _DGGSoftAdjXpFn.apply(xp_dual, k, cfg)
         elif self.edge_prob_net_mode == "u-v-dist":
+            cfg["want_bwd"] = ops.backward_will_follow(x, k, We, be)
             w, idx, val, rs = _DGGSoftAdjFn.apply(x, k, We, be, cfg)
         else:
             mlp, ex_in = self._edge_mlp_terms(avals)

@@ -487,6 +487,7 @@ class GCNII_DGG(nn.Module):
                 p_ = float(self.dropout) if self.training else 0.0
                 y = ops.GcniiStackBf16Fn.apply(layer_inner, norm_adj.values(), norm_adj.idx, norm_adj.part, norm_adj.k is not None,
                                                self._residual, p_, float(self.lamda), float(self.alpha), (int(seed[0]), int(seed[1])),
+                                               ops.backward_will_follow(layer_inner, norm_adj.values(), *[con.weight for con in self.convs]),
                                                *[con.weight for con in self.convs])
                 return self.fcs[-1](y), unnorm_adj
             # (rows wider than the list: a CSR adjacency -- the layers one by one, below)

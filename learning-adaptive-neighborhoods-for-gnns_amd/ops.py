@@ -93,6 +93,13 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def backward_will_follow(*tensors):
+    """True when autograd will record the op about to be applied to `tensors` (grad mode on and some input requires grad).  It has to
+    be evaluated by the CALLER of a torch.autograd.Function: inside Function.forward grad mode is always off, and ctx.needs_input_grad
+    reflects the inputs' requires_grad flags whatever the grad mode (it is (True, ...) under torch.no_grad())."""
+    return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)
+
+
 _KEEP = collections.deque(maxlen=64)
 
 
@@ -1813,7 +1820,8 @@ class GcniiStackBf16Fn(torch.autograd.Function):
     significant bits as well -- BASELINE configs[4] is "bf16 fwd+bwd" -- where GcniiVariantBf16Fn rounds only the product operands."""
 
     @staticmethod
-    def forward(ctx, h0, ahat, idx, part, skip_zero, residual, p, lamda, alpha, seed, *weights):
+    def forward(ctx, h0, ahat, idx, part, skip_zero, residual, p, lamda, alpha, seed, train, *weights):
+        # train: backward_will_follow(h0, ahat, *weights), evaluated by the caller (an eval forward packs one weight layout, not two)
         n, F = h0.shape
         L = len(weights)
         assert F % 256 == 0 and all(tuple(W.shape) == (2 * F, F) for W in weights)
@@ -1828,7 +1836,7 @@ class GcniiStackBf16Fn(torch.autograd.Function):
         else:
             xd, xdb = (dropout_hash(h0c, p, s0, s1) if p > 0 else h0c), None
         his, xds, xdbs, wps = [], [xd], [xdb], []
-        train = any(ctx.needs_input_grad)                        # a backward will follow: it re-uses this forward's weight packs
+        train = bool(train)                                      # a backward will follow: it re-uses this forward's weight packs
         # the product operand cat[bf16(hi) | bf16(h0)] [n, 2F]: the right half once per stack, the left half by every layer's aggregation
         if STACK_SPLIT_EPILOGUE:
             hib, ldh = torch.empty((n, 2 * F), device=h0.device, dtype=torch.bfloat16), 2 * F
@@ -1904,7 +1912,7 @@ class GcniiStackBf16Fn(torch.autograd.Function):
             Wp = ctx.wps[l - 1] if ctx.wps is not None else _packed_weight(W, False)
             _lib.check(_lib.lib().dgg_gcnii_dsupport_bf16_b(_ptr(Gp), _ptr(Wp), n, F, _ptr(gout), float(theta), float(alpha),
                                                             _ptr(dhi), _ptr(dh0), _ptr(dhib), int(l != L), _stream()), "gcnii_dsupport_bf16")   # d h0: summed over the layers in the epilogue
-            if ctx.needs_input_grad[10 + l - 1]:
+            if ctx.needs_input_grad[11 + l - 1]:
                 hiT = pack_bf16(hi, transpose=True)
                 dW = torch.empty_like(W)
                 _lib.check(_lib.lib().dgg_gemm_nt_bf16_rows2(_ptr(hiT), _ptr(h0T), F, _ptr(GT), 2 * F, F, n64, float(theta), _ptr(dW), _stream()),
@@ -1931,7 +1939,7 @@ class GcniiStackBf16Fn(torch.autograd.Function):
         else:
             dh0.add_(gx)
         _probe_end("gcnii_stack_bwd", pe)
-        return (dh0, dA, None, None, None, None, None, None, None, None) + tuple(dWs)
+        return (dh0, dA, None, None, None, None, None, None, None, None, None) + tuple(dWs)
 
 
 class GcniiEpilogueFn(torch.autograd.Function):

@@ -622,3 +622,40 @@ def test_full_size_gcn_dgg_trains_past_the_list(dev, symmetric_noise, perturb):
         torch.cuda.synchronize()
     m.dggs[0].check_ell_bound()
     assert torch.equal(out, ref)
+
+
+def test_no_grad_forward_skips_the_partition_sort(dev):
+    """ctx.needs_input_grad is (True, ...) under torch.no_grad() too, so 'a backward will follow' has to be decided by
+    the caller of the autograd node (ops.backward_will_follow): an eval forward under no_grad leaves the partition unsorted (nothing on
+    the side stream), frozen parameters likewise, and the training step that follows matches one that never saw the eval forward"""
+    import copy
+    import dgg_amd
+    N, d, h = 3000, 32, 32
+    torch.manual_seed(2)
+    m = dgg_amd.DGG_LearnableK_debug(in_dim=d, latent_dim=h, args=_args()).to(dev)
+    conv = dgg_amd.GCNConv(d, 16).to(dev)
+    m2, conv2 = copy.deepcopy(m), copy.deepcopy(conv)
+    x = torch.randn(N, d, generator=torch.Generator().manual_seed(3)).to(dev)
+    A = dgg_amd.AllPairs((10 + 10 * torch.rand(N, generator=torch.Generator().manual_seed(4))).to(dev))
+    m.set_seed(3, 4)
+    m2.set_seed(3, 4)
+    with torch.no_grad():
+        Ze, _ = m.forward_conv(x, A, conv.W)
+    layer = m._fused_layer
+    assert layer.want_backward is False and layer.saved["partp_sorted"] is False and layer.saved["side_join"] is False
+    for p_ in list(m.parameters()) + list(conv.parameters()):
+        p_.requires_grad_(False)
+    m.forward_conv(x, A, conv.W)
+    assert layer.want_backward is False and layer.saved["partp_sorted"] is False, "frozen parameters, data input: no backward can follow"
+    for p_ in list(m.parameters()) + list(conv.parameters()):
+        p_.requires_grad_(True)
+    Z, _ = m.forward_conv(x, A, conv.W)
+    assert layer.want_backward is True and layer.saved["partp_sorted"] is True and torch.equal(Z, Ze)
+    Z.sum().backward()
+    Z2, _ = m2.forward_conv(x, A, conv2.W)
+    Z2.sum().backward()
+    assert torch.equal(Z, Z2)
+    for (n1, p1), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        if p2.grad is not None:
+            np.testing.assert_allclose(Nn(p1.grad), Nn(p2.grad), rtol=0, atol=2e-4 * float(p2.grad.abs().max()) + 1e-12, err_msg=n1)
+    np.testing.assert_allclose(Nn(conv.W.grad), Nn(conv2.W.grad), rtol=0, atol=2e-4 * float(conv2.W.grad.abs().max()))

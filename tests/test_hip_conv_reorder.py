@@ -388,7 +388,7 @@ def test_gcnii_stack_bf16_matches_the_layers_one_by_one(dev, n, F, L, residual, 
         return h0.clone().requires_grad_(True), ahat.clone().requires_grad_(True), [W.clone().requires_grad_(True) for W in Ws]
 
     a_h0, a_ah, a_W = leaves()
-    y = ops.GcniiStackBf16Fn.apply(a_h0, a_ah, idx, part, True, residual, 0.0, lamda, alpha, (1, 2), *a_W)
+    y = ops.GcniiStackBf16Fn.apply(a_h0, a_ah, idx, part, True, residual, 0.0, lamda, alpha, (1, 2), True, *a_W)
     (y * cot).sum().backward()
     b_h0, b_ah, b_W = leaves()
     x = b_h0
@@ -434,9 +434,9 @@ def test_gcnii_stack_bf16_dropout_is_the_counter_based_mask(dev):
     h0, ahat, idx, part, Ws, cot = _stack_inputs(n, F, L, dev, seed=8)
     a_h0, a_ah = h0.clone().requires_grad_(True), ahat.clone().requires_grad_(True)
     a_W = [W.clone().requires_grad_(True) for W in Ws]
-    y = ops.GcniiStackBf16Fn.apply(a_h0, a_ah, idx, part, True, True, p, lamda, alpha, (s0, s1), *a_W)
+    y = ops.GcniiStackBf16Fn.apply(a_h0, a_ah, idx, part, True, True, p, lamda, alpha, (s0, s1), True, *a_W)
     (y * cot).sum().backward()
-    y2 = ops.GcniiStackBf16Fn.apply(h0, ahat, idx, part, True, True, p, lamda, alpha, (s0, s1), *Ws)
+    y2 = ops.GcniiStackBf16Fn.apply(h0, ahat, idx, part, True, True, p, lamda, alpha, (s0, s1), False, *Ws)
     assert torch.equal(y, y2), "same seeds, same mask"
     masks = [torch.from_numpy(_np_drop_keep(s0, (s1 ^ (0x9E3779B9 * l)) & 0xFFFFFFFF, n * F, p).reshape(n, F)) for l in range(L + 1)]
     assert abs(float(masks[1].double().mean()) - (1 - p)) < 0.01

@@ -172,11 +172,26 @@ def test_ranked_symmetric_noise_fallback_tiers(dev, knobs, expect):
         args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.899, deg_std=5.288, dgg_mode_edge_net="u-v-dist",
                          dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
                          symmetric_noise=True, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1)
-        m = dgg_amd.DGG_LearnableK_debug(in_dim=24, latent_dim=h, args=args).to(dev)
+        # args.dgg_sym_generator = "ranked": the module keeps the generator it was told to use and raises
+        m = dgg_amd.DGG_LearnableK_debug(in_dim=24, latent_dim=h, args=Namespace(**vars(args), dgg_sym_generator="ranked")).to(dev)
         with _rsym_env(**knobs):
             m(torch.randn(N, 24, device=dev), dgg_amd.AllPairs(torch.full((N,), 30.0, device=dev)))
         with pytest.raises(RuntimeError, match="ranked symmetric noise generator"):
             m.check_ell_bound()
+        # default (round 6): the forward that could not be settled is evaluated again under the symmetric per-pair hash generator (same
+        # law) -- a model a few Adam steps into training reaches this state at N = 100 000 -- and the module says so and stays there
+        m = dgg_amd.DGG_LearnableK_debug(in_dim=24, latent_dim=h, args=args).to(dev)
+        xin = torch.randn(N, 24, device=dev)
+        with _rsym_env(**knobs), pytest.warns(UserWarning, match="symmetric per-pair hash generator instead"):
+            adj = m(xin, dgg_amd.AllPairs(torch.full((N,), 30.0, device=dev)))
+        m.check_ell_bound()
+        assert m._sym_generator == "hash" and bool((adj.idx[:, :30] >= 0).all()), "every row settled"
+        m.set_seed(3, 4)
+        ref = dgg_amd.DGG_LearnableK_debug(in_dim=24, latent_dim=h, args=Namespace(**vars(args), dgg_sym_generator="hash")).to(dev)
+        ref.load_state_dict(m.state_dict())
+        ref.set_seed(3, 4)
+        a1, a2 = m(xin, dgg_amd.AllPairs(torch.full((N,), 30.0, device=dev))), ref(xin, dgg_amd.AllPairs(torch.full((N,), 30.0, device=dev)))
+        assert torch.equal(a1.idx, a2.idx) and torch.equal(a1.values(), a2.values())
         # rows in the dense tier without an overflow: exact, but each costs a full walk -- the module says so and moves to the hash generator
         # Default policy ("ranked"): the module only WARNS and keeps its generator (a health check must not change the noise stream of
         # a seeded run); "auto": this module -- not the shared args -- moves to the hash generator.
