@@ -167,7 +167,7 @@ int dgg_allpairs_topk(const float *xp, int64_t N, int h, int64_t row0, int64_t r
  * probe[0..4] += rows walked, blocks visited, candidates gathered, candidates scored in full, rows cut by the budget;
  * probe[5] = max(probe[5], blocks of a row).  The caller zeroes probe. */
 int dgg_allpairs_ranked_probe(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
-                              const float *k_limit, int stride, int max_blocks, unsigned long long *probe, void *stream);
+                              const float *k_limit, int stride, int max_blocks, unsigned long long *probe, const float *lpub, void *stream);
 /* dgg_allpairs_topk (noise_mode DGG_NOISE_RANKED, K = 64, learned k required) fused with dgg_softk_fwd: the ramp is applied to the
  * settled list while it is still in registers; additionally writes w [row1-row0,64] and rs [row1-row0].  Same bits as the two calls. */
 int dgg_allpairs_topk_ranked_softk(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
@@ -176,6 +176,15 @@ int dgg_allpairs_topk_ranked_softk(const float *xp, int64_t N, int h, int64_t ro
  * noise on every replay once the caller advances seed_dev between replays (the reference samples fresh noise per forward, dgm.py:1226) */
 int dgg_allpairs_topk_ranked_softk_dseed(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, const uint32_t *seed_dev,
                                          const float *k, int mode, int32_t *idx, float *val, float *w, float *rs, void *stream);
+/* the same two calls with the rows' upper bounds of log p_ij over their OTHER nodes j != i (lpub [row1-row0], nullable; from
+ * dgg_allpairs_rowmin_bound): the walk's stop test and its per-candidate cut use  G + lpub[i]  in place of the distance-free  G + 1e-8  --
+ * legitimate because the walk visits the row's own column FIRST (the ranked generator keeps the diagonal outside its rank sequence) --
+ * so that fewer ranks are walked when the latent distances spread over several noise scales; the result is the same bits.  lpub is
+ * also a trailing argument of dgg_allpairs_ranked_probe, dgg_allpairs_topk_ranked_wide and dgg_allpairs_topk_anywide.
+ * seed_dev != NULL: the seed is read from device memory (s0, s1 ignored). */
+int dgg_allpairs_topk_ranked_softk_lp(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
+                                      const uint32_t *seed_dev, const float *lpub, const float *k, int mode, int32_t *idx, float *val, float *w,
+                                      float *rs, void *stream);
 /* ---- rows wider than 64 ranks: CHUNKED rows ------------------------------------------------------------------------------------
  * The learned degree k = relu(k_net * std + mean) + 1 is unbounded (dgm.py:1580-1584) and select_top_k ramps over the whole dense row
  * (dgm.py:1402-1421): a row carries weight on its first ceil(k_i + 8.5) ranks whatever k_i.  Node i then owns the M_i = ceil(L_i / 64)
@@ -198,7 +207,7 @@ int dgg_chunk_layout(const float *k, int64_t rows, int maxm, int64_t ccap, int32
  * may walk all ccap chunks.  seed_dev != NULL: the seed is read from device memory, s0 / s1 are ignored.  w (and rs) may be NULL. */
 int dgg_allpairs_topk_ranked_wide(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
                                   const uint32_t *seed_dev, const float *k, int mode, int maxm, const int32_t *cptr, int64_t ccap, int32_t *idx,
-                                  float *val, float *w, float *rs, void *stream);
+                                  float *val, float *w, float *rs, const float *lpub, void *stream);
 /* Chunked rows of ANY width and every noise generator (dgg_topk_anywide.hip; reference dgm.py:1402-1421 on the dense row, 1580-1584 the
  * unbounded learned degree, 1211-1231 perturb_edge_prob / symmetric_noise): row i keeps its L_i = ceil(k_i + 8.5) + 1 best columns by the
  * perturbed score in the chunks [cptr[i], cptr[i+1]) of idx / val / w [ccap,64], rs [row1-row0], with the ramp and the row sums of
@@ -210,7 +219,15 @@ int dgg_allpairs_topk_ranked_wide(const float *xp, int64_t N, int h, int64_t row
 size_t dgg_allpairs_anywide_ws_bytes(int64_t ccap, int64_t rows);
 int dgg_allpairs_topk_anywide(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode, uint32_t s0, uint32_t s1,
                               const uint32_t *seed_dev, const float *k, int mode, int maxm, int min_m, const int32_t *cptr, int64_t ccap,
-                              int32_t *idx, float *val, float *w, float *rs, void *workspace, size_t ws_bytes, void *stream);
+                              int32_t *idx, float *val, float *w, float *rs, const float *lpub, void *workspace, size_t ws_bytes, void *stream);
+/* lpub [row1-row0]: for every row i a rigorous UPPER bound of log p_ij = log(exp(t ||xp_i - xp_j||) + 1e-8) over all j != i (reference
+ * dgm.py:1618-1623: the scores before the perturbation), from an fp16-MFMA lower bound of the squared distance to the row's nearest OTHER
+ * node (one sweep over all N^2 pairs on the matrix cores, dgg_topk_sweep.hip).  The noise generators bound a pair's log-score by its
+ * noise alone (log p' <= G + 1e-8); with lpub they use G + lpub[i]: fewer ranks walked / fewer candidates scored on latents whose
+ * distances spread over several noise scales.  latent_dim in {16, 32, 64, 128}, t < 0; workspace: dgg_allpairs_rowmin_ws_bytes. */
+size_t dgg_allpairs_rowmin_ws_bytes(int64_t rows, int64_t N, int h);
+int dgg_allpairs_rowmin_bound(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, float *lpub, void *workspace, size_t ws_bytes,
+                              void *stream);
 /* bytes of device workspace the pruned path needs for (N, h): a bf16 copy of xp plus discounted squared norms;
  * 0 when the pruned path does not apply (explicit noise, K != 64, latent_dim not in {16,32,64,128}) */
 size_t dgg_allpairs_workspace_bytes(int64_t N, int h, int noise_mode, int K);

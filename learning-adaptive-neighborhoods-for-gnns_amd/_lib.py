@@ -37,16 +37,19 @@ PROTOTYPES = {
     "dgg_allpairs_workspace_bytes": [_i64, _i32, _i32, _i32],
     "dgg_allpairs_sweep_ctl_offset_bytes": [_i64, _i64, _i32],
     "dgg_allpairs_rsym_ctl_offset_bytes": [_i64, _i64],
-    "dgg_allpairs_ranked_probe": [_vp, _i64, _i32, _i64, _i64, _f32, _u32, _u32, _vp, _i32, _i32, _vp, _vp],
+    "dgg_allpairs_ranked_probe": [_vp, _i64, _i32, _i64, _i64, _f32, _u32, _u32, _vp, _i32, _i32, _vp, _vp, _vp],
+    "dgg_allpairs_topk_ranked_softk_lp": [_vp, _i64, _i32, _i64, _i64, _f32, _u32, _u32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "dgg_allpairs_topk_ranked_softk": [_vp, _i64, _i32, _i64, _i64, _f32, _u32, _u32, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "dgg_literal_hard_fwd": [_vp, _i64, _i32, _vp, _vp, _f32, _i32, _vp, _i64, _u32, _u32, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp],
     "dgg_literal_hard_bwd": [_vp, _vp, _i64, _i32, _vp, _vp],
     "dgg_allpairs_topk_ranked_softk_dseed": [_vp, _i64, _i32, _i64, _i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "dgg_chunk_layout": [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp],
     "dgg_allpairs_anywide_ws_bytes": [_i64, _i64],
+    "dgg_allpairs_rowmin_ws_bytes": [_i64, _i64, _i32],
+    "dgg_allpairs_rowmin_bound": [_vp, _i64, _i32, _i64, _i64, _f32, _vp, _vp, _sz, _vp],
     "dgg_allpairs_topk_anywide": [_vp, _i64, _i32, _i64, _i64, _f32, _i32, _u32, _u32, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
-                                  _sz, _vp],
-    "dgg_allpairs_topk_ranked_wide": [_vp, _i64, _i32, _i64, _i64, _f32, _u32, _u32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
+                                  _vp, _sz, _vp],
+    "dgg_allpairs_topk_ranked_wide": [_vp, _i64, _i32, _i64, _i64, _f32, _u32, _u32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "dgg_partp_build_chunked": [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _vp],
     "dgg_ell_spmm_act_fwd_chunked": [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _vp, _vp],
     "dgg_ell_conv_bwd_partp_chunked": [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -164,7 +167,7 @@ def lib():
             fn = getattr(L, name)      # AttributeError if the library does not export a declared symbol
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        for name in ("dgg_allpairs_workspace_bytes", "dgg_allpairs_anywide_ws_bytes", "dgg_allpairs_sweep_ctl_offset_bytes", "dgg_allpairs_rsym_ctl_offset_bytes", "dgg_gemm_tn_ws_floats", "dgg_gemm_tn_multi_ws_floats", "dgg_linear_bwd_ws_floats", "dgg_part_ws_bytes", "dgg_partp_ws_bytes", "dgg_knet_x_bwd_ws_bytes",
+        for name in ("dgg_allpairs_workspace_bytes", "dgg_allpairs_anywide_ws_bytes", "dgg_allpairs_rowmin_ws_bytes", "dgg_allpairs_sweep_ctl_offset_bytes", "dgg_allpairs_rsym_ctl_offset_bytes", "dgg_gemm_tn_ws_floats", "dgg_gemm_tn_multi_ws_floats", "dgg_linear_bwd_ws_floats", "dgg_part_ws_bytes", "dgg_partp_ws_bytes", "dgg_knet_x_bwd_ws_bytes",
                      "dgg_degree_stats_ws_bytes", "dgg_ell_sddmm_b16_ws_floats", "dgg_edge_bwd_wide_rows_ws_floats"):
             getattr(L, name).restype = C.c_size_t
         _lib = L

@@ -39,7 +39,7 @@ bool dgg_allpairs_rsym_supported(int h, int K);
 
 int dgg_allpairs_topk_ranked_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0,
                                   uint32_t s1, int K, const float *klim, int32_t *idx, float *val, hipStream_t st, int softk_mode = 0,
-                                  float *w = nullptr, float *rs = nullptr, const uint32_t *seed_dev = nullptr);
+                                  float *w = nullptr, float *rs = nullptr, const uint32_t *seed_dev = nullptr, const float *lpub = nullptr);
 // partition of the forward (dgg_scatter.hip): slot map [rows*K] inside the workspace (NULL if unsupported); column pass
 const int *dgg_part_slotmap(const void *part_ws, int64_t rows, int K, int64_t ncols);
 int dgg_norm_da_cols_impl(const void *part_ws, int64_t rows, int K, int64_t ncols, const float *coef_ws, float *da,

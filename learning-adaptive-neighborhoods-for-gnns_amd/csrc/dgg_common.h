@@ -145,8 +145,13 @@ __device__ __forceinline__ float pair_noise(uint32_t s0, uint32_t s1, uint32_t i
 }
 
 // ---- "ranked" counter-based noise (noise_mode 4): same iid Gumbel(0,0.3) law, generated per row in decreasing
-// order.  -log U_(s) = sum_{t<=s} E_t/(N-t+1) (Renyi), prefix sums in exact 2^-40 fixed point (order-independent);
-// rank s sits at column sigma_i(r'), the s-th element < N of a keyed bijection of [0, 2^b) walked in order.
+// order.  -log U_(s) = sum_{t<=s} E_t/(n-t+1) (Renyi), prefix sums in exact 2^-40 fixed point (order-independent);
+// rank s sits at slot sigma_i(r'), the s-th element < n of a keyed bijection of [0, 2^b) walked in order.
+// Round 6: the sequence covers the n = N - 1 OTHER columns (slot c -> column c + (c >= i)); the row's own column has an independent
+// variate (DGG_RANKED_DIAG_KEY: -log V from the same exponential generator, no division, then the same -0.3 log) and is visited FIRST
+// by the searches (position 0 of the walk): every rank a search has not reached is another node, so its score is bounded by the row's
+// nearest-neighbour distance (dgg_allpairs_rowmin_bound) and not just by its noise.  Oracle: ora_ranked_row.
+#define DGG_RANKED_DIAG_KEY 0xA5A5A5A5u
 // Number of leading ranks of a row that can carry a non-zero soft top-k weight: the ramp 1 - 0.5 (1 + tanh(r - k))
 // (dgm.py:1412-1420) is exactly 0.0f in fp32 for r - k >= 8.5, so ranks r >= ceil(k + 8.5) never matter (+1 margin).
 __host__ __device__ inline int klimit_len(float k, int K) {

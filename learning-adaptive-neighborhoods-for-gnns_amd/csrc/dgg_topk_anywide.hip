@@ -125,9 +125,11 @@ __device__ __forceinline__ uint32_t hash_threshold_from_gmin(float gmin) {
 }
 // integer image of a row's key threshold tau (the score of its L-th best key so far): a pair can only beat tau if its log-score
 // reaches log(score(tau)); log p' <= G + 1e-8, so its noise has to reach that minus the margins (fast-math log: 1e-3 covers it)
-__device__ __forceinline__ uint32_t uthr_from_key(uint64_t tau) {
+// (lp: upper bound of log p_ij of the row over j != i -- 1e-8 without a distance bound, dgg_allpairs_rowmin_bound's otherwise; the
+//  diagonal pair, at distance 0, is passed by the callers whatever its hash)
+__device__ __forceinline__ uint32_t uthr_from_key(uint64_t tau, float lp) {
     if (tau == DGG_EMPTY_KEY) return 0u;
-    return hash_threshold_from_gmin(__logf(fmaxf(key_val(tau), 1e-37f)) - 1e-8f - 1e-3f);
+    return hash_threshold_from_gmin(__logf(fmaxf(key_val(tau), 1e-37f)) - lp - 1e-3f);
 }
 
 struct RowGeom { int64_t base; int cap, L; };                    // buffer of a row: keys[base .. base + cap), L ranks to settle
@@ -231,7 +233,8 @@ template <int H, bool SYM>
 __global__ __launch_bounds__(WAVES * 64) void aw_scan_hash(const float *__restrict__ xp, int64_t N, int64_t row0, int64_t row1, float t,
                                                            uint32_t s0, uint32_t s1, const uint32_t *__restrict__ seed_dev,
                                                            const float *__restrict__ klim, const int32_t *__restrict__ cptr,
-                                                           uint64_t *__restrict__ keys, int32_t *__restrict__ cnt_out) {
+                                                           uint64_t *__restrict__ keys, int32_t *__restrict__ cnt_out,
+                                                           const float *__restrict__ lpub) {
     constexpr int RS = H + 4;                                    // padded row stride (floats): 16-byte aligned, rows 4 banks apart
     __shared__ __attribute__((aligned(16))) float rowsL[RB * RS];
     __shared__ int s_row[RB];                                    // local row id of every row slot of the workgroup, -1: none
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_hash(const float *__restri
     __shared__ uint64_t s_thr[WAVES][RW];
     __shared__ int64_t s_base[WAVES][RW];
     __shared__ int s_cnt[WAVES][RW], s_cap[WAVES][RW], s_L[WAVES][RW];
+    __shared__ float s_lp[WAVES][RW];                            // the rows' upper bounds of log p over the OTHER nodes
     __shared__ uint32_t s_q[WAVES][QCAP];                        // (row << 28 | column) of the pairs that passed the integer filter
     const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id();
     if (seed_dev) { s0 = seed_dev[0]; s1 = seed_dev[1]; }
@@ -261,6 +265,7 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_hash(const float *__restri
         const int li = s_row[wave * RW + lane];
         const RowGeom g0 = li >= 0 ? row_geom(cptr, klim, li) : RowGeom{0, 0, 0};
         s_base[wave][lane] = g0.base; s_cap[wave][lane] = g0.cap; s_L[wave][lane] = g0.L;
+        s_lp[wave][lane] = (lpub && li >= 0) ? lpub[li] : 1e-8f;
     }
     __syncthreads();                                             // (the last barrier: the wavefronts are independent from here on)
     uint32_t uthr[RW];                                           // integer image of the rows' thresholds (wave-uniform)
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_hash(const float *__restri
             }
             if (lane == 0) { s_thr[wave][R] = tau; s_cnt[wave][R] = kept; }
             WAVE_FENCE();
-            const uint32_t ut = uthr_from_key(tau);
+            const uint32_t ut = uthr_from_key(tau, s_lp[wave][R]);
 #pragma unroll
             for (int q = 0; q < RW; q++) uthr[q] = q == R ? ut : uthr[q];
             if (mine && key > tau) {
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_hash(const float *__restri
                 if (SYM && j < i) { k1 = ck1; k2 = ck2; b = i; }
                 uint32_t x = b ^ k1;                             // pair_u24_keyed before the shift
                 x *= 0x7feb352dU; x ^= x >> 15; x += k2; x *= 0x846ca68bU;
-                const bool pass = jvalid && i != 0xffffffffu && (x >= uthr[r] || (SYM && j == i));
+                const bool pass = jvalid && i != 0xffffffffu && (x >= uthr[r] || j == i);     // (the diagonal pair sits at distance 0: outside the bound)
                 m[r] = __ballot(pass);
                 any |= m[r];
             }
@@ -398,6 +403,8 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_hash(const float *__restri
 }
 
 // ---- ranked generator, rows of more than `min_m` chunks: the walk of allpairs_topk_ranked_wide on the threshold buffer -----------------
+// (the walk's block generator of dgg_topk_ranked.hip, restated: position 0 = the row's own column with its independent variate, position
+//  p >= 1 = slot sigma(p - 1) of the n = N - 1 other columns; dgg_common.h, DGG_RANKED_DIAG_KEY)
 __device__ __forceinline__ uint64_t scan_u64(uint64_t v, int lane) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -411,7 +418,7 @@ template <int H>
 __global__ __launch_bounds__(256) void aw_ranked_walk(const float *__restrict__ xp, int64_t N, int64_t row0, int64_t row1, float t, uint32_t s0,
                                                       uint32_t s1, const uint32_t *__restrict__ seed_dev, const float *__restrict__ klim,
                                                       const int32_t *__restrict__ cptr, int min_m, uint64_t *__restrict__ keys,
-                                                      int32_t *__restrict__ cnt_out) {
+                                                      int32_t *__restrict__ cnt_out, const float *__restrict__ lpub) {
     const int lane = threadIdx.x & 63;
     if (seed_dev) { s0 = seed_dev[0]; s1 = seed_dev[1]; }
     const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
@@ -424,24 +431,29 @@ __global__ __launch_bounds__(256) void aw_ranked_walk(const float *__restrict__ 
     uint32_t k1, k2;
     rowkey(s0, s1, (uint32_t)i, k1, k2);
     const uint32_t k3 = mix32(k2 ^ 0x68E31DA4u);
-    const int b = ranked_bits(N);
+    const int64_t n = N - 1;
+    const int b = ranked_bits(n);
     const uint64_t D = (uint64_t)1 << b;
     const float *xi = xp + i * H;
+    const float lp = lpub ? lpub[lrow] : 1e-8f;                  // upper bound of log p over the OTHER nodes
     uint64_t S = 0, thr = DGG_EMPTY_KEY;
     uint32_t scount = 0;
     int cnt = 0;
     float thr_log = -INFINITY;
-    for (uint64_t rb = 0; rb < D; rb += 64) {
-        const uint32_t c = ranked_sigma((uint32_t)(rb + lane), k1, k2, k3, b);
-        const bool valid = (int64_t)c < N;
-        const uint64_t mv = __ballot(valid);
+    for (uint64_t rb = 0; rb <= D; rb += 64) {
+        const uint64_t p = rb + (uint64_t)lane;
+        const bool isdiag = p == 0ull;
+        const uint32_t cs = ranked_sigma((uint32_t)(p - 1ull), k1, k2, k3, b);
+        const bool rvalid = !isdiag && p <= D && (int64_t)cs < n;
+        const uint64_t mv = __ballot(rvalid);
         const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mv, 0u));
         const uint32_t s = scount + pos + 1;
-        const uint64_t term = valid ? ranked_term(k1, k3, s, N) : 0ull;
-        const uint64_t pre = scan_u64(term, lane) + S;
-        const float G = ranked_gumbel(pre);
+        const uint64_t term = ranked_term(k1, isdiag ? (k3 ^ DGG_RANKED_DIAG_KEY) : k3, isdiag ? 1u : s, isdiag ? (int64_t)1 : n);
+        const uint64_t pre = scan_u64(rvalid ? term : 0ull, lane) + S;
+        const float G = ranked_gumbel(isdiag ? term : pre);
+        const uint32_t c = isdiag ? (uint32_t)i : cs + (cs >= (uint32_t)i ? 1u : 0u);
         uint64_t key = DGG_EMPTY_KEY;
-        const bool want = valid && !(G + 1e-8f + 1e-3f < thr_log);
+        const bool want = (rvalid || isdiag) && !(G + lp + 1e-3f < thr_log);
         if (want) {
             const float4 *xj = reinterpret_cast<const float4 *>(xp + (int64_t)c * H);
             float d2 = 0.0f;
@@ -466,18 +478,18 @@ __global__ __launch_bounds__(256) void aw_ranked_walk(const float *__restrict__ 
                 pass = pass && key > thr;
                 m = __ballot(pass);
             }
-            const int p = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (pass) buf[p] = key;
+            const int q = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (pass) buf[q] = key;
             cnt += __builtin_popcountll(m);
         }
         const int nvalid = __builtin_popcountll(mv);
         S = shfl_u64(pre, 63);
         scount += (uint32_t)nvalid;
-        if (scount >= (uint32_t)N) break;
+        if ((int64_t)scount >= n) break;
         if (thr != DGG_EMPTY_KEY && nvalid > 0) {                // the lowest noise of this block bounds every rank still to come
             const int last = 63 - __builtin_clzll(mv);
             const float gmin = __shfl(G, last, 64);
-            if (gmin + 1e-8f + 1e-3f < thr_log) break;
+            if (gmin + lp + 1e-3f < thr_log) break;
         }
     }
     if (cnt > g.L) {
@@ -629,18 +641,18 @@ __global__ __launch_bounds__(ET) void aw_emit(const uint64_t *__restrict__ keys,
 template <int H>
 int launch_anywide(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, int noise_mode, uint32_t s0, uint32_t s1, const uint32_t *seed_dev,
                    const float *k, int mode, int maxm, int min_m, const int32_t *cptr, int64_t ccap, int32_t *idx, float *val, float *w, float *rs,
-                   uint64_t *keys, int32_t *cnt, hipStream_t st) {
+                   uint64_t *keys, int32_t *cnt, const float *lpub, hipStream_t st) {
     const int64_t rows = row1 - row0;
     const dim3 gscan((unsigned)((rows + RB - 1) / RB));
     if (noise_mode == 0)
         hipLaunchKernelGGL(aw_scan_plain<H>, gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, k, cptr, keys, cnt);
     else if (noise_mode == 2)
-        hipLaunchKernelGGL((aw_scan_hash<H, false>), gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr, keys, cnt);
+        hipLaunchKernelGGL((aw_scan_hash<H, false>), gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr, keys, cnt, lpub);
     else if (noise_mode == 3)
-        hipLaunchKernelGGL((aw_scan_hash<H, true>), gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr, keys, cnt);
+        hipLaunchKernelGGL((aw_scan_hash<H, true>), gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr, keys, cnt, lpub);
     else
         hipLaunchKernelGGL(aw_ranked_walk<H>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr,
-                           min_m, keys, cnt);
+                           min_m, keys, cnt, lpub);
     int rc = dgg_check_launch("allpairs_topk_anywide: candidate pass");
     if (rc) return rc;
     const int64_t tail = (min_m == 0 && ccap > rows) ? ccap - rows : 0;        // (every row has at least one chunk)
@@ -669,7 +681,9 @@ size_t dgg_allpairs_anywide_ws_bytes(int64_t ccap, int64_t rows) {
 // belong to dgg_allpairs_topk_ranked_wide, which also writes the spare chunks of a fixed capacity).
 int dgg_allpairs_topk_anywide(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode, uint32_t s0, uint32_t s1,
                               const uint32_t *seed_dev, const float *k, int mode, int maxm, int min_m, const int32_t *cptr, int64_t ccap,
-                              int32_t *idx, float *val, float *w, float *rs, void *workspace, size_t ws_bytes, void *stream) {
+                              int32_t *idx, float *val, float *w, float *rs, const float *lpub, void *workspace, size_t ws_bytes, void *stream) {
+    // lpub (nullable, [row1-row0]): dgg_allpairs_rowmin_bound's upper bounds of log p over a row's OTHER nodes; tightens the integer filter
+    // of the hash generators and the stop tests of the ranked walk (the result does not depend on it)
     if (row0 < 0 || row1 > N || row0 > row1) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_anywide: bad row range");
     if (mode != 0 && mode != 1 && mode != 3) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_anywide: mode must be 0, 1 or 3");
     if (!xp || !k || !cptr || !idx || !val || (w && !rs)) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_anywide: xp, k, cptr, idx, val (and rs with w) are required");
@@ -685,10 +699,10 @@ int dgg_allpairs_topk_anywide(const float *xp, int64_t N, int h, int64_t row0, i
     int32_t *cnt = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(workspace) + aw_al((size_t)ccap * KSLOT * sizeof(uint64_t)));
     hipStream_t st = (hipStream_t)stream;
     switch (h) {
-        case 16: return launch_anywide<16>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, st);
-        case 32: return launch_anywide<32>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, st);
-        case 64: return launch_anywide<64>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, st);
-        case 128: return launch_anywide<128>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, st);
+        case 16: return launch_anywide<16>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, lpub, st);
+        case 32: return launch_anywide<32>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, lpub, st);
+        case 64: return launch_anywide<64>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, lpub, st);
+        case 128: return launch_anywide<128>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, lpub, st);
         default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "allpairs_topk_anywide supports latent_dim in {16,32,64,128}");
     }
 }

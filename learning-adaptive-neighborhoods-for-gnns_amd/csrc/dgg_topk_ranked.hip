@@ -18,6 +18,7 @@ using namespace dgg;
 
 namespace {
 
+#ifdef DGG_RK_SHFLSCAN
 __device__ __forceinline__ uint64_t wave_inclusive_scan_u64(uint64_t v, int lane) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -27,19 +28,69 @@ __device__ __forceinline__ uint64_t wave_inclusive_scan_u64(uint64_t v, int lane
     }
     return v;
 }
+#else
+// 64-lane inclusive prefix sum of 64-bit integers on the DPP network: Kogge-Stone inside the rows of 16 lanes (row_shr 1, 2, 4, 8; a
+// lane without a source reads 0), then the row totals by row_bcast:15 (lane 15 of rows 0 / 2 into rows 1 / 3) and row_bcast:31 (lane 31
+// into rows 2 and 3).  Two DPP moves + one 64-bit add per step, no LDS crossbar (the shuffle form: twelve ds_bpermute round trips).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint64_t dpp_add_u64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROWMASK, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROWMASK, 0xF, false);
+    return v + (((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ uint64_t wave_inclusive_scan_u64(uint64_t v, int) {
+    v = dpp_add_u64<0x111, 0xF>(v);                              // row_shr:1
+    v = dpp_add_u64<0x112, 0xF>(v);                              // row_shr:2
+    v = dpp_add_u64<0x114, 0xF>(v);                              // row_shr:4
+    v = dpp_add_u64<0x118, 0xF>(v);                              // row_shr:8
+    v = dpp_add_u64<0x142, 0xA>(v);                              // row_bcast:15 -> rows 1, 3
+    v = dpp_add_u64<0x143, 0xC>(v);                              // row_bcast:31 -> rows 2, 3
+    return v;
+}
+#endif
+
+// One block of the ranked walk of row i: positions rb .. rb + 63 of the row's sequence.  Position 0 is the row's OWN column with its
+// independent variate (dgg_common.h, DGG_RANKED_DIAG_KEY); position p >= 1 is slot sigma(p - 1) of the n = N - 1 other columns, a
+// candidate when the slot is < n.  -> col, cand (the lane holds a candidate), G (its noise), mv (ballot of the lanes that hold a
+// RANK, i.e. all candidates but the diagonal); S / scount carry the fixed-point prefix sum and the rank count across blocks.
+struct RankedLane { uint32_t col; bool cand; float G; };
+__device__ __forceinline__ RankedLane ranked_block(uint64_t rb, int lane, uint32_t i, int64_t n, int b, uint64_t D, uint32_t k1, uint32_t k2, uint32_t k3,
+                                                   uint64_t &S, uint32_t &scount, uint64_t &mv) {
+    const uint64_t p = rb + (uint64_t)lane;
+    const bool isdiag = p == 0ull;
+    const uint32_t c = ranked_sigma((uint32_t)(p - 1ull), k1, k2, k3, b);
+    const bool rvalid = !isdiag && p <= D && (int64_t)c < n;
+    mv = __ballot(rvalid);
+    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mv, 0u));
+    const uint32_t s = scount + pos + 1;                         // 1-based rank of this lane's slot (if it holds one)
+    // the diagonal's exponential variate comes out of the same instruction stream: rank 1 of 1 under its own key (no division effect)
+    const uint64_t term = ranked_term(k1, isdiag ? (k3 ^ DGG_RANKED_DIAG_KEY) : k3, isdiag ? 1u : s, isdiag ? (int64_t)1 : n);
+    const uint64_t pre = wave_inclusive_scan_u64(rvalid ? term : 0ull, lane) + S;
+    RankedLane o;
+    o.G = ranked_gumbel(isdiag ? term : pre);
+    o.cand = rvalid || isdiag;
+    o.col = isdiag ? i : c + (c >= i ? 1u : 0u);
+    S = shfl_u64(pre, 63);                                       // inclusive sum at the last lane = block total + carry
+    scount += (uint32_t)__builtin_popcountll(mv);
+    return o;
+}
 
 // PROBE (dgg_allpairs_ranked_probe): the same walk on every `stride`-th row with a budget of `max_blocks` blocks, NO list written;
 // probe[0..5] += rows walked, blocks visited, candidates gathered, candidates scored in full, rows that hit the budget; probe[5] =
 // max blocks of a row.  The walk depth depends on the DATA -- a row visits ~ L exp(spread of 0.05 dist / 0.3) ranks -- and this is
 // how callers measure it (bench.py) or estimate it before choosing this generator (dgm.py, args.dgg_asym_generator = "auto").
+#ifndef DGG_RK_WAVES
+#define DGG_RK_WAVES 1
+#endif
 template <int H, bool PROBE = false>
-__global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restrict__ xp, int64_t N, int64_t row0,
+__global__ __launch_bounds__(256, DGG_RK_WAVES) void allpairs_topk_ranked(const float *__restrict__ xp, int64_t N, int64_t row0,
                                                             int64_t row1, float t, uint32_t s0, uint32_t s1,
                                                             const float *__restrict__ klim, int32_t *__restrict__ idx,
                                                             float *__restrict__ val, int softk_mode, float *__restrict__ w_out,
                                                             float *__restrict__ rs_out, const uint32_t *__restrict__ seed_dev,
                                                             int stride = 1, int max_blocks = 0,
-                                                            unsigned long long *__restrict__ probe = nullptr) {
+                                                            unsigned long long *__restrict__ probe = nullptr,
+                                                            const float *__restrict__ lpub = nullptr) {
     const int lane = threadIdx.x & 63;
     if (seed_dev) { s0 = seed_dev[0]; s1 = seed_dev[1]; }       // seed in device memory: ONE captured hipGraph serves fresh seeds
     // (readfirstlane: the compiler cannot know that dgg::wave_id() is wave-uniform; without it the row's own features are
@@ -54,26 +105,26 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
     uint32_t k1, k2;
     rowkey(s0, s1, (uint32_t)i, k1, k2);
     const uint32_t k3 = mix32(k2 ^ 0x68E31DA4u);
-    const int b = ranked_bits(N);
+    const int64_t n = N - 1;                                     // ranks = the OTHER columns; the row's own column is position 0
+    const int b = ranked_bits(n);
     const uint64_t D = (uint64_t)1 << b;
     const float *xi = xp + i * H;                                // wave-uniform row
+    // upper bound of log p_ij over the other nodes j: the distance-free log(1 + 1e-8), or dgg_allpairs_rowmin_bound's (every rank the
+    // walk has not reached is another node: the diagonal comes first)
+    const float lp = lpub ? lpub[lrow] : 1e-8f;
     uint64_t list = DGG_EMPTY_KEY;
     uint64_t S = 0;                                              // fixed-point prefix sum carried across blocks
     uint32_t scount = 0;                                         // ranks assigned so far
     float thr_log = -INFINITY;                                   // log of the L-th best score so far (-inf: list not full)
-    for (uint64_t rb = 0; rb < D; rb += 64) {
-        const uint32_t c = ranked_sigma((uint32_t)(rb + lane), k1, k2, k3, b);
-        const bool valid = (int64_t)c < N;
-        const uint64_t m = __ballot(valid);
-        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        const uint32_t s = scount + pos + 1;                     // 1-based rank of this lane's column (if valid)
-        uint64_t term = valid ? ranked_term(k1, k3, s, N) : 0ull;
-        uint64_t pre = wave_inclusive_scan_u64(term, lane) + S;
-        float G = ranked_gumbel(pre);
+    for (uint64_t rb = 0; rb <= D; rb += 64) {
+        uint64_t m;
+        const RankedLane rl = ranked_block(rb, lane, (uint32_t)i, n, b, D, k1, k2, k3, S, scount, m);
+        const uint32_t c = rl.col;
+        const float G = rl.G;
         uint64_t key = DGG_EMPTY_KEY;
         // per-candidate version of the stop test: a rank whose noise cannot reach the L-th log-score found so far is
         // not gathered at all (ranks come in decreasing noise order, so these are the tail lanes of the block)
-        const bool want = valid && !(G + 1e-8f + 1e-3f < thr_log);
+        const bool want = rl.cand && !(G + lp + 1e-3f < thr_log);
         if (PROBE) { nblk++; ngath += __builtin_popcountll(__ballot(want)); }
         // (Measured and rejected: staging the candidate rows through LDS so that 8 lanes read one 128-byte line -- 8x fewer L1 tag
         //  lookups, same bits -- costs two LDS round trips per block: 658 us against 257.)
@@ -133,17 +184,15 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
             list = wave_merge_top64_asc(list, key, lane);
         }
         const int nvalid = __builtin_popcountll(m);
-        S = shfl_u64(pre, 63);                                   // inclusive sum at the last lane = block total + carry
-        scount += (uint32_t)nvalid;
-        if (scount >= (uint32_t)N) break;                        // every column visited
+        if ((int64_t)scount >= n) break;                         // every column visited
         // stop test: the lowest noise of this block bounds every rank still to come
         const uint64_t k63 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(list >> 32), L - 1) << 32) |
                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)list, L - 1);
         if (k63 != DGG_EMPTY_KEY) thr_log = __logf(key_val(k63));
         if (k63 != DGG_EMPTY_KEY && nvalid > 0) {
-            const int last = 63 - __builtin_clzll(m);            // last valid lane = highest rank in the block
+            const int last = 63 - __builtin_clzll(m);            // last lane with a rank = highest rank in the block
             const float gmin = __shfl(G, last, 64);
-            if (gmin + 1e-8f + 1e-3f < thr_log) break;
+            if (gmin + lp + 1e-3f < thr_log) break;
         }
         if (PROBE && max_blocks > 0 && nblk >= (unsigned long long)max_blocks) { budget_hit = true; break; }
     }
@@ -178,9 +227,10 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked(const float *__restr
 template <int H>
 int launch_ranked(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
                   const float *klim, int32_t *idx, float *val, hipStream_t st, int softk_mode = 0, float *w = nullptr, float *rs = nullptr,
-                  const uint32_t *seed_dev = nullptr) {
+                  const uint32_t *seed_dev = nullptr, const float *lpub = nullptr) {
     dim3 grid((unsigned)((row1 - row0 + 3) / 4));
-    hipLaunchKernelGGL(allpairs_topk_ranked<H>, grid, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, klim, idx, val, softk_mode, w, rs, seed_dev);
+    hipLaunchKernelGGL(allpairs_topk_ranked<H>, grid, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, klim, idx, val, softk_mode, w, rs, seed_dev, 1, 0,
+                       (unsigned long long *)nullptr, lpub);
     return dgg_check_launch("allpairs_topk_ranked");
 }
 
@@ -322,7 +372,8 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked_wide(const float *__
                                                                  const int32_t *__restrict__ cptr, int32_t *__restrict__ idx,
                                                                  float *__restrict__ val, int softk_mode, float *__restrict__ w_out,
                                                                  float *__restrict__ rs_out, const uint32_t *__restrict__ seed_dev,
-                                                                 unsigned nrow_blocks, int64_t ccap, int skip_heavy) {
+                                                                 unsigned nrow_blocks, int64_t ccap, int skip_heavy,
+                                                                 const float *__restrict__ lpub) {
     const int lane = threadIdx.x & 63;
     if (blockIdx.x >= nrow_blocks) {
         // arrays allocated for `ccap` chunks (a capacity fixed ahead of the learned degrees, e.g. inside a captured hipGraph): the
@@ -355,26 +406,24 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked_wide(const float *__
     uint32_t k1, k2;
     rowkey(s0, s1, (uint32_t)i, k1, k2);
     const uint32_t k3 = mix32(k2 ^ 0x68E31DA4u);
-    const int b = ranked_bits(N);
+    const int64_t n = N - 1;                                     // (ranked_block: the row's own column first, then the ranks of the others)
+    const int b = ranked_bits(n);
     const uint64_t D = (uint64_t)1 << b;
     const float *xi = xp + i * H;
+    const float lp = lpub ? lpub[lrow] : 1e-8f;                  // upper bound of log p over the OTHER nodes (allpairs_topk_ranked)
     uint64_t list[MAXM];
 #pragma unroll
     for (int m = 0; m < MAXM; m++) list[m] = DGG_EMPTY_KEY;
     uint64_t S = 0;
     uint32_t scount = 0;
     float thr_log = -INFINITY;
-    for (uint64_t rb = 0; rb < D; rb += 64) {
-        const uint32_t c = ranked_sigma((uint32_t)(rb + lane), k1, k2, k3, b);
-        const bool valid = (int64_t)c < N;
-        const uint64_t mv = __ballot(valid);
-        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mv, 0u));
-        const uint32_t s = scount + pos + 1;
-        uint64_t term = valid ? ranked_term(k1, k3, s, N) : 0ull;
-        uint64_t pre = wave_inclusive_scan_u64(term, lane) + S;
-        float G = ranked_gumbel(pre);
+    for (uint64_t rb = 0; rb <= D; rb += 64) {
+        uint64_t mv;
+        const RankedLane rl = ranked_block(rb, lane, (uint32_t)i, n, b, D, k1, k2, k3, S, scount, mv);
+        const uint32_t c = rl.col;
+        const float G = rl.G;
         uint64_t key = DGG_EMPTY_KEY;
-        const bool want = valid && !(G + 1e-8f + 1e-3f < thr_log);
+        const bool want = rl.cand && !(G + lp + 1e-3f < thr_log);
         if (want) {
             const float4 *xj = reinterpret_cast<const float4 *>(xp + (int64_t)c * H);
             float d2 = 0.0f;
@@ -422,9 +471,7 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked_wide(const float *__
             }
         }
         const int nvalid = __builtin_popcountll(mv);
-        S = shfl_u64(pre, 63);
-        scount += (uint32_t)nvalid;
-        if (scount >= (uint32_t)N) break;
+        if ((int64_t)scount >= n) break;
         uint64_t kL = DGG_EMPTY_KEY;
 #pragma unroll
         for (int m = 0; m < MAXM; m++)
@@ -433,7 +480,7 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked_wide(const float *__
         if (kL != DGG_EMPTY_KEY && nvalid > 0) {
             const int last = 63 - __builtin_clzll(mv);
             const float gmin = __shfl(G, last, 64);
-            if (gmin + 1e-8f + 1e-3f < thr_log) break;
+            if (gmin + lp + 1e-3f < thr_log) break;
         }
     }
     float rsum = 0.0f;
@@ -468,13 +515,13 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked_wide(const float *__
 template <int H>
 int launch_ranked_wide(int maxm, const float *xp, int64_t N, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1, const float *klim,
                        const int32_t *cptr, int32_t *idx, float *val, hipStream_t st, int softk_mode, float *w, float *rs, const uint32_t *seed_dev,
-                       int64_t ccap) {
+                       int64_t ccap, const float *lpub) {
     const int skip_heavy = maxm > DGG_CHUNK_MAXM ? 1 : 0;
     const unsigned nrow_blocks = (unsigned)((row1 - row0 + 3) / 4);
     const int64_t tail = ccap > row1 - row0 ? ccap - (row1 - row0) : 0;         // (every row has at least one chunk)
     dim3 grid(nrow_blocks + (unsigned)((tail + 3) / 4));
 #define DGG_RW(MM) hipLaunchKernelGGL((allpairs_topk_ranked_wide<H, MM>), grid, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, klim, cptr, idx, val, \
-                                      softk_mode, w, rs, seed_dev, nrow_blocks, ccap, skip_heavy)
+                                      softk_mode, w, rs, seed_dev, nrow_blocks, ccap, skip_heavy, lpub)
     if (maxm <= 2) DGG_RW(2);
     else if (maxm <= 4) DGG_RW(4);
     else if (maxm <= 8) DGG_RW(8);
@@ -502,17 +549,17 @@ int dgg_klimit_truncate_impl(const float *klim, int64_t rows, int K, int32_t *id
 
 int dgg_allpairs_topk_ranked_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0,
                                   uint32_t s1, int K, const float *klim, int32_t *idx, float *val, hipStream_t st, int softk_mode,
-                                  float *w, float *rs, const uint32_t *seed_dev) {
+                                  float *w, float *rs, const uint32_t *seed_dev, const float *lpub) {
     if (K != 64) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path needs K = 64");
     if (N >= ((int64_t)1 << 31)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path needs N < 2^31");
     if (w && (!klim || !rs)) return dgg_set_error(DGG_ERR_ARG, "ranked-noise path: the fused ramp needs the learned k and the row-sum output");
     if (row1 <= row0) return 0;
     switch (h) {
-        case 8: return launch_ranked<8>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs, seed_dev);
-        case 16: return launch_ranked<16>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs, seed_dev);
-        case 32: return launch_ranked<32>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs, seed_dev);
-        case 64: return launch_ranked<64>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs, seed_dev);
-        case 128: return launch_ranked<128>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs, seed_dev);
+        case 8: return launch_ranked<8>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs, seed_dev, lpub);
+        case 16: return launch_ranked<16>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs, seed_dev, lpub);
+        case 32: return launch_ranked<32>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs, seed_dev, lpub);
+        case 64: return launch_ranked<64>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs, seed_dev, lpub);
+        case 128: return launch_ranked<128>(xp, N, row0, row1, t, s0, s1, klim, idx, val, st, softk_mode, w, rs, seed_dev, lpub);
         default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path supports latent_dim in {8,16,32,64,128}");
     }
 }
@@ -522,7 +569,7 @@ extern "C" {
 // blocks of 64 ranks (0: no cut); nothing but the six counters is written: probe[0..4] += rows walked, blocks visited, candidates
 // gathered, candidates scored in full, rows cut by the budget; probe[5] = max(probe[5], blocks of a row).  Caller zeroes probe.
 int dgg_allpairs_ranked_probe(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
-                              const float *k_limit, int stride, int max_blocks, unsigned long long *probe, void *stream) {
+                              const float *k_limit, int stride, int max_blocks, unsigned long long *probe, const float *lpub, void *stream) {
     if (row0 < 0 || row1 > N || row0 > row1 || stride < 1 || max_blocks < 0 || !probe)
         return dgg_set_error(DGG_ERR_ARG, "allpairs_ranked_probe: bad row range, stride, budget or NULL counters");
     if (N >= ((int64_t)1 << 31)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "ranked-noise path needs N < 2^31");
@@ -532,7 +579,7 @@ int dgg_allpairs_ranked_probe(const float *xp, int64_t N, int h, int64_t row0, i
     hipStream_t st = (hipStream_t)stream;
 #define DGG_RANKED_PROBE(HH)                                                                                               \
     hipLaunchKernelGGL((allpairs_topk_ranked<HH, true>), grid, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, k_limit, nullptr, nullptr, 0, \
-                       nullptr, nullptr, nullptr, stride, max_blocks, probe)
+                       nullptr, nullptr, nullptr, stride, max_blocks, probe, lpub)
     switch (h) {
         case 8: DGG_RANKED_PROBE(8); break;
         case 16: DGG_RANKED_PROBE(16); break;
@@ -564,6 +611,19 @@ int dgg_allpairs_topk_ranked_softk_dseed(const float *xp, int64_t N, int h, int6
     return dgg_allpairs_topk_ranked_impl(xp, N, h, row0, row1, t, 0u, 0u, 64, k, idx, val, (hipStream_t)stream, mode, w, rs, seed_dev);
 }
 
+// dgg_allpairs_topk_ranked_softk[_dseed] with the rows' upper bounds of log p over their OTHER nodes (lpub [row1-row0], nullable:
+// dgg_allpairs_rowmin_bound): the walk stops -- and skips candidates -- on  G + lpub[i]  instead of the distance-free  G + 1e-8.  Same
+// result, fewer ranks walked when the latent distances spread over several noise scales.  seed_dev != NULL: the seed is read from device
+// memory (s0, s1 ignored).
+int dgg_allpairs_topk_ranked_softk_lp(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
+                                      const uint32_t *seed_dev, const float *lpub, const float *k, int mode, int32_t *idx, float *val, float *w,
+                                      float *rs, void *stream) {
+    if (row0 < 0 || row1 > N || row0 > row1) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_softk_lp: bad row range");
+    if (mode != 0 && mode != 1 && mode != 3) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_softk_lp: mode must be 0, 1 or 3");
+    if (!k || !w || !rs) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_softk_lp: k, w and rs are required");
+    return dgg_allpairs_topk_ranked_impl(xp, N, h, row0, row1, t, s0, s1, 64, k, idx, val, (hipStream_t)stream, mode, w, rs, seed_dev, lpub);
+}
+
 // ---- chunked rows (rows wider than 64 ranks) ----
 // Layout of the chunked rows from the learned degrees: cptr [rows+1] (first chunk of every node), cnode [ccap] (node of every chunk),
 // meta int32[4 + 384] = {total chunks, max chunks of a row, flags (1: a row needs more than 64*maxm ranks, 2: more than ccap chunks), 0,
@@ -584,7 +644,7 @@ int dgg_chunk_layout(const float *k, int64_t rows, int maxm, int64_t ccap, int32
 // device memory (s0, s1 ignored).
 int dgg_allpairs_topk_ranked_wide(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, uint32_t s0, uint32_t s1,
                                   const uint32_t *seed_dev, const float *k, int mode, int maxm, const int32_t *cptr, int64_t ccap, int32_t *idx,
-                                  float *val, float *w, float *rs, void *stream) {
+                                  float *val, float *w, float *rs, const float *lpub, void *stream) {
     if (row0 < 0 || row1 > N || row0 > row1) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_wide: bad row range");
     if (mode != 0 && mode != 1 && mode != 3) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_wide: mode must be 0, 1 or 3");
     if (!k || !cptr || !idx || !val || (w && !rs)) return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_ranked_wide: k, cptr, idx, val (and rs with w) are required");
@@ -594,10 +654,10 @@ int dgg_allpairs_topk_ranked_wide(const float *xp, int64_t N, int h, int64_t row
     if (row1 == row0) return 0;
     hipStream_t st = (hipStream_t)stream;
     switch (h) {
-        case 16: return launch_ranked_wide<16>(maxm, xp, N, row0, row1, t, s0, s1, k, cptr, idx, val, st, mode, w, rs, seed_dev, ccap);
-        case 32: return launch_ranked_wide<32>(maxm, xp, N, row0, row1, t, s0, s1, k, cptr, idx, val, st, mode, w, rs, seed_dev, ccap);
-        case 64: return launch_ranked_wide<64>(maxm, xp, N, row0, row1, t, s0, s1, k, cptr, idx, val, st, mode, w, rs, seed_dev, ccap);
-        case 128: return launch_ranked_wide<128>(maxm, xp, N, row0, row1, t, s0, s1, k, cptr, idx, val, st, mode, w, rs, seed_dev, ccap);
+        case 16: return launch_ranked_wide<16>(maxm, xp, N, row0, row1, t, s0, s1, k, cptr, idx, val, st, mode, w, rs, seed_dev, ccap, lpub);
+        case 32: return launch_ranked_wide<32>(maxm, xp, N, row0, row1, t, s0, s1, k, cptr, idx, val, st, mode, w, rs, seed_dev, ccap, lpub);
+        case 64: return launch_ranked_wide<64>(maxm, xp, N, row0, row1, t, s0, s1, k, cptr, idx, val, st, mode, w, rs, seed_dev, ccap, lpub);
+        case 128: return launch_ranked_wide<128>(maxm, xp, N, row0, row1, t, s0, s1, k, cptr, idx, val, st, mode, w, rs, seed_dev, ccap, lpub);
         default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "chunked ranked-noise path supports latent_dim in {16,32,64,128}");
     }
 }

@@ -379,6 +379,121 @@ __global__ __launch_bounds__(256, 2) void sw_sweep(const uint16_t *__restrict__ 
     cnts[((grp * 64 + lane) * CS) + seg] = (unsigned short)(n > 0xffffu ? 0xffffu : n);
 }
 
+// ---- row minimum: a rigorous LOWER BOUND of the distance from every row to its nearest OTHER node --------------------------------
+// The noise generators' early-out tests bound a pair's log-score by its noise alone, log p'_ij <= G_ij + 1e-8, i.e. they assume the
+// candidate could sit at distance 0.  With d_lb(i) <= min_{j != i} ||xp_i - xp_j|| the bound tightens to
+//   log p'_ij <= G_ij + log(exp(t d_lb(i)) + 1e-8)     for every j != i
+// which is what decides how deep the ranked search walks on spread latents (a row visits ~ L exp(D / 0.3) ranks, D = the spread of
+// t d it has to allow for: DESIGN.md section 6) and how many candidates the per-pair hash filter of the chunked rows admits.
+// Same matrix-core sweep as sw_sweep -- the sign test replaced by a running maximum of E_ij = <x^_i, x^_j> + c_j per lane (the augmented
+// K-step with t = 0), L_ij = nb_i - 2 E_ij the rigorous lower bound of d^2 (header of this file) -- over ALL column tiles, the diagonal
+// masked in the tiles that overlap the wavefront's own rows; column segments combine by an atomic max on an order-preserving integer
+// image of E.  ~1 ms at N = 100 000, h = 64: only worth it when the walk is deep (the callers decide from a pilot).
+__device__ __forceinline__ uint32_t fkey(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float fkey_inv(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+template <int H, int RBLK>
+__global__ __launch_bounds__(256, 2) void sw_rowmin(const uint16_t *__restrict__ xw, int64_t npad, int64_t row0, int64_t row1, int ntiles, int nrb,
+                                                    int rbx, int CS, uint32_t *__restrict__ ekey) {
+    using TL = Tile<H>;
+    constexpr int HW = TL::HW, KS1 = TL::KS1, STRIDE = TL::STRIDE, CPC = TL::CPC, LQ = TL::LQ;
+    __shared__ __attribute__((aligned(16))) unsigned char colA[2][TL::BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), r = lane & 31, hh = lane >> 5;
+    const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int seg = kk / rbx, rowblk = (kk % rbx) * 8 + xcd;
+    if (rowblk >= nrb) return;
+    const int64_t rbase = row0 + (int64_t)rowblk * (128 * RBLK) + (int64_t)wave * (32 * RBLK);
+    bf16x8 bfr[RBLK][KS1];
+    float em[RBLK];
+#pragma unroll
+    for (int b = 0; b < RBLK; b++) {
+        const int64_t i = rbase + b * 32 + r;
+        const int64_t ic = i < row1 ? i : row1 - 1;
+#pragma unroll
+        for (int s = 0; s < KS1 - 1; s++) bfr[b][s] = *reinterpret_cast<const bf16x8 *>(xw + ic * HW + 16 * s + 8 * hh);
+        bfr[b][KS1 - 1] = aug_row(0.0f, hh);
+        em[b] = -3.0e38f;
+    }
+    uint4 stg[LQ];
+    auto tile_load = [&](int w) {
+        const int64_t c0 = (int64_t)w * TC;
+#pragma unroll
+        for (int q = 0; q < LQ; q++) {
+            stg[q] = make_uint4(0, 0, 0, 0);
+            if (c0 < npad) stg[q] = *reinterpret_cast<const uint4 *>(xw + c0 * HW + (int64_t)(q * 256 + tid) * 8);
+        }
+    };
+    auto tile_store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < LQ; q++) {
+            const int ch = q * 256 + tid;
+            *reinterpret_cast<uint4 *>(&colA[buf][(ch / CPC) * STRIDE + (ch % CPC) * 16]) = stg[q];
+        }
+    };
+    int w = seg;
+    if (w < ntiles) { tile_load(w); tile_store(0); }
+    __syncthreads();
+    for (int it = 0; w < ntiles; w += CS, it++) {
+        const int buf = it & 1;
+        const bool more = w + CS < ntiles;
+        if (more) tile_load(w + CS);
+        const int64_t c0 = (int64_t)w * TC;
+        const bool diag = c0 < rbase + 32 * RBLK && c0 + TC > rbase;        // (wave-uniform) the tile holds columns of this wavefront's rows
+#pragma unroll 1
+        for (int sub = 0; sub < TC / 32; sub++) {                       // (not unrolled: 16 chains in flight spilled 700 bytes per lane)
+            bf16x8 af[KS1];
+#pragma unroll
+            for (int s = 0; s < KS1; s++) af[s] = *reinterpret_cast<const bf16x8 *>(&colA[buf][(sub * 32 + r) * STRIDE + (16 * s + 8 * hh) * 2]);
+#pragma unroll
+            for (int b = 0; b < RBLK; b++) {
+                f32x16 acc;
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc[q] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < KS1 - 1; s++) acc = mfma_step<false>(af[s], bfr[b][s], acc);
+                acc = mfma_step<true>(af[KS1 - 1], bfr[b][KS1 - 1], acc);
+                float m = acc[0];
+#pragma unroll
+                for (int q = 1; q < 15; q += 2) m = fmaxf(fmaxf(m, acc[q]), acc[q + 1]);
+                m = fmaxf(m, acc[15]);
+                if (diag) {                                             // the pair (i, i) is not a neighbour: the maximum without it
+                    const int64_t o = rbase + b * 32 + r - (c0 + sub * 32);   // the row's own column inside this 32-column block?
+                    if (o >= 0 && o < 32 && ((o >> 2) & 1) == hh) {
+                        const int qs = (int)((o & 3) | ((o >> 3) << 2));
+                        m = -3.0e38f;
+#pragma unroll
+                        for (int q = 0; q < 16; q++) m = q == qs ? m : fmaxf(m, acc[q]);
+                    }
+                }
+                em[b] = fmaxf(em[b], m);
+            }
+        }
+        if (more) tile_store(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < RBLK; b++) {
+        const int64_t i = rbase + b * 32 + r;
+        const float e = fmaxf(em[b], __shfl_xor(em[b], 32, 64));
+        if (hh == 0 && i < row1) atomicMax(&ekey[i - row0], fkey(e));
+    }
+}
+// E_max -> upper bound of log p_ij over j != i:  d^2 >= nb_i - 2 E_max  (- the rounding of this line),  log p = log(exp(t d) + 1e-8)
+__global__ void sw_rowmin_finish(const uint32_t *__restrict__ ekey, const float *__restrict__ nb, int64_t row0, int64_t rows, float t,
+                                 float *__restrict__ lpub) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= rows) return;
+    const float nbi = nb[row0 + q], e = fkey_inv(ekey[q]);
+    float l2 = fmaf(-2.0f, e, nbi);
+    l2 -= 4e-7f * (fabsf(nbi) + 2.0f * fabsf(e)) + 1e-12f;                 // fp32 rounding of the line above
+    float ub = 1e-8f;                                                     // no usable bound: the distance-free one, log(1 + 1e-8)
+    if (nbi < 3.0e38f && e > -1.0e38f && e < 1.0e38f && l2 > 0.0f && t < 0.0f) {
+        const float dlb = sqrtf(l2) * (1.0f - 1e-6f);
+        ub = __logf(__expf(t * dlb) + 1e-8f) + 2e-6f * (1.0f + fabsf(t * dlb));      // fast-math exp / log: 2e-6 relative covers them
+        ub = fminf(ub, 1e-8f);
+    }
+    lpub[q] = ub;
+}
+
 // ---- select: tight radius from the phase-A hits -------------------------------------------------------------------------------
 // one wavefront per row.  D (loose) = <.,.> + c_j + t_loose is what phase A recorded; L = R_loose - 2 D is the pair's LOWER bound
 // and U = L + SL (nb_i + nb_j) an UPPER bound of d^2 (both roundings of the bf16 products the other way).  The verification
@@ -946,4 +1061,68 @@ int dgg_allpairs_topk_sweep_impl(const float *xp, int64_t N, int h, int64_t row0
         case 64: return launch_sweep<64, 4>(xp, N, row0, row1, t, klim, idx, val, workspace, st);
         default: return launch_sweep<128, 2>(xp, N, row0, row1, t, klim, idx, val, workspace, st);
     }
+}
+
+// row-minimum sweep: workspace = [xw npad (h+16) fp16][nb N f32][ekey rows u32]
+namespace {
+struct RowminLayout { size_t xw, nb, ekey, total; };
+RowminLayout rowmin_layout(int64_t rows, int64_t N, int h) {
+    RowminLayout L;
+    const int64_t npad = (N + TC - 1) / TC * TC;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    L.xw = take((size_t)npad * (h + 16) * 2);
+    L.nb = take((size_t)N * 4);
+    L.ekey = take((size_t)rows * 4);
+    L.total = off;
+    return L;
+}
+template <int H, int RBLK>
+int launch_rowmin(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, float *lpub, void *ws, hipStream_t st) {
+    const int64_t rows = row1 - row0;
+    const RowminLayout L = rowmin_layout(rows, N, H);
+    char *w = reinterpret_cast<char *>(ws);
+    uint16_t *xw = reinterpret_cast<uint16_t *>(w + L.xw);
+    float *nb = reinterpret_cast<float *>(w + L.nb);
+    uint32_t *ekey = reinterpret_cast<uint32_t *>(w + L.ekey);
+    const int ntiles = (int)((N + TC - 1) / TC);
+    const int64_t npad = (int64_t)ntiles * TC;
+    const int rw = 128 * RBLK, nrb = (int)((rows + rw - 1) / rw), rbx = (nrb + 7) / 8;
+    int cs = 1;                                                         // column segments: fill the chip (512 resident workgroups) with few rounds
+    {
+        int64_t best = INT64_MAX;
+        for (int c = 1; c <= 32; c++) {
+            if (c > 1 && ntiles / c < 4) break;
+            const int64_t rounds = ((int64_t)nrb * c + 511) / 512, cost = rounds * ((ntiles + c - 1) / c + 2);
+            if (cost < best) { best = cost; cs = c; }
+        }
+    }
+    if (dgg_check_hip(hipMemsetAsync(ekey, 0, (size_t)rows * 4, st), "rowmin memset") != 0) return DGG_ERR_HIP;     // key 0 = below every float
+    hipLaunchKernelGGL(sw_prep<H>, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, st, xp, N, npad, xw, nb);
+    hipLaunchKernelGGL((sw_rowmin<H, RBLK>), dim3((unsigned)(8 * rbx * cs)), dim3(256), 0, st, xw, npad, row0, row1, ntiles, nrb, rbx, cs, ekey);
+    hipLaunchKernelGGL(sw_rowmin_finish, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, ekey, nb, row0, rows, t, lpub);
+    return dgg_check_launch("allpairs_rowmin_bound");
+}
+}  // namespace
+
+extern "C" {
+// bytes of workspace dgg_allpairs_rowmin_bound needs
+size_t dgg_allpairs_rowmin_ws_bytes(int64_t rows, int64_t N, int h) { return rowmin_layout(rows, N, h).total; }
+// lpub [row1-row0]: for every row i a rigorous UPPER bound of log p_ij = log(exp(t ||xp_i - xp_j||) + 1e-8) over all j != i (reference
+// dgm.py:1618-1623), from an fp16-MFMA lower bound of the squared distance to the row's nearest other node (dgg_topk_sweep.hip).  The
+// early-out tests of the noise generators take it in place of the distance-free bound 1e-8.  latent_dim in {16, 32, 64, 128}, t < 0.
+int dgg_allpairs_rowmin_bound(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, float *lpub, void *workspace, size_t ws_bytes,
+                              void *stream) {
+    if (!xp || !lpub || row0 < 0 || row1 > N || row0 > row1) return dgg_set_error(DGG_ERR_ARG, "allpairs_rowmin_bound: bad row range or NULL arrays");
+    if (h != 16 && h != 32 && h != 64 && h != 128) return dgg_set_error(DGG_ERR_UNSUPPORTED, "allpairs_rowmin_bound: latent_dim in {16,32,64,128}");
+    if (row1 == row0) return 0;
+    if (!workspace || ws_bytes < dgg_allpairs_rowmin_ws_bytes(row1 - row0, N, h)) return dgg_set_error(DGG_ERR_ARG, "allpairs_rowmin_bound: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    switch (h) {
+        case 16: return launch_rowmin<16, 4>(xp, N, row0, row1, t, lpub, workspace, st);
+        case 32: return launch_rowmin<32, 4>(xp, N, row0, row1, t, lpub, workspace, st);
+        case 64: return launch_rowmin<64, 4>(xp, N, row0, row1, t, lpub, workspace, st);
+        default: return launch_rowmin<128, 2>(xp, N, row0, row1, t, lpub, workspace, st);
+    }
+}
 }

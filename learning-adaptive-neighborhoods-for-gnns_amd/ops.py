@@ -336,7 +336,7 @@ def allpairs_topk(xp, K=DEFAULT_K, t=T_DIST, noise_mode=NOISE_NONE, G=None, seed
     return idx, val
 
 
-def ranked_probe(xp, k_limit=None, t=T_DIST, seed=(0, 0), rows=None, stride=1, max_blocks=0):
+def ranked_probe(xp, k_limit=None, t=T_DIST, seed=(0, 0), rows=None, stride=1, max_blocks=0, lpub=None):
     """Walk statistics of the ranked search (NOISE_RANKED) on every `stride`-th row, each walk cut after `max_blocks` blocks of 64
     ranks (0: none): dict(rows, blocks_per_row, gathered_per_row, scored_per_row, budget_hit_frac, max_blocks).  One
     synchronisation; the search's depth is a property of the data (dgg_allpairs_ranked_probe)."""
@@ -348,7 +348,8 @@ def ranked_probe(xp, k_limit=None, t=T_DIST, seed=(0, 0), rows=None, stride=1, m
         sd = seed.cpu()
         seed = (int(sd[0]) & 0xFFFFFFFF, int(sd[1]) & 0xFFFFFFFF)
     _lib.check(_lib.lib().dgg_allpairs_ranked_probe(_ptr(xp), N, h, r0, r1, t, seed[0], seed[1], _ptr(None if k_limit is None else _chk(k_limit)),
-                                                    int(stride), int(max_blocks), _ptr(cnt), _stream()), "allpairs_ranked_probe")
+                                                    int(stride), int(max_blocks), _ptr(cnt), _ptr(None if lpub is None else _chk(lpub)), _stream()),
+               "allpairs_ranked_probe")
     c = [int(v) for v in cnt.cpu()]
     n = max(c[0], 1)
     return {"rows": c[0], "blocks_per_row": c[1] / n, "gathered_per_row": c[2] / n, "scored_per_row": c[3] / n,
@@ -393,9 +394,10 @@ def fast_path_failed_rows(ws, N, h, rows=None, stats=False):
     return nfail, [int(v) for v in blk[8:32].view(torch.int64)]
 
 
-def allpairs_topk_softk(xp, k, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, seed=(0, 0), rows=None):
+def allpairs_topk_softk(xp, k, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, seed=(0, 0), rows=None, lpub=None):
     """ranked-noise all-pairs top-64 with the first-k ramp fused (allpairs_topk(k_limit=k) + softk_fwd in one launch)
-    -> idx, val, w [rows,64], rs [rows]"""
+    -> idx, val, w [rows,64], rs [rows].  lpub (optional, [rows]): rowmin_logp_bound's upper bounds of log p over a row's other nodes --
+    the walk stops on G + lpub[i] instead of the distance-free G + 1e-8 (same result, fewer ranks on spread latents)."""
     xp, k = _chk(xp), _chk(k)
     N, h = xp.shape
     r0, r1 = (0, N) if rows is None else rows
@@ -404,21 +406,37 @@ def allpairs_topk_softk(xp, k, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, seed=(0, 0
     w = torch.empty((r1 - r0, 64), device=xp.device, dtype=torch.float32)
     rs = torch.empty((r1 - r0,), device=xp.device, dtype=torch.float32)
     pe = _probe_begin()
+    dseed = None
     if isinstance(seed, torch.Tensor):       # device seed [2] (int32 / uint32 bits): one captured graph, fresh noise per replay
         assert seed.is_cuda and seed.numel() == 2 and seed.element_size() == 4
-        _lib.check(_lib.lib().dgg_allpairs_topk_ranked_softk_dseed(_ptr(xp), N, h, r0, r1, t, _ptr(seed), _ptr(k), mode, _ptr(idx), _ptr(val),
-                                                                   _ptr(w), _ptr(rs), _stream()), "allpairs_topk_ranked_softk_dseed")
-    else:
-        _lib.check(_lib.lib().dgg_allpairs_topk_ranked_softk(_ptr(xp), N, h, r0, r1, t, seed[0], seed[1], _ptr(k), mode, _ptr(idx), _ptr(val),
-                                                             _ptr(w), _ptr(rs), _stream()), "allpairs_topk_ranked_softk")
+        dseed, seed = seed, (0, 0)
+    _lib.check(_lib.lib().dgg_allpairs_topk_ranked_softk_lp(_ptr(xp), N, h, r0, r1, t, seed[0], seed[1], _ptr(dseed), _ptr(None if lpub is None else _chk(lpub)),
+                                                            _ptr(k), mode, _ptr(idx), _ptr(val), _ptr(w), _ptr(rs), _stream()), "allpairs_topk_ranked_softk_lp")
     _probe_end("allpairs_topk", pe)
     return idx, val, w, rs
+
+
+def rowmin_logp_bound(xp, t=T_DIST, rows=None):
+    """-> lpub [rows]: for every row i a rigorous upper bound of log p_ij = log(exp(t ||xp_i - xp_j||) + 1e-8) over all j != i, from an
+    fp16-MFMA lower bound of the distance to the row's nearest other node (include/dgg_hip.h, dgg_allpairs_rowmin_bound: one N^2 sweep on
+    the matrix cores, ~1 ms at N = 100 000).  The searches take it in place of the distance-free bound of a pair's log-score."""
+    xp = _chk(xp)
+    N, h = xp.shape
+    r0, r1 = (0, N) if rows is None else rows
+    out = torch.empty((r1 - r0,), device=xp.device, dtype=torch.float32)
+    nb = int(_lib.lib().dgg_allpairs_rowmin_ws_bytes(r1 - r0, N, h))
+    ws = torch.empty((nb,), device=xp.device, dtype=torch.uint8)
+    pe = _probe_begin()
+    _lib.check(_lib.lib().dgg_allpairs_rowmin_bound(_ptr(xp), N, h, r0, r1, float(t), _ptr(out), _ptr(ws), nb, _stream()), "allpairs_rowmin_bound")
+    _probe_end("rowmin_bound", pe)
+    return out
 
 
 # ---- rows wider than 64 ranks: chunked rows ------------------------------------------------------------------------------------------
 CHUNK_MAXM = 32          # chunks of 64 ranks per row that the ranked search holds in REGISTER lists (2048 ranks); wider rows and the other
                          # noise generators go through threshold buffers in memory (dgg_allpairs_topk_anywide): any width
 CHUNK_MAXM_ANY = 1 << 20
+ANYWIDE_HASH_BOUND = os.environ.get("DGG_ANYWIDE_HASH_BOUND", "1") != "0"     # (0: the hash generators' wide rows on the distance-free filter)
 
 
 class ChunkCapacityError(RuntimeError):
@@ -486,12 +504,14 @@ def chunk_layout(k, maxm=None, ccap=None, ncols=None, sticky=None):
         cap = total
 
 
-def allpairs_topk_wide(xp, k, layout, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, seed=(0, 0), rows=None, ramp=True, noise_mode=None):
+def allpairs_topk_wide(xp, k, layout, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, seed=(0, 0), rows=None, ramp=True, noise_mode=None, lpub=None):
     """All-pairs top-L_i on chunked rows (rows wider than 64 ranks, ANY width): -> idx, val, w [chunks,64], rs [rows] (w / rs None with
     ramp=False).  `layout` = chunk_layout(k of these rows).  noise_mode: NOISE_RANKED (default: the register-list search for the rows
     of up to 32 chunks + the threshold-buffer walk for the wider ones), NOISE_NONE / NOISE_HASH / NOISE_HASH_SYM (threshold buffers,
     every row; include/dgg_hip.h, dgg_allpairs_topk_anywide).  NOISE_RANKED_SYM has no wide-row form of its own: callers evaluate wide
-    rows under NOISE_HASH_SYM (the same law, another realisation)."""
+    rows under NOISE_HASH_SYM (the same law, another realisation).  lpub ([rows], optional): rowmin_logp_bound's upper bounds of log p
+    over a row's other nodes, for the stop tests of the ranked search; the per-pair hash generators compute it themselves (their integer
+    filter admits 1 / E[p^(1/0.3)] times fewer candidates with it: 24 -> ~8 ms at N = 100 000, k ~ 130)."""
     xp, k = _chk(xp), _chk(k)
     N, h = xp.shape
     r0, r1 = (0, N) if rows is None else rows
@@ -507,17 +527,20 @@ def allpairs_topk_wide(xp, k, layout, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, see
     if isinstance(seed, torch.Tensor):
         assert seed.is_cuda and seed.numel() == 2 and seed.element_size() == 4
         dseed, seed = seed, (0, 0)
+    if lpub is None and nm in (NOISE_HASH, NOISE_HASH_SYM) and ANYWIDE_HASH_BOUND:
+        lpub = rowmin_logp_bound(xp, t, rows=(r0, r1))
+    lpub = None if lpub is None else _chk(lpub)
     pe = _probe_begin()
     if nm == NOISE_RANKED:
         _lib.check(_lib.lib().dgg_allpairs_topk_ranked_wide(_ptr(xp), N, h, r0, r1, t, seed[0], seed[1], _ptr(dseed), _ptr(k), mode, layout.maxm,
-                                                            _ptr(layout.cptr), C_, _ptr(idx), _ptr(val), _ptr(w), _ptr(rs), _stream()),
+                                                            _ptr(layout.cptr), C_, _ptr(idx), _ptr(val), _ptr(w), _ptr(rs), _ptr(lpub), _stream()),
                    "allpairs_topk_ranked_wide")
     if nm != NOISE_RANKED or layout.maxm > CHUNK_MAXM:
         nb = int(_lib.lib().dgg_allpairs_anywide_ws_bytes(C_, r1 - r0))
         ws = torch.empty((nb,), device=xp.device, dtype=torch.uint8)
         _lib.check(_lib.lib().dgg_allpairs_topk_anywide(_ptr(xp), N, h, r0, r1, t, nm, seed[0], seed[1], _ptr(dseed), _ptr(k), mode, layout.maxm,
                                                         CHUNK_MAXM if nm == NOISE_RANKED else 0, _ptr(layout.cptr), C_, _ptr(idx), _ptr(val),
-                                                        _ptr(w), _ptr(rs), _ptr(ws), nb, _stream()), "allpairs_topk_anywide")
+                                                        _ptr(w), _ptr(rs), _ptr(lpub), _ptr(ws), nb, _stream()), "allpairs_topk_anywide")
     _probe_end("allpairs_topk", pe)
     return idx, val, w, rs
 

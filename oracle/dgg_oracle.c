@@ -185,20 +185,30 @@ static inline float ranked_gumbel(uint64_t S) {                 /* S = fixed-poi
     float L = (float)q * 5.9604644775390625e-8f;                /* -log U_(s), resolution 2^-24 */
     return -0.3f * ora_log(L);
 }
-/* noise of row i for every column: G[j], j < N */
+/* noise of row i for every column: G[j], j < N.
+ * Round 6: the DIAGONAL has its own, independent variate; the ranked sequence covers the n = N - 1 OTHER columns (slot c of the keyed
+ * bijection -> column c + (c >= i)).  The joint law is unchanged -- order statistics of n iid uniforms on a random permutation of the
+ * off-diagonal columns, one more independent sample on the diagonal: N iid Gumbel(0, 0.3) -- and the walk of the HIP search now visits
+ * the row's own column (the one pair at distance 0) FIRST, so every rank it has not reached is another node and the search may bound
+ * its score with the row's nearest-neighbour distance (dgg_allpairs_rowmin_bound).
+ * Diagonal: E = -log V from the generator's own exponential variate (ranked_term with rank 1 of 1: the term is floor(E 2^40), no
+ * division), G = -0.3 log E in the fixed point of ranked_gumbel: -0.3 log(-log V) is Gumbel(0, 0.3). */
+#define ORA_RANKED_DIAG_KEY 0xA5A5A5A5u
 ORA_API void ora_ranked_row(uint32_t s0, uint32_t s1, uint32_t i, int64_t N, float *G) {
     uint32_t k1, k2;
     ora_rowkey(s0, s1, i, &k1, &k2);
     const uint32_t k3 = mix32(k2 ^ 0x68E31DA4u);
-    const int b = ranked_bits(N);
+    const int64_t n = N - 1;
+    const int b = ranked_bits(n);
     uint64_t S = 0;
     uint32_t s = 0;
+    if ((int64_t)i < N) G[i] = ranked_gumbel(ranked_term(k1, k3 ^ ORA_RANKED_DIAG_KEY, 1, 1));
     for (uint64_t r = 0; r < ((uint64_t)1 << b); r++) {
         uint32_t c = ranked_sigma((uint32_t)r, k1, k2, k3, b);
-        if ((int64_t)c >= N) continue;
+        if ((int64_t)c >= n) continue;
         s++;
-        S += ranked_term(k1, k3, s, N);
-        G[c] = ranked_gumbel(S);
+        S += ranked_term(k1, k3, s, n);
+        G[(int64_t)c + ((int64_t)c >= (int64_t)i ? 1 : 0)] = ranked_gumbel(S);
     }
 }
 

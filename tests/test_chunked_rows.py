@@ -215,13 +215,13 @@ def test_fixed_capacity_overflow_is_memory_safe_and_sticky(dev):
         P_ = lambda t_: C.c_void_p(t_.data_ptr())  # noqa: E731
         if nm == ops.NOISE_RANKED:
             _lib.check(L.dgg_allpairs_topk_ranked_wide(P_(xp), N, h, 0, N, ops.T_DIST, 1, 2, None, P_(k), 0, 4, P_(lay.cptr), cap, P_(idx), P_(val), P_(w),
-                                                       P_(rs), C.c_void_p(st)), "ranked_wide")
+                                                       P_(rs), None, C.c_void_p(st)), "ranked_wide")
         else:
             nb = int(L.dgg_allpairs_anywide_ws_bytes(cap, N))
             ws = torch.empty(nb + 4096, dtype=torch.uint8, device=dev)
             ws[nb:] = 0x5A
             _lib.check(L.dgg_allpairs_topk_anywide(P_(xp), N, h, 0, N, ops.T_DIST, nm, 1, 2, None, P_(k), 0, 4, 0, P_(lay.cptr), cap, P_(idx), P_(val),
-                                                   P_(w), P_(rs), P_(ws), nb, C.c_void_p(st)), "anywide")
+                                                   P_(w), P_(rs), None, P_(ws), nb, C.c_void_p(st)), "anywide")
             assert bool((ws[nb:] == 0x5A).all()), "the evaluator wrote beyond its workspace"
         torch.cuda.synchronize()
         assert bool((idx[cap:] == 12345).all()) and bool((val[cap:] == 7.0).all()) and bool((w[cap:] == 7.0).all()), "guard chunks overwritten"

@@ -2866,3 +2866,31 @@ def test_config3_500k_nodes_in_eight_row_shards(dev):
         ri, rv = O.allpairs_topk(xp_c, K=K, noise_mode=O.NOISE_RANKED, seed=(1234, 0), rows=(r, r + 1))
         m = Nn(s["idx"][r]) >= 0
         assert np.array_equal(Nn(s["idx"][r])[m], ri[0][m]) and np.array_equal(Nn(s["val"][r])[m], rv[0][m])
+
+
+@pytest.mark.parametrize("N,h,scale", [(3000, 64, 1.0), (1111, 32, 8.0), (5000, 128, 0.3), (700, 16, 20.0), (4096, 64, 4.0)])
+def test_rowmin_bound_is_rigorous_and_tight(dev, N, h, scale):
+    """dgg_allpairs_rowmin_bound: lpub[i] >= log(exp(t d_nn(i)) + 1e-8) for the distance d_nn of EVERY row to its nearest other node
+    (float64 brute force) -- a bound that is ever too small would let a search drop a pair it must score -- and within a few 1e-3 of
+    the squared norms of it (the fp16 operands' slack); duplicate rows (distance 0) and row shards included"""
+    from dgg_amd import ops
+    rng = np.random.default_rng(N + h)
+    xp = (rng.standard_normal((N, h)) * scale).astype(np.float32)
+    xp[17] = xp[3]                                               # a duplicate: nearest other node at distance 0
+    xp[5] *= 30.0                                                # a far outlier
+    t = -0.05
+    X = xp.astype(np.float64)
+    n2 = (X * X).sum(1)
+    D2 = n2[:, None] + n2[None, :] - 2.0 * X @ X.T
+    np.fill_diagonal(D2, np.inf)
+    dnn = np.sqrt(np.maximum(D2.min(1), 0.0))
+    true = np.log(np.exp(t * dnn) + 1e-8)
+    lp = Nn(ops.rowmin_logp_bound(T(xp, dev), t))
+    assert (lp >= true - 1e-7).all(), f"bound below the truth by {float((true - lp).max()):.3e}"
+    assert (lp <= 1e-8 + 1e-12).all()
+    slack = -t * (np.sqrt(np.maximum(D2.min(1), 0.0) ) - np.sqrt(np.maximum(D2.min(1) - 4.5e-3 * (n2 + n2[D2.argmin(1)]) - 1e-3, 0.0)))
+    assert (lp - true <= slack + 2e-5 * (1 + np.abs(true))).all(), f"bound looser than the fp16 slack allows: {float((lp - true - slack).max()):.3e}"
+    assert abs(lp[3] - np.log(1 + 1e-8)) < 1e-6 and abs(lp[17] - np.log(1 + 1e-8)) < 1e-6
+    lo, hi = N // 3, N // 3 + 301
+    sub = Nn(ops.rowmin_logp_bound(T(xp, dev), t, rows=(lo, hi)))
+    assert np.array_equal(sub, lp[lo:hi])
