@@ -875,6 +875,10 @@ class SyntheticRun:
         self.wide = world == 1 and not force and not emu and hasattr(ops, "chunk_layout") and h in (16, 32, 64, 128)
         if self.wide:
             self.layer.wide_rows = "auto"
+        if noise_mode == ops.NOISE_RANKED and world == 1 and not force and not emu:
+            # the search's stop tests take the rows' nearest-neighbour bound when a pilot walk says the data makes it walk deep (one probe
+            # every 16 EAGER forwards; a captured step replays the decision of the warm-up)
+            self.layer.tight_bound = os.environ.get("DGG_BENCH_TIGHT", "auto")
         self.grads = None
         # ranked noise: the seed lives in DEVICE memory and is advanced by a (captured) increment at the top of every step, so ONE
         # hipGraph draws fresh noise on every replay -- what training does per forward (reference dgm.py:1226); the other
@@ -1266,7 +1270,10 @@ def bench_synthetic(a, dev, world, rank, force):
                 e0, e1 = pv["allpairs_topk"][0]
                 regimes[name] = {"feat_scale": fs_, "data": dat_, "pilot": pilot, "pilot_estimate_ms": est * 1e-3,
                                  "measured_walk_every_16th_row": meas, "ms_per_step_ranked": ms_ranked,
-                                 "pair_stage_ms_ranked": e0.elapsed_time(e1), "pair_stage_ms_hash_guess_and_verify": ms_hash_pair}
+                                 "pair_stage_ms_ranked": e0.elapsed_time(e1), "pair_stage_ms_hash_guess_and_verify": ms_hash_pair,
+                                 # nearest-neighbour bound in the walk's stop tests (dgg_allpairs_rowmin_bound; its sweep is inside
+                                 # pair_stage_ms_ranked when on): decided by the layer's own pilot walk
+                                 "row_bound_on": bool(rr.layer._tight_on), "row_bound_pilot": rr.layer.tight_probe}
                 del rr, xp_r
                 torch.cuda.empty_cache()
             except Exception as e:  # noqa: BLE001

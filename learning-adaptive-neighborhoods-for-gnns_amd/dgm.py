@@ -674,6 +674,7 @@ class DGG_LearnableK_debug(nn.Module):
             layer = self.__dict__["_fused_layer"] = ShardedDGGConv(ops, N, K=64, t=ops.T_DIST)
         layer.cand, layer.noise_mode, layer.seed, layer.mode, layer.scorer = cand, noise_mode, seed, mode, None
         layer.sym_fallback, layer.sym_hash = getattr(a, "dgg_sym_generator", "auto") != "ranked", False
+        layer.tight_bound = getattr(a, "dgg_tight_bound", "auto")     # ranked search: nearest-neighbour bound in its stop tests when the walk is deep
         layer.x_grad = bool(x.requires_grad)
         # all-pairs rows wider than the 64-rank list (learned degrees k_i + 9.5 > 64): chunked rows inside the engine, from the forward
         # that first needs them (one readback of the chunk count per forward; a hipGraph capture replays the last eager layout)

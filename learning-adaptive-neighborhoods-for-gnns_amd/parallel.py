@@ -145,6 +145,8 @@ class ShardedDGGConv:
         # generator it names), on for the nn.Module mirror
         self.sym_fallback = False
         self.sym_hash = False
+        self.tight_bound = "off"                             # ranked search: row-minimum distance bound in its stop tests (_row_bound)
+        self._tight_on, self._tight_n, self.tight_probe = False, 0, None
 
     def check_generator(self):
         """raises if the ranked symmetric noise generator (noise_mode 5) could not settle every row inside its workspace in any
@@ -194,6 +196,34 @@ class ShardedDGGConv:
         if not lay.wide and self.wide_rows == "auto":
             return None
         return lay
+
+    def _row_bound(self, xp, k):
+        """-> lpub [own rows] or None.  The ranked search bounds the score of the ranks it has not reached by their noise alone, i.e. as
+        if they sat at distance 0; on latents whose distances spread over several noise scales it then walks ~ exp(spread / 0.3) times
+        deeper than it has to (bench.py data_regimes: 2 blocks of 64 ranks per row on unit-scale features, 2 000 at x16).  With a
+        lower bound of the distance to the row's nearest OTHER node (kern.rowmin_logp_bound: one fp16-MFMA sweep over all pairs, ~1.4 ms
+        at N = 100 000) the same stop test uses G + log p_max(i).  tight_bound: "off" | "on" | "auto" = on when a pilot walk (~1000
+        sampled rows, 64-block budget, every 16th forward and never inside a capture) puts the search's cost above 2.5 x the sweep's."""
+        kern = self.kern
+        if self.tight_bound == "off" or not hasattr(kern, "rowmin_logp_bound") or xp.shape[1] not in (16, 32, 64, 128) or self.t >= 0:
+            return None
+        if self.tight_bound == "auto":
+            capturing = xp.is_cuda and torch.cuda.is_current_stream_capturing()
+            if not capturing and self._tight_n % 16 == 0:
+                seed = self.seed
+                if torch.is_tensor(seed):
+                    sd = seed.cpu()
+                    seed = (int(sd[0]) & 0xFFFFFFFF, int(sd[1]) & 0xFFFFFFFF)
+                pr = kern.ranked_probe(xp, k, self.t, seed, rows=(self.r0, self.r1), stride=max(1, (self.r1 - self.r0) // 1024), max_blocks=64)
+                est = kern.ranked_cost_estimate(pr, self.N, rows=self.r1 - self.r0)
+                sweep_us = 1400.0 * (self.N / 1e5) * ((self.r1 - self.r0) / 1e5) * (xp.shape[1] + 16) / 80.0
+                self._tight_on = est > 2.5 * sweep_us and self.N >= 8192
+                self.tight_probe = dict(pr, ranked_us_estimate=est, sweep_us_estimate=sweep_us)
+            if not capturing:
+                self._tight_n += 1
+            if not self._tight_on:
+                return None
+        return kern.rowmin_logp_bound(xp, self.t, rows=(self.r0, self.r1))
 
     def emulate_rank(self, world, rank):
         """TIMING DIAGNOSTIC (bench.py --emulate-world): do the work of `rank` of `world` in a single process -- own row range
@@ -292,10 +322,14 @@ class ShardedDGGConv:
         elif self.noise_mode == 4 and self.K == 64 and hasattr(kern, "allpairs_topk_softk") and xp.shape[1] in (8, 16, 32, 64, 128):
             # ranked noise: the ramp is applied inside the search kernel, while the settled list is still in registers
             s["layout"] = lay = self._chunk_layout(s["k"]) if xp.shape[1] in (16, 32, 64, 128) else None
+            lkw_ = {}
+            lp = self._row_bound(xp, s["k"])        # upper bounds of log p over a row's other nodes, when the walk is deep enough to pay for them
+            if lp is not None:
+                lkw_["lpub"] = lp
             if lay is not None:                     # rows wider than 64 ranks: ceil(k_i + 8.5) + 1 ranks of every row, in chunks of 64
-                s["idx"], s["val"], s["w"], rs_local = kern.allpairs_topk_wide(xp, s["k"], lay, self.mode, self.t, self.seed, rows=(self.r0, self.r1))
+                s["idx"], s["val"], s["w"], rs_local = kern.allpairs_topk_wide(xp, s["k"], lay, self.mode, self.t, self.seed, rows=(self.r0, self.r1), **lkw_)
             else:
-                s["idx"], s["val"], s["w"], rs_local = kern.allpairs_topk_softk(xp, s["k"], self.mode, self.t, self.seed, rows=(self.r0, self.r1))
+                s["idx"], s["val"], s["w"], rs_local = kern.allpairs_topk_softk(xp, s["k"], self.mode, self.t, self.seed, rows=(self.r0, self.r1), **lkw_)
         else:
             # the generators without a row-wise early-stopping search (unperturbed scores, per-pair hash noise, the ranked symmetric
             # generator).  Rows wider than 64 ranks: chunked rows through the threshold-buffer evaluator (any width; the reference's
