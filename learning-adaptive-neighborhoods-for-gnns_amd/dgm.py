@@ -311,6 +311,7 @@ class _DGGScoresFn(torch.autograd.Function):
 
 
 _PAD_CACHE = {}
+_EDGE_MLP_FUSED = ("u-v-deg", "u-v-A_uv", "u-v-deg-dist", "edge_conv", "A_uv")     # edge-MLP scorers the fused layer covers
 
 
 def _pad_features(x, params, keys):
@@ -603,15 +604,55 @@ class DGG_LearnableK_debug(nn.Module):
         edge-MLP scorer (u-v-deg, u-v-A_uv, u-v-deg-dist, edge_conv, A_uv; edge-list candidates), k-net "x", soft
         k_times_edge_prob / k_only output, widths the partitioned backward covers, rows that fit the ELL width.
         want_norm: additionally return the NORMALISED adjacency as a differentiable EllAdjacency for the layers that read the same
-        graph after this one (GCN_DGG's second layer): its gradient flows back into the generator through the same node."""
+        graph after this one (GCN_DGG's second layer): its gradient flows back into the generator through the same node.
+        The steps: _fused_outside (configurations the node does not cover) -> candidates -> _fused_scorer (edge-MLP terms) ->
+        _fused_configure (noise generator, what rows wider than 64 ranks do, flags) -> the node -> _fused_result (what the forward's
+        learned degrees decide after the fact, the returned adjacencies)."""
         from .parallel import ShardedDGGConv
-        a = self.args
-        h = self.latent_dim
+        why = self._fused_outside(x, in_adj, conv_weight)
+        if why is not None:
+            return self._fused_fallback(why)
+        a, N = self.args, x.shape[0]
+        mlp_mode = self.edge_prob_net_mode in _EDGE_MLP_FUSED
+        wide_state = None
+        if isinstance(in_adj, AllPairs):
+            cand, deg, rowptr = None, in_adj.prior_degree, None
+            if self.__dict__.get("_ap_wide", {}).get("on") or (getattr(a, "dgg_wide_rows", "auto") == "csr" and
+                                                               N <= int(getattr(a, "dgg_allpairs_csr_max", 8192))):
+                return None                                   # (policy "csr": every column ranked, the modules' CSR form)
+        else:
+            if isinstance(in_adj, EllAdjacency):
+                in_adj = in_adj.to_sparse().detach()
+            rowptr, col, deg = csr_candidates(in_adj)
+            cand = (rowptr, col)
+            wide_state = self._wide_rows_state(in_adj, rowptr)
+            if wide_state is True:                            # (known before any kernel runs: this graph takes the CSR form -- no discarded forward)
+                return self._fused_fallback("rows wider than the list with learned degrees beyond it (CSR form)")
+        mlp, sc_static = self._fused_scorer(in_adj) if mlp_mode else (None, None)
+        layer = self.__dict__.get("_fused_layer")
+        if layer is None or layer.N != N:
+            layer = self.__dict__["_fused_layer"] = ShardedDGGConv(ops, N, K=64, t=ops.T_DIST)
+        noise_mode, chunk_active = self._fused_configure(layer, x, cand, wide_state, mlp_mode)
+        kn = self.k_net
+        params = (self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias, self.node_encode_for_k[0].weight,
+                  self.node_encode_for_k[0].bias, self.k_embed[0].weight, self.k_embed[0].bias, kn.k_mu.weight, kn.k_mu.bias,
+                  kn.k_project.weight, kn.k_project.bias, conv_weight)
+        # no backward can follow (torch.no_grad(), frozen parameters): the partition's sort -- read by the backward only -- is skipped
+        layer.want_backward = ops.backward_will_follow(x, *params, *([mlp["Wcat"], mlp["b1"], mlp["w2"], mlp["b2"]] if mlp_mode else []))
+        if mlp_mode:
+            Z, ahat = _FusedDGGMlpConvFn.apply(x, deg, layer, sc_static, mlp["Wcat"], mlp["wdu"], mlp["wdv"], mlp["wex"], mlp["b1"],
+                                               mlp["w2"], mlp["b2"], *params)
+        else:
+            Z, ahat = _FusedDGGConvFn.apply(x, deg, layer, *params)       # (ops.ChunkCapacityError: a learned degree is NaN)
+        return self._fused_result(layer, Z, ahat, in_adj, cand, rowptr, noise_mode, chunk_active, mlp_mode, want_norm)
+
+    def _fused_outside(self, x, in_adj, conv_weight):
+        """-> the reason this configuration is outside the fused layer, or None.  Which clause sends a forward to the separate modules
+        is LOGGED, once per module and clause (logger "dgg_amd", level INFO), and counted in self.fused_fallback: the separate modules
+        are ~1.7x slower at Pubmed size, and a silent fall-back looks like a performance bug of the fused layer"""
+        a, h = self.args, self.latent_dim
         fin, fout = conv_weight.shape
-        mlp_mode = self.edge_prob_net_mode in ("u-v-deg", "u-v-A_uv", "u-v-deg-dist", "edge_conv", "A_uv")
-        # which clause sends a forward to the separate modules is LOGGED, once per module and clause (logger "dgg_amd", level INFO),
-        # and counted in self.fused_fallback: the separate modules are ~1.7x slower at Pubmed size, and a silent fall-back looks like a
-        # performance bug of the fused layer
+        mlp_mode = self.edge_prob_net_mode in _EDGE_MLP_FUSED
         clauses = (
             ("scorer outside u-v-dist / the edge-MLP family", self.edge_prob_net_mode != "u-v-dist" and not mlp_mode),
             ("edge-MLP scorer on all-pairs candidates", mlp_mode and isinstance(in_adj, AllPairs)),
@@ -629,49 +670,37 @@ class DGG_LearnableK_debug(nn.Module):
             ("ell_width other than 64", self.ell_width != 64),
             ("input dtype other than float32", x.dtype != torch.float32),
         )
-        for why, hit in clauses:
-            if hit:
-                return self._fused_fallback(why)
-        if isinstance(in_adj, AllPairs):
-            cand, deg, rowptr = None, in_adj.prior_degree, None
-            if self.__dict__.get("_ap_wide", {}).get("on") or (getattr(a, "dgg_wide_rows", "auto") == "csr" and
-                                                               x.shape[0] <= int(getattr(a, "dgg_allpairs_csr_max", 8192))):
-                return None                                   # (policy "csr": every column ranked, the modules' CSR form)
-        else:
-            if isinstance(in_adj, EllAdjacency):
-                in_adj = in_adj.to_sparse().detach()
-            rowptr, col, deg = csr_candidates(in_adj)
-            cand = (rowptr, col)
-            wide_state = self._wide_rows_state(in_adj, rowptr)
-            if wide_state is True:                            # (known before any kernel runs: this graph takes the CSR form -- no discarded forward)
-                return self._fused_fallback("rows wider than the list with learned degrees beyond it (CSR form)")
-        sc_static = None
-        if mlp_mode:                                          # per-edge inputs of the scorer, in the CSR order of the candidates
-            avals = _cached("values_f32", in_adj, lambda: in_adj.coalesce().values().to(torch.float32).contiguous())
-            if self.edge_prob_net_mode in ("edge_conv", "A_uv"):
-                mlp, ex_in = self._edge_mlp_terms(avals)
-                packed = None
-            else:                                             # edge_encode.0.weight goes into the node whole (sliced inside it)
-                need = {"u-v-deg": 2, "u-v-A_uv": 1, "u-v-deg-dist": 3}[self.edge_prob_net_mode]
-                W0 = self.edge_encode[0].weight
-                assert W0.shape[1] == 2 * h + need, f"edge mode {self.edge_prob_net_mode!r} needs extra_edge_dim={need} (edge_encode.0 is {tuple(W0.shape)})"
-                cols = {"u-v-deg": (2 * h, 2 * h + 1, None), "u-v-A_uv": (None, None, 2 * h), "u-v-deg-dist": (2 * h, 2 * h + 1, 2 * h + 2)}
-                packed = (h, cols[self.edge_prob_net_mode])
-                mlp = dict(Wcat=W0, wdu=None, wdv=None, wex=None, b1=self.edge_encode[0].bias, w2=self.edge_encode[2].weight,
-                           b2=self.edge_encode[2].bias, act=ops.ACT_LEAKY, ex_mode={"u-v-deg": 0, "u-v-A_uv": 1, "u-v-deg-dist": 2}[self.edge_prob_net_mode],
-                           t_ex=-1.0 if self.edge_prob_net_mode == "u-v-deg-dist" else 0.0)
-                ex_in = avals if self.edge_prob_net_mode == "u-v-A_uv" else None
-            sc_static = dict(erow=csr_pattern(in_adj)[2], ex_in=ex_in, ex_mode=mlp["ex_mode"], t_ex=mlp["t_ex"], act=mlp["act"], packed=packed)
+        return next((why for why, hit in clauses if hit), None)
+
+    def _fused_scorer(self, in_adj):
+        """the edge-MLP scorer's parameters and per-edge inputs for the fused node, in the CSR order of the candidates -> (mlp, static)"""
+        h = self.latent_dim
+        avals = _cached("values_f32", in_adj, lambda: in_adj.coalesce().values().to(torch.float32).contiguous())
+        if self.edge_prob_net_mode in ("edge_conv", "A_uv"):
+            mlp, ex_in = self._edge_mlp_terms(avals)
+            packed = None
+        else:                                                 # edge_encode.0.weight goes into the node whole (sliced inside it)
+            need = {"u-v-deg": 2, "u-v-A_uv": 1, "u-v-deg-dist": 3}[self.edge_prob_net_mode]
+            W0 = self.edge_encode[0].weight
+            assert W0.shape[1] == 2 * h + need, f"edge mode {self.edge_prob_net_mode!r} needs extra_edge_dim={need} (edge_encode.0 is {tuple(W0.shape)})"
+            cols = {"u-v-deg": (2 * h, 2 * h + 1, None), "u-v-A_uv": (None, None, 2 * h), "u-v-deg-dist": (2 * h, 2 * h + 1, 2 * h + 2)}
+            packed = (h, cols[self.edge_prob_net_mode])
+            mlp = dict(Wcat=W0, wdu=None, wdv=None, wex=None, b1=self.edge_encode[0].bias, w2=self.edge_encode[2].weight,
+                       b2=self.edge_encode[2].bias, act=ops.ACT_LEAKY, ex_mode={"u-v-deg": 0, "u-v-A_uv": 1, "u-v-deg-dist": 2}[self.edge_prob_net_mode],
+                       t_ex=-1.0 if self.edge_prob_net_mode == "u-v-deg-dist" else 0.0)
+            ex_in = avals if self.edge_prob_net_mode == "u-v-A_uv" else None
+        return mlp, dict(erow=csr_pattern(in_adj)[2], ex_in=ex_in, ex_mode=mlp["ex_mode"], t_ex=mlp["t_ex"], act=mlp["act"], packed=packed)
+
+    def _fused_configure(self, layer, x, cand, wide_state, mlp_mode):
+        """sets the engine up for this forward: noise generator, selection mode, what rows wider than 64 ranks do, device flags
+        -> (noise_mode, chunk_active = this forward reads its chunk layout back)"""
+        a, N = self.args, x.shape[0]
         noise_mode, _, seed = self._noise_cfg()
         if cand is None and noise_mode == ops.NOISE_RANKED:
             noise_mode = self._asym_generator_now(x, seed)
         elif cand is not None:
             noise_mode = {ops.NOISE_RANKED: ops.NOISE_HASH, ops.NOISE_RANKED_SYM: ops.NOISE_HASH_SYM}.get(noise_mode, noise_mode)
         mode = ops.MODE_K_TIMES_EDGE_PROB if self.k_select_mode == "k_times_edge_prob" else ops.MODE_K_ONLY
-        N = x.shape[0]
-        layer = self.__dict__.get("_fused_layer")
-        if layer is None or layer.N != N:
-            layer = self.__dict__["_fused_layer"] = ShardedDGGConv(ops, N, K=64, t=ops.T_DIST)
         layer.cand, layer.noise_mode, layer.seed, layer.mode, layer.scorer = cand, noise_mode, seed, mode, None
         layer.sym_fallback, layer.sym_hash = getattr(a, "dgg_sym_generator", "auto") != "ranked", False
         layer.tight_bound = getattr(a, "dgg_tight_bound", "auto")     # ranked search: nearest-neighbour bound in its stop tests when the walk is deep
@@ -688,7 +717,6 @@ class DGG_LearnableK_debug(nn.Module):
             layer.wide_cap = None if last is None or last[0] == N else (last[0] + last[0] // 8 + 64, min(ops.chunk_maxm_for(N), last[1] + max(1, last[1] // 8)))
             if layer.wide_cap is None:
                 layer.wide_rows = "off"
-        chunk_active = chunked and layer.wide_rows == "auto" and layer.wide_cap is None    # (this forward reads the layout back)
         if cand is not None and not mlp_mode:                 # the ELL-width bound is tested inside the search kernel (no extra launches)
             # (a forward whose fate is decided from its own learned degrees -- wide_state None -- raises a SCRATCH flag: if it is
             #  discarded for the CSR form its flag must not reach check_ell_bound, and flags of earlier forwards must survive it)
@@ -697,18 +725,12 @@ class DGG_LearnableK_debug(nn.Module):
             if flag is None or flag.device != x.device:
                 flag = self.__dict__[name] = torch.zeros((1,), device=x.device, dtype=torch.int32)
             layer.overflow = flag
-        kn = self.k_net
-        params = (self.node_encode_for_edges[0].weight, self.node_encode_for_edges[0].bias, self.node_encode_for_k[0].weight,
-                  self.node_encode_for_k[0].bias, self.k_embed[0].weight, self.k_embed[0].bias, kn.k_mu.weight, kn.k_mu.bias,
-                  kn.k_project.weight, kn.k_project.bias, conv_weight)
-        # no backward can follow (torch.no_grad(), frozen parameters): the partition's sort -- read by the backward only -- is skipped
-        layer.want_backward = ops.backward_will_follow(x, *params, *([mlp["Wcat"], mlp["b1"], mlp["w2"], mlp["b2"]] if mlp_mode else []))
-        if mlp_mode:
-            Z, ahat = _FusedDGGMlpConvFn.apply(x, deg, layer, sc_static, mlp["Wcat"], mlp["wdu"], mlp["wdv"], mlp["wex"], mlp["b1"],
-                                               mlp["w2"], mlp["b2"], *params)
-        else:
-            Z, ahat = _FusedDGGConvFn.apply(x, deg, layer, *params)       # (ops.ChunkCapacityError: a learned degree is NaN)
-        st = layer.saved
+        return noise_mode, chunked and layer.wide_rows == "auto" and layer.wide_cap is None
+
+    def _fused_result(self, layer, Z, ahat, in_adj, cand, rowptr, noise_mode, chunk_active, mlp_mode, want_norm):
+        """after the node ran: generator status, what this forward's learned degrees decide (CSR form from here on / overflow flags),
+        and the returned adjacencies"""
+        st, N = layer.saved, layer.N
         if noise_mode == ops.NOISE_RANKED_SYM:                # the reference's DEFAULT noise (symmetric_noise=True, dgm.py:1216-1223): the
             self._note_rsym(getattr(layer, "rsym_last", None), N)     # generator's status words, checked by check_ell_bound as for the modules
             if layer.sym_hash:
@@ -794,6 +816,24 @@ class DGG_LearnableK_debug(nn.Module):
         return (policy in ("auto", "chunked") and noise_mode in (ops.NOISE_NONE, ops.NOISE_HASH, ops.NOISE_HASH_SYM, ops.NOISE_RANKED, ops.NOISE_RANKED_SYM)
                 and self.ell_width == 64
                 and self.latent_dim in (16, 32, 64, 128) and self.edge_prob_net_mode == "u-v-dist")
+
+    def wide_row_plan(self, N, all_pairs, noise_mode):
+        """What rows that need more than 64 ranks do for a graph of N nodes under args.dgg_wide_rows -- the ONE summary of the policy
+        (the predicates the forwards use: _chunk_policy, _wide_rows_state, _allpairs_wide):
+          "chunked"          all-pairs candidates: ceil(k_i + 8.5) + 1 ranks of every row in chunks of 64, any width (auto / chunked)
+          "csr"              the CSR form of select_top_k from the first forward (csr)
+          "csr_when_needed"  the CSR form from the forward whose learned degrees first need it, and from then on (auto on edge lists
+                             and for explicit noise tensors on small all-pairs graphs; csr_auto)
+          "list"             64 ranks per row, the bound enforced by check_ell_bound (ell; graphs beyond dgg_allpairs_csr_max without a
+                             chunked form)"""
+        policy = getattr(self.args, "dgg_wide_rows", "auto")
+        if not all_pairs:
+            return {"ell": "list", "csr": "csr"}.get(policy, "csr_when_needed")
+        if self._chunk_policy(noise_mode):
+            return "chunked"
+        if policy in ("ell", "chunked") or N > int(getattr(self.args, "dgg_allpairs_csr_max", 8192)):
+            return "list"
+        return "csr" if policy == "csr" else "csr_when_needed"
 
     def _track_overflow(self, k, ncand):
         over = k.detach() + 8.5 > float(self.ell_width)

@@ -160,3 +160,24 @@ def test_wide_row_policies_on_the_host():
     assert m2._wide_rows(A, rowptr, torch.full((10,), 20.0)) is False and m2._wide_rows_state(A, rowptr) is None
     assert m2._wide_rows(A, rowptr, torch.full((10,), 60.0)) is True and m2._wide_rows_state(A, rowptr) is True, "sticky once needed"
     assert m2._fused_fallback("x") is None and m2.fused_fallback == {"x": 1}
+
+
+@pytest.mark.parametrize("policy,all_pairs,noise,N,want", [
+    ("auto", True, "ranked", 100_000, "chunked"), ("auto", True, "none", 100_000, "chunked"), ("auto", True, "rsym", 3000, "chunked"),
+    ("auto", True, "explicit", 3000, "csr_when_needed"), ("auto", True, "explicit", 100_000, "list"), ("auto", False, "hash", 3000, "csr_when_needed"),
+    ("chunked", True, "hash", 100_000, "chunked"), ("chunked", True, "explicit", 3000, "list"), ("chunked", False, "hash", 3000, "csr_when_needed"),
+    ("csr", True, "ranked", 3000, "csr"), ("csr", True, "ranked", 100_000, "list"), ("csr", False, "hash", 3000, "csr"),
+    ("csr_auto", True, "ranked", 3000, "csr_when_needed"), ("csr_auto", False, "hash", 3000, "csr_when_needed"),
+    ("ell", True, "ranked", 3000, "list"), ("ell", False, "hash", 3000, "list")])
+def test_wide_row_plan_of_every_policy(policy, all_pairs, noise, N, want):
+    """args.dgg_wide_rows in one table: what rows wider than 64 ranks do per policy, candidate kind, noise
+    generator and graph size -- DGG_LearnableK_debug.wide_row_plan, built from the predicates the forwards themselves use"""
+    import dgg_amd
+    from argparse import Namespace
+    from dgg_amd import ops
+    base = dict(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=3.9, deg_std=5.3, dgg_mode_edge_net="u-v-dist", dgg_mode_k_net="x",
+                dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True, symmetric_noise=False, stochastic_k=False,
+                dgg_adj_input="input_adj", n_dgg_layers=1, dgg_wide_rows=policy)
+    m = dgg_amd.DGG_LearnableK_debug(in_dim=8, latent_dim=16, args=Namespace(**base))
+    nm = {"ranked": ops.NOISE_RANKED, "none": ops.NOISE_NONE, "rsym": ops.NOISE_RANKED_SYM, "hash": ops.NOISE_HASH, "explicit": ops.NOISE_EXPLICIT}[noise]
+    assert m.wide_row_plan(N, all_pairs, nm) == want
