@@ -564,8 +564,10 @@ def run_ppi(a, dev):
                      "kernel_ms_per_step": t_g * 1e3, "per_kernel": per_kernel, "whole_step_gemm_tflops": gemm_flop / T / 1e12,
                      "note": "GEMM flops of the GCNII layers / summed event-timed duration of the GEMM calls inside running steps"},
         "kernels_ms_per_step": {n_: v[0] for n_, v in pk.items()},
-        # (bounded sample: the whole batch when it has at most four graphs, else its four smallest)
-        "cpu_baseline": (cpu_baseline_ppi(m, sorted(graphs, key=lambda g_: g_[0].shape[0])[:4], min(os.cpu_count() or 1, 32))
+        # (the WHOLE batch, every graph once: ~20 s of CPU work for the 20 graphs of SURVEY 8(d) on 32 threads; DGG_BENCH_PPI_CPU_GRAPHS=n
+        #  bounds it to the n smallest)
+        "cpu_baseline": (cpu_baseline_ppi(m, sorted(graphs, key=lambda g_: g_[0].shape[0])[:int(os.environ.get("DGG_BENCH_PPI_CPU_GRAPHS", "1000"))],
+                                          min(os.cpu_count() or 1, 32))
                          if a.cpu_rows >= 0 else None)})
 
 
@@ -667,7 +669,7 @@ def isolate_stdout():
 
 
 LINE_LIMIT = 6000         # bytes: the driver keeps only a tail of stdout; the result line must fit in it with room to spare
-DETAIL_PATH = os.path.join("gpurun_out", "bench_detail.json")
+DETAIL_PATH = os.environ.get("DGG_BENCH_DETAIL", os.path.join("gpurun_out", "bench_detail.json"))     # (relative to the repository root)
 _TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 _SUB = {"config": ("workload", "nodes", "feat", "latent", "parallelism", "rows_per_rank", "hipgraph", "noise", "api", "graphs", "selected_edges",
                    "candidate_edges"),
@@ -1067,7 +1069,7 @@ def other_configs(a, dev):
     try:
         if "pubmed" in only:                                 # configs[0]'s graph (Cora: 2 708 nodes, 1 433 features) through the same layer
             b = copy.copy(a)
-            b.steps, b.warmup, b.edge_mode, b.cpu_dense, b.cpu_rows, b.graph = 20, 3, "u-v-dist", False, -1, "cora"
+            b.steps, b.warmup, b.edge_mode, b.cpu_dense, b.graph = 20, 3, "u-v-dist", False, "cora"           # (+ the oracle's pipeline on the host: 0.1 s)
             res["cora_uvdist"] = pick(run_edgelist(b, dev))
     except Exception as e:  # noqa: BLE001
         res["cora_uvdist"] = {"error": repr(e)}

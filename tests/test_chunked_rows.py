@@ -659,3 +659,31 @@ def test_no_grad_forward_skips_the_partition_sort(dev):
         if p2.grad is not None:
             np.testing.assert_allclose(Nn(p1.grad), Nn(p2.grad), rtol=0, atol=2e-4 * float(p2.grad.abs().max()) + 1e-12, err_msg=n1)
     np.testing.assert_allclose(Nn(conv.W.grad), Nn(conv2.W.grad), rtol=0, atol=2e-4 * float(conv2.W.grad.abs().max()))
+
+
+@pytest.mark.parametrize("noise", ["ranked", "none", "hash_sym"])
+def test_anywidth_rows_on_a_row_shard_and_with_a_device_seed(dev, noise):
+    """the any-width evaluators on a ROW SHARD (rows [r0, r1) of the graph against all N columns: what a rank of the sharded layer
+    calls) and with the noise seed read from DEVICE memory (what a captured step uses) return the rows of the whole-graph call bit for
+    bit; so does the ranked search with the rows' nearest-neighbour bound"""
+    from dgg_amd import ops
+    nm = {"ranked": ops.NOISE_RANKED, "none": ops.NOISE_NONE, "hash_sym": ops.NOISE_HASH_SYM}[noise]
+    N, h = 5000, 32
+    g = torch.Generator().manual_seed(12)
+    xp = (torch.randn(N, h, generator=g) * 0.7).to(dev)
+    k = (5.0 + 300.0 * torch.rand(N, generator=g) ** 3).to(dev)
+    k[[10, 2600, 4999]] = torch.tensor([2300.0, 2900.0, 2100.0], device=dev)          # rows beyond 32 chunks on both sides of the cut
+    lay = ops.chunk_layout(k, ncols=N)
+    full = ops.allpairs_topk_wide(xp, k, lay, seed=(21, 4), noise_mode=nm)
+    cptr = lay.cptr.long()
+    r0, r1 = 2500, 4100
+    ks = k[r0:r1].contiguous()
+    lay_s = ops.chunk_layout(ks, ncols=N)
+    dseed = torch.tensor([21, 4], dtype=torch.int32, device=dev)
+    lp = ops.rowmin_logp_bound(xp, rows=(r0, r1)) if noise == "ranked" else None
+    part = ops.allpairs_topk_wide(xp, ks, lay_s, seed=dseed, noise_mode=nm, rows=(r0, r1), lpub=lp)
+    c0, c1 = int(cptr[r0]), int(cptr[r1])
+    assert lay_s.chunks == c1 - c0
+    for a_, b_ in zip(full[:3], part[:3]):
+        assert torch.equal(a_[c0:c1], b_), "shard differs from the rows of the whole-graph call"
+    assert torch.equal(full[3][r0:r1], part[3])
