@@ -21,19 +21,15 @@
 //                    part of the kernel is ~12 integer instructions per 64 pairs and touches no feature
 //   aw_ranked_walk   ranked generator, rows of more than 32 chunks: the walk of allpairs_topk_ranked_wide (ranks in decreasing noise
 //                    order, stop when the next rank's noise cannot reach the threshold) with the buffer in place of the register lists
-// Measured and not kept for the hash generators (round 6): a per-row guess-and-verify front end in the manner of dgg_topk_gv.hip (threshold
-// from a 64-column pilot of the row, fixed-threshold integer sweep into candidate lists, one scoring pass, verification, this kernel for
-// the rows that fail).  The integer filter can only use log p' <= G + 1e-8 -- it cannot see the distance term -- so at the benchmark's
-// features it admits 1 / E[p^(1/0.3)] = 4.5 candidates for every pair that is really above the threshold: the candidate lists outgrew
-// every capacity that is a small multiple of L_i and all rows fell back (31 ms against 24).  What the moving threshold pays for the same
-// reason: ~3 800 gathered and scored candidates per row at L = 140.  The fix on both sides is a rigorous per-row LOWER BOUND of the
-// distance to any other node (an fp16-MFMA row-minimum sweep), which would tighten the filter to G >= v - t d_min(i); not built.
+//   aw_pilot_rows / aw_hash_sweep / aw_hash_score: the hash generators' guess-and-verify FRONT END (below), which leaves only the rows it cannot
+//                    settle to aw_scan_hash
 // aw_emit (one workgroup per row) sorts the surviving <= L_i keys in LDS (bitonic; rows beyond 4096 keys in buckets of 4096 split off
 // by further selections), writes idx / val / w per chunk and the row sum in the chunk-ordered, lane-wise + butterfly order.
 // Exactness: a key is dropped only when L_i better keys of the same row are known; the hash filter and the walk's stop test drop a
 // pair only when its noise alone, with margins, cannot reach a threshold that is itself the score of a known L_i-th best key.
 #include "dgg_common.h"
 #include "dgg_api_internal.h"
+#include <stdlib.h>
 
 using namespace dgg;
 
@@ -234,7 +230,10 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_hash(const float *__restri
                                                            uint32_t s0, uint32_t s1, const uint32_t *__restrict__ seed_dev,
                                                            const float *__restrict__ klim, const int32_t *__restrict__ cptr,
                                                            uint64_t *__restrict__ keys, int32_t *__restrict__ cnt_out,
-                                                           const float *__restrict__ lpub) {
+                                                           const float *__restrict__ lpub, const int32_t *__restrict__ rowlist,
+                                                           const int32_t *__restrict__ nlist) {
+    // rowlist != NULL: the rows of this launch are rowlist[0 .. *nlist) (local row ids: the rows aw_hash_score could not settle), else
+    // every row of [row0, row1)
     constexpr int RS = H + 4;                                    // padded row stride (floats): 16-byte aligned, rows 4 banks apart
     __shared__ __attribute__((aligned(16))) float rowsL[RB * RS];
     __shared__ int s_row[RB];                                    // local row id of every row slot of the workgroup, -1: none
@@ -249,9 +248,11 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_hash(const float *__restri
     __shared__ uint32_t s_q[WAVES][QCAP];                        // (row << 28 | column) of the pairs that passed the integer filter
     const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id();
     if (seed_dev) { s0 = seed_dev[0]; s1 = seed_dev[1]; }
+    const int64_t nsel = rowlist ? (int64_t)nlist[0] : row1 - row0;
+    if ((int64_t)blockIdx.x * RB >= nsel) return;
     if (tid < RB) {
         const int64_t q = (int64_t)blockIdx.x * RB + tid;
-        s_row[tid] = q < row1 - row0 ? (int)q : -1;
+        s_row[tid] = q < nsel ? (rowlist ? rowlist[q] : (int)q) : -1;
     }
     __syncthreads();
     for (int e = tid; e < RB * H; e += WAVES * 64) {
@@ -403,6 +404,194 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_hash(const float *__restri
 }
 
 // ---- ranked generator, rows of more than `min_m` chunks: the walk of allpairs_topk_ranked_wide on the threshold buffer -----------------
+// ---- per-pair hash noise, FRONT END: a threshold per row guessed from a pilot, one integer sweep, verification ------------------------
+// The moving threshold of aw_scan_hash settles slowly: a row admits ~ c L (1 + ln(N / c L)) candidates, c = 1 / E[(p / p_max)^(1/0.3)]
+// the factor by which the integer filter (which sees the noise and the row's distance BOUND, not the distance) over-admits -- 1 500
+// gathered and scored rows of xp per row at L = 140 with the nearest-neighbour bound, 3 800 without.  dgg_topk_gv.hip's answer, per ROW
+// here: guess the log-score v_i above which ~1.25 L_i + 32 of the row's pairs lie from the Gumbel tail, N M_i exp(-v / 0.3), with
+// M_i = mean_j p_ij^(1/0.3) from 64 sampled columns (aw_pilot_rows); sweep all pairs against that FIXED integer threshold
+// (aw_hash_sweep: lane = row, the column wave-uniform, ~8 integer instructions per 64 pairs, survivors appended to the row's candidate
+// list); score the candidates once (aw_hash_score) and VERIFY: every pair the sweep dropped has log-score < v_i - 1e-3 + lp - lp..., i.e.
+// below v_i, so the row is exact iff its L_i-th best log-score clears v_i.  Rows that fail -- too few candidates, a list that overflows,
+// a pilot that missed -- are listed and redone by aw_scan_hash (exact whatever the guess was).  Needs the rows' distance bound (lpub):
+// without it the filter over-admits 4.5 x at the benchmark's features and every list overflows (measured: 31 ms against 24).
+constexpr int CSLOT = 512;              // candidate slots (32-bit columns) per chunk
+constexpr int HSEG = 4;                 // column segments swept by separate wavefronts (a row's candidate slots are split among them)
+struct HashCtl { int nfail; int pad[3]; };
+
+template <int H>
+__global__ __launch_bounds__(256) void aw_pilot_rows(const float *__restrict__ xp, int64_t N, int64_t row0, int64_t row1, float t, uint32_t s0,
+                                                     uint32_t s1, const uint32_t *__restrict__ seed_dev, const float *__restrict__ klim,
+                                                     const int32_t *__restrict__ cptr, const float *__restrict__ lpub,
+                                                     uint32_t *__restrict__ uthr_row, float *__restrict__ gmin_row, HashCtl *__restrict__ ctl,
+                                                     float tscale) {
+    const int lane = threadIdx.x & 63;
+    if (seed_dev) { s0 = seed_dev[0]; s1 = seed_dev[1]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->nfail = 0;
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
+    const int64_t i = row0 + lrow;
+    if (i >= row1) return;
+    const RowGeom g = row_geom(cptr, klim, lrow);
+    const uint32_t a = mix32(mix32((uint32_t)i * 64u + (uint32_t)lane + s0) ^ (s1 * 0x9E3779B9u + 0x632BE5ABu));
+    const int64_t j = (int64_t)(((uint64_t)a * (uint64_t)N) >> 32);
+    const float4 *xi = reinterpret_cast<const float4 *>(xp + i * H), *xj = reinterpret_cast<const float4 *>(xp + j * H);
+    float d2 = 0.0f;
+#pragma unroll
+    for (int c4 = 0; c4 < H / 4; c4++) {
+        const float4 p = xi[c4], q = xj[c4];
+        d2 += (p.x - q.x) * (p.x - q.x) + (p.y - q.y) * (p.y - q.y) + (p.z - q.z) * (p.z - q.z) + (p.w - q.w) * (p.w - q.w);
+    }
+    float m = j == i ? 0.0f : __expf(__logf(__expf(t * sqrtf(d2)) + 1e-8f) * (1.0f / 0.3f));
+    m = wave_sum_dpp(m, lane) * (1.0f / 64.0f);
+    if (lane == 0) {
+        // expected pairs of the row with log-score >= v:  N M exp(-v / 0.3)  ->  v for a count of `target`; the filter passes the pairs
+        // with G >= v - lp, i.e. target / (M exp(-lp / 0.3)) candidates: they have to fit the row's slots
+        const float lp = lpub ? lpub[lrow] : 1e-8f;
+        const float target = tscale * (float)g.L + 32.0f;      // (1.25 L + 32; tests shrink the factor to force the verification to fail)
+        const float v = 0.3f * __logf(fmaxf((float)N * m, 1e-30f) / target);
+        const float ncand = target / fmaxf(m * __expf(-lp * (1.0f / 0.3f)), 1e-30f);
+        const bool usable = g.cap > 0 && m > 0.0f && v == v && fabsf(v) < 60.0f && ncand < 0.7f * (float)((g.cap / KSLOT) * CSLOT) &&
+                            target < 0.8f * (float)g.cap;
+        gmin_row[lrow] = usable ? v : INFINITY;                  // (+inf: the row is left to the moving-threshold scan)
+        uthr_row[lrow] = usable ? hash_threshold_from_gmin(v - lp) : 0xffffffffu;
+    }
+}
+
+// the integer sweep: lane = row, column wave-uniform (its key words on the scalar unit); a surviving pair costs one 4-byte store into the
+// lane's own list (row, segment): no ballots, no atomics
+template <bool SYM>
+__global__ __launch_bounds__(64) void aw_hash_sweep(int64_t N, int64_t row0, int64_t row1, uint32_t s0, uint32_t s1,
+                                                    const uint32_t *__restrict__ seed_dev, const int32_t *__restrict__ cptr,
+                                                    const uint32_t *__restrict__ uthr_row, uint32_t *__restrict__ cand, int32_t *__restrict__ ncand) {
+    const int lane = threadIdx.x;
+    if (seed_dev) { s0 = seed_dev[0]; s1 = seed_dev[1]; }
+    const int seg = blockIdx.x % HSEG;
+    const int64_t lrow = (int64_t)(blockIdx.x / HSEG) * 64 + lane;
+    const bool rvalid = lrow < row1 - row0;
+    const int64_t lr = rvalid ? lrow : row1 - row0 - 1;
+    const uint32_t i = (uint32_t)(row0 + lr);
+    uint32_t rk1, rk2;
+    rowkey(s0, s1, i, rk1, rk2);
+    const uint32_t uthr = rvalid ? uthr_row[lr] : 0xffffffffu;
+    const int c0 = cptr[lr], M = cptr[lr + 1] - c0;
+    const int capseg = M * (CSLOT / HSEG);
+    uint32_t *cb = cand + (int64_t)c0 * CSLOT + (int64_t)seg * capseg;
+    int cnt = 0;
+    const int64_t per = (N + HSEG - 1) / HSEG;
+    const int64_t j0 = (int64_t)seg * per, j1 = j0 + per < N ? j0 + per : N;
+    const bool skip = uthr == 0xffffffffu;                       // (the row goes to the moving-threshold scan: not even its diagonal is listed)
+    for (int64_t jb = j0; jb < j1; jb += 64) {
+        // symmetric noise: a pair below the diagonal is keyed by its COLUMN.  The key words of 64 columns at once, one per lane (two
+        // mix32 per column on the scalar unit -- one unit for four SIMDs -- made this sweep 2.6x slower than the asymmetric one)
+        uint32_t ck1 = 0u, ck2 = 0u;
+        if (SYM) rowkey(s0, s1, (uint32_t)jb + (uint32_t)lane, ck1, ck2);
+        const int nc = j1 - jb < 64 ? (int)(j1 - jb) : 64;
+        for (int c = 0; c < nc; c++) {
+            const uint32_t j = (uint32_t)jb + (uint32_t)c;       // wave-uniform
+            uint32_t k1 = rk1, k2 = rk2, b = j;
+            if (SYM) {
+                const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)ck1, c), c2 = (uint32_t)__builtin_amdgcn_readlane((int)ck2, c);
+                if (j < i) { k1 = c1; k2 = c2; b = i; }
+            }
+            uint32_t x = b ^ k1;
+            x *= 0x7feb352dU; x ^= x >> 15; x += k2; x *= 0x846ca68bU;
+            if (!skip && (x >= uthr || j == i)) {
+                if (cnt < capseg) cb[cnt] = j;
+                cnt++;
+            }
+        }
+    }
+    if (rvalid) ncand[lrow * HSEG + seg] = cnt;
+}
+
+// score the candidates of a row, keep its L best, verify the guess; one wavefront per row
+template <int H, bool SYM>
+__global__ __launch_bounds__(256) void aw_hash_score(const float *__restrict__ xp, int64_t N, int64_t row0, int64_t row1, float t, uint32_t s0,
+                                                     uint32_t s1, const uint32_t *__restrict__ seed_dev, const float *__restrict__ klim,
+                                                     const int32_t *__restrict__ cptr, const uint32_t *__restrict__ cand,
+                                                     const int32_t *__restrict__ ncand, const float *__restrict__ gmin_row,
+                                                     uint64_t *__restrict__ keys, int32_t *__restrict__ cnt_out, HashCtl *__restrict__ ctl,
+                                                     int32_t *__restrict__ faillist) {
+    const int lane = threadIdx.x & 63;
+    if (seed_dev) { s0 = seed_dev[0]; s1 = seed_dev[1]; }
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
+    const int64_t i = row0 + lrow;
+    if (i >= row1) return;
+    const RowGeom g = row_geom(cptr, klim, lrow);
+    if (g.cap == 0) { if (lane == 0) cnt_out[lrow] = 0; return; }
+    const float gmin = gmin_row[lrow];
+    const int M = g.cap / KSLOT, capseg = M * (CSLOT / HSEG);
+    int nseg[HSEG], C = 0;
+    bool ok = gmin < INFINITY;
+#pragma unroll
+    for (int q = 0; q < HSEG; q++) {
+        nseg[q] = ncand[lrow * HSEG + q];
+        ok = ok && nseg[q] <= capseg;
+        C += nseg[q];
+    }
+    ok = ok && C >= g.L;
+    uint64_t *buf = keys + g.base;
+    const uint32_t *cl = cand + (int64_t)(g.base / KSLOT) * CSLOT;
+    int n = 0;
+    if (ok) {
+        const float *xi = xp + i * H;                            // wave-uniform: scalar loads
+        uint64_t thr = DGG_EMPTY_KEY;                            // the candidates stream through the row's threshold buffer (more of them than it holds: compacted on the way)
+#pragma unroll
+        for (int q = 0; q < HSEG; q++) {
+            for (int base = 0; base < nseg[q]; base += 64) {
+                const int e = base + lane;
+                uint64_t key = DGG_EMPTY_KEY;
+                if (e < nseg[q]) {
+                    const uint32_t j = cl[(int64_t)q * capseg + e];
+                    const float4 *xj = reinterpret_cast<const float4 *>(xp + (int64_t)j * H);
+                    float4 bq[H / 4];
+#pragma unroll
+                    for (int c4 = 0; c4 < H / 4; c4++) bq[c4] = xj[c4];
+                    float d2 = 0.0f;
+#pragma unroll
+                    for (int c4 = 0; c4 < H / 4; c4++) {
+                        float df;
+                        df = __fadd_rn(xi[4 * c4 + 0], -bq[c4].x); d2 = __fmaf_rn(df, df, d2);
+                        df = __fadd_rn(xi[4 * c4 + 1], -bq[c4].y); d2 = __fmaf_rn(df, df, d2);
+                        df = __fadd_rn(xi[4 * c4 + 2], -bq[c4].z); d2 = __fmaf_rn(df, df, d2);
+                        df = __fadd_rn(xi[4 * c4 + 3], -bq[c4].w); d2 = __fmaf_rn(df, df, d2);
+                    }
+                    const float gn = pair_noise(s0, s1, (uint32_t)i, j, SYM);
+                    key = make_key(score_from_dist(c_sqrt(d2), t, true, gn), (int32_t)j);
+                }
+                bool pass = key != DGG_EMPTY_KEY && key > thr;
+                uint64_t m = __ballot(pass);
+                if (m != 0ull) {
+                    if (n + __builtin_popcountll(m) > g.cap) {
+                        thr = wave_select_lth(buf, n, g.L, keep_window(g.L, g.cap), lane);
+                        n = wave_compact_ge(buf, n, thr, lane);
+                        pass = pass && key > thr;
+                        m = __ballot(pass);
+                    }
+                    const int p = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (pass) buf[p] = key;
+                    n += __builtin_popcountll(m);
+                }
+            }
+        }
+        // every pair the sweep dropped has G < v - lp - 1e-3, i.e. log-score < v - 1e-3 + 1e-8: the list is exact iff its L-th best
+        // clears that (fast-math log of the score: 1e-4 of margin)
+        uint64_t tau;
+        if (n > g.L) tau = wave_select_lth(buf, n, g.L, g.L, lane);
+        else {
+            uint64_t mn = ~0ull;
+            for (int e = lane; e < n; e += 64) { const uint64_t k = buf[e]; mn = k < mn ? k : mn; }
+            tau = wave_min_u64(mn);
+        }
+        ok = n >= g.L && __logf(fmaxf(key_val(tau), 1e-37f)) - 1e-4f >= gmin - 1e-3f + 1e-6f;
+        if (ok && n > g.L) n = wave_compact_ge(buf, n, tau, lane);
+    }
+    if (lane == 0) {
+        cnt_out[lrow] = ok ? n : 0;
+        if (!ok) faillist[atomicAdd(&ctl->nfail, 1)] = (int32_t)lrow;
+    }
+}
+
 // (the walk's block generator of dgg_topk_ranked.hip, restated: position 0 = the row's own column with its independent variate, position
 //  p >= 1 = slot sigma(p - 1) of the n = N - 1 other columns; dgg_common.h, DGG_RANKED_DIAG_KEY)
 __device__ __forceinline__ uint64_t scan_u64(uint64_t v, int lane) {
@@ -638,18 +827,35 @@ __global__ __launch_bounds__(ET) void aw_emit(const uint64_t *__restrict__ keys,
     }
 }
 
+struct HashWs { uint32_t *cand; int32_t *ncand; uint32_t *uthr; float *gmin; int32_t *fail; HashCtl *ctl; };
 template <int H>
 int launch_anywide(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, int noise_mode, uint32_t s0, uint32_t s1, const uint32_t *seed_dev,
                    const float *k, int mode, int maxm, int min_m, const int32_t *cptr, int64_t ccap, int32_t *idx, float *val, float *w, float *rs,
-                   uint64_t *keys, int32_t *cnt, const float *lpub, hipStream_t st) {
+                   uint64_t *keys, int32_t *cnt, const float *lpub, const HashWs &hx, hipStream_t st) {
     const int64_t rows = row1 - row0;
     const dim3 gscan((unsigned)((rows + RB - 1) / RB));
     if (noise_mode == 0)
         hipLaunchKernelGGL(aw_scan_plain<H>, gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, k, cptr, keys, cnt);
-    else if (noise_mode == 2)
-        hipLaunchKernelGGL((aw_scan_hash<H, false>), gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr, keys, cnt, lpub);
-    else if (noise_mode == 3)
-        hipLaunchKernelGGL((aw_scan_hash<H, true>), gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr, keys, cnt, lpub);
+    else if (noise_mode == 2 || noise_mode == 3) {
+        // (read per call: tests switch the front end off / shrink its target between calls)
+        const char *ef = getenv("DGG_ANYWIDE_HASH_FRONT"), *et = getenv("DGG_ANYWIDE_HASH_TARGET");
+        const bool front = !ef || atoi(ef) != 0;
+        const float tscale = et ? (float)atof(et) : 1.25f;
+        const bool sym = noise_mode == 3;
+        const int32_t *rowlist = nullptr, *nlist = nullptr;
+        if (front && lpub) {                                     // guess-and-verify; the rows it cannot settle go through the moving threshold
+            const dim3 g4((unsigned)((rows + 3) / 4)), gsw((unsigned)(((rows + 63) / 64) * HSEG));
+            hipLaunchKernelGGL(aw_pilot_rows<H>, g4, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr, lpub, hx.uthr, hx.gmin, hx.ctl, tscale);
+            if (sym) hipLaunchKernelGGL(aw_hash_sweep<true>, gsw, dim3(64), 0, st, N, row0, row1, s0, s1, seed_dev, cptr, hx.uthr, hx.cand, hx.ncand);
+            else hipLaunchKernelGGL(aw_hash_sweep<false>, gsw, dim3(64), 0, st, N, row0, row1, s0, s1, seed_dev, cptr, hx.uthr, hx.cand, hx.ncand);
+            if (sym) hipLaunchKernelGGL((aw_hash_score<H, true>), g4, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr, hx.cand, hx.ncand, hx.gmin, keys, cnt, hx.ctl, hx.fail);
+            else hipLaunchKernelGGL((aw_hash_score<H, false>), g4, dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr, hx.cand, hx.ncand, hx.gmin, keys, cnt, hx.ctl, hx.fail);
+            rowlist = hx.fail;
+            nlist = &hx.ctl->nfail;
+        }
+        if (sym) hipLaunchKernelGGL((aw_scan_hash<H, true>), gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr, keys, cnt, lpub, rowlist, nlist);
+        else hipLaunchKernelGGL((aw_scan_hash<H, false>), gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr, keys, cnt, lpub, rowlist, nlist);
+    }
     else
         hipLaunchKernelGGL(aw_ranked_walk<H>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xp, N, row0, row1, t, s0, s1, seed_dev, k, cptr,
                            min_m, keys, cnt, lpub);
@@ -670,10 +876,13 @@ extern "C" {
 
 // bytes of workspace dgg_allpairs_topk_anywide needs for arrays of `ccap` chunks and `rows` rows: 128 keys of 8 bytes per chunk + a count per row
 static inline size_t aw_al(size_t b) { return (b + 255) & ~(size_t)255; }
-// bytes of workspace dgg_allpairs_topk_anywide needs for arrays of `ccap` chunks and `rows` rows: 128 keys of 8 bytes per chunk + a count per row
+// bytes of workspace dgg_allpairs_topk_anywide needs for arrays of `ccap` chunks and `rows` rows: keys (128 x 8 B per chunk) | counts |
+// candidate columns of the hash generators' front end (512 x 4 B per chunk) | per row: candidate counts per segment, integer thresholds,
+// guessed log-scores, fail list | control block
 size_t dgg_allpairs_anywide_ws_bytes(int64_t ccap, int64_t rows) {
     if (ccap < 0 || rows < 0) return 0;
-    return aw_al((size_t)ccap * KSLOT * sizeof(uint64_t)) + aw_al((size_t)rows * 4) + 256;
+    return aw_al((size_t)ccap * KSLOT * sizeof(uint64_t)) + aw_al((size_t)rows * 4) + aw_al((size_t)ccap * CSLOT * sizeof(uint32_t)) +
+           aw_al((size_t)rows * HSEG * 4) + 3 * aw_al((size_t)rows * 4) + 256;
 }
 
 // All-pairs top-L_i on CHUNKED rows of any width (include/dgg_hip.h).  noise_mode 0 (unperturbed), 2 (per-pair hash), 3 (symmetric per-pair
@@ -695,14 +904,22 @@ int dgg_allpairs_topk_anywide(const float *xp, int64_t N, int h, int64_t row0, i
     if (!workspace || ws_bytes < dgg_allpairs_anywide_ws_bytes(ccap, row1 - row0))
         return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_anywide: workspace missing or smaller than dgg_allpairs_anywide_ws_bytes");
     if (row1 == row0) return 0;
-    uint64_t *keys = reinterpret_cast<uint64_t *>(workspace);
-    int32_t *cnt = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(workspace) + aw_al((size_t)ccap * KSLOT * sizeof(uint64_t)));
+    char *wsp = reinterpret_cast<char *>(workspace);
+    uint64_t *keys = reinterpret_cast<uint64_t *>(wsp); wsp += aw_al((size_t)ccap * KSLOT * sizeof(uint64_t));
+    int32_t *cnt = reinterpret_cast<int32_t *>(wsp); wsp += aw_al((size_t)(row1 - row0) * 4);
+    HashWs hx;
+    hx.cand = reinterpret_cast<uint32_t *>(wsp); wsp += aw_al((size_t)ccap * CSLOT * sizeof(uint32_t));
+    hx.ncand = reinterpret_cast<int32_t *>(wsp); wsp += aw_al((size_t)(row1 - row0) * HSEG * 4);
+    hx.uthr = reinterpret_cast<uint32_t *>(wsp); wsp += aw_al((size_t)(row1 - row0) * 4);
+    hx.gmin = reinterpret_cast<float *>(wsp); wsp += aw_al((size_t)(row1 - row0) * 4);
+    hx.fail = reinterpret_cast<int32_t *>(wsp); wsp += aw_al((size_t)(row1 - row0) * 4);
+    hx.ctl = reinterpret_cast<HashCtl *>(wsp);
     hipStream_t st = (hipStream_t)stream;
     switch (h) {
-        case 16: return launch_anywide<16>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, lpub, st);
-        case 32: return launch_anywide<32>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, lpub, st);
-        case 64: return launch_anywide<64>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, lpub, st);
-        case 128: return launch_anywide<128>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, lpub, st);
+        case 16: return launch_anywide<16>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, lpub, hx, st);
+        case 32: return launch_anywide<32>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, lpub, hx, st);
+        case 64: return launch_anywide<64>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, lpub, hx, st);
+        case 128: return launch_anywide<128>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, lpub, hx, st);
         default: return dgg_set_error(DGG_ERR_UNSUPPORTED, "allpairs_topk_anywide supports latent_dim in {16,32,64,128}");
     }
 }

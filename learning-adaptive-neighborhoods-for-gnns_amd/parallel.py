@@ -119,7 +119,13 @@ class ShardedDGGConv:
         # Two independent kernels of the step run beside their neighbours on a SECOND stream (captured into the same hipGraph): the
         # partition's sort (read by the backward only) beside the forward aggregation, and the k-net backward (needs only dk, MFMA-
         # bound) beside the per-destination kernel of the score backward (gather-bound).  DGG_OVERLAP=0 keeps everything on one stream.
-        self.overlap = os.environ.get("DGG_OVERLAP", "1") != "0" and hasattr(kern, "partp_sort")
+        # DGG_OVERLAP: 2 (default) = only the k-net backward beside the score backward's column kernel; 1 = also the partition's sort
+        # beside the aggregation; 3 = only the sort; 0 = one stream.  Round 6, same box, ms per step: 1.233 (2), 1.234-1.237 (1),
+        # 1.244-1.246 (0), 1.252-1.255 (3): the sort beside the gather-bound aggregation LOSES 8 us (it stretched from 36 to 168 us and
+        # took the aggregation with it), the MFMA-bound k-net backward beside the gather-bound column kernel wins 11
+        ov = os.environ.get("DGG_OVERLAP", "2")
+        self.overlap = ov != "0" and hasattr(kern, "partp_sort")
+        self.overlap_sort, self.overlap_knet = ov in ("1", "3"), ov in ("1", "2")
         self._side = None
         self.K, self.t, self.noise_mode, self.seed, self.mode, self.algo, self.x_grad = K, t, noise_mode, seed, mode, algo, x_grad
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -364,7 +370,7 @@ class ShardedDGGConv:
         # (payload form -- records carry w rs_i^-1/2 and the score, no slot map, normalize_adj fused into its fill pass -- when the
         # namespace offers it and covers the shape)
         use_p = hasattr(kern, "partp_build") and xp.shape[1] in (16, 32, 64, 128) and H.shape[1] in (16, 32, 64, 128) and self.mode in (0, 1)
-        ov = use_p and self.overlap and s["idx"].is_cuda
+        ov = use_p and self.overlap and self.overlap_sort and s["idx"].is_cuda
         # want_backward = False (set by the autograd node under torch.no_grad() / frozen parameters): the per-bucket sort of the
         # partition -- read by the backward's column kernels only -- is not launched at all (an eval forward used to
         # leave it running on the side stream with nothing ever joining it)
@@ -482,7 +488,7 @@ class ShardedDGGConv:
             # the activation derivative of the two LeakyReLU projections is applied by the kernels that PRODUCE dxp / dxk (they hold
             # xp_j / xk in registers): the fused weight-gradient product then reads no forward output for the mask (51 MB less)
             pre = self._premask(x_local)
-            if self.overlap and self.mode == 0 and s["z"] is None and s["idx"].is_cuda:
+            if self.overlap and self.overlap_knet and self.mode == 0 and s["z"] is None and s["idx"].is_cuda:
                 # row kernel -> dk; then the k-net backward on the side stream beside the per-destination kernel on this one
                 dxp, dk, st = kern.softk_edge_bwd_p(s["xp"], s["idx"], s["val"], s["k"], dA, dA_rec, s["rs"], da, self.r0, self.t,
                                                     self.noise_mode != 0, self.mode, True, partp, ahat_rows=s["ahat"],

@@ -687,3 +687,29 @@ def test_anywidth_rows_on_a_row_shard_and_with_a_device_seed(dev, noise):
     for a_, b_ in zip(full[:3], part[:3]):
         assert torch.equal(a_[c0:c1], b_), "shard differs from the rows of the whole-graph call"
     assert torch.equal(full[3][r0:r1], part[3])
+
+
+@pytest.mark.parametrize("noise", ["hash", "hash_sym"])
+@pytest.mark.parametrize("knob", ["DGG_ANYWIDE_HASH_TARGET=0.5", "DGG_ANYWIDE_HASH_TARGET=0.95", "DGG_ANYWIDE_HASH_FRONT=0", "DGG_ANYWIDE_HASH_BOUND=0"])
+def test_hash_wide_rows_guess_and_verify_falls_back_exactly(dev, noise, knob, monkeypatch):
+    """The hash generators' wide rows: a per-row threshold guessed from a pilot, one integer sweep, verification -- and the moving-threshold
+    scan for the rows whose guess fails.  Forced here: a target of 0.5 L + 32 candidates (every wide row fails: all of them fall back), of
+    0.95 L + 32 (about half fail), the front end off, the distance bound off (the front end needs it): the same bits every time"""
+    from dgg_amd import ops
+    nm = {"hash": ops.NOISE_HASH, "hash_sym": ops.NOISE_HASH_SYM}[noise]
+    N, h = 6000, 64
+    g = torch.Generator().manual_seed(31)
+    xp = (torch.randn(N, h, generator=g) * 0.8).to(dev)
+    k = (5.0 + 400.0 * torch.rand(N, generator=g) ** 2).to(dev)
+    lay = ops.chunk_layout(k, ncols=N)
+    ref = ops.allpairs_topk_wide(xp, k, lay, seed=(8, 9), noise_mode=nm)
+    name, value = knob.split("=")
+    if name == "DGG_ANYWIDE_HASH_BOUND":
+        monkeypatch.setattr(ops, "ANYWIDE_HASH_BOUND", False)
+    else:
+        monkeypatch.setenv(name, value)
+    got = ops.allpairs_topk_wide(xp, k, lay, seed=(8, 9), noise_mode=nm)
+    for a_, b_ in zip(ref, got):
+        assert torch.equal(a_, b_)
+    rows = [0, 17, N - 1] + [int(v) for v in np.random.default_rng(2).integers(0, N, 12)]
+    _check_rows_against_oracle(lay, xp, k, *got, {"hash": O.NOISE_HASH, "hash_sym": O.NOISE_HASH_SYM}[noise], (8, 9), 0, rows=rows)
