@@ -44,7 +44,7 @@ PROTOTYPES = {
     "dgg_literal_hard_bwd": [_vp, _vp, _i64, _i32, _vp, _vp],
     "dgg_allpairs_topk_ranked_softk_dseed": [_vp, _i64, _i32, _i64, _i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "dgg_chunk_layout": [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp],
-    "dgg_allpairs_anywide_ws_bytes": [_i64, _i64],
+    "dgg_allpairs_anywide_ws_bytes": [_i64, _i64, _i64, _i32],
     "dgg_allpairs_rowmin_ws_bytes": [_i64, _i64, _i32],
     "dgg_allpairs_rowmin_bound": [_vp, _i64, _i32, _i64, _i64, _f32, _vp, _vp, _sz, _vp],
     "dgg_allpairs_topk_anywide": [_vp, _i64, _i32, _i64, _i64, _f32, _i32, _u32, _u32, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp,

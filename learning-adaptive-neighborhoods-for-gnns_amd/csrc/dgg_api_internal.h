@@ -49,3 +49,11 @@ extern "C" size_t dgg_part_ws_bytes(int64_t rows, int K, int64_t ncols);
 // (0 on success; recpos is there only when dgg_partp_has_map(rows))
 int dgg_partp_internal_ptrs(const void *partp_ws, int64_t rows, int K, int64_t ncols, const int **nodeptr, const int **recpos);
 int dgg_klimit_truncate_impl(const float *klim, int64_t rows, int K, int32_t *idx, float *val, hipStream_t st);
+
+// unperturbed chunked rows, front end (dgg_topk_sweep.hip): radius per row from a sampled sweep, one full fp16-MFMA sweep; the columns
+// inside a row's radius are appended to its dgg_plain_wide_sublists() sub-lists of `cslot` * M_i / sublists slots each (cand), their counts
+// to ncand [rows * sublists]; rad [rows]: every pair that is not listed has d^2 > rad[i]
+size_t dgg_plain_wide_front_ws_bytes(int64_t rows, int64_t N, int h);
+int dgg_plain_wide_sublists(void);
+int dgg_plain_wide_front_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, const float *klim, const int32_t *cptr, int cslot,
+                              uint32_t *cand, int32_t *ncand, float *rad, void *ws, hipStream_t st);

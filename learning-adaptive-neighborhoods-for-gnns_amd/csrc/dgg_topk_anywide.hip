@@ -36,6 +36,7 @@ using namespace dgg;
 namespace {
 
 constexpr int KSLOT = 128;              // keys of threshold buffer per chunk of 64 ranks
+constexpr int PLAIN_FEW_MAX = 2048;     // unperturbed front end: failing rows up to which the one-wavefront-per-row fallback is used
 
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
 #pragma unroll
@@ -143,15 +144,25 @@ constexpr int RW = 16, WAVES = 4, RB = RW * WAVES, TN = 64;
 template <int H>
 __global__ __launch_bounds__(WAVES * 64) void aw_scan_plain(const float *__restrict__ xp, int64_t N, int64_t row0, int64_t row1, float t,
                                                             const float *__restrict__ klim, const int32_t *__restrict__ cptr,
-                                                            uint64_t *__restrict__ keys, int32_t *__restrict__ cnt_out) {
+                                                            uint64_t *__restrict__ keys, int32_t *__restrict__ cnt_out,
+                                                            const int32_t *__restrict__ rowlist, const int32_t *__restrict__ nlist, int few_max) {
+    // rowlist != NULL: the rows of this launch are rowlist[0 .. *nlist) (local row ids: the rows aw_plain_score could not settle), else
+    // every row of [row0, row1)
     __shared__ float colT[H * TN];
     __shared__ float rowsL[RB * H];
+    __shared__ int s_row[RB];                                    // local row id of every row slot of the workgroup, -1: none
     const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id();
-    const int64_t rbase = row0 + (int64_t)blockIdx.x * RB;
+    const int64_t nsel = rowlist ? (int64_t)nlist[0] : row1 - row0;
+    if ((int64_t)blockIdx.x * RB >= nsel || (rowlist && nsel <= few_max)) return;     // (few listed rows: aw_plain_rows_all settled them)
+    if (tid < RB) {
+        const int64_t q = (int64_t)blockIdx.x * RB + tid;
+        s_row[tid] = q < nsel ? (rowlist ? rowlist[q] : (int)q) : -1;
+    }
+    __syncthreads();
     for (int e = tid; e < RB * H; e += WAVES * 64) {
         const int r = e / H, c = e % H;
-        const int64_t gi = rbase + r;
-        rowsL[e] = gi < row1 ? xp[gi * H + c] : 0.0f;
+        const int lr_ = s_row[r];
+        rowsL[e] = lr_ >= 0 ? xp[(row0 + lr_) * H + c] : 0.0f;
     }
     uint64_t thr[RW];
     int cnt[RW];
@@ -173,8 +184,9 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_plain(const float *__restr
 #pragma unroll
         for (int r = 0; r < RW; r++) {
             const int lr = wave * RW + r;
-            const int64_t i = rbase + lr;
-            if (i >= row1) continue;                             // wave-uniform
+            const int li = __builtin_amdgcn_readfirstlane(s_row[lr]);
+            if (li < 0) continue;                                // wave-uniform
+            const int64_t i = row0 + li;
             const float *xi = rowsL + lr * H;
             float d2 = 0.0f;
 #pragma unroll
@@ -204,8 +216,9 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_plain(const float *__restr
     }
 #pragma unroll
     for (int r = 0; r < RW; r++) {
-        const int64_t i = rbase + wave * RW + r;
-        if (i >= row1) continue;
+        const int li = __builtin_amdgcn_readfirstlane(s_row[wave * RW + r]);
+        if (li < 0) continue;
+        const int64_t i = row0 + li;
         const RowGeom g = row_geom(cptr, klim, i - row0);
         int n = cnt[r];
         if (n > g.L && g.cap > 0) {
@@ -215,6 +228,158 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_plain(const float *__restr
         }
         if (lane == 0) cnt_out[i - row0] = n;
     }
+}
+
+// ---- unperturbed scores, FRONT END's second half: the candidates of dgg_topk_sweep.hip's radius sweep scored, verified -------------------
+// (pw_pilot / pw_sweep: every pair that is not in the row's candidate sub-lists has d^2 > rad[i]).  One wavefront per row: exact canonical
+// squared distances and scores of the candidates streamed through the row's threshold buffer, its L best kept; VERIFIED when the L-th
+// best lies inside the radius with margins (sw_finalize's test): rows that fail -- a radius guessed too small, a sub-list that
+// overflowed -- are listed for aw_scan_plain (every pair scored: exact whatever the guess was).
+template <int H>
+__global__ __launch_bounds__(256) void aw_plain_score(const float *__restrict__ xp, int64_t N, int64_t row0, int64_t row1, float t,
+                                                      const float *__restrict__ klim, const int32_t *__restrict__ cptr,
+                                                      const uint32_t *__restrict__ cand, const int32_t *__restrict__ ncand, int nsub, int cslot,
+                                                      const float *__restrict__ rad, uint64_t *__restrict__ keys, int32_t *__restrict__ cnt_out,
+                                                      int32_t *__restrict__ nfail, int32_t *__restrict__ faillist) {
+    const int lane = threadIdx.x & 63;
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
+    const int64_t i = row0 + lrow;
+    if (i >= row1) return;
+    const RowGeom g = row_geom(cptr, klim, lrow);
+    if (g.cap == 0) { if (lane == 0) cnt_out[lrow] = 0; return; }
+    const int M = g.cap / KSLOT, capsub = M * cslot / nsub;
+    const float R = rad[lrow];
+    bool ok = R < 3.0e38f && t < 0.0f;
+    int C = 0;
+    for (int q = 0; q < nsub; q++) {
+        const int c = ncand[lrow * nsub + q];
+        ok = ok && c <= capsub;
+        C += c;
+    }
+    ok = ok && (C >= g.L || (int64_t)C >= N);
+    uint64_t *buf = keys + g.base;
+    const uint32_t *cl = cand + (int64_t)(g.base / KSLOT) * cslot;
+    int n = 0;
+    if (ok) {
+        const float *xi = xp + i * H;                            // wave-uniform: scalar loads
+        uint64_t thr = DGG_EMPTY_KEY;
+        for (int q = 0; q < nsub; q++) {
+            const int nq = ncand[lrow * nsub + q];
+            for (int base = 0; base < nq; base += 64) {
+                const int e = base + lane;
+                uint64_t key = DGG_EMPTY_KEY;
+                if (e < nq) {
+                    const uint32_t j = cl[(int64_t)q * capsub + e];
+                    const float4 *xj = reinterpret_cast<const float4 *>(xp + (int64_t)j * H);
+                    float4 bq[H / 4];
+#pragma unroll
+                    for (int c4 = 0; c4 < H / 4; c4++) bq[c4] = xj[c4];
+                    float d2 = 0.0f;
+#pragma unroll
+                    for (int c4 = 0; c4 < H / 4; c4++) {
+                        float df;
+                        df = __fadd_rn(xi[4 * c4 + 0], -bq[c4].x); d2 = __fmaf_rn(df, df, d2);
+                        df = __fadd_rn(xi[4 * c4 + 1], -bq[c4].y); d2 = __fmaf_rn(df, df, d2);
+                        df = __fadd_rn(xi[4 * c4 + 2], -bq[c4].z); d2 = __fmaf_rn(df, df, d2);
+                        df = __fadd_rn(xi[4 * c4 + 3], -bq[c4].w); d2 = __fmaf_rn(df, df, d2);
+                    }
+                    key = (int64_t)j < N ? make_key(score_from_dist(c_sqrt(d2), t, false, 0.0f), (int32_t)j) : DGG_EMPTY_KEY;
+                }
+                bool pass = key != DGG_EMPTY_KEY && key > thr;
+                uint64_t m = __ballot(pass);
+                if (m != 0ull) {
+                    if (n + __builtin_popcountll(m) > g.cap) {
+                        thr = wave_select_lth(buf, n, g.L, keep_window(g.L, g.cap), lane);
+                        n = wave_compact_ge(buf, n, thr, lane);
+                        pass = pass && key > thr;
+                        m = __ballot(pass);
+                    }
+                    const int p = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (pass) buf[p] = key;
+                    n += __builtin_popcountll(m);
+                }
+            }
+        }
+        uint64_t tau;
+        if (n > g.L) tau = wave_select_lth(buf, n, g.L, g.L, lane);
+        else {
+            uint64_t mn = ~0ull;
+            for (int e = lane; e < n; e += 64) { const uint64_t k = buf[e]; mn = k < mn ? k : mn; }
+            tau = wave_min_u64(mn);
+        }
+        if ((int64_t)C < N || n < g.L) {
+            // the distance of the L-th best (+ margins for the log and the rounding of the canonical exp) inside the radius the sweep tested
+            // against: every pair it did not list has d^2 > R (dgg_topk_sweep.hip, sw_finalize's verification)
+            const float dL = c_log(fmaxf(key_val(tau), 1e-37f)) / t + 1e-5f;
+            ok = n >= g.L && dL * dL * (1.0f + 1e-5f) <= R * (1.0f - 1e-5f) - 1e-6f * fabsf(R);
+        }
+        if (ok && n > g.L) n = wave_compact_ge(buf, n, tau, lane);
+    }
+    if (lane == 0) {
+        cnt_out[lrow] = ok ? n : 0;
+        if (!ok) faillist[atomicAdd(nfail, 1)] = (int32_t)lrow;
+    }
+}
+
+// the rows the front end could not settle when they are FEW (a handful per forward on benchmark data): one wavefront per row streams
+// ALL columns through the row's threshold buffer, lane = column, four batches of 64 gathered rows in flight.  (aw_scan_plain shares
+// column tiles among 16 rows per wavefront: right for every row of a graph, but a launch of it costs a workgroup's whole walk --
+// 23 ms at N = 100 000 -- however few rows it is given.)  nlist[0] > few_max: left to aw_scan_plain.
+template <int H>
+__global__ __launch_bounds__(256) void aw_plain_rows_all(const float *__restrict__ xp, int64_t N, int64_t row0, float t, const float *__restrict__ klim,
+                                                         const int32_t *__restrict__ cptr, uint64_t *__restrict__ keys, int32_t *__restrict__ cnt_out,
+                                                         const int32_t *__restrict__ rowlist, const int32_t *__restrict__ nlist, int few_max) {
+    const int lane = threadIdx.x & 63;
+    const int nsel = nlist[0];
+    if (nsel > few_max) return;
+    const int q = blockIdx.x * 4 + dgg::wave_id();
+    if (q >= nsel) return;
+    const int lrow = __builtin_amdgcn_readfirstlane(rowlist[q]);
+    const int64_t i = row0 + lrow;
+    const RowGeom g = row_geom(cptr, klim, lrow);
+    if (g.cap == 0) { if (lane == 0) cnt_out[lrow] = 0; return; }
+    uint64_t *buf = keys + g.base;
+    const float *xi = xp + i * H;                                // wave-uniform: scalar loads
+    uint64_t thr = DGG_EMPTY_KEY;
+    int n = 0;
+    for (int64_t j0 = 0; j0 < N; j0 += 64) {
+        const int64_t j = j0 + lane;
+        uint64_t key = DGG_EMPTY_KEY;
+        if (j < N) {
+            const float4 *xj = reinterpret_cast<const float4 *>(xp + j * H);
+            float4 bq[H / 4];
+#pragma unroll
+            for (int c4 = 0; c4 < H / 4; c4++) bq[c4] = xj[c4];
+            float d2 = 0.0f;
+#pragma unroll
+            for (int c4 = 0; c4 < H / 4; c4++) {
+                float df;
+                df = __fadd_rn(xi[4 * c4 + 0], -bq[c4].x); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(xi[4 * c4 + 1], -bq[c4].y); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(xi[4 * c4 + 2], -bq[c4].z); d2 = __fmaf_rn(df, df, d2);
+                df = __fadd_rn(xi[4 * c4 + 3], -bq[c4].w); d2 = __fmaf_rn(df, df, d2);
+            }
+            key = make_key(score_from_dist(c_sqrt(d2), t, false, 0.0f), (int32_t)j);
+        }
+        bool pass = key != DGG_EMPTY_KEY && key > thr;
+        uint64_t m = __ballot(pass);
+        if (m != 0ull) {
+            if (n + __builtin_popcountll(m) > g.cap) {
+                thr = wave_select_lth(buf, n, g.L, keep_window(g.L, g.cap), lane);
+                n = wave_compact_ge(buf, n, thr, lane);
+                pass = pass && key > thr;
+                m = __ballot(pass);
+            }
+            const int p = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (pass) buf[p] = key;
+            n += __builtin_popcountll(m);
+        }
+    }
+    if (n > g.L) {
+        const uint64_t tau = wave_select_lth(buf, n, g.L, g.L, lane);
+        n = wave_compact_ge(buf, n, tau, lane);
+    }
+    if (lane == 0) cnt_out[lrow] = n;
 }
 
 // ---- per-pair hash noise: integer filter on every pair, exact scores for the survivors -----------------------------------------------
@@ -827,15 +992,29 @@ __global__ __launch_bounds__(ET) void aw_emit(const uint64_t *__restrict__ keys,
     }
 }
 
-struct HashWs { uint32_t *cand; int32_t *ncand; uint32_t *uthr; float *gmin; int32_t *fail; HashCtl *ctl; };
+struct HashWs { uint32_t *cand; int32_t *ncand; uint32_t *uthr; float *gmin; int32_t *fail; HashCtl *ctl; void *plain_ws; };
 template <int H>
 int launch_anywide(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, int noise_mode, uint32_t s0, uint32_t s1, const uint32_t *seed_dev,
                    const float *k, int mode, int maxm, int min_m, const int32_t *cptr, int64_t ccap, int32_t *idx, float *val, float *w, float *rs,
                    uint64_t *keys, int32_t *cnt, const float *lpub, const HashWs &hx, hipStream_t st) {
     const int64_t rows = row1 - row0;
     const dim3 gscan((unsigned)((rows + RB - 1) / RB));
-    if (noise_mode == 0)
-        hipLaunchKernelGGL(aw_scan_plain<H>, gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, k, cptr, keys, cnt);
+    if (noise_mode == 0) {
+        const char *ef = getenv("DGG_ANYWIDE_PLAIN_FRONT"), *ew = getenv("DGG_ANYWIDE_PLAIN_FEW");      // (read per call: tests switch between calls)
+        const int few_max = ew ? (atoi(ew) < PLAIN_FEW_MAX ? atoi(ew) : PLAIN_FEW_MAX) : PLAIN_FEW_MAX;
+        const int32_t *rowlist = nullptr, *nlist = nullptr;
+        if ((!ef || atoi(ef) != 0) && hx.plain_ws && N >= 1024) {   // radius sweep on the matrix cores; the rows it cannot settle: every pair scored
+            if (dgg_check_hip(hipMemsetAsync(hx.ctl, 0, sizeof(HashCtl), st), "anywide memset") != 0) return DGG_ERR_HIP;
+            int rc0 = dgg_plain_wide_front_impl(xp, N, H, row0, row1, k, cptr, CSLOT, hx.cand, hx.ncand, hx.gmin, hx.plain_ws, st);
+            if (rc0) return rc0;
+            hipLaunchKernelGGL(aw_plain_score<H>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xp, N, row0, row1, t, k, cptr, hx.cand, hx.ncand,
+                               dgg_plain_wide_sublists(), CSLOT, hx.gmin, keys, cnt, &hx.ctl->nfail, hx.fail);
+            rowlist = hx.fail;
+            nlist = &hx.ctl->nfail;
+            hipLaunchKernelGGL(aw_plain_rows_all<H>, dim3(PLAIN_FEW_MAX / 4), dim3(256), 0, st, xp, N, row0, t, k, cptr, keys, cnt, rowlist, nlist, few_max);
+        }
+        hipLaunchKernelGGL(aw_scan_plain<H>, gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, k, cptr, keys, cnt, rowlist, nlist, few_max);
+    }
     else if (noise_mode == 2 || noise_mode == 3) {
         // (read per call: tests switch the front end off / shrink its target between calls)
         const char *ef = getenv("DGG_ANYWIDE_HASH_FRONT"), *et = getenv("DGG_ANYWIDE_HASH_TARGET");
@@ -876,13 +1055,14 @@ extern "C" {
 
 // bytes of workspace dgg_allpairs_topk_anywide needs for arrays of `ccap` chunks and `rows` rows: 128 keys of 8 bytes per chunk + a count per row
 static inline size_t aw_al(size_t b) { return (b + 255) & ~(size_t)255; }
-// bytes of workspace dgg_allpairs_topk_anywide needs for arrays of `ccap` chunks and `rows` rows: keys (128 x 8 B per chunk) | counts |
-// candidate columns of the hash generators' front end (512 x 4 B per chunk) | per row: candidate counts per segment, integer thresholds,
-// guessed log-scores, fail list | control block
-size_t dgg_allpairs_anywide_ws_bytes(int64_t ccap, int64_t rows) {
-    if (ccap < 0 || rows < 0) return 0;
+constexpr int NSUBMAX = 8;              // candidate sub-lists per row at most (hash front end: 4 column segments; unperturbed: 2 halves x 4)
+// bytes of workspace dgg_allpairs_topk_anywide needs for arrays of `ccap` chunks, `rows` rows of a graph of N nodes, latent width h:
+// keys (128 x 8 B per chunk) | counts | candidate columns of the front ends (512 x 4 B per chunk) | per row: candidate counts per
+// sub-list, integer thresholds, guessed log-scores / radii, fail list | control block | the unperturbed front end's fp16 copy of xp
+size_t dgg_allpairs_anywide_ws_bytes(int64_t ccap, int64_t rows, int64_t N, int h) {
+    if (ccap < 0 || rows < 0 || N < 0) return 0;
     return aw_al((size_t)ccap * KSLOT * sizeof(uint64_t)) + aw_al((size_t)rows * 4) + aw_al((size_t)ccap * CSLOT * sizeof(uint32_t)) +
-           aw_al((size_t)rows * HSEG * 4) + 3 * aw_al((size_t)rows * 4) + 256;
+           aw_al((size_t)rows * NSUBMAX * 4) + 3 * aw_al((size_t)rows * 4) + 256 + aw_al(dgg_plain_wide_front_ws_bytes(rows, N, h));
 }
 
 // All-pairs top-L_i on CHUNKED rows of any width (include/dgg_hip.h).  noise_mode 0 (unperturbed), 2 (per-pair hash), 3 (symmetric per-pair
@@ -901,7 +1081,7 @@ int dgg_allpairs_topk_anywide(const float *xp, int64_t N, int h, int64_t row0, i
     if (maxm < 1 || maxm > DGG_CHUNK_MAXM_ANY || min_m < 0 || (noise_mode != 4 && min_m != 0))
         return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_anywide: maxm in 1..2^20; min_m = 0 unless the generator is the ranked one");
     if (N >= ((int64_t)1 << 28) || ccap >= ((int64_t)1 << 24)) return dgg_set_error(DGG_ERR_UNSUPPORTED, "allpairs_topk_anywide: N < 2^28, ccap < 2^24");
-    if (!workspace || ws_bytes < dgg_allpairs_anywide_ws_bytes(ccap, row1 - row0))
+    if (!workspace || ws_bytes < dgg_allpairs_anywide_ws_bytes(ccap, row1 - row0, N, h))
         return dgg_set_error(DGG_ERR_ARG, "allpairs_topk_anywide: workspace missing or smaller than dgg_allpairs_anywide_ws_bytes");
     if (row1 == row0) return 0;
     char *wsp = reinterpret_cast<char *>(workspace);
@@ -909,11 +1089,12 @@ int dgg_allpairs_topk_anywide(const float *xp, int64_t N, int h, int64_t row0, i
     int32_t *cnt = reinterpret_cast<int32_t *>(wsp); wsp += aw_al((size_t)(row1 - row0) * 4);
     HashWs hx;
     hx.cand = reinterpret_cast<uint32_t *>(wsp); wsp += aw_al((size_t)ccap * CSLOT * sizeof(uint32_t));
-    hx.ncand = reinterpret_cast<int32_t *>(wsp); wsp += aw_al((size_t)(row1 - row0) * HSEG * 4);
+    hx.ncand = reinterpret_cast<int32_t *>(wsp); wsp += aw_al((size_t)(row1 - row0) * NSUBMAX * 4);
     hx.uthr = reinterpret_cast<uint32_t *>(wsp); wsp += aw_al((size_t)(row1 - row0) * 4);
     hx.gmin = reinterpret_cast<float *>(wsp); wsp += aw_al((size_t)(row1 - row0) * 4);
     hx.fail = reinterpret_cast<int32_t *>(wsp); wsp += aw_al((size_t)(row1 - row0) * 4);
-    hx.ctl = reinterpret_cast<HashCtl *>(wsp);
+    hx.ctl = reinterpret_cast<HashCtl *>(wsp); wsp += 256;
+    hx.plain_ws = wsp;
     hipStream_t st = (hipStream_t)stream;
     switch (h) {
         case 16: return launch_anywide<16>(xp, N, row0, row1, t, noise_mode, s0, s1, seed_dev, k, mode, maxm, min_m, cptr, ccap, idx, val, w, rs, keys, cnt, lpub, hx, st);

@@ -494,6 +494,182 @@ __global__ void sw_rowmin_finish(const uint32_t *__restrict__ ekey, const float 
     lpub[q] = ub;
 }
 
+// ---- unperturbed scores on CHUNKED rows (rows of any width): radius per row guessed from a sampled sweep, one full sweep, candidates ------
+// Front end of dgg_allpairs_topk_anywide for noise_mode 0 (dgg_topk_anywide.hip scores the candidates, verifies, and redoes the rows
+// that fail with its exhaustive scan).  Row i needs its L_i = ceil(k_i + 8.5) + 1 nearest columns, L_i anything up to N:
+//   pw_pilot   one wavefront per 32 rows over SAMPLED column tiles (stride over the column range): every half-lane keeps the 8 largest
+//              E_ij = <x^_i, x^_j> + c_j of the first P_i tiles, P_i chosen per row so that about 8 of the 2.5 L_i + 64 columns the
+//              radius should admit fall into the half-lane's sample; the 8th largest (the smaller of the two halves) is the row's
+//              threshold e_i:  E_ij >= e_i  <=>  L_ij = nb_i - 2 E_ij <= R_i = nb_i - 2 e_i   (L_ij: rigorous lower bound of d^2)
+//   pw_sweep   sw_rowmin's loop over ALL tiles with the comparison E >= e_i per accumulator; a hit appends its column to the lane's own
+//              sub-list (row, half, segment): no atomics.  Every pair that is NOT listed has d^2 >= L_ij > R_i.
+constexpr int PW_CS = 4;                // column segments of pw_sweep (sub-lists per row: 2 halves x PW_CS)
+constexpr int PW_PTMAX = 64;            // sampled tiles of pw_pilot at most
+template <int H>
+__global__ __launch_bounds__(256) void pw_pilot(const uint16_t *__restrict__ xw, const float *__restrict__ nb, int64_t N, int64_t row0, int64_t row1,
+                                                int ntiles, const float *__restrict__ klim, const int32_t *__restrict__ cptr,
+                                                float *__restrict__ ethr, float *__restrict__ rad) {
+    using TL = Tile<H>;
+    constexpr int HW = TL::HW, KS1 = TL::KS1, STRIDE = TL::STRIDE, CPC = TL::CPC, LQ = TL::LQ;
+    __shared__ __attribute__((aligned(16))) unsigned char colA[TL::BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), r = lane & 31, hh = lane >> 5;
+    const int64_t i = row0 + (int64_t)blockIdx.x * 128 + wave * 32 + r;
+    const bool rvalid = i < row1;
+    const int64_t ic = rvalid ? i : row1 - 1, lr = ic - row0;
+    bf16x8 bfr[KS1];
+#pragma unroll
+    for (int s = 0; s < KS1 - 1; s++) bfr[s] = *reinterpret_cast<const bf16x8 *>(xw + ic * HW + 16 * s + 8 * hh);
+    bfr[KS1 - 1] = aug_row(0.0f, hh);
+    const int M = cptr[lr + 1] - cptr[lr];
+    const float target = 2.5f * (float)klimit_len(klim[lr], 64 * (M > 0 ? M : 1)) + 64.0f;
+    const int pt_all = ntiles < PW_PTMAX ? ntiles : PW_PTMAX;
+    int P = (int)ceilf(8.0f * (float)N / (64.0f * target));
+    P = P < 1 ? 1 : (P > pt_all ? pt_all : P);
+    float tm[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) tm[q] = -3.0e38f;
+    const int stride_t = ntiles / pt_all;
+    const int first_t = (int)(((uint32_t)blockIdx.x * 2654435761u) % (uint32_t)stride_t);
+    uint4 stg[LQ];
+    auto tile_load = [&](int pt) {
+        const int64_t c0 = (int64_t)(first_t + pt * stride_t) * TC;
+#pragma unroll
+        for (int q = 0; q < LQ; q++) {
+            stg[q] = make_uint4(0, 0, 0, 0);
+            if (pt < pt_all) stg[q] = *reinterpret_cast<const uint4 *>(xw + c0 * HW + (int64_t)(q * 256 + tid) * 8);
+        }
+    };
+    tile_load(0);
+    for (int pt = 0; pt < pt_all; pt++) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < LQ; q++) {
+            const int ch = q * 256 + tid;
+            *reinterpret_cast<uint4 *>(&colA[(ch / CPC) * STRIDE + (ch % CPC) * 16]) = stg[q];
+        }
+        __syncthreads();
+        tile_load(pt + 1);
+        const bool mine = pt < P;                                       // (per lane: the row's sample ends after its P tiles)
+#pragma unroll 1
+        for (int sub = 0; sub < TC / 32; sub++) {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[q] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KS1; s++) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(&colA[(sub * 32 + r) * STRIDE + (16 * s + 8 * hh) * 2]);
+                acc = (s == KS1 - 1) ? mfma_step<true>(af, bfr[s], acc) : mfma_step<false>(af, bfr[s], acc);
+            }
+            if (mine) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    float m = acc[q];
+                    if (m > tm[7]) {
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { const float hi = fmaxf(m, tm[u]); m = fminf(m, tm[u]); tm[u] = hi; }
+                    }
+                }
+            }
+        }
+    }
+    // the 8th largest of the half-lane's sample; fewer than 8 columns sampled (tiny graphs): every column is admitted
+    float e = 64 * P >= 16 && (int64_t)P * TC < N ? tm[7] : -3.0e38f;
+    e = fminf(e, __shfl_xor(e, 32, 64));                                // the more permissive of the two halves
+    if (rvalid && hh == 0) {
+        const float nbi = nb[ic];
+        const bool usable = nbi < 3.0e38f && e > -1.0e38f && M > 0;
+        ethr[lr] = usable ? e : -3.0e38f;                               // (-3e38: every column is a hit: the lists overflow, the row falls back)
+        rad[lr] = usable ? fmaf(-2.0f, e, nbi) - 4e-7f * (fabsf(nbi) + 2.0f * fabsf(e)) : 3.0e38f;
+    }
+}
+template <int H, int RBLK>
+__global__ __launch_bounds__(256, 2) void pw_sweep(const uint16_t *__restrict__ xw, int64_t npad, int64_t row0, int64_t row1, int ntiles, int nrb, int rbx,
+                                                   const float *__restrict__ ethr, const int32_t *__restrict__ cptr, int cslot,
+                                                   uint32_t *__restrict__ cand, int32_t *__restrict__ ncand) {
+    using TL = Tile<H>;
+    constexpr int HW = TL::HW, KS1 = TL::KS1, STRIDE = TL::STRIDE, CPC = TL::CPC, LQ = TL::LQ, CS = PW_CS;
+    __shared__ __attribute__((aligned(16))) unsigned char colA[2][TL::BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), r = lane & 31, hh = lane >> 5;
+    const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int seg = kk / rbx, rowblk = (kk % rbx) * 8 + xcd;
+    if (rowblk >= nrb) return;
+    const int64_t rbase = row0 + (int64_t)rowblk * (128 * RBLK) + (int64_t)wave * (32 * RBLK);
+    bf16x8 bfr[RBLK][KS1];
+    float et[RBLK];
+    uint32_t *cb[RBLK];
+    int cap[RBLK], cnt[RBLK];
+#pragma unroll
+    for (int b = 0; b < RBLK; b++) {
+        const int64_t i = rbase + b * 32 + r;
+        const bool rv = i < row1;
+        const int64_t ic = rv ? i : row1 - 1, lr = ic - row0;
+#pragma unroll
+        for (int s = 0; s < KS1 - 1; s++) bfr[b][s] = *reinterpret_cast<const bf16x8 *>(xw + ic * HW + 16 * s + 8 * hh);
+        bfr[b][KS1 - 1] = aug_row(0.0f, hh);
+        et[b] = rv ? ethr[lr] : 3.0e38f;                                // (rows beyond the range: no hit ever)
+        const int c0 = cptr[lr], M = cptr[lr + 1] - c0;
+        cap[b] = M * cslot / (2 * CS);
+        cb[b] = cand + (int64_t)c0 * cslot + (int64_t)(hh * CS + seg) * cap[b];
+        cnt[b] = 0;
+    }
+    uint4 stg[LQ];
+    auto tile_load = [&](int w) {
+        const int64_t c0 = (int64_t)w * TC;
+#pragma unroll
+        for (int q = 0; q < LQ; q++) {
+            stg[q] = make_uint4(0, 0, 0, 0);
+            if (c0 < npad) stg[q] = *reinterpret_cast<const uint4 *>(xw + c0 * HW + (int64_t)(q * 256 + tid) * 8);
+        }
+    };
+    auto tile_store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < LQ; q++) {
+            const int ch = q * 256 + tid;
+            *reinterpret_cast<uint4 *>(&colA[buf][(ch / CPC) * STRIDE + (ch % CPC) * 16]) = stg[q];
+        }
+    };
+    int w = seg;
+    if (w < ntiles) { tile_load(w); tile_store(0); }
+    __syncthreads();
+    for (int it = 0; w < ntiles; w += CS, it++) {
+        const int buf = it & 1;
+        const bool more = w + CS < ntiles;
+        if (more) tile_load(w + CS);
+        const uint32_t cbase = (uint32_t)w * TC + (uint32_t)(4 * hh);
+#pragma unroll 1
+        for (int sub = 0; sub < TC / 32; sub++) {
+            bf16x8 af[KS1];
+#pragma unroll
+            for (int s = 0; s < KS1; s++) af[s] = *reinterpret_cast<const bf16x8 *>(&colA[buf][(sub * 32 + r) * STRIDE + (16 * s + 8 * hh) * 2]);
+#pragma unroll
+            for (int b = 0; b < RBLK; b++) {
+                f32x16 acc;
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc[q] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < KS1 - 1; s++) acc = mfma_step<false>(af[s], bfr[b][s], acc);
+                acc = mfma_step<true>(af[KS1 - 1], bfr[b][KS1 - 1], acc);
+                uint32_t hm = 0u;                                        // bit q: accumulator q is inside the row's radius
+#pragma unroll
+                for (int q = 0; q < 16; q++) hm |= acc[q] >= et[b] ? (1u << q) : 0u;
+                while (hm != 0u) {
+                    const uint32_t q = (uint32_t)__builtin_ctz(hm);
+                    hm &= hm - 1u;
+                    if (cnt[b] < cap[b]) cb[b][cnt[b]] = cbase + (uint32_t)(sub * 32) + ((q & 3u) | ((q & 12u) << 1));
+                    cnt[b]++;
+                }
+            }
+        }
+        if (more) tile_store(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < RBLK; b++) {
+        const int64_t i = rbase + b * 32 + r;
+        if (i < row1) ncand[(i - row0) * (2 * CS) + hh * CS + seg] = cnt[b];
+    }
+}
+
 // ---- select: tight radius from the phase-A hits -------------------------------------------------------------------------------
 // one wavefront per row.  D (loose) = <.,.> + c_j + t_loose is what phase A recorded; L = R_loose - 2 D is the pair's LOWER bound
 // and U = L + SL (nb_i + nb_j) an UPPER bound of d^2 (both roundings of the bf16 products the other way).  The verification
@@ -1125,4 +1301,37 @@ int dgg_allpairs_rowmin_bound(const float *xp, int64_t N, int h, int64_t row0, i
         default: return launch_rowmin<128, 2>(xp, N, row0, row1, t, lpub, workspace, st);
     }
 }
+}
+
+// front end of the unperturbed chunked rows (dgg_topk_anywide.hip): xw / nb / ethr live in the caller's workspace
+namespace {
+template <int H, int RBLK>
+int launch_plain_front(const float *xp, int64_t N, int64_t row0, int64_t row1, const float *klim, const int32_t *cptr, int cslot, uint32_t *cand,
+                       int32_t *ncand, float *rad, void *ws, hipStream_t st) {
+    const int64_t rows = row1 - row0;
+    const RowminLayout L = rowmin_layout(rows, N, H);
+    char *w = reinterpret_cast<char *>(ws);
+    uint16_t *xw = reinterpret_cast<uint16_t *>(w + L.xw);
+    float *nb = reinterpret_cast<float *>(w + L.nb);
+    float *ethr = reinterpret_cast<float *>(w + L.ekey);
+    const int ntiles = (int)((N + TC - 1) / TC);
+    const int64_t npad = (int64_t)ntiles * TC;
+    const int rw = 128 * RBLK, nrb = (int)((rows + rw - 1) / rw), rbx = (nrb + 7) / 8;
+    hipLaunchKernelGGL(sw_prep<H>, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, st, xp, N, npad, xw, nb);
+    hipLaunchKernelGGL(pw_pilot<H>, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, st, xw, nb, N, row0, row1, ntiles, klim, cptr, ethr, rad);
+    hipLaunchKernelGGL((pw_sweep<H, RBLK>), dim3((unsigned)(8 * rbx * PW_CS)), dim3(256), 0, st, xw, npad, row0, row1, ntiles, nrb, rbx, ethr, cptr, cslot,
+                       cand, ncand);
+    return dgg_check_launch("allpairs_topk_anywide: unperturbed front end");
+}
+}  // namespace
+size_t dgg_plain_wide_front_ws_bytes(int64_t rows, int64_t N, int h) { return rowmin_layout(rows, N, h).total; }
+int dgg_plain_wide_sublists(void) { return 2 * PW_CS; }
+int dgg_plain_wide_front_impl(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, const float *klim, const int32_t *cptr, int cslot,
+                              uint32_t *cand, int32_t *ncand, float *rad, void *ws, hipStream_t st) {
+    switch (h) {
+        case 16: return launch_plain_front<16, 4>(xp, N, row0, row1, klim, cptr, cslot, cand, ncand, rad, ws, st);
+        case 32: return launch_plain_front<32, 4>(xp, N, row0, row1, klim, cptr, cslot, cand, ncand, rad, ws, st);
+        case 64: return launch_plain_front<64, 4>(xp, N, row0, row1, klim, cptr, cslot, cand, ncand, rad, ws, st);
+        default: return launch_plain_front<128, 2>(xp, N, row0, row1, klim, cptr, cslot, cand, ncand, rad, ws, st);
+    }
 }

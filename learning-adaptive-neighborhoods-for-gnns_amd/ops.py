@@ -536,7 +536,7 @@ def allpairs_topk_wide(xp, k, layout, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, see
                                                             _ptr(layout.cptr), C_, _ptr(idx), _ptr(val), _ptr(w), _ptr(rs), _ptr(lpub), _stream()),
                    "allpairs_topk_ranked_wide")
     if nm != NOISE_RANKED or layout.maxm > CHUNK_MAXM:
-        nb = int(_lib.lib().dgg_allpairs_anywide_ws_bytes(C_, r1 - r0))
+        nb = int(_lib.lib().dgg_allpairs_anywide_ws_bytes(C_, r1 - r0, N, h))
         ws = torch.empty((nb,), device=xp.device, dtype=torch.uint8)
         _lib.check(_lib.lib().dgg_allpairs_topk_anywide(_ptr(xp), N, h, r0, r1, t, nm, seed[0], seed[1], _ptr(dseed), _ptr(k), mode, layout.maxm,
                                                         CHUNK_MAXM if nm == NOISE_RANKED else 0, _ptr(layout.cptr), C_, _ptr(idx), _ptr(val),

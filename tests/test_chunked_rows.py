@@ -217,7 +217,7 @@ def test_fixed_capacity_overflow_is_memory_safe_and_sticky(dev):
             _lib.check(L.dgg_allpairs_topk_ranked_wide(P_(xp), N, h, 0, N, ops.T_DIST, 1, 2, None, P_(k), 0, 4, P_(lay.cptr), cap, P_(idx), P_(val), P_(w),
                                                        P_(rs), None, C.c_void_p(st)), "ranked_wide")
         else:
-            nb = int(L.dgg_allpairs_anywide_ws_bytes(cap, N))
+            nb = int(L.dgg_allpairs_anywide_ws_bytes(cap, N, N, h))
             ws = torch.empty(nb + 4096, dtype=torch.uint8, device=dev)
             ws[nb:] = 0x5A
             _lib.check(L.dgg_allpairs_topk_anywide(P_(xp), N, h, 0, N, ops.T_DIST, nm, 1, 2, None, P_(k), 0, 4, 0, P_(lay.cptr), cap, P_(idx), P_(val),
@@ -713,3 +713,31 @@ def test_hash_wide_rows_guess_and_verify_falls_back_exactly(dev, noise, knob, mo
         assert torch.equal(a_, b_)
     rows = [0, 17, N - 1] + [int(v) for v in np.random.default_rng(2).integers(0, N, 12)]
     _check_rows_against_oracle(lay, xp, k, *got, {"hash": O.NOISE_HASH, "hash_sym": O.NOISE_HASH_SYM}[noise], (8, 9), 0, rows=rows)
+
+
+@pytest.mark.parametrize("knob", ["", "DGG_ANYWIDE_PLAIN_FEW=0"])
+def test_unperturbed_wide_rows_front_end_and_fallback_agree(dev, knob, monkeypatch):
+    """unperturbed scores on chunked rows: the matrix-core front end (radius per row from a sampled sweep, one full fp16-MFMA sweep,
+    candidates scored and verified, failing rows redone -- by one wavefront per row when they are few, by the tiled exhaustive scan
+    otherwise: DGG_ANYWIDE_PLAIN_FEW=0 forces the latter) against the exhaustive scan alone -- same bits -- on data with a tight cluster
+    and far outliers (rows whose guessed radius fails), and against the oracle on sampled rows"""
+    from dgg_amd import ops
+    N, h = 9000, 64
+    g = torch.Generator().manual_seed(41)
+    xp = torch.randn(N, h, generator=g) * 0.8
+    xp[2000:2600] *= 0.03                                        # a tight blob
+    xp[2600:2620] = xp[2600:2620] * 0.01 + 4.0                   # outliers far from everything
+    xp[100] = xp[7]                                              # duplicate rows
+    xp = xp.to(dev)
+    k = (5.0 + 500.0 * torch.rand(N, generator=g) ** 2).to(dev)
+    k[[3, 2005, 2610]] = torch.tensor([3000.0, 2500.0, 40.0], device=dev)
+    lay = ops.chunk_layout(k, ncols=N)
+    if knob:
+        monkeypatch.setenv(*knob.split("="))
+    got = ops.allpairs_topk_wide(xp, k, lay, seed=(0, 0), noise_mode=ops.NOISE_NONE)
+    monkeypatch.setenv("DGG_ANYWIDE_PLAIN_FRONT", "0")
+    ref = ops.allpairs_topk_wide(xp, k, lay, seed=(0, 0), noise_mode=ops.NOISE_NONE)
+    for a_, b_ in zip(ref, got):
+        assert torch.equal(a_, b_)
+    rows = [0, 3, 7, 100, 2005, 2300, 2610, N - 1] + [int(v) for v in np.random.default_rng(4).integers(0, N, 10)]
+    _check_rows_against_oracle(lay, xp, k, *got, O.NOISE_NONE, (0, 0), 0, rows=rows)
