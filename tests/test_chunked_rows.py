@@ -587,7 +587,11 @@ def test_full_size_gcn_dgg_trains_past_the_list(dev, symmetric_noise, perturb):
         m.dggs[0].k_net.k_project.weight.mul_(0.1)               # the benchmark's initialisation: k in ~[24, 41] at step 0
     opt = torch.optim.Adam([{"params": m.params1, "weight_decay": 0.01}, {"params": m.params2, "weight_decay": 5e-4}], lr=0.01)
     hist = []
+    import gc
+    gc.collect()                                                 # (what earlier tests of the session left behind is not this test's peak)
+    torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated() / 2 ** 30
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")                          # (symmetric noise: the one-time notice of the generator switch)
         for step in range(200):
@@ -600,15 +604,17 @@ def test_full_size_gcn_dgg_trains_past_the_list(dev, symmetric_noise, perturb):
             opt.step()
     first = next((s_ for s_, (km, _, _) in enumerate(hist) if km + 9.5 > 64), None)
     kmax = max(km for km, _, _ in hist)
-    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30 - base
     print(f"N = 100 000, symmetric_noise={symmetric_noise}, perturb_edge_prob={perturb}: learned degrees exceed the list from step {first}; "
           f"largest k {kmax:.0f} (widest row {max(w_ or 1 for _, w_, _ in hist)} chunks); loss {hist[0][2]:.3f} -> {hist[-1][2]:.3f}; "
           f"peak memory {peak:.1f} GiB")
     assert hist[0][1] is None, "inside the list at initialisation"
-    assert first is not None and all(w_ is not None for _, w_, _ in hist[first:])
-    assert kmax > 700
-    assert np.isfinite(hist[-1][2]) and hist[-1][2] < hist[0][2]
-    assert peak < 60, "a step's state must not outlive the step (reference cycles through the autograd node)"
+    # (the largest learned degree may dip below the list's 54.5 again for a step or two right after it first crossed it)
+    assert first is not None and first < 30 and all(w_ is not None for _, w_, _ in hist[first + 10:]), f"rows left the chunked form again: {hist[first:first + 12]}"
+    assert all((w_ is not None) == (km + 9.5 > 64) for km, w_, _ in hist), "a row wider than the list without the chunked layout (or the reverse)"
+    assert kmax > 700, f"largest learned degree {kmax}"
+    assert np.isfinite(hist[-1][2]) and hist[-1][2] < hist[0][2], f"loss {hist[0][2]} -> {hist[-1][2]}"
+    assert peak < 60, f"peak memory {peak:.1f} GiB above the start: a step's state must not outlive the step (reference cycles through the autograd node)"
     # inference under a hipGraph: the capture replays the last eager layout as a fixed capacity
     m.eval()
     m.dggs[0].set_seed(7, 7)
