@@ -311,7 +311,9 @@ __global__ __launch_bounds__(256) void aw_plain_score(const float *__restrict__ 
             // the distance of the L-th best (+ margins for the log and the rounding of the canonical exp) inside the radius the sweep tested
             // against: every pair it did not list has d^2 > R (dgg_topk_sweep.hip, sw_finalize's verification)
             const float dL = c_log(fmaxf(key_val(tau), 1e-37f)) / t + 1e-5f;
-            ok = n >= g.L && dL * dL * (1.0f + 1e-5f) <= R * (1.0f - 1e-5f) - 1e-6f * fabsf(R);
+            // (and a score in the normal range: zero / denormal scores tie over whole shells of distances, the oracle's column order then
+            //  decides also among the pairs the sweep did not list -- the row goes to the scan that scores every pair)
+            ok = n >= g.L && key_val(tau) >= 4.8e-38f && dL * dL * (1.0f + 1e-5f) <= R * (1.0f - 1e-5f) - 1e-6f * fabsf(R);
         }
         if (ok && n > g.L) n = wave_compact_ge(buf, n, tau, lane);
     }

@@ -38,6 +38,7 @@ __device__ __forceinline__ uint64_t dpp_add_u64(uint64_t v) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROWMASK, 0xF, false);
     return v + (((uint64_t)hi << 32) | lo);
 }
+#ifdef DGG_RK_MOVSCAN
 __device__ __forceinline__ uint64_t wave_inclusive_scan_u64(uint64_t v, int) {
     v = dpp_add_u64<0x111, 0xF>(v);                              // row_shr:1
     v = dpp_add_u64<0x112, 0xF>(v);                              // row_shr:2
@@ -47,6 +48,29 @@ __device__ __forceinline__ uint64_t wave_inclusive_scan_u64(uint64_t v, int) {
     v = dpp_add_u64<0x143, 0xC>(v);                              // row_bcast:31 -> rows 2, 3
     return v;
 }
+#else
+// ... with the DPP operand ON the add: v_add_co_u32_dpp / v_addc_co_u32_dpp take the shifted lane as source 0 (bound_ctrl: a lane
+// without a source adds 0; a row outside row_mask is not written), two instructions per step where the builtin form above compiles
+// to two v_mov + two v_mov_dpp + a 64-bit add.  Hand-scheduled hazards (the compiler does not look inside): a DPP read of a register
+// needs two wait states after the VALU write -- the other half's add and one s_nop sit in between.
+#define DGG_DPP_ADD64(ctrl)                                                                              \
+    "v_add_co_u32_dpp %0, vcc, %0, %0 " ctrl " bound_ctrl:0\n"                                           \
+    "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " ctrl " bound_ctrl:0\n"                                     \
+    "s_nop 0\n"
+__device__ __forceinline__ uint64_t wave_inclusive_scan_u64(uint64_t v, int) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    asm volatile("s_nop 1\n"
+                 DGG_DPP_ADD64("row_shr:1 row_mask:0xf bank_mask:0xf")
+                 DGG_DPP_ADD64("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 DGG_DPP_ADD64("row_shr:4 row_mask:0xf bank_mask:0xf")
+                 DGG_DPP_ADD64("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 DGG_DPP_ADD64("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 DGG_DPP_ADD64("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(lo), "+v"(hi) : : "vcc");
+    return ((uint64_t)hi << 32) | lo;
+}
+#undef DGG_DPP_ADD64
+#endif
 #endif
 
 // One block of the ranked walk of row i: positions rb .. rb + 63 of the row's sequence.  Position 0 is the row's OWN column with its
@@ -54,6 +78,12 @@ __device__ __forceinline__ uint64_t wave_inclusive_scan_u64(uint64_t v, int) {
 // candidate when the slot is < n.  -> col, cand (the lane holds a candidate), G (its noise), mv (ballot of the lanes that hold a
 // RANK, i.e. all candidates but the diagonal); S / scount carry the fixed-point prefix sum and the rank count across blocks.
 struct RankedLane { uint32_t col; bool cand; float G; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// log(exp(t sqrt(d2)) + 1e-8) to ~1e-5 absolute from the raw transcendental instructions (bound tests only, never a score)
+__device__ __forceinline__ float fast_logp_bound(float d2, float t) {
+    const float e = __builtin_amdgcn_exp2f(t * 1.44269504f * __builtin_amdgcn_sqrtf(d2));
+    return 0.693147181f * __builtin_amdgcn_logf(e + 1e-8f);
+}
 __device__ __forceinline__ RankedLane ranked_block(uint64_t rb, int lane, uint32_t i, int64_t n, int b, uint64_t D, uint32_t k1, uint32_t k2, uint32_t k3,
                                                    uint64_t &S, uint32_t &scount, uint64_t &mv) {
     const uint64_t p = rb + (uint64_t)lane;
@@ -133,6 +163,7 @@ __global__ __launch_bounds__(256, DGG_RK_WAVES) void allpairs_topk_ranked(const 
             float d2 = 0.0f;
             auto chain = [&](int c8) {
                 float4 b0 = xj[2 * c8], b1 = xj[2 * c8 + 1];
+#ifdef DGG_RK_SCALAR_SUB
                 float df;
                 df = __fadd_rn(xi[8 * c8 + 0], -b0.x); d2 = __fmaf_rn(df, df, d2);
                 df = __fadd_rn(xi[8 * c8 + 1], -b0.y); d2 = __fmaf_rn(df, df, d2);
@@ -142,6 +173,18 @@ __global__ __launch_bounds__(256, DGG_RK_WAVES) void allpairs_topk_ranked(const 
                 df = __fadd_rn(xi[8 * c8 + 5], -b1.y); d2 = __fmaf_rn(df, df, d2);
                 df = __fadd_rn(xi[8 * c8 + 6], -b1.z); d2 = __fmaf_rn(df, df, d2);
                 df = __fadd_rn(xi[8 * c8 + 7], -b1.w); d2 = __fmaf_rn(df, df, d2);
+#else
+                // the differences two at a time (v_pk_add_f32: the same IEEE subtraction, half the issue slots); the squares still
+                // enter the ONE ascending fmaf chain of the canonical order
+                const f32x2 a0 = {xi[8 * c8 + 0], xi[8 * c8 + 1]}, a1 = {xi[8 * c8 + 2], xi[8 * c8 + 3]};
+                const f32x2 a2 = {xi[8 * c8 + 4], xi[8 * c8 + 5]}, a3 = {xi[8 * c8 + 6], xi[8 * c8 + 7]};
+                const f32x2 e0 = a0 - f32x2{b0.x, b0.y}, e1 = a1 - f32x2{b0.z, b0.w};
+                const f32x2 e2 = a2 - f32x2{b1.x, b1.y}, e3 = a3 - f32x2{b1.z, b1.w};
+                d2 = __fmaf_rn(e0.x, e0.x, d2); d2 = __fmaf_rn(e0.y, e0.y, d2);
+                d2 = __fmaf_rn(e1.x, e1.x, d2); d2 = __fmaf_rn(e1.y, e1.y, d2);
+                d2 = __fmaf_rn(e2.x, e2.x, d2); d2 = __fmaf_rn(e2.y, e2.y, d2);
+                d2 = __fmaf_rn(e3.x, e3.x, d2); d2 = __fmaf_rn(e3.y, e3.y, d2);
+#endif
             };
             // first cache line of the row (32 features): the running sum of the fmaf chain only grows, so sqrt of the
             // partial sum is a rigorous lower bound of the distance -- if even that cannot reach the L-th log-score, the
@@ -151,7 +194,13 @@ __global__ __launch_bounds__(256, DGG_RK_WAVES) void allpairs_topk_ranked(const 
             for (int c8 = 0; c8 < HEAD; c8++) chain(c8);
             bool alive = true;
             // log p' = G + log(exp(t dist) + 1e-8) is decreasing in dist: evaluate it at the lower bound (fast math + margin)
+#ifdef DGG_RK_SLOW_BOUND
             if (HEAD < H / 8) alive = !(G + __logf(__expf(t * sqrtf(d2)) + 1e-8f) + 1e-3f < thr_log);
+#else
+            // (the hardware's sqrt / exp2 / log2 as they are -- 1 ulp each, no denormal paths: the margin is 1e-3 -- and no test at
+            //  all while the list is not full: every candidate of the first block is scored anyway)
+            if (HEAD < H / 8 && thr_log > -INFINITY) alive = !(G + fast_logp_bound(d2, t) + 1e-3f < thr_log);
+#endif
             if (alive) {
 #pragma unroll
                 for (int c8 = HEAD; c8 < H / 8; c8++) chain(c8);
@@ -429,6 +478,7 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked_wide(const float *__
             float d2 = 0.0f;
             auto chain = [&](int c8) {
                 float4 b0 = xj[2 * c8], b1 = xj[2 * c8 + 1];
+#ifdef DGG_RK_SCALAR_SUB
                 float df;
                 df = __fadd_rn(xi[8 * c8 + 0], -b0.x); d2 = __fmaf_rn(df, df, d2);
                 df = __fadd_rn(xi[8 * c8 + 1], -b0.y); d2 = __fmaf_rn(df, df, d2);
@@ -438,12 +488,30 @@ __global__ __launch_bounds__(256) void allpairs_topk_ranked_wide(const float *__
                 df = __fadd_rn(xi[8 * c8 + 5], -b1.y); d2 = __fmaf_rn(df, df, d2);
                 df = __fadd_rn(xi[8 * c8 + 6], -b1.z); d2 = __fmaf_rn(df, df, d2);
                 df = __fadd_rn(xi[8 * c8 + 7], -b1.w); d2 = __fmaf_rn(df, df, d2);
+#else
+                // the differences two at a time (v_pk_add_f32: the same IEEE subtraction, half the issue slots); the squares still
+                // enter the ONE ascending fmaf chain of the canonical order
+                const f32x2 a0 = {xi[8 * c8 + 0], xi[8 * c8 + 1]}, a1 = {xi[8 * c8 + 2], xi[8 * c8 + 3]};
+                const f32x2 a2 = {xi[8 * c8 + 4], xi[8 * c8 + 5]}, a3 = {xi[8 * c8 + 6], xi[8 * c8 + 7]};
+                const f32x2 e0 = a0 - f32x2{b0.x, b0.y}, e1 = a1 - f32x2{b0.z, b0.w};
+                const f32x2 e2 = a2 - f32x2{b1.x, b1.y}, e3 = a3 - f32x2{b1.z, b1.w};
+                d2 = __fmaf_rn(e0.x, e0.x, d2); d2 = __fmaf_rn(e0.y, e0.y, d2);
+                d2 = __fmaf_rn(e1.x, e1.x, d2); d2 = __fmaf_rn(e1.y, e1.y, d2);
+                d2 = __fmaf_rn(e2.x, e2.x, d2); d2 = __fmaf_rn(e2.y, e2.y, d2);
+                d2 = __fmaf_rn(e3.x, e3.x, d2); d2 = __fmaf_rn(e3.y, e3.y, d2);
+#endif
             };
             constexpr int HEAD = H >= 64 ? 4 : H / 8;
 #pragma unroll
             for (int c8 = 0; c8 < HEAD; c8++) chain(c8);
             bool alive = true;
+#ifdef DGG_RK_SLOW_BOUND
             if (HEAD < H / 8) alive = !(G + __logf(__expf(t * sqrtf(d2)) + 1e-8f) + 1e-3f < thr_log);
+#else
+            // (the hardware's sqrt / exp2 / log2 as they are -- 1 ulp each, no denormal paths: the margin is 1e-3 -- and no test at
+            //  all while the list is not full: every candidate of the first block is scored anyway)
+            if (HEAD < H / 8 && thr_log > -INFINITY) alive = !(G + fast_logp_bound(d2, t) + 1e-3f < thr_log);
+#endif
             if (alive) {
 #pragma unroll
                 for (int c8 = HEAD; c8 < H / 8; c8++) chain(c8);

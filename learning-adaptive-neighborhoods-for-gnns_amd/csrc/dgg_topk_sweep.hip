@@ -850,6 +850,7 @@ __device__ __forceinline__ float exact_score0(const float *__restrict__ xp, int6
 // candidates within dist_64 + 4e-6 (the margin covers ties and the 1-ulp non-monotonicity of the canonical exp) -- 64 to ~66
 // columns -- go through sqrt / exp and the ONE 64-lane sort.  (Scoring, sorting and merging every batch of 64 candidates
 // was 2.5 sorts + merges per row: 0.63 ms.)
+constexpr float SCORE_MIN_NORMAL = 4.8e-38f;   // 4 x the smallest normal float: below it exp(t d) has lost the bits that order distances
 constexpr int FCAP = 320;               // candidates of one row that sw_finalize can hold; more: the row goes to the fallback
 template <int H>
 __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp, const float *__restrict__ nb, int64_t row0, int64_t row1, float t,
@@ -977,7 +978,10 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
         // verification: full list, and its 64th distance (+ margins for the log and the rounding of the canonical exp) inside the
         // radius the sweeps tested against: R = nb_i + 2 t_tight
         const uint64_t k63 = shfl_u64(list, Lr - 1);                    // the last rank that carries weight
-        if (k63 == DGG_EMPTY_KEY) ok = false;
+        // (a score below the normal range -- t d < -87: features hundreds of units apart -- no longer identifies a distance: zero and
+        //  denormal scores tie over whole shells and the oracle breaks ties by column, also among the columns the sweeps rejected; such
+        //  a row is left to the fallback, which scores every column)
+        if (k63 == DGG_EMPTY_KEY || key_val(k63) < SCORE_MIN_NORMAL) ok = false;
         else {
             const float d63 = c_log(fmaxf(key_val(k63), 1e-37f)) / t + 1e-5f;
             const float R = fmaf(2.0f, ttight[lrow], nb[i]);

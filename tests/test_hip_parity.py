@@ -724,6 +724,38 @@ def test_full_size_unperturbed_sweep(dev, clustered):
     assert torch.equal(sub_i, ki[22_900:23_412]) and torch.equal(sub_v, kv[22_900:23_412])
 
 
+@pytest.mark.parametrize("scale", [40.0, 300.0, 600.0])
+def test_unperturbed_scores_below_the_normal_range_keep_the_oracles_column_order(dev, scale):
+    """Found by tools/fuzz_anywide.py: with features hundreds of units apart, exp(-0.05 d) leaves the normal float range (d > 1746:
+    denormal scores that tie over shells of distances; d > 2066: exactly 0.0) and the oracle -- like the reference's stable sort
+    over a row of equal scores -- orders the tie by COLUMN, also among columns the distance sweeps rejected.  Both guess-sweep-verify
+    paths (the 64-rank sweep at N >= 8192 and the chunked rows' radius front end) must hand such rows to the scan that scores every
+    column: bit-exact rows at scale 600 (every score of a row but its own is the same sub-normal-range value: the list is the row's own column, then
+    columns 0, 1, 2, ... at the clamp value of the canonical exp), at scale 300 (a row's nearest neighbours still score in the normal range, its farther ranks do not) and at
+    scale 40 (distances ~ 320: tiny but normal scores, no fallback needed)."""
+    from dgg_amd import ops
+    N, h = 8200, 32
+    g = torch.Generator().manual_seed(int(scale))
+    xp = (torch.randn(N, h, generator=g) * scale).to(dev)
+    xp_c = Nn(xp)
+    rows = [0, 1, 17, 4099, N - 1]
+    idx, val, ws = ops.allpairs_topk(xp, K, noise_mode=ops.NOISE_NONE, return_ws=True)
+    nfail = ops.fast_path_failed_rows(ws, N, h)
+    print(f"scale {scale}: {nfail} of {N} rows redone by the exhaustive fallback")
+    assert nfail == N if scale > 500 else (nfail <= N // 100 if scale < 100 else True), nfail
+    for r in rows:
+        ri, rv = O.allpairs_topk(xp_c, K=K, noise_mode=O.NOISE_NONE, rows=(r, r + 1))
+        assert np.array_equal(Nn(idx[r]), ri[0]) and np.array_equal(Nn(val[r]), rv[0]), r
+    if scale > 500:
+        # (the canonical exp clamps its argument: every other column scores the same smallest value, the tie goes by column)
+        assert float(val[:, 1:].max()) == float(val[:, 1:].min()) < 4.8e-38 and bool((idx[5000, 1:4].cpu() == torch.tensor([0, 1, 2])).all())
+    k = (1.0 + 150.0 * torch.rand(N, generator=g) ** 2).to(dev)
+    lay = ops.chunk_layout(k, ncols=N)
+    ci, cv, cw, crs = ops.allpairs_topk_wide(xp, k, lay, seed=(1, 2), noise_mode=ops.NOISE_NONE)
+    from test_chunked_rows import _check_rows_against_oracle
+    _check_rows_against_oracle(lay, xp, k, ci, cv, cw, crs, O.NOISE_NONE, (1, 2), 0, rows=rows)
+
+
 @pytest.mark.parametrize("clustered", [False, True])
 def test_full_size_ranked_symmetric_noise(dev, clustered):
     """N = 100k under the ranked SYMMETRIC generator (the reference's symmetric_noise=True) with the learned-degree limit, as the
