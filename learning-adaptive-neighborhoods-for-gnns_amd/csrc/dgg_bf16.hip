@@ -485,9 +485,12 @@ int launch_gemm(const __bf16 *A, const __bf16 *B, int M, int N, int K, float sca
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(A2)) % 16) return dgg_set_error(DGG_ERR_ARG, "gemm_nt_bf16: operands must be 16-byte aligned");
     if (M == 0 || N == 0) return 0;
     if (epi < 0) epi = ep ? 1 : 0;
-    // 128-row tiles unless they would leave the 256 CUs with fewer than two rounds of workgroups
-    const int64_t big = (int64_t)((N + BN - 1) / BN) * ((M + 127) / 128);
-    bool small = big < 192;   // (64-row tiles carry 1.5x the LDS traffic per MFMA: only when 128-row tiles would leave CUs idle)
+    // 128-row or 64-row tiles: whichever needs less time in ROUNDS of one workgroup per CU (the ring's LDS admits one).  A 64-row tile takes
+    // 0.68 of a 128-row tile's time (measured: it carries 1.5x the LDS traffic per MFMA), so it pays only while it saves a round:
+    // n = 591 (PPI's smallest graph): 160 small tiles in one round against 80 large ones; n = 1300: 336 small tiles are TWO rounds (58 us)
+    // where 176 large ones are one (45 us) -- the former rule (small below 192 large tiles) chose the 58.
+    const int64_t nt = (N + BN - 1) / BN, big = nt * ((M + 127) / 128), sml = nt * ((M + 63) / 64);
+    bool small = (double)((sml + 255) / 256) * 0.68 < (double)((big + 255) / 256);
     { const char *e = getenv("DGG_BF16_TILE"); if (e) small = atoi(e) == 64 ? true : (atoi(e) == 128 ? false : small); }
     const dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + (small ? 63 : 127)) / (small ? 64 : 128)));
     const GcniiEpi e0 = ep ? *ep : GcniiEpi{};

@@ -26,7 +26,7 @@ def t_us(fn, reps=30):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-for n in (591, 1300, 2000, 2560, 3480):
+for n in (591, 1100, 1300, 1500, 2000, 2560, 3480):
     n64 = (n + 63) // 64 * 64
     for name, (M, N, K) in {"fwd": (n, 2048, 4096), "dsup": (n, 2048, 2048), "dW": (4096, 2048, n64)}.items():
         A = torch.randn(M, K, device=dev).bfloat16()
