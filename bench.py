@@ -1164,7 +1164,10 @@ def bench_synthetic(a, dev, world, rank, force):
     noise_mode = {"ranked": ops.NOISE_RANKED, "hash": ops.NOISE_HASH, "sym": ops.NOISE_HASH_SYM, "rsym": ops.NOISE_RANKED_SYM,
                   "none": ops.NOISE_NONE}[a.noise]
     run = SyntheticRun(a, dev, world, rank, force, N, d, h, noise_mode, a.x_grad, emu, a.exchange)
-    use_graph = a.hipgraph and (world == 1 and not force or os.environ.get("DGG_BENCH_GRAPH_DIST") == "1")
+    # one rank: the step is captured -- also with DGG_FORCE_COLLECTIVES=1, so that the multi-collective step of the N > 1 path has run under
+    # capture on the one GPU there is (DGG_BENCH_GRAPH_DIST=0 times it eagerly).  Several ranks: eager unless DGG_BENCH_GRAPH_DIST=1.
+    gd = os.environ.get("DGG_BENCH_GRAPH_DIST")
+    use_graph = a.hipgraph and ((world == 1 and gd != "0") if (world == 1 and force) else (world == 1 or gd == "1"))
     times, graphed, eager_T = time_windows(run, a, world, force, dev, use_graph, a.repeats)
     T = float(np.median(times)) / a.steps
     layer, P, r0, r1 = run.layer, run.P, run.r0, run.r1

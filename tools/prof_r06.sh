@@ -48,5 +48,8 @@ DGG_BENCH_DETAIL=gpurun_out/r06/r06_cora_uvdist_bench.json python3 bench.py --st
 DGG_BENCH_DETAIL=gpurun_out/r06/r06_ppi_bf16_bench.json python3 bench.py --steps 10 --warmup 3 --workload ppi --bf16 --graphs 20 > /dev/null 2>> "$O/bench.err"
 DGG_BENCH_DETAIL=gpurun_out/r06/r06_bench_n500k_1gpu.json python3 bench.py --nodes 500000 --no-variants --no-configs > /dev/null 2>> "$O/bench.err"
 DGG_BENCH_DETAIL=gpurun_out/r06/r06_emulated_rank_of_8_strong_500k.json python3 bench.py --emulate-world 8 --nodes 62500 --no-variants --no-configs --cpu-rows -1 > /dev/null 2>> "$O/bench.err"
+# the N > 1 step's collectives on the one GPU (one-rank RCCL group): captured (the default since round 6) and eager
+DGG_FORCE_COLLECTIVES=1 DGG_BENCH_DETAIL=gpurun_out/r06/r06_forced_collectives_captured.json python3 bench.py --nodes 62500 --no-variants --no-configs --cpu-rows -1 > /dev/null 2>> "$O/bench.err"
+DGG_FORCE_COLLECTIVES=1 DGG_BENCH_GRAPH_DIST=0 DGG_BENCH_DETAIL=gpurun_out/r06/r06_forced_collectives_eager.json python3 bench.py --nodes 62500 --no-variants --no-configs --cpu-rows -1 > /dev/null 2>> "$O/bench.err"
 ls -la "$O"; grep -v "^BENCH_DETAIL" "$O/bench.err" | tail -c 600
 cat "$O/r06_bench_line.json"
