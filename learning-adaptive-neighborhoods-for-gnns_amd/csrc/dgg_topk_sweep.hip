@@ -31,6 +31,7 @@
 #include "dgg_common.h"
 #include "dgg_api_internal.h"
 #include <stdlib.h>
+#include <math.h>
 #include <stdint.h>
 
 using namespace dgg;
@@ -719,14 +720,21 @@ __global__ __launch_bounds__(256) void sw_select(const int2 *__restrict__ listA,
     }
     int total = 0;
     bool over = false;
+    // A sweep lane records its LARGEST D of a 16-column block for each of its hits in that block (sw_sweep, block_best): of records that
+    // share (row, D) -- consecutive entries of one lane list -- only the first is known to have that D; the others take no part in the
+    // order statistic (D' = -inf; they stay candidates: their true D is not larger).  At N = 100 000 3 % of the hitting lanes hold two
+    // hits of a block; at N = 8192 the loose radius admits 4 % of the columns, most hits shared a block, the statistic saw them all at
+    // the best one's distance and the tight radius came out too small for 20 % of the rows.
     auto take = [&](bool mine, const int2 &c, float nbj) {            // compaction of the row's own records into LDS
+        const int py = __shfl_up(c.y, 1, 64), px = __shfl_up(c.x, 1, 64);
+        const bool dup = mine && lane > 0 && py == c.y && (((uint32_t)px ^ (uint32_t)c.x) >> 28) == 0u && (((uint32_t)px ^ (uint32_t)c.x) & COLMASK) < 32u;
         const unsigned long long mk = __ballot(mine);
         const int at = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
         if (mine && at < SELCAP) {
             const float d = __int_as_float(c.y);
             scol[wave][at] = (int32_t)((uint32_t)c.x & COLMASK);
             sd[wave][at] = d;
-            sdp[wave][at] = d - 0.5f * SL_UPPER * (nbi + nbj);
+            sdp[wave][at] = dup ? -3.0e38f : d - 0.5f * SL_UPPER * (nbi + nbj);
         }
         total += __builtin_popcountll(mk);
     };
@@ -871,6 +879,8 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
     const int Lr = klim ? __builtin_amdgcn_readfirstlane(klimit_len(klim[lrow], 64)) : 64;
     int total = 0, nB = 0;                                             // wave-uniform
     bool ok = true;
+    int why = 7;          // (diagnostics, DGG_SWEEP_STATS=1: ctl->pad[why]++ for a failed row -- 0 phase-A overflow, 1 phase-B overflow, 2 more than
+                          //  FCAP candidates, 3 fewer than Lr, 4 list not full, 5 score below the normal range, 6 last distance outside the radius)
     auto push = [&](bool keep, int32_t col) {
         const unsigned long long m = __ballot(keep);
         const int at = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -879,7 +889,7 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
     };
     {   // phase-A hits inside the tight radius (compacted by sw_select)
         int n = keptn[lrow];
-        if (n > KCAP) { ok = false; n = 0; }                            // overflow (of the kept list or of a phase-A lane list)
+        if (n > KCAP) { ok = false; n = 0; why = 0; }                   // overflow (of the kept list or of a phase-A lane list)
         for (int base = 0; base < n; base += 64) {
             const int e = base + lane;
             push(e < n, e < n ? kept[lrow * KCAP + e] : 0);
@@ -891,7 +901,7 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
         const int nl = 2 * CSB;
         auto list_id = [&](int s) { const int h2 = s >= CSB ? 1 : 0; return (rl.base + 32 * h2) * CSB + (s - h2 * CSB); };   // (no division)
         const int myc = lane < nl ? (int)cntB[list_id(lane)] : 0;
-        if (__ballot(myc > capB) != 0ull) ok = false;
+        if (__ballot(myc > capB) != 0ull) { if (ok) why = 1; ok = false; }
         for (int g0 = 0; ok && g0 < nl; g0 += LG) {
             int n[LG];
             uint32_t rec[LG];
@@ -916,7 +926,7 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
         }
     }
     nB = total - nkept;
-    if (total > FCAP || total < Lr) ok = false;
+    if (total > FCAP || total < Lr) { if (ok) why = total > FCAP ? 2 : 3; ok = false; }
     uint64_t list = DGG_EMPTY_KEY;
     if (ok) {
         // exact squared distances, FCAP / 64 candidates per lane
@@ -981,11 +991,12 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
         // (a score below the normal range -- t d < -87: features hundreds of units apart -- no longer identifies a distance: zero and
         //  denormal scores tie over whole shells and the oracle breaks ties by column, also among the columns the sweeps rejected; such
         //  a row is left to the fallback, which scores every column)
-        if (k63 == DGG_EMPTY_KEY || key_val(k63) < SCORE_MIN_NORMAL) ok = false;
+        if (k63 == DGG_EMPTY_KEY || key_val(k63) < SCORE_MIN_NORMAL) { ok = false; why = k63 == DGG_EMPTY_KEY ? 4 : 5; }
         else {
             const float d63 = c_log(fmaxf(key_val(k63), 1e-37f)) / t + 1e-5f;
             const float R = fmaf(2.0f, ttight[lrow], nb[i]);
             ok = d63 * d63 * (1.0f + 1e-5f) <= R * (1.0f - 1e-5f) - 1e-7f * nb[i];
+            if (!ok) why = 6;
         }
     }
     if (ok) {
@@ -995,7 +1006,7 @@ __global__ __launch_bounds__(256) void sw_finalize(const float *__restrict__ xp,
     } else if (lane == 0) {
         faillist[atomicAdd(&ctl->nfail, 1)] = (int)lrow;
     }
-    if (ctl->stats_on && lane == 0) atomicAdd(&ctl->nB, (unsigned long long)nB);
+    if (ctl->stats_on && lane == 0) { atomicAdd(&ctl->nB, (unsigned long long)nB); if (!ok) atomicAdd(&ctl->pad[why], 1); }
 }
 
 // ---- fallback: rows whose radius failed verification, every column scored exactly ------------------------------------------------
@@ -1151,7 +1162,13 @@ Plan make_plan(int64_t rows, int64_t N, int h) {
     p.csa = segs(p.nA);
     p.capa = p.rblk * CAPA_ROW / (2 * p.csa);                          // per lane list: the records of the lane's RBLK rows
     p.capb = p.rblk * CAPB_ROW / (2 * p.csb);
-    int pt = (int)((int64_t)p.ntiles * 2 * PILOT_M / LOOSE_TARGET);
+    // pilot sample: the radius is the PILOT_M-th largest of 4 pt block maxima per half row (a block = 16 columns), and it should admit
+    // the fraction q = LOOSE_TARGET / N of the columns: PILOT_M = 4 pt (1 - (1 - q)^16).  (Linearised -- pt = ntiles 2 PILOT_M /
+    // LOOSE_TARGET -- it under-samples small graphs: 2 tiles at N = 8192, where the PILOT_M-th of 8 maxima is their minimum and the
+    // radius admitted 21 % of the columns; 98 % of the rows overflowed their lists into the exhaustive fallback.)
+    const double q = (double)LOOSE_TARGET / (double)(N > LOOSE_TARGET ? N : LOOSE_TARGET + 1);
+    int pt = (int)ceil((double)PILOT_M / (4.0 * (1.0 - pow(1.0 - q, 16.0))));
+    pt = pt > p.ntiles ? p.ntiles : pt;
     p.pt = pt < 1 ? 1 : pt;
     return p;
 }

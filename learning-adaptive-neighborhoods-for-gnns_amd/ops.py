@@ -387,11 +387,13 @@ def fast_path_failed_rows(ws, N, h, rows=None, stats=False):
     their guessed radius and were redone by the exhaustive fallback (synchronises); stats=True also returns the candidate
     sums (phase-A hits, those inside the tight radius, phase-B hits; collected only under DGG_SWEEP_STATS=1)"""
     off = int(_lib.lib().dgg_allpairs_sweep_ctl_offset_bytes(N if rows is None else rows, N, h))
-    blk = ws[off:off + 32].cpu()
+    blk = ws[off:off + 64].cpu()
     nfail = int(blk[0:4].view(torch.int32).item())
     if not stats:
         return nfail
-    return nfail, [int(v) for v in blk[8:32].view(torch.int64)]
+    # + the failed rows by reason (phase-A overflow, phase-B overflow, > FCAP candidates, < L candidates, list not full, score below the
+    # normal range, last distance outside the radius)
+    return nfail, [int(v) for v in blk[8:32].view(torch.int64)] + [int(v) for v in blk[32:60].view(torch.int32)]
 
 
 def allpairs_topk_softk(xp, k, mode=MODE_K_TIMES_EDGE_PROB, t=T_DIST, seed=(0, 0), rows=None, lpub=None):

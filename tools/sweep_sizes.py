@@ -39,4 +39,4 @@ for N in [int(v) for v in a.sizes.split(",")]:
         tx.append(e0.elapsed_time(e1))
         assert torch.equal(xi, idx) and torch.equal(xv, val)
     nfail, st = ops.fast_path_failed_rows(ws, N, a.h, stats=True)
-    print(f"N {N:7d} h {a.h}: {np.median(ts[1:]):8.3f} ms (exhaustive {min(tx) if tx else float('nan'):8.3f})   fallback rows {nfail:6d} ({100.0 * nfail / N:5.1f} %)   A hits/row {st[0] / N:7.1f} kept {st[1] / N:6.1f} B hits/row {st[2] / N:7.1f}", flush=True)
+    print(f"N {N:7d} h {a.h}: {np.median(ts[1:]):8.3f} ms (exhaustive {min(tx) if tx else float('nan'):8.3f})   fallback rows {nfail:6d} ({100.0 * nfail / N:5.1f} %)   A hits/row {st[0] / N:7.1f} kept {st[1] / N:6.1f} B hits/row {st[2] / N:7.1f}  why {st[3:]}", flush=True)
