@@ -36,7 +36,14 @@ using namespace dgg;
 namespace {
 
 constexpr int KSLOT = 128;              // keys of threshold buffer per chunk of 64 ranks
-constexpr int PLAIN_FEW_MAX = 2048;     // unperturbed front end: failing rows up to which the one-wavefront-per-row fallback is used
+struct HashCtl { int nfail; int pad; unsigned long long capsum; };   // rows a front end handed on; sum of their buffer capacities (keys)
+constexpr int PLAIN_FEW_MAX = 2048;
+// segments per listed row of the segmented scan (aw_plain_rows_part): the most the scratch admits for the capacities listed
+constexpr int PSEG_MAX = 32;
+__device__ __forceinline__ int plain_segments(unsigned long long capsum, long long scratch_keys) {
+    const long long s = scratch_keys / (long long)(capsum > 0ull ? capsum : 1ull);
+    return s < 1 ? 0 : (s > PSEG_MAX ? PSEG_MAX : (int)s);      // 0: the listed rows do not fit at all (aw_scan_plain takes them)
+}     // unperturbed front end: failing rows up to which the one-wavefront-per-row fallback is used
 
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
 #pragma unroll
@@ -145,15 +152,17 @@ template <int H>
 __global__ __launch_bounds__(WAVES * 64) void aw_scan_plain(const float *__restrict__ xp, int64_t N, int64_t row0, int64_t row1, float t,
                                                             const float *__restrict__ klim, const int32_t *__restrict__ cptr,
                                                             uint64_t *__restrict__ keys, int32_t *__restrict__ cnt_out,
-                                                            const int32_t *__restrict__ rowlist, const int32_t *__restrict__ nlist, int few_max) {
+                                                            const int32_t *__restrict__ rowlist, const HashCtl *__restrict__ ctl, int few_max,
+                                                            long long scratch_keys) {
     // rowlist != NULL: the rows of this launch are rowlist[0 .. *nlist) (local row ids: the rows aw_plain_score could not settle), else
     // every row of [row0, row1)
     __shared__ float colT[H * TN];
     __shared__ float rowsL[RB * H];
     __shared__ int s_row[RB];                                    // local row id of every row slot of the workgroup, -1: none
     const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id();
-    const int64_t nsel = rowlist ? (int64_t)nlist[0] : row1 - row0;
-    if ((int64_t)blockIdx.x * RB >= nsel || (rowlist && nsel <= few_max)) return;     // (few listed rows: aw_plain_rows_all settled them)
+    const int64_t nsel = rowlist ? (int64_t)ctl->nfail : row1 - row0;
+    // (few listed rows whose segments fit the scratch: aw_plain_rows_part / _merge settled them)
+    if ((int64_t)blockIdx.x * RB >= nsel || (rowlist && nsel <= few_max && plain_segments(ctl->capsum, scratch_keys) > 0)) return;
     if (tid < RB) {
         const int64_t q = (int64_t)blockIdx.x * RB + tid;
         s_row[tid] = q < nsel ? (rowlist ? rowlist[q] : (int)q) : -1;
@@ -240,7 +249,8 @@ __global__ __launch_bounds__(256) void aw_plain_score(const float *__restrict__ 
                                                       const float *__restrict__ klim, const int32_t *__restrict__ cptr,
                                                       const uint32_t *__restrict__ cand, const int32_t *__restrict__ ncand, int nsub, int cslot,
                                                       const float *__restrict__ rad, uint64_t *__restrict__ keys, int32_t *__restrict__ cnt_out,
-                                                      int32_t *__restrict__ nfail, int32_t *__restrict__ faillist) {
+                                                      int32_t *__restrict__ nfail, int32_t *__restrict__ faillist,
+                                                      unsigned long long *__restrict__ capsum, unsigned long long *__restrict__ failoff) {
     const int lane = threadIdx.x & 63;
     const int64_t lrow = (int64_t)blockIdx.x * 4 + dgg::wave_id();
     const int64_t i = row0 + lrow;
@@ -319,69 +329,118 @@ __global__ __launch_bounds__(256) void aw_plain_score(const float *__restrict__ 
     }
     if (lane == 0) {
         cnt_out[lrow] = ok ? n : 0;
-        if (!ok) faillist[atomicAdd(nfail, 1)] = (int32_t)lrow;
+        if (!ok) {
+            // listed for the scans that score every pair; its slice of the segmented scan's scratch starts at (sum of the capacities listed
+            // so far) x (segments per row, fixed once every row is listed)
+            const int pos = atomicAdd(nfail, 1);
+            faillist[pos] = (int32_t)lrow;
+            const unsigned long long off = atomicAdd(capsum, (unsigned long long)g.cap);
+            if (pos < PLAIN_FEW_MAX) failoff[pos] = off;
+        }
     }
 }
 
-// the rows the front end could not settle when they are FEW (a handful per forward on benchmark data): one wavefront per row streams
-// ALL columns through the row's threshold buffer, lane = column, four batches of 64 gathered rows in flight.  (aw_scan_plain shares
-// column tiles among 16 rows per wavefront: right for every row of a graph, but a launch of it costs a workgroup's whole walk --
-// 23 ms at N = 100 000 -- however few rows it is given.)  nlist[0] > few_max: left to aw_scan_plain.
+// the rows the front end could not settle when they are FEW (54 of 100 000 at k ~ 130, ~900 at k ~ 32 on benchmark data): every column scored,
+// lane = column, through threshold buffers.  (aw_scan_plain shares column tiles among 16 rows per wavefront: right for every row of a graph,
+// but a launch of it costs a workgroup's whole walk -- 23 ms at N = 100 000 -- however few rows it is given.)  One wavefront per row took
+// 2.7 ms for its 1 563 dependent blocks of 64 columns, whatever the number of rows: the column range of a row is cut into S SEGMENTS, one
+// wavefront each, S = the most the scratch admits (<= PSEG_MAX) for the capacities listed (ctl->capsum); aw_plain_rows_part leaves a
+// segment's best <= cap keys in the scratch, aw_plain_rows_merge streams a row's segments through its own buffer.  nlist[0] > few_max:
+// left to aw_scan_plain.
+// one block of keys into a row's threshold buffer (the moving-threshold append of every scan of this file)
+__device__ __forceinline__ void buffer_append(uint64_t *__restrict__ buf, int &n, uint64_t &thr, uint64_t key, int L, int cap, int lane) {
+    bool pass = key != DGG_EMPTY_KEY && key > thr;
+    uint64_t m = __ballot(pass);
+    if (m == 0ull) return;
+    if (n + __builtin_popcountll(m) > cap) {
+        thr = wave_select_lth(buf, n, L, keep_window(L, cap), lane);
+        n = wave_compact_ge(buf, n, thr, lane);
+        pass = pass && key > thr;
+        m = __ballot(pass);
+    }
+    const int p = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (pass) buf[p] = key;
+    n += __builtin_popcountll(m);
+}
 template <int H>
-__global__ __launch_bounds__(256) void aw_plain_rows_all(const float *__restrict__ xp, int64_t N, int64_t row0, float t, const float *__restrict__ klim,
-                                                         const int32_t *__restrict__ cptr, uint64_t *__restrict__ keys, int32_t *__restrict__ cnt_out,
-                                                         const int32_t *__restrict__ rowlist, const int32_t *__restrict__ nlist, int few_max) {
+__global__ __launch_bounds__(256) void aw_plain_rows_part(const float *__restrict__ xp, int64_t N, int64_t row0, float t, const float *__restrict__ klim,
+                                                          const int32_t *__restrict__ cptr, const int32_t *__restrict__ rowlist,
+                                                          const HashCtl *__restrict__ ctl, int few_max, const unsigned long long *__restrict__ failoff,
+                                                          uint64_t *__restrict__ scratch, long long scratch_keys, int32_t *__restrict__ pcnt) {
     const int lane = threadIdx.x & 63;
-    const int nsel = nlist[0];
+    const int nsel = ctl->nfail;
     if (nsel > few_max) return;
-    const int q = blockIdx.x * 4 + dgg::wave_id();
-    if (q >= nsel) return;
-    const int lrow = __builtin_amdgcn_readfirstlane(rowlist[q]);
-    const int64_t i = row0 + lrow;
-    const RowGeom g = row_geom(cptr, klim, lrow);
-    if (g.cap == 0) { if (lane == 0) cnt_out[lrow] = 0; return; }
-    uint64_t *buf = keys + g.base;
-    const float *xi = xp + i * H;                                // wave-uniform: scalar loads
-    uint64_t thr = DGG_EMPTY_KEY;
-    int n = 0;
-    for (int64_t j0 = 0; j0 < N; j0 += 64) {
-        const int64_t j = j0 + lane;
-        uint64_t key = DGG_EMPTY_KEY;
-        if (j < N) {
-            const float4 *xj = reinterpret_cast<const float4 *>(xp + j * H);
-            float4 bq[H / 4];
+    const int S = plain_segments(ctl->capsum, scratch_keys);
+    if (S == 0) return;
+    const int64_t per = ((N + S - 1) / S + 63) / 64 * 64;        // columns per segment
+    const int nwork = nsel * S, stride = (int)gridDim.x * 4;
+    for (int wk = blockIdx.x * 4 + dgg::wave_id(); wk < nwork; wk += stride) {
+        const int q = wk / S, sg = wk - q * S;
+        const int lrow = __builtin_amdgcn_readfirstlane(rowlist[q]);
+        const int64_t i = row0 + lrow;
+        const RowGeom g = row_geom(cptr, klim, lrow);
+        uint64_t *buf = scratch + (failoff[q] * (unsigned long long)S + (unsigned long long)sg * (unsigned long long)g.cap);
+        const float *xi = xp + i * H;                            // wave-uniform: scalar loads
+        uint64_t thr = DGG_EMPTY_KEY;
+        int n = 0;
+        const int64_t jend = (sg + 1) * per < N ? (sg + 1) * per : N;
+        for (int64_t j0 = sg * per; j0 < jend; j0 += 64) {
+            const int64_t j = j0 + lane;
+            uint64_t key = DGG_EMPTY_KEY;
+            if (j < jend) {
+                const float4 *xj = reinterpret_cast<const float4 *>(xp + j * H);
+                float4 bq[H / 4];
 #pragma unroll
-            for (int c4 = 0; c4 < H / 4; c4++) bq[c4] = xj[c4];
-            float d2 = 0.0f;
+                for (int c4 = 0; c4 < H / 4; c4++) bq[c4] = xj[c4];
+                float d2 = 0.0f;
 #pragma unroll
-            for (int c4 = 0; c4 < H / 4; c4++) {
-                float df;
-                df = __fadd_rn(xi[4 * c4 + 0], -bq[c4].x); d2 = __fmaf_rn(df, df, d2);
-                df = __fadd_rn(xi[4 * c4 + 1], -bq[c4].y); d2 = __fmaf_rn(df, df, d2);
-                df = __fadd_rn(xi[4 * c4 + 2], -bq[c4].z); d2 = __fmaf_rn(df, df, d2);
-                df = __fadd_rn(xi[4 * c4 + 3], -bq[c4].w); d2 = __fmaf_rn(df, df, d2);
+                for (int c4 = 0; c4 < H / 4; c4++) {
+                    float df;
+                    df = __fadd_rn(xi[4 * c4 + 0], -bq[c4].x); d2 = __fmaf_rn(df, df, d2);
+                    df = __fadd_rn(xi[4 * c4 + 1], -bq[c4].y); d2 = __fmaf_rn(df, df, d2);
+                    df = __fadd_rn(xi[4 * c4 + 2], -bq[c4].z); d2 = __fmaf_rn(df, df, d2);
+                    df = __fadd_rn(xi[4 * c4 + 3], -bq[c4].w); d2 = __fmaf_rn(df, df, d2);
+                }
+                key = make_key(score_from_dist(c_sqrt(d2), t, false, 0.0f), (int32_t)j);
             }
-            key = make_key(score_from_dist(c_sqrt(d2), t, false, 0.0f), (int32_t)j);
+            buffer_append(buf, n, thr, key, g.L, g.cap, lane);
         }
-        bool pass = key != DGG_EMPTY_KEY && key > thr;
-        uint64_t m = __ballot(pass);
-        if (m != 0ull) {
-            if (n + __builtin_popcountll(m) > g.cap) {
-                thr = wave_select_lth(buf, n, g.L, keep_window(g.L, g.cap), lane);
-                n = wave_compact_ge(buf, n, thr, lane);
-                pass = pass && key > thr;
-                m = __ballot(pass);
+        if (n > g.L) {
+            const uint64_t tau = wave_select_lth(buf, n, g.L, g.L, lane);
+            n = wave_compact_ge(buf, n, tau, lane);
+        }
+        if (lane == 0) pcnt[q * PSEG_MAX + sg] = n;
+    }
+}
+__global__ __launch_bounds__(256) void aw_plain_rows_merge(const float *__restrict__ klim, const int32_t *__restrict__ cptr, uint64_t *__restrict__ keys,
+                                                           int32_t *__restrict__ cnt_out, const int32_t *__restrict__ rowlist,
+                                                           const HashCtl *__restrict__ ctl, int few_max, const unsigned long long *__restrict__ failoff,
+                                                           const uint64_t *__restrict__ scratch, long long scratch_keys, const int32_t *__restrict__ pcnt) {
+    const int lane = threadIdx.x & 63;
+    const int nsel = ctl->nfail;
+    if (nsel > few_max) return;
+    const int S = plain_segments(ctl->capsum, scratch_keys);
+    if (S == 0) return;
+    for (int q = blockIdx.x * 4 + dgg::wave_id(); q < nsel; q += (int)gridDim.x * 4) {
+        const int lrow = __builtin_amdgcn_readfirstlane(rowlist[q]);
+        const RowGeom g = row_geom(cptr, klim, lrow);
+        uint64_t *buf = keys + g.base;
+        uint64_t thr = DGG_EMPTY_KEY;
+        int n = 0;
+        for (int sg = 0; sg < S; sg++) {
+            const int ns = pcnt[q * PSEG_MAX + sg];
+            const uint64_t *src = scratch + (failoff[q] * (unsigned long long)S + (unsigned long long)sg * (unsigned long long)g.cap);
+            for (int base = 0; base < ns; base += 64) {
+                const int e = base + lane;
+                buffer_append(buf, n, thr, e < ns ? src[e] : DGG_EMPTY_KEY, g.L, g.cap, lane);
             }
-            const int p = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (pass) buf[p] = key;
-            n += __builtin_popcountll(m);
         }
+        if (n > g.L) {
+            const uint64_t tau = wave_select_lth(buf, n, g.L, g.L, lane);
+            n = wave_compact_ge(buf, n, tau, lane);
+        }
+        if (lane == 0) cnt_out[lrow] = n;
     }
-    if (n > g.L) {
-        const uint64_t tau = wave_select_lth(buf, n, g.L, g.L, lane);
-        n = wave_compact_ge(buf, n, tau, lane);
-    }
-    if (lane == 0) cnt_out[lrow] = n;
 }
 
 // ---- per-pair hash noise: integer filter on every pair, exact scores for the survivors -----------------------------------------------
@@ -584,7 +643,6 @@ __global__ __launch_bounds__(WAVES * 64) void aw_scan_hash(const float *__restri
 // without it the filter over-admits 4.5 x at the benchmark's features and every list overflows (measured: 31 ms against 24).
 constexpr int CSLOT = 512;              // candidate slots (32-bit columns) per chunk
 constexpr int HSEG = 4;                 // column segments swept by separate wavefronts (a row's candidate slots are split among them)
-struct HashCtl { int nfail; int pad[3]; };
 
 template <int H>
 __global__ __launch_bounds__(256) void aw_pilot_rows(const float *__restrict__ xp, int64_t N, int64_t row0, int64_t row1, float t, uint32_t s0,
@@ -994,7 +1052,7 @@ __global__ __launch_bounds__(ET) void aw_emit(const uint64_t *__restrict__ keys,
     }
 }
 
-struct HashWs { uint32_t *cand; int32_t *ncand; uint32_t *uthr; float *gmin; int32_t *fail; HashCtl *ctl; void *plain_ws; };
+struct HashWs { uint32_t *cand; int32_t *ncand; uint32_t *uthr; float *gmin; int32_t *fail; HashCtl *ctl; unsigned long long *failoff; int32_t *pcnt; uint64_t *scratch; long long scratch_keys; void *plain_ws; };
 template <int H>
 int launch_anywide(const float *xp, int64_t N, int64_t row0, int64_t row1, float t, int noise_mode, uint32_t s0, uint32_t s1, const uint32_t *seed_dev,
                    const float *k, int mode, int maxm, int min_m, const int32_t *cptr, int64_t ccap, int32_t *idx, float *val, float *w, float *rs,
@@ -1004,18 +1062,25 @@ int launch_anywide(const float *xp, int64_t N, int64_t row0, int64_t row1, float
     if (noise_mode == 0) {
         const char *ef = getenv("DGG_ANYWIDE_PLAIN_FRONT"), *ew = getenv("DGG_ANYWIDE_PLAIN_FEW");      // (read per call: tests switch between calls)
         const int few_max = ew ? (atoi(ew) < PLAIN_FEW_MAX ? atoi(ew) : PLAIN_FEW_MAX) : PLAIN_FEW_MAX;
-        const int32_t *rowlist = nullptr, *nlist = nullptr;
+        const int32_t *rowlist = nullptr;
         if ((!ef || atoi(ef) != 0) && hx.plain_ws && N >= 1024) {   // radius sweep on the matrix cores; the rows it cannot settle: every pair scored
             if (dgg_check_hip(hipMemsetAsync(hx.ctl, 0, sizeof(HashCtl), st), "anywide memset") != 0) return DGG_ERR_HIP;
             int rc0 = dgg_plain_wide_front_impl(xp, N, H, row0, row1, k, cptr, CSLOT, hx.cand, hx.ncand, hx.gmin, hx.plain_ws, st);
             if (rc0) return rc0;
             hipLaunchKernelGGL(aw_plain_score<H>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xp, N, row0, row1, t, k, cptr, hx.cand, hx.ncand,
-                               dgg_plain_wide_sublists(), CSLOT, hx.gmin, keys, cnt, &hx.ctl->nfail, hx.fail);
+                               dgg_plain_wide_sublists(), CSLOT, hx.gmin, keys, cnt, &hx.ctl->nfail, hx.fail, &hx.ctl->capsum, hx.failoff);
             rowlist = hx.fail;
-            nlist = &hx.ctl->nfail;
-            hipLaunchKernelGGL(aw_plain_rows_all<H>, dim3(PLAIN_FEW_MAX / 4), dim3(256), 0, st, xp, N, row0, t, k, cptr, keys, cnt, rowlist, nlist, few_max);
+            hipLaunchKernelGGL(aw_plain_rows_part<H>, dim3(2048), dim3(256), 0, st, xp, N, row0, t, k, cptr, rowlist, hx.ctl, few_max, hx.failoff, hx.scratch,
+                               hx.scratch_keys, hx.pcnt);
+            hipLaunchKernelGGL(aw_plain_rows_merge, dim3(PLAIN_FEW_MAX / 4), dim3(256), 0, st, k, cptr, keys, cnt, rowlist, hx.ctl, few_max, hx.failoff,
+                               hx.scratch, hx.scratch_keys, hx.pcnt);
         }
-        hipLaunchKernelGGL(aw_scan_plain<H>, gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, k, cptr, keys, cnt, rowlist, nlist, few_max);
+        hipLaunchKernelGGL(aw_scan_plain<H>, gscan, dim3(WAVES * 64), 0, st, xp, N, row0, row1, t, k, cptr, keys, cnt, rowlist, hx.ctl, few_max, hx.scratch_keys);
+        if (rowlist && getenv("DGG_ANYWIDE_DEBUG")) {            // diagnostics only (synchronises): rows the radius front end handed on
+            int nf = -1;
+            if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(&nf, &hx.ctl->nfail, 4, hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "dgg anywide (unperturbed): %d of %lld rows not settled by the radius sweep\n", nf, (long long)rows);
+        }
     }
     else if (noise_mode == 2 || noise_mode == 3) {
         // (read per call: tests switch the front end off / shrink its target between calls)
@@ -1060,11 +1125,15 @@ static inline size_t aw_al(size_t b) { return (b + 255) & ~(size_t)255; }
 constexpr int NSUBMAX = 8;              // candidate sub-lists per row at most (hash front end: 4 column segments; unperturbed: 2 halves x 4)
 // bytes of workspace dgg_allpairs_topk_anywide needs for arrays of `ccap` chunks, `rows` rows of a graph of N nodes, latent width h:
 // keys (128 x 8 B per chunk) | counts | candidate columns of the front ends (512 x 4 B per chunk) | per row: candidate counts per
-// sub-list, integer thresholds, guessed log-scores / radii, fail list | control block | the unperturbed front end's fp16 copy of xp
+// sub-list, integer thresholds, guessed log-scores / radii, fail list | control block | segmented-scan tables + scratch | the unperturbed
+// front end's fp16 copy of xp
+// scratch of the unperturbed front end's segmented scan (keys): 64 per node, between 2^16 and 2^22 (32 MB)
+static long long aw_scratch_keys(int64_t N) { const long long v = 64ll * (long long)N; return v < (1ll << 16) ? (1ll << 16) : (v > (1ll << 22) ? (1ll << 22) : v); }
 size_t dgg_allpairs_anywide_ws_bytes(int64_t ccap, int64_t rows, int64_t N, int h) {
     if (ccap < 0 || rows < 0 || N < 0) return 0;
     return aw_al((size_t)ccap * KSLOT * sizeof(uint64_t)) + aw_al((size_t)rows * 4) + aw_al((size_t)ccap * CSLOT * sizeof(uint32_t)) +
-           aw_al((size_t)rows * NSUBMAX * 4) + 3 * aw_al((size_t)rows * 4) + 256 + aw_al(dgg_plain_wide_front_ws_bytes(rows, N, h));
+           aw_al((size_t)rows * NSUBMAX * 4) + 3 * aw_al((size_t)rows * 4) + 256 + aw_al((size_t)PLAIN_FEW_MAX * 8) +
+           aw_al((size_t)PLAIN_FEW_MAX * PSEG_MAX * 4) + aw_al((size_t)aw_scratch_keys(N) * 8) + aw_al(dgg_plain_wide_front_ws_bytes(rows, N, h));
 }
 
 // All-pairs top-L_i on CHUNKED rows of any width (include/dgg_hip.h).  noise_mode 0 (unperturbed), 2 (per-pair hash), 3 (symmetric per-pair
@@ -1096,6 +1165,10 @@ int dgg_allpairs_topk_anywide(const float *xp, int64_t N, int h, int64_t row0, i
     hx.gmin = reinterpret_cast<float *>(wsp); wsp += aw_al((size_t)(row1 - row0) * 4);
     hx.fail = reinterpret_cast<int32_t *>(wsp); wsp += aw_al((size_t)(row1 - row0) * 4);
     hx.ctl = reinterpret_cast<HashCtl *>(wsp); wsp += 256;
+    hx.failoff = reinterpret_cast<unsigned long long *>(wsp); wsp += aw_al((size_t)PLAIN_FEW_MAX * 8);
+    hx.pcnt = reinterpret_cast<int32_t *>(wsp); wsp += aw_al((size_t)PLAIN_FEW_MAX * PSEG_MAX * 4);
+    hx.scratch_keys = aw_scratch_keys(N);
+    hx.scratch = reinterpret_cast<uint64_t *>(wsp); wsp += aw_al((size_t)hx.scratch_keys * 8);
     hx.plain_ws = wsp;
     hipStream_t st = (hipStream_t)stream;
     switch (h) {
