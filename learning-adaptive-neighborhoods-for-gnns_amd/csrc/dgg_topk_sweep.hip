@@ -509,7 +509,7 @@ constexpr int PW_PTMAX = 64;            // sampled tiles of pw_pilot at most
 template <int H>
 __global__ __launch_bounds__(256) void pw_pilot(const uint16_t *__restrict__ xw, const float *__restrict__ nb, int64_t N, int64_t row0, int64_t row1,
                                                 int ntiles, const float *__restrict__ klim, const int32_t *__restrict__ cptr,
-                                                float *__restrict__ ethr, float *__restrict__ rad) {
+                                                float *__restrict__ ethr, float *__restrict__ rad, float tfac, float tadd) {
     using TL = Tile<H>;
     constexpr int HW = TL::HW, KS1 = TL::KS1, STRIDE = TL::STRIDE, CPC = TL::CPC, LQ = TL::LQ;
     __shared__ __attribute__((aligned(16))) unsigned char colA[TL::BYTES];
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void pw_pilot(const uint16_t *__restrict__ xw,
     for (int s = 0; s < KS1 - 1; s++) bfr[s] = *reinterpret_cast<const bf16x8 *>(xw + ic * HW + 16 * s + 8 * hh);
     bfr[KS1 - 1] = aug_row(0.0f, hh);
     const int M = cptr[lr + 1] - cptr[lr];
-    const float target = 2.5f * (float)klimit_len(klim[lr], 64 * (M > 0 ? M : 1)) + 64.0f;
+    const float target = tfac * (float)klimit_len(klim[lr], 64 * (M > 0 ? M : 1)) + tadd;
     const int pt_all = ntiles < PW_PTMAX ? ntiles : PW_PTMAX;
     int P = (int)ceilf(8.0f * (float)N / (64.0f * target));
     P = P < 1 ? 1 : (P > pt_all ? pt_all : P);
@@ -1339,7 +1339,8 @@ int launch_plain_front(const float *xp, int64_t N, int64_t row0, int64_t row1, c
     const int64_t npad = (int64_t)ntiles * TC;
     const int rw = 128 * RBLK, nrb = (int)((rows + rw - 1) / rw), rbx = (nrb + 7) / 8;
     hipLaunchKernelGGL(sw_prep<H>, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, st, xp, N, npad, xw, nb);
-    hipLaunchKernelGGL(pw_pilot<H>, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, st, xw, nb, N, row0, row1, ntiles, klim, cptr, ethr, rad);
+    hipLaunchKernelGGL(pw_pilot<H>, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, st, xw, nb, N, row0, row1, ntiles, klim, cptr, ethr, rad,
+                       env_float("DGG_PLAIN_TARGET_FACTOR", 2.5f), env_float("DGG_PLAIN_TARGET_ADD", 64.0f));
     hipLaunchKernelGGL((pw_sweep<H, RBLK>), dim3((unsigned)(8 * rbx * PW_CS)), dim3(256), 0, st, xw, npad, row0, row1, ntiles, nrb, rbx, ethr, cptr, cslot,
                        cand, ncand);
     return dgg_check_launch("allpairs_topk_anywide: unperturbed front end");
