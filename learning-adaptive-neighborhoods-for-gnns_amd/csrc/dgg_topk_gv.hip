@@ -29,7 +29,10 @@ constexpr int CAPS = 160;          // candidate slots per (row, segment)
 constexpr int CAPF = NSEG * CAPS;  // candidate slots per row in the fixed-threshold sweep
 constexpr float TARGET_MAX = 128.0f;   // expected number of pairs per row above the guessed threshold (need 64) ...
 constexpr float TARGET_MIN = 80.0f;    // ... lowered when distances matter (small M) so the candidate lists still fit
-constexpr float ADMIT_MAX = 0.8f * CAPF;
+constexpr float ADMIT_MAX = 0.56f * CAPF;  // pairs the noise filter may admit per row on average (358): a segment's 160 slots see 90 (7 sigma of
+                                           // headroom) and the transposed list of the triangular sweep -- 448 slots, up to ALL of a late row's
+                                           // candidates -- 358 (4.7 sigma).  (0.8 until round 6: 2.8 sigma per segment, 39 rows of 100 000
+                                           // overflowed on N(0, 0.7) features, and the last rows' transposed lists could not hold their share.)
 constexpr int PILOT_PAIRS = 262144;
 constexpr float DTIGHT = 0.1124f;      // 0.3 ln(128 / 88): gv_finalize's first stage aims at an expected 88 pairs above its threshold
 
@@ -273,6 +276,14 @@ __global__ __launch_bounds__(64) void gv_sweep_tri(int64_t N, uint32_t s0, uint3
         const uint32_t ta = rvalid ? hash_threshold_from_gmin(gmin0) : 0xffffffffu;
         uint32_t k1, k2;
         rowkey(s0, s1, iu, k1, k2);
+        // a hit that no longer fits the row's own list (the row itself fails verification and is redone alone) still reaches its PARTNER's
+        // transposed list, on the spot: the partner's candidates stay complete.  (Until round 6 an overflow was only published and
+        // gv_finalize failed EVERY row on seeing it: 24 overflowing lists among 400 000 -- the guess admits up to 0.8 of the slots on
+        // average -- sent all 100 000 rows through the exhaustive fallback: 132 ms for a 2.3 ms stage, on N(0, 0.7) features.)
+        auto spill = [&](uint32_t j) {
+            const int slot = atomicAdd(&cntT[j], 1);
+            if (slot < CAPT) pendT[(int64_t)j * CAPT + slot] = (int)iu;
+        };
         // the <= 64 columns that straddle the wavefront's own rows: row i takes column j only if j > i (j == i: the diagonal)
         int64_t j0 = c_lo;
         const int64_t diag_hi = (i0 + 64 < c_hi) ? i0 + 64 : c_hi;
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(64) void gv_sweep_tri(int64_t N, uint32_t s0, uint3
             const uint32_t j = (uint32_t)j0;
             const uint32_t x = pair_u24_keyed(k1, k2, j) << 8;
             if (rvalid && (j == iu || (j > iu && x >= ta))) {    // zero-noise diagonal: always a candidate of its own row
-                if (cnt < CAPS) pend[cnt] = (int)j;
+                if (cnt < CAPS) pend[cnt] = (int)j; else if (j != iu) spill(j);
                 cnt++;
             }
         }
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(64) void gv_sweep_tri(int64_t N, uint32_t s0, uint3
 #pragma unroll
             for (int u = 0; u < UB; u++) {
                 if (x[u] >= ta) {
-                    if (cnt < CAPS && rvalid) pend[cnt] = (int)(j0 + u);
+                    if (rvalid) { if (cnt < CAPS) pend[cnt] = (int)(j0 + u); else spill((uint32_t)(j0 + u)); }
                     cnt++;
                 }
             }
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(64) void gv_sweep_tri(int64_t N, uint32_t s0, uint3
         for (; j0 < c_hi; j0++) {
             const uint32_t j = (uint32_t)j0;
             if ((pair_u24_keyed(k1, k2, j) << 8) >= ta) {
-                if (cnt < CAPS && rvalid) pend[cnt] = (int)j;
+                if (rvalid) { if (cnt < CAPS) pend[cnt] = (int)j; else spill(j); }
                 cnt++;
             }
         }
@@ -324,10 +335,6 @@ __global__ __launch_bounds__(64) void gv_sweep_tri(int64_t N, uint32_t s0, uint3
                 }
             }
         }
-        // hits that did not fit this row's own list are missing from their partners' transposed lists: mark those partners
-        // unverifiable.  They are unknown here (not stored), so the overflow is published and gv_finalize fails EVERY row when it
-        // sees it (the rectangular sweep would fail only this row; an own list overflows only when the pilot's guess is far off).
-        if (rvalid && cnt > CAPS) atomicAdd(&ctl->pad, 1);
     }
     if (rvalid) cnt_g[i * NSEG + seg] = cnt;
 }
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(256) void gv_finalize(const float *__restrict__ xp,
         off[s + 1] = off[s] + (ns[s] <= CAPS ? ns[s] : CAPS);
     }
     const int nT = cntT ? cntT[i] : 0;
-    ok = ok && nT <= CAPT && !(cntT && ctl->pad != 0);           // (pad: an own list overflowed in the triangular sweep)
+    ok = ok && nT <= CAPT;
     const int n = off[NSEG] + (nT <= CAPT ? nT : CAPT);
     const int *pl = pend_g + lrow * CAPF;
     uint64_t list = DGG_EMPTY_KEY;

@@ -724,6 +724,28 @@ def test_full_size_unperturbed_sweep(dev, clustered):
     assert torch.equal(sub_i, ki[22_900:23_412]) and torch.equal(sub_v, kv[22_900:23_412])
 
 
+def test_symmetric_hash_sweep_list_overflow_fails_one_row_not_all(dev):
+    """Found by tools/gv_sizes.py: on N(0, 0.7) latents (mean distance 7.9, where the bench's projected features sit at 3.7) the guessed
+    threshold admits ~470 pairs per row, a few of the 4 N (row, segment) lists of the TRIANGULAR sweep (symmetric noise, whole graph)
+    overflow their 160 slots -- and until round 6 one overflow anywhere failed EVERY row: all 20 000 rows (all 100 000 at the bench's
+    size: 132 ms for a 2.3 ms stage) went through the exhaustive fallback.  Now the overflowing row alone is redone (its hits beyond
+    the list still reach their partners' transposed lists) and the filter admits at most 0.56 of the slots: a handful of fallback
+    rows, sampled rows bit-exact against the oracle, symmetric selection scores."""
+    from dgg_amd import ops
+    N, h = 20_000, 64
+    g = torch.Generator().manual_seed(20)
+    xp = (torch.randn(N, h, generator=g) * 0.7).to(dev)
+    for nm, om in ((ops.NOISE_HASH_SYM, O.NOISE_HASH_SYM), (ops.NOISE_HASH, O.NOISE_HASH)):
+        idx, val, ws = ops.allpairs_topk(xp, K, noise_mode=nm, seed=(3, 1), return_ws=True)
+        nfail = int(ws[4:8].view(torch.int32).item())
+        print(f"noise_mode {nm}: {nfail} of {N} rows redone by the fallback")
+        assert nfail <= N // 200, nfail
+        xp_c = Nn(xp)
+        for r in (0, 1, 63, 64, 9_999, N - 65, N - 2, N - 1):
+            ri, rv = O.allpairs_topk(xp_c, K=K, noise_mode=om, seed=(3, 1), rows=(r, r + 1))
+            assert np.array_equal(Nn(idx[r]), ri[0]) and np.array_equal(Nn(val[r]), rv[0]), (nm, r)
+
+
 @pytest.mark.parametrize("scale", [40.0, 300.0, 600.0])
 def test_unperturbed_scores_below_the_normal_range_keep_the_oracles_column_order(dev, scale):
     """Found by tools/fuzz_anywide.py: with features hundreds of units apart, exp(-0.05 d) leaves the normal float range (d > 1746:
