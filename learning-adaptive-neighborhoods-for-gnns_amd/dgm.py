@@ -527,6 +527,7 @@ class DGG_LearnableK_debug(nn.Module):
                                "the module switch by itself) is cheaper on such data"))
                 if auto and many:
                     self._sym_generator = "hash"
+                    self._sym_spread = True             # (rows far from everything else: the hash noise's per-row front end, _fused_configure)
         fl = self.__dict__.get("_fused_layer")
         if fl is not None and fl.wide_sticky is not None and not _capturing():
             # (a device word the layout kernel ORs into on every forward -- every replay of a captured step -- under a fixed capacity)
@@ -703,6 +704,9 @@ class DGG_LearnableK_debug(nn.Module):
         mode = ops.MODE_K_TIMES_EDGE_PROB if self.k_select_mode == "k_times_edge_prob" else ops.MODE_K_ONLY
         layer.cand, layer.noise_mode, layer.seed, layer.mode, layer.scorer = cand, noise_mode, seed, mode, None
         layer.sym_fallback, layer.sym_hash = getattr(a, "dgg_sym_generator", "auto") != "ranked", False
+        # the module fell back from the ranked symmetric generator on THIS data (spread latents): the hash noise's forwards take the
+        # chunked rows' per-row front end, whatever the learned degrees (parallel.py, force_chunked)
+        layer.force_chunked = bool(self.__dict__.get("_sym_spread")) and noise_mode == ops.NOISE_HASH_SYM and cand is None
         layer.tight_bound = getattr(a, "dgg_tight_bound", "auto")     # ranked search: nearest-neighbour bound in its stop tests when the walk is deep
         layer.x_grad = bool(x.requires_grad)
         # all-pairs rows wider than the 64-rank list (learned degrees k_i + 9.5 > 64): chunked rows inside the engine, from the forward
@@ -788,6 +792,7 @@ class DGG_LearnableK_debug(nn.Module):
                           "symmetric per-pair hash generator instead (same law) and this module stays with it "
                           "(args.dgg_sym_generator = 'ranked' keeps the ranked generator and raises instead)")
             self._sym_generator = "hash"
+        self._sym_spread = True
 
     def _note_rsym(self, st, N):
         """status words of the ranked symmetric generator (noise_mode 5) of one forward, ORed / maxed into the module's (read by

@@ -151,6 +151,12 @@ class ShardedDGGConv:
         # generator it names), on for the nn.Module mirror
         self.sym_fallback = False
         self.sym_hash = False
+        # force_chunked: rows that fit the 64-rank list go through the chunked rows' evaluator as well (one chunk per row).  Set by the module
+        # once the ranked symmetric generator has failed on its data -- latents spread over several noise scales -- because the 64-rank
+        # entry of the per-pair hash noise guesses ONE threshold for the graph from the noise law alone and loses every row to its
+        # exhaustive fallback on such data (145-170 ms at N = 100 000, features x4), while the chunked rows' front end filters on
+        # G + lpub_i with a threshold per row (6-9 ms on the same data; 2-3x the 64-rank entry where that one works)
+        self.force_chunked = False
         self.tight_bound = "off"                             # ranked search: row-minimum distance bound in its stop tests (_row_bound)
         self._tight_on, self._tight_n, self.tight_probe = False, 0, None
 
@@ -199,7 +205,7 @@ class ShardedDGGConv:
             "ShardedDGGConv: chunked rows inside a hipGraph capture need a fixed capacity (wide_cap = (chunks, lists))"
         lay = kern.chunk_layout(k, ncols=self.N)
         self.last_layout = (lay.chunks, lay.maxm)
-        if not lay.wide and self.wide_rows == "auto":
+        if not lay.wide and self.wide_rows == "auto" and not self.force_chunked:
             return None
         return lay
 

@@ -287,6 +287,42 @@ def test_chunked_step_other_generators_match_the_oracle(dev, noise):
     _full_size_gradient_parity(dense, grads, x, deg, P, perturb=noise != "none")
 
 
+def test_forced_chunked_evaluation_of_narrow_rows_equals_the_list(dev):
+    """ShardedDGGConv.force_chunked (set by the module once the ranked symmetric generator has failed on its data: spread latents, where the
+    64-rank entry of the per-pair hash noise loses every row to its exhaustive fallback): rows that all fit the 64-rank list evaluated by
+    the chunked rows' per-row front end (one chunk per row) -- the same lists, scores, weights, row sums, output and gradients as the
+    64-rank entry, under symmetric hash noise, on benchmark-like and on spread (x4) features"""
+    import bench
+    from dgg_amd import ops
+    from dgg_amd.parallel import ShardedDGGConv
+    N, d, h = 3000, 48, 32
+    P = bench.make_params(d, h, dev)
+    g = torch.Generator().manual_seed(2)
+    deg = (2 + 30 * torch.rand(N, generator=g)).to(dev)
+    for scale in (1.0, 4.0):
+        x = (torch.randn(N, d, generator=g) * scale).to(dev)
+        res = []
+        for force in (False, True):
+            layer = ShardedDGGConv(ops, N, K=64, noise_mode=ops.NOISE_HASH_SYM, seed=(99, 7))
+            layer.wide_rows = "auto"
+            layer.force_chunked = force
+            Z = layer.forward(x, deg, P)
+            grads = layer.backward(torch.ones_like(Z), x, P)
+            s = layer.saved
+            assert (s["layout"] is not None) == force and float(s["k"].max()) + 9.5 <= 64
+            if force:
+                assert s["layout"].maxm == 1 and s["layout"].chunks == N
+            res.append((Z, grads, s["idx"][:N], s["val"][:N], s["w"][:N], s["rs"]))
+        (Za, ga, *la), (Zb, gb, *lb) = res
+        for u, v in zip(la, lb):
+            assert torch.equal(u, v)
+        assert torch.equal(Za, Zb)
+        assert set(ga) == set(gb)
+        for kk in ga:
+            if ga[kk] is not None:
+                assert float((ga[kk] - gb[kk]).abs().max()) <= 2e-6 * float(ga[kk].abs().max()) + 1e-30, kk
+
+
 def test_chunked_step_matches_the_oracle(dev):
     """generator -> normalize_adj -> relu(A (x Wc)), forward and backward, with rows of 1-4 chunks through ShardedDGGConv (the engine of
     the fused layer and of bench.py): lists / scores / weights / row sums / normalised weights bit-exact against the oracle on the
