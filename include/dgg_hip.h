@@ -215,7 +215,9 @@ int dgg_allpairs_topk_ranked_wide(const float *xp, int64_t N, int h, int64_t row
  * every row of [row0,row1), min_m = 0, spare chunks of a fixed capacity written empty.  noise_mode 4 (ranked generator): only the rows of
  * MORE than min_m chunks (call dgg_allpairs_topk_ranked_wide for the others: with maxm > 32 it leaves the rows beyond 32 chunks to this
  * entry, min_m = 32).  Every row owns a threshold buffer of 128 keys per chunk in `workspace` (dgg_allpairs_anywide_ws_bytes(ccap, rows, N, h)
- * bytes, which also hold the front ends' candidate lists); a candidate is dropped only once L_i better ones of its row are known.  maxm >= max M_i (sizes the sort's LDS). */
+ * bytes, which also hold the front ends' candidate lists and, for unperturbed scores, the scratch -- 64 keys per node, at most 32 MB -- of the
+ * segmented re-scan of the rows the radius sweep cannot settle); a candidate is dropped only once L_i better ones of its row are known.
+ * maxm >= max M_i (sizes the sort's LDS). */
 size_t dgg_allpairs_anywide_ws_bytes(int64_t ccap, int64_t rows, int64_t N, int h);
 int dgg_allpairs_topk_anywide(const float *xp, int64_t N, int h, int64_t row0, int64_t row1, float t, int noise_mode, uint32_t s0, uint32_t s1,
                               const uint32_t *seed_dev, const float *k, int mode, int maxm, int min_m, const int32_t *cptr, int64_t ccap,
