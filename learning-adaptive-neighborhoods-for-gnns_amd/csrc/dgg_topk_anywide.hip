@@ -705,19 +705,51 @@ __global__ __launch_bounds__(64) void aw_hash_sweep(int64_t N, int64_t row0, int
     const int64_t per = (N + HSEG - 1) / HSEG;
     const int64_t j0 = (int64_t)seg * per, j1 = j0 + per < N ? j0 + per : N;
     const bool skip = uthr == 0xffffffffu;                       // (the row goes to the moving-threshold scan: not even its diagonal is listed)
+    // symmetric noise: a pair below the diagonal is keyed by its COLUMN (the key words of 64 columns at once, one per lane: two mix32 per
+    // column on the scalar unit -- one unit for four SIMDs -- made this sweep 2.6x slower than the asymmetric one).  Which side of the
+    // diagonal a column lies on is the same for all 64 rows of the wavefront except in the <= 2 blocks that straddle them: blocks wholly
+    // ABOVE the diagonal run the asymmetric loop (row keys, no column keys at all), blocks wholly BELOW it the same loop with the column's
+    // key words as scalars and the row as the counter -- the per-lane choice (three selects per pair) only in the straddling blocks
+    // (6.4 -> see DESIGN: the symmetric sweep was 1.8x the asymmetric one).
+    const uint32_t imin = (uint32_t)(row0 + (int64_t)(blockIdx.x / HSEG) * 64);
+    const int64_t imax_l = (int64_t)imin + 63 < row1 - 1 ? (int64_t)imin + 63 : row1 - 1;
+    const uint32_t imax = (uint32_t)imax_l;
     for (int64_t jb = j0; jb < j1; jb += 64) {
-        // symmetric noise: a pair below the diagonal is keyed by its COLUMN.  The key words of 64 columns at once, one per lane (two
-        // mix32 per column on the scalar unit -- one unit for four SIMDs -- made this sweep 2.6x slower than the asymmetric one)
-        uint32_t ck1 = 0u, ck2 = 0u;
-        if (SYM) rowkey(s0, s1, (uint32_t)jb + (uint32_t)lane, ck1, ck2);
         const int nc = j1 - jb < 64 ? (int)(j1 - jb) : 64;
-        for (int c = 0; c < nc; c++) {
-            const uint32_t j = (uint32_t)jb + (uint32_t)c;       // wave-uniform
-            uint32_t k1 = rk1, k2 = rk2, b = j;
-            if (SYM) {
-                const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)ck1, c), c2 = (uint32_t)__builtin_amdgcn_readlane((int)ck2, c);
-                if (j < i) { k1 = c1; k2 = c2; b = i; }
+        const bool below = SYM && (uint64_t)jb + (uint64_t)nc <= (uint64_t)imin;     // every column < every row of the wavefront
+        const bool above = !SYM || (uint64_t)jb > (uint64_t)imax;                      // every column > every row
+        if (above) {
+            for (int c = 0; c < nc; c++) {
+                const uint32_t j = (uint32_t)jb + (uint32_t)c;   // wave-uniform
+                uint32_t x = j ^ rk1;
+                x *= 0x7feb352dU; x ^= x >> 15; x += rk2; x *= 0x846ca68bU;
+                if (!skip && (x >= uthr || (!SYM && j == i))) {
+                    if (cnt < capseg) cb[cnt] = j;
+                    cnt++;
+                }
             }
+            continue;
+        }
+        uint32_t ck1, ck2;
+        rowkey(s0, s1, (uint32_t)jb + (uint32_t)lane, ck1, ck2);
+        if (below) {
+            for (int c = 0; c < nc; c++) {
+                const uint32_t j = (uint32_t)jb + (uint32_t)c;
+                const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)ck1, c), c2 = (uint32_t)__builtin_amdgcn_readlane((int)ck2, c);
+                uint32_t x = i ^ c1;
+                x *= 0x7feb352dU; x ^= x >> 15; x += c2; x *= 0x846ca68bU;
+                if (!skip && x >= uthr) {
+                    if (cnt < capseg) cb[cnt] = j;
+                    cnt++;
+                }
+            }
+            continue;
+        }
+        for (int c = 0; c < nc; c++) {
+            const uint32_t j = (uint32_t)jb + (uint32_t)c;
+            const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)ck1, c), c2 = (uint32_t)__builtin_amdgcn_readlane((int)ck2, c);
+            uint32_t k1 = rk1, k2 = rk2, b = j;
+            if (j < i) { k1 = c1; k2 = c2; b = i; }
             uint32_t x = b ^ k1;
             x *= 0x7feb352dU; x ^= x >> 15; x += k2; x *= 0x846ca68bU;
             if (!skip && (x >= uthr || j == i)) {
