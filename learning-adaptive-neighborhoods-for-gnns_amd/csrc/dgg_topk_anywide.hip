@@ -719,7 +719,29 @@ __global__ __launch_bounds__(64) void aw_hash_sweep(int64_t N, int64_t row0, int
         const bool below = SYM && (uint64_t)jb + (uint64_t)nc <= (uint64_t)imin;     // every column < every row of the wavefront
         const bool above = !SYM || (uint64_t)jb > (uint64_t)imax;                      // every column > every row
         if (above) {
-            for (int c = 0; c < nc; c++) {
+            // sixteen hash chains at a time, interleaved (gv_sweep's form: a chain is two quarter-rate multiplies deep), then the tests
+            constexpr int UB = 16;
+            int c = 0;
+            for (; c + UB <= nc; c += UB) {
+                uint32_t x[UB];
+#pragma unroll
+                for (int u = 0; u < UB; u++) {
+                    uint32_t v = ((uint32_t)jb + (uint32_t)(c + u)) ^ rk1;
+                    v *= 0x7feb352dU; v ^= v >> 15; v += rk2; v *= 0x846ca68bU;
+                    x[u] = v;
+                }
+#pragma unroll
+                for (int u = 0; u < UB; u++) asm volatile("" : "+v"(x[u]));   // (keeps the chains interleaved: no sinking into the tests)
+#pragma unroll
+                for (int u = 0; u < UB; u++) {
+                    const uint32_t j = (uint32_t)jb + (uint32_t)(c + u);
+                    if (!skip && (x[u] >= uthr || (!SYM && j == i))) {
+                        if (cnt < capseg) cb[cnt] = j;
+                        cnt++;
+                    }
+                }
+            }
+            for (; c < nc; c++) {
                 const uint32_t j = (uint32_t)jb + (uint32_t)c;   // wave-uniform
                 uint32_t x = j ^ rk1;
                 x *= 0x7feb352dU; x ^= x >> 15; x += rk2; x *= 0x846ca68bU;
@@ -733,7 +755,28 @@ __global__ __launch_bounds__(64) void aw_hash_sweep(int64_t N, int64_t row0, int
         uint32_t ck1, ck2;
         rowkey(s0, s1, (uint32_t)jb + (uint32_t)lane, ck1, ck2);
         if (below) {
-            for (int c = 0; c < nc; c++) {
+            constexpr int UB = 16;
+            int c = 0;
+            for (; c + UB <= nc; c += UB) {
+                uint32_t x[UB];
+#pragma unroll
+                for (int u = 0; u < UB; u++) {
+                    const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)ck1, c + u), c2 = (uint32_t)__builtin_amdgcn_readlane((int)ck2, c + u);
+                    uint32_t v = i ^ c1;
+                    v *= 0x7feb352dU; v ^= v >> 15; v += c2; v *= 0x846ca68bU;
+                    x[u] = v;
+                }
+#pragma unroll
+                for (int u = 0; u < UB; u++) asm volatile("" : "+v"(x[u]));
+#pragma unroll
+                for (int u = 0; u < UB; u++) {
+                    if (!skip && x[u] >= uthr) {
+                        if (cnt < capseg) cb[cnt] = (uint32_t)jb + (uint32_t)(c + u);
+                        cnt++;
+                    }
+                }
+            }
+            for (; c < nc; c++) {
                 const uint32_t j = (uint32_t)jb + (uint32_t)c;
                 const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)ck1, c), c2 = (uint32_t)__builtin_amdgcn_readlane((int)ck2, c);
                 uint32_t x = i ^ c1;
