@@ -565,7 +565,9 @@ class DGG_LearnableK_debug(nn.Module):
         x1 / x4 / x16): ranked 0.35 / 9.0 / 170; the per-pair hash evaluators depend on the regime just as much and are SLOWER where
         the ranked search is slow (guess-and-verify 3.5 / 198 / 318, adaptive 13.7 / 143 / 435, MFMA-bounded 41 / 123 / 226) --
         when distances and noise both matter, every pair has to be scored, which is what the exhaustive kernel costs (~200 ms).
-        So there is no cheaper exact evaluator to route to; args.dgg_asym_generator:
+        So there was no cheaper exact evaluator to route to (rounds 3-5; since round 6 the ranked search itself takes the rows'
+        nearest-neighbour bound on such data -- ShardedDGGConv.tight_bound -- and the hash generators the chunked rows' per-row front
+        end -- _hash_spread_now); args.dgg_asym_generator:
           "auto" (default)  the ranked generator, WATCHED: every `args.dgg_pilot_every` (16) forwards -- and on the first -- a pilot
                             walks ~1000 sampled rows with a budget of 64 blocks (ops.ranked_probe: one small launch, one readback);
                             when its estimate exceeds `args.dgg_ranked_warn_us` (5000) the module warns, once per regime change,
@@ -596,6 +598,28 @@ class DGG_LearnableK_debug(nn.Module):
             st.update(slow=slow, probe=dict(pr, ranked_us_estimate=est))
         st["n"] += 1
         return ops.NOISE_RANKED
+
+    def _hash_spread_now(self, x, seed):
+        """True while the latents of this module are SPREAD over several noise scales -- the regime in which the 64-rank entry of the per-pair
+        hash generators (one threshold for the whole graph, guessed from the noise law alone) loses every row to its exhaustive fallback
+        (N = 100 000, features x4: 145-170 ms) and the chunked rows' front end (threshold per row on G + the row's nearest-neighbour bound)
+        does not (7-9 ms; 2-3x the 64-rank entry on unit-scale data, hence not always).  Measured with the ranked search's pilot, which
+        walks deep on exactly that data: ~1000 sampled rows, 16-block budget, every args.dgg_pilot_every (16) forwards; more than 8 blocks
+        per row = spread (unit scale: 3, features x2: 5, x4: 16+).  Graphs below 8192 nodes and hipGraph captures are not probed."""
+        N = x.shape[0]
+        if N < 8192:
+            return False
+        st = self.__dict__.setdefault("_hash_state", {"n": 0, "spread": False})
+        every = max(1, int(getattr(self.args, "dgg_pilot_every", 16)))
+        if st["n"] % every == 0 and not _capturing():
+            with torch.no_grad():
+                xp = ops.linear_fwd(x.detach(), self.node_encode_for_edges[0].weight.detach(), self.node_encode_for_edges[0].bias.detach(),
+                                    ops.ACT_LEAKY)
+                pr = ops.ranked_probe(xp, None, ops.T_DIST, seed if seed is not None else (0, 0), stride=max(1, N // 1024), max_blocks=16)
+            st["spread"] = pr["blocks_per_row"] > 8.0
+            st["blocks"] = pr["blocks_per_row"]
+        st["n"] += 1
+        return st["spread"]
 
     def forward_conv(self, x, in_adj, conv_weight, want_norm=False):
         """`GCNConv(x, normalize_adj(self(x, in_adj)))` with conv_weight = GCNConv.W [in, out] as one fused autograd node
@@ -706,7 +730,10 @@ class DGG_LearnableK_debug(nn.Module):
         layer.sym_fallback, layer.sym_hash = getattr(a, "dgg_sym_generator", "auto") != "ranked", False
         # the module fell back from the ranked symmetric generator on THIS data (spread latents): the hash noise's forwards take the
         # chunked rows' per-row front end, whatever the learned degrees (parallel.py, force_chunked)
-        layer.force_chunked = bool(self.__dict__.get("_sym_spread")) and noise_mode == ops.NOISE_HASH_SYM and cand is None
+        # ... and so do forwards under a per-pair hash generator the CALLER chose (args.dgg_sym_generator / dgg_asym_generator = "hash")
+        # while a pilot finds the latents spread (_hash_spread_now)
+        layer.force_chunked = cand is None and noise_mode in (ops.NOISE_HASH, ops.NOISE_HASH_SYM) and \
+            ((noise_mode == ops.NOISE_HASH_SYM and bool(self.__dict__.get("_sym_spread"))) or self._hash_spread_now(x, seed))
         layer.tight_bound = getattr(a, "dgg_tight_bound", "auto")     # ranked search: nearest-neighbour bound in its stop tests when the walk is deep
         layer.x_grad = bool(x.requires_grad)
         # all-pairs rows wider than the 64-rank list (learned degrees k_i + 9.5 > 64): chunked rows inside the engine, from the forward

@@ -287,6 +287,37 @@ def test_chunked_step_other_generators_match_the_oracle(dev, noise):
     _full_size_gradient_parity(dense, grads, x, deg, P, perturb=noise != "none")
 
 
+def test_module_sends_spread_latents_under_a_chosen_hash_generator_through_the_chunked_rows(dev):
+    """args.dgg_sym_generator = "hash" (the caller's choice of the per-pair hash generator for symmetric noise): on unit-scale features the
+    64-rank entry evaluates the forward; on features x8 -- latents spread over many noise scales, where that entry's one guessed threshold
+    loses every row to the exhaustive fallback -- the module's pilot (_hash_spread_now) routes the forward through the chunked rows'
+    per-row front end although every row fits the list; the model trains on either (finite output, finite gradients on the generator's and the layers' parameters)."""
+    from argparse import Namespace
+    import dgg_amd
+    from dgg_amd.adjacency import AllPairs
+    N, d = 9000, 48
+    args = Namespace(extra_edge_dim=0, extra_k_dim=1, dgg_hard=False, deg_mean=20.0, deg_std=4.0, dgg_mode_edge_net="u-v-dist",
+                     dgg_mode_k_net="x", dgg_mode_k_select="k_times_edge_prob", debug_step=3, perturb_edge_prob=True,
+                     symmetric_noise=True, stochastic_k=False, dgg_adj_input="input_adj", n_dgg_layers=1, dgg_sym_generator="hash")
+    g = torch.Generator().manual_seed(8)
+    prior = (10 + 20 * torch.rand(N, generator=g)).to(dev)
+    for scale, want in ((1.0, False), (8.0, True)):
+        torch.manual_seed(0)
+        m = dgg_amd.GCN_DGG(nfeat=d, nhid=32, nclass=7, dropout=0.0, args=args).to(dev)
+        m.train()
+        x = (torch.randn(N, d, generator=g) * scale).to(dev)
+        out = m(x, AllPairs(prior))
+        out = out[0] if isinstance(out, tuple) else out
+        out.square().mean().backward()
+        dg = [mod for mod in m.modules() if isinstance(mod, dgg_amd.DGG_LearnableK_debug)][0]
+        fl = dg.__dict__["_fused_layer"]
+        print(f"scale {scale}: pilot {dg.__dict__['_hash_state']}, force_chunked {fl.force_chunked}")
+        assert fl.force_chunked == want and (fl.saved["layout"] is not None) == want
+        grads = {n_: p.grad for n_, p in m.named_parameters() if p.grad is not None}       # (parameters of unused scorer modes have none)
+        assert bool(torch.isfinite(out).all()) and all(bool(torch.isfinite(v).all()) for v in grads.values())
+        assert any("node_encode_for_edges" in n_ for n_ in grads) and any("k_net" in n_ for n_ in grads) and len(grads) >= 8, sorted(grads)
+
+
 def test_forced_chunked_evaluation_of_narrow_rows_equals_the_list(dev):
     """ShardedDGGConv.force_chunked (set by the module once the ranked symmetric generator has failed on its data: spread latents, where the
     64-rank entry of the per-pair hash noise loses every row to its exhaustive fallback): rows that all fit the 64-rank list evaluated by
