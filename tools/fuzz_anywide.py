@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--minutes", type=float, default=5.0)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--rows", type=int, default=24)
+ap.add_argument("--sizes", default="1023,1024,1025,2047,3000,4097,8191,12000,20000", help="node counts to draw from")
 ap.add_argument("--narrow", action="store_true", help="the 64-rank entry (ops.allpairs_topk, every generator incl. ranked symmetric) instead of the chunked rows")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -72,7 +73,7 @@ t_end = time.time() + 60.0 * a.minutes
 case = fails = 0
 while time.time() < t_end:
     case += 1
-    N = int(rng.choice([1023, 1024, 1025, 2047, 3000, 4097, 8191, 12000, 20000]))
+    N = int(rng.choice([int(v) for v in a.sizes.split(",")]))
     h = int(rng.choice([16, 32, 64, 128]))          # (the chunked rows exist for latent 16 / 32 / 64 / 128)
     fk = str(rng.choice(["randn", "clustered", "duplicates", "zeros", "huge", "onehot"]))
     dk = str(rng.choice(["narrow", "mixed", "tail", "half"] if N <= 4097 else ["narrow", "mixed", "tail"]))
