@@ -86,7 +86,7 @@ __global__ __launch_bounds__(128 * WC) void gemm_nt_bf16(const __bf16 *__restric
                                                          float scale, float *__restrict__ C, GcniiEpi ep, const __bf16 *__restrict__ A2, int ksplit) {
     static_assert(WC == 2 || (WC == 4 && RING), "eight wavefronts: ring loop only");
     constexpr int BM = 64 * AM, NB = 4 / WC, NW = 2 * WC;
-    constexpr int NST = DGG_BF16_NST, STAGE = (BM + BN) * 128;             // ring: stages of [BM + BN rows][8 chunks of 16 B]
+    constexpr int NST = AM >= 4 ? 3 : DGG_BF16_NST, STAGE = (BM + BN) * 128;   // ring: stages of [BM + BN rows][8 chunks of 16 B] (256-row tiles: 3 x 48 KB)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[RING ? NST * STAGE : 2 * (BM + BN) * LDS_STRIDE * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = dgg::wave_id(), li = lane & 31, hh = lane >> 5;
     const int wr = wave / WC, wc = wave % WC;
@@ -492,12 +492,21 @@ int launch_gemm(const __bf16 *A, const __bf16 *B, int M, int N, int K, float sca
     const int64_t nt = (N + BN - 1) / BN, big = nt * ((M + 127) / 128), sml = nt * ((M + 63) / 64);
     bool small = (double)((sml + 255) / 256) * 0.68 < (double)((big + 255) / 256);
     { const char *e = getenv("DGG_BF16_TILE"); if (e) small = atoi(e) == 64 ? true : (atoi(e) == 128 ? false : small); }
-    const dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + (small ? 63 : 127)) / (small ? 64 : 128)));
+    dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + (small ? 63 : 127)) / (small ? 64 : 128)));
     const GcniiEpi e0 = ep ? *ep : GcniiEpi{};
     bool ring = true;
     { const char *e = getenv("DGG_BF16_RING"); if (e && atoi(e) == 0) ring = false; }
     bool eight = ring;                                           // eight wavefronts per workgroup (ring loop only)
     { const char *e = getenv("DGG_BF16_WAVES"); if (e && atoi(e) == 4) eight = false; }
+    // 256-row tiles (a wavefront owns 128 x 32: five fragment reads per four MFMAs instead of three per two, half the barriers and 3/4 of the
+    // operand traffic per flop) for the plain products that make at least two full rounds of 128-row tiles: the weight gradients (M = 2F)
+    bool tall = !small && epi == 0 && eight && M % 256 == 0 && big >= 512 && !getenv("DGG_BF16_TILE");
+    { const char *e = getenv("DGG_BF16_TALL"); if (e && atoi(e) == 0) tall = false; }
+    if (tall) {
+        grid.y = (unsigned)(M / 256);
+        hipLaunchKernelGGL((gemm_nt_bf16<0, 4, true, 4>), grid, dim3(512), 0, st, A, B, M, N, K, scale, C, e0, A2, ksplit);
+        return dgg_check_launch("gemm_nt_bf16");
+    }
 #define DGG_BF16_LAUNCH2(E, AMV, RG, WCV) hipLaunchKernelGGL((gemm_nt_bf16<E, AMV, RG, WCV>), grid, dim3(128 * WCV), 0, st, A, B, M, N, K, scale, C, e0, A2, ksplit)
 #define DGG_BF16_LAUNCH(E, AMV) do { if (eight) DGG_BF16_LAUNCH2(E, AMV, true, 4); else if (ring) DGG_BF16_LAUNCH2(E, AMV, true, 2); else DGG_BF16_LAUNCH2(E, AMV, false, 2); } while (0)
     if (epi == 3) { if (small) DGG_BF16_LAUNCH(3, 1); else DGG_BF16_LAUNCH(3, 2); }
